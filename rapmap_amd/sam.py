@@ -1,0 +1,173 @@
+"""SAM emission for mapped read pairs / single reads.
+
+Mirrors the text the reference writes for `rapmap quasimap -o`:
+  header    include/RapMapUtils.hpp:97-115 (writeSAMHeader)
+  pairs     src/RapMapUtils.cpp:313-588 (writeAlignmentsToStream, paired-in-sequencing)
+  unaligned src/RapMapUtils.cpp:137-196 (writeUnalignedPairToStream)
+  flags     include/RapMapUtils.hpp:771-810 (getSamFlags)
+  clips     include/RapMapUtils.hpp:687-727 (adjustOverhang)
+It formats hit records (numpy HIT_DTYPE rows) produced by the HIP mapper; it does no mapping.
+"""
+RAPMAP_VERSION = "0.6.0"   # include/RapMapConfig.hpp:27-33
+
+_RC = {}
+for _c in range(256):
+    _RC[_c] = ord("N")
+for _a, _b in (("A", "T"), ("C", "G"), ("G", "C"), ("T", "A"), ("U", "A")):
+    _RC[ord(_a)] = ord(_b)
+    _RC[ord(_a.lower())] = ord(_b)
+_RC_TABLE = bytes(_RC[i] for i in range(256))
+
+
+def reverse_read(seq: bytes) -> bytes:
+    """src/RapMapUtils.cpp:107-128"""
+    return seq.translate(_RC_TABLE)[::-1]
+
+
+def sam_header(names, lens) -> str:
+    out = ["@HD\tVN:1.0\tSO:unknown"]
+    for n, l in zip(names, lens):
+        out.append("@SQ\tSN:%s\tLN:%d" % (n, int(l)))
+    out.append("@PG\tID:rapmap\tPN:rapmap\tVN:%s" % RAPMAP_VERSION)
+    return "\n".join(out) + "\n"
+
+
+def _read_name(name: str) -> str:
+    """src/RapMapUtils.cpp:334-351"""
+    sp = name.find(" ")
+    if sp >= 0:
+        name = name[:sp]
+    if len(name) > 2 and name[-2] == "/":
+        name = name[:-2]
+    return name
+
+
+def _adjust_overhang(pos, read_len, txp_len):
+    """include/RapMapUtils.hpp:687-711 -> (new_pos, cigar)"""
+    if pos + read_len < 0:
+        return 0, "%dS" % read_len
+    if pos < 0:
+        match = read_len + pos
+        clip = read_len - match
+        return 0, "%dS%dM" % (clip, match)
+    if pos > txp_len:
+        return pos, "%dS" % read_len
+    if pos + read_len > txp_len:
+        match = txp_len - pos
+        clip = read_len - match
+        return pos, "%dM%dS" % (match, clip)
+    return pos, "%dM" % read_len
+
+
+def _flags(fwd, mate_is_fwd, is_paired, mate_status):
+    f1 = 0x1 | (0x2 if is_paired else 0)
+    f2 = f1
+    r1_un = mate_status == 2   # PAIRED_END_RIGHT
+    r2_un = mate_status == 1   # PAIRED_END_LEFT
+    if r1_un:
+        f1 |= 0x4
+        f2 |= 0x8
+    if r2_un:
+        f2 |= 0x4
+        f1 |= 0x8
+    if not fwd:
+        f1 |= 0x10
+        f2 |= 0x20
+    if not mate_is_fwd:
+        f1 |= 0x20
+        f2 |= 0x10
+    return f1 | 0x40, f2 | 0x80
+
+
+def format_pair(name1, seq1, name2, seq2, hits, txp_names, txp_lens, max_num_hits=200) -> str:
+    """hits: the structured-array slice for this pair (may be empty)."""
+    n1, n2 = _read_name(name1), _read_name(name2)
+    nh = len(hits)
+    if nh == 0 or nh > max_num_hits:
+        tail = "\t*\t0\t255\t*\t*\t*\t0\t%s\t*\tNH:i:0\tHI:i:0\tAS:i:0\n"
+        return (n1 + "\t%d" % (0x1 | 0x4 | 0x8 | 0x40) + tail % seq1.decode() +
+                n2 + "\t%d" % (0x1 | 0x4 | 0x8 | 0x80) + tail % seq2.decode())
+    out = []
+    rev1 = rev2 = None
+    for i, h in enumerate(hits, start=1):
+        tid = int(h["tid"])
+        tname = txp_names[tid]
+        tlen = int(txp_lens[tid])
+        fwd, mfwd = bool(h["fwd"]), bool(h["mate_is_fwd"])
+        f1, f2 = _flags(fwd, mfwd, bool(h["is_paired"]), int(h["mate_status"]))
+        if i != 1:
+            f1 |= 0x100
+            f2 |= 0x100
+        aln = int(h["aln_score"])
+        if h["is_paired"]:
+            pos, cig1 = _adjust_overhang(int(h["pos"]), int(h["read_len"]), tlen)
+            mpos, cig2 = _adjust_overhang(int(h["mate_pos"]), int(h["mate_len"]), tlen)
+            if fwd:
+                s1 = seq1
+            else:
+                rev1 = rev1 if rev1 is not None else reverse_read(seq1)
+                s1 = rev1
+            if mfwd:
+                s2 = seq2
+            else:
+                rev2 = rev2 if rev2 is not None else reverse_read(seq2)
+                s2 = rev2
+            frag = int(h["frag_len"])
+            read1_first = pos < mpos
+            min_pos = pos if read1_first else mpos
+            # the reference compares/assigns through int32/uint32 casts (RapMapUtils.cpp:407-411)
+            sfrag = frag - (1 << 32) if frag >= (1 << 31) else frag
+            if min_pos + sfrag > tlen:
+                sfrag = tlen - min_pos
+            out.append("%s\t%d\t%s\t%d\t1\t%s\t=\t%d\t%d\t%s\t*\tNH:i:%d\tHI:i:%d\tAS:i:%d\n" % (
+                n1, f1, tname, pos + 1, cig1, mpos + 1, sfrag if read1_first else -sfrag, s1.decode(), nh, i, aln))
+            out.append("%s\t%d\t%s\t%d\t1\t%s\t=\t%d\t%d\t%s\t*\tNH:i:%d\tHI:i:%d\tAS:i:%d\n" % (
+                n2, f2, tname, mpos + 1, cig2, pos + 1, -sfrag if read1_first else sfrag, s2.decode(), nh, i, aln))
+        else:
+            left = int(h["mate_status"]) == 1
+            if left:
+                aname, uname, aseq, useq, fl, ufl = n1, n2, seq1, seq2, f1, f2
+            else:
+                aname, uname, aseq, useq, fl, ufl = n2, n1, seq2, seq1, f2, f1
+            if not fwd:
+                if left:
+                    rev1 = rev1 if rev1 is not None else reverse_read(seq1)
+                    aseq = rev1
+                else:
+                    rev2 = rev2 if rev2 is not None else reverse_read(seq2)
+                    aseq = rev2
+            pos, cig = _adjust_overhang(int(h["pos"]), int(h["read_len"]), tlen)
+            out.append("%s\t%d\t%s\t%d\t1\t%s\t=\t%d\t0\t%s\t*\tNH:i:%d\tHI:i:%d\tAS:i:%d\n" % (
+                aname, fl, tname, pos + 1, cig, pos + 1, aseq.decode(), nh, i, aln))
+            out.append("%s\t%d\t%s\t%d\t0\t*\t=\t%d\t0\t%s\t*\tNH:i:%d\tHI:i:%d\tAS:i:%d\n" % (
+                uname, ufl, tname, pos + 1, pos + 1, useq.decode(), nh, i, aln))
+    return "".join(out)
+
+
+def read_fastq(path):
+    """Minimal 4-line FASTQ / 2-line FASTA reader -> (names, seqs as bytes).  Qualities are dropped,
+    like the reference's parser (include/FastxParser.hpp:62-66)."""
+    names, seqs = [], []
+    opener = open
+    if path.endswith(".gz"):
+        import gzip
+        opener = gzip.open
+    with opener(path, "rb") as f:
+        while True:
+            h = f.readline()
+            if not h:
+                break
+            h = h.rstrip(b"\r\n")
+            if not h:
+                continue
+            if h[:1] == b"@":
+                s = f.readline().rstrip(b"\r\n")
+                f.readline()
+                f.readline()
+            elif h[:1] == b">":
+                s = f.readline().rstrip(b"\r\n")
+            else:
+                raise ValueError("bad record header: %r" % h[:40])
+            names.append(h[1:].decode())
+            seqs.append(s)
+    return names, seqs
