@@ -1,0 +1,157 @@
+/* qmap_mi355.h -- C ABI of libqmap_mi355.so, the MI355X-native drop-in for the
+ * `rapmap quasimap` hot path (RapMap v0.6.0).
+ *
+ * RapMap has no FFI/plugin registry: its callers compile three C++ template
+ * entry points into themselves.  This header is the
+ * batched, language-neutral face of the same three steps; each entry point
+ * cites the reference interface it replaces (paths relative to the reference
+ * tree).  Plain pointers and sizes only; no C++/torch types.  All functions
+ * return 0 on success or a negative qm_status; none of them calls exit().
+ *
+ * One call of qm_map_pairs() == for every read pair i:
+ *     SACollector::operator()(left)  ; SACollector::operator()(right)       include/SACollector.hpp:108-362
+ *     hit_manager::hitsToMappingsSimple(..., PAIRED_END_LEFT / _RIGHT, ...)  src/HitManager.cpp:691-882
+ *     utils::mergeLeftRightHits(...)                                         include/RapMapUtils.hpp:1185-1264
+ *     + the per-pair bookkeeping of processReadsPairSA                       src/RapMapSAMapper.cpp:461-551,684-701
+ * executed by one 64-lane wavefront per pair on the GPU.
+ */
+#ifndef QMAP_MI355_H
+#define QMAP_MI355_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum qm_status {
+  QM_OK = 0,
+  QM_E_ARG = -1,         /* bad argument */
+  QM_E_IO = -2,          /* index file missing / malformed */
+  QM_E_NOGPU = -3,       /* no HIP device, or HIP call failed */
+  QM_E_UNSUPPORTED = -4, /* option / index variant not implemented on the device path */
+  QM_E_TOOLONG = -5,     /* a read is longer than QM_MAX_READ_LEN */
+  QM_E_NOMEM = -6,
+  QM_E_STATE = -7        /* call order (e.g. fetch before map) */
+} qm_status;
+
+#define QM_MAX_READ_LEN 256
+
+/* Mirrors MappingOpts (src/RapMapSAMapper.cpp:114-152) for the fields that
+ * reach the hot path.  Defaults (qm_opts_default) == `rapmap quasimap` defaults
+ * (src/RapMapSAMapper.cpp:992-1023,1113-1114). */
+typedef struct qm_opts {
+  int32_t sensitive;     /* 1 unless --noSensitive (disableNIP, SACollector.hpp:40)        */
+  int32_t strict_check;  /* 1 unless --noStrictCheck (SACollector.hpp:61)                  */
+  int32_t max_num_hits;  /* -m, 200                                                       */
+  int32_t no_orphans;    /* --noOrphans                                                   */
+  int32_t no_dovetail;   /* --noDovetail                                                  */
+  int32_t fuzzy;         /* -f  (mergeLeftRightHitsFuzzy; not on the device path yet)     */
+  int32_t max_interval;  /* SACollector::setMaxInterval, 1000 (SACollector.hpp:54,77)     */
+  int32_t sel_aln;       /* -s  (not on the device path yet)                              */
+  double quasi_cov;      /* -z  (SACollector::setCoverageRequirement)                     */
+} qm_opts;
+
+/* POD image of rapmap::utils::QuasiAlignment (include/RapMapUtils.hpp:399-502),
+ * restricted to the fields that are defined on this path.  For orphan / single-end
+ * hits the reference leaves matePos and mateLen uninitialised; here they are 0. */
+typedef struct qm_hit {
+  uint32_t tid;
+  int32_t pos;
+  int32_t mate_pos;
+  uint32_t frag_len;
+  uint32_t read_len;
+  uint32_t mate_len;
+  uint8_t fwd;
+  uint8_t mate_is_fwd;
+  uint8_t is_paired;
+  uint8_t mate_status; /* MateStatus: 0 SINGLE_END 1 PE_LEFT 2 PE_RIGHT 3 PE_PAIRED (RapMapUtils.hpp:356-362) */
+  int32_t aln_score;   /* alnScore_, 0 without -s */
+} qm_hit;
+
+/* rapmap::utils::HitCounters (include/RapMapUtils.hpp:208-216) + mapped units */
+typedef struct qm_counters {
+  uint64_t pe_hits, se_hits, tot_hits, num_reads, too_many_hits, mapped;
+} qm_counters;
+
+/* rapmap::utils::SAIntervalHit<int32_t> (include/RapMapUtils.hpp:516-525) + which list it sits in */
+typedef struct qm_sa_interval_hit {
+  int32_t begin, end;
+  uint32_t len, query_pos;
+  uint8_t query_rc;
+  uint8_t list; /* 0 left-fwd, 1 left-rc, 2 right-fwd, 3 right-rc */
+  uint16_t pad;
+} qm_sa_interval_hit;
+
+typedef struct qm_index_info {
+  int32_t k;
+  int32_t big_sa;
+  int32_t perfect_hash;
+  int32_t pad;
+  int64_t text_len;
+  int64_t n_txps;
+  int64_t n_keys;
+} qm_index_info;
+
+typedef struct qm_index qm_index; /* host image of the on-disk quasi-index */
+typedef struct qm_ctx qm_ctx;     /* one device context: index replica in HBM + work buffers */
+
+const char* qm_last_error(void);
+const char* qm_version(void);
+int qm_opts_default(qm_opts* o);
+
+/* RapMapSAIndex<int32_t, RegHashT>::load (src/RapMapSAIndex.cpp:97-176): reads
+ * header.json, sa.bin, txpInfo.bin, rsd.bin, hash.bin of a "q5" index directory
+ * (files are mmap'd, not deserialised). */
+int qm_index_open(const char* dir, qm_index** out);
+int qm_index_close(qm_index* ix);
+int qm_index_info_get(const qm_index* ix, qm_index_info* info);
+const char* qm_index_txp_name(const qm_index* ix, int64_t tid); /* rmi.txpNames[tid] */
+int64_t qm_index_txp_len(const qm_index* ix, int64_t tid);      /* rmi.txpLens[tid]  */
+
+/* Replicates the index into the HBM of `device_id` as flat SoA arrays and
+ * allocates the per-context work buffers.  One ctx per GPU / per host thread. */
+int qm_ctx_create(const qm_index* ix, int device_id, qm_ctx** out);
+int qm_ctx_destroy(qm_ctx* ctx);
+int64_t qm_ctx_device_bytes(const qm_ctx* ctx);
+
+/* Map n read pairs held in HOST memory.  seqX = concatenated read bytes (ASCII,
+ * any case, N allowed), offX[n+1] = byte offsets.  Results stay in the context;
+ * *n_hits receives the total number of hits.  counters may be NULL. */
+int qm_map_pairs(qm_ctx* ctx, const qm_opts* opts, int64_t n, const char* seq1, const int64_t* off1,
+                 const char* seq2, const int64_t* off2, int64_t* n_hits, qm_counters* counters);
+/* Same for single-end reads (processReadsSingleSA, src/RapMapSAMapper.cpp:232-250). */
+int qm_map_reads(qm_ctx* ctx, const qm_opts* opts, int64_t n, const char* seq, const int64_t* off,
+                 int64_t* n_hits, qm_counters* counters);
+/* Same, with the inputs already resident in this device's memory (d_* are device
+ * pointers; seq2/off2 NULL for single-end).  `max_read_len` bounds every read. */
+int qm_map_device(qm_ctx* ctx, const qm_opts* opts, int64_t n, const void* d_seq1, const void* d_off1,
+                  const void* d_seq2, const void* d_off2, int32_t max_read_len, int64_t* n_hits,
+                  qm_counters* counters);
+/* Copy the results of the last map call to host memory:
+ * hit_offsets[n+1] (exclusive prefix sum), hits[n_hits]. */
+int qm_fetch_hits(qm_ctx* ctx, int64_t* hit_offsets, qm_hit* hits);
+/* Device pointers of the same arrays (valid until the next map call on ctx). */
+int qm_result_device(qm_ctx* ctx, const void** d_hit_offsets, const void** d_hits);
+
+/* SACollector::operator() alone (include/SACollector.hpp:108-362): the SA-interval
+ * hits (fwdSAInts / rcSAInts of HitCollectorInfo, include/HitManager.hpp:59-72) the
+ * last qm_map_pairs call collected.  int_offsets[n+1], ints[int_offsets[n]];
+ * pass ints=NULL to get only the offsets/total.  Requires qm_ctx_set_debug(ctx,1). */
+int qm_ctx_set_debug(qm_ctx* ctx, int keep_intervals);
+int qm_fetch_intervals(qm_ctx* ctx, int64_t* int_offsets, qm_sa_interval_hit* ints, int64_t cap);
+
+/* Timing of the dominant kernel of the last map call, measured with HIP events on
+ * the context's stream (milliseconds); n_launches kernels were timed. */
+int qm_last_kernel_ms(const qm_ctx* ctx, double* map_kernel_ms, double* total_ms);
+
+/* `rapmap quasiindex` (src/RapMapSAIndexer.cpp:449-819) for the dense-hash,
+ * int32 index: FASTA -> q5 index directory readable by qm_index_open (and by the
+ * reference).  Host only. */
+int qm_build_index(const char* fasta_path, const char* out_dir, int32_t k, int32_t no_clip_poly_a,
+                   int32_t keep_duplicates, int32_t n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QMAP_MI355_H */

@@ -1,0 +1,85 @@
+// qm_wave.h -- the 64-lane wavefront abstraction the mapper is written against.
+//
+// The mapper (qm_mapper.inl) is explicit about what is wave-uniform (plain
+// scalars -> SGPRs / scalar branches on gfx950) and what varies per lane
+// (LV<T>).  On the device an LV<T> is ONE register per lane and QM_LANES runs
+// its body once with the hardware lane id; ballots, lane reads and LDS atomics
+// map to the CDNA4 instructions.  When compiled with -DQM_EMU (tests/emu only,
+// never shipped in the product library) an LV<T> is a 64-entry array and
+// QM_LANES is a loop, so the *same source* runs lane-by-lane on a CPU and can
+// be checked against the oracle without a GPU.
+#pragma once
+#include <stdint.h>
+
+#ifdef QM_EMU
+#define QM_DEV inline
+#define QM_NL 64
+#define QM_LANES(l) for (int l = 0; l < 64; ++l)
+#else
+#include <hip/hip_runtime.h>
+#define QM_DEV __device__ __forceinline__
+#define QM_NL 1
+#define QM_LANES(l) for (int _qm_once = 0, l = (int)(threadIdx.x & 63); _qm_once < 1; ++_qm_once)
+#endif
+
+namespace qm {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+template <typename T>
+struct LV {
+  T v[QM_NL];
+  QM_DEV T& operator[](int l) { return v[QM_NL == 1 ? 0 : l]; }
+  QM_DEV const T& operator[](int l) const { return v[QM_NL == 1 ? 0 : l]; }
+};
+
+#ifdef QM_EMU
+QM_DEV u64 ballot(const LV<bool>& b) {
+  u64 m = 0;
+  for (int l = 0; l < 64; ++l) m |= (u64)(b.v[l] ? 1 : 0) << l;
+  return m;
+}
+template <typename T> QM_DEV T read_lane(const LV<T>& x, int lane) { return x.v[lane]; }
+QM_DEV int ctz64(u64 x) { return x ? __builtin_ctzll(x) : 64; }
+QM_DEV int popc64(u64 x) { return __builtin_popcountll(x); }
+QM_DEV u64 brev64(u64 x) {
+  x = ((x >> 1) & 0x5555555555555555ULL) | ((x & 0x5555555555555555ULL) << 1);
+  x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+  x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+  return __builtin_bswap64(x);
+}
+QM_DEV void wave_fence() {}
+QM_DEV void atomic_min_u64(u64* p, u64 v) { if (v < *p) *p = v; }
+QM_DEV u64 atomic_add_u64(u64* p, u64 v) { u64 o = *p; *p = o + v; return o; }
+template <typename T> QM_DEV T uniform(T x) { return x; }
+#else
+QM_DEV u64 ballot(const LV<bool>& b) { return __ballot(b.v[0]); }
+QM_DEV int read_lane(const LV<int>& x, int lane) { return __shfl(x.v[0], lane, 64); }
+QM_DEV u32 read_lane(const LV<u32>& x, int lane) { return (u32)__shfl((int)x.v[0], lane, 64); }
+QM_DEV u64 read_lane(const LV<u64>& x, int lane) {
+  int lo = __shfl((int)(u32)x.v[0], lane, 64), hi = __shfl((int)(u32)(x.v[0] >> 32), lane, 64);
+  return ((u64)(u32)hi << 32) | (u32)lo;
+}
+QM_DEV int ctz64(u64 x) { return x ? __builtin_ctzll(x) : 64; }
+QM_DEV int popc64(u64 x) { return __builtin_popcountll(x); }
+QM_DEV u64 brev64(u64 x) { return __brevll(x); }
+// orders this wave's LDS / global accesses across lanes (same-wave RAW through memory)
+QM_DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+QM_DEV void atomic_min_u64(u64* p, u64 v) { atomicMin(p, v); }
+QM_DEV u64 atomic_add_u64(u64* p, u64 v) { return atomicAdd(p, v); }
+// tell the compiler a value is wave-uniform (keeps control flow on the scalar unit)
+QM_DEV int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+QM_DEV u32 uniform(u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); }
+QM_DEV u64 uniform(u64 x) {
+  u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)x);
+  u32 hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(x >> 32));
+  return ((u64)hi << 32) | lo;
+}
+QM_DEV long long uniform(long long x) { return (long long)uniform((u64)x); }
+QM_DEV bool uniform(bool x) { return __builtin_amdgcn_readfirstlane((int)x) != 0; }
+#endif
+
+QM_DEV u64 lanemask_lt(int l) { return l ? (~0ULL >> (64 - l)) : 0ULL; }
+
+}  // namespace qm

@@ -1,0 +1,102 @@
+"""tests/emu/emu.py -- ctypes face of the TEST-ONLY lane emulation (libqm_emu.so)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libqm_emu.so")
+_SRC = [os.path.join(_HERE, "qm_emu.cpp"),
+        os.path.join(_HERE, "../../rapmap_amd/csrc/qm_mapper.inl"),
+        os.path.join(_HERE, "../../rapmap_amd/csrc/qm_wave.h")]
+
+HIT_DTYPE = np.dtype([
+    ("tid", "<u4"), ("pos", "<i4"), ("mate_pos", "<i4"), ("frag_len", "<u4"),
+    ("read_len", "<u4"), ("mate_len", "<u4"),
+    ("fwd", "u1"), ("mate_is_fwd", "u1"), ("is_paired", "u1"), ("mate_status", "u1"),
+    ("aln_score", "<i4"),
+])
+INT_DTYPE = np.dtype([("begin", "<i4"), ("end", "<i4"), ("len", "<u4"), ("query_pos", "<u4"),
+                      ("query_rc", "u1"), ("list", "u1"), ("pad", "<u2")])
+
+
+class QmOpts(C.Structure):
+    _fields_ = [("sensitive", C.c_int32), ("strict_check", C.c_int32), ("max_num_hits", C.c_int32),
+                ("no_orphans", C.c_int32), ("no_dovetail", C.c_int32), ("fuzzy", C.c_int32),
+                ("max_interval", C.c_int32), ("sel_aln", C.c_int32), ("quasi_cov", C.c_double)]
+
+
+def default_opts(**kw):
+    o = QmOpts(1, 1, 200, 0, 0, 0, 1000, 0, 0.0)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def build():
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unused", "-o", _LIB, _SRC[0]])
+
+
+def _lib():
+    if not os.path.exists(_LIB) or any(os.path.getmtime(_LIB) < os.path.getmtime(s) for s in _SRC):
+        build()
+    lib = C.CDLL(_LIB)
+    lib.qe_slots_cap.restype = C.c_uint64
+    lib.qe_slots_cap.argtypes = [C.c_int64]
+    return lib
+
+
+class Emu:
+    def __init__(self, ix):
+        self.lib = _lib()
+        self.ix = ix
+        n = ix.text.size
+        self.text = np.zeros(n + 128, dtype=np.uint8)
+        self.text[:n] = ix.text
+        self.n = n
+        self.SA = np.ascontiguousarray(ix.SA, dtype=np.int32)
+        self.sainfo = np.zeros(self.SA.size * 2, dtype=np.uint32)
+        self.cap = int(self.lib.qe_slots_cap(ix.hkeys.size))
+        self.slots = np.zeros(self.cap * 2, dtype=np.uint64)
+        off = np.ascontiguousarray(ix.txpOffsets, dtype=np.int32)
+        hk = np.ascontiguousarray(ix.hkeys, dtype=np.uint64)
+        hl = np.ascontiguousarray(ix.hlb, dtype=np.int32)
+        hu = np.ascontiguousarray(ix.hub, dtype=np.int32)
+        self.lib.qe_flatten(C.c_void_p(self.SA.ctypes.data), C.c_int64(self.SA.size), C.c_void_p(off.ctypes.data),
+                            C.c_int64(off.size), C.c_void_p(self.sainfo.ctypes.data), C.c_void_p(hk.ctypes.data),
+                            C.c_void_p(hl.ctypes.data), C.c_void_p(hu.ctypes.data), C.c_int64(hk.size),
+                            C.c_void_p(self.slots.ctypes.data), C.c_uint64(self.cap))
+
+    def map(self, seq1, off1, seq2=None, off2=None, opts=None, ns=2):
+        opts = opts or default_opts()
+        nunits = len(off1) - 1
+        seq1 = np.ascontiguousarray(seq1, dtype=np.uint8); off1 = np.ascontiguousarray(off1, dtype=np.int64)
+        paired = seq2 is not None
+        if paired:
+            seq2 = np.ascontiguousarray(seq2, dtype=np.uint8); off2 = np.ascontiguousarray(off2, dtype=np.int64)
+        ho = np.zeros(nunits + 1, dtype=np.int64); io = np.zeros(nunits + 1, dtype=np.int64)
+        ctr = np.zeros(6, dtype=np.uint64)
+        hp = C.c_void_p(); ip = C.c_void_p(); st = C.c_int(0)
+        rc = self.lib.qe_map(C.c_int(self.ix.k), C.c_void_p(self.text.ctypes.data), C.c_int64(self.n),
+                             C.c_void_p(self.SA.ctypes.data), C.c_int64(self.SA.size),
+                             C.c_void_p(self.sainfo.ctypes.data), C.c_void_p(self.slots.ctypes.data),
+                             C.c_uint64(self.cap - 1), C.byref(opts), C.c_int64(nunits),
+                             C.c_void_p(seq1.ctypes.data), C.c_void_p(off1.ctypes.data),
+                             C.c_void_p(seq2.ctypes.data if paired else None),
+                             C.c_void_p(off2.ctypes.data if paired else None), C.c_int(ns),
+                             C.c_void_p(ho.ctypes.data), C.byref(hp), C.c_void_p(ctr.ctypes.data),
+                             C.c_void_p(io.ctypes.data), C.byref(ip), C.byref(st))
+        assert rc == 0
+        tot = int(ho[-1])
+        hits = np.ctypeslib.as_array(C.cast(hp, C.POINTER(C.c_uint8)), shape=((tot + 1) * 32,))[: tot * 32].copy().view(HIT_DTYPE)
+        ti = int(io[-1])
+        ints = np.ctypeslib.as_array(C.cast(ip, C.POINTER(C.c_uint8)), shape=((ti + 1) * 20,))[: ti * 20].copy().view(INT_DTYPE)
+        self.lib.qe_free(hp); self.lib.qe_free(ip)
+
+        class R:
+            pass
+        r = R()
+        r.hit_offsets, r.hits, r.int_offsets, r.ints, r.status = ho, hits, io, ints, st.value
+        r.counters = dict(zip(["peHits", "seHits", "totHits", "numReads", "tooManyHits", "mappedUnits"], [int(x) for x in ctr]))
+        return r
