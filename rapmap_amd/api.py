@@ -1,0 +1,260 @@
+"""Host-side mirror of the reference's call surface, over the C ABI of libqmap_mi355.so.
+
+The reference exposes three C++ entry points to its callers:
+``SACollector::operator()`` (include/SACollector.hpp:108), ``hitsToMappingsSimple``
+(include/HitManager.hpp:130-135) and ``mergeLeftRightHits`` (include/RapMapUtils.hpp:1185),
+driven per read pair by ``processReadsPairSA`` (src/RapMapSAMapper.cpp:376).  Here the same
+three steps run batched on the GPU behind ``QuasiMapper.map_pairs``; the index object mirrors
+``RapMapSAIndex`` (include/RapMapSAIndex.hpp:70-82).
+
+There is NO CPU fallback: if the HIP library is missing or no GPU is visible the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqmap_mi355.so")
+
+HIT_DTYPE = np.dtype([
+    ("tid", "<u4"), ("pos", "<i4"), ("mate_pos", "<i4"), ("frag_len", "<u4"),
+    ("read_len", "<u4"), ("mate_len", "<u4"),
+    ("fwd", "u1"), ("mate_is_fwd", "u1"), ("is_paired", "u1"), ("mate_status", "u1"),
+    ("aln_score", "<i4"),
+])
+INTERVAL_DTYPE = np.dtype([("begin", "<i4"), ("end", "<i4"), ("len", "<u4"), ("query_pos", "<u4"),
+                           ("query_rc", "u1"), ("list", "u1"), ("pad", "<u2")])
+assert HIT_DTYPE.itemsize == 32 and INTERVAL_DTYPE.itemsize == 20
+
+# every symbol include/qmap_mi355.h declares
+ABI_SYMBOLS = [
+    "qm_last_error", "qm_version", "qm_opts_default", "qm_index_open", "qm_index_close", "qm_index_info_get",
+    "qm_index_txp_name", "qm_index_txp_len", "qm_ctx_create", "qm_ctx_destroy", "qm_ctx_device_bytes",
+    "qm_map_pairs", "qm_map_reads", "qm_map_device", "qm_fetch_hits", "qm_result_device", "qm_ctx_set_debug",
+    "qm_fetch_intervals", "qm_last_kernel_ms", "qm_build_index",
+]
+
+
+class QmError(RuntimeError):
+    pass
+
+
+class QmOpts(C.Structure):
+    """MappingOpts (src/RapMapSAMapper.cpp:114-152), hot-path fields only."""
+    _fields_ = [("sensitive", C.c_int32), ("strict_check", C.c_int32), ("max_num_hits", C.c_int32),
+                ("no_orphans", C.c_int32), ("no_dovetail", C.c_int32), ("fuzzy", C.c_int32),
+                ("max_interval", C.c_int32), ("sel_aln", C.c_int32), ("quasi_cov", C.c_double)]
+
+
+class QmCounters(C.Structure):
+    """HitCounters (include/RapMapUtils.hpp:208-216)."""
+    _fields_ = [("pe_hits", C.c_uint64), ("se_hits", C.c_uint64), ("tot_hits", C.c_uint64),
+                ("num_reads", C.c_uint64), ("too_many_hits", C.c_uint64), ("mapped", C.c_uint64)]
+
+    def as_dict(self):
+        return {"peHits": self.pe_hits, "seHits": self.se_hits, "totHits": self.tot_hits,
+                "numReads": self.num_reads, "tooManyHits": self.too_many_hits, "mappedUnits": self.mapped}
+
+
+class QmIndexInfo(C.Structure):
+    _fields_ = [("k", C.c_int32), ("big_sa", C.c_int32), ("perfect_hash", C.c_int32), ("pad", C.c_int32),
+                ("text_len", C.c_int64), ("n_txps", C.c_int64), ("n_keys", C.c_int64)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libqmap_mi355.so; fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise QmError("HIP library %s is missing - run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(there is no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.qm_last_error.restype = C.c_char_p
+    L.qm_version.restype = C.c_char_p
+    L.qm_index_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+    L.qm_index_close.argtypes = [C.c_void_p]
+    L.qm_index_info_get.argtypes = [C.c_void_p, C.POINTER(QmIndexInfo)]
+    L.qm_index_txp_name.restype = C.c_char_p
+    L.qm_index_txp_name.argtypes = [C.c_void_p, C.c_int64]
+    L.qm_index_txp_len.restype = C.c_int64
+    L.qm_index_txp_len.argtypes = [C.c_void_p, C.c_int64]
+    L.qm_ctx_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.qm_ctx_destroy.argtypes = [C.c_void_p]
+    L.qm_ctx_device_bytes.restype = C.c_int64
+    L.qm_ctx_device_bytes.argtypes = [C.c_void_p]
+    L.qm_map_pairs.argtypes = [C.c_void_p, C.POINTER(QmOpts), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.POINTER(C.c_int64), C.POINTER(QmCounters)]
+    L.qm_map_reads.argtypes = [C.c_void_p, C.POINTER(QmOpts), C.c_int64, C.c_void_p, C.c_void_p,
+                               C.POINTER(C.c_int64), C.POINTER(QmCounters)]
+    L.qm_map_device.argtypes = [C.c_void_p, C.POINTER(QmOpts), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(QmCounters)]
+    L.qm_fetch_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.qm_result_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    L.qm_ctx_set_debug.argtypes = [C.c_void_p, C.c_int]
+    L.qm_fetch_intervals.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    L.qm_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.qm_build_index.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    L.qm_opts_default.argtypes = [C.POINTER(QmOpts)]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise QmError("qmap_mi355 error %d: %s" % (rc, lib().qm_last_error().decode(errors="replace")))
+
+
+def default_opts(**kw):
+    """`rapmap quasimap` defaults (src/RapMapSAMapper.cpp:992-1023,1113-1114)."""
+    o = QmOpts()
+    _check(lib().qm_opts_default(C.byref(o)))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def build_index(fasta, out_dir, k=31, no_clip_poly_a=False, keep_duplicates=False, threads=None):
+    """`rapmap quasiindex -t FASTA -i OUT -k K` (src/RapMapSAIndexer.cpp:821-927), dense hash, int32 SA."""
+    threads = threads or min(32, os.cpu_count() or 1)
+    rc = lib().qm_build_index(os.fsencode(fasta), os.fsencode(out_dir), k, int(no_clip_poly_a), int(keep_duplicates), threads)
+    if rc != 0:
+        lib().qm_indexer_last_error.restype = C.c_char_p
+        raise QmError("qm_build_index failed (%d): %s" % (rc, lib().qm_indexer_last_error().decode()))
+
+
+def pack_reads(reads):
+    """list of bytes/str -> (uint8 concat, int64 offsets[n+1])"""
+    bs = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]
+    off = np.zeros(len(bs) + 1, dtype=np.int64)
+    if bs:
+        np.cumsum([len(b) for b in bs], out=off[1:])
+    seq = np.frombuffer(b"".join(bs), dtype=np.uint8).copy() if bs else np.zeros(0, np.uint8)
+    return seq, off
+
+
+class QuasiIndex:
+    """RapMapSAIndex<int32_t, RegHashT>: load() == qm_index_open (src/RapMapSAIndex.cpp:97-176)."""
+
+    def __init__(self, index_dir):
+        self._h = C.c_void_p()
+        _check(lib().qm_index_open(os.fsencode(index_dir), C.byref(self._h)))
+        info = QmIndexInfo()
+        _check(lib().qm_index_info_get(self._h, C.byref(info)))
+        self.k, self.text_len, self.n_txps, self.n_keys = info.k, info.text_len, info.n_txps, info.n_keys
+        self._names = None
+        self._lens = None
+
+    @property
+    def txp_names(self):
+        if self._names is None:
+            self._names = [lib().qm_index_txp_name(self._h, i).decode() for i in range(self.n_txps)]
+        return self._names
+
+    @property
+    def txp_lens(self):
+        if self._lens is None:
+            self._lens = np.array([lib().qm_index_txp_len(self._h, i) for i in range(self.n_txps)], dtype=np.int64)
+        return self._lens
+
+    def close(self):
+        if self._h:
+            lib().qm_index_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MapResult:
+    __slots__ = ("hit_offsets", "hits", "counters", "n_hits", "map_kernel_ms", "total_ms")
+
+
+class QuasiMapper:
+    """One GPU context: the index replicated in HBM + work buffers.  `map_pairs` performs, for every
+    pair, SACollector() x2 -> hitsToMappingsSimple() x2 -> mergeLeftRightHits() on one wavefront."""
+
+    def __init__(self, index: QuasiIndex, device=0, debug=False):
+        self.index = index
+        self._h = C.c_void_p()
+        _check(lib().qm_ctx_create(index._h, device, C.byref(self._h)))
+        if debug:
+            _check(lib().qm_ctx_set_debug(self._h, 1))
+        self.device = device
+
+    @property
+    def device_bytes(self):
+        return lib().qm_ctx_device_bytes(self._h)
+
+    def _finish(self, n, n_hits, ctr, fetch=True):
+        r = MapResult()
+        r.n_hits = n_hits.value
+        r.counters = ctr.as_dict()
+        a, b = C.c_double(), C.c_double()
+        _check(lib().qm_last_kernel_ms(self._h, C.byref(a), C.byref(b)))
+        r.map_kernel_ms, r.total_ms = a.value, b.value
+        if fetch:
+            r.hit_offsets = np.zeros(n + 1, dtype=np.int64)
+            r.hits = np.zeros(max(r.n_hits, 0), dtype=HIT_DTYPE)
+            _check(lib().qm_fetch_hits(self._h, r.hit_offsets.ctypes.data, r.hits.ctypes.data if r.n_hits else None))
+        else:
+            r.hit_offsets = r.hits = None
+        return r
+
+    def map_pairs(self, seq1, off1, seq2, off2, opts=None):
+        opts = opts or default_opts()
+        seq1 = np.ascontiguousarray(seq1, dtype=np.uint8); off1 = np.ascontiguousarray(off1, dtype=np.int64)
+        seq2 = np.ascontiguousarray(seq2, dtype=np.uint8); off2 = np.ascontiguousarray(off2, dtype=np.int64)
+        n = len(off1) - 1
+        if len(off2) - 1 != n:
+            raise ValueError("left/right read counts differ")
+        nh, ctr = C.c_int64(0), QmCounters()
+        # numpy gives a non-null pointer even for empty arrays
+        _check(lib().qm_map_pairs(self._h, C.byref(opts), n, seq1.ctypes.data or 1, off1.ctypes.data,
+                                  seq2.ctypes.data or 1, off2.ctypes.data, C.byref(nh), C.byref(ctr)))
+        return self._finish(n, nh, ctr)
+
+    def map_reads(self, seq, off, opts=None):
+        opts = opts or default_opts()
+        seq = np.ascontiguousarray(seq, dtype=np.uint8); off = np.ascontiguousarray(off, dtype=np.int64)
+        n = len(off) - 1
+        nh, ctr = C.c_int64(0), QmCounters()
+        _check(lib().qm_map_reads(self._h, C.byref(opts), n, seq.ctypes.data or 1, off.ctypes.data, C.byref(nh), C.byref(ctr)))
+        return self._finish(n, nh, ctr)
+
+    def map_device(self, n, d_seq1, d_off1, d_seq2, d_off2, max_read_len, opts=None, fetch=False):
+        """Inputs are raw device pointers (ints) of arrays already resident in this GPU's HBM."""
+        opts = opts or default_opts()
+        nh, ctr = C.c_int64(0), QmCounters()
+        _check(lib().qm_map_device(self._h, C.byref(opts), n, d_seq1, d_off1, d_seq2, d_off2, max_read_len,
+                                   C.byref(nh), C.byref(ctr)))
+        return self._finish(n, nh, ctr, fetch=fetch)
+
+    def intervals(self, n):
+        """fwdSAInts / rcSAInts of the last map call (needs debug=True)."""
+        offs = np.zeros(n + 1, dtype=np.int64)
+        _check(lib().qm_fetch_intervals(self._h, offs.ctypes.data, None, 0))
+        ints = np.zeros(int(offs[-1]), dtype=INTERVAL_DTYPE)
+        if ints.size:
+            _check(lib().qm_fetch_intervals(self._h, offs.ctypes.data, ints.ctypes.data, ints.size))
+        return offs, ints
+
+    def close(self):
+        if self._h:
+            lib().qm_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,468 @@
+// qm_host.hip -- host side of libqmap_mi355.so: q5 index reader (mmap), HBM replica,
+// and the C ABI declared in include/qmap_mi355.h.
+//
+// Reader follows the writers in src/RapMapSAIndexer.cpp:109-110,242-243 (sa.bin),
+// :694-731 (rsd.bin, txpInfo.bin), :433-441 + include/sparsepp/spp.h:2355-2366 (hash.bin),
+// include/IndexHeader.hpp:45-57 (header.json); semantics of
+// RapMapSAIndex::load (src/RapMapSAIndex.cpp:97-176).  Files are mmap'd, never
+// deserialised into containers; the GPU flattens them (qm_kernels.hip).
+#include <fcntl.h>
+#include <hip/hip_runtime.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "qm_mapper.inl"
+#include "qm_device.h"
+
+using namespace qm;
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+  return code;
+}
+#define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(QM_E_NOGPU, "%s: %s", #x, hipGetErrorString(_e)); } while (0)
+
+struct MMap {
+  void* p = nullptr; size_t len = 0;
+  int open(const std::string& path) {
+    int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return -1;
+    struct stat st; if (fstat(fd, &st) != 0) { ::close(fd); return -1; }
+    len = (size_t)st.st_size;
+    if (len == 0) { ::close(fd); return -1; }
+    p = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (p == MAP_FAILED) { p = nullptr; return -1; }
+    return 0;
+  }
+  void close() { if (p) munmap(p, len); p = nullptr; }
+};
+
+struct qm_index {
+  std::string dir;
+  int k = 31; bool big = false, perfect = false;
+  MMap sa, txp, rsd, hash;
+  const int32_t* SA = nullptr; int64_t nSA = 0;
+  std::vector<std::string> names;
+  const int32_t* offsets = nullptr; int64_t nTxp = 0;
+  const uint8_t* text = nullptr; int64_t n = 0;
+  const uint32_t* completeLens = nullptr;
+  std::vector<int64_t> lens;
+  const uint8_t* hashRecs = nullptr; int64_t nKeys = 0;   // K x 16 B records
+  uint64_t rsdBits = 0;
+};
+
+struct qm_ctx {
+  const qm_index* ix = nullptr;
+  int device = 0, numCU = 256;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, evA = nullptr, evB = nullptr;
+  // index replica
+  uint8_t* d_text = nullptr; int32_t* d_SA = nullptr; void* d_sainfo = nullptr; void* d_slots = nullptr;
+  uint64_t cap = 0;
+  int64_t devBytes = 0;
+  // work buffers
+  int64_t capUnits = 0, capTmp = 0, capHits = 0, capSeq1 = 0, capSeq2 = 0, capGrid = 0;
+  uint32_t* d_cnt = nullptr; long long* d_tmpoff = nullptr; qm_hit* d_tmp = nullptr; qm_hit* d_hits = nullptr;
+  long long* d_offs = nullptr; u64* d_scal = nullptr; /* cursor, counters[6], status */ u64* d_gscr = nullptr;
+  void* d_scanTmp = nullptr; size_t scanTmpBytes = 0;
+  uint8_t* d_seq1 = nullptr; uint8_t* d_seq2 = nullptr; long long* d_off1 = nullptr; long long* d_off2 = nullptr;
+  qm_sa_interval_hit* d_dbg = nullptr; uint32_t* d_dbgcnt = nullptr; int64_t capDbg = 0; int debug = 0;
+  // last result
+  int64_t lastUnits = -1, lastHits = 0;
+  double lastMapMs = 0, lastTotalMs = 0;
+};
+
+template <typename T>
+static int ensure(T*& p, int64_t& cap, int64_t want, int64_t minGrow = 0) {
+  if (want <= cap && p) return QM_OK;
+  if (p) hipFree(p);
+  p = nullptr;
+  int64_t nc = want + minGrow;
+  if (hipMalloc((void**)&p, (size_t)nc * sizeof(T)) != hipSuccess) { cap = 0; return fail(QM_E_NOMEM, "hipMalloc of %lld bytes failed", (long long)(nc * sizeof(T))); }
+  cap = nc;
+  return QM_OK;
+}
+
+extern "C" {
+
+const char* qm_last_error(void) { return g_err; }
+const char* qm_version(void) { return "qmap_mi355 0.1 (RapMap 0.6.0 quasimap hot path, gfx950)"; }
+
+int qm_opts_default(qm_opts* o) {
+  if (!o) return fail(QM_E_ARG, "null opts");
+  o->sensitive = 1; o->strict_check = 1; o->max_num_hits = 200; o->no_orphans = 0; o->no_dovetail = 0;
+  o->fuzzy = 0; o->max_interval = 1000; o->sel_aln = 0; o->quasi_cov = 0.0;
+  return QM_OK;
+}
+
+// --------------------------------------------------------------------------- index
+static bool json_field(const std::string& js, const char* name, std::string& out) {
+  std::string key = std::string("\"") + name + "\"";
+  size_t p = js.find(key);
+  if (p == std::string::npos) return false;
+  p = js.find(':', p);
+  if (p == std::string::npos) return false;
+  ++p;
+  while (p < js.size() && (js[p] == ' ' || js[p] == '\t' || js[p] == '\n')) ++p;
+  size_t e = p;
+  if (js[p] == '"') { ++p; e = js.find('"', p); }
+  else { while (e < js.size() && js[e] != ',' && js[e] != '\n' && js[e] != '}') ++e; }
+  out = js.substr(p, e - p);
+  while (!out.empty() && (out.back() == ' ' || out.back() == '\r')) out.pop_back();
+  return true;
+}
+
+int qm_index_open(const char* dirIn, qm_index** out) {
+  if (!dirIn || !out) return fail(QM_E_ARG, "null argument");
+  qm_index* ix = new qm_index();
+  ix->dir = dirIn;
+  if (ix->dir.empty() || ix->dir.back() != '/') ix->dir += '/';
+  auto bail = [&](int code) { ix->sa.close(); ix->txp.close(); ix->rsd.close(); ix->hash.close(); delete ix; return code; };
+  {  // header.json (IndexHeader.hpp:45-57)
+    FILE* f = fopen((ix->dir + "header.json").c_str(), "rb");
+    if (!f) return bail(fail(QM_E_IO, "cannot open %sheader.json", ix->dir.c_str()));
+    std::string js; char buf[4096]; size_t r;
+    while ((r = fread(buf, 1, sizeof(buf), f)) > 0) js.append(buf, r);
+    fclose(f);
+    std::string v;
+    if (!json_field(js, "KmerLen", v)) return bail(fail(QM_E_IO, "header.json: no KmerLen"));
+    ix->k = atoi(v.c_str());
+    if (json_field(js, "BigSA", v)) ix->big = (v == "true");
+    if (json_field(js, "PerfectHash", v)) ix->perfect = (v == "true");
+    if (json_field(js, "IndexVersion", v) && v != "q5") return bail(fail(QM_E_IO, "index version %s != q5", v.c_str()));
+    if (ix->k < 1 || ix->k > 31) return bail(fail(QM_E_IO, "bad k %d", ix->k));
+  }
+  if (ix->big) return bail(fail(QM_E_UNSUPPORTED, "BigSA (int64) indices are not supported yet"));
+  if (ix->perfect) return bail(fail(QM_E_UNSUPPORTED, "perfect-hash (-p) indices are not supported yet"));
+  if (ix->sa.open(ix->dir + "sa.bin")) return bail(fail(QM_E_IO, "cannot map sa.bin"));
+  if (ix->txp.open(ix->dir + "txpInfo.bin")) return bail(fail(QM_E_IO, "cannot map txpInfo.bin"));
+  if (ix->rsd.open(ix->dir + "rsd.bin")) return bail(fail(QM_E_IO, "cannot map rsd.bin"));
+  if (ix->hash.open(ix->dir + "hash.bin")) return bail(fail(QM_E_IO, "cannot map hash.bin"));
+  {  // sa.bin: u64 n, n x i32
+    const uint8_t* p = (const uint8_t*)ix->sa.p;
+    if (ix->sa.len < 8) return bail(fail(QM_E_IO, "sa.bin truncated"));
+    uint64_t n; memcpy(&n, p, 8);
+    if (ix->sa.len != 8 + n * 4) return bail(fail(QM_E_IO, "sa.bin size mismatch"));
+    ix->SA = (const int32_t*)(p + 8); ix->nSA = (int64_t)n;
+  }
+  {  // txpInfo.bin: vector<string>, vector<i32>, string(text), vector<u32>
+    const uint8_t* p = (const uint8_t*)ix->txp.p; size_t len = ix->txp.len, off = 0;
+    auto rd64 = [&](uint64_t& v) { if (off + 8 > len) return false; memcpy(&v, p + off, 8); off += 8; return true; };
+    uint64_t cnt;
+    if (!rd64(cnt)) return bail(fail(QM_E_IO, "txpInfo.bin truncated"));
+    ix->names.reserve(cnt);
+    for (uint64_t i = 0; i < cnt; ++i) {
+      uint64_t l; if (!rd64(l) || off + l > len) return bail(fail(QM_E_IO, "txpInfo.bin truncated (names)"));
+      ix->names.emplace_back((const char*)p + off, (size_t)l); off += l;
+    }
+    uint64_t c2; if (!rd64(c2) || off + c2 * 4 > len) return bail(fail(QM_E_IO, "txpInfo.bin truncated (offsets)"));
+    ix->offsets = (const int32_t*)(p + off); ix->nTxp = (int64_t)c2; off += c2 * 4;
+    uint64_t tl; if (!rd64(tl) || off + tl > len) return bail(fail(QM_E_IO, "txpInfo.bin truncated (text)"));
+    ix->text = p + off; ix->n = (int64_t)tl; off += tl;
+    uint64_t c3; if (!rd64(c3) || off + c3 * 4 > len) return bail(fail(QM_E_IO, "txpInfo.bin truncated (lens)"));
+    ix->completeLens = (const uint32_t*)(p + off); off += c3 * 4;
+    if ((int64_t)cnt != ix->nTxp || ix->nTxp == 0) return bail(fail(QM_E_IO, "txpInfo.bin: name/offset count mismatch"));
+    if (ix->n != ix->nSA) return bail(fail(QM_E_IO, "text length %lld != SA length %lld", (long long)ix->n, (long long)ix->nSA));
+    // src/RapMapSAIndex.cpp:151-163
+    ix->lens.resize(ix->nTxp);
+    for (int64_t i = 0; i + 1 < ix->nTxp; ++i) ix->lens[i] = (int64_t)ix->offsets[i + 1] - 1 - ix->offsets[i];
+    ix->lens[ix->nTxp - 1] = (ix->nSA - 1) - ix->offsets[ix->nTxp - 1];
+  }
+  {  // rsd.bin: u64 nbits + bytes (only validated; the device derives transcript ids from the offsets)
+    const uint8_t* p = (const uint8_t*)ix->rsd.p;
+    if (ix->rsd.len < 8) return bail(fail(QM_E_IO, "rsd.bin truncated"));
+    memcpy(&ix->rsdBits, p, 8);
+    if (ix->rsd.len != 8 + (ix->rsdBits + 7) / 8) return bail(fail(QM_E_IO, "rsd.bin size mismatch"));
+    if ((int64_t)ix->rsdBits != ix->n) return bail(fail(QM_E_IO, "rsd.bin bits != text length"));
+  }
+  {  // hash.bin: 3 x big-endian u32 (0xFFFFFFFF escapes to u64), group bitmaps, records
+    const uint8_t* p = (const uint8_t*)ix->hash.p; size_t len = ix->hash.len, off = 0;
+    auto be = [&](uint64_t& v) {
+      if (off + 4 > len) return false;
+      v = ((uint64_t)p[off] << 24) | ((uint64_t)p[off + 1] << 16) | ((uint64_t)p[off + 2] << 8) | p[off + 3]; off += 4;
+      if (v == 0xFFFFFFFFULL) {
+        if (off + 8 > len) return false;
+        v = 0; for (int i = 0; i < 8; ++i) v = (v << 8) | p[off + i];
+        off += 8;
+      }
+      return true;
+    };
+    uint64_t magic, tsize, nb;
+    if (!be(magic) || !be(tsize) || !be(nb)) return bail(fail(QM_E_IO, "hash.bin truncated"));
+    if (magic != 0x24687531ULL) return bail(fail(QM_E_IO, "hash.bin bad magic"));
+    off += ((tsize + 31) / 32) * 4;
+    if (off + nb * 16 != len) return bail(fail(QM_E_IO, "hash.bin size mismatch (%zu + %llu*16 != %zu)", off, (unsigned long long)nb, len));
+    ix->hashRecs = p + off; ix->nKeys = (int64_t)nb;
+  }
+  *out = ix;
+  return QM_OK;
+}
+
+int qm_index_close(qm_index* ix) {
+  if (!ix) return QM_OK;
+  ix->sa.close(); ix->txp.close(); ix->rsd.close(); ix->hash.close();
+  delete ix;
+  return QM_OK;
+}
+
+int qm_index_info_get(const qm_index* ix, qm_index_info* info) {
+  if (!ix || !info) return fail(QM_E_ARG, "null argument");
+  info->k = ix->k; info->big_sa = ix->big; info->perfect_hash = ix->perfect; info->pad = 0;
+  info->text_len = ix->n; info->n_txps = ix->nTxp; info->n_keys = ix->nKeys;
+  return QM_OK;
+}
+const char* qm_index_txp_name(const qm_index* ix, int64_t tid) {
+  if (!ix || tid < 0 || tid >= ix->nTxp) return nullptr;
+  return ix->names[tid].c_str();
+}
+int64_t qm_index_txp_len(const qm_index* ix, int64_t tid) {
+  if (!ix || tid < 0 || tid >= ix->nTxp) return -1;
+  return ix->lens[tid];
+}
+
+// --------------------------------------------------------------------------- context
+int qm_ctx_destroy(qm_ctx* c) {
+  if (!c) return QM_OK;
+  hipSetDevice(c->device);
+  void* ptrs[] = {c->d_text, c->d_SA, c->d_sainfo, c->d_slots, c->d_cnt, c->d_tmpoff, c->d_tmp, c->d_hits, c->d_offs,
+                  c->d_scal, c->d_gscr, c->d_scanTmp, c->d_seq1, c->d_seq2, c->d_off1, c->d_off2, c->d_dbg, c->d_dbgcnt};
+  for (void* p : ptrs) if (p) hipFree(p);
+  if (c->ev0) hipEventDestroy(c->ev0);
+  if (c->ev1) hipEventDestroy(c->ev1);
+  if (c->evA) hipEventDestroy(c->evA);
+  if (c->evB) hipEventDestroy(c->evB);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+  return QM_OK;
+}
+
+int qm_ctx_create(const qm_index* ix, int device_id, qm_ctx** out) {
+  if (!ix || !out) return fail(QM_E_ARG, "null argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(QM_E_NOGPU, "no HIP device visible");
+  if (device_id < 0 || device_id >= ndev) return fail(QM_E_ARG, "device %d out of range (%d devices)", device_id, ndev);
+  HIPCHK(hipSetDevice(device_id));
+  qm_ctx* c = new qm_ctx();
+  c->ix = ix; c->device = device_id;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->numCU = prop.multiProcessorCount;
+#define CK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { int rc = fail(QM_E_NOGPU, "%s: %s", #x, hipGetErrorString(_e)); qm_ctx_destroy(c); return rc; } } while (0)
+  CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  CK(hipEventCreate(&c->ev0)); CK(hipEventCreate(&c->ev1)); CK(hipEventCreate(&c->evA)); CK(hipEventCreate(&c->evB));
+  const size_t pad = 256;
+  CK(hipMalloc((void**)&c->d_text, (size_t)ix->n + pad));
+  CK(hipMemsetAsync(c->d_text + ix->n, 0, pad, c->stream));
+  CK(hipMemcpyAsync(c->d_text, ix->text, (size_t)ix->n, hipMemcpyHostToDevice, c->stream));
+  CK(hipMalloc((void**)&c->d_SA, (size_t)ix->nSA * 4));
+  CK(hipMemcpyAsync(c->d_SA, ix->SA, (size_t)ix->nSA * 4, hipMemcpyHostToDevice, c->stream));
+  CK(hipMalloc(&c->d_sainfo, (size_t)ix->nSA * sizeof(SaInfo)));
+  int32_t* d_offsets = nullptr; void* d_recs = nullptr;
+  CK(hipMalloc((void**)&d_offsets, (size_t)ix->nTxp * 4));
+  CK(hipMemcpyAsync(d_offsets, ix->offsets, (size_t)ix->nTxp * 4, hipMemcpyHostToDevice, c->stream));
+  CK(qmk_build_sainfo(c->d_SA, ix->nSA, d_offsets, ix->nTxp, c->d_sainfo, c->stream));
+  c->cap = 16;
+  while (c->cap < (uint64_t)ix->nKeys * 2) c->cap <<= 1;
+  CK(hipMalloc(&c->d_slots, c->cap * sizeof(Slot)));
+  CK(hipMalloc(&d_recs, (size_t)(ix->nKeys > 0 ? ix->nKeys : 1) * 16));
+  if (ix->nKeys > 0) CK(hipMemcpyAsync(d_recs, ix->hashRecs, (size_t)ix->nKeys * 16, hipMemcpyHostToDevice, c->stream));
+  CK(qmk_build_slots(d_recs, ix->nKeys, c->d_slots, c->cap, c->stream));
+  CK(hipMalloc((void**)&c->d_scal, 16 * sizeof(u64)));
+  CK(hipStreamSynchronize(c->stream));
+  hipFree(d_offsets); hipFree(d_recs);
+  c->devBytes = ix->n + pad + ix->nSA * 4 + ix->nSA * (int64_t)sizeof(SaInfo) + (int64_t)(c->cap * sizeof(Slot));
+#undef CK
+  *out = c;
+  return QM_OK;
+}
+
+int64_t qm_ctx_device_bytes(const qm_ctx* c) { return c ? c->devBytes : 0; }
+int qm_ctx_set_debug(qm_ctx* c, int keep) { if (!c) return fail(QM_E_ARG, "null ctx"); c->debug = keep; return QM_OK; }
+
+static int check_opts(const qm_opts* o) {
+  if (!o) return fail(QM_E_ARG, "null opts");
+  if (!o->sensitive) return fail(QM_E_UNSUPPORTED, "--noSensitive (NIP skipping) is not implemented on the device path");
+  if (o->fuzzy) return fail(QM_E_UNSUPPORTED, "--fuzzyIntersection is not implemented on the device path");
+  if (o->sel_aln) return fail(QM_E_UNSUPPORTED, "--selAln is not implemented on the device path");
+  if (o->max_num_hits < 0 || o->max_interval < 1) return fail(QM_E_ARG, "bad max_num_hits / max_interval");
+  return QM_OK;
+}
+
+int qm_map_device(qm_ctx* c, const qm_opts* o, int64_t n, const void* d_seq1, const void* d_off1, const void* d_seq2,
+                  const void* d_off2, int32_t max_read_len, int64_t* n_hits, qm_counters* counters) {
+  if (!c || n < 0 || (n > 0 && (!d_seq1 || !d_off1))) return fail(QM_E_ARG, "bad argument");
+  int rc = check_opts(o);
+  if (rc) return rc;
+  if ((d_seq2 == nullptr) != (d_off2 == nullptr)) return fail(QM_E_ARG, "seq2/off2 must both be given or both be null");
+  if (max_read_len > QM_MAX_READ_LEN) return fail(QM_E_TOOLONG, "read length %d > %d", max_read_len, QM_MAX_READ_LEN);
+  HIPCHK(hipSetDevice(c->device));
+  const int ns = max_read_len <= 128 ? 2 : 4;
+  const int grid = qmk_map_grid(n, c->numCU);
+  int64_t dummy = 0;
+  int64_t capU1 = c->capUnits;
+  if ((rc = ensure(c->d_cnt, capU1, n + 1))) return rc;
+  capU1 = c->capUnits; if ((rc = ensure(c->d_tmpoff, capU1, n + 1))) return rc;
+  capU1 = c->capUnits; if ((rc = ensure(c->d_offs, capU1, n + 1))) return rc;
+  c->capUnits = capU1;
+  if ((rc = ensure(c->d_gscr, c->capGrid, (int64_t)grid * 4 * 4 * QM_GCAP))) return rc;
+  size_t stb = qmk_scan_temp_bytes(n + 1);
+  if (stb > c->scanTmpBytes || !c->d_scanTmp) {
+    if (c->d_scanTmp) hipFree(c->d_scanTmp);
+    c->d_scanTmp = nullptr; c->scanTmpBytes = 0;
+    HIPCHK(hipMalloc(&c->d_scanTmp, stb ? stb : 16));
+    c->scanTmpBytes = stb;
+  }
+  if (c->debug) {
+    int64_t cd = c->capDbg;
+    if ((rc = ensure(c->d_dbg, cd, n * QM_DBG_CAP + 1))) return rc;
+    cd = c->capDbg; if ((rc = ensure(c->d_dbgcnt, cd, n + 1))) return rc;
+    c->capDbg = cd;
+  }
+  (void)dummy;
+  int64_t wantTmp = n * 6 + 65536;
+  if (c->capTmp < wantTmp) { if ((rc = ensure(c->d_tmp, c->capTmp, wantTmp))) return rc; }
+
+  DevIndex ix; ix.text = c->d_text; ix.n = c->ix->n; ix.SA = c->d_SA; ix.nSA = c->ix->nSA;
+  ix.sainfo = (const SaInfo*)c->d_sainfo; ix.slots = (const Slot*)c->d_slots; ix.hmask = c->cap - 1; ix.k = c->ix->k;
+  u64 hscal[16];
+  HIPCHK(hipEventRecord(c->evA, c->stream));
+  while (true) {
+    Batch B; memset(&B, 0, sizeof(B));
+    B.seq1 = (const unsigned char*)d_seq1; B.off1 = (const long long*)d_off1;
+    B.seq2 = (const unsigned char*)d_seq2; B.off2 = (const long long*)d_off2; B.n = n;
+    B.hit_count = c->d_cnt; B.tmp_off = c->d_tmpoff; B.tmp_hits = c->d_tmp; B.cursor = c->d_scal; B.tmp_cap = c->capTmp;
+    B.counters = c->d_scal + 1; B.status = (int*)(c->d_scal + 8); B.gscratch = c->d_gscr;
+    B.dbg_ints = c->debug ? c->d_dbg : nullptr; B.dbg_count = c->debug ? c->d_dbgcnt : nullptr;
+    B.strict_check = o->strict_check; B.max_num_hits = o->max_num_hits; B.no_orphans = o->no_orphans;
+    B.no_dovetail = o->no_dovetail; B.max_interval = o->max_interval; B.quasi_cov = o->quasi_cov;
+    HIPCHK(hipMemsetAsync(c->d_scal, 0, 16 * sizeof(u64), c->stream));
+    HIPCHK(hipMemsetAsync(c->d_cnt + n, 0, sizeof(uint32_t), c->stream));
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    if (n > 0) HIPCHK(qmk_map(&ix, &B, ns, grid, c->stream));
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    HIPCHK(hipMemcpyAsync(hscal, c->d_scal, 16 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int status = (int)(hscal[8] & 0xffffffffu);
+    if (status & 4) return fail(QM_E_TOOLONG, "a read is longer than max_read_len=%d", max_read_len);
+    if (status & 2) return fail(QM_E_UNSUPPORTED, "an SA-interval list exceeded %d entries (max_interval too large)", QM_GCAP);
+    if (status & 1) {            // bump allocator ran out: grow and redo the batch
+      int64_t want = (int64_t)hscal[0] + n + 65536;
+      if (want < c->capTmp * 2) want = c->capTmp * 2;
+      if ((rc = ensure(c->d_tmp, c->capTmp, want))) return rc;
+      continue;
+    }
+    break;
+  }
+  float ms = 0; hipEventElapsedTime(&ms, c->ev0, c->ev1); c->lastMapMs = ms;
+  HIPCHK(qmk_scan_counts(c->d_scanTmp, c->scanTmpBytes, c->d_cnt, c->d_offs, n + 1, c->stream));
+  int64_t total = (int64_t)hscal[0];
+  if ((rc = ensure(c->d_hits, c->capHits, total + 1, total / 8))) return rc;
+  HIPCHK(qmk_gather(n, c->d_cnt, c->d_tmpoff, c->d_offs, c->d_tmp, c->d_hits, c->stream));
+  HIPCHK(hipEventRecord(c->evB, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  hipEventElapsedTime(&ms, c->evA, c->evB); c->lastTotalMs = ms;
+  c->lastUnits = n; c->lastHits = total;
+  if (n_hits) *n_hits = total;
+  if (counters) {
+    counters->pe_hits = hscal[1]; counters->se_hits = hscal[2]; counters->tot_hits = hscal[3];
+    counters->num_reads = hscal[4]; counters->too_many_hits = hscal[5]; counters->mapped = hscal[6];
+  }
+  return QM_OK;
+}
+
+static int upload(qm_ctx* c, int64_t n, const char* seq, const int64_t* off, uint8_t*& d_seq, long long*& d_off,
+                  int64_t& capSeq, int32_t& maxLen) {
+  int64_t bytes = off[n];
+  for (int64_t i = 0; i < n; ++i) { int64_t l = off[i + 1] - off[i]; if (l < 0) return fail(QM_E_ARG, "offsets not monotone"); if (l > maxLen) maxLen = (int32_t)(l > 0x7fffffff ? 0x7fffffff : l); }
+  int rc;
+  if ((rc = ensure(d_seq, capSeq, bytes + 64))) return rc;
+  if (bytes) HIPCHK(hipMemcpyAsync(d_seq, seq, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+  (void)d_off;
+  return QM_OK;
+}
+
+static int map_host(qm_ctx* c, const qm_opts* o, int64_t n, const char* seq1, const int64_t* off1, const char* seq2,
+                    const int64_t* off2, int64_t* n_hits, qm_counters* counters) {
+  if (!c || n < 0 || (n > 0 && (!seq1 || !off1))) return fail(QM_E_ARG, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  int32_t maxLen = 0; int rc;
+  static const int64_t zero = 0;
+  if (n == 0) { off1 = &zero; if (seq2) off2 = &zero; }
+  if ((rc = upload(c, n, seq1, off1, c->d_seq1, c->d_off1, c->capSeq1, maxLen))) return rc;
+  if (seq2 && (rc = upload(c, n, seq2, off2, c->d_seq2, c->d_off2, c->capSeq2, maxLen))) return rc;
+  if (maxLen > QM_MAX_READ_LEN) return fail(QM_E_TOOLONG, "read length %d > %d", maxLen, QM_MAX_READ_LEN);
+  // offsets (separate small buffers, reallocated with the unit capacity)
+  long long* d1 = nullptr; long long* d2 = nullptr;
+  HIPCHK(hipMalloc((void**)&d1, (size_t)(n + 1) * 8));
+  HIPCHK(hipMemcpyAsync(d1, off1, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  if (seq2) {
+    HIPCHK(hipMalloc((void**)&d2, (size_t)(n + 1) * 8));
+    HIPCHK(hipMemcpyAsync(d2, off2, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  rc = qm_map_device(c, o, n, c->d_seq1, d1, seq2 ? c->d_seq2 : nullptr, seq2 ? d2 : nullptr, maxLen, n_hits, counters);
+  hipFree(d1); if (d2) hipFree(d2);
+  return rc;
+}
+
+int qm_map_pairs(qm_ctx* c, const qm_opts* o, int64_t n, const char* seq1, const int64_t* off1, const char* seq2,
+                 const int64_t* off2, int64_t* n_hits, qm_counters* counters) {
+  if (!seq2 || !off2) return fail(QM_E_ARG, "qm_map_pairs needs both mates");
+  return map_host(c, o, n, seq1, off1, seq2, off2, n_hits, counters);
+}
+
+int qm_map_reads(qm_ctx* c, const qm_opts* o, int64_t n, const char* seq, const int64_t* off, int64_t* n_hits,
+                 qm_counters* counters) {
+  return map_host(c, o, n, seq, off, nullptr, nullptr, n_hits, counters);
+}
+
+int qm_fetch_hits(qm_ctx* c, int64_t* hit_offsets, qm_hit* hits) {
+  if (!c || c->lastUnits < 0) return fail(QM_E_STATE, "no mapping result to fetch");
+  HIPCHK(hipSetDevice(c->device));
+  if (hit_offsets) HIPCHK(hipMemcpy(hit_offsets, c->d_offs, (size_t)(c->lastUnits + 1) * 8, hipMemcpyDeviceToHost));
+  if (hits && c->lastHits > 0) HIPCHK(hipMemcpy(hits, c->d_hits, (size_t)c->lastHits * sizeof(qm_hit), hipMemcpyDeviceToHost));
+  return QM_OK;
+}
+
+int qm_result_device(qm_ctx* c, const void** d_hit_offsets, const void** d_hits) {
+  if (!c || c->lastUnits < 0) return fail(QM_E_STATE, "no mapping result");
+  if (d_hit_offsets) *d_hit_offsets = c->d_offs;
+  if (d_hits) *d_hits = c->d_hits;
+  return QM_OK;
+}
+
+int qm_fetch_intervals(qm_ctx* c, int64_t* int_offsets, qm_sa_interval_hit* ints, int64_t cap) {
+  if (!c || c->lastUnits < 0 || !c->debug || !c->d_dbg) return fail(QM_E_STATE, "no interval dump (enable with qm_ctx_set_debug before mapping)");
+  if (!int_offsets) return fail(QM_E_ARG, "null int_offsets");
+  HIPCHK(hipSetDevice(c->device));
+  int64_t n = c->lastUnits;
+  std::vector<uint32_t> cnt((size_t)n + 1);
+  if (n) HIPCHK(hipMemcpy(cnt.data(), c->d_dbgcnt, (size_t)n * 4, hipMemcpyDeviceToHost));
+  int_offsets[0] = 0;
+  for (int64_t i = 0; i < n; ++i) int_offsets[i + 1] = int_offsets[i] + (cnt[i] < QM_DBG_CAP ? cnt[i] : QM_DBG_CAP);
+  if (!ints) return QM_OK;
+  if (cap < int_offsets[n]) return fail(QM_E_ARG, "interval buffer too small");
+  std::vector<qm_sa_interval_hit> all((size_t)n * QM_DBG_CAP + 1);
+  if (n) HIPCHK(hipMemcpy(all.data(), c->d_dbg, (size_t)n * QM_DBG_CAP * sizeof(qm_sa_interval_hit), hipMemcpyDeviceToHost));
+  for (int64_t i = 0; i < n; ++i)
+    for (int64_t j = 0; j < int_offsets[i + 1] - int_offsets[i]; ++j) ints[int_offsets[i] + j] = all[(size_t)i * QM_DBG_CAP + j];
+  return QM_OK;
+}
+
+int qm_last_kernel_ms(const qm_ctx* c, double* map_ms, double* total_ms) {
+  if (!c || c->lastUnits < 0) return fail(QM_E_STATE, "no mapping result");
+  if (map_ms) *map_ms = c->lastMapMs;
+  if (total_ms) *total_ms = c->lastTotalMs;
+  return QM_OK;
+}
+
+}  // extern "C"

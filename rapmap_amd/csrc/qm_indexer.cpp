@@ -1,0 +1,373 @@
+// qm_indexer.cpp -- `rapmap quasiindex` for the dense-hash / int32 index variant, host only.
+//
+// Produces the on-disk "q5" quasi-index that qm_index_open() mmaps:
+//   header.json  (include/IndexHeader.hpp:45-57)       sa.bin      (src/RapMapSAIndexer.cpp:109-110,242-243)
+//   txpInfo.bin  (src/RapMapSAIndexer.cpp:705-731)     rsd.bin     (:694-703, src/bit_array.c:2951-2989)
+//   hash.bin     (:433-441; container layout of include/sparsepp/spp.h:2355-2366,2420-2429 so that the
+//                 reference can unserialize it in place: slot = XXH64(key) & (size-1), triangular probing)
+// Text rules restate indexTranscriptsSA (:449-735): isprint filter, upper-casing, pseudo-random
+// replacement of non-ACGT (std::default_random_engine(271828) + uniform_int_distribution<>(0,3)),
+// poly-A clipping, duplicate removal keyed on XXH64 of the raw sequence, '$' after every transcript.
+// The suffix array is built with our own SA-IS (the reference links libdivsufsort; the suffix
+// array of a text is unique, so the file is identical), the k-mer -> SA-interval map is the run
+// structure of the k-prefixes of the sorted suffixes (buildHash, :262-443).
+// The four SHA digests of header.json are informational (nothing reads them back); they are
+// written as empty strings.
+#include <algorithm>
+#include <cctype>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <random>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <sys/stat.h>
+
+#include "qmap_mi355.h"
+
+namespace {
+
+// ---------------------------------------------------------------- XXH64 (public algorithm, own code)
+const uint64_t P1 = 11400714785074694791ULL, P2 = 14029467366897019727ULL, P3 = 1609587929392839161ULL,
+               P4 = 9650029242287828579ULL, P5 = 2870177450012600261ULL;
+inline uint64_t rotl(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+inline uint64_t rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+inline uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+inline uint64_t xround(uint64_t acc, uint64_t in) { return rotl(acc + in * P2, 31) * P1; }
+inline uint64_t xmerge(uint64_t acc, uint64_t v) { return (acc ^ xround(0, v)) * P1 + P4; }
+uint64_t xxh64(const void* data, size_t len, uint64_t seed) {
+  const uint8_t* p = (const uint8_t*)data; const uint8_t* end = p + len;
+  uint64_t h;
+  if (len >= 32) {
+    uint64_t v1 = seed + P1 + P2, v2 = seed + P2, v3 = seed, v4 = seed - P1;
+    const uint8_t* lim = end - 32;
+    do { v1 = xround(v1, rd64(p)); v2 = xround(v2, rd64(p + 8)); v3 = xround(v3, rd64(p + 16)); v4 = xround(v4, rd64(p + 24)); p += 32; } while (p <= lim);
+    h = rotl(v1, 1) + rotl(v2, 7) + rotl(v3, 12) + rotl(v4, 18);
+    h = xmerge(h, v1); h = xmerge(h, v2); h = xmerge(h, v3); h = xmerge(h, v4);
+  } else {
+    h = seed + P5;
+  }
+  h += (uint64_t)len;
+  while (p + 8 <= end) { h ^= xround(0, rd64(p)); h = rotl(h, 27) * P1 + P4; p += 8; }
+  if (p + 4 <= end) { h ^= (uint64_t)rd32(p) * P1; h = rotl(h, 23) * P2 + P3; p += 4; }
+  while (p < end) { h ^= (*p) * P5; h = rotl(h, 11) * P1; ++p; }
+  h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+  return h;
+}
+
+// ---------------------------------------------------------------- SA-IS (Nong, Zhang & Chan 2009)
+template <typename S>
+void getBuckets(const S* s, int32_t* bkt, int32_t n, int32_t K, bool end) {
+  std::fill(bkt, bkt + K, 0);
+  for (int32_t i = 0; i < n; ++i) ++bkt[s[i]];
+  int32_t sum = 0;
+  for (int32_t i = 0; i < K; ++i) { sum += bkt[i]; bkt[i] = end ? sum : sum - bkt[i]; }
+}
+template <typename S>
+void induceL(const uint8_t* t, int32_t* SA, const S* s, int32_t* bkt, int32_t n, int32_t K) {
+  getBuckets(s, bkt, n, K, false);
+  for (int32_t i = 0; i < n; ++i) { int32_t j = SA[i] - 1; if (j >= 0 && !t[j]) SA[bkt[s[j]]++] = j; }
+}
+template <typename S>
+void induceS(const uint8_t* t, int32_t* SA, const S* s, int32_t* bkt, int32_t n, int32_t K) {
+  getBuckets(s, bkt, n, K, true);
+  for (int32_t i = n - 1; i >= 0; --i) { int32_t j = SA[i] - 1; if (j >= 0 && t[j]) SA[--bkt[s[j]]] = j; }
+}
+// s[n-1] must be the unique smallest character
+template <typename S>
+void sais(const S* s, int32_t* SA, int32_t n, int32_t K) {
+  std::vector<uint8_t> tv((size_t)n);
+  uint8_t* t = tv.data();       // 1 = S-type
+  t[n - 1] = 1;
+  if (n >= 2) t[n - 2] = 0;
+  for (int32_t i = n - 3; i >= 0; --i) t[i] = (s[i] < s[i + 1] || (s[i] == s[i + 1] && t[i + 1])) ? 1 : 0;
+  auto isLMS = [&](int32_t i) { return i > 0 && t[i] && !t[i - 1]; };
+  std::vector<int32_t> bktv((size_t)K);
+  int32_t* bkt = bktv.data();
+  getBuckets(s, bkt, n, K, true);
+  std::fill(SA, SA + n, -1);
+  for (int32_t i = 1; i < n; ++i) if (isLMS(i)) SA[--bkt[s[i]]] = i;
+  induceL(t, SA, s, bkt, n, K);
+  induceS(t, SA, s, bkt, n, K);
+  int32_t n1 = 0;
+  for (int32_t i = 0; i < n; ++i) if (isLMS(SA[i])) SA[n1++] = SA[i];
+  std::fill(SA + n1, SA + n, -1);
+  int32_t name = 0, prev = -1;
+  for (int32_t i = 0; i < n1; ++i) {
+    int32_t pos = SA[i];
+    bool diff = false;
+    for (int32_t d = 0; d < n; ++d) {
+      if (prev == -1 || s[pos + d] != s[prev + d] || t[pos + d] != t[prev + d]) { diff = true; break; }
+      else if (d > 0 && (isLMS(pos + d) || isLMS(prev + d))) break;
+    }
+    if (diff) { ++name; prev = pos; }
+    SA[n1 + pos / 2] = name - 1;
+  }
+  for (int32_t i = n - 1, j = n - 1; i >= n1; --i) if (SA[i] >= 0) SA[j--] = SA[i];
+  int32_t* SA1 = SA; int32_t* s1 = SA + n - n1;
+  if (name < n1) sais<int32_t>(s1, SA1, n1, name);
+  else for (int32_t i = 0; i < n1; ++i) SA1[s1[i]] = i;
+  getBuckets(s, bkt, n, K, true);
+  for (int32_t i = 1, j = 0; i < n; ++i) if (isLMS(i)) s1[j++] = i;
+  for (int32_t i = 0; i < n1; ++i) SA1[i] = s1[SA1[i]];
+  std::fill(SA + n1, SA + n, -1);
+  for (int32_t i = n1 - 1; i >= 0; --i) { int32_t j = SA[i]; SA[i] = -1; SA[--bkt[s[j]]] = j; }
+  induceL(t, SA, s, bkt, n, K);
+  induceS(t, SA, s, bkt, n, K);
+}
+
+struct KmerRun { uint64_t key; int32_t lb, ub; };
+
+int8_t g_code[256];
+struct CodeInit { CodeInit() { memset(g_code, -1, 256); g_code['A'] = g_code['a'] = 0; g_code['C'] = g_code['c'] = 1; g_code['G'] = g_code['g'] = 2; g_code['T'] = g_code['t'] = 3; } } g_codeInit;
+
+// 2-bit word of text[p, p+k) or false when it runs off the text / crosses a '$'
+inline bool kmerAt(const std::string& text, int64_t p, int k, uint64_t& w) {
+  if (p + k > (int64_t)text.size()) return false;
+  w = 0;
+  for (int i = 0; i < k; ++i) { int c = g_code[(uint8_t)text[p + i]]; if (c < 0) return false; w = (w << 2) | (uint64_t)c; }
+  return true;
+}
+
+bool writeAll(const std::string& path, const void* a, size_t na, const void* b = nullptr, size_t nb = 0,
+              const void* c = nullptr, size_t nc = 0) {
+  FILE* f = fopen(path.c_str(), "wb");
+  if (!f) return false;
+  bool ok = true;
+  if (na) ok &= fwrite(a, 1, na, f) == na;
+  if (nb) ok &= fwrite(b, 1, nb, f) == nb;
+  if (nc) ok &= fwrite(c, 1, nc, f) == nc;
+  ok &= fclose(f) == 0;
+  return ok;
+}
+
+thread_local char g_ierr[256];
+
+}  // namespace
+
+extern "C" const char* qm_indexer_last_error(void) { return g_ierr; }
+
+extern "C" int qm_build_index(const char* fasta_path, const char* out_dir_c, int32_t k, int32_t no_clip_poly_a,
+                              int32_t keep_duplicates, int32_t n_threads) {
+  auto fail = [&](int code, const char* msg) { snprintf(g_ierr, sizeof(g_ierr), "%s", msg); return code; };
+  if (!fasta_path || !out_dir_c) return fail(QM_E_ARG, "null path");
+  if (k < 1 || k > 31 || (k % 2) == 0) return fail(QM_E_ARG, "k must be odd and <= 31 (RapMapSAIndexer.cpp:870-877)");
+  if (n_threads < 1) n_threads = 1;
+  std::string outDir(out_dir_c);
+  if (outDir.empty() || outDir.back() != '/') outDir += '/';
+  mkdir(outDir.c_str(), 0755);
+
+  // ---- step 1: read + transform the transcripts (:500-640)
+  FILE* f = fopen(fasta_path, "rb");
+  if (!f) return fail(QM_E_IO, "cannot open FASTA");
+  std::default_random_engine eng(271828);
+  std::uniform_int_distribution<> dis(0, 3);
+  const char bases[] = {'A', 'C', 'G', 'T'};
+  const uint32_t polyAClipLength = 10;
+  const std::string polyA(polyAClipLength, 'A');
+  const std::string sepStr = " \t";
+  struct DupInfo { uint64_t txId, txOffset; uint32_t txLen; };
+  std::map<uint64_t, std::vector<DupInfo>> potentialDuplicates;
+  std::vector<std::pair<std::string, std::string>> dupNames;   // (retained, dropped)
+  std::vector<std::string> names;
+  std::vector<int64_t> starts;
+  std::vector<uint32_t> completeLens;
+  std::vector<uint64_t> onePos;
+  std::string text;
+  uint32_t n = 0; size_t currIndex = 0;
+
+  std::string recName, readStr;
+  bool haveRec = false;
+  auto process = [&]() {
+    if (!haveRec) return;
+    readStr.erase(std::remove_if(readStr.begin(), readStr.end(), [](const char a) { return !isprint((unsigned char)a); }), readStr.end());
+    uint32_t readLen = (uint32_t)readStr.size();
+    uint32_t completeLen = readLen;
+    uint64_t h = xxh64(readStr.data(), readLen, 0);
+    for (size_t b = 0; b < readLen; ++b) {
+      readStr[b] = (char)::toupper((unsigned char)readStr[b]);
+      if (g_code[(uint8_t)readStr[b]] < 0) readStr[b] = bases[dis(eng)];
+    }
+    if (!no_clip_poly_a) {
+      if (readStr.size() > polyAClipLength && readStr.compare(readStr.size() - polyAClipLength, polyAClipLength, polyA) == 0) {
+        size_t newEnd = readStr.find_last_not_of("Aa");
+        if (newEnd == std::string::npos) readStr.resize(0); else readStr.resize(newEnd + 1);
+      }
+    }
+    readLen = (uint32_t)readStr.size();
+    if (readLen == 0) return;
+    uint32_t txpIndex = n++;
+    std::string processedName = recName.substr(0, recName.find_first_of(sepStr));
+    bool didCollide = false;
+    auto it = potentialDuplicates.find(h);
+    if (it != potentialDuplicates.end()) {
+      for (auto& d : it->second) {
+        if (readLen == d.txLen && text.compare(d.txOffset, readLen, readStr) == 0) {
+          didCollide = true;
+          dupNames.emplace_back(names[d.txId], processedName);
+        }
+      }
+    }
+    if (!keep_duplicates && didCollide) { --n; return; }
+    names.push_back(processedName);
+    starts.push_back((int64_t)currIndex);
+    completeLens.push_back(completeLen);
+    if (!keep_duplicates || !didCollide) potentialDuplicates[h].push_back({txpIndex, currIndex, readLen});
+    text += readStr;
+    text += '$';
+    currIndex += readLen + 1;
+    onePos.push_back(currIndex - 1);
+  };
+  {
+    std::vector<char> buf(1 << 20);
+    std::string line;
+    auto handleLine = [&](std::string& ln) {
+      while (!ln.empty() && (ln.back() == '\n' || ln.back() == '\r')) ln.pop_back();
+      if (!ln.empty() && ln[0] == '>') {
+        process();
+        // kseq: name = header up to the first whitespace
+        size_t e = 1; while (e < ln.size() && !isspace((unsigned char)ln[e])) ++e;
+        recName = ln.substr(1, e - 1); readStr.clear(); haveRec = true;
+      } else if (haveRec) {
+        readStr += ln;
+      }
+    };
+    while (fgets(buf.data(), (int)buf.size(), f)) {
+      line += buf.data();
+      if (!line.empty() && line.back() != '\n' && !feof(f)) continue;   // long line: keep reading
+      handleLine(line);
+      line.clear();
+    }
+    if (!line.empty()) handleLine(line);
+    process();
+    fclose(f);
+  }
+  if (names.empty()) return fail(QM_E_IO, "no transcripts in FASTA");
+  const size_t tlen = text.size();
+  if (tlen + 1 > (size_t)0x7fffffff) return fail(QM_E_UNSUPPORTED, "text needs a 64-bit suffix array (BigSA), not supported yet");
+
+  {  // duplicate_clusters.tsv (:660-670)
+    std::string s = "RetainedTxp\tDuplicateTxp\n";
+    for (auto& p : dupNames) { s += p.first; s += '\t'; s += p.second; s += '\n'; }
+    writeAll(outDir + "duplicate_clusters.tsv", s.data(), s.size());
+  }
+  {  // rsd.bin: u64 nbits + ceil(nbits/8) bytes, bit i <=> text[i]=='$'
+    uint64_t nbits = tlen; std::vector<uint8_t> bits((nbits + 7) / 8, 0);
+    for (uint64_t p : onePos) bits[p >> 3] |= (uint8_t)(1u << (p & 7));
+    if (!writeAll(outDir + "rsd.bin", &nbits, 8, bits.data(), bits.size())) return fail(QM_E_IO, "cannot write rsd.bin");
+  }
+  {  // txpInfo.bin
+    FILE* o = fopen((outDir + "txpInfo.bin").c_str(), "wb");
+    if (!o) return fail(QM_E_IO, "cannot write txpInfo.bin");
+    uint64_t c = names.size(); fwrite(&c, 8, 1, o);
+    for (auto& nm : names) { uint64_t l = nm.size(); fwrite(&l, 8, 1, o); fwrite(nm.data(), 1, nm.size(), o); }
+    std::vector<int32_t> st32(starts.size());
+    for (size_t i = 0; i < starts.size(); ++i) st32[i] = (int32_t)starts[i];
+    c = st32.size(); fwrite(&c, 8, 1, o); fwrite(st32.data(), 4, st32.size(), o);
+    c = tlen; fwrite(&c, 8, 1, o); fwrite(text.data(), 1, tlen, o);
+    c = completeLens.size(); fwrite(&c, 8, 1, o); fwrite(completeLens.data(), 4, completeLens.size(), o);
+    if (fclose(o) != 0) return fail(QM_E_IO, "cannot write txpInfo.bin");
+  }
+
+  // ---- step 2: suffix array (divsufsort in the reference, :99-101,232-234)
+  std::vector<int32_t> SA;
+  {
+    // map to {1..5} with a unique 0 sentinel appended ('$' < A < C < G < T as bytes)
+    std::vector<uint8_t> s(tlen + 1);
+    for (size_t i = 0; i < tlen; ++i) {
+      char ch = text[i];
+      s[i] = ch == '$' ? 1 : (uint8_t)(2 + g_code[(uint8_t)ch]);
+    }
+    s[tlen] = 0;
+    std::vector<int32_t> sa1(tlen + 1);
+    sais<uint8_t>(s.data(), sa1.data(), (int32_t)(tlen + 1), 6);
+    SA.assign(sa1.begin() + 1, sa1.end());   // drop the sentinel suffix
+  }
+  {
+    uint64_t c = SA.size();
+    if (!writeAll(outDir + "sa.bin", &c, 8, SA.data(), SA.size() * 4)) return fail(QM_E_IO, "cannot write sa.bin");
+  }
+
+  // ---- step 3: k-mer -> SA interval (:262-443): maximal runs of suffixes sharing a valid k-prefix
+  std::vector<std::vector<KmerRun>> parts((size_t)n_threads);
+  {
+    const int64_t N = (int64_t)tlen;
+    auto worker = [&](int t) {
+      int64_t b = N * t / n_threads, e = N * (t + 1) / n_threads;
+      // snap the chunk start forward to the first run boundary
+      uint64_t w, pw;
+      if (b > 0) {
+        while (b < e) {
+          bool v = kmerAt(text, SA[b], k, w), pv = kmerAt(text, SA[b - 1], k, pw);
+          if (v && pv && w == pw) ++b; else break;
+        }
+      }
+      int64_t i = b;
+      auto& out = parts[t];
+      while (i < e) {
+        if (!kmerAt(text, SA[i], k, w)) { ++i; continue; }
+        int64_t j = i + 1; uint64_t w2;
+        while (j < N && kmerAt(text, SA[j], k, w2) && w2 == w) ++j;   // may run past e: the next chunk snapped
+        out.push_back({w, (int32_t)i, (int32_t)j});
+        i = j;
+      }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; ++t) th.emplace_back(worker, t);
+    worker(0);
+    for (auto& x : th) x.join();
+  }
+  size_t K = 0;
+  for (auto& p : parts) K += p.size();
+
+  // ---- step 4: hash.bin in sparsepp's container layout
+  {
+    uint64_t tsize = 32;
+    while (K * 2 > tsize) tsize <<= 1;          // occupancy <= 50 % like spp's resize policy
+    const uint64_t mask = tsize - 1;
+    std::vector<uint32_t> slotOf(tsize, 0xFFFFFFFFu);    // index into the flattened run list
+    std::vector<KmerRun> runs; runs.reserve(K);
+    for (auto& p : parts) { runs.insert(runs.end(), p.begin(), p.end()); std::vector<KmerRun>().swap(p); }
+    for (size_t r = 0; r < runs.size(); ++r) {
+      uint64_t key = runs[r].key;
+      uint64_t pos = xxh64(&key, 8, 0) & mask, probes = 0;
+      while (slotOf[pos] != 0xFFFFFFFFu) { ++probes; pos = (pos + probes) & mask; }   // JUMP_ = num_probes (spp.h:2498)
+      slotOf[pos] = (uint32_t)r;
+    }
+    FILE* o = fopen((outDir + "hash.bin").c_str(), "wb");
+    if (!o) return fail(QM_E_IO, "cannot write hash.bin");
+    auto be32or64 = [&](uint64_t v) {
+      auto be = [&](uint64_t x, int nb) { for (int i = nb - 1; i >= 0; --i) fputc((int)((x >> (8 * i)) & 0xff), o); };
+      if (v < 0xFFFFFFFFULL) be(v, 4); else { be(0xFFFFFFFFULL, 4); be(v, 8); }
+    };
+    be32or64(0x24687531ULL); be32or64(tsize); be32or64((uint64_t)runs.size());
+    std::vector<uint32_t> bitmaps(tsize / 32, 0);
+    for (uint64_t p = 0; p < tsize; ++p) if (slotOf[p] != 0xFFFFFFFFu) bitmaps[p >> 5] |= (1u << (p & 31));
+    fwrite(bitmaps.data(), 4, bitmaps.size(), o);
+    std::vector<uint8_t> rec; rec.reserve(1 << 20);
+    for (uint64_t p = 0; p < tsize; ++p) {
+      uint32_t r = slotOf[p];
+      if (r == 0xFFFFFFFFu) continue;
+      uint8_t b[16]; memcpy(b, &runs[r].key, 8); memcpy(b + 8, &runs[r].lb, 4); memcpy(b + 12, &runs[r].ub, 4);
+      rec.insert(rec.end(), b, b + 16);
+      if (rec.size() >= (1 << 20)) { fwrite(rec.data(), 1, rec.size(), o); rec.clear(); }
+    }
+    if (!rec.empty()) fwrite(rec.data(), 1, rec.size(), o);
+    if (fclose(o) != 0) return fail(QM_E_IO, "cannot write hash.bin");
+  }
+  {  // header.json / refInfo.json
+    char js[1024];
+    snprintf(js, sizeof(js),
+             "{\n    \"value0\": {\n    \"IndexType\": 1,\n    \"IndexVersion\": \"q5\",\n    \"UsesKmers\": true,\n"
+             "    \"KmerLen\": %d,\n    \"BigSA\": false,\n    \"PerfectHash\": false,\n    \"SeqHash\": \"\",\n"
+             "    \"NameHash\": \"\",\n    \"SeqHash512\": \"\",\n    \"NameHash512\": \"\"\n    }\n}", k);
+    if (!writeAll(outDir + "header.json", js, strlen(js))) return fail(QM_E_IO, "cannot write header.json");
+    std::string ri = std::string("{\n    \"ReferenceFiles\": [\n        \"") + fasta_path + "\"\n    ]\n}";
+    writeAll(outDir + "refInfo.json", ri.data(), ri.size());
+  }
+  return QM_OK;
+}
