@@ -108,6 +108,10 @@ int qm_index_close(qm_index* ix);
 int qm_index_info_get(const qm_index* ix, qm_index_info* info);
 const char* qm_index_txp_name(const qm_index* ix, int64_t tid); /* rmi.txpNames[tid] */
 int64_t qm_index_txp_len(const qm_index* ix, int64_t tid);      /* rmi.txpLens[tid]  */
+/* Read-only views of rmi.seq (the '$'-separated text) and rmi.txpOffsets (include/RapMapSAIndex.hpp:70-82);
+ * valid until qm_index_close. */
+int qm_index_arrays(const qm_index* ix, const uint8_t** text, int64_t* text_len, const int32_t** txp_offsets,
+                    int64_t* n_txps);
 
 /* Replicates the index into the HBM of `device_id` as flat SoA arrays and
  * allocates the per-context work buffers.  One ctx per GPU / per host thread. */

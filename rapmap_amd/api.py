@@ -30,7 +30,7 @@ assert HIT_DTYPE.itemsize == 32 and INTERVAL_DTYPE.itemsize == 20
 # every symbol include/qmap_mi355.h declares
 ABI_SYMBOLS = [
     "qm_last_error", "qm_version", "qm_opts_default", "qm_index_open", "qm_index_close", "qm_index_info_get",
-    "qm_index_txp_name", "qm_index_txp_len", "qm_ctx_create", "qm_ctx_destroy", "qm_ctx_device_bytes",
+    "qm_index_txp_name", "qm_index_txp_len", "qm_index_arrays", "qm_ctx_create", "qm_ctx_destroy", "qm_ctx_device_bytes",
     "qm_map_pairs", "qm_map_reads", "qm_map_device", "qm_fetch_hits", "qm_result_device", "qm_ctx_set_debug",
     "qm_fetch_intervals", "qm_last_kernel_ms", "qm_build_index",
 ]
@@ -83,6 +83,8 @@ def lib():
     L.qm_index_txp_name.argtypes = [C.c_void_p, C.c_int64]
     L.qm_index_txp_len.restype = C.c_int64
     L.qm_index_txp_len.argtypes = [C.c_void_p, C.c_int64]
+    L.qm_index_arrays.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p),
+                                  C.POINTER(C.c_int64)]
     L.qm_ctx_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     L.qm_ctx_destroy.argtypes = [C.c_void_p]
     L.qm_ctx_device_bytes.restype = C.c_int64
@@ -162,6 +164,14 @@ class QuasiIndex:
         if self._lens is None:
             self._lens = np.array([lib().qm_index_txp_len(self._h, i) for i in range(self.n_txps)], dtype=np.int64)
         return self._lens
+
+    def arrays(self):
+        """(text uint8[n], txpOffsets int64[T]) -- copies of rmi.seq / rmi.txpOffsets"""
+        tp, tl, op, nt = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
+        _check(lib().qm_index_arrays(self._h, C.byref(tp), C.byref(tl), C.byref(op), C.byref(nt)))
+        text = np.ctypeslib.as_array(C.cast(tp, C.POINTER(C.c_uint8)), shape=(tl.value,)).copy()
+        raw = np.ctypeslib.as_array(C.cast(op, C.POINTER(C.c_uint8)), shape=(nt.value * 4,)).copy()
+        return text, raw.view("<i4").astype(np.int64)
 
     def close(self):
         if self._h:

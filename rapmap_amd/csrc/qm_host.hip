@@ -230,6 +230,16 @@ int64_t qm_index_txp_len(const qm_index* ix, int64_t tid) {
   return ix->lens[tid];
 }
 
+int qm_index_arrays(const qm_index* ix, const uint8_t** text, int64_t* text_len, const int32_t** txp_offsets,
+                    int64_t* n_txps) {
+  if (!ix) return fail(QM_E_ARG, "null index");
+  if (text) *text = ix->text;
+  if (text_len) *text_len = ix->n;
+  if (txp_offsets) *txp_offsets = ix->offsets;
+  if (n_txps) *n_txps = ix->nTxp;
+  return QM_OK;
+}
+
 // --------------------------------------------------------------------------- context
 int qm_ctx_destroy(qm_ctx* c) {
   if (!c) return QM_OK;

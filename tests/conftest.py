@@ -1,0 +1,100 @@
+import gzip
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+for _p in (os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "emu")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _have_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def lib_built():
+    """libqmap_mi355.so, built in-tree (hipcc cross-compiles without a GPU)."""
+    import rapmap_amd
+    if not os.path.exists(rapmap_amd.LIB_PATH):
+        if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "rapmap_amd", "csrc")])
+        else:
+            pytest.fail("libqmap_mi355.so missing and no hipcc to build it")
+    return rapmap_amd.LIB_PATH
+
+
+def _gunzip(src, dst):
+    with gzip.open(src, "rb") as g, open(dst, "wb") as o:
+        shutil.copyfileobj(g, o)
+
+
+@pytest.fixture(scope="session")
+def sample_data(tmp_path_factory, lib_built):
+    """config 1: the reference's sample_data, index built with our own quasiindex."""
+    import rapmap_amd as ra
+    from rapmap_amd import sam
+    d = tmp_path_factory.mktemp("sample")
+    idx = str(d / "idx")
+    ra.build_index(os.path.join(GOLD, "sample_data", "transcripts.fasta"), idx, threads=4)
+    n1, s1 = sam.read_fastq(os.path.join(GOLD, "sample_data", "reads_1.fastq.gz"))
+    n2, s2 = sam.read_fastq(os.path.join(GOLD, "sample_data", "reads_2.fastq.gz"))
+    return {"idx": idx, "names1": n1, "names2": n2, "reads1": s1, "reads2": s2}
+
+
+@pytest.fixture(scope="session")
+def synth_small(tmp_path_factory, lib_built):
+    import rapmap_amd as ra
+    from rapmap_amd import sam
+    d = tmp_path_factory.mktemp("synth_small")
+    fa = str(d / "txome.fa")
+    _gunzip(os.path.join(GOLD, "synth_small", "txome.fa.gz"), fa)
+    idx = str(d / "idx")
+    ra.build_index(fa, idx, threads=4)
+    n1, s1 = sam.read_fastq(os.path.join(GOLD, "synth_small", "reads_1.fastq.gz"))
+    n2, s2 = sam.read_fastq(os.path.join(GOLD, "synth_small", "reads_2.fastq.gz"))
+    return {"idx": idx, "fasta": fa, "names1": n1, "names2": n2, "reads1": s1, "reads2": s2}
+
+
+@pytest.fixture(scope="session")
+def synth_medium(tmp_path_factory, lib_built):
+    """~1/40 of config 2: 1000 genes (~5k transcripts, ~8 M chars), 60k pairs 2x100 bp, 1 % errors."""
+    import rapmap_amd as ra
+    from rapmap_amd import synth
+    d = tmp_path_factory.mktemp("synth_medium")
+    names, txps = synth.make_transcriptome(1000, seed=42, paralog_frac=0.05)
+    fa = str(d / "txome.fa")
+    synth.write_fasta(fa, names, txps)
+    idx = str(d / "idx")
+    ra.build_index(fa, idx, threads=8)
+    s1, s2, off, truth = synth.make_reads(txps, 60000, seed=43)
+    return {"idx": idx, "seq1": s1, "seq2": s2, "off": off, "txps": txps}
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    from oracle import oracle
+    oracle.build()
+    return oracle
+
+
+def load_oracle(idx_dir):
+    from oracle import oracle, q5
+    ix = q5.load(idx_dir)
+    return ix, oracle.Oracle(ix)

@@ -1,0 +1,100 @@
+"""The device mapper's SOURCE (rapmap_amd/csrc/qm_mapper.inl), lane-emulated on the CPU (tests/emu),
+against the oracle: bit-exact hits, offsets, counters and SA-interval lists.  This is how the wave
+algorithm is debugged without a GPU; the same comparisons run against the real HIP path in
+test_gpu_parity.py (-m gpu)."""
+import numpy as np
+import pytest
+
+from conftest import load_oracle
+from util import assert_hits_equal, pack
+
+VARIANTS = {
+    "default": ({}, {}),
+    "noStrictCheck": ({"strictCheck": 0}, {"strict_check": 0}),
+    "z0.9": ({"quasiCov": 0.9}, {"quasi_cov": 0.9}),
+    "m3": ({"maxNumHits": 3}, {"max_num_hits": 3}),
+    "noOrphans": ({"noOrphans": 1}, {"no_orphans": 1}),
+    "noDovetail": ({"noDovetail": 1}, {"no_dovetail": 1}),
+    "maxInterval50": ({"maxInterval": 50}, {"max_interval": 50}),
+}
+
+
+def _emu(idx):
+    import emu
+    ix, orc = load_oracle(idx)
+    return ix, orc, emu.Emu(ix), emu
+
+
+def _cmp_ints(res, er):
+    oi, ei = res.ints, er.ints
+    assert np.array_equal(res.ints_offsets, er.int_offsets)
+    for col, name in ((0, "begin"), (1, "end"), (2, "len"), (3, "query_pos"), (5, "list")):
+        assert np.array_equal(oi[:, col], ei[name].astype(np.int32)), name
+
+
+def test_sample_data(sample_data, oracle_mod):
+    ix, orc, em, emu = _emu(sample_data["idx"])
+    q1, o1 = pack(sample_data["reads1"]); q2, o2 = pack(sample_data["reads2"])
+    res = orc.map_pairs(q1, o1, q2, o2, nthreads=2, want_ints=True)
+    er = em.map(q1, o1, q2, o2)
+    assert er.status == 0
+    assert_hits_equal(res.hit_offsets, res.hits, er.hit_offsets, er.hits, "sample_data")
+    assert res.counters == er.counters
+    _cmp_ints(res, er)
+
+
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+def test_synth_small(synth_small, oracle_mod, variant):
+    ix, orc, em, emu = _emu(synth_small["idx"])
+    q1, o1 = pack(synth_small["reads1"]); q2, o2 = pack(synth_small["reads2"])
+    oo, eo = VARIANTS[variant]
+    res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=4, want_ints=True)
+    er = em.map(q1, o1, q2, o2, opts=emu.default_opts(**eo))
+    assert er.status == 0
+    assert_hits_equal(res.hit_offsets, res.hits, er.hit_offsets, er.hits, variant)
+    assert res.counters == er.counters
+    _cmp_ints(res, er)
+
+
+def test_single_end(synth_small, oracle_mod):
+    ix, orc, em, emu = _emu(synth_small["idx"])
+    q, o = pack(synth_small["reads1"] + synth_small["reads2"])
+    res = orc.map_single(q, o, nthreads=4)
+    er = em.map(q, o)
+    assert_hits_equal(res.hit_offsets, res.hits, er.hit_offsets, er.hits, "single-end")
+    assert res.counters == er.counters
+
+
+def test_long_reads_ns4(synth_small, oracle_mod):
+    """reads of 129..256 bp take the 4-word (NS=4) instantiation"""
+    from rapmap_amd import synth
+    import gzip, os
+    from conftest import GOLD
+    txt = gzip.open(os.path.join(GOLD, "synth_small", "txome.fa.gz"), "rt").read().split("\n")
+    txps = [np.frombuffer(l.upper().encode(), dtype=np.uint8) for l in txt if l and l[0] != ">"][:300]
+    txps = [t for t in txps if t.size >= 600 and not (t == ord("N")).any()]
+    s1, s2, off, _ = synth.make_reads(txps, 800, seed=5, read_len=250, err=0.01)
+    a1, a2, aoff, _ = synth.make_reads(txps, 400, seed=6, read_len=151, err=0.02)
+    q1 = np.concatenate([s1, a1]); q2 = np.concatenate([s2, a2])
+    o = np.concatenate([off, aoff[1:] + off[-1]])
+    ix, orc, em, emu = _emu(synth_small["idx"])
+    res = orc.map_pairs(q1, o, q2, o, nthreads=4, want_ints=True)
+    er = em.map(q1, o, q2, o, ns=4)
+    assert er.status == 0 and res.counters["totHits"] > 1000
+    assert_hits_equal(res.hit_offsets, res.hits, er.hit_offsets, er.hits, "ns4")
+    _cmp_ints(res, er)
+    # the NS=2 build must refuse them rather than truncate silently
+    er2 = em.map(q1, o, q2, o, ns=2)
+    assert er2.status & 4
+
+
+def test_medium(synth_medium, oracle_mod):
+    ix, orc, em, emu = _emu(synth_medium["idx"])
+    n = 20000
+    o = synth_medium["off"][: n + 1]
+    q1 = synth_medium["seq1"][: o[-1]]; q2 = synth_medium["seq2"][: o[-1]]
+    res = orc.map_pairs(q1, o, q2, o, nthreads=8, want_ints=True)
+    er = em.map(q1, o, q2, o)
+    assert_hits_equal(res.hit_offsets, res.hits, er.hit_offsets, er.hits, "medium")
+    assert res.counters == er.counters
+    _cmp_ints(res, er)

@@ -1,0 +1,183 @@
+"""Parity of the HIP path (libqmap_mi355.so, called through its C ABI) against the oracle.
+Bit-exact: hit offsets, hit records, counters, SA-interval lists.  Run on the MI355X box: -m gpu."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, load_oracle
+from util import assert_hits_equal, pack
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = {
+    "default": ({}, {}),
+    "noStrictCheck": ({"strictCheck": 0}, {"strict_check": 0}),
+    "z0.9": ({"quasiCov": 0.9}, {"quasi_cov": 0.9}),
+    "m3": ({"maxNumHits": 3}, {"max_num_hits": 3}),
+    "noOrphans": ({"noOrphans": 1}, {"no_orphans": 1}),
+    "noDovetail": ({"noDovetail": 1}, {"no_dovetail": 1}),
+    "maxInterval50": ({"maxInterval": 50}, {"max_interval": 50}),
+}
+
+
+def _gpu(idx, debug=True):
+    import rapmap_amd as ra
+    qi = ra.QuasiIndex(idx)
+    return qi, ra.QuasiMapper(qi, 0, debug=debug)
+
+
+def _cmp_ints(res, offs, ints):
+    assert np.array_equal(res.ints_offsets, offs)
+    oi = res.ints
+    for col, name in ((0, "begin"), (1, "end"), (2, "len"), (3, "query_pos"), (5, "list")):
+        assert np.array_equal(oi[:, col], ints[name].astype(np.int32)), name
+
+
+def test_native_library_is_loaded(lib_built):
+    """the extension the tests exercise is the in-tree HIP library, not a fallback"""
+    import rapmap_amd as ra
+    ra.lib()
+    maps = open("/proc/self/maps").read()
+    assert "libqmap_mi355.so" in maps and "libamdhip64" in maps
+
+
+def test_sample_data_hits_and_sam_md5(sample_data, oracle_mod):
+    import rapmap_amd as ra
+    from rapmap_amd import sam
+    ix, orc = load_oracle(sample_data["idx"])
+    qi, mp = _gpu(sample_data["idx"])
+    q1, o1 = pack(sample_data["reads1"]); q2, o2 = pack(sample_data["reads2"])
+    res = orc.map_pairs(q1, o1, q2, o2, nthreads=2, want_ints=True)
+    gr = mp.map_pairs(q1, o1, q2, o2)
+    assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "sample_data")
+    assert res.counters == gr.counters
+    _cmp_ints(res, *mp.intervals(len(o1) - 1))
+    body = "".join(sam.format_pair(sample_data["names1"][i], sample_data["reads1"][i], sample_data["names2"][i],
+                                   sample_data["reads2"][i], gr.hits[gr.hit_offsets[i]:gr.hit_offsets[i + 1]],
+                                   qi.txp_names, qi.txp_lens) for i in range(len(o1) - 1))
+    text = "".join(l for l in (sam.sam_header(qi.txp_names, qi.txp_lens) + body).splitlines(True) if not l.startswith("@PG"))
+    want = open(os.path.join(GOLD, "sample_data", "expected_sam_body.md5")).read().strip()
+    assert hashlib.md5(text.encode()).hexdigest() == want
+
+
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+def test_synth_small(synth_small, oracle_mod, variant):
+    import rapmap_amd as ra
+    ix, orc = load_oracle(synth_small["idx"])
+    qi, mp = _gpu(synth_small["idx"])
+    q1, o1 = pack(synth_small["reads1"]); q2, o2 = pack(synth_small["reads2"])
+    oo, go = VARIANTS[variant]
+    res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=4, want_ints=True)
+    gr = mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(**go))
+    assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, variant)
+    assert res.counters == gr.counters
+    _cmp_ints(res, *mp.intervals(len(o1) - 1))
+
+
+def test_single_end(synth_small, oracle_mod):
+    ix, orc = load_oracle(synth_small["idx"])
+    qi, mp = _gpu(synth_small["idx"], debug=False)
+    q, o = pack(synth_small["reads1"] + synth_small["reads2"])
+    res = orc.map_single(q, o, nthreads=4)
+    gr = mp.map_reads(q, o)
+    assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "single-end")
+    assert res.counters == gr.counters
+
+
+def test_long_reads_ns4(synth_small, oracle_mod):
+    import gzip
+    from rapmap_amd import synth
+    txt = gzip.open(os.path.join(GOLD, "synth_small", "txome.fa.gz"), "rt").read().split("\n")
+    txps = [np.frombuffer(l.upper().encode(), dtype=np.uint8) for l in txt if l and l[0] != ">"][:300]
+    txps = [t for t in txps if t.size >= 600 and not (t == ord("N")).any()]
+    s1, s2, off, _ = synth.make_reads(txps, 800, seed=5, read_len=250, err=0.01)
+    ix, orc = load_oracle(synth_small["idx"])
+    qi, mp = _gpu(synth_small["idx"])
+    res = orc.map_pairs(s1, off, s2, off, nthreads=4, want_ints=True)
+    gr = mp.map_pairs(s1, off, s2, off)
+    assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "ns4")
+    _cmp_ints(res, *mp.intervals(len(off) - 1))
+
+
+def test_edge_batches(synth_small, oracle_mod):
+    import rapmap_amd as ra
+    ix, orc = load_oracle(synth_small["idx"])
+    qi, mp = _gpu(synth_small["idx"], debug=False)
+    # empty batch
+    z = np.zeros(0, np.uint8); zo = np.zeros(1, np.int64)
+    gr = mp.map_pairs(z, zo, z, zo)
+    assert gr.n_hits == 0 and list(gr.hit_offsets) == [0] and gr.counters["numReads"] == 0
+    # batch of one, and reads that are empty / shorter than k
+    for r1, r2 in ((synth_small["reads1"][0], synth_small["reads2"][0]), (b"", b"ACGT"), (b"ACGT" * 7, b"")):
+        q1, o1 = pack([r1]); q2, o2 = pack([r2])
+        res = orc.map_pairs(q1, o1, q2, o2)
+        gr = mp.map_pairs(q1, o1, q2, o2)
+        assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "one")
+    # too-long read and unsupported options are errors, not silent fallbacks
+    q1, o1 = pack([b"A" * 300]); q2, o2 = pack([b"C" * 10])
+    with pytest.raises(ra.QmError, match="read length"):
+        mp.map_pairs(q1, o1, q2, o2)
+    q1, o1 = pack([b"ACGT" * 20]); q2, o2 = pack([b"ACGT" * 20])
+    for kw in ({"sensitive": 0}, {"fuzzy": 1}, {"sel_aln": 1}):
+        with pytest.raises(ra.QmError, match="not implemented"):
+            mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(**kw))
+
+
+def test_medium_full_parity_and_properties(synth_medium, oracle_mod):
+    """60k pairs against a ~5k-transcript index: full bit-exact parity, then size-independent properties."""
+    ix, orc = load_oracle(synth_medium["idx"])
+    qi, mp = _gpu(synth_medium["idx"], debug=False)
+    o = synth_medium["off"]; q1 = synth_medium["seq1"]; q2 = synth_medium["seq2"]
+    res = orc.map_pairs(q1, o, q2, o, nthreads=8)
+    gr = mp.map_pairs(q1, o, q2, o)
+    assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "medium")
+    assert res.counters == gr.counters
+    # idempotence
+    gr2 = mp.map_pairs(q1, o, q2, o)
+    assert np.array_equal(gr.hit_offsets, gr2.hit_offsets) and gr.hits.tobytes() == gr2.hits.tobytes()
+    # permutation of the pairs permutes the per-pair hit lists
+    n = len(o) - 1
+    perm = np.random.default_rng(1).permutation(n)
+    L = 100
+    p1 = q1.reshape(n, L)[perm].reshape(-1); p2 = q2.reshape(n, L)[perm].reshape(-1)
+    gp = mp.map_pairs(p1, o, p2, o)
+    cnt = np.diff(gr.hit_offsets); cntp = np.diff(gp.hit_offsets)
+    assert np.array_equal(cnt[perm], cntp)
+    for j in (0, 1, n // 2, n - 1):
+        i = perm[j]
+        assert gr.hits[gr.hit_offsets[i]:gr.hit_offsets[i + 1]].tobytes() == gp.hits[gp.hit_offsets[j]:gp.hit_offsets[j + 1]].tobytes()
+    assert gp.counters == gr.counters
+    # structure: per-pair lists sorted by transcript id, bounded by maxNumHits, counters consistent
+    h = gr.hits
+    assert gr.counters["totHits"] == gr.n_hits == int(gr.hit_offsets[-1])
+    assert cnt.max() <= 200
+    unit = np.repeat(np.arange(n), cnt)
+    same = unit[1:] == unit[:-1]
+    paired = h["is_paired"][1:].astype(bool) & same
+    assert (h["tid"][1:][paired] > h["tid"][:-1][paired]).all()
+    # swapping the mates mirrors every paired hit
+    gs = mp.map_pairs(q2, o, q1, o)
+    assert np.array_equal(np.diff(gs.hit_offsets)[cnt > 0] > 0, np.ones((cnt > 0).sum(), bool))
+    hp = h[h["is_paired"] == 1]; sp = gs.hits[gs.hits["is_paired"] == 1]
+    assert hp.size == sp.size
+    assert np.array_equal(hp["tid"], sp["tid"]) and np.array_equal(hp["pos"], sp["mate_pos"])
+    assert np.array_equal(hp["mate_pos"], sp["pos"]) and np.array_equal(hp["fwd"], sp["mate_is_fwd"])
+    assert np.array_equal(hp["frag_len"], sp["frag_len"])
+
+
+def test_device_resident_inputs(synth_medium, oracle_mod):
+    """qm_map_device: reads already in HBM (the path bench.py times)"""
+    import torch
+    ix, orc = load_oracle(synth_medium["idx"])
+    qi, mp = _gpu(synth_medium["idx"], debug=False)
+    n = 5000
+    o = synth_medium["off"][: n + 1]
+    q1 = synth_medium["seq1"][: o[-1]]; q2 = synth_medium["seq2"][: o[-1]]
+    d1 = torch.from_numpy(q1).cuda(); d2 = torch.from_numpy(q2).cuda(); do = torch.from_numpy(o).cuda()
+    torch.cuda.synchronize()
+    gr = mp.map_device(n, d1.data_ptr(), do.data_ptr(), d2.data_ptr(), do.data_ptr(), 100, fetch=True)
+    res = orc.map_pairs(q1, o, q2, o, nthreads=4)
+    assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "device-resident")
+    assert gr.map_kernel_ms > 0

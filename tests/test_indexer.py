@@ -1,0 +1,98 @@
+"""Our quasiindex builder against the bytes of the reference's own index (synth_small) and against
+the structural definition of the k-mer -> SA-interval map."""
+import hashlib
+import os
+import struct
+
+import numpy as np
+
+from conftest import GOLD
+
+
+def test_index_files_match_reference_bytes(synth_small):
+    want = dict(l.split()[::-1] for l in open(os.path.join(GOLD, "synth_small", "expected_index.md5")))
+    for fn in ("sa.bin", "txpInfo.bin", "rsd.bin"):
+        got = hashlib.md5(open(os.path.join(synth_small["idx"], fn), "rb").read()).hexdigest()
+        assert got == want[fn], fn
+
+
+def test_suffix_array_is_sorted_permutation(sample_data):
+    from oracle import q5
+    ix = q5.load(sample_data["idx"])
+    sa = ix.SA
+    n = ix.text.size
+    assert sa.size == n and np.array_equal(np.sort(sa), np.arange(n))
+    t = ix.text.tobytes()
+    for i in range(0, n - 1, 97):
+        assert t[sa[i]:] < t[sa[i + 1]:]
+
+
+def test_hash_is_run_structure_of_sa(sample_data):
+    """every (key,[lb,ub)) is a maximal run of suffixes with that k-prefix; every valid k-mer is a key"""
+    from oracle import q5
+    ix = q5.load(sample_data["idx"])
+    k, t, sa = ix.k, ix.text.tobytes(), ix.SA
+    code = {65: 0, 67: 1, 71: 2, 84: 3}
+
+    def kmer(p):
+        s = t[p:p + k]
+        if len(s) < k or 36 in s:
+            return None
+        w = 0
+        for c in s:
+            w = (w << 2) | code[c]
+        return w
+    pref = [kmer(int(p)) for p in sa]
+    runs = {}
+    i = 0
+    while i < len(pref):
+        if pref[i] is None:
+            i += 1
+            continue
+        j = i
+        while j < len(pref) and pref[j] == pref[i]:
+            j += 1
+        assert pref[i] not in runs
+        runs[pref[i]] = (i, j)
+        i = j
+    got = {int(a): (int(b), int(c)) for a, b, c in zip(ix.hkeys, ix.hlb, ix.hub)}
+    assert got == runs
+
+
+def test_hash_bin_is_loadable_by_sparsepp_probing(sample_data):
+    """slot = XXH64(key,seed 0) & (size-1), then +1,+2,... (spp.h:2498,3015-3050): every stored key must be
+    reachable without crossing an empty slot, else the reference could not find it after unserialize()."""
+    import xxhash
+    b = open(os.path.join(sample_data["idx"], "hash.bin"), "rb").read()
+    magic, ts, nb = struct.unpack(">III", b[:12])
+    assert magic == 0x24687531 and ts & (ts - 1) == 0 and nb * 2 <= ts
+    ng = (ts + 31) // 32
+    bm = np.frombuffer(b, dtype="<u4", count=ng, offset=12)
+    occ = np.unpackbits(bm.view(np.uint8), bitorder="little")[:ts].astype(bool)
+    recs = np.frombuffer(b, dtype=np.dtype([("k", "<u8"), ("lb", "<i4"), ("ub", "<i4")]), count=nb, offset=12 + 4 * ng)
+    pos = np.nonzero(occ)[0]
+    assert pos.size == nb and len(b) == 12 + 4 * ng + 16 * nb
+    for slot, key in zip(pos.tolist(), recs["k"].tolist()):
+        q = xxhash.xxh64(struct.pack("<Q", key), seed=0).intdigest() & (ts - 1)
+        probes = 0
+        while q != slot:
+            assert occ[q]
+            probes += 1
+            q = (q + probes) & (ts - 1)
+
+
+def test_text_rules(tmp_path, lib_built):
+    """upper-casing, poly-A clipping, duplicate removal, header truncation (RapMapSAIndexer.cpp:536-614)"""
+    import rapmap_amd as ra
+    from oracle import q5
+    fa = tmp_path / "t.fa"
+    body = "ACGTTGCATGCATGGATCCATGCTAGCTAGCTAGGATCGATCGTAGCTAGCTAGCATCGAT"
+    fa.write_text(">t1 some description\n%s\n>t2\n%s\n>t3|x\n%s\n>t4\n%s\n" % (
+        body, body.lower()[:30] + "\n" + body.lower()[30:], body + "A" * 12, body))
+    ra.build_index(str(fa), str(tmp_path / "idx"), k=31)
+    ix = q5.load(str(tmp_path / "idx"))
+    # t2 (lower case) has a different raw hash -> kept; t3's poly-A tail is clipped; t4 == t1 is dropped
+    assert ix.names == ["t1", "t2", "t3|x"]
+    assert ix.text.tobytes() == (body + "$") .encode() * 3
+    assert list(ix.completeLens) == [len(body), len(body), len(body) + 12]
+    assert list(ix.txpLens) == [len(body)] * 3
