@@ -38,7 +38,7 @@ def _cmp_ints(res, offs, ints):
 def test_native_library_is_loaded(lib_built):
     """the extension the tests exercise is the in-tree HIP library, not a fallback"""
     import rapmap_amd as ra
-    ra.lib()
+    ra.api.lib()
     maps = open("/proc/self/maps").read()
     assert "libqmap_mi355.so" in maps and "libamdhip64" in maps
 
