@@ -17,8 +17,9 @@
 
 namespace qm {
 
-template <int NS>
-__global__ __launch_bounds__(256) void qm_map_kernel(DevIndex ix, Batch B) {
+// WPS = minimum waves per SIMD the register allocator must leave room for
+template <int NS, int WPS>
+__global__ __launch_bounds__(256, WPS) void qm_map_kernel(DevIndex ix, Batch B) {
   __shared__ WaveMem<NS> mem[4];
   const int wave = threadIdx.x >> 6;
   const long long gw = (long long)blockIdx.x * 4 + wave;
@@ -103,8 +104,17 @@ int qmk_map_grid(long long n, int num_cu) {
 hipError_t qmk_map(const void* ixp, const void* bp, int ns, int grid, hipStream_t st) {
   const DevIndex& ix = *(const DevIndex*)ixp;
   const Batch& B = *(const Batch*)bp;
-  if (ns == 2) hipLaunchKernelGGL(qm_map_kernel<2>, dim3(grid), dim3(256), 0, st, ix, B);
-  else hipLaunchKernelGGL(qm_map_kernel<4>, dim3(grid), dim3(256), 0, st, ix, B);
+  static int wps = -1;
+  if (wps < 0) { const char* e = getenv("QM_WPS"); wps = e ? atoi(e) : 3; }
+  if (ns == 2) {
+    if (wps == 4) hipLaunchKernelGGL((qm_map_kernel<2, 4>), dim3(grid), dim3(256), 0, st, ix, B);
+    else if (wps == 5) hipLaunchKernelGGL((qm_map_kernel<2, 5>), dim3(grid), dim3(256), 0, st, ix, B);
+    else if (wps == 6) hipLaunchKernelGGL((qm_map_kernel<2, 6>), dim3(grid), dim3(256), 0, st, ix, B);
+    else if (wps == 8) hipLaunchKernelGGL((qm_map_kernel<2, 8>), dim3(grid), dim3(256), 0, st, ix, B);
+    else hipLaunchKernelGGL((qm_map_kernel<2, 3>), dim3(grid), dim3(256), 0, st, ix, B);
+  } else {
+    hipLaunchKernelGGL((qm_map_kernel<4, 2>), dim3(grid), dim3(256), 0, st, ix, B);
+  }
   return hipGetLastError();
 }
 

@@ -64,8 +64,8 @@ struct Batch {
 
 template <int NS>
 struct WaveMem {
-  unsigned char str[4][64 * NS];   // left fwd, left rc, right fwd, right rc
   u64 buf[4][QM_CAP];              // A, B (sort ping-pong), RL, RR
+  alignas(8) unsigned char str[4][64 * NS + 16];   // left fwd, left rc, right fwd, right rc (+16: 8-byte over-reads)
 };
 
 // ------------------------------------------------------------------ bit helpers
@@ -335,10 +335,72 @@ QM_DEV int cmp_from(const DevIndex& ix, long long s, const unsigned char* q, int
   }
 }
 
+// Closed form of extendSearchNaive for intervals of <= 64 suffixes.
+// All suffixes strictly between the fences share the query's first `startAt` characters and are
+// sorted, so the three binary searches of SASearcher.hpp:150-304 return exactly
+//   maxLen = max_j LCP(query, suffix_j),  [lower, upper) = the (contiguous) block attaining it.
+// (Search 1 ends with both neighbours of the insertion point probed, and the maximum LCP of a sorted
+// list sits next to the insertion point; searches 2/3 bracket the suffixes that have query[0,maxLen)
+// as a prefix.  The one case where the reference's loop deviates -- a suffix running off the END of
+// the text, SASearcher.hpp:154,180 -- needs the query to match the text's final '$'; queries that
+// contain '$' therefore take the literal path below.)
+// Every lane owns one suffix: one coalesced SA load, then 8 text bytes per step against a
+// wave-uniform 8-byte query word -- 2 dependent loads instead of ~2 per binary-search step.
+QM_DEV bool extend_search_wide(const DevIndex& ix, int lbIn, int ubIn, int startAt, const unsigned char* q, int m0,
+                               int& lbOut, int& ubOut, int& lenOut) {
+  const int width = ubIn - lbIn - 1;
+  if (width < 1 || width > 64) return false;
+  LV<long long> sv; LV<int> lcp; LV<bool> act;
+  QM_LANES(l) {
+    bool a = l < width;
+    sv[l] = a ? (long long)ix.SA[lbIn + 1 + l] : 0;
+    lcp[l] = a ? startAt : -1;
+    act[l] = a;
+  }
+  bool dollar = false;
+  for (int i = startAt; i < m0; i += 8) {
+    // wave-uniform 8 query bytes starting at q[i] (aligned reads + funnel shift; LDS rows are padded)
+    const unsigned char* qa = q + i;
+    unsigned long long addr = (unsigned long long)qa;
+    const u64* al = (const u64*)(addr & ~7ULL);
+    int sh = (int)(addr & 7ULL) * 8;
+    u64 lo = al[0], hi = al[1];
+    u64 qw = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+    qw = uniform(qw);
+    int nb = m0 - i < 8 ? m0 - i : 8;
+    u64 valid = nb == 8 ? ~0ULL : ((1ULL << (8 * nb)) - 1);
+    // any '$' among the valid query bytes?  (haszero trick on qw ^ 0x24..24)
+    u64 z = (qw ^ 0x2424242424242424ULL) | ~valid;
+    if (((z - 0x0101010101010101ULL) & ~z & 0x8080808080808080ULL) != 0) dollar = true;
+    LV<bool> cont;
+    QM_LANES(l) {
+      bool c = false;
+      if (act[l] && lcp[l] == i) {
+        u64 tw = load_u64_unaligned(ix.text + sv[l] + i);
+        u64 x = (tw ^ qw) & valid;
+        if (x) lcp[l] = i + (ctz64(x) >> 3);
+        else { lcp[l] = i + nb; c = nb == 8; }
+      }
+      cont[l] = c;
+    }
+    if (dollar) return false;
+    if (!ballot(cont)) break;
+  }
+  int mx = wave_max(lcp);
+  LV<bool> best;
+  QM_LANES(l) { best[l] = act[l] && lcp[l] == mx; }
+  u64 bm = ballot(best);
+  lbOut = lbIn + 1 + ctz64(bm);
+  ubOut = lbIn + 1 + (63 - clz64(bm)) + 1;
+  lenOut = mx;
+  return true;
+}
+
 // SASearcher::extendSearchNaive (SASearcher.hpp:88-309)
 QM_DEV void extend_search(const DevIndex& ix, int lbIn, int ubIn, int startAt, const unsigned char* q, int m0,
                           int& lbOut, int& ubOut, int& lenOut) {
   int rel;
+  if (extend_search_wide(ix, lbIn, ubIn, startAt, q, m0, lbOut, ubOut, lenOut)) return;
   if (ubIn - lbIn == 2) {                         // :109-126
     lbIn += 1;
     long long s = uniform((int)ix.SA[lbIn]);
@@ -749,7 +811,8 @@ QM_DEV void map_unit(const DevIndex& ix, const Batch& B, long long unit, WaveMem
     for (int s = 0; s < NS; ++s) {
       QM_LANES(l) {
         int idx = 64 * s + l;
-        if (idx < len) { unsigned char c = src[o0 + idx]; fs[idx] = c; rs[len - 1 - idx] = rc_char(c); }
+        // the forward read is kept upper-cased (every consumer applies ::toupper anyway, SASearcher.hpp:111,155)
+        if (idx < len) { unsigned char c = src[o0 + idx]; fs[idx] = (unsigned char)upc(c); rs[len - 1 - idx] = rc_char(c); }
       }
     }
     wave_fence();

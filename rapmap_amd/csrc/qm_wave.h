@@ -80,6 +80,21 @@ QM_DEV long long uniform(long long x) { return (long long)uniform((u64)x); }
 QM_DEV bool uniform(bool x) { return __builtin_amdgcn_readfirstlane((int)x) != 0; }
 #endif
 
+#ifdef QM_EMU
+QM_DEV int wave_max(const LV<int>& x) { int m = x.v[0]; for (int l = 1; l < 64; ++l) m = x.v[l] > m ? x.v[l] : m; return m; }
+QM_DEV int clz64(u64 x) { return x ? __builtin_clzll(x) : 64; }
+QM_DEV u64 load_u64_unaligned(const unsigned char* p) { u64 v; __builtin_memcpy(&v, p, 8); return v; }
+#else
+QM_DEV int wave_max(const LV<int>& x) {
+  int v = x.v[0];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+  return __builtin_amdgcn_readfirstlane(v);
+}
+QM_DEV int clz64(u64 x) { return x ? __builtin_clzll(x) : 64; }
+QM_DEV u64 load_u64_unaligned(const unsigned char* p) { u64 v; __builtin_memcpy(&v, p, 8); return v; }
+#endif
+
 QM_DEV u64 lanemask_lt(int l) { return l ? (~0ULL >> (64 - l)) : 0ULL; }
 
 }  // namespace qm
