@@ -4,15 +4,16 @@
 #include <stddef.h>
 
 #define QMK_BLOCKS_PER_CU 8
+#define QMK_DEFAULT_WPS 5
 
 extern "C" {
 hipError_t qmk_build_sainfo(const int* SA, long long nSA, const int* offsets, long long T, void* out, hipStream_t st);
 hipError_t qmk_build_slots(const void* recs, long long K, void* slots, unsigned long long cap, hipStream_t st);
 int qmk_map_grid(long long n, int num_cu);
-hipError_t qmk_map(const void* dev_index, const void* batch, int ns, int grid, hipStream_t st);
+hipError_t qmk_map_reads(const void* dev_index, const void* read_batch, int ns, int grid, hipStream_t st);
+hipError_t qmk_pair_count(const void* pair_batch, hipStream_t st);
+hipError_t qmk_pair_write(const void* pair_batch, hipStream_t st);
 size_t qmk_scan_temp_bytes(long long n);
 hipError_t qmk_scan_counts(void* temp, size_t temp_bytes, const unsigned int* cnt, long long* offs, long long n,
                            hipStream_t st);
-hipError_t qmk_gather(long long n, const unsigned int* cnt, const long long* tmp_off, const long long* offs,
-                      const void* tmp, void* out, hipStream_t st);
 }

@@ -71,14 +71,17 @@ struct qm_ctx {
   uint64_t cap = 0;
   int64_t devBytes = 0;
   // work buffers
-  int64_t capUnits = 0, capTmp = 0, capHits = 0, capSeq1 = 0, capSeq2 = 0, capGrid = 0;
-  uint32_t* d_cnt = nullptr; long long* d_tmpoff = nullptr; qm_hit* d_tmp = nullptr; qm_hit* d_hits = nullptr;
-  long long* d_offs = nullptr; u64* d_scal = nullptr; /* cursor, counters[6], status */ u64* d_gscr = nullptr;
+  int64_t capCnt = 0, capOffs = 0, capLcnt = 0, capLoff = 0, capLists = 0, capHits = 0, capSeq1 = 0, capSeq2 = 0, capGrid = 0;
+  uint32_t* d_cnt = nullptr; long long* d_offs = nullptr;      // per unit: hits, exclusive scan
+  uint32_t* d_lcnt = nullptr; long long* d_loff = nullptr;     // per read: list length / offset
+  u64* d_lists = nullptr;                                      // bump-allocated per-read hit lists
+  qm_hit* d_hits = nullptr;
+  u64* d_scal = nullptr; /* cursor, counters[6], status */ u64* d_gscr = nullptr;
   void* d_scanTmp = nullptr; size_t scanTmpBytes = 0;
   uint8_t* d_seq1 = nullptr; uint8_t* d_seq2 = nullptr; long long* d_off1 = nullptr; long long* d_off2 = nullptr;
-  qm_sa_interval_hit* d_dbg = nullptr; uint32_t* d_dbgcnt = nullptr; int64_t capDbg = 0; int debug = 0;
+  qm_sa_interval_hit* d_dbg = nullptr; uint32_t* d_dbgcnt = nullptr; int64_t capDbg = 0, capDbgCnt = 0; int debug = 0;
   // last result
-  int64_t lastUnits = -1, lastHits = 0;
+  int64_t lastUnits = -1, lastHits = 0; bool lastPaired = false;
   double lastMapMs = 0, lastTotalMs = 0;
 };
 
@@ -244,7 +247,7 @@ int qm_index_arrays(const qm_index* ix, const uint8_t** text, int64_t* text_len,
 int qm_ctx_destroy(qm_ctx* c) {
   if (!c) return QM_OK;
   hipSetDevice(c->device);
-  void* ptrs[] = {c->d_text, c->d_SA, c->d_sainfo, c->d_slots, c->d_cnt, c->d_tmpoff, c->d_tmp, c->d_hits, c->d_offs,
+  void* ptrs[] = {c->d_text, c->d_SA, c->d_sainfo, c->d_slots, c->d_cnt, c->d_lcnt, c->d_loff, c->d_lists, c->d_hits, c->d_offs,
                   c->d_scal, c->d_gscr, c->d_scanTmp, c->d_seq1, c->d_seq2, c->d_off1, c->d_off2, c->d_dbg, c->d_dbgcnt};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->ev0) hipEventDestroy(c->ev0);
@@ -316,14 +319,14 @@ int qm_map_device(qm_ctx* c, const qm_opts* o, int64_t n, const void* d_seq1, co
   if (max_read_len > QM_MAX_READ_LEN) return fail(QM_E_TOOLONG, "read length %d > %d", max_read_len, QM_MAX_READ_LEN);
   HIPCHK(hipSetDevice(c->device));
   const int ns = max_read_len <= 128 ? 2 : 4;
-  const int grid = qmk_map_grid(n, c->numCU);
-  int64_t dummy = 0;
-  int64_t capU1 = c->capUnits;
-  if ((rc = ensure(c->d_cnt, capU1, n + 1))) return rc;
-  capU1 = c->capUnits; if ((rc = ensure(c->d_tmpoff, capU1, n + 1))) return rc;
-  capU1 = c->capUnits; if ((rc = ensure(c->d_offs, capU1, n + 1))) return rc;
-  c->capUnits = capU1;
-  if ((rc = ensure(c->d_gscr, c->capGrid, (int64_t)grid * 4 * 4 * QM_GCAP))) return rc;
+  const bool paired = d_seq2 != nullptr;
+  const int64_t nreads = paired ? 2 * n : n;
+  const int grid = qmk_map_grid(nreads, c->numCU);
+  if ((rc = ensure(c->d_cnt, c->capCnt, n + 1))) return rc;
+  if ((rc = ensure(c->d_offs, c->capOffs, n + 1))) return rc;
+  if ((rc = ensure(c->d_lcnt, c->capLcnt, nreads + 1))) return rc;
+  if ((rc = ensure(c->d_loff, c->capLoff, nreads + 1))) return rc;
+  if ((rc = ensure(c->d_gscr, c->capGrid, (int64_t)grid * 4 * QM_GSCR_U64))) return rc;
   size_t stb = qmk_scan_temp_bytes(n + 1);
   if (stb > c->scanTmpBytes || !c->d_scanTmp) {
     if (c->d_scanTmp) hipFree(c->d_scanTmp);
@@ -334,30 +337,28 @@ int qm_map_device(qm_ctx* c, const qm_opts* o, int64_t n, const void* d_seq1, co
   if (c->debug) {
     int64_t cd = c->capDbg;
     if ((rc = ensure(c->d_dbg, cd, n * QM_DBG_CAP + 1))) return rc;
-    cd = c->capDbg; if ((rc = ensure(c->d_dbgcnt, cd, n + 1))) return rc;
-    c->capDbg = cd;
+    cd = c->capDbgCnt; if ((rc = ensure(c->d_dbgcnt, cd, nreads + 1))) return rc;
+    c->capDbg = n * QM_DBG_CAP + 1; c->capDbgCnt = cd;
   }
-  (void)dummy;
-  int64_t wantTmp = n * 6 + 65536;
-  if (c->capTmp < wantTmp) { if ((rc = ensure(c->d_tmp, c->capTmp, wantTmp))) return rc; }
+  int64_t wantLists = nreads * 4 + (int64_t)grid * 4 * QM_CHUNK * 2;   // chunked bump allocator: up to one open chunk per wave
+  if (c->capLists < wantLists) { if ((rc = ensure(c->d_lists, c->capLists, wantLists))) return rc; }
 
   DevIndex ix; ix.text = c->d_text; ix.n = c->ix->n; ix.SA = c->d_SA; ix.nSA = c->ix->nSA;
   ix.sainfo = (const SaInfo*)c->d_sainfo; ix.slots = (const Slot*)c->d_slots; ix.hmask = c->cap - 1; ix.k = c->ix->k;
   u64 hscal[16];
   HIPCHK(hipEventRecord(c->evA, c->stream));
+  // ---- stage A: one wavefront per read
   while (true) {
-    Batch B; memset(&B, 0, sizeof(B));
+    ReadBatch B; memset(&B, 0, sizeof(B));
     B.seq1 = (const unsigned char*)d_seq1; B.off1 = (const long long*)d_off1;
-    B.seq2 = (const unsigned char*)d_seq2; B.off2 = (const long long*)d_off2; B.n = n;
-    B.hit_count = c->d_cnt; B.tmp_off = c->d_tmpoff; B.tmp_hits = c->d_tmp; B.cursor = c->d_scal; B.tmp_cap = c->capTmp;
-    B.counters = c->d_scal + 1; B.status = (int*)(c->d_scal + 8); B.gscratch = c->d_gscr;
+    B.seq2 = (const unsigned char*)d_seq2; B.off2 = (const long long*)d_off2; B.nreads = nreads;
+    B.lcnt = c->d_lcnt; B.loff = c->d_loff; B.lists = c->d_lists; B.cursor = c->d_scal; B.lists_cap = c->capLists;
+    B.status = (int*)(c->d_scal + 8); B.gscratch = c->d_gscr;
     B.dbg_ints = c->debug ? c->d_dbg : nullptr; B.dbg_count = c->debug ? c->d_dbgcnt : nullptr;
-    B.strict_check = o->strict_check; B.max_num_hits = o->max_num_hits; B.no_orphans = o->no_orphans;
-    B.no_dovetail = o->no_dovetail; B.max_interval = o->max_interval; B.quasi_cov = o->quasi_cov;
+    B.strict_check = o->strict_check; B.max_interval = o->max_interval; B.quasi_cov = o->quasi_cov;
     HIPCHK(hipMemsetAsync(c->d_scal, 0, 16 * sizeof(u64), c->stream));
-    HIPCHK(hipMemsetAsync(c->d_cnt + n, 0, sizeof(uint32_t), c->stream));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
-    if (n > 0) HIPCHK(qmk_map(&ix, &B, ns, grid, c->stream));
+    if (nreads > 0) HIPCHK(qmk_map_reads(&ix, &B, ns, grid, c->stream));
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipMemcpyAsync(hscal, c->d_scal, 16 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -365,22 +366,33 @@ int qm_map_device(qm_ctx* c, const qm_opts* o, int64_t n, const void* d_seq1, co
     if (status & 4) return fail(QM_E_TOOLONG, "a read is longer than max_read_len=%d", max_read_len);
     if (status & 2) return fail(QM_E_UNSUPPORTED, "an SA-interval list exceeded %d entries (max_interval too large)", QM_GCAP);
     if (status & 1) {            // bump allocator ran out: grow and redo the batch
-      int64_t want = (int64_t)hscal[0] + n + 65536;
-      if (want < c->capTmp * 2) want = c->capTmp * 2;
-      if ((rc = ensure(c->d_tmp, c->capTmp, want))) return rc;
+      int64_t want = (int64_t)hscal[0] + nreads + (int64_t)grid * 4 * QM_CHUNK;
+      if (want < c->capLists * 2) want = c->capLists * 2;
+      if ((rc = ensure(c->d_lists, c->capLists, want))) return rc;
       continue;
     }
     break;
   }
   float ms = 0; hipEventElapsedTime(&ms, c->ev0, c->ev1); c->lastMapMs = ms;
+  // ---- stage B: one thread per unit: count -> scan -> write
+  PairBatch P; memset(&P, 0, sizeof(P));
+  P.n = n; P.paired = paired ? 1 : 0; P.off1 = (const long long*)d_off1; P.off2 = (const long long*)d_off2;
+  P.lcnt = c->d_lcnt; P.loff = c->d_loff; P.lists = c->d_lists; P.cnt = c->d_cnt; P.offs = c->d_offs;
+  P.counters = c->d_scal + 1; P.max_num_hits = o->max_num_hits; P.no_orphans = o->no_orphans; P.no_dovetail = o->no_dovetail;
+  HIPCHK(hipMemsetAsync(c->d_cnt + n, 0, sizeof(uint32_t), c->stream));
+  HIPCHK(qmk_pair_count(&P, c->stream));
   HIPCHK(qmk_scan_counts(c->d_scanTmp, c->scanTmpBytes, c->d_cnt, c->d_offs, n + 1, c->stream));
-  int64_t total = (int64_t)hscal[0];
-  if ((rc = ensure(c->d_hits, c->capHits, total + 1, total / 8))) return rc;
-  HIPCHK(qmk_gather(n, c->d_cnt, c->d_tmpoff, c->d_offs, c->d_tmp, c->d_hits, c->stream));
+  long long total = 0;
+  HIPCHK(hipMemcpyAsync(&total, c->d_offs + n, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(hscal, c->d_scal, 16 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if ((rc = ensure(c->d_hits, c->capHits, (int64_t)total + 1, total / 8))) return rc;
+  P.hits = c->d_hits;
+  HIPCHK(qmk_pair_write(&P, c->stream));
   HIPCHK(hipEventRecord(c->evB, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   hipEventElapsedTime(&ms, c->evA, c->evB); c->lastTotalMs = ms;
-  c->lastUnits = n; c->lastHits = total;
+  c->lastUnits = n; c->lastHits = total; c->lastPaired = paired;
   if (n_hits) *n_hits = total;
   if (counters) {
     counters->pe_hits = hscal[1]; counters->se_hits = hscal[2]; counters->tot_hits = hscal[3];
@@ -455,16 +467,26 @@ int qm_fetch_intervals(qm_ctx* c, int64_t* int_offsets, qm_sa_interval_hit* ints
   if (!int_offsets) return fail(QM_E_ARG, "null int_offsets");
   HIPCHK(hipSetDevice(c->device));
   int64_t n = c->lastUnits;
-  std::vector<uint32_t> cnt((size_t)n + 1);
-  if (n) HIPCHK(hipMemcpy(cnt.data(), c->d_dbgcnt, (size_t)n * 4, hipMemcpyDeviceToHost));
+  const int mates = c->lastPaired ? 2 : 1;
+  const int half = c->lastPaired ? QM_DBG_CAP / 2 : QM_DBG_CAP;
+  std::vector<uint32_t> cnt((size_t)n * mates + 1);
+  if (n) HIPCHK(hipMemcpy(cnt.data(), c->d_dbgcnt, (size_t)n * mates * 4, hipMemcpyDeviceToHost));
+  auto kept = [&](int64_t r) { return (int64_t)(cnt[r] < (uint32_t)half ? cnt[r] : (uint32_t)half); };
   int_offsets[0] = 0;
-  for (int64_t i = 0; i < n; ++i) int_offsets[i + 1] = int_offsets[i] + (cnt[i] < QM_DBG_CAP ? cnt[i] : QM_DBG_CAP);
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t t = 0;
+    for (int m = 0; m < mates; ++m) t += kept(i * mates + m);
+    int_offsets[i + 1] = int_offsets[i] + t;
+  }
   if (!ints) return QM_OK;
   if (cap < int_offsets[n]) return fail(QM_E_ARG, "interval buffer too small");
   std::vector<qm_sa_interval_hit> all((size_t)n * QM_DBG_CAP + 1);
   if (n) HIPCHK(hipMemcpy(all.data(), c->d_dbg, (size_t)n * QM_DBG_CAP * sizeof(qm_sa_interval_hit), hipMemcpyDeviceToHost));
-  for (int64_t i = 0; i < n; ++i)
-    for (int64_t j = 0; j < int_offsets[i + 1] - int_offsets[i]; ++j) ints[int_offsets[i] + j] = all[(size_t)i * QM_DBG_CAP + j];
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t w = int_offsets[i];
+    for (int m = 0; m < mates; ++m)
+      for (int64_t j = 0; j < kept(i * mates + m); ++j) ints[w++] = all[(size_t)i * QM_DBG_CAP + (size_t)m * half + j];
+  }
   return QM_OK;
 }
 

@@ -1,12 +1,12 @@
 // qm_kernels.hip -- gfx950 kernels of libqmap_mi355.so and their launch wrappers.
 //
-//   qm_map_kernel<NS>     one 64-lane wavefront per read pair (qm_mapper.inl); persistent
-//                         grid, 4 waves per workgroup, per-wave LDS slab, integer only.
+//   qm_read_kernel<NS>    stage A: one 64-lane wavefront per READ (qm_mapper.inl: collector + hits->mappings);
+//                         persistent grid, 4 waves per workgroup, per-wave LDS slab, integer only.
+//   qm_pair_count/write   stage B: one thread per read pair (mergeLeftRightHits + driver), count -> scan -> write
 //   build_sainfo_kernel   index flattening: (transcript id, offset) for every SA entry
 //                         (replaces rank9b::rank + txpOffsets lookups on the hot path,
 //                         src/rank9b.cpp:56-61, src/RapMapSAIndex.cpp:92-94)
 //   build_slots_kernel    index flattening: open-addressing k-mer table from hash.bin records
-//   gather_hits_kernel    bump-allocated hits -> CSR order
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <cstdlib>
@@ -17,24 +17,43 @@
 
 namespace qm {
 
-// WPS = minimum waves per SIMD the register allocator must leave room for
+// stage A: one wavefront per read.  WPS = minimum waves per SIMD the register allocator must leave room for.
 template <int NS, int WPS>
-__global__ __launch_bounds__(256, WPS) void qm_map_kernel(DevIndex ix, Batch B) {
+__global__ __launch_bounds__(256, WPS) void qm_read_kernel(DevIndex ix, ReadBatch B) {
   __shared__ WaveMem<NS> mem[4];
-  const int wave = threadIdx.x >> 6;
+  // the wave index is wave-uniform: keep it (and every address derived from it) on the scalar unit
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long long gw = (long long)blockIdx.x * 4 + wave;
   const long long nw = (long long)gridDim.x * 4;
-  u64* gscr = B.gscratch + gw * (4 * QM_GCAP);
-  WaveCounters wc = {0, 0, 0, 0, 0, 0};
-  for (long long unit = gw; unit < B.n; unit += nw) map_unit<NS>(ix, B, unit, mem[wave], gscr, wc);
-  if ((threadIdx.x & 63) == 0) {
-    if (wc.pe) atomicAdd(&B.counters[0], wc.pe);
-    if (wc.se) atomicAdd(&B.counters[1], wc.se);
-    if (wc.tot) atomicAdd(&B.counters[2], wc.tot);
-    if (wc.reads) atomicAdd(&B.counters[3], wc.reads);
-    if (wc.tooMany) atomicAdd(&B.counters[4], wc.tooMany);
-    if (wc.mapped) atomicAdd(&B.counters[5], wc.mapped);
-  }
+  u64* gscr = B.gscratch + gw * QM_GSCR_U64;
+  WaveAlloc wa; wa.base = -1; wa.used = 0;
+  for (long long r = gw; r < B.nreads; r += nw) map_read<NS>(ix, B, r, mem[wave], gscr, wa);
+}
+
+// stage B pass 1: hits per unit + the HitCounters
+__global__ __launch_bounds__(256) void qm_pair_count_kernel(PairBatch P) {
+  __shared__ unsigned long long sc[6];
+  if (threadIdx.x < 6) sc[threadIdx.x] = 0;
+  __syncthreads();
+  long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  UnitCounters uc = {0, 0, 0, 0, 0, 0};
+  if (u < P.n) P.cnt[u] = (u32)unit_merge(P, u, nullptr, 0, &uc);
+  if (uc.pe) atomicAdd(&sc[0], uc.pe);
+  if (uc.se) atomicAdd(&sc[1], uc.se);
+  if (uc.tot) atomicAdd(&sc[2], uc.tot);
+  if (uc.reads) atomicAdd(&sc[3], uc.reads);
+  if (uc.tooMany) atomicAdd(&sc[4], uc.tooMany);
+  if (uc.mapped) atomicAdd(&sc[5], uc.mapped);
+  __syncthreads();
+  if (threadIdx.x < 6 && sc[threadIdx.x]) atomicAdd((unsigned long long*)&P.counters[threadIdx.x], sc[threadIdx.x]);
+}
+
+// stage B pass 2: write the hits in CSR order
+__global__ __launch_bounds__(256) void qm_pair_write_kernel(PairBatch P) {
+  long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= P.n) return;
+  int c = (int)P.cnt[u];
+  if (c > 0) unit_merge(P, u, P.hits + P.offs[u], c, nullptr);
 }
 
 __global__ void build_sainfo_kernel(const int* SA, long long nSA, const int* offsets, long long T, SaInfo* out) {
@@ -65,16 +84,6 @@ __global__ void build_slots_kernel(const Slot* recs, long long K, Slot* slots, u
   }
 }
 
-__global__ void gather_hits_kernel(long long n, const u32* cnt, const long long* tmp_off, const long long* offs,
-                                   const qm_hit* tmp, qm_hit* out) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  u32 c = cnt[i];
-  const uint4* s = reinterpret_cast<const uint4*>(tmp + tmp_off[i]);
-  uint4* d = reinterpret_cast<uint4*>(out + offs[i]);
-  for (u32 j = 0; j < 2 * c; ++j) d[j] = s[j];
-}
-
 struct U32ToI64 { __device__ long long operator()(u32 x) const { return (long long)x; } };
 
 }  // namespace qm
@@ -95,26 +104,40 @@ hipError_t qmk_build_slots(const void* recs, long long K, void* slots, unsigned 
   return hipGetLastError();
 }
 
-int qmk_map_grid(long long n, int num_cu) {
-  long long want = (n + 3) / 4;
+int qmk_map_grid(long long nreads, int num_cu) {
+  long long want = (nreads + 3) / 4;
   long long cap = (long long)num_cu * QMK_BLOCKS_PER_CU;
   return (int)(want < cap ? (want > 0 ? want : 1) : cap);
 }
 
-hipError_t qmk_map(const void* ixp, const void* bp, int ns, int grid, hipStream_t st) {
+hipError_t qmk_map_reads(const void* ixp, const void* bp, int ns, int grid, hipStream_t st) {
   const DevIndex& ix = *(const DevIndex*)ixp;
-  const Batch& B = *(const Batch*)bp;
+  const ReadBatch& B = *(const ReadBatch*)bp;
   static int wps = -1;
-  if (wps < 0) { const char* e = getenv("QM_WPS"); wps = e ? atoi(e) : 3; }
+  if (wps < 0) { const char* e = getenv("QM_WPS"); wps = e ? atoi(e) : QMK_DEFAULT_WPS; }
   if (ns == 2) {
-    if (wps == 4) hipLaunchKernelGGL((qm_map_kernel<2, 4>), dim3(grid), dim3(256), 0, st, ix, B);
-    else if (wps == 5) hipLaunchKernelGGL((qm_map_kernel<2, 5>), dim3(grid), dim3(256), 0, st, ix, B);
-    else if (wps == 6) hipLaunchKernelGGL((qm_map_kernel<2, 6>), dim3(grid), dim3(256), 0, st, ix, B);
-    else if (wps == 8) hipLaunchKernelGGL((qm_map_kernel<2, 8>), dim3(grid), dim3(256), 0, st, ix, B);
-    else hipLaunchKernelGGL((qm_map_kernel<2, 3>), dim3(grid), dim3(256), 0, st, ix, B);
+    if (wps <= 3) hipLaunchKernelGGL((qm_read_kernel<2, 3>), dim3(grid), dim3(256), 0, st, ix, B);
+    else if (wps == 4) hipLaunchKernelGGL((qm_read_kernel<2, 4>), dim3(grid), dim3(256), 0, st, ix, B);
+    else if (wps == 5) hipLaunchKernelGGL((qm_read_kernel<2, 5>), dim3(grid), dim3(256), 0, st, ix, B);
+    else if (wps == 6) hipLaunchKernelGGL((qm_read_kernel<2, 6>), dim3(grid), dim3(256), 0, st, ix, B);
+    else hipLaunchKernelGGL((qm_read_kernel<2, 8>), dim3(grid), dim3(256), 0, st, ix, B);
   } else {
-    hipLaunchKernelGGL((qm_map_kernel<4, 2>), dim3(grid), dim3(256), 0, st, ix, B);
+    hipLaunchKernelGGL((qm_read_kernel<4, 3>), dim3(grid), dim3(256), 0, st, ix, B);
   }
+  return hipGetLastError();
+}
+
+hipError_t qmk_pair_count(const void* pp, hipStream_t st) {
+  const PairBatch& P = *(const PairBatch*)pp;
+  if (P.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(qm_pair_count_kernel, dim3((unsigned)((P.n + 255) / 256)), dim3(256), 0, st, P);
+  return hipGetLastError();
+}
+
+hipError_t qmk_pair_write(const void* pp, hipStream_t st) {
+  const PairBatch& P = *(const PairBatch*)pp;
+  if (P.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(qm_pair_write_kernel, dim3((unsigned)((P.n + 255) / 256)), dim3(256), 0, st, P);
   return hipGetLastError();
 }
 
@@ -128,15 +151,6 @@ size_t qmk_scan_temp_bytes(long long n) {
 hipError_t qmk_scan_counts(void* temp, size_t temp_bytes, const u32* cnt, long long* offs, long long n, hipStream_t st) {
   auto it = rocprim::make_transform_iterator(cnt, U32ToI64());
   return rocprim::exclusive_scan(temp, temp_bytes, it, offs, 0LL, (size_t)n, rocprim::plus<long long>(), st);
-}
-
-hipError_t qmk_gather(long long n, const u32* cnt, const long long* tmp_off, const long long* offs, const void* tmp,
-                      void* out, hipStream_t st) {
-  if (n <= 0) return hipSuccess;
-  int blocks = (int)((n + 255) / 256);
-  hipLaunchKernelGGL(gather_hits_kernel, dim3(blocks), dim3(256), 0, st, n, cnt, tmp_off, offs, (const qm_hit*)tmp,
-                     (qm_hit*)out);
-  return hipGetLastError();
 }
 
 }  // extern "C"

@@ -1,23 +1,31 @@
-// qm_mapper.inl -- the quasi-mapping hot path for ONE wavefront owning ONE read pair
-// (or one single-end read).  Written against qm_wave.h: wave-uniform state lives in
-// plain scalars, per-lane state in LV<T>.  Compiled for gfx950 by qm_kernels.hip and,
-// for tests only, lane-emulated on the CPU by tests/emu/qm_emu.cpp.
+// qm_mapper.inl -- the quasi-mapping hot path.
 //
-// Stages (reference file:line each stage restates; nothing here is copied from it):
+//   stage A  (map_read)   ONE wavefront owns ONE read: SACollector::operator() + hitsToMappingsSimple.
+//   stage B  (pair_merge) one thread per read pair: mergeLeftRightHits + the per-pair driver.
+// A pair's two mates are independent until the merge, so giving each its own wave halves the chain of
+// dependent HBM round trips a wave walks through (the kernel is latency-bound: see profiles/), and
+// keeps the per-wave state small enough for 6+ waves per SIMD.
+//
+// Written against qm_wave.h: wave-uniform state lives in plain scalars (SGPRs), per-lane state in
+// LV<T>, long-lived tables in the wave's LDS slab.  Compiled for gfx950 by qm_kernels.hip and, for
+// tests only, lane-emulated on the CPU by tests/emu/qm_emu.cpp.
+//
+// Stages of map_read (reference file:line each one restates; nothing here is copied from it):
 //   1. strand setup     Kmer.hpp:525-542 (2-bit encode), :92-100 (RC), :484-487 (homopolymer)
 //                       -- all L-k+1 k-mers of a read at once: ballots build bit planes of the
 //                       2-bit codes, every lane slices its own 31-mer out of the planes.
-//   2. seed probes      RapMapUtils.hpp:65-67,226-239 (khash.find) -- all k-mers of both
-//                       strands are probed up front (independent loads, memory-level
-//                       parallelism) and reduced to presence bitmaps + lane-held intervals.
+//   2. seed probes      RapMapUtils.hpp:65-67,226-239 (khash.find) -- every k-mer of both strands is
+//                       probed up front, all loads in flight together, and reduced to presence
+//                       bitmaps (SGPRs) + an interval table (LDS).
 //   3. collector        SACollector.hpp:108-362 (operator()), :441-677 (getSAHits_),
 //                       :366-431 (spotCheck_) replayed as a scalar state machine over the
 //                       bitmaps; a run of misses is one masked popcount.
-//   4. MMP extension    SASearcher.hpp:88-309 (extendSearchNaive): three binary searches, the
-//                       text comparison is 64 characters per step across the lanes.
+//   4. MMP extension    SASearcher.hpp:88-309 (extendSearchNaive): closed form over <= 64 suffixes
+//                       (one lane per suffix), literal three-binary-search fallback otherwise.
 //   5. hits->mappings   HitManager.cpp:691-882 (+ :587-689, :449-493, :308-322) on small
 //                       u64 lists in LDS (global scratch for the rare > QM_CAP lists).
-//   6. pair merge       RapMapUtils.hpp:1185-1264 + RapMapSAMapper.cpp:461-551,684-701.
+// pair_merge:           RapMapUtils.hpp:1185-1264 + RapMapSAMapper.cpp:461-551,684-701 (pairs),
+//                       RapMapSAMapper.cpp:232-250 (single-end).
 #pragma once
 #include "qm_wave.h"
 #include "../../include/qmap_mi355.h"
@@ -26,10 +34,16 @@ namespace qm {
 
 #define QM_CAP 64      // entries per LDS list
 #define QM_GCAP 2048   // entries per global-scratch list (2 strands x <1000 SA entries)
+#define QM_ICAP 16     // SA-interval hits per strand kept in LDS (more spill to global scratch)
+#define QM_IOVF 256    // ... overflow capacity per strand (>= 64*NS - k + 1 for NS = 4)
 #define QM_DBG_CAP 64  // debug interval records per unit
+#define QM_CHUNK 4096  // list elements a wave reserves per bump-allocator round trip (>= QM_GCAP)
+#define QM_GSCR_U64 (3 * QM_GCAP + 2 * QM_IOVF * 2)   // u64 words of global scratch per wave
 
 struct Slot { u64 key; int lb; int ub; };          // 16 B open-addressing slot, key == ~0 empty
 struct SaInfo { u32 tid; int pos; };               // transcript id + offset in transcript of SA[i]
+struct Iv { int lb, ub; };                         // seed interval
+struct IntRec { int b, e; u32 len, q; };           // SAIntervalHit (RapMapUtils.hpp:516-525)
 
 struct DevIndex {
   const unsigned char* text;  // n bytes + >= 64 bytes of zero padding
@@ -42,30 +56,44 @@ struct DevIndex {
   int k;
 };
 
-struct Batch {
+// stage A launch arguments: reads in, one sorted unique hit list per read out
+struct ReadBatch {
   const unsigned char* seq1; const long long* off1;
   const unsigned char* seq2; const long long* off2;   // null => single-end
-  long long n;
-  // outputs
-  u32* hit_count;          // [n]
-  long long* tmp_off;      // [n] offset of the unit's hits in tmp_hits
-  qm_hit* tmp_hits;        // [tmp_cap] bump-allocated, compacted into CSR order afterwards
+  long long nreads;        // 2 * pairs, or the number of single-end reads
+  u32* lcnt;               // [nreads] list length
+  long long* loff;         // [nreads] offset of the list in `lists`
+  u64* lists;              // bump-allocated list elements
   u64* cursor;             // bump pointer
-  long long tmp_cap;
-  u64* counters;           // [6] qm_counters
-  u64* gscratch;           // per wave: 4 * QM_GCAP u64
-  int* status;             // sticky error flags (bit0: tmp overflow, bit1: list overflow)
-  qm_sa_interval_hit* dbg_ints;  // optional [n * QM_DBG_CAP]
-  u32* dbg_count;                // optional [n]
-  // options
-  int strict_check, max_num_hits, no_orphans, no_dovetail, max_interval;
+  long long lists_cap;
+  u64* gscratch;           // per wave: QM_GSCR_U64 words
+  int* status;             // sticky error flags (bit0: lists overflow, bit1: interval too wide, bit2: read too long)
+  qm_sa_interval_hit* dbg_ints;  // optional [nunits * QM_DBG_CAP]
+  u32* dbg_count;                // optional [nreads]
+  int strict_check, max_interval;
   double quasi_cov;
+};
+
+// stage B launch arguments
+struct PairBatch {
+  long long n;             // pairs (or single-end reads)
+  int paired;
+  const long long* off1; const long long* off2;
+  const u32* lcnt; const long long* loff; const u64* lists;
+  u32* cnt;                // [n+1] hits per unit (pass 1 writes, scan turns into offs)
+  const long long* offs;   // [n+1] exclusive scan of cnt (pass 2 reads)
+  qm_hit* hits;            // pass 2 output, CSR order
+  u64* counters;           // [6] qm_counters
+  int max_num_hits, no_orphans, no_dovetail;
 };
 
 template <int NS>
 struct WaveMem {
-  u64 buf[4][QM_CAP];              // A, B (sort ping-pong), RL, RR
-  alignas(8) unsigned char str[4][64 * NS + 16];   // left fwd, left rc, right fwd, right rc (+16: 8-byte over-reads)
+  u64 buf[3][QM_CAP];              // A, B (sort ping-pong), R (the read's hit list)
+  Iv tab[2][64 * NS];              // seed interval of the k-mer at position p of the read / of reverseRead(read)
+  u64 planes[2][4][NS + 2];        // per strand: bit planes B0, B1 (2-bit codes), N mask, non-ACGT mask
+  IntRec ints[2][QM_ICAP];         // recorded SA-interval hits, fwd / rc strand
+  alignas(8) unsigned char str[2][64 * NS + 16];   // read, reverseRead(read) (+16: 8-byte over-reads)
 };
 
 // ------------------------------------------------------------------ bit helpers
@@ -173,48 +201,60 @@ QM_DEV unsigned char rc_char(unsigned char c) {
   return l == 'a' ? 'T' : l == 'c' ? 'G' : l == 'g' ? 'C' : (l == 't' || l == 'u') ? 'A' : 'N';
 }
 
-// dense seed hash: exact lookup (RapMapUtils.hpp:65-67).  Two keys at once so both
-// first loads are in flight together.
-QM_DEV void probe2(const DevIndex& ix, bool doit, u64 ka, u64 kb, bool& fa, int& alb, int& aub,
-                   bool& fb, int& blb, int& bub) {
-  fa = fb = false; alb = aub = blb = bub = 0;
-  if (!doit) return;
-  u64 ia = hash_mix(ka) & ix.hmask, ib = hash_mix(kb) & ix.hmask;
-  Slot sa = ix.slots[ia], sb = ix.slots[ib];
-  while (true) {
-    if (sa.key == ka) { fa = true; alb = sa.lb; aub = sa.ub; break; }
-    if (sa.key == ~0ULL) break;
-    ia = (ia + 1) & ix.hmask; sa = ix.slots[ia];
-  }
-  while (true) {
-    if (sb.key == kb) { fb = true; blb = sb.lb; bub = sb.ub; break; }
-    if (sb.key == ~0ULL) break;
-    ib = (ib + 1) & ix.hmask; sb = ix.slots[ib];
+// ------------------------------------------------------------------ stage 1+2
+// Bits helpers for lazily filled bitmaps
+template <int NS> QM_DEV void or_field(Bits<NS>& b, int p, u64 v) {   // b |= v << p  (v has <= 32 significant bits)
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    int sh = p - 64 * s;
+    if (sh >= 0 && sh < 64) b.w[s] |= v << sh;
+    else if (sh < 0 && sh > -64) b.w[s] |= v >> (-sh);
   }
 }
 
-// ------------------------------------------------------------------ stage 1+2
+// One strand of one read.  E/E2/AV depend on the characters only and are built once; F/C/K are filled
+// window by window: the reference consults the hash only at the positions its MMP walk visits
+// (~47 finds per read instead of the 2(L-k+1) of an exhaustive pre-probe), and every probe is a random
+// 64-byte sector from HBM -- the resource this kernel is bound by (profiles/).
 template <int NS>
 struct Strand {
   Bits<NS> E;    // eligible in getSAHits_: no N in [p,p+k), not a homopolymer (SACollector.hpp:498-536)
   Bits<NS> E2;   // eligible in the first-hit scan: no N in [p,p+k] (:176-192, note the <=)
   Bits<NS> AV;   // all k characters are ACGT (fromChars succeeds, :602)
+  Bits<NS> K;    // positions whose F / C bits are known
   Bits<NS> F;    // khash.find(mer) hit
   Bits<NS> C;    // khash.find(mer.getRC()) hit
-  LV<int> flb[NS], fub[NS];   // interval of mer at position 64*s+lane
-  LV<int> clb[NS], cub[NS];   // interval of its reverse complement
-  bool clean;                 // only ACGTN (either case): the rc strand is the exact mirror
+  const u64* planes;   // LDS: [4][NS+2]
+  Iv* tab;             // LDS: interval of mer at position p (valid where F)
+  int P;
 };
 
+// k-mer word at position p of the strand (partial-word semantics of Kmer.hpp:535-538), plus window flags
 template <int NS>
-QM_DEV void setup_strand(const DevIndex& ix, const unsigned char* str, int L, Strand<NS>& S) {
+QM_DEV u64 kmer_at(const u64* planes, int p, int k, bool& nwin, bool& nwin2, int& d) {
+  const u64* B0 = planes; const u64* B1 = planes + (NS + 2); const u64* NM = planes + 2 * (NS + 2); const u64* INV = planes + 3 * (NS + 2);
+  int s = p >> 6, l = p & 63;
+  u64 nmw = (NM[s] >> l) | (l ? (NM[s + 1] << (64 - l)) : 0ULL);
+  u64 ivw = (INV[s] >> l) | (l ? (INV[s + 1] << (64 - l)) : 0ULL);
+  u64 x0 = (B0[s] >> l) | (l ? (B0[s + 1] << (64 - l)) : 0ULL);
+  u64 x1 = (B1[s] >> l) | (l ? (B1[s + 1] << (64 - l)) : 0ULL);
+  const u64 maskk = (1ULL << k) - 1, maskk1 = (1ULL << (k + 1)) - 1;
+  nwin = (nmw & maskk) != 0; nwin2 = (nmw & maskk1) != 0;
+  d = ctz64(ivw | (1ULL << k));                // chars before the first non-ACGT one, capped at k
+  u64 keep = (1ULL << d) - 1;
+  x0 &= keep; x1 &= keep;
+  u64 r0 = brev64(x0) >> (64 - k), r1 = brev64(x1) >> (64 - k);
+  return spread32(r0) | (spread32(r1) << 1);
+}
+
+template <int NS>
+QM_DEV void setup_strand(const DevIndex& ix, const unsigned char* str, int L, Strand<NS>& S, u64* planes, Iv* tab) {
   const int k = ix.k;
   const int P = L - k + 1;
-  u64 B0[NS + 1], B1[NS + 1], NM[NS + 1], INV[NS + 1];
-  bool clean = true;
+  S.planes = planes; S.tab = tab; S.P = P;
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    LV<bool> b0, b1, nn, iv, odd;
+    LV<bool> b0, b1, nn, iv;
     QM_LANES(l) {
       int idx = 64 * s + l;
       unsigned char c = idx < L ? str[idx] : 0;
@@ -226,87 +266,94 @@ QM_DEV void setup_strand(const DevIndex& ix, const unsigned char* str, int L, St
       b1[l] = valid && (code & 2);
       nn[l] = idx < L && cl == 'n';
       iv[l] = !valid;
-      odd[l] = idx < L && !valid && cl != 'n';
     }
-    B0[s] = ballot(b0); B1[s] = ballot(b1); NM[s] = ballot(nn); INV[s] = ballot(iv);
-    if (ballot(odd)) clean = false;
+    u64 m0 = ballot(b0), m1 = ballot(b1), m2 = ballot(nn), m3 = ballot(iv);
+    QM_LANES(l) {
+      if (l == 0) { planes[s] = m0; planes[(NS + 2) + s] = m1; planes[2 * (NS + 2) + s] = m2; planes[3 * (NS + 2) + s] = m3; }
+    }
   }
-  B0[NS] = 0; B1[NS] = 0; NM[NS] = 0; INV[NS] = ~0ULL;
-  S.clean = clean;
-  const u64 maskk = (1ULL << k) - 1, maskk1 = (1ULL << (k + 1)) - 1;
+  QM_LANES(l) {
+    if (l < 2) { planes[NS + l] = 0; planes[(NS + 2) + NS + l] = 0; planes[2 * (NS + 2) + NS + l] = 0; planes[3 * (NS + 2) + NS + l] = ~0ULL; }
+  }
+  wave_fence();
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    LV<bool> e, e2, av, ff, fc;
+    LV<bool> e, e2, av;
     QM_LANES(l) {
       int p = 64 * s + l;
-      u64 nmw = (NM[s] >> l) | (l ? (NM[s + 1] << (64 - l)) : 0ULL);
-      u64 ivw = (INV[s] >> l) | (l ? (INV[s + 1] << (64 - l)) : 0ULL);
-      u64 x0 = (B0[s] >> l) | (l ? (B0[s + 1] << (64 - l)) : 0ULL);
-      u64 x1 = (B1[s] >> l) | (l ? (B1[s + 1] << (64 - l)) : 0ULL);
-      bool nwin = (nmw & maskk) != 0, nwin2 = (nmw & maskk1) != 0;
-      int d = ctz64(ivw | (1ULL << k));          // chars before the first non-ACGT one, capped at k
-      u64 keep = (1ULL << d) - 1;                // partial word when fromChars stops early (Kmer.hpp:535-538)
-      x0 &= keep; x1 &= keep;
-      u64 r0 = brev64(x0) >> (64 - k), r1 = brev64(x1) >> (64 - k);
-      u64 w = spread32(r0) | (spread32(r1) << 1);
+      bool nwin, nwin2; int d;
+      u64 w = kmer_at<NS>(planes, p, k, nwin, nwin2, d);
       bool hom = homopolymer(w, k);
       bool inP = p < P;
       e[l] = inP && !nwin && !hom;
       e2[l] = inP && !nwin2 && !hom;
       av[l] = inP && d >= k;
-      bool fa, fb; int alb, aub, blb, bub;
-      probe2(ix, inP && !nwin, w, word_rc(w, k), fa, alb, aub, fb, blb, bub);
-      ff[l] = fa; fc[l] = fb;
-      S.flb[s][l] = alb; S.fub[s][l] = aub; S.clb[s][l] = blb; S.cub[s][l] = bub;
     }
     S.E.w[s] = ballot(e); S.E2.w[s] = ballot(e2); S.AV.w[s] = ballot(av);
-    S.F.w[s] = ballot(ff); S.C.w[s] = ballot(fc);
+    S.K.w[s] = 0; S.F.w[s] = 0; S.C.w[s] = 0;
   }
 }
 
-template <int NS> QM_DEV int lane_arr_get(const LV<int> (&a)[NS], int p) {
-  int r = 0;
+// Probe positions [p, p+width) (width <= 32): lanes 0..31 look up the k-mer, lanes 32..63 its reverse
+// complement -- khash.find (RapMapUtils.hpp:65-67) -- one round of independent loads.
+template <int NS>
+QM_DEV void probe_window(const DevIndex& ix, Strand<NS>& S, int p, int width) {
+  const int k = ix.k;
+  if (p + width > S.P) width = S.P - p;
+  if (width <= 0) return;
+  LV<bool> found;
+  QM_LANES(l) {
+    int j = l & 31;
+    bool isC = l >= 32;
+    int pos = p + j;
+    bool hit = false; Iv v = {0, 0};
+    if (j < width) {
+      bool nwin, nwin2; int d;
+      u64 key = kmer_at<NS>(S.planes, pos, k, nwin, nwin2, d);
+      if (!nwin) {
+        if (isC) key = word_rc(key, k);
+        u64 i = hash_mix(key) & ix.hmask;
+        while (true) {
+          Slot x = ix.slots[i];
+          if (x.key == key) { hit = true; v.lb = x.lb; v.ub = x.ub; break; }
+          if (x.key == ~0ULL) break;
+          i = (i + 1) & ix.hmask;
+        }
+      }
+      if (!isC) S.tab[pos] = v;
+    }
+    found[l] = hit;
+  }
+  u64 fm = ballot(found);
+  u64 wm = width >= 32 ? 0xffffffffULL : ((1ULL << width) - 1);
+  or_field(S.F, p, fm & wm);
+  or_field(S.C, p, (fm >> 32) & wm);
+  or_field(S.K, p, wm);
+  wave_fence();
+}
+
+// first position >= p that is NOT yet probed (or 64*NS)
+template <int NS> QM_DEV int known_end(const Strand<NS>& S, int p) {
+  Bits<NS> nk;
 #pragma unroll
-  for (int s = 0; s < NS; ++s) if (s == (p >> 6)) r = read_lane(a[s], p & 63);
-  return r;
+  for (int s = 0; s < NS; ++s) nk.w[s] = ~S.K.w[s];
+  return first_set_from(nk, p);
 }
 
-// What getSAHits_ sees of one strand of one read.
-template <int NS>
-struct StrandView {
-  Bits<NS> E, AV, F, C;
-  const Strand<NS>* src;
-  int mode;   // 0: src's mer intervals at p; 1: src's complement intervals at P-1-p (mirrored rc strand)
-  int P;
-  QM_DEV void interval(int p, int& lb, int& ub) const {
-    if (mode == 0) { lb = lane_arr_get<NS>(src->flb, p); ub = lane_arr_get<NS>(src->fub, p); }
-    else { int q = P - 1 - p; lb = lane_arr_get<NS>(src->clb, q); ub = lane_arr_get<NS>(src->cub, q); }
-  }
-};
-
-// SA-interval hits of one strand, lane-distributed: hit i lives in lane i&63 of slot i>>6
-template <int NS>
+// SA-interval hits of one strand: the first QM_ICAP in LDS, the rest in the wave's global scratch
 struct IntervalList {
-  LV<int> b[NS], e[NS]; LV<u32> len[NS], q[NS];
+  IntRec* lds; IntRec* ovf;
   int n;
   QM_DEV void push(int lb, int ub, u32 ln, u32 qp) {
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      if (s == (n >> 6)) {
-        QM_LANES(l) { if (l == (n & 63)) { b[s][l] = lb; e[s][l] = ub; len[s][l] = ln; q[s][l] = qp; } }
-      }
-    }
+    IntRec r; r.b = lb; r.e = ub; r.len = ln; r.q = qp;
+    IntRec* dst = n < QM_ICAP ? &lds[n] : &ovf[n - QM_ICAP];
+    QM_LANES(l) { if (l == 0) *dst = r; }
     ++n;
+    wave_fence();
   }
   QM_DEV void get(int i, int& lb, int& ub, u32& ln, u32& qp) const {
-    lb = ub = 0; ln = qp = 0;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      if (s == (i >> 6)) {
-        lb = read_lane(b[s], i & 63); ub = read_lane(e[s], i & 63);
-        ln = read_lane(len[s], i & 63); qp = read_lane(q[s], i & 63);
-      }
-    }
+    IntRec r = i < QM_ICAP ? lds[i] : ovf[i - QM_ICAP];
+    lb = uniform(r.b); ub = uniform(r.e); ln = uniform(r.len); qp = uniform(r.q);
   }
 };
 
@@ -450,92 +497,106 @@ QM_DEV void extend_search(const DevIndex& ix, int lbIn, int ubIn, int startAt, c
 // ------------------------------------------------------------------ stage 3
 // SACollector::getSAHits_ (SACollector.hpp:441-677), NIP disabled
 template <int NS>
-QM_DEV void get_sa_hits(const DevIndex& ix, const Batch& B, const StrandView<NS>& V, const unsigned char* str, int L,
+QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, const unsigned char* str, int L,
                         int startPos, bool haveInterval, int lb, int ub, long long& cov, u32& strandHits,
-                        u32& otherHits, IntervalList<NS>& out) {
+                        u32& otherHits, IntervalList& out) {
   const int k = ix.k, P = L - k + 1;
   int p = startPos;
   bool skip = haveInterval, lastSearch = false;
   int prevMMPEnd = 0;
-  Bits<NS> hitm = b_and(V.E, V.F);
-  Bits<NS> missC = b_and(b_andn(V.E, V.F), V.C);
+  int width = 1;      // first window of a pass: a single position; after an MMP jump the walk crosses ~k positions
   while (true) {
     if (!skip) {
       if (p >= P) break;
+      if (!V.K.test(p)) { probe_window<NS>(ix, V, p, width); width = 32; }
+      int kend = known_end(V, p);
+      if (kend > P) kend = P;
+      Bits<NS> hitm = b_and(V.E, V.F);
       int ph = first_set_from(hitm, p);
-      int stop = ph < P ? ph : P;
+      int stop = ph < kend ? ph : kend;
+      Bits<NS> missC = b_and(b_andn(V.E, V.F), V.C);
       otherHits += (u32)popc_range(missC, p, stop);   // misses: spotCheck_ of the complement (:667-675)
-      if (ph >= P) break;
+      if (ph >= kend) { p = kend; width = 32; continue; }   // nothing in the probed stretch: next window (or the end)
       strandHits += 1;                                 // spotCheck_ on the hit (:545)
       otherHits += V.C.test(ph) ? 1u : 0u;
       p = ph;
-      V.interval(p, lb, ub);
+      Iv v = V.tab[p];
+      lb = uniform(v.lb); ub = uniform(v.ub);
     }
     skip = false;
     lb = lb - 1 > 0 ? lb - 1 : 0;                      // :553
     int mlen;
     extend_search(ix, lb, ub, k, str + p, L - p, lb, ub, mlen);
+    const bool more = !lastSearch && p + mlen < L;     // the walk continues at kp after this MMP
+    const int kp = p + mlen - (k - 1);
     if (ub > lb && ub - lb < B.max_interval) {          // :577-618
       out.push(lb, ub, (u32)mlen, (u32)p);
       int corr = prevMMPEnd > p ? prevMMPEnd - p : 0;
       cov += mlen - corr;
       prevMMPEnd = p + mlen;
       if (p + mlen < L) {
-        int kp = p + mlen - (k - 1);
-        if (V.AV.test(kp)) { strandHits += V.F.test(kp) ? 1u : 0u; otherHits += V.C.test(kp) ? 1u : 0u; }
+        if (V.AV.test(kp)) {
+          if (!V.K.test(kp)) probe_window<NS>(ix, V, kp, more ? 32 : 1);
+          strandHits += V.F.test(kp) ? 1u : 0u; otherHits += V.C.test(kp) ? 1u : 0u;
+        }
       }
     }
     if (lastSearch) return;
     if (p + mlen >= L) return;
-    p = p + mlen - (k - 1);                             // NIP off: lce == matchedLen (:635-647)
+    p = kp;                                             // NIP off: lce == matchedLen (:635-647)
+    width = 32;
     if (p + k == L) lastSearch = true;
   }
 }
 
 // SACollector::operator() (SACollector.hpp:108-362), disableNIP_ == true.
-// str[0] = read, str[1] = reverseRead(read).  Returns foundHit.
+// M.str[0] = read (upper-cased), M.str[1] = reverseRead(read).  Returns foundHit.
 template <int NS>
-QM_DEV bool collect_read(const DevIndex& ix, const Batch& B, const unsigned char* fwdStr, unsigned char* rcStr, int L,
-                         IntervalList<NS>& fwdInts, IntervalList<NS>& rcInts) {
+QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M, int L, IntervalList& fwdInts,
+                         IntervalList& rcInts) {
   const int k = ix.k, P = L - k + 1;
+  const unsigned char* fwdStr = M.str[0];
+  const unsigned char* rcStr = M.str[1];
   fwdInts.n = 0; rcInts.n = 0;
   if (P <= 0) return false;
   Strand<NS> S;
-  setup_strand<NS>(ix, fwdStr, L, S);
-  // first-hit scan (:167-237)
-  Bits<NS> cand = b_and(S.E2, b_or(S.F, S.C));
-  int p0 = first_set_from(cand, 0);
-  if (p0 >= P) return false;
+  setup_strand<NS>(ix, fwdStr, L, S, &M.planes[0][0][0], M.tab[0]);
+  // first-hit scan (:167-237): first E2 position whose k-mer or reverse complement is in the hash
+  int p0 = first_set_from(S.E2, 0);
+  int width = 1;
+  bool found = false;
+  while (p0 < P) {
+    if (!S.K.test(p0)) { probe_window<NS>(ix, S, p0, width); width = 32; }
+    int kend = known_end(S, p0);
+    if (kend > P) kend = P;
+    Bits<NS> cand = b_and(S.E2, b_or(S.F, S.C));
+    int ph = first_set_from(cand, p0);
+    if (ph < kend) { p0 = ph; found = true; break; }
+    p0 = first_set_from(S.E2, kend);
+  }
+  if (!found) return false;
   u32 fwdHit = S.F.test(p0) ? 1u : 0u;
   u32 rcHit = S.C.test(p0) ? 1u : 0u;
   long long fwdCov = 0, rcCov = 0;
   const bool useCoverageCheck = B.strict_check != 0;   // disableNIP_ && strictCheck_ (:138)
 
-  StrandView<NS> VF; VF.E = S.E; VF.AV = S.AV; VF.F = S.F; VF.C = S.C; VF.src = &S; VF.mode = 0; VF.P = P;
   bool didCheckFwd = false;
   if (fwdHit) {                                         // :247-254
     didCheckFwd = true;
-    int lb, ub; VF.interval(p0, lb, ub);
-    get_sa_hits<NS>(ix, B, VF, fwdStr, L, p0, true, lb, ub, fwdCov, fwdHit, rcHit, fwdInts);
+    Iv v = S.tab[p0];
+    get_sa_hits<NS>(ix, B, S, fwdStr, L, p0, true, uniform(v.lb), uniform(v.ub), fwdCov, fwdHit, rcHit, fwdInts);
   }
   bool checkRC = useCoverageCheck ? (rcHit > 0) : (rcHit >= fwdHit);
   if (checkRC) {                                        // :258-265
-    if (S.clean) {
-      StrandView<NS> VR; VR.E = mirror(S.E, P); VR.AV = mirror(S.AV, P); VR.F = mirror(S.C, P); VR.C = mirror(S.F, P);
-      VR.src = &S; VR.mode = 1; VR.P = P;
-      get_sa_hits<NS>(ix, B, VR, rcStr, L, 0, false, 0, 0, rcCov, rcHit, fwdHit, rcInts);
-    } else {
-      // IUPAC / 'U' characters: reverseRead() is not the mirror image of the 2-bit
-      // encoding any more, so the rc strand gets its own setup and probes.
-      Strand<NS> R;
-      setup_strand<NS>(ix, rcStr, L, R);
-      StrandView<NS> VR; VR.E = R.E; VR.AV = R.AV; VR.F = R.F; VR.C = R.C; VR.src = &R; VR.mode = 0; VR.P = P;
-      get_sa_hits<NS>(ix, B, VR, rcStr, L, 0, false, 0, 0, rcCov, rcHit, fwdHit, rcInts);
-    }
+    // the reverse-complemented read is treated as a string of its own (also correct for IUPAC / 'U'
+    // characters, where reverseRead() is not the mirror image of the 2-bit encoding)
+    Strand<NS> R;
+    setup_strand<NS>(ix, rcStr, L, R, &M.planes[1][0][0], M.tab[1]);
+    get_sa_hits<NS>(ix, B, R, rcStr, L, 0, false, 0, 0, rcCov, rcHit, fwdHit, rcInts);
   }
   bool checkFwd = useCoverageCheck ? (fwdHit > 0) : (fwdHit >= rcHit);
   if (!didCheckFwd && checkFwd) {                       // :271-278
-    get_sa_hits<NS>(ix, B, VF, fwdStr, L, 0, false, 0, 0, fwdCov, fwdHit, rcHit, fwdInts);
+    get_sa_hits<NS>(ix, B, S, fwdStr, L, 0, false, 0, 0, fwdCov, fwdHit, rcHit, fwdInts);
   }
   if (B.strict_check) {                                 // :280-288 (coverage mode; slack 0)
     if (fwdCov > rcCov) rcInts.n = 0;
@@ -615,8 +676,7 @@ QM_DEV int single_interval(const DevIndex& ix, const Bufs& bf, int rOff, int lb,
 
 // intersectSAHits + collectHitsSimpleSA (HitManager.cpp:587-689, :449-493, :308-322),
 // consensusFraction == 1 (maxSlack 0), strictFilter off.
-template <int NS>
-QM_DEV int multi_interval(const DevIndex& ix, const Bufs& bf, int rOff, const IntervalList<NS>& ints, bool isRC) {
+QM_DEV int multi_interval(const DevIndex& ix, const Bufs& bf, int rOff, const IntervalList& ints, bool isRC) {
   const int m = ints.n;
   int minIdx = 0, minSpan = 0x7fffffff;
   for (int i = 0; i < m; ++i) {                       // first smallest span (:636-641)
@@ -708,13 +768,12 @@ QM_DEV int multi_interval(const DevIndex& ix, const Bufs& bf, int rOff, const In
 
 // hitsToMappingsSimple (HitManager.cpp:691-882): leaves the read's hits (sorted by tid,
 // unique, fwd preferred) in bf.R[0..return)
-template <int NS>
-QM_DEV int hits_to_mappings(const DevIndex& ix, const Bufs& bf, const IntervalList<NS>& fwdInts,
-                            const IntervalList<NS>& rcInts) {
+QM_DEV int hits_to_mappings(const DevIndex& ix, const Bufs& bf, const IntervalList& fwdInts,
+                            const IntervalList& rcInts) {
   int nf = 0, nr = 0;
-  if (fwdInts.n > 1) nf = multi_interval<NS>(ix, bf, 0, fwdInts, false);
+  if (fwdInts.n > 1) nf = multi_interval(ix, bf, 0, fwdInts, false);
   else if (fwdInts.n == 1) { int lb, ub; u32 ln, qp; fwdInts.get(0, lb, ub, ln, qp); nf = single_interval(ix, bf, 0, lb, ub, qp, false); }
-  if (rcInts.n > 1) nr = multi_interval<NS>(ix, bf, nf, rcInts, true);
+  if (rcInts.n > 1) nr = multi_interval(ix, bf, nf, rcInts, true);
   else if (rcInts.n == 1) { int lb, ub; u32 ln, qp; rcInts.get(0, lb, ub, ln, qp); nr = single_interval(ix, bf, nf, lb, ub, qp, true); }
   if (nf > 0 && nr > 0) {
     // stable merge by tid, fwd first on ties, duplicates collapse to the first (:834-881)
@@ -727,10 +786,9 @@ QM_DEV int hits_to_mappings(const DevIndex& ix, const Bufs& bf, const IntervalLi
 }
 
 // largest list any stage will hold for this read (decides LDS vs global scratch)
-template <int NS>
-QM_DEV int list_bound(const IntervalList<NS>& a, const IntervalList<NS>& b) {
+QM_DEV int list_bound(const IntervalList& a, const IntervalList& b) {
   int tot = 0;
-  const IntervalList<NS>* ls[2] = {&a, &b};
+  const IntervalList* ls[2] = {&a, &b};
   for (int t = 0; t < 2; ++t) {
     int m = ls[t]->n, mn = 0x7fffffff;
     for (int i = 0; i < m; ++i) { int lb, ub; u32 ln, qp; ls[t]->get(i, lb, ub, ln, qp); if (ub - lb < mn) mn = ub - lb; }
@@ -739,16 +797,19 @@ QM_DEV int list_bound(const IntervalList<NS>& a, const IntervalList<NS>& b) {
   return tot;
 }
 
-template <int NS>
-QM_DEV void dump_intervals(const Batch& B, long long unit, int list, const IntervalList<NS>& L, int& cnt) {
+QM_DEV void dump_intervals(const ReadBatch& B, long long read, int list, const IntervalList& L, int& cnt) {
+  // debug records are grouped per unit (pair): mate 0 uses slots [0, CAP/2), mate 1 [CAP/2, CAP)
+  const long long unit = B.seq2 ? (read >> 1) : read;
+  const int half = B.seq2 ? QM_DBG_CAP / 2 : QM_DBG_CAP;
+  const int base = B.seq2 ? (int)(read & 1) * half : 0;
   for (int i = 0; i < L.n; ++i) {
     int lb, ub; u32 ln, qp; L.get(i, lb, ub, ln, qp);
-    if (cnt < QM_DBG_CAP) {
+    if (cnt < half) {
       QM_LANES(l) {
         if (l == 0) {
           qm_sa_interval_hit h; h.begin = lb; h.end = ub; h.len = ln; h.query_pos = qp;
           h.query_rc = (uint8_t)(list & 1); h.list = (uint8_t)list; h.pad = 0;
-          B.dbg_ints[unit * QM_DBG_CAP + cnt] = h;
+          B.dbg_ints[unit * QM_DBG_CAP + base + cnt] = h;
         }
       }
     }
@@ -756,8 +817,70 @@ QM_DEV void dump_intervals(const Batch& B, long long unit, int list, const Inter
   }
 }
 
-// ------------------------------------------------------------------ stage 6 + driver
-struct WaveCounters { u64 pe, se, tot, reads, tooMany, mapped; };
+// ------------------------------------------------------------------ stage A driver
+// One read: load -> collect -> hits->mappings -> list to global memory.
+struct WaveAlloc { long long base; int used; };   // the wave's current chunk of B.lists (wave-uniform)
+
+template <int NS>
+QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, WaveMem<NS>& M, u64* gscr, WaveAlloc& wa) {
+  const bool paired = B.seq2 != nullptr;
+  const int mate = paired ? (int)(read & 1) : 0;
+  const long long unit = paired ? (read >> 1) : read;
+  const unsigned char* src = mate == 0 ? B.seq1 : B.seq2;
+  const long long* off = mate == 0 ? B.off1 : B.off2;
+  long long o0 = uniform(off[unit]), o1 = uniform(off[unit + 1]);
+  int len = (int)(o1 - o0);
+  if (len > 64 * NS) { QM_LANES(l) { if (l == 0) *B.status |= 4; } len = 64 * NS; }
+  unsigned char* fs = M.str[0];
+  unsigned char* rs = M.str[1];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    QM_LANES(l) {
+      int idx = 64 * s + l;
+      // the forward read is kept upper-cased (every consumer applies ::toupper anyway, SASearcher.hpp:111,155)
+      if (idx < len) { unsigned char c = src[o0 + idx]; fs[idx] = (unsigned char)upc(c); rs[len - 1 - idx] = rc_char(c); }
+    }
+  }
+  wave_fence();
+  IntervalList fi, ri;
+  fi.lds = M.ints[0]; ri.lds = M.ints[1];
+  fi.ovf = (IntRec*)(gscr + 3 * QM_GCAP); ri.ovf = fi.ovf + QM_IOVF;
+  collect_read<NS>(ix, B, M, len, fi, ri);
+  if (B.dbg_ints) {
+    int dbg = 0;
+    dump_intervals(B, read, 2 * mate, fi, dbg); dump_intervals(B, read, 2 * mate + 1, ri, dbg);
+    QM_LANES(l) { if (l == 0) B.dbg_count[read] = (u32)dbg; }
+  }
+  Bufs bf;
+  int bound = list_bound(fi, ri);
+  if (bound <= QM_CAP) { bf.A = M.buf[0]; bf.B = M.buf[1]; bf.R = M.buf[2]; }
+  else { bf.A = gscr; bf.B = gscr + QM_GCAP; bf.R = gscr + 2 * QM_GCAP; }
+  int n = 0;
+  if (bound > QM_GCAP) {               // only reachable with max_interval > 1000
+    QM_LANES(l) { if (l == 0) *B.status |= 2; }
+  } else {
+    n = hits_to_mappings(ix, bf, fi, ri);
+  }
+  // hand the list to stage B.  One returning atomic on a single word saturates at ~88 M/s on this chip
+  // (MI355X_MICROARCH.md "dequeue"), far below the read rate, so a wave reserves QM_CHUNK elements at
+  // a time and sub-allocates from its chunk.
+  long long base = 0;
+  if (n > 0) {
+    if (wa.base < 0 || wa.used + n > QM_CHUNK) {
+      LV<u64> bv;
+      QM_LANES(l) { bv[l] = 0; if (l == 0) bv[l] = atomic_add_u64(B.cursor, (u64)QM_CHUNK); }
+      wa.base = (long long)read_lane(bv, 0); wa.used = 0;
+    }
+    base = wa.base + wa.used;
+    if (base + n > B.lists_cap) { QM_LANES(l) { if (l == 0) *B.status |= 1; } n = 0; base = 0; }
+    else wa.used += n;
+  }
+  for (int b0 = 0; b0 < n; b0 += 64) { QM_LANES(l) { int i = b0 + l; if (i < n) B.lists[base + i] = bf.R[i]; } }
+  QM_LANES(l) { if (l == 0) { B.lcnt[read] = (u32)n; B.loff[read] = base; } }
+}
+
+// ------------------------------------------------------------------ stage B: one thread per unit
+struct UnitCounters { u64 pe, se, tot, reads, tooMany, mapped; };
 
 QM_DEV qm_hit orphan_hit(u64 e, u32 readLen, int mateStatus) {
   qm_hit h; h.tid = el_tid(e); h.pos = el_pos(e); h.mate_pos = 0; h.frag_len = 0; h.read_len = readLen; h.mate_len = 0;
@@ -771,193 +894,82 @@ QM_DEV bool dovetail(const qm_hit& h) {                 // RapMapSAMapper.cpp:68
   }
   return false;
 }
-
-// allocate `cnt` hit records for this unit (lane-uniform); returns the base or -1 on overflow
-QM_DEV long long alloc_hits(const Batch& B, long long unit, int cnt) {
-  long long base = 0;
-  if (cnt > 0) {
-    LV<u64> bv;
-    QM_LANES(l) { bv[l] = 0; if (l == 0) bv[l] = atomic_add_u64(B.cursor, (u64)cnt); }
-    base = (long long)read_lane(bv, 0);
-    if (base + cnt > B.tmp_cap) {
-      QM_LANES(l) { if (l == 0) { *B.status |= 1; B.hit_count[unit] = 0; B.tmp_off[unit] = 0; } }
-      return -1;
-    }
-  }
-  QM_LANES(l) { if (l == 0) { B.hit_count[unit] = (u32)cnt; B.tmp_off[unit] = base; } }
-  return base;
+QM_DEV qm_hit paired_hit(u64 le, u64 re, u32 l1, u32 l2) {   // RapMapUtils.hpp:1212-1231
+  int s1 = el_pos(le) > 0 ? el_pos(le) : 0, s2 = el_pos(re) > 0 ? el_pos(re) : 0;
+  bool r1First = s1 < s2;
+  int fragStart = r1First ? s1 : s2;
+  int fragEnd = r1First ? (int)((u32)s2 + l2) : (int)((u32)s1 + l1);
+  qm_hit h; h.tid = el_tid(le); h.pos = s1; h.mate_pos = s2; h.frag_len = (u32)(fragEnd - fragStart);
+  h.read_len = l1; h.mate_len = l2; h.fwd = el_rc(le) ? 0 : 1; h.mate_is_fwd = el_rc(re) ? 0 : 1;
+  h.is_paired = 1; h.mate_status = 3; h.aln_score = 0;
+  return h;
 }
 
-// One unit = one read pair (or one read when B.seq2 == nullptr).
-template <int NS>
-QM_DEV void map_unit(const DevIndex& ix, const Batch& B, long long unit, WaveMem<NS>& M, u64* gscr, WaveCounters& wc) {
-  const bool paired = B.seq2 != nullptr;
-  const int nreads = paired ? 2 : 1;
-  int L[2] = {0, 0};
-  int nlist[2] = {0, 0};
-  u64* lists[2] = {M.buf[2], M.buf[3]};
-  int dbg = 0;
-  wc.reads += 1;
-  for (int r = 0; r < nreads; ++r) {
-    const unsigned char* src = r == 0 ? B.seq1 : B.seq2;
-    const long long* off = r == 0 ? B.off1 : B.off2;
-    long long o0 = off[unit], o1 = off[unit + 1];
-    int len = (int)(o1 - o0);
-    if (len > 64 * NS) { QM_LANES(l) { if (l == 0) *B.status |= 4; } len = 64 * NS; }
-    L[r] = len;
-    unsigned char* fs = M.str[2 * r];
-    unsigned char* rs = M.str[2 * r + 1];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      QM_LANES(l) {
-        int idx = 64 * s + l;
-        // the forward read is kept upper-cased (every consumer applies ::toupper anyway, SASearcher.hpp:111,155)
-        if (idx < len) { unsigned char c = src[o0 + idx]; fs[idx] = (unsigned char)upc(c); rs[len - 1 - idx] = rc_char(c); }
-      }
-    }
-    wave_fence();
-    IntervalList<NS> fi, ri;
-    collect_read<NS>(ix, B, fs, rs, len, fi, ri);
-    if (B.dbg_ints) { dump_intervals<NS>(B, unit, 2 * r, fi, dbg); dump_intervals<NS>(B, unit, 2 * r + 1, ri, dbg); }
-    Bufs bf;
-    int bound = list_bound<NS>(fi, ri);
-    if (bound <= QM_CAP) { bf.A = M.buf[0]; bf.B = M.buf[1]; bf.R = M.buf[2 + r]; }
-    else { bf.A = gscr; bf.B = gscr + QM_GCAP; bf.R = gscr + (2 + r) * QM_GCAP; }
-    lists[r] = bf.R;
-    if (bound > QM_GCAP) {               // only reachable with max_interval > 1000
-      QM_LANES(l) { if (l == 0) *B.status |= 2; }
-      nlist[r] = 0;
-    } else {
-      nlist[r] = hits_to_mappings<NS>(ix, bf, fi, ri);
-    }
-  }
-  if (B.dbg_count) { QM_LANES(l) { if (l == 0) B.dbg_count[unit] = (u32)dbg; } }
-
-  const int maxHits = B.max_num_hits;
-  if (!paired) {                                        // RapMapSAMapper.cpp:232-250
-    int n = nlist[0];
-    wc.tot += (u64)n;
+// mergeLeftRightHits (RapMapUtils.hpp:1185-1264) + per-pair driver (RapMapSAMapper.cpp:461-551,684-701),
+// or the single-end driver (:232-250).  out == nullptr: count only (and add to the counters);
+// otherwise write the unit's hits to out[0..min(return, cap)), cap = the count pass's result.
+QM_DEV int unit_merge(const PairBatch& P, long long u, qm_hit* out, int cap, UnitCounters* uc) {
+  const int maxHits = P.max_num_hits;
+  if (!P.paired) {
+    int n = (int)P.lcnt[u];
+    const u64* X = P.lists + P.loff[u];
+    u32 len = (u32)(P.off1[u + 1] - P.off1[u]);
+    if (uc) { uc->reads += 1; uc->tot += (u64)n; }       // counted before the maxNumHits clear (:240-245)
     if (n > maxHits) n = 0;
-    long long base = alloc_hits(B, unit, n);
-    if (base >= 0) {
-      for (int b0 = 0; b0 < n; b0 += 64) {
-        QM_LANES(l) { int i = b0 + l; if (i < n) B.tmp_hits[base + i] = orphan_hit(lists[0][i], (u32)L[0], 0); }
-      }
-    }
-    if (n > 0) wc.mapped += 1;
-    return;
+    if (uc && n > 0) uc->mapped += 1;
+    if (out) for (int i = 0; i < n && i < cap; ++i) out[i] = orphan_hit(X[i], len, 0);
+    return n;
   }
-
-  // mergeLeftRightHits (RapMapUtils.hpp:1185-1264)
-  const u64* LL = lists[0]; const u64* RR = lists[1];
-  const int nl = nlist[0], nr = nlist[1];
-  int nm = 0;       // matches on transcript id
-  int nkeep = 0;    // ... that survive --noDovetail
+  const int nl = (int)P.lcnt[2 * u], nr = (int)P.lcnt[2 * u + 1];
+  const u64* LL = P.lists + P.loff[2 * u];
+  const u64* RR = P.lists + P.loff[2 * u + 1];
+  const u32 l1 = (u32)(P.off1[u + 1] - P.off1[u]), l2 = (u32)(P.off2[u + 1] - P.off2[u]);
+  if (uc) uc->reads += 1;
+  // two-pointer intersection on transcript id (both lists are sorted and unique)
+  int nm = 0, nkeep = 0;
   if (nl > 0 && nr > 0) {
-    for (int b0 = 0; b0 < nl; b0 += 64) {
-      LV<bool> mt, kp;
-      QM_LANES(l) {
-        int i = b0 + l; bool m = false, kk = false;
-        if (i < nl) {
-          u32 tid = el_tid(LL[i]);
-          int lo = 0, hi = nr;
-          while (lo < hi) { int mid = (lo + hi) >> 1; if (el_tid(RR[mid]) < tid) lo = mid + 1; else hi = mid; }
-          if (lo < nr && el_tid(RR[lo]) == tid) {
-            m = true; kk = true;
-            if (B.no_dovetail) {
-              qm_hit h; h.fwd = el_rc(LL[i]) ? 0 : 1; h.mate_is_fwd = el_rc(RR[lo]) ? 0 : 1;
-              h.pos = el_pos(LL[i]) > 0 ? el_pos(LL[i]) : 0; h.mate_pos = el_pos(RR[lo]) > 0 ? el_pos(RR[lo]) : 0;
-              kk = !dovetail(h);
-            }
-          }
+    int i = 0, j = 0;
+    while (i < nl && j < nr) {
+      u32 a = el_tid(LL[i]), b = el_tid(RR[j]);
+      if (a < b) ++i;
+      else if (b < a) ++j;
+      else {
+        ++nm;
+        if (!(P.no_dovetail && dovetail(paired_hit(LL[i], RR[j], l1, l2)))) {
+          if (out && nkeep < cap) out[nkeep] = paired_hit(LL[i], RR[j], l1, l2);
+          ++nkeep;
         }
-        mt[l] = m; kp[l] = kk;
+        ++i; ++j;
       }
-      nm += popc64(ballot(mt)); nkeep += popc64(ballot(kp));
     }
   }
-  bool tooMany = nm > maxHits;                          // :1233-1234
-  if (tooMany) wc.tooMany += 1;
-  int cnt = 0; int kind = 0;                            // kind 1 paired, 2 orphans
-  if (!tooMany && nm > 0) { wc.pe += (u64)nm; cnt = nkeep; kind = 1; }
-  else if (!tooMany && nl + nr > 0) {
-    wc.se += (u64)(nl + nr);
-    cnt = nl + nr; kind = 2;
-    if (cnt > maxHits) { cnt = 0; kind = 0; }           // RapMapSAMapper.cpp:534-536
-    if (B.no_orphans) { cnt = 0; kind = 0; }            // :539-551
-    if (kind == 2 && B.no_dovetail) {
-      // the reference evaluates the dovetail predicate on orphans with an uninitialised
-      // matePos; we define matePos = 0, mateIsFwd = true (same as the oracle).
-      int c2 = 0;
+  const bool tooMany = nm > maxHits;                    // :1233-1234
+  if (uc && tooMany) uc->tooMany += 1;
+  int cnt = 0;
+  if (!tooMany && nm > 0) {
+    if (uc) uc->pe += (u64)nm;
+    cnt = nkeep;
+  } else if (!tooMany && nl + nr > 0) {
+    if (uc) uc->se += (u64)(nl + nr);
+    bool keep = true;
+    if (nl + nr > maxHits) keep = false;                // RapMapSAMapper.cpp:534-536
+    if (P.no_orphans) keep = false;                     // :539-551
+    if (keep) {
+      // --noDovetail on orphans: the reference evaluates the predicate with an uninitialised matePos;
+      // we define matePos = 0, mateIsFwd = true (same as the oracle).
       for (int t = 0; t < 2; ++t) {
-        const u64* X = t == 0 ? LL : RR; int nx = t == 0 ? nl : nr;
-        for (int b0 = 0; b0 < nx; b0 += 64) {
-          LV<bool> kp;
-          QM_LANES(l) { int i = b0 + l; kp[l] = i < nx && !dovetail(orphan_hit(X[i], 0, 1)); }
-          c2 += popc64(ballot(kp));
+        const u64* X = t == 0 ? LL : RR; int nx = t == 0 ? nl : nr; u32 ln = t == 0 ? l1 : l2;
+        for (int i = 0; i < nx; ++i) {
+          qm_hit h = orphan_hit(X[i], ln, t == 0 ? 1 : 2);
+          if (P.no_dovetail && dovetail(h)) continue;
+          if (out && cnt < cap) out[cnt] = h;
+          ++cnt;
         }
-      }
-      cnt = c2;
-    }
-  }
-  long long base = alloc_hits(B, unit, cnt);
-  wc.tot += (u64)cnt;
-  if (cnt > 0) wc.mapped += 1;
-  if (base < 0 || cnt == 0) return;
-  if (kind == 1) {
-    int outn = 0;
-    for (int b0 = 0; b0 < nl; b0 += 64) {
-      LV<bool> kp; LV<int> rj;
-      QM_LANES(l) {
-        int i = b0 + l; bool kk = false; int jj = 0;
-        if (i < nl) {
-          u32 tid = el_tid(LL[i]);
-          int lo = 0, hi = nr;
-          while (lo < hi) { int mid = (lo + hi) >> 1; if (el_tid(RR[mid]) < tid) lo = mid + 1; else hi = mid; }
-          if (lo < nr && el_tid(RR[lo]) == tid) { kk = true; jj = lo; }
-        }
-        kp[l] = kk; rj[l] = jj;
-      }
-      LV<bool> kp2;
-      LV<qm_hit> hv;
-      QM_LANES(l) {
-        bool kk = kp[l];
-        if (kk) {
-          int i = b0 + l;
-          u64 le = LL[i], re = RR[rj[l]];
-          int s1 = el_pos(le) > 0 ? el_pos(le) : 0, s2 = el_pos(re) > 0 ? el_pos(re) : 0;   // :1213-1214
-          bool r1First = s1 < s2;
-          int fragStart = r1First ? s1 : s2;
-          int fragEnd = r1First ? (int)((u32)s2 + (u32)L[1]) : (int)((u32)s1 + (u32)L[0]);
-          qm_hit h; h.tid = el_tid(le); h.pos = s1; h.mate_pos = s2; h.frag_len = (u32)(fragEnd - fragStart);
-          h.read_len = (u32)L[0]; h.mate_len = (u32)L[1]; h.fwd = el_rc(le) ? 0 : 1; h.mate_is_fwd = el_rc(re) ? 0 : 1;
-          h.is_paired = 1; h.mate_status = 3; h.aln_score = 0;
-          if (B.no_dovetail && dovetail(h)) kk = false;
-          hv[l] = h;
-        }
-        kp2[l] = kk;
-      }
-      u64 km = ballot(kp2);
-      QM_LANES(l) { if (kp2[l]) B.tmp_hits[base + outn + popc64(km & lanemask_lt(l))] = hv[l]; }
-      outn += popc64(km);
-    }
-  } else {
-    int outn = 0;
-    for (int t = 0; t < 2; ++t) {
-      const u64* X = t == 0 ? LL : RR; int nx = t == 0 ? nl : nr;
-      for (int b0 = 0; b0 < nx; b0 += 64) {
-        LV<bool> kp; LV<qm_hit> hv;
-        QM_LANES(l) {
-          int i = b0 + l; bool kk = false;
-          if (i < nx) { qm_hit h = orphan_hit(X[i], (u32)L[t], t == 0 ? 1 : 2); kk = !(B.no_dovetail && dovetail(h)); hv[l] = h; }
-          kp[l] = kk;
-        }
-        u64 km = ballot(kp);
-        QM_LANES(l) { if (kp[l]) B.tmp_hits[base + outn + popc64(km & lanemask_lt(l))] = hv[l]; }
-        outn += popc64(km);
       }
     }
   }
+  if (uc) { uc->tot += (u64)cnt; if (cnt > 0) uc->mapped += 1; }
+  return cnt;
 }
 
 }  // namespace qm

@@ -21,43 +21,63 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
            qm_sa_interval_hit** ints_out, int* status_out) {
   DevIndex ix; ix.text = text; ix.n = n; ix.SA = SA; ix.nSA = nSA; ix.sainfo = (const SaInfo*)sainfo;
   ix.slots = (const Slot*)slots; ix.hmask = hmask; ix.k = k;
-  Batch B; memset(&B, 0, sizeof(B));
-  B.seq1 = seq1; B.off1 = off1; B.seq2 = seq2; B.off2 = off2; B.n = nunits;
-  std::vector<u32> hc(nunits, 0); std::vector<long long> toff(nunits, 0);
-  long long cap = nunits * 16 + 1024;
-  std::vector<qm_hit> tmp;
-  std::vector<u64> gs(4 * QM_GCAP);
-  std::vector<qm_sa_interval_hit> dints((size_t)nunits * QM_DBG_CAP); std::vector<u32> dcnt(nunits, 0);
-  int status = 0; u64 cursor = 0; u64 ctr[6] = {0, 0, 0, 0, 0, 0};
-  B.hit_count = hc.data(); B.tmp_off = toff.data(); B.cursor = &cursor; B.counters = ctr;
+  const bool paired = seq2 != nullptr;
+  const long long nreads = paired ? 2 * nunits : nunits;
+  ReadBatch B; memset(&B, 0, sizeof(B));
+  B.seq1 = seq1; B.off1 = off1; B.seq2 = seq2; B.off2 = off2; B.nreads = nreads;
+  std::vector<u32> lcnt(nreads + 1, 0); std::vector<long long> loff(nreads + 1, 0);
+  long long cap = nreads * 4 + 16 * QM_CHUNK;
+  std::vector<u64> lists;
+  std::vector<u64> gs(QM_GSCR_U64);
+  std::vector<qm_sa_interval_hit> dints((size_t)nunits * QM_DBG_CAP + 1); std::vector<u32> dcnt(nreads + 1, 0);
+  int status = 0; u64 cursor = 0;
+  B.lcnt = lcnt.data(); B.loff = loff.data(); B.cursor = &cursor;
   B.gscratch = gs.data(); B.status = &status; B.dbg_ints = dints.data(); B.dbg_count = dcnt.data();
-  B.strict_check = o->strict_check; B.max_num_hits = o->max_num_hits; B.no_orphans = o->no_orphans;
-  B.no_dovetail = o->no_dovetail; B.max_interval = o->max_interval; B.quasi_cov = o->quasi_cov;
-  WaveCounters wc = {0, 0, 0, 0, 0, 0};
+  B.strict_check = o->strict_check; B.max_interval = o->max_interval; B.quasi_cov = o->quasi_cov;
   while (true) {
-    tmp.assign((size_t)cap, qm_hit());
-    B.tmp_hits = tmp.data(); B.tmp_cap = cap; cursor = 0; status = 0;
-    wc = WaveCounters{0, 0, 0, 0, 0, 0};
-    for (long long u = 0; u < nunits; ++u) {
-      if (ns == 2) { static WaveMem<2> M; map_unit<2>(ix, B, u, M, gs.data(), wc); }
-      else { static WaveMem<4> M; map_unit<4>(ix, B, u, M, gs.data(), wc); }
+    lists.assign((size_t)cap, 0);
+    B.lists = lists.data(); B.lists_cap = cap; cursor = 0; status = 0;
+    // emulate 7 interleaved "waves", each with its own chunk allocator
+    WaveAlloc wa[7];
+    for (auto& w : wa) { w.base = -1; w.used = 0; }
+    for (long long r = 0; r < nreads; ++r) {
+      if (ns == 2) { static WaveMem<2> M; map_read<2>(ix, B, r, M, gs.data(), wa[r % 7]); }
+      else { static WaveMem<4> M; map_read<4>(ix, B, r, M, gs.data(), wa[r % 7]); }
     }
     if (!(status & 1)) break;
     cap *= 4;
   }
+  PairBatch P; memset(&P, 0, sizeof(P));
+  std::vector<u32> hc(nunits + 1, 0); std::vector<long long> offs(nunits + 1, 0);
+  u64 ctr[6] = {0, 0, 0, 0, 0, 0};
+  P.n = nunits; P.paired = paired ? 1 : 0; P.off1 = off1; P.off2 = off2; P.lcnt = lcnt.data(); P.loff = loff.data();
+  P.lists = lists.data(); P.cnt = hc.data(); P.offs = offs.data(); P.counters = ctr;
+  P.max_num_hits = o->max_num_hits; P.no_orphans = o->no_orphans; P.no_dovetail = o->no_dovetail;
+  UnitCounters uc = {0, 0, 0, 0, 0, 0};
+  for (long long u = 0; u < nunits; ++u) hc[u] = (u32)unit_merge(P, u, nullptr, 0, &uc);
   hit_offsets[0] = 0;
   for (long long u = 0; u < nunits; ++u) hit_offsets[u + 1] = hit_offsets[u] + hc[u];
+  for (long long u = 0; u <= nunits; ++u) offs[u] = hit_offsets[u];
   qm_hit* out = (qm_hit*)malloc(sizeof(qm_hit) * (size_t)(hit_offsets[nunits] + 1));
-  for (long long u = 0; u < nunits; ++u)
-    for (u32 j = 0; j < hc[u]; ++j) out[hit_offsets[u] + j] = tmp[toff[u] + j];
+  P.hits = out;
+  for (long long u = 0; u < nunits; ++u) if (hc[u]) unit_merge(P, u, out + offs[u], (int)hc[u], nullptr);
   *hits_out = out;
-  counters[0] = wc.pe; counters[1] = wc.se; counters[2] = wc.tot; counters[3] = wc.reads;
-  counters[4] = wc.tooMany; counters[5] = wc.mapped;
+  counters[0] = uc.pe; counters[1] = uc.se; counters[2] = uc.tot; counters[3] = uc.reads;
+  counters[4] = uc.tooMany; counters[5] = uc.mapped;
+  const int mates = paired ? 2 : 1, half = paired ? QM_DBG_CAP / 2 : QM_DBG_CAP;
+  auto kept = [&](long long r) { return (long long)(dcnt[r] < (u32)half ? dcnt[r] : (u32)half); };
   int_offsets[0] = 0;
-  for (long long u = 0; u < nunits; ++u) int_offsets[u + 1] = int_offsets[u] + (dcnt[u] < QM_DBG_CAP ? dcnt[u] : QM_DBG_CAP);
+  for (long long u = 0; u < nunits; ++u) {
+    long long t = 0;
+    for (int m = 0; m < mates; ++m) t += kept(u * mates + m);
+    int_offsets[u + 1] = int_offsets[u] + t;
+  }
   qm_sa_interval_hit* io = (qm_sa_interval_hit*)malloc(sizeof(qm_sa_interval_hit) * (size_t)(int_offsets[nunits] + 1));
-  for (long long u = 0; u < nunits; ++u)
-    for (long long j = 0; j < int_offsets[u + 1] - int_offsets[u]; ++j) io[int_offsets[u] + j] = dints[u * QM_DBG_CAP + j];
+  for (long long u = 0; u < nunits; ++u) {
+    long long w = int_offsets[u];
+    for (int m = 0; m < mates; ++m)
+      for (long long j = 0; j < kept(u * mates + m); ++j) io[w++] = dints[u * QM_DBG_CAP + m * half + j];
+  }
   *ints_out = io;
   *status_out = status;
   return 0;
