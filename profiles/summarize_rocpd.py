@@ -14,5 +14,5 @@ for name, calls, tot, avg, pct in c.execute(
 print()
 print("# per-dispatch rows of the mapping kernel (start/end are ns timestamps)")
 for r in c.execute("select name, grid_x, workgroup_x, lds_size, vgpr_count, sgpr_count, scratch_size, (end-start)/1e6 "
-                   "from kernels where name like '%qm_map_kernel%' order by start"):
+                   "from kernels where name like '%qm_read_kernel%' order by start"):
     print("%s grid=%d wg=%d lds=%d vgpr=%d sgpr=%d scratch=%d dur_ms=%.3f" % r)

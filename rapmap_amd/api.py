@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqmap_mi355.so")
+LIB_PATH = os.environ.get("QM_LIB_OVERRIDE") or os.path.join(_HERE, "libqmap_mi355.so")   # override: profiling variants only
 
 HIT_DTYPE = np.dtype([
     ("tid", "<u4"), ("pos", "<i4"), ("mate_pos", "<i4"), ("frag_len", "<u4"),
