@@ -88,6 +88,43 @@ def synth_medium(tmp_path_factory, lib_built):
 
 
 @pytest.fixture(scope="session")
+def repeat_data(tmp_path_factory, lib_built):
+    """repeat families of 40 / 300 / 1100 copies of a 200-mer core with unique flanks, reads drawn inside the cores"""
+    import rapmap_amd as ra
+    from rapmap_amd import synth
+    rng = np.random.default_rng(99)
+    B = np.frombuffer(b"ACGT", dtype=np.uint8)
+    comp = np.zeros(256, np.uint8); comp[list(b"ACGT")] = list(b"TGCA")
+    names, txps = synth.make_transcriptome(40, seed=5)
+    cores = []
+    for fam, copies in (("F40", 40), ("F300", 300), ("F1100", 1100)):
+        core = B[rng.integers(0, 4, 200)]
+        cores.append(core)
+        for i in range(copies):
+            l = B[rng.integers(0, 4, int(rng.integers(30, 80)))]; r = B[rng.integers(0, 4, int(rng.integers(30, 80)))]
+            txps.append(np.concatenate([l, core, r])); names.append("%s.%d" % (fam, i))
+    d = tmp_path_factory.mktemp("repeats")
+    fa = str(d / "t.fa"); synth.write_fasta(fa, names, txps)
+    idx = str(d / "idx"); ra.build_index(fa, idx, threads=4)
+    r1, r2 = [], []
+    for core in cores:
+        for j in range(12):
+            a = core[j:j + 100].copy(); b = comp[core[200 - 100 - j:200 - j][::-1]]
+            if j % 3 == 0:
+                a[50] = B[(np.searchsorted(B, a[50]) + 1) % 4]      # one substitution: two MMPs
+            if j % 2:
+                a, b = b, a
+            r1.append(a.tobytes()); r2.append(b.tobytes())
+    # a few ordinary pairs and one read crossing from a unique flank into a core
+    s1, s2, off, _ = synth.make_reads(txps[:150], 200, seed=8)
+    r1 += [s1[off[i]:off[i + 1]].tobytes() for i in range(200)]
+    r2 += [s2[off[i]:off[i + 1]].tobytes() for i in range(200)]
+    t = txps[-1]
+    r1.append(t[10:110].tobytes()); r2.append(comp[t[120:220][::-1]].tobytes())
+    return {"idx": idx, "reads1": r1, "reads2": r2}
+
+
+@pytest.fixture(scope="session")
 def oracle_mod():
     from oracle import oracle
     oracle.build()

@@ -98,3 +98,17 @@ def test_medium(synth_medium, oracle_mod):
     assert_hits_equal(res.hit_offsets, res.hits, er.hit_offsets, er.hits, "medium")
     assert res.counters == er.counters
     _cmp_ints(res, er)
+
+
+def test_repeat_families(repeat_data, oracle_mod):
+    """reads inside repeat cores: 40 / 300 / 1100 copies -> lists beyond the LDS lists (global scratch),
+    > maxNumHits (tooManyHits) and >= maxInterval (skipped intervals)"""
+    ix, orc, em, emu = _emu(repeat_data["idx"])
+    q1, o1 = pack(repeat_data["reads1"]); q2, o2 = pack(repeat_data["reads2"])
+    res = orc.map_pairs(q1, o1, q2, o2, nthreads=4, want_ints=True)
+    er = em.map(q1, o1, q2, o2)
+    assert er.status == 0
+    assert res.counters["tooManyHits"] > 0 and res.counters["peHits"] > 0
+    assert_hits_equal(res.hit_offsets, res.hits, er.hit_offsets, er.hits, "repeats")
+    assert res.counters == er.counters
+    _cmp_ints(res, er)

@@ -181,3 +181,16 @@ def test_device_resident_inputs(synth_medium, oracle_mod):
     res = orc.map_pairs(q1, o, q2, o, nthreads=4)
     assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "device-resident")
     assert gr.map_kernel_ms > 0
+
+
+def test_repeat_families(repeat_data, oracle_mod):
+    """lists beyond a lane's private memory (wave fix-up), beyond LDS (global scratch), tooManyHits, maxInterval"""
+    ix, orc = load_oracle(repeat_data["idx"])
+    qi, mp = _gpu(repeat_data["idx"])
+    q1, o1 = pack(repeat_data["reads1"]); q2, o2 = pack(repeat_data["reads2"])
+    res = orc.map_pairs(q1, o1, q2, o2, nthreads=4, want_ints=True)
+    gr = mp.map_pairs(q1, o1, q2, o2)
+    assert res.counters["tooManyHits"] > 0
+    assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "repeats")
+    assert res.counters == gr.counters
+    _cmp_ints(res, *mp.intervals(len(o1) - 1))
