@@ -32,11 +32,11 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def build_or_reuse_index(genes, seed, k, rank, world, cache_root):
+def build_or_reuse_index(genes, seed, k, rank, world, cache_root, perfect_hash=False):
     """rank 0 builds the synthetic transcriptome + quasi-index once per box; everybody mmaps it."""
     import rapmap_amd as ra
     from rapmap_amd import synth
-    tag = "g%d_s%d_k%d" % (genes, seed, k)
+    tag = "g%d_s%d_k%d%s" % (genes, seed, k, "_ph" if perfect_hash else "")
     d = os.path.join(cache_root, "qmap_bench_" + tag)
     idx = os.path.join(d, "idx")
     done = os.path.join(d, "DONE")
@@ -49,7 +49,7 @@ def build_or_reuse_index(genes, seed, k, rank, world, cache_root):
         log("transcriptome: %d transcripts, %d bases (%.1fs)" % (len(txps), sum(x.size for x in txps), time.time() - t))
         del names, txps
         t = time.time()
-        ra.build_index(fa, idx, k=k, threads=min(32, os.cpu_count() or 1))
+        ra.build_index(fa, idx, k=k, threads=min(32, os.cpu_count() or 1), perfect_hash=perfect_hash)
         os.remove(fa)
         log("quasiindex built in %.1fs" % (time.time() - t))
         open(done, "w").write("ok\n")
@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=10_000_000, help="read pairs per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--perfect-hash", action="store_true", help="config 4: index built with `quasiindex -p` (BooPHF / FrugalBooMap probe path)")
     ap.add_argument("--cache", default=os.environ.get("QMAP_BENCH_CACHE", "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"))
     args = ap.parse_args()
 
@@ -139,7 +140,7 @@ def main():
     from rapmap_amd import dist as qd
 
     k, L = 31, 100
-    idx_dir = build_or_reuse_index(args.genes, 42, k, rank, world, args.cache)
+    idx_dir = build_or_reuse_index(args.genes, 42, k, rank, world, args.cache, args.perfect_hash)
     t = time.time()
     qi = ra.QuasiIndex(idx_dir)
     mp = ra.QuasiMapper(qi, local_rank)
@@ -189,9 +190,10 @@ def main():
             "unit": "M read-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/int32/u64 (integer & byte work, no floating point)", "data": "synthetic",
-            "config": {"workload": "configs[1]: GENCODE-like synthetic index (%d genes -> %d transcripts, %d text bytes, "
+            "config": {"workload": "configs[%d]: GENCODE-like synthetic index (%d genes -> %d transcripts, %d text bytes, "
                                    "%d 31-mers), %d pairs 2x%d bp per GPU per step, 1%% substitutions, hits only (no -s), "
-                                   "dense hash index" % (args.genes, qi.n_txps, qi.text_len, qi.n_keys, n, L),
+                                   "%s index" % (3 if args.perfect_hash else 1, args.genes, qi.n_txps, qi.text_len, qi.n_keys, n, L,
+                                                 "perfect-hash (-p)" if args.perfect_hash else "dense hash"),
                        "pairs_per_gpu_per_step": n, "parallelism": "shard%d (index replicated, counters all-reduced)" % world,
                        "hits_per_pair": round(tot["totHits"] / max(1, tot["numReads"]), 4),
                        "mreads_per_s": round(2 * value, 4)},
@@ -229,7 +231,8 @@ def main():
         pf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pf):
             try:
-                traffic = json.load(open(pf)).get("hbm_bytes_per_launch")
+                ent = json.load(open(pf)).get("perfect_hash" if args.perfect_hash else "dense") or {}
+                traffic = ent.get("hbm_bytes_per_launch") if n == 10_000_000 and args.genes == 40000 else None
             except Exception:
                 traffic = None
         out["roofline"] = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

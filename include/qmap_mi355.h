@@ -101,8 +101,9 @@ const char* qm_version(void);
 int qm_opts_default(qm_opts* o);
 
 /* RapMapSAIndex<int32_t, RegHashT>::load (src/RapMapSAIndex.cpp:97-176): reads
- * header.json, sa.bin, txpInfo.bin, rsd.bin, hash.bin of a "q5" index directory
- * (files are mmap'd, not deserialised). */
+ * header.json, sa.bin, txpInfo.bin, rsd.bin and hash.bin -- or, for a perfect-hash (-p) index
+ * (RapMapSAIndex<int32_t, PerfectHashT>, include/FrugalBooMap.hpp), hash_info.bph + hash_info.val --
+ * of a "q5" index directory (files are mmap'd, not deserialised). */
 int qm_index_open(const char* dir, qm_index** out);
 int qm_index_close(qm_index* ix);
 int qm_index_info_get(const qm_index* ix, qm_index_info* info);
@@ -149,11 +150,11 @@ int qm_fetch_intervals(qm_ctx* ctx, int64_t* int_offsets, qm_sa_interval_hit* in
  * the context's stream (milliseconds); n_launches kernels were timed. */
 int qm_last_kernel_ms(const qm_ctx* ctx, double* map_kernel_ms, double* total_ms);
 
-/* `rapmap quasiindex` (src/RapMapSAIndexer.cpp:449-819) for the dense-hash,
- * int32 index: FASTA -> q5 index directory readable by qm_index_open (and by the
- * reference).  Host only. */
+/* `rapmap quasiindex [-p]` (src/RapMapSAIndexer.cpp:449-819), int32 suffix array: FASTA -> q5 index
+ * directory readable by qm_index_open and by the reference (sa.bin, txpInfo.bin, rsd.bin and -- with
+ * perfect_hash -- hash_info.bph / hash_info.val come out byte-identical to the reference's).  Host only. */
 int qm_build_index(const char* fasta_path, const char* out_dir, int32_t k, int32_t no_clip_poly_a,
-                   int32_t keep_duplicates, int32_t n_threads);
+                   int32_t keep_duplicates, int32_t n_threads, int32_t perfect_hash);
 
 #ifdef __cplusplus
 }

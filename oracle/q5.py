@@ -119,6 +119,6 @@ def load(d):
     if not ix.perfect:
         ix.hkeys, ix.hlb, ix.hub = read_dense_hash(d, ix.big)
     else:
-        from . import q5ph  # noqa
+        from oracle import q5ph  # noqa
         ix.hkeys, ix.hlb, ix.hub = q5ph.enumerate_intervals(ix)
     return ix

@@ -100,7 +100,7 @@ def lib():
     L.qm_ctx_set_debug.argtypes = [C.c_void_p, C.c_int]
     L.qm_fetch_intervals.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     L.qm_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
-    L.qm_build_index.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    L.qm_build_index.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.qm_opts_default.argtypes = [C.POINTER(QmOpts)]
     _lib = L
     return L
@@ -122,10 +122,11 @@ def default_opts(**kw):
     return o
 
 
-def build_index(fasta, out_dir, k=31, no_clip_poly_a=False, keep_duplicates=False, threads=None):
-    """`rapmap quasiindex -t FASTA -i OUT -k K` (src/RapMapSAIndexer.cpp:821-927), dense hash, int32 SA."""
+def build_index(fasta, out_dir, k=31, no_clip_poly_a=False, keep_duplicates=False, threads=None, perfect_hash=False):
+    """`rapmap quasiindex -t FASTA -i OUT -k K [-p]` (src/RapMapSAIndexer.cpp:821-927), int32 SA."""
     threads = threads or min(32, os.cpu_count() or 1)
-    rc = lib().qm_build_index(os.fsencode(fasta), os.fsencode(out_dir), k, int(no_clip_poly_a), int(keep_duplicates), threads)
+    rc = lib().qm_build_index(os.fsencode(fasta), os.fsencode(out_dir), k, int(no_clip_poly_a), int(keep_duplicates), threads,
+                              int(perfect_hash))
     if rc != 0:
         lib().qm_indexer_last_error.restype = C.c_char_p
         raise QmError("qm_build_index failed (%d): %s" % (rc, lib().qm_indexer_last_error().decode()))
@@ -150,6 +151,7 @@ class QuasiIndex:
         info = QmIndexInfo()
         _check(lib().qm_index_info_get(self._h, C.byref(info)))
         self.k, self.text_len, self.n_txps, self.n_keys = info.k, info.text_len, info.n_txps, info.n_keys
+        self.perfect_hash = bool(info.perfect_hash)
         self._names = None
         self._lens = None
 

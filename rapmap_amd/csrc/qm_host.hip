@@ -12,6 +12,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -59,6 +60,14 @@ struct qm_index {
   std::vector<int64_t> lens;
   const uint8_t* hashRecs = nullptr; int64_t nKeys = 0;   // K x 16 B records
   uint64_t rsdBits = 0;
+  // perfect-hash flavour (hash_info.bph / hash_info.val)
+  MMap bph, val;
+  struct PhLevel { uint64_t domain, nchar, nranks; const uint8_t* words; const uint8_t* ranks; };
+  std::vector<PhLevel> phLevels;
+  uint64_t phLastRank = 0, phNelem = 0;
+  std::vector<std::pair<uint64_t, uint64_t>> phFinal;
+  const uint8_t* phData = nullptr; const uint8_t* phLens = nullptr;
+  std::vector<std::pair<int32_t, int32_t>> phOverflow;
 };
 
 struct qm_ctx {
@@ -69,6 +78,7 @@ struct qm_ctx {
   // index replica
   uint8_t* d_text = nullptr; int32_t* d_SA = nullptr; void* d_sainfo = nullptr; void* d_slots = nullptr;
   uint64_t cap = 0;
+  void* d_ph = nullptr; std::vector<void*> phAllocs;       // perfect-hash flavour: PhIndex struct + its arrays
   int64_t devBytes = 0;
   // work buffers
   int64_t capCnt = 0, capOffs = 0, capLcnt = 0, capLoff = 0, capLists = 0, capHits = 0, capSeq1 = 0, capSeq2 = 0, capGrid = 0;
@@ -130,7 +140,7 @@ int qm_index_open(const char* dirIn, qm_index** out) {
   qm_index* ix = new qm_index();
   ix->dir = dirIn;
   if (ix->dir.empty() || ix->dir.back() != '/') ix->dir += '/';
-  auto bail = [&](int code) { ix->sa.close(); ix->txp.close(); ix->rsd.close(); ix->hash.close(); delete ix; return code; };
+  auto bail = [&](int code) { ix->sa.close(); ix->txp.close(); ix->rsd.close(); ix->hash.close(); ix->bph.close(); ix->val.close(); delete ix; return code; };
   {  // header.json (IndexHeader.hpp:45-57)
     FILE* f = fopen((ix->dir + "header.json").c_str(), "rb");
     if (!f) return bail(fail(QM_E_IO, "cannot open %sheader.json", ix->dir.c_str()));
@@ -146,11 +156,15 @@ int qm_index_open(const char* dirIn, qm_index** out) {
     if (ix->k < 1 || ix->k > 31) return bail(fail(QM_E_IO, "bad k %d", ix->k));
   }
   if (ix->big) return bail(fail(QM_E_UNSUPPORTED, "BigSA (int64) indices are not supported yet"));
-  if (ix->perfect) return bail(fail(QM_E_UNSUPPORTED, "perfect-hash (-p) indices are not supported yet"));
+
   if (ix->sa.open(ix->dir + "sa.bin")) return bail(fail(QM_E_IO, "cannot map sa.bin"));
   if (ix->txp.open(ix->dir + "txpInfo.bin")) return bail(fail(QM_E_IO, "cannot map txpInfo.bin"));
   if (ix->rsd.open(ix->dir + "rsd.bin")) return bail(fail(QM_E_IO, "cannot map rsd.bin"));
-  if (ix->hash.open(ix->dir + "hash.bin")) return bail(fail(QM_E_IO, "cannot map hash.bin"));
+  if (!ix->perfect) { if (ix->hash.open(ix->dir + "hash.bin")) return bail(fail(QM_E_IO, "cannot map hash.bin")); }
+  else {
+    if (ix->bph.open(ix->dir + "hash_info.bph")) return bail(fail(QM_E_IO, "cannot map hash_info.bph"));
+    if (ix->val.open(ix->dir + "hash_info.val")) return bail(fail(QM_E_IO, "cannot map hash_info.val"));
+  }
   {  // sa.bin: u64 n, n x i32
     const uint8_t* p = (const uint8_t*)ix->sa.p;
     if (ix->sa.len < 8) return bail(fail(QM_E_IO, "sa.bin truncated"));
@@ -188,7 +202,58 @@ int qm_index_open(const char* dirIn, qm_index** out) {
     if (ix->rsd.len != 8 + (ix->rsdBits + 7) / 8) return bail(fail(QM_E_IO, "rsd.bin size mismatch"));
     if ((int64_t)ix->rsdBits != ix->n) return bail(fail(QM_E_IO, "rsd.bin bits != text length"));
   }
-  {  // hash.bin: 3 x big-endian u32 (0xFFFFFFFF escapes to u64), group bitmaps, records
+  if (ix->perfect) {
+    {  // hash_info.bph: boomphf::mphf::save (include/BooPHF.hpp:1172-1197), bitVector::save (:773-781)
+      const uint8_t* p = (const uint8_t*)ix->bph.p; size_t len = ix->bph.len, off = 0;
+      auto rd = [&](void* d, size_t n) { if (off + n > len) return false; memcpy(d, p + off, n); off += n; return true; };
+      double gamma; int32_t nl;
+      if (!rd(&gamma, 8) || !rd(&nl, 4) || !rd(&ix->phLastRank, 8) || !rd(&ix->phNelem, 8) || nl < 2 || nl > 64)
+        return bail(fail(QM_E_IO, "hash_info.bph truncated"));
+      ix->phLevels.resize(nl);
+      for (int i = 0; i < nl; ++i) {
+        uint64_t size, nchar, nr;
+        if (!rd(&size, 8) || !rd(&nchar, 8) || off + nchar * 8 > len) return bail(fail(QM_E_IO, "hash_info.bph truncated (level)"));
+        ix->phLevels[i].nchar = nchar; ix->phLevels[i].words = p + off; off += nchar * 8;
+        if (!rd(&nr, 8) || off + nr * 8 > len) return bail(fail(QM_E_IO, "hash_info.bph truncated (ranks)"));
+        ix->phLevels[i].nranks = nr; ix->phLevels[i].ranks = p + off; off += nr * 8;
+      }
+      uint64_t fn; if (!rd(&fn, 8) || off + fn * 16 != len) return bail(fail(QM_E_IO, "hash_info.bph size mismatch"));
+      for (uint64_t i = 0; i < fn; ++i) { uint64_t kk, vv; rd(&kk, 8); rd(&vv, 8); ix->phFinal.emplace_back(kk, vv); }
+      // level domains are not stored: recomputed exactly like mphf::load (:1219-1230)
+      double n = (double)ix->phNelem;
+      double proba = 1.0 - pow(((gamma * n - 1) / (gamma * n)), (double)ix->phNelem - 1);
+      uint64_t hd = (size_t)(ceil(n * gamma));
+      for (int i = 0; i < nl; ++i) {
+        uint64_t d = (((uint64_t)(hd * pow(proba, i)) + 63) / 64) * 64;
+        if (d == 0) d = 64;
+        ix->phLevels[i].domain = d;
+        if (ix->phLevels[i].nchar < d / 64) return bail(fail(QM_E_IO, "hash_info.bph: level %d smaller than its domain", i));
+      }
+    }
+    {  // hash_info.val: vector<i32> data_, vector<u8> lens_, sparsepp map overflow_ (FrugalBooMap.hpp:199-213)
+      const uint8_t* p = (const uint8_t*)ix->val.p; size_t len = ix->val.len, off = 0;
+      uint64_t n1, n2;
+      if (len < 8) return bail(fail(QM_E_IO, "hash_info.val truncated"));
+      memcpy(&n1, p, 8); off = 8;
+      if (off + n1 * 4 + 8 > len) return bail(fail(QM_E_IO, "hash_info.val truncated (data)"));
+      ix->phData = p + off; off += n1 * 4;
+      memcpy(&n2, p + off, 8); off += 8;
+      if (off + n2 > len || n1 != n2 || n1 != ix->phNelem) return bail(fail(QM_E_IO, "hash_info.val: size mismatch"));
+      ix->phLens = p + off; off += n2;
+      auto be = [&](uint64_t& v) {
+        if (off + 4 > len) return false;
+        v = ((uint64_t)p[off] << 24) | ((uint64_t)p[off + 1] << 16) | ((uint64_t)p[off + 2] << 8) | p[off + 3]; off += 4;
+        if (v == 0xFFFFFFFFULL) { if (off + 8 > len) return false; v = 0; for (int i = 0; i < 8; ++i) v = (v << 8) | p[off + i]; off += 8; }
+        return true;
+      };
+      uint64_t magic, tsize, nb;
+      if (!be(magic) || !be(tsize) || !be(nb) || magic != 0x24687531ULL) return bail(fail(QM_E_IO, "hash_info.val: bad overflow map"));
+      off += ((tsize + 31) / 32) * 4;
+      if (off + nb * 8 != len) return bail(fail(QM_E_IO, "hash_info.val size mismatch"));
+      for (uint64_t i = 0; i < nb; ++i) { int32_t a, b; memcpy(&a, p + off, 4); memcpy(&b, p + off + 4, 4); off += 8; ix->phOverflow.emplace_back(a, b); }
+      ix->nKeys = (int64_t)ix->phNelem;
+    }
+  } else {  // hash.bin: 3 x big-endian u32 (0xFFFFFFFF escapes to u64), group bitmaps, records
     const uint8_t* p = (const uint8_t*)ix->hash.p; size_t len = ix->hash.len, off = 0;
     auto be = [&](uint64_t& v) {
       if (off + 4 > len) return false;
@@ -213,7 +278,7 @@ int qm_index_open(const char* dirIn, qm_index** out) {
 
 int qm_index_close(qm_index* ix) {
   if (!ix) return QM_OK;
-  ix->sa.close(); ix->txp.close(); ix->rsd.close(); ix->hash.close();
+  ix->sa.close(); ix->txp.close(); ix->rsd.close(); ix->hash.close(); ix->bph.close(); ix->val.close();
   delete ix;
   return QM_OK;
 }
@@ -250,6 +315,7 @@ int qm_ctx_destroy(qm_ctx* c) {
   void* ptrs[] = {c->d_text, c->d_SA, c->d_sainfo, c->d_slots, c->d_cnt, c->d_lcnt, c->d_loff, c->d_lists, c->d_hits, c->d_offs,
                   c->d_scal, c->d_gscr, c->d_scanTmp, c->d_seq1, c->d_seq2, c->d_off1, c->d_off2, c->d_dbg, c->d_dbgcnt};
   for (void* p : ptrs) if (p) hipFree(p);
+  for (void* p : c->phAllocs) if (p) hipFree(p);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
   if (c->evA) hipEventDestroy(c->evA);
@@ -283,16 +349,60 @@ int qm_ctx_create(const qm_index* ix, int device_id, qm_ctx** out) {
   CK(hipMalloc((void**)&d_offsets, (size_t)ix->nTxp * 4));
   CK(hipMemcpyAsync(d_offsets, ix->offsets, (size_t)ix->nTxp * 4, hipMemcpyHostToDevice, c->stream));
   CK(qmk_build_sainfo(c->d_SA, ix->nSA, d_offsets, ix->nTxp, c->d_sainfo, c->stream));
-  c->cap = 16;
-  while (c->cap < (uint64_t)ix->nKeys * 2) c->cap <<= 1;
-  CK(hipMalloc(&c->d_slots, c->cap * sizeof(Slot)));
-  CK(hipMalloc(&d_recs, (size_t)(ix->nKeys > 0 ? ix->nKeys : 1) * 16));
-  if (ix->nKeys > 0) CK(hipMemcpyAsync(d_recs, ix->hashRecs, (size_t)ix->nKeys * 16, hipMemcpyHostToDevice, c->stream));
-  CK(qmk_build_slots(d_recs, ix->nKeys, c->d_slots, c->cap, c->stream));
+  if (!ix->perfect) {
+    c->cap = 16;
+    while (c->cap < (uint64_t)ix->nKeys * 2) c->cap <<= 1;
+    CK(hipMalloc(&c->d_slots, c->cap * sizeof(Slot)));
+    CK(hipMalloc(&d_recs, (size_t)(ix->nKeys > 0 ? ix->nKeys : 1) * 16));
+    if (ix->nKeys > 0) CK(hipMemcpyAsync(d_recs, ix->hashRecs, (size_t)ix->nKeys * 16, hipMemcpyHostToDevice, c->stream));
+    CK(qmk_build_slots(d_recs, ix->nKeys, c->d_slots, c->cap, c->stream));
+  } else {
+    // flatten BooPHF + FrugalBooMap: all levels' words / rank samples concatenated, small maps re-hashed
+    c->cap = 1;
+    PhIndex P; memset(&P, 0, sizeof(P));
+    const int nl = (int)ix->phLevels.size();
+    uint64_t totW = 0, totR = 0;
+    std::vector<u64> tab(3 * (size_t)nl);
+    for (int i = 0; i < nl; ++i) { tab[3 * i] = ix->phLevels[i].domain; tab[3 * i + 1] = totW; tab[3 * i + 2] = totR; totW += ix->phLevels[i].nchar; totR += ix->phLevels[i].nranks; }
+    auto dalloc = [&](size_t bytes) -> void* { void* q = nullptr; if (hipMalloc(&q, bytes ? bytes : 16) != hipSuccess) return nullptr; c->phAllocs.push_back(q); c->devBytes += (int64_t)bytes; return q; };
+    u64* dW = (u64*)dalloc(totW * 8); u64* dR = (u64*)dalloc(totR * 8); u64* dT = (u64*)dalloc(tab.size() * 8);
+    int* dD = (int*)dalloc((size_t)ix->phNelem * 4); unsigned char* dL = (unsigned char*)dalloc((size_t)ix->phNelem);
+    if (!dW || !dR || !dT || !dD || !dL) { int rc = fail(QM_E_NOMEM, "hipMalloc (perfect hash) failed"); qm_ctx_destroy(c); return rc; }
+    for (int i = 0; i < nl; ++i) {
+      CK(hipMemcpyAsync(dW + tab[3 * i + 1], ix->phLevels[i].words, ix->phLevels[i].nchar * 8, hipMemcpyHostToDevice, c->stream));
+      if (ix->phLevels[i].nranks) CK(hipMemcpyAsync(dR + tab[3 * i + 2], ix->phLevels[i].ranks, ix->phLevels[i].nranks * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    CK(hipMemcpyAsync(dT, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, c->stream));
+    CK(hipMemcpyAsync(dD, ix->phData, (size_t)ix->phNelem * 4, hipMemcpyHostToDevice, c->stream));
+    CK(hipMemcpyAsync(dL, ix->phLens, (size_t)ix->phNelem, hipMemcpyHostToDevice, c->stream));
+    auto mix = [](u64 x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; };
+    std::vector<OvfSlot> ov; std::vector<Slot> fin;
+    {
+      u64 cap = 16; while (cap < ix->phOverflow.size() * 2) cap <<= 1;
+      ov.assign(cap, OvfSlot{-1, 0});
+      for (auto& kv : ix->phOverflow) { u64 j = mix((u64)(uint32_t)kv.first) & (cap - 1); while (ov[j].key != -1) j = (j + 1) & (cap - 1); ov[j].key = kv.first; ov[j].val = kv.second; }
+      P.ovfMask = cap - 1;
+      u64 fc = 16; while (fc < ix->phFinal.size() * 2) fc <<= 1;
+      Slot e; e.key = ~0ULL; e.lb = 0; e.ub = 0;
+      fin.assign(fc, e);
+      for (auto& kv : ix->phFinal) { u64 j = mix(kv.first) & (fc - 1); while (fin[j].key != ~0ULL) j = (j + 1) & (fc - 1); fin[j].key = kv.first; fin[j].lb = (int)kv.second; }
+      P.finMask = fc - 1;
+    }
+    OvfSlot* dO = (OvfSlot*)dalloc(ov.size() * sizeof(OvfSlot)); Slot* dF = (Slot*)dalloc(fin.size() * sizeof(Slot));
+    void* dP = dalloc(sizeof(PhIndex));
+    if (!dO || !dF || !dP) { int rc = fail(QM_E_NOMEM, "hipMalloc (perfect hash) failed"); qm_ctx_destroy(c); return rc; }
+    CK(hipMemcpyAsync(dO, ov.data(), ov.size() * sizeof(OvfSlot), hipMemcpyHostToDevice, c->stream));
+    CK(hipMemcpyAsync(dF, fin.data(), fin.size() * sizeof(Slot), hipMemcpyHostToDevice, c->stream));
+    P.words = dW; P.ranks = dR; P.levelTab = dT; P.data = dD; P.lens = dL; P.ovf = dO; P.fin = dF;
+    P.lastbitsetrank = ix->phLastRank; P.nelem = ix->phNelem; P.nb_levels = nl;
+    CK(hipMemcpyAsync(dP, &P, sizeof(P), hipMemcpyHostToDevice, c->stream));
+    CK(hipStreamSynchronize(c->stream));    // P, tab, ov, fin are locals
+    c->d_ph = dP;
+  }
   CK(hipMalloc((void**)&c->d_scal, 16 * sizeof(u64)));
   CK(hipStreamSynchronize(c->stream));
-  hipFree(d_offsets); hipFree(d_recs);
-  c->devBytes = ix->n + pad + ix->nSA * 4 + ix->nSA * (int64_t)sizeof(SaInfo) + (int64_t)(c->cap * sizeof(Slot));
+  hipFree(d_offsets); if (d_recs) hipFree(d_recs);
+  c->devBytes += ix->n + pad + ix->nSA * 4 + ix->nSA * (int64_t)sizeof(SaInfo) + (int64_t)(ix->perfect ? 0 : c->cap * sizeof(Slot));
 #undef CK
   *out = c;
   return QM_OK;
@@ -344,7 +454,7 @@ int qm_map_device(qm_ctx* c, const qm_opts* o, int64_t n, const void* d_seq1, co
   if (c->capLists < wantLists) { if ((rc = ensure(c->d_lists, c->capLists, wantLists))) return rc; }
 
   DevIndex ix; ix.text = c->d_text; ix.n = c->ix->n; ix.SA = c->d_SA; ix.nSA = c->ix->nSA;
-  ix.sainfo = (const SaInfo*)c->d_sainfo; ix.slots = (const Slot*)c->d_slots; ix.hmask = c->cap - 1; ix.k = c->ix->k;
+  ix.sainfo = (const SaInfo*)c->d_sainfo; ix.slots = (const Slot*)c->d_slots; ix.hmask = c->cap - 1; ix.ph = (const PhIndex*)c->d_ph; ix.k = c->ix->k;
   u64 hscal[16];
   HIPCHK(hipEventRecord(c->evA, c->stream));
   // ---- stage A: one wavefront per read

@@ -1,4 +1,4 @@
-// qm_indexer.cpp -- `rapmap quasiindex` for the dense-hash / int32 index variant, host only.
+// qm_indexer.cpp -- `rapmap quasiindex [-p]` for the int32 index variants (dense hash and perfect hash), host only.
 //
 // Produces the on-disk "q5" quasi-index that qm_index_open() mmaps:
 //   header.json  (include/IndexHeader.hpp:45-57)       sa.bin      (src/RapMapSAIndexer.cpp:109-110,242-243)
@@ -15,6 +15,7 @@
 // written as empty strings.
 #include <algorithm>
 #include <cctype>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -145,6 +146,158 @@ bool writeAll(const std::string& path, const void* a, size_t na, const void* b =
   return ok;
 }
 
+// ---------------------------------------------------------------- BBHash / BooPHF (`quasiindex -p`)
+// Restates the construction of boomphf::mphf (include/BooPHF.hpp:891-963,1285-1316,1353-1366,1036-1165) with
+// gamma = 2, 25 levels, SingleHashFunctor hash64 (:394-407), xorshift128* continuation (:493-499), fastrange64
+// (:815-820): level i keeps the keys that hash alone to a bit of its array, the rest cascade; bitVector ranks
+// every 512 bits (:741-754).  The assignment is order-independent, so the file equals the reference's.
+inline uint64_t boo_hash64(uint64_t key, uint64_t seed) {
+  uint64_t hash = seed;
+  hash ^= (hash << 7) ^ key * (hash >> 3) ^ (~((hash << 11) + (key ^ (hash >> 5))));
+  hash = (~hash) + (hash << 21);
+  hash = hash ^ (hash >> 24);
+  hash = (hash + (hash << 3)) + (hash << 8);
+  hash = hash ^ (hash >> 14);
+  hash = (hash + (hash << 2)) + (hash << 4);
+  hash = hash ^ (hash >> 28);
+  hash = hash + (hash << 31);
+  return hash;
+}
+inline uint64_t fastrange64(uint64_t word, uint64_t p) { return (uint64_t)(((__uint128_t)word * (__uint128_t)p) >> 64); }
+// hash of `key` for level `lvl` (0-based), replaying the generator
+inline uint64_t boo_level_hash(uint64_t key, int lvl) {
+  uint64_t s0 = boo_hash64(key, 0xAAAAAAAA55555555ULL);
+  if (lvl == 0) return s0;
+  uint64_t s1 = boo_hash64(key, 0x33333333CCCCCCCCULL);
+  if (lvl == 1) return s1;
+  uint64_t a = s0, b = s1, h = 0;      // s[0] = a, s[1] = b
+  for (int i = 2; i <= lvl; ++i) {
+    uint64_t x = a; const uint64_t y = b;
+    a = y;
+    x ^= x << 23;
+    b = x ^ y ^ (x >> 17) ^ (y >> 26);
+    h = b + y;
+  }
+  return h;
+}
+
+struct BooLevel { uint64_t domain; std::vector<uint64_t> words; std::vector<uint64_t> ranks; };
+
+int writePerfectHash(const std::string& outDir, const std::vector<KmerRun>& runs, int n_threads) {
+  const uint64_t n = runs.size();
+  const double gamma = 2.0;
+  const int nb_levels = 25;
+  const double proba = 1.0 - pow(((gamma * (double)n - 1) / (gamma * (double)n)), (double)n - 1);   // BooPHF.hpp:1285
+  const uint64_t hash_domain = (size_t)(ceil(double(n) * gamma));
+  std::vector<BooLevel> lv(nb_levels);
+  for (int i = 0; i < nb_levels; ++i) {
+    uint64_t d = (((uint64_t)(hash_domain * pow(proba, i)) + 63) / 64) * 64;
+    if (d == 0) d = 64;
+    lv[i].domain = d;
+    lv[i].words.assign(1 + d / 64, 0);            // bitVector(n): _nchar = 1 + n/64 (:568-572)
+  }
+  std::vector<uint64_t> remaining(n);
+  for (uint64_t i = 0; i < n; ++i) remaining[i] = runs[i].key;
+  std::vector<std::pair<uint64_t, uint64_t>> finalHash;
+  uint64_t offset = 0;
+  for (int i = 0; i < nb_levels; ++i) {
+    BooLevel& L = lv[i];
+    if (i == nb_levels - 1) {                     // cascade stops: exact map (:1101-1110)
+      for (uint64_t j = 0; j < remaining.size(); ++j) finalHash.emplace_back(remaining[j], j);
+    } else if (!remaining.empty()) {
+      std::vector<uint64_t> coll(L.words.size(), 0);
+      std::vector<uint64_t> pos(remaining.size());
+      for (size_t j = 0; j < remaining.size(); ++j) {
+        uint64_t p = fastrange64(boo_level_hash(remaining[j], i), L.domain);
+        pos[j] = p;
+        uint64_t bit = 1ULL << (p & 63);
+        if (L.words[p >> 6] & bit) coll[p >> 6] |= bit; else L.words[p >> 6] |= bit;
+      }
+      for (size_t w = 0; w < L.words.size(); ++w) L.words[w] &= ~coll[w];   // clearCollisions (:652-663)
+      std::vector<uint64_t> next;
+      for (size_t j = 0; j < remaining.size(); ++j)
+        if (!((L.words[pos[j] >> 6] >> (pos[j] & 63)) & 1)) next.push_back(remaining[j]);
+      remaining.swap(next);
+    }
+    // build_ranks(offset) (:741-754)
+    uint64_t cur = offset;
+    for (size_t w = 0; w < L.words.size(); ++w) {
+      if (((w * 64) % 512) == 0) L.ranks.push_back(cur);
+      cur += (uint64_t)__builtin_popcountll(L.words[w]);
+    }
+    offset = cur;
+  }
+  const uint64_t lastbitsetrank = offset;
+  auto lookup = [&](uint64_t key) -> uint64_t {   // mphf::lookup (:971-1009)
+    for (int i = 0; i < nb_levels - 1; ++i) {
+      uint64_t p = fastrange64(boo_level_hash(key, i), lv[i].domain);
+      if ((lv[i].words[p >> 6] >> (p & 63)) & 1) {
+        uint64_t block = p / 512, r = lv[i].ranks[block];
+        for (uint64_t w = block * 8; w < (p >> 6); ++w) r += (uint64_t)__builtin_popcountll(lv[i].words[w]);
+        r += (uint64_t)__builtin_popcountll(lv[i].words[p >> 6] & ((1ULL << (p & 63)) - 1));
+        return r;
+      }
+    }
+    for (auto& kv : finalHash) if (kv.first == key) return kv.second + lastbitsetrank;
+    return ~0ULL;
+  };
+  // values in MPHF order (FrugalBooMap::add + reorder_fn_, FrugalBooMap.hpp:101-112,283-305)
+  std::vector<int32_t> data(n); std::vector<uint8_t> lens(n);
+  std::vector<std::pair<int32_t, int32_t>> overflow;
+  {
+    auto work = [&](int t) {
+      for (uint64_t j = n * t / n_threads; j < n * (t + 1) / n_threads; ++j) {
+        uint64_t idx = lookup(runs[j].key);
+        int32_t l = runs[j].ub - runs[j].lb;
+        data[idx] = runs[j].lb;
+        lens[idx] = l >= 255 ? 255 : (uint8_t)l;
+      }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+    for (uint64_t j = 0; j < n; ++j) if (runs[j].ub - runs[j].lb >= 255) overflow.emplace_back(runs[j].lb, runs[j].ub - runs[j].lb);
+  }
+  {  // hash_info.bph (mphf::save, :1172-1197)
+    FILE* o = fopen((outDir + "hash_info.bph").c_str(), "wb");
+    if (!o) return -1;
+    int32_t nl = nb_levels;
+    fwrite(&gamma, 8, 1, o); fwrite(&nl, 4, 1, o); fwrite(&lastbitsetrank, 8, 1, o); fwrite(&n, 8, 1, o);
+    for (auto& L : lv) {
+      uint64_t size = L.domain, nchar = L.words.size(), nr = L.ranks.size();
+      fwrite(&size, 8, 1, o); fwrite(&nchar, 8, 1, o); fwrite(L.words.data(), 8, nchar, o);
+      fwrite(&nr, 8, 1, o); fwrite(L.ranks.data(), 8, nr, o);
+    }
+    uint64_t fn = finalHash.size(); fwrite(&fn, 8, 1, o);
+    for (auto& kv : finalHash) { fwrite(&kv.first, 8, 1, o); fwrite(&kv.second, 8, 1, o); }
+    if (fclose(o) != 0) return -1;
+  }
+  {  // hash_info.val (FrugalBooMap::save, FrugalBooMap.hpp:199-213); overflow_ in sparsepp's layout with
+     // spp_hash<int> == identity (include/sparsepp/spp_utils.h) and triangular probing
+    FILE* o = fopen((outDir + "hash_info.val").c_str(), "wb");
+    if (!o) return -1;
+    uint64_t c = n; fwrite(&c, 8, 1, o); fwrite(data.data(), 4, n, o);
+    fwrite(&c, 8, 1, o); fwrite(lens.data(), 1, n, o);
+    uint64_t tsize = 32;
+    while (overflow.size() * 2 > tsize) tsize <<= 1;
+    std::vector<int64_t> slot(tsize, -1);
+    for (size_t r = 0; r < overflow.size(); ++r) {
+      uint64_t pos = (uint64_t)(size_t)overflow[r].first & (tsize - 1), probes = 0;
+      while (slot[pos] >= 0) { ++probes; pos = (pos + probes) & (tsize - 1); }
+      slot[pos] = (int64_t)r;
+    }
+    auto be = [&](uint64_t x, int nb) { for (int i = nb - 1; i >= 0; --i) fputc((int)((x >> (8 * i)) & 0xff), o); };
+    be(0x24687531ULL, 4); be(tsize, 4); be((uint64_t)overflow.size(), 4);
+    std::vector<uint32_t> bm(tsize / 32, 0);
+    for (uint64_t p = 0; p < tsize; ++p) if (slot[p] >= 0) bm[p >> 5] |= (1u << (p & 31));
+    fwrite(bm.data(), 4, bm.size(), o);
+    for (uint64_t p = 0; p < tsize; ++p) if (slot[p] >= 0) { fwrite(&overflow[slot[p]].first, 4, 1, o); fwrite(&overflow[slot[p]].second, 4, 1, o); }
+    if (fclose(o) != 0) return -1;
+  }
+  return 0;
+}
+
 thread_local char g_ierr[256];
 
 }  // namespace
@@ -152,7 +305,7 @@ thread_local char g_ierr[256];
 extern "C" const char* qm_indexer_last_error(void) { return g_ierr; }
 
 extern "C" int qm_build_index(const char* fasta_path, const char* out_dir_c, int32_t k, int32_t no_clip_poly_a,
-                              int32_t keep_duplicates, int32_t n_threads) {
+                              int32_t keep_duplicates, int32_t n_threads, int32_t perfect_hash) {
   auto fail = [&](int code, const char* msg) { snprintf(g_ierr, sizeof(g_ierr), "%s", msg); return code; };
   if (!fasta_path || !out_dir_c) return fail(QM_E_ARG, "null path");
   if (k < 1 || k > 31 || (k % 2) == 0) return fail(QM_E_ARG, "k must be odd and <= 31 (RapMapSAIndexer.cpp:870-877)");
@@ -324,8 +477,13 @@ extern "C" int qm_build_index(const char* fasta_path, const char* out_dir_c, int
   size_t K = 0;
   for (auto& p : parts) K += p.size();
 
-  // ---- step 4: hash.bin in sparsepp's container layout
-  {
+  // ---- step 4: the k-mer map on disk
+  if (perfect_hash) {
+    std::vector<KmerRun> runs; runs.reserve(K);
+    for (auto& p : parts) { runs.insert(runs.end(), p.begin(), p.end()); std::vector<KmerRun>().swap(p); }
+    int rc = writePerfectHash(outDir, runs, n_threads);
+    if (rc) return fail(QM_E_IO, "cannot write hash_info.bph / hash_info.val");
+  } else {
     uint64_t tsize = 32;
     while (K * 2 > tsize) tsize <<= 1;          // occupancy <= 50 % like spp's resize policy
     const uint64_t mask = tsize - 1;
@@ -363,8 +521,8 @@ extern "C" int qm_build_index(const char* fasta_path, const char* out_dir_c, int
     char js[1024];
     snprintf(js, sizeof(js),
              "{\n    \"value0\": {\n    \"IndexType\": 1,\n    \"IndexVersion\": \"q5\",\n    \"UsesKmers\": true,\n"
-             "    \"KmerLen\": %d,\n    \"BigSA\": false,\n    \"PerfectHash\": false,\n    \"SeqHash\": \"\",\n"
-             "    \"NameHash\": \"\",\n    \"SeqHash512\": \"\",\n    \"NameHash512\": \"\"\n    }\n}", k);
+             "    \"KmerLen\": %d,\n    \"BigSA\": false,\n    \"PerfectHash\": %s,\n    \"SeqHash\": \"\",\n"
+             "    \"NameHash\": \"\",\n    \"SeqHash512\": \"\",\n    \"NameHash512\": \"\"\n    }\n}", k, perfect_hash ? "true" : "false");
     if (!writeAll(outDir + "header.json", js, strlen(js))) return fail(QM_E_IO, "cannot write header.json");
     std::string ri = std::string("{\n    \"ReferenceFiles\": [\n        \"") + fasta_path + "\"\n    ]\n}";
     writeAll(outDir + "refInfo.json", ri.data(), ri.size());

@@ -45,14 +45,31 @@ struct SaInfo { u32 tid; int pos; };               // transcript id + offset in 
 struct Iv { int lb, ub; };                         // seed interval
 struct IntRec { int b, e; u32 len, q; };           // SAIntervalHit (RapMapUtils.hpp:516-525)
 
+// Perfect-hash (`quasiindex -p`) seed map, flattened: BooPHF levels + FrugalBooMap values
+// (include/BooPHF.hpp, include/FrugalBooMap.hpp).  All levels' bit arrays / rank samples are concatenated;
+// levelTab[3*i + {0,1,2}] = {hash domain, first word, first rank sample} of level i.
+struct OvfSlot { int key; int val; };              // overflow_: interval start -> length (>= 255); key -1 empty
+struct PhIndex {
+  const u64* words;
+  const u64* ranks;
+  const u64* levelTab;
+  const int* data;              // data_[idx]: SA index where the interval starts
+  const unsigned char* lens;    // lens_[idx]: interval length, 255 => overflow
+  const OvfSlot* ovf; u64 ovfMask;
+  const Slot* fin; u64 finMask; // _final_hash: key -> value (in lb), key ~0 empty
+  u64 lastbitsetrank, nelem;
+  int nb_levels;
+};
+
 struct DevIndex {
   const unsigned char* text;  // n bytes + >= 64 bytes of zero padding
   long long n;
   const int* SA;
   long long nSA;
   const SaInfo* sainfo;
-  const Slot* slots;
+  const Slot* slots;          // dense index (null for a perfect-hash index)
   u64 hmask;
+  const PhIndex* ph;          // perfect-hash index (null for a dense index), in device memory
   int k;
 };
 
@@ -201,6 +218,96 @@ QM_DEV unsigned char rc_char(unsigned char c) {
   return l == 'a' ? 'T' : l == 'c' ? 'G' : l == 'g' ? 'C' : (l == 't' || l == 'u') ? 'A' : 'N';
 }
 
+// khash.find for either index flavour.
+// dense: exact lookup in the open-addressing table (RapMapUtils.hpp:65-67).
+// perfect hash: FrugalBooMap::find (FrugalBooMap.hpp:149-167) over mphf::lookup (BooPHF.hpp:971-1009,
+// getLevel :1318-1351, hash64 :394-407, xorshift next :493-499, fastrange64 :815-820, bitVector::rank :756-769):
+// the key is not stored -- the candidate interval's first suffix is re-encoded from the text and compared.
+QM_DEV u64 boo_hash64(u64 key, u64 seed) {
+  u64 hash = seed;
+  hash ^= (hash << 7) ^ key * (hash >> 3) ^ (~((hash << 11) + (key ^ (hash >> 5))));
+  hash = (~hash) + (hash << 21);
+  hash = hash ^ (hash >> 24);
+  hash = (hash + (hash << 3)) + (hash << 8);
+  hash = hash ^ (hash >> 14);
+  hash = (hash + (hash << 2)) + (hash << 4);
+  hash = hash ^ (hash >> 28);
+  hash = hash + (hash << 31);
+  return hash;
+}
+QM_DEV u64 fastrange64(u64 word, u64 p) { return mulhi64(word, p); }
+
+// 2-bit word of text[pos, pos+k); false if a non-ACGT character (the '$' separator) is inside
+QM_DEV bool text_kmer(const DevIndex& ix, long long pos, int k, u64& w) {
+  w = 0;
+  bool ok = pos + k <= ix.n;
+  for (int base = 0; base < k; base += 8) {
+    u64 x = load_u64_unaligned(ix.text + pos + base);       // text is padded
+    int nb = k - base < 8 ? k - base : 8;
+    for (int t = 0; t < nb; ++t) {
+      unsigned c = (unsigned)(x >> (8 * t)) & 0xff;
+      bool v = c == 'A' || c == 'C' || c == 'G' || c == 'T';
+      unsigned y = (c >> 1) & 3;
+      ok = ok && v;
+      w = (w << 2) | (u64)(y ^ (y >> 1));
+    }
+  }
+  return ok;
+}
+
+QM_DEV bool find_kmer(const DevIndex& ix, u64 key, int& lb, int& ub) {
+  if (!ix.ph) {
+    u64 i = hash_mix(key) & ix.hmask;
+    while (true) {
+      Slot x = ix.slots[i];
+      if (x.key == key) { lb = x.lb; ub = x.ub; return true; }
+      if (x.key == ~0ULL) return false;
+      i = (i + 1) & ix.hmask;
+    }
+  }
+  const PhIndex& P = *ix.ph;
+  u64 s0 = 0, s1 = 0, h = 0;
+  int level = 0;
+  u64 pos = 0, w0 = 0, r0 = 0;
+  for (int ii = 0; ii < P.nb_levels - 1; ++ii) {
+    if (ii == 0) { s0 = boo_hash64(key, 0xAAAAAAAA55555555ULL); h = s0; }
+    else if (ii == 1) { s1 = boo_hash64(key, 0x33333333CCCCCCCCULL); h = s1; }
+    else { u64 a = s0; const u64 b = s1; s0 = b; a ^= a << 23; s1 = a ^ b ^ (a >> 17) ^ (b >> 26); h = s1 + b; }
+    const u64 dom = P.levelTab[3 * ii]; w0 = P.levelTab[3 * ii + 1]; r0 = P.levelTab[3 * ii + 2];
+    pos = fastrange64(h, dom);
+    if ((P.words[w0 + (pos >> 6)] >> (pos & 63)) & 1) break;
+    ++level;
+  }
+  u64 idx;
+  if (level == P.nb_levels - 1) {
+    if (!P.fin) return false;
+    u64 i = hash_mix(key) & P.finMask;
+    while (true) {
+      Slot x = P.fin[i];
+      if (x.key == key) { idx = (u64)(u32)x.lb + P.lastbitsetrank; break; }
+      if (x.key == ~0ULL) return false;
+      i = (i + 1) & P.finMask;
+    }
+  } else {
+    const u64 block = pos / 512;
+    idx = P.ranks[r0 + block];
+    for (u64 w = block * 8; w < (pos >> 6); ++w) idx += (u64)popc64(P.words[w0 + w]);
+    idx += (u64)popc64(P.words[w0 + (pos >> 6)] & ((1ULL << (pos & 63)) - 1));
+  }
+  if (idx >= P.nelem) return false;                         // FrugalBooMap.hpp:151
+  const int ind = P.data[idx];
+  u64 m;
+  text_kmer(ix, (long long)ix.SA[ind], ix.k, m);           // Kmer(txt + SA[ind]): partial word if a '$' is hit
+  if (m != key) return false;
+  int l = P.lens[idx];
+  if (l == 255) {
+    u64 i = hash_mix((u64)(u32)ind) & P.ovfMask;
+    while (true) { OvfSlot x = P.ovf[i]; if (x.key == ind) { l = x.val; break; } if (x.key == -1) { l = 0; break; } i = (i + 1) & P.ovfMask; }
+  }
+  lb = ind; ub = ind + l;
+  return true;
+}
+
 // ------------------------------------------------------------------ stage 1+2
 // Bits helpers for lazily filled bitmaps
 template <int NS> QM_DEV void or_field(Bits<NS>& b, int p, u64 v) {   // b |= v << p  (v has <= 32 significant bits)
@@ -312,13 +419,7 @@ QM_DEV void probe_window(const DevIndex& ix, Strand<NS>& S, int p, int width) {
       u64 key = kmer_at<NS>(S.planes, pos, k, nwin, nwin2, d);
       if (!nwin) {
         if (isC) key = word_rc(key, k);
-        u64 i = hash_mix(key) & ix.hmask;
-        while (true) {
-          Slot x = ix.slots[i];
-          if (x.key == key) { hit = true; v.lb = x.lb; v.ub = x.ub; break; }
-          if (x.key == ~0ULL) break;
-          i = (i + 1) & ix.hmask;
-        }
+        hit = find_kmer(ix, key, v.lb, v.ub);
       }
       if (!isC) S.tab[pos] = v;
     }

@@ -81,6 +81,12 @@ QM_DEV bool uniform(bool x) { return __builtin_amdgcn_readfirstlane((int)x) != 0
 #endif
 
 #ifdef QM_EMU
+QM_DEV u64 mulhi64(u64 a, u64 b) { return (u64)(((unsigned __int128)a * (unsigned __int128)b) >> 64); }
+#else
+QM_DEV u64 mulhi64(u64 a, u64 b) { return __umul64hi(a, b); }
+#endif
+
+#ifdef QM_EMU
 QM_DEV int wave_max(const LV<int>& x) { int m = x.v[0]; for (int l = 1; l < 64; ++l) m = x.v[l] > m ? x.v[l] : m; return m; }
 QM_DEV int clz64(u64 x) { return x ? __builtin_clzll(x) : 64; }
 QM_DEV u64 load_u64_unaligned(const unsigned char* p) { u64 v; __builtin_memcpy(&v, p, 8); return v; }

@@ -73,6 +73,18 @@ def synth_small(tmp_path_factory, lib_built):
 
 
 @pytest.fixture(scope="session")
+def synth_small_ph(synth_small, tmp_path_factory):
+    """config 4 (small): the same transcriptome indexed with `quasiindex -p` (BooPHF / FrugalBooMap)"""
+    import rapmap_amd as ra
+    d = tmp_path_factory.mktemp("synth_small_ph")
+    idx = str(d / "idx_ph")
+    ra.build_index(synth_small["fasta"], idx, threads=4, perfect_hash=True)
+    out = dict(synth_small)
+    out["idx"] = idx
+    return out
+
+
+@pytest.fixture(scope="session")
 def synth_medium(tmp_path_factory, lib_built):
     """~1/40 of config 2: 1000 genes (~5k transcripts, ~8 M chars), 60k pairs 2x100 bp, 1 % errors."""
     import rapmap_amd as ra

@@ -63,6 +63,28 @@ class Emu:
         hk = np.ascontiguousarray(ix.hkeys, dtype=np.uint64)
         hl = np.ascontiguousarray(ix.hlb, dtype=np.int32)
         hu = np.ascontiguousarray(ix.hub, dtype=np.int32)
+        self.ph = None
+        if getattr(ix, "perfect", False):
+            # perfect-hash index: the emulated device code walks the BooPHF levels itself
+            from oracle import q5ph
+            boo = q5ph.BooPHF(os.path.join(ix.dir, "hash_info.bph"))
+            data, lens, ovf = q5ph.read_val(os.path.join(ix.dir, "hash_info.val"))
+            tab, words, ranks = [], [], []
+            wo = ro = 0
+            for (size, w, r), dom in zip(boo.levels, boo.domains):
+                tab += [dom, wo, ro]; words.append(w); ranks.append(r); wo += w.size; ro += r.size
+            self._ph_keep = [np.ascontiguousarray(np.concatenate(words), dtype=np.uint64),
+                             np.ascontiguousarray(np.concatenate(ranks) if ro else np.zeros(1), dtype=np.uint64),
+                             np.array(tab, dtype=np.uint64), np.ascontiguousarray(data, dtype=np.int32),
+                             np.ascontiguousarray(lens, dtype=np.uint8),
+                             np.array([x for kv in ovf.items() for x in kv] or [0, 0], dtype=np.int32),
+                             np.array([x for kv in boo.final.items() for x in kv] or [0, 0], dtype=np.uint64)]
+            k = self._ph_keep
+            self.lib.qe_ph_create.restype = C.c_void_p
+            self.ph = self.lib.qe_ph_create(C.c_void_p(k[0].ctypes.data), C.c_void_p(k[1].ctypes.data), C.c_void_p(k[2].ctypes.data),
+                                            C.c_int(boo.nb_levels), C.c_void_p(k[3].ctypes.data), C.c_void_p(k[4].ctypes.data),
+                                            C.c_uint64(boo.nelem), C.c_uint64(boo.lastbitsetrank), C.c_void_p(k[5].ctypes.data),
+                                            C.c_int64(len(ovf)), C.c_void_p(k[6].ctypes.data), C.c_int64(len(boo.final)))
         self.lib.qe_flatten(C.c_void_p(self.SA.ctypes.data), C.c_int64(self.SA.size), C.c_void_p(off.ctypes.data),
                             C.c_int64(off.size), C.c_void_p(self.sainfo.ctypes.data), C.c_void_p(hk.ctypes.data),
                             C.c_void_p(hl.ctypes.data), C.c_void_p(hu.ctypes.data), C.c_int64(hk.size),
@@ -84,7 +106,7 @@ class Emu:
                              C.c_uint64(self.cap - 1), C.byref(opts), C.c_int64(nunits),
                              C.c_void_p(seq1.ctypes.data), C.c_void_p(off1.ctypes.data),
                              C.c_void_p(seq2.ctypes.data if paired else None),
-                             C.c_void_p(off2.ctypes.data if paired else None), C.c_int(ns),
+                             C.c_void_p(off2.ctypes.data if paired else None), C.c_int(ns), C.c_void_p(self.ph),
                              C.c_void_p(ho.ctypes.data), C.byref(hp), C.c_void_p(ctr.ctypes.data),
                              C.c_void_p(io.ctypes.data), C.byref(ip), C.byref(st))
         assert rc == 0

@@ -17,10 +17,10 @@ extern "C" {
 int qe_map(int k, const unsigned char* text, long long n, const int* SA, long long nSA, const void* sainfo,
            const void* slots, unsigned long long hmask, const qm_opts* o, long long nunits,
            const unsigned char* seq1, const long long* off1, const unsigned char* seq2, const long long* off2,
-           int ns, long long* hit_offsets, qm_hit** hits_out, unsigned long long* counters, long long* int_offsets,
+           int ns, const void* ph, long long* hit_offsets, qm_hit** hits_out, unsigned long long* counters, long long* int_offsets,
            qm_sa_interval_hit** ints_out, int* status_out) {
   DevIndex ix; ix.text = text; ix.n = n; ix.SA = SA; ix.nSA = nSA; ix.sainfo = (const SaInfo*)sainfo;
-  ix.slots = (const Slot*)slots; ix.hmask = hmask; ix.k = k;
+  ix.slots = (const Slot*)slots; ix.hmask = hmask; ix.k = k; ix.ph = (const PhIndex*)ph;
   const bool paired = seq2 != nullptr;
   const long long nreads = paired ? 2 * nunits : nunits;
   ReadBatch B; memset(&B, 0, sizeof(B));
@@ -84,6 +84,28 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
 }
 
 void qe_free(void* p) { free(p); }
+
+// perfect-hash flavour: assemble a PhIndex over caller-owned arrays (same flattening as qm_ctx_create)
+void* qe_ph_create(const unsigned long long* words, const unsigned long long* ranks, const unsigned long long* levelTab,
+                   int nb_levels, const int* data, const unsigned char* lens, unsigned long long nelem,
+                   unsigned long long lastbitsetrank, const int* ovf_kv, long long n_ovf,
+                   const unsigned long long* fin_kv, long long n_fin) {
+  PhIndex* P = new PhIndex();
+  memset(P, 0, sizeof(*P));
+  P->words = words; P->ranks = ranks; P->levelTab = levelTab; P->data = data; P->lens = lens;
+  P->nelem = nelem; P->lastbitsetrank = lastbitsetrank; P->nb_levels = nb_levels;
+  u64 cap = 16; while (cap < (u64)n_ovf * 2) cap <<= 1;
+  OvfSlot* ov = new OvfSlot[cap];
+  for (u64 i = 0; i < cap; ++i) { ov[i].key = -1; ov[i].val = 0; }
+  for (long long i = 0; i < n_ovf; ++i) { u64 j = hash_mix((u64)(u32)ovf_kv[2 * i]) & (cap - 1); while (ov[j].key != -1) j = (j + 1) & (cap - 1); ov[j].key = ovf_kv[2 * i]; ov[j].val = ovf_kv[2 * i + 1]; }
+  P->ovf = ov; P->ovfMask = cap - 1;
+  u64 fc = 16; while (fc < (u64)n_fin * 2) fc <<= 1;
+  Slot* fin = new Slot[fc];
+  for (u64 i = 0; i < fc; ++i) { fin[i].key = ~0ULL; fin[i].lb = 0; fin[i].ub = 0; }
+  for (long long i = 0; i < n_fin; ++i) { u64 j = hash_mix(fin_kv[2 * i]) & (fc - 1); while (fin[j].key != ~0ULL) j = (j + 1) & (fc - 1); fin[j].key = fin_kv[2 * i]; fin[j].lb = (int)fin_kv[2 * i + 1]; }
+  P->fin = fin; P->finMask = fc - 1;
+  return P;
+}
 
 // host-side flattening for the emulation only (the product does this on the GPU,
 // rapmap_amd/csrc/qm_kernels.hip: build_sainfo_kernel / build_slots_kernel)

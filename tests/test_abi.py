@@ -39,8 +39,8 @@ def test_index_open_errors(lib_built, tmp_path):
         ra.QuasiIndex(str(tmp_path / "nope"))
     d = tmp_path / "bad"
     d.mkdir()
-    (d / "header.json").write_text('{"value0": {"IndexVersion": "q5", "KmerLen": 31, "BigSA": false, "PerfectHash": true}}')
-    with pytest.raises(ra.QmError, match="perfect-hash"):
+    (d / "header.json").write_text('{"value0": {"IndexVersion": "q5", "KmerLen": 31, "BigSA": true, "PerfectHash": false}}')
+    with pytest.raises(ra.QmError, match="BigSA"):
         ra.QuasiIndex(str(d))
 
 

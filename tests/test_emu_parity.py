@@ -112,3 +112,20 @@ def test_repeat_families(repeat_data, oracle_mod):
     assert_hits_equal(res.hit_offsets, res.hits, er.hit_offsets, er.hits, "repeats")
     assert res.counters == er.counters
     _cmp_ints(res, er)
+
+
+def test_perfect_hash_index(synth_small, synth_small_ph, oracle_mod):
+    """config 4: BooPHF cascade + FrugalBooMap text verification in the device source; hits must equal the
+    dense-index oracle (the reference guarantees the same: SURVEY.md section 4)"""
+    ix, orc, em, emu = _emu(synth_small_ph["idx"])
+    assert ix.perfect and em.ph
+    q1, o1 = pack(synth_small_ph["reads1"]); q2, o2 = pack(synth_small_ph["reads2"])
+    res = orc.map_pairs(q1, o1, q2, o2, nthreads=4, want_ints=True)
+    er = em.map(q1, o1, q2, o2)
+    assert er.status == 0
+    assert_hits_equal(res.hit_offsets, res.hits, er.hit_offsets, er.hits, "perfect-hash")
+    assert res.counters == er.counters
+    _cmp_ints(res, er)
+    dix, dorc = load_oracle(synth_small["idx"])
+    dres = dorc.map_pairs(q1, o1, q2, o2, nthreads=4)
+    assert_hits_equal(dres.hit_offsets, dres.hits, er.hit_offsets, er.hits, "perfect-hash vs dense")

@@ -194,3 +194,16 @@ def test_repeat_families(repeat_data, oracle_mod):
     assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "repeats")
     assert res.counters == gr.counters
     _cmp_ints(res, *mp.intervals(len(o1) - 1))
+
+
+def test_perfect_hash_index(synth_small, synth_small_ph, oracle_mod):
+    """config 4: `quasiindex -p` index through the HIP path == dense-index oracle"""
+    ix, orc = load_oracle(synth_small["idx"])
+    qi, mp = _gpu(synth_small_ph["idx"])
+    assert qi.perfect_hash
+    q1, o1 = pack(synth_small_ph["reads1"]); q2, o2 = pack(synth_small_ph["reads2"])
+    res = orc.map_pairs(q1, o1, q2, o2, nthreads=4, want_ints=True)
+    gr = mp.map_pairs(q1, o1, q2, o2)
+    assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "perfect-hash")
+    assert res.counters == gr.counters
+    _cmp_ints(res, *mp.intervals(len(o1) - 1))

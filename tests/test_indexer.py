@@ -96,3 +96,26 @@ def test_text_rules(tmp_path, lib_built):
     assert ix.text.tobytes() == (body + "$") .encode() * 3
     assert list(ix.completeLens) == [len(body), len(body), len(body) + 12]
     assert list(ix.txpLens) == [len(body)] * 3
+
+
+def test_perfect_hash_files(synth_small, synth_small_ph):
+    """`quasiindex -p`: every k-mer of the dense map gets a distinct MPHF slot whose (data_, lens_, overflow_)
+    reproduce its interval; walked with the numpy model of BooPHF::lookup (oracle/q5ph.py)."""
+    from oracle import q5, q5ph
+    dense = q5.load(synth_small["idx"])
+    d = synth_small_ph["idx"]
+    boo = q5ph.BooPHF(os.path.join(d, "hash_info.bph"))
+    data, lens, ovf = q5ph.read_val(os.path.join(d, "hash_info.val"))
+    assert boo.nelem == dense.hkeys.size == data.size == lens.size and boo.gamma == 2.0 and boo.nb_levels == 25
+    assert len(ovf) > 0          # the repeat families have intervals >= 255
+    seen = set()
+    rng = np.random.default_rng(0)
+    for j in rng.choice(dense.hkeys.size, 3000, replace=False):
+        key, lb, ub = int(dense.hkeys[j]), int(dense.hlb[j]), int(dense.hub[j])
+        i = boo.lookup(key)
+        assert i is not None and i < boo.nelem and i not in seen
+        seen.add(i)
+        ln = ovf[int(data[i])] if lens[i] == 255 else int(lens[i])
+        assert int(data[i]) == lb and lb + ln == ub
+    for fn in ("sa.bin", "txpInfo.bin", "rsd.bin"):      # the rest of the index does not depend on -p
+        assert open(os.path.join(d, fn), "rb").read() == open(os.path.join(synth_small["idx"], fn), "rb").read()
