@@ -18,7 +18,8 @@
 namespace qm {
 
 // stage A: one wavefront per read.  WPS = minimum waves per SIMD the register allocator must leave room for.
-template <int NS, int WPS>
+// F: compile-time feature flags (QM_F_PH, QM_F_NIP) -- the default kernel carries no optional code.
+template <int NS, int WPS, int F>
 __global__ __launch_bounds__(256, WPS) void qm_read_kernel(DevIndex ix, ReadBatch B) {
   __shared__ WaveMem<NS> mem[4];
   // the wave index is wave-uniform: keep it (and every address derived from it) on the scalar unit
@@ -27,7 +28,7 @@ __global__ __launch_bounds__(256, WPS) void qm_read_kernel(DevIndex ix, ReadBatc
   const long long nw = (long long)gridDim.x * 4;
   u64* gscr = B.gscratch + gw * QM_GSCR_U64;
   WaveAlloc wa; wa.base = -1; wa.used = 0;
-  for (long long r = gw; r < B.nreads; r += nw) map_read<NS>(ix, B, r, mem[wave], gscr, wa);
+  for (long long r = gw; r < B.nreads; r += nw) map_read<NS, F>(ix, B, r, mem[wave], gscr, wa);
 }
 
 // stage B pass 1: hits per unit + the HitCounters
@@ -113,17 +114,24 @@ int qmk_map_grid(long long nreads, int num_cu) {
 hipError_t qmk_map_reads(const void* ixp, const void* bp, int ns, int grid, hipStream_t st) {
   const DevIndex& ix = *(const DevIndex*)ixp;
   const ReadBatch& B = *(const ReadBatch*)bp;
-  static int wps = -1;
-  if (wps < 0) { const char* e = getenv("QM_WPS"); wps = e ? atoi(e) : QMK_DEFAULT_WPS; }
+  const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP);
+#define QM_LAUNCH(NS_, WPS_, F_) hipLaunchKernelGGL((qm_read_kernel<NS_, WPS_, F_>), dim3(grid), dim3(256), 0, st, ix, B)
   if (ns == 2) {
-    if (wps <= 3) hipLaunchKernelGGL((qm_read_kernel<2, 3>), dim3(grid), dim3(256), 0, st, ix, B);
-    else if (wps == 4) hipLaunchKernelGGL((qm_read_kernel<2, 4>), dim3(grid), dim3(256), 0, st, ix, B);
-    else if (wps == 5) hipLaunchKernelGGL((qm_read_kernel<2, 5>), dim3(grid), dim3(256), 0, st, ix, B);
-    else if (wps == 6) hipLaunchKernelGGL((qm_read_kernel<2, 6>), dim3(grid), dim3(256), 0, st, ix, B);
-    else hipLaunchKernelGGL((qm_read_kernel<2, 8>), dim3(grid), dim3(256), 0, st, ix, B);
+    switch (F) {
+      case 0: QM_LAUNCH(2, QMK_DEFAULT_WPS, 0); break;
+      case QM_F_PH: QM_LAUNCH(2, 4, QM_F_PH); break;
+      case QM_F_NIP: QM_LAUNCH(2, 4, QM_F_NIP); break;
+      default: QM_LAUNCH(2, 4, QM_F_PH | QM_F_NIP); break;
+    }
   } else {
-    hipLaunchKernelGGL((qm_read_kernel<4, 3>), dim3(grid), dim3(256), 0, st, ix, B);
+    switch (F) {
+      case 0: QM_LAUNCH(4, 3, 0); break;
+      case QM_F_PH: QM_LAUNCH(4, 3, QM_F_PH); break;
+      case QM_F_NIP: QM_LAUNCH(4, 3, QM_F_NIP); break;
+      default: QM_LAUNCH(4, 3, QM_F_PH | QM_F_NIP); break;
+    }
   }
+#undef QM_LAUNCH
   return hipGetLastError();
 }
 

@@ -88,6 +88,7 @@ struct ReadBatch {
   qm_sa_interval_hit* dbg_ints;  // optional [nunits * QM_DBG_CAP]
   u32* dbg_count;                // optional [nreads]
   int strict_check, max_interval;
+  int sensitive;           // 0: --noSensitive (NIP skipping via SASearcher::lce, k-mer vote instead of coverage)
   double quasi_cov;
 };
 
@@ -218,6 +219,11 @@ QM_DEV unsigned char rc_char(unsigned char c) {
   return l == 'a' ? 'T' : l == 'c' ? 'G' : l == 'g' ? 'C' : (l == 't' || l == 'u') ? 'A' : 'N';
 }
 
+// Compile-time feature flags of a stage-A instantiation (the default dense + sensitive kernel carries none of
+// the optional code, which would otherwise cost it ~40 VGPRs and a whole wave per SIMD).
+#define QM_F_PH 1      // perfect-hash (-p) index
+#define QM_F_NIP 2     // --noSensitive: NIP skipping + k-mer vote
+
 // khash.find for either index flavour.
 // dense: exact lookup in the open-addressing table (RapMapUtils.hpp:65-67).
 // perfect hash: FrugalBooMap::find (FrugalBooMap.hpp:149-167) over mphf::lookup (BooPHF.hpp:971-1009,
@@ -255,8 +261,9 @@ QM_DEV bool text_kmer(const DevIndex& ix, long long pos, int k, u64& w) {
   return ok;
 }
 
+template <int F>
 QM_DEV bool find_kmer(const DevIndex& ix, u64 key, int& lb, int& ub) {
-  if (!ix.ph) {
+  if (!(F & QM_F_PH)) {
     u64 i = hash_mix(key) & ix.hmask;
     while (true) {
       Slot x = ix.slots[i];
@@ -331,6 +338,7 @@ struct Strand {
   Bits<NS> K;    // positions whose F / C bits are known
   Bits<NS> F;    // khash.find(mer) hit
   Bits<NS> C;    // khash.find(mer.getRC()) hit
+  Bits<NS> V;    // positions that produced a KmerDirScore entry (only used by the --noSensitive vote)
   const u64* planes;   // LDS: [4][NS+2]
   Iv* tab;             // LDS: interval of mer at position p (valid where F)
   int P;
@@ -397,13 +405,13 @@ QM_DEV void setup_strand(const DevIndex& ix, const unsigned char* str, int L, St
       av[l] = inP && d >= k;
     }
     S.E.w[s] = ballot(e); S.E2.w[s] = ballot(e2); S.AV.w[s] = ballot(av);
-    S.K.w[s] = 0; S.F.w[s] = 0; S.C.w[s] = 0;
+    S.K.w[s] = 0; S.F.w[s] = 0; S.C.w[s] = 0; S.V.w[s] = 0;
   }
 }
 
 // Probe positions [p, p+width) (width <= 32): lanes 0..31 look up the k-mer, lanes 32..63 its reverse
 // complement -- khash.find (RapMapUtils.hpp:65-67) -- one round of independent loads.
-template <int NS>
+template <int NS, int F>
 QM_DEV void probe_window(const DevIndex& ix, Strand<NS>& S, int p, int width) {
   const int k = ix.k;
   if (p + width > S.P) width = S.P - p;
@@ -419,7 +427,7 @@ QM_DEV void probe_window(const DevIndex& ix, Strand<NS>& S, int p, int width) {
       u64 key = kmer_at<NS>(S.planes, pos, k, nwin, nwin2, d);
       if (!nwin) {
         if (isC) key = word_rc(key, k);
-        hit = find_kmer(ix, key, v.lb, v.ub);
+        hit = find_kmer<F>(ix, key, v.lb, v.ub);
       }
       if (!isC) S.tab[pos] = v;
     }
@@ -595,9 +603,51 @@ QM_DEV void extend_search(const DevIndex& ix, int lbIn, int ubIn, int startAt, c
   lbOut = (int)bound1; ubOut = (int)bound2; lenOut = maxLen;
 }
 
+// SASearcher::lce (SASearcher.hpp:318-334), NIP only.  Restated literally, including its double use of
+// startAt (o1/o2 already contain it and `len` starts from it again).
+QM_DEV int lce_wave(const DevIndex& ix, int p1, int p2, int startAt, int stopAt) {
+  const long long o1 = (long long)uniform((int)ix.SA[p1]) + startAt, o2 = (long long)uniform((int)ix.SA[p2]) + startAt;
+  const long long maxIndex = o1 > o2 ? o1 : o2;
+  const long long textLen = (long long)(int)ix.n;
+  int base = startAt;
+  while (true) {
+    LV<bool> stopv;
+    QM_LANES(l) {
+      long long j = (long long)base + l;
+      bool inb = maxIndex + j < textLen;
+      bool st = true;
+      if (inb) {
+        unsigned char a = ix.text[o1 + j], b = ix.text[o2 + j];
+        st = (a != b) || a == '$' || j >= stopAt;
+      }
+      stopv[l] = st;
+    }
+    u64 mk = ballot(stopv);
+    if (mk) return base + ctz64(mk);
+    base += 64;
+  }
+}
+// set bits [a, e) of b
+template <int NS> QM_DEV void set_range_and(Bits<NS>& dst, const Bits<NS>& src, int a, int e) {
+  if (e <= a) return;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    int lo = a - 64 * s, hi = e - 64 * s;
+    if (hi <= 0 || lo >= 64) continue;
+    u64 m = ~0ULL;
+    if (lo > 0) m &= (~0ULL << lo);
+    if (hi < 64) m &= lanemask_lt(hi);
+    dst.w[s] |= src.w[s] & m;
+  }
+}
+template <int NS> QM_DEV void set_bit(Bits<NS>& b, int p) {
+#pragma unroll
+  for (int s = 0; s < NS; ++s) if (s == (p >> 6)) b.w[s] |= 1ULL << (p & 63);
+}
+
 // ------------------------------------------------------------------ stage 3
 // SACollector::getSAHits_ (SACollector.hpp:441-677), NIP disabled
-template <int NS>
+template <int NS, int F>
 QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, const unsigned char* str, int L,
                         int startPos, bool haveInterval, int lb, int ub, long long& cov, u32& strandHits,
                         u32& otherHits, IntervalList& out) {
@@ -609,7 +659,7 @@ QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, c
   while (true) {
     if (!skip) {
       if (p >= P) break;
-      if (!V.K.test(p)) { probe_window<NS>(ix, V, p, width); width = 32; }
+      if (!V.K.test(p)) { probe_window<NS, F>(ix, V, p, width); width = 32; }
       int kend = known_end(V, p);
       if (kend > P) kend = P;
       Bits<NS> hitm = b_and(V.E, V.F);
@@ -617,6 +667,7 @@ QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, c
       int stop = ph < kend ? ph : kend;
       Bits<NS> missC = b_and(b_andn(V.E, V.F), V.C);
       otherHits += (u32)popc_range(missC, p, stop);   // misses: spotCheck_ of the complement (:667-675)
+      if (((F & QM_F_NIP) != 0)) set_range_and(V.V, V.E, p, ph < kend ? ph + 1 : stop);   // spotCheck_ entries (vote)
       if (ph >= kend) { p = kend; width = 32; continue; }   // nothing in the probed stretch: next window (or the end)
       strandHits += 1;                                 // spotCheck_ on the hit (:545)
       otherHits += V.C.test(ph) ? 1u : 0u;
@@ -637,22 +688,32 @@ QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, c
       prevMMPEnd = p + mlen;
       if (p + mlen < L) {
         if (V.AV.test(kp)) {
-          if (!V.K.test(kp)) probe_window<NS>(ix, V, kp, more ? 32 : 1);
+          if (!V.K.test(kp)) probe_window<NS, F>(ix, V, kp, (more && !(F & QM_F_NIP)) ? 32 : 1);
           strandHits += V.F.test(kp) ? 1u : 0u; otherHits += V.C.test(kp) ? 1u : 0u;
+          if (((F & QM_F_NIP) != 0)) set_bit(V.V, kp);
         }
       }
     }
     if (lastSearch) return;
     if (p + mlen >= L) return;
-    p = kp;                                             // NIP off: lce == matchedLen (:635-647)
-    width = 32;
+    if (!(F & QM_F_NIP)) {
+      p = kp;                                           // NIP off: lce == matchedLen (:635-647)
+      width = 32;
+    } else {                                            // NIP: jump by the LCE of the interval's ends (:634-657)
+      int lceLen = lce_wave(ix, lb, ub - 1, mlen, L - (p + mlen));
+      int skipLCE = p + lceLen - (k - 1);
+      int np = kp > skipLCE ? kp : skipLCE;
+      if (lceLen > mlen && L > k) np = np < L - k ? np : L - k;
+      p = np;
+      width = 1;
+    }
     if (p + k == L) lastSearch = true;
   }
 }
 
 // SACollector::operator() (SACollector.hpp:108-362), disableNIP_ == true.
 // M.str[0] = read (upper-cased), M.str[1] = reverseRead(read).  Returns foundHit.
-template <int NS>
+template <int NS, int F>
 QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M, int L, IntervalList& fwdInts,
                          IntervalList& rcInts) {
   const int k = ix.k, P = L - k + 1;
@@ -667,7 +728,7 @@ QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M,
   int width = 1;
   bool found = false;
   while (p0 < P) {
-    if (!S.K.test(p0)) { probe_window<NS>(ix, S, p0, width); width = 32; }
+    if (!S.K.test(p0)) { probe_window<NS, F>(ix, S, p0, width); width = 32; }
     int kend = known_end(S, p0);
     if (kend > P) kend = P;
     Bits<NS> cand = b_and(S.E2, b_or(S.F, S.C));
@@ -679,31 +740,67 @@ QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M,
   u32 fwdHit = S.F.test(p0) ? 1u : 0u;
   u32 rcHit = S.C.test(p0) ? 1u : 0u;
   long long fwdCov = 0, rcCov = 0;
-  const bool useCoverageCheck = B.strict_check != 0;   // disableNIP_ && strictCheck_ (:138)
+  const bool useCoverageCheck = ((F & QM_F_NIP) == 0) && B.strict_check != 0;   // disableNIP_ && strictCheck_ (:138)
+  const bool vote = !useCoverageCheck && B.strict_check != 0;
+  if (vote) set_bit(S.V, p0);                          // the scan's own KmerDirScore entry (:206-225)
 
   bool didCheckFwd = false;
   if (fwdHit) {                                         // :247-254
     didCheckFwd = true;
     Iv v = S.tab[p0];
-    get_sa_hits<NS>(ix, B, S, fwdStr, L, p0, true, uniform(v.lb), uniform(v.ub), fwdCov, fwdHit, rcHit, fwdInts);
+    get_sa_hits<NS, F>(ix, B, S, fwdStr, L, p0, true, uniform(v.lb), uniform(v.ub), fwdCov, fwdHit, rcHit, fwdInts);
   }
   bool checkRC = useCoverageCheck ? (rcHit > 0) : (rcHit >= fwdHit);
+  const bool fwdFirst = didCheckFwd;
+  Strand<NS> R;
+  bool haveR = false;
   if (checkRC) {                                        // :258-265
     // the reverse-complemented read is treated as a string of its own (also correct for IUPAC / 'U'
     // characters, where reverseRead() is not the mirror image of the 2-bit encoding)
-    Strand<NS> R;
     setup_strand<NS>(ix, rcStr, L, R, &M.planes[1][0][0], M.tab[1]);
-    get_sa_hits<NS>(ix, B, R, rcStr, L, 0, false, 0, 0, rcCov, rcHit, fwdHit, rcInts);
+    haveR = true;
+    get_sa_hits<NS, F>(ix, B, R, rcStr, L, 0, false, 0, 0, rcCov, rcHit, fwdHit, rcInts);
   }
   bool checkFwd = useCoverageCheck ? (fwdHit > 0) : (fwdHit >= rcHit);
   if (!didCheckFwd && checkFwd) {                       // :271-278
-    get_sa_hits<NS>(ix, B, S, fwdStr, L, 0, false, 0, 0, fwdCov, fwdHit, rcHit, fwdInts);
+    get_sa_hits<NS, F>(ix, B, S, fwdStr, L, 0, false, 0, 0, fwdCov, fwdHit, rcHit, fwdInts);
   }
-  if (B.strict_check) {                                 // :280-288 (coverage mode; slack 0)
+  if (useCoverageCheck) {                               // :283-288 (slack 0)
     if (fwdCov > rcCov) rcInts.n = 0;
     else if (rcCov > fwdCov) fwdInts.n = 0;
+  } else if (vote) {                                    // :289-337: the k-mer "spot check" vote
+    if (fwdHit > 0 && rcHit == 0) rcInts.n = 0;
+    else if (rcHit > 0 && fwdHit == 0) fwdInts.n = 0;
+    else {
+      // one entry per forward-strand position (std::sort + std::unique on kpos); an rc-strand entry at q
+      // describes forward position P-1-q with (fwd,rc) status = (C_r[q], F_r[q]) (:417-429).  When both
+      // strands visited a position the earlier entry survives: the seeded forward pass precedes the rc pass,
+      // the forward pass from 0 follows it (the scan's own entry always comes first).
+      int fwdScore = 0, rcScore = 0;
+      Bits<NS> VRm, FRm, CRm;                           // rc-strand masks mirrored to forward positions
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) { VRm.w[s2] = 0; FRm.w[s2] = 0; CRm.w[s2] = 0; }
+      if (haveR) { VRm = mirror(R.V, P); FRm = mirror(R.C, P); CRm = mirror(R.F, P); }
+      Bits<NS> first;                                   // forward entries that precede the rc pass
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) first.w[s2] = fwdFirst ? S.V.w[s2] : 0;
+      set_bit(first, p0);
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) {
+        u64 a1 = first.w[s2];                           // forward entries, first in time
+        u64 a2 = VRm.w[s2] & ~a1;                       // rc entries
+        u64 a3 = S.V.w[s2] & ~a1 & ~a2;                 // forward entries of the late pass
+        u64 ff = (S.F.w[s2] & (a1 | a3)) | (FRm.w[s2] & a2);
+        u64 cc = (S.C.w[s2] & (a1 | a3)) | (CRm.w[s2] & a2);
+        u64 all = a1 | a2 | a3;
+        fwdScore += 2 * popc64(ff & all) - popc64(all);
+        rcScore += 2 * popc64(cc & all) - popc64(all);
+      }
+      if (fwdScore > rcScore) rcInts.n = 0;
+      else if (rcScore > fwdScore) fwdInts.n = 0;
+    }
   }
-  if (B.quasi_cov > 0.0) {                              // :343-358
+  if (B.quasi_cov > 0.0 && !(F & QM_F_NIP)) {               // :343-358 (only with NIP disabled)
     if (fwdInts.n > 0) { double f = (double)fwdCov / (double)L; if (f < B.quasi_cov) fwdInts.n = 0; }
     if (rcInts.n > 0) { double f = (double)rcCov / (double)L; if (f < B.quasi_cov) rcInts.n = 0; }
   }
@@ -922,7 +1019,7 @@ QM_DEV void dump_intervals(const ReadBatch& B, long long read, int list, const I
 // One read: load -> collect -> hits->mappings -> list to global memory.
 struct WaveAlloc { long long base; int used; };   // the wave's current chunk of B.lists (wave-uniform)
 
-template <int NS>
+template <int NS, int F>
 QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, WaveMem<NS>& M, u64* gscr, WaveAlloc& wa) {
   const bool paired = B.seq2 != nullptr;
   const int mate = paired ? (int)(read & 1) : 0;
@@ -946,7 +1043,7 @@ QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, Wav
   IntervalList fi, ri;
   fi.lds = M.ints[0]; ri.lds = M.ints[1];
   fi.ovf = (IntRec*)(gscr + 3 * QM_GCAP); ri.ovf = fi.ovf + QM_IOVF;
-  collect_read<NS>(ix, B, M, len, fi, ri);
+  collect_read<NS, F>(ix, B, M, len, fi, ri);
   if (B.dbg_ints) {
     int dbg = 0;
     dump_intervals(B, read, 2 * mate, fi, dbg); dump_intervals(B, read, 2 * mate + 1, ri, dbg);

@@ -33,7 +33,7 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
   int status = 0; u64 cursor = 0;
   B.lcnt = lcnt.data(); B.loff = loff.data(); B.cursor = &cursor;
   B.gscratch = gs.data(); B.status = &status; B.dbg_ints = dints.data(); B.dbg_count = dcnt.data();
-  B.strict_check = o->strict_check; B.max_interval = o->max_interval; B.quasi_cov = o->quasi_cov;
+  B.strict_check = o->strict_check; B.max_interval = o->max_interval; B.quasi_cov = o->quasi_cov; B.sensitive = o->sensitive;
   while (true) {
     lists.assign((size_t)cap, 0);
     B.lists = lists.data(); B.lists_cap = cap; cursor = 0; status = 0;
@@ -41,8 +41,11 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
     WaveAlloc wa[7];
     for (auto& w : wa) { w.base = -1; w.used = 0; }
     for (long long r = 0; r < nreads; ++r) {
-      if (ns == 2) { static WaveMem<2> M; map_read<2>(ix, B, r, M, gs.data(), wa[r % 7]); }
-      else { static WaveMem<4> M; map_read<4>(ix, B, r, M, gs.data(), wa[r % 7]); }
+      const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP);
+#define QE_CALL(NS_, F_) { static WaveMem<NS_> M; map_read<NS_, F_>(ix, B, r, M, gs.data(), wa[r % 7]); }
+      if (ns == 2) { switch (F) { case 0: QE_CALL(2, 0) break; case 1: QE_CALL(2, 1) break; case 2: QE_CALL(2, 2) break; default: QE_CALL(2, 3) break; } }
+      else { switch (F) { case 0: QE_CALL(4, 0) break; case 1: QE_CALL(4, 1) break; case 2: QE_CALL(4, 2) break; default: QE_CALL(4, 3) break; } }
+#undef QE_CALL
     }
     if (!(status & 1)) break;
     cap *= 4;

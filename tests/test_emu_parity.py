@@ -16,6 +16,9 @@ VARIANTS = {
     "noOrphans": ({"noOrphans": 1}, {"no_orphans": 1}),
     "noDovetail": ({"noDovetail": 1}, {"no_dovetail": 1}),
     "maxInterval50": ({"maxInterval": 50}, {"max_interval": 50}),
+    "noSensitive": ({"sensitive": 0}, {"sensitive": 0}),
+    "noSensitive_noStrict": ({"sensitive": 0, "strictCheck": 0}, {"sensitive": 0, "strict_check": 0}),
+    "noSensitive_z0.8": ({"sensitive": 0, "quasiCov": 0.8}, {"sensitive": 0, "quasi_cov": 0.8}),
 }
 
 

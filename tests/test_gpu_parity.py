@@ -19,6 +19,9 @@ VARIANTS = {
     "noOrphans": ({"noOrphans": 1}, {"no_orphans": 1}),
     "noDovetail": ({"noDovetail": 1}, {"no_dovetail": 1}),
     "maxInterval50": ({"maxInterval": 50}, {"max_interval": 50}),
+    "noSensitive": ({"sensitive": 0}, {"sensitive": 0}),
+    "noSensitive_noStrict": ({"sensitive": 0, "strictCheck": 0}, {"sensitive": 0, "strict_check": 0}),
+    "noSensitive_z0.8": ({"sensitive": 0, "quasiCov": 0.8}, {"sensitive": 0, "quasi_cov": 0.8}),
 }
 
 
@@ -120,7 +123,7 @@ def test_edge_batches(synth_small, oracle_mod):
     with pytest.raises(ra.QmError, match="read length"):
         mp.map_pairs(q1, o1, q2, o2)
     q1, o1 = pack([b"ACGT" * 20]); q2, o2 = pack([b"ACGT" * 20])
-    for kw in ({"sensitive": 0}, {"fuzzy": 1}, {"sel_aln": 1}):
+    for kw in ({"fuzzy": 1}, {"sel_aln": 1}):
         with pytest.raises(ra.QmError, match="not implemented"):
             mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(**kw))
 
