@@ -1,0 +1,155 @@
+"""`python -m rapmap_amd quasiindex|quasimap ...` -- the reference's command line on the MI355X path.
+
+Flag names, defaults and validation follow `rapmap quasiindex` (src/RapMapSAIndexer.cpp:821-927) and
+`rapmap quasimap` (src/RapMapSAMapper.cpp:984-1189, validateOpts :911-954).  Options that the device path does
+not implement (-s/--selAln and its sub-options, -f, --recoverOrphans, -c) are accepted by the parser and
+rejected with the library's error, never silently ignored.
+"""
+import argparse
+import sys
+import time
+
+import numpy as np
+
+
+def _quasiindex(argv):
+    ap = argparse.ArgumentParser(prog="rapmap_amd quasiindex", description="RapMap Indexer (MI355X build)")
+    ap.add_argument("-t", "--transcripts", required=True, help="The transcript file to be indexed")
+    ap.add_argument("-i", "--index", required=True, help="The location where the index should be written")
+    ap.add_argument("-k", "--klen", type=int, default=31, help="The length of k-mer to index (odd, <= 31)")
+    ap.add_argument("-p", "--perfectHash", action="store_true", help="Use a perfect hash instead of dense hash (BooPHF)")
+    ap.add_argument("-n", "--noClip", action="store_true", help="Don't clip poly-A tails from the ends of target sequences")
+    ap.add_argument("--keepDuplicates", action="store_true", help="Retain and index exact sequence-level duplicates")
+    ap.add_argument("-x", "--numThreads", type=int, default=4, help="Threads for the k-mer interval scan / perfect hash")
+    a = ap.parse_args(argv)
+    if a.klen % 2 == 0 or a.klen > 31 or a.klen < 1:
+        sys.exit("K-mer length should be odd and <= 31 (RapMapSAIndexer.cpp:870-877)")
+    import rapmap_amd as ra
+    t = time.time()
+    ra.build_index(a.transcripts, a.index, k=a.klen, no_clip_poly_a=a.noClip, keep_duplicates=a.keepDuplicates,
+                   threads=a.numThreads, perfect_hash=a.perfectHash)
+    print("[rapmap_amd] index written to %s (%.1fs)" % (a.index, time.time() - t), file=sys.stderr)
+
+
+def _quasimap(argv):
+    ap = argparse.ArgumentParser(prog="rapmap_amd quasimap", description="RapMap Mapper (MI355X build)")
+    ap.add_argument("-i", "--index", required=True, help="The location of the quasiindex")
+    ap.add_argument("-1", "--leftMates", default="", help="The location of the left paired-end reads")
+    ap.add_argument("-2", "--rightMates", default="", help="The location of the right paired-end reads")
+    ap.add_argument("-r", "--unmatedReads", default="", help="The location of single-end reads")
+    ap.add_argument("-t", "--numThreads", type=int, default=1, help="accepted for compatibility (the GPU does the mapping)")
+    ap.add_argument("-m", "--maxNumHits", type=int, default=200, help="Reads mapping to more than this many loci are discarded")
+    ap.add_argument("-o", "--output", default="", help="The output file (default: stdout)")
+    ap.add_argument("-z", "--quasiCoverage", type=float, default=0.0)
+    ap.add_argument("-n", "--noOutput", action="store_true", help="Don't write out any alignments (for speed testing purposes)")
+    ap.add_argument("--noSensitive", action="store_true")
+    ap.add_argument("--noStrictCheck", action="store_true")
+    ap.add_argument("-f", "--fuzzyIntersection", action="store_true")
+    ap.add_argument("-c", "--chaining", action="store_true")
+    ap.add_argument("-x", "--compressed", action="store_true", help="Compress the output SAM file using zlib")
+    ap.add_argument("-q", "--quiet", action="store_true")
+    ap.add_argument("-u", "--writeUnmapped", action="store_true")
+    ap.add_argument("--recoverOrphans", action="store_true")
+    ap.add_argument("--noDovetail", action="store_true")
+    ap.add_argument("--noOrphans", action="store_true")
+    ap.add_argument("-s", "--selAln", action="store_true")
+    ap.add_argument("--device", type=int, default=0, help="GPU to use")
+    ap.add_argument("--chunk", type=int, default=1 << 20, help="read pairs per GPU batch")
+    a = ap.parse_args(argv)
+
+    paired = bool(a.leftMates and a.rightMates)
+    single = bool(a.unmatedReads)
+    # validateOpts (src/RapMapSAMapper.cpp:911-954, :1179-1189)
+    if paired == single:
+        sys.exit("You must provide either paired-end (-1 and -2) or single-end (-r) reads, and not both")
+    if not (0.0 <= a.quasiCoverage <= 1.0):
+        sys.exit("quasiCoverage must be in [0,1]")
+    if a.recoverOrphans or a.chaining:
+        sys.exit("--recoverOrphans / --chaining are not implemented on the MI355X path")
+
+    import rapmap_amd as ra
+    from rapmap_amd import sam
+    opts = ra.default_opts(sensitive=0 if a.noSensitive else 1, strict_check=0 if a.noStrictCheck else 1,
+                           max_num_hits=a.maxNumHits, no_orphans=int(a.noOrphans), no_dovetail=int(a.noDovetail),
+                           fuzzy=int(a.fuzzyIntersection), sel_aln=int(a.selAln), quasi_cov=a.quasiCoverage)
+    qi = ra.QuasiIndex(a.index)
+    mp = ra.QuasiMapper(qi, a.device)
+    log = (lambda *x: None) if a.quiet else (lambda *x: print(*x, file=sys.stderr, flush=True))
+    out = None
+    if not a.noOutput:
+        if a.output:
+            if a.compressed:
+                import gzip
+                out = gzip.open(a.output, "wt")
+            else:
+                out = open(a.output, "w")
+        else:
+            out = sys.stdout
+        out.write(sam.sam_header(qi.txp_names, qi.txp_lens))
+    names_t, lens_t = qi.txp_names, qi.txp_lens
+    tot = {"numReads": 0, "totHits": 0, "peHits": 0, "seHits": 0, "tooManyHits": 0}
+    t0 = time.time()
+    gpu_ms = 0.0
+    if paired:
+        files1, files2 = a.leftMates.split(","), a.rightMates.split(",")
+        if len(files1) != len(files2):
+            sys.exit("the number of left and right read files differs")
+        for f1, f2 in zip(files1, files2):
+            it2 = sam.iter_fastx(f2, a.chunk)
+            for n1, s1 in sam.iter_fastx(f1, a.chunk):
+                n2, s2 = next(it2)
+                if len(s1) != len(s2):
+                    sys.exit("left and right files are not in sync")
+                q1, o1 = ra.pack_reads(s1); q2, o2 = ra.pack_reads(s2)
+                r = mp.map_pairs(q1, o1, q2, o2, opts=opts)
+                gpu_ms += r.total_ms
+                for kk in tot:
+                    tot[kk] += r.counters[kk]
+                if out is not None:
+                    buf = []
+                    ho, hits = r.hit_offsets, r.hits
+                    for i in range(len(s1)):
+                        buf.append(sam.format_pair(n1[i], s1[i], n2[i], s2[i], hits[ho[i]:ho[i + 1]], names_t, lens_t, a.maxNumHits))
+                    out.write("".join(buf))
+                log("saw %d reads : pe / read = %.4f : se / read = %.4f" % (
+                    tot["numReads"], tot["peHits"] / max(1, tot["numReads"]), tot["seHits"] / max(1, tot["numReads"])))
+    else:
+        for f in a.unmatedReads.split(","):
+            for n1, s1 in sam.iter_fastx(f, a.chunk):
+                q, o = ra.pack_reads(s1)
+                r = mp.map_reads(q, o, opts=opts)
+                gpu_ms += r.total_ms
+                for kk in tot:
+                    tot[kk] += r.counters[kk]
+                if out is not None:
+                    ho, hits = r.hit_offsets, r.hits
+                    out.write("".join(sam.format_single(n1[i], s1[i], hits[ho[i]:ho[i + 1]], names_t, lens_t) for i in range(len(s1))))
+    if out is not None and out is not sys.stdout:
+        out.close()
+    log("Done mapping reads.")
+    log("In total saw %d reads." % tot["numReads"])
+    log("Final # hits per read = %g" % (tot["totHits"] / max(1, tot["numReads"])))       # RapMapSAMapper.cpp:892-893
+    log("Elapsed time: %.3fs (GPU mapping %.3fs)" % (time.time() - t0, gpu_ms / 1e3))
+
+
+def main():
+    if len(sys.argv) < 2 or sys.argv[1] in ("-h", "--help"):
+        print("usage: python -m rapmap_amd {quasiindex,quasimap} [options]\n"
+              "  quasiindex  build a suffix array-based (SA) index\n"
+              "  quasimap    map reads using the SA-based index (on an MI355X)")
+        return
+    if sys.argv[1] in ("-v", "--version"):
+        import rapmap_amd as ra
+        print("rapmap_amd", ra.api.lib().qm_version().decode())
+        return
+    cmd = sys.argv[1]
+    if cmd == "quasiindex":
+        _quasiindex(sys.argv[2:])
+    elif cmd == "quasimap":
+        _quasimap(sys.argv[2:])
+    else:
+        sys.exit("the command %s is not yet implemented" % cmd)       # src/RapMap.cpp:86-94
+
+
+if __name__ == "__main__":
+    main()

@@ -144,6 +144,63 @@ def format_pair(name1, seq1, name2, seq2, hits, txp_names, txp_lens, max_num_hit
     return "".join(out)
 
 
+def format_single(name, seq, hits, txp_names, txp_lens) -> str:
+    """single-end records (src/RapMapUtils.cpp:198-311): MAPQ 255, flags 0x10 for rc, 0x900 on secondary hits;
+    the single-end writer only strips the name at the first blank (no /1 trimming)."""
+    sp = name.find(" ")
+    rn = name[:sp] if sp >= 0 else name
+    nh = len(hits)
+    if nh == 0:
+        return "%s\t4\t*\t0\t255\t*\t*\t0\t0\t%s\t*\tNH:i:0\tHI:i:0\tAS:i:0\n" % (rn, seq.decode())
+    out = []
+    rev = None
+    for i, h in enumerate(hits, start=1):
+        tid = int(h["tid"])
+        fl = 0 if h["fwd"] else 0x10
+        if i != 1:
+            fl |= 0x900
+        s = seq
+        if not h["fwd"]:
+            rev = rev if rev is not None else reverse_read(seq)
+            s = rev
+        pos, cig = _adjust_overhang(int(h["pos"]), int(h["read_len"]), int(txp_lens[tid]))
+        out.append("%s\t%d\t%s\t%d\t255\t%s\t*\t0\t%d\t%s\t*\tNH:i:%d\tHI:i:%d\tAS:i:%d\n" % (
+            rn, fl, txp_names[tid], pos + 1, cig, int(h["frag_len"]), s.decode(), nh, i, int(h["aln_score"])))
+    return "".join(out)
+
+
+def iter_fastx(path, chunk):
+    """yield (names, seqs) chunks of a FASTA/FASTQ(.gz) file; qualities are dropped like the reference's parser"""
+    names, seqs = [], []
+    opener = open
+    if path.endswith(".gz"):
+        import gzip
+        opener = gzip.open
+    with opener(path, "rb") as f:
+        while True:
+            h = f.readline()
+            if not h:
+                break
+            h = h.rstrip(b"\r\n")
+            if not h:
+                continue
+            if h[:1] == b"@":
+                s = f.readline().rstrip(b"\r\n")
+                f.readline()
+                f.readline()
+            elif h[:1] == b">":
+                s = f.readline().rstrip(b"\r\n")
+            else:
+                raise ValueError("bad record header: %r" % h[:40])
+            names.append(h[1:].decode())
+            seqs.append(s)
+            if len(names) >= chunk:
+                yield names, seqs
+                names, seqs = [], []
+    if names:
+        yield names, seqs
+
+
 def read_fastq(path):
     """Minimal 4-line FASTQ / 2-line FASTA reader -> (names, seqs as bytes).  Qualities are dropped,
     like the reference's parser (include/FastxParser.hpp:62-66)."""
