@@ -30,6 +30,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <string>
 #include <thread>
@@ -163,7 +164,7 @@ struct Opts {
   int32_t maxNumHits;     // -m, default 200
   int32_t noOrphans;
   int32_t noDovetail;
-  int32_t fuzzy;          // not restated yet (a13)
+  int32_t fuzzy;          // --fuzzyIntersection
   int32_t maxInterval;    // SACollector.hpp:77, 1000
   int32_t pad;
   double quasiCov;        // -z
@@ -531,6 +532,10 @@ struct Collector {
 // ----------------------------------------------------------------------------
 struct QA {   // the fields of QuasiAlignment that are defined on this path
   uint32_t tid; int32_t pos; bool fwd; uint32_t readLen; uint8_t mateStatus;
+  // With considerMultiPos off (always, without selective alignment) allPositions is {pos}
+  // (HitManager.cpp:321,736) and oppositeStrandPositions is empty or the single position of the
+  // same-transcript hit of the other orientation (HitManager.cpp:846-866).
+  bool hasOpp = false; int32_t oppPos = 0;
 };
 
 struct TQ { uint32_t pos, queryPos; bool queryRC; };
@@ -639,9 +644,16 @@ static void hitsToMappingsSimple(const OIndex& ix, uint8_t mateStatus, uint32_t 
     // :838-842 degenerates to tid<; inplace_merge is stable => fwd entry first.
     std::inplace_merge(hits.begin() + fwdHitsStart, hits.begin() + fwdHitsEnd, hits.begin() + rcHitsEnd,
                        [](const QA& a, const QA& b) { return a.tid < b.tid; });
-    auto newEnd = std::unique(hits.begin() + fwdHitsStart, hits.begin() + rcHitsEnd,
-                              [](const QA& a, const QA& b) { return a.tid == b.tid; });
-    hits.resize(std::distance(hits.begin(), newEnd));
+    // mergeOrientationUnique :846-866 -- the surviving entry of a same-transcript run keeps the
+    // positions of the dropped one as its opposite-strand positions
+    auto first = hits.begin() + fwdHitsStart, last = hits.begin() + rcHitsEnd;
+    auto result = first;
+    while (++first != last) {
+      bool distinct = !(result->tid == first->tid);
+      if (distinct && ++result != first) { *result = *first; }
+      else if (!distinct) { result->hasOpp = true; result->oppPos = first->pos; }
+    }
+    hits.resize(std::distance(hits.begin(), ++result));
   }
 }
 
@@ -696,6 +708,85 @@ static void mergeLeftRightHits(std::vector<QA>& leftHits, std::vector<QA>& right
   }
 }
 
+// include/RapMapUtils.hpp:864-1183 (--fuzzyIntersection), with considerMultiPos == false so that
+// every position list holds at most one element.  Returns nothing: the MergeResult only feeds orphan
+// recovery, which needs selective alignment.
+static void mergeLeftRightHitsFuzzy(bool leftMatches, bool rightMatches, std::vector<QA>& leftHits,
+                                    std::vector<QA>& rightHits, std::vector<Hit>& joint,
+                                    uint32_t maxNumHits, bool& tooManyHits, Counters& hctr) {
+  auto mk = [](const QA& q) {
+    Hit h{}; h.tid = q.tid; h.pos = q.pos; h.matePos = 0; h.fragLen = 0; h.readLen = q.readLen;
+    h.mateLen = 0; h.fwd = q.fwd; h.mateIsFwd = 1; h.isPaired = 0; h.mateStatus = q.mateStatus; h.alnScore = 0;
+    return h;
+  };
+  constexpr int32_t maxGap = std::numeric_limits<int32_t>::max();
+  // findBestHitFWRC :923-988 for one fwd and one rc position: lower_bound over the single rc
+  // position lands on it when rc >= fwd, else on end() whose predecessor is again that element;
+  // updateBestGap gives maxGap whenever rc < fwd, i.e. "no valid pairing".
+  auto best = [&](bool hasF, int32_t f, bool hasR, int32_t r, int32_t fwdReadLen, int32_t& gap) -> bool {
+    if (!hasF || !hasR) return false;
+    gap = (r >= f) ? std::abs(r - (f + fwdReadLen)) : maxGap;
+    return gap < maxGap;
+  };
+  if (leftHits.empty()) {
+    if (!leftMatches && !rightHits.empty()) {
+      for (auto& q : rightHits) joint.push_back(mk(q));
+      hctr.seHits += rightHits.size();
+    }
+  } else if (rightHits.empty()) {
+    if (!rightMatches) {
+      for (auto& q : leftHits) joint.push_back(mk(q));
+      hctr.seHits += leftHits.size();
+    }
+  } else {
+    auto leftIt = leftHits.begin(), leftEnd = leftHits.end();
+    auto rightIt = rightHits.begin(), rightEnd = rightHits.end();
+    size_t numHits = 0;
+    while (leftIt != leftEnd && rightIt != rightEnd) {
+      uint32_t leftTxp = leftIt->tid, rightTxp = rightIt->tid;
+      if (leftTxp < rightTxp) { ++leftIt; }
+      else {
+        if (!(rightTxp < leftTxp)) {
+          // :991-996 -- positions by strand
+          bool lHasF = leftIt->fwd, lHasR = leftIt->fwd ? leftIt->hasOpp : true;
+          int32_t lF = leftIt->pos, lR = leftIt->fwd ? leftIt->oppPos : leftIt->pos;
+          if (!leftIt->fwd) { lHasF = leftIt->hasOpp; lF = leftIt->oppPos; }
+          bool rHasF = rightIt->fwd, rHasR = rightIt->fwd ? rightIt->hasOpp : true;
+          int32_t rF = rightIt->pos, rR = rightIt->fwd ? rightIt->oppPos : rightIt->pos;
+          if (!rightIt->fwd) { rHasF = rightIt->hasOpp; rF = rightIt->oppPos; }
+          int32_t gapFWRC = maxGap, gapRCFW = maxGap;
+          bool bestFWRC = best(lHasF, lF, rHasR, rR, (int32_t)leftIt->readLen, gapFWRC);
+          bool bestRCFW = best(rHasF, rF, lHasR, lR, (int32_t)rightIt->readLen, gapRCFW);
+          bool foundValidHit = false, leftFwd = false, rightFwd = false;
+          int32_t bestGap = maxGap, leftPos = -1, rightPos = -1;
+          if (bestFWRC) { leftPos = lF; rightPos = rR; bestGap = gapFWRC; leftFwd = true; rightFwd = false; foundValidHit = true; }
+          if (bestRCFW) {
+            if (gapRCFW < bestGap) { leftPos = lR; rightPos = rF; leftFwd = false; rightFwd = true; }
+            foundValidHit = true;
+          }
+          if (foundValidHit) {                                     // :1124-1151
+            int32_t startRead1 = std::max(leftPos, 0), startRead2 = std::max(rightPos, 0);
+            bool read1First = startRead1 < startRead2;
+            int32_t fragStartPos = read1First ? startRead1 : startRead2;
+            int32_t fragEndPos = read1First ? (int32_t)(startRead2 + rightIt->readLen)
+                                            : (int32_t)(startRead1 + leftIt->readLen);
+            Hit h{}; h.tid = leftTxp; h.pos = leftPos; h.fwd = leftFwd; h.readLen = leftIt->readLen;
+            h.fragLen = (uint32_t)(fragEndPos - fragStartPos); h.isPaired = 1; h.mateLen = rightIt->readLen;
+            h.matePos = rightPos; h.mateIsFwd = rightFwd; h.mateStatus = PE_PAIRED; h.alnScore = 0;
+            joint.push_back(h);
+            ++numHits;
+            if (numHits > maxNumHits) { tooManyHits = true; break; }
+          }
+          ++leftIt;
+        }
+        ++rightIt;
+      }
+    }
+    if (tooManyHits) { joint.clear(); ++hctr.tooManyHits; }
+  }
+  if (!joint.empty()) hctr.peHits += joint.size();                 // :1176-1179 (orphans are counted too)
+}
+
 // per-pair driver -- src/RapMapSAMapper.cpp:461-551,684-701
 static void mapPair(const OIndex& ix, const Opts& o, Collector& col, const char* r1, size_t l1,
                     const char* r2, size_t l2, std::vector<Hit>& joint, Counters& hctr, Work& w,
@@ -705,12 +796,13 @@ static void mapPair(const OIndex& ix, const Opts& o, Collector& col, const char*
   bool tooManyHits = false;
   ++hctr.numReads;
   joint.clear();
-  col.collect(r1, l1, lf, lr);
-  col.collect(r2, l2, rf, rr);
+  bool lh = col.collect(r1, l1, lf, lr);
+  bool rh = col.collect(r2, l2, rf, rr);
   if (dumpInts) { dumpInts[0] = lf; dumpInts[1] = lr; dumpInts[2] = rf; dumpInts[3] = rr; }
   hitsToMappingsSimple(ix, PE_LEFT, (uint32_t)l1, lf, lr, leftHits, w);
   hitsToMappingsSimple(ix, PE_RIGHT, (uint32_t)l2, rf, rr, rightHits, w);
-  mergeLeftRightHits(leftHits, rightHits, joint, (uint32_t)o.maxNumHits, tooManyHits, hctr);
+  if (o.fuzzy) mergeLeftRightHitsFuzzy(lh, rh, leftHits, rightHits, joint, (uint32_t)o.maxNumHits, tooManyHits, hctr);
+  else mergeLeftRightHits(leftHits, rightHits, joint, (uint32_t)o.maxNumHits, tooManyHits, hctr);
   if (joint.size() > (size_t)o.maxNumHits) joint.clear();                 // :534-536
   if (!joint.empty() && o.noOrphans && joint.front().mateStatus != PE_PAIRED) joint.clear();   // :539-551
   if (o.noDovetail) {                                                     // :684-698

@@ -17,6 +17,8 @@ VARIANTS = {
     "m3": {"maxNumHits": 3},
     "noOrphans": {"noOrphans": 1},
     "noSensitive": {"sensitive": 0},
+    "fuzzy": {"fuzzy": 1},
+    "fuzzy_noOrphans_m3": {"fuzzy": 1, "noOrphans": 1, "maxNumHits": 3},
 }
 
 
