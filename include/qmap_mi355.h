@@ -46,7 +46,7 @@ typedef struct qm_opts {
   int32_t max_num_hits;  /* -m, 200                                                       */
   int32_t no_orphans;    /* --noOrphans                                                   */
   int32_t no_dovetail;   /* --noDovetail                                                  */
-  int32_t fuzzy;         /* -f  (mergeLeftRightHitsFuzzy; not on the device path yet)     */
+  int32_t fuzzy;         /* -f  mergeLeftRightHitsFuzzy, include/RapMapUtils.hpp:864-1183   */
   int32_t max_interval;  /* SACollector::setMaxInterval, 1000 (SACollector.hpp:54,77)     */
   int32_t sel_aln;       /* -s  (not on the device path yet)                              */
   double quasi_cov;      /* -z  (SACollector::setCoverageRequirement)                     */

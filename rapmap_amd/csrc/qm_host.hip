@@ -413,7 +413,6 @@ int qm_ctx_set_debug(qm_ctx* c, int keep) { if (!c) return fail(QM_E_ARG, "null 
 
 static int check_opts(const qm_opts* o) {
   if (!o) return fail(QM_E_ARG, "null opts");
-  if (o->fuzzy) return fail(QM_E_UNSUPPORTED, "--fuzzyIntersection is not implemented on the device path");
   if (o->sel_aln) return fail(QM_E_UNSUPPORTED, "--selAln is not implemented on the device path");
   if (o->max_num_hits < 0 || o->max_interval < 1) return fail(QM_E_ARG, "bad max_num_hits / max_interval");
   return QM_OK;
@@ -464,7 +463,7 @@ int qm_map_device(qm_ctx* c, const qm_opts* o, int64_t n, const void* d_seq1, co
     B.lcnt = c->d_lcnt; B.loff = c->d_loff; B.lists = c->d_lists; B.cursor = c->d_scal; B.lists_cap = c->capLists;
     B.status = (int*)(c->d_scal + 8); B.gscratch = c->d_gscr;
     B.dbg_ints = c->debug ? c->d_dbg : nullptr; B.dbg_count = c->debug ? c->d_dbgcnt : nullptr;
-    B.strict_check = o->strict_check; B.max_interval = o->max_interval; B.quasi_cov = o->quasi_cov; B.sensitive = o->sensitive;
+    B.strict_check = o->strict_check; B.max_interval = o->max_interval; B.quasi_cov = o->quasi_cov; B.sensitive = o->sensitive; B.fuzzy = (d_seq2 != nullptr) ? o->fuzzy : 0;
     HIPCHK(hipMemsetAsync(c->d_scal, 0, 16 * sizeof(u64), c->stream));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     if (nreads > 0) HIPCHK(qmk_map_reads(&ix, &B, ns, grid, c->stream));
@@ -487,7 +486,7 @@ int qm_map_device(qm_ctx* c, const qm_opts* o, int64_t n, const void* d_seq1, co
   PairBatch P; memset(&P, 0, sizeof(P));
   P.n = n; P.paired = paired ? 1 : 0; P.off1 = (const long long*)d_off1; P.off2 = (const long long*)d_off2;
   P.lcnt = c->d_lcnt; P.loff = c->d_loff; P.lists = c->d_lists; P.cnt = c->d_cnt; P.offs = c->d_offs;
-  P.counters = c->d_scal + 1; P.max_num_hits = o->max_num_hits; P.no_orphans = o->no_orphans; P.no_dovetail = o->no_dovetail;
+  P.counters = c->d_scal + 1; P.max_num_hits = o->max_num_hits; P.no_orphans = o->no_orphans; P.no_dovetail = o->no_dovetail; P.fuzzy = o->fuzzy;
   HIPCHK(hipMemsetAsync(c->d_cnt + n, 0, sizeof(uint32_t), c->stream));
   HIPCHK(qmk_pair_count(&P, c->stream));
   HIPCHK(qmk_scan_counts(c->d_scanTmp, c->scanTmpBytes, c->d_cnt, c->d_offs, n + 1, c->stream));

@@ -90,6 +90,7 @@ struct ReadBatch {
   int strict_check, max_interval;
   int sensitive;           // 0: --noSensitive (NIP skipping via SASearcher::lce, k-mer vote instead of coverage)
   double quasi_cov;
+  int fuzzy;               // --fuzzyIntersection: lists keep both orientations of a transcript, lcnt bit31 = foundHit
 };
 
 // stage B launch arguments
@@ -102,7 +103,7 @@ struct PairBatch {
   const long long* offs;   // [n+1] exclusive scan of cnt (pass 2 reads)
   qm_hit* hits;            // pass 2 output, CSR order
   u64* counters;           // [6] qm_counters
-  int max_num_hits, no_orphans, no_dovetail;
+  int max_num_hits, no_orphans, no_dovetail, fuzzy;
 };
 
 template <int NS>
@@ -966,8 +967,10 @@ QM_DEV int multi_interval(const DevIndex& ix, const Bufs& bf, int rOff, const In
 
 // hitsToMappingsSimple (HitManager.cpp:691-882): leaves the read's hits (sorted by tid,
 // unique, fwd preferred) in bf.R[0..return)
+// keepBoth (--fuzzyIntersection): a transcript hit in both orientations keeps both entries, fwd first --
+// the second one is the survivor's oppositeStrandPositions (mergeOrientationUnique, :846-866).
 QM_DEV int hits_to_mappings(const DevIndex& ix, const Bufs& bf, const IntervalList& fwdInts,
-                            const IntervalList& rcInts) {
+                            const IntervalList& rcInts, bool keepBoth) {
   int nf = 0, nr = 0;
   if (fwdInts.n > 1) nf = multi_interval(ix, bf, 0, fwdInts, false);
   else if (fwdInts.n == 1) { int lb, ub; u32 ln, qp; fwdInts.get(0, lb, ub, ln, qp); nf = single_interval(ix, bf, 0, lb, ub, qp, false); }
@@ -978,6 +981,11 @@ QM_DEV int hits_to_mappings(const DevIndex& ix, const Bufs& bf, const IntervalLi
     int n = nf + nr;
     for (int base = 0; base < n; base += 64) { QM_LANES(l) { int i = base + l; if (i < n) bf.A[i] = bf.R[i]; } }
     rank_sort(bf.A, bf.B, n);
+    if (keepBoth) {
+      for (int base = 0; base < n; base += 64) { QM_LANES(l) { int i = base + l; if (i < n) bf.R[i] = bf.B[i]; } }
+      wave_fence();
+      return n;
+    }
     return unique_emit(bf.B, n, 33, bf.R, 0, [](u64 v) { return v; });
   }
   return nf + nr;
@@ -1043,7 +1051,7 @@ QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, Wav
   IntervalList fi, ri;
   fi.lds = M.ints[0]; ri.lds = M.ints[1];
   fi.ovf = (IntRec*)(gscr + 3 * QM_GCAP); ri.ovf = fi.ovf + QM_IOVF;
-  collect_read<NS, F>(ix, B, M, len, fi, ri);
+  const bool foundHit = collect_read<NS, F>(ix, B, M, len, fi, ri);
   if (B.dbg_ints) {
     int dbg = 0;
     dump_intervals(B, read, 2 * mate, fi, dbg); dump_intervals(B, read, 2 * mate + 1, ri, dbg);
@@ -1057,7 +1065,7 @@ QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, Wav
   if (bound > QM_GCAP) {               // only reachable with max_interval > 1000
     QM_LANES(l) { if (l == 0) *B.status |= 2; }
   } else {
-    n = hits_to_mappings(ix, bf, fi, ri);
+    n = hits_to_mappings(ix, bf, fi, ri, B.fuzzy != 0);
   }
   // hand the list to stage B.  One returning atomic on a single word saturates at ~88 M/s on this chip
   // (MI355X_MICROARCH.md "dequeue"), far below the read rate, so a wave reserves QM_CHUNK elements at
@@ -1074,7 +1082,8 @@ QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, Wav
     else wa.used += n;
   }
   for (int b0 = 0; b0 < n; b0 += 64) { QM_LANES(l) { int i = b0 + l; if (i < n) B.lists[base + i] = bf.R[i]; } }
-  QM_LANES(l) { if (l == 0) { B.lcnt[read] = (u32)n; B.loff[read] = base; } }
+  const u32 flag = (B.fuzzy && foundHit) ? 0x80000000u : 0u;      // lh / rh of RapMapSAMapper.cpp:472-478
+  QM_LANES(l) { if (l == 0) { B.lcnt[read] = (u32)n | flag; B.loff[read] = base; } }
 }
 
 // ------------------------------------------------------------------ stage B: one thread per unit
@@ -1103,13 +1112,105 @@ QM_DEV qm_hit paired_hit(u64 le, u64 re, u32 l1, u32 l2) {   // RapMapUtils.hpp:
   return h;
 }
 
+// One transcript group of a fuzzy-mode list: the surviving hit plus, when the transcript was hit in
+// both orientations, the position on the other strand.  With considerMultiPos off every position
+// vector of the reference holds one element (HitManager.cpp:321,736,860).
+struct FzGroup { u32 tid; bool hasF, hasR; int f, r; int width; u64 first; };
+QM_DEV FzGroup fz_group(const u64* X, int i, int n) {
+  FzGroup g; u64 e = X[i];
+  g.first = e; g.tid = el_tid(e); g.width = 1; g.hasF = false; g.hasR = false; g.f = 0; g.r = 0;
+  if (el_rc(e)) { g.hasR = true; g.r = el_pos(e); }
+  else {
+    g.hasF = true; g.f = el_pos(e);
+    if (i + 1 < n && el_tid(X[i + 1]) == g.tid) { g.hasR = true; g.r = el_pos(X[i + 1]); g.width = 2; }
+  }
+  return g;
+}
+// findBestHitFWRC (RapMapUtils.hpp:923-988) for single-element position lists
+QM_DEV bool fz_best(bool hasF, int f, bool hasR, int r, int fwdLen, int& gap) {
+  if (!hasF || !hasR) return false;
+  if (r < f) return false;                                // updateBestGap leaves maxGap
+  int d = r - (f + fwdLen);
+  gap = d < 0 ? -d : d;
+  return true;
+}
+QM_DEV int fz_groups(const u64* X, int n) { int g = 0; for (int i = 0; i < n; i += fz_group(X, i, n).width) ++g; return g; }
+
+// mergeLeftRightHitsFuzzy (RapMapUtils.hpp:864-1183) + the per-pair driver; same contract as unit_merge.
+QM_DEV int unit_merge_fuzzy(const PairBatch& P, long long u, qm_hit* out, int cap, UnitCounters* uc) {
+  const int maxHits = P.max_num_hits;
+  const u32 c0 = P.lcnt[2 * u], c1 = P.lcnt[2 * u + 1];
+  const int nl = (int)(c0 & 0x7fffffffu), nr = (int)(c1 & 0x7fffffffu);
+  const bool lh = (c0 >> 31) != 0, rh = (c1 >> 31) != 0;
+  const u64* LL = P.lists + P.loff[2 * u];
+  const u64* RR = P.lists + P.loff[2 * u + 1];
+  const u32 l1 = (u32)(P.off1[u + 1] - P.off1[u]), l2 = (u32)(P.off2[u + 1] - P.off2[u]);
+  if (uc) uc->reads += 1;
+  int cnt = 0;
+  if (nl == 0 || nr == 0) {
+    // orphans only when the other end found no seed k-mer at all (:880-901)
+    const int t = nl == 0 ? 1 : 0;
+    const bool otherMatched = nl == 0 ? lh : rh;
+    const u64* X = t == 0 ? LL : RR; const int nx = t == 0 ? nl : nr; const u32 ln = t == 0 ? l1 : l2;
+    if (!otherMatched && nx > 0) {
+      const int g = fz_groups(X, nx);
+      if (uc) { uc->se += (u64)g; uc->pe += (u64)g; }     // jointHits.size() is added to peHits as well (:1176-1179)
+      bool keep = g <= maxHits && !P.no_orphans;          // RapMapSAMapper.cpp:534-551
+      if (keep) {
+        for (int i = 0; i < nx;) {
+          FzGroup gr = fz_group(X, i, nx); i += gr.width;
+          qm_hit h = orphan_hit(gr.first, ln, t == 0 ? 1 : 2);
+          if (P.no_dovetail && dovetail(h)) continue;
+          if (out && cnt < cap) out[cnt] = h;
+          ++cnt;
+        }
+      }
+    }
+  } else {
+    int i = 0, j = 0, nm = 0, nkeep = 0;
+    bool tooMany = false;
+    while (i < nl && j < nr) {
+      FzGroup a = fz_group(LL, i, nl), b = fz_group(RR, j, nr);
+      if (a.tid < b.tid) { i += a.width; continue; }
+      if (b.tid < a.tid) { j += b.width; continue; }
+      int gFR = 0x7fffffff, gRF = 0x7fffffff;
+      const bool fwrc = fz_best(a.hasF, a.f, b.hasR, b.r, (int)l1, gFR);   // left fwd, right rc
+      const bool rcfw = fz_best(b.hasF, b.f, a.hasR, a.r, (int)l2, gRF);   // right fwd, left rc
+      if (fwrc || rcfw) {
+        int leftPos, rightPos; bool leftFwd;
+        if (fwrc && !(rcfw && gRF < gFR)) { leftPos = a.f; rightPos = b.r; leftFwd = true; }
+        else { leftPos = a.r; rightPos = b.f; leftFwd = false; }
+        int s1 = leftPos > 0 ? leftPos : 0, s2 = rightPos > 0 ? rightPos : 0;
+        bool r1First = s1 < s2;
+        int fragStart = r1First ? s1 : s2;
+        int fragEnd = r1First ? (int)((u32)s2 + l2) : (int)((u32)s1 + l1);
+        qm_hit h; h.tid = a.tid; h.pos = leftPos; h.mate_pos = rightPos; h.frag_len = (u32)(fragEnd - fragStart);
+        h.read_len = l1; h.mate_len = l2; h.fwd = leftFwd ? 1 : 0; h.mate_is_fwd = leftFwd ? 0 : 1;
+        h.is_paired = 1; h.mate_status = 3; h.aln_score = 0;
+        ++nm;
+        if (nm > maxHits) { tooMany = true; break; }      // :1153
+        if (!(P.no_dovetail && dovetail(h))) {
+          if (out && nkeep < cap) out[nkeep] = h;
+          ++nkeep;
+        }
+      }
+      i += a.width; j += b.width;
+    }
+    if (uc && tooMany) uc->tooMany += 1;
+    if (!tooMany && nm > 0) { if (uc) uc->pe += (u64)nm; cnt = nkeep; }
+  }
+  if (uc) { uc->tot += (u64)cnt; if (cnt > 0) uc->mapped += 1; }
+  return cnt;
+}
+
 // mergeLeftRightHits (RapMapUtils.hpp:1185-1264) + per-pair driver (RapMapSAMapper.cpp:461-551,684-701),
 // or the single-end driver (:232-250).  out == nullptr: count only (and add to the counters);
 // otherwise write the unit's hits to out[0..min(return, cap)), cap = the count pass's result.
 QM_DEV int unit_merge(const PairBatch& P, long long u, qm_hit* out, int cap, UnitCounters* uc) {
   const int maxHits = P.max_num_hits;
+  if (P.paired && P.fuzzy) return unit_merge_fuzzy(P, u, out, cap, uc);
   if (!P.paired) {
-    int n = (int)P.lcnt[u];
+    int n = (int)(P.lcnt[u] & 0x7fffffffu);
     const u64* X = P.lists + P.loff[u];
     u32 len = (u32)(P.off1[u + 1] - P.off1[u]);
     if (uc) { uc->reads += 1; uc->tot += (u64)n; }       // counted before the maxNumHits clear (:240-245)

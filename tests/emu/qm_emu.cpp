@@ -33,7 +33,7 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
   int status = 0; u64 cursor = 0;
   B.lcnt = lcnt.data(); B.loff = loff.data(); B.cursor = &cursor;
   B.gscratch = gs.data(); B.status = &status; B.dbg_ints = dints.data(); B.dbg_count = dcnt.data();
-  B.strict_check = o->strict_check; B.max_interval = o->max_interval; B.quasi_cov = o->quasi_cov; B.sensitive = o->sensitive;
+  B.strict_check = o->strict_check; B.max_interval = o->max_interval; B.quasi_cov = o->quasi_cov; B.sensitive = o->sensitive; B.fuzzy = (seq2 != nullptr) ? o->fuzzy : 0;
   while (true) {
     lists.assign((size_t)cap, 0);
     B.lists = lists.data(); B.lists_cap = cap; cursor = 0; status = 0;
@@ -55,7 +55,7 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
   u64 ctr[6] = {0, 0, 0, 0, 0, 0};
   P.n = nunits; P.paired = paired ? 1 : 0; P.off1 = off1; P.off2 = off2; P.lcnt = lcnt.data(); P.loff = loff.data();
   P.lists = lists.data(); P.cnt = hc.data(); P.offs = offs.data(); P.counters = ctr;
-  P.max_num_hits = o->max_num_hits; P.no_orphans = o->no_orphans; P.no_dovetail = o->no_dovetail;
+  P.max_num_hits = o->max_num_hits; P.no_orphans = o->no_orphans; P.no_dovetail = o->no_dovetail; P.fuzzy = o->fuzzy;
   UnitCounters uc = {0, 0, 0, 0, 0, 0};
   for (long long u = 0; u < nunits; ++u) hc[u] = (u32)unit_merge(P, u, nullptr, 0, &uc);
   hit_offsets[0] = 0;

@@ -19,6 +19,10 @@ VARIANTS = {
     "noSensitive": ({"sensitive": 0}, {"sensitive": 0}),
     "noSensitive_noStrict": ({"sensitive": 0, "strictCheck": 0}, {"sensitive": 0, "strict_check": 0}),
     "noSensitive_z0.8": ({"sensitive": 0, "quasiCov": 0.8}, {"sensitive": 0, "quasi_cov": 0.8}),
+    "fuzzy": ({"fuzzy": 1}, {"fuzzy": 1}),
+    "fuzzy_noOrphans_m3": ({"fuzzy": 1, "noOrphans": 1, "maxNumHits": 3}, {"fuzzy": 1, "no_orphans": 1, "max_num_hits": 3}),
+    "fuzzy_noDovetail": ({"fuzzy": 1, "noDovetail": 1}, {"fuzzy": 1, "no_dovetail": 1}),
+    "fuzzy_noSensitive": ({"fuzzy": 1, "sensitive": 0}, {"fuzzy": 1, "sensitive": 0}),
 }
 
 
@@ -114,6 +118,12 @@ def test_repeat_families(repeat_data, oracle_mod):
     assert res.counters["tooManyHits"] > 0 and res.counters["peHits"] > 0
     assert_hits_equal(res.hit_offsets, res.hits, er.hit_offsets, er.hits, "repeats")
     assert res.counters == er.counters
+    # fuzzy merge on the same reads (lists keep both orientations; orphans need the mate to have no seed at all)
+    fres = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(fuzzy=1), nthreads=4)
+    fer = em.map(q1, o1, q2, o2, opts=emu.default_opts(fuzzy=1))
+    assert fer.status == 0
+    assert_hits_equal(fres.hit_offsets, fres.hits, fer.hit_offsets, fer.hits, "repeats-fuzzy")
+    assert fres.counters == fer.counters
     _cmp_ints(res, er)
 
 

@@ -22,6 +22,10 @@ VARIANTS = {
     "noSensitive": ({"sensitive": 0}, {"sensitive": 0}),
     "noSensitive_noStrict": ({"sensitive": 0, "strictCheck": 0}, {"sensitive": 0, "strict_check": 0}),
     "noSensitive_z0.8": ({"sensitive": 0, "quasiCov": 0.8}, {"sensitive": 0, "quasi_cov": 0.8}),
+    "fuzzy": ({"fuzzy": 1}, {"fuzzy": 1}),
+    "fuzzy_noOrphans_m3": ({"fuzzy": 1, "noOrphans": 1, "maxNumHits": 3}, {"fuzzy": 1, "no_orphans": 1, "max_num_hits": 3}),
+    "fuzzy_noDovetail": ({"fuzzy": 1, "noDovetail": 1}, {"fuzzy": 1, "no_dovetail": 1}),
+    "fuzzy_noSensitive": ({"fuzzy": 1, "sensitive": 0}, {"fuzzy": 1, "sensitive": 0}),
 }
 
 
@@ -123,7 +127,7 @@ def test_edge_batches(synth_small, oracle_mod):
     with pytest.raises(ra.QmError, match="read length"):
         mp.map_pairs(q1, o1, q2, o2)
     q1, o1 = pack([b"ACGT" * 20]); q2, o2 = pack([b"ACGT" * 20])
-    for kw in ({"fuzzy": 1}, {"sel_aln": 1}):
+    for kw in ({"sel_aln": 1},):
         with pytest.raises(ra.QmError, match="not implemented"):
             mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(**kw))
 
@@ -197,6 +201,11 @@ def test_repeat_families(repeat_data, oracle_mod):
     assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "repeats")
     assert res.counters == gr.counters
     _cmp_ints(res, *mp.intervals(len(o1) - 1))
+    import rapmap_amd as ra
+    fres = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(fuzzy=1), nthreads=4)
+    fgr = mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(fuzzy=1))
+    assert_hits_equal(fres.hit_offsets, fres.hits, fgr.hit_offsets, fgr.hits, "repeats-fuzzy")
+    assert fres.counters == fgr.counters
 
 
 def test_perfect_hash_index(synth_small, synth_small_ph, oracle_mod):
