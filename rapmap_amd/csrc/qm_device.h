@@ -4,13 +4,13 @@
 #include <stddef.h>
 
 #define QMK_BLOCKS_PER_CU 8
-#define QMK_DEFAULT_WPS 5
+#define QMK_DEFAULT_WPS 8
 
 extern "C" {
 hipError_t qmk_build_sainfo(const int* SA, long long nSA, const int* offsets, long long T, void* out, hipStream_t st);
 hipError_t qmk_build_slots(const void* recs, long long K, void* slots, unsigned long long cap, hipStream_t st);
 int qmk_map_grid(long long n, int num_cu);
-hipError_t qmk_map_reads(const void* dev_index, const void* read_batch, int ns, int grid, hipStream_t st);
+hipError_t qmk_map_reads(const void* dev_index, const void* read_batch, int ns, int grid, int num_cu, hipStream_t st);
 hipError_t qmk_pair_count(const void* pair_batch, hipStream_t st);
 hipError_t qmk_pair_write(const void* pair_batch, hipStream_t st);
 size_t qmk_scan_temp_bytes(long long n);

@@ -466,7 +466,7 @@ int qm_map_device(qm_ctx* c, const qm_opts* o, int64_t n, const void* d_seq1, co
     B.strict_check = o->strict_check; B.max_interval = o->max_interval; B.quasi_cov = o->quasi_cov; B.sensitive = o->sensitive; B.fuzzy = (d_seq2 != nullptr) ? o->fuzzy : 0;
     HIPCHK(hipMemsetAsync(c->d_scal, 0, 16 * sizeof(u64), c->stream));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
-    if (nreads > 0) HIPCHK(qmk_map_reads(&ix, &B, ns, grid, c->stream));
+    if (nreads > 0) HIPCHK(qmk_map_reads(&ix, &B, ns, grid, c->numCU, c->stream));
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipMemcpyAsync(hscal, c->d_scal, 16 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));

@@ -111,11 +111,21 @@ int qmk_map_grid(long long nreads, int num_cu) {
   return (int)(want < cap ? (want > 0 ? want : 1) : cap);
 }
 
-hipError_t qmk_map_reads(const void* ixp, const void* bp, int ns, int grid, hipStream_t st) {
+// The kernel is a persistent grid (every wave strides over the reads), so the launch must not exceed what is
+// resident at once: blocks beyond residency would run as a second, under-populated round.  The occupancy of
+// the chosen instantiation (VGPR/LDS dependent) decides the grid.
+hipError_t qmk_map_reads(const void* ixp, const void* bp, int ns, int grid, int num_cu, hipStream_t st) {
   const DevIndex& ix = *(const DevIndex*)ixp;
   const ReadBatch& B = *(const ReadBatch*)bp;
   const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP);
-#define QM_LAUNCH(NS_, WPS_, F_) hipLaunchKernelGGL((qm_read_kernel<NS_, WPS_, F_>), dim3(grid), dim3(256), 0, st, ix, B)
+#define QM_LAUNCH(NS_, WPS_, F_) do {                                                                          \
+    static int nb = 0;                                                                                          \
+    if (nb == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, qm_read_kernel<NS_, WPS_, F_>, 256, 0) != hipSuccess || nb < 1)) \
+      nb = WPS_;                                                                                                \
+    long long g = (long long)num_cu * nb;                                                                       \
+    if (g > grid) g = grid;                                                                                     \
+    hipLaunchKernelGGL((qm_read_kernel<NS_, WPS_, F_>), dim3((unsigned)g), dim3(256), 0, st, ix, B);            \
+  } while (0)
   if (ns == 2) {
     switch (F) {
       case 0: QM_LAUNCH(2, QMK_DEFAULT_WPS, 0); break;

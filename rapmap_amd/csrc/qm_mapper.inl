@@ -110,7 +110,7 @@ template <int NS>
 struct WaveMem {
   u64 buf[3][QM_CAP];              // A, B (sort ping-pong), R (the read's hit list)
   Iv tab[2][64 * NS];              // seed interval of the k-mer at position p of the read / of reverseRead(read)
-  u64 planes[2][4][NS + 2];        // per strand: bit planes B0, B1 (2-bit codes), N mask, non-ACGT mask
+  u64 planes[2][4][NS + 2];        // per strand: packed 2-bit read (2 rows), N mask, non-ACGT mask
   IntRec ints[2][QM_ICAP];         // recorded SA-interval hits, fwd / rc strand
   alignas(8) unsigned char str[2][64 * NS + 16];   // read, reverseRead(read) (+16: 8-byte over-reads)
 };
@@ -194,12 +194,10 @@ QM_DEV u64 spread32(u64 x) {
 }
 // Kmer.hpp:92-100
 QM_DEV u64 word_rc(u64 w, int k) {
-  w = ((w >> 2) & 0x3333333333333333ULL) | ((w & 0x3333333333333333ULL) << 2);
-  w = ((w >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((w & 0x0F0F0F0F0F0F0F0FULL) << 4);
-  w = ((w >> 8) & 0x00FF00FF00FF00FFULL) | ((w & 0x00FF00FF00FF00FFULL) << 8);
-  w = ((w >> 16) & 0x0000FFFF0000FFFFULL) | ((w & 0x0000FFFF0000FFFFULL) << 16);
-  w = (w >> 32) | (w << 32);
-  return (~w) >> (2 * (32 - k));
+  // reversing all 64 bits reverses the base order and swaps the two bits of every base: swap them back
+  u64 r = brev64(w);
+  r = ((r >> 1) & 0x5555555555555555ULL) | ((r & 0x5555555555555555ULL) << 1);
+  return (~r) >> (2 * (32 - k));
 }
 // Kmer.hpp:484-487
 QM_DEV bool homopolymer(u64 w, int k) {
@@ -222,6 +220,14 @@ QM_DEV unsigned char rc_char(unsigned char c) {
 
 // Compile-time feature flags of a stage-A instantiation (the default dense + sensitive kernel carries none of
 // the optional code, which would otherwise cost it ~40 VGPRs and a whole wave per SIMD).
+// event counters of the lane-emulation build (tests/emu, -DQM_PROFILE): dynamic call counts per read, used with
+// the static instruction counts of each routine to see where the VALU issue slots go.  No-ops on the device.
+#if defined(QM_EMU) && defined(QM_PROFILE)
+extern unsigned long long qm_prof[32];
+#define QM_CNT(id, n) (qm_prof[id] += (unsigned long long)(n))
+#else
+#define QM_CNT(id, n) ((void)0)
+#endif
 #define QM_F_PH 1      // perfect-hash (-p) index
 #define QM_F_NIP 2     // --noSensitive: NIP skipping + k-mer vote
 
@@ -266,8 +272,10 @@ template <int F>
 QM_DEV bool find_kmer(const DevIndex& ix, u64 key, int& lb, int& ub) {
   if (!(F & QM_F_PH)) {
     u64 i = hash_mix(key) & ix.hmask;
+    QM_CNT(0, 1);
     while (true) {
       Slot x = ix.slots[i];
+      QM_CNT(1, 1);
       if (x.key == key) { lb = x.lb; ub = x.ub; return true; }
       if (x.key == ~0ULL) return false;
       i = (i + 1) & ix.hmask;
@@ -345,28 +353,40 @@ struct Strand {
   int P;
 };
 
-// k-mer word at position p of the strand (partial-word semantics of Kmer.hpp:535-538), plus window flags
+// LDS image of one strand ("planes", [4][NS+2] u64): rows 0-1 hold the read packed 2 bits per base,
+// 32 bases per word, first base in the highest bits (PK[0 .. 2NS], one zero word of padding); row 2 the
+// 'N' mask and row 3 the non-ACGT mask, one bit per base (NS words + two words of padding: 0 / ~0).
+//
+// k-mer word at position p of the strand (partial-word semantics of Kmer.hpp:535-538), plus window flags:
+// the word is a funnel shift of two adjacent packed words.
 template <int NS>
 QM_DEV u64 kmer_at(const u64* planes, int p, int k, bool& nwin, bool& nwin2, int& d) {
-  const u64* B0 = planes; const u64* B1 = planes + (NS + 2); const u64* NM = planes + 2 * (NS + 2); const u64* INV = planes + 3 * (NS + 2);
-  int s = p >> 6, l = p & 63;
-  u64 nmw = (NM[s] >> l) | (l ? (NM[s + 1] << (64 - l)) : 0ULL);
-  u64 ivw = (INV[s] >> l) | (l ? (INV[s + 1] << (64 - l)) : 0ULL);
-  u64 x0 = (B0[s] >> l) | (l ? (B0[s + 1] << (64 - l)) : 0ULL);
-  u64 x1 = (B1[s] >> l) | (l ? (B1[s + 1] << (64 - l)) : 0ULL);
+  const u64* PK = planes; const u64* NM = planes + 2 * (NS + 2); const u64* INV = planes + 3 * (NS + 2);
+  const int j = p >> 5, sh = 2 * (p & 31);
+  u64 w = ((PK[j] << sh) | ((PK[j + 1] >> 1) >> (63 - sh))) >> (64 - 2 * k);
+  const int s = p >> 6, l = p & 63;
+  const u64 nmw = (NM[s] >> l) | ((NM[s + 1] << 1) << (63 - l));
+  const u64 ivw = (INV[s] >> l) | ((INV[s + 1] << 1) << (63 - l));
   const u64 maskk = (1ULL << k) - 1, maskk1 = (1ULL << (k + 1)) - 1;
   nwin = (nmw & maskk) != 0; nwin2 = (nmw & maskk1) != 0;
-  d = ctz64(ivw | (1ULL << k));                // chars before the first non-ACGT one, capped at k
-  u64 keep = (1ULL << d) - 1;
-  x0 &= keep; x1 &= keep;
-  u64 r0 = brev64(x0) >> (64 - k), r1 = brev64(x1) >> (64 - k);
-  return spread32(r0) | (spread32(r1) << 1);
+  d = k;
+  if (ivw & maskk) {                           // rare: only the characters before the first non-ACGT one count
+    d = ctz64(ivw);
+    w &= ~0ULL << (2 * (k - d));
+  }
+  return w;
+}
+
+// 32 bases (bit b of c0/c1 = low/high code bit of base b) -> packed word, base 0 in the two highest bits
+QM_DEV u64 pack32(u32 c0, u32 c1) {
+  return spread32(brev64((u64)c0) >> 32) | (spread32(brev64((u64)c1) >> 32) << 1);
 }
 
 template <int NS>
 QM_DEV void setup_strand(const DevIndex& ix, const unsigned char* str, int L, Strand<NS>& S, u64* planes, Iv* tab) {
   const int k = ix.k;
   const int P = L - k + 1;
+  QM_CNT(2, 1);
   S.planes = planes; S.tab = tab; S.P = P;
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
@@ -384,12 +404,13 @@ QM_DEV void setup_strand(const DevIndex& ix, const unsigned char* str, int L, St
       iv[l] = !valid;
     }
     u64 m0 = ballot(b0), m1 = ballot(b1), m2 = ballot(nn), m3 = ballot(iv);
+    const u64 pk0 = pack32((u32)m0, (u32)m1), pk1 = pack32((u32)(m0 >> 32), (u32)(m1 >> 32));
     QM_LANES(l) {
-      if (l == 0) { planes[s] = m0; planes[(NS + 2) + s] = m1; planes[2 * (NS + 2) + s] = m2; planes[3 * (NS + 2) + s] = m3; }
+      if (l == 0) { planes[2 * s] = pk0; planes[2 * s + 1] = pk1; planes[2 * (NS + 2) + s] = m2; planes[3 * (NS + 2) + s] = m3; }
     }
   }
   QM_LANES(l) {
-    if (l < 2) { planes[NS + l] = 0; planes[(NS + 2) + NS + l] = 0; planes[2 * (NS + 2) + NS + l] = 0; planes[3 * (NS + 2) + NS + l] = ~0ULL; }
+    if (l < 2) { planes[2 * NS + l] = 0; planes[2 * (NS + 2) + NS + l] = 0; planes[3 * (NS + 2) + NS + l] = ~0ULL; }
   }
   wave_fence();
 #pragma unroll
@@ -417,6 +438,7 @@ QM_DEV void probe_window(const DevIndex& ix, Strand<NS>& S, int p, int width) {
   const int k = ix.k;
   if (p + width > S.P) width = S.P - p;
   if (width <= 0) return;
+  QM_CNT(3, 1); QM_CNT(4, width);
   LV<bool> found;
   QM_LANES(l) {
     int j = l & 31;
@@ -474,6 +496,7 @@ QM_DEV int cmp_from(const DevIndex& ix, long long s, const unsigned char* q, int
                     int& rel) {
   int b = i0;
   while (true) {
+    QM_CNT(16, 1);
     LV<bool> stopv; LV<int> relv;
     QM_LANES(l) {
       int idx = b + l;
@@ -507,6 +530,7 @@ QM_DEV bool extend_search_wide(const DevIndex& ix, int lbIn, int ubIn, int start
                                int& lbOut, int& ubOut, int& lenOut) {
   const int width = ubIn - lbIn - 1;
   if (width < 1 || width > 64) return false;
+  QM_CNT(5, 1); QM_CNT(6, width); QM_CNT(9, width == 1);
   LV<long long> sv; LV<int> lcp; LV<bool> act;
   QM_LANES(l) {
     bool a = l < width;
@@ -518,6 +542,7 @@ QM_DEV bool extend_search_wide(const DevIndex& ix, int lbIn, int ubIn, int start
   for (int i = startAt; i < m0; i += 8) {
     // wave-uniform 8 query bytes starting at q[i] (aligned reads + funnel shift; LDS rows are padded)
     const unsigned char* qa = q + i;
+    QM_CNT(7, 1);
     unsigned long long addr = (unsigned long long)qa;
     const u64* al = (const u64*)(addr & ~7ULL);
     int sh = (int)(addr & 7ULL) * 8;
@@ -558,6 +583,7 @@ QM_DEV void extend_search(const DevIndex& ix, int lbIn, int ubIn, int startAt, c
                           int& lbOut, int& ubOut, int& lenOut) {
   int rel;
   if (extend_search_wide(ix, lbIn, ubIn, startAt, q, m0, lbOut, ubOut, lenOut)) return;
+  QM_CNT(8, 1);
   if (ubIn - lbIn == 2) {                         // :109-126
     lbIn += 1;
     long long s = uniform((int)ix.SA[lbIn]);
@@ -653,6 +679,7 @@ QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, c
                         int startPos, bool haveInterval, int lb, int ub, long long& cov, u32& strandHits,
                         u32& otherHits, IntervalList& out) {
   const int k = ix.k, P = L - k + 1;
+  QM_CNT(17, 1);
   int p = startPos;
   bool skip = haveInterval, lastSearch = false;
   int prevMMPEnd = 0;
@@ -679,6 +706,7 @@ QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, c
     skip = false;
     lb = lb - 1 > 0 ? lb - 1 : 0;                      // :553
     int mlen;
+    QM_CNT(18, 1);
     extend_search(ix, lb, ub, k, str + p, L - p, lb, ub, mlen);
     const bool more = !lastSearch && p + mlen < L;     // the walk continues at kp after this MMP
     const int kp = p + mlen - (k - 1);
@@ -817,6 +845,7 @@ QM_DEV int el_pos(u64 e) { return (int)(u32)e; }
 
 // rank sort of n distinct-after-tiebreak u64 keys: out[rank(in[i])] = in[i]
 QM_DEV void rank_sort(const u64* in, u64* out, int n) {
+  QM_CNT(10, 1); QM_CNT(11, n);
   wave_fence();
   for (int base = 0; base < n; base += 64) {
     QM_LANES(l) {
@@ -858,6 +887,7 @@ struct Bufs { u64* A; u64* B; u64* R; };   // sort ping-pong + the read's output
 // collectFromSingleInterval (HitManager.cpp:716-807, considerMultiPos == false)
 QM_DEV int single_interval(const DevIndex& ix, const Bufs& bf, int rOff, int lb, int ub, u32 qpos, bool isRC) {
   int n = ub - lb;
+  QM_CNT(12, 1); QM_CNT(13, n);
   for (int base = 0; base < n; base += 64) {
     QM_LANES(l) {
       int i = base + l;
@@ -877,6 +907,7 @@ QM_DEV int single_interval(const DevIndex& ix, const Bufs& bf, int rOff, int lb,
 // consensusFraction == 1 (maxSlack 0), strictFilter off.
 QM_DEV int multi_interval(const DevIndex& ix, const Bufs& bf, int rOff, const IntervalList& ints, bool isRC) {
   const int m = ints.n;
+  QM_CNT(14, 1); QM_CNT(15, m);
   int minIdx = 0, minSpan = 0x7fffffff;
   for (int i = 0; i < m; ++i) {                       // first smallest span (:636-641)
     int lb, ub; u32 ln, qp; ints.get(i, lb, ub, ln, qp);

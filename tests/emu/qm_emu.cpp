@@ -4,6 +4,9 @@
 // CPU one wavefront at a time.  Used by tests/ (not gpu-marked) to check the wave
 // algorithm against the oracle without a GPU.  Never part of libqmap_mi355.so.
 #define QM_EMU 1
+#ifdef QM_PROFILE
+namespace qm { unsigned long long qm_prof[32]; }
+#endif
 #include "../../rapmap_amd/csrc/qm_mapper.inl"
 #include <cstdlib>
 #include <cstring>
@@ -12,6 +15,9 @@
 using namespace qm;
 
 extern "C" {
+#ifdef QM_PROFILE
+unsigned long long* qe_prof() { return qm::qm_prof; }   // event counters, see QM_CNT in qm_mapper.inl
+#endif
 
 // slots: cap x {u64 key, i32 lb, i32 ub}; sainfo: nSA x {u32 tid, i32 pos}; text padded by >= 64 bytes
 int qe_map(int k, const unsigned char* text, long long n, const int* SA, long long nSA, const void* sainfo,
