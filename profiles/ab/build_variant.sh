@@ -10,7 +10,7 @@ sed -i "s|#include \"../../include/qmap_mi355.h\"|#include \"$ROOT/include/qmap_
 [ -n "$PATCH" ] && python $PATCH $W
 cd $W
 FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -Wno-unused-value -Wno-unused-result"
-/opt/rocm/bin/hipcc $FL -c qm_kernels.hip -o k.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -A8 "qm_read_kernelILi2ELi5E" | grep -E "VGPRs:|VGPRs Spill|ScratchSize" | sed 's/.*remark: *//; s/\[-R.*//' | tr '\n' ' '
+/opt/rocm/bin/hipcc $FL -c qm_kernels.hip -o k.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -A12 "qm_read_kernelILi2ELi[0-9]ELi0E" | grep -E "VGPRs:|VGPRs Spill|SGPRs Spill|ScratchSize" | sed 's/.*remark: *//; s/\[-R.*//' | tr '\n' ' '
 echo " <= $NAME"
 /opt/rocm/bin/hipcc $FL -c qm_host.hip -o h.o
 g++ -O2 -std=c++17 -fPIC -I$ROOT/include -c qm_indexer.cpp -o i.o

@@ -4,7 +4,7 @@
 #include <stddef.h>
 
 #define QMK_BLOCKS_PER_CU 8
-#define QMK_DEFAULT_WPS 8
+#define QMK_DEFAULT_WPS 5
 
 extern "C" {
 hipError_t qmk_build_sainfo(const int* SA, long long nSA, const int* offsets, long long T, void* out, hipStream_t st);

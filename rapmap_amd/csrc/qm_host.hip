@@ -471,6 +471,13 @@ int qm_map_device(qm_ctx* c, const qm_opts* o, int64_t n, const void* d_seq1, co
     HIPCHK(hipMemcpyAsync(hscal, c->d_scal, 16 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     int status = (int)(hscal[8] & 0xffffffffu);
+#ifdef QM_TIMING
+    {
+      static const char* nm[7] = {"read->LDS", "strand setup", "probe windows", "extension", "collector rest", "hits->mappings", "write-out+loop"};
+      double tot = 0; for (int i = 0; i < 7; ++i) tot += (double)hscal[9 + i];
+      for (int i = 0; i < 7; ++i) fprintf(stderr, "[qm timing] %-16s %6.2f %%  %10.0f clk/read\n", nm[i], 100.0 * hscal[9 + i] / tot, (double)hscal[9 + i] / (double)nreads);
+    }
+#endif
     if (status & 4) return fail(QM_E_TOOLONG, "a read is longer than max_read_len=%d", max_read_len);
     if (status & 2) return fail(QM_E_UNSUPPORTED, "an SA-interval list exceeded %d entries (max_interval too large)", QM_GCAP);
     if (status & 1) {            // bump allocator ran out: grow and redo the batch

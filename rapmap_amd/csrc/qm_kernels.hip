@@ -28,7 +28,24 @@ __global__ __launch_bounds__(256, WPS) void qm_read_kernel(DevIndex ix, ReadBatc
   const long long nw = (long long)gridDim.x * 4;
   u64* gscr = B.gscratch + gw * QM_GSCR_U64;
   WaveAlloc wa; wa.base = -1; wa.used = 0;
-  for (long long r = gw; r < B.nreads; r += nw) map_read<NS, F>(ix, B, r, mem[wave], gscr, wa);
+#ifdef QM_TIMING
+  if ((threadIdx.x & 63) == 0) { for (int i = 0; i < 9; ++i) qm_tim[wave][i] = 0; qm_tim[wave][9] = __builtin_readcyclecounter(); }
+#endif
+  // reads r, r + nw, ...: characters of the next read and offsets of the one after are in flight while a read is mapped
+  ReadPre<NS> cur, nxt;
+  pre_offsets<NS>(B, gw, cur);
+  pre_chars<NS>(B, gw, cur);
+  pre_offsets<NS>(B, gw + nw, cur);
+  for (long long r = gw; r < B.nreads; r += nw) {
+    nxt = cur;
+    pre_chars<NS>(B, r + nw, nxt);
+    pre_offsets<NS>(B, r + 2 * nw, nxt);
+    map_read<NS, F>(ix, B, r, cur, mem[wave], gscr, wa);
+    cur = nxt;
+  }
+#ifdef QM_TIMING
+  if ((threadIdx.x & 63) == 0) for (int i = 0; i < 7; ++i) atomicAdd((unsigned long long*)&B.cursor[9 + i], (unsigned long long)qm_tim[wave][i]);
+#endif
 }
 
 // stage B pass 1: hits per unit + the HitCounters

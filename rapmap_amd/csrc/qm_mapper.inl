@@ -228,6 +228,16 @@ extern unsigned long long qm_prof[32];
 #else
 #define QM_CNT(id, n) ((void)0)
 #endif
+// phase timers of a -DQM_TIMING device build (profiles/ab): QM_T(id) charges the shader-clock time since the wave's
+// previous mark to phase id (0 read->LDS, 1 strand setup, 2 hash probe windows, 3 MMP extension, 4 rest of the
+// collector, 5 hits->mappings, 6 list write-out + loop); the kernel adds the per-wave sums to B.cursor[9..15].
+#if defined(QM_TIMING) && !defined(QM_EMU)
+__shared__ u64 qm_tim[4][10];
+#define QM_T(id) do { u64 t_ = __builtin_readcyclecounter(); int w_ = (int)(threadIdx.x >> 6);                  \
+    if ((threadIdx.x & 63) == 0) { qm_tim[w_][id] += t_ - qm_tim[w_][9]; qm_tim[w_][9] = t_; } } while (0)
+#else
+#define QM_T(id) ((void)0)
+#endif
 #define QM_F_PH 1      // perfect-hash (-p) index
 #define QM_F_NIP 2     // --noSensitive: NIP skipping + k-mer vote
 
@@ -274,10 +284,11 @@ QM_DEV bool find_kmer(const DevIndex& ix, u64 key, int& lb, int& ub) {
     u64 i = hash_mix(key) & ix.hmask;
     QM_CNT(0, 1);
     while (true) {
-      Slot x = ix.slots[i];
+      const U4 x = load_16(&ix.slots[i]);               // {key lo, key hi, lb, ub}
+      const u64 xk = ((u64)x.y << 32) | x.x;
       QM_CNT(1, 1);
-      if (x.key == key) { lb = x.lb; ub = x.ub; return true; }
-      if (x.key == ~0ULL) return false;
+      if (xk == key) { lb = (int)x.z; ub = (int)x.w; return true; }
+      if (xk == ~0ULL) return false;
       i = (i + 1) & ix.hmask;
     }
   }
@@ -335,7 +346,7 @@ template <int NS> QM_DEV void or_field(Bits<NS>& b, int p, u64 v) {   // b |= v 
   }
 }
 
-// One strand of one read.  E/E2/AV depend on the characters only and are built once; F/C/K are filled
+// One strand of one read.  E/E2 depend on the characters only and are built once; F/C/K are filled
 // window by window: the reference consults the hash only at the positions its MMP walk visits
 // (~47 finds per read instead of the 2(L-k+1) of an exhaustive pre-probe), and every probe is a random
 // 64-byte sector from HBM -- the resource this kernel is bound by (profiles/).
@@ -343,7 +354,6 @@ template <int NS>
 struct Strand {
   Bits<NS> E;    // eligible in getSAHits_: no N in [p,p+k), not a homopolymer (SACollector.hpp:498-536)
   Bits<NS> E2;   // eligible in the first-hit scan: no N in [p,p+k] (:176-192, note the <=)
-  Bits<NS> AV;   // all k characters are ACGT (fromChars succeeds, :602)
   Bits<NS> K;    // positions whose F / C bits are known
   Bits<NS> F;    // khash.find(mer) hit
   Bits<NS> C;    // khash.find(mer.getRC()) hit
@@ -377,45 +387,41 @@ QM_DEV u64 kmer_at(const u64* planes, int p, int k, bool& nwin, bool& nwin2, int
   return w;
 }
 
-// 32 bases (bit b of c0/c1 = low/high code bit of base b) -> packed word, base 0 in the two highest bits
-QM_DEV u64 pack32(u32 c0, u32 c1) {
-  return spread32(brev64((u64)c0) >> 32) | (spread32(brev64((u64)c1) >> 32) << 1);
-}
-
 template <int NS>
 QM_DEV void setup_strand(const DevIndex& ix, const unsigned char* str, int L, Strand<NS>& S, u64* planes, Iv* tab) {
   const int k = ix.k;
   const int P = L - k + 1;
-  QM_CNT(2, 1);
+  QM_CNT(2, 1); QM_T(4);
   S.planes = planes; S.tab = tab; S.P = P;
+  QM_LANES(l) {
+    if (l < 2 * NS + 2) planes[l] = 0;                                   // packed words (+ padding)
+    if (l < 2) { planes[2 * (NS + 2) + NS + l] = 0; planes[3 * (NS + 2) + NS + l] = ~0ULL; }
+  }
+  wave_fence();
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    LV<bool> b0, b1, nn, iv;
+    LV<bool> nn, iv;
     QM_LANES(l) {
       int idx = 64 * s + l;
       unsigned char c = idx < L ? str[idx] : 0;
       unsigned char cl = c | 0x20;
       bool valid = idx < L && (cl == 'a' || cl == 'c' || cl == 'g' || cl == 't');
       int x = (c >> 1) & 3;
-      int code = x ^ (x >> 1);   // A0 C1 G2 T3 (Kmer.hpp:40-51)
-      b0[l] = valid && (code & 1);
-      b1[l] = valid && (code & 2);
+      u64 code = (u64)(x ^ (x >> 1));   // A0 C1 G2 T3 (Kmer.hpp:40-51)
+      // every lane ORs its 2-bit code into the packed word (one LDS atomic instead of a scalar bit interleave)
+      if (valid && code) atomic_or_u64(&planes[idx >> 5], code << (62 - 2 * (idx & 31)));
       nn[l] = idx < L && cl == 'n';
       iv[l] = !valid;
     }
-    u64 m0 = ballot(b0), m1 = ballot(b1), m2 = ballot(nn), m3 = ballot(iv);
-    const u64 pk0 = pack32((u32)m0, (u32)m1), pk1 = pack32((u32)(m0 >> 32), (u32)(m1 >> 32));
+    u64 m2 = ballot(nn), m3 = ballot(iv);
     QM_LANES(l) {
-      if (l == 0) { planes[2 * s] = pk0; planes[2 * s + 1] = pk1; planes[2 * (NS + 2) + s] = m2; planes[3 * (NS + 2) + s] = m3; }
+      if (l == 0) { planes[2 * (NS + 2) + s] = m2; planes[3 * (NS + 2) + s] = m3; }
     }
-  }
-  QM_LANES(l) {
-    if (l < 2) { planes[2 * NS + l] = 0; planes[2 * (NS + 2) + NS + l] = 0; planes[3 * (NS + 2) + NS + l] = ~0ULL; }
   }
   wave_fence();
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    LV<bool> e, e2, av;
+    LV<bool> e, e2;
     QM_LANES(l) {
       int p = 64 * s + l;
       bool nwin, nwin2; int d;
@@ -424,11 +430,21 @@ QM_DEV void setup_strand(const DevIndex& ix, const unsigned char* str, int L, St
       bool inP = p < P;
       e[l] = inP && !nwin && !hom;
       e2[l] = inP && !nwin2 && !hom;
-      av[l] = inP && d >= k;
     }
-    S.E.w[s] = ballot(e); S.E2.w[s] = ballot(e2); S.AV.w[s] = ballot(av);
+    S.E.w[s] = ballot(e); S.E2.w[s] = ballot(e2);
     S.K.w[s] = 0; S.F.w[s] = 0; S.C.w[s] = 0; S.V.w[s] = 0;
   }
+  QM_T(1);
+}
+
+// all k characters at [p, p+k) are ACGT, i.e. Kmer::fromChars succeeds (SACollector.hpp:602); p is wave-uniform
+template <int NS>
+QM_DEV bool all_acgt(const Strand<NS>& S, int p, int k) {
+  if (p >= S.P) return false;
+  const u64* INV = S.planes + 3 * (NS + 2);
+  const int s = p >> 6, l = p & 63;
+  const u64 ivw = uniform((INV[s] >> l) | ((INV[s + 1] << 1) << (63 - l)));
+  return (ivw & ((1ULL << k) - 1)) == 0;
 }
 
 // Probe positions [p, p+width) (width <= 32): lanes 0..31 look up the k-mer, lanes 32..63 its reverse
@@ -438,7 +454,7 @@ QM_DEV void probe_window(const DevIndex& ix, Strand<NS>& S, int p, int width) {
   const int k = ix.k;
   if (p + width > S.P) width = S.P - p;
   if (width <= 0) return;
-  QM_CNT(3, 1); QM_CNT(4, width);
+  QM_CNT(3, 1); QM_CNT(4, width); QM_T(4);
   LV<bool> found;
   QM_LANES(l) {
     int j = l & 31;
@@ -462,6 +478,7 @@ QM_DEV void probe_window(const DevIndex& ix, Strand<NS>& S, int p, int width) {
   or_field(S.C, p, (fm >> 32) & wm);
   or_field(S.K, p, wm);
   wave_fence();
+  QM_T(2);
 }
 
 // first position >= p that is NOT yet probed (or 64*NS)
@@ -706,8 +723,9 @@ QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, c
     skip = false;
     lb = lb - 1 > 0 ? lb - 1 : 0;                      // :553
     int mlen;
-    QM_CNT(18, 1);
+    QM_CNT(18, 1); QM_T(4);
     extend_search(ix, lb, ub, k, str + p, L - p, lb, ub, mlen);
+    QM_T(3);
     const bool more = !lastSearch && p + mlen < L;     // the walk continues at kp after this MMP
     const int kp = p + mlen - (k - 1);
     if (ub > lb && ub - lb < B.max_interval) {          // :577-618
@@ -716,7 +734,7 @@ QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, c
       cov += mlen - corr;
       prevMMPEnd = p + mlen;
       if (p + mlen < L) {
-        if (V.AV.test(kp)) {
+        if (all_acgt(V, kp, k)) {
           if (!V.K.test(kp)) probe_window<NS, F>(ix, V, kp, (more && !(F & QM_F_NIP)) ? 32 : 1);
           strandHits += V.F.test(kp) ? 1u : 0u; otherHits += V.C.test(kp) ? 1u : 0u;
           if (((F & QM_F_NIP) != 0)) set_bit(V.V, kp);
@@ -1058,31 +1076,76 @@ QM_DEV void dump_intervals(const ReadBatch& B, long long read, int list, const I
 // One read: load -> collect -> hits->mappings -> list to global memory.
 struct WaveAlloc { long long base; int used; };   // the wave's current chunk of B.lists (wave-uniform)
 
-template <int NS, int F>
-QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, WaveMem<NS>& M, u64* gscr, WaveAlloc& wa) {
+// Software pipeline of the persistent loop: the offsets of the read after next and the characters of the next
+// read are requested before the current read is processed, so the two dependent round trips that start a read
+// (offsets -> characters) overlap with the previous read's work.
+template <int NS>
+struct ReadPre {
+  long long o0; int len;       // next read: start offset and length (uniform)
+  long long p0, p1;            // read after next: offsets (uniform once consumed)
+  LV<u32> chars;               // lane l: characters 64*s + l of the next read, s = 0..NS-1, one byte each
+};
+QM_DEV void read_src(const ReadBatch& B, long long read, const unsigned char*& src, const long long*& off, long long& unit) {
   const bool paired = B.seq2 != nullptr;
   const int mate = paired ? (int)(read & 1) : 0;
-  const long long unit = paired ? (read >> 1) : read;
-  const unsigned char* src = mate == 0 ? B.seq1 : B.seq2;
-  const long long* off = mate == 0 ? B.off1 : B.off2;
-  long long o0 = uniform(off[unit]), o1 = uniform(off[unit + 1]);
+  unit = paired ? (read >> 1) : read;
+  src = mate == 0 ? B.seq1 : B.seq2;
+  off = mate == 0 ? B.off1 : B.off2;
+}
+// request the offsets of `read` (no use of the result here)
+template <int NS>
+QM_DEV void pre_offsets(const ReadBatch& B, long long read, ReadPre<NS>& P) {
+  P.p0 = 0; P.p1 = 0;
+  if (read >= B.nreads) return;
+  const unsigned char* src; const long long* off; long long unit;
+  read_src(B, read, src, off, unit);
+  P.p0 = off[unit]; P.p1 = off[unit + 1];
+}
+// turn the pending offsets (which belong to `read`) into character loads
+template <int NS>
+QM_DEV void pre_chars(const ReadBatch& B, long long read, ReadPre<NS>& P) {
+  P.o0 = 0; P.len = 0;
+  QM_LANES(l) { P.chars[l] = 0; }
+  if (read >= B.nreads) return;
+  const unsigned char* src; const long long* off; long long unit;
+  read_src(B, read, src, off, unit);
+  const long long o0 = uniform(P.p0), o1 = uniform(P.p1);
   int len = (int)(o1 - o0);
+  P.o0 = o0; P.len = len;
+  if (len > 64 * NS) len = 64 * NS;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    QM_LANES(l) {
+      int idx = 64 * s + l;
+      if (idx < len) P.chars[l] |= (u32)src[o0 + idx] << (8 * s);
+    }
+  }
+}
+
+template <int NS, int F>
+QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, const ReadPre<NS>& pre, WaveMem<NS>& M, u64* gscr, WaveAlloc& wa) {
+  const bool paired = B.seq2 != nullptr;
+  const int mate = paired ? (int)(read & 1) : 0;
+  int len = pre.len;
   if (len > 64 * NS) { QM_LANES(l) { if (l == 0) *B.status |= 4; } len = 64 * NS; }
   unsigned char* fs = M.str[0];
   unsigned char* rs = M.str[1];
+  QM_T(6);
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     QM_LANES(l) {
       int idx = 64 * s + l;
       // the forward read is kept upper-cased (every consumer applies ::toupper anyway, SASearcher.hpp:111,155)
-      if (idx < len) { unsigned char c = src[o0 + idx]; fs[idx] = (unsigned char)upc(c); rs[len - 1 - idx] = rc_char(c); }
+      if (idx < len) { unsigned char c = (unsigned char)(pre.chars[l] >> (8 * s)); fs[idx] = (unsigned char)upc(c); rs[len - 1 - idx] = rc_char(c); }
     }
   }
   wave_fence();
+  QM_T(0);
   IntervalList fi, ri;
   fi.lds = M.ints[0]; ri.lds = M.ints[1];
   fi.ovf = (IntRec*)(gscr + 3 * QM_GCAP); ri.ovf = fi.ovf + QM_IOVF;
   const bool foundHit = collect_read<NS, F>(ix, B, M, len, fi, ri);
+  QM_T(4);
   if (B.dbg_ints) {
     int dbg = 0;
     dump_intervals(B, read, 2 * mate, fi, dbg); dump_intervals(B, read, 2 * mate + 1, ri, dbg);
@@ -1098,6 +1161,7 @@ QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, Wav
   } else {
     n = hits_to_mappings(ix, bf, fi, ri, B.fuzzy != 0);
   }
+  QM_T(5);
   // hand the list to stage B.  One returning atomic on a single word saturates at ~88 M/s on this chip
   // (MI355X_MICROARCH.md "dequeue"), far below the read rate, so a wave reserves QM_CHUNK elements at
   // a time and sub-allocates from its chunk.
@@ -1115,6 +1179,7 @@ QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, Wav
   for (int b0 = 0; b0 < n; b0 += 64) { QM_LANES(l) { int i = b0 + l; if (i < n) B.lists[base + i] = bf.R[i]; } }
   const u32 flag = (B.fuzzy && foundHit) ? 0x80000000u : 0u;      // lh / rh of RapMapSAMapper.cpp:472-478
   QM_LANES(l) { if (l == 0) { B.lcnt[read] = (u32)n | flag; B.loff[read] = base; } }
+  QM_T(6);
 }
 
 // ------------------------------------------------------------------ stage B: one thread per unit

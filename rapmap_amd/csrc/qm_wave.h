@@ -51,6 +51,7 @@ QM_DEV u64 brev64(u64 x) {
 }
 QM_DEV void wave_fence() {}
 QM_DEV void atomic_min_u64(u64* p, u64 v) { if (v < *p) *p = v; }
+QM_DEV void atomic_or_u64(u64* p, u64 v) { *p |= v; }
 QM_DEV u64 atomic_add_u64(u64* p, u64 v) { u64 o = *p; *p = o + v; return o; }
 template <typename T> QM_DEV T uniform(T x) { return x; }
 #else
@@ -67,6 +68,7 @@ QM_DEV u64 brev64(u64 x) { return __brevll(x); }
 // orders this wave's LDS / global accesses across lanes (same-wave RAW through memory)
 QM_DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 QM_DEV void atomic_min_u64(u64* p, u64 v) { atomicMin(p, v); }
+QM_DEV void atomic_or_u64(u64* p, u64 v) { atomicOr(p, v); }
 QM_DEV u64 atomic_add_u64(u64* p, u64 v) { return atomicAdd(p, v); }
 // tell the compiler a value is wave-uniform (keeps control flow on the scalar unit)
 QM_DEV int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
@@ -90,6 +92,8 @@ QM_DEV u64 mulhi64(u64 a, u64 b) { return __umul64hi(a, b); }
 QM_DEV int wave_max(const LV<int>& x) { int m = x.v[0]; for (int l = 1; l < 64; ++l) m = x.v[l] > m ? x.v[l] : m; return m; }
 QM_DEV int clz64(u64 x) { return x ? __builtin_clzll(x) : 64; }
 QM_DEV u64 load_u64_unaligned(const unsigned char* p) { u64 v; __builtin_memcpy(&v, p, 8); return v; }
+struct U4 { u32 x, y, z, w; };
+QM_DEV U4 load_16(const void* p) { U4 v; __builtin_memcpy(&v, p, 16); return v; }
 #else
 QM_DEV int wave_max(const LV<int>& x) {
   int v = x.v[0];
@@ -99,6 +103,13 @@ QM_DEV int wave_max(const LV<int>& x) {
 }
 QM_DEV int clz64(u64 x) { return x ? __builtin_clzll(x) : 64; }
 QM_DEV u64 load_u64_unaligned(const unsigned char* p) { u64 v; __builtin_memcpy(&v, p, 8); return v; }
+// one 16-byte load that the compiler cannot split into a key load plus a dependent value load
+struct U4 { u32 x, y, z, w; };
+QM_DEV U4 load_16(const void* p) {
+  typedef u32 v4u __attribute__((ext_vector_type(4)));
+  v4u q = *(const v4u*)p;
+  U4 v; v.x = q.x; v.y = q.y; v.z = q.z; v.w = q.w; return v;
+}
 #endif
 
 QM_DEV u64 lanemask_lt(int l) { return l ? (~0ULL >> (64 - l)) : 0ULL; }

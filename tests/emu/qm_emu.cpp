@@ -48,7 +48,8 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
     for (auto& w : wa) { w.base = -1; w.used = 0; }
     for (long long r = 0; r < nreads; ++r) {
       const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP);
-#define QE_CALL(NS_, F_) { static WaveMem<NS_> M; map_read<NS_, F_>(ix, B, r, M, gs.data(), wa[r % 7]); }
+#define QE_CALL(NS_, F_) { static WaveMem<NS_> M; ReadPre<NS_> pre; pre_offsets<NS_>(B, r, pre); pre_chars<NS_>(B, r, pre); \
+                           pre_offsets<NS_>(B, r + 7, pre); map_read<NS_, F_>(ix, B, r, pre, M, gs.data(), wa[r % 7]); }
       if (ns == 2) { switch (F) { case 0: QE_CALL(2, 0) break; case 1: QE_CALL(2, 1) break; case 2: QE_CALL(2, 2) break; default: QE_CALL(2, 3) break; } }
       else { switch (F) { case 0: QE_CALL(4, 0) break; case 1: QE_CALL(4, 1) break; case 2: QE_CALL(4, 2) break; default: QE_CALL(4, 3) break; } }
 #undef QE_CALL
