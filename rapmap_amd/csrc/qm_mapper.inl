@@ -541,56 +541,75 @@ QM_DEV int cmp_from(const DevIndex& ix, long long s, const unsigned char* q, int
 // as a prefix.  The one case where the reference's loop deviates -- a suffix running off the END of
 // the text, SASearcher.hpp:154,180 -- needs the query to match the text's final '$'; queries that
 // contain '$' therefore take the literal path below.)
-// Every lane owns one suffix: one coalesced SA load, then 8 text bytes per step against a
-// wave-uniform 8-byte query word -- 2 dependent loads instead of ~2 per binary-search step.
+// The wave is split into groups of G = 64 / 2^ceil(log2(width)) lanes, one group per suffix; lane c of a group
+// compares the 16 bytes at offset 16c of the current round, so a 2x100 bp read needs one round for up to 8
+// suffixes: one coalesced SA load, then one round of text loads, instead of a dependent load per 8 bytes.
 QM_DEV bool extend_search_wide(const DevIndex& ix, int lbIn, int ubIn, int startAt, const unsigned char* q, int m0,
                                int& lbOut, int& ubOut, int& lenOut) {
   const int width = ubIn - lbIn - 1;
   if (width < 1 || width > 64) return false;
   QM_CNT(5, 1); QM_CNT(6, width); QM_CNT(9, width == 1);
+  int lg = 0;
+  while ((1 << lg) < width) ++lg;
+  const int gs = 6 - lg, G = 1 << gs;                 // lanes per suffix
   LV<long long> sv; LV<int> lcp; LV<bool> act;
   QM_LANES(l) {
-    bool a = l < width;
-    sv[l] = a ? (long long)ix.SA[lbIn + 1 + l] : 0;
-    lcp[l] = a ? startAt : -1;
+    const int j = l >> gs;
+    bool a = j < width;
+    sv[l] = a ? (long long)ix.SA[lbIn + 1 + j] : 0;
+    lcp[l] = a ? 0x7fffffff : -1;                     // 0x7fffffff: still matching
     act[l] = a;
   }
-  bool dollar = false;
-  for (int i = startAt; i < m0; i += 8) {
-    // wave-uniform 8 query bytes starting at q[i] (aligned reads + funnel shift; LDS rows are padded)
-    const unsigned char* qa = q + i;
+  for (int i0 = startAt; ; i0 += 16 * G) {
     QM_CNT(7, 1);
-    unsigned long long addr = (unsigned long long)qa;
-    const u64* al = (const u64*)(addr & ~7ULL);
-    int sh = (int)(addr & 7ULL) * 8;
-    u64 lo = al[0], hi = al[1];
-    u64 qw = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
-    qw = uniform(qw);
-    int nb = m0 - i < 8 ? m0 - i : 8;
-    u64 valid = nb == 8 ? ~0ULL : ((1ULL << (8 * nb)) - 1);
-    // any '$' among the valid query bytes?  (haszero trick on qw ^ 0x24..24)
-    u64 z = (qw ^ 0x2424242424242424ULL) | ~valid;
-    if (((z - 0x0101010101010101ULL) & ~z & 0x8080808080808080ULL) != 0) dollar = true;
+    LV<int> cand; LV<bool> dol;
+    QM_LANES(l) {
+      int cd = 0x7fffffff; bool dl = false;
+      if (act[l] && lcp[l] == 0x7fffffff) {
+        const int off = i0 + 16 * (l & (G - 1));
+        int nb = m0 - off; nb = nb > 16 ? 16 : nb;
+        int cnt = 0;
+        if (nb > 0) {
+          // 16 query bytes at q[off]: aligned LDS words + funnel shift (rows are padded for the over-read)
+          const unsigned long long addr = (unsigned long long)(q + off);
+          const u64* al = (const u64*)(addr & ~7ULL);
+          const int sh = (int)(addr & 7ULL) * 8;
+          const u64 w0 = al[0], w1 = al[1], w2 = al[2];
+          const u64 q0 = (w0 >> sh) | ((w1 << 1) << (63 - sh)), q1 = (w1 >> sh) | ((w2 << 1) << (63 - sh));
+          const u64 v0 = nb >= 8 ? ~0ULL : ((1ULL << (8 * nb)) - 1);
+          const u64 v1 = nb >= 16 ? ~0ULL : (nb > 8 ? ((1ULL << (8 * (nb - 8))) - 1) : 0ULL);
+          // any '$' among the valid query bytes?  (haszero trick on q ^ 0x24..24)
+          const u64 z0 = (q0 ^ 0x2424242424242424ULL) | ~v0, z1 = (q1 ^ 0x2424242424242424ULL) | ~v1;
+          dl = (((z0 - 0x0101010101010101ULL) & ~z0) | ((z1 - 0x0101010101010101ULL) & ~z1)) & 0x8080808080808080ULL;
+          long long tv = ix.n - (sv[l] + off);            // text bytes left (the array is padded for the over-read)
+          if (tv > 0) {
+            const u64 t0 = load_u64_unaligned(ix.text + sv[l] + off), t1 = load_u64_unaligned(ix.text + sv[l] + off + 8);
+            const u64 x0 = t0 ^ q0, x1 = t1 ^ q1;
+            cnt = x0 ? (ctz64(x0) >> 3) : (x1 ? 8 + (ctz64(x1) >> 3) : 16);
+            if (cnt > nb) cnt = nb;
+            if ((long long)cnt > tv) cnt = (int)tv;
+          }
+        }
+        if (cnt < 16) cd = off + cnt;                    // this chunk ends the match (mismatch, end of query or text)
+      }
+      cand[l] = cd; dol[l] = dl;
+    }
+    if (ballot(dol)) return false;
+    group_min(cand, G);
     LV<bool> cont;
     QM_LANES(l) {
       bool c = false;
-      if (act[l] && lcp[l] == i) {
-        u64 tw = load_u64_unaligned(ix.text + sv[l] + i);
-        u64 x = (tw ^ qw) & valid;
-        if (x) lcp[l] = i + (ctz64(x) >> 3);
-        else { lcp[l] = i + nb; c = nb == 8; }
-      }
+      if (act[l] && lcp[l] == 0x7fffffff) { if (cand[l] != 0x7fffffff) lcp[l] = cand[l]; else c = true; }
       cont[l] = c;
     }
-    if (dollar) return false;
     if (!ballot(cont)) break;
   }
   int mx = wave_max(lcp);
   LV<bool> best;
-  QM_LANES(l) { best[l] = act[l] && lcp[l] == mx; }
+  QM_LANES(l) { best[l] = act[l] && (l & (G - 1)) == 0 && lcp[l] == mx; }
   u64 bm = ballot(best);
-  lbOut = lbIn + 1 + ctz64(bm);
-  ubOut = lbIn + 1 + (63 - clz64(bm)) + 1;
+  lbOut = lbIn + 1 + (ctz64(bm) >> gs);
+  ubOut = lbIn + 1 + ((63 - clz64(bm)) >> gs) + 1;
   lenOut = mx;
   return true;
 }
@@ -810,7 +829,15 @@ QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M,
   }
   bool checkFwd = useCoverageCheck ? (fwdHit > 0) : (fwdHit >= rcHit);
   if (!didCheckFwd && checkFwd) {                       // :271-278
-    get_sa_hits<NS, F>(ix, B, S, fwdStr, L, 0, false, 0, 0, fwdCov, fwdHit, rcHit, fwdInts);
+    if (!(F & QM_F_NIP)) {
+      // rare (forward k-mers first seen while walking the reverse complement): rebuild the forward strand's
+      // masks instead of keeping them in registers across the whole reverse-complement pass
+      Strand<NS> S2;
+      setup_strand<NS>(ix, fwdStr, L, S2, &M.planes[0][0][0], M.tab[0]);
+      get_sa_hits<NS, F>(ix, B, S2, fwdStr, L, 0, false, 0, 0, fwdCov, fwdHit, rcHit, fwdInts);
+    } else {
+      get_sa_hits<NS, F>(ix, B, S, fwdStr, L, 0, false, 0, 0, fwdCov, fwdHit, rcHit, fwdInts);
+    }
   }
   if (useCoverageCheck) {                               // :283-288 (slack 0)
     if (fwdCov > rcCov) rcInts.n = 0;

@@ -90,6 +90,14 @@ QM_DEV u64 mulhi64(u64 a, u64 b) { return __umul64hi(a, b); }
 
 #ifdef QM_EMU
 QM_DEV int wave_max(const LV<int>& x) { int m = x.v[0]; for (int l = 1; l < 64; ++l) m = x.v[l] > m ? x.v[l] : m; return m; }
+// every lane gets the minimum over its aligned group of G lanes (G a power of two, wave-uniform)
+QM_DEV void group_min(LV<int>& x, int G) {
+  for (int b = 0; b < 64; b += G) {
+    int m = x.v[b];
+    for (int l = b + 1; l < b + G; ++l) m = x.v[l] < m ? x.v[l] : m;
+    for (int l = b; l < b + G; ++l) x.v[l] = m;
+  }
+}
 QM_DEV int clz64(u64 x) { return x ? __builtin_clzll(x) : 64; }
 QM_DEV u64 load_u64_unaligned(const unsigned char* p) { u64 v; __builtin_memcpy(&v, p, 8); return v; }
 struct U4 { u32 x, y, z, w; };
@@ -100,6 +108,11 @@ QM_DEV int wave_max(const LV<int>& x) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
   return __builtin_amdgcn_readfirstlane(v);
+}
+QM_DEV void group_min(LV<int>& x, int G) {
+  int v = x.v[0];
+  for (int o = 1; o < G; o <<= 1) { int t = __shfl_xor(v, o, 64); v = t < v ? t : v; }
+  x.v[0] = v;
 }
 QM_DEV int clz64(u64 x) { return x ? __builtin_clzll(x) : 64; }
 QM_DEV u64 load_u64_unaligned(const unsigned char* p) { u64 v; __builtin_memcpy(&v, p, 8); return v; }
