@@ -350,9 +350,9 @@ int qm_ctx_create(const qm_index* ix, int device_id, qm_ctx** out) {
   CK(hipMemcpyAsync(d_offsets, ix->offsets, (size_t)ix->nTxp * 4, hipMemcpyHostToDevice, c->stream));
   CK(qmk_build_sainfo(c->d_SA, ix->nSA, d_offsets, ix->nTxp, c->d_sainfo, c->stream));
   if (!ix->perfect) {
-    c->cap = 16;
-    while (c->cap < (uint64_t)ix->nKeys * 2) c->cap <<= 1;
-    CK(hipMalloc(&c->d_slots, c->cap * sizeof(Slot)));
+    c->cap = 16;                                       // buckets of four slots: load factor <= 25 %
+    while (c->cap < (uint64_t)ix->nKeys) c->cap <<= 1;
+    CK(hipMalloc(&c->d_slots, c->cap * sizeof(Bucket)));
     CK(hipMalloc(&d_recs, (size_t)(ix->nKeys > 0 ? ix->nKeys : 1) * 16));
     if (ix->nKeys > 0) CK(hipMemcpyAsync(d_recs, ix->hashRecs, (size_t)ix->nKeys * 16, hipMemcpyHostToDevice, c->stream));
     CK(qmk_build_slots(d_recs, ix->nKeys, c->d_slots, c->cap, c->stream));
@@ -402,7 +402,7 @@ int qm_ctx_create(const qm_index* ix, int device_id, qm_ctx** out) {
   CK(hipMalloc((void**)&c->d_scal, 16 * sizeof(u64)));
   CK(hipStreamSynchronize(c->stream));
   hipFree(d_offsets); if (d_recs) hipFree(d_recs);
-  c->devBytes += ix->n + pad + ix->nSA * 4 + ix->nSA * (int64_t)sizeof(SaInfo) + (int64_t)(ix->perfect ? 0 : c->cap * sizeof(Slot));
+  c->devBytes += ix->n + pad + ix->nSA * 4 + ix->nSA * (int64_t)sizeof(SaInfo) + (int64_t)(ix->perfect ? 0 : c->cap * sizeof(Bucket));
 #undef CK
   *out = c;
   return QM_OK;
@@ -452,7 +452,7 @@ int qm_map_device(qm_ctx* c, const qm_opts* o, int64_t n, const void* d_seq1, co
   if (c->capLists < wantLists) { if ((rc = ensure(c->d_lists, c->capLists, wantLists))) return rc; }
 
   DevIndex ix; ix.text = c->d_text; ix.n = c->ix->n; ix.SA = c->d_SA; ix.nSA = c->ix->nSA;
-  ix.sainfo = (const SaInfo*)c->d_sainfo; ix.slots = (const Slot*)c->d_slots; ix.hmask = c->cap - 1; ix.ph = (const PhIndex*)c->d_ph; ix.k = c->ix->k;
+  ix.sainfo = (const SaInfo*)c->d_sainfo; ix.slots = (const Bucket*)c->d_slots; ix.hmask = c->cap - 1; ix.ph = (const PhIndex*)c->d_ph; ix.k = c->ix->k;
   u64 hscal[16];
   HIPCHK(hipEventRecord(c->evA, c->stream));
   // ---- stage A: one wavefront per read

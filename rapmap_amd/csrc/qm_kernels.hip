@@ -6,7 +6,7 @@
 //   build_sainfo_kernel   index flattening: (transcript id, offset) for every SA entry
 //                         (replaces rank9b::rank + txpOffsets lookups on the hot path,
 //                         src/rank9b.cpp:56-61, src/RapMapSAIndex.cpp:92-94)
-//   build_slots_kernel    index flattening: open-addressing k-mer table from hash.bin records
+//   build_slots_kernel    index flattening: bucketized k-mer table from hash.bin records
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <cstdlib>
@@ -88,16 +88,20 @@ __global__ void build_sainfo_kernel(const int* SA, long long nSA, const int* off
 }
 
 // records: K x {u64 key, i32 lb, i32 ub} exactly as streamed from hash.bin
-__global__ void build_slots_kernel(const Slot* recs, long long K, Slot* slots, u64 hmask) {
+__global__ void build_slots_kernel(const Slot* recs, long long K, Bucket* buckets, u64 hmask) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long stride = (long long)gridDim.x * blockDim.x;
   for (; i < K; i += stride) {
     Slot r = recs[i];
-    u64 j = hash_mix(r.key) & hmask;
+    u64 b = hash_mix(r.key) & hmask;
     while (true) {
-      u64 prev = atomicCAS((unsigned long long*)&slots[j].key, ~0ULL, r.key);
-      if (prev == ~0ULL) { slots[j].lb = r.lb; slots[j].ub = r.ub; break; }
-      j = (j + 1) & hmask;
+      Bucket* bk = &buckets[b];
+      int got = -1;
+      for (int t = 0; t < 4 && got < 0; ++t)
+        if (atomicCAS((unsigned long long*)&bk->key[t], ~0ULL, r.key) == ~0ULL) got = t;
+      if (got >= 0) { bk->val[got].lb = r.lb; bk->val[got].ub = r.ub; break; }
+      atomicOr((unsigned long long*)&bk->key[0], QM_BK_OVF);      // full: remember that lookups must walk on
+      b = (b + 1) & hmask;
     }
   }
 }
@@ -116,9 +120,9 @@ hipError_t qmk_build_sainfo(const int* SA, long long nSA, const int* offsets, lo
 }
 
 hipError_t qmk_build_slots(const void* recs, long long K, void* slots, unsigned long long cap, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(slots, 0xff, cap * sizeof(Slot), st);
+  hipError_t e = hipMemsetAsync(slots, 0xff, cap * sizeof(Bucket), st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(build_slots_kernel, dim3(4096), dim3(256), 0, st, (const Slot*)recs, K, (Slot*)slots, cap - 1);
+  hipLaunchKernelGGL(build_slots_kernel, dim3(4096), dim3(256), 0, st, (const Slot*)recs, K, (Bucket*)slots, cap - 1);
   return hipGetLastError();
 }
 

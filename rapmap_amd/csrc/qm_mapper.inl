@@ -40,9 +40,16 @@ namespace qm {
 #define QM_CHUNK 4096  // list elements a wave reserves per bump-allocator round trip (>= QM_GCAP)
 #define QM_GSCR_U64 (3 * QM_GCAP + 2 * QM_IOVF * 2)   // u64 words of global scratch per wave
 
-struct Slot { u64 key; int lb; int ub; };          // 16 B open-addressing slot, key == ~0 empty
-struct SaInfo { u32 tid; int pos; };               // transcript id + offset in transcript of SA[i]
+struct Slot { u64 key; int lb; int ub; };          // hash.bin record / small linear-probing tables, key == ~0 empty
 struct Iv { int lb, ub; };                         // seed interval
+// Dense k-mer table: one 64-byte bucket (= one HBM sector) of four keys and four intervals per hash value, so a
+// lookup is a single round of loads with no probe chain.  Keys are 2k <= 62 bits; ~0 marks an empty slot, bit 63
+// of key[0] says "a key that hashes here was placed in a later bucket" (the only case a lookup walks on).
+struct Bucket { u64 key[4]; Iv val[4]; };          // 64 B; hipMalloc aligns the array
+#define QM_BK_OVF (1ULL << 63)
+QM_DEV u64 hash_mix(u64 x);
+QM_DEV u64 bucket_count(long long nkeys) { u64 c = 16; while (c < (u64)nkeys) c <<= 1; return c; }
+struct SaInfo { u32 tid; int pos; };               // transcript id + offset in transcript of SA[i]
 struct IntRec { int b, e; u32 len, q; };           // SAIntervalHit (RapMapUtils.hpp:516-525)
 
 // Perfect-hash (`quasiindex -p`) seed map, flattened: BooPHF levels + FrugalBooMap values
@@ -67,7 +74,7 @@ struct DevIndex {
   const int* SA;
   long long nSA;
   const SaInfo* sainfo;
-  const Slot* slots;          // dense index (null for a perfect-hash index)
+  const Bucket* slots;        // dense index: hmask + 1 buckets (null for a perfect-hash index)
   u64 hmask;
   const PhIndex* ph;          // perfect-hash index (null for a dense index), in device memory
   int k;
@@ -281,15 +288,18 @@ QM_DEV bool text_kmer(const DevIndex& ix, long long pos, int k, u64& w) {
 template <int F>
 QM_DEV bool find_kmer(const DevIndex& ix, u64 key, int& lb, int& ub) {
   if (!(F & QM_F_PH)) {
-    u64 i = hash_mix(key) & ix.hmask;
+    u64 b = hash_mix(key) & ix.hmask;
     QM_CNT(0, 1);
     while (true) {
-      const U4 x = load_16(&ix.slots[i]);               // {key lo, key hi, lb, ub}
-      const u64 xk = ((u64)x.y << 32) | x.x;
+      const Bucket* bk = &ix.slots[b];
+      const U4 a = load_16(&bk->key[0]), c = load_16(&bk->key[2]);
       QM_CNT(1, 1);
-      if (xk == key) { lb = (int)x.z; ub = (int)x.w; return true; }
-      if (xk == ~0ULL) return false;
-      i = (i + 1) & ix.hmask;
+      const u64 k0r = ((u64)a.y << 32) | a.x, k1 = ((u64)a.w << 32) | a.z, k2 = ((u64)c.y << 32) | c.x, k3 = ((u64)c.w << 32) | c.z;
+      const u64 k0 = k0r == ~0ULL ? k0r : (k0r & ~QM_BK_OVF);
+      const int m = k0 == key ? 0 : (k1 == key ? 1 : (k2 == key ? 2 : (k3 == key ? 3 : -1)));
+      if (m >= 0) { const Iv v = bk->val[m]; lb = v.lb; ub = v.ub; return true; }
+      if (k0r == ~0ULL || !(k0r & QM_BK_OVF)) return false;
+      b = (b + 1) & ix.hmask;
     }
   }
   const PhIndex& P = *ix.ph;

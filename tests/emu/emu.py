@@ -48,7 +48,8 @@ def _lib():
 
 
 class Emu:
-    def __init__(self, ix):
+    def __init__(self, ix, buckets=None):
+        """buckets: override the number of hash buckets (power of two) to force bucket overflow chains"""
         self.lib = _lib()
         self.ix = ix
         n = ix.text.size
@@ -57,8 +58,8 @@ class Emu:
         self.n = n
         self.SA = np.ascontiguousarray(ix.SA, dtype=np.int32)
         self.sainfo = np.zeros(self.SA.size * 2, dtype=np.uint32)
-        self.cap = int(self.lib.qe_slots_cap(ix.hkeys.size))
-        self.slots = np.zeros(self.cap * 2, dtype=np.uint64)
+        self.cap = int(buckets) if buckets else int(self.lib.qe_slots_cap(ix.hkeys.size))
+        self.slots = np.zeros(self.cap * 8 + 8, dtype=np.uint64)   # cap buckets of 64 bytes
         off = np.ascontiguousarray(ix.txpOffsets, dtype=np.int32)
         hk = np.ascontiguousarray(ix.hkeys, dtype=np.uint64)
         hl = np.ascontiguousarray(ix.hlb, dtype=np.int32)

@@ -19,14 +19,14 @@ extern "C" {
 unsigned long long* qe_prof() { return qm::qm_prof; }   // event counters, see QM_CNT in qm_mapper.inl
 #endif
 
-// slots: cap x {u64 key, i32 lb, i32 ub}; sainfo: nSA x {u32 tid, i32 pos}; text padded by >= 64 bytes
+// slots: (hmask+1) 64-byte buckets; sainfo: nSA x {u32 tid, i32 pos}; text padded by >= 64 bytes
 int qe_map(int k, const unsigned char* text, long long n, const int* SA, long long nSA, const void* sainfo,
            const void* slots, unsigned long long hmask, const qm_opts* o, long long nunits,
            const unsigned char* seq1, const long long* off1, const unsigned char* seq2, const long long* off2,
            int ns, const void* ph, long long* hit_offsets, qm_hit** hits_out, unsigned long long* counters, long long* int_offsets,
            qm_sa_interval_hit** ints_out, int* status_out) {
   DevIndex ix; ix.text = text; ix.n = n; ix.SA = SA; ix.nSA = nSA; ix.sainfo = (const SaInfo*)sainfo;
-  ix.slots = (const Slot*)slots; ix.hmask = hmask; ix.k = k; ix.ph = (const PhIndex*)ph;
+  ix.slots = (const Bucket*)slots; ix.hmask = hmask; ix.k = k; ix.ph = (const PhIndex*)ph;
   const bool paired = seq2 != nullptr;
   const long long nreads = paired ? 2 * nunits : nunits;
   ReadBatch B; memset(&B, 0, sizeof(B));
@@ -119,7 +119,7 @@ void* qe_ph_create(const unsigned long long* words, const unsigned long long* ra
 
 // host-side flattening for the emulation only (the product does this on the GPU,
 // rapmap_amd/csrc/qm_kernels.hip: build_sainfo_kernel / build_slots_kernel)
-unsigned long long qe_slots_cap(long long nkeys) { unsigned long long c = 16; while (c < (unsigned long long)nkeys * 2) c <<= 1; return c; }
+unsigned long long qe_slots_cap(long long nkeys) { return bucket_count(nkeys); }   // buckets of 64 bytes
 void qe_flatten(const int* SA, long long nSA, const int* offsets, long long T, void* sainfo_out,
                 const unsigned long long* keys, const int* lb, const int* ub, long long K, void* slots_out,
                 unsigned long long cap) {
@@ -131,12 +131,17 @@ void qe_flatten(const int* SA, long long nSA, const int* offsets, long long T, v
     long long tid = lo - 1;
     si[i].tid = (u32)tid; si[i].pos = p - offsets[tid];
   }
-  Slot* sl = (Slot*)slots_out;
-  for (unsigned long long i = 0; i < cap; ++i) { sl[i].key = ~0ULL; sl[i].lb = 0; sl[i].ub = 0; }
+  Bucket* bk = (Bucket*)slots_out;
+  memset(bk, 0xff, (size_t)cap * sizeof(Bucket));
   for (long long i = 0; i < K; ++i) {
-    u64 j = hash_mix(keys[i]) & (cap - 1);
-    while (sl[j].key != ~0ULL) j = (j + 1) & (cap - 1);
-    sl[j].key = keys[i]; sl[j].lb = lb[i]; sl[j].ub = ub[i];
+    u64 b = hash_mix(keys[i]) & (cap - 1);
+    while (true) {
+      int t = 0;
+      while (t < 4 && bk[b].key[t] != ~0ULL) ++t;
+      if (t < 4) { bk[b].key[t] = keys[i]; bk[b].val[t].lb = lb[i]; bk[b].val[t].ub = ub[i]; break; }
+      bk[b].key[0] |= QM_BK_OVF;
+      b = (b + 1) & (cap - 1);
+    }
   }
 }
 }

@@ -63,6 +63,21 @@ def test_synth_small(synth_small, oracle_mod, variant):
     _cmp_ints(res, er)
 
 
+def test_crowded_hash_buckets(synth_small, oracle_mod):
+    """a table with ~3 keys per 4-slot bucket: lookups have to follow the overflow marks into later buckets"""
+    import emu
+    ix, orc = load_oracle(synth_small["idx"])
+    nb = 16
+    while nb * 3 < ix.hkeys.size:
+        nb *= 2
+    em = emu.Emu(ix, buckets=nb)
+    q1, o1 = pack(synth_small["reads1"]); q2, o2 = pack(synth_small["reads2"])
+    res = orc.map_pairs(q1, o1, q2, o2, nthreads=4)
+    er = em.map(q1, o1, q2, o2)
+    assert_hits_equal(res.hit_offsets, res.hits, er.hit_offsets, er.hits, "crowded")
+    assert res.counters == er.counters
+
+
 def test_single_end(synth_small, oracle_mod):
     ix, orc, em, emu = _emu(synth_small["idx"])
     q, o = pack(synth_small["reads1"] + synth_small["reads2"])
