@@ -1136,7 +1136,7 @@ QM_DEV void pre_offsets(const ReadBatch& B, long long read, ReadPre<NS>& P) {
   if (read >= B.nreads) return;
   const unsigned char* src; const long long* off; long long unit;
   read_src(B, read, src, off, unit);
-  P.p0 = off[unit]; P.p1 = off[unit + 1];
+  P.p0 = load_uniform_i64(off + unit); P.p1 = load_uniform_i64(off + unit + 1);
 }
 // turn the pending offsets (which belong to `read`) into character loads
 template <int NS>

@@ -102,6 +102,7 @@ QM_DEV int clz64(u64 x) { return x ? __builtin_clzll(x) : 64; }
 QM_DEV u64 load_u64_unaligned(const unsigned char* p) { u64 v; __builtin_memcpy(&v, p, 8); return v; }
 struct U4 { u32 x, y, z, w; };
 QM_DEV U4 load_16(const void* p) { U4 v; __builtin_memcpy(&v, p, 16); return v; }
+QM_DEV long long load_uniform_i64(const long long* p) { return *p; }
 #else
 QM_DEV int wave_max(const LV<int>& x) {
   int v = x.v[0];
@@ -116,6 +117,11 @@ QM_DEV void group_min(LV<int>& x, int G) {
 }
 QM_DEV int clz64(u64 x) { return x ? __builtin_clzll(x) : 64; }
 QM_DEV u64 load_u64_unaligned(const unsigned char* p) { u64 v; __builtin_memcpy(&v, p, 8); return v; }
+// wave-uniform 8-byte load on the scalar unit (s_load): read-only data, uniform address
+QM_DEV long long load_uniform_i64(const long long* p) {
+  typedef const long long __attribute__((address_space(4)))* cptr;
+  return *(cptr)(unsigned long long)p;
+}
 // one 16-byte load that the compiler cannot split into a key load plus a dependent value load
 struct U4 { u32 x, y, z, w; };
 QM_DEV U4 load_16(const void* p) {
