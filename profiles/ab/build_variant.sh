@@ -9,7 +9,7 @@ rm -rf $W && mkdir -p $W && cp $ROOT/rapmap_amd/csrc/*.h $ROOT/rapmap_amd/csrc/*
 sed -i "s|#include \"../../include/qmap_mi355.h\"|#include \"$ROOT/include/qmap_mi355.h\"|" $W/qm_mapper.inl
 [ -n "$PATCH" ] && python $PATCH $W
 cd $W
-FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -Wno-unused-value -Wno-unused-result"
+FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -Wno-unused-value -Wno-unused-result -mllvm -sink-insts-to-avoid-spills=true $QM_XFLAGS"
 /opt/rocm/bin/hipcc $FL -c qm_kernels.hip -o k.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -A12 "qm_read_kernelILi2ELi[0-9]ELi0E" | grep -E "VGPRs:|VGPRs Spill|SGPRs Spill|ScratchSize" | sed 's/.*remark: *//; s/\[-R.*//' | tr '\n' ' '
 echo " <= $NAME"
 /opt/rocm/bin/hipcc $FL -c qm_host.hip -o h.o
