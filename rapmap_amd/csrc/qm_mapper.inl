@@ -370,6 +370,7 @@ struct Strand {
   Bits<NS> V;    // positions that produced a KmerDirScore entry (only used by the --noSensitive vote)
   const u64* planes;   // LDS: [4][NS+2]
   Iv* tab;             // LDS: interval of mer at position p (valid where F)
+  bool dollar;         // the strand's string contains '$' (extensions then take the literal binary searches)
   int P;
 };
 
@@ -549,8 +550,8 @@ QM_DEV int cmp_from(const DevIndex& ix, long long s, const unsigned char* q, int
 // (Search 1 ends with both neighbours of the insertion point probed, and the maximum LCP of a sorted
 // list sits next to the insertion point; searches 2/3 bracket the suffixes that have query[0,maxLen)
 // as a prefix.  The one case where the reference's loop deviates -- a suffix running off the END of
-// the text, SASearcher.hpp:154,180 -- needs the query to match the text's final '$'; queries that
-// contain '$' therefore take the literal path below.)
+// the text, SASearcher.hpp:154,180 -- needs the query to match the text's final '$'; reads that
+// contain '$' therefore take the literal path below: Strand::dollar, found while the read is loaded.)
 // The wave is split into groups of G = 64 / 2^ceil(log2(width)) lanes, one group per suffix; lane c of a group
 // compares the 16 bytes at offset 16c of the current round, so a 2x100 bp read needs one round for up to 8
 // suffixes: one coalesced SA load, then one round of text loads, instead of a dependent load per 8 bytes.
@@ -572,9 +573,9 @@ QM_DEV bool extend_search_wide(const DevIndex& ix, int lbIn, int ubIn, int start
   }
   for (int i0 = startAt; ; i0 += 16 * G) {
     QM_CNT(7, 1);
-    LV<int> cand; LV<bool> dol;
+    LV<int> cand;
     QM_LANES(l) {
-      int cd = 0x7fffffff; bool dl = false;
+      int cd = 0x7fffffff;
       if (act[l] && lcp[l] == 0x7fffffff) {
         const int off = i0 + 16 * (l & (G - 1));
         int nb = m0 - off; nb = nb > 16 ? 16 : nb;
@@ -586,11 +587,6 @@ QM_DEV bool extend_search_wide(const DevIndex& ix, int lbIn, int ubIn, int start
           const int sh = (int)(addr & 7ULL) * 8;
           const u64 w0 = al[0], w1 = al[1], w2 = al[2];
           const u64 q0 = (w0 >> sh) | ((w1 << 1) << (63 - sh)), q1 = (w1 >> sh) | ((w2 << 1) << (63 - sh));
-          const u64 v0 = nb >= 8 ? ~0ULL : ((1ULL << (8 * nb)) - 1);
-          const u64 v1 = nb >= 16 ? ~0ULL : (nb > 8 ? ((1ULL << (8 * (nb - 8))) - 1) : 0ULL);
-          // any '$' among the valid query bytes?  (haszero trick on q ^ 0x24..24)
-          const u64 z0 = (q0 ^ 0x2424242424242424ULL) | ~v0, z1 = (q1 ^ 0x2424242424242424ULL) | ~v1;
-          dl = (((z0 - 0x0101010101010101ULL) & ~z0) | ((z1 - 0x0101010101010101ULL) & ~z1)) & 0x8080808080808080ULL;
           long long tv = ix.n - (sv[l] + off);            // text bytes left (the array is padded for the over-read)
           if (tv > 0) {
             const u64 t0 = load_u64_unaligned(ix.text + sv[l] + off), t1 = load_u64_unaligned(ix.text + sv[l] + off + 8);
@@ -602,9 +598,8 @@ QM_DEV bool extend_search_wide(const DevIndex& ix, int lbIn, int ubIn, int start
         }
         if (cnt < 16) cd = off + cnt;                    // this chunk ends the match (mismatch, end of query or text)
       }
-      cand[l] = cd; dol[l] = dl;
+      cand[l] = cd;
     }
-    if (ballot(dol)) return false;
     group_min(cand, G);
     LV<bool> cont;
     QM_LANES(l) {
@@ -626,9 +621,9 @@ QM_DEV bool extend_search_wide(const DevIndex& ix, int lbIn, int ubIn, int start
 
 // SASearcher::extendSearchNaive (SASearcher.hpp:88-309)
 QM_DEV void extend_search(const DevIndex& ix, int lbIn, int ubIn, int startAt, const unsigned char* q, int m0,
-                          int& lbOut, int& ubOut, int& lenOut) {
+                          int& lbOut, int& ubOut, int& lenOut, bool qDollar) {
   int rel;
-  if (extend_search_wide(ix, lbIn, ubIn, startAt, q, m0, lbOut, ubOut, lenOut)) return;
+  if (!qDollar && extend_search_wide(ix, lbIn, ubIn, startAt, q, m0, lbOut, ubOut, lenOut)) return;
   QM_CNT(8, 1);
   if (ubIn - lbIn == 2) {                         // :109-126
     lbIn += 1;
@@ -753,7 +748,7 @@ QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, c
     lb = lb - 1 > 0 ? lb - 1 : 0;                      // :553
     int mlen;
     QM_CNT(18, 1); QM_T(4);
-    extend_search(ix, lb, ub, k, str + p, L - p, lb, ub, mlen);
+    extend_search(ix, lb, ub, k, str + p, L - p, lb, ub, mlen, V.dollar);
     QM_T(3);
     const bool more = !lastSearch && p + mlen < L;     // the walk continues at kp after this MMP
     const int kp = p + mlen - (k - 1);
@@ -790,8 +785,8 @@ QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, c
 // SACollector::operator() (SACollector.hpp:108-362), disableNIP_ == true.
 // M.str[0] = read (upper-cased), M.str[1] = reverseRead(read).  Returns foundHit.
 template <int NS, int F>
-QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M, int L, IntervalList& fwdInts,
-                         IntervalList& rcInts) {
+QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M, int L, bool hasDollar,
+                         IntervalList& fwdInts, IntervalList& rcInts) {
   const int k = ix.k, P = L - k + 1;
   const unsigned char* fwdStr = M.str[0];
   const unsigned char* rcStr = M.str[1];
@@ -799,6 +794,7 @@ QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M,
   if (P <= 0) return false;
   Strand<NS> S;
   setup_strand<NS>(ix, fwdStr, L, S, &M.planes[0][0][0], M.tab[0]);
+  S.dollar = hasDollar;
   // first-hit scan (:167-237): first E2 position whose k-mer or reverse complement is in the hash
   int p0 = first_set_from(S.E2, 0);
   int width = 1;
@@ -834,6 +830,7 @@ QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M,
     // the reverse-complemented read is treated as a string of its own (also correct for IUPAC / 'U'
     // characters, where reverseRead() is not the mirror image of the 2-bit encoding)
     setup_strand<NS>(ix, rcStr, L, R, &M.planes[1][0][0], M.tab[1]);
+    R.dollar = false;                                   // reverseRead() maps '$' to 'N'
     haveR = true;
     get_sa_hits<NS, F>(ix, B, R, rcStr, L, 0, false, 0, 0, rcCov, rcHit, fwdHit, rcInts);
   }
@@ -844,6 +841,7 @@ QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M,
       // masks instead of keeping them in registers across the whole reverse-complement pass
       Strand<NS> S2;
       setup_strand<NS>(ix, fwdStr, L, S2, &M.planes[0][0][0], M.tab[0]);
+      S2.dollar = hasDollar;
       get_sa_hits<NS, F>(ix, B, S2, fwdStr, L, 0, false, 0, 0, fwdCov, fwdHit, rcHit, fwdInts);
     } else {
       get_sa_hits<NS, F>(ix, B, S, fwdStr, L, 0, false, 0, 0, fwdCov, fwdHit, rcHit, fwdInts);
@@ -1168,20 +1166,27 @@ QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, con
   unsigned char* fs = M.str[0];
   unsigned char* rs = M.str[1];
   QM_T(6);
+  LV<bool> dl;
+  QM_LANES(l) { dl[l] = false; }
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     QM_LANES(l) {
       int idx = 64 * s + l;
       // the forward read is kept upper-cased (every consumer applies ::toupper anyway, SASearcher.hpp:111,155)
-      if (idx < len) { unsigned char c = (unsigned char)(pre.chars[l] >> (8 * s)); fs[idx] = (unsigned char)upc(c); rs[len - 1 - idx] = rc_char(c); }
+      if (idx < len) {
+        unsigned char c = (unsigned char)(pre.chars[l] >> (8 * s));
+        fs[idx] = (unsigned char)upc(c); rs[len - 1 - idx] = rc_char(c);
+        dl[l] = dl[l] || c == '$';
+      }
     }
   }
+  const bool hasDollar = ballot(dl) != 0;
   wave_fence();
   QM_T(0);
   IntervalList fi, ri;
   fi.lds = M.ints[0]; ri.lds = M.ints[1];
   fi.ovf = (IntRec*)(gscr + 3 * QM_GCAP); ri.ovf = fi.ovf + QM_IOVF;
-  const bool foundHit = collect_read<NS, F>(ix, B, M, len, fi, ri);
+  const bool foundHit = collect_read<NS, F>(ix, B, M, len, hasDollar, fi, ri);
   QM_T(4);
   if (B.dbg_ints) {
     int dbg = 0;

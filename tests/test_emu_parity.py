@@ -78,6 +78,31 @@ def test_crowded_hash_buckets(synth_small, oracle_mod):
     assert res.counters == er.counters
 
 
+def _dollar_reads(sd):
+    """reads with a '$' (the text's separator) spliced in, incl. right after the seed k-mer and at the last base"""
+    r1 = [bytearray(r) for r in sd["reads1"][:400]]
+    r2 = [bytearray(r) for r in sd["reads2"][:400]]
+    for i, r in enumerate(r1):
+        if len(r) > 40:
+            r[(31, 40, len(r) - 1, 5)[i % 4]] = ord("$")
+    for i, r in enumerate(r2[::3]):
+        if len(r) > 60:
+            r[60] = ord("$")
+    return [bytes(r) for r in r1], [bytes(r) for r in r2]
+
+
+def test_dollar_in_reads(synth_small, oracle_mod):
+    """'$' in a query sends the MMP extension down the literal binary searches (SASearcher.hpp:154,180)"""
+    ix, orc, em, emu = _emu(synth_small["idx"])
+    r1, r2 = _dollar_reads(synth_small)
+    q1, o1 = pack(r1); q2, o2 = pack(r2)
+    res = orc.map_pairs(q1, o1, q2, o2, nthreads=4, want_ints=True)
+    er = em.map(q1, o1, q2, o2)
+    assert_hits_equal(res.hit_offsets, res.hits, er.hit_offsets, er.hits, "dollar")
+    assert res.counters == er.counters
+    _cmp_ints(res, er)
+
+
 def test_single_end(synth_small, oracle_mod):
     ix, orc, em, emu = _emu(synth_small["idx"])
     q, o = pack(synth_small["reads1"] + synth_small["reads2"])

@@ -83,6 +83,19 @@ def test_synth_small(synth_small, oracle_mod, variant):
     _cmp_ints(res, *mp.intervals(len(o1) - 1))
 
 
+def test_dollar_in_reads(synth_small, oracle_mod):
+    from test_emu_parity import _dollar_reads
+    ix, orc = load_oracle(synth_small["idx"])
+    qi, mp = _gpu(synth_small["idx"])
+    r1, r2 = _dollar_reads(synth_small)
+    q1, o1 = pack(r1); q2, o2 = pack(r2)
+    res = orc.map_pairs(q1, o1, q2, o2, nthreads=4, want_ints=True)
+    gr = mp.map_pairs(q1, o1, q2, o2)
+    assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "dollar")
+    assert res.counters == gr.counters
+    _cmp_ints(res, *mp.intervals(len(o1) - 1))
+
+
 def test_single_end(synth_small, oracle_mod):
     ix, orc = load_oracle(synth_small["idx"])
     qi, mp = _gpu(synth_small["idx"], debug=False)
