@@ -492,6 +492,45 @@ QM_DEV void probe_window(const DevIndex& ix, Strand<NS>& S, int p, int width) {
   QM_T(2);
 }
 
+// The first probe of a read: position p (lanes 0 / 32: k-mer / reverse complement) and, in the same round of
+// loads, the read's last k-mer (position P-1, lanes 1 / 33).  The reverse complement of the last k-mer is the
+// FIRST k-mer of reverseRead(read), i.e. exactly what the reverse-complement pass would have to look up first;
+// its interval goes to rtab0 (= that strand's tab[0]).  Returns true when position P-1 was looked up here.
+template <int NS, int F>
+QM_DEV bool probe_first(const DevIndex& ix, Strand<NS>& S, int p, Iv* rtab0) {
+  const int k = ix.k;
+  const int last = S.P - 1;
+  QM_CNT(3, 1); QM_CNT(4, last != p ? 2 : 1); QM_T(4);
+  LV<bool> found;
+  QM_LANES(l) {
+    const int j = l & 31;
+    const bool isC = l >= 32;
+    const int pos = j == 0 ? p : last;
+    bool hit = false; Iv v = {0, 0};
+    if (j == 0 || (j == 1 && last != p)) {
+      bool nwin, nwin2; int d;
+      u64 key = kmer_at<NS>(S.planes, pos, k, nwin, nwin2, d);
+      if (!nwin) {
+        if (isC) key = word_rc(key, k);
+        hit = find_kmer<F>(ix, key, v.lb, v.ub);
+      }
+      if (!isC) S.tab[pos] = v;
+      else if (pos == last) *rtab0 = v;
+    }
+    found[l] = hit;
+  }
+  const u64 fm = ballot(found);
+  or_field(S.F, p, fm & 1); or_field(S.C, p, (fm >> 32) & 1); or_field(S.K, p, 1ULL);
+  if (last != p) {
+    if ((fm >> 1) & 1) set_bit(S.F, last);
+    if ((fm >> 33) & 1) set_bit(S.C, last);
+    set_bit(S.K, last);
+  }
+  wave_fence();
+  QM_T(2);
+  return true;
+}
+
 // first position >= p that is NOT yet probed (or 64*NS)
 template <int NS> QM_DEV int known_end(const Strand<NS>& S, int p) {
   Bits<NS> nk;
@@ -799,8 +838,13 @@ QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M,
   int p0 = first_set_from(S.E2, 0);
   int width = 1;
   bool found = false;
+  bool seedR = false;                                  // the rc strand's first k-mer was looked up with the first probe
   while (p0 < P) {
-    if (!S.K.test(p0)) { probe_window<NS, F>(ix, S, p0, width); width = 32; }
+    if (!S.K.test(p0)) {
+      if (width == 1) seedR = probe_first<NS, F>(ix, S, p0, &M.tab[1][0]);
+      else probe_window<NS, F>(ix, S, p0, width);
+      width = 32;
+    }
     int kend = known_end(S, p0);
     if (kend > P) kend = P;
     Bits<NS> cand = b_and(S.E2, b_or(S.F, S.C));
@@ -811,6 +855,10 @@ QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M,
   if (!found) return false;
   u32 fwdHit = S.F.test(p0) ? 1u : 0u;
   u32 rcHit = S.C.test(p0) ? 1u : 0u;
+  // what the first probe learned about the last k-mer, as seen from the reverse-complemented read (only when the
+  // window is pure ACGT: reverseRead() and the 2-bit reverse complement agree there)
+  seedR = seedR && all_acgt(S, P - 1, k);
+  const bool seedRF = seedR && S.C.test(P - 1), seedRC = seedR && S.F.test(P - 1);
   long long fwdCov = 0, rcCov = 0;
   const bool useCoverageCheck = ((F & QM_F_NIP) == 0) && B.strict_check != 0;   // disableNIP_ && strictCheck_ (:138)
   const bool vote = !useCoverageCheck && B.strict_check != 0;
@@ -831,6 +879,7 @@ QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M,
     // characters, where reverseRead() is not the mirror image of the 2-bit encoding)
     setup_strand<NS>(ix, rcStr, L, R, &M.planes[1][0][0], M.tab[1]);
     R.dollar = false;                                   // reverseRead() maps '$' to 'N'
+    if (seedR) { R.K.w[0] |= 1ULL; if (seedRF) R.F.w[0] |= 1ULL; if (seedRC) R.C.w[0] |= 1ULL; }
     haveR = true;
     get_sa_hits<NS, F>(ix, B, R, rcStr, L, 0, false, 0, 0, rcCov, rcHit, fwdHit, rcInts);
   }
