@@ -237,7 +237,7 @@ def main():
                 traffic = None
         out["roofline"] = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                           "kernel": "qm_read_kernel<2,5> (stage A: one wavefront per read)", "kernel_ms": round(avg_kernel_ms, 3),
+                           "kernel": "qm_read_kernel<2,5,0> (stage A: one wavefront per read)", "kernel_ms": round(avg_kernel_ms, 3),
                            "algorithmic_bytes_per_pair": round(bpp, 1),
                            "per_pair_counters": {kk: round(v, 2) for kk, v in w.items()},
                            "pairs_per_launch": n}

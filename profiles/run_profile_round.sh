@@ -1,0 +1,34 @@
+#!/bin/bash
+# Full profile of the mapping kernel for a round (run on the GPU box through gpurun):
+#   kernel-trace stats + separate --pmc passes (the guide's HBM recipe: FETCH_SIZE / WRITE_SIZE in their own runs).
+# usage: profiles/run_profile_round.sh <outdir> [bench args...]
+set -u
+OUT=$1; shift
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+ARGS="--no-cpu-baseline --steps 3 --warmup 1 $*"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python bench.py $ARGS > $OUT/stats.log 2>&1
+ARGS1="--no-cpu-baseline --steps 1 --warmup 0 $*"
+pass() { name=$1; shift; timeout 900 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o p -- python bench.py $ARGS1 > $OUT/$name.log 2>&1; }
+pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU
+pass sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
+pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+{
+  echo "# kernel-trace stats (rocprofv3 --kernel-trace --stats), bench args: $ARGS"
+  f=$(find $OUT/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -8 "$f"
+  echo "# PMC passes (one rocprofv3 --pmc run each), per launch of qm_read_kernel = 10 M pairs"
+  for d in sq1 sq2 fetch write tcc; do
+    f=$(find $OUT/$d -name "*counter_collection.csv" | head -1)
+    [ -n "$f" ] && python - "$f" "$d" <<'PY'
+import csv, sys, collections
+tot = collections.Counter()
+for r in csv.DictReader(open(sys.argv[1])):
+    if 'qm_read_kernel' in r['Kernel_Name']:
+        tot[r['Counter_Name']] += float(r['Counter_Value'])
+for k, v in sorted(tot.items()):
+    print("%-6s %-28s %18.0f  per pair %12.3f" % (sys.argv[2], k, v, v / 1e7))
+PY
+  done
+} | tee $OUT/summary.txt

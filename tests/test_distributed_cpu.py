@@ -43,12 +43,8 @@ def test_two_rank_sharding_matches_single_process(synth_small, oracle_mod, tmp_p
     from oracle import oracle, q5
     from rapmap_amd import dist as qd
     from util import pack
-    q1, o = pack(synth_small["reads1"]); q2, o2 = pack(synth_small["reads2"])
-    # equal-length offsets are not required: every read keeps its own offsets per mate
-    ref = oracle.Oracle(q5.load(synth_small["idx"])).map_pairs(q1, o, q2, o2, nthreads=4)
-    # the worker shards with one offsets array per mate; rebuild a joint view by padding-free re-packing
     port = _free_port()
-    # use mate-specific offsets by mapping each mate stream separately: simplest is to give both the same pairs
+    # the worker slices both mates with one offsets array, so keep the pairs whose mates have equal length
     reads1 = synth_small["reads1"]; reads2 = synth_small["reads2"]
     keep = [i for i in range(len(reads1)) if len(reads1[i]) == len(reads2[i])]
     r1 = [reads1[i] for i in keep]; r2 = [reads2[i] for i in keep]
