@@ -292,7 +292,8 @@ QM_DEV bool find_kmer(const DevIndex& ix, u64 key, int& lb, int& ub) {
     QM_CNT(0, 1);
     while (true) {
       const Bucket* bk = &ix.slots[b];
-      const U4 a = load_16(&bk->key[0]), c = load_16(&bk->key[2]);
+      U4 a, c;
+      load_32(&bk->key[0], a, c);                       // the four keys
       QM_CNT(1, 1);
       const u64 k0r = ((u64)a.y << 32) | a.x, k1 = ((u64)a.w << 32) | a.z, k2 = ((u64)c.y << 32) | c.x, k3 = ((u64)c.w << 32) | c.z;
       const u64 k0 = k0r == ~0ULL ? k0r : (k0r & ~QM_BK_OVF);

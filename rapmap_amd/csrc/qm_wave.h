@@ -103,6 +103,7 @@ QM_DEV u64 load_u64_unaligned(const unsigned char* p) { u64 v; __builtin_memcpy(
 struct U4 { u32 x, y, z, w; };
 QM_DEV U4 load_16(const void* p) { U4 v; __builtin_memcpy(&v, p, 16); return v; }
 QM_DEV long long load_uniform_i64(const long long* p) { return *p; }
+QM_DEV void load_32(const void* p, U4& a, U4& b) { a = load_16(p); b = load_16((const unsigned char*)p + 16); }
 #else
 QM_DEV int wave_max(const LV<int>& x) {
   int v = x.v[0];
@@ -128,6 +129,14 @@ QM_DEV U4 load_16(const void* p) {
   typedef u32 v4u __attribute__((ext_vector_type(4)));
   v4u q = *(const v4u*)p;
   U4 v; v.x = q.x; v.y = q.y; v.z = q.z; v.w = q.w; return v;
+}
+// two 16-byte loads issued back to back and waited for together (the empty asm keeps the compiler from sinking
+// the second load behind a branch on the first one's result)
+QM_DEV void load_32(const void* p, U4& a, U4& b) {
+  typedef u32 v4u __attribute__((ext_vector_type(4)));
+  v4u x = ((const v4u*)p)[0], y = ((const v4u*)p)[1];
+  asm volatile("" : "+v"(x), "+v"(y));
+  a.x = x.x; a.y = x.y; a.z = x.z; a.w = x.w; b.x = y.x; b.y = y.y; b.z = y.z; b.w = y.w;
 }
 #endif
 
