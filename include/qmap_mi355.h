@@ -32,7 +32,8 @@ typedef enum qm_status {
   QM_E_UNSUPPORTED = -4, /* option / index variant not implemented on the device path */
   QM_E_TOOLONG = -5,     /* a read is longer than QM_MAX_READ_LEN */
   QM_E_NOMEM = -6,
-  QM_E_STATE = -7        /* call order (e.g. fetch before map) */
+  QM_E_STATE = -7,       /* call order (e.g. fetch before map) */
+  QM_E_FORMAT = -8       /* malformed FASTA/FASTQ input */
 } qm_status;
 
 #define QM_MAX_READ_LEN 256
@@ -155,6 +156,32 @@ int qm_last_kernel_ms(const qm_ctx* ctx, double* map_kernel_ms, double* total_ms
  * perfect_hash -- hash_info.bph / hash_info.val come out byte-identical to the reference's).  Host only. */
 int qm_build_index(const char* fasta_path, const char* out_dir, int32_t k, int32_t no_clip_poly_a,
                    int32_t keep_duplicates, int32_t n_threads, int32_t perfect_hash);
+
+/* ---- host-side callers of the path -------------------------------------------
+ * Read ingest: replaces fastx_parser::FastxParser<ReadPair|ReadSeq> (include/FastxParser.hpp:62-66,
+ * src/FastxParser.cpp:229-328: one kseq producer thread, per-record std::strings).  FASTA/FASTQ, plain or
+ * gzip'd; path2 == NULL for single-end.  qm_reader_next hands out up to max_units records as packed batches
+ * in exactly the form qm_map_pairs / qm_map_reads take; the pointers stay valid until the next call.
+ * n_units == 0 means end of input.  Qualities are dropped, as the reference's parser does. */
+typedef struct qm_reader qm_reader;
+int qm_reader_open(const char* path1, const char* path2, int32_t n_threads, qm_reader** out);
+int qm_reader_next(qm_reader* r, int64_t max_units, int64_t* n_units, const char** seq1, const int64_t** off1,
+                   const char** names1, const int64_t** name_off1, const char** seq2, const int64_t** off2,
+                   const char** names2, const int64_t** name_off2);
+void qm_reader_close(qm_reader* r);
+const char* qm_io_last_error(void);
+
+/* SAM text of a mapped batch, byte for byte what `rapmap quasimap -o` writes: header = writeSAMHeader
+ * (include/RapMapUtils.hpp:97-115); records = writeAlignmentsToStream / writeUnalignedPairToStream
+ * (src/RapMapUtils.cpp:137-196,198-311,313-588) with getSamFlags / adjustOverhang
+ * (include/RapMapUtils.hpp:687-810).  seq2 == NULL: single-end records.  The text is malloc'd; release it
+ * with qm_buf_free. */
+int qm_sam_header(const qm_index* ix, char** out, int64_t* out_len);
+int qm_sam_records(const qm_index* ix, int64_t n, const char* names1, const int64_t* name_off1, const char* seq1,
+                   const int64_t* off1, const char* names2, const int64_t* name_off2, const char* seq2,
+                   const int64_t* off2, const int64_t* hit_offsets, const qm_hit* hits, int32_t max_num_hits,
+                   int32_t n_threads, char** out, int64_t* out_len);
+void qm_buf_free(char* p);
 
 #ifdef __cplusplus
 }

@@ -14,5 +14,7 @@ FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -Wno-unused-value
 echo " <= $NAME"
 /opt/rocm/bin/hipcc $FL -c qm_host.hip -o h.o
 g++ -O2 -std=c++17 -fPIC -I$ROOT/include -c qm_indexer.cpp -o i.o
+sed -i "s|#include \"../../include/qmap_mi355.h\"|#include \"$ROOT/include/qmap_mi355.h\"|" qm_io.cpp
+g++ -O2 -std=c++17 -fPIC -pthread -I$ROOT/include -c qm_io.cpp -o io.o
 mkdir -p $ROOT/rapmap_amd/variants
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/rapmap_amd/variants/$NAME.so k.o h.o i.o -pthread
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/rapmap_amd/variants/$NAME.so k.o h.o i.o io.o -pthread -lz

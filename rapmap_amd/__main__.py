@@ -37,7 +37,7 @@ def _quasimap(argv):
     ap.add_argument("-1", "--leftMates", default="", help="The location of the left paired-end reads")
     ap.add_argument("-2", "--rightMates", default="", help="The location of the right paired-end reads")
     ap.add_argument("-r", "--unmatedReads", default="", help="The location of single-end reads")
-    ap.add_argument("-t", "--numThreads", type=int, default=1, help="accepted for compatibility (the GPU does the mapping)")
+    ap.add_argument("-t", "--numThreads", type=int, default=8, help="host threads for read parsing and SAM formatting (the GPU does the mapping)")
     ap.add_argument("-m", "--maxNumHits", type=int, default=200, help="Reads mapping to more than this many loci are discarded")
     ap.add_argument("-o", "--output", default="", help="The output file (default: stdout)")
     ap.add_argument("-z", "--quasiCoverage", type=float, default=0.0)
@@ -80,51 +80,42 @@ def _quasimap(argv):
         if a.output:
             if a.compressed:
                 import gzip
-                out = gzip.open(a.output, "wt")
+                out = gzip.open(a.output, "wb")
             else:
-                out = open(a.output, "w")
+                out = open(a.output, "wb")
         else:
-            out = sys.stdout
-        out.write(sam.sam_header(qi.txp_names, qi.txp_lens))
-    names_t, lens_t = qi.txp_names, qi.txp_lens
+            out = sys.stdout.buffer
+        out.write(ra.sam_header_text(qi))
     tot = {"numReads": 0, "totHits": 0, "peHits": 0, "seHits": 0, "tooManyHits": 0}
     t0 = time.time()
     gpu_ms = 0.0
+    nthr = max(1, a.numThreads)
+    # ingest (qm_reader_*) and SAM text (qm_sam_*) are the library's native, multi-threaded host code;
+    # -t sets their worker count
     if paired:
         files1, files2 = a.leftMates.split(","), a.rightMates.split(",")
         if len(files1) != len(files2):
             sys.exit("the number of left and right read files differs")
-        for f1, f2 in zip(files1, files2):
-            it2 = sam.iter_fastx(f2, a.chunk)
-            for n1, s1 in sam.iter_fastx(f1, a.chunk):
-                n2, s2 = next(it2)
-                if len(s1) != len(s2):
-                    sys.exit("left and right files are not in sync")
-                q1, o1 = ra.pack_reads(s1); q2, o2 = ra.pack_reads(s2)
-                r = mp.map_pairs(q1, o1, q2, o2, opts=opts)
-                gpu_ms += r.total_ms
-                for kk in tot:
-                    tot[kk] += r.counters[kk]
-                if out is not None:
-                    buf = []
-                    ho, hits = r.hit_offsets, r.hits
-                    for i in range(len(s1)):
-                        buf.append(sam.format_pair(n1[i], s1[i], n2[i], s2[i], hits[ho[i]:ho[i + 1]], names_t, lens_t, a.maxNumHits))
-                    out.write("".join(buf))
+        pairs = list(zip(files1, files2))
+    else:
+        pairs = [(f, None) for f in a.unmatedReads.split(",")]
+    for f1, f2 in pairs:
+        rd = ra.FastxReader(f1, f2, threads=nthr)
+        for b in rd.chunks(a.chunk):
+            if paired:
+                r = mp.map_pairs(b.seq1, b.off1, b.seq2, b.off2, opts=opts)
+            else:
+                r = mp.map_reads(b.seq1, b.off1, opts=opts)
+            gpu_ms += r.total_ms
+            for kk in tot:
+                tot[kk] += r.counters[kk]
+            if out is not None:
+                out.write(ra.sam_records_text(qi, b, r.hit_offsets, r.hits, max_num_hits=a.maxNumHits, threads=nthr))
+            if paired:
                 log("saw %d reads : pe / read = %.4f : se / read = %.4f" % (
                     tot["numReads"], tot["peHits"] / max(1, tot["numReads"]), tot["seHits"] / max(1, tot["numReads"])))
-    else:
-        for f in a.unmatedReads.split(","):
-            for n1, s1 in sam.iter_fastx(f, a.chunk):
-                q, o = ra.pack_reads(s1)
-                r = mp.map_reads(q, o, opts=opts)
-                gpu_ms += r.total_ms
-                for kk in tot:
-                    tot[kk] += r.counters[kk]
-                if out is not None:
-                    ho, hits = r.hit_offsets, r.hits
-                    out.write("".join(sam.format_single(n1[i], s1[i], hits[ho[i]:ho[i + 1]], names_t, lens_t) for i in range(len(s1))))
-    if out is not None and out is not sys.stdout:
+        rd.close()
+    if out is not None and out is not sys.stdout.buffer:
         out.close()
     log("Done mapping reads.")
     log("In total saw %d reads." % tot["numReads"])

@@ -33,6 +33,8 @@ ABI_SYMBOLS = [
     "qm_index_txp_name", "qm_index_txp_len", "qm_index_arrays", "qm_ctx_create", "qm_ctx_destroy", "qm_ctx_device_bytes",
     "qm_map_pairs", "qm_map_reads", "qm_map_device", "qm_fetch_hits", "qm_result_device", "qm_ctx_set_debug",
     "qm_fetch_intervals", "qm_last_kernel_ms", "qm_build_index",
+    "qm_reader_open", "qm_reader_next", "qm_reader_close", "qm_io_last_error", "qm_sam_header", "qm_sam_records",
+    "qm_buf_free",
 ]
 
 
@@ -102,6 +104,14 @@ def lib():
     L.qm_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.qm_build_index.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.qm_opts_default.argtypes = [C.POINTER(QmOpts)]
+    L.qm_io_last_error.restype = C.c_char_p
+    L.qm_reader_open.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]
+    L.qm_reader_next.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int64)] + [C.POINTER(C.c_void_p)] * 8
+    L.qm_reader_close.argtypes = [C.c_void_p]
+    L.qm_sam_header.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    L.qm_sam_records.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 10 + [C.c_int32, C.c_int32,
+                                 C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    L.qm_buf_free.argtypes = [C.c_void_p]
     _lib = L
     return L
 
@@ -270,3 +280,91 @@ class QuasiMapper:
             self.close()
         except Exception:
             pass
+
+
+class ReadBatch:
+    """one chunk handed out by FastxReader: packed sequences/names (numpy views, valid until the next chunk)"""
+    pass
+
+
+class FastxReader:
+    """FASTA/FASTQ(.gz) ingest through the library's native reader (qm_reader_*): the packed batches that
+    QuasiMapper.map_pairs / map_reads take.  path2=None for single-end input."""
+
+    def __init__(self, path1, path2=None, threads=None):
+        self._h = C.c_void_p()
+        rc = lib().qm_reader_open(path1.encode(), path2.encode() if path2 else None,
+                                  int(threads or min(16, os.cpu_count() or 1)), C.byref(self._h))
+        if rc != 0:
+            raise QmError(lib().qm_io_last_error().decode())
+        self.paired = path2 is not None
+
+    def chunks(self, max_units):
+        L = lib()
+        n = C.c_int64()
+        ptr = [C.c_void_p() for _ in range(8)]
+        while True:
+            rc = L.qm_reader_next(self._h, int(max_units), C.byref(n), *[C.byref(x) for x in ptr])
+            if rc != 0:
+                raise QmError(L.qm_io_last_error().decode())
+            if n.value == 0:
+                return
+            b = ReadBatch(); b.n = n.value
+
+            def arr(p, count, dt):
+                if count == 0 or not p.value:
+                    return np.zeros(0, dtype=dt)
+                return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int64 if dt == np.int64 else C.c_uint8)), shape=(count,))
+            b.off1 = arr(ptr[1], b.n + 1, np.int64); b.seq1 = arr(ptr[0], int(b.off1[-1]), np.uint8)
+            b.name_off1 = arr(ptr[3], b.n + 1, np.int64); b.names1 = arr(ptr[2], int(b.name_off1[-1]), np.uint8)
+            if self.paired:
+                b.off2 = arr(ptr[5], b.n + 1, np.int64); b.seq2 = arr(ptr[4], int(b.off2[-1]), np.uint8)
+                b.name_off2 = arr(ptr[7], b.n + 1, np.int64); b.names2 = arr(ptr[6], int(b.name_off2[-1]), np.uint8)
+            yield b
+
+    def close(self):
+        if self._h:
+            lib().qm_reader_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _take_buf(p, n):
+    try:
+        return C.string_at(p, n.value)
+    finally:
+        lib().qm_buf_free(p)
+
+
+def sam_header_text(index: "QuasiIndex") -> bytes:
+    p = C.c_void_p(); n = C.c_int64()
+    _check(lib().qm_sam_header(index._h, C.byref(p), C.byref(n)))
+    return _take_buf(p, n)
+
+
+def sam_records_text(index: "QuasiIndex", batch, hit_offsets, hits, max_num_hits=200, threads=None) -> bytes:
+    """SAM records of one mapped ReadBatch (paired when the batch has mates), formatted by the library"""
+    def vp(a):
+        return C.c_void_p(np.ascontiguousarray(a).ctypes.data) if a is not None and len(a) else C.c_void_p(0)
+    ho = np.ascontiguousarray(hit_offsets, dtype=np.int64)
+    hh = np.ascontiguousarray(hits)
+    paired = getattr(batch, "seq2", None) is not None
+    keep = [np.ascontiguousarray(x) for x in (batch.names1, batch.name_off1, batch.seq1, batch.off1)]
+    if paired:
+        keep += [np.ascontiguousarray(x) for x in (batch.names2, batch.name_off2, batch.seq2, batch.off2)]
+    args = [C.c_void_p(a.ctypes.data) for a in keep] + ([C.c_void_p(0)] * 4 if not paired else [])
+    # a zero-length sequence array still needs a non-null pointer
+    if not keep[2].size:
+        args[2] = C.c_void_p(ho.ctypes.data)
+    p = C.c_void_p(); n = C.c_int64()
+    rc = lib().qm_sam_records(index._h, int(batch.n), *args, C.c_void_p(ho.ctypes.data),
+                              C.c_void_p(hh.ctypes.data if hh.size else ho.ctypes.data), int(max_num_hits),
+                              int(threads or min(16, os.cpu_count() or 1)), C.byref(p), C.byref(n))
+    if rc != 0:
+        raise QmError(lib().qm_io_last_error().decode())
+    return _take_buf(p, n)

@@ -1,0 +1,124 @@
+"""The library's native read ingest (qm_reader_*) and SAM writer (qm_sam_*) against the Python reader /
+formatter and the reference digests.  No GPU: hit sets come from the oracle (the checker), the code under test
+is host code of libqmap_mi355.so."""
+import gzip
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, load_oracle
+from util import pack
+
+
+def _batches(path1, path2, chunk, threads=4):
+    import rapmap_amd as ra
+    rd = ra.FastxReader(path1, path2, threads=threads)
+    out = []
+    for b in rd.chunks(chunk):
+        c = ra.ReadBatch(); c.n = b.n
+        for k in ("seq1", "off1", "names1", "name_off1", "seq2", "off2", "names2", "name_off2"):
+            if hasattr(b, k):
+                setattr(c, k, np.array(getattr(b, k), copy=True))
+        out.append(c)
+    rd.close()
+    return out
+
+
+def _join(batches, key, okey):
+    seqs = []
+    for b in batches:
+        a, o = getattr(b, key), getattr(b, okey)
+        seqs += [a[o[i]:o[i + 1]].tobytes() for i in range(b.n)]
+    return seqs
+
+
+def test_reader_matches_python_reader(sample_data, tmp_path):
+    from rapmap_amd import sam
+    p1 = os.path.join(GOLD, "sample_data", "reads_1.fastq.gz"); p2 = os.path.join(GOLD, "sample_data", "reads_2.fastq.gz")
+    if not os.path.exists(p1):
+        p1 = sample_data["paths"][0]; p2 = sample_data["paths"][1]
+    n1, s1 = sam.read_fastq(p1); n2, s2 = sam.read_fastq(p2)
+    # gzip input, odd chunk size
+    bs = _batches(p1, p2, 777)
+    assert sum(b.n for b in bs) == len(s1)
+    assert _join(bs, "seq1", "off1") == s1 and _join(bs, "seq2", "off2") == s2
+    assert [x.decode() for x in _join(bs, "names1", "name_off1")] == n1
+    # plain text, large enough to be split across parser threads; also CRLF and a trailing record without newline
+    plain1 = str(tmp_path / "r1.fq"); plain2 = str(tmp_path / "r2.fq")
+    reps = 40
+    with open(plain1, "wb") as f1, open(plain2, "wb") as f2:
+        for r in range(reps):
+            for i in range(len(s1)):
+                f1.write(b"@%s\n%s\n+\n%s\n" % (n1[i].encode(), s1[i], b"@" * len(s1[i])))   # '@' qualities on purpose
+                f2.write(b"@%s\r\n%s\r\n+\r\n%s\r\n" % (n2[i].encode(), s2[i], b"I" * len(s2[i])))
+        f1.write(b"@last/1\nACGT\n+\nIIII")
+        f2.write(b"@last/2\nTTGCA\n+\nIIIII")
+    bs = _batches(plain1, plain2, 100000, threads=8)
+    got1 = _join(bs, "seq1", "off1"); got2 = _join(bs, "seq2", "off2")
+    assert got1 == s1 * reps + [b"ACGT"] and got2 == s2 * reps + [b"TTGCA"]
+    nm = _join(bs, "names2", "name_off2")
+    assert nm[-1] == b"last/2" and nm[0].decode() == n2[0]
+
+
+def test_reader_fasta_and_errors(tmp_path):
+    import rapmap_amd as ra
+    fa = str(tmp_path / "x.fa")
+    with open(fa, "w") as f:
+        f.write(">a desc\nACGT\nAC\n>b\nGG\n\n>c\nT")
+    (b,) = _batches(fa, None, 10)
+    assert _join([b], "seq1", "off1") == [b"ACGTAC", b"GG", b"T"]
+    assert _join([b], "names1", "name_off1") == [b"a desc", b"b", b"c"]
+    bad = str(tmp_path / "bad.fq")
+    with open(bad, "w") as f:
+        f.write("@r\nACGT\nIIII\n")
+    with pytest.raises(ra.QmError):
+        _batches(bad, None, 10)
+    with pytest.raises(ra.QmError):
+        ra.FastxReader(str(tmp_path / "missing.fq"))
+
+
+def test_sam_writer_reproduces_the_reference_digest(sample_data, oracle_mod):
+    """native header + records on oracle hits == the md5 the reference's own SAM has on sample_data"""
+    import rapmap_amd as ra
+    ix, orc = load_oracle(sample_data["idx"])
+    qi = ra.QuasiIndex(sample_data["idx"])
+    q1, o1 = pack(sample_data["reads1"]); q2, o2 = pack(sample_data["reads2"])
+    res = orc.map_pairs(q1, o1, q2, o2, nthreads=2)
+    b = ra.ReadBatch(); b.n = len(o1) - 1
+    b.seq1, b.off1, b.seq2, b.off2 = q1, o1, q2, o2
+    nm1, no1 = pack([x.encode() for x in sample_data["names1"]]); nm2, no2 = pack([x.encode() for x in sample_data["names2"]])
+    b.names1, b.name_off1, b.names2, b.name_off2 = nm1, no1, nm2, no2
+    body = ra.sam_records_text(qi, b, res.hit_offsets, res.hits, threads=3)
+    head = ra.sam_header_text(qi)
+    text = b"".join(l for l in (head + body).splitlines(True) if not l.startswith(b"@PG"))
+    want = open(os.path.join(GOLD, "sample_data", "expected_sam_body.md5")).read().strip()
+    assert hashlib.md5(text).hexdigest() == want
+
+
+@pytest.mark.parametrize("opts", [{}, {"maxNumHits": 3}, {"fuzzy": 1}])
+def test_sam_writer_matches_python_formatter(synth_small, oracle_mod, opts):
+    import rapmap_amd as ra
+    from rapmap_amd import sam
+    ix, orc = load_oracle(synth_small["idx"])
+    qi = ra.QuasiIndex(synth_small["idx"])
+    q1, o1 = pack(synth_small["reads1"]); q2, o2 = pack(synth_small["reads2"])
+    oo = oracle_mod.default_opts(**opts)
+    res = orc.map_pairs(q1, o1, q2, o2, opts=oo, nthreads=4)
+    b = ra.ReadBatch(); b.n = len(o1) - 1
+    b.seq1, b.off1, b.seq2, b.off2 = q1, o1, q2, o2
+    b.names1, b.name_off1 = pack([x.encode() for x in synth_small["names1"]])
+    b.names2, b.name_off2 = pack([x.encode() for x in synth_small["names2"]])
+    got = ra.sam_records_text(qi, b, res.hit_offsets, res.hits, max_num_hits=oo.maxNumHits, threads=4)
+    want = "".join(sam.format_pair(synth_small["names1"][i], synth_small["reads1"][i], synth_small["names2"][i],
+                                   synth_small["reads2"][i], res.hits[res.hit_offsets[i]:res.hit_offsets[i + 1]],
+                                   ix.names, ix.txpLens, oo.maxNumHits) for i in range(b.n))
+    assert got == want.encode()
+    # single-end
+    rs = orc.map_single(q1, o1, opts=oo, nthreads=2)
+    sb = ra.ReadBatch(); sb.n = b.n; sb.seq1, sb.off1, sb.names1, sb.name_off1 = q1, o1, b.names1, b.name_off1
+    got = ra.sam_records_text(qi, sb, rs.hit_offsets, rs.hits, max_num_hits=oo.maxNumHits, threads=2)
+    want = "".join(sam.format_single(synth_small["names1"][i], synth_small["reads1"][i],
+                                     rs.hits[rs.hit_offsets[i]:rs.hit_offsets[i + 1]], ix.names, ix.txpLens) for i in range(sb.n))
+    assert got == want.encode()
