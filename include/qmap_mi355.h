@@ -181,6 +181,11 @@ int qm_sam_records(const qm_index* ix, int64_t n, const char* names1, const int6
                    const int64_t* off1, const char* names2, const int64_t* name_off2, const char* seq2,
                    const int64_t* off2, const int64_t* hit_offsets, const qm_hit* hits, int32_t max_num_hits,
                    int32_t n_threads, char** out, int64_t* out_len);
+/* the same text written straight to an open file descriptor (no copy through the caller) */
+int qm_sam_write(const qm_index* ix, int64_t n, const char* names1, const int64_t* name_off1, const char* seq1,
+                 const int64_t* off1, const char* names2, const int64_t* name_off2, const char* seq2,
+                 const int64_t* off2, const int64_t* hit_offsets, const qm_hit* hits, int32_t max_num_hits,
+                 int32_t n_threads, int fd, int64_t* bytes_written);
 void qm_buf_free(char* p);
 
 #ifdef __cplusplus

@@ -86,6 +86,11 @@ def _quasimap(argv):
         else:
             out = sys.stdout.buffer
         out.write(ra.sam_header_text(qi))
+        out.flush()
+    # uncompressed output goes from the library straight to the file descriptor
+    direct_fd = out.fileno() if (out is not None and not (a.output and a.compressed)) else None
+    if out is None:
+        direct_fd = None
     tot = {"numReads": 0, "totHits": 0, "peHits": 0, "seHits": 0, "tooManyHits": 0}
     t0 = time.time()
     gpu_ms = 0.0
@@ -110,7 +115,10 @@ def _quasimap(argv):
             for kk in tot:
                 tot[kk] += r.counters[kk]
             if out is not None:
-                out.write(ra.sam_records_text(qi, b, r.hit_offsets, r.hits, max_num_hits=a.maxNumHits, threads=nthr))
+                if direct_fd is not None:
+                    ra.sam_records_text(qi, b, r.hit_offsets, r.hits, max_num_hits=a.maxNumHits, threads=nthr, fd=direct_fd)
+                else:
+                    out.write(ra.sam_records_text(qi, b, r.hit_offsets, r.hits, max_num_hits=a.maxNumHits, threads=nthr))
             if paired:
                 log("saw %d reads : pe / read = %.4f : se / read = %.4f" % (
                     tot["numReads"], tot["peHits"] / max(1, tot["numReads"]), tot["seHits"] / max(1, tot["numReads"])))

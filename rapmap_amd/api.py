@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "qm_map_pairs", "qm_map_reads", "qm_map_device", "qm_fetch_hits", "qm_result_device", "qm_ctx_set_debug",
     "qm_fetch_intervals", "qm_last_kernel_ms", "qm_build_index",
     "qm_reader_open", "qm_reader_next", "qm_reader_close", "qm_io_last_error", "qm_sam_header", "qm_sam_records",
-    "qm_buf_free",
+    "qm_sam_write", "qm_buf_free",
 ]
 
 
@@ -111,6 +111,8 @@ def lib():
     L.qm_sam_header.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     L.qm_sam_records.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 10 + [C.c_int32, C.c_int32,
                                  C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    L.qm_sam_write.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 10 + [C.c_int32, C.c_int32, C.c_int,
+                               C.POINTER(C.c_int64)]
     L.qm_buf_free.argtypes = [C.c_void_p]
     _lib = L
     return L
@@ -347,8 +349,9 @@ def sam_header_text(index: "QuasiIndex") -> bytes:
     return _take_buf(p, n)
 
 
-def sam_records_text(index: "QuasiIndex", batch, hit_offsets, hits, max_num_hits=200, threads=None) -> bytes:
-    """SAM records of one mapped ReadBatch (paired when the batch has mates), formatted by the library"""
+def sam_records_text(index: "QuasiIndex", batch, hit_offsets, hits, max_num_hits=200, threads=None, fd=None):
+    """SAM records of one mapped ReadBatch (paired when the batch has mates), formatted by the library.
+    fd=None: returns the text; otherwise writes it to that file descriptor and returns the byte count."""
     def vp(a):
         return C.c_void_p(np.ascontiguousarray(a).ctypes.data) if a is not None and len(a) else C.c_void_p(0)
     ho = np.ascontiguousarray(hit_offsets, dtype=np.int64)
@@ -361,6 +364,15 @@ def sam_records_text(index: "QuasiIndex", batch, hit_offsets, hits, max_num_hits
     # a zero-length sequence array still needs a non-null pointer
     if not keep[2].size:
         args[2] = C.c_void_p(ho.ctypes.data)
+    nthr = int(threads or min(16, os.cpu_count() or 1))
+    if fd is not None:
+        nb = C.c_int64()
+        rc = lib().qm_sam_write(index._h, int(batch.n), *args, C.c_void_p(ho.ctypes.data),
+                                C.c_void_p(hh.ctypes.data if hh.size else ho.ctypes.data), int(max_num_hits), nthr, int(fd),
+                                C.byref(nb))
+        if rc != 0:
+            raise QmError(lib().qm_io_last_error().decode())
+        return nb.value
     p = C.c_void_p(); n = C.c_int64()
     rc = lib().qm_sam_records(index._h, int(batch.n), *args, C.c_void_p(ho.ctypes.data),
                               C.c_void_p(hh.ctypes.data if hh.size else ho.ctypes.data), int(max_num_hits),

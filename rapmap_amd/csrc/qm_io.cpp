@@ -426,16 +426,16 @@ int qm_sam_header(const qm_index* ix, char** out, int64_t* out_len) {
   return QM_OK;
 }
 
-int qm_sam_records(const qm_index* ix, int64_t n, const char* names1, const int64_t* name_off1, const char* seq1,
-                   const int64_t* off1, const char* names2, const int64_t* name_off2, const char* seq2,
-                   const int64_t* off2, const int64_t* hit_offsets, const qm_hit* hits, int32_t max_num_hits,
-                   int32_t n_threads, char** out, int64_t* out_len) {
-  if (!ix || !names1 || !name_off1 || !seq1 || !off1 || !hit_offsets || !out || !out_len || n < 0)
+static int sam_parts(const qm_index* ix, int64_t n, const char* names1, const int64_t* name_off1, const char* seq1,
+                     const int64_t* off1, const char* names2, const int64_t* name_off2, const char* seq2,
+                     const int64_t* off2, const int64_t* hit_offsets, const qm_hit* hits, int32_t max_num_hits,
+                     int32_t n_threads, std::vector<std::string>& parts) {
+  if (!ix || !names1 || !name_off1 || !seq1 || !off1 || !hit_offsets || n < 0)
     return io_fail(QM_E_ARG, "qm_sam_records: bad argument");
   const bool paired = seq2 != nullptr;
   if (paired && (!names2 || !name_off2 || !off2)) return io_fail(QM_E_ARG, "qm_sam_records: incomplete mate arrays");
   int T = std::max(1, std::min<int>(n_threads, (int)((n + 4095) / 4096)));
-  std::vector<std::string> parts((size_t)T);
+  parts.assign((size_t)T, std::string());
   SamCtx C{ix, max_num_hits};
   auto work = [&](int t) {
     std::string& o = parts[(size_t)t];
@@ -455,12 +455,43 @@ int qm_sam_records(const qm_index* ix, int64_t n, const char* names1, const int6
   };
   if (T == 1) work(0);
   else { std::vector<std::thread> th; for (int t = 0; t < T; ++t) th.emplace_back(work, t); for (auto& x : th) x.join(); }
+  return QM_OK;
+}
+
+int qm_sam_records(const qm_index* ix, int64_t n, const char* names1, const int64_t* name_off1, const char* seq1,
+                   const int64_t* off1, const char* names2, const int64_t* name_off2, const char* seq2,
+                   const int64_t* off2, const int64_t* hit_offsets, const qm_hit* hits, int32_t max_num_hits,
+                   int32_t n_threads, char** out, int64_t* out_len) {
+  if (!out || !out_len) return io_fail(QM_E_ARG, "qm_sam_records: bad argument");
+  std::vector<std::string> parts;
+  int rc = sam_parts(ix, n, names1, name_off1, seq1, off1, names2, name_off2, seq2, off2, hit_offsets, hits, max_num_hits, n_threads, parts);
+  if (rc) return rc;
   size_t tot = 0; for (auto& p : parts) tot += p.size();
   char* b = (char*)malloc(tot + 1);
   if (!b) return io_fail(QM_E_NOMEM, "out of memory");
   size_t at = 0; for (auto& p : parts) { memcpy(b + at, p.data(), p.size()); at += p.size(); }
   b[tot] = 0;
   *out = b; *out_len = (int64_t)tot;
+  return QM_OK;
+}
+
+int qm_sam_write(const qm_index* ix, int64_t n, const char* names1, const int64_t* name_off1, const char* seq1,
+                 const int64_t* off1, const char* names2, const int64_t* name_off2, const char* seq2,
+                 const int64_t* off2, const int64_t* hit_offsets, const qm_hit* hits, int32_t max_num_hits,
+                 int32_t n_threads, int fd, int64_t* bytes_written) {
+  std::vector<std::string> parts;
+  int rc = sam_parts(ix, n, names1, name_off1, seq1, off1, names2, name_off2, seq2, off2, hit_offsets, hits, max_num_hits, n_threads, parts);
+  if (rc) return rc;
+  int64_t tot = 0;
+  for (auto& p : parts) {
+    const char* b = p.data(); size_t left = p.size();
+    while (left > 0) {
+      ssize_t w = ::write(fd, b, left);
+      if (w < 0) return io_fail(QM_E_IO, "write failed");
+      b += w; left -= (size_t)w; tot += w;
+    }
+  }
+  if (bytes_written) *bytes_written = tot;
   return QM_OK;
 }
 

@@ -115,6 +115,11 @@ def test_sam_writer_matches_python_formatter(synth_small, oracle_mod, opts):
                                    synth_small["reads2"][i], res.hits[res.hit_offsets[i]:res.hit_offsets[i + 1]],
                                    ix.names, ix.txpLens, oo.maxNumHits) for i in range(b.n))
     assert got == want.encode()
+    import tempfile
+    with tempfile.TemporaryFile() as f:                       # same bytes through the file-descriptor writer
+        nb = ra.sam_records_text(qi, b, res.hit_offsets, res.hits, max_num_hits=oo.maxNumHits, threads=4, fd=f.fileno())
+        f.seek(0)
+        assert nb == len(got) and f.read() == got
     # single-end
     rs = orc.map_single(q1, o1, opts=oo, nthreads=2)
     sb = ra.ReadBatch(); sb.n = b.n; sb.seq1, sb.off1, sb.names1, sb.name_off1 = q1, o1, b.names1, b.name_off1
