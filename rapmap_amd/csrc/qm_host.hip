@@ -22,6 +22,7 @@
 
 #include "qm_mapper.inl"
 #include "qm_device.h"
+#include "qm_phflat.h"
 
 using namespace qm;
 
@@ -361,20 +362,30 @@ int qm_ctx_create(const qm_index* ix, int device_id, qm_ctx** out) {
     c->cap = 1;
     PhIndex P; memset(&P, 0, sizeof(P));
     const int nl = (int)ix->phLevels.size();
-    uint64_t totW = 0, totR = 0;
-    std::vector<u64> tab(3 * (size_t)nl);
-    for (int i = 0; i < nl; ++i) { tab[3 * i] = ix->phLevels[i].domain; tab[3 * i + 1] = totW; tab[3 * i + 2] = totR; totW += ix->phLevels[i].nchar; totR += ix->phLevels[i].nranks; }
-    auto dalloc = [&](size_t bytes) -> void* { void* q = nullptr; if (hipMalloc(&q, bytes ? bytes : 16) != hipSuccess) return nullptr; c->phAllocs.push_back(q); c->devBytes += (int64_t)bytes; return q; };
-    u64* dW = (u64*)dalloc(totW * 8); u64* dR = (u64*)dalloc(totR * 8); u64* dT = (u64*)dalloc(tab.size() * 8);
-    int* dD = (int*)dalloc((size_t)ix->phNelem * 4); unsigned char* dL = (unsigned char*)dalloc((size_t)ix->phNelem);
-    if (!dW || !dR || !dT || !dD || !dL) { int rc = fail(QM_E_NOMEM, "hipMalloc (perfect hash) failed"); qm_ctx_destroy(c); return rc; }
+    std::vector<PhLevelIn> lin((size_t)nl);
     for (int i = 0; i < nl; ++i) {
-      CK(hipMemcpyAsync(dW + tab[3 * i + 1], ix->phLevels[i].words, ix->phLevels[i].nchar * 8, hipMemcpyHostToDevice, c->stream));
-      if (ix->phLevels[i].nranks) CK(hipMemcpyAsync(dR + tab[3 * i + 2], ix->phLevels[i].ranks, ix->phLevels[i].nranks * 8, hipMemcpyHostToDevice, c->stream));
+      lin[i].words = (const uint64_t*)ix->phLevels[i].words; lin[i].nchar = ix->phLevels[i].nchar; lin[i].domain = ix->phLevels[i].domain;
+      lin[i].ranks = (const uint64_t*)ix->phLevels[i].ranks; lin[i].nranks = ix->phLevels[i].nranks;
     }
+    std::vector<uint64_t> blocks, tab;
+    if (!ph_flatten_blocks(lin, blocks, tab)) { int rc = fail(QM_E_IO, "hash_info.bph: rank samples do not match the bit arrays"); qm_ctx_destroy(c); return rc; }
+    auto dalloc = [&](size_t bytes) -> void* { void* q = nullptr; if (hipMalloc(&q, bytes ? bytes : 16) != hipSuccess) return nullptr; c->phAllocs.push_back(q); c->devBytes += (int64_t)bytes; return q; };
+    u64* dW = (u64*)dalloc(blocks.size() * 8); u64* dT = (u64*)dalloc(tab.size() * 8);
+    PhRec* dRec = (PhRec*)dalloc((size_t)ix->phNelem * sizeof(PhRec));
+    int* dD = nullptr; unsigned char* dL = nullptr;          // staging for the record builder
+    if (hipMalloc((void**)&dD, (size_t)(ix->phNelem ? ix->phNelem : 1) * 4) != hipSuccess || hipMalloc((void**)&dL, (size_t)(ix->phNelem ? ix->phNelem : 1)) != hipSuccess) dD = nullptr;
+    if (!dW || !dT || !dRec || !dD || !dL) { int rc = fail(QM_E_NOMEM, "hipMalloc (perfect hash) failed"); qm_ctx_destroy(c); return rc; }
+    CK(hipMemcpyAsync(dW, blocks.data(), blocks.size() * 8, hipMemcpyHostToDevice, c->stream));
     CK(hipMemcpyAsync(dT, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, c->stream));
     CK(hipMemcpyAsync(dD, ix->phData, (size_t)ix->phNelem * 4, hipMemcpyHostToDevice, c->stream));
     CK(hipMemcpyAsync(dL, ix->phLens, (size_t)ix->phNelem, hipMemcpyHostToDevice, c->stream));
+    {
+      DevIndex dix; memset(&dix, 0, sizeof(dix));
+      dix.text = c->d_text; dix.n = ix->n; dix.SA = c->d_SA; dix.nSA = ix->nSA; dix.k = ix->k;
+      CK(qmk_build_phrecs(dD, dL, ix->phNelem, &dix, dRec, c->stream));
+      CK(hipStreamSynchronize(c->stream));
+      hipFree(dD); hipFree(dL);
+    }
     auto mix = [](u64 x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; };
     std::vector<OvfSlot> ov; std::vector<Slot> fin;
     {
@@ -393,7 +404,7 @@ int qm_ctx_create(const qm_index* ix, int device_id, qm_ctx** out) {
     if (!dO || !dF || !dP) { int rc = fail(QM_E_NOMEM, "hipMalloc (perfect hash) failed"); qm_ctx_destroy(c); return rc; }
     CK(hipMemcpyAsync(dO, ov.data(), ov.size() * sizeof(OvfSlot), hipMemcpyHostToDevice, c->stream));
     CK(hipMemcpyAsync(dF, fin.data(), fin.size() * sizeof(Slot), hipMemcpyHostToDevice, c->stream));
-    P.words = dW; P.ranks = dR; P.levelTab = dT; P.data = dD; P.lens = dL; P.ovf = dO; P.fin = dF;
+    P.blocks = dW; P.levelTab = dT; P.recs = dRec; P.ovf = dO; P.fin = dF;
     P.lastbitsetrank = ix->phLastRank; P.nelem = ix->phNelem; P.nb_levels = nl;
     CK(hipMemcpyAsync(dP, &P, sizeof(P), hipMemcpyHostToDevice, c->stream));
     CK(hipStreamSynchronize(c->stream));    // P, tab, ov, fin are locals

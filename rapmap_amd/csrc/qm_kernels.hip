@@ -106,6 +106,19 @@ __global__ void build_slots_kernel(const Slot* recs, long long K, Bucket* bucket
   }
 }
 
+// perfect-hash value records: {data_[i], lens_[i], fingerprint of the k-mer at text[SA[data_[i]]]}
+__global__ void build_phrec_kernel(const int* data, const unsigned char* lens, long long n, DevIndex ix, PhRec* out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    PhRec r; r.data = data[i]; r.len = lens[i]; r.pad = 0;
+    u64 m = 0;
+    if (r.data >= 0 && r.data < ix.nSA) text_kmer(ix, (long long)ix.SA[r.data], ix.k, m);
+    r.fp = ph_fingerprint(m);
+    out[i] = r;
+  }
+}
+
 struct U32ToI64 { __device__ long long operator()(u32 x) const { return (long long)x; } };
 
 }  // namespace qm
@@ -123,6 +136,12 @@ hipError_t qmk_build_slots(const void* recs, long long K, void* slots, unsigned 
   hipError_t e = hipMemsetAsync(slots, 0xff, cap * sizeof(Bucket), st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(build_slots_kernel, dim3(4096), dim3(256), 0, st, (const Slot*)recs, K, (Bucket*)slots, cap - 1);
+  return hipGetLastError();
+}
+
+hipError_t qmk_build_phrecs(const int* data, const unsigned char* lens, long long n, const void* dev_index, void* out, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(build_phrec_kernel, dim3(4096), dim3(256), 0, st, data, lens, n, *(const DevIndex*)dev_index, (PhRec*)out);
   return hipGetLastError();
 }
 

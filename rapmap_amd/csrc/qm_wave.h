@@ -104,6 +104,10 @@ struct U4 { u32 x, y, z, w; };
 QM_DEV U4 load_16(const void* p) { U4 v; __builtin_memcpy(&v, p, 16); return v; }
 QM_DEV long long load_uniform_i64(const long long* p) { return *p; }
 QM_DEV void load_32(const void* p, U4& a, U4& b) { a = load_16(p); b = load_16((const unsigned char*)p + 16); }
+QM_DEV void load_8_16(const u64* p8, const u64* p16, u64& a, U4& b) { a = *p8; b = load_16(p16); }
+QM_DEV void load_8_16x2(const u64* p8, const u64* p16, u64& a, U4& b, const u64* q8, const u64* q16, u64& c, U4& d) {
+  load_8_16(p8, p16, a, b); load_8_16(q8, q16, c, d);
+}
 #else
 QM_DEV int wave_max(const LV<int>& x) {
   int v = x.v[0];
@@ -137,6 +141,19 @@ QM_DEV void load_32(const void* p, U4& a, U4& b) {
   v4u x = ((const v4u*)p)[0], y = ((const v4u*)p)[1];
   asm volatile("" : "+v"(x), "+v"(y));
   a.x = x.x; a.y = x.y; a.z = x.z; a.w = x.w; b.x = y.x; b.y = y.y; b.z = y.z; b.w = y.w;
+}
+// an 8-byte and a 16-byte load issued together (see load_32)
+QM_DEV void load_8_16(const u64* p8, const u64* p16, u64& a, U4& b) {
+  typedef u32 v4u __attribute__((ext_vector_type(4)));
+  u64 x = *p8; v4u y = *(const v4u*)p16;
+  asm volatile("" : "+v"(x), "+v"(y));
+  a = x; b.x = y.x; b.y = y.y; b.z = y.z; b.w = y.w;
+}
+QM_DEV void load_8_16x2(const u64* p8, const u64* p16, u64& a, U4& b, const u64* q8, const u64* q16, u64& c, U4& d) {
+  typedef u32 v4u __attribute__((ext_vector_type(4)));
+  u64 x = *p8; v4u y = *(const v4u*)p16; u64 z = *q8; v4u w = *(const v4u*)q16;
+  asm volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(w));
+  a = x; b.x = y.x; b.y = y.y; b.z = y.z; b.w = y.w; c = z; d.x = w.x; d.y = w.y; d.z = w.z; d.w = w.w;
 }
 #endif
 

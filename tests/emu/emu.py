@@ -9,7 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libqm_emu.so")
 _SRC = [os.path.join(_HERE, "qm_emu.cpp"),
         os.path.join(_HERE, "../../rapmap_amd/csrc/qm_mapper.inl"),
-        os.path.join(_HERE, "../../rapmap_amd/csrc/qm_wave.h")]
+        os.path.join(_HERE, "../../rapmap_amd/csrc/qm_wave.h"),
+        os.path.join(_HERE, "../../rapmap_amd/csrc/qm_phflat.h")]
 
 HIT_DTYPE = np.dtype([
     ("tid", "<u4"), ("pos", "<i4"), ("mate_pos", "<i4"), ("frag_len", "<u4"),
@@ -85,7 +86,10 @@ class Emu:
             self.ph = self.lib.qe_ph_create(C.c_void_p(k[0].ctypes.data), C.c_void_p(k[1].ctypes.data), C.c_void_p(k[2].ctypes.data),
                                             C.c_int(boo.nb_levels), C.c_void_p(k[3].ctypes.data), C.c_void_p(k[4].ctypes.data),
                                             C.c_uint64(boo.nelem), C.c_uint64(boo.lastbitsetrank), C.c_void_p(k[5].ctypes.data),
-                                            C.c_int64(len(ovf)), C.c_void_p(k[6].ctypes.data), C.c_int64(len(boo.final)))
+                                            C.c_int64(len(ovf)), C.c_void_p(k[6].ctypes.data), C.c_int64(len(boo.final)),
+                                            C.c_uint64(wo), C.c_uint64(ro), C.c_int(ix.k), C.c_void_p(self.text.ctypes.data),
+                                            C.c_int64(self.n), C.c_void_p(self.SA.ctypes.data), C.c_int64(self.SA.size))
+            assert self.ph, "rank samples of hash_info.bph do not match its bit arrays"
         self.lib.qe_flatten(C.c_void_p(self.SA.ctypes.data), C.c_int64(self.SA.size), C.c_void_p(off.ctypes.data),
                             C.c_int64(off.size), C.c_void_p(self.sainfo.ctypes.data), C.c_void_p(hk.ctypes.data),
                             C.c_void_p(hl.ctypes.data), C.c_void_p(hu.ctypes.data), C.c_int64(hk.size),

@@ -8,6 +8,7 @@
 namespace qm { unsigned long long qm_prof[32]; }
 #endif
 #include "../../rapmap_amd/csrc/qm_mapper.inl"
+#include "../../rapmap_amd/csrc/qm_phflat.h"
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -99,10 +100,32 @@ void qe_free(void* p) { free(p); }
 void* qe_ph_create(const unsigned long long* words, const unsigned long long* ranks, const unsigned long long* levelTab,
                    int nb_levels, const int* data, const unsigned char* lens, unsigned long long nelem,
                    unsigned long long lastbitsetrank, const int* ovf_kv, long long n_ovf,
-                   const unsigned long long* fin_kv, long long n_fin) {
+                   const unsigned long long* fin_kv, long long n_fin,
+                   unsigned long long total_words, unsigned long long total_ranks,
+                   int k, const unsigned char* text, long long n, const int* SA, long long nSA) {
   PhIndex* P = new PhIndex();
   memset(P, 0, sizeof(*P));
-  P->words = words; P->ranks = ranks; P->levelTab = levelTab; P->data = data; P->lens = lens;
+  // levelTab here: {domain, first word, first rank sample} per level, as read from hash_info.bph
+  std::vector<PhLevelIn> lin((size_t)nb_levels);
+  for (int i = 0; i < nb_levels; ++i) {
+    const u64 w0 = levelTab[3 * i + 1], r0 = levelTab[3 * i + 2];
+    const u64 w1 = i + 1 < nb_levels ? levelTab[3 * (i + 1) + 1] : total_words, r1 = i + 1 < nb_levels ? levelTab[3 * (i + 1) + 2] : total_ranks;
+    lin[i].words = (const uint64_t*)words + w0; lin[i].nchar = w1 - w0; lin[i].domain = levelTab[3 * i];
+    lin[i].ranks = (const uint64_t*)ranks + r0; lin[i].nranks = r1 - r0;
+  }
+  std::vector<uint64_t>* blocks = new std::vector<uint64_t>(); std::vector<uint64_t>* tab = new std::vector<uint64_t>();
+  if (!ph_flatten_blocks(lin, *blocks, *tab)) return nullptr;
+  P->blocks = (const u64*)blocks->data(); P->levelTab = (const u64*)tab->data();
+  PhRec* recs = new PhRec[nelem ? nelem : 1];
+  DevIndex dix; memset(&dix, 0, sizeof(dix)); dix.text = text; dix.n = n; dix.SA = SA; dix.nSA = nSA; dix.k = k;
+  for (u64 i = 0; i < nelem; ++i) {
+    PhRec r; r.data = data[i]; r.len = lens[i]; r.pad = 0;
+    u64 m = 0;
+    if (r.data >= 0 && r.data < nSA) text_kmer(dix, (long long)SA[r.data], k, m);
+    r.fp = ph_fingerprint(m);
+    recs[i] = r;
+  }
+  P->recs = recs;
   P->nelem = nelem; P->lastbitsetrank = lastbitsetrank; P->nb_levels = nb_levels;
   u64 cap = 16; while (cap < (u64)n_ovf * 2) cap <<= 1;
   OvfSlot* ov = new OvfSlot[cap];
