@@ -106,15 +106,15 @@ __global__ void build_slots_kernel(const Slot* recs, long long K, Bucket* bucket
   }
 }
 
-// perfect-hash value records: {data_[i], lens_[i], fingerprint of the k-mer at text[SA[data_[i]]]}
+// perfect-hash value records: {k-mer word at text[SA[data_[i]]] (partial word if a '$' is hit), data_[i], lens_[i]}
 __global__ void build_phrec_kernel(const int* data, const unsigned char* lens, long long n, DevIndex ix, PhRec* out) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long stride = (long long)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
-    PhRec r; r.data = data[i]; r.len = lens[i]; r.pad = 0;
+    PhRec r; r.data = data[i]; r.len = lens[i]; r.pad[0] = r.pad[1] = r.pad[2] = 0;
     u64 m = 0;
     if (r.data >= 0 && r.data < ix.nSA) text_kmer(ix, (long long)ix.SA[r.data], ix.k, m);
-    r.fp = ph_fingerprint(m);
+    r.key = m;
     out[i] = r;
   }
 }

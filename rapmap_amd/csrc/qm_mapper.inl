@@ -55,19 +55,21 @@ struct IntRec { int b, e; u32 len, q; };           // SAIntervalHit (RapMapUtils
 // Perfect-hash (`quasiindex -p`) seed map, flattened: BooPHF levels + FrugalBooMap values
 // (include/BooPHF.hpp, include/FrugalBooMap.hpp).  The level bit arrays are re-blocked so that one 64-byte
 // sector answers "bit set?" and "rank?" (qm_phflat.h); levelTab[2*i + {0,1}] = {hash domain, first block} of
-// level i.  data_/lens_ are merged into one 8-byte record per slot together with a 16-bit fingerprint of the
-// slot's k-mer, so a key that is not in the index is rejected without the SA and text reads that the
-// reference's `Kmer(txt + SA[data_[idx]]) == key` test costs (FrugalBooMap.hpp:149-167).
+// level i.  data_/lens_ are merged into one 16-byte record per slot together with the slot's k-mer word itself
+// (what the reference re-encodes from the text on every lookup: `Kmer(txt + SA[data_[idx]]) == key`,
+// FrugalBooMap.hpp:149-167), so the verification costs no SA and no text read -- 288 GB of HBM pays for it.
 #ifndef QM_PH_BLOCK_BITS
 #define QM_PH_BLOCK_BITS 384
 #endif
+#ifndef QM_PH_SPEC
+#define QM_PH_SPEC 2      // BooPHF levels looked up per round of loads
+#endif
 struct OvfSlot { int key; int val; };              // overflow_: interval start -> length (>= 255); key -1 empty
-struct PhRec { int data; unsigned char len; unsigned char pad; unsigned short fp; };
-QM_DEV unsigned short ph_fingerprint(u64 kmer_word);
+struct PhRec { u64 key; int data; unsigned char len; unsigned char pad[3]; };
 struct PhIndex {
   const u64* blocks;            // 8 u64 per block: 6 words of bits, rank of the first bit, 6 x 9-bit popcount prefix
   const u64* levelTab;
-  const PhRec* recs;            // {data_[idx]: SA index where the interval starts, lens_[idx] (255 => overflow), fingerprint}
+  const PhRec* recs;            // {k-mer word of the slot, data_[idx]: SA index where the interval starts, lens_[idx] (255 => overflow)}
   const OvfSlot* ovf; u64 ovfMask;
   const Slot* fin; u64 finMask; // _final_hash: key -> value (in lb), key ~0 empty
   u64 lastbitsetrank, nelem;
@@ -221,7 +223,6 @@ QM_DEV u64 hash_mix(u64 x) {
   x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33;
   x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x;
 }
-QM_DEV unsigned short ph_fingerprint(u64 w) { return (unsigned short)(hash_mix(w) >> 48); }
 QM_DEV int upc(unsigned char c) {   // ::toupper on a (signed) char, C locale
   int v = (signed char)c;
   return (v >= 'a' && v <= 'z') ? v - 32 : v;
@@ -314,37 +315,33 @@ QM_DEV bool find_kmer(const DevIndex& ix, u64 key, int& lb, int& ub) {
   u64 s0 = 0, s1 = 0, h = 0;
   u64 idx = 0;
   bool inLevel = false;
-  // Two levels per round: the loads of level i and i+1 are issued together, so the walk (whose depth is the
+  // QM_PH_SPEC levels per round: their loads are issued together, so the walk (whose depth is the
   // maximum over the 64 keys of a probe window) needs half as many dependent trips to HBM.
   const int nlv = P.nb_levels - 1;
-  for (int ii = 0; ii < nlv; ii += 2) {
-    u64 hh[2];
+  for (int ii = 0; ii < nlv; ii += QM_PH_SPEC) {
+    const u64* Bp[QM_PH_SPEC]; int bitp[QM_PH_SPEC]; u64 word[QM_PH_SPEC]; U4 meta[QM_PH_SPEC];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int lv = ii + t;
-      if (lv == 0) { s0 = boo_hash64(key, 0xAAAAAAAA55555555ULL); h = s0; }
-      else if (lv == 1) { s1 = boo_hash64(key, 0x33333333CCCCCCCCULL); h = s1; }
-      else { u64 a = s0; const u64 b = s1; s0 = b; a ^= a << 23; s1 = a ^ b ^ (a >> 17) ^ (b >> 26); h = s1 + b; }
-      hh[t] = h;
-    }
-    const bool two = ii + 1 < nlv;
-    const u64* Bp[2]; int bitp[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int lv = (t == 1 && !two) ? ii : ii + t;
+    for (int t = 0; t < QM_PH_SPEC; ++t) {
+      const int lv = ii + t < nlv ? ii + t : nlv - 1;       // past the last level: a harmless repeat
+      if (ii + t < nlv) {
+        if (lv == 0) { s0 = boo_hash64(key, 0xAAAAAAAA55555555ULL); h = s0; }
+        else if (lv == 1) { s1 = boo_hash64(key, 0x33333333CCCCCCCCULL); h = s1; }
+        else { u64 a = s0; const u64 b = s1; s0 = b; a ^= a << 23; s1 = a ^ b ^ (a >> 17) ^ (b >> 26); h = s1 + b; }
+      }
       const u64 dom = P.levelTab[2 * lv], fb = P.levelTab[2 * lv + 1];
-      const u64 pos = fastrange64(hh[(t == 1 && !two) ? 0 : t], dom);
+      const u64 pos = fastrange64(h, dom);
       const u64 blk = pos / QM_PH_BLOCK_BITS;
       bitp[t] = (int)(pos - blk * QM_PH_BLOCK_BITS);
       Bp[t] = P.blocks + (fb + blk) * 8;
     }
-    u64 word[2]; U4 meta[2];
-    load_8_16x2(Bp[0] + (bitp[0] >> 6), Bp[0] + 6, word[0], meta[0], Bp[1] + (bitp[1] >> 6), Bp[1] + 6, word[1], meta[1]);
+    load_8_16xN<QM_PH_SPEC>(Bp, bitp, word, meta);
     int t = -1;
-    if ((word[0] >> (bitp[0] & 63)) & 1) t = 0;
-    else if (two && ((word[1] >> (bitp[1] & 63)) & 1)) t = 1;
+#pragma unroll
+    for (int u = QM_PH_SPEC - 1; u >= 0; --u) if (ii + u < nlv && ((word[u] >> (bitp[u] & 63)) & 1)) t = u;
     if (t >= 0) {
-      const u64 wd = t == 0 ? word[0] : word[1]; const U4 mt = t == 0 ? meta[0] : meta[1]; const int bit = t == 0 ? bitp[0] : bitp[1];
+      u64 wd = word[0]; U4 mt = meta[0]; int bit = bitp[0];
+#pragma unroll
+      for (int u = 1; u < QM_PH_SPEC; ++u) if (t == u) { wd = word[u]; mt = meta[u]; bit = bitp[u]; }
       const u64 base = ((u64)mt.y << 32) | mt.x, pref = ((u64)mt.w << 32) | mt.z;
       idx = base + ((pref >> (9 * (bit >> 6))) & 511) + (u64)popc64(wd & ((1ULL << (bit & 63)) - 1));
       inLevel = true;
@@ -362,13 +359,10 @@ QM_DEV bool find_kmer(const DevIndex& ix, u64 key, int& lb, int& ub) {
     }
   }
   if (idx >= P.nelem) return false;                         // FrugalBooMap.hpp:151
-  const PhRec rec = P.recs[idx];
-  if (rec.fp != ph_fingerprint(key)) return false;          // cannot be the slot's k-mer
-  const int ind = rec.data;
-  u64 m;
-  text_kmer(ix, (long long)ix.SA[ind], ix.k, m);           // Kmer(txt + SA[ind]): partial word if a '$' is hit
-  if (m != key) return false;
-  int l = rec.len;
+  const U4 rr = load_16(&P.recs[idx]);                      // {key lo, key hi, data, len}
+  if ((((u64)rr.y << 32) | rr.x) != key) return false;      // Kmer(txt + SA[data_[idx]]) == key, precomputed
+  const int ind = (int)rr.z;
+  int l = (int)(rr.w & 0xff);
   if (l == 255) {
     u64 i = hash_mix((u64)(u32)ind) & P.ovfMask;
     while (true) { OvfSlot x = P.ovf[i]; if (x.key == ind) { l = x.val; break; } if (x.key == -1) { l = 0; break; } i = (i + 1) & P.ovfMask; }

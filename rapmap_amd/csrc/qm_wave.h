@@ -105,8 +105,8 @@ QM_DEV U4 load_16(const void* p) { U4 v; __builtin_memcpy(&v, p, 16); return v; 
 QM_DEV long long load_uniform_i64(const long long* p) { return *p; }
 QM_DEV void load_32(const void* p, U4& a, U4& b) { a = load_16(p); b = load_16((const unsigned char*)p + 16); }
 QM_DEV void load_8_16(const u64* p8, const u64* p16, u64& a, U4& b) { a = *p8; b = load_16(p16); }
-QM_DEV void load_8_16x2(const u64* p8, const u64* p16, u64& a, U4& b, const u64* q8, const u64* q16, u64& c, U4& d) {
-  load_8_16(p8, p16, a, b); load_8_16(q8, q16, c, d);
+template <int N> QM_DEV void load_8_16xN(const u64* const* B, const int* bit, u64* word, U4* meta) {
+  for (int t = 0; t < N; ++t) load_8_16(B[t] + (bit[t] >> 6), B[t] + 6, word[t], meta[t]);
 }
 #else
 QM_DEV int wave_max(const LV<int>& x) {
@@ -149,11 +149,16 @@ QM_DEV void load_8_16(const u64* p8, const u64* p16, u64& a, U4& b) {
   asm volatile("" : "+v"(x), "+v"(y));
   a = x; b.x = y.x; b.y = y.y; b.z = y.z; b.w = y.w;
 }
-QM_DEV void load_8_16x2(const u64* p8, const u64* p16, u64& a, U4& b, const u64* q8, const u64* q16, u64& c, U4& d) {
+// N (word, rank words) pairs of re-blocked BooPHF levels, all loads in flight before any is consumed
+template <int N> QM_DEV void load_8_16xN(const u64* const* B, const int* bit, u64* word, U4* meta) {
   typedef u32 v4u __attribute__((ext_vector_type(4)));
-  u64 x = *p8; v4u y = *(const v4u*)p16; u64 z = *q8; v4u w = *(const v4u*)q16;
-  asm volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(w));
-  a = x; b.x = y.x; b.y = y.y; b.z = y.z; b.w = y.w; c = z; d.x = w.x; d.y = w.y; d.z = w.z; d.w = w.w;
+  u64 x[N]; v4u y[N];
+#pragma unroll
+  for (int t = 0; t < N; ++t) { x[t] = B[t][bit[t] >> 6]; y[t] = *(const v4u*)(B[t] + 6); }
+#pragma unroll
+  for (int t = 0; t < N; ++t) asm volatile("" : "+v"(x[t]), "+v"(y[t]));
+#pragma unroll
+  for (int t = 0; t < N; ++t) { word[t] = x[t]; meta[t].x = y[t].x; meta[t].y = y[t].y; meta[t].z = y[t].z; meta[t].w = y[t].w; }
 }
 #endif
 

@@ -119,10 +119,10 @@ void* qe_ph_create(const unsigned long long* words, const unsigned long long* ra
   PhRec* recs = new PhRec[nelem ? nelem : 1];
   DevIndex dix; memset(&dix, 0, sizeof(dix)); dix.text = text; dix.n = n; dix.SA = SA; dix.nSA = nSA; dix.k = k;
   for (u64 i = 0; i < nelem; ++i) {
-    PhRec r; r.data = data[i]; r.len = lens[i]; r.pad = 0;
+    PhRec r; r.data = data[i]; r.len = lens[i]; r.pad[0] = r.pad[1] = r.pad[2] = 0;
     u64 m = 0;
     if (r.data >= 0 && r.data < nSA) text_kmer(dix, (long long)SA[r.data], k, m);
-    r.fp = ph_fingerprint(m);
+    r.key = m;
     recs[i] = r;
   }
   P->recs = recs;
