@@ -62,7 +62,7 @@ struct IntRec { int b, e; u32 len, q; };           // SAIntervalHit (RapMapUtils
 #define QM_PH_BLOCK_BITS 384
 #endif
 #ifndef QM_PH_SPEC
-#define QM_PH_SPEC 2      // BooPHF levels looked up per round of loads
+#define QM_PH_SPEC 3      // BooPHF levels looked up per round of loads
 #endif
 struct OvfSlot { int key; int val; };              // overflow_: interval start -> length (>= 255); key -1 empty
 struct PhRec { u64 key; int data; unsigned char len; unsigned char pad[3]; };
