@@ -2,8 +2,9 @@
 //   * qm_reader_*    FASTA/FASTQ(.gz) ingest into the packed (bytes, offsets[n+1]) batches qm_map_pairs takes.
 //                    Replaces the reference's single kseq producer + per-record std::string queue
 //                    (include/FastxParser.hpp:62-66, src/FastxParser.cpp:229-328): plain files are mmap'd and
-//                    parsed by n_threads workers on disjoint byte ranges, .gz files are inflated by one
-//                    thread per file; qualities are dropped like the reference's parser does.
+//                    indexed by n_threads workers on disjoint byte ranges, .gz files are inflated by one
+//                    thread per file; every byte is copied once, in parallel, into the packed batch;
+//                    qualities are dropped like the reference's parser does.
 //   * qm_sam_*       SAM text for a mapped batch, same bytes as `rapmap quasimap -o`
 //                    (writeSAMHeader include/RapMapUtils.hpp:97-115, writeAlignmentsToStream
 //                    src/RapMapUtils.cpp:198-588, writeUnalignedPairToStream :137-196, getSamFlags /
@@ -36,17 +37,10 @@ extern "C" const char* qm_io_last_error(void) { return g_ioerr; }
 
 namespace {
 
-// ------------------------------------------------------------------ parsed records of one file
-struct Records {
-  std::vector<char> seq, names;
-  std::vector<int64_t> off{0}, noff{0};
-  int64_t n() const { return (int64_t)off.size() - 1; }
-  void clear() { seq.clear(); names.clear(); off.assign(1, 0); noff.assign(1, 0); }
-  void push(const char* nm, size_t nl, const char* s, size_t sl) {
-    names.insert(names.end(), nm, nm + nl); noff.push_back((int64_t)names.size());
-    seq.insert(seq.end(), s, s + sl); off.push_back((int64_t)seq.size());
-  }
-};
+// ------------------------------------------------------------------ record index of one file
+// A parsed record is four pointers/lengths into storage that stays put (the mmap of a plain file, or a
+// decompressed block of a .gz file); bytes are copied exactly once, by qm_reader_next, into the packed batch.
+struct RecIdx { const char* nm; const char* s; uint32_t nl, sl; };
 
 static inline const char* eol(const char* p, const char* e) {
   const char* q = (const char*)memchr(p, '\n', (size_t)(e - p));
@@ -55,8 +49,9 @@ static inline const char* eol(const char* p, const char* e) {
 static inline size_t rstrip(const char* b, const char* e) { while (e > b && (e[-1] == '\r' || e[-1] == '\n')) --e; return (size_t)(e - b); }
 
 // Parse complete records in [p, e); returns the first byte not consumed (start of an incomplete record).
-// FASTQ: 4-line records; FASTA: header + one or more sequence lines (joined).  final: the buffer ends the file.
-static const char* parse_block(const char* p, const char* e, bool final, Records& R, bool& bad) {
+// FASTQ: 4-line records; FASTA: header + sequence lines; a multi-line FASTA sequence is joined into `arena`
+// (which must not reallocate: it is reserved to the block size).  final: the buffer ends the file.
+static const char* parse_block(const char* p, const char* e, bool final, std::vector<RecIdx>& R, std::vector<char>& arena, bool& bad) {
   while (p < e) {
     while (p < e && (*p == '\n' || *p == '\r')) ++p;
     if (p >= e) break;
@@ -71,23 +66,32 @@ static const char* parse_block(const char* p, const char* e, bool final, Records
       if (l3 == e) { if (!final) return rec; bad = true; return rec; }
       const char* q = l3 + 1; const char* l4 = eol(q, e);
       if (l4 == e && !final) return rec;
-      if (pl >= e || *pl != '+') { bad = true; return rec; }
-      R.push(p + 1, rstrip(p + 1, l1), s, rstrip(s, l2));
+      if (*pl != '+') { bad = true; return rec; }
+      R.push_back(RecIdx{p + 1, s, (uint32_t)rstrip(p + 1, l1), (uint32_t)rstrip(s, l2)});
       p = l4 < e ? l4 + 1 : e;
     } else if (*p == '>') {
       const char* s = l1 < e ? l1 + 1 : e;
-      size_t nl = rstrip(p + 1, l1);
-      size_t seq0 = R.seq.size();
-      const char* c = s;
+      const uint32_t nl = (uint32_t)rstrip(p + 1, l1);
+      // single-line sequence: reference it in place; several lines: join them in the arena
+      const char* c = s; int lines = 0; const char* first = s; size_t firstLen = 0;
+      const size_t a0 = arena.size();
       while (c < e && *c != '>') {
         const char* le = eol(c, e);
-        if (le == e && !final) { R.seq.resize(seq0); return rec; }
-        R.seq.insert(R.seq.end(), c, c + rstrip(c, le));
+        if (le == e && !final) { arena.resize(a0); return rec; }
+        const size_t ll = rstrip(c, le);
+        if (ll > 0) {
+          if (lines == 0) { first = c; firstLen = ll; }
+          else {
+            if (lines == 1) arena.insert(arena.end(), first, first + firstLen);
+            arena.insert(arena.end(), c, c + ll);
+          }
+          ++lines;
+        }
         c = le < e ? le + 1 : e;
       }
-      if (c >= e && !final) { R.seq.resize(seq0); return rec; }
-      R.names.insert(R.names.end(), p + 1, p + 1 + nl); R.noff.push_back((int64_t)R.names.size());
-      R.off.push_back((int64_t)R.seq.size());
+      if (c >= e && !final) { arena.resize(a0); return rec; }
+      if (lines <= 1) R.push_back(RecIdx{p + 1, first, nl, (uint32_t)firstLen});
+      else R.push_back(RecIdx{p + 1, arena.data() + a0, nl, (uint32_t)(arena.size() - a0)});
       p = c;
     } else { bad = true; return rec; }
   }
@@ -95,7 +99,8 @@ static const char* parse_block(const char* p, const char* e, bool final, Records
 }
 
 // start of the first FASTQ/FASTA record at or after p (p may be mid-record): a line starting with '@' whose
-// line-after-next starts with '+' (a quality line may itself start with '@'), or any line starting with '>'.
+// line-after-next starts with '+' and whose quality line is as long as its sequence line (a quality line may
+// itself start with '@'), or any line starting with '>'.
 static const char* sync_record(const char* base, const char* p, const char* e, bool fastq) {
   if (p == base) return p;
   const char* q = eol(p - 1, e);             // go to the next line start
@@ -106,7 +111,6 @@ static const char* sync_record(const char* base, const char* p, const char* e, b
       const char* l1 = eol(p, e); if (l1 == e) return e;
       const char* l2 = eol(l1 + 1, e); if (l2 == e) return e;
       if (l2 + 1 < e && l2[1] == '+') {
-        // the line after '+' must be a quality line as long as the sequence line
         const char* l3 = eol(l2 + 1, e);
         const char* l4 = l3 < e ? eol(l3 + 1, e) : e;
         if (l3 < e && rstrip(l3 + 1, l4) == rstrip(l1 + 1, l2)) return p;
@@ -118,15 +122,21 @@ static const char* sync_record(const char* base, const char* p, const char* e, b
   return e;
 }
 
+struct Block {                 // storage a run of RecIdx entries points into
+  std::vector<char> data;      // decompressed bytes (gz only)
+  std::vector<std::vector<char>> arenas;   // joined multi-line FASTA sequences, one per parser thread
+  int64_t last = 0;            // global index of the block's last record + 1
+};
+
 struct Source {
   std::string path;
   bool gz = false, fastq = true, eof = false, bad = false;
-  // plain
-  const char* map = nullptr; size_t len = 0, pos = 0;
-  // gz
-  gzFile gzf = nullptr; std::vector<char> carry;
-  Records ready;            // parsed, not yet handed out
-  int64_t taken = 0;        // records of `ready` already handed out
+  const char* map = nullptr; size_t len = 0, pos = 0;      // plain file
+  gzFile gzf = nullptr; std::vector<char> carry;            // gz: undigested tail of the previous block
+  std::vector<RecIdx> idx;      // parsed, not yet handed out: idx[head..)
+  size_t head = 0;
+  int64_t handed = 0, parsed = 0;   // global record counters
+  std::vector<Block*> blocks;   // FIFO of live storage blocks
 
   int open(const char* p) {
     path = p;
@@ -140,7 +150,6 @@ struct Source {
       gzf = gzopen(p, "rb");
       if (!gzf) return io_fail(QM_E_IO, "cannot gzopen %s", p);
       gzbuffer(gzf, 1 << 20);
-      fastq = true;          // decided at the first block
       return 0;
     }
     len = (size_t)st.st_size;
@@ -153,73 +162,111 @@ struct Source {
     ::close(fd);
     return 0;
   }
-  void close() { if (map) munmap((void*)map, len); map = nullptr; if (gzf) gzclose(gzf); gzf = nullptr; }
-
-  // parse roughly `bytes` more input into `ready`
-  void fill(size_t bytes, int nthreads) {
-    if (taken > 0) {          // drop what was handed out
-      Records r; int64_t n = ready.n();
-      if (taken < n) {
-        r.seq.assign(ready.seq.begin() + ready.off[taken], ready.seq.end());
-        r.names.assign(ready.names.begin() + ready.noff[taken], ready.names.end());
-        for (int64_t i = taken + 1; i <= n; ++i) { r.off.push_back(ready.off[i] - ready.off[taken]); r.noff.push_back(ready.noff[i] - ready.noff[taken]); }
-      }
-      ready = std::move(r); taken = 0;
-    }
-    if (eof || bad) return;
-    if (gz) {
-      size_t old = carry.size();
-      carry.resize(old + bytes);
-      int got = gzread(gzf, carry.data() + old, (unsigned)bytes);
-      if (got < 0) { bad = true; return; }
-      carry.resize(old + (size_t)got);
-      bool final = (size_t)got < bytes;
-      if (final) eof = true;
-      if (carry.empty()) return;
-      fastq = carry[0] != '>';
-      const char* b = carry.data(); const char* e = b + carry.size();
-      const char* rest = parse_block(b, e, final, ready, bad);
-      carry.erase(carry.begin(), carry.begin() + (rest - b));
-      return;
-    }
-    size_t end = std::min(len, pos + bytes);
-    const bool final = end == len;
-    const char* b = map + pos; const char* e = map + end;
-    int T = std::max(1, std::min(nthreads, (int)((end - pos) >> 20)));
-    if (T == 1) {
-      const char* rest = parse_block(b, e, final, ready, bad);
-      pos = (size_t)(rest - map);
-    } else {
-      // disjoint byte ranges, each starting at a record boundary; the last range's tail is left for the next call
-      std::vector<const char*> cut(T + 1);
-      cut[0] = b; cut[T] = e;
-      for (int t = 1; t < T; ++t) cut[t] = sync_record(b, b + (size_t)(e - b) * t / T, e, fastq);
-      for (int t = 1; t <= T; ++t) if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
-      std::vector<Records> parts(T); std::vector<const char*> rest(T); std::vector<char> badv(T, 0);
-      std::vector<std::thread> th;
-      for (int t = 0; t < T; ++t)
-        th.emplace_back([&, t]() { bool bd = false; rest[t] = parse_block(cut[t], cut[t + 1], t == T - 1 ? final : true, parts[t], bd); badv[t] = bd; });
-      for (auto& x : th) x.join();
-      for (int t = 0; t < T; ++t) {
-        if (badv[t] || (t < T - 1 && rest[t] != cut[t + 1])) { bad = true; break; }
-        const Records& r = parts[t];
-        int64_t so = (int64_t)ready.seq.size(), no = (int64_t)ready.names.size();
-        ready.seq.insert(ready.seq.end(), r.seq.begin(), r.seq.end());
-        ready.names.insert(ready.names.end(), r.names.begin(), r.names.end());
-        for (int64_t i = 1; i <= r.n(); ++i) { ready.off.push_back(so + r.off[i]); ready.noff.push_back(no + r.noff[i]); }
-      }
-      pos = (size_t)(rest[T - 1] - map);
-    }
-    if (pos >= len) eof = true;
+  void close() {
+    if (map) munmap((void*)map, len);
+    map = nullptr;
+    if (gzf) gzclose(gzf);
+    gzf = nullptr;
+    for (Block* b : blocks) delete b;
+    blocks.clear();
   }
-  int64_t avail() const { return ready.n() - taken; }
+  int64_t avail() const { return (int64_t)(idx.size() - head); }
+
+  // storage whose records have all been handed out AND copied (called at the start of the next hand-out)
+  void release() {
+    if (head > (1u << 20) && head * 2 > idx.size()) { idx.erase(idx.begin(), idx.begin() + (long)head); head = 0; }
+    while (!blocks.empty() && blocks.front()->last <= handed) { delete blocks.front(); blocks.erase(blocks.begin()); }
+  }
+
+  // parse roughly `bytes` more input
+  void fill(size_t bytes, int nthreads) {
+    if (eof || bad) return;
+    Block* blk = new Block();
+    const char* b; const char* e; bool final;
+    if (gz) {
+      blk->data.resize(carry.size() + bytes);
+      if (!carry.empty()) memcpy(blk->data.data(), carry.data(), carry.size());
+      int got = gzread(gzf, blk->data.data() + carry.size(), (unsigned)bytes);
+      if (got < 0) { bad = true; delete blk; return; }
+      blk->data.resize(carry.size() + (size_t)got);
+      carry.clear();
+      final = (size_t)got < bytes;
+      if (final) eof = true;
+      if (blk->data.empty()) { delete blk; return; }
+      if (parsed == 0) fastq = blk->data[0] != '>';
+      b = blk->data.data(); e = b + blk->data.size();
+    } else {
+      size_t end = std::min(len, pos + bytes);
+      final = end == len;
+      b = map + pos; e = map + end;
+    }
+    const int T = std::max(1, std::min(nthreads, (int)((size_t)(e - b) >> 20)));
+    std::vector<const char*> cut((size_t)T + 1);
+    cut[0] = b; cut[(size_t)T] = e;
+    for (int t = 1; t < T; ++t) cut[(size_t)t] = sync_record(b, b + (size_t)(e - b) * (size_t)t / (size_t)T, e, fastq);
+    for (int t = 1; t <= T; ++t) if (cut[(size_t)t] < cut[(size_t)t - 1]) cut[(size_t)t] = cut[(size_t)t - 1];
+    std::vector<std::vector<RecIdx>> parts((size_t)T); std::vector<const char*> rest((size_t)T); std::vector<char> badv((size_t)T, 0);
+    blk->arenas.resize((size_t)T);
+    auto work = [&](int t) {
+      bool bd = false;
+      if (!fastq) blk->arenas[(size_t)t].reserve((size_t)(cut[(size_t)t + 1] - cut[(size_t)t]) + 16);   // never reallocates
+      parts[(size_t)t].reserve((size_t)(cut[(size_t)t + 1] - cut[(size_t)t]) / 128 + 16);
+      rest[(size_t)t] = parse_block(cut[(size_t)t], cut[(size_t)t + 1], t == T - 1 ? final : true, parts[(size_t)t], blk->arenas[(size_t)t], bd);
+      badv[(size_t)t] = bd;
+    };
+    if (T == 1) work(0);
+    else { std::vector<std::thread> th; for (int t = 0; t < T; ++t) th.emplace_back(work, t); for (auto& x : th) x.join(); }
+    for (int t = 0; t < T; ++t) {
+      if (badv[(size_t)t] || (t < T - 1 && rest[(size_t)t] != cut[(size_t)t + 1])) { bad = true; break; }
+      idx.insert(idx.end(), parts[(size_t)t].begin(), parts[(size_t)t].end());
+      parsed += (int64_t)parts[(size_t)t].size();
+    }
+    blk->last = parsed;
+    blocks.push_back(blk);
+    const char* tail = rest[(size_t)T - 1];
+    if (gz) carry.assign(tail, e);
+    else { pos = (size_t)(tail - map); if (pos >= len) eof = true; }
+  }
 };
+
+// copy n records starting at S.idx[S.head] into one packed batch (parallel over records)
+static void pack_records(Source& S, int64_t n, int nthreads, std::vector<char>& seq, std::vector<int64_t>& off,
+                         std::vector<char>& names, std::vector<int64_t>& noff) {
+  off.resize((size_t)n + 1); noff.resize((size_t)n + 1);
+  const RecIdx* R = S.idx.data() + S.head;
+  const int T = std::max(1, std::min<int>(nthreads, (int)(n / 16384) + 1));
+  std::vector<int64_t> sb((size_t)T + 1, 0), nb((size_t)T + 1, 0);
+  auto count = [&](int t) {
+    int64_t a = 0, b = 0;
+    for (int64_t i = n * t / T; i < n * (t + 1) / T; ++i) { a += R[i].sl; b += R[i].nl; }
+    sb[(size_t)t + 1] = a; nb[(size_t)t + 1] = b;
+  };
+  auto copy = [&](int t) {
+    int64_t so = sb[(size_t)t], no = nb[(size_t)t];
+    for (int64_t i = n * t / T; i < n * (t + 1) / T; ++i) {
+      off[(size_t)i] = so; noff[(size_t)i] = no;
+      memcpy(seq.data() + so, R[i].s, R[i].sl); so += R[i].sl;
+      memcpy(names.data() + no, R[i].nm, R[i].nl); no += R[i].nl;
+    }
+  };
+  auto run = [&](auto fn) {
+    if (T == 1) { fn(0); return; }
+    std::vector<std::thread> th; for (int t = 0; t < T; ++t) th.emplace_back(fn, t); for (auto& x : th) x.join();
+  };
+  run(count);
+  for (int t = 0; t < T; ++t) { sb[(size_t)t + 1] += sb[(size_t)t]; nb[(size_t)t + 1] += nb[(size_t)t]; }
+  seq.resize((size_t)sb[(size_t)T] + 1); names.resize((size_t)nb[(size_t)T] + 1);
+  run(copy);
+  off[(size_t)n] = sb[(size_t)T]; noff[(size_t)n] = nb[(size_t)T];
+  S.head += (size_t)n; S.handed += n;
+}
 
 }  // namespace
 
 struct qm_reader {
   Source src[2]; int nsrc = 0; int nthreads = 1;
-  Records out[2];
+  std::vector<char> seq[2], names[2];
+  std::vector<int64_t> off[2], noff[2];
 };
 
 extern "C" {
@@ -246,46 +293,46 @@ int qm_reader_next(qm_reader* r, int64_t max_units, int64_t* n_units, const char
                    const char** names1, const int64_t** name_off1, const char** seq2, const int64_t** off2,
                    const char** names2, const int64_t** name_off2) {
   if (!r || !n_units || max_units <= 0) return io_fail(QM_E_ARG, "qm_reader_next: bad argument");
-  const size_t block = (size_t)64 << 20;
-  for (int s = 0; s < r->nsrc; ++s) {
-    Source& S = r->src[s];
-    while (S.avail() < max_units && !S.eof && !S.bad) {
-      if (r->nsrc == 2 && s == 0) {
-        // both files advance together: parse them concurrently
-        Source& S2 = r->src[1];
-        std::thread t2([&]() { if (S2.avail() < max_units && !S2.eof && !S2.bad) S2.fill(block, std::max(1, r->nthreads / 2)); });
-        S.fill(block, std::max(1, r->nthreads / 2));
-        t2.join();
-      } else S.fill(block, r->nthreads);
+  const size_t block = (size_t)128 << 20;
+  const int per = std::max(1, r->nthreads / r->nsrc);
+  for (int s = 0; s < r->nsrc; ++s) r->src[s].release();
+  // both files advance together: parse them concurrently until each has max_units records (or ended)
+  auto need = [&](int s) { Source& S = r->src[s]; return S.avail() < max_units && !S.eof && !S.bad; };
+  while (need(0) || (r->nsrc == 2 && need(1))) {
+    if (r->nsrc == 2 && need(0) && need(1)) {
+      std::thread t2([&]() { r->src[1].fill(block, per); });
+      r->src[0].fill(block, per);
+      t2.join();
+    } else {
+      const int s = need(0) ? 0 : 1;
+      r->src[s].fill(block, r->nthreads);
     }
-    if (S.bad) return io_fail(QM_E_FORMAT, "%s: malformed FASTA/FASTQ record", S.path.c_str());
   }
+  for (int s = 0; s < r->nsrc; ++s)
+    if (r->src[s].bad) return io_fail(QM_E_FORMAT, "%s: malformed FASTA/FASTQ record", r->src[s].path.c_str());
   int64_t n = std::min(max_units, r->src[0].avail());
   if (r->nsrc == 2) {
     n = std::min(n, r->src[1].avail());
-    if (n == 0 && (r->src[0].avail() > 0) != (r->src[1].avail() > 0) && r->src[0].eof && r->src[1].eof)
+    if (n == 0 && r->src[0].avail() != r->src[1].avail())
       return io_fail(QM_E_FORMAT, "paired files have different numbers of records");
   }
-  for (int s = 0; s < r->nsrc; ++s) {
-    Source& S = r->src[s]; Records& O = r->out[s];
-    O.clear();
-    const int64_t a = S.taken, b = S.taken + n;
-    O.seq.assign(S.ready.seq.begin() + S.ready.off[a], S.ready.seq.begin() + S.ready.off[b]);
-    O.names.assign(S.ready.names.begin() + S.ready.noff[a], S.ready.names.begin() + S.ready.noff[b]);
-    O.off.resize((size_t)n + 1); O.noff.resize((size_t)n + 1);
-    for (int64_t i = 0; i <= n; ++i) { O.off[i] = S.ready.off[a + i] - S.ready.off[a]; O.noff[i] = S.ready.noff[a + i] - S.ready.noff[a]; }
-    S.taken = b;
+  if (r->nsrc == 2 && n > 0) {
+    std::thread t2([&]() { pack_records(r->src[1], n, per, r->seq[1], r->off[1], r->names[1], r->noff[1]); });
+    pack_records(r->src[0], n, per, r->seq[0], r->off[0], r->names[0], r->noff[0]);
+    t2.join();
+  } else {
+    for (int s = 0; s < r->nsrc; ++s) pack_records(r->src[s], n, r->nthreads, r->seq[s], r->off[s], r->names[s], r->noff[s]);
   }
   *n_units = n;
-  if (seq1) *seq1 = r->out[0].seq.data();
-  if (off1) *off1 = r->out[0].off.data();
-  if (names1) *names1 = r->out[0].names.data();
-  if (name_off1) *name_off1 = r->out[0].noff.data();
+  if (seq1) *seq1 = r->seq[0].data();
+  if (off1) *off1 = r->off[0].data();
+  if (names1) *names1 = r->names[0].data();
+  if (name_off1) *name_off1 = r->noff[0].data();
   if (r->nsrc == 2) {
-    if (seq2) *seq2 = r->out[1].seq.data();
-    if (off2) *off2 = r->out[1].off.data();
-    if (names2) *names2 = r->out[1].names.data();
-    if (name_off2) *name_off2 = r->out[1].noff.data();
+    if (seq2) *seq2 = r->seq[1].data();
+    if (off2) *off2 = r->off[1].data();
+    if (names2) *names2 = r->names[1].data();
+    if (name_off2) *name_off2 = r->noff[1].data();
   }
   return QM_OK;
 }

@@ -70,6 +70,29 @@ def test_reader_fasta_and_errors(tmp_path):
     (b,) = _batches(fa, None, 10)
     assert _join([b], "seq1", "off1") == [b"ACGTAC", b"GG", b"T"]
     assert _join([b], "names1", "name_off1") == [b"a desc", b"b", b"c"]
+    # gzip'd multi-line FASTA, many records, tiny chunks (exercises the carry-over between decompressed blocks)
+    import random
+    rnd = random.Random(5)
+    recs = [("s%d some text" % i, "".join(rnd.choice("ACGT") for _ in range(rnd.randint(1, 300)))) for i in range(3000)]
+    gz = str(tmp_path / "y.fa.gz")
+    with gzip.open(gz, "wt") as f:
+        for nm, sq in recs:
+            f.write(">%s\n" % nm)
+            for j in range(0, len(sq), 60):
+                f.write(sq[j:j + 60] + "\n")
+    bs = _batches(gz, None, 257)
+    assert _join(bs, "seq1", "off1") == [sq.encode() for _, sq in recs]
+    assert _join(bs, "names1", "name_off1") == [nm.encode() for nm, _ in recs]
+    # the same records 12x in a plain file: large enough for several parser threads (joined sequences per thread)
+    big = str(tmp_path / "big.fa")
+    with open(big, "w") as f:
+        for r in range(12):
+            for nm, sq in recs:
+                f.write(">%s\n" % nm)
+                for j in range(0, len(sq), 60):
+                    f.write(sq[j:j + 60] + "\n")
+    bs = _batches(big, None, 10000, threads=8)
+    assert _join(bs, "seq1", "off1") == [sq.encode() for _, sq in recs] * 12
     bad = str(tmp_path / "bad.fq")
     with open(bad, "w") as f:
         f.write("@r\nACGT\nIIII\n")
