@@ -530,12 +530,34 @@ int qm_sam_write(const qm_index* ix, int64_t n, const char* names1, const int64_
   int rc = sam_parts(ix, n, names1, name_off1, seq1, off1, names2, name_off2, seq2, off2, hit_offsets, hits, max_num_hits, n_threads, parts);
   if (rc) return rc;
   int64_t tot = 0;
-  for (auto& p : parts) {
-    const char* b = p.data(); size_t left = p.size();
-    while (left > 0) {
-      ssize_t w = ::write(fd, b, left);
-      if (w < 0) return io_fail(QM_E_IO, "write failed");
-      b += w; left -= (size_t)w; tot += w;
+  for (auto& p : parts) tot += (int64_t)p.size();
+  // a seekable descriptor takes the parts concurrently (pwrite at precomputed offsets); pipes get them in order
+  const off_t base = lseek(fd, 0, SEEK_CUR);
+  bool done = false;
+  if (base != (off_t)-1 && parts.size() > 1) {
+    std::vector<off_t> at(parts.size());
+    off_t o = base; for (size_t i = 0; i < parts.size(); ++i) { at[i] = o; o += (off_t)parts[i].size(); }
+    std::vector<char> okv(parts.size(), 1);
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < parts.size(); ++i)
+      th.emplace_back([&, i]() {
+        const char* b = parts[i].data(); size_t left = parts[i].size(); off_t w0 = at[i];
+        while (left > 0) { ssize_t w = ::pwrite(fd, b, left, w0); if (w <= 0) { okv[i] = 0; return; } b += w; left -= (size_t)w; w0 += w; }
+      });
+    for (auto& x : th) x.join();
+    done = true;
+    for (char k : okv) if (!k) done = false;
+    if (done) lseek(fd, base + (off_t)tot, SEEK_SET);
+    else lseek(fd, base, SEEK_SET);
+  }
+  if (!done) {
+    for (auto& p : parts) {
+      const char* b = p.data(); size_t left = p.size();
+      while (left > 0) {
+        ssize_t w = ::write(fd, b, left);
+        if (w < 0) return io_fail(QM_E_IO, "write failed");
+        b += w; left -= (size_t)w;
+      }
     }
   }
   if (bytes_written) *bytes_written = tot;
