@@ -348,45 +348,70 @@ static void reverse_read(const char* s, int64_t n, std::string& out) {      // s
   out.resize((size_t)n);
   for (int64_t i = 0; i < n; ++i) out[(size_t)(n - 1 - i)] = RCT.t[(unsigned char)s[i]];
 }
-static void read_name(const char* nm, int64_t n, bool trimMate, std::string& out) {   // src/RapMapUtils.cpp:334-351
-  const char* sp = (const char*)memchr(nm, ' ', (size_t)n);
-  int64_t l = sp ? sp - nm : n;
-  if (trimMate && l > 2 && nm[l - 2] == '/') l -= 2;
-  out.assign(nm, (size_t)l);
-}
-static void app(std::string& o, long long v) { char b[24]; int n = snprintf(b, sizeof(b), "%lld", v); o.append(b, (size_t)n); }
+// Output buffer of one formatter thread: raw bytes with amortised growth, no per-character bookkeeping.
+struct Out {
+  char* b = nullptr; size_t n = 0, cap = 0;
+  ~Out() { free(b); }
+  inline void need(size_t m) {
+    if (n + m > cap) { cap = (n + m) * 2 + 4096; b = (char*)realloc(b, cap); }
+  }
+  inline void raw(const char* p, size_t l) { memcpy(b + n, p, l); n += l; }            // caller reserved
+  inline void ch(char c) { b[n++] = c; }
+  inline void num(long long v) {                                                         // decimal, no printf
+    char t[24]; int k = 0;
+    unsigned long long u = v < 0 ? (unsigned long long)(-(v + 1)) + 1ULL : (unsigned long long)v;
+    do { t[k++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) b[n++] = '-';
+    while (k) b[n++] = t[--k];
+  }
+  template <size_t N> inline void lit(const char (&x)[N]) { memcpy(b + n, x, N - 1); n += N - 1; }
+};
+struct Cigar { char c[48]; int n; };
+static inline void cg_num(Cigar& g, long long v) { char t[24]; int k = 0; do { t[k++] = (char)('0' + v % 10); v /= 10; } while (v); while (k) g.c[g.n++] = t[--k]; }
 // include/RapMapUtils.hpp:687-711
-static int32_t adjust_overhang(int32_t pos, uint32_t readLen, int64_t txpLen, std::string& cigar) {
-  cigar.clear();
+static int32_t adjust_overhang(int32_t pos, uint32_t readLen, int64_t txpLen, Cigar& g) {
+  g.n = 0;
   const long long rl = readLen;
-  if (pos + rl < 0) { app(cigar, rl); cigar += 'S'; return 0; }
-  if (pos < 0) { long long match = rl + pos, clip = rl - match; app(cigar, clip); cigar += 'S'; app(cigar, match); cigar += 'M'; return 0; }
-  if (pos > txpLen) { app(cigar, rl); cigar += 'S'; return pos; }
-  if (pos + rl > txpLen) { long long match = txpLen - pos, clip = rl - match; app(cigar, match); cigar += 'M'; app(cigar, clip); cigar += 'S'; return pos; }
-  app(cigar, rl); cigar += 'M'; return pos;
+  if (pos + rl < 0) { cg_num(g, rl); g.c[g.n++] = 'S'; return 0; }
+  if (pos < 0) { long long match = rl + pos, clip = rl - match; cg_num(g, clip); g.c[g.n++] = 'S'; cg_num(g, match); g.c[g.n++] = 'M'; return 0; }
+  if (pos > txpLen) { cg_num(g, rl); g.c[g.n++] = 'S'; return pos; }
+  if (pos + rl > txpLen) { long long match = txpLen - pos, clip = rl - match; cg_num(g, match); g.c[g.n++] = 'M'; cg_num(g, clip); g.c[g.n++] = 'S'; return pos; }
+  cg_num(g, rl); g.c[g.n++] = 'M'; return pos;
 }
-static void tags(std::string& o, long long nh, long long hi, long long as) {
-  o += "\tNH:i:"; app(o, nh); o += "\tHI:i:"; app(o, hi); o += "\tAS:i:"; app(o, as); o += '\n';
+static inline void tags(Out& o, long long nh, long long hi, long long as) {
+  o.lit("\tNH:i:"); o.num(nh); o.lit("\tHI:i:"); o.num(hi); o.lit("\tAS:i:"); o.num(as); o.ch('\n');
 }
 
-struct SamCtx { const qm_index* ix; int maxHits; };
+struct SamCtx {
+  int maxHits;
+  std::vector<const char*> tname; std::vector<uint32_t> tnl; std::vector<int64_t> tlen;   // per transcript
+};
+static inline void name_len(const char* nm, int64_t n, bool trimMate, int64_t& l) {       // src/RapMapUtils.cpp:334-351
+  const char* sp = (const char*)memchr(nm, ' ', (size_t)n);
+  l = sp ? sp - nm : n;
+  if (trimMate && l > 2 && nm[l - 2] == '/') l -= 2;
+}
 
 static void format_pair(const SamCtx& C, const char* nm1, int64_t nl1, const char* s1, int64_t l1, const char* nm2,
-                        int64_t nl2, const char* s2, int64_t l2, const qm_hit* h, int64_t nh, std::string& o,
-                        std::string& n1, std::string& n2, std::string& rev1, std::string& rev2, std::string& c1, std::string& c2) {
-  read_name(nm1, nl1, true, n1); read_name(nm2, nl2, true, n2);
+                        int64_t nl2, const char* s2, int64_t l2, const qm_hit* h, int64_t nh, Out& o,
+                        std::string& rev1, std::string& rev2) {
+  int64_t a1, a2;
+  name_len(nm1, nl1, true, a1); name_len(nm2, nl2, true, a2);
   if (nh == 0 || nh > C.maxHits) {                       // writeUnalignedPairToStream
+    o.need((size_t)(a1 + a2 + l1 + l2) + 256);
     for (int m = 0; m < 2; ++m) {
-      o += m == 0 ? n1 : n2; o += '\t'; app(o, (0x1 | 0x4 | 0x8 | (m == 0 ? 0x40 : 0x80)));
-      o += "\t*\t0\t255\t*\t*\t*\t0\t"; o.append(m == 0 ? s1 : s2, (size_t)(m == 0 ? l1 : l2)); o += "\t*\tNH:i:0\tHI:i:0\tAS:i:0\n";
+      o.raw(m == 0 ? nm1 : nm2, (size_t)(m == 0 ? a1 : a2)); o.ch('\t'); o.num(0x1 | 0x4 | 0x8 | (m == 0 ? 0x40 : 0x80));
+      o.lit("\t*\t0\t255\t*\t*\t*\t0\t"); o.raw(m == 0 ? s1 : s2, (size_t)(m == 0 ? l1 : l2)); o.lit("\t*\tNH:i:0\tHI:i:0\tAS:i:0\n");
     }
     return;
   }
   bool have1 = false, have2 = false;
+  Cigar c1, c2;
   for (int64_t i = 0; i < nh; ++i) {
     const qm_hit& q = h[i];
-    const char* tname = qm_index_txp_name(C.ix, q.tid);
-    const int64_t tlen = qm_index_txp_len(C.ix, q.tid);
+    const char* tname = C.tname[q.tid]; const size_t tnl = C.tnl[q.tid];
+    const int64_t tlen = C.tlen[q.tid];
+    o.need((size_t)(a1 + a2 + l1 + l2) + 2 * tnl + 512);
     const bool fwd = q.fwd != 0, mfwd = q.mate_is_fwd != 0, paired = q.is_paired != 0;
     // getSamFlags (include/RapMapUtils.hpp:771-810)
     int f1 = 0x1 | (paired ? 0x2 : 0), f2 = f1;
@@ -405,28 +430,29 @@ static void format_pair(const SamCtx& C, const char* nm1, int64_t nl1, const cha
       long long frag = (int32_t)q.frag_len;              // src/RapMapUtils.cpp:407-411 (int32 casts)
       const long long minPos = r1First ? pos : mpos;
       if (minPos + frag > tlen) frag = tlen - minPos;
-      o += n1; o += '\t'; app(o, f1); o += '\t'; o += tname; o += '\t'; app(o, pos + 1LL); o += "\t1\t"; o += c1; o += "\t=\t";
-      app(o, mpos + 1LL); o += '\t'; app(o, r1First ? frag : -frag); o += '\t';
-      if (fwd) o.append(s1, (size_t)l1); else o += rev1;
-      o += "\t*"; tags(o, nh, i + 1, q.aln_score);
-      o += n2; o += '\t'; app(o, f2); o += '\t'; o += tname; o += '\t'; app(o, mpos + 1LL); o += "\t1\t"; o += c2; o += "\t=\t";
-      app(o, pos + 1LL); o += '\t'; app(o, r1First ? -frag : frag); o += '\t';
-      if (mfwd) o.append(s2, (size_t)l2); else o += rev2;
-      o += "\t*"; tags(o, nh, i + 1, q.aln_score);
+      o.raw(nm1, (size_t)a1); o.ch('\t'); o.num(f1); o.ch('\t'); o.raw(tname, tnl); o.ch('\t'); o.num(pos + 1LL); o.lit("\t1\t"); o.raw(c1.c, (size_t)c1.n); o.lit("\t=\t");
+      o.num(mpos + 1LL); o.ch('\t'); o.num(r1First ? frag : -frag); o.ch('\t');
+      if (fwd) o.raw(s1, (size_t)l1); else o.raw(rev1.data(), rev1.size());
+      o.lit("\t*"); tags(o, nh, i + 1, q.aln_score);
+      o.raw(nm2, (size_t)a2); o.ch('\t'); o.num(f2); o.ch('\t'); o.raw(tname, tnl); o.ch('\t'); o.num(mpos + 1LL); o.lit("\t1\t"); o.raw(c2.c, (size_t)c2.n); o.lit("\t=\t");
+      o.num(pos + 1LL); o.ch('\t'); o.num(r1First ? -frag : frag); o.ch('\t');
+      if (mfwd) o.raw(s2, (size_t)l2); else o.raw(rev2.data(), rev2.size());
+      o.lit("\t*"); tags(o, nh, i + 1, q.aln_score);
     } else {
       const bool left = q.mate_status == 1;
-      const std::string& an = left ? n1 : n2; const std::string& un = left ? n2 : n1;
+      const char* an = left ? nm1 : nm2; const size_t anl = (size_t)(left ? a1 : a2);
+      const char* un = left ? nm2 : nm1; const size_t unl = (size_t)(left ? a2 : a1);
       const int afl = left ? f1 : f2, ufl = left ? f2 : f1;
       int32_t pos = adjust_overhang(q.pos, q.read_len, tlen, c1);
-      o += an; o += '\t'; app(o, afl); o += '\t'; o += tname; o += '\t'; app(o, pos + 1LL); o += "\t1\t"; o += c1; o += "\t=\t";
-      app(o, pos + 1LL); o += "\t0\t";
-      if (fwd) { if (left) o.append(s1, (size_t)l1); else o.append(s2, (size_t)l2); }
-      else if (left) { if (!have1) { reverse_read(s1, l1, rev1); have1 = true; } o += rev1; }
-      else { if (!have2) { reverse_read(s2, l2, rev2); have2 = true; } o += rev2; }
-      o += "\t*"; tags(o, nh, i + 1, q.aln_score);
-      o += un; o += '\t'; app(o, ufl); o += '\t'; o += tname; o += '\t'; app(o, pos + 1LL); o += "\t0\t*\t=\t"; app(o, pos + 1LL); o += "\t0\t";
-      if (left) o.append(s2, (size_t)l2); else o.append(s1, (size_t)l1);
-      o += "\t*"; tags(o, nh, i + 1, q.aln_score);
+      o.raw(an, anl); o.ch('\t'); o.num(afl); o.ch('\t'); o.raw(tname, tnl); o.ch('\t'); o.num(pos + 1LL); o.lit("\t1\t"); o.raw(c1.c, (size_t)c1.n); o.lit("\t=\t");
+      o.num(pos + 1LL); o.lit("\t0\t");
+      if (fwd) { if (left) o.raw(s1, (size_t)l1); else o.raw(s2, (size_t)l2); }
+      else if (left) { if (!have1) { reverse_read(s1, l1, rev1); have1 = true; } o.raw(rev1.data(), rev1.size()); }
+      else { if (!have2) { reverse_read(s2, l2, rev2); have2 = true; } o.raw(rev2.data(), rev2.size()); }
+      o.lit("\t*"); tags(o, nh, i + 1, q.aln_score);
+      o.raw(un, unl); o.ch('\t'); o.num(ufl); o.ch('\t'); o.raw(tname, tnl); o.ch('\t'); o.num(pos + 1LL); o.lit("\t0\t*\t=\t"); o.num(pos + 1LL); o.lit("\t0\t");
+      if (left) o.raw(s2, (size_t)l2); else o.raw(s1, (size_t)l1);
+      o.lit("\t*"); tags(o, nh, i + 1, q.aln_score);
     }
   }
 }
@@ -434,22 +460,24 @@ static void format_pair(const SamCtx& C, const char* nm1, int64_t nl1, const cha
 // single-end records (src/RapMapUtils.cpp:198-311): MAPQ 255, 0x10 for rc, 0x900 on secondary hits; the
 // single-end writer strips the name at the first blank only.
 static void format_single(const SamCtx& C, const char* nm, int64_t nl, const char* s, int64_t l, const qm_hit* h,
-                          int64_t nh, std::string& o, std::string& n1, std::string& rev, std::string& c1) {
-  read_name(nm, nl, false, n1);
+                          int64_t nh, Out& o, std::string& rev) {
+  int64_t a1; name_len(nm, nl, false, a1);
   if (nh == 0) {
-    o += n1; o += "\t4\t*\t0\t255\t*\t*\t0\t0\t"; o.append(s, (size_t)l); o += "\t*\tNH:i:0\tHI:i:0\tAS:i:0\n";
+    o.need((size_t)(a1 + l) + 128);
+    o.raw(nm, (size_t)a1); o.lit("\t4\t*\t0\t255\t*\t*\t0\t0\t"); o.raw(s, (size_t)l); o.lit("\t*\tNH:i:0\tHI:i:0\tAS:i:0\n");
     return;
   }
-  bool have = false;
+  bool have = false; Cigar c1;
   for (int64_t i = 0; i < nh; ++i) {
     const qm_hit& q = h[i];
     int fl = q.fwd ? 0 : 0x10;
     if (i != 0) fl |= 0x900;
-    int32_t pos = adjust_overhang(q.pos, q.read_len, qm_index_txp_len(C.ix, q.tid), c1);
-    o += n1; o += '\t'; app(o, fl); o += '\t'; o += qm_index_txp_name(C.ix, q.tid); o += '\t'; app(o, pos + 1LL);
-    o += "\t255\t"; o += c1; o += "\t*\t0\t"; app(o, (long long)q.frag_len); o += '\t';
-    if (q.fwd) o.append(s, (size_t)l); else { if (!have) { reverse_read(s, l, rev); have = true; } o += rev; }
-    o += "\t*"; tags(o, nh, i + 1, q.aln_score);
+    int32_t pos = adjust_overhang(q.pos, q.read_len, C.tlen[q.tid], c1);
+    o.need((size_t)(a1 + l) + C.tnl[q.tid] + 256);
+    o.raw(nm, (size_t)a1); o.ch('\t'); o.num(fl); o.ch('\t'); o.raw(C.tname[q.tid], C.tnl[q.tid]); o.ch('\t'); o.num(pos + 1LL);
+    o.lit("\t255\t"); o.raw(c1.c, (size_t)c1.n); o.lit("\t*\t0\t"); o.num((long long)q.frag_len); o.ch('\t');
+    if (q.fwd) o.raw(s, (size_t)l); else { if (!have) { reverse_read(s, l, rev); have = true; } o.raw(rev.data(), rev.size()); }
+    o.lit("\t*"); tags(o, nh, i + 1, q.aln_score);
   }
 }
 
@@ -464,7 +492,7 @@ int qm_sam_header(const qm_index* ix, char** out, int64_t* out_len) {
   qm_index_info info;
   if (qm_index_info_get(ix, &info)) return io_fail(QM_E_ARG, "qm_sam_header: bad index");
   std::string o = "@HD\tVN:1.0\tSO:unknown\n";
-  for (int64_t t = 0; t < info.n_txps; ++t) { o += "@SQ\tSN:"; o += qm_index_txp_name(ix, t); o += "\tLN:"; app(o, qm_index_txp_len(ix, t)); o += '\n'; }
+  for (int64_t t = 0; t < info.n_txps; ++t) { o += "@SQ\tSN:"; o += qm_index_txp_name(ix, t); o += "\tLN:"; o += std::to_string((long long)qm_index_txp_len(ix, t)); o += '\n'; }
   o += "@PG\tID:rapmap\tPN:rapmap\tVN:0.6.0\n";
   char* b = (char*)malloc(o.size() + 1);
   if (!b) return io_fail(QM_E_NOMEM, "out of memory");
@@ -476,28 +504,32 @@ int qm_sam_header(const qm_index* ix, char** out, int64_t* out_len) {
 static int sam_parts(const qm_index* ix, int64_t n, const char* names1, const int64_t* name_off1, const char* seq1,
                      const int64_t* off1, const char* names2, const int64_t* name_off2, const char* seq2,
                      const int64_t* off2, const int64_t* hit_offsets, const qm_hit* hits, int32_t max_num_hits,
-                     int32_t n_threads, std::vector<std::string>& parts) {
+                     int32_t n_threads, std::vector<Out>& parts) {
   if (!ix || !names1 || !name_off1 || !seq1 || !off1 || !hit_offsets || n < 0)
     return io_fail(QM_E_ARG, "qm_sam_records: bad argument");
   const bool paired = seq2 != nullptr;
   if (paired && (!names2 || !name_off2 || !off2)) return io_fail(QM_E_ARG, "qm_sam_records: incomplete mate arrays");
+  qm_index_info info;
+  if (qm_index_info_get(ix, &info)) return io_fail(QM_E_ARG, "qm_sam_records: bad index");
+  SamCtx C; C.maxHits = max_num_hits;
+  C.tname.resize((size_t)info.n_txps); C.tnl.resize((size_t)info.n_txps); C.tlen.resize((size_t)info.n_txps);
+  for (int64_t t = 0; t < info.n_txps; ++t) { C.tname[(size_t)t] = qm_index_txp_name(ix, t); C.tnl[(size_t)t] = (uint32_t)strlen(C.tname[(size_t)t]); C.tlen[(size_t)t] = qm_index_txp_len(ix, t); }
+  for (int64_t i = 0, e = hit_offsets[n]; i < e; ++i) if ((int64_t)hits[i].tid >= info.n_txps) return io_fail(QM_E_ARG, "qm_sam_records: hit with an out-of-range transcript id");
   int T = std::max(1, std::min<int>(n_threads, (int)((n + 4095) / 4096)));
-  parts.assign((size_t)T, std::string());
-  SamCtx C{ix, max_num_hits};
+  parts = std::vector<Out>((size_t)T);
   auto work = [&](int t) {
-    std::string& o = parts[(size_t)t];
-    std::string n1, n2, r1, r2, c1, c2;
+    Out& o = parts[(size_t)t];
+    std::string r1, r2;
     const int64_t b = n * t / T, e = n * (t + 1) / T;
-    o.reserve((size_t)(e - b) * 420);
+    o.need((size_t)(e - b) * 512 + 4096);
     for (int64_t u = b; u < e; ++u) {
       const qm_hit* h = hits + hit_offsets[u];
       const int64_t nh = hit_offsets[u + 1] - hit_offsets[u];
       if (paired)
         format_pair(C, names1 + name_off1[u], name_off1[u + 1] - name_off1[u], seq1 + off1[u], off1[u + 1] - off1[u],
-                    names2 + name_off2[u], name_off2[u + 1] - name_off2[u], seq2 + off2[u], off2[u + 1] - off2[u], h, nh, o,
-                    n1, n2, r1, r2, c1, c2);
+                    names2 + name_off2[u], name_off2[u + 1] - name_off2[u], seq2 + off2[u], off2[u + 1] - off2[u], h, nh, o, r1, r2);
       else
-        format_single(C, names1 + name_off1[u], name_off1[u + 1] - name_off1[u], seq1 + off1[u], off1[u + 1] - off1[u], h, nh, o, n1, r1, c1);
+        format_single(C, names1 + name_off1[u], name_off1[u + 1] - name_off1[u], seq1 + off1[u], off1[u + 1] - off1[u], h, nh, o, r1);
     }
   };
   if (T == 1) work(0);
@@ -510,13 +542,13 @@ int qm_sam_records(const qm_index* ix, int64_t n, const char* names1, const int6
                    const int64_t* off2, const int64_t* hit_offsets, const qm_hit* hits, int32_t max_num_hits,
                    int32_t n_threads, char** out, int64_t* out_len) {
   if (!out || !out_len) return io_fail(QM_E_ARG, "qm_sam_records: bad argument");
-  std::vector<std::string> parts;
+  std::vector<Out> parts;
   int rc = sam_parts(ix, n, names1, name_off1, seq1, off1, names2, name_off2, seq2, off2, hit_offsets, hits, max_num_hits, n_threads, parts);
   if (rc) return rc;
-  size_t tot = 0; for (auto& p : parts) tot += p.size();
+  size_t tot = 0; for (auto& p : parts) tot += p.n;
   char* b = (char*)malloc(tot + 1);
   if (!b) return io_fail(QM_E_NOMEM, "out of memory");
-  size_t at = 0; for (auto& p : parts) { memcpy(b + at, p.data(), p.size()); at += p.size(); }
+  size_t at = 0; for (auto& p : parts) { if (p.n) memcpy(b + at, p.b, p.n); at += p.n; }
   b[tot] = 0;
   *out = b; *out_len = (int64_t)tot;
   return QM_OK;
@@ -526,22 +558,22 @@ int qm_sam_write(const qm_index* ix, int64_t n, const char* names1, const int64_
                  const int64_t* off1, const char* names2, const int64_t* name_off2, const char* seq2,
                  const int64_t* off2, const int64_t* hit_offsets, const qm_hit* hits, int32_t max_num_hits,
                  int32_t n_threads, int fd, int64_t* bytes_written) {
-  std::vector<std::string> parts;
+  std::vector<Out> parts;
   int rc = sam_parts(ix, n, names1, name_off1, seq1, off1, names2, name_off2, seq2, off2, hit_offsets, hits, max_num_hits, n_threads, parts);
   if (rc) return rc;
   int64_t tot = 0;
-  for (auto& p : parts) tot += (int64_t)p.size();
+  for (auto& p : parts) tot += (int64_t)p.n;
   // a seekable descriptor takes the parts concurrently (pwrite at precomputed offsets); pipes get them in order
   const off_t base = lseek(fd, 0, SEEK_CUR);
   bool done = false;
   if (base != (off_t)-1 && parts.size() > 1) {
     std::vector<off_t> at(parts.size());
-    off_t o = base; for (size_t i = 0; i < parts.size(); ++i) { at[i] = o; o += (off_t)parts[i].size(); }
+    off_t o = base; for (size_t i = 0; i < parts.size(); ++i) { at[i] = o; o += (off_t)parts[i].n; }
     std::vector<char> okv(parts.size(), 1);
     std::vector<std::thread> th;
     for (size_t i = 0; i < parts.size(); ++i)
       th.emplace_back([&, i]() {
-        const char* b = parts[i].data(); size_t left = parts[i].size(); off_t w0 = at[i];
+        const char* b = parts[i].b; size_t left = parts[i].n; off_t w0 = at[i];
         while (left > 0) { ssize_t w = ::pwrite(fd, b, left, w0); if (w <= 0) { okv[i] = 0; return; } b += w; left -= (size_t)w; w0 += w; }
       });
     for (auto& x : th) x.join();
@@ -552,7 +584,7 @@ int qm_sam_write(const qm_index* ix, int64_t n, const char* names1, const int64_
   }
   if (!done) {
     for (auto& p : parts) {
-      const char* b = p.data(); size_t left = p.size();
+      const char* b = p.b; size_t left = p.n;
       while (left > 0) {
         ssize_t w = ::write(fd, b, left);
         if (w < 0) return io_fail(QM_E_IO, "write failed");
