@@ -182,3 +182,9 @@ def test_perfect_hash_index(synth_small, synth_small_ph, oracle_mod):
     dix, dorc = load_oracle(synth_small["idx"])
     dres = dorc.map_pairs(q1, o1, q2, o2, nthreads=4)
     assert_hits_equal(dres.hit_offsets, dres.hits, er.hit_offsets, er.hits, "perfect-hash vs dense")
+    # the perfect-hash lookups combined with the other compile-time / run-time variants
+    for oo, eo in (({"sensitive": 0}, {"sensitive": 0}), ({"fuzzy": 1, "strictCheck": 0}, {"fuzzy": 1, "strict_check": 0})):
+        r2 = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=4)
+        e2 = em.map(q1, o1, q2, o2, opts=emu.default_opts(**eo))
+        assert_hits_equal(r2.hit_offsets, r2.hits, e2.hit_offsets, e2.hits, "perfect-hash %s" % oo)
+        assert r2.counters == e2.counters

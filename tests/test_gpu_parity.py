@@ -232,3 +232,9 @@ def test_perfect_hash_index(synth_small, synth_small_ph, oracle_mod):
     assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "perfect-hash")
     assert res.counters == gr.counters
     _cmp_ints(res, *mp.intervals(len(o1) - 1))
+    import rapmap_amd as ra
+    for oo, go in (({"sensitive": 0}, {"sensitive": 0}), ({"fuzzy": 1, "strictCheck": 0}, {"fuzzy": 1, "strict_check": 0})):
+        r2 = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=4)
+        g2 = mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(**go))
+        assert_hits_equal(r2.hit_offsets, r2.hits, g2.hit_offsets, g2.hits, "perfect-hash %s" % oo)
+        assert r2.counters == g2.counters
