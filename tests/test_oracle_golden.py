@@ -143,3 +143,20 @@ def test_synth_small_next_single(synth_small, oracle_mod, variant):
         if mine != want.get(nm, []):
             bad.append(i)
     assert not bad, "reads whose SAM differs from the reference: %s" % bad[:10]
+
+
+def test_sample_data_fuzzy(sample_data, oracle_mod):
+    """config 1 with -f: the reference's SAM (tests/golden/sample_data/expected_fuzzy.noseq.sam.gz)"""
+    from rapmap_amd import sam
+    ix, orc = load_oracle(sample_data["idx"])
+    q1, o1 = pack(sample_data["reads1"]); q2, o2 = pack(sample_data["reads2"])
+    res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(fuzzy=1), nthreads=2)
+    want = sam_groups_from_gz(os.path.join(GOLD, "sample_data", "expected_fuzzy.noseq.sam.gz"))
+    bad = []
+    for i in range(len(sample_data["reads1"])):
+        h = res.hits[res.hit_offsets[i]:res.hit_offsets[i + 1]]
+        mine = strip_seq(sam.format_pair(sample_data["names1"][i], sample_data["reads1"][i], sample_data["names2"][i],
+                                         sample_data["reads2"][i], h, ix.names, ix.txpLens))
+        if mine != want[sam._read_name(sample_data["names1"][i])]:
+            bad.append(i)
+    assert not bad, bad[:10]
