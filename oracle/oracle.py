@@ -27,13 +27,30 @@ assert HIT_DTYPE.itemsize == 32
 class Opts(C.Structure):
     _fields_ = [("sensitive", C.c_int32), ("strictCheck", C.c_int32), ("maxNumHits", C.c_int32),
                 ("noOrphans", C.c_int32), ("noDovetail", C.c_int32), ("fuzzy", C.c_int32),
-                ("maxInterval", C.c_int32), ("pad", C.c_int32), ("quasiCov", C.c_double)]
+                ("maxInterval", C.c_int32), ("pad", C.c_int32), ("quasiCov", C.c_double),
+                ("selAln", C.c_int32), ("hardFilter", C.c_int32), ("matchScore", C.c_int32), ("mismatchPenalty", C.c_int32),
+                ("gapOpen", C.c_int32), ("gapExtend", C.c_int32), ("dpBandwidth", C.c_int32), ("maxMMPExtension", C.c_int32),
+                ("alnPolicy", C.c_int32), ("recoverOrphans", C.c_int32),
+                ("minScoreFraction", C.c_double), ("consensusSlack", C.c_double)]
 
 
 def default_opts(**kw):
     """Defaults of `rapmap quasimap` (src/RapMapSAMapper.cpp:992-1023,1113-1114)."""
     o = Opts(sensitive=1, strictCheck=1, maxNumHits=200, noOrphans=0, noDovetail=0, fuzzy=0,
-             maxInterval=1000, pad=0, quasiCov=0.0)
+             maxInterval=1000, pad=0, quasiCov=0.0,
+             # -s sub-options (src/RapMapSAMapper.cpp:1011-1023); only read when selAln is set
+             selAln=0, hardFilter=0, matchScore=2, mismatchPenalty=-4, gapOpen=4, gapExtend=2, dpBandwidth=15,
+             maxMMPExtension=7, alnPolicy=0, recoverOrphans=0, minScoreFraction=0.65, consensusSlack=0.2)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def mimic_bt2_opts(strict=False, **kw):
+    """--mimicBT2 / --mimicStrictBT2 (src/RapMapSAMapper.cpp:1149-1173)"""
+    o = default_opts(selAln=1, alnPolicy=2 if strict else 1, noOrphans=1, noDovetail=1, consensusSlack=0.35, maxNumHits=1000)
+    if strict:
+        o.minScoreFraction = 0.8; o.matchScore = 1; o.mismatchPenalty = 0; o.gapOpen = 25; o.gapExtend = 25
     for k, v in kw.items():
         setattr(o, k, v)
     return o

@@ -129,6 +129,7 @@ struct OIndex {
   const int32_t* txpOffsets = nullptr; int64_t nTxp = 0;
   const uint64_t* rsd = nullptr; uint64_t nbits = 0;
   std::vector<uint64_t> cum;  // #set bits before word w
+  std::vector<int64_t> txpLens;   // src/RapMapSAIndex.cpp:151-163
   // own open-addressing table (the oracle's data structure is free; semantics
   // = exact map lookup, RapMapUtils.hpp:65-67,226-239)
   std::vector<uint64_t> hk; std::vector<SAInterval> hv; uint64_t hmask = 0;
@@ -168,7 +169,25 @@ struct Opts {
   int32_t maxInterval;    // SACollector.hpp:77, 1000
   int32_t pad;
   double quasiCov;        // -z
+  // --selAln and its sub-options (RapMapSAMapper.cpp:1011-1023,1120-1175); all ignored unless selAln != 0
+  int32_t selAln, hardFilter, matchScore, mismatchPenalty, gapOpen, gapExtend, dpBandwidth, maxMMPExtension;
+  int32_t alnPolicy;      // 0 DEFAULT, 1 BT2, 2 BT2_STRICT (SelectiveAlignmentUtils.hpp:13)
+  int32_t recoverOrphans; // not restated: qo_map refuses it
+  double minScoreFraction, consensusSlack;
 };
+struct MapCfg {           // rapmap::utils::MappingConfig (RapMapUtils.hpp:83-89) as set up at RapMapSAMapper.cpp:181-189,409-417
+  bool doChaining = false, considerMultiPos = false; float consensusFraction = 1.0f;
+};
+static MapCfg mapCfg(const Opts& o) {
+  MapCfg mc;
+  mc.doChaining = o.selAln != 0;
+  if (mc.doChaining) {
+    float consensusSlack = (float)o.consensusSlack;     // MappingOpts::consensusSlack is a float
+    mc.consensusFraction = (consensusSlack == 0.0) ? 1.0 : (1.0 - consensusSlack);
+    mc.considerMultiPos = true;
+  }
+  return mc;
+}
 
 // POD of SURVEY.md section 8 row a16
 struct Hit {
@@ -316,10 +335,18 @@ struct Collector {
   int32_t maxInterval;
   Work& w;
   std::string rcBuffer;
+  bool doChaining = false;            // enableChainScoring (SACollector.hpp:64)
+  int32_t maxMMPExtension = 7;        // :71,686
+  size_t strictCheckSlack = 0;        // :64-65
 
   Collector(const OIndex& i, const Opts& o, Work& wk)
       : ix(i), disableNIP(o.sensitive != 0), strictCheck(o.strictCheck != 0),
-        covReq(o.quasiCov), maxInterval(o.maxInterval), w(wk) {}
+        covReq(o.quasiCov), maxInterval(o.maxInterval), w(wk) {
+    if (o.selAln) {                                      // RapMapSAMapper.cpp:187-188,415-416
+      doChaining = true; strictCheckSlack = 1;
+      if (o.maxMMPExtension > 0) maxMMPExtension = o.maxMMPExtension;
+    }
+  }
 
   static size_t findN(const char* s, size_t len, size_t from) {
     for (size_t i = from; i < len; ++i) if (s[i] == 'N' || s[i] == 'n') return i;
@@ -389,8 +416,17 @@ struct Collector {
       if (hit) {
         skipSetup = false;
         lb = std::max((int32_t)0, lb - 1);
+        // :557-575 -- with chain scoring only the MMP that starts the read may run to the read's end; every
+        // other one is cut at k + maxMMPExtension characters, and a first MMP longer than that is redone cut
+        bool firstAttempt = doChaining ? (rb == 0) : true;
+        int64_t endOff = firstAttempt ? readEnd : std::min(rb + k + maxMMPExtension, readEnd);
+        const int32_t lbP = lb, ubP = ub;
         std::tie(lb, ub, matchedLen) =
-            extendSearchNaive(ix, lb, ub, k, read + rb, readEnd - rb, w);
+            extendSearchNaive(ix, lb, ub, k, read + rb, endOff - rb, w);
+        if (doChaining && firstAttempt && !(matchedLen >= (int32_t)readLen) && matchedLen >= (int32_t)(k + maxMMPExtension)) {
+          endOff = std::min(rb + k + maxMMPExtension, readEnd);
+          std::tie(lb, ub, matchedLen) = extendSearchNaive(ix, lbP, ubP, k, read + rb, endOff - rb, w);
+        }
         int32_t diff = ub - lb;
         if (ub > lb && diff < maxInterval) {
           uint32_t queryStart = (uint32_t)rb;
@@ -493,8 +529,8 @@ struct Collector {
 
     if (strictCheck) {                                  // :280-339
       if (useCoverageCheck) {
-        if (fwdCov > rcCov) rcSAInts.clear();
-        else if (rcCov > fwdCov) fwdSAInts.clear();
+        if (fwdCov > rcCov + strictCheckSlack) rcSAInts.clear();
+        else if (rcCov > fwdCov + strictCheckSlack) fwdSAInts.clear();
       } else {
         if (fwdHit > 0 && rcHit == 0) rcSAInts.clear();
         else if (rcHit > 0 && fwdHit == 0) fwdSAInts.clear();
@@ -530,22 +566,34 @@ struct Collector {
 // ----------------------------------------------------------------------------
 // hit_manager -- src/HitManager.cpp
 // ----------------------------------------------------------------------------
-struct QA {   // the fields of QuasiAlignment that are defined on this path
+enum : uint8_t { CS_PERFECT = 0, CS_UNGAPPED = 1, CS_REGULAR = 4 };   // rapmap::utils::ChainStatus (RapMapUtils.hpp:289-295)
+
+struct QA {   // the fields of QuasiAlignment that are defined on this path (RapMapUtils.hpp:399-502)
   uint32_t tid; int32_t pos; bool fwd; uint32_t readLen; uint8_t mateStatus;
-  // With considerMultiPos off (always, without selective alignment) allPositions is {pos}
-  // (HitManager.cpp:321,736) and oppositeStrandPositions is empty or the single position of the
-  // same-transcript hit of the other orientation (HitManager.cpp:846-866).
-  bool hasOpp = false; int32_t oppPos = 0;
+  // allPositions always starts with pos (HitManager.cpp:269,321,736); more entries only with considerMultiPos.
+  // oppositeStrandPositions: the positions of the same-transcript hit of the other orientation (:846-866).
+  std::vector<int32_t> allPositions, oppositeStrandPositions;
+  bool hasMultiPos = false;
+  uint8_t csLeft = CS_REGULAR, csRight = CS_REGULAR;                  // FragmentChainStatus
+  double chainScore = std::numeric_limits<double>::lowest();
+  QA(uint32_t t, int32_t p, bool f, uint32_t rl, uint8_t ms) : tid(t), pos(p), fwd(f), readLen(rl), mateStatus(ms) {}
 };
 
-struct TQ { uint32_t pos, queryPos; bool queryRC; };
+struct TQ { uint32_t pos, queryPos; bool queryRC; uint32_t len; };     // SATxpQueryPos
 struct PSAHit { std::vector<TQ> tqvec; bool active = false; uint32_t numActive = 1; uint32_t lastActiveInterval = 1; };
 
-// HitManager.cpp:587-689 + :449-493 (consensusFraction == 1, strictFilter off)
-static std::map<int, PSAHit> intersectSAHits(const OIndex& ix, std::vector<SAIntervalHit>& inHits, Work& w) {
+// HitManager.cpp:587-689 + :449-493 (strictFilter off)
+static std::map<int, PSAHit> intersectSAHits(const OIndex& ix, std::vector<SAIntervalHit>& inHits,
+                                             float consensusFraction, Work& w) {
   std::map<int, PSAHit> outHits;
-  const int32_t requiredNumHits = (int32_t)inHits.size();
-  const int32_t maxSlack = 0;
+  const int32_t sInHitsSize = (int32_t)inHits.size();
+  float requiredFrac = sInHitsSize * consensusFraction;
+  int32_t requiredNumHits = sInHitsSize;
+  int32_t maxSlack = 0;
+  if (consensusFraction < 1.0) {                                       // :622-628
+    requiredNumHits = std::max((int32_t)1, (int32_t)std::floor(requiredFrac));
+    maxSlack = sInHitsSize - requiredNumHits;
+  }
   SAIntervalHit* minHit = &inHits[0];
   for (auto& h : inHits)
     if ((h.end - h.begin) < (minHit->end - minHit->begin)) minHit = &h;
@@ -555,9 +603,10 @@ static std::map<int, PSAHit> intersectSAHits(const OIndex& ix, std::vector<SAInt
     int tid = (int)ix.rank((uint64_t)globalPos, w);
     int32_t txpPos = globalPos - ix.txpOffsets[tid];
     auto& oh = outHits[tid];
-    oh.tqvec.push_back({(uint32_t)txpPos, minHit->queryPos, (bool)minHit->queryRC});
+    oh.tqvec.push_back({(uint32_t)txpPos, minHit->queryPos, (bool)minHit->queryRC, minHit->len});
     oh.lastActiveInterval = 1;
   }
+  const bool nonStrictIntersection = maxSlack > 0;
   uint32_t intervalCounter = 2;
   for (auto& h : inHits) {
     if (&h == minHit) continue;
@@ -569,42 +618,156 @@ static std::map<int, PSAHit> intersectSAHits(const OIndex& ix, std::vector<SAInt
       bool inOutputSet = (it != outHits.end());
       int32_t occ = inOutputSet ? (int32_t)it->second.numActive : 0;
       int32_t slack = ((int32_t)intervalCounter - 1) - occ;
-      if (slack <= maxSlack) {
+      if (nonStrictIntersection || slack <= maxSlack) {
         int32_t localPos = globalPos - ix.txpOffsets[txpID];
         if (inOutputSet) {
           it->second.numActive += (it->second.lastActiveInterval == intervalCounter) ? 0 : 1;
           it->second.lastActiveInterval = intervalCounter;
-          it->second.tqvec.push_back({(uint32_t)localPos, h.queryPos, (bool)h.queryRC});
+          it->second.tqvec.push_back({(uint32_t)localPos, h.queryPos, (bool)h.queryRC, h.len});
         } else {
           auto& oh = outHits[txpID];
-          oh.tqvec.push_back({(uint32_t)localPos, h.queryPos, (bool)h.queryRC});
+          oh.tqvec.push_back({(uint32_t)localPos, h.queryPos, (bool)h.queryRC, h.len});
           oh.lastActiveInterval = intervalCounter;
         }
       }
     }
     ++intervalCounter;
   }
-  for (auto& kv : outHits) kv.second.active = ((int32_t)kv.second.numActive >= requiredNumHits);
+  size_t numActive = 0;
+  for (auto& kv : outHits) {
+    kv.second.active = ((int32_t)kv.second.numActive >= requiredNumHits);
+    numActive += kv.second.active ? 1 : 0;
+  }
+  if (maxSlack > 0 && numActive == 0)                                  // :682-686
+    for (auto& kv : outHits) kv.second.active = true;
   return outHits;
 }
 
-// HitManager.cpp:84-326, non-chaining branch :308-322
-static void collectHitsSimpleSA(std::map<int, PSAHit>& processed, uint32_t readLen,
-                                std::vector<QA>& hits, uint8_t mateStatus) {
+// fastapprox's fastlog2 as used by the chain score (HitManager.cpp:33-42)
+static inline float fastlog2(float x) {
+  union { float f; uint32_t i; } vx = { x };
+  union { uint32_t i; float f; } mx = { (vx.i & 0x007FFFFF) | 0x3f000000 };
+  float y = vx.i;
+  y *= 1.1920928955078125e-7f;
+  return y - 124.22551499f - 1.498030302f * mx.f - 1.72587999f / (0.3520887068f + mx.f);
+}
+
+// HitManager.cpp:84-326
+static void collectHitsSimpleSA(std::map<int, PSAHit>& processed, uint32_t readLen, int32_t maxDist,
+                                std::vector<QA>& hits, uint8_t mateStatus, const MapCfg& mc) {
+  const bool findBestChain = mc.doChaining, considerMultiPos = mc.considerMultiPos;
+  std::vector<double> f; std::vector<int32_t> p; std::vector<int32_t> bestChainEndInds;
   for (auto& ph : processed) {
     if (!ph.second.active) continue;
-    auto& tq = ph.second.tqvec;
-    auto minIt = std::min_element(tq.begin(), tq.end(),
-                                  [](const TQ& a, const TQ& b) { return a.pos < b.pos; });
-    int32_t hitPos = (int32_t)(minIt->pos - minIt->queryPos);
-    hits.push_back({(uint32_t)ph.first, hitPos, !minIt->queryRC, readLen, mateStatus});
+    const uint32_t tid = (uint32_t)ph.first;
+    if (findBestChain) {                                               // :107-307 (minimap2-style chaining)
+      auto& hitVector = ph.second.tqvec;
+      std::sort(hitVector.begin(), hitVector.end(), [](const TQ& p1, const TQ& p2) -> bool {
+        auto r1 = p1.pos + p1.len; auto r2 = p2.pos + p2.len;
+        auto q1 = p1.queryPos + p1.len; auto q2 = p2.queryPos + p2.len;
+        return (r1 < r2) ? true : ((r2 < r1) ? false : (q1 < q2));
+      });
+      auto alpha = [](int32_t qdiff, int32_t rdiff, int32_t ilen) -> double {
+        double score = ilen;
+        double mindiff = (qdiff < rdiff) ? qdiff : rdiff;
+        return (score < mindiff) ? score : mindiff;
+      };
+      auto beta = [maxDist](int32_t qdiff, int32_t rdiff, double avgseed) -> double {
+        if (qdiff < 0 || (std::max(qdiff, rdiff) > maxDist)) return std::numeric_limits<double>::infinity();
+        double l = qdiff - rdiff;
+        int32_t al = std::abs(l);
+        return (l == 0) ? 0.0 : (0.01 * avgseed * al + 0.5 * fastlog2(static_cast<float>(al)));
+      };
+      double bestScore = std::numeric_limits<double>::lowest();
+      int32_t bestChainEnd = -1;
+      const double avgseed = 31.0;
+      bestChainEndInds.clear(); f.clear(); p.clear();
+      const int32_t lastHitId = (int32_t)hitVector.size() - 1;
+      for (int32_t i = 0; i < (int32_t)hitVector.size(); ++i) {
+        auto& hi = hitVector[i];
+        auto qposi = hi.queryPos + hi.len; auto rposi = hi.pos + hi.len;
+        p.push_back(i); f.push_back((double)hi.len);
+        int32_t numRounds = 2;
+        for (int32_t j = i - 1; j >= 0; --j) {
+          auto& hj = hitVector[j];
+          auto qposj = hj.queryPos + hj.len; auto rposj = hj.pos + hj.len;
+          auto qdiff = qposi - qposj; auto rdiff = rposi - rposj;      // uint32 differences, narrowed by the callees
+          auto extensionScore = f[j] + alpha(qdiff, rdiff, hi.len) - beta(qdiff, rdiff, avgseed);
+          bool extendWithJ = (extensionScore > f[i]);
+          p[i] = extendWithJ ? j : p[i];
+          f[i] = extendWithJ ? extensionScore : f[i];
+          if (p[i] < i) { numRounds--; if (numRounds <= 0) break; }
+        }
+        if (f[i] > bestScore) {
+          bestScore = f[i]; bestChainEnd = i;
+          if (considerMultiPos) { bestChainEndInds.clear(); bestChainEndInds.push_back(bestChainEnd); }
+        } else if (considerMultiPos && f[i] == bestScore) {
+          bestChainEndInds.push_back(i);
+        }
+      }
+      if (!considerMultiPos) bestChainEndInds.push_back(bestChainEnd);
+      // multi-chain backtracking (:206-246)
+      size_t numDistinctOpt = 0;
+      std::vector<int8_t> seen(f.size(), 0);
+      std::vector<int32_t> startPositions;                             // indices into hitVector
+      const int32_t lastChainHit = bestChainEnd;
+      for (int32_t bestChainEndInd : bestChainEndInds) {
+        bool validChain = true;
+        if (bestChainEndInd >= 0) {
+          int32_t lastPtr = p[bestChainEndInd];
+          while (lastPtr < bestChainEndInd) {
+            if (seen[bestChainEndInd]) { validChain = false; break; }
+            seen[bestChainEndInd] = 1;
+            bestChainEndInd = lastPtr;
+            lastPtr = p[bestChainEndInd];
+          }
+          if (seen[bestChainEndInd]) validChain = false;
+          if (validChain) { ++numDistinctOpt; startPositions.push_back(lastPtr); }
+        }
+      }
+      if (startPositions.empty()) continue;                            // the reference would dereference end()
+      {
+        const TQ& st = hitVector[startPositions[0]];
+        int32_t hitPos = (int32_t)(st.pos - st.queryPos);
+        hits.emplace_back(tid, hitPos, !st.queryRC, readLen, mateStatus);
+        QA& currHit = hits.back();
+        currHit.chainScore = bestScore;
+        currHit.allPositions.push_back(hitPos);
+        if (startPositions.size() > 1) {
+          currHit.hasMultiPos = true;
+          for (size_t t = 1; t < startPositions.size(); ++t) {
+            const TQ& o = hitVector[startPositions[t]];
+            currHit.allPositions.push_back((int32_t)(o.pos - o.queryPos));
+          }
+          std::sort(currHit.allPositions.begin(), currHit.allPositions.end());
+        }
+      }
+      if (hitVector.size() > 1 && numDistinctOpt == 1 && lastChainHit == lastHitId) {   // gapless chain (:283-305)
+        const TQ& lastHit = hitVector[lastHitId];
+        const TQ& minPos = hitVector[0];
+        int64_t queryRange = (int64_t)(lastHit.queryPos + lastHit.len) - minPos.queryPos;
+        int64_t refRange = (int64_t)(lastHit.pos + lastHit.len) - minPos.pos;
+        if (queryRange == refRange && queryRange == (int64_t)readLen) {
+          if (mateStatus == PE_RIGHT) hits.back().csRight = CS_UNGAPPED;
+          else if (mateStatus == SINGLE_END || mateStatus == PE_LEFT) hits.back().csLeft = CS_UNGAPPED;
+        }
+      }
+    } else {                                                           // :308-322
+      auto& tq = ph.second.tqvec;
+      auto minIt = std::min_element(tq.begin(), tq.end(),
+                                    [](const TQ& a, const TQ& b) { return a.pos < b.pos; });
+      int32_t hitPos = (int32_t)(minIt->pos - minIt->queryPos);
+      hits.emplace_back(tid, hitPos, !minIt->queryRC, readLen, mateStatus);
+      hits.back().allPositions.push_back(hitPos);
+    }
   }
 }
 
 // HitManager.cpp:691-882
-static void hitsToMappingsSimple(const OIndex& ix, uint8_t mateStatus, uint32_t readLen,
+static void hitsToMappingsSimple(const OIndex& ix, const MapCfg& mc, uint8_t mateStatus, uint32_t readLen,
                                  std::vector<SAIntervalHit>& fwdSAInts,
                                  std::vector<SAIntervalHit>& rcSAInts, std::vector<QA>& hits, Work& w) {
+  const int32_t maxDist = (int32_t)readLen;                            // HitCollectorInfo::maxDist (SACollector.hpp:145-146)
   size_t fwdHitsStart = hits.size();
   auto collectFromSingleInterval = [&](std::vector<SAIntervalHit>& saInts, bool isFw) {   // :716-807
     auto& h = saInts.front();
@@ -615,45 +778,61 @@ static void hitsToMappingsSimple(const OIndex& ix, uint8_t mateStatus, uint32_t 
       uint32_t txpID = (uint32_t)ix.rank((uint64_t)globalPos, w);
       int32_t pos = globalPos - ix.txpOffsets[txpID];
       int32_t hitPos = (int32_t)((uint32_t)pos - h.queryPos);
-      hits.push_back({txpID, hitPos, isFw, readLen, mateStatus});
+      hits.emplace_back(txpID, hitPos, isFw, readLen, mateStatus);
+      QA& lastHit = hits.back();
+      lastHit.allPositions.push_back(hitPos);
+      const uint8_t cs = (h.len == readLen) ? CS_PERFECT : CS_REGULAR;  // :741-752
+      if (mateStatus == PE_RIGHT) lastHit.csRight = cs;
+      else if (mateStatus == PE_LEFT || mateStatus == SINGLE_END) lastHit.csLeft = cs;
     }
     std::sort(hits.begin() + initialSize, hits.end(), [](const QA& a, const QA& b) {
       return (a.tid == b.tid) ? (a.pos < b.pos) : (a.tid < b.tid);
     });
-    auto newEnd = std::unique(hits.begin() + initialSize, hits.end(),
-                              [](const QA& a, const QA& b) { return a.tid == b.tid; });
-    hits.resize(std::distance(hits.begin(), newEnd));
+    auto first = hits.begin() + initialSize, last = hits.end();
+    if (first == last) return;
+    auto result = first;
+    if (mc.considerMultiPos) {                                          // mergeUnique :770-793
+      while (++first != last) {
+        bool distinct = !(result->tid == first->tid);
+        if (distinct && ++result != first) { *result = std::move(*first); }
+        else if (!distinct) { result->hasMultiPos = true; result->allPositions.push_back(first->pos); }
+      }
+    } else {                                                            // std::unique on tid :797-803
+      while (++first != last)
+        if (!(result->tid == first->tid) && ++result != first) *result = std::move(*first);
+    }
+    hits.erase(++result, hits.end());
   };
   if (fwdSAInts.size() > 1) {
-    auto ph = intersectSAHits(ix, fwdSAInts, w);
-    collectHitsSimpleSA(ph, readLen, hits, mateStatus);
+    auto ph = intersectSAHits(ix, fwdSAInts, mc.consensusFraction, w);
+    collectHitsSimpleSA(ph, readLen, maxDist, hits, mateStatus, mc);
   } else if (fwdSAInts.size() == 1) {
     collectFromSingleInterval(fwdSAInts, true);
   }
   size_t fwdHitsEnd = hits.size();
   size_t rcHitsStart = fwdHitsEnd;
   if (rcSAInts.size() > 1) {
-    auto ph = intersectSAHits(ix, rcSAInts, w);
-    collectHitsSimpleSA(ph, readLen, hits, mateStatus);
+    auto ph = intersectSAHits(ix, rcSAInts, mc.consensusFraction, w);
+    collectHitsSimpleSA(ph, readLen, maxDist, hits, mateStatus, mc);
   } else if (rcSAInts.size() == 1) {
     collectFromSingleInterval(rcSAInts, false);
   }
   size_t rcHitsEnd = hits.size();
   if (fwdHitsEnd > fwdHitsStart && rcHitsEnd > rcHitsStart) {   // :834-881
-    // chainScore is equal for every hit on this path, so the comparator of
-    // :838-842 degenerates to tid<; inplace_merge is stable => fwd entry first.
+    // ties on tid: the better chain score first (:838-842); without chaining every score is equal and the
+    // stable merge keeps the forward entry first
     std::inplace_merge(hits.begin() + fwdHitsStart, hits.begin() + fwdHitsEnd, hits.begin() + rcHitsEnd,
-                       [](const QA& a, const QA& b) { return a.tid < b.tid; });
+                       [](const QA& a, const QA& b) { return (a.tid == b.tid) ? a.chainScore > b.chainScore : a.tid < b.tid; });
     // mergeOrientationUnique :846-866 -- the surviving entry of a same-transcript run keeps the
     // positions of the dropped one as its opposite-strand positions
     auto first = hits.begin() + fwdHitsStart, last = hits.begin() + rcHitsEnd;
     auto result = first;
     while (++first != last) {
       bool distinct = !(result->tid == first->tid);
-      if (distinct && ++result != first) { *result = *first; }
-      else if (!distinct) { result->hasOpp = true; result->oppPos = first->pos; }
+      if (distinct && ++result != first) { *result = std::move(*first); }
+      else if (!distinct) { result->oppositeStrandPositions = first->allPositions; }
     }
-    hits.resize(std::distance(hits.begin(), ++result));
+    hits.erase(++result, hits.begin() + rcHitsEnd);
   }
 }
 
@@ -708,25 +887,42 @@ static void mergeLeftRightHits(std::vector<QA>& leftHits, std::vector<QA>& right
   }
 }
 
-// include/RapMapUtils.hpp:864-1183 (--fuzzyIntersection), with considerMultiPos == false so that
-// every position list holds at most one element.  Returns nothing: the MergeResult only feeds orphan
-// recovery, which needs selective alignment.
+// A jointHits entry before it is flattened into the POD: the hit plus what selective alignment needs.
+struct JH { Hit h; uint8_t csLeft = CS_REGULAR, csRight = CS_REGULAR; };
+
+// include/RapMapUtils.hpp:864-1183 (--fuzzyIntersection / --selAln).  Returns the MergeResult's only
+// consumer-visible effect through `joint`; the result code itself only feeds orphan recovery.
 static void mergeLeftRightHitsFuzzy(bool leftMatches, bool rightMatches, std::vector<QA>& leftHits,
-                                    std::vector<QA>& rightHits, std::vector<Hit>& joint,
+                                    std::vector<QA>& rightHits, std::vector<JH>& joint,
                                     uint32_t maxNumHits, bool& tooManyHits, Counters& hctr) {
   auto mk = [](const QA& q) {
-    Hit h{}; h.tid = q.tid; h.pos = q.pos; h.matePos = 0; h.fragLen = 0; h.readLen = q.readLen;
+    JH j; Hit& h = j.h; h = Hit{};
+    h.tid = q.tid; h.pos = q.pos; h.matePos = 0; h.fragLen = 0; h.readLen = q.readLen;
     h.mateLen = 0; h.fwd = q.fwd; h.mateIsFwd = 1; h.isPaired = 0; h.mateStatus = q.mateStatus; h.alnScore = 0;
-    return h;
+    j.csLeft = q.csLeft; j.csRight = q.csRight;
+    return j;
   };
   constexpr int32_t maxGap = std::numeric_limits<int32_t>::max();
-  // findBestHitFWRC :923-988 for one fwd and one rc position: lower_bound over the single rc
-  // position lands on it when rc >= fwd, else on end() whose predecessor is again that element;
-  // updateBestGap gives maxGap whenever rc < fwd, i.e. "no valid pairing".
-  auto best = [&](bool hasF, int32_t f, bool hasR, int32_t r, int32_t fwdReadLen, int32_t& gap) -> bool {
-    if (!hasF || !hasR) return false;
-    gap = (r >= f) ? std::abs(r - (f + fwdReadLen)) : maxGap;
-    return gap < maxGap;
+  // findBestHitFWRC :923-988: (fwPos, rcPos, gap) of the closest rc position at or after a fwd position
+  auto findBestHitFWRC = [&](std::vector<int32_t>& fwdHits, std::vector<int32_t>& rcHits, int32_t fwdReadLen,
+                             int32_t& oF, int32_t& oR, int32_t& oGap) -> bool {
+    if (fwdHits.empty() || rcHits.empty()) return false;
+    int32_t bestGap = maxGap;
+    auto bestFW = fwdHits.begin(); auto bestRC = rcHits.begin();
+    auto updateBestGap = [&](std::vector<int32_t>::iterator fwdPosIt, std::vector<int32_t>::iterator rcPosIt) {
+      int32_t gap = ((*rcPosIt) >= (*fwdPosIt)) ? std::abs((*rcPosIt) - ((*fwdPosIt) + fwdReadLen)) : maxGap;
+      if (gap < bestGap) { bestGap = gap; bestFW = fwdPosIt; bestRC = rcPosIt; }
+    };
+    auto rcBeg = rcHits.begin(), rcEnd = rcHits.end();
+    for (auto pIt = fwdHits.begin(); pIt != fwdHits.end(); ++pIt) {
+      auto lbIt = std::lower_bound(rcBeg, rcEnd, *pIt);
+      if (lbIt == rcEnd) updateBestGap(pIt, lbIt - 1);
+      else if (lbIt == rcBeg) updateBestGap(pIt, lbIt);
+      else { updateBestGap(pIt, lbIt); updateBestGap(pIt, lbIt - 1); }
+    }
+    if (bestGap == maxGap) return false;
+    oF = *bestFW; oR = *bestRC; oGap = bestGap;
+    return true;
   };
   if (leftHits.empty()) {
     if (!leftMatches && !rightHits.empty()) {
@@ -747,21 +943,18 @@ static void mergeLeftRightHitsFuzzy(bool leftMatches, bool rightMatches, std::ve
       if (leftTxp < rightTxp) { ++leftIt; }
       else {
         if (!(rightTxp < leftTxp)) {
-          // :991-996 -- positions by strand
-          bool lHasF = leftIt->fwd, lHasR = leftIt->fwd ? leftIt->hasOpp : true;
-          int32_t lF = leftIt->pos, lR = leftIt->fwd ? leftIt->oppPos : leftIt->pos;
-          if (!leftIt->fwd) { lHasF = leftIt->hasOpp; lF = leftIt->oppPos; }
-          bool rHasF = rightIt->fwd, rHasR = rightIt->fwd ? rightIt->hasOpp : true;
-          int32_t rF = rightIt->pos, rR = rightIt->fwd ? rightIt->oppPos : rightIt->pos;
-          if (!rightIt->fwd) { rHasF = rightIt->hasOpp; rF = rightIt->oppPos; }
-          int32_t gapFWRC = maxGap, gapRCFW = maxGap;
-          bool bestFWRC = best(lHasF, lF, rHasR, rR, (int32_t)leftIt->readLen, gapFWRC);
-          bool bestRCFW = best(rHasF, rF, lHasR, lR, (int32_t)rightIt->readLen, gapRCFW);
+          auto& leftFwdHits = leftIt->fwd ? leftIt->allPositions : leftIt->oppositeStrandPositions;    // :991-996
+          auto& leftRCHits = leftIt->fwd ? leftIt->oppositeStrandPositions : leftIt->allPositions;
+          auto& rightFwdHits = rightIt->fwd ? rightIt->allPositions : rightIt->oppositeStrandPositions;
+          auto& rightRCHits = rightIt->fwd ? rightIt->oppositeStrandPositions : rightIt->allPositions;
+          int32_t f1 = 0, r1 = 0, g1 = maxGap, f2 = 0, r2 = 0, g2 = maxGap;
+          bool bestFWRC = findBestHitFWRC(leftFwdHits, rightRCHits, (int32_t)leftIt->readLen, f1, r1, g1);
+          bool bestRCFW = findBestHitFWRC(rightFwdHits, leftRCHits, (int32_t)rightIt->readLen, f2, r2, g2);
           bool foundValidHit = false, leftFwd = false, rightFwd = false;
           int32_t bestGap = maxGap, leftPos = -1, rightPos = -1;
-          if (bestFWRC) { leftPos = lF; rightPos = rR; bestGap = gapFWRC; leftFwd = true; rightFwd = false; foundValidHit = true; }
+          if (bestFWRC) { leftPos = f1; rightPos = r1; bestGap = g1; leftFwd = true; rightFwd = false; foundValidHit = true; }
           if (bestRCFW) {
-            if (gapRCFW < bestGap) { leftPos = lR; rightPos = rF; leftFwd = false; rightFwd = true; }
+            if (g2 < bestGap) { leftPos = r2; rightPos = f2; leftFwd = false; rightFwd = true; }
             foundValidHit = true;
           }
           if (foundValidHit) {                                     // :1124-1151
@@ -770,10 +963,12 @@ static void mergeLeftRightHitsFuzzy(bool leftMatches, bool rightMatches, std::ve
             int32_t fragStartPos = read1First ? startRead1 : startRead2;
             int32_t fragEndPos = read1First ? (int32_t)(startRead2 + rightIt->readLen)
                                             : (int32_t)(startRead1 + leftIt->readLen);
-            Hit h{}; h.tid = leftTxp; h.pos = leftPos; h.fwd = leftFwd; h.readLen = leftIt->readLen;
+            JH j; Hit& h = j.h; h = Hit{};
+            h.tid = leftTxp; h.pos = leftPos; h.fwd = leftFwd; h.readLen = leftIt->readLen;
             h.fragLen = (uint32_t)(fragEndPos - fragStartPos); h.isPaired = 1; h.mateLen = rightIt->readLen;
             h.matePos = rightPos; h.mateIsFwd = rightFwd; h.mateStatus = PE_PAIRED; h.alnScore = 0;
-            joint.push_back(h);
+            j.csLeft = leftIt->csLeft; j.csRight = rightIt->csRight;
+            joint.push_back(j);
             ++numHits;
             if (numHits > maxNumHits) { tooManyHits = true; break; }
           }
@@ -787,53 +982,311 @@ static void mergeLeftRightHitsFuzzy(bool leftMatches, bool rightMatches, std::ve
   if (!joint.empty()) hctr.peHits += joint.size();                 // :1176-1179 (orphans are counted too)
 }
 
-// per-pair driver -- src/RapMapSAMapper.cpp:461-551,684-701
-static void mapPair(const OIndex& ix, const Opts& o, Collector& col, const char* r1, size_t l1,
+// ----------------------------------------------------------------------------
+// selective alignment (--selAln): ksw2 extension alignment + score gate
+// ----------------------------------------------------------------------------
+// ksw_extz2_sse41 (src/ksw2pp/ksw2_extz2_sse.c:18-304) in the configuration the mapper uses: score only, exact
+// max (no KSW_EZ_APPROX_MAX), no z-drop.  The SSE kernel works on 16-byte vectors of int8 differences and also
+// computes the lanes of a vector that lie outside the band; those values are later picked up as neighbours when
+// the band moves, so the byte-level layout and every out-of-band lane are reproduced here one byte at a time.
+struct KswOut { int32_t mqe, mte; };
+static KswOut kswExtz2(int qlen, const uint8_t* query, int tlen, const uint8_t* target, int8_t m, const int8_t* mat,
+                       int8_t q, int8_t e, int w) {
+  KswOut ez{-0x40000000, -0x40000000};
+  if (m <= 0 || qlen <= 0 || tlen <= 0) return ez;
+  const int qe = q + e;
+  if (w < 0) w = tlen > qlen ? tlen : qlen;
+  const int wl = w, wr = w;
+  const int tlen_ = (tlen + 15) / 16, qlen_ = (qlen + 15) / 16;
+  int min_sc = mat[1];
+  for (int t = 1; t < m * m; ++t) min_sc = min_sc < mat[t] ? min_sc : mat[t];
+  if (-min_sc > 2 * (q + e)) return ez;
+  // one zeroed block laid out like the kernel's: u v x y s (tlen_ vectors each), sf (tlen_), qr (qlen_ + 1)
+  std::vector<uint8_t> mem((size_t)(tlen_ * 6 + qlen_ + 1) * 16 + 16, 0);
+  uint8_t* u8 = mem.data(); uint8_t* v8 = u8 + tlen_ * 16; uint8_t* x8 = v8 + tlen_ * 16; uint8_t* y8 = x8 + tlen_ * 16;
+  uint8_t* s8 = y8 + tlen_ * 16; uint8_t* sf = s8 + tlen_ * 16; uint8_t* qr = sf + tlen_ * 16;
+  std::vector<int32_t> H((size_t)tlen_ * 16, -0x40000000);
+  for (int t = 0; t < qlen; ++t) qr[t] = query[qlen - 1 - t];
+  memcpy(sf, target, (size_t)tlen);
+  const uint8_t sc_mch = (uint8_t)mat[0], sc_mis = (uint8_t)mat[1], sc_N = (uint8_t)mat[m * m - 1], m1 = (uint8_t)(m - 1);
+  const uint8_t qe2 = (uint8_t)((q + e) * 2), max_sc_v = (uint8_t)(mat[0] + (q + e) * 2), qv = (uint8_t)q;
+  int last_st = -1, last_en = -1;
+  for (int r = 0; r < qlen + tlen - 1; ++r) {
+    int st = 0, en = tlen - 1;
+    const uint8_t* qrr = qr + (qlen - 1 - r);
+    if (st < r - qlen + 1) st = r - qlen + 1;
+    if (en > r) en = r;
+    if (st < (r - wr + 1) >> 1) st = (r - wr + 1) >> 1;
+    if (en > (r + wl) >> 1) en = (r + wl) >> 1;
+    if (st > en) break;                                                // zdropped
+    const int st0 = st, en0 = en;
+    st = st / 16 * 16; en = (en + 16) / 16 * 16 - 1;
+    uint8_t x1, v1;
+    if (st > 0) {
+      if (st - 1 >= last_st && st - 1 <= last_en) { x1 = x8[st - 1]; v1 = v8[st - 1]; }
+      else { x1 = 0; v1 = 0; }
+    } else { x1 = 0; v1 = r ? qv : 0; }
+    if (en >= r) { y8[r] = 0; u8[r] = r ? qv : 0; }
+    for (int t = st0; t <= en0; t += 16)                                // scores: whole vectors, unaligned loads
+      for (int l = 0; l < 16; ++l) {
+        const uint8_t sq = sf[t + l], sv = qrr[t + l];
+        uint8_t tmp = (sq == sv) ? sc_mch : sc_mis;
+        if (sq == m1 || sv == m1) tmp = sc_N;
+        s8[t + l] = tmp;
+      }
+    for (int t = st; t <= en; ++t) {                                    // the int8 recurrences, lane by lane
+      uint8_t z = (uint8_t)(s8[t] + qe2);
+      const uint8_t xt1 = x1; x1 = x8[t];                               // x[r-1][t-1]
+      const uint8_t vt1 = v1; v1 = v8[t];                               // v[r-1][t-1]
+      uint8_t a = (uint8_t)(xt1 + vt1);
+      const uint8_t ut = u8[t];
+      uint8_t b = (uint8_t)(y8[t] + ut);
+      z = (uint8_t)((int8_t)z > (int8_t)a ? z : a);                     // _mm_max_epi8 (signed)
+      z = z > b ? z : b;                                                // _mm_max_epu8
+      z = z < max_sc_v ? z : max_sc_v;                                  // _mm_min_epu8
+      u8[t] = (uint8_t)(z - vt1);
+      v8[t] = (uint8_t)(z - ut);
+      z = (uint8_t)(z - qv);
+      a = (uint8_t)(a - z); b = (uint8_t)(b - z);
+      x8[t] = (int8_t)a > 0 ? a : 0;                                    // _mm_max_epi8(a, 0)
+      y8[t] = (int8_t)b > 0 ? b : 0;
+    }
+    // exact max with the 32-bit H array (:229-268); max_H / max_t only feed the (disabled) z-drop
+    if (r > 0) {
+      H[en0] = en0 > 0 ? H[en0 - 1] + u8[en0] - qe : H[en0] + v8[en0] - qe;
+      for (int t = st0; t < en0; ++t) H[t] += (int32_t)v8[t] - qe;
+    } else H[0] = v8[0] - qe - qe;
+    if (en0 == tlen - 1 && H[en0] > ez.mte) ez.mte = H[en0];
+    if (r - st0 == qlen - 1 && H[st0] > ez.mqe) ez.mqe = H[st0];
+    last_st = st; last_en = en;
+  }
+  return ez;
+}
+
+struct Aligner {                                                       // KSW2Aligner as configured at RapMapSAMapper.cpp:420-436
+  int8_t mat[25]; int8_t q, e; int w;
+  std::vector<uint8_t> qbuf, tbuf;
+  Aligner(int a, int b, int gapo, int gape, int bw) : q((int8_t)gapo), e((int8_t)gape), w(bw) {
+    a = (int8_t)a; b = (int8_t)b;                                      // KSW2Aligner(int8_t match, int8_t mismatch)
+    a = a < 0 ? -a : a; b = b > 0 ? -b : b;
+    const int m = 5;
+    for (int i = 0; i < m - 1; ++i) { for (int j = 0; j < m - 1; ++j) mat[i * m + j] = (int8_t)(i == j ? a : b); mat[i * m + m - 1] = 0; }
+    for (int j = 0; j < m; ++j) mat[(m - 1) * m + j] = 0;
+  }
+  static uint8_t nt4(unsigned char c) {                                // seq_nt4_table_loc (KSW2Aligner.cpp:61-72)
+    switch (c) {
+      case 0: case 'A': case 'a': return 0; case 1: case 'C': case 'c': return 1;
+      case 2: case 'G': case 'g': return 2; case 3: case 'T': case 't': return 3; default: return 4;
+    }
+  }
+  int32_t extension(const char* qs, int ql, const char* ts, int tl) {  // operator()(…, EXTENSION) -> max(mqe, mte)
+    qbuf.resize((size_t)ql); tbuf.resize((size_t)tl);
+    for (int i = 0; i < ql; ++i) qbuf[(size_t)i] = nt4((unsigned char)qs[i]);
+    for (int i = 0; i < tl; ++i) tbuf[(size_t)i] = nt4((unsigned char)ts[i]);
+    KswOut ez = kswExtz2(ql, qbuf.data(), tl, tbuf.data(), 5, mat, q, e, w);
+    return std::max(ez.mqe, ez.mte);
+  }
+};
+
+// The alignment cache (tsl::hopscotch_map keyed by MetroHash64 of the target window,
+// SelectiveAlignmentUtils.hpp:23-30,317-330,361-367) is restated with the window itself as the key: equal
+// up to 64-bit hash collisions.  Note that the key leaves out the `buf` extra target characters although the
+// alignment sees them -- a cached score is reused for windows that differ only there.
+using AlnCache = std::map<std::string, int32_t>;
+
+// selective_alignment::utils::getAlnScore (SelectiveAlignmentUtils.hpp:260-373)
+static int32_t getAlnScore(Aligner& aligner, int32_t pos, const char* rptr, int32_t rlen, const char* tseq, int32_t tlen,
+                           int8_t mscore, int8_t mmcost, int32_t maxScore, uint8_t chainStat, bool multiMapping,
+                           int32_t ap, uint32_t buf, AlnCache& alnCache) {
+  if (chainStat == CS_PERFECT) return maxScore;
+  auto ungappedAln = [mscore, mmcost](const char* ref, const char* query, int32_t len) -> int32_t {
+    int32_t ungappedScore = 0;
+    for (int32_t i = 0; i < len; ++i) {
+      char c1 = ref[i], c2 = query[i];
+      c1 = (c1 == 'N' || c2 == 'N') ? c2 : c1;
+      ungappedScore += (c1 == c2) ? mscore : mmcost;
+    }
+    return ungappedScore;
+  };
+  int32_t s = std::numeric_limits<int32_t>::lowest();
+  bool invalidStart = (pos < 0);
+  bool invalidEnd = (pos + rlen >= tlen);
+  if (invalidStart) { rptr += -pos; rlen += pos; pos = 0; }
+  if ((invalidStart || invalidEnd) && (ap == 1 || ap == 2)) return s;
+  if (pos < tlen) {
+    bool doUngapped = (!invalidStart) && (chainStat == CS_UNGAPPED);
+    buf = doUngapped ? 0 : buf;
+    uint32_t lnobuf = (uint32_t)(tlen - pos);
+    uint32_t lbuf = (uint32_t)(rlen + buf);
+    bool useBuf = (lbuf < lnobuf);
+    uint32_t tlen1 = std::min(lbuf, lnobuf);
+    const char* tseq1 = tseq + pos;
+    std::string key;
+    bool didHash = false;
+    if (!alnCache.empty()) {
+      uint32_t keyLen = useBuf ? tlen1 - buf : tlen1;
+      key.assign(tseq1, keyLen); didHash = true;
+      auto hit = alnCache.find(key);
+      if (hit != alnCache.end()) s = hit->second;
+    }
+    if (s == std::numeric_limits<int32_t>::lowest()) {
+      if (doUngapped) {
+        int32_t tlen1s = (int32_t)tlen1;
+        int32_t alnLen = rlen < tlen1s ? rlen : tlen1s;
+        s = ungappedAln(tseq1, rptr, alnLen);
+      } else {
+        s = aligner.extension(rptr, rlen, tseq1, (int)tlen1);
+      }
+      if (multiMapping) {
+        if (!didHash) { uint32_t keyLen = useBuf ? tlen1 - buf : tlen1; key.assign(tseq1, keyLen); }
+        alnCache[key] = s;
+      }
+    }
+  }
+  return s;
+}
+
+// the score gate + soft/hard filter shared by the paired (RapMapSAMapper.cpp:646-683) and single-end (:289-318) drivers
+template <typename V, typename GetHit>
+static void filterByScore(V& joint, std::vector<int32_t>& scores, int32_t bestScore, bool hardFilter, GetHit hit) {
+  if (bestScore > std::numeric_limits<int32_t>::min()) {
+    size_t ctr = 0, o = 0;
+    for (size_t i = 0; i < joint.size(); ++i) {
+      bool rem = hardFilter ? (scores[ctr] < bestScore) : (scores[ctr] == std::numeric_limits<int32_t>::min());
+      ++ctr;
+      if (!rem) { if (o != i) joint[o] = joint[i]; hit(joint[o]).alnScore = scores[i]; ++o; }
+    }
+    joint.resize(o);
+  } else {
+    joint.clear();
+  }
+}
+
+// per-pair driver -- src/RapMapSAMapper.cpp:461-701
+static void mapPair(const OIndex& ix, const Opts& o, const MapCfg& mc, Collector& col, Aligner* aligner, const char* r1, size_t l1,
                     const char* r2, size_t l2, std::vector<Hit>& joint, Counters& hctr, Work& w,
                     std::vector<SAIntervalHit>* dumpInts /* 4 lists or null */) {
   std::vector<SAIntervalHit> lf, lr, rf, rr;
   std::vector<QA> leftHits, rightHits;
+  std::vector<JH> jj;
   bool tooManyHits = false;
   ++hctr.numReads;
   joint.clear();
   bool lh = col.collect(r1, l1, lf, lr);
   bool rh = col.collect(r2, l2, rf, rr);
   if (dumpInts) { dumpInts[0] = lf; dumpInts[1] = lr; dumpInts[2] = rf; dumpInts[3] = rr; }
-  hitsToMappingsSimple(ix, PE_LEFT, (uint32_t)l1, lf, lr, leftHits, w);
-  hitsToMappingsSimple(ix, PE_RIGHT, (uint32_t)l2, rf, rr, rightHits, w);
-  if (o.fuzzy) mergeLeftRightHitsFuzzy(lh, rh, leftHits, rightHits, joint, (uint32_t)o.maxNumHits, tooManyHits, hctr);
-  else mergeLeftRightHits(leftHits, rightHits, joint, (uint32_t)o.maxNumHits, tooManyHits, hctr);
-  if (joint.size() > (size_t)o.maxNumHits) joint.clear();                 // :534-536
-  if (!joint.empty() && o.noOrphans && joint.front().mateStatus != PE_PAIRED) joint.clear();   // :539-551
-  if (o.noDovetail) {                                                     // :684-698
-    joint.erase(std::remove_if(joint.begin(), joint.end(), [](const Hit& h) {
-                  if (h.fwd != h.mateIsFwd) {
-                    if (h.fwd && (h.pos > h.matePos)) return true;
-                    else if (h.mateIsFwd && (h.matePos > h.pos)) return true;
-                  }
-                  return false;
-                }), joint.end());
+  hitsToMappingsSimple(ix, mc, PE_LEFT, (uint32_t)l1, lf, lr, leftHits, w);
+  hitsToMappingsSimple(ix, mc, PE_RIGHT, (uint32_t)l2, rf, rr, rightHits, w);
+  if (o.fuzzy || o.selAln) {                                              // useSmartIntersect (:450,488-493)
+    mergeLeftRightHitsFuzzy(lh, rh, leftHits, rightHits, jj, (uint32_t)o.maxNumHits, tooManyHits, hctr);
+  } else {
+    mergeLeftRightHits(leftHits, rightHits, joint, (uint32_t)o.maxNumHits, tooManyHits, hctr);
+    for (auto& h : joint) { JH j; j.h = h; jj.push_back(j); }
+    joint.clear();
   }
+  if (jj.size() > (size_t)o.maxNumHits) jj.clear();                       // :534-536
+  if (!jj.empty() && o.noOrphans && jj.front().h.mateStatus != PE_PAIRED) jj.clear();   // :539-551
+  auto dovetail = [](const Hit& h) {
+    if (h.fwd != h.mateIsFwd) {
+      if (h.fwd && (h.pos > h.matePos)) return true;
+      else if (h.mateIsFwd && (h.matePos > h.pos)) return true;
+    }
+    return false;
+  };
+  if (o.selAln && !jj.empty()) {                                          // :554-667
+    AlnCache alnCacheLeft, alnCacheRight;
+    std::string rc1, rc2; bool have1 = false, have2 = false;
+    const int8_t a = (int8_t)o.matchScore, b = (int8_t)o.mismatchPenalty;
+    int32_t bestScore = std::numeric_limits<int32_t>::lowest();
+    std::vector<int32_t> scores(jj.size(), bestScore);
+    const double optFrac = o.minScoreFraction;
+    const int32_t maxLeftScore = a * (int32_t)l1, maxRightScore = a * (int32_t)l2;
+    const bool multiMapping = jj.size() > 1;
+    size_t idx = 0;
+    for (auto& j : jj) {
+      Hit& h = j.h;
+      int32_t score = std::numeric_limits<int32_t>::min();
+      const char* tseq = (const char*)ix.text + ix.txpOffsets[h.tid];
+      const int32_t tlen = (int32_t)ix.txpLens[h.tid];
+      const uint32_t buf = 20;
+      if (h.mateStatus == PE_PAIRED) {
+        if (!h.fwd && !have1) { reverseRead(r1, (int64_t)l1, rc1); have1 = true; }
+        if (!h.mateIsFwd && !have2) { reverseRead(r2, (int64_t)l2, rc2); have2 = true; }
+        const char* r1ptr = h.fwd ? r1 : rc1.data();
+        const char* r2ptr = h.mateIsFwd ? r2 : rc2.data();
+        int32_t s1 = getAlnScore(*aligner, h.pos, r1ptr, (int32_t)l1, tseq, tlen, a, b, maxLeftScore, j.csLeft, multiMapping, o.alnPolicy, buf, alnCacheLeft);
+        int32_t s2 = getAlnScore(*aligner, h.matePos, r2ptr, (int32_t)l2, tseq, tlen, a, b, maxRightScore, j.csRight, multiMapping, o.alnPolicy, buf, alnCacheRight);
+        if (h.fwd != h.mateIsFwd && o.noDovetail) {
+          if (h.fwd && (h.pos > h.matePos)) { s1 = s2 = std::numeric_limits<int32_t>::min(); }
+          else if (h.mateIsFwd && (h.matePos > h.pos)) { s1 = s2 = std::numeric_limits<int32_t>::min(); }
+        }
+        if ((s1 < (optFrac * maxLeftScore)) || (s2 < (optFrac * maxRightScore))) score = std::numeric_limits<int32_t>::min();
+        else score = s1 + s2;
+      } else if (h.mateStatus == PE_LEFT) {
+        if (!h.fwd && !have1) { reverseRead(r1, (int64_t)l1, rc1); have1 = true; }
+        const char* rptr = h.fwd ? r1 : rc1.data();
+        int32_t s = getAlnScore(*aligner, h.pos, rptr, (int32_t)l1, tseq, tlen, a, b, maxLeftScore, j.csLeft, multiMapping, o.alnPolicy, buf, alnCacheLeft);
+        score = (s < (optFrac * maxLeftScore)) ? std::numeric_limits<int32_t>::min() : s;
+      } else if (h.mateStatus == PE_RIGHT) {
+        if (!h.fwd && !have2) { reverseRead(r2, (int64_t)l2, rc2); have2 = true; }
+        const char* rptr = h.fwd ? r2 : rc2.data();
+        int32_t s = getAlnScore(*aligner, h.pos, rptr, (int32_t)l2, tseq, tlen, a, b, maxRightScore, j.csRight, multiMapping, o.alnPolicy, buf, alnCacheRight);
+        score = (s < (optFrac * maxRightScore)) ? std::numeric_limits<int32_t>::min() : s;
+      }
+      bestScore = (score > bestScore) ? score : bestScore;
+      scores[idx++] = score;
+    }
+    filterByScore(jj, scores, bestScore, o.hardFilter != 0, [](JH& j) -> Hit& { return j.h; });
+  } else if (o.noDovetail) {                                              // :668-683
+    jj.erase(std::remove_if(jj.begin(), jj.end(), [&](const JH& j) { return dovetail(j.h); }), jj.end());
+  }
+  for (auto& j : jj) joint.push_back(j.h);
   hctr.totHits += joint.size();                                           // :701
   if (!joint.empty()) ++hctr.mappedUnits;
   w.n_hits += joint.size();
 }
 
-// single-end driver -- src/RapMapSAMapper.cpp:232-250
-static void mapSingle(const OIndex& ix, const Opts& o, Collector& col, const char* r, size_t l,
+// single-end driver -- src/RapMapSAMapper.cpp:225-320
+static void mapSingle(const OIndex& ix, const Opts& o, const MapCfg& mc, Collector& col, Aligner* aligner, const char* r, size_t l,
                       std::vector<Hit>& out, Counters& hctr, Work& w) {
   std::vector<SAIntervalHit> f, rc;
   std::vector<QA> hits;
   ++hctr.numReads;
   out.clear();
   col.collect(r, l, f, rc);
-  hitsToMappingsSimple(ix, SINGLE_END, (uint32_t)l, f, rc, hits, w);
+  hitsToMappingsSimple(ix, mc, SINGLE_END, (uint32_t)l, f, rc, hits, w);
   hctr.totHits += hits.size();            // counted before the maxNumHits clear (:240-245)
   if (hits.size() > (size_t)o.maxNumHits) hits.clear();
+  std::vector<JH> jj;
   for (auto& q : hits) {
-    Hit h{}; h.tid = q.tid; h.pos = q.pos; h.readLen = q.readLen; h.fwd = q.fwd; h.mateIsFwd = 1;
-    h.mateStatus = SINGLE_END; out.push_back(h);
+    JH j; Hit& h = j.h; h = Hit{};
+    h.tid = q.tid; h.pos = q.pos; h.readLen = q.readLen; h.fwd = q.fwd; h.mateIsFwd = 1;
+    h.mateStatus = SINGLE_END; j.csLeft = q.csLeft; j.csRight = q.csRight; jj.push_back(j);
   }
+  if (o.selAln) {                                                          // :246-318
+    AlnCache alnCache;
+    std::string rc1; bool have1 = false;
+    const int8_t a = (int8_t)o.matchScore, b = (int8_t)o.mismatchPenalty;
+    int32_t bestScore = std::numeric_limits<int32_t>::lowest();
+    std::vector<int32_t> scores(jj.size(), bestScore);
+    const double optFrac = o.minScoreFraction;
+    const int32_t maxReadScore = a * (int32_t)l;
+    const bool multiMapping = jj.size() > 1;
+    size_t idx = 0;
+    for (auto& j : jj) {
+      Hit& h = j.h;
+      const char* tseq = (const char*)ix.text + ix.txpOffsets[h.tid];
+      const int32_t tlen = (int32_t)ix.txpLens[h.tid];
+      if (!h.fwd && !have1) { reverseRead(r, (int64_t)l, rc1); have1 = true; }
+      const char* rptr = h.fwd ? r : rc1.data();
+      int32_t s = getAlnScore(*aligner, h.pos, rptr, (int32_t)l, tseq, tlen, a, b, maxReadScore, j.csLeft, multiMapping, o.alnPolicy, 20, alnCache);
+      int32_t score = (s < (optFrac * maxReadScore)) ? std::numeric_limits<int32_t>::min() : s;
+      bestScore = (score > bestScore) ? score : bestScore;
+      scores[idx++] = score;
+    }
+    filterByScore(jj, scores, bestScore, o.hardFilter != 0, [](JH& j) -> Hit& { return j.h; });
+  }
+  for (auto& j : jj) out.push_back(j.h);
   if (!out.empty()) ++hctr.mappedUnits;
   w.n_hits += out.size();
 }
@@ -856,6 +1309,9 @@ void* qo_index_create(int k, const uint8_t* text, int64_t n, const int32_t* SA, 
   uint64_t c = 0;
   for (uint64_t i = 0; i < nwords; ++i) { ix->cum[i] = c; c += __builtin_popcountll(rsd[i]); }
   ix->cum[nwords] = c;
+  ix->txpLens.resize((size_t)nTxp);
+  for (int64_t t = 0; t < nTxp; ++t)
+    ix->txpLens[(size_t)t] = t + 1 < nTxp ? (int64_t)txpOffsets[t + 1] - 1 - txpOffsets[t] : nSA - 1 - txpOffsets[t];
   uint64_t cap = 16;
   while (cap < (uint64_t)nKeys * 2) cap <<= 1;
   ix->hk.assign(cap, ~0ULL); ix->hv.resize(cap); ix->hmask = cap - 1;
@@ -881,6 +1337,7 @@ int qo_map(void* hidx, const Opts* opts, int64_t n, const char* seq1, const int6
            const char* seq2, const int64_t* off2, int nthreads, int64_t* hit_offsets, Hit** hits_out,
            uint64_t* counters, uint64_t* work, int64_t* ints_offsets, int32_t** ints_out) {
   const OIndex& ix = *(const OIndex*)hidx;
+  if (opts->selAln && opts->recoverOrphans) return -2;      // --recoverOrphans is not restated
   if (nthreads < 1) nthreads = 1;
   std::vector<std::vector<Hit>> perHits(nthreads);
   std::vector<std::vector<int32_t>> perInts(nthreads);
@@ -891,11 +1348,13 @@ int qo_map(void* hidx, const Opts* opts, int64_t n, const char* seq1, const int6
   auto worker = [&](int t) {
     int64_t b = n * t / nthreads, e = n * (t + 1) / nthreads;
     Collector col(ix, *opts, wk[t]);
+    const MapCfg mc = mapCfg(*opts);
+    Aligner aligner(opts->matchScore, opts->mismatchPenalty, opts->gapOpen, opts->gapExtend, opts->dpBandwidth);
     std::vector<Hit> joint;
     std::vector<SAIntervalHit> dump[4];
     for (int64_t i = b; i < e; ++i) {
       if (seq2) {
-        mapPair(ix, *opts, col, seq1 + off1[i], (size_t)(off1[i + 1] - off1[i]), seq2 + off2[i],
+        mapPair(ix, *opts, mc, col, &aligner, seq1 + off1[i], (size_t)(off1[i + 1] - off1[i]), seq2 + off2[i],
                 (size_t)(off2[i + 1] - off2[i]), joint, ctr[t], wk[t], ints_out ? dump : nullptr);
         if (ints_out) {
           for (int l = 0; l < 4; ++l)
@@ -906,7 +1365,7 @@ int qo_map(void* hidx, const Opts* opts, int64_t n, const char* seq1, const int6
             }
         }
       } else {
-        mapSingle(ix, *opts, col, seq1 + off1[i], (size_t)(off1[i + 1] - off1[i]), joint, ctr[t], wk[t]);
+        mapSingle(ix, *opts, mc, col, &aligner, seq1 + off1[i], (size_t)(off1[i + 1] - off1[i]), joint, ctr[t], wk[t]);
       }
       cnt[i + 1] = (int64_t)joint.size();
       perHits[t].insert(perHits[t].end(), joint.begin(), joint.end());

@@ -160,3 +160,71 @@ def test_sample_data_fuzzy(sample_data, oracle_mod):
         if mine != want[sam._read_name(sample_data["names1"][i])]:
             bad.append(i)
     assert not bad, bad[:10]
+
+
+# ---- selective alignment (-s): chaining, multi-position hits, ksw2 extension alignment, score gate (row a17)
+def _sel(oracle_mod, **kw):
+    return oracle_mod.default_opts(selAln=1, **kw)
+
+
+SEL_PAIRED = {
+    "selAln": ("reads", lambda m: _sel(m)),
+    "selAln_hardFilter": ("reads", lambda m: _sel(m, hardFilter=1)),
+    "selAln_minScoreFrac0.9": ("reads", lambda m: _sel(m, minScoreFraction=0.9)),
+    "selAln_noOrphans_noDovetail": ("reads", lambda m: _sel(m, noOrphans=1, noDovetail=1)),
+    "mimicBT2": ("reads", lambda m: m.mimic_bt2_opts()),
+    "mimicStrictBT2": ("reads", lambda m: m.mimic_bt2_opts(strict=True)),
+    "chaining": ("reads", lambda m: m.default_opts()),              # -c without -s changes nothing (RapMapSAMapper.cpp:182)
+    "indel_selAln": ("indel", lambda m: _sel(m)),
+    "indel_selAln_hardFilter": ("indel", lambda m: _sel(m, hardFilter=1)),
+    "indel_mimicBT2": ("indel", lambda m: m.mimic_bt2_opts()),
+    "indel_selAln_maxMMPExtension3": ("indel", lambda m: _sel(m, maxMMPExtension=3)),
+}
+
+
+@pytest.mark.parametrize("variant", sorted(SEL_PAIRED))
+def test_synth_small_selective_alignment(synth_small, oracle_mod, variant):
+    from rapmap_amd import sam
+    which, mk = SEL_PAIRED[variant]
+    n1, s1, n2, s2 = _next_reads(synth_small, which)
+    ix, orc = load_oracle(synth_small["idx"])
+    q1, o1 = pack(s1); q2, o2 = pack(s2)
+    opts = mk(oracle_mod)
+    res = orc.map_pairs(q1, o1, q2, o2, opts=opts, nthreads=4)
+    want = sam_groups_from_gz(os.path.join(NEXT, "expected_%s.noseq.sam.gz" % variant))
+    bad = [i for i in range(len(s1))
+           if strip_seq(sam.format_pair(n1[i], s1[i], n2[i], s2[i], res.hits[res.hit_offsets[i]:res.hit_offsets[i + 1]],
+                                        ix.names, ix.txpLens, opts.maxNumHits)) != want[sam._read_name(n1[i])]]
+    assert not bad, "pairs whose SAM (incl. AS:i alignment scores) differs from the reference: %s" % bad[:10]
+
+
+def test_synth_small_selective_alignment_single_end(synth_small, oracle_mod):
+    from rapmap_amd import sam
+    ix, orc = load_oracle(synth_small["idx"])
+    q, o = pack(synth_small["reads1"])
+    res = orc.map_single(q, o, opts=_sel(oracle_mod), nthreads=4)
+    want = {}
+    with gzip.open(os.path.join(NEXT, "expected_single_selAln.noseq.sam.gz"), "rt") as f:
+        for l in f:
+            want.setdefault(l.split("\t", 1)[0], []).append(l)
+    bad = [i for i in range(len(synth_small["reads1"]))
+           if strip_seq(sam.format_single(synth_small["names1"][i], synth_small["reads1"][i],
+                                          res.hits[res.hit_offsets[i]:res.hit_offsets[i + 1]], ix.names, ix.txpLens))
+           != want.get(synth_small["names1"][i].split(" ")[0], [])]
+    assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize("variant", ["selAln", "selAln_hardFilter", "mimicBT2"])
+def test_sample_data_selective_alignment(sample_data, oracle_mod, variant):
+    """config 5 on the reference's own sample data"""
+    from rapmap_amd import sam
+    ix, orc = load_oracle(sample_data["idx"])
+    q1, o1 = pack(sample_data["reads1"]); q2, o2 = pack(sample_data["reads2"])
+    opts = {"selAln": _sel(oracle_mod), "selAln_hardFilter": _sel(oracle_mod, hardFilter=1), "mimicBT2": oracle_mod.mimic_bt2_opts()}[variant]
+    res = orc.map_pairs(q1, o1, q2, o2, opts=opts, nthreads=2)
+    want = sam_groups_from_gz(os.path.join(GOLD, "sample_data", "expected_%s.noseq.sam.gz" % variant))
+    bad = [i for i in range(len(sample_data["reads1"]))
+           if strip_seq(sam.format_pair(sample_data["names1"][i], sample_data["reads1"][i], sample_data["names2"][i],
+                                        sample_data["reads2"][i], res.hits[res.hit_offsets[i]:res.hit_offsets[i + 1]],
+                                        ix.names, ix.txpLens, opts.maxNumHits)) != want[sam._read_name(sample_data["names1"][i])]]
+    assert not bad, bad[:10]
