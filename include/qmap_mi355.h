@@ -49,8 +49,19 @@ typedef struct qm_opts {
   int32_t no_dovetail;   /* --noDovetail                                                  */
   int32_t fuzzy;         /* -f  mergeLeftRightHitsFuzzy, include/RapMapUtils.hpp:864-1183   */
   int32_t max_interval;  /* SACollector::setMaxInterval, 1000 (SACollector.hpp:54,77)     */
-  int32_t sel_aln;       /* -s  (not on the device path yet)                              */
+  int32_t sel_aln;       /* -s  selective alignment (not on the device path yet: QM_E_UNSUPPORTED) */
   double quasi_cov;      /* -z  (SACollector::setCoverageRequirement)                     */
+  /* sub-options of -s (src/RapMapSAMapper.cpp:1011-1023,1135-1175); read only when sel_aln != 0 */
+  int32_t hard_filter;        /* --hardFilter                                             */
+  int32_t match_score;        /* --ma, 2                                                  */
+  int32_t mismatch_penalty;   /* --mm, -4                                                 */
+  int32_t gap_open;           /* --go, 4                                                  */
+  int32_t gap_extend;         /* --ge, 2                                                  */
+  int32_t dp_bandwidth;       /* --dpBandwidth, 15                                        */
+  int32_t max_mmp_extension;  /* --maxMMPExtension, 7                                     */
+  int32_t aln_policy;         /* 0 default, 1 --mimicBT2, 2 --mimicStrictBT2              */
+  double min_score_fraction;  /* --minScoreFrac, 0.65                                     */
+  double consensus_slack;     /* --consensusSlack, 0.2                                    */
 } qm_opts;
 
 /* POD image of rapmap::utils::QuasiAlignment (include/RapMapUtils.hpp:399-502),

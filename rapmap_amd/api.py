@@ -46,7 +46,10 @@ class QmOpts(C.Structure):
     """MappingOpts (src/RapMapSAMapper.cpp:114-152), hot-path fields only."""
     _fields_ = [("sensitive", C.c_int32), ("strict_check", C.c_int32), ("max_num_hits", C.c_int32),
                 ("no_orphans", C.c_int32), ("no_dovetail", C.c_int32), ("fuzzy", C.c_int32),
-                ("max_interval", C.c_int32), ("sel_aln", C.c_int32), ("quasi_cov", C.c_double)]
+                ("max_interval", C.c_int32), ("sel_aln", C.c_int32), ("quasi_cov", C.c_double),
+                ("hard_filter", C.c_int32), ("match_score", C.c_int32), ("mismatch_penalty", C.c_int32), ("gap_open", C.c_int32),
+                ("gap_extend", C.c_int32), ("dp_bandwidth", C.c_int32), ("max_mmp_extension", C.c_int32), ("aln_policy", C.c_int32),
+                ("min_score_fraction", C.c_double), ("consensus_slack", C.c_double)]
 
 
 class QmCounters(C.Structure):

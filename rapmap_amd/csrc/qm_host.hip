@@ -116,6 +116,8 @@ int qm_opts_default(qm_opts* o) {
   if (!o) return fail(QM_E_ARG, "null opts");
   o->sensitive = 1; o->strict_check = 1; o->max_num_hits = 200; o->no_orphans = 0; o->no_dovetail = 0;
   o->fuzzy = 0; o->max_interval = 1000; o->sel_aln = 0; o->quasi_cov = 0.0;
+  o->hard_filter = 0; o->match_score = 2; o->mismatch_penalty = -4; o->gap_open = 4; o->gap_extend = 2; o->dp_bandwidth = 15;
+  o->max_mmp_extension = 7; o->aln_policy = 0; o->min_score_fraction = 0.65; o->consensus_slack = 0.2;
   return QM_OK;
 }
 

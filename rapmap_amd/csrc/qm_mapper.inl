@@ -106,6 +106,7 @@ struct ReadBatch {
   int sensitive;           // 0: --noSensitive (NIP skipping via SASearcher::lce, k-mer vote instead of coverage)
   double quasi_cov;
   int fuzzy;               // --fuzzyIntersection: lists keep both orientations of a transcript, lcnt bit31 = foundHit
+  int max_mmp_ext;         // --maxMMPExtension (QM_F_SEL kernels only)
 };
 
 // stage B launch arguments
@@ -255,6 +256,7 @@ __shared__ u64 qm_tim[4][10];
 #endif
 #define QM_F_PH 1      // perfect-hash (-p) index
 #define QM_F_NIP 2     // --noSensitive: NIP skipping + k-mer vote
+#define QM_F_SEL 4     // --selAln: chain scoring in the collector (MMPs capped at k + maxMMPExtension), coverage slack 1
 
 // khash.find for either index flavour.
 // dense: exact lookup in the open-addressing table (RapMapUtils.hpp:65-67).
@@ -813,7 +815,18 @@ QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, c
     lb = lb - 1 > 0 ? lb - 1 : 0;                      // :553
     int mlen;
     QM_CNT(18, 1); QM_T(4);
-    extend_search(ix, lb, ub, k, str + p, L - p, lb, ub, mlen, V.dollar);
+    if (!(F & QM_F_SEL)) {
+      extend_search(ix, lb, ub, k, str + p, L - p, lb, ub, mlen, V.dollar);
+    } else {
+      // chain scoring (SACollector.hpp:557-575): only the MMP that starts the read may run to its end, every other
+      // one is cut at k + maxMMPExtension characters; a first MMP longer than that (and shorter than the read) is redone cut
+      const int cut = p + k + B.max_mmp_ext < L ? p + k + B.max_mmp_ext : L;
+      const bool firstAttempt = p == 0;
+      const int lbP = lb, ubP = ub;
+      extend_search(ix, lb, ub, k, str + p, (firstAttempt ? L : cut) - p, lb, ub, mlen, V.dollar);
+      if (firstAttempt && !(mlen >= L) && mlen >= k + B.max_mmp_ext)
+        extend_search(ix, lbP, ubP, k, str + p, cut - p, lb, ub, mlen, V.dollar);
+    }
     QM_T(3);
     const bool more = !lastSearch && p + mlen < L;     // the walk continues at kp after this MMP
     const int kp = p + mlen - (k - 1);
@@ -922,9 +935,10 @@ QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M,
       get_sa_hits<NS, F>(ix, B, S, fwdStr, L, 0, false, 0, 0, fwdCov, fwdHit, rcHit, fwdInts);
     }
   }
-  if (useCoverageCheck) {                               // :283-288 (slack 0)
-    if (fwdCov > rcCov) rcInts.n = 0;
-    else if (rcCov > fwdCov) fwdInts.n = 0;
+  if (useCoverageCheck) {                               // :283-288 (strictCheckSlack_: 1 with chain scoring, else 0)
+    const long long slack = (F & QM_F_SEL) ? 1 : 0;
+    if (fwdCov > rcCov + slack) rcInts.n = 0;
+    else if (rcCov > fwdCov + slack) fwdInts.n = 0;
   } else if (vote) {                                    // :289-337: the k-mer "spot check" vote
     if (fwdHit > 0 && rcHit == 0) rcInts.n = 0;
     else if (rcHit > 0 && fwdHit == 0) fwdInts.n = 0;

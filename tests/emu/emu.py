@@ -25,11 +25,14 @@ INT_DTYPE = np.dtype([("begin", "<i4"), ("end", "<i4"), ("len", "<u4"), ("query_
 class QmOpts(C.Structure):
     _fields_ = [("sensitive", C.c_int32), ("strict_check", C.c_int32), ("max_num_hits", C.c_int32),
                 ("no_orphans", C.c_int32), ("no_dovetail", C.c_int32), ("fuzzy", C.c_int32),
-                ("max_interval", C.c_int32), ("sel_aln", C.c_int32), ("quasi_cov", C.c_double)]
+                ("max_interval", C.c_int32), ("sel_aln", C.c_int32), ("quasi_cov", C.c_double),
+                ("hard_filter", C.c_int32), ("match_score", C.c_int32), ("mismatch_penalty", C.c_int32), ("gap_open", C.c_int32),
+                ("gap_extend", C.c_int32), ("dp_bandwidth", C.c_int32), ("max_mmp_extension", C.c_int32), ("aln_policy", C.c_int32),
+                ("min_score_fraction", C.c_double), ("consensus_slack", C.c_double)]
 
 
 def default_opts(**kw):
-    o = QmOpts(1, 1, 200, 0, 0, 0, 1000, 0, 0.0)
+    o = QmOpts(1, 1, 200, 0, 0, 0, 1000, 0, 0.0, 0, 2, -4, 4, 2, 15, 7, 0, 0.65, 0.2)
     for k, v in kw.items():
         setattr(o, k, v)
     return o

@@ -25,6 +25,9 @@ def test_defaults_match_reference_cli(lib_built):
     # src/RapMapSAMapper.cpp:992-1023,1113-1114 ; include/SACollector.hpp:77
     assert (o.sensitive, o.strict_check, o.max_num_hits, o.no_orphans, o.no_dovetail, o.fuzzy, o.max_interval,
             o.sel_aln, o.quasi_cov) == (1, 1, 200, 0, 0, 0, 1000, 0, 0.0)
+    # -s sub-options, src/RapMapSAMapper.cpp:1012-1023
+    assert (o.hard_filter, o.match_score, o.mismatch_penalty, o.gap_open, o.gap_extend, o.dp_bandwidth, o.max_mmp_extension,
+            o.aln_policy, o.min_score_fraction, o.consensus_slack) == (0, 2, -4, 4, 2, 15, 7, 0, 0.65, 0.2)
 
 
 def test_struct_sizes(lib_built):

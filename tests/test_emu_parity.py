@@ -2,6 +2,8 @@
 against the oracle: bit-exact hits, offsets, counters and SA-interval lists.  This is how the wave
 algorithm is debugged without a GPU; the same comparisons run against the real HIP path in
 test_gpu_parity.py (-m gpu)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -188,3 +190,19 @@ def test_perfect_hash_index(synth_small, synth_small_ph, oracle_mod):
         e2 = em.map(q1, o1, q2, o2, opts=emu.default_opts(**eo))
         assert_hits_equal(r2.hit_offsets, r2.hits, e2.hit_offsets, e2.hits, "perfect-hash %s" % oo)
         assert r2.counters == e2.counters
+
+
+def test_selective_alignment_collector_intervals(synth_small, oracle_mod):
+    """-s, stage A only: chain scoring in the collector (MMPs cut at k + maxMMPExtension, coverage slack 1).  The rest of
+    the -s path is not on the device yet, so only the SA-interval hits are compared here."""
+    from conftest import GOLD
+    from rapmap_amd import sam
+    ix, orc, em, emu = _emu(synth_small["idx"])
+    n1, s1 = sam.read_fastq(os.path.join(GOLD, "synth_small", "next", "reads_indel_1.fastq.gz"))
+    n2, s2 = sam.read_fastq(os.path.join(GOLD, "synth_small", "next", "reads_indel_2.fastq.gz"))
+    for r1, r2 in ((synth_small["reads1"], synth_small["reads2"]), (s1, s2)):
+        q1, o1 = pack(r1); q2, o2 = pack(r2)
+        for ext in (7, 3):
+            res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(selAln=1, maxMMPExtension=ext), nthreads=4, want_ints=True)
+            er = em.map(q1, o1, q2, o2, opts=emu.default_opts(sel_aln=1, max_mmp_extension=ext))
+            _cmp_ints(res, er)
