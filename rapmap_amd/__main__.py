@@ -2,7 +2,7 @@
 
 Flag names, defaults and validation follow `rapmap quasiindex` (src/RapMapSAIndexer.cpp:821-927) and
 `rapmap quasimap` (src/RapMapSAMapper.cpp:984-1189, validateOpts :911-954).  Options that the device path does
-not implement (-s/--selAln and its sub-options, -f, --recoverOrphans, -c) are accepted by the parser and
+not implement (--recoverOrphans, -c) are accepted by the parser and
 rejected with the library's error, never silently ignored.
 """
 import argparse
@@ -52,7 +52,18 @@ def _quasimap(argv):
     ap.add_argument("--recoverOrphans", action="store_true")
     ap.add_argument("--noDovetail", action="store_true")
     ap.add_argument("--noOrphans", action="store_true")
-    ap.add_argument("-s", "--selAln", action="store_true")
+    ap.add_argument("-s", "--selAln", action="store_true", help="Perform selective alignment to validate mapping hits")
+    ap.add_argument("--go", type=int, default=4, help="[only with selAln]: gap open penalty")
+    ap.add_argument("--ge", type=int, default=2, help="[only with selAln]: gap extend penalty")
+    ap.add_argument("--mm", type=int, default=-4, help="[only with selAln]: mismatch penalty")
+    ap.add_argument("--ma", type=int, default=2, help="[only with selAln]: match score")
+    ap.add_argument("--dpBandwidth", type=int, default=15)
+    ap.add_argument("--minScoreFrac", type=float, default=0.65)
+    ap.add_argument("--consensusSlack", type=float, default=0.2)
+    ap.add_argument("--hardFilter", action="store_true")
+    ap.add_argument("--mimicBT2", action="store_true")
+    ap.add_argument("--mimicStrictBT2", action="store_true")
+    ap.add_argument("--maxMMPExtension", type=int, default=7)
     ap.add_argument("--device", type=int, default=0, help="GPU to use")
     ap.add_argument("--chunk", type=int, default=1 << 20, help="read pairs per GPU batch")
     a = ap.parse_args(argv)
@@ -72,6 +83,20 @@ def _quasimap(argv):
     opts = ra.default_opts(sensitive=0 if a.noSensitive else 1, strict_check=0 if a.noStrictCheck else 1,
                            max_num_hits=a.maxNumHits, no_orphans=int(a.noOrphans), no_dovetail=int(a.noDovetail),
                            fuzzy=int(a.fuzzyIntersection), sel_aln=int(a.selAln), quasi_cov=a.quasiCoverage)
+    # --selAln and what it implies (src/RapMapSAMapper.cpp:1124-1175)
+    if a.mimicBT2 and a.mimicStrictBT2:
+        sys.exit("Cannot set --mimicBT2 and --mimicStrictBT2 simultaneously.  Please choose one")
+    if a.mimicBT2 or a.mimicStrictBT2:
+        opts.sel_aln = 1
+    if opts.sel_aln:
+        opts.gap_open, opts.gap_extend, opts.mismatch_penalty, opts.match_score = a.go, a.ge, a.mm, a.ma
+        opts.dp_bandwidth, opts.min_score_fraction, opts.consensus_slack = a.dpBandwidth, a.minScoreFrac, a.consensusSlack
+        opts.hard_filter, opts.max_mmp_extension = int(a.hardFilter), a.maxMMPExtension
+        if a.mimicBT2 or a.mimicStrictBT2:
+            opts.aln_policy = 2 if a.mimicStrictBT2 else 1
+            opts.no_orphans = 1; opts.no_dovetail = 1; opts.consensus_slack = 0.35; opts.max_num_hits = 1000
+        if a.mimicStrictBT2:
+            opts.min_score_fraction = 0.8; opts.match_score = 1; opts.mismatch_penalty = 0; opts.gap_open = 25; opts.gap_extend = 25
     qi = ra.QuasiIndex(a.index)
     mp = ra.QuasiMapper(qi, a.device)
     log = (lambda *x: None) if a.quiet else (lambda *x: print(*x, file=sys.stderr, flush=True))
@@ -116,9 +141,9 @@ def _quasimap(argv):
                 tot[kk] += r.counters[kk]
             if out is not None:
                 if direct_fd is not None:
-                    ra.sam_records_text(qi, b, r.hit_offsets, r.hits, max_num_hits=a.maxNumHits, threads=nthr, fd=direct_fd)
+                    ra.sam_records_text(qi, b, r.hit_offsets, r.hits, max_num_hits=opts.max_num_hits, threads=nthr, fd=direct_fd)
                 else:
-                    out.write(ra.sam_records_text(qi, b, r.hit_offsets, r.hits, max_num_hits=a.maxNumHits, threads=nthr))
+                    out.write(ra.sam_records_text(qi, b, r.hit_offsets, r.hits, max_num_hits=opts.max_num_hits, threads=nthr))
             if paired:
                 log("saw %d reads : pe / read = %.4f : se / read = %.4f" % (
                     tot["numReads"], tot["peHits"] / max(1, tot["numReads"]), tot["seHits"] / max(1, tot["numReads"])))

@@ -12,6 +12,11 @@ hipError_t qmk_build_slots(const void* recs, long long K, void* slots, unsigned 
 hipError_t qmk_build_phrecs(const int* data, const unsigned char* lens, long long n, const void* dev_index, void* out, hipStream_t st);
 int qmk_map_grid(long long n, int num_cu);
 hipError_t qmk_map_reads(const void* dev_index, const void* read_batch, int ns, int grid, int num_cu, hipStream_t st);
+size_t qmk_sel_scratch_bytes(void);
+size_t qmk_sel_ksw_bytes(void);
+hipError_t qmk_sel_slots(const void* pair_batch, hipStream_t st);
+hipError_t qmk_sel_unit(const void* pair_batch, const void* sel_batch, int grid, hipStream_t st);
+hipError_t qmk_sel_compact(const void* pair_batch, const void* tmp, const void* toff, hipStream_t st);
 hipError_t qmk_pair_count(const void* pair_batch, hipStream_t st);
 hipError_t qmk_pair_write(const void* pair_batch, hipStream_t st);
 size_t qmk_scan_temp_bytes(long long n);

@@ -91,6 +91,12 @@ struct qm_ctx {
   void* d_scanTmp = nullptr; size_t scanTmpBytes = 0;
   uint8_t* d_seq1 = nullptr; uint8_t* d_seq2 = nullptr; long long* d_off1 = nullptr; long long* d_off2 = nullptr;
   qm_sa_interval_hit* d_dbg = nullptr; uint32_t* d_dbgcnt = nullptr; int64_t capDbg = 0, capDbgCnt = 0; int debug = 0;
+  // -s (selective alignment) work areas
+  int32_t* d_txpOff = nullptr; int32_t* d_txpLen = nullptr;
+  unsigned char* d_selscr = nullptr; int64_t capSelScr = 0;
+  long long* d_toff = nullptr; int64_t capToff = 0;
+  qm_hit* d_tmp = nullptr; int64_t capTmp = 0; u64* d_tkeys = nullptr; int64_t capTkeys = 0; int* d_tsc = nullptr; int64_t capTsc = 0;
+  unsigned char* d_ksw = nullptr; int64_t capKsw = 0;
   // last result
   int64_t lastUnits = -1, lastHits = 0; bool lastPaired = false;
   double lastMapMs = 0, lastTotalMs = 0;
@@ -316,7 +322,8 @@ int qm_ctx_destroy(qm_ctx* c) {
   if (!c) return QM_OK;
   hipSetDevice(c->device);
   void* ptrs[] = {c->d_text, c->d_SA, c->d_sainfo, c->d_slots, c->d_cnt, c->d_lcnt, c->d_loff, c->d_lists, c->d_hits, c->d_offs,
-                  c->d_scal, c->d_gscr, c->d_scanTmp, c->d_seq1, c->d_seq2, c->d_off1, c->d_off2, c->d_dbg, c->d_dbgcnt};
+                  c->d_scal, c->d_gscr, c->d_scanTmp, c->d_seq1, c->d_seq2, c->d_off1, c->d_off2, c->d_dbg, c->d_dbgcnt,
+                  c->d_txpOff, c->d_txpLen, c->d_selscr, c->d_toff, c->d_tmp, c->d_tkeys, c->d_tsc, c->d_ksw};
   for (void* p : ptrs) if (p) hipFree(p);
   for (void* p : c->phAllocs) if (p) hipFree(p);
   if (c->ev0) hipEventDestroy(c->ev0);
@@ -414,7 +421,14 @@ int qm_ctx_create(const qm_index* ix, int device_id, qm_ctx** out) {
   }
   CK(hipMalloc((void**)&c->d_scal, 16 * sizeof(u64)));
   CK(hipStreamSynchronize(c->stream));
-  hipFree(d_offsets); if (d_recs) hipFree(d_recs);
+  c->d_txpOff = d_offsets;                               // kept: -s reads transcript sequences by (offset, length)
+  {
+    std::vector<int32_t> l32((size_t)ix->nTxp);
+    for (int64_t t = 0; t < ix->nTxp; ++t) l32[(size_t)t] = (int32_t)ix->lens[(size_t)t];
+    CK(hipMalloc((void**)&c->d_txpLen, (size_t)(ix->nTxp ? ix->nTxp : 1) * 4));
+    CK(hipMemcpy(c->d_txpLen, l32.data(), (size_t)ix->nTxp * 4, hipMemcpyHostToDevice));
+  }
+  if (d_recs) hipFree(d_recs);
   c->devBytes += ix->n + pad + ix->nSA * 4 + ix->nSA * (int64_t)sizeof(SaInfo) + (int64_t)(ix->perfect ? 0 : c->cap * sizeof(Bucket));
 #undef CK
   *out = c;
@@ -426,7 +440,6 @@ int qm_ctx_set_debug(qm_ctx* c, int keep) { if (!c) return fail(QM_E_ARG, "null 
 
 static int check_opts(const qm_opts* o) {
   if (!o) return fail(QM_E_ARG, "null opts");
-  if (o->sel_aln) return fail(QM_E_UNSUPPORTED, "--selAln is not implemented on the device path");
   if (o->max_num_hits < 0 || o->max_interval < 1) return fail(QM_E_ARG, "bad max_num_hits / max_interval");
   return QM_OK;
 }
@@ -477,6 +490,13 @@ int qm_map_device(qm_ctx* c, const qm_opts* o, int64_t n, const void* d_seq1, co
     B.status = (int*)(c->d_scal + 8); B.gscratch = c->d_gscr;
     B.dbg_ints = c->debug ? c->d_dbg : nullptr; B.dbg_count = c->debug ? c->d_dbgcnt : nullptr;
     B.strict_check = o->strict_check; B.max_interval = o->max_interval; B.quasi_cov = o->quasi_cov; B.sensitive = o->sensitive; B.fuzzy = (d_seq2 != nullptr) ? o->fuzzy : 0;
+    if (o->sel_aln) {                                   // -s: chain scoring + per-wave scratch for chaining (qm_sel.inl)
+      if ((rc = ensure(c->d_selscr, c->capSelScr, (int64_t)grid * 4 * (int64_t)qmk_sel_scratch_bytes()))) return rc;
+      B.selscr = (SelScratch*)c->d_selscr;
+      B.max_mmp_ext = o->max_mmp_extension > 0 ? o->max_mmp_extension : 7;
+      const float cs = (float)o->consensus_slack;        // MappingOpts::consensusSlack is a float (RapMapSAMapper.cpp:138,184-185)
+      B.consensus_fraction = (cs == 0.0) ? 1.0 : (1.0 - cs);
+    }
     HIPCHK(hipMemsetAsync(c->d_scal, 0, 16 * sizeof(u64), c->stream));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     if (nreads > 0) HIPCHK(qmk_map_reads(&ix, &B, ns, grid, c->numCU, c->stream));
@@ -493,6 +513,7 @@ int qm_map_device(qm_ctx* c, const qm_opts* o, int64_t n, const void* d_seq1, co
 #endif
     if (status & 4) return fail(QM_E_TOOLONG, "a read is longer than max_read_len=%d", max_read_len);
     if (status & 2) return fail(QM_E_UNSUPPORTED, "an SA-interval list exceeded %d entries (max_interval too large)", QM_GCAP);
+    if (status & 8) return fail(QM_E_UNSUPPORTED, "selective alignment: the SA intervals of a read hold more than %d suffixes", QM_SEL_CAP);
     if (status & 1) {            // bump allocator ran out: grow and redo the batch
       int64_t want = (int64_t)hscal[0] + nreads + (int64_t)grid * 4 * QM_CHUNK;
       if (want < c->capLists * 2) want = c->capLists * 2;
@@ -508,7 +529,30 @@ int qm_map_device(qm_ctx* c, const qm_opts* o, int64_t n, const void* d_seq1, co
   P.lcnt = c->d_lcnt; P.loff = c->d_loff; P.lists = c->d_lists; P.cnt = c->d_cnt; P.offs = c->d_offs;
   P.counters = c->d_scal + 1; P.max_num_hits = o->max_num_hits; P.no_orphans = o->no_orphans; P.no_dovetail = o->no_dovetail; P.fuzzy = o->fuzzy;
   HIPCHK(hipMemsetAsync(c->d_cnt + n, 0, sizeof(uint32_t), c->stream));
-  HIPCHK(qmk_pair_count(&P, c->stream));
+  if (o->sel_aln) {
+    // -s: merge + selective alignment + filter per unit into temp slots, then compaction (qm_sel.inl)
+    HIPCHK(qmk_sel_slots(&P, c->stream));
+    HIPCHK(qmk_scan_counts(c->d_scanTmp, c->scanTmpBytes, c->d_cnt, c->d_offs, n + 1, c->stream));
+    if ((rc = ensure(c->d_toff, c->capToff, n + 1))) return rc;
+    HIPCHK(hipMemcpyAsync(c->d_toff, c->d_offs, (size_t)(n + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
+    long long slots = 0;
+    HIPCHK(hipMemcpyAsync(&slots, c->d_offs + n, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const int sgrid = c->numCU * 8;
+    if ((rc = ensure(c->d_tmp, c->capTmp, slots + 1))) return rc;
+    if ((rc = ensure(c->d_tkeys, c->capTkeys, 2 * slots + 2))) return rc;
+    if ((rc = ensure(c->d_tsc, c->capTsc, 2 * slots + 2))) return rc;
+    if ((rc = ensure(c->d_ksw, c->capKsw, (int64_t)sgrid * 64 * (int64_t)qmk_sel_ksw_bytes()))) return rc;
+    SelBatch A; memset(&A, 0, sizeof(A));
+    A.seq1 = (const unsigned char*)d_seq1; A.seq2 = (const unsigned char*)d_seq2; A.text = c->d_text;
+    A.txp_off = c->d_txpOff; A.txp_len = c->d_txpLen; A.tmp = c->d_tmp; A.toff = c->d_toff; A.tkeys = c->d_tkeys; A.tsc = c->d_tsc;
+    A.ksw = c->d_ksw; A.match = o->match_score; A.mismatch = o->mismatch_penalty; A.gap_open = o->gap_open; A.gap_extend = o->gap_extend;
+    A.bandwidth = o->dp_bandwidth; A.hard_filter = o->hard_filter; A.policy = o->aln_policy; A.min_score_fraction = o->min_score_fraction;
+    HIPCHK(hipMemsetAsync(c->d_cnt + n, 0, sizeof(uint32_t), c->stream));
+    HIPCHK(qmk_sel_unit(&P, &A, sgrid, c->stream));
+  } else {
+    HIPCHK(qmk_pair_count(&P, c->stream));
+  }
   HIPCHK(qmk_scan_counts(c->d_scanTmp, c->scanTmpBytes, c->d_cnt, c->d_offs, n + 1, c->stream));
   long long total = 0;
   HIPCHK(hipMemcpyAsync(&total, c->d_offs + n, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
@@ -516,7 +560,8 @@ int qm_map_device(qm_ctx* c, const qm_opts* o, int64_t n, const void* d_seq1, co
   HIPCHK(hipStreamSynchronize(c->stream));
   if ((rc = ensure(c->d_hits, c->capHits, (int64_t)total + 1, total / 8))) return rc;
   P.hits = c->d_hits;
-  HIPCHK(qmk_pair_write(&P, c->stream));
+  if (o->sel_aln) HIPCHK(qmk_sel_compact(&P, c->d_tmp, c->d_toff, c->stream));
+  else HIPCHK(qmk_pair_write(&P, c->stream));
   HIPCHK(hipEventRecord(c->evB, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   hipEventElapsedTime(&ms, c->evA, c->evB); c->lastTotalMs = ms;

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256, WPS) void qm_read_kernel(DevIndex ix, ReadBatc
     nxt = cur;
     pre_chars<NS>(B, r + nw, nxt);
     pre_offsets<NS>(B, r + 2 * nw, nxt);
-    map_read<NS, F>(ix, B, r, cur, mem[wave], gscr, wa);
+    map_read<NS, F>(ix, B, r, cur, mem[wave], gscr, wa, (F & QM_F_SEL) ? B.selscr + gw : nullptr);
     cur = nxt;
   }
 #ifdef QM_TIMING
@@ -72,6 +72,41 @@ __global__ __launch_bounds__(256) void qm_pair_write_kernel(PairBatch P) {
   if (u >= P.n) return;
   int c = (int)P.cnt[u];
   if (c > 0) unit_merge(P, u, P.hits + P.offs[u], c, nullptr);
+}
+
+// -s: per-unit temp slots needed = (list words of the unit) / 3 + 1 (every group has at least three words)
+__global__ __launch_bounds__(256) void qm_sel_slots_kernel(PairBatch P) {
+  long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u > P.n) return;
+  u32 w = 0;
+  if (u < P.n) w = P.paired ? (P.lcnt[2 * u] & 0x7fffffffu) + (P.lcnt[2 * u + 1] & 0x7fffffffu) : (P.lcnt[u] & 0x7fffffffu);
+  P.cnt[u] = u < P.n ? w / 3 + 1 : 0;
+}
+
+// -s stages B + C: one thread per unit (grid-stride: every thread owns a ksw2 work area)
+__global__ __launch_bounds__(64) void qm_sel_unit_kernel(PairBatch P, SelBatch A) {
+  __shared__ unsigned long long sc[6];
+  if (threadIdx.x < 6) sc[threadIdx.x] = 0;
+  __syncthreads();
+  const long long tg = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+  UnitCounters uc = {0, 0, 0, 0, 0, 0};
+  for (long long u = tg; u < P.n; u += stride) P.cnt[u] = (u32)sel_unit(P, A, u, tg, &uc);
+  if (uc.pe) atomicAdd(&sc[0], uc.pe);
+  if (uc.se) atomicAdd(&sc[1], uc.se);
+  if (uc.tot) atomicAdd(&sc[2], uc.tot);
+  if (uc.reads) atomicAdd(&sc[3], uc.reads);
+  if (uc.tooMany) atomicAdd(&sc[4], uc.tooMany);
+  if (uc.mapped) atomicAdd(&sc[5], uc.mapped);
+  __syncthreads();
+  if (threadIdx.x < 6 && sc[threadIdx.x]) atomicAdd((unsigned long long*)&P.counters[threadIdx.x], sc[threadIdx.x]);
+}
+
+// -s: surviving hits from the per-unit temp slots to CSR order
+__global__ __launch_bounds__(256) void qm_sel_compact_kernel(PairBatch P, const qm_hit* tmp, const long long* toff) {
+  long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= P.n) return;
+  const int c = (int)P.cnt[u];
+  for (int i = 0; i < c; ++i) P.hits[P.offs[u] + i] = tmp[toff[u] + i];
 }
 
 __global__ void build_sainfo_kernel(const int* SA, long long nSA, const int* offsets, long long T, SaInfo* out) {
@@ -157,7 +192,7 @@ int qmk_map_grid(long long nreads, int num_cu) {
 hipError_t qmk_map_reads(const void* ixp, const void* bp, int ns, int grid, int num_cu, hipStream_t st) {
   const DevIndex& ix = *(const DevIndex*)ixp;
   const ReadBatch& B = *(const ReadBatch*)bp;
-  const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP);
+  const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP) | (B.selscr ? QM_F_SEL : 0);
 #define QM_LAUNCH(NS_, WPS_, F_) do {                                                                          \
     static int nb = 0;                                                                                          \
     if (nb == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, qm_read_kernel<NS_, WPS_, F_>, 256, 0) != hipSuccess || nb < 1)) \
@@ -171,17 +206,45 @@ hipError_t qmk_map_reads(const void* ixp, const void* bp, int ns, int grid, int 
       case 0: QM_LAUNCH(2, QMK_DEFAULT_WPS, 0); break;
       case QM_F_PH: QM_LAUNCH(2, 4, QM_F_PH); break;
       case QM_F_NIP: QM_LAUNCH(2, 4, QM_F_NIP); break;
-      default: QM_LAUNCH(2, 4, QM_F_PH | QM_F_NIP); break;
+      case QM_F_PH | QM_F_NIP: QM_LAUNCH(2, 4, QM_F_PH | QM_F_NIP); break;
+      case QM_F_SEL: QM_LAUNCH(2, 3, QM_F_SEL); break;
+      case QM_F_SEL | QM_F_PH: QM_LAUNCH(2, 3, QM_F_SEL | QM_F_PH); break;
+      case QM_F_SEL | QM_F_NIP: QM_LAUNCH(2, 3, QM_F_SEL | QM_F_NIP); break;
+      default: QM_LAUNCH(2, 3, QM_F_SEL | QM_F_PH | QM_F_NIP); break;
     }
   } else {
     switch (F) {
       case 0: QM_LAUNCH(4, 3, 0); break;
       case QM_F_PH: QM_LAUNCH(4, 3, QM_F_PH); break;
       case QM_F_NIP: QM_LAUNCH(4, 3, QM_F_NIP); break;
-      default: QM_LAUNCH(4, 3, QM_F_PH | QM_F_NIP); break;
+      case QM_F_PH | QM_F_NIP: QM_LAUNCH(4, 3, QM_F_PH | QM_F_NIP); break;
+      case QM_F_SEL: QM_LAUNCH(4, 2, QM_F_SEL); break;
+      case QM_F_SEL | QM_F_PH: QM_LAUNCH(4, 2, QM_F_SEL | QM_F_PH); break;
+      case QM_F_SEL | QM_F_NIP: QM_LAUNCH(4, 2, QM_F_SEL | QM_F_NIP); break;
+      default: QM_LAUNCH(4, 2, QM_F_SEL | QM_F_PH | QM_F_NIP); break;
     }
   }
 #undef QM_LAUNCH
+  return hipGetLastError();
+}
+
+size_t qmk_sel_scratch_bytes(void) { return sizeof(SelScratch); }
+size_t qmk_sel_ksw_bytes(void) { return QM_KSW_BYTES; }
+hipError_t qmk_sel_slots(const void* pp, hipStream_t st) {
+  const PairBatch& P = *(const PairBatch*)pp;
+  hipLaunchKernelGGL(qm_sel_slots_kernel, dim3((unsigned)((P.n + 1 + 255) / 256)), dim3(256), 0, st, P);
+  return hipGetLastError();
+}
+hipError_t qmk_sel_unit(const void* pp, const void* ap, int grid, hipStream_t st) {
+  const PairBatch& P = *(const PairBatch*)pp;
+  if (P.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(qm_sel_unit_kernel, dim3((unsigned)grid), dim3(64), 0, st, P, *(const SelBatch*)ap);
+  return hipGetLastError();
+}
+hipError_t qmk_sel_compact(const void* pp, const void* tmp, const void* toff, hipStream_t st) {
+  const PairBatch& P = *(const PairBatch*)pp;
+  if (P.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(qm_sel_compact_kernel, dim3((unsigned)((P.n + 255) / 256)), dim3(256), 0, st, P, (const qm_hit*)tmp, (const long long*)toff);
   return hipGetLastError();
 }
 

@@ -107,6 +107,8 @@ struct ReadBatch {
   double quasi_cov;
   int fuzzy;               // --fuzzyIntersection: lists keep both orientations of a transcript, lcnt bit31 = foundHit
   int max_mmp_ext;         // --maxMMPExtension (QM_F_SEL kernels only)
+  float consensus_fraction; // 1 - consensusSlack (MappingConfig, RapMapSAMapper.cpp:184-185), QM_F_SEL only
+  struct SelScratch* selscr; // QM_F_SEL: one SelScratch per wave
 };
 
 // stage B launch arguments
@@ -1196,6 +1198,11 @@ QM_DEV void dump_intervals(const ReadBatch& B, long long read, int list, const I
   }
 }
 
+struct SelScratch;
+QM_DEV int sel_hits_to_mappings(const DevIndex& ix, const ReadBatch& B, const IntervalList& fwdInts, const IntervalList& rcInts,
+                                u32 readLen, int mate, SelScratch& S);
+QM_DEV const u64* sel_out(const SelScratch& S);
+
 // ------------------------------------------------------------------ stage A driver
 // One read: load -> collect -> hits->mappings -> list to global memory.
 struct WaveAlloc { long long base; int used; };   // the wave's current chunk of B.lists (wave-uniform)
@@ -1247,7 +1254,8 @@ QM_DEV void pre_chars(const ReadBatch& B, long long read, ReadPre<NS>& P) {
 }
 
 template <int NS, int F>
-QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, const ReadPre<NS>& pre, WaveMem<NS>& M, u64* gscr, WaveAlloc& wa) {
+QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, const ReadPre<NS>& pre, WaveMem<NS>& M, u64* gscr, WaveAlloc& wa,
+                     SelScratch* ss = nullptr) {
   const bool paired = B.seq2 != nullptr;
   const int mate = paired ? (int)(read & 1) : 0;
   int len = pre.len;
@@ -1287,11 +1295,16 @@ QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, con
   if (bound <= QM_CAP) { bf.A = M.buf[0]; bf.B = M.buf[1]; bf.R = M.buf[2]; }
   else { bf.A = gscr; bf.B = gscr + QM_GCAP; bf.R = gscr + 2 * QM_GCAP; }
   int n = 0;
-  if (bound > QM_GCAP) {               // only reachable with max_interval > 1000
+  const u64* listSrc = nullptr;
+  if (F & QM_F_SEL) {                  // -s: chaining + multi-position groups (qm_sel.inl)
+    n = sel_hits_to_mappings(ix, B, fi, ri, (u32)len, mate, *ss);
+    listSrc = sel_out(*ss);
+  } else if (bound > QM_GCAP) {        // only reachable with max_interval > 1000
     QM_LANES(l) { if (l == 0) *B.status |= 2; }
   } else {
     n = hits_to_mappings(ix, bf, fi, ri, B.fuzzy != 0);
   }
+  if (!(F & QM_F_SEL)) listSrc = bf.R;
   QM_T(5);
   // hand the list to stage B.  One returning atomic on a single word saturates at ~88 M/s on this chip
   // (MI355X_MICROARCH.md "dequeue"), far below the read rate, so a wave reserves QM_CHUNK elements at
@@ -1307,8 +1320,8 @@ QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, con
     if (base + n > B.lists_cap) { QM_LANES(l) { if (l == 0) *B.status |= 1; } n = 0; base = 0; }
     else wa.used += n;
   }
-  for (int b0 = 0; b0 < n; b0 += 64) { QM_LANES(l) { int i = b0 + l; if (i < n) B.lists[base + i] = bf.R[i]; } }
-  const u32 flag = (B.fuzzy && foundHit) ? 0x80000000u : 0u;      // lh / rh of RapMapSAMapper.cpp:472-478
+  for (int b0 = 0; b0 < n; b0 += 64) { QM_LANES(l) { int i = b0 + l; if (i < n) B.lists[base + i] = listSrc[i]; } }
+  const u32 flag = ((B.fuzzy || (F & QM_F_SEL)) && foundHit) ? 0x80000000u : 0u;      // lh / rh of RapMapSAMapper.cpp:472-478
   QM_LANES(l) { if (l == 0) { B.lcnt[read] = (u32)n | flag; B.loff[read] = base; } }
   QM_T(6);
 }
@@ -1497,5 +1510,7 @@ QM_DEV int unit_merge(const PairBatch& P, long long u, qm_hit* out, int cap, Uni
   if (uc) { uc->tot += (u64)cnt; if (cnt > 0) uc->mapped += 1; }
   return cnt;
 }
+
+#include "qm_sel.inl"
 
 }  // namespace qm

@@ -1,0 +1,606 @@
+// qm_sel.inl -- the selective-alignment (-s) variant of the path (SURVEY.md section 8 row a17 and the chaining /
+// multi-position branches of rows a9-a11, a13).  Included at the end of qm_mapper.inl, namespace qm.
+//
+//   stage A   sel_hits_to_mappings: after the (chain-scoring) collector, the wave's lanes fetch (transcript, offset)
+//             of every suffix of every SA interval in parallel -- the memory-bound part -- and lane 0 then replays
+//             intersectSAHits with slack (HitManager.cpp:587-689), the minimap2-style chaining DP with equally good
+//             chains kept as multiple positions (:84-326) and mergeOrientationUnique (:834-881) on that small set.
+//             A read's list becomes groups of words:  header = tid | primaryRC<<32 | chainStatus<<33 | nP<<36 | nO<<48,
+//             then nP positions of the surviving orientation and nO positions of the other one.
+//   stage B+C sel_unit: one thread per pair (or single read): mergeLeftRightHitsFuzzy on the position lists
+//             (RapMapUtils.hpp:864-1183), then getAlnScore for every hit (SelectiveAlignmentUtils.hpp:260-373) with
+//             ksw_extz2_sse41 reproduced lane by lane (src/ksw2pp/ksw2_extz2_sse.c), the score gate and the
+//             soft / hard filter (RapMapSAMapper.cpp:554-667, 246-318).
+// The double arithmetic of the chain score must not be contracted into FMAs: the reference is plain x86-64 code.
+
+#define QM_SEL_CAP 4096            // SA entries of one strand's intervals a read may bring (else status bit 3)
+#define QM_SEL_MAXIV 256           // SA-interval hits per strand
+enum : int { QM_CS_PERFECT = 0, QM_CS_UNGAPPED = 1, QM_CS_REGULAR = 4 };   // rapmap::utils::ChainStatus
+
+struct SelRec { u32 tid, pos, qpos, len, iv; };
+struct SelGroup { u32 tid; int cs; double score; int npos, off, ppos; };   // ppos: the hit's own position (QuasiAlignment::pos)
+struct SelScratch {                 // per wave, global memory
+  SelRec rec[QM_SEL_CAP], tmp[QM_SEL_CAP];
+  double f[QM_SEL_CAP]; int p[QM_SEL_CAP]; int seen[QM_SEL_CAP]; int ends[QM_SEL_CAP]; int starts[QM_SEL_CAP];
+  SelGroup grp[2][QM_SEL_CAP]; int pos[2][QM_SEL_CAP]; int ngrp[2], npos[2];
+  u64 out[QM_CHUNK];
+};
+
+QM_DEV const u64* sel_out(const SelScratch& S) { return S.out; }
+
+QM_DEV u64 sel_header(u32 tid, bool primaryRC, int cs, int nP, int nO) {
+  return (u64)tid | ((u64)(primaryRC ? 1 : 0) << 32) | ((u64)(cs & 7) << 33) | ((u64)(nP & 0xfff) << 36) | ((u64)(nO & 0xfff) << 48);
+}
+QM_DEV u32 selh_tid(u64 h) { return (u32)h; }
+QM_DEV bool selh_rc(u64 h) { return (h >> 32) & 1; }
+QM_DEV int selh_cs(u64 h) { return (int)((h >> 33) & 7); }
+QM_DEV int selh_np(u64 h) { return (int)((h >> 36) & 0xfff); }
+QM_DEV int selh_no(u64 h) { return (int)((h >> 48) & 0xfff); }
+
+// fastapprox's fastlog2 as used by the chain score (HitManager.cpp:33-42)
+QM_DEV float sel_fastlog2(float x) {
+#pragma clang fp contract(off)
+  union { float f; u32 i; } vx = { x };
+  union { u32 i; float f; } mx = { (vx.i & 0x007FFFFF) | 0x3f000000 };
+  float y = (float)vx.i;
+  y *= 1.1920928955078125e-7f;
+  return y - 124.22551499f - 1.498030302f * mx.f - 1.72587999f / (0.3520887068f + mx.f);
+}
+
+// stable merge sort of r[0..n) (scratch t), by `less`
+template <typename Less>
+QM_DEV void sel_sort(SelRec* r, SelRec* t, int n, Less less) {
+  for (int w = 1; w < n; w <<= 1) {
+    for (int lo = 0; lo < n; lo += 2 * w) {
+      int mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n;
+      int i = lo, j = mid, o = lo;
+      while (i < mid && j < hi) t[o++] = less(r[j], r[i]) ? r[j++] : r[i++];
+      while (i < mid) t[o++] = r[i++];
+      while (j < hi) t[o++] = r[j++];
+    }
+    for (int i = 0; i < n; ++i) r[i] = t[i];
+  }
+}
+
+// One strand: S.rec[0..n) holds every (tid, pos, qpos, len, interval) of the strand's m intervals.  Lane-0 code.
+QM_DEV void sel_strand(SelScratch& S, int s, int n, int m, u32 readLen, int mate, float consensusFraction) {
+#pragma clang fp contract(off)
+  int ng = 0, np = 0;
+  SelGroup* G = S.grp[s]; int* P = S.pos[s];
+  if (m == 1) {
+    // collectFromSingleInterval + mergeUnique (HitManager.cpp:716-807): hitPos = pos - queryPos, sorted by (tid, hitPos)
+    sel_sort(S.rec, S.tmp, n, [](const SelRec& a, const SelRec& b) {
+      return a.tid != b.tid ? a.tid < b.tid : (int)(a.pos - a.qpos) < (int)(b.pos - b.qpos); });
+    for (int i = 0; i < n; ++i) {
+      const SelRec& r = S.rec[i];
+      if (ng == 0 || G[ng - 1].tid != r.tid) {
+        SelGroup g; g.tid = r.tid; g.cs = r.len == readLen ? QM_CS_PERFECT : QM_CS_REGULAR; g.score = -1.7976931348623157e308; g.npos = 0; g.off = np;
+        g.ppos = (int)(r.pos - r.qpos);
+        G[ng++] = g;
+      }
+      P[np++] = (int)(r.pos - r.qpos); G[ng - 1].npos++;
+    }
+    S.ngrp[s] = ng; S.npos[s] = np;
+    return;
+  }
+  // intersectSAHits (HitManager.cpp:587-689): a transcript is kept when it occurs in at least requiredNumHits of the m
+  // intervals; with slack every occurrence is recorded, without it only transcripts present in ALL intervals survive,
+  // whose occurrences are then all recorded as well -- so both cases reduce to counting distinct intervals per transcript.
+  const float requiredFrac = (float)m * consensusFraction;
+  int requiredNumHits = m, maxSlack = 0;
+  if (consensusFraction < 1.0) {
+    int fl = (int)requiredFrac;                          // floor of a non-negative float
+    requiredNumHits = fl > 1 ? fl : 1;
+    maxSlack = m - requiredNumHits;
+  }
+  // chain order within a transcript: by reference end, then query end (HitManager.cpp:129-139); then group by transcript
+  sel_sort(S.rec, S.tmp, n, [](const SelRec& a, const SelRec& b) {
+    u32 r1 = a.pos + a.len, r2 = b.pos + b.len, q1 = a.qpos + a.len, q2 = b.qpos + b.len;
+    return (r1 < r2) ? true : ((r2 < r1) ? false : (q1 < q2)); });
+  sel_sort(S.rec, S.tmp, n, [](const SelRec& a, const SelRec& b) { return a.tid < b.tid; });
+  // first pass: is any transcript active?
+  bool anyActive = false;
+  for (int g0 = 0; g0 < n;) {
+    int g1 = g0; u64 mk[QM_SEL_MAXIV / 64] = {0, 0, 0, 0};
+    while (g1 < n && S.rec[g1].tid == S.rec[g0].tid) { mk[S.rec[g1].iv >> 6] |= 1ULL << (S.rec[g1].iv & 63); ++g1; }
+    int na = popc64(mk[0]) + popc64(mk[1]) + popc64(mk[2]) + popc64(mk[3]);
+    S.seen[g0] = na;                                   // parked: #intervals of the group starting at g0
+    if (na >= requiredNumHits) anyActive = true;
+    g0 = g1;
+  }
+  const bool allActive = maxSlack > 0 && !anyActive;   // :682-686
+  const int maxDist = (int)readLen;
+  for (int g0 = 0; g0 < n;) {
+    int g1 = g0;
+    while (g1 < n && S.rec[g1].tid == S.rec[g0].tid) ++g1;
+    const int na = S.seen[g0];
+    if (na >= requiredNumHits || allActive) {
+      // ---- collectHitsSimpleSA, chaining branch (HitManager.cpp:107-307)
+      const SelRec* H = S.rec + g0; const int hn = g1 - g0;
+      double* f = S.f; int* p = S.p;
+      double bestScore = -1.7976931348623157e308; int bestChainEnd = -1; int nEnds = 0;
+      const double avgseed = 31.0;
+      for (int i = 0; i < hn; ++i) {
+        const u32 qposi = H[i].qpos + H[i].len, rposi = H[i].pos + H[i].len;
+        p[i] = i; f[i] = (double)H[i].len;
+        int numRounds = 2;
+        for (int j = i - 1; j >= 0; --j) {
+          const u32 qposj = H[j].qpos + H[j].len, rposj = H[j].pos + H[j].len;
+          const int qdiff = (int)(qposi - qposj), rdiff = (int)(rposi - rposj);
+          // alpha
+          double score = (double)(int)H[i].len;
+          double mindiff = (qdiff < rdiff) ? (double)qdiff : (double)rdiff;
+          double alpha = (score < mindiff) ? score : mindiff;
+          // beta
+          double beta;
+          if (qdiff < 0 || ((qdiff > rdiff ? qdiff : rdiff) > maxDist)) beta = __builtin_inf();
+          else {
+            double l = (double)qdiff - (double)rdiff;
+            int al = (int)(l < 0 ? -l : l);
+            beta = (l == 0) ? 0.0 : (0.01 * avgseed * al + 0.5 * sel_fastlog2((float)al));
+          }
+          double extensionScore = f[j] + alpha - beta;
+          bool extendWithJ = extensionScore > f[i];
+          p[i] = extendWithJ ? j : p[i];
+          f[i] = extendWithJ ? extensionScore : f[i];
+          if (p[i] < i) { numRounds--; if (numRounds <= 0) break; }
+        }
+        if (f[i] > bestScore) { bestScore = f[i]; bestChainEnd = i; nEnds = 0; S.ends[nEnds++] = i; }
+        else if (f[i] == bestScore) S.ends[nEnds++] = i;
+      }
+      // multi-chain backtracking (:206-246)
+      for (int i = 0; i < hn; ++i) S.seen[g0 + i] = 0;
+      int* seen = S.seen + g0;
+      int numDistinctOpt = 0, nStarts = 0;
+      for (int e = 0; e < nEnds; ++e) {
+        int bestChainEndInd = S.ends[e];
+        bool validChain = true;
+        int lastPtr = p[bestChainEndInd];
+        while (lastPtr < bestChainEndInd) {
+          if (seen[bestChainEndInd]) { validChain = false; break; }
+          seen[bestChainEndInd] = 1;
+          bestChainEndInd = lastPtr;
+          lastPtr = p[bestChainEndInd];
+        }
+        if (seen[bestChainEndInd]) validChain = false;
+        if (validChain) { ++numDistinctOpt; S.starts[nStarts++] = lastPtr; }
+      }
+      if (nStarts > 0) {
+        SelGroup g; g.tid = H[0].tid; g.cs = QM_CS_REGULAR; g.score = bestScore; g.npos = nStarts; g.off = np;
+        g.ppos = (int)(H[S.starts[0]].pos - H[S.starts[0]].qpos);               // the first chain's start (:259-262)
+        for (int t = 0; t < nStarts; ++t) P[np + t] = (int)(H[S.starts[t]].pos - H[S.starts[t]].qpos);
+        for (int a = 1; a < nStarts; ++a) {                                      // allPositions is sorted (:272-276)
+          int v = P[np + a], b = a - 1;
+          while (b >= 0 && P[np + b] > v) { P[np + b + 1] = P[np + b]; --b; }
+          P[np + b + 1] = v;
+        }
+        if (hn > 1 && numDistinctOpt == 1 && bestChainEnd == hn - 1) {           // gapless chain (:283-305)
+          long long queryRange = (long long)(H[hn - 1].qpos + H[hn - 1].len) - (long long)H[0].qpos;
+          long long refRange = (long long)(H[hn - 1].pos + H[hn - 1].len) - (long long)H[0].pos;
+          if (queryRange == refRange && queryRange == (long long)readLen) g.cs = QM_CS_UNGAPPED;
+        }
+        np += nStarts;
+        G[ng++] = g;
+      }
+    }
+    (void)mate;
+    g0 = g1;
+  }
+  S.ngrp[s] = ng; S.npos[s] = np;
+}
+
+// mergeOrientationUnique (HitManager.cpp:834-881) of the two strands' groups, written as the read's list:
+//   header, own position, nP positions of the surviving orientation, nO of the other.  Returns the word count
+//   (-1: does not fit).  Lane-0 code.
+QM_DEV int sel_emit(SelScratch& S) {
+  int i = 0, j = 0, o = 0;
+  const int nf = S.ngrp[0], nr = S.ngrp[1];
+  while (i < nf || j < nr) {
+    const bool haveF = i < nf, haveR = j < nr;
+    const u32 tf = haveF ? S.grp[0][i].tid : 0xffffffffu, tr = haveR ? S.grp[1][j].tid : 0xffffffffu;
+    const SelGroup* pg; const SelGroup* og = nullptr; bool prc; int ps, os = 0;
+    if (haveF && (!haveR || tf < tr)) { pg = &S.grp[0][i]; prc = false; ps = 0; ++i; }
+    else if (haveR && (!haveF || tr < tf)) { pg = &S.grp[1][j]; prc = true; ps = 1; ++j; }
+    else {
+      // same transcript on both strands: the better chain score survives, forward on ties (stable inplace_merge)
+      const bool rcFirst = S.grp[1][j].score > S.grp[0][i].score;
+      if (rcFirst) { pg = &S.grp[1][j]; og = &S.grp[0][i]; prc = true; ps = 1; os = 0; }
+      else { pg = &S.grp[0][i]; og = &S.grp[1][j]; prc = false; ps = 0; os = 1; }
+      ++i; ++j;
+    }
+    const int nP = pg->npos, nO = og ? og->npos : 0;
+    if (nP > 0xfff || nO > 0xfff || o + 2 + nP + nO > QM_CHUNK) return -1;
+    S.out[o++] = sel_header(pg->tid, prc, pg->cs, nP, nO);
+    S.out[o++] = (u64)(u32)pg->ppos;
+    for (int t = 0; t < nP; ++t) S.out[o++] = (u64)(u32)S.pos[ps][pg->off + t];
+    for (int t = 0; t < nO; ++t) S.out[o++] = (u64)(u32)S.pos[os][og->off + t];
+  }
+  return o;
+}
+
+// Stage A, -s variant of hits_to_mappings: returns the number of list words in S.out (status bit 3 on overflow).
+QM_DEV int sel_hits_to_mappings(const DevIndex& ix, const ReadBatch& B, const IntervalList& fwdInts, const IntervalList& rcInts,
+                                u32 readLen, int mate, SelScratch& S) {
+  bool overflow = false;
+  for (int s = 0; s < 2; ++s) {
+    const IntervalList& L = s == 0 ? fwdInts : rcInts;
+    int n = 0;
+    if (L.n > QM_SEL_MAXIV) overflow = true;
+    for (int ii = 0; ii < L.n && !overflow; ++ii) {
+      int lb, ub; u32 ln, qp; L.get(ii, lb, ub, ln, qp);
+      const int cnt = ub - lb;
+      if (n + cnt > QM_SEL_CAP) { overflow = true; break; }
+      for (int base = 0; base < cnt; base += 64) {
+        QM_LANES(l) {
+          int i = base + l;
+          if (i < cnt) {
+            SaInfo e = ix.sainfo[lb + i];
+            SelRec r; r.tid = e.tid; r.pos = (u32)e.pos; r.qpos = qp; r.len = ln; r.iv = (u32)ii;
+            S.rec[n + i] = r;
+          }
+        }
+      }
+      n += cnt;
+    }
+    wave_fence();
+    if (!overflow) {
+      QM_LANES(l) { if (l == 0) { if (L.n > 0) sel_strand(S, s, n, L.n, readLen, mate, B.consensus_fraction); else { S.ngrp[s] = 0; S.npos[s] = 0; } } }
+    }
+    wave_fence();
+  }
+  if (overflow) { QM_LANES(l) { if (l == 0) *B.status |= 8; } return 0; }
+  LV<int> nw;
+  QM_LANES(l) { nw[l] = 0; if (l == 0) nw[l] = sel_emit(S); }
+  wave_fence();
+  int n = read_lane(nw, 0);
+  if (n < 0) { QM_LANES(l) { if (l == 0) *B.status |= 8; } return 0; }
+  return n;
+}
+
+// ------------------------------------------------------------------ stage B + C: one thread per unit
+#define QM_KSW_MAXLEN 288                                   // read (<= 256) + 20 extra target characters, rounded up
+#define QM_KSW_BYTES ((QM_KSW_MAXLEN / 16 * 6 + QM_KSW_MAXLEN / 16 + 2) * 16 + QM_KSW_MAXLEN * 4 + 2 * QM_KSW_MAXLEN)
+
+struct SelBatch {                    // launch arguments of the -s unit kernel (on top of PairBatch)
+  const unsigned char* seq1; const unsigned char* seq2;
+  const unsigned char* text; const int* txp_off; const int* txp_len;
+  qm_hit* tmp; const long long* toff;          // per-unit slots for jointHits before the filter
+  u64* tkeys; int* tsc;                        // alignment cache entries, two per slot (left / right)
+  unsigned char* ksw;                          // QM_KSW_BYTES per thread
+  int match, mismatch, gap_open, gap_extend, bandwidth, hard_filter, policy;
+  double min_score_fraction;
+};
+
+// ksw_extz2_sse41, score only, exact max, no z-drop (src/ksw2pp/ksw2_extz2_sse.c:18-304).  The SSE kernel works on
+// 16-byte vectors of int8 differences and also computes the lanes of a vector that lie outside the band; those
+// values are read back as neighbours when the band moves, so the byte layout (u v x y s sf qr in one zeroed block)
+// and every out-of-band lane are reproduced one byte at a time.  Returns max(mqe, mte).
+QM_DEV int sel_ksw_extz2(unsigned char* mem, int qlen, const unsigned char* query, int tlen, const unsigned char* target,
+                         const signed char* mat, int q, int e, int w) {
+  const int NEG = -0x40000000;
+  int mqe = NEG, mte = NEG;
+  const int m = 5;
+  if (qlen <= 0 || tlen <= 0) return NEG;
+  const int qe = q + e;
+  if (w < 0) w = tlen > qlen ? tlen : qlen;
+  const int tlen_ = (tlen + 15) / 16, qlen_ = (qlen + 15) / 16;
+  int min_sc = mat[1];
+  for (int t = 1; t < m * m; ++t) min_sc = min_sc < mat[t] ? min_sc : mat[t];
+  if (-min_sc > 2 * (q + e)) return NEG;
+  const int vecBytes = (tlen_ * 6 + qlen_ + 1) * 16 + 16;
+  for (int i = 0; i < vecBytes; ++i) mem[i] = 0;
+  unsigned char* u8 = mem; unsigned char* v8 = u8 + tlen_ * 16; unsigned char* x8 = v8 + tlen_ * 16; unsigned char* y8 = x8 + tlen_ * 16;
+  unsigned char* s8 = y8 + tlen_ * 16; unsigned char* sf = s8 + tlen_ * 16; unsigned char* qr = sf + tlen_ * 16;
+  int* H = (int*)(mem + ((vecBytes + 15) & ~15));
+  for (int t = 0; t < tlen_ * 16; ++t) H[t] = NEG;
+  for (int t = 0; t < qlen; ++t) qr[t] = query[qlen - 1 - t];
+  for (int t = 0; t < tlen; ++t) sf[t] = target[t];
+  const unsigned char sc_mch = (unsigned char)mat[0], sc_mis = (unsigned char)mat[1], sc_N = (unsigned char)mat[m * m - 1], m1 = (unsigned char)(m - 1);
+  const unsigned char qe2 = (unsigned char)((q + e) * 2), max_sc_v = (unsigned char)(mat[0] + (q + e) * 2), qv = (unsigned char)q;
+  int last_st = -1, last_en = -1;
+  for (int r = 0; r < qlen + tlen - 1; ++r) {
+    int st = 0, en = tlen - 1;
+    const unsigned char* qrr = qr + (qlen - 1 - r);
+    if (st < r - qlen + 1) st = r - qlen + 1;
+    if (en > r) en = r;
+    if (st < (r - w + 1) >> 1) st = (r - w + 1) >> 1;
+    if (en > (r + w) >> 1) en = (r + w) >> 1;
+    if (st > en) break;
+    const int st0 = st, en0 = en;
+    st = st / 16 * 16; en = (en + 16) / 16 * 16 - 1;
+    unsigned char x1, v1;
+    if (st > 0) {
+      if (st - 1 >= last_st && st - 1 <= last_en) { x1 = x8[st - 1]; v1 = v8[st - 1]; }
+      else { x1 = 0; v1 = 0; }
+    } else { x1 = 0; v1 = r ? qv : 0; }
+    if (en >= r) { y8[r] = 0; u8[r] = r ? qv : 0; }
+    for (int t = st0; t <= en0; t += 16)
+      for (int l = 0; l < 16; ++l) {
+        const unsigned char sq = sf[t + l], sv = qrr[t + l];
+        unsigned char tmp = (sq == sv) ? sc_mch : sc_mis;
+        if (sq == m1 || sv == m1) tmp = sc_N;
+        s8[t + l] = tmp;
+      }
+    for (int t = st; t <= en; ++t) {
+      unsigned char z = (unsigned char)(s8[t] + qe2);
+      const unsigned char xt1 = x1; x1 = x8[t];
+      const unsigned char vt1 = v1; v1 = v8[t];
+      unsigned char a = (unsigned char)(xt1 + vt1);
+      const unsigned char ut = u8[t];
+      unsigned char b = (unsigned char)(y8[t] + ut);
+      z = (unsigned char)((signed char)z > (signed char)a ? z : a);
+      z = z > b ? z : b;
+      z = z < max_sc_v ? z : max_sc_v;
+      u8[t] = (unsigned char)(z - vt1);
+      v8[t] = (unsigned char)(z - ut);
+      z = (unsigned char)(z - qv);
+      a = (unsigned char)(a - z); b = (unsigned char)(b - z);
+      x8[t] = (signed char)a > 0 ? a : 0;
+      y8[t] = (signed char)b > 0 ? b : 0;
+    }
+    if (r > 0) {
+      H[en0] = en0 > 0 ? H[en0 - 1] + u8[en0] - qe : H[en0] + v8[en0] - qe;
+      for (int t = st0; t < en0; ++t) H[t] += (int)v8[t] - qe;
+    } else H[0] = v8[0] - qe - qe;
+    if (en0 == tlen - 1 && H[en0] > mte) mte = H[en0];
+    if (r - st0 == qlen - 1 && H[st0] > mqe) mqe = H[st0];
+    last_st = st; last_en = en;
+  }
+  return mqe > mte ? mqe : mte;
+}
+
+QM_DEV unsigned char sel_nt4(unsigned char c) {               // seq_nt4_table_loc (KSW2Aligner.cpp:61-72)
+  switch (c) {
+    case 0: case 'A': case 'a': return 0; case 1: case 'C': case 'c': return 1;
+    case 2: case 'G': case 'g': return 2; case 3: case 'T': case 't': return 3; default: return 4;
+  }
+}
+
+struct SelCache { u64* keys; int* sc; int n; int stride; };   // entries of one side: keys[i*stride], sc[i*stride]
+
+// the read as the alignment sees it: forward, or reverseRead() of it (src/RapMapUtils.cpp:107-128)
+QM_DEV unsigned char sel_read_char(const unsigned char* r, int len, bool fwd, int i) { return fwd ? r[i] : rc_char(r[len - 1 - i]); }
+
+// selective_alignment::utils::getAlnScore (SelectiveAlignmentUtils.hpp:260-373)
+QM_DEV int sel_aln_score(const SelBatch& A, unsigned char* kmem, int pos, const unsigned char* read, int readLen, bool fwd,
+                         const unsigned char* tseq, int tlen, int maxScore, int chainStat, bool multiMapping, SelCache& C) {
+  if (chainStat == QM_CS_PERFECT) return maxScore;
+  const int LOWEST = (int)0x80000000;
+  int s = LOWEST;
+  int roff = 0, rlen = readLen;
+  const bool invalidStart = pos < 0;
+  const bool invalidEnd = pos + rlen >= tlen;
+  if (invalidStart) { roff = -pos; rlen += pos; pos = 0; }
+  if ((invalidStart || invalidEnd) && (A.policy == 1 || A.policy == 2)) return s;
+  if (pos < tlen) {
+    const bool doUngapped = !invalidStart && chainStat == QM_CS_UNGAPPED;
+    const u32 buf = doUngapped ? 0u : 20u;
+    const u32 lnobuf = (u32)(tlen - pos), lbuf = (u32)(rlen + (int)buf);
+    const bool useBuf = lbuf < lnobuf;
+    const u32 tlen1 = lbuf < lnobuf ? lbuf : lnobuf;
+    const unsigned char* tseq1 = tseq + pos;
+    const u32 keyLen = useBuf ? tlen1 - buf : tlen1;
+    u64 key = 0; bool didHash = false;
+    auto hashKey = [&]() {
+      u64 h = hash_mix((u64)keyLen + 0x9E3779B97F4A7C15ULL);
+      for (u32 i = 0; i < keyLen; i += 8) {
+        u64 w = 0;
+        for (u32 t = 0; t < 8 && i + t < keyLen; ++t) w |= (u64)tseq1[i + t] << (8 * t);
+        h = hash_mix(h ^ w);
+      }
+      return h;
+    };
+    if (C.n > 0) {
+      key = hashKey(); didHash = true;
+      for (int i = 0; i < C.n; ++i) if (C.keys[i * C.stride] == key) { s = C.sc[i * C.stride]; break; }
+    }
+    if (s == LOWEST) {
+      if (doUngapped) {
+        const int tlen1s = (int)tlen1;
+        const int alnLen = rlen < tlen1s ? rlen : tlen1s;
+        int sc = 0;
+        for (int i = 0; i < alnLen; ++i) {
+          unsigned char c1 = tseq1[i], c2 = sel_read_char(read, readLen, fwd, roff + i);
+          c1 = (c1 == 'N' || c2 == 'N') ? c2 : c1;
+          sc += (c1 == c2) ? A.match : A.mismatch;
+        }
+        s = sc;
+      } else {
+        // KSW2Aligner::operator()(…, EXTENSION): nt4-transform both strings, banded extension alignment
+        unsigned char* qb = kmem + QM_KSW_BYTES - 2 * QM_KSW_MAXLEN; unsigned char* tb = qb + QM_KSW_MAXLEN;
+        for (int i = 0; i < rlen; ++i) qb[i] = sel_nt4(sel_read_char(read, readLen, fwd, roff + i));
+        for (u32 i = 0; i < tlen1; ++i) tb[i] = sel_nt4(tseq1[i]);
+        signed char mat[25];
+        int a = (signed char)A.match, b = (signed char)A.mismatch;
+        a = a < 0 ? -a : a; b = b > 0 ? -b : b;
+        for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) mat[i * 5 + j] = (signed char)(i == j ? a : b); mat[i * 5 + 4] = 0; }
+        for (int j = 0; j < 5; ++j) mat[20 + j] = 0;
+        s = sel_ksw_extz2(kmem, rlen, qb, (int)tlen1, tb, mat, (signed char)A.gap_open, (signed char)A.gap_extend, A.bandwidth);
+      }
+      if (multiMapping) {
+        if (!didHash) key = hashKey();
+        C.keys[C.n * C.stride] = key; C.sc[C.n * C.stride] = s; C.n++;
+      }
+    }
+  }
+  return s;
+}
+
+// one list group as stage B sees it
+struct SelG { u32 tid; bool rc; int cs, np, no, ppos; const u64* P; const u64* O; int words; };
+QM_DEV SelG sel_group(const u64* X) {
+  SelG g; const u64 h = X[0];
+  g.tid = selh_tid(h); g.rc = selh_rc(h); g.cs = selh_cs(h); g.np = selh_np(h); g.no = selh_no(h);
+  g.ppos = (int)(u32)X[1]; g.P = X + 2; g.O = X + 2 + g.np; g.words = 2 + g.np + g.no;
+  return g;
+}
+// findBestHitFWRC (RapMapUtils.hpp:923-988) on two sorted position lists
+QM_DEV bool sel_best_fwrc(const u64* F, int nf, const u64* R, int nr, int fwdReadLen, int& oF, int& oR, int& oGap) {
+  if (nf == 0 || nr == 0) return false;
+  int bestGap = 0x7fffffff, bf = 0, br = 0;
+  for (int i = 0; i < nf; ++i) {
+    const int p1 = (int)(u32)F[i];
+    int lo = 0, hi = nr;                                   // lower_bound(R, p1)
+    while (lo < hi) { int mid = (lo + hi) >> 1; if ((int)(u32)R[mid] < p1) lo = mid + 1; else hi = mid; }
+    for (int t = 0; t < 2; ++t) {
+      int c;
+      if (lo == nr) { if (t) break; c = lo - 1; }
+      else if (lo == 0) { if (t) break; c = lo; }
+      else c = t == 0 ? lo : lo - 1;
+      const int rp = (int)(u32)R[c];
+      int gap = 0x7fffffff;
+      if (rp >= p1) { int d = rp - (p1 + fwdReadLen); gap = d < 0 ? -d : d; }
+      if (gap < bestGap) { bestGap = gap; bf = i; br = c; }
+    }
+  }
+  if (bestGap == 0x7fffffff) return false;
+  oF = (int)(u32)F[bf]; oR = (int)(u32)R[br]; oGap = bestGap;
+  return true;
+}
+
+// mergeLeftRightHitsFuzzy + the -s driver of one pair (RapMapSAMapper.cpp:461-701) / one single read (:225-320).
+// Writes the surviving hits to A.tmp + A.toff[u] (alignment scores in aln_score) and returns their number.
+QM_DEV int sel_unit(const PairBatch& P, const SelBatch& A, long long u, long long tid_global, UnitCounters* uc) {
+  const int maxHits = P.max_num_hits;
+  qm_hit* T = A.tmp + A.toff[u];
+  const int cap = (int)(A.toff[u + 1] - A.toff[u]);
+  u64* keys = A.tkeys + 2 * A.toff[u]; int* scs = A.tsc + 2 * A.toff[u];
+  unsigned char* kmem = A.ksw + (unsigned long long)tid_global * QM_KSW_BYTES;
+  const int LOWEST = (int)0x80000000;
+  int n = 0;
+  if (uc) uc->reads += 1;
+  const u32 l1 = (u32)(P.off1[u + 1] - P.off1[u]);
+  const unsigned char* r1 = A.seq1 + P.off1[u];
+  if (!P.paired) {
+    const int nw = (int)(P.lcnt[u] & 0x7fffffffu);
+    const u64* X = P.lists + P.loff[u];
+    int g = 0;
+    for (int i = 0; i < nw;) { SelG q = sel_group(X + i); i += q.words; ++g; }
+    if (uc) uc->tot += (u64)g;                           // counted before the maxNumHits clear (:240-245)
+    if (g <= maxHits) {
+      for (int i = 0; i < nw && n < cap;) {
+        SelG q = sel_group(X + i); i += q.words;
+        qm_hit h; h.tid = q.tid; h.pos = q.ppos; h.mate_pos = 0; h.frag_len = 0; h.read_len = l1; h.mate_len = 0;
+        h.fwd = q.rc ? 0 : 1; h.mate_is_fwd = 1; h.is_paired = 0; h.mate_status = 0; h.aln_score = q.cs;
+        T[n++] = h;
+      }
+    }
+    // selective alignment (:246-318)
+    SelCache C; C.keys = keys; C.sc = scs; C.n = 0; C.stride = 2;
+    int bestScore = LOWEST;
+    const int maxReadScore = A.match * (int)l1;
+    const bool multiMapping = n > 1;
+    for (int i = 0; i < n; ++i) {
+      qm_hit& h = T[i];
+      const int s = sel_aln_score(A, kmem, h.pos, r1, (int)l1, h.fwd != 0, A.text + A.txp_off[h.tid], A.txp_len[h.tid], maxReadScore,
+                                  h.aln_score, multiMapping, C);
+      const int score = ((double)s < A.min_score_fraction * (double)maxReadScore) ? LOWEST : s;
+      bestScore = score > bestScore ? score : bestScore;
+      h.aln_score = score;
+    }
+    int o = 0;
+    if (bestScore > LOWEST)
+      for (int i = 0; i < n; ++i) { const bool rem = A.hard_filter ? (T[i].aln_score < bestScore) : (T[i].aln_score == LOWEST); if (!rem) { if (o != i) T[o] = T[i]; ++o; } }
+    n = o;
+    if (uc && n > 0) uc->mapped += 1;
+    return n;
+  }
+  const u32 c0 = P.lcnt[2 * u], c1 = P.lcnt[2 * u + 1];
+  const int wl = (int)(c0 & 0x7fffffffu), wr = (int)(c1 & 0x7fffffffu);
+  const bool lh = (c0 >> 31) != 0, rh = (c1 >> 31) != 0;
+  const u64* LL = P.lists + P.loff[2 * u];
+  const u64* RR = P.lists + P.loff[2 * u + 1];
+  const u32 l2 = (u32)(P.off2[u + 1] - P.off2[u]);
+  const unsigned char* r2 = A.seq2 + P.off2[u];
+  auto orphan = [&](const SelG& q, u32 ln, int mateStatus) {
+    qm_hit h; h.tid = q.tid; h.pos = q.ppos; h.mate_pos = 0; h.frag_len = 0; h.read_len = ln; h.mate_len = 0;
+    h.fwd = q.rc ? 0 : 1; h.mate_is_fwd = 1; h.is_paired = 0; h.mate_status = (uint8_t)mateStatus;
+    h.aln_score = mateStatus == 1 ? q.cs : (q.cs << 4);   // chain status parked: left in bits 0-3, right in bits 4-7
+    return h;
+  };
+  bool tooMany = false;
+  if (wl == 0 || wr == 0) {
+    const int t = wl == 0 ? 1 : 0;
+    const bool otherMatched = wl == 0 ? lh : rh;
+    const u64* X = t == 0 ? LL : RR; const int nx = t == 0 ? wl : wr; const u32 ln = t == 0 ? l1 : l2;
+    if (!otherMatched && nx > 0) {
+      int g = 0;
+      for (int i = 0; i < nx;) { SelG q = sel_group(X + i); i += q.words; if (n < cap) T[n++] = orphan(q, ln, t == 0 ? 1 : 2); ++g; }
+      if (uc) { uc->se += (u64)g; uc->pe += (u64)g; }
+    }
+  } else {
+    int i = 0, j = 0, nm = 0;
+    while (i < wl && j < wr) {
+      SelG a = sel_group(LL + i), b = sel_group(RR + j);
+      if (a.tid < b.tid) { i += a.words; continue; }
+      if (b.tid < a.tid) { j += b.words; continue; }
+      // positions by strand (:991-996)
+      const u64* lF = a.rc ? a.O : a.P; const int nlF = a.rc ? a.no : a.np;
+      const u64* lR = a.rc ? a.P : a.O; const int nlR = a.rc ? a.np : a.no;
+      const u64* rF = b.rc ? b.O : b.P; const int nrF = b.rc ? b.no : b.np;
+      const u64* rR = b.rc ? b.P : b.O; const int nrR = b.rc ? b.np : b.no;
+      int f1 = 0, q1 = 0, g1 = 0x7fffffff, f2 = 0, q2 = 0, g2 = 0x7fffffff;
+      const bool fwrc = sel_best_fwrc(lF, nlF, rR, nrR, (int)l1, f1, q1, g1);
+      const bool rcfw = sel_best_fwrc(rF, nrF, lR, nlR, (int)l2, f2, q2, g2);
+      if (fwrc || rcfw) {
+        int leftPos = -1, rightPos = -1, bestGap = 0x7fffffff; bool leftFwd = false;
+        if (fwrc) { leftPos = f1; rightPos = q1; bestGap = g1; leftFwd = true; }
+        if (rcfw && g2 < bestGap) { leftPos = q2; rightPos = f2; leftFwd = false; }
+        const int s1 = leftPos > 0 ? leftPos : 0, s2 = rightPos > 0 ? rightPos : 0;
+        const bool r1First = s1 < s2;
+        const int fragStart = r1First ? s1 : s2;
+        const int fragEnd = r1First ? (int)((u32)s2 + l2) : (int)((u32)s1 + l1);
+        qm_hit h; h.tid = a.tid; h.pos = leftPos; h.mate_pos = rightPos; h.frag_len = (u32)(fragEnd - fragStart);
+        h.read_len = l1; h.mate_len = l2; h.fwd = leftFwd ? 1 : 0; h.mate_is_fwd = leftFwd ? 0 : 1;
+        h.is_paired = 1; h.mate_status = 3; h.aln_score = a.cs | (b.cs << 4);
+        ++nm;
+        if (nm > maxHits) { tooMany = true; break; }
+        if (n < cap) T[n++] = h;
+      }
+      i += a.words; j += b.words;
+    }
+    if (tooMany) { n = 0; if (uc) uc->tooMany += 1; }
+    if (uc && n > 0) uc->pe += (u64)n;
+  }
+  if (n > maxHits) n = 0;                                  // :534-536
+  if (n > 0 && P.no_orphans && T[0].mate_status != 3) n = 0;   // :539-551
+  if (n > 0) {                                             // :554-667
+    SelCache CL, CR;
+    CL.keys = keys; CL.sc = scs; CL.n = 0; CL.stride = 2;
+    CR.keys = keys + 1; CR.sc = scs + 1; CR.n = 0; CR.stride = 2;
+    int bestScore = LOWEST;
+    const int maxLeftScore = A.match * (int)l1, maxRightScore = A.match * (int)l2;
+    const bool multiMapping = n > 1;
+    for (int i = 0; i < n; ++i) {
+      qm_hit& h = T[i];
+      const int csL = h.aln_score & 15, csR = (h.aln_score >> 4) & 15;
+      const unsigned char* tseq = A.text + A.txp_off[h.tid];
+      const int tlen = A.txp_len[h.tid];
+      int score = LOWEST;
+      if (h.mate_status == 3) {
+        int s1 = sel_aln_score(A, kmem, h.pos, r1, (int)l1, h.fwd != 0, tseq, tlen, maxLeftScore, csL, multiMapping, CL);
+        int s2 = sel_aln_score(A, kmem, h.mate_pos, r2, (int)l2, h.mate_is_fwd != 0, tseq, tlen, maxRightScore, csR, multiMapping, CR);
+        if (h.fwd != h.mate_is_fwd && P.no_dovetail) {
+          if (h.fwd && h.pos > h.mate_pos) { s1 = LOWEST; s2 = LOWEST; }
+          else if (h.mate_is_fwd && h.mate_pos > h.pos) { s1 = LOWEST; s2 = LOWEST; }
+        }
+        if (((double)s1 < A.min_score_fraction * (double)maxLeftScore) || ((double)s2 < A.min_score_fraction * (double)maxRightScore)) score = LOWEST;
+        else score = s1 + s2;
+      } else if (h.mate_status == 1) {
+        const int s = sel_aln_score(A, kmem, h.pos, r1, (int)l1, h.fwd != 0, tseq, tlen, maxLeftScore, csL, multiMapping, CL);
+        score = ((double)s < A.min_score_fraction * (double)maxLeftScore) ? LOWEST : s;
+      } else {
+        const int s = sel_aln_score(A, kmem, h.pos, r2, (int)l2, h.fwd != 0, tseq, tlen, maxRightScore, csR, multiMapping, CR);
+        score = ((double)s < A.min_score_fraction * (double)maxRightScore) ? LOWEST : s;
+      }
+      bestScore = score > bestScore ? score : bestScore;
+      h.aln_score = score;
+    }
+    int o = 0;
+    if (bestScore > LOWEST)
+      for (int i = 0; i < n; ++i) { const bool rem = A.hard_filter ? (T[i].aln_score < bestScore) : (T[i].aln_score == LOWEST); if (!rem) { if (o != i) T[o] = T[i]; ++o; } }
+    n = o;
+  }
+  if (uc) { uc->tot += (u64)n; if (n > 0) uc->mapped += 1; }
+  return n;
+}

@@ -10,7 +10,8 @@ _LIB = os.path.join(_HERE, "libqm_emu.so")
 _SRC = [os.path.join(_HERE, "qm_emu.cpp"),
         os.path.join(_HERE, "../../rapmap_amd/csrc/qm_mapper.inl"),
         os.path.join(_HERE, "../../rapmap_amd/csrc/qm_wave.h"),
-        os.path.join(_HERE, "../../rapmap_amd/csrc/qm_phflat.h")]
+        os.path.join(_HERE, "../../rapmap_amd/csrc/qm_phflat.h"),
+        os.path.join(_HERE, "../../rapmap_amd/csrc/qm_sel.inl")]
 
 HIT_DTYPE = np.dtype([
     ("tid", "<u4"), ("pos", "<i4"), ("mate_pos", "<i4"), ("frag_len", "<u4"),
@@ -65,6 +66,8 @@ class Emu:
         self.cap = int(buckets) if buckets else int(self.lib.qe_slots_cap(ix.hkeys.size))
         self.slots = np.zeros(self.cap * 8 + 8, dtype=np.uint64)   # cap buckets of 64 bytes
         off = np.ascontiguousarray(ix.txpOffsets, dtype=np.int32)
+        self.txp_off = off
+        self.txp_len = np.ascontiguousarray(ix.txpLens, dtype=np.int32)
         hk = np.ascontiguousarray(ix.hkeys, dtype=np.uint64)
         hl = np.ascontiguousarray(ix.hlb, dtype=np.int32)
         hu = np.ascontiguousarray(ix.hub, dtype=np.int32)
@@ -116,7 +119,8 @@ class Emu:
                              C.c_void_p(seq2.ctypes.data if paired else None),
                              C.c_void_p(off2.ctypes.data if paired else None), C.c_int(ns), C.c_void_p(self.ph),
                              C.c_void_p(ho.ctypes.data), C.byref(hp), C.c_void_p(ctr.ctypes.data),
-                             C.c_void_p(io.ctypes.data), C.byref(ip), C.byref(st))
+                             C.c_void_p(io.ctypes.data), C.byref(ip), C.byref(st),
+                             C.c_void_p(self.txp_off.ctypes.data), C.c_void_p(self.txp_len.ctypes.data))
         assert rc == 0
         tot = int(ho[-1])
         hits = np.ctypeslib.as_array(C.cast(hp, C.POINTER(C.c_uint8)), shape=((tot + 1) * 32,))[: tot * 32].copy().view(HIT_DTYPE)

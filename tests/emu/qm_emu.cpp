@@ -25,7 +25,7 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
            const void* slots, unsigned long long hmask, const qm_opts* o, long long nunits,
            const unsigned char* seq1, const long long* off1, const unsigned char* seq2, const long long* off2,
            int ns, const void* ph, long long* hit_offsets, qm_hit** hits_out, unsigned long long* counters, long long* int_offsets,
-           qm_sa_interval_hit** ints_out, int* status_out) {
+           qm_sa_interval_hit** ints_out, int* status_out, const int* txp_off, const int* txp_len) {
   DevIndex ix; ix.text = text; ix.n = n; ix.SA = SA; ix.nSA = nSA; ix.sainfo = (const SaInfo*)sainfo;
   ix.slots = (const Bucket*)slots; ix.hmask = hmask; ix.k = k; ix.ph = (const PhIndex*)ph;
   const bool paired = seq2 != nullptr;
@@ -41,6 +41,12 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
   B.lcnt = lcnt.data(); B.loff = loff.data(); B.cursor = &cursor;
   B.gscratch = gs.data(); B.status = &status; B.dbg_ints = dints.data(); B.dbg_count = dcnt.data();
   B.strict_check = o->strict_check; B.max_interval = o->max_interval; B.quasi_cov = o->quasi_cov; B.sensitive = o->sensitive; B.fuzzy = (seq2 != nullptr) ? o->fuzzy : 0; B.max_mmp_ext = o->max_mmp_extension > 0 ? o->max_mmp_extension : 7;
+  static SelScratch* selscr = nullptr;
+  if (o->sel_aln && !selscr) selscr = new SelScratch();
+  {
+    float cs = (float)o->consensus_slack;                 // MappingOpts::consensusSlack is a float (RapMapSAMapper.cpp:138,184-185)
+    B.consensus_fraction = (cs == 0.0) ? 1.0 : (1.0 - cs);
+  }
   while (true) {
     lists.assign((size_t)cap, 0);
     B.lists = lists.data(); B.lists_cap = cap; cursor = 0; status = 0;
@@ -50,7 +56,7 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
     for (long long r = 0; r < nreads; ++r) {
       const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP) | (o->sel_aln ? QM_F_SEL : 0);
 #define QE_CALL(NS_, F_) { static WaveMem<NS_> M; ReadPre<NS_> pre; pre_offsets<NS_>(B, r, pre); pre_chars<NS_>(B, r, pre); \
-                           pre_offsets<NS_>(B, r + 7, pre); map_read<NS_, F_>(ix, B, r, pre, M, gs.data(), wa[r % 7]); }
+                           pre_offsets<NS_>(B, r + 7, pre); map_read<NS_, F_>(ix, B, r, pre, M, gs.data(), wa[r % 7], selscr); }
       if (ns == 2) { switch (F) { case 0: QE_CALL(2, 0) break; case 1: QE_CALL(2, 1) break; case 2: QE_CALL(2, 2) break; case 3: QE_CALL(2, 3) break;
                                   case 4: QE_CALL(2, 4) break; case 5: QE_CALL(2, 5) break; case 6: QE_CALL(2, 6) break; default: QE_CALL(2, 7) break; } }
       else { switch (F) { case 0: QE_CALL(4, 0) break; case 1: QE_CALL(4, 1) break; case 2: QE_CALL(4, 2) break; case 3: QE_CALL(4, 3) break;
@@ -67,13 +73,35 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
   P.lists = lists.data(); P.cnt = hc.data(); P.offs = offs.data(); P.counters = ctr;
   P.max_num_hits = o->max_num_hits; P.no_orphans = o->no_orphans; P.no_dovetail = o->no_dovetail; P.fuzzy = o->fuzzy;
   UnitCounters uc = {0, 0, 0, 0, 0, 0};
+  qm_hit* out = nullptr;
+  if (o->sel_aln) {
+    // -s: stage B + C per unit into per-unit temp slots, then compaction (qm_sel.inl)
+    std::vector<long long> toff(nunits + 1, 0);
+    for (long long u = 0; u < nunits; ++u) {
+      long long w = paired ? (long long)(lcnt[2 * u] & 0x7fffffffu) + (lcnt[2 * u + 1] & 0x7fffffffu) : (long long)(lcnt[u] & 0x7fffffffu);
+      toff[u + 1] = toff[u] + w / 3 + 1;
+    }
+    std::vector<qm_hit> tmp((size_t)toff[nunits] + 1); std::vector<u64> tkeys(2 * (size_t)toff[nunits] + 2); std::vector<int> tsc(2 * (size_t)toff[nunits] + 2);
+    std::vector<unsigned char> ksw(QM_KSW_BYTES);
+    SelBatch A; memset(&A, 0, sizeof(A));
+    A.seq1 = seq1; A.seq2 = seq2; A.text = text; A.txp_off = txp_off; A.txp_len = txp_len; A.tmp = tmp.data(); A.toff = toff.data();
+    A.tkeys = tkeys.data(); A.tsc = tsc.data(); A.ksw = ksw.data();
+    A.match = o->match_score; A.mismatch = o->mismatch_penalty; A.gap_open = o->gap_open; A.gap_extend = o->gap_extend;
+    A.bandwidth = o->dp_bandwidth; A.hard_filter = o->hard_filter; A.policy = o->aln_policy; A.min_score_fraction = o->min_score_fraction;
+    for (long long u = 0; u < nunits; ++u) hc[u] = (u32)sel_unit(P, A, u, 0, &uc);
+    hit_offsets[0] = 0;
+    for (long long u = 0; u < nunits; ++u) hit_offsets[u + 1] = hit_offsets[u] + hc[u];
+    out = (qm_hit*)malloc(sizeof(qm_hit) * (size_t)(hit_offsets[nunits] + 1));
+    for (long long u = 0; u < nunits; ++u) for (u32 i = 0; i < hc[u]; ++i) out[hit_offsets[u] + i] = tmp[(size_t)toff[u] + i];
+  } else {
   for (long long u = 0; u < nunits; ++u) hc[u] = (u32)unit_merge(P, u, nullptr, 0, &uc);
   hit_offsets[0] = 0;
   for (long long u = 0; u < nunits; ++u) hit_offsets[u + 1] = hit_offsets[u] + hc[u];
   for (long long u = 0; u <= nunits; ++u) offs[u] = hit_offsets[u];
-  qm_hit* out = (qm_hit*)malloc(sizeof(qm_hit) * (size_t)(hit_offsets[nunits] + 1));
+  out = (qm_hit*)malloc(sizeof(qm_hit) * (size_t)(hit_offsets[nunits] + 1));
   P.hits = out;
   for (long long u = 0; u < nunits; ++u) if (hc[u]) unit_merge(P, u, out + offs[u], (int)hc[u], nullptr);
+  }
   *hits_out = out;
   counters[0] = uc.pe; counters[1] = uc.se; counters[2] = uc.tot; counters[3] = uc.reads;
   counters[4] = uc.tooMany; counters[5] = uc.mapped;

@@ -62,5 +62,24 @@ def test_quasimap_cli_single_end_and_flags(sample_data, tmp_path, oracle_mod):
         sam.format_single(sample_data["names1"][i], sample_data["reads1"][i], res.hits[res.hit_offsets[i]:res.hit_offsets[i + 1]],
                           ix.names, ix.txpLens) for i in range(len(o) - 1))
     assert open(out).read() == want
-    r = _run(["quasimap", "-i", sample_data["idx"], "-r", os.path.join(SD, "reads_1.fastq.gz"), "-n", "-s"])
+    r = _run(["quasimap", "-i", sample_data["idx"], "-r", os.path.join(SD, "reads_1.fastq.gz"), "-n", "--recoverOrphans"])
     assert r.returncode != 0 and "not implemented" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant,flags", [("selAln", ["-s"]), ("selAln_hardFilter", ["-s", "--hardFilter"]), ("mimicBT2", ["--mimicBT2"])])
+def test_quasimap_cli_selective_alignment(sample_data, tmp_path, variant, flags):
+    """config 5 through the CLI == the reference's SAM (records incl. AS:i, SEQ column dropped in the fixture)"""
+    import gzip
+    out = tmp_path / "s.sam"
+    r = _run(["quasimap", "-i", sample_data["idx"], "-1", os.path.join(SD, "reads_1.fastq.gz"), "-2",
+              os.path.join(SD, "reads_2.fastq.gz"), "-o", str(out), "-q"] + flags)
+    assert r.returncode == 0, r.stderr
+    got = []
+    for l in open(out):
+        if l[0] == "@":
+            continue
+        c = l.split("\t")
+        got.append("\t".join(c[:9] + c[10:]))
+    want = gzip.open(os.path.join(SD, "expected_%s.noseq.sam.gz" % variant), "rt").read()
+    assert "".join(got) == want

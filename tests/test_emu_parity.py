@@ -206,3 +206,43 @@ def test_selective_alignment_collector_intervals(synth_small, oracle_mod):
             res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(selAln=1, maxMMPExtension=ext), nthreads=4, want_ints=True)
             er = em.map(q1, o1, q2, o2, opts=emu.default_opts(sel_aln=1, max_mmp_extension=ext))
             _cmp_ints(res, er)
+
+
+SEL_VARIANTS = [
+    ("reads", dict(selAln=1), dict(sel_aln=1)),
+    ("indel", dict(selAln=1), dict(sel_aln=1)),
+    ("reads", dict(selAln=1, hardFilter=1), dict(sel_aln=1, hard_filter=1)),
+    ("indel", dict(selAln=1, maxMMPExtension=3, minScoreFraction=0.9), dict(sel_aln=1, max_mmp_extension=3, min_score_fraction=0.9)),
+    ("reads", dict(selAln=1, noOrphans=1, noDovetail=1, consensusSlack=0.35, maxNumHits=1000, alnPolicy=1),
+     dict(sel_aln=1, no_orphans=1, no_dovetail=1, consensus_slack=0.35, max_num_hits=1000, aln_policy=1)),          # --mimicBT2
+    ("indel", dict(selAln=1, consensusSlack=0.0, gapOpen=6, gapExtend=3, mismatchPenalty=-6, matchScore=3, dpBandwidth=5),
+     dict(sel_aln=1, consensus_slack=0.0, gap_open=6, gap_extend=3, mismatch_penalty=-6, match_score=3, dp_bandwidth=5)),
+]
+
+
+def sel_reads(synth_small, which):
+    from conftest import GOLD
+    from rapmap_amd import sam
+    if which == "reads":
+        return synth_small["reads1"], synth_small["reads2"]
+    nx = os.path.join(GOLD, "synth_small", "next")
+    return sam.read_fastq(os.path.join(nx, "reads_indel_1.fastq.gz"))[1], sam.read_fastq(os.path.join(nx, "reads_indel_2.fastq.gz"))[1]
+
+
+@pytest.mark.parametrize("case", range(len(SEL_VARIANTS)))
+def test_selective_alignment(synth_small, oracle_mod, case):
+    """-s end to end in the device source: chaining + multi-position lists (stage A), position-list fuzzy merge, ksw2
+    extension alignment, score gate and filter (stage B + C); hits incl. alignment scores and counters == oracle"""
+    which, oo, eo = SEL_VARIANTS[case]
+    ix, orc, em, emu = _emu(synth_small["idx"])
+    s1, s2 = sel_reads(synth_small, which)
+    q1, o1 = pack(s1); q2, o2 = pack(s2)
+    res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=4)
+    er = em.map(q1, o1, q2, o2, opts=emu.default_opts(**eo))
+    assert er.status == 0
+    assert_hits_equal(res.hit_offsets, res.hits, er.hit_offsets, er.hits, "selAln %s" % oo)
+    assert res.counters == er.counters
+    rs = orc.map_single(q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=4)
+    es = em.map(q2, o2, opts=emu.default_opts(**eo))
+    assert_hits_equal(rs.hit_offsets, rs.hits, es.hit_offsets, es.hits, "selAln single-end %s" % oo)
+    assert rs.counters == es.counters

@@ -139,10 +139,6 @@ def test_edge_batches(synth_small, oracle_mod):
     q1, o1 = pack([b"A" * 300]); q2, o2 = pack([b"C" * 10])
     with pytest.raises(ra.QmError, match="read length"):
         mp.map_pairs(q1, o1, q2, o2)
-    q1, o1 = pack([b"ACGT" * 20]); q2, o2 = pack([b"ACGT" * 20])
-    for kw in ({"sel_aln": 1},):
-        with pytest.raises(ra.QmError, match="not implemented"):
-            mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(**kw))
 
 
 def test_medium_full_parity_and_properties(synth_medium, oracle_mod):
@@ -238,3 +234,37 @@ def test_perfect_hash_index(synth_small, synth_small_ph, oracle_mod):
         g2 = mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(**go))
         assert_hits_equal(r2.hit_offsets, r2.hits, g2.hit_offsets, g2.hits, "perfect-hash %s" % oo)
         assert r2.counters == g2.counters
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_selective_alignment(synth_small, oracle_mod, case):
+    """config 5 (-s) through the C ABI: hits incl. alignment scores and counters == oracle, paired and single-end"""
+    import rapmap_amd as ra
+    from test_emu_parity import SEL_VARIANTS, sel_reads
+    which, oo, go = SEL_VARIANTS[case]
+    ix, orc = load_oracle(synth_small["idx"])
+    qi, mp = _gpu(synth_small["idx"], debug=False)
+    s1, s2 = sel_reads(synth_small, which)
+    q1, o1 = pack(s1); q2, o2 = pack(s2)
+    res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=4)
+    gr = mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(**go))
+    assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "selAln %s" % oo)
+    assert res.counters == gr.counters
+    rs = orc.map_single(q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=4)
+    gs = mp.map_reads(q2, o2, opts=ra.default_opts(**go))
+    assert_hits_equal(rs.hit_offsets, rs.hits, gs.hit_offsets, gs.hits, "selAln single-end %s" % oo)
+    assert rs.counters == gs.counters
+
+
+def test_selective_alignment_medium(synth_medium, oracle_mod):
+    """-s on 20 k pairs against the ~5 k-transcript index"""
+    import rapmap_amd as ra
+    ix, orc = load_oracle(synth_medium["idx"])
+    qi, mp = _gpu(synth_medium["idx"], debug=False)
+    n = 20000
+    o = synth_medium["off"][: n + 1]
+    q1 = synth_medium["seq1"][: o[-1]]; q2 = synth_medium["seq2"][: o[-1]]
+    res = orc.map_pairs(q1, o, q2, o, opts=oracle_mod.default_opts(selAln=1), nthreads=8)
+    gr = mp.map_pairs(q1, o, q2, o, opts=ra.default_opts(sel_aln=1))
+    assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "selAln medium")
+    assert res.counters == gr.counters
