@@ -33,7 +33,7 @@ def test_defaults_match_reference_cli(lib_built):
 def test_struct_sizes(lib_built):
     import rapmap_amd as ra
     assert ra.HIT_DTYPE.itemsize == 32 and ra.INTERVAL_DTYPE.itemsize == 20
-    assert C.sizeof(ra.QmOpts) == 40
+    assert C.sizeof(ra.QmOpts) == 88      # 8 x i32 + f64 + 8 x i32 + 2 x f64
 
 
 def test_index_open_errors(lib_built, tmp_path):
