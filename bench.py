@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=10_000_000, help="read pairs per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sel-aln", action="store_true", help="config 5: selective alignment (-s): chaining + ksw2 extension alignment of every hit")
     ap.add_argument("--perfect-hash", action="store_true", help="config 4: index built with `quasiindex -p` (BooPHF / FrugalBooMap probe path)")
     ap.add_argument("--cache", default=os.environ.get("QMAP_BENCH_CACHE", "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"))
     args = ap.parse_args()
@@ -152,7 +153,8 @@ def main():
     del text
     torch.cuda.synchronize()
     n = args.pairs
-    opts = ra.default_opts()
+    opts = ra.default_opts(sel_aln=1) if args.sel_aln else ra.default_opts()
+    oopts_kw = {"selAln": 1} if args.sel_aln else {}
     ptr = (s1.data_ptr(), off.data_ptr(), s2.data_ptr(), off.data_ptr())
 
     def step():
@@ -190,10 +192,11 @@ def main():
             "unit": "M read-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/int32/u64 (integer & byte work, no floating point)", "data": "synthetic",
-            "config": {"workload": "configs[%d]: GENCODE-like synthetic index (%d genes -> %d transcripts, %d text bytes, "
-                                   "%d 31-mers), %d pairs 2x%d bp per GPU per step, 1%% substitutions, hits only (no -s), "
-                                   "%s index" % (3 if args.perfect_hash else 1, args.genes, qi.n_txps, qi.text_len, qi.n_keys, n, L,
-                                                 "perfect-hash (-p)" if args.perfect_hash else "dense hash"),
+            "config": {"workload": ("configs[%d]: GENCODE-like synthetic index (%d genes -> %d transcripts, %d text bytes, "
+                                    "%d 31-mers), %d pairs 2x%d bp per GPU per step, 1%% substitutions, %s, %s index") % (
+                                        4 if args.sel_aln else (3 if args.perfect_hash else 1), args.genes, qi.n_txps, qi.text_len, qi.n_keys, n, L,
+                                        "selective alignment (-s)" if args.sel_aln else "hits only (no -s)",
+                                        "perfect-hash (-p)" if args.perfect_hash else "dense hash"),
                        "pairs_per_gpu_per_step": n, "parallelism": "shard%d (index replicated, counters all-reduced)" % world,
                        "hits_per_pair": round(tot["totHits"] / max(1, tot["numReads"]), 4),
                        "mreads_per_s": round(2 * value, 4)},
@@ -212,11 +215,12 @@ def main():
         cores = os.cpu_count() or 1
         probe_n = min(n, 20000)
         h1 = s1[: probe_n * L].cpu().numpy(); h2 = s2[: probe_n * L].cpu().numpy(); ho = off[: probe_n + 1].cpu().numpy()
-        t = time.perf_counter(); orc.map_pairs(h1, ho, h2, ho, nthreads=cores); dt = time.perf_counter() - t
+        oopts = oracle.default_opts(**oopts_kw)
+        t = time.perf_counter(); orc.map_pairs(h1, ho, h2, ho, opts=oopts, nthreads=cores); dt = time.perf_counter() - t
         rate = probe_n / dt
         sample = int(min(n, max(probe_n, rate * args.cpu_seconds)))
         h1 = s1[: sample * L].cpu().numpy(); h2 = s2[: sample * L].cpu().numpy(); ho = off[: sample + 1].cpu().numpy()
-        t = time.perf_counter(); ores = orc.map_pairs(h1, ho, h2, ho, nthreads=cores); dt = time.perf_counter() - t
+        t = time.perf_counter(); ores = orc.map_pairs(h1, ho, h2, ho, opts=oopts, nthreads=cores); dt = time.perf_counter() - t
         cpu_val = sample / dt / 1e6
         # parity of the HIP path on exactly this sample
         gr = mp.map_device(sample, ptr[0], ptr[1], ptr[2], ptr[3], L, opts=opts, fetch=True)
@@ -232,16 +236,20 @@ def main():
         if os.path.exists(pf):
             try:
                 ent = json.load(open(pf)).get("perfect_hash" if args.perfect_hash else "dense") or {}
-                traffic = ent.get("hbm_bytes_per_launch") if n == 10_000_000 and args.genes == 40000 else None
+                traffic = ent.get("hbm_bytes_per_launch") if n == 10_000_000 and args.genes == 40000 and not args.sel_aln else None
             except Exception:
                 traffic = None
         out["roofline"] = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                           "kernel": "%s (stage A: one wavefront per read)" % ("qm_read_kernel<2,4,1>" if args.perfect_hash else "qm_read_kernel<2,5,0>"),
+                           "kernel": "%s (stage A: one wavefront per read)" % ("qm_read_kernel<2,3,4>" if args.sel_aln else ("qm_read_kernel<2,4,1>" if args.perfect_hash else "qm_read_kernel<2,5,0>")),
                            "kernel_ms": round(avg_kernel_ms, 3),
                            "algorithmic_bytes_per_pair": round(bpp, 1),
                            "per_pair_counters": {kk: round(v, 2) for kk, v in w.items()},
                            "pairs_per_launch": n}
+        if args.sel_aln:   # with -s report the DP cells separately
+            out["roofline"]["dp"] = {"alignments_per_pair": round(w.get("n_aln", 0), 3), "band_cells_per_pair": round(w.get("n_cells", 0), 1),
+                                     "G_cell_updates_per_s": round(w.get("n_cells", 0) * value * 1e6 / 1e9, 2),
+                                     "note": "ksw2 extension alignments that were actually run (cache misses, neither PERFECT nor UNGAPPED chains)"}
         out["speedup_vs_cpu_baseline"] = round(value / cpu_val, 2) if cpu_val > 0 else None
         try:   # the per-pair counters are a property of the input distribution: keep them for the N>1 runs
             json.dump({"bpp": bpp, "counters": w}, open(os.path.join(idx_dir, "algorithmic_bytes.json"), "w"))
@@ -252,7 +260,7 @@ def main():
         # per pair of this workload: recorded by an N=1 run on this box, else the committed figure of the default workload.
         out["cpu_baseline"] = None
         out["roofline"] = None
-        default_workload = n == 10_000_000 and args.genes == 40000 and L == 100 and not args.perfect_hash
+        default_workload = n == 10_000_000 and args.genes == 40000 and L == 100 and not args.perfect_hash and not args.sel_aln
         rec = None
         cands = [os.path.join(idx_dir, "algorithmic_bytes.json")]
         if default_workload:

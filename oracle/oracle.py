@@ -139,7 +139,7 @@ class Oracle:
             assert len(off2) - 1 == n
         hit_off = np.zeros(n + 1, dtype=np.int64)
         counters = np.zeros(6, dtype=np.uint64)
-        work = np.zeros(5, dtype=np.uint64)
+        work = np.zeros(8, dtype=np.uint64)
         hits_p = C.c_void_p()
         ints_off = np.zeros(n + 1, dtype=np.int64)
         ints_p = C.c_void_p()
@@ -157,7 +157,7 @@ class Oracle:
         r.hit_offsets, r.hits = hit_off, hits
         r.counters = dict(zip(["peHits", "seHits", "totHits", "numReads", "tooManyHits", "mappedUnits"],
                               [int(x) for x in counters]))
-        r.work = dict(zip(["n_probe", "n_sa", "n_text", "n_rank", "n_hits"], [int(x) for x in work]))
+        r.work = dict(zip(["n_probe", "n_sa", "n_text", "n_rank", "n_hits", "n_aln", "n_cells", "n_ungapped"], [int(x) for x in work]))
         if want_ints:
             tot = int(ints_off[-1])
             a = np.ctypeslib.as_array(C.cast(ints_p, C.POINTER(C.c_int32)), shape=(max(tot, 1) * 6,))

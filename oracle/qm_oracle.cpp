@@ -49,9 +49,12 @@ struct Work {
   uint64_t n_text = 0;   // text bytes compared
   uint64_t n_rank = 0;   // rank / transcriptAtPosition calls
   uint64_t n_hits = 0;   // final hits written
+  uint64_t n_aln = 0;    // -s: ksw2 extension alignments run (cache misses that are not PERFECT / UNGAPPED)
+  uint64_t n_cells = 0;  // -s: DP cells inside the band of those alignments
+  uint64_t n_ungapped = 0;  // -s: characters compared by the ungapped shortcut
   void add(const Work& o) {
     n_probe += o.n_probe; n_sa += o.n_sa; n_text += o.n_text;
-    n_rank += o.n_rank; n_hits += o.n_hits;
+    n_rank += o.n_rank; n_hits += o.n_hits; n_aln += o.n_aln; n_cells += o.n_cells; n_ungapped += o.n_ungapped;
   }
 };
 
@@ -991,7 +994,7 @@ static void mergeLeftRightHitsFuzzy(bool leftMatches, bool rightMatches, std::ve
 // the band moves, so the byte-level layout and every out-of-band lane are reproduced here one byte at a time.
 struct KswOut { int32_t mqe, mte; };
 static KswOut kswExtz2(int qlen, const uint8_t* query, int tlen, const uint8_t* target, int8_t m, const int8_t* mat,
-                       int8_t q, int8_t e, int w) {
+                       int8_t q, int8_t e, int w, uint64_t* cells) {
   KswOut ez{-0x40000000, -0x40000000};
   if (m <= 0 || qlen <= 0 || tlen <= 0) return ez;
   const int qe = q + e;
@@ -1020,6 +1023,7 @@ static KswOut kswExtz2(int qlen, const uint8_t* query, int tlen, const uint8_t* 
     if (en > (r + wl) >> 1) en = (r + wl) >> 1;
     if (st > en) break;                                                // zdropped
     const int st0 = st, en0 = en;
+    if (cells) *cells += (uint64_t)(en0 - st0 + 1);
     st = st / 16 * 16; en = (en + 16) / 16 * 16 - 1;
     uint8_t x1, v1;
     if (st > 0) {
@@ -1066,6 +1070,7 @@ static KswOut kswExtz2(int qlen, const uint8_t* query, int tlen, const uint8_t* 
 struct Aligner {                                                       // KSW2Aligner as configured at RapMapSAMapper.cpp:420-436
   int8_t mat[25]; int8_t q, e; int w;
   std::vector<uint8_t> qbuf, tbuf;
+  Work* wk = nullptr;
   Aligner(int a, int b, int gapo, int gape, int bw) : q((int8_t)gapo), e((int8_t)gape), w(bw) {
     a = (int8_t)a; b = (int8_t)b;                                      // KSW2Aligner(int8_t match, int8_t mismatch)
     a = a < 0 ? -a : a; b = b > 0 ? -b : b;
@@ -1083,7 +1088,8 @@ struct Aligner {                                                       // KSW2Al
     qbuf.resize((size_t)ql); tbuf.resize((size_t)tl);
     for (int i = 0; i < ql; ++i) qbuf[(size_t)i] = nt4((unsigned char)qs[i]);
     for (int i = 0; i < tl; ++i) tbuf[(size_t)i] = nt4((unsigned char)ts[i]);
-    KswOut ez = kswExtz2(ql, qbuf.data(), tl, tbuf.data(), 5, mat, q, e, w);
+    if (wk) ++wk->n_aln;
+    KswOut ez = kswExtz2(ql, qbuf.data(), tl, tbuf.data(), 5, mat, q, e, w, wk ? &wk->n_cells : nullptr);
     return std::max(ez.mqe, ez.mte);
   }
 };
@@ -1134,6 +1140,7 @@ static int32_t getAlnScore(Aligner& aligner, int32_t pos, const char* rptr, int3
         int32_t tlen1s = (int32_t)tlen1;
         int32_t alnLen = rlen < tlen1s ? rlen : tlen1s;
         s = ungappedAln(tseq1, rptr, alnLen);
+        if (aligner.wk) aligner.wk->n_ungapped += (uint64_t)alnLen;
       } else {
         s = aligner.extension(rptr, rlen, tseq1, (int)tlen1);
       }
@@ -1329,7 +1336,7 @@ void qo_index_destroy(void* h) { delete (OIndex*)h; }
 // seqX: concatenated read bytes; offX[n+1]: offsets.
 // Outputs: hit_offsets[n+1]; *hits_out = malloc'ed Hit array (free with qo_free);
 // counters[6] = {peHits, seHits, totHits, numReads, tooManyHits, mappedUnits};
-// work[5] = {n_probe, n_sa, n_text, n_rank, n_hits}.
+// work[8] = {n_probe, n_sa, n_text, n_rank, n_hits, n_aln, n_cells, n_ungapped}.
 // If ints_out != nullptr (pairs only): *ints_out = malloc'ed SA-interval records
 // {begin,end,len,queryPos,rc,list} as int32[6], list = 0..3 for
 // left-fwd,left-rc,right-fwd,right-rc, and ints_offsets[n+1].
@@ -1350,6 +1357,7 @@ int qo_map(void* hidx, const Opts* opts, int64_t n, const char* seq1, const int6
     Collector col(ix, *opts, wk[t]);
     const MapCfg mc = mapCfg(*opts);
     Aligner aligner(opts->matchScore, opts->mismatchPenalty, opts->gapOpen, opts->gapExtend, opts->dpBandwidth);
+    aligner.wk = &wk[t];
     std::vector<Hit> joint;
     std::vector<SAIntervalHit> dump[4];
     for (int64_t i = b; i < e; ++i) {
@@ -1394,6 +1402,7 @@ int qo_map(void* hidx, const Opts* opts, int64_t n, const char* seq1, const int6
   counters[0] = c.peHits; counters[1] = c.seHits; counters[2] = c.totHits; counters[3] = c.numReads;
   counters[4] = c.tooManyHits; counters[5] = c.mappedUnits;
   work[0] = w.n_probe; work[1] = w.n_sa; work[2] = w.n_text; work[3] = w.n_rank; work[4] = w.n_hits;
+  work[5] = w.n_aln; work[6] = w.n_cells; work[7] = w.n_ungapped;
   if (ints_out) {
     ints_offsets[0] = 0;
     for (int64_t i = 0; i < n; ++i) ints_offsets[i + 1] = ints_offsets[i] + icnt[i + 1];
