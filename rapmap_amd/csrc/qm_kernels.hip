@@ -86,11 +86,13 @@ __global__ __launch_bounds__(256) void qm_sel_slots_kernel(PairBatch P) {
 // -s stages B + C: one thread per unit (grid-stride: every thread owns a ksw2 work area)
 __global__ __launch_bounds__(64) void qm_sel_unit_kernel(PairBatch P, SelBatch A) {
   __shared__ unsigned long long sc[6];
+  __shared__ __attribute__((aligned(4))) unsigned char ring[64 * QM_KSW_RING_BYTES];   // ksw2 column rings, one per thread (708 B: odd word stride)
   if (threadIdx.x < 6) sc[threadIdx.x] = 0;
   __syncthreads();
   const long long tg = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
   UnitCounters uc = {0, 0, 0, 0, 0, 0};
-  for (long long u = tg; u < P.n; u += stride) P.cnt[u] = (u32)sel_unit(P, A, u, tg, &uc);
+  SelBatch At = A; At.ring = A.ring ? ring + threadIdx.x * QM_KSW_RING_BYTES : nullptr;   // host passes non-null to enable the LDS rings
+  for (long long u = tg; u < P.n; u += stride) P.cnt[u] = (u32)sel_unit(P, At, u, tg, &uc);
   if (uc.pe) atomicAdd(&sc[0], uc.pe);
   if (uc.se) atomicAdd(&sc[1], uc.se);
   if (uc.tot) atomicAdd(&sc[2], uc.tot);

@@ -267,6 +267,7 @@ struct SelBatch {                    // launch arguments of the -s unit kernel (
   qm_hit* tmp; const long long* toff;          // per-unit slots for jointHits before the filter
   u64* tkeys; int* tsc;                        // alignment cache entries, two per slot (left / right)
   unsigned char* ksw;                          // QM_KSW_BYTES per thread
+  unsigned char* ring;                         // this thread's QM_KSW_RING_BYTES (LDS on the device), or null
   int match, mismatch, gap_open, gap_extend, bandwidth, hard_filter, policy;
   double min_score_fraction;
 };
@@ -349,6 +350,94 @@ QM_DEV int sel_ksw_extz2(unsigned char* mem, int qlen, const unsigned char* quer
   return mqe > mte ? mqe : mte;
 }
 
+// The same kernel on a ring of 64 columns (for bands of at most 33): the columns a round touches lie within 47
+// of each other and the band only moves forward, so column t lives in slot t & 63 until column t + 64 needs the
+// slot; a tag tells which column a slot holds ("never computed" = the zero-initialised memory of the original).
+// 708 bytes per alignment instead of ~2.5 KB: small enough for LDS, one thread per alignment.
+#define QM_KSW_RING_BYTES 708
+struct KswRing {
+  unsigned char* u; unsigned char* v; unsigned char* x; unsigned char* y; unsigned char* s; short* tag; int* H;
+  QM_DEV void bind(unsigned char* m) { H = (int*)m; tag = (short*)(m + 256); u = m + 384; v = u + 64; x = v + 64; y = x + 64; s = y + 64; }
+  QM_DEV void touch(int t) {          // make slot t & 63 hold column t
+    const int k = t & 63;
+    if (tag[k] != (short)(t + 1)) { tag[k] = (short)(t + 1); u[k] = v[k] = x[k] = y[k] = s[k] = 0; H[k] = -0x40000000; }
+  }
+  QM_DEV bool has(int t) const { return tag[t & 63] == (short)(t + 1); }
+};
+QM_DEV int sel_ksw_extz2_ring(unsigned char* mem, int qlen, const unsigned char* query, int tlen, const unsigned char* target,
+                              const signed char* mat, int q, int e, int w) {
+  const int NEG = -0x40000000;
+  int mqe = NEG, mte = NEG;
+  const int m = 5;
+  if (qlen <= 0 || tlen <= 0) return NEG;
+  const int qe = q + e;
+  const int tlen16 = (tlen + 15) / 16 * 16;
+  int min_sc = mat[1];
+  for (int t = 1; t < m * m; ++t) min_sc = min_sc < mat[t] ? min_sc : mat[t];
+  if (-min_sc > 2 * (q + e)) return NEG;
+  KswRing R; R.bind(mem);
+  for (int i = 0; i < 64; ++i) R.tag[i] = 0;
+  // the original's memory image: sf = target padded with zeros to tlen16, directly followed by qr = reversed query + zeros
+  auto qrAt = [&](int i) -> unsigned char { return (i >= 0 && i < qlen) ? query[qlen - 1 - i] : 0; };
+  auto sfAt = [&](int i) -> unsigned char { return i < tlen ? target[i] : (i < tlen16 ? 0 : qrAt(i - tlen16)); };
+  auto qrrAt = [&](int i) -> unsigned char { return i >= 0 ? qrAt(i) : sfAt(tlen16 + i); };
+  const unsigned char sc_mch = (unsigned char)mat[0], sc_mis = (unsigned char)mat[1], sc_N = (unsigned char)mat[m * m - 1], m1 = (unsigned char)(m - 1);
+  const unsigned char qe2 = (unsigned char)((q + e) * 2), max_sc_v = (unsigned char)(mat[0] + (q + e) * 2), qv = (unsigned char)q;
+  int last_st = -1, last_en = -1;
+  for (int r = 0; r < qlen + tlen - 1; ++r) {
+    int st = 0, en = tlen - 1;
+    const int qoff = qlen - 1 - r;
+    if (st < r - qlen + 1) st = r - qlen + 1;
+    if (en > r) en = r;
+    if (st < (r - w + 1) >> 1) st = (r - w + 1) >> 1;
+    if (en > (r + w) >> 1) en = (r + w) >> 1;
+    if (st > en) break;
+    const int st0 = st, en0 = en;
+    st = st / 16 * 16; en = (en + 16) / 16 * 16 - 1;
+    unsigned char x1, v1;
+    if (st > 0) {
+      if (st - 1 >= last_st && st - 1 <= last_en && R.has(st - 1)) { x1 = R.x[(st - 1) & 63]; v1 = R.v[(st - 1) & 63]; }
+      else { x1 = 0; v1 = 0; }
+    } else { x1 = 0; v1 = r ? qv : 0; }
+    if (en >= r) { R.touch(r); R.y[r & 63] = 0; R.u[r & 63] = r ? qv : 0; }
+    for (int t = st0; t <= en0; t += 16)
+      for (int l = 0; l < 16; ++l) {
+        const unsigned char sq = sfAt(t + l), sv = qrrAt(qoff + t + l);
+        unsigned char tmp = (sq == sv) ? sc_mch : sc_mis;
+        if (sq == m1 || sv == m1) tmp = sc_N;
+        R.touch(t + l); R.s[(t + l) & 63] = tmp;
+      }
+    for (int t = st; t <= en; ++t) {
+      R.touch(t);
+      const int k = t & 63;
+      unsigned char z = (unsigned char)(R.s[k] + qe2);
+      const unsigned char xt1 = x1; x1 = R.x[k];
+      const unsigned char vt1 = v1; v1 = R.v[k];
+      unsigned char a = (unsigned char)(xt1 + vt1);
+      const unsigned char ut = R.u[k];
+      unsigned char b = (unsigned char)(R.y[k] + ut);
+      z = (unsigned char)((signed char)z > (signed char)a ? z : a);
+      z = z > b ? z : b;
+      z = z < max_sc_v ? z : max_sc_v;
+      R.u[k] = (unsigned char)(z - vt1);
+      R.v[k] = (unsigned char)(z - ut);
+      z = (unsigned char)(z - qv);
+      a = (unsigned char)(a - z); b = (unsigned char)(b - z);
+      R.x[k] = (signed char)a > 0 ? a : 0;
+      R.y[k] = (signed char)b > 0 ? b : 0;
+    }
+    if (r > 0) {
+      const int Hprev = en0 > 0 ? (R.has(en0 - 1) ? R.H[(en0 - 1) & 63] : NEG) : 0;
+      R.H[en0 & 63] = en0 > 0 ? Hprev + R.u[en0 & 63] - qe : R.H[en0 & 63] + R.v[en0 & 63] - qe;
+      for (int t = st0; t < en0; ++t) R.H[t & 63] += (int)R.v[t & 63] - qe;
+    } else R.H[0] = R.v[0] - qe - qe;
+    if (en0 == tlen - 1 && R.H[en0 & 63] > mte) mte = R.H[en0 & 63];
+    if (r - st0 == qlen - 1 && R.H[st0 & 63] > mqe) mqe = R.H[st0 & 63];
+    last_st = st; last_en = en;
+  }
+  return mqe > mte ? mqe : mte;
+}
+
 QM_DEV unsigned char sel_nt4(unsigned char c) {               // seq_nt4_table_loc (KSW2Aligner.cpp:61-72)
   switch (c) {
     case 0: case 'A': case 'a': return 0; case 1: case 'C': case 'c': return 1;
@@ -415,7 +504,10 @@ QM_DEV int sel_aln_score(const SelBatch& A, unsigned char* kmem, int pos, const 
         a = a < 0 ? -a : a; b = b > 0 ? -b : b;
         for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) mat[i * 5 + j] = (signed char)(i == j ? a : b); mat[i * 5 + 4] = 0; }
         for (int j = 0; j < 5; ++j) mat[20 + j] = 0;
-        s = sel_ksw_extz2(kmem, rlen, qb, (int)tlen1, tb, mat, (signed char)A.gap_open, (signed char)A.gap_extend, A.bandwidth);
+        if (A.bandwidth >= 0 && A.bandwidth <= 33 && A.ring)
+          s = sel_ksw_extz2_ring(A.ring, rlen, qb, (int)tlen1, tb, mat, (signed char)A.gap_open, (signed char)A.gap_extend, A.bandwidth);
+        else
+          s = sel_ksw_extz2(kmem, rlen, qb, (int)tlen1, tb, mat, (signed char)A.gap_open, (signed char)A.gap_extend, A.bandwidth);
       }
       if (multiMapping) {
         if (!didHash) key = hashKey();

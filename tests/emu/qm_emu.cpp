@@ -82,10 +82,10 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
       toff[u + 1] = toff[u] + w / 3 + 1;
     }
     std::vector<qm_hit> tmp((size_t)toff[nunits] + 1); std::vector<u64> tkeys(2 * (size_t)toff[nunits] + 2); std::vector<int> tsc(2 * (size_t)toff[nunits] + 2);
-    std::vector<unsigned char> ksw(QM_KSW_BYTES);
+    std::vector<unsigned char> ksw(QM_KSW_BYTES); std::vector<int> ringbuf(QM_KSW_RING_BYTES / 4 + 4);
     SelBatch A; memset(&A, 0, sizeof(A));
     A.seq1 = seq1; A.seq2 = seq2; A.text = text; A.txp_off = txp_off; A.txp_len = txp_len; A.tmp = tmp.data(); A.toff = toff.data();
-    A.tkeys = tkeys.data(); A.tsc = tsc.data(); A.ksw = ksw.data();
+    A.tkeys = tkeys.data(); A.tsc = tsc.data(); A.ksw = ksw.data(); A.ring = (unsigned char*)ringbuf.data();
     A.match = o->match_score; A.mismatch = o->mismatch_penalty; A.gap_open = o->gap_open; A.gap_extend = o->gap_extend;
     A.bandwidth = o->dp_bandwidth; A.hard_filter = o->hard_filter; A.policy = o->aln_policy; A.min_score_fraction = o->min_score_fraction;
     for (long long u = 0; u < nunits; ++u) hc[u] = (u32)sel_unit(P, A, u, 0, &uc);
