@@ -49,7 +49,7 @@ typedef struct qm_opts {
   int32_t no_dovetail;   /* --noDovetail                                                  */
   int32_t fuzzy;         /* -f  mergeLeftRightHitsFuzzy, include/RapMapUtils.hpp:864-1183   */
   int32_t max_interval;  /* SACollector::setMaxInterval, 1000 (SACollector.hpp:54,77)     */
-  int32_t sel_aln;       /* -s  selective alignment (not on the device path yet: QM_E_UNSUPPORTED) */
+  int32_t sel_aln;       /* -s  selective alignment (src/RapMapSAMapper.cpp:554-667)        */
   double quasi_cov;      /* -z  (SACollector::setCoverageRequirement)                     */
   /* sub-options of -s (src/RapMapSAMapper.cpp:1011-1023,1135-1175); read only when sel_aln != 0 */
   int32_t hard_filter;        /* --hardFilter                                             */

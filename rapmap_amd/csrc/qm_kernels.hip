@@ -17,11 +17,15 @@
 
 namespace qm {
 
+template <bool ON> struct SelLds { SelScratchLds s; QM_DEV SelScratchLds* ptr() { return &s; } };
+template <> struct SelLds<false> { QM_DEV SelScratchLds* ptr() { return nullptr; } };
+
 // stage A: one wavefront per read.  WPS = minimum waves per SIMD the register allocator must leave room for.
 // F: compile-time feature flags (QM_F_PH, QM_F_NIP) -- the default kernel carries no optional code.
 template <int NS, int WPS, int F>
 __global__ __launch_bounds__(256, WPS) void qm_read_kernel(DevIndex ix, ReadBatch B) {
   __shared__ WaveMem<NS> mem[4];
+  __shared__ SelLds<(F & QM_F_SEL) != 0> sels[4];       // -s kernels only: lane 0's chaining scratch
   // the wave index is wave-uniform: keep it (and every address derived from it) on the scalar unit
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long long gw = (long long)blockIdx.x * 4 + wave;
@@ -40,7 +44,7 @@ __global__ __launch_bounds__(256, WPS) void qm_read_kernel(DevIndex ix, ReadBatc
     nxt = cur;
     pre_chars<NS>(B, r + nw, nxt);
     pre_offsets<NS>(B, r + 2 * nw, nxt);
-    map_read<NS, F>(ix, B, r, cur, mem[wave], gscr, wa, (F & QM_F_SEL) ? B.selscr + gw : nullptr);
+    map_read<NS, F>(ix, B, r, cur, mem[wave], gscr, wa, (F & QM_F_SEL) ? B.selscr + gw : nullptr, sels[wave].ptr());
     cur = nxt;
   }
 #ifdef QM_TIMING

@@ -19,13 +19,18 @@ enum : int { QM_CS_PERFECT = 0, QM_CS_UNGAPPED = 1, QM_CS_REGULAR = 4 };   // ra
 
 struct SelRec { u32 tid, pos, qpos, len, iv; };
 struct SelGroup { u32 tid; int cs; double score; int npos, off, ppos; };   // ppos: the hit's own position (QuasiAlignment::pos)
-struct SelScratch {                 // per wave, global memory
-  SelRec rec[QM_SEL_CAP], tmp[QM_SEL_CAP];
-  double f[QM_SEL_CAP]; int p[QM_SEL_CAP]; int seen[QM_SEL_CAP]; int ends[QM_SEL_CAP]; int starts[QM_SEL_CAP];
-  SelGroup grp[2][QM_SEL_CAP]; int pos[2][QM_SEL_CAP]; int ngrp[2], npos[2];
-  u64 out[QM_CHUNK];
+template <int CAP, int OUTCAP>
+struct SelScratchT {                // lane 0's working set for one read
+  static constexpr int cap = CAP, outcap = OUTCAP;
+  SelRec rec[CAP], tmp[CAP];
+  double f[CAP]; int p[CAP]; int seen[CAP]; int ends[CAP]; int starts[CAP];
+  SelGroup grp[2][CAP]; int pos[2][CAP]; int ngrp[2], npos[2];
+  u64 out[OUTCAP];
 };
-
+struct SelScratch : SelScratchT<QM_SEL_CAP, QM_CHUNK> {};   // per wave, global memory: the general case
+#define QM_SEL_SMALL 48
+typedef SelScratchT<QM_SEL_SMALL, 6 * QM_SEL_SMALL> SelScratchLds;   // ~8 KB of LDS: almost every read fits, and lane 0's serial
+                                                                     // chaining then runs out of LDS instead of global memory
 QM_DEV const u64* sel_out(const SelScratch& S) { return S.out; }
 
 QM_DEV u64 sel_header(u32 tid, bool primaryRC, int cs, int nP, int nO) {
@@ -63,7 +68,8 @@ QM_DEV void sel_sort(SelRec* r, SelRec* t, int n, Less less) {
 }
 
 // One strand: S.rec[0..n) holds every (tid, pos, qpos, len, interval) of the strand's m intervals.  Lane-0 code.
-QM_DEV void sel_strand(SelScratch& S, int s, int n, int m, u32 readLen, int mate, float consensusFraction) {
+template <typename SS>
+QM_DEV void sel_strand(SS& S, int s, int n, int m, u32 readLen, int mate, float consensusFraction) {
 #pragma clang fp contract(off)
   int ng = 0, np = 0;
   SelGroup* G = S.grp[s]; int* P = S.pos[s];
@@ -192,7 +198,8 @@ QM_DEV void sel_strand(SelScratch& S, int s, int n, int m, u32 readLen, int mate
 // mergeOrientationUnique (HitManager.cpp:834-881) of the two strands' groups, written as the read's list:
 //   header, own position, nP positions of the surviving orientation, nO of the other.  Returns the word count
 //   (-1: does not fit).  Lane-0 code.
-QM_DEV int sel_emit(SelScratch& S) {
+template <typename SS>
+QM_DEV int sel_emit(SS& S) {
   int i = 0, j = 0, o = 0;
   const int nf = S.ngrp[0], nr = S.ngrp[1];
   while (i < nf || j < nr) {
@@ -209,7 +216,7 @@ QM_DEV int sel_emit(SelScratch& S) {
       ++i; ++j;
     }
     const int nP = pg->npos, nO = og ? og->npos : 0;
-    if (nP > 0xfff || nO > 0xfff || o + 2 + nP + nO > QM_CHUNK) return -1;
+    if (nP > 0xfff || nO > 0xfff || o + 2 + nP + nO > SS::outcap) return -1;
     S.out[o++] = sel_header(pg->tid, prc, pg->cs, nP, nO);
     S.out[o++] = (u64)(u32)pg->ppos;
     for (int t = 0; t < nP; ++t) S.out[o++] = (u64)(u32)S.pos[ps][pg->off + t];
@@ -218,18 +225,18 @@ QM_DEV int sel_emit(SelScratch& S) {
   return o;
 }
 
-// Stage A, -s variant of hits_to_mappings: returns the number of list words in S.out (status bit 3 on overflow).
-QM_DEV int sel_hits_to_mappings(const DevIndex& ix, const ReadBatch& B, const IntervalList& fwdInts, const IntervalList& rcInts,
-                                u32 readLen, int mate, SelScratch& S) {
-  bool overflow = false;
+// Stage A, -s variant of hits_to_mappings on scratch S: returns the number of list words in S.out, -1 when S is too small.
+template <typename SS>
+QM_DEV int sel_h2m_on(const DevIndex& ix, const ReadBatch& B, const IntervalList& fwdInts, const IntervalList& rcInts,
+                      u32 readLen, int mate, SS& S) {
   for (int s = 0; s < 2; ++s) {
     const IntervalList& L = s == 0 ? fwdInts : rcInts;
     int n = 0;
-    if (L.n > QM_SEL_MAXIV) overflow = true;
-    for (int ii = 0; ii < L.n && !overflow; ++ii) {
+    if (L.n > QM_SEL_MAXIV) return -1;
+    for (int ii = 0; ii < L.n; ++ii) {
       int lb, ub; u32 ln, qp; L.get(ii, lb, ub, ln, qp);
       const int cnt = ub - lb;
-      if (n + cnt > QM_SEL_CAP) { overflow = true; break; }
+      if (n + cnt > SS::cap) return -1;
       for (int base = 0; base < cnt; base += 64) {
         QM_LANES(l) {
           int i = base + l;
@@ -243,17 +250,22 @@ QM_DEV int sel_hits_to_mappings(const DevIndex& ix, const ReadBatch& B, const In
       n += cnt;
     }
     wave_fence();
-    if (!overflow) {
-      QM_LANES(l) { if (l == 0) { if (L.n > 0) sel_strand(S, s, n, L.n, readLen, mate, B.consensus_fraction); else { S.ngrp[s] = 0; S.npos[s] = 0; } } }
-    }
+    QM_LANES(l) { if (l == 0) { if (L.n > 0) sel_strand(S, s, n, L.n, readLen, mate, B.consensus_fraction); else { S.ngrp[s] = 0; S.npos[s] = 0; } } }
     wave_fence();
   }
-  if (overflow) { QM_LANES(l) { if (l == 0) *B.status |= 8; } return 0; }
   LV<int> nw;
   QM_LANES(l) { nw[l] = 0; if (l == 0) nw[l] = sel_emit(S); }
   wave_fence();
-  int n = read_lane(nw, 0);
-  if (n < 0) { QM_LANES(l) { if (l == 0) *B.status |= 8; } return 0; }
+  return read_lane(nw, 0);
+}
+
+// LDS scratch first (small reads: nearly all), the wave's global scratch otherwise; status bit 3 when even that overflows.
+QM_DEV int sel_hits_to_mappings(const DevIndex& ix, const ReadBatch& B, const IntervalList& fwdInts, const IntervalList& rcInts,
+                                u32 readLen, int mate, SelScratch& G, SelScratchLds* L, const u64*& src) {
+  int n = -1;
+  if (L) { n = sel_h2m_on(ix, B, fwdInts, rcInts, readLen, mate, *L); src = L->out; }
+  if (n < 0) { n = sel_h2m_on(ix, B, fwdInts, rcInts, readLen, mate, static_cast<SelScratchT<QM_SEL_CAP, QM_CHUNK>&>(G)); src = G.out; }
+  if (n < 0) { QM_LANES(l) { if (l == 0) *B.status |= 8; } n = 0; }
   return n;
 }
 

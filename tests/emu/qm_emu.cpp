@@ -41,6 +41,7 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
   B.lcnt = lcnt.data(); B.loff = loff.data(); B.cursor = &cursor;
   B.gscratch = gs.data(); B.status = &status; B.dbg_ints = dints.data(); B.dbg_count = dcnt.data();
   B.strict_check = o->strict_check; B.max_interval = o->max_interval; B.quasi_cov = o->quasi_cov; B.sensitive = o->sensitive; B.fuzzy = (seq2 != nullptr) ? o->fuzzy : 0; B.max_mmp_ext = o->max_mmp_extension > 0 ? o->max_mmp_extension : 7;
+  static SelScratchLds sellds;                            // used for half of the reads so that both scratch sizes are exercised
   static SelScratch* selscr = nullptr;
   if (o->sel_aln && !selscr) selscr = new SelScratch();
   {
@@ -56,7 +57,7 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
     for (long long r = 0; r < nreads; ++r) {
       const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP) | (o->sel_aln ? QM_F_SEL : 0);
 #define QE_CALL(NS_, F_) { static WaveMem<NS_> M; ReadPre<NS_> pre; pre_offsets<NS_>(B, r, pre); pre_chars<NS_>(B, r, pre); \
-                           pre_offsets<NS_>(B, r + 7, pre); map_read<NS_, F_>(ix, B, r, pre, M, gs.data(), wa[r % 7], selscr); }
+                           pre_offsets<NS_>(B, r + 7, pre); map_read<NS_, F_>(ix, B, r, pre, M, gs.data(), wa[r % 7], selscr, (r & 2) ? &sellds : nullptr); }
       if (ns == 2) { switch (F) { case 0: QE_CALL(2, 0) break; case 1: QE_CALL(2, 1) break; case 2: QE_CALL(2, 2) break; case 3: QE_CALL(2, 3) break;
                                   case 4: QE_CALL(2, 4) break; case 5: QE_CALL(2, 5) break; case 6: QE_CALL(2, 6) break; default: QE_CALL(2, 7) break; } }
       else { switch (F) { case 0: QE_CALL(4, 0) break; case 1: QE_CALL(4, 1) break; case 2: QE_CALL(4, 2) break; case 3: QE_CALL(4, 3) break;
