@@ -16,6 +16,8 @@ size_t qmk_sel_scratch_bytes(void);
 size_t qmk_sel_ksw_bytes(void);
 hipError_t qmk_sel_slots(const void* pair_batch, hipStream_t st);
 hipError_t qmk_sel_unit(const void* pair_batch, const void* sel_batch, int grid, hipStream_t st);
+hipError_t qmk_sel_three(const void* pair_batch, const void* sel_batch, int num_cu, hipStream_t st);
+size_t qmk_sel_task_bytes(void);
 hipError_t qmk_sel_compact(const void* pair_batch, const void* tmp, const void* toff, hipStream_t st);
 hipError_t qmk_pair_count(const void* pair_batch, hipStream_t st);
 hipError_t qmk_pair_write(const void* pair_batch, hipStream_t st);

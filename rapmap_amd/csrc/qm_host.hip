@@ -97,6 +97,7 @@ struct qm_ctx {
   long long* d_toff = nullptr; int64_t capToff = 0;
   qm_hit* d_tmp = nullptr; int64_t capTmp = 0; u64* d_tkeys = nullptr; int64_t capTkeys = 0; int* d_tsc = nullptr; int64_t capTsc = 0;
   unsigned char* d_ksw = nullptr; int64_t capKsw = 0;
+  int* d_tref = nullptr; int64_t capTref = 0; int* d_tcix = nullptr; int64_t capTcix = 0; unsigned char* d_tasks = nullptr; int64_t capTasks = 0;
   // last result
   int64_t lastUnits = -1, lastHits = 0; bool lastPaired = false;
   double lastMapMs = 0, lastTotalMs = 0;
@@ -323,7 +324,7 @@ int qm_ctx_destroy(qm_ctx* c) {
   hipSetDevice(c->device);
   void* ptrs[] = {c->d_text, c->d_SA, c->d_sainfo, c->d_slots, c->d_cnt, c->d_lcnt, c->d_loff, c->d_lists, c->d_hits, c->d_offs,
                   c->d_scal, c->d_gscr, c->d_scanTmp, c->d_seq1, c->d_seq2, c->d_off1, c->d_off2, c->d_dbg, c->d_dbgcnt,
-                  c->d_txpOff, c->d_txpLen, c->d_selscr, c->d_toff, c->d_tmp, c->d_tkeys, c->d_tsc, c->d_ksw};
+                  c->d_txpOff, c->d_txpLen, c->d_selscr, c->d_toff, c->d_tmp, c->d_tkeys, c->d_tsc, c->d_ksw, c->d_tref, c->d_tcix, c->d_tasks};
   for (void* p : ptrs) if (p) hipFree(p);
   for (void* p : c->phAllocs) if (p) hipFree(p);
   if (c->ev0) hipEventDestroy(c->ev0);
@@ -546,10 +547,22 @@ int qm_map_device(qm_ctx* c, const qm_opts* o, int64_t n, const void* d_seq1, co
     SelBatch A; memset(&A, 0, sizeof(A));
     A.seq1 = (const unsigned char*)d_seq1; A.seq2 = (const unsigned char*)d_seq2; A.text = c->d_text;
     A.txp_off = c->d_txpOff; A.txp_len = c->d_txpLen; A.tmp = c->d_tmp; A.toff = c->d_toff; A.tkeys = c->d_tkeys; A.tsc = c->d_tsc;
-    A.ksw = c->d_ksw; A.ring = getenv("QM_SEL_NO_RING") ? nullptr : (unsigned char*)1; A.match = o->match_score; A.mismatch = o->mismatch_penalty; A.gap_open = o->gap_open; A.gap_extend = o->gap_extend;
+    A.ksw = c->d_ksw; { const char* rm = getenv("QM_SEL_RING"); A.ring = (unsigned char*)(unsigned long long)(rm ? atoi(rm) : 1); } A.match = o->match_score; A.mismatch = o->mismatch_penalty; A.gap_open = o->gap_open; A.gap_extend = o->gap_extend;
     A.bandwidth = o->dp_bandwidth; A.hard_filter = o->hard_filter; A.policy = o->aln_policy; A.min_score_fraction = o->min_score_fraction;
     HIPCHK(hipMemsetAsync(c->d_cnt + n, 0, sizeof(uint32_t), c->stream));
-    HIPCHK(qmk_sel_unit(&P, &A, sgrid, c->stream));
+    // bands up to 33 wide: plan -> one wavefront per ksw2 alignment -> finish; wider bands (or QM_SEL_RING=0|1|2 for
+    // A/B runs): the one-thread-per-unit kernel
+    const bool three = o->dp_bandwidth >= 0 && o->dp_bandwidth <= 33 && !getenv("QM_SEL_RING");
+    if (three) {
+      if ((rc = ensure(c->d_tref, c->capTref, 2 * slots + 2))) return rc;
+      if ((rc = ensure(c->d_tcix, c->capTcix, 2 * slots + 2))) return rc;
+      if ((rc = ensure(c->d_tasks, c->capTasks, (2 * slots + 2) * (int64_t)qmk_sel_task_bytes()))) return rc;
+      A.tref = c->d_tref; A.tcix = c->d_tcix; A.tasks = (SelTask*)c->d_tasks; A.ntasks = c->d_scal + 9;
+      HIPCHK(hipMemsetAsync(c->d_scal + 9, 0, sizeof(u64), c->stream));
+      HIPCHK(qmk_sel_three(&P, &A, c->numCU, c->stream));
+    } else {
+      HIPCHK(qmk_sel_unit(&P, &A, sgrid, c->stream));
+    }
   } else {
     HIPCHK(qmk_pair_count(&P, c->stream));
   }

@@ -87,15 +87,19 @@ __global__ __launch_bounds__(256) void qm_sel_slots_kernel(PairBatch P) {
   P.cnt[u] = u < P.n ? w / 3 + 1 : 0;
 }
 
-// -s stages B + C: one thread per unit (grid-stride: every thread owns a ksw2 work area)
+// -s stages B + C: one thread per unit (grid-stride: every thread owns a ksw2 work area).  RING 1: the 64-column ksw2
+// ring of every thread in LDS (45 KB per wave, 3 waves per CU); RING 2: the ring in the thread's global work area
+// (no LDS, full occupancy, cache-resident); RING 0: the literal full-array kernel.
+template <int RING>
 __global__ __launch_bounds__(64) void qm_sel_unit_kernel(PairBatch P, SelBatch A) {
   __shared__ unsigned long long sc[6];
-  __shared__ __attribute__((aligned(4))) unsigned char ring[64 * QM_KSW_RING_BYTES];   // ksw2 column rings, one per thread (708 B: odd word stride)
+  __shared__ __attribute__((aligned(4))) unsigned char ring[RING == 1 ? 64 * QM_KSW_RING_BYTES : 4];
   if (threadIdx.x < 6) sc[threadIdx.x] = 0;
   __syncthreads();
   const long long tg = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
   UnitCounters uc = {0, 0, 0, 0, 0, 0};
-  SelBatch At = A; At.ring = A.ring ? ring + threadIdx.x * QM_KSW_RING_BYTES : nullptr;   // host passes non-null to enable the LDS rings
+  SelBatch At = A;
+  At.ring = RING == 1 ? ring + threadIdx.x * QM_KSW_RING_BYTES : (RING == 2 ? A.ksw + (unsigned long long)tg * QM_KSW_BYTES : nullptr);
   for (long long u = tg; u < P.n; u += stride) P.cnt[u] = (u32)sel_unit(P, At, u, tg, &uc);
   if (uc.pe) atomicAdd(&sc[0], uc.pe);
   if (uc.se) atomicAdd(&sc[1], uc.se);
@@ -105,6 +109,48 @@ __global__ __launch_bounds__(64) void qm_sel_unit_kernel(PairBatch P, SelBatch A
   if (uc.mapped) atomicAdd(&sc[5], uc.mapped);
   __syncthreads();
   if (threadIdx.x < 6 && sc[threadIdx.x]) atomicAdd((unsigned long long*)&P.counters[threadIdx.x], sc[threadIdx.x]);
+}
+
+// -s, three-kernel form: plan (per unit) -> one wavefront per ksw2 alignment -> finish (per unit)
+QM_DEV void sel_flush_counters(unsigned long long* sc, const UnitCounters& uc, u64* counters) {
+  if (uc.pe) atomicAdd(&sc[0], uc.pe);
+  if (uc.se) atomicAdd(&sc[1], uc.se);
+  if (uc.tot) atomicAdd(&sc[2], uc.tot);
+  if (uc.reads) atomicAdd(&sc[3], uc.reads);
+  if (uc.tooMany) atomicAdd(&sc[4], uc.tooMany);
+  if (uc.mapped) atomicAdd(&sc[5], uc.mapped);
+  __syncthreads();
+  if (threadIdx.x < 6 && sc[threadIdx.x]) atomicAdd((unsigned long long*)&counters[threadIdx.x], sc[threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void qm_sel_plan_kernel(PairBatch P, SelBatch A) {
+  __shared__ unsigned long long sc[6];
+  if (threadIdx.x < 6) sc[threadIdx.x] = 0;
+  __syncthreads();
+  const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  UnitCounters uc = {0, 0, 0, 0, 0, 0};
+  if (u < P.n) sel_unit_plan(P, A, u, &uc);
+  sel_flush_counters(sc, uc, P.counters);
+}
+__global__ __launch_bounds__(256) void qm_sel_align_kernel(PairBatch P, SelBatch A) {
+  __shared__ unsigned char qt[4][2 * QM_KSW_MAXLEN];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned long long nt = *A.ntasks;
+  for (unsigned long long t = (unsigned long long)blockIdx.x * 4 + wave; t < nt; t += (unsigned long long)gridDim.x * 4) {
+    const SelTask task = A.tasks[t];
+    SelTask ut;                                              // wave-uniform copy (one task per wave)
+    ut.u = uniform(task.u); ut.gslot = uniform(task.gslot); ut.side = uniform(task.side); ut.tid = uniform(task.tid); ut.pos = uniform(task.pos);
+    ut.roff = uniform(task.roff); ut.rlen = uniform(task.rlen); ut.tlen1 = uniform(task.tlen1); ut.fwd = uniform(task.fwd);
+    sel_task_align(P, A, ut, qt[wave]);
+  }
+}
+__global__ __launch_bounds__(256) void qm_sel_finish_kernel(PairBatch P, SelBatch A) {
+  __shared__ unsigned long long sc[6];
+  if (threadIdx.x < 6) sc[threadIdx.x] = 0;
+  __syncthreads();
+  const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  UnitCounters uc = {0, 0, 0, 0, 0, 0};
+  if (u < P.n) P.cnt[u] = (u32)sel_unit_finish(P, A, u, &uc);
+  sel_flush_counters(sc, uc, P.counters);
 }
 
 // -s: surviving hits from the per-unit temp slots to CSR order
@@ -244,9 +290,23 @@ hipError_t qmk_sel_slots(const void* pp, hipStream_t st) {
 hipError_t qmk_sel_unit(const void* pp, const void* ap, int grid, hipStream_t st) {
   const PairBatch& P = *(const PairBatch*)pp;
   if (P.n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(qm_sel_unit_kernel, dim3((unsigned)grid), dim3(64), 0, st, P, *(const SelBatch*)ap);
+  const SelBatch& A = *(const SelBatch*)ap;
+  const unsigned long long mode = (unsigned long long)A.ring;          // host: 0 literal arrays, 1 LDS ring, 2 ring in global memory
+  if (mode == 1) hipLaunchKernelGGL(qm_sel_unit_kernel<1>, dim3((unsigned)grid), dim3(64), 0, st, P, A);
+  else if (mode == 2) hipLaunchKernelGGL(qm_sel_unit_kernel<2>, dim3((unsigned)grid), dim3(64), 0, st, P, A);
+  else hipLaunchKernelGGL(qm_sel_unit_kernel<0>, dim3((unsigned)grid), dim3(64), 0, st, P, A);
   return hipGetLastError();
 }
+hipError_t qmk_sel_three(const void* pp, const void* ap, int num_cu, hipStream_t st) {
+  const PairBatch& P = *(const PairBatch*)pp; const SelBatch& A = *(const SelBatch*)ap;
+  if (P.n <= 0) return hipSuccess;
+  const unsigned nb = (unsigned)((P.n + 255) / 256);
+  hipLaunchKernelGGL(qm_sel_plan_kernel, dim3(nb), dim3(256), 0, st, P, A);
+  hipLaunchKernelGGL(qm_sel_align_kernel, dim3((unsigned)(num_cu * 8)), dim3(256), 0, st, P, A);
+  hipLaunchKernelGGL(qm_sel_finish_kernel, dim3(nb), dim3(256), 0, st, P, A);
+  return hipGetLastError();
+}
+size_t qmk_sel_task_bytes(void) { return sizeof(SelTask); }
 hipError_t qmk_sel_compact(const void* pp, const void* tmp, const void* toff, hipStream_t st) {
   const PairBatch& P = *(const PairBatch*)pp;
   if (P.n <= 0) return hipSuccess;

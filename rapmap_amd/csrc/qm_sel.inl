@@ -280,6 +280,11 @@ struct SelBatch {                    // launch arguments of the -s unit kernel (
   u64* tkeys; int* tsc;                        // alignment cache entries, two per slot (left / right)
   unsigned char* ksw;                          // QM_KSW_BYTES per thread
   unsigned char* ring;                         // this thread's QM_KSW_RING_BYTES (LDS on the device), or null
+  int emu_wave;                                // lane emulation only: run the wave-per-alignment kernel in place of the thread one
+  // three-kernel form (plan -> one wavefront per alignment -> finish)
+  int* tref;                                   // per slot-side: -1 score is final / pending in tsc, <= -2 copy of unit-local entry -(ref)-2
+  int* tcix;                                   // alignment-cache entries: unit-local entry a key belongs to
+  struct SelTask* tasks; u64* ntasks;          // ksw2 work list
   int match, mismatch, gap_open, gap_extend, bandwidth, hard_filter, policy;
   double min_score_fraction;
 };
@@ -450,6 +455,106 @@ QM_DEV int sel_ksw_extz2_ring(unsigned char* mem, int qlen, const unsigned char*
   return mqe > mte ? mqe : mte;
 }
 
+// The same kernel with one wavefront per alignment: lane k owns the column t with t & 63 == k of the current window
+// (the ring above, held in registers), so one anti-diagonal costs a few dozen wave instructions instead of a serial
+// walk over up to 64 bytes; the left neighbour's previous-round x / v and H come over a lane shuffle.  Wave-uniform
+// control, all lanes must call it together.  Bands of at most 33 (callers fall back to the thread version otherwise).
+QM_DEV int sel_ksw_extz2_wave(int qlen, const unsigned char* query, int tlen, const unsigned char* target,
+                              const signed char* mat, int q, int e, int w) {
+  const int NEG = -0x40000000;
+  int mqe = NEG, mte = NEG;
+  const int m = 5;
+  if (qlen <= 0 || tlen <= 0) return NEG;
+  const int qe = q + e;
+  const int tlen16 = (tlen + 15) / 16 * 16;
+  int min_sc = mat[1];
+  for (int t = 1; t < m * m; ++t) min_sc = min_sc < mat[t] ? min_sc : mat[t];
+  if (-min_sc > 2 * (q + e)) return NEG;
+  const int sc_mch = (unsigned char)mat[0], sc_mis = (unsigned char)mat[1], sc_N = (unsigned char)mat[m * m - 1], m1 = m - 1;
+  const int qe2 = (unsigned char)((q + e) * 2), max_sc_v = (unsigned char)(mat[0] + (q + e) * 2), qv = (unsigned char)q;
+  LV<int> col, U, V, X, Y, S, H;
+  QM_LANES(l) { col[l] = -1; U[l] = 0; V[l] = 0; X[l] = 0; Y[l] = 0; S[l] = 0; H[l] = NEG; }
+  int last_st = -1, last_en = -1;
+  for (int r = 0; r < qlen + tlen - 1; ++r) {
+    int st = 0, en = tlen - 1;
+    const int qoff = qlen - 1 - r;
+    if (st < r - qlen + 1) st = r - qlen + 1;
+    if (en > r) en = r;
+    if (st < (r - w + 1) >> 1) st = (r - w + 1) >> 1;
+    if (en > (r + w) >> 1) en = (r + w) >> 1;
+    if (st > en) break;
+    const int st0 = st, en0 = en;
+    st = st / 16 * 16; en = (en + 16) / 16 * 16 - 1;
+    const int smax = st0 + ((en0 - st0) / 16) * 16 + 15;       // last column the score phase writes
+    // boundary values for column st: x / v of column st - 1 as left by the last round that computed it
+    int x1b = 0, v1b = 0;
+    if (st > 0) {
+      if (st - 1 >= last_st && st - 1 <= last_en) {
+        const int kk = (st - 1) & 63;
+        if (read_lane(col, kk) == st - 1) { x1b = read_lane(X, kk); v1b = read_lane(V, kk); }
+      }
+    } else { x1b = 0; v1b = r ? qv : 0; }
+    LV<int> xo, vo, co, ho;
+    QM_LANES(l) {
+      const int t = st + ((l - st) & 63);                        // this lane's column in the window [st, st + 63]
+      // touch: the diagonal cell (en >= r), the score phase and the core all make the slot hold column t
+      const bool needs = (t <= en) || (t >= st0 && t <= smax) || (en >= r && t == r);
+      if (needs && col[l] != t) { col[l] = t; U[l] = 0; V[l] = 0; X[l] = 0; Y[l] = 0; S[l] = 0; H[l] = NEG; }
+      if (en >= r && t == r) { Y[l] = 0; U[l] = r ? qv : 0; }
+      if (t >= st0 && t <= smax) {
+        // the original's memory image: sf = target + zeros up to tlen16, directly followed by qr = reversed query + zeros
+        const int qi = qoff + t;
+        const int sv = (qi >= 0 && qi < qlen) ? query[qlen - 1 - qi] : 0;
+        int sq;
+        if (t < tlen) sq = target[t];
+        else if (t < tlen16) sq = 0;
+        else { const int j = t - tlen16; sq = (j < qlen) ? query[qlen - 1 - j] : 0; }
+        int tmp = (sq == sv) ? sc_mch : sc_mis;
+        if (sq == m1 || sv == m1) tmp = sc_N;
+        S[l] = tmp;
+      }
+      xo[l] = X[l]; vo[l] = V[l]; co[l] = col[l]; ho[l] = H[l];
+    }
+    // previous-round x, v, H of the left neighbour column
+    LV<int> xl, vl, cl, hl;
+    QM_LANES(l) { xl[l] = 0; vl[l] = 0; cl[l] = -2; hl[l] = NEG; }
+    lane_rotate_up(xo, xl); lane_rotate_up(vo, vl); lane_rotate_up(co, cl); lane_rotate_up(ho, hl);
+    QM_LANES(l) {
+      const int t = st + ((l - st) & 63);
+      if (t <= en) {
+        int xt1, vt1;
+        if (t == st) { xt1 = x1b; vt1 = v1b; }
+        else if (cl[l] == t - 1) { xt1 = xl[l]; vt1 = vl[l]; }
+        else { xt1 = 0; vt1 = 0; }
+        int z = (S[l] + qe2) & 0xff;
+        int a = (xt1 + vt1) & 0xff;
+        const int ut = U[l];
+        int b = (Y[l] + ut) & 0xff;
+        z = ((signed char)z > (signed char)a) ? z : a;
+        z = z > b ? z : b;
+        z = z < max_sc_v ? z : max_sc_v;
+        U[l] = (z - vt1) & 0xff;
+        V[l] = (z - ut) & 0xff;
+        z = (z - qv) & 0xff;
+        a = (a - z) & 0xff; b = (b - z) & 0xff;
+        X[l] = (signed char)a > 0 ? a : 0;
+        Y[l] = (signed char)b > 0 ? b : 0;
+      }
+      // H (exact max): H[en0] from the left neighbour's previous value, the other band cells accumulate v
+      if (r > 0) {
+        if (t == en0) {
+          if (en0 > 0) H[l] = ((cl[l] == en0 - 1) ? hl[l] : NEG) + U[l] - qe;
+          else H[l] = H[l] + V[l] - qe;
+        } else if (t >= st0 && t < en0) H[l] += V[l] - qe;
+      } else if (t == 0) H[l] = V[l] - qe - qe;
+    }
+    if (en0 == tlen - 1) { const int h = read_lane(H, en0 & 63); if (h > mte) mte = h; }
+    if (r - st0 == qlen - 1) { const int h = read_lane(H, st0 & 63); if (h > mqe) mqe = h; }
+    last_st = st; last_en = en;
+  }
+  return mqe > mte ? mqe : mte;
+}
+
 QM_DEV unsigned char sel_nt4(unsigned char c) {               // seq_nt4_table_loc (KSW2Aligner.cpp:61-72)
   switch (c) {
     case 0: case 'A': case 'a': return 0; case 1: case 'C': case 'c': return 1;
@@ -457,6 +562,7 @@ QM_DEV unsigned char sel_nt4(unsigned char c) {               // seq_nt4_table_l
   }
 }
 
+struct SelTask { long long u; int gslot, side, tid, pos, roff, rlen, tlen1, fwd; };   // one ksw2 extension alignment
 struct SelCache { u64* keys; int* sc; int n; int stride; };   // entries of one side: keys[i*stride], sc[i*stride]
 
 // the read as the alignment sees it: forward, or reverseRead() of it (src/RapMapUtils.cpp:107-128)
@@ -516,6 +622,11 @@ QM_DEV int sel_aln_score(const SelBatch& A, unsigned char* kmem, int pos, const 
         a = a < 0 ? -a : a; b = b > 0 ? -b : b;
         for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) mat[i * 5 + j] = (signed char)(i == j ? a : b); mat[i * 5 + 4] = 0; }
         for (int j = 0; j < 5; ++j) mat[20 + j] = 0;
+#ifdef QM_EMU
+        if (A.emu_wave && A.bandwidth >= 0 && A.bandwidth <= 33)
+          s = sel_ksw_extz2_wave(rlen, qb, (int)tlen1, tb, mat, (signed char)A.gap_open, (signed char)A.gap_extend, A.bandwidth);
+        else
+#endif
         if (A.bandwidth >= 0 && A.bandwidth <= 33 && A.ring)
           s = sel_ksw_extz2_ring(A.ring, rlen, qb, (int)tlen1, tb, mat, (signed char)A.gap_open, (signed char)A.gap_extend, A.bandwidth);
         else
@@ -564,17 +675,13 @@ QM_DEV bool sel_best_fwrc(const u64* F, int nf, const u64* R, int nr, int fwdRea
 
 // mergeLeftRightHitsFuzzy + the -s driver of one pair (RapMapSAMapper.cpp:461-701) / one single read (:225-320).
 // Writes the surviving hits to A.tmp + A.toff[u] (alignment scores in aln_score) and returns their number.
-QM_DEV int sel_unit(const PairBatch& P, const SelBatch& A, long long u, long long tid_global, UnitCounters* uc) {
+QM_DEV int sel_unit_merge(const PairBatch& P, const SelBatch& A, long long u, UnitCounters* uc) {
   const int maxHits = P.max_num_hits;
   qm_hit* T = A.tmp + A.toff[u];
   const int cap = (int)(A.toff[u + 1] - A.toff[u]);
-  u64* keys = A.tkeys + 2 * A.toff[u]; int* scs = A.tsc + 2 * A.toff[u];
-  unsigned char* kmem = A.ksw + (unsigned long long)tid_global * QM_KSW_BYTES;
-  const int LOWEST = (int)0x80000000;
   int n = 0;
   if (uc) uc->reads += 1;
   const u32 l1 = (u32)(P.off1[u + 1] - P.off1[u]);
-  const unsigned char* r1 = A.seq1 + P.off1[u];
   if (!P.paired) {
     const int nw = (int)(P.lcnt[u] & 0x7fffffffu);
     const u64* X = P.lists + P.loff[u];
@@ -589,24 +696,6 @@ QM_DEV int sel_unit(const PairBatch& P, const SelBatch& A, long long u, long lon
         T[n++] = h;
       }
     }
-    // selective alignment (:246-318)
-    SelCache C; C.keys = keys; C.sc = scs; C.n = 0; C.stride = 2;
-    int bestScore = LOWEST;
-    const int maxReadScore = A.match * (int)l1;
-    const bool multiMapping = n > 1;
-    for (int i = 0; i < n; ++i) {
-      qm_hit& h = T[i];
-      const int s = sel_aln_score(A, kmem, h.pos, r1, (int)l1, h.fwd != 0, A.text + A.txp_off[h.tid], A.txp_len[h.tid], maxReadScore,
-                                  h.aln_score, multiMapping, C);
-      const int score = ((double)s < A.min_score_fraction * (double)maxReadScore) ? LOWEST : s;
-      bestScore = score > bestScore ? score : bestScore;
-      h.aln_score = score;
-    }
-    int o = 0;
-    if (bestScore > LOWEST)
-      for (int i = 0; i < n; ++i) { const bool rem = A.hard_filter ? (T[i].aln_score < bestScore) : (T[i].aln_score == LOWEST); if (!rem) { if (o != i) T[o] = T[i]; ++o; } }
-    n = o;
-    if (uc && n > 0) uc->mapped += 1;
     return n;
   }
   const u32 c0 = P.lcnt[2 * u], c1 = P.lcnt[2 * u + 1];
@@ -615,7 +704,6 @@ QM_DEV int sel_unit(const PairBatch& P, const SelBatch& A, long long u, long lon
   const u64* LL = P.lists + P.loff[2 * u];
   const u64* RR = P.lists + P.loff[2 * u + 1];
   const u32 l2 = (u32)(P.off2[u + 1] - P.off2[u]);
-  const unsigned char* r2 = A.seq2 + P.off2[u];
   auto orphan = [&](const SelG& q, u32 ln, int mateStatus) {
     qm_hit h; h.tid = q.tid; h.pos = q.ppos; h.mate_pos = 0; h.frag_len = 0; h.read_len = ln; h.mate_len = 0;
     h.fwd = q.rc ? 0 : 1; h.mate_is_fwd = 1; h.is_paired = 0; h.mate_status = (uint8_t)mateStatus;
@@ -668,6 +756,40 @@ QM_DEV int sel_unit(const PairBatch& P, const SelBatch& A, long long u, long lon
   }
   if (n > maxHits) n = 0;                                  // :534-536
   if (n > 0 && P.no_orphans && T[0].mate_status != 3) n = 0;   // :539-551
+  return n;
+}
+
+QM_DEV int sel_unit(const PairBatch& P, const SelBatch& A, long long u, long long tid_global, UnitCounters* uc) {
+  qm_hit* T = A.tmp + A.toff[u];
+  u64* keys = A.tkeys + 2 * A.toff[u]; int* scs = A.tsc + 2 * A.toff[u];
+  unsigned char* kmem = A.ksw + (unsigned long long)tid_global * QM_KSW_BYTES;
+  const int LOWEST = (int)0x80000000;
+  int n = sel_unit_merge(P, A, u, uc);
+  const u32 l1 = (u32)(P.off1[u + 1] - P.off1[u]);
+  const unsigned char* r1 = A.seq1 + P.off1[u];
+  if (!P.paired) {
+    // selective alignment (:246-318)
+    SelCache C; C.keys = keys; C.sc = scs; C.n = 0; C.stride = 2;
+    int bestScore = LOWEST;
+    const int maxReadScore = A.match * (int)l1;
+    const bool multiMapping = n > 1;
+    for (int i = 0; i < n; ++i) {
+      qm_hit& h = T[i];
+      const int s = sel_aln_score(A, kmem, h.pos, r1, (int)l1, h.fwd != 0, A.text + A.txp_off[h.tid], A.txp_len[h.tid], maxReadScore,
+                                  h.aln_score, multiMapping, C);
+      const int score = ((double)s < A.min_score_fraction * (double)maxReadScore) ? LOWEST : s;
+      bestScore = score > bestScore ? score : bestScore;
+      h.aln_score = score;
+    }
+    int o = 0;
+    if (bestScore > LOWEST)
+      for (int i = 0; i < n; ++i) { const bool rem = A.hard_filter ? (T[i].aln_score < bestScore) : (T[i].aln_score == LOWEST); if (!rem) { if (o != i) T[o] = T[i]; ++o; } }
+    n = o;
+    if (uc && n > 0) uc->mapped += 1;
+    return n;
+  }
+  const u32 l2 = (u32)(P.off2[u + 1] - P.off2[u]);
+  const unsigned char* r2 = A.seq2 + P.off2[u];
   if (n > 0) {                                             // :554-667
     SelCache CL, CR;
     CL.keys = keys; CL.sc = scs; CL.n = 0; CL.stride = 2;
@@ -706,5 +828,186 @@ QM_DEV int sel_unit(const PairBatch& P, const SelBatch& A, long long u, long lon
     n = o;
   }
   if (uc) { uc->tot += (u64)n; if (n > 0) uc->mapped += 1; }
+  return n;
+}
+
+
+// ------------------------------------------------------------------ three-kernel form of stage B + C
+// sel_unit runs an alignment inside one thread.  Here the same work is cut in three so that every ksw2 alignment
+// gets a whole wavefront (sel_ksw_extz2_wave):  plan (per unit: merge, everything but the ksw2 scores; alignments
+// that have to be run become tasks, alignment-cache hits become references to the entry that owns the score),
+// align (one wavefront per task), finish (per unit: gate, filter, counters).
+
+// the part of getAlnScore around the alignment itself: returns true when the score is known now (in `score`);
+// otherwise a task was queued or `ref` points at the cache entry whose score will be this one's.
+QM_DEV void sel_plan_side(const SelBatch& A, long long u, long long gbase, int local, int side, u32 tid, int pos,
+                          const unsigned char* read, int readLen, bool fwd, const unsigned char* tseq, int tlen, int maxScore,
+                          int chainStat, bool multiMapping, u64* ckeys, int* cidx, int& cn) {
+  const int LOWEST = (int)0x80000000;
+  const long long g = gbase + local;
+  A.tref[g] = -1;
+  if (chainStat == QM_CS_PERFECT) { A.tsc[g] = maxScore; return; }
+  int s = LOWEST;
+  int roff = 0, rlen = readLen;
+  const bool invalidStart = pos < 0;
+  const bool invalidEnd = pos + rlen >= tlen;
+  if (invalidStart) { roff = -pos; rlen += pos; pos = 0; }
+  if ((invalidStart || invalidEnd) && (A.policy == 1 || A.policy == 2)) { A.tsc[g] = s; return; }
+  if (pos < tlen) {
+    const bool doUngapped = !invalidStart && chainStat == QM_CS_UNGAPPED;
+    const u32 buf = doUngapped ? 0u : 20u;
+    const u32 lnobuf = (u32)(tlen - pos), lbuf = (u32)(rlen + (int)buf);
+    const bool useBuf = lbuf < lnobuf;
+    const u32 tlen1 = lbuf < lnobuf ? lbuf : lnobuf;
+    const unsigned char* tseq1 = tseq + pos;
+    const u32 keyLen = useBuf ? tlen1 - buf : tlen1;
+    u64 key = 0; bool didHash = false;
+    auto hashKey = [&]() {
+      u64 h = hash_mix((u64)keyLen + 0x9E3779B97F4A7C15ULL);
+      for (u32 i = 0; i < keyLen; i += 8) {
+        u64 w = 0;
+        for (u32 t = 0; t < 8 && i + t < keyLen; ++t) w |= (u64)tseq1[i + t] << (8 * t);
+        h = hash_mix(h ^ w);
+      }
+      return h;
+    };
+    if (cn > 0) {
+      key = hashKey(); didHash = true;
+      for (int i = 0; i < cn; ++i) if (ckeys[i * 2] == key) { A.tref[g] = -(cidx[i * 2]) - 2; A.tsc[g] = LOWEST; return; }
+    }
+    if (doUngapped) {
+      const int tlen1s = (int)tlen1;
+      const int alnLen = rlen < tlen1s ? rlen : tlen1s;
+      int sc = 0;
+      for (int i = 0; i < alnLen; ++i) {
+        unsigned char c1 = tseq1[i], c2 = sel_read_char(read, readLen, fwd, roff + i);
+        c1 = (c1 == 'N' || c2 == 'N') ? c2 : c1;
+        sc += (c1 == c2) ? A.match : A.mismatch;
+      }
+      s = sc;
+    } else {
+      const u64 ti = atomic_add_u64(A.ntasks, 1ULL);
+      SelTask t; t.u = u; t.gslot = (int)g; t.side = side; t.tid = (int)tid; t.pos = pos; t.roff = roff; t.rlen = rlen; t.tlen1 = (int)tlen1; t.fwd = fwd ? 1 : 0;
+      A.tasks[ti] = t;
+    }
+    if (multiMapping) {
+      if (!didHash) key = hashKey();
+      ckeys[cn * 2] = key; cidx[cn * 2] = local; cn++;
+    }
+  }
+  A.tsc[g] = s;
+}
+
+// merge + post filters of one unit into its temp slots (chain statuses parked in aln_score); returns the hit count
+QM_DEV int sel_unit_merge(const PairBatch& P, const SelBatch& A, long long u, UnitCounters* uc);
+
+QM_DEV void sel_unit_plan(const PairBatch& P, const SelBatch& A, long long u, UnitCounters* uc) {
+  const int n = sel_unit_merge(P, A, u, uc);
+  P.cnt[u] = (u32)n;                                       // hits before the score filter; sel_unit_finish overwrites it
+  qm_hit* T = A.tmp + A.toff[u];
+  const long long gbase = 2 * A.toff[u];
+  u64* keys = A.tkeys + gbase; int* cix = A.tcix + gbase;
+  const u32 l1 = (u32)(P.off1[u + 1] - P.off1[u]);
+  const unsigned char* r1 = A.seq1 + P.off1[u];
+  const bool multiMapping = n > 1;
+  int cnL = 0, cnR = 0;
+  if (!P.paired) {
+    const int maxReadScore = A.match * (int)l1;
+    for (int i = 0; i < n; ++i) {
+      const qm_hit& h = T[i];
+      sel_plan_side(A, u, gbase, 2 * i, 0, h.tid, h.pos, r1, (int)l1, h.fwd != 0, A.text + A.txp_off[h.tid], A.txp_len[h.tid], maxReadScore,
+                    h.aln_score & 15, multiMapping, keys, cix, cnL);
+    }
+    return;
+  }
+  const u32 l2 = (u32)(P.off2[u + 1] - P.off2[u]);
+  const unsigned char* r2 = A.seq2 + P.off2[u];
+  const int maxLeftScore = A.match * (int)l1, maxRightScore = A.match * (int)l2;
+  for (int i = 0; i < n; ++i) {
+    const qm_hit& h = T[i];
+    const int csL = h.aln_score & 15, csR = (h.aln_score >> 4) & 15;
+    const unsigned char* tseq = A.text + A.txp_off[h.tid];
+    const int tlen = A.txp_len[h.tid];
+    if (h.mate_status == 3) {
+      sel_plan_side(A, u, gbase, 2 * i, 0, h.tid, h.pos, r1, (int)l1, h.fwd != 0, tseq, tlen, maxLeftScore, csL, multiMapping, keys, cix, cnL);
+      sel_plan_side(A, u, gbase, 2 * i + 1, 1, h.tid, h.mate_pos, r2, (int)l2, h.mate_is_fwd != 0, tseq, tlen, maxRightScore, csR, multiMapping, keys + 1, cix + 1, cnR);
+    } else if (h.mate_status == 1) {
+      sel_plan_side(A, u, gbase, 2 * i, 0, h.tid, h.pos, r1, (int)l1, h.fwd != 0, tseq, tlen, maxLeftScore, csL, multiMapping, keys, cix, cnL);
+    } else {
+      sel_plan_side(A, u, gbase, 2 * i + 1, 1, h.tid, h.pos, r2, (int)l2, h.fwd != 0, tseq, tlen, maxRightScore, csR, multiMapping, keys + 1, cix + 1, cnR);
+    }
+  }
+}
+
+// one ksw2 task, all lanes of a wave together; qt: 2 * QM_KSW_MAXLEN bytes private to the wave (LDS)
+QM_DEV void sel_task_align(const PairBatch& P, const SelBatch& A, const SelTask& t, unsigned char* qt) {
+  const unsigned char* read = t.side == 0 ? A.seq1 + P.off1[t.u] : A.seq2 + P.off2[t.u];
+  const int readLen = (int)(t.side == 0 ? P.off1[t.u + 1] - P.off1[t.u] : P.off2[t.u + 1] - P.off2[t.u]);
+  const unsigned char* tseq1 = A.text + A.txp_off[t.tid] + t.pos;
+  unsigned char* qb = qt; unsigned char* tb = qt + QM_KSW_MAXLEN;
+  for (int b0 = 0; b0 < QM_KSW_MAXLEN; b0 += 64) {
+    QM_LANES(l) {
+      const int i = b0 + l;
+      if (i < t.rlen) qb[i] = sel_nt4(sel_read_char(read, readLen, t.fwd != 0, t.roff + i));
+      if (i < t.tlen1) tb[i] = sel_nt4(tseq1[i]);
+    }
+  }
+  wave_fence();
+  signed char mat[25];
+  int a = (signed char)A.match, b = (signed char)A.mismatch;
+  a = a < 0 ? -a : a; b = b > 0 ? -b : b;
+  for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) mat[i * 5 + j] = (signed char)(i == j ? a : b); mat[i * 5 + 4] = 0; }
+  for (int j = 0; j < 5; ++j) mat[20 + j] = 0;
+  const int s = sel_ksw_extz2_wave(t.rlen, qb, t.tlen1, tb, mat, (signed char)A.gap_open, (signed char)A.gap_extend, A.bandwidth);
+  QM_LANES(l) { if (l == 0) A.tsc[t.gslot] = s; }
+  wave_fence();
+}
+
+QM_DEV int sel_unit_finish(const PairBatch& P, const SelBatch& A, long long u, UnitCounters* uc) {
+  const int LOWEST = (int)0x80000000;
+  int n = (int)P.cnt[u];
+  qm_hit* T = A.tmp + A.toff[u];
+  const long long gbase = 2 * A.toff[u];
+  auto score_of = [&](int local) { const int r = A.tref[gbase + local]; return r <= -2 ? A.tsc[gbase + (-(r) - 2)] : A.tsc[gbase + local]; };
+  const u32 l1 = (u32)(P.off1[u + 1] - P.off1[u]);
+  int bestScore = LOWEST;
+  if (!P.paired) {
+    const int maxReadScore = A.match * (int)l1;
+    for (int i = 0; i < n; ++i) {
+      const int s = score_of(2 * i);
+      const int score = ((double)s < A.min_score_fraction * (double)maxReadScore) ? LOWEST : s;
+      bestScore = score > bestScore ? score : bestScore;
+      T[i].aln_score = score;
+    }
+  } else {
+    const u32 l2 = (u32)(P.off2[u + 1] - P.off2[u]);
+    const int maxLeftScore = A.match * (int)l1, maxRightScore = A.match * (int)l2;
+    for (int i = 0; i < n; ++i) {
+      qm_hit& h = T[i];
+      int score = LOWEST;
+      if (h.mate_status == 3) {
+        int s1 = score_of(2 * i), s2 = score_of(2 * i + 1);
+        if (h.fwd != h.mate_is_fwd && P.no_dovetail) {
+          if (h.fwd && h.pos > h.mate_pos) { s1 = LOWEST; s2 = LOWEST; }
+          else if (h.mate_is_fwd && h.mate_pos > h.pos) { s1 = LOWEST; s2 = LOWEST; }
+        }
+        if (((double)s1 < A.min_score_fraction * (double)maxLeftScore) || ((double)s2 < A.min_score_fraction * (double)maxRightScore)) score = LOWEST;
+        else score = s1 + s2;
+      } else if (h.mate_status == 1) {
+        const int s = score_of(2 * i);
+        score = ((double)s < A.min_score_fraction * (double)maxLeftScore) ? LOWEST : s;
+      } else {
+        const int s = score_of(2 * i + 1);
+        score = ((double)s < A.min_score_fraction * (double)maxRightScore) ? LOWEST : s;
+      }
+      bestScore = score > bestScore ? score : bestScore;
+      h.aln_score = score;
+    }
+  }
+  int o = 0;
+  if (bestScore > LOWEST)
+    for (int i = 0; i < n; ++i) { const bool rem = A.hard_filter ? (T[i].aln_score < bestScore) : (T[i].aln_score == LOWEST); if (!rem) { if (o != i) T[o] = T[i]; ++o; } }
+  n = o;
+  if (uc) { if (P.paired) uc->tot += (u64)n; if (n > 0) uc->mapped += 1; }
   return n;
 }

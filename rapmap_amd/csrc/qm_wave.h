@@ -90,6 +90,8 @@ QM_DEV u64 mulhi64(u64 a, u64 b) { return __umul64hi(a, b); }
 
 #ifdef QM_EMU
 QM_DEV int wave_max(const LV<int>& x) { int m = x.v[0]; for (int l = 1; l < 64; ++l) m = x.v[l] > m ? x.v[l] : m; return m; }
+// out[l] = in[(l - 1) & 63]: every lane reads its lower neighbour (wrapping)
+QM_DEV void lane_rotate_up(const LV<int>& in, LV<int>& out) { for (int l = 0; l < 64; ++l) out.v[l] = in.v[(l + 63) & 63]; }
 // every lane gets the minimum over its aligned group of G lanes (G a power of two, wave-uniform)
 QM_DEV void group_min(LV<int>& x, int G) {
   for (int b = 0; b < 64; b += G) {
@@ -115,6 +117,7 @@ QM_DEV int wave_max(const LV<int>& x) {
   for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
   return __builtin_amdgcn_readfirstlane(v);
 }
+QM_DEV void lane_rotate_up(const LV<int>& in, LV<int>& out) { out.v[0] = __shfl(in.v[0], (int)((threadIdx.x + 63) & 63), 64); }
 QM_DEV void group_min(LV<int>& x, int G) {
   int v = x.v[0];
   for (int o = 1; o < G; o <<= 1) { int t = __shfl_xor(v, o, 64); v = t < v ? t : v; }

@@ -86,10 +86,21 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
     std::vector<unsigned char> ksw(QM_KSW_BYTES); std::vector<int> ringbuf(QM_KSW_RING_BYTES / 4 + 4);
     SelBatch A; memset(&A, 0, sizeof(A));
     A.seq1 = seq1; A.seq2 = seq2; A.text = text; A.txp_off = txp_off; A.txp_len = txp_len; A.tmp = tmp.data(); A.toff = toff.data();
-    A.tkeys = tkeys.data(); A.tsc = tsc.data(); A.ksw = ksw.data(); A.ring = (unsigned char*)ringbuf.data();
+    A.tkeys = tkeys.data(); A.tsc = tsc.data(); A.ksw = ksw.data(); A.ring = (unsigned char*)ringbuf.data(); A.emu_wave = getenv("QE_KSW_WAVE") ? 1 : 0;
     A.match = o->match_score; A.mismatch = o->mismatch_penalty; A.gap_open = o->gap_open; A.gap_extend = o->gap_extend;
     A.bandwidth = o->dp_bandwidth; A.hard_filter = o->hard_filter; A.policy = o->aln_policy; A.min_score_fraction = o->min_score_fraction;
-    for (long long u = 0; u < nunits; ++u) hc[u] = (u32)sel_unit(P, A, u, 0, &uc);
+    const bool three = o->dp_bandwidth >= 0 && o->dp_bandwidth <= 33 && !getenv("QE_SEL_UNIT");   // same rule as the host
+    if (three) {
+      std::vector<int> tref(2 * (size_t)toff[nunits] + 2), tcix(2 * (size_t)toff[nunits] + 2);
+      std::vector<SelTask> tasks(2 * (size_t)toff[nunits] + 2); u64 ntasks = 0;
+      A.tref = tref.data(); A.tcix = tcix.data(); A.tasks = tasks.data(); A.ntasks = &ntasks;
+      for (long long u = 0; u < nunits; ++u) sel_unit_plan(P, A, u, &uc);
+      std::vector<unsigned char> qt(2 * QM_KSW_MAXLEN);
+      for (u64 t = 0; t < ntasks; ++t) sel_task_align(P, A, tasks[t], qt.data());
+      for (long long u = 0; u < nunits; ++u) hc[u] = (u32)sel_unit_finish(P, A, u, &uc);
+    } else {
+      for (long long u = 0; u < nunits; ++u) hc[u] = (u32)sel_unit(P, A, u, 0, &uc);
+    }
     hit_offsets[0] = 0;
     for (long long u = 0; u < nunits; ++u) hit_offsets[u + 1] = hit_offsets[u] + hc[u];
     out = (qm_hit*)malloc(sizeof(qm_hit) * (size_t)(hit_offsets[nunits] + 1));
