@@ -69,13 +69,13 @@ QM_DEV void sel_sort(SelRec* r, SelRec* t, int n, Less less) {
 
 // One strand: S.rec[0..n) holds every (tid, pos, qpos, len, interval) of the strand's m intervals.  Lane-0 code.
 template <typename SS>
-QM_DEV void sel_strand(SS& S, int s, int n, int m, u32 readLen, int mate, float consensusFraction) {
+QM_DEV void sel_strand(SS& S, int s, int n, int m, u32 readLen, int mate, float consensusFraction, bool presorted) {
 #pragma clang fp contract(off)
   int ng = 0, np = 0;
   SelGroup* G = S.grp[s]; int* P = S.pos[s];
   if (m == 1) {
     // collectFromSingleInterval + mergeUnique (HitManager.cpp:716-807): hitPos = pos - queryPos, sorted by (tid, hitPos)
-    sel_sort(S.rec, S.tmp, n, [](const SelRec& a, const SelRec& b) {
+    if (!presorted) sel_sort(S.rec, S.tmp, n, [](const SelRec& a, const SelRec& b) {
       return a.tid != b.tid ? a.tid < b.tid : (int)(a.pos - a.qpos) < (int)(b.pos - b.qpos); });
     for (int i = 0; i < n; ++i) {
       const SelRec& r = S.rec[i];
@@ -100,10 +100,12 @@ QM_DEV void sel_strand(SS& S, int s, int n, int m, u32 readLen, int mate, float 
     maxSlack = m - requiredNumHits;
   }
   // chain order within a transcript: by reference end, then query end (HitManager.cpp:129-139); then group by transcript
-  sel_sort(S.rec, S.tmp, n, [](const SelRec& a, const SelRec& b) {
-    u32 r1 = a.pos + a.len, r2 = b.pos + b.len, q1 = a.qpos + a.len, q2 = b.qpos + b.len;
-    return (r1 < r2) ? true : ((r2 < r1) ? false : (q1 < q2)); });
-  sel_sort(S.rec, S.tmp, n, [](const SelRec& a, const SelRec& b) { return a.tid < b.tid; });
+  if (!presorted) {
+    sel_sort(S.rec, S.tmp, n, [](const SelRec& a, const SelRec& b) {
+      u32 r1 = a.pos + a.len, r2 = b.pos + b.len, q1 = a.qpos + a.len, q2 = b.qpos + b.len;
+      return (r1 < r2) ? true : ((r2 < r1) ? false : (q1 < q2)); });
+    sel_sort(S.rec, S.tmp, n, [](const SelRec& a, const SelRec& b) { return a.tid < b.tid; });
+  }
   // first pass: is any transcript active?
   bool anyActive = false;
   for (int g0 = 0; g0 < n;) {
@@ -225,6 +227,37 @@ QM_DEV int sel_emit(SS& S) {
   return o;
 }
 
+// The two stable sorts of sel_strand as one rank sort by all lanes (n <= 64): order (tid, reference end, query end, input
+// order) for several intervals, (tid, hit position, input order) for one -- what lane 0's merge sorts produce.
+template <typename SS>
+QM_DEV void sel_wave_sort(SS& S, int n, int m) {
+  LV<u64> k1, k2;
+  QM_LANES(l) {
+    k1[l] = 0; k2[l] = 0;
+    if (l < n) {
+      const SelRec r = S.rec[l];
+      if (m == 1) { k1[l] = ((u64)r.tid << 32) | (u64)(((u32)(r.pos - r.qpos)) ^ 0x80000000u); k2[l] = (u64)l; }
+      else { k1[l] = ((u64)r.tid << 32) | (u64)(u32)(r.pos + r.len); k2[l] = ((u64)(u32)(r.qpos + r.len) << 8) | (u64)l; }
+    }
+  }
+  // keys to scratch so that every lane can read every key: reuse tmp's first words
+  u64* K = (u64*)S.tmp;
+  QM_LANES(l) { if (l < n) { K[2 * l] = k1[l]; K[2 * l + 1] = k2[l]; } }
+  wave_fence();
+  LV<int> rank;
+  QM_LANES(l) {
+    int rk = 0;
+    if (l < n) for (int j = 0; j < n; ++j) { const u64 a = K[2 * j], b = K[2 * j + 1]; rk += (a < k1[l] || (a == k1[l] && b < k2[l])) ? 1 : 0; }
+    rank[l] = rk;
+  }
+  wave_fence();
+  LV<SelRec> mine;
+  QM_LANES(l) { if (l < n) mine[l] = S.rec[l]; }
+  wave_fence();
+  QM_LANES(l) { if (l < n) S.rec[rank[l]] = mine[l]; }
+  wave_fence();
+}
+
 // Stage A, -s variant of hits_to_mappings on scratch S: returns the number of list words in S.out, -1 when S is too small.
 template <typename SS>
 QM_DEV int sel_h2m_on(const DevIndex& ix, const ReadBatch& B, const IntervalList& fwdInts, const IntervalList& rcInts,
@@ -250,7 +283,9 @@ QM_DEV int sel_h2m_on(const DevIndex& ix, const ReadBatch& B, const IntervalList
       n += cnt;
     }
     wave_fence();
-    QM_LANES(l) { if (l == 0) { if (L.n > 0) sel_strand(S, s, n, L.n, readLen, mate, B.consensus_fraction); else { S.ngrp[s] = 0; S.npos[s] = 0; } } }
+    const bool presorted = n <= 64 && 2 * n * (int)sizeof(u64) <= (int)sizeof(S.tmp);
+    if (presorted && L.n > 0) sel_wave_sort(S, n, L.n);
+    QM_LANES(l) { if (l == 0) { if (L.n > 0) sel_strand(S, s, n, L.n, readLen, mate, B.consensus_fraction, presorted); else { S.ngrp[s] = 0; S.npos[s] = 0; } } }
     wave_fence();
   }
   LV<int> nw;
