@@ -529,7 +529,7 @@ QM_DEV int sel_ksw_extz2_wave(int qlen, const unsigned char* query, int tlen, co
         if (read_lane(col, kk) == st - 1) { x1b = read_lane(X, kk); v1b = read_lane(V, kk); }
       }
     } else { x1b = 0; v1b = r ? qv : 0; }
-    LV<int> xo, vo, co, ho;
+    LV<int> xo, ho;
     QM_LANES(l) {
       const int t = st + ((l - st) & 63);                        // this lane's column in the window [st, st + 63]
       // touch: the diagonal cell (en >= r), the score phase and the core all make the slot hold column t
@@ -548,18 +548,18 @@ QM_DEV int sel_ksw_extz2_wave(int qlen, const unsigned char* query, int tlen, co
         if (sq == m1 || sv == m1) tmp = sc_N;
         S[l] = tmp;
       }
-      xo[l] = X[l]; vo[l] = V[l]; co[l] = col[l]; ho[l] = H[l];
+      xo[l] = X[l] | (V[l] << 8) | ((col[l] & 0x7fff) << 16); ho[l] = H[l];   // x, v and the column id in one word
     }
-    // previous-round x, v, H of the left neighbour column
+    // previous-round x, v, H of the left neighbour column (lane l - 1)
     LV<int> xl, vl, cl, hl;
-    QM_LANES(l) { xl[l] = 0; vl[l] = 0; cl[l] = -2; hl[l] = NEG; }
-    lane_rotate_up(xo, xl); lane_rotate_up(vo, vl); lane_rotate_up(co, cl); lane_rotate_up(ho, hl);
+    lane_rotate_up(xo, xl); lane_rotate_up(ho, hl);
+    QM_LANES(l) { cl[l] = xl[l] >> 16; vl[l] = (xl[l] >> 8) & 0xff; xl[l] = xl[l] & 0xff; }
     QM_LANES(l) {
       const int t = st + ((l - st) & 63);
       if (t <= en) {
         int xt1, vt1;
         if (t == st) { xt1 = x1b; vt1 = v1b; }
-        else if (cl[l] == t - 1) { xt1 = xl[l]; vt1 = vl[l]; }
+        else if (cl[l] == ((t - 1) & 0x7fff)) { xt1 = xl[l]; vt1 = vl[l]; }
         else { xt1 = 0; vt1 = 0; }
         int z = (S[l] + qe2) & 0xff;
         int a = (xt1 + vt1) & 0xff;
@@ -578,7 +578,7 @@ QM_DEV int sel_ksw_extz2_wave(int qlen, const unsigned char* query, int tlen, co
       // H (exact max): H[en0] from the left neighbour's previous value, the other band cells accumulate v
       if (r > 0) {
         if (t == en0) {
-          if (en0 > 0) H[l] = ((cl[l] == en0 - 1) ? hl[l] : NEG) + U[l] - qe;
+          if (en0 > 0) H[l] = ((cl[l] == ((en0 - 1) & 0x7fff)) ? hl[l] : NEG) + U[l] - qe;
           else H[l] = H[l] + V[l] - qe;
         } else if (t >= st0 && t < en0) H[l] += V[l] - qe;
       } else if (t == 0) H[l] = V[l] - qe - qe;
@@ -590,11 +590,11 @@ QM_DEV int sel_ksw_extz2_wave(int qlen, const unsigned char* query, int tlen, co
   return mqe > mte ? mqe : mte;
 }
 
-QM_DEV unsigned char sel_nt4(unsigned char c) {               // seq_nt4_table_loc (KSW2Aligner.cpp:61-72)
-  switch (c) {
-    case 0: case 'A': case 'a': return 0; case 1: case 'C': case 'c': return 1;
-    case 2: case 'G': case 'g': return 2; case 3: case 'T': case 't': return 3; default: return 4;
-  }
+QM_DEV unsigned char sel_nt4(unsigned char c) {               // seq_nt4_table_loc (KSW2Aligner.cpp:61-72), branch-free
+  const unsigned char l = c | 0x20;
+  const bool acgt = (l == 'a') | (l == 'c') | (l == 'g') | (l == 't');
+  const unsigned x = (c >> 1) & 3;
+  return acgt ? (unsigned char)(x ^ (x >> 1)) : (c < 4 ? c : (unsigned char)4);   // bytes 0..3 map to themselves in that table
 }
 
 struct SelTask { long long u; int gslot, side, tid, pos, roff, rlen, tlen1, fwd; };   // one ksw2 extension alignment
@@ -980,7 +980,8 @@ QM_DEV void sel_task_align(const PairBatch& P, const SelBatch& A, const SelTask&
   const int readLen = (int)(t.side == 0 ? P.off1[t.u + 1] - P.off1[t.u] : P.off2[t.u + 1] - P.off2[t.u]);
   const unsigned char* tseq1 = A.text + A.txp_off[t.tid] + t.pos;
   unsigned char* qb = qt; unsigned char* tb = qt + QM_KSW_MAXLEN;
-  for (int b0 = 0; b0 < QM_KSW_MAXLEN; b0 += 64) {
+  const int nmax = t.rlen > t.tlen1 ? t.rlen : t.tlen1;
+  for (int b0 = 0; b0 < nmax; b0 += 64) {
     QM_LANES(l) {
       const int i = b0 + l;
       if (i < t.rlen) qb[i] = sel_nt4(sel_read_char(read, readLen, t.fwd != 0, t.roff + i));

@@ -117,7 +117,8 @@ QM_DEV int wave_max(const LV<int>& x) {
   for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
   return __builtin_amdgcn_readfirstlane(v);
 }
-QM_DEV void lane_rotate_up(const LV<int>& in, LV<int>& out) { out.v[0] = __shfl(in.v[0], (int)((threadIdx.x + 63) & 63), 64); }
+// DPP wave_ror:1 -- one VALU instruction, no trip through the LDS crossbar
+QM_DEV void lane_rotate_up(const LV<int>& in, LV<int>& out) { out.v[0] = __builtin_amdgcn_update_dpp(0, in.v[0], 0x13C, 0xf, 0xf, false); }
 QM_DEV void group_min(LV<int>& x, int G) {
   int v = x.v[0];
   for (int o = 1; o < G; o <<= 1) { int t = __shfl_xor(v, o, 64); v = t < v ? t : v; }
