@@ -67,6 +67,76 @@ QM_DEV void sel_sort(SelRec* r, SelRec* t, int n, Less less) {
   }
 }
 
+// collectHitsSimpleSA, chaining branch (HitManager.cpp:107-307), for the hn hits H of one transcript (already in chain
+// order).  f, p, seen, ends, starts: hn entries of scratch each.  Returns the number of chain starts (0: no hit), fills g
+// (all but g.off) and writes the sorted start positions to posOut (may alias ends).
+QM_DEV int sel_chain_group(const SelRec* H, int hn, double* f, int* p, int* seen, int* ends, int* starts, int maxDist,
+                           SelGroup& g, int* posOut) {
+#pragma clang fp contract(off)
+  double bestScore = -1.7976931348623157e308; int bestChainEnd = -1; int nEnds = 0;
+  const double avgseed = 31.0;
+  for (int i = 0; i < hn; ++i) {
+    const u32 qposi = H[i].qpos + H[i].len, rposi = H[i].pos + H[i].len;
+    const double leni = (double)(int)H[i].len;
+    int pi = i; double fi = (double)H[i].len;
+    int numRounds = 2;
+    for (int j = i - 1; j >= 0; --j) {
+      const u32 qposj = H[j].qpos + H[j].len, rposj = H[j].pos + H[j].len;
+      const int qdiff = (int)(qposi - qposj), rdiff = (int)(rposi - rposj);
+      // alpha
+      double mindiff = (qdiff < rdiff) ? (double)qdiff : (double)rdiff;
+      double alpha = (leni < mindiff) ? leni : mindiff;
+      // beta
+      double beta;
+      if (qdiff < 0 || ((qdiff > rdiff ? qdiff : rdiff) > maxDist)) beta = __builtin_inf();
+      else {
+        double l = (double)qdiff - (double)rdiff;
+        int al = (int)(l < 0 ? -l : l);
+        beta = (l == 0) ? 0.0 : (0.01 * avgseed * al + 0.5 * sel_fastlog2((float)al));
+      }
+      double extensionScore = f[j] + alpha - beta;
+      bool extendWithJ = extensionScore > fi;
+      pi = extendWithJ ? j : pi;
+      fi = extendWithJ ? extensionScore : fi;
+      if (pi < i) { numRounds--; if (numRounds <= 0) break; }
+    }
+    p[i] = pi; f[i] = fi;
+    if (fi > bestScore) { bestScore = fi; bestChainEnd = i; nEnds = 0; ends[nEnds++] = i; }
+    else if (fi == bestScore) ends[nEnds++] = i;
+  }
+  // multi-chain backtracking (:206-246)
+  for (int i = 0; i < hn; ++i) seen[i] = 0;
+  int numDistinctOpt = 0, nStarts = 0;
+  for (int e = 0; e < nEnds; ++e) {
+    int bestChainEndInd = ends[e];
+    bool validChain = true;
+    int lastPtr = p[bestChainEndInd];
+    while (lastPtr < bestChainEndInd) {
+      if (seen[bestChainEndInd]) { validChain = false; break; }
+      seen[bestChainEndInd] = 1;
+      bestChainEndInd = lastPtr;
+      lastPtr = p[bestChainEndInd];
+    }
+    if (seen[bestChainEndInd]) validChain = false;
+    if (validChain) { ++numDistinctOpt; starts[nStarts++] = lastPtr; }
+  }
+  if (nStarts == 0) return 0;
+  g.tid = H[0].tid; g.cs = QM_CS_REGULAR; g.score = bestScore; g.npos = nStarts; g.off = 0;
+  g.ppos = (int)(H[starts[0]].pos - H[starts[0]].qpos);                      // the first chain's start (:259-262)
+  for (int t = 0; t < nStarts; ++t) {                                        // allPositions is sorted (:272-276)
+    const int v = (int)(H[starts[t]].pos - H[starts[t]].qpos);
+    int b = t - 1;
+    while (b >= 0 && posOut[b] > v) { posOut[b + 1] = posOut[b]; --b; }
+    posOut[b + 1] = v;
+  }
+  if (hn > 1 && numDistinctOpt == 1 && bestChainEnd == hn - 1) {             // gapless chain (:283-305)
+    long long queryRange = (long long)(H[hn - 1].qpos + H[hn - 1].len) - (long long)H[0].qpos;
+    long long refRange = (long long)(H[hn - 1].pos + H[hn - 1].len) - (long long)H[0].pos;
+    if (queryRange == refRange && queryRange == (long long)maxDist) g.cs = QM_CS_UNGAPPED;
+  }
+  return nStarts;
+}
+
 // One strand: S.rec[0..n) holds every (tid, pos, qpos, len, interval) of the strand's m intervals.  Lane-0 code.
 template <typename SS>
 QM_DEV void sel_strand(SS& S, int s, int n, int m, u32 readLen, int mate, float consensusFraction, bool presorted) {
@@ -123,73 +193,9 @@ QM_DEV void sel_strand(SS& S, int s, int n, int m, u32 readLen, int mate, float 
     while (g1 < n && S.rec[g1].tid == S.rec[g0].tid) ++g1;
     const int na = S.seen[g0];
     if (na >= requiredNumHits || allActive) {
-      // ---- collectHitsSimpleSA, chaining branch (HitManager.cpp:107-307)
-      const SelRec* H = S.rec + g0; const int hn = g1 - g0;
-      double* f = S.f; int* p = S.p;
-      double bestScore = -1.7976931348623157e308; int bestChainEnd = -1; int nEnds = 0;
-      const double avgseed = 31.0;
-      for (int i = 0; i < hn; ++i) {
-        const u32 qposi = H[i].qpos + H[i].len, rposi = H[i].pos + H[i].len;
-        p[i] = i; f[i] = (double)H[i].len;
-        int numRounds = 2;
-        for (int j = i - 1; j >= 0; --j) {
-          const u32 qposj = H[j].qpos + H[j].len, rposj = H[j].pos + H[j].len;
-          const int qdiff = (int)(qposi - qposj), rdiff = (int)(rposi - rposj);
-          // alpha
-          double score = (double)(int)H[i].len;
-          double mindiff = (qdiff < rdiff) ? (double)qdiff : (double)rdiff;
-          double alpha = (score < mindiff) ? score : mindiff;
-          // beta
-          double beta;
-          if (qdiff < 0 || ((qdiff > rdiff ? qdiff : rdiff) > maxDist)) beta = __builtin_inf();
-          else {
-            double l = (double)qdiff - (double)rdiff;
-            int al = (int)(l < 0 ? -l : l);
-            beta = (l == 0) ? 0.0 : (0.01 * avgseed * al + 0.5 * sel_fastlog2((float)al));
-          }
-          double extensionScore = f[j] + alpha - beta;
-          bool extendWithJ = extensionScore > f[i];
-          p[i] = extendWithJ ? j : p[i];
-          f[i] = extendWithJ ? extensionScore : f[i];
-          if (p[i] < i) { numRounds--; if (numRounds <= 0) break; }
-        }
-        if (f[i] > bestScore) { bestScore = f[i]; bestChainEnd = i; nEnds = 0; S.ends[nEnds++] = i; }
-        else if (f[i] == bestScore) S.ends[nEnds++] = i;
-      }
-      // multi-chain backtracking (:206-246)
-      for (int i = 0; i < hn; ++i) S.seen[g0 + i] = 0;
-      int* seen = S.seen + g0;
-      int numDistinctOpt = 0, nStarts = 0;
-      for (int e = 0; e < nEnds; ++e) {
-        int bestChainEndInd = S.ends[e];
-        bool validChain = true;
-        int lastPtr = p[bestChainEndInd];
-        while (lastPtr < bestChainEndInd) {
-          if (seen[bestChainEndInd]) { validChain = false; break; }
-          seen[bestChainEndInd] = 1;
-          bestChainEndInd = lastPtr;
-          lastPtr = p[bestChainEndInd];
-        }
-        if (seen[bestChainEndInd]) validChain = false;
-        if (validChain) { ++numDistinctOpt; S.starts[nStarts++] = lastPtr; }
-      }
-      if (nStarts > 0) {
-        SelGroup g; g.tid = H[0].tid; g.cs = QM_CS_REGULAR; g.score = bestScore; g.npos = nStarts; g.off = np;
-        g.ppos = (int)(H[S.starts[0]].pos - H[S.starts[0]].qpos);               // the first chain's start (:259-262)
-        for (int t = 0; t < nStarts; ++t) P[np + t] = (int)(H[S.starts[t]].pos - H[S.starts[t]].qpos);
-        for (int a = 1; a < nStarts; ++a) {                                      // allPositions is sorted (:272-276)
-          int v = P[np + a], b = a - 1;
-          while (b >= 0 && P[np + b] > v) { P[np + b + 1] = P[np + b]; --b; }
-          P[np + b + 1] = v;
-        }
-        if (hn > 1 && numDistinctOpt == 1 && bestChainEnd == hn - 1) {           // gapless chain (:283-305)
-          long long queryRange = (long long)(H[hn - 1].qpos + H[hn - 1].len) - (long long)H[0].qpos;
-          long long refRange = (long long)(H[hn - 1].pos + H[hn - 1].len) - (long long)H[0].pos;
-          if (queryRange == refRange && queryRange == (long long)readLen) g.cs = QM_CS_UNGAPPED;
-        }
-        np += nStarts;
-        G[ng++] = g;
-      }
+      SelGroup g;
+      const int ns = sel_chain_group(S.rec + g0, g1 - g0, S.f + g0, S.p + g0, S.seen + g0, S.ends + g0, S.starts + g0, (int)readLen, g, P + np);
+      if (ns > 0) { g.off = np; np += ns; G[ng++] = g; }
     }
     (void)mate;
     g0 = g1;
@@ -258,6 +264,59 @@ QM_DEV void sel_wave_sort(SS& S, int n, int m) {
   wave_fence();
 }
 
+// sel_strand for several intervals when the n <= 64 records are already in chain order (sel_wave_sort): the lane that
+// holds a transcript's first record counts its intervals and chains its hits, all transcripts at once; the groups are
+// then packed in transcript order by prefix sums over the lanes.
+template <typename SS>
+QM_DEV void sel_strand_wave(SS& S, int s, int n, int m, u32 readLen, float consensusFraction) {
+#pragma clang fp contract(off)
+  SelGroup* G = S.grp[s]; int* P = S.pos[s];
+  const float requiredFrac = (float)m * consensusFraction;
+  int requiredNumHits = m, maxSlack = 0;
+  if (consensusFraction < 1.0) {
+    int fl = (int)requiredFrac;
+    requiredNumHits = fl > 1 ? fl : 1;
+    maxSlack = m - requiredNumHits;
+  }
+  LV<bool> head;
+  QM_LANES(l) { head[l] = l < n && (l == 0 || S.rec[l].tid != S.rec[l - 1].tid); }
+  const u64 hm = ballot(head);
+  LV<int> g1v, nav; LV<bool> req;
+  QM_LANES(l) {
+    g1v[l] = 0; nav[l] = 0; req[l] = false;
+    if (head[l]) {
+      const u64 rest = l < 63 ? (hm & ~lanemask_lt(l + 1)) : 0ULL;
+      const int g1 = rest ? ctz64(rest) : n;
+      u64 mk[QM_SEL_MAXIV / 64] = {0, 0, 0, 0};
+      for (int i = l; i < g1; ++i) { const u32 iv = S.rec[i].iv; mk[iv >> 6] |= 1ULL << (iv & 63); }
+      g1v[l] = g1; nav[l] = popc64(mk[0]) + popc64(mk[1]) + popc64(mk[2]) + popc64(mk[3]);
+      req[l] = nav[l] >= requiredNumHits;
+    }
+  }
+  const bool allActive = maxSlack > 0 && ballot(req) == 0;   // HitManager.cpp:682-686
+  LV<int> nsv; LV<SelGroup> gv; LV<bool> em;
+  QM_LANES(l) {
+    nsv[l] = 0; em[l] = false;
+    if (head[l] && (req[l] || allActive)) {
+      nsv[l] = sel_chain_group(S.rec + l, g1v[l] - l, S.f + l, S.p + l, S.seen + l, S.ends + l, S.starts + l, (int)readLen, gv[l], S.ends + l);
+      em[l] = nsv[l] > 0;
+    }
+  }
+  const u64 emm = ballot(em);
+  QM_LANES(l) { if (em[l]) S.starts[l] = nsv[l]; }
+  wave_fence();
+  QM_LANES(l) {
+    int tot = 0, mine = 0;
+    for (u64 r = emm; r; r &= r - 1) { const int j = ctz64(r); const int c = S.starts[j]; if (j < l) mine += c; tot += c; }
+    if (em[l]) {
+      SelGroup g = gv[l]; g.off = mine;
+      G[popc64(emm & lanemask_lt(l))] = g;
+      for (int t = 0; t < nsv[l]; ++t) P[mine + t] = S.ends[l + t];
+    }
+    if (l == 0) { S.ngrp[s] = popc64(emm); S.npos[s] = tot; }
+  }
+}
+
 // Stage A, -s variant of hits_to_mappings on scratch S: returns the number of list words in S.out, -1 when S is too small.
 template <typename SS>
 QM_DEV int sel_h2m_on(const DevIndex& ix, const ReadBatch& B, const IntervalList& fwdInts, const IntervalList& rcInts,
@@ -266,26 +325,48 @@ QM_DEV int sel_h2m_on(const DevIndex& ix, const ReadBatch& B, const IntervalList
     const IntervalList& L = s == 0 ? fwdInts : rcInts;
     int n = 0;
     if (L.n > QM_SEL_MAXIV) return -1;
-    for (int ii = 0; ii < L.n; ++ii) {
-      int lb, ub; u32 ln, qp; L.get(ii, lb, ub, ln, qp);
-      const int cnt = ub - lb;
-      if (n + cnt > SS::cap) return -1;
-      for (int base = 0; base < cnt; base += 64) {
-        QM_LANES(l) {
-          int i = base + l;
-          if (i < cnt) {
-            SaInfo e = ix.sainfo[lb + i];
-            SelRec r; r.tid = e.tid; r.pos = (u32)e.pos; r.qpos = qp; r.len = ln; r.iv = (u32)ii;
-            S.rec[n + i] = r;
-          }
+    for (int ii = 0; ii < L.n; ++ii) { int lb, ub; u32 ln, qp; L.get(ii, lb, ub, ln, qp); n += ub - lb; }
+    if (n > SS::cap) return -1;
+    if (n <= 64) {
+      // the usual case: one lane per suffix over all the intervals at once -- one trip to sainfo for the strand
+      LV<int> sa; LV<u32> qv, lv, iv;
+      QM_LANES(l) { sa[l] = -1; qv[l] = 0; lv[l] = 0; iv[l] = 0; }
+      int acc = 0;
+      for (int ii = 0; ii < L.n; ++ii) {
+        int lb, ub; u32 ln, qp; L.get(ii, lb, ub, ln, qp);
+        QM_LANES(l) { if (l >= acc && l < acc + (ub - lb)) { sa[l] = lb + (l - acc); qv[l] = qp; lv[l] = ln; iv[l] = (u32)ii; } }
+        acc += ub - lb;
+      }
+      QM_LANES(l) {
+        if (sa[l] >= 0) {
+          SaInfo e = ix.sainfo[sa[l]];
+          SelRec r; r.tid = e.tid; r.pos = (u32)e.pos; r.qpos = qv[l]; r.len = lv[l]; r.iv = iv[l];
+          S.rec[l] = r;
         }
       }
-      n += cnt;
+    } else {
+      n = 0;
+      for (int ii = 0; ii < L.n; ++ii) {
+        int lb, ub; u32 ln, qp; L.get(ii, lb, ub, ln, qp);
+        const int cnt = ub - lb;
+        for (int base = 0; base < cnt; base += 64) {
+          QM_LANES(l) {
+            int i = base + l;
+            if (i < cnt) {
+              SaInfo e = ix.sainfo[lb + i];
+              SelRec r; r.tid = e.tid; r.pos = (u32)e.pos; r.qpos = qp; r.len = ln; r.iv = (u32)ii;
+              S.rec[n + i] = r;
+            }
+          }
+        }
+        n += cnt;
+      }
     }
     wave_fence();
     const bool presorted = n <= 64 && 2 * n * (int)sizeof(u64) <= (int)sizeof(S.tmp);
     if (presorted && L.n > 0) sel_wave_sort(S, n, L.n);
-    QM_LANES(l) { if (l == 0) { if (L.n > 0) sel_strand(S, s, n, L.n, readLen, mate, B.consensus_fraction, presorted); else { S.ngrp[s] = 0; S.npos[s] = 0; } } }
+    if (presorted && L.n > 1) sel_strand_wave(S, s, n, L.n, readLen, B.consensus_fraction);
+    else QM_LANES(l) { if (l == 0) { if (L.n > 0) sel_strand(S, s, n, L.n, readLen, mate, B.consensus_fraction, presorted); else { S.ngrp[s] = 0; S.npos[s] = 0; } } }
     wave_fence();
   }
   LV<int> nw;
