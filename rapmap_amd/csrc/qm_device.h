@@ -4,7 +4,11 @@
 #include <stddef.h>
 
 #define QMK_BLOCKS_PER_CU 8
-#define QMK_DEFAULT_WPS 5
+// waves per SIMD the register allocator must leave room for, per flavour of the stage-A kernel (reads <= 128 bp)
+#define QMK_DEFAULT_WPS 8
+#define QMK_WPS_PH 6
+#define QMK_WPS_NIP 8
+#define QMK_WPS_PHNIP 6
 
 extern "C" {
 hipError_t qmk_build_sainfo(const int* SA, long long nSA, const int* offsets, long long T, void* out, hipStream_t st);

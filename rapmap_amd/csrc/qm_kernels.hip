@@ -256,9 +256,9 @@ hipError_t qmk_map_reads(const void* ixp, const void* bp, int ns, int grid, int 
   if (ns == 2) {
     switch (F) {
       case 0: QM_LAUNCH(2, QMK_DEFAULT_WPS, 0); break;
-      case QM_F_PH: QM_LAUNCH(2, 4, QM_F_PH); break;
-      case QM_F_NIP: QM_LAUNCH(2, 4, QM_F_NIP); break;
-      case QM_F_PH | QM_F_NIP: QM_LAUNCH(2, 4, QM_F_PH | QM_F_NIP); break;
+      case QM_F_PH: QM_LAUNCH(2, QMK_WPS_PH, QM_F_PH); break;
+      case QM_F_NIP: QM_LAUNCH(2, QMK_WPS_NIP, QM_F_NIP); break;
+      case QM_F_PH | QM_F_NIP: QM_LAUNCH(2, QMK_WPS_PHNIP, QM_F_PH | QM_F_NIP); break;
       case QM_F_SEL: QM_LAUNCH(2, 3, QM_F_SEL); break;
       case QM_F_SEL | QM_F_PH: QM_LAUNCH(2, 3, QM_F_SEL | QM_F_PH); break;
       case QM_F_SEL | QM_F_NIP: QM_LAUNCH(2, 3, QM_F_SEL | QM_F_NIP); break;

@@ -1258,8 +1258,11 @@ QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, con
                      SelScratch* ss = nullptr, SelScratchT<48, 288>* sl = nullptr) {
   const bool paired = B.seq2 != nullptr;
   const int mate = paired ? (int)(read & 1) : 0;
-  int len = pre.len;
-  if (len > 64 * NS) { QM_LANES(l) { if (l == 0) *B.status |= 4; } len = 64 * NS; }
+  const bool tooLong = pre.len > 64 * NS;
+  if (tooLong) { QM_LANES(l) { if (l == 0) *B.status |= 4; } }
+  // uniform(): the length must stay in an SGPR -- merged into the lane-0 branch above it became a per-lane value and
+  // with it every position, mask and branch of the collector moved from the scalar unit to the VALU
+  const int len = uniform(tooLong ? 64 * NS : pre.len);
   unsigned char* fs = M.str[0];
   unsigned char* rs = M.str[1];
   QM_T(6);

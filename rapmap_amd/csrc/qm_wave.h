@@ -56,10 +56,13 @@ QM_DEV u64 atomic_add_u64(u64* p, u64 v) { u64 o = *p; *p = o + v; return o; }
 template <typename T> QM_DEV T uniform(T x) { return x; }
 #else
 QM_DEV u64 ballot(const LV<bool>& b) { return __ballot(b.v[0]); }
-QM_DEV int read_lane(const LV<int>& x, int lane) { return __shfl(x.v[0], lane, 64); }
-QM_DEV u32 read_lane(const LV<u32>& x, int lane) { return (u32)__shfl((int)x.v[0], lane, 64); }
+// the lane index is wave-uniform by construction (one `lane` for the whole wavefront): v_readlane returns the value in
+// an SGPR, so everything computed from it stays on the scalar unit (a __shfl result would drag it onto the VALU)
+QM_DEV int read_lane(const LV<int>& x, int lane) { return __builtin_amdgcn_readlane(x.v[0], __builtin_amdgcn_readfirstlane(lane)); }
+QM_DEV u32 read_lane(const LV<u32>& x, int lane) { return (u32)__builtin_amdgcn_readlane((int)x.v[0], __builtin_amdgcn_readfirstlane(lane)); }
 QM_DEV u64 read_lane(const LV<u64>& x, int lane) {
-  int lo = __shfl((int)(u32)x.v[0], lane, 64), hi = __shfl((int)(u32)(x.v[0] >> 32), lane, 64);
+  const int ln = __builtin_amdgcn_readfirstlane(lane);
+  int lo = __builtin_amdgcn_readlane((int)(u32)x.v[0], ln), hi = __builtin_amdgcn_readlane((int)(u32)(x.v[0] >> 32), ln);
   return ((u64)(u32)hi << 32) | (u32)lo;
 }
 QM_DEV int ctz64(u64 x) { return x ? __builtin_ctzll(x) : 64; }
