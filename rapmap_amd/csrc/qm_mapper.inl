@@ -380,9 +380,11 @@ QM_DEV bool find_kmer(const DevIndex& ix, u64 key, int& lb, int& ub) {
 template <int NS> QM_DEV void or_field(Bits<NS>& b, int p, u64 v) {   // b |= v << p  (v has <= 32 significant bits)
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    int sh = p - 64 * s;
-    if (sh >= 0 && sh < 64) b.w[s] |= v << sh;
-    else if (sh < 0 && sh > -64) b.w[s] |= v >> (-sh);
+    // selects, not branches: p is wave-uniform and this runs on the scalar unit after every probe
+    const int sh = p - 64 * s;
+    const u64 l = v << (sh & 63), r = v >> ((-sh) & 63);
+    const u64 x = (sh >= 0) ? l : r;
+    b.w[s] |= (sh > -64 && sh < 64) ? x : 0ULL;
   }
 }
 
@@ -471,6 +473,8 @@ QM_DEV void setup_strand(const DevIndex& ix, const unsigned char* str, int L, St
       bool inP = p < P;
       e[l] = inP && !nwin && !hom;
       e2[l] = inP && !nwin2 && !hom;
+      // the k-mer word waits in the position's interval slot until the position is probed (~0: an N in the window)
+      if (inP) ((u64*)tab)[p] = nwin ? ~0ULL : w;
     }
     S.E.w[s] = ballot(e); S.E2.w[s] = ballot(e2);
     S.K.w[s] = 0; S.F.w[s] = 0; S.C.w[s] = 0; S.V.w[s] = 0;
@@ -496,16 +500,18 @@ QM_DEV void probe_window(const DevIndex& ix, Strand<NS>& S, int p, int width) {
   if (p + width > S.P) width = S.P - p;
   if (width <= 0) return;
   QM_CNT(3, 1); QM_CNT(4, width); QM_T(4);
-  LV<bool> found;
+  LV<bool> found; LV<u64> keyv;
+  // every lane fetches its word before any lane replaces one by an interval
+  QM_LANES(l) { const int j = l & 31; keyv[l] = j < width ? ((const u64*)S.tab)[p + j] : ~0ULL; }
   QM_LANES(l) {
     int j = l & 31;
     bool isC = l >= 32;
     int pos = p + j;
     bool hit = false; Iv v = {0, 0};
-    if (j < width) {
-      bool nwin, nwin2; int d;
-      u64 key = kmer_at<NS>(S.planes, pos, k, nwin, nwin2, d);
-      if (!nwin) {
+    // positions probed before keep their bits and their interval (the slot no longer holds the word)
+    if (j < width && !S.K.test(pos)) {
+      u64 key = keyv[l];
+      if (key != ~0ULL) {
         if (isC) key = word_rc(key, k);
         hit = find_kmer<F>(ix, key, v.lb, v.ub);
       }
@@ -531,16 +537,16 @@ QM_DEV bool probe_first(const DevIndex& ix, Strand<NS>& S, int p, Iv* rtab0) {
   const int k = ix.k;
   const int last = S.P - 1;
   QM_CNT(3, 1); QM_CNT(4, last != p ? 2 : 1); QM_T(4);
-  LV<bool> found;
+  LV<bool> found; LV<u64> keyv;
+  QM_LANES(l) { const int j = l & 31; keyv[l] = j < 2 ? ((const u64*)S.tab)[j == 0 ? p : last] : ~0ULL; }
   QM_LANES(l) {
     const int j = l & 31;
     const bool isC = l >= 32;
     const int pos = j == 0 ? p : last;
     bool hit = false; Iv v = {0, 0};
     if (j == 0 || (j == 1 && last != p)) {
-      bool nwin, nwin2; int d;
-      u64 key = kmer_at<NS>(S.planes, pos, k, nwin, nwin2, d);
-      if (!nwin) {
+      u64 key = keyv[l];
+      if (key != ~0ULL) {
         if (isC) key = word_rc(key, k);
         hit = find_kmer<F>(ix, key, v.lb, v.ub);
       }
@@ -918,9 +924,16 @@ QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M,
   if (checkRC) {                                        // :258-265
     // the reverse-complemented read is treated as a string of its own (also correct for IUPAC / 'U'
     // characters, where reverseRead() is not the mirror image of the 2-bit encoding)
+    LV<Iv> seed0;                                       // the first probe left this strand's first interval in tab[1][0]
+    QM_LANES(l) { if (l == 0) seed0[l] = M.tab[1][0]; }
+    wave_fence();
     setup_strand<NS>(ix, rcStr, L, R, &M.planes[1][0][0], M.tab[1]);
     R.dollar = false;                                   // reverseRead() maps '$' to 'N'
-    if (seedR) { R.K.w[0] |= 1ULL; if (seedRF) R.F.w[0] |= 1ULL; if (seedRC) R.C.w[0] |= 1ULL; }
+    if (seedR) {
+      R.K.w[0] |= 1ULL; if (seedRF) R.F.w[0] |= 1ULL; if (seedRC) R.C.w[0] |= 1ULL;
+      QM_LANES(l) { if (l == 0) M.tab[1][0] = seed0[l]; }
+      wave_fence();
+    }
     haveR = true;
     get_sa_hits<NS, F>(ix, B, R, rcStr, L, 0, false, 0, 0, rcCov, rcHit, fwdHit, rcInts);
   }
