@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void qm_sel_plan_kernel(PairBatch P, SelBatch 
   sel_flush_counters(sc, uc, P.counters);
 }
 __global__ __launch_bounds__(256) void qm_sel_align_kernel(PairBatch P, SelBatch A) {
-  __shared__ unsigned char qt[4][2 * QM_KSW_MAXLEN];
+  __shared__ unsigned char qt[4][2 * QM_KSW_MAXLEN + QM_KSW_IMG_BYTES];   // per wave: read + target codes, then the two score-phase images
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const unsigned long long nt = *A.ntasks;
   for (unsigned long long t = (unsigned long long)blockIdx.x * 4 + wave; t < nt; t += (unsigned long long)gridDim.x * 4) {
@@ -249,7 +249,8 @@ hipError_t qmk_map_reads(const void* ixp, const void* bp, int ns, int grid, int 
     static int nb = 0;                                                                                          \
     if (nb == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, qm_read_kernel<NS_, WPS_, F_>, 256, 0) != hipSuccess || nb < 1)) \
       nb = WPS_;                                                                                                \
-    long long g = (long long)num_cu * nb;                                                                       \
+    static const char* ov = getenv("QM_BLOCKS_PER_CU");   /* tuning knob: fewer resident blocks than the occupancy allows */ \
+    long long g = (long long)num_cu * ((ov && atoi(ov) > 0 && atoi(ov) < nb) ? atoi(ov) : nb);                  \
     if (g > grid) g = grid;                                                                                     \
     hipLaunchKernelGGL((qm_read_kernel<NS_, WPS_, F_>), dim3((unsigned)g), dim3(256), 0, st, ix, B);            \
   } while (0)
@@ -259,10 +260,10 @@ hipError_t qmk_map_reads(const void* ixp, const void* bp, int ns, int grid, int 
       case QM_F_PH: QM_LAUNCH(2, QMK_WPS_PH, QM_F_PH); break;
       case QM_F_NIP: QM_LAUNCH(2, QMK_WPS_NIP, QM_F_NIP); break;
       case QM_F_PH | QM_F_NIP: QM_LAUNCH(2, QMK_WPS_PHNIP, QM_F_PH | QM_F_NIP); break;
-      case QM_F_SEL: QM_LAUNCH(2, 3, QM_F_SEL); break;
-      case QM_F_SEL | QM_F_PH: QM_LAUNCH(2, 3, QM_F_SEL | QM_F_PH); break;
-      case QM_F_SEL | QM_F_NIP: QM_LAUNCH(2, 3, QM_F_SEL | QM_F_NIP); break;
-      default: QM_LAUNCH(2, 3, QM_F_SEL | QM_F_PH | QM_F_NIP); break;
+      case QM_F_SEL: QM_LAUNCH(2, 4, QM_F_SEL); break;
+      case QM_F_SEL | QM_F_PH: QM_LAUNCH(2, 4, QM_F_SEL | QM_F_PH); break;
+      case QM_F_SEL | QM_F_NIP: QM_LAUNCH(2, 4, QM_F_SEL | QM_F_NIP); break;
+      default: QM_LAUNCH(2, 4, QM_F_SEL | QM_F_PH | QM_F_NIP); break;
     }
   } else {
     switch (F) {

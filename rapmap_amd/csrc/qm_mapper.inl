@@ -1214,7 +1214,7 @@ QM_DEV void dump_intervals(const ReadBatch& B, long long read, int list, const I
 struct SelScratch;
 template <int CAP, int OUTCAP> struct SelScratchT;
 QM_DEV int sel_hits_to_mappings(const DevIndex& ix, const ReadBatch& B, const IntervalList& fwdInts, const IntervalList& rcInts,
-                                u32 readLen, int mate, SelScratch& G, SelScratchT<48, 288>* L, const u64*& src);
+                                u32 readLen, int mate, SelScratch& G, struct SelScratchLds* L, u64* ldsOut, const u64*& src);
 
 // ------------------------------------------------------------------ stage A driver
 // One read: load -> collect -> hits->mappings -> list to global memory.
@@ -1268,7 +1268,7 @@ QM_DEV void pre_chars(const ReadBatch& B, long long read, ReadPre<NS>& P) {
 
 template <int NS, int F>
 QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, const ReadPre<NS>& pre, WaveMem<NS>& M, u64* gscr, WaveAlloc& wa,
-                     SelScratch* ss = nullptr, SelScratchT<48, 288>* sl = nullptr) {
+                     SelScratch* ss = nullptr, struct SelScratchLds* sl = nullptr) {
   const bool paired = B.seq2 != nullptr;
   const int mate = paired ? (int)(read & 1) : 0;
   const bool tooLong = pre.len > 64 * NS;
@@ -1313,7 +1313,7 @@ QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, con
   int n = 0;
   const u64* listSrc = nullptr;
   if (F & QM_F_SEL) {                  // -s: chaining + multi-position groups (qm_sel.inl)
-    n = sel_hits_to_mappings(ix, B, fi, ri, (u32)len, mate, *ss, sl, listSrc);
+    n = sel_hits_to_mappings(ix, B, fi, ri, (u32)len, mate, *ss, sl, &M.buf[0][0], listSrc);
   } else if (bound > QM_GCAP) {        // only reachable with max_interval > 1000
     QM_LANES(l) { if (l == 0) *B.status |= 2; }
   } else {

@@ -18,19 +18,31 @@
 enum : int { QM_CS_PERFECT = 0, QM_CS_UNGAPPED = 1, QM_CS_REGULAR = 4 };   // rapmap::utils::ChainStatus
 
 struct SelRec { u32 tid, pos, qpos, len, iv; };
-struct SelGroup { u32 tid; int cs; double score; int npos, off, ppos; };   // ppos: the hit's own position (QuasiAlignment::pos)
+struct SelGroup { u32 tid; int ppos; double score; short npos, off; int cs; };   // ppos: the hit's own position (QuasiAlignment::pos); 24 bytes
 template <int CAP, int OUTCAP>
-struct SelScratchT {                // lane 0's working set for one read
+struct SelScratchT {                // working set of one read
   static constexpr int cap = CAP, outcap = OUTCAP;
   SelRec rec[CAP], tmp[CAP];
   double f[CAP]; int p[CAP]; int seen[CAP]; int ends[CAP]; int starts[CAP];
   SelGroup grp[2][CAP]; int pos[2][CAP]; int ngrp[2], npos[2];
   u64 out[OUTCAP];
+  QM_DEV SelGroup* grpp(int s) { return grp[s]; }
 };
 struct SelScratch : SelScratchT<QM_SEL_CAP, QM_CHUNK> {};   // per wave, global memory: the general case
 #define QM_SEL_SMALL 48
-typedef SelScratchT<QM_SEL_SMALL, 6 * QM_SEL_SMALL> SelScratchLds;   // ~8 KB of LDS: almost every read fits, and lane 0's serial
-                                                                     // chaining then runs out of LDS instead of global memory
+// The LDS edition (almost every read fits): 4.8 KB per wave so that four waves per SIMD stay resident.  The sort keys
+// share their bytes with the second strand's groups (written only after that strand's sort), and the read's list is
+// assembled in the sort buffers of WaveMem, which the -s path does not use otherwise (`out`, 3 * QM_CAP words).
+struct SelScratchLds {
+  static constexpr int cap = QM_SEL_SMALL, outcap = 3 * QM_CAP;
+  SelRec rec[QM_SEL_SMALL];
+  double f[QM_SEL_SMALL]; int p[QM_SEL_SMALL]; int seen[QM_SEL_SMALL]; int ends[QM_SEL_SMALL]; int starts[QM_SEL_SMALL];
+  SelGroup grp0[QM_SEL_SMALL];
+  union { SelGroup grp1[QM_SEL_SMALL]; SelRec tmp[QM_SEL_SMALL]; };
+  int pos[2][QM_SEL_SMALL]; int ngrp[2], npos[2];
+  u64* out;
+  QM_DEV SelGroup* grpp(int s) { return s == 0 ? grp0 : grp1; }
+};
 QM_DEV const u64* sel_out(const SelScratch& S) { return S.out; }
 
 QM_DEV u64 sel_header(u32 tid, bool primaryRC, int cs, int nP, int nO) {
@@ -121,7 +133,7 @@ QM_DEV int sel_chain_group(const SelRec* H, int hn, double* f, int* p, int* seen
     if (validChain) { ++numDistinctOpt; starts[nStarts++] = lastPtr; }
   }
   if (nStarts == 0) return 0;
-  g.tid = H[0].tid; g.cs = QM_CS_REGULAR; g.score = bestScore; g.npos = nStarts; g.off = 0;
+  g.tid = H[0].tid; g.cs = QM_CS_REGULAR; g.score = bestScore; g.npos = (short)nStarts; g.off = 0;
   g.ppos = (int)(H[starts[0]].pos - H[starts[0]].qpos);                      // the first chain's start (:259-262)
   for (int t = 0; t < nStarts; ++t) {                                        // allPositions is sorted (:272-276)
     const int v = (int)(H[starts[t]].pos - H[starts[t]].qpos);
@@ -142,7 +154,7 @@ template <typename SS>
 QM_DEV void sel_strand(SS& S, int s, int n, int m, u32 readLen, int mate, float consensusFraction, bool presorted) {
 #pragma clang fp contract(off)
   int ng = 0, np = 0;
-  SelGroup* G = S.grp[s]; int* P = S.pos[s];
+  SelGroup* G = S.grpp(s); int* P = S.pos[s];
   if (m == 1) {
     // collectFromSingleInterval + mergeUnique (HitManager.cpp:716-807): hitPos = pos - queryPos, sorted by (tid, hitPos)
     if (!presorted) sel_sort(S.rec, S.tmp, n, [](const SelRec& a, const SelRec& b) {
@@ -150,7 +162,7 @@ QM_DEV void sel_strand(SS& S, int s, int n, int m, u32 readLen, int mate, float 
     for (int i = 0; i < n; ++i) {
       const SelRec& r = S.rec[i];
       if (ng == 0 || G[ng - 1].tid != r.tid) {
-        SelGroup g; g.tid = r.tid; g.cs = r.len == readLen ? QM_CS_PERFECT : QM_CS_REGULAR; g.score = -1.7976931348623157e308; g.npos = 0; g.off = np;
+        SelGroup g; g.tid = r.tid; g.cs = r.len == readLen ? QM_CS_PERFECT : QM_CS_REGULAR; g.score = -1.7976931348623157e308; g.npos = 0; g.off = (short)np;
         g.ppos = (int)(r.pos - r.qpos);
         G[ng++] = g;
       }
@@ -195,7 +207,7 @@ QM_DEV void sel_strand(SS& S, int s, int n, int m, u32 readLen, int mate, float 
     if (na >= requiredNumHits || allActive) {
       SelGroup g;
       const int ns = sel_chain_group(S.rec + g0, g1 - g0, S.f + g0, S.p + g0, S.seen + g0, S.ends + g0, S.starts + g0, (int)readLen, g, P + np);
-      if (ns > 0) { g.off = np; np += ns; G[ng++] = g; }
+      if (ns > 0) { g.off = (short)np; np += ns; G[ng++] = g; }
     }
     (void)mate;
     g0 = g1;
@@ -210,17 +222,18 @@ template <typename SS>
 QM_DEV int sel_emit(SS& S) {
   int i = 0, j = 0, o = 0;
   const int nf = S.ngrp[0], nr = S.ngrp[1];
+  const SelGroup* GF = S.grpp(0); const SelGroup* GR = S.grpp(1);
   while (i < nf || j < nr) {
     const bool haveF = i < nf, haveR = j < nr;
-    const u32 tf = haveF ? S.grp[0][i].tid : 0xffffffffu, tr = haveR ? S.grp[1][j].tid : 0xffffffffu;
+    const u32 tf = haveF ? GF[i].tid : 0xffffffffu, tr = haveR ? GR[j].tid : 0xffffffffu;
     const SelGroup* pg; const SelGroup* og = nullptr; bool prc; int ps, os = 0;
-    if (haveF && (!haveR || tf < tr)) { pg = &S.grp[0][i]; prc = false; ps = 0; ++i; }
-    else if (haveR && (!haveF || tr < tf)) { pg = &S.grp[1][j]; prc = true; ps = 1; ++j; }
+    if (haveF && (!haveR || tf < tr)) { pg = &GF[i]; prc = false; ps = 0; ++i; }
+    else if (haveR && (!haveF || tr < tf)) { pg = &GR[j]; prc = true; ps = 1; ++j; }
     else {
       // same transcript on both strands: the better chain score survives, forward on ties (stable inplace_merge)
-      const bool rcFirst = S.grp[1][j].score > S.grp[0][i].score;
-      if (rcFirst) { pg = &S.grp[1][j]; og = &S.grp[0][i]; prc = true; ps = 1; os = 0; }
-      else { pg = &S.grp[0][i]; og = &S.grp[1][j]; prc = false; ps = 0; os = 1; }
+      const bool rcFirst = GR[j].score > GF[i].score;
+      if (rcFirst) { pg = &GR[j]; og = &GF[i]; prc = true; ps = 1; os = 0; }
+      else { pg = &GF[i]; og = &GR[j]; prc = false; ps = 0; os = 1; }
       ++i; ++j;
     }
     const int nP = pg->npos, nO = og ? og->npos : 0;
@@ -270,7 +283,7 @@ QM_DEV void sel_wave_sort(SS& S, int n, int m) {
 template <typename SS>
 QM_DEV void sel_strand_wave(SS& S, int s, int n, int m, u32 readLen, float consensusFraction) {
 #pragma clang fp contract(off)
-  SelGroup* G = S.grp[s]; int* P = S.pos[s];
+  SelGroup* G = S.grpp(s); int* P = S.pos[s];
   const float requiredFrac = (float)m * consensusFraction;
   int requiredNumHits = m, maxSlack = 0;
   if (consensusFraction < 1.0) {
@@ -309,7 +322,7 @@ QM_DEV void sel_strand_wave(SS& S, int s, int n, int m, u32 readLen, float conse
     int tot = 0, mine = 0;
     for (u64 r = emm; r; r &= r - 1) { const int j = ctz64(r); const int c = S.starts[j]; if (j < l) mine += c; tot += c; }
     if (em[l]) {
-      SelGroup g = gv[l]; g.off = mine;
+      SelGroup g = gv[l]; g.off = (short)mine;
       G[popc64(emm & lanemask_lt(l))] = g;
       for (int t = 0; t < nsv[l]; ++t) P[mine + t] = S.ends[l + t];
     }
@@ -377,9 +390,9 @@ QM_DEV int sel_h2m_on(const DevIndex& ix, const ReadBatch& B, const IntervalList
 
 // LDS scratch first (small reads: nearly all), the wave's global scratch otherwise; status bit 3 when even that overflows.
 QM_DEV int sel_hits_to_mappings(const DevIndex& ix, const ReadBatch& B, const IntervalList& fwdInts, const IntervalList& rcInts,
-                                u32 readLen, int mate, SelScratch& G, SelScratchLds* L, const u64*& src) {
+                                u32 readLen, int mate, SelScratch& G, SelScratchLds* L, u64* ldsOut, const u64*& src) {
   int n = -1;
-  if (L) { n = sel_h2m_on(ix, B, fwdInts, rcInts, readLen, mate, *L); src = L->out; }
+  if (L) { L->out = ldsOut; n = sel_h2m_on(ix, B, fwdInts, rcInts, readLen, mate, *L); src = ldsOut; }
   if (n < 0) { n = sel_h2m_on(ix, B, fwdInts, rcInts, readLen, mate, static_cast<SelScratchT<QM_SEL_CAP, QM_CHUNK>&>(G)); src = G.out; }
   if (n < 0) { QM_LANES(l) { if (l == 0) *B.status |= 8; } n = 0; }
   return n;
@@ -575,25 +588,42 @@ QM_DEV int sel_ksw_extz2_ring(unsigned char* mem, int qlen, const unsigned char*
 // (the ring above, held in registers), so one anti-diagonal costs a few dozen wave instructions instead of a serial
 // walk over up to 64 bytes; the left neighbour's previous-round x / v and H come over a lane shuffle.  Wave-uniform
 // control, all lanes must call it together.  Bands of at most 33 (callers fall back to the thread version otherwise).
+// img: QM_KSW_IMG_BYTES of scratch shared by the lanes.  The score phase of the original reads the reversed query and the
+// target out of one zeroed block (sf = target + zeros up to tlen16, directly followed by qr = reversed query + zeros) and
+// its 16-wide vectors run past both ends of the band; the two images below hold exactly what those reads return:
+//   QX[16 + i] = query[i] (0 <= i < qlen), zero before and after    -- the query character of cell (r, t) is QX[16 + r - t]
+//   TX[t] = target[t] (t < tlen), 0 (t < tlen16), query[qlen - 1 - (t - tlen16)] beyond -- a column's target character
+#define QM_KSW_IMG_BYTES (2 * QM_KSW_MAXLEN + 80)
 QM_DEV int sel_ksw_extz2_wave(int qlen, const unsigned char* query, int tlen, const unsigned char* target,
-                              const signed char* mat, int q, int e, int w) {
+                              const signed char* mat, int q, int e, int w, unsigned char* img) {
   const int NEG = -0x40000000;
   int mqe = NEG, mte = NEG;
   const int m = 5;
   if (qlen <= 0 || tlen <= 0) return NEG;
   const int qe = q + e;
   const int tlen16 = (tlen + 15) / 16 * 16;
+  unsigned char* QX = img; unsigned char* TX = img + QM_KSW_MAXLEN + 40;
+  for (int b0 = 0; b0 < tlen16 + 16 || b0 < qlen + 32; b0 += 64) {
+    QM_LANES(l) {
+      const int i = b0 + l;
+      if (i < qlen + 32) QX[i] = (i >= 16 && i < 16 + qlen) ? query[i - 16] : 0;
+      if (i < tlen16 + 16) {
+        const int j = i - tlen16;
+        TX[i] = i < tlen ? target[i] : (i < tlen16 ? 0 : (j < qlen ? query[qlen - 1 - j] : 0));
+      }
+    }
+  }
+  wave_fence();
   int min_sc = mat[1];
   for (int t = 1; t < m * m; ++t) min_sc = min_sc < mat[t] ? min_sc : mat[t];
   if (-min_sc > 2 * (q + e)) return NEG;
   const int sc_mch = (unsigned char)mat[0], sc_mis = (unsigned char)mat[1], sc_N = (unsigned char)mat[m * m - 1], m1 = m - 1;
   const int qe2 = (unsigned char)((q + e) * 2), max_sc_v = (unsigned char)(mat[0] + (q + e) * 2), qv = (unsigned char)q;
-  LV<int> col, U, V, X, Y, S, H;
-  QM_LANES(l) { col[l] = -1; U[l] = 0; V[l] = 0; X[l] = 0; Y[l] = 0; S[l] = 0; H[l] = NEG; }
+  LV<int> col, U, V, X, Y, S, H, TC;
+  QM_LANES(l) { col[l] = -1; U[l] = 0; V[l] = 0; X[l] = 0; Y[l] = 0; S[l] = 0; H[l] = NEG; TC[l] = 0; }
   int last_st = -1, last_en = -1;
   for (int r = 0; r < qlen + tlen - 1; ++r) {
     int st = 0, en = tlen - 1;
-    const int qoff = qlen - 1 - r;
     if (st < r - qlen + 1) st = r - qlen + 1;
     if (en > r) en = r;
     if (st < (r - w + 1) >> 1) st = (r - w + 1) >> 1;
@@ -615,16 +645,10 @@ QM_DEV int sel_ksw_extz2_wave(int qlen, const unsigned char* query, int tlen, co
       const int t = st + ((l - st) & 63);                        // this lane's column in the window [st, st + 63]
       // touch: the diagonal cell (en >= r), the score phase and the core all make the slot hold column t
       const bool needs = (t <= en) || (t >= st0 && t <= smax) || (en >= r && t == r);
-      if (needs && col[l] != t) { col[l] = t; U[l] = 0; V[l] = 0; X[l] = 0; Y[l] = 0; S[l] = 0; H[l] = NEG; }
+      if (needs && col[l] != t) { col[l] = t; U[l] = 0; V[l] = 0; X[l] = 0; Y[l] = 0; S[l] = 0; H[l] = NEG; TC[l] = TX[t]; }
       if (en >= r && t == r) { Y[l] = 0; U[l] = r ? qv : 0; }
       if (t >= st0 && t <= smax) {
-        // the original's memory image: sf = target + zeros up to tlen16, directly followed by qr = reversed query + zeros
-        const int qi = qoff + t;
-        const int sv = (qi >= 0 && qi < qlen) ? query[qlen - 1 - qi] : 0;
-        int sq;
-        if (t < tlen) sq = target[t];
-        else if (t < tlen16) sq = 0;
-        else { const int j = t - tlen16; sq = (j < qlen) ? query[qlen - 1 - j] : 0; }
+        const int sv = QX[16 + r - t], sq = TC[l];
         int tmp = (sq == sv) ? sc_mch : sc_mis;
         if (sq == m1 || sv == m1) tmp = sc_N;
         S[l] = tmp;
@@ -740,7 +764,7 @@ QM_DEV int sel_aln_score(const SelBatch& A, unsigned char* kmem, int pos, const 
         for (int j = 0; j < 5; ++j) mat[20 + j] = 0;
 #ifdef QM_EMU
         if (A.emu_wave && A.bandwidth >= 0 && A.bandwidth <= 33)
-          s = sel_ksw_extz2_wave(rlen, qb, (int)tlen1, tb, mat, (signed char)A.gap_open, (signed char)A.gap_extend, A.bandwidth);
+          { static thread_local unsigned char img[QM_KSW_IMG_BYTES]; s = sel_ksw_extz2_wave(rlen, qb, (int)tlen1, tb, mat, (signed char)A.gap_open, (signed char)A.gap_extend, A.bandwidth, img); }
         else
 #endif
         if (A.bandwidth >= 0 && A.bandwidth <= 33 && A.ring)
@@ -1075,7 +1099,7 @@ QM_DEV void sel_task_align(const PairBatch& P, const SelBatch& A, const SelTask&
   a = a < 0 ? -a : a; b = b > 0 ? -b : b;
   for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) mat[i * 5 + j] = (signed char)(i == j ? a : b); mat[i * 5 + 4] = 0; }
   for (int j = 0; j < 5; ++j) mat[20 + j] = 0;
-  const int s = sel_ksw_extz2_wave(t.rlen, qb, t.tlen1, tb, mat, (signed char)A.gap_open, (signed char)A.gap_extend, A.bandwidth);
+  const int s = sel_ksw_extz2_wave(t.rlen, qb, t.tlen1, tb, mat, (signed char)A.gap_open, (signed char)A.gap_extend, A.bandwidth, qt + 2 * QM_KSW_MAXLEN);
   QM_LANES(l) { if (l == 0) A.tsc[t.gslot] = s; }
   wave_fence();
 }

@@ -95,7 +95,7 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
       std::vector<SelTask> tasks(2 * (size_t)toff[nunits] + 2); u64 ntasks = 0;
       A.tref = tref.data(); A.tcix = tcix.data(); A.tasks = tasks.data(); A.ntasks = &ntasks;
       for (long long u = 0; u < nunits; ++u) sel_unit_plan(P, A, u, &uc);
-      std::vector<unsigned char> qt(2 * QM_KSW_MAXLEN);
+      std::vector<unsigned char> qt(2 * QM_KSW_MAXLEN + QM_KSW_IMG_BYTES);
       for (u64 t = 0; t < ntasks; ++t) sel_task_align(P, A, tasks[t], qt.data());
       for (long long u = 0; u < nunits; ++u) hc[u] = (u32)sel_unit_finish(P, A, u, &uc);
     } else {
