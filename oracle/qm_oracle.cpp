@@ -1440,5 +1440,14 @@ int qo_hash_find(void* hidx, uint64_t key, int32_t* lbub) {
   if (!it) return 0; lbub[0] = it->lb; lbub[1] = it->ub; return 1;
 }
 uint64_t qo_rank(void* hidx, uint64_t p) { Work w; return ((const OIndex*)hidx)->rank(p, w); }
+// the ksw2 extension kernel alone (nt4 codes in, max(mqe, mte) out) -- for differential tests of the device kernels
+int qo_ksw_extz2(int qlen, const uint8_t* query, int tlen, const uint8_t* target, int a, int b, int q, int e, int w) {
+  int8_t mat[25];
+  a = a < 0 ? -a : a; b = b > 0 ? -b : b;
+  for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) mat[i * 5 + j] = (int8_t)(i == j ? a : b); mat[i * 5 + 4] = 0; }
+  for (int j = 0; j < 5; ++j) mat[20 + j] = 0;
+  KswOut ez = kswExtz2(qlen, query, tlen, target, 5, mat, (int8_t)q, (int8_t)e, w, nullptr);
+  return ez.mqe > ez.mte ? ez.mqe : ez.mte;
+}
 
 }  // extern "C"

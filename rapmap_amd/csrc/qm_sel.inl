@@ -619,9 +619,10 @@ QM_DEV int sel_ksw_extz2_wave(int qlen, const unsigned char* query, int tlen, co
   if (-min_sc > 2 * (q + e)) return NEG;
   const int sc_mch = (unsigned char)mat[0], sc_mis = (unsigned char)mat[1], sc_N = (unsigned char)mat[m * m - 1], m1 = m - 1;
   const int qe2 = (unsigned char)((q + e) * 2), max_sc_v = (unsigned char)(mat[0] + (q + e) * 2), qv = (unsigned char)q;
-  LV<int> col, U, V, X, Y, S, H, TC;
-  QM_LANES(l) { col[l] = -1; U[l] = 0; V[l] = 0; X[l] = 0; Y[l] = 0; S[l] = 0; H[l] = NEG; TC[l] = 0; }
+  LV<int> U, V, X, Y, S, H, TC;
+  QM_LANES(l) { U[l] = 0; V[l] = 0; X[l] = 0; Y[l] = 0; S[l] = 0; H[l] = NEG; TC[l] = 0; }
   int last_st = -1, last_en = -1;
+  int hb = NEG;                                                  // H of column st - 1 (left of the window)
   for (int r = 0; r < qlen + tlen - 1; ++r) {
     int st = 0, en = tlen - 1;
     if (st < r - qlen + 1) st = r - qlen + 1;
@@ -633,19 +634,24 @@ QM_DEV int sel_ksw_extz2_wave(int qlen, const unsigned char* query, int tlen, co
     st = st / 16 * 16; en = (en + 16) / 16 * 16 - 1;
     const int smax = st0 + ((en0 - st0) / 16) * 16 + 15;       // last column the score phase writes
     // boundary values for column st: x / v of column st - 1 as left by the last round that computed it
+    // (lane l always holds column t(l) of the current window, all-zero if nobody computed that column yet)
     int x1b = 0, v1b = 0;
     if (st > 0) {
-      if (st - 1 >= last_st && st - 1 <= last_en) {
-        const int kk = (st - 1) & 63;
-        if (read_lane(col, kk) == st - 1) { x1b = read_lane(X, kk); v1b = read_lane(V, kk); }
-      }
+      if (st - 1 >= last_st && st - 1 <= last_en) { const int kk = (st - 1) & 63; x1b = read_lane(X, kk); v1b = read_lane(V, kk); }
     } else { x1b = 0; v1b = r ? qv : 0; }
     LV<int> xo, ho;
+    // the window [st, st + 63] moved (or first round): lanes whose column changed start over as a column nobody has
+    // computed yet -- all-zero state, exactly what the original finds in its zero-initialised arrays
+    if (st != last_st) {
+      hb = (st > 0 && last_st >= 0) ? read_lane(H, (st - 1) & 63) : NEG;
+      QM_LANES(l) {
+        const int t = st + ((l - st) & 63);
+        const int told = last_st < 0 ? -1 : last_st + ((l - last_st) & 63);
+        if (told != t) { U[l] = 0; V[l] = 0; X[l] = 0; Y[l] = 0; S[l] = 0; H[l] = NEG; TC[l] = t < tlen16 + 16 ? TX[t] : 0; }
+      }
+    }
     QM_LANES(l) {
       const int t = st + ((l - st) & 63);                        // this lane's column in the window [st, st + 63]
-      // touch: the diagonal cell (en >= r), the score phase and the core all make the slot hold column t
-      const bool needs = (t <= en) || (t >= st0 && t <= smax) || (en >= r && t == r);
-      if (needs && col[l] != t) { col[l] = t; U[l] = 0; V[l] = 0; X[l] = 0; Y[l] = 0; S[l] = 0; H[l] = NEG; TC[l] = TX[t]; }
       if (en >= r && t == r) { Y[l] = 0; U[l] = r ? qv : 0; }
       if (t >= st0 && t <= smax) {
         const int sv = QX[16 + r - t], sq = TC[l];
@@ -653,19 +659,18 @@ QM_DEV int sel_ksw_extz2_wave(int qlen, const unsigned char* query, int tlen, co
         if (sq == m1 || sv == m1) tmp = sc_N;
         S[l] = tmp;
       }
-      xo[l] = X[l] | (V[l] << 8) | ((col[l] & 0x7fff) << 16); ho[l] = H[l];   // x, v and the column id in one word
+      xo[l] = X[l] | (V[l] << 8); ho[l] = H[l];                  // x and v in one word
     }
     // previous-round x, v, H of the left neighbour column (lane l - 1)
-    LV<int> xl, vl, cl, hl;
+    LV<int> xl, vl, hl;
     lane_rotate_up(xo, xl); lane_rotate_up(ho, hl);
-    QM_LANES(l) { cl[l] = xl[l] >> 16; vl[l] = (xl[l] >> 8) & 0xff; xl[l] = xl[l] & 0xff; }
+    QM_LANES(l) { vl[l] = xl[l] >> 8; xl[l] = xl[l] & 0xff; }
     QM_LANES(l) {
       const int t = st + ((l - st) & 63);
       if (t <= en) {
         int xt1, vt1;
         if (t == st) { xt1 = x1b; vt1 = v1b; }
-        else if (cl[l] == ((t - 1) & 0x7fff)) { xt1 = xl[l]; vt1 = vl[l]; }
-        else { xt1 = 0; vt1 = 0; }
+        else { xt1 = xl[l]; vt1 = vl[l]; }
         int z = (S[l] + qe2) & 0xff;
         int a = (xt1 + vt1) & 0xff;
         const int ut = U[l];
@@ -683,7 +688,7 @@ QM_DEV int sel_ksw_extz2_wave(int qlen, const unsigned char* query, int tlen, co
       // H (exact max): H[en0] from the left neighbour's previous value, the other band cells accumulate v
       if (r > 0) {
         if (t == en0) {
-          if (en0 > 0) H[l] = ((cl[l] == ((en0 - 1) & 0x7fff)) ? hl[l] : NEG) + U[l] - qe;
+          if (en0 > 0) H[l] = (en0 > st ? hl[l] : hb) + U[l] - qe;
           else H[l] = H[l] + V[l] - qe;
         } else if (t >= st0 && t < en0) H[l] += V[l] - qe;
       } else if (t == 0) H[l] = V[l] - qe - qe;

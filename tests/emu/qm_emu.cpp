@@ -184,6 +184,17 @@ void* qe_ph_create(const unsigned long long* words, const unsigned long long* ra
 
 // host-side flattening for the emulation only (the product does this on the GPU,
 // rapmap_amd/csrc/qm_kernels.hip: build_sainfo_kernel / build_slots_kernel)
+// the three ksw2 kernels of qm_sel.inl on their own: variant 0 literal, 1 ring (bands <= 33), 2 one wavefront per alignment
+int qe_ksw(int variant, int qlen, const unsigned char* query, int tlen, const unsigned char* target, int a, int b, int q, int e, int w) {
+  signed char mat[25];
+  a = a < 0 ? -a : a; b = b > 0 ? -b : b;
+  for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) mat[i * 5 + j] = (signed char)(i == j ? a : b); mat[i * 5 + 4] = 0; }
+  for (int j = 0; j < 5; ++j) mat[20 + j] = 0;
+  std::vector<unsigned char> mem(QM_KSW_BYTES + 64), ring(QM_KSW_RING_BYTES + 64), img(QM_KSW_IMG_BYTES + 64);
+  if (variant == 0) return sel_ksw_extz2(mem.data(), qlen, query, tlen, target, mat, q, e, w);
+  if (variant == 1) return sel_ksw_extz2_ring(ring.data(), qlen, query, tlen, target, mat, q, e, w);
+  return sel_ksw_extz2_wave(qlen, query, tlen, target, mat, q, e, w, img.data());
+}
 unsigned long long qe_slots_cap(long long nkeys) { return bucket_count(nkeys); }   // buckets of 64 bytes
 void qe_flatten(const int* SA, long long nSA, const int* offsets, long long T, void* sainfo_out,
                 const unsigned long long* keys, const int* lb, const int* ub, long long K, void* slots_out,

@@ -1,0 +1,85 @@
+"""The three ksw2 extension kernels of the device source (rapmap_amd/csrc/qm_sel.inl: literal, 64-column ring, one
+wavefront per alignment -- run here through the lane emulation) against the oracle's restatement of ksw_extz2_sse41
+(oracle/qm_oracle.cpp: kswExtz2, pinned on the reference's `-s` SAM fixtures), on random and adversarial inputs:
+every target length 1..160 (all residues mod 16: the SSE vectors' padding lanes and the band's last rounds differ),
+indels, N's, short and long queries, several bands and scoring schemes."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, os.path.join(HERE, "emu"))
+from oracle import oracle  # noqa: E402
+import emu  # noqa: E402
+
+
+def _mutate(rng, q, tlen, sub=0.05, indel=0.02, nfrac=0.01):
+    out = []
+    i = 0
+    while len(out) < tlen:
+        r = rng.random()
+        if r < indel:            # insertion in the target
+            out.append(rng.integers(0, 4))
+        elif r < 2 * indel:      # deletion
+            i += 1
+        else:
+            c = q[i % len(q)]
+            if rng.random() < sub:
+                c = rng.integers(0, 4)
+            if rng.random() < nfrac:
+                c = 4
+            out.append(c); i += 1
+    return np.array(out[:tlen], dtype=np.uint8)
+
+
+def _cases(seed, n):
+    rng = np.random.default_rng(seed)
+    for it in range(n):
+        qlen = int(rng.integers(1, 141))
+        tlen = int(rng.integers(1, 161)) if it % 3 else min(160, qlen + 20)
+        q = rng.integers(0, 4, qlen).astype(np.uint8)
+        if rng.random() < 0.1:
+            q[rng.integers(0, qlen)] = 4
+        t = _mutate(rng, q, tlen) if rng.random() < 0.85 else rng.integers(0, 5, tlen).astype(np.uint8)
+        yield q, t
+
+
+SCHEMES = [(2, -4, 4, 2, 15), (2, -4, 4, 2, 5), (1, -1, 1, 1, 15), (2, -6, 5, 3, 33), (2, -4, 4, 2, 0), (4, -4, 6, 2, 20)]
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_ksw_variants_match_oracle(scheme):
+    a, b, q_, e_, w = scheme
+    ol = oracle._lib(); el = emu._lib()
+    ol.qo_ksw_extz2.restype = C.c_int; el.qe_ksw.restype = C.c_int
+    bad = []
+    n = 0
+    for q, t in _cases(1234 + w, 500):
+        args = (len(q), q.ctypes.data_as(C.c_void_p), len(t), t.ctypes.data_as(C.c_void_p), a, b, q_, e_, w)
+        ref = ol.qo_ksw_extz2(*args)
+        for v in (0, 1, 2):
+            got = el.qe_ksw(v, *args)
+            if got != ref:
+                bad.append((v, len(q), len(t), ref, got))
+        n += 1
+    assert not bad, "%d mismatches of %d cases, first: %r" % (len(bad), n, bad[:5])
+
+
+def test_ksw_every_target_length():
+    """query 100, perfect and 1-error targets of every length 1..160 (band 15): the rounds where the band has shrunk to
+    its last cells sit at a different place of the 16-byte vectors for every residue of tlen mod 16"""
+    ol = oracle._lib(); el = emu._lib()
+    ol.qo_ksw_extz2.restype = C.c_int; el.qe_ksw.restype = C.c_int
+    rng = np.random.default_rng(7)
+    for tlen in range(1, 161):
+        q = rng.integers(0, 4, 100).astype(np.uint8)
+        t = np.resize(q, tlen).copy()
+        if tlen > 3:
+            t[tlen // 2] ^= 1
+        args = (100, q.ctypes.data_as(C.c_void_p), tlen, t.ctypes.data_as(C.c_void_p), 2, -4, 4, 2, 15)
+        ref = ol.qo_ksw_extz2(*args)
+        for v in (0, 1, 2):
+            assert el.qe_ksw(v, *args) == ref, (v, tlen)
