@@ -241,7 +241,7 @@ def main():
                 traffic = None
         out["roofline"] = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                           "kernel": "%s (stage A: one wavefront per read)" % ("qm_read_kernel<2,3,4>" if args.sel_aln else ("qm_read_kernel<2,4,1>" if args.perfect_hash else "qm_read_kernel<2,5,0>")),
+                           "kernel": "%s (stage A: one wavefront per read)" % ("qm_read_kernel<2,4,%d>" % (5 if args.perfect_hash else 4) if args.sel_aln else ("qm_read_kernel<2,6,1>" if args.perfect_hash else "qm_read_kernel<2,8,0>")),
                            "kernel_ms": round(avg_kernel_ms, 3),
                            "algorithmic_bytes_per_pair": round(bpp, 1),
                            "per_pair_counters": {kk: round(v, 2) for kk, v in w.items()},
