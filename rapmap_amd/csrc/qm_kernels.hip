@@ -131,7 +131,16 @@ __global__ __launch_bounds__(256) void qm_sel_plan_kernel(PairBatch P, SelBatch 
   if (u < P.n) sel_unit_plan(P, A, u, &uc);
   sel_flush_counters(sc, uc, P.counters);
 }
+// one row of 16 lanes per ksw2 alignment, four alignments per wavefront (sel_ksw_extz2_rows); QM_SEL_ALIGN=wave in the
+// environment of the host library selects the older one-wavefront-per-alignment kernel below (A/B runs)
 __global__ __launch_bounds__(256) void qm_sel_align_kernel(PairBatch P, SelBatch A) {
+  __shared__ KswRow rows[4][4];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned long long nt = *A.ntasks;
+  for (unsigned long long t = ((unsigned long long)blockIdx.x * 4 + wave) * 4; t < nt; t += (unsigned long long)gridDim.x * 16)
+    sel_tasks_align_rows(P, A, t, nt, rows[wave]);
+}
+__global__ __launch_bounds__(256) void qm_sel_align_wave_kernel(PairBatch P, SelBatch A) {
   __shared__ unsigned char qt[4][2 * QM_KSW_MAXLEN + QM_KSW_IMG_BYTES];   // per wave: read + target codes, then the two score-phase images
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const unsigned long long nt = *A.ntasks;
@@ -303,7 +312,9 @@ hipError_t qmk_sel_three(const void* pp, const void* ap, int num_cu, hipStream_t
   if (P.n <= 0) return hipSuccess;
   const unsigned nb = (unsigned)((P.n + 255) / 256);
   hipLaunchKernelGGL(qm_sel_plan_kernel, dim3(nb), dim3(256), 0, st, P, A);
-  hipLaunchKernelGGL(qm_sel_align_kernel, dim3((unsigned)(num_cu * 8)), dim3(256), 0, st, P, A);
+  static const char* which = getenv("QM_SEL_ALIGN");
+  if (which && which[0] == 'w') hipLaunchKernelGGL(qm_sel_align_wave_kernel, dim3((unsigned)(num_cu * 8)), dim3(256), 0, st, P, A);
+  else hipLaunchKernelGGL(qm_sel_align_kernel, dim3((unsigned)(num_cu * 8)), dim3(256), 0, st, P, A);
   hipLaunchKernelGGL(qm_sel_finish_kernel, dim3(nb), dim3(256), 0, st, P, A);
   return hipGetLastError();
 }

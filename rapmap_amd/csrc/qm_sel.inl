@@ -700,6 +700,173 @@ QM_DEV int sel_ksw_extz2_wave(int qlen, const unsigned char* query, int tlen, co
   return mqe > mte ? mqe : mte;
 }
 
+// Four alignments per wavefront: every row of 16 lanes is one __m128i of the SSE kernel and walks the 16-column vectors
+// of its own alignment's band one after the other, like the original's inner loop.  Column state lives in a ring of 64
+// slots in LDS (column t in slot t & 63, u|v<<8|x<<16|y<<24 in one word; the band and its vector padding span at most
+// 48 + 16 columns), reset when the 16-aligned window start moves -- the same bookkeeping as sel_ksw_extz2_wave, whose
+// images QX / TX feed the score phase.  Everything is per-lane (row-uniform) VALU work: no scalar control per alignment.
+struct KswRow {                                   // one alignment's LDS block (1232 bytes)
+  unsigned char QX[QM_KSW_MAXLEN + 40], TX[QM_KSW_MAXLEN + 40];
+  u32 ST[64]; int HH[64]; unsigned char SS[64];
+};
+// qlenv / tlenv: the row's alignment (0: the row idles); blk[row]; the images must be in place.  Returns max(mqe, mte) per row.
+QM_DEV void sel_ksw_extz2_rows(const LV<int>& qlenv, const LV<int>& tlenv, KswRow* blk, const signed char* mat, int q, int e, int w,
+                               LV<int>& score) {
+  const int NEG = -0x40000000;
+  const int m = 5;
+  const int qe = q + e;
+  int min_sc = mat[1];
+  for (int t = 1; t < m * m; ++t) min_sc = min_sc < mat[t] ? min_sc : mat[t];
+  if (-min_sc > 2 * (q + e)) { QM_LANES(l) { score[l] = NEG; } return; }
+  const int sc_mch = (unsigned char)mat[0], sc_mis = (unsigned char)mat[1], sc_N = (unsigned char)mat[m * m - 1], m1 = m - 1;
+  const int qe2 = (unsigned char)((q + e) * 2), max_sc_v = (unsigned char)(mat[0] + (q + e) * 2), qv = (unsigned char)q;
+  LV<int> lastSt, lastEn, hb, mqe, mte; LV<bool> done;
+  QM_LANES(l) { lastSt[l] = -1; lastEn[l] = -1; hb[l] = NEG; mqe[l] = NEG; mte[l] = NEG; done[l] = qlenv[l] <= 0 || tlenv[l] <= 0; }
+  for (int r = 0; ; ++r) {
+    LV<int> st0v, en0v, stv, env, smaxv; LV<bool> act;
+    QM_LANES(l) {
+      const int qlen = qlenv[l], tlen = tlenv[l];
+      int st = 0, en = tlen - 1;
+      if (st < r - qlen + 1) st = r - qlen + 1;
+      if (en > r) en = r;
+      if (st < (r - w + 1) >> 1) st = (r - w + 1) >> 1;
+      if (en > (r + w) >> 1) en = (r + w) >> 1;
+      const bool a = !done[l] && r < qlen + tlen - 1 && st <= en;
+      if (!a) done[l] = true;
+      act[l] = a;
+      st0v[l] = st; en0v[l] = en; stv[l] = st / 16 * 16; env[l] = (en + 16) / 16 * 16 - 1;
+      smaxv[l] = st + ((en - st) / 16) * 16 + 15;
+    }
+    if (!ballot(act)) break;
+    // boundary of the first vector (x / v of column st - 1 as the last round left them), H of column st - 1 when the window moves
+    LV<int> bpack, hbNew; LV<bool> moved;
+    QM_LANES(l) {
+      bpack[l] = 0; hbNew[l] = NEG; moved[l] = false;
+      if (act[l]) {
+        KswRow& B = blk[l >> 4];
+        const int st = stv[l];
+        if (st > 0) {
+          if (st - 1 >= lastSt[l] && st - 1 <= lastEn[l]) bpack[l] = (int)(B.ST[(st - 1) & 63] & 0x00ffff00u);   // v, x
+        } else bpack[l] = (r ? qv : 0) << 8;
+        moved[l] = st != lastSt[l];
+        if (moved[l] && st > 0 && lastSt[l] >= 0) hbNew[l] = B.HH[(st - 1) & 63];
+      }
+    }
+    wave_fence();
+    QM_LANES(l) {
+      if (act[l] && moved[l]) {
+        KswRow& B = blk[l >> 4];
+        hb[l] = hbNew[l];
+        for (int k = 0; k < 4; ++k) {
+          const int slot = (l & 15) + 16 * k;
+          const int t = stv[l] + ((slot - stv[l]) & 63);
+          const int told = lastSt[l] < 0 ? -1 : lastSt[l] + ((slot - lastSt[l]) & 63);
+          if (told != t) { B.ST[slot] = 0; B.HH[slot] = NEG; B.SS[slot] = 0; }
+        }
+      }
+    }
+    wave_fence();
+    QM_LANES(l) {                                       // the diagonal cell: y8[r] = 0, u8[r] = r ? q : 0
+      if (act[l] && env[l] >= r && (l & 15) == (r & 15)) {
+        KswRow& B = blk[l >> 4];
+        B.ST[r & 63] = (B.ST[r & 63] & 0x00ffff00u) | (u32)(r ? qv : 0);
+      }
+    }
+    wave_fence();
+    LV<int> prevOld;
+    QM_LANES(l) { prevOld[l] = bpack[l]; }
+    for (int it = 0; it < 5; ++it) {
+      LV<int> old, sCur; LV<bool> inCore, inScore;
+      QM_LANES(l) {
+        const int t = stv[l] + 16 * it + (l & 15);
+        inCore[l] = act[l] && t <= env[l];
+        inScore[l] = act[l] && t >= st0v[l] && t <= smaxv[l];
+        old[l] = 0; sCur[l] = 0;
+        if (inCore[l] || inScore[l]) { KswRow& B = blk[l >> 4]; old[l] = (int)B.ST[t & 63]; sCur[l] = B.SS[t & 63]; }
+      }
+      LV<bool> any;
+      QM_LANES(l) { any[l] = inCore[l] || inScore[l]; }
+      if (!ballot(any)) break;
+      QM_LANES(l) {
+        if (inScore[l]) {
+          KswRow& B = blk[l >> 4];
+          const int t = stv[l] + 16 * it + (l & 15);
+          const int sv = B.QX[16 + r - t], sq = B.TX[t];
+          int tmp = (sq == sv) ? sc_mch : sc_mis;
+          if (sq == m1 || sv == m1) tmp = sc_N;
+          sCur[l] = tmp; B.SS[t & 63] = (unsigned char)tmp;
+        }
+      }
+      LV<int> nb, carry;
+      row_rotate_up(old, nb); row_rotate_up(prevOld, carry);
+      QM_LANES(l) {
+        if (inCore[l]) {
+          KswRow& B = blk[l >> 4];
+          const int t = stv[l] + 16 * it + (l & 15);
+          const int xv = (l & 15) == 0 ? carry[l] : nb[l];
+          const int xt1 = (xv >> 16) & 0xff, vt1 = (xv >> 8) & 0xff;
+          const int ut = old[l] & 0xff, yt = (old[l] >> 24) & 0xff;
+          int z = (sCur[l] + qe2) & 0xff;
+          int a = (xt1 + vt1) & 0xff;
+          int b = (yt + ut) & 0xff;
+          z = ((signed char)z > (signed char)a) ? z : a;
+          z = z > b ? z : b;
+          z = z < max_sc_v ? z : max_sc_v;
+          const int un = (z - vt1) & 0xff, vn = (z - ut) & 0xff;
+          z = (z - qv) & 0xff;
+          a = (a - z) & 0xff; b = (b - z) & 0xff;
+          const int xn = (signed char)a > 0 ? a : 0, yn = (signed char)b > 0 ? b : 0;
+          B.ST[t & 63] = (u32)un | ((u32)vn << 8) | ((u32)xn << 16) | ((u32)yn << 24);
+          prevOld[l] = old[l];
+        }
+      }
+      wave_fence();
+    }
+    // H (exact max) over the band cells st0..en0 (up to w + 1 of them): all reads, then the writes
+    LV<int> hLeft;                                      // H[en0 - 1] before this round's updates
+    QM_LANES(l) {
+      hLeft[l] = NEG;
+      if (act[l] && en0v[l] > 0) hLeft[l] = en0v[l] > stv[l] ? blk[l >> 4].HH[(en0v[l] - 1) & 63] : hb[l];
+    }
+    wave_fence();
+    for (int k = 0; k < 3; ++k) {
+      LV<int> hn; LV<bool> has;
+      QM_LANES(l) {
+        const int t = st0v[l] + (l & 15) + 16 * k;
+        has[l] = act[l] && t <= en0v[l];
+        hn[l] = NEG;
+        if (has[l]) {
+          KswRow& B = blk[l >> 4];
+          const int en0 = en0v[l];
+          const u32 pk = B.ST[t & 63];
+          const int un = (int)(pk & 0xff), vn = (int)((pk >> 8) & 0xff);
+          if (r > 0) {
+            if (t == en0) hn[l] = en0 > 0 ? (hLeft[l] + un - qe) : (B.HH[t & 63] + vn - qe);
+            else hn[l] = B.HH[t & 63] + vn - qe;
+          } else hn[l] = vn - qe - qe;                    // r == 0: the only cell is t == 0
+        }
+      }
+      if (!ballot(has)) break;
+      wave_fence();
+      QM_LANES(l) {
+        if (has[l]) {
+          KswRow& B = blk[l >> 4];
+          const int t = st0v[l] + (l & 15) + 16 * k;
+          B.HH[t & 63] = hn[l];
+          if (t == en0v[l] && en0v[l] == tlenv[l] - 1 && hn[l] > mte[l]) mte[l] = hn[l];
+          if (t == st0v[l] && r - st0v[l] == qlenv[l] - 1 && hn[l] > mqe[l]) mqe[l] = hn[l];
+        }
+      }
+      wave_fence();
+    }
+    QM_LANES(l) { if (act[l]) { lastSt[l] = stv[l]; lastEn[l] = env[l]; } }
+  }
+  LV<int> neg;
+  QM_LANES(l) { const int s = mqe[l] > mte[l] ? mqe[l] : mte[l]; neg[l] = -s; }
+  group_min(neg, 16);
+  QM_LANES(l) { score[l] = (qlenv[l] <= 0 || tlenv[l] <= 0) ? NEG : -neg[l]; }
+}
+
 QM_DEV unsigned char sel_nt4(unsigned char c) {               // seq_nt4_table_loc (KSW2Aligner.cpp:61-72), branch-free
   const unsigned char l = c | 0x20;
   const bool acgt = (l == 'a') | (l == 'c') | (l == 'g') | (l == 't');
@@ -1106,6 +1273,51 @@ QM_DEV void sel_task_align(const PairBatch& P, const SelBatch& A, const SelTask&
   for (int j = 0; j < 5; ++j) mat[20 + j] = 0;
   const int s = sel_ksw_extz2_wave(t.rlen, qb, t.tlen1, tb, mat, (signed char)A.gap_open, (signed char)A.gap_extend, A.bandwidth, qt + 2 * QM_KSW_MAXLEN);
   QM_LANES(l) { if (l == 0) A.tsc[t.gslot] = s; }
+  wave_fence();
+}
+
+// Tasks t0 .. t0+3 (those below nt), one per row of 16 lanes: stage the two score-phase images straight from the read and
+// the transcript text, run the row kernel, lane 0 of every row stores its score.
+QM_DEV void sel_tasks_align_rows(const PairBatch& P, const SelBatch& A, unsigned long long t0, unsigned long long nt, KswRow* blk) {
+  LV<int> ql, tl, gs;
+  LV<const unsigned char*> rd, tx; LV<int> rl, ro, fw;
+  QM_LANES(l) {
+    const unsigned long long ti = t0 + (unsigned long long)(l >> 4);
+    ql[l] = 0; tl[l] = 0; gs[l] = -1; rd[l] = nullptr; tx[l] = nullptr; rl[l] = 0; ro[l] = 0; fw[l] = 0;
+    if (ti < nt) {
+      const SelTask t = A.tasks[ti];
+      rd[l] = t.side == 0 ? A.seq1 + P.off1[t.u] : A.seq2 + P.off2[t.u];
+      rl[l] = (int)(t.side == 0 ? P.off1[t.u + 1] - P.off1[t.u] : P.off2[t.u + 1] - P.off2[t.u]);
+      tx[l] = A.text + A.txp_off[t.tid] + t.pos;
+      ql[l] = t.rlen; tl[l] = t.tlen1; gs[l] = t.gslot; ro[l] = t.roff; fw[l] = t.fwd;
+    }
+  }
+  for (int i0 = 0; i0 < QM_KSW_MAXLEN + 40; i0 += 16) {
+    QM_LANES(l) {
+      if (gs[l] >= 0) {
+        KswRow& B = blk[l >> 4];
+        const int i = i0 + (l & 15);
+        const int qlen = ql[l], tlen = tl[l], tlen16 = (tlen + 15) / 16 * 16;
+        if (i < QM_KSW_MAXLEN + 40) {
+          B.QX[i] = (i >= 16 && i < 16 + qlen) ? sel_nt4(sel_read_char(rd[l], rl[l], fw[l] != 0, ro[l] + i - 16)) : (unsigned char)0;
+          const int j = i - tlen16;
+          unsigned char c = 0;
+          if (i < tlen) c = sel_nt4(tx[l][i]);
+          else if (i >= tlen16 && j < qlen) c = sel_nt4(sel_read_char(rd[l], rl[l], fw[l] != 0, ro[l] + qlen - 1 - j));
+          B.TX[i] = c;
+        }
+      }
+    }
+  }
+  wave_fence();
+  signed char mat[25];
+  int a = (signed char)A.match, b = (signed char)A.mismatch;
+  a = a < 0 ? -a : a; b = b > 0 ? -b : b;
+  for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) mat[i * 5 + j] = (signed char)(i == j ? a : b); mat[i * 5 + 4] = 0; }
+  for (int j = 0; j < 5; ++j) mat[20 + j] = 0;
+  LV<int> sc;
+  sel_ksw_extz2_rows(ql, tl, blk, mat, (signed char)A.gap_open, (signed char)A.gap_extend, A.bandwidth, sc);
+  QM_LANES(l) { if (gs[l] >= 0 && (l & 15) == 0) A.tsc[gs[l]] = sc[l]; }
   wave_fence();
 }
 

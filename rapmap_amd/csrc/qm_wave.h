@@ -95,6 +95,8 @@ QM_DEV u64 mulhi64(u64 a, u64 b) { return __umul64hi(a, b); }
 QM_DEV int wave_max(const LV<int>& x) { int m = x.v[0]; for (int l = 1; l < 64; ++l) m = x.v[l] > m ? x.v[l] : m; return m; }
 // out[l] = in[(l - 1) & 63]: every lane reads its lower neighbour (wrapping)
 QM_DEV void lane_rotate_up(const LV<int>& in, LV<int>& out) { for (int l = 0; l < 64; ++l) out.v[l] = in.v[(l + 63) & 63]; }
+// the same within every row of 16 lanes: lane c of a row reads lane (c - 1) & 15 of that row
+QM_DEV void row_rotate_up(const LV<int>& in, LV<int>& out) { for (int l = 0; l < 64; ++l) out.v[l] = in.v[(l & ~15) | ((l + 15) & 15)]; }
 // every lane gets the minimum over its aligned group of G lanes (G a power of two, wave-uniform)
 QM_DEV void group_min(LV<int>& x, int G) {
   for (int b = 0; b < 64; b += G) {
@@ -122,6 +124,8 @@ QM_DEV int wave_max(const LV<int>& x) {
 }
 // DPP wave_ror:1 -- one VALU instruction, no trip through the LDS crossbar
 QM_DEV void lane_rotate_up(const LV<int>& in, LV<int>& out) { out.v[0] = __builtin_amdgcn_update_dpp(0, in.v[0], 0x13C, 0xf, 0xf, false); }
+// DPP row_ror:1
+QM_DEV void row_rotate_up(const LV<int>& in, LV<int>& out) { out.v[0] = __builtin_amdgcn_update_dpp(0, in.v[0], 0x121, 0xf, 0xf, false); }
 QM_DEV void group_min(LV<int>& x, int G) {
   int v = x.v[0];
   for (int o = 1; o < G; o <<= 1) { int t = __shfl_xor(v, o, 64); v = t < v ? t : v; }

@@ -95,8 +95,13 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
       std::vector<SelTask> tasks(2 * (size_t)toff[nunits] + 2); u64 ntasks = 0;
       A.tref = tref.data(); A.tcix = tcix.data(); A.tasks = tasks.data(); A.ntasks = &ntasks;
       for (long long u = 0; u < nunits; ++u) sel_unit_plan(P, A, u, &uc);
-      std::vector<unsigned char> qt(2 * QM_KSW_MAXLEN + QM_KSW_IMG_BYTES);
-      for (u64 t = 0; t < ntasks; ++t) sel_task_align(P, A, tasks[t], qt.data());
+      if (getenv("QE_ALIGN_WAVE")) {
+        std::vector<unsigned char> qt(2 * QM_KSW_MAXLEN + QM_KSW_IMG_BYTES);
+        for (u64 t = 0; t < ntasks; ++t) sel_task_align(P, A, tasks[t], qt.data());
+      } else {
+        std::vector<KswRow> rows(4);
+        for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows(P, A, t, ntasks, rows.data());
+      }
       for (long long u = 0; u < nunits; ++u) hc[u] = (u32)sel_unit_finish(P, A, u, &uc);
     } else {
       for (long long u = 0; u < nunits; ++u) hc[u] = (u32)sel_unit(P, A, u, 0, &uc);
@@ -194,6 +199,28 @@ int qe_ksw(int variant, int qlen, const unsigned char* query, int tlen, const un
   if (variant == 0) return sel_ksw_extz2(mem.data(), qlen, query, tlen, target, mat, q, e, w);
   if (variant == 1) return sel_ksw_extz2_ring(ring.data(), qlen, query, tlen, target, mat, q, e, w);
   return sel_ksw_extz2_wave(qlen, query, tlen, target, mat, q, e, w, img.data());
+}
+// four alignments at once through the 16-lane-row kernel: qlen[4], tlen[4], pointers to the code strings, out[4]
+void qe_ksw_rows(const int* qlen, const unsigned char* const* query, const int* tlen, const unsigned char* const* target,
+                 int a, int b, int q, int e, int w, int* out) {
+  signed char mat[25];
+  a = a < 0 ? -a : a; b = b > 0 ? -b : b;
+  for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) mat[i * 5 + j] = (signed char)(i == j ? a : b); mat[i * 5 + 4] = 0; }
+  for (int j = 0; j < 5; ++j) mat[20 + j] = 0;
+  std::vector<KswRow> blk(4);
+  LV<int> ql, tl, sc;
+  for (int g = 0; g < 4; ++g) {
+    const int tlen16 = (tlen[g] + 15) / 16 * 16;
+    memset(&blk[g], 0xAB, sizeof(KswRow));               // the kernel must not depend on what the block held before
+    for (int i = 0; i < QM_KSW_MAXLEN + 40; ++i) {
+      blk[g].QX[i] = (i >= 16 && i < 16 + qlen[g]) ? query[g][i - 16] : 0;
+      const int j = i - tlen16;
+      blk[g].TX[i] = i < tlen[g] ? target[g][i] : (i < tlen16 ? 0 : (j < qlen[g] ? query[g][qlen[g] - 1 - j] : 0));
+    }
+    for (int c = 0; c < 16; ++c) { ql[g * 16 + c] = qlen[g]; tl[g * 16 + c] = tlen[g]; }
+  }
+  sel_ksw_extz2_rows(ql, tl, blk.data(), mat, q, e, w, sc);
+  for (int g = 0; g < 4; ++g) out[g] = sc[g * 16];
 }
 unsigned long long qe_slots_cap(long long nkeys) { return bucket_count(nkeys); }   // buckets of 64 bytes
 void qe_flatten(const int* SA, long long nSA, const int* offsets, long long T, void* sainfo_out,

@@ -83,3 +83,51 @@ def test_ksw_every_target_length():
         ref = ol.qo_ksw_extz2(*args)
         for v in (0, 1, 2):
             assert el.qe_ksw(v, *args) == ref, (v, tlen)
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_ksw_rows_kernel_four_at_a_time(scheme):
+    """the 16-lane-row kernel (four alignments of different shapes per wavefront, idle rows included) against the oracle"""
+    a, b, q_, e_, w = scheme
+    ol = oracle._lib(); el = emu._lib()
+    ol.qo_ksw_extz2.restype = C.c_int
+    cases = list(_cases(4321 + w, 400))
+    rng = np.random.default_rng(5)
+    bad = []
+    for i in range(0, len(cases), 4):
+        grp = cases[i:i + 4]
+        if rng.random() < 0.2:
+            grp = grp[:int(rng.integers(1, 4))]            # a partly filled wavefront
+        ql = (C.c_int * 4)(*[len(g[0]) for g in grp] + [0] * (4 - len(grp)))
+        tl = (C.c_int * 4)(*[len(g[1]) for g in grp] + [0] * (4 - len(grp)))
+        dummy = np.zeros(1, dtype=np.uint8)
+        qp = (C.c_void_p * 4)(*[g[0].ctypes.data for g in grp] + [dummy.ctypes.data] * (4 - len(grp)))
+        tp = (C.c_void_p * 4)(*[g[1].ctypes.data for g in grp] + [dummy.ctypes.data] * (4 - len(grp)))
+        out = (C.c_int * 4)()
+        el.qe_ksw_rows(ql, qp, tl, tp, a, b, q_, e_, w, out)
+        for k, (qq, tt) in enumerate(grp):
+            ref = ol.qo_ksw_extz2(len(qq), qq.ctypes.data_as(C.c_void_p), len(tt), tt.ctypes.data_as(C.c_void_p), a, b, q_, e_, w)
+            if out[k] != ref:
+                bad.append((k, len(qq), len(tt), ref, out[k]))
+    assert not bad, "%d mismatches, first: %r" % (len(bad), bad[:5])
+
+
+def test_ksw_rows_every_target_length():
+    ol = oracle._lib(); el = emu._lib()
+    ol.qo_ksw_extz2.restype = C.c_int
+    rng = np.random.default_rng(9)
+    for t0 in range(1, 161, 4):
+        qs, ts = [], []
+        for tlen in range(t0, t0 + 4):
+            q = rng.integers(0, 4, 100).astype(np.uint8)
+            t = np.resize(q, tlen).copy()
+            if tlen > 3:
+                t[tlen // 2] ^= 1
+            qs.append(q); ts.append(t)
+        ql = (C.c_int * 4)(*[100] * 4); tl = (C.c_int * 4)(*[len(t) for t in ts])
+        qp = (C.c_void_p * 4)(*[q.ctypes.data for q in qs]); tp = (C.c_void_p * 4)(*[t.ctypes.data for t in ts])
+        out = (C.c_int * 4)()
+        el.qe_ksw_rows(ql, qp, tl, tp, 2, -4, 4, 2, 15, out)
+        for k in range(4):
+            ref = ol.qo_ksw_extz2(100, qs[k].ctypes.data_as(C.c_void_p), len(ts[k]), ts[k].ctypes.data_as(C.c_void_p), 2, -4, 4, 2, 15)
+            assert out[k] == ref, (t0 + k, ref, out[k])
