@@ -19,6 +19,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <thread>
 
 #include "qm_mapper.inl"
 #include "qm_device.h"
@@ -74,15 +75,16 @@ struct qm_index {
 struct qm_ctx {
   const qm_index* ix = nullptr;
   int device = 0, numCU = 256;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, evA = nullptr, evB = nullptr;
+  hipStream_t stream = nullptr, copyStream = nullptr;      // kernels / host-buffer uploads (overlapped chunk by chunk)
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, evA = nullptr, evB = nullptr, evCopy = nullptr, evStage[2] = {nullptr, nullptr};
+  unsigned char* h_stage = nullptr;                        // pinned, 2 x 32 MB: result download (qm_fetch_hits)
   // index replica
   uint8_t* d_text = nullptr; int32_t* d_SA = nullptr; void* d_sainfo = nullptr; void* d_slots = nullptr;
   uint64_t cap = 0;
   void* d_ph = nullptr; std::vector<void*> phAllocs;       // perfect-hash flavour: PhIndex struct + its arrays
   int64_t devBytes = 0;
   // work buffers
-  int64_t capCnt = 0, capOffs = 0, capLcnt = 0, capLoff = 0, capLists = 0, capHits = 0, capSeq1 = 0, capSeq2 = 0, capGrid = 0;
+  int64_t capCnt = 0, capOffs = 0, capLcnt = 0, capLoff = 0, capLists = 0, capHits = 0, capSeq1 = 0, capSeq2 = 0, capOff1 = 0, capOff2 = 0, capGrid = 0;
   uint32_t* d_cnt = nullptr; long long* d_offs = nullptr;      // per unit: hits, exclusive scan
   uint32_t* d_lcnt = nullptr; long long* d_loff = nullptr;     // per read: list length / offset
   u64* d_lists = nullptr;                                      // bump-allocated per-read hit lists
@@ -332,6 +334,11 @@ int qm_ctx_destroy(qm_ctx* c) {
   if (c->evA) hipEventDestroy(c->evA);
   if (c->evB) hipEventDestroy(c->evB);
   if (c->stream) hipStreamDestroy(c->stream);
+  if (c->copyStream) hipStreamDestroy(c->copyStream);
+  if (c->evCopy) hipEventDestroy(c->evCopy);
+  if (c->evStage[0]) hipEventDestroy(c->evStage[0]);
+  if (c->evStage[1]) hipEventDestroy(c->evStage[1]);
+  if (c->h_stage) hipHostFree(c->h_stage);
   delete c;
   return QM_OK;
 }
@@ -348,6 +355,8 @@ int qm_ctx_create(const qm_index* ix, int device_id, qm_ctx** out) {
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->numCU = prop.multiProcessorCount;
 #define CK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { int rc = fail(QM_E_NOGPU, "%s: %s", #x, hipGetErrorString(_e)); qm_ctx_destroy(c); return rc; } } while (0)
   CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  CK(hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
+  CK(hipEventCreateWithFlags(&c->evCopy, hipEventDisableTiming));
   CK(hipEventCreate(&c->ev0)); CK(hipEventCreate(&c->ev1)); CK(hipEventCreate(&c->evA)); CK(hipEventCreate(&c->evB));
   const size_t pad = 256;
   CK(hipMalloc((void**)&c->d_text, (size_t)ix->n + pad));
@@ -445,8 +454,17 @@ static int check_opts(const qm_opts* o) {
   return QM_OK;
 }
 
-int qm_map_device(qm_ctx* c, const qm_opts* o, int64_t n, const void* d_seq1, const void* d_off1, const void* d_seq2,
-                  const void* d_off2, int32_t max_read_len, int64_t* n_hits, qm_counters* counters) {
+// Host-buffer callers (qm_map_pairs / qm_map_reads) hand stage A its input chunk by chunk: `upload(u0, u1)` queues the
+// characters of units [u0, u1) on the copy stream, the kernel for those units waits for that copy only, so the upload of
+// chunk i + 1 runs under the kernel of chunk i.  Device-buffer callers pass no feeder: one launch over everything.
+struct ChunkFeeder {
+  int64_t chunk;                                             // units per chunk
+  int (*upload)(void* self, int64_t u0, int64_t u1);         // QM_OK or an error code (already recorded with fail())
+  void* self;
+};
+
+static int map_device_impl(qm_ctx* c, const qm_opts* o, int64_t n, const void* d_seq1, const void* d_off1, const void* d_seq2,
+                           const void* d_off2, int32_t max_read_len, int64_t* n_hits, qm_counters* counters, ChunkFeeder* feeder) {
   if (!c || n < 0 || (n > 0 && (!d_seq1 || !d_off1))) return fail(QM_E_ARG, "bad argument");
   int rc = check_opts(o);
   if (rc) return rc;
@@ -500,7 +518,23 @@ int qm_map_device(qm_ctx* c, const qm_opts* o, int64_t n, const void* d_seq1, co
     }
     HIPCHK(hipMemsetAsync(c->d_scal, 0, 16 * sizeof(u64), c->stream));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
-    if (nreads > 0) HIPCHK(qmk_map_reads(&ix, &B, ns, grid, c->numCU, c->stream));
+    if (feeder && n > 0) {
+      // first pass over host buffers: one launch per chunk, each behind its own upload.  A launch sees its chunk through
+      // shifted pointers (offsets are absolute, the per-read / per-unit arrays start at the chunk), the bump allocator,
+      // the counters and the status word are shared.
+      for (int64_t u0 = 0; u0 < n; u0 += feeder->chunk) {
+        const int64_t u1 = u0 + feeder->chunk < n ? u0 + feeder->chunk : n;
+        if ((rc = feeder->upload(feeder->self, u0, u1))) return rc;
+        HIPCHK(hipEventRecord(c->evCopy, c->copyStream));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->evCopy, 0));
+        ReadBatch C = B;
+        const int64_t r0 = paired ? 2 * u0 : u0, r1 = paired ? 2 * u1 : u1;
+        C.off1 = B.off1 + u0; if (paired) C.off2 = B.off2 + u0;
+        C.nreads = r1 - r0; C.lcnt = B.lcnt + r0; C.loff = B.loff + r0;
+        HIPCHK(qmk_map_reads(&ix, &C, ns, qmk_map_grid(r1 - r0, c->numCU), c->numCU, c->stream));
+      }
+      feeder = nullptr;                                   // a retry (list space ran out) finds everything resident
+    } else if (nreads > 0) HIPCHK(qmk_map_reads(&ix, &B, ns, grid, c->numCU, c->stream));
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipMemcpyAsync(hscal, c->d_scal, 16 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -587,14 +621,31 @@ int qm_map_device(qm_ctx* c, const qm_opts* o, int64_t n, const void* d_seq1, co
   return QM_OK;
 }
 
-static int upload(qm_ctx* c, int64_t n, const char* seq, const int64_t* off, uint8_t*& d_seq, long long*& d_off,
-                  int64_t& capSeq, int32_t& maxLen) {
-  int64_t bytes = off[n];
+int qm_map_device(qm_ctx* c, const qm_opts* o, int64_t n, const void* d_seq1, const void* d_off1, const void* d_seq2,
+                  const void* d_off2, int32_t max_read_len, int64_t* n_hits, qm_counters* counters) {
+  return map_device_impl(c, o, n, d_seq1, d_off1, d_seq2, d_off2, max_read_len, n_hits, counters, nullptr);
+}
+
+// offsets of one mate: monotone, longest read; device copies of the offsets (copy stream) and room for the characters
+static int stage_offsets(qm_ctx* c, int64_t n, const int64_t* off, uint8_t*& d_seq, int64_t& capSeq, long long*& d_off, int64_t& capOff,
+                         int32_t& maxLen) {
   for (int64_t i = 0; i < n; ++i) { int64_t l = off[i + 1] - off[i]; if (l < 0) return fail(QM_E_ARG, "offsets not monotone"); if (l > maxLen) maxLen = (int32_t)(l > 0x7fffffff ? 0x7fffffff : l); }
   int rc;
-  if ((rc = ensure(d_seq, capSeq, bytes + 64))) return rc;
-  if (bytes) HIPCHK(hipMemcpyAsync(d_seq, seq, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
-  (void)d_off;
+  if ((rc = ensure(d_seq, capSeq, off[n] + 64))) return rc;
+  if ((rc = ensure(d_off, capOff, n + 1))) return rc;
+  HIPCHK(hipMemcpyAsync(d_off, off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->copyStream));
+  return QM_OK;
+}
+
+struct HostFeed { qm_ctx* c; const char* seq1; const int64_t* off1; const char* seq2; const int64_t* off2; };
+static int host_feed_upload(void* self, int64_t u0, int64_t u1) {
+  HostFeed* f = (HostFeed*)self;
+  const int64_t a1 = f->off1[u0], b1 = f->off1[u1];
+  if (b1 > a1) HIPCHK(hipMemcpyAsync(f->c->d_seq1 + a1, f->seq1 + a1, (size_t)(b1 - a1), hipMemcpyHostToDevice, f->c->copyStream));
+  if (f->seq2) {
+    const int64_t a2 = f->off2[u0], b2 = f->off2[u1];
+    if (b2 > a2) HIPCHK(hipMemcpyAsync(f->c->d_seq2 + a2, f->seq2 + a2, (size_t)(b2 - a2), hipMemcpyHostToDevice, f->c->copyStream));
+  }
   return QM_OK;
 }
 
@@ -605,20 +656,16 @@ static int map_host(qm_ctx* c, const qm_opts* o, int64_t n, const char* seq1, co
   int32_t maxLen = 0; int rc;
   static const int64_t zero = 0;
   if (n == 0) { off1 = &zero; if (seq2) off2 = &zero; }
-  if ((rc = upload(c, n, seq1, off1, c->d_seq1, c->d_off1, c->capSeq1, maxLen))) return rc;
-  if (seq2 && (rc = upload(c, n, seq2, off2, c->d_seq2, c->d_off2, c->capSeq2, maxLen))) return rc;
-  if (maxLen > QM_MAX_READ_LEN) return fail(QM_E_TOOLONG, "read length %d > %d", maxLen, QM_MAX_READ_LEN);
-  // offsets (separate small buffers, reallocated with the unit capacity)
-  long long* d1 = nullptr; long long* d2 = nullptr;
-  HIPCHK(hipMalloc((void**)&d1, (size_t)(n + 1) * 8));
-  HIPCHK(hipMemcpyAsync(d1, off1, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-  if (seq2) {
-    HIPCHK(hipMalloc((void**)&d2, (size_t)(n + 1) * 8));
-    HIPCHK(hipMemcpyAsync(d2, off2, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-  }
-  HIPCHK(hipStreamSynchronize(c->stream));
-  rc = qm_map_device(c, o, n, c->d_seq1, d1, seq2 ? c->d_seq2 : nullptr, seq2 ? d2 : nullptr, maxLen, n_hits, counters);
-  hipFree(d1); if (d2) hipFree(d2);
+  if ((rc = stage_offsets(c, n, off1, c->d_seq1, c->capSeq1, c->d_off1, c->capOff1, maxLen))) return rc;
+  if (seq2 && (rc = stage_offsets(c, n, off2, c->d_seq2, c->capSeq2, c->d_off2, c->capOff2, maxLen))) return rc;
+  if (maxLen > QM_MAX_READ_LEN) { hipStreamSynchronize(c->copyStream); return fail(QM_E_TOOLONG, "read length %d > %d", maxLen, QM_MAX_READ_LEN); }
+  // the characters follow chunk by chunk, each chunk's kernel behind its own copy (ChunkFeeder); QM_HOST_CHUNK = units per chunk
+  HostFeed hf = {c, seq1, off1, seq2, off2};
+  const char* ce = getenv("QM_HOST_CHUNK");
+  ChunkFeeder fd; fd.chunk = ce && atoll(ce) > 0 ? atoll(ce) : (1 << 20); fd.upload = host_feed_upload; fd.self = &hf;
+  if (c->debug) fd.chunk = n > 0 ? n : 1;                 // the interval dump is indexed by absolute read number: one launch
+  rc = map_device_impl(c, o, n, c->d_seq1, c->d_off1, seq2 ? c->d_seq2 : nullptr, seq2 ? c->d_off2 : nullptr, maxLen, n_hits, counters, &fd);
+  hipStreamSynchronize(c->copyStream);                     // nothing of the caller's buffers is in flight after return (error paths too)
   return rc;
 }
 
@@ -637,7 +684,41 @@ int qm_fetch_hits(qm_ctx* c, int64_t* hit_offsets, qm_hit* hits) {
   if (!c || c->lastUnits < 0) return fail(QM_E_STATE, "no mapping result to fetch");
   HIPCHK(hipSetDevice(c->device));
   if (hit_offsets) HIPCHK(hipMemcpy(hit_offsets, c->d_offs, (size_t)(c->lastUnits + 1) * 8, hipMemcpyDeviceToHost));
-  if (hits && c->lastHits > 0) HIPCHK(hipMemcpy(hits, c->d_hits, (size_t)c->lastHits * sizeof(qm_hit), hipMemcpyDeviceToHost));
+  if (hits && c->lastHits > 0) {
+    const size_t bytes = (size_t)c->lastHits * sizeof(qm_hit);
+    if (bytes < ((size_t)64 << 20)) HIPCHK(hipMemcpy(hits, c->d_hits, bytes, hipMemcpyDeviceToHost));
+    else {
+      // A large result lands in memory the caller has usually just allocated (every page still to be faulted in), where a
+      // plain pageable hipMemcpy runs at ~9 GB/s.  Instead: DMA into two pinned staging buffers in turn at PCIe rate while
+      // host threads copy the previous chunk into the caller's array, so the page faults are spread over several cores.
+      const size_t CH = (size_t)32 << 20;
+      if (!c->h_stage) HIPCHK(hipHostMalloc((void**)&c->h_stage, 2 * CH, hipHostMallocDefault));
+      if (!c->evStage[0]) { HIPCHK(hipEventCreateWithFlags(&c->evStage[0], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->evStage[1], hipEventDisableTiming)); }
+      const size_t nch = (bytes + CH - 1) / CH;
+      auto drain = [&](size_t i) -> hipError_t {             // chunk i: staging -> caller's array, 8 threads
+        hipError_t e = hipEventSynchronize(c->evStage[i & 1]);
+        if (e != hipSuccess) return e;
+        const size_t off = i * CH, len = off + CH <= bytes ? CH : bytes - off;
+        const unsigned char* src = c->h_stage + (i & 1) * CH; unsigned char* dst = (unsigned char*)hits + off;
+        const int nt = 8; std::vector<std::thread> th;
+        const size_t per = ((len + nt - 1) / nt + 4095) & ~(size_t)4095;
+        for (int t = 0; t < nt; ++t) {
+          const size_t a0 = per * (size_t)t; if (a0 >= len) break;
+          const size_t l0 = a0 + per <= len ? per : len - a0;
+          th.emplace_back([=]() { memcpy(dst + a0, src + a0, l0); });
+        }
+        for (auto& x : th) x.join();
+        return hipSuccess;
+      };
+      for (size_t i = 0; i < nch; ++i) {
+        const size_t off = i * CH, len = off + CH <= bytes ? CH : bytes - off;
+        HIPCHK(hipMemcpyAsync(c->h_stage + (i & 1) * CH, (const unsigned char*)c->d_hits + off, len, hipMemcpyDeviceToHost, c->copyStream));
+        HIPCHK(hipEventRecord(c->evStage[i & 1], c->copyStream));
+        if (i > 0) HIPCHK(drain(i - 1));
+      }
+      HIPCHK(drain(nch - 1));
+    }
+  }
   return QM_OK;
 }
 

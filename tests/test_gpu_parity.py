@@ -183,6 +183,43 @@ def test_medium_full_parity_and_properties(synth_medium, oracle_mod):
     assert np.array_equal(hp["frag_len"], sp["frag_len"])
 
 
+def test_host_buffers_chunked_upload(synth_medium, oracle_mod, monkeypatch):
+    """qm_map_pairs / qm_map_reads on host buffers upload the reads chunk by chunk, every chunk's kernel behind its own
+    copy: many small, ragged chunks (QM_HOST_CHUNK) must give what one launch gives -- paired, single-end and -s"""
+    import rapmap_amd as ra
+    ix, orc = load_oracle(synth_medium["idx"])
+    qi, mp = _gpu(synth_medium["idx"], debug=False)
+    n = 30000
+    o = synth_medium["off"][: n + 1]
+    q1 = synth_medium["seq1"][: o[-1]]; q2 = synth_medium["seq2"][: o[-1]]
+    res = orc.map_pairs(q1, o, q2, o, nthreads=8)
+    for chunk in ("7001", "1", None):
+        if chunk == "1":
+            m = 300                                            # one unit per launch: keep it short
+            oo = o[: m + 1]; a1 = q1[: oo[-1]]; a2 = q2[: oo[-1]]
+            monkeypatch.setenv("QM_HOST_CHUNK", chunk)
+            gr = mp.map_pairs(a1, oo, a2, oo)
+            rs = orc.map_pairs(a1, oo, a2, oo, nthreads=4)
+            assert_hits_equal(rs.hit_offsets, rs.hits, gr.hit_offsets, gr.hits, "chunk=1")
+            continue
+        if chunk:
+            monkeypatch.setenv("QM_HOST_CHUNK", chunk)
+        else:
+            monkeypatch.delenv("QM_HOST_CHUNK", raising=False)
+        gr = mp.map_pairs(q1, o, q2, o)
+        assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "chunk=%s" % chunk)
+        assert res.counters == gr.counters
+    monkeypatch.setenv("QM_HOST_CHUNK", "4999")
+    gs = mp.map_reads(q1, o)
+    rs = orc.map_single(q1, o, nthreads=8)
+    assert_hits_equal(rs.hit_offsets, rs.hits, gs.hit_offsets, gs.hits, "single-end chunked")
+    m = 12000
+    oo = o[: m + 1]; a1 = q1[: oo[-1]]; a2 = q2[: oo[-1]]
+    gsel = mp.map_pairs(a1, oo, a2, oo, opts=ra.default_opts(sel_aln=1))
+    rsel = orc.map_pairs(a1, oo, a2, oo, opts=oracle_mod.default_opts(selAln=1), nthreads=8)
+    assert_hits_equal(rsel.hit_offsets, rsel.hits, gsel.hit_offsets, gsel.hits, "-s chunked")
+
+
 def test_device_resident_inputs(synth_medium, oracle_mod):
     """qm_map_device: reads already in HBM (the path bench.py times)"""
     import torch
