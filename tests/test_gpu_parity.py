@@ -220,6 +220,66 @@ def test_host_buffers_chunked_upload(synth_medium, oracle_mod, monkeypatch):
     assert_hits_equal(rsel.hit_offsets, rsel.hits, gsel.hit_offsets, gsel.hits, "-s chunked")
 
 
+def _fuzz_reads(text, offsets, n, seed, max_len):
+    """fragments of the indexed transcripts with substitutions, indels, N's, lower case, random tails and ragged lengths
+    (0 .. max_len): nothing a sequencer would not produce, everything the 100-bp ACGT bench reads never exercise"""
+    rng = np.random.default_rng(seed)
+    comp = np.zeros(256, np.uint8); comp[:] = ord("N")
+    for a, b in zip(b"ACGTacgt", b"TGCAtgca"):
+        comp[a] = b
+    lens = np.diff(np.append(offsets, text.size)) - 1          # every transcript is followed by '$'
+    ok = np.nonzero(lens >= 300)[0]
+    r1, r2 = [], []
+    for i in range(n):
+        t = ok[rng.integers(0, ok.size)]
+        fl = int(rng.integers(60, min(400, lens[t])))
+        st = int(rng.integers(0, lens[t] - fl + 1))
+        frag = text[offsets[t] + st: offsets[t] + st + fl].copy()
+        mates = []
+        for m in range(2):
+            L = int(rng.integers(0, max_len + 1)) if rng.random() < 0.15 else int(rng.integers(max(31, max_len // 3), max_len + 1))
+            seq = frag[:L].copy() if m == 0 else comp[frag[::-1][:L]].copy()
+            k = rng.random()
+            if seq.size and k < 0.5:                           # substitutions
+                w = rng.random(seq.size) < 0.015
+                seq[w] = rng.choice(np.frombuffer(b"ACGT", np.uint8), int(w.sum()))
+            if seq.size > 40 and 0.3 < k < 0.6:                # an indel
+                p = int(rng.integers(5, seq.size - 5))
+                seq = np.delete(seq, p) if rng.random() < 0.5 else np.insert(seq, p, rng.choice(np.frombuffer(b"ACGT", np.uint8)))
+            if seq.size and rng.random() < 0.1:
+                seq[rng.integers(0, seq.size)] = ord("N")
+            if seq.size and rng.random() < 0.1:
+                seq = np.frombuffer(seq.tobytes().lower(), np.uint8).copy()
+            if seq.size > 50 and rng.random() < 0.05:          # a random tail (adapter)
+                seq[-20:] = rng.choice(np.frombuffer(b"ACGT", np.uint8), 20)
+            mates.append(seq[:max_len].tobytes())
+        if rng.random() < 0.5:
+            mates.reverse()
+        r1.append(mates[0]); r2.append(mates[1])
+    return r1, r2
+
+
+@pytest.mark.parametrize("max_len", [120, 250])
+def test_fuzz_ragged_reads(synth_medium, oracle_mod, max_len):
+    """ragged, dirty reads through both read-length kernels (<= 128 bp, <= 256 bp): default, --noSensitive, fuzzy and -s"""
+    import rapmap_amd as ra
+    ix, orc = load_oracle(synth_medium["idx"])
+    qi, mp = _gpu(synth_medium["idx"], debug=False)
+    text, offsets = qi.arrays()
+    n = 6000
+    r1, r2 = _fuzz_reads(np.asarray(text), np.asarray(offsets, dtype=np.int64), n, 77 + max_len, max_len)
+    q1, o1 = pack(r1); q2, o2 = pack(r2)
+    for oo, go in (({}, {}), ({"sensitive": 0}, {"sensitive": 0}), ({"fuzzy": 1}, {"fuzzy": 1}), ({"selAln": 1}, {"sel_aln": 1}),
+                   ({"selAln": 1, "hardFilter": 1}, {"sel_aln": 1, "hard_filter": 1})):
+        res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=8)
+        gr = mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(**go))
+        assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "fuzz %s len<=%d" % (oo, max_len))
+        assert res.counters == gr.counters
+    rs = orc.map_single(q2, o2, opts=oracle_mod.default_opts(selAln=1), nthreads=8)
+    gs = mp.map_reads(q2, o2, opts=ra.default_opts(sel_aln=1))
+    assert_hits_equal(rs.hit_offsets, rs.hits, gs.hit_offsets, gs.hits, "fuzz single-end -s len<=%d" % max_len)
+
+
 def test_device_resident_inputs(synth_medium, oracle_mod):
     """qm_map_device: reads already in HBM (the path bench.py times)"""
     import torch
