@@ -579,6 +579,7 @@ template <int NS> QM_DEV int known_end(const Strand<NS>& S, int p) {
 struct IntervalList {
   IntRec* lds; IntRec* ovf;
   int n;
+  u32* pf; int pfcap;      // LDS staging for the (tid, pos) of the first interval's suffixes: tids at pf[0..), positions at pf[pfcap..)
   QM_DEV void push(int lb, int ub, u32 ln, u32 qp) {
     IntRec r; r.b = lb; r.e = ub; r.len = ln; r.q = qp;
     IntRec* dst = n < QM_ICAP ? &lds[n] : &ovf[n - QM_ICAP];
@@ -839,6 +840,13 @@ QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, c
     const bool more = !lastSearch && p + mlen < L;     // the walk continues at kp after this MMP
     const int kp = p + mlen - (k - 1);
     if (ub > lb && ub - lb < B.max_interval) {          // :577-618
+      if (!(F & QM_F_SEL) && out.n == 0 && ub - lb <= out.pfcap) {
+        // three reads in four end with exactly one interval per strand, whose (tid, pos) entries hits->mappings needs next:
+        // ask for them now, straight into LDS, so that the trip to sainfo runs under the rest of the walk
+        QM_LANES(l) {
+          if (l < ub - lb) { const u32* g = (const u32*)&ix.sainfo[lb + l]; lds_dma_u32(g, out.pf, l); lds_dma_u32(g + 1, out.pf + out.pfcap, l); }
+        }
+      }
       out.push(lb, ub, (u32)mlen, (u32)p);
       int corr = prevMMPEnd > p ? prevMMPEnd - p : 0;
       cov += mlen - corr;
@@ -877,7 +885,10 @@ QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M,
   const unsigned char* fwdStr = M.str[0];
   const unsigned char* rcStr = M.str[1];
   fwdInts.n = 0; rcInts.n = 0;
+  fwdInts.pf = nullptr; fwdInts.pfcap = 0; rcInts.pf = nullptr; rcInts.pfcap = 0;
   if (P <= 0) return false;
+  // the interval tables have one slot per read position: the slots past the last k-mer are free for the sainfo staging
+  fwdInts.pf = (u32*)(M.tab[0] + P); rcInts.pf = (u32*)(M.tab[1] + P); fwdInts.pfcap = rcInts.pfcap = 64 * NS - P;
   Strand<NS> S;
   setup_strand<NS>(ix, fwdStr, L, S, &M.planes[0][0][0], M.tab[0]);
   S.dollar = hasDollar;
@@ -1042,9 +1053,18 @@ QM_DEV int unique_emit(const u64* sorted, int n, int shift, u64* dst, int dstOff
 struct Bufs { u64* A; u64* B; u64* R; };   // sort ping-pong + the read's output list
 
 // collectFromSingleInterval (HitManager.cpp:716-807, considerMultiPos == false)
-QM_DEV int single_interval(const DevIndex& ix, const Bufs& bf, int rOff, int lb, int ub, u32 qpos, bool isRC) {
+QM_DEV int single_interval(const DevIndex& ix, const Bufs& bf, int rOff, int lb, int ub, u32 qpos, bool isRC, const u32* pf, int pfcap) {
   int n = ub - lb;
   QM_CNT(12, 1); QM_CNT(13, n);
+  if (pf && n <= pfcap) {                                // the only interval of the list is the first one recorded: staged by get_sa_hits
+    lds_dma_wait();
+    QM_LANES(l) {
+      if (l < n) {
+        const int hitPos = (int)(pf[pfcap + l] - qpos);
+        bf.A[l] = ((u64)pf[l] << 32) | ((u32)hitPos ^ 0x80000000u);
+      }
+    }
+  } else
   for (int base = 0; base < n; base += 64) {
     QM_LANES(l) {
       int i = base + l;
@@ -1161,9 +1181,9 @@ QM_DEV int hits_to_mappings(const DevIndex& ix, const Bufs& bf, const IntervalLi
                             const IntervalList& rcInts, bool keepBoth) {
   int nf = 0, nr = 0;
   if (fwdInts.n > 1) nf = multi_interval(ix, bf, 0, fwdInts, false);
-  else if (fwdInts.n == 1) { int lb, ub; u32 ln, qp; fwdInts.get(0, lb, ub, ln, qp); nf = single_interval(ix, bf, 0, lb, ub, qp, false); }
+  else if (fwdInts.n == 1) { int lb, ub; u32 ln, qp; fwdInts.get(0, lb, ub, ln, qp); nf = single_interval(ix, bf, 0, lb, ub, qp, false, fwdInts.pf, fwdInts.pfcap); }
   if (rcInts.n > 1) nr = multi_interval(ix, bf, nf, rcInts, true);
-  else if (rcInts.n == 1) { int lb, ub; u32 ln, qp; rcInts.get(0, lb, ub, ln, qp); nr = single_interval(ix, bf, nf, lb, ub, qp, true); }
+  else if (rcInts.n == 1) { int lb, ub; u32 ln, qp; rcInts.get(0, lb, ub, ln, qp); nr = single_interval(ix, bf, nf, lb, ub, qp, true, rcInts.pf, rcInts.pfcap); }
   if (nf > 0 && nr > 0) {
     // stable merge by tid, fwd first on ties, duplicates collapse to the first (:834-881)
     int n = nf + nr;

@@ -110,6 +110,10 @@ QM_DEV u64 load_u64_unaligned(const unsigned char* p) { u64 v; __builtin_memcpy(
 struct U4 { u32 x, y, z, w; };
 QM_DEV U4 load_16(const void* p) { U4 v; __builtin_memcpy(&v, p, 16); return v; }
 QM_DEV long long load_uniform_i64(const long long* p) { return *p; }
+// lane `lane` copies one dword from global memory straight into ldsBase[lane] (no register in between); lds_dma_wait()
+// before the wave reads what it asked for
+QM_DEV void lds_dma_u32(const u32* g, u32* ldsBase, int lane) { ldsBase[lane] = *g; }
+QM_DEV void lds_dma_wait() {}
 QM_DEV void load_32(const void* p, U4& a, U4& b) { a = load_16(p); b = load_16((const unsigned char*)p + 16); }
 QM_DEV void load_8_16(const u64* p8, const u64* p16, u64& a, U4& b) { a = *p8; b = load_16(p16); }
 template <int N> QM_DEV void load_8_16xN(const u64* const* B, const int* bit, u64* word, U4* meta) {
@@ -138,6 +142,13 @@ QM_DEV long long load_uniform_i64(const long long* p) {
   typedef const long long __attribute__((address_space(4)))* cptr;
   return *(cptr)(unsigned long long)p;
 }
+// global_load_lds_dword: every active lane fetches one dword from its own global address, the hardware writes it to
+// LDS at ldsBase + 4 * lane id -- an asynchronous gather that costs no VGPR for the data.  `lane` must be the lane id.
+QM_DEV void lds_dma_u32(const u32* g, u32* ldsBase, int) {
+  typedef const u32 __attribute__((address_space(1)))* gptr; typedef u32 __attribute__((address_space(3)))* lptr;
+  __builtin_amdgcn_global_load_lds((gptr)(unsigned long long)g, (lptr)(unsigned)(unsigned long long)ldsBase, 4, 0, 0);
+}
+QM_DEV void lds_dma_wait() { __builtin_amdgcn_s_waitcnt(0x0F70); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }   // vmcnt(0)
 // one 16-byte load that the compiler cannot split into a key load plus a dependent value load
 struct U4 { u32 x, y, z, w; };
 QM_DEV U4 load_16(const void* p) {
