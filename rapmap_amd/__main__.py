@@ -98,7 +98,7 @@ def _quasimap(argv):
         if a.mimicStrictBT2:
             opts.min_score_fraction = 0.8; opts.match_score = 1; opts.mismatch_penalty = 0; opts.gap_open = 25; opts.gap_extend = 25
     qi = ra.QuasiIndex(a.index)
-    mp = ra.QuasiMapper(qi, a.device)
+    mp = ra.QuasiMapper(qi, a.device, reuse_results=True)
     log = (lambda *x: None) if a.quiet else (lambda *x: print(*x, file=sys.stderr, flush=True))
     out = None
     if not a.noOutput:

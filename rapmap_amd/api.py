@@ -210,7 +210,13 @@ class QuasiMapper:
     """One GPU context: the index replicated in HBM + work buffers.  `map_pairs` performs, for every
     pair, SACollector() x2 -> hitsToMappingsSimple() x2 -> mergeLeftRightHits() on one wavefront."""
 
-    def __init__(self, index: QuasiIndex, device=0, debug=False):
+    def __init__(self, index: QuasiIndex, device=0, debug=False, reuse_results=False):
+        """reuse_results: hit arrays of successive calls share one buffer (views valid until the next call) instead of
+        a fresh allocation per batch, whose pages would have to be faulted in again every time -- for streaming callers
+        that are done with a batch before they map the next (the CLI)"""
+        self._reuse = bool(reuse_results)
+        self._buf_hits = None
+        self._buf_offs = None
         self.index = index
         self._h = C.c_void_p()
         _check(lib().qm_ctx_create(index._h, device, C.byref(self._h)))
@@ -229,7 +235,16 @@ class QuasiMapper:
         a, b = C.c_double(), C.c_double()
         _check(lib().qm_last_kernel_ms(self._h, C.byref(a), C.byref(b)))
         r.map_kernel_ms, r.total_ms = a.value, b.value
-        if fetch:
+        if fetch and self._reuse:
+            nh = max(r.n_hits, 0)
+            if self._buf_hits is None or self._buf_hits.size < nh:
+                self._buf_hits = np.empty(nh + nh // 4 + 1024, dtype=HIT_DTYPE)
+            if self._buf_offs is None or self._buf_offs.size < n + 1:
+                self._buf_offs = np.empty(n + 1 + n // 4, dtype=np.int64)
+            r.hit_offsets = self._buf_offs[: n + 1]
+            r.hits = self._buf_hits[:nh]
+            _check(lib().qm_fetch_hits(self._h, r.hit_offsets.ctypes.data, r.hits.ctypes.data if r.n_hits else None))
+        elif fetch:
             r.hit_offsets = np.zeros(n + 1, dtype=np.int64)
             r.hits = np.zeros(max(r.n_hits, 0), dtype=HIT_DTYPE)
             _check(lib().qm_fetch_hits(self._h, r.hit_offsets.ctypes.data, r.hits.ctypes.data if r.n_hits else None))
