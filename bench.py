@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sel-aln", action="store_true", help="config 5: selective alignment (-s): chaining + ksw2 extension alignment of every hit")
     ap.add_argument("--perfect-hash", action="store_true", help="config 4: index built with `quasiindex -p` (BooPHF / FrugalBooMap probe path)")
+    ap.add_argument("--read-len", type=int, default=100, help="read length (BASELINE.json: 100; 129..256 runs the NS=4 kernels)")
     ap.add_argument("--cache", default=os.environ.get("QMAP_BENCH_CACHE", "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"))
     args = ap.parse_args()
 
@@ -140,7 +141,7 @@ def main():
     import rapmap_amd as ra
     from rapmap_amd import dist as qd
 
-    k, L = 31, 100
+    k, L = 31, args.read_len
     idx_dir = build_or_reuse_index(args.genes, 42, k, rank, world, args.cache, args.perfect_hash)
     t = time.time()
     qi = ra.QuasiIndex(idx_dir)

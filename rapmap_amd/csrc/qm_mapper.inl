@@ -140,7 +140,8 @@ struct Bits {
   QM_DEV bool test(int p) const {
     u64 x = 0;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) if (s == (p >> 6)) x = w[s];
+    for (int s = 0; s < NS; ++s) x |= (s == (p >> 6)) ? w[s] : 0ULL;   // selects over all words: an `if` chain is turned back into
+                                                                        // w[p >> 6], and one dynamic index parks the whole Strand in scratch
     return (x >> (p & 63)) & 1;
   }
 };
@@ -196,7 +197,7 @@ template <int NS> QM_DEV Bits<NS> mirror(const Bits<NS>& in, int P) {
   for (int s = 0; s < NS; ++s) {
     u64 lo = 0, hi = 0;
 #pragma unroll
-    for (int t = 0; t < 2 * NS; ++t) { if (t == s + ws) { lo = rev[t]; hi = rev[t + 1]; } }
+    for (int t = 0; t < 2 * NS; ++t) { const bool m = t == s + ws; lo |= m ? rev[t] : 0ULL; hi |= m ? rev[t + 1] : 0ULL; }
     out.w[s] = (lo >> bs) | (bs ? (hi << (64 - bs)) : 0ULL);
   }
   return out;
@@ -786,7 +787,7 @@ template <int NS> QM_DEV void set_range_and(Bits<NS>& dst, const Bits<NS>& src, 
 }
 template <int NS> QM_DEV void set_bit(Bits<NS>& b, int p) {
 #pragma unroll
-  for (int s = 0; s < NS; ++s) if (s == (p >> 6)) b.w[s] |= 1ULL << (p & 63);
+  for (int s = 0; s < NS; ++s) b.w[s] |= (s == (p >> 6)) ? (1ULL << (p & 63)) : 0ULL;   // every word written: see Bits::test
 }
 
 // ------------------------------------------------------------------ stage 3
