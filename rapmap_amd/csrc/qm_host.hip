@@ -471,7 +471,7 @@ static int map_device_impl(qm_ctx* c, const qm_opts* o, int64_t n, const void* d
   if ((d_seq2 == nullptr) != (d_off2 == nullptr)) return fail(QM_E_ARG, "seq2/off2 must both be given or both be null");
   if (max_read_len > QM_MAX_READ_LEN) return fail(QM_E_TOOLONG, "read length %d > %d", max_read_len, QM_MAX_READ_LEN);
   HIPCHK(hipSetDevice(c->device));
-  const int ns = max_read_len <= 128 ? 2 : 4;
+  const int ns = max_read_len <= 128 ? 2 : (max_read_len <= 192 ? 3 : 4);   // 64-character slots per read: picks the kernel instantiation
   const bool paired = d_seq2 != nullptr;
   const int64_t nreads = paired ? 2 * n : n;
   const int grid = qmk_map_grid(nreads, c->numCU);

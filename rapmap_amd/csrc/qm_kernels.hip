@@ -274,6 +274,17 @@ hipError_t qmk_map_reads(const void* ixp, const void* bp, int ns, int grid, int 
       case QM_F_SEL | QM_F_NIP: QM_LAUNCH(2, 4, QM_F_SEL | QM_F_NIP); break;
       default: QM_LAUNCH(2, 4, QM_F_SEL | QM_F_PH | QM_F_NIP); break;
     }
+  } else if (ns == 3) {                                    // 129..192 bp (2 x 150 bp reads)
+    switch (F) {
+      case 0: QM_LAUNCH(3, 6, 0); break;
+      case QM_F_PH: QM_LAUNCH(3, 5, QM_F_PH); break;
+      case QM_F_NIP: QM_LAUNCH(3, 6, QM_F_NIP); break;
+      case QM_F_PH | QM_F_NIP: QM_LAUNCH(3, 5, QM_F_PH | QM_F_NIP); break;
+      case QM_F_SEL: QM_LAUNCH(3, 3, QM_F_SEL); break;
+      case QM_F_SEL | QM_F_PH: QM_LAUNCH(3, 3, QM_F_SEL | QM_F_PH); break;
+      case QM_F_SEL | QM_F_NIP: QM_LAUNCH(3, 3, QM_F_SEL | QM_F_NIP); break;
+      default: QM_LAUNCH(3, 3, QM_F_SEL | QM_F_PH | QM_F_NIP); break;
+    }
   } else {
     switch (F) {
       case 0: QM_LAUNCH(4, 3, 0); break;

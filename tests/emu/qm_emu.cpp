@@ -60,6 +60,8 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
                            pre_offsets<NS_>(B, r + 7, pre); map_read<NS_, F_>(ix, B, r, pre, M, gs.data(), wa[r % 7], selscr, (r & 2) ? &sellds : nullptr); }
       if (ns == 2) { switch (F) { case 0: QE_CALL(2, 0) break; case 1: QE_CALL(2, 1) break; case 2: QE_CALL(2, 2) break; case 3: QE_CALL(2, 3) break;
                                   case 4: QE_CALL(2, 4) break; case 5: QE_CALL(2, 5) break; case 6: QE_CALL(2, 6) break; default: QE_CALL(2, 7) break; } }
+      else if (ns == 3) { switch (F) { case 0: QE_CALL(3, 0) break; case 1: QE_CALL(3, 1) break; case 2: QE_CALL(3, 2) break; case 3: QE_CALL(3, 3) break;
+                                       case 4: QE_CALL(3, 4) break; case 5: QE_CALL(3, 5) break; case 6: QE_CALL(3, 6) break; default: QE_CALL(3, 7) break; } }
       else { switch (F) { case 0: QE_CALL(4, 0) break; case 1: QE_CALL(4, 1) break; case 2: QE_CALL(4, 2) break; case 3: QE_CALL(4, 3) break;
                           case 4: QE_CALL(4, 4) break; case 5: QE_CALL(4, 5) break; case 6: QE_CALL(4, 6) break; default: QE_CALL(4, 7) break; } }
 #undef QE_CALL

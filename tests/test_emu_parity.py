@@ -135,6 +135,17 @@ def test_long_reads_ns4(synth_small, oracle_mod):
     # the NS=2 build must refuse them rather than truncate silently
     er2 = em.map(q1, o, q2, o, ns=2)
     assert er2.status & 4
+    # three 64-character slots: the instantiation 2 x 150 bp reads run on (129..192 bp)
+    res3 = orc.map_pairs(a1, aoff, a2, aoff, nthreads=4, want_ints=True)
+    er3 = em.map(a1, aoff, a2, aoff, ns=3)
+    assert er3.status == 0
+    assert_hits_equal(res3.hit_offsets, res3.hits, er3.hit_offsets, er3.hits, "ns3")
+    _cmp_ints(res3, er3)
+    for oo, go in (({"sensitive": 0}, {"sensitive": 0}), ({"selAln": 1}, {"sel_aln": 1})):
+        r = orc.map_pairs(a1, aoff, a2, aoff, opts=oracle_mod.default_opts(**oo), nthreads=4)
+        e = em.map(a1, aoff, a2, aoff, opts=emu.default_opts(**go), ns=3)
+        assert_hits_equal(r.hit_offsets, r.hits, e.hit_offsets, e.hits, "ns3 %s" % oo)
+    assert em.map(q1, o, q2, o, ns=3).status & 4          # the 250 bp reads do not fit three slots
 
 
 def test_medium(synth_medium, oracle_mod):
