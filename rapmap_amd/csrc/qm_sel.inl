@@ -21,7 +21,7 @@ struct SelRec { u32 tid, pos, qpos, len, iv; };
 struct SelGroup { u32 tid; int ppos; double score; short npos, off; int cs; };   // ppos: the hit's own position (QuasiAlignment::pos); 24 bytes
 template <int CAP, int OUTCAP>
 struct SelScratchT {                // working set of one read
-  static constexpr int cap = CAP, outcap = OUTCAP;
+  static constexpr int cap = CAP, outcap = OUTCAP, gcap = CAP;
   SelRec rec[CAP], tmp[CAP];
   double f[CAP]; int p[CAP]; int seen[CAP]; int ends[CAP]; int starts[CAP];
   SelGroup grp[2][CAP]; int pos[2][CAP]; int ngrp[2], npos[2];
@@ -34,7 +34,7 @@ struct SelScratch : SelScratchT<QM_SEL_CAP, QM_CHUNK> {};   // per wave, global 
 // share their bytes with the second strand's groups (written only after that strand's sort), and the read's list is
 // assembled in the sort buffers of WaveMem, which the -s path does not use otherwise (`out`, 3 * QM_CAP words).
 struct SelScratchLds {
-  static constexpr int cap = QM_SEL_SMALL, outcap = 3 * QM_CAP;
+  static constexpr int cap = QM_SEL_SMALL, outcap = 3 * QM_CAP, gcap = QM_SEL_SMALL;
   SelRec rec[QM_SEL_SMALL];
   double f[QM_SEL_SMALL]; int p[QM_SEL_SMALL]; int seen[QM_SEL_SMALL]; int ends[QM_SEL_SMALL]; int starts[QM_SEL_SMALL];
   SelGroup grp0[QM_SEL_SMALL];
@@ -246,40 +246,45 @@ QM_DEV int sel_emit(SS& S) {
   return o;
 }
 
-// The two stable sorts of sel_strand as one rank sort by all lanes (n <= 64): order (tid, reference end, query end, input
-// order) for several intervals, (tid, hit position, input order) for one -- what lane 0's merge sorts produce.
+// The two stable sorts of sel_strand as one rank sort by all lanes (n <= 64 * QM_SEL_CHUNKS, lane l owns the records
+// l, l + 64, ...): order (tid, reference end, query end, input order) for several intervals, (tid, hit position, input
+// order) for one -- what lane 0's merge sorts produce.
+#define QM_SEL_CHUNKS 4
 template <typename SS>
 QM_DEV void sel_wave_sort(SS& S, int n, int m) {
-  LV<u64> k1, k2;
-  QM_LANES(l) {
-    k1[l] = 0; k2[l] = 0;
-    if (l < n) {
-      const SelRec r = S.rec[l];
-      if (m == 1) { k1[l] = ((u64)r.tid << 32) | (u64)(((u32)(r.pos - r.qpos)) ^ 0x80000000u); k2[l] = (u64)l; }
-      else { k1[l] = ((u64)r.tid << 32) | (u64)(u32)(r.pos + r.len); k2[l] = ((u64)(u32)(r.qpos + r.len) << 8) | (u64)l; }
+  u64* K = (u64*)S.tmp;                              // keys where every lane can read them (2 words per record)
+  for (int c = 0; c < QM_SEL_CHUNKS && 64 * c < n; ++c) {
+    QM_LANES(l) {
+      const int i = 64 * c + l;
+      if (i < n) {
+        const SelRec r = S.rec[i];
+        if (m == 1) { K[2 * i] = ((u64)r.tid << 32) | (u64)(((u32)(r.pos - r.qpos)) ^ 0x80000000u); K[2 * i + 1] = (u64)i; }
+        else { K[2 * i] = ((u64)r.tid << 32) | (u64)(u32)(r.pos + r.len); K[2 * i + 1] = ((u64)(u32)(r.qpos + r.len) << 16) | (u64)i; }
+      }
     }
   }
-  // keys to scratch so that every lane can read every key: reuse tmp's first words
-  u64* K = (u64*)S.tmp;
-  QM_LANES(l) { if (l < n) { K[2 * l] = k1[l]; K[2 * l + 1] = k2[l]; } }
   wave_fence();
-  LV<int> rank;
-  QM_LANES(l) {
-    int rk = 0;
-    if (l < n) for (int j = 0; j < n; ++j) { const u64 a = K[2 * j], b = K[2 * j + 1]; rk += (a < k1[l] || (a == k1[l] && b < k2[l])) ? 1 : 0; }
-    rank[l] = rk;
+  LV<int> rank[QM_SEL_CHUNKS]; LV<SelRec> mine[QM_SEL_CHUNKS];
+  for (int c = 0; c < QM_SEL_CHUNKS && 64 * c < n; ++c) {
+    QM_LANES(l) {
+      const int i = 64 * c + l;
+      int rk = 0;
+      if (i < n) {
+        const u64 k1 = K[2 * i], k2 = K[2 * i + 1];
+        for (int j = 0; j < n; ++j) { const u64 a = K[2 * j], b = K[2 * j + 1]; rk += (a < k1 || (a == k1 && b < k2)) ? 1 : 0; }
+        mine[c][l] = S.rec[i];
+      }
+      rank[c][l] = rk;
+    }
   }
   wave_fence();
-  LV<SelRec> mine;
-  QM_LANES(l) { if (l < n) mine[l] = S.rec[l]; }
-  wave_fence();
-  QM_LANES(l) { if (l < n) S.rec[rank[l]] = mine[l]; }
+  for (int c = 0; c < QM_SEL_CHUNKS && 64 * c < n; ++c) { QM_LANES(l) { if (64 * c + l < n) S.rec[rank[c][l]] = mine[c][l]; } }
   wave_fence();
 }
 
-// sel_strand for several intervals when the n <= 64 records are already in chain order (sel_wave_sort): the lane that
-// holds a transcript's first record counts its intervals and chains its hits, all transcripts at once; the groups are
-// then packed in transcript order by prefix sums over the lanes.
+// sel_strand for several intervals when the n <= 64 * QM_SEL_CHUNKS records are already in chain order (sel_wave_sort): the
+// lane that holds a transcript's first record counts its intervals and chains its hits, all transcripts of a 64-record
+// chunk at once; the groups are then packed in transcript order by prefix sums over the lanes and chunks.
 template <typename SS>
 QM_DEV void sel_strand_wave(SS& S, int s, int n, int m, u32 readLen, float consensusFraction) {
 #pragma clang fp contract(off)
@@ -291,42 +296,72 @@ QM_DEV void sel_strand_wave(SS& S, int s, int n, int m, u32 readLen, float conse
     requiredNumHits = fl > 1 ? fl : 1;
     maxSlack = m - requiredNumHits;
   }
-  LV<bool> head;
-  QM_LANES(l) { head[l] = l < n && (l == 0 || S.rec[l].tid != S.rec[l - 1].tid); }
-  const u64 hm = ballot(head);
-  LV<int> g1v, nav; LV<bool> req;
-  QM_LANES(l) {
-    g1v[l] = 0; nav[l] = 0; req[l] = false;
-    if (head[l]) {
-      const u64 rest = l < 63 ? (hm & ~lanemask_lt(l + 1)) : 0ULL;
-      const int g1 = rest ? ctz64(rest) : n;
-      u64 mk[QM_SEL_MAXIV / 64] = {0, 0, 0, 0};
-      for (int i = l; i < g1; ++i) { const u32 iv = S.rec[i].iv; mk[iv >> 6] |= 1ULL << (iv & 63); }
-      g1v[l] = g1; nav[l] = popc64(mk[0]) + popc64(mk[1]) + popc64(mk[2]) + popc64(mk[3]);
-      req[l] = nav[l] >= requiredNumHits;
-    }
+  u64 hm[QM_SEL_CHUNKS] = {0, 0, 0, 0};
+  LV<bool> head[QM_SEL_CHUNKS];
+  for (int c = 0; c < QM_SEL_CHUNKS; ++c) {
+    QM_LANES(l) { const int i = 64 * c + l; head[c][l] = i < n && (i == 0 || S.rec[i].tid != S.rec[i - 1].tid); }
+    hm[c] = ballot(head[c]);
   }
-  const bool allActive = maxSlack > 0 && ballot(req) == 0;   // HitManager.cpp:682-686
-  LV<int> nsv; LV<SelGroup> gv; LV<bool> em;
-  QM_LANES(l) {
-    nsv[l] = 0; em[l] = false;
-    if (head[l] && (req[l] || allActive)) {
-      nsv[l] = sel_chain_group(S.rec + l, g1v[l] - l, S.f + l, S.p + l, S.seen + l, S.ends + l, S.starts + l, (int)readLen, gv[l], S.ends + l);
-      em[l] = nsv[l] > 0;
+  LV<int> g1v[QM_SEL_CHUNKS]; LV<bool> req[QM_SEL_CHUNKS];
+  bool anyReq = false;
+  for (int c = 0; c < QM_SEL_CHUNKS && 64 * c < n; ++c) {
+    QM_LANES(l) {
+      g1v[c][l] = 0; req[c][l] = false;
+      if (head[c][l]) {
+        const int i = 64 * c + l;
+        // the group ends at the next head: above this lane in the same chunk, else the first head of a later chunk
+        int g1 = n;
+        u64 rest = l < 63 ? (hm[c] & ~lanemask_lt(l + 1)) : 0ULL;
+        if (rest) g1 = 64 * c + ctz64(rest);
+        else for (int d = c + 1; d < QM_SEL_CHUNKS; ++d) if (hm[d]) { g1 = 64 * d + ctz64(hm[d]); break; }
+        u64 mk[QM_SEL_MAXIV / 64] = {0, 0, 0, 0};
+        for (int j = i; j < g1; ++j) { const u32 iv = S.rec[j].iv; mk[iv >> 6] |= 1ULL << (iv & 63); }
+        g1v[c][l] = g1;
+        req[c][l] = popc64(mk[0]) + popc64(mk[1]) + popc64(mk[2]) + popc64(mk[3]) >= requiredNumHits;
+      }
     }
+    anyReq = anyReq || ballot(req[c]) != 0;
   }
-  const u64 emm = ballot(em);
-  QM_LANES(l) { if (em[l]) S.starts[l] = nsv[l]; }
+  const bool allActive = maxSlack > 0 && !anyReq;           // HitManager.cpp:682-686
+  LV<int> nsv[QM_SEL_CHUNKS]; LV<SelGroup> gv[QM_SEL_CHUNKS]; LV<bool> em[QM_SEL_CHUNKS];
+  u64 emm[QM_SEL_CHUNKS] = {0, 0, 0, 0};
+  for (int c = 0; c < QM_SEL_CHUNKS; ++c) {
+    QM_LANES(l) {
+      nsv[c][l] = 0; em[c][l] = false;
+      if (64 * c < n && head[c][l] && (req[c][l] || allActive)) {
+        const int i = 64 * c + l;
+        nsv[c][l] = sel_chain_group(S.rec + i, g1v[c][l] - i, S.f + i, S.p + i, S.seen + i, S.ends + i, S.starts + i, (int)readLen, gv[c][l], S.ends + i);
+        em[c][l] = nsv[c][l] > 0;
+      }
+    }
+    emm[c] = ballot(em[c]);
+    QM_LANES(l) { if (em[c][l]) S.starts[64 * c + l] = nsv[c][l]; }
+  }
   wave_fence();
-  QM_LANES(l) {
-    int tot = 0, mine = 0;
-    for (u64 r = emm; r; r &= r - 1) { const int j = ctz64(r); const int c = S.starts[j]; if (j < l) mine += c; tot += c; }
-    if (em[l]) {
-      SelGroup g = gv[l]; g.off = (short)mine;
-      G[popc64(emm & lanemask_lt(l))] = g;
-      for (int t = 0; t < nsv[l]; ++t) P[mine + t] = S.ends[l + t];
+  int ngAll = 0;
+  for (int c = 0; c < QM_SEL_CHUNKS; ++c) ngAll += popc64(emm[c]);
+  if (ngAll > SS::gcap) { QM_LANES(l) { if (l == 0) S.ngrp[s] = -1; } return; }   // more transcripts than this scratch holds
+  for (int c = 0; c < QM_SEL_CHUNKS; ++c) {
+    QM_LANES(l) {
+      if (em[c][l]) {
+        int mine = 0, ord = 0;                             // positions / groups emitted by the heads before this one
+        for (int d = 0; d <= c; ++d) {
+          u64 r = d < c ? emm[d] : (emm[d] & lanemask_lt(l));
+          ord += popc64(r);
+          for (; r; r &= r - 1) mine += S.starts[64 * d + ctz64(r)];
+        }
+        SelGroup g = gv[c][l]; g.off = (short)mine;
+        G[ord] = g;
+        for (int t = 0; t < nsv[c][l]; ++t) P[mine + t] = S.ends[64 * c + l + t];
+      }
     }
-    if (l == 0) { S.ngrp[s] = popc64(emm); S.npos[s] = tot; }
+  }
+  QM_LANES(l) {
+    if (l == 0) {
+      int tot = 0;
+      for (int d = 0; d < QM_SEL_CHUNKS; ++d) for (u64 r = emm[d]; r; r &= r - 1) tot += S.starts[64 * d + ctz64(r)];
+      S.ngrp[s] = ngAll; S.npos[s] = tot;
+    }
   }
 }
 
@@ -340,21 +375,23 @@ QM_DEV int sel_h2m_on(const DevIndex& ix, const ReadBatch& B, const IntervalList
     if (L.n > QM_SEL_MAXIV) return -1;
     for (int ii = 0; ii < L.n; ++ii) { int lb, ub; u32 ln, qp; L.get(ii, lb, ub, ln, qp); n += ub - lb; }
     if (n > SS::cap) return -1;
-    if (n <= 64) {
-      // the usual case: one lane per suffix over all the intervals at once -- one trip to sainfo for the strand
-      LV<int> sa; LV<u32> qv, lv, iv;
-      QM_LANES(l) { sa[l] = -1; qv[l] = 0; lv[l] = 0; iv[l] = 0; }
-      int acc = 0;
-      for (int ii = 0; ii < L.n; ++ii) {
-        int lb, ub; u32 ln, qp; L.get(ii, lb, ub, ln, qp);
-        QM_LANES(l) { if (l >= acc && l < acc + (ub - lb)) { sa[l] = lb + (l - acc); qv[l] = qp; lv[l] = ln; iv[l] = (u32)ii; } }
-        acc += ub - lb;
-      }
-      QM_LANES(l) {
-        if (sa[l] >= 0) {
-          SaInfo e = ix.sainfo[sa[l]];
-          SelRec r; r.tid = e.tid; r.pos = (u32)e.pos; r.qpos = qv[l]; r.len = lv[l]; r.iv = iv[l];
-          S.rec[l] = r;
+    if (n <= 64 * QM_SEL_CHUNKS) {
+      // the usual case: one lane per suffix over all the intervals at once -- one trip to sainfo per 64 suffixes of the strand
+      for (int base = 0; base < n; base += 64) {
+        LV<int> sa; LV<u32> qv, lv, iv;
+        QM_LANES(l) { sa[l] = -1; qv[l] = 0; lv[l] = 0; iv[l] = 0; }
+        int acc = 0;
+        for (int ii = 0; ii < L.n && acc < base + 64; ++ii) {
+          int lb, ub; u32 ln, qp; L.get(ii, lb, ub, ln, qp);
+          QM_LANES(l) { const int i = base + l; if (i >= acc && i < acc + (ub - lb)) { sa[l] = lb + (i - acc); qv[l] = qp; lv[l] = ln; iv[l] = (u32)ii; } }
+          acc += ub - lb;
+        }
+        QM_LANES(l) {
+          if (sa[l] >= 0) {
+            SaInfo e = ix.sainfo[sa[l]];
+            SelRec r; r.tid = e.tid; r.pos = (u32)e.pos; r.qpos = qv[l]; r.len = lv[l]; r.iv = iv[l];
+            S.rec[base + l] = r;
+          }
         }
       }
     } else {
@@ -376,11 +413,13 @@ QM_DEV int sel_h2m_on(const DevIndex& ix, const ReadBatch& B, const IntervalList
       }
     }
     wave_fence();
-    const bool presorted = n <= 64 && 2 * n * (int)sizeof(u64) <= (int)sizeof(S.tmp);
+    const bool presorted = n <= 64 * QM_SEL_CHUNKS && 2 * n * (int)sizeof(u64) <= (int)sizeof(S.tmp);
     if (presorted && L.n > 0) sel_wave_sort(S, n, L.n);
     if (presorted && L.n > 1) sel_strand_wave(S, s, n, L.n, readLen, B.consensus_fraction);
     else QM_LANES(l) { if (l == 0) { if (L.n > 0) sel_strand(S, s, n, L.n, readLen, mate, B.consensus_fraction, presorted); else { S.ngrp[s] = 0; S.npos[s] = 0; } } }
     wave_fence();
+    LV<int> ngv; QM_LANES(l) { ngv[l] = S.ngrp[s]; }
+    if (read_lane(ngv, 0) < 0) return -1;
   }
   LV<int> nw;
   QM_LANES(l) { nw[l] = 0; if (l == 0) nw[l] = sel_emit(S); }

@@ -160,6 +160,27 @@ def test_medium(synth_medium, oracle_mod):
     _cmp_ints(res, er)
 
 
+def test_selective_alignment_long_reads_many_suffixes(synth_medium, oracle_mod):
+    """-s on 150 and 250 bp reads against the isoform-rich medium index: 15-30 seed intervals per strand bring 45-200
+    suffixes, i.e. the lane-parallel sort / chaining over several 64-record chunks (and, beyond 256, lane 0's fallback)"""
+    import rapmap_amd as ra
+    from rapmap_amd import synth
+    ix, orc, em, emu = _emu(synth_medium["idx"])
+    qi = ra.QuasiIndex(synth_medium["idx"])
+    text, offsets = qi.arrays()
+    text = np.asarray(text); offsets = np.asarray(offsets, dtype=np.int64)
+    ends = np.append(offsets[1:], text.size)
+    txps = [text[a:b - 1] for a, b in zip(offsets, ends) if b - 1 - a >= 700][:1500]
+    for L, ns, n in ((150, 3, 1500), (250, 4, 600)):
+        s1, s2, off, _ = synth.make_reads(txps, n, seed=11 + L, read_len=L, err=0.01)
+        for oo, go in (({"selAln": 1}, {"sel_aln": 1}), ({"selAln": 1, "consensusSlack": 0.35}, {"sel_aln": 1, "consensus_slack": 0.35})):
+            res = orc.map_pairs(s1, off, s2, off, opts=oracle_mod.default_opts(**oo), nthreads=8)
+            er = em.map(s1, off, s2, off, opts=emu.default_opts(**go), ns=ns)
+            assert er.status == 0
+            assert_hits_equal(res.hit_offsets, res.hits, er.hit_offsets, er.hits, "-s %d bp %s" % (L, oo))
+            assert res.counters == er.counters
+
+
 def test_repeat_families(repeat_data, oracle_mod):
     """reads inside repeat cores: 40 / 300 / 1100 copies -> lists beyond the LDS lists (global scratch),
     > maxNumHits (tooManyHits) and >= maxInterval (skipped intervals)"""
