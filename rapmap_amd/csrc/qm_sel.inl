@@ -149,6 +149,14 @@ QM_DEV int sel_chain_group(const SelRec* H, int hn, double* f, int* p, int* seen
   return nStarts;
 }
 
+// set of SA intervals a transcript occurs in (<= QM_SEL_MAXIV = 256): four words updated by selects -- indexing an array
+// with iv >> 6 would put it in scratch memory
+struct SelIvSet {
+  u64 a = 0, b = 0, c = 0, d = 0;
+  QM_DEV void add(u32 iv) { const u64 bit = 1ULL << (iv & 63); const u32 w = iv >> 6; a |= w == 0 ? bit : 0ULL; b |= w == 1 ? bit : 0ULL; c |= w == 2 ? bit : 0ULL; d |= w == 3 ? bit : 0ULL; }
+  QM_DEV int count() const { return popc64(a) + popc64(b) + popc64(c) + popc64(d); }
+};
+
 // One strand: S.rec[0..n) holds every (tid, pos, qpos, len, interval) of the strand's m intervals.  Lane-0 code.
 template <typename SS>
 QM_DEV void sel_strand(SS& S, int s, int n, int m, u32 readLen, int mate, float consensusFraction, bool presorted) {
@@ -191,9 +199,9 @@ QM_DEV void sel_strand(SS& S, int s, int n, int m, u32 readLen, int mate, float 
   // first pass: is any transcript active?
   bool anyActive = false;
   for (int g0 = 0; g0 < n;) {
-    int g1 = g0; u64 mk[QM_SEL_MAXIV / 64] = {0, 0, 0, 0};
-    while (g1 < n && S.rec[g1].tid == S.rec[g0].tid) { mk[S.rec[g1].iv >> 6] |= 1ULL << (S.rec[g1].iv & 63); ++g1; }
-    int na = popc64(mk[0]) + popc64(mk[1]) + popc64(mk[2]) + popc64(mk[3]);
+    int g1 = g0; SelIvSet mk;
+    while (g1 < n && S.rec[g1].tid == S.rec[g0].tid) { mk.add(S.rec[g1].iv); ++g1; }
+    int na = mk.count();
     S.seen[g0] = na;                                   // parked: #intervals of the group starting at g0
     if (na >= requiredNumHits) anyActive = true;
     g0 = g1;
@@ -253,7 +261,9 @@ QM_DEV int sel_emit(SS& S) {
 template <typename SS>
 QM_DEV void sel_wave_sort(SS& S, int n, int m) {
   u64* K = (u64*)S.tmp;                              // keys where every lane can read them (2 words per record)
-  for (int c = 0; c < QM_SEL_CHUNKS && 64 * c < n; ++c) {
+#pragma unroll
+  for (int c = 0; c < QM_SEL_CHUNKS; ++c) {
+    if (64 * c >= n) continue;
     QM_LANES(l) {
       const int i = 64 * c + l;
       if (i < n) {
@@ -265,7 +275,9 @@ QM_DEV void sel_wave_sort(SS& S, int n, int m) {
   }
   wave_fence();
   LV<int> rank[QM_SEL_CHUNKS]; LV<SelRec> mine[QM_SEL_CHUNKS];
-  for (int c = 0; c < QM_SEL_CHUNKS && 64 * c < n; ++c) {
+#pragma unroll
+  for (int c = 0; c < QM_SEL_CHUNKS; ++c) {
+    if (64 * c >= n) continue;
     QM_LANES(l) {
       const int i = 64 * c + l;
       int rk = 0;
@@ -278,7 +290,8 @@ QM_DEV void sel_wave_sort(SS& S, int n, int m) {
     }
   }
   wave_fence();
-  for (int c = 0; c < QM_SEL_CHUNKS && 64 * c < n; ++c) { QM_LANES(l) { if (64 * c + l < n) S.rec[rank[c][l]] = mine[c][l]; } }
+#pragma unroll
+  for (int c = 0; c < QM_SEL_CHUNKS; ++c) { if (64 * c < n) { QM_LANES(l) { if (64 * c + l < n) S.rec[rank[c][l]] = mine[c][l]; } } }
   wave_fence();
 }
 
@@ -298,13 +311,16 @@ QM_DEV void sel_strand_wave(SS& S, int s, int n, int m, u32 readLen, float conse
   }
   u64 hm[QM_SEL_CHUNKS] = {0, 0, 0, 0};
   LV<bool> head[QM_SEL_CHUNKS];
+#pragma unroll
   for (int c = 0; c < QM_SEL_CHUNKS; ++c) {
     QM_LANES(l) { const int i = 64 * c + l; head[c][l] = i < n && (i == 0 || S.rec[i].tid != S.rec[i - 1].tid); }
     hm[c] = ballot(head[c]);
   }
   LV<int> g1v[QM_SEL_CHUNKS]; LV<bool> req[QM_SEL_CHUNKS];
   bool anyReq = false;
-  for (int c = 0; c < QM_SEL_CHUNKS && 64 * c < n; ++c) {
+#pragma unroll
+  for (int c = 0; c < QM_SEL_CHUNKS; ++c) {
+    if (64 * c >= n) continue;
     QM_LANES(l) {
       g1v[c][l] = 0; req[c][l] = false;
       if (head[c][l]) {
@@ -313,11 +329,14 @@ QM_DEV void sel_strand_wave(SS& S, int s, int n, int m, u32 readLen, float conse
         int g1 = n;
         u64 rest = l < 63 ? (hm[c] & ~lanemask_lt(l + 1)) : 0ULL;
         if (rest) g1 = 64 * c + ctz64(rest);
-        else for (int d = c + 1; d < QM_SEL_CHUNKS; ++d) if (hm[d]) { g1 = 64 * d + ctz64(hm[d]); break; }
-        u64 mk[QM_SEL_MAXIV / 64] = {0, 0, 0, 0};
-        for (int j = i; j < g1; ++j) { const u32 iv = S.rec[j].iv; mk[iv >> 6] |= 1ULL << (iv & 63); }
+        else {
+#pragma unroll
+          for (int d = QM_SEL_CHUNKS - 1; d > 0; --d) if (d > c && hm[d]) g1 = 64 * d + ctz64(hm[d]);   // the lowest such d wins
+        }
+        SelIvSet mk;
+        for (int j = i; j < g1; ++j) mk.add(S.rec[j].iv);
         g1v[c][l] = g1;
-        req[c][l] = popc64(mk[0]) + popc64(mk[1]) + popc64(mk[2]) + popc64(mk[3]) >= requiredNumHits;
+        req[c][l] = mk.count() >= requiredNumHits;
       }
     }
     anyReq = anyReq || ballot(req[c]) != 0;
@@ -325,6 +344,7 @@ QM_DEV void sel_strand_wave(SS& S, int s, int n, int m, u32 readLen, float conse
   const bool allActive = maxSlack > 0 && !anyReq;           // HitManager.cpp:682-686
   LV<int> nsv[QM_SEL_CHUNKS]; LV<SelGroup> gv[QM_SEL_CHUNKS]; LV<bool> em[QM_SEL_CHUNKS];
   u64 emm[QM_SEL_CHUNKS] = {0, 0, 0, 0};
+#pragma unroll
   for (int c = 0; c < QM_SEL_CHUNKS; ++c) {
     QM_LANES(l) {
       nsv[c][l] = 0; em[c][l] = false;
@@ -339,13 +359,17 @@ QM_DEV void sel_strand_wave(SS& S, int s, int n, int m, u32 readLen, float conse
   }
   wave_fence();
   int ngAll = 0;
+#pragma unroll
   for (int c = 0; c < QM_SEL_CHUNKS; ++c) ngAll += popc64(emm[c]);
   if (ngAll > SS::gcap) { QM_LANES(l) { if (l == 0) S.ngrp[s] = -1; } return; }   // more transcripts than this scratch holds
+#pragma unroll
   for (int c = 0; c < QM_SEL_CHUNKS; ++c) {
     QM_LANES(l) {
       if (em[c][l]) {
         int mine = 0, ord = 0;                             // positions / groups emitted by the heads before this one
-        for (int d = 0; d <= c; ++d) {
+#pragma unroll
+        for (int d = 0; d < QM_SEL_CHUNKS; ++d) {
+          if (d > c) continue;
           u64 r = d < c ? emm[d] : (emm[d] & lanemask_lt(l));
           ord += popc64(r);
           for (; r; r &= r - 1) mine += S.starts[64 * d + ctz64(r)];
@@ -359,6 +383,7 @@ QM_DEV void sel_strand_wave(SS& S, int s, int n, int m, u32 readLen, float conse
   QM_LANES(l) {
     if (l == 0) {
       int tot = 0;
+#pragma unroll
       for (int d = 0; d < QM_SEL_CHUNKS; ++d) for (u64 r = emm[d]; r; r &= r - 1) tot += S.starts[64 * d + ctz64(r)];
       S.ngrp[s] = ngAll; S.npos[s] = tot;
     }
