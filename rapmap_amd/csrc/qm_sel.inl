@@ -840,49 +840,50 @@ QM_DEV void sel_ksw_extz2_rows(const LV<int>& qlenv, const LV<int>& tlenv, KswRo
     LV<int> prevOld;
     QM_LANES(l) { prevOld[l] = bpack[l]; }
     for (int it = 0; it < 5; ++it) {
+      // every lane computes its cell whether it is in range or not (all loads stay inside the row's block: ring slots, and
+      // image indices clamped into the images); only the two stores are predicated -- far fewer exec-mask round trips
       LV<int> old, sCur; LV<bool> inCore, inScore;
       QM_LANES(l) {
         const int t = stv[l] + 16 * it + (l & 15);
+        KswRow& B = blk[l >> 4];
         inCore[l] = act[l] && t <= env[l];
         inScore[l] = act[l] && t >= st0v[l] && t <= smaxv[l];
-        old[l] = 0; sCur[l] = 0;
-        if (inCore[l] || inScore[l]) { KswRow& B = blk[l >> 4]; old[l] = (int)B.ST[t & 63]; sCur[l] = B.SS[t & 63]; }
+        old[l] = (int)B.ST[t & 63]; sCur[l] = B.SS[t & 63];
       }
       LV<bool> any;
       QM_LANES(l) { any[l] = inCore[l] || inScore[l]; }
       if (!ballot(any)) break;
       QM_LANES(l) {
-        if (inScore[l]) {
-          KswRow& B = blk[l >> 4];
-          const int t = stv[l] + 16 * it + (l & 15);
-          const int sv = B.QX[16 + r - t], sq = B.TX[t];
-          int tmp = (sq == sv) ? sc_mch : sc_mis;
-          if (sq == m1 || sv == m1) tmp = sc_N;
-          sCur[l] = tmp; B.SS[t & 63] = (unsigned char)tmp;
-        }
+        KswRow& B = blk[l >> 4];
+        const int t = stv[l] + 16 * it + (l & 15);
+        int qi = 16 + r - t; qi = qi < 0 ? 0 : (qi > QM_KSW_MAXLEN + 39 ? QM_KSW_MAXLEN + 39 : qi);
+        const int ti = t > QM_KSW_MAXLEN + 39 ? QM_KSW_MAXLEN + 39 : t;
+        const int sv = B.QX[qi], sq = B.TX[ti];
+        int tmp = (sq == sv) ? sc_mch : sc_mis;
+        tmp = (sq == m1 || sv == m1) ? sc_N : tmp;
+        sCur[l] = inScore[l] ? tmp : sCur[l];
+        if (inScore[l]) B.SS[t & 63] = (unsigned char)tmp;
       }
       LV<int> nb, carry;
       row_rotate_up(old, nb); row_rotate_up(prevOld, carry);
       QM_LANES(l) {
-        if (inCore[l]) {
-          KswRow& B = blk[l >> 4];
-          const int t = stv[l] + 16 * it + (l & 15);
-          const int xv = (l & 15) == 0 ? carry[l] : nb[l];
-          const int xt1 = (xv >> 16) & 0xff, vt1 = (xv >> 8) & 0xff;
-          const int ut = old[l] & 0xff, yt = (old[l] >> 24) & 0xff;
-          int z = (sCur[l] + qe2) & 0xff;
-          int a = (xt1 + vt1) & 0xff;
-          int b = (yt + ut) & 0xff;
-          z = ((signed char)z > (signed char)a) ? z : a;
-          z = z > b ? z : b;
-          z = z < max_sc_v ? z : max_sc_v;
-          const int un = (z - vt1) & 0xff, vn = (z - ut) & 0xff;
-          z = (z - qv) & 0xff;
-          a = (a - z) & 0xff; b = (b - z) & 0xff;
-          const int xn = (signed char)a > 0 ? a : 0, yn = (signed char)b > 0 ? b : 0;
-          B.ST[t & 63] = (u32)un | ((u32)vn << 8) | ((u32)xn << 16) | ((u32)yn << 24);
-          prevOld[l] = old[l];
-        }
+        KswRow& B = blk[l >> 4];
+        const int t = stv[l] + 16 * it + (l & 15);
+        const int xv = (l & 15) == 0 ? carry[l] : nb[l];
+        const int xt1 = (xv >> 16) & 0xff, vt1 = (xv >> 8) & 0xff;
+        const int ut = old[l] & 0xff, yt = (old[l] >> 24) & 0xff;
+        int z = (sCur[l] + qe2) & 0xff;
+        int a = (xt1 + vt1) & 0xff;
+        int b = (yt + ut) & 0xff;
+        z = ((signed char)z > (signed char)a) ? z : a;
+        z = z > b ? z : b;
+        z = z < max_sc_v ? z : max_sc_v;
+        const int un = (z - vt1) & 0xff, vn = (z - ut) & 0xff;
+        z = (z - qv) & 0xff;
+        a = (a - z) & 0xff; b = (b - z) & 0xff;
+        const int xn = (signed char)a > 0 ? a : 0, yn = (signed char)b > 0 ? b : 0;
+        if (inCore[l]) B.ST[t & 63] = (u32)un | ((u32)vn << 8) | ((u32)xn << 16) | ((u32)yn << 24);
+        prevOld[l] = inCore[l] ? old[l] : prevOld[l];
       }
       wave_fence();
     }
@@ -898,17 +899,13 @@ QM_DEV void sel_ksw_extz2_rows(const LV<int>& qlenv, const LV<int>& tlenv, KswRo
       QM_LANES(l) {
         const int t = st0v[l] + (l & 15) + 16 * k;
         has[l] = act[l] && t <= en0v[l];
-        hn[l] = NEG;
-        if (has[l]) {
-          KswRow& B = blk[l >> 4];
-          const int en0 = en0v[l];
-          const u32 pk = B.ST[t & 63];
-          const int un = (int)(pk & 0xff), vn = (int)((pk >> 8) & 0xff);
-          if (r > 0) {
-            if (t == en0) hn[l] = en0 > 0 ? (hLeft[l] + un - qe) : (B.HH[t & 63] + vn - qe);
-            else hn[l] = B.HH[t & 63] + vn - qe;
-          } else hn[l] = vn - qe - qe;                    // r == 0: the only cell is t == 0
-        }
+        KswRow& B = blk[l >> 4];
+        const int en0 = en0v[l];
+        const u32 pk = B.ST[t & 63];
+        const int un = (int)(pk & 0xff), vn = (int)((pk >> 8) & 0xff);
+        const int hOwn = B.HH[t & 63] + vn - qe;
+        const int hTop = en0 > 0 ? (hLeft[l] + un - qe) : hOwn;
+        hn[l] = r > 0 ? (t == en0 ? hTop : hOwn) : (vn - qe - qe);   // r == 0: the only cell is t == 0
       }
       if (!ballot(has)) break;
       wave_fence();
