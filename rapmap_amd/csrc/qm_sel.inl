@@ -805,20 +805,17 @@ QM_DEV void sel_ksw_extz2_rows(const LV<int>& qlenv, const LV<int>& tlenv, KswRo
     // boundary of the first vector (x / v of column st - 1 as the last round left them), H of column st - 1 when the window moves
     LV<int> bpack, hbNew; LV<bool> moved;
     QM_LANES(l) {
-      bpack[l] = 0; hbNew[l] = NEG; moved[l] = false;
-      if (act[l]) {
-        KswRow& B = blk[l >> 4];
-        const int st = stv[l];
-        if (st > 0) {
-          if (st - 1 >= lastSt[l] && st - 1 <= lastEn[l]) bpack[l] = (int)(B.ST[(st - 1) & 63] & 0x00ffff00u);   // v, x
-        } else bpack[l] = (r ? qv : 0) << 8;
-        moved[l] = st != lastSt[l];
-        if (moved[l] && st > 0 && lastSt[l] >= 0) hbNew[l] = B.HH[(st - 1) & 63];
-      }
+      KswRow& B = blk[l >> 4];
+      const int st = stv[l];
+      const int left = (int)(B.ST[(st - 1) & 63] & 0x00ffff00u), hleft = B.HH[(st - 1) & 63];   // v, x and H of column st - 1
+      bpack[l] = st > 0 ? ((st - 1 >= lastSt[l] && st - 1 <= lastEn[l]) ? left : 0) : ((r ? qv : 0) << 8);
+      moved[l] = act[l] && st != lastSt[l];
+      hbNew[l] = (st > 0 && lastSt[l] >= 0) ? hleft : NEG;
     }
     wave_fence();
+    if (ballot(moved))                                    // rare: a row's window advances every ~32 rounds
     QM_LANES(l) {
-      if (act[l] && moved[l]) {
+      if (moved[l]) {
         KswRow& B = blk[l >> 4];
         hb[l] = hbNew[l];
         for (int k = 0; k < 4; ++k) {
@@ -830,8 +827,11 @@ QM_DEV void sel_ksw_extz2_rows(const LV<int>& qlenv, const LV<int>& tlenv, KswRo
       }
     }
     wave_fence();
+    LV<bool> diag;
+    QM_LANES(l) { diag[l] = act[l] && env[l] >= r && (l & 15) == (r & 15); }
+    if (ballot(diag))                                     // only while the band still touches the diagonal (the first ~w rounds)
     QM_LANES(l) {                                       // the diagonal cell: y8[r] = 0, u8[r] = r ? q : 0
-      if (act[l] && env[l] >= r && (l & 15) == (r & 15)) {
+      if (diag[l]) {
         KswRow& B = blk[l >> 4];
         B.ST[r & 63] = (B.ST[r & 63] & 0x00ffff00u) | (u32)(r ? qv : 0);
       }
