@@ -134,7 +134,10 @@ int64_t qm_ctx_device_bytes(const qm_ctx* ctx);
 
 /* Map n read pairs held in HOST memory.  seqX = concatenated read bytes (ASCII,
  * any case, N allowed), offX[n+1] = byte offsets.  Results stay in the context;
- * *n_hits receives the total number of hits.  counters may be NULL. */
+ * *n_hits receives the total number of hits.  counters may be NULL.
+ * The buffers may be pageable: the characters are uploaded in chunks on a copy
+ * stream and every chunk is mapped as soon as it has arrived, so transfer and
+ * mapping overlap inside one call; nothing is in flight once the call returns. */
 int qm_map_pairs(qm_ctx* ctx, const qm_opts* opts, int64_t n, const char* seq1, const int64_t* off1,
                  const char* seq2, const int64_t* off2, int64_t* n_hits, qm_counters* counters);
 /* Same for single-end reads (processReadsSingleSA, src/RapMapSAMapper.cpp:232-250). */
@@ -146,7 +149,8 @@ int qm_map_device(qm_ctx* ctx, const qm_opts* opts, int64_t n, const void* d_seq
                   const void* d_seq2, const void* d_off2, int32_t max_read_len, int64_t* n_hits,
                   qm_counters* counters);
 /* Copy the results of the last map call to host memory:
- * hit_offsets[n+1] (exclusive prefix sum), hits[n_hits]. */
+ * hit_offsets[n+1] (exclusive prefix sum), hits[n_hits].  Large results come
+ * down through pinned staging buffers and are placed by several host threads. */
 int qm_fetch_hits(qm_ctx* ctx, int64_t* hit_offsets, qm_hit* hits);
 /* Device pointers of the same arrays (valid until the next map call on ctx). */
 int qm_result_device(qm_ctx* ctx, const void** d_hit_offsets, const void** d_hits);
