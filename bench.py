@@ -5,8 +5,10 @@ One "step" = one pass of the hot path (qm_map_device: SACollector x2 -> hitsToMa
 mergeLeftRightHits for every pair, then the CSR compaction of the hits and the counter read-back)
 over one batch of synthetic 2x100 bp read pairs that is already resident in HBM.  Workload at N=1 =
 BASELINE.json configs[1]: GENCODE-like ~200k-transcript index, 10 M pairs per GPU, hits only.
-For N>1 every rank owns its own 10 M-pair shard (weak scaling), the index is replicated, and the only
-collective is the all-reduce of the six HitCounters per step (RCCL over xGMI).
+For N>1 every rank owns its own shard of pairs generated from its own seed (weak scaling: 10 M pairs per GPU; at
+N=8 12.5 M per GPU = BASELINE.json configs[2], 100 M pairs over the node), the index is replicated, and the only
+collective is the all-reduce of the six HitCounters per step (RCCL over xGMI).  `python bench.py --gpus N` without a
+launcher re-executes itself under torch.distributed.run with N ranks.
 
 Prints ONE JSON line on rank 0 (see the driver contract) with `roofline` and `cpu_baseline` objects.
 """
@@ -118,7 +120,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--genes", type=int, default=40000, help="synthetic genes (40000 ~ 200k transcripts, 3e8 bases)")
-    ap.add_argument("--pairs", type=int, default=10_000_000, help="read pairs per GPU per step")
+    ap.add_argument("--pairs", type=int, default=None, help="read pairs per GPU per step (default: 10 M = configs[1]; "
+                    "12.5 M at 8 GPUs = configs[2], 100 M pairs over the node)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sel-aln", action="store_true", help="config 5: selective alignment (-s): chaining + ksw2 extension alignment of every hit")
@@ -127,11 +130,26 @@ def main():
     ap.add_argument("--cache", default=os.environ.get("QMAP_BENCH_CACHE", "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"))
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as a plain `python bench.py --gpus N`: become the launcher the driver would have used -- one rank per GPU
+        # under torch.distributed.run, rendezvous on 127.0.0.1 -- and hand its exit code on.  Rank 0's JSON line goes to our stdout.
+        import socket
+        import subprocess
+        s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and rank == 0:
+        log("--gpus %d but WORLD_SIZE=%d: the launcher decides, running %d rank(s)" % (args.gpus, world, world))
+    if args.pairs is None:
+        args.pairs = 12_500_000 if world == 8 else 10_000_000
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d has no GPU of its own (%d visible): one process per GPU" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -195,7 +213,7 @@ def main():
             "vs_baseline": None, "dtype": "u8/int32/u64 (integer & byte work, no floating point)", "data": "synthetic",
             "config": {"workload": ("configs[%d]: GENCODE-like synthetic index (%d genes -> %d transcripts, %d text bytes, "
                                     "%d 31-mers), %d pairs 2x%d bp per GPU per step, 1%% substitutions, %s, %s index") % (
-                                        4 if args.sel_aln else (3 if args.perfect_hash else 1), args.genes, qi.n_txps, qi.text_len, qi.n_keys, n, L,
+                                        4 if args.sel_aln else (3 if args.perfect_hash else (2 if world == 8 else 1)), args.genes, qi.n_txps, qi.text_len, qi.n_keys, n, L,
                                         "selective alignment (-s)" if args.sel_aln else "hits only (no -s)",
                                         "perfect-hash (-p)" if args.perfect_hash else "dense hash"),
                        "pairs_per_gpu_per_step": n, "parallelism": "shard%d (index replicated, counters all-reduced)" % world,
@@ -261,7 +279,7 @@ def main():
         # per pair of this workload: recorded by an N=1 run on this box, else the committed figure of the default workload.
         out["cpu_baseline"] = None
         out["roofline"] = None
-        default_workload = n == 10_000_000 and args.genes == 40000 and L == 100 and not args.perfect_hash and not args.sel_aln
+        default_workload = args.genes == 40000 and L == 100 and not args.perfect_hash and not args.sel_aln   # bytes per PAIR do not depend on n
         rec = None
         cands = [os.path.join(idx_dir, "algorithmic_bytes.json")]
         if default_workload:
@@ -278,7 +296,9 @@ def main():
             traffic = None
             try:
                 ent = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("perfect_hash" if args.perfect_hash else "dense") or {}
-                traffic = ent.get("hbm_bytes_per_launch") if (n == 10_000_000 and args.genes == 40000) else None
+                traffic = ent.get("hbm_bytes_per_launch") if args.genes == 40000 else None
+                if traffic is not None:
+                    traffic = traffic * (n / 10_000_000)       # measured on a 10 M-pair launch; bytes per pair are what was measured
             except Exception:
                 pass
             out["roofline"] = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

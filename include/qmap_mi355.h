@@ -166,6 +166,13 @@ int qm_fetch_intervals(qm_ctx* ctx, int64_t* int_offsets, qm_sa_interval_hit* in
  * the context's stream (milliseconds); n_launches kernels were timed. */
 int qm_last_kernel_ms(const qm_ctx* ctx, double* map_kernel_ms, double* total_ms);
 
+/* Diagnostics of the last map call on ctx (tests, tuning): which = QM_STAT_RELAUNCHES -- how often stage A was run again
+ * because the per-read hit lists outgrew their buffer (the buffer is grown and the batch redone; results are unaffected),
+ * QM_STAT_LIST_WORDS -- capacity of that buffer in 8-byte words, QM_STAT_SLOW_READS -- reads that took the per-read
+ * overflow path of -s (more suffixes than the wave's scratch holds). */
+enum { QM_STAT_RELAUNCHES = 0, QM_STAT_LIST_WORDS = 1, QM_STAT_SLOW_READS = 2 };
+int qm_ctx_stat(const qm_ctx* ctx, int which, int64_t* value);
+
 /* `rapmap quasiindex [-p]` (src/RapMapSAIndexer.cpp:449-819), int32 suffix array: FASTA -> q5 index
  * directory readable by qm_index_open and by the reference (sa.bin, txpInfo.bin, rsd.bin and -- with
  * perfect_hash -- hash_info.bph / hash_info.val come out byte-identical to the reference's).  Host only. */

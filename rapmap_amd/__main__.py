@@ -2,8 +2,9 @@
 
 Flag names, defaults and validation follow `rapmap quasiindex` (src/RapMapSAIndexer.cpp:821-927) and
 `rapmap quasimap` (src/RapMapSAMapper.cpp:984-1189, validateOpts :911-954).  Options that the device path does
-not implement (--recoverOrphans, -c) are accepted by the parser and
-rejected with the library's error, never silently ignored.
+not implement (--recoverOrphans) are accepted by the parser and rejected, never silently ignored.  -c/--chaining is
+accepted like the reference accepts it: on its own it changes nothing there either (MappingConfig::doChaining is set from
+--selAln alone, src/RapMapSAMapper.cpp:182,410).
 """
 import argparse
 import sys
@@ -40,7 +41,7 @@ def _quasimap(argv):
     ap.add_argument("-t", "--numThreads", type=int, default=8, help="host threads for read parsing and SAM formatting (the GPU does the mapping)")
     ap.add_argument("-m", "--maxNumHits", type=int, default=200, help="Reads mapping to more than this many loci are discarded")
     ap.add_argument("-o", "--output", default="", help="The output file (default: stdout)")
-    ap.add_argument("-z", "--quasiCoverage", type=float, default=0.0)
+    ap.add_argument("-z", "--quasiCoverage", type=float, default=None)
     ap.add_argument("-n", "--noOutput", action="store_true", help="Don't write out any alignments (for speed testing purposes)")
     ap.add_argument("--noSensitive", action="store_true")
     ap.add_argument("--noStrictCheck", action="store_true")
@@ -73,10 +74,19 @@ def _quasimap(argv):
     # validateOpts (src/RapMapSAMapper.cpp:911-954, :1179-1189)
     if paired == single:
         sys.exit("You must provide either paired-end (-1 and -2) or single-end (-r) reads, and not both")
+    zset = a.quasiCoverage is not None                     # TCLAP isSet(): the flag was given, whatever its value
+    if not zset:
+        a.quasiCoverage = 0.0
     if not (0.0 <= a.quasiCoverage <= 1.0):
         sys.exit("quasiCoverage must be in [0,1]")
-    if a.recoverOrphans or a.chaining:
-        sys.exit("--recoverOrphans / --chaining are not implemented on the MI355X path")
+    if a.recoverOrphans:
+        sys.exit("--recoverOrphans is not implemented on the MI355X path")
+    if zset and a.noSensitive:                             # src/RapMapSAMapper.cpp:1178-1181
+        print("The --quasiCoverage option is set to %g, but the --noSensitive flag was also set. The former forbids the later. "
+              "Enabling sensitive mode." % a.quasiCoverage, file=sys.stderr)
+        a.noSensitive = False
+    if a.chaining and not (a.selAln or a.mimicBT2 or a.mimicStrictBT2):
+        print("--chaining without --selAln does not change the mapping (as in the reference: doChaining follows --selAln)", file=sys.stderr)
 
     import rapmap_amd as ra
     from rapmap_amd import sam

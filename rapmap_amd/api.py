@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "qm_last_error", "qm_version", "qm_opts_default", "qm_index_open", "qm_index_close", "qm_index_info_get",
     "qm_index_txp_name", "qm_index_txp_len", "qm_index_arrays", "qm_ctx_create", "qm_ctx_destroy", "qm_ctx_device_bytes",
     "qm_map_pairs", "qm_map_reads", "qm_map_device", "qm_fetch_hits", "qm_result_device", "qm_ctx_set_debug",
-    "qm_fetch_intervals", "qm_last_kernel_ms", "qm_build_index",
+    "qm_fetch_intervals", "qm_last_kernel_ms", "qm_ctx_stat", "qm_build_index",
     "qm_reader_open", "qm_reader_next", "qm_reader_close", "qm_io_last_error", "qm_sam_header", "qm_sam_records",
     "qm_sam_write", "qm_buf_free",
 ]
@@ -105,6 +105,7 @@ def lib():
     L.qm_ctx_set_debug.argtypes = [C.c_void_p, C.c_int]
     L.qm_fetch_intervals.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     L.qm_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.qm_ctx_stat.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
     L.qm_build_index.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.qm_opts_default.argtypes = [C.POINTER(QmOpts)]
     L.qm_io_last_error.restype = C.c_char_p
@@ -280,6 +281,12 @@ class QuasiMapper:
         _check(lib().qm_map_device(self._h, C.byref(opts), n, d_seq1, d_off1, d_seq2, d_off2, max_read_len,
                                    C.byref(nh), C.byref(ctr)))
         return self._finish(n, nh, ctr, fetch=fetch)
+
+    def stat(self, which):
+        """qm_ctx_stat: 0 stage-A relaunches of the last call, 1 list buffer capacity (words), 2 reads on the -s slow path"""
+        v = C.c_int64()
+        _check(lib().qm_ctx_stat(self._h, int(which), C.byref(v)))
+        return v.value
 
     def intervals(self, n):
         """fwdSAInts / rcSAInts of the last map call (needs debug=True)."""

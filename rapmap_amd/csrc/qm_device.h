@@ -17,9 +17,11 @@ hipError_t qmk_build_phrecs(const int* data, const unsigned char* lens, long lon
 int qmk_map_grid(long long n, int num_cu);
 hipError_t qmk_map_reads(const void* dev_index, const void* read_batch, int ns, int grid, int num_cu, hipStream_t st);
 size_t qmk_sel_scratch_bytes(void);
-size_t qmk_sel_ksw_bytes(void);
+size_t qmk_sel_dyn_struct_bytes(void);
+unsigned long long qmk_sel_dyn_bytes(long long n);
+void qmk_sel_dyn_bind(void* host_struct, void* dev_base, long long n);
+hipError_t qmk_collect_slow(const unsigned int* lcnt, long long nreads, long long* q, unsigned long long* count, hipStream_t st);
 hipError_t qmk_sel_slots(const void* pair_batch, hipStream_t st);
-hipError_t qmk_sel_unit(const void* pair_batch, const void* sel_batch, int grid, hipStream_t st);
 hipError_t qmk_sel_three(const void* pair_batch, const void* sel_batch, int num_cu, hipStream_t st);
 size_t qmk_sel_task_bytes(void);
 hipError_t qmk_sel_compact(const void* pair_batch, const void* tmp, const void* toff, hipStream_t st);

@@ -96,13 +96,15 @@ struct qm_ctx {
   // -s (selective alignment) work areas
   int32_t* d_txpOff = nullptr; int32_t* d_txpLen = nullptr;
   unsigned char* d_selscr = nullptr; int64_t capSelScr = 0;
+  long long* d_slowq = nullptr; int64_t capSlowq = 0;          // -s slow pass: queue, per-wave scratch descriptors and their memory
+  unsigned char* d_dyn = nullptr; int64_t capDyn = 0; unsigned char* d_dynmem = nullptr; int64_t capDynMem = 0;
   long long* d_toff = nullptr; int64_t capToff = 0;
   qm_hit* d_tmp = nullptr; int64_t capTmp = 0; u64* d_tkeys = nullptr; int64_t capTkeys = 0; int* d_tsc = nullptr; int64_t capTsc = 0;
-  unsigned char* d_ksw = nullptr; int64_t capKsw = 0;
   int* d_tref = nullptr; int64_t capTref = 0; int* d_tcix = nullptr; int64_t capTcix = 0; unsigned char* d_tasks = nullptr; int64_t capTasks = 0;
   // last result
   int64_t lastUnits = -1, lastHits = 0; bool lastPaired = false;
   double lastMapMs = 0, lastTotalMs = 0;
+  int64_t lastRelaunches = 0, lastSlowReads = 0;
 };
 
 template <typename T>
@@ -326,7 +328,7 @@ int qm_ctx_destroy(qm_ctx* c) {
   hipSetDevice(c->device);
   void* ptrs[] = {c->d_text, c->d_SA, c->d_sainfo, c->d_slots, c->d_cnt, c->d_lcnt, c->d_loff, c->d_lists, c->d_hits, c->d_offs,
                   c->d_scal, c->d_gscr, c->d_scanTmp, c->d_seq1, c->d_seq2, c->d_off1, c->d_off2, c->d_dbg, c->d_dbgcnt,
-                  c->d_txpOff, c->d_txpLen, c->d_selscr, c->d_toff, c->d_tmp, c->d_tkeys, c->d_tsc, c->d_ksw, c->d_tref, c->d_tcix, c->d_tasks};
+                  c->d_txpOff, c->d_txpLen, c->d_selscr, c->d_slowq, c->d_dyn, c->d_dynmem, c->d_toff, c->d_tmp, c->d_tkeys, c->d_tsc, c->d_tref, c->d_tcix, c->d_tasks};
   for (void* p : ptrs) if (p) hipFree(p);
   for (void* p : c->phAllocs) if (p) hipFree(p);
   if (c->ev0) hipEventDestroy(c->ev0);
@@ -429,7 +431,7 @@ int qm_ctx_create(const qm_index* ix, int device_id, qm_ctx** out) {
     CK(hipStreamSynchronize(c->stream));    // P, tab, ov, fin are locals
     c->d_ph = dP;
   }
-  CK(hipMalloc((void**)&c->d_scal, 16 * sizeof(u64)));
+  CK(hipMalloc((void**)&c->d_scal, QM_SC_WORDS * sizeof(u64)));
   CK(hipStreamSynchronize(c->stream));
   c->d_txpOff = d_offsets;                               // kept: -s reads transcript sequences by (offset, length)
   {
@@ -498,7 +500,8 @@ static int map_device_impl(qm_ctx* c, const qm_opts* o, int64_t n, const void* d
 
   DevIndex ix; ix.text = c->d_text; ix.n = c->ix->n; ix.SA = c->d_SA; ix.nSA = c->ix->nSA;
   ix.sainfo = (const SaInfo*)c->d_sainfo; ix.slots = (const Bucket*)c->d_slots; ix.hmask = c->cap - 1; ix.ph = (const PhIndex*)c->d_ph; ix.k = c->ix->k;
-  u64 hscal[16];
+  u64 hscal[QM_SC_WORDS];
+  c->lastRelaunches = 0; c->lastSlowReads = 0;
   HIPCHK(hipEventRecord(c->evA, c->stream));
   // ---- stage A: one wavefront per read
   while (true) {
@@ -506,7 +509,7 @@ static int map_device_impl(qm_ctx* c, const qm_opts* o, int64_t n, const void* d
     B.seq1 = (const unsigned char*)d_seq1; B.off1 = (const long long*)d_off1;
     B.seq2 = (const unsigned char*)d_seq2; B.off2 = (const long long*)d_off2; B.nreads = nreads;
     B.lcnt = c->d_lcnt; B.loff = c->d_loff; B.lists = c->d_lists; B.cursor = c->d_scal; B.lists_cap = c->capLists;
-    B.status = (int*)(c->d_scal + 8); B.gscratch = c->d_gscr;
+    B.status = (int*)(c->d_scal + QM_SC_STATUS); B.gscratch = c->d_gscr;
     B.dbg_ints = c->debug ? c->d_dbg : nullptr; B.dbg_count = c->debug ? c->d_dbgcnt : nullptr;
     B.strict_check = o->strict_check; B.max_interval = o->max_interval; B.quasi_cov = o->quasi_cov; B.sensitive = o->sensitive; B.fuzzy = (d_seq2 != nullptr) ? o->fuzzy : 0;
     if (o->sel_aln) {                                   // -s: chain scoring + per-wave scratch for chaining (qm_sel.inl)
@@ -516,7 +519,7 @@ static int map_device_impl(qm_ctx* c, const qm_opts* o, int64_t n, const void* d
       const float cs = (float)o->consensus_slack;        // MappingOpts::consensusSlack is a float (RapMapSAMapper.cpp:138,184-185)
       B.consensus_fraction = (cs == 0.0) ? 1.0 : (1.0 - cs);
     }
-    HIPCHK(hipMemsetAsync(c->d_scal, 0, 16 * sizeof(u64), c->stream));
+    HIPCHK(hipMemsetAsync(c->d_scal, 0, QM_SC_WORDS * sizeof(u64), c->stream));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     if (feeder && n > 0) {
       // first pass over host buffers: one launch per chunk, each behind its own upload.  A launch sees its chunk through
@@ -536,23 +539,49 @@ static int map_device_impl(qm_ctx* c, const qm_opts* o, int64_t n, const void* d
       feeder = nullptr;                                   // a retry (list space ran out) finds everything resident
     } else if (nreads > 0) HIPCHK(qmk_map_reads(&ix, &B, ns, grid, c->numCU, c->stream));
     HIPCHK(hipEventRecord(c->ev1, c->stream));
-    HIPCHK(hipMemcpyAsync(hscal, c->d_scal, 16 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    int status = (int)(hscal[8] & 0xffffffffu);
+    int status = (int)(hscal[QM_SC_STATUS] & 0xffffffffu);
+    if (o->sel_aln && hscal[QM_SC_SLOWCNT] > 0 && !(status & 7)) {
+      // -s: reads whose SA intervals hold more suffixes than a wave's scratch (repeats, low-complexity reads) were left on
+      // the slow queue: gather them, give a few waves scratch sized for the largest, and map them with the same kernel
+      const int64_t ns_ = (int64_t)hscal[QM_SC_SLOWCNT];
+      const int64_t need = (((int64_t)hscal[QM_SC_SLOWMAX] + 63) / 64) * 64 + 64;
+      if ((rc = ensure(c->d_slowq, c->capSlowq, ns_))) return rc;
+      HIPCHK(qmk_collect_slow(c->d_lcnt, nreads, c->d_slowq, (unsigned long long*)(c->d_scal + QM_SC_SLOWQ), c->stream));
+      const unsigned long long per = (qmk_sel_dyn_bytes(need) + 255) & ~255ULL;
+      int64_t waves = ns_ < 256 ? ns_ : 256;
+      while (waves > 4 && (unsigned long long)waves * per > (8ULL << 30)) waves /= 2;      // at most 8 GB of scratch
+      const int sgrid = (int)((waves + 3) / 4);
+      if ((rc = ensure(c->d_dynmem, c->capDynMem, (int64_t)((unsigned long long)sgrid * 4 * per)))) return rc;
+      const size_t sb = qmk_sel_dyn_struct_bytes();
+      std::vector<unsigned char> hd((size_t)sgrid * 4 * sb);
+      for (int w = 0; w < sgrid * 4; ++w) qmk_sel_dyn_bind(hd.data() + (size_t)w * sb, c->d_dynmem + (unsigned long long)w * per, need);
+      if ((rc = ensure(c->d_dyn, c->capDyn, (int64_t)hd.size()))) return rc;
+      HIPCHK(hipMemcpyAsync(c->d_dyn, hd.data(), hd.size(), hipMemcpyHostToDevice, c->stream));
+      ReadBatch S2 = B;
+      S2.slowq = c->d_slowq; S2.dyn = (SelScratchDyn*)c->d_dyn; S2.nreads = ns_;
+      HIPCHK(qmk_map_reads(&ix, &S2, ns, sgrid, c->numCU, c->stream));
+      HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));                 // hd is a local
+      status = (int)(hscal[QM_SC_STATUS] & 0xffffffffu);
+      c->lastSlowReads = ns_;
+    }
 #ifdef QM_TIMING
     {
       static const char* nm[7] = {"read->LDS", "strand setup", "probe windows", "extension", "collector rest", "hits->mappings", "write-out+loop"};
-      double tot = 0; for (int i = 0; i < 7; ++i) tot += (double)hscal[9 + i];
-      for (int i = 0; i < 7; ++i) fprintf(stderr, "[qm timing] %-16s %6.2f %%  %10.0f clk/read\n", nm[i], 100.0 * hscal[9 + i] / tot, (double)hscal[9 + i] / (double)nreads);
+      double tot = 0; for (int i = 0; i < 7; ++i) tot += (double)hscal[20 + i];
+      for (int i = 0; i < 7; ++i) fprintf(stderr, "[qm timing] %-16s %6.2f %%  %10.0f clk/read\n", nm[i], 100.0 * hscal[20 + i] / tot, (double)hscal[20 + i] / (double)nreads);
     }
 #endif
     if (status & 4) return fail(QM_E_TOOLONG, "a read is longer than max_read_len=%d", max_read_len);
     if (status & 2) return fail(QM_E_UNSUPPORTED, "an SA-interval list exceeded %d entries (max_interval too large)", QM_GCAP);
-    if (status & 8) return fail(QM_E_UNSUPPORTED, "selective alignment: the SA intervals of a read hold more than %d suffixes", QM_SEL_CAP);
+    if (status & 8) return fail(QM_E_STATE, "selective alignment: a read overflowed the scratch sized for it (internal error)");
     if (status & 1) {            // bump allocator ran out: grow and redo the batch
       int64_t want = (int64_t)hscal[0] + nreads + (int64_t)grid * 4 * QM_CHUNK;
       if (want < c->capLists * 2) want = c->capLists * 2;
       if ((rc = ensure(c->d_lists, c->capLists, want))) return rc;
+      c->lastRelaunches += 1;
       continue;
     }
     break;
@@ -573,37 +602,29 @@ static int map_device_impl(qm_ctx* c, const qm_opts* o, int64_t n, const void* d
     long long slots = 0;
     HIPCHK(hipMemcpyAsync(&slots, c->d_offs + n, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    const int sgrid = c->numCU * 8;
     if ((rc = ensure(c->d_tmp, c->capTmp, slots + 1))) return rc;
     if ((rc = ensure(c->d_tkeys, c->capTkeys, 2 * slots + 2))) return rc;
     if ((rc = ensure(c->d_tsc, c->capTsc, 2 * slots + 2))) return rc;
-    if ((rc = ensure(c->d_ksw, c->capKsw, (int64_t)sgrid * 64 * (int64_t)qmk_sel_ksw_bytes()))) return rc;
     SelBatch A; memset(&A, 0, sizeof(A));
     A.seq1 = (const unsigned char*)d_seq1; A.seq2 = (const unsigned char*)d_seq2; A.text = c->d_text;
     A.txp_off = c->d_txpOff; A.txp_len = c->d_txpLen; A.tmp = c->d_tmp; A.toff = c->d_toff; A.tkeys = c->d_tkeys; A.tsc = c->d_tsc;
-    A.ksw = c->d_ksw; { const char* rm = getenv("QM_SEL_RING"); A.ring = (unsigned char*)(unsigned long long)(rm ? atoi(rm) : 1); } A.match = o->match_score; A.mismatch = o->mismatch_penalty; A.gap_open = o->gap_open; A.gap_extend = o->gap_extend;
+    A.match = o->match_score; A.mismatch = o->mismatch_penalty; A.gap_open = o->gap_open; A.gap_extend = o->gap_extend;
     A.bandwidth = o->dp_bandwidth; A.hard_filter = o->hard_filter; A.policy = o->aln_policy; A.min_score_fraction = o->min_score_fraction;
     HIPCHK(hipMemsetAsync(c->d_cnt + n, 0, sizeof(uint32_t), c->stream));
-    // bands up to 33 wide: plan -> one wavefront per ksw2 alignment -> finish; wider bands (or QM_SEL_RING=0|1|2 for
-    // A/B runs): the one-thread-per-unit kernel
-    const bool three = o->dp_bandwidth >= 0 && o->dp_bandwidth <= 33 && !getenv("QM_SEL_RING");
-    if (three) {
-      if ((rc = ensure(c->d_tref, c->capTref, 2 * slots + 2))) return rc;
-      if ((rc = ensure(c->d_tcix, c->capTcix, 2 * slots + 2))) return rc;
-      if ((rc = ensure(c->d_tasks, c->capTasks, (2 * slots + 2) * (int64_t)qmk_sel_task_bytes()))) return rc;
-      A.tref = c->d_tref; A.tcix = c->d_tcix; A.tasks = (SelTask*)c->d_tasks; A.ntasks = c->d_scal + 9;
-      HIPCHK(hipMemsetAsync(c->d_scal + 9, 0, sizeof(u64), c->stream));
-      HIPCHK(qmk_sel_three(&P, &A, c->numCU, c->stream));
-    } else {
-      HIPCHK(qmk_sel_unit(&P, &A, sgrid, c->stream));
-    }
+    // plan (per unit) -> ksw2 extension alignments, four per wavefront, any band -> finish (per unit)
+    if ((rc = ensure(c->d_tref, c->capTref, 2 * slots + 2))) return rc;
+    if ((rc = ensure(c->d_tcix, c->capTcix, 2 * slots + 2))) return rc;
+    if ((rc = ensure(c->d_tasks, c->capTasks, (2 * slots + 2) * (int64_t)qmk_sel_task_bytes()))) return rc;
+    A.tref = c->d_tref; A.tcix = c->d_tcix; A.tasks = (SelTask*)c->d_tasks; A.ntasks = c->d_scal + QM_SC_NTASKS;
+    HIPCHK(hipMemsetAsync(c->d_scal + QM_SC_NTASKS, 0, sizeof(u64), c->stream));
+    HIPCHK(qmk_sel_three(&P, &A, c->numCU, c->stream));
   } else {
     HIPCHK(qmk_pair_count(&P, c->stream));
   }
   HIPCHK(qmk_scan_counts(c->d_scanTmp, c->scanTmpBytes, c->d_cnt, c->d_offs, n + 1, c->stream));
   long long total = 0;
   HIPCHK(hipMemcpyAsync(&total, c->d_offs + n, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemcpyAsync(hscal, c->d_scal, 16 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   if ((rc = ensure(c->d_hits, c->capHits, (int64_t)total + 1, total / 8))) return rc;
   P.hits = c->d_hits;
@@ -753,6 +774,17 @@ int qm_fetch_intervals(qm_ctx* c, int64_t* int_offsets, qm_sa_interval_hit* ints
     int64_t w = int_offsets[i];
     for (int m = 0; m < mates; ++m)
       for (int64_t j = 0; j < kept(i * mates + m); ++j) ints[w++] = all[(size_t)i * QM_DBG_CAP + (size_t)m * half + j];
+  }
+  return QM_OK;
+}
+
+int qm_ctx_stat(const qm_ctx* c, int which, int64_t* value) {
+  if (!c || !value) return fail(QM_E_ARG, "null argument");
+  switch (which) {
+    case QM_STAT_RELAUNCHES: *value = c->lastRelaunches; break;
+    case QM_STAT_LIST_WORDS: *value = c->capLists; break;
+    case QM_STAT_SLOW_READS: *value = c->lastSlowReads; break;
+    default: return fail(QM_E_ARG, "unknown statistic %d", which);
   }
   return QM_OK;
 }

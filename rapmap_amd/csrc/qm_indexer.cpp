@@ -27,6 +27,7 @@
 #include <vector>
 
 #include <sys/stat.h>
+#include <zlib.h>
 
 #include "qmap_mi355.h"
 
@@ -315,8 +316,10 @@ extern "C" int qm_build_index(const char* fasta_path, const char* out_dir_c, int
   mkdir(outDir.c_str(), 0755);
 
   // ---- step 1: read + transform the transcripts (:500-640)
-  FILE* f = fopen(fasta_path, "rb");
+  // through zlib like the reference's kseq reader (src/FastxParser.cpp:229-328: gzopen / kseq): plain and gzip'd FASTA alike
+  gzFile f = gzopen(fasta_path, "rb");
   if (!f) return fail(QM_E_IO, "cannot open FASTA");
+  gzbuffer(f, 1 << 20);
   std::default_random_engine eng(271828);
   std::uniform_int_distribution<> dis(0, 3);
   const char bases[] = {'A', 'C', 'G', 'T'};
@@ -389,15 +392,15 @@ extern "C" int qm_build_index(const char* fasta_path, const char* out_dir_c, int
         readStr += ln;
       }
     };
-    while (fgets(buf.data(), (int)buf.size(), f)) {
+    while (gzgets(f, buf.data(), (int)buf.size())) {
       line += buf.data();
-      if (!line.empty() && line.back() != '\n' && !feof(f)) continue;   // long line: keep reading
+      if (!line.empty() && line.back() != '\n' && !gzeof(f)) continue;   // long line: keep reading
       handleLine(line);
       line.clear();
     }
     if (!line.empty()) handleLine(line);
     process();
-    fclose(f);
+    gzclose(f);
   }
   if (names.empty()) return fail(QM_E_IO, "no transcripts in FASTA");
   const size_t tlen = text.size();

@@ -564,9 +564,13 @@ int qm_sam_write(const qm_index* ix, int64_t n, const char* names1, const int64_
   int64_t tot = 0;
   for (auto& p : parts) tot += (int64_t)p.n;
   // a seekable descriptor takes the parts concurrently (pwrite at precomputed offsets); pipes get them in order
+  // -- but not one opened with O_APPEND (a shell's `>>`): there pwrite ignores its offset and appends, which would leave
+  // the parts in completion order
   const off_t base = lseek(fd, 0, SEEK_CUR);
+  const int fl = fcntl(fd, F_GETFL);
+  const bool appendMode = fl != -1 && (fl & O_APPEND);
   bool done = false;
-  if (base != (off_t)-1 && parts.size() > 1) {
+  if (base != (off_t)-1 && !appendMode && parts.size() > 1) {
     std::vector<off_t> at(parts.size());
     off_t o = base; for (size_t i = 0; i < parts.size(); ++i) { at[i] = o; o += (off_t)parts[i].n; }
     std::vector<char> okv(parts.size(), 1);

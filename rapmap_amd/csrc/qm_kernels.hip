@@ -44,11 +44,12 @@ __global__ __launch_bounds__(256, WPS) void qm_read_kernel(DevIndex ix, ReadBatc
     nxt = cur;
     pre_chars<NS>(B, r + nw, nxt);
     pre_offsets<NS>(B, r + 2 * nw, nxt);
-    map_read<NS, F>(ix, B, r, cur, mem[wave], gscr, wa, (F & QM_F_SEL) ? B.selscr + gw : nullptr, sels[wave].ptr());
+    map_read<NS, F>(ix, B, read_id(B, r), cur, mem[wave], gscr, wa, (F & QM_F_SEL) ? B.selscr + gw : nullptr, sels[wave].ptr(),
+                    ((F & QM_F_SEL) && B.dyn) ? B.dyn + gw : nullptr);
     cur = nxt;
   }
 #ifdef QM_TIMING
-  if ((threadIdx.x & 63) == 0) for (int i = 0; i < 7; ++i) atomicAdd((unsigned long long*)&B.cursor[9 + i], (unsigned long long)qm_tim[wave][i]);
+  if ((threadIdx.x & 63) == 0) for (int i = 0; i < 7; ++i) atomicAdd((unsigned long long*)&B.cursor[20 + i], (unsigned long long)qm_tim[wave][i]);
 #endif
 }
 
@@ -87,31 +88,7 @@ __global__ __launch_bounds__(256) void qm_sel_slots_kernel(PairBatch P) {
   P.cnt[u] = u < P.n ? w / 3 + 1 : 0;
 }
 
-// -s stages B + C: one thread per unit (grid-stride: every thread owns a ksw2 work area).  RING 1: the 64-column ksw2
-// ring of every thread in LDS (45 KB per wave, 3 waves per CU); RING 2: the ring in the thread's global work area
-// (no LDS, full occupancy, cache-resident); RING 0: the literal full-array kernel.
-template <int RING>
-__global__ __launch_bounds__(64) void qm_sel_unit_kernel(PairBatch P, SelBatch A) {
-  __shared__ unsigned long long sc[6];
-  __shared__ __attribute__((aligned(4))) unsigned char ring[RING == 1 ? 64 * QM_KSW_RING_BYTES : 4];
-  if (threadIdx.x < 6) sc[threadIdx.x] = 0;
-  __syncthreads();
-  const long long tg = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
-  UnitCounters uc = {0, 0, 0, 0, 0, 0};
-  SelBatch At = A;
-  At.ring = RING == 1 ? ring + threadIdx.x * QM_KSW_RING_BYTES : (RING == 2 ? A.ksw + (unsigned long long)tg * QM_KSW_BYTES : nullptr);
-  for (long long u = tg; u < P.n; u += stride) P.cnt[u] = (u32)sel_unit(P, At, u, tg, &uc);
-  if (uc.pe) atomicAdd(&sc[0], uc.pe);
-  if (uc.se) atomicAdd(&sc[1], uc.se);
-  if (uc.tot) atomicAdd(&sc[2], uc.tot);
-  if (uc.reads) atomicAdd(&sc[3], uc.reads);
-  if (uc.tooMany) atomicAdd(&sc[4], uc.tooMany);
-  if (uc.mapped) atomicAdd(&sc[5], uc.mapped);
-  __syncthreads();
-  if (threadIdx.x < 6 && sc[threadIdx.x]) atomicAdd((unsigned long long*)&P.counters[threadIdx.x], sc[threadIdx.x]);
-}
-
-// -s, three-kernel form: plan (per unit) -> one wavefront per ksw2 alignment -> finish (per unit)
+// -s stages B + C: plan (per unit) -> ksw2 alignments, four per wavefront -> finish (per unit)
 QM_DEV void sel_flush_counters(unsigned long long* sc, const UnitCounters& uc, u64* counters) {
   if (uc.pe) atomicAdd(&sc[0], uc.pe);
   if (uc.se) atomicAdd(&sc[1], uc.se);
@@ -131,26 +108,15 @@ __global__ __launch_bounds__(256) void qm_sel_plan_kernel(PairBatch P, SelBatch 
   if (u < P.n) sel_unit_plan(P, A, u, &uc);
   sel_flush_counters(sc, uc, P.counters);
 }
-// one row of 16 lanes per ksw2 alignment, four alignments per wavefront (sel_ksw_extz2_rows); QM_SEL_ALIGN=wave in the
-// environment of the host library selects the older one-wavefront-per-alignment kernel below (A/B runs)
-__global__ __launch_bounds__(256) void qm_sel_align_kernel(PairBatch P, SelBatch A) {
-  __shared__ KswRow rows[4][4];
+// one row of 16 lanes per ksw2 alignment, four alignments per wavefront (sel_ksw_extz2_rows); RING = column slots per
+// alignment, chosen from --dpBandwidth at launch (sel_ksw_ring_slots)
+template <int RING, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void qm_sel_align_kernel(PairBatch P, SelBatch A) {
+  __shared__ KswRowT<RING> rows[WAVES][4];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const unsigned long long nt = *A.ntasks;
-  for (unsigned long long t = ((unsigned long long)blockIdx.x * 4 + wave) * 4; t < nt; t += (unsigned long long)gridDim.x * 16)
-    sel_tasks_align_rows(P, A, t, nt, rows[wave]);
-}
-__global__ __launch_bounds__(256) void qm_sel_align_wave_kernel(PairBatch P, SelBatch A) {
-  __shared__ unsigned char qt[4][2 * QM_KSW_MAXLEN + QM_KSW_IMG_BYTES];   // per wave: read + target codes, then the two score-phase images
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const unsigned long long nt = *A.ntasks;
-  for (unsigned long long t = (unsigned long long)blockIdx.x * 4 + wave; t < nt; t += (unsigned long long)gridDim.x * 4) {
-    const SelTask task = A.tasks[t];
-    SelTask ut;                                              // wave-uniform copy (one task per wave)
-    ut.u = uniform(task.u); ut.gslot = uniform(task.gslot); ut.side = uniform(task.side); ut.tid = uniform(task.tid); ut.pos = uniform(task.pos);
-    ut.roff = uniform(task.roff); ut.rlen = uniform(task.rlen); ut.tlen1 = uniform(task.tlen1); ut.fwd = uniform(task.fwd);
-    sel_task_align(P, A, ut, qt[wave]);
-  }
+  for (unsigned long long t = ((unsigned long long)blockIdx.x * WAVES + wave) * 4; t < nt; t += (unsigned long long)gridDim.x * (4 * WAVES))
+    sel_tasks_align_rows<RING>(P, A, t, nt, rows[wave]);
 }
 __global__ __launch_bounds__(256) void qm_sel_finish_kernel(PairBatch P, SelBatch A) {
   __shared__ unsigned long long sc[6];
@@ -160,6 +126,12 @@ __global__ __launch_bounds__(256) void qm_sel_finish_kernel(PairBatch P, SelBatc
   UnitCounters uc = {0, 0, 0, 0, 0, 0};
   if (u < P.n) P.cnt[u] = (u32)sel_unit_finish(P, A, u, &uc);
   sel_flush_counters(sc, uc, P.counters);
+}
+
+// -s: the reads stage A left on the slow queue (lcnt == QM_LCNT_SLOW), gathered into q[0 .. *count)
+__global__ __launch_bounds__(256) void qm_collect_slow_kernel(const u32* lcnt, long long nreads, long long* q, u64* count) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < nreads && lcnt[r] == QM_LCNT_SLOW) q[atomicAdd((unsigned long long*)count, 1ULL)] = r;
 }
 
 // -s: surviving hits from the per-unit temp slots to CSR order
@@ -302,20 +274,18 @@ hipError_t qmk_map_reads(const void* ixp, const void* bp, int ns, int grid, int 
 }
 
 size_t qmk_sel_scratch_bytes(void) { return sizeof(SelScratch); }
-size_t qmk_sel_ksw_bytes(void) { return QM_KSW_BYTES; }
+size_t qmk_sel_dyn_struct_bytes(void) { return sizeof(SelScratchDyn); }
+unsigned long long qmk_sel_dyn_bytes(long long n) { return SelScratchDyn::bytes_for(n); }
+// host image of wave w's SelScratchDyn over device memory at `base`
+void qmk_sel_dyn_bind(void* host_struct, void* dev_base, long long n) { ((SelScratchDyn*)host_struct)->bind((unsigned char*)dev_base, n); }
+hipError_t qmk_collect_slow(const unsigned int* lcnt, long long nreads, long long* q, unsigned long long* count, hipStream_t st) {
+  if (nreads <= 0) return hipSuccess;
+  hipLaunchKernelGGL(qm_collect_slow_kernel, dim3((unsigned)((nreads + 255) / 256)), dim3(256), 0, st, lcnt, nreads, q, (u64*)count);
+  return hipGetLastError();
+}
 hipError_t qmk_sel_slots(const void* pp, hipStream_t st) {
   const PairBatch& P = *(const PairBatch*)pp;
   hipLaunchKernelGGL(qm_sel_slots_kernel, dim3((unsigned)((P.n + 1 + 255) / 256)), dim3(256), 0, st, P);
-  return hipGetLastError();
-}
-hipError_t qmk_sel_unit(const void* pp, const void* ap, int grid, hipStream_t st) {
-  const PairBatch& P = *(const PairBatch*)pp;
-  if (P.n <= 0) return hipSuccess;
-  const SelBatch& A = *(const SelBatch*)ap;
-  const unsigned long long mode = (unsigned long long)A.ring;          // host: 0 literal arrays, 1 LDS ring, 2 ring in global memory
-  if (mode == 1) hipLaunchKernelGGL(qm_sel_unit_kernel<1>, dim3((unsigned)grid), dim3(64), 0, st, P, A);
-  else if (mode == 2) hipLaunchKernelGGL(qm_sel_unit_kernel<2>, dim3((unsigned)grid), dim3(64), 0, st, P, A);
-  else hipLaunchKernelGGL(qm_sel_unit_kernel<0>, dim3((unsigned)grid), dim3(64), 0, st, P, A);
   return hipGetLastError();
 }
 hipError_t qmk_sel_three(const void* pp, const void* ap, int num_cu, hipStream_t st) {
@@ -323,9 +293,11 @@ hipError_t qmk_sel_three(const void* pp, const void* ap, int num_cu, hipStream_t
   if (P.n <= 0) return hipSuccess;
   const unsigned nb = (unsigned)((P.n + 255) / 256);
   hipLaunchKernelGGL(qm_sel_plan_kernel, dim3(nb), dim3(256), 0, st, P, A);
-  static const char* which = getenv("QM_SEL_ALIGN");
-  if (which && which[0] == 'w') hipLaunchKernelGGL(qm_sel_align_wave_kernel, dim3((unsigned)(num_cu * 8)), dim3(256), 0, st, P, A);
-  else hipLaunchKernelGGL(qm_sel_align_kernel, dim3((unsigned)(num_cu * 8)), dim3(256), 0, st, P, A);
+  switch (sel_ksw_ring_slots(A.bandwidth)) {            // one kernel for every --dpBandwidth: the band decides the ring
+    case 64: hipLaunchKernelGGL((qm_sel_align_kernel<64, 4>), dim3((unsigned)(num_cu * 8)), dim3(256), 0, st, P, A); break;
+    case 128: hipLaunchKernelGGL((qm_sel_align_kernel<128, 4>), dim3((unsigned)(num_cu * 4)), dim3(256), 0, st, P, A); break;
+    default: hipLaunchKernelGGL((qm_sel_align_kernel<512, 2>), dim3((unsigned)(num_cu * 3)), dim3(128), 0, st, P, A); break;   // 42 KB of LDS per block
+  }
   hipLaunchKernelGGL(qm_sel_finish_kernel, dim3(nb), dim3(256), 0, st, P, A);
   return hipGetLastError();
 }

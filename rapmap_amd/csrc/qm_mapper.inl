@@ -39,6 +39,15 @@ namespace qm {
 #define QM_DBG_CAP 64  // debug interval records per unit
 #define QM_CHUNK 4096  // list elements a wave reserves per bump-allocator round trip (>= QM_GCAP)
 #define QM_GSCR_U64 (3 * QM_GCAP + 2 * QM_IOVF * 2)   // u64 words of global scratch per wave
+// slots of the context's scalar block (ReadBatch::cursor points at slot 0): bump pointer, qm_counters[6], status, ksw2 task
+// count, then the slow queue of -s (reads that overflowed the per-wave scratch: how many, suffixes of the largest)
+#define QM_SC_WORDS 32
+#define QM_SC_STATUS 8
+#define QM_SC_NTASKS 9
+#define QM_SC_SLOWCNT 16
+#define QM_SC_SLOWMAX 17
+#define QM_SC_SLOWQ 18
+#define QM_LCNT_SLOW 0x7fffffffu   // lcnt value of a read waiting on the slow queue
 
 struct Slot { u64 key; int lb; int ub; };          // hash.bin record / small linear-probing tables, key == ~0 empty
 struct Iv { int lb, ub; };                         // seed interval
@@ -109,6 +118,9 @@ struct ReadBatch {
   int max_mmp_ext;         // --maxMMPExtension (QM_F_SEL kernels only)
   float consensus_fraction; // 1 - consensusSlack (MappingConfig, RapMapSAMapper.cpp:184-185), QM_F_SEL only
   struct SelScratch* selscr; // QM_F_SEL: one SelScratch per wave
+  // second launch of a -s batch over the slow queue: slot r of the launch maps read slowq[r] on scratch dyn[wave]
+  const long long* slowq;
+  struct SelScratchDyn* dyn;
 };
 
 // stage B launch arguments
@@ -1233,9 +1245,10 @@ QM_DEV void dump_intervals(const ReadBatch& B, long long read, int list, const I
 }
 
 struct SelScratch;
+struct SelScratchDyn;
 template <int CAP, int OUTCAP> struct SelScratchT;
 QM_DEV int sel_hits_to_mappings(const DevIndex& ix, const ReadBatch& B, const IntervalList& fwdInts, const IntervalList& rcInts,
-                                u32 readLen, int mate, SelScratch& G, struct SelScratchLds* L, u64* ldsOut, const u64*& src);
+                                u32 readLen, int mate, SelScratch& G, struct SelScratchLds* L, u64* ldsOut, const u64*& src, SelScratchDyn* dyn);
 
 // ------------------------------------------------------------------ stage A driver
 // One read: load -> collect -> hits->mappings -> list to global memory.
@@ -1250,6 +1263,8 @@ struct ReadPre {
   long long p0, p1;            // read after next: offsets (uniform once consumed)
   LV<u32> chars;               // lane l: characters 64*s + l of the next read, s = 0..NS-1, one byte each
 };
+// slot of a launch -> read: the identity, except in the slow pass of -s (the launch walks the slow queue)
+QM_DEV long long read_id(const ReadBatch& B, long long slot) { return B.slowq ? uniform(B.slowq[slot]) : slot; }
 QM_DEV void read_src(const ReadBatch& B, long long read, const unsigned char*& src, const long long*& off, long long& unit) {
   const bool paired = B.seq2 != nullptr;
   const int mate = paired ? (int)(read & 1) : 0;
@@ -1259,21 +1274,21 @@ QM_DEV void read_src(const ReadBatch& B, long long read, const unsigned char*& s
 }
 // request the offsets of `read` (no use of the result here)
 template <int NS>
-QM_DEV void pre_offsets(const ReadBatch& B, long long read, ReadPre<NS>& P) {
+QM_DEV void pre_offsets(const ReadBatch& B, long long slot, ReadPre<NS>& P) {
   P.p0 = 0; P.p1 = 0;
-  if (read >= B.nreads) return;
+  if (slot >= B.nreads) return;
   const unsigned char* src; const long long* off; long long unit;
-  read_src(B, read, src, off, unit);
+  read_src(B, read_id(B, slot), src, off, unit);
   P.p0 = load_uniform_i64(off + unit); P.p1 = load_uniform_i64(off + unit + 1);
 }
 // turn the pending offsets (which belong to `read`) into character loads
 template <int NS>
-QM_DEV void pre_chars(const ReadBatch& B, long long read, ReadPre<NS>& P) {
+QM_DEV void pre_chars(const ReadBatch& B, long long slot, ReadPre<NS>& P) {
   P.o0 = 0; P.len = 0;
   QM_LANES(l) { P.chars[l] = 0; }
-  if (read >= B.nreads) return;
+  if (slot >= B.nreads) return;
   const unsigned char* src; const long long* off; long long unit;
-  read_src(B, read, src, off, unit);
+  read_src(B, read_id(B, slot), src, off, unit);
   const long long o0 = uniform(P.p0), o1 = uniform(P.p1);
   int len = (int)(o1 - o0);
   P.o0 = o0; P.len = len;
@@ -1289,7 +1304,7 @@ QM_DEV void pre_chars(const ReadBatch& B, long long read, ReadPre<NS>& P) {
 
 template <int NS, int F>
 QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, const ReadPre<NS>& pre, WaveMem<NS>& M, u64* gscr, WaveAlloc& wa,
-                     SelScratch* ss = nullptr, struct SelScratchLds* sl = nullptr) {
+                     SelScratch* ss = nullptr, struct SelScratchLds* sl = nullptr, SelScratchDyn* dyn = nullptr) {
   const bool paired = B.seq2 != nullptr;
   const int mate = paired ? (int)(read & 1) : 0;
   const bool tooLong = pre.len > 64 * NS;
@@ -1334,7 +1349,11 @@ QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, con
   int n = 0;
   const u64* listSrc = nullptr;
   if (F & QM_F_SEL) {                  // -s: chaining + multi-position groups (qm_sel.inl)
-    n = sel_hits_to_mappings(ix, B, fi, ri, (u32)len, mate, *ss, sl, &M.buf[0][0], listSrc);
+    n = sel_hits_to_mappings(ix, B, fi, ri, (u32)len, mate, *ss, sl, &M.buf[0][0], listSrc, dyn);
+    if (n == -2) {                     // waits on the slow queue: no list yet
+      QM_LANES(l) { if (l == 0) { B.lcnt[read] = QM_LCNT_SLOW; B.loff[read] = 0; } }
+      return;
+    }
   } else if (bound > QM_GCAP) {        // only reachable with max_interval > 1000
     QM_LANES(l) { if (l == 0) *B.status |= 2; }
   } else {
@@ -1346,7 +1365,12 @@ QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, con
   // (MI355X_MICROARCH.md "dequeue"), far below the read rate, so a wave reserves QM_CHUNK elements at
   // a time and sub-allocates from its chunk.
   long long base = 0;
-  if (n > 0) {
+  if (n > QM_CHUNK) {                  // only the slow pass of -s makes lists this long: an allocation of its own
+    LV<u64> bv;
+    QM_LANES(l) { bv[l] = 0; if (l == 0) bv[l] = atomic_add_u64(B.cursor, (u64)n); }
+    base = (long long)read_lane(bv, 0);
+    if (base + n > B.lists_cap) { QM_LANES(l) { if (l == 0) *B.status |= 1; } n = 0; base = 0; }
+  } else if (n > 0) {
     if (wa.base < 0 || wa.used + n > QM_CHUNK) {
       LV<u64> bv;
       QM_LANES(l) { bv[l] = 0; if (l == 0) bv[l] = atomic_add_u64(B.cursor, (u64)QM_CHUNK); }

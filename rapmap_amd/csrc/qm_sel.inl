@@ -5,12 +5,12 @@
 //             of every suffix of every SA interval in parallel -- the memory-bound part -- and lane 0 then replays
 //             intersectSAHits with slack (HitManager.cpp:587-689), the minimap2-style chaining DP with equally good
 //             chains kept as multiple positions (:84-326) and mergeOrientationUnique (:834-881) on that small set.
-//             A read's list becomes groups of words:  header = tid | primaryRC<<32 | chainStatus<<33 | nP<<36 | nO<<48,
-//             then nP positions of the surviving orientation and nO positions of the other one.
-//   stage B+C sel_unit: one thread per pair (or single read): mergeLeftRightHitsFuzzy on the position lists
-//             (RapMapUtils.hpp:864-1183), then getAlnScore for every hit (SelectiveAlignmentUtils.hpp:260-373) with
-//             ksw_extz2_sse41 reproduced lane by lane (src/ksw2pp/ksw2_extz2_sse.c), the score gate and the
-//             soft / hard filter (RapMapSAMapper.cpp:554-667, 246-318).
+//             A read's list becomes groups of words:  header = tid | primaryRC<<32 | chainStatus<<33 | nP<<36, then
+//             own position | nO<<32, then nP positions of the surviving orientation and nO positions of the other one.
+//   stage B+C plan / align / finish: mergeLeftRightHitsFuzzy on the position lists (RapMapUtils.hpp:864-1183) and
+//             getAlnScore for every hit (SelectiveAlignmentUtils.hpp:260-373) per unit, the ksw_extz2_sse41 alignments
+//             that have to be run four to a wavefront with the SSE lanes reproduced exactly (src/ksw2pp/ksw2_extz2_sse.c),
+//             then the score gate and the soft / hard filter (RapMapSAMapper.cpp:554-667, 246-318).
 // The double arithmetic of the chain score must not be contracted into FMAs: the reference is plain x86-64 code.
 
 #define QM_SEL_CAP 4096            // SA entries of one strand's intervals a read may bring (else status bit 3)
@@ -18,10 +18,17 @@
 enum : int { QM_CS_PERFECT = 0, QM_CS_UNGAPPED = 1, QM_CS_REGULAR = 4 };   // rapmap::utils::ChainStatus
 
 struct SelRec { u32 tid, pos, qpos, len, iv; };
-struct SelGroup { u32 tid; int ppos; double score; short npos, off; int cs; };   // ppos: the hit's own position (QuasiAlignment::pos); 24 bytes
+struct SelGroup {                  // ppos: the hit's own position (QuasiAlignment::pos); 24 bytes (the LDS edition holds 96 of them)
+  u32 tid; int ppos; double score; int npos; u32 offcs;      // offcs: first position in pos[] (28 bits) | chain status << 28
+  QM_DEV int off() const { return (int)(offcs & 0x0fffffffu); }
+  QM_DEV int cs() const { return (int)(offcs >> 28); }
+  QM_DEV void set_off(int o) { offcs = (offcs & 0xf0000000u) | (u32)o; }
+  QM_DEV void set_cs(int c) { offcs = (offcs & 0x0fffffffu) | ((u32)c << 28); }
+};
 template <int CAP, int OUTCAP>
 struct SelScratchT {                // working set of one read
-  static constexpr int cap = CAP, outcap = OUTCAP, gcap = CAP;
+  QM_DEV int cap() const { return CAP; } QM_DEV int outcap() const { return OUTCAP; } QM_DEV int gcap() const { return CAP; }
+  QM_DEV int tmp_bytes() const { return (int)sizeof(tmp); }
   SelRec rec[CAP], tmp[CAP];
   double f[CAP]; int p[CAP]; int seen[CAP]; int ends[CAP]; int starts[CAP];
   SelGroup grp[2][CAP]; int pos[2][CAP]; int ngrp[2], npos[2];
@@ -29,12 +36,40 @@ struct SelScratchT {                // working set of one read
   QM_DEV SelGroup* grpp(int s) { return grp[s]; }
 };
 struct SelScratch : SelScratchT<QM_SEL_CAP, QM_CHUNK> {};   // per wave, global memory: the general case
+// The third edition: arrays sized by the host from the largest read of the slow queue (reads whose intervals hold more
+// suffixes than SelScratch -- repeats, low-complexity reads).  Same member names, pointers instead of arrays.
+struct SelScratchDyn {
+  int capN, outN;
+  SelRec* rec; SelRec* tmp;
+  double* f; int* p; int* seen; int* ends; int* starts;
+  SelGroup* grp0; SelGroup* grp1; int* pos[2]; int* ngrp; int* npos;
+  u64* out;
+  QM_DEV int cap() const { return capN; } QM_DEV int outcap() const { return outN; } QM_DEV int gcap() const { return capN; }
+  QM_DEV int tmp_bytes() const { return capN * (int)sizeof(SelRec); }
+  QM_DEV SelGroup* grpp(int s) { return s == 0 ? grp0 : grp1; }
+  // bytes of device memory one wave's arrays take for `n` suffixes per strand (host: qmk_sel_dyn_bytes / qmk_sel_dyn_bind)
+  static inline unsigned long long bytes_for(long long n) {
+    return (unsigned long long)n * (2 * sizeof(SelRec) + sizeof(double) + 4 * sizeof(int) + 2 * sizeof(SelGroup) + 2 * sizeof(int) + 6 * sizeof(u64)) + 64;
+  }
+  inline void bind(unsigned char* base, long long n) {
+    capN = (int)n; outN = (int)(6 * n);
+    unsigned char* q = base;
+    f = (double*)q; q += n * sizeof(double);
+    out = (u64*)q; q += 6 * n * sizeof(u64);
+    grp0 = (SelGroup*)q; q += n * sizeof(SelGroup); grp1 = (SelGroup*)q; q += n * sizeof(SelGroup);
+    rec = (SelRec*)q; q += n * sizeof(SelRec); tmp = (SelRec*)q; q += n * sizeof(SelRec);
+    p = (int*)q; q += n * 4; seen = (int*)q; q += n * 4; ends = (int*)q; q += n * 4; starts = (int*)q; q += n * 4;
+    pos[0] = (int*)q; q += n * 4; pos[1] = (int*)q; q += n * 4;
+    ngrp = (int*)q; npos = ngrp + 2;
+  }
+};
 #define QM_SEL_SMALL 48
 // The LDS edition (almost every read fits): 4.8 KB per wave so that four waves per SIMD stay resident.  The sort keys
 // share their bytes with the second strand's groups (written only after that strand's sort), and the read's list is
 // assembled in the sort buffers of WaveMem, which the -s path does not use otherwise (`out`, 3 * QM_CAP words).
 struct SelScratchLds {
-  static constexpr int cap = QM_SEL_SMALL, outcap = 3 * QM_CAP, gcap = QM_SEL_SMALL;
+  QM_DEV int cap() const { return QM_SEL_SMALL; } QM_DEV int outcap() const { return 3 * QM_CAP; } QM_DEV int gcap() const { return QM_SEL_SMALL; }
+  QM_DEV int tmp_bytes() const { return (int)sizeof(tmp); }
   SelRec rec[QM_SEL_SMALL];
   double f[QM_SEL_SMALL]; int p[QM_SEL_SMALL]; int seen[QM_SEL_SMALL]; int ends[QM_SEL_SMALL]; int starts[QM_SEL_SMALL];
   SelGroup grp0[QM_SEL_SMALL];
@@ -45,14 +80,13 @@ struct SelScratchLds {
 };
 QM_DEV const u64* sel_out(const SelScratch& S) { return S.out; }
 
-QM_DEV u64 sel_header(u32 tid, bool primaryRC, int cs, int nP, int nO) {
-  return (u64)tid | ((u64)(primaryRC ? 1 : 0) << 32) | ((u64)(cs & 7) << 33) | ((u64)(nP & 0xfff) << 36) | ((u64)(nO & 0xfff) << 48);
+QM_DEV u64 sel_header(u32 tid, bool primaryRC, int cs, int nP) {
+  return (u64)tid | ((u64)(primaryRC ? 1 : 0) << 32) | ((u64)(cs & 7) << 33) | ((u64)(u32)nP << 36);
 }
 QM_DEV u32 selh_tid(u64 h) { return (u32)h; }
 QM_DEV bool selh_rc(u64 h) { return (h >> 32) & 1; }
 QM_DEV int selh_cs(u64 h) { return (int)((h >> 33) & 7); }
-QM_DEV int selh_np(u64 h) { return (int)((h >> 36) & 0xfff); }
-QM_DEV int selh_no(u64 h) { return (int)((h >> 48) & 0xfff); }
+QM_DEV int selh_np(u64 h) { return (int)(h >> 36); }
 
 // fastapprox's fastlog2 as used by the chain score (HitManager.cpp:33-42)
 QM_DEV float sel_fastlog2(float x) {
@@ -81,7 +115,7 @@ QM_DEV void sel_sort(SelRec* r, SelRec* t, int n, Less less) {
 
 // collectHitsSimpleSA, chaining branch (HitManager.cpp:107-307), for the hn hits H of one transcript (already in chain
 // order).  f, p, seen, ends, starts: hn entries of scratch each.  Returns the number of chain starts (0: no hit), fills g
-// (all but g.off) and writes the sorted start positions to posOut (may alias ends).
+// (all but its offset) and writes the sorted start positions to posOut (may alias ends).
 QM_DEV int sel_chain_group(const SelRec* H, int hn, double* f, int* p, int* seen, int* ends, int* starts, int maxDist,
                            SelGroup& g, int* posOut) {
 #pragma clang fp contract(off)
@@ -133,7 +167,7 @@ QM_DEV int sel_chain_group(const SelRec* H, int hn, double* f, int* p, int* seen
     if (validChain) { ++numDistinctOpt; starts[nStarts++] = lastPtr; }
   }
   if (nStarts == 0) return 0;
-  g.tid = H[0].tid; g.cs = QM_CS_REGULAR; g.score = bestScore; g.npos = (short)nStarts; g.off = 0;
+  g.tid = H[0].tid; g.offcs = 0; g.set_cs(QM_CS_REGULAR); g.score = bestScore; g.npos = nStarts;
   g.ppos = (int)(H[starts[0]].pos - H[starts[0]].qpos);                      // the first chain's start (:259-262)
   for (int t = 0; t < nStarts; ++t) {                                        // allPositions is sorted (:272-276)
     const int v = (int)(H[starts[t]].pos - H[starts[t]].qpos);
@@ -144,7 +178,7 @@ QM_DEV int sel_chain_group(const SelRec* H, int hn, double* f, int* p, int* seen
   if (hn > 1 && numDistinctOpt == 1 && bestChainEnd == hn - 1) {             // gapless chain (:283-305)
     long long queryRange = (long long)(H[hn - 1].qpos + H[hn - 1].len) - (long long)H[0].qpos;
     long long refRange = (long long)(H[hn - 1].pos + H[hn - 1].len) - (long long)H[0].pos;
-    if (queryRange == refRange && queryRange == (long long)maxDist) g.cs = QM_CS_UNGAPPED;
+    if (queryRange == refRange && queryRange == (long long)maxDist) g.set_cs(QM_CS_UNGAPPED);
   }
   return nStarts;
 }
@@ -170,7 +204,7 @@ QM_DEV void sel_strand(SS& S, int s, int n, int m, u32 readLen, int mate, float 
     for (int i = 0; i < n; ++i) {
       const SelRec& r = S.rec[i];
       if (ng == 0 || G[ng - 1].tid != r.tid) {
-        SelGroup g; g.tid = r.tid; g.cs = r.len == readLen ? QM_CS_PERFECT : QM_CS_REGULAR; g.score = -1.7976931348623157e308; g.npos = 0; g.off = (short)np;
+        SelGroup g; g.tid = r.tid; g.offcs = 0; g.set_cs(r.len == readLen ? QM_CS_PERFECT : QM_CS_REGULAR); g.score = -1.7976931348623157e308; g.npos = 0; g.set_off(np);
         g.ppos = (int)(r.pos - r.qpos);
         G[ng++] = g;
       }
@@ -215,7 +249,7 @@ QM_DEV void sel_strand(SS& S, int s, int n, int m, u32 readLen, int mate, float 
     if (na >= requiredNumHits || allActive) {
       SelGroup g;
       const int ns = sel_chain_group(S.rec + g0, g1 - g0, S.f + g0, S.p + g0, S.seen + g0, S.ends + g0, S.starts + g0, (int)readLen, g, P + np);
-      if (ns > 0) { g.off = (short)np; np += ns; G[ng++] = g; }
+      if (ns > 0) { g.set_off(np); np += ns; G[ng++] = g; }
     }
     (void)mate;
     g0 = g1;
@@ -245,11 +279,11 @@ QM_DEV int sel_emit(SS& S) {
       ++i; ++j;
     }
     const int nP = pg->npos, nO = og ? og->npos : 0;
-    if (nP > 0xfff || nO > 0xfff || o + 2 + nP + nO > SS::outcap) return -1;
-    S.out[o++] = sel_header(pg->tid, prc, pg->cs, nP, nO);
-    S.out[o++] = (u64)(u32)pg->ppos;
-    for (int t = 0; t < nP; ++t) S.out[o++] = (u64)(u32)S.pos[ps][pg->off + t];
-    for (int t = 0; t < nO; ++t) S.out[o++] = (u64)(u32)S.pos[os][og->off + t];
+    if (o + 2 + nP + nO > S.outcap()) return -1;
+    S.out[o++] = sel_header(pg->tid, prc, pg->cs(), nP);
+    S.out[o++] = (u64)(u32)pg->ppos | ((u64)(u32)nO << 32);
+    for (int t = 0; t < nP; ++t) S.out[o++] = (u64)(u32)S.pos[ps][pg->off() + t];
+    for (int t = 0; t < nO; ++t) S.out[o++] = (u64)(u32)S.pos[os][og->off() + t];
   }
   return o;
 }
@@ -361,7 +395,7 @@ QM_DEV void sel_strand_wave(SS& S, int s, int n, int m, u32 readLen, float conse
   int ngAll = 0;
 #pragma unroll
   for (int c = 0; c < QM_SEL_CHUNKS; ++c) ngAll += popc64(emm[c]);
-  if (ngAll > SS::gcap) { QM_LANES(l) { if (l == 0) S.ngrp[s] = -1; } return; }   // more transcripts than this scratch holds
+  if (ngAll > S.gcap()) { QM_LANES(l) { if (l == 0) S.ngrp[s] = -1; } return; }   // more transcripts than this scratch holds
 #pragma unroll
   for (int c = 0; c < QM_SEL_CHUNKS; ++c) {
     QM_LANES(l) {
@@ -374,7 +408,7 @@ QM_DEV void sel_strand_wave(SS& S, int s, int n, int m, u32 readLen, float conse
           ord += popc64(r);
           for (; r; r &= r - 1) mine += S.starts[64 * d + ctz64(r)];
         }
-        SelGroup g = gv[c][l]; g.off = (short)mine;
+        SelGroup g = gv[c][l]; g.set_off(mine);
         G[ord] = g;
         for (int t = 0; t < nsv[c][l]; ++t) P[mine + t] = S.ends[64 * c + l + t];
       }
@@ -399,7 +433,7 @@ QM_DEV int sel_h2m_on(const DevIndex& ix, const ReadBatch& B, const IntervalList
     int n = 0;
     if (L.n > QM_SEL_MAXIV) return -1;
     for (int ii = 0; ii < L.n; ++ii) { int lb, ub; u32 ln, qp; L.get(ii, lb, ub, ln, qp); n += ub - lb; }
-    if (n > SS::cap) return -1;
+    if (n > S.cap()) return -1;
     if (n <= 64 * QM_SEL_CHUNKS) {
       // the usual case: one lane per suffix over all the intervals at once -- one trip to sainfo per 64 suffixes of the strand
       for (int base = 0; base < n; base += 64) {
@@ -438,7 +472,7 @@ QM_DEV int sel_h2m_on(const DevIndex& ix, const ReadBatch& B, const IntervalList
       }
     }
     wave_fence();
-    const bool presorted = n <= 64 * QM_SEL_CHUNKS && 2 * n * (int)sizeof(u64) <= (int)sizeof(S.tmp);
+    const bool presorted = n <= 64 * QM_SEL_CHUNKS && 2 * n * (int)sizeof(u64) <= S.tmp_bytes();
     if (presorted && L.n > 0) sel_wave_sort(S, n, L.n);
     if (presorted && L.n > 1) sel_strand_wave(S, s, n, L.n, readLen, B.consensus_fraction);
     else QM_LANES(l) { if (l == 0) { if (L.n > 0) sel_strand(S, s, n, L.n, readLen, mate, B.consensus_fraction, presorted); else { S.ngrp[s] = 0; S.npos[s] = 0; } } }
@@ -452,29 +486,39 @@ QM_DEV int sel_h2m_on(const DevIndex& ix, const ReadBatch& B, const IntervalList
   return read_lane(nw, 0);
 }
 
-// LDS scratch first (small reads: nearly all), the wave's global scratch otherwise; status bit 3 when even that overflows.
+// LDS scratch first (small reads: nearly all), the wave's global scratch otherwise.  A read that overflows that as well
+// (repeats, low-complexity reads: a strand may bring several SA intervals of up to maxInterval suffixes each) is put on the
+// slow queue -- returns -2, the caller marks the read -- and is redone by a second, small launch of the same kernel whose
+// waves own scratch sized from the largest queued read (ReadBatch::dyn); the reference maps such reads like any other.
 QM_DEV int sel_hits_to_mappings(const DevIndex& ix, const ReadBatch& B, const IntervalList& fwdInts, const IntervalList& rcInts,
-                                u32 readLen, int mate, SelScratch& G, SelScratchLds* L, u64* ldsOut, const u64*& src) {
+                                u32 readLen, int mate, SelScratch& G, SelScratchLds* L, u64* ldsOut, const u64*& src, SelScratchDyn* dyn) {
   int n = -1;
-  if (L) { L->out = ldsOut; n = sel_h2m_on(ix, B, fwdInts, rcInts, readLen, mate, *L); src = ldsOut; }
-  if (n < 0) { n = sel_h2m_on(ix, B, fwdInts, rcInts, readLen, mate, static_cast<SelScratchT<QM_SEL_CAP, QM_CHUNK>&>(G)); src = G.out; }
-  if (n < 0) { QM_LANES(l) { if (l == 0) *B.status |= 8; } n = 0; }
+  if (!dyn) {
+    if (L) { L->out = ldsOut; n = sel_h2m_on(ix, B, fwdInts, rcInts, readLen, mate, *L); src = ldsOut; }
+    if (n < 0) { n = sel_h2m_on(ix, B, fwdInts, rcInts, readLen, mate, static_cast<SelScratchT<QM_SEL_CAP, QM_CHUNK>&>(G)); src = G.out; }
+    if (n >= 0) return n;
+    int need = 0;                                           // suffixes of the larger strand: sizes the slow pass's scratch
+    for (int s = 0; s < 2; ++s) {
+      const IntervalList& I = s == 0 ? fwdInts : rcInts;
+      int t = 0;
+      for (int ii = 0; ii < I.n; ++ii) { int lb, ub; u32 ln, qp; I.get(ii, lb, ub, ln, qp); t += ub - lb; }
+      need = t > need ? t : need;
+    }
+    QM_LANES(l) { if (l == 0) { atomic_add_u64(B.cursor + QM_SC_SLOWCNT, 1ULL); atomic_max_u64(B.cursor + QM_SC_SLOWMAX, (u64)need); } }
+    return -2;
+  }
+  SelScratchDyn D = *dyn;
+  n = sel_h2m_on(ix, B, fwdInts, rcInts, readLen, mate, D); src = D.out;
+  if (n < 0) { QM_LANES(l) { if (l == 0) *B.status |= 8; } n = 0; }   // cannot happen: the scratch was sized for this read
   return n;
 }
 
-// ------------------------------------------------------------------ stage B + C: one thread per unit
-#define QM_KSW_MAXLEN 288                                   // read (<= 256) + 20 extra target characters, rounded up
-#define QM_KSW_BYTES ((QM_KSW_MAXLEN / 16 * 6 + QM_KSW_MAXLEN / 16 + 2) * 16 + QM_KSW_MAXLEN * 4 + 2 * QM_KSW_MAXLEN)
-
-struct SelBatch {                    // launch arguments of the -s unit kernel (on top of PairBatch)
+// ------------------------------------------------------------------ stages B + C: plan (per unit) -> ksw2 (four per wavefront) -> finish (per unit)
+struct SelBatch {                    // launch arguments of the -s kernels (on top of PairBatch)
   const unsigned char* seq1; const unsigned char* seq2;
   const unsigned char* text; const int* txp_off; const int* txp_len;
   qm_hit* tmp; const long long* toff;          // per-unit slots for jointHits before the filter
   u64* tkeys; int* tsc;                        // alignment cache entries, two per slot (left / right)
-  unsigned char* ksw;                          // QM_KSW_BYTES per thread
-  unsigned char* ring;                         // this thread's QM_KSW_RING_BYTES (LDS on the device), or null
-  int emu_wave;                                // lane emulation only: run the wave-per-alignment kernel in place of the thread one
-  // three-kernel form (plan -> one wavefront per alignment -> finish)
   int* tref;                                   // per slot-side: -1 score is final / pending in tsc, <= -2 copy of unit-local entry -(ref)-2
   int* tcix;                                   // alignment-cache entries: unit-local entry a key belongs to
   struct SelTask* tasks; u64* ntasks;          // ksw2 work list
@@ -482,300 +526,40 @@ struct SelBatch {                    // launch arguments of the -s unit kernel (
   double min_score_fraction;
 };
 
-// ksw_extz2_sse41, score only, exact max, no z-drop (src/ksw2pp/ksw2_extz2_sse.c:18-304).  The SSE kernel works on
-// 16-byte vectors of int8 differences and also computes the lanes of a vector that lie outside the band; those
-// values are read back as neighbours when the band moves, so the byte layout (u v x y s sf qr in one zeroed block)
-// and every out-of-band lane are reproduced one byte at a time.  Returns max(mqe, mte).
-QM_DEV int sel_ksw_extz2(unsigned char* mem, int qlen, const unsigned char* query, int tlen, const unsigned char* target,
-                         const signed char* mat, int q, int e, int w) {
-  const int NEG = -0x40000000;
-  int mqe = NEG, mte = NEG;
-  const int m = 5;
-  if (qlen <= 0 || tlen <= 0) return NEG;
-  const int qe = q + e;
-  if (w < 0) w = tlen > qlen ? tlen : qlen;
-  const int tlen_ = (tlen + 15) / 16, qlen_ = (qlen + 15) / 16;
-  int min_sc = mat[1];
-  for (int t = 1; t < m * m; ++t) min_sc = min_sc < mat[t] ? min_sc : mat[t];
-  if (-min_sc > 2 * (q + e)) return NEG;
-  const int vecBytes = (tlen_ * 6 + qlen_ + 1) * 16 + 16;
-  for (int i = 0; i < vecBytes; ++i) mem[i] = 0;
-  unsigned char* u8 = mem; unsigned char* v8 = u8 + tlen_ * 16; unsigned char* x8 = v8 + tlen_ * 16; unsigned char* y8 = x8 + tlen_ * 16;
-  unsigned char* s8 = y8 + tlen_ * 16; unsigned char* sf = s8 + tlen_ * 16; unsigned char* qr = sf + tlen_ * 16;
-  int* H = (int*)(mem + ((vecBytes + 15) & ~15));
-  for (int t = 0; t < tlen_ * 16; ++t) H[t] = NEG;
-  for (int t = 0; t < qlen; ++t) qr[t] = query[qlen - 1 - t];
-  for (int t = 0; t < tlen; ++t) sf[t] = target[t];
-  const unsigned char sc_mch = (unsigned char)mat[0], sc_mis = (unsigned char)mat[1], sc_N = (unsigned char)mat[m * m - 1], m1 = (unsigned char)(m - 1);
-  const unsigned char qe2 = (unsigned char)((q + e) * 2), max_sc_v = (unsigned char)(mat[0] + (q + e) * 2), qv = (unsigned char)q;
-  int last_st = -1, last_en = -1;
-  for (int r = 0; r < qlen + tlen - 1; ++r) {
-    int st = 0, en = tlen - 1;
-    const unsigned char* qrr = qr + (qlen - 1 - r);
-    if (st < r - qlen + 1) st = r - qlen + 1;
-    if (en > r) en = r;
-    if (st < (r - w + 1) >> 1) st = (r - w + 1) >> 1;
-    if (en > (r + w) >> 1) en = (r + w) >> 1;
-    if (st > en) break;
-    const int st0 = st, en0 = en;
-    st = st / 16 * 16; en = (en + 16) / 16 * 16 - 1;
-    unsigned char x1, v1;
-    if (st > 0) {
-      if (st - 1 >= last_st && st - 1 <= last_en) { x1 = x8[st - 1]; v1 = v8[st - 1]; }
-      else { x1 = 0; v1 = 0; }
-    } else { x1 = 0; v1 = r ? qv : 0; }
-    if (en >= r) { y8[r] = 0; u8[r] = r ? qv : 0; }
-    for (int t = st0; t <= en0; t += 16)
-      for (int l = 0; l < 16; ++l) {
-        const unsigned char sq = sf[t + l], sv = qrr[t + l];
-        unsigned char tmp = (sq == sv) ? sc_mch : sc_mis;
-        if (sq == m1 || sv == m1) tmp = sc_N;
-        s8[t + l] = tmp;
-      }
-    for (int t = st; t <= en; ++t) {
-      unsigned char z = (unsigned char)(s8[t] + qe2);
-      const unsigned char xt1 = x1; x1 = x8[t];
-      const unsigned char vt1 = v1; v1 = v8[t];
-      unsigned char a = (unsigned char)(xt1 + vt1);
-      const unsigned char ut = u8[t];
-      unsigned char b = (unsigned char)(y8[t] + ut);
-      z = (unsigned char)((signed char)z > (signed char)a ? z : a);
-      z = z > b ? z : b;
-      z = z < max_sc_v ? z : max_sc_v;
-      u8[t] = (unsigned char)(z - vt1);
-      v8[t] = (unsigned char)(z - ut);
-      z = (unsigned char)(z - qv);
-      a = (unsigned char)(a - z); b = (unsigned char)(b - z);
-      x8[t] = (signed char)a > 0 ? a : 0;
-      y8[t] = (signed char)b > 0 ? b : 0;
-    }
-    if (r > 0) {
-      H[en0] = en0 > 0 ? H[en0 - 1] + u8[en0] - qe : H[en0] + v8[en0] - qe;
-      for (int t = st0; t < en0; ++t) H[t] += (int)v8[t] - qe;
-    } else H[0] = v8[0] - qe - qe;
-    if (en0 == tlen - 1 && H[en0] > mte) mte = H[en0];
-    if (r - st0 == qlen - 1 && H[st0] > mqe) mqe = H[st0];
-    last_st = st; last_en = en;
-  }
-  return mqe > mte ? mqe : mte;
-}
-
-// The same kernel on a ring of 64 columns (for bands of at most 33): the columns a round touches lie within 47
-// of each other and the band only moves forward, so column t lives in slot t & 63 until column t + 64 needs the
-// slot; a tag tells which column a slot holds ("never computed" = the zero-initialised memory of the original).
-// 708 bytes per alignment instead of ~2.5 KB: small enough for LDS, one thread per alignment.
-#define QM_KSW_RING_BYTES 708
-struct KswRing {
-  unsigned char* u; unsigned char* v; unsigned char* x; unsigned char* y; unsigned char* s; short* tag; int* H;
-  QM_DEV void bind(unsigned char* m) { H = (int*)m; tag = (short*)(m + 256); u = m + 384; v = u + 64; x = v + 64; y = x + 64; s = y + 64; }
-  QM_DEV void touch(int t) {          // make slot t & 63 hold column t
-    const int k = t & 63;
-    if (tag[k] != (short)(t + 1)) { tag[k] = (short)(t + 1); u[k] = v[k] = x[k] = y[k] = s[k] = 0; H[k] = -0x40000000; }
-  }
-  QM_DEV bool has(int t) const { return tag[t & 63] == (short)(t + 1); }
-};
-QM_DEV int sel_ksw_extz2_ring(unsigned char* mem, int qlen, const unsigned char* query, int tlen, const unsigned char* target,
-                              const signed char* mat, int q, int e, int w) {
-  const int NEG = -0x40000000;
-  int mqe = NEG, mte = NEG;
-  const int m = 5;
-  if (qlen <= 0 || tlen <= 0) return NEG;
-  const int qe = q + e;
-  const int tlen16 = (tlen + 15) / 16 * 16;
-  int min_sc = mat[1];
-  for (int t = 1; t < m * m; ++t) min_sc = min_sc < mat[t] ? min_sc : mat[t];
-  if (-min_sc > 2 * (q + e)) return NEG;
-  KswRing R; R.bind(mem);
-  for (int i = 0; i < 64; ++i) R.tag[i] = 0;
-  // the original's memory image: sf = target padded with zeros to tlen16, directly followed by qr = reversed query + zeros
-  auto qrAt = [&](int i) -> unsigned char { return (i >= 0 && i < qlen) ? query[qlen - 1 - i] : 0; };
-  auto sfAt = [&](int i) -> unsigned char { return i < tlen ? target[i] : (i < tlen16 ? 0 : qrAt(i - tlen16)); };
-  auto qrrAt = [&](int i) -> unsigned char { return i >= 0 ? qrAt(i) : sfAt(tlen16 + i); };
-  const unsigned char sc_mch = (unsigned char)mat[0], sc_mis = (unsigned char)mat[1], sc_N = (unsigned char)mat[m * m - 1], m1 = (unsigned char)(m - 1);
-  const unsigned char qe2 = (unsigned char)((q + e) * 2), max_sc_v = (unsigned char)(mat[0] + (q + e) * 2), qv = (unsigned char)q;
-  int last_st = -1, last_en = -1;
-  for (int r = 0; r < qlen + tlen - 1; ++r) {
-    int st = 0, en = tlen - 1;
-    const int qoff = qlen - 1 - r;
-    if (st < r - qlen + 1) st = r - qlen + 1;
-    if (en > r) en = r;
-    if (st < (r - w + 1) >> 1) st = (r - w + 1) >> 1;
-    if (en > (r + w) >> 1) en = (r + w) >> 1;
-    if (st > en) break;
-    const int st0 = st, en0 = en;
-    st = st / 16 * 16; en = (en + 16) / 16 * 16 - 1;
-    unsigned char x1, v1;
-    if (st > 0) {
-      if (st - 1 >= last_st && st - 1 <= last_en && R.has(st - 1)) { x1 = R.x[(st - 1) & 63]; v1 = R.v[(st - 1) & 63]; }
-      else { x1 = 0; v1 = 0; }
-    } else { x1 = 0; v1 = r ? qv : 0; }
-    if (en >= r) { R.touch(r); R.y[r & 63] = 0; R.u[r & 63] = r ? qv : 0; }
-    for (int t = st0; t <= en0; t += 16)
-      for (int l = 0; l < 16; ++l) {
-        const unsigned char sq = sfAt(t + l), sv = qrrAt(qoff + t + l);
-        unsigned char tmp = (sq == sv) ? sc_mch : sc_mis;
-        if (sq == m1 || sv == m1) tmp = sc_N;
-        R.touch(t + l); R.s[(t + l) & 63] = tmp;
-      }
-    for (int t = st; t <= en; ++t) {
-      R.touch(t);
-      const int k = t & 63;
-      unsigned char z = (unsigned char)(R.s[k] + qe2);
-      const unsigned char xt1 = x1; x1 = R.x[k];
-      const unsigned char vt1 = v1; v1 = R.v[k];
-      unsigned char a = (unsigned char)(xt1 + vt1);
-      const unsigned char ut = R.u[k];
-      unsigned char b = (unsigned char)(R.y[k] + ut);
-      z = (unsigned char)((signed char)z > (signed char)a ? z : a);
-      z = z > b ? z : b;
-      z = z < max_sc_v ? z : max_sc_v;
-      R.u[k] = (unsigned char)(z - vt1);
-      R.v[k] = (unsigned char)(z - ut);
-      z = (unsigned char)(z - qv);
-      a = (unsigned char)(a - z); b = (unsigned char)(b - z);
-      R.x[k] = (signed char)a > 0 ? a : 0;
-      R.y[k] = (signed char)b > 0 ? b : 0;
-    }
-    if (r > 0) {
-      const int Hprev = en0 > 0 ? (R.has(en0 - 1) ? R.H[(en0 - 1) & 63] : NEG) : 0;
-      R.H[en0 & 63] = en0 > 0 ? Hprev + R.u[en0 & 63] - qe : R.H[en0 & 63] + R.v[en0 & 63] - qe;
-      for (int t = st0; t < en0; ++t) R.H[t & 63] += (int)R.v[t & 63] - qe;
-    } else R.H[0] = R.v[0] - qe - qe;
-    if (en0 == tlen - 1 && R.H[en0 & 63] > mte) mte = R.H[en0 & 63];
-    if (r - st0 == qlen - 1 && R.H[st0 & 63] > mqe) mqe = R.H[st0 & 63];
-    last_st = st; last_en = en;
-  }
-  return mqe > mte ? mqe : mte;
-}
-
-// The same kernel with one wavefront per alignment: lane k owns the column t with t & 63 == k of the current window
-// (the ring above, held in registers), so one anti-diagonal costs a few dozen wave instructions instead of a serial
-// walk over up to 64 bytes; the left neighbour's previous-round x / v and H come over a lane shuffle.  Wave-uniform
-// control, all lanes must call it together.  Bands of at most 33 (callers fall back to the thread version otherwise).
-// img: QM_KSW_IMG_BYTES of scratch shared by the lanes.  The score phase of the original reads the reversed query and the
-// target out of one zeroed block (sf = target + zeros up to tlen16, directly followed by qr = reversed query + zeros) and
-// its 16-wide vectors run past both ends of the band; the two images below hold exactly what those reads return:
+// ksw_extz2_sse41, score only, exact max, no z-drop (src/ksw2pp/ksw2_extz2_sse.c:18-304), as the reference calls it for
+// every extension alignment (KSW2Aligner::operator(), EXTENSION).  The SSE kernel works on 16-byte vectors of int8
+// differences and also computes the lanes of a vector that lie outside the band; those values are read back as neighbours
+// when the band moves, so the out-of-band lanes, the byte wrap-around and the zero-initialised state of columns nobody
+// has computed yet are all reproduced.
+//
+// Four alignments per wavefront: every row of 16 lanes is one __m128i of the SSE kernel and walks the 16-column vectors
+// of its own alignment's band one after the other, like the original's inner loop.  Column state lives in a ring of RING
+// slots in LDS (column t in slot t & (RING - 1), u|v<<8|x<<16|y<<24 in one word), reset when the 16-aligned window start
+// moves.  A round touches the columns [st, max(en, smax)] with st = 16-aligned band start, en = 16-aligned band end,
+// smax <= band end + 15: at most w + 31 columns, so RING >= w + 31 (64 slots for --dpBandwidth <= 33, 128 up to 97, 512
+// for anything else -- 512 slots hold every column of the longest alignment, the window then never moves).
+// The score phase of the original reads the reversed query and the target out of one zeroed block (sf = target + zeros up
+// to tlen16, directly followed by qr = reversed query + zeros) and its 16-wide vectors run past both ends of the band; the
+// two images hold exactly what those reads return:
 //   QX[16 + i] = query[i] (0 <= i < qlen), zero before and after    -- the query character of cell (r, t) is QX[16 + r - t]
 //   TX[t] = target[t] (t < tlen), 0 (t < tlen16), query[qlen - 1 - (t - tlen16)] beyond -- a column's target character
-#define QM_KSW_IMG_BYTES (2 * QM_KSW_MAXLEN + 80)
-QM_DEV int sel_ksw_extz2_wave(int qlen, const unsigned char* query, int tlen, const unsigned char* target,
-                              const signed char* mat, int q, int e, int w, unsigned char* img) {
-  const int NEG = -0x40000000;
-  int mqe = NEG, mte = NEG;
-  const int m = 5;
-  if (qlen <= 0 || tlen <= 0) return NEG;
-  const int qe = q + e;
-  const int tlen16 = (tlen + 15) / 16 * 16;
-  unsigned char* QX = img; unsigned char* TX = img + QM_KSW_MAXLEN + 40;
-  for (int b0 = 0; b0 < tlen16 + 16 || b0 < qlen + 32; b0 += 64) {
-    QM_LANES(l) {
-      const int i = b0 + l;
-      if (i < qlen + 32) QX[i] = (i >= 16 && i < 16 + qlen) ? query[i - 16] : 0;
-      if (i < tlen16 + 16) {
-        const int j = i - tlen16;
-        TX[i] = i < tlen ? target[i] : (i < tlen16 ? 0 : (j < qlen ? query[qlen - 1 - j] : 0));
-      }
-    }
-  }
-  wave_fence();
-  int min_sc = mat[1];
-  for (int t = 1; t < m * m; ++t) min_sc = min_sc < mat[t] ? min_sc : mat[t];
-  if (-min_sc > 2 * (q + e)) return NEG;
-  const int sc_mch = (unsigned char)mat[0], sc_mis = (unsigned char)mat[1], sc_N = (unsigned char)mat[m * m - 1], m1 = m - 1;
-  const int qe2 = (unsigned char)((q + e) * 2), max_sc_v = (unsigned char)(mat[0] + (q + e) * 2), qv = (unsigned char)q;
-  LV<int> U, V, X, Y, S, H, TC;
-  QM_LANES(l) { U[l] = 0; V[l] = 0; X[l] = 0; Y[l] = 0; S[l] = 0; H[l] = NEG; TC[l] = 0; }
-  int last_st = -1, last_en = -1;
-  int hb = NEG;                                                  // H of column st - 1 (left of the window)
-  for (int r = 0; r < qlen + tlen - 1; ++r) {
-    int st = 0, en = tlen - 1;
-    if (st < r - qlen + 1) st = r - qlen + 1;
-    if (en > r) en = r;
-    if (st < (r - w + 1) >> 1) st = (r - w + 1) >> 1;
-    if (en > (r + w) >> 1) en = (r + w) >> 1;
-    if (st > en) break;
-    const int st0 = st, en0 = en;
-    st = st / 16 * 16; en = (en + 16) / 16 * 16 - 1;
-    const int smax = st0 + ((en0 - st0) / 16) * 16 + 15;       // last column the score phase writes
-    // boundary values for column st: x / v of column st - 1 as left by the last round that computed it
-    // (lane l always holds column t(l) of the current window, all-zero if nobody computed that column yet)
-    int x1b = 0, v1b = 0;
-    if (st > 0) {
-      if (st - 1 >= last_st && st - 1 <= last_en) { const int kk = (st - 1) & 63; x1b = read_lane(X, kk); v1b = read_lane(V, kk); }
-    } else { x1b = 0; v1b = r ? qv : 0; }
-    LV<int> xo, ho;
-    // the window [st, st + 63] moved (or first round): lanes whose column changed start over as a column nobody has
-    // computed yet -- all-zero state, exactly what the original finds in its zero-initialised arrays
-    if (st != last_st) {
-      hb = (st > 0 && last_st >= 0) ? read_lane(H, (st - 1) & 63) : NEG;
-      QM_LANES(l) {
-        const int t = st + ((l - st) & 63);
-        const int told = last_st < 0 ? -1 : last_st + ((l - last_st) & 63);
-        if (told != t) { U[l] = 0; V[l] = 0; X[l] = 0; Y[l] = 0; S[l] = 0; H[l] = NEG; TC[l] = t < tlen16 + 16 ? TX[t] : 0; }
-      }
-    }
-    QM_LANES(l) {
-      const int t = st + ((l - st) & 63);                        // this lane's column in the window [st, st + 63]
-      if (en >= r && t == r) { Y[l] = 0; U[l] = r ? qv : 0; }
-      if (t >= st0 && t <= smax) {
-        const int sv = QX[16 + r - t], sq = TC[l];
-        int tmp = (sq == sv) ? sc_mch : sc_mis;
-        if (sq == m1 || sv == m1) tmp = sc_N;
-        S[l] = tmp;
-      }
-      xo[l] = X[l] | (V[l] << 8); ho[l] = H[l];                  // x and v in one word
-    }
-    // previous-round x, v, H of the left neighbour column (lane l - 1)
-    LV<int> xl, vl, hl;
-    lane_rotate_up(xo, xl); lane_rotate_up(ho, hl);
-    QM_LANES(l) { vl[l] = xl[l] >> 8; xl[l] = xl[l] & 0xff; }
-    QM_LANES(l) {
-      const int t = st + ((l - st) & 63);
-      if (t <= en) {
-        int xt1, vt1;
-        if (t == st) { xt1 = x1b; vt1 = v1b; }
-        else { xt1 = xl[l]; vt1 = vl[l]; }
-        int z = (S[l] + qe2) & 0xff;
-        int a = (xt1 + vt1) & 0xff;
-        const int ut = U[l];
-        int b = (Y[l] + ut) & 0xff;
-        z = ((signed char)z > (signed char)a) ? z : a;
-        z = z > b ? z : b;
-        z = z < max_sc_v ? z : max_sc_v;
-        U[l] = (z - vt1) & 0xff;
-        V[l] = (z - ut) & 0xff;
-        z = (z - qv) & 0xff;
-        a = (a - z) & 0xff; b = (b - z) & 0xff;
-        X[l] = (signed char)a > 0 ? a : 0;
-        Y[l] = (signed char)b > 0 ? b : 0;
-      }
-      // H (exact max): H[en0] from the left neighbour's previous value, the other band cells accumulate v
-      if (r > 0) {
-        if (t == en0) {
-          if (en0 > 0) H[l] = (en0 > st ? hl[l] : hb) + U[l] - qe;
-          else H[l] = H[l] + V[l] - qe;
-        } else if (t >= st0 && t < en0) H[l] += V[l] - qe;
-      } else if (t == 0) H[l] = V[l] - qe - qe;
-    }
-    if (en0 == tlen - 1) { const int h = read_lane(H, en0 & 63); if (h > mte) mte = h; }
-    if (r - st0 == qlen - 1) { const int h = read_lane(H, st0 & 63); if (h > mqe) mqe = h; }
-    last_st = st; last_en = en;
-  }
-  return mqe > mte ? mqe : mte;
-}
-
-// Four alignments per wavefront: every row of 16 lanes is one __m128i of the SSE kernel and walks the 16-column vectors
-// of its own alignment's band one after the other, like the original's inner loop.  Column state lives in a ring of 64
-// slots in LDS (column t in slot t & 63, u|v<<8|x<<16|y<<24 in one word; the band and its vector padding span at most
-// 48 + 16 columns), reset when the 16-aligned window start moves -- the same bookkeeping as sel_ksw_extz2_wave, whose
-// images QX / TX feed the score phase.  Everything is per-lane (row-uniform) VALU work: no scalar control per alignment.
-struct KswRow {                                   // one alignment's LDS block (1232 bytes)
+// Everything is per-lane (row-uniform) VALU work: no scalar control per alignment.
+#define QM_KSW_MAXLEN 288                                   // read (<= 256) + 20 extra target characters, rounded up
+template <int RING>
+struct KswRowT {                                  // one alignment's LDS block (1232 bytes at RING = 64)
   unsigned char QX[QM_KSW_MAXLEN + 40], TX[QM_KSW_MAXLEN + 40];
-  u32 ST[64]; int HH[64]; unsigned char SS[64];
+  u32 ST[RING]; int HH[RING]; unsigned char SS[RING];
 };
-// qlenv / tlenv: the row's alignment (0: the row idles); blk[row]; the images must be in place.  Returns max(mqe, mte) per row.
-QM_DEV void sel_ksw_extz2_rows(const LV<int>& qlenv, const LV<int>& tlenv, KswRow* blk, const signed char* mat, int q, int e, int w,
+inline constexpr int sel_ksw_ring_slots(int w) {   // host + device (constexpr)
+  return (w >= 0 && w <= 33) ? 64 : ((w >= 0 && w <= 97) ? 128 : 512); }
+// qlenv / tlenv: the row's alignment (0: the row idles); blk[row]; the images must be in place.  wIn < 0: the band is the
+// whole matrix (ksw2_extz2_sse.c:45).  Returns max(mqe, mte) per row.
+template <int RING>
+QM_DEV void sel_ksw_extz2_rows(const LV<int>& qlenv, const LV<int>& tlenv, KswRowT<RING>* blk, const signed char* mat, int q, int e, int wIn,
                                LV<int>& score) {
+  typedef KswRowT<RING> Row;
+  constexpr int RM = RING - 1;
+  constexpr int NV = RING / 16 + 1;                 // 16-column vectors a round may touch
   const int NEG = -0x40000000;
   const int m = 5;
   const int qe = q + e;
@@ -784,12 +568,15 @@ QM_DEV void sel_ksw_extz2_rows(const LV<int>& qlenv, const LV<int>& tlenv, KswRo
   if (-min_sc > 2 * (q + e)) { QM_LANES(l) { score[l] = NEG; } return; }
   const int sc_mch = (unsigned char)mat[0], sc_mis = (unsigned char)mat[1], sc_N = (unsigned char)mat[m * m - 1], m1 = m - 1;
   const int qe2 = (unsigned char)((q + e) * 2), max_sc_v = (unsigned char)(mat[0] + (q + e) * 2), qv = (unsigned char)q;
-  LV<int> lastSt, lastEn, hb, mqe, mte; LV<bool> done;
-  QM_LANES(l) { lastSt[l] = -1; lastEn[l] = -1; hb[l] = NEG; mqe[l] = NEG; mte[l] = NEG; done[l] = qlenv[l] <= 0 || tlenv[l] <= 0; }
+  LV<int> lastSt, lastEn, hb, mqe, mte, wv; LV<bool> done;
+  QM_LANES(l) {
+    lastSt[l] = -1; lastEn[l] = -1; hb[l] = NEG; mqe[l] = NEG; mte[l] = NEG; done[l] = qlenv[l] <= 0 || tlenv[l] <= 0;
+    wv[l] = wIn < 0 ? (tlenv[l] > qlenv[l] ? tlenv[l] : qlenv[l]) : wIn;
+  }
   for (int r = 0; ; ++r) {
     LV<int> st0v, en0v, stv, env, smaxv; LV<bool> act;
     QM_LANES(l) {
-      const int qlen = qlenv[l], tlen = tlenv[l];
+      const int qlen = qlenv[l], tlen = tlenv[l], w = wv[l];
       int st = 0, en = tlen - 1;
       if (st < r - qlen + 1) st = r - qlen + 1;
       if (en > r) en = r;
@@ -805,9 +592,9 @@ QM_DEV void sel_ksw_extz2_rows(const LV<int>& qlenv, const LV<int>& tlenv, KswRo
     // boundary of the first vector (x / v of column st - 1 as the last round left them), H of column st - 1 when the window moves
     LV<int> bpack, hbNew; LV<bool> moved;
     QM_LANES(l) {
-      KswRow& B = blk[l >> 4];
+      Row& B = blk[l >> 4];
       const int st = stv[l];
-      const int left = (int)(B.ST[(st - 1) & 63] & 0x00ffff00u), hleft = B.HH[(st - 1) & 63];   // v, x and H of column st - 1
+      const int left = (int)(B.ST[(st - 1) & RM] & 0x00ffff00u), hleft = B.HH[(st - 1) & RM];   // v, x and H of column st - 1
       bpack[l] = st > 0 ? ((st - 1 >= lastSt[l] && st - 1 <= lastEn[l]) ? left : 0) : ((r ? qv : 0) << 8);
       moved[l] = act[l] && st != lastSt[l];
       hbNew[l] = (st > 0 && lastSt[l] >= 0) ? hleft : NEG;
@@ -816,12 +603,12 @@ QM_DEV void sel_ksw_extz2_rows(const LV<int>& qlenv, const LV<int>& tlenv, KswRo
     if (ballot(moved))                                    // rare: a row's window advances every ~32 rounds
     QM_LANES(l) {
       if (moved[l]) {
-        KswRow& B = blk[l >> 4];
+        Row& B = blk[l >> 4];
         hb[l] = hbNew[l];
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < RING / 16; ++k) {
           const int slot = (l & 15) + 16 * k;
-          const int t = stv[l] + ((slot - stv[l]) & 63);
-          const int told = lastSt[l] < 0 ? -1 : lastSt[l] + ((slot - lastSt[l]) & 63);
+          const int t = stv[l] + ((slot - stv[l]) & RM);
+          const int told = lastSt[l] < 0 ? -1 : lastSt[l] + ((slot - lastSt[l]) & RM);
           if (told != t) { B.ST[slot] = 0; B.HH[slot] = NEG; B.SS[slot] = 0; }
         }
       }
@@ -832,29 +619,29 @@ QM_DEV void sel_ksw_extz2_rows(const LV<int>& qlenv, const LV<int>& tlenv, KswRo
     if (ballot(diag))                                     // only while the band still touches the diagonal (the first ~w rounds)
     QM_LANES(l) {                                       // the diagonal cell: y8[r] = 0, u8[r] = r ? q : 0
       if (diag[l]) {
-        KswRow& B = blk[l >> 4];
-        B.ST[r & 63] = (B.ST[r & 63] & 0x00ffff00u) | (u32)(r ? qv : 0);
+        Row& B = blk[l >> 4];
+        B.ST[r & RM] = (B.ST[r & RM] & 0x00ffff00u) | (u32)(r ? qv : 0);
       }
     }
     wave_fence();
     LV<int> prevOld;
     QM_LANES(l) { prevOld[l] = bpack[l]; }
-    for (int it = 0; it < 5; ++it) {
+    for (int it = 0; it < NV; ++it) {
       // every lane computes its cell whether it is in range or not (all loads stay inside the row's block: ring slots, and
       // image indices clamped into the images); only the two stores are predicated -- far fewer exec-mask round trips
       LV<int> old, sCur; LV<bool> inCore, inScore;
       QM_LANES(l) {
         const int t = stv[l] + 16 * it + (l & 15);
-        KswRow& B = blk[l >> 4];
+        Row& B = blk[l >> 4];
         inCore[l] = act[l] && t <= env[l];
         inScore[l] = act[l] && t >= st0v[l] && t <= smaxv[l];
-        old[l] = (int)B.ST[t & 63]; sCur[l] = B.SS[t & 63];
+        old[l] = (int)B.ST[t & RM]; sCur[l] = B.SS[t & RM];
       }
       LV<bool> any;
       QM_LANES(l) { any[l] = inCore[l] || inScore[l]; }
       if (!ballot(any)) break;
       QM_LANES(l) {
-        KswRow& B = blk[l >> 4];
+        Row& B = blk[l >> 4];
         const int t = stv[l] + 16 * it + (l & 15);
         int qi = 16 + r - t; qi = qi < 0 ? 0 : (qi > QM_KSW_MAXLEN + 39 ? QM_KSW_MAXLEN + 39 : qi);
         const int ti = t > QM_KSW_MAXLEN + 39 ? QM_KSW_MAXLEN + 39 : t;
@@ -862,12 +649,12 @@ QM_DEV void sel_ksw_extz2_rows(const LV<int>& qlenv, const LV<int>& tlenv, KswRo
         int tmp = (sq == sv) ? sc_mch : sc_mis;
         tmp = (sq == m1 || sv == m1) ? sc_N : tmp;
         sCur[l] = inScore[l] ? tmp : sCur[l];
-        if (inScore[l]) B.SS[t & 63] = (unsigned char)tmp;
+        if (inScore[l]) B.SS[t & RM] = (unsigned char)tmp;
       }
       LV<int> nb, carry;
       row_rotate_up(old, nb); row_rotate_up(prevOld, carry);
       QM_LANES(l) {
-        KswRow& B = blk[l >> 4];
+        Row& B = blk[l >> 4];
         const int t = stv[l] + 16 * it + (l & 15);
         const int xv = (l & 15) == 0 ? carry[l] : nb[l];
         const int xt1 = (xv >> 16) & 0xff, vt1 = (xv >> 8) & 0xff;
@@ -882,7 +669,7 @@ QM_DEV void sel_ksw_extz2_rows(const LV<int>& qlenv, const LV<int>& tlenv, KswRo
         z = (z - qv) & 0xff;
         a = (a - z) & 0xff; b = (b - z) & 0xff;
         const int xn = (signed char)a > 0 ? a : 0, yn = (signed char)b > 0 ? b : 0;
-        if (inCore[l]) B.ST[t & 63] = (u32)un | ((u32)vn << 8) | ((u32)xn << 16) | ((u32)yn << 24);
+        if (inCore[l]) B.ST[t & RM] = (u32)un | ((u32)vn << 8) | ((u32)xn << 16) | ((u32)yn << 24);
         prevOld[l] = inCore[l] ? old[l] : prevOld[l];
       }
       wave_fence();
@@ -891,19 +678,19 @@ QM_DEV void sel_ksw_extz2_rows(const LV<int>& qlenv, const LV<int>& tlenv, KswRo
     LV<int> hLeft;                                      // H[en0 - 1] before this round's updates
     QM_LANES(l) {
       hLeft[l] = NEG;
-      if (act[l] && en0v[l] > 0) hLeft[l] = en0v[l] > stv[l] ? blk[l >> 4].HH[(en0v[l] - 1) & 63] : hb[l];
+      if (act[l] && en0v[l] > 0) hLeft[l] = en0v[l] > stv[l] ? blk[l >> 4].HH[(en0v[l] - 1) & RM] : hb[l];
     }
     wave_fence();
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < RING / 16; ++k) {
       LV<int> hn; LV<bool> has;
       QM_LANES(l) {
         const int t = st0v[l] + (l & 15) + 16 * k;
         has[l] = act[l] && t <= en0v[l];
-        KswRow& B = blk[l >> 4];
+        Row& B = blk[l >> 4];
         const int en0 = en0v[l];
-        const u32 pk = B.ST[t & 63];
+        const u32 pk = B.ST[t & RM];
         const int un = (int)(pk & 0xff), vn = (int)((pk >> 8) & 0xff);
-        const int hOwn = B.HH[t & 63] + vn - qe;
+        const int hOwn = B.HH[t & RM] + vn - qe;
         const int hTop = en0 > 0 ? (hLeft[l] + un - qe) : hOwn;
         hn[l] = r > 0 ? (t == en0 ? hTop : hOwn) : (vn - qe - qe);   // r == 0: the only cell is t == 0
       }
@@ -911,9 +698,9 @@ QM_DEV void sel_ksw_extz2_rows(const LV<int>& qlenv, const LV<int>& tlenv, KswRo
       wave_fence();
       QM_LANES(l) {
         if (has[l]) {
-          KswRow& B = blk[l >> 4];
+          Row& B = blk[l >> 4];
           const int t = st0v[l] + (l & 15) + 16 * k;
-          B.HH[t & 63] = hn[l];
+          B.HH[t & RM] = hn[l];
           if (t == en0v[l] && en0v[l] == tlenv[l] - 1 && hn[l] > mte[l]) mte[l] = hn[l];
           if (t == st0v[l] && r - st0v[l] == qlenv[l] - 1 && hn[l] > mqe[l]) mqe[l] = hn[l];
         }
@@ -936,89 +723,15 @@ QM_DEV unsigned char sel_nt4(unsigned char c) {               // seq_nt4_table_l
 }
 
 struct SelTask { long long u; int gslot, side, tid, pos, roff, rlen, tlen1, fwd; };   // one ksw2 extension alignment
-struct SelCache { u64* keys; int* sc; int n; int stride; };   // entries of one side: keys[i*stride], sc[i*stride]
 
 // the read as the alignment sees it: forward, or reverseRead() of it (src/RapMapUtils.cpp:107-128)
 QM_DEV unsigned char sel_read_char(const unsigned char* r, int len, bool fwd, int i) { return fwd ? r[i] : rc_char(r[len - 1 - i]); }
-
-// selective_alignment::utils::getAlnScore (SelectiveAlignmentUtils.hpp:260-373)
-QM_DEV int sel_aln_score(const SelBatch& A, unsigned char* kmem, int pos, const unsigned char* read, int readLen, bool fwd,
-                         const unsigned char* tseq, int tlen, int maxScore, int chainStat, bool multiMapping, SelCache& C) {
-  if (chainStat == QM_CS_PERFECT) return maxScore;
-  const int LOWEST = (int)0x80000000;
-  int s = LOWEST;
-  int roff = 0, rlen = readLen;
-  const bool invalidStart = pos < 0;
-  const bool invalidEnd = pos + rlen >= tlen;
-  if (invalidStart) { roff = -pos; rlen += pos; pos = 0; }
-  if ((invalidStart || invalidEnd) && (A.policy == 1 || A.policy == 2)) return s;
-  if (pos < tlen) {
-    const bool doUngapped = !invalidStart && chainStat == QM_CS_UNGAPPED;
-    const u32 buf = doUngapped ? 0u : 20u;
-    const u32 lnobuf = (u32)(tlen - pos), lbuf = (u32)(rlen + (int)buf);
-    const bool useBuf = lbuf < lnobuf;
-    const u32 tlen1 = lbuf < lnobuf ? lbuf : lnobuf;
-    const unsigned char* tseq1 = tseq + pos;
-    const u32 keyLen = useBuf ? tlen1 - buf : tlen1;
-    u64 key = 0; bool didHash = false;
-    auto hashKey = [&]() {
-      u64 h = hash_mix((u64)keyLen + 0x9E3779B97F4A7C15ULL);
-      for (u32 i = 0; i < keyLen; i += 8) {
-        u64 w = 0;
-        for (u32 t = 0; t < 8 && i + t < keyLen; ++t) w |= (u64)tseq1[i + t] << (8 * t);
-        h = hash_mix(h ^ w);
-      }
-      return h;
-    };
-    if (C.n > 0) {
-      key = hashKey(); didHash = true;
-      for (int i = 0; i < C.n; ++i) if (C.keys[i * C.stride] == key) { s = C.sc[i * C.stride]; break; }
-    }
-    if (s == LOWEST) {
-      if (doUngapped) {
-        const int tlen1s = (int)tlen1;
-        const int alnLen = rlen < tlen1s ? rlen : tlen1s;
-        int sc = 0;
-        for (int i = 0; i < alnLen; ++i) {
-          unsigned char c1 = tseq1[i], c2 = sel_read_char(read, readLen, fwd, roff + i);
-          c1 = (c1 == 'N' || c2 == 'N') ? c2 : c1;
-          sc += (c1 == c2) ? A.match : A.mismatch;
-        }
-        s = sc;
-      } else {
-        // KSW2Aligner::operator()(…, EXTENSION): nt4-transform both strings, banded extension alignment
-        unsigned char* qb = kmem + QM_KSW_BYTES - 2 * QM_KSW_MAXLEN; unsigned char* tb = qb + QM_KSW_MAXLEN;
-        for (int i = 0; i < rlen; ++i) qb[i] = sel_nt4(sel_read_char(read, readLen, fwd, roff + i));
-        for (u32 i = 0; i < tlen1; ++i) tb[i] = sel_nt4(tseq1[i]);
-        signed char mat[25];
-        int a = (signed char)A.match, b = (signed char)A.mismatch;
-        a = a < 0 ? -a : a; b = b > 0 ? -b : b;
-        for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) mat[i * 5 + j] = (signed char)(i == j ? a : b); mat[i * 5 + 4] = 0; }
-        for (int j = 0; j < 5; ++j) mat[20 + j] = 0;
-#ifdef QM_EMU
-        if (A.emu_wave && A.bandwidth >= 0 && A.bandwidth <= 33)
-          { static thread_local unsigned char img[QM_KSW_IMG_BYTES]; s = sel_ksw_extz2_wave(rlen, qb, (int)tlen1, tb, mat, (signed char)A.gap_open, (signed char)A.gap_extend, A.bandwidth, img); }
-        else
-#endif
-        if (A.bandwidth >= 0 && A.bandwidth <= 33 && A.ring)
-          s = sel_ksw_extz2_ring(A.ring, rlen, qb, (int)tlen1, tb, mat, (signed char)A.gap_open, (signed char)A.gap_extend, A.bandwidth);
-        else
-          s = sel_ksw_extz2(kmem, rlen, qb, (int)tlen1, tb, mat, (signed char)A.gap_open, (signed char)A.gap_extend, A.bandwidth);
-      }
-      if (multiMapping) {
-        if (!didHash) key = hashKey();
-        C.keys[C.n * C.stride] = key; C.sc[C.n * C.stride] = s; C.n++;
-      }
-    }
-  }
-  return s;
-}
 
 // one list group as stage B sees it
 struct SelG { u32 tid; bool rc; int cs, np, no, ppos; const u64* P; const u64* O; int words; };
 QM_DEV SelG sel_group(const u64* X) {
   SelG g; const u64 h = X[0];
-  g.tid = selh_tid(h); g.rc = selh_rc(h); g.cs = selh_cs(h); g.np = selh_np(h); g.no = selh_no(h);
+  g.tid = selh_tid(h); g.rc = selh_rc(h); g.cs = selh_cs(h); g.np = selh_np(h); g.no = (int)(X[1] >> 32);
   g.ppos = (int)(u32)X[1]; g.P = X + 2; g.O = X + 2 + g.np; g.words = 2 + g.np + g.no;
   return g;
 }
@@ -1132,84 +845,11 @@ QM_DEV int sel_unit_merge(const PairBatch& P, const SelBatch& A, long long u, Un
   return n;
 }
 
-QM_DEV int sel_unit(const PairBatch& P, const SelBatch& A, long long u, long long tid_global, UnitCounters* uc) {
-  qm_hit* T = A.tmp + A.toff[u];
-  u64* keys = A.tkeys + 2 * A.toff[u]; int* scs = A.tsc + 2 * A.toff[u];
-  unsigned char* kmem = A.ksw + (unsigned long long)tid_global * QM_KSW_BYTES;
-  const int LOWEST = (int)0x80000000;
-  int n = sel_unit_merge(P, A, u, uc);
-  const u32 l1 = (u32)(P.off1[u + 1] - P.off1[u]);
-  const unsigned char* r1 = A.seq1 + P.off1[u];
-  if (!P.paired) {
-    // selective alignment (:246-318)
-    SelCache C; C.keys = keys; C.sc = scs; C.n = 0; C.stride = 2;
-    int bestScore = LOWEST;
-    const int maxReadScore = A.match * (int)l1;
-    const bool multiMapping = n > 1;
-    for (int i = 0; i < n; ++i) {
-      qm_hit& h = T[i];
-      const int s = sel_aln_score(A, kmem, h.pos, r1, (int)l1, h.fwd != 0, A.text + A.txp_off[h.tid], A.txp_len[h.tid], maxReadScore,
-                                  h.aln_score, multiMapping, C);
-      const int score = ((double)s < A.min_score_fraction * (double)maxReadScore) ? LOWEST : s;
-      bestScore = score > bestScore ? score : bestScore;
-      h.aln_score = score;
-    }
-    int o = 0;
-    if (bestScore > LOWEST)
-      for (int i = 0; i < n; ++i) { const bool rem = A.hard_filter ? (T[i].aln_score < bestScore) : (T[i].aln_score == LOWEST); if (!rem) { if (o != i) T[o] = T[i]; ++o; } }
-    n = o;
-    if (uc && n > 0) uc->mapped += 1;
-    return n;
-  }
-  const u32 l2 = (u32)(P.off2[u + 1] - P.off2[u]);
-  const unsigned char* r2 = A.seq2 + P.off2[u];
-  if (n > 0) {                                             // :554-667
-    SelCache CL, CR;
-    CL.keys = keys; CL.sc = scs; CL.n = 0; CL.stride = 2;
-    CR.keys = keys + 1; CR.sc = scs + 1; CR.n = 0; CR.stride = 2;
-    int bestScore = LOWEST;
-    const int maxLeftScore = A.match * (int)l1, maxRightScore = A.match * (int)l2;
-    const bool multiMapping = n > 1;
-    for (int i = 0; i < n; ++i) {
-      qm_hit& h = T[i];
-      const int csL = h.aln_score & 15, csR = (h.aln_score >> 4) & 15;
-      const unsigned char* tseq = A.text + A.txp_off[h.tid];
-      const int tlen = A.txp_len[h.tid];
-      int score = LOWEST;
-      if (h.mate_status == 3) {
-        int s1 = sel_aln_score(A, kmem, h.pos, r1, (int)l1, h.fwd != 0, tseq, tlen, maxLeftScore, csL, multiMapping, CL);
-        int s2 = sel_aln_score(A, kmem, h.mate_pos, r2, (int)l2, h.mate_is_fwd != 0, tseq, tlen, maxRightScore, csR, multiMapping, CR);
-        if (h.fwd != h.mate_is_fwd && P.no_dovetail) {
-          if (h.fwd && h.pos > h.mate_pos) { s1 = LOWEST; s2 = LOWEST; }
-          else if (h.mate_is_fwd && h.mate_pos > h.pos) { s1 = LOWEST; s2 = LOWEST; }
-        }
-        if (((double)s1 < A.min_score_fraction * (double)maxLeftScore) || ((double)s2 < A.min_score_fraction * (double)maxRightScore)) score = LOWEST;
-        else score = s1 + s2;
-      } else if (h.mate_status == 1) {
-        const int s = sel_aln_score(A, kmem, h.pos, r1, (int)l1, h.fwd != 0, tseq, tlen, maxLeftScore, csL, multiMapping, CL);
-        score = ((double)s < A.min_score_fraction * (double)maxLeftScore) ? LOWEST : s;
-      } else {
-        const int s = sel_aln_score(A, kmem, h.pos, r2, (int)l2, h.fwd != 0, tseq, tlen, maxRightScore, csR, multiMapping, CR);
-        score = ((double)s < A.min_score_fraction * (double)maxRightScore) ? LOWEST : s;
-      }
-      bestScore = score > bestScore ? score : bestScore;
-      h.aln_score = score;
-    }
-    int o = 0;
-    if (bestScore > LOWEST)
-      for (int i = 0; i < n; ++i) { const bool rem = A.hard_filter ? (T[i].aln_score < bestScore) : (T[i].aln_score == LOWEST); if (!rem) { if (o != i) T[o] = T[i]; ++o; } }
-    n = o;
-  }
-  if (uc) { uc->tot += (u64)n; if (n > 0) uc->mapped += 1; }
-  return n;
-}
-
-
-// ------------------------------------------------------------------ three-kernel form of stage B + C
-// sel_unit runs an alignment inside one thread.  Here the same work is cut in three so that every ksw2 alignment
-// gets a whole wavefront (sel_ksw_extz2_wave):  plan (per unit: merge, everything but the ksw2 scores; alignments
-// that have to be run become tasks, alignment-cache hits become references to the entry that owns the score),
-// align (one wavefront per task), finish (per unit: gate, filter, counters).
+// ------------------------------------------------------------------ plan / align / finish
+// The per-pair work of the reference (merge, getAlnScore for every hit, gate, filter) is cut in three so that the ksw2
+// alignments run four to a wavefront (sel_ksw_extz2_rows):  plan (per unit: merge, everything of getAlnScore but the ksw2
+// scores; alignments that have to be run become tasks, alignment-cache hits become references to the entry that owns the
+// score), align (a row of 16 lanes per task), finish (per unit: gate, filter, counters).
 
 // the part of getAlnScore around the alignment itself: returns true when the score is known now (in `score`);
 // otherwise a task was queued or `ref` points at the cache entry whose score will be this one's.
@@ -1312,34 +952,10 @@ QM_DEV void sel_unit_plan(const PairBatch& P, const SelBatch& A, long long u, Un
   }
 }
 
-// one ksw2 task, all lanes of a wave together; qt: 2 * QM_KSW_MAXLEN bytes private to the wave (LDS)
-QM_DEV void sel_task_align(const PairBatch& P, const SelBatch& A, const SelTask& t, unsigned char* qt) {
-  const unsigned char* read = t.side == 0 ? A.seq1 + P.off1[t.u] : A.seq2 + P.off2[t.u];
-  const int readLen = (int)(t.side == 0 ? P.off1[t.u + 1] - P.off1[t.u] : P.off2[t.u + 1] - P.off2[t.u]);
-  const unsigned char* tseq1 = A.text + A.txp_off[t.tid] + t.pos;
-  unsigned char* qb = qt; unsigned char* tb = qt + QM_KSW_MAXLEN;
-  const int nmax = t.rlen > t.tlen1 ? t.rlen : t.tlen1;
-  for (int b0 = 0; b0 < nmax; b0 += 64) {
-    QM_LANES(l) {
-      const int i = b0 + l;
-      if (i < t.rlen) qb[i] = sel_nt4(sel_read_char(read, readLen, t.fwd != 0, t.roff + i));
-      if (i < t.tlen1) tb[i] = sel_nt4(tseq1[i]);
-    }
-  }
-  wave_fence();
-  signed char mat[25];
-  int a = (signed char)A.match, b = (signed char)A.mismatch;
-  a = a < 0 ? -a : a; b = b > 0 ? -b : b;
-  for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) mat[i * 5 + j] = (signed char)(i == j ? a : b); mat[i * 5 + 4] = 0; }
-  for (int j = 0; j < 5; ++j) mat[20 + j] = 0;
-  const int s = sel_ksw_extz2_wave(t.rlen, qb, t.tlen1, tb, mat, (signed char)A.gap_open, (signed char)A.gap_extend, A.bandwidth, qt + 2 * QM_KSW_MAXLEN);
-  QM_LANES(l) { if (l == 0) A.tsc[t.gslot] = s; }
-  wave_fence();
-}
-
 // Tasks t0 .. t0+3 (those below nt), one per row of 16 lanes: stage the two score-phase images straight from the read and
 // the transcript text, run the row kernel, lane 0 of every row stores its score.
-QM_DEV void sel_tasks_align_rows(const PairBatch& P, const SelBatch& A, unsigned long long t0, unsigned long long nt, KswRow* blk) {
+template <int RING>
+QM_DEV void sel_tasks_align_rows(const PairBatch& P, const SelBatch& A, unsigned long long t0, unsigned long long nt, KswRowT<RING>* blk) {
   LV<int> ql, tl, gs;
   LV<const unsigned char*> rd, tx; LV<int> rl, ro, fw;
   QM_LANES(l) {
@@ -1356,7 +972,7 @@ QM_DEV void sel_tasks_align_rows(const PairBatch& P, const SelBatch& A, unsigned
   for (int i0 = 0; i0 < QM_KSW_MAXLEN + 40; i0 += 16) {
     QM_LANES(l) {
       if (gs[l] >= 0) {
-        KswRow& B = blk[l >> 4];
+        KswRowT<RING>& B = blk[l >> 4];
         const int i = i0 + (l & 15);
         const int qlen = ql[l], tlen = tl[l], tlen16 = (tlen + 15) / 16 * 16;
         if (i < QM_KSW_MAXLEN + 40) {
@@ -1377,7 +993,7 @@ QM_DEV void sel_tasks_align_rows(const PairBatch& P, const SelBatch& A, unsigned
   for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) mat[i * 5 + j] = (signed char)(i == j ? a : b); mat[i * 5 + 4] = 0; }
   for (int j = 0; j < 5; ++j) mat[20 + j] = 0;
   LV<int> sc;
-  sel_ksw_extz2_rows(ql, tl, blk, mat, (signed char)A.gap_open, (signed char)A.gap_extend, A.bandwidth, sc);
+  sel_ksw_extz2_rows<RING>(ql, tl, blk, mat, (signed char)A.gap_open, (signed char)A.gap_extend, A.bandwidth, sc);
   QM_LANES(l) { if (gs[l] >= 0 && (l & 15) == 0) A.tsc[gs[l]] = sc[l]; }
   wave_fence();
 }

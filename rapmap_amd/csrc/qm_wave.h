@@ -51,6 +51,7 @@ QM_DEV u64 brev64(u64 x) {
 }
 QM_DEV void wave_fence() {}
 QM_DEV void atomic_min_u64(u64* p, u64 v) { if (v < *p) *p = v; }
+QM_DEV void atomic_max_u64(u64* p, u64 v) { if (v > *p) *p = v; }
 QM_DEV void atomic_or_u64(u64* p, u64 v) { *p |= v; }
 QM_DEV u64 atomic_add_u64(u64* p, u64 v) { u64 o = *p; *p = o + v; return o; }
 template <typename T> QM_DEV T uniform(T x) { return x; }
@@ -71,6 +72,7 @@ QM_DEV u64 brev64(u64 x) { return __brevll(x); }
 // orders this wave's LDS / global accesses across lanes (same-wave RAW through memory)
 QM_DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 QM_DEV void atomic_min_u64(u64* p, u64 v) { atomicMin(p, v); }
+QM_DEV void atomic_max_u64(u64* p, u64 v) { atomicMax(p, v); }
 QM_DEV void atomic_or_u64(u64* p, u64 v) { atomicOr(p, v); }
 QM_DEV u64 atomic_add_u64(u64* p, u64 v) { return atomicAdd(p, v); }
 // tell the compiler a value is wave-uniform (keeps control flow on the scalar unit)

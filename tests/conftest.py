@@ -96,12 +96,25 @@ def synth_medium(tmp_path_factory, lib_built):
     idx = str(d / "idx")
     ra.build_index(fa, idx, threads=8)
     s1, s2, off, truth = synth.make_reads(txps, 60000, seed=43)
-    return {"idx": idx, "seq1": s1, "seq2": s2, "off": off, "txps": txps}
+    return {"idx": idx, "seq1": s1, "seq2": s2, "off": off, "txps": txps, "fasta": fa}
+
+
+@pytest.fixture(scope="session")
+def synth_medium_ph(synth_medium, tmp_path_factory):
+    """the medium transcriptome indexed with `quasiindex -p`"""
+    import rapmap_amd as ra
+    d = tmp_path_factory.mktemp("synth_medium_ph")
+    idx = str(d / "idx_ph")
+    ra.build_index(synth_medium["fasta"], idx, threads=8, perfect_hash=True)
+    out = dict(synth_medium)
+    out["idx"] = idx
+    return out
 
 
 @pytest.fixture(scope="session")
 def repeat_data(tmp_path_factory, lib_built):
-    """repeat families of 40 / 300 / 1100 copies of a 200-mer core with unique flanks, reads drawn inside the cores"""
+    """repeat families of 40 / 300 / 900 / 1100 copies of a 200-mer core with unique flanks, reads drawn inside the cores
+    (900 copies: below maxInterval, so with -s a strand's five or more capped MMPs bring > 4096 suffixes: the slow pass)"""
     import rapmap_amd as ra
     from rapmap_amd import synth
     rng = np.random.default_rng(99)
@@ -109,7 +122,7 @@ def repeat_data(tmp_path_factory, lib_built):
     comp = np.zeros(256, np.uint8); comp[list(b"ACGT")] = list(b"TGCA")
     names, txps = synth.make_transcriptome(40, seed=5)
     cores = []
-    for fam, copies in (("F40", 40), ("F300", 300), ("F1100", 1100)):
+    for fam, copies in (("F40", 40), ("F300", 300), ("F1100", 1100), ("F900", 900)):
         core = B[rng.integers(0, 4, 200)]
         cores.append(core)
         for i in range(copies):

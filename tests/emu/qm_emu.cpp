@@ -37,8 +37,8 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
   std::vector<u64> lists;
   std::vector<u64> gs(QM_GSCR_U64);
   std::vector<qm_sa_interval_hit> dints((size_t)nunits * QM_DBG_CAP + 1); std::vector<u32> dcnt(nreads + 1, 0);
-  int status = 0; u64 cursor = 0;
-  B.lcnt = lcnt.data(); B.loff = loff.data(); B.cursor = &cursor;
+  int status = 0; u64 scal[QM_SC_WORDS]; u64& cursor = scal[0];
+  B.lcnt = lcnt.data(); B.loff = loff.data(); B.cursor = scal;
   B.gscratch = gs.data(); B.status = &status; B.dbg_ints = dints.data(); B.dbg_count = dcnt.data();
   B.strict_check = o->strict_check; B.max_interval = o->max_interval; B.quasi_cov = o->quasi_cov; B.sensitive = o->sensitive; B.fuzzy = (seq2 != nullptr) ? o->fuzzy : 0; B.max_mmp_ext = o->max_mmp_extension > 0 ? o->max_mmp_extension : 7;
   static SelScratchLds sellds;                            // used for half of the reads so that both scratch sizes are exercised
@@ -50,7 +50,7 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
   }
   while (true) {
     lists.assign((size_t)cap, 0);
-    B.lists = lists.data(); B.lists_cap = cap; cursor = 0; status = 0;
+    B.lists = lists.data(); B.lists_cap = cap; memset(scal, 0, sizeof(scal)); status = 0;
     // emulate 7 interleaved "waves", each with its own chunk allocator
     WaveAlloc wa[7];
     for (auto& w : wa) { w.base = -1; w.used = 0; }
@@ -65,6 +65,24 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
       else { switch (F) { case 0: QE_CALL(4, 0) break; case 1: QE_CALL(4, 1) break; case 2: QE_CALL(4, 2) break; case 3: QE_CALL(4, 3) break;
                           case 4: QE_CALL(4, 4) break; case 5: QE_CALL(4, 5) break; case 6: QE_CALL(4, 6) break; default: QE_CALL(4, 7) break; } }
 #undef QE_CALL
+    }
+    if (o->sel_aln && scal[QM_SC_SLOWCNT] > 0 && !(status & 1)) {
+      // the slow pass of -s (see qm_host.hip): the queued reads again, on scratch sized for the largest of them
+      const long long need = (((long long)scal[QM_SC_SLOWMAX] + 63) / 64) * 64 + 64;
+      std::vector<unsigned char> dmem((size_t)SelScratchDyn::bytes_for(need));
+      SelScratchDyn dyn; dyn.bind(dmem.data(), need);
+      std::vector<long long> q;
+      for (long long r = 0; r < nreads; ++r) if (lcnt[r] == QM_LCNT_SLOW) q.push_back(r);
+      ReadBatch S2 = B; S2.slowq = q.data(); S2.dyn = &dyn; S2.nreads = (long long)q.size();
+      const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP) | QM_F_SEL;
+      for (long long r = 0; r < (long long)q.size(); ++r) {
+#define QE_SLOW(NS_, F_) { static WaveMem<NS_> M; ReadPre<NS_> pre; pre_offsets<NS_>(S2, r, pre); pre_chars<NS_>(S2, r, pre); \
+                           map_read<NS_, F_>(ix, S2, read_id(S2, r), pre, M, gs.data(), wa[r % 7], selscr, &sellds, &dyn); }
+        if (ns == 2) { switch (F) { case 4: QE_SLOW(2, 4) break; case 5: QE_SLOW(2, 5) break; case 6: QE_SLOW(2, 6) break; default: QE_SLOW(2, 7) break; } }
+        else if (ns == 3) { switch (F) { case 4: QE_SLOW(3, 4) break; case 5: QE_SLOW(3, 5) break; case 6: QE_SLOW(3, 6) break; default: QE_SLOW(3, 7) break; } }
+        else { switch (F) { case 4: QE_SLOW(4, 4) break; case 5: QE_SLOW(4, 5) break; case 6: QE_SLOW(4, 6) break; default: QE_SLOW(4, 7) break; } }
+#undef QE_SLOW
+      }
     }
     if (!(status & 1)) break;
     cap *= 4;
@@ -85,28 +103,22 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
       toff[u + 1] = toff[u] + w / 3 + 1;
     }
     std::vector<qm_hit> tmp((size_t)toff[nunits] + 1); std::vector<u64> tkeys(2 * (size_t)toff[nunits] + 2); std::vector<int> tsc(2 * (size_t)toff[nunits] + 2);
-    std::vector<unsigned char> ksw(QM_KSW_BYTES); std::vector<int> ringbuf(QM_KSW_RING_BYTES / 4 + 4);
     SelBatch A; memset(&A, 0, sizeof(A));
     A.seq1 = seq1; A.seq2 = seq2; A.text = text; A.txp_off = txp_off; A.txp_len = txp_len; A.tmp = tmp.data(); A.toff = toff.data();
-    A.tkeys = tkeys.data(); A.tsc = tsc.data(); A.ksw = ksw.data(); A.ring = (unsigned char*)ringbuf.data(); A.emu_wave = getenv("QE_KSW_WAVE") ? 1 : 0;
+    A.tkeys = tkeys.data(); A.tsc = tsc.data();
     A.match = o->match_score; A.mismatch = o->mismatch_penalty; A.gap_open = o->gap_open; A.gap_extend = o->gap_extend;
     A.bandwidth = o->dp_bandwidth; A.hard_filter = o->hard_filter; A.policy = o->aln_policy; A.min_score_fraction = o->min_score_fraction;
-    const bool three = o->dp_bandwidth >= 0 && o->dp_bandwidth <= 33 && !getenv("QE_SEL_UNIT");   // same rule as the host
-    if (three) {
+    {
       std::vector<int> tref(2 * (size_t)toff[nunits] + 2), tcix(2 * (size_t)toff[nunits] + 2);
       std::vector<SelTask> tasks(2 * (size_t)toff[nunits] + 2); u64 ntasks = 0;
       A.tref = tref.data(); A.tcix = tcix.data(); A.tasks = tasks.data(); A.ntasks = &ntasks;
       for (long long u = 0; u < nunits; ++u) sel_unit_plan(P, A, u, &uc);
-      if (getenv("QE_ALIGN_WAVE")) {
-        std::vector<unsigned char> qt(2 * QM_KSW_MAXLEN + QM_KSW_IMG_BYTES);
-        for (u64 t = 0; t < ntasks; ++t) sel_task_align(P, A, tasks[t], qt.data());
-      } else {
-        std::vector<KswRow> rows(4);
-        for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows(P, A, t, ntasks, rows.data());
+      switch (sel_ksw_ring_slots(A.bandwidth)) {         // same rule as the launch wrapper
+        case 64: { std::vector<KswRowT<64>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<64>(P, A, t, ntasks, rows.data()); } break;
+        case 128: { std::vector<KswRowT<128>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<128>(P, A, t, ntasks, rows.data()); } break;
+        default: { std::vector<KswRowT<512>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<512>(P, A, t, ntasks, rows.data()); } break;
       }
       for (long long u = 0; u < nunits; ++u) hc[u] = (u32)sel_unit_finish(P, A, u, &uc);
-    } else {
-      for (long long u = 0; u < nunits; ++u) hc[u] = (u32)sel_unit(P, A, u, 0, &uc);
     }
     hit_offsets[0] = 0;
     for (long long u = 0; u < nunits; ++u) hit_offsets[u + 1] = hit_offsets[u] + hc[u];
@@ -139,7 +151,7 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
       for (long long j = 0; j < kept(u * mates + m); ++j) io[w++] = dints[u * QM_DBG_CAP + m * half + j];
   }
   *ints_out = io;
-  *status_out = status;
+  *status_out = status | (int)(scal[QM_SC_SLOWCNT] << 8);   // bits 8..: reads that took the slow pass of -s
   return 0;
 }
 
@@ -191,29 +203,16 @@ void* qe_ph_create(const unsigned long long* words, const unsigned long long* ra
 
 // host-side flattening for the emulation only (the product does this on the GPU,
 // rapmap_amd/csrc/qm_kernels.hip: build_sainfo_kernel / build_slots_kernel)
-// the three ksw2 kernels of qm_sel.inl on their own: variant 0 literal, 1 ring (bands <= 33), 2 one wavefront per alignment
-int qe_ksw(int variant, int qlen, const unsigned char* query, int tlen, const unsigned char* target, int a, int b, int q, int e, int w) {
-  signed char mat[25];
-  a = a < 0 ? -a : a; b = b > 0 ? -b : b;
-  for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) mat[i * 5 + j] = (signed char)(i == j ? a : b); mat[i * 5 + 4] = 0; }
-  for (int j = 0; j < 5; ++j) mat[20 + j] = 0;
-  std::vector<unsigned char> mem(QM_KSW_BYTES + 64), ring(QM_KSW_RING_BYTES + 64), img(QM_KSW_IMG_BYTES + 64);
-  if (variant == 0) return sel_ksw_extz2(mem.data(), qlen, query, tlen, target, mat, q, e, w);
-  if (variant == 1) return sel_ksw_extz2_ring(ring.data(), qlen, query, tlen, target, mat, q, e, w);
-  return sel_ksw_extz2_wave(qlen, query, tlen, target, mat, q, e, w, img.data());
-}
 // four alignments at once through the 16-lane-row kernel: qlen[4], tlen[4], pointers to the code strings, out[4]
-void qe_ksw_rows(const int* qlen, const unsigned char* const* query, const int* tlen, const unsigned char* const* target,
-                 int a, int b, int q, int e, int w, int* out) {
-  signed char mat[25];
-  a = a < 0 ? -a : a; b = b > 0 ? -b : b;
-  for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) mat[i * 5 + j] = (signed char)(i == j ? a : b); mat[i * 5 + 4] = 0; }
-  for (int j = 0; j < 5; ++j) mat[20 + j] = 0;
-  std::vector<KswRow> blk(4);
+}  // extern "C"
+template <int RING>
+static void ksw_rows_run(const int* qlen, const unsigned char* const* query, const int* tlen, const unsigned char* const* target,
+                         const signed char* mat, int q, int e, int w, int* out) {
+  std::vector<KswRowT<RING>> blk(4);
   LV<int> ql, tl, sc;
   for (int g = 0; g < 4; ++g) {
     const int tlen16 = (tlen[g] + 15) / 16 * 16;
-    memset(&blk[g], 0xAB, sizeof(KswRow));               // the kernel must not depend on what the block held before
+    memset(&blk[g], 0xAB, sizeof(KswRowT<RING>));        // the kernel must not depend on what the block held before
     for (int i = 0; i < QM_KSW_MAXLEN + 40; ++i) {
       blk[g].QX[i] = (i >= 16 && i < 16 + qlen[g]) ? query[g][i - 16] : 0;
       const int j = i - tlen16;
@@ -221,8 +220,21 @@ void qe_ksw_rows(const int* qlen, const unsigned char* const* query, const int* 
     }
     for (int c = 0; c < 16; ++c) { ql[g * 16 + c] = qlen[g]; tl[g * 16 + c] = tlen[g]; }
   }
-  sel_ksw_extz2_rows(ql, tl, blk.data(), mat, q, e, w, sc);
+  sel_ksw_extz2_rows<RING>(ql, tl, blk.data(), mat, q, e, w, sc);
   for (int g = 0; g < 4; ++g) out[g] = sc[g * 16];
+}
+extern "C" {
+// ring < 0: the ring the launch wrapper would pick for this band; otherwise force 64 / 128 / 512 slots
+void qe_ksw_rows(const int* qlen, const unsigned char* const* query, const int* tlen, const unsigned char* const* target,
+                 int a, int b, int q, int e, int w, int* out, int ring) {
+  signed char mat[25];
+  a = a < 0 ? -a : a; b = b > 0 ? -b : b;
+  for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) mat[i * 5 + j] = (signed char)(i == j ? a : b); mat[i * 5 + 4] = 0; }
+  for (int j = 0; j < 5; ++j) mat[20 + j] = 0;
+  if (ring < 0) ring = sel_ksw_ring_slots(w);
+  if (ring == 64) ksw_rows_run<64>(qlen, query, tlen, target, mat, q, e, w, out);
+  else if (ring == 128) ksw_rows_run<128>(qlen, query, tlen, target, mat, q, e, w, out);
+  else ksw_rows_run<512>(qlen, query, tlen, target, mat, q, e, w, out);
 }
 unsigned long long qe_slots_cap(long long nkeys) { return bucket_count(nkeys); }   // buckets of 64 bytes
 void qe_flatten(const int* SA, long long nSA, const int* offsets, long long T, void* sainfo_out,

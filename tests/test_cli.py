@@ -30,6 +30,8 @@ def test_quasimap_cli_validation(sample_data):
     assert r.returncode != 0 and "paired-end" in r.stderr
     r = _run(["quasimap", "-i", sample_data["idx"], "-1", "a", "-2", "b", "-r", "c"])
     assert r.returncode != 0 and "not both" in r.stderr
+    r = _run(["quasimap", "-i", sample_data["idx"], "-r", "x.fq", "--recoverOrphans"])
+    assert r.returncode != 0 and "recoverOrphans" in r.stderr
     r = _run(["frobnicate"])
     assert r.returncode != 0 and "not yet implemented" in r.stderr
 

@@ -1,0 +1,86 @@
+"""The N>1 path on real GPUs: mirror of tests/test_distributed_cpu.py with the HIP mapper as the per-rank engine and
+RCCL ("nccl") as the backend.  Two ranks shard the read pairs (contiguous static split, no data-path collective),
+each maps its shard on its own GPU through the C ABI, one all-reduce sums the HitCounters.
+Needs >= 2 GPUs in the box: skipped on the 1-GPU box, runs on the driver's multi-GPU node."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+def _launch(nproc, script_args, env=None):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + script_args
+    e = dict(os.environ); e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if env:
+        e.update(env)
+    return subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=1500)
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs (RCCL over xGMI)")
+def test_two_ranks_over_rccl_match_the_oracle(synth_small, oracle_mod, tmp_path):
+    from oracle import oracle, q5
+    from rapmap_amd import dist as qd
+    from util import pack
+    reads1 = synth_small["reads1"]; reads2 = synth_small["reads2"]
+    a1, o1 = pack(reads1); a2, o2 = pack(reads2)
+    np.save(tmp_path / "a1.npy", a1); np.save(tmp_path / "o1.npy", o1); np.save(tmp_path / "a2.npy", a2); np.save(tmp_path / "o2.npy", o2)
+    ref = oracle.Oracle(q5.load(synth_small["idx"])).map_pairs(a1, o1, a2, o2, nthreads=4)
+    r = _launch(2, [os.path.join(ROOT, "tests", "dist_gpu_worker.py"), synth_small["idx"], str(tmp_path)])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    hits = np.concatenate([np.load(tmp_path / "hits_0.npy"), np.load(tmp_path / "hits_1.npy")])
+    cnt = np.concatenate([np.load(tmp_path / "cnt_0.npy"), np.load(tmp_path / "cnt_1.npy")])
+    assert np.array_equal(cnt, np.diff(ref.hit_offsets)) and hits.tobytes() == ref.hits.tobytes()
+    tot = np.load(tmp_path / "total.npy")
+    assert [int(x) for x in tot] == [ref.counters[k] for k in qd.COUNTER_KEYS]
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs")
+def test_bench_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it must run two ranks and say so"""
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e["QMAP_BENCH_CACHE"] = str(tmp_path)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--genes", "800", "--pairs", "200000"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
+    assert out["config"]["pairs_per_gpu_per_step"] == 200000
+
+
+def test_bench_single_gpu_line_has_the_contract_fields(tmp_path):
+    """the N=1 line on a small workload: metric fields, roofline, cpu_baseline, parity against the oracle"""
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e["QMAP_BENCH_CACHE"] = str(tmp_path)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--genes", "800",
+                        "--pairs", "100000", "--cpu-seconds", "2"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["parity"]["bit_identical_to_oracle"] is True
+    assert out["roofline"]["bound"] == "hbm" and 0 < out["roofline"]["frac"] < 1
+    assert out["cpu_baseline"]["kind"] in ("port", "reference") and out["cpu_baseline"]["value"] > 0

@@ -278,3 +278,35 @@ def test_selective_alignment(synth_small, oracle_mod, case):
     es = em.map(q2, o2, opts=emu.default_opts(**eo))
     assert_hits_equal(rs.hit_offsets, rs.hits, es.hit_offsets, es.hits, "selAln single-end %s" % oo)
     assert rs.counters == es.counters
+
+
+def test_selective_alignment_repeats_take_the_slow_pass(repeat_data, oracle_mod):
+    """-s on reads inside repeat cores: the 900-copy family brings more suffixes per strand than a wave's scratch holds
+    (QM_SEL_CAP), so those reads are queued and redone on scratch sized for them -- same hits as the oracle, which (like the
+    reference) treats them as any other read"""
+    ix, orc, em, emu = _emu(repeat_data["idx"])
+    q1, o1 = pack(repeat_data["reads1"]); q2, o2 = pack(repeat_data["reads2"])
+    for oo, eo in ((dict(selAln=1), dict(sel_aln=1)), (dict(selAln=1, maxNumHits=5000, hardFilter=1), dict(sel_aln=1, max_num_hits=5000, hard_filter=1)),
+                   (dict(selAln=1, maxNumHits=5000, consensusSlack=0.5), dict(sel_aln=1, max_num_hits=5000, consensus_slack=0.5))):
+        res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=4)
+        er = em.map(q1, o1, q2, o2, opts=emu.default_opts(**eo))
+        assert (er.status & 0xff) == 0 and (er.status >> 8) > 0, er.status
+        assert_hits_equal(res.hit_offsets, res.hits, er.hit_offsets, er.hits, "repeats -s %s" % oo)
+        assert res.counters == er.counters
+    rs = orc.map_single(q1, o1, opts=oracle_mod.default_opts(selAln=1, maxNumHits=5000), nthreads=4)
+    es = em.map(q1, o1, opts=emu.default_opts(sel_aln=1, max_num_hits=5000))
+    assert (es.status >> 8) > 0
+    assert_hits_equal(rs.hit_offsets, rs.hits, es.hit_offsets, es.hits, "repeats -s single-end")
+
+
+@pytest.mark.parametrize("band", [34, 64, 120, -1])
+def test_selective_alignment_wide_bands(synth_small, oracle_mod, band):
+    """--dpBandwidth beyond 33: the same ksw2 kernel on a larger column ring (128 / 512 slots)"""
+    ix, orc, em, emu = _emu(synth_small["idx"])
+    s1, s2 = sel_reads(synth_small, "indel")
+    q1, o1 = pack(s1); q2, o2 = pack(s2)
+    res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(selAln=1, dpBandwidth=band), nthreads=4)
+    er = em.map(q1, o1, q2, o2, opts=emu.default_opts(sel_aln=1, dp_bandwidth=band))
+    assert er.status == 0
+    assert_hits_equal(res.hit_offsets, res.hits, er.hit_offsets, er.hits, "selAln band %d" % band)
+    assert res.counters == er.counters

@@ -365,3 +365,111 @@ def test_selective_alignment_medium(synth_medium, oracle_mod):
     gr = mp.map_pairs(q1, o, q2, o, opts=ra.default_opts(sel_aln=1))
     assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "selAln medium")
     assert res.counters == gr.counters
+
+
+def _medium_txps(idx, min_len=700, cap=1500):
+    import rapmap_amd as ra
+    qi = ra.QuasiIndex(idx)
+    text, offsets = qi.arrays()
+    text = np.asarray(text); offsets = np.asarray(offsets, dtype=np.int64)
+    ends = np.append(offsets[1:], text.size)
+    return [text[a:b - 1] for a, b in zip(offsets, ends) if b - 1 - a >= min_len][:cap]
+
+
+@pytest.mark.parametrize("variant", ["default", "noSensitive", "fuzzy", "selAln", "perfectHash", "perfectHash_noSensitive", "perfectHash_selAln"])
+def test_reads_150bp_take_the_three_slot_kernels(synth_medium, synth_medium_ph, oracle_mod, variant):
+    """2 x 150 bp (every read 129..192 bp long): the NS=3 instantiations of stage A -- dense / -p, default / --noSensitive /
+    fuzzy / -s -- none of which the 100 bp and 250 bp cases reach"""
+    import rapmap_amd as ra
+    from rapmap_amd import synth
+    ph = variant.startswith("perfectHash")
+    ix, orc = load_oracle(synth_medium["idx"])                # the oracle maps on the dense index: same hits by construction
+    qi, mp = _gpu((synth_medium_ph if ph else synth_medium)["idx"], debug=False)
+    assert qi.perfect_hash == ph
+    s1, s2, off, _ = synth.make_reads(_medium_txps(synth_medium["idx"]), 6000, seed=150, read_len=150, err=0.01)
+    # ragged lengths inside the slot range, so that nothing rides on "exactly 150"
+    rng = np.random.default_rng(3)
+    lens = rng.integers(129, 151, size=len(off) - 1)
+    r1 = [s1[off[i]:off[i] + lens[i]].tobytes() for i in range(len(off) - 1)]
+    r2 = [s2[off[i]:off[i] + lens[-1 - i]].tobytes() for i in range(len(off) - 1)]
+    q1, o1 = pack(r1); q2, o2 = pack(r2)
+    assert 128 < int(np.diff(o1).max()) <= 192 and 128 < int(np.diff(o2).max()) <= 192
+    oo, go = {"default": ({}, {}), "noSensitive": ({"sensitive": 0}, {"sensitive": 0}), "fuzzy": ({"fuzzy": 1}, {"fuzzy": 1}),
+              "selAln": ({"selAln": 1}, {"sel_aln": 1}), "perfectHash": ({}, {}),
+              "perfectHash_noSensitive": ({"sensitive": 0}, {"sensitive": 0}), "perfectHash_selAln": ({"selAln": 1}, {"sel_aln": 1})}[variant]
+    res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=8)
+    gr = mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(**go))
+    assert res.counters["totHits"] > 3000
+    assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "150 bp %s" % variant)
+    assert res.counters == gr.counters
+    rs = orc.map_single(q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=8)
+    gs = mp.map_reads(q2, o2, opts=ra.default_opts(**go))
+    assert_hits_equal(rs.hit_offsets, rs.hits, gs.hit_offsets, gs.hits, "150 bp single-end %s" % variant)
+
+
+@pytest.mark.parametrize("band", [34, 40, 64, 120, 1000, -1])
+def test_selective_alignment_wide_bands(synth_small, synth_medium, oracle_mod, band):
+    """--dpBandwidth beyond 33 runs the same four-per-wavefront ksw2 kernel on a larger column ring"""
+    import rapmap_amd as ra
+    from test_emu_parity import sel_reads
+    ix, orc = load_oracle(synth_small["idx"])
+    qi, mp = _gpu(synth_small["idx"], debug=False)
+    s1, s2 = sel_reads(synth_small, "indel")
+    q1, o1 = pack(s1); q2, o2 = pack(s2)
+    res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(selAln=1, dpBandwidth=band), nthreads=4)
+    gr = mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(sel_aln=1, dp_bandwidth=band))
+    assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "selAln band %d" % band)
+    assert res.counters == gr.counters
+    # and on 250 bp reads (the longest alignments: 256 x 276 cells inside the band)
+    ix2, orc2 = load_oracle(synth_medium["idx"])
+    qi2, mp2 = _gpu(synth_medium["idx"], debug=False)
+    from rapmap_amd import synth
+    a1, a2, ao, _ = synth.make_reads(_medium_txps(synth_medium["idx"]), 1500, seed=250 + band, read_len=250, err=0.02)
+    r2 = orc2.map_pairs(a1, ao, a2, ao, opts=oracle_mod.default_opts(selAln=1, dpBandwidth=band), nthreads=8)
+    g2 = mp2.map_pairs(a1, ao, a2, ao, opts=ra.default_opts(sel_aln=1, dp_bandwidth=band))
+    assert_hits_equal(r2.hit_offsets, r2.hits, g2.hit_offsets, g2.hits, "selAln 250 bp band %d" % band)
+
+
+def test_selective_alignment_repeats_take_the_slow_pass(repeat_data, oracle_mod):
+    """-s, reads inside a 900-copy repeat: more suffixes per strand than a wave's scratch (QM_SEL_CAP) -- queued and redone
+    on scratch sized for them; the batch must not fail and the hits must be the oracle's"""
+    import rapmap_amd as ra
+    ix, orc = load_oracle(repeat_data["idx"])
+    qi, mp = _gpu(repeat_data["idx"], debug=False)
+    q1, o1 = pack(repeat_data["reads1"]); q2, o2 = pack(repeat_data["reads2"])
+    for oo, go in ((dict(selAln=1), dict(sel_aln=1)), (dict(selAln=1, maxNumHits=5000, hardFilter=1), dict(sel_aln=1, max_num_hits=5000, hard_filter=1)),
+                   (dict(selAln=1, maxNumHits=5000, consensusSlack=0.5), dict(sel_aln=1, max_num_hits=5000, consensus_slack=0.5))):
+        res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=4)
+        gr = mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(**go))
+        assert mp.stat(2) > 0, "no read took the slow pass"
+        assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "repeats -s %s" % oo)
+        assert res.counters == gr.counters
+    rs = orc.map_single(q1, o1, opts=oracle_mod.default_opts(selAln=1, maxNumHits=5000), nthreads=4)
+    gs = mp.map_reads(q1, o1, opts=ra.default_opts(sel_aln=1, max_num_hits=5000))
+    assert_hits_equal(rs.hit_offsets, rs.hits, gs.hit_offsets, gs.hits, "repeats -s single-end")
+
+
+def test_list_buffer_overflow_relaunches_stage_a(repeat_data, oracle_mod):
+    """a batch whose per-read hit lists outgrow the buffer sized for an ordinary batch (every read sits in a 300- or 900-copy
+    repeat): stage A flags the overflow, the host grows the buffer and redoes the batch -- same results, and the relaunch
+    is visible in qm_ctx_stat"""
+    ix, orc = load_oracle(repeat_data["idx"])
+    core = [i for i in range(48) if 12 <= i < 24 or 36 <= i < 48]         # F300 and F900 reads of the fixture
+    u1 = [repeat_data["reads1"][i] for i in core]; u2 = [repeat_data["reads2"][i] for i in core]
+    a1, ao1 = pack(u1); a2, ao2 = pack(u2)
+    ref = orc.map_pairs(a1, ao1, a2, ao2, nthreads=4)
+    reps = 6000                                                            # 144 000 pairs, ~170 M list words
+    q1, o1 = pack(u1 * reps); q2, o2 = pack(u2 * reps)
+    qi, mp = _gpu(repeat_data["idx"], debug=False)                        # a fresh context: the list buffer starts at its default size
+    gr = mp.map_pairs(q1, o1, q2, o2)
+    assert mp.stat(0) >= 1, "the batch fitted: no relaunch was exercised (list words %d)" % mp.stat(1)
+    nu = len(core)
+    cnt = np.diff(gr.hit_offsets).reshape(reps, nu)
+    assert (cnt == np.diff(ref.hit_offsets)[None, :]).all()
+    for rep in (0, reps // 2, reps - 1):
+        b, e = gr.hit_offsets[rep * nu], gr.hit_offsets[(rep + 1) * nu]
+        assert gr.hits[b:e].tobytes() == ref.hits.tobytes()
+    assert gr.counters["numReads"] == reps * nu and gr.counters["tooManyHits"] == reps * ref.counters["tooManyHits"]
+    # the grown buffer serves the next call without another relaunch
+    gr2 = mp.map_pairs(q1, o1, q2, o2)
+    assert mp.stat(0) == 0 and gr2.hits.tobytes() == gr.hits.tobytes()

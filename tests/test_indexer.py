@@ -119,3 +119,19 @@ def test_perfect_hash_files(synth_small, synth_small_ph):
         assert int(data[i]) == lb and lb + ln == ub
     for fn in ("sa.bin", "txpInfo.bin", "rsd.bin"):      # the rest of the index does not depend on -p
         assert open(os.path.join(d, fn), "rb").read() == open(os.path.join(synth_small["idx"], fn), "rb").read()
+
+
+def test_gzipped_fasta_gives_the_same_index(tmp_path, lib_built):
+    """the reference's indexer reads its FASTA through zlib (kseq over gzFile): a .fa.gz must index like the plain file"""
+    import gzip
+    import shutil
+    import rapmap_amd as ra
+    from conftest import GOLD
+    src = os.path.join(GOLD, "sample_data", "transcripts.fasta")
+    gz = str(tmp_path / "t.fa.gz")
+    with open(src, "rb") as i, gzip.open(gz, "wb") as o:
+        shutil.copyfileobj(i, o)
+    ra.build_index(src, str(tmp_path / "a"), threads=2)
+    ra.build_index(gz, str(tmp_path / "b"), threads=2)
+    for fn in ("sa.bin", "txpInfo.bin", "rsd.bin", "hash.bin"):
+        assert open(tmp_path / "a" / fn, "rb").read() == open(tmp_path / "b" / fn, "rb").read(), fn

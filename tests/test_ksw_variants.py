@@ -1,6 +1,7 @@
-"""The three ksw2 extension kernels of the device source (rapmap_amd/csrc/qm_sel.inl: literal, 64-column ring, one
-wavefront per alignment -- run here through the lane emulation) against the oracle's restatement of ksw_extz2_sse41
-(oracle/qm_oracle.cpp: kswExtz2, pinned on the reference's `-s` SAM fixtures), on random and adversarial inputs:
+"""The ksw2 extension kernel of the device source (rapmap_amd/csrc/qm_sel.inl: sel_ksw_extz2_rows, four alignments per
+wavefront, one kernel for every --dpBandwidth -- run here through the lane emulation) against the oracle's restatement of
+ksw_extz2_sse41 (oracle/qm_oracle.cpp: kswExtz2, itself checked against the reference's own ksw2 sources compiled into
+oracle/_ref and against the reference's `-s` SAM fixtures), on random and adversarial inputs:
 every target length 1..160 (all residues mod 16: the SSE vectors' padding lanes and the band's last rounds differ),
 indels, N's, short and long queries, several bands and scoring schemes."""
 import ctypes as C
@@ -47,42 +48,22 @@ def _cases(seed, n):
         yield q, t
 
 
-SCHEMES = [(2, -4, 4, 2, 15), (2, -4, 4, 2, 5), (1, -1, 1, 1, 15), (2, -6, 5, 3, 33), (2, -4, 4, 2, 0), (4, -4, 6, 2, 20)]
+# (match, mismatch, gap open, gap extend, band): bands <= 33 run on the 64-slot ring, <= 97 on 128 slots, everything else
+# (and the "whole matrix" band -1) on 512
+SCHEMES = [(2, -4, 4, 2, 15), (2, -4, 4, 2, 5), (1, -1, 1, 1, 15), (2, -6, 5, 3, 33), (2, -4, 4, 2, 0), (4, -4, 6, 2, 20),
+           (2, -4, 4, 2, 34), (2, -4, 4, 2, 40), (2, -6, 5, 3, 64), (1, -1, 1, 1, 97), (2, -4, 4, 2, 98), (2, -4, 4, 2, 150),
+           (2, -4, 4, 2, 1000), (2, -4, 4, 2, -1)]
 
 
-@pytest.mark.parametrize("scheme", SCHEMES)
-def test_ksw_variants_match_oracle(scheme):
-    a, b, q_, e_, w = scheme
-    ol = oracle._lib(); el = emu._lib()
-    ol.qo_ksw_extz2.restype = C.c_int; el.qe_ksw.restype = C.c_int
-    bad = []
-    n = 0
-    for q, t in _cases(1234 + w, 500):
-        args = (len(q), q.ctypes.data_as(C.c_void_p), len(t), t.ctypes.data_as(C.c_void_p), a, b, q_, e_, w)
-        ref = ol.qo_ksw_extz2(*args)
-        for v in (0, 1, 2):
-            got = el.qe_ksw(v, *args)
-            if got != ref:
-                bad.append((v, len(q), len(t), ref, got))
-        n += 1
-    assert not bad, "%d mismatches of %d cases, first: %r" % (len(bad), n, bad[:5])
-
-
-def test_ksw_every_target_length():
-    """query 100, perfect and 1-error targets of every length 1..160 (band 15): the rounds where the band has shrunk to
-    its last cells sit at a different place of the 16-byte vectors for every residue of tlen mod 16"""
-    ol = oracle._lib(); el = emu._lib()
-    ol.qo_ksw_extz2.restype = C.c_int; el.qe_ksw.restype = C.c_int
-    rng = np.random.default_rng(7)
-    for tlen in range(1, 161):
-        q = rng.integers(0, 4, 100).astype(np.uint8)
-        t = np.resize(q, tlen).copy()
-        if tlen > 3:
-            t[tlen // 2] ^= 1
-        args = (100, q.ctypes.data_as(C.c_void_p), tlen, t.ctypes.data_as(C.c_void_p), 2, -4, 4, 2, 15)
-        ref = ol.qo_ksw_extz2(*args)
-        for v in (0, 1, 2):
-            assert el.qe_ksw(v, *args) == ref, (v, tlen)
+def _rows(el, grp, a, b, q_, e_, w, ring=-1):
+    ql = (C.c_int * 4)(*[len(g[0]) for g in grp] + [0] * (4 - len(grp)))
+    tl = (C.c_int * 4)(*[len(g[1]) for g in grp] + [0] * (4 - len(grp)))
+    dummy = np.zeros(1, dtype=np.uint8)
+    qp = (C.c_void_p * 4)(*[g[0].ctypes.data for g in grp] + [dummy.ctypes.data] * (4 - len(grp)))
+    tp = (C.c_void_p * 4)(*[g[1].ctypes.data for g in grp] + [dummy.ctypes.data] * (4 - len(grp)))
+    out = (C.c_int * 4)()
+    el.qe_ksw_rows(ql, qp, tl, tp, a, b, q_, e_, w, out, ring)
+    return list(out)
 
 
 @pytest.mark.parametrize("scheme", SCHEMES)
@@ -98,13 +79,7 @@ def test_ksw_rows_kernel_four_at_a_time(scheme):
         grp = cases[i:i + 4]
         if rng.random() < 0.2:
             grp = grp[:int(rng.integers(1, 4))]            # a partly filled wavefront
-        ql = (C.c_int * 4)(*[len(g[0]) for g in grp] + [0] * (4 - len(grp)))
-        tl = (C.c_int * 4)(*[len(g[1]) for g in grp] + [0] * (4 - len(grp)))
-        dummy = np.zeros(1, dtype=np.uint8)
-        qp = (C.c_void_p * 4)(*[g[0].ctypes.data for g in grp] + [dummy.ctypes.data] * (4 - len(grp)))
-        tp = (C.c_void_p * 4)(*[g[1].ctypes.data for g in grp] + [dummy.ctypes.data] * (4 - len(grp)))
-        out = (C.c_int * 4)()
-        el.qe_ksw_rows(ql, qp, tl, tp, a, b, q_, e_, w, out)
+        out = _rows(el, grp, a, b, q_, e_, w)
         for k, (qq, tt) in enumerate(grp):
             ref = ol.qo_ksw_extz2(len(qq), qq.ctypes.data_as(C.c_void_p), len(tt), tt.ctypes.data_as(C.c_void_p), a, b, q_, e_, w)
             if out[k] != ref:
@@ -112,22 +87,55 @@ def test_ksw_rows_kernel_four_at_a_time(scheme):
     assert not bad, "%d mismatches, first: %r" % (len(bad), bad[:5])
 
 
-def test_ksw_rows_every_target_length():
+@pytest.mark.parametrize("ring", [64, 128, 512])
+def test_ksw_rows_every_ring_gives_the_same_scores(ring):
+    """a band that fits the smallest ring must score the same on the larger ones (the ring is storage, not arithmetic)"""
+    ol = oracle._lib(); el = emu._lib()
+    ol.qo_ksw_extz2.restype = C.c_int
+    cases = list(_cases(99, 200))
+    for w in (15, 33):
+        for i in range(0, len(cases), 4):
+            grp = cases[i:i + 4]
+            out = _rows(el, grp, 2, -4, 4, 2, w, ring)
+            for k, (qq, tt) in enumerate(grp):
+                ref = ol.qo_ksw_extz2(len(qq), qq.ctypes.data_as(C.c_void_p), len(tt), tt.ctypes.data_as(C.c_void_p), 2, -4, 4, 2, w)
+                assert out[k] == ref, (ring, w, len(qq), len(tt), ref, out[k])
+
+
+def test_ksw_rows_longest_alignments():
+    """256-base queries against 276-base targets (the longest the -s path produces), narrow to full band"""
+    ol = oracle._lib(); el = emu._lib()
+    ol.qo_ksw_extz2.restype = C.c_int
+    rng = np.random.default_rng(31)
+    for w in (15, 33, 60, 97, 200, -1):
+        grp = []
+        for _ in range(4):
+            q = rng.integers(0, 4, int(rng.integers(230, 257))).astype(np.uint8)
+            t = _mutate(rng, q, min(276, len(q) + 20), sub=0.03, indel=0.01)
+            grp.append((q, t))
+        out = _rows(el, grp, 2, -4, 4, 2, w)
+        for k, (qq, tt) in enumerate(grp):
+            ref = ol.qo_ksw_extz2(len(qq), qq.ctypes.data_as(C.c_void_p), len(tt), tt.ctypes.data_as(C.c_void_p), 2, -4, 4, 2, w)
+            assert out[k] == ref, (w, len(qq), len(tt), ref, out[k])
+
+
+@pytest.mark.parametrize("w", [15, 40, 120])
+def test_ksw_rows_every_target_length(w):
+    """query 100, perfect and 1-error targets of every length 1..160: the rounds where the band has shrunk to its last cells
+    sit at a different place of the 16-byte vectors for every residue of tlen mod 16"""
     ol = oracle._lib(); el = emu._lib()
     ol.qo_ksw_extz2.restype = C.c_int
     rng = np.random.default_rng(9)
     for t0 in range(1, 161, 4):
-        qs, ts = [], []
+        grp = []
         for tlen in range(t0, t0 + 4):
             q = rng.integers(0, 4, 100).astype(np.uint8)
             t = np.resize(q, tlen).copy()
             if tlen > 3:
                 t[tlen // 2] ^= 1
-            qs.append(q); ts.append(t)
-        ql = (C.c_int * 4)(*[100] * 4); tl = (C.c_int * 4)(*[len(t) for t in ts])
-        qp = (C.c_void_p * 4)(*[q.ctypes.data for q in qs]); tp = (C.c_void_p * 4)(*[t.ctypes.data for t in ts])
-        out = (C.c_int * 4)()
-        el.qe_ksw_rows(ql, qp, tl, tp, 2, -4, 4, 2, 15, out)
+            grp.append((q, t))
+        out = _rows(el, grp, 2, -4, 4, 2, w)
         for k in range(4):
-            ref = ol.qo_ksw_extz2(100, qs[k].ctypes.data_as(C.c_void_p), len(ts[k]), ts[k].ctypes.data_as(C.c_void_p), 2, -4, 4, 2, 15)
-            assert out[k] == ref, (t0 + k, ref, out[k])
+            qq, tt = grp[k]
+            ref = ol.qo_ksw_extz2(100, qq.ctypes.data_as(C.c_void_p), len(tt), tt.ctypes.data_as(C.c_void_p), 2, -4, 4, 2, w)
+            assert out[k] == ref, (w, t0 + k, ref, out[k])

@@ -143,6 +143,15 @@ def test_sam_writer_matches_python_formatter(synth_small, oracle_mod, opts):
         nb = ra.sam_records_text(qi, b, res.hit_offsets, res.hits, max_num_hits=oo.maxNumHits, threads=4, fd=f.fileno())
         f.seek(0)
         assert nb == len(got) and f.read() == got
+    # a descriptor opened for appending (a shell's `>>`): pwrite would ignore its offsets there, the parts must still land in order
+    with tempfile.NamedTemporaryFile() as nf:
+        nf.write(b"@HD\tpre-existing line\n"); nf.flush()
+        fd = os.open(nf.name, os.O_WRONLY | os.O_APPEND)
+        try:
+            nb = ra.sam_records_text(qi, b, res.hit_offsets, res.hits, max_num_hits=oo.maxNumHits, threads=4, fd=fd)
+        finally:
+            os.close(fd)
+        assert nb == len(got) and open(nf.name, "rb").read() == b"@HD\tpre-existing line\n" + got
     # single-end
     rs = orc.map_single(q1, o1, opts=oo, nthreads=2)
     sb = ra.ReadBatch(); sb.n = b.n; sb.seq1, sb.off1, sb.names1, sb.name_off1 = q1, o1, b.names1, b.name_off1
