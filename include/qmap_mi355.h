@@ -13,7 +13,7 @@
  *     hit_manager::hitsToMappingsSimple(..., PAIRED_END_LEFT / _RIGHT, ...)  src/HitManager.cpp:691-882
  *     utils::mergeLeftRightHits(...)                                         include/RapMapUtils.hpp:1185-1264
  *     + the per-pair bookkeeping of processReadsPairSA                       src/RapMapSAMapper.cpp:461-551,684-701
- * executed by one 64-lane wavefront per pair on the GPU.
+ * executed on the GPU: one 64-lane wavefront per read for the first two steps, one thread per pair for the merge.
  */
 #ifndef QMAP_MI355_H
 #define QMAP_MI355_H
@@ -61,7 +61,7 @@ typedef struct qm_opts {
   int32_t max_mmp_extension;  /* --maxMMPExtension, 7                                     */
   int32_t aln_policy;         /* 0 default, 1 --mimicBT2, 2 --mimicStrictBT2              */
   double min_score_fraction;  /* --minScoreFrac, 0.65                                     */
-  double consensus_slack;     /* --consensusSlack, 0.2                                    */
+  double consensus_slack;     /* --consensusSlack, 0.2; a negative value -f gives MappingConfig::consensusFraction = f directly */
 } qm_opts;
 
 /* POD image of rapmap::utils::QuasiAlignment (include/RapMapUtils.hpp:399-502),
@@ -127,7 +127,9 @@ int qm_index_arrays(const qm_index* ix, const uint8_t** text, int64_t* text_len,
                     int64_t* n_txps);
 
 /* Replicates the index into the HBM of `device_id` as flat SoA arrays and
- * allocates the per-context work buffers.  One ctx per GPU / per host thread. */
+ * allocates the per-context work buffers.  One ctx per GPU / per host thread (a context is not thread-safe); the
+ * contexts of one index on one device share a single replica, which is freed with the last of them.  Destroy the
+ * contexts before closing the index. */
 int qm_ctx_create(const qm_index* ix, int device_id, qm_ctx** out);
 int qm_ctx_destroy(qm_ctx* ctx);
 int64_t qm_ctx_device_bytes(const qm_ctx* ctx);
@@ -155,12 +157,49 @@ int qm_fetch_hits(qm_ctx* ctx, int64_t* hit_offsets, qm_hit* hits);
 /* Device pointers of the same arrays (valid until the next map call on ctx). */
 int qm_result_device(qm_ctx* ctx, const void** d_hit_offsets, const void** d_hits);
 
-/* SACollector::operator() alone (include/SACollector.hpp:108-362): the SA-interval
- * hits (fwdSAInts / rcSAInts of HitCollectorInfo, include/HitManager.hpp:59-72) the
- * last qm_map_pairs call collected.  int_offsets[n+1], ints[int_offsets[n]];
- * pass ints=NULL to get only the offsets/total.  Requires qm_ctx_set_debug(ctx,1). */
-int qm_ctx_set_debug(qm_ctx* ctx, int keep_intervals);
+/* ---- the reference's three entry points as calls of their own ---------------------------------------------------------
+ * RapMap's callers (and Salmon) drive the path per read through three C++ entry points; include/qmap_rapmap_compat.hpp
+ * gives them back with the reference's signatures and fills them from the batched calls below.  Each call works on a
+ * whole batch; results stay in the context until the next call on it.
+ *
+ * (1) SACollector::operator()(read, saSearcher, hcInfo)        include/SACollector.hpp:108-362
+ *     qm_collect_reads: n reads in, per read the SA-interval hits (HitCollectorInfo::fwdSAInts then rcSAInts,
+ *     include/HitManager.hpp:59-72) and the call's return value (foundHit).  opts: sensitive, strict_check, quasi_cov,
+ *     max_interval, and with sel_aln the chain-scoring collector (enableChainScoring / setMaxMMPExtension).
+ *     qm_fetch_intervals: int_offsets[n+1], ints[int_offsets[n]] (ints = NULL: offsets only); the `list` field tells the
+ *     strand (and, after qm_map_pairs / qm_map_pairs_stages on a context with qm_ctx_set_debug, the mate: a pair's four lists
+ *     follow each other).  No cap on the number of intervals.
+ * (2) hit_manager::hitsToMappingsSimple(rmi, mc, mateStatus, hcinfo, hits)   include/HitManager.hpp:130-135, src/HitManager.cpp:691-882
+ *     qm_hits_to_mappings: per read its length and its SA-interval hits (forward-strand records first) in, the read's hit
+ *     list out.  opts: fuzzy keeps both orientations of a transcript (what the -f merge consumes); sel_aln = MappingConfig
+ *     {doChaining, considerMultiPos} with consensus_slack.  qm_fetch_read_lists: list_offsets[n+1], words[].
+ *     List words without sel_aln: one per hit, ascending, tid << 33 | isRC << 32 | (uint32) hitPos.
+ *     With sel_aln: per hit  tid | primaryRC << 32 | chainStatus << 33 | nP << 36,  then  (uint32) pos | nO << 32,
+ *     then nP positions of the surviving orientation (QuasiAlignment::allPositions) and nO of the other
+ *     (oppositeStrandPositions), each in the low 32 bits of a word.
+ * (3) utils::mergeLeftRightHits / mergeLeftRightHitsFuzzy          include/RapMapUtils.hpp:1185-1264, :864-1183
+ *     qm_merge_lists: per pair the two mates' lists (same word format), their lengths and -- for the fuzzy merge
+ *     (opts.fuzzy or opts.sel_aln) -- leftMatches / rightMatches; jointHits come back through qm_fetch_hits, the
+ *     tooManyHits out-parameter through qm_fetch_too_many (bit 0; bit 1: the mates shared a transcript), the HitCounters the merge bumps (peHits, seHits, tooManyHits)
+ *     in `counters`.  Nothing of the caller's bookkeeping that follows the merge in processReadsPairSA is applied
+ *     (src/RapMapSAMapper.cpp:534-551,684-701).  With sel_aln the hits' aln_score carries the chain statuses
+ *     (left | right << 4; rapmap::utils::ChainStatus), not a score: the merge does not align.
+ * qm_map_pairs_stages = (1)-(3) for a batch of pairs in one fused pass, every stage's output kept: intervals
+ * (qm_fetch_intervals, four lists per pair), foundHit (qm_fetch_found, [2n]: left, right, left, ...), per-read lists
+ * (qm_fetch_read_lists, [2n+1] offsets), merge results (qm_fetch_hits, qm_fetch_too_many). */
+int qm_ctx_set_debug(qm_ctx* ctx, int keep_intervals);   /* fused calls keep the SA-interval hits for qm_fetch_intervals */
+int qm_collect_reads(qm_ctx* ctx, const qm_opts* opts, int64_t n, const char* seq, const int64_t* off, int64_t* n_intervals);
 int qm_fetch_intervals(qm_ctx* ctx, int64_t* int_offsets, qm_sa_interval_hit* ints, int64_t cap);
+int qm_fetch_found(qm_ctx* ctx, uint8_t* found);
+int qm_hits_to_mappings(qm_ctx* ctx, const qm_opts* opts, int64_t n, const int32_t* read_len, const int64_t* int_offsets,
+                        const qm_sa_interval_hit* ints, int64_t* n_words);
+int qm_fetch_read_lists(qm_ctx* ctx, int64_t* list_offsets, uint64_t* words, int64_t cap);
+int qm_merge_lists(qm_ctx* ctx, const qm_opts* opts, int64_t n, const int64_t* loff_left, const uint64_t* words_left,
+                   const int64_t* loff_right, const uint64_t* words_right, const uint8_t* found_left, const uint8_t* found_right,
+                   const int32_t* len_left, const int32_t* len_right, int64_t* n_hits, qm_counters* counters);
+int qm_fetch_too_many(qm_ctx* ctx, uint8_t* too_many);
+int qm_map_pairs_stages(qm_ctx* ctx, const qm_opts* opts, int64_t n, const char* seq1, const int64_t* off1, const char* seq2,
+                        const int64_t* off2, int64_t* n_hits, qm_counters* counters);
 
 /* Timing of the dominant kernel of the last map call, measured with HIP events on
  * the context's stream (milliseconds); n_launches kernels were timed. */

@@ -1,0 +1,673 @@
+// qmap_rapmap_compat.hpp -- RapMap's C++ call surface on top of libqmap_mi355.so.
+//
+// A RapMap / Salmon-style caller drives the quasi-mapping path per read through three entry points
+//     SACollector<IndexT>::operator()(read, saSearcher, hcInfo)              include/SACollector.hpp:35-108
+//     rapmap::hit_manager::hitsToMappingsSimple(rmi, mc, mateStatus, hcinfo, hits)   include/HitManager.hpp:59-72,130-135
+//     rapmap::utils::mergeLeftRightHits / mergeLeftRightHitsFuzzy(...)       include/RapMapUtils.hpp:1185, :864
+// in the sequence of src/RapMapSAMapper.cpp:466-531.  This header declares those names -- same namespaces, same argument
+// lists, same result types -- so that such a caller compiles against it unchanged, and fills every call from the GPU
+// library (include/qmap_mi355.h: qm_collect_reads, qm_hits_to_mappings, qm_merge_lists).  No mapping work is done on the
+// host: a call either takes its answer out of a chunk that was mapped in one batched pass (see prefetch below) or runs a
+// batch of one on the device.
+//
+// A GPU wants batches, the reference's loop is per read.  The bridge is ONE added line per chunk of reads:
+//
+//     while (parser->refill(rg)) {
+//       hitCollector.prefetch(rg);                         // <- added: the whole chunk in one fused GPU pass
+//       for (auto& rpair : rg) {                           //    everything below is the reference's loop, unchanged
+//         bool lh = hitCollector(rpair.first.seq, saSearcher, leftHCInfo);
+//         bool rh = hitCollector(rpair.second.seq, saSearcher, rightHCInfo);
+//         rapmap::hit_manager::hitsToMappingsSimple(rmi, mc, MateStatus::PAIRED_END_LEFT, leftHCInfo, leftHits);
+//         rapmap::hit_manager::hitsToMappingsSimple(rmi, mc, MateStatus::PAIRED_END_RIGHT, rightHCInfo, rightHits);
+//         rapmap::utils::mergeLeftRightHits(leftHits, rightHits, jointHits, readLen, maxNumHits, tooManyHits, hctr);
+//         ...
+//
+// prefetch() maps the chunk with qm_map_pairs_stages (collector, hits->mappings and merge of every pair, each stage's
+// output kept); the per-read calls recognise their read (by the address of its characters), hand out the stage's output and
+// tag it, and the next stage recognises the tag.  Without prefetch, or when a call's input is not what the chunk produced
+// (a caller that edits hcInfo or the hit vectors between the calls), the call runs its stage on the device for that one
+// read: correct, and as slow as one GPU launch per call must be.
+//
+// Thread model as in the reference: the index object is shared, SACollector / SASearcher / HitCollectorInfo are per
+// thread.  Every host thread gets its own device context; contexts of one index on one device share the index replica.
+#ifndef QMAP_RAPMAP_COMPAT_HPP
+#define QMAP_RAPMAP_COMPAT_HPP
+
+#include <atomic>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "qmap_mi355.h"
+
+namespace qmap {
+class Error : public std::runtime_error {
+ public:
+  Error(int code, const char* what) : std::runtime_error(what), code_(code) {}
+  int code() const { return code_; }
+ private:
+  int code_;
+};
+namespace detail {
+inline void check(int rc) { if (rc) throw Error(rc, qm_last_error()); }
+struct Chunk;
+}  // namespace detail
+}  // namespace qmap
+
+// ------------------------------------------------------------------------------------------------ rapmap::utils types
+namespace rapmap {
+namespace utils {
+
+// include/RapMapUtils.hpp:289-295
+enum class ChainStatus : uint8_t { PERFECT = 0, UNGAPPED = 1, ALIGNED_ON_LEFT = 2, ALIGNED_ON_RIGHT = 3, REGULAR = 4 };
+
+// include/RapMapUtils.hpp:321-354
+class FragmentChainStatus {
+ public:
+  FragmentChainStatus() : left(static_cast<uint8_t>(ChainStatus::REGULAR)), right(static_cast<uint8_t>(ChainStatus::REGULAR)) {}
+  FragmentChainStatus(ChainStatus ls, ChainStatus rs) : left(static_cast<uint8_t>(ls)), right(static_cast<uint8_t>(rs)) {}
+  void setLeft(ChainStatus s) { left = static_cast<uint8_t>(s); }
+  void setRight(ChainStatus s) { right = static_cast<uint8_t>(s); }
+  ChainStatus getLeft() const { return static_cast<ChainStatus>(left); }
+  ChainStatus getRight() const { return static_cast<ChainStatus>(right); }
+ private:
+  uint8_t left : 4, right : 4;
+};
+
+// include/RapMapUtils.hpp:356-362
+enum class MateStatus : uint8_t {
+  SINGLE_END = 0, PAIRED_END_LEFT = 1, PAIRED_END_RIGHT = 2, PAIRED_END_PAIRED = 3, NOTHING = std::numeric_limits<uint8_t>::max()
+};
+
+// include/RapMapUtils.hpp:83-89
+class MappingConfig {
+ public:
+  bool consistentHits{false};
+  bool doChaining{false};
+  float consensusFraction{1.0};
+  bool considerMultiPos{false};
+};
+
+// include/RapMapUtils.hpp:208-216
+struct HitCounters {
+  std::atomic<uint64_t> peHits{0};
+  std::atomic<uint64_t> seHits{0};
+  std::atomic<uint64_t> trueHits{0};
+  std::atomic<uint64_t> totHits{0};
+  std::atomic<uint64_t> numReads{0};
+  std::atomic<uint64_t> tooManyHits{0};
+  std::atomic<uint64_t> lastPrint{0};
+};
+
+// include/RapMapUtils.hpp:399-502 (chobo::small_vector<int32_t> is a std::vector here)
+struct QuasiAlignment {
+  QuasiAlignment()
+      : tid(std::numeric_limits<uint32_t>::max()), pos(std::numeric_limits<int32_t>::max()), fwd(true),
+        fragLen(std::numeric_limits<uint32_t>::max()), readLen(std::numeric_limits<uint32_t>::max()), isPaired(false) {}
+  QuasiAlignment(uint32_t tidIn, int32_t posIn, bool fwdIn, uint32_t readLenIn, uint32_t fragLenIn = 0, bool isPairedIn = false)
+      : tid(tidIn), pos(posIn), fwd(fwdIn), fragLen(fragLenIn), readLen(readLenIn), isPaired(isPairedIn) {}
+  inline void setChainScore(double chainScoreIn) { chainScore_ = chainScoreIn; }
+  inline double chainScore() const { return chainScore_; }
+  inline uint32_t transcriptID() const { return tid; }
+  inline double score() const { return score_; }
+  inline void score(double scoreIn) { score_ = scoreIn; }
+  inline int32_t alnScore() const { return alnScore_; }
+  inline void alnScore(int32_t alnScoreIn) { alnScore_ = alnScoreIn; }
+  inline uint32_t fragLength() const { return fragLen; }
+  inline int32_t hitPos() { return pos < matePos ? pos : matePos; }
+
+  bool hasMultiPos{false};
+  std::vector<int32_t> allPositions;
+  std::vector<int32_t> oppositeStrandPositions;
+  uint32_t tid;
+  int32_t pos;
+  int32_t matePos{0};
+  bool fwd;
+  bool mateIsFwd{true};
+  uint32_t fragLen;
+  uint32_t readLen;
+  uint32_t mateLen{0};
+  bool isPaired;
+  MateStatus mateStatus{MateStatus::NOTHING};
+  double score_{1.0};
+  int32_t alnScore_{0};
+  FragmentChainStatus chainStatus;
+  // The device does not hand chain scores out: a hit that came from it holds lowest() here, as non-chained hits do in the
+  // reference.  (mergeOrientationUnique, the one consumer of chainScore, runs inside hitsToMappingsSimple on the device.)
+  double chainScore_{std::numeric_limits<double>::lowest()};
+  // where this hit came from when it was handed out of a prefetched chunk (not part of the reference's type)
+  const qmap::detail::Chunk* qm_chunk_{nullptr};
+  uint64_t qm_gen_{0};
+  int64_t qm_read_{-1};
+};
+
+// include/RapMapUtils.hpp:516-525
+template <typename OffsetT>
+struct SAIntervalHit {
+  SAIntervalHit(OffsetT beginIn, OffsetT endIn, uint32_t lenIn, uint32_t queryPosIn, bool queryRCIn)
+      : begin(beginIn), end(endIn), len(lenIn), queryPos(queryPosIn), queryRC(queryRCIn) {}
+  OffsetT span() { return end - begin; }
+  OffsetT begin, end;
+  uint32_t len, queryPos;
+  bool queryRC;
+};
+
+// include/RapMapUtils.hpp:855-862
+enum class MergeResult : uint8_t { HAD_NONE, HAD_EMPTY_INTERSECTION, HAD_CONCORDANT, HAD_DISCORDANT, HAD_ONLY_LEFT, HAD_ONLY_RIGHT };
+
+}  // namespace utils
+
+namespace hit_manager {
+// include/HitManager.hpp:52-72
+template <typename T> using SAIntervalVector = std::vector<T>;
+template <typename SAIntervalHitT>
+class HitCollectorInfo {
+ public:
+  void clear() {
+    readLen = 0;
+    maxDist = 0;
+    fwdSAInts.clear();
+    rcSAInts.clear();
+    qm_chunk_ = nullptr; qm_read_ = -1;
+  }
+  size_t readLen{0};
+  int32_t maxDist{0};
+  SAIntervalVector<SAIntervalHitT> fwdSAInts;
+  SAIntervalVector<SAIntervalHitT> rcSAInts;
+  // set by SACollector::operator() when the intervals came out of a prefetched chunk (not part of the reference's type)
+  const qmap::detail::Chunk* qm_chunk_{nullptr};
+  uint64_t qm_gen_{0};
+  int64_t qm_read_{-1};
+};
+}  // namespace hit_manager
+}  // namespace rapmap
+
+// ------------------------------------------------------------------------------------------------ index
+// Hash flavours of the reference's four index instantiations (src/RapMapSAMapper.cpp:1209-1240); tags only: the on-disk
+// header says which table the directory holds and the library loads either.
+struct RegHashT {};
+struct PerfectHashT {};
+
+// RapMapSAIndex<IndexT, HashT> (include/RapMapSAIndex.hpp:47-83): load() + the members a mapping caller reads.
+template <typename IndexT, typename HashT>
+class RapMapSAIndex {
+ public:
+  using IndexType = IndexT;
+  using HashType = HashT;
+  RapMapSAIndex() = default;
+  ~RapMapSAIndex() { if (ix_) qm_index_close(ix_); }
+  RapMapSAIndex(const RapMapSAIndex&) = delete;
+  RapMapSAIndex& operator=(const RapMapSAIndex&) = delete;
+
+  bool load(const std::string& indDir) {
+    static_assert(sizeof(IndexT) == 4, "64-bit suffix arrays (BigSA) are not on the device path yet");
+    qmap::detail::check(qm_index_open(indDir.c_str(), &ix_));
+    qm_index_info info;
+    qmap::detail::check(qm_index_info_get(ix_, &info));
+    k_ = info.k; perfect_ = info.perfect_hash != 0;
+    const uint8_t* text = nullptr; int64_t tl = 0; const int32_t* offs = nullptr; int64_t nt = 0;
+    qmap::detail::check(qm_index_arrays(ix_, &text, &tl, &offs, &nt));
+    seq.assign(reinterpret_cast<const char*>(text), static_cast<size_t>(tl));
+    txpOffsets.assign(offs, offs + nt);
+    txpNames.clear(); txpLens.clear();
+    for (int64_t i = 0; i < nt; ++i) { txpNames.emplace_back(qm_index_txp_name(ix_, i)); txpLens.push_back(static_cast<IndexT>(qm_index_txp_len(ix_, i))); }
+    return true;
+  }
+  // GPU the contexts of this index live on (before the first mapping call; default 0)
+  void setDevice(int d) { device_ = d; }
+  int device() const { return device_; }
+  uint32_t k() const { return static_cast<uint32_t>(k_); }
+  bool perfectHash() const { return perfect_; }
+  const qm_index* handle() const { return ix_; }
+
+  std::string seq;
+  std::vector<std::string> txpNames;
+  std::vector<IndexT> txpOffsets;
+  std::vector<IndexT> txpLens;
+
+ private:
+  qm_index* ix_{nullptr};
+  int device_{0};
+  int k_{31};
+  bool perfect_{false};
+};
+using SAIndex32BitDense = RapMapSAIndex<int32_t, RegHashT>;
+using SAIndex32BitPerfect = RapMapSAIndex<int32_t, PerfectHashT>;
+
+// ------------------------------------------------------------------------------------------------ plumbing
+namespace qmap {
+namespace detail {
+
+// One thread's device context per index (contexts are not shared between threads; the index replica in HBM is).
+inline qm_ctx*& last_ctx() { thread_local qm_ctx* c = nullptr; return c; }   // the calling thread's most recent context
+struct ThreadCtx {
+  const qm_index* ix{nullptr};
+  qm_ctx* ctx{nullptr};
+  ~ThreadCtx() { if (ctx) qm_ctx_destroy(ctx); }
+};
+template <typename RapMapIndexT>
+inline qm_ctx* thread_ctx(RapMapIndexT& rmi) {
+  thread_local std::vector<std::unique_ptr<ThreadCtx>> tl;
+  for (auto& t : tl) if (t->ix == rmi.handle()) return last_ctx() = t->ctx;
+  std::unique_ptr<ThreadCtx> t(new ThreadCtx());
+  t->ix = rmi.handle();
+  check(qm_ctx_create(rmi.handle(), rmi.device(), &t->ctx));
+  tl.push_back(std::move(t));
+  return last_ctx() = tl.back()->ctx;
+}
+
+// Everything one fused pass over a chunk produced, per read (paired: read 2u = left mate of pair u, 2u + 1 = right).
+struct Chunk {
+  uint64_t gen{0};
+  bool paired{false};
+  qm_opts opts{};                       // what the chunk was mapped with: a stage call with other settings does not use it
+  int64_t nreads{0};
+  std::vector<const char*> key; std::vector<size_t> keyLen;
+  std::vector<int64_t> ivOff; std::vector<qm_sa_interval_hit> iv; std::vector<uint8_t> found;
+  std::vector<int64_t> listOff; std::vector<uint64_t> words;
+  std::vector<int64_t> hitOff; std::vector<qm_hit> hits; std::vector<uint8_t> tooMany;
+  int64_t cursor{0};
+};
+inline uint64_t next_gen() { static std::atomic<uint64_t> g{1}; return g++; }
+
+inline void decode_hit(const qm_hit& h, rapmap::utils::QuasiAlignment& q) {
+  using namespace rapmap::utils;
+  q.tid = h.tid; q.pos = h.pos; q.matePos = h.mate_pos; q.fwd = h.fwd != 0; q.mateIsFwd = h.mate_is_fwd != 0;
+  q.fragLen = h.frag_len; q.readLen = h.read_len; q.mateLen = h.mate_len; q.isPaired = h.is_paired != 0;
+  q.mateStatus = static_cast<MateStatus>(h.mate_status);
+}
+
+// per-read list words (qmap_mi355.h, "List words") -> the vector hitsToMappingsSimple fills
+inline void decode_list(const uint64_t* w, int64_t n, bool chained, uint32_t readLen, rapmap::utils::MateStatus ms,
+                        std::vector<rapmap::utils::QuasiAlignment>& hits) {
+  using namespace rapmap::utils;
+  if (!chained) {
+    for (int64_t i = 0; i < n; ++i) {
+      hits.emplace_back(static_cast<uint32_t>(w[i] >> 33), static_cast<int32_t>(static_cast<uint32_t>(w[i])), ((w[i] >> 32) & 1) == 0, readLen);
+      hits.back().mateStatus = ms;
+      // --fuzzyIntersection lists keep both orientations of a transcript: the second entry is the first one's
+      // oppositeStrandPositions (mergeOrientationUnique, src/HitManager.cpp:846-866)
+      const size_t m = hits.size();
+      if (m >= 2 && hits[m - 2].tid == hits[m - 1].tid) { hits[m - 2].oppositeStrandPositions.push_back(hits[m - 1].pos); hits.pop_back(); continue; }
+      hits.back().allPositions.push_back(hits.back().pos);
+    }
+    return;
+  }
+  for (int64_t i = 0; i < n;) {
+    const uint64_t h = w[i];
+    const int32_t np = static_cast<int32_t>(h >> 36), no = static_cast<int32_t>(w[i + 1] >> 32);
+    hits.emplace_back(static_cast<uint32_t>(h), static_cast<int32_t>(static_cast<uint32_t>(w[i + 1])), ((h >> 32) & 1) == 0, readLen);
+    QuasiAlignment& q = hits.back();
+    q.mateStatus = ms;
+    const ChainStatus cs = static_cast<ChainStatus>((h >> 33) & 7);
+    if (ms == MateStatus::PAIRED_END_RIGHT) q.chainStatus.setRight(cs); else q.chainStatus.setLeft(cs);
+    for (int32_t t = 0; t < np; ++t) q.allPositions.push_back(static_cast<int32_t>(static_cast<uint32_t>(w[i + 2 + t])));
+    for (int32_t t = 0; t < no; ++t) q.oppositeStrandPositions.push_back(static_cast<int32_t>(static_cast<uint32_t>(w[i + 2 + np + t])));
+    q.hasMultiPos = np > 1;
+    i += 2 + np + no;
+  }
+}
+
+// the inverse, for a merge call whose hit vectors did not come out of a chunk
+inline void encode_list(const std::vector<rapmap::utils::QuasiAlignment>& hits, bool chained, bool right, std::vector<uint64_t>& w) {
+  using namespace rapmap::utils;
+  for (const QuasiAlignment& q : hits) {
+    if (!chained) {
+      w.push_back((static_cast<uint64_t>(q.tid) << 33) | (static_cast<uint64_t>(q.fwd ? 0 : 1) << 32) | static_cast<uint32_t>(q.pos));
+      for (int32_t p : q.oppositeStrandPositions)
+        w.push_back((static_cast<uint64_t>(q.tid) << 33) | (static_cast<uint64_t>(q.fwd ? 1 : 0) << 32) | static_cast<uint32_t>(p));
+    } else {
+      const ChainStatus cs = right ? q.chainStatus.getRight() : q.chainStatus.getLeft();
+      w.push_back(static_cast<uint64_t>(q.tid) | (static_cast<uint64_t>(q.fwd ? 0 : 1) << 32) | (static_cast<uint64_t>(cs) << 33) |
+                  (static_cast<uint64_t>(q.allPositions.size()) << 36));
+      w.push_back(static_cast<uint64_t>(static_cast<uint32_t>(q.pos)) | (static_cast<uint64_t>(q.oppositeStrandPositions.size()) << 32));
+      for (int32_t p : q.allPositions) w.push_back(static_cast<uint32_t>(p));
+      for (int32_t p : q.oppositeStrandPositions) w.push_back(static_cast<uint32_t>(p));
+    }
+  }
+}
+
+inline bool same_stage_opts(const qm_opts& a, const qm_opts& b) {
+  return a.sensitive == b.sensitive && a.strict_check == b.strict_check && a.max_interval == b.max_interval && a.quasi_cov == b.quasi_cov &&
+         a.sel_aln == b.sel_aln && a.max_mmp_extension == b.max_mmp_extension && a.consensus_slack == b.consensus_slack && a.fuzzy == b.fuzzy;
+}
+
+// MappingConfig -> the library's options for hitsToMappingsSimple.  The device implements the two configurations the
+// reference's own driver uses (src/RapMapSAMapper.cpp:180-190): plain, and chaining with multiple positions.
+inline void apply_mc(const rapmap::utils::MappingConfig& mc, qm_opts& o) {
+  if (mc.consistentHits) throw Error(QM_E_UNSUPPORTED, "MappingConfig::consistentHits is not on the device path");
+  if (mc.doChaining != mc.considerMultiPos) throw Error(QM_E_UNSUPPORTED, "MappingConfig: doChaining and considerMultiPos go together on the device path");
+  if (!mc.doChaining && mc.consensusFraction != 1.0f) throw Error(QM_E_UNSUPPORTED, "MappingConfig: consensusFraction < 1 needs doChaining on the device path");
+  o.sel_aln = mc.doChaining ? 1 : 0;
+  o.consensus_slack = mc.doChaining ? -static_cast<double>(mc.consensusFraction) : 0.2;   // negative: the fraction itself (qmap_mi355.h)
+}
+
+}  // namespace detail
+}  // namespace qmap
+
+// ------------------------------------------------------------------------------------------------ SASearcher / SACollector
+// SASearcher (include/SASearcher.hpp): the collector's suffix-array search object.  Its work happens on the device inside
+// the collector call; the class exists so that the caller's `SASearcher<RapMapIndexT> saSearcher(&rmi);` compiles.
+template <typename RapMapIndexT>
+class SASearcher {
+ public:
+  using OffsetT = typename RapMapIndexT::IndexType;
+  explicit SASearcher(RapMapIndexT* rmi) : rmi_(rmi) {}
+  RapMapIndexT* index() const { return rmi_; }
+ private:
+  RapMapIndexT* rmi_;
+};
+
+// SACollector (include/SACollector.hpp:35-108)
+template <typename RapMapIndexT>
+class SACollector {
+ public:
+  using OffsetT = typename RapMapIndexT::IndexType;
+  using HCInfo = rapmap::hit_manager::HitCollectorInfo<rapmap::utils::SAIntervalHit<OffsetT>>;
+
+  void disableNIP() { disableNIP_ = true; }
+  void enableNIP() { disableNIP_ = false; }
+  void setCoverageRequirement(double req) { covReq_ = req; }
+  double getCoverageRequirement() const { return covReq_; }
+  void setMaxInterval(OffsetT maxInterval) { maxInterval_ = maxInterval; }
+  OffsetT getMaxInterval(OffsetT) const { return maxInterval_; }
+  bool getStrictCheck() const { return strictCheck_; }
+  void setStrictCheck(bool sc) { strictCheck_ = sc; }
+  void enableChainScoring() { doChaining_ = true; }
+  void disableChainScoring() { doChaining_ = false; }
+  bool getChainScoring() const { return doChaining_; }
+  void setMaxMMPExtension(int32_t ext) { if (ext > 0) { maxMMPExtension_ = ext; } }
+  int32_t getMaxMMPExtension() const { return maxMMPExtension_; }
+
+  explicit SACollector(RapMapIndexT* rmi) : rmi_(rmi) {}
+
+  // ---- the added call (see the head of this file): map a whole chunk in one fused GPU pass --------------------------
+  // PairRange: anything iterable whose elements have .first.seq and .second.seq (fastx_parser's ReadPair chunk, a
+  // std::vector<std::pair<Read, Read>>, ...).  The strings must stay where they are until their per-read calls were made.
+  // `mc` and `fuzzyMerge` say how the later stages will be called (defaults: the plain configuration).
+  template <typename PairRange>
+  void prefetch(PairRange& rg, const rapmap::utils::MappingConfig& mc = rapmap::utils::MappingConfig(), bool fuzzyMerge = false,
+                uint32_t maxNumHits = 200) {
+    std::vector<const std::string*> l, r;
+    for (auto& rp : rg) { l.push_back(&rp.first.seq); r.push_back(&rp.second.seq); }
+    prefetchPairs(l, r, mc, fuzzyMerge, maxNumHits);
+  }
+  void prefetchPairs(const std::vector<const std::string*>& left, const std::vector<const std::string*>& right,
+                     const rapmap::utils::MappingConfig& mc, bool fuzzyMerge, uint32_t maxNumHits) {
+    using namespace qmap::detail;
+    const int64_t n = static_cast<int64_t>(left.size());
+    std::unique_ptr<Chunk> ch(new Chunk());
+    ch->gen = next_gen(); ch->paired = true; ch->nreads = 2 * n;
+    stageOpts(ch->opts);
+    apply_mc(mc, ch->opts);
+    ch->opts.fuzzy = (fuzzyMerge || mc.doChaining) ? 1 : 0;
+    ch->opts.max_num_hits = static_cast<int32_t>(maxNumHits);
+    s1_.clear(); s2_.clear(); o1_.assign(1, 0); o2_.assign(1, 0);
+    ch->key.resize(2 * n); ch->keyLen.resize(2 * n);
+    for (int64_t i = 0; i < n; ++i) {
+      s1_.insert(s1_.end(), left[i]->begin(), left[i]->end()); o1_.push_back(static_cast<int64_t>(s1_.size()));
+      s2_.insert(s2_.end(), right[i]->begin(), right[i]->end()); o2_.push_back(static_cast<int64_t>(s2_.size()));
+      ch->key[2 * i] = left[i]->data(); ch->keyLen[2 * i] = left[i]->size();
+      ch->key[2 * i + 1] = right[i]->data(); ch->keyLen[2 * i + 1] = right[i]->size();
+    }
+    qm_ctx* ctx = thread_ctx(*rmi_);
+    int64_t nHits = 0; qm_counters c{};
+    check(qm_map_pairs_stages(ctx, &ch->opts, n, s1_.data(), o1_.data(), s2_.data(), o2_.data(), &nHits, &c));
+    // stage 1: intervals (four lists per pair -> two per read) and foundHit
+    std::vector<int64_t> uoff(static_cast<size_t>(n) + 1);
+    check(qm_fetch_intervals(ctx, uoff.data(), nullptr, 0));
+    ch->iv.resize(static_cast<size_t>(uoff[n]));
+    if (uoff[n]) check(qm_fetch_intervals(ctx, uoff.data(), ch->iv.data(), uoff[n]));
+    ch->ivOff.assign(static_cast<size_t>(2 * n) + 1, 0);
+    for (int64_t u = 0; u < n; ++u) {
+      int64_t nl = 0;
+      for (int64_t j = uoff[u]; j < uoff[u + 1]; ++j) if (ch->iv[static_cast<size_t>(j)].list < 2) ++nl;
+      ch->ivOff[2 * u + 1] = uoff[u] + nl; ch->ivOff[2 * u + 2] = uoff[u + 1];
+    }
+    ch->found.resize(static_cast<size_t>(2 * n) + 1);
+    check(qm_fetch_found(ctx, ch->found.data()));
+    // stage 2: per-read lists
+    ch->listOff.resize(static_cast<size_t>(2 * n) + 1);
+    check(qm_fetch_read_lists(ctx, ch->listOff.data(), nullptr, 0));
+    ch->words.resize(static_cast<size_t>(ch->listOff[2 * n]) + 1);
+    check(qm_fetch_read_lists(ctx, ch->listOff.data(), ch->words.data(), ch->listOff[2 * n]));
+    // stage 3: merge results
+    ch->hitOff.resize(static_cast<size_t>(n) + 1); ch->hits.resize(static_cast<size_t>(nHits) + 1);
+    check(qm_fetch_hits(ctx, ch->hitOff.data(), ch->hits.data()));
+    ch->tooMany.resize(static_cast<size_t>(n) + 1);
+    check(qm_fetch_too_many(ctx, ch->tooMany.data()));
+    chunk_ = std::move(ch);
+  }
+
+  // SACollector::operator() (include/SACollector.hpp:108-362)
+  bool operator()(std::string& read, SASearcher<RapMapIndexT>& /*saSearcher*/, HCInfo& hcInfo) {
+    using namespace qmap::detail;
+    hcInfo.readLen = read.length();
+    hcInfo.maxDist = static_cast<int32_t>(read.length());
+    Chunk* ch = chunk_.get();
+    if (ch) {
+      qm_opts now; stageOpts(now); now.sel_aln = ch->opts.sel_aln; now.consensus_slack = ch->opts.consensus_slack; now.fuzzy = ch->opts.fuzzy;
+      int64_t idx = -1;
+      if (ch->cursor < ch->nreads && ch->key[ch->cursor] == read.data() && ch->keyLen[ch->cursor] == read.size()) idx = ch->cursor++;
+      if (idx >= 0 && same_stage_opts(now, ch->opts) && (doChaining_ ? 1 : 0) == ch->opts.sel_aln) {
+        for (int64_t j = ch->ivOff[idx]; j < ch->ivOff[idx + 1]; ++j) {
+          const qm_sa_interval_hit& h = ch->iv[static_cast<size_t>(j)];
+          (h.query_rc ? hcInfo.rcSAInts : hcInfo.fwdSAInts).emplace_back(static_cast<OffsetT>(h.begin), static_cast<OffsetT>(h.end), h.len, h.query_pos, h.query_rc != 0);
+        }
+        hcInfo.qm_chunk_ = ch; hcInfo.qm_gen_ = ch->gen; hcInfo.qm_read_ = idx;
+        return ch->found[static_cast<size_t>(idx)] != 0;
+      }
+    }
+    // a batch of one
+    qm_opts o; stageOpts(o);
+    qm_ctx* ctx = thread_ctx(*rmi_);
+    const int64_t off[2] = {0, static_cast<int64_t>(read.size())};
+    int64_t ni = 0;
+    check(qm_collect_reads(ctx, &o, 1, read.data(), off, &ni));
+    int64_t ioff[2] = {0, 0};
+    std::vector<qm_sa_interval_hit> iv(static_cast<size_t>(ni) + 1);
+    check(qm_fetch_intervals(ctx, ioff, iv.data(), ni));
+    for (int64_t j = 0; j < ioff[1]; ++j) {
+      const qm_sa_interval_hit& h = iv[static_cast<size_t>(j)];
+      (h.query_rc ? hcInfo.rcSAInts : hcInfo.fwdSAInts).emplace_back(static_cast<OffsetT>(h.begin), static_cast<OffsetT>(h.end), h.len, h.query_pos, h.query_rc != 0);
+    }
+    hcInfo.qm_chunk_ = nullptr; hcInfo.qm_read_ = -1;
+    uint8_t f = 0;
+    check(qm_fetch_found(ctx, &f));
+    return f != 0;
+  }
+
+ private:
+  void stageOpts(qm_opts& o) const {
+    qm_opts_default(&o);
+    o.sensitive = disableNIP_ ? 1 : 0;       // --noSensitive leaves NIP skipping on; the CLI default disables it (RapMapSAMapper.cpp:1113-1114)
+    o.strict_check = strictCheck_ ? 1 : 0;
+    o.quasi_cov = covReq_;
+    o.max_interval = static_cast<int32_t>(maxInterval_);
+    o.sel_aln = doChaining_ ? 1 : 0;
+    o.max_mmp_extension = maxMMPExtension_;
+  }
+  RapMapIndexT* rmi_;
+  // the reference's constructor defaults (SACollector.hpp:77-81)
+  bool disableNIP_{false};
+  double covReq_{0.0};
+  OffsetT maxInterval_{1000};
+  bool strictCheck_{false};
+  bool doChaining_{false};
+  int32_t maxMMPExtension_{7};
+  std::unique_ptr<qmap::detail::Chunk> chunk_;
+  std::vector<char> s1_, s2_;
+  std::vector<int64_t> o1_, o2_;
+};
+
+// ------------------------------------------------------------------------------------------------ hitsToMappingsSimple
+namespace rapmap {
+namespace hit_manager {
+
+// include/HitManager.hpp:130-135, src/HitManager.cpp:691-882
+template <typename RapMapIndexT>
+void hitsToMappingsSimple(RapMapIndexT& rmi, rapmap::utils::MappingConfig& mc, rapmap::utils::MateStatus mateStatus,
+                          HitCollectorInfo<rapmap::utils::SAIntervalHit<typename RapMapIndexT::IndexType>>& hcinfo,
+                          std::vector<rapmap::utils::QuasiAlignment>& hits) {
+  using namespace qmap::detail;
+  const size_t before = hits.size();
+  const uint32_t readLen = static_cast<uint32_t>(hcinfo.readLen);
+  const Chunk* ch = hcinfo.qm_chunk_;
+  qm_opts o; qm_opts_default(&o);
+  apply_mc(mc, o);
+  if (ch && ch->gen == hcinfo.qm_gen_ && hcinfo.qm_read_ >= 0 && (mc.doChaining ? 1 : 0) == ch->opts.sel_aln &&
+      (!mc.doChaining || o.consensus_slack == ch->opts.consensus_slack) &&
+      static_cast<int64_t>(hcinfo.fwdSAInts.size() + hcinfo.rcSAInts.size()) == ch->ivOff[hcinfo.qm_read_ + 1] - ch->ivOff[hcinfo.qm_read_]) {
+    // the chunk's pass already turned exactly these intervals into the read's list
+    const int64_t r = hcinfo.qm_read_;
+    decode_list(ch->words.data() + ch->listOff[r], ch->listOff[r + 1] - ch->listOff[r], mc.doChaining, readLen, mateStatus, hits);
+    for (size_t i = before; i < hits.size(); ++i) { hits[i].qm_chunk_ = ch; hits[i].qm_gen_ = ch->gen; hits[i].qm_read_ = r; }
+    return;
+  }
+  // a batch of one, from the intervals the caller holds
+  std::vector<qm_sa_interval_hit> iv;
+  for (int t = 0; t < 2; ++t) {
+    auto& v = t == 0 ? hcinfo.fwdSAInts : hcinfo.rcSAInts;
+    for (auto& h : v) { qm_sa_interval_hit x; x.begin = static_cast<int32_t>(h.begin); x.end = static_cast<int32_t>(h.end); x.len = h.len; x.query_pos = h.queryPos; x.query_rc = static_cast<uint8_t>(t); x.list = static_cast<uint8_t>(t); x.pad = 0; iv.push_back(x); }
+  }
+  const int32_t len = static_cast<int32_t>(readLen);
+  const int64_t ioff[2] = {0, static_cast<int64_t>(iv.size())};
+  o.fuzzy = 1;                                               // both orientations kept: decode_list folds them into oppositeStrandPositions
+  qm_ctx* ctx = thread_ctx(rmi);
+  int64_t nw = 0;
+  check(qm_hits_to_mappings(ctx, &o, 1, &len, ioff, iv.data(), &nw));
+  int64_t loff[2] = {0, 0};
+  std::vector<uint64_t> w(static_cast<size_t>(nw) + 1);
+  check(qm_fetch_read_lists(ctx, loff, w.data(), nw));
+  decode_list(w.data(), loff[1], mc.doChaining, readLen, mateStatus, hits);
+}
+
+}  // namespace hit_manager
+
+// ------------------------------------------------------------------------------------------------ the merges
+namespace utils {
+namespace qm_detail {
+
+// the pair both vectors were produced for, if they came out of one chunk untouched
+inline const qmap::detail::Chunk* merge_source(const std::vector<QuasiAlignment>& l, const std::vector<QuasiAlignment>& r, bool chained, bool fuzzy,
+                                               uint32_t maxNumHits, int64_t& unit) {
+  const QuasiAlignment* a = l.empty() ? nullptr : &l.front();
+  const QuasiAlignment* b = r.empty() ? nullptr : &r.front();
+  const QuasiAlignment* any = a ? a : b;
+  if (!any || !any->qm_chunk_ || any->qm_chunk_->gen != any->qm_gen_) return nullptr;
+  const qmap::detail::Chunk* ch = any->qm_chunk_;
+  if (!ch->paired || (ch->opts.sel_aln != 0) != chained || ((ch->opts.fuzzy != 0) != (fuzzy || chained)) || static_cast<uint32_t>(ch->opts.max_num_hits) != maxNumHits) return nullptr;
+  if (a && b && (b->qm_chunk_ != ch || b->qm_gen_ != ch->gen || b->qm_read_ != a->qm_read_ + 1)) return nullptr;
+  const int64_t rd = a ? a->qm_read_ : b->qm_read_ - 1;
+  if (rd < 0 || (rd & 1)) return nullptr;
+  // the other mate's list must be what the chunk has for it (an emptied vector is an edit)
+  auto count = [&](int64_t read) {
+    int64_t g = 0; const uint64_t* w = ch->words.data() + ch->listOff[read]; const int64_t n = ch->listOff[read + 1] - ch->listOff[read];
+    if (!chained) { for (int64_t i = 0; i < n; ++i) if (i == 0 || (w[i] >> 33) != (w[i - 1] >> 33)) ++g; return g; }
+    for (int64_t i = 0; i < n;) { i += 2 + static_cast<int64_t>(w[i] >> 36) + static_cast<int64_t>(w[i + 1] >> 32); ++g; }
+    return g;
+  };
+  if (count(rd) != static_cast<int64_t>(l.size()) || count(rd + 1) != static_cast<int64_t>(r.size())) return nullptr;
+  unit = rd >> 1;
+  return ch;
+}
+
+template <typename HitCountersT>
+inline MergeResult merge_impl(bool fuzzy, bool leftMatches, bool rightMatches, std::vector<QuasiAlignment>& leftHits,
+                              std::vector<QuasiAlignment>& rightHits, std::vector<QuasiAlignment>& jointHits, bool chained,
+                              uint32_t maxNumHits, bool& tooManyHits, HitCountersT& hctr, qm_ctx* ctx_or_null) {
+  using namespace qmap::detail;
+  MergeResult res = MergeResult::HAD_NONE;
+  // orphans are the caller's own objects moved over, exactly as the reference moves them (RapMapUtils.hpp:880-901,1251-1262)
+  auto moveAll = [&](std::vector<QuasiAlignment>& v) { jointHits.insert(jointHits.end(), std::make_move_iterator(v.begin()), std::make_move_iterator(v.end())); };
+  if (fuzzy) {
+    if (leftHits.empty()) {
+      if (!leftMatches && !rightHits.empty()) { moveAll(rightHits); hctr.seHits += rightHits.size(); res = MergeResult::HAD_ONLY_RIGHT; }
+      if (jointHits.size() > 0) hctr.peHits += jointHits.size();
+      return res;
+    }
+    if (rightHits.empty()) {
+      if (!rightMatches) { moveAll(leftHits); hctr.seHits += leftHits.size(); res = MergeResult::HAD_ONLY_LEFT; }
+      if (jointHits.size() > 0) hctr.peHits += jointHits.size();
+      return res;
+    }
+  } else if (leftHits.empty() || rightHits.empty()) {
+    const size_t numHits = leftHits.size() + rightHits.size();
+    if (numHits > 0) { hctr.seHits += numHits; moveAll(leftHits); moveAll(rightHits); }
+    return res;
+  }
+  // both mates have hits: the intersection is device work
+  const uint32_t l1 = leftHits.front().readLen, l2 = rightHits.front().readLen;
+  int64_t unit = -1;
+  const Chunk* ch = merge_source(leftHits, rightHits, chained, fuzzy, maxNumHits, unit);
+  std::vector<qm_hit> own; const qm_hit* hb = nullptr; int64_t nh = 0; uint8_t flags = 0;
+  if (ch) {
+    hb = ch->hits.data() + ch->hitOff[unit]; nh = ch->hitOff[unit + 1] - ch->hitOff[unit]; flags = ch->tooMany[static_cast<size_t>(unit)];
+  } else {
+    if (!ctx_or_null) throw qmap::Error(QM_E_STATE, "merge of hit vectors that did not come from this thread's device context");
+    qm_opts o; qm_opts_default(&o);
+    o.fuzzy = fuzzy ? 1 : 0; o.sel_aln = chained ? 1 : 0; o.max_num_hits = static_cast<int32_t>(maxNumHits);
+    std::vector<uint64_t> wl, wr;
+    encode_list(leftHits, chained, false, wl); encode_list(rightHits, chained, true, wr);
+    const int64_t ol[2] = {0, static_cast<int64_t>(wl.size())}, orr[2] = {0, static_cast<int64_t>(wr.size())};
+    const uint8_t fl = leftMatches ? 1 : 0, fr = rightMatches ? 1 : 0;
+    const int32_t ll = static_cast<int32_t>(l1), lr = static_cast<int32_t>(l2);
+    qm_counters c{};
+    check(qm_merge_lists(ctx_or_null, &o, 1, ol, wl.data(), orr, wr.data(), &fl, &fr, &ll, &lr, &nh, &c));
+    int64_t ho[2] = {0, 0};
+    own.resize(static_cast<size_t>(nh) + 1);
+    check(qm_fetch_hits(ctx_or_null, ho, own.data()));
+    check(qm_fetch_too_many(ctx_or_null, &flags));
+    hb = own.data();
+  }
+  const bool tooMany = (flags & 1) != 0, sameTxp = (flags & 2) != 0;
+  if (tooMany) { tooManyHits = true; ++hctr.tooManyHits; }
+  int64_t paired = 0;
+  for (int64_t i = 0; i < nh; ++i) if (hb[i].is_paired) ++paired;
+  if (paired > 0) {
+    for (int64_t i = 0; i < nh; ++i) {
+      jointHits.emplace_back();
+      decode_hit(hb[i], jointHits.back());
+      if (chained) jointHits.back().chainStatus = FragmentChainStatus(static_cast<ChainStatus>(hb[i].aln_score & 15), static_cast<ChainStatus>((hb[i].aln_score >> 4) & 15));
+    }
+    hctr.peHits += jointHits.size();
+    res = MergeResult::HAD_CONCORDANT;
+  } else if (fuzzy) {
+    res = tooMany ? MergeResult::HAD_CONCORDANT : (sameTxp ? MergeResult::HAD_DISCORDANT : MergeResult::HAD_EMPTY_INTERSECTION);
+  } else if (!tooMany) {
+    // no common transcript: the single-end hits of both mates (RapMapUtils.hpp:1246-1262)
+    hctr.seHits += leftHits.size() + rightHits.size();
+    moveAll(leftHits); moveAll(rightHits);
+  }
+  return res;
+}
+}  // namespace qm_detail
+
+// The merges have no index argument; one that has to go to the device uses the calling thread's most recent context (the
+// collector / hitsToMappingsSimple calls that produced its inputs set it).
+
+// include/RapMapUtils.hpp:1185-1264
+inline void mergeLeftRightHits(std::vector<QuasiAlignment>& leftHits, std::vector<QuasiAlignment>& rightHits,
+                               std::vector<QuasiAlignment>& jointHits, uint32_t /*readLen*/, uint32_t maxNumHits, bool& tooManyHits,
+                               HitCounters& hctr) {
+  qm_detail::merge_impl(false, true, true, leftHits, rightHits, jointHits, false, maxNumHits, tooManyHits, hctr, qmap::detail::last_ctx());
+}
+
+// include/RapMapUtils.hpp:864-1183
+inline MergeResult mergeLeftRightHitsFuzzy(bool leftMatches, bool rightMatches, std::vector<QuasiAlignment>& leftHits,
+                                           std::vector<QuasiAlignment>& rightHits, std::vector<QuasiAlignment>& jointHits,
+                                           rapmap::utils::MappingConfig& mc, uint32_t /*readLen*/, uint32_t maxNumHits, bool& tooManyHits,
+                                           HitCounters& hctr) {
+  return qm_detail::merge_impl(true, leftMatches, rightMatches, leftHits, rightHits, jointHits, mc.considerMultiPos, maxNumHits, tooManyHits,
+                               hctr, qmap::detail::last_ctx());
+}
+
+}  // namespace utils
+}  // namespace rapmap
+
+#endif  // QMAP_RAPMAP_COMPAT_HPP

@@ -33,6 +33,8 @@ ABI_SYMBOLS = [
     "qm_index_txp_name", "qm_index_txp_len", "qm_index_arrays", "qm_ctx_create", "qm_ctx_destroy", "qm_ctx_device_bytes",
     "qm_map_pairs", "qm_map_reads", "qm_map_device", "qm_fetch_hits", "qm_result_device", "qm_ctx_set_debug",
     "qm_fetch_intervals", "qm_last_kernel_ms", "qm_ctx_stat", "qm_build_index",
+    "qm_collect_reads", "qm_fetch_found", "qm_hits_to_mappings", "qm_fetch_read_lists", "qm_merge_lists", "qm_fetch_too_many",
+    "qm_map_pairs_stages",
     "qm_reader_open", "qm_reader_next", "qm_reader_close", "qm_io_last_error", "qm_sam_header", "qm_sam_records",
     "qm_sam_write", "qm_buf_free",
 ]
@@ -106,6 +108,13 @@ def lib():
     L.qm_fetch_intervals.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     L.qm_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.qm_ctx_stat.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
+    L.qm_collect_reads.argtypes = [C.c_void_p, C.POINTER(QmOpts), C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+    L.qm_fetch_found.argtypes = [C.c_void_p, C.c_void_p]
+    L.qm_hits_to_mappings.argtypes = [C.c_void_p, C.POINTER(QmOpts), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+    L.qm_fetch_read_lists.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    L.qm_merge_lists.argtypes = [C.c_void_p, C.POINTER(QmOpts), C.c_int64] + [C.c_void_p] * 8 + [C.POINTER(C.c_int64), C.POINTER(QmCounters)]
+    L.qm_fetch_too_many.argtypes = [C.c_void_p, C.c_void_p]
+    L.qm_map_pairs_stages.argtypes = L.qm_map_pairs.argtypes
     L.qm_build_index.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.qm_opts_default.argtypes = [C.POINTER(QmOpts)]
     L.qm_io_last_error.restype = C.c_char_p
@@ -288,8 +297,65 @@ class QuasiMapper:
         _check(lib().qm_ctx_stat(self._h, int(which), C.byref(v)))
         return v.value
 
+    # ---- the reference's three entry points as calls of their own (include/qmap_mi355.h) ----
+    def collect_reads(self, seq, off, opts=None):
+        """SACollector::operator() for every read: (found uint8[n], int_offsets int64[n+1], intervals)"""
+        opts = opts or default_opts()
+        seq = np.ascontiguousarray(seq, dtype=np.uint8); off = np.ascontiguousarray(off, dtype=np.int64)
+        n = len(off) - 1
+        ni = C.c_int64(0)
+        _check(lib().qm_collect_reads(self._h, C.byref(opts), n, seq.ctypes.data or 1, off.ctypes.data, C.byref(ni)))
+        found = np.zeros(n + 1, dtype=np.uint8)
+        _check(lib().qm_fetch_found(self._h, found.ctypes.data))
+        offs, ints = self.intervals(n)
+        return found[:n], offs, ints
+
+    def hits_to_mappings(self, read_len, int_offsets, ints, opts=None):
+        """hitsToMappingsSimple for every read from its SA-interval hits: (list_offsets int64[n+1], words uint64[])"""
+        opts = opts or default_opts()
+        read_len = np.ascontiguousarray(read_len, dtype=np.int32); int_offsets = np.ascontiguousarray(int_offsets, dtype=np.int64)
+        ints = np.ascontiguousarray(ints, dtype=INTERVAL_DTYPE)
+        n = len(read_len)
+        nw = C.c_int64(0)
+        _check(lib().qm_hits_to_mappings(self._h, C.byref(opts), n, read_len.ctypes.data or 1, int_offsets.ctypes.data,
+                                         ints.ctypes.data if ints.size else None, C.byref(nw)))
+        return self.read_lists(n)
+
+    def read_lists(self, nreads):
+        lo = np.zeros(nreads + 1, dtype=np.int64)
+        _check(lib().qm_fetch_read_lists(self._h, lo.ctypes.data, None, 0))
+        w = np.zeros(int(lo[-1]) + 1, dtype=np.uint64)
+        _check(lib().qm_fetch_read_lists(self._h, lo.ctypes.data, w.ctypes.data, int(lo[-1])))
+        return lo, w[: int(lo[-1])]
+
+    def merge_lists(self, lo_l, w_l, lo_r, w_r, found_l, found_r, len_l, len_r, opts=None):
+        """mergeLeftRightHits[Fuzzy] for every pair: MapResult (hits, counters) + .too_many uint8[n]"""
+        opts = opts or default_opts()
+        a = [np.ascontiguousarray(lo_l, dtype=np.int64), np.ascontiguousarray(w_l, dtype=np.uint64), np.ascontiguousarray(lo_r, dtype=np.int64),
+             np.ascontiguousarray(w_r, dtype=np.uint64), np.ascontiguousarray(found_l, dtype=np.uint8), np.ascontiguousarray(found_r, dtype=np.uint8),
+             np.ascontiguousarray(len_l, dtype=np.int32), np.ascontiguousarray(len_r, dtype=np.int32)]
+        n = len(a[0]) - 1
+        nh, ctr = C.c_int64(0), QmCounters()
+        _check(lib().qm_merge_lists(self._h, C.byref(opts), n, *[x.ctypes.data if x.size else None for x in a], C.byref(nh), C.byref(ctr)))
+        r = self._finish(n, nh, ctr)
+        tm = np.zeros(n + 1, dtype=np.uint8)
+        _check(lib().qm_fetch_too_many(self._h, tm.ctypes.data))
+        r_too = tm[:n]
+        return r, r_too
+
+    def map_pairs_stages(self, seq1, off1, seq2, off2, opts=None):
+        """the three stages fused, every stage's output kept: MapResult of the merge (no caller-level bookkeeping)"""
+        opts = opts or default_opts()
+        seq1 = np.ascontiguousarray(seq1, dtype=np.uint8); off1 = np.ascontiguousarray(off1, dtype=np.int64)
+        seq2 = np.ascontiguousarray(seq2, dtype=np.uint8); off2 = np.ascontiguousarray(off2, dtype=np.int64)
+        n = len(off1) - 1
+        nh, ctr = C.c_int64(0), QmCounters()
+        _check(lib().qm_map_pairs_stages(self._h, C.byref(opts), n, seq1.ctypes.data or 1, off1.ctypes.data,
+                                         seq2.ctypes.data or 1, off2.ctypes.data, C.byref(nh), C.byref(ctr)))
+        return self._finish(n, nh, ctr)
+
     def intervals(self, n):
-        """fwdSAInts / rcSAInts of the last map call (needs debug=True)."""
+        """fwdSAInts / rcSAInts kept by the last call (fused calls: needs debug=True)."""
         offs = np.zeros(n + 1, dtype=np.int64)
         _check(lib().qm_fetch_intervals(self._h, offs.ctypes.data, None, 0))
         ints = np.zeros(int(offs[-1]), dtype=INTERVAL_DTYPE)

@@ -16,6 +16,9 @@ hipError_t qmk_build_slots(const void* recs, long long K, void* slots, unsigned 
 hipError_t qmk_build_phrecs(const int* data, const unsigned char* lens, long long n, const void* dev_index, void* out, hipStream_t st);
 int qmk_map_grid(long long n, int num_cu);
 hipError_t qmk_map_reads(const void* dev_index, const void* read_batch, int ns, int grid, int num_cu, hipStream_t st);
+// ns < 0: the "collector only" stage entry (NS=4 kernels with QM_F_COLLECT)
+hipError_t qmk_h2m(const void* dev_index, const void* read_batch, int grid, int num_cu, hipStream_t st);
+hipError_t qmk_sel_merge(const void* pair_batch, const void* sel_batch, hipStream_t st);
 size_t qmk_sel_scratch_bytes(void);
 size_t qmk_sel_dyn_struct_bytes(void);
 unsigned long long qmk_sel_dyn_bytes(long long n);

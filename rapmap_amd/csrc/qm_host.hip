@@ -20,6 +20,9 @@
 #include <string>
 #include <vector>
 #include <thread>
+#include <map>
+#include <memory>
+#include <mutex>
 
 #include "qm_mapper.inl"
 #include "qm_device.h"
@@ -72,8 +75,25 @@ struct qm_index {
   std::vector<std::pair<int32_t, int32_t>> phOverflow;
 };
 
+// The index replica of one device: built by the first context on (index, device), shared read-only by every later one
+// (one context per host thread is the intended use: a Salmon-style caller has many), freed with the last of them.
+struct Replica {
+  int device = 0;
+  uint8_t* d_text = nullptr; int32_t* d_SA = nullptr; void* d_sainfo = nullptr; void* d_slots = nullptr; uint64_t cap = 0;
+  void* d_ph = nullptr; std::vector<void*> phAllocs; int32_t* d_txpOff = nullptr; int32_t* d_txpLen = nullptr; int64_t devBytes = 0;
+  ~Replica() {
+    hipSetDevice(device);
+    void* ptrs[] = {d_text, d_SA, d_sainfo, d_slots, d_txpOff, d_txpLen};
+    for (void* p : ptrs) if (p) hipFree(p);
+    for (void* p : phAllocs) if (p) hipFree(p);
+  }
+};
+static std::mutex g_repMu;
+static std::map<std::pair<const qm_index*, int>, std::weak_ptr<Replica>> g_reps;
+
 struct qm_ctx {
   const qm_index* ix = nullptr;
+  std::shared_ptr<Replica> rep;
   int device = 0, numCU = 256;
   hipStream_t stream = nullptr, copyStream = nullptr;      // kernels / host-buffer uploads (overlapped chunk by chunk)
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evA = nullptr, evB = nullptr, evCopy = nullptr, evStage[2] = {nullptr, nullptr};
@@ -92,7 +112,13 @@ struct qm_ctx {
   u64* d_scal = nullptr; /* cursor, counters[6], status */ u64* d_gscr = nullptr;
   void* d_scanTmp = nullptr; size_t scanTmpBytes = 0;
   uint8_t* d_seq1 = nullptr; uint8_t* d_seq2 = nullptr; long long* d_off1 = nullptr; long long* d_off2 = nullptr;
-  qm_sa_interval_hit* d_dbg = nullptr; uint32_t* d_dbgcnt = nullptr; int64_t capDbg = 0, capDbgCnt = 0; int debug = 0;
+  // SA-interval hits as an output (qm_fetch_intervals), foundHit flags, tooMany flags of a merge-only call
+  qm_sa_interval_hit* d_iv = nullptr; uint32_t* d_ivcnt = nullptr; long long* d_ivoff = nullptr; int64_t capIv = 0, capIvCnt = 0, capIvOff = 0; int debug = 0;
+  unsigned char* d_found = nullptr; int64_t capFound = 0; unsigned char* d_tooMany = nullptr; int64_t capTooMany = 0;
+  // inputs of the stage entries
+  qm_sa_interval_hit* d_ivIn = nullptr; int64_t capIvIn = 0; long long* d_ivInOff = nullptr; int64_t capIvInOff = 0;
+  int* d_lenIn = nullptr; int64_t capLenIn = 0; unsigned char* d_foundIn = nullptr; int64_t capFoundIn = 0;
+  int64_t lastIvTotal = 0, lastIvReads = -1, lastFoundReads = -1, lastListReads = -1, lastListWords = 0, lastTooManyUnits = -1;
   // -s (selective alignment) work areas
   int32_t* d_txpOff = nullptr; int32_t* d_txpLen = nullptr;
   unsigned char* d_selscr = nullptr; int64_t capSelScr = 0;
@@ -326,11 +352,15 @@ int qm_index_arrays(const qm_index* ix, const uint8_t** text, int64_t* text_len,
 int qm_ctx_destroy(qm_ctx* c) {
   if (!c) return QM_OK;
   hipSetDevice(c->device);
-  void* ptrs[] = {c->d_text, c->d_SA, c->d_sainfo, c->d_slots, c->d_cnt, c->d_lcnt, c->d_loff, c->d_lists, c->d_hits, c->d_offs,
-                  c->d_scal, c->d_gscr, c->d_scanTmp, c->d_seq1, c->d_seq2, c->d_off1, c->d_off2, c->d_dbg, c->d_dbgcnt,
-                  c->d_txpOff, c->d_txpLen, c->d_selscr, c->d_slowq, c->d_dyn, c->d_dynmem, c->d_toff, c->d_tmp, c->d_tkeys, c->d_tsc, c->d_tref, c->d_tcix, c->d_tasks};
+  if (!c->rep) {               // creation failed half-way: the index arrays are still this context's own
+    void* own[] = {c->d_text, c->d_SA, c->d_sainfo, c->d_slots, c->d_txpOff, c->d_txpLen};
+    for (void* p : own) if (p) hipFree(p);
+    for (void* p : c->phAllocs) if (p) hipFree(p);
+  }
+  void* ptrs[] = {c->d_cnt, c->d_lcnt, c->d_loff, c->d_lists, c->d_hits, c->d_offs,
+                  c->d_scal, c->d_gscr, c->d_scanTmp, c->d_seq1, c->d_seq2, c->d_off1, c->d_off2, c->d_iv, c->d_ivcnt, c->d_ivoff, c->d_found, c->d_tooMany, c->d_ivIn, c->d_ivInOff, c->d_lenIn, c->d_foundIn,
+                  c->d_selscr, c->d_slowq, c->d_dyn, c->d_dynmem, c->d_toff, c->d_tmp, c->d_tkeys, c->d_tsc, c->d_tref, c->d_tcix, c->d_tasks};
   for (void* p : ptrs) if (p) hipFree(p);
-  for (void* p : c->phAllocs) if (p) hipFree(p);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
   if (c->evA) hipEventDestroy(c->evA);
@@ -341,6 +371,7 @@ int qm_ctx_destroy(qm_ctx* c) {
   if (c->evStage[0]) hipEventDestroy(c->evStage[0]);
   if (c->evStage[1]) hipEventDestroy(c->evStage[1]);
   if (c->h_stage) hipHostFree(c->h_stage);
+  { std::lock_guard<std::mutex> lk(g_repMu); c->rep.reset(); }   // the last context on (index, device) frees the replica
   delete c;
   return QM_OK;
 }
@@ -360,6 +391,19 @@ int qm_ctx_create(const qm_index* ix, int device_id, qm_ctx** out) {
   CK(hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
   CK(hipEventCreateWithFlags(&c->evCopy, hipEventDisableTiming));
   CK(hipEventCreate(&c->ev0)); CK(hipEventCreate(&c->ev1)); CK(hipEventCreate(&c->evA)); CK(hipEventCreate(&c->evB));
+  CK(hipMalloc((void**)&c->d_scal, QM_SC_WORDS * sizeof(u64)));
+  {
+    std::lock_guard<std::mutex> lk(g_repMu);
+    auto it = g_reps.find(std::make_pair(ix, device_id));
+    if (it != g_reps.end()) c->rep = it->second.lock();
+    if (c->rep) {
+      Replica& R = *c->rep;
+      c->d_text = R.d_text; c->d_SA = R.d_SA; c->d_sainfo = R.d_sainfo; c->d_slots = R.d_slots; c->cap = R.cap; c->d_ph = R.d_ph;
+      c->d_txpOff = R.d_txpOff; c->d_txpLen = R.d_txpLen; c->devBytes = R.devBytes;
+      *out = c;
+      return QM_OK;
+    }
+  }
   const size_t pad = 256;
   CK(hipMalloc((void**)&c->d_text, (size_t)ix->n + pad));
   CK(hipMemsetAsync(c->d_text + ix->n, 0, pad, c->stream));
@@ -431,7 +475,6 @@ int qm_ctx_create(const qm_index* ix, int device_id, qm_ctx** out) {
     CK(hipStreamSynchronize(c->stream));    // P, tab, ov, fin are locals
     c->d_ph = dP;
   }
-  CK(hipMalloc((void**)&c->d_scal, QM_SC_WORDS * sizeof(u64)));
   CK(hipStreamSynchronize(c->stream));
   c->d_txpOff = d_offsets;                               // kept: -s reads transcript sequences by (offset, length)
   {
@@ -443,6 +486,14 @@ int qm_ctx_create(const qm_index* ix, int device_id, qm_ctx** out) {
   if (d_recs) hipFree(d_recs);
   c->devBytes += ix->n + pad + ix->nSA * 4 + ix->nSA * (int64_t)sizeof(SaInfo) + (int64_t)(ix->perfect ? 0 : c->cap * sizeof(Bucket));
 #undef CK
+  {
+    auto R = std::make_shared<Replica>();
+    R->device = device_id; R->d_text = c->d_text; R->d_SA = c->d_SA; R->d_sainfo = c->d_sainfo; R->d_slots = c->d_slots; R->cap = c->cap;
+    R->d_ph = c->d_ph; R->phAllocs.swap(c->phAllocs); R->d_txpOff = c->d_txpOff; R->d_txpLen = c->d_txpLen; R->devBytes = c->devBytes;
+    std::lock_guard<std::mutex> lk(g_repMu);
+    c->rep = R;
+    g_reps[std::make_pair(ix, device_id)] = R;
+  }
   *out = c;
   return QM_OK;
 }
@@ -465,65 +516,76 @@ struct ChunkFeeder {
   void* self;
 };
 
-static int map_device_impl(qm_ctx* c, const qm_opts* o, int64_t n, const void* d_seq1, const void* d_off1, const void* d_seq2,
-                           const void* d_off2, int32_t max_read_len, int64_t* n_hits, qm_counters* counters, ChunkFeeder* feeder) {
-  if (!c || n < 0 || (n > 0 && (!d_seq1 || !d_off1))) return fail(QM_E_ARG, "bad argument");
-  int rc = check_opts(o);
-  if (rc) return rc;
-  if ((d_seq2 == nullptr) != (d_off2 == nullptr)) return fail(QM_E_ARG, "seq2/off2 must both be given or both be null");
-  if (max_read_len > QM_MAX_READ_LEN) return fail(QM_E_TOOLONG, "read length %d > %d", max_read_len, QM_MAX_READ_LEN);
-  HIPCHK(hipSetDevice(c->device));
-  const int ns = max_read_len <= 128 ? 2 : (max_read_len <= 192 ? 3 : 4);   // 64-character slots per read: picks the kernel instantiation
+// What a call asks of the path.  The fused calls (qm_map_pairs / _reads / _device) run everything; the stage entries run one
+// of the reference's three entry points on its own (SACollector::operator(), hitsToMappingsSimple, mergeLeftRightHits[Fuzzy]).
+enum { QM_RUN_FUSED = 0, QM_RUN_COLLECT = 1, QM_RUN_FROM_INTERVALS = 2 };
+struct RunReq {
+  int mode = QM_RUN_FUSED;
+  bool keepIntervals = false;     // SA-interval hits kept for qm_fetch_intervals
+  bool keepFound = false;         // foundHit per read kept for qm_fetch_found
+  bool mergeOnly = false;         // stage B without the caller-level bookkeeping, tooMany flags kept
+  // QM_RUN_FROM_INTERVALS: device arrays
+  const qm_sa_interval_hit* ivIn = nullptr; const long long* ivInOff = nullptr; const int* lenIn = nullptr; const unsigned char* foundIn = nullptr;
+};
+
+static DevIndex dev_index(const qm_ctx* c) {
+  DevIndex ix; ix.text = c->d_text; ix.n = c->ix->n; ix.SA = c->d_SA; ix.nSA = c->ix->nSA;
+  ix.sainfo = (const SaInfo*)c->d_sainfo; ix.slots = (const Bucket*)c->d_slots; ix.hmask = c->cap - 1; ix.ph = (const PhIndex*)c->d_ph; ix.k = c->ix->k;
+  return ix;
+}
+
+// ---- stage A: one wavefront per read (collector + hits->mappings, or one of the two alone), with its retries: the per-read
+// lists or the interval output outgrew their buffers (grow, redo), -s reads left on the slow queue (second, small launch).
+static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n, const void* d_seq1, const void* d_off1, const void* d_seq2,
+                       const void* d_off2, int ns, ChunkFeeder* feeder, u64* hscal) {
+  int rc;
   const bool paired = d_seq2 != nullptr;
   const int64_t nreads = paired ? 2 * n : n;
   const int grid = qmk_map_grid(nreads, c->numCU);
-  if ((rc = ensure(c->d_cnt, c->capCnt, n + 1))) return rc;
-  if ((rc = ensure(c->d_offs, c->capOffs, n + 1))) return rc;
   if ((rc = ensure(c->d_lcnt, c->capLcnt, nreads + 1))) return rc;
   if ((rc = ensure(c->d_loff, c->capLoff, nreads + 1))) return rc;
   if ((rc = ensure(c->d_gscr, c->capGrid, (int64_t)grid * 4 * QM_GSCR_U64))) return rc;
-  size_t stb = qmk_scan_temp_bytes(n + 1);
-  if (stb > c->scanTmpBytes || !c->d_scanTmp) {
-    if (c->d_scanTmp) hipFree(c->d_scanTmp);
-    c->d_scanTmp = nullptr; c->scanTmpBytes = 0;
-    HIPCHK(hipMalloc(&c->d_scanTmp, stb ? stb : 16));
-    c->scanTmpBytes = stb;
+  if (rq.mode != QM_RUN_COLLECT) {
+    int64_t wantLists = nreads * 4 + (int64_t)grid * 4 * QM_CHUNK * 2;   // chunked bump allocator: up to one open chunk per wave
+    if (c->capLists < wantLists) { if ((rc = ensure(c->d_lists, c->capLists, wantLists))) return rc; }
   }
-  if (c->debug) {
-    int64_t cd = c->capDbg;
-    if ((rc = ensure(c->d_dbg, cd, n * QM_DBG_CAP + 1))) return rc;
-    cd = c->capDbgCnt; if ((rc = ensure(c->d_dbgcnt, cd, nreads + 1))) return rc;
-    c->capDbg = n * QM_DBG_CAP + 1; c->capDbgCnt = cd;
+  const bool wantIv = rq.keepIntervals || rq.mode == QM_RUN_COLLECT;
+  if (wantIv) {
+    if ((rc = ensure(c->d_ivcnt, c->capIvCnt, nreads + 1))) return rc;
+    if ((rc = ensure(c->d_ivoff, c->capIvOff, nreads + 1))) return rc;
+    const int64_t want = nreads * (o->sel_aln ? 16 : 4) + 1024;
+    if (c->capIv < want) { if ((rc = ensure(c->d_iv, c->capIv, want))) return rc; }
   }
-  int64_t wantLists = nreads * 4 + (int64_t)grid * 4 * QM_CHUNK * 2;   // chunked bump allocator: up to one open chunk per wave
-  if (c->capLists < wantLists) { if ((rc = ensure(c->d_lists, c->capLists, wantLists))) return rc; }
-
-  DevIndex ix; ix.text = c->d_text; ix.n = c->ix->n; ix.SA = c->d_SA; ix.nSA = c->ix->nSA;
-  ix.sainfo = (const SaInfo*)c->d_sainfo; ix.slots = (const Bucket*)c->d_slots; ix.hmask = c->cap - 1; ix.ph = (const PhIndex*)c->d_ph; ix.k = c->ix->k;
-  u64 hscal[QM_SC_WORDS];
-  c->lastRelaunches = 0; c->lastSlowReads = 0;
-  HIPCHK(hipEventRecord(c->evA, c->stream));
-  // ---- stage A: one wavefront per read
+  if (rq.keepFound || rq.mode == QM_RUN_COLLECT) { if ((rc = ensure(c->d_found, c->capFound, nreads + 1))) return rc; }
+  const DevIndex ix = dev_index(c);
+  c->lastRelaunches = 0; c->lastSlowReads = 0; c->lastIvTotal = 0;
   while (true) {
     ReadBatch B; memset(&B, 0, sizeof(B));
     B.seq1 = (const unsigned char*)d_seq1; B.off1 = (const long long*)d_off1;
     B.seq2 = (const unsigned char*)d_seq2; B.off2 = (const long long*)d_off2; B.nreads = nreads;
     B.lcnt = c->d_lcnt; B.loff = c->d_loff; B.lists = c->d_lists; B.cursor = c->d_scal; B.lists_cap = c->capLists;
     B.status = (int*)(c->d_scal + QM_SC_STATUS); B.gscratch = c->d_gscr;
-    B.dbg_ints = c->debug ? c->d_dbg : nullptr; B.dbg_count = c->debug ? c->d_dbgcnt : nullptr;
-    B.strict_check = o->strict_check; B.max_interval = o->max_interval; B.quasi_cov = o->quasi_cov; B.sensitive = o->sensitive; B.fuzzy = (d_seq2 != nullptr) ? o->fuzzy : 0;
+    if (wantIv) { B.iv_out = c->d_iv; B.iv_cnt = c->d_ivcnt; B.iv_off = c->d_ivoff; B.iv_cap = c->capIv; }
+    if (rq.keepFound || rq.mode == QM_RUN_COLLECT) B.found_out = c->d_found;
+    B.iv_in = rq.ivIn; B.iv_in_off = rq.ivInOff; B.len_in = rq.lenIn; B.found_in = rq.foundIn;
+    B.strict_check = o->strict_check; B.max_interval = o->max_interval; B.quasi_cov = o->quasi_cov; B.sensitive = o->sensitive; B.fuzzy = paired ? o->fuzzy : 0;
+    if (rq.mode == QM_RUN_FROM_INTERVALS) B.fuzzy = o->fuzzy;   // the caller says what kind of list it wants (both orientations kept or not)
     if (o->sel_aln) {                                   // -s: chain scoring + per-wave scratch for chaining (qm_sel.inl)
       if ((rc = ensure(c->d_selscr, c->capSelScr, (int64_t)grid * 4 * (int64_t)qmk_sel_scratch_bytes()))) return rc;
       B.selscr = (SelScratch*)c->d_selscr;
       B.max_mmp_ext = o->max_mmp_extension > 0 ? o->max_mmp_extension : 7;
       const float cs = (float)o->consensus_slack;        // MappingOpts::consensusSlack is a float (RapMapSAMapper.cpp:138,184-185)
-      B.consensus_fraction = (cs == 0.0) ? 1.0 : (1.0 - cs);
+      B.consensus_fraction = cs < 0 ? -cs : ((cs == 0.0) ? 1.0 : (1.0 - cs));   // negative: MappingConfig::consensusFraction itself (qmap_mi355.h)
     }
     HIPCHK(hipMemsetAsync(c->d_scal, 0, QM_SC_WORDS * sizeof(u64), c->stream));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
+    auto launch = [&](const ReadBatch& X, int g) -> hipError_t {
+      if (rq.mode == QM_RUN_FROM_INTERVALS) return qmk_h2m(&ix, &X, g, c->numCU, c->stream);
+      return qmk_map_reads(&ix, &X, rq.mode == QM_RUN_COLLECT ? -1 : ns, g, c->numCU, c->stream);
+    };
     if (feeder && n > 0) {
       // first pass over host buffers: one launch per chunk, each behind its own upload.  A launch sees its chunk through
-      // shifted pointers (offsets are absolute, the per-read / per-unit arrays start at the chunk), the bump allocator,
+      // shifted pointers (offsets are absolute, the per-read / per-unit arrays start at the chunk), the bump allocators,
       // the counters and the status word are shared.
       for (int64_t u0 = 0; u0 < n; u0 += feeder->chunk) {
         const int64_t u1 = u0 + feeder->chunk < n ? u0 + feeder->chunk : n;
@@ -534,15 +596,17 @@ static int map_device_impl(qm_ctx* c, const qm_opts* o, int64_t n, const void* d
         const int64_t r0 = paired ? 2 * u0 : u0, r1 = paired ? 2 * u1 : u1;
         C.off1 = B.off1 + u0; if (paired) C.off2 = B.off2 + u0;
         C.nreads = r1 - r0; C.lcnt = B.lcnt + r0; C.loff = B.loff + r0;
-        HIPCHK(qmk_map_reads(&ix, &C, ns, qmk_map_grid(r1 - r0, c->numCU), c->numCU, c->stream));
+        if (C.iv_cnt) { C.iv_cnt = B.iv_cnt + r0; C.iv_off = B.iv_off + r0; }
+        if (C.found_out) C.found_out = B.found_out + r0;
+        HIPCHK(launch(C, qmk_map_grid(r1 - r0, c->numCU)));
       }
-      feeder = nullptr;                                   // a retry (list space ran out) finds everything resident
-    } else if (nreads > 0) HIPCHK(qmk_map_reads(&ix, &B, ns, grid, c->numCU, c->stream));
+      feeder = nullptr;                                   // a retry finds everything resident
+    } else if (nreads > 0) HIPCHK(launch(B, grid));
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     int status = (int)(hscal[QM_SC_STATUS] & 0xffffffffu);
-    if (o->sel_aln && hscal[QM_SC_SLOWCNT] > 0 && !(status & 7)) {
+    if (o->sel_aln && rq.mode != QM_RUN_COLLECT && hscal[QM_SC_SLOWCNT] > 0 && !(status & 23)) {
       // -s: reads whose SA intervals hold more suffixes than a wave's scratch (repeats, low-complexity reads) were left on
       // the slow queue: gather them, give a few waves scratch sized for the largest, and map them with the same kernel
       const int64_t ns_ = (int64_t)hscal[QM_SC_SLOWCNT];
@@ -561,7 +625,8 @@ static int map_device_impl(qm_ctx* c, const qm_opts* o, int64_t n, const void* d
       HIPCHK(hipMemcpyAsync(c->d_dyn, hd.data(), hd.size(), hipMemcpyHostToDevice, c->stream));
       ReadBatch S2 = B;
       S2.slowq = c->d_slowq; S2.dyn = (SelScratchDyn*)c->d_dyn; S2.nreads = ns_;
-      HIPCHK(qmk_map_reads(&ix, &S2, ns, sgrid, c->numCU, c->stream));
+      S2.iv_out = nullptr; S2.found_out = nullptr;            // already written by the first pass
+      HIPCHK(launch(S2, sgrid));
       HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));                 // hd is a local
       status = (int)(hscal[QM_SC_STATUS] & 0xffffffffu);
@@ -574,24 +639,58 @@ static int map_device_impl(qm_ctx* c, const qm_opts* o, int64_t n, const void* d
       for (int i = 0; i < 7; ++i) fprintf(stderr, "[qm timing] %-16s %6.2f %%  %10.0f clk/read\n", nm[i], 100.0 * hscal[20 + i] / tot, (double)hscal[20 + i] / (double)nreads);
     }
 #endif
-    if (status & 4) return fail(QM_E_TOOLONG, "a read is longer than max_read_len=%d", max_read_len);
+    if (status & 4) return fail(QM_E_TOOLONG, "a read is longer than the kernel's %d characters", ns > 0 ? 64 * ns : QM_MAX_READ_LEN);
     if (status & 2) return fail(QM_E_UNSUPPORTED, "an SA-interval list exceeded %d entries (max_interval too large)", QM_GCAP);
     if (status & 8) return fail(QM_E_STATE, "selective alignment: a read overflowed the scratch sized for it (internal error)");
-    if (status & 1) {            // bump allocator ran out: grow and redo the batch
-      int64_t want = (int64_t)hscal[0] + nreads + (int64_t)grid * 4 * QM_CHUNK;
-      if (want < c->capLists * 2) want = c->capLists * 2;
-      if ((rc = ensure(c->d_lists, c->capLists, want))) return rc;
+    if (status & 17) {           // a bump allocator ran out: grow and redo the batch
+      if (status & 1) {
+        int64_t want = (int64_t)hscal[0] + nreads + (int64_t)grid * 4 * QM_CHUNK;
+        if (want < c->capLists * 2) want = c->capLists * 2;
+        if ((rc = ensure(c->d_lists, c->capLists, want))) return rc;
+      }
+      if (status & 16) {
+        int64_t want = (int64_t)hscal[QM_SC_IVCUR] + nreads + 1024;
+        if (want < c->capIv * 2) want = c->capIv * 2;
+        if ((rc = ensure(c->d_iv, c->capIv, want))) return rc;
+      }
       c->lastRelaunches += 1;
       continue;
     }
     break;
   }
+  c->lastIvTotal = wantIv ? (int64_t)hscal[QM_SC_IVCUR] : 0;
+  c->lastIvReads = wantIv ? nreads : -1;
+  c->lastFoundReads = (rq.keepFound || rq.mode == QM_RUN_COLLECT) ? nreads : -1;
+  c->lastListReads = rq.mode != QM_RUN_COLLECT ? nreads : -1;
+  c->lastListWords = (int64_t)hscal[0];
   float ms = 0; hipEventElapsedTime(&ms, c->ev0, c->ev1); c->lastMapMs = ms;
-  // ---- stage B: one thread per unit: count -> scan -> write
+  return QM_OK;
+}
+
+// ---- stage B (+ C with -s): the per-read lists in d_lists -> the units' hits in CSR order.  One thread per unit: count -> scan -> write.
+static int run_stage_b(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n, bool paired, const void* d_seq1, const void* d_off1,
+                       const void* d_seq2, const void* d_off2, u64* hscal, long long& total) {
+  int rc;
+  if ((rc = ensure(c->d_cnt, c->capCnt, n + 1))) return rc;
+  if ((rc = ensure(c->d_offs, c->capOffs, n + 1))) return rc;
+  size_t stb = qmk_scan_temp_bytes(n + 1);
+  if (stb > c->scanTmpBytes || !c->d_scanTmp) {
+    if (c->d_scanTmp) hipFree(c->d_scanTmp);
+    c->d_scanTmp = nullptr; c->scanTmpBytes = 0;
+    HIPCHK(hipMalloc(&c->d_scanTmp, stb ? stb : 16));
+    c->scanTmpBytes = stb;
+  }
   PairBatch P; memset(&P, 0, sizeof(P));
   P.n = n; P.paired = paired ? 1 : 0; P.off1 = (const long long*)d_off1; P.off2 = (const long long*)d_off2;
   P.lcnt = c->d_lcnt; P.loff = c->d_loff; P.lists = c->d_lists; P.cnt = c->d_cnt; P.offs = c->d_offs;
-  P.counters = c->d_scal + 1; P.max_num_hits = o->max_num_hits; P.no_orphans = o->no_orphans; P.no_dovetail = o->no_dovetail; P.fuzzy = o->fuzzy;
+  P.counters = c->d_scal + 1; P.max_num_hits = o->max_num_hits; P.no_orphans = rq.mergeOnly ? 0 : o->no_orphans;
+  P.no_dovetail = rq.mergeOnly ? 0 : o->no_dovetail; P.fuzzy = o->fuzzy; P.merge_only = rq.mergeOnly ? 1 : 0;
+  if (rq.mergeOnly) {
+    if ((rc = ensure(c->d_tooMany, c->capTooMany, n + 1))) return rc;
+    HIPCHK(hipMemsetAsync(c->d_tooMany, 0, (size_t)(n + 1), c->stream));
+    P.too_many = c->d_tooMany;
+  }
+  c->lastTooManyUnits = rq.mergeOnly ? n : -1;
   HIPCHK(hipMemsetAsync(c->d_cnt + n, 0, sizeof(uint32_t), c->stream));
   if (o->sel_aln) {
     // -s: merge + selective alignment + filter per unit into temp slots, then compaction (qm_sel.inl)
@@ -611,18 +710,22 @@ static int map_device_impl(qm_ctx* c, const qm_opts* o, int64_t n, const void* d
     A.match = o->match_score; A.mismatch = o->mismatch_penalty; A.gap_open = o->gap_open; A.gap_extend = o->gap_extend;
     A.bandwidth = o->dp_bandwidth; A.hard_filter = o->hard_filter; A.policy = o->aln_policy; A.min_score_fraction = o->min_score_fraction;
     HIPCHK(hipMemsetAsync(c->d_cnt + n, 0, sizeof(uint32_t), c->stream));
-    // plan (per unit) -> ksw2 extension alignments, four per wavefront, any band -> finish (per unit)
-    if ((rc = ensure(c->d_tref, c->capTref, 2 * slots + 2))) return rc;
-    if ((rc = ensure(c->d_tcix, c->capTcix, 2 * slots + 2))) return rc;
-    if ((rc = ensure(c->d_tasks, c->capTasks, (2 * slots + 2) * (int64_t)qmk_sel_task_bytes()))) return rc;
-    A.tref = c->d_tref; A.tcix = c->d_tcix; A.tasks = (SelTask*)c->d_tasks; A.ntasks = c->d_scal + QM_SC_NTASKS;
-    HIPCHK(hipMemsetAsync(c->d_scal + QM_SC_NTASKS, 0, sizeof(u64), c->stream));
-    HIPCHK(qmk_sel_three(&P, &A, c->numCU, c->stream));
+    if (rq.mergeOnly) {
+      HIPCHK(qmk_sel_merge(&P, &A, c->stream));            // the merge alone: no alignment, chain statuses stay in aln_score
+    } else {
+      // plan (per unit) -> ksw2 extension alignments, four per wavefront, any band -> finish (per unit)
+      if ((rc = ensure(c->d_tref, c->capTref, 2 * slots + 2))) return rc;
+      if ((rc = ensure(c->d_tcix, c->capTcix, 2 * slots + 2))) return rc;
+      if ((rc = ensure(c->d_tasks, c->capTasks, (2 * slots + 2) * (int64_t)qmk_sel_task_bytes()))) return rc;
+      A.tref = c->d_tref; A.tcix = c->d_tcix; A.tasks = (SelTask*)c->d_tasks; A.ntasks = c->d_scal + QM_SC_NTASKS;
+      HIPCHK(hipMemsetAsync(c->d_scal + QM_SC_NTASKS, 0, sizeof(u64), c->stream));
+      HIPCHK(qmk_sel_three(&P, &A, c->numCU, c->stream));
+    }
   } else {
     HIPCHK(qmk_pair_count(&P, c->stream));
   }
   HIPCHK(qmk_scan_counts(c->d_scanTmp, c->scanTmpBytes, c->d_cnt, c->d_offs, n + 1, c->stream));
-  long long total = 0;
+  total = 0;
   HIPCHK(hipMemcpyAsync(&total, c->d_offs + n, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -630,9 +733,31 @@ static int map_device_impl(qm_ctx* c, const qm_opts* o, int64_t n, const void* d
   P.hits = c->d_hits;
   if (o->sel_aln) HIPCHK(qmk_sel_compact(&P, c->d_tmp, c->d_toff, c->stream));
   else HIPCHK(qmk_pair_write(&P, c->stream));
+  return QM_OK;
+}
+
+static int map_device_impl(qm_ctx* c, const qm_opts* o, int64_t n, const void* d_seq1, const void* d_off1, const void* d_seq2,
+                           const void* d_off2, int32_t max_read_len, int64_t* n_hits, qm_counters* counters, ChunkFeeder* feeder,
+                           const RunReq& rq = RunReq()) {
+  if (!c || n < 0 || (n > 0 && (!d_seq1 || !d_off1))) return fail(QM_E_ARG, "bad argument");
+  int rc = check_opts(o);
+  if (rc) return rc;
+  if ((d_seq2 == nullptr) != (d_off2 == nullptr)) return fail(QM_E_ARG, "seq2/off2 must both be given or both be null");
+  if (max_read_len > QM_MAX_READ_LEN) return fail(QM_E_TOOLONG, "read length %d > %d", max_read_len, QM_MAX_READ_LEN);
+  HIPCHK(hipSetDevice(c->device));
+  const int ns = max_read_len <= 128 ? 2 : (max_read_len <= 192 ? 3 : 4);   // 64-character slots per read: picks the kernel instantiation
+  const bool paired = d_seq2 != nullptr;
+  u64 hscal[QM_SC_WORDS];
+  c->lastUnits = -1;
+  HIPCHK(hipEventRecord(c->evA, c->stream));
+  RunReq r2 = rq;
+  r2.keepIntervals = rq.keepIntervals || c->debug != 0;
+  if ((rc = run_stage_a(c, o, r2, n, d_seq1, d_off1, d_seq2, d_off2, ns, feeder, hscal))) return rc;
+  long long total = 0;
+  if ((rc = run_stage_b(c, o, r2, n, paired, d_seq1, d_off1, d_seq2, d_off2, hscal, total))) return rc;
   HIPCHK(hipEventRecord(c->evB, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  hipEventElapsedTime(&ms, c->evA, c->evB); c->lastTotalMs = ms;
+  float ms = 0; hipEventElapsedTime(&ms, c->evA, c->evB); c->lastTotalMs = ms;
   c->lastUnits = n; c->lastHits = total; c->lastPaired = paired;
   if (n_hits) *n_hits = total;
   if (counters) {
@@ -671,7 +796,7 @@ static int host_feed_upload(void* self, int64_t u0, int64_t u1) {
 }
 
 static int map_host(qm_ctx* c, const qm_opts* o, int64_t n, const char* seq1, const int64_t* off1, const char* seq2,
-                    const int64_t* off2, int64_t* n_hits, qm_counters* counters) {
+                    const int64_t* off2, int64_t* n_hits, qm_counters* counters, const RunReq& rq) {
   if (!c || n < 0 || (n > 0 && (!seq1 || !off1))) return fail(QM_E_ARG, "bad argument");
   HIPCHK(hipSetDevice(c->device));
   int32_t maxLen = 0; int rc;
@@ -684,8 +809,7 @@ static int map_host(qm_ctx* c, const qm_opts* o, int64_t n, const char* seq1, co
   HostFeed hf = {c, seq1, off1, seq2, off2};
   const char* ce = getenv("QM_HOST_CHUNK");
   ChunkFeeder fd; fd.chunk = ce && atoll(ce) > 0 ? atoll(ce) : (1 << 20); fd.upload = host_feed_upload; fd.self = &hf;
-  if (c->debug) fd.chunk = n > 0 ? n : 1;                 // the interval dump is indexed by absolute read number: one launch
-  rc = map_device_impl(c, o, n, c->d_seq1, c->d_off1, seq2 ? c->d_seq2 : nullptr, seq2 ? c->d_off2 : nullptr, maxLen, n_hits, counters, &fd);
+  rc = map_device_impl(c, o, n, c->d_seq1, c->d_off1, seq2 ? c->d_seq2 : nullptr, seq2 ? c->d_off2 : nullptr, maxLen, n_hits, counters, &fd, rq);
   hipStreamSynchronize(c->copyStream);                     // nothing of the caller's buffers is in flight after return (error paths too)
   return rc;
 }
@@ -693,12 +817,12 @@ static int map_host(qm_ctx* c, const qm_opts* o, int64_t n, const char* seq1, co
 int qm_map_pairs(qm_ctx* c, const qm_opts* o, int64_t n, const char* seq1, const int64_t* off1, const char* seq2,
                  const int64_t* off2, int64_t* n_hits, qm_counters* counters) {
   if (!seq2 || !off2) return fail(QM_E_ARG, "qm_map_pairs needs both mates");
-  return map_host(c, o, n, seq1, off1, seq2, off2, n_hits, counters);
+  return map_host(c, o, n, seq1, off1, seq2, off2, n_hits, counters, RunReq());
 }
 
 int qm_map_reads(qm_ctx* c, const qm_opts* o, int64_t n, const char* seq, const int64_t* off, int64_t* n_hits,
                  qm_counters* counters) {
-  return map_host(c, o, n, seq, off, nullptr, nullptr, n_hits, counters);
+  return map_host(c, o, n, seq, off, nullptr, nullptr, n_hits, counters, RunReq());
 }
 
 int qm_fetch_hits(qm_ctx* c, int64_t* hit_offsets, qm_hit* hits) {
@@ -751,31 +875,202 @@ int qm_result_device(qm_ctx* c, const void** d_hit_offsets, const void** d_hits)
 }
 
 int qm_fetch_intervals(qm_ctx* c, int64_t* int_offsets, qm_sa_interval_hit* ints, int64_t cap) {
-  if (!c || c->lastUnits < 0 || !c->debug || !c->d_dbg) return fail(QM_E_STATE, "no interval dump (enable with qm_ctx_set_debug before mapping)");
+  if (!c || c->lastIvReads < 0) return fail(QM_E_STATE, "no SA-interval hits kept (qm_ctx_set_debug / qm_collect_reads / qm_map_pairs_stages before mapping)");
   if (!int_offsets) return fail(QM_E_ARG, "null int_offsets");
   HIPCHK(hipSetDevice(c->device));
-  int64_t n = c->lastUnits;
-  const int mates = c->lastPaired ? 2 : 1;
-  const int half = c->lastPaired ? QM_DBG_CAP / 2 : QM_DBG_CAP;
-  std::vector<uint32_t> cnt((size_t)n * mates + 1);
-  if (n) HIPCHK(hipMemcpy(cnt.data(), c->d_dbgcnt, (size_t)n * mates * 4, hipMemcpyDeviceToHost));
-  auto kept = [&](int64_t r) { return (int64_t)(cnt[r] < (uint32_t)half ? cnt[r] : (uint32_t)half); };
+  // per unit: a pair's four lists (left fwd, left rc, right fwd, right rc) follow each other; a single read's two
+  const int64_t nreads = c->lastIvReads;
+  const int mates = (c->lastUnits >= 0 && c->lastPaired && c->lastIvReads == 2 * c->lastUnits) ? 2 : 1;
+  const int64_t n = nreads / mates;
+  std::vector<uint32_t> cnt((size_t)nreads + 1); std::vector<long long> off((size_t)nreads + 1);
+  if (nreads) {
+    HIPCHK(hipMemcpy(cnt.data(), c->d_ivcnt, (size_t)nreads * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(off.data(), c->d_ivoff, (size_t)nreads * 8, hipMemcpyDeviceToHost));
+  }
   int_offsets[0] = 0;
   for (int64_t i = 0; i < n; ++i) {
     int64_t t = 0;
-    for (int m = 0; m < mates; ++m) t += kept(i * mates + m);
+    for (int m = 0; m < mates; ++m) t += cnt[(size_t)(i * mates + m)];
     int_offsets[i + 1] = int_offsets[i] + t;
   }
   if (!ints) return QM_OK;
   if (cap < int_offsets[n]) return fail(QM_E_ARG, "interval buffer too small");
-  std::vector<qm_sa_interval_hit> all((size_t)n * QM_DBG_CAP + 1);
-  if (n) HIPCHK(hipMemcpy(all.data(), c->d_dbg, (size_t)n * QM_DBG_CAP * sizeof(qm_sa_interval_hit), hipMemcpyDeviceToHost));
+  std::vector<qm_sa_interval_hit> all((size_t)c->lastIvTotal + 1);
+  if (c->lastIvTotal) HIPCHK(hipMemcpy(all.data(), c->d_iv, (size_t)c->lastIvTotal * sizeof(qm_sa_interval_hit), hipMemcpyDeviceToHost));
+  int64_t w = 0;
+  for (int64_t r = 0; r < nreads; ++r)
+    for (uint32_t j = 0; j < cnt[(size_t)r]; ++j) ints[w++] = all[(size_t)(off[(size_t)r] + j)];
+  return QM_OK;
+}
+
+// ---- the reference's three entry points as calls of their own (include/qmap_rapmap_compat.hpp sits on these) ----------------
+
+static int upload(qm_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (bytes) HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  return QM_OK;
+}
+
+static int map_host(qm_ctx* c, const qm_opts* o, int64_t n, const char* seq1, const int64_t* off1, const char* seq2,
+                    const int64_t* off2, int64_t* n_hits, qm_counters* counters, const RunReq& rq);
+
+int qm_collect_reads(qm_ctx* c, const qm_opts* o, int64_t n, const char* seq, const int64_t* off, int64_t* n_intervals) {
+  if (!c || n < 0 || (n > 0 && (!seq || !off))) return fail(QM_E_ARG, "bad argument");
+  int rc = check_opts(o);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(c->device));
+  static const int64_t zero = 0;
+  if (n == 0) off = &zero;
+  int32_t maxLen = 0;
+  for (int64_t i = 0; i < n; ++i) { const int64_t l = off[i + 1] - off[i]; if (l < 0) return fail(QM_E_ARG, "offsets not monotone"); if (l > maxLen) maxLen = (int32_t)(l > 0x7fffffff ? 0x7fffffff : l); }
+  if (maxLen > QM_MAX_READ_LEN) return fail(QM_E_TOOLONG, "read length %d > %d", maxLen, QM_MAX_READ_LEN);
+  if ((rc = ensure(c->d_seq1, c->capSeq1, off[n] + 64))) return rc;
+  if ((rc = ensure(c->d_off1, c->capOff1, n + 1))) return rc;
+  if ((rc = upload(c, c->d_off1, off, (size_t)(n + 1) * 8))) return rc;
+  if ((rc = upload(c, c->d_seq1, seq, (size_t)off[n]))) return rc;
+  RunReq rq; rq.mode = QM_RUN_COLLECT;
+  u64 hscal[QM_SC_WORDS];
+  c->lastUnits = -1;
+  if ((rc = run_stage_a(c, o, rq, n, c->d_seq1, c->d_off1, nullptr, nullptr, 4, nullptr, hscal))) return rc;
+  if (n_intervals) *n_intervals = c->lastIvTotal;
+  return QM_OK;
+}
+
+int qm_fetch_found(qm_ctx* c, uint8_t* found) {
+  if (!c || c->lastFoundReads < 0) return fail(QM_E_STATE, "no foundHit flags kept by the last call");
+  if (!found) return fail(QM_E_ARG, "null buffer");
+  HIPCHK(hipSetDevice(c->device));
+  if (c->lastFoundReads) HIPCHK(hipMemcpy(found, c->d_found, (size_t)c->lastFoundReads, hipMemcpyDeviceToHost));
+  return QM_OK;
+}
+
+int qm_hits_to_mappings(qm_ctx* c, const qm_opts* o, int64_t n, const int32_t* read_len, const int64_t* int_offsets,
+                        const qm_sa_interval_hit* ints, int64_t* n_words) {
+  if (!c || n < 0 || (n > 0 && (!read_len || !int_offsets))) return fail(QM_E_ARG, "bad argument");
+  int rc = check_opts(o);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(c->device));
+  static const int64_t zero = 0;
+  if (n == 0) int_offsets = &zero;
+  const int64_t ni = int_offsets[n];
+  if (ni > 0 && !ints) return fail(QM_E_ARG, "null intervals");
   for (int64_t i = 0; i < n; ++i) {
-    int64_t w = int_offsets[i];
-    for (int m = 0; m < mates; ++m)
-      for (int64_t j = 0; j < kept(i * mates + m); ++j) ints[w++] = all[(size_t)i * QM_DBG_CAP + (size_t)m * half + j];
+    if (int_offsets[i + 1] < int_offsets[i]) return fail(QM_E_ARG, "interval offsets not monotone");
+    if (read_len[i] < 0 || read_len[i] > QM_MAX_READ_LEN) return fail(QM_E_TOOLONG, "read length %d > %d", read_len[i], QM_MAX_READ_LEN);
+    int nf = 0, nr = 0; bool seenRc = false;
+    for (int64_t j = int_offsets[i]; j < int_offsets[i + 1]; ++j) {
+      if (ints[j].query_rc) { ++nr; seenRc = true; } else { ++nf; if (seenRc) return fail(QM_E_ARG, "read %lld: forward-strand intervals must precede the reverse-complement ones", (long long)i); }
+      if (ints[j].begin < 0 || ints[j].end > c->ix->nSA || ints[j].end < ints[j].begin) return fail(QM_E_ARG, "read %lld: SA interval out of range", (long long)i);
+    }
+    if (nf > QM_ICAP + QM_IOVF || nr > QM_ICAP + QM_IOVF) return fail(QM_E_ARG, "read %lld: more than %d intervals on one strand", (long long)i, QM_ICAP + QM_IOVF);
+  }
+  if ((rc = ensure(c->d_ivIn, c->capIvIn, ni + 1))) return rc;
+  if ((rc = ensure(c->d_ivInOff, c->capIvInOff, n + 1))) return rc;
+  if ((rc = ensure(c->d_lenIn, c->capLenIn, n + 1))) return rc;
+  if ((rc = upload(c, c->d_ivIn, ints, (size_t)ni * sizeof(qm_sa_interval_hit)))) return rc;
+  if ((rc = upload(c, c->d_ivInOff, int_offsets, (size_t)(n + 1) * 8))) return rc;
+  if ((rc = upload(c, c->d_lenIn, read_len, (size_t)n * 4))) return rc;
+  RunReq rq; rq.mode = QM_RUN_FROM_INTERVALS; rq.ivIn = c->d_ivIn; rq.ivInOff = c->d_ivInOff; rq.lenIn = c->d_lenIn;
+  u64 hscal[QM_SC_WORDS];
+  c->lastUnits = -1;
+  // the kernel walks the reads of one "mate"; seq/off are not touched in this mode (a non-null seq1 keeps the argument checks simple)
+  if ((rc = run_stage_a(c, o, rq, n, c->d_lenIn, c->d_ivInOff, nullptr, nullptr, 4, nullptr, hscal))) return rc;
+  if (n_words) {
+    std::vector<uint32_t> cnt((size_t)n + 1);
+    if (n) HIPCHK(hipMemcpy(cnt.data(), c->d_lcnt, (size_t)n * 4, hipMemcpyDeviceToHost));
+    int64_t t = 0; for (int64_t i = 0; i < n; ++i) t += cnt[(size_t)i] & 0x7fffffffu;
+    *n_words = t;
   }
   return QM_OK;
+}
+
+int qm_fetch_read_lists(qm_ctx* c, int64_t* list_offsets, uint64_t* words, int64_t cap) {
+  if (!c || c->lastListReads < 0) return fail(QM_E_STATE, "no per-read hit lists kept by the last call");
+  if (!list_offsets) return fail(QM_E_ARG, "null list_offsets");
+  HIPCHK(hipSetDevice(c->device));
+  const int64_t nreads = c->lastListReads;
+  std::vector<uint32_t> cnt((size_t)nreads + 1); std::vector<long long> off((size_t)nreads + 1);
+  if (nreads) {
+    HIPCHK(hipMemcpy(cnt.data(), c->d_lcnt, (size_t)nreads * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(off.data(), c->d_loff, (size_t)nreads * 8, hipMemcpyDeviceToHost));
+  }
+  list_offsets[0] = 0;
+  for (int64_t r = 0; r < nreads; ++r) list_offsets[r + 1] = list_offsets[r] + (int64_t)(cnt[(size_t)r] & 0x7fffffffu);
+  if (!words) return QM_OK;
+  if (cap < list_offsets[nreads]) return fail(QM_E_ARG, "list buffer too small");
+  // the lists sit in bump-allocated chunks: bring the used part of the buffer down once, gather on the host
+  const int64_t used = c->lastListWords < c->capLists ? c->lastListWords : c->capLists;
+  std::vector<uint64_t> all((size_t)used + 1);
+  if (used) HIPCHK(hipMemcpy(all.data(), c->d_lists, (size_t)used * 8, hipMemcpyDeviceToHost));
+  for (int64_t r = 0; r < nreads; ++r) {
+    const int64_t k = (int64_t)(cnt[(size_t)r] & 0x7fffffffu);
+    if (k) memcpy(words + list_offsets[r], all.data() + off[(size_t)r], (size_t)k * 8);
+  }
+  return QM_OK;
+}
+
+int qm_merge_lists(qm_ctx* c, const qm_opts* o, int64_t n, const int64_t* loff_left, const uint64_t* words_left, const int64_t* loff_right,
+                   const uint64_t* words_right, const uint8_t* found_left, const uint8_t* found_right, const int32_t* len_left,
+                   const int32_t* len_right, int64_t* n_hits, qm_counters* counters) {
+  if (!c || n < 0 || (n > 0 && (!loff_left || !loff_right || !len_left || !len_right))) return fail(QM_E_ARG, "bad argument");
+  int rc = check_opts(o);
+  if (rc) return rc;
+  if (o->sel_aln && !(found_left && found_right)) return fail(QM_E_ARG, "mergeLeftRightHitsFuzzy needs leftMatches / rightMatches");
+  HIPCHK(hipSetDevice(c->device));
+  static const int64_t zero = 0;
+  if (n == 0) { loff_left = &zero; loff_right = &zero; }
+  const int64_t wl = loff_left[n], wr = loff_right[n];
+  if ((wl > 0 && !words_left) || (wr > 0 && !words_right)) return fail(QM_E_ARG, "null list words");
+  // device image: read 2u = left list of unit u, read 2u + 1 = right list; left words first, right words behind them
+  std::vector<uint32_t> cnt((size_t)(2 * n) + 1); std::vector<long long> off((size_t)(2 * n) + 1), o1((size_t)n + 1), o2((size_t)n + 1);
+  const bool flags = o->fuzzy || o->sel_aln;
+  o1[0] = 0; o2[0] = 0;
+  for (int64_t u = 0; u < n; ++u) {
+    const int64_t a = loff_left[u + 1] - loff_left[u], b = loff_right[u + 1] - loff_right[u];
+    if (a < 0 || b < 0 || a > 0x7ffffffe || b > 0x7ffffffe) return fail(QM_E_ARG, "list offsets not monotone");
+    cnt[(size_t)(2 * u)] = (uint32_t)a | ((flags && found_left && found_left[u]) ? 0x80000000u : 0u);
+    cnt[(size_t)(2 * u + 1)] = (uint32_t)b | ((flags && found_right && found_right[u]) ? 0x80000000u : 0u);
+    off[(size_t)(2 * u)] = loff_left[u]; off[(size_t)(2 * u + 1)] = wl + loff_right[u];
+    o1[(size_t)u + 1] = o1[(size_t)u] + len_left[u]; o2[(size_t)u + 1] = o2[(size_t)u] + len_right[u];
+  }
+  if ((rc = ensure(c->d_lcnt, c->capLcnt, 2 * n + 1))) return rc;
+  if ((rc = ensure(c->d_loff, c->capLoff, 2 * n + 1))) return rc;
+  if (c->capLists < wl + wr + 1) { if ((rc = ensure(c->d_lists, c->capLists, wl + wr + 1))) return rc; }
+  if ((rc = ensure(c->d_off1, c->capOff1, n + 1))) return rc;
+  if ((rc = ensure(c->d_off2, c->capOff2, n + 1))) return rc;
+  if ((rc = upload(c, c->d_lcnt, cnt.data(), (size_t)(2 * n) * 4))) return rc;
+  if ((rc = upload(c, c->d_loff, off.data(), (size_t)(2 * n) * 8))) return rc;
+  if ((rc = upload(c, c->d_lists, words_left, (size_t)wl * 8))) return rc;
+  if ((rc = upload(c, c->d_lists + wl, words_right, (size_t)wr * 8))) return rc;
+  if ((rc = upload(c, c->d_off1, o1.data(), (size_t)(n + 1) * 8))) return rc;
+  if ((rc = upload(c, c->d_off2, o2.data(), (size_t)(n + 1) * 8))) return rc;
+  HIPCHK(hipMemsetAsync(c->d_scal, 0, QM_SC_WORDS * sizeof(u64), c->stream));
+  RunReq rq; rq.mergeOnly = true;
+  u64 hscal[QM_SC_WORDS]; long long total = 0;
+  c->lastUnits = -1; c->lastListReads = -1; c->lastIvReads = -1; c->lastFoundReads = -1;
+  if ((rc = run_stage_b(c, o, rq, n, true, nullptr, c->d_off1, nullptr, c->d_off2, hscal, total))) return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->lastUnits = n; c->lastHits = total; c->lastPaired = true; c->lastMapMs = 0; c->lastTotalMs = 0;
+  if (n_hits) *n_hits = total;
+  if (counters) {
+    counters->pe_hits = hscal[1]; counters->se_hits = hscal[2]; counters->tot_hits = hscal[3];
+    counters->num_reads = hscal[4]; counters->too_many_hits = hscal[5]; counters->mapped = hscal[6];
+  }
+  return QM_OK;
+}
+
+int qm_fetch_too_many(qm_ctx* c, uint8_t* too_many) {
+  if (!c || c->lastTooManyUnits < 0) return fail(QM_E_STATE, "no tooManyHits flags kept by the last call");
+  if (!too_many) return fail(QM_E_ARG, "null buffer");
+  HIPCHK(hipSetDevice(c->device));
+  if (c->lastTooManyUnits) HIPCHK(hipMemcpy(too_many, c->d_tooMany, (size_t)c->lastTooManyUnits, hipMemcpyDeviceToHost));
+  return QM_OK;
+}
+
+int qm_map_pairs_stages(qm_ctx* c, const qm_opts* o, int64_t n, const char* seq1, const int64_t* off1, const char* seq2,
+                        const int64_t* off2, int64_t* n_hits, qm_counters* counters) {
+  if (!seq2 || !off2) return fail(QM_E_ARG, "qm_map_pairs_stages needs both mates");
+  RunReq rq; rq.keepIntervals = true; rq.keepFound = true; rq.mergeOnly = true;
+  return map_host(c, o, n, seq1, off1, seq2, off2, n_hits, counters, rq);
 }
 
 int qm_ctx_stat(const qm_ctx* c, int which, int64_t* value) {

@@ -53,6 +53,37 @@ __global__ __launch_bounds__(256, WPS) void qm_read_kernel(DevIndex ix, ReadBatc
 #endif
 }
 
+// Stage entry "from intervals" (hit_manager::hitsToMappingsSimple as a call of its own, include/HitManager.hpp:130-135): one
+// wavefront per read, the read's SA-interval hits come from the caller instead of the collector.  F: 0 or QM_F_SEL.
+template <int F>
+__global__ __launch_bounds__(256, 2) void qm_h2m_kernel(DevIndex ix, ReadBatch B) {
+  __shared__ WaveMem<4> mem[4];
+  __shared__ SelLds<(F & QM_F_SEL) != 0> sels[4];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long long gw = (long long)blockIdx.x * 4 + wave;
+  const long long nw = (long long)gridDim.x * 4;
+  u64* gscr = B.gscratch + gw * QM_GSCR_U64;
+  WaveAlloc wa; wa.base = -1; wa.used = 0;
+  for (long long r = gw; r < B.nreads; r += nw) {
+    const long long read = read_id(B, r);
+    WaveMem<4>& M = mem[wave];
+    IntervalList fi, ri;
+    fi.lds = M.ints[0]; ri.lds = M.ints[1];
+    fi.ovf = (IntRec*)(gscr + 3 * QM_GCAP); ri.ovf = fi.ovf + QM_IOVF;
+    fi.n = 0; ri.n = 0; fi.pf = nullptr; ri.pf = nullptr; fi.pfcap = 0; ri.pfcap = 0;
+    const long long i0 = uniform(B.iv_in_off[read]), i1 = uniform(B.iv_in_off[read + 1]);
+    for (long long i = i0; i < i1; ++i) {
+      const qm_sa_interval_hit h = B.iv_in[i];
+      const int lb = uniform(h.begin), ub = uniform(h.end); const u32 ln = uniform(h.len), qp = uniform(h.query_pos);
+      if (uniform((int)h.query_rc)) ri.push(lb, ub, ln, qp); else fi.push(lb, ub, ln, qp);
+    }
+    const int len = uniform(B.len_in[read]);
+    const bool found = B.found_in ? uniform((int)B.found_in[read]) != 0 : false;
+    finish_read<4, F>(ix, B, read, len, 0, found, M, gscr, wa, fi, ri, (F & QM_F_SEL) ? B.selscr + gw : nullptr, sels[wave].ptr(),
+                      ((F & QM_F_SEL) && B.dyn) ? B.dyn + gw : nullptr);
+  }
+}
+
 // stage B pass 1: hits per unit + the HitCounters
 __global__ __launch_bounds__(256) void qm_pair_count_kernel(PairBatch P) {
   __shared__ unsigned long long sc[6];
@@ -125,6 +156,18 @@ __global__ __launch_bounds__(256) void qm_sel_finish_kernel(PairBatch P, SelBatc
   const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   UnitCounters uc = {0, 0, 0, 0, 0, 0};
   if (u < P.n) P.cnt[u] = (u32)sel_unit_finish(P, A, u, &uc);
+  sel_flush_counters(sc, uc, P.counters);
+}
+
+// -s, stage entry "merge only": mergeLeftRightHitsFuzzy on the position lists into the per-unit temp slots (chain statuses
+// stay parked in aln_score), no alignment
+__global__ __launch_bounds__(256) void qm_sel_merge_kernel(PairBatch P, SelBatch A) {
+  __shared__ unsigned long long sc[6];
+  if (threadIdx.x < 6) sc[threadIdx.x] = 0;
+  __syncthreads();
+  const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  UnitCounters uc = {0, 0, 0, 0, 0, 0};
+  if (u < P.n) P.cnt[u] = (u32)sel_unit_merge(P, A, u, &uc);
   sel_flush_counters(sc, uc, P.counters);
 }
 
@@ -226,6 +269,21 @@ hipError_t qmk_map_reads(const void* ixp, const void* bp, int ns, int grid, int 
   const DevIndex& ix = *(const DevIndex*)ixp;
   const ReadBatch& B = *(const ReadBatch*)bp;
   const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP) | (B.selscr ? QM_F_SEL : 0);
+  if (ns < 0) {        // stage entry "collector only": the NS=4 kernels (every read length up to QM_MAX_READ_LEN) without the second half
+#define QM_LAUNCH_C(F_) hipLaunchKernelGGL((qm_read_kernel<4, 2, (F_) | QM_F_COLLECT>), dim3((unsigned)(grid < num_cu * 2 ? grid : num_cu * 2)), dim3(256), 0, st, ix, B)
+    switch (F) {
+      case 0: QM_LAUNCH_C(0); break;
+      case QM_F_PH: QM_LAUNCH_C(QM_F_PH); break;
+      case QM_F_NIP: QM_LAUNCH_C(QM_F_NIP); break;
+      case QM_F_PH | QM_F_NIP: QM_LAUNCH_C(QM_F_PH | QM_F_NIP); break;
+      case QM_F_SEL: QM_LAUNCH_C(QM_F_SEL); break;
+      case QM_F_SEL | QM_F_PH: QM_LAUNCH_C(QM_F_SEL | QM_F_PH); break;
+      case QM_F_SEL | QM_F_NIP: QM_LAUNCH_C(QM_F_SEL | QM_F_NIP); break;
+      default: QM_LAUNCH_C(QM_F_SEL | QM_F_PH | QM_F_NIP); break;
+    }
+#undef QM_LAUNCH_C
+    return hipGetLastError();
+  }
 #define QM_LAUNCH(NS_, WPS_, F_) do {                                                                          \
     static int nb = 0;                                                                                          \
     if (nb == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, qm_read_kernel<NS_, WPS_, F_>, 256, 0) != hipSuccess || nb < 1)) \
@@ -273,6 +331,20 @@ hipError_t qmk_map_reads(const void* ixp, const void* bp, int ns, int grid, int 
   return hipGetLastError();
 }
 
+hipError_t qmk_h2m(const void* ixp, const void* bp, int grid, int num_cu, hipStream_t st) {
+  const DevIndex& ix = *(const DevIndex*)ixp;
+  const ReadBatch& B = *(const ReadBatch*)bp;
+  const unsigned g = (unsigned)(grid < num_cu * 2 ? grid : num_cu * 2);
+  if (B.selscr) hipLaunchKernelGGL(qm_h2m_kernel<QM_F_SEL>, dim3(g), dim3(256), 0, st, ix, B);
+  else hipLaunchKernelGGL(qm_h2m_kernel<0>, dim3(g), dim3(256), 0, st, ix, B);
+  return hipGetLastError();
+}
+hipError_t qmk_sel_merge(const void* pp, const void* ap, hipStream_t st) {
+  const PairBatch& P = *(const PairBatch*)pp; const SelBatch& A = *(const SelBatch*)ap;
+  if (P.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(qm_sel_merge_kernel, dim3((unsigned)((P.n + 255) / 256)), dim3(256), 0, st, P, A);
+  return hipGetLastError();
+}
 size_t qmk_sel_scratch_bytes(void) { return sizeof(SelScratch); }
 size_t qmk_sel_dyn_struct_bytes(void) { return sizeof(SelScratchDyn); }
 unsigned long long qmk_sel_dyn_bytes(long long n) { return SelScratchDyn::bytes_for(n); }

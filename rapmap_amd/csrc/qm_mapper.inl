@@ -36,7 +36,6 @@ namespace qm {
 #define QM_GCAP 2048   // entries per global-scratch list (2 strands x <1000 SA entries)
 #define QM_ICAP 16     // SA-interval hits per strand kept in LDS (more spill to global scratch)
 #define QM_IOVF 256    // ... overflow capacity per strand (>= 64*NS - k + 1 for NS = 4)
-#define QM_DBG_CAP 64  // debug interval records per unit
 #define QM_CHUNK 4096  // list elements a wave reserves per bump-allocator round trip (>= QM_GCAP)
 #define QM_GSCR_U64 (3 * QM_GCAP + 2 * QM_IOVF * 2)   // u64 words of global scratch per wave
 // slots of the context's scalar block (ReadBatch::cursor points at slot 0): bump pointer, qm_counters[6], status, ksw2 task
@@ -47,6 +46,7 @@ namespace qm {
 #define QM_SC_SLOWCNT 16
 #define QM_SC_SLOWMAX 17
 #define QM_SC_SLOWQ 18
+#define QM_SC_IVCUR 19             // bump pointer of the SA-interval output
 #define QM_LCNT_SLOW 0x7fffffffu   // lcnt value of a read waiting on the slow queue
 
 struct Slot { u64 key; int lb; int ub; };          // hash.bin record / small linear-probing tables, key == ~0 empty
@@ -108,9 +108,13 @@ struct ReadBatch {
   u64* cursor;             // bump pointer
   long long lists_cap;
   u64* gscratch;           // per wave: QM_GSCR_U64 words
-  int* status;             // sticky error flags (bit0: lists overflow, bit1: interval too wide, bit2: read too long)
-  qm_sa_interval_hit* dbg_ints;  // optional [nunits * QM_DBG_CAP]
-  u32* dbg_count;                // optional [nreads]
+  int* status;             // sticky error flags (bit0: lists overflow, bit1: interval too wide, bit2: read too long, bit4: interval output overflow)
+  // SA-interval hits as an output of their own (HitCollectorInfo::fwdSAInts / rcSAInts): read r's records sit at
+  // iv_out[iv_off[r] .. + iv_cnt[r]), forward strand first.  Null unless the caller asked for them.
+  qm_sa_interval_hit* iv_out; u32* iv_cnt; long long* iv_off; long long iv_cap;
+  unsigned char* found_out;      // optional [nreads]: what SACollector::operator() returned
+  // stage entry "from intervals" (qm_h2m_kernel): read r's intervals are iv_in[iv_in_off[r] .. iv_in_off[r + 1]), its length len_in[r]
+  const qm_sa_interval_hit* iv_in; const long long* iv_in_off; const int* len_in; const unsigned char* found_in;
   int strict_check, max_interval;
   int sensitive;           // 0: --noSensitive (NIP skipping via SASearcher::lce, k-mer vote instead of coverage)
   double quasi_cov;
@@ -134,6 +138,10 @@ struct PairBatch {
   qm_hit* hits;            // pass 2 output, CSR order
   u64* counters;           // [6] qm_counters
   int max_num_hits, no_orphans, no_dovetail, fuzzy;
+  // stage entry "merge only": mergeLeftRightHits[Fuzzy] as a call of its own -- none of the caller's bookkeeping that follows
+  // it in processReadsPairSA (the jointHits.size() > maxNumHits clear, --noOrphans, --noDovetail; RapMapSAMapper.cpp:534-551,684-701)
+  int merge_only;
+  unsigned char* too_many;   // optional [n]: the merge's tooManyHits out-parameter
 };
 
 template <int NS>
@@ -272,6 +280,7 @@ __shared__ u64 qm_tim[4][10];
 #define QM_F_PH 1      // perfect-hash (-p) index
 #define QM_F_NIP 2     // --noSensitive: NIP skipping + k-mer vote
 #define QM_F_SEL 4     // --selAln: chain scoring in the collector (MMPs capped at k + maxMMPExtension), coverage slack 1
+#define QM_F_COLLECT 8 // stage entry: the collector alone (intervals + foundHit out, no hit list)
 
 // khash.find for either index flavour.
 // dense: exact lookup in the open-addressing table (RapMapUtils.hpp:65-67).
@@ -1224,23 +1233,32 @@ QM_DEV int list_bound(const IntervalList& a, const IntervalList& b) {
   return tot;
 }
 
-QM_DEV void dump_intervals(const ReadBatch& B, long long read, int list, const IntervalList& L, int& cnt) {
-  // debug records are grouped per unit (pair): mate 0 uses slots [0, CAP/2), mate 1 [CAP/2, CAP)
-  const long long unit = B.seq2 ? (read >> 1) : read;
-  const int half = B.seq2 ? QM_DBG_CAP / 2 : QM_DBG_CAP;
-  const int base = B.seq2 ? (int)(read & 1) * half : 0;
-  for (int i = 0; i < L.n; ++i) {
-    int lb, ub; u32 ln, qp; L.get(i, lb, ub, ln, qp);
-    if (cnt < half) {
+// the read's SA-interval hits to B.iv_out: one reservation per read (a secondary output: the single-word atomic is fine here)
+QM_DEV void dump_intervals(const ReadBatch& B, long long read, int mate, const IntervalList& F, const IntervalList& R) {
+  const int n = F.n + R.n;
+  long long base = 0;
+  if (n > 0) {
+    LV<u64> bv;
+    QM_LANES(l) { bv[l] = 0; if (l == 0) bv[l] = atomic_add_u64(B.cursor + QM_SC_IVCUR, (u64)n); }
+    base = (long long)read_lane(bv, 0);
+  }
+  const bool fits = base + n <= B.iv_cap;
+  if (!fits) { QM_LANES(l) { if (l == 0) *B.status |= 16; } }
+  QM_LANES(l) { if (l == 0) { B.iv_cnt[read] = fits ? (u32)n : 0u; B.iv_off[read] = base; } }
+  if (!fits) return;
+  for (int t = 0; t < 2; ++t) {
+    const IntervalList& L = t == 0 ? F : R;
+    const long long o = base + (t == 0 ? 0 : F.n);
+    for (int i = 0; i < L.n; ++i) {
+      int lb, ub; u32 ln, qp; L.get(i, lb, ub, ln, qp);
       QM_LANES(l) {
         if (l == 0) {
           qm_sa_interval_hit h; h.begin = lb; h.end = ub; h.len = ln; h.query_pos = qp;
-          h.query_rc = (uint8_t)(list & 1); h.list = (uint8_t)list; h.pad = 0;
-          B.dbg_ints[unit * QM_DBG_CAP + base + cnt] = h;
+          h.query_rc = (uint8_t)t; h.list = (uint8_t)(2 * mate + t); h.pad = 0;
+          B.iv_out[o + i] = h;
         }
       }
     }
-    ++cnt;
   }
 }
 
@@ -1302,46 +1320,11 @@ QM_DEV void pre_chars(const ReadBatch& B, long long slot, ReadPre<NS>& P) {
   }
 }
 
+// Second half of a read: SA-interval hits -> the read's hit list in B.lists (hitsToMappingsSimple), shared by the fused
+// kernel and by the stage entry that starts from caller-supplied intervals (qm_h2m_kernel).
 template <int NS, int F>
-QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, const ReadPre<NS>& pre, WaveMem<NS>& M, u64* gscr, WaveAlloc& wa,
-                     SelScratch* ss = nullptr, struct SelScratchLds* sl = nullptr, SelScratchDyn* dyn = nullptr) {
-  const bool paired = B.seq2 != nullptr;
-  const int mate = paired ? (int)(read & 1) : 0;
-  const bool tooLong = pre.len > 64 * NS;
-  if (tooLong) { QM_LANES(l) { if (l == 0) *B.status |= 4; } }
-  // uniform(): the length must stay in an SGPR -- merged into the lane-0 branch above it became a per-lane value and
-  // with it every position, mask and branch of the collector moved from the scalar unit to the VALU
-  const int len = uniform(tooLong ? 64 * NS : pre.len);
-  unsigned char* fs = M.str[0];
-  unsigned char* rs = M.str[1];
-  QM_T(6);
-  LV<bool> dl;
-  QM_LANES(l) { dl[l] = false; }
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    QM_LANES(l) {
-      int idx = 64 * s + l;
-      // the forward read is kept upper-cased (every consumer applies ::toupper anyway, SASearcher.hpp:111,155)
-      if (idx < len) {
-        unsigned char c = (unsigned char)(pre.chars[l] >> (8 * s));
-        fs[idx] = (unsigned char)upc(c); rs[len - 1 - idx] = rc_char(c);
-        dl[l] = dl[l] || c == '$';
-      }
-    }
-  }
-  const bool hasDollar = ballot(dl) != 0;
-  wave_fence();
-  QM_T(0);
-  IntervalList fi, ri;
-  fi.lds = M.ints[0]; ri.lds = M.ints[1];
-  fi.ovf = (IntRec*)(gscr + 3 * QM_GCAP); ri.ovf = fi.ovf + QM_IOVF;
-  const bool foundHit = collect_read<NS, F>(ix, B, M, len, hasDollar, fi, ri);
-  QM_T(4);
-  if (B.dbg_ints) {
-    int dbg = 0;
-    dump_intervals(B, read, 2 * mate, fi, dbg); dump_intervals(B, read, 2 * mate + 1, ri, dbg);
-    QM_LANES(l) { if (l == 0) B.dbg_count[read] = (u32)dbg; }
-  }
+QM_DEV void finish_read(const DevIndex& ix, const ReadBatch& B, long long read, int len, int mate, bool foundHit, WaveMem<NS>& M, u64* gscr,
+                        WaveAlloc& wa, IntervalList& fi, IntervalList& ri, SelScratch* ss, struct SelScratchLds* sl, SelScratchDyn* dyn) {
   Bufs bf;
   int bound = list_bound(fi, ri);
   if (bound <= QM_CAP) { bf.A = M.buf[0]; bf.B = M.buf[1]; bf.R = M.buf[2]; }
@@ -1384,6 +1367,48 @@ QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, con
   const u32 flag = ((B.fuzzy || (F & QM_F_SEL)) && foundHit) ? 0x80000000u : 0u;      // lh / rh of RapMapSAMapper.cpp:472-478
   QM_LANES(l) { if (l == 0) { B.lcnt[read] = (u32)n | flag; B.loff[read] = base; } }
   QM_T(6);
+}
+
+
+template <int NS, int F>
+QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, const ReadPre<NS>& pre, WaveMem<NS>& M, u64* gscr, WaveAlloc& wa,
+                     SelScratch* ss = nullptr, struct SelScratchLds* sl = nullptr, SelScratchDyn* dyn = nullptr) {
+  const bool paired = B.seq2 != nullptr;
+  const int mate = paired ? (int)(read & 1) : 0;
+  const bool tooLong = pre.len > 64 * NS;
+  if (tooLong) { QM_LANES(l) { if (l == 0) *B.status |= 4; } }
+  // uniform(): the length must stay in an SGPR -- merged into the lane-0 branch above it became a per-lane value and
+  // with it every position, mask and branch of the collector moved from the scalar unit to the VALU
+  const int len = uniform(tooLong ? 64 * NS : pre.len);
+  unsigned char* fs = M.str[0];
+  unsigned char* rs = M.str[1];
+  QM_T(6);
+  LV<bool> dl;
+  QM_LANES(l) { dl[l] = false; }
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    QM_LANES(l) {
+      int idx = 64 * s + l;
+      // the forward read is kept upper-cased (every consumer applies ::toupper anyway, SASearcher.hpp:111,155)
+      if (idx < len) {
+        unsigned char c = (unsigned char)(pre.chars[l] >> (8 * s));
+        fs[idx] = (unsigned char)upc(c); rs[len - 1 - idx] = rc_char(c);
+        dl[l] = dl[l] || c == '$';
+      }
+    }
+  }
+  const bool hasDollar = ballot(dl) != 0;
+  wave_fence();
+  QM_T(0);
+  IntervalList fi, ri;
+  fi.lds = M.ints[0]; ri.lds = M.ints[1];
+  fi.ovf = (IntRec*)(gscr + 3 * QM_GCAP); ri.ovf = fi.ovf + QM_IOVF;
+  const bool foundHit = collect_read<NS, F>(ix, B, M, len, hasDollar, fi, ri);
+  QM_T(4);
+  if (B.iv_out) dump_intervals(B, read, mate, fi, ri);
+  if (B.found_out) { QM_LANES(l) { if (l == 0) B.found_out[read] = foundHit ? 1 : 0; } }
+  if (F & QM_F_COLLECT) return;          // stage entry "collector only" (SACollector::operator() as a call of its own)
+  finish_read<NS, F>(ix, B, read, len, mate, foundHit, M, gscr, wa, fi, ri, ss, sl, dyn);
 }
 
 // ------------------------------------------------------------------ stage B: one thread per unit
@@ -1455,7 +1480,7 @@ QM_DEV int unit_merge_fuzzy(const PairBatch& P, long long u, qm_hit* out, int ca
     if (!otherMatched && nx > 0) {
       const int g = fz_groups(X, nx);
       if (uc) { uc->se += (u64)g; uc->pe += (u64)g; }     // jointHits.size() is added to peHits as well (:1176-1179)
-      bool keep = g <= maxHits && !P.no_orphans;          // RapMapSAMapper.cpp:534-551
+      bool keep = P.merge_only || (g <= maxHits && !P.no_orphans);   // RapMapSAMapper.cpp:534-551
       if (keep) {
         for (int i = 0; i < nx;) {
           FzGroup gr = fz_group(X, i, nx); i += gr.width;
@@ -1468,11 +1493,12 @@ QM_DEV int unit_merge_fuzzy(const PairBatch& P, long long u, qm_hit* out, int ca
     }
   } else {
     int i = 0, j = 0, nm = 0, nkeep = 0;
-    bool tooMany = false;
+    bool tooMany = false, sameTxp = false;
     while (i < nl && j < nr) {
       FzGroup a = fz_group(LL, i, nl), b = fz_group(RR, j, nr);
       if (a.tid < b.tid) { i += a.width; continue; }
       if (b.tid < a.tid) { j += b.width; continue; }
+      sameTxp = true;
       int gFR = 0x7fffffff, gRF = 0x7fffffff;
       const bool fwrc = fz_best(a.hasF, a.f, b.hasR, b.r, (int)l1, gFR);   // left fwd, right rc
       const bool rcfw = fz_best(b.hasF, b.f, a.hasR, a.r, (int)l2, gRF);   // right fwd, left rc
@@ -1497,6 +1523,7 @@ QM_DEV int unit_merge_fuzzy(const PairBatch& P, long long u, qm_hit* out, int ca
       i += a.width; j += b.width;
     }
     if (uc && tooMany) uc->tooMany += 1;
+    if (uc && P.too_many) P.too_many[u] = (tooMany ? 1 : 0) | (sameTxp ? 2 : 0);
     if (!tooMany && nm > 0) { if (uc) uc->pe += (u64)nm; cnt = nkeep; }
   }
   if (uc) { uc->tot += (u64)cnt; if (cnt > 0) uc->mapped += 1; }
@@ -1544,6 +1571,7 @@ QM_DEV int unit_merge(const PairBatch& P, long long u, qm_hit* out, int cap, Uni
   }
   const bool tooMany = nm > maxHits;                    // :1233-1234
   if (uc && tooMany) uc->tooMany += 1;
+  if (uc && P.too_many) P.too_many[u] = (tooMany ? 1 : 0) | (nm > 0 ? 2 : 0);
   int cnt = 0;
   if (!tooMany && nm > 0) {
     if (uc) uc->pe += (u64)nm;
@@ -1551,8 +1579,8 @@ QM_DEV int unit_merge(const PairBatch& P, long long u, qm_hit* out, int cap, Uni
   } else if (!tooMany && nl + nr > 0) {
     if (uc) uc->se += (u64)(nl + nr);
     bool keep = true;
-    if (nl + nr > maxHits) keep = false;                // RapMapSAMapper.cpp:534-536
-    if (P.no_orphans) keep = false;                     // :539-551
+    if (nl + nr > maxHits && !P.merge_only) keep = false;   // RapMapSAMapper.cpp:534-536
+    if (P.no_orphans && !P.merge_only) keep = false;        // :539-551
     if (keep) {
       // --noDovetail on orphans: the reference evaluates the predicate with an uninitialised matePos;
       // we define matePos = 0, mateIsFwd = true (same as the oracle).

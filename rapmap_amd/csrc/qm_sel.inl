@@ -796,7 +796,7 @@ QM_DEV int sel_unit_merge(const PairBatch& P, const SelBatch& A, long long u, Un
     h.aln_score = mateStatus == 1 ? q.cs : (q.cs << 4);   // chain status parked: left in bits 0-3, right in bits 4-7
     return h;
   };
-  bool tooMany = false;
+  bool tooMany = false, sameTxp = false;
   if (wl == 0 || wr == 0) {
     const int t = wl == 0 ? 1 : 0;
     const bool otherMatched = wl == 0 ? lh : rh;
@@ -812,6 +812,7 @@ QM_DEV int sel_unit_merge(const PairBatch& P, const SelBatch& A, long long u, Un
       SelG a = sel_group(LL + i), b = sel_group(RR + j);
       if (a.tid < b.tid) { i += a.words; continue; }
       if (b.tid < a.tid) { j += b.words; continue; }
+      sameTxp = true;
       // positions by strand (:991-996)
       const u64* lF = a.rc ? a.O : a.P; const int nlF = a.rc ? a.no : a.np;
       const u64* lR = a.rc ? a.P : a.O; const int nlR = a.rc ? a.np : a.no;
@@ -840,6 +841,8 @@ QM_DEV int sel_unit_merge(const PairBatch& P, const SelBatch& A, long long u, Un
     if (tooMany) { n = 0; if (uc) uc->tooMany += 1; }
     if (uc && n > 0) uc->pe += (u64)n;
   }
+  if (uc && P.too_many) P.too_many[u] = (tooMany ? 1 : 0) | (sameTxp ? 2 : 0);
+  if (P.merge_only) return n;
   if (n > maxHits) n = 0;                                  // :534-536
   if (n > 0 && P.no_orphans && T[0].mate_status != 3) n = 0;   // :539-551
   return n;

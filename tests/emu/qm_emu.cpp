@@ -36,10 +36,10 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
   long long cap = nreads * 4 + 16 * QM_CHUNK;
   std::vector<u64> lists;
   std::vector<u64> gs(QM_GSCR_U64);
-  std::vector<qm_sa_interval_hit> dints((size_t)nunits * QM_DBG_CAP + 1); std::vector<u32> dcnt(nreads + 1, 0);
+  std::vector<qm_sa_interval_hit> dints((size_t)nreads * 600 + 1024); std::vector<u32> dcnt(nreads + 1, 0); std::vector<long long> doff(nreads + 1, 0);
   int status = 0; u64 scal[QM_SC_WORDS]; u64& cursor = scal[0];
   B.lcnt = lcnt.data(); B.loff = loff.data(); B.cursor = scal;
-  B.gscratch = gs.data(); B.status = &status; B.dbg_ints = dints.data(); B.dbg_count = dcnt.data();
+  B.gscratch = gs.data(); B.status = &status; B.iv_out = dints.data(); B.iv_cnt = dcnt.data(); B.iv_off = doff.data(); B.iv_cap = (long long)dints.size();
   B.strict_check = o->strict_check; B.max_interval = o->max_interval; B.quasi_cov = o->quasi_cov; B.sensitive = o->sensitive; B.fuzzy = (seq2 != nullptr) ? o->fuzzy : 0; B.max_mmp_ext = o->max_mmp_extension > 0 ? o->max_mmp_extension : 7;
   static SelScratchLds sellds;                            // used for half of the reads so that both scratch sizes are exercised
   static SelScratch* selscr = nullptr;
@@ -73,7 +73,7 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
       SelScratchDyn dyn; dyn.bind(dmem.data(), need);
       std::vector<long long> q;
       for (long long r = 0; r < nreads; ++r) if (lcnt[r] == QM_LCNT_SLOW) q.push_back(r);
-      ReadBatch S2 = B; S2.slowq = q.data(); S2.dyn = &dyn; S2.nreads = (long long)q.size();
+      ReadBatch S2 = B; S2.slowq = q.data(); S2.dyn = &dyn; S2.nreads = (long long)q.size(); S2.iv_out = nullptr;
       const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP) | QM_F_SEL;
       for (long long r = 0; r < (long long)q.size(); ++r) {
 #define QE_SLOW(NS_, F_) { static WaveMem<NS_> M; ReadPre<NS_> pre; pre_offsets<NS_>(S2, r, pre); pre_chars<NS_>(S2, r, pre); \
@@ -136,19 +136,17 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
   *hits_out = out;
   counters[0] = uc.pe; counters[1] = uc.se; counters[2] = uc.tot; counters[3] = uc.reads;
   counters[4] = uc.tooMany; counters[5] = uc.mapped;
-  const int mates = paired ? 2 : 1, half = paired ? QM_DBG_CAP / 2 : QM_DBG_CAP;
-  auto kept = [&](long long r) { return (long long)(dcnt[r] < (u32)half ? dcnt[r] : (u32)half); };
+  const int mates = paired ? 2 : 1;
   int_offsets[0] = 0;
   for (long long u = 0; u < nunits; ++u) {
     long long t = 0;
-    for (int m = 0; m < mates; ++m) t += kept(u * mates + m);
+    for (int m = 0; m < mates; ++m) t += dcnt[u * mates + m];
     int_offsets[u + 1] = int_offsets[u] + t;
   }
   qm_sa_interval_hit* io = (qm_sa_interval_hit*)malloc(sizeof(qm_sa_interval_hit) * (size_t)(int_offsets[nunits] + 1));
-  for (long long u = 0; u < nunits; ++u) {
-    long long w = int_offsets[u];
-    for (int m = 0; m < mates; ++m)
-      for (long long j = 0; j < kept(u * mates + m); ++j) io[w++] = dints[u * QM_DBG_CAP + m * half + j];
+  {
+    long long w = 0;
+    for (long long r = 0; r < nreads; ++r) for (u32 j = 0; j < dcnt[r]; ++j) io[w++] = dints[(size_t)(doff[r] + j)];
   }
   *ints_out = io;
   *status_out = status | (int)(scal[QM_SC_SLOWCNT] << 8);   // bits 8..: reads that took the slow pass of -s

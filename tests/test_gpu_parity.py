@@ -473,3 +473,50 @@ def test_list_buffer_overflow_relaunches_stage_a(repeat_data, oracle_mod):
     # the grown buffer serves the next call without another relaunch
     gr2 = mp.map_pairs(q1, o1, q2, o2)
     assert mp.stat(0) == 0 and gr2.hits.tobytes() == gr.hits.tobytes()
+
+
+@pytest.mark.parametrize("mode", ["plain", "fuzzy", "chain", "noSensitive"])
+def test_stage_entry_points_compose_to_the_fused_path(synth_small, oracle_mod, mode):
+    """SACollector::operator(), hitsToMappingsSimple and mergeLeftRightHits[Fuzzy] as device calls of their own
+    (qm_collect_reads -> qm_hits_to_mappings -> qm_merge_lists): intervals == the oracle's, and the three chained give what
+    the fused pass (qm_map_pairs_stages) gives"""
+    import rapmap_amd as ra
+    ix, orc = load_oracle(synth_small["idx"])
+    qi, mp = _gpu(synth_small["idx"], debug=False)
+    q1, o1 = pack(synth_small["reads1"]); q2, o2 = pack(synth_small["reads2"])
+    n = len(o1) - 1
+    go = {"plain": {}, "fuzzy": {"fuzzy": 1}, "chain": {"sel_aln": 1, "fuzzy": 1}, "noSensitive": {"sensitive": 0}}[mode]
+    oo = {"plain": {}, "fuzzy": {"fuzzy": 1}, "chain": {"selAln": 1}, "noSensitive": {"sensitive": 0}}[mode]
+    opts = ra.default_opts(**go)
+    res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=4, want_ints=True)
+    # (1) the collector alone, mate by mate
+    fl, iol, il = mp.collect_reads(q1, o1, opts=opts)
+    fr, ior, ir = mp.collect_reads(q2, o2, opts=opts)
+    oi = res.ints; ooff = res.ints_offsets
+    for u in (0, 1, n // 2, n - 1):
+        w = oi[ooff[u]:ooff[u + 1]]
+        left = w[w[:, 5] < 2]; right = w[w[:, 5] >= 2]
+        g = il[iol[u]:iol[u + 1]]; h = ir[ior[u]:ior[u + 1]]
+        assert np.array_equal(left[:, 0], g["begin"]) and np.array_equal(left[:, 1], g["end"]) and np.array_equal(left[:, 3], g["query_pos"].astype(np.int32))
+        assert np.array_equal(right[:, 0], h["begin"]) and np.array_equal(right[:, 2], h["len"].astype(np.int32))
+    assert int(iol[-1] + ior[-1]) == int(ooff[-1])
+    # (2) hits -> mappings from those intervals
+    ll, wl = mp.hits_to_mappings(np.diff(o1), iol, il, opts=opts)
+    lr, wr = mp.hits_to_mappings(np.diff(o2), ior, ir, opts=opts)
+    # (3) the merge
+    mr, too = mp.merge_lists(ll, wl, lr, wr, fl, fr, np.diff(o1), np.diff(o2), opts=opts)
+    fused = mp.map_pairs_stages(q1, o1, q2, o2, opts=opts)
+    assert_hits_equal(fused.hit_offsets, fused.hits, mr.hit_offsets, mr.hits, "staged vs fused (%s)" % mode)
+    assert fused.counters["peHits"] == mr.counters["peHits"] and fused.counters["seHits"] == mr.counters["seHits"]
+    assert fused.counters["tooManyHits"] == mr.counters["tooManyHits"] == int((too & 1).sum())
+    # the fused pass keeps the same per-stage outputs
+    fo, fi_ = mp.intervals(n)
+    assert int(fo[-1]) == int(ooff[-1])
+    flo, fw = mp.read_lists(2 * n)
+    assert np.array_equal(np.diff(flo)[0::2], np.diff(ll)) and np.array_equal(np.diff(flo)[1::2], np.diff(lr))
+    if mode in ("plain", "noSensitive"):
+        # without the caller-level bookkeeping the merge result differs from the driver's only where that bookkeeping acts
+        full = mp.map_pairs(q1, o1, q2, o2, opts=opts)
+        same = np.diff(full.hit_offsets) == np.diff(fused.hit_offsets)
+        assert same.mean() > 0.95
+        assert_hits_equal(res.hit_offsets, res.hits, full.hit_offsets, full.hits, "fused driver path")

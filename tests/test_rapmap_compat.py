@@ -1,0 +1,101 @@
+"""Face 2 of the boundary: include/qmap_rapmap_compat.hpp gives RapMap's own call surface -- SACollector::operator(),
+hit_manager::hitsToMappingsSimple, utils::mergeLeftRightHits[Fuzzy] with the reference's argument lists -- filled from the
+GPU library.  tests/compat/rapmap_caller.cpp is written against the reference's call sequence
+(src/RapMapSAMapper.cpp:466-551) and compiles against that header alone; on the GPU box it must produce the oracle's
+jointHits, from a prefetched chunk and from batches of one alike."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_oracle
+from util import pack
+
+SRC = os.path.join(ROOT, "tests", "compat", "rapmap_caller.cpp")
+
+
+@pytest.fixture(scope="module")
+def caller(tmp_path_factory, lib_built):
+    d = tmp_path_factory.mktemp("compat")
+    exe = str(d / "rapmap_caller")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), SRC, "-o", exe, lib_built,
+                           "-Wl,-rpath," + os.path.dirname(lib_built), "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-pthread"])
+    return exe
+
+
+def test_reference_style_caller_compiles_against_the_header_alone(caller, sample_data):
+    """no include of anything but qmap_rapmap_compat.hpp; opening an index needs no GPU"""
+    text = open(SRC).read()
+    assert [l for l in text.splitlines() if l.startswith('#include "')] == ['#include "qmap_rapmap_compat.hpp"']
+    r = subprocess.run([caller, sample_data["idx"]], capture_output=True, text=True)
+    assert r.returncode == 0 and "k 31 txps 15 ph 0" in r.stdout, r.stdout + r.stderr
+
+
+def _write_pairs(path, r1, r2):
+    with open(path, "w") as f:
+        for a, b in zip(r1, r2):
+            f.write((a.decode() or "-") + " " + (b.decode() or "-") + "\n")
+
+
+def _want(res, n):
+    out = []
+    for i in range(n):
+        hs = res.hits[res.hit_offsets[i]:res.hit_offsets[i + 1]]
+        out.append(" ".join([str(len(hs))] + ["%d:%d:%d:%d%d:%d:%d" % (h["tid"], h["pos"], h["mate_pos"], h["fwd"], h["mate_is_fwd"], h["frag_len"], h["mate_status"]) for h in hs]))
+    c = res.counters
+    out.append("counters %d %d %d %d %d" % (c["peHits"], c["seHits"], c["totHits"], c["numReads"], c["tooManyHits"]))
+    return out
+
+
+def _run(caller, idx, pairs, out, *flags):
+    r = subprocess.run([caller, idx, str(pairs), str(out)] + list(flags), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return open(out).read().splitlines()
+
+
+def _clean(reads):
+    # the pairs file is whitespace separated: keep reads without blanks (all of them here) and map empty reads to "-"
+    return [r for r in reads]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["sample_data", "synth_small"])
+@pytest.mark.parametrize("mode", ["plain", "fuzzy", "noOrphans_m3", "fuzzy_m3"])
+def test_caller_reproduces_the_oracles_joint_hits(caller, sample_data, synth_small, oracle_mod, tmp_path, which, mode):
+    sd = sample_data if which == "sample_data" else synth_small
+    keep = [i for i in range(len(sd["reads1"])) if b" " not in sd["reads1"][i] and b" " not in sd["reads2"][i]][:6000]
+    r1 = [sd["reads1"][i] for i in keep]; r2 = [sd["reads2"][i] for i in keep]
+    _write_pairs(tmp_path / "pairs.txt", r1, r2)
+    oo, flags = {"plain": ({}, []), "fuzzy": ({"fuzzy": 1}, ["--fuzzy"]), "noOrphans_m3": ({"noOrphans": 1, "maxNumHits": 3}, ["--noOrphans", "--maxNumHits", "3"]),
+                 "fuzzy_m3": ({"fuzzy": 1, "maxNumHits": 3}, ["--fuzzy", "--maxNumHits", "3"])}[mode]
+    ix, orc = load_oracle(sd["idx"])
+    q1, o1 = pack(r1); q2, o2 = pack(r2)
+    res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=4)
+    want = _want(res, len(r1))
+    got = _run(caller, sd["idx"], tmp_path / "pairs.txt", tmp_path / "out.txt", *flags)
+    assert got == want, "prefetched chunk: first difference at line %d" % next(i for i, (a, b) in enumerate(zip(got, want)) if a != b)
+    # the same calls as batches of one (no prefetch): a few hundred pairs, one GPU launch per call
+    m = 300
+    _write_pairs(tmp_path / "few.txt", r1[:m], r2[:m])
+    resf = orc.map_pairs(*pack(r1[:m]), *pack(r2[:m]), opts=oracle_mod.default_opts(**oo), nthreads=2)
+    gotf = _run(caller, sd["idx"], tmp_path / "few.txt", tmp_path / "outf.txt", "--no-prefetch", *flags)
+    assert gotf == _want(resf, m)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [[], ["--fuzzy"], ["--chain"]])
+def test_edited_intervals_and_chaining_agree_between_chunk_and_single_calls(caller, synth_small, tmp_path, flags):
+    """a caller that edits hcInfo between the collector and hitsToMappingsSimple gets the edited intervals mapped (the chunk's
+    answer is not used for that read); the chaining configuration (doChaining + considerMultiPos) gives the same jointHits
+    from a chunk and from single calls"""
+    r1 = synth_small["reads1"][:400]; r2 = synth_small["reads2"][:400]
+    keep = [i for i in range(len(r1)) if b" " not in r1[i] and b" " not in r2[i]]
+    _write_pairs(tmp_path / "p.txt", [r1[i] for i in keep], [r2[i] for i in keep])
+    for extra in ([], ["--edit"]):
+        a = _run(caller, synth_small["idx"], tmp_path / "p.txt", tmp_path / "a.txt", *flags, *extra)
+        b = _run(caller, synth_small["idx"], tmp_path / "p.txt", tmp_path / "b.txt", "--no-prefetch", *flags, *extra)
+        assert a == b, (flags, extra)
+    plain = _run(caller, synth_small["idx"], tmp_path / "p.txt", tmp_path / "c.txt", *flags)
+    edited = _run(caller, synth_small["idx"], tmp_path / "p.txt", tmp_path / "d.txt", *flags, "--edit")
+    assert plain != edited, "dropping intervals changed nothing: the edit was not looked at"
