@@ -416,8 +416,7 @@ int qm_ctx_create(const qm_index* ix, int device_id, qm_ctx** out) {
   CK(hipMemcpyAsync(d_offsets, ix->offsets, (size_t)ix->nTxp * 4, hipMemcpyHostToDevice, c->stream));
   CK(qmk_build_sainfo(c->d_SA, ix->nSA, d_offsets, ix->nTxp, c->d_sainfo, c->stream));
   if (!ix->perfect) {
-    c->cap = 16;                                       // buckets of four slots: load factor <= 25 %
-    while (c->cap < (uint64_t)ix->nKeys) c->cap <<= 1;
+    c->cap = bucket_count(ix->nKeys);                  // 32-byte buckets of two slots, at least two buckets per key
     CK(hipMalloc(&c->d_slots, c->cap * sizeof(Bucket)));
     CK(hipMalloc(&d_recs, (size_t)(ix->nKeys > 0 ? ix->nKeys : 1) * 16));
     if (ix->nKeys > 0) CK(hipMemcpyAsync(d_recs, ix->hashRecs, (size_t)ix->nKeys * 16, hipMemcpyHostToDevice, c->stream));

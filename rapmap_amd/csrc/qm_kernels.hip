@@ -6,7 +6,7 @@
 //   build_sainfo_kernel   index flattening: (transcript id, offset) for every SA entry
 //                         (replaces rank9b::rank + txpOffsets lookups on the hot path,
 //                         src/rank9b.cpp:56-61, src/RapMapSAIndex.cpp:92-94)
-//   build_slots_kernel    index flattening: bucketized k-mer table from hash.bin records
+//   build_slots_kernel    index flattening: bucketized k-mer table (32-byte buckets of two slots) from hash.bin records
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <cstdlib>
@@ -23,30 +23,38 @@ template <> struct SelLds<false> { QM_DEV SelScratchLds* ptr() { return nullptr;
 // stage A: one wavefront per read.  WPS = minimum waves per SIMD the register allocator must leave room for.
 // F: compile-time feature flags (QM_F_PH, QM_F_NIP) -- the default kernel carries no optional code.
 template <int NS, int WPS, int F>
-__global__ __launch_bounds__(256, WPS) void qm_read_kernel(DevIndex ix, ReadBatch B) {
+__global__ __launch_bounds__(256, WPS) void qm_read_kernel(DevIndex ix_, ReadBatch B_) {
+  // The two argument structs (~70 dwords) are read through the kernarg segment where they are used -- scalar loads from
+  // constant memory -- instead of being loaded into SGPRs at entry and kept there: at 8 waves/SIMD a wave has 78 SGPRs, and
+  // half of the v_readlane / v_writelane spill traffic of this kernel was for these words.
+  struct Args { DevIndex ix; ReadBatch B; };
+  typedef const Args __attribute__((address_space(4)))* AP4;
+  const Args* args = (const Args*)(AP4)__builtin_amdgcn_kernarg_segment_ptr();
+  const DevIndex& ix = args->ix; const ReadBatch& B = args->B;
   __shared__ WaveMem<NS> mem[4];
   __shared__ SelLds<(F & QM_F_SEL) != 0> sels[4];       // -s kernels only: lane 0's chaining scratch
   // the wave index is wave-uniform: keep it (and every address derived from it) on the scalar unit
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const long long gw = (long long)blockIdx.x * 4 + wave;
-  const long long nw = (long long)gridDim.x * 4;
-  u64* gscr = B.gscratch + gw * QM_GSCR_U64;
+  const int gw = (int)blockIdx.x * 4 + wave;             // reads per launch < 2^31: 32-bit slot arithmetic
+  const int nw = (int)gridDim.x * 4;
+  const int nreads = (int)B.nreads;
+  u64* gscr = B.gscratch + (long long)gw * QM_GSCR_U64;
   WaveAlloc wa; wa.base = -1; wa.used = 0;
 #ifdef QM_TIMING
   if ((threadIdx.x & 63) == 0) { for (int i = 0; i < 9; ++i) qm_tim[wave][i] = 0; qm_tim[wave][9] = __builtin_readcyclecounter(); }
 #endif
-  // reads r, r + nw, ...: characters of the next read and offsets of the one after are in flight while a read is mapped
-  ReadPre<NS> cur, nxt;
-  pre_offsets<NS>(B, gw, cur);
-  pre_chars<NS>(B, gw, cur);
-  pre_offsets<NS>(B, gw + nw, cur);
-  for (long long r = gw; r < B.nreads; r += nw) {
-    nxt = cur;
-    pre_chars<NS>(B, r + nw, nxt);
-    pre_offsets<NS>(B, r + 2 * nw, nxt);
-    map_read<NS, F>(ix, B, read_id(B, r), cur, mem[wave], gscr, wa, (F & QM_F_SEL) ? B.selscr + gw : nullptr, sels[wave].ptr(),
+  // reads gw, gw + nw, ...: characters of the next read and offsets of the one after are staged in LDS while a read is mapped
+  WaveMem<NS>& M = mem[wave];
+  stage_offsets<NS, F>(B, gw, M, 0);
+  lds_dma_wait();
+  stage_chars<NS, F>(B, gw, M, 0);
+  stage_offsets<NS, F>(B, gw + nw, M, 1);
+  lds_dma_wait();
+  int par = 0;
+  for (int r = gw; r < nreads; r += nw) {
+    map_read<NS, F>(ix, B, read_id<F>(B, r), r, nw, par, M, gscr, wa, (F & QM_F_SEL) ? B.selscr + gw : nullptr, sels[wave].ptr(),
                     ((F & QM_F_SEL) && B.dyn) ? B.dyn + gw : nullptr);
-    cur = nxt;
+    par ^= 1;
   }
 #ifdef QM_TIMING
   if ((threadIdx.x & 63) == 0) for (int i = 0; i < 7; ++i) atomicAdd((unsigned long long*)&B.cursor[20 + i], (unsigned long long)qm_tim[wave][i]);
@@ -65,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void qm_h2m_kernel(DevIndex ix, ReadBatch B
   u64* gscr = B.gscratch + gw * QM_GSCR_U64;
   WaveAlloc wa; wa.base = -1; wa.used = 0;
   for (long long r = gw; r < B.nreads; r += nw) {
-    const long long read = read_id(B, r);
+    const long long read = read_id<F>(B, r);
     WaveMem<4>& M = mem[wave];
     IntervalList fi, ri;
     fi.lds = M.ints[0]; ri.lds = M.ints[1];
@@ -204,11 +212,11 @@ __global__ void build_slots_kernel(const Slot* recs, long long K, Bucket* bucket
   long long stride = (long long)gridDim.x * blockDim.x;
   for (; i < K; i += stride) {
     Slot r = recs[i];
-    u64 b = hash_mix(r.key) & hmask;
+    u64 b = (u64)bucket_hash(r.key) & hmask;
     while (true) {
       Bucket* bk = &buckets[b];
       int got = -1;
-      for (int t = 0; t < 4 && got < 0; ++t)
+      for (int t = 0; t < 2 && got < 0; ++t)
         if (atomicCAS((unsigned long long*)&bk->key[t], ~0ULL, r.key) == ~0ULL) got = t;
       if (got >= 0) { bk->val[got].lb = r.lb; bk->val[got].ub = r.ub; break; }
       atomicOr((unsigned long long*)&bk->key[0], QM_BK_OVF);      // full: remember that lookups must walk on

@@ -51,13 +51,22 @@ namespace qm {
 
 struct Slot { u64 key; int lb; int ub; };          // hash.bin record / small linear-probing tables, key == ~0 empty
 struct Iv { int lb, ub; };                         // seed interval
-// Dense k-mer table: one 64-byte bucket (= one HBM sector) of four keys and four intervals per hash value, so a
-// lookup is a single round of loads with no probe chain.  Keys are 2k <= 62 bits; ~0 marks an empty slot, bit 63
-// of key[0] says "a key that hashes here was placed in a later bucket" (the only case a lookup walks on).
-struct Bucket { u64 key[4]; Iv val[4]; };          // 64 B; hipMalloc aligns the array
+// Dense k-mer table: 32-byte buckets of two keys and their two intervals, two buckets to an HBM sector, at least two
+// buckets per key (load <= 25 % of the slots).  A lookup is ONE round of two 16-byte loads -- the keys and, in the same
+// round, the intervals -- with no probe chain and no dependent load for the value.  Keys are 2k <= 62 bits; ~0 marks an
+// empty slot, bit 63 of key[0] says "a key that hashes here was placed in a later bucket" (the only case a lookup walks
+// on: 0.4 % of the buckets at this load).
+struct Bucket { u64 key[2]; Iv val[2]; };          // 32 B; hipMalloc aligns the array
 #define QM_BK_OVF (1ULL << 63)
 QM_DEV u64 hash_mix(u64 x);
-QM_DEV u64 bucket_count(long long nkeys) { u64 c = 16; while (c < (u64)nkeys) c <<= 1; return c; }
+inline constexpr u64 bucket_count(long long nkeys) { u64 c = 32; while (c < 2 * (u64)nkeys) c <<= 1; return c; }   // host + device
+// Bucket of a key: one 32 x 32 -> 64-bit multiply of the key's two halves, folded (the core of wyhash / "mum").  On the
+// k-mers of a transcriptome it fills the buckets like the two-multiply 64-bit finaliser it replaced (Poisson occupancy,
+// measured), at a fifth of the issue slots -- 32-bit integer multiplies are quarter rate on this chip.
+QM_DEV u32 bucket_hash(u64 key) {
+  const u64 p = (u64)((u32)key ^ 0x9E3779B1u) * (u64)((u32)(key >> 32) ^ 0x85EBCA6Bu);
+  return (u32)(p >> 32) ^ (u32)p;
+}
 struct SaInfo { u32 tid; int pos; };               // transcript id + offset in transcript of SA[i]
 struct IntRec { int b, e; u32 len, q; };           // SAIntervalHit (RapMapUtils.hpp:516-525)
 
@@ -151,6 +160,9 @@ struct WaveMem {
   u64 planes[2][4][NS + 2];        // per strand: packed 2-bit read (2 rows), N mask, non-ACGT mask
   IntRec ints[2][QM_ICAP];         // recorded SA-interval hits, fwd / rc strand
   alignas(8) unsigned char str[2][64 * NS + 16];   // read, reverseRead(read) (+16: 8-byte over-reads)
+  // software pipeline of the persistent loop (see ReadStage below): raw characters of the next read, offsets of the next two
+  u32 stage[64 * ((16 * NS + 1 + 63) / 64)];
+  u32 ostage[2][4];
 };
 
 // ------------------------------------------------------------------ bit helpers
@@ -322,17 +334,17 @@ QM_DEV bool text_kmer(const DevIndex& ix, long long pos, int k, u64& w) {
 template <int F>
 QM_DEV bool find_kmer(const DevIndex& ix, u64 key, int& lb, int& ub) {
   if (!(F & QM_F_PH)) {
-    u64 b = hash_mix(key) & ix.hmask;
+    u64 b = (u64)bucket_hash(key) & ix.hmask;
     QM_CNT(0, 1);
     while (true) {
       const Bucket* bk = &ix.slots[b];
       U4 a, c;
-      load_32(&bk->key[0], a, c);                       // the four keys
+      load_32(bk, a, c);                                // both keys, both intervals: one round
       QM_CNT(1, 1);
-      const u64 k0r = ((u64)a.y << 32) | a.x, k1 = ((u64)a.w << 32) | a.z, k2 = ((u64)c.y << 32) | c.x, k3 = ((u64)c.w << 32) | c.z;
+      const u64 k0r = ((u64)a.y << 32) | a.x, k1 = ((u64)a.w << 32) | a.z;
       const u64 k0 = k0r == ~0ULL ? k0r : (k0r & ~QM_BK_OVF);
-      const int m = k0 == key ? 0 : (k1 == key ? 1 : (k2 == key ? 2 : (k3 == key ? 3 : -1)));
-      if (m >= 0) { const Iv v = bk->val[m]; lb = v.lb; ub = v.ub; return true; }
+      if (k0 == key) { lb = (int)c.x; ub = (int)c.y; return true; }
+      if (k1 == key) { lb = (int)c.z; ub = (int)c.w; return true; }
       if (k0r == ~0ULL || !(k0r & QM_BK_OVF)) return false;
       b = (b + 1) & ix.hmask;
     }
@@ -428,6 +440,37 @@ struct Strand {
   int P;
 };
 
+// ---- four characters at a time (one dword per lane) ----
+// 0x80 in every byte of x that equals c (exact zero-byte test of x ^ cccc)
+QM_DEV u32 eq_bytes(u32 x, u32 c) {
+  const u32 t = x ^ (c * 0x01010101u);
+  return ~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t | 0x7f7f7f7fu);
+}
+// bit j = bit 7 of byte j
+QM_DEV u32 movemask4(u32 m) { return (((m >> 7) & 0x01010101u) * 0x01020408u) >> 24; }
+// ::toupper of every byte (C locale: only 'a'..'z' change)
+QM_DEV u32 upcase4(u32 d) {
+  const u32 lo = d & 0x7f7f7f7fu;
+  const u32 ge_a = lo + 0x1f1f1f1fu, gt_z = lo + 0x05050505u;          // bit 7: byte >= 'a' / byte > 'z'
+  const u32 lower = ge_a & ~gt_z & ~d & 0x80808080u;
+  return d ^ (lower >> 2);
+}
+// canonical upper-case letter of every byte whose low three bits name one of A C G T [U] (0xFF elsewhere): a byte b is that
+// nucleotide, in either case, exactly when (b & 0xDF) equals it
+QM_DEV u32 canon4(u32 d, bool withU) {
+  // index: 1 'A', 3 'C', 4 'T', 5 'U', 7 'G'
+  return perm8(withU ? 0x47ff5554u : 0x47ffff54u, 0x43ff41ffu, d & 0x07070707u);
+}
+// src/RapMapUtils.cpp:63-72 reverseRead table, four characters: A<->T, C<->G, U->A, everything else 'N' (byte order kept)
+QM_DEV u32 rc_char4(u32 d) {
+  const u32 canon = canon4(d, true);
+  const u32 t = (d & 0xdfdfdfdfu) ^ canon;
+  const u32 valid = ~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t | 0x7f7f7f7fu);    // 0x80 where the byte is A C G T U (either case)
+  const u32 comp = perm8(0x43ff4141u, 0x47ff54ffu, d & 0x07070707u);           // 1->'T' 3->'G' 4->'A' 5->'A' 7->'C'
+  const u32 vm = (valid >> 7) * 0xffu;
+  return (comp & vm) | (0x4e4e4e4eu & ~vm);
+}
+
 // LDS image of one strand ("planes", [4][NS+2] u64): rows 0-1 hold the read packed 2 bits per base,
 // 32 bases per word, first base in the highest bits (PK[0 .. 2NS], one zero word of padding); row 2 the
 // 'N' mask and row 3 the non-ACGT mask, one bit per base (NS words + two words of padding: 0 / ~0).
@@ -458,32 +501,70 @@ QM_DEV void setup_strand(const DevIndex& ix, const unsigned char* str, int L, St
   const int P = L - k + 1;
   QM_CNT(2, 1); QM_T(4);
   S.planes = planes; S.tab = tab; S.P = P;
-  QM_LANES(l) {
-    if (l < 2 * NS + 2) planes[l] = 0;                                   // packed words (+ padding)
-    if (l < 2) { planes[2 * (NS + 2) + NS + l] = 0; planes[3 * (NS + 2) + NS + l] = ~0ULL; }
-  }
-  wave_fence();
+  // Four characters per lane, straight from the string's words in LDS: SWAR classification, the four 2-bit codes of a lane
+  // folded into one byte of the packed image by a multiply, the mask nibbles of two neighbouring lanes joined over DPP --
+  // every byte of the image is written exactly once (no zeroing pass, no LDS atomics, no ballots).
+  unsigned char* PKb = (unsigned char*)planes;
+  unsigned char* NMb = (unsigned char*)(planes + 2 * (NS + 2));
+  unsigned char* IVb = (unsigned char*)(planes + 3 * (NS + 2));
+  constexpr int NC = (NS + 3) / 4;
+  u64 dirty = 0;                                                           // lanes holding a character that is not A C G T
 #pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    LV<bool> nn, iv;
+  for (int c = 0; c < NC; ++c) {
+    LV<u32> nn, iv, nn2, iv2; LV<bool> bad;
     QM_LANES(l) {
-      int idx = 64 * s + l;
-      unsigned char c = idx < L ? str[idx] : 0;
-      unsigned char cl = c | 0x20;
-      bool valid = idx < L && (cl == 'a' || cl == 'c' || cl == 'g' || cl == 't');
-      int x = (c >> 1) & 3;
-      u64 code = (u64)(x ^ (x >> 1));   // A0 C1 G2 T3 (Kmer.hpp:40-51)
-      // every lane ORs its 2-bit code into the packed word (one LDS atomic instead of a scalar bit interleave)
-      if (valid && code) atomic_or_u64(&planes[idx >> 5], code << (62 - 2 * (idx & 31)));
-      nn[l] = idx < L && cl == 'n';
-      iv[l] = !valid;
+      const int base = 256 * c + 4 * l;
+      u32 pk = 0, nnib = 0, vnib = 0;
+      bad[l] = false;
+      if (base < 64 * NS) {
+        const u32 d = ((const u32*)str)[base >> 2];
+        const int nb = L - base;                                          // characters of this word inside the read
+        const u32 lenmask = nb >= 4 ? 0xffffffffu : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
+        const u32 t = (d & 0xdfdfdfdfu) ^ canon4(d, false);
+        const u32 valid = ~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t | 0x7f7f7f7fu) & lenmask;    // 0x80: A C G T in either case
+        const u32 nmask = eq_bytes(d | 0x20202020u, (u32)'n') & lenmask;
+        const u32 x = (d >> 1) & 0x03030303u;
+        const u32 code = (x ^ ((x >> 1) & 0x01010101u)) & ((valid >> 7) * 3u);                  // A0 C1 G2 T3 (Kmer.hpp:40-51)
+        pk = (code * 0x40100401u) >> 24;                                                        // first character in the top bits
+        nnib = movemask4(nmask); vnib = movemask4(valid);
+        bad[l] = (~valid & lenmask & 0x80808080u) != 0;
+      }
+      const int bi = 64 * c + l;                                          // byte of the packed image: characters 4 bi .. 4 bi + 3
+      if ((bi >> 3) < 2 * NS + 2) PKb[8 * (bi >> 3) + 7 - (bi & 7)] = (unsigned char)pk;
+      nn[l] = nnib; iv[l] = (~vnib) & 0xfu;
     }
-    u64 m2 = ballot(nn), m3 = ballot(iv);
+    dirty |= ballot(bad);
+    lane_xor1(nn, nn2); lane_xor1(iv, iv2);
     QM_LANES(l) {
-      if (l == 0) { planes[2 * (NS + 2) + s] = m2; planes[3 * (NS + 2) + s] = m3; }
+      const int mb = 32 * c + (l >> 1);                                   // byte of the masks: characters 8 mb .. 8 mb + 7
+      if (!(l & 1) && mb < 8 * (NS + 2)) { NMb[mb] = (unsigned char)(nn[l] | (nn2[l] << 4)); IVb[mb] = (unsigned char)(iv[l] | (iv2[l] << 4)); }
     }
   }
+  QM_LANES(l) {                                                           // padding words the lanes above do not reach
+    if (2 * NS + 2 > 8 * NC && l < 2 * NS + 2 - 8 * NC) planes[8 * NC + l] = 0;
+    if (NS + 2 > 4 * NC && l < NS + 2 - 4 * NC) { planes[2 * (NS + 2) + 4 * NC + l] = 0; planes[3 * (NS + 2) + 4 * NC + l] = ~0ULL; }
+  }
   wave_fence();
+  if (!dirty) {
+    // nearly every read: nothing but A C G T, so no window holds an N or a partial word -- the k-mer at p is one funnel
+    // shift of two packed words and the only thing to test is the homopolymer rule
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      LV<bool> e;
+      QM_LANES(l) {
+        const int p = 64 * s + l;
+        const int j = p >> 5, sh = 2 * (p & 31);
+        const u64 w = ((planes[j] << sh) | ((planes[j + 1] >> 1) >> (63 - sh))) >> (64 - 2 * k);
+        const bool inP = p < P;
+        e[l] = inP && !homopolymer(w, k);
+        if (inP) ((u64*)tab)[p] = w;
+      }
+      S.E.w[s] = ballot(e); S.E2.w[s] = S.E.w[s];
+      S.K.w[s] = 0; S.F.w[s] = 0; S.C.w[s] = 0; S.V.w[s] = 0;
+    }
+    QM_T(1);
+    return;
+  }
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     LV<bool> e, e2;
@@ -1272,51 +1353,55 @@ QM_DEV int sel_hits_to_mappings(const DevIndex& ix, const ReadBatch& B, const In
 // One read: load -> collect -> hits->mappings -> list to global memory.
 struct WaveAlloc { long long base; int used; };   // the wave's current chunk of B.lists (wave-uniform)
 
-// Software pipeline of the persistent loop: the offsets of the read after next and the characters of the next
-// read are requested before the current read is processed, so the two dependent round trips that start a read
-// (offsets -> characters) overlap with the previous read's work.
-template <int NS>
-struct ReadPre {
-  long long o0; int len;       // next read: start offset and length (uniform)
-  long long p0, p1;            // read after next: offsets (uniform once consumed)
-  LV<u32> chars;               // lane l: characters 64*s + l of the next read, s = 0..NS-1, one byte each
-};
+// Software pipeline of the persistent loop: the offsets of the read after next and the characters of the next read are
+// requested while the current read is processed, so the two dependent round trips that start a read (offsets ->
+// characters) overlap with it.  Both requests are LDS-direct loads (global_load_lds_dword: the data goes from memory
+// straight into the wave's staging rows, no destination register), because a prefetch held in registers does not survive
+// this compiler: scalar loads have to land in SGPRs that stay live across the whole read (it waited for them on the spot
+// and spilled them), vector loads are waited for wherever their registers are next written or packed, and any wait that
+// follows the previous read's list stores also waits for those stores (gfx9 counts loads and stores in one vmcnt).  With
+// LDS staging the only wait is the one finish_read places before its stores, by which time the loads have long landed.
+//   stage[]    raw bytes of the next read, fetched as aligned dwords from (src + o0) & ~3 on
+//   ostage[j]  two offsets (4 dwords) of a read: slot parity j holds the current read's, j ^ 1 the next one's
 // slot of a launch -> read: the identity, except in the slow pass of -s (the launch walks the slow queue)
-QM_DEV long long read_id(const ReadBatch& B, long long slot) { return B.slowq ? uniform(B.slowq[slot]) : slot; }
+template <int F>
+QM_DEV long long read_id(const ReadBatch& B, long long slot) {
+  if (!(F & QM_F_SEL)) return slot;
+  return B.slowq ? uniform(B.slowq[slot]) : slot;
+}
 QM_DEV void read_src(const ReadBatch& B, long long read, const unsigned char*& src, const long long*& off, long long& unit) {
-  const bool paired = B.seq2 != nullptr;
-  const int mate = paired ? (int)(read & 1) : 0;
-  unit = paired ? (read >> 1) : read;
-  src = mate == 0 ? B.seq1 : B.seq2;
-  off = mate == 0 ? B.off1 : B.off2;
+  // seq1, off1, seq2, off2 sit next to each other in ReadBatch: mate m's pair of pointers is one indexed scalar load
+  const int paired = B.seq2 != nullptr ? 1 : 0;
+  const int mate = (int)(read & paired);
+  unit = read >> paired;
+  src = (&B.seq1)[2 * mate];
+  off = (const long long*)(&B.seq1)[2 * mate + 1];
 }
-// request the offsets of `read` (no use of the result here)
-template <int NS>
-QM_DEV void pre_offsets(const ReadBatch& B, long long slot, ReadPre<NS>& P) {
-  P.p0 = 0; P.p1 = 0;
+// request the two offsets of the read in `slot` into ostage[par]
+template <int NS, int F>
+QM_DEV void stage_offsets(const ReadBatch& B, long long slot, WaveMem<NS>& M, int par) {
   if (slot >= B.nreads) return;
   const unsigned char* src; const long long* off; long long unit;
-  read_src(B, read_id(B, slot), src, off, unit);
-  P.p0 = load_uniform_i64(off + unit); P.p1 = load_uniform_i64(off + unit + 1);
+  read_src(B, read_id<F>(B, slot), src, off, unit);
+  QM_LANES(l) { if (l < 4) lds_dma_u32((const u32*)(off + unit) + l, M.ostage[par], l); }
 }
-// turn the pending offsets (which belong to `read`) into character loads
-template <int NS>
-QM_DEV void pre_chars(const ReadBatch& B, long long slot, ReadPre<NS>& P) {
-  P.o0 = 0; P.len = 0;
-  QM_LANES(l) { P.chars[l] = 0; }
+QM_DEV long long staged_offset(const u32* o, int j) { return (long long)(((u64)uniform(o[2 * j + 1]) << 32) | (u64)uniform(o[2 * j])); }
+// turn the offsets in ostage[par] (which belong to the read in `slot`, and have landed) into the request for its characters
+template <int NS, int F>
+QM_DEV void stage_chars(const ReadBatch& B, long long slot, WaveMem<NS>& M, int par) {
   if (slot >= B.nreads) return;
   const unsigned char* src; const long long* off; long long unit;
-  read_src(B, read_id(B, slot), src, off, unit);
-  const long long o0 = uniform(P.p0), o1 = uniform(P.p1);
+  read_src(B, read_id<F>(B, slot), src, off, unit);
+  const long long o0 = staged_offset(M.ostage[par], 0), o1 = staged_offset(M.ostage[par], 1);
   int len = (int)(o1 - o0);
-  P.o0 = o0; P.len = len;
   if (len > 64 * NS) len = 64 * NS;
+  const unsigned char* p = src + o0;
+  const int mis = (int)((unsigned long long)p & 3ULL);
+  const u32* g = (const u32*)(p - mis);                                  // aligned: never reads past the word holding the last character
+  const int nd = (mis + len + 3) >> 2;
 #pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    QM_LANES(l) {
-      int idx = 64 * s + l;
-      if (idx < len) P.chars[l] |= (u32)src[o0 + idx] << (8 * s);
-    }
+  for (int c = 0; c < (16 * NS + 1 + 63) / 64; ++c) {
+    if (64 * c < nd) { QM_LANES(l) { if (64 * c + l < nd) lds_dma_u32(g + 64 * c + l, M.stage + 64 * c, l); } }
   }
 }
 
@@ -1344,6 +1429,9 @@ QM_DEV void finish_read(const DevIndex& ix, const ReadBatch& B, long long read, 
   }
   if (!(F & QM_F_SEL)) listSrc = bf.R;
   QM_T(5);
+  // Everything this wave has in flight -- the staged prefetch of the next read -- lands before the first store: a later
+  // wait could not tell the loads from the stores (one counter), and the next iteration reads the staging rows without one.
+  lds_dma_wait();
   // hand the list to stage B.  One returning atomic on a single word saturates at ~88 M/s on this chip
   // (MI355X_MICROARCH.md "dequeue"), far below the read rate, so a wave reserves QM_CHUNK elements at
   // a time and sub-allocates from its chunk.
@@ -1370,41 +1458,60 @@ QM_DEV void finish_read(const DevIndex& ix, const ReadBatch& B, long long read, 
 }
 
 
+// slot: position in the launch (the pipeline prefetches slot + nw and slot + 2 nw); par: parity of the iteration
 template <int NS, int F>
-QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, const ReadPre<NS>& pre, WaveMem<NS>& M, u64* gscr, WaveAlloc& wa,
+QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, long long slot, long long nw, int par, WaveMem<NS>& M, u64* gscr, WaveAlloc& wa,
                      SelScratch* ss = nullptr, struct SelScratchLds* sl = nullptr, SelScratchDyn* dyn = nullptr) {
   const bool paired = B.seq2 != nullptr;
   const int mate = paired ? (int)(read & 1) : 0;
-  const bool tooLong = pre.len > 64 * NS;
+  // this read's offsets and raw characters were staged while the previous read was mapped
+  const long long o0 = staged_offset(M.ostage[par], 0), o1 = staged_offset(M.ostage[par], 1);
+  const int rawLen = (int)(o1 - o0);
+  const bool tooLong = rawLen > 64 * NS;
   if (tooLong) { QM_LANES(l) { if (l == 0) *B.status |= 4; } }
   // uniform(): the length must stay in an SGPR -- merged into the lane-0 branch above it became a per-lane value and
   // with it every position, mask and branch of the collector moved from the scalar unit to the VALU
-  const int len = uniform(tooLong ? 64 * NS : pre.len);
+  const int len = uniform(tooLong ? 64 * NS : rawLen);
+  int mis;
+  { const unsigned char* src; const long long* off; long long unit; read_src(B, read, src, off, unit); mis = (int)((unsigned long long)(src + o0) & 3ULL); }
   unsigned char* fs = M.str[0];
   unsigned char* rs = M.str[1];
   QM_T(6);
+  // four characters per lane: the upper-cased read goes to fs as whole words (every consumer applies ::toupper anyway,
+  // SASearcher.hpp:111,155), reverseRead() of it (src/RapMapUtils.cpp:107-128) byte by byte to rs
   LV<bool> dl;
   QM_LANES(l) { dl[l] = false; }
 #pragma unroll
-  for (int s = 0; s < NS; ++s) {
+  for (int c = 0; c < (NS + 3) / 4; ++c) {
     QM_LANES(l) {
-      int idx = 64 * s + l;
-      // the forward read is kept upper-cased (every consumer applies ::toupper anyway, SASearcher.hpp:111,155)
-      if (idx < len) {
-        unsigned char c = (unsigned char)(pre.chars[l] >> (8 * s));
-        fs[idx] = (unsigned char)upc(c); rs[len - 1 - idx] = rc_char(c);
-        dl[l] = dl[l] || c == '$';
+      const int base = 256 * c + 4 * l;
+      if (base < len) {
+        const u32 w0 = M.stage[64 * c + l], w1 = M.stage[64 * c + l + 1];   // (the row has a spare word behind the last one read)
+        const u32 d = align_bytes(w1, w0, mis);                            // characters base .. base + 3
+        const int nb = len - base < 4 ? len - base : 4;
+        const u32 lenmask = nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
+        ((u32*)fs)[base >> 2] = upcase4(d);
+        const u32 rc = rc_char4(d);                        // byte j = complement of character base + j
+        rs[len - 1 - base] = (unsigned char)rc;
+        if (nb > 1) rs[len - 2 - base] = (unsigned char)(rc >> 8);
+        if (nb > 2) rs[len - 3 - base] = (unsigned char)(rc >> 16);
+        if (nb > 3) rs[len - 4 - base] = (unsigned char)(rc >> 24);
+        dl[l] = dl[l] || (eq_bytes(d, (u32)'$') & lenmask) != 0;
       }
     }
   }
   const bool hasDollar = ballot(dl) != 0;
   wave_fence();
+  // the staging rows are free again: next read's characters, and the offsets of the one after it
+  stage_chars<NS, F>(B, slot + nw, M, par ^ 1);
+  stage_offsets<NS, F>(B, slot + 2 * nw, M, par);
   QM_T(0);
   IntervalList fi, ri;
   fi.lds = M.ints[0]; ri.lds = M.ints[1];
   fi.ovf = (IntRec*)(gscr + 3 * QM_GCAP); ri.ovf = fi.ovf + QM_IOVF;
   const bool foundHit = collect_read<NS, F>(ix, B, M, len, hasDollar, fi, ri);
   QM_T(4);
+  if (B.iv_out || B.found_out || (F & QM_F_COLLECT)) lds_dma_wait();   // the staged prefetch must have landed before any store follows it
   if (B.iv_out) dump_intervals(B, read, mate, fi, ri);
   if (B.found_out) { QM_LANES(l) { if (l == 0) B.found_out[read] = foundHit ? 1 : 0; } }
   if (F & QM_F_COLLECT) return;          // stage entry "collector only" (SACollector::operator() as a call of its own)

@@ -109,6 +109,17 @@ QM_DEV void group_min(LV<int>& x, int G) {
 }
 QM_DEV int clz64(u64 x) { return x ? __builtin_clzll(x) : 64; }
 QM_DEV u64 load_u64_unaligned(const unsigned char* p) { u64 v; __builtin_memcpy(&v, p, 8); return v; }
+QM_DEV u32 load_u32_unaligned(const unsigned char* p) { u32 v; __builtin_memcpy(&v, p, 4); return v; }
+// v_perm_b32 with selectors 0..7: byte j of the result = byte sel_j of the eight bytes {hi, lo} (0..3 from lo, 4..7 from hi)
+QM_DEV u32 perm8(u32 hi, u32 lo, u32 sel) {
+  const u64 tab = ((u64)hi << 32) | lo; u32 r = 0;
+  for (int j = 0; j < 4; ++j) r |= (u32)((tab >> (8 * ((sel >> (8 * j)) & 7))) & 0xff) << (8 * j);
+  return r;
+}
+// out[l] = in[l ^ 1]: every lane reads its neighbour within a pair
+QM_DEV void lane_xor1(const LV<u32>& in, LV<u32>& out) { for (int l = 0; l < 64; ++l) out.v[l] = in.v[l ^ 1]; }
+// v_alignbyte_b32: the eight bytes {hi, lo} shifted right by `shift` (0..3) bytes, low dword
+QM_DEV u32 align_bytes(u32 hi, u32 lo, int shift) { return (u32)((((u64)hi << 32) | lo) >> (8 * shift)); }
 struct U4 { u32 x, y, z, w; };
 QM_DEV U4 load_16(const void* p) { U4 v; __builtin_memcpy(&v, p, 16); return v; }
 QM_DEV long long load_uniform_i64(const long long* p) { return *p; }
@@ -139,6 +150,12 @@ QM_DEV void group_min(LV<int>& x, int G) {
 }
 QM_DEV int clz64(u64 x) { return x ? __builtin_clzll(x) : 64; }
 QM_DEV u64 load_u64_unaligned(const unsigned char* p) { u64 v; __builtin_memcpy(&v, p, 8); return v; }
+QM_DEV u32 load_u32_unaligned(const unsigned char* p) { u32 v; __builtin_memcpy(&v, p, 4); return v; }
+QM_DEV u32 perm8(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }     // v_perm_b32
+QM_DEV void lane_xor1(const LV<u32>& in, LV<u32>& out) {                                     // DPP quad_perm:[1,0,3,2]
+  out.v[0] = (u32)__builtin_amdgcn_update_dpp(0, (int)in.v[0], 0xB1, 0xf, 0xf, false);
+}
+QM_DEV u32 align_bytes(u32 hi, u32 lo, int shift) { return __builtin_amdgcn_alignbyte(hi, lo, (u32)shift); }
 // wave-uniform 8-byte load on the scalar unit (s_load): read-only data, uniform address
 QM_DEV long long load_uniform_i64(const long long* p) {
   typedef const long long __attribute__((address_space(4)))* cptr;

@@ -64,7 +64,7 @@ class Emu:
         self.SA = np.ascontiguousarray(ix.SA, dtype=np.int32)
         self.sainfo = np.zeros(self.SA.size * 2, dtype=np.uint32)
         self.cap = int(buckets) if buckets else int(self.lib.qe_slots_cap(ix.hkeys.size))
-        self.slots = np.zeros(self.cap * 8 + 8, dtype=np.uint64)   # cap buckets of 64 bytes
+        self.slots = np.zeros(self.cap * 4 + 8, dtype=np.uint64)   # cap buckets of 32 bytes
         off = np.ascontiguousarray(ix.txpOffsets, dtype=np.int32)
         self.txp_off = off
         self.txp_len = np.ascontiguousarray(ix.txpLens, dtype=np.int32)
@@ -104,10 +104,11 @@ class Emu:
     def map(self, seq1, off1, seq2=None, off2=None, opts=None, ns=2):
         opts = opts or default_opts()
         nunits = len(off1) - 1
-        seq1 = np.ascontiguousarray(seq1, dtype=np.uint8); off1 = np.ascontiguousarray(off1, dtype=np.int64)
+        pad = np.zeros(8, dtype=np.uint8)                        # reads are fetched four characters at a time
+        seq1 = np.concatenate([np.asarray(seq1, dtype=np.uint8), pad]); off1 = np.ascontiguousarray(off1, dtype=np.int64)
         paired = seq2 is not None
         if paired:
-            seq2 = np.ascontiguousarray(seq2, dtype=np.uint8); off2 = np.ascontiguousarray(off2, dtype=np.int64)
+            seq2 = np.concatenate([np.asarray(seq2, dtype=np.uint8), pad]); off2 = np.ascontiguousarray(off2, dtype=np.int64)
         ho = np.zeros(nunits + 1, dtype=np.int64); io = np.zeros(nunits + 1, dtype=np.int64)
         ctr = np.zeros(6, dtype=np.uint64)
         hp = C.c_void_p(); ip = C.c_void_p(); st = C.c_int(0)

@@ -20,7 +20,7 @@ extern "C" {
 unsigned long long* qe_prof() { return qm::qm_prof; }   // event counters, see QM_CNT in qm_mapper.inl
 #endif
 
-// slots: (hmask+1) 64-byte buckets; sainfo: nSA x {u32 tid, i32 pos}; text padded by >= 64 bytes
+// slots: (hmask+1) 32-byte buckets; sainfo: nSA x {u32 tid, i32 pos}; text padded by >= 64 bytes
 int qe_map(int k, const unsigned char* text, long long n, const int* SA, long long nSA, const void* sainfo,
            const void* slots, unsigned long long hmask, const qm_opts* o, long long nunits,
            const unsigned char* seq1, const long long* off1, const unsigned char* seq2, const long long* off2,
@@ -56,8 +56,8 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
     for (auto& w : wa) { w.base = -1; w.used = 0; }
     for (long long r = 0; r < nreads; ++r) {
       const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP) | (o->sel_aln ? QM_F_SEL : 0);
-#define QE_CALL(NS_, F_) { static WaveMem<NS_> M; ReadPre<NS_> pre; pre_offsets<NS_>(B, r, pre); pre_chars<NS_>(B, r, pre); \
-                           pre_offsets<NS_>(B, r + 7, pre); map_read<NS_, F_>(ix, B, r, pre, M, gs.data(), wa[r % 7], selscr, (r & 2) ? &sellds : nullptr); }
+#define QE_CALL(NS_, F_) { static WaveMem<NS_> M; stage_offsets<NS_, F_>(B, r, M, 0); stage_chars<NS_, F_>(B, r, M, 0); \
+                           map_read<NS_, F_>(ix, B, r, r, B.nreads, 0, M, gs.data(), wa[r % 7], selscr, (r & 2) ? &sellds : nullptr); }
       if (ns == 2) { switch (F) { case 0: QE_CALL(2, 0) break; case 1: QE_CALL(2, 1) break; case 2: QE_CALL(2, 2) break; case 3: QE_CALL(2, 3) break;
                                   case 4: QE_CALL(2, 4) break; case 5: QE_CALL(2, 5) break; case 6: QE_CALL(2, 6) break; default: QE_CALL(2, 7) break; } }
       else if (ns == 3) { switch (F) { case 0: QE_CALL(3, 0) break; case 1: QE_CALL(3, 1) break; case 2: QE_CALL(3, 2) break; case 3: QE_CALL(3, 3) break;
@@ -76,8 +76,8 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
       ReadBatch S2 = B; S2.slowq = q.data(); S2.dyn = &dyn; S2.nreads = (long long)q.size(); S2.iv_out = nullptr;
       const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP) | QM_F_SEL;
       for (long long r = 0; r < (long long)q.size(); ++r) {
-#define QE_SLOW(NS_, F_) { static WaveMem<NS_> M; ReadPre<NS_> pre; pre_offsets<NS_>(S2, r, pre); pre_chars<NS_>(S2, r, pre); \
-                           map_read<NS_, F_>(ix, S2, read_id(S2, r), pre, M, gs.data(), wa[r % 7], selscr, &sellds, &dyn); }
+#define QE_SLOW(NS_, F_) { static WaveMem<NS_> M; stage_offsets<NS_, F_>(S2, r, M, 0); stage_chars<NS_, F_>(S2, r, M, 0); \
+                           map_read<NS_, F_>(ix, S2, read_id<F_>(S2, r), r, S2.nreads, 0, M, gs.data(), wa[r % 7], selscr, &sellds, &dyn); }
         if (ns == 2) { switch (F) { case 4: QE_SLOW(2, 4) break; case 5: QE_SLOW(2, 5) break; case 6: QE_SLOW(2, 6) break; default: QE_SLOW(2, 7) break; } }
         else if (ns == 3) { switch (F) { case 4: QE_SLOW(3, 4) break; case 5: QE_SLOW(3, 5) break; case 6: QE_SLOW(3, 6) break; default: QE_SLOW(3, 7) break; } }
         else { switch (F) { case 4: QE_SLOW(4, 4) break; case 5: QE_SLOW(4, 5) break; case 6: QE_SLOW(4, 6) break; default: QE_SLOW(4, 7) break; } }
@@ -234,7 +234,7 @@ void qe_ksw_rows(const int* qlen, const unsigned char* const* query, const int* 
   else if (ring == 128) ksw_rows_run<128>(qlen, query, tlen, target, mat, q, e, w, out);
   else ksw_rows_run<512>(qlen, query, tlen, target, mat, q, e, w, out);
 }
-unsigned long long qe_slots_cap(long long nkeys) { return bucket_count(nkeys); }   // buckets of 64 bytes
+unsigned long long qe_slots_cap(long long nkeys) { return bucket_count(nkeys); }   // buckets of 32 bytes
 void qe_flatten(const int* SA, long long nSA, const int* offsets, long long T, void* sainfo_out,
                 const unsigned long long* keys, const int* lb, const int* ub, long long K, void* slots_out,
                 unsigned long long cap) {
@@ -249,11 +249,11 @@ void qe_flatten(const int* SA, long long nSA, const int* offsets, long long T, v
   Bucket* bk = (Bucket*)slots_out;
   memset(bk, 0xff, (size_t)cap * sizeof(Bucket));
   for (long long i = 0; i < K; ++i) {
-    u64 b = hash_mix(keys[i]) & (cap - 1);
+    u64 b = (u64)bucket_hash(keys[i]) & (cap - 1);
     while (true) {
       int t = 0;
-      while (t < 4 && bk[b].key[t] != ~0ULL) ++t;
-      if (t < 4) { bk[b].key[t] = keys[i]; bk[b].val[t].lb = lb[i]; bk[b].val[t].ub = ub[i]; break; }
+      while (t < 2 && bk[b].key[t] != ~0ULL) ++t;
+      if (t < 2) { bk[b].key[t] = keys[i]; bk[b].val[t].lb = lb[i]; bk[b].val[t].ub = ub[i]; break; }
       bk[b].key[0] |= QM_BK_OVF;
       b = (b + 1) & (cap - 1);
     }

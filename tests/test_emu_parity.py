@@ -66,11 +66,11 @@ def test_synth_small(synth_small, oracle_mod, variant):
 
 
 def test_crowded_hash_buckets(synth_small, oracle_mod):
-    """a table with ~3 keys per 4-slot bucket: lookups have to follow the overflow marks into later buckets"""
+    """a table with ~1.4 keys per 2-slot bucket: lookups have to follow the overflow marks into later buckets"""
     import emu
     ix, orc = load_oracle(synth_small["idx"])
     nb = 16
-    while nb * 3 < ix.hkeys.size:
+    while nb * 1.4 < ix.hkeys.size:
         nb *= 2
     em = emu.Emu(ix, buckets=nb)
     q1, o1 = pack(synth_small["reads1"]); q2, o2 = pack(synth_small["reads2"])
