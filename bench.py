@@ -126,6 +126,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sel-aln", action="store_true", help="config 5: selective alignment (-s): chaining + ksw2 extension alignment of every hit")
     ap.add_argument("--perfect-hash", action="store_true", help="config 4: index built with `quasiindex -p` (BooPHF / FrugalBooMap probe path)")
+    ap.add_argument("--ph-compact", action="store_true", help="with --perfect-hash: keep the BooPHF / FrugalBooMap structure on the device "
+                    "(walked per lookup) instead of expanding the -p index into the one-sector bucket table at load time")
     ap.add_argument("--read-len", type=int, default=100, help="read length (BASELINE.json: 100; 129..256 runs the NS=4 kernels)")
     ap.add_argument("--cache", default=os.environ.get("QMAP_BENCH_CACHE", "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"))
     args = ap.parse_args()
@@ -163,7 +165,7 @@ def main():
     idx_dir = build_or_reuse_index(args.genes, 42, k, rank, world, args.cache, args.perfect_hash)
     t = time.time()
     qi = ra.QuasiIndex(idx_dir)
-    mp = ra.QuasiMapper(qi, local_rank)
+    mp = ra.QuasiMapper(qi, local_rank, ph_compact=args.ph_compact)
     if rank == 0:
         log("index in HBM: %d transcripts, %d text bytes, %d k-mers, %.2f GB on device (%.1fs)" % (
             qi.n_txps, qi.text_len, qi.n_keys, mp.device_bytes / 1e9, time.time() - t))
@@ -215,7 +217,7 @@ def main():
                                     "%d 31-mers), %d pairs 2x%d bp per GPU per step, 1%% substitutions, %s, %s index") % (
                                         4 if args.sel_aln else (3 if args.perfect_hash else (2 if world == 8 else 1)), args.genes, qi.n_txps, qi.text_len, qi.n_keys, n, L,
                                         "selective alignment (-s)" if args.sel_aln else "hits only (no -s)",
-                                        "perfect-hash (-p)" if args.perfect_hash else "dense hash"),
+                                        ("perfect-hash (-p), BooPHF walked on the device" if args.ph_compact else "perfect-hash (-p), expanded into the bucket table at load") if args.perfect_hash else "dense hash"),
                        "pairs_per_gpu_per_step": n, "parallelism": "shard%d (index replicated, counters all-reduced)" % world,
                        "hits_per_pair": round(tot["totHits"] / max(1, tot["numReads"]), 4),
                        "mreads_per_s": round(2 * value, 4)},
@@ -254,13 +256,13 @@ def main():
         pf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pf):
             try:
-                ent = json.load(open(pf)).get("perfect_hash" if args.perfect_hash else "dense") or {}
+                ent = json.load(open(pf)).get("perfect_hash" if (args.perfect_hash and args.ph_compact) else "dense") or {}
                 traffic = ent.get("hbm_bytes_per_launch") if n == 10_000_000 and args.genes == 40000 and not args.sel_aln else None
             except Exception:
                 traffic = None
         out["roofline"] = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                           "kernel": "%s (stage A: one wavefront per read)" % ("qm_read_kernel<2,4,%d>" % (5 if args.perfect_hash else 4) if args.sel_aln else ("qm_read_kernel<2,6,1>" if args.perfect_hash else "qm_read_kernel<2,8,0>")),
+                           "kernel": "%s (stage A: one wavefront per read)" % ("qm_read_kernel<2,4,%d>" % (5 if (args.perfect_hash and args.ph_compact) else 4) if args.sel_aln else ("qm_read_kernel<2,6,1>" if (args.perfect_hash and args.ph_compact) else "qm_read_kernel<2,8,0>")),
                            "kernel_ms": round(avg_kernel_ms, 3),
                            "algorithmic_bytes_per_pair": round(bpp, 1),
                            "per_pair_counters": {kk: round(v, 2) for kk, v in w.items()},
@@ -295,7 +297,7 @@ def main():
             ach = bpp * n / (avg_kernel_ms * 1e-3) / 1e9
             traffic = None
             try:
-                ent = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("perfect_hash" if args.perfect_hash else "dense") or {}
+                ent = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("perfect_hash" if (args.perfect_hash and args.ph_compact) else "dense") or {}
                 traffic = ent.get("hbm_bytes_per_launch") if args.genes == 40000 else None
                 if traffic is not None:
                     traffic = traffic * (n / 10_000_000)       # measured on a 10 M-pair launch; bytes per pair are what was measured

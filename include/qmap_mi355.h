@@ -131,6 +131,12 @@ int qm_index_arrays(const qm_index* ix, const uint8_t** text, int64_t* text_len,
  * contexts of one index on one device share a single replica, which is freed with the last of them.  Destroy the
  * contexts before closing the index. */
 int qm_ctx_create(const qm_index* ix, int device_id, qm_ctx** out);
+/* flags: QM_CTX_PH_COMPACT -- a perfect-hash (-p) index keeps the reference's frugal structure on the device (re-blocked
+ * BooPHF levels walked per lookup, include/BooPHF.hpp:971-1009, + one 16-byte record per k-mer: 1.3 GB for 80 M k-mers).
+ * By default a -p index is expanded at load time into the same one-sector bucket table a dense index gets (8.6 GB), after
+ * every record has been looked up through the BooPHF walk itself: identical answers, a single HBM round trip per lookup. */
+enum { QM_CTX_PH_COMPACT = 1 };
+int qm_ctx_create_ex(const qm_index* ix, int device_id, uint32_t flags, qm_ctx** out);
 int qm_ctx_destroy(qm_ctx* ctx);
 int64_t qm_ctx_device_bytes(const qm_ctx* ctx);
 

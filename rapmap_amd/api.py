@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "qm_map_pairs", "qm_map_reads", "qm_map_device", "qm_fetch_hits", "qm_result_device", "qm_ctx_set_debug",
     "qm_fetch_intervals", "qm_last_kernel_ms", "qm_ctx_stat", "qm_build_index",
     "qm_collect_reads", "qm_fetch_found", "qm_hits_to_mappings", "qm_fetch_read_lists", "qm_merge_lists", "qm_fetch_too_many",
-    "qm_map_pairs_stages",
+    "qm_map_pairs_stages", "qm_ctx_create_ex",
     "qm_reader_open", "qm_reader_next", "qm_reader_close", "qm_io_last_error", "qm_sam_header", "qm_sam_records",
     "qm_sam_write", "qm_buf_free",
 ]
@@ -93,6 +93,7 @@ def lib():
     L.qm_index_arrays.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p),
                                   C.POINTER(C.c_int64)]
     L.qm_ctx_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.qm_ctx_create_ex.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_void_p)]
     L.qm_ctx_destroy.argtypes = [C.c_void_p]
     L.qm_ctx_device_bytes.restype = C.c_int64
     L.qm_ctx_device_bytes.argtypes = [C.c_void_p]
@@ -220,7 +221,7 @@ class QuasiMapper:
     """One GPU context: the index replicated in HBM + work buffers.  `map_pairs` performs, for every
     pair, SACollector() x2 -> hitsToMappingsSimple() x2 -> mergeLeftRightHits() on one wavefront."""
 
-    def __init__(self, index: QuasiIndex, device=0, debug=False, reuse_results=False):
+    def __init__(self, index: QuasiIndex, device=0, debug=False, reuse_results=False, ph_compact=False):
         """reuse_results: hit arrays of successive calls share one buffer (views valid until the next call) instead of
         a fresh allocation per batch, whose pages would have to be faulted in again every time -- for streaming callers
         that are done with a batch before they map the next (the CLI)"""
@@ -229,7 +230,8 @@ class QuasiMapper:
         self._buf_offs = None
         self.index = index
         self._h = C.c_void_p()
-        _check(lib().qm_ctx_create(index._h, device, C.byref(self._h)))
+        # ph_compact: a -p index keeps the BooPHF / FrugalBooMap structure on the device instead of the expanded bucket table
+        _check(lib().qm_ctx_create_ex(index._h, device, 1 if ph_compact else 0, C.byref(self._h)))
         if debug:
             _check(lib().qm_ctx_set_debug(self._h, 1))
         self.device = device

@@ -89,7 +89,7 @@ struct Replica {
   }
 };
 static std::mutex g_repMu;
-static std::map<std::pair<const qm_index*, int>, std::weak_ptr<Replica>> g_reps;
+static std::map<std::pair<const qm_index*, int>, std::weak_ptr<Replica>> g_reps;   // key: index, device * 2 + (compact perfect hash)
 
 struct qm_ctx {
   const qm_index* ix = nullptr;
@@ -376,8 +376,12 @@ int qm_ctx_destroy(qm_ctx* c) {
   return QM_OK;
 }
 
-int qm_ctx_create(const qm_index* ix, int device_id, qm_ctx** out) {
+int qm_ctx_create(const qm_index* ix, int device_id, qm_ctx** out) { return qm_ctx_create_ex(ix, device_id, 0, out); }
+
+int qm_ctx_create_ex(const qm_index* ix, int device_id, uint32_t flags, qm_ctx** out) {
   if (!ix || !out) return fail(QM_E_ARG, "null argument");
+  const bool phCompact = ix->perfect && (flags & QM_CTX_PH_COMPACT);
+  const int repKey = device_id * 2 + (phCompact ? 1 : 0);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(QM_E_NOGPU, "no HIP device visible");
   if (device_id < 0 || device_id >= ndev) return fail(QM_E_ARG, "device %d out of range (%d devices)", device_id, ndev);
@@ -394,7 +398,7 @@ int qm_ctx_create(const qm_index* ix, int device_id, qm_ctx** out) {
   CK(hipMalloc((void**)&c->d_scal, QM_SC_WORDS * sizeof(u64)));
   {
     std::lock_guard<std::mutex> lk(g_repMu);
-    auto it = g_reps.find(std::make_pair(ix, device_id));
+    auto it = g_reps.find(std::make_pair(ix, repKey));
     if (it != g_reps.end()) c->rep = it->second.lock();
     if (c->rep) {
       Replica& R = *c->rep;
@@ -473,6 +477,24 @@ int qm_ctx_create(const qm_index* ix, int device_id, qm_ctx** out) {
     CK(hipMemcpyAsync(dP, &P, sizeof(P), hipMemcpyHostToDevice, c->stream));
     CK(hipStreamSynchronize(c->stream));    // P, tab, ov, fin are locals
     c->d_ph = dP;
+    if (!phCompact) {
+      // Default device image of a -p index: the same one-sector bucket table a dense index gets, filled from the MPHF's own
+      // records after each was looked up through the BooPHF walk (so the table is known to answer like FrugalBooMap::find on
+      // this file).  288 GB of HBM make the frugal structure unnecessary on this device; QM_CTX_PH_COMPACT keeps it.
+      c->cap = bucket_count((long long)ix->phNelem);
+      unsigned long long* dBad = nullptr; unsigned long long hBad = 0;
+      CK(hipMalloc(&c->d_slots, c->cap * sizeof(Bucket)));
+      CK(hipMalloc((void**)&dBad, sizeof(unsigned long long)));
+      DevIndex dix; memset(&dix, 0, sizeof(dix));
+      dix.text = c->d_text; dix.n = ix->n; dix.SA = c->d_SA; dix.nSA = ix->nSA; dix.k = ix->k; dix.ph = (const PhIndex*)dP;
+      CK(qmk_build_slots_from_ph(&dix, (long long)ix->phNelem, c->d_slots, c->cap, dBad, c->stream));
+      CK(hipMemcpyAsync(&hBad, dBad, sizeof(hBad), hipMemcpyDeviceToHost, c->stream));
+      CK(hipStreamSynchronize(c->stream));
+      hipFree(dBad);
+      if (hBad) { int rc = fail(QM_E_IO, "hash_info.bph / hash_info.val: %llu k-mers are not found by the perfect hash they were stored with", hBad); qm_ctx_destroy(c); return rc; }
+      for (void* q : c->phAllocs) if (q) hipFree(q);
+      c->phAllocs.clear(); c->d_ph = nullptr; c->devBytes = (int64_t)(c->cap * sizeof(Bucket));
+    }
   }
   CK(hipStreamSynchronize(c->stream));
   c->d_txpOff = d_offsets;                               // kept: -s reads transcript sequences by (offset, length)
@@ -491,7 +513,7 @@ int qm_ctx_create(const qm_index* ix, int device_id, qm_ctx** out) {
     R->d_ph = c->d_ph; R->phAllocs.swap(c->phAllocs); R->d_txpOff = c->d_txpOff; R->d_txpLen = c->d_txpLen; R->devBytes = c->devBytes;
     std::lock_guard<std::mutex> lk(g_repMu);
     c->rep = R;
-    g_reps[std::make_pair(ix, device_id)] = R;
+    g_reps[std::make_pair(ix, repKey)] = R;
   }
   *out = c;
   return QM_OK;

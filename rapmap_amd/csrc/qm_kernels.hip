@@ -238,6 +238,33 @@ __global__ void build_phrec_kernel(const int* data, const unsigned char* lens, l
   }
 }
 
+// A perfect-hash index expanded into the dense bucket table: slot i of the MPHF holds the interval [data_[i], data_[i] +
+// lens_[i]) of the k-mer that starts the suffix SA[data_[i]] -- every (k-mer, interval) pair of the index, i.e. exactly
+// the contents of a dense hash.bin.  Each record is first looked up through the BooPHF walk itself (find_kmer<QM_F_PH>, what
+// FrugalBooMap::find does with this file): it must come back with its own interval, so the table is known to answer like
+// the on-disk structure; `bad` counts the records for which it does not.
+__global__ void build_slots_from_ph_kernel(DevIndex ix, long long n, Bucket* buckets, u64 hmask, unsigned long long* bad) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  const PhIndex& P = *ix.ph;
+  for (; i < n; i += stride) {
+    const PhRec r = P.recs[i];
+    int lb = 0, ub = 0;
+    const bool found = find_kmer<QM_F_PH>(ix, r.key, lb, ub);
+    if (!found || lb != r.data) { atomicAdd(bad, 1ULL); continue; }
+    u64 b = (u64)bucket_hash(r.key) & hmask;
+    while (true) {
+      Bucket* bk = &buckets[b];
+      int got = -1;
+      for (int t = 0; t < 2 && got < 0; ++t)
+        if (atomicCAS((unsigned long long*)&bk->key[t], ~0ULL, r.key) == ~0ULL) got = t;
+      if (got >= 0) { bk->val[got].lb = lb; bk->val[got].ub = ub; break; }
+      atomicOr((unsigned long long*)&bk->key[0], QM_BK_OVF);
+      b = (b + 1) & hmask;
+    }
+  }
+}
+
 struct U32ToI64 { __device__ long long operator()(u32 x) const { return (long long)x; } };
 
 }  // namespace qm
@@ -255,6 +282,15 @@ hipError_t qmk_build_slots(const void* recs, long long K, void* slots, unsigned 
   hipError_t e = hipMemsetAsync(slots, 0xff, cap * sizeof(Bucket), st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(build_slots_kernel, dim3(4096), dim3(256), 0, st, (const Slot*)recs, K, (Bucket*)slots, cap - 1);
+  return hipGetLastError();
+}
+
+hipError_t qmk_build_slots_from_ph(const void* dev_index, long long n, void* slots, unsigned long long cap, unsigned long long* d_bad, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(slots, 0xff, cap * sizeof(Bucket), st);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(d_bad, 0, sizeof(unsigned long long), st);
+  if (e != hipSuccess) return e;
+  if (n > 0) hipLaunchKernelGGL(build_slots_from_ph_kernel, dim3(4096), dim3(256), 0, st, *(const DevIndex*)dev_index, n, (Bucket*)slots, cap - 1, d_bad);
   return hipGetLastError();
 }
 

@@ -29,10 +29,10 @@ VARIANTS = {
 }
 
 
-def _gpu(idx, debug=True):
+def _gpu(idx, debug=True, ph_compact=False):
     import rapmap_amd as ra
     qi = ra.QuasiIndex(idx)
-    return qi, ra.QuasiMapper(qi, 0, debug=debug)
+    return qi, ra.QuasiMapper(qi, 0, debug=debug, ph_compact=ph_compact)
 
 
 def _cmp_ints(res, offs, ints):
@@ -314,10 +314,13 @@ def test_repeat_families(repeat_data, oracle_mod):
     assert fres.counters == fgr.counters
 
 
-def test_perfect_hash_index(synth_small, synth_small_ph, oracle_mod):
-    """config 4: `quasiindex -p` index through the HIP path == dense-index oracle"""
+@pytest.mark.parametrize("compact", [False, True])
+def test_perfect_hash_index(synth_small, synth_small_ph, oracle_mod, compact):
+    """config 4: `quasiindex -p` index through the HIP path == dense-index oracle; both device images of the index: the
+    default (expanded into the one-sector bucket table after every record was checked through the BooPHF walk) and the
+    compact one (QM_CTX_PH_COMPACT: the BooPHF levels walked per lookup, as FrugalBooMap::find does)"""
     ix, orc = load_oracle(synth_small["idx"])
-    qi, mp = _gpu(synth_small_ph["idx"])
+    qi, mp = _gpu(synth_small_ph["idx"], ph_compact=compact)
     assert qi.perfect_hash
     q1, o1 = pack(synth_small_ph["reads1"]); q2, o2 = pack(synth_small_ph["reads2"])
     res = orc.map_pairs(q1, o1, q2, o2, nthreads=4, want_ints=True)
@@ -376,7 +379,8 @@ def _medium_txps(idx, min_len=700, cap=1500):
     return [text[a:b - 1] for a, b in zip(offsets, ends) if b - 1 - a >= min_len][:cap]
 
 
-@pytest.mark.parametrize("variant", ["default", "noSensitive", "fuzzy", "selAln", "perfectHash", "perfectHash_noSensitive", "perfectHash_selAln"])
+@pytest.mark.parametrize("variant", ["default", "noSensitive", "fuzzy", "selAln", "perfectHash", "perfectHash_noSensitive", "perfectHash_selAln",
+                                     "perfectHashCompact", "perfectHashCompact_noSensitive", "perfectHashCompact_selAln"])
 def test_reads_150bp_take_the_three_slot_kernels(synth_medium, synth_medium_ph, oracle_mod, variant):
     """2 x 150 bp (every read 129..192 bp long): the NS=3 instantiations of stage A -- dense / -p, default / --noSensitive /
     fuzzy / -s -- none of which the 100 bp and 250 bp cases reach"""
@@ -384,7 +388,7 @@ def test_reads_150bp_take_the_three_slot_kernels(synth_medium, synth_medium_ph, 
     from rapmap_amd import synth
     ph = variant.startswith("perfectHash")
     ix, orc = load_oracle(synth_medium["idx"])                # the oracle maps on the dense index: same hits by construction
-    qi, mp = _gpu((synth_medium_ph if ph else synth_medium)["idx"], debug=False)
+    qi, mp = _gpu((synth_medium_ph if ph else synth_medium)["idx"], debug=False, ph_compact="Compact" in variant)
     assert qi.perfect_hash == ph
     s1, s2, off, _ = synth.make_reads(_medium_txps(synth_medium["idx"]), 6000, seed=150, read_len=150, err=0.01)
     # ragged lengths inside the slot range, so that nothing rides on "exactly 150"
@@ -396,7 +400,9 @@ def test_reads_150bp_take_the_three_slot_kernels(synth_medium, synth_medium_ph, 
     assert 128 < int(np.diff(o1).max()) <= 192 and 128 < int(np.diff(o2).max()) <= 192
     oo, go = {"default": ({}, {}), "noSensitive": ({"sensitive": 0}, {"sensitive": 0}), "fuzzy": ({"fuzzy": 1}, {"fuzzy": 1}),
               "selAln": ({"selAln": 1}, {"sel_aln": 1}), "perfectHash": ({}, {}),
-              "perfectHash_noSensitive": ({"sensitive": 0}, {"sensitive": 0}), "perfectHash_selAln": ({"selAln": 1}, {"sel_aln": 1})}[variant]
+              "perfectHash_noSensitive": ({"sensitive": 0}, {"sensitive": 0}), "perfectHash_selAln": ({"selAln": 1}, {"sel_aln": 1}),
+              "perfectHashCompact": ({}, {}), "perfectHashCompact_noSensitive": ({"sensitive": 0}, {"sensitive": 0}),
+              "perfectHashCompact_selAln": ({"selAln": 1}, {"sel_aln": 1})}[variant]
     res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=8)
     gr = mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(**go))
     assert res.counters["totHits"] > 3000
