@@ -8,13 +8,18 @@
 // __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may load it; the
 // product (rapmap_amd/csrc, libqmap_mi355.so) never links, imports or calls it.
 //
-// PARITY PINNING STATUS: the reference cannot be built in this image under the
-// round's rules (it needs the un-vendored cereal library; writing a stand-in is
-// not allowed), and the reference's own tests hold no golden vectors
-// (SURVEY.md section 4).  The only reference outputs available are the ones the
-// survey stage recorded (md5 of the sample_data SAM body,
-// 28 506 records, 1.4253 hits/read) -- tests/test_oracle_golden.py checks the
-// oracle against those.  Beyond that: "parity unpinned".  See DESIGN.md.
+// PARITY PINNING STATUS.  The reference's own tests hold no golden vectors, and its quasimap
+// cannot be built in this image under the round's rules: every template of the path (SACollector, SASearcher, HitManager)
+// includes the un-vendored cereal library, and writing a stand-in is not allowed.  What IS pinned against the reference
+// itself, compiled from its own source files in place (oracle/Makefile.ref -> oracle/_ref, tests/test_oracle_ref.py):
+//   kswExtz2 (the byte-exact ksw_extz2_sse41 emulation)  == ksw2pp::KSW2Aligner(EXTENSION) as getAlnScore calls it
+//   kmerFromChars / wordRC / isHomopolymer               == Kmer<32,1>::fromChars / getRC / isHomoPolymer
+//   rank                                                 == rank9b::rank over the same rsd.bin bits
+//   (and oracle/q5ph.py's BooPHF lookup                  == boomphf::mphf::load + lookup on a .bph the reference wrote)
+// The collector, the MMP search, hits->mappings and the merges are "parity unpinned": corroborated by the SAM the survey
+// stage's probe build of the unmodified reference wrote (tests/golden/, tests/test_oracle_golden.py -- 30 option sets incl.
+// the sample_data digest of SURVEY.md section 8c) and by an index the reference wrote (tests/test_reference_index.py), both
+// produced with a cereal stand-in and therefore not a pin under the rules.  See DESIGN.md section 2.
 //
 // Layout of the inputs (all flat arrays owned by the caller, see oracle/q5.py):
 //   text  : the concatenated transcript text, one '$' after each transcript
@@ -1348,22 +1353,26 @@ int qo_map(void* hidx, const Opts* opts, int64_t n, const char* seq1, const int6
   if (nthreads < 1) nthreads = 1;
   std::vector<std::vector<Hit>> perHits(nthreads);
   std::vector<std::vector<int32_t>> perInts(nthreads);
-  std::vector<Counters> ctr(nthreads, Counters{0, 0, 0, 0, 0, 0});
-  std::vector<Work> wk(nthreads);
+  // per-thread counters on cache lines of their own: they are bumped on every probe, and packed side by side (as they
+  // were) the threads spent their time stealing each other's lines
+  struct alignas(128) PerThread { Work wk; Counters ctr{0, 0, 0, 0, 0, 0}; };
+  std::vector<PerThread> pt(nthreads);
   std::vector<int64_t> cnt(n + 1, 0), icnt(n + 1, 0);
   // static contiguous split: thread t owns [t*n/T,(t+1)*n/T) -- deterministic order
   auto worker = [&](int t) {
     int64_t b = n * t / nthreads, e = n * (t + 1) / nthreads;
-    Collector col(ix, *opts, wk[t]);
+    Work& wkt = pt[t].wk; Counters& ctrt = pt[t].ctr;
+    Collector col(ix, *opts, wkt);
     const MapCfg mc = mapCfg(*opts);
     Aligner aligner(opts->matchScore, opts->mismatchPenalty, opts->gapOpen, opts->gapExtend, opts->dpBandwidth);
-    aligner.wk = &wk[t];
+    aligner.wk = &wkt;
     std::vector<Hit> joint;
+    perHits[t].reserve((size_t)(e - b) * 4);
     std::vector<SAIntervalHit> dump[4];
     for (int64_t i = b; i < e; ++i) {
       if (seq2) {
         mapPair(ix, *opts, mc, col, &aligner, seq1 + off1[i], (size_t)(off1[i + 1] - off1[i]), seq2 + off2[i],
-                (size_t)(off2[i + 1] - off2[i]), joint, ctr[t], wk[t], ints_out ? dump : nullptr);
+                (size_t)(off2[i + 1] - off2[i]), joint, ctrt, wkt, ints_out ? dump : nullptr);
         if (ints_out) {
           for (int l = 0; l < 4; ++l)
             for (auto& s : dump[l]) {
@@ -1373,7 +1382,7 @@ int qo_map(void* hidx, const Opts* opts, int64_t n, const char* seq1, const int6
             }
         }
       } else {
-        mapSingle(ix, *opts, mc, col, &aligner, seq1 + off1[i], (size_t)(off1[i + 1] - off1[i]), joint, ctr[t], wk[t]);
+        mapSingle(ix, *opts, mc, col, &aligner, seq1 + off1[i], (size_t)(off1[i + 1] - off1[i]), joint, ctrt, wkt);
       }
       cnt[i + 1] = (int64_t)joint.size();
       perHits[t].insert(perHits[t].end(), joint.begin(), joint.end());
@@ -1395,9 +1404,10 @@ int qo_map(void* hidx, const Opts* opts, int64_t n, const char* seq1, const int6
   *hits_out = out;
   Counters c{0, 0, 0, 0, 0, 0}; Work w;
   for (int t = 0; t < nthreads; ++t) {
-    c.peHits += ctr[t].peHits; c.seHits += ctr[t].seHits; c.totHits += ctr[t].totHits;
-    c.numReads += ctr[t].numReads; c.tooManyHits += ctr[t].tooManyHits; c.mappedUnits += ctr[t].mappedUnits;
-    w.add(wk[t]);
+    const Counters& ct = pt[t].ctr;
+    c.peHits += ct.peHits; c.seHits += ct.seHits; c.totHits += ct.totHits;
+    c.numReads += ct.numReads; c.tooManyHits += ct.tooManyHits; c.mappedUnits += ct.mappedUnits;
+    w.add(pt[t].wk);
   }
   counters[0] = c.peHits; counters[1] = c.seHits; counters[2] = c.totHits; counters[3] = c.numReads;
   counters[4] = c.tooManyHits; counters[5] = c.mappedUnits;

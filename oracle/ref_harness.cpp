@@ -1,0 +1,90 @@
+// oracle/ref_harness.cpp -- TEST INFRASTRUCTURE.  C entry points over the pieces of the REFERENCE that compile from their own
+// source files without anything this image lacks (oracle/Makefile.ref builds them where they lie under /root/reference, into
+// oracle/_ref/libqm_ref.so; nothing of the reference is copied into this repository).  The hot path's templates
+// (SACollector / SASearcher / HitManager) all include the un-vendored cereal headers and are NOT among them; what is:
+//   ksw2pp::KSW2Aligner + ksw_extz2_sse{2,41}   src/ksw2pp/{KSW2Aligner.cpp,ksw2_extz2_sse.c,ksw2_extz.c,kalloc.c}   (row a17)
+//   rapmap's Kmer<32,1> codec                    include/Kmer.hpp                                                   (row a1)
+//   boomphf::mphf (load + lookup)                include/BooPHF.hpp                                                 (row a3)
+//   rank9b + BIT_ARRAY                           src/rank9b.cpp, src/bit_array.c                                    (row a8)
+// The oracle's restatements of exactly these functions are checked against them in tests/test_oracle_ref.py.
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "ksw2pp/KSW2Aligner.hpp"
+#include "Kmer.hpp"
+#include "BooPHF.hpp"
+#include "rank9b.h"
+extern "C" {
+#include "bit_array.h"
+}
+
+extern "C" {
+
+// getAlnScore's aligner call (include/SelectiveAlignmentUtils.hpp:316-359) with the configuration of
+// src/RapMapSAMapper.cpp:198-208: score-only extension alignment, max(mqe, mte)
+int ref_ksw_extension(const char* query, int qlen, const char* target, int tlen, int match, int mismatch, int gapo, int gape, int bandwidth) {
+  ksw2pp::KSW2Config config;
+  config.dropoff = -1;
+  config.gapo = (int8_t)gapo;
+  config.gape = (int8_t)gape;
+  config.bandwidth = bandwidth;
+  config.flag = 0;
+  config.flag |= KSW_EZ_SCORE_ONLY;
+  ksw2pp::KSW2Aligner aligner((int8_t)match, (int8_t)mismatch);
+  aligner.config() = config;
+  ksw_extz_t ez;
+  memset(&ez, 0, sizeof(ksw_extz_t));
+  ez.max_q = ez.max_t = ez.mqe_t = ez.mte_q = -1;
+  ez.max = 0, ez.mqe = ez.mte = KSW_NEG_INF;
+  ez.n_cigar = 0;
+  aligner(query, qlen, target, tlen, &ez, ksw2pp::EnumToType<ksw2pp::KSW2AlignmentType::EXTENSION>());
+  return ez.mqe > ez.mte ? ez.mqe : ez.mte;
+}
+
+// Kmer<32,1>: fromChars (returns whether all k characters were valid), the word, its reverse complement, isHomoPolymer
+using ref_mer = combinelib::kmers::Kmer<32, 1>;
+int ref_kmer(const char* s, int k, uint64_t* word, uint64_t* rc, int* homopolymer) {
+  ref_mer::k(k);
+  ref_mer m;
+  const bool ok = m.fromChars(s);
+  *word = m.word(0);
+  *rc = m.getRC().word(0);
+  *homopolymer = m.isHomoPolymer() ? 1 : 0;
+  return ok ? 1 : 0;
+}
+
+// boomphf::mphf<uint64_t, SingleHashFunctor<uint64_t>> as FrugalBooMap instantiates it (include/FrugalBooMap.hpp:90-91)
+using ref_mphf = boomphf::mphf<uint64_t, boomphf::SingleHashFunctor<uint64_t>>;
+void* ref_mphf_load(const char* path) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return nullptr;
+  ref_mphf* p = new ref_mphf();
+  p->load(f);
+  return p;
+}
+void ref_mphf_lookup(void* h, const uint64_t* keys, int64_t n, uint64_t* out) {
+  ref_mphf* p = (ref_mphf*)h;
+  for (int64_t i = 0; i < n; ++i) out[i] = p->lookup(keys[i]);
+}
+void ref_mphf_free(void* h) { delete (ref_mphf*)h; }
+
+// rank9b over the bits of an rsd.bin image (u64 nbits + bytes): as RapMapSAIndex::load builds it (src/RapMapSAIndex.cpp:118-131)
+struct RefRank { BIT_ARRAY* ba; rank9b* r; };
+void* ref_rank_create(const uint8_t* bytes, uint64_t nbits) {
+  RefRank* x = new RefRank();
+  x->ba = bit_array_create(nbits);
+  for (uint64_t i = 0; i < nbits; ++i) if ((bytes[i >> 3] >> (i & 7)) & 1) bit_array_set_bit(x->ba, i);
+  x->r = new rank9b(x->ba->words, nbits);
+  return x;
+}
+void ref_rank_query(void* h, const uint64_t* pos, int64_t n, uint64_t* out) {
+  RefRank* x = (RefRank*)h;
+  for (int64_t i = 0; i < n; ++i) out[i] = x->r->rank(pos[i]);
+}
+void ref_rank_free(void* h) { RefRank* x = (RefRank*)h; delete x->r; bit_array_free(x->ba); delete x; }
+
+}  // extern "C"
