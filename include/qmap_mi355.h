@@ -36,7 +36,7 @@ typedef enum qm_status {
   QM_E_FORMAT = -8       /* malformed FASTA/FASTQ input */
 } qm_status;
 
-#define QM_MAX_READ_LEN 256
+#define QM_MAX_READ_LEN 512
 
 /* Mirrors MappingOpts (src/RapMapSAMapper.cpp:114-152) for the fields that
  * reach the hot path.  Defaults (qm_opts_default) == `rapmap quasimap` defaults

@@ -766,7 +766,7 @@ static int map_device_impl(qm_ctx* c, const qm_opts* o, int64_t n, const void* d
   if ((d_seq2 == nullptr) != (d_off2 == nullptr)) return fail(QM_E_ARG, "seq2/off2 must both be given or both be null");
   if (max_read_len > QM_MAX_READ_LEN) return fail(QM_E_TOOLONG, "read length %d > %d", max_read_len, QM_MAX_READ_LEN);
   HIPCHK(hipSetDevice(c->device));
-  const int ns = max_read_len <= 128 ? 2 : (max_read_len <= 192 ? 3 : 4);   // 64-character slots per read: picks the kernel instantiation
+  const int ns = max_read_len <= 128 ? 2 : (max_read_len <= 192 ? 3 : (max_read_len <= 256 ? 4 : 8));   // 64-character slots per read: picks the kernel instantiation
   const bool paired = d_seq2 != nullptr;
   u64 hscal[QM_SC_WORDS];
   c->lastUnits = -1;
@@ -951,7 +951,7 @@ int qm_collect_reads(qm_ctx* c, const qm_opts* o, int64_t n, const char* seq, co
   RunReq rq; rq.mode = QM_RUN_COLLECT;
   u64 hscal[QM_SC_WORDS];
   c->lastUnits = -1;
-  if ((rc = run_stage_a(c, o, rq, n, c->d_seq1, c->d_off1, nullptr, nullptr, 4, nullptr, hscal))) return rc;
+  if ((rc = run_stage_a(c, o, rq, n, c->d_seq1, c->d_off1, nullptr, nullptr, 8, nullptr, hscal))) return rc;
   if (n_intervals) *n_intervals = c->lastIvTotal;
   return QM_OK;
 }

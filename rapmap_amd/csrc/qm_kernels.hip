@@ -313,8 +313,8 @@ hipError_t qmk_map_reads(const void* ixp, const void* bp, int ns, int grid, int 
   const DevIndex& ix = *(const DevIndex*)ixp;
   const ReadBatch& B = *(const ReadBatch*)bp;
   const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP) | (B.selscr ? QM_F_SEL : 0);
-  if (ns < 0) {        // stage entry "collector only": the NS=4 kernels (every read length up to QM_MAX_READ_LEN) without the second half
-#define QM_LAUNCH_C(F_) hipLaunchKernelGGL((qm_read_kernel<4, 2, (F_) | QM_F_COLLECT>), dim3((unsigned)(grid < num_cu * 2 ? grid : num_cu * 2)), dim3(256), 0, st, ix, B)
+  if (ns < 0) {        // stage entry "collector only": the NS=8 kernels (every read length up to QM_MAX_READ_LEN) without the second half
+#define QM_LAUNCH_C(F_) hipLaunchKernelGGL((qm_read_kernel<8, 2, (F_) | QM_F_COLLECT>), dim3((unsigned)(grid < num_cu * 2 ? grid : num_cu * 2)), dim3(256), 0, st, ix, B)
     switch (F) {
       case 0: QM_LAUNCH_C(0); break;
       case QM_F_PH: QM_LAUNCH_C(QM_F_PH); break;
@@ -358,6 +358,17 @@ hipError_t qmk_map_reads(const void* ixp, const void* bp, int ns, int grid, int 
       case QM_F_SEL | QM_F_PH: QM_LAUNCH(3, 3, QM_F_SEL | QM_F_PH); break;
       case QM_F_SEL | QM_F_NIP: QM_LAUNCH(3, 3, QM_F_SEL | QM_F_NIP); break;
       default: QM_LAUNCH(3, 3, QM_F_SEL | QM_F_PH | QM_F_NIP); break;
+    }
+  } else if (ns > 4) {                                     // 257..512 bp (merged / long reads): eight 64-character slots
+    switch (F) {
+      case 0: QM_LAUNCH(8, 2, 0); break;
+      case QM_F_PH: QM_LAUNCH(8, 2, QM_F_PH); break;
+      case QM_F_NIP: QM_LAUNCH(8, 2, QM_F_NIP); break;
+      case QM_F_PH | QM_F_NIP: QM_LAUNCH(8, 2, QM_F_PH | QM_F_NIP); break;
+      case QM_F_SEL: QM_LAUNCH(8, 1, QM_F_SEL); break;
+      case QM_F_SEL | QM_F_PH: QM_LAUNCH(8, 1, QM_F_SEL | QM_F_PH); break;
+      case QM_F_SEL | QM_F_NIP: QM_LAUNCH(8, 1, QM_F_SEL | QM_F_NIP); break;
+      default: QM_LAUNCH(8, 1, QM_F_SEL | QM_F_PH | QM_F_NIP); break;
     }
   } else {
     switch (F) {
@@ -412,7 +423,7 @@ hipError_t qmk_sel_three(const void* pp, const void* ap, int num_cu, hipStream_t
   switch (sel_ksw_ring_slots(A.bandwidth)) {            // one kernel for every --dpBandwidth: the band decides the ring
     case 64: hipLaunchKernelGGL((qm_sel_align_kernel<64, 4>), dim3((unsigned)(num_cu * 8)), dim3(256), 0, st, P, A); break;
     case 128: hipLaunchKernelGGL((qm_sel_align_kernel<128, 4>), dim3((unsigned)(num_cu * 4)), dim3(256), 0, st, P, A); break;
-    default: hipLaunchKernelGGL((qm_sel_align_kernel<512, 2>), dim3((unsigned)(num_cu * 3)), dim3(128), 0, st, P, A); break;   // 42 KB of LDS per block
+    default: hipLaunchKernelGGL((qm_sel_align_kernel<1024, 2>), dim3((unsigned)(num_cu * 2)), dim3(128), 0, st, P, A); break;   // 83 KB of LDS per block
   }
   hipLaunchKernelGGL(qm_sel_finish_kernel, dim3(nb), dim3(256), 0, st, P, A);
   return hipGetLastError();

@@ -35,7 +35,7 @@ namespace qm {
 #define QM_CAP 64      // entries per LDS list
 #define QM_GCAP 2048   // entries per global-scratch list (2 strands x <1000 SA entries)
 #define QM_ICAP 16     // SA-interval hits per strand kept in LDS (more spill to global scratch)
-#define QM_IOVF 256    // ... overflow capacity per strand (>= 64*NS - k + 1 for NS = 4)
+#define QM_IOVF 512    // ... overflow capacity per strand (>= 64*NS - k + 1 for NS = 8)
 #define QM_CHUNK 4096  // list elements a wave reserves per bump-allocator round trip (>= QM_GCAP)
 #define QM_GSCR_U64 (3 * QM_GCAP + 2 * QM_IOVF * 2)   // u64 words of global scratch per wave
 // slots of the context's scalar block (ReadBatch::cursor points at slot 0): bump pointer, qm_counters[6], status, ksw2 task

@@ -14,7 +14,6 @@
 // The double arithmetic of the chain score must not be contracted into FMAs: the reference is plain x86-64 code.
 
 #define QM_SEL_CAP 4096            // SA entries of one strand's intervals a read may bring (else status bit 3)
-#define QM_SEL_MAXIV 256           // SA-interval hits per strand
 enum : int { QM_CS_PERFECT = 0, QM_CS_UNGAPPED = 1, QM_CS_REGULAR = 4 };   // rapmap::utils::ChainStatus
 
 struct SelRec { u32 tid, pos, qpos, len, iv; };
@@ -183,8 +182,8 @@ QM_DEV int sel_chain_group(const SelRec* H, int hn, double* f, int* p, int* seen
   return nStarts;
 }
 
-// set of SA intervals a transcript occurs in (<= QM_SEL_MAXIV = 256): four words updated by selects -- indexing an array
-// with iv >> 6 would put it in scratch memory
+// set of SA intervals a transcript occurs in, for the lane-parallel path (at most 64 * QM_SEL_CHUNKS = 256 records, hence at
+// most 256 intervals): four words updated by selects -- indexing an array with iv >> 6 would put it in scratch memory
 struct SelIvSet {
   u64 a = 0, b = 0, c = 0, d = 0;
   QM_DEV void add(u32 iv) { const u64 bit = 1ULL << (iv & 63); const u32 w = iv >> 6; a |= w == 0 ? bit : 0ULL; b |= w == 1 ? bit : 0ULL; c |= w == 2 ? bit : 0ULL; d |= w == 3 ? bit : 0ULL; }
@@ -230,12 +229,13 @@ QM_DEV void sel_strand(SS& S, int s, int n, int m, u32 readLen, int mate, float 
       return (r1 < r2) ? true : ((r2 < r1) ? false : (q1 < q2)); });
     sel_sort(S.rec, S.tmp, n, [](const SelRec& a, const SelRec& b) { return a.tid < b.tid; });
   }
-  // first pass: is any transcript active?
+  // first pass: is any transcript active?  Distinct intervals of a transcript are counted with stamps (S.p[iv] = group): any
+  // number of intervals (long reads bring hundreds); S.p is free until the chaining below, and n >= m entries long
   bool anyActive = false;
+  for (int i = 0; i < m; ++i) S.p[i] = -1;
   for (int g0 = 0; g0 < n;) {
-    int g1 = g0; SelIvSet mk;
-    while (g1 < n && S.rec[g1].tid == S.rec[g0].tid) { mk.add(S.rec[g1].iv); ++g1; }
-    int na = mk.count();
+    int g1 = g0; int na = 0;
+    while (g1 < n && S.rec[g1].tid == S.rec[g0].tid) { const int iv = (int)S.rec[g1].iv; if (S.p[iv] != g0) { S.p[iv] = g0; ++na; } ++g1; }
     S.seen[g0] = na;                                   // parked: #intervals of the group starting at g0
     if (na >= requiredNumHits) anyActive = true;
     g0 = g1;
@@ -431,7 +431,6 @@ QM_DEV int sel_h2m_on(const DevIndex& ix, const ReadBatch& B, const IntervalList
   for (int s = 0; s < 2; ++s) {
     const IntervalList& L = s == 0 ? fwdInts : rcInts;
     int n = 0;
-    if (L.n > QM_SEL_MAXIV) return -1;
     for (int ii = 0; ii < L.n; ++ii) { int lb, ub; u32 ln, qp; L.get(ii, lb, ub, ln, qp); n += ub - lb; }
     if (n > S.cap()) return -1;
     if (n <= 64 * QM_SEL_CHUNKS) {
@@ -536,22 +535,23 @@ struct SelBatch {                    // launch arguments of the -s kernels (on t
 // of its own alignment's band one after the other, like the original's inner loop.  Column state lives in a ring of RING
 // slots in LDS (column t in slot t & (RING - 1), u|v<<8|x<<16|y<<24 in one word), reset when the 16-aligned window start
 // moves.  A round touches the columns [st, max(en, smax)] with st = 16-aligned band start, en = 16-aligned band end,
-// smax <= band end + 15: at most w + 31 columns, so RING >= w + 31 (64 slots for --dpBandwidth <= 33, 128 up to 97, 512
-// for anything else -- 512 slots hold every column of the longest alignment, the window then never moves).
+// smax <= band end + 15: at most w + 31 columns, so RING >= w + 31 (64 slots for --dpBandwidth <= 33, 128 up to 97, 1024
+// for anything else -- 1024 slots hold every column of the longest alignment, the window then never moves).
 // The score phase of the original reads the reversed query and the target out of one zeroed block (sf = target + zeros up
 // to tlen16, directly followed by qr = reversed query + zeros) and its 16-wide vectors run past both ends of the band; the
 // two images hold exactly what those reads return:
 //   QX[16 + i] = query[i] (0 <= i < qlen), zero before and after    -- the query character of cell (r, t) is QX[16 + r - t]
 //   TX[t] = target[t] (t < tlen), 0 (t < tlen16), query[qlen - 1 - (t - tlen16)] beyond -- a column's target character
 // Everything is per-lane (row-uniform) VALU work: no scalar control per alignment.
-#define QM_KSW_MAXLEN 288                                   // read (<= 256) + 20 extra target characters, rounded up
+#define QM_KSW_MAXLEN (QM_MAX_READ_LEN + 32)                // read + 20 extra target characters, rounded up
 template <int RING>
 struct KswRowT {                                  // one alignment's LDS block (1232 bytes at RING = 64)
   unsigned char QX[QM_KSW_MAXLEN + 40], TX[QM_KSW_MAXLEN + 40];
   u32 ST[RING]; int HH[RING]; unsigned char SS[RING];
 };
 inline constexpr int sel_ksw_ring_slots(int w) {   // host + device (constexpr)
-  return (w >= 0 && w <= 33) ? 64 : ((w >= 0 && w <= 97) ? 128 : 512); }
+  return (w >= 0 && w <= 33) ? 64 : ((w >= 0 && w <= 97) ? 128 : 1024); }
+static_assert(QM_KSW_MAXLEN + 48 <= 1024, "the full-band ring must hold every column of the longest alignment");
 // qlenv / tlenv: the row's alignment (0: the row idles); blk[row]; the images must be in place.  wIn < 0: the band is the
 // whole matrix (ksw2_extz2_sse.c:45).  Returns max(mqe, mte) per row.
 template <int RING>

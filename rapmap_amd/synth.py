@@ -56,7 +56,7 @@ def make_reads(txps, n_pairs, seed=43, read_len=100, err=0.01, n_rate=0.0, chunk
     starts = np.zeros(len(txps) + 1, dtype=np.int64)
     np.cumsum(lens, out=starts[1:])
     cat = np.concatenate(txps)
-    ok = np.nonzero(lens >= 400)[0]
+    ok = np.nonzero(lens >= max(400, read_len))[0]
     if ok.size == 0:
         ok = np.nonzero(lens >= read_len)[0]
     L = read_len
@@ -68,7 +68,10 @@ def make_reads(txps, n_pairs, seed=43, read_len=100, err=0.01, n_rate=0.0, chunk
         e = min(n_pairs, b + chunk)
         m = e - b
         tid = ok[rng.integers(0, ok.size, m)]
-        flen = np.clip(rng.normal(250, 25, m).astype(np.int64), L, 400)
+        if L <= 400:
+            flen = np.clip(rng.normal(250, 25, m).astype(np.int64), L, 400)
+        else:                                                  # long reads: fragments of about two read lengths
+            flen = np.clip(rng.normal(2 * L, 40, m).astype(np.int64), L, 3 * L)
         flen = np.minimum(flen, lens[tid])
         st = (rng.random(m) * (lens[tid] - flen + 1)).astype(np.int64)
         g0 = starts[tid] + st

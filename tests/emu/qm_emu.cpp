@@ -62,6 +62,8 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
                                   case 4: QE_CALL(2, 4) break; case 5: QE_CALL(2, 5) break; case 6: QE_CALL(2, 6) break; default: QE_CALL(2, 7) break; } }
       else if (ns == 3) { switch (F) { case 0: QE_CALL(3, 0) break; case 1: QE_CALL(3, 1) break; case 2: QE_CALL(3, 2) break; case 3: QE_CALL(3, 3) break;
                                        case 4: QE_CALL(3, 4) break; case 5: QE_CALL(3, 5) break; case 6: QE_CALL(3, 6) break; default: QE_CALL(3, 7) break; } }
+      else if (ns == 8) { switch (F) { case 0: QE_CALL(8, 0) break; case 1: QE_CALL(8, 1) break; case 2: QE_CALL(8, 2) break; case 3: QE_CALL(8, 3) break;
+                                       case 4: QE_CALL(8, 4) break; case 5: QE_CALL(8, 5) break; case 6: QE_CALL(8, 6) break; default: QE_CALL(8, 7) break; } }
       else { switch (F) { case 0: QE_CALL(4, 0) break; case 1: QE_CALL(4, 1) break; case 2: QE_CALL(4, 2) break; case 3: QE_CALL(4, 3) break;
                           case 4: QE_CALL(4, 4) break; case 5: QE_CALL(4, 5) break; case 6: QE_CALL(4, 6) break; default: QE_CALL(4, 7) break; } }
 #undef QE_CALL
@@ -80,6 +82,7 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
                            map_read<NS_, F_>(ix, S2, read_id<F_>(S2, r), r, S2.nreads, 0, M, gs.data(), wa[r % 7], selscr, &sellds, &dyn); }
         if (ns == 2) { switch (F) { case 4: QE_SLOW(2, 4) break; case 5: QE_SLOW(2, 5) break; case 6: QE_SLOW(2, 6) break; default: QE_SLOW(2, 7) break; } }
         else if (ns == 3) { switch (F) { case 4: QE_SLOW(3, 4) break; case 5: QE_SLOW(3, 5) break; case 6: QE_SLOW(3, 6) break; default: QE_SLOW(3, 7) break; } }
+        else if (ns == 8) { switch (F) { case 4: QE_SLOW(8, 4) break; case 5: QE_SLOW(8, 5) break; case 6: QE_SLOW(8, 6) break; default: QE_SLOW(8, 7) break; } }
         else { switch (F) { case 4: QE_SLOW(4, 4) break; case 5: QE_SLOW(4, 5) break; case 6: QE_SLOW(4, 6) break; default: QE_SLOW(4, 7) break; } }
 #undef QE_SLOW
       }
@@ -116,7 +119,7 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
       switch (sel_ksw_ring_slots(A.bandwidth)) {         // same rule as the launch wrapper
         case 64: { std::vector<KswRowT<64>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<64>(P, A, t, ntasks, rows.data()); } break;
         case 128: { std::vector<KswRowT<128>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<128>(P, A, t, ntasks, rows.data()); } break;
-        default: { std::vector<KswRowT<512>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<512>(P, A, t, ntasks, rows.data()); } break;
+        default: { std::vector<KswRowT<1024>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<1024>(P, A, t, ntasks, rows.data()); } break;
       }
       for (long long u = 0; u < nunits; ++u) hc[u] = (u32)sel_unit_finish(P, A, u, &uc);
     }
@@ -222,7 +225,7 @@ static void ksw_rows_run(const int* qlen, const unsigned char* const* query, con
   for (int g = 0; g < 4; ++g) out[g] = sc[g * 16];
 }
 extern "C" {
-// ring < 0: the ring the launch wrapper would pick for this band; otherwise force 64 / 128 / 512 slots
+// ring < 0: the ring the launch wrapper would pick for this band; otherwise force 64 / 128 / 1024 slots
 void qe_ksw_rows(const int* qlen, const unsigned char* const* query, const int* tlen, const unsigned char* const* target,
                  int a, int b, int q, int e, int w, int* out, int ring) {
   signed char mat[25];
@@ -232,7 +235,7 @@ void qe_ksw_rows(const int* qlen, const unsigned char* const* query, const int* 
   if (ring < 0) ring = sel_ksw_ring_slots(w);
   if (ring == 64) ksw_rows_run<64>(qlen, query, tlen, target, mat, q, e, w, out);
   else if (ring == 128) ksw_rows_run<128>(qlen, query, tlen, target, mat, q, e, w, out);
-  else ksw_rows_run<512>(qlen, query, tlen, target, mat, q, e, w, out);
+  else ksw_rows_run<1024>(qlen, query, tlen, target, mat, q, e, w, out);
 }
 unsigned long long qe_slots_cap(long long nkeys) { return bucket_count(nkeys); }   // buckets of 32 bytes
 void qe_flatten(const int* SA, long long nSA, const int* offsets, long long T, void* sainfo_out,

@@ -310,3 +310,25 @@ def test_selective_alignment_wide_bands(synth_small, oracle_mod, band):
     assert er.status == 0
     assert_hits_equal(res.hit_offsets, res.hits, er.hit_offsets, er.hits, "selAln band %d" % band)
     assert res.counters == er.counters
+
+
+def test_reads_of_300_and_500_bp_take_the_eight_slot_kernels(synth_medium, oracle_mod):
+    """reads longer than 256 bp (merged pairs, long-insert libraries): the NS=8 instantiations, default / --noSensitive / -s"""
+    import rapmap_amd as ra
+    from rapmap_amd import synth
+    ix, orc, em, emu = _emu(synth_medium["idx"])
+    qi = ra.QuasiIndex(synth_medium["idx"])
+    text, offsets = qi.arrays()
+    text = np.asarray(text); offsets = np.asarray(offsets, dtype=np.int64)
+    ends = np.append(offsets[1:], text.size)
+    txps = [text[a:b - 1] for a, b in zip(offsets, ends) if b - 1 - a >= 1200][:800]
+    for L, n in ((300, 500), (500, 250)):
+        s1, s2, off, _ = synth.make_reads(txps, n, seed=3 + L, read_len=L, err=0.015)
+        for oo, go in (({}, {}), ({"sensitive": 0}, {"sensitive": 0}), ({"selAln": 1}, {"sel_aln": 1})):
+            res = orc.map_pairs(s1, off, s2, off, opts=oracle_mod.default_opts(**oo), nthreads=8)
+            er = em.map(s1, off, s2, off, opts=emu.default_opts(**go), ns=8)
+            assert (er.status & 0xff) == 0, er.status
+            assert res.counters["totHits"] > n // 2
+            assert_hits_equal(res.hit_offsets, res.hits, er.hit_offsets, er.hits, "%d bp %s" % (L, oo))
+            assert res.counters == er.counters
+    assert em.map(s1, off, s2, off, ns=4).status & 4          # 500 bp does not fit four slots

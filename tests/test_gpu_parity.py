@@ -136,7 +136,7 @@ def test_edge_batches(synth_small, oracle_mod):
         gr = mp.map_pairs(q1, o1, q2, o2)
         assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "one")
     # too-long read and unsupported options are errors, not silent fallbacks
-    q1, o1 = pack([b"A" * 300]); q2, o2 = pack([b"C" * 10])
+    q1, o1 = pack([b"A" * 600]); q2, o2 = pack([b"C" * 10])
     with pytest.raises(ra.QmError, match="read length"):
         mp.map_pairs(q1, o1, q2, o2)
 
@@ -526,3 +526,31 @@ def test_stage_entry_points_compose_to_the_fused_path(synth_small, oracle_mod, m
         same = np.diff(full.hit_offsets) == np.diff(fused.hit_offsets)
         assert same.mean() > 0.95
         assert_hits_equal(res.hit_offsets, res.hits, full.hit_offsets, full.hits, "fused driver path")
+
+
+@pytest.mark.parametrize("L", [300, 500])
+def test_reads_longer_than_256_bp(synth_medium, synth_medium_ph, oracle_mod, L):
+    """2 x 300 and 2 x 500 bp (merged pairs, long-insert libraries): the eight-slot kernels -- dense / -p, default /
+    --noSensitive / -s -- instead of QM_E_TOOLONG; a batch that mixes them with short reads runs on the same kernels"""
+    import rapmap_amd as ra
+    from rapmap_amd import synth
+    ix, orc = load_oracle(synth_medium["idx"])
+    txps = _medium_txps(synth_medium["idx"], min_len=1200, cap=800)
+    s1, s2, off, _ = synth.make_reads(txps, 1500, seed=3 + L, read_len=L, err=0.015)
+    for idx, compact in ((synth_medium["idx"], False), (synth_medium_ph["idx"], True)):
+        qi, mp = _gpu(idx, debug=False, ph_compact=compact)
+        for oo, go in (({}, {}), ({"sensitive": 0}, {"sensitive": 0}), ({"selAln": 1}, {"sel_aln": 1}), ({"fuzzy": 1}, {"fuzzy": 1})):
+            res = orc.map_pairs(s1, off, s2, off, opts=oracle_mod.default_opts(**oo), nthreads=8)
+            gr = mp.map_pairs(s1, off, s2, off, opts=ra.default_opts(**go))
+            assert res.counters["totHits"] > 700
+            assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "%d bp %s" % (L, oo))
+            assert res.counters == gr.counters
+    # mixed with 100 bp reads
+    a1, a2, ao, _ = synth.make_reads(txps, 1000, seed=9, read_len=100, err=0.01)
+    r1 = [s1[off[i]:off[i + 1]].tobytes() for i in range(300)] + [a1[ao[i]:ao[i + 1]].tobytes() for i in range(1000)]
+    r2 = [s2[off[i]:off[i + 1]].tobytes() for i in range(300)] + [a2[ao[i]:ao[i + 1]].tobytes() for i in range(1000)]
+    q1, o1 = pack(r1); q2, o2 = pack(r2)
+    qi, mp = _gpu(synth_medium["idx"], debug=False)
+    res = orc.map_pairs(q1, o1, q2, o2, nthreads=8)
+    gr = mp.map_pairs(q1, o1, q2, o2)
+    assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "mixed lengths")

@@ -49,7 +49,7 @@ def _cases(seed, n):
 
 
 # (match, mismatch, gap open, gap extend, band): bands <= 33 run on the 64-slot ring, <= 97 on 128 slots, everything else
-# (and the "whole matrix" band -1) on 512
+# (and the "whole matrix" band -1) on 1024
 SCHEMES = [(2, -4, 4, 2, 15), (2, -4, 4, 2, 5), (1, -1, 1, 1, 15), (2, -6, 5, 3, 33), (2, -4, 4, 2, 0), (4, -4, 6, 2, 20),
            (2, -4, 4, 2, 34), (2, -4, 4, 2, 40), (2, -6, 5, 3, 64), (1, -1, 1, 1, 97), (2, -4, 4, 2, 98), (2, -4, 4, 2, 150),
            (2, -4, 4, 2, 1000), (2, -4, 4, 2, -1)]
@@ -87,7 +87,7 @@ def test_ksw_rows_kernel_four_at_a_time(scheme):
     assert not bad, "%d mismatches, first: %r" % (len(bad), bad[:5])
 
 
-@pytest.mark.parametrize("ring", [64, 128, 512])
+@pytest.mark.parametrize("ring", [64, 128, 1024])
 def test_ksw_rows_every_ring_gives_the_same_scores(ring):
     """a band that fits the smallest ring must score the same on the larger ones (the ring is storage, not arithmetic)"""
     ol = oracle._lib(); el = emu._lib()
@@ -102,16 +102,17 @@ def test_ksw_rows_every_ring_gives_the_same_scores(ring):
                 assert out[k] == ref, (ring, w, len(qq), len(tt), ref, out[k])
 
 
-def test_ksw_rows_longest_alignments():
-    """256-base queries against 276-base targets (the longest the -s path produces), narrow to full band"""
+@pytest.mark.parametrize("qmax", [256, 512])
+def test_ksw_rows_longest_alignments(qmax):
+    """queries of up to 512 bases against targets 20 longer (the longest the -s path produces), narrow to full band"""
     ol = oracle._lib(); el = emu._lib()
     ol.qo_ksw_extz2.restype = C.c_int
-    rng = np.random.default_rng(31)
+    rng = np.random.default_rng(31 + qmax)
     for w in (15, 33, 60, 97, 200, -1):
         grp = []
         for _ in range(4):
-            q = rng.integers(0, 4, int(rng.integers(230, 257))).astype(np.uint8)
-            t = _mutate(rng, q, min(276, len(q) + 20), sub=0.03, indel=0.01)
+            q = rng.integers(0, 4, int(rng.integers(qmax - 26, qmax + 1))).astype(np.uint8)
+            t = _mutate(rng, q, len(q) + 20, sub=0.03, indel=0.01)
             grp.append((q, t))
         out = _rows(el, grp, 2, -4, 4, 2, w)
         for k, (qq, tt) in enumerate(grp):
