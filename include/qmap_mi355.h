@@ -160,6 +160,8 @@ int qm_map_device(qm_ctx* ctx, const qm_opts* opts, int64_t n, const void* d_seq
  * hit_offsets[n+1] (exclusive prefix sum), hits[n_hits].  Large results come
  * down through pinned staging buffers and are placed by several host threads. */
 int qm_fetch_hits(qm_ctx* ctx, int64_t* hit_offsets, qm_hit* hits);
+/* The same into PAGE-LOCKED destination memory (hipHostMalloc / hipHostRegister): straight DMA, no staging, no host copy. */
+int qm_fetch_hits_pinned(qm_ctx* ctx, int64_t* hit_offsets, qm_hit* hits);
 /* Device pointers of the same arrays (valid until the next map call on ctx). */
 int qm_result_device(qm_ctx* ctx, const void** d_hit_offsets, const void** d_hits);
 
@@ -237,6 +239,29 @@ int qm_reader_next(qm_reader* r, int64_t max_units, int64_t* n_units, const char
                    const char** names2, const int64_t** name_off2);
 void qm_reader_close(qm_reader* r);
 const char* qm_io_last_error(void);
+
+/* FASTA/FASTQ files -> mapped batches, pipelined (the ingest side of the path; replaces the single kseq
+ * producer + per-record std::strings of src/FastxParser.cpp:229-328).  A reader thread parses the next batch into pinned
+ * host buffers while two device contexts (sharing the index replica) upload, map and download the previous ones; the caller
+ * drains the batches in input order.  Everything a batch points to -- reads, names, hit offsets, hits -- is pinned memory owned by
+ * the stream and stays valid until the next qm_stream_next call.  n_units == 0: end of input.  path2 == NULL: single-end. */
+typedef struct qm_stream qm_stream;
+typedef struct qm_stream_batch {
+  int64_t n_units;
+  const char* seq1; const int64_t* off1; const char* names1; const int64_t* name_off1;
+  const char* seq2; const int64_t* off2; const char* names2; const int64_t* name_off2;
+  const int64_t* hit_offsets; const qm_hit* hits; int64_t n_hits;
+  qm_counters counters;
+  double gpu_ms;
+} qm_stream_batch;
+int qm_stream_open(const qm_index* ix, int device_id, uint32_t ctx_flags, const qm_opts* opts, const char* path1, const char* path2,
+                   int64_t batch_units, int32_t reader_threads, qm_stream** out);
+int qm_stream_next(qm_stream* s, qm_stream_batch* batch);
+void qm_stream_close(qm_stream* s);
+/* seconds spent so far: [0] reader (parse + pack), [1] upload + kernels (both contexts), [2] download, [3] the caller waiting in
+ * qm_stream_next, [4] qm_stream_open, [5] growing the pinned result buffers */
+int qm_stream_stats(qm_stream* s, double* out6);
+const char* qm_stream_last_error(void);
 
 /* SAM text of a mapped batch, byte for byte what `rapmap quasimap -o` writes: header = writeSAMHeader
  * (include/RapMapUtils.hpp:97-115); records = writeAlignmentsToStream / writeUnalignedPairToStream

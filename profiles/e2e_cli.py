@@ -16,28 +16,15 @@ import rapmap_amd as ra  # noqa: E402
 from rapmap_amd import synth  # noqa: E402
 
 
-def write_fastq(path, seq, n, L, mate):
-    # fixed-width records: "@r%09d/m\n" + L + "\n+\n" + L + "\n"
-    rec = np.empty((n, 13), dtype=np.uint8)
-    rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
-    idx = np.arange(n, dtype=np.int64)
-    for d in range(9):
-        rec[:, 10 - d] = ord("0") + (idx // (10 ** d)) % 10
-    rec[:, 11] = ord("/"); rec[:, 12] = ord(str(mate))
-    body = np.empty((n, 1 + L + 3 + L + 1), dtype=np.uint8)
-    body[:, 0] = ord("\n")
-    body[:, 1:1 + L] = seq.reshape(n, L)
-    body[:, 1 + L] = ord("\n"); body[:, 2 + L] = ord("+"); body[:, 3 + L] = ord("\n")
-    body[:, 4 + L:4 + 2 * L] = ord("I")
-    body[:, 4 + 2 * L] = ord("\n")
-    out = np.concatenate([rec, body], axis=1)
-    out.tofile(path)
+write_fastq = synth.write_fastq
 
 
 def main():
     genes = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
     pairs = int(sys.argv[2]) if len(sys.argv) > 2 else 2_000_000
     threads = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+    chunks = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [1 << 20]
+    thr_list = [int(x) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else [threads]
     d = tempfile.mkdtemp(prefix="qme2e", dir="/dev/shm")
     names, txps = synth.make_transcriptome(genes, seed=42)
     fa = os.path.join(d, "t.fa"); synth.write_fasta(fa, names, txps)
@@ -47,10 +34,14 @@ def main():
     f1 = os.path.join(d, "r1.fq"); f2 = os.path.join(d, "r2.fq")
     write_fastq(f1, s1, pairs, 100, 1); write_fastq(f2, s2, pairs, 100, 2)
     print("[e2e] FASTQ: 2 x %.0f MB on tmpfs" % (os.path.getsize(f1) / 1e6), flush=True)
-    base = [sys.executable, "-m", "rapmap_amd", "quasimap", "-i", os.path.join(d, "idx"), "-1", f1, "-2", f2, "-t", str(threads),
-            "--chunk", str(1 << 20)]
     env = dict(os.environ, PYTHONPATH=ROOT)
-    for label, extra in (("FASTQ -> hits (-n)", ["-n"]), ("FASTQ -> SAM on tmpfs (-o)", ["-o", os.path.join(d, "out.sam")])):
+    runs = []
+    for ch in chunks:
+        for th in thr_list:
+            runs.append(("FASTQ -> hits (-n) chunk %d t%d" % (ch, th), ["-n"], ch, th))
+    runs.append(("FASTQ -> SAM on tmpfs (-o)", ["-o", os.path.join(d, "out.sam")], chunks[-1], thr_list[-1]))
+    for label, extra, ch, th in runs:
+        base = [sys.executable, "-m", "rapmap_amd", "quasimap", "-i", os.path.join(d, "idx"), "-1", f1, "-2", f2, "-t", str(th), "--chunk", str(ch)]
         best = None
         for rep in range(2):
             t = time.time()
@@ -59,7 +50,7 @@ def main():
             if r.returncode != 0:
                 print(r.stderr[-2000:]); sys.exit(1)
             best = dt if best is None else min(best, dt)
-        tail = [l for l in r.stderr.splitlines() if "Elapsed" in l or "Final" in l]
+        tail = [l for l in r.stderr.splitlines() if "Elapsed" in l or "Final" in l or l.startswith("stream:")]
         print("[e2e] %-28s %6.2f s  -> %6.2f M pairs/s end to end (process start to exit; %s)" % (label, best, pairs / best / 1e6, "; ".join(tail)), flush=True)
     if os.path.exists(os.path.join(d, "out.sam")):
         print("[e2e] SAM size %.0f MB" % (os.path.getsize(os.path.join(d, "out.sam")) / 1e6))

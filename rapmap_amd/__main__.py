@@ -66,7 +66,7 @@ def _quasimap(argv):
     ap.add_argument("--mimicStrictBT2", action="store_true")
     ap.add_argument("--maxMMPExtension", type=int, default=7)
     ap.add_argument("--device", type=int, default=0, help="GPU to use")
-    ap.add_argument("--chunk", type=int, default=1 << 20, help="read pairs per GPU batch")
+    ap.add_argument("--chunk", type=int, default=1 << 18, help="read pairs per GPU batch")
     a = ap.parse_args(argv)
 
     paired = bool(a.leftMates and a.rightMates)
@@ -108,7 +108,6 @@ def _quasimap(argv):
         if a.mimicStrictBT2:
             opts.min_score_fraction = 0.8; opts.match_score = 1; opts.mismatch_penalty = 0; opts.gap_open = 25; opts.gap_extend = 25
     qi = ra.QuasiIndex(a.index)
-    mp = ra.QuasiMapper(qi, a.device, reuse_results=True)
     log = (lambda *x: None) if a.quiet else (lambda *x: print(*x, file=sys.stderr, flush=True))
     out = None
     if not a.noOutput:
@@ -130,8 +129,9 @@ def _quasimap(argv):
     t0 = time.time()
     gpu_ms = 0.0
     nthr = max(1, a.numThreads)
-    # ingest (qm_reader_*) and SAM text (qm_sam_*) are the library's native, multi-threaded host code;
-    # -t sets their worker count
+    # ingest, mapping and result download are the library's pipelined stream (qm_stream_*): a reader thread parses the next
+    # batch into pinned memory while two device contexts map the previous ones; SAM text (qm_sam_*) is formatted here from
+    # the batch's pinned arrays.  -t sets the reader's / the formatter's worker count.
     if paired:
         files1, files2 = a.leftMates.split(","), a.rightMates.split(",")
         if len(files1) != len(files2):
@@ -140,24 +140,21 @@ def _quasimap(argv):
     else:
         pairs = [(f, None) for f in a.unmatedReads.split(",")]
     for f1, f2 in pairs:
-        rd = ra.FastxReader(f1, f2, threads=nthr)
-        for b in rd.chunks(a.chunk):
-            if paired:
-                r = mp.map_pairs(b.seq1, b.off1, b.seq2, b.off2, opts=opts)
-            else:
-                r = mp.map_reads(b.seq1, b.off1, opts=opts)
-            gpu_ms += r.total_ms
+        st = ra.MappedStream(qi, f1, f2, opts=opts, device=a.device, batch_units=a.chunk, threads=nthr)
+        for b in st:
+            gpu_ms += b.gpu_ms
             for kk in tot:
-                tot[kk] += r.counters[kk]
+                tot[kk] += b.counters[kk]
             if out is not None:
                 if direct_fd is not None:
-                    ra.sam_records_text(qi, b, r.hit_offsets, r.hits, max_num_hits=opts.max_num_hits, threads=nthr, fd=direct_fd)
+                    ra.sam_records_text(qi, b, b.hit_offsets, b.hits, max_num_hits=opts.max_num_hits, threads=nthr, fd=direct_fd)
                 else:
-                    out.write(ra.sam_records_text(qi, b, r.hit_offsets, r.hits, max_num_hits=opts.max_num_hits, threads=nthr))
+                    out.write(ra.sam_records_text(qi, b, b.hit_offsets, b.hits, max_num_hits=opts.max_num_hits, threads=nthr))
             if paired:
                 log("saw %d reads : pe / read = %.4f : se / read = %.4f" % (
                     tot["numReads"], tot["peHits"] / max(1, tot["numReads"]), tot["seHits"] / max(1, tot["numReads"])))
-        rd.close()
+        log("stream: " + ", ".join("%s %.3f" % kv for kv in st.stats().items()))
+        st.close()
     if out is not None and out is not sys.stdout.buffer:
         out.close()
     log("Done mapping reads.")

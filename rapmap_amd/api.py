@@ -34,7 +34,8 @@ ABI_SYMBOLS = [
     "qm_map_pairs", "qm_map_reads", "qm_map_device", "qm_fetch_hits", "qm_result_device", "qm_ctx_set_debug",
     "qm_fetch_intervals", "qm_last_kernel_ms", "qm_ctx_stat", "qm_build_index",
     "qm_collect_reads", "qm_fetch_found", "qm_hits_to_mappings", "qm_fetch_read_lists", "qm_merge_lists", "qm_fetch_too_many",
-    "qm_map_pairs_stages", "qm_ctx_create_ex",
+    "qm_map_pairs_stages", "qm_ctx_create_ex", "qm_fetch_hits_pinned",
+    "qm_stream_open", "qm_stream_next", "qm_stream_close", "qm_stream_last_error", "qm_stream_stats",
     "qm_reader_open", "qm_reader_next", "qm_reader_close", "qm_io_last_error", "qm_sam_header", "qm_sam_records",
     "qm_sam_write", "qm_buf_free",
 ]
@@ -62,6 +63,19 @@ class QmCounters(C.Structure):
     def as_dict(self):
         return {"peHits": self.pe_hits, "seHits": self.se_hits, "totHits": self.tot_hits,
                 "numReads": self.num_reads, "tooManyHits": self.too_many_hits, "mappedUnits": self.mapped}
+
+
+class QmHitRaw(C.Structure):
+    _fields_ = [("b", C.c_uint8 * 32)]
+
+
+class QmStreamBatch(C.Structure):
+    """qm_stream_batch (include/qmap_mi355.h): pointers into the stream's pinned buffers"""
+    _fields_ = [("n_units", C.c_int64),
+                ("seq1", C.c_void_p), ("off1", C.c_void_p), ("names1", C.c_void_p), ("name_off1", C.c_void_p),
+                ("seq2", C.c_void_p), ("off2", C.c_void_p), ("names2", C.c_void_p), ("name_off2", C.c_void_p),
+                ("hit_offsets", C.c_void_p), ("hits", C.c_void_p), ("n_hits", C.c_int64),
+                ("counters", QmCounters), ("gpu_ms", C.c_double)]
 
 
 class QmIndexInfo(C.Structure):
@@ -116,6 +130,12 @@ def lib():
     L.qm_merge_lists.argtypes = [C.c_void_p, C.POINTER(QmOpts), C.c_int64] + [C.c_void_p] * 8 + [C.POINTER(C.c_int64), C.POINTER(QmCounters)]
     L.qm_fetch_too_many.argtypes = [C.c_void_p, C.c_void_p]
     L.qm_map_pairs_stages.argtypes = L.qm_map_pairs.argtypes
+    L.qm_stream_open.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(QmOpts), C.c_char_p, C.c_char_p, C.c_int64, C.c_int32,
+                                 C.POINTER(C.c_void_p)]
+    L.qm_stream_next.argtypes = [C.c_void_p, C.POINTER(QmStreamBatch)]
+    L.qm_stream_close.argtypes = [C.c_void_p]
+    L.qm_stream_last_error.restype = C.c_char_p
+    L.qm_fetch_hits_pinned.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.qm_build_index.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.qm_opts_default.argtypes = [C.POINTER(QmOpts)]
     L.qm_io_last_error.restype = C.c_char_p
@@ -420,6 +440,67 @@ class FastxReader:
     def close(self):
         if self._h:
             lib().qm_reader_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MappedStream:
+    """FASTA/FASTQ files -> mapped batches through the library's pipelined stream (qm_stream_*): reader thread, two device
+    contexts, results in pinned memory.  Iterating yields ReadBatch objects that also carry hit_offsets / hits / counters;
+    every array is a zero-copy view that stays valid until the next batch is taken."""
+
+    def __init__(self, index: QuasiIndex, path1, path2=None, opts=None, device=0, batch_units=1 << 20, threads=None, ph_compact=False):
+        self._h = C.c_void_p()
+        self.paired = path2 is not None
+        opts = opts or default_opts()
+        rc = lib().qm_stream_open(index._h, int(device), 1 if ph_compact else 0, C.byref(opts), os.fsencode(path1),
+                                  os.fsencode(path2) if path2 else None, int(batch_units),
+                                  int(threads or min(32, os.cpu_count() or 1)), C.byref(self._h))
+        if rc != 0:
+            raise QmError("qm_stream_open failed (%d): %s" % (rc, lib().qm_stream_last_error().decode(errors="replace")))
+
+    def __iter__(self):
+        L = lib()
+        sb = QmStreamBatch()
+
+        def arr(p, count, dt):
+            if count == 0 or not p:
+                return np.zeros(0, dtype=dt)
+            ct = {np.int64: C.c_int64, np.uint8: C.c_uint8}.get(dt, C.c_uint8)
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(count,))
+        while True:
+            rc = L.qm_stream_next(self._h, C.byref(sb))
+            if rc != 0:
+                raise QmError("qm_stream_next failed (%d): %s" % (rc, L.qm_stream_last_error().decode(errors="replace")))
+            if sb.n_units == 0:
+                return
+            b = ReadBatch(); b.n = n = sb.n_units
+            b.off1 = arr(sb.off1, n + 1, np.int64); b.seq1 = arr(sb.seq1, int(b.off1[-1]), np.uint8)
+            b.name_off1 = arr(sb.name_off1, n + 1, np.int64); b.names1 = arr(sb.names1, int(b.name_off1[-1]), np.uint8)
+            if self.paired:
+                b.off2 = arr(sb.off2, n + 1, np.int64); b.seq2 = arr(sb.seq2, int(b.off2[-1]), np.uint8)
+                b.name_off2 = arr(sb.name_off2, n + 1, np.int64); b.names2 = arr(sb.names2, int(b.name_off2[-1]), np.uint8)
+            b.hit_offsets = arr(sb.hit_offsets, n + 1, np.int64)
+            b.n_hits = sb.n_hits
+            b.hits = arr(sb.hits, sb.n_hits * 32, np.uint8).view(HIT_DTYPE) if sb.n_hits else np.zeros(0, dtype=HIT_DTYPE)
+            b.counters = sb.counters.as_dict()
+            b.gpu_ms = sb.gpu_ms
+            yield b
+
+    def stats(self):
+        a = (C.c_double * 6)()
+        lib().qm_stream_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        _check(lib().qm_stream_stats(self._h, a))
+        return dict(zip(("read_s", "map_s", "fetch_s", "caller_wait_s", "open_s", "alloc_s"), [float(x) for x in a]))
+
+    def close(self):
+        if self._h:
+            lib().qm_stream_close(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -16,6 +16,10 @@ hipError_t qmk_build_slots(const void* recs, long long K, void* slots, unsigned 
 hipError_t qmk_build_slots_from_ph(const void* dev_index, long long n, void* slots, unsigned long long cap, unsigned long long* d_bad, hipStream_t st);
 hipError_t qmk_build_phrecs(const int* data, const unsigned char* lens, long long n, const void* dev_index, void* out, hipStream_t st);
 int qmk_map_grid(long long n, int num_cu);
+hipError_t qmk_launch_reads_ns2(const void* dev_index, const void* read_batch, int collect, int grid, int num_cu, hipStream_t st);
+hipError_t qmk_launch_reads_ns3(const void* dev_index, const void* read_batch, int collect, int grid, int num_cu, hipStream_t st);
+hipError_t qmk_launch_reads_ns4(const void* dev_index, const void* read_batch, int collect, int grid, int num_cu, hipStream_t st);
+hipError_t qmk_launch_reads_ns8(const void* dev_index, const void* read_batch, int collect, int grid, int num_cu, hipStream_t st);
 hipError_t qmk_map_reads(const void* dev_index, const void* read_batch, int ns, int grid, int num_cu, hipStream_t st);
 // ns < 0: the "collector only" stage entry (NS=4 kernels with QM_F_COLLECT)
 hipError_t qmk_h2m(const void* dev_index, const void* read_batch, int grid, int num_cu, hipStream_t st);

@@ -888,6 +888,15 @@ int qm_fetch_hits(qm_ctx* c, int64_t* hit_offsets, qm_hit* hits) {
   return QM_OK;
 }
 
+int qm_fetch_hits_pinned(qm_ctx* c, int64_t* hit_offsets, qm_hit* hits) {
+  if (!c || c->lastUnits < 0) return fail(QM_E_STATE, "no mapping result to fetch");
+  HIPCHK(hipSetDevice(c->device));
+  if (hit_offsets) HIPCHK(hipMemcpyAsync(hit_offsets, c->d_offs, (size_t)(c->lastUnits + 1) * 8, hipMemcpyDeviceToHost, c->copyStream));
+  if (hits && c->lastHits > 0) HIPCHK(hipMemcpyAsync(hits, c->d_hits, (size_t)c->lastHits * sizeof(qm_hit), hipMemcpyDeviceToHost, c->copyStream));
+  HIPCHK(hipStreamSynchronize(c->copyStream));
+  return QM_OK;
+}
+
 int qm_result_device(qm_ctx* c, const void** d_hit_offsets, const void** d_hits) {
   if (!c || c->lastUnits < 0) return fail(QM_E_STATE, "no mapping result");
   if (d_hit_offsets) *d_hit_offsets = c->d_offs;

@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "../../include/qmap_mi355.h"
+#include "qm_io_internal.h"
 
 static thread_local char g_ioerr[512] = "";
 static int io_fail(int code, const char* fmt, ...) {
@@ -229,10 +230,22 @@ struct Source {
   }
 };
 
-// copy n records starting at S.idx[S.head] into one packed batch (parallel over records)
-static void pack_records(Source& S, int64_t n, int nthreads, std::vector<char>& seq, std::vector<int64_t>& off,
-                         std::vector<char>& names, std::vector<int64_t>& noff) {
-  off.resize((size_t)n + 1); noff.resize((size_t)n + 1);
+// copy n records starting at S.idx[S.head] into one packed batch (parallel over records).  Dst owns four growable arrays.
+struct Dst {
+  char** seq; int64_t** off; char** names; int64_t** noff;
+  size_t* capSeq; size_t* capOff; size_t* capNames; size_t* capNoff;
+  void* (*alloc)(size_t); void (*release)(void*);
+  template <typename T> bool ensure(T** p, size_t* cap, size_t want) {
+    if (*p && *cap >= want) return true;
+    if (*p) release(*p);
+    const size_t nc = want + want / 4 + 4096;
+    *p = (T*)alloc(nc * sizeof(T)); *cap = *p ? nc : 0;
+    return *p != nullptr;
+  }
+};
+static bool pack_records(Source& S, int64_t n, int nthreads, Dst& D) {
+  if (!D.ensure(D.off, D.capOff, (size_t)n + 1) || !D.ensure(D.noff, D.capNoff, (size_t)n + 1)) return false;
+  int64_t* off = *D.off; int64_t* noff = *D.noff;
   const RecIdx* R = S.idx.data() + S.head;
   const int T = std::max(1, std::min<int>(nthreads, (int)(n / 16384) + 1));
   std::vector<int64_t> sb((size_t)T + 1, 0), nb((size_t)T + 1, 0);
@@ -241,12 +254,13 @@ static void pack_records(Source& S, int64_t n, int nthreads, std::vector<char>& 
     for (int64_t i = n * t / T; i < n * (t + 1) / T; ++i) { a += R[i].sl; b += R[i].nl; }
     sb[(size_t)t + 1] = a; nb[(size_t)t + 1] = b;
   };
+  char* seq = nullptr; char* names = nullptr;
   auto copy = [&](int t) {
     int64_t so = sb[(size_t)t], no = nb[(size_t)t];
     for (int64_t i = n * t / T; i < n * (t + 1) / T; ++i) {
       off[(size_t)i] = so; noff[(size_t)i] = no;
-      memcpy(seq.data() + so, R[i].s, R[i].sl); so += R[i].sl;
-      memcpy(names.data() + no, R[i].nm, R[i].nl); no += R[i].nl;
+      memcpy(seq + so, R[i].s, R[i].sl); so += R[i].sl;
+      memcpy(names + no, R[i].nm, R[i].nl); no += R[i].nl;
     }
   };
   auto run = [&](auto fn) {
@@ -255,18 +269,22 @@ static void pack_records(Source& S, int64_t n, int nthreads, std::vector<char>& 
   };
   run(count);
   for (int t = 0; t < T; ++t) { sb[(size_t)t + 1] += sb[(size_t)t]; nb[(size_t)t + 1] += nb[(size_t)t]; }
-  seq.resize((size_t)sb[(size_t)T] + 1); names.resize((size_t)nb[(size_t)T] + 1);
+  if (!D.ensure(D.seq, D.capSeq, (size_t)sb[(size_t)T] + 64) || !D.ensure(D.names, D.capNames, (size_t)nb[(size_t)T] + 1)) return false;
+  seq = *D.seq; names = *D.names;
   run(copy);
+  memset(seq + sb[(size_t)T], 0, 64);                       // the mapper fetches reads a word at a time: defined bytes behind the last one
   off[(size_t)n] = sb[(size_t)T]; noff[(size_t)n] = nb[(size_t)T];
   S.head += (size_t)n; S.handed += n;
+  return true;
 }
 
 }  // namespace
 
 struct qm_reader {
   Source src[2]; int nsrc = 0; int nthreads = 1;
-  std::vector<char> seq[2], names[2];
-  std::vector<int64_t> off[2], noff[2];
+  qm_batch_bufs own;           // the buffers qm_reader_next hands out (plain malloc)
+  qm_reader() { memset(&own, 0, sizeof(own)); own.alloc = malloc; own.release = free; }
+  ~qm_reader() { for (int s = 0; s < 2; ++s) { free(own.seq[s]); free(own.off[s]); free(own.names[s]); free(own.noff[s]); } }
 };
 
 extern "C" {
@@ -289,10 +307,9 @@ void qm_reader_close(qm_reader* r) {
   delete r;
 }
 
-int qm_reader_next(qm_reader* r, int64_t max_units, int64_t* n_units, const char** seq1, const int64_t** off1,
-                   const char** names1, const int64_t** name_off1, const char** seq2, const int64_t** off2,
-                   const char** names2, const int64_t** name_off2) {
-  if (!r || !n_units || max_units <= 0) return io_fail(QM_E_ARG, "qm_reader_next: bad argument");
+// parse until max_units records are available (or the input ends) and pack them into B's buffers (grown through B's allocator)
+int qm_reader_next_into(qm_reader* r, int64_t max_units, int64_t* n_units, qm_batch_bufs* B) {
+  if (!r || !n_units || !B || max_units <= 0) return io_fail(QM_E_ARG, "qm_reader_next: bad argument");
   const size_t block = (size_t)128 << 20;
   const int per = std::max(1, r->nthreads / r->nsrc);
   for (int s = 0; s < r->nsrc; ++s) r->src[s].release();
@@ -316,23 +333,39 @@ int qm_reader_next(qm_reader* r, int64_t max_units, int64_t* n_units, const char
     if (n == 0 && r->src[0].avail() != r->src[1].avail())
       return io_fail(QM_E_FORMAT, "paired files have different numbers of records");
   }
+  Dst D[2];
+  for (int s = 0; s < 2; ++s)
+    D[s] = Dst{&B->seq[s], &B->off[s], &B->names[s], &B->noff[s], &B->cap_seq[s], &B->cap_off[s], &B->cap_names[s], &B->cap_noff[s], B->alloc, B->release};
+  bool ok = true;
   if (r->nsrc == 2 && n > 0) {
-    std::thread t2([&]() { pack_records(r->src[1], n, per, r->seq[1], r->off[1], r->names[1], r->noff[1]); });
-    pack_records(r->src[0], n, per, r->seq[0], r->off[0], r->names[0], r->noff[0]);
+    bool ok2 = true;
+    std::thread t2([&]() { ok2 = pack_records(r->src[1], n, per, D[1]); });
+    ok = pack_records(r->src[0], n, per, D[0]);
     t2.join();
+    ok = ok && ok2;
   } else {
-    for (int s = 0; s < r->nsrc; ++s) pack_records(r->src[s], n, r->nthreads, r->seq[s], r->off[s], r->names[s], r->noff[s]);
+    for (int s = 0; s < r->nsrc; ++s) ok = pack_records(r->src[s], n, r->nthreads, D[s]) && ok;
   }
+  if (!ok) return io_fail(QM_E_NOMEM, "out of memory for a batch of %lld reads", (long long)n);
   *n_units = n;
-  if (seq1) *seq1 = r->seq[0].data();
-  if (off1) *off1 = r->off[0].data();
-  if (names1) *names1 = r->names[0].data();
-  if (name_off1) *name_off1 = r->noff[0].data();
+  return QM_OK;
+}
+
+int qm_reader_next(qm_reader* r, int64_t max_units, int64_t* n_units, const char** seq1, const int64_t** off1,
+                   const char** names1, const int64_t** name_off1, const char** seq2, const int64_t** off2,
+                   const char** names2, const int64_t** name_off2) {
+  if (!r) return io_fail(QM_E_ARG, "qm_reader_next: bad argument");
+  int rc = qm_reader_next_into(r, max_units, n_units, &r->own);
+  if (rc) return rc;
+  if (seq1) *seq1 = r->own.seq[0];
+  if (off1) *off1 = r->own.off[0];
+  if (names1) *names1 = r->own.names[0];
+  if (name_off1) *name_off1 = r->own.noff[0];
   if (r->nsrc == 2) {
-    if (seq2) *seq2 = r->seq[1].data();
-    if (off2) *off2 = r->off[1].data();
-    if (names2) *names2 = r->names[1].data();
-    if (name_off2) *name_off2 = r->noff[1].data();
+    if (seq2) *seq2 = r->own.seq[1];
+    if (off2) *off2 = r->own.off[1];
+    if (names2) *names2 = r->own.names[1];
+    if (name_off2) *name_off2 = r->own.noff[1];
   }
   return QM_OK;
 }

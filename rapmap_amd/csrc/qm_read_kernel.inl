@@ -1,0 +1,100 @@
+// qm_read_kernel.inl -- the stage-A kernel template and its per-slot-count launch wrappers.  The 40 instantiations
+// (read-length class x index flavour x --noSensitive x -s, plus the collector-only stage entry) are spread over four
+// translation units -- qm_kernels_ns{2,3,4,8}.hip, each defining qmk_launch_reads_ns<N> -- so that they compile in parallel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include "qm_mapper.inl"
+#include "qm_device.h"
+
+namespace qm {
+
+template <bool ON> struct SelLds { SelScratchLds s; QM_DEV SelScratchLds* ptr() { return &s; } };
+template <> struct SelLds<false> { QM_DEV SelScratchLds* ptr() { return nullptr; } };
+
+// stage A: one wavefront per read.  WPS = minimum waves per SIMD the register allocator must leave room for.
+// F: compile-time feature flags (QM_F_PH, QM_F_NIP) -- the default kernel carries no optional code.
+template <int NS, int WPS, int F>
+__global__ __launch_bounds__(256, WPS) void qm_read_kernel(DevIndex ix_, ReadBatch B_) {
+  // The two argument structs (~70 dwords) are read through the kernarg segment where they are used -- scalar loads from
+  // constant memory -- instead of being loaded into SGPRs at entry and kept there: at 8 waves/SIMD a wave has 78 SGPRs, and
+  // half of the v_readlane / v_writelane spill traffic of this kernel was for these words.
+  struct Args { DevIndex ix; ReadBatch B; };
+  typedef const Args __attribute__((address_space(4)))* AP4;
+  const Args* args = (const Args*)(AP4)__builtin_amdgcn_kernarg_segment_ptr();
+  const DevIndex& ix = args->ix; const ReadBatch& B = args->B;
+  __shared__ WaveMem<NS> mem[4];
+  __shared__ SelLds<(F & QM_F_SEL) != 0> sels[4];       // -s kernels only: lane 0's chaining scratch
+  // the wave index is wave-uniform: keep it (and every address derived from it) on the scalar unit
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int gw = (int)blockIdx.x * 4 + wave;             // reads per launch < 2^31: 32-bit slot arithmetic
+  const int nw = (int)gridDim.x * 4;
+  const int nreads = (int)B.nreads;
+  u64* gscr = B.gscratch + (long long)gw * QM_GSCR_U64;
+  WaveAlloc wa; wa.base = -1; wa.used = 0;
+#ifdef QM_TIMING
+  if ((threadIdx.x & 63) == 0) { for (int i = 0; i < 9; ++i) qm_tim[wave][i] = 0; qm_tim[wave][9] = __builtin_readcyclecounter(); }
+#endif
+  // reads gw, gw + nw, ...: characters of the next read and offsets of the one after are staged in LDS while a read is mapped
+  WaveMem<NS>& M = mem[wave];
+  stage_offsets<NS, F>(B, gw, M, 0);
+  lds_dma_wait();
+  stage_chars<NS, F>(B, gw, M, 0);
+  stage_offsets<NS, F>(B, gw + nw, M, 1);
+  lds_dma_wait();
+  int par = 0;
+  for (int r = gw; r < nreads; r += nw) {
+    map_read<NS, F>(ix, B, read_id<F>(B, r), r, nw, par, M, gscr, wa, (F & QM_F_SEL) ? B.selscr + gw : nullptr, sels[wave].ptr(),
+                    ((F & QM_F_SEL) && B.dyn) ? B.dyn + gw : nullptr);
+    par ^= 1;
+  }
+#ifdef QM_TIMING
+  if ((threadIdx.x & 63) == 0) for (int i = 0; i < 7; ++i) atomicAdd((unsigned long long*)&B.cursor[20 + i], (unsigned long long)qm_tim[wave][i]);
+#endif
+}
+
+
+// launch of one slot-count class; collect: the collector-only stage entry (QM_F_COLLECT)
+template <int NS, int W0, int WPH, int WNIP, int WPHNIP, int WSEL, bool WITH_COLLECT>
+static hipError_t launch_reads_ns(const DevIndex& ix, const ReadBatch& B, bool collect, int grid, int num_cu, hipStream_t st) {
+  const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP) | (B.selscr ? QM_F_SEL : 0);
+  // The kernel is a persistent grid (every wave strides over the reads), so the launch must not exceed what is resident at
+  // once: blocks beyond residency would run as a second, under-populated round.  The occupancy of the chosen instantiation
+  // (VGPR/LDS dependent) decides the grid.
+#define QM_LAUNCH(WPS_, F_) do {                                                                               \
+    static int nb = 0;                                                                                          \
+    if (nb == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, qm_read_kernel<NS, WPS_, F_>, 256, 0) != hipSuccess || nb < 1)) \
+      nb = WPS_;                                                                                                \
+    static const char* ov = getenv("QM_BLOCKS_PER_CU");   /* tuning knob: fewer resident blocks than the occupancy allows */ \
+    long long g = (long long)num_cu * ((ov && atoi(ov) > 0 && atoi(ov) < nb) ? atoi(ov) : nb);                  \
+    if (g > grid) g = grid;                                                                                     \
+    hipLaunchKernelGGL((qm_read_kernel<NS, WPS_, F_>), dim3((unsigned)g), dim3(256), 0, st, ix, B);             \
+  } while (0)
+  if constexpr (WITH_COLLECT) if (collect) {
+    switch (F) {
+      case 0: QM_LAUNCH(W0, QM_F_COLLECT); break;
+      case QM_F_PH: QM_LAUNCH(WPH, QM_F_PH | QM_F_COLLECT); break;
+      case QM_F_NIP: QM_LAUNCH(WNIP, QM_F_NIP | QM_F_COLLECT); break;
+      case QM_F_PH | QM_F_NIP: QM_LAUNCH(WPHNIP, QM_F_PH | QM_F_NIP | QM_F_COLLECT); break;
+      case QM_F_SEL: QM_LAUNCH(WSEL, QM_F_SEL | QM_F_COLLECT); break;
+      case QM_F_SEL | QM_F_PH: QM_LAUNCH(WSEL, QM_F_SEL | QM_F_PH | QM_F_COLLECT); break;
+      case QM_F_SEL | QM_F_NIP: QM_LAUNCH(WSEL, QM_F_SEL | QM_F_NIP | QM_F_COLLECT); break;
+      default: QM_LAUNCH(WSEL, QM_F_SEL | QM_F_PH | QM_F_NIP | QM_F_COLLECT); break;
+    }
+    return hipGetLastError();
+  }
+  switch (F) {
+    case 0: QM_LAUNCH(W0, 0); break;
+    case QM_F_PH: QM_LAUNCH(WPH, QM_F_PH); break;
+    case QM_F_NIP: QM_LAUNCH(WNIP, QM_F_NIP); break;
+    case QM_F_PH | QM_F_NIP: QM_LAUNCH(WPHNIP, QM_F_PH | QM_F_NIP); break;
+    case QM_F_SEL: QM_LAUNCH(WSEL, QM_F_SEL); break;
+    case QM_F_SEL | QM_F_PH: QM_LAUNCH(WSEL, QM_F_SEL | QM_F_PH); break;
+    case QM_F_SEL | QM_F_NIP: QM_LAUNCH(WSEL, QM_F_SEL | QM_F_NIP); break;
+    default: QM_LAUNCH(WSEL, QM_F_SEL | QM_F_PH | QM_F_NIP); break;
+  }
+#undef QM_LAUNCH
+  return hipGetLastError();
+}
+
+}  // namespace qm

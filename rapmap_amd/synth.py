@@ -93,3 +93,20 @@ def make_reads(txps, n_pairs, seed=43, read_len=100, err=0.01, n_rate=0.0, chunk
         truth[b:e, 1] = st
     off = np.arange(n_pairs + 1, dtype=np.int64) * L
     return s1, s2, off, truth
+
+
+def write_fastq(path, seq, n, L, mate):
+    """n fixed-width FASTQ records "@r%09d/m" + L bases + "+" + L quality characters, written in one go"""
+    rec = np.empty((n, 13), dtype=np.uint8)
+    rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
+    idx = np.arange(n, dtype=np.int64)
+    for d in range(9):
+        rec[:, 10 - d] = ord("0") + (idx // (10 ** d)) % 10
+    rec[:, 11] = ord("/"); rec[:, 12] = ord(str(mate))
+    body = np.empty((n, 1 + L + 3 + L + 1), dtype=np.uint8)
+    body[:, 0] = ord("\n")
+    body[:, 1:1 + L] = np.asarray(seq).reshape(n, L)
+    body[:, 1 + L] = ord("\n"); body[:, 2 + L] = ord("+"); body[:, 3 + L] = ord("\n")
+    body[:, 4 + L:4 + 2 * L] = ord("I")
+    body[:, 4 + 2 * L] = ord("\n")
+    np.concatenate([rec, body], axis=1).tofile(path)

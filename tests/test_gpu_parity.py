@@ -288,7 +288,8 @@ def test_device_resident_inputs(synth_medium, oracle_mod):
     n = 5000
     o = synth_medium["off"][: n + 1]
     q1 = synth_medium["seq1"][: o[-1]]; q2 = synth_medium["seq2"][: o[-1]]
-    d1 = torch.from_numpy(q1).cuda(); d2 = torch.from_numpy(q2).cuda(); do = torch.from_numpy(o).cuda()
+    pad = np.zeros(8, np.uint8)                                  # the device buffers extend past the last read (qmap_mi355.h)
+    d1 = torch.from_numpy(np.concatenate([q1, pad])).cuda(); d2 = torch.from_numpy(np.concatenate([q2, pad])).cuda(); do = torch.from_numpy(o).cuda()
     torch.cuda.synchronize()
     gr = mp.map_device(n, d1.data_ptr(), do.data_ptr(), d2.data_ptr(), do.data_ptr(), 100, fetch=True)
     res = orc.map_pairs(q1, o, q2, o, nthreads=4)

@@ -159,3 +159,34 @@ def test_sam_writer_matches_python_formatter(synth_small, oracle_mod, opts):
     want = "".join(sam.format_single(synth_small["names1"][i], synth_small["reads1"][i],
                                      rs.hits[rs.hit_offsets[i]:rs.hit_offsets[i + 1]], ix.names, ix.txpLens) for i in range(sb.n))
     assert got == want.encode()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [777, 4096, 1 << 20])
+def test_pipelined_stream_matches_the_oracle(sample_data, oracle_mod, batch):
+    """qm_stream_*: FASTQ(.gz) -> mapped batches, reader and two device contexts running ahead of the caller; batches come back in
+    input order with the oracle's hits, whatever the batch size (many small batches keep every slot of the ring in flight)"""
+    import rapmap_amd as ra
+    ix, orc = load_oracle(sample_data["idx"])
+    qi = ra.QuasiIndex(sample_data["idx"])
+    q1, o1 = pack(sample_data["reads1"]); q2, o2 = pack(sample_data["reads2"])
+    res = orc.map_pairs(q1, o1, q2, o2, nthreads=2)
+    st = ra.MappedStream(qi, os.path.join(GOLD, "sample_data", "reads_1.fastq.gz"), os.path.join(GOLD, "sample_data", "reads_2.fastq.gz"),
+                         batch_units=batch, threads=4)
+    u = 0; tot = 0; cnts = []; hits = []
+    for b in st:
+        assert bytes(b.seq1[: b.off1[1]]) == sample_data["reads1"][u]
+        cnts.append(np.diff(b.hit_offsets).copy()); hits.append(b.hits.copy()); tot += b.counters["totHits"]; u += b.n
+    st.close()
+    assert u == len(o1) - 1 and tot == res.counters["totHits"]
+    assert np.array_equal(np.concatenate(cnts), np.diff(res.hit_offsets))
+    assert np.concatenate(hits).tobytes() == res.hits.tobytes()
+    # single-end, plain text input through a temporary file
+    import gzip, tempfile
+    with tempfile.NamedTemporaryFile(suffix=".fq") as f:
+        f.write(gzip.open(os.path.join(GOLD, "sample_data", "reads_2.fastq.gz")).read()); f.flush()
+        st = ra.MappedStream(qi, f.name, None, batch_units=batch, threads=3)
+        rs = orc.map_single(q2, o2, nthreads=2)
+        got = np.concatenate([b.hits.copy() for b in st]) if True else None
+        st.close()
+        assert got.tobytes() == rs.hits.tobytes()
