@@ -89,7 +89,6 @@ def _quasimap(argv):
         print("--chaining without --selAln does not change the mapping (as in the reference: doChaining follows --selAln)", file=sys.stderr)
 
     import rapmap_amd as ra
-    from rapmap_amd import sam
     opts = ra.default_opts(sensitive=0 if a.noSensitive else 1, strict_check=0 if a.noStrictCheck else 1,
                            max_num_hits=a.maxNumHits, no_orphans=int(a.noOrphans), no_dovetail=int(a.noDovetail),
                            fuzzy=int(a.fuzzyIntersection), sel_aln=int(a.selAln), quasi_cov=a.quasiCoverage)

@@ -49,7 +49,7 @@ def _gunzip(src, dst):
 def sample_data(tmp_path_factory, lib_built):
     """config 1: the reference's sample_data, index built with our own quasiindex."""
     import rapmap_amd as ra
-    from rapmap_amd import sam
+    import samfmt as sam
     d = tmp_path_factory.mktemp("sample")
     idx = str(d / "idx")
     ra.build_index(os.path.join(GOLD, "sample_data", "transcripts.fasta"), idx, threads=4)
@@ -61,7 +61,7 @@ def sample_data(tmp_path_factory, lib_built):
 @pytest.fixture(scope="session")
 def synth_small(tmp_path_factory, lib_built):
     import rapmap_amd as ra
-    from rapmap_amd import sam
+    import samfmt as sam
     d = tmp_path_factory.mktemp("synth_small")
     fa = str(d / "txome.fa")
     _gunzip(os.path.join(GOLD, "synth_small", "txome.fa.gz"), fa)

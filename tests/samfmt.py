@@ -1,4 +1,5 @@
-"""SAM emission for mapped read pairs / single reads.
+"""TEST INFRASTRUCTURE: an independent Python formatter of the SAM text the reference writes (the product formats SAM in
+the library: rapmap_amd/csrc/qm_io.cpp qm_sam_*), used to cross-check it and to compare oracle hits with the reference's SAM fixtures.
 
 Mirrors the text the reference writes for `rapmap quasimap -o`:
   header    include/RapMapUtils.hpp:97-115 (writeSAMHeader)

@@ -52,7 +52,7 @@ def test_quasimap_cli_sample_data_sam(sample_data, tmp_path):
 @pytest.mark.gpu
 def test_quasimap_cli_single_end_and_flags(sample_data, tmp_path, oracle_mod):
     from conftest import load_oracle
-    from rapmap_amd import sam
+    import samfmt as sam
     from util import pack
     out = tmp_path / "se.sam"
     r = _run(["quasimap", "-i", sample_data["idx"], "-r", os.path.join(SD, "reads_1.fastq.gz"), "-o", str(out), "-m", "2", "-q"])

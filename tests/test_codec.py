@@ -36,7 +36,7 @@ def test_encode_rc_homopolymer(oracle_mod):
 
 
 def test_reverse_read(oracle_mod):
-    from rapmap_amd import sam
+    import samfmt as sam
     lib = oracle_mod._lib()
     s = b"ACGTacgtNnUuRYKM-*xX"
     out = C.create_string_buffer(len(s))

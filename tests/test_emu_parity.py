@@ -228,7 +228,7 @@ def test_selective_alignment_collector_intervals(synth_small, oracle_mod):
     """-s, stage A only: chain scoring in the collector (MMPs cut at k + maxMMPExtension, coverage slack 1).  The rest of
     the -s path is not on the device yet, so only the SA-interval hits are compared here."""
     from conftest import GOLD
-    from rapmap_amd import sam
+    import samfmt as sam
     ix, orc, em, emu = _emu(synth_small["idx"])
     n1, s1 = sam.read_fastq(os.path.join(GOLD, "synth_small", "next", "reads_indel_1.fastq.gz"))
     n2, s2 = sam.read_fastq(os.path.join(GOLD, "synth_small", "next", "reads_indel_2.fastq.gz"))
@@ -254,7 +254,7 @@ SEL_VARIANTS = [
 
 def sel_reads(synth_small, which):
     from conftest import GOLD
-    from rapmap_amd import sam
+    import samfmt as sam
     if which == "reads":
         return synth_small["reads1"], synth_small["reads2"]
     nx = os.path.join(GOLD, "synth_small", "next")

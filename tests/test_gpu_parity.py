@@ -52,7 +52,7 @@ def test_native_library_is_loaded(lib_built):
 
 def test_sample_data_hits_and_sam_md5(sample_data, oracle_mod):
     import rapmap_amd as ra
-    from rapmap_amd import sam
+    import samfmt as sam
     ix, orc = load_oracle(sample_data["idx"])
     qi, mp = _gpu(sample_data["idx"])
     q1, o1 = pack(sample_data["reads1"]); q2, o2 = pack(sample_data["reads2"])

@@ -35,7 +35,7 @@ def _join(batches, key, okey):
 
 
 def test_reader_matches_python_reader(sample_data, tmp_path):
-    from rapmap_amd import sam
+    import samfmt as sam
     p1 = os.path.join(GOLD, "sample_data", "reads_1.fastq.gz"); p2 = os.path.join(GOLD, "sample_data", "reads_2.fastq.gz")
     if not os.path.exists(p1):
         p1 = sample_data["paths"][0]; p2 = sample_data["paths"][1]
@@ -123,7 +123,7 @@ def test_sam_writer_reproduces_the_reference_digest(sample_data, oracle_mod):
 @pytest.mark.parametrize("opts", [{}, {"maxNumHits": 3}, {"fuzzy": 1}])
 def test_sam_writer_matches_python_formatter(synth_small, oracle_mod, opts):
     import rapmap_amd as ra
-    from rapmap_amd import sam
+    import samfmt as sam
     ix, orc = load_oracle(synth_small["idx"])
     qi = ra.QuasiIndex(synth_small["idx"])
     q1, o1 = pack(synth_small["reads1"]); q2, o2 = pack(synth_small["reads2"])

@@ -24,7 +24,7 @@ VARIANTS = {
 
 
 def test_sample_data_sam_md5(sample_data, oracle_mod):
-    from rapmap_amd import sam
+    import samfmt as sam
     ix, orc = load_oracle(sample_data["idx"])
     q1, o1 = pack(sample_data["reads1"]); q2, o2 = pack(sample_data["reads2"])
     res = orc.map_pairs(q1, o1, q2, o2, nthreads=2)
@@ -44,7 +44,7 @@ def test_sample_data_sam_md5(sample_data, oracle_mod):
 
 @pytest.mark.parametrize("variant", sorted(VARIANTS))
 def test_synth_small_sam(synth_small, oracle_mod, variant):
-    from rapmap_amd import sam
+    import samfmt as sam
     ix, orc = load_oracle(synth_small["idx"])
     q1, o1 = pack(synth_small["reads1"]); q2, o2 = pack(synth_small["reads2"])
     opts = oracle_mod.default_opts(**VARIANTS[variant])
@@ -84,7 +84,7 @@ NEXT_SINGLE = {
 
 
 def _next_reads(synth_small, which):
-    from rapmap_amd import sam
+    import samfmt as sam
     if which == "reads":
         return synth_small["names1"], synth_small["reads1"], synth_small["names2"], synth_small["reads2"]
     n1, s1 = sam.read_fastq(os.path.join(NEXT, "reads_indel_1.fastq.gz"))
@@ -94,7 +94,7 @@ def _next_reads(synth_small, which):
 
 @pytest.mark.parametrize("variant", sorted(NEXT_PAIRED))
 def test_synth_small_next_paired(synth_small, oracle_mod, variant):
-    from rapmap_amd import sam
+    import samfmt as sam
     which, kw = NEXT_PAIRED[variant]
     n1, s1, n2, s2 = _next_reads(synth_small, which)
     ix, orc = load_oracle(synth_small["idx"])
@@ -123,7 +123,7 @@ def test_synth_small_next_paired(synth_small, oracle_mod, variant):
 
 @pytest.mark.parametrize("variant", sorted(NEXT_SINGLE))
 def test_synth_small_next_single(synth_small, oracle_mod, variant):
-    from rapmap_amd import sam
+    import samfmt as sam
     which, kw = NEXT_SINGLE[variant]
     names = synth_small["names1"] if which == "reads_1" else synth_small["names2"]
     reads = synth_small["reads1"] if which == "reads_1" else synth_small["reads2"]
@@ -147,7 +147,7 @@ def test_synth_small_next_single(synth_small, oracle_mod, variant):
 
 def test_sample_data_fuzzy(sample_data, oracle_mod):
     """config 1 with -f: the reference's SAM (tests/golden/sample_data/expected_fuzzy.noseq.sam.gz)"""
-    from rapmap_amd import sam
+    import samfmt as sam
     ix, orc = load_oracle(sample_data["idx"])
     q1, o1 = pack(sample_data["reads1"]); q2, o2 = pack(sample_data["reads2"])
     res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(fuzzy=1), nthreads=2)
@@ -184,7 +184,7 @@ SEL_PAIRED = {
 
 @pytest.mark.parametrize("variant", sorted(SEL_PAIRED))
 def test_synth_small_selective_alignment(synth_small, oracle_mod, variant):
-    from rapmap_amd import sam
+    import samfmt as sam
     which, mk = SEL_PAIRED[variant]
     n1, s1, n2, s2 = _next_reads(synth_small, which)
     ix, orc = load_oracle(synth_small["idx"])
@@ -199,7 +199,7 @@ def test_synth_small_selective_alignment(synth_small, oracle_mod, variant):
 
 
 def test_synth_small_selective_alignment_single_end(synth_small, oracle_mod):
-    from rapmap_amd import sam
+    import samfmt as sam
     ix, orc = load_oracle(synth_small["idx"])
     q, o = pack(synth_small["reads1"])
     res = orc.map_single(q, o, opts=_sel(oracle_mod), nthreads=4)
@@ -217,7 +217,7 @@ def test_synth_small_selective_alignment_single_end(synth_small, oracle_mod):
 @pytest.mark.parametrize("variant", ["selAln", "selAln_hardFilter", "mimicBT2"])
 def test_sample_data_selective_alignment(sample_data, oracle_mod, variant):
     """config 5 on the reference's own sample data"""
-    from rapmap_amd import sam
+    import samfmt as sam
     ix, orc = load_oracle(sample_data["idx"])
     q1, o1 = pack(sample_data["reads1"]); q2, o2 = pack(sample_data["reads2"])
     opts = {"selAln": _sel(oracle_mod), "selAln_hardFilter": _sel(oracle_mod, hardFilter=1), "mimicBT2": oracle_mod.mimic_bt2_opts()}[variant]

@@ -52,7 +52,7 @@ def test_library_opens_the_references_index(ref_index, lib_built):
 
 def test_oracle_on_the_references_index_reproduces_its_sam_digest(ref_index, sample_data, oracle_mod):
     """oracle hits on the reference-written index + SAM formatting == the md5 of the reference's own SAM"""
-    from rapmap_amd import sam
+    import samfmt as sam
     ix, orc = load_oracle(ref_index["dense"])
     q1, o1 = pack(sample_data["reads1"]); q2, o2 = pack(sample_data["reads2"])
     res = orc.map_pairs(q1, o1, q2, o2, nthreads=2)
