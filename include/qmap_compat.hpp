@@ -55,6 +55,12 @@ struct MappingOpts {
   bool selAln{false};
   bool noOrphans{false};
   bool noDovetail{false};
+  // sub-options of --selAln (src/RapMapSAMapper.cpp:1011-1023,1135-1175); read only when selAln is set
+  bool hardFilter{false};
+  int32_t matchScore{2}, mismatchPenalty{-4}, gapOpenPenalty{4}, gapExtendPenalty{2}, dpBandwidth{15}, maxMMPExtension{7};
+  int32_t alnPolicy{0};          // 0 default, 1 --mimicBT2, 2 --mimicStrictBT2
+  double minScoreFrac{0.65};
+  float consensusSlack{0.2f};
 };
 
 class Error : public std::runtime_error {
@@ -99,6 +105,9 @@ class QuasiMapper {
     qm_opts_default(&o_);
     o_.sensitive = m.sensitive; o_.strict_check = m.strictCheck; o_.max_num_hits = (int32_t)m.maxNumHits;
     o_.no_orphans = m.noOrphans; o_.no_dovetail = m.noDovetail; o_.quasi_cov = m.quasiCov; o_.fuzzy = m.fuzzy; o_.sel_aln = m.selAln;
+    o_.hard_filter = m.hardFilter; o_.match_score = m.matchScore; o_.mismatch_penalty = m.mismatchPenalty; o_.gap_open = m.gapOpenPenalty;
+    o_.gap_extend = m.gapExtendPenalty; o_.dp_bandwidth = m.dpBandwidth; o_.max_mmp_extension = m.maxMMPExtension; o_.aln_policy = m.alnPolicy;
+    o_.min_score_fraction = m.minScoreFrac; o_.consensus_slack = m.consensusSlack;
   }
   ~QuasiMapper() { if (ctx_) qm_ctx_destroy(ctx_); }
   QuasiMapper(const QuasiMapper&) = delete;

@@ -570,14 +570,19 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
     int64_t wantLists = nreads * 4 + (int64_t)grid * 4 * QM_CHUNK * 2;   // chunked bump allocator: up to one open chunk per wave
     if (c->capLists < wantLists) { if ((rc = ensure(c->d_lists, c->capLists, wantLists))) return rc; }
   }
-  const bool wantIv = rq.keepIntervals || rq.mode == QM_RUN_COLLECT;
+  // A fused -s call runs stage A as two launches: the chain-scoring collector alone (its memory-bound walk, at the default
+  // kernel's occupancy: without the chaining code it needs half the registers and no LDS scratch) leaves every read's
+  // SA-interval hits in HBM, then one wavefront per read turns them into the read's list (sort, slack intersection, chaining).
+  const bool twoPass = rq.mode == QM_RUN_FUSED && o->sel_aln != 0;
+  const bool wantIv = rq.keepIntervals || rq.mode == QM_RUN_COLLECT || twoPass;
   if (wantIv) {
     if ((rc = ensure(c->d_ivcnt, c->capIvCnt, nreads + 1))) return rc;
     if ((rc = ensure(c->d_ivoff, c->capIvOff, nreads + 1))) return rc;
-    const int64_t want = nreads * (o->sel_aln ? 16 : 4) + 1024;
+    const int64_t want = nreads * (o->sel_aln ? 16 : 4) + (int64_t)grid * 4 * QM_IVCHUNK * 2;   // chunked allocator: up to one open chunk per wave
     if (c->capIv < want) { if ((rc = ensure(c->d_iv, c->capIv, want))) return rc; }
   }
-  if (rq.keepFound || rq.mode == QM_RUN_COLLECT) { if ((rc = ensure(c->d_found, c->capFound, nreads + 1))) return rc; }
+  const bool wantFound = rq.keepFound || rq.mode == QM_RUN_COLLECT || twoPass;
+  if (wantFound) { if ((rc = ensure(c->d_found, c->capFound, nreads + 1))) return rc; }
   const DevIndex ix = dev_index(c);
   c->lastRelaunches = 0; c->lastSlowReads = 0; c->lastIvTotal = 0;
   while (true) {
@@ -587,7 +592,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
     B.lcnt = c->d_lcnt; B.loff = c->d_loff; B.lists = c->d_lists; B.cursor = c->d_scal; B.lists_cap = c->capLists;
     B.status = (int*)(c->d_scal + QM_SC_STATUS); B.gscratch = c->d_gscr;
     if (wantIv) { B.iv_out = c->d_iv; B.iv_cnt = c->d_ivcnt; B.iv_off = c->d_ivoff; B.iv_cap = c->capIv; }
-    if (rq.keepFound || rq.mode == QM_RUN_COLLECT) B.found_out = c->d_found;
+    if (wantFound) B.found_out = c->d_found;
     B.iv_in = rq.ivIn; B.iv_in_off = rq.ivInOff; B.len_in = rq.lenIn; B.found_in = rq.foundIn;
     B.strict_check = o->strict_check; B.max_interval = o->max_interval; B.quasi_cov = o->quasi_cov; B.sensitive = o->sensitive; B.fuzzy = paired ? o->fuzzy : 0;
     if (rq.mode == QM_RUN_FROM_INTERVALS) B.fuzzy = o->fuzzy;   // the caller says what kind of list it wants (both orientations kept or not)
@@ -602,8 +607,16 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     auto launch = [&](const ReadBatch& X, int g) -> hipError_t {
       if (rq.mode == QM_RUN_FROM_INTERVALS) return qmk_h2m(&ix, &X, g, c->numCU, c->stream);
+      if (twoPass) return qmk_map_reads_ex(&ix, &X, ns, 1, g, c->numCU, c->stream);
       return qmk_map_reads(&ix, &X, rq.mode == QM_RUN_COLLECT ? -1 : ns, g, c->numCU, c->stream);
     };
+    // second pass of a two-pass -s call (also the slow pass's kernel): intervals -> lists
+    ReadBatch H = B;
+    if (twoPass) {
+      H.iv_in = c->d_iv; H.iv_in_off = c->d_ivoff; H.iv_in_cnt = c->d_ivcnt; H.found_in = c->d_found;
+      if (!rq.keepIntervals) { }                       // the interval output stays valid either way: it is this pass's input
+      H.iv_out = nullptr; H.found_out = nullptr;
+    }
     if (feeder && n > 0) {
       // first pass over host buffers: one launch per chunk, each behind its own upload.  A launch sees its chunk through
       // shifted pointers (offsets are absolute, the per-read / per-unit arrays start at the chunk), the bump allocators,
@@ -623,6 +636,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
       }
       feeder = nullptr;                                   // a retry finds everything resident
     } else if (nreads > 0) HIPCHK(launch(B, grid));
+    if (twoPass && nreads > 0) HIPCHK(qmk_h2m(&ix, &H, grid, c->numCU, c->stream));
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -644,10 +658,11 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
       for (int w = 0; w < sgrid * 4; ++w) qmk_sel_dyn_bind(hd.data() + (size_t)w * sb, c->d_dynmem + (unsigned long long)w * per, need);
       if ((rc = ensure(c->d_dyn, c->capDyn, (int64_t)hd.size()))) return rc;
       HIPCHK(hipMemcpyAsync(c->d_dyn, hd.data(), hd.size(), hipMemcpyHostToDevice, c->stream));
-      ReadBatch S2 = B;
+      ReadBatch S2 = twoPass ? H : B;
       S2.slowq = c->d_slowq; S2.dyn = (SelScratchDyn*)c->d_dyn; S2.nreads = ns_;
       S2.iv_out = nullptr; S2.found_out = nullptr;            // already written by the first pass
-      HIPCHK(launch(S2, sgrid));
+      if (twoPass) HIPCHK(qmk_h2m(&ix, &S2, sgrid, c->numCU, c->stream));
+      else HIPCHK(launch(S2, sgrid));
       HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));                 // hd is a local
       status = (int)(hscal[QM_SC_STATUS] & 0xffffffffu);
@@ -670,7 +685,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
         if ((rc = ensure(c->d_lists, c->capLists, want))) return rc;
       }
       if (status & 16) {
-        int64_t want = (int64_t)hscal[QM_SC_IVCUR] + nreads + 1024;
+        int64_t want = (int64_t)hscal[QM_SC_IVCUR] + nreads + (int64_t)grid * 4 * QM_IVCHUNK;
         if (want < c->capIv * 2) want = c->capIv * 2;
         if ((rc = ensure(c->d_iv, c->capIv, want))) return rc;
       }
@@ -681,7 +696,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
   }
   c->lastIvTotal = wantIv ? (int64_t)hscal[QM_SC_IVCUR] : 0;
   c->lastIvReads = wantIv ? nreads : -1;
-  c->lastFoundReads = (rq.keepFound || rq.mode == QM_RUN_COLLECT) ? nreads : -1;
+  c->lastFoundReads = wantFound ? nreads : -1;
   c->lastListReads = rq.mode != QM_RUN_COLLECT ? nreads : -1;
   c->lastListWords = (int64_t)hscal[0];
   float ms = 0; hipEventElapsedTime(&ms, c->ev0, c->ev1); c->lastMapMs = ms;
@@ -961,7 +976,12 @@ int qm_collect_reads(qm_ctx* c, const qm_opts* o, int64_t n, const char* seq, co
   u64 hscal[QM_SC_WORDS];
   c->lastUnits = -1;
   if ((rc = run_stage_a(c, o, rq, n, c->d_seq1, c->d_off1, nullptr, nullptr, 8, nullptr, hscal))) return rc;
-  if (n_intervals) *n_intervals = c->lastIvTotal;
+  if (n_intervals) {
+    std::vector<uint32_t> cnt((size_t)n + 1);
+    if (n) HIPCHK(hipMemcpy(cnt.data(), c->d_ivcnt, (size_t)n * 4, hipMemcpyDeviceToHost));
+    int64_t t = 0; for (int64_t i = 0; i < n; ++i) t += cnt[(size_t)i];
+    *n_intervals = t;
+  }
   return QM_OK;
 }
 

@@ -22,31 +22,57 @@ template <> struct SelLds<false> { QM_DEV SelScratchLds* ptr() { return nullptr;
 
 // Stage entry "from intervals" (hit_manager::hitsToMappingsSimple as a call of its own, include/HitManager.hpp:130-135): one
 // wavefront per read, the read's SA-interval hits come from the caller instead of the collector.  F: 0 or QM_F_SEL.
+struct H2mMem { u64 buf[3][QM_CAP]; IntRec ints[2][QM_ICAP]; };        // 2 KB per wave: sort buffers + the first intervals of each strand
 template <int F>
-__global__ __launch_bounds__(256, 2) void qm_h2m_kernel(DevIndex ix, ReadBatch B) {
-  __shared__ WaveMem<4> mem[4];
+__global__ __launch_bounds__(256, 4) void qm_h2m_kernel(DevIndex ix, ReadBatch B) {
+  __shared__ H2mMem mem[4];
   __shared__ SelLds<(F & QM_F_SEL) != 0> sels[4];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long long gw = (long long)blockIdx.x * 4 + wave;
   const long long nw = (long long)gridDim.x * 4;
   u64* gscr = B.gscratch + gw * QM_GSCR_U64;
-  WaveAlloc wa; wa.base = -1; wa.used = 0;
+  WaveAlloc wa; wa.base = -1; wa.used = 0; wa.ivBase = -1; wa.ivUsed = 0;
   for (long long r = gw; r < B.nreads; r += nw) {
     const long long read = read_id<F>(B, r);
-    WaveMem<4>& M = mem[wave];
+    H2mMem& M = mem[wave];
     IntervalList fi, ri;
     fi.lds = M.ints[0]; ri.lds = M.ints[1];
     fi.ovf = (IntRec*)(gscr + 3 * QM_GCAP); ri.ovf = fi.ovf + QM_IOVF;
     fi.n = 0; ri.n = 0; fi.pf = nullptr; ri.pf = nullptr; fi.pfcap = 0; ri.pfcap = 0;
-    const long long i0 = uniform(B.iv_in_off[read]), i1 = uniform(B.iv_in_off[read + 1]);
-    for (long long i = i0; i < i1; ++i) {
-      const qm_sa_interval_hit h = B.iv_in[i];
-      const int lb = uniform(h.begin), ub = uniform(h.end); const u32 ln = uniform(h.len), qp = uniform(h.query_pos);
-      if (uniform((int)h.query_rc)) ri.push(lb, ub, ln, qp); else fi.push(lb, ub, ln, qp);
+    long long i0, i1; int len, mate = 0;
+    if (B.iv_in_cnt) {                                  // second pass of a fused -s call: what the collector pass left for this read
+      i0 = uniform(B.iv_in_off[read]); i1 = i0 + (long long)uniform(B.iv_in_cnt[read]);
+      const unsigned char* src; const long long* off; long long unit;
+      read_src(B, read, src, off, unit);
+      len = (int)(uniform(off[unit + 1]) - uniform(off[unit]));
+      mate = B.seq2 ? (int)(read & 1) : 0;
+    } else {
+      i0 = uniform(B.iv_in_off[read]); i1 = uniform(B.iv_in_off[read + 1]);
+      len = uniform(B.len_in[read]);
     }
-    const int len = uniform(B.len_in[read]);
+    // all of the read's records in one round of loads: lane l takes record base + l and files it behind the records of its
+    // strand that precede it (forward-strand records come first)
+    for (long long base = i0; base < i1; base += 64) {
+      LV<bool> isF, isR;
+      qm_sa_interval_hit h; h.begin = 0; h.end = 0; h.len = 0; h.query_pos = 0; h.query_rc = 0;
+      const bool have = base + (long long)(threadIdx.x & 63) < i1;
+      if (have) h = B.iv_in[base + (long long)(threadIdx.x & 63)];
+      isF.v[0] = have && h.query_rc == 0; isR.v[0] = have && h.query_rc != 0;
+      const u64 fm = ballot(isF), rm = ballot(isR);
+      if (have) {
+        const int l = (int)(threadIdx.x & 63);
+        const bool rc = h.query_rc != 0;
+        const int idx = rc ? ri.n + popc64(rm & lanemask_lt(l)) : fi.n + popc64(fm & lanemask_lt(l));
+        IntRec r; r.b = h.begin; r.e = h.end; r.len = h.len; r.q = h.query_pos;
+        IntervalList& L = rc ? ri : fi;
+        IntRec* dst = idx < QM_ICAP ? &L.lds[idx] : &L.ovf[idx - QM_ICAP];
+        *dst = r;
+      }
+      fi.n += popc64(fm); ri.n += popc64(rm);
+    }
+    wave_fence();
     const bool found = B.found_in ? uniform((int)B.found_in[read]) != 0 : false;
-    finish_read<4, F>(ix, B, read, len, 0, found, M, gscr, wa, fi, ri, (F & QM_F_SEL) ? B.selscr + gw : nullptr, sels[wave].ptr(),
+    finish_read<4, F>(ix, B, read, len, mate, found, M.buf, gscr, wa, fi, ri, (F & QM_F_SEL) ? B.selscr + gw : nullptr, sels[wave].ptr(),
                       ((F & QM_F_SEL) && B.dyn) ? B.dyn + gw : nullptr);
   }
 }
@@ -270,8 +296,16 @@ int qmk_map_grid(long long nreads, int num_cu) {
 // the chosen instantiation (VGPR/LDS dependent) decides the grid.
 // stage A: the slot-count class picks the translation unit that holds its instantiations (qm_read_kernel.inl).
 // ns < 0: the "collector only" stage entry, on the eight-slot kernels (every read length up to QM_MAX_READ_LEN).
-hipError_t qmk_map_reads(const void* ixp, const void* bp, int ns, int grid, int num_cu, hipStream_t st) {
-  if (ns < 0) return qmk_launch_reads_ns8(ixp, bp, 1, grid < num_cu * 2 ? grid : num_cu * 2, num_cu, st);
+// collect: collector-only kernels (ns < 0: those of the stage entry, eight slots; otherwise the chain-scoring ones of slot count ns)
+hipError_t qmk_map_reads(const void* ixp, const void* bp, int ns, int grid, int num_cu, hipStream_t st) { return qmk_map_reads_ex(ixp, bp, ns, 0, grid, num_cu, st); }
+hipError_t qmk_map_reads_ex(const void* ixp, const void* bp, int ns, int collect, int grid, int num_cu, hipStream_t st) {
+  if (ns < 0) return qmk_launch_reads_ns8(ixp, bp, 1, grid, num_cu, st);
+  if (collect) {
+    if (ns == 2) return qmk_launch_reads_ns2(ixp, bp, 1, grid, num_cu, st);
+    if (ns == 3) return qmk_launch_reads_ns3(ixp, bp, 1, grid, num_cu, st);
+    if (ns > 4) return qmk_launch_reads_ns8(ixp, bp, 1, grid, num_cu, st);
+    return qmk_launch_reads_ns4(ixp, bp, 1, grid, num_cu, st);
+  }
   if (ns == 2) return qmk_launch_reads_ns2(ixp, bp, 0, grid, num_cu, st);
   if (ns == 3) return qmk_launch_reads_ns3(ixp, bp, 0, grid, num_cu, st);
   if (ns > 4) return qmk_launch_reads_ns8(ixp, bp, 0, grid, num_cu, st);
@@ -281,7 +315,11 @@ hipError_t qmk_map_reads(const void* ixp, const void* bp, int ns, int grid, int 
 hipError_t qmk_h2m(const void* ixp, const void* bp, int grid, int num_cu, hipStream_t st) {
   const DevIndex& ix = *(const DevIndex*)ixp;
   const ReadBatch& B = *(const ReadBatch*)bp;
-  const unsigned g = (unsigned)(grid < num_cu * 2 ? grid : num_cu * 2);
+  static int nbSel = 0, nbPlain = 0;                         // persistent grids: no more blocks than are resident at once
+  if (nbSel == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbSel, qm_h2m_kernel<QM_F_SEL>, 256, 0) != hipSuccess || nbSel < 1)) nbSel = 2;
+  if (nbPlain == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbPlain, qm_h2m_kernel<0>, 256, 0) != hipSuccess || nbPlain < 1)) nbPlain = 2;
+  const int nb = B.selscr ? nbSel : nbPlain;
+  const unsigned g = (unsigned)(grid < num_cu * nb ? grid : num_cu * nb);
   if (B.selscr) hipLaunchKernelGGL(qm_h2m_kernel<QM_F_SEL>, dim3(g), dim3(256), 0, st, ix, B);
   else hipLaunchKernelGGL(qm_h2m_kernel<0>, dim3(g), dim3(256), 0, st, ix, B);
   return hipGetLastError();

@@ -123,7 +123,8 @@ struct ReadBatch {
   qm_sa_interval_hit* iv_out; u32* iv_cnt; long long* iv_off; long long iv_cap;
   unsigned char* found_out;      // optional [nreads]: what SACollector::operator() returned
   // stage entry "from intervals" (qm_h2m_kernel): read r's intervals are iv_in[iv_in_off[r] .. iv_in_off[r + 1]), its length len_in[r]
-  const qm_sa_interval_hit* iv_in; const long long* iv_in_off; const int* len_in; const unsigned char* found_in;
+  // iv_in_cnt != null: the (offset, count) form the collector pass of the same call left behind (iv_off / iv_cnt), lengths from off1 / off2
+  const qm_sa_interval_hit* iv_in; const long long* iv_in_off; const u32* iv_in_cnt; const int* len_in; const unsigned char* found_in;
   int strict_check, max_interval;
   int sensitive;           // 0: --noSensitive (NIP skipping via SASearcher::lce, k-mer vote instead of coverage)
   double quasi_cov;
@@ -1314,14 +1315,24 @@ QM_DEV int list_bound(const IntervalList& a, const IntervalList& b) {
   return tot;
 }
 
-// the read's SA-interval hits to B.iv_out: one reservation per read (a secondary output: the single-word atomic is fine here)
-QM_DEV void dump_intervals(const ReadBatch& B, long long read, int mate, const IntervalList& F, const IntervalList& R) {
+// the read's SA-interval hits to B.iv_out.  Like the hit lists they go through a chunked bump allocator: a returning atomic on
+// one word per read would cap the kernel at ~88 M reads/s (and did: the first pass of -s took 246 ms per 20 M reads with it).
+#define QM_IVCHUNK 2048
+struct WaveAlloc;
+QM_DEV void dump_intervals(const ReadBatch& B, long long read, int mate, const IntervalList& F, const IntervalList& R, long long& ivBase, int& ivUsed) {
   const int n = F.n + R.n;
   long long base = 0;
-  if (n > 0) {
+  if (n > QM_IVCHUNK) {                                   // cannot happen below 1024 positions per strand; kept for safety
     LV<u64> bv;
     QM_LANES(l) { bv[l] = 0; if (l == 0) bv[l] = atomic_add_u64(B.cursor + QM_SC_IVCUR, (u64)n); }
     base = (long long)read_lane(bv, 0);
+  } else if (n > 0) {
+    if (ivBase < 0 || ivUsed + n > QM_IVCHUNK) {
+      LV<u64> bv;
+      QM_LANES(l) { bv[l] = 0; if (l == 0) bv[l] = atomic_add_u64(B.cursor + QM_SC_IVCUR, (u64)QM_IVCHUNK); }
+      ivBase = (long long)read_lane(bv, 0); ivUsed = 0;
+    }
+    base = ivBase + ivUsed; ivUsed += n;
   }
   const bool fits = base + n <= B.iv_cap;
   if (!fits) { QM_LANES(l) { if (l == 0) *B.status |= 16; } }
@@ -1351,7 +1362,7 @@ QM_DEV int sel_hits_to_mappings(const DevIndex& ix, const ReadBatch& B, const In
 
 // ------------------------------------------------------------------ stage A driver
 // One read: load -> collect -> hits->mappings -> list to global memory.
-struct WaveAlloc { long long base; int used; };   // the wave's current chunk of B.lists (wave-uniform)
+struct WaveAlloc { long long base; int used; long long ivBase; int ivUsed; };   // the wave's current chunks of B.lists / B.iv_out (wave-uniform)
 
 // Software pipeline of the persistent loop: the offsets of the read after next and the characters of the next read are
 // requested while the current read is processed, so the two dependent round trips that start a read (offsets ->
@@ -1408,16 +1419,16 @@ QM_DEV void stage_chars(const ReadBatch& B, long long slot, WaveMem<NS>& M, int 
 // Second half of a read: SA-interval hits -> the read's hit list in B.lists (hitsToMappingsSimple), shared by the fused
 // kernel and by the stage entry that starts from caller-supplied intervals (qm_h2m_kernel).
 template <int NS, int F>
-QM_DEV void finish_read(const DevIndex& ix, const ReadBatch& B, long long read, int len, int mate, bool foundHit, WaveMem<NS>& M, u64* gscr,
+QM_DEV void finish_read(const DevIndex& ix, const ReadBatch& B, long long read, int len, int mate, bool foundHit, u64 (*buf)[QM_CAP], u64* gscr,
                         WaveAlloc& wa, IntervalList& fi, IntervalList& ri, SelScratch* ss, struct SelScratchLds* sl, SelScratchDyn* dyn) {
   Bufs bf;
   int bound = list_bound(fi, ri);
-  if (bound <= QM_CAP) { bf.A = M.buf[0]; bf.B = M.buf[1]; bf.R = M.buf[2]; }
+  if (bound <= QM_CAP) { bf.A = buf[0]; bf.B = buf[1]; bf.R = buf[2]; }
   else { bf.A = gscr; bf.B = gscr + QM_GCAP; bf.R = gscr + 2 * QM_GCAP; }
   int n = 0;
   const u64* listSrc = nullptr;
   if (F & QM_F_SEL) {                  // -s: chaining + multi-position groups (qm_sel.inl)
-    n = sel_hits_to_mappings(ix, B, fi, ri, (u32)len, mate, *ss, sl, &M.buf[0][0], listSrc, dyn);
+    n = sel_hits_to_mappings(ix, B, fi, ri, (u32)len, mate, *ss, sl, &buf[0][0], listSrc, dyn);
     if (n == -2) {                     // waits on the slow queue: no list yet
       QM_LANES(l) { if (l == 0) { B.lcnt[read] = QM_LCNT_SLOW; B.loff[read] = 0; } }
       return;
@@ -1512,10 +1523,10 @@ QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, lon
   const bool foundHit = collect_read<NS, F>(ix, B, M, len, hasDollar, fi, ri);
   QM_T(4);
   if (B.iv_out || B.found_out || (F & QM_F_COLLECT)) lds_dma_wait();   // the staged prefetch must have landed before any store follows it
-  if (B.iv_out) dump_intervals(B, read, mate, fi, ri);
+  if (B.iv_out) dump_intervals(B, read, mate, fi, ri, wa.ivBase, wa.ivUsed);
   if (B.found_out) { QM_LANES(l) { if (l == 0) B.found_out[read] = foundHit ? 1 : 0; } }
   if (F & QM_F_COLLECT) return;          // stage entry "collector only" (SACollector::operator() as a call of its own)
-  finish_read<NS, F>(ix, B, read, len, mate, foundHit, M, gscr, wa, fi, ri, ss, sl, dyn);
+  finish_read<NS, F>(ix, B, read, len, mate, foundHit, M.buf, gscr, wa, fi, ri, ss, sl, dyn);
 }
 
 // ------------------------------------------------------------------ stage B: one thread per unit

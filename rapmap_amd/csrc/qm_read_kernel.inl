@@ -24,14 +24,14 @@ __global__ __launch_bounds__(256, WPS) void qm_read_kernel(DevIndex ix_, ReadBat
   const Args* args = (const Args*)(AP4)__builtin_amdgcn_kernarg_segment_ptr();
   const DevIndex& ix = args->ix; const ReadBatch& B = args->B;
   __shared__ WaveMem<NS> mem[4];
-  __shared__ SelLds<(F & QM_F_SEL) != 0> sels[4];       // -s kernels only: lane 0's chaining scratch
+  __shared__ SelLds<(F & QM_F_SEL) != 0 && (F & QM_F_COLLECT) == 0> sels[4];   // -s kernels that chain: the LDS edition of the scratch
   // the wave index is wave-uniform: keep it (and every address derived from it) on the scalar unit
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int gw = (int)blockIdx.x * 4 + wave;             // reads per launch < 2^31: 32-bit slot arithmetic
   const int nw = (int)gridDim.x * 4;
   const int nreads = (int)B.nreads;
   u64* gscr = B.gscratch + (long long)gw * QM_GSCR_U64;
-  WaveAlloc wa; wa.base = -1; wa.used = 0;
+  WaveAlloc wa; wa.base = -1; wa.used = 0; wa.ivBase = -1; wa.ivUsed = 0;
 #ifdef QM_TIMING
   if ((threadIdx.x & 63) == 0) { for (int i = 0; i < 9; ++i) qm_tim[wave][i] = 0; qm_tim[wave][9] = __builtin_readcyclecounter(); }
 #endif
@@ -71,15 +71,23 @@ static hipError_t launch_reads_ns(const DevIndex& ix, const ReadBatch& B, bool c
     hipLaunchKernelGGL((qm_read_kernel<NS, WPS_, F_>), dim3((unsigned)g), dim3(256), 0, st, ix, B);             \
   } while (0)
   if constexpr (WITH_COLLECT) if (collect) {
+    // collector-only kernels: the chain-scoring flavours for every slot count (first pass of a fused -s call: without the
+    // chaining code they fit the register budget of the default kernel, so they are built for its occupancy), the others
+    // only at eight slots (the stage entry qm_collect_reads, any read length)
     switch (F) {
-      case 0: QM_LAUNCH(W0, QM_F_COLLECT); break;
-      case QM_F_PH: QM_LAUNCH(WPH, QM_F_PH | QM_F_COLLECT); break;
-      case QM_F_NIP: QM_LAUNCH(WNIP, QM_F_NIP | QM_F_COLLECT); break;
-      case QM_F_PH | QM_F_NIP: QM_LAUNCH(WPHNIP, QM_F_PH | QM_F_NIP | QM_F_COLLECT); break;
-      case QM_F_SEL: QM_LAUNCH(WSEL, QM_F_SEL | QM_F_COLLECT); break;
-      case QM_F_SEL | QM_F_PH: QM_LAUNCH(WSEL, QM_F_SEL | QM_F_PH | QM_F_COLLECT); break;
-      case QM_F_SEL | QM_F_NIP: QM_LAUNCH(WSEL, QM_F_SEL | QM_F_NIP | QM_F_COLLECT); break;
-      default: QM_LAUNCH(WSEL, QM_F_SEL | QM_F_PH | QM_F_NIP | QM_F_COLLECT); break;
+      case QM_F_SEL: QM_LAUNCH(W0, QM_F_SEL | QM_F_COLLECT); break;
+      case QM_F_SEL | QM_F_PH: QM_LAUNCH(WPH, QM_F_SEL | QM_F_PH | QM_F_COLLECT); break;
+      case QM_F_SEL | QM_F_NIP: QM_LAUNCH(WNIP, QM_F_SEL | QM_F_NIP | QM_F_COLLECT); break;
+      case QM_F_SEL | QM_F_PH | QM_F_NIP: QM_LAUNCH(WPHNIP, QM_F_SEL | QM_F_PH | QM_F_NIP | QM_F_COLLECT); break;
+      default:
+        if constexpr (NS == 8) {
+          switch (F) {
+            case 0: QM_LAUNCH(W0, QM_F_COLLECT); break;
+            case QM_F_PH: QM_LAUNCH(WPH, QM_F_PH | QM_F_COLLECT); break;
+            case QM_F_NIP: QM_LAUNCH(WNIP, QM_F_NIP | QM_F_COLLECT); break;
+            default: QM_LAUNCH(WPHNIP, QM_F_PH | QM_F_NIP | QM_F_COLLECT); break;
+          }
+        } else return hipErrorInvalidValue;
     }
     return hipGetLastError();
   }

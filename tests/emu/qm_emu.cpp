@@ -53,7 +53,7 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
     B.lists = lists.data(); B.lists_cap = cap; memset(scal, 0, sizeof(scal)); status = 0;
     // emulate 7 interleaved "waves", each with its own chunk allocator
     WaveAlloc wa[7];
-    for (auto& w : wa) { w.base = -1; w.used = 0; }
+    for (auto& w : wa) { w.base = -1; w.used = 0; w.ivBase = -1; w.ivUsed = 0; }
     for (long long r = 0; r < nreads; ++r) {
       const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP) | (o->sel_aln ? QM_F_SEL : 0);
 #define QE_CALL(NS_, F_) { static WaveMem<NS_> M; stage_offsets<NS_, F_>(B, r, M, 0); stage_chars<NS_, F_>(B, r, M, 0); \
