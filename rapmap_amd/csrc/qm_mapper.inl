@@ -438,6 +438,7 @@ struct Strand {
   const u64* planes;   // LDS: [4][NS+2]
   Iv* tab;             // LDS: interval of mer at position p (valid where F)
   bool dollar;         // the strand's string contains '$' (extensions then take the literal binary searches)
+  bool lazy;           // pure-ACGT read without a long run: tab holds no k-mer words, a probe shifts its word out of the image
   int P;
 };
 
@@ -496,6 +497,12 @@ QM_DEV u64 kmer_at(const u64* planes, int p, int k, bool& nwin, bool& nwin2, int
   return w;
 }
 
+// k-mer word at position p of a strand whose characters are all A C G T (Strand::lazy)
+QM_DEV u64 clean_kmer(const u64* planes, int p, int k) {
+  const int j = p >> 5, sh = 2 * (p & 31);
+  return ((planes[j] << sh) | ((planes[j + 1] >> 1) >> (63 - sh))) >> (64 - 2 * k);
+}
+
 template <int NS>
 QM_DEV void setup_strand(const DevIndex& ix, const unsigned char* str, int L, Strand<NS>& S, u64* planes, Iv* tab) {
   const int k = ix.k;
@@ -510,13 +517,15 @@ QM_DEV void setup_strand(const DevIndex& ix, const unsigned char* str, int L, St
   unsigned char* IVb = (unsigned char*)(planes + 3 * (NS + 2));
   constexpr int NC = (NS + 3) / 4;
   u64 dirty = 0;                                                           // lanes holding a character that is not A C G T
+  int runs = 0;                                                            // lanes whose four characters are one repeated base
+  S.lazy = false;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    LV<u32> nn, iv, nn2, iv2; LV<bool> bad;
+    LV<u32> nn, iv, nn2, iv2; LV<bool> bad, rep;
     QM_LANES(l) {
       const int base = 256 * c + 4 * l;
       u32 pk = 0, nnib = 0, vnib = 0;
-      bad[l] = false;
+      bad[l] = false; rep[l] = false;
       if (base < 64 * NS) {
         const u32 d = ((const u32*)str)[base >> 2];
         const int nb = L - base;                                          // characters of this word inside the read
@@ -529,12 +538,14 @@ QM_DEV void setup_strand(const DevIndex& ix, const unsigned char* str, int L, St
         pk = (code * 0x40100401u) >> 24;                                                        // first character in the top bits
         nnib = movemask4(nmask); vnib = movemask4(valid);
         bad[l] = (~valid & lenmask & 0x80808080u) != 0;
+        rep[l] = nb >= 4 && ((pk ^ (pk >> 2)) & 0x3fu) == 0;
       }
       const int bi = 64 * c + l;                                          // byte of the packed image: characters 4 bi .. 4 bi + 3
       if ((bi >> 3) < 2 * NS + 2) PKb[8 * (bi >> 3) + 7 - (bi & 7)] = (unsigned char)pk;
       nn[l] = nnib; iv[l] = (~vnib) & 0xfu;
     }
     dirty |= ballot(bad);
+    runs += popc64(ballot(rep));
     lane_xor1(nn, nn2); lane_xor1(iv, iv2);
     QM_LANES(l) {
       const int mb = 32 * c + (l >> 1);                                   // byte of the masks: characters 8 mb .. 8 mb + 7
@@ -546,9 +557,24 @@ QM_DEV void setup_strand(const DevIndex& ix, const unsigned char* str, int L, St
     if (NS + 2 > 4 * NC && l < NS + 2 - 4 * NC) { planes[2 * (NS + 2) + 4 * NC + l] = 0; planes[3 * (NS + 2) + 4 * NC + l] = ~0ULL; }
   }
   wave_fence();
+  if (!dirty && 4 * runs + 6 < k) {
+    // nearly every read: nothing but A C G T and no homopolymer window (k equal characters cover at least (k - 6) / 4 whole
+    // lanes of the loop above).  Every position with a whole k-mer is eligible and nothing is tabulated: a probe shifts
+    // its word out of the packed image when it gets there (clean_kmer), tab only ever receives intervals.
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int r = P - 64 * s;
+      S.E.w[s] = r >= 64 ? ~0ULL : (r <= 0 ? 0ULL : ((1ULL << r) - 1));
+      S.E2.w[s] = S.E.w[s];
+      S.K.w[s] = 0; S.F.w[s] = 0; S.C.w[s] = 0; S.V.w[s] = 0;
+    }
+    S.lazy = true;
+    QM_T(1);
+    return;
+  }
   if (!dirty) {
-    // nearly every read: nothing but A C G T, so no window holds an N or a partial word -- the k-mer at p is one funnel
-    // shift of two packed words and the only thing to test is the homopolymer rule
+    // pure A C G T with a long run: no window holds an N or a partial word -- the k-mer at p is one funnel shift of two
+    // packed words and the only thing to test is the homopolymer rule
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       LV<bool> e;
@@ -606,7 +632,8 @@ QM_DEV void probe_window(const DevIndex& ix, Strand<NS>& S, int p, int width) {
   QM_CNT(3, 1); QM_CNT(4, width); QM_T(4);
   LV<bool> found; LV<u64> keyv;
   // every lane fetches its word before any lane replaces one by an interval
-  QM_LANES(l) { const int j = l & 31; keyv[l] = j < width ? ((const u64*)S.tab)[p + j] : ~0ULL; }
+  if (S.lazy) { QM_LANES(l) { const int j = l & 31; keyv[l] = j < width ? clean_kmer(S.planes, p + j, k) : ~0ULL; } }
+  else { QM_LANES(l) { const int j = l & 31; keyv[l] = j < width ? ((const u64*)S.tab)[p + j] : ~0ULL; } }
   QM_LANES(l) {
     int j = l & 31;
     bool isC = l >= 32;
@@ -642,7 +669,8 @@ QM_DEV bool probe_first(const DevIndex& ix, Strand<NS>& S, int p, Iv* rtab0) {
   const int last = S.P - 1;
   QM_CNT(3, 1); QM_CNT(4, last != p ? 2 : 1); QM_T(4);
   LV<bool> found; LV<u64> keyv;
-  QM_LANES(l) { const int j = l & 31; keyv[l] = j < 2 ? ((const u64*)S.tab)[j == 0 ? p : last] : ~0ULL; }
+  if (S.lazy) { QM_LANES(l) { const int j = l & 31; keyv[l] = j < 2 ? clean_kmer(S.planes, j == 0 ? p : last, k) : ~0ULL; } }
+  else { QM_LANES(l) { const int j = l & 31; keyv[l] = j < 2 ? ((const u64*)S.tab)[j == 0 ? p : last] : ~0ULL; } }
   QM_LANES(l) {
     const int j = l & 31;
     const bool isC = l >= 32;
@@ -980,14 +1008,35 @@ QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, c
   }
 }
 
+// rs = reverseRead(fs) (src/RapMapUtils.cpp:63-72,107-128; the table is case-blind, so the upper-cased string serves),
+// four characters per lane
+template <int NS>
+QM_DEV void reverse_string(const unsigned char* fs, unsigned char* rs, int len) {
+#pragma unroll
+  for (int c = 0; c < (NS + 3) / 4; ++c) {
+    QM_LANES(l) {
+      const int base = 256 * c + 4 * l;
+      if (base < len) {
+        const int nb = len - base < 4 ? len - base : 4;
+        const u32 rc = rc_char4(((const u32*)fs)[base >> 2]);          // byte j = complement of character base + j
+        rs[len - 1 - base] = (unsigned char)rc;
+        if (nb > 1) rs[len - 2 - base] = (unsigned char)(rc >> 8);
+        if (nb > 2) rs[len - 3 - base] = (unsigned char)(rc >> 16);
+        if (nb > 3) rs[len - 4 - base] = (unsigned char)(rc >> 24);
+      }
+    }
+  }
+  wave_fence();
+}
+
 // SACollector::operator() (SACollector.hpp:108-362), disableNIP_ == true.
-// M.str[0] = read (upper-cased), M.str[1] = reverseRead(read).  Returns foundHit.
+// M.str[0] = read (upper-cased); M.str[1] receives reverseRead(read) when that strand is walked.  Returns foundHit.
 template <int NS, int F>
 QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M, int L, bool hasDollar,
                          IntervalList& fwdInts, IntervalList& rcInts) {
   const int k = ix.k, P = L - k + 1;
   const unsigned char* fwdStr = M.str[0];
-  const unsigned char* rcStr = M.str[1];
+  unsigned char* rcStr = M.str[1];
   fwdInts.n = 0; rcInts.n = 0;
   fwdInts.pf = nullptr; fwdInts.pfcap = 0; rcInts.pf = nullptr; rcInts.pfcap = 0;
   if (P <= 0) return false;
@@ -1042,6 +1091,7 @@ QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M,
     LV<Iv> seed0;                                       // the first probe left this strand's first interval in tab[1][0]
     QM_LANES(l) { if (l == 0) seed0[l] = M.tab[1][0]; }
     wave_fence();
+    reverse_string<NS>(fwdStr, rcStr, L);
     setup_strand<NS>(ix, rcStr, L, R, &M.planes[1][0][0], M.tab[1]);
     R.dollar = false;                                   // reverseRead() maps '$' to 'N'
     if (seedR) {
@@ -1462,7 +1512,12 @@ QM_DEV void finish_read(const DevIndex& ix, const ReadBatch& B, long long read, 
     if (base + n > B.lists_cap) { QM_LANES(l) { if (l == 0) *B.status |= 1; } n = 0; base = 0; }
     else wa.used += n;
   }
-  for (int b0 = 0; b0 < n; b0 += 64) { QM_LANES(l) { int i = b0 + l; if (i < n) B.lists[base + i] = listSrc[i]; } }
+  if (!(F & QM_F_SEL) && bound <= QM_CAP) {          // the usual case, spelled out so that the source is addressed as LDS (not flat)
+    const u64* src = buf[2];
+    for (int b0 = 0; b0 < n; b0 += 64) { QM_LANES(l) { int i = b0 + l; if (i < n) B.lists[base + i] = src[i]; } }
+  } else {
+    for (int b0 = 0; b0 < n; b0 += 64) { QM_LANES(l) { int i = b0 + l; if (i < n) B.lists[base + i] = listSrc[i]; } }
+  }
   const u32 flag = ((B.fuzzy || (F & QM_F_SEL)) && foundHit) ? 0x80000000u : 0u;      // lh / rh of RapMapSAMapper.cpp:472-478
   QM_LANES(l) { if (l == 0) { B.lcnt[read] = (u32)n | flag; B.loff[read] = base; } }
   QM_T(6);
@@ -1486,10 +1541,9 @@ QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, lon
   int mis;
   { const unsigned char* src; const long long* off; long long unit; read_src(B, read, src, off, unit); mis = (int)((unsigned long long)(src + o0) & 3ULL); }
   unsigned char* fs = M.str[0];
-  unsigned char* rs = M.str[1];
   QM_T(6);
   // four characters per lane: the upper-cased read goes to fs as whole words (every consumer applies ::toupper anyway,
-  // SASearcher.hpp:111,155), reverseRead() of it (src/RapMapUtils.cpp:107-128) byte by byte to rs
+  // SASearcher.hpp:111,155); reverseRead() of it is only written when the collector turns to that strand (reverse_string)
   LV<bool> dl;
   QM_LANES(l) { dl[l] = false; }
 #pragma unroll
@@ -1502,11 +1556,6 @@ QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, lon
         const int nb = len - base < 4 ? len - base : 4;
         const u32 lenmask = nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
         ((u32*)fs)[base >> 2] = upcase4(d);
-        const u32 rc = rc_char4(d);                        // byte j = complement of character base + j
-        rs[len - 1 - base] = (unsigned char)rc;
-        if (nb > 1) rs[len - 2 - base] = (unsigned char)(rc >> 8);
-        if (nb > 2) rs[len - 3 - base] = (unsigned char)(rc >> 16);
-        if (nb > 3) rs[len - 4 - base] = (unsigned char)(rc >> 24);
         dl[l] = dl[l] || (eq_bytes(d, (u32)'$') & lenmask) != 0;
       }
     }

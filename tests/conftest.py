@@ -32,6 +32,12 @@ def _have_gpu():
 def lib_built():
     """libqmap_mi355.so, built in-tree (hipcc cross-compiles without a GPU)."""
     import rapmap_amd
+    # torch carries a HIP runtime of its own; it has to open the device before the library's runtime does, or its
+    # initialisation fails later in the same process ("No HIP GPUs are available") -- some tests hand torch tensors to the
+    # library, whatever order pytest runs them in
+    if _have_gpu():
+        import torch
+        torch.cuda.init()
     if not os.path.exists(rapmap_amd.LIB_PATH):
         if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
             subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "rapmap_amd", "csrc")])
@@ -146,6 +152,46 @@ def repeat_data(tmp_path_factory, lib_built):
     r2 += [s2[off[i]:off[i + 1]].tobytes() for i in range(200)]
     t = txps[-1]
     r1.append(t[10:110].tobytes()); r2.append(comp[t[120:220][::-1]].tobytes())
+    return {"idx": idx, "reads1": r1, "reads2": r2}
+
+
+@pytest.fixture(scope="session")
+def runs_data(tmp_path_factory, lib_built):
+    """transcripts with homopolymer runs of 24 .. 40 bases (and dinucleotide repeats) inside them; reads start 0 .. 70 bases
+    before a run, so the run sits at every alignment of the four-characters-per-lane setup and windows of exactly k equal
+    bases exist or just do not (isHomoPolymer, SACollector.hpp:498-536 / Kmer.hpp:484-487)"""
+    import rapmap_amd as ra
+    from rapmap_amd import synth
+    rng = np.random.default_rng(4242)
+    B = np.frombuffer(b"ACGT", dtype=np.uint8)
+    comp = np.zeros(256, np.uint8); comp[list(b"ACGT")] = list(b"TGCA")
+    names, txps, spots = [], [], []
+    for i, run in enumerate(list(range(24, 41)) + [31, 31, 32, 30, 64, 90]):
+        base = B[i % 4]
+        mid = np.full(run, base, np.uint8)
+        if i % 7 == 3:                                   # dinucleotide repeat instead of a homopolymer
+            mid = np.tile(np.array([base, B[(i + 1) % 4]], np.uint8), (run + 1) // 2)[:run]
+        l = B[rng.integers(0, 4, 150)]; r = B[rng.integers(0, 4, 150)]
+        if l[-1] == base: l[-1] = B[(i + 1) % 4]
+        if r[0] == base: r[0] = B[(i + 2) % 4]
+        txps.append(np.concatenate([l, mid, r])); names.append("run%d_%d" % (run, i)); spots.append((150, run))
+    d = tmp_path_factory.mktemp("runs")
+    fa = str(d / "t.fa"); synth.write_fasta(fa, names, txps)
+    idx = str(d / "idx"); ra.build_index(fa, idx, threads=2)
+    r1, r2 = [], []
+    for t, (st, run) in zip(txps, spots):
+        for back in list(range(0, 8)) + [17, 30, 45, 69, 70, 71, 99]:
+            a0 = max(0, st - back)
+            a = t[a0:a0 + 100].copy()
+            b0 = min(len(t) - 100, a0 + 120)
+            b = comp[t[b0:b0 + 100][::-1]]
+            if back % 5 == 4:
+                a[min(99, back + run + 3)] = B[(np.searchsorted(B, a[min(99, back + run + 3)]) + 1) % 4]
+            if back % 2:
+                a, b = b, a
+            r1.append(a.tobytes()); r2.append(b.tobytes())
+    r1.append(b"A" * 100); r2.append(b"T" * 100)          # nothing but one base
+    r1.append(b"A" * 31 + t[:69].tobytes()); r2.append(b"C" * 30 + t[:70].tobytes())
     return {"idx": idx, "reads1": r1, "reads2": r2}
 
 

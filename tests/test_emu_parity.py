@@ -201,6 +201,24 @@ def test_repeat_families(repeat_data, oracle_mod):
     _cmp_ints(res, er)
 
 
+@pytest.mark.parametrize("variant", ["default", "noSensitive", "fuzzy", "sel"])
+def test_homopolymer_runs(runs_data, oracle_mod, variant):
+    """windows of k equal bases at every alignment: the setup's shortcut for reads without such a window must agree with
+    the tabulating pass and with isHomoPolymer"""
+    ix, orc, em, emu = _emu(runs_data["idx"])
+    q1, o1 = pack(runs_data["reads1"]); q2, o2 = pack(runs_data["reads2"])
+    oo, eo = {"default": ({}, {}), "noSensitive": ({"sensitive": 0}, {"sensitive": 0}), "fuzzy": ({"fuzzy": 1}, {"fuzzy": 1}),
+              "sel": ({"selAln": 1}, {"sel_aln": 1})}[variant]
+    res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=4, want_ints=variant != "sel")
+    er = em.map(q1, o1, q2, o2, opts=emu.default_opts(**eo))
+    assert er.status == 0
+    assert res.counters["peHits"] > 0
+    assert_hits_equal(res.hit_offsets, res.hits, er.hit_offsets, er.hits, "runs-" + variant)
+    assert res.counters == er.counters
+    if variant != "sel":
+        _cmp_ints(res, er)
+
+
 def test_perfect_hash_index(synth_small, synth_small_ph, oracle_mod):
     """config 4: BooPHF cascade + FrugalBooMap text verification in the device source; hits must equal the
     dense-index oracle (the reference guarantees the same: SURVEY.md section 4)"""

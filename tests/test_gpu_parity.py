@@ -315,6 +315,25 @@ def test_repeat_families(repeat_data, oracle_mod):
     assert fres.counters == fgr.counters
 
 
+@pytest.mark.parametrize("variant", ["default", "noSensitive", "fuzzy", "sel"])
+def test_homopolymer_runs(runs_data, oracle_mod, variant):
+    """windows of k equal bases at every alignment of the four-characters-per-lane strand setup (its shortcut for reads
+    without such a window against the tabulating pass and isHomoPolymer, Kmer.hpp:484-487)"""
+    import rapmap_amd as ra
+    ix, orc = load_oracle(runs_data["idx"])
+    qi, mp = _gpu(runs_data["idx"])
+    q1, o1 = pack(runs_data["reads1"]); q2, o2 = pack(runs_data["reads2"])
+    oo, go = {"default": ({}, {}), "noSensitive": ({"sensitive": 0}, {"sensitive": 0}), "fuzzy": ({"fuzzy": 1}, {"fuzzy": 1}),
+              "sel": ({"selAln": 1}, {"sel_aln": 1})}[variant]
+    res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=4, want_ints=variant != "sel")
+    gr = mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(**go))
+    assert res.counters["peHits"] > 0
+    assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "runs-" + variant)
+    assert res.counters == gr.counters
+    if variant != "sel":
+        _cmp_ints(res, *mp.intervals(len(o1) - 1))
+
+
 @pytest.mark.parametrize("compact", [False, True])
 def test_perfect_hash_index(synth_small, synth_small_ph, oracle_mod, compact):
     """config 4: `quasiindex -p` index through the HIP path == dense-index oracle; both device images of the index: the
