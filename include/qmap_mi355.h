@@ -273,11 +273,23 @@ int qm_sam_records(const qm_index* ix, int64_t n, const char* names1, const int6
                    const int64_t* off1, const char* names2, const int64_t* name_off2, const char* seq2,
                    const int64_t* off2, const int64_t* hit_offsets, const qm_hit* hits, int32_t max_num_hits,
                    int32_t n_threads, char** out, int64_t* out_len);
-/* the same text written straight to an open file descriptor (no copy through the caller) */
+/* the same text written straight to an open file descriptor (no copy through the caller); formatted by n_threads
+ * workers, written in order by the calling thread */
 int qm_sam_write(const qm_index* ix, int64_t n, const char* names1, const int64_t* name_off1, const char* seq1,
                  const int64_t* off1, const char* names2, const int64_t* name_off2, const char* seq2,
                  const int64_t* off2, const int64_t* hit_offsets, const qm_hit* hits, int32_t max_num_hits,
                  int32_t n_threads, int fd, int64_t* bytes_written);
+/* A writer for a whole run: qm_sam_writer_put formats a batch with the writer's worker threads and returns; a thread of
+ * the writer's own puts the text on the descriptor in batch order while the caller fetches and formats the next batch
+ * (two batches of text are buffered; put blocks while both wait).  The batch's arrays are not referenced after put
+ * returns.  A write error is reported by the next put and by close; close drains, reports the bytes written and
+ * releases the writer (the descriptor stays the caller's). */
+typedef struct qm_sam_writer qm_sam_writer;
+int qm_sam_writer_open(const qm_index* ix, int fd, int32_t max_num_hits, int32_t n_threads, qm_sam_writer** out);
+int qm_sam_writer_put(qm_sam_writer* w, int64_t n, const char* names1, const int64_t* name_off1, const char* seq1,
+                      const int64_t* off1, const char* names2, const int64_t* name_off2, const char* seq2,
+                      const int64_t* off2, const int64_t* hit_offsets, const qm_hit* hits);
+int qm_sam_writer_close(qm_sam_writer* w, int64_t* bytes_written);
 void qm_buf_free(char* p);
 
 #ifdef __cplusplus

@@ -124,6 +124,7 @@ def _quasimap(argv):
     direct_fd = out.fileno() if (out is not None and not (a.output and a.compressed)) else None
     if out is None:
         direct_fd = None
+    writer = ra.SamWriter(qi, direct_fd, max_num_hits=opts.max_num_hits, threads=max(1, a.numThreads)) if direct_fd is not None else None
     tot = {"numReads": 0, "totHits": 0, "peHits": 0, "seHits": 0, "tooManyHits": 0}
     t0 = time.time()
     gpu_ms = 0.0
@@ -145,8 +146,8 @@ def _quasimap(argv):
             for kk in tot:
                 tot[kk] += b.counters[kk]
             if out is not None:
-                if direct_fd is not None:
-                    ra.sam_records_text(qi, b, b.hit_offsets, b.hits, max_num_hits=opts.max_num_hits, threads=nthr, fd=direct_fd)
+                if writer is not None:
+                    writer.put(b, b.hit_offsets, b.hits)       # formats now; the writer's thread writes while the next batch comes in
                 else:
                     out.write(ra.sam_records_text(qi, b, b.hit_offsets, b.hits, max_num_hits=opts.max_num_hits, threads=nthr))
             if paired:
@@ -154,6 +155,8 @@ def _quasimap(argv):
                     tot["numReads"], tot["peHits"] / max(1, tot["numReads"]), tot["seHits"] / max(1, tot["numReads"])))
         log("stream: " + ", ".join("%s %.3f" % kv for kv in st.stats().items()))
         st.close()
+    if writer is not None:
+        writer.close()
     if out is not None and out is not sys.stdout.buffer:
         out.close()
     log("Done mapping reads.")

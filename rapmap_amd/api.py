@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     "qm_map_pairs_stages", "qm_ctx_create_ex", "qm_fetch_hits_pinned",
     "qm_stream_open", "qm_stream_next", "qm_stream_close", "qm_stream_last_error", "qm_stream_stats",
     "qm_reader_open", "qm_reader_next", "qm_reader_close", "qm_io_last_error", "qm_sam_header", "qm_sam_records",
-    "qm_sam_write", "qm_buf_free",
+    "qm_sam_write", "qm_sam_writer_open", "qm_sam_writer_put", "qm_sam_writer_close", "qm_buf_free",
 ]
 
 
@@ -147,6 +147,9 @@ def lib():
                                  C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     L.qm_sam_write.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 10 + [C.c_int32, C.c_int32, C.c_int,
                                C.POINTER(C.c_int64)]
+    L.qm_sam_writer_open.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    L.qm_sam_writer_put.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 10
+    L.qm_sam_writer_close.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     L.qm_buf_free.argtypes = [C.c_void_p]
     _lib = L
     return L
@@ -521,6 +524,49 @@ def sam_header_text(index: "QuasiIndex") -> bytes:
     p = C.c_void_p(); n = C.c_int64()
     _check(lib().qm_sam_header(index._h, C.byref(p), C.byref(n)))
     return _take_buf(p, n)
+
+
+def _sam_batch_args(batch, hit_offsets, hits):
+    ho = np.ascontiguousarray(hit_offsets, dtype=np.int64)
+    hh = np.ascontiguousarray(hits)
+    paired = getattr(batch, "seq2", None) is not None
+    keep = [np.ascontiguousarray(x) for x in (batch.names1, batch.name_off1, batch.seq1, batch.off1)]
+    if paired:
+        keep += [np.ascontiguousarray(x) for x in (batch.names2, batch.name_off2, batch.seq2, batch.off2)]
+    args = [C.c_void_p(a.ctypes.data) for a in keep] + ([C.c_void_p(0)] * 4 if not paired else [])
+    if not keep[2].size:                       # a zero-length sequence array still needs a non-null pointer
+        args[2] = C.c_void_p(ho.ctypes.data)
+    args += [C.c_void_p(ho.ctypes.data), C.c_void_p(hh.ctypes.data if hh.size else ho.ctypes.data)]
+    return args, (keep, ho, hh)
+
+
+class SamWriter:
+    """qm_sam_writer_*: SAM records of a run onto one file descriptor; put() formats a batch and returns while the writer's
+    own thread writes the previous one."""
+
+    def __init__(self, index: "QuasiIndex", fd, max_num_hits=200, threads=None):
+        self._h = C.c_void_p()
+        self._index = index
+        rc = lib().qm_sam_writer_open(index._h, int(fd), int(max_num_hits), int(threads or min(16, os.cpu_count() or 1)), C.byref(self._h))
+        if rc != 0:
+            raise QmError(lib().qm_io_last_error().decode())
+
+    def put(self, batch, hit_offsets, hits):
+        args, keep = _sam_batch_args(batch, hit_offsets, hits)
+        rc = lib().qm_sam_writer_put(self._h, int(batch.n), *args)
+        if rc != 0:
+            raise QmError(lib().qm_io_last_error().decode())
+
+    def close(self):
+        """drains the writer; returns the bytes written"""
+        if not self._h:
+            return 0
+        nb = C.c_int64()
+        rc = lib().qm_sam_writer_close(self._h, C.byref(nb))
+        self._h = C.c_void_p()
+        if rc != 0:
+            raise QmError(lib().qm_io_last_error().decode())
+        return nb.value
 
 
 def sam_records_text(index: "QuasiIndex", batch, hit_offsets, hits, max_num_hits=200, threads=None, fd=None):

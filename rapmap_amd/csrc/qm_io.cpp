@@ -10,6 +10,7 @@
 //                    src/RapMapUtils.cpp:198-588, writeUnalignedPairToStream :137-196, getSamFlags /
 //                    adjustOverhang include/RapMapUtils.hpp:687-810), formatted by n_threads workers.
 // Plain C++ (no HIP); part of libqmap_mi355.so.
+#include <errno.h>
 #include <fcntl.h>
 #include <stdarg.h>
 #include <stdint.h>
@@ -22,6 +23,8 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -384,6 +387,10 @@ static void reverse_read(const char* s, int64_t n, std::string& out) {      // s
 // Output buffer of one formatter thread: raw bytes with amortised growth, no per-character bookkeeping.
 struct Out {
   char* b = nullptr; size_t n = 0, cap = 0;
+  Out() = default;
+  Out(const Out&) = delete; Out& operator=(const Out&) = delete;
+  Out(Out&& o) noexcept : b(o.b), n(o.n), cap(o.cap) { o.b = nullptr; o.n = o.cap = 0; }
+  Out& operator=(Out&& o) noexcept { if (this != &o) { free(b); b = o.b; n = o.n; cap = o.cap; o.b = nullptr; o.n = o.cap = 0; } return *this; }
   ~Out() { free(b); }
   inline void need(size_t m) {
     if (n + m > cap) { cap = (n + m) * 2 + 4096; b = (char*)realloc(b, cap); }
@@ -534,6 +541,31 @@ int qm_sam_header(const qm_index* ix, char** out, int64_t* out_len) {
   return QM_OK;
 }
 
+// formatting buffers kept between calls (a batch's worth of SAM text is hundreds of MB: handing it back to the allocator
+// means unmapping it, and faulting fresh zeroed pages in again for the next batch)
+static std::mutex g_poolMu;
+static std::vector<std::vector<Out>> g_pool;
+struct PartPool {
+  std::vector<Out> parts;
+  PartPool() { std::lock_guard<std::mutex> lk(g_poolMu); if (!g_pool.empty()) { parts.swap(g_pool.back()); g_pool.pop_back(); } }
+  ~PartPool() { std::lock_guard<std::mutex> lk(g_poolMu); if (g_pool.size() < 2) { g_pool.emplace_back(); g_pool.back().swap(parts); } }
+};
+
+// The parts of a batch go out in order from ONE thread.  Writes to one inode serialise on its lock, and contending for it
+// costs more than it gains: on this box's tmpfs one thread writes 7.7 GB/s, four or sixteen threads calling pwrite at
+// disjoint offsets 3.3 GB/s together, copies into a shared mapping 1-3.5 GB/s (profiles/microbench/tmpfs_write_ceiling.py).
+static int write_parts(int fd, const std::vector<Out>& parts) {
+  for (auto& p : parts) {
+    const char* b = p.b; size_t left = p.n;
+    while (left > 0) {
+      ssize_t w = ::write(fd, b, left);
+      if (w < 0) { if (errno == EINTR) continue; return io_fail(QM_E_IO, "write failed: %s", strerror(errno)); }
+      b += w; left -= (size_t)w;
+    }
+  }
+  return QM_OK;
+}
+
 static int sam_parts(const qm_index* ix, int64_t n, const char* names1, const int64_t* name_off1, const char* seq1,
                      const int64_t* off1, const char* names2, const int64_t* name_off2, const char* seq2,
                      const int64_t* off2, const int64_t* hit_offsets, const qm_hit* hits, int32_t max_num_hits,
@@ -549,7 +581,8 @@ static int sam_parts(const qm_index* ix, int64_t n, const char* names1, const in
   for (int64_t t = 0; t < info.n_txps; ++t) { C.tname[(size_t)t] = qm_index_txp_name(ix, t); C.tnl[(size_t)t] = (uint32_t)strlen(C.tname[(size_t)t]); C.tlen[(size_t)t] = qm_index_txp_len(ix, t); }
   for (int64_t i = 0, e = hit_offsets[n]; i < e; ++i) if ((int64_t)hits[i].tid >= info.n_txps) return io_fail(QM_E_ARG, "qm_sam_records: hit with an out-of-range transcript id");
   int T = std::max(1, std::min<int>(n_threads, (int)((n + 4095) / 4096)));
-  parts = std::vector<Out>((size_t)T);
+  if (parts.size() < (size_t)T) parts.resize((size_t)T);
+  for (auto& p : parts) p.n = 0;
   auto work = [&](int t) {
     Out& o = parts[(size_t)t];
     std::string r1, r2;
@@ -591,46 +624,82 @@ int qm_sam_write(const qm_index* ix, int64_t n, const char* names1, const int64_
                  const int64_t* off1, const char* names2, const int64_t* name_off2, const char* seq2,
                  const int64_t* off2, const int64_t* hit_offsets, const qm_hit* hits, int32_t max_num_hits,
                  int32_t n_threads, int fd, int64_t* bytes_written) {
-  std::vector<Out> parts;
+  PartPool pool;                                   // formatting buffers live across calls: no fresh pages per batch
+  std::vector<Out>& parts = pool.parts;
   int rc = sam_parts(ix, n, names1, name_off1, seq1, off1, names2, name_off2, seq2, off2, hit_offsets, hits, max_num_hits, n_threads, parts);
   if (rc) return rc;
   int64_t tot = 0;
   for (auto& p : parts) tot += (int64_t)p.n;
-  // a seekable descriptor takes the parts concurrently (pwrite at precomputed offsets); pipes get them in order
-  // -- but not one opened with O_APPEND (a shell's `>>`): there pwrite ignores its offset and appends, which would leave
-  // the parts in completion order
-  const off_t base = lseek(fd, 0, SEEK_CUR);
-  const int fl = fcntl(fd, F_GETFL);
-  const bool appendMode = fl != -1 && (fl & O_APPEND);
-  bool done = false;
-  if (base != (off_t)-1 && !appendMode && parts.size() > 1) {
-    std::vector<off_t> at(parts.size());
-    off_t o = base; for (size_t i = 0; i < parts.size(); ++i) { at[i] = o; o += (off_t)parts[i].n; }
-    std::vector<char> okv(parts.size(), 1);
-    std::vector<std::thread> th;
-    for (size_t i = 0; i < parts.size(); ++i)
-      th.emplace_back([&, i]() {
-        const char* b = parts[i].b; size_t left = parts[i].n; off_t w0 = at[i];
-        while (left > 0) { ssize_t w = ::pwrite(fd, b, left, w0); if (w <= 0) { okv[i] = 0; return; } b += w; left -= (size_t)w; w0 += w; }
-      });
-    for (auto& x : th) x.join();
-    done = true;
-    for (char k : okv) if (!k) done = false;
-    if (done) lseek(fd, base + (off_t)tot, SEEK_SET);
-    else lseek(fd, base, SEEK_SET);
-  }
-  if (!done) {
-    for (auto& p : parts) {
-      const char* b = p.b; size_t left = p.n;
-      while (left > 0) {
-        ssize_t w = ::write(fd, b, left);
-        if (w < 0) return io_fail(QM_E_IO, "write failed");
-        b += w; left -= (size_t)w;
-      }
-    }
-  }
+  if ((rc = write_parts(fd, parts))) return rc;
   if (bytes_written) *bytes_written = tot;
   return QM_OK;
+}
+
+/* ---- SAM writer: formatting of batch i+1 overlaps the write of batch i ---- */
+struct qm_sam_writer {
+  const qm_index* ix = nullptr; int fd = -1; int threads = 1; int32_t maxHits = 0;
+  std::vector<Out> bufs[2];
+  int state[2] = {0, 0};            // 0 free, 1 formatted (waits for the writer)
+  int fill = 0, drain = 0;
+  bool stop = false; int err = 0; char errmsg[256] = ""; int64_t bytes = 0;
+  std::mutex mu; std::condition_variable cv; std::thread wt;
+};
+static void sam_writer_loop(qm_sam_writer* w) {
+  while (true) {
+    int k;
+    {
+      std::unique_lock<std::mutex> lk(w->mu);
+      w->cv.wait(lk, [&] { return w->state[w->drain] == 1 || w->stop; });
+      if (w->state[w->drain] != 1) return;               // stop, nothing left
+      k = w->drain;
+    }
+    int rc = w->err ? 0 : write_parts(w->fd, w->bufs[k]);  // after a failure the remaining batches are dropped
+    std::unique_lock<std::mutex> lk(w->mu);
+    if (rc) { w->err = rc; snprintf(w->errmsg, sizeof(w->errmsg), "%s", qm_io_last_error()); }
+    else if (!w->err) for (auto& p : w->bufs[k]) w->bytes += (int64_t)p.n;
+    w->state[k] = 0; w->drain ^= 1;
+    w->cv.notify_all();
+  }
+}
+int qm_sam_writer_open(const qm_index* ix, int fd, int32_t max_num_hits, int32_t n_threads, qm_sam_writer** out) {
+  if (!ix || fd < 0 || !out) return io_fail(QM_E_ARG, "qm_sam_writer_open: bad argument");
+  qm_sam_writer* w = new qm_sam_writer();
+  w->ix = ix; w->fd = fd; w->threads = n_threads > 0 ? n_threads : 1; w->maxHits = max_num_hits;
+  w->wt = std::thread(sam_writer_loop, w);
+  *out = w;
+  return QM_OK;
+}
+int qm_sam_writer_put(qm_sam_writer* w, int64_t n, const char* names1, const int64_t* name_off1, const char* seq1, const int64_t* off1,
+                      const char* names2, const int64_t* name_off2, const char* seq2, const int64_t* off2,
+                      const int64_t* hit_offsets, const qm_hit* hits) {
+  if (!w) return io_fail(QM_E_ARG, "qm_sam_writer_put: bad argument");
+  int k;
+  {
+    std::unique_lock<std::mutex> lk(w->mu);
+    w->cv.wait(lk, [&] { return w->state[w->fill] == 0; });
+    if (w->err) return io_fail(w->err, "%s", w->errmsg);
+    k = w->fill;
+  }
+  int rc = sam_parts(w->ix, n, names1, name_off1, seq1, off1, names2, name_off2, seq2, off2, hit_offsets, hits, w->maxHits, w->threads, w->bufs[k]);
+  if (rc) return rc;
+  std::unique_lock<std::mutex> lk(w->mu);
+  w->state[k] = 1; w->fill ^= 1;
+  w->cv.notify_all();
+  return QM_OK;
+}
+int qm_sam_writer_close(qm_sam_writer* w, int64_t* bytes_written) {
+  if (!w) return QM_OK;
+  {
+    std::unique_lock<std::mutex> lk(w->mu);
+    w->cv.wait(lk, [&] { return w->state[0] == 0 && w->state[1] == 0; });
+    w->stop = true; w->cv.notify_all();
+  }
+  w->wt.join();
+  const int rc = w->err;
+  if (bytes_written) *bytes_written = w->bytes;
+  if (rc) io_fail(rc, "%s", w->errmsg);
+  delete w;
+  return rc;
 }
 
 }  // extern "C"

@@ -143,6 +143,57 @@ def test_sam_writer_matches_python_formatter(synth_small, oracle_mod, opts):
         nb = ra.sam_records_text(qi, b, res.hit_offsets, res.hits, max_num_hits=oo.maxNumHits, threads=4, fd=f.fileno())
         f.seek(0)
         assert nb == len(got) and f.read() == got
+    # the run-long writer (formatting overlaps the previous batch's write): five batches behind an existing header line
+    with tempfile.NamedTemporaryFile() as nf:
+        nf.write(b"@HD\tpre-existing line\n"); nf.flush()
+        fd = os.open(nf.name, os.O_WRONLY)
+        try:
+            os.lseek(fd, 0, os.SEEK_END)
+            w = ra.SamWriter(qi, fd, max_num_hits=oo.maxNumHits, threads=4)
+            for _ in range(5):
+                w.put(b, res.hit_offsets, res.hits)
+            assert w.close() == 5 * len(got)
+        finally:
+            os.close(fd)
+        assert open(nf.name, "rb").read() == b"@HD\tpre-existing line\n" + got * 5
+    # ... and a descriptor that cannot be written: the error surfaces in put or close, not as a crash
+    rfd = os.open(os.devnull, os.O_RDONLY)
+    try:
+        w = ra.SamWriter(qi, rfd, max_num_hits=oo.maxNumHits, threads=2)
+        with pytest.raises(ra.QmError):
+            for _ in range(4):
+                w.put(b, res.hit_offsets, res.hits)
+            w.close()
+        try:
+            w.close()
+        except ra.QmError:
+            pass
+    finally:
+        os.close(rfd)
+    # a batch large enough for several formatter threads: their parts go out in order
+    if not opts:
+        R = 8
+        def tile(seq, off):
+            return np.tile(seq[:off[-1]], R), np.concatenate([[0], (off[1:][None, :] + off[-1] * np.arange(R)[:, None]).ravel()]).astype(np.int64)
+        bb = ra.ReadBatch(); bb.n = b.n * R
+        bb.seq1, bb.off1 = tile(q1, o1); bb.seq2, bb.off2 = tile(q2, o2)
+        bb.names1, bb.name_off1 = tile(b.names1, b.name_off1); bb.names2, bb.name_off2 = tile(b.names2, b.name_off2)
+        bh, bho = tile(res.hits, res.hit_offsets)
+        big = ra.sam_records_text(qi, bb, bho, bh, max_num_hits=oo.maxNumHits, threads=6)
+        assert big == got * R
+        with tempfile.TemporaryFile() as f:
+            f.write(b"x" * 5000); f.flush()
+            nb = ra.sam_records_text(qi, bb, bho, bh, max_num_hits=oo.maxNumHits, threads=6, fd=f.fileno())
+            f.seek(5000)
+            assert nb == len(big) and f.read() == big
+    # write-only descriptor (a shell's `>`)
+    with tempfile.NamedTemporaryFile() as nf:
+        fd = os.open(nf.name, os.O_WRONLY)
+        try:
+            nb = ra.sam_records_text(qi, b, res.hit_offsets, res.hits, max_num_hits=oo.maxNumHits, threads=4, fd=fd)
+        finally:
+            os.close(fd)
+        assert nb == len(got) and open(nf.name, "rb").read() == got
     # a descriptor opened for appending (a shell's `>>`): pwrite would ignore its offsets there, the parts must still land in order
     with tempfile.NamedTemporaryFile() as nf:
         nf.write(b"@HD\tpre-existing line\n"); nf.flush()
