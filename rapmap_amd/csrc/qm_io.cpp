@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -40,6 +41,41 @@ static int io_fail(int code, const char* fmt, ...) {
 extern "C" const char* qm_io_last_error(void) { return g_ioerr; }
 
 namespace {
+
+// Worker threads that live as long as the reader / writer that owns them: a batch of 2^18 pairs is a few milliseconds of
+// work per phase, about what starting and joining 64 threads costs.  run(T, fn) calls fn(0) .. fn(T-1), the caller included.
+class Pool {
+  std::vector<std::thread> th_;
+  std::mutex mu_; std::condition_variable work_, done_;
+  const std::function<void(int)>* fn_ = nullptr;
+  int T_ = 0, next_ = 0, finished_ = 0; bool stop_ = false;
+  void drain(std::unique_lock<std::mutex>& lk) {
+    while (next_ < T_) {
+      const int t = next_++;
+      const std::function<void(int)>* f = fn_;
+      lk.unlock(); (*f)(t); lk.lock();
+      if (++finished_ == T_) done_.notify_all();
+    }
+  }
+ public:
+  explicit Pool(int n) {
+    for (int i = 1; i < n; ++i) th_.emplace_back([this]() {
+      std::unique_lock<std::mutex> lk(mu_);
+      while (true) { work_.wait(lk, [&] { return stop_ || next_ < T_; }); if (stop_) return; drain(lk); }
+    });
+  }
+  ~Pool() { { std::lock_guard<std::mutex> lk(mu_); stop_ = true; } work_.notify_all(); for (auto& t : th_) t.join(); }
+  int size() const { return (int)th_.size() + 1; }
+  void run(int T, const std::function<void(int)>& fn) {
+    if (T <= 1) { if (T == 1) fn(0); return; }
+    std::unique_lock<std::mutex> lk(mu_);
+    fn_ = &fn; T_ = T; next_ = 0; finished_ = 0;
+    work_.notify_all();
+    drain(lk);
+    done_.wait(lk, [&] { return finished_ == T_; });
+    T_ = 0; next_ = 0; fn_ = nullptr;
+  }
+};
 
 // ------------------------------------------------------------------ record index of one file
 // A parsed record is four pointers/lengths into storage that stays put (the mmap of a plain file, or a
@@ -139,6 +175,9 @@ struct Source {
   gzFile gzf = nullptr; std::vector<char> carry;            // gz: undigested tail of the previous block
   std::vector<RecIdx> idx;      // parsed, not yet handed out: idx[head..)
   size_t head = 0;
+  // the parser threads' record lists, kept between blocks: freshly allocated vectors of this size are fresh pages every
+  // time (the allocator maps and unmaps them), and faulting those in cost more than the parsing itself
+  std::vector<std::vector<RecIdx>> partsKeep;
   int64_t handed = 0, parsed = 0;   // global record counters
   std::vector<Block*> blocks;   // FIFO of live storage blocks
 
@@ -162,6 +201,7 @@ struct Source {
       if (map == MAP_FAILED) { map = nullptr; ::close(fd); return io_fail(QM_E_IO, "cannot mmap %s", p); }
       madvise((void*)map, len, MADV_SEQUENTIAL);
       fastq = map[0] != '>';
+      idx.reserve((size_t)1 << 22);          // the list of parsed records never reallocates in steady state (see release())
     } else eof = true;
     ::close(fd);
     return 0;
@@ -178,12 +218,14 @@ struct Source {
 
   // storage whose records have all been handed out AND copied (called at the start of the next hand-out)
   void release() {
-    if (head > (1u << 20) && head * 2 > idx.size()) { idx.erase(idx.begin(), idx.begin() + (long)head); head = 0; }
+    if (head == idx.size()) { idx.clear(); head = 0; }                       // (keeps the capacity)
+    else if (head > (1u << 20) && head * 2 > idx.size()) { idx.erase(idx.begin(), idx.begin() + (long)head); head = 0; }
     while (!blocks.empty() && blocks.front()->last <= handed) { delete blocks.front(); blocks.erase(blocks.begin()); }
   }
 
   // parse roughly `bytes` more input
-  void fill(size_t bytes, int nthreads) {
+  void fill(size_t bytes, Pool& pool) {
+    const int nthreads = pool.size();
     if (eof || bad) return;
     Block* blk = new Block();
     const char* b; const char* e; bool final;
@@ -209,17 +251,25 @@ struct Source {
     cut[0] = b; cut[(size_t)T] = e;
     for (int t = 1; t < T; ++t) cut[(size_t)t] = sync_record(b, b + (size_t)(e - b) * (size_t)t / (size_t)T, e, fastq);
     for (int t = 1; t <= T; ++t) if (cut[(size_t)t] < cut[(size_t)t - 1]) cut[(size_t)t] = cut[(size_t)t - 1];
-    std::vector<std::vector<RecIdx>> parts((size_t)T); std::vector<const char*> rest((size_t)T); std::vector<char> badv((size_t)T, 0);
+    if (partsKeep.size() < (size_t)T) partsKeep.resize((size_t)T);
+    std::vector<std::vector<RecIdx>>& parts = partsKeep;
+    for (auto& v : parts) v.clear();
+    std::vector<const char*> rest((size_t)T); std::vector<char> badv((size_t)T, 0);
     blk->arenas.resize((size_t)T);
     auto work = [&](int t) {
       bool bd = false;
       if (!fastq) blk->arenas[(size_t)t].reserve((size_t)(cut[(size_t)t + 1] - cut[(size_t)t]) + 16);   // never reallocates
       parts[(size_t)t].reserve((size_t)(cut[(size_t)t + 1] - cut[(size_t)t]) / 128 + 16);
+#ifdef MADV_POPULATE_READ
+      if (!gz && cut[(size_t)t + 1] > cut[(size_t)t]) {     // map this slice's pages in one call instead of a fault per 16 pages
+        const uintptr_t a = (uintptr_t)cut[(size_t)t] & ~(uintptr_t)4095;
+        madvise((void*)a, (size_t)((uintptr_t)cut[(size_t)t + 1] - a), MADV_POPULATE_READ);
+      }
+#endif
       rest[(size_t)t] = parse_block(cut[(size_t)t], cut[(size_t)t + 1], t == T - 1 ? final : true, parts[(size_t)t], blk->arenas[(size_t)t], bd);
       badv[(size_t)t] = bd;
     };
-    if (T == 1) work(0);
-    else { std::vector<std::thread> th; for (int t = 0; t < T; ++t) th.emplace_back(work, t); for (auto& x : th) x.join(); }
+    pool.run(T, work);
     for (int t = 0; t < T; ++t) {
       if (badv[(size_t)t] || (t < T - 1 && rest[(size_t)t] != cut[(size_t)t + 1])) { bad = true; break; }
       idx.insert(idx.end(), parts[(size_t)t].begin(), parts[(size_t)t].end());
@@ -246,7 +296,8 @@ struct Dst {
     return *p != nullptr;
   }
 };
-static bool pack_records(Source& S, int64_t n, int nthreads, Dst& D) {
+static bool pack_records(Source& S, int64_t n, Pool& pool, Dst& D) {
+  const int nthreads = pool.size();
   if (!D.ensure(D.off, D.capOff, (size_t)n + 1) || !D.ensure(D.noff, D.capNoff, (size_t)n + 1)) return false;
   int64_t* off = *D.off; int64_t* noff = *D.noff;
   const RecIdx* R = S.idx.data() + S.head;
@@ -266,10 +317,7 @@ static bool pack_records(Source& S, int64_t n, int nthreads, Dst& D) {
       memcpy(names + no, R[i].nm, R[i].nl); no += R[i].nl;
     }
   };
-  auto run = [&](auto fn) {
-    if (T == 1) { fn(0); return; }
-    std::vector<std::thread> th; for (int t = 0; t < T; ++t) th.emplace_back(fn, t); for (auto& x : th) x.join();
-  };
+  auto run = [&](const std::function<void(int)>& fn) { pool.run(T, fn); };
   run(count);
   for (int t = 0; t < T; ++t) { sb[(size_t)t + 1] += sb[(size_t)t]; nb[(size_t)t + 1] += nb[(size_t)t]; }
   if (!D.ensure(D.seq, D.capSeq, (size_t)sb[(size_t)T] + 64) || !D.ensure(D.names, D.capNames, (size_t)nb[(size_t)T] + 1)) return false;
@@ -285,9 +333,10 @@ static bool pack_records(Source& S, int64_t n, int nthreads, Dst& D) {
 
 struct qm_reader {
   Source src[2]; int nsrc = 0; int nthreads = 1;
+  Pool* pool[2] = {nullptr, nullptr};     // paired input: the two files are parsed and packed side by side, half the workers each
   qm_batch_bufs own;           // the buffers qm_reader_next hands out (plain malloc)
   qm_reader() { memset(&own, 0, sizeof(own)); own.alloc = malloc; own.release = free; }
-  ~qm_reader() { for (int s = 0; s < 2; ++s) { free(own.seq[s]); free(own.off[s]); free(own.names[s]); free(own.noff[s]); } }
+  ~qm_reader() { for (int s = 0; s < 2; ++s) { delete pool[s]; free(own.seq[s]); free(own.off[s]); free(own.names[s]); free(own.noff[s]); } }
 };
 
 extern "C" {
@@ -300,6 +349,8 @@ int qm_reader_open(const char* path1, const char* path2, int32_t n_threads, qm_r
   int rc = r->src[0].open(path1);
   if (!rc && path2) rc = r->src[1].open(path2);
   if (rc) { r->src[0].close(); r->src[1].close(); delete r; return rc; }
+  const int per = std::max(1, r->nthreads / r->nsrc);
+  for (int s = 0; s < r->nsrc; ++s) r->pool[s] = new Pool(per);
   *out = r;
   return QM_OK;
 }
@@ -314,18 +365,17 @@ void qm_reader_close(qm_reader* r) {
 int qm_reader_next_into(qm_reader* r, int64_t max_units, int64_t* n_units, qm_batch_bufs* B) {
   if (!r || !n_units || !B || max_units <= 0) return io_fail(QM_E_ARG, "qm_reader_next: bad argument");
   const size_t block = (size_t)128 << 20;
-  const int per = std::max(1, r->nthreads / r->nsrc);
   for (int s = 0; s < r->nsrc; ++s) r->src[s].release();
   // both files advance together: parse them concurrently until each has max_units records (or ended)
   auto need = [&](int s) { Source& S = r->src[s]; return S.avail() < max_units && !S.eof && !S.bad; };
   while (need(0) || (r->nsrc == 2 && need(1))) {
     if (r->nsrc == 2 && need(0) && need(1)) {
-      std::thread t2([&]() { r->src[1].fill(block, per); });
-      r->src[0].fill(block, per);
+      std::thread t2([&]() { r->src[1].fill(block, *r->pool[1]); });
+      r->src[0].fill(block, *r->pool[0]);
       t2.join();
     } else {
       const int s = need(0) ? 0 : 1;
-      r->src[s].fill(block, r->nthreads);
+      r->src[s].fill(block, *r->pool[s]);
     }
   }
   for (int s = 0; s < r->nsrc; ++s)
@@ -342,12 +392,12 @@ int qm_reader_next_into(qm_reader* r, int64_t max_units, int64_t* n_units, qm_ba
   bool ok = true;
   if (r->nsrc == 2 && n > 0) {
     bool ok2 = true;
-    std::thread t2([&]() { ok2 = pack_records(r->src[1], n, per, D[1]); });
-    ok = pack_records(r->src[0], n, per, D[0]);
+    std::thread t2([&]() { ok2 = pack_records(r->src[1], n, *r->pool[1], D[1]); });
+    ok = pack_records(r->src[0], n, *r->pool[0], D[0]);
     t2.join();
     ok = ok && ok2;
   } else {
-    for (int s = 0; s < r->nsrc; ++s) ok = pack_records(r->src[s], n, r->nthreads, D[s]) && ok;
+    for (int s = 0; s < r->nsrc; ++s) ok = pack_records(r->src[s], n, *r->pool[s], D[s]) && ok;
   }
   if (!ok) return io_fail(QM_E_NOMEM, "out of memory for a batch of %lld reads", (long long)n);
   *n_units = n;
@@ -569,7 +619,7 @@ static int write_parts(int fd, const std::vector<Out>& parts) {
 static int sam_parts(const qm_index* ix, int64_t n, const char* names1, const int64_t* name_off1, const char* seq1,
                      const int64_t* off1, const char* names2, const int64_t* name_off2, const char* seq2,
                      const int64_t* off2, const int64_t* hit_offsets, const qm_hit* hits, int32_t max_num_hits,
-                     int32_t n_threads, std::vector<Out>& parts) {
+                     int32_t n_threads, std::vector<Out>& parts, Pool* pool = nullptr) {
   if (!ix || !names1 || !name_off1 || !seq1 || !off1 || !hit_offsets || n < 0)
     return io_fail(QM_E_ARG, "qm_sam_records: bad argument");
   const bool paired = seq2 != nullptr;
@@ -599,6 +649,7 @@ static int sam_parts(const qm_index* ix, int64_t n, const char* names1, const in
     }
   };
   if (T == 1) work(0);
+  else if (pool) pool->run(T, work);
   else { std::vector<std::thread> th; for (int t = 0; t < T; ++t) th.emplace_back(work, t); for (auto& x : th) x.join(); }
   return QM_OK;
 }
@@ -639,6 +690,7 @@ int qm_sam_write(const qm_index* ix, int64_t n, const char* names1, const int64_
 struct qm_sam_writer {
   const qm_index* ix = nullptr; int fd = -1; int threads = 1; int32_t maxHits = 0;
   std::vector<Out> bufs[2];
+  Pool* pool = nullptr;             // the formatter's workers
   int state[2] = {0, 0};            // 0 free, 1 formatted (waits for the writer)
   int fill = 0, drain = 0;
   bool stop = false; int err = 0; char errmsg[256] = ""; int64_t bytes = 0;
@@ -665,6 +717,7 @@ int qm_sam_writer_open(const qm_index* ix, int fd, int32_t max_num_hits, int32_t
   if (!ix || fd < 0 || !out) return io_fail(QM_E_ARG, "qm_sam_writer_open: bad argument");
   qm_sam_writer* w = new qm_sam_writer();
   w->ix = ix; w->fd = fd; w->threads = n_threads > 0 ? n_threads : 1; w->maxHits = max_num_hits;
+  w->pool = new Pool(w->threads);
   w->wt = std::thread(sam_writer_loop, w);
   *out = w;
   return QM_OK;
@@ -680,7 +733,7 @@ int qm_sam_writer_put(qm_sam_writer* w, int64_t n, const char* names1, const int
     if (w->err) return io_fail(w->err, "%s", w->errmsg);
     k = w->fill;
   }
-  int rc = sam_parts(w->ix, n, names1, name_off1, seq1, off1, names2, name_off2, seq2, off2, hit_offsets, hits, w->maxHits, w->threads, w->bufs[k]);
+  int rc = sam_parts(w->ix, n, names1, name_off1, seq1, off1, names2, name_off2, seq2, off2, hit_offsets, hits, w->maxHits, w->threads, w->bufs[k], w->pool);
   if (rc) return rc;
   std::unique_lock<std::mutex> lk(w->mu);
   w->state[k] = 1; w->fill ^= 1;
@@ -698,6 +751,7 @@ int qm_sam_writer_close(qm_sam_writer* w, int64_t* bytes_written) {
   const int rc = w->err;
   if (bytes_written) *bytes_written = w->bytes;
   if (rc) io_fail(rc, "%s", w->errmsg);
+  delete w->pool;
   delete w;
   return rc;
 }
