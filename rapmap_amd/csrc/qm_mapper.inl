@@ -332,6 +332,48 @@ QM_DEV bool text_kmer(const DevIndex& ix, long long pos, int k, u64& w) {
   return ok;
 }
 
+// khash.find on the dense table for a whole probe round, without per-lane control flow: every lane issues its bucket load
+// (lanes with nothing to look up read bucket 0, a line that stays in cache), key match and value are selects, and the walk to
+// a following bucket -- 0.4 % of the buckets carry the overflow mark -- is a wave-level branch taken when any lane needs it.
+// A per-lane `while` here costs ~35 scalar instructions of exec-mask bookkeeping per round; the scalar unit is what this
+// kernel runs out of first.
+QM_DEV void find_dense_round(const DevIndex& ix, const LV<u64>& key, const LV<bool>& want, LV<bool>& hit, LV<Iv>& val) {
+  LV<bool> more; LV<u64> bkt;
+  QM_LANES(l) {
+    const u64 b = want[l] ? ((u64)bucket_hash(key[l]) & ix.hmask) : 0ULL;
+    U4 a, c;
+    load_32(&ix.slots[b], a, c);
+    QM_CNT(0, want[l] ? 1 : 0); QM_CNT(1, want[l] ? 1 : 0);
+    const u64 k0r = ((u64)a.y << 32) | a.x, k1 = ((u64)a.w << 32) | a.z;
+    const u64 k0 = k0r == ~0ULL ? k0r : (k0r & ~QM_BK_OVF);
+    const bool h0 = k0 == key[l], h1 = k1 == key[l];
+    Iv v; v.lb = (int)(h0 ? c.x : c.z); v.ub = (int)(h0 ? c.y : c.w);
+    const bool h = want[l] && (h0 || h1);
+    if (!h) { v.lb = 0; v.ub = 0; }
+    hit[l] = h; val[l] = v;
+    more[l] = want[l] && !h && k0r != ~0ULL && (k0r & QM_BK_OVF) != 0;
+    bkt[l] = b;
+  }
+  if (ballot(more)) {
+    QM_LANES(l) {
+      if (more[l]) {
+        u64 b = (bkt[l] + 1) & ix.hmask;
+        while (true) {
+          U4 a, c;
+          load_32(&ix.slots[b], a, c);
+          QM_CNT(1, 1);
+          const u64 k0r = ((u64)a.y << 32) | a.x, k1 = ((u64)a.w << 32) | a.z;
+          const u64 k0 = k0r == ~0ULL ? k0r : (k0r & ~QM_BK_OVF);
+          if (k0 == key[l]) { hit[l] = true; val[l].lb = (int)c.x; val[l].ub = (int)c.y; break; }
+          if (k1 == key[l]) { hit[l] = true; val[l].lb = (int)c.z; val[l].ub = (int)c.w; break; }
+          if (k0r == ~0ULL || !(k0r & QM_BK_OVF)) break;
+          b = (b + 1) & ix.hmask;
+        }
+      }
+    }
+  }
+}
+
 template <int F>
 QM_DEV bool find_kmer(const DevIndex& ix, u64 key, int& lb, int& ub) {
   if (!(F & QM_F_PH)) {
@@ -634,6 +676,19 @@ QM_DEV void probe_window(const DevIndex& ix, Strand<NS>& S, int p, int width) {
   // every lane fetches its word before any lane replaces one by an interval
   if (S.lazy) { QM_LANES(l) { const int j = l & 31; keyv[l] = j < width ? clean_kmer(S.planes, p + j, k) : ~0ULL; } }
   else { QM_LANES(l) { const int j = l & 31; keyv[l] = j < width ? ((const u64*)S.tab)[p + j] : ~0ULL; } }
+  if (!(F & QM_F_PH)) {
+    LV<u64> kq; LV<bool> want, fresh; LV<Iv> val;
+    QM_LANES(l) {
+      const int j = l & 31;
+      const u64 key = keyv[l], rc = word_rc(key, k);
+      // positions probed before keep their bits and their interval (the slot no longer holds the word)
+      fresh[l] = j < width && !S.K.test(p + j);
+      want[l] = fresh[l] && key != ~0ULL;
+      kq[l] = l >= 32 ? rc : key;
+    }
+    find_dense_round(ix, kq, want, found, val);
+    QM_LANES(l) { if (fresh[l] && l < 32) S.tab[p + l] = val[l]; }
+  } else
   QM_LANES(l) {
     int j = l & 31;
     bool isC = l >= 32;
@@ -671,6 +726,24 @@ QM_DEV bool probe_first(const DevIndex& ix, Strand<NS>& S, int p, Iv* rtab0) {
   LV<bool> found; LV<u64> keyv;
   if (S.lazy) { QM_LANES(l) { const int j = l & 31; keyv[l] = j < 2 ? clean_kmer(S.planes, j == 0 ? p : last, k) : ~0ULL; } }
   else { QM_LANES(l) { const int j = l & 31; keyv[l] = j < 2 ? ((const u64*)S.tab)[j == 0 ? p : last] : ~0ULL; } }
+  if (!(F & QM_F_PH)) {
+    LV<u64> kq; LV<bool> want, on; LV<Iv> val;
+    QM_LANES(l) {
+      const int j = l & 31;
+      const u64 key = keyv[l], rc = word_rc(key, k);
+      on[l] = j == 0 || (j == 1 && last != p);
+      want[l] = on[l] && key != ~0ULL;
+      kq[l] = l >= 32 ? rc : key;
+    }
+    find_dense_round(ix, kq, want, found, val);
+    QM_LANES(l) {
+      if (on[l]) {
+        const int pos = (l & 31) == 0 ? p : last;
+        if (l < 32) S.tab[pos] = val[l];
+        else if (pos == last) *rtab0 = val[l];
+      }
+    }
+  } else
   QM_LANES(l) {
     const int j = l & 31;
     const bool isC = l >= 32;
