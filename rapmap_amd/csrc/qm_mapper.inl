@@ -167,56 +167,13 @@ struct WaveMem {
 };
 
 // ------------------------------------------------------------------ bit helpers
+// one bit per read position, NS 64-bit words, wave-uniform (the --noSensitive vote's bitmaps; the walk itself keeps its
+// per-position flags in a vector register, see Strand)
 template <int NS>
 struct Bits {
   u64 w[NS];
-  QM_DEV bool test(int p) const {
-    u64 x = 0;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) x |= (s == (p >> 6)) ? w[s] : 0ULL;   // selects over all words: an `if` chain is turned back into
-                                                                        // w[p >> 6], and one dynamic index parks the whole Strand in scratch
-    return (x >> (p & 63)) & 1;
-  }
 };
 
-template <int NS> QM_DEV Bits<NS> b_and(const Bits<NS>& a, const Bits<NS>& b) { Bits<NS> r;
-#pragma unroll
-  for (int s = 0; s < NS; ++s) r.w[s] = a.w[s] & b.w[s]; return r; }
-template <int NS> QM_DEV Bits<NS> b_or(const Bits<NS>& a, const Bits<NS>& b) { Bits<NS> r;
-#pragma unroll
-  for (int s = 0; s < NS; ++s) r.w[s] = a.w[s] | b.w[s]; return r; }
-template <int NS> QM_DEV Bits<NS> b_andn(const Bits<NS>& a, const Bits<NS>& b) { Bits<NS> r;
-#pragma unroll
-  for (int s = 0; s < NS; ++s) r.w[s] = a.w[s] & ~b.w[s]; return r; }
-
-// first set bit at position >= p, or 64*NS
-template <int NS> QM_DEV int first_set_from(const Bits<NS>& b, int p) {
-  int res = 64 * NS;
-#pragma unroll
-  for (int s = NS - 1; s >= 0; --s) {
-    u64 x = b.w[s];
-    int ws = p >> 6;
-    if (s < ws) x = 0;
-    else if (s == ws) x &= (~0ULL << (p & 63));
-    if (x) res = 64 * s + ctz64(x);
-  }
-  return res;
-}
-// number of set bits in [a, b)
-template <int NS> QM_DEV int popc_range(const Bits<NS>& b, int a, int e) {
-  int c = 0;
-  if (e <= a) return 0;
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    int lo = a - 64 * s, hi = e - 64 * s;
-    if (hi <= 0 || lo >= 64) continue;
-    u64 m = ~0ULL;
-    if (lo > 0) m &= (~0ULL << lo);
-    if (hi < 64) m &= lanemask_lt(hi);
-    c += popc64(b.w[s] & m);
-  }
-  return c;
-}
 // out bit q = in bit (P-1-q), q < P
 template <int NS> QM_DEV Bits<NS> mirror(const Bits<NS>& in, int P) {
   u64 rev[2 * NS + 1];
@@ -453,36 +410,84 @@ QM_DEV bool find_kmer(const DevIndex& ix, u64 key, int& lb, int& ub) {
 }
 
 // ------------------------------------------------------------------ stage 1+2
-// Bits helpers for lazily filled bitmaps
-template <int NS> QM_DEV void or_field(Bits<NS>& b, int p, u64 v) {   // b |= v << p  (v has <= 32 significant bits)
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    // selects, not branches: p is wave-uniform and this runs on the scalar unit after every probe
-    const int sh = p - 64 * s;
-    const u64 l = v << (sh & 63), r = v >> ((-sh) & 63);
-    const u64 x = (sh >= 0) ? l : r;
-    b.w[s] |= (sh > -64 && sh < 64) ? x : 0ULL;
-  }
-}
-
 // One strand of one read.  E/E2 depend on the characters only and are built once; F/C/K are filled
 // window by window: the reference consults the hash only at the positions its MMP walk visits
 // (~47 finds per read instead of the 2(L-k+1) of an exhaustive pre-probe), and every probe is a random
 // 64-byte sector from HBM -- the resource this kernel is bound by (profiles/).
+//
+// The six per-position flags live in ONE vector register: lane l holds, for each word s < NS, the flags of position
+// 64 s + l (bit f * NS + s = flag f).  Round 1 kept them as six NS x 64-bit bitmaps in SGPRs: every test, shift-in and
+// find-first was scalar code, 24+ SGPRs were live through the whole walk (151 of them spilled), and the scalar unit --
+// one per CU, shared by the four SIMDs -- was what the kernel ran out of first (profiles/r02_stage_a_ablation.txt).
+// Here a probe leaves its result in the lane that owns the position, a find-first is a compare + ballot, and the walk's
+// state is a register per strand.
+enum { FL_E = 0,    // eligible in getSAHits_: no N in [p,p+k), not a homopolymer (SACollector.hpp:498-536)
+       FL_E2 = 1,   // eligible in the first-hit scan: no N in [p,p+k] (:176-192, note the <=)
+       FL_K = 2,    // the F / C flags of the position are known
+       FL_F = 3,    // khash.find(mer) hit
+       FL_C = 4,    // khash.find(mer.getRC()) hit
+       FL_V = 5 };  // the position produced a KmerDirScore entry (only used by the --noSensitive vote)
+template <bool WIDE> struct FlagWord { typedef u32 type; };
+template <> struct FlagWord<true> { typedef u64 type; };
 template <int NS>
 struct Strand {
-  Bits<NS> E;    // eligible in getSAHits_: no N in [p,p+k), not a homopolymer (SACollector.hpp:498-536)
-  Bits<NS> E2;   // eligible in the first-hit scan: no N in [p,p+k] (:176-192, note the <=)
-  Bits<NS> K;    // positions whose F / C bits are known
-  Bits<NS> F;    // khash.find(mer) hit
-  Bits<NS> C;    // khash.find(mer.getRC()) hit
-  Bits<NS> V;    // positions that produced a KmerDirScore entry (only used by the --noSensitive vote)
+  typedef typename FlagWord<(6 * NS > 32)>::type FT;
+  LV<FT> fl;
+  static QM_DEV FT bit(int f, int s) { return (FT)1 << (f * NS + s); }
+  // flag word of the lane that owns position p (wave-uniform), and one flag of it
+  QM_DEV FT word_at(int p) const { return read_lane(fl, p & 63); }
+  static QM_DEV bool flag(FT w, int f, int p) { return (unsigned)p < 64u * NS && ((w >> (f * NS + (p >> 6))) & 1) != 0; }
+  QM_DEV bool test(int f, int p) const { return flag(word_at(p), f, p); }
+  // fl |= m << (p >> 6) in the lane that owns p; m holds flags of word 0
+  QM_DEV void or_at(int p, FT m) {
+    if ((unsigned)p >= 64u * NS) return;
+    const FT mm = m << (p >> 6);
+    QM_LANES(l) { fl[l] |= (l == (p & 63)) ? mm : (FT)0; }
+  }
   const u64* planes;   // LDS: [4][NS+2]
   Iv* tab;             // LDS: interval of mer at position p (valid where F)
   bool dollar;         // the strand's string contains '$' (extensions then take the literal binary searches)
   bool lazy;           // pure-ACGT read without a long run: tab holds no k-mer words, a probe shifts its word out of the image
   int P;
 };
+
+// first position >= p whose flags satisfy pred(word, s) (64 NS: none)
+template <int NS, typename Pred>
+QM_DEV int fl_first(const Strand<NS>& S, int p, Pred pred) {
+  int res = 64 * NS;
+#pragma unroll
+  for (int s = NS - 1; s >= 0; --s) {
+    LV<bool> pr;
+    QM_LANES(l) { pr[l] = pred(S.fl[l], s) && 64 * s + l >= p; }
+    const u64 m = ballot(pr);
+    if (m) res = 64 * s + ctz64(m);
+  }
+  return res;
+}
+// number of positions in [a, e) whose flags satisfy pred
+template <int NS, typename Pred>
+QM_DEV int fl_count(const Strand<NS>& S, int a, int e, Pred pred) {
+  int c = 0;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    LV<bool> pr;
+    QM_LANES(l) { const int q = 64 * s + l; pr[l] = pred(S.fl[l], s) && q >= a && q < e; }
+    c += popc64(ballot(pr));
+  }
+  return c;
+}
+// one flag as a bitmap over the positions (the --noSensitive vote works on those)
+template <int NS>
+QM_DEV Bits<NS> fl_bits(const Strand<NS>& S, int f) {
+  Bits<NS> r;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    LV<bool> pr;
+    QM_LANES(l) { pr[l] = ((S.fl[l] >> (f * NS + s)) & 1) != 0; }
+    r.w[s] = ballot(pr);
+  }
+  return r;
+}
 
 // ---- four characters at a time (one dword per lane) ----
 // 0x80 in every byte of x that equals c (exact zero-byte test of x ^ cccc)
@@ -603,53 +608,47 @@ QM_DEV void setup_strand(const DevIndex& ix, const unsigned char* str, int L, St
     // nearly every read: nothing but A C G T and no homopolymer window (k equal characters cover at least (k - 6) / 4 whole
     // lanes of the loop above).  Every position with a whole k-mer is eligible and nothing is tabulated: a probe shifts
     // its word out of the packed image when it gets there (clean_kmer), tab only ever receives intervals.
+    QM_LANES(l) {
+      typename Strand<NS>::FT f = 0;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const int r = P - 64 * s;
-      S.E.w[s] = r >= 64 ? ~0ULL : (r <= 0 ? 0ULL : ((1ULL << r) - 1));
-      S.E2.w[s] = S.E.w[s];
-      S.K.w[s] = 0; S.F.w[s] = 0; S.C.w[s] = 0; S.V.w[s] = 0;
+      for (int s = 0; s < NS; ++s) f |= (64 * s + l < P) ? (Strand<NS>::bit(FL_E, s) | Strand<NS>::bit(FL_E2, s)) : 0;
+      S.fl[l] = f;
     }
     S.lazy = true;
     QM_T(1);
     return;
   }
+  QM_LANES(l) { S.fl[l] = 0; }
   if (!dirty) {
     // pure A C G T with a long run: no window holds an N or a partial word -- the k-mer at p is one funnel shift of two
     // packed words and the only thing to test is the homopolymer rule
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      LV<bool> e;
       QM_LANES(l) {
         const int p = 64 * s + l;
         const int j = p >> 5, sh = 2 * (p & 31);
         const u64 w = ((planes[j] << sh) | ((planes[j + 1] >> 1) >> (63 - sh))) >> (64 - 2 * k);
         const bool inP = p < P;
-        e[l] = inP && !homopolymer(w, k);
+        if (inP && !homopolymer(w, k)) S.fl[l] |= Strand<NS>::bit(FL_E, s) | Strand<NS>::bit(FL_E2, s);
         if (inP) ((u64*)tab)[p] = w;
       }
-      S.E.w[s] = ballot(e); S.E2.w[s] = S.E.w[s];
-      S.K.w[s] = 0; S.F.w[s] = 0; S.C.w[s] = 0; S.V.w[s] = 0;
     }
     QM_T(1);
     return;
   }
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    LV<bool> e, e2;
     QM_LANES(l) {
       int p = 64 * s + l;
       bool nwin, nwin2; int d;
       u64 w = kmer_at<NS>(planes, p, k, nwin, nwin2, d);
       bool hom = homopolymer(w, k);
       bool inP = p < P;
-      e[l] = inP && !nwin && !hom;
-      e2[l] = inP && !nwin2 && !hom;
+      if (inP && !nwin && !hom) S.fl[l] |= Strand<NS>::bit(FL_E, s);
+      if (inP && !nwin2 && !hom) S.fl[l] |= Strand<NS>::bit(FL_E2, s);
       // the k-mer word waits in the position's interval slot until the position is probed (~0: an N in the window)
       if (inP) ((u64*)tab)[p] = nwin ? ~0ULL : w;
     }
-    S.E.w[s] = ballot(e); S.E2.w[s] = ballot(e2);
-    S.K.w[s] = 0; S.F.w[s] = 0; S.C.w[s] = 0; S.V.w[s] = 0;
   }
   QM_T(1);
 }
@@ -664,52 +663,54 @@ QM_DEV bool all_acgt(const Strand<NS>& S, int p, int k) {
   return (ivw & ((1ULL << k) - 1)) == 0;
 }
 
-// Probe positions [p, p+width) (width <= 32): lanes 0..31 look up the k-mer, lanes 32..63 its reverse
-// complement -- khash.find (RapMapUtils.hpp:65-67) -- one round of independent loads.
+// Probe positions [p, p+width) (width <= 32), k-mer and reverse complement -- khash.find (RapMapUtils.hpp:65-67) -- in one
+// round of independent loads.  Lane t takes the position whose flags it owns, or whose flags its partner t ^ 32 owns:
+//   d = (t - p) & 63:   d < 32: the k-mer of position p + d (that position lives in lane t);
+//                       d >= 32: the reverse complement of the k-mer of position p + d - 32 (which lives in lane t ^ 32)
+// so a result is where it is kept, or one lane swap away from it.
 template <int NS, int F>
 QM_DEV void probe_window(const DevIndex& ix, Strand<NS>& S, int p, int width) {
+  typedef typename Strand<NS>::FT FT;
   const int k = ix.k;
   if (p + width > S.P) width = S.P - p;
   if (width <= 0) return;
   QM_CNT(3, 1); QM_CNT(4, width); QM_T(4);
-  LV<bool> found; LV<u64> keyv;
-  // every lane fetches its word before any lane replaces one by an interval
-  if (S.lazy) { QM_LANES(l) { const int j = l & 31; keyv[l] = j < width ? clean_kmer(S.planes, p + j, k) : ~0ULL; } }
-  else { QM_LANES(l) { const int j = l & 31; keyv[l] = j < width ? ((const u64*)S.tab)[p + j] : ~0ULL; } }
-  if (!(F & QM_F_PH)) {
-    LV<u64> kq; LV<bool> want, fresh; LV<Iv> val;
-    QM_LANES(l) {
-      const int j = l & 31;
-      const u64 key = keyv[l], rc = word_rc(key, k);
-      // positions probed before keep their bits and their interval (the slot no longer holds the word)
-      fresh[l] = j < width && !S.K.test(p + j);
-      want[l] = fresh[l] && key != ~0ULL;
-      kq[l] = l >= 32 ? rc : key;
-    }
-    find_dense_round(ix, kq, want, found, val);
-    QM_LANES(l) { if (fresh[l] && l < 32) S.tab[p + l] = val[l]; }
-  } else
+  LV<FT> flx;
+  swap32(S.fl, flx);
+  LV<bool> found, fresh, want; LV<u64> kq; LV<int> posv; LV<Iv> val;
   QM_LANES(l) {
-    int j = l & 31;
-    bool isC = l >= 32;
-    int pos = p + j;
-    bool hit = false; Iv v = {0, 0};
-    // positions probed before keep their bits and their interval (the slot no longer holds the word)
-    if (j < width && !S.K.test(pos)) {
-      u64 key = keyv[l];
-      if (key != ~0ULL) {
-        if (isC) key = word_rc(key, k);
-        hit = find_kmer<F>(ix, key, v.lb, v.ub);
-      }
-      if (!isC) S.tab[pos] = v;
-    }
-    found[l] = hit;
+    const int d = (l - p) & 63, j = d & 31;
+    const bool in = j < width;
+    const int q = in ? p + j : p;
+    const FT w = d >= 32 ? flx[l] : S.fl[l];
+    // positions probed before keep their flags and their interval (the slot no longer holds the word)
+    fresh[l] = in && ((w >> (FL_K * NS + (q >> 6))) & 1) == 0;
+    posv[l] = q;
+    // every lane fetches its word before any lane replaces one by an interval
+    const u64 w0 = S.lazy ? clean_kmer(S.planes, q, k) : ((const u64*)S.tab)[q];
+    const u64 rc = word_rc(w0, k);
+    want[l] = fresh[l] && w0 != ~0ULL;                     // ~0: an N in the window
+    kq[l] = d >= 32 ? rc : w0;
   }
-  u64 fm = ballot(found);
-  u64 wm = width >= 32 ? 0xffffffffULL : ((1ULL << width) - 1);
-  or_field(S.F, p, fm & wm);
-  or_field(S.C, p, (fm >> 32) & wm);
-  or_field(S.K, p, wm);
+  wave_fence();
+  if (!(F & QM_F_PH)) find_dense_round(ix, kq, want, found, val);
+  else {
+    QM_LANES(l) {
+      bool hit = false; Iv v = {0, 0};
+      if (want[l]) hit = find_kmer<F>(ix, kq[l], v.lb, v.ub);
+      found[l] = hit; val[l] = v;
+    }
+  }
+  LV<u32> fo, fx;
+  QM_LANES(l) { fo[l] = found[l] ? 1u : 0u; }
+  swap32(fo, fx);                                          // the partner's result: the same position's reverse complement
+  QM_LANES(l) {
+    if (fresh[l] && ((l - p) & 63) < 32) {
+      const int s = posv[l] >> 6;
+      S.fl[l] |= Strand<NS>::bit(FL_K, s) | (found[l] ? Strand<NS>::bit(FL_F, s) : (FT)0) | (fx[l] ? Strand<NS>::bit(FL_C, s) : (FT)0);
+      S.tab[posv[l]] = val[l];
+    }
+  }
   wave_fence();
   QM_T(2);
 }
@@ -720,53 +721,40 @@ QM_DEV void probe_window(const DevIndex& ix, Strand<NS>& S, int p, int width) {
 // its interval goes to rtab0 (= that strand's tab[0]).  Returns true when position P-1 was looked up here.
 template <int NS, int F>
 QM_DEV bool probe_first(const DevIndex& ix, Strand<NS>& S, int p, Iv* rtab0) {
+  typedef typename Strand<NS>::FT FT;
   const int k = ix.k;
   const int last = S.P - 1;
   QM_CNT(3, 1); QM_CNT(4, last != p ? 2 : 1); QM_T(4);
-  LV<bool> found; LV<u64> keyv;
-  if (S.lazy) { QM_LANES(l) { const int j = l & 31; keyv[l] = j < 2 ? clean_kmer(S.planes, j == 0 ? p : last, k) : ~0ULL; } }
-  else { QM_LANES(l) { const int j = l & 31; keyv[l] = j < 2 ? ((const u64*)S.tab)[j == 0 ? p : last] : ~0ULL; } }
-  if (!(F & QM_F_PH)) {
-    LV<u64> kq; LV<bool> want, on; LV<Iv> val;
-    QM_LANES(l) {
-      const int j = l & 31;
-      const u64 key = keyv[l], rc = word_rc(key, k);
-      on[l] = j == 0 || (j == 1 && last != p);
-      want[l] = on[l] && key != ~0ULL;
-      kq[l] = l >= 32 ? rc : key;
-    }
-    find_dense_round(ix, kq, want, found, val);
-    QM_LANES(l) {
-      if (on[l]) {
-        const int pos = (l & 31) == 0 ? p : last;
-        if (l < 32) S.tab[pos] = val[l];
-        else if (pos == last) *rtab0 = val[l];
-      }
-    }
-  } else
+  LV<bool> found, want, on; LV<u64> kq; LV<Iv> val;
   QM_LANES(l) {
     const int j = l & 31;
-    const bool isC = l >= 32;
-    const int pos = j == 0 ? p : last;
-    bool hit = false; Iv v = {0, 0};
-    if (j == 0 || (j == 1 && last != p)) {
-      u64 key = keyv[l];
-      if (key != ~0ULL) {
-        if (isC) key = word_rc(key, k);
-        hit = find_kmer<F>(ix, key, v.lb, v.ub);
-      }
-      if (!isC) S.tab[pos] = v;
-      else if (pos == last) *rtab0 = v;
+    on[l] = j == 0 || (j == 1 && last != p);
+    const int q = j == 0 ? p : last;
+    const u64 key = S.lazy ? clean_kmer(S.planes, q, k) : ((const u64*)S.tab)[q];
+    const u64 rc = word_rc(key, k);
+    want[l] = on[l] && key != ~0ULL;
+    kq[l] = l >= 32 ? rc : key;
+  }
+  wave_fence();
+  if (!(F & QM_F_PH)) find_dense_round(ix, kq, want, found, val);
+  else {
+    QM_LANES(l) {
+      bool hit = false; Iv v = {0, 0};
+      if (want[l]) hit = find_kmer<F>(ix, kq[l], v.lb, v.ub);
+      found[l] = hit; val[l] = v;
     }
-    found[l] = hit;
+  }
+  QM_LANES(l) {
+    if (on[l]) {
+      const int pos = (l & 31) == 0 ? p : last;
+      if (l < 32) S.tab[pos] = val[l];
+      else if (pos == last) *rtab0 = val[l];
+    }
   }
   const u64 fm = ballot(found);
-  or_field(S.F, p, fm & 1); or_field(S.C, p, (fm >> 32) & 1); or_field(S.K, p, 1ULL);
-  if (last != p) {
-    if ((fm >> 1) & 1) set_bit(S.F, last);
-    if ((fm >> 33) & 1) set_bit(S.C, last);
-    set_bit(S.K, last);
-  }
+  S.or_at(p, Strand<NS>::bit(FL_K, 0) | ((fm & 1) ? Strand<NS>::bit(FL_F, 0) : (FT)0) | (((fm >> 32) & 1) ? Strand<NS>::bit(FL_C, 0) : (FT)0));
+  if (last != p)
+    S.or_at(last, Strand<NS>::bit(FL_K, 0) | (((fm >> 1) & 1) ? Strand<NS>::bit(FL_F, 0) : (FT)0) | (((fm >> 33) & 1) ? Strand<NS>::bit(FL_C, 0) : (FT)0));
   wave_fence();
   QM_T(2);
   return true;
@@ -774,10 +762,7 @@ QM_DEV bool probe_first(const DevIndex& ix, Strand<NS>& S, int p, Iv* rtab0) {
 
 // first position >= p that is NOT yet probed (or 64*NS)
 template <int NS> QM_DEV int known_end(const Strand<NS>& S, int p) {
-  Bits<NS> nk;
-#pragma unroll
-  for (int s = 0; s < NS; ++s) nk.w[s] = ~S.K.w[s];
-  return first_set_from(nk, p);
+  return fl_first(S, p, [](typename Strand<NS>::FT w, int s) { return ((w >> (FL_K * NS + s)) & 1) == 0; });
 }
 
 // SA-interval hits of one strand: the first QM_ICAP in LDS, the rest in the wave's global scratch
@@ -976,19 +961,6 @@ QM_DEV int lce_wave(const DevIndex& ix, int p1, int p2, int startAt, int stopAt)
     base += 64;
   }
 }
-// set bits [a, e) of b
-template <int NS> QM_DEV void set_range_and(Bits<NS>& dst, const Bits<NS>& src, int a, int e) {
-  if (e <= a) return;
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    int lo = a - 64 * s, hi = e - 64 * s;
-    if (hi <= 0 || lo >= 64) continue;
-    u64 m = ~0ULL;
-    if (lo > 0) m &= (~0ULL << lo);
-    if (hi < 64) m &= lanemask_lt(hi);
-    dst.w[s] |= src.w[s] & m;
-  }
-}
 template <int NS> QM_DEV void set_bit(Bits<NS>& b, int p) {
 #pragma unroll
   for (int s = 0; s < NS; ++s) b.w[s] |= (s == (p >> 6)) ? (1ULL << (p & 63)) : 0ULL;   // every word written: see Bits::test
@@ -1009,18 +981,27 @@ QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, c
   while (true) {
     if (!skip) {
       if (p >= P) break;
-      if (!V.K.test(p)) { probe_window<NS, F>(ix, V, p, width); width = 32; }
+      typedef typename Strand<NS>::FT FT;
+      if (!V.test(FL_K, p)) { probe_window<NS, F>(ix, V, p, width); width = 32; }
       int kend = known_end(V, p);
       if (kend > P) kend = P;
-      Bits<NS> hitm = b_and(V.E, V.F);
-      int ph = first_set_from(hitm, p);
+      const int ph = fl_first(V, p, [](FT w, int s) { return ((w >> (FL_E * NS + s)) & (w >> (FL_F * NS + s)) & 1) != 0; });
       int stop = ph < kend ? ph : kend;
-      Bits<NS> missC = b_and(b_andn(V.E, V.F), V.C);
-      otherHits += (u32)popc_range(missC, p, stop);   // misses: spotCheck_ of the complement (:667-675)
-      if (((F & QM_F_NIP) != 0)) set_range_and(V.V, V.E, p, ph < kend ? ph + 1 : stop);   // spotCheck_ entries (vote)
+      // misses: spotCheck_ of the complement (:667-675)
+      otherHits += (u32)fl_count(V, p, stop, [](FT w, int s) { return ((w >> (FL_E * NS + s)) & ~(w >> (FL_F * NS + s)) & (w >> (FL_C * NS + s)) & 1) != 0; });
+      if (((F & QM_F_NIP) != 0)) {                     // spotCheck_ entries (vote): V |= E over [p, e)
+        const int e = ph < kend ? ph + 1 : stop;
+        QM_LANES(l) {
+#pragma unroll
+          for (int s2 = 0; s2 < NS; ++s2) {
+            const int q = 64 * s2 + l;
+            if (q >= p && q < e && ((V.fl[l] >> (FL_E * NS + s2)) & 1)) V.fl[l] |= Strand<NS>::bit(FL_V, s2);
+          }
+        }
+      }
       if (ph >= kend) { p = kend; width = 32; continue; }   // nothing in the probed stretch: next window (or the end)
       strandHits += 1;                                 // spotCheck_ on the hit (:545)
-      otherHits += V.C.test(ph) ? 1u : 0u;
+      otherHits += V.test(FL_C, ph) ? 1u : 0u;
       p = ph;
       Iv v = V.tab[p];
       lb = uniform(v.lb); ub = uniform(v.ub);
@@ -1058,9 +1039,10 @@ QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, c
       prevMMPEnd = p + mlen;
       if (p + mlen < L) {
         if (all_acgt(V, kp, k)) {
-          if (!V.K.test(kp)) probe_window<NS, F>(ix, V, kp, (more && !(F & QM_F_NIP)) ? 32 : 1);
-          strandHits += V.F.test(kp) ? 1u : 0u; otherHits += V.C.test(kp) ? 1u : 0u;
-          if (((F & QM_F_NIP) != 0)) set_bit(V.V, kp);
+          if (!V.test(FL_K, kp)) probe_window<NS, F>(ix, V, kp, (more && !(F & QM_F_NIP)) ? 32 : 1);
+          const typename Strand<NS>::FT wk = V.word_at(kp);
+          strandHits += Strand<NS>::flag(wk, FL_F, kp) ? 1u : 0u; otherHits += Strand<NS>::flag(wk, FL_C, kp) ? 1u : 0u;
+          if (((F & QM_F_NIP) != 0)) V.or_at(kp, Strand<NS>::bit(FL_V, 0));
         }
       }
     }
@@ -1119,34 +1101,37 @@ QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M,
   setup_strand<NS>(ix, fwdStr, L, S, &M.planes[0][0][0], M.tab[0]);
   S.dollar = hasDollar;
   // first-hit scan (:167-237): first E2 position whose k-mer or reverse complement is in the hash
-  int p0 = first_set_from(S.E2, 0);
+  typedef typename Strand<NS>::FT FT;
+  auto isE2 = [](FT w, int s) { return ((w >> (FL_E2 * NS + s)) & 1) != 0; };
+  int p0 = fl_first(S, 0, isE2);
   int width = 1;
   bool found = false;
   bool seedR = false;                                  // the rc strand's first k-mer was looked up with the first probe
   while (p0 < P) {
-    if (!S.K.test(p0)) {
+    if (!S.test(FL_K, p0)) {
       if (width == 1) seedR = probe_first<NS, F>(ix, S, p0, &M.tab[1][0]);
       else probe_window<NS, F>(ix, S, p0, width);
       width = 32;
     }
     int kend = known_end(S, p0);
     if (kend > P) kend = P;
-    Bits<NS> cand = b_and(S.E2, b_or(S.F, S.C));
-    int ph = first_set_from(cand, p0);
+    int ph = fl_first(S, p0, [](FT w, int s) { return ((w >> (FL_E2 * NS + s)) & ((w >> (FL_F * NS + s)) | (w >> (FL_C * NS + s))) & 1) != 0; });
     if (ph < kend) { p0 = ph; found = true; break; }
-    p0 = first_set_from(S.E2, kend);
+    p0 = fl_first(S, kend, isE2);
   }
   if (!found) return false;
-  u32 fwdHit = S.F.test(p0) ? 1u : 0u;
-  u32 rcHit = S.C.test(p0) ? 1u : 0u;
+  const FT w0 = S.word_at(p0);
+  u32 fwdHit = Strand<NS>::flag(w0, FL_F, p0) ? 1u : 0u;
+  u32 rcHit = Strand<NS>::flag(w0, FL_C, p0) ? 1u : 0u;
   // what the first probe learned about the last k-mer, as seen from the reverse-complemented read (only when the
   // window is pure ACGT: reverseRead() and the 2-bit reverse complement agree there)
   seedR = seedR && all_acgt(S, P - 1, k);
-  const bool seedRF = seedR && S.C.test(P - 1), seedRC = seedR && S.F.test(P - 1);
+  const FT wl = S.word_at(P - 1);
+  const bool seedRF = seedR && Strand<NS>::flag(wl, FL_C, P - 1), seedRC = seedR && Strand<NS>::flag(wl, FL_F, P - 1);
   long long fwdCov = 0, rcCov = 0;
   const bool useCoverageCheck = ((F & QM_F_NIP) == 0) && B.strict_check != 0;   // disableNIP_ && strictCheck_ (:138)
   const bool vote = !useCoverageCheck && B.strict_check != 0;
-  if (vote) set_bit(S.V, p0);                          // the scan's own KmerDirScore entry (:206-225)
+  if (vote) S.or_at(p0, Strand<NS>::bit(FL_V, 0));     // the scan's own KmerDirScore entry (:206-225)
 
   bool didCheckFwd = false;
   if (fwdHit) {                                         // :247-254
@@ -1168,7 +1153,7 @@ QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M,
     setup_strand<NS>(ix, rcStr, L, R, &M.planes[1][0][0], M.tab[1]);
     R.dollar = false;                                   // reverseRead() maps '$' to 'N'
     if (seedR) {
-      R.K.w[0] |= 1ULL; if (seedRF) R.F.w[0] |= 1ULL; if (seedRC) R.C.w[0] |= 1ULL;
+      R.or_at(0, Strand<NS>::bit(FL_K, 0) | (seedRF ? Strand<NS>::bit(FL_F, 0) : (FT)0) | (seedRC ? Strand<NS>::bit(FL_C, 0) : (FT)0));
       QM_LANES(l) { if (l == 0) M.tab[1][0] = seed0[l]; }
       wave_fence();
     }
@@ -1204,18 +1189,19 @@ QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M,
       Bits<NS> VRm, FRm, CRm;                           // rc-strand masks mirrored to forward positions
 #pragma unroll
       for (int s2 = 0; s2 < NS; ++s2) { VRm.w[s2] = 0; FRm.w[s2] = 0; CRm.w[s2] = 0; }
-      if (haveR) { VRm = mirror(R.V, P); FRm = mirror(R.C, P); CRm = mirror(R.F, P); }
+      if (haveR) { VRm = mirror(fl_bits(R, FL_V), P); FRm = mirror(fl_bits(R, FL_C), P); CRm = mirror(fl_bits(R, FL_F), P); }
+      const Bits<NS> SV = fl_bits(S, FL_V), SF = fl_bits(S, FL_F), SC = fl_bits(S, FL_C);
       Bits<NS> first;                                   // forward entries that precede the rc pass
 #pragma unroll
-      for (int s2 = 0; s2 < NS; ++s2) first.w[s2] = fwdFirst ? S.V.w[s2] : 0;
+      for (int s2 = 0; s2 < NS; ++s2) first.w[s2] = fwdFirst ? SV.w[s2] : 0;
       set_bit(first, p0);
 #pragma unroll
       for (int s2 = 0; s2 < NS; ++s2) {
         u64 a1 = first.w[s2];                           // forward entries, first in time
         u64 a2 = VRm.w[s2] & ~a1;                       // rc entries
-        u64 a3 = S.V.w[s2] & ~a1 & ~a2;                 // forward entries of the late pass
-        u64 ff = (S.F.w[s2] & (a1 | a3)) | (FRm.w[s2] & a2);
-        u64 cc = (S.C.w[s2] & (a1 | a3)) | (CRm.w[s2] & a2);
+        u64 a3 = SV.w[s2] & ~a1 & ~a2;                  // forward entries of the late pass
+        u64 ff = (SF.w[s2] & (a1 | a3)) | (FRm.w[s2] & a2);
+        u64 cc = (SC.w[s2] & (a1 | a3)) | (CRm.w[s2] & a2);
         u64 all = a1 | a2 | a3;
         fwdScore += 2 * popc64(ff & all) - popc64(all);
         rcScore += 2 * popc64(cc & all) - popc64(all);

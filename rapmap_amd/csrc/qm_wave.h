@@ -118,6 +118,8 @@ QM_DEV u32 perm8(u32 hi, u32 lo, u32 sel) {
 }
 // out[l] = in[l ^ 1]: every lane reads its neighbour within a pair
 QM_DEV void lane_xor1(const LV<u32>& in, LV<u32>& out) { for (int l = 0; l < 64; ++l) out.v[l] = in.v[l ^ 1]; }
+// out[l] = in[l ^ 32]: the two halves of the wavefront trade places
+template <typename T> QM_DEV void swap32(const LV<T>& in, LV<T>& out) { for (int l = 0; l < 64; ++l) out.v[l] = in.v[l ^ 32]; }
 // v_alignbyte_b32: the eight bytes {hi, lo} shifted right by `shift` (0..3) bytes, low dword
 QM_DEV u32 align_bytes(u32 hi, u32 lo, int shift) { return (u32)((((u64)hi << 32) | lo) >> (8 * shift)); }
 struct U4 { u32 x, y, z, w; };
@@ -154,6 +156,11 @@ QM_DEV u32 load_u32_unaligned(const unsigned char* p) { u32 v; __builtin_memcpy(
 QM_DEV u32 perm8(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }     // v_perm_b32
 QM_DEV void lane_xor1(const LV<u32>& in, LV<u32>& out) {                                     // DPP quad_perm:[1,0,3,2]
   out.v[0] = (u32)__builtin_amdgcn_update_dpp(0, (int)in.v[0], 0xB1, 0xf, 0xf, false);
+}
+QM_DEV void swap32(const LV<u32>& in, LV<u32>& out) { out.v[0] = (u32)__shfl_xor((int)in.v[0], 32, 64); }
+QM_DEV void swap32(const LV<u64>& in, LV<u64>& out) {
+  const u32 lo = (u32)__shfl_xor((int)(u32)in.v[0], 32, 64), hi = (u32)__shfl_xor((int)(u32)(in.v[0] >> 32), 32, 64);
+  out.v[0] = ((u64)hi << 32) | lo;
 }
 QM_DEV u32 align_bytes(u32 hi, u32 lo, int shift) { return __builtin_amdgcn_alignbyte(hi, lo, (u32)shift); }
 // wave-uniform 8-byte load on the scalar unit (s_load): read-only data, uniform address
