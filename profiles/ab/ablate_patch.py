@@ -15,8 +15,8 @@ ins("  IntervalList fi, ri;\n  fi.lds = M.ints[0]; ri.lds = M.ints[1];",
     "#if defined(QM_ABLATE) && QM_ABLATE == 1\n  lds_dma_wait(); QM_LANES(l) { if (l == 0) { B.lcnt[read] = 0; B.loff[read] = 0; } } return;\n#endif")
 ins("  setup_strand<NS>(ix, fwdStr, L, S, &M.planes[0][0][0], M.tab[0]);\n  S.dollar = hasDollar;",
     "#if defined(QM_ABLATE) && QM_ABLATE == 2\n  return S.P == 12345;\n#endif")
-ins("  if (!found) return false;\n  u32 fwdHit = S.F.test(p0) ? 1u : 0u;",
-    "#if defined(QM_ABLATE) && QM_ABLATE == 3\n  return fwdHit != 0;\n#endif")
+ins("  if (!found) return false;\n  const FT w0 = S.word_at(p0);",
+    "#if defined(QM_ABLATE) && QM_ABLATE == 3\n  return w0 == 12345;\n#endif")
 ins("  bool checkRC = useCoverageCheck ? (rcHit > 0) : (rcHit >= fwdHit);",
     "#if defined(QM_ABLATE) && QM_ABLATE == 4\n  return true;\n#endif")
 ins("  if (F & QM_F_COLLECT) return;          // stage entry",
