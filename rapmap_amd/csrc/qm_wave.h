@@ -135,19 +135,34 @@ template <int N> QM_DEV void load_8_16xN(const u64* const* B, const int* bit, u6
   for (int t = 0; t < N; ++t) load_8_16(B[t] + (bit[t] >> 6), B[t] + 6, word[t], meta[t]);
 }
 #else
+// DPP reductions (profiles/microbench/dpp_check.hip: row_shr:n gives lane i the value of lane i - n of its row of 16;
+// a lane without a source keeps `old`).  A step is one VALU instruction and no trip through the LDS crossbar --
+// __shfl_xor is a ds_bpermute with an address computation and a wait each.
+template <int CTRL, int ROWMASK> QM_DEV int dpp_get(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROWMASK, 0xf, false); }
 QM_DEV int wave_max(const LV<int>& x) {
-  int v = x.v[0];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
-  return __builtin_amdgcn_readfirstlane(v);
+  int v = x.v[0], t;
+  t = dpp_get<0x111, 0xf>(v); v = t > v ? t : v;           // row_shr:1, 2, 4, 8: lane 15 of every row holds the row's maximum
+  t = dpp_get<0x112, 0xf>(v); v = t > v ? t : v;
+  t = dpp_get<0x114, 0xf>(v); v = t > v ? t : v;
+  t = dpp_get<0x118, 0xf>(v); v = t > v ? t : v;
+  t = dpp_get<0x142, 0xa>(v); v = t > v ? t : v;           // row_bcast:15 into rows 1 and 3
+  t = dpp_get<0x143, 0xc>(v); v = t > v ? t : v;           // row_bcast:31 into rows 2 and 3: lane 63 has it all
+  return __builtin_amdgcn_readlane(v, 63);
 }
 // DPP wave_ror:1 -- one VALU instruction, no trip through the LDS crossbar
 QM_DEV void lane_rotate_up(const LV<int>& in, LV<int>& out) { out.v[0] = __builtin_amdgcn_update_dpp(0, in.v[0], 0x13C, 0xf, 0xf, false); }
 // DPP row_ror:1
 QM_DEV void row_rotate_up(const LV<int>& in, LV<int>& out) { out.v[0] = __builtin_amdgcn_update_dpp(0, in.v[0], 0x121, 0xf, 0xf, false); }
+// butterfly inside a row of 16 with DPP pairings: lanes ^1, lanes ^2 (quad permutes), then the mirror image within 8 and
+// within 16 -- once the quads are uniform any pairing of the two halves does; across rows the crossbar
 QM_DEV void group_min(LV<int>& x, int G) {
-  int v = x.v[0];
-  for (int o = 1; o < G; o <<= 1) { int t = __shfl_xor(v, o, 64); v = t < v ? t : v; }
+  int v = x.v[0], t;
+  if (G > 1) { t = dpp_get<0xB1, 0xf>(v); v = t < v ? t : v; }         // quad_perm:[1,0,3,2]
+  if (G > 2) { t = dpp_get<0x4E, 0xf>(v); v = t < v ? t : v; }         // quad_perm:[2,3,0,1]
+  if (G > 4) { t = dpp_get<0x141, 0xf>(v); v = t < v ? t : v; }        // row_half_mirror
+  if (G > 8) { t = dpp_get<0x140, 0xf>(v); v = t < v ? t : v; }        // row_mirror
+  if (G > 16) { t = __shfl_xor(v, 16, 64); v = t < v ? t : v; }
+  if (G > 32) { t = __shfl_xor(v, 32, 64); v = t < v ? t : v; }
   x.v[0] = v;
 }
 QM_DEV int clz64(u64 x) { return x ? __builtin_clzll(x) : 64; }
