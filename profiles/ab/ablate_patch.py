@@ -2,7 +2,7 @@
 """profiles/ab/ablate_patch.py <csrc dir>: early returns at phase boundaries of stage A, selected by -DQM_ABLATE=n, so that the
 per-phase instruction counts can be read off PMC deltas between variants (there is no PC sampling / thread trace on the box):
   1 read staged, upper-cased (no collector)      2 + forward strand set up      3 + first-hit scan
-  4 + forward get_sa_hits                         5 whole collector, no hits->mappings / write-out      (unset: everything)
+  4 + forward get_sa_hits                         5 whole collector, no hits->mappings / write-out      6 + hits->mappings, empty list written      (unset: everything)
 Results are wrong by construction; only the counters of these builds mean anything."""
 import sys
 p = sys.argv[1] + "/qm_mapper.inl"
@@ -21,4 +21,6 @@ ins("  bool checkRC = useCoverageCheck ? (rcHit > 0) : (rcHit >= fwdHit);",
     "#if defined(QM_ABLATE) && QM_ABLATE == 4\n  return true;\n#endif")
 ins("  if (F & QM_F_COLLECT) return;          // stage entry",
     "#if defined(QM_ABLATE) && QM_ABLATE == 5\n  lds_dma_wait(); QM_LANES(l) { if (l == 0) { B.lcnt[read] = (u32)((fi.n + ri.n) & 0); B.loff[read] = 0; } } return;\n#endif", after=False)
+ins("  if (!(F & QM_F_SEL)) listSrc = bf.R;\n  QM_T(5);",
+    "#if defined(QM_ABLATE) && QM_ABLATE == 6\n  n = 0;\n#endif")
 open(p, "w").write(s)

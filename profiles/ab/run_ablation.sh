@@ -4,7 +4,7 @@
 set -u
 OUT=$1; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for v in abl1 abl2 abl3 abl4 abl5 main; do
+for v in ${QM_ABL_LIST:-abl1 abl2 abl3 abl4 abl5 abl6 main}; do
   if [ "$v" = main ]; then unset QM_LIB_OVERRIDE; else export QM_LIB_OVERRIDE=$GRAFT_REPO_ROOT/rapmap_amd/variants/$v.so; fi
   timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAVES \
     --kernel-trace --output-format csv -d $OUT/$v -o p -- python bench.py --no-cpu-baseline --steps 1 --warmup 0 > $OUT/$v.log 2>&1

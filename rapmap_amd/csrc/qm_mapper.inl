@@ -1293,6 +1293,42 @@ QM_DEV int single_interval(const DevIndex& ix, const Bufs& bf, int rOff, int lb,
     return mk_elem((u32)(v >> 32), isRC, (int)((u32)v ^ 0x80000000u)); });
 }
 
+// collectFromSingleInterval for an interval of at most 64 suffixes, in registers: lane l holds suffix l's (tid, position);
+// a lane's entry survives when no other entry of its transcript sorts before it (position, then input order -- the first
+// element of the transcript's run in the stable sort of :761-767), and goes to the slot given by the number of surviving
+// entries with a smaller transcript id.  No sort buffers, no trips through LDS but the one that delivers the list.
+QM_DEV int single_interval_small(const DevIndex& ix, u64* R, int rOff, int lb, int ub, u32 qpos, bool isRC, const u32* pf, int pfcap) {
+  const int n = ub - lb;
+  QM_CNT(12, 1); QM_CNT(13, n);
+  LV<u64> e;
+  if (pf && n <= pfcap) {                                // staged by get_sa_hits while the walk went on
+    lds_dma_wait();
+    QM_LANES(l) { e[l] = l < n ? (((u64)pf[l] << 32) | ((u32)(pf[pfcap + l] - qpos) ^ 0x80000000u)) : ~0ULL; }
+  } else {
+    QM_LANES(l) {
+      u64 v = ~0ULL;
+      if (l < n) { const SaInfo si = ix.sainfo[lb + l]; v = ((u64)si.tid << 32) | (((u32)si.pos - qpos) ^ 0x80000000u); }
+      e[l] = v;
+    }
+  }
+  LV<bool> keep;
+  QM_LANES(l) { keep[l] = l < n; }
+  for (int j = 0; j < n; ++j) {
+    const u64 kj = read_lane(e, j);
+    QM_LANES(l) { if ((u32)(kj >> 32) == (u32)(e[l] >> 32) && (kj < e[l] || (kj == e[l] && j < l))) keep[l] = false; }
+  }
+  const u64 km = ballot(keep);
+  LV<int> slot;
+  QM_LANES(l) { slot[l] = 0; }
+  for (u64 r = km; r; r &= r - 1) {
+    const u32 tj = (u32)(read_lane(e, ctz64(r)) >> 32);
+    QM_LANES(l) { slot[l] += tj < (u32)(e[l] >> 32) ? 1 : 0; }
+  }
+  QM_LANES(l) { if (keep[l]) R[rOff + slot[l]] = mk_elem((u32)(e[l] >> 32), isRC, (int)((u32)e[l] ^ 0x80000000u)); }
+  wave_fence();
+  return popc64(km);
+}
+
 // intersectSAHits + collectHitsSimpleSA (HitManager.cpp:587-689, :449-493, :308-322),
 // consensusFraction == 1 (maxSlack 0), strictFilter off.
 QM_DEV int multi_interval(const DevIndex& ix, const Bufs& bf, int rOff, const IntervalList& ints, bool isRC) {
@@ -1394,9 +1430,17 @@ QM_DEV int hits_to_mappings(const DevIndex& ix, const Bufs& bf, const IntervalLi
                             const IntervalList& rcInts, bool keepBoth) {
   int nf = 0, nr = 0;
   if (fwdInts.n > 1) nf = multi_interval(ix, bf, 0, fwdInts, false);
-  else if (fwdInts.n == 1) { int lb, ub; u32 ln, qp; fwdInts.get(0, lb, ub, ln, qp); nf = single_interval(ix, bf, 0, lb, ub, qp, false, fwdInts.pf, fwdInts.pfcap); }
+  else if (fwdInts.n == 1) {
+    int lb, ub; u32 ln, qp; fwdInts.get(0, lb, ub, ln, qp);
+    nf = ub - lb <= 64 ? single_interval_small(ix, bf.R, 0, lb, ub, qp, false, fwdInts.pf, fwdInts.pfcap)
+                       : single_interval(ix, bf, 0, lb, ub, qp, false, fwdInts.pf, fwdInts.pfcap);
+  }
   if (rcInts.n > 1) nr = multi_interval(ix, bf, nf, rcInts, true);
-  else if (rcInts.n == 1) { int lb, ub; u32 ln, qp; rcInts.get(0, lb, ub, ln, qp); nr = single_interval(ix, bf, nf, lb, ub, qp, true, rcInts.pf, rcInts.pfcap); }
+  else if (rcInts.n == 1) {
+    int lb, ub; u32 ln, qp; rcInts.get(0, lb, ub, ln, qp);
+    nr = ub - lb <= 64 ? single_interval_small(ix, bf.R, nf, lb, ub, qp, true, rcInts.pf, rcInts.pfcap)
+                       : single_interval(ix, bf, nf, lb, ub, qp, true, rcInts.pf, rcInts.pfcap);
+  }
   if (nf > 0 && nr > 0) {
     // stable merge by tid, fwd first on ties, duplicates collapse to the first (:834-881)
     int n = nf + nr;
