@@ -1574,10 +1574,7 @@ QM_DEV void stage_chars(const ReadBatch& B, long long slot, WaveMem<NS>& M, int 
 template <int NS, int F>
 QM_DEV void finish_read(const DevIndex& ix, const ReadBatch& B, long long read, int len, int mate, bool foundHit, u64 (*buf)[QM_CAP], u64* gscr,
                         WaveAlloc& wa, IntervalList& fi, IntervalList& ri, SelScratch* ss, struct SelScratchLds* sl, SelScratchDyn* dyn) {
-  Bufs bf;
   int bound = list_bound(fi, ri);
-  if (bound <= QM_CAP) { bf.A = buf[0]; bf.B = buf[1]; bf.R = buf[2]; }
-  else { bf.A = gscr; bf.B = gscr + QM_GCAP; bf.R = gscr + 2 * QM_GCAP; }
   int n = 0;
   const u64* listSrc = nullptr;
   if (F & QM_F_SEL) {                  // -s: chaining + multi-position groups (qm_sel.inl)
@@ -1588,10 +1585,18 @@ QM_DEV void finish_read(const DevIndex& ix, const ReadBatch& B, long long read, 
     }
   } else if (bound > QM_GCAP) {        // only reachable with max_interval > 1000
     QM_LANES(l) { if (l == 0) *B.status |= 2; }
-  } else {
+  } else if (bound <= QM_CAP) {
+    // the two homes of the sort buffers are two expansions of the routine: behind one set of pointers that may be LDS or
+    // global every access is a FLAT instruction -- through the vector-memory path even when it lands in LDS (it was a third
+    // of this phase's time)
+    Bufs bf; bf.A = buf[0]; bf.B = buf[1]; bf.R = buf[2];
     n = hits_to_mappings(ix, bf, fi, ri, B.fuzzy != 0);
+    listSrc = bf.R;
+  } else {
+    Bufs bf; bf.A = gscr; bf.B = gscr + QM_GCAP; bf.R = gscr + 2 * QM_GCAP;
+    n = hits_to_mappings(ix, bf, fi, ri, B.fuzzy != 0);
+    listSrc = bf.R;
   }
-  if (!(F & QM_F_SEL)) listSrc = bf.R;
   QM_T(5);
   // Everything this wave has in flight -- the staged prefetch of the next read -- lands before the first store: a later
   // wait could not tell the loads from the stores (one counter), and the next iteration reads the staging rows without one.
