@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256, 4) void qm_h2m_kernel(DevIndex ix, ReadBatch B
     const long long read = read_id<F>(B, r);
     H2mMem& M = mem[wave];
     IntervalList fi, ri;
-    fi.lds = M.ints[0]; ri.lds = M.ints[1];
+    fi.lds = (QM_LDS(IntRec)*)M.ints[0]; ri.lds = (QM_LDS(IntRec)*)M.ints[1];
     fi.ovf = (IntRec*)(gscr + 3 * QM_GCAP); ri.ovf = fi.ovf + QM_IOVF;
     fi.n = 0; ri.n = 0; fi.pf = nullptr; ri.pf = nullptr; fi.pfcap = 0; ri.pfcap = 0;
     long long i0, i1; int len, mate = 0;
@@ -65,8 +65,8 @@ __global__ __launch_bounds__(256, 4) void qm_h2m_kernel(DevIndex ix, ReadBatch B
         const int idx = rc ? ri.n + popc64(rm & lanemask_lt(l)) : fi.n + popc64(fm & lanemask_lt(l));
         IntRec r; r.b = h.begin; r.e = h.end; r.len = h.len; r.q = h.query_pos;
         IntervalList& L = rc ? ri : fi;
-        IntRec* dst = idx < QM_ICAP ? &L.lds[idx] : &L.ovf[idx - QM_ICAP];
-        *dst = r;
+        if (idx < QM_ICAP) { L.lds[idx].b = r.b; L.lds[idx].e = r.e; L.lds[idx].len = r.len; L.lds[idx].q = r.q; }
+        else L.ovf[idx - QM_ICAP] = r;
       }
       fi.n += popc64(fm); ri.n += popc64(rm);
     }

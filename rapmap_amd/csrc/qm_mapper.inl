@@ -767,18 +767,21 @@ template <int NS> QM_DEV int known_end(const Strand<NS>& S, int p) {
 
 // SA-interval hits of one strand: the first QM_ICAP in LDS, the rest in the wave's global scratch
 struct IntervalList {
-  IntRec* lds; IntRec* ovf;
+  QM_LDS(IntRec)* lds; IntRec* ovf;
   int n;
   u32* pf; int pfcap;      // LDS staging for the (tid, pos) of the first interval's suffixes: tids at pf[0..), positions at pf[pfcap..)
   QM_DEV void push(int lb, int ub, u32 ln, u32 qp) {
     IntRec r; r.b = lb; r.e = ub; r.len = ln; r.q = qp;
-    IntRec* dst = n < QM_ICAP ? &lds[n] : &ovf[n - QM_ICAP];
-    QM_LANES(l) { if (l == 0) *dst = r; }
+    // a branch per home, not one pointer that is either: that would be a FLAT store (vector-memory path even into LDS)
+    if (n < QM_ICAP) { QM_LANES(l) { if (l == 0) { lds[n].b = r.b; lds[n].e = r.e; lds[n].len = r.len; lds[n].q = r.q; } } }
+    else { QM_LANES(l) { if (l == 0) ovf[n - QM_ICAP] = r; } }
     ++n;
     wave_fence();
   }
   QM_DEV void get(int i, int& lb, int& ub, u32& ln, u32& qp) const {
-    IntRec r = i < QM_ICAP ? lds[i] : ovf[i - QM_ICAP];
+    IntRec r;
+    if (i < QM_ICAP) { r.b = lds[i].b; r.e = lds[i].e; r.len = lds[i].len; r.q = lds[i].q; }
+    else r = ovf[i - QM_ICAP];
     lb = uniform(r.b); ub = uniform(r.e); ln = uniform(r.len); qp = uniform(r.q);
   }
 };
@@ -848,9 +851,11 @@ QM_DEV bool extend_search_wide(const DevIndex& ix, int lbIn, int ubIn, int start
         int cnt = 0;
         if (nb > 0) {
           // 16 query bytes at q[off]: aligned LDS words + funnel shift (rows are padded for the over-read)
-          const unsigned long long addr = (unsigned long long)(q + off);
-          const u64* al = (const u64*)(addr & ~7ULL);
-          const int sh = (int)(addr & 7ULL) * 8;
+          // (the aligned pointer by pointer arithmetic: through an integer it would lose its address space and the three
+          // loads would be FLAT instructions instead of LDS reads)
+          const int mis = (int)((unsigned long long)(q + off) & 7ULL);
+          const u64* al = (const u64*)(q + off - mis);
+          const int sh = mis * 8;
           const u64 w0 = al[0], w1 = al[1], w2 = al[2];
           const u64 q0 = (w0 >> sh) | ((w1 << 1) << (63 - sh)), q1 = (w1 >> sh) | ((w2 << 1) << (63 - sh));
           long long tv = ix.n - (sv[l] + off);            // text bytes left (the array is padded for the over-read)
@@ -1675,7 +1680,7 @@ QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, lon
   stage_offsets<NS, F>(B, slot + 2 * nw, M, par);
   QM_T(0);
   IntervalList fi, ri;
-  fi.lds = M.ints[0]; ri.lds = M.ints[1];
+  fi.lds = (QM_LDS(IntRec)*)M.ints[0]; ri.lds = (QM_LDS(IntRec)*)M.ints[1];
   fi.ovf = (IntRec*)(gscr + 3 * QM_GCAP); ri.ovf = fi.ovf + QM_IOVF;
   const bool foundHit = collect_read<NS, F>(ix, B, M, len, hasDollar, fi, ri);
   QM_T(4);

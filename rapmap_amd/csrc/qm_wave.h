@@ -11,12 +11,16 @@
 #pragma once
 #include <stdint.h>
 
+// QM_LDS(T): T in this wave's LDS slab, for pointers that must never be mistaken for generic ones (a generic pointer is
+// dereferenced with FLAT instructions -- the vector-memory path, even when it lands in LDS)
 #ifdef QM_EMU
+#define QM_LDS(T) T
 #define QM_DEV inline
 #define QM_NL 64
 #define QM_LANES(l) for (int l = 0; l < 64; ++l)
 #else
 #include <hip/hip_runtime.h>
+#define QM_LDS(T) T __attribute__((address_space(3)))
 #define QM_DEV __device__ __forceinline__
 #define QM_NL 1
 #define QM_LANES(l) for (int _qm_once = 0, l = (int)(threadIdx.x & 63); _qm_once < 1; ++_qm_once)
