@@ -11,7 +11,7 @@ def ins(anchor, text, after=True):
     global s
     assert anchor in s, anchor
     s = s.replace(anchor, anchor + "\n" + text if after else text + "\n" + anchor, 1)
-ins("  IntervalList fi, ri;\n  fi.lds = M.ints[0]; ri.lds = M.ints[1];",
+ins("  IntervalList fi, ri;\n  fi.lds = (QM_LDS(IntRec)*)M.ints[0]; ri.lds = (QM_LDS(IntRec)*)M.ints[1];",
     "#if defined(QM_ABLATE) && QM_ABLATE == 1\n  lds_dma_wait(); QM_LANES(l) { if (l == 0) { B.lcnt[read] = 0; B.loff[read] = 0; } } return;\n#endif")
 ins("  setup_strand<NS>(ix, fwdStr, L, S, &M.planes[0][0][0], M.tab[0]);\n  S.dollar = hasDollar;",
     "#if defined(QM_ABLATE) && QM_ABLATE == 2\n  return S.P == 12345;\n#endif")
@@ -21,6 +21,6 @@ ins("  bool checkRC = useCoverageCheck ? (rcHit > 0) : (rcHit >= fwdHit);",
     "#if defined(QM_ABLATE) && QM_ABLATE == 4\n  return true;\n#endif")
 ins("  if (F & QM_F_COLLECT) return;          // stage entry",
     "#if defined(QM_ABLATE) && QM_ABLATE == 5\n  lds_dma_wait(); QM_LANES(l) { if (l == 0) { B.lcnt[read] = (u32)((fi.n + ri.n) & 0); B.loff[read] = 0; } } return;\n#endif", after=False)
-ins("  if (!(F & QM_F_SEL)) listSrc = bf.R;\n  QM_T(5);",
+ins("    listSrc = bf.R;\n  }\n  QM_T(5);",
     "#if defined(QM_ABLATE) && QM_ABLATE == 6\n  n = 0;\n#endif")
 open(p, "w").write(s)

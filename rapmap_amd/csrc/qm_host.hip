@@ -80,7 +80,7 @@ struct qm_index {
 struct Replica {
   int device = 0;
   uint8_t* d_text = nullptr; int32_t* d_SA = nullptr; void* d_sainfo = nullptr; void* d_slots = nullptr; uint64_t cap = 0;
-  void* d_ph = nullptr; std::vector<void*> phAllocs; int32_t* d_txpOff = nullptr; int32_t* d_txpLen = nullptr; int64_t devBytes = 0;
+  void* d_ph = nullptr; PhIndex hPh; std::vector<void*> phAllocs; int32_t* d_txpOff = nullptr; int32_t* d_txpLen = nullptr; int64_t devBytes = 0;
   ~Replica() {
     hipSetDevice(device);
     void* ptrs[] = {d_text, d_SA, d_sainfo, d_slots, d_txpOff, d_txpLen};
@@ -102,6 +102,7 @@ struct qm_ctx {
   uint8_t* d_text = nullptr; int32_t* d_SA = nullptr; void* d_sainfo = nullptr; void* d_slots = nullptr;
   uint64_t cap = 0;
   void* d_ph = nullptr; std::vector<void*> phAllocs;       // perfect-hash flavour: PhIndex struct + its arrays
+  PhIndex hPh;                                              // host copy (passed to the kernels by value inside DevIndex)
   int64_t devBytes = 0;
   // work buffers
   int64_t capCnt = 0, capOffs = 0, capLcnt = 0, capLoff = 0, capLists = 0, capHits = 0, capSeq1 = 0, capSeq2 = 0, capOff1 = 0, capOff2 = 0, capGrid = 0;
@@ -402,7 +403,7 @@ int qm_ctx_create_ex(const qm_index* ix, int device_id, uint32_t flags, qm_ctx**
     if (it != g_reps.end()) c->rep = it->second.lock();
     if (c->rep) {
       Replica& R = *c->rep;
-      c->d_text = R.d_text; c->d_SA = R.d_SA; c->d_sainfo = R.d_sainfo; c->d_slots = R.d_slots; c->cap = R.cap; c->d_ph = R.d_ph;
+      c->d_text = R.d_text; c->d_SA = R.d_SA; c->d_sainfo = R.d_sainfo; c->d_slots = R.d_slots; c->cap = R.cap; c->d_ph = R.d_ph; c->hPh = R.hPh;
       c->d_txpOff = R.d_txpOff; c->d_txpLen = R.d_txpLen; c->devBytes = R.devBytes;
       *out = c;
       return QM_OK;
@@ -476,7 +477,7 @@ int qm_ctx_create_ex(const qm_index* ix, int device_id, uint32_t flags, qm_ctx**
     P.lastbitsetrank = ix->phLastRank; P.nelem = ix->phNelem; P.nb_levels = nl;
     CK(hipMemcpyAsync(dP, &P, sizeof(P), hipMemcpyHostToDevice, c->stream));
     CK(hipStreamSynchronize(c->stream));    // P, tab, ov, fin are locals
-    c->d_ph = dP;
+    c->d_ph = dP; c->hPh = P;
     if (!phCompact) {
       // Default device image of a -p index: the same one-sector bucket table a dense index gets, filled from the MPHF's own
       // records after each was looked up through the BooPHF walk (so the table is known to answer like FrugalBooMap::find on
@@ -486,7 +487,7 @@ int qm_ctx_create_ex(const qm_index* ix, int device_id, uint32_t flags, qm_ctx**
       CK(hipMalloc(&c->d_slots, c->cap * sizeof(Bucket)));
       CK(hipMalloc((void**)&dBad, sizeof(unsigned long long)));
       DevIndex dix; memset(&dix, 0, sizeof(dix));
-      dix.text = c->d_text; dix.n = ix->n; dix.SA = c->d_SA; dix.nSA = ix->nSA; dix.k = ix->k; dix.ph = (const PhIndex*)dP;
+      dix.text = c->d_text; dix.n = ix->n; dix.SA = c->d_SA; dix.nSA = ix->nSA; dix.k = ix->k; dix.ph = (const PhIndex*)dP; dix.phv = P;
       CK(qmk_build_slots_from_ph(&dix, (long long)ix->phNelem, c->d_slots, c->cap, dBad, c->stream));
       CK(hipMemcpyAsync(&hBad, dBad, sizeof(hBad), hipMemcpyDeviceToHost, c->stream));
       CK(hipStreamSynchronize(c->stream));
@@ -510,7 +511,7 @@ int qm_ctx_create_ex(const qm_index* ix, int device_id, uint32_t flags, qm_ctx**
   {
     auto R = std::make_shared<Replica>();
     R->device = device_id; R->d_text = c->d_text; R->d_SA = c->d_SA; R->d_sainfo = c->d_sainfo; R->d_slots = c->d_slots; R->cap = c->cap;
-    R->d_ph = c->d_ph; R->phAllocs.swap(c->phAllocs); R->d_txpOff = c->d_txpOff; R->d_txpLen = c->d_txpLen; R->devBytes = c->devBytes;
+    R->d_ph = c->d_ph; R->hPh = c->hPh; R->phAllocs.swap(c->phAllocs); R->d_txpOff = c->d_txpOff; R->d_txpLen = c->d_txpLen; R->devBytes = c->devBytes;
     std::lock_guard<std::mutex> lk(g_repMu);
     c->rep = R;
     g_reps[std::make_pair(ix, repKey)] = R;
@@ -552,6 +553,7 @@ struct RunReq {
 static DevIndex dev_index(const qm_ctx* c) {
   DevIndex ix; ix.text = c->d_text; ix.n = c->ix->n; ix.SA = c->d_SA; ix.nSA = c->ix->nSA;
   ix.sainfo = (const SaInfo*)c->d_sainfo; ix.slots = (const Bucket*)c->d_slots; ix.hmask = c->cap - 1; ix.ph = (const PhIndex*)c->d_ph; ix.k = c->ix->k;
+  memset(&ix.phv, 0, sizeof(ix.phv)); if (c->d_ph) ix.phv = c->hPh;
   return ix;
 }
 

@@ -231,7 +231,7 @@ __global__ void build_phrec_kernel(const int* data, const unsigned char* lens, l
 __global__ void build_slots_from_ph_kernel(DevIndex ix, long long n, Bucket* buckets, u64 hmask, unsigned long long* bad) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long stride = (long long)gridDim.x * blockDim.x;
-  const PhIndex& P = *ix.ph;
+  const PhIndex& P = ix.phv;
   for (; i < n; i += stride) {
     const PhRec r = P.recs[i];
     int lb = 0, ub = 0;

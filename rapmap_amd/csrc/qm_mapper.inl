@@ -102,7 +102,10 @@ struct DevIndex {
   const SaInfo* sainfo;
   const Bucket* slots;        // dense index: hmask + 1 buckets (null for a perfect-hash index)
   u64 hmask;
-  const PhIndex* ph;          // perfect-hash index (null for a dense index), in device memory
+  const PhIndex* ph;          // perfect-hash index (null for a dense index): the flag the kernels are chosen by
+  PhIndex phv;                // ... and its contents, by value: as kernel arguments the fields are scalar loads and the
+                              // pointers are known to be global (loaded from a struct in memory they would be generic
+                              // pointers, dereferenced with FLAT instructions)
   int k;
 };
 
@@ -349,7 +352,7 @@ QM_DEV bool find_kmer(const DevIndex& ix, u64 key, int& lb, int& ub) {
       b = (b + 1) & ix.hmask;
     }
   }
-  const PhIndex& P = *ix.ph;
+  const PhIndex& P = ix.phv;
   u64 s0 = 0, s1 = 0, h = 0;
   u64 idx = 0;
   bool inLevel = false;

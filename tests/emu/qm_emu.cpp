@@ -28,6 +28,7 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
            qm_sa_interval_hit** ints_out, int* status_out, const int* txp_off, const int* txp_len) {
   DevIndex ix; ix.text = text; ix.n = n; ix.SA = SA; ix.nSA = nSA; ix.sainfo = (const SaInfo*)sainfo;
   ix.slots = (const Bucket*)slots; ix.hmask = hmask; ix.k = k; ix.ph = (const PhIndex*)ph;
+  memset(&ix.phv, 0, sizeof(ix.phv)); if (ph) ix.phv = *(const PhIndex*)ph;
   const bool paired = seq2 != nullptr;
   const long long nreads = paired ? 2 * nunits : nunits;
   ReadBatch B; memset(&B, 0, sizeof(B));
