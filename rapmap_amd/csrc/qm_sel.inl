@@ -26,6 +26,7 @@ struct SelGroup {                  // ppos: the hit's own position (QuasiAlignme
 };
 template <int CAP, int OUTCAP>
 struct SelScratchT {                // working set of one read
+  static constexpr int NCH = 4;     // 64-record chunks the lane-parallel sort / chaining handle (sel_wave_sort)
   QM_DEV int cap() const { return CAP; } QM_DEV int outcap() const { return OUTCAP; } QM_DEV int gcap() const { return CAP; }
   QM_DEV int tmp_bytes() const { return (int)sizeof(tmp); }
   SelRec rec[CAP], tmp[CAP];
@@ -38,6 +39,7 @@ struct SelScratch : SelScratchT<QM_SEL_CAP, QM_CHUNK> {};   // per wave, global 
 // The third edition: arrays sized by the host from the largest read of the slow queue (reads whose intervals hold more
 // suffixes than SelScratch -- repeats, low-complexity reads).  Same member names, pointers instead of arrays.
 struct SelScratchDyn {
+  static constexpr int NCH = 4;
   int capN, outN;
   SelRec* rec; SelRec* tmp;
   double* f; int* p; int* seen; int* ends; int* starts;
@@ -67,6 +69,7 @@ struct SelScratchDyn {
 // share their bytes with the second strand's groups (written only after that strand's sort), and the read's list is
 // assembled in the sort buffers of WaveMem, which the -s path does not use otherwise (`out`, 3 * QM_CAP words).
 struct SelScratchLds {
+  static constexpr int NCH = 1;     // at most QM_SEL_SMALL < 64 records: one chunk, a quarter of the code and registers
   QM_DEV int cap() const { return QM_SEL_SMALL; } QM_DEV int outcap() const { return 3 * QM_CAP; } QM_DEV int gcap() const { return QM_SEL_SMALL; }
   QM_DEV int tmp_bytes() const { return (int)sizeof(tmp); }
   SelRec rec[QM_SEL_SMALL];
@@ -291,12 +294,12 @@ QM_DEV int sel_emit(SS& S) {
 // The two stable sorts of sel_strand as one rank sort by all lanes (n <= 64 * QM_SEL_CHUNKS, lane l owns the records
 // l, l + 64, ...): order (tid, reference end, query end, input order) for several intervals, (tid, hit position, input
 // order) for one -- what lane 0's merge sorts produce.
-#define QM_SEL_CHUNKS 4
+#define QM_SEL_CHUNKS 4      // the most chunks any scratch edition handles lane-parallel (SS::NCH)
 template <typename SS>
 QM_DEV void sel_wave_sort(SS& S, int n, int m) {
   u64* K = (u64*)S.tmp;                              // keys where every lane can read them (2 words per record)
 #pragma unroll
-  for (int c = 0; c < QM_SEL_CHUNKS; ++c) {
+  for (int c = 0; c < SS::NCH; ++c) {
     if (64 * c >= n) continue;
     QM_LANES(l) {
       const int i = 64 * c + l;
@@ -308,9 +311,9 @@ QM_DEV void sel_wave_sort(SS& S, int n, int m) {
     }
   }
   wave_fence();
-  LV<int> rank[QM_SEL_CHUNKS]; LV<SelRec> mine[QM_SEL_CHUNKS];
+  LV<int> rank[SS::NCH]; LV<SelRec> mine[SS::NCH];
 #pragma unroll
-  for (int c = 0; c < QM_SEL_CHUNKS; ++c) {
+  for (int c = 0; c < SS::NCH; ++c) {
     if (64 * c >= n) continue;
     QM_LANES(l) {
       const int i = 64 * c + l;
@@ -325,11 +328,11 @@ QM_DEV void sel_wave_sort(SS& S, int n, int m) {
   }
   wave_fence();
 #pragma unroll
-  for (int c = 0; c < QM_SEL_CHUNKS; ++c) { if (64 * c < n) { QM_LANES(l) { if (64 * c + l < n) S.rec[rank[c][l]] = mine[c][l]; } } }
+  for (int c = 0; c < SS::NCH; ++c) { if (64 * c < n) { QM_LANES(l) { if (64 * c + l < n) S.rec[rank[c][l]] = mine[c][l]; } } }
   wave_fence();
 }
 
-// sel_strand for several intervals when the n <= 64 * QM_SEL_CHUNKS records are already in chain order (sel_wave_sort): the
+// sel_strand for several intervals when the n <= 64 * SS::NCH records are already in chain order (sel_wave_sort): the
 // lane that holds a transcript's first record counts its intervals and chains its hits, all transcripts of a 64-record
 // chunk at once; the groups are then packed in transcript order by prefix sums over the lanes and chunks.
 template <typename SS>
@@ -343,17 +346,19 @@ QM_DEV void sel_strand_wave(SS& S, int s, int n, int m, u32 readLen, float conse
     requiredNumHits = fl > 1 ? fl : 1;
     maxSlack = m - requiredNumHits;
   }
-  u64 hm[QM_SEL_CHUNKS] = {0, 0, 0, 0};
-  LV<bool> head[QM_SEL_CHUNKS];
+  u64 hm[SS::NCH];
 #pragma unroll
-  for (int c = 0; c < QM_SEL_CHUNKS; ++c) {
+  for (int c = 0; c < SS::NCH; ++c) hm[c] = 0;
+  LV<bool> head[SS::NCH];
+#pragma unroll
+  for (int c = 0; c < SS::NCH; ++c) {
     QM_LANES(l) { const int i = 64 * c + l; head[c][l] = i < n && (i == 0 || S.rec[i].tid != S.rec[i - 1].tid); }
     hm[c] = ballot(head[c]);
   }
-  LV<int> g1v[QM_SEL_CHUNKS]; LV<bool> req[QM_SEL_CHUNKS];
+  LV<int> g1v[SS::NCH]; LV<bool> req[SS::NCH];
   bool anyReq = false;
 #pragma unroll
-  for (int c = 0; c < QM_SEL_CHUNKS; ++c) {
+  for (int c = 0; c < SS::NCH; ++c) {
     if (64 * c >= n) continue;
     QM_LANES(l) {
       g1v[c][l] = 0; req[c][l] = false;
@@ -365,7 +370,7 @@ QM_DEV void sel_strand_wave(SS& S, int s, int n, int m, u32 readLen, float conse
         if (rest) g1 = 64 * c + ctz64(rest);
         else {
 #pragma unroll
-          for (int d = QM_SEL_CHUNKS - 1; d > 0; --d) if (d > c && hm[d]) g1 = 64 * d + ctz64(hm[d]);   // the lowest such d wins
+          for (int d = SS::NCH - 1; d > 0; --d) if (d > c && hm[d]) g1 = 64 * d + ctz64(hm[d]);   // the lowest such d wins
         }
         SelIvSet mk;
         for (int j = i; j < g1; ++j) mk.add(S.rec[j].iv);
@@ -376,10 +381,12 @@ QM_DEV void sel_strand_wave(SS& S, int s, int n, int m, u32 readLen, float conse
     anyReq = anyReq || ballot(req[c]) != 0;
   }
   const bool allActive = maxSlack > 0 && !anyReq;           // HitManager.cpp:682-686
-  LV<int> nsv[QM_SEL_CHUNKS]; LV<SelGroup> gv[QM_SEL_CHUNKS]; LV<bool> em[QM_SEL_CHUNKS];
-  u64 emm[QM_SEL_CHUNKS] = {0, 0, 0, 0};
+  LV<int> nsv[SS::NCH]; LV<SelGroup> gv[SS::NCH]; LV<bool> em[SS::NCH];
+  u64 emm[SS::NCH];
 #pragma unroll
-  for (int c = 0; c < QM_SEL_CHUNKS; ++c) {
+  for (int c = 0; c < SS::NCH; ++c) emm[c] = 0;
+#pragma unroll
+  for (int c = 0; c < SS::NCH; ++c) {
     QM_LANES(l) {
       nsv[c][l] = 0; em[c][l] = false;
       if (64 * c < n && head[c][l] && (req[c][l] || allActive)) {
@@ -394,15 +401,15 @@ QM_DEV void sel_strand_wave(SS& S, int s, int n, int m, u32 readLen, float conse
   wave_fence();
   int ngAll = 0;
 #pragma unroll
-  for (int c = 0; c < QM_SEL_CHUNKS; ++c) ngAll += popc64(emm[c]);
+  for (int c = 0; c < SS::NCH; ++c) ngAll += popc64(emm[c]);
   if (ngAll > S.gcap()) { QM_LANES(l) { if (l == 0) S.ngrp[s] = -1; } return; }   // more transcripts than this scratch holds
 #pragma unroll
-  for (int c = 0; c < QM_SEL_CHUNKS; ++c) {
+  for (int c = 0; c < SS::NCH; ++c) {
     QM_LANES(l) {
       if (em[c][l]) {
         int mine = 0, ord = 0;                             // positions / groups emitted by the heads before this one
 #pragma unroll
-        for (int d = 0; d < QM_SEL_CHUNKS; ++d) {
+        for (int d = 0; d < SS::NCH; ++d) {
           if (d > c) continue;
           u64 r = d < c ? emm[d] : (emm[d] & lanemask_lt(l));
           ord += popc64(r);
@@ -418,7 +425,7 @@ QM_DEV void sel_strand_wave(SS& S, int s, int n, int m, u32 readLen, float conse
     if (l == 0) {
       int tot = 0;
 #pragma unroll
-      for (int d = 0; d < QM_SEL_CHUNKS; ++d) for (u64 r = emm[d]; r; r &= r - 1) tot += S.starts[64 * d + ctz64(r)];
+      for (int d = 0; d < SS::NCH; ++d) for (u64 r = emm[d]; r; r &= r - 1) tot += S.starts[64 * d + ctz64(r)];
       S.ngrp[s] = ngAll; S.npos[s] = tot;
     }
   }
@@ -433,7 +440,7 @@ QM_DEV int sel_h2m_on(const DevIndex& ix, const ReadBatch& B, const IntervalList
     int n = 0;
     for (int ii = 0; ii < L.n; ++ii) { int lb, ub; u32 ln, qp; L.get(ii, lb, ub, ln, qp); n += ub - lb; }
     if (n > S.cap()) return -1;
-    if (n <= 64 * QM_SEL_CHUNKS) {
+    if (n <= 64 * SS::NCH) {
       // the usual case: one lane per suffix over all the intervals at once -- one trip to sainfo per 64 suffixes of the strand
       for (int base = 0; base < n; base += 64) {
         LV<int> sa; LV<u32> qv, lv, iv;
@@ -471,7 +478,7 @@ QM_DEV int sel_h2m_on(const DevIndex& ix, const ReadBatch& B, const IntervalList
       }
     }
     wave_fence();
-    const bool presorted = n <= 64 * QM_SEL_CHUNKS && 2 * n * (int)sizeof(u64) <= S.tmp_bytes();
+    const bool presorted = n <= 64 * SS::NCH && 2 * n * (int)sizeof(u64) <= S.tmp_bytes();
     if (presorted && L.n > 0) sel_wave_sort(S, n, L.n);
     if (presorted && L.n > 1) sel_strand_wave(S, s, n, L.n, readLen, B.consensus_fraction);
     else QM_LANES(l) { if (l == 0) { if (L.n > 0) sel_strand(S, s, n, L.n, readLen, mate, B.consensus_fraction, presorted); else { S.ngrp[s] = 0; S.npos[s] = 0; } } }
