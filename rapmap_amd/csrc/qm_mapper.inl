@@ -1631,6 +1631,9 @@ QM_DEV void finish_read(const DevIndex& ix, const ReadBatch& B, long long read, 
   if (!(F & QM_F_SEL) && bound <= QM_CAP) {          // the usual case, spelled out so that the source is addressed as LDS (not flat)
     const u64* src = buf[2];
     for (int b0 = 0; b0 < n; b0 += 64) { QM_LANES(l) { int i = b0 + l; if (i < n) B.lists[base + i] = src[i]; } }
+  } else if ((F & QM_F_SEL) && listSrc == (const u64*)&buf[0][0]) {   // -s, the LDS edition of the scratch: likewise
+    const u64* src = &buf[0][0];
+    for (int b0 = 0; b0 < n; b0 += 64) { QM_LANES(l) { int i = b0 + l; if (i < n) B.lists[base + i] = src[i]; } }
   } else {
     for (int b0 = 0; b0 < n; b0 += 64) { QM_LANES(l) { int i = b0 + l; if (i < n) B.lists[base + i] = listSrc[i]; } }
   }

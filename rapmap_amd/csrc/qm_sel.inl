@@ -77,7 +77,7 @@ struct SelScratchLds {
   SelGroup grp0[QM_SEL_SMALL];
   union { SelGroup grp1[QM_SEL_SMALL]; SelRec tmp[QM_SEL_SMALL]; };
   int pos[2][QM_SEL_SMALL]; int ngrp[2], npos[2];
-  u64* out;
+  QM_LDS(u64)* out;                 // (typed: a plain pointer read back from this struct would be generic, its stores FLAT)
   QM_DEV SelGroup* grpp(int s) { return s == 0 ? grp0 : grp1; }
 };
 QM_DEV const u64* sel_out(const SelScratch& S) { return S.out; }
@@ -500,7 +500,7 @@ QM_DEV int sel_hits_to_mappings(const DevIndex& ix, const ReadBatch& B, const In
                                 u32 readLen, int mate, SelScratch& G, SelScratchLds* L, u64* ldsOut, const u64*& src, SelScratchDyn* dyn) {
   int n = -1;
   if (!dyn) {
-    if (L) { L->out = ldsOut; n = sel_h2m_on(ix, B, fwdInts, rcInts, readLen, mate, *L); src = ldsOut; }
+    if (L) { L->out = (QM_LDS(u64)*)ldsOut; n = sel_h2m_on(ix, B, fwdInts, rcInts, readLen, mate, *L); src = ldsOut; }
     if (n < 0) { n = sel_h2m_on(ix, B, fwdInts, rcInts, readLen, mate, static_cast<SelScratchT<QM_SEL_CAP, QM_CHUNK>&>(G)); src = G.out; }
     if (n >= 0) return n;
     int need = 0;                                           // suffixes of the larger strand: sizes the slow pass's scratch
