@@ -255,9 +255,9 @@ __shared__ u64 qm_tim[4][10];
 #define QM_F_SEL 4     // --selAln: chain scoring in the collector (MMPs capped at k + maxMMPExtension), coverage slack 1
 #define QM_F_COLLECT 8 // stage entry: the collector alone (intervals + foundHit out, no hit list)
 
-// khash.find for either index flavour.
-// dense: exact lookup in the open-addressing table (RapMapUtils.hpp:65-67).
-// perfect hash: FrugalBooMap::find (FrugalBooMap.hpp:149-167) over mphf::lookup (BooPHF.hpp:971-1009,
+// khash.find.
+// dense: exact lookup in the bucket table (RapMapUtils.hpp:65-67), a whole probe round at a time: find_dense_round.
+// perfect hash (find_kmer): FrugalBooMap::find (FrugalBooMap.hpp:149-167) over mphf::lookup (BooPHF.hpp:971-1009,
 // getLevel :1318-1351, hash64 :394-407, xorshift next :493-499, fastrange64 :815-820, bitVector::rank :756-769):
 // the key is not stored -- the candidate interval's first suffix is re-encoded from the text and compared.
 QM_DEV u64 boo_hash64(u64 key, u64 seed) {
@@ -335,23 +335,7 @@ QM_DEV void find_dense_round(const DevIndex& ix, const LV<u64>& key, const LV<bo
 }
 
 template <int F>
-QM_DEV bool find_kmer(const DevIndex& ix, u64 key, int& lb, int& ub) {
-  if (!(F & QM_F_PH)) {
-    u64 b = (u64)bucket_hash(key) & ix.hmask;
-    QM_CNT(0, 1);
-    while (true) {
-      const Bucket* bk = &ix.slots[b];
-      U4 a, c;
-      load_32(bk, a, c);                                // both keys, both intervals: one round
-      QM_CNT(1, 1);
-      const u64 k0r = ((u64)a.y << 32) | a.x, k1 = ((u64)a.w << 32) | a.z;
-      const u64 k0 = k0r == ~0ULL ? k0r : (k0r & ~QM_BK_OVF);
-      if (k0 == key) { lb = (int)c.x; ub = (int)c.y; return true; }
-      if (k1 == key) { lb = (int)c.z; ub = (int)c.w; return true; }
-      if (k0r == ~0ULL || !(k0r & QM_BK_OVF)) return false;
-      b = (b + 1) & ix.hmask;
-    }
-  }
+QM_DEV bool find_kmer(const DevIndex& ix, u64 key, int& lb, int& ub) {     // perfect-hash flavour only (dense: find_dense_round)
   const PhIndex& P = ix.phv;
   u64 s0 = 0, s1 = 0, h = 0;
   u64 idx = 0;
