@@ -355,6 +355,23 @@ int qm_reader_open(const char* path1, const char* path2, int32_t n_threads, qm_r
   return QM_OK;
 }
 
+// Average sequence / name bytes per record at the head of source s (plain files only: a look at the first 256 KB of the
+// mapping; 0, 0 when it cannot tell).  qm_stream_open sizes its pinned batch buffers from it before the first batch is read.
+void qm_reader_estimate(qm_reader* r, int s, double* seq_bytes, double* name_bytes) {
+  *seq_bytes = 0; *name_bytes = 0;
+  if (!r || s < 0 || s >= r->nsrc) return;
+  Source& S = r->src[s];
+  if (S.gz || !S.map || S.len == 0) return;
+  const size_t n = std::min(S.len, (size_t)256 << 10);
+  std::vector<RecIdx> R; std::vector<char> arena; bool bad = false;
+  arena.reserve(n + 16);
+  parse_block(S.map, S.map + n, n == S.len, R, arena, bad);
+  if (R.empty()) return;
+  double a = 0, b = 0;
+  for (const RecIdx& x : R) { a += x.sl; b += x.nl; }
+  *seq_bytes = a / (double)R.size(); *name_bytes = b / (double)R.size();
+}
+
 void qm_reader_close(qm_reader* r) {
   if (!r) return;
   r->src[0].close(); r->src[1].close();

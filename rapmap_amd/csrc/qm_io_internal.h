@@ -11,4 +11,5 @@ typedef struct qm_batch_bufs {
   void* (*alloc)(size_t); void (*release)(void*);          // where the buffers live: malloc / pinned host memory
 } qm_batch_bufs;
 int qm_reader_next_into(qm_reader* r, int64_t max_units, int64_t* n_units, qm_batch_bufs* B);
+void qm_reader_estimate(qm_reader* r, int s, double* seq_bytes, double* name_bytes);
 }

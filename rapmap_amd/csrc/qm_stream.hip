@@ -143,14 +143,42 @@ int qm_stream_open(const qm_index* ix, int device_id, uint32_t ctx_flags, const 
   s->ix = ix; s->device = device_id; s->opts = *opts; s->paired = path2 != nullptr; s->batchUnits = batch_units;
   int rc = qm_reader_open(path1, path2, reader_threads > 0 ? reader_threads : 8, &s->reader);
   if (rc) { sfail(rc, qm_io_last_error()); delete s; return rc; }
+  s->slots.resize(4);
+  for (Slot& S : s->slots) { memset(&S.in, 0, sizeof(S.in)); S.in.alloc = pin_alloc; S.in.release = pin_free; }
+  // The batches' pinned buffers, sized from the head of the files and pinned while the contexts are being created: pinning
+  // ~300 MB inside the first batches cost as much as reading 5 M pairs.  (A wrong guess only means the reader grows them.)
+  std::vector<std::thread> pinners;
+  {
+    const int nsrc = path2 ? 2 : 1;
+    for (int m = 0; m < nsrc; ++m) {
+      double sb = 0, nb = 0;
+      qm_reader_estimate(s->reader, m, &sb, &nb);
+      if (sb <= 0) continue;
+      const size_t capSeq = (size_t)((double)batch_units * (sb * 1.05 + 1.0)) + 4096, capNames = (size_t)((double)batch_units * (nb * 1.05 + 1.0)) + 4096;
+      const size_t capOff = (size_t)batch_units + 1 + 4096;
+      for (Slot& S : s->slots)
+        pinners.emplace_back([&S, m, capSeq, capNames, capOff, device_id]() {
+          hipSetDevice(device_id);
+          if ((S.in.seq[m] = (char*)pin_alloc(capSeq))) S.in.cap_seq[m] = capSeq;
+          if ((S.in.names[m] = (char*)pin_alloc(capNames))) S.in.cap_names[m] = capNames;
+          if ((S.in.off[m] = (int64_t*)pin_alloc(capOff * 8))) S.in.cap_off[m] = capOff;
+          if ((S.in.noff[m] = (int64_t*)pin_alloc(capOff * 8))) S.in.cap_noff[m] = capOff;
+        });
+    }
+  }
+  auto joinPinners = [&]() { for (auto& t : pinners) t.join(); pinners.clear(); };
   for (int i = 0; i < 2; ++i) {
     qm_ctx* c = nullptr;
     rc = qm_ctx_create_ex(ix, device_id, ctx_flags, &c);
-    if (rc) { sfail(rc, qm_last_error()); for (qm_ctx* x : s->ctx) qm_ctx_destroy(x); qm_reader_close(s->reader); delete s; return rc; }
+    if (rc) {
+      sfail(rc, qm_last_error()); joinPinners();
+      for (Slot& S : s->slots) for (int m = 0; m < 2; ++m) { pin_free(S.in.seq[m]); pin_free(S.in.off[m]); pin_free(S.in.names[m]); pin_free(S.in.noff[m]); }
+      for (qm_ctx* x : s->ctx) qm_ctx_destroy(x);
+      qm_reader_close(s->reader); delete s; return rc;
+    }
     s->ctx.push_back(c);
   }
-  s->slots.resize(4);
-  for (Slot& S : s->slots) { memset(&S.in, 0, sizeof(S.in)); S.in.alloc = pin_alloc; S.in.release = pin_free; }
+  joinPinners();
   s->readerThread = std::thread(reader_loop, s);
   for (int i = 0; i < 2; ++i) s->mapThreads.emplace_back(map_loop, s, i);
   s->tOpen = now_s() - tOpen0;
