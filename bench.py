@@ -151,13 +151,21 @@ def main():
         args.pairs = 12_500_000 if world == 8 else 10_000_000
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    if local_rank >= torch.cuda.device_count():
+    # QMAP_BENCH_REHEARSAL=1 (tests only): the ranks share the visible GPUs and talk over gloo, so that everything of the
+    # N>1 path but RCCL itself -- launcher hand-over, index build by rank 0 behind a barrier, shard seeds, counter
+    # all-reduce, max-over-ranks timing, rank 0's line -- runs on a 1-GPU box.  Its numbers mean nothing.
+    rehearsal = os.environ.get("QMAP_BENCH_REHEARSAL") == "1"
+    if local_rank >= torch.cuda.device_count() and not rehearsal:
         raise SystemExit("rank %d has no GPU of its own (%d visible): one process per GPU" % (local_rank, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_id = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+    torch.cuda.set_device(dev_id)
+    device = torch.device("cuda", dev_id)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import rapmap_amd as ra
     from rapmap_amd import dist as qd
@@ -166,7 +174,7 @@ def main():
     idx_dir = build_or_reuse_index(args.genes, 42, k, rank, world, args.cache, args.perfect_hash)
     t = time.time()
     qi = ra.QuasiIndex(idx_dir)
-    mp = ra.QuasiMapper(qi, local_rank, ph_compact=args.ph_compact)
+    mp = ra.QuasiMapper(qi, dev_id, ph_compact=args.ph_compact)
     if rank == 0:
         log("index in HBM: %d transcripts, %d text bytes, %d k-mers, %.2f GB on device (%.1fs)" % (
             qi.n_txps, qi.text_len, qi.n_keys, mp.device_bytes / 1e9, time.time() - t))
@@ -321,7 +329,7 @@ def main():
             f1 = os.path.join(d_e, "r1.fq"); f2 = os.path.join(d_e, "r2.fq")
             _syn.write_fastq(f1, hs1[: ne * L], ne, L, 1); _syn.write_fastq(f2, hs2[: ne * L], ne, L, 2)
             t = time.perf_counter()
-            st = ra.MappedStream(qi, f1, f2, opts=opts, device=local_rank, batch_units=1 << 18, threads=min(64, cores), ph_compact=args.ph_compact)
+            st = ra.MappedStream(qi, f1, f2, opts=opts, device=dev_id, batch_units=1 << 18, threads=min(64, cores), ph_compact=args.ph_compact)
             nh = 0
             for b_ in st:
                 nh += b_.n_hits

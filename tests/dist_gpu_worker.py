@@ -16,9 +16,15 @@ sys.path.insert(0, ROOT)
 def main():
     idx, work = sys.argv[1], sys.argv[2]
     rank = int(os.environ["RANK"]); local = int(os.environ["LOCAL_RANK"]); world = int(os.environ["WORLD_SIZE"])
+    share = os.environ.get("QMAP_TEST_SHARE_GPU") == "1"        # rehearsal on a 1-GPU box: ranks share the GPU, gloo instead of RCCL
+    if share:
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    if share:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     import rapmap_amd as ra
     from rapmap_amd import dist as qd
     a1 = np.load(os.path.join(work, "a1.npy")); o1 = np.load(os.path.join(work, "o1.npy"))

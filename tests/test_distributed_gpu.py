@@ -52,6 +52,46 @@ def test_two_ranks_over_rccl_match_the_oracle(synth_small, oracle_mod, tmp_path)
     assert [int(x) for x in tot] == [ref.counters[k] for k in qd.COUNTER_KEYS]
 
 
+def _rehearse_worker(synth_small, tmp_path, nproc):
+    from oracle import oracle, q5
+    from rapmap_amd import dist as qd
+    from util import pack
+    a1, o1 = pack(synth_small["reads1"]); a2, o2 = pack(synth_small["reads2"])
+    np.save(tmp_path / "a1.npy", a1); np.save(tmp_path / "o1.npy", o1); np.save(tmp_path / "a2.npy", a2); np.save(tmp_path / "o2.npy", o2)
+    ref = oracle.Oracle(q5.load(synth_small["idx"])).map_pairs(a1, o1, a2, o2, nthreads=4)
+    r = _launch(nproc, [os.path.join(ROOT, "tests", "dist_gpu_worker.py"), synth_small["idx"], str(tmp_path)], env={"QMAP_TEST_SHARE_GPU": "1"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    hits = np.concatenate([np.load(tmp_path / ("hits_%d.npy" % i)) for i in range(nproc)])
+    cnt = np.concatenate([np.load(tmp_path / ("cnt_%d.npy" % i)) for i in range(nproc)])
+    assert np.array_equal(cnt, np.diff(ref.hit_offsets)) and hits.tobytes() == ref.hits.tobytes()
+    tot = np.load(tmp_path / "total.npy")
+    assert [int(x) for x in tot] == [ref.counters[k] for k in qd.COUNTER_KEYS]
+
+
+@pytest.mark.parametrize("nproc", [2, 3])
+def test_ranks_sharing_one_gpu_match_the_oracle(synth_small, oracle_mod, tmp_path, nproc):
+    """rehearsal of the N>1 path where only one GPU exists: the ranks share it and all-reduce over gloo -- everything but
+    RCCL itself (shard bounds, per-rank mapping through the C ABI, counter sum, shard concatenation) against the oracle"""
+    _rehearse_worker(synth_small, tmp_path, nproc)
+
+
+def test_bench_two_ranks_rehearsal(tmp_path):
+    """`python bench.py --gpus 2` end to end on whatever GPUs there are (QMAP_BENCH_REHEARSAL: shared GPU, gloo): the
+    launcher hand-over, rank 0 building the index behind a barrier, per-rank seeds, max-over-ranks timing, ONE line from rank 0"""
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e["QMAP_BENCH_CACHE"] = str(tmp_path); e["QMAP_BENCH_REHEARSAL"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--genes", "800", "--pairs", "200000"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
+    assert out["config"]["pairs_per_gpu_per_step"] == 200000
+
+
 @pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs")
 def test_bench_spawns_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` with no launcher around it must run two ranks and say so"""
