@@ -3,9 +3,9 @@
 set -u
 OUT=$1; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python bench.py --perfect-hash --no-cpu-baseline > $OUT/bench_ph.log 2>&1
+python bench.py --perfect-hash ${QM_PH_FLAGS:-} --no-cpu-baseline > $OUT/bench_ph.log 2>&1
 tail -1 $OUT/bench_ph.log | cut -c1-600
-A="--perfect-hash --no-cpu-baseline --steps 1 --warmup 0"
+A="--perfect-hash ${QM_PH_FLAGS:-} --no-cpu-baseline --steps 1 --warmup 0"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -o p -- python bench.py $A > $OUT/$c.log 2>&1
   f=$(find $OUT/$c -name "*counter_collection.csv" | head -1)
