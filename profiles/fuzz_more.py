@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Extra fuzzing of the HIP path against the oracle beyond what the -m gpu suite runs each time: more seeds, more read-length
+classes, more option sets.  python profiles/fuzz_more.py [n_pairs] [seeds]  (GPU box; builds a small synthetic index)."""
+import os, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch; torch.cuda.init()
+import rapmap_amd as ra
+from rapmap_amd import synth
+from oracle import oracle, q5
+from util import pack, assert_hits_equal
+import test_gpu_parity as T
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+oracle.build()
+d = tempfile.mkdtemp(prefix="fuzz", dir="/dev/shm")
+names, txps = synth.make_transcriptome(600, seed=11)
+fa = os.path.join(d, "t.fa"); synth.write_fasta(fa, names, txps)
+bad = 0
+for ph in (False, True):
+    idx = os.path.join(d, "idx_ph" if ph else "idx"); ra.build_index(fa, idx, threads=16, perfect_hash=ph)
+    orc = oracle.Oracle(q5.load(idx)); qi = ra.QuasiIndex(idx)
+    text, offsets = qi.arrays()
+    for compact in ((False, True) if ph else (False,)):
+        mp = ra.QuasiMapper(qi, 0, ph_compact=compact)
+        for seed in range(seeds):
+            for max_len in (100, 128, 150, 192, 250, 400):
+                r1, r2 = T._fuzz_reads(np.asarray(text), np.asarray(offsets, dtype=np.int64), n if max_len <= 256 else n // 4, 1000 * seed + max_len, max_len)
+                q1, o1 = pack(r1); q2, o2 = pack(r2)
+                sets = [({}, {}), ({"sensitive": 0}, {"sensitive": 0}), ({"fuzzy": 1}, {"fuzzy": 1}), ({"strictCheck": 0}, {"strict_check": 0}),
+                        ({"maxNumHits": 2, "noOrphans": 1}, {"max_num_hits": 2, "no_orphans": 1}), ({"quasiCov": 0.8}, {"quasi_cov": 0.8})]
+                if max_len <= 250:
+                    sets += [({"selAln": 1}, {"sel_aln": 1}), ({"selAln": 1, "consensusSlack": 0.35, "dpBandwidth": 40}, {"sel_aln": 1, "consensus_slack": 0.35, "dp_bandwidth": 40})]
+                for oo, go in sets:
+                    res = orc.map_pairs(q1, o1, q2, o2, opts=oracle.default_opts(**oo), nthreads=32)
+                    gr = mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(**go))
+                    try:
+                        assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "fuzz")
+                        assert res.counters == gr.counters
+                    except AssertionError as e:
+                        bad += 1; print("MISMATCH ph=%s compact=%s seed=%d len<=%d opts=%s: %s" % (ph, compact, seed, max_len, oo, str(e)[:200]), flush=True)
+            print("ph=%s compact=%s seed %d done" % (ph, compact, seed), flush=True)
+        mp.close()
+print("fuzz_more: %d mismatching runs" % bad)
+sys.exit(1 if bad else 0)
