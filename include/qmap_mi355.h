@@ -286,6 +286,13 @@ int qm_sam_write(const qm_index* ix, int64_t n, const char* names1, const int64_
  * releases the writer (the descriptor stays the caller's). */
 typedef struct qm_sam_writer qm_sam_writer;
 int qm_sam_writer_open(const qm_index* ix, int fd, int32_t max_num_hits, int32_t n_threads, qm_sam_writer** out);
+/* flags: QM_SAM_GZIP = `-x / --compressed` (src/RapMapSAMapper.cpp:832-833 wraps the output buffer in a zstr::ostream, i.e. a
+ * zlib deflate stream): every formatter part becomes a gzip member of its own, compressed by the worker that formatted it,
+ * written in order -- the concatenation is one valid .gz stream.  Bits 8-11: deflate level 1..9 (0: level 1).
+ * qm_sam_writer_header puts the SAM header through the same queue (compressed like everything else). */
+#define QM_SAM_GZIP 1u
+int qm_sam_writer_open_ex(const qm_index* ix, int fd, int32_t max_num_hits, int32_t n_threads, uint32_t flags, qm_sam_writer** out);
+int qm_sam_writer_header(qm_sam_writer* w);
 int qm_sam_writer_put(qm_sam_writer* w, int64_t n, const char* names1, const int64_t* name_off1, const char* seq1,
                       const int64_t* off1, const char* names2, const int64_t* name_off2, const char* seq2,
                       const int64_t* off2, const int64_t* hit_offsets, const qm_hit* hits);

@@ -40,6 +40,7 @@ def main():
         for th in thr_list:
             runs.append(("FASTQ -> hits (-n) chunk %d t%d" % (ch, th), ["-n"], ch, th))
     runs.append(("FASTQ -> SAM on tmpfs (-o)", ["-o", os.path.join(d, "out.sam")], chunks[-1], thr_list[-1]))
+    runs.append(("FASTQ -> SAM.gz on tmpfs (-o -x)", ["-o", os.path.join(d, "out.sam.gz"), "-x"], chunks[-1], thr_list[-1]))
     for label, extra, ch, th in runs:
         base = [sys.executable, "-m", "rapmap_amd", "quasimap", "-i", os.path.join(d, "idx"), "-1", f1, "-2", f2, "-t", str(th), "--chunk", str(ch)]
         best = None
@@ -52,8 +53,9 @@ def main():
             best = dt if best is None else min(best, dt)
         tail = [l for l in r.stderr.splitlines() if "Elapsed" in l or "Final" in l or l.startswith("stream:")]
         print("[e2e] %-28s %6.2f s  -> %6.2f M pairs/s end to end (process start to exit; %s)" % (label, best, pairs / best / 1e6, "; ".join(tail)), flush=True)
-    if os.path.exists(os.path.join(d, "out.sam")):
-        print("[e2e] SAM size %.0f MB" % (os.path.getsize(os.path.join(d, "out.sam")) / 1e6))
+    for f in ("out.sam", "out.sam.gz"):
+        if os.path.exists(os.path.join(d, f)):
+            print("[e2e] %s size %.0f MB" % (f, os.path.getsize(os.path.join(d, f)) / 1e6))
     subprocess.run(["rm", "-rf", d])
 
 

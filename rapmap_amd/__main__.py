@@ -109,22 +109,25 @@ def _quasimap(argv):
     qi = ra.QuasiIndex(a.index)
     log = (lambda *x: None) if a.quiet else (lambda *x: print(*x, file=sys.stderr, flush=True))
     out = None
+    direct_fd = None
     if not a.noOutput:
-        if a.output:
-            if a.compressed:
-                import gzip
-                out = gzip.open(a.output, "wb")
-            else:
-                out = open(a.output, "wb")
-        else:
-            out = sys.stdout.buffer
-        out.write(ra.sam_header_text(qi))
+        out = open(a.output, "wb") if a.output else sys.stdout.buffer
         out.flush()
-    # uncompressed output goes from the library straight to the file descriptor
-    direct_fd = out.fileno() if (out is not None and not (a.output and a.compressed)) else None
-    if out is None:
-        direct_fd = None
-    writer = ra.SamWriter(qi, direct_fd, max_num_hits=opts.max_num_hits, threads=max(1, a.numThreads)) if direct_fd is not None else None
+        try:
+            direct_fd = out.fileno()
+        except (OSError, ValueError, AttributeError):
+            direct_fd = None                                 # a stdout that is not a descriptor: text goes through Python
+    # header and records go from the library straight to the descriptor; -x: as gzip members compressed by the formatter's
+    # workers (the reference wraps its output stream in a zlib compressor, src/RapMapSAMapper.cpp:832-833)
+    writer = None
+    if direct_fd is not None:
+        writer = ra.SamWriter(qi, direct_fd, max_num_hits=opts.max_num_hits, threads=max(1, a.numThreads), gzip=bool(a.compressed))
+        writer.header()
+    elif out is not None:
+        if a.compressed:
+            import gzip
+            out = gzip.GzipFile(fileobj=out, mode="wb")
+        out.write(ra.sam_header_text(qi))
     tot = {"numReads": 0, "totHits": 0, "peHits": 0, "seHits": 0, "tooManyHits": 0}
     t0 = time.time()
     gpu_ms = 0.0

@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     "qm_map_pairs_stages", "qm_ctx_create_ex", "qm_fetch_hits_pinned",
     "qm_stream_open", "qm_stream_next", "qm_stream_close", "qm_stream_last_error", "qm_stream_stats",
     "qm_reader_open", "qm_reader_next", "qm_reader_close", "qm_io_last_error", "qm_sam_header", "qm_sam_records",
-    "qm_sam_write", "qm_sam_writer_open", "qm_sam_writer_put", "qm_sam_writer_close", "qm_buf_free",
+    "qm_sam_write", "qm_sam_writer_open", "qm_sam_writer_open_ex", "qm_sam_writer_header", "qm_sam_writer_put", "qm_sam_writer_close", "qm_buf_free",
 ]
 
 
@@ -148,6 +148,8 @@ def lib():
     L.qm_sam_write.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 10 + [C.c_int32, C.c_int32, C.c_int,
                                C.POINTER(C.c_int64)]
     L.qm_sam_writer_open.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    L.qm_sam_writer_open_ex.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.qm_sam_writer_header.argtypes = [C.c_void_p]
     L.qm_sam_writer_put.argtypes = [C.c_void_p, C.c_int64] + [C.c_void_p] * 10
     L.qm_sam_writer_close.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     L.qm_buf_free.argtypes = [C.c_void_p]
@@ -544,10 +546,18 @@ class SamWriter:
     """qm_sam_writer_*: SAM records of a run onto one file descriptor; put() formats a batch and returns while the writer's
     own thread writes the previous one."""
 
-    def __init__(self, index: "QuasiIndex", fd, max_num_hits=200, threads=None):
+    def __init__(self, index: "QuasiIndex", fd, max_num_hits=200, threads=None, gzip=False, level=1):
+        """gzip=True: `-x` -- every part of a batch becomes a gzip member compressed by its own worker (a valid .gz stream)"""
         self._h = C.c_void_p()
         self._index = index
-        rc = lib().qm_sam_writer_open(index._h, int(fd), int(max_num_hits), int(threads or min(16, os.cpu_count() or 1)), C.byref(self._h))
+        flags = (1 | (int(level) & 15) << 8) if gzip else 0
+        rc = lib().qm_sam_writer_open_ex(index._h, int(fd), int(max_num_hits), int(threads or min(16, os.cpu_count() or 1)), flags, C.byref(self._h))
+        if rc != 0:
+            raise QmError(lib().qm_io_last_error().decode())
+
+    def header(self):
+        """the SAM header, through the writer's queue (compressed like the records when gzip=True)"""
+        rc = lib().qm_sam_writer_header(self._h)
         if rc != 0:
             raise QmError(lib().qm_io_last_error().decode())
 

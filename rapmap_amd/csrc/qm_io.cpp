@@ -704,9 +704,38 @@ int qm_sam_write(const qm_index* ix, int64_t n, const char* names1, const int64_
 }
 
 /* ---- SAM writer: formatting of batch i+1 overlaps the write of batch i ---- */
+// one gzip member (RFC 1952) per formatter part: the members are compressed side by side by the formatter's workers and
+// written one after the other -- a concatenation of members is a valid .gz file (zlib's gzread, gzip -d and zcat read it
+// as one stream), which is what makes `-x` parallel; the reference deflates its whole output in the writer thread
+static int gz_member(const Out& in, Out& z, int level) {
+  z.n = 0;
+  if (in.n == 0) return QM_OK;
+  z_stream zs; memset(&zs, 0, sizeof(zs));
+  if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return io_fail(QM_E_IO, "deflateInit2 failed");
+  size_t done = 0;
+  while (done < in.n) {                                   // zlib counts in 32 bits: feed at most 1 GB at a time
+    const size_t chunk = std::min(in.n - done, (size_t)1 << 30);
+    zs.next_in = (Bytef*)(in.b + done); zs.avail_in = (uInt)chunk; done += chunk;
+    const int flush = done == in.n ? Z_FINISH : Z_NO_FLUSH;
+    int rc;
+    do {
+      z.need(std::max<size_t>((size_t)deflateBound(&zs, (uLong)zs.avail_in) + 64, 1 << 16));
+      zs.next_out = (Bytef*)(z.b + z.n); zs.avail_out = (uInt)std::min<size_t>(z.cap - z.n, (size_t)1 << 30);
+      const uInt before = zs.avail_out;
+      rc = deflate(&zs, flush);
+      z.n += before - zs.avail_out;
+      if (rc == Z_STREAM_ERROR) { deflateEnd(&zs); return io_fail(QM_E_IO, "deflate failed"); }
+    } while (zs.avail_in > 0 || (flush == Z_FINISH && rc != Z_STREAM_END));
+  }
+  deflateEnd(&zs);
+  return QM_OK;
+}
+
 struct qm_sam_writer {
   const qm_index* ix = nullptr; int fd = -1; int threads = 1; int32_t maxHits = 0;
+  bool gzip = false; int level = 1;
   std::vector<Out> bufs[2];
+  std::vector<Out> zbufs[2];        // gzip members of the parts (QM_SAM_GZIP)
   Pool* pool = nullptr;             // the formatter's workers
   int state[2] = {0, 0};            // 0 free, 1 formatted (waits for the writer)
   int fill = 0, drain = 0;
@@ -722,18 +751,40 @@ static void sam_writer_loop(qm_sam_writer* w) {
       if (w->state[w->drain] != 1) return;               // stop, nothing left
       k = w->drain;
     }
-    int rc = w->err ? 0 : write_parts(w->fd, w->bufs[k]);  // after a failure the remaining batches are dropped
+    std::vector<Out>& outp = w->gzip ? w->zbufs[k] : w->bufs[k];
+    int rc = w->err ? 0 : write_parts(w->fd, outp);         // after a failure the remaining batches are dropped
     std::unique_lock<std::mutex> lk(w->mu);
     if (rc) { w->err = rc; snprintf(w->errmsg, sizeof(w->errmsg), "%s", qm_io_last_error()); }
-    else if (!w->err) for (auto& p : w->bufs[k]) w->bytes += (int64_t)p.n;
+    else if (!w->err) for (auto& p : outp) w->bytes += (int64_t)p.n;
     w->state[k] = 0; w->drain ^= 1;
     w->cv.notify_all();
   }
 }
 int qm_sam_writer_open(const qm_index* ix, int fd, int32_t max_num_hits, int32_t n_threads, qm_sam_writer** out) {
+  return qm_sam_writer_open_ex(ix, fd, max_num_hits, n_threads, 0, out);
+}
+// queue what is in bufs[k] (compressing it first with QM_SAM_GZIP)
+static int sam_writer_submit(qm_sam_writer* w, int k) {
+  if (w->gzip) {
+    std::vector<Out>& P = w->bufs[k]; std::vector<Out>& Z = w->zbufs[k];
+    if (Z.size() < P.size()) Z.resize(P.size());
+    for (auto& z : Z) z.n = 0;
+    std::vector<int> rcs(P.size(), 0);
+    const std::function<void(int)> fn = [&](int t) { rcs[(size_t)t] = gz_member(P[(size_t)t], Z[(size_t)t], w->level); };
+    w->pool->run((int)P.size(), fn);
+    for (int r : rcs) if (r) return r;
+  }
+  std::unique_lock<std::mutex> lk(w->mu);
+  w->state[k] = 1; w->fill ^= 1;
+  w->cv.notify_all();
+  return QM_OK;
+}
+int qm_sam_writer_open_ex(const qm_index* ix, int fd, int32_t max_num_hits, int32_t n_threads, uint32_t flags, qm_sam_writer** out) {
   if (!ix || fd < 0 || !out) return io_fail(QM_E_ARG, "qm_sam_writer_open: bad argument");
   qm_sam_writer* w = new qm_sam_writer();
   w->ix = ix; w->fd = fd; w->threads = n_threads > 0 ? n_threads : 1; w->maxHits = max_num_hits;
+  w->gzip = (flags & QM_SAM_GZIP) != 0;
+  w->level = (int)((flags >> 8) & 15u); if (w->level < 1 || w->level > 9) w->level = 1;
   w->pool = new Pool(w->threads);
   w->wt = std::thread(sam_writer_loop, w);
   *out = w;
@@ -752,10 +803,26 @@ int qm_sam_writer_put(qm_sam_writer* w, int64_t n, const char* names1, const int
   }
   int rc = sam_parts(w->ix, n, names1, name_off1, seq1, off1, names2, name_off2, seq2, off2, hit_offsets, hits, w->maxHits, w->threads, w->bufs[k], w->pool);
   if (rc) return rc;
-  std::unique_lock<std::mutex> lk(w->mu);
-  w->state[k] = 1; w->fill ^= 1;
-  w->cv.notify_all();
-  return QM_OK;
+  return sam_writer_submit(w, k);
+}
+int qm_sam_writer_header(qm_sam_writer* w) {
+  if (!w) return io_fail(QM_E_ARG, "qm_sam_writer_header: bad argument");
+  char* h = nullptr; int64_t hn = 0;
+  int rc = qm_sam_header(w->ix, &h, &hn);
+  if (rc) return rc;
+  int k;
+  {
+    std::unique_lock<std::mutex> lk(w->mu);
+    w->cv.wait(lk, [&] { return w->state[w->fill] == 0; });
+    if (w->err) { qm_buf_free(h); return io_fail(w->err, "%s", w->errmsg); }
+    k = w->fill;
+  }
+  std::vector<Out>& P = w->bufs[k];
+  if (P.empty()) P.resize(1);
+  for (auto& p : P) p.n = 0;
+  P[0].need((size_t)hn + 1); P[0].raw(h, (size_t)hn);
+  qm_buf_free(h);
+  return sam_writer_submit(w, k);
 }
 int qm_sam_writer_close(qm_sam_writer* w, int64_t* bytes_written) {
   if (!w) return QM_OK;

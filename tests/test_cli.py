@@ -47,6 +47,13 @@ def test_quasimap_cli_sample_data_sam(sample_data, tmp_path):
     text = "".join(l for l in open(out) if not l.startswith("@PG"))
     want = open(os.path.join(SD, "expected_sam_body.md5")).read().strip()
     assert hashlib.md5(text.encode()).hexdigest() == want
+    # -x: the same text as a gzip stream (members compressed in parallel by the writer), to a file and to stdout
+    import gzip
+    outz = tmp_path / "out.sam.gz"
+    r = _run(["quasimap", "-i", sample_data["idx"], "-1", os.path.join(SD, "reads_1.fastq.gz"), "-2",
+              os.path.join(SD, "reads_2.fastq.gz"), "-o", str(outz), "-t", "3", "-x"])
+    assert r.returncode == 0, r.stderr
+    assert gzip.open(outz, "rb").read() == open(out, "rb").read()
 
 
 @pytest.mark.gpu

@@ -156,6 +156,22 @@ def test_sam_writer_matches_python_formatter(synth_small, oracle_mod, opts):
         finally:
             os.close(fd)
         assert open(nf.name, "rb").read() == b"@HD\tpre-existing line\n" + got * 5
+    # -x: gzip members compressed side by side; the file is one valid .gz stream holding header + records
+    import gzip as _gz
+    with tempfile.NamedTemporaryFile(suffix=".sam.gz") as nf:
+        fd = os.open(nf.name, os.O_WRONLY)
+        try:
+            w = ra.SamWriter(qi, fd, max_num_hits=oo.maxNumHits, threads=4, gzip=True)
+            w.header()
+            for _ in range(3):
+                w.put(b, res.hit_offsets, res.hits)
+            nbz = w.close()
+        finally:
+            os.close(fd)
+        raw = open(nf.name, "rb").read()
+        assert nbz == len(raw) and raw[:2] == b"\x1f\x8b"
+        assert _gz.decompress(raw) == ra.sam_header_text(qi) + got * 3
+        assert len(raw) < (len(got) * 3) // 2
     # ... and a descriptor that cannot be written: the error surfaces in put or close, not as a crash
     rfd = os.open(os.devnull, os.O_RDONLY)
     try:
