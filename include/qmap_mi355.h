@@ -225,6 +225,10 @@ int qm_ctx_stat(const qm_ctx* ctx, int which, int64_t* value);
  * perfect_hash -- hash_info.bph / hash_info.val come out byte-identical to the reference's).  Host only. */
 int qm_build_index(const char* fasta_path, const char* out_dir, int32_t k, int32_t no_clip_poly_a,
                    int32_t keep_duplicates, int32_t n_threads, int32_t perfect_hash);
+/* ... with `-s / --headerSep` (src/RapMapSAIndexer.cpp:833-835,868,588): the transcript's name is its header up to the first
+ * of these characters (NULL: space or tab, the default) */
+int qm_build_index_ex(const char* fasta_path, const char* out_dir, int32_t k, int32_t no_clip_poly_a,
+                      int32_t keep_duplicates, int32_t n_threads, int32_t perfect_hash, const char* header_sep);
 
 /* ---- host-side callers of the path -------------------------------------------
  * Read ingest: replaces fastx_parser::FastxParser<ReadPair|ReadSeq> (include/FastxParser.hpp:62-66,

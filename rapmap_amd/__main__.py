@@ -21,6 +21,8 @@ def _quasiindex(argv):
     ap.add_argument("-p", "--perfectHash", action="store_true", help="Use a perfect hash instead of dense hash (BooPHF)")
     ap.add_argument("-n", "--noClip", action="store_true", help="Don't clip poly-A tails from the ends of target sequences")
     ap.add_argument("--keepDuplicates", action="store_true", help="Retain and index exact sequence-level duplicates")
+    ap.add_argument("-s", "--headerSep", default=None, help="Instead of a space or tab, break the header at the first occurrence of "
+                    "(one of the characters of) this string, and name the transcript as the token before the first separator")
     ap.add_argument("-x", "--numThreads", type=int, default=4, help="Threads for the k-mer interval scan / perfect hash")
     a = ap.parse_args(argv)
     if a.klen % 2 == 0 or a.klen > 31 or a.klen < 1:
@@ -28,7 +30,7 @@ def _quasiindex(argv):
     import rapmap_amd as ra
     t = time.time()
     ra.build_index(a.transcripts, a.index, k=a.klen, no_clip_poly_a=a.noClip, keep_duplicates=a.keepDuplicates,
-                   threads=a.numThreads, perfect_hash=a.perfectHash)
+                   threads=a.numThreads, perfect_hash=a.perfectHash, header_sep=a.headerSep)
     print("[rapmap_amd] index written to %s (%.1fs)" % (a.index, time.time() - t), file=sys.stderr)
 
 

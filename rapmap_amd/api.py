@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "qm_last_error", "qm_version", "qm_opts_default", "qm_index_open", "qm_index_close", "qm_index_info_get",
     "qm_index_txp_name", "qm_index_txp_len", "qm_index_arrays", "qm_ctx_create", "qm_ctx_destroy", "qm_ctx_device_bytes",
     "qm_map_pairs", "qm_map_reads", "qm_map_device", "qm_fetch_hits", "qm_result_device", "qm_ctx_set_debug",
-    "qm_fetch_intervals", "qm_last_kernel_ms", "qm_ctx_stat", "qm_build_index",
+    "qm_fetch_intervals", "qm_last_kernel_ms", "qm_ctx_stat", "qm_build_index", "qm_build_index_ex",
     "qm_collect_reads", "qm_fetch_found", "qm_hits_to_mappings", "qm_fetch_read_lists", "qm_merge_lists", "qm_fetch_too_many",
     "qm_map_pairs_stages", "qm_ctx_create_ex", "qm_fetch_hits_pinned",
     "qm_stream_open", "qm_stream_next", "qm_stream_close", "qm_stream_last_error", "qm_stream_stats",
@@ -137,6 +137,7 @@ def lib():
     L.qm_stream_last_error.restype = C.c_char_p
     L.qm_fetch_hits_pinned.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.qm_build_index.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    L.qm_build_index_ex.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_char_p]
     L.qm_opts_default.argtypes = [C.POINTER(QmOpts)]
     L.qm_io_last_error.restype = C.c_char_p
     L.qm_reader_open.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]
@@ -173,11 +174,11 @@ def default_opts(**kw):
     return o
 
 
-def build_index(fasta, out_dir, k=31, no_clip_poly_a=False, keep_duplicates=False, threads=None, perfect_hash=False):
-    """`rapmap quasiindex -t FASTA -i OUT -k K [-p]` (src/RapMapSAIndexer.cpp:821-927), int32 SA."""
+def build_index(fasta, out_dir, k=31, no_clip_poly_a=False, keep_duplicates=False, threads=None, perfect_hash=False, header_sep=None):
+    """`rapmap quasiindex -t FASTA -i OUT -k K [-p] [-s SEP]` (src/RapMapSAIndexer.cpp:821-927), int32 SA."""
     threads = threads or min(32, os.cpu_count() or 1)
-    rc = lib().qm_build_index(os.fsencode(fasta), os.fsencode(out_dir), k, int(no_clip_poly_a), int(keep_duplicates), threads,
-                              int(perfect_hash))
+    rc = lib().qm_build_index_ex(os.fsencode(fasta), os.fsencode(out_dir), k, int(no_clip_poly_a), int(keep_duplicates), threads,
+                                 int(perfect_hash), header_sep.encode() if header_sep is not None else None)
     if rc != 0:
         lib().qm_indexer_last_error.restype = C.c_char_p
         raise QmError("qm_build_index failed (%d): %s" % (rc, lib().qm_indexer_last_error().decode()))

@@ -305,8 +305,14 @@ thread_local char g_ierr[256];
 
 extern "C" const char* qm_indexer_last_error(void) { return g_ierr; }
 
+extern "C" int qm_build_index_ex(const char* fasta_path, const char* out_dir_c, int32_t k, int32_t no_clip_poly_a,
+                                 int32_t keep_duplicates, int32_t n_threads, int32_t perfect_hash, const char* header_sep);
 extern "C" int qm_build_index(const char* fasta_path, const char* out_dir_c, int32_t k, int32_t no_clip_poly_a,
                               int32_t keep_duplicates, int32_t n_threads, int32_t perfect_hash) {
+  return qm_build_index_ex(fasta_path, out_dir_c, k, no_clip_poly_a, keep_duplicates, n_threads, perfect_hash, nullptr);
+}
+extern "C" int qm_build_index_ex(const char* fasta_path, const char* out_dir_c, int32_t k, int32_t no_clip_poly_a,
+                                 int32_t keep_duplicates, int32_t n_threads, int32_t perfect_hash, const char* header_sep) {
   auto fail = [&](int code, const char* msg) { snprintf(g_ierr, sizeof(g_ierr), "%s", msg); return code; };
   if (!fasta_path || !out_dir_c) return fail(QM_E_ARG, "null path");
   if (k < 1 || k > 31 || (k % 2) == 0) return fail(QM_E_ARG, "k must be odd and <= 31 (RapMapSAIndexer.cpp:870-877)");
@@ -325,7 +331,7 @@ extern "C" int qm_build_index(const char* fasta_path, const char* out_dir_c, int
   const char bases[] = {'A', 'C', 'G', 'T'};
   const uint32_t polyAClipLength = 10;
   const std::string polyA(polyAClipLength, 'A');
-  const std::string sepStr = " \t";
+  const std::string sepStr = header_sep ? header_sep : " \t";   // -s / --headerSep (RapMapSAIndexer.cpp:833-835,868): a set of characters, as find_first_of takes it
   struct DupInfo { uint64_t txId, txOffset; uint32_t txLen; };
   std::map<uint64_t, std::vector<DupInfo>> potentialDuplicates;
   std::vector<std::pair<std::string, std::string>> dupNames;   // (retained, dropped)
