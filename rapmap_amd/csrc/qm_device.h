@@ -5,6 +5,7 @@
 
 #define QMK_BLOCKS_PER_CU 8
 // waves per SIMD the register allocator must leave room for, per flavour of the stage-A kernel (reads <= 128 bp)
+#define QM_SEL_CHUNKS_B 4      // -s: chunks of units the plan -> ksw2 -> finish kernels go through (host side)
 #define QMK_DEFAULT_WPS 8
 #define QMK_WPS_PH 6
 #define QMK_WPS_NIP 8
@@ -31,7 +32,8 @@ unsigned long long qmk_sel_dyn_bytes(long long n);
 void qmk_sel_dyn_bind(void* host_struct, void* dev_base, long long n);
 hipError_t qmk_collect_slow(const unsigned int* lcnt, long long nreads, long long* q, unsigned long long* count, hipStream_t st);
 hipError_t qmk_sel_slots(const void* pair_batch, hipStream_t st);
-hipError_t qmk_sel_three(const void* pair_batch, const void* sel_batch, int num_cu, hipStream_t st);
+hipError_t qmk_sel_plan(const void* pair_batch, const void* sel_batch, hipStream_t st);
+hipError_t qmk_sel_align_finish(const void* pair_batch, const void* sel_batch, int num_cu, hipStream_t st);
 size_t qmk_sel_task_bytes(void);
 hipError_t qmk_sel_compact(const void* pair_batch, const void* tmp, const void* toff, hipStream_t st);
 hipError_t qmk_pair_count(const void* pair_batch, hipStream_t st);

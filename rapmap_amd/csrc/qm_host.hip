@@ -96,6 +96,9 @@ struct qm_ctx {
   std::shared_ptr<Replica> rep;
   int device = 0, numCU = 256;
   hipStream_t stream = nullptr, copyStream = nullptr;      // kernels / host-buffer uploads (overlapped chunk by chunk)
+  hipStream_t planStream = nullptr;                         // -s: the plan kernels of the later chunks, under the ksw2 kernel of the earlier ones
+  hipEvent_t evPlan[QM_SEL_CHUNKS_B + 1] = {};              // ... [i]: chunk i planned; [last]: the plan stream may start
+  u64* d_ntk = nullptr;                                     // ... one task counter per chunk
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evA = nullptr, evB = nullptr, evCopy = nullptr, evStage[2] = {nullptr, nullptr};
   unsigned char* h_stage = nullptr;                        // pinned, 2 x 32 MB: result download (qm_fetch_hits)
   // index replica
@@ -368,6 +371,9 @@ int qm_ctx_destroy(qm_ctx* c) {
   if (c->evB) hipEventDestroy(c->evB);
   if (c->stream) hipStreamDestroy(c->stream);
   if (c->copyStream) hipStreamDestroy(c->copyStream);
+  if (c->planStream) hipStreamDestroy(c->planStream);
+  for (hipEvent_t e : c->evPlan) if (e) hipEventDestroy(e);
+  if (c->d_ntk) hipFree(c->d_ntk);
   if (c->evCopy) hipEventDestroy(c->evCopy);
   if (c->evStage[0]) hipEventDestroy(c->evStage[0]);
   if (c->evStage[1]) hipEventDestroy(c->evStage[1]);
@@ -394,6 +400,9 @@ int qm_ctx_create_ex(const qm_index* ix, int device_id, uint32_t flags, qm_ctx**
 #define CK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { int rc = fail(QM_E_NOGPU, "%s: %s", #x, hipGetErrorString(_e)); qm_ctx_destroy(c); return rc; } } while (0)
   CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   CK(hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
+  CK(hipStreamCreateWithFlags(&c->planStream, hipStreamNonBlocking));
+  for (hipEvent_t& e : c->evPlan) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  CK(hipMalloc((void**)&c->d_ntk, QM_SEL_CHUNKS_B * sizeof(u64)));
   CK(hipEventCreateWithFlags(&c->evCopy, hipEventDisableTiming));
   CK(hipEventCreate(&c->ev0)); CK(hipEventCreate(&c->ev1)); CK(hipEventCreate(&c->evA)); CK(hipEventCreate(&c->evB));
   CK(hipMalloc((void**)&c->d_scal, QM_SC_WORDS * sizeof(u64)));
@@ -738,7 +747,15 @@ static int run_stage_b(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
     HIPCHK(hipMemcpyAsync(c->d_toff, c->d_offs, (size_t)(n + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
     long long slots = 0;
     HIPCHK(hipMemcpyAsync(&slots, c->d_offs + n, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    // chunks of units for plan -> ksw2 -> finish, and where each chunk's slots start (its share of the task buffer)
+    const char* cuEnv = getenv("QM_SEL_CHUNK_UNITS");        // (tests: chunk small batches too)
+    const int64_t minChunk = cuEnv && atoll(cuEnv) > 0 ? atoll(cuEnv) : 65536;
+    const int K = n >= (int64_t)QM_SEL_CHUNKS_B * minChunk ? QM_SEL_CHUNKS_B : 1;
+    long long cu[QM_SEL_CHUNKS_B + 1], cslot[QM_SEL_CHUNKS_B + 1];
+    for (int i = 0; i <= K; ++i) { cu[i] = n * i / K; cslot[i] = 0; }
+    for (int i = 1; i < K; ++i) HIPCHK(hipMemcpyAsync(&cslot[i], c->d_offs + cu[i], sizeof(long long), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    cslot[K] = slots;
     if ((rc = ensure(c->d_tmp, c->capTmp, slots + 1))) return rc;
     if ((rc = ensure(c->d_tkeys, c->capTkeys, 2 * slots + 2))) return rc;
     if ((rc = ensure(c->d_tsc, c->capTsc, 2 * slots + 2))) return rc;
@@ -754,10 +771,26 @@ static int run_stage_b(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
       // plan (per unit) -> ksw2 extension alignments, four per wavefront, any band -> finish (per unit)
       if ((rc = ensure(c->d_tref, c->capTref, 2 * slots + 2))) return rc;
       if ((rc = ensure(c->d_tcix, c->capTcix, 2 * slots + 2))) return rc;
-      if ((rc = ensure(c->d_tasks, c->capTasks, (2 * slots + 2) * (int64_t)qmk_sel_task_bytes()))) return rc;
-      A.tref = c->d_tref; A.tcix = c->d_tcix; A.tasks = (SelTask*)c->d_tasks; A.ntasks = c->d_scal + QM_SC_NTASKS;
-      HIPCHK(hipMemsetAsync(c->d_scal + QM_SC_NTASKS, 0, sizeof(u64), c->stream));
-      HIPCHK(qmk_sel_three(&P, &A, c->numCU, c->stream));
+      if ((rc = ensure(c->d_tasks, c->capTasks, (2 * slots + 2 * K + 2) * (int64_t)qmk_sel_task_bytes()))) return rc;
+      A.tref = c->d_tref; A.tcix = c->d_tcix;
+      HIPCHK(hipMemsetAsync(c->d_ntk, 0, QM_SEL_CHUNKS_B * sizeof(u64), c->stream));
+      // The plan kernel is one divergent thread per unit -- 4 ms of instructions, 29 ms of latency on 10 M units -- and the
+      // ksw2 kernel is bound by VALU issue: the plans of chunks 1.. run on a stream of their own while the alignments of
+      // the chunks before them are computed.
+      HIPCHK(hipEventRecord(c->evPlan[QM_SEL_CHUNKS_B], c->stream));
+      HIPCHK(hipStreamWaitEvent(c->planStream, c->evPlan[QM_SEL_CHUNKS_B], 0));
+      SelBatch Ak[QM_SEL_CHUNKS_B];
+      for (int i = 0; i < K; ++i) {
+        Ak[i] = A; Ak[i].u0 = cu[i]; Ak[i].u1 = cu[i + 1];
+        Ak[i].tasks = (SelTask*)(c->d_tasks + (size_t)(2 * cslot[i] + 2 * i) * qmk_sel_task_bytes());   // at most two tasks per slot
+        Ak[i].ntasks = c->d_ntk + i;
+        HIPCHK(qmk_sel_plan(&P, &Ak[i], K > 1 ? c->planStream : c->stream));
+        if (K > 1) HIPCHK(hipEventRecord(c->evPlan[i], c->planStream));
+      }
+      for (int i = 0; i < K; ++i) {
+        if (K > 1) HIPCHK(hipStreamWaitEvent(c->stream, c->evPlan[i], 0));
+        HIPCHK(qmk_sel_align_finish(&P, &Ak[i], c->numCU, c->stream));
+      }
     }
   } else {
     HIPCHK(qmk_pair_count(&P, c->stream));

@@ -127,9 +127,9 @@ __global__ __launch_bounds__(256) void qm_sel_plan_kernel(PairBatch P, SelBatch 
   __shared__ unsigned long long sc[6];
   if (threadIdx.x < 6) sc[threadIdx.x] = 0;
   __syncthreads();
-  const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long u = A.u0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
   UnitCounters uc = {0, 0, 0, 0, 0, 0};
-  if (u < P.n) sel_unit_plan(P, A, u, &uc);
+  if (u < A.u1) sel_unit_plan(P, A, u, &uc);
   sel_flush_counters(sc, uc, P.counters);
 }
 // one row of 16 lanes per ksw2 alignment, four alignments per wavefront (sel_ksw_extz2_rows); RING = column slots per
@@ -146,9 +146,9 @@ __global__ __launch_bounds__(256) void qm_sel_finish_kernel(PairBatch P, SelBatc
   __shared__ unsigned long long sc[6];
   if (threadIdx.x < 6) sc[threadIdx.x] = 0;
   __syncthreads();
-  const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long u = A.u0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
   UnitCounters uc = {0, 0, 0, 0, 0, 0};
-  if (u < P.n) P.cnt[u] = (u32)sel_unit_finish(P, A, u, &uc);
+  if (u < A.u1) P.cnt[u] = (u32)sel_unit_finish(P, A, u, &uc);
   sel_flush_counters(sc, uc, P.counters);
 }
 
@@ -345,11 +345,17 @@ hipError_t qmk_sel_slots(const void* pp, hipStream_t st) {
   hipLaunchKernelGGL(qm_sel_slots_kernel, dim3((unsigned)((P.n + 1 + 255) / 256)), dim3(256), 0, st, P);
   return hipGetLastError();
 }
-hipError_t qmk_sel_three(const void* pp, const void* ap, int num_cu, hipStream_t st) {
+// the three steps of a chunk of units [A.u0, A.u1): plan (per unit) -> ksw2 (four alignments per wavefront) -> finish (per unit)
+hipError_t qmk_sel_plan(const void* pp, const void* ap, hipStream_t st) {
   const PairBatch& P = *(const PairBatch*)pp; const SelBatch& A = *(const SelBatch*)ap;
-  if (P.n <= 0) return hipSuccess;
-  const unsigned nb = (unsigned)((P.n + 255) / 256);
-  hipLaunchKernelGGL(qm_sel_plan_kernel, dim3(nb), dim3(256), 0, st, P, A);
+  if (A.u1 <= A.u0) return hipSuccess;
+  hipLaunchKernelGGL(qm_sel_plan_kernel, dim3((unsigned)((A.u1 - A.u0 + 255) / 256)), dim3(256), 0, st, P, A);
+  return hipGetLastError();
+}
+hipError_t qmk_sel_align_finish(const void* pp, const void* ap, int num_cu, hipStream_t st) {
+  const PairBatch& P = *(const PairBatch*)pp; const SelBatch& A = *(const SelBatch*)ap;
+  if (A.u1 <= A.u0) return hipSuccess;
+  const unsigned nb = (unsigned)((A.u1 - A.u0 + 255) / 256);
   switch (sel_ksw_ring_slots(A.bandwidth)) {            // one kernel for every --dpBandwidth: the band decides the ring
     case 64: hipLaunchKernelGGL((qm_sel_align_kernel<64, 4>), dim3((unsigned)(num_cu * 8)), dim3(256), 0, st, P, A); break;
     case 128: hipLaunchKernelGGL((qm_sel_align_kernel<128, 4>), dim3((unsigned)(num_cu * 4)), dim3(256), 0, st, P, A); break;

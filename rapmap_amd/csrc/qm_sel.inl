@@ -528,6 +528,8 @@ struct SelBatch {                    // launch arguments of the -s kernels (on t
   int* tref;                                   // per slot-side: -1 score is final / pending in tsc, <= -2 copy of unit-local entry -(ref)-2
   int* tcix;                                   // alignment-cache entries: unit-local entry a key belongs to
   struct SelTask* tasks; u64* ntasks;          // ksw2 work list
+  long long u0, u1;                            // the units [u0, u1) this launch of plan / finish covers (the batch goes through
+                                               // plan -> align -> finish in chunks: the plan of chunk i+1 runs under the align of chunk i)
   int match, mismatch, gap_open, gap_extend, bandwidth, hard_filter, policy;
   double min_score_fraction;
 };

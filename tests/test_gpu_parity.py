@@ -376,6 +376,24 @@ def test_selective_alignment(synth_small, oracle_mod, case):
     assert rs.counters == gs.counters
 
 
+def test_selective_alignment_in_chunks(synth_small, oracle_mod, monkeypatch):
+    """stage B/C of -s in four chunks of units (the plan kernels of the later chunks on a stream of their own under the ksw2
+    kernel of the earlier ones): what 10 M-pair batches do, forced onto a small one"""
+    import rapmap_amd as ra
+    monkeypatch.setenv("QM_SEL_CHUNK_UNITS", "500")
+    ix, orc = load_oracle(synth_small["idx"])
+    qi, mp = _gpu(synth_small["idx"], debug=False)
+    q1, o1 = pack(synth_small["reads1"]); q2, o2 = pack(synth_small["reads2"])
+    for oo, go in (({"selAln": 1}, {"sel_aln": 1}), ({"selAln": 1, "hardFilter": 1, "maxNumHits": 5}, {"sel_aln": 1, "hard_filter": 1, "max_num_hits": 5})):
+        res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=4)
+        gr = mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(**go))
+        assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "-s in chunks %s" % oo)
+        assert res.counters == gr.counters
+    rs = orc.map_single(q1, o1, opts=oracle_mod.default_opts(selAln=1), nthreads=4)
+    gs = mp.map_reads(q1, o1, opts=ra.default_opts(sel_aln=1))
+    assert_hits_equal(rs.hit_offsets, rs.hits, gs.hit_offsets, gs.hits, "-s in chunks, single-end")
+
+
 def test_selective_alignment_medium(synth_medium, oracle_mod):
     """-s on 20 k pairs against the ~5 k-transcript index"""
     import rapmap_amd as ra
