@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Extra fuzzing of the HIP path against the oracle beyond what the -m gpu suite runs each time: more seeds, more read-length
-classes, more option sets.  python profiles/fuzz_more.py [n_pairs] [seeds]  (GPU box; builds a small synthetic index)."""
+classes, more option sets.  python profiles/fuzz_more.py [n_pairs] [seeds] [first seed]  (GPU box; builds a small synthetic index)."""
 import os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -14,6 +14,7 @@ import test_gpu_parity as T
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 oracle.build()
 d = tempfile.mkdtemp(prefix="fuzz", dir="/dev/shm")
 names, txps = synth.make_transcriptome(600, seed=11)
@@ -25,7 +26,7 @@ for ph in (False, True):
     text, offsets = qi.arrays()
     for compact in ((False, True) if ph else (False,)):
         mp = ra.QuasiMapper(qi, 0, ph_compact=compact)
-        for seed in range(seeds):
+        for seed in range(seed0, seed0 + seeds):
             for max_len in (100, 128, 150, 192, 250, 400):
                 r1, r2 = T._fuzz_reads(np.asarray(text), np.asarray(offsets, dtype=np.int64), n if max_len <= 256 else n // 4, 1000 * seed + max_len, max_len)
                 q1, o1 = pack(r1); q2, o2 = pack(r2)
