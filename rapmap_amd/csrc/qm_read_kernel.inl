@@ -96,10 +96,8 @@ static hipError_t launch_reads_ns(const DevIndex& ix, const ReadBatch& B, bool c
     case QM_F_PH: QM_LAUNCH(WPH, QM_F_PH); break;
     case QM_F_NIP: QM_LAUNCH(WNIP, QM_F_NIP); break;
     case QM_F_PH | QM_F_NIP: QM_LAUNCH(WPHNIP, QM_F_PH | QM_F_NIP); break;
-    case QM_F_SEL: QM_LAUNCH(WSEL, QM_F_SEL); break;
-    case QM_F_SEL | QM_F_PH: QM_LAUNCH(WSEL, QM_F_SEL | QM_F_PH); break;
-    case QM_F_SEL | QM_F_NIP: QM_LAUNCH(WSEL, QM_F_SEL | QM_F_NIP); break;
-    default: QM_LAUNCH(WSEL, QM_F_SEL | QM_F_PH | QM_F_NIP); break;
+    // -s never runs as one fused kernel: the host launches the chain-scoring collector (above) and qm_h2m_kernel<QM_F_SEL>
+    default: return hipErrorInvalidValue;
   }
 #undef QM_LAUNCH
   return hipGetLastError();
