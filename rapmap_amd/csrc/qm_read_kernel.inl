@@ -1,4 +1,4 @@
-// qm_read_kernel.inl -- the stage-A kernel template and its per-slot-count launch wrappers.  The 40 instantiations
+// qm_read_kernel.inl -- the stage-A kernel template and its per-slot-count launch wrappers.  The 36 instantiations
 // (read-length class x index flavour x --noSensitive x -s, plus the collector-only stage entry) are spread over four
 // translation units -- qm_kernels_ns{2,3,4,8}.hip, each defining qmk_launch_reads_ns<N> -- so that they compile in parallel.
 #pragma once
