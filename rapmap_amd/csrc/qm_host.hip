@@ -96,6 +96,7 @@ struct qm_ctx {
   std::shared_ptr<Replica> rep;
   int device = 0, numCU = 256;
   hipStream_t stream = nullptr, copyStream = nullptr;      // kernels / host-buffer uploads (overlapped chunk by chunk)
+  unsigned int* d_sanext = nullptr;                         // -s: text characters behind every suffix's k-mer, built at the first -s call
   hipStream_t planStream = nullptr;                         // -s: the plan kernels of the later chunks, under the ksw2 kernel of the earlier ones
   hipEvent_t evPlan[QM_SEL_CHUNKS_B + 1] = {};              // ... [i]: chunk i planned; [last]: the plan stream may start
   u64* d_ntk = nullptr;                                     // ... one task counter per chunk
@@ -371,6 +372,7 @@ int qm_ctx_destroy(qm_ctx* c) {
   if (c->evB) hipEventDestroy(c->evB);
   if (c->stream) hipStreamDestroy(c->stream);
   if (c->copyStream) hipStreamDestroy(c->copyStream);
+  if (c->d_sanext) hipFree(c->d_sanext);
   if (c->planStream) hipStreamDestroy(c->planStream);
   for (hipEvent_t e : c->evPlan) if (e) hipEventDestroy(e);
   if (c->d_ntk) hipFree(c->d_ntk);
@@ -563,6 +565,7 @@ static DevIndex dev_index(const qm_ctx* c) {
   DevIndex ix; ix.text = c->d_text; ix.n = c->ix->n; ix.SA = c->d_SA; ix.nSA = c->ix->nSA;
   ix.sainfo = (const SaInfo*)c->d_sainfo; ix.slots = (const Bucket*)c->d_slots; ix.hmask = c->cap - 1; ix.ph = (const PhIndex*)c->d_ph; ix.k = c->ix->k;
   memset(&ix.phv, 0, sizeof(ix.phv)); if (c->d_ph) ix.phv = c->hPh;
+  ix.sanext = c->d_sanext;
   return ix;
 }
 
@@ -594,6 +597,13 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
   }
   const bool wantFound = rq.keepFound || rq.mode == QM_RUN_COLLECT || twoPass;
   if (wantFound) { if ((rc = ensure(c->d_found, c->capFound, nreads + 1))) return rc; }
+  if (o->sel_aln && rq.mode != QM_RUN_FROM_INTERVALS && !c->d_sanext && c->ix->nSA > 0) {
+    // first -s call of this context: the table that turns a capped MMP extension into one trip (sanext_entry); 4 bytes per
+    // suffix-array entry, built from text and SA as they sit in HBM
+    HIPCHK(hipMalloc((void**)&c->d_sanext, (size_t)c->ix->nSA * sizeof(unsigned int)));
+    HIPCHK(qmk_build_sanext(c->d_text, c->ix->n, c->d_SA, c->ix->nSA, c->ix->k, c->d_sanext, c->stream));
+    c->devBytes += c->ix->nSA * 4;
+  }
   const DevIndex ix = dev_index(c);
   c->lastRelaunches = 0; c->lastSlowReads = 0; c->lastIvTotal = 0;
   while (true) {

@@ -191,6 +191,13 @@ __global__ void build_sainfo_kernel(const int* SA, long long nSA, const int* off
   }
 }
 
+// -s: the text characters behind the k-mer of every suffix (sanext_entry)
+__global__ void build_sanext_kernel(const unsigned char* text, long long n, const int* SA, long long nSA, int k, u32* out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < nSA; i += stride) out[i] = sanext_entry(text, n, (long long)SA[i] + k);
+}
+
 // records: K x {u64 key, i32 lb, i32 ub} exactly as streamed from hash.bin
 __global__ void build_slots_kernel(const Slot* recs, long long K, Bucket* buckets, u64 hmask) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -263,6 +270,10 @@ hipError_t qmk_build_sainfo(const int* SA, long long nSA, const int* offsets, lo
   return hipGetLastError();
 }
 
+hipError_t qmk_build_sanext(const unsigned char* text, long long n, const int* SA, long long nSA, int k, unsigned int* out, hipStream_t st) {
+  if (nSA > 0) hipLaunchKernelGGL(build_sanext_kernel, dim3(4096), dim3(256), 0, st, text, n, SA, nSA, k, out);
+  return hipGetLastError();
+}
 hipError_t qmk_build_slots(const void* recs, long long K, void* slots, unsigned long long cap, hipStream_t st) {
   hipError_t e = hipMemsetAsync(slots, 0xff, cap * sizeof(Bucket), st);
   if (e != hipSuccess) return e;

@@ -102,6 +102,7 @@ struct DevIndex {
   const SaInfo* sainfo;
   const Bucket* slots;        // dense index: hmask + 1 buckets (null for a perfect-hash index)
   u64 hmask;
+  const u32* sanext;          // -s: per SA entry, the QM_NEXT_BASES text characters behind its k-mer (sanext_entry), or null
   const PhIndex* ph;          // perfect-hash index (null for a dense index): the flag the kernels are chosen by
   PhIndex phv;                // ... and its contents, by value: as kernel arguments the fields are scalar loads and the
                               // pointers are known to be global (loaded from a struct in memory they would be generic
@@ -254,6 +255,25 @@ __shared__ u64 qm_tim[4][10];
 #define QM_F_NIP 2     // --noSensitive: NIP skipping + k-mer vote
 #define QM_F_SEL 4     // --selAln: chain scoring in the collector (MMPs capped at k + maxMMPExtension), coverage slack 1
 #define QM_F_COLLECT 8 // stage entry: the collector alone (intervals + foundHit out, no hit list)
+
+// -s caps every MMP but a read's first at k + maxMMPExtension characters (SACollector.hpp:557-575): what such an extension
+// compares is the handful of text characters behind the k-mer of each suffix of the interval.  sanext[i] holds them for
+// suffix SA[i], indexed like the interval itself, so the capped extension is ONE trip (to this table) instead of two
+// dependent ones (suffix array, then text): QM_NEXT_BASES characters at 2 bits, the first in the highest bits of a
+// 28-bit field, and in bits 28-31 how many of them are A C G T before a '$' or the end of the text.
+#define QM_NEXT_BASES 14
+QM_DEV u32 sanext_entry(const unsigned char* text, long long n, long long pos) {
+  u32 e = 0; int nv = 0;
+  for (int t = 0; t < QM_NEXT_BASES; ++t) {
+    if (pos + t >= n) break;
+    const unsigned char c = text[pos + t];
+    if (c != 'A' && c != 'C' && c != 'G' && c != 'T') break;
+    const u32 x = (c >> 1) & 3u;
+    e |= (x ^ (x >> 1)) << (26 - 2 * t);
+    nv = t + 1;
+  }
+  return e | ((u32)nv << 28);
+}
 
 // khash.find.
 // dense: exact lookup in the bucket table (RapMapUtils.hpp:65-67), a whole probe round at a time: find_dense_round.
@@ -812,9 +832,34 @@ QM_DEV int cmp_from(const DevIndex& ix, long long s, const unsigned char* q, int
 // compares the 16 bytes at offset 16c of the current round, so a 2x100 bp read needs one round for up to 8
 // suffixes: one coalesced SA load, then one round of text loads, instead of a dependent load per 8 bytes.
 QM_DEV bool extend_search_wide(const DevIndex& ix, int lbIn, int ubIn, int startAt, const unsigned char* q, int m0,
-                               int& lbOut, int& ubOut, int& lenOut) {
+                               int& lbOut, int& ubOut, int& lenOut, u32 qn, int nq) {
   const int width = ubIn - lbIn - 1;
   if (width < 1 || width > 64) return false;
+  if (nq > 0 && ix.sanext) {
+    // a capped extension of a clean strand: the nq (<= QM_NEXT_BASES) query characters behind the k-mer, packed like the
+    // table's entries (qn), against the entry of every suffix of the interval -- one lane per suffix, one load
+    LV<int> lc; LV<bool> on;
+    QM_LANES(l) {
+      int v = -1;
+      if (l < width) {
+        const u32 e = ix.sanext[lbIn + 1 + l];
+        const u32 x = ((e & 0x0fffffffu) >> (28 - 2 * nq)) ^ qn;
+        int matched = x ? ((__builtin_clz(x) - (32 - 2 * nq)) >> 1) : nq;
+        const int nv = (int)(e >> 28);
+        matched = matched < nv ? matched : nv;
+        v = startAt + matched;
+      }
+      lc[l] = v; on[l] = l < width;
+    }
+    const int mxq = wave_max(lc);
+    LV<bool> bestq;
+    QM_LANES(l) { bestq[l] = on[l] && lc[l] == mxq; }
+    const u64 bq = ballot(bestq);
+    lbOut = lbIn + 1 + ctz64(bq);
+    ubOut = lbIn + 1 + (63 - clz64(bq)) + 1;
+    lenOut = mxq;
+    return true;
+  }
   QM_CNT(5, 1); QM_CNT(6, width); QM_CNT(9, width == 1);
   int lg = 0;
   while ((1 << lg) < width) ++lg;
@@ -879,9 +924,9 @@ QM_DEV bool extend_search_wide(const DevIndex& ix, int lbIn, int ubIn, int start
 
 // SASearcher::extendSearchNaive (SASearcher.hpp:88-309)
 QM_DEV void extend_search(const DevIndex& ix, int lbIn, int ubIn, int startAt, const unsigned char* q, int m0,
-                          int& lbOut, int& ubOut, int& lenOut, bool qDollar) {
+                          int& lbOut, int& ubOut, int& lenOut, bool qDollar, u32 qn = 0, int nq = 0) {
   int rel;
-  if (!qDollar && extend_search_wide(ix, lbIn, ubIn, startAt, q, m0, lbOut, ubOut, lenOut)) return;
+  if (!qDollar && extend_search_wide(ix, lbIn, ubIn, startAt, q, m0, lbOut, ubOut, lenOut, qn, nq)) return;
   QM_CNT(8, 1);
   if (ubIn - lbIn == 2) {                         // :109-126
     lbIn += 1;
@@ -1010,9 +1055,14 @@ QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, c
       const int cut = p + k + B.max_mmp_ext < L ? p + k + B.max_mmp_ext : L;
       const bool firstAttempt = p == 0;
       const int lbP = lb, ubP = ub;
-      extend_search(ix, lb, ub, k, str + p, (firstAttempt ? L : cut) - p, lb, ub, mlen, V.dollar);
+      // the characters a capped extension may use, packed like the entries of ix.sanext (clean strands only: the image
+      // holds nothing but A C G T there)
+      const int nqc = cut - p - k;
+      u32 qn = 0; int nq = 0;
+      if (V.lazy && nqc >= 1 && nqc <= QM_NEXT_BASES) { qn = (u32)clean_kmer(V.planes, p + k, nqc); nq = nqc; }
+      extend_search(ix, lb, ub, k, str + p, (firstAttempt ? L : cut) - p, lb, ub, mlen, V.dollar, firstAttempt ? 0u : qn, firstAttempt ? 0 : nq);
       if (firstAttempt && !(mlen >= L) && mlen >= k + B.max_mmp_ext)
-        extend_search(ix, lbP, ubP, k, str + p, cut - p, lb, ub, mlen, V.dollar);
+        extend_search(ix, lbP, ubP, k, str + p, cut - p, lb, ub, mlen, V.dollar, qn, nq);
     }
     QM_T(3);
     const bool more = !lastSearch && p + mlen < L;     // the walk continues at kp after this MMP

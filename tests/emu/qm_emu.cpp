@@ -29,6 +29,13 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
   DevIndex ix; ix.text = text; ix.n = n; ix.SA = SA; ix.nSA = nSA; ix.sainfo = (const SaInfo*)sainfo;
   ix.slots = (const Bucket*)slots; ix.hmask = hmask; ix.k = k; ix.ph = (const PhIndex*)ph;
   memset(&ix.phv, 0, sizeof(ix.phv)); if (ph) ix.phv = *(const PhIndex*)ph;
+  std::vector<u32> sanext;                 // -s: the table of qm_host.hip's first -s call (build_sanext_kernel)
+  ix.sanext = nullptr;
+  if (o->sel_aln) {
+    sanext.resize((size_t)nSA);
+    for (long long i = 0; i < nSA; ++i) sanext[(size_t)i] = sanext_entry(text, n, (long long)SA[i] + k);
+    ix.sanext = sanext.data();
+  }
   const bool paired = seq2 != nullptr;
   const long long nreads = paired ? 2 * nunits : nunits;
   ReadBatch B; memset(&B, 0, sizeof(B));
