@@ -1,3 +1,5 @@
+"""First-pass vs second-pass cost of the pipelined stream in one process (plain / after torch init / with a large host array
+held): python profiles/e2e_probe2.py plain|torch|torchbig.  8 M synthetic pairs on tmpfs, two passes, stream stats printed."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 mode = sys.argv[1]
