@@ -10,10 +10,13 @@ N=8 12.5 M per GPU = BASELINE.json configs[2], 100 M pairs over the node), the i
 collective is the all-reduce of the six HitCounters per step (RCCL over xGMI).  `python bench.py --gpus N` without a
 launcher re-executes itself under torch.distributed.run with N ranks.
 
-Prints ONE JSON line on rank 0 (see the driver contract) with `roofline` and `cpu_baseline` objects.
+Prints ONE JSON line on rank 0 (see the driver contract) with `roofline` and `cpu_baseline` objects.  At N=1 the same
+line also carries, under `other_configs`, bounded legs of configs[3] (the -p index: BooPHF walked on the device, and the
+same index expanded into the bucket table at load) and configs[4] (-s), each with its own value, kernel time, roofline
+and parity against the oracle, and under `pcie_inclusive` / `end_to_end` what a caller with host buffers / FASTQ files sees.
 """
 import argparse
-import hashlib
+import ctypes
 import json
 import os
 import sys
@@ -28,6 +31,15 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+# the kernels a configuration launches for stage A (template arguments: 64-character slots, waves per SIMD the launch is
+# sized for, feature flags QM_F_PH = 1, QM_F_NIP = 2, QM_F_SEL = 4, QM_F_COLLECT = 8)
+KERNELS = {
+    "dense": "qm_read_kernel<2,8,0> (stage A: one wavefront per read)",
+    "ph_compact": "qm_read_kernel<2,6,1> (stage A: one wavefront per read, BooPHF levels walked per lookup)",
+    "ph_expanded": "qm_read_kernel<2,8,0> (stage A: one wavefront per read; the -p index expanded into the bucket table at load)",
+    "sel": "qm_read_kernel<2,8,12> (chain-scoring collector) + qm_h2m_kernel<4> (intervals -> position lists, chaining)",
+}
 
 
 def log(*a):
@@ -53,7 +65,7 @@ def build_or_reuse_index(genes, seed, k, rank, world, cache_root, perfect_hash=F
         t = time.time()
         ra.build_index(fa, idx, k=k, threads=min(32, os.cpu_count() or 1), perfect_hash=perfect_hash)
         os.remove(fa)
-        log("quasiindex built in %.1fs" % (time.time() - t))
+        log("quasiindex%s built in %.1fs" % (" -p" if perfect_hash else "", time.time() - t))
         open(done, "w").write("ok\n")
     if world > 1:
         dist.barrier()
@@ -115,6 +127,151 @@ def algorithmic_bytes_per_pair(work, n, read_len):
     return (2 * read_len + 16 * w["n_probe"] + 4 * w["n_sa"] + w["n_text"] + 24 * w["n_rank"] + 36 * w["n_hits"]), w
 
 
+def ph_walk_addend(idx_dir, n_probe):
+    """a probe of the reference's -p structure costs (levels visited) x 8 + 8 (rank sample) + 4 (data_) +
+    4 (SA) + 31 (text) + 1 (lens) bytes instead of the 16 of a dense find.  Levels visited: the expectation for a k-mer that
+    is not in the index (the large majority of the finds), from the bit densities of the levels of this hash_info.bph."""
+    from oracle import q5ph
+    boo = q5ph.BooPHF(os.path.join(idx_dir, "hash_info.bph"))
+    reach, levels = 1.0, 0.0
+    for (size, words, ranks), dom in zip(boo.levels, boo.domains):
+        dens = float(np.unpackbits(np.ascontiguousarray(words).view(np.uint8)).sum()) / max(1, dom)
+        levels += reach
+        reach *= (1.0 - dens)
+    return n_probe * (levels * 8 + 8 + 4 + 4 + 31 + 1 - 16), levels
+
+
+def pmc_traffic(key, n, genes):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this command (profiles/pmc_traffic.json): a counter
+    run cannot happen inside this process, so the figure is the one measured on this workload when the profile was taken --
+    per pair, scaled to this launch -- and says so."""
+    try:
+        ent = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(key) or {}
+        b = ent.get("hbm_bytes_per_launch")
+        if b is None or genes != 40000:
+            return None, None
+        return b * (n / float(ent.get("pairs_per_launch", 10_000_000))), ent.get("source", "profiles/pmc_traffic.json")
+    except Exception:
+        return None, None
+
+
+def fstype_of(path):
+    best, typ = "", "?"
+    try:
+        for line in open("/proc/mounts"):
+            f = line.split()
+            if len(f) >= 3 and os.path.abspath(path).startswith(f[1]) and len(f[1]) > len(best):
+                best, typ = f[1], f[2]
+    except Exception:
+        pass
+    return typ
+
+
+def interleave_memory(on):
+    """set_mempolicy(MPOL_INTERLEAVE over all nodes) for the allocations that follow (the oracle's 12 GB index is probed at
+    random by threads on both sockets: first-touch placement would put all of it behind one socket's memory controllers)"""
+    try:
+        libc = ctypes.CDLL(None, use_errno=True)
+        if on:
+            nodes = [int(x[4:]) for x in os.listdir("/sys/devices/system/node") if x.startswith("node") and x[4:].isdigit()]
+            if len(nodes) < 2:
+                return False
+            mask = ctypes.c_ulong(sum(1 << i for i in nodes))
+            return libc.syscall(238, 3, ctypes.byref(mask), ctypes.c_ulong(max(nodes) + 2)) == 0
+        return libc.syscall(238, 0, None, ctypes.c_ulong(0)) == 0
+    except Exception:
+        return False
+
+
+class Oracles:
+    """the CPU restatement, one instance per index directory (test infrastructure: the checker and the cpu_baseline leg)"""
+
+    def __init__(self):
+        self.cache = {}
+        self.interleaved = False
+
+    def get(self, idx_dir):
+        if idx_dir not in self.cache:
+            from oracle import oracle, q5
+            t = time.time()
+            oracle.build()
+            self.interleaved = interleave_memory(True)
+            try:
+                self.cache[idx_dir] = oracle.Oracle(q5.load(idx_dir))
+            finally:
+                interleave_memory(False)
+            log("oracle index %s ready (%.1fs)" % (os.path.basename(os.path.dirname(idx_dir)), time.time() - t))
+        return self.cache[idx_dir]
+
+
+def timed_steps(mp, opts, ptr, n, L, steps, warmup, world, device, qd):
+    """W untimed + K timed passes of the hot path, bracketed by barrier + synchronize; max over ranks"""
+    def step():
+        r = mp.map_device(n, ptr[0], ptr[1], ptr[2], ptr[3], L, opts=opts, fetch=False)
+        tot = qd.all_reduce_counters(r.counters, device=device)   # the path's only collective
+        return r, tot
+    for _ in range(warmup):
+        step()
+    kernel_ms = []
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r, tot = step()
+        kernel_ms.append(r.map_kernel_ms)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    tt = torch.tensor([el], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt.item()), kernel_ms, tot
+
+
+def cpu_and_parity(orc, mp, opts, oopts, s1, s2, off, ptr, n, L, cpu_seconds, sweep=True):
+    """the oracle on a bounded sample of the batch (thread sweep + sample on the same sample size when they fit the budget),
+    and the HIP path's hits on exactly that sample compared bit for bit"""
+    cores = os.cpu_count() or 1
+    res = {}
+    probe_n = min(n, 1_000_000)
+    h1 = s1[: probe_n * L].cpu().numpy(); h2 = s2[: probe_n * L].cpu().numpy(); ho = off[: probe_n + 1].cpu().numpy()
+    sweep_rates = {}
+    cand = sorted({cores, max(1, cores // 2), max(1, cores // 4)}, reverse=True) if sweep else [max(1, cores // 4)]
+    orc.map_pairs(h1[: 20000 * L], ho[:20001], h2[: 20000 * L], ho[:20001], opts=oopts, nthreads=cand[-1])   # page the index in
+    for T in cand:
+        r = orc.map_pairs(h1, ho, h2, ho, opts=oopts, nthreads=T)
+        sweep_rates[T] = probe_n / r.map_seconds
+    best_t = max(sweep_rates, key=sweep_rates.get)
+    rate = sweep_rates[best_t]
+    sample = int(min(n, max(probe_n, rate * cpu_seconds)))
+    h1 = s1[: sample * L].cpu().numpy(); h2 = s2[: sample * L].cpu().numpy(); ho = off[: sample + 1].cpu().numpy()
+    ores = orc.map_pairs(h1, ho, h2, ho, opts=oopts, nthreads=best_t)
+    gr = mp.map_device(sample, ptr[0], ptr[1], ptr[2], ptr[3], L, opts=opts, fetch=True)
+    parity = bool(np.array_equal(gr.hit_offsets, ores.hit_offsets) and gr.hits.tobytes() == ores.hits.tobytes())
+    res.update(sample=sample, best_t=best_t, sweep={str(k_): round(v / 1e6, 4) for k_, v in sorted(sweep_rates.items())}, probe_n=probe_n,
+               cpu_val=sample / ores.map_seconds / 1e6, map_seconds=ores.map_seconds, call_seconds=ores.call_seconds,
+               parity=parity, hits=int(ores.hit_offsets[-1]), work=ores.work, cores=cores, ores=ores)
+    return res
+
+
+def roofline(bpp, w, n, kernel_ms, kernel, traffic_key, genes, step_ms=None, extra=None):
+    ach = bpp * n / (kernel_ms * 1e-3) / 1e9
+    traffic, src = pmc_traffic(traffic_key, n, genes)
+    out = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+           "traffic": traffic, "traffic_source": src, "kernel": kernel, "kernel_ms": round(kernel_ms, 3),
+           "algorithmic_bytes_per_pair": round(bpp, 1), "per_pair_counters": {kk: round(v, 2) for kk, v in w.items()},
+           "pairs_per_launch": n}
+    if step_ms:
+        out["frac_of_whole_step"] = round(bpp * n / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+    if extra:
+        out.update(extra)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,12 +282,16 @@ def main():
                     "12.5 M at 8 GPUs = configs[2], 100 M pairs over the node)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="N=1: skip the bounded legs of configs[3] and configs[4]")
+    ap.add_argument("--no-side-legs", action="store_true", help="N=1: skip pcie_inclusive / end_to_end")
     ap.add_argument("--sel-aln", action="store_true", help="config 5: selective alignment (-s): chaining + ksw2 extension alignment of every hit")
     ap.add_argument("--perfect-hash", action="store_true", help="config 4: index built with `quasiindex -p` (BooPHF / FrugalBooMap probe path)")
     ap.add_argument("--ph-compact", action="store_true", help="with --perfect-hash: keep the BooPHF / FrugalBooMap structure on the device "
                     "(walked per lookup) instead of expanding the -p index into the one-sector bucket table at load time")
     ap.add_argument("--read-len", type=int, default=100, help="read length (BASELINE.json: 100; 129..256 runs the NS=4 kernels)")
     ap.add_argument("--cache", default=os.environ.get("QMAP_BENCH_CACHE", "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"))
+    ap.add_argument("--e2e-dir", default=os.environ.get("QMAP_BENCH_E2E_DIR", "/tmp"), help="where the end_to_end leg puts its FASTQ files")
+    ap.add_argument("--e2e-threads", type=int, default=32)
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -186,32 +347,9 @@ def main():
     opts = ra.default_opts(sel_aln=1) if args.sel_aln else ra.default_opts()
     oopts_kw = {"selAln": 1} if args.sel_aln else {}
     ptr = (s1.data_ptr(), off.data_ptr(), s2.data_ptr(), off.data_ptr())
+    head_key = "sel" if args.sel_aln else (("ph_compact" if args.ph_compact else "ph_expanded") if args.perfect_hash else "dense")
 
-    def step():
-        r = mp.map_device(n, ptr[0], ptr[1], ptr[2], ptr[3], L, opts=opts, fetch=False)
-        tot = qd.all_reduce_counters(r.counters, device=device)   # the path's only collective
-        return r, tot
-
-    for _ in range(args.warmup):
-        step()
-    kernel_ms = []
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        r, tot = step()
-        kernel_ms.append(r.map_kernel_ms)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    tt = torch.tensor([el], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    el = float(tt.item())
+    el, kernel_ms, tot = timed_steps(mp, opts, ptr, n, L, args.steps, args.warmup, world, device, qd)
     total_pairs = n * world * args.steps
     value = total_pairs / el / 1e6
 
@@ -236,43 +374,18 @@ def main():
 
     # ---- cpu_baseline + roofline counters: rank 0, N=1 only, bounded sample of the same workload
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle, q5
-        t = time.time()
-        oracle.build()
-        oix = q5.load(idx_dir)
-        orc = oracle.Oracle(oix)
-        log("oracle index ready (%.1fs)" % (time.time() - t))
+        from oracle import oracle
+        oracles = Oracles()
+        orc = oracles.get(idx_dir)
         cores = os.cpu_count() or 1
         oopts = oracle.default_opts(**oopts_kw)
-        # short sweep over thread counts (the workload is memory-latency bound on the host too: all hardware threads is not
-        # always the best), then the bounded sample at the best one
-        probe_n = min(n, 200000)
-        h1 = s1[: probe_n * L].cpu().numpy(); h2 = s2[: probe_n * L].cpu().numpy(); ho = off[: probe_n + 1].cpu().numpy()
-        sweep = {}
-        for T in sorted({cores, max(1, cores // 2), max(1, cores // 4)}, reverse=True):
-            t = time.perf_counter(); orc.map_pairs(h1, ho, h2, ho, opts=oopts, nthreads=T); sweep[T] = probe_n / (time.perf_counter() - t)
-        best_t = max(sweep, key=sweep.get)
-        rate = sweep[best_t]
-        sample = int(min(n, max(probe_n, rate * args.cpu_seconds)))
-        h1 = s1[: sample * L].cpu().numpy(); h2 = s2[: sample * L].cpu().numpy(); ho = off[: sample + 1].cpu().numpy()
-        t = time.perf_counter(); ores = orc.map_pairs(h1, ho, h2, ho, opts=oopts, nthreads=best_t); dt = time.perf_counter() - t
-        cpu_val = sample / dt / 1e6
-        # parity of the HIP path on exactly this sample
-        gr = mp.map_device(sample, ptr[0], ptr[1], ptr[2], ptr[3], L, opts=opts, fetch=True)
-        parity = bool(np.array_equal(gr.hit_offsets, ores.hit_offsets) and gr.hits.tobytes() == ores.hits.tobytes())
-        bpp, w = algorithmic_bytes_per_pair(ores.work, sample, L)
+        cp = cpu_and_parity(orc, mp, opts, oopts, s1, s2, off, ptr, n, L, args.cpu_seconds)
+        sample, best_t, cpu_val = cp["sample"], cp["best_t"], cp["cpu_val"]
+        bpp, w = algorithmic_bytes_per_pair(cp["work"], sample, L)
         ph_levels = None
-        if args.perfect_hash:
-            # a probe of the reference's -p structure costs (levels visited) x 8 + 8 (rank sample) + 4 (data_) + 4 (SA)
-            # + 31 (text) + 1 (lens) bytes instead of the 16 of a dense find.  Levels visited: the expectation for a k-mer that is not in
-            # the index (the large majority of the finds), from the bit densities of the levels of this hash_info.bph.
-            from oracle import q5ph
-            boo = q5ph.BooPHF(os.path.join(idx_dir, "hash_info.bph"))
-            reach, ph_levels = 1.0, 0.0
-            for (size, words, ranks), dom in zip(boo.levels, boo.domains):
-                dens = float(np.unpackbits(np.ascontiguousarray(words).view(np.uint8)).sum()) / max(1, dom)
-                ph_levels += reach; reach *= (1.0 - dens)
-            bpp += w["n_probe"] * (ph_levels * 8 + 8 + 4 + 4 + 31 + 1 - 16)
+        if args.perfect_hash and args.ph_compact:      # the expanded image never walks the levels: its bytes are the dense ones
+            add, ph_levels = ph_walk_addend(idx_dir, w["n_probe"])
+            bpp += add
         por = None
         try:
             por = json.load(open(os.path.join(ROOT, "profiles", "port_over_reference.json")))
@@ -280,76 +393,49 @@ def main():
             pass
         out["cpu_baseline"] = {"value": round(cpu_val, 5), "unit": "M read-pairs/s", "cores": best_t, "kind": "port",
                                "host_hw_threads": cores, "threads_best": best_t,
-                               "threads_sweep_Mpairs_s": {str(k_): round(v / 1e6, 4) for k_, v in sorted(sweep.items())},
-                               "pairs_per_s_per_thread": round(sample / dt / best_t, 1),
+                               "threads_sweep_Mpairs_s": cp["sweep"], "threads_sweep_pairs": cp["probe_n"],
+                               "pairs_per_s_per_thread": round(sample / cp["map_seconds"] / best_t, 1),
+                               "timed": "the mapping section of the port (worker threads started .. joined, %.2f s): the span the reference's own "
+                                        "timer covers (src/RapMapSAMapper.cpp:856-889, output discarded with -n); the whole native call incl. "
+                                        "assembling one result array took %.2f s" % (cp["map_seconds"], cp["call_seconds"]),
+                               "index_memory_interleaved_over_numa_nodes": oracles.interleaved,
                                "port_over_reference": (por or {}).get("port_over_reference"),
                                "port_over_reference_note": (por or {}).get("note"),
                                "sample": "first %d pairs of the same batch, oracle (CPU restatement of the reference's algorithm) on %d threads "
-                                         "(best of a sweep over %s), %.1f s; the reference's quasimap cannot be built in this image (un-vendored cereal); "
-                                         "port / reference throughput measured in the build container: profiles/port_over_reference.json"
-                                         % (sample, best_t, sorted(sweep), dt)}
-        out["parity"] = {"sample_pairs": sample, "bit_identical_to_oracle": parity, "hits": int(ores.hit_offsets[-1])}
-        ach = bpp * n / (avg_kernel_ms * 1e-3) / 1e9
-        traffic = None
-        pf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pf):
-            try:
-                ent = json.load(open(pf)).get("perfect_hash" if (args.perfect_hash and args.ph_compact) else "dense") or {}
-                traffic = ent.get("hbm_bytes_per_launch") if n == 10_000_000 and args.genes == 40000 and not args.sel_aln else None
-            except Exception:
-                traffic = None
-        out["roofline"] = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                           "kernel": "%s (stage A: one wavefront per read)" % ("qm_read_kernel<2,4,%d>" % (5 if (args.perfect_hash and args.ph_compact) else 4) if args.sel_aln else ("qm_read_kernel<2,6,1>" if (args.perfect_hash and args.ph_compact) else "qm_read_kernel<2,8,0>")),
-                           "kernel_ms": round(avg_kernel_ms, 3),
-                           "algorithmic_bytes_per_pair": round(bpp, 1),
-                           "per_pair_counters": {kk: round(v, 2) for kk, v in w.items()},
-                           "pairs_per_launch": n}
+                                         "(best of a sweep over %s on the first %d pairs); the reference's quasimap cannot be built in this image "
+                                         "(un-vendored cereal); port / reference throughput measured in the build container: profiles/port_over_reference.json"
+                                         % (sample, best_t, sorted(int(x) for x in cp["sweep"]), cp["probe_n"])}
+        out["parity"] = {"sample_pairs": sample, "bit_identical_to_oracle": cp["parity"], "hits": cp["hits"]}
+        extra = {}
         if ph_levels is not None:
-            out["roofline"]["ph_levels_per_probe"] = round(ph_levels, 3)
+            extra["ph_levels_per_probe"] = round(ph_levels, 3)
         if args.sel_aln:   # with -s report the DP cells separately
-            out["roofline"]["dp"] = {"alignments_per_pair": round(w.get("n_aln", 0), 3), "band_cells_per_pair": round(w.get("n_cells", 0), 1),
-                                     "G_cell_updates_per_s": round(w.get("n_cells", 0) * value * 1e6 / 1e9, 2),
-                                     "note": "ksw2 extension alignments that were actually run (cache misses, neither PERFECT nor UNGAPPED chains)"}
+            extra["dp"] = {"alignments_per_pair": round(w.get("n_aln", 0), 3), "band_cells_per_pair": round(w.get("n_cells", 0), 1),
+                           "G_cell_updates_per_s": round(w.get("n_cells", 0) * value * 1e6 / 1e9, 2),
+                           "note": "ksw2 extension alignments that were actually run (cache misses, neither PERFECT nor UNGAPPED chains)"}
+        out["roofline"] = roofline(bpp, w, n, avg_kernel_ms, KERNELS[head_key], head_key, args.genes, step_ms=el / args.steps * 1e3, extra=extra)
         out["speedup_vs_cpu_baseline"] = round(value / cpu_val, 2) if cpu_val > 0 else None
-        # ---- what a caller sees beyond the in-HBM figure (SURVEY.md section 8d, last bullet); never `value`
-        try:
-            # (1) PCIe inclusive: the same batch from pageable host buffers through qm_map_pairs + qm_fetch_hits
-            hs1 = s1.cpu().numpy(); hs2 = s2.cpu().numpy(); hoff = off.cpu().numpy()
-            mp.map_pairs(hs1[: 1000 * L], hoff[:1001], hs2[: 1000 * L], hoff[:1001], opts=opts)
-            t = time.perf_counter(); rh = mp.map_pairs(hs1, hoff, hs2, hoff, opts=opts); dt_h = time.perf_counter() - t
-            out["pcie_inclusive"] = {"value": round(n / dt_h / 1e6, 3), "unit": "M read-pairs/s",
-                                     "what": "qm_map_pairs on pageable host buffers (%d MB in) + qm_fetch_hits into a fresh array (%d MB out), one call"
-                                             % ((2 * hs1.nbytes + 2 * hoff.nbytes) >> 20, (rh.hits.nbytes + rh.hit_offsets.nbytes) >> 20)}
-            del rh
-            # (2) end to end: FASTQ on tmpfs -> hits in pinned memory through the pipelined stream (reader + two device contexts)
-            from rapmap_amd import synth as _syn
-            ne = min(n, 8_000_000)
-            d_e = os.path.join(args.cache, "qmap_bench_e2e_%d" % os.getpid()); os.makedirs(d_e, exist_ok=True)
-            f1 = os.path.join(d_e, "r1.fq"); f2 = os.path.join(d_e, "r2.fq")
-            _syn.write_fastq(f1, hs1[: ne * L], ne, L, 1); _syn.write_fastq(f2, hs2[: ne * L], ne, L, 2)
-            t = time.perf_counter()
-            st = ra.MappedStream(qi, f1, f2, opts=opts, device=dev_id, batch_units=1 << 18, threads=min(64, cores), ph_compact=args.ph_compact)
-            nh = 0
-            for b_ in st:
-                nh += b_.n_hits
-            dt_e = time.perf_counter() - t
-            ss = st.stats(); st.close()
-            for f_ in (f1, f2):
-                os.remove(f_)
-            os.rmdir(d_e)
-            out["end_to_end"] = {"value": round(ne / dt_e / 1e6, 3), "unit": "M read-pairs/s",
-                                 "what": "%d pairs as two plain FASTQ files on tmpfs (%d MB) -> qm_stream_* (reader threads, two device contexts sharing "
-                                         "the index replica, hits handed out in pinned memory), stream open to last batch; reader %.2f s, upload + kernels %.2f s, "
-                                         "download %.2f s, opening (contexts) %.2f s" % (ne, 2 * (ne * (2 * L + 19)) >> 20, ss["read_s"], ss["map_s"], ss["fetch_s"], ss["open_s"]),
-                                 "hits": int(nh)}
-        except Exception as ex:           # these two legs are side measurements: they must not take the bench line down
-            out.setdefault("end_to_end", None); out.setdefault("pcie_inclusive", None)
-            log("side measurements failed: %r" % (ex,))
         try:   # the per-pair counters are a property of the input distribution: keep them for the N>1 runs
             json.dump({"bpp": bpp, "counters": w}, open(os.path.join(idx_dir, "algorithmic_bytes.json"), "w"))
         except Exception:
             pass
+
+        # ---- what a caller sees beyond the in-HBM figure (SURVEY.md section 8d, last bullet); never `value`
+        if not args.no_side_legs:
+            try:
+                side_legs(out, args, ra, qi, mp, opts, s1, s2, off, n, L, dev_id, cores)
+            except Exception as ex:           # side measurements: they must not take the bench line down
+                out.setdefault("end_to_end", None); out.setdefault("pcie_inclusive", None)
+                log("side measurements failed: %r" % (ex,))
+
+        # ---- configs[3] and configs[4] in the same run: bounded legs, each with its own value / kernel time / roofline / parity
+        if not args.no_other_configs and head_key == "dense" and L == 100:
+            out["other_configs"] = {}
+            try:
+                other_configs(out["other_configs"], args, ra, qd, oracles, oracle, qi, idx_dir, mp, s1, s2, off, ptr, n, L, dev_id, device, k, w, bpp)
+            except Exception as ex:
+                out["other_configs"]["error"] = repr(ex)
+                log("other_configs failed: %r" % (ex,))
     elif rank == 0:
         # N>1 (or --no-cpu-baseline): no oracle leg.  The roofline of rank 0's kernel still uses the algorithmic bytes
         # per pair of this workload: recorded by an N=1 run on this box, else the committed figure of the default workload.
@@ -367,27 +453,122 @@ def main():
                 except Exception:
                     rec = None
         if rec and kernel_ms:
-            bpp = float(rec["bpp"])
-            ach = bpp * n / (avg_kernel_ms * 1e-3) / 1e9
-            traffic = None
-            try:
-                ent = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("perfect_hash" if (args.perfect_hash and args.ph_compact) else "dense") or {}
-                traffic = ent.get("hbm_bytes_per_launch") if args.genes == 40000 else None
-                if traffic is not None:
-                    traffic = traffic * (n / 10_000_000)       # measured on a 10 M-pair launch; bytes per pair are what was measured
-            except Exception:
-                pass
-            out["roofline"] = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                               "kernel": "qm_read_kernel (stage A: one wavefront per read), rank 0's launches", "kernel_ms": round(avg_kernel_ms, 3),
-                               "algorithmic_bytes_per_pair": round(bpp, 1), "per_pair_counters": rec.get("counters"),
-                               "pairs_per_launch": n}
+            out["roofline"] = roofline(float(rec["bpp"]), rec.get("counters") or {}, n, avg_kernel_ms,
+                                       KERNELS[head_key] + ", rank 0's launches", head_key, args.genes, step_ms=el / args.steps * 1e3)
 
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def side_legs(out, args, ra, qi, mp, opts, s1, s2, off, n, L, dev_id, cores):
+    # (1) PCIe inclusive: the same batch from pageable host buffers through qm_map_pairs + qm_fetch_hits
+    hs1 = s1.cpu().numpy(); hs2 = s2.cpu().numpy(); hoff = off.cpu().numpy()
+    mp.map_pairs(hs1[: 1000 * L], hoff[:1001], hs2[: 1000 * L], hoff[:1001], opts=opts)
+    t = time.perf_counter(); rh = mp.map_pairs(hs1, hoff, hs2, hoff, opts=opts); dt_h = time.perf_counter() - t
+    out["pcie_inclusive"] = {"value": round(n / dt_h / 1e6, 3), "unit": "M read-pairs/s",
+                             "what": "qm_map_pairs on pageable host buffers (%d MB in) + qm_fetch_hits into a fresh array (%d MB out), one call"
+                                     % ((2 * hs1.nbytes + 2 * hoff.nbytes) >> 20, (rh.hits.nbytes + rh.hit_offsets.nbytes) >> 20)}
+    del rh
+    # (2) end to end: two FASTQ files -> hits in pinned memory through the pipelined stream (ingest workers + device contexts).
+    # The files go to a local filesystem directory by default, not to tmpfs: on this box's kernel the FIRST read of freshly
+    # written tmpfs pages runs at ~16 GB/s whatever the thread count or access method (profiles/r03_tmpfs_read_passes.txt),
+    # a property of the host, not of the reader; page-cache pages of a disk filesystem do not show it.
+    from rapmap_amd import synth as _syn
+    ne = n
+    base = args.e2e_dir if os.path.isdir(args.e2e_dir) else args.cache
+    d_e = os.path.join(base, "qmap_bench_e2e_%d" % os.getpid()); os.makedirs(d_e, exist_ok=True)
+    f1 = os.path.join(d_e, "r1.fq"); f2 = os.path.join(d_e, "r2.fq")
+    try:
+        _syn.write_fastq(f1, hs1[: ne * L], ne, L, 1); _syn.write_fastq(f2, hs2[: ne * L], ne, L, 2)
+        thr = max(1, min(args.e2e_threads, cores))
+        batch = 1 << 18
+        runs = {}
+        for names in (True, False):
+            t = time.perf_counter()
+            st = ra.MappedStream(qi, f1, f2, opts=opts, device=dev_id, batch_units=batch, threads=thr, ph_compact=args.ph_compact, names=names)
+            nh = 0
+            for b_ in st:
+                nh += b_.n_hits
+            dt_e = time.perf_counter() - t
+            ss = st.stats(); st.close()
+            runs[names] = (dt_e, ss, nh)
+        dt_e, ss, nh = runs[True]
+        out["end_to_end"] = {
+            "value": round(ne / dt_e / 1e6, 3), "unit": "M read-pairs/s", "pairs": ne, "hits": int(nh),
+            "input": "two plain FASTQ files, %d MB together, in %s (%s), read once right after they were written" % (
+                (os.path.getsize(f1) + os.path.getsize(f2)) >> 20, d_e, fstype_of(d_e)),
+            "ingest_threads": thr, "batch_units": batch, "names_kept": True,
+            "seconds": {"total_open_to_last_batch_handed_out": round(dt_e, 4), "open": round(ss["open_s"], 4),
+                        "first_batch_packed": round(ss["first_batch_s"], 4), "ingest_open_to_last_batch_packed": round(ss["read_s"], 4),
+                        "last_batch_mapped": round(ss["last_mapped_s"], 4),
+                        "upload_and_kernels_summed_over_contexts": round(ss["map_s"], 4), "download_summed_over_contexts": round(ss["fetch_s"], 4),
+                        "caller_waiting": round(ss["caller_wait_s"], 4), "parse_tasks_cpu": round(ss["parse_cpu_s"], 4),
+                        "copy_tasks_cpu": round(ss["copy_cpu_s"], 4)},
+            "without_read_names": {"value": round(ne / runs[False][0] / 1e6, 3), "seconds_total": round(runs[False][0], 4)},
+            "what": "qm_stream_*: ingest workers parse the files chunk-parallel and pack batches straight into pinned slots, device contexts "
+                    "sharing the index replica upload / map / download, hits handed out in pinned memory in input order; stream open to last batch"}
+    finally:
+        for f_ in (f1, f2):
+            if os.path.exists(f_):
+                os.remove(f_)
+        try:
+            os.rmdir(d_e)
+        except OSError:
+            pass
+
+
+def other_configs(oc, args, ra, qd, oracles, oracle, qi, idx_dir, mp, s1, s2, off, ptr, n, L, dev_id, device, k, w_dense, bpp_dense):
+    """bounded legs (3 timed steps each) of the configurations the headline does not cover, on the same reads"""
+    steps, warm = 3, 1
+
+    def leg(name, mapper, o, key, bpp, w, cp, workload, extra=None):
+        el, kms, tot = timed_steps(mapper, o, ptr, n, L, steps, warm, 1, device, qd)
+        val = n * steps / el / 1e6
+        km = float(np.mean(kms))
+        oc[name] = {"workload": workload, "value": round(val, 4), "unit": "M read-pairs/s", "steps": steps, "warmup": warm,
+                    "ms_per_step": round(el / steps * 1e3, 3), "kernel_ms": round(km, 3),
+                    "hits_per_pair": round(tot["totHits"] / max(1, tot["numReads"]), 4),
+                    "roofline": roofline(bpp, w, n, km, KERNELS[key], key, args.genes, step_ms=el / steps * 1e3, extra=extra),
+                    "parity": {"sample_pairs": cp["sample"], "bit_identical_to_oracle": cp["parity"], "hits": cp["hits"]},
+                    "cpu_baseline": {"value": round(cp["cpu_val"], 5), "unit": "M read-pairs/s", "cores": cp["best_t"], "kind": "port"}}
+        log("other_configs %s: %.1f M pairs/s, kernel %.2f ms, parity %s" % (name, val, km, cp["parity"]))
+
+    # configs[4]: -s on the dense index (the headline's mapper, selective-alignment options)
+    o_sel = ra.default_opts(sel_aln=1)
+    oo_sel = oracle.default_opts(selAln=1)
+    mp.map_device(min(n, 100000), ptr[0], ptr[1], ptr[2], ptr[3], L, opts=o_sel, fetch=False)      # builds the -s extension table
+    cp = cpu_and_parity(oracles.get(idx_dir), mp, o_sel, oo_sel, s1, s2, off, ptr, n, L, args.cpu_seconds, sweep=False)
+    bpp, w = algorithmic_bytes_per_pair(cp["work"], cp["sample"], L)
+    leg("configs[4] selective alignment (-s)", mp, o_sel, "sel", bpp, w, cp,
+        "the headline's index and reads with -s: chain-scoring collector, chaining, ksw2 extension alignment, score gate",
+        extra={"dp": {"alignments_per_pair": round(w.get("n_aln", 0), 3), "band_cells_per_pair": round(w.get("n_cells", 0), 1)},
+               "note": "kernel_ms spans the two stage-A launches (collector, then intervals -> lists); the plan / ksw2 / finish kernels of stage B-C "
+                       "are in ms_per_step only"})
+
+    # configs[3]: the same transcriptome indexed with -p, in both device images, same reads (the text is the same)
+    idx_ph = build_or_reuse_index(args.genes, 42, k, 0, 1, args.cache, True)
+    qi_ph = ra.QuasiIndex(idx_ph)
+    assert qi_ph.text_len == qi.text_len and qi_ph.n_txps == qi.n_txps
+    o = ra.default_opts()
+    orc_ph = oracles.get(idx_ph)
+    mp_c = ra.QuasiMapper(qi_ph, dev_id, ph_compact=True)
+    cp = cpu_and_parity(orc_ph, mp_c, o, oracle.default_opts(), s1, s2, off, ptr, n, L, max(args.cpu_seconds, 30.0), sweep=False)
+    bpp, w = algorithmic_bytes_per_pair(cp["work"], cp["sample"], L)
+    add, lv = ph_walk_addend(idx_ph, w["n_probe"])
+    leg("configs[3] -p index, BooPHF walked on the device (QM_CTX_PH_COMPACT)", mp_c, o, "ph_compact", bpp + add, w, cp,
+        "`quasiindex -p` index of the same transcriptome, FrugalBooMap probe path kept on the device", extra={"ph_levels_per_probe": round(lv, 3)})
+    mp_c.close()
+    mp_e = ra.QuasiMapper(qi_ph, dev_id)
+    gr = mp_e.map_device(cp["sample"], ptr[0], ptr[1], ptr[2], ptr[3], L, opts=o, fetch=True)
+    ref = cp["ores"]                                          # the oracle's hits on the -p index, computed for the leg above
+    cp2 = dict(cp); cp2["parity"] = bool(np.array_equal(gr.hit_offsets, ref.hit_offsets) and gr.hits.tobytes() == ref.hits.tobytes())
+    leg("configs[3] -p index, expanded into the bucket table at load (default image)", mp_e, o, "ph_expanded", bpp, w, cp2,
+        "the same -p index answered from the one-sector bucket table built from it at load: the dense kernel, the dense algorithmic bytes")
+    mp_e.close()
+    qi_ph.close()
 
 
 if __name__ == "__main__":

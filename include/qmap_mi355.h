@@ -245,10 +245,15 @@ void qm_reader_close(qm_reader* r);
 const char* qm_io_last_error(void);
 
 /* FASTA/FASTQ files -> mapped batches, pipelined (the ingest side of the path; replaces the single kseq
- * producer + per-record std::strings of src/FastxParser.cpp:229-328).  A reader thread parses the next batch into pinned
- * host buffers while two device contexts (sharing the index replica) upload, map and download the previous ones; the caller
- * drains the batches in input order.  Everything a batch points to -- reads, names, hit offsets, hits -- is pinned memory owned by
- * the stream and stays valid until the next qm_stream_next call.  n_units == 0: end of input.  path2 == NULL: single-end. */
+ * producer + per-record std::strings of src/FastxParser.cpp:229-328, and the worker threads of spawnProcessReadsThreads,
+ * src/RapMapSAMapper.cpp:752-799).  `reader_threads` workers parse the files chunk-parallel (plain files are cut at byte
+ * offsets with record resync; .gz files are inflated by one thread per file, pipelined with the parsers) and pack batches
+ * straight into pinned host slots, several batches in flight, while two device contexts per device (sharing that device's
+ * index replica) upload, map and download the previous ones; with several devices consecutive batches go to different
+ * devices (the static sharding of SURVEY.md section 8e inside one process).  The caller drains the batches IN INPUT ORDER,
+ * whichever device mapped them.  Everything a batch points to -- reads, names, hit offsets, hits -- is pinned memory owned by
+ * the stream and stays valid until the next qm_stream_next call.  n_units == 0: end of input.  path2 == NULL: single-end.
+ * Counters come per batch; a run's HitCounters are their sum. */
 typedef struct qm_stream qm_stream;
 typedef struct qm_stream_batch {
   int64_t n_units;
@@ -257,14 +262,25 @@ typedef struct qm_stream_batch {
   const int64_t* hit_offsets; const qm_hit* hits; int64_t n_hits;
   qm_counters counters;
   double gpu_ms;
+  int32_t device;  /* the device that mapped this batch */
+  int32_t pad;
 } qm_stream_batch;
 int qm_stream_open(const qm_index* ix, int device_id, uint32_t ctx_flags, const qm_opts* opts, const char* path1, const char* path2,
                    int64_t batch_units, int32_t reader_threads, qm_stream** out);
+/* ... on the devices devices[0..n_devices).  stream_flags: QM_STREAM_NO_NAMES -- read names are not kept (names* / name_off*
+ * of the batches are NULL): for callers that only want hits. */
+#define QM_STREAM_NO_NAMES 1u
+int qm_stream_open_ex(const qm_index* ix, const int32_t* devices, int32_t n_devices, uint32_t ctx_flags, const qm_opts* opts,
+                      const char* path1, const char* path2, int64_t batch_units, int32_t reader_threads, uint32_t stream_flags,
+                      qm_stream** out);
 int qm_stream_next(qm_stream* s, qm_stream_batch* batch);
 void qm_stream_close(qm_stream* s);
-/* seconds spent so far: [0] reader (parse + pack), [1] upload + kernels (both contexts), [2] download, [3] the caller waiting in
- * qm_stream_next, [4] qm_stream_open, [5] growing the pinned result buffers */
+/* seconds spent so far: [0] the ingest engine, open to its last batch packed (wall), [1] upload + kernels (summed over the
+ * contexts), [2] download (summed), [3] the caller waiting in qm_stream_next, [4] qm_stream_open, [5] growing the pinned result
+ * buffers; qm_stream_stats_ex(n <= 12) adds [6] open to the first batch packed, [7] parse tasks (CPU seconds over all workers),
+ * [8] copy tasks, [9] inflate threads, [10] bytes parsed, [11] open to the last batch mapped and downloaded (wall) */
 int qm_stream_stats(qm_stream* s, double* out6);
+int qm_stream_stats_ex(qm_stream* s, double* out, int32_t n);
 const char* qm_stream_last_error(void);
 
 /* SAM text of a mapped batch, byte for byte what `rapmap quasimap -o` writes: header = writeSAMHeader

@@ -139,7 +139,7 @@ class Oracle:
             assert len(off2) - 1 == n
         hit_off = np.zeros(n + 1, dtype=np.int64)
         counters = np.zeros(6, dtype=np.uint64)
-        work = np.zeros(8, dtype=np.uint64)
+        work = np.zeros(10, dtype=np.uint64)
         hits_p = C.c_void_p()
         ints_off = np.zeros(n + 1, dtype=np.int64)
         ints_p = C.c_void_p()
@@ -153,11 +153,15 @@ class Oracle:
         hits = np.ctypeslib.as_array(C.cast(hits_p, C.POINTER(C.c_uint8)), shape=(max(total, 1) * 32,))
         hits = hits[: total * 32].copy().view(HIT_DTYPE)
         self.lib.qo_free(hits_p)
+        r_map_s, r_call_s = float(work[8]) * 1e-9, float(work[9]) * 1e-9
         r = MapResult()
         r.hit_offsets, r.hits = hit_off, hits
         r.counters = dict(zip(["peHits", "seHits", "totHits", "numReads", "tooManyHits", "mappedUnits"],
                               [int(x) for x in counters]))
-        r.work = dict(zip(["n_probe", "n_sa", "n_text", "n_rank", "n_hits", "n_aln", "n_cells", "n_ungapped"], [int(x) for x in work]))
+        r.work = dict(zip(["n_probe", "n_sa", "n_text", "n_rank", "n_hits", "n_aln", "n_cells", "n_ungapped"], [int(x) for x in work[:8]]))
+        # seconds of the mapping section alone (worker threads started .. joined: the span the reference's own timer covers)
+        # and of the whole native call (+ one contiguous result array)
+        r.map_seconds, r.call_seconds = r_map_s, r_call_s
         if want_ints:
             tot = int(ints_off[-1])
             a = np.ctypeslib.as_array(C.cast(ints_p, C.POINTER(C.c_int32)), shape=(max(tot, 1) * 6,))

@@ -29,6 +29,7 @@
 //   hkeys/hlb/hub : the k-mer -> [lb,ub) SA-interval map (any order)
 // =============================================================================
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <cmath>
 #include <cstdint>
@@ -1341,7 +1342,9 @@ void qo_index_destroy(void* h) { delete (OIndex*)h; }
 // seqX: concatenated read bytes; offX[n+1]: offsets.
 // Outputs: hit_offsets[n+1]; *hits_out = malloc'ed Hit array (free with qo_free);
 // counters[6] = {peHits, seHits, totHits, numReads, tooManyHits, mappedUnits};
-// work[8] = {n_probe, n_sa, n_text, n_rank, n_hits, n_aln, n_cells, n_ungapped}.
+// work[10] = {n_probe, n_sa, n_text, n_rank, n_hits, n_aln, n_cells, n_ungapped, ns of the mapping section (threads started
+// to threads joined: what the reference's ScopedTimer around its worker threads covers, src/RapMapSAMapper.cpp:856-889),
+// ns of the whole call (+ assembling one contiguous result array, which the reference never does)}.
 // If ints_out != nullptr (pairs only): *ints_out = malloc'ed SA-interval records
 // {begin,end,len,queryPos,rc,list} as int32[6], list = 0..3 for
 // left-fwd,left-rc,right-fwd,right-rc, and ints_offsets[n+1].
@@ -1388,18 +1391,31 @@ int qo_map(void* hidx, const Opts* opts, int64_t n, const char* seq1, const int6
       perHits[t].insert(perHits[t].end(), joint.begin(), joint.end());
     }
   };
-  std::vector<std::thread> th;
-  for (int t = 1; t < nthreads; ++t) th.emplace_back(worker, t);
-  worker(0);
-  for (auto& x : th) x.join();
-  hit_offsets[0] = 0;
-  for (int64_t i = 0; i < n; ++i) hit_offsets[i + 1] = hit_offsets[i] + cnt[i + 1];
-  int64_t total = hit_offsets[n];
+  const auto tc0 = std::chrono::steady_clock::now();
+  {
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; ++t) th.emplace_back(worker, t);
+    worker(0);
+    for (auto& x : th) x.join();
+  }
+  const auto tc1 = std::chrono::steady_clock::now();
+  // one contiguous result: every thread places its own share (offsets first: a thread's units are contiguous)
+  std::vector<int64_t> base((size_t)nthreads + 1, 0);
+  for (int t = 0; t < nthreads; ++t) base[(size_t)t + 1] = base[(size_t)t] + (int64_t)perHits[t].size();
+  const int64_t total = base[(size_t)nthreads];
   Hit* out = (Hit*)malloc(sizeof(Hit) * (size_t)std::max<int64_t>(total, 1));
-  int64_t p = 0;
-  for (int t = 0; t < nthreads; ++t) {
-    if (!perHits[t].empty()) memcpy(out + p, perHits[t].data(), perHits[t].size() * sizeof(Hit));
-    p += (int64_t)perHits[t].size();
+  hit_offsets[0] = 0;
+  {
+    auto place = [&](int t) {
+      const int64_t b = n * t / nthreads, e = n * (t + 1) / nthreads;
+      int64_t h = base[(size_t)t];
+      for (int64_t i = b; i < e; ++i) { h += cnt[i + 1]; hit_offsets[i + 1] = h; }
+      if (!perHits[t].empty()) memcpy(out + base[(size_t)t], perHits[t].data(), perHits[t].size() * sizeof(Hit));
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; ++t) th.emplace_back(place, t);
+    place(0);
+    for (auto& x : th) x.join();
   }
   *hits_out = out;
   Counters c{0, 0, 0, 0, 0, 0}; Work w;
@@ -1413,6 +1429,7 @@ int qo_map(void* hidx, const Opts* opts, int64_t n, const char* seq1, const int6
   counters[4] = c.tooManyHits; counters[5] = c.mappedUnits;
   work[0] = w.n_probe; work[1] = w.n_sa; work[2] = w.n_text; work[3] = w.n_rank; work[4] = w.n_hits;
   work[5] = w.n_aln; work[6] = w.n_cells; work[7] = w.n_ungapped;
+  work[8] = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(tc1 - tc0).count();
   if (ints_out) {
     ints_offsets[0] = 0;
     for (int64_t i = 0; i < n; ++i) ints_offsets[i + 1] = ints_offsets[i] + icnt[i + 1];
@@ -1425,6 +1442,7 @@ int qo_map(void* hidx, const Opts* opts, int64_t n, const char* seq1, const int6
     }
     *ints_out = io;
   }
+  work[9] = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tc0).count();
   return 0;
 }
 

@@ -68,6 +68,8 @@ def _quasimap(argv):
     ap.add_argument("--mimicStrictBT2", action="store_true")
     ap.add_argument("--maxMMPExtension", type=int, default=7)
     ap.add_argument("--device", type=int, default=0, help="GPU to use")
+    ap.add_argument("--devices", default="", help="comma-separated GPUs to use, or 'all': the read batches are dealt round-robin to the devices "
+                    "(each holds its own index replica), results come back in input order")
     ap.add_argument("--chunk", type=int, default=1 << 18, help="read pairs per GPU batch")
     a = ap.parse_args(argv)
 
@@ -109,6 +111,23 @@ def _quasimap(argv):
         if a.mimicStrictBT2:
             opts.min_score_fraction = 0.8; opts.match_score = 1; opts.mismatch_penalty = 0; opts.gap_open = 25; opts.gap_extend = 25
     qi = ra.QuasiIndex(a.index)
+    if a.devices:
+        if a.devices == "all":
+            import ctypes as _C
+            nd = _C.c_int(0)
+            hip = _C.CDLL("libamdhip64.so")
+            if hip.hipGetDeviceCount(_C.byref(nd)) != 0 or nd.value <= 0:
+                sys.exit("no HIP device visible")
+            devices = list(range(nd.value))
+        else:
+            try:
+                devices = [int(x) for x in a.devices.split(",") if x != ""]
+            except ValueError:
+                sys.exit("--devices takes a comma-separated list of device numbers, or 'all'")
+            if not devices:
+                sys.exit("--devices: no device given")
+    else:
+        devices = [a.device]
     log = (lambda *x: None) if a.quiet else (lambda *x: print(*x, file=sys.stderr, flush=True))
     out = None
     direct_fd = None
@@ -144,8 +163,11 @@ def _quasimap(argv):
         pairs = list(zip(files1, files2))
     else:
         pairs = [(f, None) for f in a.unmatedReads.split(",")]
+    # one context per device lives for the whole run: the index replica stays resident between the files of a multi-file run
+    # (a stream's own contexts share it)
+    keep = [ra.QuasiMapper(qi, d) for d in sorted(set(devices))]
     for f1, f2 in pairs:
-        st = ra.MappedStream(qi, f1, f2, opts=opts, device=a.device, batch_units=a.chunk, threads=nthr)
+        st = ra.MappedStream(qi, f1, f2, opts=opts, device=devices, batch_units=a.chunk, threads=nthr, names=out is not None)
         for b in st:
             gpu_ms += b.gpu_ms
             for kk in tot:
@@ -160,6 +182,8 @@ def _quasimap(argv):
                     tot["numReads"], tot["peHits"] / max(1, tot["numReads"]), tot["seHits"] / max(1, tot["numReads"])))
         log("stream: " + ", ".join("%s %.3f" % kv for kv in st.stats().items()))
         st.close()
+    for k_ in keep:
+        k_.close()
     if writer is not None:
         writer.close()
     if out is not None and out is not sys.stdout.buffer:

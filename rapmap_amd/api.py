@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "qm_fetch_intervals", "qm_last_kernel_ms", "qm_ctx_stat", "qm_build_index", "qm_build_index_ex",
     "qm_collect_reads", "qm_fetch_found", "qm_hits_to_mappings", "qm_fetch_read_lists", "qm_merge_lists", "qm_fetch_too_many",
     "qm_map_pairs_stages", "qm_ctx_create_ex", "qm_fetch_hits_pinned",
-    "qm_stream_open", "qm_stream_next", "qm_stream_close", "qm_stream_last_error", "qm_stream_stats",
+    "qm_stream_open", "qm_stream_open_ex", "qm_stream_next", "qm_stream_close", "qm_stream_last_error", "qm_stream_stats", "qm_stream_stats_ex",
     "qm_reader_open", "qm_reader_next", "qm_reader_close", "qm_io_last_error", "qm_sam_header", "qm_sam_records",
     "qm_sam_write", "qm_sam_writer_open", "qm_sam_writer_open_ex", "qm_sam_writer_header", "qm_sam_writer_put", "qm_sam_writer_close", "qm_buf_free",
 ]
@@ -75,7 +75,7 @@ class QmStreamBatch(C.Structure):
                 ("seq1", C.c_void_p), ("off1", C.c_void_p), ("names1", C.c_void_p), ("name_off1", C.c_void_p),
                 ("seq2", C.c_void_p), ("off2", C.c_void_p), ("names2", C.c_void_p), ("name_off2", C.c_void_p),
                 ("hit_offsets", C.c_void_p), ("hits", C.c_void_p), ("n_hits", C.c_int64),
-                ("counters", QmCounters), ("gpu_ms", C.c_double)]
+                ("counters", QmCounters), ("gpu_ms", C.c_double), ("device", C.c_int32), ("pad", C.c_int32)]
 
 
 class QmIndexInfo(C.Structure):
@@ -132,6 +132,10 @@ def lib():
     L.qm_map_pairs_stages.argtypes = L.qm_map_pairs.argtypes
     L.qm_stream_open.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(QmOpts), C.c_char_p, C.c_char_p, C.c_int64, C.c_int32,
                                  C.POINTER(C.c_void_p)]
+    L.qm_stream_open_ex.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_uint32, C.POINTER(QmOpts), C.c_char_p, C.c_char_p,
+                                    C.c_int64, C.c_int32, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.qm_stream_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    L.qm_stream_stats_ex.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int32]
     L.qm_stream_next.argtypes = [C.c_void_p, C.POINTER(QmStreamBatch)]
     L.qm_stream_close.argtypes = [C.c_void_p]
     L.qm_stream_last_error.restype = C.c_char_p
@@ -403,6 +407,26 @@ class QuasiMapper:
             pass
 
 
+class _Mem:
+    """array-interface carrier: np.asarray(_Mem(...)) is a zero-copy view of foreign memory in a few microseconds
+    (np.ctypeslib.as_array builds a new ctypes array type per shape: ~1 ms per view, which at 2^18-pair batches was a third
+    of the stream's wall time)"""
+    __slots__ = ("__array_interface__",)
+
+    def __init__(self, addr, count, dt):
+        self.__array_interface__ = {"data": (addr, False), "shape": (count,), "typestr": dt.str, "version": 3}
+        if dt.fields:
+            self.__array_interface__["descr"] = dt.descr
+
+
+def _view(p, count, dt):
+    """zero-copy numpy view of `count` elements of dtype dt at the address held by a ctypes pointer / integer"""
+    addr = p.value if hasattr(p, "value") else p
+    if count == 0 or not addr:
+        return np.zeros(0, dtype=dt)
+    return np.asarray(_Mem(int(addr), int(count), np.dtype(dt)))
+
+
 class ReadBatch:
     """one chunk handed out by FastxReader: packed sequences/names (numpy views, valid until the next chunk)"""
     pass
@@ -432,10 +456,7 @@ class FastxReader:
                 return
             b = ReadBatch(); b.n = n.value
 
-            def arr(p, count, dt):
-                if count == 0 or not p.value:
-                    return np.zeros(0, dtype=dt)
-                return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int64 if dt == np.int64 else C.c_uint8)), shape=(count,))
+            arr = _view
             b.off1 = arr(ptr[1], b.n + 1, np.int64); b.seq1 = arr(ptr[0], int(b.off1[-1]), np.uint8)
             b.name_off1 = arr(ptr[3], b.n + 1, np.int64); b.names1 = arr(ptr[2], int(b.name_off1[-1]), np.uint8)
             if self.paired:
@@ -456,29 +477,33 @@ class FastxReader:
 
 
 class MappedStream:
-    """FASTA/FASTQ files -> mapped batches through the library's pipelined stream (qm_stream_*): reader thread, two device
-    contexts, results in pinned memory.  Iterating yields ReadBatch objects that also carry hit_offsets / hits / counters;
-    every array is a zero-copy view that stays valid until the next batch is taken."""
+    """FASTA/FASTQ files -> mapped batches through the library's pipelined stream (qm_stream_*): ingest workers packing batches
+    into pinned slots, two device contexts per device, results in pinned memory.  `device` may be one id or a list of ids
+    (consecutive batches go to different devices; batches still come back in input order).  Iterating yields ReadBatch
+    objects that also carry hit_offsets / hits / counters / device; every array is a zero-copy view that stays valid until
+    the next batch is taken.  names=False: read names are not kept (hits-only callers)."""
 
-    def __init__(self, index: QuasiIndex, path1, path2=None, opts=None, device=0, batch_units=1 << 20, threads=None, ph_compact=False):
+    def __init__(self, index: QuasiIndex, path1, path2=None, opts=None, device=0, batch_units=1 << 20, threads=None, ph_compact=False,
+                 names=True):
         self._h = C.c_void_p()
         self.paired = path2 is not None
+        self.names = bool(names)
         opts = opts or default_opts()
-        rc = lib().qm_stream_open(index._h, int(device), 1 if ph_compact else 0, C.byref(opts), os.fsencode(path1),
-                                  os.fsencode(path2) if path2 else None, int(batch_units),
-                                  int(threads or min(32, os.cpu_count() or 1)), C.byref(self._h))
+        devs = [int(d) for d in device] if isinstance(device, (list, tuple)) else [int(device)]
+        self.devices = devs
+        darr = (C.c_int32 * len(devs))(*devs)
+        rc = lib().qm_stream_open_ex(index._h, darr, len(devs), 1 if ph_compact else 0, C.byref(opts), os.fsencode(path1),
+                                     os.fsencode(path2) if path2 else None, int(batch_units),
+                                     int(threads or min(32, os.cpu_count() or 1)), 0 if names else 1, C.byref(self._h))
         if rc != 0:
             raise QmError("qm_stream_open failed (%d): %s" % (rc, lib().qm_stream_last_error().decode(errors="replace")))
+        self._index = index
 
     def __iter__(self):
         L = lib()
         sb = QmStreamBatch()
 
-        def arr(p, count, dt):
-            if count == 0 or not p:
-                return np.zeros(0, dtype=dt)
-            ct = {np.int64: C.c_int64, np.uint8: C.c_uint8}.get(dt, C.c_uint8)
-            return np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(count,))
+        arr = _view
         while True:
             rc = L.qm_stream_next(self._h, C.byref(sb))
             if rc != 0:
@@ -487,22 +512,27 @@ class MappedStream:
                 return
             b = ReadBatch(); b.n = n = sb.n_units
             b.off1 = arr(sb.off1, n + 1, np.int64); b.seq1 = arr(sb.seq1, int(b.off1[-1]), np.uint8)
-            b.name_off1 = arr(sb.name_off1, n + 1, np.int64); b.names1 = arr(sb.names1, int(b.name_off1[-1]), np.uint8)
+            if self.names:
+                b.name_off1 = arr(sb.name_off1, n + 1, np.int64); b.names1 = arr(sb.names1, int(b.name_off1[-1]), np.uint8)
             if self.paired:
                 b.off2 = arr(sb.off2, n + 1, np.int64); b.seq2 = arr(sb.seq2, int(b.off2[-1]), np.uint8)
-                b.name_off2 = arr(sb.name_off2, n + 1, np.int64); b.names2 = arr(sb.names2, int(b.name_off2[-1]), np.uint8)
+                if self.names:
+                    b.name_off2 = arr(sb.name_off2, n + 1, np.int64); b.names2 = arr(sb.names2, int(b.name_off2[-1]), np.uint8)
+            b.device = sb.device
             b.hit_offsets = arr(sb.hit_offsets, n + 1, np.int64)
             b.n_hits = sb.n_hits
-            b.hits = arr(sb.hits, sb.n_hits * 32, np.uint8).view(HIT_DTYPE) if sb.n_hits else np.zeros(0, dtype=HIT_DTYPE)
+            b.hits = arr(sb.hits, sb.n_hits, HIT_DTYPE) if sb.n_hits else np.zeros(0, dtype=HIT_DTYPE)
             b.counters = sb.counters.as_dict()
             b.gpu_ms = sb.gpu_ms
             yield b
 
     def stats(self):
-        a = (C.c_double * 6)()
-        lib().qm_stream_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
-        _check(lib().qm_stream_stats(self._h, a))
-        return dict(zip(("read_s", "map_s", "fetch_s", "caller_wait_s", "open_s", "alloc_s"), [float(x) for x in a]))
+        """seconds: read_s = open to the last batch packed (wall), map_s / fetch_s = upload + kernels / download summed over the
+        contexts, parse_cpu_s / copy_cpu_s = the ingest workers' task time summed over the workers"""
+        a = (C.c_double * 12)()
+        _check(lib().qm_stream_stats_ex(self._h, a, 12))
+        return dict(zip(("read_s", "map_s", "fetch_s", "caller_wait_s", "open_s", "alloc_s", "first_batch_s", "parse_cpu_s", "copy_cpu_s",
+                         "inflate_s", "bytes_parsed", "last_mapped_s"), [float(x) for x in a]))
 
     def close(self):
         if self._h:

@@ -81,22 +81,24 @@ struct Replica {
   int device = 0;
   uint8_t* d_text = nullptr; int32_t* d_SA = nullptr; void* d_sainfo = nullptr; void* d_slots = nullptr; uint64_t cap = 0;
   void* d_ph = nullptr; PhIndex hPh; std::vector<void*> phAllocs; int32_t* d_txpOff = nullptr; int32_t* d_txpLen = nullptr; int64_t devBytes = 0;
+  std::mutex sanextMu; unsigned int* d_sanext = nullptr;   // -s: built by the first -s call of any context of this replica
   ~Replica() {
     hipSetDevice(device);
-    void* ptrs[] = {d_text, d_SA, d_sainfo, d_slots, d_txpOff, d_txpLen};
+    void* ptrs[] = {d_text, d_SA, d_sainfo, d_slots, d_txpOff, d_txpLen, d_sanext};
     for (void* p : ptrs) if (p) hipFree(p);
     for (void* p : phAllocs) if (p) hipFree(p);
   }
 };
 static std::mutex g_repMu;
 static std::map<std::pair<const qm_index*, int>, std::weak_ptr<Replica>> g_reps;   // key: index, device * 2 + (compact perfect hash)
+static std::map<std::pair<const qm_index*, int>, std::shared_ptr<std::mutex>> g_repBuild;   // one builder per key at a time
 
 struct qm_ctx {
   const qm_index* ix = nullptr;
   std::shared_ptr<Replica> rep;
   int device = 0, numCU = 256;
   hipStream_t stream = nullptr, copyStream = nullptr;      // kernels / host-buffer uploads (overlapped chunk by chunk)
-  unsigned int* d_sanext = nullptr;                         // -s: text characters behind every suffix's k-mer, built at the first -s call
+  unsigned int* d_sanext = nullptr;                         // -s: text characters behind every suffix's k-mer (the replica's, built at its first -s call)
   hipStream_t planStream = nullptr;                         // -s: the plan kernels of the later chunks, under the ksw2 kernel of the earlier ones
   hipEvent_t evPlan[QM_SEL_CHUNKS_B + 1] = {};              // ... [i]: chunk i planned; [last]: the plan stream may start
   u64* d_ntk = nullptr;                                     // ... one task counter per chunk
@@ -323,6 +325,11 @@ int qm_index_open(const char* dirIn, qm_index** out) {
 
 int qm_index_close(qm_index* ix) {
   if (!ix) return QM_OK;
+  {   // a later index may be allocated at this address: nothing registered under it may survive it
+    std::lock_guard<std::mutex> lk(g_repMu);
+    for (auto it = g_reps.begin(); it != g_reps.end();) { if (it->first.first == ix) it = g_reps.erase(it); else ++it; }
+    for (auto it = g_repBuild.begin(); it != g_repBuild.end();) { if (it->first.first == ix) it = g_repBuild.erase(it); else ++it; }
+  }
   ix->sa.close(); ix->txp.close(); ix->rsd.close(); ix->hash.close(); ix->bph.close(); ix->val.close();
   delete ix;
   return QM_OK;
@@ -372,7 +379,6 @@ int qm_ctx_destroy(qm_ctx* c) {
   if (c->evB) hipEventDestroy(c->evB);
   if (c->stream) hipStreamDestroy(c->stream);
   if (c->copyStream) hipStreamDestroy(c->copyStream);
-  if (c->d_sanext) hipFree(c->d_sanext);
   if (c->planStream) hipStreamDestroy(c->planStream);
   for (hipEvent_t e : c->evPlan) if (e) hipEventDestroy(e);
   if (c->d_ntk) hipFree(c->d_ntk);
@@ -380,7 +386,11 @@ int qm_ctx_destroy(qm_ctx* c) {
   if (c->evStage[0]) hipEventDestroy(c->evStage[0]);
   if (c->evStage[1]) hipEventDestroy(c->evStage[1]);
   if (c->h_stage) hipHostFree(c->h_stage);
-  { std::lock_guard<std::mutex> lk(g_repMu); c->rep.reset(); }   // the last context on (index, device) frees the replica
+  {   // the last context on (index, device) frees the replica
+    std::lock_guard<std::mutex> lk(g_repMu);
+    c->rep.reset();
+    for (auto it = g_reps.begin(); it != g_reps.end();) { if (it->second.expired()) it = g_reps.erase(it); else ++it; }
+  }
   delete c;
   return QM_OK;
 }
@@ -408,6 +418,16 @@ int qm_ctx_create_ex(const qm_index* ix, int device_id, uint32_t flags, qm_ctx**
   CK(hipEventCreateWithFlags(&c->evCopy, hipEventDisableTiming));
   CK(hipEventCreate(&c->ev0)); CK(hipEventCreate(&c->ev1)); CK(hipEventCreate(&c->evA)); CK(hipEventCreate(&c->evB));
   CK(hipMalloc((void**)&c->d_scal, QM_SC_WORDS * sizeof(u64)));
+  // one builder per (index, device image) at a time: a second thread that asks for the same replica while the first one is
+  // still uploading waits here and then shares it
+  std::shared_ptr<std::mutex> buildMu;
+  {
+    std::lock_guard<std::mutex> lk(g_repMu);
+    auto& m = g_repBuild[std::make_pair(ix, repKey)];
+    if (!m) m = std::make_shared<std::mutex>();
+    buildMu = m;
+  }
+  std::lock_guard<std::mutex> buildLock(*buildMu);
   {
     std::lock_guard<std::mutex> lk(g_repMu);
     auto it = g_reps.find(std::make_pair(ix, repKey));
@@ -416,6 +436,7 @@ int qm_ctx_create_ex(const qm_index* ix, int device_id, uint32_t flags, qm_ctx**
       Replica& R = *c->rep;
       c->d_text = R.d_text; c->d_SA = R.d_SA; c->d_sainfo = R.d_sainfo; c->d_slots = R.d_slots; c->cap = R.cap; c->d_ph = R.d_ph; c->hPh = R.hPh;
       c->d_txpOff = R.d_txpOff; c->d_txpLen = R.d_txpLen; c->devBytes = R.devBytes;
+      { std::lock_guard<std::mutex> l2(R.sanextMu); c->d_sanext = R.d_sanext; }
       *out = c;
       return QM_OK;
     }
@@ -597,12 +618,20 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
   }
   const bool wantFound = rq.keepFound || rq.mode == QM_RUN_COLLECT || twoPass;
   if (wantFound) { if ((rc = ensure(c->d_found, c->capFound, nreads + 1))) return rc; }
-  if (o->sel_aln && rq.mode != QM_RUN_FROM_INTERVALS && !c->d_sanext && c->ix->nSA > 0) {
-    // first -s call of this context: the table that turns a capped MMP extension into one trip (sanext_entry); 4 bytes per
-    // suffix-array entry, built from text and SA as they sit in HBM
-    HIPCHK(hipMalloc((void**)&c->d_sanext, (size_t)c->ix->nSA * sizeof(unsigned int)));
-    HIPCHK(qmk_build_sanext(c->d_text, c->ix->n, c->d_SA, c->ix->nSA, c->ix->k, c->d_sanext, c->stream));
-    c->devBytes += c->ix->nSA * 4;
+  if (o->sel_aln && rq.mode != QM_RUN_FROM_INTERVALS && !c->d_sanext && c->ix->nSA > 0 && c->rep) {
+    // first -s call on this replica: the table that turns a capped MMP extension into one trip (sanext_entry); 4 bytes per
+    // suffix-array entry, built from text and SA as they sit in HBM, shared by every context of the replica
+    Replica& R = *c->rep;
+    std::lock_guard<std::mutex> lk(R.sanextMu);
+    if (!R.d_sanext) {
+      unsigned int* p = nullptr;
+      HIPCHK(hipMalloc((void**)&p, (size_t)c->ix->nSA * sizeof(unsigned int)));
+      hipError_t e = qmk_build_sanext(c->d_text, c->ix->n, c->d_SA, c->ix->nSA, c->ix->k, p, c->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+      if (e != hipSuccess) { hipFree(p); return fail(QM_E_NOGPU, "building the -s extension table: %s", hipGetErrorString(e)); }
+      R.d_sanext = p; R.devBytes += c->ix->nSA * 4;
+    }
+    c->d_sanext = R.d_sanext; c->devBytes = R.devBytes;
   }
   const DevIndex ix = dev_index(c);
   c->lastRelaunches = 0; c->lastSlowReads = 0; c->lastIvTotal = 0;
@@ -985,11 +1014,17 @@ int qm_fetch_intervals(qm_ctx* c, int64_t* int_offsets, qm_sa_interval_hit* ints
   }
   if (!ints) return QM_OK;
   if (cap < int_offsets[n]) return fail(QM_E_ARG, "interval buffer too small");
-  std::vector<qm_sa_interval_hit> all((size_t)c->lastIvTotal + 1);
-  if (c->lastIvTotal) HIPCHK(hipMemcpy(all.data(), c->d_iv, (size_t)c->lastIvTotal * sizeof(qm_sa_interval_hit), hipMemcpyDeviceToHost));
+  // the cursor of the chunked allocator may stand up to one chunk behind the buffer's end (a chunk is reserved whole, the
+  // overflow check is per read): only what lies inside the allocation is copied -- every recorded interval does
+  const int64_t used = c->lastIvTotal < c->capIv ? c->lastIvTotal : c->capIv;
+  std::vector<qm_sa_interval_hit> all((size_t)used + 1);
+  if (used) HIPCHK(hipMemcpy(all.data(), c->d_iv, (size_t)used * sizeof(qm_sa_interval_hit), hipMemcpyDeviceToHost));
   int64_t w = 0;
   for (int64_t r = 0; r < nreads; ++r)
-    for (uint32_t j = 0; j < cnt[(size_t)r]; ++j) ints[w++] = all[(size_t)(off[(size_t)r] + j)];
+    for (uint32_t j = 0; j < cnt[(size_t)r]; ++j) {
+      if (off[(size_t)r] + (long long)j >= used) return fail(QM_E_STATE, "interval list of read %lld lies outside the buffer (internal error)", (long long)r);
+      ints[w++] = all[(size_t)(off[(size_t)r] + j)];
+    }
   return QM_OK;
 }
 

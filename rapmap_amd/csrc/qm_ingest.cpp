@@ -1,0 +1,709 @@
+// qm_ingest.cpp -- FASTA/FASTQ(.gz) files -> packed batches (bytes, offsets[n+1]) of qm_map_pairs / qm_map_reads, at the
+// rate the mapping kernels consume them.
+//
+// The reference feeds its mapping threads from ONE kseq producer thread that hands every record over as std::strings
+// (src/FastxParser.cpp:229-328, used at src/RapMapSAMapper.cpp:853,869-871).  Here nothing about ingest is serial but the
+// bookkeeping:
+//   * a plain file is cut at fixed byte offsets into chunks; a chunk starts at the first record boundary at or behind its
+//     offset (record resync: sync_record), so any worker can parse any chunk without having seen the bytes before it;
+//   * a PARSE task turns one chunk into a table of (name, sequence) positions plus running byte counts -- the only pass
+//     that looks for line ends;
+//   * chunks complete out of order; as soon as the in-order frontier of both files holds a batch's worth of records the
+//     batch gets a slot (buffers from the caller's allocator: pinned host memory for qm_stream) and is cut into COPY tasks,
+//     each of which moves the characters of a run of records from the file mapping STRAIGHT into their final place in the
+//     slot and writes their offsets (the destination of every record is known from the running counts: no staging copy,
+//     no second pass over a finished batch);
+//   * workers prefer copy tasks (they finish batches) over parse tasks (they start new ones); several batches are in
+//     flight at once, bounded by the number of slots and by a read-ahead limit per file;
+//   * .gz input: one inflate thread per file produces blocks that end on a record boundary; they enter the same parse ->
+//     copy pipeline, so decompression of block i+1 overlaps parsing and packing of block i.
+// Batches leave in input order.  Qualities are dropped, as the reference's parser does.
+// Plain C++ (no HIP); part of libqmap_mi355.so.
+#include <errno.h>
+#include <fcntl.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/qmap_mi355.h"
+#include "qm_io_internal.h"
+
+namespace {
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+inline const char* eol(const char* p, const char* e) {
+  const char* q = (const char*)memchr(p, '\n', (size_t)(e - p));
+  return q ? q : e;
+}
+inline size_t rstrip(const char* b, const char* e) { while (e > b && (e[-1] == '\r' || e[-1] == '\n')) --e; return (size_t)(e - b); }
+
+// Start of the first FASTQ/FASTA record at or after p (p may be mid-record): a line starting with '@' whose
+// line-after-next starts with '+' and whose quality line is as long as its sequence line (a quality line may
+// itself start with '@'), or any line starting with '>'.  *hitEnd: the search looked at the end of the buffer -- with more
+// bytes behind e the answer could be different (callers that see only a window of the file widen it and ask again).
+const char* sync_record(const char* base, const char* p, const char* e, bool fastq, bool* hitEnd = nullptr) {
+  bool dummy; bool& hit = hitEnd ? *hitEnd : dummy; hit = false;
+  if (p <= base) return base;
+  if (p >= e) { hit = true; return e; }
+  const char* q = eol(p - 1, e);             // go to the next line start
+  p = q < e ? q + 1 : e;
+  while (p < e) {
+    if (!fastq) { if (*p == '>') return p; }
+    else if (*p == '@') {
+      const char* l1 = eol(p, e); if (l1 == e) break;
+      const char* l2 = eol(l1 + 1, e); if (l2 == e) break;
+      if (l2 + 1 >= e) break;
+      if (l2[1] == '+') {
+        const char* l3 = eol(l2 + 1, e);
+        if (l3 == e) break;
+        const char* l4 = eol(l3 + 1, e);
+        if (l4 == e) hit = true;
+        if (rstrip(l3 + 1, l4) == rstrip(l1 + 1, l2)) return p;
+        if (l4 == e) break;
+      }
+    }
+    const char* l = eol(p, e);
+    p = l < e ? l + 1 : e;
+  }
+  hit = true;
+  return e;
+}
+
+// One record of a parsed chunk: where its name and its sequence start (relative to the chunk's first byte; ARENA: the
+// sequence was joined from several FASTA lines and sits in the chunk's arena) and how many sequence / name bytes precede it
+// in the chunk.  recs[n] closes the table with the totals.
+struct Rec { uint32_t nameOff, seqOff, cumSeq, cumName; };
+constexpr uint32_t ARENA = 0x80000000u;
+
+struct Chunk {
+  int src = 0; int64_t id = 0;
+  const char* base = nullptr; const char* end = nullptr;
+  std::vector<Rec> recs; uint32_t n = 0;
+  std::vector<char> arena;           // joined multi-line FASTA sequences
+  std::vector<char> data;            // gz: the decompressed bytes this chunk owns
+  int pending = 0;                   // copy tasks still reading from it
+  bool assigned = false;             // every record belongs to a batch
+  bool bad = false;
+};
+
+// Parse the whole records of [b, e) -- the range starts on a record boundary and ends on one (or at the end of the file).
+// FASTQ: 4-line records; FASTA: header + sequence lines, a multi-line sequence is joined in the arena.
+bool parse_chunk(Chunk& C, bool fastq) {
+  const char* b = C.base; const char* e = C.end; const char* p = b;
+  std::vector<Rec>& R = C.recs;
+  R.clear(); C.arena.clear();
+  if ((size_t)(e - b) >= (size_t)ARENA) return false;
+  R.reserve((size_t)(e - b) / (fastq ? 160 : 400) + 16);
+  uint32_t cs = 0, cn = 0;
+  while (p < e) {
+    while (p < e && (*p == '\n' || *p == '\r')) ++p;
+    if (p >= e) break;
+    const char* l1 = eol(p, e);
+    if (*p == '@' && fastq) {
+      if (l1 == e) return false;
+      const char* s = l1 + 1; const char* l2 = eol(s, e);
+      if (l2 == e) return false;
+      const char* pl = l2 + 1; const char* l3 = eol(pl, e);
+      if (l3 == e || *pl != '+') return false;
+      const char* q = l3 + 1; const char* l4 = eol(q, e);
+      const uint32_t nl = (uint32_t)rstrip(p + 1, l1), sl = (uint32_t)rstrip(s, l2);
+      R.push_back(Rec{(uint32_t)(p + 1 - b), (uint32_t)(s - b), cs, cn});
+      cs += sl; cn += nl;
+      p = l4 < e ? l4 + 1 : e;
+    } else if (*p == '>' && !fastq) {
+      const char* s = l1 < e ? l1 + 1 : e;
+      const uint32_t nl = (uint32_t)rstrip(p + 1, l1);
+      // single-line sequence: referenced in place; several lines: joined in the arena
+      const char* c = s; int lines = 0; const char* first = s; size_t firstLen = 0;
+      const size_t a0 = C.arena.size();
+      while (c < e && *c != '>') {
+        const char* le = eol(c, e);
+        const size_t ll = rstrip(c, le);
+        if (ll > 0) {
+          if (lines == 0) { first = c; firstLen = ll; }
+          else {
+            if (lines == 1) C.arena.insert(C.arena.end(), first, first + firstLen);
+            C.arena.insert(C.arena.end(), c, c + ll);
+          }
+          ++lines;
+        }
+        c = le < e ? le + 1 : e;
+      }
+      uint32_t sl;
+      if (lines <= 1) { R.push_back(Rec{(uint32_t)(p + 1 - b), (uint32_t)(first - b), cs, cn}); sl = (uint32_t)firstLen; }
+      else {
+        if (C.arena.size() >= (size_t)ARENA) return false;
+        R.push_back(Rec{(uint32_t)(p + 1 - b), (uint32_t)a0 | ARENA, cs, cn}); sl = (uint32_t)(C.arena.size() - a0);
+      }
+      cs += sl; cn += nl;
+      p = c;
+    } else return false;
+  }
+  C.n = (uint32_t)R.size();
+  R.push_back(Rec{0, 0, cs, cn});
+  return true;
+}
+
+struct CopyTask { int slot; Chunk* ch; uint32_t r0, r1; int64_t dstRec, dstSeq, dstName; };
+
+struct InSlot {
+  qm_batch_bufs bufs;
+  int64_t n = 0, seqNo = -1;
+  int pending = 0;
+  int state = 0;                 // 0 free, 1 being filled, 2 complete, 3 with a consumer
+  int allocLeft = 0;             // buffers the allocator threads still owe this slot (it is not used before they are done)
+};
+
+struct Src {
+  std::string path;
+  bool gz = false, fastq = true;
+  const char* map = nullptr; size_t len = 0;      // plain: the file; gz: the compressed file
+  int fd = -1; bool pread = false;                // plain, QM_INGEST_PREAD: chunks are read() into buffers instead of mapped
+  size_t chunkBytes = 0; int64_t nChunks = 0;      // plain
+  int64_t nextParse = 0;                           // next chunk id for a parser
+  int64_t frontier = 0;                            // chunks [0, frontier) are linked in order
+  std::map<int64_t, Chunk*> done;                  // parsed, waiting for their predecessors
+  std::deque<Chunk*> line;                         // linked in order, not yet fully assigned
+  uint32_t headRec = 0;                            // first unassigned record of line.front()
+  int64_t avail = 0;                               // records linked and not yet assigned
+  int64_t inParse = 0;                             // chunks with a parser right now
+  int64_t doneRecs = 0;                            // records of the chunks in `done`
+  int64_t linkedChunks = 0, linkedRecs = 0;        // totals so far (records per chunk: what a chunk in flight is expected to bring)
+  bool allHanded = false;                          // plain: nextParse == nChunks; gz: the inflater is done and its queue is empty
+  bool eof() const { return allHanded && inParse == 0 && done.empty(); }
+  // gz: blocks from the inflate thread, in order
+  std::thread inflater; std::deque<Chunk*> blocks; bool inflDone = false;
+};
+
+}  // namespace
+
+struct qm_ingest {
+  int nsrc = 0; Src src[2];
+  int64_t batchUnits = 0; uint32_t flags = 0;
+  std::vector<InSlot> slots;
+  std::vector<std::thread> workers, allocators;
+  std::mutex mu; std::condition_variable cvWork, cvOut, cvInfl;
+  std::deque<CopyTask> copyQ;
+  std::vector<Chunk*> freeChunks;
+  int64_t nextSeq = 0, nextHand = 0;
+  bool ended = false, stop = false;
+  int failed = 0; char err[384] = "";
+  // statistics
+  double tOpen = 0, tFirst = 0, tEnd = 0, tParse = 0, tCopy = 0, tInfl = 0; int64_t bytesParsed = 0, nParse = 0, nCopy = 0;
+};
+
+namespace {
+
+void set_fail(qm_ingest* g, int code, const char* fmt, ...) {
+  if (g->failed) return;
+  g->failed = code;
+  va_list ap; va_start(ap, fmt); vsnprintf(g->err, sizeof(g->err), fmt, ap); va_end(ap);
+}
+
+template <typename T>
+bool ensure_buf(const qm_batch_bufs& B, T** p, size_t* cap, size_t want) {
+  if (*p && *cap >= want) return true;
+  if (*p) B.release(*p);
+  const size_t nc = want + want / 4 + 4096;
+  *p = (T*)B.alloc(nc * sizeof(T)); *cap = *p ? nc : 0;
+  return *p != nullptr;
+}
+
+Chunk* get_chunk(qm_ingest* g) {                    // (lock held) parse tables are recycled: fresh vectors are fresh pages
+  if (!g->freeChunks.empty()) { Chunk* c = g->freeChunks.back(); g->freeChunks.pop_back(); return c; }
+  return new Chunk();
+}
+void put_chunk(qm_ingest* g, Chunk* c) {            // (lock held)
+  c->pending = 0; c->assigned = false; c->bad = false; c->n = 0; c->base = c->end = nullptr;
+  if (c->data.capacity() > ((size_t)64 << 20)) { std::vector<char>().swap(c->data); }
+  if (g->freeChunks.size() < 256) g->freeChunks.push_back(c); else delete c;
+}
+
+// (lock held) Turn linked records into batches while both files hold enough of them and a slot is free.
+void form_batches(qm_ingest* g) {
+  while (!g->failed && !g->ended) {
+    int64_t n = g->batchUnits;
+    bool ready = true, allEof = true;
+    for (int s = 0; s < g->nsrc; ++s) {
+      Src& S = g->src[s];
+      if (S.avail < g->batchUnits && !S.eof()) ready = false;
+      if (!S.eof()) allEof = false;
+      n = std::min(n, S.avail);
+    }
+    if (!ready) return;
+    if (n == 0) {
+      if (allEof) {
+        for (int s = 0; s < g->nsrc; ++s) if (g->src[s].avail != 0) { set_fail(g, QM_E_FORMAT, "paired files have different numbers of records"); break; }
+        g->ended = true; g->cvOut.notify_all();
+      } else {
+        // one file has ended with nothing left, the other still has records: more of it than of its mate
+        bool someEofEmpty = false; for (int s = 0; s < g->nsrc; ++s) if (g->src[s].eof() && g->src[s].avail == 0) someEofEmpty = true;
+        if (someEofEmpty) { set_fail(g, QM_E_FORMAT, "paired files have different numbers of records"); g->cvOut.notify_all(); }
+      }
+      return;
+    }
+    int si = -1;
+    for (size_t i = 0; i < g->slots.size(); ++i) if (g->slots[i].state == 0 && g->slots[i].allocLeft == 0) { si = (int)i; break; }
+    if (si < 0) return;
+    InSlot& L = g->slots[(size_t)si];
+    qm_batch_bufs& B = L.bufs;
+    const bool names = !(g->flags & QM_INGEST_NO_NAMES);
+    // sizes first (the buffers may have to grow), then the copy tasks
+    struct Piece { Chunk* ch; uint32_t r0, r1; };
+    std::vector<Piece> pieces[2];
+    bool ok = true;
+    for (int s = 0; s < g->nsrc && ok; ++s) {
+      Src& S = g->src[s];
+      int64_t left = n, seqBytes = 0, nameBytes = 0; uint32_t h = S.headRec;
+      for (size_t ci = 0; left > 0; ++ci) {
+        Chunk* c = S.line[ci];
+        const uint32_t take = (uint32_t)std::min<int64_t>(left, (int64_t)c->n - h);
+        if (take) {
+          pieces[s].push_back(Piece{c, h, h + take});
+          seqBytes += c->recs[h + take].cumSeq - c->recs[h].cumSeq; nameBytes += c->recs[h + take].cumName - c->recs[h].cumName;
+        }
+        left -= take; h = 0;
+      }
+      ok = ensure_buf(B, &B.off[s], &B.cap_off[s], (size_t)n + 1) && ensure_buf(B, &B.seq[s], &B.cap_seq[s], (size_t)seqBytes + 64);
+      if (ok && names) ok = ensure_buf(B, &B.noff[s], &B.cap_noff[s], (size_t)n + 1) && ensure_buf(B, &B.names[s], &B.cap_names[s], (size_t)nameBytes + 1);
+      if (ok) {
+        B.off[s][n] = seqBytes; memset(B.seq[s] + seqBytes, 0, 64);   // the mapper fetches reads a word at a time: defined bytes behind the last one
+        if (names) B.noff[s][n] = nameBytes;
+      }
+    }
+    if (!ok) { set_fail(g, QM_E_NOMEM, "out of memory for a batch of %lld reads", (long long)n); g->cvOut.notify_all(); return; }
+    L.n = n; L.seqNo = g->nextSeq++; L.state = 1; L.pending = 0;
+    const uint32_t maxRun = 8192;                          // records per copy task
+    size_t made = 0;
+    for (int s = 0; s < g->nsrc; ++s) {
+      Src& S = g->src[s];
+      int64_t dRec = 0, dSeq = 0, dName = 0;
+      for (const Piece& P : pieces[s]) {
+        for (uint32_t r = P.r0; r < P.r1; r += maxRun) {
+          const uint32_t r1 = std::min(P.r1, r + maxRun);
+          g->copyQ.push_back(CopyTask{si, P.ch, r, r1, dRec, dSeq, dName});
+          dRec += r1 - r; dSeq += P.ch->recs[r1].cumSeq - P.ch->recs[r].cumSeq; dName += P.ch->recs[r1].cumName - P.ch->recs[r].cumName;
+          P.ch->pending++; L.pending++; ++made;
+        }
+        if (P.r1 == P.ch->n) P.ch->assigned = true;
+      }
+      // advance the head of the line
+      int64_t left = n;
+      while (left > 0) {
+        Chunk* c = S.line.front();
+        const int64_t take = std::min<int64_t>(left, (int64_t)c->n - S.headRec);
+        left -= take; S.headRec += (uint32_t)take;
+        if (S.headRec == c->n) { S.line.pop_front(); S.headRec = 0; }
+      }
+      S.avail -= n;
+    }
+    if (made > 1) g->cvWork.notify_all(); else g->cvWork.notify_one();
+  }
+}
+
+// (lock held) a parsed chunk joins the line as soon as every chunk before it has
+void link_done(qm_ingest* g, Src& S) {
+  while (true) {
+    auto it = S.done.find(S.frontier);
+    if (it == S.done.end()) break;
+    Chunk* c = it->second; S.done.erase(it); S.frontier++;
+    S.doneRecs -= c->n; S.linkedChunks++; S.linkedRecs += c->n;
+    if (c->n == 0) { put_chunk(g, c); continue; }
+    S.line.push_back(c); S.avail += c->n;
+  }
+}
+
+void run_copy(qm_ingest* g, const CopyTask& T) {
+  InSlot& L = g->slots[(size_t)T.slot];
+  const Chunk& C = *T.ch; const int s = C.src;
+  const qm_batch_bufs& B = L.bufs;
+  const bool names = !(g->flags & QM_INGEST_NO_NAMES);
+  char* seq = B.seq[s]; int64_t* off = B.off[s]; char* nm = names ? B.names[s] : nullptr; int64_t* noff = names ? B.noff[s] : nullptr;
+  const Rec* R = C.recs.data();
+  const int64_t s0 = T.dstSeq - R[T.r0].cumSeq, n0 = T.dstName - R[T.r0].cumName;
+  int64_t d = T.dstRec;
+  for (uint32_t i = T.r0; i < T.r1; ++i, ++d) {
+    const uint32_t sl = R[i + 1].cumSeq - R[i].cumSeq;
+    const char* sp = (R[i].seqOff & ARENA) ? C.arena.data() + (R[i].seqOff & ~ARENA) : C.base + R[i].seqOff;
+    off[d] = s0 + R[i].cumSeq;
+    memcpy(seq + s0 + R[i].cumSeq, sp, sl);
+    if (names) {
+      noff[d] = n0 + R[i].cumName;
+      memcpy(nm + n0 + R[i].cumName, C.base + R[i].nameOff, R[i + 1].cumName - R[i].cumName);
+    }
+  }
+}
+
+// A parser's next job, if any (lock held): the next chunk (plain) or the oldest inflated block (gz) of the file that has
+// the fewest records in sight, unless that file is already two batches ahead of the batch being formed.
+Chunk* take_parse(qm_ingest* g) {
+  int best = -1; int64_t bestSight = 0;
+  for (int s = 0; s < g->nsrc; ++s) {
+    Src& S = g->src[s];
+    if (S.allHanded) continue;
+    if (S.gz && S.blocks.empty()) continue;
+    const int64_t live = (int64_t)S.line.size() + (int64_t)S.done.size() + S.inParse;
+    const int64_t per = S.linkedChunks ? std::max<int64_t>(1, S.linkedRecs / S.linkedChunks) : 1;
+    const int64_t sight = S.avail + S.doneRecs + S.inParse * per;
+    if (sight >= 2 * g->batchUnits && live >= 4) continue;          // read-ahead limit
+    if (live >= 8192) continue;
+    if (best < 0 || sight < bestSight) { best = s; bestSight = sight; }
+  }
+  if (best < 0) return nullptr;
+  Src& S = g->src[best];
+  Chunk* c;
+  if (S.gz) {
+    c = S.blocks.front(); S.blocks.pop_front();
+    if (S.blocks.empty() && S.inflDone) S.allHanded = true;
+    g->cvInfl.notify_all();
+  } else {
+    c = get_chunk(g);
+    c->src = best;
+    if (S.nextParse + 1 == S.nChunks) S.allHanded = true;
+  }
+  c->id = S.nextParse++;
+  S.inParse++;
+  return c;
+}
+
+// Plain file without a mapping: the bytes of chunk c -- from the first record boundary at or behind its offset to the first one
+// at or behind the next chunk's offset -- are pread() into the chunk's own buffer (one copy out of the page cache, no page
+// faults, no address-space lock), with enough slack behind the chunk's end to find that boundary; widened until both cuts
+// were decided without looking at the end of the window, so neighbouring chunks agree on them.
+bool load_chunk_pread(Src& S, Chunk& c) {
+  const size_t off0 = (size_t)c.id * S.chunkBytes, off1 = std::min(S.len, off0 + S.chunkBytes);
+  const size_t A = off0 ? off0 - 1 : 0;
+  size_t have = 0;
+  for (size_t slack = (size_t)256 << 10;; slack *= 4) {
+    const size_t B = std::min(S.len, off1 + slack);
+    if (c.data.size() < B - A) c.data.resize(B - A);
+    while (have < B - A) {
+      const ssize_t r = ::pread(S.fd, c.data.data() + have, B - A - have, (off_t)(A + have));
+      if (r < 0) { if (errno == EINTR) continue; return false; }
+      if (r == 0) return false;                            // the file shrank under us
+      have += (size_t)r;
+    }
+    const char* buf = c.data.data(); const char* e = buf + (B - A);
+    bool h0 = false, h1 = false;
+    const char* beg = off0 ? sync_record(buf, buf + 1, e, S.fastq, &h0) : buf;
+    const char* end = off1 >= S.len ? e : sync_record(buf, buf + (off1 - A), e, S.fastq, &h1);
+    if ((h0 || h1) && B < S.len) continue;
+    c.base = beg; c.end = end < beg ? beg : end;
+    return true;
+  }
+}
+
+void worker_loop(qm_ingest* g) {
+  std::unique_lock<std::mutex> lk(g->mu);
+  while (true) {
+    if (g->stop) return;
+    if (!g->copyQ.empty()) {
+      CopyTask T = g->copyQ.front(); g->copyQ.pop_front();
+      lk.unlock();
+      const double t0 = now_s();
+      run_copy(g, T);
+      const double dt = now_s() - t0;
+      lk.lock();
+      g->tCopy += dt; g->nCopy++;
+      InSlot& L = g->slots[(size_t)T.slot];
+      if (--L.pending == 0) { L.state = 2; g->tEnd = now_s() - g->tOpen; if (g->tFirst == 0) g->tFirst = g->tEnd; g->cvOut.notify_all(); }
+      Chunk* c = T.ch;
+      if (--c->pending == 0 && c->assigned) { put_chunk(g, c); g->cvWork.notify_one(); }   // room for another parse
+      continue;
+    }
+    if (!g->failed && !g->ended) {
+      Chunk* c = take_parse(g);
+      if (c) {
+        Src& S = g->src[c->src];
+        lk.unlock();
+        const double t0 = now_s();
+        bool ok = true;
+        if (!S.gz && S.pread) ok = load_chunk_pread(S, *c);
+        else if (!S.gz) {
+          const char* b = S.map; const char* e = S.map + S.len;
+          c->base = sync_record(b, b + (size_t)c->id * S.chunkBytes, e, S.fastq);
+          c->end = c->id + 1 >= S.nChunks ? e : sync_record(b, b + (size_t)(c->id + 1) * S.chunkBytes, e, S.fastq);
+          if (c->end < c->base) c->end = c->base;
+#ifdef MADV_POPULATE_READ
+          if (c->end > c->base) {        // map this chunk's pages in one call instead of a fault per 16 pages
+            const uintptr_t a = (uintptr_t)c->base & ~(uintptr_t)4095;
+            madvise((void*)a, (size_t)((uintptr_t)c->end - a), MADV_POPULATE_READ);
+          }
+#endif
+        }
+        if (ok) ok = parse_chunk(*c, S.fastq);
+        const double dt = now_s() - t0;
+        lk.lock();
+        g->tParse += dt; g->nParse++; g->bytesParsed += (int64_t)(c->end - c->base);
+        S.inParse--;
+        if (!ok) { set_fail(g, QM_E_FORMAT, "%s: malformed FASTA/FASTQ record", S.path.c_str()); put_chunk(g, c); g->cvOut.notify_all(); g->cvWork.notify_all(); continue; }
+        S.done[c->id] = c; S.doneRecs += c->n;
+        link_done(g, S);
+        form_batches(g);
+        if (g->ended || g->failed) g->cvWork.notify_all();
+        continue;
+      }
+    }
+    g->cvWork.wait(lk);
+  }
+}
+
+// The last position in [b, e) up to which the buffer holds whole records (b is a record start): FASTQ -- resync a little
+// before the end and walk whole records from there; FASTA -- the last header line (its record may continue behind e).
+const char* last_boundary(const char* b, const char* e, bool fastq) {
+  if (!fastq) {
+    const char* p = e;
+    while (p > b) {
+      const char* q = (const char*)memrchr(b, '>', (size_t)(p - b));
+      if (!q) return b;
+      if (q == b || q[-1] == '\n') return q;
+      p = q;
+    }
+    return b;
+  }
+  for (size_t back = (size_t)64 << 10;; back *= 4) {
+    const bool whole = back >= (size_t)(e - b);
+    const char* p = whole ? b : sync_record(b, e - back, e, true);
+    if (p < e) {
+      const char* cut = p;
+      while (true) {                               // walk whole 4-line records
+        const char* q = cut; int lines = 0;
+        while (lines < 4 && q < e) { const char* l = eol(q, e); if (l == e) break; q = l + 1; ++lines; }
+        if (lines < 4) break;
+        cut = q;
+      }
+      if (cut > p || whole) return cut;
+    }
+    if (whole) return b;
+  }
+}
+
+void inflate_loop(qm_ingest* g, int s) {
+  Src& S = g->src[s];
+  gzFile f = gzopen(S.path.c_str(), "rb");
+  if (!f) { std::lock_guard<std::mutex> lk(g->mu); set_fail(g, QM_E_IO, "cannot gzopen %s", S.path.c_str()); S.inflDone = true; S.allHanded = S.blocks.empty(); g->cvWork.notify_all(); g->cvOut.notify_all(); return; }
+  gzbuffer(f, 1 << 20);
+  const size_t BLK = (size_t)4 << 20;
+  std::vector<char> carry; bool first = true;
+  while (true) {
+    Chunk* c;
+    {
+      std::unique_lock<std::mutex> lk(g->mu);
+      g->cvInfl.wait(lk, [&] { return g->stop || g->failed || S.blocks.size() < 8; });
+      if (g->stop || g->failed) break;
+      c = get_chunk(g);
+    }
+    const double t0 = now_s();
+    c->src = s; c->data.resize(carry.size() + BLK);
+    if (!carry.empty()) memcpy(c->data.data(), carry.data(), carry.size());
+    size_t have = carry.size(); carry.clear();
+    bool eof = false, bad = false; const char* cut = nullptr;
+    while (true) {
+      const int got = gzread(f, c->data.data() + have, (unsigned)(c->data.size() - have));
+      if (got < 0) { bad = true; break; }
+      have += (size_t)got;
+      if ((size_t)got < c->data.size() - (have - (size_t)got)) eof = true;
+      if (first && have > 0) { S.fastq = c->data[0] != '>'; first = false; }
+      if (eof) { cut = c->data.data() + have; break; }
+      cut = last_boundary(c->data.data(), c->data.data() + have, S.fastq);
+      if (cut > c->data.data()) break;
+      c->data.resize(c->data.size() * 2);                 // one record larger than the block: keep reading
+    }
+    if (!bad) {
+      carry.assign(cut, (const char*)c->data.data() + have);
+      c->base = c->data.data(); c->end = cut;
+    }
+    const double dt = now_s() - t0;
+    std::unique_lock<std::mutex> lk(g->mu);
+    g->tInfl += dt;
+    if (bad) { set_fail(g, QM_E_IO, "%s: gzip stream is corrupt", S.path.c_str()); put_chunk(g, c); S.inflDone = true; S.allHanded = S.blocks.empty(); g->cvWork.notify_all(); g->cvOut.notify_all(); break; }
+    if (c->end > c->base) S.blocks.push_back(c); else put_chunk(g, c);
+    if (eof) { S.inflDone = true; if (S.blocks.empty()) S.allHanded = true; g->cvWork.notify_all(); break; }
+    g->cvWork.notify_one();
+  }
+  gzclose(f);
+  std::lock_guard<std::mutex> lk(g->mu);
+  if (!S.inflDone) { S.inflDone = true; S.allHanded = S.blocks.empty(); }
+  g->cvWork.notify_all();
+}
+
+int open_src(Src& S, const char* p) {
+  S.path = p;
+  int fd = ::open(p, O_RDONLY);
+  if (fd < 0) return qm_io_fail(QM_E_IO, "cannot open %s", p);
+  struct stat st;
+  if (fstat(fd, &st) != 0) { ::close(fd); return qm_io_fail(QM_E_IO, "cannot stat %s", p); }
+  S.len = (size_t)st.st_size;
+  unsigned char magic[2] = {0, 0};
+  const ssize_t got = ::pread(fd, magic, 2, 0);
+  S.gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+  if (S.len > 0 && !S.gz) {
+    S.map = (const char*)mmap(nullptr, S.len, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (S.map == MAP_FAILED) { S.map = nullptr; ::close(fd); return qm_io_fail(QM_E_IO, "cannot mmap %s", p); }
+    madvise((void*)S.map, S.len, MADV_SEQUENTIAL);
+    S.fastq = S.map[0] != '>';
+    const char* pe = getenv("QM_INGEST_PREAD");
+    S.pread = pe && atoi(pe) != 0;
+    if (S.pread) { S.fd = fd; return 0; }
+  }
+  ::close(fd);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qm_ingest_open(const char* path1, const char* path2, int32_t n_threads, int64_t batch_units, int32_t n_slots, uint32_t flags,
+                   void* (*alloc)(size_t), void (*release)(void*), qm_ingest** out) {
+  if (!path1 || !out || batch_units <= 0 || !alloc || !release) return qm_io_fail(QM_E_ARG, "qm_ingest_open: bad argument");
+  qm_ingest* g = new qm_ingest();
+  g->tOpen = now_s();
+  g->nsrc = path2 ? 2 : 1; g->batchUnits = batch_units; g->flags = flags;
+  int rc = open_src(g->src[0], path1);
+  if (!rc && path2) rc = open_src(g->src[1], path2);
+  if (rc) { for (int s = 0; s < 2; ++s) { if (g->src[s].map) munmap((void*)g->src[s].map, g->src[s].len); if (g->src[s].fd >= 0) ::close(g->src[s].fd); } delete g; return rc; }
+  const char* ce = getenv("QM_INGEST_CHUNK");
+  const size_t chunkBytes = ce && atoll(ce) > 0 ? (size_t)atoll(ce) : ((size_t)2 << 20);
+  for (int s = 0; s < g->nsrc; ++s) {
+    Src& S = g->src[s];
+    if (S.gz) continue;
+    S.chunkBytes = chunkBytes;
+    S.nChunks = (int64_t)((S.len + chunkBytes - 1) / chunkBytes);
+    if (S.nChunks == 0) S.allHanded = true;
+  }
+  g->slots.resize((size_t)std::max(2, (int)n_slots));
+  for (InSlot& L : g->slots) { memset(&L.bufs, 0, sizeof(L.bufs)); L.bufs.alloc = alloc; L.bufs.release = release; }
+  // The slots' buffers are sized from the head of the files and allocated by threads of their own WHILE the workers already
+  // parse (pinning a few hundred MB takes tens of milliseconds: as long as reading millions of records): one thread per
+  // array kind walks the slots in order, so slot 0 is complete first and the first batch can be packed a few milliseconds
+  // after the open.  A slot whose size could not be guessed (gz input) starts empty; form_batches grows what is too small.
+  {
+    const bool names = !(flags & QM_INGEST_NO_NAMES);
+    for (InSlot& L : g->slots) L.allocLeft = 0;
+    for (int s = 0; s < g->nsrc; ++s) {
+      Src& S = g->src[s];
+      if (S.gz || !S.map) continue;
+      Chunk c; c.base = S.map; c.end = S.map + std::min(S.len, (size_t)256 << 10);
+      if (c.end < S.map + S.len) { const char* lb = last_boundary(c.base, c.end, S.fastq); if (lb > c.base) c.end = lb; else continue; }
+      if (!parse_chunk(c, S.fastq) || c.n == 0) continue;
+      const double sb = (double)c.recs[c.n].cumSeq / c.n, nb = (double)c.recs[c.n].cumName / c.n;
+      const size_t capSeq = (size_t)((double)batch_units * (sb * 1.05 + 1.0)) + 4096, capNames = (size_t)((double)batch_units * (nb * 1.05 + 1.0)) + 4096;
+      const size_t capOff = (size_t)batch_units + 1 + 4096;
+      for (int kind = 0; kind < (names ? 4 : 2); ++kind) {
+        for (InSlot& L : g->slots) L.allocLeft++;
+        g->allocators.emplace_back([g, s, kind, capSeq, capNames, capOff]() {
+          for (size_t i = 0; i < g->slots.size(); ++i) {
+            { std::lock_guard<std::mutex> lk(g->mu); if (g->stop) return; }
+            qm_batch_bufs& B = g->slots[i].bufs;
+            const size_t bytes = kind == 0 ? capSeq : (kind == 2 ? capNames : capOff * 8);
+            void* p = B.alloc(bytes);
+            std::lock_guard<std::mutex> lk(g->mu);
+            if (p) {
+              if (kind == 0) { B.seq[s] = (char*)p; B.cap_seq[s] = capSeq; }
+              else if (kind == 1) { B.off[s] = (int64_t*)p; B.cap_off[s] = capOff; }
+              else if (kind == 2) { B.names[s] = (char*)p; B.cap_names[s] = capNames; }
+              else { B.noff[s] = (int64_t*)p; B.cap_noff[s] = capOff; }
+            }
+            if (--g->slots[i].allocLeft == 0) { form_batches(g); g->cvWork.notify_all(); }
+          }
+        });
+      }
+    }
+  }
+  for (int s = 0; s < g->nsrc; ++s) if (g->src[s].gz) g->src[s].inflater = std::thread(inflate_loop, g, s);
+  const int W = std::max(1, (int)n_threads);
+  for (int i = 0; i < W; ++i) g->workers.emplace_back(worker_loop, g);
+  {   // empty inputs end the stream without a single task
+    std::lock_guard<std::mutex> lk(g->mu);
+    form_batches(g);
+  }
+  *out = g;
+  return QM_OK;
+}
+
+int qm_ingest_next(qm_ingest* g, int* slot, int64_t* n_units, int64_t* seq_no, const qm_batch_bufs** bufs) {
+  if (!g || !slot || !n_units) return qm_io_fail(QM_E_ARG, "qm_ingest_next: bad argument");
+  std::unique_lock<std::mutex> lk(g->mu);
+  int si = -1;
+  g->cvOut.wait(lk, [&] {
+    if (g->failed || g->stop) return true;
+    for (size_t i = 0; i < g->slots.size(); ++i) if (g->slots[i].state == 2 && g->slots[i].seqNo == g->nextHand) { si = (int)i; return true; }
+    return g->ended && g->nextHand == g->nextSeq;
+  });
+  if (g->failed) return qm_io_fail(g->failed, "%s", g->err);
+  *slot = -1; *n_units = 0;
+  if (si < 0) return QM_OK;
+  InSlot& L = g->slots[(size_t)si];
+  L.state = 3; g->nextHand++;
+  *slot = si; *n_units = L.n;
+  if (seq_no) *seq_no = L.seqNo;
+  if (bufs) *bufs = &L.bufs;
+  return QM_OK;
+}
+
+void qm_ingest_release(qm_ingest* g, int slot) {
+  if (!g || slot < 0 || (size_t)slot >= g->slots.size()) return;
+  std::lock_guard<std::mutex> lk(g->mu);
+  g->slots[(size_t)slot].state = 0;
+  form_batches(g);
+  g->cvWork.notify_all();
+}
+
+/* [0] seconds from open to the first complete batch, [1] parse tasks (summed over the workers), [2] copy tasks (summed),
+ * [3] inflate threads, [4] bytes parsed, [5] tasks run, [6] seconds from open to the last complete batch so far, [7] batches */
+void qm_ingest_stats(qm_ingest* g, double* out8) {
+  if (!g || !out8) return;
+  std::lock_guard<std::mutex> lk(g->mu);
+  out8[0] = g->tFirst; out8[1] = g->tParse; out8[2] = g->tCopy; out8[3] = g->tInfl; out8[4] = (double)g->bytesParsed; out8[5] = (double)(g->nParse + g->nCopy);
+  out8[6] = g->tEnd; out8[7] = (double)g->nextSeq;
+}
+
+/* no further batches: consumers waiting in qm_ingest_next return (end of input), workers wind down */
+void qm_ingest_cancel(qm_ingest* g) {
+  if (!g) return;
+  std::lock_guard<std::mutex> lk(g->mu);
+  g->stop = true; g->cvWork.notify_all(); g->cvOut.notify_all(); g->cvInfl.notify_all();
+}
+
+void qm_ingest_close(qm_ingest* g) {
+  if (!g) return;
+  { std::lock_guard<std::mutex> lk(g->mu); g->stop = true; g->cvWork.notify_all(); g->cvOut.notify_all(); g->cvInfl.notify_all(); }
+  for (auto& t : g->workers) t.join();
+  for (auto& t : g->allocators) t.join();
+  for (int s = 0; s < g->nsrc; ++s) if (g->src[s].inflater.joinable()) g->src[s].inflater.join();
+  for (int s = 0; s < g->nsrc; ++s) {
+    Src& S = g->src[s];
+    for (auto& kv : S.done) delete kv.second;
+    for (Chunk* c : S.line) delete c;
+    for (Chunk* c : S.blocks) delete c;
+    if (S.map) munmap((void*)S.map, S.len);
+    if (S.fd >= 0) ::close(S.fd);
+  }
+  for (Chunk* c : g->freeChunks) delete c;
+  for (InSlot& L : g->slots) {
+    qm_batch_bufs& B = L.bufs;
+    for (int m = 0; m < 2; ++m) { if (B.seq[m]) B.release(B.seq[m]); if (B.off[m]) B.release(B.off[m]); if (B.names[m]) B.release(B.names[m]); if (B.noff[m]) B.release(B.noff[m]); }
+  }
+  delete g;
+}
+
+}  // extern "C"

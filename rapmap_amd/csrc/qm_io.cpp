@@ -1,10 +1,8 @@
 // qm_io.cpp -- host-side callers of the hot path:
-//   * qm_reader_*    FASTA/FASTQ(.gz) ingest into the packed (bytes, offsets[n+1]) batches qm_map_pairs takes.
-//                    Replaces the reference's single kseq producer + per-record std::string queue
-//                    (include/FastxParser.hpp:62-66, src/FastxParser.cpp:229-328): plain files are mmap'd and
-//                    indexed by n_threads workers on disjoint byte ranges, .gz files are inflated by one
-//                    thread per file; every byte is copied once, in parallel, into the packed batch;
-//                    qualities are dropped like the reference's parser does.
+//   * qm_reader_*    FASTA/FASTQ(.gz) ingest into the packed (bytes, offsets[n+1]) batches qm_map_pairs takes:
+//                    the ingest engine of qm_ingest.cpp (which replaces the reference's single kseq producer +
+//                    per-record std::string queue, include/FastxParser.hpp:62-66, src/FastxParser.cpp:229-328)
+//                    with malloc'd slots, handed out one batch at a time.
 //   * qm_sam_*       SAM text for a mapped batch, same bytes as `rapmap quasimap -o`
 //                    (writeSAMHeader include/RapMapUtils.hpp:97-115, writeAlignmentsToStream
 //                    src/RapMapUtils.cpp:198-588, writeUnalignedPairToStream :137-196, getSamFlags /
@@ -34,10 +32,11 @@
 #include "qm_io_internal.h"
 
 static thread_local char g_ioerr[512] = "";
-static int io_fail(int code, const char* fmt, ...) {
+int qm_io_fail(int code, const char* fmt, ...) {          // (shared with qm_ingest.cpp)
   va_list ap; va_start(ap, fmt); vsnprintf(g_ioerr, sizeof(g_ioerr), fmt, ap); va_end(ap);
   return code;
 }
+#define io_fail qm_io_fail
 extern "C" const char* qm_io_last_error(void) { return g_ioerr; }
 
 namespace {
@@ -77,370 +76,82 @@ class Pool {
   }
 };
 
-// ------------------------------------------------------------------ record index of one file
-// A parsed record is four pointers/lengths into storage that stays put (the mmap of a plain file, or a
-// decompressed block of a .gz file); bytes are copied exactly once, by qm_reader_next, into the packed batch.
-struct RecIdx { const char* nm; const char* s; uint32_t nl, sl; };
-
-static inline const char* eol(const char* p, const char* e) {
-  const char* q = (const char*)memchr(p, '\n', (size_t)(e - p));
-  return q ? q : e;
-}
-static inline size_t rstrip(const char* b, const char* e) { while (e > b && (e[-1] == '\r' || e[-1] == '\n')) --e; return (size_t)(e - b); }
-
-// Parse complete records in [p, e); returns the first byte not consumed (start of an incomplete record).
-// FASTQ: 4-line records; FASTA: header + sequence lines; a multi-line FASTA sequence is joined into `arena`
-// (which must not reallocate: it is reserved to the block size).  final: the buffer ends the file.
-static const char* parse_block(const char* p, const char* e, bool final, std::vector<RecIdx>& R, std::vector<char>& arena, bool& bad) {
-  while (p < e) {
-    while (p < e && (*p == '\n' || *p == '\r')) ++p;
-    if (p >= e) break;
-    const char* rec = p;
-    const char* l1 = eol(p, e);
-    if (l1 == e && !final) return rec;
-    if (*p == '@') {
-      if (l1 == e) { bad = true; return rec; }
-      const char* s = l1 + 1; const char* l2 = eol(s, e);
-      if (l2 == e) { if (!final) return rec; bad = true; return rec; }
-      const char* pl = l2 + 1; const char* l3 = eol(pl, e);
-      if (l3 == e) { if (!final) return rec; bad = true; return rec; }
-      const char* q = l3 + 1; const char* l4 = eol(q, e);
-      if (l4 == e && !final) return rec;
-      if (*pl != '+') { bad = true; return rec; }
-      R.push_back(RecIdx{p + 1, s, (uint32_t)rstrip(p + 1, l1), (uint32_t)rstrip(s, l2)});
-      p = l4 < e ? l4 + 1 : e;
-    } else if (*p == '>') {
-      const char* s = l1 < e ? l1 + 1 : e;
-      const uint32_t nl = (uint32_t)rstrip(p + 1, l1);
-      // single-line sequence: reference it in place; several lines: join them in the arena
-      const char* c = s; int lines = 0; const char* first = s; size_t firstLen = 0;
-      const size_t a0 = arena.size();
-      while (c < e && *c != '>') {
-        const char* le = eol(c, e);
-        if (le == e && !final) { arena.resize(a0); return rec; }
-        const size_t ll = rstrip(c, le);
-        if (ll > 0) {
-          if (lines == 0) { first = c; firstLen = ll; }
-          else {
-            if (lines == 1) arena.insert(arena.end(), first, first + firstLen);
-            arena.insert(arena.end(), c, c + ll);
-          }
-          ++lines;
-        }
-        c = le < e ? le + 1 : e;
-      }
-      if (c >= e && !final) { arena.resize(a0); return rec; }
-      if (lines <= 1) R.push_back(RecIdx{p + 1, first, nl, (uint32_t)firstLen});
-      else R.push_back(RecIdx{p + 1, arena.data() + a0, nl, (uint32_t)(arena.size() - a0)});
-      p = c;
-    } else { bad = true; return rec; }
-  }
-  return e;
-}
-
-// start of the first FASTQ/FASTA record at or after p (p may be mid-record): a line starting with '@' whose
-// line-after-next starts with '+' and whose quality line is as long as its sequence line (a quality line may
-// itself start with '@'), or any line starting with '>'.
-static const char* sync_record(const char* base, const char* p, const char* e, bool fastq) {
-  if (p == base) return p;
-  const char* q = eol(p - 1, e);             // go to the next line start
-  p = q < e ? q + 1 : e;
-  while (p < e) {
-    if (!fastq) { if (*p == '>') return p; }
-    else if (*p == '@') {
-      const char* l1 = eol(p, e); if (l1 == e) return e;
-      const char* l2 = eol(l1 + 1, e); if (l2 == e) return e;
-      if (l2 + 1 < e && l2[1] == '+') {
-        const char* l3 = eol(l2 + 1, e);
-        const char* l4 = l3 < e ? eol(l3 + 1, e) : e;
-        if (l3 < e && rstrip(l3 + 1, l4) == rstrip(l1 + 1, l2)) return p;
-      }
-    }
-    const char* l = eol(p, e);
-    p = l < e ? l + 1 : e;
-  }
-  return e;
-}
-
-struct Block {                 // storage a run of RecIdx entries points into
-  std::vector<char> data;      // decompressed bytes (gz only)
-  std::vector<std::vector<char>> arenas;   // joined multi-line FASTA sequences, one per parser thread
-  int64_t last = 0;            // global index of the block's last record + 1
-};
-
-struct Source {
-  std::string path;
-  bool gz = false, fastq = true, eof = false, bad = false;
-  const char* map = nullptr; size_t len = 0, pos = 0;      // plain file
-  gzFile gzf = nullptr; std::vector<char> carry;            // gz: undigested tail of the previous block
-  std::vector<RecIdx> idx;      // parsed, not yet handed out: idx[head..)
-  size_t head = 0;
-  // the parser threads' record lists, kept between blocks: freshly allocated vectors of this size are fresh pages every
-  // time (the allocator maps and unmaps them), and faulting those in cost more than the parsing itself
-  std::vector<std::vector<RecIdx>> partsKeep;
-  int64_t handed = 0, parsed = 0;   // global record counters
-  std::vector<Block*> blocks;   // FIFO of live storage blocks
-
-  int open(const char* p) {
-    path = p;
-    int fd = ::open(p, O_RDONLY);
-    if (fd < 0) return io_fail(QM_E_IO, "cannot open %s", p);
-    unsigned char magic[2] = {0, 0};
-    ssize_t got = ::read(fd, magic, 2);
-    struct stat st; fstat(fd, &st);
-    if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
-      ::close(fd); gz = true;
-      gzf = gzopen(p, "rb");
-      if (!gzf) return io_fail(QM_E_IO, "cannot gzopen %s", p);
-      gzbuffer(gzf, 1 << 20);
-      return 0;
-    }
-    len = (size_t)st.st_size;
-    if (len > 0) {
-      map = (const char*)mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
-      if (map == MAP_FAILED) { map = nullptr; ::close(fd); return io_fail(QM_E_IO, "cannot mmap %s", p); }
-      madvise((void*)map, len, MADV_SEQUENTIAL);
-      fastq = map[0] != '>';
-      idx.reserve((size_t)1 << 22);          // the list of parsed records never reallocates in steady state (see release())
-    } else eof = true;
-    ::close(fd);
-    return 0;
-  }
-  void close() {
-    if (map) munmap((void*)map, len);
-    map = nullptr;
-    if (gzf) gzclose(gzf);
-    gzf = nullptr;
-    for (Block* b : blocks) delete b;
-    blocks.clear();
-  }
-  int64_t avail() const { return (int64_t)(idx.size() - head); }
-
-  // storage whose records have all been handed out AND copied (called at the start of the next hand-out)
-  void release() {
-    if (head == idx.size()) { idx.clear(); head = 0; }                       // (keeps the capacity)
-    else if (head > (1u << 20) && head * 2 > idx.size()) { idx.erase(idx.begin(), idx.begin() + (long)head); head = 0; }
-    while (!blocks.empty() && blocks.front()->last <= handed) { delete blocks.front(); blocks.erase(blocks.begin()); }
-  }
-
-  // parse roughly `bytes` more input
-  void fill(size_t bytes, Pool& pool) {
-    const int nthreads = pool.size();
-    if (eof || bad) return;
-    Block* blk = new Block();
-    const char* b; const char* e; bool final;
-    if (gz) {
-      blk->data.resize(carry.size() + bytes);
-      if (!carry.empty()) memcpy(blk->data.data(), carry.data(), carry.size());
-      int got = gzread(gzf, blk->data.data() + carry.size(), (unsigned)bytes);
-      if (got < 0) { bad = true; delete blk; return; }
-      blk->data.resize(carry.size() + (size_t)got);
-      carry.clear();
-      final = (size_t)got < bytes;
-      if (final) eof = true;
-      if (blk->data.empty()) { delete blk; return; }
-      if (parsed == 0) fastq = blk->data[0] != '>';
-      b = blk->data.data(); e = b + blk->data.size();
-    } else {
-      size_t end = std::min(len, pos + bytes);
-      final = end == len;
-      b = map + pos; e = map + end;
-    }
-    const int T = std::max(1, std::min(nthreads, (int)((size_t)(e - b) >> 20)));
-    std::vector<const char*> cut((size_t)T + 1);
-    cut[0] = b; cut[(size_t)T] = e;
-    for (int t = 1; t < T; ++t) cut[(size_t)t] = sync_record(b, b + (size_t)(e - b) * (size_t)t / (size_t)T, e, fastq);
-    for (int t = 1; t <= T; ++t) if (cut[(size_t)t] < cut[(size_t)t - 1]) cut[(size_t)t] = cut[(size_t)t - 1];
-    if (partsKeep.size() < (size_t)T) partsKeep.resize((size_t)T);
-    std::vector<std::vector<RecIdx>>& parts = partsKeep;
-    for (auto& v : parts) v.clear();
-    std::vector<const char*> rest((size_t)T); std::vector<char> badv((size_t)T, 0);
-    blk->arenas.resize((size_t)T);
-    auto work = [&](int t) {
-      bool bd = false;
-      if (!fastq) blk->arenas[(size_t)t].reserve((size_t)(cut[(size_t)t + 1] - cut[(size_t)t]) + 16);   // never reallocates
-      parts[(size_t)t].reserve((size_t)(cut[(size_t)t + 1] - cut[(size_t)t]) / 128 + 16);
-#ifdef MADV_POPULATE_READ
-      if (!gz && cut[(size_t)t + 1] > cut[(size_t)t]) {     // map this slice's pages in one call instead of a fault per 16 pages
-        const uintptr_t a = (uintptr_t)cut[(size_t)t] & ~(uintptr_t)4095;
-        madvise((void*)a, (size_t)((uintptr_t)cut[(size_t)t + 1] - a), MADV_POPULATE_READ);
-      }
-#endif
-      rest[(size_t)t] = parse_block(cut[(size_t)t], cut[(size_t)t + 1], t == T - 1 ? final : true, parts[(size_t)t], blk->arenas[(size_t)t], bd);
-      badv[(size_t)t] = bd;
-    };
-    pool.run(T, work);
-    for (int t = 0; t < T; ++t) {
-      if (badv[(size_t)t] || (t < T - 1 && rest[(size_t)t] != cut[(size_t)t + 1])) { bad = true; break; }
-      idx.insert(idx.end(), parts[(size_t)t].begin(), parts[(size_t)t].end());
-      parsed += (int64_t)parts[(size_t)t].size();
-    }
-    blk->last = parsed;
-    blocks.push_back(blk);
-    const char* tail = rest[(size_t)T - 1];
-    if (gz) carry.assign(tail, e);
-    else { pos = (size_t)(tail - map); if (pos >= len) eof = true; }
-  }
-};
-
-// copy n records starting at S.idx[S.head] into one packed batch (parallel over records).  Dst owns four growable arrays.
-struct Dst {
-  char** seq; int64_t** off; char** names; int64_t** noff;
-  size_t* capSeq; size_t* capOff; size_t* capNames; size_t* capNoff;
-  void* (*alloc)(size_t); void (*release)(void*);
-  template <typename T> bool ensure(T** p, size_t* cap, size_t want) {
-    if (*p && *cap >= want) return true;
-    if (*p) release(*p);
-    const size_t nc = want + want / 4 + 4096;
-    *p = (T*)alloc(nc * sizeof(T)); *cap = *p ? nc : 0;
-    return *p != nullptr;
-  }
-};
-static bool pack_records(Source& S, int64_t n, Pool& pool, Dst& D) {
-  const int nthreads = pool.size();
-  if (!D.ensure(D.off, D.capOff, (size_t)n + 1) || !D.ensure(D.noff, D.capNoff, (size_t)n + 1)) return false;
-  int64_t* off = *D.off; int64_t* noff = *D.noff;
-  const RecIdx* R = S.idx.data() + S.head;
-  const int T = std::max(1, std::min<int>(nthreads, (int)(n / 16384) + 1));
-  std::vector<int64_t> sb((size_t)T + 1, 0), nb((size_t)T + 1, 0);
-  auto count = [&](int t) {
-    int64_t a = 0, b = 0;
-    for (int64_t i = n * t / T; i < n * (t + 1) / T; ++i) { a += R[i].sl; b += R[i].nl; }
-    sb[(size_t)t + 1] = a; nb[(size_t)t + 1] = b;
-  };
-  char* seq = nullptr; char* names = nullptr;
-  auto copy = [&](int t) {
-    int64_t so = sb[(size_t)t], no = nb[(size_t)t];
-    for (int64_t i = n * t / T; i < n * (t + 1) / T; ++i) {
-      off[(size_t)i] = so; noff[(size_t)i] = no;
-      memcpy(seq + so, R[i].s, R[i].sl); so += R[i].sl;
-      memcpy(names + no, R[i].nm, R[i].nl); no += R[i].nl;
-    }
-  };
-  auto run = [&](const std::function<void(int)>& fn) { pool.run(T, fn); };
-  run(count);
-  for (int t = 0; t < T; ++t) { sb[(size_t)t + 1] += sb[(size_t)t]; nb[(size_t)t + 1] += nb[(size_t)t]; }
-  if (!D.ensure(D.seq, D.capSeq, (size_t)sb[(size_t)T] + 64) || !D.ensure(D.names, D.capNames, (size_t)nb[(size_t)T] + 1)) return false;
-  seq = *D.seq; names = *D.names;
-  run(copy);
-  memset(seq + sb[(size_t)T], 0, 64);                       // the mapper fetches reads a word at a time: defined bytes behind the last one
-  off[(size_t)n] = sb[(size_t)T]; noff[(size_t)n] = nb[(size_t)T];
-  S.head += (size_t)n; S.handed += n;
-  return true;
-}
-
 }  // namespace
 
+// ------------------------------------------------------------------ qm_reader_*: the ingest engine (qm_ingest.cpp) behind the reader calls
+// A reader is the engine with plain malloc'd slots; the engine parses and packs ahead of the caller (three slots).  The
+// batch size is fixed by the first qm_reader_next call; a later call that asks for fewer units gets the current batch in pieces.
 struct qm_reader {
-  Source src[2]; int nsrc = 0; int nthreads = 1;
-  Pool* pool[2] = {nullptr, nullptr};     // paired input: the two files are parsed and packed side by side, half the workers each
-  qm_batch_bufs own;           // the buffers qm_reader_next hands out (plain malloc)
-  qm_reader() { memset(&own, 0, sizeof(own)); own.alloc = malloc; own.release = free; }
-  ~qm_reader() { for (int s = 0; s < 2; ++s) { delete pool[s]; free(own.seq[s]); free(own.off[s]); free(own.names[s]); free(own.noff[s]); } }
+  std::string path1, path2; bool paired = false; int nthreads = 1;
+  qm_ingest* g = nullptr; int64_t batchUnits = 0;
+  int slot = -1; int64_t n = 0, served = 0; const qm_batch_bufs* bufs = nullptr;
+  std::vector<int64_t> offTmp[2], noffTmp[2];       // rebased offsets of a piece that does not start the batch
 };
 
 extern "C" {
 
 int qm_reader_open(const char* path1, const char* path2, int32_t n_threads, qm_reader** out) {
   if (!path1 || !out) return io_fail(QM_E_ARG, "qm_reader_open: null argument");
+  for (const char* p : {path1, path2}) {
+    if (!p) continue;
+    int fd = ::open(p, O_RDONLY);
+    if (fd < 0) return io_fail(QM_E_IO, "cannot open %s", p);
+    ::close(fd);
+  }
   qm_reader* r = new qm_reader();
+  r->path1 = path1; r->paired = path2 != nullptr; if (path2) r->path2 = path2;
   r->nthreads = n_threads > 0 ? n_threads : 1;
-  r->nsrc = path2 ? 2 : 1;
-  int rc = r->src[0].open(path1);
-  if (!rc && path2) rc = r->src[1].open(path2);
-  if (rc) { r->src[0].close(); r->src[1].close(); delete r; return rc; }
-  const int per = std::max(1, r->nthreads / r->nsrc);
-  for (int s = 0; s < r->nsrc; ++s) r->pool[s] = new Pool(per);
   *out = r;
   return QM_OK;
 }
 
-// Average sequence / name bytes per record at the head of source s (plain files only: a look at the first 256 KB of the
-// mapping; 0, 0 when it cannot tell).  qm_stream_open sizes its pinned batch buffers from it before the first batch is read.
-void qm_reader_estimate(qm_reader* r, int s, double* seq_bytes, double* name_bytes) {
-  *seq_bytes = 0; *name_bytes = 0;
-  if (!r || s < 0 || s >= r->nsrc) return;
-  Source& S = r->src[s];
-  if (S.gz || !S.map || S.len == 0) return;
-  const size_t n = std::min(S.len, (size_t)256 << 10);
-  std::vector<RecIdx> R; std::vector<char> arena; bool bad = false;
-  arena.reserve(n + 16);
-  parse_block(S.map, S.map + n, n == S.len, R, arena, bad);
-  if (R.empty()) return;
-  double a = 0, b = 0;
-  for (const RecIdx& x : R) { a += x.sl; b += x.nl; }
-  *seq_bytes = a / (double)R.size(); *name_bytes = b / (double)R.size();
-}
-
 void qm_reader_close(qm_reader* r) {
   if (!r) return;
-  r->src[0].close(); r->src[1].close();
+  if (r->g) qm_ingest_close(r->g);
   delete r;
-}
-
-// parse until max_units records are available (or the input ends) and pack them into B's buffers (grown through B's allocator)
-int qm_reader_next_into(qm_reader* r, int64_t max_units, int64_t* n_units, qm_batch_bufs* B) {
-  if (!r || !n_units || !B || max_units <= 0) return io_fail(QM_E_ARG, "qm_reader_next: bad argument");
-  const size_t block = (size_t)128 << 20;
-  for (int s = 0; s < r->nsrc; ++s) r->src[s].release();
-  // both files advance together: parse them concurrently until each has max_units records (or ended)
-  auto need = [&](int s) { Source& S = r->src[s]; return S.avail() < max_units && !S.eof && !S.bad; };
-  while (need(0) || (r->nsrc == 2 && need(1))) {
-    if (r->nsrc == 2 && need(0) && need(1)) {
-      std::thread t2([&]() { r->src[1].fill(block, *r->pool[1]); });
-      r->src[0].fill(block, *r->pool[0]);
-      t2.join();
-    } else {
-      const int s = need(0) ? 0 : 1;
-      r->src[s].fill(block, *r->pool[s]);
-    }
-  }
-  for (int s = 0; s < r->nsrc; ++s)
-    if (r->src[s].bad) return io_fail(QM_E_FORMAT, "%s: malformed FASTA/FASTQ record", r->src[s].path.c_str());
-  int64_t n = std::min(max_units, r->src[0].avail());
-  if (r->nsrc == 2) {
-    n = std::min(n, r->src[1].avail());
-    if (n == 0 && r->src[0].avail() != r->src[1].avail())
-      return io_fail(QM_E_FORMAT, "paired files have different numbers of records");
-  }
-  Dst D[2];
-  for (int s = 0; s < 2; ++s)
-    D[s] = Dst{&B->seq[s], &B->off[s], &B->names[s], &B->noff[s], &B->cap_seq[s], &B->cap_off[s], &B->cap_names[s], &B->cap_noff[s], B->alloc, B->release};
-  bool ok = true;
-  if (r->nsrc == 2 && n > 0) {
-    bool ok2 = true;
-    std::thread t2([&]() { ok2 = pack_records(r->src[1], n, *r->pool[1], D[1]); });
-    ok = pack_records(r->src[0], n, *r->pool[0], D[0]);
-    t2.join();
-    ok = ok && ok2;
-  } else {
-    for (int s = 0; s < r->nsrc; ++s) ok = pack_records(r->src[s], n, *r->pool[s], D[s]) && ok;
-  }
-  if (!ok) return io_fail(QM_E_NOMEM, "out of memory for a batch of %lld reads", (long long)n);
-  *n_units = n;
-  return QM_OK;
 }
 
 int qm_reader_next(qm_reader* r, int64_t max_units, int64_t* n_units, const char** seq1, const int64_t** off1,
                    const char** names1, const int64_t** name_off1, const char** seq2, const int64_t** off2,
                    const char** names2, const int64_t** name_off2) {
-  if (!r) return io_fail(QM_E_ARG, "qm_reader_next: bad argument");
-  int rc = qm_reader_next_into(r, max_units, n_units, &r->own);
-  if (rc) return rc;
-  if (seq1) *seq1 = r->own.seq[0];
-  if (off1) *off1 = r->own.off[0];
-  if (names1) *names1 = r->own.names[0];
-  if (name_off1) *name_off1 = r->own.noff[0];
-  if (r->nsrc == 2) {
-    if (seq2) *seq2 = r->own.seq[1];
-    if (off2) *off2 = r->own.off[1];
-    if (names2) *names2 = r->own.names[1];
-    if (name_off2) *name_off2 = r->own.noff[1];
+  if (!r || !n_units || max_units <= 0) return io_fail(QM_E_ARG, "qm_reader_next: bad argument");
+  int rc;
+  if (!r->g) {
+    r->batchUnits = max_units;
+    if ((rc = qm_ingest_open(r->path1.c_str(), r->paired ? r->path2.c_str() : nullptr, r->nthreads, max_units, 3, 0, malloc, free, &r->g))) return rc;
+  }
+  if (r->slot < 0 || r->served >= r->n) {
+    if (r->slot >= 0) { qm_ingest_release(r->g, r->slot); r->slot = -1; }
+    if ((rc = qm_ingest_next(r->g, &r->slot, &r->n, nullptr, &r->bufs))) return rc;
+    r->served = 0;
+    if (r->n == 0) { *n_units = 0; return QM_OK; }
+  }
+  const int64_t i0 = r->served, cnt = std::min(max_units, r->n - i0);
+  r->served += cnt;
+  *n_units = cnt;
+  const qm_batch_bufs& B = *r->bufs;
+  const char** seqOut[2] = {seq1, seq2}; const int64_t** offOut[2] = {off1, off2};
+  const char** nmOut[2] = {names1, names2}; const int64_t** noffOut[2] = {name_off1, name_off2};
+  for (int s = 0; s < (r->paired ? 2 : 1); ++s) {
+    if (i0 == 0) {
+      if (seqOut[s]) *seqOut[s] = B.seq[s];
+      if (offOut[s]) *offOut[s] = B.off[s];
+      if (nmOut[s]) *nmOut[s] = B.names[s];
+      if (noffOut[s]) *noffOut[s] = B.noff[s];
+    } else {                                   // a later piece of the batch: same bytes, offsets rebased to the piece
+      r->offTmp[s].resize((size_t)cnt + 1); r->noffTmp[s].resize((size_t)cnt + 1);
+      for (int64_t i = 0; i <= cnt; ++i) { r->offTmp[s][(size_t)i] = B.off[s][i0 + i] - B.off[s][i0]; r->noffTmp[s][(size_t)i] = B.noff[s][i0 + i] - B.noff[s][i0]; }
+      if (seqOut[s]) *seqOut[s] = B.seq[s] + B.off[s][i0];
+      if (offOut[s]) *offOut[s] = r->offTmp[s].data();
+      if (nmOut[s]) *nmOut[s] = B.names[s] + B.noff[s][i0];
+      if (noffOut[s]) *noffOut[s] = r->noffTmp[s].data();
+    }
   }
   return QM_OK;
 }
 
 }  // extern "C"
+
 
 // ------------------------------------------------------------------ SAM
 namespace {

@@ -10,6 +10,17 @@ typedef struct qm_batch_bufs {
   size_t cap_seq[2], cap_off[2], cap_names[2], cap_noff[2];
   void* (*alloc)(size_t); void (*release)(void*);          // where the buffers live: malloc / pinned host memory
 } qm_batch_bufs;
-int qm_reader_next_into(qm_reader* r, int64_t max_units, int64_t* n_units, qm_batch_bufs* B);
-void qm_reader_estimate(qm_reader* r, int s, double* seq_bytes, double* name_bytes);
+/* The ingest engine (qm_ingest.cpp): files -> packed batches in `n_slots` slots whose buffers come from alloc/release,
+ * filled by n_threads workers, several batches in flight.  qm_ingest_next blocks for the next batch in input order (any
+ * number of consumer threads; n_units == 0: end of input) and lends its slot until qm_ingest_release. */
+typedef struct qm_ingest qm_ingest;
+enum { QM_INGEST_NO_NAMES = 1 };     /* read names are not kept (names / noff stay NULL) */
+int qm_ingest_open(const char* path1, const char* path2, int32_t n_threads, int64_t batch_units, int32_t n_slots, uint32_t flags,
+                   void* (*alloc)(size_t), void (*release)(void*), qm_ingest** out);
+int qm_ingest_next(qm_ingest* g, int* slot, int64_t* n_units, int64_t* seq_no, const qm_batch_bufs** bufs);
+void qm_ingest_release(qm_ingest* g, int slot);
+void qm_ingest_stats(qm_ingest* g, double* out8);
+void qm_ingest_cancel(qm_ingest* g);
+void qm_ingest_close(qm_ingest* g);
+int qm_io_fail(int code, const char* fmt, ...);
 }

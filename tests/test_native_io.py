@@ -257,3 +257,116 @@ def test_pipelined_stream_matches_the_oracle(sample_data, oracle_mod, batch):
         got = np.concatenate([b.hits.copy() for b in st]) if True else None
         st.close()
         assert got.tobytes() == rs.hits.tobytes()
+
+
+@pytest.mark.parametrize("chunk,batch,threads", [(777, 1, 3), (1500, 13, 1), (4096, 1000, 6), (1 << 20, 257, 4)])
+def test_ingest_engine_chunk_boundaries(tmp_path, monkeypatch, chunk, batch, threads):
+    """qm_ingest: chunks cut at arbitrary byte offsets resynchronise on record boundaries (quality lines that start with '@'
+    or '+', CRLF, empty reads, names with blanks), batches span chunks, both files advance together"""
+    import random
+    import rapmap_amd as ra
+    monkeypatch.setenv("QM_INGEST_CHUNK", str(chunk))
+    rnd = random.Random(chunk * 31 + batch)
+    n = 3000
+    recs1, recs2 = [], []
+    p1 = str(tmp_path / "a.fq"); p2 = str(tmp_path / "b.fq")
+    with open(p1, "wb") as f1, open(p2, "wb") as f2:
+        for i in range(n):
+            for f, recs, nl in ((f1, recs1, b"\n"), (f2, recs2, b"\r\n" if i % 7 == 0 else b"\n")):
+                L = rnd.choice([0, 1, 30, 31, 100, 100, 100, 250]) if i % 50 == 0 else 100
+                s = "".join(rnd.choice("ACGTN") for _ in range(L)).encode()
+                q = "".join(rnd.choice("@+I5#") for _ in range(L)).encode()
+                nm = ("r%d some text/%d" % (i * 7919, 1 + (f is f2))).encode()
+                f.write(b"@" + nm + nl + s + nl + b"+" + (nm if i % 3 == 0 else b"") + nl + q + nl)
+                recs.append((nm, s))
+    bs = _batches(p1, p2, batch, threads=threads)
+    assert all(b.n <= batch for b in bs) and sum(b.n for b in bs) == n
+    assert _join(bs, "seq1", "off1") == [s for _, s in recs1] and _join(bs, "seq2", "off2") == [s for _, s in recs2]
+    assert _join(bs, "names1", "name_off1") == [nm for nm, _ in recs1] and _join(bs, "names2", "name_off2") == [nm for nm, _ in recs2]
+    # the same through gzip (one inflate thread per file, blocks cut on record boundaries)
+    g1 = str(tmp_path / "a.fq.gz"); g2 = str(tmp_path / "b.fq.gz")
+    for src, dst in ((p1, g1), (p2, g2)):
+        with gzip.open(dst, "wb") as g:
+            g.write(open(src, "rb").read())
+    bs = _batches(g1, g2, batch, threads=threads)
+    assert _join(bs, "seq1", "off1") == [s for _, s in recs1] and _join(bs, "seq2", "off2") == [s for _, s in recs2]
+    assert _join(bs, "names2", "name_off2") == [nm for nm, _ in recs2]
+
+
+def test_ingest_engine_errors_and_empty_inputs(tmp_path):
+    import rapmap_amd as ra
+    e = str(tmp_path / "empty.fq"); open(e, "w").close()
+    assert _batches(e, None, 10) == [] and _batches(e, e, 10) == []
+    a = str(tmp_path / "a.fq"); b = str(tmp_path / "b.fq")
+    with open(a, "w") as f:
+        f.write("".join("@r%d\nACGT\n+\nIIII\n" % i for i in range(100)))
+    with open(b, "w") as f:
+        f.write("".join("@r%d\nACGT\n+\nIIII\n" % i for i in range(99)))
+    with pytest.raises(ra.QmError, match="different numbers"):
+        _batches(a, b, 10)
+    with pytest.raises(ra.QmError, match="different numbers"):
+        _batches(b, a, 1000)
+    with pytest.raises(ra.QmError, match="different numbers"):
+        _batches(a, e, 10)
+    t = str(tmp_path / "trunc.fq")
+    with open(t, "w") as f:
+        f.write("@r0\nACGT\n+\nIIII\n@r1\nACGT\n+")
+    with pytest.raises(ra.QmError, match="malformed"):
+        _batches(t, None, 10)
+    # a reader that is closed before it was drained (workers mid-flight) shuts down cleanly
+    big = str(tmp_path / "big.fq")
+    with open(big, "w") as f:
+        f.write("".join("@r%d\n%s\n+\n%s\n" % (i, "ACGT" * 25, "I" * 100) for i in range(50000)))
+    rd = ra.FastxReader(big, None, threads=4)
+    it = rd.chunks(100)
+    assert next(it).n == 100
+    rd.close()
+    # the batch size may shrink between calls: the current batch comes in pieces, nothing is lost or reordered
+    rd = ra.FastxReader(a, None, threads=2)
+    L = ra.api.lib(); import ctypes as C
+    n = C.c_int64(); ptr = [C.c_void_p() for _ in range(8)]; got = []
+    for want in (64, 7, 7, 100, 100, 100):
+        assert L.qm_reader_next(rd._h, want, C.byref(n), *[C.byref(x) for x in ptr]) == 0
+        if n.value:
+            off = np.ctypeslib.as_array(C.cast(ptr[1], C.POINTER(C.c_int64)), shape=(n.value + 1,))
+            nof = np.ctypeslib.as_array(C.cast(ptr[3], C.POINTER(C.c_int64)), shape=(n.value + 1,))
+            assert off[0] == 0 and nof[0] == 0 and n.value <= want
+            got += [C.string_at(ptr[2].value + int(nof[i]), int(nof[i + 1] - nof[i])) for i in range(n.value)]
+    rd.close()
+    assert got == [b"r%d" % i for i in range(100)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch,names", [(611, True), (4096, False)])
+def test_multi_device_stream_matches_the_oracle(synth_small, oracle_mod, tmp_path, batch, names):
+    """qm_stream_open_ex over several devices (two GPUs when the box has them, otherwise the same GPU listed twice: four
+    contexts, two replicas' worth of map threads): batches are dealt to the devices' contexts and still come back in input
+    order with the oracle's hits and counters"""
+    import torch
+    import rapmap_amd as ra
+    ix, orc = load_oracle(synth_small["idx"])
+    qi = ra.QuasiIndex(synth_small["idx"])
+    q1, o1 = pack(synth_small["reads1"]); q2, o2 = pack(synth_small["reads2"])
+    res = orc.map_pairs(q1, o1, q2, o2, nthreads=4)
+    f1 = str(tmp_path / "r1.fq"); f2 = str(tmp_path / "r2.fq")
+    for f, nms, rds in ((f1, synth_small["names1"], synth_small["reads1"]), (f2, synth_small["names2"], synth_small["reads2"])):
+        with open(f, "wb") as fh:
+            for nm, r in zip(nms, rds):
+                fh.write(b"@" + nm.encode() + b"\n" + r + b"\n+\n" + b"I" * len(r) + b"\n")
+    devs = [0, 1] if torch.cuda.device_count() >= 2 else [0, 0]
+    st = ra.MappedStream(qi, f1, f2, device=devs, batch_units=batch, threads=4, names=names)
+    u = 0; cnts = []; hits = []; tot = {k: 0 for k in res.counters}; seen = set()
+    for b in st:
+        assert bytes(b.seq1[: b.off1[1]]) == synth_small["reads1"][u]
+        if names:
+            assert bytes(b.names2[: b.name_off2[1]]).decode() == synth_small["names2"][u]
+        else:
+            assert not hasattr(b, "names1")
+        cnts.append(np.diff(b.hit_offsets).copy()); hits.append(b.hits.copy()); u += b.n; seen.add(b.device)
+        for k in tot:
+            tot[k] += b.counters[k]
+    ss = st.stats(); st.close()
+    assert u == len(o1) - 1 and tot == res.counters and seen == set(devs)
+    assert np.array_equal(np.concatenate(cnts), np.diff(res.hit_offsets))
+    assert np.concatenate(hits).tobytes() == res.hits.tobytes()
+    assert ss["bytes_parsed"] == os.path.getsize(f1) + os.path.getsize(f2)
