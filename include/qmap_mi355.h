@@ -230,6 +230,11 @@ int qm_build_index(const char* fasta_path, const char* out_dir, int32_t k, int32
 int qm_build_index_ex(const char* fasta_path, const char* out_dir, int32_t k, int32_t no_clip_poly_a,
                       int32_t keep_duplicates, int32_t n_threads, int32_t perfect_hash, const char* header_sep);
 
+/* XXH64 as the index builder uses it: KmerKeyHasher (include/RapMapUtils.hpp:236-238: XXH64 of the key's 8 bytes, seed 0) places
+ * the records of hash.bin so that the reference's spp::sparse_hash_map finds them after unserialize(); also the key of the
+ * duplicate-transcript filter.  (Diagnostics: tests hold it against the reference's src/xxhash.c.) */
+uint64_t qm_xxh64(const void* data, uint64_t len, uint64_t seed);
+
 /* ---- host-side callers of the path -------------------------------------------
  * Read ingest: replaces fastx_parser::FastxParser<ReadPair|ReadSeq> (include/FastxParser.hpp:62-66,
  * src/FastxParser.cpp:229-328: one kseq producer thread, per-record std::strings).  FASTA/FASTQ, plain or

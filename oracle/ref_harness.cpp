@@ -6,6 +6,8 @@
 //   rapmap's Kmer<32,1> codec                    include/Kmer.hpp                                                   (row a1)
 //   boomphf::mphf (load + lookup)                include/BooPHF.hpp                                                 (row a3)
 //   rank9b + BIT_ARRAY                           src/rank9b.cpp, src/bit_array.c                                    (row a8)
+//   spp::sparse_hash_map unserialize + find      include/sparsepp/spp.h, include/SparseHashSerializer.hpp           (row a2: hash.bin)
+//   XXH64                                        src/xxhash.c                                                       (row a2: KmerKeyHasher)
 // The oracle's restatements of exactly these functions are checked against them in tests/test_oracle_ref.py.
 #include <cstdint>
 #include <cstring>
@@ -18,6 +20,9 @@
 #include "Kmer.hpp"
 #include "BooPHF.hpp"
 #include "rank9b.h"
+#include "sparsepp/spp.h"
+#include "SparseHashSerializer.hpp"
+#include "xxhash.h"
 extern "C" {
 #include "bit_array.h"
 }
@@ -86,5 +91,39 @@ void ref_rank_query(void* h, const uint64_t* pos, int64_t n, uint64_t* out) {
   for (int64_t i = 0; i < n; ++i) out[i] = x->r->rank(pos[i]);
 }
 void ref_rank_free(void* h) { RefRank* x = (RefRank*)h; delete x->r; bit_array_free(x->ba); delete x; }
+
+
+// The dense k-mer hash as RapMapSAIndex::load reads it (src/RapMapSAIndex.cpp:67-76): RegHashT<uint64_t, SAInterval<int32_t>,
+// KmerKeyHasher> = spp::sparse_hash_map (include/RapMapUtils.hpp:67) unserialized with pod_hash_serializer.  The value and
+// hasher types live in include/RapMapUtils.hpp, which includes the un-vendored cereal; they are two trivial definitions --
+// a pair of int32 and "XXH64 of the 8 key bytes, seed 0" (:180-205, :236-238) -- repeated here member for member.  The
+// container, its (un)serialisation, its probing and XXH64 are the reference's code.
+struct RefSAInterval { int32_t begin_; int32_t end_; };
+struct RefKmerKeyHasher { size_t operator()(const uint64_t& m) const { return XXH64(static_cast<void*>(const_cast<uint64_t*>(&m)), sizeof(m), 0); } };
+using RefDenseHash = spp::sparse_hash_map<uint64_t, RefSAInterval, RefKmerKeyHasher>;
+void* ref_spp_load(const char* path) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return nullptr;
+  RefDenseHash* h = new RefDenseHash();
+  if (!h->unserialize(spp_utils::pod_hash_serializer<uint64_t, RefSAInterval>(), &f)) { delete h; return nullptr; }
+  return h;
+}
+int64_t ref_spp_size(void* h) { return (int64_t)((RefDenseHash*)h)->size(); }
+// iteration order of the container (= file order of the records)
+void ref_spp_dump(void* h, uint64_t* keys, int32_t* lb, int32_t* ub) {
+  int64_t i = 0;
+  for (auto& kv : *(RefDenseHash*)h) { keys[i] = kv.first; lb[i] = kv.second.begin_; ub[i] = kv.second.end_; ++i; }
+}
+// khash.find(key) for n keys: found[i], and the interval when found
+void ref_spp_find(void* h, const uint64_t* keys, int64_t n, uint8_t* found, int32_t* lb, int32_t* ub) {
+  RefDenseHash* m = (RefDenseHash*)h;
+  for (int64_t i = 0; i < n; ++i) {
+    auto it = m->find(keys[i]);
+    found[i] = it != m->end();
+    if (found[i]) { lb[i] = it->second.begin_; ub[i] = it->second.end_; }
+  }
+}
+void ref_spp_free(void* h) { delete (RefDenseHash*)h; }
+uint64_t ref_xxh64(const void* p, uint64_t len, uint64_t seed) { return XXH64(p, (size_t)len, seed); }
 
 }  // extern "C"

@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "qm_map_pairs", "qm_map_reads", "qm_map_device", "qm_fetch_hits", "qm_result_device", "qm_ctx_set_debug",
     "qm_fetch_intervals", "qm_last_kernel_ms", "qm_ctx_stat", "qm_build_index", "qm_build_index_ex",
     "qm_collect_reads", "qm_fetch_found", "qm_hits_to_mappings", "qm_fetch_read_lists", "qm_merge_lists", "qm_fetch_too_many",
-    "qm_map_pairs_stages", "qm_ctx_create_ex", "qm_fetch_hits_pinned",
+    "qm_map_pairs_stages", "qm_ctx_create_ex", "qm_fetch_hits_pinned", "qm_xxh64",
     "qm_stream_open", "qm_stream_open_ex", "qm_stream_next", "qm_stream_close", "qm_stream_last_error", "qm_stream_stats", "qm_stream_stats_ex",
     "qm_reader_open", "qm_reader_next", "qm_reader_close", "qm_io_last_error", "qm_sam_header", "qm_sam_records",
     "qm_sam_write", "qm_sam_writer_open", "qm_sam_writer_open_ex", "qm_sam_writer_header", "qm_sam_writer_put", "qm_sam_writer_close", "qm_buf_free",

@@ -304,6 +304,9 @@ thread_local char g_ierr[256];
 }  // namespace
 
 extern "C" const char* qm_indexer_last_error(void) { return g_ierr; }
+// the indexer's XXH64 (hash.bin slot placement = KmerKeyHasher, include/RapMapUtils.hpp:236-238; duplicate removal): exported so
+// that tests can hold it against the reference's src/xxhash.c
+extern "C" uint64_t qm_xxh64(const void* data, uint64_t len, uint64_t seed) { return xxh64(data, (size_t)len, seed); }
 
 extern "C" int qm_build_index_ex(const char* fasta_path, const char* out_dir_c, int32_t k, int32_t no_clip_poly_a,
                                  int32_t keep_duplicates, int32_t n_threads, int32_t perfect_hash, const char* header_sep);

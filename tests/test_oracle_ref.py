@@ -156,3 +156,144 @@ def test_rank_equals_the_references(ref, ref_index, oracle_mod):
     notsep = text[pos.astype(np.int64)] != ord("$")
     tid = np.searchsorted(offs, pos.astype(np.int64), side="right") - 1
     assert np.array_equal(out[notsep].astype(np.int64), tid[notsep])
+
+
+def _spp(ref):
+    ref.ref_spp_load.restype = C.c_void_p; ref.ref_spp_load.argtypes = [C.c_char_p]
+    ref.ref_spp_size.restype = C.c_int64; ref.ref_spp_size.argtypes = [C.c_void_p]
+    ref.ref_spp_dump.argtypes = [C.c_void_p] * 4
+    ref.ref_spp_find.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    ref.ref_spp_free.argtypes = [C.c_void_p]
+    ref.ref_xxh64.restype = C.c_uint64; ref.ref_xxh64.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+    return ref
+
+
+def _spp_dump(ref, path):
+    h = ref.ref_spp_load(path.encode())
+    assert h, "the reference's sparse_hash_map could not unserialize " + path
+    n = ref.ref_spp_size(h)
+    keys = np.zeros(n, dtype=np.uint64); lb = np.zeros(n, dtype=np.int32); ub = np.zeros(n, dtype=np.int32)
+    ref.ref_spp_dump(h, keys.ctypes.data, lb.ctypes.data, ub.ctypes.data)
+    return h, keys, lb, ub
+
+
+def test_dense_hash_file_equals_the_references_container(ref, ref_index, oracle_mod):
+    """hash.bin written by the reference, read back by the reference's own spp::sparse_hash_map::unserialize
+    (include/sparsepp/spp.h:2355-2429 through include/SparseHashSerializer.hpp:31-47, as RapMapSAIndex::load does,
+    src/RapMapSAIndex.cpp:67-76): the oracle's numpy reader (oracle/q5.py) must see the same key -> interval map, and the
+    oracle's find (what every parity test's lookups go through) must answer like the container's find, for present and absent keys"""
+    from oracle import q5
+    from conftest import load_oracle
+    _spp(ref)
+    d = ref_index["dense"]
+    h, keys, lb, ub = _spp_dump(ref, os.path.join(d, "hash.bin"))
+    try:
+        k2, l2, u2 = q5.read_dense_hash(d)
+        assert len(keys) == len(k2) == 18902
+        o1 = np.argsort(keys); o2 = np.argsort(k2)
+        assert np.array_equal(keys[o1], k2[o2]) and np.array_equal(lb[o1], l2[o2]) and np.array_equal(ub[o1], u2[o2])
+        assert np.array_equal(keys, k2)                       # even the record order: the reader walks the file like the container
+        ix, orc = load_oracle(d)
+        rng = np.random.default_rng(3)
+        probe = np.concatenate([keys, rng.integers(0, 1 << 62, 20000, dtype=np.uint64), keys ^ np.uint64(1)])
+        found = np.zeros(len(probe), dtype=np.uint8); fl = np.zeros(len(probe), dtype=np.int32); fu = np.zeros(len(probe), dtype=np.int32)
+        ref.ref_spp_find(h, probe.ctypes.data, len(probe), found.ctypes.data, fl.ctypes.data, fu.ctypes.data)
+        assert found[: len(keys)].all() and not found[len(keys): len(keys) + 20000].any()
+        ol = oracle_mod._lib()
+        out = (C.c_int32 * 2)()
+        for i in range(0, len(probe), 7):                    # every 7th probe through the oracle's own find
+            got = ol.qo_hash_find(orc.h, int(probe[i]), out)
+            assert bool(got) == bool(found[i])
+            if got:
+                assert (out[0], out[1]) == (fl[i], fu[i])
+    finally:
+        ref.ref_spp_free(h)
+
+
+def test_our_hash_file_loads_in_the_references_container(ref, sample_data, lib_built):
+    """hash.bin written by OUR index builder (rapmap_amd/csrc/qm_indexer.cpp) goes through the reference's unserialize, and the
+    reference's find -- XXH64 + its own probing over the slots we chose -- returns every record: the file is a container the
+    reference can use, not just the same map"""
+    from oracle import q5
+    _spp(ref)
+    d = sample_data["idx"]
+    h, keys, lb, ub = _spp_dump(ref, os.path.join(d, "hash.bin"))
+    try:
+        k2, l2, u2 = q5.read_dense_hash(d)
+        assert np.array_equal(keys, k2) and np.array_equal(lb, l2) and np.array_equal(ub, u2) and len(keys) > 1000
+        found = np.zeros(len(keys), dtype=np.uint8); fl = np.zeros(len(keys), dtype=np.int32); fu = np.zeros(len(keys), dtype=np.int32)
+        ref.ref_spp_find(h, keys.ctypes.data, len(keys), found.ctypes.data, fl.ctypes.data, fu.ctypes.data)
+        assert found.all() and np.array_equal(fl, lb) and np.array_equal(fu, ub)
+    finally:
+        ref.ref_spp_free(h)
+
+
+def test_xxh64_equals_the_references(ref, lib_built):
+    """the index builder's XXH64 (slot placement in hash.bin, duplicate filter) == src/xxhash.c, every length class of the
+    algorithm (< 4, < 8, < 32, >= 32 bytes, unaligned tails), several seeds"""
+    import rapmap_amd as ra
+    _spp(ref)
+    L = ra.api.lib()
+    L.qm_xxh64.restype = C.c_uint64; L.qm_xxh64.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+    rng = np.random.default_rng(11)
+    buf = rng.integers(0, 256, 4096, dtype=np.uint8)
+    for ln in list(range(0, 100)) + [127, 128, 129, 1000, 4095]:
+        for seed in (0, 1, 0x9E3779B97F4A7C15):
+            for shift in (0, 1, 3):
+                p = buf.ctypes.data + shift
+                if shift + ln > buf.size:
+                    continue
+                assert L.qm_xxh64(p, ln, seed) == ref.ref_xxh64(p, ln, seed), (ln, seed, shift)
+    keys = rng.integers(0, 1 << 62, 5000, dtype=np.uint64)
+    for i in range(len(keys)):
+        assert L.qm_xxh64(keys[i:].ctypes.data, 8, 0) == ref.ref_xxh64(keys[i:].ctypes.data, 8, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,compact", [("dense", False), ("perfect", False), ("perfect", True)])
+def test_device_lookup_answers_like_the_references_container(ref, ref_index, lib_built, kind, compact):
+    """the device's k-mer -> SA-interval lookup (bucket table built in HBM from hash.bin / from the -p files, or the BooPHF walk)
+    against the REFERENCE's own container on the reference-written hash.bin: every indexed k-mer, given to the collector as
+    a read of exactly k characters, must come back as the interval khash.find returns; random k-mers that the container does
+    not hold (neither strand) must come back empty"""
+    import rapmap_amd as ra
+    _spp(ref)
+    h, keys, lb, ub = _spp_dump(ref, os.path.join(ref_index["dense"], "hash.bin"))
+    try:
+        k = 31
+        def decode(words):
+            sh = np.arange(k - 1, -1, -1, dtype=np.uint64) * np.uint64(2)
+            return np.frombuffer(b"ACGT", dtype=np.uint8)[((words[:, None] >> sh[None, :]) & np.uint64(3)).astype(np.int64)]
+        def rc(words):
+            c = decode(words)[:, ::-1]
+            m = np.zeros(256, dtype=np.uint64); m[ord("A")] = 3; m[ord("C")] = 2; m[ord("G")] = 1; m[ord("T")] = 0
+            sh = np.arange(k - 1, -1, -1, dtype=np.uint64) * np.uint64(2)
+            return (m[c] << sh[None, :]).sum(axis=1).astype(np.uint64)
+        rng = np.random.default_rng(5)
+        absent = rng.integers(0, 1 << 62, 30000, dtype=np.uint64)
+        f1 = np.zeros(len(absent), dtype=np.uint8); f2 = np.zeros(len(absent), dtype=np.uint8); t = np.zeros(len(absent), dtype=np.int32)
+        ra_ = rc(absent)
+        ref.ref_spp_find(h, absent.ctypes.data, len(absent), f1.ctypes.data, t.ctypes.data, t.ctypes.data)
+        ref.ref_spp_find(h, ra_.ctypes.data, len(ra_), f2.ctypes.data, t.ctypes.data, t.ctypes.data)
+        absent = absent[(f1 == 0) & (f2 == 0)]
+        words = np.concatenate([keys, absent])
+        seq = decode(words).reshape(-1).copy(); off = np.arange(len(words) + 1, dtype=np.int64) * k
+        qi = ra.QuasiIndex(ref_index[kind]); mp = ra.QuasiMapper(qi, 0, ph_compact=compact)
+        found, ioff, ints = mp.collect_reads(seq, off)
+        cnt = np.diff(ioff)
+        assert not cnt[len(keys):].any() and not found[len(keys):].any()
+        checked = 0
+        for i in range(len(keys)):
+            if not (0 < ub[i] - lb[i] < 1000):
+                continue                                    # the collector does not record intervals of >= maxInterval suffixes
+            g = ints[ioff[i]:ioff[i + 1]]
+            fw = g[(g["query_rc"] == 0) & (g["query_pos"] == 0)]
+            if len(fw) == 0:                               # homopolymer k-mers are never probed (include/SACollector.hpp:176-181)
+                w = int(keys[i]); assert w in (0, (1 << 62) - 1) or len(set(decode(keys[i:i + 1])[0].tolist())) == 1, hex(w)
+                continue
+            assert len(fw) == 1 and (int(fw["begin"][0]), int(fw["end"][0]), int(fw["len"][0])) == (int(lb[i]), int(ub[i]), k), i
+            checked += 1
+        assert checked > 18000
+        mp.close(); qi.close()
+    finally:
+        ref.ref_spp_free(h)
