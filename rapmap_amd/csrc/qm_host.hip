@@ -507,6 +507,16 @@ int qm_ctx_create_ex(const qm_index* ix, int device_id, uint32_t flags, qm_ctx**
     CK(hipMemcpyAsync(dF, fin.data(), fin.size() * sizeof(Slot), hipMemcpyHostToDevice, c->stream));
     P.blocks = dW; P.levelTab = dT; P.recs = dRec; P.ovf = dO; P.fin = dF;
     P.lastbitsetrank = ix->phLastRank; P.nelem = ix->phNelem; P.nb_levels = nl;
+    if (phCompact && !getenv("QM_PH_NO_FILTER")) {
+      // the membership pre-filter of the compact image (PhIndex::filter): absent k-mers -- most lookups -- are rejected after
+      // one sector instead of a walk through the levels.  QM_PH_NO_FILTER (profiling): the bare reference structure.
+      const u64 fw = ph_filter_words(ix->phNelem);
+      u64* dFil = (u64*)dalloc(fw * 8);
+      if (!dFil) { int rc = fail(QM_E_NOMEM, "hipMalloc (perfect hash filter) failed"); qm_ctx_destroy(c); return rc; }
+      CK(hipMemsetAsync(dFil, 0, fw * 8, c->stream));
+      CK(qmk_build_phfilter(dRec, (long long)ix->phNelem, dFil, fw - 1, c->stream));
+      P.filter = dFil; P.filterMask = fw - 1;
+    }
     CK(hipMemcpyAsync(dP, &P, sizeof(P), hipMemcpyHostToDevice, c->stream));
     CK(hipStreamSynchronize(c->stream));    // P, tab, ov, fin are locals
     c->d_ph = dP; c->hPh = P;

@@ -230,6 +230,17 @@ __global__ void build_phrec_kernel(const int* data, const unsigned char* lens, l
   }
 }
 
+// membership pre-filter of the compact -p image (PhIndex::filter): four bits per key of the index
+__global__ void build_phfilter_kernel(const PhRec* recs, long long n, unsigned long long* filter, u64 mask) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    u64 w, bits;
+    ph_filter_slot(recs[i].key, mask, w, bits);
+    atomicOr(&filter[w], (unsigned long long)bits);
+  }
+}
+
 // A perfect-hash index expanded into the dense bucket table: slot i of the MPHF holds the interval [data_[i], data_[i] +
 // lens_[i]) of the k-mer that starts the suffix SA[data_[i]] -- every (k-mer, interval) pair of the index, i.e. exactly
 // the contents of a dense hash.bin.  Each record is first looked up through the BooPHF walk itself (find_kmer<QM_F_PH>, what
@@ -293,6 +304,12 @@ hipError_t qmk_build_slots_from_ph(const void* dev_index, long long n, void* slo
 hipError_t qmk_build_phrecs(const int* data, const unsigned char* lens, long long n, const void* dev_index, void* out, hipStream_t st) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(build_phrec_kernel, dim3(4096), dim3(256), 0, st, data, lens, n, *(const DevIndex*)dev_index, (PhRec*)out);
+  return hipGetLastError();
+}
+
+hipError_t qmk_build_phfilter(const void* recs, long long n, void* filter, unsigned long long mask, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(build_phfilter_kernel, dim3(4096), dim3(256), 0, st, (const PhRec*)recs, n, (unsigned long long*)filter, (u64)mask);
   return hipGetLastError();
 }
 

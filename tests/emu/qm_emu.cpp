@@ -197,6 +197,13 @@ void* qe_ph_create(const unsigned long long* words, const unsigned long long* ra
   }
   P->recs = recs;
   P->nelem = nelem; P->lastbitsetrank = lastbitsetrank; P->nb_levels = nb_levels;
+  if (!getenv("QM_PH_NO_FILTER")) {      // the membership pre-filter of the compact image, as qm_ctx_create_ex builds it on the GPU
+    const u64 fw = ph_filter_words(nelem);
+    u64* fil = new u64[fw];
+    for (u64 i = 0; i < fw; ++i) fil[i] = 0;
+    for (u64 i = 0; i < nelem; ++i) { u64 w, bits; ph_filter_slot(recs[i].key, fw - 1, w, bits); fil[w] |= bits; }
+    P->filter = fil; P->filterMask = fw - 1;
+  }
   u64 cap = 16; while (cap < (u64)n_ovf * 2) cap <<= 1;
   OvfSlot* ov = new OvfSlot[cap];
   for (u64 i = 0; i < cap; ++i) { ov[i].key = -1; ov[i].val = 0; }
