@@ -634,55 +634,70 @@ QM_DEV void sel_ksw_extz2_rows(const LV<int>& qlenv, const LV<int>& tlenv, KswRo
       }
     }
     wave_fence();
+    // The difference recurrence, TWO 16-column vectors per pass: a lane owns column t0 = st + 32 it + c and column t0 + 16.
+    // The four int8 quantities of its two cells travel as four registers of two 16-bit halves with the int8 in the HIGH byte
+    // of each half: there a 16-bit add / subtract wraps exactly like the SSE kernel's 8-bit one, a signed / unsigned 16-bit
+    // max / min orders like the 8-bit one, and the whole recurrence is 13 packed instructions for the two cells
+    // (v_pk_add_u16, v_pk_sub_i16, v_pk_max_i16, v_pk_max_u16, v_pk_min_u16) between four byte shuffles in and four out.
+    const u32 QE2 = ((u32)qe2 << 8) | ((u32)qe2 << 24), MAXSC = ((u32)max_sc_v << 8) | ((u32)max_sc_v << 24), QV = ((u32)qv << 8) | ((u32)qv << 24);
     LV<int> prevOld;
     QM_LANES(l) { prevOld[l] = bpack[l]; }
-    for (int it = 0; it < NV; ++it) {
-      // every lane computes its cell whether it is in range or not (all loads stay inside the row's block: ring slots, and
-      // image indices clamped into the images); only the two stores are predicated -- far fewer exec-mask round trips
-      LV<int> old, sCur; LV<bool> inCore, inScore;
+    for (int it = 0; ; ++it) {
+      // every lane computes its cells whether they are in range or not (all loads stay inside the row's block: ring slots, and
+      // image indices clamped into the images); only the stores are predicated -- far fewer exec-mask round trips
+      LV<int> old0, old1, s0, s1; LV<bool> inCore0, inCore1, inScore0, inScore1;
       QM_LANES(l) {
-        const int t = stv[l] + 16 * it + (l & 15);
+        const int t0 = stv[l] + 32 * it + (l & 15), t1 = t0 + 16;
         Row& B = blk[l >> 4];
-        inCore[l] = act[l] && t <= env[l];
-        inScore[l] = act[l] && t >= st0v[l] && t <= smaxv[l];
-        old[l] = (int)B.ST[t & RM]; sCur[l] = B.SS[t & RM];
+        inCore0[l] = act[l] && t0 <= env[l]; inCore1[l] = act[l] && t1 <= env[l];
+        inScore0[l] = act[l] && t0 >= st0v[l] && t0 <= smaxv[l]; inScore1[l] = act[l] && t1 >= st0v[l] && t1 <= smaxv[l];
+        old0[l] = (int)B.ST[t0 & RM]; old1[l] = (int)B.ST[t1 & RM]; s0[l] = B.SS[t0 & RM]; s1[l] = B.SS[t1 & RM];
       }
-      LV<bool> any;
-      QM_LANES(l) { any[l] = inCore[l] || inScore[l]; }
-      if (!ballot(any)) break;
       QM_LANES(l) {
         Row& B = blk[l >> 4];
-        const int t = stv[l] + 16 * it + (l & 15);
-        int qi = 16 + r - t; qi = qi < 0 ? 0 : (qi > QM_KSW_MAXLEN + 39 ? QM_KSW_MAXLEN + 39 : qi);
-        const int ti = t > QM_KSW_MAXLEN + 39 ? QM_KSW_MAXLEN + 39 : t;
-        const int sv = B.QX[qi], sq = B.TX[ti];
-        int tmp = (sq == sv) ? sc_mch : sc_mis;
-        tmp = (sq == m1 || sv == m1) ? sc_N : tmp;
-        sCur[l] = inScore[l] ? tmp : sCur[l];
-        if (inScore[l]) B.SS[t & RM] = (unsigned char)tmp;
+        const int t0 = stv[l] + 32 * it + (l & 15), t1 = t0 + 16;
+        int qi0 = 16 + r - t0; qi0 = qi0 < 0 ? 0 : (qi0 > QM_KSW_MAXLEN + 39 ? QM_KSW_MAXLEN + 39 : qi0);
+        int qi1 = 16 + r - t1; qi1 = qi1 < 0 ? 0 : (qi1 > QM_KSW_MAXLEN + 39 ? QM_KSW_MAXLEN + 39 : qi1);
+        const int ti0 = t0 > QM_KSW_MAXLEN + 39 ? QM_KSW_MAXLEN + 39 : t0, ti1 = t1 > QM_KSW_MAXLEN + 39 ? QM_KSW_MAXLEN + 39 : t1;
+        const int sv0 = B.QX[qi0], sq0 = B.TX[ti0], sv1 = B.QX[qi1], sq1 = B.TX[ti1];
+        int tmp0 = (sq0 == sv0) ? sc_mch : sc_mis; tmp0 = (sq0 == m1 || sv0 == m1) ? sc_N : tmp0;
+        int tmp1 = (sq1 == sv1) ? sc_mch : sc_mis; tmp1 = (sq1 == m1 || sv1 == m1) ? sc_N : tmp1;
+        s0[l] = inScore0[l] ? tmp0 : s0[l]; s1[l] = inScore1[l] ? tmp1 : s1[l];
+        if (inScore0[l]) B.SS[t0 & RM] = (unsigned char)tmp0;
+        if (inScore1[l]) B.SS[t1 & RM] = (unsigned char)tmp1;
       }
-      LV<int> nb, carry;
-      row_rotate_up(old, nb); row_rotate_up(prevOld, carry);
+      LV<int> r0, r1, carry;
+      row_rotate_up(old0, r0); row_rotate_up(old1, r1); row_rotate_up(prevOld, carry);
       QM_LANES(l) {
         Row& B = blk[l >> 4];
-        const int t = stv[l] + 16 * it + (l & 15);
-        const int xv = (l & 15) == 0 ? carry[l] : nb[l];
-        const int xt1 = (xv >> 16) & 0xff, vt1 = (xv >> 8) & 0xff;
-        const int ut = old[l] & 0xff, yt = (old[l] >> 24) & 0xff;
-        int z = (sCur[l] + qe2) & 0xff;
-        int a = (xt1 + vt1) & 0xff;
-        int b = (yt + ut) & 0xff;
-        z = ((signed char)z > (signed char)a) ? z : a;
-        z = z > b ? z : b;
-        z = z < max_sc_v ? z : max_sc_v;
-        const int un = (z - vt1) & 0xff, vn = (z - ut) & 0xff;
-        z = (z - qv) & 0xff;
-        a = (a - z) & 0xff; b = (b - z) & 0xff;
-        const int xn = (signed char)a > 0 ? a : 0, yn = (signed char)b > 0 ? b : 0;
-        if (inCore[l]) B.ST[t & RM] = (u32)un | ((u32)vn << 8) | ((u32)xn << 16) | ((u32)yn << 24);
-        prevOld[l] = inCore[l] ? old[l] : prevOld[l];
+        const int t0 = stv[l] + 32 * it + (l & 15), t1 = t0 + 16;
+        // column t - 1 as the last round left it: the lower neighbour's word; for the first lane of a vector the last column
+        // of the vector before it (the boundary column for the very first)
+        const u32 nb0 = (l & 15) == 0 ? (u32)carry[l] : (u32)r0[l], nb1 = (l & 15) == 0 ? (u32)r0[l] : (u32)r1[l];
+        const u32 o0 = (u32)old0[l], o1 = (u32)old1[l];
+        const u32 U = perm8(o1, o0, 0x040c000cu), Y = perm8(o1, o0, 0x070c030cu);      // u, y of the own columns
+        const u32 V1 = perm8(nb1, nb0, 0x050c010cu), X1 = perm8(nb1, nb0, 0x060c020cu); // v, x of the columns before them
+        const u32 S = ((u32)s0[l] << 8) | ((u32)s1[l] << 24);
+        u32 Z = pk_add(S, QE2), A = pk_add(X1, V1), Bq = pk_add(Y, U);
+        Z = pk_max_i(Z, A);                                 // _mm_max_epi8
+        Z = pk_max_u(Z, Bq);                                // _mm_max_epu8
+        Z = pk_min_u(Z, MAXSC);                             // _mm_min_epu8
+        const u32 UN = pk_sub(Z, V1), VN = pk_sub(Z, U);
+        Z = pk_sub(Z, QV);
+        A = pk_sub(A, Z); Bq = pk_sub(Bq, Z);
+        const u32 XN = pk_max_i(A, 0u), YN = pk_max_i(Bq, 0u);
+        const u32 uv = perm8(VN, UN, 0x07030501u), xy = perm8(YN, XN, 0x07030501u);    // (u0 v0 u1 v1), (x0 y0 x1 y1)
+        if (inCore0[l]) B.ST[t0 & RM] = perm8(xy, uv, 0x05040100u);
+        if (inCore1[l]) B.ST[t1 & RM] = perm8(xy, uv, 0x07060302u);
+        prevOld[l] = inCore1[l] ? old1[l] : (inCore0[l] ? old0[l] : prevOld[l]);
       }
       wave_fence();
+      // another pass only when some row's columns reach beyond these 32 (never for --dpBandwidth <= 15: st .. max(en, smax)
+      // spans at most 31 columns there); decided from the bounds alone, before anything is loaded
+      if (it + 1 >= (NV + 1) / 2) break;
+      LV<bool> more;
+      QM_LANES(l) { more[l] = act[l] && stv[l] + 32 * (it + 1) <= (env[l] > smaxv[l] ? env[l] : smaxv[l]); }
+      if (!ballot(more)) break;
     }
     // H (exact max) over the band cells st0..en0 (up to w + 1 of them): all reads, then the writes
     LV<int> hLeft;                                      // H[en0 - 1] before this round's updates
@@ -691,7 +706,7 @@ QM_DEV void sel_ksw_extz2_rows(const LV<int>& qlenv, const LV<int>& tlenv, KswRo
       if (act[l] && en0v[l] > 0) hLeft[l] = en0v[l] > stv[l] ? blk[l >> 4].HH[(en0v[l] - 1) & RM] : hb[l];
     }
     wave_fence();
-    for (int k = 0; k < RING / 16; ++k) {
+    for (int k = 0; ; ++k) {
       LV<int> hn; LV<bool> has;
       QM_LANES(l) {
         const int t = st0v[l] + (l & 15) + 16 * k;
@@ -704,7 +719,6 @@ QM_DEV void sel_ksw_extz2_rows(const LV<int>& qlenv, const LV<int>& tlenv, KswRo
         const int hTop = en0 > 0 ? (hLeft[l] + un - qe) : hOwn;
         hn[l] = r > 0 ? (t == en0 ? hTop : hOwn) : (vn - qe - qe);   // r == 0: the only cell is t == 0
       }
-      if (!ballot(has)) break;
       wave_fence();
       QM_LANES(l) {
         if (has[l]) {
@@ -716,6 +730,10 @@ QM_DEV void sel_ksw_extz2_rows(const LV<int>& qlenv, const LV<int>& tlenv, KswRo
         }
       }
       wave_fence();
+      if (k + 1 >= RING / 16) break;                      // band cells beyond these 16 (only with --dpBandwidth > 15)?
+      LV<bool> moreH;
+      QM_LANES(l) { moreH[l] = act[l] && st0v[l] + 16 * (k + 1) <= en0v[l]; }
+      if (!ballot(moreH)) break;
     }
     QM_LANES(l) { if (act[l]) { lastSt[l] = stv[l]; lastEn[l] = env[l]; } }
   }

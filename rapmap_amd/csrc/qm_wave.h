@@ -115,11 +115,20 @@ QM_DEV int clz64(u64 x) { return x ? __builtin_clzll(x) : 64; }
 QM_DEV u64 load_u64_unaligned(const unsigned char* p) { u64 v; __builtin_memcpy(&v, p, 8); return v; }
 QM_DEV u32 load_u32_unaligned(const unsigned char* p) { u32 v; __builtin_memcpy(&v, p, 4); return v; }
 // v_perm_b32 with selectors 0..7: byte j of the result = byte sel_j of the eight bytes {hi, lo} (0..3 from lo, 4..7 from hi)
-QM_DEV u32 perm8(u32 hi, u32 lo, u32 sel) {
+QM_DEV u32 perm8(u32 hi, u32 lo, u32 sel) {                 // (selector 0x0c: the constant byte 0x00)
   const u64 tab = ((u64)hi << 32) | lo; u32 r = 0;
-  for (int j = 0; j < 4; ++j) r |= (u32)((tab >> (8 * ((sel >> (8 * j)) & 7))) & 0xff) << (8 * j);
+  for (int j = 0; j < 4; ++j) { const u32 sj = (sel >> (8 * j)) & 0xff; if (sj != 0x0c) r |= (u32)((tab >> (8 * (sj & 7))) & 0xff) << (8 * j); }
   return r;
 }
+// packed 16-bit arithmetic on the two halves of a dword (v_pk_add_u16, v_pk_sub_i16, v_pk_max_i16, v_pk_max_u16, v_pk_min_u16)
+QM_DEV u32 pk_add(u32 a, u32 b) { return ((a + b) & 0xffffu) | (((a >> 16) + (b >> 16)) << 16); }
+QM_DEV u32 pk_sub(u32 a, u32 b) { return ((a - b) & 0xffffu) | (((a >> 16) - (b >> 16)) << 16); }
+QM_DEV u32 pk_max_i(u32 a, u32 b) {
+  const short al = (short)a, bl = (short)b, ah = (short)(a >> 16), bh = (short)(b >> 16);
+  return (u32)(unsigned short)(al > bl ? al : bl) | ((u32)(unsigned short)(ah > bh ? ah : bh) << 16);
+}
+QM_DEV u32 pk_max_u(u32 a, u32 b) { const u32 al = a & 0xffffu, bl = b & 0xffffu, ah = a >> 16, bh = b >> 16; return (al > bl ? al : bl) | ((ah > bh ? ah : bh) << 16); }
+QM_DEV u32 pk_min_u(u32 a, u32 b) { const u32 al = a & 0xffffu, bl = b & 0xffffu, ah = a >> 16, bh = b >> 16; return (al < bl ? al : bl) | ((ah < bh ? ah : bh) << 16); }
 // out[l] = in[l ^ 1]: every lane reads its neighbour within a pair
 QM_DEV void lane_xor1(const LV<u32>& in, LV<u32>& out) { for (int l = 0; l < 64; ++l) out.v[l] = in.v[l ^ 1]; }
 // out[l] = in[l ^ 32]: the two halves of the wavefront trade places
@@ -173,6 +182,14 @@ QM_DEV int clz64(u64 x) { return x ? __builtin_clzll(x) : 64; }
 QM_DEV u64 load_u64_unaligned(const unsigned char* p) { u64 v; __builtin_memcpy(&v, p, 8); return v; }
 QM_DEV u32 load_u32_unaligned(const unsigned char* p) { u32 v; __builtin_memcpy(&v, p, 4); return v; }
 QM_DEV u32 perm8(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }     // v_perm_b32
+// packed 16-bit arithmetic on the two halves of a dword: one VALU instruction for two values
+typedef short qm_s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short qm_u16x2 __attribute__((ext_vector_type(2)));
+QM_DEV u32 pk_add(u32 a, u32 b) { return __builtin_bit_cast(u32, __builtin_bit_cast(qm_u16x2, a) + __builtin_bit_cast(qm_u16x2, b)); }
+QM_DEV u32 pk_sub(u32 a, u32 b) { return __builtin_bit_cast(u32, __builtin_bit_cast(qm_u16x2, a) - __builtin_bit_cast(qm_u16x2, b)); }
+QM_DEV u32 pk_max_i(u32 a, u32 b) { return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(qm_s16x2, a), __builtin_bit_cast(qm_s16x2, b))); }
+QM_DEV u32 pk_max_u(u32 a, u32 b) { return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(qm_u16x2, a), __builtin_bit_cast(qm_u16x2, b))); }
+QM_DEV u32 pk_min_u(u32 a, u32 b) { return __builtin_bit_cast(u32, __builtin_elementwise_min(__builtin_bit_cast(qm_u16x2, a), __builtin_bit_cast(qm_u16x2, b))); }
 QM_DEV void lane_xor1(const LV<u32>& in, LV<u32>& out) {                                     // DPP quad_perm:[1,0,3,2]
   out.v[0] = (u32)__builtin_amdgcn_update_dpp(0, (int)in.v[0], 0xB1, 0xf, 0xf, false);
 }
