@@ -23,6 +23,7 @@ hipError_t qmk_launch_reads_ns2(const void* dev_index, const void* read_batch, i
 hipError_t qmk_launch_reads_ns3(const void* dev_index, const void* read_batch, int collect, int grid, int num_cu, hipStream_t st);
 hipError_t qmk_launch_reads_ns4(const void* dev_index, const void* read_batch, int collect, int grid, int num_cu, hipStream_t st);
 hipError_t qmk_launch_reads_ns8(const void* dev_index, const void* read_batch, int collect, int grid, int num_cu, hipStream_t st);
+hipError_t qmk_launch_reads_ns32(const void* dev_index, const void* read_batch, int collect, int grid, int num_cu, hipStream_t st);
 hipError_t qmk_map_reads(const void* dev_index, const void* read_batch, int ns, int grid, int num_cu, hipStream_t st);
 hipError_t qmk_map_reads_ex(const void* dev_index, const void* read_batch, int ns, int collect, int grid, int num_cu, hipStream_t st);
 // ns < 0: the "collector only" stage entry (NS=4 kernels with QM_F_COLLECT)

@@ -664,6 +664,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
       B.consensus_fraction = cs < 0 ? -cs : ((cs == 0.0) ? 1.0 : (1.0 - cs));   // negative: MappingConfig::consensusFraction itself (qmap_mi355.h)
     }
     HIPCHK(hipMemsetAsync(c->d_scal, 0, QM_SC_WORDS * sizeof(u64), c->stream));
+    if (rq.mode == QM_RUN_COLLECT || twoPass) HIPCHK(hipMemsetAsync(c->d_lcnt, 0, (size_t)(nreads + 1) * sizeof(uint32_t), c->stream));   // collector-only kernels write no list lengths: the array only carries the long-read marks
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     auto launch = [&](const ReadBatch& X, int g) -> hipError_t {
       if (rq.mode == QM_RUN_FROM_INTERVALS) return qmk_h2m(&ix, &X, g, c->numCU, c->stream);
@@ -701,6 +702,24 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
     HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     int status = (int)(hscal[QM_SC_STATUS] & 0xffffffffu);
+    if (!o->sel_aln && rq.mode != QM_RUN_FROM_INTERVALS && hscal[QM_SC_SLOWCNT] > 0 && !(status & 23)) {
+      // reads longer than the slot class of this launch (always: longer than QM_MAX_READ_LEN) were set aside: gather them
+      // and map them with the 32-slot kernels -- a second, small launch; everything it writes (lists, intervals, foundHit)
+      // goes where the first pass would have put it
+      const int64_t nl_ = (int64_t)hscal[QM_SC_SLOWCNT];
+      if ((int64_t)hscal[QM_SC_SLOWMAX] > QM_MAX_LONG_READ_LEN)
+        return fail(QM_E_TOOLONG, "a read of %lld characters: longer than the %d the long-read pass takes", (long long)hscal[QM_SC_SLOWMAX], QM_MAX_LONG_READ_LEN);
+      if ((rc = ensure(c->d_slowq, c->capSlowq, nl_))) return rc;
+      HIPCHK(qmk_collect_slow(c->d_lcnt, nreads, c->d_slowq, (unsigned long long*)(c->d_scal + QM_SC_SLOWQ), c->stream));
+      ReadBatch S2 = B;
+      S2.slowq = c->d_slowq; S2.nreads = nl_;
+      const int g2 = qmk_map_grid(nl_, c->numCU);
+      HIPCHK(qmk_map_reads(&ix, &S2, rq.mode == QM_RUN_COLLECT ? -32 : 32, g2 < grid ? g2 : grid, c->numCU, c->stream));
+      HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      status = (int)(hscal[QM_SC_STATUS] & 0xffffffffu);
+      c->lastSlowReads = nl_;
+    }
     if (o->sel_aln && rq.mode != QM_RUN_COLLECT && hscal[QM_SC_SLOWCNT] > 0 && !(status & 23)) {
       // -s: reads whose SA intervals hold more suffixes than a wave's scratch (repeats, low-complexity reads) were left on
       // the slow queue: gather them, give a few waves scratch sized for the largest, and map them with the same kernel
@@ -735,7 +754,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
       for (int i = 0; i < 7; ++i) fprintf(stderr, "[qm timing] %-16s %6.2f %%  %10.0f clk/read\n", nm[i], 100.0 * hscal[20 + i] / tot, (double)hscal[20 + i] / (double)nreads);
     }
 #endif
-    if (status & 4) return fail(QM_E_TOOLONG, "a read is longer than the kernel's %d characters", ns > 0 ? 64 * ns : QM_MAX_READ_LEN);
+    if (status & 4) return fail(QM_E_TOOLONG, "a read is longer than %d characters (-s: the alignment kernels are sized for that; otherwise the long-read pass takes up to %d)", o->sel_aln ? QM_MAX_READ_LEN : QM_MAX_LONG_READ_LEN, QM_MAX_LONG_READ_LEN);
     if (status & 2) return fail(QM_E_UNSUPPORTED, "an SA-interval list exceeded %d entries (max_interval too large)", QM_GCAP);
     if (status & 8) return fail(QM_E_STATE, "selective alignment: a read overflowed the scratch sized for it (internal error)");
     if (status & 17) {           // a bump allocator ran out: grow and redo the batch
@@ -858,14 +877,19 @@ static int run_stage_b(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
 
 static int map_device_impl(qm_ctx* c, const qm_opts* o, int64_t n, const void* d_seq1, const void* d_off1, const void* d_seq2,
                            const void* d_off2, int32_t max_read_len, int64_t* n_hits, qm_counters* counters, ChunkFeeder* feeder,
-                           const RunReq& rq = RunReq()) {
+                           const RunReq& rq = RunReq(), int32_t short_read_len = 0) {
   if (!c || n < 0 || (n > 0 && (!d_seq1 || !d_off1))) return fail(QM_E_ARG, "bad argument");
   int rc = check_opts(o);
   if (rc) return rc;
   if ((d_seq2 == nullptr) != (d_off2 == nullptr)) return fail(QM_E_ARG, "seq2/off2 must both be given or both be null");
-  if (max_read_len > QM_MAX_READ_LEN) return fail(QM_E_TOOLONG, "read length %d > %d", max_read_len, QM_MAX_READ_LEN);
+  if (max_read_len > (o->sel_aln ? QM_MAX_READ_LEN : QM_MAX_LONG_READ_LEN))
+    return fail(QM_E_TOOLONG, "read length %d > %d", max_read_len, o->sel_aln ? QM_MAX_READ_LEN : QM_MAX_LONG_READ_LEN);
   HIPCHK(hipSetDevice(c->device));
-  const int ns = max_read_len <= 128 ? 2 : (max_read_len <= 192 ? 3 : (max_read_len <= 256 ? 4 : 8));   // 64-character slots per read: picks the kernel instantiation
+  // 64-character slots per read: picks the kernel instantiation.  `short_read_len` (host callers: the longest read that is not
+  // beyond QM_MAX_READ_LEN) picks it when the batch also holds long reads -- those are set aside by the launch whatever its
+  // slot class and mapped by the long-read pass
+  const int pick = (max_read_len > QM_MAX_READ_LEN && short_read_len > 0) ? short_read_len : (max_read_len > QM_MAX_READ_LEN ? QM_MAX_READ_LEN : max_read_len);
+  const int ns = pick <= 128 ? 2 : (pick <= 192 ? 3 : (pick <= 256 ? 4 : 8));
   const bool paired = d_seq2 != nullptr;
   u64 hscal[QM_SC_WORDS];
   c->lastUnits = -1;
@@ -894,8 +918,13 @@ int qm_map_device(qm_ctx* c, const qm_opts* o, int64_t n, const void* d_seq1, co
 
 // offsets of one mate: monotone, longest read; device copies of the offsets (copy stream) and room for the characters
 static int stage_offsets(qm_ctx* c, int64_t n, const int64_t* off, uint8_t*& d_seq, int64_t& capSeq, long long*& d_off, int64_t& capOff,
-                         int32_t& maxLen) {
-  for (int64_t i = 0; i < n; ++i) { int64_t l = off[i + 1] - off[i]; if (l < 0) return fail(QM_E_ARG, "offsets not monotone"); if (l > maxLen) maxLen = (int32_t)(l > 0x7fffffff ? 0x7fffffff : l); }
+                         int32_t& maxLen, int32_t& maxShort) {
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t l = off[i + 1] - off[i];
+    if (l < 0) return fail(QM_E_ARG, "offsets not monotone");
+    if (l > maxLen) maxLen = (int32_t)(l > 0x7fffffff ? 0x7fffffff : l);
+    if (l <= QM_MAX_READ_LEN && l > maxShort) maxShort = (int32_t)l;
+  }
   int rc;
   if ((rc = ensure(d_seq, capSeq, off[n] + 64))) return rc;
   if ((rc = ensure(d_off, capOff, n + 1))) return rc;
@@ -919,17 +948,19 @@ static int map_host(qm_ctx* c, const qm_opts* o, int64_t n, const char* seq1, co
                     const int64_t* off2, int64_t* n_hits, qm_counters* counters, const RunReq& rq) {
   if (!c || n < 0 || (n > 0 && (!seq1 || !off1))) return fail(QM_E_ARG, "bad argument");
   HIPCHK(hipSetDevice(c->device));
-  int32_t maxLen = 0; int rc;
+  int32_t maxLen = 0, maxShort = 0; int rc;
   static const int64_t zero = 0;
   if (n == 0) { off1 = &zero; if (seq2) off2 = &zero; }
-  if ((rc = stage_offsets(c, n, off1, c->d_seq1, c->capSeq1, c->d_off1, c->capOff1, maxLen))) return rc;
-  if (seq2 && (rc = stage_offsets(c, n, off2, c->d_seq2, c->capSeq2, c->d_off2, c->capOff2, maxLen))) return rc;
-  if (maxLen > QM_MAX_READ_LEN) { hipStreamSynchronize(c->copyStream); return fail(QM_E_TOOLONG, "read length %d > %d", maxLen, QM_MAX_READ_LEN); }
+  if ((rc = check_opts(o))) return rc;
+  if ((rc = stage_offsets(c, n, off1, c->d_seq1, c->capSeq1, c->d_off1, c->capOff1, maxLen, maxShort))) return rc;
+  if (seq2 && (rc = stage_offsets(c, n, off2, c->d_seq2, c->capSeq2, c->d_off2, c->capOff2, maxLen, maxShort))) return rc;
+  const int32_t lim = o->sel_aln ? QM_MAX_READ_LEN : QM_MAX_LONG_READ_LEN;
+  if (maxLen > lim) { hipStreamSynchronize(c->copyStream); return fail(QM_E_TOOLONG, "read length %d > %d%s", maxLen, lim, o->sel_aln ? " (-s)" : ""); }
   // the characters follow chunk by chunk, each chunk's kernel behind its own copy (ChunkFeeder); QM_HOST_CHUNK = units per chunk
   HostFeed hf = {c, seq1, off1, seq2, off2};
   const char* ce = getenv("QM_HOST_CHUNK");
   ChunkFeeder fd; fd.chunk = ce && atoll(ce) > 0 ? atoll(ce) : (1 << 20); fd.upload = host_feed_upload; fd.self = &hf;
-  rc = map_device_impl(c, o, n, c->d_seq1, c->d_off1, seq2 ? c->d_seq2 : nullptr, seq2 ? c->d_off2 : nullptr, maxLen, n_hits, counters, &fd, rq);
+  rc = map_device_impl(c, o, n, c->d_seq1, c->d_off1, seq2 ? c->d_seq2 : nullptr, seq2 ? c->d_off2 : nullptr, maxLen, n_hits, counters, &fd, rq, maxShort > 0 ? maxShort : 1);
   hipStreamSynchronize(c->copyStream);                     // nothing of the caller's buffers is in flight after return (error paths too)
   return rc;
 }
@@ -1057,7 +1088,7 @@ int qm_collect_reads(qm_ctx* c, const qm_opts* o, int64_t n, const char* seq, co
   if (n == 0) off = &zero;
   int32_t maxLen = 0;
   for (int64_t i = 0; i < n; ++i) { const int64_t l = off[i + 1] - off[i]; if (l < 0) return fail(QM_E_ARG, "offsets not monotone"); if (l > maxLen) maxLen = (int32_t)(l > 0x7fffffff ? 0x7fffffff : l); }
-  if (maxLen > QM_MAX_READ_LEN) return fail(QM_E_TOOLONG, "read length %d > %d", maxLen, QM_MAX_READ_LEN);
+  if (maxLen > (o->sel_aln ? QM_MAX_READ_LEN : QM_MAX_LONG_READ_LEN)) return fail(QM_E_TOOLONG, "read length %d > %d", maxLen, o->sel_aln ? QM_MAX_READ_LEN : QM_MAX_LONG_READ_LEN);
   if ((rc = ensure(c->d_seq1, c->capSeq1, off[n] + 64))) return rc;
   if ((rc = ensure(c->d_off1, c->capOff1, n + 1))) return rc;
   if ((rc = upload(c, c->d_off1, off, (size_t)(n + 1) * 8))) return rc;
@@ -1095,7 +1126,7 @@ int qm_hits_to_mappings(qm_ctx* c, const qm_opts* o, int64_t n, const int32_t* r
   if (ni > 0 && !ints) return fail(QM_E_ARG, "null intervals");
   for (int64_t i = 0; i < n; ++i) {
     if (int_offsets[i + 1] < int_offsets[i]) return fail(QM_E_ARG, "interval offsets not monotone");
-    if (read_len[i] < 0 || read_len[i] > QM_MAX_READ_LEN) return fail(QM_E_TOOLONG, "read length %d > %d", read_len[i], QM_MAX_READ_LEN);
+    if (read_len[i] < 0 || read_len[i] > (o->sel_aln ? QM_MAX_READ_LEN : QM_MAX_LONG_READ_LEN)) return fail(QM_E_TOOLONG, "read length %d > %d", read_len[i], o->sel_aln ? QM_MAX_READ_LEN : QM_MAX_LONG_READ_LEN);
     int nf = 0, nr = 0; bool seenRc = false;
     for (int64_t j = int_offsets[i]; j < int_offsets[i + 1]; ++j) {
       if (ints[j].query_rc) { ++nr; seenRc = true; } else { ++nf; if (seenRc) return fail(QM_E_ARG, "read %lld: forward-strand intervals must precede the reverse-complement ones", (long long)i); }

@@ -327,6 +327,8 @@ int qmk_map_grid(long long nreads, int num_cu) {
 // collect: collector-only kernels (ns < 0: those of the stage entry, eight slots; otherwise the chain-scoring ones of slot count ns)
 hipError_t qmk_map_reads(const void* ixp, const void* bp, int ns, int grid, int num_cu, hipStream_t st) { return qmk_map_reads_ex(ixp, bp, ns, 0, grid, num_cu, st); }
 hipError_t qmk_map_reads_ex(const void* ixp, const void* bp, int ns, int collect, int grid, int num_cu, hipStream_t st) {
+  if (ns == -32) return qmk_launch_reads_ns32(ixp, bp, 1, grid, num_cu, st);   // long-read pass of the collector-only stage entry
+  if (ns == 32) return qmk_launch_reads_ns32(ixp, bp, 0, grid, num_cu, st);    // long-read pass (reads of 513 .. 2048 characters)
   if (ns < 0) return qmk_launch_reads_ns8(ixp, bp, 1, grid, num_cu, st);
   if (collect) {
     if (ns == 2) return qmk_launch_reads_ns2(ixp, bp, 1, grid, num_cu, st);

@@ -35,7 +35,7 @@ namespace qm {
 #define QM_CAP 64      // entries per LDS list
 #define QM_GCAP 2048   // entries per global-scratch list (2 strands x <1000 SA entries)
 #define QM_ICAP 16     // SA-interval hits per strand kept in LDS (more spill to global scratch)
-#define QM_IOVF 512    // ... overflow capacity per strand (>= 64*NS - k + 1 for NS = 8)
+#define QM_IOVF 2048   // ... overflow capacity per strand (>= 64*NS - k + 1 for NS = 32, the long-read kernels)
 #define QM_CHUNK 4096  // list elements a wave reserves per bump-allocator round trip (>= QM_GCAP)
 #define QM_GSCR_U64 (3 * QM_GCAP + 2 * QM_IOVF * 2)   // u64 words of global scratch per wave
 // slots of the context's scalar block (ReadBatch::cursor points at slot 0): bump pointer, qm_counters[6], status, ksw2 task
@@ -462,11 +462,13 @@ enum { FL_E = 0,    // eligible in getSAHits_: no N in [p,p+k), not a homopolyme
        FL_F = 3,    // khash.find(mer) hit
        FL_C = 4,    // khash.find(mer.getRC()) hit
        FL_V = 5 };  // the position produced a KmerDirScore entry (only used by the --noSensitive vote)
-template <bool WIDE> struct FlagWord { typedef u32 type; };
-template <> struct FlagWord<true> { typedef u64 type; };
+// the flag word of a slot count: a dword up to 5 slots, a register pair up to 10, Wide<> beyond (the long-read kernels)
+template <int BITS, bool FITS32 = (BITS <= 32), bool FITS64 = (BITS <= 64)> struct FlagWord { typedef Wide<(BITS + 63) / 64> type; };
+template <int BITS> struct FlagWord<BITS, true, true> { typedef u32 type; };
+template <int BITS> struct FlagWord<BITS, false, true> { typedef u64 type; };
 template <int NS>
 struct Strand {
-  typedef typename FlagWord<(6 * NS > 32)>::type FT;
+  typedef typename FlagWord<6 * NS>::type FT;
   LV<FT> fl;
   static QM_DEV FT bit(int f, int s) { return (FT)1 << (f * NS + s); }
   // flag word of the lane that owns position p (wave-uniform), and one flag of it
@@ -1062,7 +1064,7 @@ QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, c
 #pragma unroll
           for (int s2 = 0; s2 < NS; ++s2) {
             const int q = 64 * s2 + l;
-            if (q >= p && q < e && ((V.fl[l] >> (FL_E * NS + s2)) & 1)) V.fl[l] |= Strand<NS>::bit(FL_V, s2);
+            if (q >= p && q < e && ((V.fl[l] >> (FL_E * NS + s2)) & 1) != 0) V.fl[l] |= Strand<NS>::bit(FL_V, s2);
           }
         }
       }
@@ -1599,10 +1601,11 @@ struct WaveAlloc { long long base; int used; long long ivBase; int ivUsed; };   
 // LDS staging the only wait is the one finish_read places before its stores, by which time the loads have long landed.
 //   stage[]    raw bytes of the next read, fetched as aligned dwords from (src + o0) & ~3 on
 //   ostage[j]  two offsets (4 dwords) of a read: slot parity j holds the current read's, j ^ 1 the next one's
-// slot of a launch -> read: the identity, except in the slow pass of -s (the launch walks the slow queue)
-template <int F>
+// slot of a launch -> read: the identity, except in the slow pass of -s and in the long-read pass (NS > 8), whose launches walk
+// a queue of reads the first pass set aside
+template <int F, int NS = 0>
 QM_DEV long long read_id(const ReadBatch& B, long long slot) {
-  if (!(F & QM_F_SEL)) return slot;
+  if (!(F & QM_F_SEL) && NS <= 8) return slot;
   return B.slowq ? uniform(B.slowq[slot]) : slot;
 }
 QM_DEV void read_src(const ReadBatch& B, long long read, const unsigned char*& src, const long long*& off, long long& unit) {
@@ -1618,7 +1621,7 @@ template <int NS, int F>
 QM_DEV void stage_offsets(const ReadBatch& B, long long slot, WaveMem<NS>& M, int par) {
   if (slot >= B.nreads) return;
   const unsigned char* src; const long long* off; long long unit;
-  read_src(B, read_id<F>(B, slot), src, off, unit);
+  read_src(B, read_id<F, NS>(B, slot), src, off, unit);
   QM_LANES(l) { if (l < 4) lds_dma_u32((const u32*)(off + unit) + l, M.ostage[par], l); }
 }
 QM_DEV long long staged_offset(const u32* o, int j) { return (long long)(((u64)uniform(o[2 * j + 1]) << 32) | (u64)uniform(o[2 * j])); }
@@ -1627,7 +1630,7 @@ template <int NS, int F>
 QM_DEV void stage_chars(const ReadBatch& B, long long slot, WaveMem<NS>& M, int par) {
   if (slot >= B.nreads) return;
   const unsigned char* src; const long long* off; long long unit;
-  read_src(B, read_id<F>(B, slot), src, off, unit);
+  read_src(B, read_id<F, NS>(B, slot), src, off, unit);
   const long long o0 = staged_offset(M.ostage[par], 0), o1 = staged_offset(M.ostage[par], 1);
   int len = (int)(o1 - o0);
   if (len > 64 * NS) len = 64 * NS;
@@ -1717,7 +1720,18 @@ QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, lon
   const long long o0 = staged_offset(M.ostage[par], 0), o1 = staged_offset(M.ostage[par], 1);
   const int rawLen = (int)(o1 - o0);
   const bool tooLong = rawLen > 64 * NS;
-  if (tooLong) { QM_LANES(l) { if (l == 0) *B.status |= 4; } }
+  // A read that does not fit this kernel's slots is set aside for the long-read pass (a second, small launch of the NS = 32
+  // kernels over the queue of such reads; the host sizes nothing from it but checks the longest against QM_MAX_LONG_READ_LEN).
+  // With -s there is no such pass (the ksw2 images are sized for QM_MAX_READ_LEN): the batch fails as before.
+  const bool setAside = tooLong && !(F & QM_F_SEL) && NS < 32;
+  if (tooLong) {
+    QM_LANES(l) {
+      if (l == 0) {
+        if (setAside) { B.lcnt[read] = QM_LCNT_SLOW; B.loff[read] = 0; atomic_add_u64(B.cursor + QM_SC_SLOWCNT, 1ULL); atomic_max_u64(B.cursor + QM_SC_SLOWMAX, (u64)rawLen); }
+        else *B.status |= 4;
+      }
+    }
+  }
   // uniform(): the length must stay in an SGPR -- merged into the lane-0 branch above it became a per-lane value and
   // with it every position, mask and branch of the collector moved from the scalar unit to the VALU
   const int len = uniform(tooLong ? 64 * NS : rawLen);
@@ -1749,6 +1763,7 @@ QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, lon
   stage_chars<NS, F>(B, slot + nw, M, par ^ 1);
   stage_offsets<NS, F>(B, slot + 2 * nw, M, par);
   QM_T(0);
+  if (setAside) { lds_dma_wait(); return; }               // mapped by the long-read pass (the next iteration reads the staging rows: what was just requested must have landed)
   IntervalList fi, ri;
   fi.lds = (QM_LDS(IntRec)*)M.ints[0]; ri.lds = (QM_LDS(IntRec)*)M.ints[1];
   fi.ovf = (IntRec*)(gscr + 3 * QM_GCAP); ri.ovf = fi.ovf + QM_IOVF;

@@ -14,8 +14,11 @@ template <> struct SelLds<false> { QM_DEV SelScratchLds* ptr() { return nullptr;
 
 // stage A: one wavefront per read.  WPS = minimum waves per SIMD the register allocator must leave room for.
 // F: compile-time feature flags (QM_F_PH, QM_F_NIP) -- the default kernel carries no optional code.
+// Waves per workgroup: four, except in the long-read kernels, whose per-wave LDS slab (41 KB at NS = 32) allows two.
+template <int NS> struct WavesPerBlock { static constexpr int value = NS > 16 ? 2 : 4; };
 template <int NS, int WPS, int F>
-__global__ __launch_bounds__(256, WPS) void qm_read_kernel(DevIndex ix_, ReadBatch B_) {
+__global__ __launch_bounds__(64 * WavesPerBlock<NS>::value, WPS) void qm_read_kernel(DevIndex ix_, ReadBatch B_) {
+  constexpr int WB = WavesPerBlock<NS>::value;
   // The two argument structs (~70 dwords) are read through the kernarg segment where they are used -- scalar loads from
   // constant memory -- instead of being loaded into SGPRs at entry and kept there: at 8 waves/SIMD a wave has 78 SGPRs, and
   // half of the v_readlane / v_writelane spill traffic of this kernel was for these words.
@@ -23,12 +26,12 @@ __global__ __launch_bounds__(256, WPS) void qm_read_kernel(DevIndex ix_, ReadBat
   typedef const Args __attribute__((address_space(4)))* AP4;
   const Args* args = (const Args*)(AP4)__builtin_amdgcn_kernarg_segment_ptr();
   const DevIndex& ix = args->ix; const ReadBatch& B = args->B;
-  __shared__ WaveMem<NS> mem[4];
-  __shared__ SelLds<(F & QM_F_SEL) != 0 && (F & QM_F_COLLECT) == 0> sels[4];   // -s kernels that chain: the LDS edition of the scratch
+  __shared__ WaveMem<NS> mem[WB];
+  __shared__ SelLds<(F & QM_F_SEL) != 0 && (F & QM_F_COLLECT) == 0> sels[WB];   // -s kernels that chain: the LDS edition of the scratch
   // the wave index is wave-uniform: keep it (and every address derived from it) on the scalar unit
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int gw = (int)blockIdx.x * 4 + wave;             // reads per launch < 2^31: 32-bit slot arithmetic
-  const int nw = (int)gridDim.x * 4;
+  const int gw = (int)blockIdx.x * WB + wave;            // reads per launch < 2^31: 32-bit slot arithmetic
+  const int nw = (int)gridDim.x * WB;
   const int nreads = (int)B.nreads;
   u64* gscr = B.gscratch + (long long)gw * QM_GSCR_U64;
   WaveAlloc wa; wa.base = -1; wa.used = 0; wa.ivBase = -1; wa.ivUsed = 0;
@@ -44,7 +47,7 @@ __global__ __launch_bounds__(256, WPS) void qm_read_kernel(DevIndex ix_, ReadBat
   lds_dma_wait();
   int par = 0;
   for (int r = gw; r < nreads; r += nw) {
-    map_read<NS, F>(ix, B, read_id<F>(B, r), r, nw, par, M, gscr, wa, (F & QM_F_SEL) ? B.selscr + gw : nullptr, sels[wave].ptr(),
+    map_read<NS, F>(ix, B, read_id<F, NS>(B, r), r, nw, par, M, gscr, wa, (F & QM_F_SEL) ? B.selscr + gw : nullptr, sels[wave].ptr(),
                     ((F & QM_F_SEL) && B.dyn) ? B.dyn + gw : nullptr);
     par ^= 1;
   }
@@ -63,24 +66,30 @@ static hipError_t launch_reads_ns(const DevIndex& ix, const ReadBatch& B, bool c
   // (VGPR/LDS dependent) decides the grid.
 #define QM_LAUNCH(WPS_, F_) do {                                                                               \
     static int nb = 0;                                                                                          \
-    if (nb == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, qm_read_kernel<NS, WPS_, F_>, 256, 0) != hipSuccess || nb < 1)) \
+    if (nb == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, qm_read_kernel<NS, WPS_, F_>, 64 * WavesPerBlock<NS>::value, 0) != hipSuccess || nb < 1)) \
       nb = WPS_;                                                                                                \
     static const char* ov = getenv("QM_BLOCKS_PER_CU");   /* tuning knob: fewer resident blocks than the occupancy allows */ \
     long long g = (long long)num_cu * ((ov && atoi(ov) > 0 && atoi(ov) < nb) ? atoi(ov) : nb);                  \
     if (g > grid) g = grid;                                                                                     \
-    hipLaunchKernelGGL((qm_read_kernel<NS, WPS_, F_>), dim3((unsigned)g), dim3(256), 0, st, ix, B);             \
+    hipLaunchKernelGGL((qm_read_kernel<NS, WPS_, F_>), dim3((unsigned)g), dim3(64 * WavesPerBlock<NS>::value), 0, st, ix, B); \
   } while (0)
   if constexpr (WITH_COLLECT) if (collect) {
     // collector-only kernels: the chain-scoring flavours for every slot count (first pass of a fused -s call: without the
     // chaining code they fit the register budget of the default kernel, so they are built for its occupancy), the others
     // only at eight slots (the stage entry qm_collect_reads, any read length)
+    if constexpr (NS <= 8) {
+      switch (F) {
+        case QM_F_SEL: QM_LAUNCH(W0, QM_F_SEL | QM_F_COLLECT); return hipGetLastError();
+        case QM_F_SEL | QM_F_PH: QM_LAUNCH(WPH, QM_F_SEL | QM_F_PH | QM_F_COLLECT); return hipGetLastError();
+        case QM_F_SEL | QM_F_NIP: QM_LAUNCH(WNIP, QM_F_SEL | QM_F_NIP | QM_F_COLLECT); return hipGetLastError();
+        case QM_F_SEL | QM_F_PH | QM_F_NIP: QM_LAUNCH(WPHNIP, QM_F_SEL | QM_F_PH | QM_F_NIP | QM_F_COLLECT); return hipGetLastError();
+        default: break;
+      }
+    }
+    if (F & QM_F_SEL) return hipErrorInvalidValue;
     switch (F) {
-      case QM_F_SEL: QM_LAUNCH(W0, QM_F_SEL | QM_F_COLLECT); break;
-      case QM_F_SEL | QM_F_PH: QM_LAUNCH(WPH, QM_F_SEL | QM_F_PH | QM_F_COLLECT); break;
-      case QM_F_SEL | QM_F_NIP: QM_LAUNCH(WNIP, QM_F_SEL | QM_F_NIP | QM_F_COLLECT); break;
-      case QM_F_SEL | QM_F_PH | QM_F_NIP: QM_LAUNCH(WPHNIP, QM_F_SEL | QM_F_PH | QM_F_NIP | QM_F_COLLECT); break;
       default:
-        if constexpr (NS == 8) {
+        if constexpr (NS == 8 || NS == 32) {
           switch (F) {
             case 0: QM_LAUNCH(W0, QM_F_COLLECT); break;
             case QM_F_PH: QM_LAUNCH(WPH, QM_F_PH | QM_F_COLLECT); break;

@@ -248,4 +248,65 @@ template <int N> QM_DEV void load_8_16xN(const u64* const* B, const int* bit, u6
 
 QM_DEV u64 lanemask_lt(int l) { return l ? (~0ULL >> (64 - l)) : 0ULL; }
 
+// An N x 64-bit unsigned integer with just the operators the collector's per-position flag word needs (shifts, and / or / not,
+// comparison with small constants): the flag word of the long-read kernels, whose six flags x NS slots no longer fit a register
+// pair (qm_mapper.inl, Strand).  Slow and simple on purpose: those kernels run on the few reads of a batch that need them.
+template <int N>
+struct Wide {
+  u64 w[N];
+  QM_DEV Wide() { for (int i = 0; i < N; ++i) w[i] = 0; }
+  QM_DEV Wide(unsigned long long x) { w[0] = x; for (int i = 1; i < N; ++i) w[i] = 0; }
+  QM_DEV Wide operator<<(int n) const {
+    Wide r; const int ws = n >> 6, bs = n & 63;
+    for (int i = 0; i < N; ++i) {
+      u64 v = 0;
+      for (int j = 0; j < N; ++j) {
+        if (j == i - ws) v |= w[j] << bs;
+        if (j == i - ws - 1 && bs) v |= w[j] >> (64 - bs);
+      }
+      r.w[i] = v;
+    }
+    return r;
+  }
+  QM_DEV Wide operator>>(int n) const {
+    Wide r; const int ws = n >> 6, bs = n & 63;
+    for (int i = 0; i < N; ++i) {
+      u64 v = 0;
+      for (int j = 0; j < N; ++j) {
+        if (j == i + ws) v |= w[j] >> bs;
+        if (j == i + ws + 1 && bs) v |= w[j] << (64 - bs);
+      }
+      r.w[i] = v;
+    }
+    return r;
+  }
+  QM_DEV Wide operator&(const Wide& o) const { Wide r; for (int i = 0; i < N; ++i) r.w[i] = w[i] & o.w[i]; return r; }
+  QM_DEV Wide operator|(const Wide& o) const { Wide r; for (int i = 0; i < N; ++i) r.w[i] = w[i] | o.w[i]; return r; }
+  QM_DEV Wide operator~() const { Wide r; for (int i = 0; i < N; ++i) r.w[i] = ~w[i]; return r; }
+  QM_DEV Wide& operator|=(const Wide& o) { for (int i = 0; i < N; ++i) w[i] |= o.w[i]; return *this; }
+  QM_DEV bool operator==(const Wide& o) const { bool e = true; for (int i = 0; i < N; ++i) e = e && w[i] == o.w[i]; return e; }
+  QM_DEV bool operator!=(const Wide& o) const { return !(*this == o); }
+};
+template <int N> QM_DEV Wide<N> read_lane(const LV<Wide<N>>& x, int lane) {
+  Wide<N> r;
+#ifdef QM_EMU
+  r = x.v[lane];
+#else
+  const int ln = __builtin_amdgcn_readfirstlane(lane);
+  for (int i = 0; i < N; ++i) {
+    const int lo = __builtin_amdgcn_readlane((int)(u32)x.v[0].w[i], ln), hi = __builtin_amdgcn_readlane((int)(u32)(x.v[0].w[i] >> 32), ln);
+    r.w[i] = ((u64)(u32)hi << 32) | (u32)lo;
+  }
+#endif
+  return r;
+}
+#ifndef QM_EMU
+template <int N> QM_DEV void swap32(const LV<Wide<N>>& in, LV<Wide<N>>& out) {
+  for (int i = 0; i < N; ++i) {
+    const u32 lo = (u32)__shfl_xor((int)(u32)in.v[0].w[i], 32, 64), hi = (u32)__shfl_xor((int)(u32)(in.v[0].w[i] >> 32), 32, 64);
+    out.v[0].w[i] = ((u64)hi << 32) | lo;
+  }
+}
+#endif
+
 }  // namespace qm

@@ -76,6 +76,22 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
                           case 4: QE_CALL(4, 4) break; case 5: QE_CALL(4, 5) break; case 6: QE_CALL(4, 6) break; default: QE_CALL(4, 7) break; } }
 #undef QE_CALL
     }
+    if (!o->sel_aln && scal[QM_SC_SLOWCNT] > 0 && !(status & 1)) {
+      // the long-read pass (see qm_host.hip): reads beyond the slot count of the first pass again, on the 32-slot kernels
+      std::vector<long long> q;
+      for (long long r = 0; r < nreads; ++r) if (lcnt[r] == QM_LCNT_SLOW) q.push_back(r);
+      ReadBatch S2 = B; S2.slowq = q.data(); S2.nreads = (long long)q.size();
+      if ((long long)scal[QM_SC_SLOWMAX] > QM_MAX_LONG_READ_LEN) { status |= 4; for (long long r : q) lcnt[r] = 0; }   // (the host fails the call here)
+      else {
+        const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP);
+        for (long long r = 0; r < (long long)q.size(); ++r) {
+#define QE_LONG(F_) { static WaveMem<32> M; stage_offsets<32, F_>(S2, r, M, 0); stage_chars<32, F_>(S2, r, M, 0); \
+                      map_read<32, F_>(ix, S2, read_id<F_, 32>(S2, r), r, S2.nreads, 0, M, gs.data(), wa[r % 7]); }
+          switch (F) { case 0: QE_LONG(0) break; case 1: QE_LONG(1) break; case 2: QE_LONG(2) break; default: QE_LONG(3) break; }
+#undef QE_LONG
+        }
+      }
+    }
     if (o->sel_aln && scal[QM_SC_SLOWCNT] > 0 && !(status & 1)) {
       // the slow pass of -s (see qm_host.hip): the queued reads again, on scratch sized for the largest of them
       const long long need = (((long long)scal[QM_SC_SLOWMAX] + 63) / 64) * 64 + 64;

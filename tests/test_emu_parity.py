@@ -132,9 +132,10 @@ def test_long_reads_ns4(synth_small, oracle_mod):
     assert er.status == 0 and res.counters["totHits"] > 1000
     assert_hits_equal(res.hit_offsets, res.hits, er.hit_offsets, er.hits, "ns4")
     _cmp_ints(res, er)
-    # the NS=2 build must refuse them rather than truncate silently
+    # the NS=2 build must not truncate them silently: they are set aside for the long-read pass, same hits
     er2 = em.map(q1, o, q2, o, ns=2)
-    assert er2.status & 4
+    assert (er2.status & 0xff) == 0
+    assert_hits_equal(res.hit_offsets, res.hits, er2.hit_offsets, er2.hits, "ns2 + long-read pass")
     # three 64-character slots: the instantiation 2 x 150 bp reads run on (129..192 bp)
     res3 = orc.map_pairs(a1, aoff, a2, aoff, nthreads=4, want_ints=True)
     er3 = em.map(a1, aoff, a2, aoff, ns=3)
@@ -145,7 +146,7 @@ def test_long_reads_ns4(synth_small, oracle_mod):
         r = orc.map_pairs(a1, aoff, a2, aoff, opts=oracle_mod.default_opts(**oo), nthreads=4)
         e = em.map(a1, aoff, a2, aoff, opts=emu.default_opts(**go), ns=3)
         assert_hits_equal(r.hit_offsets, r.hits, e.hit_offsets, e.hits, "ns3 %s" % oo)
-    assert em.map(q1, o, q2, o, ns=3).status & 4          # the 250 bp reads do not fit three slots
+    assert em.map(q1, o, q2, o, opts=emu.default_opts(sel_aln=1), ns=3).status & 4   # the 250 bp reads do not fit three slots, and -s has no long-read pass
 
 
 def test_medium(synth_medium, oracle_mod):
@@ -349,4 +350,46 @@ def test_reads_of_300_and_500_bp_take_the_eight_slot_kernels(synth_medium, oracl
             assert res.counters["totHits"] > n // 2
             assert_hits_equal(res.hit_offsets, res.hits, er.hit_offsets, er.hits, "%d bp %s" % (L, oo))
             assert res.counters == er.counters
-    assert em.map(s1, off, s2, off, ns=4).status & 4          # 500 bp does not fit four slots
+    # 500 bp does not fit four slots: the reads are set aside and mapped by the long-read pass, same hits
+    er = em.map(s1, off, s2, off, ns=4)
+    res = orc.map_pairs(s1, off, s2, off, nthreads=8)
+    assert (er.status & 0xff) == 0, er.status
+    assert_hits_equal(res.hit_offsets, res.hits, er.hit_offsets, er.hits, "500 bp through the long-read pass")
+    assert em.map(s1, off, s2, off, opts=emu.default_opts(sel_aln=1), ns=4).status & 4   # -s has no such pass
+
+
+@pytest.mark.parametrize("variant", ["default", "noSensitive", "fuzzy", "perfectHash"])
+def test_reads_beyond_512_bp_take_the_long_read_pass(synth_medium, synth_medium_ph, oracle_mod, variant):
+    """a batch of 2 x 100 bp pairs with reads of 600 .. 2048 bp among them (the reference takes any std::string,
+    include/SACollector.hpp:108): the short reads run on the two-slot kernels, the long ones are set aside and mapped by the
+    32-slot kernels (Wide<> flag word, per-read queue); hits, counters and SA-interval lists equal the oracle's"""
+    from rapmap_amd import synth
+    import rapmap_amd as ra
+    idx = (synth_medium_ph if variant == "perfectHash" else synth_medium)["idx"]
+    ix, orc, em, emu = _emu(idx)
+    qi = ra.QuasiIndex(synth_medium["idx"])
+    text, offsets = qi.arrays()
+    text = np.asarray(text); offsets = np.asarray(offsets, dtype=np.int64)
+    ends = np.append(offsets[1:], text.size)
+    txps = [text[a:b - 1] for a, b in zip(offsets, ends) if b - 1 - a >= 2100][:300]
+    assert len(txps) > 20
+    a1, a2, ao, _ = synth.make_reads(txps, 300, seed=9, read_len=100, err=0.01)
+    r1 = [a1[ao[i]:ao[i + 1]].tobytes() for i in range(300)]; r2 = [a2[ao[i]:ao[i + 1]].tobytes() for i in range(300)]
+    for L, n, err in ((600, 12, 0.01), (1300, 10, 0.02), (2048, 10, 0.005), (2000, 4, 0.0)):
+        s1, s2, off, _ = synth.make_reads(txps, n, seed=L, read_len=L, err=err)
+        for i in range(n):                                 # long reads land between the short ones, on either mate
+            at = (37 * i + L) % len(r1)
+            r1.insert(at, s1[off[i]:off[i + 1]].tobytes()); r2.insert(at, s2[off[i]:off[i + 1]].tobytes() if i % 3 else a2[ao[i]:ao[i + 1]].tobytes())
+    q1, o1 = pack(r1); q2, o2 = pack(r2)
+    oo, go = {"default": ({}, {}), "noSensitive": ({"sensitive": 0}, {"sensitive": 0}), "fuzzy": ({"fuzzy": 1}, {"fuzzy": 1}), "perfectHash": ({}, {})}[variant]
+    res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=8, want_ints=True)
+    er = em.map(q1, o1, q2, o2, opts=emu.default_opts(**go), ns=2)
+    assert (er.status & 0xff) == 0, er.status
+    assert_hits_equal(res.hit_offsets, res.hits, er.hit_offsets, er.hits, "long reads, %s" % variant)
+    assert res.counters == er.counters
+    _cmp_ints(res, er)
+    long_units = [u for u in range(len(r1)) if len(r1[u]) > 512]
+    assert sum(int(res.hit_offsets[u + 1] - res.hit_offsets[u]) > 0 for u in long_units) > len(long_units) // 2
+    # one character too many: the call fails
+    r1[5] = bytes(txps[0][:2049]); q1, o1 = pack(r1)
+    assert em.map(q1, o1, q2, o2, ns=2).status & 4

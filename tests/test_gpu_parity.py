@@ -136,9 +136,13 @@ def test_edge_batches(synth_small, oracle_mod):
         gr = mp.map_pairs(q1, o1, q2, o2)
         assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "one")
     # too-long read and unsupported options are errors, not silent fallbacks
-    q1, o1 = pack([b"A" * 600]); q2, o2 = pack([b"C" * 10])
+    q1, o1 = pack([b"A" * 2100]); q2, o2 = pack([b"C" * 10])
     with pytest.raises(ra.QmError, match="read length"):
         mp.map_pairs(q1, o1, q2, o2)
+    q1, o1 = pack([b"A" * 600]); q2, o2 = pack([b"C" * 10])
+    with pytest.raises(ra.QmError, match="read length"):
+        mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(sel_aln=1))
+    assert mp.map_pairs(q1, o1, q2, o2).n_hits == 0          # without -s a 600-character read takes the long-read pass
 
 
 def test_medium_full_parity_and_properties(synth_medium, oracle_mod):
@@ -592,3 +596,57 @@ def test_reads_longer_than_256_bp(synth_medium, synth_medium_ph, oracle_mod, L):
     res = orc.map_pairs(q1, o1, q2, o2, nthreads=8)
     gr = mp.map_pairs(q1, o1, q2, o2)
     assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "mixed lengths")
+
+
+@pytest.mark.parametrize("variant", ["default", "noSensitive", "fuzzy", "perfectHash", "perfectHashCompact"])
+def test_reads_beyond_512_bp_take_the_long_read_pass(synth_medium, synth_medium_ph, oracle_mod, variant):
+    """a batch of 2 x 100 bp pairs with reads of 600 .. 2048 bp among them (the reference takes any std::string,
+    include/SACollector.hpp:108): the short reads run on the two-slot kernels, the long ones are set aside by that launch and
+    mapped by a second, small launch of the 32-slot kernels; hits and counters equal the oracle's.  With -s, and beyond 2048
+    characters, the call fails loudly instead."""
+    import rapmap_amd as ra
+    from rapmap_amd import synth
+    ph = variant.startswith("perfectHash")
+    idx = (synth_medium_ph if ph else synth_medium)["idx"]
+    ix, orc = load_oracle(idx)
+    txps = _medium_txps(synth_medium["idx"], min_len=2100, cap=300)
+    assert len(txps) > 20
+    a1, a2, ao, _ = synth.make_reads(txps, 3000, seed=9, read_len=100, err=0.01)
+    r1 = [a1[ao[i]:ao[i + 1]].tobytes() for i in range(3000)]; r2 = [a2[ao[i]:ao[i + 1]].tobytes() for i in range(3000)]
+    for L, n, err in ((600, 40, 0.01), (1300, 30, 0.02), (2048, 30, 0.005), (2000, 6, 0.0), (513, 10, 0.01)):
+        s1, s2, off, _ = synth.make_reads(txps, n, seed=L, read_len=L, err=err)
+        for i in range(n):                                 # long reads land between the short ones, on either mate
+            at = (37 * i + L) % len(r1)
+            r1.insert(at, s1[off[i]:off[i + 1]].tobytes()); r2.insert(at, s2[off[i]:off[i + 1]].tobytes() if i % 3 else a2[ao[i]:ao[i + 1]].tobytes())
+    q1, o1 = pack(r1); q2, o2 = pack(r2)
+    oo, go = {"default": ({}, {}), "noSensitive": ({"sensitive": 0}, {"sensitive": 0}), "fuzzy": ({"fuzzy": 1}, {"fuzzy": 1}),
+              "perfectHash": ({}, {}), "perfectHashCompact": ({}, {})}[variant]
+    res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=8, want_ints=True)
+    qi, mp = _gpu(idx, debug=True, ph_compact=variant == "perfectHashCompact")
+    gr = mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(**go))
+    assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "long reads, %s" % variant)
+    assert res.counters == gr.counters
+    long_units = [u for u in range(len(r1)) if len(r1[u]) > 512 or len(r2[u]) > 512]
+    assert mp.stat(2) == sum((len(r1[u]) > 512) + (len(r2[u]) > 512) for u in long_units)       # QM_STAT_SLOW_READS: the reads of the second launch
+    assert sum(int(res.hit_offsets[u + 1] - res.hit_offsets[u]) > 0 for u in long_units) > len(long_units) // 2
+    io, ints = mp.intervals(len(r1))                         # the SA-interval lists of the fused pass, long reads included
+    assert np.array_equal(io, res.ints_offsets)
+    assert np.array_equal(ints["begin"], res.ints[:, 0]) and np.array_equal(ints["len"].astype(np.int32), res.ints[:, 2])
+    if variant == "default":
+        # the collector as a call of its own, single-end reads, the same reads already on the device
+        fl, iol, il = mp.collect_reads(q1, o1)
+        left = res.ints[res.ints[:, 5] < 2]
+        assert int(iol[-1]) == len(left) and np.array_equal(il["begin"], left[:, 0]) and np.array_equal(il["query_pos"].astype(np.int32), left[:, 3])
+        rs = orc.map_single(q1, o1, nthreads=8)
+        gs = mp.map_reads(q1, o1)
+        assert_hits_equal(rs.hit_offsets, rs.hits, gs.hit_offsets, gs.hits, "long reads, single-end")
+        import torch
+        d1 = torch.from_numpy(np.concatenate([q1, np.zeros(64, np.uint8)])).cuda(); d2 = torch.from_numpy(np.concatenate([q2, np.zeros(64, np.uint8)])).cuda()
+        p1 = torch.from_numpy(o1).cuda(); p2 = torch.from_numpy(o2).cuda()
+        gd = mp.map_device(len(r1), d1.data_ptr(), p1.data_ptr(), d2.data_ptr(), p2.data_ptr(), 2048, fetch=True)
+        assert_hits_equal(res.hit_offsets, res.hits, gd.hit_offsets, gd.hits, "long reads, device-resident input")
+        with pytest.raises(ra.QmError, match="512"):
+            mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(sel_aln=1))
+        r1[5] = bytes(txps[0][:2049]); q1, o1 = pack(r1)
+        with pytest.raises(ra.QmError, match="2048"):
+            mp.map_pairs(q1, o1, q2, o2)
