@@ -40,7 +40,7 @@ def _quasimap(argv):
     ap.add_argument("-1", "--leftMates", default="", help="The location of the left paired-end reads")
     ap.add_argument("-2", "--rightMates", default="", help="The location of the right paired-end reads")
     ap.add_argument("-r", "--unmatedReads", default="", help="The location of single-end reads")
-    ap.add_argument("-t", "--numThreads", type=int, default=8, help="host threads for read parsing and SAM formatting (the GPU does the mapping)")
+    ap.add_argument("-t", "--numThreads", type=int, default=16, help="host threads for read parsing and SAM formatting (the GPU does the mapping)")
     ap.add_argument("-m", "--maxNumHits", type=int, default=200, help="Reads mapping to more than this many loci are discarded")
     ap.add_argument("-o", "--output", default="", help="The output file (default: stdout)")
     ap.add_argument("-z", "--quasiCoverage", type=float, default=None)
