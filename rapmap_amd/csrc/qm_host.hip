@@ -82,9 +82,10 @@ struct Replica {
   uint8_t* d_text = nullptr; int32_t* d_SA = nullptr; void* d_sainfo = nullptr; void* d_slots = nullptr; uint64_t cap = 0;
   void* d_ph = nullptr; PhIndex hPh; std::vector<void*> phAllocs; int32_t* d_txpOff = nullptr; int32_t* d_txpLen = nullptr; int64_t devBytes = 0;
   std::mutex sanextMu; unsigned int* d_sanext = nullptr;   // -s: built by the first -s call of any context of this replica
+  void* d_saext = nullptr;                                  // the packed characters behind every suffix's k-mer (SaExt), or null
   ~Replica() {
     hipSetDevice(device);
-    void* ptrs[] = {d_text, d_SA, d_sainfo, d_slots, d_txpOff, d_txpLen, d_sanext};
+    void* ptrs[] = {d_text, d_SA, d_sainfo, d_slots, d_txpOff, d_txpLen, d_sanext, d_saext};
     for (void* p : ptrs) if (p) hipFree(p);
     for (void* p : phAllocs) if (p) hipFree(p);
   }
@@ -99,6 +100,7 @@ struct qm_ctx {
   int device = 0, numCU = 256;
   hipStream_t stream = nullptr, copyStream = nullptr;      // kernels / host-buffer uploads (overlapped chunk by chunk)
   unsigned int* d_sanext = nullptr;                         // -s: text characters behind every suffix's k-mer (the replica's, built at its first -s call)
+  void* d_saext = nullptr;                                  // the replica's SaExt table
   hipStream_t planStream = nullptr;                         // -s: the plan kernels of the later chunks, under the ksw2 kernel of the earlier ones
   hipEvent_t evPlan[QM_SEL_CHUNKS_B + 1] = {};              // ... [i]: chunk i planned; [last]: the plan stream may start
   u64* d_ntk = nullptr;                                     // ... one task counter per chunk
@@ -365,7 +367,7 @@ int qm_ctx_destroy(qm_ctx* c) {
   if (!c) return QM_OK;
   hipSetDevice(c->device);
   if (!c->rep) {               // creation failed half-way: the index arrays are still this context's own
-    void* own[] = {c->d_text, c->d_SA, c->d_sainfo, c->d_slots, c->d_txpOff, c->d_txpLen};
+    void* own[] = {c->d_text, c->d_SA, c->d_sainfo, c->d_slots, c->d_txpOff, c->d_txpLen, c->d_saext};
     for (void* p : own) if (p) hipFree(p);
     for (void* p : c->phAllocs) if (p) hipFree(p);
   }
@@ -437,6 +439,7 @@ int qm_ctx_create_ex(const qm_index* ix, int device_id, uint32_t flags, qm_ctx**
       c->d_text = R.d_text; c->d_SA = R.d_SA; c->d_sainfo = R.d_sainfo; c->d_slots = R.d_slots; c->cap = R.cap; c->d_ph = R.d_ph; c->hPh = R.hPh;
       c->d_txpOff = R.d_txpOff; c->d_txpLen = R.d_txpLen; c->devBytes = R.devBytes;
       { std::lock_guard<std::mutex> l2(R.sanextMu); c->d_sanext = R.d_sanext; }
+      c->d_saext = R.d_saext;
       *out = c;
       return QM_OK;
     }
@@ -452,6 +455,12 @@ int qm_ctx_create_ex(const qm_index* ix, int device_id, uint32_t flags, qm_ctx**
   CK(hipMalloc((void**)&d_offsets, (size_t)ix->nTxp * 4));
   CK(hipMemcpyAsync(d_offsets, ix->offsets, (size_t)ix->nTxp * 4, hipMemcpyHostToDevice, c->stream));
   CK(qmk_build_sainfo(c->d_SA, ix->nSA, d_offsets, ix->nTxp, c->d_sainfo, c->stream));
+  if (!getenv("QM_NO_SAEXT") && ix->nSA > 0) {
+    // the packed characters behind every suffix's k-mer: an MMP extension becomes one trip instead of two (saext_entry);
+    // 32 bytes per suffix-array entry.  QM_NO_SAEXT (profiling): without the table, extensions read suffix array and text.
+    if (hipMalloc(&c->d_saext, (size_t)ix->nSA * sizeof(SaExt)) != hipSuccess) { c->d_saext = nullptr; (void)hipGetLastError(); }   // no room: the text path
+    else { CK(qmk_build_saext(c->d_text, ix->n, c->d_SA, ix->nSA, ix->k, c->d_saext, c->stream)); }
+  }
   if (!ix->perfect) {
     c->cap = bucket_count(ix->nKeys);                  // 32-byte buckets of two slots, at least two buckets per key
     CK(hipMalloc(&c->d_slots, c->cap * sizeof(Bucket)));
@@ -548,12 +557,14 @@ int qm_ctx_create_ex(const qm_index* ix, int device_id, uint32_t flags, qm_ctx**
     CK(hipMemcpy(c->d_txpLen, l32.data(), (size_t)ix->nTxp * 4, hipMemcpyHostToDevice));
   }
   if (d_recs) hipFree(d_recs);
-  c->devBytes += ix->n + pad + ix->nSA * 4 + ix->nSA * (int64_t)sizeof(SaInfo) + (int64_t)(ix->perfect ? 0 : c->cap * sizeof(Bucket));
+  c->devBytes += ix->n + pad + ix->nSA * 4 + ix->nSA * (int64_t)sizeof(SaInfo) + (int64_t)(ix->perfect ? 0 : c->cap * sizeof(Bucket))
+                 + (c->d_saext ? ix->nSA * (int64_t)sizeof(SaExt) : 0);
 #undef CK
   {
     auto R = std::make_shared<Replica>();
     R->device = device_id; R->d_text = c->d_text; R->d_SA = c->d_SA; R->d_sainfo = c->d_sainfo; R->d_slots = c->d_slots; R->cap = c->cap;
     R->d_ph = c->d_ph; R->hPh = c->hPh; R->phAllocs.swap(c->phAllocs); R->d_txpOff = c->d_txpOff; R->d_txpLen = c->d_txpLen; R->devBytes = c->devBytes;
+    R->d_saext = c->d_saext;
     std::lock_guard<std::mutex> lk(g_repMu);
     c->rep = R;
     g_reps[std::make_pair(ix, repKey)] = R;
@@ -596,7 +607,7 @@ static DevIndex dev_index(const qm_ctx* c) {
   DevIndex ix; ix.text = c->d_text; ix.n = c->ix->n; ix.SA = c->d_SA; ix.nSA = c->ix->nSA;
   ix.sainfo = (const SaInfo*)c->d_sainfo; ix.slots = (const Bucket*)c->d_slots; ix.hmask = c->cap - 1; ix.ph = (const PhIndex*)c->d_ph; ix.k = c->ix->k;
   memset(&ix.phv, 0, sizeof(ix.phv)); if (c->d_ph) ix.phv = c->hPh;
-  ix.sanext = c->d_sanext;
+  ix.sanext = c->d_sanext; ix.saext = (const SaExt*)c->d_saext;
   return ix;
 }
 

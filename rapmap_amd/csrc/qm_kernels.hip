@@ -191,6 +191,13 @@ __global__ void build_sainfo_kernel(const int* SA, long long nSA, const int* off
   }
 }
 
+// the 96 text characters behind the k-mer of every suffix, packed (saext_entry): one-trip MMP extensions
+__global__ void build_saext_kernel(const unsigned char* text, long long n, const int* SA, long long nSA, int k, SaExt* out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < nSA; i += stride) out[i] = saext_entry(text, n, (long long)SA[i] + k);
+}
+
 // -s: the text characters behind the k-mer of every suffix (sanext_entry)
 __global__ void build_sanext_kernel(const unsigned char* text, long long n, const int* SA, long long nSA, int k, u32* out) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -281,6 +288,10 @@ hipError_t qmk_build_sainfo(const int* SA, long long nSA, const int* offsets, lo
   return hipGetLastError();
 }
 
+hipError_t qmk_build_saext(const unsigned char* text, long long n, const int* SA, long long nSA, int k, void* out, hipStream_t st) {
+  if (nSA > 0) hipLaunchKernelGGL(build_saext_kernel, dim3(8192), dim3(256), 0, st, text, n, SA, nSA, k, (SaExt*)out);
+  return hipGetLastError();
+}
 hipError_t qmk_build_sanext(const unsigned char* text, long long n, const int* SA, long long nSA, int k, unsigned int* out, hipStream_t st) {
   if (nSA > 0) hipLaunchKernelGGL(build_sanext_kernel, dim3(4096), dim3(256), 0, st, text, n, SA, nSA, k, out);
   return hipGetLastError();

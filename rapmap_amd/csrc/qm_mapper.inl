@@ -117,6 +117,7 @@ struct DevIndex {
   const Bucket* slots;        // dense index: hmask + 1 buckets (null for a perfect-hash index)
   u64 hmask;
   const u32* sanext;          // -s: per SA entry, the QM_NEXT_BASES text characters behind its k-mer (sanext_entry), or null
+  const struct SaExt* saext;  // per SA entry, the QM_EXT_BASES text characters behind its k-mer (saext_entry), or null
   const PhIndex* ph;          // perfect-hash index (null for a dense index): the flag the kernels are chosen by
   PhIndex phv;                // ... and its contents, by value: as kernel arguments the fields are scalar loads and the
                               // pointers are known to be global (loaded from a struct in memory they would be generic
@@ -276,6 +277,34 @@ __shared__ u64 qm_tim[4][10];
 // dependent ones (suffix array, then text): QM_NEXT_BASES characters at 2 bits, the first in the highest bits of a
 // 28-bit field, and in bits 28-31 how many of them are A C G T before a '$' or the end of the text.
 #define QM_NEXT_BASES 14
+// The same idea for EVERY extension of a clean strand (round 3): saext[i] holds the QM_EXT_BASES text characters behind the
+// k-mer of suffix SA[i] at 2 bits -- three words, the first character in the highest bits of w[0] -- and how many of them
+// are A C G T before a '$' or the end of the text.  An MMP extension over an interval of <= 64 suffixes is then ONE trip (a
+// 32-byte load per suffix, indexed like the interval itself) instead of two dependent ones (suffix array, then text), and
+// its comparison is three XORs and a count-leading-zeros instead of byte compares over 16-byte text chunks.  96 characters
+// cover every extension of a read of up to 127 characters; a longer match continues on the text (the old path).
+// 32 bytes per suffix-array entry: 8.3 GB for config 2 -- HBM spent to shorten the chain of dependent round trips.
+#define QM_EXT_BASES 96
+struct SaExt { u64 w[3]; u32 nv; u32 pad; };
+QM_DEV SaExt saext_entry(const unsigned char* text, long long n, long long pos) {
+  SaExt e; e.w[0] = 0; e.w[1] = 0; e.w[2] = 0; e.pad = 0;
+  int nv = 0;
+  for (int t = 0; t < QM_EXT_BASES; ++t) {
+    if (pos + t >= n) break;
+    const unsigned char c = text[pos + t];
+    if (c != 'A' && c != 'C' && c != 'G' && c != 'T') break;
+    const u64 x = (c >> 1) & 3u;
+    const u64 code = x ^ (x >> 1);
+    const u64 bit = code << (62 - 2 * (t & 31));
+    if (t < 32) e.w[0] |= bit; else if (t < 64) e.w[1] |= bit; else e.w[2] |= bit;
+    nv = t + 1;
+  }
+  e.nv = (u32)nv;
+  return e;
+}
+// the query side of such an extension: the strand's characters behind the k-mer, packed the same way (clean strands only)
+struct ExtQuery { u64 q[3]; int nq; };   // nq: characters of the query behind the k-mer (0: no packed query, take the text path)
+
 QM_DEV u32 sanext_entry(const unsigned char* text, long long n, long long pos) {
   u32 e = 0; int nv = 0;
   for (int t = 0; t < QM_NEXT_BASES; ++t) {
@@ -485,6 +514,7 @@ struct Strand {
   Iv* tab;             // LDS: interval of mer at position p (valid where F)
   bool dollar;         // the strand's string contains '$' (extensions then take the literal binary searches)
   bool lazy;           // pure-ACGT read without a long run: tab holds no k-mer words, a probe shifts its word out of the image
+  bool clean;          // nothing but A C G T in the strand: the packed image alone describes it
   int P;
 };
 
@@ -602,7 +632,7 @@ QM_DEV void setup_strand(const DevIndex& ix, const unsigned char* str, int L, St
   constexpr int NC = (NS + 3) / 4;
   u64 dirty = 0;                                                           // lanes holding a character that is not A C G T
   int runs = 0;                                                            // lanes whose four characters are one repeated base
-  S.lazy = false;
+  S.lazy = false; S.clean = false;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     LV<u32> nn, iv, nn2, iv2; LV<bool> bad, rep;
@@ -641,6 +671,7 @@ QM_DEV void setup_strand(const DevIndex& ix, const unsigned char* str, int L, St
     if (NS + 2 > 4 * NC && l < NS + 2 - 4 * NC) { planes[2 * (NS + 2) + 4 * NC + l] = 0; planes[3 * (NS + 2) + 4 * NC + l] = ~0ULL; }
   }
   wave_fence();
+  S.clean = dirty == 0;
   if (!dirty && 4 * runs + 6 < k) {
     // nearly every read: nothing but A C G T and no homopolymer window (k equal characters cover at least (k - 6) / 4 whole
     // lanes of the loop above).  Every position with a whole k-mer is eligible and nothing is tabulated: a probe shifts
@@ -864,9 +895,43 @@ QM_DEV int cmp_from(const DevIndex& ix, long long s, const unsigned char* q, int
 // compares the 16 bytes at offset 16c of the current round, so a 2x100 bp read needs one round for up to 8
 // suffixes: one coalesced SA load, then one round of text loads, instead of a dependent load per 8 bytes.
 QM_DEV bool extend_search_wide(const DevIndex& ix, int lbIn, int ubIn, int startAt, const unsigned char* q, int m0,
-                               int& lbOut, int& ubOut, int& lenOut, u32 qn, int nq) {
+                               int& lbOut, int& ubOut, int& lenOut, u32 qn, int nq, const ExtQuery* xq) {
   const int width = ubIn - lbIn - 1;
   if (width < 1 || width > 64) return false;
+  if (xq && xq->nq >= 0 && ix.saext && !(nq > 0 && ix.sanext)) {
+    // a clean strand: the query's characters behind the k-mer against the packed characters behind every suffix's k-mer --
+    // one lane per suffix, one 32-byte load each, no trip to the suffix array or the text
+    const int rem = xq->nq;                               // characters of the query behind the first startAt
+    const int cap = rem < QM_EXT_BASES ? rem : QM_EXT_BASES;
+    LV<int> lc; LV<bool> on, full;
+    QM_LANES(l) {
+      int v = -1; bool fl = false;
+      if (l < width) {
+        U4 a, b;
+        load_32(&ix.saext[lbIn + 1 + l], a, b);
+        const u64 w0 = ((u64)a.y << 32) | a.x, w1 = ((u64)a.w << 32) | a.z, w2 = ((u64)b.y << 32) | b.x;
+        const int nv = (int)b.z;
+        const u64 x0 = w0 ^ xq->q[0], x1 = w1 ^ xq->q[1], x2 = w2 ^ xq->q[2];
+        int matched = x0 ? (clz64(x0) >> 1) : (x1 ? 32 + (clz64(x1) >> 1) : (x2 ? 64 + (clz64(x2) >> 1) : 96));
+        matched = matched < nv ? matched : nv;
+        matched = matched < cap ? matched : cap;
+        fl = matched == QM_EXT_BASES && rem > QM_EXT_BASES;   // the match may go on behind what the table holds
+        v = startAt + matched;
+      }
+      lc[l] = v; on[l] = l < width; full[l] = fl;
+    }
+    if (!ballot(full)) {
+      const int mxq = wave_max(lc);
+      LV<bool> bestq;
+      QM_LANES(l) { bestq[l] = on[l] && lc[l] == mxq; }
+      const u64 bq = ballot(bestq);
+      lbOut = lbIn + 1 + ctz64(bq);
+      ubOut = lbIn + 1 + (63 - clz64(bq)) + 1;
+      lenOut = mxq;
+      return true;
+    }
+    // (rare: reads longer than k + 96 that match that far -- the text path below)
+  }
   if (nq > 0 && ix.sanext) {
     // a capped extension of a clean strand: the nq (<= QM_NEXT_BASES) query characters behind the k-mer, packed like the
     // table's entries (qn), against the entry of every suffix of the interval -- one lane per suffix, one load
@@ -956,9 +1021,9 @@ QM_DEV bool extend_search_wide(const DevIndex& ix, int lbIn, int ubIn, int start
 
 // SASearcher::extendSearchNaive (SASearcher.hpp:88-309)
 QM_DEV void extend_search(const DevIndex& ix, int lbIn, int ubIn, int startAt, const unsigned char* q, int m0,
-                          int& lbOut, int& ubOut, int& lenOut, bool qDollar, u32 qn = 0, int nq = 0) {
+                          int& lbOut, int& ubOut, int& lenOut, bool qDollar, u32 qn = 0, int nq = 0, const ExtQuery* xq = nullptr) {
   int rel;
-  if (!qDollar && extend_search_wide(ix, lbIn, ubIn, startAt, q, m0, lbOut, ubOut, lenOut, qn, nq)) return;
+  if (!qDollar && extend_search_wide(ix, lbIn, ubIn, startAt, q, m0, lbOut, ubOut, lenOut, qn, nq, xq)) return;
   QM_CNT(8, 1);
   if (ubIn - lbIn == 2) {                         // :109-126
     lbIn += 1;
@@ -1035,6 +1100,19 @@ template <int NS> QM_DEV void set_bit(Bits<NS>& b, int p) {
   for (int s = 0; s < NS; ++s) b.w[s] |= (s == (p >> 6)) ? (1ULL << (p & 63)) : 0ULL;   // every word written: see Bits::test
 }
 
+// characters [pos, pos + 96) of a clean strand's packed image as three words (first character in the top bits of q[0]);
+// rem = characters of the strand from pos on.  Words that would lie behind the image read as zero.
+template <int NS>
+QM_DEV void ext_query(const u64* planes, int pos, int rem, ExtQuery& xq) {
+  xq.nq = rem < 0 ? 0 : rem;
+  const int j = pos >> 5, sh = 2 * (pos & 31);
+  u64 w[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) w[t] = (j + t) < 2 * NS + 2 ? uniform(planes[(j + t) < 2 * NS + 2 ? j + t : 0]) : 0ULL;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) xq.q[t] = (w[t] << sh) | ((w[t + 1] >> 1) >> (63 - sh));
+}
+
 // ------------------------------------------------------------------ stage 3
 // SACollector::getSAHits_ (SACollector.hpp:441-677), NIP disabled
 template <int NS, int F>
@@ -1079,8 +1157,12 @@ QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, c
     lb = lb - 1 > 0 ? lb - 1 : 0;                      // :553
     int mlen;
     QM_CNT(18, 1); QM_T(4);
+    // the strand's characters behind this k-mer, packed like the entries of ix.saext (clean strands only)
+    ExtQuery xq; xq.nq = -1;
+    // (-s: every MMP but a read's first is capped and answered by the narrower table above: no packed query needed there)
+    if (ix.saext && V.clean && (!(F & QM_F_SEL) || p == 0 || !ix.sanext)) ext_query<NS>(V.planes, p + k, L - (p + k), xq);
     if (!(F & QM_F_SEL)) {
-      extend_search(ix, lb, ub, k, str + p, L - p, lb, ub, mlen, V.dollar);
+      extend_search(ix, lb, ub, k, str + p, L - p, lb, ub, mlen, V.dollar, 0u, 0, &xq);
     } else {
       // chain scoring (SACollector.hpp:557-575): only the MMP that starts the read may run to its end, every other
       // one is cut at k + maxMMPExtension characters; a first MMP longer than that (and shorter than the read) is redone cut
@@ -1092,9 +1174,10 @@ QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, c
       const int nqc = cut - p - k;
       u32 qn = 0; int nq = 0;
       if (V.lazy && nqc >= 1 && nqc <= QM_NEXT_BASES) { qn = (u32)clean_kmer(V.planes, p + k, nqc); nq = nqc; }
-      extend_search(ix, lb, ub, k, str + p, (firstAttempt ? L : cut) - p, lb, ub, mlen, V.dollar, firstAttempt ? 0u : qn, firstAttempt ? 0 : nq);
+      ExtQuery xc = xq; if (xc.nq >= 0 && !firstAttempt) xc.nq = cut - p - k;      // a capped extension compares fewer characters
+      extend_search(ix, lb, ub, k, str + p, (firstAttempt ? L : cut) - p, lb, ub, mlen, V.dollar, firstAttempt ? 0u : qn, firstAttempt ? 0 : nq, &xc);
       if (firstAttempt && !(mlen >= L) && mlen >= k + B.max_mmp_ext)
-        extend_search(ix, lbP, ubP, k, str + p, cut - p, lb, ub, mlen, V.dollar, qn, nq);
+        { ExtQuery x2 = xq; if (x2.nq >= 0) x2.nq = cut - p - k; extend_search(ix, lbP, ubP, k, str + p, cut - p, lb, ub, mlen, V.dollar, qn, nq, &x2); }
     }
     QM_T(3);
     const bool more = !lastSearch && p + mlen < L;     // the walk continues at kp after this MMP

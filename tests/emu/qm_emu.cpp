@@ -31,6 +31,16 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
   memset(&ix.phv, 0, sizeof(ix.phv)); if (ph) ix.phv = *(const PhIndex*)ph;
   std::vector<u32> sanext;                 // -s: the table of qm_host.hip's first -s call (build_sanext_kernel)
   ix.sanext = nullptr;
+  static std::vector<SaExt> saext; static const int* saextFor = nullptr; static const unsigned char* saextText = nullptr;   // the replica's SaExt table (build_saext_kernel), kept between calls on one index
+  ix.saext = nullptr;
+  if (!getenv("QM_NO_SAEXT")) {
+    if (saextFor != SA || saextText != text || (long long)saext.size() != nSA) {
+      saext.resize((size_t)nSA);
+      for (long long i = 0; i < nSA; ++i) saext[(size_t)i] = saext_entry(text, n, (long long)SA[i] + k);
+      saextFor = SA; saextText = text;
+    }
+    ix.saext = saext.data();
+  }
   if (o->sel_aln) {
     sanext.resize((size_t)nSA);
     for (long long i = 0; i < nSA; ++i) sanext[(size_t)i] = sanext_entry(text, n, (long long)SA[i] + k);
