@@ -452,8 +452,19 @@ class SACollector {
     Chunk* ch = chunk_.get();
     if (ch) {
       qm_opts now; stageOpts(now); now.sel_aln = ch->opts.sel_aln; now.consensus_slack = ch->opts.consensus_slack; now.fuzzy = ch->opts.fuzzy;
+      // The chunk's reads are recognised in order: by the address and length of their characters AND by the characters
+      // themselves (a parser that refills its string buffers in place hands out the same addresses with new contents).  A
+      // read the caller skipped does not end the fast path: the next few entries are looked at as well.
       int64_t idx = -1;
-      if (ch->cursor < ch->nreads && ch->key[ch->cursor] == read.data() && ch->keyLen[ch->cursor] == read.size()) idx = ch->cursor++;
+      for (int64_t c = ch->cursor, lim = c + 64 < ch->nreads ? c + 64 : ch->nreads; c < lim; ++c) {
+        if (ch->key[c] != read.data() || ch->keyLen[c] != read.size()) continue;
+        const std::vector<char>& sq = (ch->paired && (c & 1)) ? s2_ : s1_;
+        const std::vector<int64_t>& so = (ch->paired && (c & 1)) ? o2_ : o1_;
+        const int64_t u = ch->paired ? (c >> 1) : c;
+        if (static_cast<size_t>(u + 1) >= so.size() || static_cast<size_t>(so[u + 1] - so[u]) != read.size()) continue;
+        if (read.size() && std::memcmp(sq.data() + so[u], read.data(), read.size()) != 0) continue;
+        idx = c; ch->cursor = c + 1; break;
+      }
       if (idx >= 0 && same_stage_opts(now, ch->opts) && (doChaining_ ? 1 : 0) == ch->opts.sel_aln) {
         for (int64_t j = ch->ivOff[idx]; j < ch->ivOff[idx + 1]; ++j) {
           const qm_sa_interval_hit& h = ch->iv[static_cast<size_t>(j)];

@@ -4,14 +4,19 @@
 // reference declares are used; the single addition is the `hitCollector.prefetch(rg)` line (skipped with --no-prefetch:
 // every call is then a batch of one on the device).
 //
-//   rapmap_caller INDEX PAIRS.txt OUT.txt [--fuzzy] [--chain] [--no-prefetch] [--noOrphans] [--maxNumHits N] [--edit]
+//   rapmap_caller INDEX PAIRS.txt OUT.txt [--fuzzy] [--chain] [--no-prefetch] [--noOrphans] [--maxNumHits N] [--edit] [--refill] [--evens-first]
 //
 // PAIRS.txt: "left right" per line.  OUT.txt: per pair "<n> tid:pos:matePos:fwd mateIsFwd:fragLen:mateStatus ..." and a
 // last line with the HitCounters.  --edit: drops the last forward interval of every 5th left read between the collector
 // and hitsToMappingsSimple (a caller that touches hcInfo): that read must be re-done from the edited intervals.
+// --refill: after the prefetch, every 7th pair's left read is overwritten IN PLACE with the left read of the pair behind it when
+// the two are equally long (a parser that refills its string buffers without a new prefetch: same address, same length, other
+// characters): the stale chunk entry must not be handed out.  --evens-first: the chunk's pairs are processed 0, 2, 4, ... and
+// then 1, 3, 5, ... (a caller that skips reads and comes back): answers still belong to the read that was asked about.
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -22,7 +27,7 @@ using ReadPair = std::pair<Read, Read>;
 
 template <typename RapMapIndexT>
 int run(RapMapIndexT& rmi, std::vector<ReadPair>& all, const char* outPath, bool fuzzy, bool chain, bool prefetch, bool noOrphans,
-        uint32_t maxNumHits, bool edit) {
+        uint32_t maxNumHits, bool edit, bool refill, bool evensFirst) {
   using OffsetT = typename RapMapIndexT::IndexType;
   using rapmap::utils::MateStatus;
   using rapmap::utils::QuasiAlignment;
@@ -45,7 +50,7 @@ int run(RapMapIndexT& rmi, std::vector<ReadPair>& all, const char* outPath, bool
   }
   bool useSmartIntersect = fuzzy || chain;
   SASearcher<RapMapIndexT> saSearcher(&rmi);
-  std::ofstream out(outPath);
+  std::ofstream outFile(outPath);
   bool tooManyHits = false;
   uint32_t readLen = 0;
   const size_t chunkSize = 5000;                // the parser's read groups
@@ -53,7 +58,17 @@ int run(RapMapIndexT& rmi, std::vector<ReadPair>& all, const char* outPath, bool
   for (size_t c0 = 0; c0 < all.size(); c0 += chunkSize) {
     std::vector<ReadPair> rg(all.begin() + c0, all.begin() + std::min(all.size(), c0 + chunkSize));
     if (prefetch) hitCollector.prefetch(rg, mc, fuzzy, maxNumHits);           // <- the one added line
-    for (auto& rpair : rg) {
+    if (refill)
+      for (size_t i = 0; i + 1 < rg.size(); i += 7)
+        if (rg[i].first.seq.size() == rg[i + 1].first.seq.size())
+          std::memcpy(&rg[i].first.seq[0], rg[i + 1].first.seq.data(), rg[i].first.seq.size());
+    std::vector<size_t> order;
+    for (size_t i = 0; i < rg.size(); i += evensFirst ? 2 : 1) order.push_back(i);
+    if (evensFirst) for (size_t i = 1; i < rg.size(); i += 2) order.push_back(i);
+    std::vector<std::string> lines(rg.size());
+    for (size_t oi : order) {
+      auto& rpair = rg[oi];
+      std::ostringstream out;
       // ---- src/RapMapSAMapper.cpp:461-551
       tooManyHits = false;
       readLen = rpair.first.seq.length();
@@ -91,10 +106,12 @@ int run(RapMapIndexT& rmi, std::vector<ReadPair>& all, const char* outPath, bool
             << (paired ? q.fragLen : 0u) << ':' << (int)q.mateStatus;
       }
       out << '\n';
+      lines[oi] = out.str();
       ++pairNo;
     }
+    for (auto& l : lines) outFile << l;
   }
-  out << "counters " << hctr.peHits.load() << ' ' << hctr.seHits.load() << ' ' << hctr.totHits.load() << ' ' << hctr.numReads.load() << ' '
+  outFile << "counters " << hctr.peHits.load() << ' ' << hctr.seHits.load() << ' ' << hctr.totHits.load() << ' ' << hctr.numReads.load() << ' '
       << hctr.tooManyHits.load() << '\n';
   return 0;
 }
@@ -106,18 +123,20 @@ int main(int argc, char** argv) {
     rmi.load(argv[1]);
     std::printf("k %u txps %zu ph %d\n", rmi.k(), rmi.txpNames.size(), (int)rmi.perfectHash());
     if (argc < 4) return 0;
-    bool fuzzy = false, chain = false, prefetch = true, noOrphans = false, edit = false; uint32_t maxNumHits = 200;
+    bool fuzzy = false, chain = false, prefetch = true, noOrphans = false, edit = false, refill = false, evensFirst = false; uint32_t maxNumHits = 200;
     for (int i = 4; i < argc; ++i) {
       if (!std::strcmp(argv[i], "--fuzzy")) fuzzy = true;
       else if (!std::strcmp(argv[i], "--chain")) chain = true;
       else if (!std::strcmp(argv[i], "--no-prefetch")) prefetch = false;
       else if (!std::strcmp(argv[i], "--noOrphans")) noOrphans = true;
       else if (!std::strcmp(argv[i], "--edit")) edit = true;
+      else if (!std::strcmp(argv[i], "--refill")) refill = true;
+      else if (!std::strcmp(argv[i], "--evens-first")) evensFirst = true;
       else if (!std::strcmp(argv[i], "--maxNumHits") && i + 1 < argc) maxNumHits = (uint32_t)std::atoi(argv[++i]);
     }
     std::vector<ReadPair> all;
     std::ifstream f(argv[2]); std::string a, b;
     while (f >> a >> b) { ReadPair p; p.first.seq = a == "-" ? "" : a; p.second.seq = b == "-" ? "" : b; all.push_back(p); }
-    return run(rmi, all, argv[3], fuzzy, chain, prefetch, noOrphans, maxNumHits, edit);
+    return run(rmi, all, argv[3], fuzzy, chain, prefetch, noOrphans, maxNumHits, edit, refill, evensFirst);
   } catch (const qmap::Error& e) { std::printf("qmap error %d: %s\n", e.code(), e.what()); return 3; }
 }

@@ -99,3 +99,29 @@ def test_edited_intervals_and_chaining_agree_between_chunk_and_single_calls(call
     plain = _run(caller, synth_small["idx"], tmp_path / "p.txt", tmp_path / "c.txt", *flags)
     edited = _run(caller, synth_small["idx"], tmp_path / "p.txt", tmp_path / "d.txt", *flags, "--edit")
     assert plain != edited, "dropping intervals changed nothing: the edit was not looked at"
+
+
+@pytest.mark.gpu
+def test_refilled_buffers_and_out_of_order_calls_never_get_a_stale_chunk_entry(caller, sample_data, oracle_mod, tmp_path):
+    """the chunk recognises its reads by address, length AND content, and looks a little ahead when the caller skipped reads:
+    a string buffer that was refilled in place after the prefetch is mapped on its own (not answered with what used to be
+    there), and a caller that walks the chunk 0, 2, 4, ... and then 1, 3, 5, ... gets every read's own answer"""
+    sd = sample_data
+    keep = [i for i in range(len(sd["reads1"])) if b" " not in sd["reads1"][i] and b" " not in sd["reads2"][i]][:3000]
+    r1 = [sd["reads1"][i] for i in keep]; r2 = [sd["reads2"][i] for i in keep]
+    _write_pairs(tmp_path / "pairs.txt", r1, r2)
+    ix, orc = load_oracle(sd["idx"])
+    # what the caller's --refill does to the left reads (chunks of 5000 pairs: one chunk here)
+    m1 = list(r1)
+    changed = 0
+    for i in range(0, len(m1) - 1, 7):
+        if len(m1[i]) == len(r1[i + 1]):
+            changed += m1[i] != r1[i + 1]
+            m1[i] = r1[i + 1]
+    assert changed > 100
+    res = orc.map_pairs(*pack(m1), *pack(r2), nthreads=4)
+    got = _run(caller, sd["idx"], tmp_path / "pairs.txt", tmp_path / "out.txt", "--refill")
+    assert got == _want(res, len(r1))
+    res0 = orc.map_pairs(*pack(r1), *pack(r2), nthreads=4)
+    got = _run(caller, sd["idx"], tmp_path / "pairs.txt", tmp_path / "out2.txt", "--evens-first")
+    assert got == _want(res0, len(r1))
