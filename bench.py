@@ -477,6 +477,10 @@ def side_legs(out, args, ra, qi, mp, opts, s1, s2, off, n, L, dev_id, cores):
     # written tmpfs pages runs at ~16 GB/s whatever the thread count or access method (profiles/r03_tmpfs_read_passes.txt),
     # a property of the host, not of the reader; page-cache pages of a disk filesystem do not show it.
     from rapmap_amd import synth as _syn
+    # the slots' pinned memory comes out of the library's process-wide pool, reserved here -- in the background, while the
+    # FASTQ files are being written -- as the CLI reserves it while the index uploads (pinning runs at 5.5 GB/s on this host
+    # whatever the thread count: inside the timed region the first batches would wait for their slots)
+    ra.reserve_stream_memory(768 << 20)
     ne = n
     base = args.e2e_dir if os.path.isdir(args.e2e_dir) else args.cache
     d_e = os.path.join(base, "qmap_bench_e2e_%d" % os.getpid()); os.makedirs(d_e, exist_ok=True)
@@ -501,6 +505,7 @@ def side_legs(out, args, ra, qi, mp, opts, s1, s2, off, n, L, dev_id, cores):
             "input": "two plain FASTQ files, %d MB together, in %s (%s), read once right after they were written" % (
                 (os.path.getsize(f1) + os.path.getsize(f2)) >> 20, d_e, fstype_of(d_e)),
             "ingest_threads": thr, "batch_units": batch, "names_kept": True,
+            "pinned_pool": "768 MB reserved with qm_stream_reserve before the timed region (pinned in the background, as the CLI does under the index upload)",
             "seconds": {"total_open_to_last_batch_handed_out": round(dt_e, 4), "open": round(ss["open_s"], 4),
                         "first_batch_packed": round(ss["first_batch_s"], 4), "ingest_open_to_last_batch_packed": round(ss["read_s"], 4),
                         "last_batch_mapped": round(ss["last_mapped_s"], 4),

@@ -283,6 +283,12 @@ int qm_stream_open(const qm_index* ix, int device_id, uint32_t ctx_flags, const 
 int qm_stream_open_ex(const qm_index* ix, const int32_t* devices, int32_t n_devices, uint32_t ctx_flags, const qm_opts* opts,
                       const char* path1, const char* path2, int64_t batch_units, int32_t reader_threads, uint32_t stream_flags,
                       qm_stream** out);
+/* Pinning host memory is slow (about 5.5 GB/s on this platform, whatever the number of threads): a stream's slots -- a few hundred
+ * MB -- cost as much as mapping millions of pairs.  qm_stream_reserve(bytes) pins a process-wide pool in the background and
+ * returns at once; streams carve their slots out of it and hand them back when they close, so only the first reservation of a
+ * process pays.  Call it as early as possible (the CLI does, before it uploads the index); 512 MB serve one single-device
+ * stream of 2^18-pair batches of 2 x 100 bp reads.  Optional: without it a stream pins its own slots while it starts. */
+int qm_stream_reserve(int64_t bytes);
 int qm_stream_next(qm_stream* s, qm_stream_batch* batch);
 void qm_stream_close(qm_stream* s);
 /* seconds spent so far: [0] the ingest engine, open to its last batch packed (wall), [1] upload + kernels (summed over the

@@ -23,6 +23,8 @@ synth.write_fastq(f1, s1[: n * L].cpu().numpy(), n, L, 1); synth.write_fastq(f2,
 del s1, s2, text
 torch.cuda.empty_cache()
 print("files: 2 x %.0f MB, host threads %d" % (os.path.getsize(f1) / 1e6, os.cpu_count()), flush=True)
+if os.environ.get("E2E_RESERVE", "1") != "0":
+    ra.reserve_stream_memory(768 << 20)
 keep = ra.QuasiMapper(qi, 0)      # keeps the index replica resident between the runs (as the CLI does)
 
 def run(threads, batch, names, label=""):

@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "qm_fetch_intervals", "qm_last_kernel_ms", "qm_ctx_stat", "qm_build_index", "qm_build_index_ex",
     "qm_collect_reads", "qm_fetch_found", "qm_hits_to_mappings", "qm_fetch_read_lists", "qm_merge_lists", "qm_fetch_too_many",
     "qm_map_pairs_stages", "qm_ctx_create_ex", "qm_fetch_hits_pinned", "qm_xxh64",
-    "qm_stream_open", "qm_stream_open_ex", "qm_stream_next", "qm_stream_close", "qm_stream_last_error", "qm_stream_stats", "qm_stream_stats_ex",
+    "qm_stream_open", "qm_stream_open_ex", "qm_stream_reserve", "qm_stream_next", "qm_stream_close", "qm_stream_last_error", "qm_stream_stats", "qm_stream_stats_ex",
     "qm_reader_open", "qm_reader_next", "qm_reader_close", "qm_io_last_error", "qm_sam_header", "qm_sam_records",
     "qm_sam_write", "qm_sam_writer_open", "qm_sam_writer_open_ex", "qm_sam_writer_header", "qm_sam_writer_put", "qm_sam_writer_close", "qm_buf_free",
 ]
@@ -134,6 +134,7 @@ def lib():
                                  C.POINTER(C.c_void_p)]
     L.qm_stream_open_ex.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_uint32, C.POINTER(QmOpts), C.c_char_p, C.c_char_p,
                                     C.c_int64, C.c_int32, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.qm_stream_reserve.argtypes = [C.c_int64]
     L.qm_stream_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.qm_stream_stats_ex.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int32]
     L.qm_stream_next.argtypes = [C.c_void_p, C.POINTER(QmStreamBatch)]
@@ -474,6 +475,12 @@ class FastxReader:
             self.close()
         except Exception:
             pass
+
+
+def reserve_stream_memory(nbytes=512 << 20):
+    """qm_stream_reserve: pin the process-wide pool the streams' slots come out of, in the background (returns at once).  Call it
+    early -- before the index is uploaded -- so that pinning (5.5 GB/s) runs under other work."""
+    _check(lib().qm_stream_reserve(int(nbytes)))
 
 
 class MappedStream:

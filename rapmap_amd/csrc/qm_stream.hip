@@ -31,9 +31,59 @@
 
 namespace {
 
-// portable: the slots are read by the DMA engines of every device of the stream
-void* pin_alloc(size_t bytes) { void* p = nullptr; return hipHostMalloc(&p, bytes ? bytes : 64, hipHostMallocPortable) == hipSuccess ? p : nullptr; }
-void pin_free(void* p) { if (p) hipHostFree(p); }
+// Pinned host memory for the slots.  Pinning is slow on this platform -- 5.5 GB/s whatever the number of threads (the driver
+// serialises it; profiles/microbench/pin_cost.py): the 430 MB of a stream's six slots take 77 ms, half the time the whole
+// stream needs for 10 M pairs, and the first batches wait for their slots.  So the library keeps a process-wide POOL of
+// pinned arenas: qm_stream_reserve() pins it in a background thread (the CLI calls it before it creates its contexts, i.e.
+// under the upload of the index), streams carve their buffers out of it (first fit over 1 MB granules, neighbours merged
+// on release) and hand them back when they close -- the next stream of the process (the next file of a multi-file run)
+// pins nothing.  Requests the pool cannot serve fall through to hipHostMalloc.  Portable: the slots are read by the DMA
+// engines of every device of the stream.
+struct PinPool {
+  struct Arena { char* base; size_t bytes; std::vector<unsigned char> used; };   // one flag per 1 MB granule
+  static constexpr size_t GR = (size_t)1 << 20;
+  std::mutex mu; std::condition_variable cv;
+  std::vector<Arena> arenas;
+  size_t pending = 0;                               // bytes a background reservation still has to pin
+  void* take(size_t bytes) {
+    const size_t g = (bytes + GR - 1) / GR;
+    std::unique_lock<std::mutex> lk(mu);
+    while (true) {
+      for (Arena& A : arenas) {
+        const size_t n = A.used.size();
+        for (size_t i = 0; i + g <= n;) {
+          size_t j = i; while (j < i + g && !A.used[j]) ++j;
+          if (j == i + g) { for (size_t t = i; t < i + g; ++t) A.used[t] = (unsigned char)(t == i ? 2 : 1); return A.base + i * GR; }   // 2: first granule of a block
+          i = j + 1;
+        }
+      }
+      if (pending == 0) return nullptr;
+      cv.wait(lk);                                  // a reservation is under way: what it pins next may serve this request
+    }
+  }
+  bool give(void* p) {                              // true: p was a pool block
+    std::lock_guard<std::mutex> lk(mu);
+    for (Arena& A : arenas) {
+      if ((char*)p < A.base || (char*)p >= A.base + A.bytes) continue;
+      size_t i = (size_t)((char*)p - A.base) / GR;
+      if (A.used[i] != 2) return true;              // (not the start of a block: ignore)
+      A.used[i] = 0;
+      for (size_t t = i + 1; t < A.used.size() && A.used[t] == 1; ++t) A.used[t] = 0;
+      cv.notify_all();
+      return true;
+    }
+    return false;
+  }
+  size_t total() { std::lock_guard<std::mutex> lk(mu); size_t t = pending; for (Arena& A : arenas) t += A.bytes; return t; }
+};
+PinPool& pin_pool() { static PinPool* P = new PinPool(); return *P; }      // (never destroyed: its memory lives as long as the process)
+
+void* pin_alloc(size_t bytes) {
+  if (void* q = pin_pool().take(bytes ? bytes : 64)) return q;
+  void* p = nullptr;
+  return hipHostMalloc(&p, bytes ? bytes : 64, hipHostMallocPortable) == hipSuccess ? p : nullptr;
+}
+void pin_free(void* p) { if (p && !pin_pool().give(p)) hipHostFree(p); }
 
 struct OutSlot {                 // the result side of ingest slot i
   const qm_batch_bufs* in = nullptr;
@@ -154,6 +204,33 @@ int qm_stream_open_ex(const qm_index* ix, const int32_t* devices, int32_t n_devi
   for (int i = 0; i < nctx; ++i) s->mapThreads.emplace_back(map_loop, s, i);
   s->tOpen = now_s() - s->t0;
   *out = s;
+  return QM_OK;
+}
+
+/* Pin `bytes` of host memory for the slots of the streams this process will open, in the background (returns at once; a stream
+ * that opens meanwhile takes what is already there and waits for the rest).  The pool is never shrunk. */
+int qm_stream_reserve(int64_t bytes) {
+  if (bytes <= 0) return QM_OK;
+  PinPool& P = pin_pool();
+  const size_t ARENA = (size_t)64 << 20;
+  size_t want = ((size_t)bytes + ARENA - 1) / ARENA * ARENA;
+  {
+    std::lock_guard<std::mutex> lk(P.mu);
+    size_t have = P.pending; for (PinPool::Arena& A : P.arenas) have += A.bytes;
+    if (have >= want) return QM_OK;
+    want -= have; P.pending += want;
+  }
+  std::thread([want, ARENA]() {
+    PinPool& P = pin_pool();
+    for (size_t done = 0; done < want; done += ARENA) {
+      void* p = nullptr;
+      const bool ok = hipHostMalloc(&p, ARENA, hipHostMallocPortable) == hipSuccess;
+      std::lock_guard<std::mutex> lk(P.mu);
+      if (ok) { PinPool::Arena A; A.base = (char*)p; A.bytes = ARENA; A.used.assign(ARENA / PinPool::GR, 0); P.arenas.push_back(std::move(A)); }
+      P.pending -= ARENA;
+      P.cv.notify_all();
+    }
+  }).detach();
   return QM_OK;
 }
 
