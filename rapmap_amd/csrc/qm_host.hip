@@ -455,11 +455,11 @@ int qm_ctx_create_ex(const qm_index* ix, int device_id, uint32_t flags, qm_ctx**
   CK(hipMalloc((void**)&d_offsets, (size_t)ix->nTxp * 4));
   CK(hipMemcpyAsync(d_offsets, ix->offsets, (size_t)ix->nTxp * 4, hipMemcpyHostToDevice, c->stream));
   CK(qmk_build_sainfo(c->d_SA, ix->nSA, d_offsets, ix->nTxp, c->d_sainfo, c->stream));
-  if (!getenv("QM_NO_SAEXT") && ix->nSA > 0) {
+  if (!getenv("QM_NO_SAEXT") && ix->nSA > 0 && ix->nTxp < (1LL << QM_EXT_TID_BITS)) {
     // the packed characters behind every suffix's k-mer: an MMP extension becomes one trip instead of two (saext_entry);
     // 32 bytes per suffix-array entry.  QM_NO_SAEXT (profiling): without the table, extensions read suffix array and text.
     if (hipMalloc(&c->d_saext, (size_t)ix->nSA * sizeof(SaExt)) != hipSuccess) { c->d_saext = nullptr; (void)hipGetLastError(); }   // no room: the text path
-    else { CK(qmk_build_saext(c->d_text, ix->n, c->d_SA, ix->nSA, ix->k, c->d_saext, c->stream)); }
+    else { CK(qmk_build_saext(c->d_text, ix->n, c->d_SA, ix->nSA, ix->k, c->d_sainfo, c->d_saext, c->stream)); }
   }
   if (!ix->perfect) {
     c->cap = bucket_count(ix->nKeys);                  // 32-byte buckets of two slots, at least two buckets per key

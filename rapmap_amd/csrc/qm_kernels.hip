@@ -192,10 +192,10 @@ __global__ void build_sainfo_kernel(const int* SA, long long nSA, const int* off
 }
 
 // the 96 text characters behind the k-mer of every suffix, packed (saext_entry): one-trip MMP extensions
-__global__ void build_saext_kernel(const unsigned char* text, long long n, const int* SA, long long nSA, int k, SaExt* out) {
+__global__ void build_saext_kernel(const unsigned char* text, long long n, const int* SA, long long nSA, int k, const SaInfo* sainfo, SaExt* out) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long stride = (long long)gridDim.x * blockDim.x;
-  for (; i < nSA; i += stride) out[i] = saext_entry(text, n, (long long)SA[i] + k);
+  for (; i < nSA; i += stride) { const SaInfo si = sainfo[i]; out[i] = saext_entry(text, n, (long long)SA[i] + k, si.tid, si.pos); }
 }
 
 // -s: the text characters behind the k-mer of every suffix (sanext_entry)
@@ -288,8 +288,8 @@ hipError_t qmk_build_sainfo(const int* SA, long long nSA, const int* offsets, lo
   return hipGetLastError();
 }
 
-hipError_t qmk_build_saext(const unsigned char* text, long long n, const int* SA, long long nSA, int k, void* out, hipStream_t st) {
-  if (nSA > 0) hipLaunchKernelGGL(build_saext_kernel, dim3(8192), dim3(256), 0, st, text, n, SA, nSA, k, (SaExt*)out);
+hipError_t qmk_build_saext(const unsigned char* text, long long n, const int* SA, long long nSA, int k, const void* sainfo, void* out, hipStream_t st) {
+  if (nSA > 0) hipLaunchKernelGGL(build_saext_kernel, dim3(8192), dim3(256), 0, st, text, n, SA, nSA, k, (const SaInfo*)sainfo, (SaExt*)out);
   return hipGetLastError();
 }
 hipError_t qmk_build_sanext(const unsigned char* text, long long n, const int* SA, long long nSA, int k, unsigned int* out, hipStream_t st) {

@@ -285,9 +285,14 @@ __shared__ u64 qm_tim[4][10];
 // cover every extension of a read of up to 127 characters; a longer match continues on the text (the old path).
 // 32 bytes per suffix-array entry: 8.3 GB for config 2 -- HBM spent to shorten the chain of dependent round trips.
 #define QM_EXT_BASES 96
-struct SaExt { u64 w[3]; u32 nv; u32 pad; };
-QM_DEV SaExt saext_entry(const unsigned char* text, long long n, long long pos) {
-  SaExt e; e.w[0] = 0; e.w[1] = 0; e.w[2] = 0; e.pad = 0;
+// The entry also carries what hits->mappings will ask about the suffix -- its transcript and the offset in it (the sainfo
+// record; the count of valid characters rides in the top 7 bits of the transcript word, so the table serves indices of up
+// to 2^25 transcripts) -- so the extension's one trip also brings the (tid, pos) of every suffix of the interval it
+// settles on: for a read with one interval (three in four) there is no trip to sainfo at all.
+#define QM_EXT_TID_BITS 25
+struct SaExt { u64 w[3]; u32 tidnv; int pos; };
+QM_DEV SaExt saext_entry(const unsigned char* text, long long n, long long pos, u32 tid, int tpos) {
+  SaExt e; e.w[0] = 0; e.w[1] = 0; e.w[2] = 0; e.pos = tpos;
   int nv = 0;
   for (int t = 0; t < QM_EXT_BASES; ++t) {
     if (pos + t >= n) break;
@@ -299,9 +304,11 @@ QM_DEV SaExt saext_entry(const unsigned char* text, long long n, long long pos) 
     if (t < 32) e.w[0] |= bit; else if (t < 64) e.w[1] |= bit; else e.w[2] |= bit;
     nv = t + 1;
   }
-  e.nv = (u32)nv;
+  e.tidnv = (tid & ((1u << QM_EXT_TID_BITS) - 1)) | ((u32)nv << QM_EXT_TID_BITS);
   return e;
 }
+// where extend_search may leave the (tid, pos) of the suffixes of the interval it returns (LDS; IntervalList::pf)
+struct ExtStage { u32* pf; int pfcap; bool done; };
 // the query side of such an extension: the strand's characters behind the k-mer, packed the same way (clean strands only)
 struct ExtQuery { u64 q[3]; int nq; };   // nq: characters of the query behind the k-mer (0: no packed query, take the text path)
 
@@ -895,7 +902,7 @@ QM_DEV int cmp_from(const DevIndex& ix, long long s, const unsigned char* q, int
 // compares the 16 bytes at offset 16c of the current round, so a 2x100 bp read needs one round for up to 8
 // suffixes: one coalesced SA load, then one round of text loads, instead of a dependent load per 8 bytes.
 QM_DEV bool extend_search_wide(const DevIndex& ix, int lbIn, int ubIn, int startAt, const unsigned char* q, int m0,
-                               int& lbOut, int& ubOut, int& lenOut, u32 qn, int nq, const ExtQuery* xq) {
+                               int& lbOut, int& ubOut, int& lenOut, u32 qn, int nq, const ExtQuery* xq, ExtStage* xs) {
   const int width = ubIn - lbIn - 1;
   if (width < 1 || width > 64) return false;
   if (xq && xq->nq >= 0 && ix.saext && !(nq > 0 && ix.sanext)) {
@@ -903,14 +910,16 @@ QM_DEV bool extend_search_wide(const DevIndex& ix, int lbIn, int ubIn, int start
     // one lane per suffix, one 32-byte load each, no trip to the suffix array or the text
     const int rem = xq->nq;                               // characters of the query behind the first startAt
     const int cap = rem < QM_EXT_BASES ? rem : QM_EXT_BASES;
-    LV<int> lc; LV<bool> on, full;
+    LV<int> lc, tpv; LV<u32> tdv; LV<bool> on, full;
     QM_LANES(l) {
       int v = -1; bool fl = false;
+      tdv[l] = 0; tpv[l] = 0;
       if (l < width) {
         U4 a, b;
         load_32(&ix.saext[lbIn + 1 + l], a, b);
         const u64 w0 = ((u64)a.y << 32) | a.x, w1 = ((u64)a.w << 32) | a.z, w2 = ((u64)b.y << 32) | b.x;
-        const int nv = (int)b.z;
+        const int nv = (int)(b.z >> QM_EXT_TID_BITS);
+        tdv[l] = b.z & ((1u << QM_EXT_TID_BITS) - 1); tpv[l] = (int)b.w;
         const u64 x0 = w0 ^ xq->q[0], x1 = w1 ^ xq->q[1], x2 = w2 ^ xq->q[2];
         int matched = x0 ? (clz64(x0) >> 1) : (x1 ? 32 + (clz64(x1) >> 1) : (x2 ? 64 + (clz64(x2) >> 1) : 96));
         matched = matched < nv ? matched : nv;
@@ -925,9 +934,15 @@ QM_DEV bool extend_search_wide(const DevIndex& ix, int lbIn, int ubIn, int start
       LV<bool> bestq;
       QM_LANES(l) { bestq[l] = on[l] && lc[l] == mxq; }
       const u64 bq = ballot(bestq);
-      lbOut = lbIn + 1 + ctz64(bq);
-      ubOut = lbIn + 1 + (63 - clz64(bq)) + 1;
+      const int first = ctz64(bq), cnt = (63 - clz64(bq)) + 1 - first;
+      lbOut = lbIn + 1 + first;
+      ubOut = lbOut + cnt;
       lenOut = mxq;
+      if (xs && xs->pf && cnt <= xs->pfcap) {               // the (tid, pos) of the block's suffixes, where hits->mappings looks for them
+        QM_LANES(l) { if (l >= first && l < first + cnt) { xs->pf[l - first] = tdv[l]; xs->pf[xs->pfcap + l - first] = (u32)tpv[l]; } }
+        xs->done = true;
+        wave_fence();
+      }
       return true;
     }
     // (rare: reads longer than k + 96 that match that far -- the text path below)
@@ -1021,9 +1036,10 @@ QM_DEV bool extend_search_wide(const DevIndex& ix, int lbIn, int ubIn, int start
 
 // SASearcher::extendSearchNaive (SASearcher.hpp:88-309)
 QM_DEV void extend_search(const DevIndex& ix, int lbIn, int ubIn, int startAt, const unsigned char* q, int m0,
-                          int& lbOut, int& ubOut, int& lenOut, bool qDollar, u32 qn = 0, int nq = 0, const ExtQuery* xq = nullptr) {
+                          int& lbOut, int& ubOut, int& lenOut, bool qDollar, u32 qn = 0, int nq = 0, const ExtQuery* xq = nullptr,
+                          ExtStage* xs = nullptr) {
   int rel;
-  if (!qDollar && extend_search_wide(ix, lbIn, ubIn, startAt, q, m0, lbOut, ubOut, lenOut, qn, nq, xq)) return;
+  if (!qDollar && extend_search_wide(ix, lbIn, ubIn, startAt, q, m0, lbOut, ubOut, lenOut, qn, nq, xq, xs)) return;
   QM_CNT(8, 1);
   if (ubIn - lbIn == 2) {                         // :109-126
     lbIn += 1;
@@ -1161,8 +1177,10 @@ QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, c
     ExtQuery xq; xq.nq = -1;
     // (-s: every MMP but a read's first is capped and answered by the narrower table above: no packed query needed there)
     if (ix.saext && V.clean && (!(F & QM_F_SEL) || p == 0 || !ix.sanext)) ext_query<NS>(V.planes, p + k, L - (p + k), xq);
+    ExtStage xs; xs.pf = nullptr; xs.pfcap = 0; xs.done = false;
     if (!(F & QM_F_SEL)) {
-      extend_search(ix, lb, ub, k, str + p, L - p, lb, ub, mlen, V.dollar, 0u, 0, &xq);
+      if (out.n == 0) { xs.pf = out.pf; xs.pfcap = out.pfcap; }     // the first interval of the strand: its sainfo records are staged for hits->mappings
+      extend_search(ix, lb, ub, k, str + p, L - p, lb, ub, mlen, V.dollar, 0u, 0, &xq, &xs);
     } else {
       // chain scoring (SACollector.hpp:557-575): only the MMP that starts the read may run to its end, every other
       // one is cut at k + maxMMPExtension characters; a first MMP longer than that (and shorter than the read) is redone cut
@@ -1183,7 +1201,7 @@ QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, c
     const bool more = !lastSearch && p + mlen < L;     // the walk continues at kp after this MMP
     const int kp = p + mlen - (k - 1);
     if (ub > lb && ub - lb < B.max_interval) {          // :577-618
-      if (!(F & QM_F_SEL) && out.n == 0 && ub - lb <= out.pfcap) {
+      if (!(F & QM_F_SEL) && out.n == 0 && ub - lb <= out.pfcap && !xs.done) {
         // three reads in four end with exactly one interval per strand, whose (tid, pos) entries hits->mappings needs next:
         // ask for them now, straight into LDS, so that the trip to sainfo runs under the rest of the walk
         QM_LANES(l) {

@@ -36,7 +36,7 @@ int qe_map(int k, const unsigned char* text, long long n, const int* SA, long lo
   if (!getenv("QM_NO_SAEXT")) {
     if (saextFor != SA || saextText != text || (long long)saext.size() != nSA) {
       saext.resize((size_t)nSA);
-      for (long long i = 0; i < nSA; ++i) saext[(size_t)i] = saext_entry(text, n, (long long)SA[i] + k);
+      for (long long i = 0; i < nSA; ++i) { const SaInfo si = ((const SaInfo*)sainfo)[i]; saext[(size_t)i] = saext_entry(text, n, (long long)SA[i] + k, si.tid, si.pos); }
       saextFor = SA; saextText = text;
     }
     ix.saext = saext.data();
