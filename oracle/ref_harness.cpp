@@ -8,6 +8,7 @@
 //   rank9b + BIT_ARRAY                           src/rank9b.cpp, src/bit_array.c                                    (row a8)
 //   spp::sparse_hash_map unserialize + find      include/sparsepp/spp.h, include/SparseHashSerializer.hpp           (row a2: hash.bin)
 //   XXH64                                        src/xxhash.c                                                       (row a2: KmerKeyHasher)
+//   fastx_parser::FastxParser<ReadPair|ReadSeq>  src/FastxParser.cpp, include/FastxParser.hpp, include/kseq.h       (row f3: read ingest)
 // The oracle's restatements of exactly these functions are checked against them in tests/test_oracle_ref.py.
 #include <cstdint>
 #include <cstring>
@@ -23,6 +24,7 @@
 #include "sparsepp/spp.h"
 #include "SparseHashSerializer.hpp"
 #include "xxhash.h"
+#include "FastxParser.hpp"
 extern "C" {
 #include "bit_array.h"
 }
@@ -125,5 +127,34 @@ void ref_spp_find(void* h, const uint64_t* keys, int64_t n, uint8_t* found, int3
 }
 void ref_spp_free(void* h) { delete (RefDenseHash*)h; }
 uint64_t ref_xxh64(const void* p, uint64_t len, uint64_t seed) { return XXH64(p, (size_t)len, seed); }
+
+
+// The reference's read parser as processReadsPairSA / processReadsSingleSA drive it (src/RapMapSAMapper.cpp:853,869-871 and
+// :461-463: getReadGroup, refill, iterate), one parsing thread, one consumer: every record as "name<TAB>seq" ("<TAB>name2<TAB>seq2"
+// for pairs) and a newline, in file order, into one malloc'd buffer.  (Names are kseq's: the header up to the first blank.)
+int64_t ref_fastx_dump(const char* path1, const char* path2, char** out) {
+  std::string buf;
+  if (path2) {
+    std::vector<std::string> f1{path1}, f2{path2};
+    fastx_parser::FastxParser<fastx_parser::ReadPair> parser(f1, f2, 1, 1);
+    parser.start();
+    auto rg = parser.getReadGroup();
+    while (parser.refill(rg))
+      for (auto& rp : rg) { buf += rp.first.name; buf += '\t'; buf += rp.first.seq; buf += '\t'; buf += rp.second.name; buf += '\t'; buf += rp.second.seq; buf += '\n'; }
+    parser.stop();
+  } else {
+    std::vector<std::string> f1{path1};
+    fastx_parser::FastxParser<fastx_parser::ReadSeq> parser(f1, 1, 1);
+    parser.start();
+    auto rg = parser.getReadGroup();
+    while (parser.refill(rg))
+      for (auto& r : rg) { buf += r.name; buf += '\t'; buf += r.seq; buf += '\n'; }
+    parser.stop();
+  }
+  *out = (char*)malloc(buf.size() + 1);
+  memcpy(*out, buf.data(), buf.size()); (*out)[buf.size()] = 0;
+  return (int64_t)buf.size();
+}
+void ref_free(void* p) { free(p); }
 
 }  // extern "C"

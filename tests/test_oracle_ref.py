@@ -297,3 +297,67 @@ def test_device_lookup_answers_like_the_references_container(ref, ref_index, lib
         mp.close(); qi.close()
     finally:
         ref.ref_spp_free(h)
+
+
+def _ref_fastx(ref, p1, p2=None):
+    ref.ref_fastx_dump.restype = C.c_int64; ref.ref_fastx_dump.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
+    ref.ref_free.argtypes = [C.c_void_p]
+    out = C.c_void_p()
+    n = ref.ref_fastx_dump(p1.encode(), p2.encode() if p2 else None, C.byref(out))
+    try:
+        return [l.split(b"\t") for l in C.string_at(out, n).split(b"\n")[:-1]]
+    finally:
+        ref.ref_free(out)
+
+
+def test_ingest_engine_reads_what_the_references_parser_reads(ref, lib_built, tmp_path):
+    """the ingest engine (rapmap_amd/csrc/qm_ingest.cpp: chunk-parallel parse with record resync, gz blocks) against the
+    REFERENCE's own fastx_parser::FastxParser<ReadPair / ReadSeq> (src/FastxParser.cpp over kseq, compiled in place) on the same
+    files: the reference's sample reads (gz), a plain paired FASTQ cut into 3 kB chunks with qualities that start with '@'
+    and '+', CRLF lines and ragged lengths, and a multi-line FASTA -- same records, same order, same sequences; our names
+    are the whole header line, the reference's end at the first blank (where the SAM writer cuts ours, src/RapMapUtils.cpp:334-351)"""
+    import random
+    import gzip as gz
+    import rapmap_amd as ra
+
+    def ours(p1, p2, batch, threads):
+        rd = ra.FastxReader(p1, p2, threads=threads)
+        out = []
+        for b in rd.chunks(batch):
+            for i in range(b.n):
+                rec = [bytes(b.names1[b.name_off1[i]:b.name_off1[i + 1]]).split(b" ")[0].split(b"\t")[0], bytes(b.seq1[b.off1[i]:b.off1[i + 1]])]
+                if p2:
+                    rec += [bytes(b.names2[b.name_off2[i]:b.name_off2[i + 1]]).split(b" ")[0].split(b"\t")[0], bytes(b.seq2[b.off2[i]:b.off2[i + 1]])]
+                out.append(rec)
+        rd.close()
+        return out
+
+    g1 = os.path.join(GOLD, "sample_data", "reads_1.fastq.gz"); g2 = os.path.join(GOLD, "sample_data", "reads_2.fastq.gz")
+    want = _ref_fastx(ref, g1, g2)
+    assert len(want) == 10000 and ours(g1, g2, 777, 3) == want
+    assert ours(g1, None, 4096, 2) == _ref_fastx(ref, g1)
+    rnd = random.Random(7)
+    p1 = str(tmp_path / "a.fq"); p2 = str(tmp_path / "b.fq")
+    with open(p1, "wb") as f1, open(p2, "wb") as f2:
+        for i in range(20000):
+            for f, nl in ((f1, b"\n"), (f2, b"\r\n" if i % 5 == 0 else b"\n")):
+                L = rnd.choice([1, 30, 31, 100, 100, 250]) if i % 40 == 0 else 100
+                s = "".join(rnd.choice("ACGTN") for _ in range(L)).encode()
+                q = "".join(rnd.choice("@+I5#") for _ in range(L)).encode()
+                nm = ("r%d desc text/%d" % (i * 7919, 1 + (f is f2))).encode()
+                f.write(b"@" + nm + nl + s + nl + b"+" + nl + q + nl)
+    os.environ["QM_INGEST_CHUNK"] = "3000"
+    try:
+        got = ours(p1, p2, 1000, 6)
+    finally:
+        del os.environ["QM_INGEST_CHUNK"]
+    want = _ref_fastx(ref, p1, p2)
+    assert len(want) == 20000 and got == want
+    fa = str(tmp_path / "t.fa.gz")
+    with gz.open(fa, "wt") as f:
+        for i in range(3000):
+            sq = "".join(rnd.choice("ACGT") for _ in range(rnd.randint(1, 400)))
+            f.write(">t%d gene=%d\n" % (i, i // 3))
+            for j in range(0, len(sq), 60):
+                f.write(sq[j:j + 60] + "\n")
+    assert ours(fa, None, 257, 4) == _ref_fastx(ref, fa)
