@@ -91,7 +91,8 @@ typedef struct qm_counters {
   uint64_t pe_hits, se_hits, tot_hits, num_reads, too_many_hits, mapped;
 } qm_counters;
 
-/* rapmap::utils::SAIntervalHit<int32_t> (include/RapMapUtils.hpp:516-525) + which list it sits in */
+/* rapmap::utils::SAIntervalHit<OffsetT> (include/RapMapUtils.hpp:516-525) + which list it sits in.  begin / end are the device's
+ * 32-bit offsets: for a BigSA index (OffsetT = int64_t in the reference) read them as uint32_t */
 typedef struct qm_sa_interval_hit {
   int32_t begin, end;
   uint32_t len, query_pos;
@@ -127,7 +128,8 @@ int qm_index_info_get(const qm_index* ix, qm_index_info* info);
 const char* qm_index_txp_name(const qm_index* ix, int64_t tid); /* rmi.txpNames[tid] */
 int64_t qm_index_txp_len(const qm_index* ix, int64_t tid);      /* rmi.txpLens[tid]  */
 /* Read-only views of rmi.seq (the '$'-separated text) and rmi.txpOffsets (include/RapMapSAIndex.hpp:70-82);
- * valid until qm_index_close. */
+ * valid until qm_index_close.  The offsets are UNSIGNED 32-bit values (read them as uint32_t for a BigSA index, whose text may
+ * pass 2^31 characters; the int64 vectors of such an index are narrowed at open and its text must stay below 2^32 - 2). */
 int qm_index_arrays(const qm_index* ix, const uint8_t** text, int64_t* text_len, const int32_t** txp_offsets,
                     int64_t* n_txps);
 
@@ -225,9 +227,12 @@ int qm_last_kernel_ms(const qm_ctx* ctx, double* map_kernel_ms, double* total_ms
 enum { QM_STAT_RELAUNCHES = 0, QM_STAT_LIST_WORDS = 1, QM_STAT_SLOW_READS = 2 };
 int qm_ctx_stat(const qm_ctx* ctx, int which, int64_t* value);
 
-/* `rapmap quasiindex [-p]` (src/RapMapSAIndexer.cpp:449-819), int32 suffix array: FASTA -> q5 index
- * directory readable by qm_index_open and by the reference (sa.bin, txpInfo.bin, rsd.bin and -- with
- * perfect_hash -- hash_info.bph / hash_info.val come out byte-identical to the reference's).  Host only. */
+/* `rapmap quasiindex [-p]` (src/RapMapSAIndexer.cpp:449-819): FASTA -> q5 index directory readable by
+ * qm_index_open and by the reference (sa.bin, txpInfo.bin, rsd.bin and -- with perfect_hash --
+ * hash_info.bph / hash_info.val come out byte-identical to the reference's).  A text of more than
+ * 2^31 - 2 characters gets the reference's int64 form ("BigSA": true: 8-byte transcript starts, suffix
+ * array entries and interval bounds, :682-683,711-722,743-765); the environment variable QM_FORCE_BIGSA=1
+ * writes that form for any text (tests).  Host only. */
 int qm_build_index(const char* fasta_path, const char* out_dir, int32_t k, int32_t no_clip_poly_a,
                    int32_t keep_duplicates, int32_t n_threads, int32_t perfect_hash);
 /* ... with `-s / --headerSep` (src/RapMapSAIndexer.cpp:833-835,868,588): the transcript's name is its header up to the first

@@ -205,15 +205,17 @@ class RapMapSAIndex {
   RapMapSAIndex& operator=(const RapMapSAIndex&) = delete;
 
   bool load(const std::string& indDir) {
-    static_assert(sizeof(IndexT) == 4, "64-bit suffix arrays (BigSA) are not on the device path yet");
     qmap::detail::check(qm_index_open(indDir.c_str(), &ix_));
     qm_index_info info;
     qmap::detail::check(qm_index_info_get(ix_, &info));
+    // the caller picks the instantiation from header.json's BigSA like the reference does (src/RapMapSAMapper.cpp:1209-1240); a
+    // mismatch would make the reference misread the files, here it is an error
+    if ((info.big_sa != 0) != (sizeof(IndexT) == 8)) throw std::runtime_error("RapMapSAIndex: IndexT does not match the index's BigSA flag");
     k_ = info.k; perfect_ = info.perfect_hash != 0;
     const uint8_t* text = nullptr; int64_t tl = 0; const int32_t* offs = nullptr; int64_t nt = 0;
     qmap::detail::check(qm_index_arrays(ix_, &text, &tl, &offs, &nt));
     seq.assign(reinterpret_cast<const char*>(text), static_cast<size_t>(tl));
-    txpOffsets.assign(offs, offs + nt);
+    { const uint32_t* uo = reinterpret_cast<const uint32_t*>(offs); txpOffsets.clear(); for (int64_t i = 0; i < nt; ++i) txpOffsets.push_back(static_cast<IndexT>(uo[i])); }   // unsigned on the device path
     txpNames.clear(); txpLens.clear();
     for (int64_t i = 0; i < nt; ++i) { txpNames.emplace_back(qm_index_txp_name(ix_, i)); txpLens.push_back(static_cast<IndexT>(qm_index_txp_len(ix_, i))); }
     return true;
@@ -238,6 +240,8 @@ class RapMapSAIndex {
 };
 using SAIndex32BitDense = RapMapSAIndex<int32_t, RegHashT>;
 using SAIndex32BitPerfect = RapMapSAIndex<int32_t, PerfectHashT>;
+using SAIndex64BitDense = RapMapSAIndex<int64_t, RegHashT>;          // BigSA indices (src/HitManager.cpp:889-892)
+using SAIndex64BitPerfect = RapMapSAIndex<int64_t, PerfectHashT>;
 
 // ------------------------------------------------------------------------------------------------ plumbing
 namespace qmap {
@@ -468,7 +472,7 @@ class SACollector {
       if (idx >= 0 && same_stage_opts(now, ch->opts) && (doChaining_ ? 1 : 0) == ch->opts.sel_aln) {
         for (int64_t j = ch->ivOff[idx]; j < ch->ivOff[idx + 1]; ++j) {
           const qm_sa_interval_hit& h = ch->iv[static_cast<size_t>(j)];
-          (h.query_rc ? hcInfo.rcSAInts : hcInfo.fwdSAInts).emplace_back(static_cast<OffsetT>(h.begin), static_cast<OffsetT>(h.end), h.len, h.query_pos, h.query_rc != 0);
+          (h.query_rc ? hcInfo.rcSAInts : hcInfo.fwdSAInts).emplace_back(static_cast<OffsetT>(static_cast<uint32_t>(h.begin)), static_cast<OffsetT>(static_cast<uint32_t>(h.end)), h.len, h.query_pos, h.query_rc != 0);
         }
         hcInfo.qm_chunk_ = ch; hcInfo.qm_gen_ = ch->gen; hcInfo.qm_read_ = idx;
         return ch->found[static_cast<size_t>(idx)] != 0;
@@ -485,7 +489,7 @@ class SACollector {
     check(qm_fetch_intervals(ctx, ioff, iv.data(), ni));
     for (int64_t j = 0; j < ioff[1]; ++j) {
       const qm_sa_interval_hit& h = iv[static_cast<size_t>(j)];
-      (h.query_rc ? hcInfo.rcSAInts : hcInfo.fwdSAInts).emplace_back(static_cast<OffsetT>(h.begin), static_cast<OffsetT>(h.end), h.len, h.query_pos, h.query_rc != 0);
+      (h.query_rc ? hcInfo.rcSAInts : hcInfo.fwdSAInts).emplace_back(static_cast<OffsetT>(static_cast<uint32_t>(h.begin)), static_cast<OffsetT>(static_cast<uint32_t>(h.end)), h.len, h.query_pos, h.query_rc != 0);
     }
     hcInfo.qm_chunk_ = nullptr; hcInfo.qm_read_ = -1;
     uint8_t f = 0;

@@ -14,6 +14,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libqm_oracle.so")
+_LIB64 = os.path.join(_HERE, "libqm_oracle64.so")     # IndexT = int64_t: the instantiation of a BigSA index
 
 HIT_DTYPE = np.dtype([
     ("tid", "<u4"), ("pos", "<i4"), ("mate_pos", "<i4"), ("frag_len", "<u4"),
@@ -60,10 +61,13 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
 
-def _lib():
-    if not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "qm_oracle.cpp")):
+def _lib(big=False):
+    path = _LIB64 if big else _LIB
+    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(os.path.join(_HERE, "qm_oracle.cpp")):
         build()
-    lib = C.CDLL(_LIB)
+    lib = C.CDLL(path)
+    lib.qo_index_bytes.restype = C.c_int
+    assert lib.qo_index_bytes() == (8 if big else 4)
     lib.qo_index_create.restype = C.c_void_p
     lib.qo_index_create.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                     C.c_int64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
@@ -105,17 +109,17 @@ class MapResult:
 
 class Oracle:
     def __init__(self, ix):
-        assert not ix.big, "oracle restates the int32 index type only"
-        self.lib = _lib()
+        self.lib = _lib(bool(ix.big))
         self.ix = ix
+        it = np.int64 if ix.big else np.int32              # RapMapSAIndex<IndexT, ...>::IndexType
         # keep references alive
         self._text = np.ascontiguousarray(ix.text, dtype=np.uint8)
-        self._sa = np.ascontiguousarray(ix.SA, dtype=np.int32)
-        self._off = np.ascontiguousarray(ix.txpOffsets, dtype=np.int32)
+        self._sa = np.ascontiguousarray(ix.SA, dtype=it)
+        self._off = np.ascontiguousarray(ix.txpOffsets, dtype=it)
         self._rsd = np.ascontiguousarray(ix.rsd, dtype=np.uint64)
         self._hk = np.ascontiguousarray(ix.hkeys, dtype=np.uint64)
-        self._hlb = np.ascontiguousarray(ix.hlb, dtype=np.int32)
-        self._hub = np.ascontiguousarray(ix.hub, dtype=np.int32)
+        self._hlb = np.ascontiguousarray(ix.hlb, dtype=it)
+        self._hub = np.ascontiguousarray(ix.hub, dtype=it)
         self.h = self.lib.qo_index_create(
             ix.k, self._text.ctypes.data, self._text.size, self._sa.ctypes.data, self._sa.size,
             self._off.ctypes.data, self._off.size, self._rsd.ctypes.data, ix.nbits,

@@ -129,13 +129,19 @@ static void reverseRead(const char* s, int64_t len, std::string& out) {
 // ----------------------------------------------------------------------------
 // index view
 // ----------------------------------------------------------------------------
-struct SAInterval { int32_t lb, ub; };
+// RapMapSAIndex<IndexT, ...>::IndexType: int32_t, or int64_t for a BigSA index (src/RapMapSAMapper.cpp:1209-1240).  The file is
+// compiled once per type: libqm_oracle.so (int32_t) and libqm_oracle64.so (-DQO_INDEX_T=int64_t), see the Makefile.
+#ifndef QO_INDEX_T
+#define QO_INDEX_T int32_t
+#endif
+typedef QO_INDEX_T IndexT;
+struct SAInterval { IndexT lb, ub; };
 
 struct OIndex {
   int k = 31;
   const uint8_t* text = nullptr; int64_t n = 0;
-  const int32_t* SA = nullptr; int64_t nSA = 0;
-  const int32_t* txpOffsets = nullptr; int64_t nTxp = 0;
+  const IndexT* SA = nullptr; int64_t nSA = 0;
+  const IndexT* txpOffsets = nullptr; int64_t nTxp = 0;
   const uint64_t* rsd = nullptr; uint64_t nbits = 0;
   std::vector<uint64_t> cum;  // #set bits before word w
   std::vector<int64_t> txpLens;   // src/RapMapSAIndex.cpp:151-163
@@ -207,7 +213,7 @@ struct Hit {
 };
 static_assert(sizeof(Hit) == 32, "hit POD is 32 bytes");
 
-struct SAIntervalHit { int32_t begin, end; uint32_t len, queryPos; uint8_t queryRC; };
+struct SAIntervalHit { IndexT begin, end; uint32_t len, queryPos; uint8_t queryRC; };
 
 enum : uint8_t { SINGLE_END = 0, PE_LEFT = 1, PE_RIGHT = 2, PE_PAIRED = 3 };
 
@@ -218,10 +224,10 @@ static inline signed char up(char c) {
   return (c >= 'a' && c <= 'z') ? (signed char)(c - 32) : (signed char)c;
 }
 
-static std::tuple<int32_t, int32_t, int32_t>
-extendSearchNaive(const OIndex& ix, int32_t lbIn, int32_t ubIn, int32_t startAt,
+static std::tuple<IndexT, IndexT, IndexT>
+extendSearchNaive(const OIndex& ix, IndexT lbIn, IndexT ubIn, IndexT startAt,
                   const char* qb, int64_t m, Work& w) {
-  const int32_t* SA = ix.SA;
+  const IndexT* SA = ix.SA;
   const signed char* sb = (const signed char*)ix.text;
   const int64_t n = ix.n;
 
@@ -236,7 +242,7 @@ extendSearchNaive(const OIndex& ix, int32_t lbIn, int32_t ubIn, int32_t startAt,
       if (q < sb[s + i]) break; else if (q > sb[s + i]) break;
       ++i;
     }
-    return std::make_tuple(lbIn, ubIn, (int32_t)i);
+    return std::make_tuple(lbIn, ubIn, (IndexT)i);
   }
 
   int64_t l = lbIn, r = ubIn;
@@ -311,18 +317,18 @@ extendSearchNaive(const OIndex& ix, int32_t lbIn, int32_t ubIn, int32_t startAt,
     }
   }
   if (bound1 == bound2) bound2 += 1;           // :307
-  return std::make_tuple((int32_t)bound1, (int32_t)bound2, (int32_t)maxLen);
+  return std::make_tuple((IndexT)bound1, (IndexT)bound2, (IndexT)maxLen);
 }
 
 // SASearcher::lce -- include/SASearcher.hpp:318-334 (NIP only)
-static int32_t lce(const OIndex& ix, int32_t p1, int32_t p2, int32_t startAt,
-                   int32_t stopAt, Work& w) {
-  int32_t len = startAt;
+static IndexT lce(const OIndex& ix, IndexT p1, IndexT p2, IndexT startAt,
+                  IndexT stopAt, Work& w) {
+  IndexT len = startAt;
   w.n_sa += 2;
   int64_t o1 = (int64_t)ix.SA[p1] + startAt;
   int64_t o2 = (int64_t)ix.SA[p2] + startAt;
   int64_t maxIndex = std::max(o1, o2);
-  int32_t textLen = (int32_t)ix.n;
+  IndexT textLen = (IndexT)ix.n;
   while (maxIndex + len < textLen && ix.text[o1 + len] == ix.text[o2 + len]) {
     ++w.n_text;
     if (ix.text[o1 + len] == '$') break;
@@ -390,7 +396,7 @@ struct Collector {
     const int64_t skipOverlap = k - 1;
     int64_t rb = 0;                 // offsets instead of iterators
     const int64_t readEnd = (int64_t)readLen;
-    int32_t lb = 0, ub = 0, matchedLen = 0;
+    IndexT lb = 0, ub = 0, matchedLen = 0;
     size_t invalidPos = 0, pos = 0;
     uint64_t mer = 0;
     const SAInterval* merIt = nullptr;
@@ -424,19 +430,19 @@ struct Collector {
       }
       if (hit) {
         skipSetup = false;
-        lb = std::max((int32_t)0, lb - 1);
+        lb = std::max((IndexT)0, lb - 1);
         // :557-575 -- with chain scoring only the MMP that starts the read may run to the read's end; every
         // other one is cut at k + maxMMPExtension characters, and a first MMP longer than that is redone cut
         bool firstAttempt = doChaining ? (rb == 0) : true;
         int64_t endOff = firstAttempt ? readEnd : std::min(rb + k + maxMMPExtension, readEnd);
-        const int32_t lbP = lb, ubP = ub;
+        const IndexT lbP = lb, ubP = ub;
         std::tie(lb, ub, matchedLen) =
             extendSearchNaive(ix, lb, ub, k, read + rb, endOff - rb, w);
-        if (doChaining && firstAttempt && !(matchedLen >= (int32_t)readLen) && matchedLen >= (int32_t)(k + maxMMPExtension)) {
+        if (doChaining && firstAttempt && !(matchedLen >= (IndexT)readLen) && matchedLen >= (IndexT)(k + maxMMPExtension)) {
           endOff = std::min(rb + k + maxMMPExtension, readEnd);
           std::tie(lb, ub, matchedLen) = extendSearchNaive(ix, lbP, ubP, k, read + rb, endOff - rb, w);
         }
-        int32_t diff = ub - lb;
+        IndexT diff = ub - lb;
         if (ub > lb && diff < maxInterval) {
           uint32_t queryStart = (uint32_t)rb;
           saInts.push_back({lb, ub, (uint32_t)matchedLen, queryStart, (uint8_t)isRC});
@@ -456,8 +462,8 @@ struct Collector {
         int64_t mismatch = rb + matchedLen;
         if (mismatch >= readEnd) return;
         int64_t remaining = readEnd - mismatch;
-        int32_t lceLen = disableNIP ? matchedLen
-                                    : lce(ix, lb, ub - 1, matchedLen, (int32_t)remaining, w);
+        IndexT lceLen = disableNIP ? matchedLen
+                                   : lce(ix, lb, ub - 1, matchedLen, (IndexT)remaining, w);
         int64_t skipMatch = mismatch - skipOverlap;
         int64_t skipLCE = rb + lceLen - skipOverlap;
         rb = std::max(skipMatch, skipLCE);
@@ -606,11 +612,11 @@ static std::map<int, PSAHit> intersectSAHits(const OIndex& ix, std::vector<SAInt
   SAIntervalHit* minHit = &inHits[0];
   for (auto& h : inHits)
     if ((h.end - h.begin) < (minHit->end - minHit->begin)) minHit = &h;
-  for (int32_t i = minHit->begin; i < minHit->end; ++i) {
+  for (IndexT i = minHit->begin; i < minHit->end; ++i) {
     ++w.n_sa;
-    int32_t globalPos = ix.SA[i];
+    IndexT globalPos = ix.SA[i];
     int tid = (int)ix.rank((uint64_t)globalPos, w);
-    int32_t txpPos = globalPos - ix.txpOffsets[tid];
+    int32_t txpPos = (int32_t)(globalPos - ix.txpOffsets[tid]);
     auto& oh = outHits[tid];
     oh.tqvec.push_back({(uint32_t)txpPos, minHit->queryPos, (bool)minHit->queryRC, minHit->len});
     oh.lastActiveInterval = 1;
@@ -619,16 +625,16 @@ static std::map<int, PSAHit> intersectSAHits(const OIndex& ix, std::vector<SAInt
   uint32_t intervalCounter = 2;
   for (auto& h : inHits) {
     if (&h == minHit) continue;
-    for (int32_t i = h.begin; i != h.end; ++i) {      // :463-492
+    for (IndexT i = h.begin; i != h.end; ++i) {       // :463-492
       ++w.n_sa;
-      int32_t globalPos = ix.SA[i];
+      IndexT globalPos = ix.SA[i];
       int txpID = (int)ix.rank((uint64_t)globalPos, w);
       auto it = outHits.find(txpID);
       bool inOutputSet = (it != outHits.end());
       int32_t occ = inOutputSet ? (int32_t)it->second.numActive : 0;
       int32_t slack = ((int32_t)intervalCounter - 1) - occ;
       if (nonStrictIntersection || slack <= maxSlack) {
-        int32_t localPos = globalPos - ix.txpOffsets[txpID];
+        int32_t localPos = (int32_t)(globalPos - ix.txpOffsets[txpID]);
         if (inOutputSet) {
           it->second.numActive += (it->second.lastActiveInterval == intervalCounter) ? 0 : 1;
           it->second.lastActiveInterval = intervalCounter;
@@ -781,11 +787,11 @@ static void hitsToMappingsSimple(const OIndex& ix, const MapCfg& mc, uint8_t mat
   auto collectFromSingleInterval = [&](std::vector<SAIntervalHit>& saInts, bool isFw) {   // :716-807
     auto& h = saInts.front();
     size_t initialSize = hits.size();
-    for (int32_t i = h.begin; i != h.end; ++i) {
+    for (IndexT i = h.begin; i != h.end; ++i) {
       ++w.n_sa;
-      int32_t globalPos = ix.SA[i];
+      IndexT globalPos = ix.SA[i];
       uint32_t txpID = (uint32_t)ix.rank((uint64_t)globalPos, w);
-      int32_t pos = globalPos - ix.txpOffsets[txpID];
+      int32_t pos = (int32_t)(globalPos - ix.txpOffsets[txpID]);
       int32_t hitPos = (int32_t)((uint32_t)pos - h.queryPos);
       hits.emplace_back(txpID, hitPos, isFw, readLen, mateStatus);
       QA& lastHit = hits.back();
@@ -1311,9 +1317,11 @@ static void mapSingle(const OIndex& ix, const Opts& o, const MapCfg& mc, Collect
 // =============================================================================
 extern "C" {
 
-void* qo_index_create(int k, const uint8_t* text, int64_t n, const int32_t* SA, int64_t nSA,
-                      const int32_t* txpOffsets, int64_t nTxp, const uint64_t* rsd, uint64_t nbits,
-                      const uint64_t* hkeys, const int32_t* hlb, const int32_t* hub, int64_t nKeys) {
+int qo_index_bytes(void) { return (int)sizeof(IndexT); }     // 4, or 8 in libqm_oracle64.so
+
+void* qo_index_create(int k, const uint8_t* text, int64_t n, const IndexT* SA, int64_t nSA,
+                      const IndexT* txpOffsets, int64_t nTxp, const uint64_t* rsd, uint64_t nbits,
+                      const uint64_t* hkeys, const IndexT* hlb, const IndexT* hub, int64_t nKeys) {
   OIndex* ix = new OIndex();
   ix->k = k; ix->text = text; ix->n = n; ix->SA = SA; ix->nSA = nSA;
   ix->txpOffsets = txpOffsets; ix->nTxp = nTxp; ix->rsd = rsd; ix->nbits = nbits;
@@ -1379,7 +1387,7 @@ int qo_map(void* hidx, const Opts* opts, int64_t n, const char* seq1, const int6
         if (ints_out) {
           for (int l = 0; l < 4; ++l)
             for (auto& s : dump[l]) {
-              int32_t rec[6] = {s.begin, s.end, (int32_t)s.len, (int32_t)s.queryPos, (int32_t)s.queryRC, l};
+              int32_t rec[6] = {(int32_t)(uint32_t)s.begin, (int32_t)(uint32_t)s.end, (int32_t)s.len, (int32_t)s.queryPos, (int32_t)s.queryRC, l};
               perInts[t].insert(perInts[t].end(), rec, rec + 6);
               ++icnt[i + 1];
             }
@@ -1459,13 +1467,14 @@ void qo_reverse_read(const char* s, int64_t len, char* out) {
 }
 void qo_extend_search(void* hidx, int32_t lbIn, int32_t ubIn, int32_t startAt, const char* q, int64_t m,
                       int32_t* out3) {
-  Work w; int32_t a, b, c;
+  Work w; IndexT a, b, c;
   std::tie(a, b, c) = extendSearchNaive(*(const OIndex*)hidx, lbIn, ubIn, startAt, q, m, w);
-  out3[0] = a; out3[1] = b; out3[2] = c;
+  out3[0] = (int32_t)a; out3[1] = (int32_t)b; out3[2] = (int32_t)c;
 }
 int qo_hash_find(void* hidx, uint64_t key, int32_t* lbub) {
   Work w; const SAInterval* it = ((const OIndex*)hidx)->find(key, w);
-  if (!it) return 0; lbub[0] = it->lb; lbub[1] = it->ub; return 1;
+  if (!it) return 0;
+  lbub[0] = (int32_t)it->lb; lbub[1] = (int32_t)it->ub; return 1;
 }
 uint64_t qo_rank(void* hidx, uint64_t p) { Work w; return ((const OIndex*)hidx)->rank(p, w); }
 // the ksw2 extension kernel alone (nt4 codes in, max(mqe, mte) out) -- for differential tests of the device kernels

@@ -128,6 +128,22 @@ void ref_spp_find(void* h, const uint64_t* keys, int64_t n, uint8_t* found, int3
 void ref_spp_free(void* h) { delete (RefDenseHash*)h; }
 uint64_t ref_xxh64(const void* p, uint64_t len, uint64_t seed) { return XXH64(p, (size_t)len, seed); }
 
+// FrugalBooMap::overflow_ of a BigSA index (include/FrugalBooMap.hpp:318 with IndexT = int64_t: default hasher spp_hash<int64_t>),
+// unserialised from a file that holds just the map (the tail of hash_info.val, :244) and asked for n keys
+void* ref_spp64_load(const char* path) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return nullptr;
+  auto* h = new spp::sparse_hash_map<int64_t, int64_t>();
+  if (!h->unserialize(spp_utils::pod_hash_serializer<int64_t, int64_t>(), &f)) { delete h; return nullptr; }
+  return h;
+}
+int64_t ref_spp64_size(void* h) { return (int64_t)((spp::sparse_hash_map<int64_t, int64_t>*)h)->size(); }
+void ref_spp64_find(void* h, const int64_t* keys, int64_t n, uint8_t* found, int64_t* val) {
+  auto* m = (spp::sparse_hash_map<int64_t, int64_t>*)h;
+  for (int64_t i = 0; i < n; ++i) { auto it = m->find(keys[i]); found[i] = it != m->end(); if (found[i]) val[i] = it->second; }
+}
+void ref_spp64_free(void* h) { delete (spp::sparse_hash_map<int64_t, int64_t>*)h; }
+
 
 // The reference's read parser as processReadsPairSA / processReadsSingleSA drive it (src/RapMapSAMapper.cpp:853,869-871 and
 // :461-463: getReadGroup, refill, iterate), one parsing thread, one consumer: every record as "name<TAB>seq" ("<TAB>name2<TAB>seq2"

@@ -180,7 +180,7 @@ def default_opts(**kw):
 
 
 def build_index(fasta, out_dir, k=31, no_clip_poly_a=False, keep_duplicates=False, threads=None, perfect_hash=False, header_sep=None):
-    """`rapmap quasiindex -t FASTA -i OUT -k K [-p] [-s SEP]` (src/RapMapSAIndexer.cpp:821-927), int32 SA."""
+    """`rapmap quasiindex -t FASTA -i OUT -k K [-p] [-s SEP]` (src/RapMapSAIndexer.cpp:821-927); int64 ("BigSA") form for a text beyond 2^31 - 2 characters."""
     threads = threads or min(32, os.cpu_count() or 1)
     rc = lib().qm_build_index_ex(os.fsencode(fasta), os.fsencode(out_dir), k, int(no_clip_poly_a), int(keep_duplicates), threads,
                                  int(perfect_hash), header_sep.encode() if header_sep is not None else None)
@@ -200,7 +200,7 @@ def pack_reads(reads):
 
 
 class QuasiIndex:
-    """RapMapSAIndex<int32_t, RegHashT>: load() == qm_index_open (src/RapMapSAIndex.cpp:97-176)."""
+    """RapMapSAIndex<int32_t | int64_t, RegHashT | PerfectHashT>: load() == qm_index_open (src/RapMapSAIndex.cpp:97-176)."""
 
     def __init__(self, index_dir):
         self._h = C.c_void_p()
@@ -209,6 +209,7 @@ class QuasiIndex:
         _check(lib().qm_index_info_get(self._h, C.byref(info)))
         self.k, self.text_len, self.n_txps, self.n_keys = info.k, info.text_len, info.n_txps, info.n_keys
         self.perfect_hash = bool(info.perfect_hash)
+        self.big_sa = bool(info.big_sa)     # int64 on disk (RapMapSAIndex<int64_t, ...>), unsigned 32-bit offsets on the device
         self._names = None
         self._lens = None
 
@@ -230,7 +231,7 @@ class QuasiIndex:
         _check(lib().qm_index_arrays(self._h, C.byref(tp), C.byref(tl), C.byref(op), C.byref(nt)))
         text = np.ctypeslib.as_array(C.cast(tp, C.POINTER(C.c_uint8)), shape=(tl.value,)).copy()
         raw = np.ctypeslib.as_array(C.cast(op, C.POINTER(C.c_uint8)), shape=(nt.value * 4,)).copy()
-        return text, raw.view("<i4").astype(np.int64)
+        return text, raw.view("<u4").astype(np.int64)      # unsigned: a BigSA index has offsets beyond 2^31
 
     def close(self):
         if self._h:

@@ -12,6 +12,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -57,9 +58,12 @@ struct qm_index {
   std::string dir;
   int k = 31; bool big = false, perfect = false;
   MMap sa, txp, rsd, hash;
-  const int32_t* SA = nullptr; int64_t nSA = 0;
+  // SA entries, transcript offsets and interval bounds are UNSIGNED 32-bit from here on (qm_mapper.inl, struct Iv).  A BigSA index
+  // (int64 on disk: text > 2^31 - 1 characters, src/RapMapSAIndexer.cpp:682-683) is narrowed into the *Narrow vectors at open.
+  const uint32_t* SA = nullptr; int64_t nSA = 0;
   std::vector<std::string> names;
-  const int32_t* offsets = nullptr; int64_t nTxp = 0;
+  const uint32_t* offsets = nullptr; int64_t nTxp = 0;
+  std::vector<uint32_t> saNarrow, offNarrow, phDataNarrow; std::vector<uint8_t> hashNarrow;
   const uint8_t* text = nullptr; int64_t n = 0;
   const uint32_t* completeLens = nullptr;
   std::vector<int64_t> lens;
@@ -72,15 +76,15 @@ struct qm_index {
   uint64_t phLastRank = 0, phNelem = 0;
   std::vector<std::pair<uint64_t, uint64_t>> phFinal;
   const uint8_t* phData = nullptr; const uint8_t* phLens = nullptr;
-  std::vector<std::pair<int32_t, int32_t>> phOverflow;
+  std::vector<std::pair<uint32_t, uint32_t>> phOverflow;
 };
 
 // The index replica of one device: built by the first context on (index, device), shared read-only by every later one
 // (one context per host thread is the intended use: a Salmon-style caller has many), freed with the last of them.
 struct Replica {
   int device = 0;
-  uint8_t* d_text = nullptr; int32_t* d_SA = nullptr; void* d_sainfo = nullptr; void* d_slots = nullptr; uint64_t cap = 0;
-  void* d_ph = nullptr; PhIndex hPh; std::vector<void*> phAllocs; int32_t* d_txpOff = nullptr; int32_t* d_txpLen = nullptr; int64_t devBytes = 0;
+  uint8_t* d_text = nullptr; uint32_t* d_SA = nullptr; void* d_sainfo = nullptr; void* d_slots = nullptr; uint64_t cap = 0;
+  void* d_ph = nullptr; PhIndex hPh; std::vector<void*> phAllocs; uint32_t* d_txpOff = nullptr; int32_t* d_txpLen = nullptr; int64_t devBytes = 0;
   std::mutex sanextMu; unsigned int* d_sanext = nullptr;   // -s: built by the first -s call of any context of this replica
   void* d_saext = nullptr;                                  // the packed characters behind every suffix's k-mer (SaExt), or null
   ~Replica() {
@@ -107,7 +111,7 @@ struct qm_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evA = nullptr, evB = nullptr, evCopy = nullptr, evStage[2] = {nullptr, nullptr};
   unsigned char* h_stage = nullptr;                        // pinned, 2 x 32 MB: result download (qm_fetch_hits)
   // index replica
-  uint8_t* d_text = nullptr; int32_t* d_SA = nullptr; void* d_sainfo = nullptr; void* d_slots = nullptr;
+  uint8_t* d_text = nullptr; uint32_t* d_SA = nullptr; void* d_sainfo = nullptr; void* d_slots = nullptr;
   uint64_t cap = 0;
   void* d_ph = nullptr; std::vector<void*> phAllocs;       // perfect-hash flavour: PhIndex struct + its arrays
   PhIndex hPh;                                              // host copy (passed to the kernels by value inside DevIndex)
@@ -129,7 +133,7 @@ struct qm_ctx {
   int* d_lenIn = nullptr; int64_t capLenIn = 0; unsigned char* d_foundIn = nullptr; int64_t capFoundIn = 0;
   int64_t lastIvTotal = 0, lastIvReads = -1, lastFoundReads = -1, lastListReads = -1, lastListWords = 0, lastTooManyUnits = -1;
   // -s (selective alignment) work areas
-  int32_t* d_txpOff = nullptr; int32_t* d_txpLen = nullptr;
+  uint32_t* d_txpOff = nullptr; int32_t* d_txpLen = nullptr;
   unsigned char* d_selscr = nullptr; int64_t capSelScr = 0;
   long long* d_slowq = nullptr; int64_t capSlowq = 0;          // -s slow pass: queue, per-wave scratch descriptors and their memory
   unsigned char* d_dyn = nullptr; int64_t capDyn = 0; unsigned char* d_dynmem = nullptr; int64_t capDynMem = 0;
@@ -184,6 +188,23 @@ static bool json_field(const std::string& js, const char* name, std::string& out
   return true;
 }
 
+// int64 -> uint32 over a large array (a BigSA index at open), on a few threads; false if a value does not fit
+static bool narrow_i64(const uint8_t* src, size_t n, uint32_t* dst) {
+  const int nt = n > (1u << 22) ? 16 : 1;
+  std::atomic<bool> ok{true};
+  auto work = [&](int t) {
+    const size_t b = n * (size_t)t / nt, e = n * (size_t)(t + 1) / nt;
+    bool good = true;
+    for (size_t i = b; i < e; ++i) { int64_t v; memcpy(&v, src + 8 * i, 8); if (v < 0 || v >= 0xffffffffLL) good = false; dst[i] = (uint32_t)v; }
+    if (!good) ok = false;
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto& x : th) x.join();
+  return ok;
+}
+
 int qm_index_open(const char* dirIn, qm_index** out) {
   if (!dirIn || !out) return fail(QM_E_ARG, "null argument");
   qm_index* ix = new qm_index();
@@ -204,7 +225,6 @@ int qm_index_open(const char* dirIn, qm_index** out) {
     if (json_field(js, "IndexVersion", v) && v != "q5") return bail(fail(QM_E_IO, "index version %s != q5", v.c_str()));
     if (ix->k < 1 || ix->k > 31) return bail(fail(QM_E_IO, "bad k %d", ix->k));
   }
-  if (ix->big) return bail(fail(QM_E_UNSUPPORTED, "BigSA (int64) indices are not supported yet"));
 
   if (ix->sa.open(ix->dir + "sa.bin")) return bail(fail(QM_E_IO, "cannot map sa.bin"));
   if (ix->txp.open(ix->dir + "txpInfo.bin")) return bail(fail(QM_E_IO, "cannot map txpInfo.bin"));
@@ -218,8 +238,16 @@ int qm_index_open(const char* dirIn, qm_index** out) {
     const uint8_t* p = (const uint8_t*)ix->sa.p;
     if (ix->sa.len < 8) return bail(fail(QM_E_IO, "sa.bin truncated"));
     uint64_t n; memcpy(&n, p, 8);
-    if (ix->sa.len != 8 + n * 4) return bail(fail(QM_E_IO, "sa.bin size mismatch"));
-    ix->SA = (const int32_t*)(p + 8); ix->nSA = (int64_t)n;
+    const size_t isz = ix->big ? 8 : 4;
+    if (ix->sa.len != 8 + n * isz) return bail(fail(QM_E_IO, "sa.bin size mismatch"));
+    // the device's offsets are 32-bit unsigned: a BigSA index fits as long as its text does (0xffffffff is the "none" value)
+    if (n >= 0xfffffffeULL) return bail(fail(QM_E_UNSUPPORTED, "text of %llu characters: more than the 2^32 - 2 the device's 32-bit offsets hold", (unsigned long long)n));
+    if (ix->big) {
+      ix->saNarrow.resize(n);
+      if (!narrow_i64(p + 8, n, ix->saNarrow.data())) return bail(fail(QM_E_IO, "sa.bin: entry out of range"));
+      ix->SA = ix->saNarrow.data();
+    } else ix->SA = (const uint32_t*)(p + 8);
+    ix->nSA = (int64_t)n;
   }
   {  // txpInfo.bin: vector<string>, vector<i32>, string(text), vector<u32>
     const uint8_t* p = (const uint8_t*)ix->txp.p; size_t len = ix->txp.len, off = 0;
@@ -231,8 +259,14 @@ int qm_index_open(const char* dirIn, qm_index** out) {
       uint64_t l; if (!rd64(l) || off + l > len) return bail(fail(QM_E_IO, "txpInfo.bin truncated (names)"));
       ix->names.emplace_back((const char*)p + off, (size_t)l); off += l;
     }
-    uint64_t c2; if (!rd64(c2) || off + c2 * 4 > len) return bail(fail(QM_E_IO, "txpInfo.bin truncated (offsets)"));
-    ix->offsets = (const int32_t*)(p + off); ix->nTxp = (int64_t)c2; off += c2 * 4;
+    const size_t isz = ix->big ? 8 : 4;                  // vector<int64_t> in a BigSA index (src/RapMapSAIndexer.cpp:711-722)
+    uint64_t c2; if (!rd64(c2) || off + c2 * isz > len) return bail(fail(QM_E_IO, "txpInfo.bin truncated (offsets)"));
+    if (ix->big) {
+      ix->offNarrow.resize(c2);
+      if (!narrow_i64(p + off, c2, ix->offNarrow.data())) return bail(fail(QM_E_IO, "txpInfo.bin: offset out of range"));
+      ix->offsets = ix->offNarrow.data();
+    } else ix->offsets = (const uint32_t*)(p + off);
+    ix->nTxp = (int64_t)c2; off += c2 * isz;
     uint64_t tl; if (!rd64(tl) || off + tl > len) return bail(fail(QM_E_IO, "txpInfo.bin truncated (text)"));
     ix->text = p + off; ix->n = (int64_t)tl; off += tl;
     uint64_t c3; if (!rd64(c3) || off + c3 * 4 > len) return bail(fail(QM_E_IO, "txpInfo.bin truncated (lens)"));
@@ -284,8 +318,14 @@ int qm_index_open(const char* dirIn, qm_index** out) {
       uint64_t n1, n2;
       if (len < 8) return bail(fail(QM_E_IO, "hash_info.val truncated"));
       memcpy(&n1, p, 8); off = 8;
-      if (off + n1 * 4 + 8 > len) return bail(fail(QM_E_IO, "hash_info.val truncated (data)"));
-      ix->phData = p + off; off += n1 * 4;
+      const size_t isz = ix->big ? 8 : 4;                // data_ is vector<IndexT>, overflow_ maps IndexT -> IndexT
+      if (off + n1 * isz + 8 > len) return bail(fail(QM_E_IO, "hash_info.val truncated (data)"));
+      if (ix->big) {
+        ix->phDataNarrow.resize(n1);
+        if (!narrow_i64(p + off, n1, ix->phDataNarrow.data())) return bail(fail(QM_E_IO, "hash_info.val: entry out of range"));
+        ix->phData = (const uint8_t*)ix->phDataNarrow.data();
+      } else ix->phData = p + off;
+      off += n1 * isz;
       memcpy(&n2, p + off, 8); off += 8;
       if (off + n2 > len || n1 != n2 || n1 != ix->phNelem) return bail(fail(QM_E_IO, "hash_info.val: size mismatch"));
       ix->phLens = p + off; off += n2;
@@ -298,8 +338,11 @@ int qm_index_open(const char* dirIn, qm_index** out) {
       uint64_t magic, tsize, nb;
       if (!be(magic) || !be(tsize) || !be(nb) || magic != 0x24687531ULL) return bail(fail(QM_E_IO, "hash_info.val: bad overflow map"));
       off += ((tsize + 31) / 32) * 4;
-      if (off + nb * 8 != len) return bail(fail(QM_E_IO, "hash_info.val size mismatch"));
-      for (uint64_t i = 0; i < nb; ++i) { int32_t a, b; memcpy(&a, p + off, 4); memcpy(&b, p + off + 4, 4); off += 8; ix->phOverflow.emplace_back(a, b); }
+      if (off + nb * 2 * isz != len) return bail(fail(QM_E_IO, "hash_info.val size mismatch"));
+      for (uint64_t i = 0; i < nb; ++i) {
+        uint64_t a = 0, b = 0; memcpy(&a, p + off, isz); memcpy(&b, p + off + isz, isz); off += 2 * isz;
+        ix->phOverflow.emplace_back((uint32_t)a, (uint32_t)b);
+      }
       ix->nKeys = (int64_t)ix->phNelem;
     }
   } else {  // hash.bin: 3 x big-endian u32 (0xFFFFFFFF escapes to u64), group bitmaps, records
@@ -318,8 +361,20 @@ int qm_index_open(const char* dirIn, qm_index** out) {
     if (!be(magic) || !be(tsize) || !be(nb)) return bail(fail(QM_E_IO, "hash.bin truncated"));
     if (magic != 0x24687531ULL) return bail(fail(QM_E_IO, "hash.bin bad magic"));
     off += ((tsize + 31) / 32) * 4;
-    if (off + nb * 16 != len) return bail(fail(QM_E_IO, "hash.bin size mismatch (%zu + %llu*16 != %zu)", off, (unsigned long long)nb, len));
-    ix->hashRecs = p + off; ix->nKeys = (int64_t)nb;
+    const size_t rsz = ix->big ? 24 : 16;                // {u64 key, IndexT begin, IndexT end}
+    if (off + nb * rsz != len) return bail(fail(QM_E_IO, "hash.bin size mismatch (%zu + %llu*%zu != %zu)", off, (unsigned long long)nb, rsz, len));
+    if (ix->big) {
+      ix->hashNarrow.resize(nb * 16);
+      for (uint64_t i = 0; i < nb; ++i) {
+        const uint8_t* r = p + off + 24 * i; uint8_t* w = ix->hashNarrow.data() + 16 * i;
+        int64_t b, e; memcpy(&b, r + 8, 8); memcpy(&e, r + 16, 8);
+        if (b < 0 || e < b || e > (int64_t)ix->nSA) return bail(fail(QM_E_IO, "hash.bin: interval out of range"));
+        const uint32_t b32 = (uint32_t)b, e32 = (uint32_t)e;
+        memcpy(w, r, 8); memcpy(w + 8, &b32, 4); memcpy(w + 12, &e32, 4);
+      }
+      ix->hashRecs = ix->hashNarrow.data();
+    } else ix->hashRecs = p + off;
+    ix->nKeys = (int64_t)nb;
   }
   *out = ix;
   return QM_OK;
@@ -357,7 +412,7 @@ int qm_index_arrays(const qm_index* ix, const uint8_t** text, int64_t* text_len,
   if (!ix) return fail(QM_E_ARG, "null index");
   if (text) *text = ix->text;
   if (text_len) *text_len = ix->n;
-  if (txp_offsets) *txp_offsets = ix->offsets;
+  if (txp_offsets) *txp_offsets = (const int32_t*)ix->offsets;      // unsigned values for a BigSA index
   if (n_txps) *n_txps = ix->nTxp;
   return QM_OK;
 }
@@ -451,7 +506,7 @@ int qm_ctx_create_ex(const qm_index* ix, int device_id, uint32_t flags, qm_ctx**
   CK(hipMalloc((void**)&c->d_SA, (size_t)ix->nSA * 4));
   CK(hipMemcpyAsync(c->d_SA, ix->SA, (size_t)ix->nSA * 4, hipMemcpyHostToDevice, c->stream));
   CK(hipMalloc(&c->d_sainfo, (size_t)ix->nSA * sizeof(SaInfo)));
-  int32_t* d_offsets = nullptr; void* d_recs = nullptr;
+  uint32_t* d_offsets = nullptr; void* d_recs = nullptr;
   CK(hipMalloc((void**)&d_offsets, (size_t)ix->nTxp * 4));
   CK(hipMemcpyAsync(d_offsets, ix->offsets, (size_t)ix->nTxp * 4, hipMemcpyHostToDevice, c->stream));
   CK(qmk_build_sainfo(c->d_SA, ix->nSA, d_offsets, ix->nTxp, c->d_sainfo, c->stream));
@@ -482,7 +537,7 @@ int qm_ctx_create_ex(const qm_index* ix, int device_id, uint32_t flags, qm_ctx**
     auto dalloc = [&](size_t bytes) -> void* { void* q = nullptr; if (hipMalloc(&q, bytes ? bytes : 16) != hipSuccess) return nullptr; c->phAllocs.push_back(q); c->devBytes += (int64_t)bytes; return q; };
     u64* dW = (u64*)dalloc(blocks.size() * 8); u64* dT = (u64*)dalloc(tab.size() * 8);
     PhRec* dRec = (PhRec*)dalloc((size_t)ix->phNelem * sizeof(PhRec));
-    int* dD = nullptr; unsigned char* dL = nullptr;          // staging for the record builder
+    unsigned int* dD = nullptr; unsigned char* dL = nullptr; // staging for the record builder
     if (hipMalloc((void**)&dD, (size_t)(ix->phNelem ? ix->phNelem : 1) * 4) != hipSuccess || hipMalloc((void**)&dL, (size_t)(ix->phNelem ? ix->phNelem : 1)) != hipSuccess) dD = nullptr;
     if (!dW || !dT || !dRec || !dD || !dL) { int rc = fail(QM_E_NOMEM, "hipMalloc (perfect hash) failed"); qm_ctx_destroy(c); return rc; }
     CK(hipMemcpyAsync(dW, blocks.data(), blocks.size() * 8, hipMemcpyHostToDevice, c->stream));
@@ -500,8 +555,8 @@ int qm_ctx_create_ex(const qm_index* ix, int device_id, uint32_t flags, qm_ctx**
     std::vector<OvfSlot> ov; std::vector<Slot> fin;
     {
       u64 cap = 16; while (cap < ix->phOverflow.size() * 2) cap <<= 1;
-      ov.assign(cap, OvfSlot{-1, 0});
-      for (auto& kv : ix->phOverflow) { u64 j = mix((u64)(uint32_t)kv.first) & (cap - 1); while (ov[j].key != -1) j = (j + 1) & (cap - 1); ov[j].key = kv.first; ov[j].val = kv.second; }
+      ov.assign(cap, OvfSlot{~0u, 0u});
+      for (auto& kv : ix->phOverflow) { u64 j = mix((u64)kv.first) & (cap - 1); while (ov[j].key != ~0u) j = (j + 1) & (cap - 1); ov[j].key = kv.first; ov[j].val = kv.second; }
       P.ovfMask = cap - 1;
       u64 fc = 16; while (fc < ix->phFinal.size() * 2) fc <<= 1;
       Slot e; e.key = ~0ULL; e.lb = 0; e.ub = 0;
@@ -1141,7 +1196,7 @@ int qm_hits_to_mappings(qm_ctx* c, const qm_opts* o, int64_t n, const int32_t* r
     int nf = 0, nr = 0; bool seenRc = false;
     for (int64_t j = int_offsets[i]; j < int_offsets[i + 1]; ++j) {
       if (ints[j].query_rc) { ++nr; seenRc = true; } else { ++nf; if (seenRc) return fail(QM_E_ARG, "read %lld: forward-strand intervals must precede the reverse-complement ones", (long long)i); }
-      if (ints[j].begin < 0 || ints[j].end > c->ix->nSA || ints[j].end < ints[j].begin) return fail(QM_E_ARG, "read %lld: SA interval out of range", (long long)i);
+      if ((int64_t)(uint32_t)ints[j].end > c->ix->nSA || (uint32_t)ints[j].end < (uint32_t)ints[j].begin) return fail(QM_E_ARG, "read %lld: SA interval out of range", (long long)i);
     }
     if (nf > QM_ICAP + QM_IOVF || nr > QM_ICAP + QM_IOVF) return fail(QM_E_ARG, "read %lld: more than %d intervals on one strand", (long long)i, QM_ICAP + QM_IOVF);
   }

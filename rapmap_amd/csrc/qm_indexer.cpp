@@ -62,67 +62,68 @@ uint64_t xxh64(const void* data, size_t len, uint64_t seed) {
 }
 
 // ---------------------------------------------------------------- SA-IS (Nong, Zhang & Chan 2009)
-template <typename S>
-void getBuckets(const S* s, int32_t* bkt, int32_t n, int32_t K, bool end) {
+template <typename S, typename I>
+void getBuckets(const S* s, I* bkt, I n, I K, bool end) {
   std::fill(bkt, bkt + K, 0);
-  for (int32_t i = 0; i < n; ++i) ++bkt[s[i]];
-  int32_t sum = 0;
-  for (int32_t i = 0; i < K; ++i) { sum += bkt[i]; bkt[i] = end ? sum : sum - bkt[i]; }
+  for (I i = 0; i < n; ++i) ++bkt[s[i]];
+  I sum = 0;
+  for (I i = 0; i < K; ++i) { sum += bkt[i]; bkt[i] = end ? sum : sum - bkt[i]; }
 }
-template <typename S>
-void induceL(const uint8_t* t, int32_t* SA, const S* s, int32_t* bkt, int32_t n, int32_t K) {
+template <typename S, typename I>
+void induceL(const uint8_t* t, I* SA, const S* s, I* bkt, I n, I K) {
   getBuckets(s, bkt, n, K, false);
-  for (int32_t i = 0; i < n; ++i) { int32_t j = SA[i] - 1; if (j >= 0 && !t[j]) SA[bkt[s[j]]++] = j; }
+  for (I i = 0; i < n; ++i) { I j = SA[i] - 1; if (j >= 0 && !t[j]) SA[bkt[s[j]]++] = j; }
 }
-template <typename S>
-void induceS(const uint8_t* t, int32_t* SA, const S* s, int32_t* bkt, int32_t n, int32_t K) {
+template <typename S, typename I>
+void induceS(const uint8_t* t, I* SA, const S* s, I* bkt, I n, I K) {
   getBuckets(s, bkt, n, K, true);
-  for (int32_t i = n - 1; i >= 0; --i) { int32_t j = SA[i] - 1; if (j >= 0 && t[j]) SA[--bkt[s[j]]] = j; }
+  for (I i = n - 1; i >= 0; --i) { I j = SA[i] - 1; if (j >= 0 && t[j]) SA[--bkt[s[j]]] = j; }
 }
-// s[n-1] must be the unique smallest character
-template <typename S>
-void sais(const S* s, int32_t* SA, int32_t n, int32_t K) {
+// s[n-1] must be the unique smallest character; I = int32_t, or int64_t for a text that needs the reference's 64-bit
+// suffix array (src/RapMapSAIndexer.cpp:743-750)
+template <typename S, typename I>
+void sais(const S* s, I* SA, I n, I K) {
   std::vector<uint8_t> tv((size_t)n);
   uint8_t* t = tv.data();       // 1 = S-type
   t[n - 1] = 1;
   if (n >= 2) t[n - 2] = 0;
-  for (int32_t i = n - 3; i >= 0; --i) t[i] = (s[i] < s[i + 1] || (s[i] == s[i + 1] && t[i + 1])) ? 1 : 0;
-  auto isLMS = [&](int32_t i) { return i > 0 && t[i] && !t[i - 1]; };
-  std::vector<int32_t> bktv((size_t)K);
-  int32_t* bkt = bktv.data();
+  for (I i = n - 3; i >= 0; --i) t[i] = (s[i] < s[i + 1] || (s[i] == s[i + 1] && t[i + 1])) ? 1 : 0;
+  auto isLMS = [&](I i) { return i > 0 && t[i] && !t[i - 1]; };
+  std::vector<I> bktv((size_t)K);
+  I* bkt = bktv.data();
   getBuckets(s, bkt, n, K, true);
   std::fill(SA, SA + n, -1);
-  for (int32_t i = 1; i < n; ++i) if (isLMS(i)) SA[--bkt[s[i]]] = i;
+  for (I i = 1; i < n; ++i) if (isLMS(i)) SA[--bkt[s[i]]] = i;
   induceL(t, SA, s, bkt, n, K);
   induceS(t, SA, s, bkt, n, K);
-  int32_t n1 = 0;
-  for (int32_t i = 0; i < n; ++i) if (isLMS(SA[i])) SA[n1++] = SA[i];
+  I n1 = 0;
+  for (I i = 0; i < n; ++i) if (isLMS(SA[i])) SA[n1++] = SA[i];
   std::fill(SA + n1, SA + n, -1);
-  int32_t name = 0, prev = -1;
-  for (int32_t i = 0; i < n1; ++i) {
-    int32_t pos = SA[i];
+  I name = 0, prev = -1;
+  for (I i = 0; i < n1; ++i) {
+    I pos = SA[i];
     bool diff = false;
-    for (int32_t d = 0; d < n; ++d) {
+    for (I d = 0; d < n; ++d) {
       if (prev == -1 || s[pos + d] != s[prev + d] || t[pos + d] != t[prev + d]) { diff = true; break; }
       else if (d > 0 && (isLMS(pos + d) || isLMS(prev + d))) break;
     }
     if (diff) { ++name; prev = pos; }
     SA[n1 + pos / 2] = name - 1;
   }
-  for (int32_t i = n - 1, j = n - 1; i >= n1; --i) if (SA[i] >= 0) SA[j--] = SA[i];
-  int32_t* SA1 = SA; int32_t* s1 = SA + n - n1;
-  if (name < n1) sais<int32_t>(s1, SA1, n1, name);
-  else for (int32_t i = 0; i < n1; ++i) SA1[s1[i]] = i;
+  for (I i = n - 1, j = n - 1; i >= n1; --i) if (SA[i] >= 0) SA[j--] = SA[i];
+  I* SA1 = SA; I* s1 = SA + n - n1;
+  if (name < n1) sais<I, I>(s1, SA1, n1, name);
+  else for (I i = 0; i < n1; ++i) SA1[s1[i]] = i;
   getBuckets(s, bkt, n, K, true);
-  for (int32_t i = 1, j = 0; i < n; ++i) if (isLMS(i)) s1[j++] = i;
-  for (int32_t i = 0; i < n1; ++i) SA1[i] = s1[SA1[i]];
+  for (I i = 1, j = 0; i < n; ++i) if (isLMS(i)) s1[j++] = i;
+  for (I i = 0; i < n1; ++i) SA1[i] = s1[SA1[i]];
   std::fill(SA + n1, SA + n, -1);
-  for (int32_t i = n1 - 1; i >= 0; --i) { int32_t j = SA[i]; SA[i] = -1; SA[--bkt[s[j]]] = j; }
+  for (I i = n1 - 1; i >= 0; --i) { I j = SA[i]; SA[i] = -1; SA[--bkt[s[j]]] = j; }
   induceL(t, SA, s, bkt, n, K);
   induceS(t, SA, s, bkt, n, K);
 }
 
-struct KmerRun { uint64_t key; int32_t lb, ub; };
+struct KmerRun { uint64_t key; int64_t lb, ub; };
 
 int8_t g_code[256];
 struct CodeInit { CodeInit() { memset(g_code, -1, 256); g_code['A'] = g_code['a'] = 0; g_code['C'] = g_code['c'] = 1; g_code['G'] = g_code['g'] = 2; g_code['T'] = g_code['t'] = 3; } } g_codeInit;
@@ -184,7 +185,16 @@ inline uint64_t boo_level_hash(uint64_t key, int lvl) {
 
 struct BooLevel { uint64_t domain; std::vector<uint64_t> words; std::vector<uint64_t> ranks; };
 
-int writePerfectHash(const std::string& outDir, const std::vector<KmerRun>& runs, int n_threads) {
+// spp_hash<int64_t> (include/sparsepp/spp_utils.h:189-198,272-275: Thomas Wang's 64-bit mix), the hasher of a BigSA index's
+// overflow_ map; spp_hash<int32_t> is the identity
+inline uint64_t spp_mix_64(uint64_t a) {
+  a = (~a) + (a << 21); a = a ^ (a >> 24); a = (a + (a << 3)) + (a << 8); a = a ^ (a >> 14);
+  a = (a + (a << 2)) + (a << 4); a = a ^ (a >> 28); a = a + (a << 31);
+  return a;
+}
+
+// big: IndexT = int64_t (data_ and overflow_ hold 8-byte values)
+int writePerfectHash(const std::string& outDir, const std::vector<KmerRun>& runs, int n_threads, bool big) {
   const uint64_t n = runs.size();
   const double gamma = 2.0;
   const int nb_levels = 25;
@@ -243,13 +253,13 @@ int writePerfectHash(const std::string& outDir, const std::vector<KmerRun>& runs
     return ~0ULL;
   };
   // values in MPHF order (FrugalBooMap::add + reorder_fn_, FrugalBooMap.hpp:101-112,283-305)
-  std::vector<int32_t> data(n); std::vector<uint8_t> lens(n);
-  std::vector<std::pair<int32_t, int32_t>> overflow;
+  std::vector<int64_t> data(n); std::vector<uint8_t> lens(n);
+  std::vector<std::pair<int64_t, int64_t>> overflow;
   {
     auto work = [&](int t) {
       for (uint64_t j = n * t / n_threads; j < n * (t + 1) / n_threads; ++j) {
         uint64_t idx = lookup(runs[j].key);
-        int32_t l = runs[j].ub - runs[j].lb;
+        int64_t l = runs[j].ub - runs[j].lb;
         data[idx] = runs[j].lb;
         lens[idx] = l >= 255 ? 255 : (uint8_t)l;
       }
@@ -278,13 +288,16 @@ int writePerfectHash(const std::string& outDir, const std::vector<KmerRun>& runs
      // spp_hash<int> == identity (include/sparsepp/spp_utils.h) and triangular probing
     FILE* o = fopen((outDir + "hash_info.val").c_str(), "wb");
     if (!o) return -1;
-    uint64_t c = n; fwrite(&c, 8, 1, o); fwrite(data.data(), 4, n, o);
+    const size_t isz = big ? 8 : 4;
+    uint64_t c = n; fwrite(&c, 8, 1, o);
+    if (big) fwrite(data.data(), 8, n, o);
+    else { std::vector<int32_t> d32(data.begin(), data.end()); fwrite(d32.data(), 4, n, o); }
     fwrite(&c, 8, 1, o); fwrite(lens.data(), 1, n, o);
     uint64_t tsize = 32;
     while (overflow.size() * 2 > tsize) tsize <<= 1;
     std::vector<int64_t> slot(tsize, -1);
     for (size_t r = 0; r < overflow.size(); ++r) {
-      uint64_t pos = (uint64_t)(size_t)overflow[r].first & (tsize - 1), probes = 0;
+      uint64_t pos = (big ? spp_mix_64((uint64_t)overflow[r].first) : (uint64_t)(size_t)(int32_t)overflow[r].first) & (tsize - 1), probes = 0;
       while (slot[pos] >= 0) { ++probes; pos = (pos + probes) & (tsize - 1); }
       slot[pos] = (int64_t)r;
     }
@@ -293,7 +306,7 @@ int writePerfectHash(const std::string& outDir, const std::vector<KmerRun>& runs
     std::vector<uint32_t> bm(tsize / 32, 0);
     for (uint64_t p = 0; p < tsize; ++p) if (slot[p] >= 0) bm[p >> 5] |= (1u << (p & 31));
     fwrite(bm.data(), 4, bm.size(), o);
-    for (uint64_t p = 0; p < tsize; ++p) if (slot[p] >= 0) { fwrite(&overflow[slot[p]].first, 4, 1, o); fwrite(&overflow[slot[p]].second, 4, 1, o); }
+    for (uint64_t p = 0; p < tsize; ++p) if (slot[p] >= 0) { fwrite(&overflow[slot[p]].first, isz, 1, o); fwrite(&overflow[slot[p]].second, isz, 1, o); }
     if (fclose(o) != 0) return -1;
   }
   return 0;
@@ -413,7 +426,9 @@ extern "C" int qm_build_index_ex(const char* fasta_path, const char* out_dir_c, 
   }
   if (names.empty()) return fail(QM_E_IO, "no transcripts in FASTA");
   const size_t tlen = text.size();
-  if (tlen + 1 > (size_t)0x7fffffff) return fail(QM_E_UNSUPPORTED, "text needs a 64-bit suffix array (BigSA), not supported yet");
+  // a text beyond int32 gets the reference's int64 instantiation (BigSA: 8-byte transcript starts, suffix array entries and
+  // interval bounds, src/RapMapSAIndexer.cpp:682-683,711-722,743-765).  QM_FORCE_BIGSA=1 (tests) writes that form for any text.
+  const bool big = tlen + 1 > (size_t)0x7fffffff || (getenv("QM_FORCE_BIGSA") && atoi(getenv("QM_FORCE_BIGSA")) != 0);
 
   {  // duplicate_clusters.tsv (:660-670)
     std::string s = "RetainedTxp\tDuplicateTxp\n";
@@ -430,16 +445,16 @@ extern "C" int qm_build_index_ex(const char* fasta_path, const char* out_dir_c, 
     if (!o) return fail(QM_E_IO, "cannot write txpInfo.bin");
     uint64_t c = names.size(); fwrite(&c, 8, 1, o);
     for (auto& nm : names) { uint64_t l = nm.size(); fwrite(&l, 8, 1, o); fwrite(nm.data(), 1, nm.size(), o); }
-    std::vector<int32_t> st32(starts.size());
-    for (size_t i = 0; i < starts.size(); ++i) st32[i] = (int32_t)starts[i];
-    c = st32.size(); fwrite(&c, 8, 1, o); fwrite(st32.data(), 4, st32.size(), o);
+    c = starts.size(); fwrite(&c, 8, 1, o);
+    if (big) { std::vector<int64_t> st64(starts.begin(), starts.end()); fwrite(st64.data(), 8, st64.size(), o); }
+    else { std::vector<int32_t> st32(starts.size()); for (size_t i = 0; i < starts.size(); ++i) st32[i] = (int32_t)starts[i]; fwrite(st32.data(), 4, st32.size(), o); }
     c = tlen; fwrite(&c, 8, 1, o); fwrite(text.data(), 1, tlen, o);
     c = completeLens.size(); fwrite(&c, 8, 1, o); fwrite(completeLens.data(), 4, completeLens.size(), o);
     if (fclose(o) != 0) return fail(QM_E_IO, "cannot write txpInfo.bin");
   }
 
   // ---- step 2: suffix array (divsufsort in the reference, :99-101,232-234)
-  std::vector<int32_t> SA;
+  std::vector<int32_t> SA; std::vector<int64_t> SA64;
   {
     // map to {1..5} with a unique 0 sentinel appended ('$' < A < C < G < T as bytes)
     std::vector<uint8_t> s(tlen + 1);
@@ -448,14 +463,22 @@ extern "C" int qm_build_index_ex(const char* fasta_path, const char* out_dir_c, 
       s[i] = ch == '$' ? 1 : (uint8_t)(2 + g_code[(uint8_t)ch]);
     }
     s[tlen] = 0;
-    std::vector<int32_t> sa1(tlen + 1);
-    sais<uint8_t>(s.data(), sa1.data(), (int32_t)(tlen + 1), 6);
-    SA.assign(sa1.begin() + 1, sa1.end());   // drop the sentinel suffix
+    if (big) {
+      SA64.resize(tlen + 1);
+      sais<uint8_t, int64_t>(s.data(), SA64.data(), (int64_t)(tlen + 1), (int64_t)6);
+      SA64.erase(SA64.begin());              // drop the sentinel suffix
+    } else {
+      std::vector<int32_t> sa1(tlen + 1);
+      sais<uint8_t, int32_t>(s.data(), sa1.data(), (int32_t)(tlen + 1), 6);
+      SA.assign(sa1.begin() + 1, sa1.end());
+    }
   }
   {
-    uint64_t c = SA.size();
-    if (!writeAll(outDir + "sa.bin", &c, 8, SA.data(), SA.size() * 4)) return fail(QM_E_IO, "cannot write sa.bin");
+    uint64_t c = tlen;
+    if (!(big ? writeAll(outDir + "sa.bin", &c, 8, SA64.data(), SA64.size() * 8) : writeAll(outDir + "sa.bin", &c, 8, SA.data(), SA.size() * 4)))
+      return fail(QM_E_IO, "cannot write sa.bin");
   }
+  auto saAt = [&](int64_t i) -> int64_t { return big ? SA64[(size_t)i] : (int64_t)SA[(size_t)i]; };
 
   // ---- step 3: k-mer -> SA interval (:262-443): maximal runs of suffixes sharing a valid k-prefix
   std::vector<std::vector<KmerRun>> parts((size_t)n_threads);
@@ -467,17 +490,17 @@ extern "C" int qm_build_index_ex(const char* fasta_path, const char* out_dir_c, 
       uint64_t w, pw;
       if (b > 0) {
         while (b < e) {
-          bool v = kmerAt(text, SA[b], k, w), pv = kmerAt(text, SA[b - 1], k, pw);
+          bool v = kmerAt(text, saAt(b), k, w), pv = kmerAt(text, saAt(b - 1), k, pw);
           if (v && pv && w == pw) ++b; else break;
         }
       }
       int64_t i = b;
       auto& out = parts[t];
       while (i < e) {
-        if (!kmerAt(text, SA[i], k, w)) { ++i; continue; }
+        if (!kmerAt(text, saAt(i), k, w)) { ++i; continue; }
         int64_t j = i + 1; uint64_t w2;
-        while (j < N && kmerAt(text, SA[j], k, w2) && w2 == w) ++j;   // may run past e: the next chunk snapped
-        out.push_back({w, (int32_t)i, (int32_t)j});
+        while (j < N && kmerAt(text, saAt(j), k, w2) && w2 == w) ++j;   // may run past e: the next chunk snapped
+        out.push_back({w, i, j});
         i = j;
       }
     };
@@ -493,7 +516,7 @@ extern "C" int qm_build_index_ex(const char* fasta_path, const char* out_dir_c, 
   if (perfect_hash) {
     std::vector<KmerRun> runs; runs.reserve(K);
     for (auto& p : parts) { runs.insert(runs.end(), p.begin(), p.end()); std::vector<KmerRun>().swap(p); }
-    int rc = writePerfectHash(outDir, runs, n_threads);
+    int rc = writePerfectHash(outDir, runs, n_threads, big);
     if (rc) return fail(QM_E_IO, "cannot write hash_info.bph / hash_info.val");
   } else {
     uint64_t tsize = 32;
@@ -522,8 +545,10 @@ extern "C" int qm_build_index_ex(const char* fasta_path, const char* out_dir_c, 
     for (uint64_t p = 0; p < tsize; ++p) {
       uint32_t r = slotOf[p];
       if (r == 0xFFFFFFFFu) continue;
-      uint8_t b[16]; memcpy(b, &runs[r].key, 8); memcpy(b + 8, &runs[r].lb, 4); memcpy(b + 12, &runs[r].ub, 4);
-      rec.insert(rec.end(), b, b + 16);
+      uint8_t b[24]; memcpy(b, &runs[r].key, 8);          // {key, SAInterval<IndexT>}: 16 bytes, 24 in a BigSA index
+      if (big) { memcpy(b + 8, &runs[r].lb, 8); memcpy(b + 16, &runs[r].ub, 8); }
+      else { const int32_t l32 = (int32_t)runs[r].lb, u32 = (int32_t)runs[r].ub; memcpy(b + 8, &l32, 4); memcpy(b + 12, &u32, 4); }
+      rec.insert(rec.end(), b, b + (big ? 24 : 16));
       if (rec.size() >= (1 << 20)) { fwrite(rec.data(), 1, rec.size(), o); rec.clear(); }
     }
     if (!rec.empty()) fwrite(rec.data(), 1, rec.size(), o);
@@ -533,8 +558,8 @@ extern "C" int qm_build_index_ex(const char* fasta_path, const char* out_dir_c, 
     char js[1024];
     snprintf(js, sizeof(js),
              "{\n    \"value0\": {\n    \"IndexType\": 1,\n    \"IndexVersion\": \"q5\",\n    \"UsesKmers\": true,\n"
-             "    \"KmerLen\": %d,\n    \"BigSA\": false,\n    \"PerfectHash\": %s,\n    \"SeqHash\": \"\",\n"
-             "    \"NameHash\": \"\",\n    \"SeqHash512\": \"\",\n    \"NameHash512\": \"\"\n    }\n}", k, perfect_hash ? "true" : "false");
+             "    \"KmerLen\": %d,\n    \"BigSA\": %s,\n    \"PerfectHash\": %s,\n    \"SeqHash\": \"\",\n"
+             "    \"NameHash\": \"\",\n    \"SeqHash512\": \"\",\n    \"NameHash512\": \"\"\n    }\n}", k, big ? "true" : "false", perfect_hash ? "true" : "false");
     if (!writeAll(outDir + "header.json", js, strlen(js))) return fail(QM_E_IO, "cannot write header.json");
     std::string ri = std::string("{\n    \"ReferenceFiles\": [\n        \"") + fasta_path + "\"\n    ]\n}";
     writeAll(outDir + "refInfo.json", ri.data(), ri.size());

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256, 4) void qm_h2m_kernel(DevIndex ix, ReadBatch B
         const int l = (int)(threadIdx.x & 63);
         const bool rc = h.query_rc != 0;
         const int idx = rc ? ri.n + popc64(rm & lanemask_lt(l)) : fi.n + popc64(fm & lanemask_lt(l));
-        IntRec r; r.b = h.begin; r.e = h.end; r.len = h.len; r.q = h.query_pos;
+        IntRec r; r.b = (u32)h.begin; r.e = (u32)h.end; r.len = h.len; r.q = h.query_pos;
         IntervalList& L = rc ? ri : fi;
         if (idx < QM_ICAP) { L.lds[idx].b = r.b; L.lds[idx].e = r.e; L.lds[idx].len = r.len; L.lds[idx].q = r.q; }
         else L.ovf[idx - QM_ICAP] = r;
@@ -178,34 +178,34 @@ __global__ __launch_bounds__(256) void qm_sel_compact_kernel(PairBatch P, const 
   for (int i = 0; i < c; ++i) P.hits[P.offs[u] + i] = tmp[toff[u] + i];
 }
 
-__global__ void build_sainfo_kernel(const int* SA, long long nSA, const int* offsets, long long T, SaInfo* out) {
+__global__ void build_sainfo_kernel(const u32* SA, long long nSA, const u32* offsets, long long T, SaInfo* out) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long stride = (long long)gridDim.x * blockDim.x;
   for (; i < nSA; i += stride) {
-    int p = SA[i];
+    const u32 p = SA[i];
     long long lo = 0, hi = T;   // upper_bound(offsets, p) - 1  == #'$' in text[0,p)
     while (lo < hi) { long long mid = (lo + hi) >> 1; if (offsets[mid] <= p) lo = mid + 1; else hi = mid; }
     long long tid = lo - 1;
-    SaInfo e; e.tid = (u32)tid; e.pos = p - offsets[tid];
+    SaInfo e; e.tid = (u32)tid; e.pos = (int)(p - offsets[tid]);
     out[i] = e;
   }
 }
 
 // the 96 text characters behind the k-mer of every suffix, packed (saext_entry): one-trip MMP extensions
-__global__ void build_saext_kernel(const unsigned char* text, long long n, const int* SA, long long nSA, int k, const SaInfo* sainfo, SaExt* out) {
+__global__ void build_saext_kernel(const unsigned char* text, long long n, const u32* SA, long long nSA, int k, const SaInfo* sainfo, SaExt* out) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long stride = (long long)gridDim.x * blockDim.x;
   for (; i < nSA; i += stride) { const SaInfo si = sainfo[i]; out[i] = saext_entry(text, n, (long long)SA[i] + k, si.tid, si.pos); }
 }
 
 // -s: the text characters behind the k-mer of every suffix (sanext_entry)
-__global__ void build_sanext_kernel(const unsigned char* text, long long n, const int* SA, long long nSA, int k, u32* out) {
+__global__ void build_sanext_kernel(const unsigned char* text, long long n, const u32* SA, long long nSA, int k, u32* out) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (; i < nSA; i += stride) out[i] = sanext_entry(text, n, (long long)SA[i] + k);
 }
 
-// records: K x {u64 key, i32 lb, i32 ub} exactly as streamed from hash.bin
+// records: K x {u64 key, u32 lb, u32 ub}: the records of hash.bin (a BigSA index's int64 pairs narrowed by the loader)
 __global__ void build_slots_kernel(const Slot* recs, long long K, Bucket* buckets, u64 hmask) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long stride = (long long)gridDim.x * blockDim.x;
@@ -217,7 +217,7 @@ __global__ void build_slots_kernel(const Slot* recs, long long K, Bucket* bucket
       int got = -1;
       for (int t = 0; t < 2 && got < 0; ++t)
         if (atomicCAS((unsigned long long*)&bk->key[t], ~0ULL, r.key) == ~0ULL) got = t;
-      if (got >= 0) { bk->val[got].lb = r.lb; bk->val[got].ub = r.ub; break; }
+      if (got >= 0) { bk->val[got].lb = (u32)r.lb; bk->val[got].ub = (u32)r.ub; break; }
       atomicOr((unsigned long long*)&bk->key[0], QM_BK_OVF);      // full: remember that lookups must walk on
       b = (b + 1) & hmask;
     }
@@ -225,13 +225,13 @@ __global__ void build_slots_kernel(const Slot* recs, long long K, Bucket* bucket
 }
 
 // perfect-hash value records: {k-mer word at text[SA[data_[i]]] (partial word if a '$' is hit), data_[i], lens_[i]}
-__global__ void build_phrec_kernel(const int* data, const unsigned char* lens, long long n, DevIndex ix, PhRec* out) {
+__global__ void build_phrec_kernel(const u32* data, const unsigned char* lens, long long n, DevIndex ix, PhRec* out) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long stride = (long long)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
     PhRec r; r.data = data[i]; r.len = lens[i]; r.pad[0] = r.pad[1] = r.pad[2] = 0;
     u64 m = 0;
-    if (r.data >= 0 && r.data < ix.nSA) text_kmer(ix, (long long)ix.SA[r.data], ix.k, m);
+    if ((long long)r.data < ix.nSA) text_kmer(ix, (long long)ix.SA[r.data], ix.k, m);
     r.key = m;
     out[i] = r;
   }
@@ -259,7 +259,7 @@ __global__ void build_slots_from_ph_kernel(DevIndex ix, long long n, Bucket* buc
   const PhIndex& P = ix.phv;
   for (; i < n; i += stride) {
     const PhRec r = P.recs[i];
-    int lb = 0, ub = 0;
+    u32 lb = 0, ub = 0;
     const bool found = find_kmer<QM_F_PH>(ix, r.key, lb, ub);
     if (!found || lb != r.data) { atomicAdd(bad, 1ULL); continue; }
     u64 b = (u64)bucket_hash(r.key) & hmask;
@@ -283,16 +283,16 @@ using namespace qm;
 
 extern "C" {
 
-hipError_t qmk_build_sainfo(const int* SA, long long nSA, const int* offsets, long long T, void* out, hipStream_t st) {
+hipError_t qmk_build_sainfo(const unsigned int* SA, long long nSA, const unsigned int* offsets, long long T, void* out, hipStream_t st) {
   hipLaunchKernelGGL(build_sainfo_kernel, dim3(4096), dim3(256), 0, st, SA, nSA, offsets, T, (SaInfo*)out);
   return hipGetLastError();
 }
 
-hipError_t qmk_build_saext(const unsigned char* text, long long n, const int* SA, long long nSA, int k, const void* sainfo, void* out, hipStream_t st) {
+hipError_t qmk_build_saext(const unsigned char* text, long long n, const unsigned int* SA, long long nSA, int k, const void* sainfo, void* out, hipStream_t st) {
   if (nSA > 0) hipLaunchKernelGGL(build_saext_kernel, dim3(8192), dim3(256), 0, st, text, n, SA, nSA, k, (const SaInfo*)sainfo, (SaExt*)out);
   return hipGetLastError();
 }
-hipError_t qmk_build_sanext(const unsigned char* text, long long n, const int* SA, long long nSA, int k, unsigned int* out, hipStream_t st) {
+hipError_t qmk_build_sanext(const unsigned char* text, long long n, const unsigned int* SA, long long nSA, int k, unsigned int* out, hipStream_t st) {
   if (nSA > 0) hipLaunchKernelGGL(build_sanext_kernel, dim3(4096), dim3(256), 0, st, text, n, SA, nSA, k, out);
   return hipGetLastError();
 }
@@ -312,7 +312,7 @@ hipError_t qmk_build_slots_from_ph(const void* dev_index, long long n, void* slo
   return hipGetLastError();
 }
 
-hipError_t qmk_build_phrecs(const int* data, const unsigned char* lens, long long n, const void* dev_index, void* out, hipStream_t st) {
+hipError_t qmk_build_phrecs(const unsigned int* data, const unsigned char* lens, long long n, const void* dev_index, void* out, hipStream_t st) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(build_phrec_kernel, dim3(4096), dim3(256), 0, st, data, lens, n, *(const DevIndex*)dev_index, (PhRec*)out);
   return hipGetLastError();

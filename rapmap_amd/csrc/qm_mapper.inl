@@ -50,7 +50,10 @@ namespace qm {
 #define QM_LCNT_SLOW 0x7fffffffu   // lcnt value of a read waiting on the slow queue
 
 struct Slot { u64 key; int lb; int ub; };          // hash.bin record / small linear-probing tables, key == ~0 empty
-struct Iv { int lb, ub; };                         // seed interval
+// SA indexes and text positions are UNSIGNED 32-bit on the device: an index whose text needs the reference's int64 instantiation
+// (BigSA, text > 2^31 - 1 characters) fits as long as the text is below 2^32 - 2 characters, at half the bytes per SA entry
+// and per interval of the reference's int64 form
+struct Iv { u32 lb, ub; };                         // seed interval
 // Dense k-mer table: 32-byte buckets of two keys and their two intervals, two buckets to an HBM sector, at least two
 // buckets per key (load <= 25 % of the slots).  A lookup is ONE round of two 16-byte loads -- the keys and, in the same
 // round, the intervals -- with no probe chain and no dependent load for the value.  Keys are 2k <= 62 bits; ~0 marks an
@@ -68,7 +71,7 @@ QM_DEV u32 bucket_hash(u64 key) {
   return (u32)(p >> 32) ^ (u32)p;
 }
 struct SaInfo { u32 tid; int pos; };               // transcript id + offset in transcript of SA[i]
-struct IntRec { int b, e; u32 len, q; };           // SAIntervalHit (RapMapUtils.hpp:516-525)
+struct IntRec { u32 b, e; u32 len, q; };           // SAIntervalHit (RapMapUtils.hpp:516-525)
 
 // Perfect-hash (`quasiindex -p`) seed map, flattened: BooPHF levels + FrugalBooMap values
 // (include/BooPHF.hpp, include/FrugalBooMap.hpp).  The level bit arrays are re-blocked so that one 64-byte
@@ -82,8 +85,8 @@ struct IntRec { int b, e; u32 len, q; };           // SAIntervalHit (RapMapUtils
 #ifndef QM_PH_SPEC
 #define QM_PH_SPEC 3      // BooPHF levels looked up per round of loads
 #endif
-struct OvfSlot { int key; int val; };              // overflow_: interval start -> length (>= 255); key -1 empty
-struct PhRec { u64 key; int data; unsigned char len; unsigned char pad[3]; };
+struct OvfSlot { u32 key; u32 val; };              // overflow_: interval start -> length (>= 255); key ~0 empty
+struct PhRec { u64 key; u32 data; unsigned char len; unsigned char pad[3]; };
 struct PhIndex {
   const u64* blocks;            // 8 u64 per block: 6 words of bits, rank of the first bit, 6 x 9-bit popcount prefix
   const u64* levelTab;
@@ -111,7 +114,7 @@ inline constexpr u64 ph_filter_words(u64 nelem) { u64 c = 64; while (c < nelem /
 struct DevIndex {
   const unsigned char* text;  // n bytes + >= 64 bytes of zero padding
   long long n;
-  const int* SA;
+  const u32* SA;
   long long nSA;
   const SaInfo* sainfo;
   const Bucket* slots;        // dense index: hmask + 1 buckets (null for a perfect-hash index)
@@ -377,7 +380,7 @@ QM_DEV void find_dense_round(const DevIndex& ix, const LV<u64>& key, const LV<bo
     const u64 k0r = ((u64)a.y << 32) | a.x, k1 = ((u64)a.w << 32) | a.z;
     const u64 k0 = k0r == ~0ULL ? k0r : (k0r & ~QM_BK_OVF);
     const bool h0 = k0 == key[l], h1 = k1 == key[l];
-    Iv v; v.lb = (int)(h0 ? c.x : c.z); v.ub = (int)(h0 ? c.y : c.w);
+    Iv v; v.lb = h0 ? c.x : c.z; v.ub = h0 ? c.y : c.w;
     const bool h = want[l] && (h0 || h1);
     if (!h) { v.lb = 0; v.ub = 0; }
     hit[l] = h; val[l] = v;
@@ -394,8 +397,8 @@ QM_DEV void find_dense_round(const DevIndex& ix, const LV<u64>& key, const LV<bo
           QM_CNT(1, 1);
           const u64 k0r = ((u64)a.y << 32) | a.x, k1 = ((u64)a.w << 32) | a.z;
           const u64 k0 = k0r == ~0ULL ? k0r : (k0r & ~QM_BK_OVF);
-          if (k0 == key[l]) { hit[l] = true; val[l].lb = (int)c.x; val[l].ub = (int)c.y; break; }
-          if (k1 == key[l]) { hit[l] = true; val[l].lb = (int)c.z; val[l].ub = (int)c.w; break; }
+          if (k0 == key[l]) { hit[l] = true; val[l].lb = c.x; val[l].ub = c.y; break; }
+          if (k1 == key[l]) { hit[l] = true; val[l].lb = c.z; val[l].ub = c.w; break; }
           if (k0r == ~0ULL || !(k0r & QM_BK_OVF)) break;
           b = (b + 1) & ix.hmask;
         }
@@ -419,7 +422,7 @@ QM_DEV void ph_filter_round(const DevIndex& ix, const LV<u64>& key, LV<bool>& wa
 }
 
 template <int F>
-QM_DEV bool find_kmer(const DevIndex& ix, u64 key, int& lb, int& ub) {     // perfect-hash flavour only (dense: find_dense_round)
+QM_DEV bool find_kmer(const DevIndex& ix, u64 key, u32& lb, u32& ub) {     // perfect-hash flavour only (dense: find_dense_round)
   const PhIndex& P = ix.phv;
   u64 s0 = 0, s1 = 0, h = 0;
   u64 idx = 0;
@@ -470,11 +473,11 @@ QM_DEV bool find_kmer(const DevIndex& ix, u64 key, int& lb, int& ub) {     // pe
   if (idx >= P.nelem) return false;                         // FrugalBooMap.hpp:151
   const U4 rr = load_16(&P.recs[idx]);                      // {key lo, key hi, data, len}
   if ((((u64)rr.y << 32) | rr.x) != key) return false;      // Kmer(txt + SA[data_[idx]]) == key, precomputed
-  const int ind = (int)rr.z;
-  int l = (int)(rr.w & 0xff);
+  const u32 ind = rr.z;
+  u32 l = rr.w & 0xff;
   if (l == 255) {
-    u64 i = hash_mix((u64)(u32)ind) & P.ovfMask;
-    while (true) { OvfSlot x = P.ovf[i]; if (x.key == ind) { l = x.val; break; } if (x.key == -1) { l = 0; break; } i = (i + 1) & P.ovfMask; }
+    u64 i = hash_mix((u64)ind) & P.ovfMask;
+    while (true) { OvfSlot x = P.ovf[i]; if (x.key == ind) { l = x.val; break; } if (x.key == ~0u) { l = 0; break; } i = (i + 1) & P.ovfMask; }
   }
   lb = ind; ub = ind + l;
   return true;
@@ -847,7 +850,7 @@ struct IntervalList {
   QM_LDS(IntRec)* lds; IntRec* ovf;
   int n;
   u32* pf; int pfcap;      // LDS staging for the (tid, pos) of the first interval's suffixes: tids at pf[0..), positions at pf[pfcap..)
-  QM_DEV void push(int lb, int ub, u32 ln, u32 qp) {
+  QM_DEV void push(u32 lb, u32 ub, u32 ln, u32 qp) {
     IntRec r; r.b = lb; r.e = ub; r.len = ln; r.q = qp;
     // a branch per home, not one pointer that is either: that would be a FLAT store (vector-memory path even into LDS)
     if (n < QM_ICAP) { QM_LANES(l) { if (l == 0) { lds[n].b = r.b; lds[n].e = r.e; lds[n].len = r.len; lds[n].q = r.q; } } }
@@ -855,7 +858,7 @@ struct IntervalList {
     ++n;
     wave_fence();
   }
-  QM_DEV void get(int i, int& lb, int& ub, u32& ln, u32& qp) const {
+  QM_DEV void get(int i, u32& lb, u32& ub, u32& ln, u32& qp) const {
     IntRec r;
     if (i < QM_ICAP) { r.b = lds[i].b; r.e = lds[i].e; r.len = lds[i].len; r.q = lds[i].q; }
     else r = ovf[i - QM_ICAP];
@@ -901,9 +904,9 @@ QM_DEV int cmp_from(const DevIndex& ix, long long s, const unsigned char* q, int
 // The wave is split into groups of G = 64 / 2^ceil(log2(width)) lanes, one group per suffix; lane c of a group
 // compares the 16 bytes at offset 16c of the current round, so a 2x100 bp read needs one round for up to 8
 // suffixes: one coalesced SA load, then one round of text loads, instead of a dependent load per 8 bytes.
-QM_DEV bool extend_search_wide(const DevIndex& ix, int lbIn, int ubIn, int startAt, const unsigned char* q, int m0,
-                               int& lbOut, int& ubOut, int& lenOut, u32 qn, int nq, const ExtQuery* xq, ExtStage* xs) {
-  const int width = ubIn - lbIn - 1;
+QM_DEV bool extend_search_wide(const DevIndex& ix, u32 lbIn, u32 ubIn, int startAt, const unsigned char* q, int m0,
+                               u32& lbOut, u32& ubOut, int& lenOut, u32 qn, int nq, const ExtQuery* xq, ExtStage* xs) {
+  const int width = (int)(ubIn - lbIn - 1);
   if (width < 1 || width > 64) return false;
   if (xq && xq->nq >= 0 && ix.saext && !(nq > 0 && ix.sanext)) {
     // a clean strand: the query's characters behind the k-mer against the packed characters behind every suffix's k-mer --
@@ -1035,15 +1038,15 @@ QM_DEV bool extend_search_wide(const DevIndex& ix, int lbIn, int ubIn, int start
 }
 
 // SASearcher::extendSearchNaive (SASearcher.hpp:88-309)
-QM_DEV void extend_search(const DevIndex& ix, int lbIn, int ubIn, int startAt, const unsigned char* q, int m0,
-                          int& lbOut, int& ubOut, int& lenOut, bool qDollar, u32 qn = 0, int nq = 0, const ExtQuery* xq = nullptr,
+QM_DEV void extend_search(const DevIndex& ix, u32 lbIn, u32 ubIn, int startAt, const unsigned char* q, int m0,
+                          u32& lbOut, u32& ubOut, int& lenOut, bool qDollar, u32 qn = 0, int nq = 0, const ExtQuery* xq = nullptr,
                           ExtStage* xs = nullptr) {
   int rel;
   if (!qDollar && extend_search_wide(ix, lbIn, ubIn, startAt, q, m0, lbOut, ubOut, lenOut, qn, nq, xq, xs)) return;
   QM_CNT(8, 1);
   if (ubIn - lbIn == 2) {                         // :109-126
     lbIn += 1;
-    long long s = uniform((int)ix.SA[lbIn]);
+    long long s = (long long)uniform(ix.SA[lbIn]);
     int i = cmp_from(ix, s, q, m0, startAt, 0, rel);
     lbOut = lbIn; ubOut = ubIn; lenOut = i;
     return;
@@ -1053,7 +1056,7 @@ QM_DEV void extend_search(const DevIndex& ix, int lbIn, int ubIn, int startAt, c
   while (true) {                                  // :150-209
     c = (l + r) / 2;
     i = lcpLP < lcpRP ? lcpLP : lcpRP;
-    long long s = uniform((int)ix.SA[c]);
+    long long s = (long long)uniform(ix.SA[c]);
     i = cmp_from(ix, s, q, m0, i, 0, rel);
     bool plt = rel != 2;
     if (rel == 2) { if (i > prevILow) prevILow = i; }
@@ -1076,7 +1079,7 @@ QM_DEV void extend_search(const DevIndex& ix, int lbIn, int ubIn, int startAt, c
     while (true) {
       c = (l + r) / 2;
       i = lcpLP < lcpRP ? lcpLP : lcpRP;
-      long long s = uniform((int)ix.SA[c]);
+      long long s = (long long)uniform(ix.SA[c]);
       i = cmp_from(ix, s, q, m, i, sentinel, rel);
       if (rel != 2) { if (c == l + 1) { res = c; break; } r = c; lcpRP = i; }
       else { if (c == r - 1) { res = r; break; } l = c; lcpLP = i; }
@@ -1084,15 +1087,15 @@ QM_DEV void extend_search(const DevIndex& ix, int lbIn, int ubIn, int startAt, c
     if (pass == 0) bound1 = res; else bound2 = res;
   }
   if (bound1 == bound2) bound2 += 1;              // :307
-  lbOut = (int)bound1; ubOut = (int)bound2; lenOut = maxLen;
+  lbOut = (u32)bound1; ubOut = (u32)bound2; lenOut = maxLen;
 }
 
 // SASearcher::lce (SASearcher.hpp:318-334), NIP only.  Restated literally, including its double use of
 // startAt (o1/o2 already contain it and `len` starts from it again).
-QM_DEV int lce_wave(const DevIndex& ix, int p1, int p2, int startAt, int stopAt) {
-  const long long o1 = (long long)uniform((int)ix.SA[p1]) + startAt, o2 = (long long)uniform((int)ix.SA[p2]) + startAt;
+QM_DEV int lce_wave(const DevIndex& ix, u32 p1, u32 p2, int startAt, int stopAt) {
+  const long long o1 = (long long)uniform(ix.SA[p1]) + startAt, o2 = (long long)uniform(ix.SA[p2]) + startAt;
   const long long maxIndex = o1 > o2 ? o1 : o2;
-  const long long textLen = (long long)(int)ix.n;
+  const long long textLen = ix.n;
   int base = startAt;
   while (true) {
     LV<bool> stopv;
@@ -1133,7 +1136,7 @@ QM_DEV void ext_query(const u64* planes, int pos, int rem, ExtQuery& xq) {
 // SACollector::getSAHits_ (SACollector.hpp:441-677), NIP disabled
 template <int NS, int F>
 QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, const unsigned char* str, int L,
-                        int startPos, bool haveInterval, int lb, int ub, long long& cov, u32& strandHits,
+                        int startPos, bool haveInterval, u32 lb, u32 ub, long long& cov, u32& strandHits,
                         u32& otherHits, IntervalList& out) {
   const int k = ix.k, P = L - k + 1;
   QM_CNT(17, 1);
@@ -1170,7 +1173,7 @@ QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, c
       lb = uniform(v.lb); ub = uniform(v.ub);
     }
     skip = false;
-    lb = lb - 1 > 0 ? lb - 1 : 0;                      // :553
+    lb = lb ? lb - 1 : 0;                              // :553
     int mlen;
     QM_CNT(18, 1); QM_T(4);
     // the strand's characters behind this k-mer, packed like the entries of ix.saext (clean strands only)
@@ -1186,7 +1189,7 @@ QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, c
       // one is cut at k + maxMMPExtension characters; a first MMP longer than that (and shorter than the read) is redone cut
       const int cut = p + k + B.max_mmp_ext < L ? p + k + B.max_mmp_ext : L;
       const bool firstAttempt = p == 0;
-      const int lbP = lb, ubP = ub;
+      const u32 lbP = lb, ubP = ub;
       // the characters a capped extension may use, packed like the entries of ix.sanext (clean strands only: the image
       // holds nothing but A C G T there)
       const int nqc = cut - p - k;
@@ -1200,12 +1203,12 @@ QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, c
     QM_T(3);
     const bool more = !lastSearch && p + mlen < L;     // the walk continues at kp after this MMP
     const int kp = p + mlen - (k - 1);
-    if (ub > lb && ub - lb < B.max_interval) {          // :577-618
-      if (!(F & QM_F_SEL) && out.n == 0 && ub - lb <= out.pfcap && !xs.done) {
+    if (ub > lb && ub - lb < (u32)B.max_interval) {     // :577-618
+      if (!(F & QM_F_SEL) && out.n == 0 && ub - lb <= (u32)out.pfcap && !xs.done) {
         // three reads in four end with exactly one interval per strand, whose (tid, pos) entries hits->mappings needs next:
         // ask for them now, straight into LDS, so that the trip to sainfo runs under the rest of the walk
         QM_LANES(l) {
-          if (l < ub - lb) { const u32* g = (const u32*)&ix.sainfo[lb + l]; lds_dma_u32(g, out.pf, l); lds_dma_u32(g + 1, out.pf + out.pfcap, l); }
+          if (l < (int)(ub - lb)) { const u32* g = (const u32*)&ix.sainfo[lb + l]; lds_dma_u32(g, out.pf, l); lds_dma_u32(g + 1, out.pf + out.pfcap, l); }
         }
       }
       out.push(lb, ub, (u32)mlen, (u32)p);
@@ -1441,8 +1444,8 @@ QM_DEV int unique_emit(const u64* sorted, int n, int shift, u64* dst, int dstOff
 struct Bufs { u64* A; u64* B; u64* R; };   // sort ping-pong + the read's output list
 
 // collectFromSingleInterval (HitManager.cpp:716-807, considerMultiPos == false)
-QM_DEV int single_interval(const DevIndex& ix, const Bufs& bf, int rOff, int lb, int ub, u32 qpos, bool isRC, const u32* pf, int pfcap) {
-  int n = ub - lb;
+QM_DEV int single_interval(const DevIndex& ix, const Bufs& bf, int rOff, u32 lb, u32 ub, u32 qpos, bool isRC, const u32* pf, int pfcap) {
+  int n = (int)(ub - lb);
   QM_CNT(12, 1); QM_CNT(13, n);
   if (pf && n <= pfcap) {                                // the only interval of the list is the first one recorded: staged by get_sa_hits
     lds_dma_wait();
@@ -1472,8 +1475,8 @@ QM_DEV int single_interval(const DevIndex& ix, const Bufs& bf, int rOff, int lb,
 // a lane's entry survives when no other entry of its transcript sorts before it (position, then input order -- the first
 // element of the transcript's run in the stable sort of :761-767), and goes to the slot given by the number of surviving
 // entries with a smaller transcript id.  No sort buffers, no trips through LDS but the one that delivers the list.
-QM_DEV int single_interval_small(const DevIndex& ix, u64* R, int rOff, int lb, int ub, u32 qpos, bool isRC, const u32* pf, int pfcap) {
-  const int n = ub - lb;
+QM_DEV int single_interval_small(const DevIndex& ix, u64* R, int rOff, u32 lb, u32 ub, u32 qpos, bool isRC, const u32* pf, int pfcap) {
+  const int n = (int)(ub - lb);
   QM_CNT(12, 1); QM_CNT(13, n);
   LV<u64> e;
   if (pf && n <= pfcap) {                                // staged by get_sa_hits while the walk went on
@@ -1511,11 +1514,11 @@ QM_DEV int multi_interval(const DevIndex& ix, const Bufs& bf, int rOff, const In
   QM_CNT(14, 1); QM_CNT(15, m);
   int minIdx = 0, minSpan = 0x7fffffff;
   for (int i = 0; i < m; ++i) {                       // first smallest span (:636-641)
-    int lb, ub; u32 ln, qp; ints.get(i, lb, ub, ln, qp);
-    if (ub - lb < minSpan) { minSpan = ub - lb; minIdx = i; }
+    u32 lb, ub, ln, qp; ints.get(i, lb, ub, ln, qp);
+    if ((int)(ub - lb) < minSpan) { minSpan = (int)(ub - lb); minIdx = i; }
   }
-  int lb0, ub0; u32 ln0, q0; ints.get(minIdx, lb0, ub0, ln0, q0);
-  int n0 = ub0 - lb0;
+  u32 lb0, ub0, ln0, q0; ints.get(minIdx, lb0, ub0, ln0, q0);
+  int n0 = (int)(ub0 - lb0);
   for (int base = 0; base < n0; base += 64) {
     QM_LANES(l) {
       int i = base + l;
@@ -1538,8 +1541,8 @@ QM_DEV int multi_interval(const DevIndex& ix, const Bufs& bf, int rOff, const In
   for (int ii = 0; ii < m; ++ii) {
     if (ii == minIdx) continue;
     ++order;                                          // intervalCounter - 1
-    int lb, ub; u32 ln, qp; ints.get(ii, lb, ub, ln, qp);
-    int n = ub - lb;
+    u32 lb, ub, ln, qp; ints.get(ii, lb, ub, ln, qp);
+    int n = (int)(ub - lb);
     for (int base = 0; base < n; base += 64) {
       QM_LANES(l) {
         int i = base + l;
@@ -1580,7 +1583,7 @@ QM_DEV int multi_interval(const DevIndex& ix, const Bufs& bf, int rOff, const In
     LV<u32> qps;
     QM_LANES(l) { qps[l] = 0; }
     for (int ii = 0; ii < m; ++ii) {
-      int lb, ub; u32 ln, qp; ints.get(ii, lb, ub, ln, qp);
+      u32 lb, ub, ln, qp; ints.get(ii, lb, ub, ln, qp);
       QM_LANES(l) { if (iidx[l] == ii) qps[l] = qp; }
     }
     u64 am = ballot(act);
@@ -1606,14 +1609,14 @@ QM_DEV int hits_to_mappings(const DevIndex& ix, const Bufs& bf, const IntervalLi
   int nf = 0, nr = 0;
   if (fwdInts.n > 1) nf = multi_interval(ix, bf, 0, fwdInts, false);
   else if (fwdInts.n == 1) {
-    int lb, ub; u32 ln, qp; fwdInts.get(0, lb, ub, ln, qp);
-    nf = ub - lb <= 64 ? single_interval_small(ix, bf.R, 0, lb, ub, qp, false, fwdInts.pf, fwdInts.pfcap)
+    u32 lb, ub, ln, qp; fwdInts.get(0, lb, ub, ln, qp);
+    nf = ub - lb <= 64u ? single_interval_small(ix, bf.R, 0, lb, ub, qp, false, fwdInts.pf, fwdInts.pfcap)
                        : single_interval(ix, bf, 0, lb, ub, qp, false, fwdInts.pf, fwdInts.pfcap);
   }
   if (rcInts.n > 1) nr = multi_interval(ix, bf, nf, rcInts, true);
   else if (rcInts.n == 1) {
-    int lb, ub; u32 ln, qp; rcInts.get(0, lb, ub, ln, qp);
-    nr = ub - lb <= 64 ? single_interval_small(ix, bf.R, nf, lb, ub, qp, true, rcInts.pf, rcInts.pfcap)
+    u32 lb, ub, ln, qp; rcInts.get(0, lb, ub, ln, qp);
+    nr = ub - lb <= 64u ? single_interval_small(ix, bf.R, nf, lb, ub, qp, true, rcInts.pf, rcInts.pfcap)
                        : single_interval(ix, bf, nf, lb, ub, qp, true, rcInts.pf, rcInts.pfcap);
   }
   if (nf > 0 && nr > 0) {
@@ -1637,7 +1640,7 @@ QM_DEV int list_bound(const IntervalList& a, const IntervalList& b) {
   const IntervalList* ls[2] = {&a, &b};
   for (int t = 0; t < 2; ++t) {
     int m = ls[t]->n, mn = 0x7fffffff;
-    for (int i = 0; i < m; ++i) { int lb, ub; u32 ln, qp; ls[t]->get(i, lb, ub, ln, qp); if (ub - lb < mn) mn = ub - lb; }
+    for (int i = 0; i < m; ++i) { u32 lb, ub, ln, qp; ls[t]->get(i, lb, ub, ln, qp); if ((int)(ub - lb) < mn) mn = (int)(ub - lb); }
     if (m > 0) tot += mn;
   }
   return tot;
@@ -1670,10 +1673,10 @@ QM_DEV void dump_intervals(const ReadBatch& B, long long read, int mate, const I
     const IntervalList& L = t == 0 ? F : R;
     const long long o = base + (t == 0 ? 0 : F.n);
     for (int i = 0; i < L.n; ++i) {
-      int lb, ub; u32 ln, qp; L.get(i, lb, ub, ln, qp);
+      u32 lb, ub, ln, qp; L.get(i, lb, ub, ln, qp);
       QM_LANES(l) {
         if (l == 0) {
-          qm_sa_interval_hit h; h.begin = lb; h.end = ub; h.len = ln; h.query_pos = qp;
+          qm_sa_interval_hit h; h.begin = (int)lb; h.end = (int)ub; h.len = ln; h.query_pos = qp;
           h.query_rc = (uint8_t)t; h.list = (uint8_t)(2 * mate + t); h.pad = 0;
           B.iv_out[o + i] = h;
         }

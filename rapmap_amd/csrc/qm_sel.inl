@@ -439,21 +439,22 @@ QM_DEV int sel_h2m_on(const DevIndex& ix, const ReadBatch& B, const IntervalList
   for (int s = 0; s < 2; ++s) {
     const IntervalList& L = s == 0 ? fwdInts : rcInts;
     int n = 0;
-    for (int ii = 0; ii < L.n; ++ii) { int lb, ub; u32 ln, qp; L.get(ii, lb, ub, ln, qp); n += ub - lb; }
+    for (int ii = 0; ii < L.n; ++ii) { u32 lb, ub, ln, qp; L.get(ii, lb, ub, ln, qp); n += (int)(ub - lb); }
     if (n > S.cap()) return -1;
     if (n <= 64 * SS::NCH) {
       // the usual case: one lane per suffix over all the intervals at once -- one trip to sainfo per 64 suffixes of the strand
       for (int base = 0; base < n; base += 64) {
-        LV<int> sa; LV<u32> qv, lv, iv;
-        QM_LANES(l) { sa[l] = -1; qv[l] = 0; lv[l] = 0; iv[l] = 0; }
+        LV<u32> sa, qv, lv, iv; LV<bool> hs;
+        QM_LANES(l) { sa[l] = 0; hs[l] = false; qv[l] = 0; lv[l] = 0; iv[l] = 0; }
         int acc = 0;
         for (int ii = 0; ii < L.n && acc < base + 64; ++ii) {
-          int lb, ub; u32 ln, qp; L.get(ii, lb, ub, ln, qp);
-          QM_LANES(l) { const int i = base + l; if (i >= acc && i < acc + (ub - lb)) { sa[l] = lb + (i - acc); qv[l] = qp; lv[l] = ln; iv[l] = (u32)ii; } }
-          acc += ub - lb;
+          u32 lb, ub, ln, qp; L.get(ii, lb, ub, ln, qp);
+          const int span = (int)(ub - lb);
+          QM_LANES(l) { const int i = base + l; if (i >= acc && i < acc + span) { sa[l] = lb + (u32)(i - acc); hs[l] = true; qv[l] = qp; lv[l] = ln; iv[l] = (u32)ii; } }
+          acc += span;
         }
         QM_LANES(l) {
-          if (sa[l] >= 0) {
+          if (hs[l]) {
             SaInfo e = ix.sainfo[sa[l]];
             SelRec r; r.tid = e.tid; r.pos = (u32)e.pos; r.qpos = qv[l]; r.len = lv[l]; r.iv = iv[l];
             S.rec[base + l] = r;
@@ -463,8 +464,8 @@ QM_DEV int sel_h2m_on(const DevIndex& ix, const ReadBatch& B, const IntervalList
     } else {
       n = 0;
       for (int ii = 0; ii < L.n; ++ii) {
-        int lb, ub; u32 ln, qp; L.get(ii, lb, ub, ln, qp);
-        const int cnt = ub - lb;
+        u32 lb, ub, ln, qp; L.get(ii, lb, ub, ln, qp);
+        const int cnt = (int)(ub - lb);
         for (int base = 0; base < cnt; base += 64) {
           QM_LANES(l) {
             int i = base + l;
@@ -508,7 +509,7 @@ QM_DEV int sel_hits_to_mappings(const DevIndex& ix, const ReadBatch& B, const In
     for (int s = 0; s < 2; ++s) {
       const IntervalList& I = s == 0 ? fwdInts : rcInts;
       int t = 0;
-      for (int ii = 0; ii < I.n; ++ii) { int lb, ub; u32 ln, qp; I.get(ii, lb, ub, ln, qp); t += ub - lb; }
+      for (int ii = 0; ii < I.n; ++ii) { u32 lb, ub, ln, qp; I.get(ii, lb, ub, ln, qp); t += (int)(ub - lb); }
       need = t > need ? t : need;
     }
     QM_LANES(l) { if (l == 0) { atomic_add_u64(B.cursor + QM_SC_SLOWCNT, 1ULL); atomic_max_u64(B.cursor + QM_SC_SLOWMAX, (u64)need); } }
@@ -523,7 +524,7 @@ QM_DEV int sel_hits_to_mappings(const DevIndex& ix, const ReadBatch& B, const In
 // ------------------------------------------------------------------ stages B + C: plan (per unit) -> ksw2 (four per wavefront) -> finish (per unit)
 struct SelBatch {                    // launch arguments of the -s kernels (on top of PairBatch)
   const unsigned char* seq1; const unsigned char* seq2;
-  const unsigned char* text; const int* txp_off; const int* txp_len;
+  const unsigned char* text; const u32* txp_off; const int* txp_len;
   qm_hit* tmp; const long long* toff;          // per-unit slots for jointHits before the filter
   u64* tkeys; int* tsc;                        // alignment cache entries, two per slot (left / right)
   int* tref;                                   // per slot-side: -1 score is final / pending in tsc, <= -2 copy of unit-local entry -(ref)-2

@@ -116,27 +116,37 @@ int run(RapMapIndexT& rmi, std::vector<ReadPair>& all, const char* outPath, bool
   return 0;
 }
 
+template <typename RapMapIndexT>
+int mainT(int argc, char** argv) {
+  RapMapIndexT rmi;
+  rmi.load(argv[1]);
+  std::printf("k %u txps %zu ph %d big %d\n", rmi.k(), rmi.txpNames.size(), (int)rmi.perfectHash(), (int)(sizeof(typename RapMapIndexT::IndexType) == 8));
+  if (argc < 4) return 0;
+  bool fuzzy = false, chain = false, prefetch = true, noOrphans = false, edit = false, refill = false, evensFirst = false; uint32_t maxNumHits = 200;
+  for (int i = 4; i < argc; ++i) {
+    if (!std::strcmp(argv[i], "--fuzzy")) fuzzy = true;
+    else if (!std::strcmp(argv[i], "--chain")) chain = true;
+    else if (!std::strcmp(argv[i], "--no-prefetch")) prefetch = false;
+    else if (!std::strcmp(argv[i], "--noOrphans")) noOrphans = true;
+    else if (!std::strcmp(argv[i], "--edit")) edit = true;
+    else if (!std::strcmp(argv[i], "--refill")) refill = true;
+    else if (!std::strcmp(argv[i], "--evens-first")) evensFirst = true;
+    else if (!std::strcmp(argv[i], "--maxNumHits") && i + 1 < argc) maxNumHits = (uint32_t)std::atoi(argv[++i]);
+  }
+  std::vector<ReadPair> all;
+  std::ifstream f(argv[2]); std::string a, b;
+  while (f >> a >> b) { ReadPair p; p.first.seq = a == "-" ? "" : a; p.second.seq = b == "-" ? "" : b; all.push_back(p); }
+  return run(rmi, all, argv[3], fuzzy, chain, prefetch, noOrphans, maxNumHits, edit, refill, evensFirst);
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) { std::fprintf(stderr, "usage: rapmap_caller INDEX [PAIRS OUT [flags]]\n"); return 2; }
   try {
-    SAIndex32BitDense rmi;                       // RapMapSAIndex<int32_t, RegHashT>
-    rmi.load(argv[1]);
-    std::printf("k %u txps %zu ph %d\n", rmi.k(), rmi.txpNames.size(), (int)rmi.perfectHash());
-    if (argc < 4) return 0;
-    bool fuzzy = false, chain = false, prefetch = true, noOrphans = false, edit = false, refill = false, evensFirst = false; uint32_t maxNumHits = 200;
-    for (int i = 4; i < argc; ++i) {
-      if (!std::strcmp(argv[i], "--fuzzy")) fuzzy = true;
-      else if (!std::strcmp(argv[i], "--chain")) chain = true;
-      else if (!std::strcmp(argv[i], "--no-prefetch")) prefetch = false;
-      else if (!std::strcmp(argv[i], "--noOrphans")) noOrphans = true;
-      else if (!std::strcmp(argv[i], "--edit")) edit = true;
-      else if (!std::strcmp(argv[i], "--refill")) refill = true;
-      else if (!std::strcmp(argv[i], "--evens-first")) evensFirst = true;
-      else if (!std::strcmp(argv[i], "--maxNumHits") && i + 1 < argc) maxNumHits = (uint32_t)std::atoi(argv[++i]);
-    }
-    std::vector<ReadPair> all;
-    std::ifstream f(argv[2]); std::string a, b;
-    while (f >> a >> b) { ReadPair p; p.first.seq = a == "-" ? "" : a; p.second.seq = b == "-" ? "" : b; all.push_back(p); }
-    return run(rmi, all, argv[3], fuzzy, chain, prefetch, noOrphans, maxNumHits, edit, refill, evensFirst);
+    // the instantiation is picked from header.json like `rapmap quasimap` does (src/RapMapSAMapper.cpp:1209-1240)
+    std::ifstream hf(std::string(argv[1]) + "/header.json");
+    std::string hs((std::istreambuf_iterator<char>(hf)), std::istreambuf_iterator<char>());
+    const size_t bp = hs.find("\"BigSA\"");
+    const bool big = bp != std::string::npos && hs.find("true", bp) < hs.find(',', bp);
+    return big ? mainT<SAIndex64BitDense>(argc, argv) : mainT<SAIndex32BitDense>(argc, argv);   // RapMapSAIndex<int64_t | int32_t, RegHashT>
   } catch (const qmap::Error& e) { std::printf("qmap error %d: %s\n", e.code(), e.what()); return 3; }
 }

@@ -90,6 +90,36 @@ def synth_small_ph(synth_small, tmp_path_factory):
     return out
 
 
+def _build_big(fasta, idx, **kw):
+    """the indexer's int64 ("BigSA") form of an index, forced for a text that does not need it (QM_FORCE_BIGSA)"""
+    import rapmap_amd as ra
+    os.environ["QM_FORCE_BIGSA"] = "1"
+    try:
+        ra.build_index(fasta, idx, **kw)
+    finally:
+        del os.environ["QM_FORCE_BIGSA"]
+
+
+@pytest.fixture(scope="session")
+def synth_small_big(synth_small, tmp_path_factory):
+    """synth_small indexed in the int64 form the reference writes for texts beyond 2^31 characters
+    (src/RapMapSAIndexer.cpp:682-683,743-765): 8-byte suffix array entries, transcript starts and interval bounds"""
+    d = tmp_path_factory.mktemp("synth_small_big")
+    out = dict(synth_small)
+    out["idx"] = str(d / "idx_big")
+    _build_big(synth_small["fasta"], out["idx"], threads=4)
+    return out
+
+
+@pytest.fixture(scope="session")
+def synth_small_big_ph(synth_small, tmp_path_factory):
+    d = tmp_path_factory.mktemp("synth_small_big_ph")
+    out = dict(synth_small)
+    out["idx"] = str(d / "idx_big_ph")
+    _build_big(synth_small["fasta"], out["idx"], threads=4, perfect_hash=True)
+    return out
+
+
 @pytest.fixture(scope="session")
 def synth_medium(tmp_path_factory, lib_built):
     """~1/40 of config 2: 1000 genes (~5k transcripts, ~8 M chars), 60k pairs 2x100 bp, 1 % errors."""

@@ -61,31 +61,31 @@ class Emu:
         self.text = np.zeros(n + 128, dtype=np.uint8)
         self.text[:n] = ix.text
         self.n = n
-        self.SA = np.ascontiguousarray(ix.SA, dtype=np.int32)
+        self.SA = np.ascontiguousarray(ix.SA, dtype=np.uint32)     # unsigned 32-bit on the device, also for a BigSA index (int64 on disk)
         self.sainfo = np.zeros(self.SA.size * 2, dtype=np.uint32)
         self.cap = int(buckets) if buckets else int(self.lib.qe_slots_cap(ix.hkeys.size))
         self.slots = np.zeros(self.cap * 4 + 8, dtype=np.uint64)   # cap buckets of 32 bytes
-        off = np.ascontiguousarray(ix.txpOffsets, dtype=np.int32)
+        off = np.ascontiguousarray(ix.txpOffsets, dtype=np.uint32)
         self.txp_off = off
         self.txp_len = np.ascontiguousarray(ix.txpLens, dtype=np.int32)
         hk = np.ascontiguousarray(ix.hkeys, dtype=np.uint64)
-        hl = np.ascontiguousarray(ix.hlb, dtype=np.int32)
-        hu = np.ascontiguousarray(ix.hub, dtype=np.int32)
+        hl = np.ascontiguousarray(ix.hlb, dtype=np.uint32)
+        hu = np.ascontiguousarray(ix.hub, dtype=np.uint32)
         self.ph = None
         if getattr(ix, "perfect", False):
             # perfect-hash index: the emulated device code walks the BooPHF levels itself
             from oracle import q5ph
             boo = q5ph.BooPHF(os.path.join(ix.dir, "hash_info.bph"))
-            data, lens, ovf = q5ph.read_val(os.path.join(ix.dir, "hash_info.val"))
+            data, lens, ovf = q5ph.read_val(os.path.join(ix.dir, "hash_info.val"), big=bool(ix.big))
             tab, words, ranks = [], [], []
             wo = ro = 0
             for (size, w, r), dom in zip(boo.levels, boo.domains):
                 tab += [dom, wo, ro]; words.append(w); ranks.append(r); wo += w.size; ro += r.size
             self._ph_keep = [np.ascontiguousarray(np.concatenate(words), dtype=np.uint64),
                              np.ascontiguousarray(np.concatenate(ranks) if ro else np.zeros(1), dtype=np.uint64),
-                             np.array(tab, dtype=np.uint64), np.ascontiguousarray(data, dtype=np.int32),
+                             np.array(tab, dtype=np.uint64), np.ascontiguousarray(data, dtype=np.uint32),
                              np.ascontiguousarray(lens, dtype=np.uint8),
-                             np.array([x for kv in ovf.items() for x in kv] or [0, 0], dtype=np.int32),
+                             np.array([x for kv in ovf.items() for x in kv] or [0, 0], dtype=np.uint32),
                              np.array([x for kv in boo.final.items() for x in kv] or [0, 0], dtype=np.uint64)]
             k = self._ph_keep
             self.lib.qe_ph_create.restype = C.c_void_p

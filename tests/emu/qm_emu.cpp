@@ -21,17 +21,17 @@ unsigned long long* qe_prof() { return qm::qm_prof; }   // event counters, see Q
 #endif
 
 // slots: (hmask+1) 32-byte buckets; sainfo: nSA x {u32 tid, i32 pos}; text padded by >= 64 bytes
-int qe_map(int k, const unsigned char* text, long long n, const int* SA, long long nSA, const void* sainfo,
+int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long long nSA, const void* sainfo,
            const void* slots, unsigned long long hmask, const qm_opts* o, long long nunits,
            const unsigned char* seq1, const long long* off1, const unsigned char* seq2, const long long* off2,
            int ns, const void* ph, long long* hit_offsets, qm_hit** hits_out, unsigned long long* counters, long long* int_offsets,
-           qm_sa_interval_hit** ints_out, int* status_out, const int* txp_off, const int* txp_len) {
+           qm_sa_interval_hit** ints_out, int* status_out, const u32* txp_off, const int* txp_len) {
   DevIndex ix; ix.text = text; ix.n = n; ix.SA = SA; ix.nSA = nSA; ix.sainfo = (const SaInfo*)sainfo;
   ix.slots = (const Bucket*)slots; ix.hmask = hmask; ix.k = k; ix.ph = (const PhIndex*)ph;
   memset(&ix.phv, 0, sizeof(ix.phv)); if (ph) ix.phv = *(const PhIndex*)ph;
   std::vector<u32> sanext;                 // -s: the table of qm_host.hip's first -s call (build_sanext_kernel)
   ix.sanext = nullptr;
-  static std::vector<SaExt> saext; static const int* saextFor = nullptr; static const unsigned char* saextText = nullptr;   // the replica's SaExt table (build_saext_kernel), kept between calls on one index
+  static std::vector<SaExt> saext; static const u32* saextFor = nullptr; static const unsigned char* saextText = nullptr;   // the replica's SaExt table (build_saext_kernel), kept between calls on one index
   ix.saext = nullptr;
   if (!getenv("QM_NO_SAEXT")) {
     if (saextFor != SA || saextText != text || (long long)saext.size() != nSA) {
@@ -194,11 +194,11 @@ void qe_free(void* p) { free(p); }
 
 // perfect-hash flavour: assemble a PhIndex over caller-owned arrays (same flattening as qm_ctx_create)
 void* qe_ph_create(const unsigned long long* words, const unsigned long long* ranks, const unsigned long long* levelTab,
-                   int nb_levels, const int* data, const unsigned char* lens, unsigned long long nelem,
-                   unsigned long long lastbitsetrank, const int* ovf_kv, long long n_ovf,
+                   int nb_levels, const u32* data, const unsigned char* lens, unsigned long long nelem,
+                   unsigned long long lastbitsetrank, const u32* ovf_kv, long long n_ovf,
                    const unsigned long long* fin_kv, long long n_fin,
                    unsigned long long total_words, unsigned long long total_ranks,
-                   int k, const unsigned char* text, long long n, const int* SA, long long nSA) {
+                   int k, const unsigned char* text, long long n, const u32* SA, long long nSA) {
   PhIndex* P = new PhIndex();
   memset(P, 0, sizeof(*P));
   // levelTab here: {domain, first word, first rank sample} per level, as read from hash_info.bph
@@ -217,7 +217,7 @@ void* qe_ph_create(const unsigned long long* words, const unsigned long long* ra
   for (u64 i = 0; i < nelem; ++i) {
     PhRec r; r.data = data[i]; r.len = lens[i]; r.pad[0] = r.pad[1] = r.pad[2] = 0;
     u64 m = 0;
-    if (r.data >= 0 && r.data < nSA) text_kmer(dix, (long long)SA[r.data], k, m);
+    if ((long long)r.data < nSA) text_kmer(dix, (long long)SA[r.data], k, m);
     r.key = m;
     recs[i] = r;
   }
@@ -232,8 +232,8 @@ void* qe_ph_create(const unsigned long long* words, const unsigned long long* ra
   }
   u64 cap = 16; while (cap < (u64)n_ovf * 2) cap <<= 1;
   OvfSlot* ov = new OvfSlot[cap];
-  for (u64 i = 0; i < cap; ++i) { ov[i].key = -1; ov[i].val = 0; }
-  for (long long i = 0; i < n_ovf; ++i) { u64 j = hash_mix((u64)(u32)ovf_kv[2 * i]) & (cap - 1); while (ov[j].key != -1) j = (j + 1) & (cap - 1); ov[j].key = ovf_kv[2 * i]; ov[j].val = ovf_kv[2 * i + 1]; }
+  for (u64 i = 0; i < cap; ++i) { ov[i].key = ~0u; ov[i].val = 0; }
+  for (long long i = 0; i < n_ovf; ++i) { u64 j = hash_mix((u64)ovf_kv[2 * i]) & (cap - 1); while (ov[j].key != ~0u) j = (j + 1) & (cap - 1); ov[j].key = ovf_kv[2 * i]; ov[j].val = ovf_kv[2 * i + 1]; }
   P->ovf = ov; P->ovfMask = cap - 1;
   u64 fc = 16; while (fc < (u64)n_fin * 2) fc <<= 1;
   Slot* fin = new Slot[fc];
@@ -279,16 +279,16 @@ void qe_ksw_rows(const int* qlen, const unsigned char* const* query, const int* 
   else ksw_rows_run<1024>(qlen, query, tlen, target, mat, q, e, w, out);
 }
 unsigned long long qe_slots_cap(long long nkeys) { return bucket_count(nkeys); }   // buckets of 32 bytes
-void qe_flatten(const int* SA, long long nSA, const int* offsets, long long T, void* sainfo_out,
-                const unsigned long long* keys, const int* lb, const int* ub, long long K, void* slots_out,
+void qe_flatten(const u32* SA, long long nSA, const u32* offsets, long long T, void* sainfo_out,
+                const unsigned long long* keys, const u32* lb, const u32* ub, long long K, void* slots_out,
                 unsigned long long cap) {
   SaInfo* si = (SaInfo*)sainfo_out;
   for (long long i = 0; i < nSA; ++i) {
-    int p = SA[i];
+    const u32 p = SA[i];
     long long lo = 0, hi = T;   // upper_bound(offsets, p) - 1
     while (lo < hi) { long long mid = (lo + hi) >> 1; if (offsets[mid] <= p) lo = mid + 1; else hi = mid; }
     long long tid = lo - 1;
-    si[i].tid = (u32)tid; si[i].pos = p - offsets[tid];
+    si[i].tid = (u32)tid; si[i].pos = (int)(p - offsets[tid]);
   }
   Bucket* bk = (Bucket*)slots_out;
   memset(bk, 0xff, (size_t)cap * sizeof(Bucket));

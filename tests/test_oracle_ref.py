@@ -36,6 +36,37 @@ def ref():
     return L
 
 
+def _ref():
+    """the harness library for tests outside this module (None when it is neither built nor buildable here)"""
+    if not os.path.exists(REF_SO):
+        if not os.path.isdir("/root/reference/src/ksw2pp"):
+            return None
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "-f", "Makefile.ref"])
+    return C.CDLL(REF_SO)
+
+
+def check_spp64(L, blob, expect):
+    """`blob` (a serialised spp::sparse_hash_map<int64_t, int64_t>) loads in the reference's container and holds exactly `expect`"""
+    import tempfile
+    L.ref_spp64_load.restype = C.c_void_p; L.ref_spp64_load.argtypes = [C.c_char_p]
+    L.ref_spp64_size.restype = C.c_int64; L.ref_spp64_size.argtypes = [C.c_void_p]
+    L.ref_spp64_find.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    L.ref_spp64_free.argtypes = [C.c_void_p]
+    with tempfile.NamedTemporaryFile(suffix=".spp") as f:
+        f.write(blob); f.flush()
+        h = L.ref_spp64_load(f.name.encode())
+    assert h
+    try:
+        assert L.ref_spp64_size(h) == len(expect)
+        keys = np.array(sorted(expect) + [max(expect) + 1, -5, 1 << 40], dtype=np.int64)
+        found = np.zeros(keys.size, dtype=np.uint8); val = np.zeros(keys.size, dtype=np.int64)
+        L.ref_spp64_find(h, keys.ctypes.data, keys.size, found.ctypes.data, val.ctypes.data)
+        assert found[:-3].all() and not found[-3:].any()
+        assert [int(v) for v in val[:-3]] == [expect[int(k)] for k in keys[:-3]]
+    finally:
+        L.ref_spp64_free(h)
+
+
 @pytest.fixture(scope="module")
 def ref_index(tmp_path_factory):
     d = tmp_path_factory.mktemp("ref_index_o")

@@ -32,6 +32,31 @@ def test_reference_style_caller_compiles_against_the_header_alone(caller, sample
     assert r.returncode == 0 and "k 31 txps 15 ph 0" in r.stdout, r.stdout + r.stderr
 
 
+def test_caller_opens_a_bigsa_index_with_the_int64_instantiation(caller, synth_small_big):
+    """RapMapSAIndex<int64_t, RegHashT> (SAIndex64BitDense, src/HitManager.cpp:889-892), picked from header.json"""
+    r = subprocess.run([caller, synth_small_big["idx"]], capture_output=True, text=True)
+    assert r.returncode == 0 and "ph 0 big 1" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["plain", "chain"])
+def test_int64_instantiation_reproduces_the_oracles_joint_hits(caller, synth_small, synth_small_big, oracle_mod, tmp_path, mode):
+    """the reference-style caller on SACollector<RapMapSAIndex<int64_t, ...>> / SAIntervalHit<int64_t> == the int64 oracle"""
+    sd = synth_small_big
+    keep = [i for i in range(len(sd["reads1"])) if b" " not in sd["reads1"][i] and b" " not in sd["reads2"][i]][:3000]
+    r1 = [sd["reads1"][i] for i in keep]; r2 = [sd["reads2"][i] for i in keep]
+    _write_pairs(tmp_path / "pairs.txt", r1, r2)
+    if mode == "plain":
+        ix, orc = load_oracle(sd["idx"])
+        res = orc.map_pairs(*pack(r1), *pack(r2), nthreads=4)
+        assert _run(caller, sd["idx"], tmp_path / "pairs.txt", tmp_path / "out.txt") == _want(res, len(r1))
+        assert _run(caller, sd["idx"], tmp_path / "pairs.txt", tmp_path / "out2.txt", "--no-prefetch", "--edit") == \
+            _run(caller, synth_small["idx"], tmp_path / "pairs.txt", tmp_path / "out3.txt", "--no-prefetch", "--edit")
+    else:
+        assert _run(caller, sd["idx"], tmp_path / "pairs.txt", tmp_path / "a.txt", "--chain") == \
+            _run(caller, synth_small["idx"], tmp_path / "pairs.txt", tmp_path / "b.txt", "--chain")
+
+
 def _write_pairs(path, r1, r2):
     with open(path, "w") as f:
         for a, b in zip(r1, r2):
