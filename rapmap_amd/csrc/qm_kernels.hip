@@ -398,6 +398,7 @@ hipError_t qmk_sel_align_finish(const void* pp, const void* ap, int num_cu, hipS
   if (A.u1 <= A.u0) return hipSuccess;
   const unsigned nb = (unsigned)((A.u1 - A.u0 + 255) / 256);
   switch (sel_ksw_ring_slots(A.bandwidth)) {            // one kernel for every --dpBandwidth: the band decides the ring
+    case 32: hipLaunchKernelGGL((qm_sel_align_kernel<32, 4>), dim3((unsigned)(num_cu * 8)), dim3(256), 0, st, P, A); break;   // register edition (--dpBandwidth <= 15)
     case 64: hipLaunchKernelGGL((qm_sel_align_kernel<64, 4>), dim3((unsigned)(num_cu * 8)), dim3(256), 0, st, P, A); break;
     case 128: hipLaunchKernelGGL((qm_sel_align_kernel<128, 4>), dim3((unsigned)(num_cu * 4)), dim3(256), 0, st, P, A); break;
     default: hipLaunchKernelGGL((qm_sel_align_kernel<1024, 2>), dim3((unsigned)(num_cu * 2)), dim3(128), 0, st, P, A); break;   // 83 KB of LDS per block

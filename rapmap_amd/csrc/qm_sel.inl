@@ -560,14 +560,154 @@ struct KswRowT {                                  // one alignment's LDS block (
   unsigned char QX[QM_KSW_MAXLEN + 40], TX[QM_KSW_MAXLEN + 40];
   u32 ST[RING]; int HH[RING]; unsigned char SS[RING];
 };
+// --dpBandwidth <= 15 (the default): a round touches at most 32 columns, two per lane -- the register edition
+// (sel_ksw_extz2_rows_reg, "32 slots"): no ring at all, the block holds the two images only
+template <>
+struct KswRowT<32> { unsigned char QX[QM_KSW_MAXLEN + 40], TX[QM_KSW_MAXLEN + 40]; };
 inline constexpr int sel_ksw_ring_slots(int w) {   // host + device (constexpr)
-  return (w >= 0 && w <= 33) ? 64 : ((w >= 0 && w <= 97) ? 128 : 1024); }
+  return (w >= 0 && w <= 15) ? 32 : ((w >= 0 && w <= 33) ? 64 : ((w >= 0 && w <= 97) ? 128 : 1024)); }
 static_assert(QM_KSW_MAXLEN + 48 <= 1024, "the full-band ring must hold every column of the longest alignment");
 // qlenv / tlenv: the row's alignment (0: the row idles); blk[row]; the images must be in place.  wIn < 0: the band is the
 // whole matrix (ksw2_extz2_sse.c:45).  Returns max(mqe, mte) per row.
+// The register edition of the row kernel below, for bands of at most 15 (w + 1 <= 16 band cells, a round's columns
+// [st, max(en, smax)] within 32 of the 16-aligned window start): lane c of a row OWNS the columns t0 = stv + c and t1 = t0 + 16
+// for as long as the window stands (it advances by exactly 16 columns every ~32 rounds: t0's state <- t1's, t1 starts fresh), so
+// the four difference bytes, the score byte and H of both columns live in registers -- no ring in LDS, no slot arithmetic, no
+// stores; neighbours come over DPP.  Cell for cell the same arithmetic as sel_ksw_extz2_rows<RING> (see there for the SSE kernel's
+// conventions it reproduces); the two are held against each other and against the reference's kernel by tests/test_ksw_variants.py.
+QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>& qlenv, const LV<int>& tlenv, KswRowT<32>* blk, const signed char* mat, int q, int e, int wIn,
+                                   LV<int>& score) {
+  typedef KswRowT<32> Row;
+  const int NEG = -0x40000000;
+  const int m = 5;
+  const int qe = q + e;
+  int min_sc = mat[1];
+  for (int t = 1; t < m * m; ++t) min_sc = min_sc < mat[t] ? min_sc : mat[t];
+  if (-min_sc > 2 * (q + e)) { QM_LANES(l) { score[l] = NEG; } return; }
+  const int sc_mch = (unsigned char)mat[0], sc_mis = (unsigned char)mat[1], sc_N = (unsigned char)mat[m * m - 1], m1 = m - 1;
+  const int qe2 = (unsigned char)((q + e) * 2), max_sc_v = (unsigned char)(mat[0] + (q + e) * 2), qv = (unsigned char)q;
+  const u32 QE2 = ((u32)qe2 << 8) | ((u32)qe2 << 24), MAXSC = ((u32)max_sc_v << 8) | ((u32)max_sc_v << 24), QV = ((u32)qv << 8) | ((u32)qv << 24);
+  LV<int> lastSt, hb, mqe, mte; LV<bool> done;
+  LV<int> ST0, ST1, HH0, HH1, SS0, SS1;             // the two owned columns: (u, v, x, y) bytes, H, score byte
+  QM_LANES(l) {
+    lastSt[l] = -1; hb[l] = NEG; mqe[l] = NEG; mte[l] = NEG; done[l] = qlenv[l] <= 0 || tlenv[l] <= 0;
+    ST0[l] = 0; ST1[l] = 0; HH0[l] = NEG; HH1[l] = NEG; SS0[l] = 0; SS1[l] = 0;
+  }
+  for (int r = 0; ; ++r) {
+    LV<int> st0v, en0v, stv, env, smaxv; LV<bool> act, moved;
+    QM_LANES(l) {
+      const int qlen = qlenv[l], tlen = tlenv[l], w = wIn;
+      int st = 0, en = tlen - 1;
+      if (st < r - qlen + 1) st = r - qlen + 1;
+      if (en > r) en = r;
+      if (st < (r - w + 1) >> 1) st = (r - w + 1) >> 1;
+      if (en > (r + w) >> 1) en = (r + w) >> 1;
+      const bool a = !done[l] && r < qlen + tlen - 1 && st <= en;
+      if (!a) done[l] = true;
+      act[l] = a;
+      // (st >= 0; an active row has st <= en <= st + w, so the quotient of the original's (en - st) / 16 is 0 here; en >= 0)
+      st0v[l] = st; en0v[l] = en; stv[l] = st & ~15; env[l] = (((en + 16) >> 4) << 4) - 1;
+      smaxv[l] = st + 15;
+      moved[l] = a && stv[l] != lastSt[l];
+    }
+    if (!ballot(act)) break;
+    // v, x of the column before the window: what its last owner (the row's last lane, as t0) left, in the round the window moves;
+    // nothing (or the first column's boundary) otherwise
+    LV<int> bpack;
+    QM_LANES(l) { bpack[l] = stv[l] > 0 ? 0 : ((r ? qv : 0) << 8); }
+    if (ballot(moved)) {                                  // rare: every ~32 rounds per row (and each row's first round)
+      LV<int> lastS, lastH;
+      row_last(ST0, lastS); row_last(HH0, lastH);
+      QM_LANES(l) {
+        if (moved[l]) {
+          const bool first = lastSt[l] < 0;
+          if (!first && stv[l] > 0) bpack[l] = (int)((u32)lastS[l] & 0x00ffff00u);
+          hb[l] = (stv[l] > 0 && !first) ? lastH[l] : NEG;
+          ST0[l] = first ? 0 : ST1[l]; HH0[l] = first ? NEG : HH1[l]; SS0[l] = first ? 0 : SS1[l];
+          ST1[l] = 0; HH1[l] = NEG; SS1[l] = 0;
+        }
+      }
+    }
+    LV<bool> diag;
+    QM_LANES(l) { diag[l] = act[l] && env[l] >= r && (l & 15) == (r & 15); }
+    if (ballot(diag))                                     // only while the band still touches the diagonal (the first ~w rounds)
+    QM_LANES(l) {                                       // the diagonal cell: y8[r] = 0, u8[r] = r ? q : 0
+      if (diag[l]) {
+        const int t0 = stv[l] + (l & 15);
+        const u32 uval = (u32)(r ? qv : 0);
+        if (t0 == r) ST0[l] = (int)(((u32)ST0[l] & 0x00ffff00u) | uval);
+        else if (t0 + 16 == r) ST1[l] = (int)(((u32)ST1[l] & 0x00ffff00u) | uval);
+      }
+    }
+    // the difference recurrence on the two owned columns (13 packed 16-bit instructions, see sel_ksw_extz2_rows)
+    LV<bool> inCore0, inCore1;
+    QM_LANES(l) {
+      Row& B = blk[l >> 4];
+      const int t0 = stv[l] + (l & 15), t1 = t0 + 16;
+      inCore0[l] = act[l] && t0 <= env[l]; inCore1[l] = act[l] && t1 <= env[l];
+      const bool inScore0 = act[l] && t0 >= st0v[l] && t0 <= smaxv[l], inScore1 = act[l] && t1 >= st0v[l] && t1 <= smaxv[l];
+      int qi0 = 16 + r - t0; qi0 = qi0 < 0 ? 0 : (qi0 > QM_KSW_MAXLEN + 39 ? QM_KSW_MAXLEN + 39 : qi0);
+      int qi1 = 16 + r - t1; qi1 = qi1 < 0 ? 0 : (qi1 > QM_KSW_MAXLEN + 39 ? QM_KSW_MAXLEN + 39 : qi1);
+      const int ti0 = t0 > QM_KSW_MAXLEN + 39 ? QM_KSW_MAXLEN + 39 : t0, ti1 = t1 > QM_KSW_MAXLEN + 39 ? QM_KSW_MAXLEN + 39 : t1;
+      const int sv0 = B.QX[qi0], sq0 = B.TX[ti0], sv1 = B.QX[qi1], sq1 = B.TX[ti1];
+      int tmp0 = (sq0 == sv0) ? sc_mch : sc_mis; tmp0 = (sq0 == m1 || sv0 == m1) ? sc_N : tmp0;
+      int tmp1 = (sq1 == sv1) ? sc_mch : sc_mis; tmp1 = (sq1 == m1 || sv1 == m1) ? sc_N : tmp1;
+      SS0[l] = inScore0 ? tmp0 : SS0[l]; SS1[l] = inScore1 ? tmp1 : SS1[l];
+    }
+    LV<int> r0, r1, carry;
+    row_rotate_up(ST0, r0); row_rotate_up(ST1, r1); row_rotate_up(bpack, carry);
+    QM_LANES(l) {
+      const u32 nb0 = (l & 15) == 0 ? (u32)carry[l] : (u32)r0[l], nb1 = (l & 15) == 0 ? (u32)r0[l] : (u32)r1[l];
+      const u32 o0 = (u32)ST0[l], o1 = (u32)ST1[l];
+      const u32 U = perm8(o1, o0, 0x040c000cu), Y = perm8(o1, o0, 0x070c030cu);
+      const u32 V1 = perm8(nb1, nb0, 0x050c010cu), X1 = perm8(nb1, nb0, 0x060c020cu);
+      const u32 S = ((u32)SS0[l] << 8) | ((u32)SS1[l] << 24);
+      u32 Z = pk_add(S, QE2), A = pk_add(X1, V1), Bq = pk_add(Y, U);
+      Z = pk_max_i(Z, A);
+      Z = pk_max_u(Z, Bq);
+      Z = pk_min_u(Z, MAXSC);
+      const u32 UN = pk_sub(Z, V1), VN = pk_sub(Z, U);
+      Z = pk_sub(Z, QV);
+      A = pk_sub(A, Z); Bq = pk_sub(Bq, Z);
+      const u32 XN = pk_max_i(A, 0u), YN = pk_max_i(Bq, 0u);
+      const u32 uv = perm8(VN, UN, 0x07030501u), xy = perm8(YN, XN, 0x07030501u);
+      if (inCore0[l]) ST0[l] = (int)perm8(xy, uv, 0x05040100u);
+      if (inCore1[l]) ST1[l] = (int)perm8(xy, uv, 0x07060302u);
+    }
+    // H (exact max) on the band cells st0..en0: at most 16 of them, so at most one of a lane's two columns
+    LV<int> rh0, rh1;
+    row_rotate_up(HH0, rh0); row_rotate_up(HH1, rh1);     // H of the column to the left, before this round's updates
+    QM_LANES(l) {
+      const int t0 = stv[l] + (l & 15), t1 = t0 + 16, st0 = st0v[l], en0 = en0v[l];
+      const bool in0 = act[l] && t0 >= st0 && t0 <= en0, in1 = act[l] && t1 >= st0 && t1 <= en0;
+      const int t = in1 ? t1 : t0;
+      const u32 pk = (u32)(in1 ? ST1[l] : ST0[l]);
+      const int hOld = in1 ? HH1[l] : HH0[l];
+      const int hl = in1 ? ((l & 15) == 0 ? rh0[l] : rh1[l]) : ((l & 15) == 0 ? hb[l] : rh0[l]);
+      const int un = (int)(pk & 0xff), vn = (int)((pk >> 8) & 0xff);
+      const int hOwn = hOld + vn - qe;
+      const int hTop = en0 > 0 ? (hl + un - qe) : hOwn;
+      const int hn = r > 0 ? (t == en0 ? hTop : hOwn) : (vn - qe - qe);
+      if (in0) HH0[l] = hn;
+      if (in1) HH1[l] = hn;
+      if (in0 || in1) {
+        if (t == en0 && en0 == tlenv[l] - 1 && hn > mte[l]) mte[l] = hn;
+        if (t == st0 && r - st0 == qlenv[l] - 1 && hn > mqe[l]) mqe[l] = hn;
+      }
+    }
+    QM_LANES(l) { if (act[l]) lastSt[l] = stv[l]; }
+  }
+  LV<int> neg;
+  QM_LANES(l) { const int s = mqe[l] > mte[l] ? mqe[l] : mte[l]; neg[l] = -s; }
+  group_min(neg, 16);
+  QM_LANES(l) { score[l] = (qlenv[l] <= 0 || tlenv[l] <= 0) ? NEG : -neg[l]; }
+}
+
 template <int RING>
 QM_DEV void sel_ksw_extz2_rows(const LV<int>& qlenv, const LV<int>& tlenv, KswRowT<RING>* blk, const signed char* mat, int q, int e, int wIn,
                                LV<int>& score) {
+  if constexpr (RING == 32) { sel_ksw_extz2_rows_reg(qlenv, tlenv, blk, mat, q, e, wIn, score); return; }
+  else {
   typedef KswRowT<RING> Row;
   constexpr int RM = RING - 1;
   constexpr int NV = RING / 16 + 1;                 // 16-column vectors a round may touch
@@ -742,6 +882,7 @@ QM_DEV void sel_ksw_extz2_rows(const LV<int>& qlenv, const LV<int>& tlenv, KswRo
   QM_LANES(l) { const int s = mqe[l] > mte[l] ? mqe[l] : mte[l]; neg[l] = -s; }
   group_min(neg, 16);
   QM_LANES(l) { score[l] = (qlenv[l] <= 0 || tlenv[l] <= 0) ? NEG : -neg[l]; }
+  }
 }
 
 QM_DEV unsigned char sel_nt4(unsigned char c) {               // seq_nt4_table_loc (KSW2Aligner.cpp:61-72), branch-free
@@ -1001,7 +1142,13 @@ QM_DEV void sel_tasks_align_rows(const PairBatch& P, const SelBatch& A, unsigned
       ql[l] = t.rlen; tl[l] = t.tlen1; gs[l] = t.gslot; ro[l] = t.roff; fw[l] = t.fwd;
     }
   }
-  for (int i0 = 0; i0 < QM_KSW_MAXLEN + 40; i0 += 16) {
+  // the images are read up to column max(en) + 31 < tlen + 31 and query index qlen + 30; their defined part ends at
+  // tlen16 + qlen (TX) and 16 + qlen (QX): stage that much (of the longest of the four alignments), not the whole block
+  LV<int> need;
+  QM_LANES(l) { need[l] = gs[l] >= 0 ? ((tl[l] + 15) / 16 * 16) + ql[l] + 48 : 0; }
+  const int needMax = wave_max(need);
+  const int stageEnd = needMax < QM_KSW_MAXLEN + 40 ? needMax : QM_KSW_MAXLEN + 40;
+  for (int i0 = 0; i0 < stageEnd; i0 += 16) {
     QM_LANES(l) {
       if (gs[l] >= 0) {
         KswRowT<RING>& B = blk[l >> 4];

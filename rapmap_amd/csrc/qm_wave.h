@@ -103,6 +103,8 @@ QM_DEV int wave_max(const LV<int>& x) { int m = x.v[0]; for (int l = 1; l < 64; 
 QM_DEV void lane_rotate_up(const LV<int>& in, LV<int>& out) { for (int l = 0; l < 64; ++l) out.v[l] = in.v[(l + 63) & 63]; }
 // the same within every row of 16 lanes: lane c of a row reads lane (c - 1) & 15 of that row
 QM_DEV void row_rotate_up(const LV<int>& in, LV<int>& out) { for (int l = 0; l < 64; ++l) out.v[l] = in.v[(l & ~15) | ((l + 15) & 15)]; }
+// every lane of a row of 16 gets the value of the row's last lane
+QM_DEV void row_last(const LV<int>& in, LV<int>& out) { for (int l = 0; l < 64; ++l) out.v[l] = in.v[l | 15]; }
 // every lane gets the minimum over its aligned group of G lanes (G a power of two, wave-uniform)
 QM_DEV void group_min(LV<int>& x, int G) {
   for (int b = 0; b < 64; b += G) {
@@ -166,6 +168,8 @@ QM_DEV int wave_max(const LV<int>& x) {
 QM_DEV void lane_rotate_up(const LV<int>& in, LV<int>& out) { out.v[0] = __builtin_amdgcn_update_dpp(0, in.v[0], 0x13C, 0xf, 0xf, false); }
 // DPP row_ror:1
 QM_DEV void row_rotate_up(const LV<int>& in, LV<int>& out) { out.v[0] = __builtin_amdgcn_update_dpp(0, in.v[0], 0x121, 0xf, 0xf, false); }
+// (rare callers only: a trip through the LDS crossbar)
+QM_DEV void row_last(const LV<int>& in, LV<int>& out) { out.v[0] = __shfl(in.v[0], (int)((threadIdx.x & 63) | 15), 64); }
 // butterfly inside a row of 16 with DPP pairings: lanes ^1, lanes ^2 (quad permutes), then the mirror image within 8 and
 // within 16 -- once the quads are uniform any pairing of the two halves does; across rows the crossbar
 QM_DEV void group_min(LV<int>& x, int G) {

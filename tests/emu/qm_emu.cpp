@@ -151,6 +151,7 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
       A.tref = tref.data(); A.tcix = tcix.data(); A.tasks = tasks.data(); A.ntasks = &ntasks;
       for (long long u = 0; u < nunits; ++u) sel_unit_plan(P, A, u, &uc);
       switch (sel_ksw_ring_slots(A.bandwidth)) {         // same rule as the launch wrapper
+        case 32: { std::vector<KswRowT<32>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<32>(P, A, t, ntasks, rows.data()); } break;
         case 64: { std::vector<KswRowT<64>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<64>(P, A, t, ntasks, rows.data()); } break;
         case 128: { std::vector<KswRowT<128>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<128>(P, A, t, ntasks, rows.data()); } break;
         default: { std::vector<KswRowT<1024>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<1024>(P, A, t, ntasks, rows.data()); } break;
@@ -255,7 +256,8 @@ static void ksw_rows_run(const int* qlen, const unsigned char* const* query, con
   for (int g = 0; g < 4; ++g) {
     const int tlen16 = (tlen[g] + 15) / 16 * 16;
     memset(&blk[g], 0xAB, sizeof(KswRowT<RING>));        // the kernel must not depend on what the block held before
-    for (int i = 0; i < QM_KSW_MAXLEN + 40; ++i) {
+    // only what sel_tasks_align_rows stages for an alignment of this size: the rest keeps the garbage
+    for (int i = 0; i < QM_KSW_MAXLEN + 40 && i < tlen16 + qlen[g] + 48; ++i) {
       blk[g].QX[i] = (i >= 16 && i < 16 + qlen[g]) ? query[g][i - 16] : 0;
       const int j = i - tlen16;
       blk[g].TX[i] = i < tlen[g] ? target[g][i] : (i < tlen16 ? 0 : (j < qlen[g] ? query[g][qlen[g] - 1 - j] : 0));
@@ -274,7 +276,8 @@ void qe_ksw_rows(const int* qlen, const unsigned char* const* query, const int* 
   for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) mat[i * 5 + j] = (signed char)(i == j ? a : b); mat[i * 5 + 4] = 0; }
   for (int j = 0; j < 5; ++j) mat[20 + j] = 0;
   if (ring < 0) ring = sel_ksw_ring_slots(w);
-  if (ring == 64) ksw_rows_run<64>(qlen, query, tlen, target, mat, q, e, w, out);
+  if (ring == 32) ksw_rows_run<32>(qlen, query, tlen, target, mat, q, e, w, out);
+  else if (ring == 64) ksw_rows_run<64>(qlen, query, tlen, target, mat, q, e, w, out);
   else if (ring == 128) ksw_rows_run<128>(qlen, query, tlen, target, mat, q, e, w, out);
   else ksw_rows_run<1024>(qlen, query, tlen, target, mat, q, e, w, out);
 }

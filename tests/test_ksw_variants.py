@@ -48,9 +48,10 @@ def _cases(seed, n):
         yield q, t
 
 
-# (match, mismatch, gap open, gap extend, band): bands <= 33 run on the 64-slot ring, <= 97 on 128 slots, everything else
-# (and the "whole matrix" band -1) on 1024
+# (match, mismatch, gap open, gap extend, band): bands <= 15 run on the register edition of the row kernel ("32"), <= 33 on the
+# 64-slot ring, <= 97 on 128 slots, everything else (and the "whole matrix" band -1) on 1024
 SCHEMES = [(2, -4, 4, 2, 15), (2, -4, 4, 2, 5), (1, -1, 1, 1, 15), (2, -6, 5, 3, 33), (2, -4, 4, 2, 0), (4, -4, 6, 2, 20),
+           (2, -4, 4, 2, 1), (2, -6, 5, 3, 8), (1, 0, 25, 25, 15), (2, -4, 4, 2, 14), (2, -4, 4, 2, 16),
            (2, -4, 4, 2, 34), (2, -4, 4, 2, 40), (2, -6, 5, 3, 64), (1, -1, 1, 1, 97), (2, -4, 4, 2, 98), (2, -4, 4, 2, 150),
            (2, -4, 4, 2, 1000), (2, -4, 4, 2, -1)]
 
@@ -87,13 +88,14 @@ def test_ksw_rows_kernel_four_at_a_time(scheme):
     assert not bad, "%d mismatches, first: %r" % (len(bad), bad[:5])
 
 
-@pytest.mark.parametrize("ring", [64, 128, 1024])
+@pytest.mark.parametrize("ring", [32, 64, 128, 1024])
 def test_ksw_rows_every_ring_gives_the_same_scores(ring):
-    """a band that fits the smallest ring must score the same on the larger ones (the ring is storage, not arithmetic)"""
+    """a band that fits the smallest ring must score the same on the larger ones (the ring is storage, not arithmetic); 32: the
+    register edition, bands up to 15 only"""
     ol = oracle._lib(); el = emu._lib()
     ol.qo_ksw_extz2.restype = C.c_int
     cases = list(_cases(99, 200))
-    for w in (15, 33):
+    for w in ((15, 7) if ring == 32 else (15, 33)):
         for i in range(0, len(cases), 4):
             grp = cases[i:i + 4]
             out = _rows(el, grp, 2, -4, 4, 2, w, ring)
