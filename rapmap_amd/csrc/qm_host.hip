@@ -818,6 +818,9 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
       static const char* nm[7] = {"read->LDS", "strand setup", "probe windows", "extension", "collector rest", "hits->mappings", "write-out+loop"};
       double tot = 0; for (int i = 0; i < 7; ++i) tot += (double)hscal[20 + i];
       for (int i = 0; i < 7; ++i) fprintf(stderr, "[qm timing] %-16s %6.2f %%  %10.0f clk/read\n", nm[i], 100.0 * hscal[20 + i] / tot, (double)hscal[20 + i] / (double)nreads);
+      static const char* hm[8] = {"intervals in", "suffix gather", "sort", "groups+chain", "list assembly", "(after)", "write-out", "-"};
+      double ht = 0; for (int i = 0; i < 8; ++i) ht += (double)hscal[32 + i];
+      if (ht > 0) for (int i = 0; i < 8; ++i) fprintf(stderr, "[qm timing h2m] %-16s %6.2f %%  %10.0f clk/read\n", hm[i], 100.0 * hscal[32 + i] / ht, (double)hscal[32 + i] / (double)nreads);
     }
 #endif
     if (status & 4) return fail(QM_E_TOOLONG, "a read is longer than %d characters (-s: the alignment kernels are sized for that; otherwise the long-read pass takes up to %d)", o->sel_aln ? QM_MAX_READ_LEN : QM_MAX_LONG_READ_LEN, QM_MAX_LONG_READ_LEN);

@@ -32,6 +32,9 @@ __global__ __launch_bounds__(256, 4) void qm_h2m_kernel(DevIndex ix, ReadBatch B
   const long long nw = (long long)gridDim.x * 4;
   u64* gscr = B.gscratch + gw * QM_GSCR_U64;
   WaveAlloc wa; wa.base = -1; wa.used = 0; wa.ivBase = -1; wa.ivUsed = 0;
+#ifdef QM_TIMING       // phases of this kernel (-s): 0 interval records in, 1 suffixes gathered, 2 sort, 3 groups + chaining, 4 list assembled, 6 write-out
+  if ((threadIdx.x & 63) == 0) { for (int i = 0; i < 9; ++i) qm_tim[wave][i] = 0; qm_tim[wave][9] = __builtin_readcyclecounter(); }
+#endif
   for (long long r = gw; r < B.nreads; r += nw) {
     const long long read = read_id<F>(B, r);
     H2mMem& M = mem[wave];
@@ -71,10 +74,14 @@ __global__ __launch_bounds__(256, 4) void qm_h2m_kernel(DevIndex ix, ReadBatch B
       fi.n += popc64(fm); ri.n += popc64(rm);
     }
     wave_fence();
+    QM_T(0);
     const bool found = B.found_in ? uniform((int)B.found_in[read]) != 0 : false;
     finish_read<4, F>(ix, B, read, len, mate, found, M.buf, gscr, wa, fi, ri, (F & QM_F_SEL) ? B.selscr + gw : nullptr, sels[wave].ptr(),
                       ((F & QM_F_SEL) && B.dyn) ? B.dyn + gw : nullptr);
   }
+#ifdef QM_TIMING
+  if ((threadIdx.x & 63) == 0) for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long*)&B.cursor[32 + i], (unsigned long long)qm_tim[wave][i]);
+#endif
 }
 
 // stage B pass 1: hits per unit + the HitCounters

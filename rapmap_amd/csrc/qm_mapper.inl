@@ -40,7 +40,11 @@ namespace qm {
 #define QM_GSCR_U64 (3 * QM_GCAP + 2 * QM_IOVF * 2)   // u64 words of global scratch per wave
 // slots of the context's scalar block (ReadBatch::cursor points at slot 0): bump pointer, qm_counters[6], status, ksw2 task
 // count, then the slow queue of -s (reads that overflowed the per-wave scratch: how many, suffixes of the largest)
+#ifdef QM_TIMING
+#define QM_SC_WORDS 48               // + the phase sums of qm_h2m_kernel at [32, 40)
+#else
 #define QM_SC_WORDS 32
+#endif
 #define QM_SC_STATUS 8
 #define QM_SC_NTASKS 9
 #define QM_SC_SLOWCNT 16

@@ -480,17 +480,21 @@ QM_DEV int sel_h2m_on(const DevIndex& ix, const ReadBatch& B, const IntervalList
       }
     }
     wave_fence();
+    QM_T(1);
     const bool presorted = n <= 64 * SS::NCH && 2 * n * (int)sizeof(u64) <= S.tmp_bytes();
     if (presorted && L.n > 0) sel_wave_sort(S, n, L.n);
+    QM_T(2);
     if (presorted && L.n > 1) sel_strand_wave(S, s, n, L.n, readLen, B.consensus_fraction);
     else QM_LANES(l) { if (l == 0) { if (L.n > 0) sel_strand(S, s, n, L.n, readLen, mate, B.consensus_fraction, presorted); else { S.ngrp[s] = 0; S.npos[s] = 0; } } }
     wave_fence();
+    QM_T(3);
     LV<int> ngv; QM_LANES(l) { ngv[l] = S.ngrp[s]; }
     if (read_lane(ngv, 0) < 0) return -1;
   }
   LV<int> nw;
   QM_LANES(l) { nw[l] = 0; if (l == 0) nw[l] = sel_emit(S); }
   wave_fence();
+  QM_T(4);
   return read_lane(nw, 0);
 }
 
