@@ -191,6 +191,7 @@ struct Src {
   bool eof() const { return allHanded && inParse == 0 && done.empty(); }
   // gz: blocks from the inflate thread, in order
   std::thread inflater; std::deque<Chunk*> blocks; bool inflDone = false;
+  int bgzfHelpers = 0;                             // gz: > 0 for a BGZF file (mapped): that many helper threads inflate its blocks
 };
 
 }  // namespace
@@ -496,11 +497,129 @@ const char* last_boundary(const char* b, const char* e, bool fastq) {
   }
 }
 
+// A BGZF file (bgzip, htslib; also what bcl2fastq writes): a series of complete gzip members of at most 64 KiB, each announcing
+// its own compressed size in an extra field ('B','C', RFC 1952 FEXTRA; SAM specification 4.1).  One gzip stream can only be
+// inflated by one thread; these members are independent, and their boundaries are known without inflating anything, so a few
+// helper threads inflate groups of them side by side and the inflate thread of the source hands the groups on in file order.
+// (The reference reads every gz input through one zlib thread, src/FastxParser.cpp:229-328; a plain gzip file still takes
+// that road here: gzread below.)
+struct BgzfReader {
+  const unsigned char* map = nullptr; size_t len = 0, pos = 0;    // the compressed file, and the next block to hand to a helper
+  struct Job { const unsigned char* in; size_t inLen; std::vector<char> out; size_t outLen; bool done = false, bad = false; };
+  std::deque<Job*> q;                          // in file order; helpers take the first one not yet taken
+  size_t nextTake = 0;                         // q[nextTake] is the next job for a helper
+  std::vector<std::thread> helpers;
+  std::mutex mu; std::condition_variable cvJob, cvDone;
+  bool stop = false, failed = false;
+  Job* cur = nullptr; size_t curOff = 0;       // the job read() is copying out of
+  size_t inFlightCap = 0;
+
+  // is there a BGZF block at `p`?  -> its total size and uncompressed size
+  static bool block_at(const unsigned char* p, size_t avail, size_t& bsize, size_t& isize) {
+    if (avail < 28 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return false;
+    const size_t xlen = (size_t)p[10] | ((size_t)p[11] << 8);
+    if (12 + xlen > avail) return false;
+    size_t o = 12; bool found = false;
+    while (o + 4 <= 12 + xlen) {
+      const size_t slen = (size_t)p[o + 2] | ((size_t)p[o + 3] << 8);
+      if (p[o] == 'B' && p[o + 1] == 'C' && slen == 2 && o + 6 <= 12 + xlen) { bsize = ((size_t)p[o + 4] | ((size_t)p[o + 5] << 8)) + 1; found = true; }
+      o += 4 + slen;
+    }
+    if (!found || bsize < 12 + xlen + 8 || bsize > avail) return false;
+    isize = (size_t)p[bsize - 4] | ((size_t)p[bsize - 3] << 8) | ((size_t)p[bsize - 2] << 16) | ((size_t)p[bsize - 1] << 24);
+    return isize <= 65536;
+  }
+  static bool is_bgzf(const unsigned char* p, size_t avail) { size_t b, i; return block_at(p, avail, b, i); }
+
+  void helper_loop() {
+    z_stream zs; memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, 15 + 16) != Z_OK) { std::lock_guard<std::mutex> lk(mu); failed = true; cvDone.notify_all(); return; }
+    while (true) {
+      Job* j;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cvJob.wait(lk, [&] { return stop || nextTake < q.size(); });
+        if (stop) break;
+        j = q[nextTake++];
+      }
+      // the group: whole members one after the other (zlib checks each member's CRC-32 and length)
+      size_t in = 0, out = 0; bool bad = false;
+      while (in < j->inLen && !bad) {
+        inflateReset(&zs);
+        zs.next_in = (Bytef*)(j->in + in); zs.avail_in = (uInt)std::min<size_t>(j->inLen - in, 1u << 30);
+        zs.next_out = (Bytef*)(j->out.data() + out); zs.avail_out = (uInt)(j->out.size() - out);
+        const int rc = inflate(&zs, Z_FINISH);
+        if (rc != Z_STREAM_END) { bad = true; break; }
+        in = (size_t)((const unsigned char*)zs.next_in - j->in); out = (size_t)((char*)zs.next_out - j->out.data());
+      }
+      if (out != j->outLen) bad = true;
+      std::lock_guard<std::mutex> lk(mu);
+      j->bad = bad; j->done = true;
+      cvDone.notify_all();
+    }
+    inflateEnd(&zs);
+  }
+  void start(const unsigned char* m, size_t l, int nHelpers) {
+    map = m; len = l; pos = 0; inFlightCap = (size_t)nHelpers * 3;
+    for (int i = 0; i < nHelpers; ++i) helpers.emplace_back([this] { helper_loop(); });
+  }
+  // queue further groups of blocks (about 1 MiB of output each) up to the in-flight cap; false: the file is not BGZF here
+  bool feed() {
+    std::lock_guard<std::mutex> lk(mu);
+    while (pos < len && q.size() < inFlightCap) {
+      size_t p = pos, outSum = 0; int nb = 0;
+      while (p < len && outSum < ((size_t)1 << 20) && nb < 64) {
+        size_t bs, is;
+        if (!block_at(map + p, len - p, bs, is)) { failed = true; return false; }
+        p += bs; outSum += is; ++nb;
+      }
+      Job* j = new Job(); j->in = map + pos; j->inLen = p - pos; j->outLen = outSum; j->out.resize(outSum ? outSum : 1);
+      q.push_back(j); pos = p;
+      cvJob.notify_one();
+    }
+    return true;
+  }
+  // gzread's contract: up to `want` bytes, fewer only at the end of the input; -1 on a corrupt file
+  long read(char* dst, size_t want) {
+    size_t got = 0;
+    while (got < want) {
+      if (!cur) {
+        if (!feed()) return -1;
+        std::unique_lock<std::mutex> lk(mu);
+        if (q.empty()) break;                                  // end of file
+        Job* j = q.front();
+        cvDone.wait(lk, [&] { return j->done || failed; });
+        if (failed || j->bad) return -1;
+        q.pop_front(); --nextTake;
+        cur = j; curOff = 0;
+      }
+      const size_t n = std::min(want - got, cur->outLen - curOff);
+      memcpy(dst + got, cur->out.data() + curOff, n);
+      got += n; curOff += n;
+      if (curOff == cur->outLen) { delete cur; cur = nullptr; }
+    }
+    return (long)got;
+  }
+  ~BgzfReader() {
+    { std::lock_guard<std::mutex> lk(mu); stop = true; cvJob.notify_all(); }
+    for (auto& t : helpers) t.join();
+    for (Job* j : q) delete j;
+    delete cur;
+  }
+};
+
 void inflate_loop(qm_ingest* g, int s) {
   Src& S = g->src[s];
-  gzFile f = gzopen(S.path.c_str(), "rb");
-  if (!f) { std::lock_guard<std::mutex> lk(g->mu); set_fail(g, QM_E_IO, "cannot gzopen %s", S.path.c_str()); S.inflDone = true; S.allHanded = S.blocks.empty(); g->cvWork.notify_all(); g->cvOut.notify_all(); return; }
-  gzbuffer(f, 1 << 20);
+  // BGZF (independent gzip members that say how long they are): S.bgzfHelpers threads inflate side by side; any other gzip
+  // file: one zlib stream, one thread
+  BgzfReader* bz = nullptr;
+  gzFile f = nullptr;
+  if (S.map && S.bgzfHelpers > 0) { bz = new BgzfReader(); bz->start((const unsigned char*)S.map, S.len, S.bgzfHelpers); }
+  else {
+    f = gzopen(S.path.c_str(), "rb");
+    if (!f) { std::lock_guard<std::mutex> lk(g->mu); set_fail(g, QM_E_IO, "cannot gzopen %s", S.path.c_str()); S.inflDone = true; S.allHanded = S.blocks.empty(); g->cvWork.notify_all(); g->cvOut.notify_all(); return; }
+    gzbuffer(f, 1 << 20);
+  }
   const size_t BLK = (size_t)4 << 20;
   std::vector<char> carry; bool first = true;
   while (true) {
@@ -517,7 +636,7 @@ void inflate_loop(qm_ingest* g, int s) {
     size_t have = carry.size(); carry.clear();
     bool eof = false, bad = false; const char* cut = nullptr;
     while (true) {
-      const int got = gzread(f, c->data.data() + have, (unsigned)(c->data.size() - have));
+      const long got = bz ? bz->read(c->data.data() + have, c->data.size() - have) : (long)gzread(f, c->data.data() + have, (unsigned)(c->data.size() - have));
       if (got < 0) { bad = true; break; }
       have += (size_t)got;
       if ((size_t)got < c->data.size() - (have - (size_t)got)) eof = true;
@@ -539,7 +658,8 @@ void inflate_loop(qm_ingest* g, int s) {
     if (eof) { S.inflDone = true; if (S.blocks.empty()) S.allHanded = true; g->cvWork.notify_all(); break; }
     g->cvWork.notify_one();
   }
-  gzclose(f);
+  if (f) gzclose(f);
+  delete bz;
   std::lock_guard<std::mutex> lk(g->mu);
   if (!S.inflDone) { S.inflDone = true; S.allHanded = S.blocks.empty(); }
   g->cvWork.notify_all();
@@ -555,6 +675,13 @@ int open_src(Src& S, const char* p) {
   unsigned char magic[2] = {0, 0};
   const ssize_t got = ::pread(fd, magic, 2, 0);
   S.gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+  if (S.gz && S.len >= 28 && !(getenv("QM_INGEST_NO_BGZF") && atoi(getenv("QM_INGEST_NO_BGZF")) != 0)) {
+    const char* m = (const char*)mmap(nullptr, S.len, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m != MAP_FAILED) {
+      if (BgzfReader::is_bgzf((const unsigned char*)m, S.len)) { S.map = m; S.bgzfHelpers = 1; madvise((void*)m, S.len, MADV_SEQUENTIAL); }   // the count is set at open
+      else munmap((void*)m, S.len);
+    }
+  }
   if (S.len > 0 && !S.gz) {
     S.map = (const char*)mmap(nullptr, S.len, PROT_READ, MAP_PRIVATE, fd, 0);
     if (S.map == MAP_FAILED) { S.map = nullptr; ::close(fd); return qm_io_fail(QM_E_IO, "cannot mmap %s", p); }
@@ -585,7 +712,14 @@ int qm_ingest_open(const char* path1, const char* path2, int32_t n_threads, int6
   const size_t chunkBytes = ce && atoll(ce) > 0 ? (size_t)atoll(ce) : ((size_t)2 << 20);
   for (int s = 0; s < g->nsrc; ++s) {
     Src& S = g->src[s];
-    if (S.gz) continue;
+    if (S.gz) {
+      if (S.bgzfHelpers) {                               // helper threads per BGZF file: the workers' share, 2 .. 16 (QM_INGEST_BGZF_THREADS)
+        const char* be = getenv("QM_INGEST_BGZF_THREADS");
+        int h = be && atoi(be) > 0 ? atoi(be) : (int)n_threads / g->nsrc;
+        S.bgzfHelpers = h < 2 ? 2 : (h > 16 && !be ? 16 : h);
+      }
+      continue;
+    }
     S.chunkBytes = chunkBytes;
     S.nChunks = (int64_t)((S.len + chunkBytes - 1) / chunkBytes);
     if (S.nChunks == 0) S.allHanded = true;

@@ -293,6 +293,58 @@ def test_ingest_engine_chunk_boundaries(tmp_path, monkeypatch, chunk, batch, thr
     assert _join(bs, "names2", "name_off2") == [nm for nm, _ in recs2]
 
 
+@pytest.mark.parametrize("threads", [1, 6])
+def test_ingest_engine_inflates_bgzf_blocks_in_parallel(tmp_path, monkeypatch, threads):
+    """a BGZF file (independent gzip members that announce their size) is inflated by helper threads side by side and read
+    exactly like the plain file and like the same bytes as one ordinary gzip stream; Python's gzip module agrees that the
+    file is a valid (multi-member) gzip file"""
+    import gzip
+    import random
+    import rapmap_amd as ra
+    from util import write_bgzf
+    rnd = random.Random(11)
+    recs1, recs2 = [], []
+    for i in range(30000):
+        L = rnd.choice([1, 31, 100, 100, 100, 250, 2000]) if i % 50 == 0 else 100
+        for recs, m in ((recs1, 1), (recs2, 2)):
+            s = "".join(rnd.choice("ACGTN") for _ in range(L)); q = "".join(rnd.choice("@+I5#") for _ in range(L))
+            recs.append(("@r%d/%d some text\n%s\n+\n%s\n" % (i, m, s, q)).encode())
+    d1, d2 = b"".join(recs1), b"".join(recs2)
+    plain = (str(tmp_path / "a.fq"), str(tmp_path / "b.fq")); bg = (str(tmp_path / "a.bgz.fq.gz"), str(tmp_path / "b.bgz.fq.gz"))
+    gzs = (str(tmp_path / "a.fq.gz"), str(tmp_path / "b.fq.gz"))
+    for data, pp, pb, pg in ((d1, plain[0], bg[0], gzs[0]), (d2, plain[1], bg[1], gzs[1])):
+        open(pp, "wb").write(data)
+        write_bgzf(pb, data, block=rnd.choice([777, 60000, 65280]))
+        with gzip.open(pg, "wb") as f:
+            f.write(data)
+        assert gzip.open(pb, "rb").read() == data
+    monkeypatch.setenv("QM_INGEST_BGZF_THREADS", str(threads))
+
+    def read(p1, p2):
+        out = []
+        for b in _batches(p1, p2, 4096, threads=4):
+            for i in range(b.n):
+                out.append((bytes(b.names1[b.name_off1[i]:b.name_off1[i + 1]]), bytes(b.seq1[b.off1[i]:b.off1[i + 1]]),
+                            bytes(b.names2[b.name_off2[i]:b.name_off2[i + 1]]), bytes(b.seq2[b.off2[i]:b.off2[i + 1]])))
+        return out
+    want = read(*plain)
+    assert len(want) == 30000
+    assert read(*bg) == want and read(*gzs) == want
+    assert read(bg[0], gzs[1]) == want                       # one file of each kind
+    monkeypatch.setenv("QM_INGEST_NO_BGZF", "1")             # the same file through the single zlib stream
+    assert read(*bg) == want
+    monkeypatch.delenv("QM_INGEST_NO_BGZF")
+    # a block whose payload is damaged (CRC-32 mismatch), and a file cut inside a block: errors, not silence
+    raw = bytearray(open(bg[0], "rb").read())
+    raw[len(raw) // 2] ^= 0x55
+    bad = str(tmp_path / "bad.fq.gz"); open(bad, "wb").write(bytes(raw))
+    with pytest.raises(ra.QmError):
+        read(bad, bg[1])
+    cut = str(tmp_path / "cut.fq.gz"); open(cut, "wb").write(open(bg[0], "rb").read()[:100000])
+    with pytest.raises(ra.QmError):
+        read(cut, bg[1])
+
+
 def test_ingest_engine_errors_and_empty_inputs(tmp_path):
     import rapmap_amd as ra
     e = str(tmp_path / "empty.fq"); open(e, "w").close()

@@ -384,6 +384,12 @@ def test_ingest_engine_reads_what_the_references_parser_reads(ref, lib_built, tm
         del os.environ["QM_INGEST_CHUNK"]
     want = _ref_fastx(ref, p1, p2)
     assert len(want) == 20000 and got == want
+    # the same pair as BGZF files (independent gzip members, inflated by helper threads side by side here; one multi-member gzip
+    # stream to the reference's kseq / gzread)
+    from util import write_bgzf
+    b1 = str(tmp_path / "a.bgzf.fq.gz"); b2 = str(tmp_path / "b.bgzf.fq.gz")
+    write_bgzf(b1, open(p1, "rb").read(), block=5000); write_bgzf(b2, open(p2, "rb").read(), block=65280)
+    assert _ref_fastx(ref, b1, b2) == want and ours(b1, b2, 3000, 4) == want
     fa = str(tmp_path / "t.fa.gz")
     with gz.open(fa, "wt") as f:
         for i in range(3000):

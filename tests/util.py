@@ -35,3 +35,18 @@ def assert_hits_equal(a_off, a_hits, b_off, b_hits, what=""):
         i = bad[0]
         raise AssertionError("%s: %d units differ; first unit %d:\n%s\nvs\n%s" % (
             what, len(bad), i, a_hits[a_off[i]:a_off[i + 1]], b_hits[b_off[i]:b_off[i + 1]]))
+
+
+def write_bgzf(path, data, block=60000, level=6, eof_marker=True):
+    """`data` as a BGZF file (SAM specification 4.1; what `bgzip` writes): complete gzip members of at most 64 KiB, each with
+    the 'BC' extra field that holds its compressed size - 1"""
+    import struct
+    import zlib
+    with open(path, "wb") as f:
+        chunks = [data[i:i + block] for i in range(0, len(data), block)] + ([b""] if eof_marker else [])
+        for c in chunks:
+            co = zlib.compressobj(level, zlib.DEFLATED, -15)
+            body = co.compress(c) + co.flush()
+            bsize = 12 + 6 + len(body) + 8
+            f.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1))
+            f.write(body + struct.pack("<II", zlib.crc32(c) & 0xffffffff, len(c) & 0xffffffff))
