@@ -74,6 +74,7 @@ def main():
         pool.map(_gz_whole, [(x, x + ".gz") for x in p])
     log("compressed %.1fs" % (time.time() - t))
     out = {"pairs": a.pairs, "threads": a.threads, "bytes": {k: sum(os.path.getsize(x + sfx) for x in p) for k, sfx in (("plain", ""), ("gzip", ".gz"), ("bgzf", ".bgzf.gz"))}}
+    mp = ra.QuasiMapper(qi, 0)          # keeps the device's index replica alive: the streams' contexts share it (as in bench.py, as in the CLI)
     want = None
     for kind, sfx in (("plain", ""), ("bgzf", ".bgzf.gz"), ("gzip", ".gz"), ("plain", ""), ("bgzf", ".bgzf.gz")):
         t = time.time()

@@ -505,14 +505,12 @@ const char* last_boundary(const char* b, const char* e, bool fastq) {
 // that road here: gzread below.)
 struct BgzfReader {
   const unsigned char* map = nullptr; size_t len = 0, pos = 0;    // the compressed file, and the next block to hand to a helper
-  struct Job { const unsigned char* in; size_t inLen; std::vector<char> out; size_t outLen; bool done = false, bad = false; };
+  struct Job { const unsigned char* in; size_t inLen; char* out; size_t outLen; bool done = false, bad = false; };   // out: inside the chunk the group belongs to
   std::deque<Job*> q;                          // in file order; helpers take the first one not yet taken
   size_t nextTake = 0;                         // q[nextTake] is the next job for a helper
   std::vector<std::thread> helpers;
   std::mutex mu; std::condition_variable cvJob, cvDone;
   bool stop = false, failed = false;
-  Job* cur = nullptr; size_t curOff = 0;       // the job read() is copying out of
-  size_t inFlightCap = 0;
 
   // is there a BGZF block at `p`?  -> its total size and uncompressed size
   static bool block_at(const unsigned char* p, size_t avail, size_t& bsize, size_t& isize) {
@@ -547,10 +545,10 @@ struct BgzfReader {
       while (in < j->inLen && !bad) {
         inflateReset(&zs);
         zs.next_in = (Bytef*)(j->in + in); zs.avail_in = (uInt)std::min<size_t>(j->inLen - in, 1u << 30);
-        zs.next_out = (Bytef*)(j->out.data() + out); zs.avail_out = (uInt)(j->out.size() - out);
+        zs.next_out = (Bytef*)(j->out + out); zs.avail_out = (uInt)(j->outLen - out);
         const int rc = inflate(&zs, Z_FINISH);
         if (rc != Z_STREAM_END) { bad = true; break; }
-        in = (size_t)((const unsigned char*)zs.next_in - j->in); out = (size_t)((char*)zs.next_out - j->out.data());
+        in = (size_t)((const unsigned char*)zs.next_in - j->in); out = (size_t)((char*)zs.next_out - j->out);
       }
       if (out != j->outLen) bad = true;
       std::lock_guard<std::mutex> lk(mu);
@@ -560,53 +558,138 @@ struct BgzfReader {
     inflateEnd(&zs);
   }
   void start(const unsigned char* m, size_t l, int nHelpers) {
-    map = m; len = l; pos = 0; inFlightCap = (size_t)nHelpers * 3;
+    map = m; len = l; pos = 0;
     for (int i = 0; i < nHelpers; ++i) helpers.emplace_back([this] { helper_loop(); });
   }
-  // queue further groups of blocks (about 1 MiB of output each) up to the in-flight cap; false: the file is not BGZF here
-  bool feed() {
+  // The next chunk's worth of blocks (about `want` bytes of output, at least one block; 0 at the end of the file, -1 when the
+  // file stops being BGZF): how many bytes they inflate to.  plan() only walks the headers.
+  struct Plan { size_t from, to, outLen; };
+  long plan(size_t want, Plan& P) {
+    size_t p = pos, outSum = 0;
+    while (p < len && outSum < want) {
+      size_t bs, is;
+      if (!block_at(map + p, len - p, bs, is)) { std::lock_guard<std::mutex> lk(mu); failed = true; return -1; }
+      p += bs; outSum += is;
+    }
+    P.from = pos; P.to = p; P.outLen = outSum; pos = p;
+    return (long)outSum;
+  }
+  // hand the plan's blocks to the helpers in groups of about 1 MiB of output, inflating straight into dst[0, P.outLen)
+  void submit(const Plan& P, char* dst, std::vector<Job*>& jobs) {
+    size_t p = P.from, o = 0;
     std::lock_guard<std::mutex> lk(mu);
-    while (pos < len && q.size() < inFlightCap) {
-      size_t p = pos, outSum = 0; int nb = 0;
-      while (p < len && outSum < ((size_t)1 << 20) && nb < 64) {
-        size_t bs, is;
-        if (!block_at(map + p, len - p, bs, is)) { failed = true; return false; }
-        p += bs; outSum += is; ++nb;
-      }
-      Job* j = new Job(); j->in = map + pos; j->inLen = p - pos; j->outLen = outSum; j->out.resize(outSum ? outSum : 1);
-      q.push_back(j); pos = p;
+    while (p < P.to) {
+      size_t q0 = p, outSum = 0;
+      while (p < P.to && outSum < ((size_t)1 << 20)) { size_t bs, is; block_at(map + p, len - p, bs, is); p += bs; outSum += is; }
+      Job* j = new Job(); j->in = map + q0; j->inLen = p - q0; j->out = dst + o; j->outLen = outSum;
+      o += outSum;
+      q.push_back(j); jobs.push_back(j);
       cvJob.notify_one();
     }
-    return true;
   }
-  // gzread's contract: up to `want` bytes, fewer only at the end of the input; -1 on a corrupt file
-  long read(char* dst, size_t want) {
-    size_t got = 0;
-    while (got < want) {
-      if (!cur) {
-        if (!feed()) return -1;
-        std::unique_lock<std::mutex> lk(mu);
-        if (q.empty()) break;                                  // end of file
-        Job* j = q.front();
-        cvDone.wait(lk, [&] { return j->done || failed; });
-        if (failed || j->bad) return -1;
-        q.pop_front(); --nextTake;
-        cur = j; curOff = 0;
-      }
-      const size_t n = std::min(want - got, cur->outLen - curOff);
-      memcpy(dst + got, cur->out.data() + curOff, n);
-      got += n; curOff += n;
-      if (curOff == cur->outLen) { delete cur; cur = nullptr; }
+  // all of a chunk's jobs done?  false: a block was corrupt
+  bool wait(std::vector<Job*>& jobs) {
+    std::unique_lock<std::mutex> lk(mu);
+    bool ok = true;
+    for (Job* j : jobs) {
+      cvDone.wait(lk, [&] { return j->done || failed; });
+      if (failed || j->bad) ok = false;
     }
-    return (long)got;
+    // the finished jobs are the front of the queue (chunks are waited for in the order they were submitted)
+    for (Job* j : jobs) { if (!q.empty() && q.front() == j) { q.pop_front(); --nextTake; } }
+    for (Job* j : jobs) delete j;
+    jobs.clear();
+    return ok && !failed;
   }
   ~BgzfReader() {
     { std::lock_guard<std::mutex> lk(mu); stop = true; cvJob.notify_all(); }
     for (auto& t : helpers) t.join();
     for (Job* j : q) delete j;
-    delete cur;
   }
 };
+
+// The inflate thread of a BGZF source: it only plans and stitches.  A chunk is ~4 MiB worth of blocks, whose inflated sizes
+// are known from the block trailers, so the helpers inflate STRAIGHT into the chunk's buffer at their offsets (no copy of the
+// decompressed bytes anywhere); a few chunks are in flight at once.  When a chunk's groups are all in, the partial record the
+// previous chunk ended with is put in front (a gap is left for it), the chunk is cut at its last record boundary and queued for
+// the parse workers like a block of the single-stream gz path.
+void bgzf_loop(qm_ingest* g, int s, BgzfReader* bz) {
+  Src& S = g->src[s];
+  const size_t BLK = (size_t)4 << 20, GAP = (size_t)256 << 10;
+  const size_t DEPTH = 4;
+  struct Fly { Chunk* c; BgzfReader::Plan P; std::vector<BgzfReader::Job*> jobs; };
+  std::deque<Fly*> fly;
+  std::vector<char> carry; bool first = true, planEnd = false, bad = false;
+  auto finish = [&](bool failed) {
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (failed) set_fail(g, QM_E_IO, "%s: BGZF block is corrupt or truncated", S.path.c_str());
+    for (Fly* f : fly) { put_chunk(g, f->c); }
+    S.inflDone = true; S.allHanded = S.blocks.empty();
+    g->cvWork.notify_all(); if (failed) g->cvOut.notify_all();
+  };
+  while (true) {
+    {
+      std::unique_lock<std::mutex> lk(g->mu);
+      g->cvInfl.wait(lk, [&] { return g->stop || g->failed || S.blocks.size() + fly.size() < 8 || !fly.empty(); });
+      if (g->stop || g->failed) break;
+    }
+    while (!planEnd && !bad && fly.size() < DEPTH) {
+      { std::lock_guard<std::mutex> lk(g->mu); if (S.blocks.size() + fly.size() >= 8 && !fly.empty()) break; }
+      BgzfReader::Plan P;
+      const long n = bz->plan(BLK, P);
+      if (n < 0) { bad = true; break; }
+      if (n == 0 && P.from == P.to) { planEnd = true; break; }
+      Fly* f = new Fly(); f->P = P;
+      { std::lock_guard<std::mutex> lk(g->mu); f->c = get_chunk(g); }
+      f->c->src = s; f->c->data.resize(GAP + P.outLen);
+      bz->submit(P, f->c->data.data() + GAP, f->jobs);
+      fly.push_back(f);
+    }
+    if (fly.empty()) { if (bad) { finish(true); for (Fly* f : fly) delete f; fly.clear(); return; } if (planEnd) break; continue; }
+    const double t0 = now_s();
+    Fly* f = fly.front(); fly.pop_front();
+    const bool ok = bz->wait(f->jobs);
+    Chunk* c = f->c; const size_t outLen = f->P.outLen;
+    delete f;
+    if (!ok || bad) {
+      // (the helpers may still be writing into the chunks in flight: let them finish before the buffers are recycled)
+      for (Fly* x : fly) bz->wait(x->jobs);
+      { std::lock_guard<std::mutex> lk(g->mu); put_chunk(g, c); }
+      finish(true);
+      for (Fly* x : fly) delete x;
+      fly.clear();
+      return;
+    }
+    char* base;
+    if (carry.size() <= GAP) { base = c->data.data() + GAP - carry.size(); if (!carry.empty()) memcpy(base, carry.data(), carry.size()); }
+    else {                                                 // a record longer than the gap: the slow way
+      std::vector<char> t(carry.size() + outLen);
+      memcpy(t.data(), carry.data(), carry.size()); memcpy(t.data() + carry.size(), c->data.data() + GAP, outLen);
+      c->data.swap(t); base = c->data.data();
+    }
+    const char* end = base + carry.size() + outLen;
+    if (first && end > base) { S.fastq = base[0] != '>'; first = false; }
+    const bool last = planEnd && fly.empty();
+    const char* cut = last ? end : last_boundary(base, end, S.fastq);
+    carry.assign(cut, end);
+    c->base = base; c->end = cut;
+    const double dt = now_s() - t0;
+    std::unique_lock<std::mutex> lk(g->mu);
+    g->tInfl += dt;
+    if (c->end > c->base) S.blocks.push_back(c); else put_chunk(g, c);
+    if (last) { S.inflDone = true; if (S.blocks.empty()) S.allHanded = true; g->cvWork.notify_all(); return; }
+    g->cvWork.notify_one();
+  }
+  // stopped, or the file was empty of blocks
+  for (Fly* x : fly) bz->wait(x->jobs);
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    for (Fly* x : fly) put_chunk(g, x->c);
+    if (!S.inflDone) { S.inflDone = true; S.allHanded = S.blocks.empty(); }
+    g->cvWork.notify_all();
+  }
+  for (Fly* x : fly) delete x;
+}
 
 void inflate_loop(qm_ingest* g, int s) {
   Src& S = g->src[s];
@@ -614,8 +697,13 @@ void inflate_loop(qm_ingest* g, int s) {
   // file: one zlib stream, one thread
   BgzfReader* bz = nullptr;
   gzFile f = nullptr;
-  if (S.map && S.bgzfHelpers > 0) { bz = new BgzfReader(); bz->start((const unsigned char*)S.map, S.len, S.bgzfHelpers); }
-  else {
+  if (S.map && S.bgzfHelpers > 0) {
+    bz = new BgzfReader(); bz->start((const unsigned char*)S.map, S.len, S.bgzfHelpers);
+    bgzf_loop(g, s, bz);
+    delete bz;
+    return;
+  }
+  {
     f = gzopen(S.path.c_str(), "rb");
     if (!f) { std::lock_guard<std::mutex> lk(g->mu); set_fail(g, QM_E_IO, "cannot gzopen %s", S.path.c_str()); S.inflDone = true; S.allHanded = S.blocks.empty(); g->cvWork.notify_all(); g->cvOut.notify_all(); return; }
     gzbuffer(f, 1 << 20);
@@ -636,7 +724,7 @@ void inflate_loop(qm_ingest* g, int s) {
     size_t have = carry.size(); carry.clear();
     bool eof = false, bad = false; const char* cut = nullptr;
     while (true) {
-      const long got = bz ? bz->read(c->data.data() + have, c->data.size() - have) : (long)gzread(f, c->data.data() + have, (unsigned)(c->data.size() - have));
+      const int got = gzread(f, c->data.data() + have, (unsigned)(c->data.size() - have));
       if (got < 0) { bad = true; break; }
       have += (size_t)got;
       if ((size_t)got < c->data.size() - (have - (size_t)got)) eof = true;
@@ -659,7 +747,6 @@ void inflate_loop(qm_ingest* g, int s) {
     g->cvWork.notify_one();
   }
   if (f) gzclose(f);
-  delete bz;
   std::lock_guard<std::mutex> lk(g->mu);
   if (!S.inflDone) { S.inflDone = true; S.allHanded = S.blocks.empty(); }
   g->cvWork.notify_all();
