@@ -511,6 +511,8 @@ struct BgzfReader {
   std::vector<std::thread> helpers;
   std::mutex mu; std::condition_variable cvJob, cvDone;
   bool stop = false, failed = false;
+  double busy = 0; long njobs = 0;             // helpers' inflate time, summed (profiling)
+  size_t jobBytes = getenv("QM_INGEST_BGZF_JOB") && atoll(getenv("QM_INGEST_BGZF_JOB")) > 0 ? (size_t)atoll(getenv("QM_INGEST_BGZF_JOB")) : ((size_t)256 << 10);
 
   // is there a BGZF block at `p`?  -> its total size and uncompressed size
   static bool block_at(const unsigned char* p, size_t avail, size_t& bsize, size_t& isize) {
@@ -532,6 +534,10 @@ struct BgzfReader {
   void helper_loop() {
     z_stream zs; memset(&zs, 0, sizeof(zs));
     if (inflateInit2(&zs, 15 + 16) != Z_OK) { std::lock_guard<std::mutex> lk(mu); failed = true; cvDone.notify_all(); return; }
+    // inflate writes AND re-reads its output (matches copy from the last 32 KiB): into a small buffer of the thread's own that
+    // stays in its cache, then one streaming copy to the group's place in the chunk -- measured against inflating straight into
+    // the (cold) chunk: 600 vs 435 MB/s per thread on the box (profiles/microbench/bgzf_inflate_scaling.c)
+    std::vector<char> hot;
     while (true) {
       Job* j;
       {
@@ -541,17 +547,21 @@ struct BgzfReader {
         j = q[nextTake++];
       }
       // the group: whole members one after the other (zlib checks each member's CRC-32 and length)
+      const double th0 = now_s();
       size_t in = 0, out = 0; bool bad = false;
+      if (hot.size() < j->outLen + 1) hot.resize(j->outLen + 1);
       while (in < j->inLen && !bad) {
         inflateReset(&zs);
         zs.next_in = (Bytef*)(j->in + in); zs.avail_in = (uInt)std::min<size_t>(j->inLen - in, 1u << 30);
-        zs.next_out = (Bytef*)(j->out + out); zs.avail_out = (uInt)(j->outLen - out);
+        zs.next_out = (Bytef*)(hot.data() + out); zs.avail_out = (uInt)(j->outLen - out);
         const int rc = inflate(&zs, Z_FINISH);
         if (rc != Z_STREAM_END) { bad = true; break; }
-        in = (size_t)((const unsigned char*)zs.next_in - j->in); out = (size_t)((char*)zs.next_out - j->out);
+        in = (size_t)((const unsigned char*)zs.next_in - j->in); out = (size_t)((char*)zs.next_out - hot.data());
       }
       if (out != j->outLen) bad = true;
+      else memcpy(j->out, hot.data(), out);
       std::lock_guard<std::mutex> lk(mu);
+      busy += now_s() - th0; ++njobs;
       j->bad = bad; j->done = true;
       cvDone.notify_all();
     }
@@ -574,13 +584,13 @@ struct BgzfReader {
     P.from = pos; P.to = p; P.outLen = outSum; pos = p;
     return (long)outSum;
   }
-  // hand the plan's blocks to the helpers in groups of about 1 MiB of output, inflating straight into dst[0, P.outLen)
+  // hand the plan's blocks to the helpers in groups of about jobBytes of output, each group with its place in dst[0, P.outLen)
   void submit(const Plan& P, char* dst, std::vector<Job*>& jobs) {
     size_t p = P.from, o = 0;
     std::lock_guard<std::mutex> lk(mu);
     while (p < P.to) {
       size_t q0 = p, outSum = 0;
-      while (p < P.to && outSum < ((size_t)1 << 20)) { size_t bs, is; block_at(map + p, len - p, bs, is); p += bs; outSum += is; }
+      while (p < P.to && outSum < jobBytes) { size_t bs, is; block_at(map + p, len - p, bs, is); p += bs; outSum += is; }
       Job* j = new Job(); j->in = map + q0; j->inLen = p - q0; j->out = dst + o; j->outLen = outSum;
       o += outSum;
       q.push_back(j); jobs.push_back(j);
@@ -615,11 +625,14 @@ struct BgzfReader {
 // the parse workers like a block of the single-stream gz path.
 void bgzf_loop(qm_ingest* g, int s, BgzfReader* bz) {
   Src& S = g->src[s];
-  const size_t BLK = (size_t)4 << 20, GAP = (size_t)256 << 10;
-  const size_t DEPTH = 4;
+  const size_t GAP = (size_t)256 << 10;
+  // tuning knobs (profiling): bytes per chunk, chunks in flight
+  const size_t BLK = getenv("QM_INGEST_BGZF_CHUNK") && atoll(getenv("QM_INGEST_BGZF_CHUNK")) > 0 ? (size_t)atoll(getenv("QM_INGEST_BGZF_CHUNK")) : ((size_t)4 << 20);
+  const size_t DEPTH = getenv("QM_INGEST_BGZF_DEPTH") && atoi(getenv("QM_INGEST_BGZF_DEPTH")) > 0 ? (size_t)atoi(getenv("QM_INGEST_BGZF_DEPTH")) : 4;
   struct Fly { Chunk* c; BgzfReader::Plan P; std::vector<BgzfReader::Job*> jobs; };
   std::deque<Fly*> fly;
   std::vector<char> carry; bool first = true, planEnd = false, bad = false;
+  double dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const double tStart = now_s();
   auto finish = [&](bool failed) {
     std::lock_guard<std::mutex> lk(g->mu);
     if (failed) set_fail(g, QM_E_IO, "%s: BGZF block is corrupt or truncated", S.path.c_str());
@@ -629,26 +642,35 @@ void bgzf_loop(qm_ingest* g, int s, BgzfReader* bz) {
   };
   while (true) {
     {
+      const double tg0 = now_s();
       std::unique_lock<std::mutex> lk(g->mu);
-      g->cvInfl.wait(lk, [&] { return g->stop || g->failed || S.blocks.size() + fly.size() < 8 || !fly.empty(); });
+      g->cvInfl.wait(lk, [&] { return g->stop || g->failed || S.blocks.size() + fly.size() < 8 + DEPTH || !fly.empty(); });
+      dbg[6] += now_s() - tg0;
       if (g->stop || g->failed) break;
     }
     while (!planEnd && !bad && fly.size() < DEPTH) {
-      { std::lock_guard<std::mutex> lk(g->mu); if (S.blocks.size() + fly.size() >= 8 && !fly.empty()) break; }
+      { std::lock_guard<std::mutex> lk(g->mu); if (S.blocks.size() + fly.size() >= 8 + DEPTH && !fly.empty()) break; }
       BgzfReader::Plan P;
+      const double tp0 = now_s();
       const long n = bz->plan(BLK, P);
+      dbg[0] += now_s() - tp0;
       if (n < 0) { bad = true; break; }
       if (n == 0 && P.from == P.to) { planEnd = true; break; }
       Fly* f = new Fly(); f->P = P;
+      const double ts0 = now_s();
       { std::lock_guard<std::mutex> lk(g->mu); f->c = get_chunk(g); }
+      const double ts1 = now_s();
       f->c->src = s; f->c->data.resize(GAP + P.outLen);
+      const double ts2 = now_s();
       bz->submit(P, f->c->data.data() + GAP, f->jobs);
+      dbg[1] += ts1 - ts0; dbg[2] += ts2 - ts1; dbg[3] += now_s() - ts2;
       fly.push_back(f);
     }
     if (fly.empty()) { if (bad) { finish(true); for (Fly* f : fly) delete f; fly.clear(); return; } if (planEnd) break; continue; }
     const double t0 = now_s();
     Fly* f = fly.front(); fly.pop_front();
     const bool ok = bz->wait(f->jobs);
+    dbg[4] += now_s() - t0;
     Chunk* c = f->c; const size_t outLen = f->P.outLen;
     delete f;
     if (!ok || bad) {
@@ -677,7 +699,12 @@ void bgzf_loop(qm_ingest* g, int s, BgzfReader* bz) {
     std::unique_lock<std::mutex> lk(g->mu);
     g->tInfl += dt;
     if (c->end > c->base) S.blocks.push_back(c); else put_chunk(g, c);
-    if (last) { S.inflDone = true; if (S.blocks.empty()) S.allHanded = true; g->cvWork.notify_all(); return; }
+    dbg[5] += dt;
+    if (last) {
+      S.inflDone = true; if (S.blocks.empty()) S.allHanded = true; g->cvWork.notify_all();
+      if (getenv("QM_INGEST_DEBUG")) fprintf(stderr, "[bgzf %d] plan %.3f get_chunk %.3f resize %.3f submit %.3f wait %.3f (wait+stitch %.3f) gate %.3f total %.3f s\n", s, dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6], now_s() - tStart);
+      return;
+    }
     g->cvWork.notify_one();
   }
   // stopped, or the file was empty of blocks
@@ -700,6 +727,7 @@ void inflate_loop(qm_ingest* g, int s) {
   if (S.map && S.bgzfHelpers > 0) {
     bz = new BgzfReader(); bz->start((const unsigned char*)S.map, S.len, S.bgzfHelpers);
     bgzf_loop(g, s, bz);
+    if (getenv("QM_INGEST_DEBUG")) fprintf(stderr, "[bgzf %d] helpers: %ld jobs, %.3f s busy in total\n", s, bz->njobs, bz->busy);
     delete bz;
     return;
   }
