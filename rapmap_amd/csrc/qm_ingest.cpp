@@ -534,9 +534,8 @@ struct BgzfReader {
   void helper_loop() {
     z_stream zs; memset(&zs, 0, sizeof(zs));
     if (inflateInit2(&zs, 15 + 16) != Z_OK) { std::lock_guard<std::mutex> lk(mu); failed = true; cvDone.notify_all(); return; }
-    // inflate writes AND re-reads its output (matches copy from the last 32 KiB): into a small buffer of the thread's own that
-    // stays in its cache, then one streaming copy to the group's place in the chunk -- measured against inflating straight into
-    // the (cold) chunk: 600 vs 435 MB/s per thread on the box (profiles/microbench/bgzf_inflate_scaling.c)
+    // inflate writes AND re-reads its output (matches copy from the last 32 KiB): into a small buffer of the thread's own, then
+    // one copy to the group's place in the chunk (measured no slower than inflating straight into the chunk, profiles/r03/bgzf_notes.txt)
     std::vector<char> hot;
     while (true) {
       Job* j;
