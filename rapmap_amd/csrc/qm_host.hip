@@ -654,6 +654,7 @@ struct RunReq {
   bool keepIntervals = false;     // SA-interval hits kept for qm_fetch_intervals
   bool keepFound = false;         // foundHit per read kept for qm_fetch_found
   bool mergeOnly = false;         // stage B without the caller-level bookkeeping, tooMany flags kept
+  bool longReads = false;         // the batch holds reads beyond QM_MAX_READ_LEN (set by map_device_impl from max_read_len)
   // QM_RUN_FROM_INTERVALS: device arrays
   const qm_sa_interval_hit* ivIn = nullptr; const long long* ivInOff = nullptr; const int* lenIn = nullptr; const unsigned char* foundIn = nullptr;
 };
@@ -668,6 +669,13 @@ static DevIndex dev_index(const qm_ctx* c) {
 
 // ---- stage A: one wavefront per read (collector + hits->mappings, or one of the two alone), with its retries: the per-read
 // lists or the interval output outgrew their buffers (grow, redo), -s reads left on the slow queue (second, small launch).
+// the longest read a call takes: QM_MAX_LONG_READ_LEN; with -s only while the band's ring edition of the alignment kernel has a
+// long-image form (--dpBandwidth 0 .. 97; the full-band ring holds every column of a 512-base alignment and no more)
+static int len_limit(const qm_opts* o) {
+  if (!o->sel_aln) return QM_MAX_LONG_READ_LEN;
+  return (o->dp_bandwidth >= 0 && o->dp_bandwidth <= 97) ? QM_MAX_LONG_READ_LEN : QM_MAX_READ_LEN;
+}
+
 static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n, const void* d_seq1, const void* d_off1, const void* d_seq2,
                        const void* d_off2, int ns, ChunkFeeder* feeder, u64* hscal) {
   int rc;
@@ -763,12 +771,33 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
       }
       feeder = nullptr;                                   // a retry finds everything resident
     } else if (nreads > 0) HIPCHK(launch(B, grid));
+    if (twoPass && rq.longReads && nreads > 0) {
+      // -s with reads beyond QM_MAX_READ_LEN in the batch: the collector set them aside (map_read); their intervals come from a
+      // second, small launch of the 32-slot chain-scoring collector, before the list kernel goes over all reads
+      HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      const int st1 = (int)(hscal[QM_SC_STATUS] & 0xffffffffu);
+      if (hscal[QM_SC_SLOWCNT] > 0 && !(st1 & 23)) {
+        const int64_t nl_ = (int64_t)hscal[QM_SC_SLOWCNT];
+        if ((int64_t)hscal[QM_SC_SLOWMAX] > QM_MAX_LONG_READ_LEN)
+          return fail(QM_E_TOOLONG, "a read of %lld characters: longer than the %d the long-read pass takes", (long long)hscal[QM_SC_SLOWMAX], QM_MAX_LONG_READ_LEN);
+        if ((rc = ensure(c->d_slowq, c->capSlowq, nl_))) return rc;
+        HIPCHK(qmk_collect_slow(c->d_lcnt, nreads, c->d_slowq, (unsigned long long*)(c->d_scal + QM_SC_SLOWQ), c->stream));
+        ReadBatch S2 = B;
+        S2.slowq = c->d_slowq; S2.nreads = nl_;
+        const int g2 = qmk_map_grid(nl_, c->numCU);
+        HIPCHK(qmk_map_reads(&ix, &S2, -32, g2 < grid ? g2 : grid, c->numCU, c->stream));
+        // the list kernel's own slow queue (reads whose intervals overflow its scratch) starts from zero
+        HIPCHK(hipMemsetAsync(c->d_scal + QM_SC_SLOWCNT, 0, 3 * sizeof(u64), c->stream));
+        c->lastSlowReads = nl_;
+      }
+    }
     if (twoPass && nreads > 0) HIPCHK(qmk_h2m(&ix, &H, grid, c->numCU, c->stream));
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     int status = (int)(hscal[QM_SC_STATUS] & 0xffffffffu);
-    if (!o->sel_aln && rq.mode != QM_RUN_FROM_INTERVALS && hscal[QM_SC_SLOWCNT] > 0 && !(status & 23)) {
+    if ((!o->sel_aln || rq.mode == QM_RUN_COLLECT) && rq.mode != QM_RUN_FROM_INTERVALS && hscal[QM_SC_SLOWCNT] > 0 && !(status & 23)) {
       // reads longer than the slot class of this launch (always: longer than QM_MAX_READ_LEN) were set aside: gather them
       // and map them with the 32-slot kernels -- a second, small launch; everything it writes (lists, intervals, foundHit)
       // goes where the first pass would have put it
@@ -823,7 +852,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
       if (ht > 0) for (int i = 0; i < 8; ++i) fprintf(stderr, "[qm timing h2m] %-16s %6.2f %%  %10.0f clk/read\n", hm[i], 100.0 * hscal[32 + i] / ht, (double)hscal[32 + i] / (double)nreads);
     }
 #endif
-    if (status & 4) return fail(QM_E_TOOLONG, "a read is longer than %d characters (-s: the alignment kernels are sized for that; otherwise the long-read pass takes up to %d)", o->sel_aln ? QM_MAX_READ_LEN : QM_MAX_LONG_READ_LEN, QM_MAX_LONG_READ_LEN);
+    if (status & 4) return fail(QM_E_TOOLONG, "a read is longer than %d characters (-s: the alignment kernels are sized for that; otherwise the long-read pass takes up to %d)", len_limit(o), QM_MAX_LONG_READ_LEN);
     if (status & 2) return fail(QM_E_UNSUPPORTED, "an SA-interval list exceeded %d entries (max_interval too large)", QM_GCAP);
     if (status & 8) return fail(QM_E_STATE, "selective alignment: a read overflowed the scratch sized for it (internal error)");
     if (status & 17) {           // a bump allocator ran out: grow and redo the batch
@@ -900,6 +929,7 @@ static int run_stage_b(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
     A.seq1 = (const unsigned char*)d_seq1; A.seq2 = (const unsigned char*)d_seq2; A.text = c->d_text;
     A.txp_off = c->d_txpOff; A.txp_len = c->d_txpLen; A.tmp = c->d_tmp; A.toff = c->d_toff; A.tkeys = c->d_tkeys; A.tsc = c->d_tsc;
     A.match = o->match_score; A.mismatch = o->mismatch_penalty; A.gap_open = o->gap_open; A.gap_extend = o->gap_extend;
+    A.long_reads = rq.longReads ? 1 : 0;
     A.bandwidth = o->dp_bandwidth; A.hard_filter = o->hard_filter; A.policy = o->aln_policy; A.min_score_fraction = o->min_score_fraction;
     HIPCHK(hipMemsetAsync(c->d_cnt + n, 0, sizeof(uint32_t), c->stream));
     if (rq.mergeOnly) {
@@ -951,8 +981,8 @@ static int map_device_impl(qm_ctx* c, const qm_opts* o, int64_t n, const void* d
   int rc = check_opts(o);
   if (rc) return rc;
   if ((d_seq2 == nullptr) != (d_off2 == nullptr)) return fail(QM_E_ARG, "seq2/off2 must both be given or both be null");
-  if (max_read_len > (o->sel_aln ? QM_MAX_READ_LEN : QM_MAX_LONG_READ_LEN))
-    return fail(QM_E_TOOLONG, "read length %d > %d", max_read_len, o->sel_aln ? QM_MAX_READ_LEN : QM_MAX_LONG_READ_LEN);
+  if (max_read_len > (len_limit(o)))
+    return fail(QM_E_TOOLONG, "read length %d > %d", max_read_len, len_limit(o));
   HIPCHK(hipSetDevice(c->device));
   // 64-character slots per read: picks the kernel instantiation.  `short_read_len` (host callers: the longest read that is not
   // beyond QM_MAX_READ_LEN) picks it when the batch also holds long reads -- those are set aside by the launch whatever its
@@ -965,6 +995,7 @@ static int map_device_impl(qm_ctx* c, const qm_opts* o, int64_t n, const void* d
   HIPCHK(hipEventRecord(c->evA, c->stream));
   RunReq r2 = rq;
   r2.keepIntervals = rq.keepIntervals || c->debug != 0;
+  r2.longReads = max_read_len > QM_MAX_READ_LEN;
   if ((rc = run_stage_a(c, o, r2, n, d_seq1, d_off1, d_seq2, d_off2, ns, feeder, hscal))) return rc;
   long long total = 0;
   if ((rc = run_stage_b(c, o, r2, n, paired, d_seq1, d_off1, d_seq2, d_off2, hscal, total))) return rc;
@@ -1023,7 +1054,7 @@ static int map_host(qm_ctx* c, const qm_opts* o, int64_t n, const char* seq1, co
   if ((rc = check_opts(o))) return rc;
   if ((rc = stage_offsets(c, n, off1, c->d_seq1, c->capSeq1, c->d_off1, c->capOff1, maxLen, maxShort))) return rc;
   if (seq2 && (rc = stage_offsets(c, n, off2, c->d_seq2, c->capSeq2, c->d_off2, c->capOff2, maxLen, maxShort))) return rc;
-  const int32_t lim = o->sel_aln ? QM_MAX_READ_LEN : QM_MAX_LONG_READ_LEN;
+  const int32_t lim = len_limit(o);
   if (maxLen > lim) { hipStreamSynchronize(c->copyStream); return fail(QM_E_TOOLONG, "read length %d > %d%s", maxLen, lim, o->sel_aln ? " (-s)" : ""); }
   // the characters follow chunk by chunk, each chunk's kernel behind its own copy (ChunkFeeder); QM_HOST_CHUNK = units per chunk
   HostFeed hf = {c, seq1, off1, seq2, off2};
@@ -1157,7 +1188,7 @@ int qm_collect_reads(qm_ctx* c, const qm_opts* o, int64_t n, const char* seq, co
   if (n == 0) off = &zero;
   int32_t maxLen = 0;
   for (int64_t i = 0; i < n; ++i) { const int64_t l = off[i + 1] - off[i]; if (l < 0) return fail(QM_E_ARG, "offsets not monotone"); if (l > maxLen) maxLen = (int32_t)(l > 0x7fffffff ? 0x7fffffff : l); }
-  if (maxLen > (o->sel_aln ? QM_MAX_READ_LEN : QM_MAX_LONG_READ_LEN)) return fail(QM_E_TOOLONG, "read length %d > %d", maxLen, o->sel_aln ? QM_MAX_READ_LEN : QM_MAX_LONG_READ_LEN);
+  if (maxLen > (len_limit(o))) return fail(QM_E_TOOLONG, "read length %d > %d", maxLen, len_limit(o));
   if ((rc = ensure(c->d_seq1, c->capSeq1, off[n] + 64))) return rc;
   if ((rc = ensure(c->d_off1, c->capOff1, n + 1))) return rc;
   if ((rc = upload(c, c->d_off1, off, (size_t)(n + 1) * 8))) return rc;
@@ -1195,7 +1226,7 @@ int qm_hits_to_mappings(qm_ctx* c, const qm_opts* o, int64_t n, const int32_t* r
   if (ni > 0 && !ints) return fail(QM_E_ARG, "null intervals");
   for (int64_t i = 0; i < n; ++i) {
     if (int_offsets[i + 1] < int_offsets[i]) return fail(QM_E_ARG, "interval offsets not monotone");
-    if (read_len[i] < 0 || read_len[i] > (o->sel_aln ? QM_MAX_READ_LEN : QM_MAX_LONG_READ_LEN)) return fail(QM_E_TOOLONG, "read length %d > %d", read_len[i], o->sel_aln ? QM_MAX_READ_LEN : QM_MAX_LONG_READ_LEN);
+    if (read_len[i] < 0 || read_len[i] > (len_limit(o))) return fail(QM_E_TOOLONG, "read length %d > %d", read_len[i], len_limit(o));
     int nf = 0, nr = 0; bool seenRc = false;
     for (int64_t j = int_offsets[i]; j < int_offsets[i + 1]; ++j) {
       if (ints[j].query_rc) { ++nr; seenRc = true; } else { ++nf; if (seenRc) return fail(QM_E_ARG, "read %lld: forward-strand intervals must precede the reverse-complement ones", (long long)i); }

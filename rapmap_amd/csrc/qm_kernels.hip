@@ -141,13 +141,14 @@ __global__ __launch_bounds__(256) void qm_sel_plan_kernel(PairBatch P, SelBatch 
 }
 // one row of 16 lanes per ksw2 alignment, four alignments per wavefront (sel_ksw_extz2_rows); RING = column slots per
 // alignment, chosen from --dpBandwidth at launch (sel_ksw_ring_slots)
-template <int RING, int WAVES>
+// MAXLEN: QM_KSW_MAXLEN, or QM_KSW_MAXLEN_LONG for a batch with reads beyond QM_MAX_READ_LEN (images of 2 120 bytes)
+template <int RING, int WAVES, int MAXLEN = QM_KSW_MAXLEN>
 __global__ __launch_bounds__(64 * WAVES) void qm_sel_align_kernel(PairBatch P, SelBatch A) {
-  __shared__ KswRowT<RING> rows[WAVES][4];
+  __shared__ KswRowT<RING, MAXLEN> rows[WAVES][4];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const unsigned long long nt = *A.ntasks;
   for (unsigned long long t = ((unsigned long long)blockIdx.x * WAVES + wave) * 4; t < nt; t += (unsigned long long)gridDim.x * (4 * WAVES))
-    sel_tasks_align_rows<RING>(P, A, t, nt, rows[wave]);
+    sel_tasks_align_rows<RING, MAXLEN>(P, A, t, nt, rows[wave]);
 }
 __global__ __launch_bounds__(256) void qm_sel_finish_kernel(PairBatch P, SelBatch A) {
   __shared__ unsigned long long sc[6];
@@ -404,6 +405,14 @@ hipError_t qmk_sel_align_finish(const void* pp, const void* ap, int num_cu, hipS
   const PairBatch& P = *(const PairBatch*)pp; const SelBatch& A = *(const SelBatch*)ap;
   if (A.u1 <= A.u0) return hipSuccess;
   const unsigned nb = (unsigned)((A.u1 - A.u0 + 255) / 256);
+  if (A.long_reads) {                                    // reads of 513 .. 2048 characters in the batch: two waves per block, long images
+    switch (sel_ksw_ring_slots(A.bandwidth)) {
+      case 32: hipLaunchKernelGGL((qm_sel_align_kernel<32, 2, QM_KSW_MAXLEN_LONG>), dim3((unsigned)(num_cu * 4)), dim3(128), 0, st, P, A); break;
+      case 64: hipLaunchKernelGGL((qm_sel_align_kernel<64, 2, QM_KSW_MAXLEN_LONG>), dim3((unsigned)(num_cu * 4)), dim3(128), 0, st, P, A); break;
+      case 128: hipLaunchKernelGGL((qm_sel_align_kernel<128, 2, QM_KSW_MAXLEN_LONG>), dim3((unsigned)(num_cu * 3)), dim3(128), 0, st, P, A); break;
+      default: return hipErrorInvalidValue;               // the full-band ring holds every column of a 512-base alignment only (the host refuses the combination)
+    }
+  } else
   switch (sel_ksw_ring_slots(A.bandwidth)) {            // one kernel for every --dpBandwidth: the band decides the ring
     case 32: hipLaunchKernelGGL((qm_sel_align_kernel<32, 4>), dim3((unsigned)(num_cu * 8)), dim3(256), 0, st, P, A); break;   // register edition (--dpBandwidth <= 15)
     case 64: hipLaunchKernelGGL((qm_sel_align_kernel<64, 4>), dim3((unsigned)(num_cu * 8)), dim3(256), 0, st, P, A); break;

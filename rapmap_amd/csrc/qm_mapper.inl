@@ -1830,8 +1830,8 @@ QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, lon
   const bool tooLong = rawLen > 64 * NS;
   // A read that does not fit this kernel's slots is set aside for the long-read pass (a second, small launch of the NS = 32
   // kernels over the queue of such reads; the host sizes nothing from it but checks the longest against QM_MAX_LONG_READ_LEN).
-  // With -s there is no such pass (the ksw2 images are sized for QM_MAX_READ_LEN): the batch fails as before.
-  const bool setAside = tooLong && !(F & QM_F_SEL) && NS < 32;
+  // (-s: the set-aside reads get their intervals from the 32-slot chain-scoring collector before the list kernel runs.)
+  const bool setAside = tooLong && NS < 32;
   if (tooLong) {
     QM_LANES(l) {
       if (l == 0) {

@@ -77,7 +77,7 @@ static hipError_t launch_reads_ns(const DevIndex& ix, const ReadBatch& B, bool c
     // collector-only kernels: the chain-scoring flavours for every slot count (first pass of a fused -s call: without the
     // chaining code they fit the register budget of the default kernel, so they are built for its occupancy), the others
     // only at eight slots (the stage entry qm_collect_reads, any read length)
-    if constexpr (NS <= 8) {
+    if constexpr (NS <= 8 || NS == 32) {                   // (32: the long-read pass of a -s call)
       switch (F) {
         case QM_F_SEL: QM_LAUNCH(W0, QM_F_SEL | QM_F_COLLECT); return hipGetLastError();
         case QM_F_SEL | QM_F_PH: QM_LAUNCH(WPH, QM_F_SEL | QM_F_PH | QM_F_COLLECT); return hipGetLastError();

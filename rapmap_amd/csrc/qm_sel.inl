@@ -537,6 +537,7 @@ struct SelBatch {                    // launch arguments of the -s kernels (on t
   long long u0, u1;                            // the units [u0, u1) this launch of plan / finish covers (the batch goes through
                                                // plan -> align -> finish in chunks: the plan of chunk i+1 runs under the align of chunk i)
   int match, mismatch, gap_open, gap_extend, bandwidth, hard_filter, policy;
+  int long_reads;                              // the batch holds reads beyond QM_MAX_READ_LEN: the long editions of the alignment kernel
   double min_score_fraction;
 };
 
@@ -559,15 +560,16 @@ struct SelBatch {                    // launch arguments of the -s kernels (on t
 //   TX[t] = target[t] (t < tlen), 0 (t < tlen16), query[qlen - 1 - (t - tlen16)] beyond -- a column's target character
 // Everything is per-lane (row-uniform) VALU work: no scalar control per alignment.
 #define QM_KSW_MAXLEN (QM_MAX_READ_LEN + 32)                // read + 20 extra target characters, rounded up
-template <int RING>
+#define QM_KSW_MAXLEN_LONG (QM_MAX_LONG_READ_LEN + 32)      // ... of a batch that holds reads beyond QM_MAX_READ_LEN (the long editions of the kernel)
+template <int RING, int MAXLEN = QM_KSW_MAXLEN>
 struct KswRowT {                                  // one alignment's LDS block (1232 bytes at RING = 64)
-  unsigned char QX[QM_KSW_MAXLEN + 40], TX[QM_KSW_MAXLEN + 40];
+  unsigned char QX[MAXLEN + 40], TX[MAXLEN + 40];
   u32 ST[RING]; int HH[RING]; unsigned char SS[RING];
 };
 // --dpBandwidth <= 15 (the default): a round touches at most 32 columns, two per lane -- the register edition
 // (sel_ksw_extz2_rows_reg, "32 slots"): no ring at all, the block holds the two images only
-template <>
-struct KswRowT<32> { unsigned char QX[QM_KSW_MAXLEN + 40], TX[QM_KSW_MAXLEN + 40]; };
+template <int MAXLEN>
+struct KswRowT<32, MAXLEN> { unsigned char QX[MAXLEN + 40], TX[MAXLEN + 40]; };
 inline constexpr int sel_ksw_ring_slots(int w) {   // host + device (constexpr)
   return (w >= 0 && w <= 15) ? 32 : ((w >= 0 && w <= 33) ? 64 : ((w >= 0 && w <= 97) ? 128 : 1024)); }
 static_assert(QM_KSW_MAXLEN + 48 <= 1024, "the full-band ring must hold every column of the longest alignment");
@@ -579,9 +581,10 @@ static_assert(QM_KSW_MAXLEN + 48 <= 1024, "the full-band ring must hold every co
 // the four difference bytes, the score byte and H of both columns live in registers -- no ring in LDS, no slot arithmetic, no
 // stores; neighbours come over DPP.  Cell for cell the same arithmetic as sel_ksw_extz2_rows<RING> (see there for the SSE kernel's
 // conventions it reproduces); the two are held against each other and against the reference's kernel by tests/test_ksw_variants.py.
-QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>& qlenv, const LV<int>& tlenv, KswRowT<32>* blk, const signed char* mat, int q, int e, int wIn,
+template <int MAXLEN>
+QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>& qlenv, const LV<int>& tlenv, KswRowT<32, MAXLEN>* blk, const signed char* mat, int q, int e, int wIn,
                                    LV<int>& score) {
-  typedef KswRowT<32> Row;
+  typedef KswRowT<32, MAXLEN> Row;
   const int NEG = -0x40000000;
   const int m = 5;
   const int qe = q + e;
@@ -650,9 +653,9 @@ QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>& qlenv, const LV<int>& tlenv, K
       const int t0 = stv[l] + (l & 15), t1 = t0 + 16;
       inCore0[l] = act[l] && t0 <= env[l]; inCore1[l] = act[l] && t1 <= env[l];
       const bool inScore0 = act[l] && t0 >= st0v[l] && t0 <= smaxv[l], inScore1 = act[l] && t1 >= st0v[l] && t1 <= smaxv[l];
-      int qi0 = 16 + r - t0; qi0 = qi0 < 0 ? 0 : (qi0 > QM_KSW_MAXLEN + 39 ? QM_KSW_MAXLEN + 39 : qi0);
-      int qi1 = 16 + r - t1; qi1 = qi1 < 0 ? 0 : (qi1 > QM_KSW_MAXLEN + 39 ? QM_KSW_MAXLEN + 39 : qi1);
-      const int ti0 = t0 > QM_KSW_MAXLEN + 39 ? QM_KSW_MAXLEN + 39 : t0, ti1 = t1 > QM_KSW_MAXLEN + 39 ? QM_KSW_MAXLEN + 39 : t1;
+      int qi0 = 16 + r - t0; qi0 = qi0 < 0 ? 0 : (qi0 > MAXLEN + 39 ? MAXLEN + 39 : qi0);
+      int qi1 = 16 + r - t1; qi1 = qi1 < 0 ? 0 : (qi1 > MAXLEN + 39 ? MAXLEN + 39 : qi1);
+      const int ti0 = t0 > MAXLEN + 39 ? MAXLEN + 39 : t0, ti1 = t1 > MAXLEN + 39 ? MAXLEN + 39 : t1;
       const int sv0 = B.QX[qi0], sq0 = B.TX[ti0], sv1 = B.QX[qi1], sq1 = B.TX[ti1];
       int tmp0 = (sq0 == sv0) ? sc_mch : sc_mis; tmp0 = (sq0 == m1 || sv0 == m1) ? sc_N : tmp0;
       int tmp1 = (sq1 == sv1) ? sc_mch : sc_mis; tmp1 = (sq1 == m1 || sv1 == m1) ? sc_N : tmp1;
@@ -707,12 +710,12 @@ QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>& qlenv, const LV<int>& tlenv, K
   QM_LANES(l) { score[l] = (qlenv[l] <= 0 || tlenv[l] <= 0) ? NEG : -neg[l]; }
 }
 
-template <int RING>
-QM_DEV void sel_ksw_extz2_rows(const LV<int>& qlenv, const LV<int>& tlenv, KswRowT<RING>* blk, const signed char* mat, int q, int e, int wIn,
+template <int RING, int MAXLEN = QM_KSW_MAXLEN>
+QM_DEV void sel_ksw_extz2_rows(const LV<int>& qlenv, const LV<int>& tlenv, KswRowT<RING, MAXLEN>* blk, const signed char* mat, int q, int e, int wIn,
                                LV<int>& score) {
-  if constexpr (RING == 32) { sel_ksw_extz2_rows_reg(qlenv, tlenv, blk, mat, q, e, wIn, score); return; }
+  if constexpr (RING == 32) { sel_ksw_extz2_rows_reg<MAXLEN>(qlenv, tlenv, blk, mat, q, e, wIn, score); return; }
   else {
-  typedef KswRowT<RING> Row;
+  typedef KswRowT<RING, MAXLEN> Row;
   constexpr int RM = RING - 1;
   constexpr int NV = RING / 16 + 1;                 // 16-column vectors a round may touch
   const int NEG = -0x40000000;
@@ -801,9 +804,9 @@ QM_DEV void sel_ksw_extz2_rows(const LV<int>& qlenv, const LV<int>& tlenv, KswRo
       QM_LANES(l) {
         Row& B = blk[l >> 4];
         const int t0 = stv[l] + 32 * it + (l & 15), t1 = t0 + 16;
-        int qi0 = 16 + r - t0; qi0 = qi0 < 0 ? 0 : (qi0 > QM_KSW_MAXLEN + 39 ? QM_KSW_MAXLEN + 39 : qi0);
-        int qi1 = 16 + r - t1; qi1 = qi1 < 0 ? 0 : (qi1 > QM_KSW_MAXLEN + 39 ? QM_KSW_MAXLEN + 39 : qi1);
-        const int ti0 = t0 > QM_KSW_MAXLEN + 39 ? QM_KSW_MAXLEN + 39 : t0, ti1 = t1 > QM_KSW_MAXLEN + 39 ? QM_KSW_MAXLEN + 39 : t1;
+        int qi0 = 16 + r - t0; qi0 = qi0 < 0 ? 0 : (qi0 > MAXLEN + 39 ? MAXLEN + 39 : qi0);
+        int qi1 = 16 + r - t1; qi1 = qi1 < 0 ? 0 : (qi1 > MAXLEN + 39 ? MAXLEN + 39 : qi1);
+        const int ti0 = t0 > MAXLEN + 39 ? MAXLEN + 39 : t0, ti1 = t1 > MAXLEN + 39 ? MAXLEN + 39 : t1;
         const int sv0 = B.QX[qi0], sq0 = B.TX[ti0], sv1 = B.QX[qi1], sq1 = B.TX[ti1];
         int tmp0 = (sq0 == sv0) ? sc_mch : sc_mis; tmp0 = (sq0 == m1 || sv0 == m1) ? sc_N : tmp0;
         int tmp1 = (sq1 == sv1) ? sc_mch : sc_mis; tmp1 = (sq1 == m1 || sv1 == m1) ? sc_N : tmp1;
@@ -1131,8 +1134,8 @@ QM_DEV void sel_unit_plan(const PairBatch& P, const SelBatch& A, long long u, Un
 
 // Tasks t0 .. t0+3 (those below nt), one per row of 16 lanes: stage the two score-phase images straight from the read and
 // the transcript text, run the row kernel, lane 0 of every row stores its score.
-template <int RING>
-QM_DEV void sel_tasks_align_rows(const PairBatch& P, const SelBatch& A, unsigned long long t0, unsigned long long nt, KswRowT<RING>* blk) {
+template <int RING, int MAXLEN = QM_KSW_MAXLEN>
+QM_DEV void sel_tasks_align_rows(const PairBatch& P, const SelBatch& A, unsigned long long t0, unsigned long long nt, KswRowT<RING, MAXLEN>* blk) {
   LV<int> ql, tl, gs;
   LV<const unsigned char*> rd, tx; LV<int> rl, ro, fw;
   QM_LANES(l) {
@@ -1151,14 +1154,14 @@ QM_DEV void sel_tasks_align_rows(const PairBatch& P, const SelBatch& A, unsigned
   LV<int> need;
   QM_LANES(l) { need[l] = gs[l] >= 0 ? ((tl[l] + 15) / 16 * 16) + ql[l] + 48 : 0; }
   const int needMax = wave_max(need);
-  const int stageEnd = needMax < QM_KSW_MAXLEN + 40 ? needMax : QM_KSW_MAXLEN + 40;
+  const int stageEnd = needMax < MAXLEN + 40 ? needMax : MAXLEN + 40;
   for (int i0 = 0; i0 < stageEnd; i0 += 16) {
     QM_LANES(l) {
       if (gs[l] >= 0) {
-        KswRowT<RING>& B = blk[l >> 4];
+        KswRowT<RING, MAXLEN>& B = blk[l >> 4];
         const int i = i0 + (l & 15);
         const int qlen = ql[l], tlen = tl[l], tlen16 = (tlen + 15) / 16 * 16;
-        if (i < QM_KSW_MAXLEN + 40) {
+        if (i < MAXLEN + 40) {
           B.QX[i] = (i >= 16 && i < 16 + qlen) ? sel_nt4(sel_read_char(rd[l], rl[l], fw[l] != 0, ro[l] + i - 16)) : (unsigned char)0;
           const int j = i - tlen16;
           unsigned char c = 0;
@@ -1176,7 +1179,7 @@ QM_DEV void sel_tasks_align_rows(const PairBatch& P, const SelBatch& A, unsigned
   for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) mat[i * 5 + j] = (signed char)(i == j ? a : b); mat[i * 5 + 4] = 0; }
   for (int j = 0; j < 5; ++j) mat[20 + j] = 0;
   LV<int> sc;
-  sel_ksw_extz2_rows<RING>(ql, tl, blk, mat, (signed char)A.gap_open, (signed char)A.gap_extend, A.bandwidth, sc);
+  sel_ksw_extz2_rows<RING, MAXLEN>(ql, tl, blk, mat, (signed char)A.gap_open, (signed char)A.gap_extend, A.bandwidth, sc);
   QM_LANES(l) { if (gs[l] >= 0 && (l & 15) == 0) A.tsc[gs[l]] = sc[l]; }
   wave_fence();
 }

@@ -102,7 +102,30 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
         }
       }
     }
+    auto rawLen = [&](long long r) -> long long {
+      const unsigned char* src; const long long* off; long long unit; read_src(B, r, src, off, unit);
+      return off[unit + 1] - off[unit];
+    };
     if (o->sel_aln && scal[QM_SC_SLOWCNT] > 0 && !(status & 1)) {
+      // -s, reads beyond the slot class (the device: the 32-slot chain-scoring collector, then the list kernel; here the fused
+      // 32-slot kernel).  A read whose intervals overflow the scratch is queued again, for the slow pass below.
+      std::vector<long long> q;
+      for (long long r = 0; r < nreads; ++r) if (lcnt[r] == QM_LCNT_SLOW && rawLen(r) > 64 * ns) q.push_back(r);
+      bool tooLong = false;
+      for (long long r : q) if (rawLen(r) > QM_MAX_LONG_READ_LEN) tooLong = true;
+      if (tooLong || (!q.empty() && sel_ksw_ring_slots(o->dp_bandwidth) > 128)) { status |= 4; for (long long r : q) lcnt[r] = 0; }
+      else if (!q.empty()) {
+        ReadBatch S2 = B; S2.slowq = q.data(); S2.nreads = (long long)q.size();
+        const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP) | QM_F_SEL;
+        for (long long r = 0; r < (long long)q.size(); ++r) {
+#define QE_LONGS(F_) { static WaveMem<32> M; stage_offsets<32, F_>(S2, r, M, 0); stage_chars<32, F_>(S2, r, M, 0); \
+                       map_read<32, F_>(ix, S2, read_id<F_, 32>(S2, r), r, S2.nreads, 0, M, gs.data(), wa[r % 7], selscr, nullptr); }
+          switch (F) { case 4: QE_LONGS(4) break; case 5: QE_LONGS(5) break; case 6: QE_LONGS(6) break; default: QE_LONGS(7) break; }
+#undef QE_LONGS
+        }
+      }
+    }
+    if (o->sel_aln && scal[QM_SC_SLOWCNT] > 0 && !(status & (1 | 4))) {
       // the slow pass of -s (see qm_host.hip): the queued reads again, on scratch sized for the largest of them
       const long long need = (((long long)scal[QM_SC_SLOWMAX] + 63) / 64) * 64 + 64;
       std::vector<unsigned char> dmem((size_t)SelScratchDyn::bytes_for(need));
@@ -114,11 +137,16 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
       for (long long r = 0; r < (long long)q.size(); ++r) {
 #define QE_SLOW(NS_, F_) { static WaveMem<NS_> M; stage_offsets<NS_, F_>(S2, r, M, 0); stage_chars<NS_, F_>(S2, r, M, 0); \
                            map_read<NS_, F_>(ix, S2, read_id<F_>(S2, r), r, S2.nreads, 0, M, gs.data(), wa[r % 7], selscr, &sellds, &dyn); }
+#define QE_SLOWL(F_) { static WaveMem<32> M; stage_offsets<32, F_>(S2, r, M, 0); stage_chars<32, F_>(S2, r, M, 0); \
+                       map_read<32, F_>(ix, S2, read_id<F_, 32>(S2, r), r, S2.nreads, 0, M, gs.data(), wa[r % 7], selscr, &sellds, &dyn); }
+        if (rawLen(q[(size_t)r]) > 64 * ns) { switch (F) { case 4: QE_SLOWL(4) break; case 5: QE_SLOWL(5) break; case 6: QE_SLOWL(6) break; default: QE_SLOWL(7) break; } }
+        else
         if (ns == 2) { switch (F) { case 4: QE_SLOW(2, 4) break; case 5: QE_SLOW(2, 5) break; case 6: QE_SLOW(2, 6) break; default: QE_SLOW(2, 7) break; } }
         else if (ns == 3) { switch (F) { case 4: QE_SLOW(3, 4) break; case 5: QE_SLOW(3, 5) break; case 6: QE_SLOW(3, 6) break; default: QE_SLOW(3, 7) break; } }
         else if (ns == 8) { switch (F) { case 4: QE_SLOW(8, 4) break; case 5: QE_SLOW(8, 5) break; case 6: QE_SLOW(8, 6) break; default: QE_SLOW(8, 7) break; } }
         else { switch (F) { case 4: QE_SLOW(4, 4) break; case 5: QE_SLOW(4, 5) break; case 6: QE_SLOW(4, 6) break; default: QE_SLOW(4, 7) break; } }
 #undef QE_SLOW
+#undef QE_SLOWL
       }
     }
     if (!(status & 1)) break;
@@ -150,6 +178,15 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
       std::vector<SelTask> tasks(2 * (size_t)toff[nunits] + 2); u64 ntasks = 0;
       A.tref = tref.data(); A.tcix = tcix.data(); A.tasks = tasks.data(); A.ntasks = &ntasks;
       for (long long u = 0; u < nunits; ++u) sel_unit_plan(P, A, u, &uc);
+      bool longReads = false;
+      for (long long u = 0; u < nunits; ++u) { if (off1[u + 1] - off1[u] > QM_MAX_READ_LEN || (paired && off2[u + 1] - off2[u] > QM_MAX_READ_LEN)) longReads = true; }
+      A.long_reads = longReads ? 1 : 0;
+      if (longReads) switch (sel_ksw_ring_slots(A.bandwidth)) {
+        case 32: { std::vector<KswRowT<32, QM_KSW_MAXLEN_LONG>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<32, QM_KSW_MAXLEN_LONG>(P, A, t, ntasks, rows.data()); } break;
+        case 64: { std::vector<KswRowT<64, QM_KSW_MAXLEN_LONG>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<64, QM_KSW_MAXLEN_LONG>(P, A, t, ntasks, rows.data()); } break;
+        default: { std::vector<KswRowT<128, QM_KSW_MAXLEN_LONG>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<128, QM_KSW_MAXLEN_LONG>(P, A, t, ntasks, rows.data()); } break;
+      }
+      else
       switch (sel_ksw_ring_slots(A.bandwidth)) {         // same rule as the launch wrapper
         case 32: { std::vector<KswRowT<32>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<32>(P, A, t, ntasks, rows.data()); } break;
         case 64: { std::vector<KswRowT<64>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<64>(P, A, t, ntasks, rows.data()); } break;

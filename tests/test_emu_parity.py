@@ -146,7 +146,11 @@ def test_long_reads_ns4(synth_small, oracle_mod):
         r = orc.map_pairs(a1, aoff, a2, aoff, opts=oracle_mod.default_opts(**oo), nthreads=4)
         e = em.map(a1, aoff, a2, aoff, opts=emu.default_opts(**go), ns=3)
         assert_hits_equal(r.hit_offsets, r.hits, e.hit_offsets, e.hits, "ns3 %s" % oo)
-    assert em.map(q1, o, q2, o, opts=emu.default_opts(sel_aln=1), ns=3).status & 4   # the 250 bp reads do not fit three slots, and -s has no long-read pass
+    # the 250 bp reads do not fit three slots: with -s too they are set aside and mapped by the 32-slot kernels
+    r = orc.map_pairs(q1, o, q2, o, opts=oracle_mod.default_opts(selAln=1), nthreads=4)
+    e = em.map(q1, o, q2, o, opts=emu.default_opts(sel_aln=1), ns=3)
+    assert (e.status & 0xff) == 0
+    assert_hits_equal(r.hit_offsets, r.hits, e.hit_offsets, e.hits, "-s, reads beyond the slot class")
 
 
 def test_medium(synth_medium, oracle_mod):
@@ -355,7 +359,47 @@ def test_reads_of_300_and_500_bp_take_the_eight_slot_kernels(synth_medium, oracl
     res = orc.map_pairs(s1, off, s2, off, nthreads=8)
     assert (er.status & 0xff) == 0, er.status
     assert_hits_equal(res.hit_offsets, res.hits, er.hit_offsets, er.hits, "500 bp through the long-read pass")
-    assert em.map(s1, off, s2, off, opts=emu.default_opts(sel_aln=1), ns=4).status & 4   # -s has no such pass
+    rs = orc.map_pairs(s1, off, s2, off, opts=oracle_mod.default_opts(selAln=1), nthreads=8)
+    es = em.map(s1, off, s2, off, opts=emu.default_opts(sel_aln=1), ns=4)
+    assert (es.status & 0xff) == 0
+    assert_hits_equal(rs.hit_offsets, rs.hits, es.hit_offsets, es.hits, "-s, 500 bp through the long-read pass")
+
+
+@pytest.mark.parametrize("variant", ["selAln", "selAln_band40", "selAln_noSensitive", "selAln_band120"])
+def test_selective_alignment_of_reads_beyond_512_bp(synth_medium, oracle_mod, variant):
+    """-s on a batch that mixes 2 x 100 bp pairs with reads of 600 .. 2048 bp (the reference aligns any length): the long reads
+    are set aside by the collector, get their intervals from the 32-slot chain-scoring collector, chaining and list assembly are
+    length-blind, and the ksw2 row kernel runs with images sized for the longest read (register edition, 64- and 128-slot rings).
+    Beyond --dpBandwidth 97 (the full-band ring) the limit stays at 512 characters"""
+    from rapmap_amd import synth
+    import rapmap_amd as ra
+    ix, orc, em, emu = _emu(synth_medium["idx"])
+    qi = ra.QuasiIndex(synth_medium["idx"])
+    text, offsets = qi.arrays()
+    text = np.asarray(text); offsets = np.asarray(offsets, dtype=np.int64)
+    ends = np.append(offsets[1:], text.size)
+    txps = [text[a:b - 1] for a, b in zip(offsets, ends) if b - 1 - a >= 2100][:300]
+    a1, a2, ao, _ = synth.make_reads(txps, 200, seed=9, read_len=100, err=0.01)
+    r1 = [a1[ao[i]:ao[i + 1]].tobytes() for i in range(200)]; r2 = [a2[ao[i]:ao[i + 1]].tobytes() for i in range(200)]
+    for L, n, err in ((600, 8, 0.01), (1300, 6, 0.02), (2048, 6, 0.005), (2000, 3, 0.0), (513, 4, 0.01)):
+        s1, s2, off, _ = synth.make_reads(txps, n, seed=L, read_len=L, err=err)
+        for i in range(n):
+            at = (37 * i + L) % len(r1)
+            r1.insert(at, s1[off[i]:off[i + 1]].tobytes()); r2.insert(at, s2[off[i]:off[i + 1]].tobytes() if i % 3 else a2[ao[i]:ao[i + 1]].tobytes())
+    q1, o1 = pack(r1); q2, o2 = pack(r2)
+    oo, go = {"selAln": ({"selAln": 1}, {"sel_aln": 1}), "selAln_band40": ({"selAln": 1, "dpBandwidth": 40}, {"sel_aln": 1, "dp_bandwidth": 40}),
+              "selAln_noSensitive": ({"selAln": 1, "sensitive": 0}, {"sel_aln": 1, "sensitive": 0}),
+              "selAln_band120": ({"selAln": 1, "dpBandwidth": 120}, {"sel_aln": 1, "dp_bandwidth": 120})}[variant]
+    er = em.map(q1, o1, q2, o2, opts=emu.default_opts(**go), ns=2)
+    if variant == "selAln_band120":
+        assert er.status & 4
+        return
+    res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=8)
+    assert (er.status & 0xff) == 0, er.status
+    assert_hits_equal(res.hit_offsets, res.hits, er.hit_offsets, er.hits, "-s long reads, %s" % variant)
+    assert res.counters == er.counters
+    long_units = [u for u in range(len(r1)) if len(r1[u]) > 512]
+    assert sum(int(res.hit_offsets[u + 1] - res.hit_offsets[u]) > 0 for u in long_units) > len(long_units) // 2
 
 
 @pytest.mark.parametrize("variant", ["default", "noSensitive", "fuzzy", "perfectHash"])

@@ -140,9 +140,10 @@ def test_edge_batches(synth_small, oracle_mod):
     with pytest.raises(ra.QmError, match="read length"):
         mp.map_pairs(q1, o1, q2, o2)
     q1, o1 = pack([b"A" * 600]); q2, o2 = pack([b"C" * 10])
-    with pytest.raises(ra.QmError, match="read length"):
-        mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(sel_aln=1))
-    assert mp.map_pairs(q1, o1, q2, o2).n_hits == 0          # without -s a 600-character read takes the long-read pass
+    with pytest.raises(ra.QmError, match="read length"):     # -s beyond --dpBandwidth 97: the full-band ring's images stop at 512 characters
+        mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(sel_aln=1, dp_bandwidth=120))
+    assert mp.map_pairs(q1, o1, q2, o2).n_hits == 0          # a 600-character read takes the long-read pass, with -s too
+    assert mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(sel_aln=1)).n_hits == 0
 
 
 def test_medium_full_parity_and_properties(synth_medium, oracle_mod):
@@ -598,6 +599,53 @@ def test_reads_longer_than_256_bp(synth_medium, synth_medium_ph, oracle_mod, L):
     assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "mixed lengths")
 
 
+@pytest.mark.parametrize("variant", ["selAln", "selAln_band40", "selAln_band20", "selAln_noSensitive", "selAln_perfectHash", "mimicBT2"])
+def test_selective_alignment_of_reads_beyond_512_bp(synth_medium, synth_medium_ph, oracle_mod, variant):
+    """-s on a batch that mixes 2 x 100 bp pairs with reads of 513 .. 2048 bp (the reference aligns any length): the collector sets
+    the long reads aside, a second small launch of the 32-slot chain-scoring collector delivers their intervals, the list kernel
+    and the plan are length-blind, and the ksw2 row kernel runs in its long-image editions (register, 64- and 128-slot rings)"""
+    import rapmap_amd as ra
+    from rapmap_amd import synth
+    ph = variant == "selAln_perfectHash"
+    idx = (synth_medium_ph if ph else synth_medium)["idx"]
+    ix, orc = load_oracle(idx)
+    txps = _medium_txps(synth_medium["idx"], min_len=2100, cap=300)
+    a1, a2, ao, _ = synth.make_reads(txps, 3000, seed=9, read_len=100, err=0.01)
+    r1 = [a1[ao[i]:ao[i + 1]].tobytes() for i in range(3000)]; r2 = [a2[ao[i]:ao[i + 1]].tobytes() for i in range(3000)]
+    for L, n, err in ((600, 40, 0.01), (1300, 30, 0.02), (2048, 30, 0.005), (2000, 6, 0.0), (513, 10, 0.01)):
+        s1, s2, off, _ = synth.make_reads(txps, n, seed=L, read_len=L, err=err)
+        for i in range(n):
+            at = (37 * i + L) % len(r1)
+            r1.insert(at, s1[off[i]:off[i + 1]].tobytes()); r2.insert(at, s2[off[i]:off[i + 1]].tobytes() if i % 3 else a2[ao[i]:ao[i + 1]].tobytes())
+    q1, o1 = pack(r1); q2, o2 = pack(r2)
+    if variant == "mimicBT2":
+        oopts = oracle_mod.mimic_bt2_opts()
+        gopts = ra.default_opts(sel_aln=1, aln_policy=1, no_orphans=1, no_dovetail=1, consensus_slack=0.35, max_num_hits=1000)
+    else:
+        oo, go = {"selAln": ({"selAln": 1}, {"sel_aln": 1}), "selAln_band40": ({"selAln": 1, "dpBandwidth": 40}, {"sel_aln": 1, "dp_bandwidth": 40}),
+                  "selAln_band20": ({"selAln": 1, "dpBandwidth": 20}, {"sel_aln": 1, "dp_bandwidth": 20}),
+                  "selAln_noSensitive": ({"selAln": 1, "sensitive": 0}, {"sel_aln": 1, "sensitive": 0}),
+                  "selAln_perfectHash": ({"selAln": 1}, {"sel_aln": 1})}[variant]
+        oopts = oracle_mod.default_opts(**oo); gopts = ra.default_opts(**go)
+    res = orc.map_pairs(q1, o1, q2, o2, opts=oopts, nthreads=8)
+    qi, mp = _gpu(idx, debug=False)
+    gr = mp.map_pairs(q1, o1, q2, o2, opts=gopts)
+    assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "-s long reads, %s" % variant)
+    assert res.counters == gr.counters
+    long_units = [u for u in range(len(r1)) if len(r1[u]) > 512 or len(r2[u]) > 512]
+    assert sum(int(res.hit_offsets[u + 1] - res.hit_offsets[u]) > 0 for u in long_units) > len(long_units) // (4 if variant == "mimicBT2" else 2)   # (no orphans there)
+    if variant == "selAln":
+        rs = orc.map_single(q1, o1, opts=oopts, nthreads=8)
+        gs = mp.map_reads(q1, o1, opts=gopts)
+        assert_hits_equal(rs.hit_offsets, rs.hits, gs.hit_offsets, gs.hits, "-s long reads, single-end")
+        # a batch of long reads only
+        lo1 = [r1[u] for u in long_units]; lo2 = [r2[u] for u in long_units]
+        p1, po1 = pack(lo1); p2, po2 = pack(lo2)
+        rl = orc.map_pairs(p1, po1, p2, po2, opts=oopts, nthreads=8)
+        gl = mp.map_pairs(p1, po1, p2, po2, opts=gopts)
+        assert_hits_equal(rl.hit_offsets, rl.hits, gl.hit_offsets, gl.hits, "-s, long reads only")
+
+
 @pytest.mark.parametrize("variant", ["default", "noSensitive", "fuzzy", "perfectHash", "perfectHashCompact"])
 def test_reads_beyond_512_bp_take_the_long_read_pass(synth_medium, synth_medium_ph, oracle_mod, variant):
     """a batch of 2 x 100 bp pairs with reads of 600 .. 2048 bp among them (the reference takes any std::string,
@@ -646,7 +694,7 @@ def test_reads_beyond_512_bp_take_the_long_read_pass(synth_medium, synth_medium_
         gd = mp.map_device(len(r1), d1.data_ptr(), p1.data_ptr(), d2.data_ptr(), p2.data_ptr(), 2048, fetch=True)
         assert_hits_equal(res.hit_offsets, res.hits, gd.hit_offsets, gd.hits, "long reads, device-resident input")
         with pytest.raises(ra.QmError, match="512"):
-            mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(sel_aln=1))
+            mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(sel_aln=1, dp_bandwidth=-1))
         r1[5] = bytes(txps[0][:2049]); q1, o1 = pack(r1)
         with pytest.raises(ra.QmError, match="2048"):
             mp.map_pairs(q1, o1, q2, o2)
