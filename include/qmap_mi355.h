@@ -30,7 +30,7 @@ typedef enum qm_status {
   QM_E_IO = -2,          /* index file missing / malformed */
   QM_E_NOGPU = -3,       /* no HIP device, or HIP call failed */
   QM_E_UNSUPPORTED = -4, /* option / index variant not implemented on the device path */
-  QM_E_TOOLONG = -5,     /* a read is longer than QM_MAX_LONG_READ_LEN (QM_MAX_READ_LEN with -s) */
+  QM_E_TOOLONG = -5,     /* a read is longer than QM_MAX_LONG_READ_LEN (QM_MAX_READ_LEN with -s and --dpBandwidth beyond 0..97) */
   QM_E_NOMEM = -6,
   QM_E_STATE = -7,       /* call order (e.g. fetch before map) */
   QM_E_FORMAT = -8       /* malformed FASTA/FASTQ input */
@@ -38,8 +38,10 @@ typedef enum qm_status {
 
 /* Reads of up to QM_MAX_READ_LEN characters are mapped by the main kernels (64-character slot classes 2 / 3 / 4 / 8).  Longer
  * reads of a batch -- up to QM_MAX_LONG_READ_LEN -- are set aside by the main launch and mapped by a second, small launch of
- * 32-slot kernels (the reference takes any std::string, include/SACollector.hpp:108); beyond that, and for any read longer
- * than QM_MAX_READ_LEN with -s (the alignment kernels' images are sized for it), the call fails with QM_E_TOOLONG. */
+ * 32-slot kernels (the reference takes any std::string, include/SACollector.hpp:108); with -s the same happens in the
+ * collector pass and the alignment kernel runs in its long-image editions.  Beyond QM_MAX_LONG_READ_LEN -- and beyond
+ * QM_MAX_READ_LEN with -s when --dpBandwidth is not in 0..97 (the full-band ring of the alignment kernel holds every column of a
+ * 512-base alignment and no more) -- the call fails with QM_E_TOOLONG. */
 #define QM_MAX_READ_LEN 512
 #define QM_MAX_LONG_READ_LEN 2048
 
