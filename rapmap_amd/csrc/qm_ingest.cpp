@@ -529,7 +529,14 @@ struct BgzfReader {
     isize = (size_t)p[bsize - 4] | ((size_t)p[bsize - 3] << 8) | ((size_t)p[bsize - 2] << 16) | ((size_t)p[bsize - 1] << 24);
     return isize <= 65536;
   }
-  static bool is_bgzf(const unsigned char* p, size_t avail) { size_t b, i; return block_at(p, avail, b, i); }
+  // BGZF from the first byte to the last?  (walks the block headers: a file that merely starts like one -- a BGZF member followed
+  // by ordinary gzip members, a file cut inside a block -- is left to the single zlib stream, which reads any valid gzip file and
+  // reports a truncated one)
+  static bool is_bgzf(const unsigned char* p, size_t avail) {
+    size_t o = 0;
+    while (o < avail) { size_t b, i; if (!block_at(p + o, avail - o, b, i)) return false; o += b; }
+    return avail > 0;
+  }
 
   void helper_loop() {
     z_stream zs; memset(&zs, 0, sizeof(zs));
