@@ -1056,42 +1056,42 @@ QM_DEV void extend_search(const DevIndex& ix, u32 lbIn, u32 ubIn, int startAt, c
     return;
   }
   long long l = lbIn, r = ubIn, c;
-  int lcpLP = startAt, lcpRP = startAt, prevILow = startAt, prevIHigh = startAt, maxLen = 0, i;
+  int lcpLo = startAt, lcpHi = startAt, seenBelow = startAt, seenAbove = startAt, maxLen = 0, i;
   while (true) {                                  // :150-209
     c = (l + r) / 2;
-    i = lcpLP < lcpRP ? lcpLP : lcpRP;
+    i = lcpLo < lcpHi ? lcpLo : lcpHi;
     long long s = (long long)uniform(ix.SA[c]);
     i = cmp_from(ix, s, q, m0, i, 0, rel);
     bool plt = rel != 2;
-    if (rel == 2) { if (i > prevILow) prevILow = i; }
-    else { if (i > prevIHigh) prevIHigh = i; }    // q<t mismatch, or ran off either end
+    if (rel == 2) { if (i > seenBelow) seenBelow = i; }
+    else { if (i > seenAbove) seenAbove = i; }    // q<t mismatch, or ran off either end
     if (plt) {
-      if (c == l + 1) { maxLen = i > prevILow ? i : prevILow; if (prevIHigh > maxLen) maxLen = prevIHigh; break; }
-      r = c; lcpRP = i;
+      if (c == l + 1) { maxLen = i > seenBelow ? i : seenBelow; if (seenAbove > maxLen) maxLen = seenAbove; break; }
+      r = c; lcpHi = i;
     } else {
-      if (c == r - 1) { maxLen = i > prevILow ? i : prevILow; if (prevIHigh > maxLen) maxLen = prevIHigh; break; }
-      l = c; lcpLP = i;
+      if (c == r - 1) { maxLen = i > seenBelow ? i : seenBelow; if (seenAbove > maxLen) maxLen = seenAbove; break; }
+      l = c; lcpLo = i;
     }
   }
   int m = maxLen + 1;
-  long long bound1 = 0, bound2 = 0;
+  long long firstAt = 0, pastAt = 0;
   for (int pass = 0; pass < 2; ++pass) {          // :215-258, :261-304
     int sentinel = pass == 0 ? '#' : '{';
-    l = pass == 0 ? (long long)lbIn : bound1 - 1;
-    r = ubIn; lcpLP = startAt; lcpRP = startAt;
+    l = pass == 0 ? (long long)lbIn : firstAt - 1;
+    r = ubIn; lcpLo = startAt; lcpHi = startAt;
     long long res;
     while (true) {
       c = (l + r) / 2;
-      i = lcpLP < lcpRP ? lcpLP : lcpRP;
+      i = lcpLo < lcpHi ? lcpLo : lcpHi;
       long long s = (long long)uniform(ix.SA[c]);
       i = cmp_from(ix, s, q, m, i, sentinel, rel);
-      if (rel != 2) { if (c == l + 1) { res = c; break; } r = c; lcpRP = i; }
-      else { if (c == r - 1) { res = r; break; } l = c; lcpLP = i; }
+      if (rel != 2) { if (c == l + 1) { res = c; break; } r = c; lcpHi = i; }
+      else { if (c == r - 1) { res = r; break; } l = c; lcpLo = i; }
     }
-    if (pass == 0) bound1 = res; else bound2 = res;
+    if (pass == 0) firstAt = res; else pastAt = res;
   }
-  if (bound1 == bound2) bound2 += 1;              // :307
-  lbOut = (u32)bound1; ubOut = (u32)bound2; lenOut = maxLen;
+  if (firstAt == pastAt) pastAt += 1;              // :307
+  lbOut = (u32)firstAt; ubOut = (u32)pastAt; lenOut = maxLen;
 }
 
 // SASearcher::lce (SASearcher.hpp:318-334), NIP only.  Restated literally, including its double use of

@@ -122,52 +122,52 @@ QM_DEV void sel_sort(SelRec* r, SelRec* t, int n, Less less) {
 QM_DEV int sel_chain_group(const SelRec* H, int hn, double* f, int* p, int* seen, int* ends, int* starts, int maxDist,
                            SelGroup& g, int* posOut) {
 #pragma clang fp contract(off)
-  double bestScore = -1.7976931348623157e308; int bestChainEnd = -1; int nEnds = 0;
-  const double avgseed = 31.0;
+  double bestScore = -1.7976931348623157e308; int lastBest = -1; int nEnds = 0;
+  const double seedLen = 31.0;
   for (int i = 0; i < hn; ++i) {
-    const u32 qposi = H[i].qpos + H[i].len, rposi = H[i].pos + H[i].len;
+    const u32 qEnd = H[i].qpos + H[i].len, tEnd = H[i].pos + H[i].len;
     const double leni = (double)(int)H[i].len;
     int pi = i; double fi = (double)H[i].len;
-    int numRounds = 2;
+    int looksLeft = 2;
     for (int j = i - 1; j >= 0; --j) {
-      const u32 qposj = H[j].qpos + H[j].len, rposj = H[j].pos + H[j].len;
-      const int qdiff = (int)(qposi - qposj), rdiff = (int)(rposi - rposj);
+      const u32 qEndJ = H[j].qpos + H[j].len, tEndJ = H[j].pos + H[j].len;
+      const int dq = (int)(qEnd - qEndJ), dt = (int)(tEnd - tEndJ);
       // alpha
-      double mindiff = (qdiff < rdiff) ? (double)qdiff : (double)rdiff;
-      double alpha = (leni < mindiff) ? leni : mindiff;
+      double gapMin = (dq < dt) ? (double)dq : (double)dt;
+      double alpha = (leni < gapMin) ? leni : gapMin;
       // beta
       double beta;
-      if (qdiff < 0 || ((qdiff > rdiff ? qdiff : rdiff) > maxDist)) beta = __builtin_inf();
+      if (dq < 0 || ((dq > dt ? dq : dt) > maxDist)) beta = __builtin_inf();
       else {
-        double l = (double)qdiff - (double)rdiff;
+        double l = (double)dq - (double)dt;
         int al = (int)(l < 0 ? -l : l);
-        beta = (l == 0) ? 0.0 : (0.01 * avgseed * al + 0.5 * sel_fastlog2((float)al));
+        beta = (l == 0) ? 0.0 : (0.01 * seedLen * al + 0.5 * sel_fastlog2((float)al));
       }
-      double extensionScore = f[j] + alpha - beta;
-      bool extendWithJ = extensionScore > fi;
-      pi = extendWithJ ? j : pi;
-      fi = extendWithJ ? extensionScore : fi;
-      if (pi < i) { numRounds--; if (numRounds <= 0) break; }
+      double cand = f[j] + alpha - beta;
+      bool take = cand > fi;
+      pi = take ? j : pi;
+      fi = take ? cand : fi;
+      if (pi < i) { looksLeft--; if (looksLeft <= 0) break; }
     }
     p[i] = pi; f[i] = fi;
-    if (fi > bestScore) { bestScore = fi; bestChainEnd = i; nEnds = 0; ends[nEnds++] = i; }
+    if (fi > bestScore) { bestScore = fi; lastBest = i; nEnds = 0; ends[nEnds++] = i; }
     else if (fi == bestScore) ends[nEnds++] = i;
   }
   // multi-chain backtracking (:206-246)
   for (int i = 0; i < hn; ++i) seen[i] = 0;
-  int numDistinctOpt = 0, nStarts = 0;
+  int nOptimal = 0, nStarts = 0;
   for (int e = 0; e < nEnds; ++e) {
-    int bestChainEndInd = ends[e];
-    bool validChain = true;
-    int lastPtr = p[bestChainEndInd];
-    while (lastPtr < bestChainEndInd) {
-      if (seen[bestChainEndInd]) { validChain = false; break; }
-      seen[bestChainEndInd] = 1;
-      bestChainEndInd = lastPtr;
-      lastPtr = p[bestChainEndInd];
+    int cur = ends[e];
+    bool fresh = true;
+    int prev = p[cur];
+    while (prev < cur) {
+      if (seen[cur]) { fresh = false; break; }
+      seen[cur] = 1;
+      cur = prev;
+      prev = p[cur];
     }
-    if (seen[bestChainEndInd]) validChain = false;
-    if (validChain) { ++numDistinctOpt; starts[nStarts++] = lastPtr; }
+    if (seen[cur]) fresh = false;
+    if (fresh) { ++nOptimal; starts[nStarts++] = prev; }
   }
   if (nStarts == 0) return 0;
   g.tid = H[0].tid; g.offcs = 0; g.set_cs(QM_CS_REGULAR); g.score = bestScore; g.npos = nStarts;
@@ -178,10 +178,10 @@ QM_DEV int sel_chain_group(const SelRec* H, int hn, double* f, int* p, int* seen
     while (b >= 0 && posOut[b] > v) { posOut[b + 1] = posOut[b]; --b; }
     posOut[b + 1] = v;
   }
-  if (hn > 1 && numDistinctOpt == 1 && bestChainEnd == hn - 1) {             // gapless chain (:283-305)
-    long long queryRange = (long long)(H[hn - 1].qpos + H[hn - 1].len) - (long long)H[0].qpos;
-    long long refRange = (long long)(H[hn - 1].pos + H[hn - 1].len) - (long long)H[0].pos;
-    if (queryRange == refRange && queryRange == (long long)maxDist) g.set_cs(QM_CS_UNGAPPED);
+  if (hn > 1 && nOptimal == 1 && lastBest == hn - 1) {             // gapless chain (:283-305)
+    long long qSpan = (long long)(H[hn - 1].qpos + H[hn - 1].len) - (long long)H[0].qpos;
+    long long tSpan = (long long)(H[hn - 1].pos + H[hn - 1].len) - (long long)H[0].pos;
+    if (qSpan == tSpan && qSpan == (long long)maxDist) g.set_cs(QM_CS_UNGAPPED);
   }
   return nStarts;
 }
