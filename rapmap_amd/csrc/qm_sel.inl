@@ -596,12 +596,17 @@ QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>& qlenv, const LV<int>& tlenv, K
   const u32 QE2 = ((u32)qe2 << 8) | ((u32)qe2 << 24), MAXSC = ((u32)max_sc_v << 8) | ((u32)max_sc_v << 24), QV = ((u32)qv << 8) | ((u32)qv << 24);
   LV<int> lastSt, hb, mqe, mte; LV<bool> done;
   LV<int> ST0, ST1, HH0, HH1, SS0, SS1;             // the two owned columns: (u, v, x, y) bytes, H, score byte
+  LV<int> TQ, QS;                                   // target characters of the two owned columns (byte 0 / 1; they stand with the
+                                                    // window) and their query characters of this round (a shift register along the row)
   QM_LANES(l) {
     lastSt[l] = -1; hb[l] = NEG; mqe[l] = NEG; mte[l] = NEG; done[l] = qlenv[l] <= 0 || tlenv[l] <= 0;
-    ST0[l] = 0; ST1[l] = 0; HH0[l] = NEG; HH1[l] = NEG; SS0[l] = 0; SS1[l] = 0;
+    ST0[l] = 0; ST1[l] = 0; HH0[l] = NEG; HH1[l] = NEG; SS0[l] = 0; SS1[l] = 0; TQ[l] = 0; QS[l] = 0;
   }
+  const int FAR = 0x40000000;                       // "column offset" of an idle row: every range test below fails
   for (int r = 0; ; ++r) {
-    LV<int> st0v, en0v, stv, env, smaxv; LV<bool> act, moved;
+    // everything below is in offsets from st0, the band's first column: d0 = owned column t0 - st0 (t1: d0 + 16), eb = en0 - st0,
+    // ce = 16-aligned window end - st0, rd = r - st0 (the diagonal's column); stv is the window start
+    LV<int> stv, d0v, ebv, cev, rdv, en0v; LV<bool> act, moved;
     QM_LANES(l) {
       const int qlen = qlenv[l], tlen = tlenv[l], w = wIn;
       int st = 0, en = tlen - 1;
@@ -613,8 +618,9 @@ QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>& qlenv, const LV<int>& tlenv, K
       if (!a) done[l] = true;
       act[l] = a;
       // (st >= 0; an active row has st <= en <= st + w, so the quotient of the original's (en - st) / 16 is 0 here; en >= 0)
-      st0v[l] = st; en0v[l] = en; stv[l] = st & ~15; env[l] = (((en + 16) >> 4) << 4) - 1;
-      smaxv[l] = st + 15;
+      stv[l] = st & ~15;
+      d0v[l] = a ? stv[l] + (l & 15) - st : FAR;
+      ebv[l] = en - st > 0 ? en - st : 0; cev[l] = (((en + 16) >> 4) << 4) - 1 - st; rdv[l] = r - st; en0v[l] = en;
       moved[l] = a && stv[l] != lastSt[l];
     }
     if (!ballot(act)) break;
@@ -622,6 +628,18 @@ QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>& qlenv, const LV<int>& tlenv, K
     // nothing (or the first column's boundary) otherwise
     LV<int> bpack;
     QM_LANES(l) { bpack[l] = stv[l] > 0 ? 0 : ((r ? qv : 0) << 8); }
+    // the query character of cell (r, t) is QX[16 + r - t]: next round it belongs to the column to the right, so the characters
+    // travel along the row (column t1 = t0 + 16 continues where the row's last lane leaves off) and only the row's first lane
+    // reads a new one; the target characters stand with the window
+    {
+      LV<int> fresh, rq;
+      QM_LANES(l) {
+        int qi = 16 + r - stv[l]; qi = act[l] ? (qi > MAXLEN + 39 ? MAXLEN + 39 : qi) : 0;
+        fresh[l] = blk[l >> 4].QX[qi];
+      }
+      row_rotate_up(QS, rq);
+      QM_LANES(l) { QS[l] = (l & 15) == 0 ? (int)((u32)fresh[l] | (((u32)rq[l] & 0xffu) << 8)) : rq[l]; }
+    }
     if (ballot(moved)) {                                  // rare: every ~32 rounds per row (and each row's first round)
       LV<int> lastS, lastH;
       row_last(ST0, lastS); row_last(HH0, lastH);
@@ -632,38 +650,40 @@ QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>& qlenv, const LV<int>& tlenv, K
           hb[l] = (stv[l] > 0 && !first) ? lastH[l] : NEG;
           ST0[l] = first ? 0 : ST1[l]; HH0[l] = first ? NEG : HH1[l]; SS0[l] = first ? 0 : SS1[l];
           ST1[l] = 0; HH1[l] = NEG; SS1[l] = 0;
+          Row& B = blk[l >> 4];
+          const int t0 = stv[l] + (l & 15), t1 = t0 + 16;
+          int qi0 = 16 + r - t0; qi0 = qi0 < 0 ? 0 : (qi0 > MAXLEN + 39 ? MAXLEN + 39 : qi0);
+          int qi1 = 16 + r - t1; qi1 = qi1 < 0 ? 0 : (qi1 > MAXLEN + 39 ? MAXLEN + 39 : qi1);
+          const int ti0 = t0 > MAXLEN + 39 ? MAXLEN + 39 : t0, ti1 = t1 > MAXLEN + 39 ? MAXLEN + 39 : t1;
+          QS[l] = (int)((u32)B.QX[qi0] | ((u32)B.QX[qi1] << 8));
+          TQ[l] = (int)((u32)B.TX[ti0] | ((u32)B.TX[ti1] << 8));
         }
       }
     }
     LV<bool> diag;
-    QM_LANES(l) { diag[l] = act[l] && env[l] >= r && (l & 15) == (r & 15); }
+    QM_LANES(l) { diag[l] = cev[l] >= rdv[l] && (d0v[l] == rdv[l] || d0v[l] + 16 == rdv[l]); }
     if (ballot(diag))                                     // only while the band still touches the diagonal (the first ~w rounds)
     QM_LANES(l) {                                       // the diagonal cell: y8[r] = 0, u8[r] = r ? q : 0
       if (diag[l]) {
-        const int t0 = stv[l] + (l & 15);
         const u32 uval = (u32)(r ? qv : 0);
-        if (t0 == r) ST0[l] = (int)(((u32)ST0[l] & 0x00ffff00u) | uval);
-        else if (t0 + 16 == r) ST1[l] = (int)(((u32)ST1[l] & 0x00ffff00u) | uval);
+        if (d0v[l] == rdv[l]) ST0[l] = (int)(((u32)ST0[l] & 0x00ffff00u) | uval);
+        else ST1[l] = (int)(((u32)ST1[l] & 0x00ffff00u) | uval);
       }
     }
-    // the difference recurrence on the two owned columns (13 packed 16-bit instructions, see sel_ksw_extz2_rows)
-    LV<bool> inCore0, inCore1;
+    // the scores of the 16 columns st0 .. st0 + 15 (the original's 16-wide score vectors start at st0)
     QM_LANES(l) {
-      Row& B = blk[l >> 4];
-      const int t0 = stv[l] + (l & 15), t1 = t0 + 16;
-      inCore0[l] = act[l] && t0 <= env[l]; inCore1[l] = act[l] && t1 <= env[l];
-      const bool inScore0 = act[l] && t0 >= st0v[l] && t0 <= smaxv[l], inScore1 = act[l] && t1 >= st0v[l] && t1 <= smaxv[l];
-      int qi0 = 16 + r - t0; qi0 = qi0 < 0 ? 0 : (qi0 > MAXLEN + 39 ? MAXLEN + 39 : qi0);
-      int qi1 = 16 + r - t1; qi1 = qi1 < 0 ? 0 : (qi1 > MAXLEN + 39 ? MAXLEN + 39 : qi1);
-      const int ti0 = t0 > MAXLEN + 39 ? MAXLEN + 39 : t0, ti1 = t1 > MAXLEN + 39 ? MAXLEN + 39 : t1;
-      const int sv0 = B.QX[qi0], sq0 = B.TX[ti0], sv1 = B.QX[qi1], sq1 = B.TX[ti1];
+      const u32 qs = (u32)QS[l], tq = (u32)TQ[l];
+      const int sv0 = (int)(qs & 0xff), sv1 = (int)((qs >> 8) & 0xff), sq0 = (int)(tq & 0xff), sq1 = (int)((tq >> 8) & 0xff);
       int tmp0 = (sq0 == sv0) ? sc_mch : sc_mis; tmp0 = (sq0 == m1 || sv0 == m1) ? sc_N : tmp0;
       int tmp1 = (sq1 == sv1) ? sc_mch : sc_mis; tmp1 = (sq1 == m1 || sv1 == m1) ? sc_N : tmp1;
+      const bool inScore0 = (u32)d0v[l] <= 15u, inScore1 = (u32)(d0v[l] + 16) <= 15u;
       SS0[l] = inScore0 ? tmp0 : SS0[l]; SS1[l] = inScore1 ? tmp1 : SS1[l];
     }
+    // the difference recurrence on the two owned columns (13 packed 16-bit instructions, see sel_ksw_extz2_rows)
     LV<int> r0, r1, carry;
     row_rotate_up(ST0, r0); row_rotate_up(ST1, r1); row_rotate_up(bpack, carry);
     QM_LANES(l) {
+      const bool inCore0 = d0v[l] <= cev[l], inCore1 = d0v[l] + 16 <= cev[l];
       const u32 nb0 = (l & 15) == 0 ? (u32)carry[l] : (u32)r0[l], nb1 = (l & 15) == 0 ? (u32)r0[l] : (u32)r1[l];
       const u32 o0 = (u32)ST0[l], o1 = (u32)ST1[l];
       const u32 U = perm8(o1, o0, 0x040c000cu), Y = perm8(o1, o0, 0x070c030cu);
@@ -678,28 +698,28 @@ QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>& qlenv, const LV<int>& tlenv, K
       A = pk_sub(A, Z); Bq = pk_sub(Bq, Z);
       const u32 XN = pk_max_i(A, 0u), YN = pk_max_i(Bq, 0u);
       const u32 uv = perm8(VN, UN, 0x07030501u), xy = perm8(YN, XN, 0x07030501u);
-      if (inCore0[l]) ST0[l] = (int)perm8(xy, uv, 0x05040100u);
-      if (inCore1[l]) ST1[l] = (int)perm8(xy, uv, 0x07060302u);
+      if (inCore0) ST0[l] = (int)perm8(xy, uv, 0x05040100u);
+      if (inCore1) ST1[l] = (int)perm8(xy, uv, 0x07060302u);
     }
     // H (exact max) on the band cells st0..en0: at most 16 of them, so at most one of a lane's two columns
     LV<int> rh0, rh1;
     row_rotate_up(HH0, rh0); row_rotate_up(HH1, rh1);     // H of the column to the left, before this round's updates
     QM_LANES(l) {
-      const int t0 = stv[l] + (l & 15), t1 = t0 + 16, st0 = st0v[l], en0 = en0v[l];
-      const bool in0 = act[l] && t0 >= st0 && t0 <= en0, in1 = act[l] && t1 >= st0 && t1 <= en0;
-      const int t = in1 ? t1 : t0;
+      const bool in0 = (u32)d0v[l] <= (u32)ebv[l], in1 = (u32)(d0v[l] + 16) <= (u32)ebv[l];
+      const int dsel = in1 ? d0v[l] + 16 : d0v[l], en0 = en0v[l];
       const u32 pk = (u32)(in1 ? ST1[l] : ST0[l]);
       const int hOld = in1 ? HH1[l] : HH0[l];
       const int hl = in1 ? ((l & 15) == 0 ? rh0[l] : rh1[l]) : ((l & 15) == 0 ? hb[l] : rh0[l]);
       const int un = (int)(pk & 0xff), vn = (int)((pk >> 8) & 0xff);
       const int hOwn = hOld + vn - qe;
       const int hTop = en0 > 0 ? (hl + un - qe) : hOwn;
-      const int hn = r > 0 ? (t == en0 ? hTop : hOwn) : (vn - qe - qe);
+      const bool top = dsel == ebv[l];
+      const int hn = r > 0 ? (top ? hTop : hOwn) : (vn - qe - qe);
       if (in0) HH0[l] = hn;
       if (in1) HH1[l] = hn;
       if (in0 || in1) {
-        if (t == en0 && en0 == tlenv[l] - 1 && hn > mte[l]) mte[l] = hn;
-        if (t == st0 && r - st0 == qlenv[l] - 1 && hn > mqe[l]) mqe[l] = hn;
+        if (top && en0 == tlenv[l] - 1 && hn > mte[l]) mte[l] = hn;
+        if (dsel == 0 && rdv[l] == qlenv[l] - 1 && hn > mqe[l]) mqe[l] = hn;
       }
     }
     QM_LANES(l) { if (act[l]) lastSt[l] = stv[l]; }
