@@ -1673,17 +1673,19 @@ QM_DEV void dump_intervals(const ReadBatch& B, long long read, int mate, const I
   if (!fits) { QM_LANES(l) { if (l == 0) *B.status |= 16; } }
   QM_LANES(l) { if (l == 0) { B.iv_cnt[read] = fits ? (u32)n : 0u; B.iv_off[read] = base; } }
   if (!fits) return;
-  for (int t = 0; t < 2; ++t) {
-    const IntervalList& L = t == 0 ? F : R;
-    const long long o = base + (t == 0 ? 0 : F.n);
-    for (int i = 0; i < L.n; ++i) {
-      u32 lb, ub, ln, qp; L.get(i, lb, ub, ln, qp);
-      QM_LANES(l) {
-        if (l == 0) {
-          qm_sa_interval_hit h; h.begin = (int)lb; h.end = (int)ub; h.len = ln; h.query_pos = qp;
-          h.query_rc = (uint8_t)t; h.list = (uint8_t)(2 * mate + t); h.pad = 0;
-          B.iv_out[o + i] = h;
-        }
+  // one lane per record (forward strand's first): the lists were lane 0's business while they grew, writing them out is not
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    QM_LANES(l) {
+      const int i = i0 + l;
+      if (i < n) {
+        const int t = i >= F.n ? 1 : 0, j = t ? i - F.n : i;
+        IntRec r;
+        // a branch per home of a record (LDS / the wave's global scratch), as in get()
+        if (j < QM_ICAP) { if (t) { r.b = R.lds[j].b; r.e = R.lds[j].e; r.len = R.lds[j].len; r.q = R.lds[j].q; } else { r.b = F.lds[j].b; r.e = F.lds[j].e; r.len = F.lds[j].len; r.q = F.lds[j].q; } }
+        else r = t ? R.ovf[j - QM_ICAP] : F.ovf[j - QM_ICAP];
+        qm_sa_interval_hit h; h.begin = (int)r.b; h.end = (int)r.e; h.len = r.len; h.query_pos = r.q;
+        h.query_rc = (uint8_t)t; h.list = (uint8_t)(2 * mate + t); h.pad = 0;
+        B.iv_out[base + i] = h;
       }
     }
   }

@@ -373,10 +373,11 @@ QM_DEV void sel_strand_wave(SS& S, int s, int n, int m, u32 readLen, float conse
 #pragma unroll
           for (int d = SS::NCH - 1; d > 0; --d) if (d > c && hm[d]) g1 = 64 * d + ctz64(hm[d]);   // the lowest such d wins
         }
-        SelIvSet mk;
-        for (int j = i; j < g1; ++j) mk.add(S.rec[j].iv);
+        int nIv;
+        if (m <= 64) { u64 mk = 0; for (int j = i; j < g1; ++j) mk |= 1ULL << S.rec[j].iv; nIv = popc64(mk); }   // (m is the same for every lane)
+        else { SelIvSet mk; for (int j = i; j < g1; ++j) mk.add(S.rec[j].iv); nIv = mk.count(); }
         g1v[c][l] = g1;
-        req[c][l] = mk.count() >= requiredNumHits;
+        req[c][l] = nIv >= requiredNumHits;
       }
     }
     anyReq = anyReq || ballot(req[c]) != 0;
@@ -439,10 +440,43 @@ QM_DEV int sel_h2m_on(const DevIndex& ix, const ReadBatch& B, const IntervalList
   for (int s = 0; s < 2; ++s) {
     const IntervalList& L = s == 0 ? fwdInts : rcInts;
     int n = 0;
-    for (int ii = 0; ii < L.n; ++ii) { u32 lb, ub, ln, qp; L.get(ii, lb, ub, ln, qp); n += (int)(ub - lb); }
+    // at most 64 intervals (every read of the short-read kernels): lane j takes interval j's width, the widths go to S.p (free until the
+    // chaining) and every lane adds them up -- the walk over the list is not lane 0's with a broadcast per field
+    const bool few = L.n <= 64;
+    if (few) {
+      QM_LANES(l) {
+        if (l < L.n) {
+          u32 b, e;
+          if (l < QM_ICAP) { b = L.lds[l].b; e = L.lds[l].e; } else { b = L.ovf[l - QM_ICAP].b; e = L.ovf[l - QM_ICAP].e; }
+          S.p[l] = (int)(e - b);
+        }
+      }
+      wave_fence();
+      LV<int> tot;
+      QM_LANES(l) { int a = 0; for (int j = 0; j < L.n; ++j) a += S.p[j]; tot[l] = a; }
+      n = read_lane(tot, 0);
+    } else {
+      for (int ii = 0; ii < L.n; ++ii) { u32 lb, ub, ln, qp; L.get(ii, lb, ub, ln, qp); n += (int)(ub - lb); }
+    }
     if (n > S.cap()) return -1;
-    if (n <= 64 * SS::NCH) {
-      // the usual case: one lane per suffix over all the intervals at once -- one trip to sainfo per 64 suffixes of the strand
+    if (n <= 64 * SS::NCH && few) {
+      // the usual case: one lane per suffix over all the intervals at once -- one trip to sainfo per 64 suffixes of the strand;
+      // a lane finds the interval of its suffix by running down the widths
+      for (int base = 0; base < n; base += 64) {
+        QM_LANES(l) {
+          const int i = base + l;
+          if (i < n) {
+            int ii = 0, start = 0, acc = 0;
+            for (int j = 0; j < L.n; ++j) { acc += S.p[j]; if (i >= acc) { ii = j + 1; start = acc; } }
+            IntRec q;
+            if (ii < QM_ICAP) { q.b = L.lds[ii].b; q.e = L.lds[ii].e; q.len = L.lds[ii].len; q.q = L.lds[ii].q; } else q = L.ovf[ii - QM_ICAP];
+            SaInfo e = ix.sainfo[q.b + (u32)(i - start)];
+            SelRec r; r.tid = e.tid; r.pos = (u32)e.pos; r.qpos = q.q; r.len = q.len; r.iv = (u32)ii;
+            S.rec[i] = r;
+          }
+        }
+      }
+    } else if (n <= 64 * SS::NCH) {
       for (int base = 0; base < n; base += 64) {
         LV<u32> sa, qv, lv, iv; LV<bool> hs;
         QM_LANES(l) { sa[l] = 0; hs[l] = false; qv[l] = 0; lv[l] = 0; iv[l] = 0; }
@@ -581,9 +615,15 @@ static_assert(QM_KSW_MAXLEN + 48 <= 1024, "the full-band ring must hold every co
 // the four difference bytes, the score byte and H of both columns live in registers -- no ring in LDS, no slot arithmetic, no
 // stores; neighbours come over DPP.  Cell for cell the same arithmetic as sel_ksw_extz2_rows<RING> (see there for the SSE kernel's
 // conventions it reproduces); the two are held against each other and against the reference's kernel by tests/test_ksw_variants.py.
-template <int MAXLEN>
-QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>& qlenv, const LV<int>& tlenv, KswRowT<32, MAXLEN>* blk, const signed char* mat, int q, int e, int wIn,
+// UNI: the rows that hold an alignment all have the lengths (uq, ut) -- four reads of one length well inside their transcripts,
+// nearly every wavefront of a fixed-length run -- so the band's bounds, the window, the "moved" / diagonal / last-rounds tests are
+// the same numbers in every lane: the compiler keeps them on the scalar unit (a third of the round's VALU instructions); rows
+// without an alignment run along on whatever their images hold, nobody reads their score.
+template <int MAXLEN, bool UNI>
+QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>& qlenvIn, const LV<int>& tlenvIn, int uq, int ut, KswRowT<32, MAXLEN>* blk, const signed char* mat, int q, int e, int wIn,
                                    LV<int>& score) {
+  LV<int> qlenv, tlenv;
+  QM_LANES(l) { qlenv[l] = UNI ? uq : qlenvIn[l]; tlenv[l] = UNI ? ut : tlenvIn[l]; }
   typedef KswRowT<32, MAXLEN> Row;
   const int NEG = -0x40000000;
   const int m = 5;
@@ -594,16 +634,38 @@ QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>& qlenv, const LV<int>& tlenv, K
   const int sc_mch = (unsigned char)mat[0], sc_mis = (unsigned char)mat[1], sc_N = (unsigned char)mat[m * m - 1], m1 = m - 1;
   const int qe2 = (unsigned char)((q + e) * 2), max_sc_v = (unsigned char)(mat[0] + (q + e) * 2), qv = (unsigned char)q;
   const u32 QE2 = ((u32)qe2 << 8) | ((u32)qe2 << 24), MAXSC = ((u32)max_sc_v << 8) | ((u32)max_sc_v << 24), QV = ((u32)qv << 8) | ((u32)qv << 24);
-  LV<int> lastSt, hb, mqe, mte; LV<bool> done;
-  LV<int> ST0, ST1, HH0, HH1, SS0, SS1;             // the two owned columns: (u, v, x, y) bytes, H, score byte
+  // the score of a pair of characters (nt4 codes 0 .. 4) as one byte lookup: y = (t ^ q) | ((t | q) & 4) is 0 for a match, 1 .. 3 for
+  // a mismatch, 4 .. 7 when either is an N (ksw_gen_simple_mat's matrix: mat[0], mat[1], mat[24])
+  const u32 LUTLO = (u32)sc_mch | ((u32)sc_mis << 8) | ((u32)sc_mis << 16) | ((u32)sc_mis << 24), LUTHI = (u32)sc_N * 0x01010101u;
+  LV<int> lastSt, mqe, mte; LV<bool> done;
+  LV<int> ST0, ST1, HB, SSP;                        // the two owned columns: (u, v, x, y) bytes; their score bytes (byte 1 / 3: the packed
+                                                    // recurrence's layout); H of the one that is a band cell (a band has at most 16 cells, so
+                                                    // never both: a column enters the band as its top cell, whose H comes from the column to
+                                                    // the left, and the lane's other column is 16 away)
   LV<int> TQ, QS;                                   // target characters of the two owned columns (byte 0 / 1; they stand with the
                                                     // window) and their query characters of this round (a shift register along the row)
   QM_LANES(l) {
-    lastSt[l] = -1; hb[l] = NEG; mqe[l] = NEG; mte[l] = NEG; done[l] = qlenv[l] <= 0 || tlenv[l] <= 0;
-    ST0[l] = 0; ST1[l] = 0; HH0[l] = NEG; HH1[l] = NEG; SS0[l] = 0; SS1[l] = 0; TQ[l] = 0; QS[l] = 0;
+    lastSt[l] = -1; mqe[l] = NEG; mte[l] = NEG; done[l] = qlenv[l] <= 0 || tlenv[l] <= 0;
+    ST0[l] = 0; ST1[l] = 0; HB[l] = NEG; SSP[l] = 0; TQ[l] = 0; QS[l] = 0;
   }
   const int FAR = 0x40000000;                       // "column offset" of an idle row: every range test below fails
+  bool uDone = false; int uLastSt = -1;             // UNI: the wave-level tests of a round as plain numbers (no ballots)
   for (int r = 0; ; ++r) {
+    bool uAct = false, uMoved = false, uDiag = false, uLate = false;
+    if (UNI) {
+      int st = 0, en = ut - 1;
+      if (st < r - uq + 1) st = r - uq + 1;
+      if (en > r) en = r;
+      if (st < (r - wIn + 1) >> 1) st = (r - wIn + 1) >> 1;
+      if (en > (r + wIn) >> 1) en = (r + wIn) >> 1;
+      uAct = !uDone && r < uq + ut - 1 && st <= en;
+      if (!uAct) uDone = true;
+      const int stw = st & ~15, rd = r - st, dc = rd - (stw - st);     // the diagonal's column is owned by lane dc (t0) or dc - 16 (t1) of the row
+      uMoved = uAct && stw != uLastSt;
+      uDiag = uAct && (((en + 16) >> 4) << 4) - 1 - st >= rd && dc >= 0 && dc < 32;
+      uLate = uAct && (en == ut - 1 || rd == uq - 1);
+      if (uAct) uLastSt = stw;
+    }
     // everything below is in offsets from st0, the band's first column: d0 = owned column t0 - st0 (t1: d0 + 16), eb = en0 - st0,
     // ce = 16-aligned window end - st0, rd = r - st0 (the diagonal's column); stv is the window start
     LV<int> stv, d0v, ebv, cev, rdv, en0v; LV<bool> act, moved;
@@ -623,7 +685,7 @@ QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>& qlenv, const LV<int>& tlenv, K
       ebv[l] = en - st > 0 ? en - st : 0; cev[l] = (((en + 16) >> 4) << 4) - 1 - st; rdv[l] = r - st; en0v[l] = en;
       moved[l] = a && stv[l] != lastSt[l];
     }
-    if (!ballot(act)) break;
+    if (UNI ? !uAct : !ballot(act)) break;
     // v, x of the column before the window: what its last owner (the row's last lane, as t0) left, in the round the window moves;
     // nothing (or the first column's boundary) otherwise
     LV<int> bpack;
@@ -640,16 +702,15 @@ QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>& qlenv, const LV<int>& tlenv, K
       row_rotate_up(QS, rq);
       QM_LANES(l) { QS[l] = (l & 15) == 0 ? (int)((u32)fresh[l] | (((u32)rq[l] & 0xffu) << 8)) : rq[l]; }
     }
-    if (ballot(moved)) {                                  // rare: every ~32 rounds per row (and each row's first round)
-      LV<int> lastS, lastH;
-      row_last(ST0, lastS); row_last(HH0, lastH);
+    if (UNI ? uMoved : ballot(moved) != 0) {              // rare: every ~32 rounds per row (and each row's first round)
+      LV<int> lastS;
+      row_last(ST0, lastS);
       QM_LANES(l) {
         if (moved[l]) {
           const bool first = lastSt[l] < 0;
           if (!first && stv[l] > 0) bpack[l] = (int)((u32)lastS[l] & 0x00ffff00u);
-          hb[l] = (stv[l] > 0 && !first) ? lastH[l] : NEG;
-          ST0[l] = first ? 0 : ST1[l]; HH0[l] = first ? NEG : HH1[l]; SS0[l] = first ? 0 : SS1[l];
-          ST1[l] = 0; HH1[l] = NEG; SS1[l] = 0;
+          ST0[l] = first ? 0 : ST1[l]; SSP[l] = first ? 0 : (int)((u32)SSP[l] >> 16);
+          ST1[l] = 0;
           Row& B = blk[l >> 4];
           const int t0 = stv[l] + (l & 15), t1 = t0 + 16;
           int qi0 = 16 + r - t0; qi0 = qi0 < 0 ? 0 : (qi0 > MAXLEN + 39 ? MAXLEN + 39 : qi0);
@@ -662,7 +723,7 @@ QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>& qlenv, const LV<int>& tlenv, K
     }
     LV<bool> diag;
     QM_LANES(l) { diag[l] = cev[l] >= rdv[l] && (d0v[l] == rdv[l] || d0v[l] + 16 == rdv[l]); }
-    if (ballot(diag))                                     // only while the band still touches the diagonal (the first ~w rounds)
+    if (UNI ? uDiag : ballot(diag) != 0)                  // only while the band still touches the diagonal (the first ~w rounds)
     QM_LANES(l) {                                       // the diagonal cell: y8[r] = 0, u8[r] = r ? q : 0
       if (diag[l]) {
         const u32 uval = (u32)(r ? qv : 0);
@@ -673,11 +734,11 @@ QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>& qlenv, const LV<int>& tlenv, K
     // the scores of the 16 columns st0 .. st0 + 15 (the original's 16-wide score vectors start at st0)
     QM_LANES(l) {
       const u32 qs = (u32)QS[l], tq = (u32)TQ[l];
-      const int sv0 = (int)(qs & 0xff), sv1 = (int)((qs >> 8) & 0xff), sq0 = (int)(tq & 0xff), sq1 = (int)((tq >> 8) & 0xff);
-      int tmp0 = (sq0 == sv0) ? sc_mch : sc_mis; tmp0 = (sq0 == m1 || sv0 == m1) ? sc_N : tmp0;
-      int tmp1 = (sq1 == sv1) ? sc_mch : sc_mis; tmp1 = (sq1 == m1 || sv1 == m1) ? sc_N : tmp1;
-      const bool inScore0 = (u32)d0v[l] <= 15u, inScore1 = (u32)(d0v[l] + 16) <= 15u;
-      SS0[l] = inScore0 ? tmp0 : SS0[l]; SS1[l] = inScore1 ? tmp1 : SS1[l];
+      const u32 y = (tq ^ qs) | ((tq | qs) & 0x0404u);                                    // bytes 0, 1: the two columns' lookup indices
+      const u32 sn = perm8(LUTHI, LUTLO, perm8(y, 0x0c0c0c0cu, 0x05000400u));              // their scores in bytes 1, 3 (0 in bytes 0, 2)
+      const bool inScore0 = (u32)d0v[l] <= 15u, inScore1 = (u32)(d0v[l] + 16) <= 15u;      // (never both)
+      const u32 keep = inScore0 ? 0xffff0000u : (inScore1 ? 0x0000ffffu : 0xffffffffu);
+      SSP[l] = (int)(((u32)SSP[l] & keep) | (sn & ~keep));
     }
     // the difference recurrence on the two owned columns (13 packed 16-bit instructions, see sel_ksw_extz2_rows)
     LV<int> r0, r1, carry;
@@ -688,7 +749,7 @@ QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>& qlenv, const LV<int>& tlenv, K
       const u32 o0 = (u32)ST0[l], o1 = (u32)ST1[l];
       const u32 U = perm8(o1, o0, 0x040c000cu), Y = perm8(o1, o0, 0x070c030cu);
       const u32 V1 = perm8(nb1, nb0, 0x050c010cu), X1 = perm8(nb1, nb0, 0x060c020cu);
-      const u32 S = ((u32)SS0[l] << 8) | ((u32)SS1[l] << 24);
+      const u32 S = (u32)SSP[l];
       u32 Z = pk_add(S, QE2), A = pk_add(X1, V1), Bq = pk_add(Y, U);
       Z = pk_max_i(Z, A);
       Z = pk_max_u(Z, Bq);
@@ -702,24 +763,30 @@ QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>& qlenv, const LV<int>& tlenv, K
       if (inCore1) ST1[l] = (int)perm8(xy, uv, 0x07060302u);
     }
     // H (exact max) on the band cells st0..en0: at most 16 of them, so at most one of a lane's two columns
-    LV<int> rh0, rh1;
-    row_rotate_up(HH0, rh0); row_rotate_up(HH1, rh1);     // H of the column to the left, before this round's updates
+    LV<int> rh, hnv, cellv;
+    row_rotate_up(HB, rh);                                // H of the column to the left (the top cell's neighbour), before this round's updates
     QM_LANES(l) {
       const bool in0 = (u32)d0v[l] <= (u32)ebv[l], in1 = (u32)(d0v[l] + 16) <= (u32)ebv[l];
       const int dsel = in1 ? d0v[l] + 16 : d0v[l], en0 = en0v[l];
       const u32 pk = (u32)(in1 ? ST1[l] : ST0[l]);
-      const int hOld = in1 ? HH1[l] : HH0[l];
-      const int hl = in1 ? ((l & 15) == 0 ? rh0[l] : rh1[l]) : ((l & 15) == 0 ? hb[l] : rh0[l]);
+      const int hOld = HB[l], hl = rh[l];
       const int un = (int)(pk & 0xff), vn = (int)((pk >> 8) & 0xff);
       const int hOwn = hOld + vn - qe;
       const int hTop = en0 > 0 ? (hl + un - qe) : hOwn;
       const bool top = dsel == ebv[l];
       const int hn = r > 0 ? (top ? hTop : hOwn) : (vn - qe - qe);
-      if (in0) HH0[l] = hn;
-      if (in1) HH1[l] = hn;
-      if (in0 || in1) {
-        if (top && en0 == tlenv[l] - 1 && hn > mte[l]) mte[l] = hn;
-        if (dsel == 0 && rdv[l] == qlenv[l] - 1 && hn > mqe[l]) mqe[l] = hn;
+      if (in0 || in1) HB[l] = hn;
+      hnv[l] = hn; cellv[l] = (in0 || in1) ? dsel : -1;
+    }
+    // the two maxima live on the last target column and the last query row: only a row's last rounds have such a cell
+    LV<bool> late;
+    QM_LANES(l) { late[l] = d0v[l] != FAR && (en0v[l] == tlenv[l] - 1 || rdv[l] == qlenv[l] - 1); }
+    if (UNI ? uLate : ballot(late) != 0)
+    QM_LANES(l) {
+      if (late[l] && cellv[l] >= 0) {
+        const int hn = hnv[l];
+        if (cellv[l] == ebv[l] && en0v[l] == tlenv[l] - 1 && hn > mte[l]) mte[l] = hn;
+        if (cellv[l] == 0 && rdv[l] == qlenv[l] - 1 && hn > mqe[l]) mqe[l] = hn;
       }
     }
     QM_LANES(l) { if (act[l]) lastSt[l] = stv[l]; }
@@ -727,13 +794,22 @@ QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>& qlenv, const LV<int>& tlenv, K
   LV<int> neg;
   QM_LANES(l) { const int s = mqe[l] > mte[l] ? mqe[l] : mte[l]; neg[l] = -s; }
   group_min(neg, 16);
-  QM_LANES(l) { score[l] = (qlenv[l] <= 0 || tlenv[l] <= 0) ? NEG : -neg[l]; }
+  QM_LANES(l) { score[l] = (qlenvIn[l] <= 0 || tlenvIn[l] <= 0) ? NEG : -neg[l]; }
 }
 
 template <int RING, int MAXLEN = QM_KSW_MAXLEN>
 QM_DEV void sel_ksw_extz2_rows(const LV<int>& qlenv, const LV<int>& tlenv, KswRowT<RING, MAXLEN>* blk, const signed char* mat, int q, int e, int wIn,
                                LV<int>& score) {
-  if constexpr (RING == 32) { sel_ksw_extz2_rows_reg<MAXLEN>(qlenv, tlenv, blk, mat, q, e, wIn, score); return; }
+  if constexpr (RING == 32) {
+    // do the rows that hold an alignment share their lengths?
+    LV<int> key; LV<bool> odd;
+    QM_LANES(l) { key[l] = (qlenv[l] > 0 && tlenv[l] > 0) ? ((qlenv[l] << 16) | tlenv[l]) : -1; }
+    const int kmax = wave_max(key);
+    QM_LANES(l) { odd[l] = key[l] >= 0 && key[l] != kmax; }
+    if (kmax >= 0 && !ballot(odd)) sel_ksw_extz2_rows_reg<MAXLEN, true>(qlenv, tlenv, kmax >> 16, kmax & 0xffff, blk, mat, q, e, wIn, score);
+    else sel_ksw_extz2_rows_reg<MAXLEN, false>(qlenv, tlenv, 0, 0, blk, mat, q, e, wIn, score);
+    return;
+  }
   else {
   typedef KswRowT<RING, MAXLEN> Row;
   constexpr int RM = RING - 1;
@@ -1175,19 +1251,41 @@ QM_DEV void sel_tasks_align_rows(const PairBatch& P, const SelBatch& A, unsigned
   QM_LANES(l) { need[l] = gs[l] >= 0 ? ((tl[l] + 15) / 16 * 16) + ql[l] + 48 : 0; }
   const int needMax = wave_max(need);
   const int stageEnd = needMax < MAXLEN + 40 ? needMax : MAXLEN + 40;
-  for (int i0 = 0; i0 < stageEnd; i0 += 16) {
+  // two positions per lane and pass, no branches: an address (clamped to something readable) and a select per image, so the four
+  // loads of a pass are in flight together
+  for (int i0 = 0; i0 < stageEnd; i0 += 32) {
     QM_LANES(l) {
       if (gs[l] >= 0) {
         KswRowT<RING, MAXLEN>& B = blk[l >> 4];
-        const int i = i0 + (l & 15);
         const int qlen = ql[l], tlen = tl[l], tlen16 = (tlen + 15) / 16 * 16;
-        if (i < MAXLEN + 40) {
-          B.QX[i] = (i >= 16 && i < 16 + qlen) ? sel_nt4(sel_read_char(rd[l], rl[l], fw[l] != 0, ro[l] + i - 16)) : (unsigned char)0;
+        const bool fwd = fw[l] != 0;
+        const unsigned char* rp = rd[l]; const unsigned char* tp = tx[l];
+        const int rlast = rl[l] - 1, rof = ro[l];
+        unsigned char cq[2], ct[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int i = i0 + 16 * h + (l & 15);
+          // QX[i]: query character i - 16
+          const bool qok = i >= 16 && i < 16 + qlen;
+          const int qj = qok ? rof + i - 16 : 0;
+          cq[h] = rp[fwd ? qj : rlast - qj];
+          // TX[i]: target character i, or query character qlen - 1 - (i - tlen16) behind the padded target
           const int j = i - tlen16;
-          unsigned char c = 0;
-          if (i < tlen) c = sel_nt4(tx[l][i]);
-          else if (i >= tlen16 && j < qlen) c = sel_nt4(sel_read_char(rd[l], rl[l], fw[l] != 0, ro[l] + qlen - 1 - j));
-          B.TX[i] = c;
+          const bool isT = i < tlen, isQ = !isT && j >= 0 && j < qlen;
+          const int tj = isQ ? rof + qlen - 1 - j : 0;
+          const unsigned char* ta = isT ? tp + i : rp + (fwd ? tj : rlast - tj);
+          ct[h] = *ta;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int i = i0 + 16 * h + (l & 15);
+          const bool qok = i >= 16 && i < 16 + qlen;
+          const int j = i - tlen16;
+          const bool isT = i < tlen, isQ = !isT && j >= 0 && j < qlen;
+          if (i < MAXLEN + 40) {
+            B.QX[i] = qok ? sel_nt4(fwd ? cq[h] : rc_char(cq[h])) : (unsigned char)0;
+            B.TX[i] = isT ? sel_nt4(ct[h]) : (isQ ? sel_nt4(fwd ? ct[h] : rc_char(ct[h])) : (unsigned char)0);
+          }
         }
       }
     }

@@ -60,7 +60,7 @@ QM_DEV void atomic_or_u64(u64* p, u64 v) { *p |= v; }
 QM_DEV u64 atomic_add_u64(u64* p, u64 v) { u64 o = *p; *p = o + v; return o; }
 template <typename T> QM_DEV T uniform(T x) { return x; }
 #else
-QM_DEV u64 ballot(const LV<bool>& b) { return __ballot(b.v[0]); }
+QM_DEV u64 ballot(const LV<bool>& b) { return __builtin_amdgcn_ballot_w64(b.v[0]); }
 // the lane index is wave-uniform by construction (one `lane` for the whole wavefront): v_readlane returns the value in
 // an SGPR, so everything computed from it stays on the scalar unit (a __shfl result would drag it onto the VALU)
 QM_DEV int read_lane(const LV<int>& x, int lane) { return __builtin_amdgcn_readlane(x.v[0], __builtin_amdgcn_readfirstlane(lane)); }
@@ -167,7 +167,7 @@ QM_DEV int wave_max(const LV<int>& x) {
 // DPP wave_ror:1 -- one VALU instruction, no trip through the LDS crossbar
 QM_DEV void lane_rotate_up(const LV<int>& in, LV<int>& out) { out.v[0] = __builtin_amdgcn_update_dpp(0, in.v[0], 0x13C, 0xf, 0xf, false); }
 // DPP row_ror:1
-QM_DEV void row_rotate_up(const LV<int>& in, LV<int>& out) { out.v[0] = __builtin_amdgcn_update_dpp(0, in.v[0], 0x121, 0xf, 0xf, false); }
+QM_DEV void row_rotate_up(const LV<int>& in, LV<int>& out) { out.v[0] = __builtin_amdgcn_update_dpp(0, in.v[0], 0x121, 0xf, 0xf, true); }   // (every lane has a source: no old value to keep)
 // (rare callers only: a trip through the LDS crossbar)
 QM_DEV void row_last(const LV<int>& in, LV<int>& out) { out.v[0] = __shfl(in.v[0], (int)((threadIdx.x & 63) | 15), 64); }
 // butterfly inside a row of 16 with DPP pairings: lanes ^1, lanes ^2 (quad permutes), then the mirror image within 8 and

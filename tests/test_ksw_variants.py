@@ -142,3 +142,31 @@ def test_ksw_rows_every_target_length(w):
             qq, tt = grp[k]
             ref = ol.qo_ksw_extz2(100, qq.ctypes.data_as(C.c_void_p), len(tt), tt.ctypes.data_as(C.c_void_p), 2, -4, 4, 2, w)
             assert out[k] == ref, (w, t0 + k, ref, out[k])
+
+
+@pytest.mark.parametrize("scheme", [(2, -4, 4, 2, 15), (2, -6, 5, 3, 8), (1, -1, 1, 1, 0), (2, -4, 4, 2, 5), (1, 0, 25, 25, 15)])
+def test_ksw_rows_same_shape_wavefronts(scheme):
+    """four (or fewer: idle rows) alignments of ONE shape per wavefront -- the register edition then keeps the band's geometry on
+    the scalar unit (sel_ksw_extz2_rows_reg<.., UNI = true>): every query length class and target length residue, indels, N's"""
+    a, b, q_, e_, w = scheme
+    ol = oracle._lib(); el = emu._lib()
+    ol.qo_ksw_extz2.restype = C.c_int
+    rng = np.random.default_rng(77 + w)
+    bad = []
+    shapes = [(100, 120), (100, 100), (100, 87), (1, 1), (1, 21), (31, 51), (75, 95), (140, 160), (50, 1), (16, 16), (17, 33), (128, 148)]
+    shapes += [(int(rng.integers(1, 141)), int(rng.integers(1, 161))) for _ in range(60)]
+    for qlen, tlen in shapes:
+        for n in (4, 4, int(rng.integers(1, 4))):
+            grp = []
+            for _ in range(n):
+                q = rng.integers(0, 4, qlen).astype(np.uint8)
+                if rng.random() < 0.2:
+                    q[rng.integers(0, qlen)] = 4
+                t = _mutate(rng, q, tlen) if rng.random() < 0.85 else rng.integers(0, 5, tlen).astype(np.uint8)
+                grp.append((q, t))
+            out = _rows(el, grp, a, b, q_, e_, w)
+            for k, (qq, tt) in enumerate(grp):
+                ref = ol.qo_ksw_extz2(len(qq), qq.ctypes.data_as(C.c_void_p), len(tt), tt.ctypes.data_as(C.c_void_p), a, b, q_, e_, w)
+                if out[k] != ref:
+                    bad.append((k, n, len(qq), len(tt), ref, out[k]))
+    assert not bad, "%d mismatches, first: %r" % (len(bad), bad[:5])
