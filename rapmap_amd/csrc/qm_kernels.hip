@@ -143,12 +143,15 @@ __global__ __launch_bounds__(256) void qm_sel_plan_kernel(PairBatch P, SelBatch 
 // alignment, chosen from --dpBandwidth at launch (sel_ksw_ring_slots)
 // MAXLEN: QM_KSW_MAXLEN, or QM_KSW_MAXLEN_LONG for a batch with reads beyond QM_MAX_READ_LEN (images of 2 120 bytes)
 template <int RING, int WAVES, int MAXLEN = QM_KSW_MAXLEN>
-__global__ __launch_bounds__(64 * WAVES) void qm_sel_align_kernel(PairBatch P, SelBatch A) {
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void qm_sel_align_kernel(PairBatch P, SelBatch A) {
   __shared__ KswRowT<RING, MAXLEN> rows[WAVES][4];
+  __shared__ unsigned char codes[512];
+  sel_ksw_fill_codes((QM_LDS(unsigned char)*)codes, (int)threadIdx.x, 64 * WAVES);
+  __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const unsigned long long nt = *A.ntasks;
   for (unsigned long long t = ((unsigned long long)blockIdx.x * WAVES + wave) * 4; t < nt; t += (unsigned long long)gridDim.x * (4 * WAVES))
-    sel_tasks_align_rows<RING, MAXLEN>(P, A, t, nt, rows[wave]);
+    sel_tasks_align_rows<RING, MAXLEN>(P, A, t, nt, rows[wave], (const QM_LDS(unsigned char)*)codes);
 }
 __global__ __launch_bounds__(256) void qm_sel_finish_kernel(PairBatch P, SelBatch A) {
   __shared__ unsigned long long sc[6];

@@ -642,6 +642,8 @@ QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>& qlenvIn, const LV<int>& tlenvI
                                                     // recurrence's layout); H of the one that is a band cell (a band has at most 16 cells, so
                                                     // never both: a column enters the band as its top cell, whose H comes from the column to
                                                     // the left, and the lane's other column is 16 away)
+  LV<int> freshNext;
+  QM_LANES(l) { freshNext[l] = 0; }
   LV<int> TQ, QS;                                   // target characters of the two owned columns (byte 0 / 1; they stand with the
                                                     // window) and their query characters of this round (a shift register along the row)
   QM_LANES(l) {
@@ -693,14 +695,16 @@ QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>& qlenvIn, const LV<int>& tlenvI
     // the query character of cell (r, t) is QX[16 + r - t]: next round it belongs to the column to the right, so the characters
     // travel along the row (column t1 = t0 + 16 continues where the row's last lane leaves off) and only the row's first lane
     // reads a new one; the target characters stand with the window
+    // (read one round ahead -- freshNext, asked for last round with that round's window: when the window has moved since, the
+    // branch below reads the row's characters afresh anyway -- so that no round waits for its LDS read)
     {
-      LV<int> fresh, rq;
-      QM_LANES(l) {
-        int qi = 16 + r - stv[l]; qi = act[l] ? (qi > MAXLEN + 39 ? MAXLEN + 39 : qi) : 0;
-        fresh[l] = blk[l >> 4].QX[qi];
-      }
+      LV<int> rq;
       row_rotate_up(QS, rq);
-      QM_LANES(l) { QS[l] = (l & 15) == 0 ? (int)((u32)fresh[l] | (((u32)rq[l] & 0xffu) << 8)) : rq[l]; }
+      QM_LANES(l) { QS[l] = (l & 15) == 0 ? (int)((u32)freshNext[l] | (((u32)rq[l] & 0xffu) << 8)) : rq[l]; }
+      QM_LANES(l) {
+        int qi = 17 + r - stv[l]; qi = act[l] ? (qi > MAXLEN + 39 ? MAXLEN + 39 : qi) : 0;
+        freshNext[l] = blk[l >> 4].QX[qi];
+      }
     }
     if (UNI ? uMoved : ballot(moved) != 0) {              // rare: every ~32 rounds per row (and each row's first round)
       LV<int> lastS;
@@ -995,7 +999,8 @@ QM_DEV unsigned char sel_nt4(unsigned char c) {               // seq_nt4_table_l
   return acgt ? (unsigned char)(x ^ (x >> 1)) : (c < 4 ? c : (unsigned char)4);   // bytes 0..3 map to themselves in that table
 }
 
-struct SelTask { long long u; int gslot, side, tid, pos, roff, rlen, tlen1, fwd; };   // one ksw2 extension alignment
+struct SelTask { const unsigned char* rd; const unsigned char* tx; int gslot, rl, roff, rlen, tlen1, fwd; };   // one ksw2 extension alignment: the read, its
+                                     // length, where the target starts -- resolved by the plan, so that the alignment kernel's first load is its only descriptor load
 
 // the read as the alignment sees it: forward, or reverseRead() of it (src/RapMapUtils.cpp:107-128)
 QM_DEV unsigned char sel_read_char(const unsigned char* r, int len, bool fwd, int i) { return fwd ? r[i] : rc_char(r[len - 1 - i]); }
@@ -1155,7 +1160,8 @@ QM_DEV void sel_plan_side(const SelBatch& A, long long u, long long gbase, int l
       u64 h = hash_mix((u64)keyLen + 0x9E3779B97F4A7C15ULL);
       for (u32 i = 0; i < keyLen; i += 8) {
         u64 w = 0;
-        for (u32 t = 0; t < 8 && i + t < keyLen; ++t) w |= (u64)tseq1[i + t] << (8 * t);
+        if (i + 8 <= keyLen) w = load_u64_unaligned(tseq1 + i);      // (little endian: the same word as the byte loop's)
+        else for (u32 t = 0; t < 8 && i + t < keyLen; ++t) w |= (u64)tseq1[i + t] << (8 * t);
         h = hash_mix(h ^ w);
       }
       return h;
@@ -1168,7 +1174,18 @@ QM_DEV void sel_plan_side(const SelBatch& A, long long u, long long gbase, int l
       const int tlen1s = (int)tlen1;
       const int alnLen = rlen < tlen1s ? rlen : tlen1s;
       int sc = 0;
-      for (int i = 0; i < alnLen; ++i) {
+      int i = 0;
+      for (; i + 8 <= alnLen; i += 8) {                             // eight characters per pair of loads
+        const u64 tw = load_u64_unaligned(tseq1 + i);
+        const u64 rw = fwd ? load_u64_unaligned(read + roff + i) : load_u64_unaligned(read + (readLen - 1 - (roff + i) - 7));
+        for (int t = 0; t < 8; ++t) {
+          unsigned char c1 = (unsigned char)(tw >> (8 * t));
+          const unsigned char c2 = fwd ? (unsigned char)(rw >> (8 * t)) : rc_char((unsigned char)(rw >> (8 * (7 - t))));
+          c1 = (c1 == 'N' || c2 == 'N') ? c2 : c1;
+          sc += (c1 == c2) ? A.match : A.mismatch;
+        }
+      }
+      for (; i < alnLen; ++i) {
         unsigned char c1 = tseq1[i], c2 = sel_read_char(read, readLen, fwd, roff + i);
         c1 = (c1 == 'N' || c2 == 'N') ? c2 : c1;
         sc += (c1 == c2) ? A.match : A.mismatch;
@@ -1176,7 +1193,7 @@ QM_DEV void sel_plan_side(const SelBatch& A, long long u, long long gbase, int l
       s = sc;
     } else {
       const u64 ti = atomic_add_u64(A.ntasks, 1ULL);
-      SelTask t; t.u = u; t.gslot = (int)g; t.side = side; t.tid = (int)tid; t.pos = pos; t.roff = roff; t.rlen = rlen; t.tlen1 = (int)tlen1; t.fwd = fwd ? 1 : 0;
+      SelTask t; t.rd = read; t.tx = tseq1; t.gslot = (int)g; t.rl = readLen; t.roff = roff; t.rlen = rlen; t.tlen1 = (int)tlen1; t.fwd = fwd ? 1 : 0;
       A.tasks[ti] = t;
     }
     if (multiMapping) {
@@ -1230,8 +1247,15 @@ QM_DEV void sel_unit_plan(const PairBatch& P, const SelBatch& A, long long u, Un
 
 // Tasks t0 .. t0+3 (those below nt), one per row of 16 lanes: stage the two score-phase images straight from the read and
 // the transcript text, run the row kernel, lane 0 of every row stores its score.
+#define QM_KSW_STAGE_UNROLL 4
+// character -> nt4 code of the score phase, for a read taken as it is (codes[c]) and reverse-complemented (codes[256 + c]): one
+// table look-up in LDS per staged character instead of a dozen compares (the block fills it once, sel_ksw_fill_codes)
+QM_DEV void sel_ksw_fill_codes(QM_LDS(unsigned char)* codes, int tid, int nthreads) {
+  for (int c = tid; c < 256; c += nthreads) { codes[c] = sel_nt4((unsigned char)c); codes[256 + c] = sel_nt4(rc_char((unsigned char)c)); }
+}
 template <int RING, int MAXLEN = QM_KSW_MAXLEN>
-QM_DEV void sel_tasks_align_rows(const PairBatch& P, const SelBatch& A, unsigned long long t0, unsigned long long nt, KswRowT<RING, MAXLEN>* blk) {
+QM_DEV void sel_tasks_align_rows(const PairBatch& P, const SelBatch& A, unsigned long long t0, unsigned long long nt, KswRowT<RING, MAXLEN>* blk,
+                                 const QM_LDS(unsigned char)* codes) {
   LV<int> ql, tl, gs;
   LV<const unsigned char*> rd, tx; LV<int> rl, ro, fw;
   QM_LANES(l) {
@@ -1239,9 +1263,7 @@ QM_DEV void sel_tasks_align_rows(const PairBatch& P, const SelBatch& A, unsigned
     ql[l] = 0; tl[l] = 0; gs[l] = -1; rd[l] = nullptr; tx[l] = nullptr; rl[l] = 0; ro[l] = 0; fw[l] = 0;
     if (ti < nt) {
       const SelTask t = A.tasks[ti];
-      rd[l] = t.side == 0 ? A.seq1 + P.off1[t.u] : A.seq2 + P.off2[t.u];
-      rl[l] = (int)(t.side == 0 ? P.off1[t.u + 1] - P.off1[t.u] : P.off2[t.u + 1] - P.off2[t.u]);
-      tx[l] = A.text + A.txp_off[t.tid] + t.pos;
+      rd[l] = t.rd; rl[l] = t.rl; tx[l] = t.tx;
       ql[l] = t.rlen; tl[l] = t.tlen1; gs[l] = t.gslot; ro[l] = t.roff; fw[l] = t.fwd;
     }
   }
@@ -1251,19 +1273,20 @@ QM_DEV void sel_tasks_align_rows(const PairBatch& P, const SelBatch& A, unsigned
   QM_LANES(l) { need[l] = gs[l] >= 0 ? ((tl[l] + 15) / 16 * 16) + ql[l] + 48 : 0; }
   const int needMax = wave_max(need);
   const int stageEnd = needMax < MAXLEN + 40 ? needMax : MAXLEN + 40;
-  // two positions per lane and pass, no branches: an address (clamped to something readable) and a select per image, so the four
-  // loads of a pass are in flight together
-  for (int i0 = 0; i0 < stageEnd; i0 += 32) {
+  // four positions per lane and pass, no branches: an address (clamped to something readable) and a select per image -- the eight
+  // loads of a pass are in flight together, then their eight code look-ups
+  for (int i0 = 0; i0 < stageEnd; i0 += 16 * QM_KSW_STAGE_UNROLL) {
     QM_LANES(l) {
       if (gs[l] >= 0) {
         KswRowT<RING, MAXLEN>& B = blk[l >> 4];
         const int qlen = ql[l], tlen = tl[l], tlen16 = (tlen + 15) / 16 * 16;
+        const int rcOff = fw[l] != 0 ? 0 : 256;
         const bool fwd = fw[l] != 0;
         const unsigned char* rp = rd[l]; const unsigned char* tp = tx[l];
         const int rlast = rl[l] - 1, rof = ro[l];
-        unsigned char cq[2], ct[2];
+        unsigned char cq[QM_KSW_STAGE_UNROLL], ct[QM_KSW_STAGE_UNROLL];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < QM_KSW_STAGE_UNROLL; ++h) {
           const int i = i0 + 16 * h + (l & 15);
           // QX[i]: query character i - 16
           const bool qok = i >= 16 && i < 16 + qlen;
@@ -1277,14 +1300,21 @@ QM_DEV void sel_tasks_align_rows(const PairBatch& P, const SelBatch& A, unsigned
           ct[h] = *ta;
         }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < QM_KSW_STAGE_UNROLL; ++h) {
+          const int i = i0 + 16 * h + (l & 15);
+          const bool isT = i < tlen;
+          cq[h] = codes[rcOff + cq[h]];
+          ct[h] = codes[(isT ? 0 : rcOff) + ct[h]];
+        }
+#pragma unroll
+        for (int h = 0; h < QM_KSW_STAGE_UNROLL; ++h) {
           const int i = i0 + 16 * h + (l & 15);
           const bool qok = i >= 16 && i < 16 + qlen;
           const int j = i - tlen16;
           const bool isT = i < tlen, isQ = !isT && j >= 0 && j < qlen;
           if (i < MAXLEN + 40) {
-            B.QX[i] = qok ? sel_nt4(fwd ? cq[h] : rc_char(cq[h])) : (unsigned char)0;
-            B.TX[i] = isT ? sel_nt4(ct[h]) : (isQ ? sel_nt4(fwd ? ct[h] : rc_char(ct[h])) : (unsigned char)0);
+            B.QX[i] = qok ? cq[h] : (unsigned char)0;
+            B.TX[i] = (isT || isQ) ? ct[h] : (unsigned char)0;
           }
         }
       }

@@ -178,20 +178,21 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
       std::vector<SelTask> tasks(2 * (size_t)toff[nunits] + 2); u64 ntasks = 0;
       A.tref = tref.data(); A.tcix = tcix.data(); A.tasks = tasks.data(); A.ntasks = &ntasks;
       for (long long u = 0; u < nunits; ++u) sel_unit_plan(P, A, u, &uc);
+      unsigned char codes[512]; sel_ksw_fill_codes(codes, 0, 1);
       bool longReads = false;
       for (long long u = 0; u < nunits; ++u) { if (off1[u + 1] - off1[u] > QM_MAX_READ_LEN || (paired && off2[u + 1] - off2[u] > QM_MAX_READ_LEN)) longReads = true; }
       A.long_reads = longReads ? 1 : 0;
       if (longReads) switch (sel_ksw_ring_slots(A.bandwidth)) {
-        case 32: { std::vector<KswRowT<32, QM_KSW_MAXLEN_LONG>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<32, QM_KSW_MAXLEN_LONG>(P, A, t, ntasks, rows.data()); } break;
-        case 64: { std::vector<KswRowT<64, QM_KSW_MAXLEN_LONG>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<64, QM_KSW_MAXLEN_LONG>(P, A, t, ntasks, rows.data()); } break;
-        default: { std::vector<KswRowT<128, QM_KSW_MAXLEN_LONG>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<128, QM_KSW_MAXLEN_LONG>(P, A, t, ntasks, rows.data()); } break;
+        case 32: { std::vector<KswRowT<32, QM_KSW_MAXLEN_LONG>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<32, QM_KSW_MAXLEN_LONG>(P, A, t, ntasks, rows.data(), codes); } break;
+        case 64: { std::vector<KswRowT<64, QM_KSW_MAXLEN_LONG>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<64, QM_KSW_MAXLEN_LONG>(P, A, t, ntasks, rows.data(), codes); } break;
+        default: { std::vector<KswRowT<128, QM_KSW_MAXLEN_LONG>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<128, QM_KSW_MAXLEN_LONG>(P, A, t, ntasks, rows.data(), codes); } break;
       }
       else
       switch (sel_ksw_ring_slots(A.bandwidth)) {         // same rule as the launch wrapper
-        case 32: { std::vector<KswRowT<32>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<32>(P, A, t, ntasks, rows.data()); } break;
-        case 64: { std::vector<KswRowT<64>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<64>(P, A, t, ntasks, rows.data()); } break;
-        case 128: { std::vector<KswRowT<128>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<128>(P, A, t, ntasks, rows.data()); } break;
-        default: { std::vector<KswRowT<1024>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<1024>(P, A, t, ntasks, rows.data()); } break;
+        case 32: { std::vector<KswRowT<32>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<32>(P, A, t, ntasks, rows.data(), codes); } break;
+        case 64: { std::vector<KswRowT<64>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<64>(P, A, t, ntasks, rows.data(), codes); } break;
+        case 128: { std::vector<KswRowT<128>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<128>(P, A, t, ntasks, rows.data(), codes); } break;
+        default: { std::vector<KswRowT<1024>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<1024>(P, A, t, ntasks, rows.data(), codes); } break;
       }
       for (long long u = 0; u < nunits; ++u) hc[u] = (u32)sel_unit_finish(P, A, u, &uc);
     }
