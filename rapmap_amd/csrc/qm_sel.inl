@@ -653,7 +653,8 @@ QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>& qlenvIn, const LV<int>& tlenvI
   const int FAR = 0x40000000;                       // "column offset" of an idle row: every range test below fails
   bool uDone = false; int uLastSt = -1;             // UNI: the wave-level tests of a round as plain numbers (no ballots)
   for (int r = 0; ; ++r) {
-    bool uAct = false, uMoved = false, uDiag = false, uLate = false;
+    bool uAct = false, uMoved = false, uDiag = false, uLate = false, uFirst = false;
+    int uSt = 0, uEn = 0;
     if (UNI) {
       int st = 0, en = ut - 1;
       if (st < r - uq + 1) st = r - uq + 1;
@@ -663,29 +664,35 @@ QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>& qlenvIn, const LV<int>& tlenvI
       uAct = !uDone && r < uq + ut - 1 && st <= en;
       if (!uAct) uDone = true;
       const int stw = st & ~15, rd = r - st, dc = rd - (stw - st);     // the diagonal's column is owned by lane dc (t0) or dc - 16 (t1) of the row
-      uMoved = uAct && stw != uLastSt;
+      uMoved = uAct && stw != uLastSt; uFirst = uLastSt < 0;
       uDiag = uAct && (((en + 16) >> 4) << 4) - 1 - st >= rd && dc >= 0 && dc < 32;
       uLate = uAct && (en == ut - 1 || rd == uq - 1);
       if (uAct) uLastSt = stw;
+      uSt = st; uEn = en;
     }
     // everything below is in offsets from st0, the band's first column: d0 = owned column t0 - st0 (t1: d0 + 16), eb = en0 - st0,
     // ce = 16-aligned window end - st0, rd = r - st0 (the diagonal's column); stv is the window start
     LV<int> stv, d0v, ebv, cev, rdv, en0v; LV<bool> act, moved;
     QM_LANES(l) {
-      const int qlen = qlenv[l], tlen = tlenv[l], w = wIn;
-      int st = 0, en = tlen - 1;
-      if (st < r - qlen + 1) st = r - qlen + 1;
-      if (en > r) en = r;
-      if (st < (r - w + 1) >> 1) st = (r - w + 1) >> 1;
-      if (en > (r + w) >> 1) en = (r + w) >> 1;
-      const bool a = !done[l] && r < qlen + tlen - 1 && st <= en;
-      if (!a) done[l] = true;
+      int st, en; bool a, mv;
+      if (UNI) { st = uSt; en = uEn; a = uAct; mv = uMoved; }
+      else {
+        const int qlen = qlenv[l], tlen = tlenv[l], w = wIn;
+        st = 0; en = tlen - 1;
+        if (st < r - qlen + 1) st = r - qlen + 1;
+        if (en > r) en = r;
+        if (st < (r - w + 1) >> 1) st = (r - w + 1) >> 1;
+        if (en > (r + w) >> 1) en = (r + w) >> 1;
+        a = !done[l] && r < qlen + tlen - 1 && st <= en;
+        if (!a) done[l] = true;
+        mv = a && (st & ~15) != lastSt[l];
+      }
       act[l] = a;
       // (st >= 0; an active row has st <= en <= st + w, so the quotient of the original's (en - st) / 16 is 0 here; en >= 0)
       stv[l] = st & ~15;
       d0v[l] = a ? stv[l] + (l & 15) - st : FAR;
       ebv[l] = en - st > 0 ? en - st : 0; cev[l] = (((en + 16) >> 4) << 4) - 1 - st; rdv[l] = r - st; en0v[l] = en;
-      moved[l] = a && stv[l] != lastSt[l];
+      moved[l] = mv;
     }
     if (UNI ? !uAct : !ballot(act)) break;
     // v, x of the column before the window: what its last owner (the row's last lane, as t0) left, in the round the window moves;
@@ -711,7 +718,7 @@ QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>& qlenvIn, const LV<int>& tlenvI
       row_last(ST0, lastS);
       QM_LANES(l) {
         if (moved[l]) {
-          const bool first = lastSt[l] < 0;
+          const bool first = UNI ? uFirst : lastSt[l] < 0;
           if (!first && stv[l] > 0) bpack[l] = (int)((u32)lastS[l] & 0x00ffff00u);
           ST0[l] = first ? 0 : ST1[l]; SSP[l] = first ? 0 : (int)((u32)SSP[l] >> 16);
           ST1[l] = 0;
