@@ -659,6 +659,7 @@ QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>& qlenvIn, const LV<int>& tlenvI
       int st = 0, en = ut - 1;
       if (st < r - uq + 1) st = r - uq + 1;
       if (en > r) en = r;
+      QM_SCALAR(en);
       if (st < (r - wIn + 1) >> 1) st = (r - wIn + 1) >> 1;
       if (en > (r + wIn) >> 1) en = (r + wIn) >> 1;
       uAct = !uDone && r < uq + ut - 1 && st <= en;

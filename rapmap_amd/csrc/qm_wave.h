@@ -18,12 +18,16 @@
 #define QM_DEV inline
 #define QM_NL 64
 #define QM_LANES(l) for (int l = 0; l < 64; ++l)
+#define QM_SCALAR(x) ((void)0)
 #else
 #include <hip/hip_runtime.h>
 #define QM_LDS(T) T __attribute__((address_space(3)))
 #define QM_DEV __device__ __forceinline__
 #define QM_NL 1
 #define QM_LANES(l) for (int _qm_once = 0, l = (int)(threadIdx.x & 63); _qm_once < 1; ++_qm_once)
+// pins a wave-uniform int in an SGPR at this point (an opaque copy): keeps the compiler from fusing scalar arithmetic into a
+// three-operand VALU instruction (v_min3 / v_max3 have no scalar form; it then pays moves and a v_readfirstlane around one)
+#define QM_SCALAR(x) asm volatile("" : "+s"(x))
 #endif
 
 namespace qm {
