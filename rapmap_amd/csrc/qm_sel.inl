@@ -619,36 +619,43 @@ static_assert(QM_KSW_MAXLEN + 48 <= 1024, "the full-band ring must hold every co
 // nearly every wavefront of a fixed-length run -- so the band's bounds, the window, the "moved" / diagonal / last-rounds tests are
 // the same numbers in every lane: the compiler keeps them on the scalar unit (a third of the round's VALU instructions); rows
 // without an alignment run along on whatever their images hold, nobody reads their score.
-template <int MAXLEN, bool UNI>
-QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>& qlenvIn, const LV<int>& tlenvIn, int uq, int ut, KswRowT<32, MAXLEN>* blk, const signed char* mat, int q, int e, int wIn,
-                                   LV<int>& score) {
+// SETS = 2 (UNI only): the wavefront carries two groups of four alignments of that one shape -- rows blk[0..3] and blk[4..7], two sets of
+// state registers -- through the same rounds: the kernel is bound by the CU's scalar unit (one instruction per cycle for all four
+// SIMDs), and the scalar work of a round is then shared by eight alignments instead of four.
+struct KswSetState { LV<int> ST0, ST1, HB, SSP, TQ, QS, freshNext, mqe, mte; };
+template <int MAXLEN, bool UNI, int SETS = 1>
+QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>* qlenvIn, const LV<int>* tlenvIn, int uq, int ut, KswRowT<32, MAXLEN>* blk, const signed char* mat, int q, int e, int wIn,
+                                   LV<int>* score) {
+  static_assert(UNI || SETS == 1, "several sets per wavefront share the band's geometry");
   LV<int> qlenv, tlenv;
-  QM_LANES(l) { qlenv[l] = UNI ? uq : qlenvIn[l]; tlenv[l] = UNI ? ut : tlenvIn[l]; }
+  QM_LANES(l) { qlenv[l] = UNI ? uq : qlenvIn[0][l]; tlenv[l] = UNI ? ut : tlenvIn[0][l]; }
   typedef KswRowT<32, MAXLEN> Row;
   const int NEG = -0x40000000;
   const int m = 5;
   const int qe = q + e;
   int min_sc = mat[1];
   for (int t = 1; t < m * m; ++t) min_sc = min_sc < mat[t] ? min_sc : mat[t];
-  if (-min_sc > 2 * (q + e)) { QM_LANES(l) { score[l] = NEG; } return; }
+  if (-min_sc > 2 * (q + e)) { for (int s = 0; s < SETS; ++s) { QM_LANES(l) { score[s][l] = NEG; } } return; }
   const int sc_mch = (unsigned char)mat[0], sc_mis = (unsigned char)mat[1], sc_N = (unsigned char)mat[m * m - 1], m1 = m - 1;
   const int qe2 = (unsigned char)((q + e) * 2), max_sc_v = (unsigned char)(mat[0] + (q + e) * 2), qv = (unsigned char)q;
   const u32 QE2 = ((u32)qe2 << 8) | ((u32)qe2 << 24), MAXSC = ((u32)max_sc_v << 8) | ((u32)max_sc_v << 24), QV = ((u32)qv << 8) | ((u32)qv << 24);
   // the score of a pair of characters (nt4 codes 0 .. 4) as one byte lookup: y = (t ^ q) | ((t | q) & 4) is 0 for a match, 1 .. 3 for
   // a mismatch, 4 .. 7 when either is an N (ksw_gen_simple_mat's matrix: mat[0], mat[1], mat[24])
   const u32 LUTLO = (u32)sc_mch | ((u32)sc_mis << 8) | ((u32)sc_mis << 16) | ((u32)sc_mis << 24), LUTHI = (u32)sc_N * 0x01010101u;
-  LV<int> lastSt, mqe, mte; LV<bool> done;
-  LV<int> ST0, ST1, HB, SSP;                        // the two owned columns: (u, v, x, y) bytes; their score bytes (byte 1 / 3: the packed
+  LV<int> lastSt; LV<bool> done;
+  KswSetState W[SETS];                              // per set: ST0, ST1, HB, SSP -- the two owned columns: (u, v, x, y) bytes; their score bytes (byte 1 / 3: the packed
                                                     // recurrence's layout); H of the one that is a band cell (a band has at most 16 cells, so
                                                     // never both: a column enters the band as its top cell, whose H comes from the column to
                                                     // the left, and the lane's other column is 16 away)
-  LV<int> freshNext;
-  QM_LANES(l) { freshNext[l] = 0; }
-  LV<int> TQ, QS;                                   // target characters of the two owned columns (byte 0 / 1; they stand with the
+                                                    // TQ, QS: target characters of the two owned columns (byte 0 / 1; they stand with the
                                                     // window) and their query characters of this round (a shift register along the row)
-  QM_LANES(l) {
-    lastSt[l] = -1; mqe[l] = NEG; mte[l] = NEG; done[l] = qlenv[l] <= 0 || tlenv[l] <= 0;
-    ST0[l] = 0; ST1[l] = 0; HB[l] = NEG; SSP[l] = 0; TQ[l] = 0; QS[l] = 0;
+  QM_LANES(l) { lastSt[l] = -1; done[l] = qlenv[l] <= 0 || tlenv[l] <= 0; }
+#pragma unroll
+  for (int s = 0; s < SETS; ++s) {
+    QM_LANES(l) {
+      W[s].mqe[l] = NEG; W[s].mte[l] = NEG; W[s].freshNext[l] = 0;
+      W[s].ST0[l] = 0; W[s].ST1[l] = 0; W[s].HB[l] = NEG; W[s].SSP[l] = 0; W[s].TQ[l] = 0; W[s].QS[l] = 0;
+    }
   }
   const int FAR = 0x40000000;                       // "column offset" of an idle row: every range test below fails
   bool uDone = false; int uLastSt = -1;             // UNI: the wave-level tests of a round as plain numbers (no ballots)
@@ -698,70 +705,80 @@ QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>& qlenvIn, const LV<int>& tlenvI
     if (UNI ? !uAct : !ballot(act)) break;
     // v, x of the column before the window: what its last owner (the row's last lane, as t0) left, in the round the window moves;
     // nothing (or the first column's boundary) otherwise
-    LV<int> bpack;
-    QM_LANES(l) { bpack[l] = stv[l] > 0 ? 0 : ((r ? qv : 0) << 8); }
+    LV<int> bpack[SETS];
+#pragma unroll
+    for (int s = 0; s < SETS; ++s) { QM_LANES(l) { bpack[s][l] = stv[l] > 0 ? 0 : ((r ? qv : 0) << 8); } }
     // the query character of cell (r, t) is QX[16 + r - t]: next round it belongs to the column to the right, so the characters
     // travel along the row (column t1 = t0 + 16 continues where the row's last lane leaves off) and only the row's first lane
     // reads a new one; the target characters stand with the window
     // (read one round ahead -- freshNext, asked for last round with that round's window: when the window has moved since, the
     // branch below reads the row's characters afresh anyway -- so that no round waits for its LDS read)
-    {
+#pragma unroll
+    for (int s = 0; s < SETS; ++s) {
       LV<int> rq;
-      row_rotate_up(QS, rq);
-      QM_LANES(l) { QS[l] = (l & 15) == 0 ? (int)((u32)freshNext[l] | (((u32)rq[l] & 0xffu) << 8)) : rq[l]; }
+      row_rotate_up(W[s].QS, rq);
+      QM_LANES(l) { W[s].QS[l] = (l & 15) == 0 ? (int)((u32)W[s].freshNext[l] | (((u32)rq[l] & 0xffu) << 8)) : rq[l]; }
       QM_LANES(l) {
         int qi = 17 + r - stv[l]; qi = act[l] ? (qi > MAXLEN + 39 ? MAXLEN + 39 : qi) : 0;
-        freshNext[l] = blk[l >> 4].QX[qi];
+        W[s].freshNext[l] = blk[4 * s + (l >> 4)].QX[qi];
       }
     }
     if (UNI ? uMoved : ballot(moved) != 0) {              // rare: every ~32 rounds per row (and each row's first round)
+#pragma unroll
+      for (int s = 0; s < SETS; ++s) {
       LV<int> lastS;
-      row_last(ST0, lastS);
+      row_last(W[s].ST0, lastS);
       QM_LANES(l) {
         if (moved[l]) {
           const bool first = UNI ? uFirst : lastSt[l] < 0;
-          if (!first && stv[l] > 0) bpack[l] = (int)((u32)lastS[l] & 0x00ffff00u);
-          ST0[l] = first ? 0 : ST1[l]; SSP[l] = first ? 0 : (int)((u32)SSP[l] >> 16);
-          ST1[l] = 0;
-          Row& B = blk[l >> 4];
+          if (!first && stv[l] > 0) bpack[s][l] = (int)((u32)lastS[l] & 0x00ffff00u);
+          W[s].ST0[l] = first ? 0 : W[s].ST1[l]; W[s].SSP[l] = first ? 0 : (int)((u32)W[s].SSP[l] >> 16);
+          W[s].ST1[l] = 0;
+          Row& B = blk[4 * s + (l >> 4)];
           const int t0 = stv[l] + (l & 15), t1 = t0 + 16;
           int qi0 = 16 + r - t0; qi0 = qi0 < 0 ? 0 : (qi0 > MAXLEN + 39 ? MAXLEN + 39 : qi0);
           int qi1 = 16 + r - t1; qi1 = qi1 < 0 ? 0 : (qi1 > MAXLEN + 39 ? MAXLEN + 39 : qi1);
           const int ti0 = t0 > MAXLEN + 39 ? MAXLEN + 39 : t0, ti1 = t1 > MAXLEN + 39 ? MAXLEN + 39 : t1;
-          QS[l] = (int)((u32)B.QX[qi0] | ((u32)B.QX[qi1] << 8));
-          TQ[l] = (int)((u32)B.TX[ti0] | ((u32)B.TX[ti1] << 8));
+          W[s].QS[l] = (int)((u32)B.QX[qi0] | ((u32)B.QX[qi1] << 8));
+          W[s].TQ[l] = (int)((u32)B.TX[ti0] | ((u32)B.TX[ti1] << 8));
         }
+      }
       }
     }
     LV<bool> diag;
     QM_LANES(l) { diag[l] = cev[l] >= rdv[l] && (d0v[l] == rdv[l] || d0v[l] + 16 == rdv[l]); }
-    if (UNI ? uDiag : ballot(diag) != 0)                  // only while the band still touches the diagonal (the first ~w rounds)
+    if (UNI ? uDiag : ballot(diag) != 0) {                // only while the band still touches the diagonal (the first ~w rounds)
+#pragma unroll
+    for (int s = 0; s < SETS; ++s)
     QM_LANES(l) {                                       // the diagonal cell: y8[r] = 0, u8[r] = r ? q : 0
       if (diag[l]) {
         const u32 uval = (u32)(r ? qv : 0);
-        if (d0v[l] == rdv[l]) ST0[l] = (int)(((u32)ST0[l] & 0x00ffff00u) | uval);
-        else ST1[l] = (int)(((u32)ST1[l] & 0x00ffff00u) | uval);
+        if (d0v[l] == rdv[l]) W[s].ST0[l] = (int)(((u32)W[s].ST0[l] & 0x00ffff00u) | uval);
+        else W[s].ST1[l] = (int)(((u32)W[s].ST1[l] & 0x00ffff00u) | uval);
       }
     }
+    }
+#pragma unroll
+    for (int s = 0; s < SETS; ++s) {
     // the scores of the 16 columns st0 .. st0 + 15 (the original's 16-wide score vectors start at st0)
     QM_LANES(l) {
-      const u32 qs = (u32)QS[l], tq = (u32)TQ[l];
+      const u32 qs = (u32)W[s].QS[l], tq = (u32)W[s].TQ[l];
       const u32 y = (tq ^ qs) | ((tq | qs) & 0x0404u);                                    // bytes 0, 1: the two columns' lookup indices
       const u32 sn = perm8(LUTHI, LUTLO, perm8(y, 0x0c0c0c0cu, 0x05000400u));              // their scores in bytes 1, 3 (0 in bytes 0, 2)
       const bool inScore0 = (u32)d0v[l] <= 15u, inScore1 = (u32)(d0v[l] + 16) <= 15u;      // (never both)
       const u32 keep = inScore0 ? 0xffff0000u : (inScore1 ? 0x0000ffffu : 0xffffffffu);
-      SSP[l] = (int)(((u32)SSP[l] & keep) | (sn & ~keep));
+      W[s].SSP[l] = (int)(((u32)W[s].SSP[l] & keep) | (sn & ~keep));
     }
     // the difference recurrence on the two owned columns (13 packed 16-bit instructions, see sel_ksw_extz2_rows)
     LV<int> r0, r1, carry;
-    row_rotate_up(ST0, r0); row_rotate_up(ST1, r1); row_rotate_up(bpack, carry);
+    row_rotate_up(W[s].ST0, r0); row_rotate_up(W[s].ST1, r1); row_rotate_up(bpack[s], carry);
     QM_LANES(l) {
       const bool inCore0 = d0v[l] <= cev[l], inCore1 = d0v[l] + 16 <= cev[l];
       const u32 nb0 = (l & 15) == 0 ? (u32)carry[l] : (u32)r0[l], nb1 = (l & 15) == 0 ? (u32)r0[l] : (u32)r1[l];
-      const u32 o0 = (u32)ST0[l], o1 = (u32)ST1[l];
+      const u32 o0 = (u32)W[s].ST0[l], o1 = (u32)W[s].ST1[l];
       const u32 U = perm8(o1, o0, 0x040c000cu), Y = perm8(o1, o0, 0x070c030cu);
       const u32 V1 = perm8(nb1, nb0, 0x050c010cu), X1 = perm8(nb1, nb0, 0x060c020cu);
-      const u32 S = (u32)SSP[l];
+      const u32 S = (u32)W[s].SSP[l];
       u32 Z = pk_add(S, QE2), A = pk_add(X1, V1), Bq = pk_add(Y, U);
       Z = pk_max_i(Z, A);
       Z = pk_max_u(Z, Bq);
@@ -771,23 +788,23 @@ QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>& qlenvIn, const LV<int>& tlenvI
       A = pk_sub(A, Z); Bq = pk_sub(Bq, Z);
       const u32 XN = pk_max_i(A, 0u), YN = pk_max_i(Bq, 0u);
       const u32 uv = perm8(VN, UN, 0x07030501u), xy = perm8(YN, XN, 0x07030501u);
-      if (inCore0) ST0[l] = (int)perm8(xy, uv, 0x05040100u);
-      if (inCore1) ST1[l] = (int)perm8(xy, uv, 0x07060302u);
+      if (inCore0) W[s].ST0[l] = (int)perm8(xy, uv, 0x05040100u);
+      if (inCore1) W[s].ST1[l] = (int)perm8(xy, uv, 0x07060302u);
     }
     // H (exact max) on the band cells st0..en0: at most 16 of them, so at most one of a lane's two columns
     LV<int> rh, hnv, cellv;
-    row_rotate_up(HB, rh);                                // H of the column to the left (the top cell's neighbour), before this round's updates
+    row_rotate_up(W[s].HB, rh);                                // H of the column to the left (the top cell's neighbour), before this round's updates
     QM_LANES(l) {
       const bool in0 = (u32)d0v[l] <= (u32)ebv[l], in1 = (u32)(d0v[l] + 16) <= (u32)ebv[l];
       const int dsel = in1 ? d0v[l] + 16 : d0v[l], en0 = en0v[l];
-      const u32 pk = (u32)(in1 ? ST1[l] : ST0[l]);
-      const int hOld = HB[l], hl = rh[l];
+      const u32 pk = (u32)(in1 ? W[s].ST1[l] : W[s].ST0[l]);
+      const int hOld = W[s].HB[l], hl = rh[l];
       const int un = (int)(pk & 0xff), vn = (int)((pk >> 8) & 0xff);
       const int hOwn = hOld + vn - qe;
       const int hTop = en0 > 0 ? (hl + un - qe) : hOwn;
       const bool top = dsel == ebv[l];
       const int hn = r > 0 ? (top ? hTop : hOwn) : (vn - qe - qe);
-      if (in0 || in1) HB[l] = hn;
+      if (in0 || in1) W[s].HB[l] = hn;
       hnv[l] = hn; cellv[l] = (in0 || in1) ? dsel : -1;
     }
     // the two maxima live on the last target column and the last query row: only a row's last rounds have such a cell
@@ -797,16 +814,20 @@ QM_DEV void sel_ksw_extz2_rows_reg(const LV<int>& qlenvIn, const LV<int>& tlenvI
     QM_LANES(l) {
       if (late[l] && cellv[l] >= 0) {
         const int hn = hnv[l];
-        if (cellv[l] == ebv[l] && en0v[l] == tlenv[l] - 1 && hn > mte[l]) mte[l] = hn;
-        if (cellv[l] == 0 && rdv[l] == qlenv[l] - 1 && hn > mqe[l]) mqe[l] = hn;
+        if (cellv[l] == ebv[l] && en0v[l] == tlenv[l] - 1 && hn > W[s].mte[l]) W[s].mte[l] = hn;
+        if (cellv[l] == 0 && rdv[l] == qlenv[l] - 1 && hn > W[s].mqe[l]) W[s].mqe[l] = hn;
       }
+    }
     }
     QM_LANES(l) { if (act[l]) lastSt[l] = stv[l]; }
   }
-  LV<int> neg;
-  QM_LANES(l) { const int s = mqe[l] > mte[l] ? mqe[l] : mte[l]; neg[l] = -s; }
-  group_min(neg, 16);
-  QM_LANES(l) { score[l] = (qlenvIn[l] <= 0 || tlenvIn[l] <= 0) ? NEG : -neg[l]; }
+#pragma unroll
+  for (int s = 0; s < SETS; ++s) {
+    LV<int> neg;
+    QM_LANES(l) { const int sc = W[s].mqe[l] > W[s].mte[l] ? W[s].mqe[l] : W[s].mte[l]; neg[l] = -sc; }
+    group_min(neg, 16);
+    QM_LANES(l) { score[s][l] = (qlenvIn[s][l] <= 0 || tlenvIn[s][l] <= 0) ? NEG : -neg[l]; }
+  }
 }
 
 template <int RING, int MAXLEN = QM_KSW_MAXLEN>
@@ -818,8 +839,8 @@ QM_DEV void sel_ksw_extz2_rows(const LV<int>& qlenv, const LV<int>& tlenv, KswRo
     QM_LANES(l) { key[l] = (qlenv[l] > 0 && tlenv[l] > 0) ? ((qlenv[l] << 16) | tlenv[l]) : -1; }
     const int kmax = wave_max(key);
     QM_LANES(l) { odd[l] = key[l] >= 0 && key[l] != kmax; }
-    if (kmax >= 0 && !ballot(odd)) sel_ksw_extz2_rows_reg<MAXLEN, true>(qlenv, tlenv, kmax >> 16, kmax & 0xffff, blk, mat, q, e, wIn, score);
-    else sel_ksw_extz2_rows_reg<MAXLEN, false>(qlenv, tlenv, 0, 0, blk, mat, q, e, wIn, score);
+    if (kmax >= 0 && !ballot(odd)) sel_ksw_extz2_rows_reg<MAXLEN, true>(&qlenv, &tlenv, kmax >> 16, kmax & 0xffff, blk, mat, q, e, wIn, &score);
+    else sel_ksw_extz2_rows_reg<MAXLEN, false>(&qlenv, &tlenv, 0, 0, blk, mat, q, e, wIn, &score);
     return;
   }
   else {
@@ -1261,10 +1282,10 @@ QM_DEV void sel_unit_plan(const PairBatch& P, const SelBatch& A, long long u, Un
 QM_DEV void sel_ksw_fill_codes(QM_LDS(unsigned char)* codes, int tid, int nthreads) {
   for (int c = tid; c < 256; c += nthreads) { codes[c] = sel_nt4((unsigned char)c); codes[256 + c] = sel_nt4(rc_char((unsigned char)c)); }
 }
-template <int RING, int MAXLEN = QM_KSW_MAXLEN>
-QM_DEV void sel_tasks_align_rows(const PairBatch& P, const SelBatch& A, unsigned long long t0, unsigned long long nt, KswRowT<RING, MAXLEN>* blk,
-                                 const QM_LDS(unsigned char)* codes) {
-  LV<int> ql, tl, gs;
+// stage the images of tasks t0 .. t0+3 (those below nt) into blk[0..3]; ql / tl / gs: each row's lengths and score slot (-1: no task)
+template <int RING, int MAXLEN>
+QM_DEV void sel_tasks_stage(const SelBatch& A, unsigned long long t0, unsigned long long nt, KswRowT<RING, MAXLEN>* blk,
+                            const QM_LDS(unsigned char)* codes, LV<int>& ql, LV<int>& tl, LV<int>& gs) {
   LV<const unsigned char*> rd, tx; LV<int> rl, ro, fw;
   QM_LANES(l) {
     const unsigned long long ti = t0 + (unsigned long long)(l >> 4);
@@ -1329,14 +1350,52 @@ QM_DEV void sel_tasks_align_rows(const PairBatch& P, const SelBatch& A, unsigned
     }
   }
   wave_fence();
-  signed char mat[25];
+}
+QM_DEV void sel_ksw_matrix(const SelBatch& A, signed char* mat) {      // ksw_gen_simple_mat as the reference's aligner sets it up
   int a = (signed char)A.match, b = (signed char)A.mismatch;
   a = a < 0 ? -a : a; b = b > 0 ? -b : b;
   for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) mat[i * 5 + j] = (signed char)(i == j ? a : b); mat[i * 5 + 4] = 0; }
   for (int j = 0; j < 5; ++j) mat[20 + j] = 0;
+}
+template <int RING, int MAXLEN = QM_KSW_MAXLEN>
+QM_DEV void sel_tasks_align_rows(const PairBatch& P, const SelBatch& A, unsigned long long t0, unsigned long long nt, KswRowT<RING, MAXLEN>* blk,
+                                 const QM_LDS(unsigned char)* codes) {
+  LV<int> ql, tl, gs;
+  sel_tasks_stage<RING, MAXLEN>(A, t0, nt, blk, codes, ql, tl, gs);
+  signed char mat[25];
+  sel_ksw_matrix(A, mat);
   LV<int> sc;
   sel_ksw_extz2_rows<RING, MAXLEN>(ql, tl, blk, mat, (signed char)A.gap_open, (signed char)A.gap_extend, A.bandwidth, sc);
   QM_LANES(l) { if (gs[l] >= 0 && (l & 15) == 0) A.tsc[gs[l]] = sc[l]; }
+  wave_fence();
+}
+// The register edition, eight tasks per wavefront (t0 .. t0+7 in blk[0..7]): when all of them share their lengths they go through
+// the rounds together as two sets (sel_ksw_extz2_rows_reg<.., UNI, 2>), else four and four
+template <int MAXLEN>
+QM_DEV void sel_tasks_align_rows2(const PairBatch& P, const SelBatch& A, unsigned long long t0, unsigned long long nt, KswRowT<32, MAXLEN>* blk,
+                                  const QM_LDS(unsigned char)* codes) {
+  LV<int> ql[2], tl[2], gs[2];
+  sel_tasks_stage<32, MAXLEN>(A, t0, nt, blk, codes, ql[0], tl[0], gs[0]);
+  sel_tasks_stage<32, MAXLEN>(A, t0 + 4, nt, blk + 4, codes, ql[1], tl[1], gs[1]);
+  signed char mat[25];
+  sel_ksw_matrix(A, mat);
+  LV<int> sc[2];
+  LV<int> key; LV<bool> odd;
+  QM_LANES(l) { const int k0 = gs[0][l] >= 0 ? ((ql[0][l] << 16) | tl[0][l]) : -1, k1 = gs[1][l] >= 0 ? ((ql[1][l] << 16) | tl[1][l]) : -1; key[l] = k0 > k1 ? k0 : k1; }
+  const int kmax = wave_max(key);
+  QM_LANES(l) {
+    const int k0 = gs[0][l] >= 0 ? ((ql[0][l] << 16) | tl[0][l]) : -1, k1 = gs[1][l] >= 0 ? ((ql[1][l] << 16) | tl[1][l]) : -1;
+    odd[l] = (k0 >= 0 && k0 != kmax) || (k1 >= 0 && k1 != kmax) || (ql[0][l] <= 0 && gs[0][l] >= 0) || (tl[0][l] <= 0 && gs[0][l] >= 0);
+  }
+  LV<bool> has1; QM_LANES(l) { has1[l] = gs[1][l] >= 0; }
+  const bool both = ballot(has1) != 0;
+  if (kmax > 0 && both && !ballot(odd) && (kmax >> 16) > 0 && (kmax & 0xffff) > 0 && A.bandwidth >= 0 && A.bandwidth <= 15) {
+    sel_ksw_extz2_rows_reg<MAXLEN, true, 2>(ql, tl, kmax >> 16, kmax & 0xffff, blk, mat, (signed char)A.gap_open, (signed char)A.gap_extend, A.bandwidth, sc);
+  } else {
+    sel_ksw_extz2_rows<32, MAXLEN>(ql[0], tl[0], blk, mat, (signed char)A.gap_open, (signed char)A.gap_extend, A.bandwidth, sc[0]);
+    sel_ksw_extz2_rows<32, MAXLEN>(ql[1], tl[1], blk + 4, mat, (signed char)A.gap_open, (signed char)A.gap_extend, A.bandwidth, sc[1]);
+  }
+  for (int s = 0; s < 2; ++s) { QM_LANES(l) { if (gs[s][l] >= 0 && (l & 15) == 0) A.tsc[gs[s][l]] = sc[s][l]; } }
   wave_fence();
 }
 

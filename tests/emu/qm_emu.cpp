@@ -189,7 +189,7 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
       }
       else
       switch (sel_ksw_ring_slots(A.bandwidth)) {         // same rule as the launch wrapper
-        case 32: { std::vector<KswRowT<32>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<32>(P, A, t, ntasks, rows.data(), codes); } break;
+        case 32: { std::vector<KswRowT<32>> rows(8); for (u64 t = 0; t < ntasks; t += 8) sel_tasks_align_rows2<QM_KSW_MAXLEN>(P, A, t, ntasks, rows.data(), codes); } break;   // as qm_sel_align2_kernel
         case 64: { std::vector<KswRowT<64>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<64>(P, A, t, ntasks, rows.data(), codes); } break;
         case 128: { std::vector<KswRowT<128>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<128>(P, A, t, ntasks, rows.data(), codes); } break;
         default: { std::vector<KswRowT<1024>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<1024>(P, A, t, ntasks, rows.data(), codes); } break;
@@ -305,7 +305,33 @@ static void ksw_rows_run(const int* qlen, const unsigned char* const* query, con
   sel_ksw_extz2_rows<RING>(ql, tl, blk.data(), mat, q, e, w, sc);
   for (int g = 0; g < 4; ++g) out[g] = sc[g * 16];
 }
+// eight alignments of ONE shape (n of them real, the rest idle rows) as two sets through the register edition: out[8]
+static void ksw_rows_run8(int n, int qlen, const unsigned char* const* query, int tlen, const unsigned char* const* target,
+                          const signed char* mat, int q, int e, int w, int* out) {
+  std::vector<KswRowT<32>> blk(8);
+  LV<int> ql[2], tl[2], sc[2];
+  const int tlen16 = (tlen + 15) / 16 * 16;
+  for (int g = 0; g < 8; ++g) {
+    memset(&blk[g], 0xAB, sizeof(KswRowT<32>));
+    if (g < n) for (int i = 0; i < QM_KSW_MAXLEN + 40 && i < tlen16 + qlen + 48; ++i) {
+      blk[g].QX[i] = (i >= 16 && i < 16 + qlen) ? query[g][i - 16] : 0;
+      const int j = i - tlen16;
+      blk[g].TX[i] = i < tlen ? target[g][i] : (i < tlen16 ? 0 : (j < qlen ? query[g][qlen - 1 - j] : 0));
+    }
+    for (int c = 0; c < 16; ++c) { ql[g / 4][(g & 3) * 16 + c] = g < n ? qlen : 0; tl[g / 4][(g & 3) * 16 + c] = g < n ? tlen : 0; }
+  }
+  sel_ksw_extz2_rows_reg<QM_KSW_MAXLEN, true, 2>(ql, tl, qlen, tlen, blk.data(), mat, q, e, w, sc);
+  for (int g = 0; g < 8; ++g) out[g] = sc[g / 4][(g & 3) * 16];
+}
 extern "C" {
+void qe_ksw_rows8(int n, int qlen, const unsigned char* const* query, int tlen, const unsigned char* const* target,
+                  int a, int b, int q, int e, int w, int* out) {
+  signed char mat[25];
+  a = a < 0 ? -a : a; b = b > 0 ? -b : b;
+  for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) mat[i * 5 + j] = (signed char)(i == j ? a : b); mat[i * 5 + 4] = 0; }
+  for (int j = 0; j < 5; ++j) mat[20 + j] = 0;
+  ksw_rows_run8(n, qlen, query, tlen, target, mat, q, e, w, out);
+}
 // ring < 0: the ring the launch wrapper would pick for this band; otherwise force 64 / 128 / 1024 slots
 void qe_ksw_rows(const int* qlen, const unsigned char* const* query, const int* tlen, const unsigned char* const* target,
                  int a, int b, int q, int e, int w, int* out, int ring) {

@@ -170,3 +170,35 @@ def test_ksw_rows_same_shape_wavefronts(scheme):
                 if out[k] != ref:
                     bad.append((k, n, len(qq), len(tt), ref, out[k]))
     assert not bad, "%d mismatches, first: %r" % (len(bad), bad[:5])
+
+
+@pytest.mark.parametrize("scheme", [(2, -4, 4, 2, 15), (2, -6, 5, 3, 8), (1, -1, 1, 1, 0), (2, -4, 4, 2, 5)])
+def test_ksw_rows_eight_per_wavefront(scheme):
+    """eight alignments of one shape as two sets of state through the same rounds (sel_ksw_extz2_rows_reg<.., UNI, 2>, what
+    qm_sel_align2_kernel runs when a wavefront's eight tasks share their lengths), 5 .. 8 of them real"""
+    a, b, q_, e_, w = scheme
+    ol = oracle._lib(); el = emu._lib()
+    ol.qo_ksw_extz2.restype = C.c_int
+    rng = np.random.default_rng(177 + w)
+    bad = []
+    shapes = [(100, 120), (100, 100), (100, 87), (1, 1), (31, 51), (75, 95), (140, 160), (16, 16), (17, 33), (128, 148)]
+    shapes += [(int(rng.integers(1, 141)), int(rng.integers(1, 161))) for _ in range(40)]
+    for qlen, tlen in shapes:
+        for n in (8, int(rng.integers(5, 8))):
+            grp = []
+            for _ in range(n):
+                q = rng.integers(0, 4, qlen).astype(np.uint8)
+                if rng.random() < 0.2:
+                    q[rng.integers(0, qlen)] = 4
+                t = _mutate(rng, q, tlen) if rng.random() < 0.85 else rng.integers(0, 5, tlen).astype(np.uint8)
+                grp.append((q, t))
+            dummy = np.zeros(1, dtype=np.uint8)
+            qp = (C.c_void_p * 8)(*[g[0].ctypes.data for g in grp] + [dummy.ctypes.data] * (8 - n))
+            tp = (C.c_void_p * 8)(*[g[1].ctypes.data for g in grp] + [dummy.ctypes.data] * (8 - n))
+            out = (C.c_int * 8)()
+            el.qe_ksw_rows8(n, qlen, qp, tlen, tp, a, b, q_, e_, w, out)
+            for k, (qq, tt) in enumerate(grp):
+                ref = ol.qo_ksw_extz2(len(qq), qq.ctypes.data_as(C.c_void_p), len(tt), tt.ctypes.data_as(C.c_void_p), a, b, q_, e_, w)
+                if out[k] != ref:
+                    bad.append((k, n, qlen, tlen, ref, out[k]))
+    assert not bad, "%d mismatches, first: %r" % (len(bad), bad[:5])
