@@ -655,6 +655,7 @@ struct RunReq {
   bool keepFound = false;         // foundHit per read kept for qm_fetch_found
   bool mergeOnly = false;         // stage B without the caller-level bookkeeping, tooMany flags kept
   bool longReads = false;         // the batch holds reads beyond QM_MAX_READ_LEN (set by map_device_impl from max_read_len)
+  int shortLen = 0;               // the longest read that is not beyond QM_MAX_READ_LEN (0: unknown)
   // QM_RUN_FROM_INTERVALS: device arrays
   const qm_sa_interval_hit* ivIn = nullptr; const long long* ivInOff = nullptr; const int* lenIn = nullptr; const unsigned char* foundIn = nullptr;
 };
@@ -930,6 +931,7 @@ static int run_stage_b(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
     A.txp_off = c->d_txpOff; A.txp_len = c->d_txpLen; A.tmp = c->d_tmp; A.toff = c->d_toff; A.tkeys = c->d_tkeys; A.tsc = c->d_tsc;
     A.match = o->match_score; A.mismatch = o->mismatch_penalty; A.gap_open = o->gap_open; A.gap_extend = o->gap_extend;
     A.long_reads = rq.longReads ? 1 : 0;
+    A.short_len = rq.shortLen;
     A.bandwidth = o->dp_bandwidth; A.hard_filter = o->hard_filter; A.policy = o->aln_policy; A.min_score_fraction = o->min_score_fraction;
     HIPCHK(hipMemsetAsync(c->d_cnt + n, 0, sizeof(uint32_t), c->stream));
     if (rq.mergeOnly) {
@@ -996,6 +998,7 @@ static int map_device_impl(qm_ctx* c, const qm_opts* o, int64_t n, const void* d
   RunReq r2 = rq;
   r2.keepIntervals = rq.keepIntervals || c->debug != 0;
   r2.longReads = max_read_len > QM_MAX_READ_LEN;
+  r2.shortLen = pick;
   if ((rc = run_stage_a(c, o, r2, n, d_seq1, d_off1, d_seq2, d_off2, ns, feeder, hscal))) return rc;
   long long total = 0;
   if ((rc = run_stage_b(c, o, r2, n, paired, d_seq1, d_off1, d_seq2, d_off2, hscal, total))) return rc;

@@ -155,15 +155,16 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(8, 8
 }
 // the register edition for reads of up to QM_MAX_READ_LEN, eight alignments per wavefront (sel_tasks_align_rows2): 37.9 KB of LDS per
 // block, four blocks per CU -- as many alignments in flight as eight blocks of the four-per-wavefront kernel, half its scalar work
+template <int MAXLEN>
 __global__ __launch_bounds__(256) void qm_sel_align2_kernel(PairBatch P, SelBatch A) {
-  __shared__ KswRowT<32, QM_KSW_MAXLEN> rows[4][8];
+  __shared__ KswRowT<32, MAXLEN> rows[4][8];
   __shared__ unsigned char codes[512];
   sel_ksw_fill_codes((QM_LDS(unsigned char)*)codes, (int)threadIdx.x, 256);
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const unsigned long long nt = *A.ntasks;
   for (unsigned long long t = ((unsigned long long)blockIdx.x * 4 + wave) * 8; t < nt; t += (unsigned long long)gridDim.x * 32)
-    sel_tasks_align_rows2<QM_KSW_MAXLEN>(P, A, t, nt, rows[wave], (const QM_LDS(unsigned char)*)codes);
+    sel_tasks_align_rows2<MAXLEN>(P, A, t, nt, rows[wave], (const QM_LDS(unsigned char)*)codes);
 }
 __global__ __launch_bounds__(256) void qm_sel_finish_kernel(PairBatch P, SelBatch A) {
   __shared__ unsigned long long sc[6];
@@ -429,7 +430,13 @@ hipError_t qmk_sel_align_finish(const void* pp, const void* ap, int num_cu, hipS
     }
   } else
   switch (sel_ksw_ring_slots(A.bandwidth)) {            // one kernel for every --dpBandwidth: the band decides the ring
-    case 32: hipLaunchKernelGGL(qm_sel_align2_kernel, dim3((unsigned)(num_cu * 4)), dim3(256), 0, st, P, A); break;   // register edition (--dpBandwidth <= 15), eight per wavefront
+    case 32:                                                                             // register edition (--dpBandwidth <= 15), eight per wavefront
+      // images sized by the read-length class of the batch (the stage-A kernels' slot classes): 13 / 17 / 21 / 37 KB of LDS per block
+      if (A.short_len > 0 && A.short_len <= 128) hipLaunchKernelGGL(qm_sel_align2_kernel<128 + 32>, dim3((unsigned)(num_cu * 8)), dim3(256), 0, st, P, A);
+      else if (A.short_len > 0 && A.short_len <= 192) hipLaunchKernelGGL(qm_sel_align2_kernel<192 + 32>, dim3((unsigned)(num_cu * 8)), dim3(256), 0, st, P, A);
+      else if (A.short_len > 0 && A.short_len <= 256) hipLaunchKernelGGL(qm_sel_align2_kernel<256 + 32>, dim3((unsigned)(num_cu * 7)), dim3(256), 0, st, P, A);
+      else hipLaunchKernelGGL(qm_sel_align2_kernel<QM_KSW_MAXLEN>, dim3((unsigned)(num_cu * 4)), dim3(256), 0, st, P, A);
+      break;
     case 64: hipLaunchKernelGGL((qm_sel_align_kernel<64, 4>), dim3((unsigned)(num_cu * 8)), dim3(256), 0, st, P, A); break;
     case 128: hipLaunchKernelGGL((qm_sel_align_kernel<128, 4>), dim3((unsigned)(num_cu * 4)), dim3(256), 0, st, P, A); break;
     default: hipLaunchKernelGGL((qm_sel_align_kernel<1024, 2>), dim3((unsigned)(num_cu * 2)), dim3(128), 0, st, P, A); break;   // 83 KB of LDS per block

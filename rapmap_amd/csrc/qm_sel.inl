@@ -572,6 +572,8 @@ struct SelBatch {                    // launch arguments of the -s kernels (on t
                                                // plan -> align -> finish in chunks: the plan of chunk i+1 runs under the align of chunk i)
   int match, mismatch, gap_open, gap_extend, bandwidth, hard_filter, policy;
   int long_reads;                              // the batch holds reads beyond QM_MAX_READ_LEN: the long editions of the alignment kernel
+  int short_len;                               // longest read of the batch that is not beyond QM_MAX_READ_LEN (0: unknown): reads of up to 128
+                                               // characters run the alignment kernel with 192-byte images (twice the resident wavefronts)
   double min_score_fraction;
 };
 
