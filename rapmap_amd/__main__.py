@@ -110,9 +110,6 @@ def _quasimap(argv):
             opts.no_orphans = 1; opts.no_dovetail = 1; opts.consensus_slack = 0.35; opts.max_num_hits = 1000
         if a.mimicStrictBT2:
             opts.min_score_fraction = 0.8; opts.match_score = 1; opts.mismatch_penalty = 0; opts.gap_open = 25; opts.gap_extend = 25
-    # pinned memory for the stream's slots, pinned in the background while the index is opened and uploaded
-    ra.reserve_stream_memory((768 << 20) * max(1, len(a.devices.split(",")) if a.devices and a.devices != "all" else 1))
-    qi = ra.QuasiIndex(a.index)
     if a.devices:
         if a.devices == "all":
             import ctypes as _C
@@ -130,6 +127,10 @@ def _quasimap(argv):
                 sys.exit("--devices: no device given")
     else:
         devices = [a.device]
+    # pinned memory for the stream's slots (every device of the run has its own), pinned in the background while the index is
+    # opened and uploaded
+    ra.reserve_stream_memory((768 << 20) * len(devices))
+    qi = ra.QuasiIndex(a.index)
     log = (lambda *x: None) if a.quiet else (lambda *x: print(*x, file=sys.stderr, flush=True))
     out = None
     direct_fd = None

@@ -364,8 +364,10 @@ Chunk* take_parse(qm_ingest* g) {
     const int64_t live = (int64_t)S.line.size() + (int64_t)S.done.size() + S.inParse;
     const int64_t per = S.linkedChunks ? std::max<int64_t>(1, S.linkedRecs / S.linkedChunks) : 1;
     const int64_t sight = S.avail + S.doneRecs + S.inParse * per;
-    if (sight >= 2 * g->batchUnits && live >= 4) continue;          // read-ahead limit
-    if (live >= 8192) continue;
+    // read-ahead limit.  It is counted in RECORDS in sight, never in chunks alone: a batch needs batchUnits records linked
+    // before it can be formed, however many chunks that takes (a cap on live chunks hung the stream when batch_units x bytes per
+    // record outgrew cap x chunk size)
+    if (sight >= 2 * g->batchUnits && live >= 4) continue;
     if (best < 0 || sight < bestSight) { best = s; bestSight = sight; }
   }
   if (best < 0) return nullptr;
@@ -697,6 +699,9 @@ void bgzf_loop(qm_ingest* g, int s, BgzfReader* bz) {
     }
     const char* end = base + carry.size() + outLen;
     if (first && end > base) { S.fastq = base[0] != '>'; first = false; }
+    // the last chunk is decided from the READER's position, not from whether plan() has already run into the end: when the
+    // parse workers are behind, the gate above stops planning, so the final chunk can be popped before plan() was asked again
+    if (fly.empty() && !planEnd && bz->pos == bz->len) planEnd = true;
     const bool last = planEnd && fly.empty();
     const char* cut = last ? end : last_boundary(base, end, S.fastq);
     carry.assign(cut, end);
@@ -718,6 +723,12 @@ void bgzf_loop(qm_ingest* g, int s, BgzfReader* bz) {
   {
     std::lock_guard<std::mutex> lk(g->mu);
     for (Fly* x : fly) put_chunk(g, x->c);
+    if (!carry.empty() && !g->stop && !g->failed) {        // never drop a tail: what is still carried is the file's last record(s)
+      Chunk* c = get_chunk(g);
+      c->src = s; c->data.assign(carry.begin(), carry.end());
+      c->base = c->data.data(); c->end = c->base + c->data.size();
+      S.blocks.push_back(c); carry.clear();
+    }
     if (!S.inflDone) { S.inflDone = true; S.allHanded = S.blocks.empty(); }
     g->cvWork.notify_all();
   }
@@ -864,7 +875,7 @@ int qm_ingest_open(const char* path1, const char* path2, int32_t n_threads, int6
       const size_t capSeq = (size_t)((double)batch_units * (sb * 1.05 + 1.0)) + 4096, capNames = (size_t)((double)batch_units * (nb * 1.05 + 1.0)) + 4096;
       const size_t capOff = (size_t)batch_units + 1 + 4096;
       for (int kind = 0; kind < (names ? 4 : 2); ++kind) {
-        for (InSlot& L : g->slots) L.allocLeft++;
+        { std::lock_guard<std::mutex> lk(g->mu); for (InSlot& L : g->slots) L.allocLeft++; }   // (allocators of earlier kinds are already counting down)
         g->allocators.emplace_back([g, s, kind, capSeq, capNames, capOff]() {
           for (size_t i = 0; i < g->slots.size(); ++i) {
             { std::lock_guard<std::mutex> lk(g->mu); if (g->stop) return; }

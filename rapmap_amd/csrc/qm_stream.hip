@@ -42,11 +42,13 @@ namespace {
 struct PinPool {
   struct Arena { char* base; size_t bytes; std::vector<unsigned char> used; };   // one flag per 1 MB granule
   static constexpr size_t GR = (size_t)1 << 20;
+  static constexpr size_t ARENA = (size_t)64 << 20;   // every arena is one hipHostMalloc of this size
   std::mutex mu; std::condition_variable cv;
   std::vector<Arena> arenas;
   size_t pending = 0;                               // bytes a background reservation still has to pin
   void* take(size_t bytes) {
     const size_t g = (bytes + GR - 1) / GR;
+    if (g > ARENA / GR) return nullptr;             // no arena can ever hold it: do not wait for the reservation, pin it directly
     std::unique_lock<std::mutex> lk(mu);
     while (true) {
       for (Arena& A : arenas) {
@@ -212,7 +214,7 @@ int qm_stream_open_ex(const qm_index* ix, const int32_t* devices, int32_t n_devi
 int qm_stream_reserve(int64_t bytes) {
   if (bytes <= 0) return QM_OK;
   PinPool& P = pin_pool();
-  const size_t ARENA = (size_t)64 << 20;
+  const size_t ARENA = PinPool::ARENA;
   size_t want = ((size_t)bytes + ARENA - 1) / ARENA * ARENA;
   {
     std::lock_guard<std::mutex> lk(P.mu);
@@ -220,7 +222,8 @@ int qm_stream_reserve(int64_t bytes) {
     if (have >= want) return QM_OK;
     want -= have; P.pending += want;
   }
-  std::thread([want, ARENA]() {
+  std::thread([want]() {
+    const size_t ARENA = PinPool::ARENA;
     PinPool& P = pin_pool();
     for (size_t done = 0; done < want; done += ARENA) {
       void* p = nullptr;

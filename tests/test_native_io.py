@@ -345,6 +345,35 @@ def test_ingest_engine_inflates_bgzf_blocks_in_parallel(tmp_path, monkeypatch, t
         read(cut, bg[1])
 
 
+@pytest.mark.parametrize("kind", ["fasta", "fastq_no_final_newline", "fastq"])
+def test_ingest_bgzf_slow_consumer_keeps_the_last_record(tmp_path, monkeypatch, kind):
+    """a consumer slower than the inflate threads: the planner is gated by the full block queue, so the final chunk is popped
+    BEFORE plan() has run into the end of the file -- its tail (for FASTA always the last record) must still come out"""
+    import time
+    import rapmap_amd as ra
+    from util import write_bgzf
+    n = 6000
+    if kind == "fasta":
+        data = b"".join(b">r%d\n%s\n" % (i, b"ACGT" * 25) for i in range(n))
+    else:
+        data = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, b"ACGT" * 25, b"I" * 100) for i in range(n))
+        if kind == "fastq_no_final_newline":
+            data = data[:-1]
+    p1 = str(tmp_path / "a.gz"); write_bgzf(p1, data, block=3000)
+    monkeypatch.setenv("QM_INGEST_BGZF_CHUNK", "20000")
+    for paired in (False, True):
+        rd = ra.FastxReader(p1, p1 if paired else None, threads=3)
+        names = []
+        for b in rd.chunks(100):
+            names += [bytes(b.names1[b.name_off1[i]:b.name_off1[i + 1]]) for i in range(b.n)]
+            if paired:
+                assert bytes(b.seq2[: b.off2[-1]]) == bytes(b.seq1[: b.off1[-1]])
+            if len(names) < 3000:
+                time.sleep(0.01)
+        rd.close()
+        assert names == [b"r%d" % i for i in range(n)]
+
+
 def test_ingest_engine_errors_and_empty_inputs(tmp_path):
     import rapmap_amd as ra
     e = str(tmp_path / "empty.fq"); open(e, "w").close()
