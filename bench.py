@@ -67,8 +67,13 @@ def build_or_reuse_index(genes, seed, k, rank, world, cache_root, perfect_hash=F
         os.remove(fa)
         log("quasiindex%s built in %.1fs" % (" -p" if perfect_hash else "", time.time() - t))
         open(done, "w").write("ok\n")
-    if world > 1:
-        dist.barrier()
+    # the other ranks wait for the DONE file, not in a collective: a rank that finds the index there starts at once (no rank
+    # ever sits in a RCCL barrier for the length of an index build), and the replicas of all ranks upload side by side
+    t0 = time.time()
+    while not os.path.exists(done):
+        if time.time() - t0 > 3600:
+            raise SystemExit("rank %d: no index after an hour (%s)" % (rank, done))
+        time.sleep(0.25)
     return idx
 
 
@@ -214,7 +219,7 @@ def timed_steps(mp, opts, ptr, n, L, steps, warmup, world, device, qd):
         step()
     kernel_ms = []
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -222,12 +227,12 @@ def timed_steps(mp, opts, ptr, n, L, steps, warmup, world, device, qd):
         r, tot = step()
         kernel_ms.append(r.map_kernel_ms)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     tt = torch.tensor([el], dtype=torch.float64, device=device)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     return float(tt.item()), kernel_ms, tot
 
@@ -272,6 +277,72 @@ def roofline(bpp, w, n, kernel_ms, kernel, traffic_key, genes, step_ms=None, ext
     return out
 
 
+def build_compat_bench(out_dir):
+    """tests/compat/compat_bench.cpp (a caller written against the reference's call sequence, include/qmap_rapmap_compat.hpp alone)
+    -> executable; g++ only"""
+    import subprocess
+    import rapmap_amd
+    exe = os.path.join(out_dir, "compat_bench")
+    src = os.path.join(ROOT, "tests", "compat", "compat_bench.cpp")
+    lib_path = rapmap_amd.LIB_PATH
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", exe, lib_path,
+                           "-Wl,-rpath," + os.path.dirname(lib_path), "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-pthread"])
+    return exe
+
+
+def compat_digest(hit_offsets, hits):
+    """the digest compat_bench.cpp prints (hit_digest there), from CSR hits: per hit a 64-bit mix of (unit, index in unit, tid,
+    pos, matePos, orientation/status flags, fragLen), summed with wrap-around"""
+    off = np.asarray(hit_offsets, dtype=np.int64)
+    n = len(off) - 1
+    cnt = np.diff(off)
+    unit = np.repeat(np.arange(n, dtype=np.uint64), cnt)
+    j = (np.arange(int(off[-1]), dtype=np.int64) - np.repeat(off[:-1], cnt)).astype(np.uint64)
+    h = hits[: int(off[-1])]
+    u64 = lambda a: np.asarray(a).astype(np.uint64)
+    paired = h["mate_status"] == 3
+    mate_pos = np.where(paired, h["mate_pos"].astype(np.int64) & 0xFFFFFFFF, 0).astype(np.uint64)
+    frag = np.where(paired, h["frag_len"], 0).astype(np.uint64)
+    flags = (h["fwd"] != 0).astype(np.uint64) | (np.where(paired, h["mate_is_fwd"] != 0, True).astype(np.uint64) << np.uint64(1)) | (u64(h["mate_status"]) << np.uint64(2))
+    K = [np.uint64(x) for x in (0x9E3779B97F4A7C15, 0xD6E8FEB86659FD93, 0xC2B2AE3D27D4EB4F, 0x165667B19E3779F9, 0x27D4EB2F165667C5,
+                                 0x85EBCA77C2B2AE63, 0xFF51AFD7ED558CCD, 0xC4CEB9FE1A85EC53)]
+    with np.errstate(over="ignore"):
+        v = unit * K[0] + j * K[1] + u64(h["tid"]) * K[2] + (h["pos"].astype(np.int64) & 0xFFFFFFFF).astype(np.uint64) * K[3] + mate_pos * K[4] + flags * K[5] + frag * K[6]
+        v ^= v >> np.uint64(31); v *= K[7]; v ^= v >> np.uint64(29)
+        return "%016x" % int(v.sum(dtype=np.uint64))
+
+
+def compat_face_leg(out, args, idx_dir, hs1, hs2, n, L, want_digest_fn, cores):
+    """the reference's own call surface (SACollector::operator() / hitsToMappingsSimple / mergeLeftRightHits per read, read groups
+    of 10 000 pairs as the parser hands them out, src/RapMapSAMapper.cpp:853) at 1 / 8 / 32 host threads"""
+    import subprocess
+    import tempfile
+    nc = int(min(n, args.compat_pairs))
+    with tempfile.TemporaryDirectory(dir=args.cache if os.path.isdir(args.cache) else None) as td:
+        exe = build_compat_bench(td)
+        rp = os.path.join(td, "reads.bin")
+        with open(rp, "wb") as f:
+            f.write(hs1[: nc * L].tobytes()); f.write(hs2[: nc * L].tobytes())
+        runs = {}
+        for T in sorted({1, min(8, cores), min(32, cores)}):
+            npairs = nc if T > 1 else min(nc, max(200_000, nc // 8))          # one thread: an eighth of the sample is plenty
+            r = subprocess.run([exe, idx_dir, rp, str(nc), str(L), str(T), "10000", "--use", str(npairs)] + (["--repeat", "2"] if T > 1 else []),
+                               capture_output=True, text=True, timeout=900)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not line:
+                runs[str(T)] = {"error": (r.stdout + r.stderr)[-300:]}
+                continue
+            j = json.loads(line[-1])
+            runs[str(T)] = {"value": round(j["mpairs_per_s"], 3), "pairs": j["pairs"], "seconds": round(j["seconds"], 4),
+                            "bit_identical_joint_hits": j["digest"] == want_digest_fn(npairs), "totHits": j["totHits"]}
+        best = max((v.get("value", 0) for v in runs.values()), default=0)
+        out["compat_face"] = {"value": best, "unit": "M read-pairs/s", "chunk_pairs": 10000, "by_host_threads": runs,
+                              "what": "tests/compat/compat_bench.cpp: T threads, each takes read groups of 10 000 pairs and runs the reference's per-pair "
+                                      "sequence (src/RapMapSAMapper.cpp:461-551) through include/qmap_rapmap_compat.hpp, one added line "
+                                      "`hitCollector.prefetch(rg)`; strings built before the timed region; digest of every jointHits vector against the "
+                                      "fused path's hits on the same pairs (themselves checked against the oracle in `parity`)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -292,6 +363,7 @@ def main():
     ap.add_argument("--cache", default=os.environ.get("QMAP_BENCH_CACHE", "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"))
     ap.add_argument("--e2e-dir", default=os.environ.get("QMAP_BENCH_E2E_DIR", "/tmp"), help="where the end_to_end leg puts its FASTQ files")
     ap.add_argument("--e2e-threads", type=int, default=32)
+    ap.add_argument("--compat-pairs", type=int, default=4_000_000, help="pairs of the batch the compat_face leg runs through the reference's call surface")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -321,7 +393,11 @@ def main():
     dev_id = local_rank % torch.cuda.device_count() if rehearsal else local_rank
     torch.cuda.set_device(dev_id)
     device = torch.device("cuda", dev_id)
-    if world > 1:
+    # a process group whenever a launcher set one up -- also for ONE rank (torch.distributed.run --nproc-per-node 1, or RANK /
+    # WORLD_SIZE / MASTER_* in the environment): RCCL then creates its communicator and runs the per-step all-reduce on a single
+    # GPU, which is the only way that code executes on a 1-GPU box
+    grouped = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -333,6 +409,7 @@ def main():
 
     k, L = 31, args.read_len
     idx_dir = build_or_reuse_index(args.genes, 42, k, rank, world, args.cache, args.perfect_hash)
+    args._idx_dir = idx_dir
     t = time.time()
     qi = ra.QuasiIndex(idx_dir)
     mp = ra.QuasiMapper(qi, dev_id, ph_compact=args.ph_compact)
@@ -371,6 +448,9 @@ def main():
         }
         avg_kernel_ms = float(np.mean(kernel_ms))
         out["config"]["map_kernel_ms"] = round(avg_kernel_ms, 3)
+        out["collective"] = ({"backend": dist.get_backend(), "world_size": dist.get_world_size(), "op": "all_reduce(SUM) of the six HitCounters, 48 bytes",
+                              "calls": args.steps + args.warmup, "sum_equals_rank_sums": bool(tot["numReads"] == n * world)}
+                             if grouped else None)
 
     # ---- cpu_baseline + roofline counters: rank 0, N=1 only, bounded sample of the same workload
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -458,7 +538,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -471,6 +551,15 @@ def side_legs(out, args, ra, qi, mp, opts, s1, s2, off, n, L, dev_id, cores):
     out["pcie_inclusive"] = {"value": round(n / dt_h / 1e6, 3), "unit": "M read-pairs/s",
                              "what": "qm_map_pairs on pageable host buffers (%d MB in) + qm_fetch_hits into a fresh array (%d MB out), one call"
                                      % ((2 * hs1.nbytes + 2 * hoff.nbytes) >> 20, (rh.hits.nbytes + rh.hit_offsets.nbytes) >> 20)}
+    # (1b) the reference's call surface on the same pairs
+    try:
+        hoffs, hhits = rh.hit_offsets, rh.hits
+        compat_face_leg(out, args, qi.path if hasattr(qi, "path") else args._idx_dir, hs1, hs2, n, L,
+                        lambda m: compat_digest(hoffs[: m + 1], hhits), cores)
+        log("compat_face: %s" % json.dumps(out["compat_face"]["by_host_threads"]))
+    except Exception as ex:
+        out["compat_face"] = {"error": repr(ex)}
+        log("compat_face failed: %r" % (ex,))
     del rh
     # (2) end to end: two FASTQ files -> hits in pinned memory through the pipelined stream (ingest workers + device contexts).
     # The files go to a local filesystem directory by default, not to tmpfs: on this box's kernel the FIRST read of freshly

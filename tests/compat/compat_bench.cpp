@@ -1,0 +1,158 @@
+// tests/compat/compat_bench.cpp -- throughput of the REFERENCE'S OWN CALL SURFACE (include/qmap_rapmap_compat.hpp) driven the
+// way `rapmap quasimap` drives it: T worker threads (src/RapMapSAMapper.cpp:752-799), each taking read groups of CHUNK pairs
+// from a shared hand-out (the parser's chunks of 10 000, :853,:869-871) and running the body of processReadsPairSA
+// (:461-551) on every pair -- collector x2 -> hitsToMappingsSimple x2 -> mergeLeftRightHits -> maxNumHits / counters.  The
+// only added line is `hitCollector.prefetch(rg)`.  Compiled against the header ALONE (bench.py's `compat_face` leg and
+// tests/test_rapmap_compat.py build it with g++).
+//
+//   compat_bench INDEX READS.bin NPAIRS READLEN THREADS CHUNK [--no-prefetch] [--repeat R] [--use N]
+//
+// READS.bin: NPAIRS*READLEN characters of the left mates, then as many of the right mates (what bench.py holds in HBM for the
+// headline, copied to the host).  The read groups (std::string pairs, as the parser hands them out) are built before the
+// timed region; a group is only ever touched by the thread that took it.  Prints one JSON line: pairs/s, the HitCounters and
+// an order-sensitive digest of every jointHits vector (bench.py / the test compute the same digest from the oracle's hits).
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "qmap_rapmap_compat.hpp"
+
+struct Read { std::string seq; };
+using ReadPair = std::pair<Read, Read>;
+using Group = std::vector<ReadPair>;
+
+static inline uint64_t hit_digest(uint64_t unit, uint64_t j, const rapmap::utils::QuasiAlignment& q) {
+  using rapmap::utils::MateStatus;
+  const bool paired = q.mateStatus == MateStatus::PAIRED_END_PAIRED;
+  const uint64_t matePos = paired ? (uint64_t)(uint32_t)q.matePos : 0, fragLen = paired ? (uint64_t)q.fragLen : 0;
+  const uint64_t flags = (q.fwd ? 1u : 0u) | ((paired ? q.mateIsFwd : true) ? 2u : 0u) | ((uint64_t)(uint8_t)q.mateStatus << 2);
+  uint64_t v = unit * 0x9E3779B97F4A7C15ull + j * 0xD6E8FEB86659FD93ull + (uint64_t)q.tid * 0xC2B2AE3D27D4EB4Full +
+               (uint64_t)(uint32_t)q.pos * 0x165667B19E3779F9ull + matePos * 0x27D4EB2F165667C5ull + flags * 0x85EBCA77C2B2AE63ull +
+               fragLen * 0xFF51AFD7ED558CCDull;
+  v ^= v >> 31; v *= 0xC4CEB9FE1A85EC53ull; v ^= v >> 29;
+  return v;
+}
+
+struct Totals { uint64_t digest = 0, pe = 0, se = 0, tot = 0, reads = 0, tooMany = 0, mapped = 0; };
+
+template <typename RapMapIndexT>
+static void worker(RapMapIndexT& rmi, std::vector<Group>& groups, const std::vector<size_t>& firstUnit, std::atomic<size_t>& next, bool prefetch,
+                   uint32_t maxNumHits, Totals& T, rapmap::utils::HitCounters& hctr, Group* warm, std::atomic<int>& ready, std::atomic<int>& go) {
+  using OffsetT = typename RapMapIndexT::IndexType;
+  using rapmap::utils::MateStatus;
+  using rapmap::utils::QuasiAlignment;
+  std::vector<QuasiAlignment> leftHits, rightHits, jointHits;
+  SACollector<RapMapIndexT> hitCollector(&rmi);
+  hitCollector.disableNIP();
+  hitCollector.setStrictCheck(true);
+  rapmap::hit_manager::HitCollectorInfo<rapmap::utils::SAIntervalHit<OffsetT>> leftHCInfo, rightHCInfo;
+  rapmap::utils::MappingConfig mc;
+  mc.consistentHits = false; mc.doChaining = false;
+  SASearcher<RapMapIndexT> saSearcher(&rmi);
+  bool tooManyHits = false;
+  uint32_t readLen = 0;
+  rapmap::utils::HitCounters scratchCtr;
+  auto run_group = [&](Group& rg, size_t unit0, bool count) {
+    rapmap::utils::HitCounters& hc = count ? hctr : scratchCtr;
+    if (prefetch) hitCollector.prefetch(rg, mc, false, maxNumHits);           // <- the one added line
+    size_t u = unit0;
+    for (auto& rpair : rg) {
+      // ---- src/RapMapSAMapper.cpp:461-551
+      tooManyHits = false;
+      readLen = rpair.first.seq.length();
+      ++hc.numReads;
+      leftHCInfo.clear(); rightHCInfo.clear();
+      jointHits.clear(); leftHits.clear(); rightHits.clear();
+      bool lh = hitCollector(rpair.first.seq, saSearcher, leftHCInfo);
+      bool rh = hitCollector(rpair.second.seq, saSearcher, rightHCInfo);
+      (void)lh; (void)rh;
+      rapmap::hit_manager::hitsToMappingsSimple(rmi, mc, MateStatus::PAIRED_END_LEFT, leftHCInfo, leftHits);
+      rapmap::hit_manager::hitsToMappingsSimple(rmi, mc, MateStatus::PAIRED_END_RIGHT, rightHCInfo, rightHits);
+      rapmap::utils::mergeLeftRightHits(leftHits, rightHits, jointHits, readLen, maxNumHits, tooManyHits, hc);
+      if (jointHits.size() > maxNumHits) { jointHits.clear(); }
+      hc.totHits += jointHits.size();
+      if (count) {
+        if (!jointHits.empty()) ++T.mapped;
+        for (size_t j = 0; j < jointHits.size(); ++j) T.digest += hit_digest(u, j, jointHits[j]);
+      }
+      ++u;
+    }
+  };
+  if (warm) run_group(*warm, 0, false);               // context creation, first launches, buffer growth: outside the timed region
+  ++ready;
+  while (!go.load()) std::this_thread::yield();
+  while (true) {
+    const size_t g = next.fetch_add(1);
+    if (g >= groups.size()) break;
+    run_group(groups[g], firstUnit[g], true);
+  }
+}
+
+int main(int argc, char** argv) {
+  if (argc < 7) { std::fprintf(stderr, "usage: compat_bench INDEX READS.bin NPAIRS READLEN THREADS CHUNK [--no-prefetch] [--repeat R] [--use N]\n"); return 2; }
+  try {
+    const char* idx = argv[1]; const char* path = argv[2];
+    const size_t nFile = (size_t)std::atoll(argv[3]), L = (size_t)std::atoll(argv[4]);
+    const int threads = std::atoi(argv[5]); const size_t chunk = (size_t)std::atoll(argv[6]);
+    bool prefetch = true; int repeat = 1; size_t n = nFile;
+    for (int i = 7; i < argc; ++i) {
+      if (!std::strcmp(argv[i], "--no-prefetch")) prefetch = false;
+      else if (!std::strcmp(argv[i], "--repeat") && i + 1 < argc) repeat = std::atoi(argv[++i]);
+      else if (!std::strcmp(argv[i], "--use") && i + 1 < argc) n = std::min(nFile, (size_t)std::atoll(argv[++i]));   // only the first N pairs of the file
+    }
+    std::vector<char> raw(2 * nFile * L);
+    { FILE* f = std::fopen(path, "rb"); if (!f || std::fread(raw.data(), 1, raw.size(), f) != raw.size()) { std::fprintf(stderr, "cannot read %s\n", path); return 2; } std::fclose(f); }
+    SAIndex32BitDense rmi;
+    rmi.load(idx);
+    const size_t ng = (n + chunk - 1) / chunk;
+    std::vector<size_t> firstUnit(ng);
+    for (size_t g = 0; g < ng; ++g) firstUnit[g] = g * chunk;
+    auto build = [&](std::vector<Group>& groups) {
+      groups.assign(ng, Group());
+      std::atomic<size_t> nb{0};
+      std::vector<std::thread> th;
+      for (int t = 0; t < std::max(1, threads); ++t)
+        th.emplace_back([&] {
+          for (size_t g; (g = nb.fetch_add(1)) < ng;) {
+            const size_t a = g * chunk, b = std::min(n, a + chunk);
+            groups[g].resize(b - a);
+            for (size_t u = a; u < b; ++u) { groups[g][u - a].first.seq.assign(raw.data() + u * L, L); groups[g][u - a].second.seq.assign(raw.data() + (nFile + u) * L, L); }
+          }
+        });
+      for (auto& t : th) t.join();
+    };
+    double best = 0, secs = 0; Totals tot; uint64_t ctr[5] = {0, 0, 0, 0, 0};
+    for (int rep = 0; rep < repeat; ++rep) {
+      std::vector<Group> groups; build(groups);
+      std::vector<Group> warm((size_t)threads);
+      for (int t = 0; t < threads; ++t) { const Group& g0 = groups[(size_t)t % ng]; warm[(size_t)t] = g0; }
+      std::vector<Totals> T((size_t)threads);
+      rapmap::utils::HitCounters hctr;
+      std::atomic<size_t> next{0}; std::atomic<int> ready{0}, go{0};
+      std::vector<std::thread> th;
+      for (int t = 0; t < threads; ++t)
+        th.emplace_back([&, t] { worker(rmi, groups, firstUnit, next, prefetch, 200u, T[(size_t)t], hctr, &warm[(size_t)t], ready, go); });
+      while (ready.load() < threads) std::this_thread::yield();
+      const auto t0 = std::chrono::steady_clock::now();
+      go = 1;
+      for (auto& t : th) t.join();
+      const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      Totals S;
+      for (auto& x : T) { S.digest += x.digest; S.mapped += x.mapped; }
+      if (rep == 0 || (double)n / dt > best) { best = (double)n / dt; secs = dt; }
+      tot = S;
+      ctr[0] = hctr.peHits.load(); ctr[1] = hctr.seHits.load(); ctr[2] = hctr.totHits.load(); ctr[3] = hctr.numReads.load(); ctr[4] = hctr.tooManyHits.load();
+    }
+    std::printf("{\"pairs\": %zu, \"read_len\": %zu, \"threads\": %d, \"chunk\": %zu, \"prefetch\": %s, \"seconds\": %.6f, \"mpairs_per_s\": %.4f, "
+                "\"digest\": \"%016llx\", \"mapped\": %llu, \"peHits\": %llu, \"seHits\": %llu, \"totHits\": %llu, \"numReads\": %llu, \"tooManyHits\": %llu}\n",
+                n, L, threads, chunk, prefetch ? "true" : "false", secs, best / 1e6, (unsigned long long)tot.digest, (unsigned long long)tot.mapped,
+                (unsigned long long)ctr[0], (unsigned long long)ctr[1], (unsigned long long)ctr[2], (unsigned long long)ctr[3], (unsigned long long)ctr[4]);
+    return 0;
+  } catch (const qmap::Error& e) { std::printf("qmap error %d: %s\n", e.code(), e.what()); return 3; }
+}

@@ -35,6 +35,8 @@ def main():
     mp = ra.QuasiMapper(qi, local)
     res = mp.map_pairs(a1[o1[b]:o1[e]], o1[b:e + 1] - o1[b], a2[o2[b]:o2[e]], o2[b:e + 1] - o2[b])
     tot = qd.all_reduce_counters(res.counters, device=device)
+    if rank == 0:
+        print("backend %s world %d" % (dist.get_backend(), dist.get_world_size()), flush=True)
     np.save(os.path.join(work, "hits_%d.npy" % rank), res.hits)
     np.save(os.path.join(work, "cnt_%d.npy" % rank), np.diff(res.hit_offsets))
     if rank == 0:

@@ -52,6 +52,36 @@ def test_two_ranks_over_rccl_match_the_oracle(synth_small, oracle_mod, tmp_path)
     assert [int(x) for x in tot] == [ref.counters[k] for k in qd.COUNTER_KEYS]
 
 
+def test_one_rank_over_rccl_matches_the_oracle(synth_small, oracle_mod, tmp_path):
+    """RCCL itself on the 1-GPU box: torch.distributed.run with ONE rank on the "nccl" backend (no gloo, no shared-GPU rehearsal) --
+    the communicator is created on cuda:0 and the HitCounters go through a real all-reduce; shard = the whole input"""
+    from oracle import oracle, q5
+    from rapmap_amd import dist as qd
+    from util import pack
+    a1, o1 = pack(synth_small["reads1"]); a2, o2 = pack(synth_small["reads2"])
+    np.save(tmp_path / "a1.npy", a1); np.save(tmp_path / "o1.npy", o1); np.save(tmp_path / "a2.npy", a2); np.save(tmp_path / "o2.npy", o2)
+    ref = oracle.Oracle(q5.load(synth_small["idx"])).map_pairs(a1, o1, a2, o2, nthreads=4)
+    r = _launch(1, [os.path.join(ROOT, "tests", "dist_gpu_worker.py"), synth_small["idx"], str(tmp_path)], env={"QMAP_TEST_SHARE_GPU": "0"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "backend nccl world 1" in r.stdout, r.stdout[-2000:]
+    assert np.array_equal(np.load(tmp_path / "cnt_0.npy"), np.diff(ref.hit_offsets)) and np.load(tmp_path / "hits_0.npy").tobytes() == ref.hits.tobytes()
+    assert [int(x) for x in np.load(tmp_path / "total.npy")] == [ref.counters[k] for k in qd.COUNTER_KEYS]
+
+
+def test_bench_one_rank_on_the_nccl_backend(tmp_path):
+    """bench.py as the driver launches it for N>1, with one rank: process group on "nccl", the per-step counter all-reduce and the
+    barriers around the timed region run through RCCL; the line says which backend carried them"""
+    e = dict(os.environ)
+    e["QMAP_BENCH_CACHE"] = str(tmp_path); e.pop("QMAP_BENCH_REHEARSAL", None)
+    r = _launch(1, [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--genes", "800", "--pairs", "200000",
+                    "--cpu-seconds", "2", "--no-other-configs", "--no-side-legs"], env=e)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["collective"]["backend"] == "nccl" and out["collective"]["world_size"] == 1
+    assert out["collective"]["calls"] == 3 and out["collective"]["sum_equals_rank_sums"] is True
+    assert out["parity"]["bit_identical_to_oracle"] is True
+
+
 def _rehearse_worker(synth_small, tmp_path, nproc):
     from oracle import oracle, q5
     from rapmap_amd import dist as qd

@@ -150,3 +150,44 @@ def test_refilled_buffers_and_out_of_order_calls_never_get_a_stale_chunk_entry(c
     res0 = orc.map_pairs(*pack(r1), *pack(r2), nthreads=4)
     got = _run(caller, sd["idx"], tmp_path / "pairs.txt", tmp_path / "out2.txt", "--evens-first")
     assert got == _want(res0, len(r1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads,chunk", [(1, 10000), (4, 1000), (16, 700)])
+def test_reference_call_surface_under_worker_threads(synth_medium, oracle_mod, tmp_path, threads, chunk):
+    """tests/compat/compat_bench.cpp -- T worker threads taking read groups from a shared hand-out and running the reference's
+    per-pair sequence through the header (what bench.py's `compat_face` leg times): every jointHits vector and the HitCounters
+    equal the oracle's, whatever the thread count and group size (contexts per thread, chunks in flight side by side)"""
+    import json
+    import bench
+    sd = synth_medium
+    ix, orc = load_oracle(sd["idx"])
+    res = orc.map_pairs(sd["seq1"], sd["off"], sd["seq2"], sd["off"], nthreads=4)
+    n = len(sd["off"]) - 1; L = int(sd["off"][1])
+    assert np.array_equal(np.diff(sd["off"]), np.full(n, L))
+    exe = bench.build_compat_bench(str(tmp_path))
+    rp = str(tmp_path / "reads.bin")
+    with open(rp, "wb") as f:
+        f.write(np.asarray(sd["seq1"][: n * L]).tobytes()); f.write(np.asarray(sd["seq2"][: n * L]).tobytes())
+    r = subprocess.run([exe, sd["idx"], rp, str(n), str(L), str(threads), str(chunk)], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout + r.stderr
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    c = res.counters
+    assert j["digest"] == bench.compat_digest(res.hit_offsets, res.hits)
+    assert (j["peHits"], j["seHits"], j["totHits"], j["numReads"], j["tooManyHits"]) == (c["peHits"], c["seHits"], c["totHits"], c["numReads"], c["tooManyHits"])
+    # a shorter prefix of the same file (--use): units keep their numbers
+    r = subprocess.run([exe, sd["idx"], rp, str(n), str(L), "2", "512", "--use", "5000"], capture_output=True, text=True, timeout=1200)
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["pairs"] == 5000 and j["digest"] == bench.compat_digest(res.hit_offsets[:5001], res.hits)
+
+
+def test_compat_digest_is_order_and_field_sensitive():
+    import bench
+    from rapmap_amd.api import HIT_DTYPE
+    h = np.zeros(3, dtype=HIT_DTYPE); h["tid"] = [1, 2, 3]; h["pos"] = [5, -6, 7]; h["mate_status"] = [3, 1, 2]; h["fwd"] = 1; h["mate_is_fwd"] = 1
+    off = np.array([0, 2, 3]); d0 = bench.compat_digest(off, h)
+    assert d0 != bench.compat_digest(np.array([0, 1, 3]), h) and d0 != bench.compat_digest(off, h[[1, 0, 2]])
+    g = h.copy(); g["mate_pos"][1] = 9                    # an orphan's matePos is not part of the record
+    assert d0 == bench.compat_digest(off, g)
+    g = h.copy(); g["mate_pos"][0] = 9
+    assert d0 != bench.compat_digest(off, g)
