@@ -318,7 +318,8 @@ def compat_face_leg(out, args, idx_dir, hs1, hs2, n, L, want_digest_fn, cores):
     import subprocess
     import tempfile
     nc = int(min(n, args.compat_pairs))
-    with tempfile.TemporaryDirectory(dir=args.cache if os.path.isdir(args.cache) else None) as td:
+    # (the executable cannot live under /dev/shm: mounted noexec on the GPU box)
+    with tempfile.TemporaryDirectory(dir=args.e2e_dir if os.path.isdir(args.e2e_dir) else None) as td:
         exe = build_compat_bench(td)
         rp = os.path.join(td, "reads.bin")
         with open(rp, "wb") as f:

@@ -217,6 +217,29 @@ int qm_merge_lists(qm_ctx* ctx, const qm_opts* opts, int64_t n, const int64_t* l
 int qm_fetch_too_many(qm_ctx* ctx, uint8_t* too_many);
 int qm_map_pairs_stages(qm_ctx* ctx, const qm_opts* opts, int64_t n, const char* seq1, const int64_t* off1, const char* seq2,
                         const int64_t* off2, int64_t* n_hits, qm_counters* counters);
+/* Everything qm_map_pairs_stages kept, brought to the host in ONE go (round 4; what a caller of the reference's per-read call
+ * surface needs for a parser chunk of ~10 000 pairs -- src/RapMapSAMapper.cpp:853 -- where five separate fetches, each a
+ * synchronous copy of a bump-allocated device buffer, cost far more than the mapping itself).  The per-read interval records
+ * and list words are compacted into CSR order ON THE DEVICE (scan + gather), then the eight arrays come down with asynchronous
+ * copies on the context's stream and one synchronisation, laid out in an arena the CALLER owns -- page-locked memory
+ * (qm_pinned_alloc) makes the copies true DMA; pageable memory works, slower.  qm_stage_bytes says how large the arena must be
+ * for the last qm_map_pairs_stages call.  The view's pointers point into the arena.
+ *   iv_off[n_reads + 1] / iv[]       per READ (2u = left mate of pair u, 2u + 1 = right): SA-interval hits, forward strand first
+ *   found[n_reads]                   SACollector::operator()'s return value
+ *   list_off[n_reads + 1] / words[]  per read: hitsToMappingsSimple's list ("List words" above)
+ *   hit_off[n_units + 1] / hits[]    per pair: the merge's jointHits;  too_many[n_units]: bit 0 tooManyHits, bit 1 shared transcript */
+typedef struct qm_stage_view {
+  int64_t n_units, n_reads;
+  const int64_t* iv_off; const qm_sa_interval_hit* iv; const uint8_t* found;
+  const int64_t* list_off; const uint64_t* words;
+  const int64_t* hit_off; const qm_hit* hits; const uint8_t* too_many;
+} qm_stage_view;
+int qm_stage_bytes(qm_ctx* ctx, int64_t* bytes);
+int qm_fetch_stages(qm_ctx* ctx, void* arena, int64_t arena_bytes, qm_stage_view* view);
+/* Page-locked host memory for callers that have no HIP runtime of their own to ask (input buffers of the qm_map_* calls,
+ * arenas of qm_fetch_stages): hipHostMalloc / hipHostFree. */
+void* qm_pinned_alloc(int64_t bytes);
+void qm_pinned_free(void* p);
 
 /* Timing of the dominant kernel of the last map call, measured with HIP events on
  * the context's stream (milliseconds); n_launches kernels were timed. */

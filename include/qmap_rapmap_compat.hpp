@@ -36,10 +36,13 @@
 #include <atomic>
 #include <cstdint>
 #include <cstring>
+#include <initializer_list>
 #include <limits>
 #include <memory>
+#include <new>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -57,6 +60,63 @@ namespace detail {
 inline void check(int rc) { if (rc) throw Error(rc, qm_last_error()); }
 struct Chunk;
 }  // namespace detail
+
+// The reference's position lists are chobo::small_vector<int32_t> (include/RapMapUtils.hpp:469-470; static capacity 16): a hit
+// that is created per read and per transcript must not cost a heap allocation.  Same idea, for trivially copyable elements:
+// the first N live inside the object, more go to the heap.
+template <typename T, size_t N = 16>
+class small_vector {
+  static_assert(std::is_trivially_copyable<T>::value, "qmap::small_vector holds trivially copyable elements");
+ public:
+  typedef T value_type; typedef T* iterator; typedef const T* const_iterator; typedef size_t size_type;
+  typedef T& reference; typedef const T& const_reference;
+  small_vector() : p_(inl()), n_(0), cap_(N) {}
+  small_vector(const small_vector& o) : p_(inl()), n_(0), cap_(N) { assign(o.begin(), o.end()); }
+  small_vector(small_vector&& o) noexcept : p_(inl()), n_(0), cap_(N) { take(o); }
+  small_vector(std::initializer_list<T> il) : p_(inl()), n_(0), cap_(N) { assign(il.begin(), il.end()); }
+  ~small_vector() { if (p_ != inl()) ::operator delete(p_); }
+  small_vector& operator=(const small_vector& o) { if (this != &o) assign(o.begin(), o.end()); return *this; }
+  small_vector& operator=(small_vector&& o) noexcept { if (this != &o) { if (p_ != inl()) ::operator delete(p_); p_ = inl(); n_ = 0; cap_ = N; take(o); } return *this; }
+  iterator begin() { return p_; } iterator end() { return p_ + n_; }
+  const_iterator begin() const { return p_; } const_iterator end() const { return p_ + n_; }
+  const_iterator cbegin() const { return p_; } const_iterator cend() const { return p_ + n_; }
+  size_t size() const { return n_; } bool empty() const { return n_ == 0; } size_t capacity() const { return cap_; }
+  T* data() { return p_; } const T* data() const { return p_; }
+  T& operator[](size_t i) { return p_[i]; } const T& operator[](size_t i) const { return p_[i]; }
+  T& front() { return p_[0]; } const T& front() const { return p_[0]; }
+  T& back() { return p_[n_ - 1]; } const T& back() const { return p_[n_ - 1]; }
+  void clear() { n_ = 0; }
+  void reserve(size_t c) { if (c > cap_) grow(c); }
+  void resize(size_t n, const T& v = T()) { reserve(n); for (size_t i = n_; i < n; ++i) p_[i] = v; n_ = n; }
+  void push_back(const T& v) { if (n_ == cap_) grow(2 * cap_); p_[n_++] = v; }
+  template <typename... A> T& emplace_back(A&&... a) { if (n_ == cap_) grow(2 * cap_); p_[n_] = T(std::forward<A>(a)...); return p_[n_++]; }
+  void pop_back() { --n_; }
+  template <typename It> void assign(It first, It last) { n_ = 0; for (; first != last; ++first) push_back(*first); }
+  iterator erase(const_iterator pos) { T* q = p_ + (pos - p_); std::memmove(q, q + 1, (size_t)(p_ + n_ - (q + 1)) * sizeof(T)); --n_; return q; }
+  iterator insert(const_iterator pos, const T& v) {
+    const size_t at = (size_t)(pos - p_);
+    if (n_ == cap_) grow(2 * cap_);
+    std::memmove(p_ + at + 1, p_ + at, (n_ - at) * sizeof(T)); p_[at] = v; ++n_;
+    return p_ + at;
+  }
+  bool operator==(const small_vector& o) const { return n_ == o.n_ && (n_ == 0 || std::memcmp(p_, o.p_, n_ * sizeof(T)) == 0); }
+  bool operator!=(const small_vector& o) const { return !(*this == o); }
+ private:
+  T* inl() { return reinterpret_cast<T*>(st_); }
+  void grow(size_t c) {
+    T* q = static_cast<T*>(::operator new(c * sizeof(T)));
+    if (n_) std::memcpy(q, p_, n_ * sizeof(T));
+    if (p_ != inl()) ::operator delete(p_);
+    p_ = q; cap_ = c;
+  }
+  void take(small_vector& o) {                      // *this is empty and inline
+    if (o.p_ != o.inl()) { p_ = o.p_; n_ = o.n_; cap_ = o.cap_; o.p_ = o.inl(); o.cap_ = N; }
+    else { if (o.n_) std::memcpy(p_, o.p_, o.n_ * sizeof(T)); n_ = o.n_; }
+    o.n_ = 0;
+  }
+  T* p_; size_t n_, cap_;
+  alignas(T) unsigned char st_[N * sizeof(T)];
+};
 }  // namespace qmap
 
 // ------------------------------------------------------------------------------------------------ rapmap::utils types
@@ -104,7 +164,8 @@ struct HitCounters {
   std::atomic<uint64_t> lastPrint{0};
 };
 
-// include/RapMapUtils.hpp:399-502 (chobo::small_vector<int32_t> is a std::vector here)
+// include/RapMapUtils.hpp:399-502 (chobo::small_vector<int32_t> -> qmap::small_vector<int32_t>: same inline capacity, no heap
+// allocation for the usual one-position hit)
 struct QuasiAlignment {
   QuasiAlignment()
       : tid(std::numeric_limits<uint32_t>::max()), pos(std::numeric_limits<int32_t>::max()), fwd(true),
@@ -122,8 +183,8 @@ struct QuasiAlignment {
   inline int32_t hitPos() { return pos < matePos ? pos : matePos; }
 
   bool hasMultiPos{false};
-  std::vector<int32_t> allPositions;
-  std::vector<int32_t> oppositeStrandPositions;
+  qmap::small_vector<int32_t> allPositions;
+  qmap::small_vector<int32_t> oppositeStrandPositions;
   uint32_t tid;
   int32_t pos;
   int32_t matePos{0};
@@ -266,15 +327,32 @@ inline qm_ctx* thread_ctx(RapMapIndexT& rmi) {
 }
 
 // Everything one fused pass over a chunk produced, per read (paired: read 2u = left mate of pair u, 2u + 1 = right).
+// page-locked host memory, grown on demand (qm_pinned_alloc: the device's DMA engines read / write it directly)
+struct PinnedBuf {
+  void* p{nullptr}; size_t cap{0};
+  PinnedBuf() = default;
+  PinnedBuf(const PinnedBuf&) = delete;
+  PinnedBuf& operator=(const PinnedBuf&) = delete;
+  ~PinnedBuf() { if (p) qm_pinned_free(p); }
+  void* need(size_t bytes, bool keep = false) {
+    if (bytes <= cap) return p;
+    const size_t nc = bytes + bytes / 2 + 4096;
+    void* q = qm_pinned_alloc(static_cast<int64_t>(nc));
+    if (!q) throw Error(QM_E_NOMEM, "out of page-locked host memory");
+    if (keep && p && cap) std::memcpy(q, p, cap);
+    if (p) qm_pinned_free(p);
+    p = q; cap = nc;
+    return p;
+  }
+};
 struct Chunk {
   uint64_t gen{0};
   bool paired{false};
   qm_opts opts{};                       // what the chunk was mapped with: a stage call with other settings does not use it
   int64_t nreads{0};
   std::vector<const char*> key; std::vector<size_t> keyLen;
-  std::vector<int64_t> ivOff; std::vector<qm_sa_interval_hit> iv; std::vector<uint8_t> found;
-  std::vector<int64_t> listOff; std::vector<uint64_t> words;
-  std::vector<int64_t> hitOff; std::vector<qm_hit> hits; std::vector<uint8_t> tooMany;
+  qm_stage_view v{};                    // every stage's output, per read / per pair, in arena (one download: qm_fetch_stages)
+  PinnedBuf arena;
   int64_t cursor{0};
 };
 inline uint64_t next_gen() { static std::atomic<uint64_t> g{1}; return g++; }
@@ -405,47 +483,41 @@ class SACollector {
                      const rapmap::utils::MappingConfig& mc, bool fuzzyMerge, uint32_t maxNumHits) {
     using namespace qmap::detail;
     const int64_t n = static_cast<int64_t>(left.size());
-    std::unique_ptr<Chunk> ch(new Chunk());
-    ch->gen = next_gen(); ch->paired = true; ch->nreads = 2 * n;
+    // the chunk object and its page-locked buffers are reused from group to group; a new generation number makes everything
+    // that was handed out of the previous group stale
+    if (!chunk_) chunk_.reset(new Chunk());
+    Chunk* ch = chunk_.get();
+    ch->gen = next_gen(); ch->paired = true; ch->nreads = 0; ch->cursor = 0;
     stageOpts(ch->opts);
     apply_mc(mc, ch->opts);
     ch->opts.fuzzy = (fuzzyMerge || mc.doChaining) ? 1 : 0;
     ch->opts.max_num_hits = static_cast<int32_t>(maxNumHits);
-    s1_.clear(); s2_.clear(); o1_.assign(1, 0); o2_.assign(1, 0);
-    ch->key.resize(2 * n); ch->keyLen.resize(2 * n);
+    // the reads packed into page-locked buffers: the upload is a DMA straight out of them
+    size_t b1 = 0, b2 = 0;
+    for (int64_t i = 0; i < n; ++i) { b1 += left[i]->size(); b2 += right[i]->size(); }
+    s1_ = static_cast<char*>(in_[0].need(b1 + 64)); s2_ = static_cast<char*>(in_[1].need(b2 + 64));
+    o1_ = static_cast<int64_t*>(in_[2].need(static_cast<size_t>(n + 1) * 8)); o2_ = static_cast<int64_t*>(in_[3].need(static_cast<size_t>(n + 1) * 8));
+    ch->key.resize(static_cast<size_t>(2 * n)); ch->keyLen.resize(static_cast<size_t>(2 * n));
+    size_t p1 = 0, p2 = 0;
+    o1_[0] = 0; o2_[0] = 0;
     for (int64_t i = 0; i < n; ++i) {
-      s1_.insert(s1_.end(), left[i]->begin(), left[i]->end()); o1_.push_back(static_cast<int64_t>(s1_.size()));
-      s2_.insert(s2_.end(), right[i]->begin(), right[i]->end()); o2_.push_back(static_cast<int64_t>(s2_.size()));
-      ch->key[2 * i] = left[i]->data(); ch->keyLen[2 * i] = left[i]->size();
-      ch->key[2 * i + 1] = right[i]->data(); ch->keyLen[2 * i + 1] = right[i]->size();
+      const std::string& l = *left[i]; const std::string& r = *right[i];
+      std::memcpy(s1_ + p1, l.data(), l.size()); p1 += l.size(); o1_[i + 1] = static_cast<int64_t>(p1);
+      std::memcpy(s2_ + p2, r.data(), r.size()); p2 += r.size(); o2_[i + 1] = static_cast<int64_t>(p2);
+      ch->key[2 * i] = l.data(); ch->keyLen[2 * i] = l.size();
+      ch->key[2 * i + 1] = r.data(); ch->keyLen[2 * i + 1] = r.size();
     }
+    nPacked_ = n;
     qm_ctx* ctx = thread_ctx(*rmi_);
     int64_t nHits = 0; qm_counters c{};
-    check(qm_map_pairs_stages(ctx, &ch->opts, n, s1_.data(), o1_.data(), s2_.data(), o2_.data(), &nHits, &c));
-    // stage 1: intervals (four lists per pair -> two per read) and foundHit
-    std::vector<int64_t> uoff(static_cast<size_t>(n) + 1);
-    check(qm_fetch_intervals(ctx, uoff.data(), nullptr, 0));
-    ch->iv.resize(static_cast<size_t>(uoff[n]));
-    if (uoff[n]) check(qm_fetch_intervals(ctx, uoff.data(), ch->iv.data(), uoff[n]));
-    ch->ivOff.assign(static_cast<size_t>(2 * n) + 1, 0);
-    for (int64_t u = 0; u < n; ++u) {
-      int64_t nl = 0;
-      for (int64_t j = uoff[u]; j < uoff[u + 1]; ++j) if (ch->iv[static_cast<size_t>(j)].list < 2) ++nl;
-      ch->ivOff[2 * u + 1] = uoff[u] + nl; ch->ivOff[2 * u + 2] = uoff[u + 1];
-    }
-    ch->found.resize(static_cast<size_t>(2 * n) + 1);
-    check(qm_fetch_found(ctx, ch->found.data()));
-    // stage 2: per-read lists
-    ch->listOff.resize(static_cast<size_t>(2 * n) + 1);
-    check(qm_fetch_read_lists(ctx, ch->listOff.data(), nullptr, 0));
-    ch->words.resize(static_cast<size_t>(ch->listOff[2 * n]) + 1);
-    check(qm_fetch_read_lists(ctx, ch->listOff.data(), ch->words.data(), ch->listOff[2 * n]));
-    // stage 3: merge results
-    ch->hitOff.resize(static_cast<size_t>(n) + 1); ch->hits.resize(static_cast<size_t>(nHits) + 1);
-    check(qm_fetch_hits(ctx, ch->hitOff.data(), ch->hits.data()));
-    ch->tooMany.resize(static_cast<size_t>(n) + 1);
-    check(qm_fetch_too_many(ctx, ch->tooMany.data()));
-    chunk_ = std::move(ch);
+    check(qm_map_pairs_stages(ctx, &ch->opts, n, s1_, o1_, s2_, o2_, &nHits, &c));
+    // every stage's output in one download: intervals and foundHit per read (stage 1), per-read lists (stage 2), merge results
+    // and tooMany flags per pair (stage 3) -- compacted on the device, laid out in this chunk's own arena
+    int64_t need = 0;
+    check(qm_stage_bytes(ctx, &need));
+    ch->arena.need(static_cast<size_t>(need));
+    check(qm_fetch_stages(ctx, ch->arena.p, static_cast<int64_t>(ch->arena.cap), &ch->v));
+    ch->nreads = 2 * n;
   }
 
   // SACollector::operator() (include/SACollector.hpp:108-362)
@@ -462,20 +534,20 @@ class SACollector {
       int64_t idx = -1;
       for (int64_t c = ch->cursor, lim = c + 64 < ch->nreads ? c + 64 : ch->nreads; c < lim; ++c) {
         if (ch->key[c] != read.data() || ch->keyLen[c] != read.size()) continue;
-        const std::vector<char>& sq = (ch->paired && (c & 1)) ? s2_ : s1_;
-        const std::vector<int64_t>& so = (ch->paired && (c & 1)) ? o2_ : o1_;
+        const char* sq = (ch->paired && (c & 1)) ? s2_ : s1_;
+        const int64_t* so = (ch->paired && (c & 1)) ? o2_ : o1_;
         const int64_t u = ch->paired ? (c >> 1) : c;
-        if (static_cast<size_t>(u + 1) >= so.size() || static_cast<size_t>(so[u + 1] - so[u]) != read.size()) continue;
-        if (read.size() && std::memcmp(sq.data() + so[u], read.data(), read.size()) != 0) continue;
+        if (u >= nPacked_ || static_cast<size_t>(so[u + 1] - so[u]) != read.size()) continue;
+        if (read.size() && std::memcmp(sq + so[u], read.data(), read.size()) != 0) continue;
         idx = c; ch->cursor = c + 1; break;
       }
       if (idx >= 0 && same_stage_opts(now, ch->opts) && (doChaining_ ? 1 : 0) == ch->opts.sel_aln) {
-        for (int64_t j = ch->ivOff[idx]; j < ch->ivOff[idx + 1]; ++j) {
-          const qm_sa_interval_hit& h = ch->iv[static_cast<size_t>(j)];
+        for (int64_t j = ch->v.iv_off[idx]; j < ch->v.iv_off[idx + 1]; ++j) {
+          const qm_sa_interval_hit& h = ch->v.iv[j];
           (h.query_rc ? hcInfo.rcSAInts : hcInfo.fwdSAInts).emplace_back(static_cast<OffsetT>(static_cast<uint32_t>(h.begin)), static_cast<OffsetT>(static_cast<uint32_t>(h.end)), h.len, h.query_pos, h.query_rc != 0);
         }
         hcInfo.qm_chunk_ = ch; hcInfo.qm_gen_ = ch->gen; hcInfo.qm_read_ = idx;
-        return ch->found[static_cast<size_t>(idx)] != 0;
+        return ch->v.found[idx] != 0;
       }
     }
     // a batch of one
@@ -516,8 +588,10 @@ class SACollector {
   bool doChaining_{false};
   int32_t maxMMPExtension_{7};
   std::unique_ptr<qmap::detail::Chunk> chunk_;
-  std::vector<char> s1_, s2_;
-  std::vector<int64_t> o1_, o2_;
+  qmap::detail::PinnedBuf in_[4];                 // the chunk's reads as the library takes them: characters and offsets of both mates
+  char* s1_{nullptr}; char* s2_{nullptr};
+  int64_t* o1_{nullptr}; int64_t* o2_{nullptr};
+  int64_t nPacked_{0};
 };
 
 // ------------------------------------------------------------------------------------------------ hitsToMappingsSimple
@@ -537,10 +611,10 @@ void hitsToMappingsSimple(RapMapIndexT& rmi, rapmap::utils::MappingConfig& mc, r
   apply_mc(mc, o);
   if (ch && ch->gen == hcinfo.qm_gen_ && hcinfo.qm_read_ >= 0 && (mc.doChaining ? 1 : 0) == ch->opts.sel_aln &&
       (!mc.doChaining || o.consensus_slack == ch->opts.consensus_slack) &&
-      static_cast<int64_t>(hcinfo.fwdSAInts.size() + hcinfo.rcSAInts.size()) == ch->ivOff[hcinfo.qm_read_ + 1] - ch->ivOff[hcinfo.qm_read_]) {
+      static_cast<int64_t>(hcinfo.fwdSAInts.size() + hcinfo.rcSAInts.size()) == ch->v.iv_off[hcinfo.qm_read_ + 1] - ch->v.iv_off[hcinfo.qm_read_]) {
     // the chunk's pass already turned exactly these intervals into the read's list
     const int64_t r = hcinfo.qm_read_;
-    decode_list(ch->words.data() + ch->listOff[r], ch->listOff[r + 1] - ch->listOff[r], mc.doChaining, readLen, mateStatus, hits);
+    decode_list(ch->v.words + ch->v.list_off[r], ch->v.list_off[r + 1] - ch->v.list_off[r], mc.doChaining, readLen, mateStatus, hits);
     for (size_t i = before; i < hits.size(); ++i) { hits[i].qm_chunk_ = ch; hits[i].qm_gen_ = ch->gen; hits[i].qm_read_ = r; }
     return;
   }
@@ -582,7 +656,7 @@ inline const qmap::detail::Chunk* merge_source(const std::vector<QuasiAlignment>
   if (rd < 0 || (rd & 1)) return nullptr;
   // the other mate's list must be what the chunk has for it (an emptied vector is an edit)
   auto count = [&](int64_t read) {
-    int64_t g = 0; const uint64_t* w = ch->words.data() + ch->listOff[read]; const int64_t n = ch->listOff[read + 1] - ch->listOff[read];
+    int64_t g = 0; const uint64_t* w = ch->v.words + ch->v.list_off[read]; const int64_t n = ch->v.list_off[read + 1] - ch->v.list_off[read];
     if (!chained) { for (int64_t i = 0; i < n; ++i) if (i == 0 || (w[i] >> 33) != (w[i - 1] >> 33)) ++g; return g; }
     for (int64_t i = 0; i < n;) { i += 2 + static_cast<int64_t>(w[i] >> 36) + static_cast<int64_t>(w[i + 1] >> 32); ++g; }
     return g;
@@ -622,7 +696,7 @@ inline MergeResult merge_impl(bool fuzzy, bool leftMatches, bool rightMatches, s
   const Chunk* ch = merge_source(leftHits, rightHits, chained, fuzzy, maxNumHits, unit);
   std::vector<qm_hit> own; const qm_hit* hb = nullptr; int64_t nh = 0; uint8_t flags = 0;
   if (ch) {
-    hb = ch->hits.data() + ch->hitOff[unit]; nh = ch->hitOff[unit + 1] - ch->hitOff[unit]; flags = ch->tooMany[static_cast<size_t>(unit)];
+    hb = ch->v.hits + ch->v.hit_off[unit]; nh = ch->v.hit_off[unit + 1] - ch->v.hit_off[unit]; flags = ch->v.too_many[unit];
   } else {
     if (!ctx_or_null) throw qmap::Error(QM_E_STATE, "merge of hit vectors that did not come from this thread's device context");
     qm_opts o; qm_opts_default(&o);

@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "qm_map_pairs", "qm_map_reads", "qm_map_device", "qm_fetch_hits", "qm_result_device", "qm_ctx_set_debug",
     "qm_fetch_intervals", "qm_last_kernel_ms", "qm_ctx_stat", "qm_build_index", "qm_build_index_ex",
     "qm_collect_reads", "qm_fetch_found", "qm_hits_to_mappings", "qm_fetch_read_lists", "qm_merge_lists", "qm_fetch_too_many",
-    "qm_map_pairs_stages", "qm_ctx_create_ex", "qm_fetch_hits_pinned", "qm_xxh64",
+    "qm_map_pairs_stages", "qm_stage_bytes", "qm_fetch_stages", "qm_pinned_alloc", "qm_pinned_free", "qm_ctx_create_ex", "qm_fetch_hits_pinned", "qm_xxh64",
     "qm_stream_open", "qm_stream_open_ex", "qm_stream_reserve", "qm_stream_next", "qm_stream_close", "qm_stream_last_error", "qm_stream_stats", "qm_stream_stats_ex",
     "qm_reader_open", "qm_reader_next", "qm_reader_close", "qm_io_last_error", "qm_sam_header", "qm_sam_records",
     "qm_sam_write", "qm_sam_writer_open", "qm_sam_writer_open_ex", "qm_sam_writer_header", "qm_sam_writer_put", "qm_sam_writer_close", "qm_buf_free",
@@ -76,6 +76,11 @@ class QmStreamBatch(C.Structure):
                 ("seq2", C.c_void_p), ("off2", C.c_void_p), ("names2", C.c_void_p), ("name_off2", C.c_void_p),
                 ("hit_offsets", C.c_void_p), ("hits", C.c_void_p), ("n_hits", C.c_int64),
                 ("counters", QmCounters), ("gpu_ms", C.c_double), ("device", C.c_int32), ("pad", C.c_int32)]
+
+
+class QmStageView(C.Structure):
+    _fields_ = [("n_units", C.c_int64), ("n_reads", C.c_int64), ("iv_off", C.c_void_p), ("iv", C.c_void_p), ("found", C.c_void_p),
+                ("list_off", C.c_void_p), ("words", C.c_void_p), ("hit_off", C.c_void_p), ("hits", C.c_void_p), ("too_many", C.c_void_p)]
 
 
 class QmIndexInfo(C.Structure):
@@ -130,6 +135,10 @@ def lib():
     L.qm_merge_lists.argtypes = [C.c_void_p, C.POINTER(QmOpts), C.c_int64] + [C.c_void_p] * 8 + [C.POINTER(C.c_int64), C.POINTER(QmCounters)]
     L.qm_fetch_too_many.argtypes = [C.c_void_p, C.c_void_p]
     L.qm_map_pairs_stages.argtypes = L.qm_map_pairs.argtypes
+    L.qm_stage_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    L.qm_fetch_stages.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(QmStageView)]
+    L.qm_pinned_alloc.argtypes = [C.c_int64]; L.qm_pinned_alloc.restype = C.c_void_p
+    L.qm_pinned_free.argtypes = [C.c_void_p]; L.qm_pinned_free.restype = None
     L.qm_stream_open.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(QmOpts), C.c_char_p, C.c_char_p, C.c_int64, C.c_int32,
                                  C.POINTER(C.c_void_p)]
     L.qm_stream_open_ex.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_uint32, C.POINTER(QmOpts), C.c_char_p, C.c_char_p,
@@ -388,6 +397,35 @@ class QuasiMapper:
                                          seq2.ctypes.data or 1, off2.ctypes.data, C.byref(nh), C.byref(ctr)))
         return self._finish(n, nh, ctr)
 
+    def fetch_stages(self, pinned=True):
+        """qm_fetch_stages after map_pairs_stages: every stage's output in one download, compacted on the device.  Returns a dict of
+        numpy views into an arena this mapper keeps (valid until the next fetch_stages): iv_off / iv / found per READ (2u left,
+        2u + 1 right), list_off / words per read, hit_off / hits / too_many per pair."""
+        need = C.c_int64(0)
+        _check(lib().qm_stage_bytes(self._h, C.byref(need)))
+        if getattr(self, "_arena_cap", 0) < need.value:
+            if getattr(self, "_arena", None) and self._arena_pinned:
+                lib().qm_pinned_free(self._arena)
+            self._arena_cap = need.value + need.value // 2 + 4096
+            self._arena_pinned = bool(pinned)
+            if pinned:
+                self._arena = lib().qm_pinned_alloc(self._arena_cap)
+                if not self._arena:
+                    raise QmError("out of page-locked host memory")
+            else:
+                self._arena_np = np.zeros(self._arena_cap, dtype=np.uint8)
+                self._arena = self._arena_np.ctypes.data
+        v = QmStageView()
+        _check(lib().qm_fetch_stages(self._h, C.c_void_p(self._arena), self._arena_cap, C.byref(v)))
+        nr, n = v.n_reads, v.n_units
+        out = {"n_units": n, "n_reads": nr}
+        out["iv_off"] = _view(v.iv_off, nr + 1, np.int64); out["iv"] = _view(v.iv, int(out["iv_off"][-1]), INTERVAL_DTYPE)
+        out["found"] = _view(v.found, nr, np.uint8)
+        out["list_off"] = _view(v.list_off, nr + 1, np.int64); out["words"] = _view(v.words, int(out["list_off"][-1]), np.uint64)
+        out["hit_off"] = _view(v.hit_off, n + 1, np.int64); out["hits"] = _view(v.hits, int(out["hit_off"][-1]), HIT_DTYPE)
+        out["too_many"] = _view(v.too_many, n, np.uint8)
+        return out
+
     def intervals(self, n):
         """fwdSAInts / rcSAInts kept by the last call (fused calls: needs debug=True)."""
         offs = np.zeros(n + 1, dtype=np.int64)
@@ -399,6 +437,9 @@ class QuasiMapper:
 
     def close(self):
         if self._h:
+            if getattr(self, "_arena", None) and getattr(self, "_arena_pinned", False):
+                lib().qm_pinned_free(self._arena)
+            self._arena = None; self._arena_cap = 0
             lib().qm_ctx_destroy(self._h)
             self._h = C.c_void_p()
 

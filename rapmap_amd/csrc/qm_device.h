@@ -45,4 +45,10 @@ hipError_t qmk_pair_write(const void* pair_batch, hipStream_t st);
 size_t qmk_scan_temp_bytes(long long n);
 hipError_t qmk_scan_counts(void* temp, size_t temp_bytes, const unsigned int* cnt, long long* offs, long long n,
                            hipStream_t st);
+// the same over (cnt & 0x7fffffff): list lengths carry the foundHit flag in bit 31
+hipError_t qmk_scan_counts_masked(void* temp, size_t temp_bytes, const unsigned int* cnt, long long* offs, long long n, hipStream_t st);
+// per read: its interval records and list words from their bump-allocated homes to CSR order (qm_fetch_stages)
+hipError_t qmk_stage_gather(long long nreads, const unsigned int* ivcnt, const long long* ivoff, const void* iv, const long long* ivcsr, void* iv_out,
+                            const unsigned int* lcnt, const long long* loff, const unsigned long long* lists, const long long* lcsr,
+                            unsigned long long* words_out, hipStream_t st);
 }

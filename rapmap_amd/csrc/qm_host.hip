@@ -140,6 +140,11 @@ struct qm_ctx {
   long long* d_toff = nullptr; int64_t capToff = 0;
   qm_hit* d_tmp = nullptr; int64_t capTmp = 0; u64* d_tkeys = nullptr; int64_t capTkeys = 0; int* d_tsc = nullptr; int64_t capTsc = 0;
   int* d_tref = nullptr; int64_t capTref = 0; int* d_tcix = nullptr; int64_t capTcix = 0; unsigned char* d_tasks = nullptr; int64_t capTasks = 0;
+  // qm_fetch_stages: CSR offsets of the per-read interval records / list words (scans queued behind stage A), their totals
+  // (pinned: they arrive with stage B's synchronisation), the compacted copies
+  long long* d_ivcsr = nullptr; int64_t capIvcsr = 0; long long* d_lcsr = nullptr; int64_t capLcsr = 0;
+  qm_sa_interval_hit* d_ivC = nullptr; int64_t capIvC = 0; u64* d_wordsC = nullptr; int64_t capWordsC = 0;
+  long long* h_tot = nullptr; int64_t stReads = -1, stUnits = -1;
   // last result
   int64_t lastUnits = -1, lastHits = 0; bool lastPaired = false;
   double lastMapMs = 0, lastTotalMs = 0;
@@ -439,6 +444,11 @@ int qm_ctx_destroy(qm_ctx* c) {
   if (c->planStream) hipStreamDestroy(c->planStream);
   for (hipEvent_t e : c->evPlan) if (e) hipEventDestroy(e);
   if (c->d_ntk) hipFree(c->d_ntk);
+  if (c->d_ivcsr) hipFree(c->d_ivcsr);
+  if (c->d_lcsr) hipFree(c->d_lcsr);
+  if (c->d_ivC) hipFree(c->d_ivC);
+  if (c->d_wordsC) hipFree(c->d_wordsC);
+  if (c->h_tot) hipHostFree(c->h_tot);
   if (c->evCopy) hipEventDestroy(c->evCopy);
   if (c->evStage[0]) hipEventDestroy(c->evStage[0]);
   if (c->evStage[1]) hipEventDestroy(c->evStage[1]);
@@ -654,6 +664,7 @@ struct RunReq {
   bool keepIntervals = false;     // SA-interval hits kept for qm_fetch_intervals
   bool keepFound = false;         // foundHit per read kept for qm_fetch_found
   bool mergeOnly = false;         // stage B without the caller-level bookkeeping, tooMany flags kept
+  bool stageView = false;         // qm_map_pairs_stages: queue the CSR scans of the per-read outputs behind stage A (qm_fetch_stages)
   bool longReads = false;         // the batch holds reads beyond QM_MAX_READ_LEN (set by map_device_impl from max_read_len)
   int shortLen = 0;               // the longest read that is not beyond QM_MAX_READ_LEN (0: unknown)
   // QM_RUN_FROM_INTERVALS: device arrays
@@ -1000,12 +1011,36 @@ static int map_device_impl(qm_ctx* c, const qm_opts* o, int64_t n, const void* d
   r2.longReads = max_read_len > QM_MAX_READ_LEN;
   r2.shortLen = pick;
   if ((rc = run_stage_a(c, o, r2, n, d_seq1, d_off1, d_seq2, d_off2, ns, feeder, hscal))) return rc;
+  c->stReads = -1; c->stUnits = -1;
+  if (r2.stageView) {
+    // where every read's interval records and list words will sit in CSR order: two scans behind stage A; their totals come
+    // down with the synchronisation stage B needs anyway
+    const int64_t nreads = paired ? 2 * n : n;
+    if ((rc = ensure(c->d_ivcsr, c->capIvcsr, nreads + 1))) return rc;
+    if ((rc = ensure(c->d_lcsr, c->capLcsr, nreads + 1))) return rc;
+    if (!c->h_tot) HIPCHK(hipHostMalloc((void**)&c->h_tot, 2 * sizeof(long long), hipHostMallocDefault));
+    const size_t stb = qmk_scan_temp_bytes(nreads + 1);
+    if (stb > c->scanTmpBytes || !c->d_scanTmp) {
+      if (c->d_scanTmp) hipFree(c->d_scanTmp);
+      c->d_scanTmp = nullptr; c->scanTmpBytes = 0;
+      HIPCHK(hipMalloc(&c->d_scanTmp, stb ? stb : 16));
+      c->scanTmpBytes = stb;
+    }
+    HIPCHK(hipMemsetAsync(c->d_ivcnt + nreads, 0, sizeof(uint32_t), c->stream));
+    HIPCHK(hipMemsetAsync(c->d_lcnt + nreads, 0, sizeof(uint32_t), c->stream));
+    HIPCHK(qmk_scan_counts(c->d_scanTmp, c->scanTmpBytes, c->d_ivcnt, c->d_ivcsr, nreads + 1, c->stream));
+    HIPCHK(qmk_scan_counts_masked(c->d_scanTmp, c->scanTmpBytes, c->d_lcnt, c->d_lcsr, nreads + 1, c->stream));
+    HIPCHK(hipMemcpyAsync(&c->h_tot[0], c->d_ivcsr + nreads, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&c->h_tot[1], c->d_lcsr + nreads, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    c->stReads = nreads;
+  }
   long long total = 0;
   if ((rc = run_stage_b(c, o, r2, n, paired, d_seq1, d_off1, d_seq2, d_off2, hscal, total))) return rc;
   HIPCHK(hipEventRecord(c->evB, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   float ms = 0; hipEventElapsedTime(&ms, c->evA, c->evB); c->lastTotalMs = ms;
   c->lastUnits = n; c->lastHits = total; c->lastPaired = paired;
+  if (r2.stageView) c->stUnits = n;
   if (n_hits) *n_hits = total;
   if (counters) {
     counters->pe_hits = hscal[1]; counters->se_hits = hscal[2]; counters->tot_hits = hscal[3];
@@ -1343,9 +1378,70 @@ int qm_fetch_too_many(qm_ctx* c, uint8_t* too_many) {
 int qm_map_pairs_stages(qm_ctx* c, const qm_opts* o, int64_t n, const char* seq1, const int64_t* off1, const char* seq2,
                         const int64_t* off2, int64_t* n_hits, qm_counters* counters) {
   if (!seq2 || !off2) return fail(QM_E_ARG, "qm_map_pairs_stages needs both mates");
-  RunReq rq; rq.keepIntervals = true; rq.keepFound = true; rq.mergeOnly = true;
+  RunReq rq; rq.keepIntervals = true; rq.keepFound = true; rq.mergeOnly = true; rq.stageView = true;
   return map_host(c, o, n, seq1, off1, seq2, off2, n_hits, counters, rq);
 }
+
+// layout of a qm_fetch_stages arena: eight arrays, each aligned to 64 bytes
+namespace {
+struct StageLayout { size_t ivOff, iv, found, listOff, words, hitOff, hits, tooMany, total; };
+StageLayout stage_layout(int64_t nreads, int64_t n, int64_t nIv, int64_t nWords, int64_t nHits) {
+  StageLayout L; size_t p = 0;
+  auto take = [&](size_t bytes) { const size_t at = p; p += (bytes + 63) & ~(size_t)63; return at; };
+  L.ivOff = take((size_t)(nreads + 1) * 8); L.iv = take((size_t)(nIv + 1) * sizeof(qm_sa_interval_hit)); L.found = take((size_t)nreads + 1);
+  L.listOff = take((size_t)(nreads + 1) * 8); L.words = take((size_t)(nWords + 1) * 8);
+  L.hitOff = take((size_t)(n + 1) * 8); L.hits = take((size_t)(nHits + 1) * sizeof(qm_hit)); L.tooMany = take((size_t)n + 1);
+  L.total = p;
+  return L;
+}
+}  // namespace
+
+int qm_stage_bytes(qm_ctx* c, int64_t* bytes) {
+  if (!c || !bytes) return fail(QM_E_ARG, "null argument");
+  if (c->stUnits < 0 || c->stReads < 0 || c->lastUnits != c->stUnits) return fail(QM_E_STATE, "qm_stage_bytes: the last call on this context was not qm_map_pairs_stages");
+  *bytes = (int64_t)stage_layout(c->stReads, c->stUnits, c->h_tot[0], c->h_tot[1], c->lastHits).total;
+  return QM_OK;
+}
+
+int qm_fetch_stages(qm_ctx* c, void* arena, int64_t arena_bytes, qm_stage_view* v) {
+  if (!c || !arena || !v) return fail(QM_E_ARG, "null argument");
+  if (c->stUnits < 0 || c->stReads < 0 || c->lastUnits != c->stUnits) return fail(QM_E_STATE, "qm_fetch_stages: the last call on this context was not qm_map_pairs_stages");
+  HIPCHK(hipSetDevice(c->device));
+  const int64_t nreads = c->stReads, n = c->stUnits, nIv = c->h_tot[0], nWords = c->h_tot[1], nHits = c->lastHits;
+  const StageLayout L = stage_layout(nreads, n, nIv, nWords, nHits);
+  if ((int64_t)L.total > arena_bytes) return fail(QM_E_ARG, "qm_fetch_stages: arena of %lld bytes, %lld needed (qm_stage_bytes)", (long long)arena_bytes, (long long)L.total);
+  int rc;
+  if ((rc = ensure(c->d_ivC, c->capIvC, nIv + 1, nIv / 4))) return rc;
+  if ((rc = ensure(c->d_wordsC, c->capWordsC, nWords + 1, nWords / 4))) return rc;
+  HIPCHK(qmk_stage_gather(nreads, c->d_ivcnt, c->d_ivoff, c->d_iv, c->d_ivcsr, c->d_ivC, c->d_lcnt, c->d_loff, (const unsigned long long*)c->d_lists, c->d_lcsr,
+                          (unsigned long long*)c->d_wordsC, c->stream));
+  unsigned char* A = (unsigned char*)arena;
+  auto down = [&](size_t at, const void* src, size_t bytes) -> hipError_t {
+    return bytes ? hipMemcpyAsync(A + at, src, bytes, hipMemcpyDeviceToHost, c->stream) : hipSuccess;
+  };
+  HIPCHK(down(L.ivOff, c->d_ivcsr, (size_t)(nreads + 1) * 8));
+  HIPCHK(down(L.iv, c->d_ivC, (size_t)nIv * sizeof(qm_sa_interval_hit)));
+  HIPCHK(down(L.found, c->d_found, (size_t)nreads));
+  HIPCHK(down(L.listOff, c->d_lcsr, (size_t)(nreads + 1) * 8));
+  HIPCHK(down(L.words, c->d_wordsC, (size_t)nWords * 8));
+  HIPCHK(down(L.hitOff, c->d_offs, (size_t)(n + 1) * 8));
+  HIPCHK(down(L.hits, c->d_hits, (size_t)nHits * sizeof(qm_hit)));
+  HIPCHK(down(L.tooMany, c->d_tooMany, (size_t)n));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  v->n_units = n; v->n_reads = nreads;
+  v->iv_off = (const int64_t*)(A + L.ivOff); v->iv = (const qm_sa_interval_hit*)(A + L.iv); v->found = A + L.found;
+  v->list_off = (const int64_t*)(A + L.listOff); v->words = (const uint64_t*)(A + L.words);
+  v->hit_off = (const int64_t*)(A + L.hitOff); v->hits = (const qm_hit*)(A + L.hits); v->too_many = A + L.tooMany;
+  if (nreads == 0) { ((int64_t*)(A + L.ivOff))[0] = 0; ((int64_t*)(A + L.listOff))[0] = 0; }
+  if (n == 0) ((int64_t*)(A + L.hitOff))[0] = 0;
+  return QM_OK;
+}
+
+void* qm_pinned_alloc(int64_t bytes) {
+  void* p = nullptr;
+  return hipHostMalloc(&p, bytes > 0 ? (size_t)bytes : 64, hipHostMallocPortable) == hipSuccess ? p : nullptr;
+}
+void qm_pinned_free(void* p) { if (p) hipHostFree(p); }
 
 int qm_ctx_stat(const qm_ctx* c, int which, int64_t* value) {
   if (!c || !value) return fail(QM_E_ARG, "null argument");

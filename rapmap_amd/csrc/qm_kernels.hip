@@ -300,6 +300,27 @@ __global__ void build_slots_from_ph_kernel(DevIndex ix, long long n, Bucket* buc
 }
 
 struct U32ToI64 { __device__ long long operator()(u32 x) const { return (long long)x; } };
+struct U32MaskToI64 { __device__ long long operator()(u32 x) const { return (long long)(x & 0x7fffffffu); } };
+
+// qm_fetch_stages: read r's SA-interval records and list words leave their bump-allocated chunks (one open chunk per wave: the
+// used part of those buffers is hundreds of MB for a batch of 20 000 reads) for CSR order -- four threads per read
+__global__ __launch_bounds__(256) void qm_stage_gather_kernel(long long nreads, const u32* ivcnt, const long long* ivoff, const qm_sa_interval_hit* iv,
+                                                              const long long* ivcsr, qm_sa_interval_hit* ivOut, const u32* lcnt, const long long* loff,
+                                                              const u64* lists, const long long* lcsr, u64* wordsOut) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long r = t >> 2; const int sub = (int)(t & 3);
+  if (r >= nreads) return;
+  const int ni = (int)ivcnt[r];
+  if (ni > 0) {
+    const u32* src = (const u32*)(iv + ivoff[r]); u32* dst = (u32*)(ivOut + ivcsr[r]);
+    for (int i = sub; i < 5 * ni; i += 4) dst[i] = src[i];          // 20-byte records
+  }
+  const int nl = (int)(lcnt[r] & 0x7fffffffu);
+  if (nl > 0) {
+    const u64* src = lists + loff[r]; u64* dst = wordsOut + lcsr[r];
+    for (int i = sub; i < nl; i += 4) dst[i] = src[i];
+  }
+}
 
 }  // namespace qm
 
@@ -476,6 +497,20 @@ size_t qmk_scan_temp_bytes(long long n) {
 hipError_t qmk_scan_counts(void* temp, size_t temp_bytes, const u32* cnt, long long* offs, long long n, hipStream_t st) {
   auto it = rocprim::make_transform_iterator(cnt, U32ToI64());
   return rocprim::exclusive_scan(temp, temp_bytes, it, offs, 0LL, (size_t)n, rocprim::plus<long long>(), st);
+}
+
+hipError_t qmk_scan_counts_masked(void* temp, size_t temp_bytes, const u32* cnt, long long* offs, long long n, hipStream_t st) {
+  auto it = rocprim::make_transform_iterator(cnt, U32MaskToI64());
+  return rocprim::exclusive_scan(temp, temp_bytes, it, offs, 0LL, (size_t)n, rocprim::plus<long long>(), st);
+}
+
+hipError_t qmk_stage_gather(long long nreads, const u32* ivcnt, const long long* ivoff, const void* iv, const long long* ivcsr, void* iv_out,
+                            const u32* lcnt, const long long* loff, const unsigned long long* lists, const long long* lcsr,
+                            unsigned long long* words_out, hipStream_t st) {
+  if (nreads <= 0) return hipSuccess;
+  hipLaunchKernelGGL(qm_stage_gather_kernel, dim3((unsigned)((nreads * 4 + 255) / 256)), dim3(256), 0, st, nreads, ivcnt, ivoff,
+                     (const qm_sa_interval_hit*)iv, ivcsr, (qm_sa_interval_hit*)iv_out, lcnt, loff, (const u64*)lists, lcsr, (u64*)words_out);
+  return hipGetLastError();
 }
 
 }  // extern "C"

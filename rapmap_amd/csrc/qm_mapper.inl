@@ -750,19 +750,22 @@ QM_DEV bool all_acgt(const Strand<NS>& S, int p, int k) {
 //   d = (t - p) & 63:   d < 32: the k-mer of position p + d (that position lives in lane t);
 //                       d >= 32: the reverse complement of the k-mer of position p + d - 32 (which lives in lane t ^ 32)
 // so a result is where it is kept, or one lane swap away from it.
+// `stride` (a power of two): only every stride-th position of the window is looked up -- the -s walk, whose capped MMPs advance by
+// exactly maxMMPExtension + 1 positions while the read keeps matching, never asks about the positions in between (each of
+// which would cost two random sectors); a position that was not looked up stays unknown, and the walk probes it when it gets there.
 template <int NS, int F>
-QM_DEV void probe_window(const DevIndex& ix, Strand<NS>& S, int p, int width) {
+QM_DEV void probe_window(const DevIndex& ix, Strand<NS>& S, int p, int width, int stride = 1) {
   typedef typename Strand<NS>::FT FT;
   const int k = ix.k;
   if (p + width > S.P) width = S.P - p;
   if (width <= 0) return;
-  QM_CNT(3, 1); QM_CNT(4, width); QM_T(4);
+  QM_CNT(3, 1); QM_CNT(4, (width + stride - 1) / stride); QM_T(4);
   LV<FT> flx;
   swap32(S.fl, flx);
   LV<bool> found, fresh, want; LV<u64> kq; LV<int> posv; LV<Iv> val;
   QM_LANES(l) {
     const int d = (l - p) & 63, j = d & 31;
-    const bool in = j < width;
+    const bool in = j < width && (j & (stride - 1)) == 0;
     const int q = in ? p + j : p;
     const FT w = d >= 32 ? flx[l] : S.fl[l];
     // positions probed before keep their flags and their interval (the slot no longer holds the word)
@@ -1221,7 +1224,13 @@ QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, c
       prevMMPEnd = p + mlen;
       if (p + mlen < L) {
         if (all_acgt(V, kp, k)) {
-          if (!V.test(FL_K, kp)) probe_window<NS, F>(ix, V, kp, (more && !(F & QM_F_NIP)) ? 32 : 1);
+          if (!V.test(FL_K, kp)) {
+            // -s: an MMP that was cut at k + maxMMPExtension is followed by the next one maxMMPExtension + 1 positions on, and
+            // so on while the read matches: look up those positions only (one in eight by default: 8 sectors instead of 64)
+            int stride = 1;
+            if ((F & QM_F_SEL) && mlen == k + B.max_mmp_ext) { const int st = B.max_mmp_ext + 1; if ((st & (st - 1)) == 0 && st <= 32) stride = st; }
+            probe_window<NS, F>(ix, V, kp, (more && !(F & QM_F_NIP)) ? 32 : 1, stride);
+          }
           const typename Strand<NS>::FT wk = V.word_at(kp);
           strandHits += Strand<NS>::flag(wk, FL_F, kp) ? 1u : 0u; otherHits += Strand<NS>::flag(wk, FL_C, kp) ? 1u : 0u;
           if (((F & QM_F_NIP) != 0)) V.or_at(kp, Strand<NS>::bit(FL_V, 0));

@@ -563,6 +563,18 @@ def test_stage_entry_points_compose_to_the_fused_path(synth_small, oracle_mod, m
     assert int(fo[-1]) == int(ooff[-1])
     flo, fw = mp.read_lists(2 * n)
     assert np.array_equal(np.diff(flo)[0::2], np.diff(ll)) and np.array_equal(np.diff(flo)[1::2], np.diff(lr))
+    ftm = np.zeros(n + 1, dtype=np.uint8)
+    assert ra.api.lib().qm_fetch_too_many(mp._h, ftm.ctypes.data) == 0
+    # ... and qm_fetch_stages brings all of them down at once, compacted on the device: the same arrays, per read
+    for pinned in (True, False):
+        v = mp.fetch_stages(pinned=pinned)
+        assert v["n_units"] == n and v["n_reads"] == 2 * n
+        assert np.array_equal(v["list_off"], flo) and np.array_equal(v["words"], fw)
+        assert np.array_equal(v["iv_off"][0::2], fo) and v["iv"].tobytes() == fi_.tobytes()
+        assert np.array_equal(v["iv_off"][1::2] - v["iv_off"][0:-1:2], np.diff(iol)) and np.array_equal(v["found"][0::2], fl) and np.array_equal(v["found"][1::2], fr)
+        assert np.array_equal(v["hit_off"], fused.hit_offsets) and v["hits"].tobytes() == fused.hits.tobytes()
+        assert np.array_equal(v["too_many"], ftm[:n])
+        mp._arena_cap = 0                                  # (the next round allocates the other kind of arena)
     if mode in ("plain", "noSensitive"):
         # without the caller-level bookkeeping the merge result differs from the driver's only where that bookkeeping acts
         full = mp.map_pairs(q1, o1, q2, o2, opts=opts)
