@@ -89,6 +89,8 @@ def _lib(big=False):
                                      C.c_void_p]
     lib.qo_hash_find.restype = C.c_int
     lib.qo_hash_find.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.qo_kpos_ties.argtypes = [C.POINTER(C.c_longlong), C.c_int]
+    lib.qo_kpos_ties.restype = None
     lib.qo_rank.restype = C.c_uint64
     lib.qo_rank.argtypes = [C.c_void_p, C.c_uint64]
     return lib
@@ -179,3 +181,13 @@ class Oracle:
 
     def map_single(self, seq, off, opts=None, nthreads=1):
         return self._map(seq, off, None, None, opts, nthreads, False)
+
+
+def kpos_ties(reset=True, big=False):
+    """the --noSensitive vote (SACollector.hpp:289-337) since the last reset: dict(ties = positions that entered kmerScores more
+    than once, conflicts = ties whose entries carry different scores, conflicts_without_U = ... in a window without U / u,
+    conflict_reads, decision_differs = reads where libstdc++'s unstable std::sort -- what the reference calls -- would have
+    decided the strand differently from the stable sort of the restatement)"""
+    a = (C.c_longlong * 5)()
+    _lib(big).qo_kpos_ties(a, 1 if reset else 0)
+    return dict(zip(("ties", "conflicts", "conflicts_without_U", "conflict_reads", "decision_differs"), [int(x) for x in a]))

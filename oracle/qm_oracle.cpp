@@ -341,6 +341,7 @@ static IndexT lce(const OIndex& ix, IndexT p1, IndexT p2, IndexT startAt,
 // ----------------------------------------------------------------------------
 // SACollector -- include/SACollector.hpp
 // ----------------------------------------------------------------------------
+static std::atomic<long long> g_kposTies{0}, g_kposConflicts{0}, g_kposConflictsNoU{0}, g_kposConflictReads{0}, g_kposDecisionDiffers{0};   // the --noSensitive vote: see SACollector::operator()'s restatement
 struct KmerDirScore { uint64_t kmer; int32_t kpos; int8_t fwdScore, rcScore; };
 
 struct Collector {
@@ -553,8 +554,36 @@ struct Collector {
           // std::sort + std::unique on kpos (:297-298).  Entries with equal
           // kpos describe the same read k-mer, hence carry equal statuses for
           // ACGTN reads; a stable sort makes the survivor well defined.
+          std::vector<KmerDirScore> asRef(kmerScores.begin(), kmerScores.end());   // (for the comparison below)
           std::stable_sort(kmerScores.begin(), kmerScores.end(),
                            [](const KmerDirScore& a, const KmerDirScore& b) { return a.kpos < b.kpos; });
+          // Checked, not assumed.  Entries with equal kpos CAN carry different scores: a window holding 'U' / 'u' is a partial word
+          // in the forward pass (Kmer::fromChars stops at the U: absent / absent) and a whole k-mer in the reverse-complement
+          // pass (reverseRead maps U to A).  There the reference's answer depends on what its unstable std::sort does with
+          // ties -- insertion sort (stable) up to 16 entries in libstdc++, introsort beyond.  This restatement keeps the FIRST
+          // entry (stable sort); qo_kpos_ties() reports how many tied positions were seen, how many disagreed, and for how many
+          // reads libstdc++'s std::sort on the same sequence would have led to a different strand decision.
+          bool conflict = false;
+          for (size_t i = 1; i < kmerScores.size(); ++i)
+            if (kmerScores[i].kpos == kmerScores[i - 1].kpos) {
+              g_kposTies.fetch_add(1, std::memory_order_relaxed);
+              if (kmerScores[i].fwdScore != kmerScores[i - 1].fwdScore || kmerScores[i].rcScore != kmerScores[i - 1].rcScore) {
+                g_kposConflicts.fetch_add(1, std::memory_order_relaxed); conflict = true;
+                bool hasU = false;
+                for (int32_t t = kmerScores[i].kpos; t < kmerScores[i].kpos + (int32_t)k && t < (int32_t)readLen; ++t) hasU = hasU || read[t] == 'U' || read[t] == 'u';
+                if (!hasU) g_kposConflictsNoU.fetch_add(1, std::memory_order_relaxed);
+              }
+            }
+          if (conflict) {
+            std::sort(asRef.begin(), asRef.end(), [](const KmerDirScore& a, const KmerDirScore& b) { return a.kpos < b.kpos; });
+            auto e2 = std::unique(asRef.begin(), asRef.end(), [](const KmerDirScore& a, const KmerDirScore& b) { return a.kpos == b.kpos; });
+            int32_t f2 = 0, r2 = 0, f1 = 0, r1 = 0;
+            for (auto it = asRef.begin(); it != e2; ++it) { f2 += it->fwdScore; r2 += it->rcScore; }
+            for (size_t i = 0; i < kmerScores.size(); ++i) if (i == 0 || kmerScores[i].kpos != kmerScores[i - 1].kpos) { f1 += kmerScores[i].fwdScore; r1 += kmerScores[i].rcScore; }
+            const int d1 = f1 > r1 ? 1 : (r1 > f1 ? -1 : 0), d2 = f2 > r2 ? 1 : (r2 > f2 ? -1 : 0);
+            g_kposConflictReads.fetch_add(1, std::memory_order_relaxed);
+            if (d1 != d2) g_kposDecisionDiffers.fetch_add(1, std::memory_order_relaxed);
+          }
           auto e = std::unique(kmerScores.begin(), kmerScores.end(),
                                [](const KmerDirScore& a, const KmerDirScore& b) { return a.kpos == b.kpos; });
           int32_t fwdScore = 0, rcScore = 0;
@@ -1345,6 +1374,14 @@ void* qo_index_create(int k, const uint8_t* text, int64_t n, const IndexT* SA, i
 }
 
 void qo_index_destroy(void* h) { delete (OIndex*)h; }
+// the k-mer vote of --noSensitive (include/SACollector.hpp:289-337): positions that entered kmerScores more than once, and how many
+// of those carried different (fwdScore, rcScore) in their entries; reset = 1 zeroes both after reading
+void qo_kpos_ties(long long* out5, int reset) {
+  // [0] tied positions, [1] ties whose entries disagree, [2] ... in a window without U / u, [3] reads with a disagreeing tie,
+  // [4] reads where libstdc++'s std::sort (what the reference calls) would have decided the strand differently
+  if (out5) { out5[0] = g_kposTies.load(); out5[1] = g_kposConflicts.load(); out5[2] = g_kposConflictsNoU.load(); out5[3] = g_kposConflictReads.load(); out5[4] = g_kposDecisionDiffers.load(); }
+  if (reset) { g_kposTies = 0; g_kposConflicts = 0; g_kposConflictsNoU = 0; g_kposConflictReads = 0; g_kposDecisionDiffers = 0; }
+}
 
 // Map n read pairs (or n single reads when seq2 == nullptr).
 // seqX: concatenated read bytes; offX[n+1]: offsets.

@@ -39,7 +39,8 @@ static inline uint64_t hit_digest(uint64_t unit, uint64_t j, const rapmap::utils
   return v;
 }
 
-struct Totals { uint64_t digest = 0, pe = 0, se = 0, tot = 0, reads = 0, tooMany = 0, mapped = 0; };
+struct Totals { uint64_t digest = 0, pe = 0, se = 0, tot = 0, reads = 0, tooMany = 0, mapped = 0; double prefetchS = 0, loopS = 0; };
+static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 template <typename RapMapIndexT>
 static void worker(RapMapIndexT& rmi, std::vector<Group>& groups, const std::vector<size_t>& firstUnit, std::atomic<size_t>& next, bool prefetch,
@@ -60,7 +61,9 @@ static void worker(RapMapIndexT& rmi, std::vector<Group>& groups, const std::vec
   rapmap::utils::HitCounters scratchCtr;
   auto run_group = [&](Group& rg, size_t unit0, bool count) {
     rapmap::utils::HitCounters& hc = count ? hctr : scratchCtr;
+    const double tp0 = now_s();
     if (prefetch) hitCollector.prefetch(rg, mc, false, maxNumHits);           // <- the one added line
+    const double tp1 = now_s();
     size_t u = unit0;
     for (auto& rpair : rg) {
       // ---- src/RapMapSAMapper.cpp:461-551
@@ -83,6 +86,7 @@ static void worker(RapMapIndexT& rmi, std::vector<Group>& groups, const std::vec
       }
       ++u;
     }
+    if (count) { T.prefetchS += tp1 - tp0; T.loopS += now_s() - tp1; }
   };
   if (warm) run_group(*warm, 0, false);               // context creation, first launches, buffer growth: outside the timed region
   ++ready;
@@ -144,14 +148,14 @@ int main(int argc, char** argv) {
       for (auto& t : th) t.join();
       const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       Totals S;
-      for (auto& x : T) { S.digest += x.digest; S.mapped += x.mapped; }
+      for (auto& x : T) { S.digest += x.digest; S.mapped += x.mapped; S.prefetchS += x.prefetchS; S.loopS += x.loopS; }
       if (rep == 0 || (double)n / dt > best) { best = (double)n / dt; secs = dt; }
       tot = S;
       ctr[0] = hctr.peHits.load(); ctr[1] = hctr.seHits.load(); ctr[2] = hctr.totHits.load(); ctr[3] = hctr.numReads.load(); ctr[4] = hctr.tooManyHits.load();
     }
     std::printf("{\"pairs\": %zu, \"read_len\": %zu, \"threads\": %d, \"chunk\": %zu, \"prefetch\": %s, \"seconds\": %.6f, \"mpairs_per_s\": %.4f, "
-                "\"digest\": \"%016llx\", \"mapped\": %llu, \"peHits\": %llu, \"seHits\": %llu, \"totHits\": %llu, \"numReads\": %llu, \"tooManyHits\": %llu}\n",
-                n, L, threads, chunk, prefetch ? "true" : "false", secs, best / 1e6, (unsigned long long)tot.digest, (unsigned long long)tot.mapped,
+                "\"prefetch_thread_s\": %.4f, \"loop_thread_s\": %.4f, \"digest\": \"%016llx\", \"mapped\": %llu, \"peHits\": %llu, \"seHits\": %llu, \"totHits\": %llu, \"numReads\": %llu, \"tooManyHits\": %llu}\n",
+                n, L, threads, chunk, prefetch ? "true" : "false", secs, best / 1e6, tot.prefetchS, tot.loopS, (unsigned long long)tot.digest, (unsigned long long)tot.mapped,
                 (unsigned long long)ctr[0], (unsigned long long)ctr[1], (unsigned long long)ctr[2], (unsigned long long)ctr[3], (unsigned long long)ctr[4]);
     return 0;
   } catch (const qmap::Error& e) { std::printf("qmap error %d: %s\n", e.code(), e.what()); return 3; }

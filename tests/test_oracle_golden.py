@@ -228,3 +228,61 @@ def test_sample_data_selective_alignment(sample_data, oracle_mod, variant):
                                         sample_data["reads2"][i], res.hits[res.hit_offsets[i]:res.hit_offsets[i + 1]],
                                         ix.names, ix.txpLens, opts.maxNumHits)) != want[sam._read_name(sample_data["names1"][i])]]
     assert not bad, bad[:10]
+
+
+def test_vote_ties_disagree_only_over_U(synth_small, oracle_mod):
+    """--noSensitive decides the strand by a k-mer vote over kmerScores after std::sort + std::unique on kpos
+    (include/SACollector.hpp:289-337, :297-298).  std::sort is not stable, so the reference's answer is well defined only where
+    entries with equal kpos carry equal scores.  The restatement uses a stable sort (first entry wins) and COUNTS what it sees.
+    Fuzz: chimeric reads (a forward piece + a reverse-complemented piece: both strands are walked, positions are entered from
+    both passes), dirtied with IUPAC codes, lower case, N -- and, separately, with U.
+      * without U: many ties, none that disagrees (the stable sort changes nothing the reference could do differently);
+      * with U: a window holding a U is a partial word in the forward pass and a whole k-mer in the reverse-complement pass
+        (reverseRead: U -> A), the entries disagree -- there the reference itself depends on its standard library's sort; the
+        restatement (and the device) keep the first entry, and the count of reads where libstdc++'s std::sort would have
+        chosen the other strand is reported."""
+    import random
+    ix, orc = load_oracle(synth_small["idx"])
+    rnd = random.Random(5)
+    seqs, cur = [], []
+    for line in open(synth_small["fasta"]):
+        if line.startswith(">"):
+            if cur:
+                seqs.append("".join(cur)); cur = []
+        else:
+            cur.append(line.strip())
+    seqs.append("".join(cur))
+    seqs = [t for t in seqs if len(t) >= 300]
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    rc = lambda t: "".join(comp.get(c, "N") for c in reversed(t))
+
+    def piece(L):
+        t = rnd.choice(seqs); a = rnd.randrange(0, len(t) - L)
+        return t[a:a + L]
+
+    def make(dirt):
+        L1 = rnd.choice([40, 50, 60, 75]); L2 = rnd.choice([40, 50, 60, 75])
+        mode = rnd.randrange(4)
+        r = piece(L1) + rc(piece(L2)) if mode == 0 else (rc(piece(L1)) + piece(L2) if mode == 1 else (piece(L1 + L2) if mode == 2 else rc(piece(L1 + L2))))
+        r = list(r)
+        for _ in range(rnd.choice([0, 0, 1, 1, 2, 4])):
+            r[rnd.randrange(len(r))] = rnd.choice(dirt)
+        if rnd.random() < 0.3:
+            a = rnd.randrange(len(r)); b = min(len(r), a + rnd.randrange(1, 30))
+            r[a:b] = [c.lower() for c in r[a:b]]
+        return "".join(r).encode()
+
+    def run(dirt):
+        r1 = [make(dirt) for _ in range(6000)]; r2 = [make(dirt) for _ in range(6000)]
+        oracle_mod.kpos_ties()
+        for kw in ({"sensitive": 0}, {"sensitive": 0, "fuzzy": 1}, {"sensitive": 0, "maxNumHits": 50}):
+            res = orc.map_pairs(*pack(r1), *pack(r2), opts=oracle_mod.default_opts(**kw), nthreads=4)
+            assert res.counters["numReads"] == 6000
+        rs = orc.map_single(*pack(r1), opts=oracle_mod.default_opts(sensitive=0), nthreads=4)
+        assert rs.counters["numReads"] == 6000
+        return oracle_mod.kpos_ties()
+    clean = run("RYKMSWBDHVNn")
+    assert clean["ties"] > 1000 and clean["conflicts"] == 0, clean
+    withU = run("RYKMSWBDHVNnUu")
+    assert withU["conflicts"] > 0 and withU["conflicts_without_U"] == 0, withU
+    print("vote ties with U in the reads:", withU)
