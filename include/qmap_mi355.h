@@ -134,6 +134,12 @@ int64_t qm_index_txp_len(const qm_index* ix, int64_t tid);      /* rmi.txpLens[t
  * pass 2^31 characters; the int64 vectors of such an index are narrowed at open and its text must stay below 2^32 - 2). */
 int qm_index_arrays(const qm_index* ix, const uint8_t** text, int64_t* text_len, const int32_t** txp_offsets,
                     int64_t* n_txps);
+/* The other arrays of an open index as the library holds them, for inspection and cross-checks (profiles/r04/big_index_crosscheck.py
+ * holds them against the oracle's independent numpy reader and the reference's own container): which = QM_RAW_SA -- the suffix
+ * array as uint32_t[count] (a BigSA index's int64 entries narrowed at open), QM_RAW_HASH -- the dense hash's records, count x 16
+ * bytes {uint64 k-mer word, uint32 lb, uint32 ub} in file order (NULL / 0 for a -p index), QM_RAW_COMPLETE_LENS -- uint32_t[count]. */
+enum { QM_RAW_SA = 0, QM_RAW_HASH = 1, QM_RAW_COMPLETE_LENS = 2 };
+int qm_index_raw(const qm_index* ix, int which, const void** data, int64_t* count);
 
 /* Replicates the index into the HBM of `device_id` as flat SoA arrays and
  * allocates the per-context work buffers.  One ctx per GPU / per host thread (a context is not thread-safe); the

@@ -30,7 +30,7 @@ assert HIT_DTYPE.itemsize == 32 and INTERVAL_DTYPE.itemsize == 20
 # every symbol include/qmap_mi355.h declares
 ABI_SYMBOLS = [
     "qm_last_error", "qm_version", "qm_opts_default", "qm_index_open", "qm_index_close", "qm_index_info_get",
-    "qm_index_txp_name", "qm_index_txp_len", "qm_index_arrays", "qm_ctx_create", "qm_ctx_destroy", "qm_ctx_device_bytes",
+    "qm_index_txp_name", "qm_index_txp_len", "qm_index_arrays", "qm_index_raw", "qm_ctx_create", "qm_ctx_destroy", "qm_ctx_device_bytes",
     "qm_map_pairs", "qm_map_reads", "qm_map_device", "qm_fetch_hits", "qm_result_device", "qm_ctx_set_debug",
     "qm_fetch_intervals", "qm_last_kernel_ms", "qm_ctx_stat", "qm_build_index", "qm_build_index_ex",
     "qm_collect_reads", "qm_fetch_found", "qm_hits_to_mappings", "qm_fetch_read_lists", "qm_merge_lists", "qm_fetch_too_many",
@@ -241,6 +241,14 @@ class QuasiIndex:
         text = np.ctypeslib.as_array(C.cast(tp, C.POINTER(C.c_uint8)), shape=(tl.value,)).copy()
         raw = np.ctypeslib.as_array(C.cast(op, C.POINTER(C.c_uint8)), shape=(nt.value * 4,)).copy()
         return text, raw.view("<u4").astype(np.int64)      # unsigned: a BigSA index has offsets beyond 2^31
+
+    def raw(self, which):
+        """zero-copy view of one of the library's own arrays of the open index (qm_index_raw): "sa" uint32[nSA], "hash" records
+        {key u8, lb u4, ub u4} in file order (empty for a -p index), "complete_lens" uint32[T]; valid until close()"""
+        code, dt = {"sa": (0, np.dtype("<u4")), "hash": (1, np.dtype([("key", "<u8"), ("lb", "<u4"), ("ub", "<u4")])), "complete_lens": (2, np.dtype("<u4"))}[which]
+        p, n = C.c_void_p(), C.c_int64()
+        _check(lib().qm_index_raw(self._h, code, C.byref(p), C.byref(n)))
+        return _view(p, n.value, dt)
 
     def close(self):
         if self._h:

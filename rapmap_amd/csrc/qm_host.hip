@@ -422,6 +422,17 @@ int qm_index_arrays(const qm_index* ix, const uint8_t** text, int64_t* text_len,
   return QM_OK;
 }
 
+int qm_index_raw(const qm_index* ix, int which, const void** data, int64_t* count) {
+  if (!ix || !data || !count) return fail(QM_E_ARG, "null argument");
+  switch (which) {
+    case QM_RAW_SA: *data = ix->SA; *count = ix->nSA; break;
+    case QM_RAW_HASH: *data = ix->perfect ? nullptr : ix->hashRecs; *count = ix->perfect ? 0 : ix->nKeys; break;
+    case QM_RAW_COMPLETE_LENS: *data = ix->completeLens; *count = ix->nTxp; break;
+    default: return fail(QM_E_ARG, "qm_index_raw: unknown array %d", which);
+  }
+  return QM_OK;
+}
+
 // --------------------------------------------------------------------------- context
 int qm_ctx_destroy(qm_ctx* c) {
   if (!c) return QM_OK;

@@ -11,19 +11,24 @@
 // tests only, lane-emulated on the CPU by tests/emu/qm_emu.cpp.
 //
 // Stages of map_read (reference file:line each one restates; nothing here is copied from it):
-//   1. strand setup     Kmer.hpp:525-542 (2-bit encode), :92-100 (RC), :484-487 (homopolymer)
-//                       -- all L-k+1 k-mers of a read at once: ballots build bit planes of the
-//                       2-bit codes, every lane slices its own 31-mer out of the planes.
-//   2. seed probes      RapMapUtils.hpp:65-67,226-239 (khash.find) -- every k-mer of both strands is
-//                       probed up front, all loads in flight together, and reduced to presence
-//                       bitmaps (SGPRs) + an interval table (LDS).
-//   3. collector        SACollector.hpp:108-362 (operator()), :441-677 (getSAHits_),
-//                       :366-431 (spotCheck_) replayed as a scalar state machine over the
-//                       bitmaps; a run of misses is one masked popcount.
-//   4. MMP extension    SASearcher.hpp:88-309 (extendSearchNaive): closed form over <= 64 suffixes
-//                       (one lane per suffix), literal three-binary-search fallback otherwise.
-//   5. hits->mappings   HitManager.cpp:691-882 (+ :587-689, :449-493, :308-322) on small
-//                       u64 lists in LDS (global scratch for the rare > QM_CAP lists).
+//   1. strand setup     Kmer.hpp:525-542 (2-bit encode), :92-100 (RC), :484-487 (homopolymer) -- setup_strand: four characters
+//                       per lane (SWAR classification), a packed 2-bit image + N / non-ACGT masks of the strand in LDS.  A read
+//                       that is pure A C G T without a run of k equal bases (nearly all) tabulates nothing: every position
+//                       with a whole k-mer is eligible and a probe shifts its word out of the image when it gets there.
+//   2. seed probes      RapMapUtils.hpp:65-67,226-239 (khash.find) -- LAZILY, where the collector's walk arrives: probe_first
+//                       (the first eligible k-mer and the read's last, both strands' words) and probe_window (up to 32
+//                       positions, k-mer and reverse complement, one round of independent bucket loads; with -s only the
+//                       positions the capped MMPs will visit).  Results live where they are used: six per-position flags
+//                       (eligible x2, probed, k-mer found, reverse complement found, vote entry) are bits of ONE vector
+//                       register per strand (lane l owns positions l, 64 + l, ...: struct Strand), intervals in LDS.
+//   3. collector        SACollector.hpp:108-362 (operator()), :441-677 (getSAHits_), :366-431 (spotCheck_): collect_read /
+//                       get_sa_hits walk the flags -- "next hit at or after p" is a compare + ballot + find-first, a run of
+//                       misses a ballot + popcount.
+//   4. MMP extension    SASearcher.hpp:88-309 (extendSearchNaive): closed form over <= 64 suffixes, one lane per suffix, in
+//                       ONE trip against the packed characters behind every suffix's k-mer (saext / sanext tables);
+//                       text path and literal three-binary-search fallback otherwise.
+//   5. hits->mappings   HitManager.cpp:691-882 (+ :587-689, :449-493, :308-322): one interval of <= 64 suffixes in
+//                       registers, otherwise small u64 lists in LDS (global scratch for the rare > QM_CAP lists).
 // pair_merge:           RapMapUtils.hpp:1185-1264 + RapMapSAMapper.cpp:461-551,684-701 (pairs),
 //                       RapMapSAMapper.cpp:232-250 (single-end).
 #pragma once
