@@ -117,6 +117,39 @@ class small_vector {
   T* p_; size_t n_, cap_;
   alignas(T) unsigned char st_[N * sizeof(T)];
 };
+// A counter many threads bump and few read: every thread adds into a cache line of its own (a slot picked once per thread), a
+// read sums the slots.  The interface is the part of std::atomic<uint64_t> that counter code uses.
+class sharded_counter {
+ public:
+  static constexpr int kSlots = 64;
+  sharded_counter() { for (auto& s : s_) s.v.store(0, std::memory_order_relaxed); }
+  sharded_counter(uint64_t v) : sharded_counter() { s_[0].v.store(v, std::memory_order_relaxed); }
+  sharded_counter(const sharded_counter&) = delete;
+  sharded_counter& operator=(const sharded_counter&) = delete;
+  uint64_t load(std::memory_order = std::memory_order_seq_cst) const {
+    uint64_t t = 0; for (const auto& s : s_) t += s.v.load(std::memory_order_relaxed); return t;
+  }
+  operator uint64_t() const { return load(); }
+  void store(uint64_t v, std::memory_order = std::memory_order_seq_cst) {
+    for (auto& s : s_) s.v.store(0, std::memory_order_relaxed);
+    s_[0].v.store(v, std::memory_order_relaxed);
+  }
+  uint64_t operator=(uint64_t v) { store(v); return v; }
+  uint64_t fetch_add(uint64_t d, std::memory_order = std::memory_order_seq_cst) { const uint64_t before = load(); mine().fetch_add(d, std::memory_order_relaxed); return before; }
+  // (no value comes back from ++ / +=: a sum over the slots per increment would undo the point; code that wants one uses fetch_add)
+  void operator+=(uint64_t d) { mine().fetch_add(d, std::memory_order_relaxed); }
+  void operator++() { mine().fetch_add(1, std::memory_order_relaxed); }
+  void operator++(int) { mine().fetch_add(1, std::memory_order_relaxed); }
+ private:
+  struct alignas(64) Slot { std::atomic<uint64_t> v; };
+  static int slot_of_thread() {
+    static std::atomic<int> next{0};
+    thread_local int mineSlot = next.fetch_add(1, std::memory_order_relaxed) % kSlots;
+    return mineSlot;
+  }
+  std::atomic<uint64_t>& mine() { return s_[slot_of_thread()].v; }
+  Slot s_[kSlots];
+};
 }  // namespace qmap
 
 // ------------------------------------------------------------------------------------------------ rapmap::utils types
@@ -153,15 +186,19 @@ class MappingConfig {
   bool considerMultiPos{false};
 };
 
-// include/RapMapUtils.hpp:208-216
+// include/RapMapUtils.hpp:208-216.  The reference's members are std::atomic<uint64_t> shared by every worker thread and bumped
+// several times per read pair -- harmless when a pair costs microseconds of mapping, but here the per-pair host work is ~0.1 us
+// and 32 workers incrementing one cache line ran 30x slower than one (profiles/r04/compat_probe.txt).  Same member names and
+// the operations callers use on them (++, +=, load(), store(), conversion to uint64_t), counted in per-thread cache lines and
+// summed when read.
 struct HitCounters {
-  std::atomic<uint64_t> peHits{0};
-  std::atomic<uint64_t> seHits{0};
-  std::atomic<uint64_t> trueHits{0};
-  std::atomic<uint64_t> totHits{0};
-  std::atomic<uint64_t> numReads{0};
-  std::atomic<uint64_t> tooManyHits{0};
-  std::atomic<uint64_t> lastPrint{0};
+  qmap::sharded_counter peHits;
+  qmap::sharded_counter seHits;
+  qmap::sharded_counter trueHits;
+  qmap::sharded_counter totHits;
+  qmap::sharded_counter numReads;
+  qmap::sharded_counter tooManyHits;
+  qmap::sharded_counter lastPrint;
 };
 
 // include/RapMapUtils.hpp:399-502 (chobo::small_vector<int32_t> -> qmap::small_vector<int32_t>: same inline capacity, no heap

@@ -22,7 +22,7 @@ with open("/tmp/cp/reads.bin", "wb") as f:
     f.write(h1.tobytes()); f.write(h2.tobytes())
 mp.close()
 for T in threads:
-    p = subprocess.run([exe, idx, "/tmp/cp/reads.bin", str(n), "100", str(T), "10000"] + extra, capture_output=True, text=True)
+    p = subprocess.run([exe, idx, "/tmp/cp/reads.bin", str(n), "100", str(T), "10000"] + extra, capture_output=True, text=True, timeout=240)
     line = [l for l in p.stdout.splitlines() if l.startswith("{")]
     if not line:
         print(T, "FAILED", p.stdout[-300:], p.stderr[-300:]); continue

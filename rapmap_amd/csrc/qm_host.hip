@@ -483,10 +483,6 @@ int qm_ctx_create_ex(const qm_index* ix, int device_id, uint32_t flags, qm_ctx**
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(QM_E_NOGPU, "no HIP device visible");
   if (device_id < 0 || device_id >= ndev) return fail(QM_E_ARG, "device %d out of range (%d devices)", device_id, ndev);
   HIPCHK(hipSetDevice(device_id));
-  if (const char* bs = getenv("QM_BLOCKING_SYNC")) {       // tuning knob: synchronisations sleep instead of spinning (many host threads, few cores)
-    static std::once_flag once;
-    if (atoi(bs) > 0) std::call_once(once, [] { (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); });
-  }
   qm_ctx* c = new qm_ctx();
   c->ix = ix; c->device = device_id;
   hipDeviceProp_t prop;

@@ -59,7 +59,9 @@ static void worker(RapMapIndexT& rmi, std::vector<Group>& groups, const std::vec
   bool tooManyHits = false;
   uint32_t readLen = 0;
   rapmap::utils::HitCounters scratchCtr;
+  Totals mine;                                         // (T is one element of a vector shared with the other threads: written once, at the end)
   auto run_group = [&](Group& rg, size_t unit0, bool count) {
+    Totals& T = mine;
     rapmap::utils::HitCounters& hc = count ? hctr : scratchCtr;
     const double tp0 = now_s();
     if (prefetch) hitCollector.prefetch(rg, mc, false, maxNumHits);           // <- the one added line
@@ -96,6 +98,7 @@ static void worker(RapMapIndexT& rmi, std::vector<Group>& groups, const std::vec
     if (g >= groups.size()) break;
     run_group(groups[g], firstUnit[g], true);
   }
+  T = mine;
 }
 
 int main(int argc, char** argv) {

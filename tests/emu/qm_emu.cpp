@@ -72,10 +72,17 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
     // emulate 7 interleaved "waves", each with its own chunk allocator
     WaveAlloc wa[7];
     for (auto& w : wa) { w.base = -1; w.used = 0; w.ivBase = -1; w.ivUsed = 0; }
-    for (long long r = 0; r < nreads; ++r) {
+    {
+      // the persistent loop of qm_read_kernel with three "waves": wave w maps slots w, w + 3, ... with the kernel's own software
+      // pipeline (characters of the next read and offsets of the one after staged while a read is mapped), so that what rides on
+      // it -- the first-probe prefetch for the wave's next read -- runs here as it does on the device
       const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP) | (o->sel_aln ? QM_F_SEL : 0);
-#define QE_CALL(NS_, F_) { static WaveMem<NS_> M; stage_offsets<NS_, F_>(B, r, M, 0); stage_chars<NS_, F_>(B, r, M, 0); \
-                           map_read<NS_, F_>(ix, B, r, r, B.nreads, 0, M, gs.data(), wa[r % 7], selscr, (r & 2) ? &sellds : nullptr); }
+#define QE_CALL(NS_, F_) { const long long NW = 3; static WaveMem<NS_> Ms[3];                                                  \
+        for (long long w = 0; w < NW; ++w) { WaveMem<NS_>& M = Ms[w]; M.pfslot = ~0u;                                              \
+          stage_offsets<NS_, F_>(B, w, M, 0); stage_chars<NS_, F_>(B, w, M, 0); stage_offsets<NS_, F_>(B, w + NW, M, 1);          \
+          int par = 0;                                                                                                             \
+          for (long long r = w; r < nreads; r += NW) {                                                                             \
+            map_read<NS_, F_>(ix, B, r, r, NW, par, M, gs.data(), wa[r % 7], selscr, (r & 2) ? &sellds : nullptr); par ^= 1; } } }
       if (ns == 2) { switch (F) { case 0: QE_CALL(2, 0) break; case 1: QE_CALL(2, 1) break; case 2: QE_CALL(2, 2) break; case 3: QE_CALL(2, 3) break;
                                   case 4: QE_CALL(2, 4) break; case 5: QE_CALL(2, 5) break; case 6: QE_CALL(2, 6) break; default: QE_CALL(2, 7) break; } }
       else if (ns == 3) { switch (F) { case 0: QE_CALL(3, 0) break; case 1: QE_CALL(3, 1) break; case 2: QE_CALL(3, 2) break; case 3: QE_CALL(3, 3) break;
@@ -95,7 +102,7 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
       else {
         const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP);
         for (long long r = 0; r < (long long)q.size(); ++r) {
-#define QE_LONG(F_) { static WaveMem<32> M; stage_offsets<32, F_>(S2, r, M, 0); stage_chars<32, F_>(S2, r, M, 0); \
+#define QE_LONG(F_) { static WaveMem<32> M; M.pfslot = ~0u; stage_offsets<32, F_>(S2, r, M, 0); stage_chars<32, F_>(S2, r, M, 0); \
                       map_read<32, F_>(ix, S2, read_id<F_, 32>(S2, r), r, S2.nreads, 0, M, gs.data(), wa[r % 7]); }
           switch (F) { case 0: QE_LONG(0) break; case 1: QE_LONG(1) break; case 2: QE_LONG(2) break; default: QE_LONG(3) break; }
 #undef QE_LONG
@@ -118,7 +125,7 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
         ReadBatch S2 = B; S2.slowq = q.data(); S2.nreads = (long long)q.size();
         const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP) | QM_F_SEL;
         for (long long r = 0; r < (long long)q.size(); ++r) {
-#define QE_LONGS(F_) { static WaveMem<32> M; stage_offsets<32, F_>(S2, r, M, 0); stage_chars<32, F_>(S2, r, M, 0); \
+#define QE_LONGS(F_) { static WaveMem<32> M; M.pfslot = ~0u; stage_offsets<32, F_>(S2, r, M, 0); stage_chars<32, F_>(S2, r, M, 0); \
                        map_read<32, F_>(ix, S2, read_id<F_, 32>(S2, r), r, S2.nreads, 0, M, gs.data(), wa[r % 7], selscr, nullptr); }
           switch (F) { case 4: QE_LONGS(4) break; case 5: QE_LONGS(5) break; case 6: QE_LONGS(6) break; default: QE_LONGS(7) break; }
 #undef QE_LONGS
@@ -135,9 +142,9 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
       ReadBatch S2 = B; S2.slowq = q.data(); S2.dyn = &dyn; S2.nreads = (long long)q.size(); S2.iv_out = nullptr;
       const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP) | QM_F_SEL;
       for (long long r = 0; r < (long long)q.size(); ++r) {
-#define QE_SLOW(NS_, F_) { static WaveMem<NS_> M; stage_offsets<NS_, F_>(S2, r, M, 0); stage_chars<NS_, F_>(S2, r, M, 0); \
+#define QE_SLOW(NS_, F_) { static WaveMem<NS_> M; M.pfslot = ~0u; stage_offsets<NS_, F_>(S2, r, M, 0); stage_chars<NS_, F_>(S2, r, M, 0); \
                            map_read<NS_, F_>(ix, S2, read_id<F_>(S2, r), r, S2.nreads, 0, M, gs.data(), wa[r % 7], selscr, &sellds, &dyn); }
-#define QE_SLOWL(F_) { static WaveMem<32> M; stage_offsets<32, F_>(S2, r, M, 0); stage_chars<32, F_>(S2, r, M, 0); \
+#define QE_SLOWL(F_) { static WaveMem<32> M; M.pfslot = ~0u; stage_offsets<32, F_>(S2, r, M, 0); stage_chars<32, F_>(S2, r, M, 0); \
                        map_read<32, F_>(ix, S2, read_id<F_, 32>(S2, r), r, S2.nreads, 0, M, gs.data(), wa[r % 7], selscr, &sellds, &dyn); }
         if (rawLen(q[(size_t)r]) > 64 * ns) { switch (F) { case 4: QE_SLOWL(4) break; case 5: QE_SLOWL(5) break; case 6: QE_SLOWL(6) break; default: QE_SLOWL(7) break; } }
         else
