@@ -34,9 +34,15 @@
 #define QMAP_RAPMAP_COMPAT_HPP
 
 #include <atomic>
+#include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <initializer_list>
+#include <map>
+#include <mutex>
+#include <thread>
 #include <limits>
 #include <memory>
 #include <new>
@@ -59,6 +65,7 @@ class Error : public std::runtime_error {
 namespace detail {
 inline void check(int rc) { if (rc) throw Error(rc, qm_last_error()); }
 struct Chunk;
+inline void drop_services(const qm_index* ix);       // the batching service of an index (below) goes before the index does
 }  // namespace detail
 
 // The reference's position lists are chobo::small_vector<int32_t> (include/RapMapUtils.hpp:469-470; static capacity 16): a hit
@@ -298,7 +305,7 @@ class RapMapSAIndex {
   using IndexType = IndexT;
   using HashType = HashT;
   RapMapSAIndex() = default;
-  ~RapMapSAIndex() { if (ix_) qm_index_close(ix_); }
+  ~RapMapSAIndex() { if (ix_) { qmap::detail::drop_services(ix_); qm_index_close(ix_); } }
   RapMapSAIndex(const RapMapSAIndex&) = delete;
   RapMapSAIndex& operator=(const RapMapSAIndex&) = delete;
 
@@ -345,22 +352,33 @@ using SAIndex64BitPerfect = RapMapSAIndex<int64_t, PerfectHashT>;
 namespace qmap {
 namespace detail {
 
-// One thread's device context per index (contexts are not shared between threads; the index replica in HBM is).
+// One thread's device context per index, for the calls that run a batch of one (contexts are not shared between threads; the
+// index replica in HBM is).  Chunks of read groups do not use these: they go through the batching service below.
 inline qm_ctx*& last_ctx() { thread_local qm_ctx* c = nullptr; return c; }   // the calling thread's most recent context
+struct LastIndex { const qm_index* ix{nullptr}; int device{0}; };
+inline LastIndex& last_index() { thread_local LastIndex li; return li; }     // ... and the index its calls were about
 struct ThreadCtx {
   const qm_index* ix{nullptr};
   qm_ctx* ctx{nullptr};
   ~ThreadCtx() { if (ctx) qm_ctx_destroy(ctx); }
 };
-template <typename RapMapIndexT>
-inline qm_ctx* thread_ctx(RapMapIndexT& rmi) {
+inline qm_ctx* thread_ctx_of(const qm_index* ix, int device) {
   thread_local std::vector<std::unique_ptr<ThreadCtx>> tl;
-  for (auto& t : tl) if (t->ix == rmi.handle()) return last_ctx() = t->ctx;
+  for (auto& t : tl) if (t->ix == ix) return last_ctx() = t->ctx;
   std::unique_ptr<ThreadCtx> t(new ThreadCtx());
-  t->ix = rmi.handle();
-  check(qm_ctx_create(rmi.handle(), rmi.device(), &t->ctx));
+  t->ix = ix;
+  check(qm_ctx_create(ix, device, &t->ctx));
   tl.push_back(std::move(t));
   return last_ctx() = tl.back()->ctx;
+}
+template <typename RapMapIndexT>
+inline qm_ctx* thread_ctx(RapMapIndexT& rmi) { last_index().ix = rmi.handle(); last_index().device = rmi.device(); return thread_ctx_of(rmi.handle(), rmi.device()); }
+// the context a merge that has to go to the device runs on: the thread's most recent one, or one for the index its last
+// collector call was about
+inline qm_ctx* merge_ctx() {
+  if (last_ctx()) return last_ctx();
+  if (last_index().ix) return thread_ctx_of(last_index().ix, last_index().device);
+  return nullptr;
 }
 
 // Everything one fused pass over a chunk produced, per read (paired: read 2u = left mate of pair u, 2u + 1 = right).
@@ -382,15 +400,160 @@ struct PinnedBuf {
     return p;
   }
 };
+// ---- the batching service -------------------------------------------------------------------------------------------
+// The reference's workers each take a read group of ~10 000 pairs from the parser and map it on their own
+// (src/RapMapSAMapper.cpp:752-799,853).  One GPU pass per group and thread is the wrong shape for the device: a pass has a fixed
+// cost (a dozen launches, four synchronisations) that dwarfs the 40 us of kernel time 10 000 pairs need, and 32 host threads
+// each driving a context of their own spend their time inside the runtime's locks (profiles/r04/compat_probe.txt: 4.9 M
+// pairs/s on one thread, 4.4 on 32).  So the groups of all threads are mapped TOGETHER: a worker's prefetch() joins the batch
+// that is currently open -- it reserves its place in the batch's page-locked input buffers under a lock, packs its reads there
+// side by side with the other workers, and waits -- and a dispatcher thread that owns a device context closes the batch when
+// it is free to, maps it in one fused pass (qm_map_pairs_stages), brings every stage's output down in one go
+// (qm_fetch_stages) and wakes the workers, which then run the reference's per-read loop on their slice of the shared result.
+// While one batch is on the device the next one fills: the batch size adapts to the load by itself (one group when one thread
+// asks, dozens when many do).  Two dispatchers (QMAP_COMPAT_CONTEXTS) keep two batches in flight.
+struct Batch {
+  PinnedBuf in[4];                         // characters and offsets of both mates, filled by the joining workers
+  char* s1{nullptr}; char* s2{nullptr}; int64_t* o1{nullptr}; int64_t* o2{nullptr};
+  size_t cap1{0}, cap2{0}, used1{0}, used2{0};
+  int64_t capUnits{0}, units{0};
+  int joined{0}, packed{0}, readers{0};
+  int state{0};                            // 0 free, 1 open, 2 closed (packing / on the device), 3 done, 4 failed
+  qm_opts opts{};
+  qm_stage_view v{}; PinnedBuf arena;
+  int rc{0}; std::string err;
+  void size_for(size_t b1, size_t b2, int64_t n) {
+    const size_t w1 = b1 + 64 > (size_t(40) << 20) ? b1 + 64 : (size_t(40) << 20), w2 = b2 + 64 > (size_t(40) << 20) ? b2 + 64 : (size_t(40) << 20);
+    const int64_t wu = n + 1 > (int64_t(1) << 19) ? n + 1 : (int64_t(1) << 19);
+    s1 = static_cast<char*>(in[0].need(w1)); s2 = static_cast<char*>(in[1].need(w2));
+    o1 = static_cast<int64_t*>(in[2].need(static_cast<size_t>(wu + 1) * 8)); o2 = static_cast<int64_t*>(in[3].need(static_cast<size_t>(wu + 1) * 8));
+    cap1 = in[0].cap - 64; cap2 = in[1].cap - 64; capUnits = static_cast<int64_t>(in[2].cap / 8) - 2;
+    if (static_cast<int64_t>(in[3].cap / 8) - 2 < capUnits) capUnits = static_cast<int64_t>(in[3].cap / 8) - 2;
+  }
+};
+class Service {
+ public:
+  Service(const qm_index* ix, int device) : ix_(ix), device_(device) {
+    const char* e = std::getenv("QMAP_COMPAT_CONTEXTS");
+    int n = e && std::atoi(e) > 0 ? std::atoi(e) : 2;
+    if (n > 8) n = 8;
+    for (int i = 0; i < n; ++i) th_.emplace_back([this] { dispatch(); });
+  }
+  ~Service() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+    cvWork_.notify_all(); cvDone_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  // a worker's group joins a batch: its place among the units / characters of the batch
+  struct Place { Batch* b; int64_t u0; size_t c1, c2; };
+  Place join(const qm_opts& opts, int64_t n, size_t b1, size_t b2) {
+    std::unique_lock<std::mutex> lk(mu_);
+    Batch* b = open_;
+    if (b && (std::memcmp(&b->opts, &opts, sizeof(qm_opts)) != 0 || b->units + n > b->capUnits || b->used1 + b1 > b->cap1 || b->used2 + b2 > b->cap2)) {
+      b->state = 2; ready_.push_back(b); open_ = nullptr; b = nullptr;        // other settings, or full: off it goes
+    }
+    if (!b) {
+      for (auto& x : all_) if (x->state == 0) { b = x.get(); break; }
+      if (!b) { all_.emplace_back(new Batch()); b = all_.back().get(); }
+      b->size_for(b1, b2, n);
+      b->opts = opts; b->units = 0; b->used1 = 0; b->used2 = 0; b->joined = 0; b->packed = 0; b->readers = 0; b->rc = 0; b->err.clear();
+      b->o1[0] = 0; b->o2[0] = 0;
+      b->state = 1; open_ = b;
+    }
+    Place p{b, b->units, b->used1, b->used2};
+    b->units += n; b->used1 += b1; b->used2 += b2; b->joined++; b->readers++;
+    lk.unlock();
+    cvWork_.notify_all();
+    return p;
+  }
+  // the worker has packed its reads: wait until the batch has been mapped
+  void packed_and_wait(Batch* b) {
+    std::unique_lock<std::mutex> lk(mu_);
+    b->packed++;
+    cvWork_.notify_all();
+    cvDone_.wait(lk, [&] { return b->state >= 3 || stop_; });
+    if (b->state != 3) {
+      const int rc = b->rc ? b->rc : QM_E_STATE; const std::string msg = b->err.empty() ? std::string("the batching service stopped") : b->err;
+      release_locked(b);
+      throw Error(rc, msg.c_str());
+    }
+  }
+  void release(Batch* b) { std::lock_guard<std::mutex> lk(mu_); release_locked(b); }
+ private:
+  void release_locked(Batch* b) { if (--b->readers == 0 && b->state >= 3) b->state = 0; }
+  void dispatch() {
+    qm_ctx* ctx = nullptr;
+    std::unique_lock<std::mutex> lk(mu_);
+    while (!stop_) {
+      Batch* b = nullptr;
+      if (!ready_.empty()) { b = ready_.front(); ready_.pop_front(); }
+      else if (open_ && open_->joined > 0) { b = open_; open_ = nullptr; b->state = 2; }
+      if (!b) { cvWork_.wait(lk); continue; }
+      cvWork_.wait(lk, [&] { return b->packed == b->joined || stop_; });      // the last joiners are still copying their characters
+      if (stop_) { b->state = 4; break; }
+      lk.unlock();
+      int rc = 0; std::string err;
+      if (!ctx) { rc = qm_ctx_create(ix_, device_, &ctx); if (rc) { err = qm_last_error(); ctx = nullptr; } }
+      if (!rc) {
+        int64_t nHits = 0; qm_counters c{};
+        rc = qm_map_pairs_stages(ctx, &b->opts, b->units, b->s1, b->o1, b->s2, b->o2, &nHits, &c);
+        int64_t need = 0;
+        if (!rc) rc = qm_stage_bytes(ctx, &need);
+        if (!rc) {
+          try { b->arena.need(static_cast<size_t>(need)); } catch (const Error& e) { rc = e.code(); err = e.what(); }
+        }
+        if (!rc) rc = qm_fetch_stages(ctx, b->arena.p, static_cast<int64_t>(b->arena.cap), &b->v);
+        if (rc && err.empty()) err = qm_last_error();
+      }
+      lk.lock();
+      b->rc = rc; b->err = err; b->state = rc ? 4 : 3;
+      if (b->readers == 0) b->state = 0;
+      cvDone_.notify_all();
+    }
+    lk.unlock();
+    cvDone_.notify_all();
+    if (ctx) qm_ctx_destroy(ctx);
+  }
+  const qm_index* ix_; int device_;
+  std::mutex mu_; std::condition_variable cvWork_, cvDone_;
+  std::vector<std::unique_ptr<Batch>> all_;
+  std::deque<Batch*> ready_;
+  Batch* open_{nullptr};
+  std::vector<std::thread> th_;
+  bool stop_{false};
+};
+// the services of this process, one per (index, device); created on first use, dropped when their index is closed (an index
+// that is never closed keeps its service until the process ends: the registry itself is never destroyed)
+struct Registry { std::mutex mu; std::map<std::pair<const qm_index*, int>, std::unique_ptr<Service>> m; };
+inline Registry& registry() { static Registry* r = new Registry(); return *r; }
+inline Service* service_of(const qm_index* ix, int device) {
+  Registry& R = registry();
+  std::lock_guard<std::mutex> lk(R.mu);
+  auto& s = R.m[std::make_pair(ix, device)];
+  if (!s) s.reset(new Service(ix, device));
+  return s.get();
+}
+inline void drop_services(const qm_index* ix) {
+  Registry& R = registry();
+  std::vector<std::unique_ptr<Service>> gone;
+  { std::lock_guard<std::mutex> lk(R.mu);
+    for (auto it = R.m.begin(); it != R.m.end();) { if (it->first.first == ix) { gone.push_back(std::move(it->second)); it = R.m.erase(it); } else ++it; } }
+  gone.clear();                                                // (joins the dispatchers, which destroy their contexts)
+}
+
+// A worker's view of its read group inside a mapped batch (paired: read 2u = left mate of pair u, 2u + 1 = right).
 struct Chunk {
   uint64_t gen{0};
   bool paired{false};
   qm_opts opts{};                       // what the chunk was mapped with: a stage call with other settings does not use it
   int64_t nreads{0};
   std::vector<const char*> key; std::vector<size_t> keyLen;
-  qm_stage_view v{};                    // every stage's output, per read / per pair, in arena (one download: qm_fetch_stages)
-  PinnedBuf arena;
+  qm_stage_view v{};                    // every stage's output of the BATCH, per read / per pair (absolute CSR offsets) ...
+  int64_t rbase{0}, ubase{0};           // ... and where this group's reads / pairs start in it
+  Service* svc{nullptr}; Batch* batch{nullptr};
   int64_t cursor{0};
+  void release() { if (batch && svc) svc->release(batch); batch = nullptr; nreads = 0; }
+  ~Chunk() { release(); }
 };
 inline uint64_t next_gen() { static std::atomic<uint64_t> g{1}; return g++; }
 
@@ -520,40 +683,43 @@ class SACollector {
                      const rapmap::utils::MappingConfig& mc, bool fuzzyMerge, uint32_t maxNumHits) {
     using namespace qmap::detail;
     const int64_t n = static_cast<int64_t>(left.size());
-    // the chunk object and its page-locked buffers are reused from group to group; a new generation number makes everything
-    // that was handed out of the previous group stale
+    // the chunk object is reused from group to group; a new generation number makes everything that was handed out of the
+    // previous group stale, and the batch that group was mapped in is given back
     if (!chunk_) chunk_.reset(new Chunk());
     Chunk* ch = chunk_.get();
+    ch->release();
     ch->gen = next_gen(); ch->paired = true; ch->nreads = 0; ch->cursor = 0;
     stageOpts(ch->opts);
     apply_mc(mc, ch->opts);
     ch->opts.fuzzy = (fuzzyMerge || mc.doChaining) ? 1 : 0;
     ch->opts.max_num_hits = static_cast<int32_t>(maxNumHits);
-    // the reads packed into page-locked buffers: the upload is a DMA straight out of them
+    last_index().ix = rmi_->handle(); last_index().device = rmi_->device();
+    nPacked_ = 0;
+    if (n == 0) return;
     size_t b1 = 0, b2 = 0;
     for (int64_t i = 0; i < n; ++i) { b1 += left[i]->size(); b2 += right[i]->size(); }
-    s1_ = static_cast<char*>(in_[0].need(b1 + 64)); s2_ = static_cast<char*>(in_[1].need(b2 + 64));
-    o1_ = static_cast<int64_t*>(in_[2].need(static_cast<size_t>(n + 1) * 8)); o2_ = static_cast<int64_t*>(in_[3].need(static_cast<size_t>(n + 1) * 8));
+    // join the batch that is open (qmap::detail::Service): this group's place in the batch's page-locked input buffers ...
+    Service* svc = service_of(rmi_->handle(), rmi_->device());
+    const Service::Place pl = svc->join(ch->opts, n, b1, b2);
+    Batch* bt = pl.b;
+    ch->svc = svc; ch->batch = bt;
+    // ... the reads packed there, next to the other workers' (the upload is a DMA straight out of these buffers) ...
     ch->key.resize(static_cast<size_t>(2 * n)); ch->keyLen.resize(static_cast<size_t>(2 * n));
-    size_t p1 = 0, p2 = 0;
-    o1_[0] = 0; o2_[0] = 0;
+    size_t p1 = pl.c1, p2 = pl.c2;
+    int64_t* o1 = bt->o1 + pl.u0; int64_t* o2 = bt->o2 + pl.u0;
     for (int64_t i = 0; i < n; ++i) {
       const std::string& l = *left[i]; const std::string& r = *right[i];
-      std::memcpy(s1_ + p1, l.data(), l.size()); p1 += l.size(); o1_[i + 1] = static_cast<int64_t>(p1);
-      std::memcpy(s2_ + p2, r.data(), r.size()); p2 += r.size(); o2_[i + 1] = static_cast<int64_t>(p2);
+      std::memcpy(bt->s1 + p1, l.data(), l.size()); p1 += l.size(); o1[i + 1] = static_cast<int64_t>(p1);
+      std::memcpy(bt->s2 + p2, r.data(), r.size()); p2 += r.size(); o2[i + 1] = static_cast<int64_t>(p2);
       ch->key[2 * i] = l.data(); ch->keyLen[2 * i] = l.size();
       ch->key[2 * i + 1] = r.data(); ch->keyLen[2 * i + 1] = r.size();
     }
+    // ... and the wait for the batch's one fused pass: every stage's output of every group in it, compacted on the device and
+    // brought down in one go (intervals and foundHit per read, per-read lists, merge results and tooMany flags per pair)
+    try { svc->packed_and_wait(bt); } catch (...) { ch->batch = nullptr; throw; }
+    ch->v = bt->v; ch->ubase = pl.u0; ch->rbase = 2 * pl.u0;
+    s1_ = bt->s1; s2_ = bt->s2; o1_ = o1; o2_ = o2;
     nPacked_ = n;
-    qm_ctx* ctx = thread_ctx(*rmi_);
-    int64_t nHits = 0; qm_counters c{};
-    check(qm_map_pairs_stages(ctx, &ch->opts, n, s1_, o1_, s2_, o2_, &nHits, &c));
-    // every stage's output in one download: intervals and foundHit per read (stage 1), per-read lists (stage 2), merge results
-    // and tooMany flags per pair (stage 3) -- compacted on the device, laid out in this chunk's own arena
-    int64_t need = 0;
-    check(qm_stage_bytes(ctx, &need));
-    ch->arena.need(static_cast<size_t>(need));
-    check(qm_fetch_stages(ctx, ch->arena.p, static_cast<int64_t>(ch->arena.cap), &ch->v));
     ch->nreads = 2 * n;
   }
 
@@ -579,12 +745,12 @@ class SACollector {
         idx = c; ch->cursor = c + 1; break;
       }
       if (idx >= 0 && same_stage_opts(now, ch->opts) && (doChaining_ ? 1 : 0) == ch->opts.sel_aln) {
-        for (int64_t j = ch->v.iv_off[idx]; j < ch->v.iv_off[idx + 1]; ++j) {
+        for (int64_t j = ch->v.iv_off[ch->rbase + idx]; j < ch->v.iv_off[ch->rbase + idx + 1]; ++j) {
           const qm_sa_interval_hit& h = ch->v.iv[j];
           (h.query_rc ? hcInfo.rcSAInts : hcInfo.fwdSAInts).emplace_back(static_cast<OffsetT>(static_cast<uint32_t>(h.begin)), static_cast<OffsetT>(static_cast<uint32_t>(h.end)), h.len, h.query_pos, h.query_rc != 0);
         }
         hcInfo.qm_chunk_ = ch; hcInfo.qm_gen_ = ch->gen; hcInfo.qm_read_ = idx;
-        return ch->v.found[idx] != 0;
+        return ch->v.found[ch->rbase + idx] != 0;
       }
     }
     // a batch of one
@@ -625,9 +791,9 @@ class SACollector {
   bool doChaining_{false};
   int32_t maxMMPExtension_{7};
   std::unique_ptr<qmap::detail::Chunk> chunk_;
-  qmap::detail::PinnedBuf in_[4];                 // the chunk's reads as the library takes them: characters and offsets of both mates
-  char* s1_{nullptr}; char* s2_{nullptr};
-  int64_t* o1_{nullptr}; int64_t* o2_{nullptr};
+  // the chunk's reads as they were packed for the device (the batch's input buffers; o1_ / o2_ start at this group's first pair)
+  const char* s1_{nullptr}; const char* s2_{nullptr};
+  const int64_t* o1_{nullptr}; const int64_t* o2_{nullptr};
   int64_t nPacked_{0};
 };
 
@@ -648,10 +814,10 @@ void hitsToMappingsSimple(RapMapIndexT& rmi, rapmap::utils::MappingConfig& mc, r
   apply_mc(mc, o);
   if (ch && ch->gen == hcinfo.qm_gen_ && hcinfo.qm_read_ >= 0 && (mc.doChaining ? 1 : 0) == ch->opts.sel_aln &&
       (!mc.doChaining || o.consensus_slack == ch->opts.consensus_slack) &&
-      static_cast<int64_t>(hcinfo.fwdSAInts.size() + hcinfo.rcSAInts.size()) == ch->v.iv_off[hcinfo.qm_read_ + 1] - ch->v.iv_off[hcinfo.qm_read_]) {
+      static_cast<int64_t>(hcinfo.fwdSAInts.size() + hcinfo.rcSAInts.size()) == ch->v.iv_off[ch->rbase + hcinfo.qm_read_ + 1] - ch->v.iv_off[ch->rbase + hcinfo.qm_read_]) {
     // the chunk's pass already turned exactly these intervals into the read's list
-    const int64_t r = hcinfo.qm_read_;
-    decode_list(ch->v.words + ch->v.list_off[r], ch->v.list_off[r + 1] - ch->v.list_off[r], mc.doChaining, readLen, mateStatus, hits);
+    const int64_t r = hcinfo.qm_read_, ar = ch->rbase + r;
+    decode_list(ch->v.words + ch->v.list_off[ar], ch->v.list_off[ar + 1] - ch->v.list_off[ar], mc.doChaining, readLen, mateStatus, hits);
     for (size_t i = before; i < hits.size(); ++i) { hits[i].qm_chunk_ = ch; hits[i].qm_gen_ = ch->gen; hits[i].qm_read_ = r; }
     return;
   }
@@ -693,7 +859,8 @@ inline const qmap::detail::Chunk* merge_source(const std::vector<QuasiAlignment>
   if (rd < 0 || (rd & 1)) return nullptr;
   // the other mate's list must be what the chunk has for it (an emptied vector is an edit)
   auto count = [&](int64_t read) {
-    int64_t g = 0; const uint64_t* w = ch->v.words + ch->v.list_off[read]; const int64_t n = ch->v.list_off[read + 1] - ch->v.list_off[read];
+    const int64_t ar = ch->rbase + read;
+    int64_t g = 0; const uint64_t* w = ch->v.words + ch->v.list_off[ar]; const int64_t n = ch->v.list_off[ar + 1] - ch->v.list_off[ar];
     if (!chained) { for (int64_t i = 0; i < n; ++i) if (i == 0 || (w[i] >> 33) != (w[i - 1] >> 33)) ++g; return g; }
     for (int64_t i = 0; i < n;) { i += 2 + static_cast<int64_t>(w[i] >> 36) + static_cast<int64_t>(w[i + 1] >> 32); ++g; }
     return g;
@@ -733,7 +900,8 @@ inline MergeResult merge_impl(bool fuzzy, bool leftMatches, bool rightMatches, s
   const Chunk* ch = merge_source(leftHits, rightHits, chained, fuzzy, maxNumHits, unit);
   std::vector<qm_hit> own; const qm_hit* hb = nullptr; int64_t nh = 0; uint8_t flags = 0;
   if (ch) {
-    hb = ch->v.hits + ch->v.hit_off[unit]; nh = ch->v.hit_off[unit + 1] - ch->v.hit_off[unit]; flags = ch->v.too_many[unit];
+    const int64_t au = ch->ubase + unit;
+    hb = ch->v.hits + ch->v.hit_off[au]; nh = ch->v.hit_off[au + 1] - ch->v.hit_off[au]; flags = ch->v.too_many[au];
   } else {
     if (!ctx_or_null) throw qmap::Error(QM_E_STATE, "merge of hit vectors that did not come from this thread's device context");
     qm_opts o; qm_opts_default(&o);
@@ -781,7 +949,7 @@ inline MergeResult merge_impl(bool fuzzy, bool leftMatches, bool rightMatches, s
 inline void mergeLeftRightHits(std::vector<QuasiAlignment>& leftHits, std::vector<QuasiAlignment>& rightHits,
                                std::vector<QuasiAlignment>& jointHits, uint32_t /*readLen*/, uint32_t maxNumHits, bool& tooManyHits,
                                HitCounters& hctr) {
-  qm_detail::merge_impl(false, true, true, leftHits, rightHits, jointHits, false, maxNumHits, tooManyHits, hctr, qmap::detail::last_ctx());
+  qm_detail::merge_impl(false, true, true, leftHits, rightHits, jointHits, false, maxNumHits, tooManyHits, hctr, qmap::detail::merge_ctx());
 }
 
 // include/RapMapUtils.hpp:864-1183
@@ -790,7 +958,7 @@ inline MergeResult mergeLeftRightHitsFuzzy(bool leftMatches, bool rightMatches, 
                                            rapmap::utils::MappingConfig& mc, uint32_t /*readLen*/, uint32_t maxNumHits, bool& tooManyHits,
                                            HitCounters& hctr) {
   return qm_detail::merge_impl(true, leftMatches, rightMatches, leftHits, rightHits, jointHits, mc.considerMultiPos, maxNumHits, tooManyHits,
-                               hctr, qmap::detail::last_ctx());
+                               hctr, qmap::detail::merge_ctx());
 }
 
 }  // namespace utils

@@ -156,6 +156,7 @@ struct ReadBatch {
   // stage entry "from intervals" (qm_h2m_kernel): read r's intervals are iv_in[iv_in_off[r] .. iv_in_off[r + 1]), its length len_in[r]
   // iv_in_cnt != null: the (offset, count) form the collector pass of the same call left behind (iv_off / iv_cnt), lengths from off1 / off2
   const qm_sa_interval_hit* iv_in; const long long* iv_in_off; const u32* iv_in_cnt; const int* len_in; const unsigned char* found_in;
+  int tune;                // profiling switches (QM_TUNE in the environment; no effect on results): 1 no first-probe prefetch, 2 no staged sanext entries
   int strict_check, max_interval;
   int sensitive;           // 0: --noSensitive (NIP skipping via SASearcher::lce, k-mer vote instead of coverage)
   double quasi_cov;
@@ -1307,7 +1308,7 @@ QM_DEV u32 stage_next_entries(const DevIndex& ix, const Strand<NS>& V, int p0, i
 template <int NS, int F>
 QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, const unsigned char* str, int L,
                         int startPos, bool haveInterval, u32 lb, u32 ub, long long& cov, u32& strandHits,
-                        u32& otherHits, IntervalList& out) {
+                        u32& otherHits, IntervalList& out, WaveMem<NS>& M, long long nslot, int npar, bool& pfPending) {
   const int k = ix.k, P = L - k + 1;
   QM_CNT(17, 1);
   int p = startPos;
@@ -1378,6 +1379,14 @@ QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, c
         { ExtQuery x2 = xq; if (x2.nq >= 0) x2.nq = cut - p - k; extend_search(ix, lbP, ubP, k, str + p, cut - p, lb, ub, mlen, V.dollar, qn, nq, &x2); }
     }
     QM_T(3);
+    if (pfPending) {
+      // the read's first extension has just consumed its loads, so everything older has landed -- among it the characters of the
+      // wave's NEXT read in the staging rows (requested when this read started; a first probe served from LDS waits for nothing,
+      // so this is the first point where that is certain).  Ask for that read's first probe now: it has the rest of this walk,
+      // hits->mappings and the write-out to arrive.
+      pfPending = false;
+      prefetch_first_probe<NS, F>(ix, B, M, nslot, npar);
+    }
     const bool more = !lastSearch && p + mlen < L;     // the walk continues at kp after this MMP
     const int kp = p + mlen - (k - 1);
     if (ub > lb && ub - lb < (u32)B.max_interval) {     // :577-618
@@ -1400,7 +1409,7 @@ QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, c
             int stride = 1;
             if ((F & QM_F_SEL) && mlen == k + B.max_mmp_ext) { const int st = B.max_mmp_ext + 1; if ((st & (st - 1)) == 0 && st <= 32) stride = st; }
             probe_window<NS, F>(ix, V, kp, (more && !(F & QM_F_NIP)) ? 32 : 1, stride);
-            if ((F & QM_F_SEL) && stride > 1 && more && V.lazy && ix.sanext && out.pf && 2 * out.pfcap >= 4 * QM_NEXT_SLOT) {
+            if ((F & QM_F_SEL) && stride > 1 && more && V.lazy && ix.sanext && out.pf && 2 * out.pfcap >= 4 * QM_NEXT_SLOT && !(B.tune & 2)) {
               stMask = stage_next_entries<NS>(ix, V, kp, stride, out.pf);
               stBase = kp; stStep = stride;
             }
@@ -1478,9 +1487,6 @@ QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M,
       if (width == 1) {
         const bool mine = !(F & QM_F_PH) && NS <= 8 && uniform(M.pfslot) == (u32)slot;
         seedR = probe_first<NS, F>(ix, S, p0, &M.tab[1][0], mine ? &M.pfb[0][0] : nullptr, M.pfid);
-        // (everything this wave had in flight has landed -- the round above waited for its loads, or the previous read's
-        // write-out did -- so the next read's characters are in the staging rows)
-        prefetch_first_probe<NS, F>(ix, B, M, slot + nw, par ^ 1);
       } else probe_window<NS, F>(ix, S, p0, width);
       width = 32;
     }
@@ -1500,6 +1506,8 @@ QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M,
   const FT wl = S.word_at(P - 1);
   const bool seedRF = seedR && Strand<NS>::flag(wl, FL_C, P - 1), seedRC = seedR && Strand<NS>::flag(wl, FL_F, P - 1);
   long long fwdCov = 0, rcCov = 0;
+  bool pfPending = !(F & QM_F_PH) && NS <= 8 && !(B.tune & 1);                  // the next read's first probe is still to be requested
+  const long long nslot = slot + nw; const int npar = par ^ 1;
   const bool useCoverageCheck = ((F & QM_F_NIP) == 0) && B.strict_check != 0;   // disableNIP_ && strictCheck_ (:138)
   const bool vote = !useCoverageCheck && B.strict_check != 0;
   if (vote) S.or_at(p0, Strand<NS>::bit(FL_V, 0));     // the scan's own KmerDirScore entry (:206-225)
@@ -1508,7 +1516,7 @@ QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M,
   if (fwdHit) {                                         // :247-254
     didCheckFwd = true;
     Iv v = S.tab[p0];
-    get_sa_hits<NS, F>(ix, B, S, fwdStr, L, p0, true, uniform(v.lb), uniform(v.ub), fwdCov, fwdHit, rcHit, fwdInts);
+    get_sa_hits<NS, F>(ix, B, S, fwdStr, L, p0, true, uniform(v.lb), uniform(v.ub), fwdCov, fwdHit, rcHit, fwdInts, M, nslot, npar, pfPending);
   }
   bool checkRC = useCoverageCheck ? (rcHit > 0) : (rcHit >= fwdHit);
   const bool fwdFirst = didCheckFwd;
@@ -1529,7 +1537,7 @@ QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M,
       wave_fence();
     }
     haveR = true;
-    get_sa_hits<NS, F>(ix, B, R, rcStr, L, 0, false, 0, 0, rcCov, rcHit, fwdHit, rcInts);
+    get_sa_hits<NS, F>(ix, B, R, rcStr, L, 0, false, 0, 0, rcCov, rcHit, fwdHit, rcInts, M, nslot, npar, pfPending);
   }
   bool checkFwd = useCoverageCheck ? (fwdHit > 0) : (fwdHit >= rcHit);
   if (!didCheckFwd && checkFwd) {                       // :271-278
@@ -1539,9 +1547,9 @@ QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M,
       Strand<NS> S2;
       setup_strand<NS>(ix, fwdStr, L, S2, &M.planes[0][0][0], M.tab[0]);
       S2.dollar = hasDollar;
-      get_sa_hits<NS, F>(ix, B, S2, fwdStr, L, 0, false, 0, 0, fwdCov, fwdHit, rcHit, fwdInts);
+      get_sa_hits<NS, F>(ix, B, S2, fwdStr, L, 0, false, 0, 0, fwdCov, fwdHit, rcHit, fwdInts, M, nslot, npar, pfPending);
     } else {
-      get_sa_hits<NS, F>(ix, B, S, fwdStr, L, 0, false, 0, 0, fwdCov, fwdHit, rcHit, fwdInts);
+      get_sa_hits<NS, F>(ix, B, S, fwdStr, L, 0, false, 0, 0, fwdCov, fwdHit, rcHit, fwdInts, M, nslot, npar, pfPending);
     }
   }
   if (useCoverageCheck) {                               // :283-288 (strictCheckSlack_: 1 with chain scoring, else 0)
