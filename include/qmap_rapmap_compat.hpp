@@ -34,6 +34,7 @@
 #define QMAP_RAPMAP_COMPAT_HPP
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
@@ -419,6 +420,7 @@ struct Batch {
   int64_t capUnits{0}, units{0};
   int joined{0}, packed{0}, readers{0};
   int state{0};                            // 0 free, 1 open, 2 closed (packing / on the device), 3 done, 4 failed
+  std::chrono::steady_clock::time_point t0;   // when the first group joined
   qm_opts opts{};
   qm_stage_view v{}; PinnedBuf arena;
   int rc{0}; std::string err;
@@ -437,6 +439,8 @@ class Service {
     const char* e = std::getenv("QMAP_COMPAT_CONTEXTS");
     int n = e && std::atoi(e) > 0 ? std::atoi(e) : 2;
     if (n > 8) n = 8;
+    const char* l = std::getenv("QMAP_COMPAT_LINGER_US");
+    lingerUs_ = l && std::atoi(l) >= 0 ? std::atoi(l) : 300;
     for (int i = 0; i < n; ++i) th_.emplace_back([this] { dispatch(); });
   }
   ~Service() {
@@ -459,6 +463,7 @@ class Service {
       b->opts = opts; b->units = 0; b->used1 = 0; b->used2 = 0; b->joined = 0; b->packed = 0; b->readers = 0; b->rc = 0; b->err.clear();
       b->o1[0] = 0; b->o2[0] = 0;
       b->state = 1; open_ = b;
+      b->t0 = std::chrono::steady_clock::now();
     }
     Place p{b, b->units, b->used1, b->used2};
     b->units += n; b->used1 += b1; b->used2 += b2; b->joined++; b->readers++;
@@ -479,6 +484,9 @@ class Service {
     }
   }
   void release(Batch* b) { std::lock_guard<std::mutex> lk(mu_); release_locked(b); }
+  // a collector starts / stops sending its groups here (how many there are tells the dispatchers how long to wait for company)
+  void attach() { std::lock_guard<std::mutex> lk(mu_); ++workers_; }
+  void detach() { std::lock_guard<std::mutex> lk(mu_); if (workers_ > 0) --workers_; }
  private:
   void release_locked(Batch* b) { if (--b->readers == 0 && b->state >= 3) b->state = 0; }
   void dispatch() {
@@ -487,7 +495,18 @@ class Service {
     while (!stop_) {
       Batch* b = nullptr;
       if (!ready_.empty()) { b = ready_.front(); ready_.pop_front(); }
-      else if (open_ && open_->joined > 0) { b = open_; open_ = nullptr; b->state = 2; }
+      else if (open_ && open_->joined > 0) {
+        // A pass has a fixed cost of about a millisecond whatever it carries, so an idle dispatcher does not run off with the
+        // first group that shows up when many workers are at it: it gives the others a moment -- until half of the workers
+        // this service has seen are in, or lingerUs_ after the first one came.  One worker alone never waits.
+        Batch* o = open_;
+        const int want = workers_ > 1 ? (workers_ + 1) / 2 : 1;
+        if (o->joined < want) {
+          const auto dl = o->t0 + std::chrono::microseconds(lingerUs_);
+          if (std::chrono::steady_clock::now() < dl) { cvWork_.wait_until(lk, dl); continue; }
+        }
+        b = o; open_ = nullptr; b->state = 2;
+      }
       if (!b) { cvWork_.wait(lk); continue; }
       cvWork_.wait(lk, [&] { return b->packed == b->joined || stop_; });      // the last joiners are still copying their characters
       if (stop_) { b->state = 4; break; }
@@ -521,6 +540,7 @@ class Service {
   Batch* open_{nullptr};
   std::vector<std::thread> th_;
   bool stop_{false};
+  int workers_{0}, lingerUs_{300};
 };
 // the services of this process, one per (index, device); created on first use, dropped when their index is closed (an index
 // that is never closed keeps its service until the process ends: the registry itself is never destroyed)
@@ -553,7 +573,8 @@ struct Chunk {
   Service* svc{nullptr}; Batch* batch{nullptr};
   int64_t cursor{0};
   void release() { if (batch && svc) svc->release(batch); batch = nullptr; nreads = 0; }
-  ~Chunk() { release(); }
+  void bind(Service* s) { if (svc != s) { if (svc) svc->detach(); svc = s; if (svc) svc->attach(); } }
+  ~Chunk() { release(); if (svc) svc->detach(); }
 };
 inline uint64_t next_gen() { static std::atomic<uint64_t> g{1}; return g++; }
 
@@ -700,9 +721,10 @@ class SACollector {
     for (int64_t i = 0; i < n; ++i) { b1 += left[i]->size(); b2 += right[i]->size(); }
     // join the batch that is open (qmap::detail::Service): this group's place in the batch's page-locked input buffers ...
     Service* svc = service_of(rmi_->handle(), rmi_->device());
+    ch->bind(svc);
     const Service::Place pl = svc->join(ch->opts, n, b1, b2);
     Batch* bt = pl.b;
-    ch->svc = svc; ch->batch = bt;
+    ch->batch = bt;
     // ... the reads packed there, next to the other workers' (the upload is a DMA straight out of these buffers) ...
     ch->key.resize(static_cast<size_t>(2 * n)); ch->keyLen.resize(static_cast<size_t>(2 * n));
     size_t p1 = pl.c1, p2 = pl.c2;

@@ -20,7 +20,7 @@ import emu  # noqa: E402
 NAMES = ["find_kmer calls", "slot loads", "setup_strand", "probe_window calls", "probe_window positions",
          "extend_wide calls", "extend_wide suffix lanes", "extend_wide 8B steps", "extend literal", "extend_wide width==1",
          "rank_sort calls", "rank_sort n", "single_interval calls", "single_interval n", "multi_interval calls",
-         "multi_interval m", "cmp_from steps", "get_sa_hits calls", "extension calls", "first-probe buckets served from the prefetch"]
+         "multi_interval m", "cmp_from steps", "get_sa_hits calls", "extension calls"]
 
 
 def main():

@@ -752,7 +752,6 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
     if (wantFound) B.found_out = c->d_found;
     B.iv_in = rq.ivIn; B.iv_in_off = rq.ivInOff; B.len_in = rq.lenIn; B.found_in = rq.foundIn;
     B.strict_check = o->strict_check; B.max_interval = o->max_interval; B.quasi_cov = o->quasi_cov; B.sensitive = o->sensitive; B.fuzzy = paired ? o->fuzzy : 0;
-    { static const int tune = getenv("QM_TUNE") ? atoi(getenv("QM_TUNE")) : 0; B.tune = tune; }   // profiling switches (ReadBatch::tune)
     if (rq.mode == QM_RUN_FROM_INTERVALS) B.fuzzy = o->fuzzy;   // the caller says what kind of list it wants (both orientations kept or not)
     if (o->sel_aln) {                                   // -s: chain scoring + per-wave scratch for chaining (qm_sel.inl)
       if ((rc = ensure(c->d_selscr, c->capSelScr, (int64_t)grid * 4 * (int64_t)qmk_sel_scratch_bytes()))) return rc;

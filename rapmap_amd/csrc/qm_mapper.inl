@@ -92,7 +92,7 @@ struct IntRec { u32 b, e; u32 len, q; };           // SAIntervalHit (RapMapUtils
 #define QM_PH_BLOCK_BITS 384
 #endif
 #ifndef QM_PH_SPEC
-#define QM_PH_SPEC 3      // BooPHF levels looked up per round of loads
+#define QM_PH_SPEC 2      // BooPHF levels looked up per round of loads (measured behind the pre-filter, round 4: 1 -> 164, 2 -> 170, 3 -> 164 M pairs/s)
 #endif
 struct OvfSlot { u32 key; u32 val; };              // overflow_: interval start -> length (>= 255); key ~0 empty
 struct PhRec { u64 key; u32 data; unsigned char len; unsigned char pad[3]; };
@@ -156,7 +156,6 @@ struct ReadBatch {
   // stage entry "from intervals" (qm_h2m_kernel): read r's intervals are iv_in[iv_in_off[r] .. iv_in_off[r + 1]), its length len_in[r]
   // iv_in_cnt != null: the (offset, count) form the collector pass of the same call left behind (iv_off / iv_cnt), lengths from off1 / off2
   const qm_sa_interval_hit* iv_in; const long long* iv_in_off; const u32* iv_in_cnt; const int* len_in; const unsigned char* found_in;
-  int tune;                // profiling switches (QM_TUNE in the environment; no effect on results): 1 no first-probe prefetch, 2 no staged sanext entries
   int strict_check, max_interval;
   int sensitive;           // 0: --noSensitive (NIP skipping via SASearcher::lce, k-mer vote instead of coverage)
   double quasi_cov;
@@ -196,12 +195,6 @@ struct WaveMem {
   // software pipeline of the persistent loop (see ReadStage below): raw characters of the next read, offsets of the next two
   u32 stage[64 * ((16 * NS + 1 + 63) / 64)];
   u32 ostage[2][4];
-  // the NEXT read's first probe, asked for while this read is mapped (prefetch_first_probe): four buckets of the dense table --
-  // first k-mer, last k-mer, their reverse complements -- as they sit in HBM, the bucket numbers they were read from, and the
-  // launch slot of the read they belong to
-  u32 pfb[4][8];
-  u32 pfid[4];
-  u32 pfslot;
 };
 
 // ------------------------------------------------------------------ bit helpers
@@ -289,24 +282,6 @@ __shared__ u64 qm_tim[4][10];
 #define QM_F_NIP 2     // --noSensitive: NIP skipping + k-mer vote
 #define QM_F_SEL 4     // --selAln: chain scoring in the collector (MMPs capped at k + maxMMPExtension), coverage slack 1
 #define QM_F_COLLECT 8 // stage entry: the collector alone (intervals + foundHit out, no hit list)
-
-// slot of a launch -> read, where a read's characters live, an offset out of the staging rows (used by the persistent loop's
-// software pipeline further down and by the first-probe prefetch)
-template <int F, int NS = 0>
-QM_DEV long long read_id(const ReadBatch& B, long long slot) {
-  if (!(F & QM_F_SEL) && NS <= 8) return slot;
-  return B.slowq ? uniform(B.slowq[slot]) : slot;
-}
-QM_DEV void read_src(const ReadBatch& B, long long read, const unsigned char*& src, const long long*& off, long long& unit) {
-  // seq1, off1, seq2, off2 sit next to each other in ReadBatch: mate m's pair of pointers is one indexed scalar load
-  const int paired = B.seq2 != nullptr ? 1 : 0;
-  const int mate = (int)(read & paired);
-  unit = read >> paired;
-  src = (&B.seq1)[2 * mate];
-  off = (const long long*)(&B.seq1)[2 * mate + 1];
-}
-QM_DEV long long staged_offset(const u32* o, int j) { return (long long)(((u64)uniform(o[2 * j + 1]) << 32) | (u64)uniform(o[2 * j])); }
-
 
 // -s caps every MMP but a read's first at k + maxMMPExtension characters (SACollector.hpp:557-575): what such an extension
 // compares is the handful of text characters behind the k-mer of each suffix of the interval.  sanext[i] holds them for
@@ -831,78 +806,12 @@ QM_DEV void probe_window(const DevIndex& ix, Strand<NS>& S, int p, int width, in
   QM_T(2);
 }
 
-// The first probe of the NEXT read of this wave, issued while the current read is mapped.  The first thing a read asks the
-// index is fixed by its characters alone -- its first k-mer and its last one, both strands (probe_first) -- and the characters
-// of the next read are already in the staging rows; so the four buckets are requested now, straight into LDS
-// (global_load_lds_dword: 32 lanes, one dword each), and the next read's probe_first finds them there instead of starting its
-// walk with a trip to HBM (one of the ~3-4 dependent trips of a read).  Purely a hint: probe_first takes a bucket from here
-// only when launch slot and bucket number agree with what it computes itself, anything else goes the usual way.
-// Skipped when the next read is not plain (shorter than 32 characters, longer than this kernel's slots, a character that is
-// not A C G T in either k-mer) -- those reads start like before.
-template <int NS, int F>
-QM_DEV void prefetch_first_probe(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M, long long nslot, int npar) {
-  if ((F & QM_F_PH) || NS > 8) return;
-  if (nslot >= B.nreads || (ix.hmask >> 32) != 0) return;
-  const int k = ix.k;
-  const unsigned char* src; const long long* off; long long unit;
-  read_src(B, read_id<F, NS>(B, nslot), src, off, unit);
-  const long long o0 = staged_offset(M.ostage[npar], 0), o1 = staged_offset(M.ostage[npar], 1);
-  const long long len64 = o1 - o0;
-  if (len64 > 64 * NS || len64 < 32) return;
-  const int len = (int)len64;
-  const int mis = (int)((unsigned long long)(src + o0) & 3ULL);
-  // lanes 0-7: characters [0, 32) of the next read, lanes 8-15: characters [len - 32, len); four per lane, packed like
-  // setup_strand packs them (first character in the top bits of the word)
-  unsigned char* scr = (unsigned char*)&M.pfb[0][0];          // 16 bytes of scratch: the area is free until the request below
-  LV<bool> bad;
-  QM_LANES(l) {
-    bad[l] = false;
-    if (l < 16) {
-      const int g = l >> 3, j = l & 7;
-      const int cpos = (g ? len - 32 : 0) + 4 * j;
-      const int bo = mis + cpos;
-      const u32 w0 = M.stage[bo >> 2], w1 = M.stage[(bo >> 2) + 1];
-      const u32 d = align_bytes(w1, w0, bo & 3);
-      const u32 t = (d & 0xdfdfdfdfu) ^ canon4(d, false);
-      const u32 valid = ~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t | 0x7f7f7f7fu);   // 0x80: A C G T in either case
-      const u32 x = (d >> 1) & 0x03030303u;
-      const u32 code = (x ^ ((x >> 1) & 0x01010101u)) & ((valid >> 7) * 3u);
-      scr[8 * g + 7 - j] = (unsigned char)((code * 0x40100401u) >> 24);
-      // the characters of this lane that belong to the k-mer: the first k of group 0, the last k of group 1
-      u32 need = 0;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { const int idx = 4 * j + c; if (g ? idx >= 32 - k : idx < k) need |= 0x80u << (8 * c); }
-      bad[l] = (~valid & need) != 0;
-    }
-  }
-  const u64 bm = ballot(bad);
-  wave_fence();
-  const bool ok0 = (bm & 0xffULL) == 0, ok1 = (bm & 0xff00ULL) == 0;
-  LV<u32> bk;
-  QM_LANES(l) {
-    const int sl = (l >> 3) & 3;                              // 0: first k-mer, 1: last k-mer, 2 / 3: their reverse complements
-    const u64 w = ((const u64*)scr)[sl & 1];
-    const u64 km = (sl & 1) ? (w & ((1ULL << (2 * k)) - 1ULL)) : (w >> (64 - 2 * k));
-    const u64 key = (sl & 2) ? word_rc(km, k) : km;
-    bk[l] = (u32)((u64)bucket_hash(key) & ix.hmask);
-  }
-  wave_fence();                                               // every lane has read its word: the scratch may be overwritten
-  QM_LANES(l) {
-    const int sl = (l >> 3) & 3;
-    const bool on = l < 32 && ((sl & 1) ? ok1 : ok0);
-    if (on) lds_dma_u32((const u32*)&ix.slots[bk[l]] + (l & 7), &M.pfb[0][0], l);
-    if (l < 32 && (l & 7) == 0) M.pfid[sl] = on ? bk[l] : 0xffffffffu;
-    if (l == 0) M.pfslot = (u32)nslot;
-  }
-}
-
 // The first probe of a read: position p (lanes 0 / 32: k-mer / reverse complement) and, in the same round of
 // loads, the read's last k-mer (position P-1, lanes 1 / 33).  The reverse complement of the last k-mer is the
 // FIRST k-mer of reverseRead(read), i.e. exactly what the reverse-complement pass would have to look up first;
 // its interval goes to rtab0 (= that strand's tab[0]).  Returns true when position P-1 was looked up here.
-// pre: the buckets prefetch_first_probe left for THIS read (WaveMem::pfb / pfid), or null
 template <int NS, int F>
-QM_DEV bool probe_first(const DevIndex& ix, Strand<NS>& S, int p, Iv* rtab0, const u32* pre = nullptr, const u32* preId = nullptr) {
+QM_DEV bool probe_first(const DevIndex& ix, Strand<NS>& S, int p, Iv* rtab0) {
   typedef typename Strand<NS>::FT FT;
   const int k = ix.k;
   const int last = S.P - 1;
@@ -918,33 +827,8 @@ QM_DEV bool probe_first(const DevIndex& ix, Strand<NS>& S, int p, Iv* rtab0, con
     kq[l] = l >= 32 ? rc : key;
   }
   wave_fence();
-  if (!(F & QM_F_PH)) {
-    LV<bool> rest;
-    QM_LANES(l) { rest[l] = want[l]; found[l] = false; val[l].lb = 0; val[l].ub = 0; }
-    if (pre) {
-      // lanes 0 / 1 / 32 / 33 ask about the first k-mer, the last one and their reverse complements: slots 0, 1, 2, 3 of the
-      // prefetch.  A bucket is taken from there when it is the bucket this lane would read; a key that may live in a later
-      // bucket (the overflow mark) goes the usual way.
-      QM_LANES(l) {
-        const int sl = (l & 1) + 2 * (l >> 5);
-        const u32 b = (u32)((u64)bucket_hash(kq[l]) & ix.hmask);
-        if (want[l] && (l & 31) < 2 && preId[sl] == b) {
-          const u32* w = pre + 8 * sl;
-          const u64 k0r = ((u64)w[1] << 32) | w[0], k1 = ((u64)w[3] << 32) | w[2];
-          const u64 k0 = k0r == ~0ULL ? k0r : (k0r & ~QM_BK_OVF);
-          const bool h0 = k0 == kq[l], h1 = k1 == kq[l];
-          if (h0 || h1) { found[l] = true; val[l].lb = h0 ? w[4] : w[6]; val[l].ub = h0 ? w[5] : w[7]; rest[l] = false; }
-          else if (k0r == ~0ULL || (k0r & QM_BK_OVF) == 0) rest[l] = false;      // not in the index
-          QM_CNT(19, 1);
-        }
-      }
-    }
-    if (ballot(rest)) {
-      LV<bool> f2; LV<Iv> v2;
-      find_dense_round(ix, kq, rest, f2, v2);
-      QM_LANES(l) { if (rest[l]) { found[l] = f2[l]; val[l] = v2[l]; } }
-    }
-  } else {
+  if (!(F & QM_F_PH)) find_dense_round(ix, kq, want, found, val);
+  else {
     ph_filter_round(ix, kq, want);
     QM_LANES(l) {
       bool hit = false; Iv v = {0, 0};
@@ -1033,8 +917,7 @@ QM_DEV int cmp_from(const DevIndex& ix, long long s, const unsigned char* q, int
 // compares the 16 bytes at offset 16c of the current round, so a 2x100 bp read needs one round for up to 8
 // suffixes: one coalesced SA load, then one round of text loads, instead of a dependent load per 8 bytes.
 QM_DEV bool extend_search_wide(const DevIndex& ix, u32 lbIn, u32 ubIn, int startAt, const unsigned char* q, int m0,
-                               u32& lbOut, u32& ubOut, int& lenOut, u32 qn, int nq, const ExtQuery* xq, ExtStage* xs,
-                               const u32* stagedNext = nullptr) {
+                               u32& lbOut, u32& ubOut, int& lenOut, u32 qn, int nq, const ExtQuery* xq, ExtStage* xs) {
   const int width = (int)(ubIn - lbIn - 1);
   if (width < 1 || width > 64) return false;
   if (xq && xq->nq >= 0 && ix.saext && !(nq > 0 && ix.sanext)) {
@@ -1082,19 +965,11 @@ QM_DEV bool extend_search_wide(const DevIndex& ix, u32 lbIn, u32 ubIn, int start
   if (nq > 0 && ix.sanext) {
     // a capped extension of a clean strand: the nq (<= QM_NEXT_BASES) query characters behind the k-mer, packed like the
     // table's entries (qn), against the entry of every suffix of the interval -- one lane per suffix, one load
-    LV<int> lc; LV<bool> on; LV<u32> ev;
-    if (stagedNext) {
-      // the entries of this interval were asked for together with those of the next few positions of the walk, when the
-      // strided probe that found them returned (stage_next_entries): no trip of its own
-      lds_dma_wait();
-      QM_LANES(l) { ev[l] = l < width ? stagedNext[l] : 0u; }
-    } else {
-      QM_LANES(l) { ev[l] = l < width ? ix.sanext[lbIn + 1 + l] : 0u; }
-    }
+    LV<int> lc; LV<bool> on;
     QM_LANES(l) {
       int v = -1;
       if (l < width) {
-        const u32 e = ev[l];
+        const u32 e = ix.sanext[lbIn + 1 + l];
         const u32 x = ((e & 0x0fffffffu) >> (28 - 2 * nq)) ^ qn;
         int matched = x ? ((__builtin_clz(x) - (32 - 2 * nq)) >> 1) : nq;
         const int nv = (int)(e >> 28);
@@ -1177,9 +1052,9 @@ QM_DEV bool extend_search_wide(const DevIndex& ix, u32 lbIn, u32 ubIn, int start
 // SASearcher::extendSearchNaive (SASearcher.hpp:88-309)
 QM_DEV void extend_search(const DevIndex& ix, u32 lbIn, u32 ubIn, int startAt, const unsigned char* q, int m0,
                           u32& lbOut, u32& ubOut, int& lenOut, bool qDollar, u32 qn = 0, int nq = 0, const ExtQuery* xq = nullptr,
-                          ExtStage* xs = nullptr, const u32* stagedNext = nullptr) {
+                          ExtStage* xs = nullptr) {
   int rel;
-  if (!qDollar && extend_search_wide(ix, lbIn, ubIn, startAt, q, m0, lbOut, ubOut, lenOut, qn, nq, xq, xs, stagedNext)) return;
+  if (!qDollar && extend_search_wide(ix, lbIn, ubIn, startAt, q, m0, lbOut, ubOut, lenOut, qn, nq, xq, xs)) return;
   QM_CNT(8, 1);
   if (ubIn - lbIn == 2) {                         // :109-126
     lbIn += 1;
@@ -1269,54 +1144,18 @@ QM_DEV void ext_query(const u64* planes, int pos, int rem, ExtQuery& xq) {
   for (int t = 0; t < 3; ++t) xq.q[t] = (w[t] << sh) | ((w[t + 1] >> 1) >> (63 - sh));
 }
 
-// -s: the capped MMPs of a matching read advance by a fixed step, so after the strided probe at p0 the walk's next few
-// extensions are known in advance -- positions p0, p0 + step, ... -- and each would make a dependent trip to ix.sanext for the
-// entries of its k-mer's interval.  Ask for all of them NOW, in one instruction: the entries of position p0 + j * step go to
-// area[16 j ..) (intervals of more than 16 suffixes are left out: their extension loads for itself).  Returns the mask of
-// the positions that were staged.  area: 64 dwords of LDS.
-#define QM_NEXT_SLOT 16
-template <int NS>
-QM_DEV u32 stage_next_entries(const DevIndex& ix, const Strand<NS>& V, int p0, int step, u32* area) {
-  u32 first[4], cnt[4]; u32 mask = 0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int q = p0 + j * step;
-    first[j] = 0; cnt[j] = 0;
-    if (q < V.P && j * step < 32) {
-      const typename Strand<NS>::FT w = V.word_at(q);
-      if (Strand<NS>::flag(w, FL_K, q) && Strand<NS>::flag(w, FL_F, q) && Strand<NS>::flag(w, FL_E, q)) {
-        const Iv v = V.tab[q];
-        const u32 lb = uniform(v.lb), ub = uniform(v.ub);
-        const u32 lbIn = lb ? lb - 1 : 0;                  // the fence get_sa_hits passes to the extension (SACollector.hpp:553)
-        const u32 c = ub > lbIn + 1 ? ub - lbIn - 1 : 0;
-        if (c >= 1 && c <= QM_NEXT_SLOT) { first[j] = lbIn + 1; cnt[j] = c; mask |= 1u << j; }
-      }
-    }
-  }
-  if (!mask) return 0;
-  QM_LANES(l) {
-    const int j = l >> 4, t = l & 15;
-    const u32 f = j == 0 ? first[0] : (j == 1 ? first[1] : (j == 2 ? first[2] : first[3]));
-    const u32 c = j == 0 ? cnt[0] : (j == 1 ? cnt[1] : (j == 2 ? cnt[2] : cnt[3]));
-    if ((u32)t < c) lds_dma_u32(ix.sanext + f + t, area, l);
-  }
-  return mask;
-}
-
 // ------------------------------------------------------------------ stage 3
 // SACollector::getSAHits_ (SACollector.hpp:441-677), NIP disabled
 template <int NS, int F>
 QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, const unsigned char* str, int L,
                         int startPos, bool haveInterval, u32 lb, u32 ub, long long& cov, u32& strandHits,
-                        u32& otherHits, IntervalList& out, WaveMem<NS>& M, long long nslot, int npar, bool& pfPending) {
+                        u32& otherHits, IntervalList& out) {
   const int k = ix.k, P = L - k + 1;
   QM_CNT(17, 1);
   int p = startPos;
   bool skip = haveInterval, lastSearch = false;
   int prevMMPEnd = 0;
   int width = 1;      // first window of a pass: a single position; after an MMP jump the walk crosses ~k positions
-  // -s: the sanext entries staged for the next positions of the walk (stage_next_entries): first position, step, which
-  int stBase = 0, stStep = 0; u32 stMask = 0;
   while (true) {
     if (!skip) {
       if (p >= P) break;
@@ -1369,24 +1208,11 @@ QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, c
       u32 qn = 0; int nq = 0;
       if (V.lazy && nqc >= 1 && nqc <= QM_NEXT_BASES) { qn = (u32)clean_kmer(V.planes, p + k, nqc); nq = nqc; }
       ExtQuery xc = xq; if (xc.nq >= 0 && !firstAttempt) xc.nq = cut - p - k;      // a capped extension compares fewer characters
-      const u32* staged = nullptr;
-      if (stMask && !firstAttempt && nq > 0 && p >= stBase) {
-        const int dj = p - stBase, j = stStep > 0 ? dj / stStep : 4;
-        if (j < 4 && j * stStep == dj && ((stMask >> j) & 1) && ub - lb - 1 <= (u32)QM_NEXT_SLOT) staged = out.pf + QM_NEXT_SLOT * j;
-      }
-      extend_search(ix, lb, ub, k, str + p, (firstAttempt ? L : cut) - p, lb, ub, mlen, V.dollar, firstAttempt ? 0u : qn, firstAttempt ? 0 : nq, &xc, nullptr, staged);
+      extend_search(ix, lb, ub, k, str + p, (firstAttempt ? L : cut) - p, lb, ub, mlen, V.dollar, firstAttempt ? 0u : qn, firstAttempt ? 0 : nq, &xc);
       if (firstAttempt && !(mlen >= L) && mlen >= k + B.max_mmp_ext)
         { ExtQuery x2 = xq; if (x2.nq >= 0) x2.nq = cut - p - k; extend_search(ix, lbP, ubP, k, str + p, cut - p, lb, ub, mlen, V.dollar, qn, nq, &x2); }
     }
     QM_T(3);
-    if (pfPending) {
-      // the read's first extension has just consumed its loads, so everything older has landed -- among it the characters of the
-      // wave's NEXT read in the staging rows (requested when this read started; a first probe served from LDS waits for nothing,
-      // so this is the first point where that is certain).  Ask for that read's first probe now: it has the rest of this walk,
-      // hits->mappings and the write-out to arrive.
-      pfPending = false;
-      prefetch_first_probe<NS, F>(ix, B, M, nslot, npar);
-    }
     const bool more = !lastSearch && p + mlen < L;     // the walk continues at kp after this MMP
     const int kp = p + mlen - (k - 1);
     if (ub > lb && ub - lb < (u32)B.max_interval) {     // :577-618
@@ -1409,10 +1235,6 @@ QM_DEV void get_sa_hits(const DevIndex& ix, const ReadBatch& B, Strand<NS>& V, c
             int stride = 1;
             if ((F & QM_F_SEL) && mlen == k + B.max_mmp_ext) { const int st = B.max_mmp_ext + 1; if ((st & (st - 1)) == 0 && st <= 32) stride = st; }
             probe_window<NS, F>(ix, V, kp, (more && !(F & QM_F_NIP)) ? 32 : 1, stride);
-            if ((F & QM_F_SEL) && stride > 1 && more && V.lazy && ix.sanext && out.pf && 2 * out.pfcap >= 4 * QM_NEXT_SLOT && !(B.tune & 2)) {
-              stMask = stage_next_entries<NS>(ix, V, kp, stride, out.pf);
-              stBase = kp; stStep = stride;
-            }
           }
           const typename Strand<NS>::FT wk = V.word_at(kp);
           strandHits += Strand<NS>::flag(wk, FL_F, kp) ? 1u : 0u; otherHits += Strand<NS>::flag(wk, FL_C, kp) ? 1u : 0u;
@@ -1460,10 +1282,9 @@ QM_DEV void reverse_string(const unsigned char* fs, unsigned char* rs, int len) 
 
 // SACollector::operator() (SACollector.hpp:108-362), disableNIP_ == true.
 // M.str[0] = read (upper-cased); M.str[1] receives reverseRead(read) when that strand is walked.  Returns foundHit.
-// slot / nw / par: this read's place in the launch (the wave's next read is slot + nw, its offsets sit in ostage[par ^ 1])
 template <int NS, int F>
 QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M, int L, bool hasDollar,
-                         IntervalList& fwdInts, IntervalList& rcInts, long long slot, long long nw, int par) {
+                         IntervalList& fwdInts, IntervalList& rcInts) {
   const int k = ix.k, P = L - k + 1;
   const unsigned char* fwdStr = M.str[0];
   unsigned char* rcStr = M.str[1];
@@ -1484,10 +1305,8 @@ QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M,
   bool seedR = false;                                  // the rc strand's first k-mer was looked up with the first probe
   while (p0 < P) {
     if (!S.test(FL_K, p0)) {
-      if (width == 1) {
-        const bool mine = !(F & QM_F_PH) && NS <= 8 && uniform(M.pfslot) == (u32)slot;
-        seedR = probe_first<NS, F>(ix, S, p0, &M.tab[1][0], mine ? &M.pfb[0][0] : nullptr, M.pfid);
-      } else probe_window<NS, F>(ix, S, p0, width);
+      if (width == 1) seedR = probe_first<NS, F>(ix, S, p0, &M.tab[1][0]);
+      else probe_window<NS, F>(ix, S, p0, width);
       width = 32;
     }
     int kend = known_end(S, p0);
@@ -1506,8 +1325,6 @@ QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M,
   const FT wl = S.word_at(P - 1);
   const bool seedRF = seedR && Strand<NS>::flag(wl, FL_C, P - 1), seedRC = seedR && Strand<NS>::flag(wl, FL_F, P - 1);
   long long fwdCov = 0, rcCov = 0;
-  bool pfPending = !(F & QM_F_PH) && NS <= 8 && !(B.tune & 1);                  // the next read's first probe is still to be requested
-  const long long nslot = slot + nw; const int npar = par ^ 1;
   const bool useCoverageCheck = ((F & QM_F_NIP) == 0) && B.strict_check != 0;   // disableNIP_ && strictCheck_ (:138)
   const bool vote = !useCoverageCheck && B.strict_check != 0;
   if (vote) S.or_at(p0, Strand<NS>::bit(FL_V, 0));     // the scan's own KmerDirScore entry (:206-225)
@@ -1516,7 +1333,7 @@ QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M,
   if (fwdHit) {                                         // :247-254
     didCheckFwd = true;
     Iv v = S.tab[p0];
-    get_sa_hits<NS, F>(ix, B, S, fwdStr, L, p0, true, uniform(v.lb), uniform(v.ub), fwdCov, fwdHit, rcHit, fwdInts, M, nslot, npar, pfPending);
+    get_sa_hits<NS, F>(ix, B, S, fwdStr, L, p0, true, uniform(v.lb), uniform(v.ub), fwdCov, fwdHit, rcHit, fwdInts);
   }
   bool checkRC = useCoverageCheck ? (rcHit > 0) : (rcHit >= fwdHit);
   const bool fwdFirst = didCheckFwd;
@@ -1537,7 +1354,7 @@ QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M,
       wave_fence();
     }
     haveR = true;
-    get_sa_hits<NS, F>(ix, B, R, rcStr, L, 0, false, 0, 0, rcCov, rcHit, fwdHit, rcInts, M, nslot, npar, pfPending);
+    get_sa_hits<NS, F>(ix, B, R, rcStr, L, 0, false, 0, 0, rcCov, rcHit, fwdHit, rcInts);
   }
   bool checkFwd = useCoverageCheck ? (fwdHit > 0) : (fwdHit >= rcHit);
   if (!didCheckFwd && checkFwd) {                       // :271-278
@@ -1547,9 +1364,9 @@ QM_DEV bool collect_read(const DevIndex& ix, const ReadBatch& B, WaveMem<NS>& M,
       Strand<NS> S2;
       setup_strand<NS>(ix, fwdStr, L, S2, &M.planes[0][0][0], M.tab[0]);
       S2.dollar = hasDollar;
-      get_sa_hits<NS, F>(ix, B, S2, fwdStr, L, 0, false, 0, 0, fwdCov, fwdHit, rcHit, fwdInts, M, nslot, npar, pfPending);
+      get_sa_hits<NS, F>(ix, B, S2, fwdStr, L, 0, false, 0, 0, fwdCov, fwdHit, rcHit, fwdInts);
     } else {
-      get_sa_hits<NS, F>(ix, B, S, fwdStr, L, 0, false, 0, 0, fwdCov, fwdHit, rcHit, fwdInts, M, nslot, npar, pfPending);
+      get_sa_hits<NS, F>(ix, B, S, fwdStr, L, 0, false, 0, 0, fwdCov, fwdHit, rcHit, fwdInts);
     }
   }
   if (useCoverageCheck) {                               // :283-288 (strictCheckSlack_: 1 with chain scoring, else 0)
@@ -1910,6 +1727,19 @@ struct WaveAlloc { long long base; int used; long long ivBase; int ivUsed; };   
 //   ostage[j]  two offsets (4 dwords) of a read: slot parity j holds the current read's, j ^ 1 the next one's
 // slot of a launch -> read: the identity, except in the slow pass of -s and in the long-read pass (NS > 8), whose launches walk
 // a queue of reads the first pass set aside
+template <int F, int NS = 0>
+QM_DEV long long read_id(const ReadBatch& B, long long slot) {
+  if (!(F & QM_F_SEL) && NS <= 8) return slot;
+  return B.slowq ? uniform(B.slowq[slot]) : slot;
+}
+QM_DEV void read_src(const ReadBatch& B, long long read, const unsigned char*& src, const long long*& off, long long& unit) {
+  // seq1, off1, seq2, off2 sit next to each other in ReadBatch: mate m's pair of pointers is one indexed scalar load
+  const int paired = B.seq2 != nullptr ? 1 : 0;
+  const int mate = (int)(read & paired);
+  unit = read >> paired;
+  src = (&B.seq1)[2 * mate];
+  off = (const long long*)(&B.seq1)[2 * mate + 1];
+}
 // request the two offsets of the read in `slot` into ostage[par]
 template <int NS, int F>
 QM_DEV void stage_offsets(const ReadBatch& B, long long slot, WaveMem<NS>& M, int par) {
@@ -1918,6 +1748,7 @@ QM_DEV void stage_offsets(const ReadBatch& B, long long slot, WaveMem<NS>& M, in
   read_src(B, read_id<F, NS>(B, slot), src, off, unit);
   QM_LANES(l) { if (l < 4) lds_dma_u32((const u32*)(off + unit) + l, M.ostage[par], l); }
 }
+QM_DEV long long staged_offset(const u32* o, int j) { return (long long)(((u64)uniform(o[2 * j + 1]) << 32) | (u64)uniform(o[2 * j])); }
 // turn the offsets in ostage[par] (which belong to the read in `slot`, and have landed) into the request for its characters
 template <int NS, int F>
 QM_DEV void stage_chars(const ReadBatch& B, long long slot, WaveMem<NS>& M, int par) {
@@ -2060,7 +1891,7 @@ QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, lon
   IntervalList fi, ri;
   fi.lds = (QM_LDS(IntRec)*)M.ints[0]; ri.lds = (QM_LDS(IntRec)*)M.ints[1];
   fi.ovf = (IntRec*)(gscr + 3 * QM_GCAP); ri.ovf = fi.ovf + QM_IOVF;
-  const bool foundHit = collect_read<NS, F>(ix, B, M, len, hasDollar, fi, ri, slot, nw, par);
+  const bool foundHit = collect_read<NS, F>(ix, B, M, len, hasDollar, fi, ri);
   QM_T(4);
   if (B.iv_out || B.found_out || (F & QM_F_COLLECT)) lds_dma_wait();   // the staged prefetch must have landed before any store follows it
   if (B.iv_out) dump_intervals(B, read, mate, fi, ri, wa.ivBase, wa.ivUsed);

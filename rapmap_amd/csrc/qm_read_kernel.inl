@@ -40,7 +40,6 @@ __global__ __launch_bounds__(64 * WavesPerBlock<NS>::value, WPS) void qm_read_ke
 #endif
   // reads gw, gw + nw, ...: characters of the next read and offsets of the one after are staged in LDS while a read is mapped
   WaveMem<NS>& M = mem[wave];
-  if ((threadIdx.x & 63) == 0) M.pfslot = ~0u;            // no first-probe prefetch yet (LDS keeps what the previous kernel left)
   stage_offsets<NS, F>(B, gw, M, 0);
   lds_dma_wait();
   stage_chars<NS, F>(B, gw, M, 0);

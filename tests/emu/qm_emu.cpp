@@ -78,7 +78,7 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
       // it -- the first-probe prefetch for the wave's next read -- runs here as it does on the device
       const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP) | (o->sel_aln ? QM_F_SEL : 0);
 #define QE_CALL(NS_, F_) { const long long NW = 3; static WaveMem<NS_> Ms[3];                                                  \
-        for (long long w = 0; w < NW; ++w) { WaveMem<NS_>& M = Ms[w]; M.pfslot = ~0u;                                              \
+        for (long long w = 0; w < NW; ++w) { WaveMem<NS_>& M = Ms[w];                                              \
           stage_offsets<NS_, F_>(B, w, M, 0); stage_chars<NS_, F_>(B, w, M, 0); stage_offsets<NS_, F_>(B, w + NW, M, 1);          \
           int par = 0;                                                                                                             \
           for (long long r = w; r < nreads; r += NW) {                                                                             \
@@ -102,7 +102,7 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
       else {
         const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP);
         for (long long r = 0; r < (long long)q.size(); ++r) {
-#define QE_LONG(F_) { static WaveMem<32> M; M.pfslot = ~0u; stage_offsets<32, F_>(S2, r, M, 0); stage_chars<32, F_>(S2, r, M, 0); \
+#define QE_LONG(F_) { static WaveMem<32> M; stage_offsets<32, F_>(S2, r, M, 0); stage_chars<32, F_>(S2, r, M, 0); \
                       map_read<32, F_>(ix, S2, read_id<F_, 32>(S2, r), r, S2.nreads, 0, M, gs.data(), wa[r % 7]); }
           switch (F) { case 0: QE_LONG(0) break; case 1: QE_LONG(1) break; case 2: QE_LONG(2) break; default: QE_LONG(3) break; }
 #undef QE_LONG
@@ -125,7 +125,7 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
         ReadBatch S2 = B; S2.slowq = q.data(); S2.nreads = (long long)q.size();
         const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP) | QM_F_SEL;
         for (long long r = 0; r < (long long)q.size(); ++r) {
-#define QE_LONGS(F_) { static WaveMem<32> M; M.pfslot = ~0u; stage_offsets<32, F_>(S2, r, M, 0); stage_chars<32, F_>(S2, r, M, 0); \
+#define QE_LONGS(F_) { static WaveMem<32> M; stage_offsets<32, F_>(S2, r, M, 0); stage_chars<32, F_>(S2, r, M, 0); \
                        map_read<32, F_>(ix, S2, read_id<F_, 32>(S2, r), r, S2.nreads, 0, M, gs.data(), wa[r % 7], selscr, nullptr); }
           switch (F) { case 4: QE_LONGS(4) break; case 5: QE_LONGS(5) break; case 6: QE_LONGS(6) break; default: QE_LONGS(7) break; }
 #undef QE_LONGS
@@ -142,9 +142,9 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
       ReadBatch S2 = B; S2.slowq = q.data(); S2.dyn = &dyn; S2.nreads = (long long)q.size(); S2.iv_out = nullptr;
       const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP) | QM_F_SEL;
       for (long long r = 0; r < (long long)q.size(); ++r) {
-#define QE_SLOW(NS_, F_) { static WaveMem<NS_> M; M.pfslot = ~0u; stage_offsets<NS_, F_>(S2, r, M, 0); stage_chars<NS_, F_>(S2, r, M, 0); \
+#define QE_SLOW(NS_, F_) { static WaveMem<NS_> M; stage_offsets<NS_, F_>(S2, r, M, 0); stage_chars<NS_, F_>(S2, r, M, 0); \
                            map_read<NS_, F_>(ix, S2, read_id<F_>(S2, r), r, S2.nreads, 0, M, gs.data(), wa[r % 7], selscr, &sellds, &dyn); }
-#define QE_SLOWL(F_) { static WaveMem<32> M; M.pfslot = ~0u; stage_offsets<32, F_>(S2, r, M, 0); stage_chars<32, F_>(S2, r, M, 0); \
+#define QE_SLOWL(F_) { static WaveMem<32> M; stage_offsets<32, F_>(S2, r, M, 0); stage_chars<32, F_>(S2, r, M, 0); \
                        map_read<32, F_>(ix, S2, read_id<F_, 32>(S2, r), r, S2.nreads, 0, M, gs.data(), wa[r % 7], selscr, &sellds, &dyn); }
         if (rawLen(q[(size_t)r]) > 64 * ns) { switch (F) { case 4: QE_SLOWL(4) break; case 5: QE_SLOWL(5) break; case 6: QE_SLOWL(6) break; default: QE_SLOWL(7) break; } }
         else
