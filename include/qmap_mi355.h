@@ -30,7 +30,7 @@ typedef enum qm_status {
   QM_E_IO = -2,          /* index file missing / malformed */
   QM_E_NOGPU = -3,       /* no HIP device, or HIP call failed */
   QM_E_UNSUPPORTED = -4, /* option / index variant not implemented on the device path */
-  QM_E_TOOLONG = -5,     /* a read is longer than QM_MAX_LONG_READ_LEN (QM_MAX_READ_LEN with -s and --dpBandwidth beyond 0..97) */
+  QM_E_TOOLONG = -5,     /* a read is longer than QM_MAX_LONG_READ_LEN */
   QM_E_NOMEM = -6,
   QM_E_STATE = -7,       /* call order (e.g. fetch before map) */
   QM_E_FORMAT = -8       /* malformed FASTA/FASTQ input */
@@ -39,9 +39,9 @@ typedef enum qm_status {
 /* Reads of up to QM_MAX_READ_LEN characters are mapped by the main kernels (64-character slot classes 2 / 3 / 4 / 8).  Longer
  * reads of a batch -- up to QM_MAX_LONG_READ_LEN -- are set aside by the main launch and mapped by a second, small launch of
  * 32-slot kernels (the reference takes any std::string, include/SACollector.hpp:108); with -s the same happens in the
- * collector pass and the alignment kernel runs in its long-image editions.  Beyond QM_MAX_LONG_READ_LEN -- and beyond
- * QM_MAX_READ_LEN with -s when --dpBandwidth is not in 0..97 (the full-band ring of the alignment kernel holds every column of a
- * 512-base alignment and no more) -- the call fails with QM_E_TOOLONG. */
+ * collector pass and the alignment kernel runs in its long-image editions (with --dpBandwidth beyond 97 or negative: on blocks
+ * in device memory, a ring that holds every column of a 2048-base alignment -- slow, and rare).  Beyond QM_MAX_LONG_READ_LEN the
+ * call fails with QM_E_TOOLONG. */
 #define QM_MAX_READ_LEN 512
 #define QM_MAX_LONG_READ_LEN 2048
 

@@ -36,6 +36,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -441,6 +442,7 @@ class Service {
     if (n > 8) n = 8;
     const char* l = std::getenv("QMAP_COMPAT_LINGER_US");
     lingerUs_ = l && std::atoi(l) >= 0 ? std::atoi(l) : 300;
+    debug_ = std::getenv("QMAP_COMPAT_DEBUG") != nullptr;
     for (int i = 0; i < n; ++i) th_.emplace_back([this] { dispatch(); });
   }
   ~Service() {
@@ -510,19 +512,29 @@ class Service {
       if (!b) { cvWork_.wait(lk); continue; }
       cvWork_.wait(lk, [&] { return b->packed == b->joined || stop_; });      // the last joiners are still copying their characters
       if (stop_) { b->state = 4; break; }
+      const auto tw = std::chrono::steady_clock::now();
       lk.unlock();
       int rc = 0; std::string err;
       if (!ctx) { rc = qm_ctx_create(ix_, device_, &ctx); if (rc) { err = qm_last_error(); ctx = nullptr; } }
+      auto t1 = tw, t2 = tw, t3 = tw;
       if (!rc) {
         int64_t nHits = 0; qm_counters c{};
         rc = qm_map_pairs_stages(ctx, &b->opts, b->units, b->s1, b->o1, b->s2, b->o2, &nHits, &c);
+        t1 = std::chrono::steady_clock::now();
         int64_t need = 0;
         if (!rc) rc = qm_stage_bytes(ctx, &need);
         if (!rc) {
           try { b->arena.need(static_cast<size_t>(need)); } catch (const Error& e) { rc = e.code(); err = e.what(); }
         }
+        t2 = std::chrono::steady_clock::now();
         if (!rc) rc = qm_fetch_stages(ctx, b->arena.p, static_cast<int64_t>(b->arena.cap), &b->v);
+        t3 = std::chrono::steady_clock::now();
         if (rc && err.empty()) err = qm_last_error();
+      }
+      if (debug_) {
+        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return (long long)std::chrono::duration_cast<std::chrono::microseconds>(c - a).count(); };
+        std::fprintf(stderr, "[qmap service] batch of %lld pairs in %d groups: waited %lld us for company / packers, map %lld us, arena %lld us, fetch %lld us\n",
+                     (long long)b->units, b->joined, us(b->t0, tw), us(tw, t1), us(t1, t2), us(t2, t3));
       }
       lk.lock();
       b->rc = rc; b->err = err; b->state = rc ? 4 : 3;
@@ -541,6 +553,7 @@ class Service {
   std::vector<std::thread> th_;
   bool stop_{false};
   int workers_{0}, lingerUs_{300};
+  bool debug_{false};
 };
 // the services of this process, one per (index, device); created on first use, dropped when their index is closed (an index
 // that is never closed keeps its service until the process ends: the registry itself is never destroyed)

@@ -39,6 +39,7 @@ hipError_t qmk_sel_slots(const void* pair_batch, hipStream_t st);
 hipError_t qmk_sel_plan(const void* pair_batch, const void* sel_batch, hipStream_t st);
 hipError_t qmk_sel_align_finish(const void* pair_batch, const void* sel_batch, int num_cu, hipStream_t st);
 size_t qmk_sel_task_bytes(void);
+size_t qmk_sel_gmem_rows_bytes(int num_cu);   // device memory of qm_sel_align_gmem_kernel's alignment blocks (long reads under a band beyond 97)
 hipError_t qmk_sel_compact(const void* pair_batch, const void* tmp, const void* toff, hipStream_t st);
 hipError_t qmk_pair_count(const void* pair_batch, hipStream_t st);
 hipError_t qmk_pair_write(const void* pair_batch, hipStream_t st);

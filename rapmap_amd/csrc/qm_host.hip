@@ -135,6 +135,7 @@ struct qm_ctx {
   // -s (selective alignment) work areas
   uint32_t* d_txpOff = nullptr; int32_t* d_txpLen = nullptr;
   unsigned char* d_selscr = nullptr; int64_t capSelScr = 0;
+  unsigned char* d_kswRows = nullptr; int64_t capKswRows = 0;   // -s: alignment blocks of the device-memory edition (long reads, band beyond 97)
   long long* d_slowq = nullptr; int64_t capSlowq = 0;          // -s slow pass: queue, per-wave scratch descriptors and their memory
   unsigned char* d_dyn = nullptr; int64_t capDyn = 0; unsigned char* d_dynmem = nullptr; int64_t capDynMem = 0;
   long long* d_toff = nullptr; int64_t capToff = 0;
@@ -444,7 +445,7 @@ int qm_ctx_destroy(qm_ctx* c) {
   }
   void* ptrs[] = {c->d_cnt, c->d_lcnt, c->d_loff, c->d_lists, c->d_hits, c->d_offs,
                   c->d_scal, c->d_gscr, c->d_scanTmp, c->d_seq1, c->d_seq2, c->d_off1, c->d_off2, c->d_iv, c->d_ivcnt, c->d_ivoff, c->d_found, c->d_tooMany, c->d_ivIn, c->d_ivInOff, c->d_lenIn, c->d_foundIn,
-                  c->d_selscr, c->d_slowq, c->d_dyn, c->d_dynmem, c->d_toff, c->d_tmp, c->d_tkeys, c->d_tsc, c->d_tref, c->d_tcix, c->d_tasks};
+                  c->d_selscr, c->d_kswRows, c->d_slowq, c->d_dyn, c->d_dynmem, c->d_toff, c->d_tmp, c->d_tkeys, c->d_tsc, c->d_tref, c->d_tcix, c->d_tasks};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
@@ -695,8 +696,8 @@ static DevIndex dev_index(const qm_ctx* c) {
 // the longest read a call takes: QM_MAX_LONG_READ_LEN; with -s only while the band's ring edition of the alignment kernel has a
 // long-image form (--dpBandwidth 0 .. 97; the full-band ring holds every column of a 512-base alignment and no more)
 static int len_limit(const qm_opts* o) {
-  if (!o->sel_aln) return QM_MAX_LONG_READ_LEN;
-  return (o->dp_bandwidth >= 0 && o->dp_bandwidth <= 97) ? QM_MAX_LONG_READ_LEN : QM_MAX_READ_LEN;
+  (void)o;                                                   // (round 4: with -s too, whatever the band -- a band beyond 97 takes the device-memory edition of the alignment kernel)
+  return QM_MAX_LONG_READ_LEN;
 }
 
 static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n, const void* d_seq1, const void* d_off1, const void* d_seq2,
@@ -953,6 +954,11 @@ static int run_stage_b(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
     A.txp_off = c->d_txpOff; A.txp_len = c->d_txpLen; A.tmp = c->d_tmp; A.toff = c->d_toff; A.tkeys = c->d_tkeys; A.tsc = c->d_tsc;
     A.match = o->match_score; A.mismatch = o->mismatch_penalty; A.gap_open = o->gap_open; A.gap_extend = o->gap_extend;
     A.long_reads = rq.longReads ? 1 : 0;
+    if (rq.longReads && !rq.mergeOnly && sel_ksw_ring_slots(o->dp_bandwidth) > 128) {
+      // reads beyond QM_MAX_READ_LEN under a band beyond 97: the alignment blocks of that (slow, rare) edition live in device memory
+      if ((rc = ensure(c->d_kswRows, c->capKswRows, (int64_t)qmk_sel_gmem_rows_bytes(c->numCU)))) return rc;
+      A.ksw_rows = c->d_kswRows;
+    }
     A.short_len = rq.shortLen;
     A.bandwidth = o->dp_bandwidth; A.hard_filter = o->hard_filter; A.policy = o->aln_policy; A.min_score_fraction = o->min_score_fraction;
     HIPCHK(hipMemsetAsync(c->d_cnt + n, 0, sizeof(uint32_t), c->stream));

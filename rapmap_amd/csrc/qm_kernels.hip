@@ -153,6 +153,19 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(8, 8
   for (unsigned long long t = ((unsigned long long)blockIdx.x * WAVES + wave) * 4; t < nt; t += (unsigned long long)gridDim.x * (4 * WAVES))
     sel_tasks_align_rows<RING, MAXLEN>(P, A, t, nt, rows[wave], (const QM_LDS(unsigned char)*)codes);
 }
+// reads beyond QM_MAX_READ_LEN under a band beyond 97: the same row kernel on blocks in device memory (QM_KSW_RING_GMEM)
+#define QMK_GMEM_WAVES 2
+__global__ __launch_bounds__(64 * QMK_GMEM_WAVES) void qm_sel_align_gmem_kernel(PairBatch P, SelBatch A) {
+  typedef KswRowT<QM_KSW_RING_GMEM, QM_KSW_MAXLEN_LONG> Row;
+  __shared__ unsigned char codes[512];
+  sel_ksw_fill_codes((QM_LDS(unsigned char)*)codes, (int)threadIdx.x, 64 * QMK_GMEM_WAVES);
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  Row* rows = (Row*)A.ksw_rows + ((size_t)blockIdx.x * QMK_GMEM_WAVES + (size_t)wave) * 4;
+  const unsigned long long nt = *A.ntasks;
+  for (unsigned long long t = ((unsigned long long)blockIdx.x * QMK_GMEM_WAVES + wave) * 4; t < nt; t += (unsigned long long)gridDim.x * (4 * QMK_GMEM_WAVES))
+    sel_tasks_align_rows<QM_KSW_RING_GMEM, QM_KSW_MAXLEN_LONG>(P, A, t, nt, rows, (const QM_LDS(unsigned char)*)codes);
+}
 // the register edition for reads of up to QM_MAX_READ_LEN, eight alignments per wavefront (sel_tasks_align_rows2): 37.9 KB of LDS per
 // block, four blocks per CU -- as many alignments in flight as eight blocks of the four-per-wavefront kernel, half its scalar work
 template <int MAXLEN>
@@ -447,7 +460,9 @@ hipError_t qmk_sel_align_finish(const void* pp, const void* ap, int num_cu, hipS
       case 32: hipLaunchKernelGGL((qm_sel_align_kernel<32, 2, QM_KSW_MAXLEN_LONG>), dim3((unsigned)(num_cu * 4)), dim3(128), 0, st, P, A); break;
       case 64: hipLaunchKernelGGL((qm_sel_align_kernel<64, 2, QM_KSW_MAXLEN_LONG>), dim3((unsigned)(num_cu * 4)), dim3(128), 0, st, P, A); break;
       case 128: hipLaunchKernelGGL((qm_sel_align_kernel<128, 2, QM_KSW_MAXLEN_LONG>), dim3((unsigned)(num_cu * 3)), dim3(128), 0, st, P, A); break;
-      default: return hipErrorInvalidValue;               // the full-band ring holds every column of a 512-base alignment only (the host refuses the combination)
+      default:                                             // bands beyond 97: blocks in device memory (the host sized A.ksw_rows for num_cu blocks)
+        if (!A.ksw_rows) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(qm_sel_align_gmem_kernel, dim3((unsigned)num_cu), dim3(64 * QMK_GMEM_WAVES), 0, st, P, A); break;
     }
   } else
   switch (sel_ksw_ring_slots(A.bandwidth)) {            // one kernel for every --dpBandwidth: the band decides the ring
@@ -466,6 +481,7 @@ hipError_t qmk_sel_align_finish(const void* pp, const void* ap, int num_cu, hipS
   return hipGetLastError();
 }
 size_t qmk_sel_task_bytes(void) { return sizeof(SelTask); }
+size_t qmk_sel_gmem_rows_bytes(int num_cu) { return (size_t)num_cu * QMK_GMEM_WAVES * 4 * sizeof(KswRowT<QM_KSW_RING_GMEM, QM_KSW_MAXLEN_LONG>); }
 hipError_t qmk_sel_compact(const void* pp, const void* tmp, const void* toff, hipStream_t st) {
   const PairBatch& P = *(const PairBatch*)pp;
   if (P.n <= 0) return hipSuccess;

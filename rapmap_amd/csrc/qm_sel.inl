@@ -572,6 +572,7 @@ struct SelBatch {                    // launch arguments of the -s kernels (on t
                                                // plan -> align -> finish in chunks: the plan of chunk i+1 runs under the align of chunk i)
   int match, mismatch, gap_open, gap_extend, bandwidth, hard_filter, policy;
   int long_reads;                              // the batch holds reads beyond QM_MAX_READ_LEN: the long editions of the alignment kernel
+  void* ksw_rows;                              // long reads under a band beyond 97: the alignment blocks in device memory (KswRowT<QM_KSW_RING_GMEM, QM_KSW_MAXLEN_LONG>, four per wavefront)
   int short_len;                               // longest read of the batch that is not beyond QM_MAX_READ_LEN (0: unknown): reads of up to 128
                                                // characters run the alignment kernel with 192-byte images (twice the resident wavefronts)
   double min_score_fraction;
@@ -609,6 +610,12 @@ struct KswRowT<32, MAXLEN> { unsigned char QX[MAXLEN + 40], TX[MAXLEN + 40]; };
 inline constexpr int sel_ksw_ring_slots(int w) {   // host + device (constexpr)
   return (w >= 0 && w <= 15) ? 32 : ((w >= 0 && w <= 33) ? 64 : ((w >= 0 && w <= 97) ? 128 : 1024)); }
 static_assert(QM_KSW_MAXLEN + 48 <= 1024, "the full-band ring must hold every column of the longest alignment");
+// A batch that holds reads beyond QM_MAX_READ_LEN under a band beyond 97: the ring that holds every column of a 2048-base alignment
+// has 4096 slots -- 41 KB per alignment, four alignments per wavefront: more than a CU's LDS -- so those blocks live in device
+// memory (SelBatch::ksw_rows; qm_sel_align_gmem_kernel).  Slow, and rare: the reference takes any read under any band
+// (src/RapMapSAMapper.cpp:1017, src/ksw2pp/ksw2_extz2_sse.c has no length bound), a batch must not fail over one such read.
+#define QM_KSW_RING_GMEM 4096
+static_assert(QM_KSW_MAXLEN_LONG + 48 <= QM_KSW_RING_GMEM, "the device-memory ring must hold every column of the longest alignment");
 // qlenv / tlenv: the row's alignment (0: the row idles); blk[row]; the images must be in place.  wIn < 0: the band is the
 // whole matrix (ksw2_extz2_sse.c:45).  Returns max(mqe, mte) per row.
 // The register edition of the row kernel below, for bands of at most 15 (w + 1 <= 16 band cells, a round's columns

@@ -120,7 +120,7 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
       for (long long r = 0; r < nreads; ++r) if (lcnt[r] == QM_LCNT_SLOW && rawLen(r) > 64 * ns) q.push_back(r);
       bool tooLong = false;
       for (long long r : q) if (rawLen(r) > QM_MAX_LONG_READ_LEN) tooLong = true;
-      if (tooLong || (!q.empty() && sel_ksw_ring_slots(o->dp_bandwidth) > 128)) { status |= 4; for (long long r : q) lcnt[r] = 0; }
+      if (tooLong) { status |= 4; for (long long r : q) lcnt[r] = 0; }
       else if (!q.empty()) {
         ReadBatch S2 = B; S2.slowq = q.data(); S2.nreads = (long long)q.size();
         const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP) | QM_F_SEL;
@@ -192,7 +192,8 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
       if (longReads) switch (sel_ksw_ring_slots(A.bandwidth)) {
         case 32: { std::vector<KswRowT<32, QM_KSW_MAXLEN_LONG>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<32, QM_KSW_MAXLEN_LONG>(P, A, t, ntasks, rows.data(), codes); } break;
         case 64: { std::vector<KswRowT<64, QM_KSW_MAXLEN_LONG>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<64, QM_KSW_MAXLEN_LONG>(P, A, t, ntasks, rows.data(), codes); } break;
-        default: { std::vector<KswRowT<128, QM_KSW_MAXLEN_LONG>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<128, QM_KSW_MAXLEN_LONG>(P, A, t, ntasks, rows.data(), codes); } break;
+        case 128: { std::vector<KswRowT<128, QM_KSW_MAXLEN_LONG>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<128, QM_KSW_MAXLEN_LONG>(P, A, t, ntasks, rows.data(), codes); } break;
+        default: { std::vector<KswRowT<QM_KSW_RING_GMEM, QM_KSW_MAXLEN_LONG>> rows(4); for (u64 t = 0; t < ntasks; t += 4) sel_tasks_align_rows<QM_KSW_RING_GMEM, QM_KSW_MAXLEN_LONG>(P, A, t, ntasks, rows.data(), codes); } break;   // as qm_sel_align_gmem_kernel
       }
       else
       switch (sel_ksw_ring_slots(A.bandwidth)) {         // same rule as the launch wrapper

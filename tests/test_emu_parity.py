@@ -365,12 +365,13 @@ def test_reads_of_300_and_500_bp_take_the_eight_slot_kernels(synth_medium, oracl
     assert_hits_equal(rs.hit_offsets, rs.hits, es.hit_offsets, es.hits, "-s, 500 bp through the long-read pass")
 
 
-@pytest.mark.parametrize("variant", ["selAln", "selAln_band40", "selAln_noSensitive", "selAln_band120"])
+@pytest.mark.parametrize("variant", ["selAln", "selAln_band40", "selAln_noSensitive", "selAln_band120", "selAln_fullband"])
 def test_selective_alignment_of_reads_beyond_512_bp(synth_medium, oracle_mod, variant):
     """-s on a batch that mixes 2 x 100 bp pairs with reads of 600 .. 2048 bp (the reference aligns any length): the long reads
     are set aside by the collector, get their intervals from the 32-slot chain-scoring collector, chaining and list assembly are
     length-blind, and the ksw2 row kernel runs with images sized for the longest read (register edition, 64- and 128-slot rings).
-    Beyond --dpBandwidth 97 (the full-band ring) the limit stays at 512 characters"""
+    Beyond --dpBandwidth 97 (and with the whole matrix as the band, -1) the blocks of the row kernel live in device memory: a ring
+    of 4096 slots holds every column of a 2048-base alignment (round 4; before, such a batch failed with QM_E_TOOLONG)"""
     from rapmap_amd import synth
     import rapmap_amd as ra
     ix, orc, em, emu = _emu(synth_medium["idx"])
@@ -389,11 +390,9 @@ def test_selective_alignment_of_reads_beyond_512_bp(synth_medium, oracle_mod, va
     q1, o1 = pack(r1); q2, o2 = pack(r2)
     oo, go = {"selAln": ({"selAln": 1}, {"sel_aln": 1}), "selAln_band40": ({"selAln": 1, "dpBandwidth": 40}, {"sel_aln": 1, "dp_bandwidth": 40}),
               "selAln_noSensitive": ({"selAln": 1, "sensitive": 0}, {"sel_aln": 1, "sensitive": 0}),
-              "selAln_band120": ({"selAln": 1, "dpBandwidth": 120}, {"sel_aln": 1, "dp_bandwidth": 120})}[variant]
+              "selAln_band120": ({"selAln": 1, "dpBandwidth": 120}, {"sel_aln": 1, "dp_bandwidth": 120}),
+              "selAln_fullband": ({"selAln": 1, "dpBandwidth": -1}, {"sel_aln": 1, "dp_bandwidth": -1})}[variant]
     er = em.map(q1, o1, q2, o2, opts=emu.default_opts(**go), ns=2)
-    if variant == "selAln_band120":
-        assert er.status & 4
-        return
     res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=8)
     assert (er.status & 0xff) == 0, er.status
     assert_hits_equal(res.hit_offsets, res.hits, er.hit_offsets, er.hits, "-s long reads, %s" % variant)
