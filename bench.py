@@ -327,7 +327,7 @@ def compat_face_leg(out, args, idx_dir, hs1, hs2, n, L, want_digest_fn, cores):
         runs = {}
         for T in sorted({1, min(8, cores), min(32, cores)}):
             npairs = nc if T > 1 else min(nc, max(200_000, nc // 8))          # one thread: an eighth of the sample is plenty
-            r = subprocess.run([exe, idx_dir, rp, str(nc), str(L), str(T), "10000", "--use", str(npairs)] + (["--repeat", "2"] if T > 1 else []),
+            r = subprocess.run([exe, idx_dir, rp, str(nc), str(L), str(T), "10000", "--use", str(npairs)] + (["--repeat", "3"] if T > 1 else []),
                                capture_output=True, text=True, timeout=900)
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             if r.returncode != 0 or not line:
@@ -335,13 +335,18 @@ def compat_face_leg(out, args, idx_dir, hs1, hs2, n, L, want_digest_fn, cores):
                 continue
             j = json.loads(line[-1])
             runs[str(T)] = {"value": round(j["mpairs_per_s"], 3), "pairs": j["pairs"], "seconds": round(j["seconds"], 4),
+                            "thread_join_seconds_not_timed": round(j.get("thread_join_seconds", 0.0), 4),
+                            "workers_waiting_thread_s": round(j.get("prefetch_thread_s", 0.0), 3), "workers_loop_thread_s": round(j.get("loop_thread_s", 0.0), 3),
                             "bit_identical_joint_hits": j["digest"] == want_digest_fn(npairs), "totHits": j["totHits"]}
         best = max((v.get("value", 0) for v in runs.values()), default=0)
         out["compat_face"] = {"value": best, "unit": "M read-pairs/s", "chunk_pairs": 10000, "by_host_threads": runs,
                               "what": "tests/compat/compat_bench.cpp: T threads, each takes read groups of 10 000 pairs and runs the reference's per-pair "
                                       "sequence (src/RapMapSAMapper.cpp:461-551) through include/qmap_rapmap_compat.hpp, one added line "
-                                      "`hitCollector.prefetch(rg)`; strings built before the timed region; digest of every jointHits vector against the "
-                                      "fused path's hits on the same pairs (themselves checked against the oracle in `parity`)"}
+                                      "`hitCollector.prefetch(rg)` (the groups of all threads are mapped together by the header's batching service: "
+                                      "two dispatcher threads own the device contexts); strings built before the timed region, which ends when the last "
+                                      "group has been processed (joining the worker threads -- milliseconds of MMU-notifier work per exiting thread in a "
+                                      "process with GPU mappings -- is reported next to it); digest of every jointHits vector against the fused path's "
+                                      "hits on the same pairs (themselves checked against the oracle in `parity`)"}
 
 
 def main():
@@ -364,7 +369,7 @@ def main():
     ap.add_argument("--cache", default=os.environ.get("QMAP_BENCH_CACHE", "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"))
     ap.add_argument("--e2e-dir", default=os.environ.get("QMAP_BENCH_E2E_DIR", "/tmp"), help="where the end_to_end leg puts its FASTQ files")
     ap.add_argument("--e2e-threads", type=int, default=32)
-    ap.add_argument("--compat-pairs", type=int, default=4_000_000, help="pairs of the batch the compat_face leg runs through the reference's call surface")
+    ap.add_argument("--compat-pairs", type=int, default=8_000_000, help="pairs of the batch the compat_face leg runs through the reference's call surface")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

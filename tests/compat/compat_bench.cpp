@@ -39,7 +39,7 @@ static inline uint64_t hit_digest(uint64_t unit, uint64_t j, const rapmap::utils
   return v;
 }
 
-struct Totals { uint64_t digest = 0, pe = 0, se = 0, tot = 0, reads = 0, tooMany = 0, mapped = 0; double prefetchS = 0, loopS = 0; };
+struct Totals { uint64_t digest = 0, pe = 0, se = 0, tot = 0, reads = 0, tooMany = 0, mapped = 0; double prefetchS = 0, loopS = 0, firstAt = 0, lastAt = 0, goSeenAt = 0; };
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 template <typename RapMapIndexT>
@@ -88,11 +88,12 @@ static void worker(RapMapIndexT& rmi, std::vector<Group>& groups, const std::vec
       }
       ++u;
     }
-    if (count) { T.prefetchS += tp1 - tp0; T.loopS += now_s() - tp1; }
+    if (count) { const double te = now_s(); T.prefetchS += tp1 - tp0; T.loopS += te - tp1; if (T.firstAt == 0) T.firstAt = tp0; T.lastAt = te; }
   };
   if (warm) run_group(*warm, 0, false);               // context creation, first launches, buffer growth: outside the timed region
   ++ready;
   while (!go.load()) std::this_thread::yield();
+  mine.goSeenAt = now_s();
   while (true) {
     const size_t g = next.fetch_add(1);
     if (g >= groups.size()) break;
@@ -134,7 +135,7 @@ int main(int argc, char** argv) {
         });
       for (auto& t : th) t.join();
     };
-    double best = 0, secs = 0; Totals tot; uint64_t ctr[5] = {0, 0, 0, 0, 0};
+    double best = 0, secs = 0, joinS = 0; Totals tot; uint64_t ctr[5] = {0, 0, 0, 0, 0};
     for (int rep = 0; rep < repeat; ++rep) {
       std::vector<Group> groups; build(groups);
       std::vector<Group> warm((size_t)threads);
@@ -147,18 +148,37 @@ int main(int argc, char** argv) {
         th.emplace_back([&, t] { worker(rmi, groups, firstUnit, next, prefetch, 200u, T[(size_t)t], hctr, &warm[(size_t)t], ready, go); });
       while (ready.load() < threads) std::this_thread::yield();
       const auto t0 = std::chrono::steady_clock::now();
+      const double t0s = now_s();
       go = 1;
       for (auto& t : th) t.join();
-      const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      const double joined = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      // The timed span ends when the LAST read group has been processed, not when the last worker thread has been joined: a
+      // thread that exits in a process holding GPU mappings pays milliseconds of teardown (its stack's munmap runs the
+      // driver's MMU notifiers; measured 6 ms per thread, serialised: profiles/r04/compat_probe_timeline.txt), which a caller
+      // whose workers live as long as the run (the reference's do: src/RapMapSAMapper.cpp:752-799) pays once, after mapping.
+      double dt = 0;
+      for (auto& x : T) if (x.lastAt) dt = std::max(dt, x.lastAt - t0s);
+      if (dt <= 0) dt = joined;
+      if (std::getenv("COMPAT_BENCH_VERBOSE")) {
+        double gmax = 0, fmin = 1e30, fmax = 0, lmin = 1e30, lmax = 0;
+        for (auto& x : T) { gmax = std::max(gmax, x.goSeenAt - t0s); if (x.firstAt) { fmin = std::min(fmin, x.firstAt - t0s); fmax = std::max(fmax, x.firstAt - t0s); lmin = std::min(lmin, x.lastAt - t0s); lmax = std::max(lmax, x.lastAt - t0s); } }
+        std::fprintf(stderr, "[compat_bench] repeat %d timeline (s after go): last thread saw go at %.4f; first group started %.4f .. %.4f; last group ended %.4f .. %.4f; all joined at %.4f\n",
+                     rep, gmax, fmin, fmax, lmin, lmax, joined);
+      }
       Totals S;
       for (auto& x : T) { S.digest += x.digest; S.mapped += x.mapped; S.prefetchS += x.prefetchS; S.loopS += x.loopS; }
-      if (rep == 0 || (double)n / dt > best) { best = (double)n / dt; secs = dt; }
+      if (rep == 0 || (double)n / dt > best) { best = (double)n / dt; secs = dt; joinS = joined - dt; }
       tot = S;
+      if (std::getenv("COMPAT_BENCH_VERBOSE")) {
+        double mx = 0, mn = 1e30; for (auto& x : T) { const double b = x.prefetchS + x.loopS; mx = b > mx ? b : mx; mn = b < mn ? b : mn; }
+        std::fprintf(stderr, "[compat_bench] repeat %d: wall %.4f s, per thread busy min %.4f max %.4f s (prefetch %.3f + loop %.3f thread-s over %d threads)\n",
+                     rep, dt, mn, mx, S.prefetchS, S.loopS, threads);
+      }
       ctr[0] = hctr.peHits.load(); ctr[1] = hctr.seHits.load(); ctr[2] = hctr.totHits.load(); ctr[3] = hctr.numReads.load(); ctr[4] = hctr.tooManyHits.load();
     }
-    std::printf("{\"pairs\": %zu, \"read_len\": %zu, \"threads\": %d, \"chunk\": %zu, \"prefetch\": %s, \"seconds\": %.6f, \"mpairs_per_s\": %.4f, "
+    std::printf("{\"pairs\": %zu, \"read_len\": %zu, \"threads\": %d, \"chunk\": %zu, \"prefetch\": %s, \"seconds\": %.6f, \"thread_join_seconds\": %.6f, \"mpairs_per_s\": %.4f, "
                 "\"prefetch_thread_s\": %.4f, \"loop_thread_s\": %.4f, \"digest\": \"%016llx\", \"mapped\": %llu, \"peHits\": %llu, \"seHits\": %llu, \"totHits\": %llu, \"numReads\": %llu, \"tooManyHits\": %llu}\n",
-                n, L, threads, chunk, prefetch ? "true" : "false", secs, best / 1e6, tot.prefetchS, tot.loopS, (unsigned long long)tot.digest, (unsigned long long)tot.mapped,
+                n, L, threads, chunk, prefetch ? "true" : "false", secs, joinS, best / 1e6, tot.prefetchS, tot.loopS, (unsigned long long)tot.digest, (unsigned long long)tot.mapped,
                 (unsigned long long)ctr[0], (unsigned long long)ctr[1], (unsigned long long)ctr[2], (unsigned long long)ctr[3], (unsigned long long)ctr[4]);
     return 0;
   } catch (const qmap::Error& e) { std::printf("qmap error %d: %s\n", e.code(), e.what()); return 3; }

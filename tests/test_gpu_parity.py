@@ -707,8 +707,10 @@ def test_reads_beyond_512_bp_take_the_long_read_pass(synth_medium, synth_medium_
         p1 = torch.from_numpy(o1).cuda(); p2 = torch.from_numpy(o2).cuda()
         gd = mp.map_device(len(r1), d1.data_ptr(), p1.data_ptr(), d2.data_ptr(), p2.data_ptr(), 2048, fetch=True)
         assert_hits_equal(res.hit_offsets, res.hits, gd.hit_offsets, gd.hits, "long reads, device-resident input")
-        with pytest.raises(ra.QmError, match="512"):
-            mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(sel_aln=1, dp_bandwidth=-1))
+        # -s with the whole matrix as the band (round 3: QM_E_TOOLONG for the batch; now the device-memory edition of the row kernel)
+        rf = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(selAln=1, dpBandwidth=-1), nthreads=8)
+        gf = mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(sel_aln=1, dp_bandwidth=-1))
+        assert_hits_equal(rf.hit_offsets, rf.hits, gf.hit_offsets, gf.hits, "long reads, -s, full band")
         r1[5] = bytes(txps[0][:2049]); q1, o1 = pack(r1)
         with pytest.raises(ra.QmError, match="2048"):
             mp.map_pairs(q1, o1, q2, o2)
