@@ -368,7 +368,8 @@ def main():
     ap.add_argument("--read-len", type=int, default=100, help="read length (BASELINE.json: 100; 129..256 runs the NS=4 kernels)")
     ap.add_argument("--cache", default=os.environ.get("QMAP_BENCH_CACHE", "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"))
     ap.add_argument("--e2e-dir", default=os.environ.get("QMAP_BENCH_E2E_DIR", "/tmp"), help="where the end_to_end leg puts its FASTQ files")
-    ap.add_argument("--e2e-threads", type=int, default=32)
+    ap.add_argument("--e2e-threads", type=int, default=16, help="ingest workers of the end_to_end leg (the engine peaks at 16-24 on this host: profiles/r04/ingest_after.log)")
+    ap.add_argument("--e2e-copies", type=int, default=4, help="the end_to_end leg's FASTQ files hold the batch this many times (4 x 10 M = 40 M pairs)")
     ap.add_argument("--compat-pairs", type=int, default=8_000_000, help="pairs of the batch the compat_face leg runs through the reference's call surface")
     args = ap.parse_args()
 
@@ -576,12 +577,16 @@ def side_legs(out, args, ra, qi, mp, opts, s1, s2, off, n, L, dev_id, cores):
     # FASTQ files are being written -- as the CLI reserves it while the index uploads (pinning runs at 5.5 GB/s on this host
     # whatever the thread count: inside the timed region the first batches would wait for their slots)
     ra.reserve_stream_memory(768 << 20)
-    ne = n
+    # the files hold the batch's pairs `e2e_copies` times over (40 M pairs by default: at ~100 M pairs/s a 10 M-pair run is a
+    # tenth of a second, inside the noise of thread start-up)
+    reps = max(1, int(args.e2e_copies))
+    ne = n * reps
     base = args.e2e_dir if os.path.isdir(args.e2e_dir) else args.cache
     d_e = os.path.join(base, "qmap_bench_e2e_%d" % os.getpid()); os.makedirs(d_e, exist_ok=True)
     f1 = os.path.join(d_e, "r1.fq"); f2 = os.path.join(d_e, "r2.fq")
     try:
-        _syn.write_fastq(f1, hs1[: ne * L], ne, L, 1); _syn.write_fastq(f2, hs2[: ne * L], ne, L, 2)
+        for rep in range(reps):
+            _syn.write_fastq(f1, hs1[: n * L], n, L, 1, start=rep * n, append=rep > 0); _syn.write_fastq(f2, hs2[: n * L], n, L, 2, start=rep * n, append=rep > 0)
         thr = max(1, min(args.e2e_threads, cores))
         batch = 1 << 18
         runs = {}

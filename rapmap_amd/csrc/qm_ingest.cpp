@@ -203,6 +203,7 @@ struct qm_ingest {
   std::vector<std::thread> workers, allocators;
   std::mutex mu; std::condition_variable cvWork, cvOut, cvInfl;
   std::deque<CopyTask> copyQ;
+  int sleepers = 0;                    // workers waiting on cvWork (a worker that takes a task and sees more wakes ONE of them)
   std::vector<Chunk*> freeChunks;
   int64_t nextSeq = 0, nextHand = 0;
   bool ended = false, stop = false;
@@ -292,7 +293,7 @@ void form_batches(qm_ingest* g) {
     }
     if (!ok) { set_fail(g, QM_E_NOMEM, "out of memory for a batch of %lld reads", (long long)n); g->cvOut.notify_all(); return; }
     L.n = n; L.seqNo = g->nextSeq++; L.state = 1; L.pending = 0;
-    const uint32_t maxRun = 8192;                          // records per copy task
+    static const uint32_t maxRun = [] { const char* e = getenv("QM_INGEST_COPY_RUN"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 16384u; }();   // records per copy task
     size_t made = 0;
     for (int s = 0; s < g->nsrc; ++s) {
       Src& S = g->src[s];
@@ -316,7 +317,10 @@ void form_batches(qm_ingest* g) {
       }
       S.avail -= n;
     }
-    if (made > 1) g->cvWork.notify_all(); else g->cvWork.notify_one();
+    // ONE sleeper is woken here; it wakes the next one when it finds more tasks than it takes (worker_loop).  Waking them all
+    // for every batch made the engine SLOWER with every worker added beyond ~16: dozens of threads woke, queued for the mutex,
+    // found nothing and went back to sleep, in the way of the ones with work (profiles/r04/ingest_hyp.log).
+    if (made > 0) g->cvWork.notify_one();
   }
 }
 
@@ -420,6 +424,7 @@ void worker_loop(qm_ingest* g) {
     if (g->stop) return;
     if (!g->copyQ.empty()) {
       CopyTask T = g->copyQ.front(); g->copyQ.pop_front();
+      if (!g->copyQ.empty() && g->sleepers > 0) g->cvWork.notify_one();      // more where this came from: pass the word on
       lk.unlock();
       const double t0 = now_s();
       run_copy(g, T);
@@ -436,6 +441,7 @@ void worker_loop(qm_ingest* g) {
       Chunk* c = take_parse(g);
       if (c) {
         Src& S = g->src[c->src];
+        if (g->sleepers > 0) g->cvWork.notify_one();                           // there may be another chunk to parse: one more worker looks
         lk.unlock();
         const double t0 = now_s();
         bool ok = true;
@@ -465,7 +471,9 @@ void worker_loop(qm_ingest* g) {
         continue;
       }
     }
+    ++g->sleepers;
     g->cvWork.wait(lk);
+    --g->sleepers;
   }
 }
 
@@ -841,7 +849,16 @@ int qm_ingest_open(const char* path1, const char* path2, int32_t n_threads, int6
   if (!rc && path2) rc = open_src(g->src[1], path2);
   if (rc) { for (int s = 0; s < 2; ++s) { if (g->src[s].map) munmap((void*)g->src[s].map, g->src[s].len); if (g->src[s].fd >= 0) ::close(g->src[s].fd); } delete g; return rc; }
   const char* ce = getenv("QM_INGEST_CHUNK");
-  const size_t chunkBytes = ce && atoll(ce) > 0 ? (size_t)atoll(ce) : ((size_t)2 << 20);
+  // chunk = one parse task: large enough that the bookkeeping between tasks (one mutex) stays small next to the task --
+  // 8 MB chunks scaled to 64 workers where 2 MB ones stopped at 16 (profiles/r04/ingest_hyp.log) -- but never so large that a
+  // small file leaves workers without a chunk
+  size_t chunkBytes = (size_t)8 << 20;
+  {
+    size_t longest = 0; for (int s = 0; s < g->nsrc; ++s) if (!g->src[s].gz) longest = std::max(longest, g->src[s].len);
+    const size_t per = longest / (size_t)(4 * std::max(1, (int)n_threads)) + 1;
+    if (per < chunkBytes) chunkBytes = std::max(per, (size_t)1 << 20);
+  }
+  if (ce && atoll(ce) > 0) chunkBytes = (size_t)atoll(ce);
   for (int s = 0; s < g->nsrc; ++s) {
     Src& S = g->src[s];
     if (S.gz) {
@@ -931,7 +948,7 @@ void qm_ingest_release(qm_ingest* g, int slot) {
   std::lock_guard<std::mutex> lk(g->mu);
   g->slots[(size_t)slot].state = 0;
   form_batches(g);
-  g->cvWork.notify_all();
+  g->cvWork.notify_one();
 }
 
 /* [0] seconds from open to the first complete batch, [1] parse tasks (summed over the workers), [2] copy tasks (summed),

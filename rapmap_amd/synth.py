@@ -95,11 +95,12 @@ def make_reads(txps, n_pairs, seed=43, read_len=100, err=0.01, n_rate=0.0, chunk
     return s1, s2, off, truth
 
 
-def write_fastq(path, seq, n, L, mate):
-    """n fixed-width FASTQ records "@r%09d/m" + L bases + "+" + L quality characters, written in one go"""
+def write_fastq(path, seq, n, L, mate, start=0, append=False):
+    """n fixed-width FASTQ records "@r%09d/m" + L bases + "+" + L quality characters, written in one go (record numbers from
+    `start`; append=True adds them to an existing file)"""
     rec = np.empty((n, 13), dtype=np.uint8)
     rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
-    idx = np.arange(n, dtype=np.int64)
+    idx = np.arange(start, start + n, dtype=np.int64)
     for d in range(9):
         rec[:, 10 - d] = ord("0") + (idx // (10 ** d)) % 10
     rec[:, 11] = ord("/"); rec[:, 12] = ord(str(mate))
@@ -109,4 +110,9 @@ def write_fastq(path, seq, n, L, mate):
     body[:, 1 + L] = ord("\n"); body[:, 2 + L] = ord("+"); body[:, 3 + L] = ord("\n")
     body[:, 4 + L:4 + 2 * L] = ord("I")
     body[:, 4 + 2 * L] = ord("\n")
-    np.concatenate([rec, body], axis=1).tofile(path)
+    out = np.concatenate([rec, body], axis=1)
+    if append:
+        with open(path, "ab") as f:
+            out.tofile(f)
+    else:
+        out.tofile(path)
