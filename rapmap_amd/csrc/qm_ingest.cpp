@@ -30,6 +30,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#include <emmintrin.h>
 
 #include <algorithm>
 #include <atomic>
@@ -54,6 +55,19 @@ inline const char* eol(const char* p, const char* e) {
   return q ? q : e;
 }
 inline size_t rstrip(const char* b, const char* e) { while (e > b && (e[-1] == '\r' || e[-1] == '\n')) --e; return (size_t)(e - b); }
+
+// true when [a, a + len) holds no '\n'.  16 bytes at a time (SSE2: every x86-64 has it), the tail by an overlapping load when the
+// range is at least 16 long.  The FASTQ fast path of parse_chunk asks this about every line of a record whose layout it
+// predicts from the record before: four libc memchr calls per 212-byte record were what bounded a parse task at ~2.6 GB/s.
+inline bool no_newline(const char* a, size_t len) {
+  if (len < 16) { for (size_t i = 0; i < len; ++i) if (a[i] == '\n') return false; return true; }
+  const __m128i nl = _mm_set1_epi8('\n');
+  __m128i acc = _mm_setzero_si128();
+  size_t i = 0;
+  for (; i + 16 <= len; i += 16) acc = _mm_or_si128(acc, _mm_cmpeq_epi8(_mm_loadu_si128((const __m128i*)(a + i)), nl));
+  if (i < len) acc = _mm_or_si128(acc, _mm_cmpeq_epi8(_mm_loadu_si128((const __m128i*)(a + len - 16)), nl));
+  return _mm_movemask_epi8(acc) == 0;
+}
 
 // Start of the first FASTQ/FASTA record at or after p (p may be mid-record): a line starting with '@' whose
 // line-after-next starts with '+' and whose quality line is as long as its sequence line (a quality line may
@@ -113,7 +127,25 @@ bool parse_chunk(Chunk& C, bool fastq) {
   if ((size_t)(e - b) >= (size_t)ARENA) return false;
   R.reserve((size_t)(e - b) / (fastq ? 160 : 400) + 16);
   uint32_t cs = 0, cn = 0;
+  // layout of the previous FASTQ record when it was "plain" (no blank lines before it, no '\r'): lengths of its four lines
+  // including their '\n'.  Nearly every record of a file repeats it (fixed-length reads; the name grows a digit now and then).
+  size_t n1 = 0, n2 = 0, n3 = 0, n4 = 0;
   while (p < e) {
+    if (fastq && n1 && (size_t)(e - p) >= n1 + n2 + n3 + n4) {
+      // The record at p has the previous one's layout exactly when: '@' starts it, each predicted line end is a '\n' that is
+      // not preceded by a '\r', the third line starts with '+', and NO other '\n' lies inside the four lines (then the first
+      // newline behind each line start is the predicted one, which is all the general path below would establish).
+      const char* s = p + n1; const char* pl = s + n2; const char* q = pl + n3; const char* nx = q + n4;
+      if (*p == '@' && s[-1] == '\n' && pl[-1] == '\n' && *pl == '+' && q[-1] == '\n' && nx[-1] == '\n' &&
+          (n1 < 2 || s[-2] != '\r') && (n2 < 2 || pl[-2] != '\r') && (n4 < 2 || nx[-2] != '\r') &&
+          no_newline(p, n1 - 1) && no_newline(s, n2 - 1) && no_newline(pl, n3 - 1) && no_newline(q, n4 - 1)) {
+        R.push_back(Rec{(uint32_t)(p + 1 - b), (uint32_t)(s - b), cs, cn});
+        cs += (uint32_t)(n2 - 1); cn += (uint32_t)(n1 - 2);
+        p = nx;
+        continue;
+      }
+    }
+    n1 = 0;
     while (p < e && (*p == '\n' || *p == '\r')) ++p;
     if (p >= e) break;
     const char* l1 = eol(p, e);
@@ -127,6 +159,10 @@ bool parse_chunk(Chunk& C, bool fastq) {
       const uint32_t nl = (uint32_t)rstrip(p + 1, l1), sl = (uint32_t)rstrip(s, l2);
       R.push_back(Rec{(uint32_t)(p + 1 - b), (uint32_t)(s - b), cs, cn});
       cs += sl; cn += nl;
+      // a plain record (every line ended by a bare '\n', nothing stripped): its layout is the prediction for the next one
+      if (l4 < e && nl == (uint32_t)(l1 - (p + 1)) && sl == (uint32_t)(l2 - s) && (l3 == pl + 1 || l3[-1] != '\r') && (l4 == q || l4[-1] != '\r')) {
+        n1 = (size_t)(l1 + 1 - p); n2 = (size_t)(l2 + 1 - s); n3 = (size_t)(l3 + 1 - pl); n4 = (size_t)(l4 + 1 - q);
+      }
       p = l4 < e ? l4 + 1 : e;
     } else if (*p == '>' && !fastq) {
       const char* s = l1 < e ? l1 + 1 : e;
@@ -293,7 +329,8 @@ void form_batches(qm_ingest* g) {
     }
     if (!ok) { set_fail(g, QM_E_NOMEM, "out of memory for a batch of %lld reads", (long long)n); g->cvOut.notify_all(); return; }
     L.n = n; L.seqNo = g->nextSeq++; L.state = 1; L.pending = 0;
-    static const uint32_t maxRun = [] { const char* e = getenv("QM_INGEST_COPY_RUN"); return e && atoi(e) > 0 ? (uint32_t)atoi(e) : 16384u; }();   // records per copy task
+    const char* mre = getenv("QM_INGEST_COPY_RUN");
+    const uint32_t maxRun = mre && atoi(mre) > 0 ? (uint32_t)atoi(mre) : 16384u;   // records per copy task
     size_t made = 0;
     for (int s = 0; s < g->nsrc; ++s) {
       Src& S = g->src[s];
@@ -345,14 +382,27 @@ void run_copy(qm_ingest* g, const CopyTask& T) {
   const Rec* R = C.recs.data();
   const int64_t s0 = T.dstSeq - R[T.r0].cumSeq, n0 = T.dstName - R[T.r0].cumName;
   int64_t d = T.dstRec;
+  // Short reads and names are moved 16 bytes at a time without a call: the store may run up to 15 bytes past the record's end --
+  // over the places of the NEXT records of this task, which are written right after -- and the load up to 15 bytes past its
+  // source, which must still lie inside the chunk.  A record whose over-run would leave the task's own stretch of the
+  // destination (its neighbour there belongs to another task, or is the batch's padding) and anything long or arena-backed
+  // go through memcpy.
+  const char* const srcEnd = C.end - 16;
+  const int64_t endSeq = s0 + R[T.r1].cumSeq, endName = n0 + R[T.r1].cumName;
+  auto put = [srcEnd](char* base, int64_t at, int64_t end, const char* src, uint32_t n, bool exact) {
+    char* dst = base + at;
+    if (exact || n > 512 || src + n > srcEnd || at + (int64_t)((n + 15u) & ~15u) > end) { memcpy(dst, src, n); return; }
+    for (uint32_t i = 0; i < n; i += 16) _mm_storeu_si128((__m128i*)(dst + i), _mm_loadu_si128((const __m128i*)(src + i)));
+  };
   for (uint32_t i = T.r0; i < T.r1; ++i, ++d) {
     const uint32_t sl = R[i + 1].cumSeq - R[i].cumSeq;
-    const char* sp = (R[i].seqOff & ARENA) ? C.arena.data() + (R[i].seqOff & ~ARENA) : C.base + R[i].seqOff;
+    const bool arena = (R[i].seqOff & ARENA) != 0;
+    const char* sp = arena ? C.arena.data() + (R[i].seqOff & ~ARENA) : C.base + R[i].seqOff;
     off[d] = s0 + R[i].cumSeq;
-    memcpy(seq + s0 + R[i].cumSeq, sp, sl);
+    put(seq, s0 + R[i].cumSeq, endSeq, sp, sl, arena);
     if (names) {
       noff[d] = n0 + R[i].cumName;
-      memcpy(nm + n0 + R[i].cumName, C.base + R[i].nameOff, R[i + 1].cumName - R[i].cumName);
+      put(nm, n0 + R[i].cumName, endName, C.base + R[i].nameOff, R[i + 1].cumName - R[i].cumName, false);
     }
   }
 }

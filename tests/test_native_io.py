@@ -259,13 +259,17 @@ def test_pipelined_stream_matches_the_oracle(sample_data, oracle_mod, batch):
         assert got.tobytes() == rs.hits.tobytes()
 
 
-@pytest.mark.parametrize("chunk,batch,threads", [(777, 1, 3), (1500, 13, 1), (4096, 1000, 6), (1 << 20, 257, 4)])
+@pytest.mark.parametrize("chunk,batch,threads", [(777, 1, 3), (1500, 13, 1), (4096, 1000, 6), (1 << 20, 257, 4), (3000, 64, 5)])
 def test_ingest_engine_chunk_boundaries(tmp_path, monkeypatch, chunk, batch, threads):
     """qm_ingest: chunks cut at arbitrary byte offsets resynchronise on record boundaries (quality lines that start with '@'
     or '+', CRLF, empty reads, names with blanks), batches span chunks, both files advance together"""
     import random
     import rapmap_amd as ra
     monkeypatch.setenv("QM_INGEST_CHUNK", str(chunk))
+    if chunk == 3000:
+        # copy tasks of three records: the 16-byte moves of short reads and names (their over-run must stay inside the task's own
+        # stretch of the batch) next to tasks of other workers on every side
+        monkeypatch.setenv("QM_INGEST_COPY_RUN", "3")
     rnd = random.Random(chunk * 31 + batch)
     n = 3000
     recs1, recs2 = [], []
@@ -274,9 +278,11 @@ def test_ingest_engine_chunk_boundaries(tmp_path, monkeypatch, chunk, batch, thr
         for i in range(n):
             for f, recs, nl in ((f1, recs1, b"\n"), (f2, recs2, b"\r\n" if i % 7 == 0 else b"\n")):
                 L = rnd.choice([0, 1, 30, 31, 100, 100, 100, 250]) if i % 50 == 0 else 100
+                if chunk == 3000:
+                    L = rnd.choice([0, 1, 5, 12, 15, 16, 17, 33])         # every record shorter than a few 16-byte moves
                 s = "".join(rnd.choice("ACGTN") for _ in range(L)).encode()
                 q = "".join(rnd.choice("@+I5#") for _ in range(L)).encode()
-                nm = ("r%d some text/%d" % (i * 7919, 1 + (f is f2))).encode()
+                nm = ("r%d some text/%d" % (i * 7919, 1 + (f is f2))).encode() if chunk != 3000 else ("r%d" % i).encode()
                 f.write(b"@" + nm + nl + s + nl + b"+" + (nm if i % 3 == 0 else b"") + nl + q + nl)
                 recs.append((nm, s))
     bs = _batches(p1, p2, batch, threads=threads)
