@@ -33,8 +33,10 @@ def run(thr, env=None, cpus=None):
     print((p.stdout.strip().splitlines() or [p.stderr[-300:]])[-1], flush=True)
 mode = sys.argv[1] if len(sys.argv) > 1 else "all"
 if mode == "after":                                   # after the chain wake-ups / adaptive chunk size of round 4
-    for thr in (8, 16, 32, 48, 64, 96, 128):
+    for thr in (8, 16, 24, 32, 48, 64, 96, 128):
         run(thr)
+    for thr in (16, 32, 64):
+        run(thr, {"QM_INGEST_PIN": "0"})
     for thr in (32, 64):
         run(thr, {"QM_INGEST_COPY_RUN": "8192"})
     for thr in (32, 64):
