@@ -29,6 +29,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <sched.h>
+#include <sys/syscall.h>
 #include <pthread.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -976,7 +977,26 @@ int qm_ingest_open(const char* path1, const char* path2, int32_t n_threads, int6
     if (!(pe && atoi(pe) == 0)) {
       cpu_set_t set; CPU_ZERO(&set); int ncpu = 0;
       unsigned cpu = 0, node = 0;
-      if (getcpu(&cpu, &node) == 0) {
+      bool haveNode = getcpu(&cpu, &node) == 0;
+      // ... or rather the node that holds the FILE's pages, when the file is mapped and in the page cache: the opener's own
+      // node is wherever the scheduler left that thread, and workers pinned across the socket link from their input ran at
+      // half speed (bimodal stream timings, profiles/r04/stream_after_pin.log).  move_pages with no target nodes only asks.
+      for (int si = 0; si < g->nsrc; ++si) {
+        const Src& S = g->src[si];
+        if (S.gz || !S.map || S.len < 4096) continue;
+        int votes[64] = {0}; int best = -1;
+        for (int k = 0; k < 5; ++k) {
+          const size_t at = ((S.len - 1) / 4 * (size_t)k) & ~(size_t)4095;
+          volatile char touch = S.map[at]; (void)touch;
+          void* page = (void*)((uintptr_t)(S.map + at) & ~(uintptr_t)4095); int status = -1;
+          if (syscall(SYS_move_pages, 0, 1UL, &page, nullptr, &status, 0) == 0 && status >= 0 && status < 64) {
+            if (++votes[status] > (best < 0 ? 0 : votes[best])) best = status;
+          }
+        }
+        if (best >= 0) { node = (unsigned)best; haveNode = true; }
+        break;                                                       // (the first mapped source decides)
+      }
+      if (haveNode) {
         char path[96]; snprintf(path, sizeof(path), "/sys/devices/system/node/node%u/cpulist", node);
         if (FILE* f = fopen(path, "r")) {
           char buf[1024]; buf[0] = 0;
