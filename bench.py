@@ -368,7 +368,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=100, help="read length (BASELINE.json: 100; 129..256 runs the NS=4 kernels)")
     ap.add_argument("--cache", default=os.environ.get("QMAP_BENCH_CACHE", "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"))
     ap.add_argument("--e2e-dir", default=os.environ.get("QMAP_BENCH_E2E_DIR", "/tmp"), help="where the end_to_end leg puts its FASTQ files")
-    ap.add_argument("--e2e-threads", type=int, default=16, help="ingest workers of the end_to_end leg (the engine peaks at 16-24 on this host: profiles/r04/ingest_after.log)")
+    ap.add_argument("--e2e-threads", type=int, default=24, help="ingest workers of the end_to_end leg (the engine alone peaks at 16-32 on this host, pinned to the socket that holds the files: profiles/r04/ingest_after_pin.log)")
     ap.add_argument("--e2e-copies", type=int, default=4, help="the end_to_end leg's FASTQ files hold the batch this many times (4 x 10 M = 40 M pairs)")
     ap.add_argument("--compat-pairs", type=int, default=8_000_000, help="pairs of the batch the compat_face leg runs through the reference's call surface")
     args = ap.parse_args()
@@ -576,7 +576,7 @@ def side_legs(out, args, ra, qi, mp, opts, s1, s2, off, n, L, dev_id, cores):
     # the slots' pinned memory comes out of the library's process-wide pool, reserved here -- in the background, while the
     # FASTQ files are being written -- as the CLI reserves it while the index uploads (pinning runs at 5.5 GB/s on this host
     # whatever the thread count: inside the timed region the first batches would wait for their slots)
-    ra.reserve_stream_memory(768 << 20)
+    ra.reserve_stream_memory(1280 << 20)
     # the files hold the batch's pairs `e2e_copies` times over (40 M pairs by default: at ~100 M pairs/s a 10 M-pair run is a
     # tenth of a second, inside the noise of thread start-up)
     reps = max(1, int(args.e2e_copies))
@@ -605,7 +605,7 @@ def side_legs(out, args, ra, qi, mp, opts, s1, s2, off, n, L, dev_id, cores):
             "input": "two plain FASTQ files, %d MB together, in %s (%s), read once right after they were written" % (
                 (os.path.getsize(f1) + os.path.getsize(f2)) >> 20, d_e, fstype_of(d_e)),
             "ingest_threads": thr, "batch_units": batch, "names_kept": True,
-            "pinned_pool": "768 MB reserved with qm_stream_reserve before the timed region (pinned in the background, as the CLI does under the index upload)",
+            "pinned_pool": "1280 MB reserved with qm_stream_reserve before the timed region (pinned in the background, as the CLI does under the index upload)",
             "seconds": {"total_open_to_last_batch_handed_out": round(dt_e, 4), "open": round(ss["open_s"], 4),
                         "first_batch_packed": round(ss["first_batch_s"], 4), "ingest_open_to_last_batch_packed": round(ss["read_s"], 4),
                         "last_batch_mapped": round(ss["last_mapped_s"], 4),

@@ -294,7 +294,7 @@ const char* qm_io_last_error(void);
  * producer + per-record std::strings of src/FastxParser.cpp:229-328, and the worker threads of spawnProcessReadsThreads,
  * src/RapMapSAMapper.cpp:752-799).  `reader_threads` workers parse the files chunk-parallel (plain files are cut at byte
  * offsets with record resync; .gz files are inflated by one thread per file, pipelined with the parsers) and pack batches
- * straight into pinned host slots, several batches in flight, while two device contexts per device (sharing that device's
+ * straight into pinned host slots, several batches in flight, while four device contexts per device (QM_STREAM_CTX_PER_DEVICE) (sharing that device's
  * index replica) upload, map and download the previous ones; with several devices consecutive batches go to different
  * devices (the static sharding of SURVEY.md section 8e inside one process).  The caller drains the batches IN INPUT ORDER,
  * whichever device mapped them.  Everything a batch points to -- reads, names, hit offsets, hits -- is pinned memory owned by

@@ -34,11 +34,9 @@ def stream(thr, names, env=None):
     for k in (env or {}): os.environ.pop(k)
     print(json.dumps({"threads": thr, "names": names, "env": env, "M_pairs_s": round(n * reps / dt / 1e6, 2), "s": round(dt, 4), "hits": int(nh),
                       **{k: round(v, 4) for k, v in ss.items() if k in ("read_s", "first_batch_s", "parse_cpu_s", "copy_cpu_s", "caller_wait_s", "map_s")}}), flush=True)
-stream(16, False); stream(16, False)
-for thr in (16, 24, 32, 48):
-    stream(thr, False); stream(thr, True)
-stream(32, False, {"QM_INGEST_PIN": "0"})
-stream(32, False, {"QM_STREAM_CTX_PER_DEVICE": "3"})
+stream(24, False)
+for c in ("2", "3", "4", "6"):
+    stream(24, False, {"QM_STREAM_CTX_PER_DEVICE": c}); stream(24, True, {"QM_STREAM_CTX_PER_DEVICE": c})
 os.remove(f1); os.remove(f2)
 PY
 grep -v amdgpu $OUT/stream.log | tail -14

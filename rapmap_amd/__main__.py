@@ -129,7 +129,7 @@ def _quasimap(argv):
         devices = [a.device]
     # pinned memory for the stream's slots (every device of the run has its own), pinned in the background while the index is
     # opened and uploaded
-    ra.reserve_stream_memory((768 << 20) * len(devices))
+    ra.reserve_stream_memory((1280 << 20) * len(devices))
     qi = ra.QuasiIndex(a.index)
     log = (lambda *x: None) if a.quiet else (lambda *x: print(*x, file=sys.stderr, flush=True))
     out = None

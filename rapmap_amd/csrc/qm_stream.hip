@@ -171,7 +171,10 @@ int qm_stream_open_ex(const qm_index* ix, const int32_t* devices, int32_t n_devi
   s->t0 = now_s();
   s->ix = ix; s->opts = *opts; s->paired = path2 != nullptr;
   const char* cpd = getenv("QM_STREAM_CTX_PER_DEVICE");
-  const int perDev = cpd && atoi(cpd) > 0 ? atoi(cpd) : 2;
+  // contexts (map threads) per device: each uploads, maps and downloads its batch in turn, so several of them keep the link and
+  // the kernels busy at once -- 2 / 3 / 4 / 6 contexts: 118 / 124-132 / 133-144 / 116-122 M pairs/s on 40 M pairs (round 4,
+  // profiles/r04/stream_contexts_sweep.log)
+  const int perDev = cpd && atoi(cpd) > 0 ? atoi(cpd) : 4;
   const int nctx = perDev * n_devices;
   // the files first (they may not exist), then the engine fills its slots while the contexts are being created
   int rc = qm_ingest_open(path1, path2, reader_threads > 0 ? reader_threads : 8, batch_units, 2 * nctx + 2,
