@@ -171,6 +171,25 @@ int qm_map_reads(qm_ctx* ctx, const qm_opts* opts, int64_t n, const char* seq, c
 int qm_map_device(qm_ctx* ctx, const qm_opts* opts, int64_t n, const void* d_seq1, const void* d_off1,
                   const void* d_seq2, const void* d_off2, int32_t max_read_len, int64_t* n_hits,
                   qm_counters* counters);
+/* ---- 2-bit packed reads (replaces the per-record std::strings of src/FastxParser.cpp:229-328 on the way
+ * to the device).  A host-buffer call moves 100 bytes per 100-bp read over PCIe; packed it moves 26.  The format keeps EVERY
+ * character (the collector treats lower case, N, IUPAC codes and U differently, include/SACollector.hpp:176-192,498-536):
+ *   read i's characters [off[i], off[i+1]) sit four to a byte -- character j of a group in bits 2j, 2j+1; A 0, C 1, G 2, T 3,
+ *   upper case only -- from byte qm_packed_offset(off, i) = (off[i] >> 2) + i on (reads never share a byte: any number of
+ *   threads may pack different reads of one batch side by side);
+ *   every other character is an EXCEPTION {position in the concatenated sequence, character} and has code 0 in the packed bytes.
+ * The device unpacks into the ASCII image the kernels read (one thread per group of four, then one per exception) and maps as
+ * qm_map_pairs / qm_map_reads do: same results, bit for bit.  qm_pack_reads is the host-side packer (the ingest engine packs
+ * in its copy tasks with the same routine); QM_E_ARG when the exceptions outgrow exc_cap (callers then send the plain characters). */
+typedef struct qm_pack_exc { uint32_t pos; uint32_t ch; } qm_pack_exc;
+int64_t qm_packed_offset(const int64_t* off, int64_t i);   /* (off[i] >> 2) + i: where read i's packed bytes start */
+int64_t qm_packed_bytes(const int64_t* off, int64_t n);    /* (off[n] >> 2) + n + 8: bytes a packed batch of n reads takes */
+int qm_pack_reads(const char* seq, const int64_t* off, int64_t n, uint8_t* packed, qm_pack_exc* exc, int64_t exc_cap, int64_t* n_exc);
+int qm_map_pairs_packed(qm_ctx* ctx, const qm_opts* opts, int64_t n, const uint8_t* packed1, const int64_t* off1, const qm_pack_exc* exc1,
+                        int64_t n_exc1, const uint8_t* packed2, const int64_t* off2, const qm_pack_exc* exc2, int64_t n_exc2,
+                        int64_t* n_hits, qm_counters* counters);
+int qm_map_reads_packed(qm_ctx* ctx, const qm_opts* opts, int64_t n, const uint8_t* packed, const int64_t* off, const qm_pack_exc* exc,
+                        int64_t n_exc, int64_t* n_hits, qm_counters* counters);
 /* Copy the results of the last map call to host memory:
  * hit_offsets[n+1] (exclusive prefix sum), hits[n_hits].  Large results come
  * down through pinned staging buffers and are placed by several host threads. */

@@ -31,7 +31,7 @@ assert HIT_DTYPE.itemsize == 32 and INTERVAL_DTYPE.itemsize == 20
 ABI_SYMBOLS = [
     "qm_last_error", "qm_version", "qm_opts_default", "qm_index_open", "qm_index_close", "qm_index_info_get",
     "qm_index_txp_name", "qm_index_txp_len", "qm_index_arrays", "qm_index_raw", "qm_ctx_create", "qm_ctx_destroy", "qm_ctx_device_bytes",
-    "qm_map_pairs", "qm_map_reads", "qm_map_device", "qm_fetch_hits", "qm_result_device", "qm_ctx_set_debug",
+    "qm_map_pairs", "qm_map_reads", "qm_map_device", "qm_pack_reads", "qm_packed_offset", "qm_packed_bytes", "qm_map_pairs_packed", "qm_map_reads_packed", "qm_fetch_hits", "qm_result_device", "qm_ctx_set_debug",
     "qm_fetch_intervals", "qm_last_kernel_ms", "qm_ctx_stat", "qm_build_index", "qm_build_index_ex",
     "qm_collect_reads", "qm_fetch_found", "qm_hits_to_mappings", "qm_fetch_read_lists", "qm_merge_lists", "qm_fetch_too_many",
     "qm_map_pairs_stages", "qm_stage_bytes", "qm_fetch_stages", "qm_pinned_alloc", "qm_pinned_free", "qm_ctx_create_ex", "qm_fetch_hits_pinned", "qm_xxh64",
@@ -135,6 +135,11 @@ def lib():
     L.qm_merge_lists.argtypes = [C.c_void_p, C.POINTER(QmOpts), C.c_int64] + [C.c_void_p] * 8 + [C.POINTER(C.c_int64), C.POINTER(QmCounters)]
     L.qm_fetch_too_many.argtypes = [C.c_void_p, C.c_void_p]
     L.qm_map_pairs_stages.argtypes = L.qm_map_pairs.argtypes
+    L.qm_pack_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    L.qm_map_pairs_packed.argtypes = [C.c_void_p, C.POINTER(QmOpts), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(QmCounters)]
+    L.qm_map_reads_packed.argtypes = [C.c_void_p, C.POINTER(QmOpts), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                      C.POINTER(C.c_int64), C.POINTER(QmCounters)]
     L.qm_stage_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     L.qm_fetch_stages.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(QmStageView)]
     L.qm_pinned_alloc.argtypes = [C.c_int64]; L.qm_pinned_alloc.restype = C.c_void_p
@@ -394,6 +399,24 @@ class QuasiMapper:
         r_too = tm[:n]
         return r, r_too
 
+    def map_pairs_packed(self, seq1, off1, seq2, off2, opts=None):
+        """map_pairs with the reads sent 2-bit packed (qm_pack_reads on the host, qm_map_pairs_packed): same result"""
+        opts = opts or default_opts()
+        a = [pack_2bit(seq1, off1), pack_2bit(seq2, off2)]
+        n = len(a[0][1]) - 1
+        nh, ctr = C.c_int64(0), QmCounters()
+        _check(lib().qm_map_pairs_packed(self._h, C.byref(opts), n, a[0][0].ctypes.data, a[0][1].ctypes.data, a[0][2].ctypes.data, len(a[0][2]),
+                                         a[1][0].ctypes.data, a[1][1].ctypes.data, a[1][2].ctypes.data, len(a[1][2]), C.byref(nh), C.byref(ctr)))
+        return self._finish(n, nh, ctr)
+
+    def map_reads_packed(self, seq, off, opts=None):
+        opts = opts or default_opts()
+        pk, off, exc = pack_2bit(seq, off)
+        n = len(off) - 1
+        nh, ctr = C.c_int64(0), QmCounters()
+        _check(lib().qm_map_reads_packed(self._h, C.byref(opts), n, pk.ctypes.data, off.ctypes.data, exc.ctypes.data, len(exc), C.byref(nh), C.byref(ctr)))
+        return self._finish(n, nh, ctr)
+
     def map_pairs_stages(self, seq1, off1, seq2, off2, opts=None):
         """the three stages fused, every stage's output kept: MapResult of the merge (no caller-level bookkeeping)"""
         opts = opts or default_opts()
@@ -456,6 +479,38 @@ class QuasiMapper:
             self.close()
         except Exception:
             pass
+
+
+PACK_EXC_DTYPE = np.dtype([("pos", "<u4"), ("ch", "<u4")])
+
+
+def pack_2bit(seq, off):
+    """qm_pack_reads: (packed uint8[], off int64[n+1], exceptions {pos, ch}[]) of a batch of reads -- four characters to a byte,
+    read i from byte (off[i] >> 2) + i on, everything that is not upper-case A C G T as an exception"""
+    seq = np.ascontiguousarray(seq, dtype=np.uint8); off = np.ascontiguousarray(off, dtype=np.int64)
+    n = len(off) - 1
+    pk = np.zeros((int(off[-1]) >> 2) + n + 8, dtype=np.uint8)
+    cap = int(off[-1]) + 16
+    exc = np.zeros(cap, dtype=PACK_EXC_DTYPE)
+    ne = C.c_int64(0)
+    rc = lib().qm_pack_reads(seq.ctypes.data or 1, off.ctypes.data, n, pk.ctypes.data, exc.ctypes.data, cap, C.byref(ne))
+    if rc != 0:
+        raise QmError(lib().qm_io_last_error().decode())
+    return pk, off, exc[: ne.value].copy()
+
+
+def unpack_2bit(pk, off, exc):
+    """the inverse, in numpy (tests): the characters the device's unpack kernels write"""
+    off = np.asarray(off, dtype=np.int64); n = len(off) - 1
+    out = np.zeros(int(off[-1]), dtype=np.uint8)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for i in range(n):
+        o, e = int(off[i]), int(off[i + 1])
+        b = pk[(o >> 2) + i:(o >> 2) + i + (e - o + 3) // 4]
+        codes = ((b[:, None] >> (2 * np.arange(4))[None, :]) & 3).reshape(-1)[: e - o]
+        out[o:e] = lut[codes]
+    out[exc["pos"]] = exc["ch"].astype(np.uint8)
+    return out
 
 
 class _Mem:
@@ -586,10 +641,10 @@ class MappedStream:
     def stats(self):
         """seconds: read_s = open to the last batch packed (wall), map_s / fetch_s = upload + kernels / download summed over the
         contexts, parse_cpu_s / copy_cpu_s = the ingest workers' task time summed over the workers"""
-        a = (C.c_double * 12)()
-        _check(lib().qm_stream_stats_ex(self._h, a, 12))
+        a = (C.c_double * 13)()
+        _check(lib().qm_stream_stats_ex(self._h, a, 13))
         return dict(zip(("read_s", "map_s", "fetch_s", "caller_wait_s", "open_s", "alloc_s", "first_batch_s", "parse_cpu_s", "copy_cpu_s",
-                         "inflate_s", "bytes_parsed", "last_mapped_s"), [float(x) for x in a]))
+                         "inflate_s", "bytes_parsed", "last_mapped_s", "packed_batches"), [float(x) for x in a]))
 
     def close(self):
         if self._h:

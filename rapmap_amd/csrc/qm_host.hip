@@ -135,6 +135,8 @@ struct qm_ctx {
   // -s (selective alignment) work areas
   uint32_t* d_txpOff = nullptr; int32_t* d_txpLen = nullptr;
   unsigned char* d_selscr = nullptr; int64_t capSelScr = 0;
+  uint8_t* d_pk1 = nullptr; uint8_t* d_pk2 = nullptr; int64_t capPk1 = 0, capPk2 = 0;          // 2-bit packed reads as uploaded (qm_map_*_packed)
+  qm_pack_exc* d_exc1 = nullptr; qm_pack_exc* d_exc2 = nullptr; int64_t capExc1 = 0, capExc2 = 0;
   unsigned char* d_kswRows = nullptr; int64_t capKswRows = 0;   // -s: alignment blocks of the device-memory edition (long reads, band beyond 97)
   long long* d_slowq = nullptr; int64_t capSlowq = 0;          // -s slow pass: queue, per-wave scratch descriptors and their memory
   unsigned char* d_dyn = nullptr; int64_t capDyn = 0; unsigned char* d_dynmem = nullptr; int64_t capDynMem = 0;
@@ -445,7 +447,7 @@ int qm_ctx_destroy(qm_ctx* c) {
   }
   void* ptrs[] = {c->d_cnt, c->d_lcnt, c->d_loff, c->d_lists, c->d_hits, c->d_offs,
                   c->d_scal, c->d_gscr, c->d_scanTmp, c->d_seq1, c->d_seq2, c->d_off1, c->d_off2, c->d_iv, c->d_ivcnt, c->d_ivoff, c->d_found, c->d_tooMany, c->d_ivIn, c->d_ivInOff, c->d_lenIn, c->d_foundIn,
-                  c->d_selscr, c->d_kswRows, c->d_slowq, c->d_dyn, c->d_dynmem, c->d_toff, c->d_tmp, c->d_tkeys, c->d_tsc, c->d_tref, c->d_tcix, c->d_tasks};
+                  c->d_selscr, c->d_kswRows, c->d_pk1, c->d_pk2, c->d_exc1, c->d_exc2, c->d_slowq, c->d_dyn, c->d_dynmem, c->d_toff, c->d_tmp, c->d_tkeys, c->d_tsc, c->d_tref, c->d_tcix, c->d_tasks};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
@@ -1129,6 +1131,60 @@ int qm_map_pairs(qm_ctx* c, const qm_opts* o, int64_t n, const char* seq1, const
 int qm_map_reads(qm_ctx* c, const qm_opts* o, int64_t n, const char* seq, const int64_t* off, int64_t* n_hits,
                  qm_counters* counters) {
   return map_host(c, o, n, seq, off, nullptr, nullptr, n_hits, counters, RunReq());
+}
+
+// 2-bit packed reads in, the ASCII image the kernels read built on the device (include/qmap_mi355.h)
+static int unpack_mate(qm_ctx* c, int64_t n, const uint8_t* pk, const int64_t* off, const qm_pack_exc* exc, int64_t nexc, uint8_t*& d_seq, int64_t& capSeq,
+                       long long*& d_off, int64_t& capOff, uint8_t*& d_pk, int64_t& capPk, qm_pack_exc*& d_exc, int64_t& capExc, int32_t& maxLen, int32_t& maxShort) {
+  int32_t mateMax = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t l = off[i + 1] - off[i];
+    if (l < 0) return fail(QM_E_ARG, "offsets not monotone");
+    if (l > mateMax) mateMax = (int32_t)(l > 0x7fffffff ? 0x7fffffff : l);
+    if (l <= QM_MAX_READ_LEN && l > maxShort) maxShort = (int32_t)l;
+  }
+  if (mateMax > maxLen) maxLen = mateMax;
+  if (off[n] > 0xffffffffLL) return fail(QM_E_ARG, "more than 2^32 characters in one packed batch");
+  int rc;
+  const int64_t pkBytes = qm_packed_bytes(off, n);
+  if ((rc = ensure(d_seq, capSeq, off[n] + 64))) return rc;
+  if ((rc = ensure(d_off, capOff, n + 1))) return rc;
+  if ((rc = ensure(d_pk, capPk, pkBytes))) return rc;
+  if ((rc = ensure(d_exc, capExc, nexc + 1))) return rc;
+  HIPCHK(hipMemcpyAsync(d_off, off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d_pk, pk, (size_t)pkBytes - 8, hipMemcpyHostToDevice, c->stream));
+  if (nexc > 0) HIPCHK(hipMemcpyAsync(d_exc, exc, (size_t)nexc * sizeof(qm_pack_exc), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemsetAsync(d_seq + off[n], 0, 64, c->stream));      // the mapper fetches reads a word at a time: defined bytes behind the last one
+  HIPCHK(qmk_unpack_reads(d_pk, d_off, n, (mateMax + 3) / 4, d_seq, d_exc, nexc, c->stream));
+  return QM_OK;
+}
+
+static int map_packed(qm_ctx* c, const qm_opts* o, int64_t n, const uint8_t* pk1, const int64_t* off1, const qm_pack_exc* exc1, int64_t nexc1,
+                      const uint8_t* pk2, const int64_t* off2, const qm_pack_exc* exc2, int64_t nexc2, int64_t* n_hits, qm_counters* counters) {
+  if (!c || n < 0 || (n > 0 && (!pk1 || !off1)) || nexc1 < 0 || nexc2 < 0 || (nexc1 > 0 && !exc1) || (nexc2 > 0 && !exc2)) return fail(QM_E_ARG, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  int rc;
+  if ((rc = check_opts(o))) return rc;
+  static const int64_t zero[2] = {0, 0};
+  static const uint8_t none[8] = {0};
+  if (n == 0) { off1 = zero; pk1 = none; if (pk2) { off2 = zero; pk2 = none; } }
+  int32_t maxLen = 0, maxShort = 0;
+  if ((rc = unpack_mate(c, n, pk1, off1, exc1, nexc1, c->d_seq1, c->capSeq1, c->d_off1, c->capOff1, c->d_pk1, c->capPk1, c->d_exc1, c->capExc1, maxLen, maxShort))) return rc;
+  if (pk2 && (rc = unpack_mate(c, n, pk2, off2, exc2, nexc2, c->d_seq2, c->capSeq2, c->d_off2, c->capOff2, c->d_pk2, c->capPk2, c->d_exc2, c->capExc2, maxLen, maxShort))) return rc;
+  if (maxLen > len_limit(o)) { hipStreamSynchronize(c->stream); return fail(QM_E_TOOLONG, "read length %d > %d", maxLen, len_limit(o)); }
+  rc = map_device_impl(c, o, n, c->d_seq1, c->d_off1, pk2 ? c->d_seq2 : nullptr, pk2 ? c->d_off2 : nullptr, maxLen, n_hits, counters, nullptr, RunReq(), maxShort > 0 ? maxShort : 1);
+  hipStreamSynchronize(c->stream);                         // nothing of the caller's buffers is in flight after return (error paths too)
+  return rc;
+}
+
+int qm_map_pairs_packed(qm_ctx* c, const qm_opts* o, int64_t n, const uint8_t* pk1, const int64_t* off1, const qm_pack_exc* exc1, int64_t nexc1,
+                        const uint8_t* pk2, const int64_t* off2, const qm_pack_exc* exc2, int64_t nexc2, int64_t* n_hits, qm_counters* counters) {
+  if (!pk2 || !off2) return fail(QM_E_ARG, "qm_map_pairs_packed needs both mates");
+  return map_packed(c, o, n, pk1, off1, exc1, nexc1, pk2, off2, exc2, nexc2, n_hits, counters);
+}
+int qm_map_reads_packed(qm_ctx* c, const qm_opts* o, int64_t n, const uint8_t* pk, const int64_t* off, const qm_pack_exc* exc, int64_t nexc,
+                        int64_t* n_hits, qm_counters* counters) {
+  return map_packed(c, o, n, pk, off, exc, nexc, nullptr, nullptr, nullptr, 0, n_hits, counters);
 }
 
 int qm_fetch_hits(qm_ctx* c, int64_t* hit_offsets, qm_hit* hits) {

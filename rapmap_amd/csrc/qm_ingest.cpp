@@ -48,6 +48,7 @@
 
 #include "../../include/qmap_mi355.h"
 #include "qm_io_internal.h"
+#include "qm_pack.h"
 
 namespace {
 
@@ -325,6 +326,10 @@ void form_batches(qm_ingest* g) {
       }
       ok = ensure_buf(B, &B.off[s], &B.cap_off[s], (size_t)n + 1) && ensure_buf(B, &B.seq[s], &B.cap_seq[s], (size_t)seqBytes + 64);
       if (ok && names) ok = ensure_buf(B, &B.noff[s], &B.cap_noff[s], (size_t)n + 1) && ensure_buf(B, &B.names[s], &B.cap_names[s], (size_t)nameBytes + 1);
+      if (ok && (g->flags & QM_INGEST_PACK)) {
+        ok = ensure_buf(B, &B.pk[s], &B.cap_pk[s], (size_t)(seqBytes >> 2) + (size_t)n + 8) && ensure_buf(B, &B.exc[s], &B.cap_exc[s], (size_t)(seqBytes >> 5) + 4096);
+        B.n_exc[s] = 0;
+      }
       if (ok) {
         B.off[s][n] = seqBytes; memset(B.seq[s] + seqBytes, 0, 64);   // the mapper fetches reads a word at a time: defined bytes behind the last one
         if (names) B.noff[s][n] = nameBytes;
@@ -379,8 +384,10 @@ void link_done(qm_ingest* g, Src& S) {
 void run_copy(qm_ingest* g, const CopyTask& T) {
   InSlot& L = g->slots[(size_t)T.slot];
   const Chunk& C = *T.ch; const int s = C.src;
-  const qm_batch_bufs& B = L.bufs;
+  qm_batch_bufs& B = L.bufs;
   const bool names = !(g->flags & QM_INGEST_NO_NAMES);
+  const bool pack = (g->flags & QM_INGEST_PACK) != 0 && B.pk[s] != nullptr;
+  uint8_t* pk = B.pk[s]; qm_pack_exc* exc = B.exc[s]; int64_t* nexc = &B.n_exc[s]; const int64_t excCap = (int64_t)B.cap_exc[s];
   char* seq = B.seq[s]; int64_t* off = B.off[s]; char* nm = names ? B.names[s] : nullptr; int64_t* noff = names ? B.noff[s] : nullptr;
   const Rec* R = C.recs.data();
   const int64_t s0 = T.dstSeq - R[T.r0].cumSeq, n0 = T.dstName - R[T.r0].cumName;
@@ -403,6 +410,15 @@ void run_copy(qm_ingest* g, const CopyTask& T) {
     const char* sp = arena ? C.arena.data() + (R[i].seqOff & ~ARENA) : C.base + R[i].seqOff;
     off[d] = s0 + R[i].cumSeq;
     put(seq, s0 + R[i].cumSeq, endSeq, sp, sl, arena);
+    if (pack) {
+      // the same characters four to a byte, in the bytes that are this read's alone; what is not A C G T goes on the slot's
+      // exception list (an atomic counter: such characters are rare)
+      const int64_t o = s0 + R[i].cumSeq;
+      qm_pack::pack_read((const unsigned char*)sp, sl, pk + (o >> 2) + d, [&](size_t j, unsigned char c) {
+        const int64_t at = __atomic_fetch_add(nexc, (int64_t)1, __ATOMIC_RELAXED);
+        if (at < excCap) exc[at] = qm_pack_exc{(uint32_t)(o + (int64_t)j), (uint32_t)c};
+      });
+    }
     if (names) {
       noff[d] = n0 + R[i].cumName;
       put(nm, n0 + R[i].cumName, endName, C.base + R[i].nameOff, R[i + 1].cumName - R[i].cumName, false);
@@ -944,20 +960,26 @@ int qm_ingest_open(const char* path1, const char* path2, int32_t n_threads, int6
       const double sb = (double)c.recs[c.n].cumSeq / c.n, nb = (double)c.recs[c.n].cumName / c.n;
       const size_t capSeq = (size_t)((double)batch_units * (sb * 1.05 + 1.0)) + 4096, capNames = (size_t)((double)batch_units * (nb * 1.05 + 1.0)) + 4096;
       const size_t capOff = (size_t)batch_units + 1 + 4096;
-      for (int kind = 0; kind < (names ? 4 : 2); ++kind) {
+      const bool packed = (flags & QM_INGEST_PACK) != 0;
+      for (int kind = 0; kind < 6; ++kind) {
+        if ((kind == 2 || kind == 3) && !names) continue;
+        if (kind >= 4 && !packed) continue;
         { std::lock_guard<std::mutex> lk(g->mu); for (InSlot& L : g->slots) L.allocLeft++; }   // (allocators of earlier kinds are already counting down)
         g->allocators.emplace_back([g, s, kind, capSeq, capNames, capOff]() {
           for (size_t i = 0; i < g->slots.size(); ++i) {
             { std::lock_guard<std::mutex> lk(g->mu); if (g->stop) return; }
             qm_batch_bufs& B = g->slots[i].bufs;
-            const size_t bytes = kind == 0 ? capSeq : (kind == 2 ? capNames : capOff * 8);
+            const size_t capPk = capSeq / 4 + capOff + 8, capExc = capSeq / 32 + 4096;
+            const size_t bytes = kind == 0 ? capSeq : (kind == 2 ? capNames : (kind == 4 ? capPk : (kind == 5 ? capExc * sizeof(qm_pack_exc) : capOff * 8)));
             void* p = B.alloc(bytes);
             std::lock_guard<std::mutex> lk(g->mu);
             if (p) {
               if (kind == 0) { B.seq[s] = (char*)p; B.cap_seq[s] = capSeq; }
               else if (kind == 1) { B.off[s] = (int64_t*)p; B.cap_off[s] = capOff; }
               else if (kind == 2) { B.names[s] = (char*)p; B.cap_names[s] = capNames; }
-              else { B.noff[s] = (int64_t*)p; B.cap_noff[s] = capOff; }
+              else if (kind == 3) { B.noff[s] = (int64_t*)p; B.cap_noff[s] = capOff; }
+              else if (kind == 4) { B.pk[s] = (uint8_t*)p; B.cap_pk[s] = capPk; }
+              else { B.exc[s] = (qm_pack_exc*)p; B.cap_exc[s] = capExc; }
             }
             if (--g->slots[i].allocLeft == 0) { form_batches(g); g->cvWork.notify_all(); }
           }
@@ -1090,7 +1112,7 @@ void qm_ingest_close(qm_ingest* g) {
   for (Chunk* c : g->freeChunks) delete c;
   for (InSlot& L : g->slots) {
     qm_batch_bufs& B = L.bufs;
-    for (int m = 0; m < 2; ++m) { if (B.seq[m]) B.release(B.seq[m]); if (B.off[m]) B.release(B.off[m]); if (B.names[m]) B.release(B.names[m]); if (B.noff[m]) B.release(B.noff[m]); }
+    for (int m = 0; m < 2; ++m) { if (B.seq[m]) B.release(B.seq[m]); if (B.off[m]) B.release(B.off[m]); if (B.names[m]) B.release(B.names[m]); if (B.noff[m]) B.release(B.noff[m]); if (B.pk[m]) B.release(B.pk[m]); if (B.exc[m]) B.release(B.exc[m]); }
   }
   delete g;
 }

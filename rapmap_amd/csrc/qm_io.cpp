@@ -30,6 +30,7 @@
 
 #include "../../include/qmap_mi355.h"
 #include "qm_io_internal.h"
+#include "qm_pack.h"
 
 static thread_local char g_ioerr[512] = "";
 int qm_io_fail(int code, const char* fmt, ...) {          // (shared with qm_ingest.cpp)
@@ -89,6 +90,35 @@ struct qm_reader {
 };
 
 extern "C" {
+
+int64_t qm_packed_offset(const int64_t* off, int64_t i) { return (off[i] >> 2) + i; }
+int64_t qm_packed_bytes(const int64_t* off, int64_t n) { return (off[n] >> 2) + n + 8; }
+
+int qm_pack_reads(const char* seq, const int64_t* off, int64_t n, uint8_t* packed, qm_pack_exc* exc, int64_t exc_cap, int64_t* n_exc) {
+  if (n < 0 || (n > 0 && (!seq || !off || !packed)) || !n_exc) return io_fail(QM_E_ARG, "qm_pack_reads: bad argument");
+  if (n > 0 && off[n] > 0xffffffffLL) return io_fail(QM_E_ARG, "qm_pack_reads: more than 2^32 characters in one batch");
+  // reads never share a packed byte: the batch is cut into runs of reads that threads pack side by side
+  const int nt = n >= (1 << 16) ? 8 : 1;
+  std::vector<std::vector<qm_pack_exc>> ex((size_t)nt);
+  std::vector<std::thread> th;
+  auto work = [&](int t) {
+    const int64_t a = n * t / nt, b = n * (t + 1) / nt;
+    for (int64_t i = a; i < b; ++i) {
+      const int64_t o = off[i], len = off[i + 1] - o;
+      if (len < 0) continue;
+      qm_pack::pack_read((const unsigned char*)seq + o, (size_t)len, packed + qm_packed_offset(off, i),
+                         [&](size_t j, unsigned char c) { ex[(size_t)t].push_back(qm_pack_exc{(uint32_t)(o + (int64_t)j), (uint32_t)c}); });
+    }
+  };
+  for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto& x : th) x.join();
+  int64_t tot = 0; for (auto& v : ex) tot += (int64_t)v.size();
+  *n_exc = tot;
+  if (tot > exc_cap || (tot > 0 && !exc)) return io_fail(QM_E_ARG, "qm_pack_reads: %lld exceptions, room for %lld", (long long)tot, (long long)exc_cap);
+  int64_t w = 0; for (auto& v : ex) { if (!v.empty()) memcpy(exc + w, v.data(), v.size() * sizeof(qm_pack_exc)); w += (int64_t)v.size(); }
+  return QM_OK;
+}
 
 int qm_reader_open(const char* path1, const char* path2, int32_t n_threads, qm_reader** out) {
   if (!path1 || !out) return io_fail(QM_E_ARG, "qm_reader_open: null argument");

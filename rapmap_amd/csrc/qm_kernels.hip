@@ -312,6 +312,25 @@ __global__ void build_slots_from_ph_kernel(DevIndex ix, long long n, Bucket* buc
   }
 }
 
+// 2-bit packed reads (include/qmap_mi355.h): thread (read r, group g) turns packed byte (off[r] >> 2) + r + g into the characters
+// off[r] + 4g .. + 3 of the ASCII image; exceptions (anything but upper-case A C G T) are written over it afterwards
+__global__ __launch_bounds__(256) void qm_unpack_kernel(const unsigned char* packed, const long long* off, long long n, int G, unsigned char* seq) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long r = t / G; const int g = (int)(t - r * G);
+  if (r >= n) return;
+  const long long o = off[r]; const int len = (int)(off[r + 1] - o);
+  if (4 * g >= len) return;
+  const unsigned b = packed[(o >> 2) + r + g];
+  const unsigned lut = 0x54474341u;                       // 'A' 'C' 'G' 'T' from the low byte up
+  unsigned char* d = seq + o + 4 * g;
+  const int m = len - 4 * g < 4 ? len - 4 * g : 4;
+  for (int j = 0; j < m; ++j) d[j] = (unsigned char)(lut >> (8 * ((b >> (2 * j)) & 3u)));
+}
+__global__ __launch_bounds__(256) void qm_unpack_exc_kernel(const qm_pack_exc* exc, long long n, unsigned char* seq) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) seq[exc[t].pos] = (unsigned char)exc[t].ch;
+}
+
 struct U32ToI64 { __device__ long long operator()(u32 x) const { return (long long)x; } };
 struct U32MaskToI64 { __device__ long long operator()(u32 x) const { return (long long)(x & 0x7fffffffu); } };
 
@@ -500,6 +519,16 @@ hipError_t qmk_pair_write(const void* pp, hipStream_t st) {
   const PairBatch& P = *(const PairBatch*)pp;
   if (P.n <= 0) return hipSuccess;
   hipLaunchKernelGGL(qm_pair_write_kernel, dim3((unsigned)((P.n + 255) / 256)), dim3(256), 0, st, P);
+  return hipGetLastError();
+}
+
+hipError_t qmk_unpack_reads(const unsigned char* packed, const long long* off, long long n, int G, unsigned char* seq, const void* exc, long long n_exc,
+                            hipStream_t st) {
+  if (n > 0 && G > 0) {
+    const long long threads = n * (long long)G;
+    hipLaunchKernelGGL(qm_unpack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, packed, off, n, G, seq);
+  }
+  if (n_exc > 0) hipLaunchKernelGGL(qm_unpack_exc_kernel, dim3((unsigned)((n_exc + 255) / 256)), dim3(256), 0, st, (const qm_pack_exc*)exc, n_exc, seq);
   return hipGetLastError();
 }
 

@@ -102,6 +102,8 @@ struct qm_stream {
   const qm_index* ix = nullptr;
   qm_opts opts{};
   bool paired = false;
+  bool packed = true;                      // batches go to the device 2-bit packed (QM_STREAM_NO_PACK=1: as characters)
+  int64_t nPacked = 0;                     // batches that did
   qm_ingest* g = nullptr;
   std::vector<qm_ctx*> ctx; std::vector<int> ctxDev;
   std::vector<OutSlot> slots;
@@ -136,7 +138,14 @@ static void map_loop(qm_stream* s, int which) {
     OutSlot& S = s->slots[(size_t)si];
     { std::unique_lock<std::mutex> lk(s->mu); S.in = in; S.n = n; S.seqNo = seq; S.state = 1; S.device = s->ctxDev[(size_t)which]; }
     const double t0 = now_s(); double t1 = t0, t2 = t0, ta = 0;
-    if (s->paired) rc = qm_map_pairs(c, &s->opts, n, in->seq[0], in->off[0], in->seq[1], in->off[1], &S.nHits, &S.ctr);
+    // the batch travels 2-bit packed (26 bytes per 100-bp read instead of 100) unless its exceptions outgrew their list
+    const bool packed = s->packed && in->pk[0] && in->n_exc[0] <= (int64_t)in->cap_exc[0] && (!s->paired || (in->pk[1] && in->n_exc[1] <= (int64_t)in->cap_exc[1]));
+    if (packed) {
+      if (s->paired) rc = qm_map_pairs_packed(c, &s->opts, n, in->pk[0], in->off[0], in->exc[0], in->n_exc[0], in->pk[1], in->off[1], in->exc[1], in->n_exc[1], &S.nHits, &S.ctr);
+      else rc = qm_map_reads_packed(c, &s->opts, n, in->pk[0], in->off[0], in->exc[0], in->n_exc[0], &S.nHits, &S.ctr);
+      __atomic_fetch_add(&s->nPacked, 1, __ATOMIC_RELAXED);
+    }
+    else if (s->paired) rc = qm_map_pairs(c, &s->opts, n, in->seq[0], in->off[0], in->seq[1], in->off[1], &S.nHits, &S.ctr);
     else rc = qm_map_reads(c, &s->opts, n, in->seq[0], in->off[0], &S.nHits, &S.ctr);
     t1 = now_s();
     if (!rc) {
@@ -170,6 +179,7 @@ int qm_stream_open_ex(const qm_index* ix, const int32_t* devices, int32_t n_devi
   qm_stream* s = new qm_stream();
   s->t0 = now_s();
   s->ix = ix; s->opts = *opts; s->paired = path2 != nullptr;
+  { const char* np = getenv("QM_STREAM_NO_PACK"); s->packed = !(np && atoi(np) != 0); }
   const char* cpd = getenv("QM_STREAM_CTX_PER_DEVICE");
   // contexts (map threads) per device: each uploads, maps and downloads its batch in turn, so several of them keep the link and
   // the kernels busy at once -- 2 / 3 / 4 / 6 contexts: 118 / 124-132 / 133-144 / 116-122 M pairs/s on 40 M pairs (round 4,
@@ -178,7 +188,7 @@ int qm_stream_open_ex(const qm_index* ix, const int32_t* devices, int32_t n_devi
   const int nctx = perDev * n_devices;
   // the files first (they may not exist), then the engine fills its slots while the contexts are being created
   int rc = qm_ingest_open(path1, path2, reader_threads > 0 ? reader_threads : 8, batch_units, 2 * nctx + 2,
-                          (stream_flags & QM_STREAM_NO_NAMES) ? QM_INGEST_NO_NAMES : 0u, pin_alloc, pin_free, &s->g);
+                          ((stream_flags & QM_STREAM_NO_NAMES) ? QM_INGEST_NO_NAMES : 0u) | (s->packed ? QM_INGEST_PACK : 0u), pin_alloc, pin_free, &s->g);
   if (rc) { sfail(rc, qm_io_last_error()); delete s; return rc; }
   s->slots.resize((size_t)(2 * nctx + 2));
   // one thread per device creates that device's contexts one after the other: the first builds the index replica, the
@@ -279,15 +289,17 @@ int qm_stream_next(qm_stream* s, qm_stream_batch* b) {
 /* seconds spent so far: [0] the ingest engine, open to its last batch packed (wall), [1] upload + kernels (summed over the
  * contexts), [2] download (summed), [3] the caller waiting in qm_stream_next, [4] qm_stream_open, [5] growing the pinned result
  * buffers; qm_stream_stats_ex adds [6] open to the first batch packed, [7] parse tasks (summed over the workers), [8] copy tasks
- * (summed), [9] inflate threads, [10] bytes parsed, [11] open to the last batch mapped and downloaded (wall) */
+ * (summed), [9] inflate threads, [10] bytes parsed, [11] open to the last batch mapped and downloaded (wall), [12] batches that
+ * went to the device 2-bit packed */
 int qm_stream_stats_ex(qm_stream* s, double* out, int32_t n) {
   if (!s || !out || n < 0) return sfail(QM_E_ARG, "qm_stream_stats: bad argument");
-  double v[12] = {0}; double ing[8] = {0};
+  double v[13] = {0}; double ing[8] = {0};
   qm_ingest_stats(s->g, ing);
   std::unique_lock<std::mutex> lk(s->mu);
   v[0] = ing[6]; v[1] = s->tMap; v[2] = s->tFetch; v[3] = s->tWait; v[4] = s->tOpen; v[5] = s->tAlloc;
   v[6] = ing[0]; v[7] = ing[1]; v[8] = ing[2]; v[9] = ing[3]; v[10] = ing[4]; v[11] = s->tLastMapped;
-  for (int i = 0; i < n && i < 12; ++i) out[i] = v[i];
+  v[12] = (double)__atomic_load_n(&s->nPacked, __ATOMIC_RELAXED);
+  for (int i = 0; i < n && i < 13; ++i) out[i] = v[i];
   return QM_OK;
 }
 int qm_stream_stats(qm_stream* s, double* out6) { return qm_stream_stats_ex(s, out6, 6); }

@@ -43,3 +43,33 @@ def test_reverse_read(oracle_mod):
     lib.qo_reverse_read(s, len(s), out)
     assert out.raw == b"NNNNNNNNAANNACGTACGT"
     assert sam.reverse_read(s) == out.raw
+
+
+def test_two_bit_packing_round_trip(lib_built):
+    """qm_pack_reads (the host-side packer the ingest engine's copy tasks share) against the numpy restatement of what the device's
+    unpack kernels write: every character comes back -- upper-case A C G T out of the packed bytes, everything else (lower case,
+    N, IUPAC codes, U, '$') out of the exception list -- for ragged lengths incl. empty reads, reads around the 32-character
+    vector width and batches large enough for the threaded path; reads never share a packed byte"""
+    import random
+    import numpy as np
+    from rapmap_amd import api
+    rnd = random.Random(3)
+    alphabet = "ACGT" * 12 + "acgtNnRYKMSWBDHVUu$"
+    for nreads, lens in ((400, [0, 1, 2, 3, 4, 5, 31, 32, 33, 63, 64, 65, 100, 127, 250]), (70000, [100, 100, 100, 101, 36])):
+        reads = []
+        for i in range(nreads):
+            L = rnd.choice(lens)
+            dirty = rnd.random() < 0.3
+            reads.append("".join(rnd.choice(alphabet if dirty else "ACGT") for _ in range(L)).encode())
+        seq = np.frombuffer(b"".join(reads), dtype=np.uint8); off = np.zeros(nreads + 1, dtype=np.int64); off[1:] = np.cumsum([len(r) for r in reads])
+        pk, o2, exc = api.pack_2bit(seq, off)
+        assert np.array_equal(api.unpack_2bit(pk, off, exc), seq)
+        want = np.nonzero(~np.isin(seq, np.frombuffer(b"ACGT", dtype=np.uint8)))[0]
+        assert np.array_equal(np.sort(exc["pos"]), want.astype(np.uint32)) and np.array_equal(seq[exc["pos"]], exc["ch"].astype(np.uint8))
+        start = (off[:-1] >> 2) + np.arange(nreads); end = start + (np.diff(off) + 3) // 4
+        assert np.all(end[:-1] <= start[1:]) and end[-1] <= pk.size - 8
+    # an exception list that is too small is an error the caller can act on (it then sends the characters)
+    import ctypes as C
+    seq = np.frombuffer(b"NNNNNNNN", dtype=np.uint8); off = np.array([0, 8], dtype=np.int64)
+    pk = np.zeros(16, dtype=np.uint8); exc = np.zeros(4, dtype=api.PACK_EXC_DTYPE); ne = C.c_int64(0)
+    assert api.lib().qm_pack_reads(seq.ctypes.data, off.ctypes.data, 1, pk.ctypes.data, exc.ctypes.data, 4, C.byref(ne)) != 0 and ne.value == 8

@@ -714,3 +714,26 @@ def test_reads_beyond_512_bp_take_the_long_read_pass(synth_medium, synth_medium_
         r1[5] = bytes(txps[0][:2049]); q1, o1 = pack(r1)
         with pytest.raises(ra.QmError, match="2048"):
             mp.map_pairs(q1, o1, q2, o2)
+
+
+@pytest.mark.parametrize("variant", ["default", "fuzzy", "selAln", "noSensitive"])
+def test_two_bit_packed_reads_map_like_their_characters(synth_small, oracle_mod, variant):
+    """qm_map_pairs_packed / qm_map_reads_packed (2-bit packed batches over PCIe, unpacked on the device): the dirty
+    reads of synth_small -- N, lower case, IUPAC, U, '$', reads shorter than k, ragged lengths -- give the oracle's hits and
+    counters bit for bit, as the plain-character calls do"""
+    import rapmap_amd as ra
+    ix, orc = load_oracle(synth_small["idx"])
+    qi, mp = _gpu(synth_small["idx"], debug=False)
+    q1, o1 = pack(synth_small["reads1"]); q2, o2 = pack(synth_small["reads2"])
+    oo, go = {"default": ({}, {}), "fuzzy": ({"fuzzy": 1}, {"fuzzy": 1}), "selAln": ({"selAln": 1}, {"sel_aln": 1}),
+              "noSensitive": ({"sensitive": 0}, {"sensitive": 0})}[variant]
+    res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=4)
+    gr = mp.map_pairs_packed(q1, o1, q2, o2, opts=ra.default_opts(**go))
+    assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "packed pairs, %s" % variant)
+    assert res.counters == gr.counters
+    rs = orc.map_single(q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=4)
+    gs = mp.map_reads_packed(q2, o2, opts=ra.default_opts(**go))
+    assert_hits_equal(rs.hit_offsets, rs.hits, gs.hit_offsets, gs.hits, "packed single-end, %s" % variant)
+    if variant == "default":
+        z = np.zeros(0, np.uint8); zo = np.zeros(1, np.int64)
+        assert mp.map_pairs_packed(z, zo, z, zo).n_hits == 0                 # an empty batch

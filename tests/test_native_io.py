@@ -453,7 +453,39 @@ def test_multi_device_stream_matches_the_oracle(synth_small, oracle_mod, tmp_pat
         for k in tot:
             tot[k] += b.counters[k]
     ss = st.stats(); st.close()
+    assert ss["packed_batches"] > 0                      # the batches went to the devices 2-bit packed
     assert u == len(o1) - 1 and tot == res.counters and seen == set(devs)
     assert np.array_equal(np.concatenate(cnts), np.diff(res.hit_offsets))
     assert np.concatenate(hits).tobytes() == res.hits.tobytes()
     assert ss["bytes_parsed"] == os.path.getsize(f1) + os.path.getsize(f2)
+
+
+@pytest.mark.gpu
+def test_stream_batches_full_of_exceptions_travel_as_characters(synth_small, oracle_mod, tmp_path, monkeypatch):
+    """a batch whose reads are mostly N / lower case outgrows the exception list of the 2-bit packing: the stream sends such a
+    batch as plain characters (no error, same hits); QM_STREAM_NO_PACK=1 sends every batch that way"""
+    import random
+    import rapmap_amd as ra
+    ix, orc = load_oracle(synth_small["idx"])
+    qi = ra.QuasiIndex(synth_small["idx"])
+    rnd = random.Random(2)
+    r1 = list(synth_small["reads1"][:1500]); r2 = list(synth_small["reads2"][:1500])
+    for i in range(0, 1500, 2):                          # every second read: a quarter of its characters lower case / N
+        b = bytearray(r1[i])
+        for j in range(0, len(b), 4):
+            b[j] = ord("n") if rnd.random() < 0.5 else (b[j] | 0x20)
+        r1[i] = bytes(b)
+    q1, o1 = pack(r1); q2, o2 = pack(r2)
+    res = orc.map_pairs(q1, o1, q2, o2, nthreads=4)
+    f1 = str(tmp_path / "r1.fq"); f2 = str(tmp_path / "r2.fq")
+    for f, rds in ((f1, r1), (f2, r2)):
+        with open(f, "wb") as fh:
+            for k, r in enumerate(rds):
+                fh.write(b"@r%d\n" % k + r + b"\n+\n" + b"I" * len(r) + b"\n")
+    for nopack in (False, True):
+        if nopack:
+            monkeypatch.setenv("QM_STREAM_NO_PACK", "1")
+        st = ra.MappedStream(qi, f1, f2, batch_units=1500, threads=3, names=False)
+        hits = np.concatenate([b.hits.copy() for b in st]); ss = st.stats(); st.close()
+        assert hits.tobytes() == res.hits.tobytes()
+        assert ss["packed_batches"] == 0                 # overflowed (first round) / switched off (second)
