@@ -645,7 +645,9 @@ def other_configs(oc, args, ra, qd, oracles, oracle, qi, idx_dir, mp, s1, s2, of
     o_sel = ra.default_opts(sel_aln=1)
     oo_sel = oracle.default_opts(selAln=1)
     mp.map_device(min(n, 100000), ptr[0], ptr[1], ptr[2], ptr[3], L, opts=o_sel, fetch=False)      # builds the -s extension table
-    cp = cpu_and_parity(oracles.get(idx_dir), mp, o_sel, oo_sel, s1, s2, off, ptr, n, L, args.cpu_seconds, sweep=False)
+    # (the oracle maps ~0.45 M pairs/s with -s on this host: 26 s cover the whole batch of 10 M pairs, so that the leg's parity is the
+    # full batch like the other legs')
+    cp = cpu_and_parity(oracles.get(idx_dir), mp, o_sel, oo_sel, s1, s2, off, ptr, n, L, max(args.cpu_seconds, 26.0) if n >= 5_000_000 else args.cpu_seconds, sweep=False)
     bpp, w = algorithmic_bytes_per_pair(cp["work"], cp["sample"], L)
     leg("configs[4] selective alignment (-s)", mp, o_sel, "sel", bpp, w, cp,
         "the headline's index and reads with -s: chain-scoring collector, chaining, ksw2 extension alignment, score gate",
