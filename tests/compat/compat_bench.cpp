@@ -5,7 +5,7 @@
 // only added line is `hitCollector.prefetch(rg)`.  Compiled against the header ALONE (bench.py's `compat_face` leg and
 // tests/test_rapmap_compat.py build it with g++).
 //
-//   compat_bench INDEX READS.bin NPAIRS READLEN THREADS CHUNK [--no-prefetch] [--repeat R] [--use N]
+//   compat_bench INDEX READS.bin NPAIRS READLEN THREADS CHUNK [--no-prefetch] [--repeat R] [--use N] [--mixed]
 //
 // READS.bin: NPAIRS*READLEN characters of the left mates, then as many of the right mates (what bench.py holds in HBM for the
 // headline, copied to the host).  The read groups (std::string pairs, as the parser hands them out) are built before the
@@ -44,7 +44,7 @@ static inline double now_s() { return std::chrono::duration<double>(std::chrono:
 
 template <typename RapMapIndexT>
 static void worker(RapMapIndexT& rmi, std::vector<Group>& groups, const std::vector<size_t>& firstUnit, std::atomic<size_t>& next, bool prefetch,
-                   uint32_t maxNumHits, Totals& T, rapmap::utils::HitCounters& hctr, Group* warm, std::atomic<int>& ready, std::atomic<int>& go) {
+                   uint32_t maxNumHits, Totals& T, rapmap::utils::HitCounters& hctr, Group* warm, std::atomic<int>& ready, std::atomic<int>& go, bool mixed = false) {
   using OffsetT = typename RapMapIndexT::IndexType;
   using rapmap::utils::MateStatus;
   using rapmap::utils::QuasiAlignment;
@@ -60,11 +60,11 @@ static void worker(RapMapIndexT& rmi, std::vector<Group>& groups, const std::vec
   uint32_t readLen = 0;
   rapmap::utils::HitCounters scratchCtr;
   Totals mine;                                         // (T is one element of a vector shared with the other threads: written once, at the end)
-  auto run_group = [&](Group& rg, size_t unit0, bool count) {
+  auto run_group = [&](Group& rg, size_t unit0, bool count, bool fuzzy = false) {
     Totals& T = mine;
     rapmap::utils::HitCounters& hc = count ? hctr : scratchCtr;
     const double tp0 = now_s();
-    if (prefetch) hitCollector.prefetch(rg, mc, false, maxNumHits);           // <- the one added line
+    if (prefetch) hitCollector.prefetch(rg, mc, fuzzy, maxNumHits);           // <- the one added line
     const double tp1 = now_s();
     size_t u = unit0;
     for (auto& rpair : rg) {
@@ -79,7 +79,8 @@ static void worker(RapMapIndexT& rmi, std::vector<Group>& groups, const std::vec
       (void)lh; (void)rh;
       rapmap::hit_manager::hitsToMappingsSimple(rmi, mc, MateStatus::PAIRED_END_LEFT, leftHCInfo, leftHits);
       rapmap::hit_manager::hitsToMappingsSimple(rmi, mc, MateStatus::PAIRED_END_RIGHT, rightHCInfo, rightHits);
-      rapmap::utils::mergeLeftRightHits(leftHits, rightHits, jointHits, readLen, maxNumHits, tooManyHits, hc);
+      if (fuzzy) rapmap::utils::mergeLeftRightHitsFuzzy(lh, rh, leftHits, rightHits, jointHits, mc, readLen, maxNumHits, tooManyHits, hc);
+      else rapmap::utils::mergeLeftRightHits(leftHits, rightHits, jointHits, readLen, maxNumHits, tooManyHits, hc);
       if (jointHits.size() > maxNumHits) { jointHits.clear(); }
       hc.totHits += jointHits.size();
       if (count) {
@@ -97,7 +98,7 @@ static void worker(RapMapIndexT& rmi, std::vector<Group>& groups, const std::vec
   while (true) {
     const size_t g = next.fetch_add(1);
     if (g >= groups.size()) break;
-    run_group(groups[g], firstUnit[g], true);
+    run_group(groups[g], firstUnit[g], true, mixed && (g & 1));        // --mixed: odd groups under --fuzzyIntersection
   }
   T = mine;
 }
@@ -108,9 +109,10 @@ int main(int argc, char** argv) {
     const char* idx = argv[1]; const char* path = argv[2];
     const size_t nFile = (size_t)std::atoll(argv[3]), L = (size_t)std::atoll(argv[4]);
     const int threads = std::atoi(argv[5]); const size_t chunk = (size_t)std::atoll(argv[6]);
-    bool prefetch = true; int repeat = 1; size_t n = nFile;
+    bool prefetch = true, mixed = false; int repeat = 1; size_t n = nFile;
     for (int i = 7; i < argc; ++i) {
       if (!std::strcmp(argv[i], "--no-prefetch")) prefetch = false;
+      else if (!std::strcmp(argv[i], "--mixed")) mixed = true;
       else if (!std::strcmp(argv[i], "--repeat") && i + 1 < argc) repeat = std::atoi(argv[++i]);
       else if (!std::strcmp(argv[i], "--use") && i + 1 < argc) n = std::min(nFile, (size_t)std::atoll(argv[++i]));   // only the first N pairs of the file
     }
@@ -145,7 +147,7 @@ int main(int argc, char** argv) {
       std::atomic<size_t> next{0}; std::atomic<int> ready{0}, go{0};
       std::vector<std::thread> th;
       for (int t = 0; t < threads; ++t)
-        th.emplace_back([&, t] { worker(rmi, groups, firstUnit, next, prefetch, 200u, T[(size_t)t], hctr, &warm[(size_t)t], ready, go); });
+        th.emplace_back([&, t] { worker(rmi, groups, firstUnit, next, prefetch, 200u, T[(size_t)t], hctr, &warm[(size_t)t], ready, go, mixed); });
       while (ready.load() < threads) std::this_thread::yield();
       const auto t0 = std::chrono::steady_clock::now();
       const double t0s = now_s();

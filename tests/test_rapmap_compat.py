@@ -191,3 +191,83 @@ def test_compat_digest_is_order_and_field_sensitive():
     assert d0 == bench.compat_digest(off, g)
     g = h.copy(); g["mate_pos"][0] = 9
     assert d0 != bench.compat_digest(off, g)
+
+
+UNIT = r"""
+#include <cstdio>
+#include <thread>
+#include <vector>
+#include <algorithm>
+#include "qmap_rapmap_compat.hpp"
+#define CHECK(x) do { if (!(x)) { std::printf("FAILED line %d: %s\n", __LINE__, #x); return 1; } } while (0)
+int main() {
+  // qmap::small_vector: inline up to 16, heap beyond, copies / moves, what the reference's code does with its position lists
+  qmap::small_vector<int32_t> a;
+  CHECK(a.empty() && a.capacity() == 16);
+  for (int i = 0; i < 16; ++i) a.push_back(100 - i);
+  const int32_t* inl = a.data();
+  CHECK(a.size() == 16 && a.front() == 100 && a.back() == 85);
+  a.push_back(7); CHECK(a.size() == 17 && a.data() != inl && a[16] == 7 && a[3] == 97);
+  std::sort(a.begin(), a.end()); CHECK(a.front() == 7 && a.back() == 100);
+  qmap::small_vector<int32_t> b = a; CHECK(b == a && b.data() != a.data());
+  qmap::small_vector<int32_t> c = std::move(a); CHECK(c == b && a.empty() && a.capacity() == 16);
+  a.push_back(1); CHECK(a.size() == 1 && c.size() == 17);
+  qmap::small_vector<int32_t> d{1, 2, 3}; d.insert(d.begin() + 1, 9); d.erase(d.begin()); CHECK(d.size() == 3 && d[0] == 9 && d[1] == 2 && d[2] == 3);
+  qmap::small_vector<int32_t> e = std::move(d); CHECK(e.size() == 3 && e[0] == 9 && d.empty());      // inline contents move by copy
+  b = e; CHECK(b.size() == 3 && b[2] == 3); b.resize(5, -1); CHECK(b[4] == -1); b.clear(); CHECK(b.empty());
+  rapmap::utils::QuasiAlignment q(5, 17, true, 100); q.allPositions.push_back(17);
+  std::vector<rapmap::utils::QuasiAlignment> v; for (int i = 0; i < 100; ++i) v.push_back(q);        // reallocation moves the elements
+  CHECK(v[99].allPositions.size() == 1 && v[0].allPositions[0] == 17 && v[50].tid == 5);
+  // HitCounters: the reference's member names, counted per thread, summed when read
+  rapmap::utils::HitCounters hc;
+  std::vector<std::thread> th;
+  for (int t = 0; t < 8; ++t) th.emplace_back([&hc] { for (int i = 0; i < 100000; ++i) { ++hc.numReads; hc.totHits += 3; hc.peHits++; } });
+  for (auto& t : th) t.join();
+  CHECK(hc.numReads.load() == 800000 && hc.totHits == 2400000u && hc.peHits.load() == 800000 && hc.seHits.load() == 0);
+  hc.lastPrint.store(42); CHECK(hc.lastPrint.load() == 42); hc.lastPrint = 7; CHECK(uint64_t(hc.lastPrint) == 7);
+  CHECK(hc.tooManyHits.fetch_add(5) == 0 && hc.tooManyHits.load() == 5);
+  std::printf("ok\n");
+  return 0;
+}
+"""
+
+
+def test_header_containers_behave(tmp_path, lib_built):
+    """the host-side pieces of include/qmap_rapmap_compat.hpp that replaced reference types for speed -- qmap::small_vector (for
+    chobo::small_vector) and the sharded HitCounters (for std::atomic members) -- do what the reference's code expects of them"""
+    src = tmp_path / "unit.cpp"; src.write_text(UNIT)
+    exe = tmp_path / "unit"
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), lib_built,
+                           "-Wl,-rpath," + os.path.dirname(lib_built), "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-pthread"])
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_worker_threads_with_different_settings_share_the_service(synth_medium, oracle_mod, tmp_path):
+    """compat_bench --mixed: even read groups are mapped plain, odd ones with the fuzzy merge -- groups of different settings
+    arrive at the batching service interleaved from 6 threads and must never ride in one batch: every jointHits vector equals
+    the oracle's under the settings of its group"""
+    import json
+    import bench
+    sd = synth_medium
+    ix, orc = load_oracle(sd["idx"])
+    n = len(sd["off"]) - 1; L = int(sd["off"][1]); chunk = 500
+    plain = orc.map_pairs(sd["seq1"], sd["off"], sd["seq2"], sd["off"], nthreads=4)
+    fuzzy = orc.map_pairs(sd["seq1"], sd["off"], sd["seq2"], sd["off"], opts=oracle_mod.default_opts(fuzzy=1), nthreads=4)
+    # the expected hits: unit u takes the fuzzy result when its group (u // chunk) is odd
+    use_f = ((np.arange(n) // chunk) & 1) == 1
+    cnt = np.where(use_f, np.diff(fuzzy.hit_offsets), np.diff(plain.hit_offsets))
+    off = np.zeros(n + 1, dtype=np.int64); off[1:] = np.cumsum(cnt)
+    hits = np.zeros(int(off[-1]), dtype=plain.hits.dtype)
+    for u in range(n):
+        src = fuzzy if use_f[u] else plain
+        hits[off[u]:off[u + 1]] = src.hits[src.hit_offsets[u]:src.hit_offsets[u + 1]]
+    exe = bench.build_compat_bench(str(tmp_path))
+    rp = str(tmp_path / "reads.bin")
+    with open(rp, "wb") as f:
+        f.write(np.asarray(sd["seq1"][: n * L]).tobytes()); f.write(np.asarray(sd["seq2"][: n * L]).tobytes())
+    r = subprocess.run([exe, sd["idx"], rp, str(n), str(L), "6", str(chunk), "--mixed"], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout + r.stderr
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["digest"] == bench.compat_digest(off, hits)
