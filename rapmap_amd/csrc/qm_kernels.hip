@@ -23,8 +23,11 @@ template <> struct SelLds<false> { QM_DEV SelScratchLds* ptr() { return nullptr;
 // Stage entry "from intervals" (hit_manager::hitsToMappingsSimple as a call of its own, include/HitManager.hpp:130-135): one
 // wavefront per read, the read's SA-interval hits come from the caller instead of the collector.  F: 0 or QM_F_SEL.
 struct H2mMem { u64 buf[3][QM_CAP]; IntRec ints[2][QM_ICAP]; };        // 2 KB per wave: sort buffers + the first intervals of each strand
+#ifndef QM_H2M_WPS
+#define QM_H2M_WPS 4       // waves per SIMD the list kernel is built for (its LDS -- 39 KB per block -- allows no more)
+#endif
 template <int F>
-__global__ __launch_bounds__(256, 4) void qm_h2m_kernel(DevIndex ix, ReadBatch B) {
+__global__ __launch_bounds__(256, QM_H2M_WPS) void qm_h2m_kernel(DevIndex ix, ReadBatch B) {
   __shared__ H2mMem mem[4];
   __shared__ SelLds<(F & QM_F_SEL) != 0> sels[4];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

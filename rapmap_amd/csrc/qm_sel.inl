@@ -64,7 +64,9 @@ struct SelScratchDyn {
     ngrp = (int*)q; npos = ngrp + 2;
   }
 };
+#ifndef QM_SEL_SMALL
 #define QM_SEL_SMALL 64
+#endif
 // The LDS edition (almost every read fits): one 64-record chunk, 6.4 KB per wave -- four waves per SIMD stay resident in
 // qm_h2m_kernel<QM_F_SEL>, which the kernel's registers limit it to anyway.  The sort keys
 // share their bytes with the second strand's groups (written only after that strand's sort), and the read's list is
