@@ -38,7 +38,9 @@ __global__ __launch_bounds__(256, QM_H2M_WPS) void qm_h2m_kernel(DevIndex ix, Re
 #ifdef QM_TIMING       // phases of this kernel (-s): 0 interval records in, 1 suffixes gathered, 2 sort, 3 groups + chaining, 4 list assembled, 6 write-out
   if ((threadIdx.x & 63) == 0) { for (int i = 0; i < 9; ++i) qm_tim[wave][i] = 0; qm_tim[wave][9] = __builtin_readcyclecounter(); }
 #endif
-  for (long long r = gw; r < B.nreads; r += nw) {
+  long long nslots = B.nreads;
+  if (B.nreads_dev) { const long long q = (long long)uniform(*B.nreads_dev); nslots = q < nslots ? q : nslots; }
+  for (long long r = gw; r < nslots; r += nw) {
     const long long read = read_id<F>(B, r);
     H2mMem& M = mem[wave];
     IntervalList fi, ri;
@@ -85,6 +87,23 @@ __global__ __launch_bounds__(256, QM_H2M_WPS) void qm_h2m_kernel(DevIndex ix, Re
 #ifdef QM_TIMING
   if ((threadIdx.x & 63) == 0) for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long*)&B.cursor[32 + i], (unsigned long long)qm_tim[wave][i]);
 #endif
+}
+
+// The list kernel of a fused -s call, several reads per wavefront (qm_selpack.inl): every wavefront owns a contiguous range of
+// the reads and walks it in batches of as many reads as fit its 64 lanes; what it cannot take goes to `todoq` for qm_h2m_kernel.
+#ifndef QM_PK_WPS
+#define QM_PK_WPS 6
+#endif
+__global__ __launch_bounds__(256, QM_PK_WPS) void qm_h2m_pack_kernel(DevIndex ix, ReadBatch B, long long* todoq) {
+  __shared__ PackMem mem[4];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long long gw = (long long)blockIdx.x * 4 + wave;
+  const long long nw = (long long)gridDim.x * 4;
+  const long long per = (B.nreads + nw - 1) / nw;
+  long long r = gw * per;
+  const long long rEnd = r + per < B.nreads ? r + per : B.nreads;
+  WaveAlloc wa; wa.base = -1; wa.used = 0; wa.ivBase = -1; wa.ivUsed = 0;
+  while (r < rEnd) r += (long long)sel_pack_batch(ix, B, r, rEnd, mem[wave], wa, todoq);
 }
 
 // stage B pass 1: hits per unit + the HitCounters
@@ -443,6 +462,15 @@ hipError_t qmk_h2m(const void* ixp, const void* bp, int grid, int num_cu, hipStr
   const unsigned g = (unsigned)(grid < num_cu * nb ? grid : num_cu * nb);
   if (B.selscr) hipLaunchKernelGGL(qm_h2m_kernel<QM_F_SEL>, dim3(g), dim3(256), 0, st, ix, B);
   else hipLaunchKernelGGL(qm_h2m_kernel<0>, dim3(g), dim3(256), 0, st, ix, B);
+  return hipGetLastError();
+}
+hipError_t qmk_h2m_pack(const void* ixp, const void* bp, long long* todoq, int grid, int num_cu, hipStream_t st) {
+  const DevIndex& ix = *(const DevIndex*)ixp;
+  const ReadBatch& B = *(const ReadBatch*)bp;
+  static int nb = 0;
+  if (nb == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, qm_h2m_pack_kernel, 256, 0) != hipSuccess || nb < 1)) nb = 2;
+  const unsigned g = (unsigned)(grid < num_cu * nb ? grid : num_cu * nb);
+  hipLaunchKernelGGL(qm_h2m_pack_kernel, dim3(g), dim3(256), 0, st, ix, B, todoq);
   return hipGetLastError();
 }
 hipError_t qmk_sel_merge(const void* pp, const void* ap, hipStream_t st) {

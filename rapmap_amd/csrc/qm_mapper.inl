@@ -166,6 +166,7 @@ struct ReadBatch {
   // second launch of a -s batch over the slow queue: slot r of the launch maps read slowq[r] on scratch dyn[wave]
   const long long* slowq;
   struct SelScratchDyn* dyn;
+  const u64* nreads_dev;   // qm_h2m_kernel: when set, the launch covers min(nreads, *nreads_dev) slots (a queue filled by the kernel before it)
 };
 
 // stage B launch arguments
@@ -2089,5 +2090,6 @@ QM_DEV int unit_merge(const PairBatch& P, long long u, qm_hit* out, int cap, Uni
 }
 
 #include "qm_sel.inl"
+#include "qm_selpack.inl"
 
 }  // namespace qm

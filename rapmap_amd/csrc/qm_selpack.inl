@@ -1,0 +1,272 @@
+// qm_selpack.inl -- the list kernel of -s, SEVERAL reads per wavefront (round 4).  Included at the end of qm_mapper.inl.
+//
+// qm_h2m_kernel<QM_F_SEL> gives a wavefront one read: its suffixes (a dozen on a transcriptome: the SA intervals of a read
+// hold one suffix per isoform) occupy a fifth of the lanes, and the kernel is bound by the instructions it issues, not by
+// memory.  Here a wavefront takes a run of consecutive reads whose intervals AND suffixes fit its 64 lanes -- four or five
+// reads at a time on 2 x 100 bp -- and walks them through the same steps together: one lane per interval, one lane per
+// suffix, a rank sort inside each read's segment of lanes, the lane holding a transcript's first record counts its
+// intervals and chains its hits (sel_chain_group, unchanged), prefix sums place every group's words in the batch's output.
+// What it computes per read is sel_hits_to_mappings for a read whose hits lie on ONE strand (HitManager.cpp:587-689 slack
+// intersection, :84-326 chaining, :716-807 single interval, :834-881 with an empty other side); a read with hits on both
+// strands, with more than 64 intervals or more than 64 suffixes goes on a queue for qm_h2m_kernel, which runs after this
+// one over that queue alone.
+
+#define QM_PK_READS 16             // reads a wavefront looks at per batch (it keeps the leading ones that fit)
+#define QM_SC_TODO 28              // slot of the context's scalar block: reads left for qm_h2m_kernel
+
+struct PackMem {                   // one wavefront's LDS: 5.3 KB
+  long long ivoff[QM_PK_READS];    // per read of the batch: where its interval records start in iv_in,
+  int ivcnt[QM_PK_READS];          //   how many (m: the intervals of its one strand),
+  int rlen[QM_PK_READS];           //   its length,
+  int ivs[QM_PK_READS];            //   the lane of its first interval,
+  int rb[QM_PK_READS], rn[QM_PK_READS];   // the lane of its first suffix, its suffixes (-1: the read is left for qm_h2m_kernel)
+  int rrc[QM_PK_READS];            //   1: its hits are on the reverse-complement strand
+  union {
+    struct { IntRec iv[64]; int slot[64]; int rs[64]; } a;   // per interval: the record, its read, the lane of its first suffix
+    u64 out[192];                                           // the batch's list words (a group of h records: at most 2 + h words)
+  };
+  int mark[64];
+  SelRec rec[64];                  // (iv: interval in its read | read of the batch << 8)
+  union {
+    struct { u64 k1[64], k2[64]; } k;                        // sort keys
+    struct { double f[64]; int p[64], seen[64]; } c;         // chaining DP
+  };
+  int ends[64], starts[64];
+  int sw[64];                      // a scan, where every lane can read it
+};
+
+// One batch: the reads r0 .. of the wave's range [r0, rEnd).  Returns how many it consumed (>= 1).
+QM_DEV int sel_pack_batch(const DevIndex& ix, const ReadBatch& B, long long r0, long long rEnd, PackMem& M, WaveAlloc& wa, long long* todoq) {
+#pragma clang fp contract(off)
+  const bool paired = B.seq2 != nullptr;
+  // ---- the candidates: interval count, offsets, length and foundHit of up to 16 reads, one per lane
+  LV<int> cnt, scan; LV<u32> fflag;
+  QM_LANES(l) {
+    const long long read = r0 + l;
+    int c = 0; u32 ff = 0;
+    if (l < QM_PK_READS && read < rEnd) {
+      c = (int)B.iv_in_cnt[read];
+      M.ivoff[l] = B.iv_in_off[read];
+      const int mate = paired ? (int)(read & 1) : 0; const long long unit = paired ? (read >> 1) : read;
+      const long long* off = mate ? B.off2 : B.off1;
+      M.rlen[l] = (int)(off[unit + 1] - off[unit]);
+      M.ivcnt[l] = c;
+      ff = (B.found_in && B.found_in[read]) ? 0x80000000u : 0u;
+    }
+    cnt[l] = c; scan[l] = c; fflag[l] = ff;
+  }
+  lane_scan_add(scan);
+  LV<bool> ok;
+  QM_LANES(l) { ok[l] = l < QM_PK_READS && r0 + l < rEnd && scan[l] <= 64; }
+  int R = ctz64(~ballot(ok));                             // the leading reads whose intervals fit the 64 lanes
+  if (R == 0) {                                           // more than 64 intervals in one read (long reads)
+    QM_LANES(l) { if (l == 0) { const u64 q = atomic_add_u64(B.cursor + QM_SC_TODO, 1ULL); todoq[q] = r0; } }
+    return 1;
+  }
+  const int NI = read_lane(scan, R - 1);
+  QM_LANES(l) { if (l < QM_PK_READS) M.ivs[l] = scan[l] - cnt[l]; M.mark[l] = 0; }
+  wave_fence();
+  // ---- one lane per interval; a lane finds its read by a running maximum over marks left at every read's first lane
+  QM_LANES(l) { if (l < R && cnt[l] > 0) M.mark[scan[l] - cnt[l]] = l; }
+  wave_fence();
+  LV<int> slot;
+  QM_LANES(l) { slot[l] = M.mark[l]; }
+  lane_scan_max(slot);
+  LV<int> w, wsc; LV<bool> isF, isR;
+  QM_LANES(l) {
+    int ww = 0; bool f = false, r = false;
+    if (l < NI) {
+      const int s = slot[l];
+      const qm_sa_interval_hit h = B.iv_in[M.ivoff[s] + (long long)(l - M.ivs[s])];
+      IntRec q; q.b = (u32)h.begin; q.e = (u32)h.end; q.len = h.len; q.q = h.query_pos;
+      M.a.iv[l] = q; M.a.slot[l] = s;
+      ww = (int)(q.e - q.b); r = h.query_rc != 0; f = !r;
+    }
+    w[l] = ww; wsc[l] = ww; isF[l] = f; isR[l] = r;
+  }
+  const u64 fm = ballot(isF), rm = ballot(isR);
+  lane_scan_add(wsc);
+  QM_LANES(l) { M.sw[l] = wsc[l]; M.mark[l] = 0; }
+  wave_fence();
+  // ---- per read: its suffixes, whether this kernel takes it; then the leading reads whose suffixes fit the 64 lanes
+  LV<int> rcnt, rscan; LV<bool> pk;
+  QM_LANES(l) {
+    int n = 0; bool p = false; int rc = 0;
+    if (l < R) {
+      const int c = cnt[l], s = scan[l] - c;
+      p = true;
+      if (c > 0) {
+        n = M.sw[s + c - 1] - (s > 0 ? M.sw[s - 1] : 0);
+        const u64 range = lanemask_lt(s + c) & ~lanemask_lt(s);
+        const bool hf = (fm & range) != 0, hr = (rm & range) != 0;
+        p = !(hf && hr) && n <= 64;
+        rc = hr ? 1 : 0;
+      }
+      if (!p) n = 0;
+      M.rrc[l] = rc;
+    }
+    rcnt[l] = n; rscan[l] = n; pk[l] = p;
+  }
+  lane_scan_add(rscan);
+  LV<bool> fit;
+  QM_LANES(l) { fit[l] = l < R && rscan[l] <= 64; }
+  R = ctz64(~ballot(fit));                                // >= 1: no read brings more than 64
+  const int NR = read_lane(rscan, R - 1);
+  QM_LANES(l) { if (l < R) { M.rb[l] = rscan[l] - rcnt[l]; M.rn[l] = pk[l] ? rcnt[l] : -1; } }
+  LV<bool> td;
+  QM_LANES(l) { td[l] = l < R && !pk[l]; }
+  const u64 tdm = ballot(td);
+  if (tdm) {
+    LV<u64> qb;
+    QM_LANES(l) { qb[l] = 0; if (l == 0) qb[l] = atomic_add_u64(B.cursor + QM_SC_TODO, (u64)popc64(tdm)); }
+    const u64 q0 = read_lane(qb, 0);
+    QM_LANES(l) { if (td[l]) todoq[q0 + (u64)popc64(tdm & lanemask_lt(l))] = r0 + l; }
+  }
+  wave_fence();
+  // ---- one lane per suffix: marks at every interval's first suffix, a running maximum again, one trip to sainfo
+  QM_LANES(l) {
+    if (l < NI) {
+      const int s = slot[l];
+      if (s < R && M.rn[s] > 0 && w[l] > 0) {
+        const int first = M.ivs[s];
+        const int rs = M.rb[s] + (wsc[l] - w[l]) - (first > 0 ? M.sw[first - 1] : 0);
+        M.a.rs[l] = rs; M.mark[rs] = l;
+      }
+    }
+  }
+  wave_fence();
+  LV<int> ivl;
+  QM_LANES(l) { ivl[l] = M.mark[l]; }
+  lane_scan_max(ivl);
+  LV<SelRec> mine; LV<int> myslot;
+  QM_LANES(l) {
+    myslot[l] = 0;
+    if (l < NR) {
+      const int j = ivl[l];
+      const IntRec q = M.a.iv[j]; const int s = M.a.slot[j];
+      const SaInfo e = ix.sainfo[q.b + (u32)(l - M.a.rs[j])];
+      SelRec r; r.tid = e.tid; r.pos = (u32)e.pos; r.qpos = q.q; r.len = q.len; r.iv = (u32)(j - M.ivs[s]) | ((u32)s << 8);
+      // the order of sel_wave_sort: (tid, hit position, input order) for one interval, (tid, reference end, query end, input order) for several
+      if (M.ivcnt[s] == 1) { M.k.k1[l] = ((u64)r.tid << 32) | (u64)(((u32)(r.pos - r.qpos)) ^ 0x80000000u); M.k.k2[l] = (u64)l; }
+      else { M.k.k1[l] = ((u64)r.tid << 32) | (u64)(u32)(r.pos + r.len); M.k.k2[l] = ((u64)(u32)(r.qpos + r.len) << 16) | (u64)l; }
+      mine[l] = r; myslot[l] = s;
+    }
+  }
+  wave_fence();
+  // ---- rank sort inside every read's segment
+  const int maxn = wave_max(rcnt);                        // (lanes beyond the batch's reads hold 0 or a read left for the next batch: harmless)
+  LV<int> rank;
+  QM_LANES(l) {
+    int rk = 0;
+    if (l < NR) {
+      const int s = myslot[l]; const int b = M.rb[s], n = M.rn[s];
+      const u64 a1 = M.k.k1[l], a2 = M.k.k2[l];
+      for (int t = 0; t < maxn; ++t) {
+        if (t < n) { const u64 c1 = M.k.k1[b + t], c2 = M.k.k2[b + t]; rk += (c1 < a1 || (c1 == a1 && c2 < a2)) ? 1 : 0; }
+      }
+      rk += b;
+    }
+    rank[l] = rk;
+  }
+  wave_fence();
+  QM_LANES(l) { if (l < NR) M.rec[rank[l]] = mine[l]; }
+  wave_fence();
+  // ---- groups: the lane of a transcript's first record of a read
+  LV<SelRec> rr; LV<bool> head; LV<int> sl;
+  QM_LANES(l) {
+    head[l] = false; sl[l] = 0;
+    if (l < NR) {
+      const SelRec x = M.rec[l]; rr[l] = x;
+      const int s = (int)(x.iv >> 8); sl[l] = s;
+      head[l] = l == M.rb[s] || M.rec[l - 1].tid != x.tid;
+      if (M.ivcnt[s] == 1) M.ends[l] = (int)(x.pos - x.qpos);      // one interval: every occurrence is a position (HitManager.cpp:716-807)
+    }
+  }
+  const u64 hm = ballot(head);
+  LV<int> g1v, reqN; LV<bool> req;
+  QM_LANES(l) {
+    g1v[l] = 0; req[l] = false; reqN[l] = 0;
+    if (head[l]) {
+      const u64 rest = l < 63 ? (hm & ~lanemask_lt(l + 1)) : 0ULL;
+      const int g1 = rest ? ctz64(rest) : NR;               // (the next read's first record is a head too)
+      g1v[l] = g1;
+      const int m = M.ivcnt[sl[l]];
+      if (m > 1) {
+        // intersectSAHits (HitManager.cpp:587-689) reduces to counting the distinct intervals of a transcript (see sel_strand)
+        const float requiredFrac = (float)m * B.consensus_fraction;
+        int requiredNumHits = m;
+        if (B.consensus_fraction < 1.0) { const int fl = (int)requiredFrac; requiredNumHits = fl > 1 ? fl : 1; }
+        u64 mk = 0;
+        for (int j = l; j < g1; ++j) mk |= 1ULL << (M.rec[j].iv & 63u);
+        req[l] = popc64(mk) >= requiredNumHits;
+        reqN[l] = requiredNumHits;
+      }
+    }
+  }
+  const u64 reqm = ballot(req);
+  LV<int> nsv; LV<bool> em; LV<SelGroup> gv;
+  QM_LANES(l) {
+    nsv[l] = 0; em[l] = false;
+    if (head[l]) {
+      const int s = sl[l]; const int m = M.ivcnt[s];
+      const int hn = g1v[l] - l;
+      const u32 readLen = (u32)M.rlen[s];
+      if (m == 1) {
+        const SelRec x = rr[l];
+        SelGroup g; g.tid = x.tid; g.offcs = 0; g.set_cs(x.len == readLen ? QM_CS_PERFECT : QM_CS_REGULAR); g.score = -1.7976931348623157e308;
+        g.npos = hn; g.ppos = (int)(x.pos - x.qpos);
+        gv[l] = g; nsv[l] = hn; em[l] = true;
+      } else {
+        const int b = M.rb[s], n = M.rn[s];
+        const u64 range = lanemask_lt(b + n) & ~lanemask_lt(b);
+        const bool allActive = (m - reqN[l]) > 0 && (reqm & range) == 0;          // HitManager.cpp:682-686
+        if (req[l] || allActive) {
+          SelGroup g;
+          const int ns = sel_chain_group(M.rec + l, hn, M.c.f + l, M.c.p + l, M.c.seen + l, M.ends + l, M.starts + l, (int)readLen, g, M.ends + l);
+          if (ns > 0) { gv[l] = g; nsv[l] = ns; em[l] = true; }
+        }
+      }
+    }
+  }
+  wave_fence();
+  // ---- the batch's words: header, own position, positions of every group (mergeOrientationUnique with an empty other side)
+  LV<int> wv, ws;
+  QM_LANES(l) { wv[l] = em[l] ? 2 + nsv[l] : 0; ws[l] = wv[l]; }
+  lane_scan_add(ws);
+  QM_LANES(l) { M.sw[l] = ws[l]; }
+  const int W = read_lane(ws, 63);
+  long long base = 0; bool fits = true;
+  if (W > 0) {
+    if (wa.base < 0 || wa.used + W > QM_CHUNK) {
+      LV<u64> bv;
+      QM_LANES(l) { bv[l] = 0; if (l == 0) bv[l] = atomic_add_u64(B.cursor, (u64)QM_CHUNK); }
+      wa.base = (long long)read_lane(bv, 0); wa.used = 0;
+    }
+    base = wa.base + wa.used;
+    if (base + W > B.lists_cap) { QM_LANES(l) { if (l == 0) *B.status |= 1; } fits = false; }
+    else wa.used += W;
+  }
+  QM_LANES(l) {
+    if (em[l]) {
+      const int o = ws[l] - wv[l];
+      const SelGroup g = gv[l];
+      M.out[o] = sel_header(g.tid, M.rrc[sl[l]] != 0, g.cs(), nsv[l]);
+      M.out[o + 1] = (u64)(u32)g.ppos;
+      for (int t = 0; t < nsv[l]; ++t) M.out[o + 2 + t] = (u64)(u32)M.ends[l + t];
+    }
+  }
+  wave_fence();
+  QM_LANES(l) {
+    if (l < R && pk[l]) {
+      const int n = rcnt[l], b = rscan[l] - rcnt[l];
+      int nw = 0, wb = 0;
+      if (n > 0) { wb = b > 0 ? M.sw[b - 1] : 0; nw = M.sw[b + n - 1] - wb; }
+      if (!fits) nw = 0;
+      B.lcnt[r0 + l] = (u32)nw | fflag[l];
+      B.loff[r0 + l] = nw > 0 ? base + wb : 0;
+    }
+  }
+  if (fits) { for (int b0 = 0; b0 < W; b0 += 64) { QM_LANES(l) { if (b0 + l < W) B.lists[base + b0 + l] = M.out[b0 + l]; } } }
+  wave_fence();
+  return R;
+}

@@ -103,6 +103,9 @@ QM_DEV u64 mulhi64(u64 a, u64 b) { return __umul64hi(a, b); }
 
 #ifdef QM_EMU
 QM_DEV int wave_max(const LV<int>& x) { int m = x.v[0]; for (int l = 1; l < 64; ++l) m = x.v[l] > m ? x.v[l] : m; return m; }
+// inclusive scans over the lanes: x[l] = x[0] + ... + x[l]  /  max(x[0], ..., x[l]) (values >= 0)
+QM_DEV void lane_scan_add(LV<int>& x) { for (int l = 1; l < 64; ++l) x.v[l] += x.v[l - 1]; }
+QM_DEV void lane_scan_max(LV<int>& x) { for (int l = 1; l < 64; ++l) x.v[l] = x.v[l - 1] > x.v[l] ? x.v[l - 1] : x.v[l]; }
 // out[l] = in[(l - 1) & 63]: every lane reads its lower neighbour (wrapping)
 QM_DEV void lane_rotate_up(const LV<int>& in, LV<int>& out) { for (int l = 0; l < 64; ++l) out.v[l] = in.v[(l + 63) & 63]; }
 // the same within every row of 16 lanes: lane c of a row reads lane (c - 1) & 15 of that row
@@ -167,6 +170,28 @@ QM_DEV int wave_max(const LV<int>& x) {
   t = dpp_get<0x142, 0xa>(v); v = t > v ? t : v;           // row_bcast:15 into rows 1 and 3
   t = dpp_get<0x143, 0xc>(v); v = t > v ? t : v;           // row_bcast:31 into rows 2 and 3: lane 63 has it all
   return __builtin_amdgcn_readlane(v, 63);
+}
+// inclusive scans over the 64 lanes (all lanes active): four row_shr steps inside every row of 16 -- a lane without a source
+// takes the identity 0 --, then the last lane of row 0 / 2 into row 1 / 3 and lane 31 into rows 2 and 3
+QM_DEV void lane_scan_add(LV<int>& x) {
+  int v = x.v[0];
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+  x.v[0] = v;
+}
+QM_DEV void lane_scan_max(LV<int>& x) {     // values >= 0
+  int v = x.v[0], t;
+  t = __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); v = t > v ? t : v;
+  t = __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false); v = t > v ? t : v;
+  t = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false); v = t > v ? t : v;
+  t = __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false); v = t > v ? t : v;
+  t = __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); v = t > v ? t : v;
+  t = __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); v = t > v ? t : v;
+  x.v[0] = v;
 }
 // DPP wave_ror:1 -- one VALU instruction, no trip through the LDS crossbar
 QM_DEV void lane_rotate_up(const LV<int>& in, LV<int>& out) { out.v[0] = __builtin_amdgcn_update_dpp(0, in.v[0], 0x13C, 0xf, 0xf, false); }

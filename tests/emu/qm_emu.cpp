@@ -11,6 +11,7 @@ namespace qm { unsigned long long qm_prof[32]; }
 #include "../../rapmap_amd/csrc/qm_phflat.h"
 #include <cstdlib>
 #include <cstring>
+#include <cstdio>
 #include <vector>
 
 using namespace qm;
@@ -154,6 +155,40 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
         else { switch (F) { case 4: QE_SLOW(4, 4) break; case 5: QE_SLOW(4, 5) break; case 6: QE_SLOW(4, 6) break; default: QE_SLOW(4, 7) break; } }
 #undef QE_SLOW
 #undef QE_SLOWL
+      }
+    }
+    if (o->sel_aln && !(status & (1 | 4)) && !getenv("QM_EMU_NO_PACK")) {
+      // the packed list kernel (qm_selpack.inl: several reads per wavefront) over the intervals the passes above left behind, three
+      // "waves" with a contiguous range of the reads each; every list it writes must be the one the fused path wrote for that read
+      // word for word, and the reads it leaves for the one-read kernel must be exactly those on its queue
+      std::vector<u32> lcnt2(nreads + 1, 0); std::vector<long long> loff2(nreads + 1, 0); std::vector<unsigned char> fnd(nreads + 1, 0);
+      std::vector<long long> todo((size_t)nreads + 1, -1);
+      for (long long r = 0; r < nreads; ++r) fnd[r] = (lcnt[r] >> 31) & 1;
+      ReadBatch H = B; H.iv_in = dints.data(); H.iv_in_off = doff.data(); H.iv_in_cnt = dcnt.data(); H.found_in = fnd.data();
+      H.iv_out = nullptr; H.lcnt = lcnt2.data(); H.loff = loff2.data();
+      scal[QM_SC_TODO] = 0;
+      static PackMem pm[3];
+      const long long NW = 3, per = (nreads + NW - 1) / NW;
+      for (long long w = 0; w < NW; ++w) {
+        WaveAlloc pw; pw.base = -1; pw.used = 0; pw.ivBase = -1; pw.ivUsed = 0;
+        long long r = w * per; const long long rEnd = r + per < nreads ? r + per : nreads;
+        while (r < rEnd) r += sel_pack_batch(ix, H, r, rEnd, pm[w], pw, todo.data());
+      }
+      if (!(status & 1)) {
+        std::vector<char> isTodo(nreads + 1, 0);
+        for (long long q = 0; q < (long long)scal[QM_SC_TODO]; ++q) isTodo[todo[q]] = 1;
+        long long bad = 0, npk = 0;
+        for (long long r = 0; r < nreads; ++r) {
+          if (isTodo[r]) continue;
+          ++npk;
+          bool same = lcnt2[r] == lcnt[r];
+          const long long nwd = lcnt[r] & 0x7fffffffu;
+          for (long long t = 0; same && t < nwd; ++t) same = lists[loff2[r] + t] == lists[loff[r] + t];
+          if (!same) { if (bad < 5) fprintf(stderr, "[qm emu] packed list kernel: read %lld differs (words %u vs %u)\n", r, lcnt2[r] & 0x7fffffffu, lcnt[r] & 0x7fffffffu); ++bad; }
+          else { loff[r] = loff2[r]; }        // downstream reads the packed kernel's copy
+        }
+        if (getenv("QM_EMU_PACK_STATS")) fprintf(stderr, "[qm emu] packed list kernel took %lld of %lld reads\n", npk, nreads);
+        if (bad) status |= 64;
       }
     }
     if (!(status & 1)) break;
