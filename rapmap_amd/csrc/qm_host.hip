@@ -820,7 +820,8 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
       }
     }
     if (twoPass && nreads > 0) {
-      static const bool packed = !(getenv("QM_SEL_PACK") && atoi(getenv("QM_SEL_PACK")) == 0);
+      const char* pe = getenv("QM_SEL_PACK");              // 0: the one-read-per-wavefront list kernel for every read (A/B timing, tests)
+      const bool packed = !(pe && atoi(pe) == 0);
       if (packed) {
         // several reads per wavefront first (qm_selpack.inl); what that kernel cannot take -- hits on both strands, more than 64
         // intervals or suffixes -- it queues, and the one-read-per-wavefront kernel runs over the queue (its length stays on the device)
@@ -887,6 +888,9 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
       static const char* hm[8] = {"intervals in", "suffix gather", "sort", "groups+chain", "list assembly", "(after)", "write-out", "-"};
       double ht = 0; for (int i = 0; i < 8; ++i) ht += (double)hscal[32 + i];
       if (ht > 0) for (int i = 0; i < 8; ++i) fprintf(stderr, "[qm timing h2m] %-16s %6.2f %%  %10.0f clk/read\n", hm[i], 100.0 * hscal[32 + i] / ht, (double)hscal[32 + i] / (double)nreads);
+      static const char* pm[8] = {"cand+intervals", "gather+keys", "rank sort", "heads+count", "chaining", "words", "write-out", "-"};
+      double pt = 0; for (int i = 0; i < 8; ++i) pt += (double)hscal[40 + i];
+      if (pt > 0) for (int i = 0; i < 8; ++i) fprintf(stderr, "[qm timing pack] %-16s %6.2f %%  %10.0f clk/read\n", pm[i], 100.0 * hscal[40 + i] / pt, (double)hscal[40 + i] / (double)nreads);
     }
 #endif
     if (status & 4) return fail(QM_E_TOOLONG, "a read is longer than %d characters (-s: the alignment kernels are sized for that; otherwise the long-read pass takes up to %d)", len_limit(o), QM_MAX_LONG_READ_LEN);

@@ -103,7 +103,13 @@ __global__ __launch_bounds__(256, QM_PK_WPS) void qm_h2m_pack_kernel(DevIndex ix
   long long r = gw * per;
   const long long rEnd = r + per < B.nreads ? r + per : B.nreads;
   WaveAlloc wa; wa.base = -1; wa.used = 0; wa.ivBase = -1; wa.ivUsed = 0;
+#ifdef QM_TIMING       // phases: 0 candidates + intervals, 1 suffix gather + keys, 2 rank sort, 3 heads + interval counting, 4 chaining, 5 words, 6 write-out
+  if ((threadIdx.x & 63) == 0) { for (int i = 0; i < 9; ++i) qm_tim[wave][i] = 0; qm_tim[wave][9] = __builtin_readcyclecounter(); }
+#endif
   while (r < rEnd) r += (long long)sel_pack_batch(ix, B, r, rEnd, mem[wave], wa, todoq);
+#ifdef QM_TIMING
+  if ((threadIdx.x & 63) == 0) for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long*)&B.cursor[40 + i], (unsigned long long)qm_tim[wave][i]);
+#endif
 }
 
 // stage B pass 1: hits per unit + the HitCounters

@@ -35,6 +35,70 @@ struct PackMem {                   // one wavefront's LDS: 5.3 KB
   int sw[64];                      // a scan, where every lane can read it
 };
 
+// sel_chain_group for hn <= 8 hits H (in chain order) that share one diagonal (pos - qpos): the same DP, end collection and
+// backtracking with everything in registers.  With dq == dt for every pair of hits the gap cost beta is 0 (dq >= 0 by the
+// order, dq <= the read's length), alpha = min(len_i, dq), and every score is an integer below 2^31: the comparisons
+// `cand > fi`, `fi > bestScore`, `fi == bestScore` come out as they do on the doubles.  Returns 0 when the group is not of that
+// kind (the caller takes sel_chain_group); otherwise the number of chain starts, g filled (all but its offset; the score is
+// not needed by a read with hits on one strand) and posOut[0 .. starts) = the diagonal.
+QM_DEV int sel_chain_diag8(const SelRec* H, int hn, int maxDist, SelGroup& g, int* posOut) {
+  if (hn > 8) return 0;
+  int e[8], ln[8];
+  const SelRec h0 = H[0];
+  const int diag = (int)(h0.pos - h0.qpos);
+  bool same = true;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    e[i] = 0; ln[i] = 0;
+    if (i < hn) { const SelRec h = H[i]; e[i] = (int)(h.qpos + h.len); ln[i] = (int)h.len; same = same && (int)(h.pos - h.qpos) == diag; }
+  }
+  if (!same) return 0;
+  int f[8]; u32 P = 0;                                     // p[i]: four bits each
+  int best = -1, lastBest = -1; u32 endsMask = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    f[i] = 0;
+    if (i < hn) {
+      int fi = ln[i], pi = i, looksLeft = 2; bool done = false;
+#pragma unroll
+      for (int j = i - 1; j >= 0; --j) {
+        if (!done) {
+          const int dq = e[i] - e[j];
+          const int cand = f[j] + (ln[i] < dq ? ln[i] : dq);
+          const bool take = cand > fi;
+          pi = take ? j : pi; fi = take ? cand : fi;
+          if (pi < i) { --looksLeft; if (looksLeft <= 0) done = true; }
+        }
+      }
+      f[i] = fi; P |= (u32)pi << (4 * i);
+      if (fi > best) { best = fi; lastBest = i; endsMask = 1u << i; }
+      else if (fi == best) endsMask |= 1u << i;
+    }
+  }
+  // multi-chain backtracking (:206-246)
+  u32 seen = 0; int nOptimal = 0, nStarts = 0;
+  for (u32 em = endsMask; em; em &= em - 1) {
+    int cur = __builtin_ctz(em);
+    bool fresh = true;
+    int prev = (int)((P >> (4 * cur)) & 15u);
+    while (prev < cur) {
+      if ((seen >> cur) & 1u) { fresh = false; break; }
+      seen |= 1u << cur;
+      cur = prev;
+      prev = (int)((P >> (4 * cur)) & 15u);
+    }
+    if ((seen >> cur) & 1u) fresh = false;
+    if (fresh) { ++nOptimal; posOut[nStarts++] = diag; }   // every start lies on the diagonal: allPositions is that value, nStarts times
+  }
+  g.tid = h0.tid; g.offcs = 0; g.set_cs(QM_CS_REGULAR); g.score = (double)best; g.npos = nStarts; g.ppos = diag;
+  if (hn > 1 && nOptimal == 1 && lastBest == hn - 1) {       // gapless chain (:283-305): on one diagonal the two spans are equal
+    const SelRec hl = H[hn - 1];
+    const long long qSpan = (long long)(hl.qpos + hl.len) - (long long)h0.qpos;
+    if (qSpan == (long long)maxDist) g.set_cs(QM_CS_UNGAPPED);
+  }
+  return nStarts;
+}
+
 // One batch: the reads r0 .. of the wave's range [r0, rEnd).  Returns how many it consumed (>= 1).
 QM_DEV int sel_pack_batch(const DevIndex& ix, const ReadBatch& B, long long r0, long long rEnd, PackMem& M, WaveAlloc& wa, long long* todoq) {
 #pragma clang fp contract(off)
@@ -85,6 +149,7 @@ QM_DEV int sel_pack_batch(const DevIndex& ix, const ReadBatch& B, long long r0, 
     w[l] = ww; wsc[l] = ww; isF[l] = f; isR[l] = r;
   }
   const u64 fm = ballot(isF), rm = ballot(isR);
+  QM_T(0);
   lane_scan_add(wsc);
   QM_LANES(l) { M.sw[l] = wsc[l]; M.mark[l] = 0; }
   wave_fence();
@@ -153,8 +218,11 @@ QM_DEV int sel_pack_batch(const DevIndex& ix, const ReadBatch& B, long long r0, 
     }
   }
   wave_fence();
+  QM_T(1);
   // ---- rank sort inside every read's segment
-  const int maxn = wave_max(rcnt);                        // (lanes beyond the batch's reads hold 0 or a read left for the next batch: harmless)
+  LV<int> rin;
+  QM_LANES(l) { rin[l] = l < R ? rcnt[l] : 0; }
+  const int maxn = wave_max(rin);                         // the largest segment of the batch
   LV<int> rank;
   QM_LANES(l) {
     int rk = 0;
@@ -171,6 +239,7 @@ QM_DEV int sel_pack_batch(const DevIndex& ix, const ReadBatch& B, long long r0, 
   wave_fence();
   QM_LANES(l) { if (l < NR) M.rec[rank[l]] = mine[l]; }
   wave_fence();
+  QM_T(2);
   // ---- groups: the lane of a transcript's first record of a read
   LV<SelRec> rr; LV<bool> head; LV<int> sl;
   QM_LANES(l) {
@@ -204,9 +273,10 @@ QM_DEV int sel_pack_batch(const DevIndex& ix, const ReadBatch& B, long long r0, 
     }
   }
   const u64 reqm = ballot(req);
-  LV<int> nsv; LV<bool> em; LV<SelGroup> gv;
+  QM_T(3);
+  LV<int> nsv, chainN, chainLen; LV<bool> em; LV<SelGroup> gv;
   QM_LANES(l) {
-    nsv[l] = 0; em[l] = false;
+    nsv[l] = 0; em[l] = false; chainN[l] = 0; chainLen[l] = 0;
     if (head[l]) {
       const int s = sl[l]; const int m = M.ivcnt[s];
       const int hn = g1v[l] - l;
@@ -220,15 +290,33 @@ QM_DEV int sel_pack_batch(const DevIndex& ix, const ReadBatch& B, long long r0, 
         const int b = M.rb[s], n = M.rn[s];
         const u64 range = lanemask_lt(b + n) & ~lanemask_lt(b);
         const bool allActive = (m - reqN[l]) > 0 && (reqm & range) == 0;          // HitManager.cpp:682-686
-        if (req[l] || allActive) {
-          SelGroup g;
-          const int ns = sel_chain_group(M.rec + l, hn, M.c.f + l, M.c.p + l, M.c.seen + l, M.ends + l, M.starts + l, (int)readLen, g, M.ends + l);
-          if (ns > 0) { gv[l] = g; nsv[l] = ns; em[l] = true; }
-        }
+        if (req[l] || allActive) { chainN[l] = hn; chainLen[l] = (int)readLen; }
+      }
+    }
+  }
+  // chaining (HitManager.cpp:107-307).  Nearly every transcript's hits lie on ONE diagonal; up to eight of them go through an edition of the
+  // DP that lives in registers -- on one diagonal the gap cost is zero and every score a small integer, so integer arithmetic decides every
+  // comparison as the doubles do --; anything else takes sel_chain_group, and the wavefront only enters that when some lane needs it
+  LV<bool> slow;
+  QM_LANES(l) {
+    slow[l] = false;
+    if (chainN[l] > 0) {
+      SelGroup g;
+      const int ns = sel_chain_diag8(M.rec + l, chainN[l], chainLen[l], g, M.ends + l);
+      if (ns > 0) { gv[l] = g; nsv[l] = ns; em[l] = true; } else slow[l] = true;
+    }
+  }
+  if (ballot(slow)) {
+    QM_LANES(l) {
+      if (slow[l]) {
+        SelGroup g;
+        const int ns = sel_chain_group(M.rec + l, chainN[l], M.c.f + l, M.c.p + l, M.c.seen + l, M.ends + l, M.starts + l, chainLen[l], g, M.ends + l);
+        if (ns > 0) { gv[l] = g; nsv[l] = ns; em[l] = true; }
       }
     }
   }
   wave_fence();
+  QM_T(4);
   // ---- the batch's words: header, own position, positions of every group (mergeOrientationUnique with an empty other side)
   LV<int> wv, ws;
   QM_LANES(l) { wv[l] = em[l] ? 2 + nsv[l] : 0; ws[l] = wv[l]; }
@@ -256,6 +344,7 @@ QM_DEV int sel_pack_batch(const DevIndex& ix, const ReadBatch& B, long long r0, 
     }
   }
   wave_fence();
+  QM_T(5);
   QM_LANES(l) {
     if (l < R && pk[l]) {
       const int n = rcnt[l], b = rscan[l] - rcnt[l];
@@ -268,5 +357,6 @@ QM_DEV int sel_pack_batch(const DevIndex& ix, const ReadBatch& B, long long r0, 
   }
   if (fits) { for (int b0 = 0; b0 < W; b0 += 64) { QM_LANES(l) { if (b0 + l < W) B.lists[base + b0 + l] = M.out[b0 + l]; } } }
   wave_fence();
+  QM_T(6);
   return R;
 }

@@ -412,6 +412,33 @@ def test_selective_alignment_medium(synth_medium, oracle_mod):
     assert res.counters == gr.counters
 
 
+def test_selective_alignment_list_kernels_agree(synth_medium, repeat_data, oracle_mod, monkeypatch):
+    """-s: the list kernel that shares a wavefront among several reads (qm_selpack.inl) and the one-read-per-wavefront kernel
+    (QM_SEL_PACK=0: every read) leave the same words for every read, and the hits are the oracle's either way; the repeat
+    families bring reads the packed kernel hands on (hits on both strands, more than 64 suffixes)"""
+    import rapmap_amd as ra
+    n = 12000
+    o = synth_medium["off"][: n + 1]
+    sets = [(synth_medium["idx"], synth_medium["seq1"][: o[-1]], o, synth_medium["seq2"][: o[-1]], o)]
+    q1, o1 = pack(repeat_data["reads1"]); q2, o2 = pack(repeat_data["reads2"])
+    sets.append((repeat_data["idx"], q1, o1, q2, o2))
+    for idx, a, oa, b, ob in sets:
+        ix, orc = load_oracle(idx)
+        qi, mp = _gpu(idx, debug=True)
+        res = orc.map_pairs(a, oa, b, ob, opts=oracle_mod.default_opts(selAln=1, consensusSlack=0.35), nthreads=8)
+        words = {}
+        for knob in ("1", "0"):
+            monkeypatch.setenv("QM_SEL_PACK", knob)
+            gr = mp.map_pairs_stages(a, oa, b, ob, opts=ra.default_opts(sel_aln=1, consensus_slack=0.35))
+            v = mp.fetch_stages()
+            words[knob] = (v["list_off"].copy(), v["words"].copy())
+            full = mp.map_pairs(a, oa, b, ob, opts=ra.default_opts(sel_aln=1, consensus_slack=0.35))
+            assert_hits_equal(res.hit_offsets, res.hits, full.hit_offsets, full.hits, "-s, QM_SEL_PACK=%s" % knob)
+            assert res.counters == full.counters
+        assert np.array_equal(words["1"][0], words["0"][0]) and np.array_equal(words["1"][1], words["0"][1])
+        assert words["1"][1].size > 1000
+
+
 def _medium_txps(idx, min_len=700, cap=1500):
     import rapmap_amd as ra
     qi = ra.QuasiIndex(idx)
