@@ -30,6 +30,8 @@ hipError_t qmk_map_reads_ex(const void* dev_index, const void* read_batch, int n
 // ns < 0: the "collector only" stage entry (NS=4 kernels with QM_F_COLLECT)
 hipError_t qmk_h2m(const void* dev_index, const void* read_batch, int grid, int num_cu, hipStream_t st);
 // the -s list kernel, several reads per wavefront; reads it leaves for qmk_h2m are queued in todoq (count: scalar slot QM_SC_TODO)
+// dst[i] = src[i] + add, i < n (a part's hit offsets into the whole batch's: map_device_split)
+hipError_t qmk_rebase_offsets(const long long* src, long long* dst, long long n, long long add, hipStream_t st);
 hipError_t qmk_h2m_pack(const void* dev_index, const void* read_batch, long long* todoq, int grid, int num_cu, hipStream_t st);
 hipError_t qmk_sel_merge(const void* pair_batch, const void* sel_batch, hipStream_t st);
 size_t qmk_sel_scratch_bytes(void);

@@ -24,6 +24,8 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <condition_variable>
+#include <functional>
 
 #include "qm_mapper.inl"
 #include "qm_device.h"
@@ -153,6 +155,41 @@ struct qm_ctx {
   int64_t lastUnits = -1, lastHits = 0; bool lastPaired = false;
   double lastMapMs = 0, lastTotalMs = 0;
   int64_t lastRelaunches = 0, lastSlowReads = 0;
+  // qm_map_device on a large batch: its parts on helper contexts of the same replica, in flight together (map_device_split)
+  uint32_t flags = 0; bool isHelper = false;
+  std::vector<qm_ctx*> helpers; struct SplitPool* pool = nullptr;
+};
+
+// a few parked threads that run one job per part and call (thread exit in a process with device mappings is slow: they live with the context)
+struct SplitPool {
+  std::vector<std::thread> th; std::mutex mu; std::condition_variable cv, done;
+  std::function<void(int)> job; unsigned long gen = 0; int pending = 0, parts = 0; bool stop = false;
+  explicit SplitPool(int n) {
+    for (int i = 0; i < n; ++i) th.emplace_back([this, i]() {
+      unsigned long seen = 0;
+      for (;;) {
+        std::function<void(int)> j;
+        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || (gen != seen && i < parts); }); if (stop) return; seen = gen; j = job; }
+        j(i);
+        { std::lock_guard<std::mutex> lk(mu); if (--pending == 0) done.notify_all(); }
+      }
+    });
+  }
+  void run(int n, std::function<void(int)> f) {
+    std::unique_lock<std::mutex> lk(mu);
+    job = std::move(f); parts = n; pending = n; ++gen;
+    cv.notify_all();
+    done.wait(lk, [&] { return pending == 0; });
+  }
+  ~SplitPool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for (auto& t : th) t.join(); }
+};
+// where the parts of a split call meet: every part brings its hit count once its units are counted; the last one sizes the
+// caller's result array, then each part writes its hits behind those of the parts before it
+struct SplitJoin {
+  qm_ctx* owner; int K; std::mutex mu; std::condition_variable cv;
+  long long total[8] = {0}, base[9] = {0}; int arrived = 0; bool ready = false; int failed = 0;
+  int arrive(int part, long long tot, long long& b, qm_hit*& dst);
+  void abort(int rc) { std::lock_guard<std::mutex> lk(mu); if (!failed) failed = rc ? rc : QM_E_STATE; cv.notify_all(); }
 };
 
 template <typename T>
@@ -441,6 +478,9 @@ int qm_index_raw(const qm_index* ix, int which, const void** data, int64_t* coun
 int qm_ctx_destroy(qm_ctx* c) {
   if (!c) return QM_OK;
   hipSetDevice(c->device);
+  delete c->pool; c->pool = nullptr;
+  for (qm_ctx* h : c->helpers) qm_ctx_destroy(h);
+  c->helpers.clear();
   if (!c->rep) {               // creation failed half-way: the index arrays are still this context's own
     void* own[] = {c->d_text, c->d_SA, c->d_sainfo, c->d_slots, c->d_txpOff, c->d_txpLen, c->d_saext};
     for (void* p : own) if (p) hipFree(p);
@@ -488,7 +528,7 @@ int qm_ctx_create_ex(const qm_index* ix, int device_id, uint32_t flags, qm_ctx**
   if (device_id < 0 || device_id >= ndev) return fail(QM_E_ARG, "device %d out of range (%d devices)", device_id, ndev);
   HIPCHK(hipSetDevice(device_id));
   qm_ctx* c = new qm_ctx();
-  c->ix = ix; c->device = device_id;
+  c->ix = ix; c->device = device_id; c->flags = flags;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->numCU = prop.multiProcessorCount;
 #define CK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { int rc = fail(QM_E_NOGPU, "%s: %s", #x, hipGetErrorString(_e)); qm_ctx_destroy(c); return rc; } } while (0)
@@ -684,6 +724,7 @@ struct RunReq {
   int shortLen = 0;               // the longest read that is not beyond QM_MAX_READ_LEN (0: unknown)
   // QM_RUN_FROM_INTERVALS: device arrays
   const qm_sa_interval_hit* ivIn = nullptr; const long long* ivInOff = nullptr; const int* lenIn = nullptr; const unsigned char* foundIn = nullptr;
+  SplitJoin* join = nullptr; int part = 0;   // one part of a split call (map_device_split): the hits go to the caller's array
 };
 
 static DevIndex dev_index(const qm_ctx* c) {
@@ -1014,8 +1055,14 @@ static int run_stage_b(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
   HIPCHK(hipMemcpyAsync(&total, c->d_offs + n, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  if ((rc = ensure(c->d_hits, c->capHits, (int64_t)total + 1, total / 8))) return rc;
-  P.hits = c->d_hits;
+  if (rq.join) {
+    long long b = 0; qm_hit* dst = nullptr;
+    if ((rc = rq.join->arrive(rq.part, total, b, dst))) return rc;
+    P.hits = dst + b;
+  } else {
+    if ((rc = ensure(c->d_hits, c->capHits, (int64_t)total + 1, total / 8))) return rc;
+    P.hits = c->d_hits;
+  }
   if (o->sel_aln) HIPCHK(qmk_sel_compact(&P, c->d_tmp, c->d_toff, c->stream));
   else HIPCHK(qmk_pair_write(&P, c->stream));
   return QM_OK;
@@ -1083,8 +1130,96 @@ static int map_device_impl(qm_ctx* c, const qm_opts* o, int64_t n, const void* d
   return QM_OK;
 }
 
+int SplitJoin::arrive(int part, long long tot, long long& b, qm_hit*& dst) {
+  std::unique_lock<std::mutex> lk(mu);
+  total[part] = tot;
+  if (++arrived == K && !failed) {
+    for (int i = 0; i < K; ++i) base[i + 1] = base[i] + total[i];
+    const int rc = ensure(owner->d_hits, owner->capHits, (int64_t)base[K] + 1, base[K] / 8);
+    if (rc) failed = rc; else ready = true;
+    cv.notify_all();
+  }
+  cv.wait(lk, [&] { return ready || failed; });
+  if (failed) return failed == QM_E_NOMEM ? fail(QM_E_NOMEM, "hipMalloc of the result array failed") : fail(failed, "another part of the batch failed");
+  b = base[part]; dst = owner->d_hits;
+  return QM_OK;
+}
+
+// A large device-resident batch in K parts, each on a helper context of the same replica (own stream, own work buffers),
+// in flight together: the tail of one part's persistent stage-A grid, its scans, its host round trips and (with -s) its
+// VALU-bound alignment kernels run under the other parts' stage A, which is bound by the scalar unit and by waiting
+// (profiles/r04/sel_overlap.txt).  Units, hits and counters are those of one call: part i maps units [n i / K, n (i + 1) / K),
+// its hits land in the caller's array behind those of the parts before it, its offsets are rebased into the caller's.
+static int map_device_split(qm_ctx* c, const qm_opts* o, int K, int64_t n, const void* d_seq1, const void* d_off1, const void* d_seq2,
+                            const void* d_off2, int32_t max_read_len, int64_t* n_hits, qm_counters* counters) {
+  int rc;
+  HIPCHK(hipSetDevice(c->device));
+  while ((int)c->helpers.size() < K) {
+    qm_ctx* h = nullptr;
+    if ((rc = qm_ctx_create_ex(c->ix, c->device, c->flags, &h))) return rc;
+    h->isHelper = true; c->helpers.push_back(h);
+  }
+  if (!c->pool || (int)c->pool->th.size() < K) { delete c->pool; c->pool = new SplitPool(K); }
+  if ((rc = ensure(c->d_offs, c->capOffs, n + 1))) return rc;
+  SplitJoin J; J.owner = c; J.K = K;
+  int64_t nh[8] = {0}; qm_counters ctr[8]; int rcs[8] = {0}; char errs[8][256];
+  memset(ctr, 0, sizeof(ctr));
+  const bool paired = d_seq2 != nullptr;
+  c->lastUnits = -1;
+  HIPCHK(hipEventRecord(c->evA, c->stream));
+  c->pool->run(K, [&](int i) {
+    qm_ctx* h = c->helpers[(size_t)i];
+    const int64_t u0 = n * i / K, u1 = n * (i + 1) / K;
+    RunReq rq; rq.join = &J; rq.part = i;
+    errs[i][0] = 0;
+    int r = map_device_impl(h, o, u1 - u0, d_seq1, (const long long*)d_off1 + u0, d_seq2, d_seq2 ? (const long long*)d_off2 + u0 : nullptr,
+                            max_read_len, &nh[i], &ctr[i], nullptr, rq);
+    if (r == QM_OK) {
+      // this part's offsets into the caller's array (the last part also writes the closing one)
+      hipError_t e = qmk_rebase_offsets(h->d_offs, c->d_offs + u0, (u1 - u0) + (i == K - 1 ? 1 : 0), J.base[i], h->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+      if (e != hipSuccess) r = fail(QM_E_NOGPU, "rebasing a part's offsets: %s", hipGetErrorString(e));
+    }
+    if (r != QM_OK) { snprintf(errs[i], sizeof(errs[i]), "%s", g_err); J.abort(r); }
+    rcs[i] = r;
+  });
+  for (int i = 0; i < K; ++i) if (rcs[i]) return fail(rcs[i], "%s", errs[i]);
+  HIPCHK(hipEventRecord(c->evB, c->stream));
+  HIPCHK(hipEventSynchronize(c->evB));
+  // stage A's span: first start to last end over the parts (events of different streams of one device compare)
+  float first = 1e30f, last = 0, t = 0;
+  for (int i = 0; i < K; ++i) {
+    qm_ctx* h = c->helpers[(size_t)i];
+    if (hipEventElapsedTime(&t, c->evA, h->ev0) == hipSuccess && t < first) first = t;
+    if (hipEventElapsedTime(&t, c->evA, h->ev1) == hipSuccess && t > last) last = t;
+  }
+  c->lastMapMs = last > first ? last - first : 0;
+  float ms = 0; hipEventElapsedTime(&ms, c->evA, c->evB); c->lastTotalMs = ms;
+  c->lastRelaunches = 0; c->lastSlowReads = 0;
+  qm_counters sum; memset(&sum, 0, sizeof(sum));
+  for (int i = 0; i < K; ++i) {
+    sum.pe_hits += ctr[i].pe_hits; sum.se_hits += ctr[i].se_hits; sum.tot_hits += ctr[i].tot_hits; sum.num_reads += ctr[i].num_reads;
+    sum.too_many_hits += ctr[i].too_many_hits; sum.mapped += ctr[i].mapped;
+    c->lastRelaunches += c->helpers[(size_t)i]->lastRelaunches; c->lastSlowReads += c->helpers[(size_t)i]->lastSlowReads;
+  }
+  c->lastUnits = n; c->lastHits = J.base[K]; c->lastPaired = paired;
+  c->lastIvReads = -1; c->lastFoundReads = -1; c->lastListReads = -1; c->lastTooManyUnits = -1; c->stReads = -1; c->stUnits = -1;
+  if (n_hits) *n_hits = J.base[K];
+  if (counters) *counters = sum;
+  return QM_OK;
+}
+
 int qm_map_device(qm_ctx* c, const qm_opts* o, int64_t n, const void* d_seq1, const void* d_off1, const void* d_seq2,
                   const void* d_off2, int32_t max_read_len, int64_t* n_hits, qm_counters* counters) {
+  // parts in flight together for batches of 2 M units and more (QM_SPLIT: how many; 1: none): three, with -s two (measured)
+  const char* me = getenv("QM_SPLIT_MIN");                 // (tests: split small batches too)
+  const int64_t minUnits = me && atoll(me) > 0 ? atoll(me) : ((int64_t)1 << 21);
+  if (c && o && !c->isHelper && !c->debug && n >= minUnits && d_seq1 && d_off1 && (d_seq2 == nullptr) == (d_off2 == nullptr) && check_opts(o) == QM_OK) {
+    const char* se = getenv("QM_SPLIT");
+    int K = se ? atoi(se) : (o->sel_aln ? 2 : 3);
+    if (K > 8) K = 8;
+    if (K > 1) return map_device_split(c, o, K, n, d_seq1, d_off1, d_seq2, d_off2, max_read_len, n_hits, counters);
+  }
   return map_device_impl(c, o, n, d_seq1, d_off1, d_seq2, d_off2, max_read_len, n_hits, counters, nullptr);
 }
 

@@ -470,6 +470,15 @@ hipError_t qmk_h2m(const void* ixp, const void* bp, int grid, int num_cu, hipStr
   else hipLaunchKernelGGL(qm_h2m_kernel<0>, dim3(g), dim3(256), 0, st, ix, B);
   return hipGetLastError();
 }
+__global__ __launch_bounds__(256) void qm_rebase_offsets_kernel(const long long* src, long long* dst, long long n, long long add) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[i] + add;
+}
+hipError_t qmk_rebase_offsets(const long long* src, long long* dst, long long n, long long add, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(qm_rebase_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n, add);
+  return hipGetLastError();
+}
 hipError_t qmk_h2m_pack(const void* ixp, const void* bp, long long* todoq, int grid, int num_cu, hipStream_t st) {
   const DevIndex& ix = *(const DevIndex*)ixp;
   const ReadBatch& B = *(const ReadBatch*)bp;

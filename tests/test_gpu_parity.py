@@ -301,6 +301,40 @@ def test_device_resident_inputs(synth_medium, oracle_mod):
     assert gr.map_kernel_ms > 0
 
 
+def test_device_resident_batch_in_parts(synth_medium, oracle_mod, monkeypatch):
+    """qm_map_device on a large batch maps it as parts in flight together on helper contexts (map_device_split); forced onto a
+    small one: offsets, hits and counters are those of the unsplit call and the oracle's -- default, -s, single-end, and an
+    uneven number of parts"""
+    import torch
+    import rapmap_amd as ra
+    ix, orc = load_oracle(synth_medium["idx"])
+    qi, mp = _gpu(synth_medium["idx"], debug=False)
+    n = 20001
+    o = synth_medium["off"][: n + 1]
+    q1 = synth_medium["seq1"][: o[-1]]; q2 = synth_medium["seq2"][: o[-1]]
+    pad = np.zeros(8, np.uint8)
+    d1 = torch.from_numpy(np.concatenate([q1, pad])).cuda(); d2 = torch.from_numpy(np.concatenate([q2, pad])).cuda(); do = torch.from_numpy(o).cuda()
+    torch.cuda.synchronize()
+    for oo, go in (({}, {}), ({"selAln": 1}, {"sel_aln": 1}), ({"sensitive": 0}, {"sensitive": 0})):
+        res = orc.map_pairs(q1, o, q2, o, opts=oracle_mod.default_opts(**oo), nthreads=8)
+        monkeypatch.setenv("QM_SPLIT", "1")
+        whole = mp.map_device(n, d1.data_ptr(), do.data_ptr(), d2.data_ptr(), do.data_ptr(), 100, opts=ra.default_opts(**go), fetch=True)
+        monkeypatch.setenv("QM_SPLIT_MIN", "1000")
+        for parts in ("2", "3", "5"):
+            monkeypatch.setenv("QM_SPLIT", parts)
+            gr = mp.map_device(n, d1.data_ptr(), do.data_ptr(), d2.data_ptr(), do.data_ptr(), 100, opts=ra.default_opts(**go), fetch=True)
+            assert np.array_equal(gr.hit_offsets, whole.hit_offsets) and gr.hits.tobytes() == whole.hits.tobytes(), (oo, parts)
+            assert gr.counters == whole.counters and gr.map_kernel_ms > 0
+        assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "in parts %s" % oo)
+        assert res.counters == gr.counters
+        monkeypatch.delenv("QM_SPLIT_MIN")
+    # single-end
+    monkeypatch.setenv("QM_SPLIT_MIN", "1000"); monkeypatch.setenv("QM_SPLIT", "3")
+    gs = mp.map_device(n, d1.data_ptr(), do.data_ptr(), 0, 0, 100, fetch=True)
+    rs = orc.map_single(q1, o, nthreads=8)
+    assert_hits_equal(rs.hit_offsets, rs.hits, gs.hit_offsets, gs.hits, "in parts, single-end")
+
+
 def test_repeat_families(repeat_data, oracle_mod):
     """lists beyond a lane's private memory (wave fix-up), beyond LDS (global scratch), tooManyHits, maxInterval"""
     ix, orc = load_oracle(repeat_data["idx"])
