@@ -1,16 +1,21 @@
 #!/bin/bash
-# A/B of a stage-A change: the in-tree library against profiles/variants/libqmap_base.so (the previous source), alternating, same box
+# kernel trace of split runs: when do the parts' stage-A kernels start and end?  + part-count sweep
 set -u
 OUT=$1; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-B="--no-other-configs --no-side-legs --no-cpu-baseline --steps 10 --warmup 2"
-line() { python -c "import json,sys; d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(sys.argv[2], d['value'], d['ms_per_step'], d['config'].get('map_kernel_ms'))" $1 "$2"; }
-for r in 1 2; do
-  timeout 600 python bench.py $B > $OUT/dense_new$r.json 2> $OUT/err.log; line $OUT/dense_new$r.json "dense new"
-  QM_LIB_OVERRIDE=$GRAFT_REPO_ROOT/profiles/variants/libqmap_base.so timeout 600 python bench.py $B > $OUT/dense_base$r.json 2> $OUT/err.log; line $OUT/dense_base$r.json "dense base"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python bench.py --no-cpu-baseline --no-other-configs --no-side-legs --steps 3 --warmup 1 > $OUT/trace.log 2>&1
+python - $OUT <<'PY'
+import csv, sys, glob
+f = glob.glob(sys.argv[1] + "/trace/*kernel_trace.csv")[0]
+rows = [r for r in csv.DictReader(open(f)) if "qm_read_kernel" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+t0 = int(rows[0]["Start_Timestamp"])
+for r in rows[-9:]:
+    print("stage A  start %9.3f ms  end %9.3f ms  dur %7.3f ms  grid %s" % ((int(r["Start_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, r.get("Grid_Size", "?")))
+PY
+f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1); head -6 "$f" | cut -c1-180
+for k in 5 6 8; do
+  QM_SPLIT=$k timeout 600 python bench.py --no-cpu-baseline --no-other-configs --no-side-legs --steps 10 --warmup 3 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('dense QM_SPLIT=$k', d['value'], d['ms_per_step'], d['config'].get('map_kernel_ms'))"
 done
-timeout 600 python bench.py $B --sel-aln > $OUT/sel_new.json 2> $OUT/err.log; line $OUT/sel_new.json "sel new"
-QM_LIB_OVERRIDE=$GRAFT_REPO_ROOT/profiles/variants/libqmap_base.so timeout 600 python bench.py $B --sel-aln > $OUT/sel_base.json 2> $OUT/err.log; line $OUT/sel_base.json "sel base"
-timeout 600 python bench.py $B --perfect-hash --ph-compact > $OUT/ph_new.json 2> $OUT/err.log; line $OUT/ph_new.json "ph new"
-QM_LIB_OVERRIDE=$GRAFT_REPO_ROOT/profiles/variants/libqmap_base.so timeout 600 python bench.py $B --perfect-hash --ph-compact > $OUT/ph_base.json 2> $OUT/err.log; line $OUT/ph_base.json "ph base"
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x > $OUT/pytest_parity.log 2>&1; tail -2 $OUT/pytest_parity.log

@@ -1,19 +1,21 @@
 #!/bin/bash
-# -s list kernel: occupancy variants (QM_SEL_SMALL records in the LDS edition of the scratch, waves per SIMD it is built for)
+# oversubscribed stage-A grids as the default (QM_GRID_OVERSUB=4), parts only with -s: full gpu suite, then the three head lines and a few alternatives
 set -u
 OUT=$1; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-B="--no-other-configs --no-side-legs --no-cpu-baseline --steps 5 --warmup 2 --sel-aln"
-for v in base 48_5 48_4 32_6 base; do
-  if [ $v = base ]; then unset QM_LIB_OVERRIDE; else export QM_LIB_OVERRIDE=$GRAFT_REPO_ROOT/profiles/variants/libqmap_h2m_$v.so; fi
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/st_$v -o s -- python bench.py $B > $OUT/sel_$v.log 2>&1
-  f=$(find $OUT/st_$v -name "*kernel_stats.csv" | head -1)
-  echo "== $v: $(tail -1 $OUT/sel_$v.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")"
-  grep "qm_h2m_kernel\|qm_read_kernel" $f | cut -d, -f1,2,4 | cut -c1-120
-done
-unset QM_LIB_OVERRIDE
-for L in 150 250; do for v in base 48_5; do
-  if [ $v = base ]; then unset QM_LIB_OVERRIDE; else export QM_LIB_OVERRIDE=$GRAFT_REPO_ROOT/profiles/variants/libqmap_h2m_$v.so; fi
-  timeout 600 python bench.py $B --read-len $L --pairs 4000000 > $OUT/sel_${v}_L$L.json 2> $OUT/err.log
-  echo "== $v 2x$L: $(tail -1 $OUT/sel_${v}_L$L.json | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['config'].get('map_kernel_ms'))")"
-done; done
+timeout 1800 python -m pytest tests -m gpu -q -x > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
+run() { # name, env, flags
+  env $2 timeout 600 python bench.py $3 --no-cpu-baseline --no-other-configs --no-side-legs --steps 10 --warmup 3 2>$OUT/$1.err | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['value'], d['ms_per_step'], d['config'].get('map_kernel_ms'))"
+}
+run dense_default "X=1" ""
+run dense_over6 "QM_GRID_OVERSUB=6" ""
+run sel_default "X=1" "--sel-aln"
+run sel_split2_over2 "QM_SPLIT=2 QM_GRID_OVERSUB=2" "--sel-aln"
+run sel_split1 "QM_SPLIT=1" "--sel-aln"
+run sel_split3 "QM_SPLIT=3" "--sel-aln"
+run ph_default "X=1" "--perfect-hash --ph-compact"
+run ph_split2 "QM_SPLIT=2" "--perfect-hash --ph-compact"
+run ph_split3_over2 "QM_SPLIT=3 QM_GRID_OVERSUB=2" "--perfect-hash --ph-compact"
+run phx_default "X=1" "--perfect-hash"

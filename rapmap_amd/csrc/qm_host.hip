@@ -799,7 +799,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
     B.strict_check = o->strict_check; B.max_interval = o->max_interval; B.quasi_cov = o->quasi_cov; B.sensitive = o->sensitive; B.fuzzy = paired ? o->fuzzy : 0;
     if (rq.mode == QM_RUN_FROM_INTERVALS) B.fuzzy = o->fuzzy;   // the caller says what kind of list it wants (both orientations kept or not)
     if (o->sel_aln) {                                   // -s: chain scoring + per-wave scratch for chaining (qm_sel.inl)
-      if ((rc = ensure(c->d_selscr, c->capSelScr, (int64_t)grid * 4 * (int64_t)qmk_sel_scratch_bytes()))) return rc;
+      if ((rc = ensure(c->d_selscr, c->capSelScr, (int64_t)qmk_resident_grid(nreads, c->numCU) * 4 * (int64_t)qmk_sel_scratch_bytes()))) return rc;   // (the list kernels' grids stay within residency)
       B.selscr = (SelScratch*)c->d_selscr;
       B.max_mmp_ext = o->max_mmp_extension > 0 ? o->max_mmp_extension : 7;
       const float cs = (float)o->consensus_slack;        // MappingOpts::consensusSlack is a float (RapMapSAMapper.cpp:138,184-185)
@@ -1211,12 +1211,13 @@ static int map_device_split(qm_ctx* c, const qm_opts* o, int K, int64_t n, const
 
 int qm_map_device(qm_ctx* c, const qm_opts* o, int64_t n, const void* d_seq1, const void* d_off1, const void* d_seq2,
                   const void* d_off2, int32_t max_read_len, int64_t* n_hits, qm_counters* counters) {
-  // parts in flight together for batches of 2 M units and more (QM_SPLIT: how many; 1: none): three, with -s two (measured)
+  // -s: two parts in flight together for batches of 2 M units and more (QM_SPLIT: how many, any mode; 1: none).  Without -s a call
+  // is stage A and little else, and the oversubscribed grid (qmk_map_grid) already gives one launch what the parts gave three.
   const char* me = getenv("QM_SPLIT_MIN");                 // (tests: split small batches too)
   const int64_t minUnits = me && atoll(me) > 0 ? atoll(me) : ((int64_t)1 << 21);
   if (c && o && !c->isHelper && !c->debug && n >= minUnits && d_seq1 && d_off1 && (d_seq2 == nullptr) == (d_off2 == nullptr) && check_opts(o) == QM_OK) {
     const char* se = getenv("QM_SPLIT");
-    int K = se ? atoi(se) : (o->sel_aln ? 2 : 3);
+    int K = se ? atoi(se) : (o->sel_aln ? 2 : 1);
     if (K > 8) K = 8;
     if (K > 1) return map_device_split(c, o, K, n, d_seq1, d_off1, d_seq2, d_off2, max_read_len, n_hits, counters);
   }

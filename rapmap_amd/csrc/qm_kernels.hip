@@ -429,15 +429,27 @@ hipError_t qmk_build_phfilter(const void* recs, long long n, void* filter, unsig
   return hipGetLastError();
 }
 
-int qmk_map_grid(long long nreads, int num_cu) {
+int qmk_grid_oversub(void) {
+  static int m = 0;
+  if (m == 0) { const char* e = getenv("QM_GRID_OVERSUB"); m = e && atoi(e) > 0 && atoi(e) <= 16 ? atoi(e) : 4; }
+  return m;
+}
+int qmk_resident_grid(long long nreads, int num_cu) {
   long long want = (nreads + 3) / 4;
   long long cap = (long long)num_cu * QMK_BLOCKS_PER_CU;
   return (int)(want < cap ? (want > 0 ? want : 1) : cap);
 }
+int qmk_map_grid(long long nreads, int num_cu) {
+  long long want = (nreads + 3) / 4;
+  long long cap = (long long)num_cu * QMK_BLOCKS_PER_CU * qmk_grid_oversub();
+  return (int)(want < cap ? (want > 0 ? want : 1) : cap);
+}
 
-// The kernel is a persistent grid (every wave strides over the reads), so the launch must not exceed what is
-// resident at once: blocks beyond residency would run as a second, under-populated round.  The occupancy of
-// the chosen instantiation (VGPR/LDS dependent) decides the grid.
+// The stage-A kernels are persistent grids: every wave strides over the reads.  Launched with exactly the blocks that are
+// resident at once, the reads are divided statically and the launch lasts as long as its slowest wave -- 13 % longer than the
+// average one on config 2.  Launched with QM_GRID_OVERSUB (4) times that many, a block owns a quarter of the reads and the
+// hardware hands out the blocks as slots free up: 41.6 -> 36.1 ms (profiles/r04/grid_oversub.txt; 8x: the same).  The occupancy
+// of the chosen instantiation (VGPR/LDS dependent) decides the resident count.
 // stage A: the slot-count class picks the translation unit that holds its instantiations (qm_read_kernel.inl).
 // ns < 0: the "collector only" stage entry, on the eight-slot kernels (every read length up to QM_MAX_READ_LEN).
 // collect: collector-only kernels (ns < 0: those of the stage entry, eight slots; otherwise the chain-scoring ones of slot count ns)
@@ -484,7 +496,8 @@ hipError_t qmk_h2m_pack(const void* ixp, const void* bp, long long* todoq, int g
   const ReadBatch& B = *(const ReadBatch*)bp;
   static int nb = 0;
   if (nb == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, qm_h2m_pack_kernel, 256, 0) != hipSuccess || nb < 1)) nb = 2;
-  const unsigned g = (unsigned)(grid < num_cu * nb ? grid : num_cu * nb);
+  const long long cap = (long long)num_cu * nb * qmk_grid_oversub();                 // contiguous ranges of reads per wave: more, smaller ranges balance better
+  const unsigned g = (unsigned)(grid < cap ? grid : cap);
   hipLaunchKernelGGL(qm_h2m_pack_kernel, dim3(g), dim3(256), 0, st, ix, B, todoq);
   return hipGetLastError();
 }

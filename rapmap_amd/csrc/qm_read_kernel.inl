@@ -61,15 +61,14 @@ __global__ __launch_bounds__(64 * WavesPerBlock<NS>::value, WPS) void qm_read_ke
 template <int NS, int W0, int WPH, int WNIP, int WPHNIP, int WSEL, bool WITH_COLLECT>
 static hipError_t launch_reads_ns(const DevIndex& ix, const ReadBatch& B, bool collect, int grid, int num_cu, hipStream_t st) {
   const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP) | (B.selscr ? QM_F_SEL : 0);
-  // The kernel is a persistent grid (every wave strides over the reads), so the launch must not exceed what is resident at
-  // once: blocks beyond residency would run as a second, under-populated round.  The occupancy of the chosen instantiation
-  // (VGPR/LDS dependent) decides the grid.
+  // A persistent grid (every wave strides over the reads) of QM_GRID_OVERSUB times the blocks that are resident at once: see
+  // qmk_map_grid in qm_kernels.hip.  The occupancy of the chosen instantiation (VGPR/LDS dependent) decides the resident count.
 #define QM_LAUNCH(WPS_, F_) do {                                                                               \
     static int nb = 0;                                                                                          \
     if (nb == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, qm_read_kernel<NS, WPS_, F_>, 64 * WavesPerBlock<NS>::value, 0) != hipSuccess || nb < 1)) \
       nb = WPS_;                                                                                                \
     static const char* ov = getenv("QM_BLOCKS_PER_CU");   /* tuning knob: fewer resident blocks than the occupancy allows */ \
-    long long g = (long long)num_cu * ((ov && atoi(ov) > 0 && atoi(ov) < nb) ? atoi(ov) : nb);                  \
+    long long g = (long long)num_cu * ((ov && atoi(ov) > 0 && atoi(ov) < nb) ? atoi(ov) : nb) * qmk_grid_oversub();  \
     if (g > grid) g = grid;                                                                                     \
     hipLaunchKernelGGL((qm_read_kernel<NS, WPS_, F_>), dim3((unsigned)g), dim3(64 * WavesPerBlock<NS>::value), 0, st, ix, B); \
   } while (0)

@@ -567,7 +567,7 @@ def test_list_buffer_overflow_relaunches_stage_a(repeat_data, oracle_mod):
     u1 = [repeat_data["reads1"][i] for i in core]; u2 = [repeat_data["reads2"][i] for i in core]
     a1, ao1 = pack(u1); a2, ao2 = pack(u2)
     ref = orc.map_pairs(a1, ao1, a2, ao2, nthreads=4)
-    reps = 6000                                                            # 144 000 pairs, ~170 M list words
+    reps = 12000                                                           # 288 000 pairs, ~340 M list words (the default buffer of a batch this size: 270 M)
     q1, o1 = pack(u1 * reps); q2, o2 = pack(u2 * reps)
     qi, mp = _gpu(repeat_data["idx"], debug=False)                        # a fresh context: the list buffer starts at its default size
     gr = mp.map_pairs(q1, o1, q2, o2)
