@@ -533,11 +533,13 @@ hipError_t qmk_sel_align_finish(const void* pp, const void* ap, int num_cu, hipS
   const PairBatch& P = *(const PairBatch*)pp; const SelBatch& A = *(const SelBatch*)ap;
   if (A.u1 <= A.u0) return hipSuccess;
   const unsigned nb = (unsigned)((A.u1 - A.u0 + 255) / 256);
+  // the alignment kernels stride over the tasks like stage A over the reads: oversubscribed grids for the same reason (qmk_map_grid)
+  static const int ao = getenv("QM_ALIGN_OVERSUB") && atoi(getenv("QM_ALIGN_OVERSUB")) > 0 ? atoi(getenv("QM_ALIGN_OVERSUB")) : qmk_grid_oversub();
   if (A.long_reads) {                                    // reads of 513 .. 2048 characters in the batch: two waves per block, long images
     switch (sel_ksw_ring_slots(A.bandwidth)) {
-      case 32: hipLaunchKernelGGL((qm_sel_align_kernel<32, 2, QM_KSW_MAXLEN_LONG>), dim3((unsigned)(num_cu * 4)), dim3(128), 0, st, P, A); break;
-      case 64: hipLaunchKernelGGL((qm_sel_align_kernel<64, 2, QM_KSW_MAXLEN_LONG>), dim3((unsigned)(num_cu * 4)), dim3(128), 0, st, P, A); break;
-      case 128: hipLaunchKernelGGL((qm_sel_align_kernel<128, 2, QM_KSW_MAXLEN_LONG>), dim3((unsigned)(num_cu * 3)), dim3(128), 0, st, P, A); break;
+      case 32: hipLaunchKernelGGL((qm_sel_align_kernel<32, 2, QM_KSW_MAXLEN_LONG>), dim3((unsigned)(num_cu * 4 * ao)), dim3(128), 0, st, P, A); break;
+      case 64: hipLaunchKernelGGL((qm_sel_align_kernel<64, 2, QM_KSW_MAXLEN_LONG>), dim3((unsigned)(num_cu * 4 * ao)), dim3(128), 0, st, P, A); break;
+      case 128: hipLaunchKernelGGL((qm_sel_align_kernel<128, 2, QM_KSW_MAXLEN_LONG>), dim3((unsigned)(num_cu * 3 * ao)), dim3(128), 0, st, P, A); break;
       default:                                             // bands beyond 97: blocks in device memory (the host sized A.ksw_rows for num_cu blocks)
         if (!A.ksw_rows) return hipErrorInvalidValue;
         hipLaunchKernelGGL(qm_sel_align_gmem_kernel, dim3((unsigned)num_cu), dim3(64 * QMK_GMEM_WAVES), 0, st, P, A); break;
@@ -546,14 +548,14 @@ hipError_t qmk_sel_align_finish(const void* pp, const void* ap, int num_cu, hipS
   switch (sel_ksw_ring_slots(A.bandwidth)) {            // one kernel for every --dpBandwidth: the band decides the ring
     case 32:                                                                             // register edition (--dpBandwidth <= 15), eight per wavefront
       // images sized by the read-length class of the batch (the stage-A kernels' slot classes): 13 / 17 / 21 / 37 KB of LDS per block
-      if (A.short_len > 0 && A.short_len <= 128) hipLaunchKernelGGL(qm_sel_align2_kernel<128 + 32>, dim3((unsigned)(num_cu * 8)), dim3(256), 0, st, P, A);
-      else if (A.short_len > 0 && A.short_len <= 192) hipLaunchKernelGGL(qm_sel_align2_kernel<192 + 32>, dim3((unsigned)(num_cu * 8)), dim3(256), 0, st, P, A);
-      else if (A.short_len > 0 && A.short_len <= 256) hipLaunchKernelGGL(qm_sel_align2_kernel<256 + 32>, dim3((unsigned)(num_cu * 7)), dim3(256), 0, st, P, A);
-      else hipLaunchKernelGGL(qm_sel_align2_kernel<QM_KSW_MAXLEN>, dim3((unsigned)(num_cu * 4)), dim3(256), 0, st, P, A);
+      if (A.short_len > 0 && A.short_len <= 128) hipLaunchKernelGGL(qm_sel_align2_kernel<128 + 32>, dim3((unsigned)(num_cu * 8 * ao)), dim3(256), 0, st, P, A);
+      else if (A.short_len > 0 && A.short_len <= 192) hipLaunchKernelGGL(qm_sel_align2_kernel<192 + 32>, dim3((unsigned)(num_cu * 8 * ao)), dim3(256), 0, st, P, A);
+      else if (A.short_len > 0 && A.short_len <= 256) hipLaunchKernelGGL(qm_sel_align2_kernel<256 + 32>, dim3((unsigned)(num_cu * 7 * ao)), dim3(256), 0, st, P, A);
+      else hipLaunchKernelGGL(qm_sel_align2_kernel<QM_KSW_MAXLEN>, dim3((unsigned)(num_cu * 4 * ao)), dim3(256), 0, st, P, A);
       break;
-    case 64: hipLaunchKernelGGL((qm_sel_align_kernel<64, 4>), dim3((unsigned)(num_cu * 8)), dim3(256), 0, st, P, A); break;
-    case 128: hipLaunchKernelGGL((qm_sel_align_kernel<128, 4>), dim3((unsigned)(num_cu * 4)), dim3(256), 0, st, P, A); break;
-    default: hipLaunchKernelGGL((qm_sel_align_kernel<1024, 2>), dim3((unsigned)(num_cu * 2)), dim3(128), 0, st, P, A); break;   // 83 KB of LDS per block
+    case 64: hipLaunchKernelGGL((qm_sel_align_kernel<64, 4>), dim3((unsigned)(num_cu * 8 * ao)), dim3(256), 0, st, P, A); break;
+    case 128: hipLaunchKernelGGL((qm_sel_align_kernel<128, 4>), dim3((unsigned)(num_cu * 4 * ao)), dim3(256), 0, st, P, A); break;
+    default: hipLaunchKernelGGL((qm_sel_align_kernel<1024, 2>), dim3((unsigned)(num_cu * 2 * ao)), dim3(128), 0, st, P, A); break;   // 83 KB of LDS per block
   }
   hipLaunchKernelGGL(qm_sel_finish_kernel, dim3(nb), dim3(256), 0, st, P, A);
   return hipGetLastError();
