@@ -34,6 +34,8 @@ hipError_t qmk_map_reads_ex(const void* dev_index, const void* read_batch, int n
 // ns < 0: the "collector only" stage entry (NS=4 kernels with QM_F_COLLECT)
 hipError_t qmk_h2m(const void* dev_index, const void* read_batch, int grid, int num_cu, hipStream_t st);
 // the -s list kernel, several reads per wavefront; reads it leaves for qmk_h2m are queued in todoq (count: scalar slot QM_SC_TODO)
+// ... its wide edition over the queue `ids` (*nids entries) the narrow kernel left; what it hands on goes to todoq (count: QM_SC_TODO2)
+hipError_t qmk_h2m_packw(const void* dev_index, const void* read_batch, const long long* ids, const unsigned long long* nids, long long* todoq, int grid, int num_cu, hipStream_t st);
 // dst[i] = src[i] + add, i < n (a part's hit offsets into the whole batch's: map_device_split)
 hipError_t qmk_rebase_offsets(const long long* src, long long* dst, long long n, long long add, hipStream_t st);
 hipError_t qmk_h2m_pack(const void* dev_index, const void* read_batch, long long* todoq, int grid, int num_cu, hipStream_t st);

@@ -140,7 +140,7 @@ struct qm_ctx {
   uint8_t* d_pk1 = nullptr; uint8_t* d_pk2 = nullptr; int64_t capPk1 = 0, capPk2 = 0;          // 2-bit packed reads as uploaded (qm_map_*_packed)
   qm_pack_exc* d_exc1 = nullptr; qm_pack_exc* d_exc2 = nullptr; int64_t capExc1 = 0, capExc2 = 0;
   unsigned char* d_kswRows = nullptr; int64_t capKswRows = 0;   // -s: alignment blocks of the device-memory edition (long reads, band beyond 97)
-  long long* d_todoq = nullptr; int64_t capTodoq = 0;          // -s: reads the packed list kernel left for the one-read-per-wavefront kernel
+  long long* d_todoq = nullptr; int64_t capTodoq = 0; long long* d_todoq2 = nullptr; int64_t capTodoq2 = 0;          // -s: reads the packed list kernel left for the one-read-per-wavefront kernel
   long long* d_slowq = nullptr; int64_t capSlowq = 0;          // -s slow pass: queue, per-wave scratch descriptors and their memory
   unsigned char* d_dyn = nullptr; int64_t capDyn = 0; unsigned char* d_dynmem = nullptr; int64_t capDynMem = 0;
   long long* d_toff = nullptr; int64_t capToff = 0;
@@ -498,7 +498,7 @@ int qm_ctx_destroy(qm_ctx* c) {
   }
   void* ptrs[] = {c->d_cnt, c->d_lcnt, c->d_loff, c->d_lists, c->d_hits, c->d_offs,
                   c->d_scal, c->d_gscr, c->d_scanTmp, c->d_seq1, c->d_seq2, c->d_off1, c->d_off2, c->d_iv, c->d_ivcnt, c->d_ivoff, c->d_found, c->d_tooMany, c->d_ivIn, c->d_ivInOff, c->d_lenIn, c->d_foundIn,
-                  c->d_selscr, c->d_kswRows, c->d_pk1, c->d_pk2, c->d_exc1, c->d_exc2, c->d_slowq, c->d_todoq, c->d_dyn, c->d_dynmem, c->d_toff, c->d_tmp, c->d_tkeys, c->d_tsc, c->d_tref, c->d_tcix, c->d_tasks};
+                  c->d_selscr, c->d_kswRows, c->d_pk1, c->d_pk2, c->d_exc1, c->d_exc2, c->d_slowq, c->d_todoq, c->d_todoq2, c->d_dyn, c->d_dynmem, c->d_toff, c->d_tmp, c->d_tkeys, c->d_tsc, c->d_tref, c->d_tcix, c->d_tasks};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
@@ -878,7 +878,10 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
         // intervals or suffixes -- it queues, and the one-read-per-wavefront kernel runs over the queue (its length stays on the device)
         if ((rc = ensure(c->d_todoq, c->capTodoq, nreads))) return rc;
         HIPCHK(qmk_h2m_pack(&ix, &H, c->d_todoq, grid, c->numCU, c->stream));
-        ReadBatch T = H; T.slowq = c->d_todoq; T.nreads_dev = c->d_scal + QM_SC_TODO;
+        // ... then the wide edition (256 lanes' worth per batch: reads of 150 bp and more) over that queue, which leaves one of its own
+        if ((rc = ensure(c->d_todoq2, c->capTodoq2, nreads))) return rc;
+        HIPCHK(qmk_h2m_packw(&ix, &H, c->d_todoq, (const unsigned long long*)(c->d_scal + QM_SC_TODO), c->d_todoq2, grid, c->numCU, c->stream));
+        ReadBatch T = H; T.slowq = c->d_todoq2; T.nreads_dev = c->d_scal + QM_SC_TODO2;
         HIPCHK(qmk_h2m(&ix, &T, grid, c->numCU, c->stream));
       } else HIPCHK(qmk_h2m(&ix, &H, grid, c->numCU, c->stream));
     }

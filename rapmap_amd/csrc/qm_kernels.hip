@@ -112,6 +112,21 @@ __global__ __launch_bounds__(256, QM_PK_WPS) void qm_h2m_pack_kernel(DevIndex ix
 #endif
 }
 
+// ... and its wide edition (256 intervals / suffixes per batch) over the queue the narrow one leaves: reads of 150 bp and more
+__global__ __launch_bounds__(256, 2) void qm_h2m_packw_kernel(DevIndex ix, ReadBatch B, const long long* ids, const u64* nids, long long* todoq) {
+  __shared__ PackMemW<4> mem[4];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long long gw = (long long)blockIdx.x * 4 + wave;
+  const long long nw = (long long)gridDim.x * 4;
+  long long nq = (long long)uniform(*nids);
+  if (nq > B.nreads) nq = B.nreads;
+  const long long per = (nq + nw - 1) / nw;
+  long long q = gw * per;
+  const long long qEnd = q + per < nq ? q + per : nq;
+  WaveAlloc wa; wa.base = -1; wa.used = 0; wa.ivBase = -1; wa.ivUsed = 0;
+  while (q < qEnd) q += (long long)sel_pack_batch_wide<4>(ix, B, ids, q, qEnd, mem[wave], wa, todoq);
+}
+
 // stage B pass 1: hits per unit + the HitCounters
 __global__ __launch_bounds__(256) void qm_pair_count_kernel(PairBatch P) {
   __shared__ unsigned long long sc[6];
@@ -499,6 +514,16 @@ hipError_t qmk_h2m_pack(const void* ixp, const void* bp, long long* todoq, int g
   const long long cap = (long long)num_cu * nb * qmk_grid_oversub();                 // contiguous ranges of reads per wave: more, smaller ranges balance better
   const unsigned g = (unsigned)(grid < cap ? grid : cap);
   hipLaunchKernelGGL(qm_h2m_pack_kernel, dim3(g), dim3(256), 0, st, ix, B, todoq);
+  return hipGetLastError();
+}
+hipError_t qmk_h2m_packw(const void* ixp, const void* bp, const long long* ids, const unsigned long long* nids, long long* todoq, int grid, int num_cu, hipStream_t st) {
+  const DevIndex& ix = *(const DevIndex*)ixp;
+  const ReadBatch& B = *(const ReadBatch*)bp;
+  static int nb = 0;
+  if (nb == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, qm_h2m_packw_kernel, 256, 0) != hipSuccess || nb < 1)) nb = 1;
+  const long long cap = (long long)num_cu * nb * qmk_grid_oversub();
+  const unsigned g = (unsigned)(grid < cap ? grid : cap);
+  hipLaunchKernelGGL(qm_h2m_packw_kernel, dim3(g), dim3(256), 0, st, ix, B, ids, (const u64*)nids, todoq);
   return hipGetLastError();
 }
 hipError_t qmk_sel_merge(const void* pp, const void* ap, hipStream_t st) {

@@ -360,3 +360,331 @@ QM_DEV int sel_pack_batch(const DevIndex& ix, const ReadBatch& B, long long r0, 
   QM_T(6);
   return R;
 }
+
+// ------------------------------------------------------------------ the wide edition: 64 * C intervals / suffixes per batch
+// Reads of 150 and 250 bp bring 45 .. 90 suffixes per strand (an interval every maxMMPExtension + 1 positions, a suffix per isoform in
+// each): they do not fit the 64 lanes above and went to the one-read kernel's device-memory scratch -- 725 ms per 4 M reads of 250 bp.
+// Here a lane owns C records (i = 64 c + l), the scans carry from chunk to chunk, a read still has at most 64 intervals (their set is a
+// 64-bit mask) and hits on one strand.  It runs over the queue the narrow kernel leaves (ids), and leaves a queue of its own.
+#define QM_SC_TODO2 29
+template <int C>
+struct PackMemW {
+  static constexpr int N = 64 * C;
+  long long ivoff[QM_PK_READS]; long long rid[QM_PK_READS];
+  int ivcnt[QM_PK_READS], rlen[QM_PK_READS], ivs[QM_PK_READS], rb[QM_PK_READS], rn[QM_PK_READS], rrc[QM_PK_READS];
+  int hasF[QM_PK_READS], hasR[QM_PK_READS], anyreq[QM_PK_READS];
+  union {
+    struct { IntRec iv[N]; int slot[N]; int rs[N]; } a;
+    u64 out[3 * N];
+  };
+  int mark[N];
+  SelRec rec[N];
+  union {
+    struct { u64 k1[N], k2[N]; } k;
+    struct { double f[N]; int p[N], seen[N]; } c;
+  };
+  int ends[N], starts[N];
+  int sw[N];
+};
+template <int C> QM_DEV void scan_add_c(LV<int> (&x)[C]) {
+  int carry = 0;
+#pragma unroll
+  for (int c = 0; c < C; ++c) { lane_scan_add(x[c]); QM_LANES(l) { x[c][l] += carry; } carry = read_lane(x[c], 63); }
+}
+template <int C> QM_DEV void scan_max_c(LV<int> (&x)[C]) {
+  int carry = 0;
+#pragma unroll
+  for (int c = 0; c < C; ++c) { lane_scan_max(x[c]); QM_LANES(l) { x[c][l] = x[c][l] > carry ? x[c][l] : carry; } carry = read_lane(x[c], 63); }
+}
+
+// One batch of the queue slots q0 .. of the wave's range [q0, qEnd): read ids[q].  Returns how many slots it consumed (>= 1).
+template <int C>
+QM_DEV int sel_pack_batch_wide(const DevIndex& ix, const ReadBatch& B, const long long* ids, long long q0, long long qEnd, PackMemW<C>& M,
+                               WaveAlloc& wa, long long* todoq) {
+#pragma clang fp contract(off)
+  constexpr int N = 64 * C;
+  const bool paired = B.seq2 != nullptr;
+  LV<int> cnt, scan; LV<u32> fflag; LV<bool> big; LV<long long> rdv;
+  QM_LANES(l) {
+    int c = 0; u32 ff = 0; bool bg = false; long long read = 0;
+    if (l < QM_PK_READS && q0 + l < qEnd) {
+      read = ids[q0 + l];
+      c = (int)B.iv_in_cnt[read];
+      M.ivoff[l] = B.iv_in_off[read];
+      const int mate = paired ? (int)(read & 1) : 0; const long long unit = paired ? (read >> 1) : read;
+      const long long* off = mate ? B.off2 : B.off1;
+      M.rlen[l] = (int)(off[unit + 1] - off[unit]);
+      bg = c > 64;                                          // the interval set of a transcript is a 64-bit mask: such a read is handed on
+      if (bg) c = 0;
+      M.ivcnt[l] = c; M.hasF[l] = 0; M.hasR[l] = 0; M.anyreq[l] = 0;
+      ff = (B.found_in && B.found_in[read]) ? 0x80000000u : 0u;
+    }
+    cnt[l] = c; scan[l] = c; fflag[l] = ff; big[l] = bg; rdv[l] = read;
+  }
+  lane_scan_add(scan);
+  LV<bool> ok;
+  QM_LANES(l) { ok[l] = l < QM_PK_READS && q0 + l < qEnd && scan[l] <= N; }
+  int R = ctz64(~ballot(ok));                             // >= 1: a read's (counted) intervals are at most 64
+  const int NI = read_lane(scan, R - 1);
+  QM_LANES(l) { if (l < QM_PK_READS) M.ivs[l] = scan[l] - cnt[l]; }
+#pragma unroll
+  for (int c = 0; c < C; ++c) { QM_LANES(l) { M.mark[64 * c + l] = 0; } }
+  wave_fence();
+  QM_LANES(l) { if (l < R && cnt[l] > 0) M.mark[scan[l] - cnt[l]] = l; }
+  wave_fence();
+  LV<int> slot[C], w[C], wsc[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) { QM_LANES(l) { slot[c][l] = M.mark[64 * c + l]; } }
+  scan_max_c<C>(slot);
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    QM_LANES(l) {
+      const int i = 64 * c + l;
+      int ww = 0;
+      if (i < NI) {
+        const int s = slot[c][l];
+        const qm_sa_interval_hit h = B.iv_in[M.ivoff[s] + (long long)(i - M.ivs[s])];
+        IntRec q; q.b = (u32)h.begin; q.e = (u32)h.end; q.len = h.len; q.q = h.query_pos;
+        M.a.iv[i] = q; M.a.slot[i] = s;
+        ww = (int)(q.e - q.b);
+        if (h.query_rc != 0) M.hasR[s] = 1; else M.hasF[s] = 1;
+      }
+      w[c][l] = ww; wsc[c][l] = ww;
+    }
+  }
+  scan_add_c<C>(wsc);
+#pragma unroll
+  for (int c = 0; c < C; ++c) { QM_LANES(l) { M.sw[64 * c + l] = wsc[c][l]; M.mark[64 * c + l] = 0; } }
+  wave_fence();
+  LV<int> rcnt, rscan; LV<bool> pk;
+  QM_LANES(l) {
+    int n = 0; bool p = false;
+    if (l < R) {
+      const int c = cnt[l], s = scan[l] - c;
+      p = !big[l];
+      int rc = 0;
+      if (c > 0) {
+        n = M.sw[s + c - 1] - (s > 0 ? M.sw[s - 1] : 0);
+        const bool hf = M.hasF[l] != 0, hr = M.hasR[l] != 0;
+        p = !(hf && hr) && n <= N;
+        rc = hr ? 1 : 0;
+      }
+      if (!p) n = 0;
+      M.rrc[l] = rc;
+    }
+    rcnt[l] = n; rscan[l] = n; pk[l] = p;
+  }
+  lane_scan_add(rscan);
+  LV<bool> fit;
+  QM_LANES(l) { fit[l] = l < R && rscan[l] <= N; }
+  R = ctz64(~ballot(fit));
+  const int NR = read_lane(rscan, R - 1);
+  QM_LANES(l) { if (l < R) { M.rb[l] = rscan[l] - rcnt[l]; M.rn[l] = pk[l] ? rcnt[l] : -1; } }
+  LV<bool> td;
+  QM_LANES(l) { td[l] = l < R && !pk[l]; }
+  const u64 tdm = ballot(td);
+  if (tdm) {
+    LV<u64> qb;
+    QM_LANES(l) { qb[l] = 0; if (l == 0) qb[l] = atomic_add_u64(B.cursor + QM_SC_TODO2, (u64)popc64(tdm)); }
+    const u64 qq = read_lane(qb, 0);
+    QM_LANES(l) { if (td[l]) todoq[qq + (u64)popc64(tdm & lanemask_lt(l))] = rdv[l]; }
+  }
+  wave_fence();
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    QM_LANES(l) {
+      const int i = 64 * c + l;
+      if (i < NI) {
+        const int s = slot[c][l];
+        if (s < R && M.rn[s] > 0 && w[c][l] > 0) {
+          const int first = M.ivs[s];
+          const int rs = M.rb[s] + (wsc[c][l] - w[c][l]) - (first > 0 ? M.sw[first - 1] : 0);
+          M.a.rs[i] = rs; M.mark[rs] = i;
+        }
+      }
+    }
+  }
+  wave_fence();
+  LV<int> ivl[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) { QM_LANES(l) { ivl[c][l] = M.mark[64 * c + l]; } }
+  scan_max_c<C>(ivl);
+  LV<SelRec> mine[C]; LV<int> myslot[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    QM_LANES(l) {
+      const int i = 64 * c + l;
+      myslot[c][l] = 0;
+      if (i < NR) {
+        const int j = ivl[c][l];
+        const IntRec q = M.a.iv[j]; const int s = M.a.slot[j];
+        const SaInfo e = ix.sainfo[q.b + (u32)(i - M.a.rs[j])];
+        SelRec r; r.tid = e.tid; r.pos = (u32)e.pos; r.qpos = q.q; r.len = q.len; r.iv = (u32)(j - M.ivs[s]) | ((u32)s << 8);
+        if (M.ivcnt[s] == 1) { M.k.k1[i] = ((u64)r.tid << 32) | (u64)(((u32)(r.pos - r.qpos)) ^ 0x80000000u); M.k.k2[i] = (u64)i; }
+        else { M.k.k1[i] = ((u64)r.tid << 32) | (u64)(u32)(r.pos + r.len); M.k.k2[i] = ((u64)(u32)(r.qpos + r.len) << 16) | (u64)i; }
+        mine[c][l] = r; myslot[c][l] = s;
+      }
+    }
+  }
+  wave_fence();
+  LV<int> rin;
+  QM_LANES(l) { rin[l] = l < R ? rcnt[l] : 0; }
+  const int maxn = wave_max(rin);
+  LV<int> rank[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    if (64 * c >= NR) continue;
+    QM_LANES(l) {
+      const int i = 64 * c + l;
+      int rk = 0;
+      if (i < NR) {
+        const int s = myslot[c][l]; const int b = M.rb[s], n = M.rn[s];
+        const u64 a1 = M.k.k1[i], a2 = M.k.k2[i];
+        for (int t = 0; t < maxn; ++t) {
+          if (t < n) { const u64 c1 = M.k.k1[b + t], c2 = M.k.k2[b + t]; rk += (c1 < a1 || (c1 == a1 && c2 < a2)) ? 1 : 0; }
+        }
+        rk += b;
+      }
+      rank[c][l] = rk;
+    }
+  }
+  wave_fence();
+#pragma unroll
+  for (int c = 0; c < C; ++c) { QM_LANES(l) { if (64 * c + l < NR) M.rec[rank[c][l]] = mine[c][l]; } }
+  wave_fence();
+  LV<SelRec> rr[C]; LV<bool> head[C]; LV<int> sl[C];
+  u64 hm[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    QM_LANES(l) {
+      const int i = 64 * c + l;
+      head[c][l] = false; sl[c][l] = 0;
+      if (i < NR) {
+        const SelRec x = M.rec[i]; rr[c][l] = x;
+        const int s = (int)(x.iv >> 8); sl[c][l] = s;
+        head[c][l] = i == M.rb[s] || M.rec[i - 1].tid != x.tid;
+        if (M.ivcnt[s] == 1) M.ends[i] = (int)(x.pos - x.qpos);
+      }
+    }
+    hm[c] = ballot(head[c]);
+  }
+  LV<int> g1v[C], reqN[C]; LV<bool> req[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    QM_LANES(l) {
+      g1v[c][l] = 0; req[c][l] = false; reqN[c][l] = 0;
+      if (head[c][l]) {
+        const int i = 64 * c + l;
+        int g1 = NR;
+        const u64 rest = l < 63 ? (hm[c] & ~lanemask_lt(l + 1)) : 0ULL;
+        if (rest) g1 = 64 * c + ctz64(rest);
+        else {
+#pragma unroll
+          for (int d = C - 1; d > 0; --d) if (d > c && hm[d]) g1 = 64 * d + ctz64(hm[d]);   // the lowest such d wins
+        }
+        g1v[c][l] = g1;
+        const int s = sl[c][l];
+        const int m = M.ivcnt[s];
+        if (m > 1) {
+          const float requiredFrac = (float)m * B.consensus_fraction;
+          int requiredNumHits = m;
+          if (B.consensus_fraction < 1.0) { const int fl = (int)requiredFrac; requiredNumHits = fl > 1 ? fl : 1; }
+          u64 mk = 0;
+          for (int j = i; j < g1; ++j) mk |= 1ULL << (M.rec[j].iv & 63u);
+          const bool rq = popc64(mk) >= requiredNumHits;
+          req[c][l] = rq; reqN[c][l] = requiredNumHits;
+          if (rq) M.anyreq[s] = 1;
+        }
+      }
+    }
+  }
+  wave_fence();
+  LV<int> nsv[C], chainN[C], chainLen[C]; LV<bool> em[C]; LV<SelGroup> gv[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    QM_LANES(l) {
+      nsv[c][l] = 0; em[c][l] = false; chainN[c][l] = 0; chainLen[c][l] = 0;
+      if (head[c][l]) {
+        const int i = 64 * c + l;
+        const int s = sl[c][l]; const int m = M.ivcnt[s];
+        const int hn = g1v[c][l] - i;
+        const u32 readLen = (u32)M.rlen[s];
+        if (m == 1) {
+          const SelRec x = rr[c][l];
+          SelGroup g; g.tid = x.tid; g.offcs = 0; g.set_cs(x.len == readLen ? QM_CS_PERFECT : QM_CS_REGULAR); g.score = -1.7976931348623157e308;
+          g.npos = hn; g.ppos = (int)(x.pos - x.qpos);
+          gv[c][l] = g; nsv[c][l] = hn; em[c][l] = true;
+        } else {
+          const bool allActive = (m - reqN[c][l]) > 0 && M.anyreq[s] == 0;
+          if (req[c][l] || allActive) { chainN[c][l] = hn; chainLen[c][l] = (int)readLen; }
+        }
+      }
+    }
+    LV<bool> slow;
+    QM_LANES(l) {
+      slow[l] = false;
+      if (chainN[c][l] > 0) {
+        const int i = 64 * c + l;
+        SelGroup g;
+        const int ns = sel_chain_diag8(M.rec + i, chainN[c][l], chainLen[c][l], g, M.ends + i);
+        if (ns > 0) { gv[c][l] = g; nsv[c][l] = ns; em[c][l] = true; } else slow[l] = true;
+      }
+    }
+    if (ballot(slow)) {
+      QM_LANES(l) {
+        if (slow[l]) {
+          const int i = 64 * c + l;
+          SelGroup g;
+          const int ns = sel_chain_group(M.rec + i, chainN[c][l], M.c.f + i, M.c.p + i, M.c.seen + i, M.ends + i, M.starts + i, chainLen[c][l], g, M.ends + i);
+          if (ns > 0) { gv[c][l] = g; nsv[c][l] = ns; em[c][l] = true; }
+        }
+      }
+    }
+  }
+  wave_fence();
+  LV<int> wv[C], ws[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) { QM_LANES(l) { wv[c][l] = em[c][l] ? 2 + nsv[c][l] : 0; ws[c][l] = wv[c][l]; } }
+  scan_add_c<C>(ws);
+#pragma unroll
+  for (int c = 0; c < C; ++c) { QM_LANES(l) { M.sw[64 * c + l] = ws[c][l]; } }
+  const int W = read_lane(ws[C - 1], 63);
+  long long base = 0; bool fits = true;
+  if (W > 0) {
+    if (wa.base < 0 || wa.used + W > QM_CHUNK) {
+      LV<u64> bv;
+      QM_LANES(l) { bv[l] = 0; if (l == 0) bv[l] = atomic_add_u64(B.cursor, (u64)QM_CHUNK); }
+      wa.base = (long long)read_lane(bv, 0); wa.used = 0;
+    }
+    base = wa.base + wa.used;
+    if (base + W > B.lists_cap) { QM_LANES(l) { if (l == 0) *B.status |= 1; } fits = false; }
+    else wa.used += W;
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    QM_LANES(l) {
+      if (em[c][l]) {
+        const int i = 64 * c + l;
+        const int o = ws[c][l] - wv[c][l];
+        const SelGroup g = gv[c][l];
+        M.out[o] = sel_header(g.tid, M.rrc[sl[c][l]] != 0, g.cs(), nsv[c][l]);
+        M.out[o + 1] = (u64)(u32)g.ppos;
+        for (int t = 0; t < nsv[c][l]; ++t) M.out[o + 2 + t] = (u64)(u32)M.ends[i + t];
+      }
+    }
+  }
+  wave_fence();
+  QM_LANES(l) {
+    if (l < R && pk[l]) {
+      const int n = rcnt[l], b = rscan[l] - rcnt[l];
+      int nw = 0, wb = 0;
+      if (n > 0) { wb = b > 0 ? M.sw[b - 1] : 0; nw = M.sw[b + n - 1] - wb; }
+      if (!fits) nw = 0;
+      B.lcnt[rdv[l]] = (u32)nw | fflag[l];
+      B.loff[rdv[l]] = nw > 0 ? base + wb : 0;
+    }
+  }
+  if (fits) { for (int b0 = 0; b0 < W; b0 += 64) { QM_LANES(l) { if (b0 + l < W) B.lists[base + b0 + l] = M.out[b0 + l]; } } }
+  wave_fence();
+  return R;
+}

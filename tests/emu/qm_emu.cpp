@@ -174,6 +174,20 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
         long long r = w * per; const long long rEnd = r + per < nreads ? r + per : nreads;
         while (r < rEnd) r += sel_pack_batch(ix, H, r, rEnd, pm[w], pw, todo.data());
       }
+      // the wide edition (256 intervals / suffixes per batch) over the queue the narrow one left, two "waves"
+      std::vector<long long> todo2((size_t)nreads + 1, -1);
+      scal[QM_SC_TODO2] = 0;
+      if (!getenv("QM_EMU_NO_PACKW")) {
+        static PackMemW<4> pw4[2];
+        const long long nq = (long long)scal[QM_SC_TODO], NQW = 2, perq = (nq + NQW - 1) / NQW;
+        for (long long w = 0; w < NQW; ++w) {
+          WaveAlloc pw; pw.base = -1; pw.used = 0; pw.ivBase = -1; pw.ivUsed = 0;
+          long long q = w * perq; const long long qEnd = q + perq < nq ? q + perq : nq;
+          while (q < qEnd) q += sel_pack_batch_wide<4>(ix, H, todo.data(), q, qEnd, pw4[w], pw, todo2.data());
+        }
+        if (getenv("QM_EMU_PACK_STATS")) fprintf(stderr, "[qm emu] wide packed list kernel took %lld of %lld queued reads\n", nq - (long long)scal[QM_SC_TODO2], nq);
+        todo.swap(todo2); scal[QM_SC_TODO] = scal[QM_SC_TODO2];
+      }
       if (!(status & 1)) {
         std::vector<char> isTodo(nreads + 1, 0);
         for (long long q = 0; q < (long long)scal[QM_SC_TODO]; ++q) isTodo[todo[q]] = 1;
