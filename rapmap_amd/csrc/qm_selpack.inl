@@ -361,6 +361,52 @@ QM_DEV int sel_pack_batch(const DevIndex& ix, const ReadBatch& B, long long r0, 
   return R;
 }
 
+// sel_chain_group for hn hits of ONE diagonal, any hn: the DP of sel_chain_diag8 with its arrays in memory (f as integers).  Returns 0
+// when the hits are not on one diagonal.  posOut may alias ends.
+QM_DEV int sel_chain_diag_mem(const SelRec* H, int hn, int maxDist, int* f, int* p, int* seen, int* ends, SelGroup& g, int* posOut) {
+  const SelRec h0 = H[0];
+  const int diag = (int)(h0.pos - h0.qpos);
+  for (int i = 1; i < hn; ++i) { const SelRec h = H[i]; if ((int)(h.pos - h.qpos) != diag) return 0; }
+  int best = -1, lastBest = -1, nEnds = 0;
+  for (int i = 0; i < hn; ++i) {
+    const SelRec hi = H[i];
+    const int ei = (int)(hi.qpos + hi.len), leni = (int)hi.len;
+    int fi = leni, pi = i, looksLeft = 2;
+    for (int j = i - 1; j >= 0; --j) {
+      const int dq = ei - (int)(H[j].qpos + H[j].len);
+      const int cand = f[j] + (leni < dq ? leni : dq);
+      const bool take = cand > fi;
+      pi = take ? j : pi; fi = take ? cand : fi;
+      if (pi < i) { --looksLeft; if (looksLeft <= 0) break; }
+    }
+    p[i] = pi; f[i] = fi;
+    if (fi > best) { best = fi; lastBest = i; nEnds = 0; ends[nEnds++] = i; }
+    else if (fi == best) ends[nEnds++] = i;
+  }
+  for (int i = 0; i < hn; ++i) seen[i] = 0;
+  int nOptimal = 0, nStarts = 0;
+  for (int e = 0; e < nEnds; ++e) {
+    int cur = ends[e];
+    bool fresh = true;
+    int prev = p[cur];
+    while (prev < cur) {
+      if (seen[cur]) { fresh = false; break; }
+      seen[cur] = 1;
+      cur = prev;
+      prev = p[cur];
+    }
+    if (seen[cur]) fresh = false;
+    if (fresh) { ++nOptimal; ++nStarts; }
+  }
+  for (int t = 0; t < nStarts; ++t) posOut[t] = diag;
+  g.tid = h0.tid; g.offcs = 0; g.set_cs(QM_CS_REGULAR); g.score = (double)best; g.npos = nStarts; g.ppos = diag;
+  if (hn > 1 && nOptimal == 1 && lastBest == hn - 1) {
+    const SelRec hl = H[hn - 1];
+    if ((long long)(hl.qpos + hl.len) - (long long)h0.qpos == (long long)maxDist) g.set_cs(QM_CS_UNGAPPED);
+  }
+  return nStarts;
+}
+
 // ------------------------------------------------------------------ the wide edition: 64 * C intervals / suffixes per batch
 // Reads of 150 and 250 bp bring 45 .. 90 suffixes per strand (an interval every maxMMPExtension + 1 positions, a suffix per isoform in
 // each): they do not fit the 64 lanes above and went to the one-read kernel's device-memory scratch -- 725 ms per 4 M reads of 250 bp.
@@ -385,7 +431,7 @@ struct PackMemW {
   };
   int ends[N], starts[N];
   int sw[N];
-};
+};                                 // (19.8 KB for C = 4: two blocks of four waves per CU -- one more array and it is one)
 template <int C> QM_DEV void scan_add_c(LV<int> (&x)[C]) {
   int carry = 0;
 #pragma unroll
@@ -620,23 +666,57 @@ QM_DEV int sel_pack_batch_wide(const DevIndex& ix, const ReadBatch& B, const lon
         }
       }
     }
-    LV<bool> slow;
+  }
+  // chaining: the groups that need it are spread over the chunks' lanes; gathered into one list, a lane per job, they run side by side in as
+  // few divergent rounds as there are 64 jobs -- results through LDS: starts[first] = chain starts | status << 16, seen[first] = own position
+  int njobs = 0;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    LV<bool> hj;
+    QM_LANES(l) { hj[l] = chainN[c][l] > 0; }
+    const u64 jm = ballot(hj);
+    QM_LANES(l) { if (hj[l]) M.mark[njobs + popc64(jm & lanemask_lt(l))] = (64 * c + l) | (chainN[c][l] << 16); }   // (mark: free since the suffix gather)
+    njobs += popc64(jm);
+  }
+  wave_fence();
+  for (int j0 = 0; j0 < njobs; j0 += 64) {
+    LV<bool> slow; LV<int> ji, jn, jl;
     QM_LANES(l) {
-      slow[l] = false;
-      if (chainN[c][l] > 0) {
-        const int i = 64 * c + l;
+      slow[l] = false; ji[l] = 0; jn[l] = 0; jl[l] = 0;
+      if (j0 + l < njobs) {
+        const int jb = M.mark[j0 + l];
+        const int i = jb & 0xffff, hn = jb >> 16;
+        const int readLen = M.rlen[M.rec[i].iv >> 8];
+        ji[l] = i; jn[l] = hn; jl[l] = readLen;
         SelGroup g;
-        const int ns = sel_chain_diag8(M.rec + i, chainN[c][l], chainLen[c][l], g, M.ends + i);
-        if (ns > 0) { gv[c][l] = g; nsv[c][l] = ns; em[c][l] = true; } else slow[l] = true;
+        int ns = hn <= 8 ? sel_chain_diag8(M.rec + i, hn, readLen, g, M.ends + i)
+                         : sel_chain_diag_mem(M.rec + i, hn, readLen, (int*)(M.c.f + i), M.c.p + i, M.c.seen + i, M.ends + i, g, M.ends + i);
+        if (ns > 0) { M.starts[i] = ns | (g.cs() << 16); M.c.seen[i] = g.ppos; } else slow[l] = true;
       }
     }
     if (ballot(slow)) {
       QM_LANES(l) {
         if (slow[l]) {
-          const int i = 64 * c + l;
-          SelGroup g;
-          const int ns = sel_chain_group(M.rec + i, chainN[c][l], M.c.f + i, M.c.p + i, M.c.seen + i, M.ends + i, M.starts + i, chainLen[c][l], g, M.ends + i);
-          if (ns > 0) { gv[c][l] = g; nsv[c][l] = ns; em[c][l] = true; }
+          const int i = ji[l];
+          SelGroup g; g.offcs = 0; g.ppos = 0;
+          const int ns = sel_chain_group(M.rec + i, jn[l], M.c.f + i, M.c.p + i, M.c.seen + i, M.ends + i, M.starts + i, jl[l], g, M.ends + i);
+          M.starts[i] = ns > 0 ? (ns | (g.cs() << 16)) : 0;
+          M.c.seen[i] = g.ppos;
+        }
+      }
+    }
+  }
+  wave_fence();
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    QM_LANES(l) {
+      if (chainN[c][l] > 0) {
+        const int i = 64 * c + l;
+        const int rs = M.starts[i];
+        const int ns = rs & 0xffff;
+        if (ns > 0) {
+          SelGroup g; g.tid = rr[c][l].tid; g.offcs = 0; g.set_cs(rs >> 16); g.score = 0; g.npos = ns; g.ppos = M.c.seen[i];
+          gv[c][l] = g; nsv[c][l] = ns; em[c][l] = true;
         }
       }
     }
