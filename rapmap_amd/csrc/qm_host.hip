@@ -877,10 +877,14 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
         // several reads per wavefront first (qm_selpack.inl); what that kernel cannot take -- hits on both strands, more than 64
         // intervals or suffixes -- it queues, and the one-read-per-wavefront kernel runs over the queue (its length stays on the device)
         if ((rc = ensure(c->d_todoq, c->capTodoq, nreads))) return rc;
-        HIPCHK(qmk_h2m_pack(&ix, &H, c->d_todoq, grid, c->numCU, c->stream));
-        // ... then the wide edition (256 lanes' worth per batch: reads of 150 bp and more) over that queue, which leaves one of its own
+        // ... then the wide edition (256 lanes' worth per batch: reads of 150 bp and more) over that queue, which leaves one of its own.
+        // A batch of reads beyond 192 characters goes to the wide edition directly: hardly any of them fits the narrow one's 64 lanes
         if ((rc = ensure(c->d_todoq2, c->capTodoq2, nreads))) return rc;
-        HIPCHK(qmk_h2m_packw(&ix, &H, c->d_todoq, (const unsigned long long*)(c->d_scal + QM_SC_TODO), c->d_todoq2, grid, c->numCU, c->stream));
+        if (rq.shortLen > 192) HIPCHK(qmk_h2m_packw(&ix, &H, nullptr, nullptr, c->d_todoq2, grid, c->numCU, c->stream));
+        else {
+          HIPCHK(qmk_h2m_pack(&ix, &H, c->d_todoq, grid, c->numCU, c->stream));
+          HIPCHK(qmk_h2m_packw(&ix, &H, c->d_todoq, (const unsigned long long*)(c->d_scal + QM_SC_TODO), c->d_todoq2, grid, c->numCU, c->stream));
+        }
         ReadBatch T = H; T.slowq = c->d_todoq2; T.nreads_dev = c->d_scal + QM_SC_TODO2;
         HIPCHK(qmk_h2m(&ix, &T, grid, c->numCU, c->stream));
       } else HIPCHK(qmk_h2m(&ix, &H, grid, c->numCU, c->stream));

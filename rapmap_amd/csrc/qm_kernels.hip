@@ -118,8 +118,8 @@ __global__ __launch_bounds__(256, 2) void qm_h2m_packw_kernel(DevIndex ix, ReadB
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const long long gw = (long long)blockIdx.x * 4 + wave;
   const long long nw = (long long)gridDim.x * 4;
-  long long nq = (long long)uniform(*nids);
-  if (nq > B.nreads) nq = B.nreads;
+  long long nq = B.nreads;
+  if (nids) { const long long d = (long long)uniform(*nids); nq = d < nq ? d : nq; }
   const long long per = (nq + nw - 1) / nw;
   long long q = gw * per;
   const long long qEnd = q + per < nq ? q + per : nq;

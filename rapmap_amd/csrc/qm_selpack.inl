@@ -454,7 +454,7 @@ QM_DEV int sel_pack_batch_wide(const DevIndex& ix, const ReadBatch& B, const lon
   QM_LANES(l) {
     int c = 0; u32 ff = 0; bool bg = false; long long read = 0;
     if (l < QM_PK_READS && q0 + l < qEnd) {
-      read = ids[q0 + l];
+      read = ids ? ids[q0 + l] : q0 + l;                     // (no queue: every read of the batch, in order)
       c = (int)B.iv_in_cnt[read];
       M.ivoff[l] = B.iv_in_off[read];
       const int mate = paired ? (int)(read & 1) : 0; const long long unit = paired ? (read >> 1) : read;
