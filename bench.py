@@ -38,7 +38,8 @@ KERNELS = {
     "dense": "qm_read_kernel<2,8,0> (stage A: one wavefront per read)",
     "ph_compact": "qm_read_kernel<2,6,1> (stage A: one wavefront per read, BooPHF levels walked per lookup)",
     "ph_expanded": "qm_read_kernel<2,8,0> (stage A: one wavefront per read; the -p index expanded into the bucket table at load)",
-    "sel": "qm_read_kernel<2,8,12> (chain-scoring collector) + qm_h2m_kernel<4> (intervals -> position lists, chaining)",
+    "sel": "qm_read_kernel<2,8,12> (chain-scoring collector) + qm_h2m_pack_kernel (intervals -> position lists, chaining; several reads per wavefront) "
+           "[+ its wide edition and qm_h2m_kernel<4> for the reads those hand on]; the batch runs as two parts in flight, kernel_ms spans stage A of both",
 }
 
 

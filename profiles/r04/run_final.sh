@@ -18,5 +18,6 @@ e=d.get("end_to_end") or {}; print("e2e", e.get("value"), e.get("pairs"), e.get(
 print("compat_face", json.dumps({k:(v.get("value"), v.get("bit_identical_joint_hits")) for k,v in (d.get("compat_face", {}).get("by_host_threads") or {}).items()}))
 PY
 bash profiles/r04/run_profile.sh $OUT/prof_dense > /dev/null 2>&1
-bash profiles/r04/run_profile.sh $OUT/prof_sel --sel-aln > /dev/null 2>&1
-grep -A3 "^\"Name\"" $OUT/prof_dense/summary.txt | cut -c1-160; grep "qm_read_kernel\|qm_h2m\|align2" $OUT/prof_sel/summary.txt | head -4 | cut -c1-160
+QM_SPLIT=1 bash profiles/r04/run_profile.sh $OUT/prof_sel --sel-aln > /dev/null 2>&1      # (one launch per kernel and step: counters per 10 M pairs)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_sel_parts -o s -- python bench.py --sel-aln --no-cpu-baseline --no-other-configs --no-side-legs --steps 3 --warmup 1 > $OUT/stats_sel_parts.log 2>&1   # the default: two parts in flight
+grep -A3 "^\"Name\"" $OUT/prof_dense/summary.txt | cut -c1-160; grep "qm_read_kernel\|qm_h2m\|align2" $OUT/prof_sel/summary.txt | head -6 | cut -c1-160; f=$(find $OUT/stats_sel_parts -name "*kernel_stats.csv" | head -1); head -8 "$f" | cut -c1-160
