@@ -124,7 +124,13 @@ __global__ __launch_bounds__(256, 2) void qm_h2m_packw_kernel(DevIndex ix, ReadB
   long long q = gw * per;
   const long long qEnd = q + per < nq ? q + per : nq;
   WaveAlloc wa; wa.base = -1; wa.used = 0; wa.ivBase = -1; wa.ivUsed = 0;
+#ifdef QM_TIMING
+  if ((threadIdx.x & 63) == 0) { for (int i = 0; i < 9; ++i) qm_tim[wave][i] = 0; qm_tim[wave][9] = __builtin_readcyclecounter(); }
+#endif
   while (q < qEnd) q += (long long)sel_pack_batch_wide<4>(ix, B, ids, q, qEnd, mem[wave], wa, todoq);
+#ifdef QM_TIMING       // (the narrow kernel's slots: [qm timing pack] of a batch of long reads is this kernel)
+  if ((threadIdx.x & 63) == 0) for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long*)&B.cursor[40 + i], (unsigned long long)qm_tim[wave][i]);
+#endif
 }
 
 // stage B pass 1: hits per unit + the HitCounters

@@ -14,6 +14,24 @@
 #define QM_PK_READS 16             // reads a wavefront looks at per batch (it keeps the leading ones that fit)
 #define QM_SC_TODO 28              // slot of the context's scalar block: reads left for qm_h2m_kernel
 
+// (k1, k2) < (a1, a2) for the rank sorts' keys (k2 and a2 below 2^32: query end << 16 | lane), counted into cnt: the borrow of the
+// 96-bit subtraction (k1 : k2) - (a1 : a2), added with carry -- four full-rate instructions.  (Written as compares, or as __builtin_subc,
+// the compiler makes three 64-bit compares of it, which run at a fraction of the rate.)  A key of all ones is below nothing.
+QM_DEV void key_count(u64 c1, u64 c2, u64 a1, u64 a2, int& cnt) {
+#ifdef QM_EMU
+  cnt += (int)(c1 < a1) | ((int)(c1 == a1) & (int)((u32)c2 < (u32)a2));
+#else
+  u32 tmp;
+  asm("v_sub_co_u32 %1, vcc, %2, %3\n\t"
+      "v_subb_co_u32 %1, vcc, %4, %5, vcc\n\t"
+      "v_subb_co_u32 %1, vcc, %6, %7, vcc\n\t"
+      "v_addc_co_u32 %0, vcc, 0, %0, vcc"
+      : "+v"(cnt), "=&v"(tmp)
+      : "v"((u32)c2), "v"((u32)a2), "v"((u32)c1), "v"((u32)a1), "v"((u32)(c1 >> 32)), "v"((u32)(a1 >> 32))
+      : "vcc");
+#endif
+}
+
 struct PackMem {                   // one wavefront's LDS: 5.3 KB
   long long ivoff[QM_PK_READS];    // per read of the batch: where its interval records start in iv_in,
   int ivcnt[QM_PK_READS];          //   how many (m: the intervals of its one strand),
@@ -229,8 +247,12 @@ QM_DEV int sel_pack_batch(const DevIndex& ix, const ReadBatch& B, long long r0, 
     if (l < NR) {
       const int s = myslot[l]; const int b = M.rb[s], n = M.rn[s];
       const u64 a1 = M.k.k1[l], a2 = M.k.k2[l];
+      // (no branch around the loads: a clamped index and a select, so that the trips' LDS reads are in flight together)
+#pragma unroll 4
       for (int t = 0; t < maxn; ++t) {
-        if (t < n) { const u64 c1 = M.k.k1[b + t], c2 = M.k.k2[b + t]; rk += (c1 < a1 || (c1 == a1 && c2 < a2)) ? 1 : 0; }
+        const int tt = t < n ? t : 0;
+        const u64 c1 = M.k.k1[b + tt], c2 = M.k.k2[b + tt];
+        rk += (int)(t < n) & ((int)(c1 < a1) | ((int)(c1 == a1) & (int)(c2 < a2)));     // (bit operators: && / || come back as branches)
       }
       rk += b;
     }
@@ -364,39 +386,68 @@ QM_DEV int sel_pack_batch(const DevIndex& ix, const ReadBatch& B, long long r0, 
 // sel_chain_group for hn hits of ONE diagonal, any hn: the DP of sel_chain_diag8 with its arrays in memory (f as integers).  Returns 0
 // when the hits are not on one diagonal.  posOut may alias ends.
 QM_DEV int sel_chain_diag_mem(const SelRec* H, int hn, int maxDist, int* f, int* p, int* seen, int* ends, SelGroup& g, int* posOut) {
+  // The chain of a read's hits on one transcript is nearly always hit i-1 <- hit i: f and the query end of the two previous hits stay in
+  // registers (the look-back stops two looks after the first predecessor), the next record is requested before this one's stores, the
+  // one-diagonal test rides along (a return of 0 midway leaves scratch that sel_chain_group overwrites), and a chain that is linear from an
+  // end beyond hit 0 has one start without the walk back (every later end runs into the first one's marks).
   const SelRec h0 = H[0];
   const int diag = (int)(h0.pos - h0.qpos);
-  for (int i = 1; i < hn; ++i) { const SelRec h = H[i]; if ((int)(h.pos - h.qpos) != diag) return 0; }
-  int best = -1, lastBest = -1, nEnds = 0;
+  int best = -1, lastBest = -1, nEnds = 0, firstEnd = 0;
+  int f1 = 0, e1 = 0, f2 = 0, e2 = 0;
+  bool linear = true;
+  SelRec hi = h0;
   for (int i = 0; i < hn; ++i) {
-    const SelRec hi = H[i];
+    const SelRec hnx = H[i + 1 < hn ? i + 1 : i];
+    if ((int)(hi.pos - hi.qpos) != diag) return 0;
     const int ei = (int)(hi.qpos + hi.len), leni = (int)hi.len;
     int fi = leni, pi = i, looksLeft = 2;
-    for (int j = i - 1; j >= 0; --j) {
-      const int dq = ei - (int)(H[j].qpos + H[j].len);
-      const int cand = f[j] + (leni < dq ? leni : dq);
+    bool done = false;
+    if (i >= 1) {
+      const int dq = ei - e1;
+      const int cand = f1 + (leni < dq ? leni : dq);
       const bool take = cand > fi;
-      pi = take ? j : pi; fi = take ? cand : fi;
-      if (pi < i) { --looksLeft; if (looksLeft <= 0) break; }
+      pi = take ? i - 1 : pi; fi = take ? cand : fi;
+      if (pi < i) --looksLeft;
+    }
+    if (i >= 2) {
+      const int dq = ei - e2;
+      const int cand = f2 + (leni < dq ? leni : dq);
+      const bool take = cand > fi;
+      pi = take ? i - 2 : pi; fi = take ? cand : fi;
+      if (pi < i) { --looksLeft; done = looksLeft <= 0; }
+    }
+    if (!done) {
+      for (int j = i - 3; j >= 0; --j) {
+        const int dq = ei - (int)(H[j].qpos + H[j].len);
+        const int cand = f[j] + (leni < dq ? leni : dq);
+        const bool take = cand > fi;
+        pi = take ? j : pi; fi = take ? cand : fi;
+        if (pi < i) { --looksLeft; if (looksLeft <= 0) break; }
+      }
     }
     p[i] = pi; f[i] = fi;
-    if (fi > best) { best = fi; lastBest = i; nEnds = 0; ends[nEnds++] = i; }
+    linear = linear && (i == 0 || pi == i - 1);
+    if (fi > best) { best = fi; lastBest = i; nEnds = 0; ends[nEnds++] = i; firstEnd = i; }
     else if (fi == best) ends[nEnds++] = i;
+    f2 = f1; e2 = e1; f1 = fi; e1 = ei; hi = hnx;
   }
-  for (int i = 0; i < hn; ++i) seen[i] = 0;
   int nOptimal = 0, nStarts = 0;
-  for (int e = 0; e < nEnds; ++e) {
-    int cur = ends[e];
-    bool fresh = true;
-    int prev = p[cur];
-    while (prev < cur) {
-      if (seen[cur]) { fresh = false; break; }
-      seen[cur] = 1;
-      cur = prev;
-      prev = p[cur];
+  if (linear && firstEnd > 0) { nOptimal = 1; nStarts = 1; }
+  else {
+    for (int i = 0; i < hn; ++i) seen[i] = 0;
+    for (int e = 0; e < nEnds; ++e) {
+      int cur = ends[e];
+      bool fresh = true;
+      int prev = p[cur];
+      while (prev < cur) {
+        if (seen[cur]) { fresh = false; break; }
+        seen[cur] = 1;
+        cur = prev;
+        prev = p[cur];
+      }
+      if (seen[cur]) fresh = false;
+      if (fresh) { ++nOptimal; ++nStarts; }
     }
-    if (seen[cur]) fresh = false;
-    if (fresh) { ++nOptimal; ++nStarts; }
   }
   for (int t = 0; t < nStarts; ++t) posOut[t] = diag;
   g.tid = h0.tid; g.offcs = 0; g.set_cs(QM_CS_REGULAR); g.score = (double)best; g.npos = nStarts; g.ppos = diag;
@@ -413,6 +464,7 @@ QM_DEV int sel_chain_diag_mem(const SelRec* H, int hn, int maxDist, int* f, int*
 // Here a lane owns C records (i = 64 c + l), the scans carry from chunk to chunk, a read still has at most 64 intervals (their set is a
 // 64-bit mask) and hits on one strand.  It runs over the queue the narrow kernel leaves (ids), and leaves a queue of its own.
 #define QM_SC_TODO2 29
+template <int V> struct IntC { static constexpr int value = V; };     // a compile-time int as a lambda's argument
 template <int C>
 struct PackMemW {
   static constexpr int N = 64 * C;
@@ -426,7 +478,7 @@ struct PackMemW {
   int mark[N];
   SelRec rec[N];
   union {
-    struct { u64 k1[N], k2[N]; } k;
+    struct { u64 k1[N + 1], k2[N + 1]; } k;                 // (+1: the rank sort's sentinel, a key below nothing)
     struct { double f[N]; int p[N], seen[N]; } c;
   };
   int ends[N], starts[N];
@@ -551,6 +603,7 @@ QM_DEV int sel_pack_batch_wide(const DevIndex& ix, const ReadBatch& B, const lon
     }
   }
   wave_fence();
+  QM_T(0);
   LV<int> ivl[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) { QM_LANES(l) { ivl[c][l] = M.mark[64 * c + l]; } }
@@ -572,32 +625,60 @@ QM_DEV int sel_pack_batch_wide(const DevIndex& ix, const ReadBatch& B, const lon
       }
     }
   }
+  QM_LANES(l) { if (l == 0) { M.k.k1[N] = ~0ULL; M.k.k2[N] = ~0ULL; } }    // (the chaining arrays of the previous batch lie over it)
   wave_fence();
+  QM_T(1);
   LV<int> rin;
   QM_LANES(l) { rin[l] = l < R ? rcnt[l] : 0; }
   const int maxn = wave_max(rin);
-  LV<int> rank[C];
+  // the trip over a segment's records is the OUTER loop and the chunks are inside it, no branch around the loads (clamped index, select):
+  // a trip's 2 C LDS reads are in flight together -- with a loop per chunk every trip waited for its own two (57 % of the kernel on 2 x 250 bp)
+  LV<int> rank[C], sb[C], sn[C]; LV<u64> ka[C], kb[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) {
-    if (64 * c >= NR) continue;
     QM_LANES(l) {
       const int i = 64 * c + l;
-      int rk = 0;
-      if (i < NR) {
-        const int s = myslot[c][l]; const int b = M.rb[s], n = M.rn[s];
-        const u64 a1 = M.k.k1[i], a2 = M.k.k2[i];
-        for (int t = 0; t < maxn; ++t) {
-          if (t < n) { const u64 c1 = M.k.k1[b + t], c2 = M.k.k2[b + t]; rk += (c1 < a1 || (c1 == a1 && c2 < a2)) ? 1 : 0; }
-        }
-        rk += b;
-      }
-      rank[c][l] = rk;
+      rank[c][l] = 0; sb[c][l] = 0; sn[c][l] = 0; ka[c][l] = 0; kb[c][l] = 0;
+      if (i < NR) { const int s = myslot[c][l]; sb[c][l] = M.rb[s]; sn[c][l] = M.rn[s]; ka[c][l] = M.k.k1[i]; kb[c][l] = M.k.k2[i]; }
     }
   }
+  // (one straight-line edition per number of chunks in use: a test per chunk inside the trip would put a branch -- and a wait -- between the chunks' reads)
+  auto trips = [&](auto ca) {
+    constexpr int CA = decltype(ca)::value;
+    for (int t = 0; t < maxn; t += 2) {                     // two trips at a time (t + 1 == maxn: no lane has that many), every read of the
+      LV<u64> x1[CA], x2[CA], y1[CA], y2[CA];               // pair requested before the first compare
+#pragma unroll
+      for (int c = 0; c < CA; ++c) {
+        QM_LANES(l) {
+          const int n = sn[c][l]; const int j0 = sb[c][l] + t;
+          const int ja = t < n ? j0 : N; const int jb = t + 1 < n ? j0 + 1 : N;          // (past the lane's segment: the sentinel)
+          x1[c][l] = M.k.k1[ja]; x2[c][l] = M.k.k2[ja]; y1[c][l] = M.k.k1[jb]; y2[c][l] = M.k.k2[jb];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < CA; ++c) {
+        QM_LANES(l) {
+          const u64 a1 = ka[c][l], a2 = kb[c][l];
+          key_count(x1[c][l], x2[c][l], a1, a2, rank[c][l]);
+          key_count(y1[c][l], y2[c][l], a1, a2, rank[c][l]);
+        }
+      }
+    }
+  };
+  {
+    const int CAn = (NR + 63) >> 6;
+    if (CAn <= 1) trips(IntC<1>{});
+    else if (CAn == 2) trips(IntC<(C >= 2 ? 2 : C)>{});
+    else if (CAn == 3) trips(IntC<(C >= 3 ? 3 : C)>{});
+    else trips(IntC<C>{});
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) { QM_LANES(l) { rank[c][l] += sb[c][l]; } }
   wave_fence();
 #pragma unroll
   for (int c = 0; c < C; ++c) { QM_LANES(l) { if (64 * c + l < NR) M.rec[rank[c][l]] = mine[c][l]; } }
   wave_fence();
+  QM_T(2);
   LV<SelRec> rr[C]; LV<bool> head[C]; LV<int> sl[C];
   u64 hm[C];
 #pragma unroll
@@ -667,6 +748,7 @@ QM_DEV int sel_pack_batch_wide(const DevIndex& ix, const ReadBatch& B, const lon
       }
     }
   }
+  QM_T(3);
   // chaining: the groups that need it are spread over the chunks' lanes; gathered into one list, a lane per job, they run side by side in as
   // few divergent rounds as there are 64 jobs -- results through LDS: starts[first] = chain starts | status << 16, seen[first] = own position
   int njobs = 0;
@@ -722,6 +804,7 @@ QM_DEV int sel_pack_batch_wide(const DevIndex& ix, const ReadBatch& B, const lon
     }
   }
   wave_fence();
+  QM_T(4);
   LV<int> wv[C], ws[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) { QM_LANES(l) { wv[c][l] = em[c][l] ? 2 + nsv[c][l] : 0; ws[c][l] = wv[c][l]; } }
@@ -754,6 +837,7 @@ QM_DEV int sel_pack_batch_wide(const DevIndex& ix, const ReadBatch& B, const lon
     }
   }
   wave_fence();
+  QM_T(5);
   QM_LANES(l) {
     if (l < R && pk[l]) {
       const int n = rcnt[l], b = rscan[l] - rcnt[l];
@@ -766,5 +850,6 @@ QM_DEV int sel_pack_batch_wide(const DevIndex& ix, const ReadBatch& B, const lon
   }
   if (fits) { for (int b0 = 0; b0 < W; b0 += 64) { QM_LANES(l) { if (b0 + l < W) B.lists[base + b0 + l] = M.out[b0 + l]; } } }
   wave_fence();
+  QM_T(6);
   return R;
 }

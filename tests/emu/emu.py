@@ -11,7 +11,8 @@ _SRC = [os.path.join(_HERE, "qm_emu.cpp"),
         os.path.join(_HERE, "../../rapmap_amd/csrc/qm_mapper.inl"),
         os.path.join(_HERE, "../../rapmap_amd/csrc/qm_wave.h"),
         os.path.join(_HERE, "../../rapmap_amd/csrc/qm_phflat.h"),
-        os.path.join(_HERE, "../../rapmap_amd/csrc/qm_sel.inl")]
+        os.path.join(_HERE, "../../rapmap_amd/csrc/qm_sel.inl"),
+        os.path.join(_HERE, "../../rapmap_amd/csrc/qm_selpack.inl")]
 
 HIT_DTYPE = np.dtype([
     ("tid", "<u4"), ("pos", "<i4"), ("mate_pos", "<i4"), ("frag_len", "<u4"),
