@@ -880,7 +880,8 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
         // ... then the wide edition (256 lanes' worth per batch: reads of 150 bp and more) over that queue, which leaves one of its own.
         // A batch of reads beyond 192 characters goes to the wide edition directly: hardly any of them fits the narrow one's 64 lanes
         if ((rc = ensure(c->d_todoq2, c->capTodoq2, nreads))) return rc;
-        if (rq.shortLen > 192) HIPCHK(qmk_h2m_packw(&ix, &H, nullptr, nullptr, c->d_todoq2, grid, c->numCU, c->stream));
+        static const int wideFrom = [] { const char* e = getenv("QM_SEL_WIDE_FROM"); return e ? atoi(e) : 192; }();   // (tuning knob)
+        if (rq.shortLen > wideFrom) HIPCHK(qmk_h2m_packw(&ix, &H, nullptr, nullptr, c->d_todoq2, grid, c->numCU, c->stream));
         else {
           HIPCHK(qmk_h2m_pack(&ix, &H, c->d_todoq, grid, c->numCU, c->stream));
           HIPCHK(qmk_h2m_packw(&ix, &H, c->d_todoq, (const unsigned long long*)(c->d_scal + QM_SC_TODO), c->d_todoq2, grid, c->numCU, c->stream));

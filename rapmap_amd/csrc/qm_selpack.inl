@@ -117,6 +117,7 @@ QM_DEV int sel_chain_diag8(const SelRec* H, int hn, int maxDist, SelGroup& g, in
   return nStarts;
 }
 
+QM_DEV int sel_chain_diag_mem(const SelRec* H, int hn, int maxDist, int* f, int* p, int* seen, int* ends, SelGroup& g, int* posOut);
 // One batch: the reads r0 .. of the wave's range [r0, rEnd).  Returns how many it consumed (>= 1).
 QM_DEV int sel_pack_batch(const DevIndex& ix, const ReadBatch& B, long long r0, long long rEnd, PackMem& M, WaveAlloc& wa, long long* todoq) {
 #pragma clang fp contract(off)
@@ -324,7 +325,8 @@ QM_DEV int sel_pack_batch(const DevIndex& ix, const ReadBatch& B, long long r0, 
     slow[l] = false;
     if (chainN[l] > 0) {
       SelGroup g;
-      const int ns = sel_chain_diag8(M.rec + l, chainN[l], chainLen[l], g, M.ends + l);
+      const int ns = chainN[l] <= 8 ? sel_chain_diag8(M.rec + l, chainN[l], chainLen[l], g, M.ends + l)
+                                    : sel_chain_diag_mem(M.rec + l, chainN[l], chainLen[l], (int*)(M.c.f + l), M.c.p + l, M.c.seen + l, M.ends + l, g, M.ends + l);
       if (ns > 0) { gv[l] = g; nsv[l] = ns; em[l] = true; } else slow[l] = true;
     }
   }
