@@ -275,6 +275,14 @@ QM_DEV int sel_pack_batch(const DevIndex& ix, const ReadBatch& B, long long r0, 
     }
   }
   const u64 hm = ballot(head);
+  // the set of a transcript's intervals (a 64-bit mask): every record ORs its bit into the word of its group's first lane (the sort keys' array
+  // is free by now) -- a loop of the first lane over its records was a chain of LDS round trips as long as the largest group
+  LV<int> hidx;
+  QM_LANES(l) { hidx[l] = head[l] ? l : 0; if (head[l]) M.k.k1[l] = 0; }
+  lane_scan_max(hidx);
+  wave_fence();
+  QM_LANES(l) { if (l < NR && M.ivcnt[sl[l]] > 1) atomic_or_u64(&M.k.k1[hidx[l]], 1ULL << (rr[l].iv & 63u)); }
+  wave_fence();
   LV<int> g1v, reqN; LV<bool> req;
   QM_LANES(l) {
     g1v[l] = 0; req[l] = false; reqN[l] = 0;
@@ -288,8 +296,7 @@ QM_DEV int sel_pack_batch(const DevIndex& ix, const ReadBatch& B, long long r0, 
         const float requiredFrac = (float)m * B.consensus_fraction;
         int requiredNumHits = m;
         if (B.consensus_fraction < 1.0) { const int fl = (int)requiredFrac; requiredNumHits = fl > 1 ? fl : 1; }
-        u64 mk = 0;
-        for (int j = l; j < g1; ++j) mk |= 1ULL << (M.rec[j].iv & 63u);
+        const u64 mk = M.k.k1[l];
         req[l] = popc64(mk) >= requiredNumHits;
         reqN[l] = requiredNumHits;
       }
@@ -697,6 +704,17 @@ QM_DEV int sel_pack_batch_wide(const DevIndex& ix, const ReadBatch& B, const lon
     }
     hm[c] = ballot(head[c]);
   }
+  // (the interval sets: as in the narrow kernel, every record ORs its bit into the word of its group's first record)
+  LV<int> hidx[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) { QM_LANES(l) { hidx[c][l] = head[c][l] ? 64 * c + l : 0; if (head[c][l]) M.k.k1[64 * c + l] = 0; } }
+  scan_max_c<C>(hidx);
+  wave_fence();
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    QM_LANES(l) { if (64 * c + l < NR && M.ivcnt[sl[c][l]] > 1) atomic_or_u64(&M.k.k1[hidx[c][l]], 1ULL << (rr[c][l].iv & 63u)); }
+  }
+  wave_fence();
   LV<int> g1v[C], reqN[C]; LV<bool> req[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) {
@@ -718,8 +736,7 @@ QM_DEV int sel_pack_batch_wide(const DevIndex& ix, const ReadBatch& B, const lon
           const float requiredFrac = (float)m * B.consensus_fraction;
           int requiredNumHits = m;
           if (B.consensus_fraction < 1.0) { const int fl = (int)requiredFrac; requiredNumHits = fl > 1 ? fl : 1; }
-          u64 mk = 0;
-          for (int j = i; j < g1; ++j) mk |= 1ULL << (M.rec[j].iv & 63u);
+          const u64 mk = M.k.k1[i];
           const bool rq = popc64(mk) >= requiredNumHits;
           req[c][l] = rq; reqN[c][l] = requiredNumHits;
           if (rq) M.anyreq[s] = 1;
