@@ -947,7 +947,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
       static const char* hm[8] = {"intervals in", "suffix gather", "sort", "groups+chain", "list assembly", "(after)", "write-out", "-"};
       double ht = 0; for (int i = 0; i < 8; ++i) ht += (double)hscal[32 + i];
       if (ht > 0) for (int i = 0; i < 8; ++i) fprintf(stderr, "[qm timing h2m] %-16s %6.2f %%  %10.0f clk/read\n", hm[i], 100.0 * hscal[32 + i] / ht, (double)hscal[32 + i] / (double)nreads);
-      static const char* pm[8] = {"cand+intervals", "gather+keys", "rank sort", "heads+count", "chaining", "words", "write-out", "-"};
+      static const char* pm[8] = {"cand+intervals", "gather+keys", "rank sort", "heads+count", "chaining", "words", "write-out", "chaining, parallel"};
       double pt = 0; for (int i = 0; i < 8; ++i) pt += (double)hscal[40 + i];
       if (pt > 0) for (int i = 0; i < 8; ++i) fprintf(stderr, "[qm timing pack] %-16s %6.2f %%  %10.0f clk/read\n", pm[i], 100.0 * hscal[40 + i] / pt, (double)hscal[40 + i] / (double)nreads);
     }

@@ -324,6 +324,59 @@ QM_DEV int sel_pack_batch(const DevIndex& ix, const ReadBatch& B, long long r0, 
       }
     }
   }
+  // chaining, lane-parallel for the groups whose chain is hit 0 <- hit 1 <- ... on one diagonal (see sel_pack_batch_wide for the argument):
+  // f is a prefix sum over the record lanes, every record checks its own conditions, a failed check leaves the group to the editions below
+  {
+    LV<int> Sv;
+    QM_LANES(l) {
+      int g = 0;
+      if (l < NR && M.ivcnt[sl[l]] > 1) {
+        const SelRec x = rr[l];
+        g = (int)x.len;
+        if (!head[l]) { const SelRec y = M.rec[l - 1]; const int dq = (int)(x.qpos + x.len) - (int)(y.qpos + y.len); g = g < dq ? g : dq; }
+      }
+      Sv[l] = g;
+      if (head[l]) M.k.k1[l] = 0;                           // (the interval set has been read: the word now collects failed checks)
+    }
+    lane_scan_add(Sv);
+    QM_LANES(l) { M.sw[l] = Sv[l]; }
+    wave_fence();
+    QM_LANES(l) {
+      if (l < NR && M.ivcnt[sl[l]] > 1 && !head[l]) {
+        const int h = hidx[l];
+        const int base = h > 0 ? M.sw[h - 1] : 0;
+        const int F = Sv[l] - base;
+        const SelRec x = rr[l]; const SelRec hd = M.rec[h];
+        int ok = (int)((int)(x.pos - x.qpos) == (int)(hd.pos - hd.qpos)) & (int)(F > (int)x.len);
+        if (l >= h + 2) {
+          const SelRec y2 = M.rec[l - 2];
+          const int dq2 = (int)(x.qpos + x.len) - (int)(y2.qpos + y2.len);
+          const int cand2 = (M.sw[l - 2] - base) + ((int)x.len < dq2 ? (int)x.len : dq2);
+          ok &= (int)(cand2 <= F);
+        }
+        if (!ok) atomic_or_u64(&M.k.k1[h], 1ULL);
+      }
+    }
+    wave_fence();
+    QM_LANES(l) {
+      const int hn = chainN[l];
+      if (hn > 0 && M.k.k1[l] == 0) {
+        const int base = l > 0 ? M.sw[l - 1] : 0;
+        const int Flast = M.sw[l + hn - 1] - base;
+        const SelRec x = rr[l];
+        if (hn == 1 || Flast > (int)x.len) {
+          SelGroup g; g.tid = x.tid; g.offcs = 0; g.set_cs(QM_CS_REGULAR); g.score = 0; g.npos = 1; g.ppos = (int)(x.pos - x.qpos);
+          if (hn > 1) {
+            const int Fprev = M.sw[l + hn - 2] - base; const SelRec hl = M.rec[l + hn - 1];
+            if (Flast > Fprev && (int)(hl.qpos + hl.len) - (int)x.qpos == chainLen[l]) g.set_cs(QM_CS_UNGAPPED);
+          }
+          M.ends[l] = g.ppos;
+          gv[l] = g; nsv[l] = 1; em[l] = true; chainN[l] = 0;
+        }
+      }
+    }
+    wave_fence();
+  }
   // chaining (HitManager.cpp:107-307).  Nearly every transcript's hits lie on ONE diagonal; up to eight of them go through an edition of the
   // DP that lives in registers -- on one diagonal the gap cost is zero and every score a small integer, so integer arithmetic decides every
   // comparison as the doubles do --; anything else takes sel_chain_group, and the wavefront only enters that when some lane needs it
@@ -404,9 +457,9 @@ QM_DEV int sel_chain_diag_mem(const SelRec* H, int hn, int maxDist, int* f, int*
   int best = -1, lastBest = -1, nEnds = 0, firstEnd = 0;
   int f1 = 0, e1 = 0, f2 = 0, e2 = 0;
   bool linear = true;
-  SelRec hi = h0;
+  SelRec hi = h0, hnx = H[1 < hn ? 1 : 0];                 // (records are requested two hits ahead: an LDS round trip is longer than a hit's arithmetic)
   for (int i = 0; i < hn; ++i) {
-    const SelRec hnx = H[i + 1 < hn ? i + 1 : i];
+    const SelRec hnx2 = H[i + 2 < hn ? i + 2 : hn - 1];
     if ((int)(hi.pos - hi.qpos) != diag) return 0;
     const int ei = (int)(hi.qpos + hi.len), leni = (int)hi.len;
     int fi = leni, pi = i, looksLeft = 2;
@@ -438,7 +491,7 @@ QM_DEV int sel_chain_diag_mem(const SelRec* H, int hn, int maxDist, int* f, int*
     linear = linear && (i == 0 || pi == i - 1);
     if (fi > best) { best = fi; lastBest = i; nEnds = 0; ends[nEnds++] = i; firstEnd = i; }
     else if (fi == best) ends[nEnds++] = i;
-    f2 = f1; e2 = e1; f1 = fi; e1 = ei; hi = hnx;
+    f2 = f1; e2 = e1; f1 = fi; e1 = ei; hi = hnx; hnx = hnx2;
   }
   int nOptimal = 0, nStarts = 0;
   if (linear && firstEnd > 0) { nOptimal = 1; nStarts = 1; }
@@ -768,6 +821,80 @@ QM_DEV int sel_pack_batch_wide(const DevIndex& ix, const ReadBatch& B, const lon
     }
   }
   QM_T(3);
+  // Chaining, lane-parallel for the usual group: hits on one diagonal whose chain is hit 0 <- hit 1 <- ... (HitManager.cpp:107-307 with
+  // p[i] = i - 1).  Under that hypothesis f[i] = len_0 + sum of min(len_t, e_t - e_(t-1)) -- a prefix sum over the record lanes --, and the
+  // hypothesis holds exactly when every hit takes its predecessor (f[i-1] + gain > len_i) and does not prefer the hit before it
+  // (f[i-2] + min(len_i, e_i - e_(i-2)) <= f[i]): the look-back stops there (two looks after the first predecessor).  Every record checks
+  // its own two conditions and the diagonal; a group with a failed check (or with no gain at all: its first end would be hit 0) keeps
+  // its job for the serial editions below.  A linear chain from an end beyond hit 0 has ONE start (sel_chain_diag_mem).
+  {
+    LV<int> gn[C], Sv[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      QM_LANES(l) {
+        const int i = 64 * c + l;
+        int g = 0;
+        if (i < NR && M.ivcnt[sl[c][l]] > 1) {
+          const SelRec x = rr[c][l];
+          g = (int)x.len;
+          if (!head[c][l]) { const SelRec y = M.rec[i - 1]; const int dq = (int)(x.qpos + x.len) - (int)(y.qpos + y.len); g = g < dq ? g : dq; }
+        }
+        gn[c][l] = g; Sv[c][l] = g;
+        if (head[c][l]) M.k.k1[i] = 0;                      // (the group's interval set has been read: the word now collects failed checks)
+      }
+    }
+    scan_add_c<C>(Sv);
+#pragma unroll
+    for (int c = 0; c < C; ++c) { QM_LANES(l) { M.sw[64 * c + l] = Sv[c][l]; } }
+    wave_fence();
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      QM_LANES(l) {
+        const int i = 64 * c + l;
+        if (i < NR && M.ivcnt[sl[c][l]] > 1 && !head[c][l]) {
+          const int h = hidx[c][l];
+          const int base = h > 0 ? M.sw[h - 1] : 0;
+          const int F = Sv[c][l] - base;
+          const SelRec x = rr[c][l]; const SelRec hd = M.rec[h];
+          int ok = (int)((int)(x.pos - x.qpos) == (int)(hd.pos - hd.qpos)) & (int)(F > (int)x.len);
+          if (i >= h + 2) {
+            const SelRec y2 = M.rec[i - 2];
+            const int dq2 = (int)(x.qpos + x.len) - (int)(y2.qpos + y2.len);
+            const int cand2 = (M.sw[i - 2] - base) + ((int)x.len < dq2 ? (int)x.len : dq2);
+            ok &= (int)(cand2 <= F);
+          }
+          if (!ok) atomic_or_u64(&M.k.k1[h], 1ULL);
+        }
+      }
+    }
+    wave_fence();
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      QM_LANES(l) {
+        const int hn = chainN[c][l];
+        if (hn > 0) {
+          const int i = 64 * c + l;
+          if (M.k.k1[i] == 0) {
+            const int base = i > 0 ? M.sw[i - 1] : 0;
+            const int Flast = M.sw[i + hn - 1] - base;
+            const SelRec x = rr[c][l];
+            if (hn == 1 || Flast > (int)x.len) {
+              SelGroup g; g.offcs = 0; g.set_cs(QM_CS_REGULAR);
+              if (hn > 1) {
+                const int Fprev = M.sw[i + hn - 2] - base; const SelRec hl = M.rec[i + hn - 1];
+                if (Flast > Fprev && (int)(hl.qpos + hl.len) - (int)x.qpos == chainLen[c][l]) g.set_cs(QM_CS_UNGAPPED);
+              }
+              const int diag = (int)(x.pos - x.qpos);
+              M.starts[i] = 1 | (g.cs() << 16); M.c.seen[i] = diag; M.ends[i] = diag;
+              chainN[c][l] = -hn;                           // done: no job
+            }
+          }
+        }
+      }
+    }
+    wave_fence();
+  }
+  QM_T(7);                                                // (the lane-parallel chaining; 4: the serial jobs that are left)
   // chaining: the groups that need it are spread over the chunks' lanes; gathered into one list, a lane per job, they run side by side in as
   // few divergent rounds as there are 64 jobs -- results through LDS: starts[first] = chain starts | status << 16, seen[first] = own position
   int njobs = 0;
@@ -811,7 +938,7 @@ QM_DEV int sel_pack_batch_wide(const DevIndex& ix, const ReadBatch& B, const lon
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     QM_LANES(l) {
-      if (chainN[c][l] > 0) {
+      if (chainN[c][l] != 0) {
         const int i = 64 * c + l;
         const int rs = M.starts[i];
         const int ns = rs & 0xffff;
