@@ -46,7 +46,7 @@ struct PackMem {                   // one wavefront's LDS: 5.3 KB
   int mark[64];
   SelRec rec[64];                  // (iv: interval in its read | read of the batch << 8)
   union {
-    struct { u64 k1[64], k2[64]; } k;                        // sort keys
+    struct { u64 k1[64 + 1], k2[64 + 1]; } k;                // sort keys (+1: the rank sort's sentinel, a key below nothing)
     struct { double f[64]; int p[64], seen[64]; } c;         // chaining DP
   };
   int ends[64], starts[64];
@@ -236,6 +236,7 @@ QM_DEV int sel_pack_batch(const DevIndex& ix, const ReadBatch& B, long long r0, 
       mine[l] = r; myslot[l] = s;
     }
   }
+  QM_LANES(l) { if (l == 0) { M.k.k1[64] = ~0ULL; M.k.k2[64] = ~0ULL; } }     // (the chaining arrays of the previous batch lie over it)
   wave_fence();
   QM_T(1);
   // ---- rank sort inside every read's segment
@@ -248,12 +249,13 @@ QM_DEV int sel_pack_batch(const DevIndex& ix, const ReadBatch& B, long long r0, 
     if (l < NR) {
       const int s = myslot[l]; const int b = M.rb[s], n = M.rn[s];
       const u64 a1 = M.k.k1[l], a2 = M.k.k2[l];
-      // (no branch around the loads: a clamped index and a select, so that the trips' LDS reads are in flight together)
-#pragma unroll 4
-      for (int t = 0; t < maxn; ++t) {
-        const int tt = t < n ? t : 0;
-        const u64 c1 = M.k.k1[b + tt], c2 = M.k.k2[b + tt];
-        rk += (int)(t < n) & ((int)(c1 < a1) | ((int)(c1 == a1) & (int)(c2 < a2)));     // (bit operators: && / || come back as branches)
+      // four trips at a time, their LDS reads requested before the first compare; past the lane's segment the sentinel (no branch, no t < n test)
+      for (int t = 0; t < maxn; t += 4) {
+        u64 c1[4], c2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int j = t + u < n ? b + t + u : 64; c1[u] = M.k.k1[j]; c2[u] = M.k.k2[j]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) key_count(c1[u], c2[u], a1, a2, rk);
       }
       rk += b;
     }
