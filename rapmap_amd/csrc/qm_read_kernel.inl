@@ -26,7 +26,13 @@ __global__ __launch_bounds__(64 * WavesPerBlock<NS>::value, WPS) void qm_read_ke
   typedef const Args __attribute__((address_space(4)))* AP4;
   const Args* args = (const Args*)(AP4)__builtin_amdgcn_kernarg_segment_ptr();
   const DevIndex& ix = args->ix; const ReadBatch& B = args->B;
-  __shared__ WaveMem<NS> mem[WB];
+  // The collector-only kernels never reach finish_read, the one user of WaveMem::buf (its first member, 1.5 KB): their waves' slabs are laid
+  // over each other by that much -- wave w's buf is the tail of wave w-1's slab, wave 0's a pad in front -- and four waves take 4.6 KB less:
+  // 8 blocks per CU instead of 6 at three slots (-s on 2 x 150 bp), 6 instead of 5 at four (2 x 250 bp).
+  constexpr unsigned SKIP = (F & QM_F_COLLECT) ? (unsigned)sizeof(((WaveMem<NS>*)nullptr)->buf) : 0u;
+  constexpr unsigned STRIDE = (unsigned)sizeof(WaveMem<NS>) - SKIP;
+  static_assert(STRIDE % alignof(WaveMem<NS>) == 0 && SKIP % alignof(WaveMem<NS>) == 0, "slab overlap keeps the alignment");
+  __shared__ __attribute__((aligned(16))) unsigned char memraw[SKIP + WB * STRIDE];
   __shared__ SelLds<(F & QM_F_SEL) != 0 && (F & QM_F_COLLECT) == 0> sels[WB];   // -s kernels that chain: the LDS edition of the scratch
   // the wave index is wave-uniform: keep it (and every address derived from it) on the scalar unit
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -39,7 +45,7 @@ __global__ __launch_bounds__(64 * WavesPerBlock<NS>::value, WPS) void qm_read_ke
   if ((threadIdx.x & 63) == 0) { for (int i = 0; i < 9; ++i) qm_tim[wave][i] = 0; qm_tim[wave][9] = __builtin_readcyclecounter(); }
 #endif
   // reads gw, gw + nw, ...: characters of the next read and offsets of the one after are staged in LDS while a read is mapped
-  WaveMem<NS>& M = mem[wave];
+  WaveMem<NS>& M = *reinterpret_cast<WaveMem<NS>*>(memraw + (unsigned)wave * STRIDE);
   stage_offsets<NS, F>(B, gw, M, 0);
   lds_dma_wait();
   stage_chars<NS, F>(B, gw, M, 0);
