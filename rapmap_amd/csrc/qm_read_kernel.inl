@@ -64,7 +64,7 @@ __global__ __launch_bounds__(64 * WavesPerBlock<NS>::value, WPS) void qm_read_ke
 
 
 // launch of one slot-count class; collect: the collector-only stage entry (QM_F_COLLECT)
-template <int NS, int W0, int WPH, int WNIP, int WPHNIP, int WSEL, bool WITH_COLLECT>
+template <int NS, int W0, int WPH, int WNIP, int WPHNIP, int WSEL, bool WITH_COLLECT, int WCOLL = W0>     // WCOLL: the -s collector of the default index
 static hipError_t launch_reads_ns(const DevIndex& ix, const ReadBatch& B, bool collect, int grid, int num_cu, hipStream_t st) {
   const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP) | (B.selscr ? QM_F_SEL : 0);
   // A persistent grid (every wave strides over the reads) of QM_GRID_OVERSUB times the blocks that are resident at once: see
@@ -84,7 +84,7 @@ static hipError_t launch_reads_ns(const DevIndex& ix, const ReadBatch& B, bool c
     // only at eight slots (the stage entry qm_collect_reads, any read length)
     if constexpr (NS <= 8 || NS == 32) {                   // (32: the long-read pass of a -s call)
       switch (F) {
-        case QM_F_SEL: QM_LAUNCH(W0, QM_F_SEL | QM_F_COLLECT); return hipGetLastError();
+        case QM_F_SEL: QM_LAUNCH(WCOLL, QM_F_SEL | QM_F_COLLECT); return hipGetLastError();
         case QM_F_SEL | QM_F_PH: QM_LAUNCH(WPH, QM_F_SEL | QM_F_PH | QM_F_COLLECT); return hipGetLastError();
         case QM_F_SEL | QM_F_NIP: QM_LAUNCH(WNIP, QM_F_SEL | QM_F_NIP | QM_F_COLLECT); return hipGetLastError();
         case QM_F_SEL | QM_F_PH | QM_F_NIP: QM_LAUNCH(WPHNIP, QM_F_SEL | QM_F_PH | QM_F_NIP | QM_F_COLLECT); return hipGetLastError();
