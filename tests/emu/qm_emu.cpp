@@ -428,3 +428,22 @@ void qe_flatten(const u32* SA, long long nSA, const u32* offsets, long long T, v
   }
 }
 }
+
+// differential check of the integer one-diagonal chaining editions (qm_selpack.inl) against sel_chain_group (the doubles): recs = hn x
+// {tid, pos, qpos, len, iv} in chain order.  Returns 0 when the edition declines the group (not one diagonal / more than 8 hits for which == 8),
+// 1 when it agrees with sel_chain_group in starts, status, own position and positions, -1 when it differs.
+extern "C" int qe_chain_diag_check(const unsigned* recs, int hn, int maxDist, int which) {
+  using namespace qm;
+  std::vector<SelRec> H(hn);
+  for (int i = 0; i < hn; ++i) { H[i].tid = recs[5 * i]; H[i].pos = recs[5 * i + 1]; H[i].qpos = recs[5 * i + 2]; H[i].len = recs[5 * i + 3]; H[i].iv = recs[5 * i + 4]; }
+  std::vector<double> f(hn + 1); std::vector<int> p(hn + 1), seen(hn + 1), ends(hn + 1), starts(hn + 1), posA(hn + 1), posB(hn + 1);
+  SelGroup ga, gb; ga.offcs = 0; gb.offcs = 0;
+  const int na = sel_chain_group(H.data(), hn, f.data(), p.data(), seen.data(), ends.data(), starts.data(), maxDist, ga, posA.data());
+  std::vector<int> fi(2 * hn + 2), pi(hn + 1), si(hn + 1), ei(hn + 1);
+  const int nb = which == 8 ? sel_chain_diag8(H.data(), hn, maxDist, gb, posB.data())
+                            : sel_chain_diag_mem(H.data(), hn, maxDist, fi.data(), pi.data(), si.data(), ei.data(), gb, posB.data());
+  if (nb == 0) return 0;
+  if (na != nb || ga.cs() != gb.cs() || ga.ppos != gb.ppos || ga.tid != gb.tid) return -1;
+  for (int t = 0; t < na; ++t) if (posA[t] != posB[t]) return -1;
+  return 1;
+}

@@ -436,3 +436,54 @@ def test_reads_beyond_512_bp_take_the_long_read_pass(synth_medium, synth_medium_
     # one character too many: the call fails
     r1[5] = bytes(txps[0][:2049]); q1, o1 = pack(r1)
     assert em.map(q1, o1, q2, o2, ns=2).status & 4
+
+
+def test_one_diagonal_chaining_editions_equal_the_doubles():
+    """The integer chaining editions of the packed -s list kernels (qm_selpack.inl: sel_chain_diag8 in registers, sel_chain_diag_mem with
+    the two previous hits in registers and no walk back on linear chains) against sel_chain_group (the doubles of HitManager.cpp:107-307) on
+    random groups of hits on one diagonal: equal query ends, hits without gain, a long first hit, short hits behind long gaps -- the cases
+    in which the chain is NOT hit 0 <- hit 1 <- ... included.  Groups on two diagonals must be declined."""
+    import ctypes as C
+    import emu
+    lib = emu._lib()
+    lib.qe_chain_diag_check.restype = C.c_int
+    lib.qe_chain_diag_check.argtypes = [C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_int]
+    rng = np.random.default_rng(20260930)
+    agreed = {8: 0, 0: 0}
+    for trial in range(12000):
+        read_len = int(rng.choice([75, 100, 150, 250]))
+        hn = int(rng.integers(1, 9)) if trial % 2 == 0 else int(rng.integers(1, 40))
+        diag = int(rng.integers(0, 5000))
+        mode = trial % 5
+        ends = []
+        e = int(rng.integers(20, 60))
+        for i in range(hn):
+            if mode == 0:   step = int(rng.integers(0, 3))            # many ties / tiny gains
+            elif mode == 1: step = 8                                   # the capped walk of -s
+            elif mode == 2: step = int(rng.integers(0, 50))            # gaps longer than a hit
+            elif mode == 3: step = int(rng.choice([0, 1, 8, 39, 47]))
+            else:           step = int(rng.integers(1, 12))
+            e = e + (step if i > 0 else 0)
+            ends.append(e)
+        recs = np.zeros((hn, 5), np.uint32)
+        for i, e in enumerate(ends):
+            ln = int(rng.integers(1, 45)) if mode in (0, 2) else int(rng.integers(31, 39))
+            if i == 0 and trial % 7 == 0:
+                ln = int(rng.integers(31, read_len))                   # the read's first MMP is not capped
+            ln = min(ln, e)
+            q = e - ln
+            recs[i] = (7, diag + q, q, ln, i & 63)
+        if trial % 11 == 0 and hn > 1:                                 # an exon the isoform skips: a second diagonal
+            k = int(rng.integers(1, hn))
+            recs[k:, 1] += 120
+        ptr = recs.ctypes.data_as(C.POINTER(C.c_uint32))
+        for which in (8, 0):
+            r = lib.qe_chain_diag_check(ptr, hn, read_len, which)
+            assert r >= 0, "trial %d: edition %d differs from sel_chain_group on %s" % (trial, which, recs.tolist())
+            two_diagonals = trial % 11 == 0 and hn > 1
+            if two_diagonals or (which == 8 and hn > 8):
+                assert r == 0, "trial %d: edition %d took a group it must decline" % (trial, which)
+            else:
+                assert r == 1, "trial %d: edition %d declined a one-diagonal group" % (trial, which)
+                agreed[which] += 1
+    assert agreed[8] > 4000 and agreed[0] > 9000
