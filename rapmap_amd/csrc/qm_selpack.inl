@@ -4,8 +4,11 @@
 // hold one suffix per isoform) occupy a fifth of the lanes, and the kernel is bound by the instructions it issues, not by
 // memory.  Here a wavefront takes a run of consecutive reads whose intervals AND suffixes fit its 64 lanes -- four or five
 // reads at a time on 2 x 100 bp -- and walks them through the same steps together: one lane per interval, one lane per
-// suffix, a rank sort inside each read's segment of lanes, the lane holding a transcript's first record counts its
-// intervals and chains its hits (sel_chain_group, unchanged), prefix sums place every group's words in the batch's output.
+// suffix, a rank sort inside each read's segment of lanes (key compare = the borrow of a 96-bit subtraction, a sentinel key past
+// the segment), every record ORs its interval's bit into its transcript's first word (one LDS atomic) and checks its own link of
+// the chain hit 0 <- hit 1 <- ... -- a transcript whose hits all pass is chained by a prefix sum; the others (several diagonals,
+// ties) keep a serial job on the lane of their first record: sel_chain_diag8 / sel_chain_diag_mem (integers, one diagonal) or
+// sel_chain_group (the doubles, unchanged) --, prefix sums place every group's words in the batch's output.
 // What it computes per read is sel_hits_to_mappings for a read whose hits lie on ONE strand (HitManager.cpp:587-689 slack
 // intersection, :84-326 chaining, :716-807 single interval, :834-881 with an empty other side); a read with hits on both
 // strands, with more than 64 intervals or more than 64 suffixes goes on a queue for qm_h2m_kernel, which runs after this
