@@ -1187,11 +1187,13 @@ static int map_device_split(qm_ctx* c, const qm_opts* o, int K, int64_t n, const
   int64_t nh[8] = {0}; qm_counters ctr[8]; int rcs[8] = {0}; char errs[8][256];
   memset(ctr, 0, sizeof(ctr));
   const bool paired = d_seq2 != nullptr;
+  static const int firstPct = [] { const char* e = getenv("QM_SPLIT_FIRST"); const int v = e ? atoi(e) : 0; return v > 0 && v < 100 ? v : 0; }();   // (tuning knob: two parts of unequal size)
   c->lastUnits = -1;
   HIPCHK(hipEventRecord(c->evA, c->stream));
   c->pool->run(K, [&](int i) {
     qm_ctx* h = c->helpers[(size_t)i];
-    const int64_t u0 = n * i / K, u1 = n * (i + 1) / K;
+    int64_t u0 = n * i / K, u1 = n * (i + 1) / K;
+    if (K == 2 && firstPct > 0) { const int64_t cut = n * firstPct / 100; u0 = i == 0 ? 0 : cut; u1 = i == 0 ? cut : n; }
     RunReq rq; rq.join = &J; rq.part = i;
     errs[i][0] = 0;
     int r = map_device_impl(h, o, u1 - u0, d_seq1, (const long long*)d_off1 + u0, d_seq2, d_seq2 ? (const long long*)d_off2 + u0 : nullptr,
