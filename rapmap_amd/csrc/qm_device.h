@@ -20,6 +20,8 @@ hipError_t qmk_build_slots_from_ph(const void* dev_index, long long n, void* slo
 hipError_t qmk_build_phrecs(const unsigned int* data, const unsigned char* lens, long long n, const void* dev_index, void* out, hipStream_t st);
 hipError_t qmk_build_phfilter(const void* recs, long long n, void* filter, unsigned long long mask, hipStream_t st);
 int qmk_map_grid(long long n, int num_cu);
+int qmk_map_grid_ex(long long n, int num_cu, int ph_compact);   // ph_compact: the compact -p kernels' oversubscription
+int qmk_grid_oversub_ph(void);
 // blocks launched per resident block of a persistent stage-A grid (QM_GRID_OVERSUB, default 4); qmk_map_grid counts them in,
 // qmk_resident_grid does not (kernels that own per-wave scratch in device memory: the list kernels)
 int qmk_grid_oversub(void);

@@ -759,7 +759,8 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
   int rc;
   const bool paired = d_seq2 != nullptr;
   const int64_t nreads = paired ? 2 * n : n;
-  const int grid = qmk_map_grid(nreads, c->numCU);
+  const int phc = c->d_ph ? 1 : 0;                        // (the compact -p image: its kernels take a larger grid)
+  const int grid = qmk_map_grid_ex(nreads, c->numCU, phc);
   if ((rc = ensure(c->d_lcnt, c->capLcnt, nreads + 1))) return rc;
   if ((rc = ensure(c->d_loff, c->capLoff, nreads + 1))) return rc;
   if ((rc = ensure(c->d_gscr, c->capGrid, (int64_t)grid * 4 * QM_GSCR_U64))) return rc;
@@ -845,7 +846,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
         C.nreads = r1 - r0; C.lcnt = B.lcnt + r0; C.loff = B.loff + r0;
         if (C.iv_cnt) { C.iv_cnt = B.iv_cnt + r0; C.iv_off = B.iv_off + r0; }
         if (C.found_out) C.found_out = B.found_out + r0;
-        HIPCHK(launch(C, qmk_map_grid(r1 - r0, c->numCU)));
+        HIPCHK(launch(C, qmk_map_grid_ex(r1 - r0, c->numCU, phc)));
       }
       feeder = nullptr;                                   // a retry finds everything resident
     } else if (nreads > 0) HIPCHK(launch(B, grid));
@@ -863,7 +864,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
         HIPCHK(qmk_collect_slow(c->d_lcnt, nreads, c->d_slowq, (unsigned long long*)(c->d_scal + QM_SC_SLOWQ), c->stream));
         ReadBatch S2 = B;
         S2.slowq = c->d_slowq; S2.nreads = nl_;
-        const int g2 = qmk_map_grid(nl_, c->numCU);
+        const int g2 = qmk_map_grid_ex(nl_, c->numCU, phc);
         HIPCHK(qmk_map_reads(&ix, &S2, -32, g2 < grid ? g2 : grid, c->numCU, c->stream));
         // the list kernel's own slow queue (reads whose intervals overflow its scratch) starts from zero
         HIPCHK(hipMemsetAsync(c->d_scal + QM_SC_SLOWCNT, 0, 3 * sizeof(u64), c->stream));
@@ -905,7 +906,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
       HIPCHK(qmk_collect_slow(c->d_lcnt, nreads, c->d_slowq, (unsigned long long*)(c->d_scal + QM_SC_SLOWQ), c->stream));
       ReadBatch S2 = B;
       S2.slowq = c->d_slowq; S2.nreads = nl_;
-      const int g2 = qmk_map_grid(nl_, c->numCU);
+      const int g2 = qmk_map_grid_ex(nl_, c->numCU, phc);
       HIPCHK(qmk_map_reads(&ix, &S2, rq.mode == QM_RUN_COLLECT ? -32 : 32, g2 < grid ? g2 : grid, c->numCU, c->stream));
       HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));

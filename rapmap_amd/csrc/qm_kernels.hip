@@ -455,14 +455,22 @@ int qmk_grid_oversub(void) {
   if (m == 0) { const char* e = getenv("QM_GRID_OVERSUB"); m = e && atoi(e) > 0 && atoi(e) <= 16 ? atoi(e) : 4; }
   return m;
 }
+// the compact -p kernels (BooPHF walked per lookup: reads differ more in work, 6 waves per SIMD) keep gaining up to twelve times the
+// resident blocks: 181.9 / 185.5 / 187.4 / 189.1 / 189.0 M pairs/s at 4 / 6 / 8 / 12 / 16 (profiles/r04/ph_oversub.txt)
+int qmk_grid_oversub_ph(void) {
+  static int m = 0;
+  if (m == 0) { const char* e = getenv("QM_GRID_OVERSUB_PH"); m = e && atoi(e) > 0 && atoi(e) <= 16 ? atoi(e) : (getenv("QM_GRID_OVERSUB") ? qmk_grid_oversub() : 12); }
+  return m;
+}
 int qmk_resident_grid(long long nreads, int num_cu) {
   long long want = (nreads + 3) / 4;
   long long cap = (long long)num_cu * QMK_BLOCKS_PER_CU;
   return (int)(want < cap ? (want > 0 ? want : 1) : cap);
 }
-int qmk_map_grid(long long nreads, int num_cu) {
+int qmk_map_grid(long long nreads, int num_cu) { return qmk_map_grid_ex(nreads, num_cu, 0); }
+int qmk_map_grid_ex(long long nreads, int num_cu, int ph_compact) {
   long long want = (nreads + 3) / 4;
-  long long cap = (long long)num_cu * QMK_BLOCKS_PER_CU * qmk_grid_oversub();
+  long long cap = (long long)num_cu * QMK_BLOCKS_PER_CU * (ph_compact ? qmk_grid_oversub_ph() : qmk_grid_oversub());
   return (int)(want < cap ? (want > 0 ? want : 1) : cap);
 }
 

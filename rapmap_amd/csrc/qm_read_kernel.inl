@@ -74,7 +74,7 @@ static hipError_t launch_reads_ns(const DevIndex& ix, const ReadBatch& B, bool c
     if (nb == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, qm_read_kernel<NS, WPS_, F_>, 64 * WavesPerBlock<NS>::value, 0) != hipSuccess || nb < 1)) \
       nb = WPS_;                                                                                                \
     static const char* ov = getenv("QM_BLOCKS_PER_CU");   /* tuning knob: fewer resident blocks than the occupancy allows */ \
-    long long g = (long long)num_cu * ((ov && atoi(ov) > 0 && atoi(ov) < nb) ? atoi(ov) : nb) * qmk_grid_oversub();  \
+    long long g = (long long)num_cu * ((ov && atoi(ov) > 0 && atoi(ov) < nb) ? atoi(ov) : nb) * (((F_) & QM_F_PH) ? qmk_grid_oversub_ph() : qmk_grid_oversub());  \
     if (g > grid) g = grid;                                                                                     \
     hipLaunchKernelGGL((qm_read_kernel<NS, WPS_, F_>), dim3((unsigned)g), dim3(64 * WavesPerBlock<NS>::value), 0, st, ix, B); \
   } while (0)
