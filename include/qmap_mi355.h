@@ -274,7 +274,7 @@ int qm_last_kernel_ms(const qm_ctx* ctx, double* map_kernel_ms, double* total_ms
  * because the per-read hit lists outgrew their buffer (the buffer is grown and the batch redone; results are unaffected),
  * QM_STAT_LIST_WORDS -- capacity of that buffer in 8-byte words, QM_STAT_SLOW_READS -- reads that took the per-read
  * overflow path of -s (more suffixes than the wave's scratch holds). */
-enum { QM_STAT_RELAUNCHES = 0, QM_STAT_LIST_WORDS = 1, QM_STAT_SLOW_READS = 2 };
+enum { QM_STAT_RELAUNCHES = 0, QM_STAT_LIST_WORDS = 1, QM_STAT_SLOW_READS = 2, QM_STAT_LEAN_READS = 3, QM_STAT_LEAN_DEFERRED = 4 };
 int qm_ctx_stat(const qm_ctx* ctx, int which, int64_t* value);
 
 /* `rapmap quasiindex [-p]` (src/RapMapSAIndexer.cpp:449-819): FASTA -> q5 index directory readable by

@@ -31,6 +31,8 @@ hipError_t qmk_launch_reads_ns3(const void* dev_index, const void* read_batch, i
 hipError_t qmk_launch_reads_ns4(const void* dev_index, const void* read_batch, int collect, int grid, int num_cu, hipStream_t st);
 hipError_t qmk_launch_reads_ns8(const void* dev_index, const void* read_batch, int collect, int grid, int num_cu, hipStream_t st);
 hipError_t qmk_launch_reads_ns32(const void* dev_index, const void* read_batch, int collect, int grid, int num_cu, hipStream_t st);
+// the lean stage-A kernel (qm_kernels_lean.hip): reads of up to 128 clean characters, two per wavefront and iteration
+hipError_t qmk_launch_lean(const void* dev_index, const void* read_batch, int num_cu, hipStream_t st);
 hipError_t qmk_map_reads(const void* dev_index, const void* read_batch, int ns, int grid, int num_cu, hipStream_t st);
 hipError_t qmk_map_reads_ex(const void* dev_index, const void* read_batch, int ns, int collect, int grid, int num_cu, hipStream_t st);
 // ns < 0: the "collector only" stage entry (NS=4 kernels with QM_F_COLLECT)

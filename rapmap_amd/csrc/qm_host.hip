@@ -28,6 +28,7 @@
 #include <functional>
 
 #include "qm_mapper.inl"
+#include "qm_lean.inl"
 #include "qm_device.h"
 #include "qm_phflat.h"
 
@@ -154,7 +155,7 @@ struct qm_ctx {
   // last result
   int64_t lastUnits = -1, lastHits = 0; bool lastPaired = false;
   double lastMapMs = 0, lastTotalMs = 0;
-  int64_t lastRelaunches = 0, lastSlowReads = 0;
+  int64_t lastRelaunches = 0, lastSlowReads = 0, lastLeanReads = -1, lastLeanDeferred = 0;   // lastLeanReads: reads the lean kernel was launched over (-1: not used)
   // qm_map_device on a large batch: its parts on helper contexts of the same replica, in flight together (map_device_split)
   uint32_t flags = 0; bool isHelper = false;
   std::vector<qm_ctx*> helpers; struct SplitPool* pool = nullptr;
@@ -763,7 +764,13 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
   const int grid = qmk_map_grid_ex(nreads, c->numCU, phc);
   if ((rc = ensure(c->d_lcnt, c->capLcnt, nreads + 1))) return rc;
   if ((rc = ensure(c->d_loff, c->capLoff, nreads + 1))) return rc;
-  if ((rc = ensure(c->d_gscr, c->capGrid, (int64_t)grid * 4 * QM_GSCR_U64))) return rc;
+  // The lean kernel (qm_lean.inl: two reads per wavefront and iteration, reads of up to 128 clean characters) takes the fused default
+  // call on a dense table; the reads it marks instead of mapping go through the general kernel in a second, small launch below.
+  // It owns no per-wave scratch in device memory: that is only reserved -- for the small grid -- when the second launch happens.
+  static const bool leanOff = [] { const char* e = getenv("QM_NO_LEAN"); return e && atoi(e) != 0; }();
+  const bool useLean = !leanOff && rq.mode == QM_RUN_FUSED && !o->sel_aln && o->sensitive && ns == 2 && c->d_slots && !c->d_ph && c->d_saext &&
+                       !rq.keepIntervals && !rq.keepFound && c->ix->k <= 31;
+  if (!useLean) { if ((rc = ensure(c->d_gscr, c->capGrid, (int64_t)grid * 4 * QM_GSCR_U64))) return rc; }
   if (rq.mode != QM_RUN_COLLECT) {
     int64_t wantLists = nreads * 4 + (int64_t)grid * 4 * QM_CHUNK * 2;   // chunked bump allocator: up to one open chunk per wave
     if (c->capLists < wantLists) { if ((rc = ensure(c->d_lists, c->capLists, wantLists))) return rc; }
@@ -797,7 +804,8 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
     c->d_sanext = R.d_sanext; c->devBytes = R.devBytes;
   }
   const DevIndex ix = dev_index(c);
-  c->lastRelaunches = 0; c->lastSlowReads = 0; c->lastIvTotal = 0;
+  c->lastRelaunches = 0; c->lastSlowReads = 0; c->lastIvTotal = 0; c->lastLeanReads = useLean ? nreads : -1; c->lastLeanDeferred = 0;
+  float leanExtraMs = 0;
   while (true) {
     ReadBatch B; memset(&B, 0, sizeof(B));
     B.seq1 = (const unsigned char*)d_seq1; B.off1 = (const long long*)d_off1;
@@ -820,6 +828,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
     if (rq.mode == QM_RUN_COLLECT || twoPass) HIPCHK(hipMemsetAsync(c->d_lcnt, 0, (size_t)(nreads + 1) * sizeof(uint32_t), c->stream));   // collector-only kernels write no list lengths: the array only carries the long-read marks
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     auto launch = [&](const ReadBatch& X, int g) -> hipError_t {
+      if (useLean) return qmk_launch_lean(&ix, &X, c->numCU, c->stream);
       if (rq.mode == QM_RUN_FROM_INTERVALS) return qmk_h2m(&ix, &X, g, c->numCU, c->stream);
       if (twoPass) return qmk_map_reads_ex(&ix, &X, ns, 1, g, c->numCU, c->stream);
       return qmk_map_reads(&ix, &X, rq.mode == QM_RUN_COLLECT ? -1 : ns, g, c->numCU, c->stream);
@@ -895,6 +904,29 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
     HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     int status = (int)(hscal[QM_SC_STATUS] & 0xffffffffu);
+    if (useLean && hscal[QM_SC_LEANQ] > 0 && !(status & 23)) {
+      // what the lean kernel marked instead of mapping (a character that is not A C G T, a long run of one base, a read beyond 128
+      // characters, a wide interval, hits on both strands ...): gathered into a queue and mapped by the general kernel; everything it
+      // writes goes where the first launch would have put it, and the reads it sets aside in turn (beyond its slot class) take the
+      // long-read pass below
+      const int64_t nq = (int64_t)hscal[QM_SC_LEANQ];
+      if ((rc = ensure(c->d_slowq, c->capSlowq, nq))) return rc;
+      const int g2 = qmk_map_grid_ex(nq, c->numCU, 0);
+      if ((rc = ensure(c->d_gscr, c->capGrid, (int64_t)g2 * 4 * QM_GSCR_U64))) return rc;
+      HIPCHK(hipMemsetAsync(c->d_scal + QM_SC_SLOWQ, 0, sizeof(u64), c->stream));
+      HIPCHK(qmk_collect_slow(c->d_lcnt, nreads, c->d_slowq, (unsigned long long*)(c->d_scal + QM_SC_SLOWQ), c->stream));
+      ReadBatch S2 = B;
+      S2.slowq = c->d_slowq; S2.nreads = nq; S2.gscratch = c->d_gscr;      // (B was filled in before the scratch existed)
+      HIPCHK(hipEventRecord(c->evA, c->stream));
+      HIPCHK(qmk_map_reads(&ix, &S2, ns, g2, c->numCU, c->stream));
+      HIPCHK(hipEventRecord(c->evB, c->stream));
+      HIPCHK(hipMemsetAsync(c->d_scal + QM_SC_SLOWQ, 0, sizeof(u64), c->stream));   // (the long-read pass gathers with the same counter)
+      HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      status = (int)(hscal[QM_SC_STATUS] & 0xffffffffu);
+      float t = 0; if (hipEventElapsedTime(&t, c->evA, c->evB) == hipSuccess) leanExtraMs += t;
+      c->lastLeanDeferred = nq;
+    }
     if ((!o->sel_aln || rq.mode == QM_RUN_COLLECT) && rq.mode != QM_RUN_FROM_INTERVALS && hscal[QM_SC_SLOWCNT] > 0 && !(status & 23)) {
       // reads longer than the slot class of this launch (always: longer than QM_MAX_READ_LEN) were set aside: gather them
       // and map them with the 32-slot kernels -- a second, small launch; everything it writes (lists, intervals, foundHit)
@@ -907,6 +939,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
       ReadBatch S2 = B;
       S2.slowq = c->d_slowq; S2.nreads = nl_;
       const int g2 = qmk_map_grid_ex(nl_, c->numCU, phc);
+      if (useLean) { if ((rc = ensure(c->d_gscr, c->capGrid, (int64_t)(g2 < grid ? g2 : grid) * 4 * QM_GSCR_U64))) return rc; S2.gscratch = c->d_gscr; }
       HIPCHK(qmk_map_reads(&ix, &S2, rq.mode == QM_RUN_COLLECT ? -32 : 32, g2 < grid ? g2 : grid, c->numCU, c->stream));
       HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
@@ -977,7 +1010,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
   c->lastFoundReads = wantFound ? nreads : -1;
   c->lastListReads = rq.mode != QM_RUN_COLLECT ? nreads : -1;
   c->lastListWords = (int64_t)hscal[0];
-  float ms = 0; hipEventElapsedTime(&ms, c->ev0, c->ev1); c->lastMapMs = ms;
+  float ms = 0; hipEventElapsedTime(&ms, c->ev0, c->ev1); c->lastMapMs = ms + leanExtraMs;
   return QM_OK;
 }
 
@@ -1698,6 +1731,8 @@ int qm_ctx_stat(const qm_ctx* c, int which, int64_t* value) {
     case QM_STAT_RELAUNCHES: *value = c->lastRelaunches; break;
     case QM_STAT_LIST_WORDS: *value = c->capLists; break;
     case QM_STAT_SLOW_READS: *value = c->lastSlowReads; break;
+    case QM_STAT_LEAN_READS: *value = c->lastLeanReads; break;
+    case QM_STAT_LEAN_DEFERRED: *value = c->lastLeanDeferred; break;
     default: return fail(QM_E_ARG, "unknown statistic %d", which);
   }
   return QM_OK;

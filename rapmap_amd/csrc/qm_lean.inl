@@ -1,0 +1,453 @@
+// qm_lean.inl -- stage A for the reads that make up nearly all of a batch: at most 128 characters, nothing but A C G T (either
+// case), no run of k equal bases, seed intervals of at most 64 suffixes, hits on one strand.  Same algorithm and same answers
+// as map_read (SACollector::operator() + hitsToMappingsSimple, the lines qm_mapper.inl cites), another shape:
+//
+//   * TWO reads per wavefront and iteration (the two mates of a pair, or two consecutive single-end reads): lanes 0-31 take
+//     the first, lanes 32-63 the second -- 32 lanes x 4 characters is exactly a 128-character read -- so the regular phases
+//     (offsets, characters -> 2-bit image, the first probe: eight look-ups in one round) are issued once for both.  The walks
+//     of the two reads follow one another.
+//   * no per-position flag registers and no interval table: a probe of 32 positions leaves two 32-bit masks in SGPRs (k-mer
+//     found / reverse complement found) and the intervals in the lanes that looked them up; the walk is find-first / popcount
+//     on those masks and a v_readlane for the interval.  The walk never turns back, so nothing older than the current window
+//     is needed (a position that falls out of the window and is asked for again is looked up again: look-ups are pure).
+//   * the reverse-complemented read is not a string of its own: every lane that packs four characters also writes the
+//     reverse complement of its byte at the mirrored place of a second image; position q of reverseRead(read) is position
+//     q + (128 - L) of that image.  The complement of a window's k-mers comes out of it by the same funnel shift as the
+//     k-mers themselves (no per-lane word_rc), and a read that maps to the reverse strand needs no second strand set-up.
+//   * hits -> mappings in registers for every list shape: the (transcript, position) of each suffix arrives with the MMP
+//     extension's own load (SaExt), is parked in LDS per strand, and one loop of lane reads does the per-transcript minimum,
+//     the intersection over the intervals (a bit per interval) and the rank by transcript; the list goes from the registers
+//     to B.lists.
+//
+// A read this kernel does not take -- dirty or long reads, wide intervals, more than 64 suffixes on a strand, hits on both
+// strands, a 128-character read that matches beyond the SaExt window -- is marked (QM_LCNT_SLOW in its list-length word, count in
+// scalar slot QM_SC_LEANQ) before anything else was written for it; the host gathers the marks into a queue and qm_read_kernel
+// maps the queue in a second, small launch.
+// Options the kernel is built for: dense table (or the -p image expanded into one), sensitive mode, no -s, no interval /
+// foundHit output; the host launches the general kernel for everything else.
+#pragma once
+#include "qm_mapper.inl"
+
+namespace qm {
+
+#define QM_LEAN_MAXLEN 128
+#define QM_LEAN_SUF 64           // suffixes a strand's intervals may hold together
+#define QM_LEAN_MAXIV 32         // intervals per strand (a bit each)
+#define QM_SC_LEANQ 30           // scalar slot: reads on the lean kernel's queue
+
+struct LeanSuf { u32 tid, pos, qp, iv; };      // one suffix of a recorded interval: transcript, offset in it, queryPos and index of the interval
+
+struct LeanMem {                               // one wave's LDS slab (2 656 bytes)
+  u64 pk[2][2][8];                             // [read of the iteration][0: the read, 1: mirrored reverse complement][word]: 2 bits per base, first
+                                               // base in the top bits of word 0; words 4-7 stay zero (extension queries read past the image)
+  LeanSuf suf[2][QM_LEAN_SUF];                 // [strand]: suffixes of the intervals recorded for the read being mapped
+  u32 stage[2][36];                            // raw characters of the next iteration's two reads (global_load_lds target)
+  u32 ostage[2][8];                            // offsets (dwords) of the next / the next but one iteration
+};
+
+// the current probe window of a walk: positions [wb, wb + ww) of the strand, bit j of Fm / Cm = k-mer / reverse complement of
+// position wb + j found, lane j (< 32) holds that position's interval
+struct LeanWin { int wb, ww; u32 Fm, Cm; LV<u32> lb, ub; };
+struct LeanStrand { int n, sufN, minIdx, minSpan, cov; };   // intervals, their suffixes, the first smallest interval (HitManager.cpp:636-641), coverage
+
+QM_DEV int ctz32(u32 x) { return x ? __builtin_ctz(x) : 32; }
+QM_DEV int popc32(u32 x) { return __builtin_popcount(x); }
+
+// k-mer word at position q of an image (Kmer.hpp:525-542 over clean characters)
+QM_DEV u64 lean_kmer(const QM_LDS(u64)* img, int q, int k) {
+  const int j = q >> 5, sh = 2 * (q & 31);
+  const u64 w0 = img[j], w1 = img[j + 1];
+  return ((w0 << sh) | ((w1 >> 1) >> (63 - sh))) >> (64 - 2 * k);
+}
+
+// khash.find (RapMapUtils.hpp:65-67) for one key per lane in one round of loads; lanes that are not `on` read bucket 0
+QM_DEV void lean_find(const DevIndex& ix, const LV<u64>& key, const LV<bool>& on, LV<bool>& hit, LV<u32>& lb, LV<u32>& ub) {
+  LV<bool> more; LV<u64> bkt;
+  QM_LANES(l) {
+    const u64 b = on[l] ? ((u64)bucket_hash(key[l]) & ix.hmask) : 0ULL;
+    U4 a, c;
+    load_32(&ix.slots[b], a, c);
+    QM_CNT(1, on[l] ? 1 : 0);
+    const u64 k0r = ((u64)a.y << 32) | a.x, k1 = ((u64)a.w << 32) | a.z;
+    // keys are 2k <= 62 bits: an empty slot (~0) and the overflow mark (bit 63) never equal one
+    const bool h0 = (k0r & ~QM_BK_OVF) == key[l], h1 = k1 == key[l];
+    const bool h = on[l] && (h0 || h1);
+    hit[l] = h; lb[l] = h0 ? c.x : c.z; ub[l] = h0 ? c.y : c.w;
+    more[l] = on[l] && !h && k0r != ~0ULL && (k0r & QM_BK_OVF) != 0;
+    bkt[l] = b;
+  }
+  if (ballot(more)) {                                  // 0.4 % of the buckets: a key that hashes here lives in a later bucket
+    QM_LANES(l) {
+      if (more[l]) {
+        u64 b = (bkt[l] + 1) & ix.hmask;
+        while (true) {
+          U4 a, c;
+          load_32(&ix.slots[b], a, c);
+          QM_CNT(1, 1);
+          const u64 k0r = ((u64)a.y << 32) | a.x, k1 = ((u64)a.w << 32) | a.z;
+          if ((k0r & ~QM_BK_OVF) == key[l]) { hit[l] = true; lb[l] = c.x; ub[l] = c.y; break; }
+          if (k1 == key[l]) { hit[l] = true; lb[l] = c.z; ub[l] = c.w; break; }
+          if (k0r == ~0ULL || !(k0r & QM_BK_OVF)) break;
+          b = (b + 1) & ix.hmask;
+        }
+      }
+    }
+  }
+}
+
+// Probe positions [wb, wb + ww) (ww <= 32) of strand V of a read: lanes 0-31 look up the k-mers, lanes 32-63 their reverse
+// complements -- the k-mer at position P - 1 - q of the other strand's image.  pk2: the read's two images (8 words each),
+// D = 128 - L: where reverseRead(read) starts in the second one.
+QM_DEV void lean_probe(const DevIndex& ix, const QM_LDS(u64)* pk2, int D, int V, int P, int k, int wb, int ww, LeanWin& W) {
+  if (wb + ww > P) ww = P - wb;
+  QM_CNT(3, 1); QM_CNT(4, ww);
+  LV<u64> key; LV<bool> on, hit;
+  QM_LANES(l) {
+    const int j = l & 31;
+    const bool in = j < ww, comp = l >= 32;
+    const int s = comp ? 1 - V : V;
+    const int q = comp ? P - 1 - (wb + j) : wb + j;
+    key[l] = lean_kmer(pk2 + 8 * s, in ? q + (s ? D : 0) : 0, k);
+    on[l] = in;
+  }
+  lean_find(ix, key, on, hit, W.lb, W.ub);
+  const u64 fm = ballot(hit);
+  W.Fm = (u32)fm; W.Cm = (u32)(fm >> 32); W.wb = wb; W.ww = ww;
+}
+
+// SACollector::getSAHits_ (SACollector.hpp:441-677, NIP disabled) over a clean strand: every position below P is eligible,
+// every window is A C G T.  The MMP extension (SASearcher.hpp:88-309) is the closed form of extend_search_wide against the
+// packed characters behind every suffix's k-mer (one lane per suffix, one 32-byte load each); the (transcript, position) words
+// of the block it settles on go to suf[].  false: a case the lean kernel leaves to the general one.
+QM_DEV bool lean_walk(const DevIndex& ix, const ReadBatch& B, const QM_LDS(u64)* pk2, QM_LDS(LeanSuf)* suf, int D, int V, int L, int P,
+                      LeanWin& W, int startPos, bool haveInterval, u32 lb, u32 ub, LeanStrand& S, u32& strandHits, u32& otherHits) {
+  const int k = ix.k;
+  QM_CNT(17, 1);
+  int p = startPos;
+  bool skip = haveInterval, lastSearch = false;
+  int prevEnd = 0, width = 1;
+  while (true) {
+    if (!skip) {
+      if (p >= P) break;
+      if ((unsigned)(p - W.wb) >= (unsigned)W.ww) lean_probe(ix, pk2, D, V, P, k, p, width, W);
+      width = 32;
+      const int rel = p - W.wb, avail = W.ww - rel;
+      const u32 fm = W.Fm >> rel, cm = W.Cm >> rel;       // (no bits beyond the window)
+      const int ph = ctz32(fm);
+      const int stop = fm ? ph : avail;
+      otherHits += (u32)popc32(cm & ~fm & (u32)((1ULL << stop) - 1ULL));   // misses: spotCheck_ of the complement (:667-675)
+      if (!fm) { p = W.wb + W.ww; continue; }
+      strandHits += 1;                                   // spotCheck_ on the hit (:545)
+      otherHits += (cm >> ph) & 1u;
+      p += ph;
+      lb = read_lane(W.lb, p - W.wb); ub = read_lane(W.ub, p - W.wb);
+    }
+    skip = false;
+    const u32 lbIn = lb ? lb - 1 : 0;                    // :553
+    const int wiv = (int)(ub - lbIn - 1);
+    if (wiv < 1 || wiv > 64) return false;
+    QM_CNT(18, 1);
+    const int pos = p + k, rem = L - pos, cap = rem < QM_EXT_BASES ? rem : QM_EXT_BASES;
+    LV<int> lc; LV<u32> tdv, tpv; LV<bool> fullv;
+    QM_LANES(l) {
+      // the strand's characters from pos on, packed like the table's entries (the same words in every lane: broadcast reads)
+      const int gq = pos + (V ? D : 0), j = gq >> 5, sh = 2 * (gq & 31);
+      const QM_LDS(u64)* img = pk2 + 8 * V + j;
+      const u64 w0 = img[0], w1 = img[1], w2 = img[2], w3 = img[3];
+      const u64 q0 = (w0 << sh) | ((w1 >> 1) >> (63 - sh)), q1 = (w1 << sh) | ((w2 >> 1) >> (63 - sh)), q2 = (w2 << sh) | ((w3 >> 1) >> (63 - sh));
+      U4 a, b;
+      load_32(&ix.saext[lbIn + 1 + (u32)(l < wiv ? l : wiv - 1)], a, b);
+      const u64 x0 = (((u64)a.y << 32) | a.x) ^ q0, x1 = (((u64)a.w << 32) | a.z) ^ q1, x2 = (((u64)b.y << 32) | b.x) ^ q2;
+      const int nv = (int)(b.z >> QM_EXT_TID_BITS);
+      int matched = x0 ? (clz64(x0) >> 1) : (x1 ? 32 + (clz64(x1) >> 1) : (x2 ? 64 + (clz64(x2) >> 1) : 96));
+      matched = matched < nv ? matched : nv;
+      matched = matched < cap ? matched : cap;
+      fullv[l] = matched == QM_EXT_BASES;
+      lc[l] = l < wiv ? k + matched : -1;
+      tdv[l] = b.z & ((1u << QM_EXT_TID_BITS) - 1); tpv[l] = b.w;
+    }
+    if (rem > QM_EXT_BASES && ballot(fullv)) return false;   // (a 128-character read matching beyond what the table holds)
+    const int mlen = wave_max(lc);
+    LV<bool> best;
+    QM_LANES(l) { best[l] = lc[l] == mlen; }
+    const u64 bq = ballot(best);
+    const int first = ctz64(bq), cnt = 64 - clz64(bq) - first;
+    lb = lbIn + 1 + (u32)first; ub = lb + (u32)cnt;
+    const bool more = !lastSearch && p + mlen < L;
+    const int kp = p + mlen - (k - 1);
+    if (ub > lb && ub - lb < (u32)B.max_interval) {     // :577-618
+      if (S.sufN + cnt > QM_LEAN_SUF || S.n >= QM_LEAN_MAXIV) return false;
+      QM_LANES(l) {
+        if (l >= first && l < first + cnt) {
+          QM_LDS(LeanSuf)* d = suf + (S.sufN + l - first);
+          d->tid = tdv[l]; d->pos = tpv[l]; d->qp = (u32)p; d->iv = (u32)S.n;
+        }
+      }
+      if (cnt < S.minSpan) { S.minSpan = cnt; S.minIdx = S.n; }
+      S.sufN += cnt; S.n += 1;
+      const int corr = prevEnd > p ? prevEnd - p : 0;
+      S.cov += mlen - corr;
+      prevEnd = p + mlen;
+      if (p + mlen < L) {                                 // the k-mer the walk goes on with is spot-checked here (:602-611); kp < P
+        if ((unsigned)(kp - W.wb) >= (unsigned)W.ww) lean_probe(ix, pk2, D, V, P, k, kp, more ? 32 : 1, W);
+        const int rk = kp - W.wb;
+        strandHits += (W.Fm >> rk) & 1u; otherHits += (W.Cm >> rk) & 1u;
+      }
+    }
+    if (lastSearch) return true;
+    if (p + mlen >= L) return true;
+    p = kp;                                               // NIP off: lce == matchedLen (:635-647)
+    width = 32;
+    if (p + k == L) lastSearch = true;
+  }
+  return true;
+}
+
+// hitsToMappingsSimple (HitManager.cpp:691-882) for one strand whose intervals hold n <= 64 suffixes, in registers.  Lane l
+// holds suffix l.  Its transcript survives when it was seen in every interval (:669-678, slack 0: a bit per interval), and it
+// is represented by the entry with the smallest position, the earlier interval in processing order on ties (the first smallest
+// interval first: :636-641, :309-313; one interval: the stable sort + std::unique of :757-803).  Survivors go out in ascending
+// transcript order: slot = number of surviving entries with a smaller transcript id.
+QM_DEV int lean_h2m(const QM_LDS(LeanSuf)* suf, const LeanStrand& S, bool isRC, LV<u64>& elem, LV<bool>& keep, LV<int>& slot) {
+  const int n = S.sufN, m = S.n;
+  QM_CNT(12, 1); QM_CNT(13, n);
+  LV<u32> tid, pos, ordl, ivb, seen, less;
+  QM_LANES(l) {
+    const QM_LDS(LeanSuf)* e = suf + (l < n ? l : 0);
+    const u32 t = e->tid, ps = e->pos, qp = e->qp, iv = e->iv;
+    tid[l] = l < n ? t : 0xffffffffu; pos[l] = ps;
+    const u32 ord = iv == (u32)S.minIdx ? 0u : (iv < (u32)S.minIdx ? iv + 1u : iv);
+    ordl[l] = ord * 64u + (u32)l;
+    ivb[l] = 1u << iv; seen[l] = ivb[l]; less[l] = 0;
+    elem[l] = mk_elem(t, isRC, (int)(ps - qp));          // pos - queryPos (:315, :761-767)
+    keep[l] = l < n;
+  }
+  for (int j = 0; j < n; ++j) {
+    const u32 tj = read_lane(tid, j), pj = read_lane(pos, j), oj = read_lane(ordl, j), bj = read_lane(ivb, j);
+    QM_LANES(l) {
+      const bool same = tj == tid[l];
+      if (same && (pj < pos[l] || (pj == pos[l] && oj < ordl[l]))) keep[l] = false;
+      less[l] += tj < tid[l] ? 1u : 0u;
+      if (same) seen[l] |= bj;
+    }
+  }
+  const u32 all = m >= 32 ? 0xffffffffu : ((1u << m) - 1u);
+  QM_LANES(l) { keep[l] = keep[l] && seen[l] == all; }
+  const u64 km = ballot(keep);
+  const int cnt = popc64(km);
+  if (cnt == n) { QM_LANES(l) { slot[l] = (int)less[l]; } }          // nothing dropped: every transcript once
+  else {
+    QM_LANES(l) { slot[l] = 0; }
+    for (u64 r = km; r; r &= r - 1) {
+      const u32 tj = read_lane(tid, ctz64(r));
+      QM_LANES(l) { slot[l] += tj < tid[l] ? 1 : 0; }
+    }
+  }
+  return cnt;
+}
+
+// a read for the general kernel: marked in its list-length word and counted (the host gathers the marks into a queue, like the
+// reads the general kernels set aside for the long-read pass); nothing else was written for it
+QM_DEV void lean_defer(const ReadBatch& B, long long read) {
+  QM_CNT(19, 1);
+  QM_LANES(l) { if (l == 0) { B.lcnt[read] = QM_LCNT_SLOW; B.loff[read] = 0; atomic_add_u64(B.cursor + QM_SC_LEANQ, 1ULL); } }
+}
+
+// offsets of iteration `it` into ostage[par]: pairs: off1[it], off1[it + 1], off2[it], off2[it + 1]; single-end reads 2 it and
+// 2 it + 1: off1[2 it .. 2 it + 2] (the last one only if the second read exists)
+QM_DEV void lean_stage_offsets(const ReadBatch& B, long long it, long long nit, LeanMem& M, int par) {
+  if (it >= nit) return;
+  const bool paired = B.seq2 != nullptr;
+  const int nd = paired ? 8 : (2 * it + 1 < B.nreads ? 6 : 4);
+  QM_LANES(l) {
+    if (l < nd) {
+      const long long* o = paired ? ((l < 4 ? B.off1 : B.off2) + it) : (B.off1 + 2 * it);
+      lds_dma_u32((const u32*)o + (paired ? (l & 3) : l), M.ostage[par], l);
+    }
+  }
+}
+QM_DEV long long lean_off64(const LV<u32>& ov, int d) { return (long long)(((u64)read_lane(ov, d + 1) << 32) | (u64)read_lane(ov, d)); }
+// the offsets in ostage[par] (landed) into the request for the two reads' characters
+QM_DEV void lean_stage_chars(const ReadBatch& B, long long it, long long nit, LeanMem& M, int par) {
+  if (it >= nit) return;
+  const bool paired = B.seq2 != nullptr;
+  const bool have1 = 2 * it + 1 < B.nreads;
+  LV<u32> ov;
+  QM_LANES(l) { ov[l] = M.ostage[par][l & 7]; }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (h && !have1) break;
+    const int d0 = h ? (paired ? 4 : 2) : 0;
+    const long long o0 = lean_off64(ov, d0), o1 = lean_off64(ov, d0 + 2);
+    int len = (int)(o1 - o0);
+    if (len > QM_LEAN_MAXLEN) len = QM_LEAN_MAXLEN;
+    const unsigned char* p = ((h && paired) ? B.seq2 : B.seq1) + o0;
+    const int mis = (int)((unsigned long long)p & 3ULL);
+    const u32* g = (const u32*)(p - mis);
+    const int nd = (mis + len + 3) >> 2;                  // <= 33
+    QM_LANES(l) { if (l < nd) lds_dma_u32(g + l, M.stage[h], l); }
+  }
+}
+
+// one iteration: reads 2 it and 2 it + 1
+QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, long long it, long long nit, long long nw, int par, LeanMem& M, WaveAlloc& wa) {
+  const int k = ix.k;
+  const bool paired = B.seq2 != nullptr;
+  const long long r0 = 2 * it;
+  const bool have1 = r0 + 1 < B.nreads;
+  // ---- the two reads' characters -> 2-bit images of both strands, four characters per lane
+  LV<u32> ov;
+  QM_LANES(l) { ov[l] = M.ostage[par][l & 7]; }
+  const u32 a0 = read_lane(ov, 0), a1 = read_lane(ov, 2);
+  const u32 b0 = read_lane(ov, paired ? 4 : 2), b1 = read_lane(ov, paired ? 6 : 4);
+  const int raw0 = (int)(a1 - a0), raw1 = have1 ? (int)(b1 - b0) : 0;
+  const int len0 = raw0 > QM_LEAN_MAXLEN ? QM_LEAN_MAXLEN : raw0, len1 = raw1 > QM_LEAN_MAXLEN ? QM_LEAN_MAXLEN : raw1;
+  const int mis0 = (int)(((u32)(unsigned long long)B.seq1 + a0) & 3u);
+  const int mis1 = (int)(((u32)(unsigned long long)(paired ? B.seq2 : B.seq1) + b0) & 3u);
+  QM_LDS(unsigned char)* PKb = (QM_LDS(unsigned char)*)&M.pk[0][0][0];
+  LV<bool> bad, rep;
+  QM_LANES(l) {
+    const int h = l >> 5, jj = l & 31, base = 4 * jj;
+    const int len = h ? len1 : len0, mis = h ? mis1 : mis0;
+    const u32 w0 = M.stage[h][jj], w1 = M.stage[h][jj + 1];
+    const u32 d = align_bytes(w1, w0, mis);                                   // characters base .. base + 3
+    const int nb = len - base;
+    const u32 lenmask = nb >= 4 ? 0xffffffffu : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
+    const u32 t = (d & 0xdfdfdfdfu) ^ canon4(d, false);
+    const u32 valid = ~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t | 0x7f7f7f7fu) & lenmask;       // 0x80: A C G T in either case
+    bad[l] = (~valid & lenmask & 0x80808080u) != 0;
+    const u32 x = (d >> 1) & 0x03030303u;
+    const u32 code = (x ^ ((x >> 1) & 0x01010101u)) & ((valid >> 7) * 3u);     // A0 C1 G2 T3 (Kmer.hpp:40-51)
+    const u32 pk = (code * 0x40100401u) >> 24;                                 // first character in the top bits
+    rep[l] = nb >= 4 && ((pk ^ (pk >> 2)) & 0x3fu) == 0;
+    // the same four bases reverse-complemented (Kmer.hpp:92-100 on a byte): order reversed, every code inverted
+    u32 r = brev32(pk) >> 24;
+    r = (~(((r >> 1) & 0x55u) | ((r & 0x55u) << 1))) & 0xffu;
+    const int img = 128 * h;                                                   // bytes: image (h, strand) starts at 128 h + 64 strand
+    PKb[img + 8 * (jj >> 3) + 7 - (jj & 7)] = (unsigned char)pk;
+    const int mj = 31 - jj;
+    PKb[img + 64 + 8 * (mj >> 3) + 7 - (mj & 7)] = (unsigned char)r;
+  }
+  const u64 dirty = ballot(bad), reps = ballot(rep);
+  wave_fence();
+  // the staging rows are free again: the next iteration's characters, and the offsets of the one after it
+  lean_stage_chars(B, it + nw, nit, M, par ^ 1);
+  lean_stage_offsets(B, it + 2 * nw, nit, M, par);
+  // what this kernel takes: no character but A C G T, no window of k equal bases (k equal characters cover at least (k - 6) / 4
+  // whole lanes above: setup_strand's rule for its lazy strands), at most 128 characters
+  const bool defer0 = raw0 > QM_LEAN_MAXLEN || (u32)dirty != 0 || 4 * popc32((u32)reps) + 6 >= k;
+  const bool defer1 = raw1 > QM_LEAN_MAXLEN || (u32)(dirty >> 32) != 0 || 4 * popc32((u32)(reps >> 32)) + 6 >= k;
+  const int P0 = len0 - k + 1, P1 = len1 - k + 1;
+  const bool ok0 = !defer0 && P0 >= 1, ok1 = have1 && !defer1 && P1 >= 1;
+  // ---- the first probe of both reads in one round (SACollector.hpp:167-237 starts at position 0; the read's last k-mer is the
+  // first thing the reverse-complement pass asks for): lanes 0-3 of each half = the read's k-mer 0, its k-mer P - 1, and --
+  // from the second image -- the reverse complements of those two
+  LV<u64> key; LV<bool> on, hit; LV<u32> plb, pub;
+  QM_LANES(l) {
+    const int h = l >> 5, jj = l & 31;
+    const int P = h ? P1 : P0, D = QM_LEAN_MAXLEN - (h ? len1 : len0);
+    const int s = (jj >> 1) & 1;
+    const bool lastq = jj == 1 || jj == 2;                 // jj 0: read[0]  1: read[P-1]  2: rc[P-1] (= complement of read[0])  3: rc[0]
+    const bool o = (h ? ok1 : ok0) && jj < 4 && (P > 1 || !(jj & 1));
+    const int q = (lastq ? P - 1 : 0) + (s ? D : 0);
+    key[l] = lean_kmer((const QM_LDS(u64)*)&M.pk[0][0][0] + 16 * h + 8 * s, o ? q : 0, k);
+    on[l] = o;
+  }
+  QM_CNT(3, 1);
+  lean_find(ix, key, on, hit, plb, pub);
+  const u64 fm0 = ballot(hit);
+  lds_dma_wait();                                          // what was requested above has landed by now: no store follows an open request
+#pragma nounroll
+  for (int h = 0; h < 2; ++h) {
+    if (h && !have1) break;
+    const long long read = r0 + h;
+    if (h ? defer1 : defer0) { lean_defer(B, read); continue; }
+    const int L = h ? len1 : len0, P = L - k + 1, D = QM_LEAN_MAXLEN - L;
+    int n = 0; bool foundHit = false, bail = false;
+    LV<u64> elem; LV<bool> keep; LV<int> slot;
+    QM_LANES(l) { keep[l] = false; slot[l] = 0; elem[l] = 0; }
+    if (P >= 1) {
+      const QM_LDS(u64)* pk2 = (const QM_LDS(u64)*)&M.pk[0][0][0] + 16 * h;
+      const u32 fmh = (u32)(fm0 >> (32 * h));
+      const u32 F0 = fmh & 1u, C0 = (fmh >> 2) & 1u;
+      const u32 Fl = P > 1 ? (fmh >> 1) & 1u : F0, Cl = P > 1 ? (fmh >> 3) & 1u : C0;
+      const int sl = 32 * h, rl = sl + (P > 1 ? 3 : 2);
+      const u32 s0lb = read_lane(plb, sl), s0ub = read_lane(pub, sl), r0lb = read_lane(plb, rl), r0ub = read_lane(pub, rl);
+      LeanWin W; W.wb = 0; W.ww = 1; W.Fm = F0; W.Cm = C0;
+      QM_LANES(l) { W.lb[l] = s0lb; W.ub[l] = s0ub; }
+      // first-hit scan (:167-237): the first position whose k-mer or reverse complement is in the hash
+      int p0 = 0; bool found = false;
+      while (p0 < P) {
+        if ((unsigned)(p0 - W.wb) >= (unsigned)W.ww) lean_probe(ix, pk2, D, 0, P, k, p0, 32, W);
+        const u32 mm = (W.Fm | W.Cm) >> (p0 - W.wb);
+        if (mm) { p0 += ctz32(mm); found = true; break; }
+        p0 = W.wb + W.ww;
+      }
+      if (found) {
+        foundHit = true;
+        const int rel = p0 - W.wb;
+        u32 fwdHit = (W.Fm >> rel) & 1u, rcHit = (W.Cm >> rel) & 1u;
+        const bool useCov = B.strict_check != 0;           // disableNIP_ && strictCheck_ (:138)
+        LeanStrand SF, SR;
+        SF.n = 0; SF.sufN = 0; SF.minIdx = 0; SF.minSpan = 0x7fffffff; SF.cov = 0; SR = SF;
+        bool didFwd = false;
+        // the three passes of :247-278 through one expansion of the walk: the read from its first hit, reverseRead(read)
+        // from 0, the read from 0 when forward k-mers were first seen while the reverse complement was walked
+#pragma nounroll
+        for (int pass = 0; pass < 3 && !bail; ++pass) {
+          bool run; int V = pass == 1 ? 1 : 0, start = 0; bool seeded = false; u32 lb = 0, ub = 0;
+          if (pass == 0) {
+            run = fwdHit != 0; start = p0; seeded = true;
+            if (run) { lb = read_lane(W.lb, rel); ub = read_lane(W.ub, rel); didFwd = true; }
+          } else if (pass == 1) {
+            run = useCov ? (rcHit > 0) : (rcHit >= fwdHit);                    // :258
+            if (run) { W.wb = 0; W.ww = 1; W.Fm = Cl; W.Cm = Fl; QM_LANES(l) { W.lb[l] = r0lb; W.ub[l] = r0ub; } }
+          } else {
+            run = !didFwd && (useCov ? (fwdHit > 0) : (fwdHit >= rcHit));      // :271
+            if (run) { W.wb = 0; W.ww = 1; W.Fm = F0; W.Cm = C0; QM_LANES(l) { W.lb[l] = s0lb; W.ub[l] = s0ub; } }
+          }
+          if (!run) continue;
+          LeanStrand S = V ? SR : SF;
+          u32 sh = V ? rcHit : fwdHit, oh = V ? fwdHit : rcHit;
+          const bool okw = lean_walk(ix, B, pk2, (QM_LDS(LeanSuf)*)M.suf[0] + QM_LEAN_SUF * V, D, V, L, P, W, start, seeded, lb, ub, S, sh, oh);
+          if (V) { SR = S; rcHit = sh; fwdHit = oh; } else { SF = S; fwdHit = sh; rcHit = oh; }
+          if (!okw) bail = true;
+        }
+        if (!bail) {
+          if (useCov) {                                    // :283-288 (no slack without chain scoring)
+            if (SF.cov > SR.cov) SR.n = 0;
+            else if (SR.cov > SF.cov) SF.n = 0;
+          }
+          if (B.quasi_cov > 0.0) {                         // :343-358
+            if (SF.n > 0) { const double f = (double)SF.cov / (double)L; if (f < B.quasi_cov) SF.n = 0; }
+            if (SR.n > 0) { const double f = (double)SR.cov / (double)L; if (f < B.quasi_cov) SR.n = 0; }
+          }
+          if (SF.n > 0 && SR.n > 0) bail = true;           // hits on both strands: the general kernel's merge (HitManager.cpp:834-881)
+          else if (SF.n > 0 || SR.n > 0) {
+            const bool isRC = SR.n > 0;
+            wave_fence();
+            n = lean_h2m((const QM_LDS(LeanSuf)*)M.suf[0] + (isRC ? QM_LEAN_SUF : 0), isRC ? SR : SF, isRC, elem, keep, slot);
+          }
+        }
+      }
+    }
+    if (bail) { lean_defer(B, read); continue; }
+    // ---- the list to B.lists through the wave's chunk of the bump allocator (finish_read)
+    long long base = 0;
+    if (n > 0) {
+      if (wa.base < 0 || wa.used + n > QM_CHUNK) {
+        LV<u64> bv;
+        QM_LANES(l) { bv[l] = 0; if (l == 0) bv[l] = atomic_add_u64(B.cursor, (u64)QM_CHUNK); }
+        wa.base = (long long)read_lane(bv, 0); wa.used = 0;
+      }
+      base = wa.base + wa.used;
+      if (base + n > B.lists_cap) { QM_LANES(l) { if (l == 0) *B.status |= 1; } n = 0; base = 0; }
+      else wa.used += n;
+    }
+    if (n > 0) { QM_LANES(l) { if (keep[l]) B.lists[base + slot[l]] = elem[l]; } }
+    const u32 flag = (B.fuzzy && foundHit) ? 0x80000000u : 0u;
+    QM_LANES(l) { if (l == 0) { B.lcnt[read] = (u32)n | flag; B.loff[read] = base; } }
+  }
+}
+
+}  // namespace qm

@@ -1726,11 +1726,10 @@ struct WaveAlloc { long long base; int used; long long ivBase; int ivUsed; };   
 // LDS staging the only wait is the one finish_read places before its stores, by which time the loads have long landed.
 //   stage[]    raw bytes of the next read, fetched as aligned dwords from (src + o0) & ~3 on
 //   ostage[j]  two offsets (4 dwords) of a read: slot parity j holds the current read's, j ^ 1 the next one's
-// slot of a launch -> read: the identity, except in the slow pass of -s and in the long-read pass (NS > 8), whose launches walk
-// a queue of reads the first pass set aside
+// slot of a launch -> read: the identity, except in the launches that walk a queue of reads an earlier pass set aside (the slow
+// pass of -s, the long-read pass, the reads qm_lean_kernel leaves to qm_read_kernel)
 template <int F, int NS = 0>
 QM_DEV long long read_id(const ReadBatch& B, long long slot) {
-  if (!(F & QM_F_SEL) && NS <= 8) return slot;
   return B.slowq ? uniform(B.slowq[slot]) : slot;
 }
 QM_DEV void read_src(const ReadBatch& B, long long read, const unsigned char*& src, const long long*& off, long long& unit) {

@@ -57,6 +57,7 @@ QM_DEV u64 brev64(u64 x) {
   x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
   return __builtin_bswap64(x);
 }
+QM_DEV u32 brev32(u32 x) { return (u32)(brev64((u64)x) >> 32); }
 QM_DEV void wave_fence() {}
 QM_DEV void atomic_min_u64(u64* p, u64 v) { if (v < *p) *p = v; }
 QM_DEV void atomic_max_u64(u64* p, u64 v) { if (v > *p) *p = v; }
@@ -77,6 +78,7 @@ QM_DEV u64 read_lane(const LV<u64>& x, int lane) {
 QM_DEV int ctz64(u64 x) { return x ? __builtin_ctzll(x) : 64; }
 QM_DEV int popc64(u64 x) { return __builtin_popcountll(x); }
 QM_DEV u64 brev64(u64 x) { return __brevll(x); }
+QM_DEV u32 brev32(u32 x) { return __builtin_bitreverse32(x); }
 // orders this wave's LDS / global accesses across lanes (same-wave RAW through memory)
 QM_DEV void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 QM_DEV void atomic_min_u64(u64* p, u64 v) { atomicMin(p, v); }

@@ -8,6 +8,7 @@
 namespace qm { unsigned long long qm_prof[32]; }
 #endif
 #include "../../rapmap_amd/csrc/qm_mapper.inl"
+#include "../../rapmap_amd/csrc/qm_lean.inl"
 #include "../../rapmap_amd/csrc/qm_phflat.h"
 #include <cstdlib>
 #include <cstring>
@@ -207,6 +208,36 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
     }
     if (!(status & 1)) break;
     cap *= 4;
+  }
+  if (ns == 2 && ix.slots && ix.saext && B.sensitive && !o->sel_aln && !(status & 1) && !getenv("QM_EMU_NO_LEAN")) {
+    // the lean kernel (qm_lean.inl: two reads per wavefront and iteration) over the same batch, three "waves" with the kernel's own
+    // software pipeline: every list it writes must be the one the general kernel wrote for that read word for word (flag bit
+    // included); the reads it marks instead are the general kernel's
+    std::vector<u32> lcnt2(nreads + 1, 0); std::vector<long long> loff2(nreads + 1, 0);
+    std::vector<u64> lists2((size_t)cap, 0);
+    u64 scal2[QM_SC_WORDS]; memset(scal2, 0, sizeof(scal2)); int status2 = 0;
+    ReadBatch Lb = B; Lb.lcnt = lcnt2.data(); Lb.loff = loff2.data(); Lb.lists = lists2.data(); Lb.lists_cap = cap; Lb.cursor = scal2; Lb.status = &status2;
+    Lb.iv_out = nullptr; Lb.iv_cnt = nullptr; Lb.iv_off = nullptr;
+    const long long nit = (nreads + 1) >> 1, NW = 3;
+    static LeanMem Ms[3];
+    for (long long w = 0; w < NW; ++w) {
+      LeanMem& M = Ms[w]; memset(&M, 0, sizeof(M));
+      WaveAlloc wl; wl.base = -1; wl.used = 0; wl.ivBase = -1; wl.ivUsed = 0;
+      lean_stage_offsets(Lb, w, nit, M, 0); lean_stage_chars(Lb, w, nit, M, 0); lean_stage_offsets(Lb, w + NW, nit, M, 1);
+      int par = 0;
+      for (long long it = w; it < nit; it += NW) { lean_iter(ix, Lb, it, nit, NW, par, M, wl); par ^= 1; }
+    }
+    long long bad = 0, deferred = 0;
+    for (long long r = 0; r < nreads; ++r) {
+      if (lcnt2[r] == QM_LCNT_SLOW) { ++deferred; continue; }
+      bool same = lcnt2[r] == lcnt[r];
+      const long long nwd = lcnt[r] & 0x7fffffffu;
+      for (long long t = 0; same && t < nwd; ++t) same = lists2[loff2[r] + t] == lists[loff[r] + t];
+      if (!same) { if (bad < 5) fprintf(stderr, "[qm emu] lean kernel: read %lld differs (words %u vs %u)\n", r, lcnt2[r], lcnt[r]); ++bad; }
+    }
+    if ((long long)scal2[QM_SC_LEANQ] != deferred) { fprintf(stderr, "[qm emu] lean kernel: %lld marks, counter says %llu\n", deferred, (unsigned long long)scal2[QM_SC_LEANQ]); ++bad; }
+    if (getenv("QM_EMU_LEAN_STATS")) fprintf(stderr, "[qm emu] lean kernel took %lld of %lld reads\n", nreads - deferred, nreads);
+    if (bad || (status2 & ~1)) status |= 128;
   }
   PairBatch P; memset(&P, 0, sizeof(P));
   std::vector<u32> hc(nunits + 1, 0); std::vector<long long> offs(nunits + 1, 0);
