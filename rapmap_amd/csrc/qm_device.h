@@ -15,7 +15,7 @@ extern "C" {
 hipError_t qmk_build_sainfo(const unsigned int* SA, long long nSA, const unsigned int* offsets, long long T, void* out, hipStream_t st);
 hipError_t qmk_build_saext(const unsigned char* text, long long n, const unsigned int* SA, long long nSA, int k, const void* sainfo, void* out, hipStream_t st);
 hipError_t qmk_build_sanext(const unsigned char* text, long long n, const unsigned int* SA, long long nSA, int k, unsigned int* out, hipStream_t st);
-hipError_t qmk_build_slots(const void* recs, long long K, void* slots, unsigned long long cap, hipStream_t st);
+hipError_t qmk_build_slots(const void* recs, long long K, void* slots, unsigned long long cap, int k, hipStream_t st);
 hipError_t qmk_build_slots_from_ph(const void* dev_index, long long n, void* slots, unsigned long long cap, unsigned long long* d_bad, hipStream_t st);
 hipError_t qmk_build_phrecs(const unsigned int* data, const unsigned char* lens, long long n, const void* dev_index, void* out, hipStream_t st);
 hipError_t qmk_build_phfilter(const void* recs, long long n, void* filter, unsigned long long mask, hipStream_t st);

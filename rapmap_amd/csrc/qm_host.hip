@@ -593,11 +593,11 @@ int qm_ctx_create_ex(const qm_index* ix, int device_id, uint32_t flags, qm_ctx**
     else { CK(qmk_build_saext(c->d_text, ix->n, c->d_SA, ix->nSA, ix->k, c->d_sainfo, c->d_saext, c->stream)); }
   }
   if (!ix->perfect) {
-    c->cap = bucket_count(ix->nKeys);                  // 32-byte buckets of two slots, at least two buckets per key
+    c->cap = bucket_count(ix->nKeys);                  // 64-byte buckets of two canonical entries, at least two buckets per key
     CK(hipMalloc(&c->d_slots, c->cap * sizeof(Bucket)));
     CK(hipMalloc(&d_recs, (size_t)(ix->nKeys > 0 ? ix->nKeys : 1) * 16));
     if (ix->nKeys > 0) CK(hipMemcpyAsync(d_recs, ix->hashRecs, (size_t)ix->nKeys * 16, hipMemcpyHostToDevice, c->stream));
-    CK(qmk_build_slots(d_recs, ix->nKeys, c->d_slots, c->cap, c->stream));
+    CK(qmk_build_slots(d_recs, ix->nKeys, c->d_slots, c->cap, ix->k, c->stream));
   } else {
     // flatten BooPHF + FrugalBooMap: all levels' words / rank samples concatenated, small maps re-hashed
     c->cap = 1;

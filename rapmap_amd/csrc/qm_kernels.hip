@@ -292,21 +292,14 @@ __global__ void build_sanext_kernel(const unsigned char* text, long long n, cons
 }
 
 // records: K x {u64 key, u32 lb, u32 ub}: the records of hash.bin (a BigSA index's int64 pairs narrowed by the loader)
-__global__ void build_slots_kernel(const Slot* recs, long long K, Bucket* buckets, u64 hmask) {
+__global__ void build_slots_kernel(const Slot* recs, long long K, Bucket* buckets, u64 hmask, int k) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long stride = (long long)gridDim.x * blockDim.x;
   for (; i < K; i += stride) {
     Slot r = recs[i];
-    u64 b = (u64)bucket_hash(r.key) & hmask;
-    while (true) {
-      Bucket* bk = &buckets[b];
-      int got = -1;
-      for (int t = 0; t < 2 && got < 0; ++t)
-        if (atomicCAS((unsigned long long*)&bk->key[t], ~0ULL, r.key) == ~0ULL) got = t;
-      if (got >= 0) { bk->val[got].lb = (u32)r.lb; bk->val[got].ub = (u32)r.ub; break; }
-      atomicOr((unsigned long long*)&bk->key[0], QM_BK_OVF);      // full: remember that lookups must walk on
-      b = (b + 1) & hmask;
-    }
+    bucket_insert(buckets, hmask, r.key, k, (u32)r.lb, (u32)r.ub,
+                  [](u64* p, u64 cmp, u64 val) { return (u64)atomicCAS((unsigned long long*)p, (unsigned long long)cmp, (unsigned long long)val); },
+                  [](u64* p, u64 v) { atomicOr((unsigned long long*)p, (unsigned long long)v); });
   }
 }
 
@@ -348,16 +341,9 @@ __global__ void build_slots_from_ph_kernel(DevIndex ix, long long n, Bucket* buc
     u32 lb = 0, ub = 0;
     const bool found = find_kmer<QM_F_PH>(ix, r.key, lb, ub);
     if (!found || lb != r.data) { atomicAdd(bad, 1ULL); continue; }
-    u64 b = (u64)bucket_hash(r.key) & hmask;
-    while (true) {
-      Bucket* bk = &buckets[b];
-      int got = -1;
-      for (int t = 0; t < 2 && got < 0; ++t)
-        if (atomicCAS((unsigned long long*)&bk->key[t], ~0ULL, r.key) == ~0ULL) got = t;
-      if (got >= 0) { bk->val[got].lb = lb; bk->val[got].ub = ub; break; }
-      atomicOr((unsigned long long*)&bk->key[0], QM_BK_OVF);
-      b = (b + 1) & hmask;
-    }
+    bucket_insert(buckets, hmask, r.key, ix.k, lb, ub,
+                  [](u64* p, u64 cmp, u64 val) { return (u64)atomicCAS((unsigned long long*)p, (unsigned long long)cmp, (unsigned long long)val); },
+                  [](u64* p, u64 v) { atomicOr((unsigned long long*)p, (unsigned long long)v); });
   }
 }
 
@@ -422,10 +408,10 @@ hipError_t qmk_build_sanext(const unsigned char* text, long long n, const unsign
   if (nSA > 0) hipLaunchKernelGGL(build_sanext_kernel, dim3(4096), dim3(256), 0, st, text, n, SA, nSA, k, out);
   return hipGetLastError();
 }
-hipError_t qmk_build_slots(const void* recs, long long K, void* slots, unsigned long long cap, hipStream_t st) {
+hipError_t qmk_build_slots(const void* recs, long long K, void* slots, unsigned long long cap, int k, hipStream_t st) {
   hipError_t e = hipMemsetAsync(slots, 0xff, cap * sizeof(Bucket), st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(build_slots_kernel, dim3(4096), dim3(256), 0, st, (const Slot*)recs, K, (Bucket*)slots, cap - 1);
+  hipLaunchKernelGGL(build_slots_kernel, dim3(4096), dim3(256), 0, st, (const Slot*)recs, K, (Bucket*)slots, cap - 1, k);
   return hipGetLastError();
 }
 

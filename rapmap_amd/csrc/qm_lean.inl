@@ -60,20 +60,24 @@ QM_DEV u64 lean_kmer(const QM_LDS(u64)* img, int q, int k) {
   return ((w0 << sh) | ((w1 >> 1) >> (63 - sh))) >> (64 - 2 * k);
 }
 
-// khash.find (RapMapUtils.hpp:65-67) for one key per lane in one round of loads; lanes that are not `on` read bucket 0
-QM_DEV void lean_find(const DevIndex& ix, const LV<u64>& key, const LV<bool>& on, LV<bool>& hit, LV<u32>& lb, LV<u32>& ub) {
+// khash.find (RapMapUtils.hpp:65-67) for one key per lane in one round of loads; lanes that are not `on` read bucket 0.
+// ck: the canonical word of the lane's k-mer (the smaller of it and its reverse complement), isr: the k-mer is the larger one --
+// the two lanes that ask about a position's k-mer and about its reverse complement read the same 64-byte bucket.
+QM_DEV void lean_find(const DevIndex& ix, const LV<u64>& ck, const LV<bool>& isr, const LV<bool>& on, LV<bool>& hit, LV<u32>& lb, LV<u32>& ub) {
   LV<bool> more; LV<u64> bkt;
   QM_LANES(l) {
-    const u64 b = on[l] ? ((u64)bucket_hash(key[l]) & ix.hmask) : 0ULL;
+    const u64 b = on[l] ? ((u64)bucket_hash(ck[l]) & ix.hmask) : 0ULL;
     U4 a, c;
-    load_32(&ix.slots[b], a, c);
+    const unsigned char* bp = (const unsigned char*)&ix.slots[b];
+    load_16x2(bp, bp + (isr[l] ? 32 : 16), a, c);
     QM_CNT(1, on[l] ? 1 : 0);
     const u64 k0r = ((u64)a.y << 32) | a.x, k1 = ((u64)a.w << 32) | a.z;
-    // keys are 2k <= 62 bits: an empty slot (~0) and the overflow mark (bit 63) never equal one
-    const bool h0 = (k0r & ~QM_BK_OVF) == key[l], h1 = k1 == key[l];
-    const bool h = on[l] && (h0 || h1);
-    hit[l] = h; lb[l] = h0 ? c.x : c.z; ub[l] = h0 ? c.y : c.w;
-    more[l] = on[l] && !h && k0r != ~0ULL && (k0r & QM_BK_OVF) != 0;
+    // keys are 2k <= 62 bits: an empty entry (~0) and the overflow mark (bit 63) never equal one
+    const bool h0 = (k0r & ~QM_BK_OVF) == ck[l], h1 = k1 == ck[l];
+    const u32 vlb = h0 ? c.x : c.z;
+    hit[l] = on[l] && (h0 || h1) && vlb != QM_IV_NONE;
+    lb[l] = vlb; ub[l] = h0 ? c.y : c.w;
+    more[l] = on[l] && !(h0 || h1) && k0r != ~0ULL && (k0r & QM_BK_OVF) != 0;
     bkt[l] = b;
   }
   if (ballot(more)) {                                  // 0.4 % of the buckets: a key that hashes here lives in a later bucket
@@ -82,11 +86,12 @@ QM_DEV void lean_find(const DevIndex& ix, const LV<u64>& key, const LV<bool>& on
         u64 b = (bkt[l] + 1) & ix.hmask;
         while (true) {
           U4 a, c;
-          load_32(&ix.slots[b], a, c);
+          const unsigned char* bp = (const unsigned char*)&ix.slots[b];
+          load_16x2(bp, bp + (isr[l] ? 32 : 16), a, c);
           QM_CNT(1, 1);
           const u64 k0r = ((u64)a.y << 32) | a.x, k1 = ((u64)a.w << 32) | a.z;
-          if ((k0r & ~QM_BK_OVF) == key[l]) { hit[l] = true; lb[l] = c.x; ub[l] = c.y; break; }
-          if (k1 == key[l]) { hit[l] = true; lb[l] = c.z; ub[l] = c.w; break; }
+          if ((k0r & ~QM_BK_OVF) == ck[l]) { if (c.x != QM_IV_NONE) { hit[l] = true; lb[l] = c.x; ub[l] = c.y; } break; }
+          if (k1 == ck[l]) { if (c.z != QM_IV_NONE) { hit[l] = true; lb[l] = c.z; ub[l] = c.w; } break; }
           if (k0r == ~0ULL || !(k0r & QM_BK_OVF)) break;
           b = (b + 1) & ix.hmask;
         }
@@ -95,22 +100,25 @@ QM_DEV void lean_find(const DevIndex& ix, const LV<u64>& key, const LV<bool>& on
   }
 }
 
-// Probe positions [wb, wb + ww) (ww <= 32) of strand V of a read: lanes 0-31 look up the k-mers, lanes 32-63 their reverse
-// complements -- the k-mer at position P - 1 - q of the other strand's image.  pk2: the read's two images (8 words each),
-// D = 128 - L: where reverseRead(read) starts in the second one.
+// Probe positions [wb, wb + ww) (ww <= 32) of strand V of a read: lanes 0-31 ask for the k-mers, lanes 32-63 for their reverse
+// complements.  Both words of a position come out of the read's two images by the same funnel shift -- the reverse complement
+// of the k-mer at q is the k-mer at P - 1 - q of the other image -- and the two lanes of a position read the same bucket.
+// pk2: the read's two images (8 words each), D = 128 - L: where reverseRead(read) starts in the second one.
 QM_DEV void lean_probe(const DevIndex& ix, const QM_LDS(u64)* pk2, int D, int V, int P, int k, int wb, int ww, LeanWin& W) {
   if (wb + ww > P) ww = P - wb;
   QM_CNT(3, 1); QM_CNT(4, ww);
-  LV<u64> key; LV<bool> on, hit;
+  LV<u64> ck; LV<bool> isr, on, hit;
   QM_LANES(l) {
     const int j = l & 31;
-    const bool in = j < ww, comp = l >= 32;
-    const int s = comp ? 1 - V : V;
-    const int q = comp ? P - 1 - (wb + j) : wb + j;
-    key[l] = lean_kmer(pk2 + 8 * s, in ? q + (s ? D : 0) : 0, k);
+    const bool in = j < ww;
+    const int q = in ? wb + j : 0;
+    const u64 w = lean_kmer(pk2 + 8 * V, q + (V ? D : 0), k), wr = lean_kmer(pk2 + 8 * (1 - V), P - 1 - q + (V ? 0 : D), k);
+    const bool big = wr < w;                             // the strand's k-mer is the larger of the two
+    ck[l] = big ? wr : w;
+    isr[l] = big != (l >= 32);                           // lanes 32-63 ask for the other orientation
     on[l] = in;
   }
-  lean_find(ix, key, on, hit, W.lb, W.ub);
+  lean_find(ix, ck, isr, on, hit, W.lb, W.ub);
   const u64 fm = ballot(hit);
   W.Fm = (u32)fm; W.Cm = (u32)(fm >> 32); W.wb = wb; W.ww = ww;
 }
@@ -342,19 +350,22 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, long long it, long
   // ---- the first probe of both reads in one round (SACollector.hpp:167-237 starts at position 0; the read's last k-mer is the
   // first thing the reverse-complement pass asks for): lanes 0-3 of each half = the read's k-mer 0, its k-mer P - 1, and --
   // from the second image -- the reverse complements of those two
-  LV<u64> key; LV<bool> on, hit; LV<u32> plb, pub;
+  LV<u64> ck; LV<bool> isr, on, hit; LV<u32> plb, pub;
   QM_LANES(l) {
     const int h = l >> 5, jj = l & 31;
     const int P = h ? P1 : P0, D = QM_LEAN_MAXLEN - (h ? len1 : len0);
-    const int s = (jj >> 1) & 1;
     const bool lastq = jj == 1 || jj == 2;                 // jj 0: read[0]  1: read[P-1]  2: rc[P-1] (= complement of read[0])  3: rc[0]
     const bool o = (h ? ok1 : ok0) && jj < 4 && (P > 1 || !(jj & 1));
-    const int q = (lastq ? P - 1 : 0) + (s ? D : 0);
-    key[l] = lean_kmer((const QM_LDS(u64)*)&M.pk[0][0][0] + 16 * h + 8 * s, o ? q : 0, k);
-    on[l] = o;
+    const int q = (o && lastq) ? P - 1 : 0;                // position in the lane's own strand (jj >> 1) ...
+    const int qo = o ? P - 1 - q : 0;                      // ... and of the reverse complement in the other one
+    const QM_LDS(u64)* pkh = (const QM_LDS(u64)*)&M.pk[0][0][0] + 16 * h;
+    const bool s = (jj >> 1) & 1;
+    const u64 w = lean_kmer(pkh + (s ? 8 : 0), q + (s ? D : 0), k), wr = lean_kmer(pkh + (s ? 0 : 8), qo + (s ? 0 : D), k);
+    const bool big = wr < w;
+    ck[l] = big ? wr : w; isr[l] = big; on[l] = o;
   }
   QM_CNT(3, 1);
-  lean_find(ix, key, on, hit, plb, pub);
+  lean_find(ix, ck, isr, on, hit, plb, pub);
   const u64 fm0 = ballot(hit);
   lds_dma_wait();                                          // what was requested above has landed by now: no store follows an open request
 #pragma nounroll

@@ -63,14 +63,20 @@ struct Slot { u64 key; int lb; int ub; };          // hash.bin record / small li
 // (BigSA, text > 2^31 - 1 characters) fits as long as the text is below 2^32 - 2 characters, at half the bytes per SA entry
 // and per interval of the reference's int64 form
 struct Iv { u32 lb, ub; };                         // seed interval
-// Dense k-mer table: 32-byte buckets of two keys and their two intervals, two buckets to an HBM sector, at least two
-// buckets per key (load <= 25 % of the slots).  A lookup is ONE round of two 16-byte loads -- the keys and, in the same
-// round, the intervals -- with no probe chain and no dependent load for the value.  Keys are 2k <= 62 bits; ~0 marks an
-// empty slot, bit 63 of key[0] says "a key that hashes here was placed in a later bucket" (the only case a lookup walks
-// on: 0.4 % of the buckets at this load).
-struct Bucket { u64 key[2]; Iv val[2]; };          // 32 B; hipMalloc aligns the array
+// Dense k-mer table (round 5: canonical buckets).  A read asks for every k-mer AND its reverse complement (the collector's spot
+// checks), so the table is keyed by the CANONICAL word -- the smaller of a k-mer and its reverse complement -- and an entry holds the
+// SA intervals of both orientations: one 64-byte HBM sector answers both questions about a read position (the table of rounds 1-4
+// spent one sector per orientation, and those sectors were 90 % of the stage-A kernel's traffic).  A bucket is one sector: two
+// entries {key, interval of the canonical k-mer (f), interval of its reverse complement (r)}; an interval whose lb is ~0 says
+// "that orientation is not in the index".  At least two buckets per key (load <= 25 % of the entries).  A lookup is ONE round of
+// two 16-byte loads -- the keys and, in the same round, the interval pair of the orientation asked for -- with no probe chain and
+// no dependent load for the value.  Keys are 2k <= 62 bits; ~0 marks an empty entry, bit 63 of key[0] says "a key that hashes here
+// was placed in a later bucket" (the only case a lookup walks on: 0.4 % of the buckets at this load).
+struct Bucket { u64 key[2]; Iv f[2]; Iv r[2]; u64 pad[2]; };   // 64 B; hipMalloc aligns the array
 #define QM_BK_OVF (1ULL << 63)
+#define QM_IV_NONE 0xffffffffu
 QM_DEV u64 hash_mix(u64 x);
+QM_DEV u64 word_rc(u64 w, int k);
 inline constexpr u64 bucket_count(long long nkeys) { u64 c = 32; while (c < 2 * (u64)nkeys) c <<= 1; return c; }   // host + device
 // Bucket of a key: one 32 x 32 -> 64-bit multiply of the key's two halves, folded (the core of wyhash / "mum").  On the
 // k-mers of a transcriptome it fills the buckets like the two-multiply 64-bit finaliser it replaced (Poisson occupancy,
@@ -379,41 +385,70 @@ QM_DEV bool text_kmer(const DevIndex& ix, long long pos, int k, u64& w) {
 // (lanes with nothing to look up read bucket 0, a line that stays in cache), key match and value are selects, and the walk to
 // a following bucket -- 0.4 % of the buckets carry the overflow mark -- is a wave-level branch taken when any lane needs it.
 // A per-lane `while` here costs ~35 scalar instructions of exec-mask bookkeeping per round; the scalar unit is what this
-// kernel runs out of first.
-QM_DEV void find_dense_round(const DevIndex& ix, const LV<u64>& key, const LV<bool>& want, LV<bool>& hit, LV<Iv>& val) {
+// kernel runs out of first.  krc: the reverse complement of every key (the bucket is that of the smaller).
+QM_DEV void find_dense_round(const DevIndex& ix, const LV<u64>& key, const LV<u64>& krc, const LV<bool>& want, LV<bool>& hit, LV<Iv>& val) {
   LV<bool> more; LV<u64> bkt;
   QM_LANES(l) {
-    const u64 b = want[l] ? ((u64)bucket_hash(key[l]) & ix.hmask) : 0ULL;
+    const bool isr = krc[l] < key[l];                      // the key is the reverse complement of its bucket's key
+    const u64 ck = isr ? krc[l] : key[l];
+    const u64 b = want[l] ? ((u64)bucket_hash(ck) & ix.hmask) : 0ULL;
     U4 a, c;
-    load_32(&ix.slots[b], a, c);
+    const unsigned char* bp = (const unsigned char*)&ix.slots[b];
+    load_16x2(bp, bp + (isr ? 32 : 16), a, c);
     QM_CNT(0, want[l] ? 1 : 0); QM_CNT(1, want[l] ? 1 : 0);
     const u64 k0r = ((u64)a.y << 32) | a.x, k1 = ((u64)a.w << 32) | a.z;
-    const u64 k0 = k0r == ~0ULL ? k0r : (k0r & ~QM_BK_OVF);
-    const bool h0 = k0 == key[l], h1 = k1 == key[l];
+    const bool h0 = (k0r & ~QM_BK_OVF) == ck, h1 = k1 == ck;   // (keys are <= 62 bits: an empty entry, ~0, never matches)
     Iv v; v.lb = h0 ? c.x : c.z; v.ub = h0 ? c.y : c.w;
-    const bool h = want[l] && (h0 || h1);
+    const bool h = want[l] && (h0 || h1) && v.lb != QM_IV_NONE;
     if (!h) { v.lb = 0; v.ub = 0; }
     hit[l] = h; val[l] = v;
-    more[l] = want[l] && !h && k0r != ~0ULL && (k0r & QM_BK_OVF) != 0;
+    more[l] = want[l] && !(h0 || h1) && k0r != ~0ULL && (k0r & QM_BK_OVF) != 0;
     bkt[l] = b;
   }
   if (ballot(more)) {
     QM_LANES(l) {
       if (more[l]) {
+        const bool isr = krc[l] < key[l];
+        const u64 ck = isr ? krc[l] : key[l];
         u64 b = (bkt[l] + 1) & ix.hmask;
         while (true) {
           U4 a, c;
-          load_32(&ix.slots[b], a, c);
+          const unsigned char* bp = (const unsigned char*)&ix.slots[b];
+          load_16x2(bp, bp + (isr ? 32 : 16), a, c);
           QM_CNT(1, 1);
           const u64 k0r = ((u64)a.y << 32) | a.x, k1 = ((u64)a.w << 32) | a.z;
-          const u64 k0 = k0r == ~0ULL ? k0r : (k0r & ~QM_BK_OVF);
-          if (k0 == key[l]) { hit[l] = true; val[l].lb = c.x; val[l].ub = c.y; break; }
-          if (k1 == key[l]) { hit[l] = true; val[l].lb = c.z; val[l].ub = c.w; break; }
+          if ((k0r & ~QM_BK_OVF) == ck) { if (c.x != QM_IV_NONE) { hit[l] = true; val[l].lb = c.x; val[l].ub = c.y; } break; }
+          if (k1 == ck) { if (c.z != QM_IV_NONE) { hit[l] = true; val[l].lb = c.z; val[l].ub = c.w; } break; }
           if (k0r == ~0ULL || !(k0r & QM_BK_OVF)) break;
           b = (b + 1) & ix.hmask;
         }
       }
     }
+  }
+}
+
+// The table's one insertion routine (device builders and the emulation's): the entry of the key's canonical word is found or
+// created along the bucket chain, the interval goes to the orientation the key has in it (both for a k-mer that is its own reverse
+// complement: even k only).  cas / orf: atomic compare-and-swap / or on a u64 (plain operations in the emulation).
+template <typename Cas, typename Orf>
+QM_DEV void bucket_insert(Bucket* buckets, u64 hmask, u64 key, int k, u32 lb, u32 ub, Cas cas, Orf orf) {
+  const u64 rc = word_rc(key, k);
+  const u64 ck = rc < key ? rc : key;
+  u64 b = (u64)bucket_hash(ck) & hmask;
+  while (true) {
+    Bucket* bk = &buckets[b];
+    int got = -1;
+    for (int t = 0; t < 2 && got < 0; ++t) {
+      const u64 old = cas(&bk->key[t], ~0ULL, ck);
+      if (old == ~0ULL || (old & ~QM_BK_OVF) == ck) got = t;
+    }
+    if (got >= 0) {
+      if (key == ck) { bk->f[got].lb = lb; bk->f[got].ub = ub; }
+      if (rc == ck) { bk->r[got].lb = lb; bk->r[got].ub = ub; }
+      return;
+    }
+    orf(&bk->key[0], QM_BK_OVF);                           // full: remember that lookups must walk on
+    b = (b + 1) & hmask;
   }
 }
 
@@ -768,7 +803,7 @@ QM_DEV void probe_window(const DevIndex& ix, Strand<NS>& S, int p, int width, in
   QM_CNT(3, 1); QM_CNT(4, (width + stride - 1) / stride); QM_T(4);
   LV<FT> flx;
   swap32(S.fl, flx);
-  LV<bool> found, fresh, want; LV<u64> kq; LV<int> posv; LV<Iv> val;
+  LV<bool> found, fresh, want; LV<u64> kq, kr; LV<int> posv; LV<Iv> val;
   QM_LANES(l) {
     const int d = (l - p) & 63, j = d & 31;
     const bool in = j < width && (j & (stride - 1)) == 0;
@@ -781,10 +816,10 @@ QM_DEV void probe_window(const DevIndex& ix, Strand<NS>& S, int p, int width, in
     const u64 w0 = S.lazy ? clean_kmer(S.planes, q, k) : ((const u64*)S.tab)[q];
     const u64 rc = word_rc(w0, k);
     want[l] = fresh[l] && w0 != ~0ULL;                     // ~0: an N in the window
-    kq[l] = d >= 32 ? rc : w0;
+    kq[l] = d >= 32 ? rc : w0; kr[l] = d >= 32 ? w0 : rc;
   }
   wave_fence();
-  if (!(F & QM_F_PH)) find_dense_round(ix, kq, want, found, val);
+  if (!(F & QM_F_PH)) find_dense_round(ix, kq, kr, want, found, val);
   else {
     ph_filter_round(ix, kq, want);
     QM_LANES(l) {
@@ -817,7 +852,7 @@ QM_DEV bool probe_first(const DevIndex& ix, Strand<NS>& S, int p, Iv* rtab0) {
   const int k = ix.k;
   const int last = S.P - 1;
   QM_CNT(3, 1); QM_CNT(4, last != p ? 2 : 1); QM_T(4);
-  LV<bool> found, want, on; LV<u64> kq; LV<Iv> val;
+  LV<bool> found, want, on; LV<u64> kq, kr; LV<Iv> val;
   QM_LANES(l) {
     const int j = l & 31;
     on[l] = j == 0 || (j == 1 && last != p);
@@ -825,10 +860,10 @@ QM_DEV bool probe_first(const DevIndex& ix, Strand<NS>& S, int p, Iv* rtab0) {
     const u64 key = S.lazy ? clean_kmer(S.planes, q, k) : ((const u64*)S.tab)[q];
     const u64 rc = word_rc(key, k);
     want[l] = on[l] && key != ~0ULL;
-    kq[l] = l >= 32 ? rc : key;
+    kq[l] = l >= 32 ? rc : key; kr[l] = l >= 32 ? key : rc;
   }
   wave_fence();
-  if (!(F & QM_F_PH)) find_dense_round(ix, kq, want, found, val);
+  if (!(F & QM_F_PH)) find_dense_round(ix, kq, kr, want, found, val);
   else {
     ph_filter_round(ix, kq, want);
     QM_LANES(l) {

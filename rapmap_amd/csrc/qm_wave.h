@@ -154,6 +154,7 @@ QM_DEV long long load_uniform_i64(const long long* p) { return *p; }
 QM_DEV void lds_dma_u32(const u32* g, u32* ldsBase, int lane) { ldsBase[lane] = *g; }
 QM_DEV void lds_dma_wait() {}
 QM_DEV void load_32(const void* p, U4& a, U4& b) { a = load_16(p); b = load_16((const unsigned char*)p + 16); }
+QM_DEV void load_16x2(const void* p, const void* q, U4& a, U4& b) { a = load_16(p); b = load_16(q); }
 QM_DEV void load_8_16(const u64* p8, const u64* p16, u64& a, U4& b) { a = *p8; b = load_16(p16); }
 template <int N> QM_DEV void load_8_16xN(const u64* const* B, const int* bit, u64* word, U4* meta) {
   for (int t = 0; t < N; ++t) load_8_16(B[t] + (bit[t] >> 6), B[t] + 6, word[t], meta[t]);
@@ -258,6 +259,13 @@ QM_DEV U4 load_16(const void* p) {
 QM_DEV void load_32(const void* p, U4& a, U4& b) {
   typedef u32 v4u __attribute__((ext_vector_type(4)));
   v4u x = ((const v4u*)p)[0], y = ((const v4u*)p)[1];
+  asm volatile("" : "+v"(x), "+v"(y));
+  a.x = x.x; a.y = x.y; a.z = x.z; a.w = x.w; b.x = y.x; b.y = y.y; b.z = y.z; b.w = y.w;
+}
+// two 16-byte loads from two addresses issued back to back and waited for together
+QM_DEV void load_16x2(const void* p, const void* q, U4& a, U4& b) {
+  typedef u32 v4u __attribute__((ext_vector_type(4)));
+  v4u x = *(const v4u*)p, y = *(const v4u*)q;
   asm volatile("" : "+v"(x), "+v"(y));
   a.x = x.x; a.y = x.y; a.z = x.z; a.w = x.w; b.x = y.x; b.y = y.y; b.z = y.z; b.w = y.w;
 }

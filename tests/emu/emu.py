@@ -66,7 +66,7 @@ class Emu:
         self.SA = np.ascontiguousarray(ix.SA, dtype=np.uint32)     # unsigned 32-bit on the device, also for a BigSA index (int64 on disk)
         self.sainfo = np.zeros(self.SA.size * 2, dtype=np.uint32)
         self.cap = int(buckets) if buckets else int(self.lib.qe_slots_cap(ix.hkeys.size))
-        self.slots = np.zeros(self.cap * 4 + 8, dtype=np.uint64)   # cap buckets of 32 bytes
+        self.slots = np.zeros(self.cap * 8 + 8, dtype=np.uint64)   # cap buckets of 64 bytes
         off = np.ascontiguousarray(ix.txpOffsets, dtype=np.uint32)
         self.txp_off = off
         self.txp_len = np.ascontiguousarray(ix.txpLens, dtype=np.int32)
@@ -101,7 +101,7 @@ class Emu:
         self.lib.qe_flatten(C.c_void_p(self.SA.ctypes.data), C.c_int64(self.SA.size), C.c_void_p(off.ctypes.data),
                             C.c_int64(off.size), C.c_void_p(self.sainfo.ctypes.data), C.c_void_p(hk.ctypes.data),
                             C.c_void_p(hl.ctypes.data), C.c_void_p(hu.ctypes.data), C.c_int64(hk.size),
-                            C.c_void_p(self.slots.ctypes.data), C.c_uint64(self.cap))
+                            C.c_void_p(self.slots.ctypes.data), C.c_uint64(self.cap), C.c_int(ix.k))
 
     def map(self, seq1, off1, seq2=None, off2=None, opts=None, ns=2):
         opts = opts or default_opts()

@@ -433,10 +433,10 @@ void qe_ksw_rows(const int* qlen, const unsigned char* const* query, const int* 
   else if (ring == 128) ksw_rows_run<128>(qlen, query, tlen, target, mat, q, e, w, out);
   else ksw_rows_run<1024>(qlen, query, tlen, target, mat, q, e, w, out);
 }
-unsigned long long qe_slots_cap(long long nkeys) { return bucket_count(nkeys); }   // buckets of 32 bytes
+unsigned long long qe_slots_cap(long long nkeys) { return bucket_count(nkeys); }   // buckets of 64 bytes
 void qe_flatten(const u32* SA, long long nSA, const u32* offsets, long long T, void* sainfo_out,
                 const unsigned long long* keys, const u32* lb, const u32* ub, long long K, void* slots_out,
-                unsigned long long cap) {
+                unsigned long long cap, int k) {
   SaInfo* si = (SaInfo*)sainfo_out;
   for (long long i = 0; i < nSA; ++i) {
     const u32 p = SA[i];
@@ -447,16 +447,10 @@ void qe_flatten(const u32* SA, long long nSA, const u32* offsets, long long T, v
   }
   Bucket* bk = (Bucket*)slots_out;
   memset(bk, 0xff, (size_t)cap * sizeof(Bucket));
-  for (long long i = 0; i < K; ++i) {
-    u64 b = (u64)bucket_hash(keys[i]) & (cap - 1);
-    while (true) {
-      int t = 0;
-      while (t < 2 && bk[b].key[t] != ~0ULL) ++t;
-      if (t < 2) { bk[b].key[t] = keys[i]; bk[b].val[t].lb = lb[i]; bk[b].val[t].ub = ub[i]; break; }
-      bk[b].key[0] |= QM_BK_OVF;
-      b = (b + 1) & (cap - 1);
-    }
-  }
+  for (long long i = 0; i < K; ++i)
+    bucket_insert(bk, cap - 1, keys[i], k, lb[i], ub[i],
+                  [](u64* p, u64 cmp, u64 val) { const u64 o = *p; if (o == cmp) *p = val; return o; },
+                  [](u64* p, u64 v) { *p |= v; });
 }
 }
 
