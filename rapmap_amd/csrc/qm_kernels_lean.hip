@@ -7,6 +7,7 @@
 
 namespace qm {
 
+template <bool PAIRED>
 __global__ __launch_bounds__(256, 8) void qm_lean_kernel(DevIndex ix_, ReadBatch B_) {
   // the argument structs are read through the kernarg segment where they are used (see qm_read_kernel)
   struct Args { DevIndex ix; ReadBatch B; };
@@ -17,18 +18,18 @@ __global__ __launch_bounds__(256, 8) void qm_lean_kernel(DevIndex ix_, ReadBatch
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int gw = (int)blockIdx.x * 4 + wave;
   const int nw = (int)gridDim.x * 4;
-  const long long nit = (B.nreads + 1) >> 1;                 // iterations: two reads each
+  const int nit = (int)((B.nreads + 1) >> 1);                // iterations: two reads each (reads per launch < 2^31)
   LeanMem& M = mem[wave];
   { const int l = (int)(threadIdx.x & 63); if (l < 16) M.pk[l >> 3][(l >> 2) & 1][4 + (l & 3)] = 0; }   // the words behind the images stay zero
   WaveAlloc wa; wa.base = -1; wa.used = 0; wa.ivBase = -1; wa.ivUsed = 0;
-  lean_stage_offsets(B, gw, nit, M, 0);
+  lean_stage_offsets<PAIRED>(B, gw, nit, M, 0);
   lds_dma_wait();
-  lean_stage_chars(B, gw, nit, M, 0);
-  lean_stage_offsets(B, (long long)gw + nw, nit, M, 1);
+  lean_stage_chars<PAIRED>(B, gw, nit, M, 0);
+  lean_stage_offsets<PAIRED>(B, gw + nw, nit, M, 1);
   lds_dma_wait();
   int par = 0;
-  for (long long it = gw; it < nit; it += nw) {
-    lean_iter(ix, B, it, nit, nw, par, M, wa);
+  for (int it = gw; it < nit; it += nw) {
+    lean_iter<PAIRED>(ix, B, it, nit, nw, par, M, wa);
     par ^= 1;
   }
 }
@@ -42,7 +43,7 @@ extern "C" hipError_t qmk_launch_lean(const void* ixp, const void* bp, int num_c
   const DevIndex& ix = *(const DevIndex*)ixp; const ReadBatch& B = *(const ReadBatch*)bp;
   static const int nb = [] {
     int v = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, qm_lean_kernel, 256, 0) != hipSuccess || v < 1) v = 8;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, qm_lean_kernel<true>, 256, 0) != hipSuccess || v < 1) v = 8;
     const char* ov = getenv("QM_BLOCKS_PER_CU");
     if (ov && atoi(ov) > 0 && atoi(ov) < v) v = atoi(ov);
     return v;
@@ -52,6 +53,7 @@ extern "C" hipError_t qmk_launch_lean(const void* ixp, const void* bp, int num_c
   const long long want = (nit + 3) / 4;
   if (g > want) g = want;
   if (g < 1) g = 1;
-  hipLaunchKernelGGL(qm_lean_kernel, dim3((unsigned)g), dim3(256), 0, st, ix, B);
+  if (B.seq2) hipLaunchKernelGGL(qm_lean_kernel<true>, dim3((unsigned)g), dim3(256), 0, st, ix, B);
+  else hipLaunchKernelGGL(qm_lean_kernel<false>, dim3((unsigned)g), dim3(256), 0, st, ix, B);
   return hipGetLastError();
 }

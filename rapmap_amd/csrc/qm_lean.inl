@@ -37,10 +37,10 @@ namespace qm {
 
 struct LeanSuf { u32 tid, pos, qp, iv; };      // one suffix of a recorded interval: transcript, offset in it, queryPos and index of the interval
 
-struct LeanMem {                               // one wave's LDS slab (2 656 bytes)
+struct LeanMem {                               // one wave's LDS slab (1 632 bytes)
   u64 pk[2][2][8];                             // [read of the iteration][0: the read, 1: mirrored reverse complement][word]: 2 bits per base, first
                                                // base in the top bits of word 0; words 4-7 stay zero (extension queries read past the image)
-  LeanSuf suf[2][QM_LEAN_SUF];                 // [strand]: suffixes of the intervals recorded for the read being mapped
+  LeanSuf suf[QM_LEAN_SUF];                    // suffixes of the intervals recorded for the read being mapped (one strand is walked)
   u32 stage[2][36];                            // raw characters of the next iteration's two reads (global_load_lds target)
   u32 ostage[2][8];                            // offsets (dwords) of the next / the next but one iteration
 };
@@ -80,22 +80,21 @@ QM_DEV void lean_find(const DevIndex& ix, const LV<u64>& ck, const LV<bool>& isr
     more[l] = on[l] && !(h0 || h1) && k0r != ~0ULL && (k0r & QM_BK_OVF) != 0;
     bkt[l] = b;
   }
-  if (ballot(more)) {                                  // 0.4 % of the buckets: a key that hashes here lives in a later bucket
+  // 0.4 % of the buckets: a key that hashes here lives in a later bucket.  A wave-level loop, no per-lane control flow: the lanes
+  // that still look step to their next bucket together, the others read bucket 0 again
+  while (ballot(more)) {
     QM_LANES(l) {
-      if (more[l]) {
-        u64 b = (bkt[l] + 1) & ix.hmask;
-        while (true) {
-          U4 a, c;
-          const unsigned char* bp = (const unsigned char*)&ix.slots[b];
-          load_16x2(bp, bp + (isr[l] ? 32 : 16), a, c);
-          QM_CNT(1, 1);
-          const u64 k0r = ((u64)a.y << 32) | a.x, k1 = ((u64)a.w << 32) | a.z;
-          if ((k0r & ~QM_BK_OVF) == ck[l]) { if (c.x != QM_IV_NONE) { hit[l] = true; lb[l] = c.x; ub[l] = c.y; } break; }
-          if (k1 == ck[l]) { if (c.z != QM_IV_NONE) { hit[l] = true; lb[l] = c.z; ub[l] = c.w; } break; }
-          if (k0r == ~0ULL || !(k0r & QM_BK_OVF)) break;
-          b = (b + 1) & ix.hmask;
-        }
-      }
+      const u64 b = more[l] ? ((bkt[l] + 1) & ix.hmask) : 0ULL;
+      U4 a, c;
+      const unsigned char* bp = (const unsigned char*)&ix.slots[b];
+      load_16x2(bp, bp + (isr[l] ? 32 : 16), a, c);
+      QM_CNT(1, more[l] ? 1 : 0);
+      const u64 k0r = ((u64)a.y << 32) | a.x, k1 = ((u64)a.w << 32) | a.z;
+      const bool h0 = (k0r & ~QM_BK_OVF) == ck[l], h1 = k1 == ck[l];
+      const u32 vlb = h0 ? c.x : c.z;
+      if (more[l] && (h0 || h1)) { hit[l] = vlb != QM_IV_NONE; lb[l] = vlb; ub[l] = h0 ? c.y : c.w; }
+      more[l] = more[l] && !(h0 || h1) && k0r != ~0ULL && (k0r & QM_BK_OVF) != 0;
+      bkt[l] = b;
     }
   }
 }
@@ -121,94 +120,6 @@ QM_DEV void lean_probe(const DevIndex& ix, const QM_LDS(u64)* pk2, int D, int V,
   lean_find(ix, ck, isr, on, hit, W.lb, W.ub);
   const u64 fm = ballot(hit);
   W.Fm = (u32)fm; W.Cm = (u32)(fm >> 32); W.wb = wb; W.ww = ww;
-}
-
-// SACollector::getSAHits_ (SACollector.hpp:441-677, NIP disabled) over a clean strand: every position below P is eligible,
-// every window is A C G T.  The MMP extension (SASearcher.hpp:88-309) is the closed form of extend_search_wide against the
-// packed characters behind every suffix's k-mer (one lane per suffix, one 32-byte load each); the (transcript, position) words
-// of the block it settles on go to suf[].  false: a case the lean kernel leaves to the general one.
-QM_DEV bool lean_walk(const DevIndex& ix, const ReadBatch& B, const QM_LDS(u64)* pk2, QM_LDS(LeanSuf)* suf, int D, int V, int L, int P,
-                      LeanWin& W, int startPos, bool haveInterval, u32 lb, u32 ub, LeanStrand& S, u32& strandHits, u32& otherHits) {
-  const int k = ix.k;
-  QM_CNT(17, 1);
-  int p = startPos;
-  bool skip = haveInterval, lastSearch = false;
-  int prevEnd = 0, width = 1;
-  while (true) {
-    if (!skip) {
-      if (p >= P) break;
-      if ((unsigned)(p - W.wb) >= (unsigned)W.ww) lean_probe(ix, pk2, D, V, P, k, p, width, W);
-      width = 32;
-      const int rel = p - W.wb, avail = W.ww - rel;
-      const u32 fm = W.Fm >> rel, cm = W.Cm >> rel;       // (no bits beyond the window)
-      const int ph = ctz32(fm);
-      const int stop = fm ? ph : avail;
-      otherHits += (u32)popc32(cm & ~fm & (u32)((1ULL << stop) - 1ULL));   // misses: spotCheck_ of the complement (:667-675)
-      if (!fm) { p = W.wb + W.ww; continue; }
-      strandHits += 1;                                   // spotCheck_ on the hit (:545)
-      otherHits += (cm >> ph) & 1u;
-      p += ph;
-      lb = read_lane(W.lb, p - W.wb); ub = read_lane(W.ub, p - W.wb);
-    }
-    skip = false;
-    const u32 lbIn = lb ? lb - 1 : 0;                    // :553
-    const int wiv = (int)(ub - lbIn - 1);
-    if (wiv < 1 || wiv > 64) return false;
-    QM_CNT(18, 1);
-    const int pos = p + k, rem = L - pos, cap = rem < QM_EXT_BASES ? rem : QM_EXT_BASES;
-    LV<int> lc; LV<u32> tdv, tpv; LV<bool> fullv;
-    QM_LANES(l) {
-      // the strand's characters from pos on, packed like the table's entries (the same words in every lane: broadcast reads)
-      const int gq = pos + (V ? D : 0), j = gq >> 5, sh = 2 * (gq & 31);
-      const QM_LDS(u64)* img = pk2 + 8 * V + j;
-      const u64 w0 = img[0], w1 = img[1], w2 = img[2], w3 = img[3];
-      const u64 q0 = (w0 << sh) | ((w1 >> 1) >> (63 - sh)), q1 = (w1 << sh) | ((w2 >> 1) >> (63 - sh)), q2 = (w2 << sh) | ((w3 >> 1) >> (63 - sh));
-      U4 a, b;
-      load_32(&ix.saext[lbIn + 1 + (u32)(l < wiv ? l : wiv - 1)], a, b);
-      const u64 x0 = (((u64)a.y << 32) | a.x) ^ q0, x1 = (((u64)a.w << 32) | a.z) ^ q1, x2 = (((u64)b.y << 32) | b.x) ^ q2;
-      const int nv = (int)(b.z >> QM_EXT_TID_BITS);
-      int matched = x0 ? (clz64(x0) >> 1) : (x1 ? 32 + (clz64(x1) >> 1) : (x2 ? 64 + (clz64(x2) >> 1) : 96));
-      matched = matched < nv ? matched : nv;
-      matched = matched < cap ? matched : cap;
-      fullv[l] = matched == QM_EXT_BASES;
-      lc[l] = l < wiv ? k + matched : -1;
-      tdv[l] = b.z & ((1u << QM_EXT_TID_BITS) - 1); tpv[l] = b.w;
-    }
-    if (rem > QM_EXT_BASES && ballot(fullv)) return false;   // (a 128-character read matching beyond what the table holds)
-    const int mlen = wave_max(lc);
-    LV<bool> best;
-    QM_LANES(l) { best[l] = lc[l] == mlen; }
-    const u64 bq = ballot(best);
-    const int first = ctz64(bq), cnt = 64 - clz64(bq) - first;
-    lb = lbIn + 1 + (u32)first; ub = lb + (u32)cnt;
-    const bool more = !lastSearch && p + mlen < L;
-    const int kp = p + mlen - (k - 1);
-    if (ub > lb && ub - lb < (u32)B.max_interval) {     // :577-618
-      if (S.sufN + cnt > QM_LEAN_SUF || S.n >= QM_LEAN_MAXIV) return false;
-      QM_LANES(l) {
-        if (l >= first && l < first + cnt) {
-          QM_LDS(LeanSuf)* d = suf + (S.sufN + l - first);
-          d->tid = tdv[l]; d->pos = tpv[l]; d->qp = (u32)p; d->iv = (u32)S.n;
-        }
-      }
-      if (cnt < S.minSpan) { S.minSpan = cnt; S.minIdx = S.n; }
-      S.sufN += cnt; S.n += 1;
-      const int corr = prevEnd > p ? prevEnd - p : 0;
-      S.cov += mlen - corr;
-      prevEnd = p + mlen;
-      if (p + mlen < L) {                                 // the k-mer the walk goes on with is spot-checked here (:602-611); kp < P
-        if ((unsigned)(kp - W.wb) >= (unsigned)W.ww) lean_probe(ix, pk2, D, V, P, k, kp, more ? 32 : 1, W);
-        const int rk = kp - W.wb;
-        strandHits += (W.Fm >> rk) & 1u; otherHits += (W.Cm >> rk) & 1u;
-      }
-    }
-    if (lastSearch) return true;
-    if (p + mlen >= L) return true;
-    p = kp;                                               // NIP off: lce == matchedLen (:635-647)
-    width = 32;
-    if (p + k == L) lastSearch = true;
-  }
-  return true;
 }
 
 // hitsToMappingsSimple (HitManager.cpp:691-882) for one strand whose intervals hold n <= 64 suffixes, in registers.  Lane l
@@ -256,40 +167,40 @@ QM_DEV int lean_h2m(const QM_LDS(LeanSuf)* suf, const LeanStrand& S, bool isRC, 
 
 // a read for the general kernel: marked in its list-length word and counted (the host gathers the marks into a queue, like the
 // reads the general kernels set aside for the long-read pass); nothing else was written for it
-QM_DEV void lean_defer(const ReadBatch& B, long long read) {
+QM_DEV void lean_defer(const ReadBatch& B, int read) {
   QM_CNT(19, 1);
   QM_LANES(l) { if (l == 0) { B.lcnt[read] = QM_LCNT_SLOW; B.loff[read] = 0; atomic_add_u64(B.cursor + QM_SC_LEANQ, 1ULL); } }
 }
 
 // offsets of iteration `it` into ostage[par]: pairs: off1[it], off1[it + 1], off2[it], off2[it + 1]; single-end reads 2 it and
-// 2 it + 1: off1[2 it .. 2 it + 2] (the last one only if the second read exists)
-QM_DEV void lean_stage_offsets(const ReadBatch& B, long long it, long long nit, LeanMem& M, int par) {
+// 2 it + 1: off1[2 it .. 2 it + 2] (the last one only if the second read exists).  Iterations, like reads, are below 2^31 per launch.
+template <bool PAIRED>
+QM_DEV void lean_stage_offsets(const ReadBatch& B, int it, int nit, LeanMem& M, int par) {
   if (it >= nit) return;
-  const bool paired = B.seq2 != nullptr;
-  const int nd = paired ? 8 : (2 * it + 1 < B.nreads ? 6 : 4);
+  const int nd = PAIRED ? 8 : (2 * it + 1 < (int)B.nreads ? 6 : 4);
   QM_LANES(l) {
     if (l < nd) {
-      const long long* o = paired ? ((l < 4 ? B.off1 : B.off2) + it) : (B.off1 + 2 * it);
-      lds_dma_u32((const u32*)o + (paired ? (l & 3) : l), M.ostage[par], l);
+      const long long* o = PAIRED ? ((l < 4 ? B.off1 : B.off2) + it) : (B.off1 + 2 * it);
+      lds_dma_u32((const u32*)o + (PAIRED ? (l & 3) : l), M.ostage[par], l);
     }
   }
 }
 QM_DEV long long lean_off64(const LV<u32>& ov, int d) { return (long long)(((u64)read_lane(ov, d + 1) << 32) | (u64)read_lane(ov, d)); }
 // the offsets in ostage[par] (landed) into the request for the two reads' characters
-QM_DEV void lean_stage_chars(const ReadBatch& B, long long it, long long nit, LeanMem& M, int par) {
+template <bool PAIRED>
+QM_DEV void lean_stage_chars(const ReadBatch& B, int it, int nit, LeanMem& M, int par) {
   if (it >= nit) return;
-  const bool paired = B.seq2 != nullptr;
-  const bool have1 = 2 * it + 1 < B.nreads;
+  const bool have1 = 2 * it + 1 < (int)B.nreads;
   LV<u32> ov;
   QM_LANES(l) { ov[l] = M.ostage[par][l & 7]; }
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     if (h && !have1) break;
-    const int d0 = h ? (paired ? 4 : 2) : 0;
-    const long long o0 = lean_off64(ov, d0), o1 = lean_off64(ov, d0 + 2);
-    int len = (int)(o1 - o0);
+    const int d0 = h ? (PAIRED ? 4 : 2) : 0;
+    const long long o0 = lean_off64(ov, d0);
+    int len = (int)(read_lane(ov, d0 + 2) - (u32)o0);
     if (len > QM_LEAN_MAXLEN) len = QM_LEAN_MAXLEN;
-    const unsigned char* p = ((h && paired) ? B.seq2 : B.seq1) + o0;
+    const unsigned char* p = ((h && PAIRED) ? B.seq2 : B.seq1) + o0;
     const int mis = (int)((unsigned long long)p & 3ULL);
     const u32* g = (const u32*)(p - mis);
     const int nd = (mis + len + 3) >> 2;                  // <= 33
@@ -297,21 +208,23 @@ QM_DEV void lean_stage_chars(const ReadBatch& B, long long it, long long nit, Le
   }
 }
 
-// one iteration: reads 2 it and 2 it + 1
-QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, long long it, long long nit, long long nw, int par, LeanMem& M, WaveAlloc& wa) {
+// One iteration: reads 2 it and 2 it + 1.  Wave-uniform flags are ints on purpose: a bool that lives across a branch is kept as a
+// 64-bit lane mask by this compiler (three scalar instructions per test instead of a compare), and the scalar unit is what these
+// kernels run out of first.
+template <bool PAIRED>
+QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, int nw, int par, LeanMem& M, WaveAlloc& wa) {
   const int k = ix.k;
-  const bool paired = B.seq2 != nullptr;
-  const long long r0 = 2 * it;
-  const bool have1 = r0 + 1 < B.nreads;
+  const int r0 = 2 * it;
+  const int have1 = r0 + 1 < (int)B.nreads ? 1 : 0;
   // ---- the two reads' characters -> 2-bit images of both strands, four characters per lane
   LV<u32> ov;
   QM_LANES(l) { ov[l] = M.ostage[par][l & 7]; }
   const u32 a0 = read_lane(ov, 0), a1 = read_lane(ov, 2);
-  const u32 b0 = read_lane(ov, paired ? 4 : 2), b1 = read_lane(ov, paired ? 6 : 4);
+  const u32 b0 = read_lane(ov, PAIRED ? 4 : 2), b1 = read_lane(ov, PAIRED ? 6 : 4);
   const int raw0 = (int)(a1 - a0), raw1 = have1 ? (int)(b1 - b0) : 0;
   const int len0 = raw0 > QM_LEAN_MAXLEN ? QM_LEAN_MAXLEN : raw0, len1 = raw1 > QM_LEAN_MAXLEN ? QM_LEAN_MAXLEN : raw1;
   const int mis0 = (int)(((u32)(unsigned long long)B.seq1 + a0) & 3u);
-  const int mis1 = (int)(((u32)(unsigned long long)(paired ? B.seq2 : B.seq1) + b0) & 3u);
+  const int mis1 = (int)(((u32)(unsigned long long)(PAIRED ? B.seq2 : B.seq1) + b0) & 3u);
   QM_LDS(unsigned char)* PKb = (QM_LDS(unsigned char)*)&M.pk[0][0][0];
   LV<bool> bad, rep;
   QM_LANES(l) {
@@ -339,14 +252,19 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, long long it, long
   const u64 dirty = ballot(bad), reps = ballot(rep);
   wave_fence();
   // the staging rows are free again: the next iteration's characters, and the offsets of the one after it
-  lean_stage_chars(B, it + nw, nit, M, par ^ 1);
-  lean_stage_offsets(B, it + 2 * nw, nit, M, par);
+  lean_stage_chars<PAIRED>(B, it + nw, nit, M, par ^ 1);
+  lean_stage_offsets<PAIRED>(B, it + 2 * nw, nit, M, par);
+#if defined(QM_LEAN_ABLATE) && QM_LEAN_ABLATE == 1    // profiling builds (profiles/r05/ablate_build.sh): the phases up to here, empty lists out
+  lds_dma_wait();
+  QM_LANES(l) { if (l < 2 && r0 + l < (int)B.nreads) { B.lcnt[r0 + l] = (u32)(dirty & reps & 1); B.loff[r0 + l] = 0; } }
+  return;
+#endif
   // what this kernel takes: no character but A C G T, no window of k equal bases (k equal characters cover at least (k - 6) / 4
   // whole lanes above: setup_strand's rule for its lazy strands), at most 128 characters
-  const bool defer0 = raw0 > QM_LEAN_MAXLEN || (u32)dirty != 0 || 4 * popc32((u32)reps) + 6 >= k;
-  const bool defer1 = raw1 > QM_LEAN_MAXLEN || (u32)(dirty >> 32) != 0 || 4 * popc32((u32)(reps >> 32)) + 6 >= k;
+  const int defer0 = (raw0 > QM_LEAN_MAXLEN || (u32)dirty != 0 || 4 * popc32((u32)reps) + 6 >= k) ? 1 : 0;
+  const int defer1 = (raw1 > QM_LEAN_MAXLEN || (u32)(dirty >> 32) != 0 || 4 * popc32((u32)(reps >> 32)) + 6 >= k) ? 1 : 0;
   const int P0 = len0 - k + 1, P1 = len1 - k + 1;
-  const bool ok0 = !defer0 && P0 >= 1, ok1 = have1 && !defer1 && P1 >= 1;
+  const int ok0 = (!defer0 && P0 >= 1) ? 1 : 0, ok1 = (have1 && !defer1 && P1 >= 1) ? 1 : 0;
   // ---- the first probe of both reads in one round (SACollector.hpp:167-237 starts at position 0; the read's last k-mer is the
   // first thing the reverse-complement pass asks for): lanes 0-3 of each half = the read's k-mer 0, its k-mer P - 1, and --
   // from the second image -- the reverse complements of those two
@@ -355,7 +273,7 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, long long it, long
     const int h = l >> 5, jj = l & 31;
     const int P = h ? P1 : P0, D = QM_LEAN_MAXLEN - (h ? len1 : len0);
     const bool lastq = jj == 1 || jj == 2;                 // jj 0: read[0]  1: read[P-1]  2: rc[P-1] (= complement of read[0])  3: rc[0]
-    const bool o = (h ? ok1 : ok0) && jj < 4 && (P > 1 || !(jj & 1));
+    const bool o = (h ? ok1 : ok0) != 0 && jj < 4 && (P > 1 || !(jj & 1));
     const int q = (o && lastq) ? P - 1 : 0;                // position in the lane's own strand (jj >> 1) ...
     const int qo = o ? P - 1 - q : 0;                      // ... and of the reverse complement in the other one
     const QM_LDS(u64)* pkh = (const QM_LDS(u64)*)&M.pk[0][0][0] + 16 * h;
@@ -368,76 +286,153 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, long long it, long
   lean_find(ix, ck, isr, on, hit, plb, pub);
   const u64 fm0 = ballot(hit);
   lds_dma_wait();                                          // what was requested above has landed by now: no store follows an open request
+#if defined(QM_LEAN_ABLATE) && QM_LEAN_ABLATE == 2
+  QM_LANES(l) { if (l < 2 && r0 + l < (int)B.nreads) { B.lcnt[r0 + l] = (u32)(fm0 & 1 & plb[l] & pub[l]); B.loff[r0 + l] = 0; } }
+  return;
+#endif
+  const int useCov = B.strict_check != 0 ? 1 : 0;          // disableNIP_ && strictCheck_ (SACollector.hpp:138)
+  const u32 maxIv = (u32)B.max_interval;
 #pragma nounroll
   for (int h = 0; h < 2; ++h) {
-    if (h && !have1) break;
-    const long long read = r0 + h;
+    if (h > have1) break;
+    const int read = r0 + h;
     if (h ? defer1 : defer0) { lean_defer(B, read); continue; }
     const int L = h ? len1 : len0, P = L - k + 1, D = QM_LEAN_MAXLEN - L;
-    int n = 0; bool foundHit = false, bail = false;
+    int n = 0, foundHit = 0, bail = 0;
     LV<u64> elem; LV<bool> keep; LV<int> slot;
     QM_LANES(l) { keep[l] = false; slot[l] = 0; elem[l] = 0; }
     if (P >= 1) {
       const QM_LDS(u64)* pk2 = (const QM_LDS(u64)*)&M.pk[0][0][0] + 16 * h;
       const u32 fmh = (u32)(fm0 >> (32 * h));
       const u32 F0 = fmh & 1u, C0 = (fmh >> 2) & 1u;
-      const u32 Fl = P > 1 ? (fmh >> 1) & 1u : F0, Cl = P > 1 ? (fmh >> 3) & 1u : C0;
-      const int sl = 32 * h, rl = sl + (P > 1 ? 3 : 2);
-      const u32 s0lb = read_lane(plb, sl), s0ub = read_lane(pub, sl), r0lb = read_lane(plb, rl), r0ub = read_lane(pub, rl);
       LeanWin W; W.wb = 0; W.ww = 1; W.Fm = F0; W.Cm = C0;
-      QM_LANES(l) { W.lb[l] = s0lb; W.ub[l] = s0ub; }
+      { const u32 s0lb = read_lane(plb, 32 * h), s0ub = read_lane(pub, 32 * h); QM_LANES(l) { W.lb[l] = s0lb; W.ub[l] = s0ub; } }
       // first-hit scan (:167-237): the first position whose k-mer or reverse complement is in the hash
-      int p0 = 0; bool found = false;
+      int p0 = 0;
       while (p0 < P) {
         if ((unsigned)(p0 - W.wb) >= (unsigned)W.ww) lean_probe(ix, pk2, D, 0, P, k, p0, 32, W);
         const u32 mm = (W.Fm | W.Cm) >> (p0 - W.wb);
-        if (mm) { p0 += ctz32(mm); found = true; break; }
+        if (mm) { p0 += ctz32(mm); foundHit = 1; break; }
         p0 = W.wb + W.ww;
       }
-      if (found) {
-        foundHit = true;
-        const int rel = p0 - W.wb;
-        u32 fwdHit = (W.Fm >> rel) & 1u, rcHit = (W.Cm >> rel) & 1u;
-        const bool useCov = B.strict_check != 0;           // disableNIP_ && strictCheck_ (:138)
-        LeanStrand SF, SR;
-        SF.n = 0; SF.sufN = 0; SF.minIdx = 0; SF.minSpan = 0x7fffffff; SF.cov = 0; SR = SF;
-        bool didFwd = false;
-        // the three passes of :247-278 through one expansion of the walk: the read from its first hit, reverseRead(read)
-        // from 0, the read from 0 when forward k-mers were first seen while the reverse complement was walked
-#pragma nounroll
-        for (int pass = 0; pass < 3 && !bail; ++pass) {
-          bool run; int V = pass == 1 ? 1 : 0, start = 0; bool seeded = false; u32 lb = 0, ub = 0;
-          if (pass == 0) {
-            run = fwdHit != 0; start = p0; seeded = true;
-            if (run) { lb = read_lane(W.lb, rel); ub = read_lane(W.ub, rel); didFwd = true; }
-          } else if (pass == 1) {
-            run = useCov ? (rcHit > 0) : (rcHit >= fwdHit);                    // :258
-            if (run) { W.wb = 0; W.ww = 1; W.Fm = Cl; W.Cm = Fl; QM_LANES(l) { W.lb[l] = r0lb; W.ub[l] = r0ub; } }
-          } else {
-            run = !didFwd && (useCov ? (fwdHit > 0) : (fwdHit >= rcHit));      // :271
-            if (run) { W.wb = 0; W.ww = 1; W.Fm = F0; W.Cm = C0; QM_LANES(l) { W.lb[l] = s0lb; W.ub[l] = s0ub; } }
-          }
-          if (!run) continue;
-          LeanStrand S = V ? SR : SF;
-          u32 sh = V ? rcHit : fwdHit, oh = V ? fwdHit : rcHit;
-          const bool okw = lean_walk(ix, B, pk2, (QM_LDS(LeanSuf)*)M.suf[0] + QM_LEAN_SUF * V, D, V, L, P, W, start, seeded, lb, ub, S, sh, oh);
-          if (V) { SR = S; rcHit = sh; fwdHit = oh; } else { SF = S; fwdHit = sh; rcHit = oh; }
-          if (!okw) bail = true;
+      if (foundHit) {
+        // ONE walk per read: the read itself from its first hit when that hit is a forward one (:247-254), else reverseRead(read)
+        // from 0 (:258-265).  ha / hb: hits of the walked strand / of the other one.  A read that then asks for the other strand as
+        // well (:258, :271: k-mers of the other orientation seen on the way) is rare and left to the general kernel.
+        const int rel0 = p0 - W.wb;
+        const int V = ((W.Fm >> rel0) & 1u) ? 0 : 1;
+        u32 ha = 1u, hb = V ? 0u : ((W.Cm >> rel0) & 1u);
+        int p = 0, skip = 0;
+        u32 lb = 0, ub = 0;
+        if (V == 0) { p = p0; skip = 1; lb = read_lane(W.lb, rel0); ub = read_lane(W.ub, rel0); }
+        else {
+          // what the first probe learned about the read's last k-mer is the first k-mer of reverseRead(read)
+          const u32 Fl = P > 1 ? (fmh >> 1) & 1u : F0, Cl = P > 1 ? (fmh >> 3) & 1u : C0;
+          const int rl = 32 * h + (P > 1 ? 3 : 2);
+          const u32 rlb = read_lane(plb, rl), rub = read_lane(pub, rl);
+          W.wb = 0; W.ww = 1; W.Fm = Cl; W.Cm = Fl;
+          QM_LANES(l) { W.lb[l] = rlb; W.ub[l] = rub; }
         }
+        // ---- SACollector::getSAHits_ (SACollector.hpp:441-677, NIP disabled) over a clean strand: every position below P is
+        // eligible, every window is A C G T.  The MMP extension (SASearcher.hpp:88-309) is the closed form of extend_search_wide
+        // against the packed characters behind every suffix's k-mer (one lane per suffix, one 32-byte load each); the
+        // (transcript, position) words of the block it settles on go to M.suf.
+        QM_LDS(LeanSuf)* suf = (QM_LDS(LeanSuf)*)M.suf;
+        const int imgOff = V ? D : 0;
+        int lastSearch = 0, prevEnd = 0, width = 1, spot = 0, stopAfter = 0;
+        int sn = 0, sufN = 0, minIdx = 0, minSpan = 0x7fffffff, cov = 0;
+        QM_CNT(17, 1);
+        while (true) {
+          if (!skip) {
+            if (p >= P) break;
+            if ((unsigned)(p - W.wb) >= (unsigned)W.ww) lean_probe(ix, pk2, D, V, P, k, p, width, W);
+            width = 32;
+            const int rel = p - W.wb;
+            const u32 fm = W.Fm >> rel, cm = W.Cm >> rel;             // (no bits beyond the window)
+            if (spot) {                                               // the k-mer the walk goes on with, spot-checked (:602-611)
+              ha += fm & 1u; hb += cm & 1u; spot = 0;
+              if (stopAfter) break;
+            }
+            const u32 below = (fm & (0u - fm)) - 1u;                  // the positions before the first hit (all of them without one)
+            hb += (u32)popc32(cm & ~fm & below);                      // misses: spotCheck_ of the complement (:667-675)
+            if (!fm) { p = W.wb + W.ww; continue; }
+            const int ph = ctz32(fm);
+            ha += 1;                                                  // spotCheck_ on the hit (:545)
+            hb += (cm >> ph) & 1u;
+            p += ph;
+            lb = read_lane(W.lb, p - W.wb); ub = read_lane(W.ub, p - W.wb);
+          }
+          skip = 0;
+          const u32 lbIn = lb ? lb - 1 : 0;                           // :553
+          const int wiv = (int)(ub - lbIn - 1);
+          if (wiv < 1 || wiv > 64) { bail = 1; break; }
+          QM_CNT(18, 1);
+          const int pos = p + k, rem = L - pos, cap = rem < QM_EXT_BASES ? rem : QM_EXT_BASES;
+          LV<int> lc; LV<u32> tdv, tpv; LV<bool> fullv;
+          QM_LANES(l) {
+            // the strand's characters from pos on, packed like the table's entries (the same words in every lane: broadcast reads)
+            const int gq = pos + imgOff, j = gq >> 5, sh = 2 * (gq & 31);
+            const QM_LDS(u64)* img = pk2 + 8 * V + j;
+            const u64 w0 = img[0], w1 = img[1], w2 = img[2], w3 = img[3];
+            const u64 q0 = (w0 << sh) | ((w1 >> 1) >> (63 - sh)), q1 = (w1 << sh) | ((w2 >> 1) >> (63 - sh)), q2 = (w2 << sh) | ((w3 >> 1) >> (63 - sh));
+            U4 a, b;
+            load_32(&ix.saext[lbIn + 1 + (u32)(l < wiv ? l : wiv - 1)], a, b);
+            const u64 x0 = (((u64)a.y << 32) | a.x) ^ q0, x1 = (((u64)a.w << 32) | a.z) ^ q1, x2 = (((u64)b.y << 32) | b.x) ^ q2;
+            const int nv = (int)(b.z >> QM_EXT_TID_BITS);
+            // the first word that differs and where (selects, no branches)
+            const u64 xs = x0 ? x0 : (x1 ? x1 : x2);
+            const int xb = x0 ? 0 : (x1 ? 32 : 64);
+            int matched = xs ? xb + (clz64(xs | 1ULL) >> 1) : QM_EXT_BASES;
+            matched = matched < nv ? matched : nv;
+            matched = matched < cap ? matched : cap;
+            fullv[l] = matched == QM_EXT_BASES;
+            lc[l] = l < wiv ? k + matched : -1;
+            tdv[l] = b.z & ((1u << QM_EXT_TID_BITS) - 1); tpv[l] = b.w;
+          }
+          if (rem > QM_EXT_BASES) { if (ballot(fullv)) { bail = 1; break; } }   // (a 128-character read matching beyond what the table holds)
+          const int mlen = wave_max(lc);
+          LV<bool> best;
+          QM_LANES(l) { best[l] = lc[l] == mlen; }
+          const u64 bq = ballot(best);
+          const int first = ctz64(bq), cnt = 64 - clz64(bq) - first;
+          lb = lbIn + 1 + (u32)first; ub = lb + (u32)cnt;
+          const int kp = p + mlen - (k - 1);
+          int recorded = 0;
+          if ((u32)cnt < maxIv) {                                      // ub > lb && ub - lb < maxInterval (:577-618)
+            if (sufN + cnt > QM_LEAN_SUF || sn >= QM_LEAN_MAXIV) { bail = 1; break; }
+            QM_LANES(l) {
+              if (l >= first && l < first + cnt) {
+                QM_LDS(LeanSuf)* d = suf + (sufN + l - first);
+                d->tid = tdv[l]; d->pos = tpv[l]; d->qp = (u32)p; d->iv = (u32)sn;
+              }
+            }
+            if (cnt < minSpan) { minSpan = cnt; minIdx = sn; }
+            sufN += cnt; sn += 1;
+            const int corr = prevEnd > p ? prevEnd - p : 0;
+            cov += mlen - corr;
+            prevEnd = p + mlen;
+            recorded = 1;
+          }
+          if (p + mlen >= L) break;
+          spot = recorded;                                             // (:602-611: only behind a recorded interval; kp < P here)
+          stopAfter = lastSearch;
+          if (lastSearch && !spot) break;
+          p = kp;                                                      // NIP off: lce == matchedLen (:635-647)
+          width = stopAfter ? 1 : 32;
+          if (p + k == L) lastSearch = 1;
+        }
+        // the other strand's turn (:258 checkRC after the read's own pass, :271 checkFwd after the reverse complement's)?
+        if (!bail && (useCov ? (hb > 0) : (hb >= ha))) bail = 1;
         if (!bail) {
-          if (useCov) {                                    // :283-288 (no slack without chain scoring)
-            if (SF.cov > SR.cov) SR.n = 0;
-            else if (SR.cov > SF.cov) SF.n = 0;
-          }
-          if (B.quasi_cov > 0.0) {                         // :343-358
-            if (SF.n > 0) { const double f = (double)SF.cov / (double)L; if (f < B.quasi_cov) SF.n = 0; }
-            if (SR.n > 0) { const double f = (double)SR.cov / (double)L; if (f < B.quasi_cov) SR.n = 0; }
-          }
-          if (SF.n > 0 && SR.n > 0) bail = true;           // hits on both strands: the general kernel's merge (HitManager.cpp:834-881)
-          else if (SF.n > 0 || SR.n > 0) {
-            const bool isRC = SR.n > 0;
+          // (:283-288: the other strand has no coverage and no intervals -- nothing to clear)
+          if (B.quasi_cov > 0.0 && sn > 0) { const double f = (double)cov / (double)L; if (f < B.quasi_cov) sn = 0; }   // :343-358
+#if defined(QM_LEAN_ABLATE) && QM_LEAN_ABLATE == 3
+          foundHit = ((sn + cov + minIdx + sufN) & 0x40000000) != 0; sn = 0;
+#endif
+          if (sn > 0) {
+            LeanStrand S; S.n = sn; S.sufN = sufN; S.minIdx = minIdx; S.minSpan = 0; S.cov = 0;
             wave_fence();
-            n = lean_h2m((const QM_LDS(LeanSuf)*)M.suf[0] + (isRC ? QM_LEAN_SUF : 0), isRC ? SR : SF, isRC, elem, keep, slot);
+            n = lean_h2m(suf, S, V != 0, elem, keep, slot);
           }
         }
       }

@@ -223,9 +223,15 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
     for (long long w = 0; w < NW; ++w) {
       LeanMem& M = Ms[w]; memset(&M, 0, sizeof(M));
       WaveAlloc wl; wl.base = -1; wl.used = 0; wl.ivBase = -1; wl.ivUsed = 0;
-      lean_stage_offsets(Lb, w, nit, M, 0); lean_stage_chars(Lb, w, nit, M, 0); lean_stage_offsets(Lb, w + NW, nit, M, 1);
-      int par = 0;
-      for (long long it = w; it < nit; it += NW) { lean_iter(ix, Lb, it, nit, NW, par, M, wl); par ^= 1; }
+      if (paired) {
+        lean_stage_offsets<true>(Lb, (int)w, (int)nit, M, 0); lean_stage_chars<true>(Lb, (int)w, (int)nit, M, 0); lean_stage_offsets<true>(Lb, (int)(w + NW), (int)nit, M, 1);
+        int par = 0;
+        for (long long it = w; it < nit; it += NW) { lean_iter<true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
+      } else {
+        lean_stage_offsets<false>(Lb, (int)w, (int)nit, M, 0); lean_stage_chars<false>(Lb, (int)w, (int)nit, M, 0); lean_stage_offsets<false>(Lb, (int)(w + NW), (int)nit, M, 1);
+        int par = 0;
+        for (long long it = w; it < nit; it += NW) { lean_iter<false>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
+      }
     }
     long long bad = 0, deferred = 0;
     for (long long r = 0; r < nreads; ++r) {
