@@ -49,6 +49,7 @@ size_t qmk_sel_dyn_struct_bytes(void);
 unsigned long long qmk_sel_dyn_bytes(long long n);
 void qmk_sel_dyn_bind(void* host_struct, void* dev_base, long long n);
 hipError_t qmk_collect_slow(const unsigned int* lcnt, long long nreads, long long* q, unsigned long long* count, hipStream_t st);
+hipError_t qmk_collect_lean(const unsigned int* lcnt, long long nreads, long long* q, unsigned long long* count, hipStream_t st);
 hipError_t qmk_sel_slots(const void* pair_batch, hipStream_t st);
 hipError_t qmk_sel_plan(const void* pair_batch, const void* sel_batch, hipStream_t st);
 hipError_t qmk_sel_align_finish(const void* pair_batch, const void* sel_batch, int num_cu, hipStream_t st);

@@ -771,6 +771,9 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
   const bool useLean = !leanOff && rq.mode == QM_RUN_FUSED && !o->sel_aln && o->sensitive && ns == 2 && c->d_slots && !c->d_ph && c->d_saext &&
                        !rq.keepIntervals && !rq.keepFound && c->ix->k <= 31;
   if (!useLean) { if ((rc = ensure(c->d_gscr, c->capGrid, (int64_t)grid * 4 * QM_GSCR_U64))) return rc; }
+  // ... and its -s edition stands in for the chain-scoring collector of a fused -s call (intervals and foundHit out; the list kernels
+  // that follow are the same)
+  const bool useLeanSel = !leanOff && rq.mode == QM_RUN_FUSED && o->sel_aln && o->sensitive && ns == 2 && c->d_slots && !c->d_ph && c->d_saext && c->ix->k <= 31;
   if (rq.mode != QM_RUN_COLLECT) {
     int64_t wantLists = nreads * 4 + (int64_t)grid * 4 * QM_CHUNK * 2;   // chunked bump allocator: up to one open chunk per wave
     if (c->capLists < wantLists) { if ((rc = ensure(c->d_lists, c->capLists, wantLists))) return rc; }
@@ -828,7 +831,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
     if (rq.mode == QM_RUN_COLLECT || twoPass) HIPCHK(hipMemsetAsync(c->d_lcnt, 0, (size_t)(nreads + 1) * sizeof(uint32_t), c->stream));   // collector-only kernels write no list lengths: the array only carries the long-read marks
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     auto launch = [&](const ReadBatch& X, int g) -> hipError_t {
-      if (useLean) return qmk_launch_lean(&ix, &X, c->numCU, c->stream);
+      if (useLean || (useLeanSel && ix.sanext)) return qmk_launch_lean(&ix, &X, c->numCU, c->stream);
       if (rq.mode == QM_RUN_FROM_INTERVALS) return qmk_h2m(&ix, &X, g, c->numCU, c->stream);
       if (twoPass) return qmk_map_reads_ex(&ix, &X, ns, 1, g, c->numCU, c->stream);
       return qmk_map_reads(&ix, &X, rq.mode == QM_RUN_COLLECT ? -1 : ns, g, c->numCU, c->stream);
@@ -859,6 +862,26 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
       }
       feeder = nullptr;                                   // a retry finds everything resident
     } else if (nreads > 0) HIPCHK(launch(B, grid));
+    if (useLeanSel && ix.sanext && nreads > 0) {
+      // what the lean collector marked instead of walking: gathered and walked by the general chain-scoring collector, before the
+      // list kernels go over all reads
+      HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      const int st0 = (int)(hscal[QM_SC_STATUS] & 0xffffffffu);
+      if (hscal[QM_SC_LEANQ] > 0 && !(st0 & 23)) {
+        const int64_t nq = (int64_t)hscal[QM_SC_LEANQ];
+        if ((rc = ensure(c->d_slowq, c->capSlowq, nq))) return rc;
+        HIPCHK(hipMemsetAsync(c->d_scal + QM_SC_SLOWQ, 0, sizeof(u64), c->stream));
+        HIPCHK(qmk_collect_lean(c->d_lcnt, nreads, c->d_slowq, (unsigned long long*)(c->d_scal + QM_SC_SLOWQ), c->stream));
+        ReadBatch S2 = B;
+        S2.slowq = c->d_slowq; S2.nreads = nq;
+        const int g2 = qmk_map_grid_ex(nq, c->numCU, phc);
+        HIPCHK(qmk_map_reads_ex(&ix, &S2, ns, 1, g2 < grid ? g2 : grid, c->numCU, c->stream));
+        HIPCHK(hipMemsetAsync(c->d_scal + QM_SC_SLOWQ, 0, sizeof(u64), c->stream));   // (the passes below gather with the same counter)
+        c->lastLeanDeferred = nq;
+      }
+      c->lastLeanReads = nreads;
+    }
     if (twoPass && rq.longReads && nreads > 0) {
       // -s with reads beyond QM_MAX_READ_LEN in the batch: the collector set them aside (map_read); their intervals come from a
       // second, small launch of the 32-slot chain-scoring collector, before the list kernel goes over all reads
@@ -914,7 +937,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
       const int g2 = qmk_map_grid_ex(nq, c->numCU, 0);
       if ((rc = ensure(c->d_gscr, c->capGrid, (int64_t)g2 * 4 * QM_GSCR_U64))) return rc;
       HIPCHK(hipMemsetAsync(c->d_scal + QM_SC_SLOWQ, 0, sizeof(u64), c->stream));
-      HIPCHK(qmk_collect_slow(c->d_lcnt, nreads, c->d_slowq, (unsigned long long*)(c->d_scal + QM_SC_SLOWQ), c->stream));
+      HIPCHK(qmk_collect_lean(c->d_lcnt, nreads, c->d_slowq, (unsigned long long*)(c->d_scal + QM_SC_SLOWQ), c->stream));
       ReadBatch S2 = B;
       S2.slowq = c->d_slowq; S2.nreads = nq; S2.gscratch = c->d_gscr;      // (B was filled in before the scratch existed)
       HIPCHK(hipEventRecord(c->evA, c->stream));

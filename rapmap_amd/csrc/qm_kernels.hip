@@ -251,9 +251,9 @@ __global__ __launch_bounds__(256) void qm_sel_merge_kernel(PairBatch P, SelBatch
 }
 
 // -s: the reads stage A left on the slow queue (lcnt == QM_LCNT_SLOW), gathered into q[0 .. *count)
-__global__ __launch_bounds__(256) void qm_collect_slow_kernel(const u32* lcnt, long long nreads, long long* q, u64* count) {
+__global__ __launch_bounds__(256) void qm_collect_slow_kernel(const u32* lcnt, long long nreads, long long* q, u64* count, u32 mark) {
   const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < nreads && lcnt[r] == QM_LCNT_SLOW) q[atomicAdd((unsigned long long*)count, 1ULL)] = r;
+  if (r < nreads && lcnt[r] == mark) q[atomicAdd((unsigned long long*)count, 1ULL)] = r;
 }
 
 // -s: surviving hits from the per-unit temp slots to CSR order
@@ -539,7 +539,13 @@ unsigned long long qmk_sel_dyn_bytes(long long n) { return SelScratchDyn::bytes_
 void qmk_sel_dyn_bind(void* host_struct, void* dev_base, long long n) { ((SelScratchDyn*)host_struct)->bind((unsigned char*)dev_base, n); }
 hipError_t qmk_collect_slow(const unsigned int* lcnt, long long nreads, long long* q, unsigned long long* count, hipStream_t st) {
   if (nreads <= 0) return hipSuccess;
-  hipLaunchKernelGGL(qm_collect_slow_kernel, dim3((unsigned)((nreads + 255) / 256)), dim3(256), 0, st, lcnt, nreads, q, (u64*)count);
+  hipLaunchKernelGGL(qm_collect_slow_kernel, dim3((unsigned)((nreads + 255) / 256)), dim3(256), 0, st, lcnt, nreads, q, (u64*)count, (u32)QM_LCNT_SLOW);
+  return hipGetLastError();
+}
+// the same for the reads qm_lean_kernel marked (QM_LCNT_LEAN)
+hipError_t qmk_collect_lean(const unsigned int* lcnt, long long nreads, long long* q, unsigned long long* count, hipStream_t st) {
+  if (nreads <= 0) return hipSuccess;
+  hipLaunchKernelGGL(qm_collect_slow_kernel, dim3((unsigned)((nreads + 255) / 256)), dim3(256), 0, st, lcnt, nreads, q, (u64*)count, (u32)QM_LCNT_LEAN);
   return hipGetLastError();
 }
 hipError_t qmk_sel_slots(const void* pp, hipStream_t st) {

@@ -7,7 +7,7 @@
 
 namespace qm {
 
-template <bool PAIRED>
+template <bool PAIRED, bool SEL>
 __global__ __launch_bounds__(256, 8) void qm_lean_kernel(DevIndex ix_, ReadBatch B_) {
   // the argument structs are read through the kernarg segment where they are used (see qm_read_kernel)
   struct Args { DevIndex ix; ReadBatch B; };
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256, 8) void qm_lean_kernel(DevIndex ix_, ReadBatch
   lds_dma_wait();
   int par = 0;
   for (int it = gw; it < nit; it += nw) {
-    lean_iter<PAIRED>(ix, B, it, nit, nw, par, M, wa);
+    lean_iter<PAIRED, SEL>(ix, B, it, nit, nw, par, M, wa);
     par ^= 1;
   }
 }
@@ -43,7 +43,7 @@ extern "C" hipError_t qmk_launch_lean(const void* ixp, const void* bp, int num_c
   const DevIndex& ix = *(const DevIndex*)ixp; const ReadBatch& B = *(const ReadBatch*)bp;
   static const int nb = [] {
     int v = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, qm_lean_kernel<true>, 256, 0) != hipSuccess || v < 1) v = 8;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, qm_lean_kernel<true, false>, 256, 0) != hipSuccess || v < 1) v = 8;
     const char* ov = getenv("QM_BLOCKS_PER_CU");
     if (ov && atoi(ov) > 0 && atoi(ov) < v) v = atoi(ov);
     return v;
@@ -53,7 +53,13 @@ extern "C" hipError_t qmk_launch_lean(const void* ixp, const void* bp, int num_c
   const long long want = (nit + 3) / 4;
   if (g > want) g = want;
   if (g < 1) g = 1;
-  if (B.seq2) hipLaunchKernelGGL(qm_lean_kernel<true>, dim3((unsigned)g), dim3(256), 0, st, ix, B);
-  else hipLaunchKernelGGL(qm_lean_kernel<false>, dim3((unsigned)g), dim3(256), 0, st, ix, B);
+  // (B.selscr set: the chain-scoring collector of a -s call -- intervals and foundHit out, no lists)
+  if (B.selscr) {
+    if (B.seq2) hipLaunchKernelGGL((qm_lean_kernel<true, true>), dim3((unsigned)g), dim3(256), 0, st, ix, B);
+    else hipLaunchKernelGGL((qm_lean_kernel<false, true>), dim3((unsigned)g), dim3(256), 0, st, ix, B);
+  } else {
+    if (B.seq2) hipLaunchKernelGGL((qm_lean_kernel<true, false>), dim3((unsigned)g), dim3(256), 0, st, ix, B);
+    else hipLaunchKernelGGL((qm_lean_kernel<false, false>), dim3((unsigned)g), dim3(256), 0, st, ix, B);
+  }
   return hipGetLastError();
 }

@@ -20,7 +20,7 @@
 //     to B.lists.
 //
 // A read this kernel does not take -- dirty or long reads, wide intervals, more than 64 suffixes on a strand, hits on both
-// strands, a 128-character read that matches beyond the SaExt window -- is marked (QM_LCNT_SLOW in its list-length word, count in
+// strands, a 128-character read that matches beyond the SaExt window -- is marked (QM_LCNT_LEAN in its list-length word, count in
 // scalar slot QM_SC_LEANQ) before anything else was written for it; the host gathers the marks into a queue and qm_read_kernel
 // maps the queue in a second, small launch.
 // Options the kernel is built for: dense table (or the -p image expanded into one), sensitive mode, no -s, no interval /
@@ -40,14 +40,17 @@ struct LeanSuf { u32 tid, pos, qp, iv; };      // one suffix of a recorded inter
 struct LeanMem {                               // one wave's LDS slab (1 632 bytes)
   u64 pk[2][2][8];                             // [read of the iteration][0: the read, 1: mirrored reverse complement][word]: 2 bits per base, first
                                                // base in the top bits of word 0; words 4-7 stay zero (extension queries read past the image)
-  LeanSuf suf[QM_LEAN_SUF];                    // suffixes of the intervals recorded for the read being mapped (one strand is walked)
+  union {
+    LeanSuf suf[QM_LEAN_SUF];                  // suffixes of the intervals recorded for the read being mapped (one strand is walked)
+    IntRec ints[QM_LEAN_MAXIV];                // -s collector: the interval records themselves (SAIntervalHit)
+  };
   u32 stage[2][36];                            // raw characters of the next iteration's two reads (global_load_lds target)
   u32 ostage[2][8];                            // offsets (dwords) of the next / the next but one iteration
 };
 
 // the current probe window of a walk: positions [wb, wb + ww) of the strand, bit j of Fm / Cm = k-mer / reverse complement of
 // position wb + j found, lane j (< 32) holds that position's interval
-struct LeanWin { int wb, ww; u32 Fm, Cm; LV<u32> lb, ub; };
+struct LeanWin { int wb, ww; u32 Fm, Cm, Km; LV<u32> lb, ub; };   // Km: positions of the window that were looked up (-s probes every stride-th)
 struct LeanStrand { int n, sufN, minIdx, minSpan, cov; };   // intervals, their suffixes, the first smallest interval (HitManager.cpp:636-641), coverage
 
 QM_DEV int ctz32(u32 x) { return x ? __builtin_ctz(x) : 32; }
@@ -103,13 +106,15 @@ QM_DEV void lean_find(const DevIndex& ix, const LV<u64>& ck, const LV<bool>& isr
 // complements.  Both words of a position come out of the read's two images by the same funnel shift -- the reverse complement
 // of the k-mer at q is the k-mer at P - 1 - q of the other image -- and the two lanes of a position read the same bucket.
 // pk2: the read's two images (8 words each), D = 128 - L: where reverseRead(read) starts in the second one.
-QM_DEV void lean_probe(const DevIndex& ix, const QM_LDS(u64)* pk2, int D, int V, int P, int k, int wb, int ww, LeanWin& W) {
+// stride (a power of two): only every stride-th position is looked up -- the -s walk, whose capped MMPs advance by exactly
+// maxMMPExtension + 1 positions while the read keeps matching, never asks about the positions in between (probe_window).
+QM_DEV void lean_probe(const DevIndex& ix, const QM_LDS(u64)* pk2, int D, int V, int P, int k, int wb, int ww, LeanWin& W, int stride = 1) {
   if (wb + ww > P) ww = P - wb;
-  QM_CNT(3, 1); QM_CNT(4, ww);
+  QM_CNT(3, 1); QM_CNT(4, (ww + stride - 1) / stride);
   LV<u64> ck; LV<bool> isr, on, hit;
   QM_LANES(l) {
     const int j = l & 31;
-    const bool in = j < ww;
+    const bool in = j < ww && (j & (stride - 1)) == 0;
     const int q = in ? wb + j : 0;
     const u64 w = lean_kmer(pk2 + 8 * V, q + (V ? D : 0), k), wr = lean_kmer(pk2 + 8 * (1 - V), P - 1 - q + (V ? 0 : D), k);
     const bool big = wr < w;                             // the strand's k-mer is the larger of the two
@@ -119,7 +124,7 @@ QM_DEV void lean_probe(const DevIndex& ix, const QM_LDS(u64)* pk2, int D, int V,
   }
   lean_find(ix, ck, isr, on, hit, W.lb, W.ub);
   const u64 fm = ballot(hit);
-  W.Fm = (u32)fm; W.Cm = (u32)(fm >> 32); W.wb = wb; W.ww = ww;
+  W.Fm = (u32)fm; W.Cm = (u32)(fm >> 32); W.Km = (u32)ballot(on); W.wb = wb; W.ww = ww;
 }
 
 // hitsToMappingsSimple (HitManager.cpp:691-882) for one strand whose intervals hold n <= 64 suffixes, in registers.  Lane l
@@ -169,7 +174,7 @@ QM_DEV int lean_h2m(const QM_LDS(LeanSuf)* suf, const LeanStrand& S, bool isRC, 
 // reads the general kernels set aside for the long-read pass); nothing else was written for it
 QM_DEV void lean_defer(const ReadBatch& B, int read) {
   QM_CNT(19, 1);
-  QM_LANES(l) { if (l == 0) { B.lcnt[read] = QM_LCNT_SLOW; B.loff[read] = 0; atomic_add_u64(B.cursor + QM_SC_LEANQ, 1ULL); } }
+  QM_LANES(l) { if (l == 0) { B.lcnt[read] = QM_LCNT_LEAN; B.loff[read] = 0; atomic_add_u64(B.cursor + QM_SC_LEANQ, 1ULL); } }
 }
 
 // offsets of iteration `it` into ostage[par]: pairs: off1[it], off1[it + 1], off2[it], off2[it + 1]; single-end reads 2 it and
@@ -211,7 +216,7 @@ QM_DEV void lean_stage_chars(const ReadBatch& B, int it, int nit, LeanMem& M, in
 // One iteration: reads 2 it and 2 it + 1.  Wave-uniform flags are ints on purpose: a bool that lives across a branch is kept as a
 // 64-bit lane mask by this compiler (three scalar instructions per test instead of a compare), and the scalar unit is what these
 // kernels run out of first.
-template <bool PAIRED>
+template <bool PAIRED, bool SEL>
 QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, int nw, int par, LeanMem& M, WaveAlloc& wa) {
   const int k = ix.k;
   const int r0 = 2 * it;
@@ -298,14 +303,14 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
     const int read = r0 + h;
     if (h ? defer1 : defer0) { lean_defer(B, read); continue; }
     const int L = h ? len1 : len0, P = L - k + 1, D = QM_LEAN_MAXLEN - L;
-    int n = 0, foundHit = 0, bail = 0;
+    int n = 0, foundHit = 0, bail = 0, selV = 0;
     LV<u64> elem; LV<bool> keep; LV<int> slot;
     QM_LANES(l) { keep[l] = false; slot[l] = 0; elem[l] = 0; }
     if (P >= 1) {
       const QM_LDS(u64)* pk2 = (const QM_LDS(u64)*)&M.pk[0][0][0] + 16 * h;
       const u32 fmh = (u32)(fm0 >> (32 * h));
       const u32 F0 = fmh & 1u, C0 = (fmh >> 2) & 1u;
-      LeanWin W; W.wb = 0; W.ww = 1; W.Fm = F0; W.Cm = C0;
+      LeanWin W; W.wb = 0; W.ww = 1; W.Fm = F0; W.Cm = C0; W.Km = 1u;
       { const u32 s0lb = read_lane(plb, 32 * h), s0ub = read_lane(pub, 32 * h); QM_LANES(l) { W.lb[l] = s0lb; W.ub[l] = s0ub; } }
       // first-hit scan (:167-237): the first position whose k-mer or reverse complement is in the hash
       int p0 = 0;
@@ -330,7 +335,7 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
           const u32 Fl = P > 1 ? (fmh >> 1) & 1u : F0, Cl = P > 1 ? (fmh >> 3) & 1u : C0;
           const int rl = 32 * h + (P > 1 ? 3 : 2);
           const u32 rlb = read_lane(plb, rl), rub = read_lane(pub, rl);
-          W.wb = 0; W.ww = 1; W.Fm = Cl; W.Cm = Fl;
+          W.wb = 0; W.ww = 1; W.Fm = Cl; W.Cm = Fl; W.Km = 1u;
           QM_LANES(l) { W.lb[l] = rlb; W.ub[l] = rub; }
         }
         // ---- SACollector::getSAHits_ (SACollector.hpp:441-677, NIP disabled) over a clean strand: every position below P is
@@ -338,24 +343,37 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
         // against the packed characters behind every suffix's k-mer (one lane per suffix, one 32-byte load each); the
         // (transcript, position) words of the block it settles on go to M.suf.
         QM_LDS(LeanSuf)* suf = (QM_LDS(LeanSuf)*)M.suf;
+        QM_LDS(IntRec)* ints = (QM_LDS(IntRec)*)M.ints;
         const int imgOff = V ? D : 0;
-        int lastSearch = 0, prevEnd = 0, width = 1, spot = 0, stopAfter = 0;
+        const int ext = SEL ? B.max_mmp_ext : 0;                     // -s: every MMP but a read's first is cut at k + maxMMPExtension (:557-575)
+        int lastSearch = 0, prevEnd = 0, width = 1, spot = 0, stopAfter = 0, pstride = 1;
         int sn = 0, sufN = 0, minIdx = 0, minSpan = 0x7fffffff, cov = 0;
         QM_CNT(17, 1);
         while (true) {
           if (!skip) {
             if (p >= P) break;
-            if ((unsigned)(p - W.wb) >= (unsigned)W.ww) lean_probe(ix, pk2, D, V, P, k, p, width, W);
-            width = 32;
+            {
+              const unsigned relp = (unsigned)(p - W.wb);
+              const bool known = relp < (unsigned)W.ww && (!SEL || ((W.Km >> (relp & 31u)) & 1u) != 0);
+              if (!known) lean_probe(ix, pk2, D, V, P, k, p, width, W, SEL ? pstride : 1);
+            }
+            width = 32; pstride = 1;
             const int rel = p - W.wb;
-            const u32 fm = W.Fm >> rel, cm = W.Cm >> rel;             // (no bits beyond the window)
+            u32 fm = W.Fm >> rel, cm = W.Cm >> rel;                   // (no bits beyond the window)
+            int avail = W.ww - rel;
+            if (SEL) {                                                // the stretch of looked-up positions that starts at p
+              const int run = ctz32(~(W.Km >> rel));
+              avail = run < avail ? run : avail;
+              const u32 km = avail >= 32 ? 0xffffffffu : ((1u << avail) - 1u);
+              fm &= km; cm &= km;
+            }
             if (spot) {                                               // the k-mer the walk goes on with, spot-checked (:602-611)
               ha += fm & 1u; hb += cm & 1u; spot = 0;
               if (stopAfter) break;
             }
             const u32 below = (fm & (0u - fm)) - 1u;                  // the positions before the first hit (all of them without one)
             hb += (u32)popc32(cm & ~fm & below);                      // misses: spotCheck_ of the complement (:667-675)
-            if (!fm) { p = W.wb + W.ww; continue; }
+            if (!fm) { p += avail; continue; }
             const int ph = ctz32(fm);
             ha += 1;                                                  // spotCheck_ on the hit (:545)
             hb += (cm >> ph) & 1u;
@@ -367,47 +385,79 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
           const int wiv = (int)(ub - lbIn - 1);
           if (wiv < 1 || wiv > 64) { bail = 1; break; }
           QM_CNT(18, 1);
-          const int pos = p + k, rem = L - pos, cap = rem < QM_EXT_BASES ? rem : QM_EXT_BASES;
-          LV<int> lc; LV<u32> tdv, tpv; LV<bool> fullv;
-          QM_LANES(l) {
-            // the strand's characters from pos on, packed like the table's entries (the same words in every lane: broadcast reads)
-            const int gq = pos + imgOff, j = gq >> 5, sh = 2 * (gq & 31);
-            const QM_LDS(u64)* img = pk2 + 8 * V + j;
-            const u64 w0 = img[0], w1 = img[1], w2 = img[2], w3 = img[3];
-            const u64 q0 = (w0 << sh) | ((w1 >> 1) >> (63 - sh)), q1 = (w1 << sh) | ((w2 >> 1) >> (63 - sh)), q2 = (w2 << sh) | ((w3 >> 1) >> (63 - sh));
-            U4 a, b;
-            load_32(&ix.saext[lbIn + 1 + (u32)(l < wiv ? l : wiv - 1)], a, b);
-            const u64 x0 = (((u64)a.y << 32) | a.x) ^ q0, x1 = (((u64)a.w << 32) | a.z) ^ q1, x2 = (((u64)b.y << 32) | b.x) ^ q2;
-            const int nv = (int)(b.z >> QM_EXT_TID_BITS);
-            // the first word that differs and where (selects, no branches)
-            const u64 xs = x0 ? x0 : (x1 ? x1 : x2);
-            const int xb = x0 ? 0 : (x1 ? 32 : 64);
-            int matched = xs ? xb + (clz64(xs | 1ULL) >> 1) : QM_EXT_BASES;
-            matched = matched < nv ? matched : nv;
-            matched = matched < cap ? matched : cap;
-            fullv[l] = matched == QM_EXT_BASES;
-            lc[l] = l < wiv ? k + matched : -1;
-            tdv[l] = b.z & ((1u << QM_EXT_TID_BITS) - 1); tpv[l] = b.w;
+          const int pos = p + k;
+          // -s: only the MMP that starts the read may run to its end; one that then stops beyond k + maxMMPExtension (and short of the
+          // read's end) is redone cut, from the same interval
+          int capped = (SEL && p != 0) ? 1 : 0;
+          int mlen = 0, first = 0, cnt = 0;
+          LV<u32> tdv, tpv;
+          while (true) {
+            const int cutrem = (L - pos) < ext ? (L - pos) : ext;     // characters a capped extension may use
+            const int rem = capped ? cutrem : L - pos;
+            LV<int> lc; LV<bool> fullv;
+            if (SEL && capped && rem >= 1 && rem <= QM_NEXT_BASES && ix.sanext) {
+              // a capped extension: the rem (<= 14) characters behind the k-mer against the narrow table's entry of every suffix
+              QM_LANES(l) {
+                const u32 qn = (u32)lean_kmer(pk2 + 8 * V, pos + imgOff, rem);
+                const u32 e = ix.sanext[lbIn + 1 + (u32)(l < wiv ? l : wiv - 1)];
+                const u32 x = ((e & 0x0fffffffu) >> (28 - 2 * rem)) ^ qn;
+                int matched = x ? ((__builtin_clz(x) - (32 - 2 * rem)) >> 1) : rem;
+                const int nv = (int)(e >> 28);
+                matched = matched < nv ? matched : nv;
+                lc[l] = l < wiv ? k + matched : -1;
+                fullv[l] = false; tdv[l] = 0; tpv[l] = 0;
+              }
+            } else {
+              const int cap = rem < QM_EXT_BASES ? rem : QM_EXT_BASES;
+              QM_LANES(l) {
+                // the strand's characters from pos on, packed like the table's entries (the same words in every lane: broadcast reads)
+                const int gq = pos + imgOff, j = gq >> 5, sh = 2 * (gq & 31);
+                const QM_LDS(u64)* img = pk2 + 8 * V + j;
+                const u64 w0 = img[0], w1 = img[1], w2 = img[2], w3 = img[3];
+                const u64 q0 = (w0 << sh) | ((w1 >> 1) >> (63 - sh)), q1 = (w1 << sh) | ((w2 >> 1) >> (63 - sh)), q2 = (w2 << sh) | ((w3 >> 1) >> (63 - sh));
+                U4 a, b;
+                load_32(&ix.saext[lbIn + 1 + (u32)(l < wiv ? l : wiv - 1)], a, b);
+                const u64 x0 = (((u64)a.y << 32) | a.x) ^ q0, x1 = (((u64)a.w << 32) | a.z) ^ q1, x2 = (((u64)b.y << 32) | b.x) ^ q2;
+                const int nv = (int)(b.z >> QM_EXT_TID_BITS);
+                // the first word that differs and where (selects, no branches)
+                const u64 xs = x0 ? x0 : (x1 ? x1 : x2);
+                const int xb = x0 ? 0 : (x1 ? 32 : 64);
+                int matched = xs ? xb + (clz64(xs | 1ULL) >> 1) : QM_EXT_BASES;
+                matched = matched < nv ? matched : nv;
+                matched = matched < cap ? matched : cap;
+                fullv[l] = matched == QM_EXT_BASES;
+                lc[l] = l < wiv ? k + matched : -1;
+                tdv[l] = b.z & ((1u << QM_EXT_TID_BITS) - 1); tpv[l] = b.w;
+              }
+              if (rem > QM_EXT_BASES) { if (ballot(fullv)) { bail = 1; break; } }   // (a 128-character read matching beyond what the table holds)
+            }
+            mlen = wave_max(lc);
+            LV<bool> best;
+            QM_LANES(l) { best[l] = lc[l] == mlen; }
+            const u64 bq = ballot(best);
+            first = ctz64(bq); cnt = 64 - clz64(bq) - first;
+            if (SEL && !capped && mlen < L && mlen >= k + ext) { capped = 1; continue; }   // (p == 0 here: mlen >= L <=> the whole read)
+            break;
           }
-          if (rem > QM_EXT_BASES) { if (ballot(fullv)) { bail = 1; break; } }   // (a 128-character read matching beyond what the table holds)
-          const int mlen = wave_max(lc);
-          LV<bool> best;
-          QM_LANES(l) { best[l] = lc[l] == mlen; }
-          const u64 bq = ballot(best);
-          const int first = ctz64(bq), cnt = 64 - clz64(bq) - first;
+          if (bail) break;
           lb = lbIn + 1 + (u32)first; ub = lb + (u32)cnt;
           const int kp = p + mlen - (k - 1);
           int recorded = 0;
           if ((u32)cnt < maxIv) {                                      // ub > lb && ub - lb < maxInterval (:577-618)
-            if (sufN + cnt > QM_LEAN_SUF || sn >= QM_LEAN_MAXIV) { bail = 1; break; }
-            QM_LANES(l) {
-              if (l >= first && l < first + cnt) {
-                QM_LDS(LeanSuf)* d = suf + (sufN + l - first);
-                d->tid = tdv[l]; d->pos = tpv[l]; d->qp = (u32)p; d->iv = (u32)sn;
+            if ((!SEL && sufN + cnt > QM_LEAN_SUF) || sn >= QM_LEAN_MAXIV) { bail = 1; break; }
+            if (SEL) {
+              QM_LANES(l) { if (l == 0) { QM_LDS(IntRec)* d = ints + sn; d->b = lb; d->e = ub; d->len = (u32)mlen; d->q = (u32)p; } }
+            } else {
+              QM_LANES(l) {
+                if (l >= first && l < first + cnt) {
+                  QM_LDS(LeanSuf)* d = suf + (sufN + l - first);
+                  d->tid = tdv[l]; d->pos = tpv[l]; d->qp = (u32)p; d->iv = (u32)sn;
+                }
               }
+              if (cnt < minSpan) { minSpan = cnt; minIdx = sn; }
+              sufN += cnt;
             }
-            if (cnt < minSpan) { minSpan = cnt; minIdx = sn; }
-            sufN += cnt; sn += 1;
+            sn += 1;
             const int corr = prevEnd > p ? prevEnd - p : 0;
             cov += mlen - corr;
             prevEnd = p + mlen;
@@ -417,6 +467,9 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
           spot = recorded;                                             // (:602-611: only behind a recorded interval; kp < P here)
           stopAfter = lastSearch;
           if (lastSearch && !spot) break;
+          // -s: an MMP that was cut at k + maxMMPExtension is followed by the next one maxMMPExtension + 1 positions on, and so on while
+          // the read matches: the spot check's probe looks up those positions only
+          if (SEL && recorded && mlen == k + ext) { const int st = ext + 1; if ((st & (st - 1)) == 0 && st <= 32) pstride = st; }
           p = kp;                                                      // NIP off: lce == matchedLen (:635-647)
           width = stopAfter ? 1 : 32;
           if (p + k == L) lastSearch = 1;
@@ -424,12 +477,13 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
         // the other strand's turn (:258 checkRC after the read's own pass, :271 checkFwd after the reverse complement's)?
         if (!bail && (useCov ? (hb > 0) : (hb >= ha))) bail = 1;
         if (!bail) {
-          // (:283-288: the other strand has no coverage and no intervals -- nothing to clear)
+          // (:283-288: the other strand has no coverage and no intervals -- nothing to clear, with or without the slack of -s)
           if (B.quasi_cov > 0.0 && sn > 0) { const double f = (double)cov / (double)L; if (f < B.quasi_cov) sn = 0; }   // :343-358
 #if defined(QM_LEAN_ABLATE) && QM_LEAN_ABLATE == 3
           foundHit = ((sn + cov + minIdx + sufN) & 0x40000000) != 0; sn = 0;
 #endif
-          if (sn > 0) {
+          if (SEL) { n = sn; selV = V; }
+          else if (sn > 0) {
             LeanStrand S; S.n = sn; S.sufN = sufN; S.minIdx = minIdx; S.minSpan = 0; S.cov = 0;
             wave_fence();
             n = lean_h2m(suf, S, V != 0, elem, keep, slot);
@@ -438,6 +492,33 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
       }
     }
     if (bail) { lean_defer(B, read); continue; }
+    if (SEL) {
+      // ---- the collector's output: the read's SA-interval records (one strand's) through the wave's chunk of B.iv_out (dump_intervals),
+      // and what SACollector::operator() returned
+      long long base = 0;
+      if (n > 0) {
+        if (wa.ivBase < 0 || wa.ivUsed + n > QM_IVCHUNK) {
+          LV<u64> bv;
+          QM_LANES(l) { bv[l] = 0; if (l == 0) bv[l] = atomic_add_u64(B.cursor + QM_SC_IVCUR, (u64)QM_IVCHUNK); }
+          wa.ivBase = (long long)read_lane(bv, 0); wa.ivUsed = 0;
+        }
+        base = wa.ivBase + wa.ivUsed; wa.ivUsed += n;
+      }
+      const bool fits = base + n <= B.iv_cap;
+      if (!fits) { QM_LANES(l) { if (l == 0) *B.status |= 16; } }
+      const int mate = PAIRED ? h : 0;
+      wave_fence();
+      QM_LANES(l) {
+        if (l == 0) { B.iv_cnt[read] = fits ? (u32)n : 0u; B.iv_off[read] = base; B.found_out[read] = foundHit ? 1 : 0; }
+        if (fits && l < n) {
+          const QM_LDS(IntRec)* r = (const QM_LDS(IntRec)*)M.ints + l;
+          qm_sa_interval_hit hh; hh.begin = (int)r->b; hh.end = (int)r->e; hh.len = r->len; hh.query_pos = r->q;
+          hh.query_rc = (uint8_t)selV; hh.list = (uint8_t)(2 * mate + selV); hh.pad = 0;
+          B.iv_out[base + l] = hh;
+        }
+      }
+      continue;
+    }
     // ---- the list to B.lists through the wave's chunk of the bump allocator (finish_read)
     long long base = 0;
     if (n > 0) {

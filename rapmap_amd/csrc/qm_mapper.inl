@@ -57,6 +57,7 @@ namespace qm {
 #define QM_SC_SLOWQ 18
 #define QM_SC_IVCUR 19             // bump pointer of the SA-interval output
 #define QM_LCNT_SLOW 0x7fffffffu   // lcnt value of a read waiting on the slow queue
+#define QM_LCNT_LEAN 0x7ffffffeu   // ... of a read qm_lean_kernel left to the general kernel (qm_lean.inl)
 
 struct Slot { u64 key; int lb; int ub; };          // hash.bin record / small linear-probing tables, key == ~0 empty
 // SA indexes and text positions are UNSIGNED 32-bit on the device: an index whose text needs the reference's int64 instantiation

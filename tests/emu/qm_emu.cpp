@@ -226,16 +226,16 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
       if (paired) {
         lean_stage_offsets<true>(Lb, (int)w, (int)nit, M, 0); lean_stage_chars<true>(Lb, (int)w, (int)nit, M, 0); lean_stage_offsets<true>(Lb, (int)(w + NW), (int)nit, M, 1);
         int par = 0;
-        for (long long it = w; it < nit; it += NW) { lean_iter<true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
+        for (long long it = w; it < nit; it += NW) { lean_iter<true, false>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
       } else {
         lean_stage_offsets<false>(Lb, (int)w, (int)nit, M, 0); lean_stage_chars<false>(Lb, (int)w, (int)nit, M, 0); lean_stage_offsets<false>(Lb, (int)(w + NW), (int)nit, M, 1);
         int par = 0;
-        for (long long it = w; it < nit; it += NW) { lean_iter<false>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
+        for (long long it = w; it < nit; it += NW) { lean_iter<false, false>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
       }
     }
     long long bad = 0, deferred = 0;
     for (long long r = 0; r < nreads; ++r) {
-      if (lcnt2[r] == QM_LCNT_SLOW) { ++deferred; continue; }
+      if (lcnt2[r] == QM_LCNT_LEAN) { ++deferred; continue; }
       bool same = lcnt2[r] == lcnt[r];
       const long long nwd = lcnt[r] & 0x7fffffffu;
       for (long long t = 0; same && t < nwd; ++t) same = lists2[loff2[r] + t] == lists[loff[r] + t];
@@ -243,6 +243,44 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
     }
     if ((long long)scal2[QM_SC_LEANQ] != deferred) { fprintf(stderr, "[qm emu] lean kernel: %lld marks, counter says %llu\n", deferred, (unsigned long long)scal2[QM_SC_LEANQ]); ++bad; }
     if (getenv("QM_EMU_LEAN_STATS")) fprintf(stderr, "[qm emu] lean kernel took %lld of %lld reads\n", nreads - deferred, nreads);
+    if (bad || (status2 & ~1)) status |= 128;
+  }
+  if (ns == 2 && ix.slots && ix.saext && ix.sanext && B.sensitive && o->sel_aln && !(status & 1) && !getenv("QM_EMU_NO_LEAN")) {
+    // the lean kernel's -s edition (chain-scoring collector: intervals + foundHit out) over the same batch: every read it takes must
+    // carry exactly the interval records the general kernel's walk left for it
+    std::vector<u32> lcnt2(nreads + 1, 0); std::vector<long long> loff2(nreads + 1, 0);
+    std::vector<qm_sa_interval_hit> di2(dints.size()); std::vector<u32> dc2(nreads + 1, 0); std::vector<long long> do2(nreads + 1, 0);
+    std::vector<unsigned char> fo2(nreads + 1, 0);
+    u64 scal2[QM_SC_WORDS]; memset(scal2, 0, sizeof(scal2)); int status2 = 0;
+    ReadBatch Lb = B; Lb.lcnt = lcnt2.data(); Lb.loff = loff2.data(); Lb.cursor = scal2; Lb.status = &status2;
+    Lb.iv_out = di2.data(); Lb.iv_cnt = dc2.data(); Lb.iv_off = do2.data(); Lb.iv_cap = (long long)di2.size(); Lb.found_out = fo2.data();
+    const long long nit = (nreads + 1) >> 1, NW = 3;
+    static LeanMem Ms[3];
+    for (long long w = 0; w < NW; ++w) {
+      LeanMem& M = Ms[w]; memset(&M, 0, sizeof(M));
+      WaveAlloc wl; wl.base = -1; wl.used = 0; wl.ivBase = -1; wl.ivUsed = 0;
+      if (paired) {
+        lean_stage_offsets<true>(Lb, (int)w, (int)nit, M, 0); lean_stage_chars<true>(Lb, (int)w, (int)nit, M, 0); lean_stage_offsets<true>(Lb, (int)(w + NW), (int)nit, M, 1);
+        int par = 0;
+        for (long long it = w; it < nit; it += NW) { lean_iter<true, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
+      } else {
+        lean_stage_offsets<false>(Lb, (int)w, (int)nit, M, 0); lean_stage_chars<false>(Lb, (int)w, (int)nit, M, 0); lean_stage_offsets<false>(Lb, (int)(w + NW), (int)nit, M, 1);
+        int par = 0;
+        for (long long it = w; it < nit; it += NW) { lean_iter<false, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
+      }
+    }
+    long long bad = 0, deferred = 0;
+    for (long long r = 0; r < nreads; ++r) {
+      if (lcnt2[r] == QM_LCNT_LEAN) { ++deferred; continue; }
+      bool same = dc2[r] == dcnt[r] && (fo2[r] != 0) == (((lcnt[r] >> 31) & 1) != 0);
+      for (u32 t = 0; same && t < dcnt[r]; ++t) {
+        const qm_sa_interval_hit& a = di2[(size_t)(do2[r] + t)]; const qm_sa_interval_hit& b = dints[(size_t)(doff[r] + t)];
+        same = a.begin == b.begin && a.end == b.end && a.len == b.len && a.query_pos == b.query_pos && a.query_rc == b.query_rc && a.list == b.list;
+      }
+      if (!same) { if (bad < 5) fprintf(stderr, "[qm emu] lean -s collector: read %lld differs (%u vs %u records, found %d vs %u)\n", r, dc2[r], dcnt[r], (int)fo2[r], (lcnt[r] >> 31) & 1); ++bad; }
+    }
+    if ((long long)scal2[QM_SC_LEANQ] != deferred) { fprintf(stderr, "[qm emu] lean -s collector: %lld marks, counter says %llu\n", deferred, (unsigned long long)scal2[QM_SC_LEANQ]); ++bad; }
+    if (getenv("QM_EMU_LEAN_STATS")) fprintf(stderr, "[qm emu] lean -s collector took %lld of %lld reads\n", nreads - deferred, nreads);
     if (bad || (status2 & ~1)) status |= 128;
   }
   PairBatch P; memset(&P, 0, sizeof(P));
