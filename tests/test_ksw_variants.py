@@ -202,3 +202,37 @@ def test_ksw_rows_eight_per_wavefront(scheme):
                 if out[k] != ref:
                     bad.append((k, n, qlen, tlen, ref, out[k]))
     assert not bad, "%d mismatches, first: %r" % (len(bad), bad[:5])
+
+
+@pytest.mark.parametrize("scheme", [(2, -4, 4, 2, 15), (2, -4, 4, 2, 1), (2, -4, 4, 2, 5), (1, -1, 1, 1, 15), (2, -6, 5, 3, 33), (4, -4, 6, 2, 20),
+                                    (2, -4, 4, 2, 98), (2, -4, 4, 2, -1), (3, -2, 2, 1, 15), (1, 0, 25, 25, 15)])
+def test_gapless_path_wins_when_it_loses_no_more_than_one_gap(scheme):
+    """sel_plan_side's shortcut (rapmap_amd/csrc/qm_sel.inl): with the target at least as long as the query, an extension alignment
+    whose gapless path loses at most q + e against 'every query character at its best' scores exactly what that path scores.
+    Held against the oracle's ksw_extz2 (itself pinned to the reference's kernel compiled in place) on queries with zero, one or
+    two differences, N's on either side, indels right behind the start, every length class and band (but --dpBandwidth 0, whose
+    odd anti-diagonals are empty: the kernel stops at the second one, and the shortcut stays away from it)."""
+    a, b, q_, e_, w = scheme
+    ol = oracle._lib()
+    ol.qo_ksw_extz2.restype = C.c_int
+    rng = np.random.default_rng(1234 + w)
+    hits = 0
+    for it in range(4000):
+        qlen = int(rng.integers(1, 141))
+        tlen = qlen + int(rng.integers(0, 25))
+        q = rng.integers(0, 4, qlen).astype(np.uint8)
+        t = np.concatenate([q, rng.integers(0, 4, tlen - qlen).astype(np.uint8)])
+        for _ in range(int(rng.integers(0, 3))):              # substitutions in the target
+            t[rng.integers(0, qlen)] = rng.integers(0, 4)
+        if rng.random() < 0.15: q[rng.integers(0, qlen)] = 4  # an N in the query
+        if rng.random() < 0.15: t[rng.integers(0, tlen)] = 4  # ... in the target
+        if rng.random() < 0.1 and qlen > 4:                   # a deletion: the target continues one character further on
+            p = int(rng.integers(0, qlen - 1)); t = np.concatenate([t[:p], t[p + 1:], rng.integers(0, 4, 1).astype(np.uint8)])
+        aa, bb = abs(a), -abs(b)
+        sc = np.where((q < 4) & (t[:qlen] < 4), np.where(q == t[:qlen], aa, bb), 0)
+        smax = int(np.where(q < 4, aa, 0).sum()); U = int(sc.sum())
+        if smax - U <= q_ + e_:
+            ref = ol.qo_ksw_extz2(qlen, q.ctypes.data_as(C.c_void_p), len(t), t.ctypes.data_as(C.c_void_p), a, b, q_, e_, w)
+            assert ref == U, (scheme, qlen, tlen, smax, U, ref)
+            hits += 1
+    assert hits > 500
