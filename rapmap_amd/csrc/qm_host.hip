@@ -768,12 +768,12 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
   // call on a dense table; the reads it marks instead of mapping go through the general kernel in a second, small launch below.
   // It owns no per-wave scratch in device memory: that is only reserved -- for the small grid -- when the second launch happens.
   static const bool leanOff = [] { const char* e = getenv("QM_NO_LEAN"); return e && atoi(e) != 0; }();
-  const bool useLean = !leanOff && rq.mode == QM_RUN_FUSED && !o->sel_aln && o->sensitive && ns == 2 && c->d_slots && !c->d_ph && c->d_saext &&
+  const bool useLean = !leanOff && rq.mode == QM_RUN_FUSED && !o->sel_aln && o->sensitive && ns == 2 && (c->d_slots || c->d_ph) && c->d_saext &&
                        !rq.keepIntervals && !rq.keepFound && c->ix->k <= 31;
   if (!useLean) { if ((rc = ensure(c->d_gscr, c->capGrid, (int64_t)grid * 4 * QM_GSCR_U64))) return rc; }
   // ... and its -s edition stands in for the chain-scoring collector of a fused -s call (intervals and foundHit out; the list kernels
   // that follow are the same)
-  const bool useLeanSel = !leanOff && rq.mode == QM_RUN_FUSED && o->sel_aln && o->sensitive && ns == 2 && c->d_slots && !c->d_ph && c->d_saext && c->ix->k <= 31;
+  const bool useLeanSel = !leanOff && rq.mode == QM_RUN_FUSED && o->sel_aln && o->sensitive && ns == 2 && (c->d_slots || c->d_ph) && c->d_saext && c->ix->k <= 31;
   if (rq.mode != QM_RUN_COLLECT) {
     int64_t wantLists = nreads * 4 + (int64_t)grid * 4 * QM_CHUNK * 2;   // chunked bump allocator: up to one open chunk per wave
     if (c->capLists < wantLists) { if ((rc = ensure(c->d_lists, c->capLists, wantLists))) return rc; }

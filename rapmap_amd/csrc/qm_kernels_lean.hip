@@ -7,7 +7,7 @@
 
 namespace qm {
 
-template <bool PAIRED, bool SEL>
+template <bool PAIRED, bool SEL, bool PH>
 __global__ __launch_bounds__(256, 8) void qm_lean_kernel(DevIndex ix_, ReadBatch B_) {
   // the argument structs are read through the kernarg segment where they are used (see qm_read_kernel)
   struct Args { DevIndex ix; ReadBatch B; };
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256, 8) void qm_lean_kernel(DevIndex ix_, ReadBatch
   lds_dma_wait();
   int par = 0;
   for (int it = gw; it < nit; it += nw) {
-    lean_iter<PAIRED, SEL>(ix, B, it, nit, nw, par, M, wa);
+    lean_iter<PAIRED, SEL, PH>(ix, B, it, nit, nw, par, M, wa);
     par ^= 1;
   }
 }
@@ -39,27 +39,36 @@ __global__ __launch_bounds__(256, 8) void qm_lean_kernel(DevIndex ix_, ReadBatch
 using namespace qm;
 
 // grid: QM_GRID_OVERSUB times the resident blocks (qmk_map_grid), but no more blocks than iterations / 4
-extern "C" hipError_t qmk_launch_lean(const void* ixp, const void* bp, int num_cu, hipStream_t st) {
-  const DevIndex& ix = *(const DevIndex*)ixp; const ReadBatch& B = *(const ReadBatch*)bp;
+template <bool PAIRED, bool SEL, bool PH>
+static hipError_t launch_lean(const DevIndex& ix, const ReadBatch& B, int num_cu, hipStream_t st) {
   static const int nb = [] {
     int v = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, qm_lean_kernel<true, false>, 256, 0) != hipSuccess || v < 1) v = 8;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, qm_lean_kernel<PAIRED, SEL, PH>, 256, 0) != hipSuccess || v < 1) v = 8;
     const char* ov = getenv("QM_BLOCKS_PER_CU");
     if (ov && atoi(ov) > 0 && atoi(ov) < v) v = atoi(ov);
     return v;
   }();
   const long long nit = (B.nreads + 1) >> 1;
-  long long g = (long long)num_cu * nb * qmk_grid_oversub();
+  long long g = (long long)num_cu * nb * (PH ? qmk_grid_oversub_ph() : qmk_grid_oversub());
   const long long want = (nit + 3) / 4;
   if (g > want) g = want;
   if (g < 1) g = 1;
-  // (B.selscr set: the chain-scoring collector of a -s call -- intervals and foundHit out, no lists)
-  if (B.selscr) {
-    if (B.seq2) hipLaunchKernelGGL((qm_lean_kernel<true, true>), dim3((unsigned)g), dim3(256), 0, st, ix, B);
-    else hipLaunchKernelGGL((qm_lean_kernel<false, true>), dim3((unsigned)g), dim3(256), 0, st, ix, B);
-  } else {
-    if (B.seq2) hipLaunchKernelGGL((qm_lean_kernel<true, false>), dim3((unsigned)g), dim3(256), 0, st, ix, B);
-    else hipLaunchKernelGGL((qm_lean_kernel<false, false>), dim3((unsigned)g), dim3(256), 0, st, ix, B);
-  }
+  hipLaunchKernelGGL((qm_lean_kernel<PAIRED, SEL, PH>), dim3((unsigned)g), dim3(256), 0, st, ix, B);
   return hipGetLastError();
+}
+// grid: QM_GRID_OVERSUB times the resident blocks (qmk_map_grid), but no more blocks than iterations / 4.
+// B.selscr set: the chain-scoring collector of a -s call (intervals and foundHit out, no lists); ix.ph set: the compact -p image.
+extern "C" hipError_t qmk_launch_lean(const void* ixp, const void* bp, int num_cu, hipStream_t st) {
+  const DevIndex& ix = *(const DevIndex*)ixp; const ReadBatch& B = *(const ReadBatch*)bp;
+  const int v = (B.seq2 ? 4 : 0) | (B.selscr ? 2 : 0) | (ix.ph ? 1 : 0);
+  switch (v) {
+    case 0: return launch_lean<false, false, false>(ix, B, num_cu, st);
+    case 1: return launch_lean<false, false, true>(ix, B, num_cu, st);
+    case 2: return launch_lean<false, true, false>(ix, B, num_cu, st);
+    case 3: return launch_lean<false, true, true>(ix, B, num_cu, st);
+    case 4: return launch_lean<true, false, false>(ix, B, num_cu, st);
+    case 5: return launch_lean<true, false, true>(ix, B, num_cu, st);
+    case 6: return launch_lean<true, true, false>(ix, B, num_cu, st);
+    default: return launch_lean<true, true, true>(ix, B, num_cu, st);
+  }
 }

@@ -102,12 +102,28 @@ QM_DEV void lean_find(const DevIndex& ix, const LV<u64>& ck, const LV<bool>& isr
   }
 }
 
+// the same through the compact -p image: the pre-filter for the whole round (one sector per key, no per-lane control flow), then the
+// BooPHF walk for the keys it lets through (present keys and 2e-4 of the absent ones)
+QM_DEV void lean_find_ph(const DevIndex& ix, const LV<u64>& key, const LV<bool>& on, LV<bool>& hit, LV<u32>& lb, LV<u32>& ub) {
+  LV<bool> want;
+  QM_LANES(l) { want[l] = on[l]; }
+  ph_filter_round(ix, key, want);
+  QM_LANES(l) {
+    bool h = false; u32 a = 0, b = 0;
+    if (want[l]) h = find_kmer<QM_F_PH>(ix, key[l], a, b);
+    hit[l] = h; lb[l] = a; ub[l] = b;
+  }
+}
+
 // Probe positions [wb, wb + ww) (ww <= 32) of strand V of a read: lanes 0-31 ask for the k-mers, lanes 32-63 for their reverse
 // complements.  Both words of a position come out of the read's two images by the same funnel shift -- the reverse complement
 // of the k-mer at q is the k-mer at P - 1 - q of the other image -- and the two lanes of a position read the same bucket.
 // pk2: the read's two images (8 words each), D = 128 - L: where reverseRead(read) starts in the second one.
 // stride (a power of two): only every stride-th position is looked up -- the -s walk, whose capped MMPs advance by exactly
 // maxMMPExtension + 1 positions while the read keeps matching, never asks about the positions in between (probe_window).
+// PH: the compact image of a -p index (FrugalBooMap::find over the BooPHF walk, find_kmer<QM_F_PH>, behind the membership pre-filter):
+// the structure is keyed by the k-mer itself, so every lane looks up its own word.
+template <bool PH>
 QM_DEV void lean_probe(const DevIndex& ix, const QM_LDS(u64)* pk2, int D, int V, int P, int k, int wb, int ww, LeanWin& W, int stride = 1) {
   if (wb + ww > P) ww = P - wb;
   QM_CNT(3, 1); QM_CNT(4, (ww + stride - 1) / stride);
@@ -116,13 +132,20 @@ QM_DEV void lean_probe(const DevIndex& ix, const QM_LDS(u64)* pk2, int D, int V,
     const int j = l & 31;
     const bool in = j < ww && (j & (stride - 1)) == 0;
     const int q = in ? wb + j : 0;
-    const u64 w = lean_kmer(pk2 + 8 * V, q + (V ? D : 0), k), wr = lean_kmer(pk2 + 8 * (1 - V), P - 1 - q + (V ? 0 : D), k);
-    const bool big = wr < w;                             // the strand's k-mer is the larger of the two
-    ck[l] = big ? wr : w;
-    isr[l] = big != (l >= 32);                           // lanes 32-63 ask for the other orientation
+    if (PH) {
+      const bool comp = l >= 32;                           // lanes 32-63: the reverse complement = the other image's k-mer at P - 1 - q
+      ck[l] = lean_kmer(pk2 + 8 * (comp ? 1 - V : V), comp ? P - 1 - q + (V ? 0 : D) : q + (V ? D : 0), k);
+      isr[l] = false;
+    } else {
+      const u64 w = lean_kmer(pk2 + 8 * V, q + (V ? D : 0), k), wr = lean_kmer(pk2 + 8 * (1 - V), P - 1 - q + (V ? 0 : D), k);
+      const bool big = wr < w;                             // the strand's k-mer is the larger of the two
+      ck[l] = big ? wr : w;
+      isr[l] = big != (l >= 32);                           // lanes 32-63 ask for the other orientation
+    }
     on[l] = in;
   }
-  lean_find(ix, ck, isr, on, hit, W.lb, W.ub);
+  if (PH) lean_find_ph(ix, ck, on, hit, W.lb, W.ub);
+  else lean_find(ix, ck, isr, on, hit, W.lb, W.ub);
   const u64 fm = ballot(hit);
   W.Fm = (u32)fm; W.Cm = (u32)(fm >> 32); W.Km = (u32)ballot(on); W.wb = wb; W.ww = ww;
 }
@@ -216,7 +239,7 @@ QM_DEV void lean_stage_chars(const ReadBatch& B, int it, int nit, LeanMem& M, in
 // One iteration: reads 2 it and 2 it + 1.  Wave-uniform flags are ints on purpose: a bool that lives across a branch is kept as a
 // 64-bit lane mask by this compiler (three scalar instructions per test instead of a compare), and the scalar unit is what these
 // kernels run out of first.
-template <bool PAIRED, bool SEL>
+template <bool PAIRED, bool SEL, bool PH>
 QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, int nw, int par, LeanMem& M, WaveAlloc& wa) {
   const int k = ix.k;
   const int r0 = 2 * it;
@@ -283,12 +306,18 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
     const int qo = o ? P - 1 - q : 0;                      // ... and of the reverse complement in the other one
     const QM_LDS(u64)* pkh = (const QM_LDS(u64)*)&M.pk[0][0][0] + 16 * h;
     const bool s = (jj >> 1) & 1;
-    const u64 w = lean_kmer(pkh + (s ? 8 : 0), q + (s ? D : 0), k), wr = lean_kmer(pkh + (s ? 0 : 8), qo + (s ? 0 : D), k);
-    const bool big = wr < w;
-    ck[l] = big ? wr : w; isr[l] = big; on[l] = o;
+    const u64 w = lean_kmer(pkh + (s ? 8 : 0), q + (s ? D : 0), k);
+    if (PH) { ck[l] = w; isr[l] = false; }                   // (the lane's own word: jj 2 / 3 read the second image)
+    else {
+      const u64 wr = lean_kmer(pkh + (s ? 0 : 8), qo + (s ? 0 : D), k);
+      const bool big = wr < w;
+      ck[l] = big ? wr : w; isr[l] = big;
+    }
+    on[l] = o;
   }
   QM_CNT(3, 1);
-  lean_find(ix, ck, isr, on, hit, plb, pub);
+  if (PH) lean_find_ph(ix, ck, on, hit, plb, pub);
+  else lean_find(ix, ck, isr, on, hit, plb, pub);
   const u64 fm0 = ballot(hit);
   lds_dma_wait();                                          // what was requested above has landed by now: no store follows an open request
 #if defined(QM_LEAN_ABLATE) && QM_LEAN_ABLATE == 2
@@ -315,7 +344,7 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
       // first-hit scan (:167-237): the first position whose k-mer or reverse complement is in the hash
       int p0 = 0;
       while (p0 < P) {
-        if ((unsigned)(p0 - W.wb) >= (unsigned)W.ww) lean_probe(ix, pk2, D, 0, P, k, p0, 32, W);
+        if ((unsigned)(p0 - W.wb) >= (unsigned)W.ww) lean_probe<PH>(ix, pk2, D, 0, P, k, p0, 32, W);
         const u32 mm = (W.Fm | W.Cm) >> (p0 - W.wb);
         if (mm) { p0 += ctz32(mm); foundHit = 1; break; }
         p0 = W.wb + W.ww;
@@ -355,7 +384,7 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
             {
               const unsigned relp = (unsigned)(p - W.wb);
               const bool known = relp < (unsigned)W.ww && (!SEL || ((W.Km >> (relp & 31u)) & 1u) != 0);
-              if (!known) lean_probe(ix, pk2, D, V, P, k, p, width, W, SEL ? pstride : 1);
+              if (!known) lean_probe<PH>(ix, pk2, D, V, P, k, p, width, W, SEL ? pstride : 1);
             }
             width = 32; pstride = 1;
             const int rel = p - W.wb;

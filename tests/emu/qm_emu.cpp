@@ -209,7 +209,7 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
     if (!(status & 1)) break;
     cap *= 4;
   }
-  if (ns == 2 && ix.slots && ix.saext && B.sensitive && !o->sel_aln && !(status & 1) && !getenv("QM_EMU_NO_LEAN")) {
+  if (ns == 2 && (ix.slots || ix.ph) && ix.saext && B.sensitive && !o->sel_aln && !(status & 1) && !getenv("QM_EMU_NO_LEAN")) {
     // the lean kernel (qm_lean.inl: two reads per wavefront and iteration) over the same batch, three "waves" with the kernel's own
     // software pipeline: every list it writes must be the one the general kernel wrote for that read word for word (flag bit
     // included); the reads it marks instead are the general kernel's
@@ -226,11 +226,11 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
       if (paired) {
         lean_stage_offsets<true>(Lb, (int)w, (int)nit, M, 0); lean_stage_chars<true>(Lb, (int)w, (int)nit, M, 0); lean_stage_offsets<true>(Lb, (int)(w + NW), (int)nit, M, 1);
         int par = 0;
-        for (long long it = w; it < nit; it += NW) { lean_iter<true, false>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
+        for (long long it = w; it < nit; it += NW) { if (ix.ph) lean_iter<true, false, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); else lean_iter<true, false, false>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
       } else {
         lean_stage_offsets<false>(Lb, (int)w, (int)nit, M, 0); lean_stage_chars<false>(Lb, (int)w, (int)nit, M, 0); lean_stage_offsets<false>(Lb, (int)(w + NW), (int)nit, M, 1);
         int par = 0;
-        for (long long it = w; it < nit; it += NW) { lean_iter<false, false>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
+        for (long long it = w; it < nit; it += NW) { if (ix.ph) lean_iter<false, false, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); else lean_iter<false, false, false>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
       }
     }
     long long bad = 0, deferred = 0;
@@ -245,7 +245,7 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
     if (getenv("QM_EMU_LEAN_STATS")) fprintf(stderr, "[qm emu] lean kernel took %lld of %lld reads\n", nreads - deferred, nreads);
     if (bad || (status2 & ~1)) status |= 128;
   }
-  if (ns == 2 && ix.slots && ix.saext && ix.sanext && B.sensitive && o->sel_aln && !(status & 1) && !getenv("QM_EMU_NO_LEAN")) {
+  if (ns == 2 && (ix.slots || ix.ph) && ix.saext && ix.sanext && B.sensitive && o->sel_aln && !(status & 1) && !getenv("QM_EMU_NO_LEAN")) {
     // the lean kernel's -s edition (chain-scoring collector: intervals + foundHit out) over the same batch: every read it takes must
     // carry exactly the interval records the general kernel's walk left for it
     std::vector<u32> lcnt2(nreads + 1, 0); std::vector<long long> loff2(nreads + 1, 0);
@@ -262,11 +262,11 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
       if (paired) {
         lean_stage_offsets<true>(Lb, (int)w, (int)nit, M, 0); lean_stage_chars<true>(Lb, (int)w, (int)nit, M, 0); lean_stage_offsets<true>(Lb, (int)(w + NW), (int)nit, M, 1);
         int par = 0;
-        for (long long it = w; it < nit; it += NW) { lean_iter<true, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
+        for (long long it = w; it < nit; it += NW) { if (ix.ph) lean_iter<true, true, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); else lean_iter<true, true, false>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
       } else {
         lean_stage_offsets<false>(Lb, (int)w, (int)nit, M, 0); lean_stage_chars<false>(Lb, (int)w, (int)nit, M, 0); lean_stage_offsets<false>(Lb, (int)(w + NW), (int)nit, M, 1);
         int par = 0;
-        for (long long it = w; it < nit; it += NW) { lean_iter<false, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
+        for (long long it = w; it < nit; it += NW) { if (ix.ph) lean_iter<false, true, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); else lean_iter<false, true, false>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
       }
     }
     long long bad = 0, deferred = 0;
