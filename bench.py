@@ -35,12 +35,18 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # the kernels a configuration launches for stage A (template arguments: 64-character slots, waves per SIMD the launch is
 # sized for, feature flags QM_F_PH = 1, QM_F_NIP = 2, QM_F_SEL = 4, QM_F_COLLECT = 8)
 KERNELS = {
-    "dense": "qm_read_kernel<2,8,0> (stage A: one wavefront per read)",
-    "ph_compact": "qm_read_kernel<2,6,1> (stage A: one wavefront per read, BooPHF levels walked per lookup)",
-    "ph_expanded": "qm_read_kernel<2,8,0> (stage A: one wavefront per read; the -p index expanded into the bucket table at load)",
-    "sel": "qm_read_kernel<2,8,12> (chain-scoring collector) + qm_h2m_pack_kernel (intervals -> position lists, chaining; several reads per wavefront) "
-           "[+ its wide edition and qm_h2m_kernel<4> for the reads those hand on]; the batch runs as two parts in flight, kernel_ms spans stage A of both",
+    "dense": "qm_lean_kernel<paired, plain, dense> (stage A: two reads per wavefront and iteration, canonical bucket table; the reads it "
+             "leaves -- none on this input -- go through qm_read_kernel<2,8,0>)",
+    "ph_compact": "qm_lean_kernel<paired, plain, -p> (stage A: two reads per wavefront and iteration, pre-filter + BooPHF levels walked per lookup)",
+    "ph_expanded": "qm_lean_kernel<paired, plain, dense> (the -p index expanded into the canonical bucket table at load)",
+    "sel": "qm_lean_kernel<paired, -s, dense> (chain-scoring collector) + qm_h2m_pack_kernel (intervals -> position lists, chaining; several reads per "
+           "wavefront) [+ its wide edition and qm_h2m_kernel<4> for the reads those hand on]; the batch runs as two parts in flight, kernel_ms spans stage A of both",
 }
+RANDOM_SECTOR_CEILING_G = 51.0   # G random 64-byte sectors per second: profiles/r01_random_gather_roofline.txt (profiles/microbench/gather_bench.hip)
+# VALU issue peak for the ksw2 recurrence (-s): 1 024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction
+# (MI355X_MICROARCH.md "Wave scheduling" and "Per-instruction cycle constants": v_fma_f32 wave64 2 cyc) = 1.2288e12 wave
+# instructions/s; the recurrence is 13 packed 16-bit instructions for the two cells of each of 64 lanes (qm_sel.inl)
+KSW2_PEAK_G_CELLS = 1024 * 2.4e9 / 2 * (128.0 / 13.0) / 1e9
 
 
 def log(*a):
@@ -148,17 +154,18 @@ def ph_walk_addend(idx_dir, n_probe):
 
 
 def pmc_traffic(key, n, genes):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of this command (profiles/pmc_traffic.json): a counter
-    run cannot happen inside this process, so the figure is the one measured on this workload when the profile was taken --
-    per pair, scaled to this launch -- and says so."""
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this command (profiles/pmc_traffic.json, written by
+    profiles/r05/make_pmc_traffic.py from the passes of profiles/r05/pmc_all.sh): a counter run cannot happen inside this process,
+    so the figure is the one measured on this workload when the profile was taken -- per pair, scaled to this launch -- and says so.
+    -> (bytes of the dominant kernel's launch, source, the whole entry)"""
     try:
         ent = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(key) or {}
         b = ent.get("hbm_bytes_per_launch")
         if b is None or genes != 40000:
-            return None, None
-        return b * (n / float(ent.get("pairs_per_launch", 10_000_000))), ent.get("source", "profiles/pmc_traffic.json")
+            return None, None, {}
+        return b * (n / float(ent.get("pairs_per_launch", 10_000_000))), ent.get("source", "profiles/pmc_traffic.json"), ent
     except Exception:
-        return None, None
+        return None, None, {}
 
 
 def fstype_of(path):
@@ -264,18 +271,54 @@ def cpu_and_parity(orc, mp, opts, oopts, s1, s2, off, ptr, n, L, cpu_seconds, sw
     return res
 
 
-def roofline(bpp, w, n, kernel_ms, kernel, traffic_key, genes, step_ms=None, extra=None):
-    ach = bpp * n / (kernel_ms * 1e-3) / 1e9
-    traffic, src = pmc_traffic(traffic_key, n, genes)
+def roofline(bpp, w, n, kernel_ms, kernel, traffic_key, genes, step_ms=None, extra=None, whole_step=False):
+    """SURVEY.md section 8d's two rooflines for the dominant kernel of a leg: (i) algorithmic bytes / kernel time against the HBM
+    peak, (ii) 64-byte sectors actually fetched (TCC misses of the committed PMC pass, per pair) / kernel time against the measured
+    random-sector ceiling.  whole_step (-s): the step is a chain of kernels -- bytes, traffic and time are the whole step's."""
+    t_ms = step_ms if (whole_step and step_ms) else kernel_ms
+    ach = bpp * n / (t_ms * 1e-3) / 1e9
+    traffic, src, ent = pmc_traffic(traffic_key, n, genes)
+    if whole_step and ent.get("step_hbm_bytes_per_launch") is not None:
+        traffic = ent["step_hbm_bytes_per_launch"] * (n / float(ent.get("pairs_per_launch", 10_000_000)))
     out = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
            "traffic": traffic, "traffic_source": src, "kernel": kernel, "kernel_ms": round(kernel_ms, 3),
            "algorithmic_bytes_per_pair": round(bpp, 1), "per_pair_counters": {kk: round(v, 2) for kk, v in w.items()},
            "pairs_per_launch": n}
+    if whole_step:
+        out["frac_is"] = "whole step: algorithmic bytes of the step / ms_per_step (kernel_ms -- stage A of the two parts in flight -- is reported next to it)"
+        if step_ms:
+            out["stage_a_share_of_step"] = round(kernel_ms / step_ms, 3)
+    sect = ent.get("step_sectors_per_pair" if whole_step else "sectors_per_pair")
+    if sect is not None and genes == 40000:
+        gs = sect * n / (t_ms * 1e-3) / 1e9
+        out["random_access"] = {"sectors_per_pair": round(sect, 1), "g_sectors_per_s": round(gs, 2), "ceiling_g_sectors_per_s": RANDOM_SECTOR_CEILING_G,
+                                "frac": round(gs / RANDOM_SECTOR_CEILING_G, 4),
+                                "source": "TCC_MISS_sum of the same committed PMC passes, per pair; ceiling: profiles/r01_random_gather_roofline.txt"}
     if step_ms:
         out["frac_of_whole_step"] = round(bpp * n / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
     if extra:
         out.update(extra)
     return out
+
+
+def dp_roofline(w, pairs_per_s, step_ms, n, genes):
+    """-s: the ksw2 work as a compute roofline -- band cells of the reference's algorithm (the alignments it runs: cache misses,
+    neither PERFECT nor UNGAPPED chains; oracle counters on this input) per second, against the VALU issue peak for the
+    recurrence.  The device answers part of those alignments without running them (sel_plan_side: a gapless path that loses
+    no more than one gap); the cells are the reference's either way."""
+    cells = w.get("n_cells", 0.0)
+    _, _, ent = pmc_traffic("sel", n, genes)
+    d = {"alignments_per_pair": round(w.get("n_aln", 0), 3), "band_cells_per_pair": round(cells, 1),
+         "G_cell_updates_per_s": round(cells * pairs_per_s / 1e9, 2), "bound": "valu", "peak_G_cell_updates_per_s": round(KSW2_PEAK_G_CELLS, 1),
+         "frac": round(cells * pairs_per_s / 1e9 / KSW2_PEAK_G_CELLS, 5),
+         "peak_is": "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction x 128 cells per 13 packed 16-bit instructions (the recurrence alone)",
+         "note": "whole-step rate (the alignment kernels overlap the plan kernels of the following chunks)"}
+    if ent.get("ksw2_kernel_ms_per_step") and genes == 40000:
+        km = ent["ksw2_kernel_ms_per_step"] * (n / float(ent.get("pairs_per_launch", 10_000_000)))
+        d["in_ksw2_kernels"] = {"kernel_ms_per_step": round(km, 2), "G_cell_updates_per_s": round(cells * n / (km * 1e-3) / 1e9, 1),
+                                "frac": round(cells * n / (km * 1e-3) / 1e9 / KSW2_PEAK_G_CELLS, 4),
+                                "source": ent.get("source", "profiles/pmc_traffic.json") + " (kernel-trace sum of the alignment kernels of one step)"}
+    return d
 
 
 def build_compat_bench(out_dir):
@@ -498,10 +541,9 @@ def main():
         if ph_levels is not None:
             extra["ph_levels_per_probe"] = round(ph_levels, 3)
         if args.sel_aln:   # with -s report the DP cells separately
-            extra["dp"] = {"alignments_per_pair": round(w.get("n_aln", 0), 3), "band_cells_per_pair": round(w.get("n_cells", 0), 1),
-                           "G_cell_updates_per_s": round(w.get("n_cells", 0) * value * 1e6 / 1e9, 2),
-                           "note": "ksw2 extension alignments that were actually run (cache misses, neither PERFECT nor UNGAPPED chains)"}
-        out["roofline"] = roofline(bpp, w, n, avg_kernel_ms, KERNELS[head_key], head_key, args.genes, step_ms=el / args.steps * 1e3, extra=extra)
+            extra["dp"] = dp_roofline(w, value * 1e6, el / args.steps * 1e3, n, args.genes)
+        out["roofline"] = roofline(bpp, w, n, avg_kernel_ms, KERNELS[head_key], head_key, args.genes, step_ms=el / args.steps * 1e3, extra=extra,
+                                   whole_step=bool(args.sel_aln))
         out["speedup_vs_cpu_baseline"] = round(value / cpu_val, 2) if cpu_val > 0 else None
         try:   # the per-pair counters are a property of the input distribution: keep them for the N>1 runs
             json.dump({"bpp": bpp, "counters": w}, open(os.path.join(idx_dir, "algorithmic_bytes.json"), "w"))
@@ -630,14 +672,15 @@ def other_configs(oc, args, ra, qd, oracles, oracle, qi, idx_dir, mp, s1, s2, of
     """bounded legs (3 timed steps each) of the configurations the headline does not cover, on the same reads"""
     steps, warm = 3, 1
 
-    def leg(name, mapper, o, key, bpp, w, cp, workload, extra=None):
+    def leg(name, mapper, o, key, bpp, w, cp, workload, extra=None, whole_step=False):
         el, kms, tot = timed_steps(mapper, o, ptr, n, L, steps, warm, 1, device, qd)
         val = n * steps / el / 1e6
         km = float(np.mean(kms))
         oc[name] = {"workload": workload, "value": round(val, 4), "unit": "M read-pairs/s", "steps": steps, "warmup": warm,
                     "ms_per_step": round(el / steps * 1e3, 3), "kernel_ms": round(km, 3),
                     "hits_per_pair": round(tot["totHits"] / max(1, tot["numReads"]), 4),
-                    "roofline": roofline(bpp, w, n, km, KERNELS[key], key, args.genes, step_ms=el / steps * 1e3, extra=extra),
+                    "roofline": roofline(bpp, w, n, km, KERNELS[key], key, args.genes, step_ms=el / steps * 1e3,
+                                         extra=(extra(val, el / steps * 1e3) if callable(extra) else extra), whole_step=whole_step),
                     "parity": {"sample_pairs": cp["sample"], "bit_identical_to_oracle": cp["parity"], "hits": cp["hits"]},
                     "cpu_baseline": {"value": round(cp["cpu_val"], 5), "unit": "M read-pairs/s", "cores": cp["best_t"], "kind": "port"}}
         log("other_configs %s: %.1f M pairs/s, kernel %.2f ms, parity %s" % (name, val, km, cp["parity"]))
@@ -652,9 +695,10 @@ def other_configs(oc, args, ra, qd, oracles, oracle, qi, idx_dir, mp, s1, s2, of
     bpp, w = algorithmic_bytes_per_pair(cp["work"], cp["sample"], L)
     leg("configs[4] selective alignment (-s)", mp, o_sel, "sel", bpp, w, cp,
         "the headline's index and reads with -s: chain-scoring collector, chaining, ksw2 extension alignment, score gate",
-        extra={"dp": {"alignments_per_pair": round(w.get("n_aln", 0), 3), "band_cells_per_pair": round(w.get("n_cells", 0), 1)},
-               "note": "kernel_ms spans the two stage-A launches (collector, then intervals -> lists); the plan / ksw2 / finish kernels of stage B-C "
-                       "are in ms_per_step only"})
+        extra=lambda val, step_ms: {"dp": dp_roofline(w, val * 1e6, step_ms, n, args.genes),
+                                    "note": "kernel_ms spans the two stage-A launches (collector, then intervals -> lists); the plan / ksw2 / finish "
+                                            "kernels of stage B-C are in ms_per_step, which is what `frac` is taken over"},
+        whole_step=True)
 
     # configs[3]: the same transcriptome indexed with -p, in both device images, same reads (the text is the same)
     idx_ph = build_or_reuse_index(args.genes, 42, k, 0, 1, args.cache, True)

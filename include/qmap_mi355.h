@@ -274,8 +274,17 @@ int qm_last_kernel_ms(const qm_ctx* ctx, double* map_kernel_ms, double* total_ms
  * because the per-read hit lists outgrew their buffer (the buffer is grown and the batch redone; results are unaffected),
  * QM_STAT_LIST_WORDS -- capacity of that buffer in 8-byte words, QM_STAT_SLOW_READS -- reads that took the per-read
  * overflow path of -s (more suffixes than the wave's scratch holds). */
-enum { QM_STAT_RELAUNCHES = 0, QM_STAT_LIST_WORDS = 1, QM_STAT_SLOW_READS = 2, QM_STAT_LEAN_READS = 3, QM_STAT_LEAN_DEFERRED = 4 };
+enum { QM_STAT_RELAUNCHES = 0, QM_STAT_LIST_WORDS = 1, QM_STAT_SLOW_READS = 2, QM_STAT_LEAN_READS = 3, QM_STAT_LEAN_DEFERRED = 4, QM_STAT_SKIPPED_READS = 5 };
 int qm_ctx_stat(const qm_ctx* ctx, int which, int64_t* value);
+
+/* Reads of the last map call on ctx that were SKIPPED, not mapped (round 5; before, one such read failed the whole batch): a read
+ * longer than QM_MAX_LONG_READ_LEN characters (code 1: the reference takes any std::string, include/SACollector.hpp:108 -- the
+ * device kernels' longest slot class does not), a read whose SA-interval lists outgrow the per-wave scratch (code 2: only with
+ * max_interval above its default of 1000, include/SACollector.hpp:54,77).  Such a read has an empty result -- no intervals, no
+ * hits, foundHit false; its mate is mapped as usual -- and everything else in the batch is mapped as if it were not there.
+ * *total = how many there were; the first min(total, cap, 4096) are listed: reads[i] = index of the read in the call (paired
+ * calls: 2 * pair + mate), codes[i] as above.  Either array may be null. */
+int qm_fetch_skipped(const qm_ctx* ctx, int64_t* reads, int32_t* codes, int64_t cap, int64_t* total);
 
 /* `rapmap quasiindex [-p]` (src/RapMapSAIndexer.cpp:449-819): FASTA -> q5 index directory readable by
  * qm_index_open and by the reference (sa.bin, txpInfo.bin, rsd.bin and -- with perfect_hash --

@@ -35,6 +35,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdint>
@@ -212,6 +213,9 @@ struct HitCounters {
 
 // include/RapMapUtils.hpp:399-502 (chobo::small_vector<int32_t> -> qmap::small_vector<int32_t>: same inline capacity, no heap
 // allocation for the usual one-position hit)
+// With RAPMAP_SALMON_SUPPORT defined the type carries what Salmon reads from it (include/RapMapUtils.hpp:41-43,407-421,446-467):
+// logProb, logBias, format / libFormat() and fragLengthPedantic().  LibraryFormat is Salmon's own type (its LibraryFormat.hpp),
+// which the caller includes before this header, as the reference's header does.
 struct QuasiAlignment {
   QuasiAlignment()
       : tid(std::numeric_limits<uint32_t>::max()), pos(std::numeric_limits<int32_t>::max()), fwd(true),
@@ -227,6 +231,24 @@ struct QuasiAlignment {
   inline void alnScore(int32_t alnScoreIn) { alnScore_ = alnScoreIn; }
   inline uint32_t fragLength() const { return fragLen; }
   inline int32_t hitPos() { return pos < matePos ? pos : matePos; }
+#ifdef RAPMAP_SALMON_SUPPORT
+  // include/RapMapUtils.hpp:446-467
+  inline uint32_t fragLengthPedantic(uint32_t txpLen) const {
+    if (mateStatus != MateStatus::PAIRED_END_PAIRED || fwd == mateIsFwd) return 0;
+    int32_t p1 = fwd ? pos : matePos;
+    const int32_t sTxpLen = static_cast<int32_t>(txpLen);
+    p1 = (p1 < 0) ? 0 : p1;
+    p1 = (p1 > sTxpLen) ? sTxpLen : p1;
+    int32_t p2 = fwd ? static_cast<int32_t>(matePos + mateLen) : static_cast<int32_t>(pos + readLen);
+    p2 = (p2 < 0) ? 0 : p2;
+    p2 = (p2 > sTxpLen) ? sTxpLen : p2;
+    return (p1 > p2) ? p1 - p2 : p2 - p1;
+  }
+  double logProb{HUGE_VAL};
+  double logBias{HUGE_VAL};
+  inline LibraryFormat libFormat() { return format; }
+  LibraryFormat format{LibraryFormat::formatFromID(0)};       // (both constructors: RapMapUtils.hpp:407-421)
+#endif
 
   bool hasMultiPos{false};
   qmap::small_vector<int32_t> allPositions;
@@ -473,11 +495,15 @@ class Service {
     cvWork_.notify_all();
     return p;
   }
-  // the worker has packed its reads: wait until the batch has been mapped
-  void packed_and_wait(Batch* b) {
-    std::unique_lock<std::mutex> lk(mu_);
-    b->packed++;
+  // the worker has packed its reads (it may go on with other work: prefetch_async) ...
+  void packed(Batch* b) {
+    { std::lock_guard<std::mutex> lk(mu_); b->packed++; }
     cvWork_.notify_all();
+  }
+  // ... and waits until the batch has been mapped
+  void packed_and_wait(Batch* b) { packed(b); wait_done(b); }
+  void wait_done(Batch* b) {
+    std::unique_lock<std::mutex> lk(mu_);
     cvDone_.wait(lk, [&] { return b->state >= 3 || stop_; });
     if (b->state != 3) {
       const int rc = b->rc ? b->rc : QM_E_STATE; const std::string msg = b->err.empty() ? std::string("the batching service stopped") : b->err;
@@ -585,6 +611,10 @@ struct Chunk {
   int64_t rbase{0}, ubase{0};           // ... and where this group's reads / pairs start in it
   Service* svc{nullptr}; Batch* batch{nullptr};
   int64_t cursor{0};
+  // the group's reads as they were packed for the device (the batch's input buffers; o1 / o2 start at this group's first pair)
+  const char* s1{nullptr}; const char* s2{nullptr}; const int64_t* o1{nullptr}; const int64_t* o2{nullptr};
+  int64_t nPacked{0};
+  const void* firstRead{nullptr};      // the group a prefetch_async was issued for (prefetch / wait recognise it)
   void release() { if (batch && svc) svc->release(batch); batch = nullptr; nreads = 0; }
   void bind(Service* s) { if (svc != s) { if (svc) svc->detach(); svc = s; if (svc) svc->attach(); } }
   ~Chunk() { release(); if (svc) svc->detach(); }
@@ -713,50 +743,97 @@ class SACollector {
     for (auto& rp : rg) { l.push_back(&rp.first.seq); r.push_back(&rp.second.seq); }
     prefetchPairs(l, r, mc, fuzzyMerge, maxNumHits);
   }
+  // The same in two halves (round 5), so that a worker can have its NEXT group on the device while it runs the per-read loop over
+  // the current one: prefetch_async(rg) packs the group into the open batch and returns; wait() -- or prefetch(rg) for the same
+  // group -- makes the oldest group that was sent this way the current one.  Groups become current in the order they were sent.
+  //     auto next = parser.getReadGroup(); parser.refill(next); hitCollector.prefetch_async(next);
+  //     for (...) { hitCollector.wait(); /* per-read calls over the current group */ ... refill + prefetch_async of the one after next ... }
+  template <typename PairRange>
+  void prefetch_async(PairRange& rg, const rapmap::utils::MappingConfig& mc = rapmap::utils::MappingConfig(), bool fuzzyMerge = false,
+                      uint32_t maxNumHits = 200) {
+    std::vector<const std::string*> l, r;
+    for (auto& rp : rg) { l.push_back(&rp.first.seq); r.push_back(&rp.second.seq); }
+    submitPairs(l, r, mc, fuzzyMerge, maxNumHits);
+  }
+  size_t pending() const { return pending_.size(); }
+  // the oldest group sent with prefetch_async becomes the current one (blocks until its batch has been mapped)
+  void wait() {
+    using namespace qmap::detail;
+    if (pending_.empty()) throw qmap::Error(QM_E_STATE, "SACollector::wait(): no group was sent with prefetch_async");
+    std::unique_ptr<Chunk> ch = std::move(pending_.front());
+    pending_.pop_front();
+    // the group that was current is given back: its batch is released, a new generation number makes everything that was handed
+    // out of it stale, and the object itself is kept for a later group (hits and interval lists hold a pointer to it)
+    if (chunk_) { chunk_->release(); chunk_->gen = next_gen(); spare_.push_back(std::move(chunk_)); }
+    if (ch->batch) {
+      Batch* bt = ch->batch;
+      try { ch->svc->wait_done(bt); } catch (...) { ch->batch = nullptr; throw; }
+      ch->v = bt->v;
+      ch->nreads = 2 * ch->nPacked;
+    }
+    last_index().ix = rmi_->handle(); last_index().device = rmi_->device();
+    chunk_ = std::move(ch);
+  }
   void prefetchPairs(const std::vector<const std::string*>& left, const std::vector<const std::string*>& right,
                      const rapmap::utils::MappingConfig& mc, bool fuzzyMerge, uint32_t maxNumHits) {
+    // the group was sent ahead: wait for it; otherwise send it now (behind nothing) and wait
+    const void* first = left.empty() ? nullptr : static_cast<const void*>(left[0]);
+    if (!pending_.empty()) {
+      if (pending_.front()->firstRead != first || pending_.front()->nPacked != static_cast<int64_t>(left.size()))
+        throw qmap::Error(QM_E_STATE, "SACollector::prefetch(): another group was sent with prefetch_async before this one; groups become current in the order they were sent");
+    } else submitPairs(left, right, mc, fuzzyMerge, maxNumHits);
+    wait();
+  }
+ private:
+  void submitPairs(const std::vector<const std::string*>& left, const std::vector<const std::string*>& right,
+                   const rapmap::utils::MappingConfig& mc, bool fuzzyMerge, uint32_t maxNumHits) {
     using namespace qmap::detail;
     const int64_t n = static_cast<int64_t>(left.size());
-    // the chunk object is reused from group to group; a new generation number makes everything that was handed out of the
-    // previous group stale, and the batch that group was mapped in is given back
-    if (!chunk_) chunk_.reset(new Chunk());
-    Chunk* ch = chunk_.get();
-    ch->release();
+    // a chunk object per group in flight; a new generation number per group makes everything that was handed out of an earlier
+    // group stale once that group's chunk is given back
+    std::unique_ptr<Chunk> chp;
+    if (!spare_.empty()) { chp = std::move(spare_.back()); spare_.pop_back(); } else chp.reset(new Chunk());
+    Chunk* ch = chp.get();
     ch->gen = next_gen(); ch->paired = true; ch->nreads = 0; ch->cursor = 0;
     stageOpts(ch->opts);
     apply_mc(mc, ch->opts);
     ch->opts.fuzzy = (fuzzyMerge || mc.doChaining) ? 1 : 0;
     ch->opts.max_num_hits = static_cast<int32_t>(maxNumHits);
-    last_index().ix = rmi_->handle(); last_index().device = rmi_->device();
-    nPacked_ = 0;
-    if (n == 0) return;
-    size_t b1 = 0, b2 = 0;
-    for (int64_t i = 0; i < n; ++i) { b1 += left[i]->size(); b2 += right[i]->size(); }
-    // join the batch that is open (qmap::detail::Service): this group's place in the batch's page-locked input buffers ...
-    Service* svc = service_of(rmi_->handle(), rmi_->device());
-    ch->bind(svc);
-    const Service::Place pl = svc->join(ch->opts, n, b1, b2);
-    Batch* bt = pl.b;
-    ch->batch = bt;
-    // ... the reads packed there, next to the other workers' (the upload is a DMA straight out of these buffers) ...
-    ch->key.resize(static_cast<size_t>(2 * n)); ch->keyLen.resize(static_cast<size_t>(2 * n));
-    size_t p1 = pl.c1, p2 = pl.c2;
-    int64_t* o1 = bt->o1 + pl.u0; int64_t* o2 = bt->o2 + pl.u0;
-    for (int64_t i = 0; i < n; ++i) {
-      const std::string& l = *left[i]; const std::string& r = *right[i];
-      std::memcpy(bt->s1 + p1, l.data(), l.size()); p1 += l.size(); o1[i + 1] = static_cast<int64_t>(p1);
-      std::memcpy(bt->s2 + p2, r.data(), r.size()); p2 += r.size(); o2[i + 1] = static_cast<int64_t>(p2);
-      ch->key[2 * i] = l.data(); ch->keyLen[2 * i] = l.size();
-      ch->key[2 * i + 1] = r.data(); ch->keyLen[2 * i + 1] = r.size();
+    ch->firstRead = n ? static_cast<const void*>(left[0]) : nullptr;
+    ch->nPacked = n;
+    if (n > 0) {
+      size_t b1 = 0, b2 = 0;
+      for (int64_t i = 0; i < n; ++i) { b1 += left[i]->size(); b2 += right[i]->size(); }
+      // everything that can throw happens before the group joins a batch (a joined group that never reports "packed" would
+      // hold the batch's dispatcher, and every other worker in the batch, forever)
+      ch->key.resize(static_cast<size_t>(2 * n)); ch->keyLen.resize(static_cast<size_t>(2 * n));
+      pending_.emplace_back(nullptr);                          // (the deque's node, allocated now)
+      pending_.pop_back();
+      // join the batch that is open (qmap::detail::Service): this group's place in the batch's page-locked input buffers ...
+      Service* svc = service_of(rmi_->handle(), rmi_->device());
+      ch->bind(svc);
+      const Service::Place pl = svc->join(ch->opts, n, b1, b2);
+      Batch* bt = pl.b;
+      ch->batch = bt;
+      // ... the reads packed there, next to the other workers' (the upload is a DMA straight out of these buffers) ...
+      size_t p1 = pl.c1, p2 = pl.c2;
+      int64_t* o1 = bt->o1 + pl.u0; int64_t* o2 = bt->o2 + pl.u0;
+      for (int64_t i = 0; i < n; ++i) {
+        const std::string& l = *left[i]; const std::string& r = *right[i];
+        std::memcpy(bt->s1 + p1, l.data(), l.size()); p1 += l.size(); o1[i + 1] = static_cast<int64_t>(p1);
+        std::memcpy(bt->s2 + p2, r.data(), r.size()); p2 += r.size(); o2[i + 1] = static_cast<int64_t>(p2);
+        ch->key[2 * i] = l.data(); ch->keyLen[2 * i] = l.size();
+        ch->key[2 * i + 1] = r.data(); ch->keyLen[2 * i + 1] = r.size();
+      }
+      ch->ubase = pl.u0; ch->rbase = 2 * pl.u0;
+      ch->s1 = bt->s1; ch->s2 = bt->s2; ch->o1 = o1; ch->o2 = o2;
+      // ... and handed to the dispatcher: the batch's one fused pass brings every stage's output of every group in it down in one
+      // go (intervals and foundHit per read, per-read lists, merge results and tooMany flags per pair); wait() picks it up
+      svc->packed(bt);
     }
-    // ... and the wait for the batch's one fused pass: every stage's output of every group in it, compacted on the device and
-    // brought down in one go (intervals and foundHit per read, per-read lists, merge results and tooMany flags per pair)
-    try { svc->packed_and_wait(bt); } catch (...) { ch->batch = nullptr; throw; }
-    ch->v = bt->v; ch->ubase = pl.u0; ch->rbase = 2 * pl.u0;
-    s1_ = bt->s1; s2_ = bt->s2; o1_ = o1; o2_ = o2;
-    nPacked_ = n;
-    ch->nreads = 2 * n;
+    pending_.push_back(std::move(chp));
   }
+ public:
 
   // SACollector::operator() (include/SACollector.hpp:108-362)
   bool operator()(std::string& read, SASearcher<RapMapIndexT>& /*saSearcher*/, HCInfo& hcInfo) {
@@ -772,10 +849,10 @@ class SACollector {
       int64_t idx = -1;
       for (int64_t c = ch->cursor, lim = c + 64 < ch->nreads ? c + 64 : ch->nreads; c < lim; ++c) {
         if (ch->key[c] != read.data() || ch->keyLen[c] != read.size()) continue;
-        const char* sq = (ch->paired && (c & 1)) ? s2_ : s1_;
-        const int64_t* so = (ch->paired && (c & 1)) ? o2_ : o1_;
+        const char* sq = (ch->paired && (c & 1)) ? ch->s2 : ch->s1;
+        const int64_t* so = (ch->paired && (c & 1)) ? ch->o2 : ch->o1;
         const int64_t u = ch->paired ? (c >> 1) : c;
-        if (u >= nPacked_ || static_cast<size_t>(so[u + 1] - so[u]) != read.size()) continue;
+        if (u >= ch->nPacked || static_cast<size_t>(so[u + 1] - so[u]) != read.size()) continue;
         if (read.size() && std::memcmp(sq + so[u], read.data(), read.size()) != 0) continue;
         idx = c; ch->cursor = c + 1; break;
       }
@@ -825,11 +902,9 @@ class SACollector {
   bool strictCheck_{false};
   bool doChaining_{false};
   int32_t maxMMPExtension_{7};
-  std::unique_ptr<qmap::detail::Chunk> chunk_;
-  // the chunk's reads as they were packed for the device (the batch's input buffers; o1_ / o2_ start at this group's first pair)
-  const char* s1_{nullptr}; const char* s2_{nullptr};
-  const int64_t* o1_{nullptr}; const int64_t* o2_{nullptr};
-  int64_t nPacked_{0};
+  std::unique_ptr<qmap::detail::Chunk> chunk_;                 // the current group
+  std::deque<std::unique_ptr<qmap::detail::Chunk>> pending_;   // groups sent ahead (prefetch_async), oldest first
+  std::vector<std::unique_ptr<qmap::detail::Chunk>> spare_;    // chunk objects of groups that were given back
 };
 
 // ------------------------------------------------------------------------------------------------ hitsToMappingsSimple

@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "qm_last_error", "qm_version", "qm_opts_default", "qm_index_open", "qm_index_close", "qm_index_info_get",
     "qm_index_txp_name", "qm_index_txp_len", "qm_index_arrays", "qm_index_raw", "qm_ctx_create", "qm_ctx_destroy", "qm_ctx_device_bytes",
     "qm_map_pairs", "qm_map_reads", "qm_map_device", "qm_pack_reads", "qm_packed_offset", "qm_packed_bytes", "qm_map_pairs_packed", "qm_map_reads_packed", "qm_fetch_hits", "qm_result_device", "qm_ctx_set_debug",
-    "qm_fetch_intervals", "qm_last_kernel_ms", "qm_ctx_stat", "qm_build_index", "qm_build_index_ex",
+    "qm_fetch_intervals", "qm_last_kernel_ms", "qm_ctx_stat", "qm_fetch_skipped", "qm_build_index", "qm_build_index_ex",
     "qm_collect_reads", "qm_fetch_found", "qm_hits_to_mappings", "qm_fetch_read_lists", "qm_merge_lists", "qm_fetch_too_many",
     "qm_map_pairs_stages", "qm_stage_bytes", "qm_fetch_stages", "qm_pinned_alloc", "qm_pinned_free", "qm_ctx_create_ex", "qm_fetch_hits_pinned", "qm_xxh64",
     "qm_stream_open", "qm_stream_open_ex", "qm_stream_reserve", "qm_stream_next", "qm_stream_close", "qm_stream_last_error", "qm_stream_stats", "qm_stream_stats_ex",
@@ -128,6 +128,7 @@ def lib():
     L.qm_fetch_intervals.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     L.qm_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.qm_ctx_stat.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
+    L.qm_fetch_skipped.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
     L.qm_collect_reads.argtypes = [C.c_void_p, C.POINTER(QmOpts), C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
     L.qm_fetch_found.argtypes = [C.c_void_p, C.c_void_p]
     L.qm_hits_to_mappings.argtypes = [C.c_void_p, C.POINTER(QmOpts), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
@@ -347,8 +348,21 @@ class QuasiMapper:
                                    C.byref(nh), C.byref(ctr)))
         return self._finish(n, nh, ctr, fetch=fetch)
 
+    def skipped(self):
+        """qm_fetch_skipped: the reads of the last call that were skipped, not mapped -> (total, reads int64[], codes int32[]);
+        code 1: longer than QM_MAX_LONG_READ_LEN characters, 2: interval lists beyond the scratch (max_interval above its default)"""
+        tot = C.c_int64()
+        _check(lib().qm_fetch_skipped(self._h, None, None, 0, C.byref(tot)))
+        n = min(tot.value, 4096)
+        reads = np.zeros(n, dtype=np.int64); codes = np.zeros(n, dtype=np.int32)
+        if n:
+            _check(lib().qm_fetch_skipped(self._h, reads.ctypes.data, codes.ctypes.data, n, C.byref(tot)))
+        return tot.value, reads, codes
+
     def stat(self, which):
-        """qm_ctx_stat: 0 stage-A relaunches of the last call, 1 list buffer capacity (words), 2 reads on the -s slow path"""
+        """qm_ctx_stat: 0 stage-A relaunches of the last call, 1 list buffer capacity (words), 2 reads on the -s slow path,
+        3 reads the lean stage-A kernel was launched over (-1: the general kernel ran), 4 reads it left to the general kernel,
+        5 reads that were skipped (qm_fetch_skipped)"""
         v = C.c_int64()
         _check(lib().qm_ctx_stat(self._h, int(which), C.byref(v)))
         return v.value

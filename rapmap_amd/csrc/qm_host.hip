@@ -126,6 +126,7 @@ struct qm_ctx {
   u64* d_lists = nullptr;                                      // bump-allocated per-read hit lists
   qm_hit* d_hits = nullptr;
   u64* d_scal = nullptr; /* cursor, counters[6], status */ u64* d_gscr = nullptr;
+  u64* d_skip = nullptr; std::vector<uint64_t> skipList; int64_t lastSkipped = 0;   // reads the last call skipped (ReadBatch::skiplist)
   void* d_scanTmp = nullptr; size_t scanTmpBytes = 0;
   uint8_t* d_seq1 = nullptr; uint8_t* d_seq2 = nullptr; long long* d_off1 = nullptr; long long* d_off2 = nullptr;
   // SA-interval hits as an output (qm_fetch_intervals), foundHit flags, tooMany flags of a merge-only call
@@ -498,7 +499,7 @@ int qm_ctx_destroy(qm_ctx* c) {
     for (void* p : c->phAllocs) if (p) hipFree(p);
   }
   void* ptrs[] = {c->d_cnt, c->d_lcnt, c->d_loff, c->d_lists, c->d_hits, c->d_offs,
-                  c->d_scal, c->d_gscr, c->d_scanTmp, c->d_seq1, c->d_seq2, c->d_off1, c->d_off2, c->d_iv, c->d_ivcnt, c->d_ivoff, c->d_found, c->d_tooMany, c->d_ivIn, c->d_ivInOff, c->d_lenIn, c->d_foundIn,
+                  c->d_scal, c->d_skip, c->d_gscr, c->d_scanTmp, c->d_seq1, c->d_seq2, c->d_off1, c->d_off2, c->d_iv, c->d_ivcnt, c->d_ivoff, c->d_found, c->d_tooMany, c->d_ivIn, c->d_ivInOff, c->d_lenIn, c->d_foundIn,
                   c->d_selscr, c->d_kswRows, c->d_pk1, c->d_pk2, c->d_exc1, c->d_exc2, c->d_slowq, c->d_todoq, c->d_todoq2, c->d_dyn, c->d_dynmem, c->d_toff, c->d_tmp, c->d_tkeys, c->d_tsc, c->d_tref, c->d_tcix, c->d_tasks};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->ev0) hipEventDestroy(c->ev0);
@@ -551,6 +552,7 @@ int qm_ctx_create_ex(const qm_index* ix, int device_id, uint32_t flags, qm_ctx**
   CK(hipEventCreateWithFlags(&c->evCopy, hipEventDisableTiming));
   CK(hipEventCreate(&c->ev0)); CK(hipEventCreate(&c->ev1)); CK(hipEventCreate(&c->evA)); CK(hipEventCreate(&c->evB));
   CK(hipMalloc((void**)&c->d_scal, QM_SC_WORDS * sizeof(u64)));
+  CK(hipMalloc((void**)&c->d_skip, QM_SKIP_CAP * sizeof(u64)));
   // one builder per (index, device image) at a time: a second thread that asks for the same replica while the first one is
   // still uploading waits here and then shares it
   std::shared_ptr<std::mutex> buildMu;
@@ -814,7 +816,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
     B.seq1 = (const unsigned char*)d_seq1; B.off1 = (const long long*)d_off1;
     B.seq2 = (const unsigned char*)d_seq2; B.off2 = (const long long*)d_off2; B.nreads = nreads;
     B.lcnt = c->d_lcnt; B.loff = c->d_loff; B.lists = c->d_lists; B.cursor = c->d_scal; B.lists_cap = c->capLists;
-    B.status = (int*)(c->d_scal + QM_SC_STATUS); B.gscratch = c->d_gscr;
+    B.status = (int*)(c->d_scal + QM_SC_STATUS); B.gscratch = c->d_gscr; B.skiplist = c->d_skip;
     if (wantIv) { B.iv_out = c->d_iv; B.iv_cnt = c->d_ivcnt; B.iv_off = c->d_ivoff; B.iv_cap = c->capIv; }
     if (wantFound) B.found_out = c->d_found;
     B.iv_in = rq.ivIn; B.iv_in_off = rq.ivInOff; B.len_in = rq.lenIn; B.found_in = rq.foundIn;
@@ -890,8 +892,6 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
       const int st1 = (int)(hscal[QM_SC_STATUS] & 0xffffffffu);
       if (hscal[QM_SC_SLOWCNT] > 0 && !(st1 & 23)) {
         const int64_t nl_ = (int64_t)hscal[QM_SC_SLOWCNT];
-        if ((int64_t)hscal[QM_SC_SLOWMAX] > QM_MAX_LONG_READ_LEN)
-          return fail(QM_E_TOOLONG, "a read of %lld characters: longer than the %d the long-read pass takes", (long long)hscal[QM_SC_SLOWMAX], QM_MAX_LONG_READ_LEN);
         if ((rc = ensure(c->d_slowq, c->capSlowq, nl_))) return rc;
         HIPCHK(qmk_collect_slow(c->d_lcnt, nreads, c->d_slowq, (unsigned long long*)(c->d_scal + QM_SC_SLOWQ), c->stream));
         ReadBatch S2 = B;
@@ -955,8 +955,6 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
       // and map them with the 32-slot kernels -- a second, small launch; everything it writes (lists, intervals, foundHit)
       // goes where the first pass would have put it
       const int64_t nl_ = (int64_t)hscal[QM_SC_SLOWCNT];
-      if ((int64_t)hscal[QM_SC_SLOWMAX] > QM_MAX_LONG_READ_LEN)
-        return fail(QM_E_TOOLONG, "a read of %lld characters: longer than the %d the long-read pass takes", (long long)hscal[QM_SC_SLOWMAX], QM_MAX_LONG_READ_LEN);
       if ((rc = ensure(c->d_slowq, c->capSlowq, nl_))) return rc;
       HIPCHK(qmk_collect_slow(c->d_lcnt, nreads, c->d_slowq, (unsigned long long*)(c->d_scal + QM_SC_SLOWQ), c->stream));
       ReadBatch S2 = B;
@@ -1027,6 +1025,12 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
       continue;
     }
     break;
+  }
+  // reads that were skipped, not mapped (beyond QM_MAX_LONG_READ_LEN characters; interval lists beyond the scratch): their list
+  c->lastSkipped = (int64_t)hscal[QM_SC_SKIPCNT]; c->skipList.clear();
+  if (c->lastSkipped > 0) {
+    c->skipList.resize((size_t)(c->lastSkipped < QM_SKIP_CAP ? c->lastSkipped : QM_SKIP_CAP));
+    HIPCHK(hipMemcpy(c->skipList.data(), c->d_skip, c->skipList.size() * sizeof(u64), hipMemcpyDeviceToHost));
   }
   c->lastIvTotal = wantIv ? (int64_t)hscal[QM_SC_IVCUR] : 0;
   c->lastIvReads = wantIv ? nreads : -1;
@@ -1151,8 +1155,7 @@ static int map_device_impl(qm_ctx* c, const qm_opts* o, int64_t n, const void* d
   int rc = check_opts(o);
   if (rc) return rc;
   if ((d_seq2 == nullptr) != (d_off2 == nullptr)) return fail(QM_E_ARG, "seq2/off2 must both be given or both be null");
-  if (max_read_len > (len_limit(o)))
-    return fail(QM_E_TOOLONG, "read length %d > %d", max_read_len, len_limit(o));
+  // (a read beyond len_limit() is skipped, not mapped: qm_fetch_skipped)
   HIPCHK(hipSetDevice(c->device));
   // 64-character slots per read: picks the kernel instantiation.  `short_read_len` (host callers: the longest read that is not
   // beyond QM_MAX_READ_LEN) picks it when the batch also holds long reads -- those are set aside by the launch whatever its
@@ -1277,12 +1280,19 @@ static int map_device_split(qm_ctx* c, const qm_opts* o, int K, int64_t n, const
   }
   c->lastMapMs = last > first ? last - first : 0;
   float ms = 0; hipEventElapsedTime(&ms, c->evA, c->evB); c->lastTotalMs = ms;
-  c->lastRelaunches = 0; c->lastSlowReads = 0;
+  c->lastRelaunches = 0; c->lastSlowReads = 0; c->lastSkipped = 0; c->skipList.clear();
   qm_counters sum; memset(&sum, 0, sizeof(sum));
   for (int i = 0; i < K; ++i) {
     sum.pe_hits += ctr[i].pe_hits; sum.se_hits += ctr[i].se_hits; sum.tot_hits += ctr[i].tot_hits; sum.num_reads += ctr[i].num_reads;
     sum.too_many_hits += ctr[i].too_many_hits; sum.mapped += ctr[i].mapped;
-    c->lastRelaunches += c->helpers[(size_t)i]->lastRelaunches; c->lastSlowReads += c->helpers[(size_t)i]->lastSlowReads;
+    qm_ctx* h = c->helpers[(size_t)i];
+    c->lastRelaunches += h->lastRelaunches; c->lastSlowReads += h->lastSlowReads;
+    // the part's skipped reads, as reads of the whole batch
+    int64_t u0 = n * i / K;
+    if (K == 2 && firstPct > 0) u0 = i == 0 ? 0 : n * firstPct / 100;
+    c->lastSkipped += h->lastSkipped;
+    for (uint64_t e : h->skipList)
+      if (c->skipList.size() < QM_SKIP_CAP) c->skipList.push_back(((e & ((1ULL << 56) - 1)) + (uint64_t)(paired ? 2 * u0 : u0)) | (e & ~((1ULL << 56) - 1)));
   }
   c->lastUnits = n; c->lastHits = J.base[K]; c->lastPaired = paired;
   c->lastIvReads = -1; c->lastFoundReads = -1; c->lastListReads = -1; c->lastTooManyUnits = -1; c->stReads = -1; c->stUnits = -1;
@@ -1345,7 +1355,6 @@ static int map_host(qm_ctx* c, const qm_opts* o, int64_t n, const char* seq1, co
   if ((rc = stage_offsets(c, n, off1, c->d_seq1, c->capSeq1, c->d_off1, c->capOff1, maxLen, maxShort))) return rc;
   if (seq2 && (rc = stage_offsets(c, n, off2, c->d_seq2, c->capSeq2, c->d_off2, c->capOff2, maxLen, maxShort))) return rc;
   const int32_t lim = len_limit(o);
-  if (maxLen > lim) { hipStreamSynchronize(c->copyStream); return fail(QM_E_TOOLONG, "read length %d > %d%s", maxLen, lim, o->sel_aln ? " (-s)" : ""); }
   // the characters follow chunk by chunk, each chunk's kernel behind its own copy (ChunkFeeder); QM_HOST_CHUNK = units per chunk
   HostFeed hf = {c, seq1, off1, seq2, off2};
   const char* ce = getenv("QM_HOST_CHUNK");
@@ -1404,7 +1413,6 @@ static int map_packed(qm_ctx* c, const qm_opts* o, int64_t n, const uint8_t* pk1
   int32_t maxLen = 0, maxShort = 0;
   if ((rc = unpack_mate(c, n, pk1, off1, exc1, nexc1, c->d_seq1, c->capSeq1, c->d_off1, c->capOff1, c->d_pk1, c->capPk1, c->d_exc1, c->capExc1, maxLen, maxShort))) return rc;
   if (pk2 && (rc = unpack_mate(c, n, pk2, off2, exc2, nexc2, c->d_seq2, c->capSeq2, c->d_off2, c->capOff2, c->d_pk2, c->capPk2, c->d_exc2, c->capExc2, maxLen, maxShort))) return rc;
-  if (maxLen > len_limit(o)) { hipStreamSynchronize(c->stream); return fail(QM_E_TOOLONG, "read length %d > %d", maxLen, len_limit(o)); }
   rc = map_device_impl(c, o, n, c->d_seq1, c->d_off1, pk2 ? c->d_seq2 : nullptr, pk2 ? c->d_off2 : nullptr, maxLen, n_hits, counters, nullptr, RunReq(), maxShort > 0 ? maxShort : 1);
   hipStreamSynchronize(c->stream);                         // nothing of the caller's buffers is in flight after return (error paths too)
   return rc;
@@ -1757,7 +1765,19 @@ int qm_ctx_stat(const qm_ctx* c, int which, int64_t* value) {
     case QM_STAT_SLOW_READS: *value = c->lastSlowReads; break;
     case QM_STAT_LEAN_READS: *value = c->lastLeanReads; break;
     case QM_STAT_LEAN_DEFERRED: *value = c->lastLeanDeferred; break;
+    case QM_STAT_SKIPPED_READS: *value = c->lastSkipped; break;
     default: return fail(QM_E_ARG, "unknown statistic %d", which);
+  }
+  return QM_OK;
+}
+
+int qm_fetch_skipped(const qm_ctx* c, int64_t* reads, int32_t* codes, int64_t cap, int64_t* total) {
+  if (!c || !total) return fail(QM_E_ARG, "null argument");
+  *total = c->lastSkipped;
+  const int64_t n = (int64_t)c->skipList.size() < cap ? (int64_t)c->skipList.size() : cap;
+  for (int64_t i = 0; i < n; ++i) {
+    if (reads) reads[i] = (int64_t)(c->skipList[(size_t)i] & ((1ULL << 56) - 1));
+    if (codes) codes[i] = (int32_t)(c->skipList[(size_t)i] >> 56);
   }
   return QM_OK;
 }

@@ -460,10 +460,21 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
               }
               if (rem > QM_EXT_BASES) { if (ballot(fullv)) { bail = 1; break; } }   // (a 128-character read matching beyond what the table holds)
             }
-            mlen = wave_max(lc);
-            LV<bool> best;
-            QM_LANES(l) { best[l] = lc[l] == mlen; }
-            const u64 bq = ballot(best);
+            // the suffixes with the longest match are one run of lanes.  A capped extension usually matches all it may use on some
+            // of them (the read keeps matching): that case needs no maximum over the lanes
+            u64 bq = 0;
+            if (SEL && capped) {
+              LV<bool> fullc;
+              QM_LANES(l) { fullc[l] = lc[l] == k + rem; }
+              bq = ballot(fullc);
+              mlen = k + rem;
+            }
+            if (!bq) {
+              mlen = wave_max(lc);
+              LV<bool> best;
+              QM_LANES(l) { best[l] = lc[l] == mlen; }
+              bq = ballot(best);
+            }
             first = ctz64(bq); cnt = 64 - clz64(bq) - first;
             if (SEL && !capped && mlen < L && mlen >= k + ext) { capped = 1; continue; }   // (p == 0 here: mlen >= L <=> the whole read)
             break;

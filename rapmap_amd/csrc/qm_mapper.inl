@@ -2,9 +2,10 @@
 //
 //   stage A  (map_read)   ONE wavefront owns ONE read: SACollector::operator() + hitsToMappingsSimple.
 //   stage B  (pair_merge) one thread per read pair: mergeLeftRightHits + the per-pair driver.
-// A pair's two mates are independent until the merge, so giving each its own wave halves the chain of
-// dependent HBM round trips a wave walks through (the kernel is latency-bound: see profiles/), and
-// keeps the per-wave state small enough for 6+ waves per SIMD.
+// This file is the GENERAL stage A: every read length class, index flavour and option.  Since round 5 the reads that make up
+// nearly all of a batch (<= 128 clean characters, dense or -p table, sensitive mode) are mapped by qm_lean.inl -- two reads per
+// wavefront, window masks on the scalar unit -- and this kernel takes what that one leaves, the longer read classes and the other
+// option sets.  It is bound by instruction issue on both pipes at 8 waves per SIMD, not by latency.
 //
 // Written against qm_wave.h: wave-uniform state lives in plain scalars (SGPRs), per-lane state in
 // LV<T>, long-lived tables in the wave's LDS slab.  Compiled for gfx950 by qm_kernels.hip and, for
@@ -56,6 +57,8 @@ namespace qm {
 #define QM_SC_SLOWMAX 17
 #define QM_SC_SLOWQ 18
 #define QM_SC_IVCUR 19             // bump pointer of the SA-interval output
+#define QM_SC_SKIPCNT 31           // reads that were skipped, not mapped (ReadBatch::skiplist)
+#define QM_SKIP_CAP 4096           // ... of which this many are listed
 #define QM_LCNT_SLOW 0x7fffffffu   // lcnt value of a read waiting on the slow queue
 #define QM_LCNT_LEAN 0x7ffffffeu   // ... of a read qm_lean_kernel left to the general kernel (qm_lean.inl)
 
@@ -174,6 +177,10 @@ struct ReadBatch {
   const long long* slowq;
   struct SelScratchDyn* dyn;
   const u64* nreads_dev;   // qm_h2m_kernel: when set, the launch covers min(nreads, *nreads_dev) slots (a queue filled by the kernel before it)
+  // reads the device does not map: a read beyond QM_MAX_LONG_READ_LEN characters (code 1), a read whose interval lists outgrow the
+  // scratch (code 2: only with max_interval above its default).  Such a read gets an empty result and an entry here (read | code << 56);
+  // the rest of the batch is mapped as if it were not there.  Count: scalar slot QM_SC_SKIPCNT.
+  u64* skiplist;
 };
 
 // stage B launch arguments
@@ -892,6 +899,15 @@ QM_DEV bool probe_first(const DevIndex& ix, Strand<NS>& S, int p, Iv* rtab0) {
 // first position >= p that is NOT yet probed (or 64*NS)
 template <int NS> QM_DEV int known_end(const Strand<NS>& S, int p) {
   return fl_first(S, p, [](typename Strand<NS>::FT w, int s) { return ((w >> (FL_K * NS + s)) & 1) == 0; });
+}
+
+QM_DEV void skip_read(const ReadBatch& B, long long read, int code) {
+  QM_LANES(l) {
+    if (l == 0) {
+      const u64 i = atomic_add_u64(B.cursor + QM_SC_SKIPCNT, 1ULL);
+      if (B.skiplist && i < QM_SKIP_CAP) B.skiplist[i] = (u64)read | ((u64)code << 56);
+    }
+  }
 }
 
 // SA-interval hits of one strand: the first QM_ICAP in LDS, the rest in the wave's global scratch
@@ -1818,8 +1834,8 @@ QM_DEV void finish_read(const DevIndex& ix, const ReadBatch& B, long long read, 
       QM_LANES(l) { if (l == 0) { B.lcnt[read] = QM_LCNT_SLOW; B.loff[read] = 0; } }
       return;
     }
-  } else if (bound > QM_GCAP) {        // only reachable with max_interval > 1000
-    QM_LANES(l) { if (l == 0) *B.status |= 2; }
+  } else if (bound > QM_GCAP) {        // only reachable with max_interval > 1000: this read goes without hits, and says so
+    skip_read(B, read, 2);
   } else if (bound <= QM_CAP) {
     // the two homes of the sort buffers are two expansions of the routine: behind one set of pointers that may be LDS or
     // global every access is a FLAT instruction -- through the vector-memory path even when it lands in LDS (it was a third
@@ -1883,14 +1899,17 @@ QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, lon
   // A read that does not fit this kernel's slots is set aside for the long-read pass (a second, small launch of the NS = 32
   // kernels over the queue of such reads; the host sizes nothing from it but checks the longest against QM_MAX_LONG_READ_LEN).
   // (-s: the set-aside reads get their intervals from the 32-slot chain-scoring collector before the list kernel runs.)
-  const bool setAside = tooLong && NS < 32;
+  // A read beyond the 32-slot kernels too (QM_MAX_LONG_READ_LEN characters) is not mapped: empty result, an entry in the batch's
+  // list of skipped reads (round 5; before, it failed the whole batch).
+  const bool setAside = tooLong && NS < 32, skipLong = tooLong && NS >= 32;
   if (tooLong) {
     QM_LANES(l) {
       if (l == 0) {
         if (setAside) { B.lcnt[read] = QM_LCNT_SLOW; B.loff[read] = 0; atomic_add_u64(B.cursor + QM_SC_SLOWCNT, 1ULL); atomic_max_u64(B.cursor + QM_SC_SLOWMAX, (u64)rawLen); }
-        else *B.status |= 4;
+        else { B.lcnt[read] = 0; B.loff[read] = 0; }
       }
     }
+    if (skipLong) skip_read(B, read, 1);
   }
   // uniform(): the length must stay in an SGPR -- merged into the lane-0 branch above it became a per-lane value and
   // with it every position, mask and branch of the collector moved from the scalar unit to the VALU
@@ -1923,7 +1942,11 @@ QM_DEV void map_read(const DevIndex& ix, const ReadBatch& B, long long read, lon
   stage_chars<NS, F>(B, slot + nw, M, par ^ 1);
   stage_offsets<NS, F>(B, slot + 2 * nw, M, par);
   QM_T(0);
-  if (setAside) { lds_dma_wait(); return; }               // mapped by the long-read pass (the next iteration reads the staging rows: what was just requested must have landed)
+  if (setAside || skipLong) {                             // mapped by the long-read pass / not at all (the next iteration reads the staging rows: what was just requested must have landed)
+    lds_dma_wait();
+    if (skipLong) { QM_LANES(l) { if (l == 0) { if (B.iv_out) { B.iv_cnt[read] = 0; B.iv_off[read] = 0; } if (B.found_out) B.found_out[read] = 0; } } }
+    return;
+  }
   IntervalList fi, ri;
   fi.lds = (QM_LDS(IntRec)*)M.ints[0]; ri.lds = (QM_LDS(IntRec)*)M.ints[1];
   fi.ovf = (IntRec*)(gscr + 3 * QM_GCAP); ri.ovf = fi.ovf + QM_IOVF;

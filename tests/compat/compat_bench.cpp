@@ -2,10 +2,10 @@
 // way `rapmap quasimap` drives it: T worker threads (src/RapMapSAMapper.cpp:752-799), each taking read groups of CHUNK pairs
 // from a shared hand-out (the parser's chunks of 10 000, :853,:869-871) and running the body of processReadsPairSA
 // (:461-551) on every pair -- collector x2 -> hitsToMappingsSimple x2 -> mergeLeftRightHits -> maxNumHits / counters.  The
-// only added line is `hitCollector.prefetch(rg)`.  Compiled against the header ALONE (bench.py's `compat_face` leg and
+// only added lines are `hitCollector.prefetch(rg)` and -- for the next group, sent ahead -- `hitCollector.prefetch_async(rg)`.  Compiled against the header ALONE (bench.py's `compat_face` leg and
 // tests/test_rapmap_compat.py build it with g++).
 //
-//   compat_bench INDEX READS.bin NPAIRS READLEN THREADS CHUNK [--no-prefetch] [--repeat R] [--use N] [--mixed]
+//   compat_bench INDEX READS.bin NPAIRS READLEN THREADS CHUNK [--no-prefetch] [--repeat R] [--use N] [--mixed] [--depth D]
 //
 // READS.bin: NPAIRS*READLEN characters of the left mates, then as many of the right mates (what bench.py holds in HBM for the
 // headline, copied to the host).  The read groups (std::string pairs, as the parser hands them out) are built before the
@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <string>
 #include <thread>
 #include <vector>
@@ -44,7 +45,8 @@ static inline double now_s() { return std::chrono::duration<double>(std::chrono:
 
 template <typename RapMapIndexT>
 static void worker(RapMapIndexT& rmi, std::vector<Group>& groups, const std::vector<size_t>& firstUnit, std::atomic<size_t>& next, bool prefetch,
-                   uint32_t maxNumHits, Totals& T, rapmap::utils::HitCounters& hctr, Group* warm, std::atomic<int>& ready, std::atomic<int>& go, bool mixed = false) {
+                   uint32_t maxNumHits, Totals& T, rapmap::utils::HitCounters& hctr, Group* warm, std::atomic<int>& ready, std::atomic<int>& go, bool mixed = false,
+                   int depth = 2) {
   using OffsetT = typename RapMapIndexT::IndexType;
   using rapmap::utils::MateStatus;
   using rapmap::utils::QuasiAlignment;
@@ -95,10 +97,21 @@ static void worker(RapMapIndexT& rmi, std::vector<Group>& groups, const std::vec
   ++ready;
   while (!go.load()) std::this_thread::yield();
   mine.goSeenAt = now_s();
-  while (true) {
+  // up to `depth` groups of this worker are on their way at a time: the next group is packed and sent (prefetch_async) before the
+  // per-read loop over the current one starts, so that the device pass of one hides under the host loop of the other
+  std::deque<size_t> taken;
+  auto take = [&]() {
     const size_t g = next.fetch_add(1);
-    if (g >= groups.size()) break;
+    if (g >= groups.size()) return false;
+    if (prefetch && depth > 1) hitCollector.prefetch_async(groups[g], mc, mixed && (g & 1), maxNumHits);    // <- the second added line
+    taken.push_back(g);
+    return true;
+  };
+  while ((int)taken.size() < depth && take()) {}
+  while (!taken.empty()) {
+    const size_t g = taken.front(); taken.pop_front();
     run_group(groups[g], firstUnit[g], true, mixed && (g & 1));        // --mixed: odd groups under --fuzzyIntersection
+    take();
   }
   T = mine;
 }
@@ -109,11 +122,12 @@ int main(int argc, char** argv) {
     const char* idx = argv[1]; const char* path = argv[2];
     const size_t nFile = (size_t)std::atoll(argv[3]), L = (size_t)std::atoll(argv[4]);
     const int threads = std::atoi(argv[5]); const size_t chunk = (size_t)std::atoll(argv[6]);
-    bool prefetch = true, mixed = false; int repeat = 1; size_t n = nFile;
+    bool prefetch = true, mixed = false; int repeat = 1, depth = 2; size_t n = nFile;
     for (int i = 7; i < argc; ++i) {
       if (!std::strcmp(argv[i], "--no-prefetch")) prefetch = false;
       else if (!std::strcmp(argv[i], "--mixed")) mixed = true;
       else if (!std::strcmp(argv[i], "--repeat") && i + 1 < argc) repeat = std::atoi(argv[++i]);
+      else if (!std::strcmp(argv[i], "--depth") && i + 1 < argc) depth = std::max(1, std::atoi(argv[++i]));   // groups a worker has in flight (1: prefetch() alone)
       else if (!std::strcmp(argv[i], "--use") && i + 1 < argc) n = std::min(nFile, (size_t)std::atoll(argv[++i]));   // only the first N pairs of the file
     }
     std::vector<char> raw(2 * nFile * L);
@@ -147,7 +161,7 @@ int main(int argc, char** argv) {
       std::atomic<size_t> next{0}; std::atomic<int> ready{0}, go{0};
       std::vector<std::thread> th;
       for (int t = 0; t < threads; ++t)
-        th.emplace_back([&, t] { worker(rmi, groups, firstUnit, next, prefetch, 200u, T[(size_t)t], hctr, &warm[(size_t)t], ready, go, mixed); });
+        th.emplace_back([&, t] { worker(rmi, groups, firstUnit, next, prefetch, 200u, T[(size_t)t], hctr, &warm[(size_t)t], ready, go, mixed, depth); });
       while (ready.load() < threads) std::this_thread::yield();
       const auto t0 = std::chrono::steady_clock::now();
       const double t0s = now_s();

@@ -100,8 +100,7 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
       std::vector<long long> q;
       for (long long r = 0; r < nreads; ++r) if (lcnt[r] == QM_LCNT_SLOW) q.push_back(r);
       ReadBatch S2 = B; S2.slowq = q.data(); S2.nreads = (long long)q.size();
-      if ((long long)scal[QM_SC_SLOWMAX] > QM_MAX_LONG_READ_LEN) { status |= 4; for (long long r : q) lcnt[r] = 0; }   // (the host fails the call here)
-      else {
+      {                                                   // (a read beyond QM_MAX_LONG_READ_LEN is skipped by that pass: empty result, scalar slot QM_SC_SKIPCNT)
         const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP);
         for (long long r = 0; r < (long long)q.size(); ++r) {
 #define QE_LONG(F_) { static WaveMem<32> M; stage_offsets<32, F_>(S2, r, M, 0); stage_chars<32, F_>(S2, r, M, 0); \
@@ -120,10 +119,7 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
       // 32-slot kernel).  A read whose intervals overflow the scratch is queued again, for the slow pass below.
       std::vector<long long> q;
       for (long long r = 0; r < nreads; ++r) if (lcnt[r] == QM_LCNT_SLOW && rawLen(r) > 64 * ns) q.push_back(r);
-      bool tooLong = false;
-      for (long long r : q) if (rawLen(r) > QM_MAX_LONG_READ_LEN) tooLong = true;
-      if (tooLong) { status |= 4; for (long long r : q) lcnt[r] = 0; }
-      else if (!q.empty()) {
+      if (!q.empty()) {
         ReadBatch S2 = B; S2.slowq = q.data(); S2.nreads = (long long)q.size();
         const int F = (ix.ph ? QM_F_PH : 0) | (B.sensitive ? 0 : QM_F_NIP) | QM_F_SEL;
         for (long long r = 0; r < (long long)q.size(); ++r) {
@@ -357,7 +353,7 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
     for (long long r = 0; r < nreads; ++r) for (u32 j = 0; j < dcnt[r]; ++j) io[w++] = dints[(size_t)(doff[r] + j)];
   }
   *ints_out = io;
-  *status_out = status | (int)(scal[QM_SC_SLOWCNT] << 8);   // bits 8..: reads that took the slow pass of -s
+  *status_out = status | (int)(scal[QM_SC_SLOWCNT] << 8) | (int)((scal[QM_SC_SKIPCNT] & 0x7f) << 24);   // bits 8..: reads that took the slow pass of -s; bits 24..: skipped reads
   return 0;
 }
 

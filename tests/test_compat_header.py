@@ -65,3 +65,21 @@ def test_cpp_caller_gets_oracle_hits(sample_data, lib_built, tmp_path, oracle_mo
         want.append(" ".join([str(len(hs))] + ["%d:%d:%d:%d%d:%d:%d" % (h["tid"], h["pos"], h["mate_pos"], h["fwd"], h["mate_is_fwd"], h["frag_len"], h["mate_status"]) for h in hs]))
     assert open(tmp_path / "out.txt").read().splitlines() == want
     assert "reads %d tot %d" % (n, res.counters["totHits"]) in r.stdout
+
+
+def test_salmon_support_members_of_quasi_alignment(tmp_path):
+    """RAPMAP_SALMON_SUPPORT (the reference's include/RapMapUtils.hpp:41-43,407-421,446-467): logProb, logBias, format / libFormat()
+    and fragLengthPedantic() exist and behave; the translation unit needs nothing but the header (and Salmon's LibraryFormat)."""
+    exe = tmp_path / "salmon_members"
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "compat", "salmon_members.cpp"), "-o", str(exe), "-pthread"])
+    assert subprocess.run([str(exe)]).returncode == 0
+
+
+def test_reference_style_callers_compile_with_the_salmon_macro(tmp_path):
+    """the reference-style caller and the call-surface bench compile against the header with RAPMAP_SALMON_SUPPORT defined"""
+    lf = tmp_path / "LibraryFormat.hpp"
+    lf.write_text("#pragma once\n#include <cstdint>\nstruct LibraryFormat { uint8_t id; static LibraryFormat formatFromID(uint8_t i) { return LibraryFormat{i}; } };\n")
+    for src in ("rapmap_caller.cpp", "compat_bench.cpp"):
+        subprocess.check_call(["g++", "-std=c++14", "-fsyntax-only", "-Wall", "-DRAPMAP_SALMON_SUPPORT", "-include", str(lf), "-I", os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "tests", "compat", src)])

@@ -433,9 +433,16 @@ def test_reads_beyond_512_bp_take_the_long_read_pass(synth_medium, synth_medium_
     _cmp_ints(res, er)
     long_units = [u for u in range(len(r1)) if len(r1[u]) > 512]
     assert sum(int(res.hit_offsets[u + 1] - res.hit_offsets[u]) > 0 for u in long_units) > len(long_units) // 2
-    # one character too many: the call fails
-    r1[5] = bytes(txps[0][:2049]); q1, o1 = pack(r1)
-    assert em.map(q1, o1, q2, o2, ns=2).status & 4
+    # one character too many: that read is skipped (empty result, counted), everything else is mapped as before (round 5: the call failed)
+    was5 = r1[5]
+    r1[5] = bytes(txps[0][:2049]); q1b, o1b = pack(r1)
+    er2 = em.map(q1b, o1b, q2, o2, opts=emu.default_opts(**go), ns=2)
+    assert (er2.status & 0xff) == 0 and (er2.status >> 24) == 1, er2.status
+    r1[5] = b""; q1c, o1c = pack(r1)                        # what the oracle is asked: the same batch with nothing in that read's place
+    res2 = orc.map_pairs(q1c, o1c, q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=8)
+    assert_hits_equal(res2.hit_offsets, res2.hits, er2.hit_offsets, er2.hits, "skipped read, %s" % variant)
+    assert res2.counters == er2.counters
+    r1[5] = was5
 
 
 def test_one_diagonal_chaining_editions_equal_the_doubles():

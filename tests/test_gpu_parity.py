@@ -135,10 +135,24 @@ def test_edge_batches(synth_small, oracle_mod):
         res = orc.map_pairs(q1, o1, q2, o2)
         gr = mp.map_pairs(q1, o1, q2, o2)
         assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "one")
-    # too-long read and unsupported options are errors, not silent fallbacks
-    q1, o1 = pack([b"A" * 2100]); q2, o2 = pack([b"C" * 10])
-    with pytest.raises(ra.QmError, match="read length"):
-        mp.map_pairs(q1, o1, q2, o2)
+    # a read beyond QM_MAX_LONG_READ_LEN is skipped -- empty result, listed by qm_fetch_skipped -- and the rest of the batch is mapped
+    # as if it were not there (round 5; before, the call failed): parity with the oracle on the same batch with nothing in its place
+    n0 = 40
+    r1 = list(synth_small["reads1"][:n0]); r2 = list(synth_small["reads2"][:n0])
+    long1 = bytes(np.asarray(ix.text[:2100]).tobytes()).replace(b"$", b"A")
+    r1[7] = long1; r2[19] = long1 + b"ACGT"
+    q1, o1 = pack(r1); q2, o2 = pack(r2)
+    for go, oo in (({}, {}), ({"sel_aln": 1}, {"selAln": 1}), ({"sensitive": 0}, {"sensitive": 0})):
+        gr = mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(**go))
+        tot, reads, codes = mp.skipped()
+        assert tot == 2 and sorted(reads.tolist()) == [2 * 7, 2 * 19 + 1] and set(codes.tolist()) == {1}, (go, tot, reads, codes)
+        e1 = list(r1); e2 = list(r2); e1[7] = b""; e2[19] = b""
+        p1, po1 = pack(e1); p2, po2 = pack(e2)
+        res = orc.map_pairs(p1, po1, p2, po2, opts=oracle_mod.default_opts(**oo))
+        assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "skipped reads %s" % (go,))
+        assert res.counters == gr.counters
+    gr = mp.map_pairs(*pack(list(synth_small["reads1"][:n0])), *pack(list(synth_small["reads2"][:n0])))
+    assert mp.skipped()[0] == 0
     q1, o1 = pack([b"A" * 600]); q2, o2 = pack([b"C" * 10])
     assert mp.map_pairs(q1, o1, q2, o2).n_hits == 0          # a 600-character read takes the long-read pass, with -s too,
     assert mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(sel_aln=1)).n_hits == 0
@@ -772,9 +786,14 @@ def test_reads_beyond_512_bp_take_the_long_read_pass(synth_medium, synth_medium_
         rf = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(selAln=1, dpBandwidth=-1), nthreads=8)
         gf = mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(sel_aln=1, dp_bandwidth=-1))
         assert_hits_equal(rf.hit_offsets, rf.hits, gf.hit_offsets, gf.hits, "long reads, -s, full band")
+        # one character too many: that read is skipped and listed, the batch is mapped (round 5: the call failed)
         r1[5] = bytes(txps[0][:2049]); q1, o1 = pack(r1)
-        with pytest.raises(ra.QmError, match="2048"):
-            mp.map_pairs(q1, o1, q2, o2)
+        gk = mp.map_pairs(q1, o1, q2, o2)
+        tot, reads, codes = mp.skipped()
+        assert tot == 1 and reads.tolist() == [10] and codes.tolist() == [1]
+        r1[5] = b""; q1, o1 = pack(r1)
+        rk = orc.map_pairs(q1, o1, q2, o2, nthreads=8)
+        assert_hits_equal(rk.hit_offsets, rk.hits, gk.hit_offsets, gk.hits, "long reads, one skipped")
 
 
 @pytest.mark.parametrize("variant", ["default", "fuzzy", "selAln", "noSensitive"])
@@ -798,3 +817,79 @@ def test_two_bit_packed_reads_map_like_their_characters(synth_small, oracle_mod,
     if variant == "default":
         z = np.zeros(0, np.uint8); zo = np.zeros(1, np.int64)
         assert mp.map_pairs_packed(z, zo, z, zo).n_hits == 0                 # an empty batch
+
+
+def _lean_edge_reads(idx, n=600, seed=5):
+    """reads that walk the lean kernel's edges: every length from below k to 128 (a 128-character perfect match runs past the SaExt
+    window), lower case, N's, long runs of one base, two errors, reverse-complemented mates, empty reads"""
+    import rapmap_amd as ra
+    rng = np.random.default_rng(seed)
+    qi = ra.QuasiIndex(idx)
+    text, offsets = qi.arrays()
+    text = np.asarray(text); offsets = np.asarray(offsets, dtype=np.int64)
+    ends = np.append(offsets[1:], text.size) - 1
+    qi.close()
+    comp = np.zeros(256, np.uint8); comp[list(b"ACGT")] = list(b"TGCA")
+    ok = np.nonzero(ends - offsets >= 300)[0]
+    r1, r2 = [], []
+    lens = [0, 5, 30, 31, 32, 33, 63, 64, 65, 99, 100, 101, 126, 127, 128]
+    for i in range(n):
+        t = ok[rng.integers(0, ok.size)]
+        L = lens[i % len(lens)] if i % 3 else 100
+        a = int(offsets[t] + rng.integers(0, ends[t] - offsets[t] - 260))
+        f = text[a:a + L].copy(); m = comp[text[a + 150:a + 150 + L][::-1]].copy()
+        kind = (i // len(lens)) % 8
+        for r in (f, m):
+            if r.size == 0:
+                continue
+            if kind == 1: r[rng.integers(0, r.size)] = ord("N")
+            if kind == 2 and r.size > 40: r[10:10 + 33] = ord("A")
+            if kind == 3:
+                for _ in range(2): r[rng.integers(0, r.size)] = b"ACGT"[rng.integers(0, 4)]
+            if kind == 4: r[:] = np.frombuffer(bytes(r).lower(), dtype=np.uint8)
+            if kind == 5 and r.size > 3: r[rng.integers(0, r.size)] = ord("$")
+        if kind == 6: f, m = m, f
+        r1.append(bytes(f)); r2.append(bytes(m))
+    return r1, r2
+
+
+@pytest.mark.parametrize("variant", ["default", "noStrictCheck", "quasiCov", "fuzzy", "maxInterval3", "noOrphans"])
+def test_lean_kernel_edges_match_the_oracle(synth_medium, oracle_mod, variant):
+    """the lean stage-A kernel (two reads per wavefront; qm_lean.inl) on reads at its edges, paired and single-end with an odd count:
+    what it takes and what it leaves to the general kernel must add up to the oracle's hits"""
+    import rapmap_amd as ra
+    oo, go = {"default": ({}, {}), "noStrictCheck": ({"strictCheck": 0}, {"strict_check": 0}), "quasiCov": ({"quasiCov": 0.7}, {"quasi_cov": 0.7}),
+              "fuzzy": ({"fuzzy": 1}, {"fuzzy": 1}), "maxInterval3": ({"maxInterval": 3}, {"max_interval": 3}),
+              "noOrphans": ({"noOrphans": 1}, {"no_orphans": 1})}[variant]
+    ix, orc = load_oracle(synth_medium["idx"])
+    qi, mp = _gpu(synth_medium["idx"], debug=False)
+    r1, r2 = _lean_edge_reads(synth_medium["idx"])
+    q1, o1 = pack(r1); q2, o2 = pack(r2)
+    res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=4)
+    gr = mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(**go))
+    assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "lean edges %s" % variant)
+    assert res.counters == gr.counters
+    assert mp.stat(3) == 2 * len(r1), "the lean kernel was not the one launched"
+    assert 0 < mp.stat(4) < 2 * len(r1), "expected some reads left to the general kernel, and most taken"
+    one = r1[:-1] + r2[1:2]                                 # single-end, an odd number of reads
+    qs, os_ = pack(one)
+    if "fuzzy" not in go and "no_orphans" not in go:
+        rs = orc.map_single(qs, os_, opts=oracle_mod.default_opts(**oo), nthreads=4)
+        gs = mp.map_reads(qs, os_, opts=ra.default_opts(**go))
+        assert_hits_equal(rs.hit_offsets, rs.hits, gs.hit_offsets, gs.hits, "lean edges single-end %s" % variant)
+        assert mp.stat(3) == len(one)
+
+
+def test_lean_kernel_on_the_compact_perfect_hash_image(synth_medium, synth_medium_ph, oracle_mod):
+    import rapmap_amd as ra
+    ix, orc = load_oracle(synth_medium_ph["idx"])
+    qi, mp = _gpu(synth_medium_ph["idx"], debug=False, ph_compact=True)
+    r1, r2 = _lean_edge_reads(synth_medium["idx"], n=400, seed=6)
+    q1, o1 = pack(r1); q2, o2 = pack(r2)
+    res = orc.map_pairs(q1, o1, q2, o2, nthreads=4)
+    gr = mp.map_pairs(q1, o1, q2, o2)
+    assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "lean edges, compact -p")
+    assert res.counters == gr.counters and mp.stat(3) == 2 * len(r1)
+    gs = mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(sel_aln=1))
+    rs = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(selAln=1), nthreads=4)
+    assert_hits_equal(rs.hit_offsets, rs.hits, gs.hit_offsets, gs.hits, "lean edges, compact -p, -s")
