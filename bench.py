@@ -594,6 +594,7 @@ def main():
 
 
 def side_legs(out, args, ra, qi, mp, opts, s1, s2, off, n, L, dev_id, cores):
+    os.environ.setdefault("QM_INGEST_PIN", "1")   # the end_to_end leg's one ingest engine: workers on the NUMA node that holds the files' pages (opt-in since round 5)
     # (1) PCIe inclusive: the same batch from pageable host buffers through qm_map_pairs + qm_fetch_hits
     hs1 = s1.cpu().numpy(); hs2 = s2.cpu().numpy(); hoff = off.cpu().numpy()
     mp.map_pairs(hs1[: 1000 * L], hoff[:1001], hs2[: 1000 * L], hoff[:1001], opts=opts)

@@ -1,3 +1,4 @@
+import os
 """`python -m rapmap_amd quasiindex|quasimap ...` -- the reference's command line on the MI355X path.
 
 Flag names, defaults and validation follow `rapmap quasiindex` (src/RapMapSAIndexer.cpp:821-927) and
@@ -170,6 +171,7 @@ def _quasimap(argv):
     # (a stream's own contexts share it)
     keep = [ra.QuasiMapper(qi, d) for d in sorted(set(devices))]
     for f1, f2 in pairs:
+        os.environ.setdefault("QM_INGEST_PIN", "1")   # a whole-machine job with one ingest engine: its workers on the NUMA node that holds the files' pages
         st = ra.MappedStream(qi, f1, f2, opts=opts, device=devices, batch_units=a.chunk, threads=nthr, names=out is not None)
         for b in st:
             gpu_ms += b.gpu_ms

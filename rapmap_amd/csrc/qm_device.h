@@ -59,7 +59,7 @@ hipError_t qmk_sel_compact(const void* pair_batch, const void* tmp, const void* 
 hipError_t qmk_pair_count(const void* pair_batch, hipStream_t st);
 hipError_t qmk_pair_write(const void* pair_batch, hipStream_t st);
 // 2-bit packed reads -> the ASCII image the kernels read (include/qmap_mi355.h, "2-bit packed reads"): groups of four, then exceptions
-hipError_t qmk_unpack_reads(const unsigned char* packed, const long long* off, long long n, int groups_per_read, unsigned char* seq,
+hipError_t qmk_unpack_reads(const unsigned char* packed, const long long* off, long long n, long long total_chars, unsigned char* seq,
                             const void* exc, long long n_exc, hipStream_t st);
 size_t qmk_scan_temp_bytes(long long n);
 hipError_t qmk_scan_counts(void* temp, size_t temp_bytes, const unsigned int* cnt, long long* offs, long long n,

@@ -763,7 +763,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
   const bool paired = d_seq2 != nullptr;
   const int64_t nreads = paired ? 2 * n : n;
   const int phc = c->d_ph ? 1 : 0;                        // (the compact -p image: its kernels take a larger grid)
-  const int grid = qmk_map_grid_ex(nreads, c->numCU, phc);
+  int grid = qmk_map_grid_ex(nreads, c->numCU, phc);
   if ((rc = ensure(c->d_lcnt, c->capLcnt, nreads + 1))) return rc;
   if ((rc = ensure(c->d_loff, c->capLoff, nreads + 1))) return rc;
   // The lean kernel (qm_lean.inl: two reads per wavefront and iteration, reads of up to 128 clean characters) takes the fused default
@@ -772,7 +772,13 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
   static const bool leanOff = [] { const char* e = getenv("QM_NO_LEAN"); return e && atoi(e) != 0; }();
   const bool useLean = !leanOff && rq.mode == QM_RUN_FUSED && !o->sel_aln && o->sensitive && ns == 2 && (c->d_slots || c->d_ph) && c->d_saext &&
                        !rq.keepIntervals && !rq.keepFound && c->ix->k <= 31;
-  if (!useLean) { if ((rc = ensure(c->d_gscr, c->capGrid, (int64_t)grid * 4 * QM_GSCR_U64))) return rc; }
+  if (!useLean) {
+    // every launched wave of the general kernels owns 112 KB of scratch (and open allocator chunks): an oversubscribed grid is 4 to 12
+    // times the resident one.  When that does not fit next to the index, the launch falls back to the resident grid.
+    rc = ensure(c->d_gscr, c->capGrid, (int64_t)grid * 4 * QM_GSCR_U64);
+    if (rc == QM_E_NOMEM) { grid = qmk_resident_grid(nreads, c->numCU); rc = ensure(c->d_gscr, c->capGrid, (int64_t)grid * 4 * QM_GSCR_U64); }
+    if (rc) return rc;
+  }
   // ... and its -s edition stands in for the chain-scoring collector of a fused -s call (intervals and foundHit out; the list kernels
   // that follow are the same)
   const bool useLeanSel = !leanOff && rq.mode == QM_RUN_FUSED && o->sel_aln && o->sensitive && ns == 2 && (c->d_slots || c->d_ph) && c->d_saext && c->ix->k <= 31;
@@ -1397,7 +1403,7 @@ static int unpack_mate(qm_ctx* c, int64_t n, const uint8_t* pk, const int64_t* o
   HIPCHK(hipMemcpyAsync(d_pk, pk, (size_t)pkBytes - 8, hipMemcpyHostToDevice, c->stream));
   if (nexc > 0) HIPCHK(hipMemcpyAsync(d_exc, exc, (size_t)nexc * sizeof(qm_pack_exc), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemsetAsync(d_seq + off[n], 0, 64, c->stream));      // the mapper fetches reads a word at a time: defined bytes behind the last one
-  HIPCHK(qmk_unpack_reads(d_pk, d_off, n, (mateMax + 3) / 4, d_seq, d_exc, nexc, c->stream));
+  HIPCHK(qmk_unpack_reads(d_pk, d_off, n, off[n], d_seq, d_exc, nexc, c->stream));
   return QM_OK;
 }
 

@@ -993,10 +993,12 @@ int qm_ingest_open(const char* path1, const char* path2, int32_t n_threads, int6
   // The workers of one engine stay on ONE NUMA node -- the node of the thread that opened it -- when they fit there: they pass
   // chunks, parse tables and slot buffers to each other, and with the parse at memory speed (round 4) a worker set spread over
   // both sockets of this host ran at 107 M pairs/s where the same 32 workers on one socket ran at 185
-  // (profiles/r04/ingest_affinity_after_fastparse.log).  QM_INGEST_PIN=0 leaves them to the scheduler.
+  // (profiles/r04/ingest_affinity_after_fastparse.log).  Opt-in (round 5): a library does not change thread affinity behind its
+  // caller's back, and engines opened side by side on one file would all pick the same node -- QM_INGEST_PIN=1 turns it on; the
+  // `quasimap` CLI and bench.py's end_to_end leg (one engine per run, whole-machine jobs) set it.
   {
     const char* pe = getenv("QM_INGEST_PIN");
-    if (!(pe && atoi(pe) == 0)) {
+    if (pe && atoi(pe) != 0) {
       cpu_set_t set; CPU_ZERO(&set); int ncpu = 0;
       unsigned cpu = 0, node = 0;
       bool haveNode = getcpu(&cpu, &node) == 0;

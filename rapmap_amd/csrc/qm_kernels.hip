@@ -179,7 +179,10 @@ QM_DEV void sel_flush_counters(unsigned long long* sc, const UnitCounters& uc, u
   __syncthreads();
   if (threadIdx.x < 6 && sc[threadIdx.x]) atomicAdd((unsigned long long*)&counters[threadIdx.x], sc[threadIdx.x]);
 }
-__global__ __launch_bounds__(256) void qm_sel_plan_kernel(PairBatch P, SelBatch A) {
+#ifndef QM_PLAN_WPS
+#define QM_PLAN_WPS 4     // waves per SIMD the plan kernel is built for (100 VGPRs; 6 / 8 spill 30 / 91 of them: profiles/r05/plan_wps_ab.txt)
+#endif
+__global__ __launch_bounds__(256, QM_PLAN_WPS) void qm_sel_plan_kernel(PairBatch P, SelBatch A) {
   __shared__ unsigned long long sc[6];
   if (threadIdx.x < 6) sc[threadIdx.x] = 0;
   __syncthreads();
@@ -349,21 +352,26 @@ __global__ void build_slots_from_ph_kernel(DevIndex ix, long long n, Bucket* buc
 
 // 2-bit packed reads (include/qmap_mi355.h): thread (read r, group g) turns packed byte (off[r] >> 2) + r + g into the characters
 // off[r] + 4g .. + 3 of the ASCII image; exceptions (anything but upper-case A C G T) are written over it afterwards
-__global__ __launch_bounds__(256) void qm_unpack_kernel(const unsigned char* packed, const long long* off, long long n, int G, unsigned char* seq) {
+// (eight threads per read, each striding over the read's groups: a launch sized by the LONGEST read of the batch -- one 2048-character
+// read among 2^19 reads of 100 -- would start twenty times the threads the batch needs)
+#define QM_UNPACK_TPR 8
+__global__ __launch_bounds__(256) void qm_unpack_kernel(const unsigned char* packed, const long long* off, long long n, unsigned char* seq) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long r = t / G; const int g = (int)(t - r * G);
+  const long long r = t / QM_UNPACK_TPR; const int sub = (int)(t - r * QM_UNPACK_TPR);
   if (r >= n) return;
   const long long o = off[r]; const int len = (int)(off[r + 1] - o);
-  if (4 * g >= len) return;
-  const unsigned b = packed[(o >> 2) + r + g];
   const unsigned lut = 0x54474341u;                       // 'A' 'C' 'G' 'T' from the low byte up
-  unsigned char* d = seq + o + 4 * g;
-  const int m = len - 4 * g < 4 ? len - 4 * g : 4;
-  for (int j = 0; j < m; ++j) d[j] = (unsigned char)(lut >> (8 * ((b >> (2 * j)) & 3u)));
+  for (int g = sub; 4 * g < len; g += QM_UNPACK_TPR) {
+    const unsigned b = packed[(o >> 2) + r + g];
+    unsigned char* d = seq + o + 4 * g;
+    const int m = len - 4 * g < 4 ? len - 4 * g : 4;
+    for (int j = 0; j < m; ++j) d[j] = (unsigned char)(lut >> (8 * ((b >> (2 * j)) & 3u)));
+  }
 }
-__global__ __launch_bounds__(256) void qm_unpack_exc_kernel(const qm_pack_exc* exc, long long n, unsigned char* seq) {
+// (an exception whose position lies outside the batch's characters is ignored: the list is caller-supplied)
+__global__ __launch_bounds__(256) void qm_unpack_exc_kernel(const qm_pack_exc* exc, long long n, unsigned char* seq, unsigned long long total) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < n) seq[exc[t].pos] = (unsigned char)exc[t].ch;
+  if (t < n && (unsigned long long)exc[t].pos < total) seq[exc[t].pos] = (unsigned char)exc[t].ch;
 }
 
 struct U32ToI64 { __device__ long long operator()(u32 x) const { return (long long)x; } };
@@ -437,15 +445,13 @@ hipError_t qmk_build_phfilter(const void* recs, long long n, void* filter, unsig
 }
 
 int qmk_grid_oversub(void) {
-  static int m = 0;
-  if (m == 0) { const char* e = getenv("QM_GRID_OVERSUB"); m = e && atoi(e) > 0 && atoi(e) <= 16 ? atoi(e) : 4; }
+  static const int m = [] { const char* e = getenv("QM_GRID_OVERSUB"); return e && atoi(e) > 0 && atoi(e) <= 16 ? atoi(e) : 4; }();
   return m;
 }
-// the compact -p kernels (BooPHF walked per lookup: reads differ more in work, 6 waves per SIMD) keep gaining up to twelve times the
+// the compact -p kernels (BooPHF walked per lookup: reads differ more in work) keep gaining up to twelve times the
 // resident blocks: 181.9 / 185.5 / 187.4 / 189.1 / 189.0 M pairs/s at 4 / 6 / 8 / 12 / 16 (profiles/r04/ph_oversub.txt)
 int qmk_grid_oversub_ph(void) {
-  static int m = 0;
-  if (m == 0) { const char* e = getenv("QM_GRID_OVERSUB_PH"); m = e && atoi(e) > 0 && atoi(e) <= 16 ? atoi(e) : (getenv("QM_GRID_OVERSUB") ? qmk_grid_oversub() : 12); }
+  static const int m = [] { const char* e = getenv("QM_GRID_OVERSUB_PH"); return e && atoi(e) > 0 && atoi(e) <= 16 ? atoi(e) : (getenv("QM_GRID_OVERSUB") ? qmk_grid_oversub() : 12); }();
   return m;
 }
 int qmk_resident_grid(long long nreads, int num_cu) {
@@ -614,13 +620,13 @@ hipError_t qmk_pair_write(const void* pp, hipStream_t st) {
   return hipGetLastError();
 }
 
-hipError_t qmk_unpack_reads(const unsigned char* packed, const long long* off, long long n, int G, unsigned char* seq, const void* exc, long long n_exc,
-                            hipStream_t st) {
-  if (n > 0 && G > 0) {
-    const long long threads = n * (long long)G;
-    hipLaunchKernelGGL(qm_unpack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, packed, off, n, G, seq);
+hipError_t qmk_unpack_reads(const unsigned char* packed, const long long* off, long long n, long long total_chars, unsigned char* seq, const void* exc,
+                            long long n_exc, hipStream_t st) {
+  if (n > 0) {
+    const long long threads = n * (long long)QM_UNPACK_TPR;
+    hipLaunchKernelGGL(qm_unpack_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, packed, off, n, seq);
   }
-  if (n_exc > 0) hipLaunchKernelGGL(qm_unpack_exc_kernel, dim3((unsigned)((n_exc + 255) / 256)), dim3(256), 0, st, (const qm_pack_exc*)exc, n_exc, seq);
+  if (n_exc > 0) hipLaunchKernelGGL(qm_unpack_exc_kernel, dim3((unsigned)((n_exc + 255) / 256)), dim3(256), 0, st, (const qm_pack_exc*)exc, n_exc, seq, (unsigned long long)total_chars);
   return hipGetLastError();
 }
 

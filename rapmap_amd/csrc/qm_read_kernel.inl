@@ -70,9 +70,9 @@ static hipError_t launch_reads_ns(const DevIndex& ix, const ReadBatch& B, bool c
   // A persistent grid (every wave strides over the reads) of QM_GRID_OVERSUB times the blocks that are resident at once: see
   // qmk_map_grid in qm_kernels.hip.  The occupancy of the chosen instantiation (VGPR/LDS dependent) decides the resident count.
 #define QM_LAUNCH(WPS_, F_) do {                                                                               \
-    static int nb = 0;                                                                                          \
-    if (nb == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, qm_read_kernel<NS, WPS_, F_>, 64 * WavesPerBlock<NS>::value, 0) != hipSuccess || nb < 1)) \
-      nb = WPS_;                                                                                                \
+    static const int nb = [] { int v = 0;                                                                       \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, qm_read_kernel<NS, WPS_, F_>, 64 * WavesPerBlock<NS>::value, 0) != hipSuccess || v < 1) v = WPS_; \
+      return v; }();                                                                                            \
     static const char* ov = getenv("QM_BLOCKS_PER_CU");   /* tuning knob: fewer resident blocks than the occupancy allows */ \
     long long g = (long long)num_cu * ((ov && atoi(ov) > 0 && atoi(ov) < nb) ? atoi(ov) : nb) * (((F_) & QM_F_PH) ? qmk_grid_oversub_ph() : qmk_grid_oversub());  \
     if (g > grid) g = grid;                                                                                     \
