@@ -48,6 +48,7 @@
 
 #include "../../include/qmap_mi355.h"
 #include "qm_io_internal.h"
+#include "qm_pgz.h"
 #include "qm_pack.h"
 
 namespace {
@@ -232,6 +233,7 @@ struct Src {
   // gz: blocks from the inflate thread, in order
   std::thread inflater; std::deque<Chunk*> blocks; bool inflDone = false;
   int bgzfHelpers = 0;                             // gz: > 0 for a BGZF file (mapped): that many helper threads inflate its blocks
+  int pgzThreads = 0;                              // gz: > 0 for any other gzip file (mapped): one stream inflated by that many threads (qm_pgz.h)
 };
 
 }  // namespace
@@ -825,7 +827,13 @@ void inflate_loop(qm_ingest* g, int s) {
     delete bz;
     return;
   }
-  {
+  pgz::PGz* pz = nullptr;
+  if (S.map && S.pgzThreads > 0) {
+    // one gzip stream, several threads (qm_pgz.h): guessed block starts, symbols for the unknown window, every guess checked
+    pz = new pgz::PGz();
+    if (!pz->open((const unsigned char*)S.map, S.len, S.pgzThreads)) { delete pz; pz = nullptr; }     // (not a header it knows: zlib's turn)
+  }
+  if (!pz) {
     f = gzopen(S.path.c_str(), "rb");
     if (!f) { std::lock_guard<std::mutex> lk(g->mu); set_fail(g, QM_E_IO, "cannot gzopen %s", S.path.c_str()); S.inflDone = true; S.allHanded = S.blocks.empty(); g->cvWork.notify_all(); g->cvOut.notify_all(); return; }
     gzbuffer(f, 1 << 20);
@@ -846,7 +854,7 @@ void inflate_loop(qm_ingest* g, int s) {
     size_t have = carry.size(); carry.clear();
     bool eof = false, bad = false; const char* cut = nullptr;
     while (true) {
-      const int got = gzread(f, c->data.data() + have, (unsigned)(c->data.size() - have));
+      const long got = pz ? pz->read(c->data.data() + have, c->data.size() - have) : (long)gzread(f, c->data.data() + have, (unsigned)(c->data.size() - have));
       if (got < 0) { bad = true; break; }
       have += (size_t)got;
       if ((size_t)got < c->data.size() - (have - (size_t)got)) eof = true;
@@ -869,6 +877,10 @@ void inflate_loop(qm_ingest* g, int s) {
     g->cvWork.notify_one();
   }
   if (f) gzclose(f);
+  if (pz) {
+    if (getenv("QM_INGEST_DEBUG")) fprintf(stderr, "[pgz %d] %d threads, %ld rounds: %ld stretches taken as guessed, %ld decoded again; decode %.3f stitch %.3f resolve %.3f s\n", s, S.pgzThreads, pz->rounds, pz->accepted, pz->redone, pz->tDecode, pz->tStitch, pz->tResolve);
+    delete pz;
+  }
   std::lock_guard<std::mutex> lk(g->mu);
   if (!S.inflDone) { S.inflDone = true; S.allHanded = S.blocks.empty(); }
   g->cvWork.notify_all();
@@ -888,6 +900,7 @@ int open_src(Src& S, const char* p) {
     const char* m = (const char*)mmap(nullptr, S.len, PROT_READ, MAP_PRIVATE, fd, 0);
     if (m != MAP_FAILED) {
       if (BgzfReader::is_bgzf((const unsigned char*)m, S.len)) { S.map = m; S.bgzfHelpers = 1; madvise((void*)m, S.len, MADV_SEQUENTIAL); }   // the count is set at open
+      else if (!(getenv("QM_INGEST_NO_PGZ") && atoi(getenv("QM_INGEST_NO_PGZ")) != 0)) { S.map = m; S.pgzThreads = 1; madvise((void*)m, S.len, MADV_SEQUENTIAL); }   // an ordinary gzip file: qm_pgz.h
       else munmap((void*)m, S.len);
     }
   }
@@ -935,6 +948,11 @@ int qm_ingest_open(const char* path1, const char* path2, int32_t n_threads, int6
         const char* be = getenv("QM_INGEST_BGZF_THREADS");
         int h = be && atoi(be) > 0 ? atoi(be) : (int)n_threads / g->nsrc;
         S.bgzfHelpers = h < 2 ? 2 : (h > 16 && !be ? 16 : h);
+      }
+      if (S.pgzThreads) {                                // threads that inflate an ordinary gzip file's ONE stream side by side: the workers' share, 1 .. 32 (QM_INGEST_PGZ_THREADS)
+        const char* be = getenv("QM_INGEST_PGZ_THREADS");
+        int h = be && atoi(be) > 0 ? atoi(be) : (int)n_threads / g->nsrc;
+        S.pgzThreads = h < 1 ? 1 : (h > 32 && !be ? 32 : h);
       }
       continue;
     }

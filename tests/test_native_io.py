@@ -489,3 +489,77 @@ def test_stream_batches_full_of_exceptions_travel_as_characters(synth_small, ora
         hits = np.concatenate([b.hits.copy() for b in st]); ss = st.stats(); st.close()
         assert hits.tobytes() == res.hits.tobytes()
         assert ss["packed_batches"] == 0                 # overflowed (first round) / switched off (second)
+
+
+@pytest.mark.parametrize("threads,stretch", [(1, 4096), (3, 4096), (6, 20000), (4, 1 << 22)])
+def test_ingest_engine_inflates_one_gzip_stream_on_several_threads(tmp_path, monkeypatch, threads, stretch):
+    """an ORDINARY gzip file -- one deflate stream, what `gzip` writes and the reference reads through one zlib stream
+    (src/FastxParser.cpp:229-328) -- is inflated by several threads (qm_pgz.h: guessed block starts, symbols for the unknown window,
+    every guess checked against the stretch in front, CRC-32 of every member): the same records as the plain file at every
+    compression level, with stored blocks, as several members in one file, with the guesses forced to fail; damaged and truncated
+    files are errors"""
+    import gzip
+    import random
+    import zlib
+    import rapmap_amd as ra
+    rnd = random.Random(5)
+    genome = "".join(rnd.choice("ACGT") for _ in range(200000))
+    recs1, recs2 = [], []
+    for i in range(40000):
+        L = rnd.choice([1, 31, 100, 250, 2000]) if i % 97 == 0 else 100
+        for recs, m in ((recs1, 1), (recs2, 2)):
+            a = rnd.randrange(0, len(genome) - L)
+            sq = genome[a:a + L]; q = "".join(rnd.choice("FFFFF:,#") for _ in range(L))
+            recs.append(("@SRR1.%d %d/%d\n%s\n+\n%s\n" % (i, i, m, sq, q)).encode())
+    d1, d2 = b"".join(recs1), b"".join(recs2)
+    plain = (str(tmp_path / "a.fq"), str(tmp_path / "b.fq"))
+    open(plain[0], "wb").write(d1); open(plain[1], "wb").write(d2)
+    monkeypatch.setenv("QM_INGEST_PGZ_THREADS", str(threads))
+    monkeypatch.setenv("QM_PGZ_STRETCH", str(stretch))
+
+    def read(p1, p2):
+        out = []
+        for b in _batches(p1, p2, 4096, threads=4):
+            for i in range(b.n):
+                out.append((bytes(b.names1[b.name_off1[i]:b.name_off1[i + 1]]), bytes(b.seq1[b.off1[i]:b.off1[i + 1]]),
+                            bytes(b.names2[b.name_off2[i]:b.name_off2[i + 1]]), bytes(b.seq2[b.off2[i]:b.off2[i + 1]])))
+        return out
+    want = read(*plain)
+    assert len(want) == 40000
+
+    def gz(data, path, level, members=1):
+        with open(path, "wb") as f:
+            step = (len(data) + members - 1) // members
+            for m in range(members):
+                f.write(gzip.compress(data[m * step:(m + 1) * step], compresslevel=level))
+        return path
+    for level, members in ((6, 1), (1, 1), (9, 1), (0, 1), (6, 3)):
+        g1 = gz(d1, str(tmp_path / ("a%d_%d.fq.gz" % (level, members))), level, members)
+        g2 = gz(d2, str(tmp_path / ("b%d_%d.fq.gz" % (level, members))), level, members)
+        assert read(g1, g2) == want, (level, members)
+    g1 = str(tmp_path / "a6_1.fq.gz"); g2 = str(tmp_path / "b6_1.fq.gz")
+    # a header with a file name and a comment, and trailing garbage behind the last member (zlib's gzread ignores it)
+    raw = open(g1, "rb").read()
+    fancy = str(tmp_path / "fancy.fq.gz")
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    body = co.compress(d1) + co.flush()
+    import struct
+    open(fancy, "wb").write(b"\x1f\x8b\x08\x18\x00\x00\x00\x00\x00\x03" + b"reads_1.fastq\x00" + b"a comment\x00" + body +
+                            struct.pack("<II", zlib.crc32(d1) & 0xffffffff, len(d1) & 0xffffffff) + b"\x00" * 1000)
+    assert read(fancy, g2) == want
+    # the single zlib stream gives the same
+    monkeypatch.setenv("QM_INGEST_NO_PGZ", "1")
+    assert read(g1, g2) == want
+    monkeypatch.delenv("QM_INGEST_NO_PGZ")
+    # damaged payload (CRC-32 / symbol check), a file cut in the middle, a wrong CRC in the trailer
+    bad = bytearray(raw); bad[len(bad) // 2] ^= 0x55
+    p = str(tmp_path / "bad.fq.gz"); open(p, "wb").write(bytes(bad))
+    with pytest.raises(ra.QmError):
+        read(p, g2)
+    p = str(tmp_path / "cut.fq.gz"); open(p, "wb").write(raw[:len(raw) // 2])
+    with pytest.raises(ra.QmError):
+        read(p, g2)
+    bad = bytearray(raw); bad[-6] ^= 1
+    p = str(tmp_path / "crc.fq.gz"); open(p, "wb").write(bytes(bad))
+    with pytest.raises(ra.QmError):
+        read(p, g2)
