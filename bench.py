@@ -413,6 +413,7 @@ def main():
     ap.add_argument("--cache", default=os.environ.get("QMAP_BENCH_CACHE", "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"))
     ap.add_argument("--e2e-dir", default=os.environ.get("QMAP_BENCH_E2E_DIR", "/tmp"), help="where the end_to_end leg puts its FASTQ files")
     ap.add_argument("--e2e-threads", type=int, default=24, help="ingest workers of the end_to_end leg (the engine alone peaks at 16-32 on this host, pinned to the socket that holds the files: profiles/r04/ingest_after_pin.log)")
+    ap.add_argument("--gz-leg", type=int, default=0, help="N=1: also map the first GZ_LEG pairs from ordinary `gzip -6` files (end_to_end_gzip; opt-in: writing the files takes about a minute per 4 M pairs)")
     ap.add_argument("--e2e-copies", type=int, default=4, help="the end_to_end leg's FASTQ files hold the batch this many times (4 x 10 M = 40 M pairs)")
     ap.add_argument("--compat-pairs", type=int, default=8_000_000, help="pairs of the batch the compat_face leg runs through the reference's call surface")
     args = ap.parse_args()
@@ -659,6 +660,35 @@ def side_legs(out, args, ra, qi, mp, opts, s1, s2, off, n, L, dev_id, cores):
             "without_read_names": {"value": round(ne / runs[False][0] / 1e6, 3), "seconds_total": round(runs[False][0], 4)},
             "what": "qm_stream_*: ingest workers parse the files chunk-parallel and pack batches straight into pinned slots, device contexts "
                     "sharing the index replica upload / map / download, hits handed out in pinned memory in input order; stream open to last batch"}
+        if getattr(args, "gz_leg", 0):
+            # (3) the same through ORDINARY gzip files (one deflate stream each, `gzip -6`: what real callers have): the
+            # first gz_leg pairs of the batch, inflated by several threads per file (rapmap_amd/csrc/qm_pgz.h), next to the single zlib
+            # stream the reference reads them with (QM_INGEST_NO_PGZ=1).  Opt-in: gzip takes a minute to WRITE such files.
+            import subprocess
+            ng = min(n, int(args.gz_leg))
+            g1 = os.path.join(d_e, "g1.fq"); g2 = os.path.join(d_e, "g2.fq")
+            _syn.write_fastq(g1, hs1[: ng * L], ng, L, 1); _syn.write_fastq(g2, hs2[: ng * L], ng, L, 2)
+            ps = [subprocess.Popen("gzip -6 -f %s" % x, shell=True) for x in (g1, g2)]
+            assert all(q.wait() == 0 for q in ps)
+            leg = {}
+            for kind, env in (("several_threads_per_file", {}), ("one_zlib_stream_per_file", {"QM_INGEST_NO_PGZ": "1"})):
+                os.environ.update(env)
+                best = None
+                for _ in range(2):
+                    t = time.perf_counter()
+                    st = ra.MappedStream(qi, g1 + ".gz", g2 + ".gz", opts=opts, device=dev_id, batch_units=batch, threads=max(thr, min(48, cores)), ph_compact=args.ph_compact, names=False)
+                    nh_g = sum(b_.n_hits for b_ in st)
+                    dtg = time.perf_counter() - t
+                    st.close()
+                    best = dtg if best is None or dtg < best else best
+                for k_ in env:
+                    del os.environ[k_]
+                leg[kind] = {"value": round(ng / best / 1e6, 3), "seconds": round(best, 4), "hits": int(nh_g)}
+            leg.update(unit="M read-pairs/s", pairs=ng, input="two `gzip -6` files, %d MB together" % ((os.path.getsize(g1 + ".gz") + os.path.getsize(g2 + ".gz")) >> 20),
+                       same_hits=leg["several_threads_per_file"]["hits"] == leg["one_zlib_stream_per_file"]["hits"])
+            out["end_to_end_gzip"] = leg
+            for x in (g1 + ".gz", g2 + ".gz"):
+                os.remove(x)
     finally:
         for f_ in (f1, f2):
             if os.path.exists(f_):

@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """profiles/pmc_traffic.json from the passes of profiles/r05/pmc_all.sh.
-usage: python profiles/r05/make_pmc_traffic.py gpurun_out/<dir> <tag>   (copies the three summaries to profiles/r05/ as well)"""
+usage (on the GPU box, behind pmc_all.sh): python profiles/r05/make_pmc_traffic.py gpurun_out/<dir> <tag> [outdir]
+writes pmc_traffic.json and the three summaries (named as they are committed under profiles/r05/) into outdir (default: the
+repository's profiles/ and profiles/r05/); with an outdir under gpurun_out/ they travel back and are copied into place by hand"""
 import collections, csv, glob, json, os, shutil, sys
 
 src, tag = sys.argv[1], sys.argv[2]
+outdir = sys.argv[3] if len(sys.argv) > 3 else None
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 N = 10_000_000
 
@@ -36,7 +39,7 @@ def hbm(c):
 out = {}
 names = {"dense": "kernel_stats_and_pmc_dense_%s.txt", "ph_compact": "kernel_stats_and_pmc_ph_compact_%s.txt", "sel": "kernel_stats_and_pmc_sel_%s.txt"}
 for key in ("dense", "ph_compact", "sel"):
-    shutil.copy(os.path.join(src, key, "summary.txt"), os.path.join(ROOT, "profiles", "r05", names[key] % tag))
+    shutil.copy(os.path.join(src, key, "summary.txt"), os.path.join(outdir or os.path.join(ROOT, "profiles", "r05"), names[key] % tag))
 for key in ("dense", "ph_compact"):
     C, _ = counters(key); T = trace_ms(key)
     k = [x for x in C if "qm_lean_kernel" in x][0]
@@ -68,6 +71,6 @@ out["sel"] = {"hbm_bytes_per_launch": sum(hbm(C[k]) for k in stageA), "step_hbm_
               "kernel_ms_trace": {k: {"calls_in_4_steps": T[k][0], "avg_ms": T[k][1]} for k in T if "build_" not in k},
               "note": "FETCH_SIZE + WRITE_SIZE (KiB, separate --pmc passes) per dispatch x dispatches per step of every kernel of an unsplit -s step of 10 M pairs: " + "; ".join(parts),
               "source": "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE of these kernels on this workload (r05, %s); not re-measured by the run that prints it" % f}
-json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(outdir or os.path.join(ROOT, "profiles"), "pmc_traffic.json"), "w"), indent=1)
 for k, v in out.items():
     print(k, "%.2f GB" % (v["hbm_bytes_per_launch"] / 1e9), "sectors/pair %.1f" % v["sectors_per_pair"], v.get("per_pair"), v.get("step_hbm_bytes_per_launch"))

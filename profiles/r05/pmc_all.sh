@@ -9,3 +9,6 @@ bash profiles/r05/run_profile.sh $OUT/dense > /dev/null 2>&1
 bash profiles/r05/run_profile.sh $OUT/ph_compact --perfect-hash --ph-compact > /dev/null 2>&1
 QM_SPLIT=1 bash profiles/r05/run_profile.sh $OUT/sel --sel-aln > /dev/null 2>&1
 for d in dense ph_compact sel; do echo "== $d"; grep -A4 "^\"Name\"" $OUT/$d/summary.txt | cut -c1-140; done
+# the JSON and the summaries that are committed, made here (the per-dispatch csv files are too large to travel back)
+mkdir -p $OUT/commit && python profiles/r05/make_pmc_traffic.py $OUT ${2:-r05} $OUT/commit
+for d in dense ph_compact sel; do find $OUT/$d -name "*.csv" -delete; done
