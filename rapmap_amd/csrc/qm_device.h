@@ -51,7 +51,8 @@ void qmk_sel_dyn_bind(void* host_struct, void* dev_base, long long n);
 hipError_t qmk_collect_slow(const unsigned int* lcnt, long long nreads, long long* q, unsigned long long* count, hipStream_t st);
 hipError_t qmk_collect_lean(const unsigned int* lcnt, long long nreads, long long* q, unsigned long long* count, hipStream_t st);
 hipError_t qmk_sel_slots(const void* pair_batch, hipStream_t st);
-hipError_t qmk_sel_plan(const void* pair_batch, const void* sel_batch, hipStream_t st);
+hipError_t qmk_sel_plan(const void* pair_batch, const void* sel_batch, int num_cu, hipStream_t st);
+size_t qmk_sel_side_bytes(void);
 hipError_t qmk_sel_align_finish(const void* pair_batch, const void* sel_batch, int num_cu, hipStream_t st);
 size_t qmk_sel_task_bytes(void);
 size_t qmk_sel_gmem_rows_bytes(int num_cu);   // device memory of qm_sel_align_gmem_kernel's alignment blocks (long reads under a band beyond 97)

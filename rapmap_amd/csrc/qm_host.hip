@@ -110,7 +110,7 @@ struct qm_ctx {
   void* d_saext = nullptr;                                  // the replica's SaExt table
   hipStream_t planStream = nullptr;                         // -s: the plan kernels of the later chunks, under the ksw2 kernel of the earlier ones
   hipEvent_t evPlan[QM_SEL_CHUNKS_B + 1] = {};              // ... [i]: chunk i planned; [last]: the plan stream may start
-  u64* d_ntk = nullptr;                                     // ... one task counter per chunk
+  u64* d_ntk = nullptr;                                     // ... per chunk: a task counter, then (at QM_SEL_CHUNKS_B + i) a counter of alignment questions
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evA = nullptr, evB = nullptr, evCopy = nullptr, evStage[2] = {nullptr, nullptr};
   unsigned char* h_stage = nullptr;                        // pinned, 2 x 32 MB: result download (qm_fetch_hits)
   // index replica
@@ -146,8 +146,8 @@ struct qm_ctx {
   long long* d_slowq = nullptr; int64_t capSlowq = 0;          // -s slow pass: queue, per-wave scratch descriptors and their memory
   unsigned char* d_dyn = nullptr; int64_t capDyn = 0; unsigned char* d_dynmem = nullptr; int64_t capDynMem = 0;
   long long* d_toff = nullptr; int64_t capToff = 0;
-  qm_hit* d_tmp = nullptr; int64_t capTmp = 0; u64* d_tkeys = nullptr; int64_t capTkeys = 0; int* d_tsc = nullptr; int64_t capTsc = 0;
-  int* d_tref = nullptr; int64_t capTref = 0; int* d_tcix = nullptr; int64_t capTcix = 0; unsigned char* d_tasks = nullptr; int64_t capTasks = 0;
+  qm_hit* d_tmp = nullptr; int64_t capTmp = 0; unsigned char* d_sides = nullptr; int64_t capSides = 0; int* d_tsc = nullptr; int64_t capTsc = 0;
+  int* d_tref = nullptr; int64_t capTref = 0; u64* d_torder = nullptr; int64_t capTorder = 0; unsigned char* d_tasks = nullptr; int64_t capTasks = 0;
   // qm_fetch_stages: CSR offsets of the per-read interval records / list words (scans queued behind stage A), their totals
   // (pinned: they arrive with stage B's synchronisation), the compacted copies
   long long* d_ivcsr = nullptr; int64_t capIvcsr = 0; long long* d_lcsr = nullptr; int64_t capLcsr = 0;
@@ -500,7 +500,7 @@ int qm_ctx_destroy(qm_ctx* c) {
   }
   void* ptrs[] = {c->d_cnt, c->d_lcnt, c->d_loff, c->d_lists, c->d_hits, c->d_offs,
                   c->d_scal, c->d_skip, c->d_gscr, c->d_scanTmp, c->d_seq1, c->d_seq2, c->d_off1, c->d_off2, c->d_iv, c->d_ivcnt, c->d_ivoff, c->d_found, c->d_tooMany, c->d_ivIn, c->d_ivInOff, c->d_lenIn, c->d_foundIn,
-                  c->d_selscr, c->d_kswRows, c->d_pk1, c->d_pk2, c->d_exc1, c->d_exc2, c->d_slowq, c->d_todoq, c->d_todoq2, c->d_dyn, c->d_dynmem, c->d_toff, c->d_tmp, c->d_tkeys, c->d_tsc, c->d_tref, c->d_tcix, c->d_tasks};
+                  c->d_selscr, c->d_kswRows, c->d_pk1, c->d_pk2, c->d_exc1, c->d_exc2, c->d_slowq, c->d_todoq, c->d_todoq2, c->d_dyn, c->d_dynmem, c->d_toff, c->d_tmp, c->d_sides, c->d_tsc, c->d_tref, c->d_torder, c->d_tasks};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
@@ -548,7 +548,7 @@ int qm_ctx_create_ex(const qm_index* ix, int device_id, uint32_t flags, qm_ctx**
   CK(hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
   CK(hipStreamCreateWithFlags(&c->planStream, hipStreamNonBlocking));
   for (hipEvent_t& e : c->evPlan) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  CK(hipMalloc((void**)&c->d_ntk, QM_SEL_CHUNKS_B * sizeof(u64)));
+  CK(hipMalloc((void**)&c->d_ntk, 2 * QM_SEL_CHUNKS_B * sizeof(u64)));
   CK(hipEventCreateWithFlags(&c->evCopy, hipEventDisableTiming));
   CK(hipEventCreate(&c->ev0)); CK(hipEventCreate(&c->ev1)); CK(hipEventCreate(&c->evA)); CK(hipEventCreate(&c->evB));
   CK(hipMalloc((void**)&c->d_scal, QM_SC_WORDS * sizeof(u64)));
@@ -1090,11 +1090,10 @@ static int run_stage_b(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
     HIPCHK(hipStreamSynchronize(c->stream));
     cslot[K] = slots;
     if ((rc = ensure(c->d_tmp, c->capTmp, slots + 1))) return rc;
-    if ((rc = ensure(c->d_tkeys, c->capTkeys, 2 * slots + 2))) return rc;
     if ((rc = ensure(c->d_tsc, c->capTsc, 2 * slots + 2))) return rc;
     SelBatch A; memset(&A, 0, sizeof(A));
     A.seq1 = (const unsigned char*)d_seq1; A.seq2 = (const unsigned char*)d_seq2; A.text = c->d_text;
-    A.txp_off = c->d_txpOff; A.txp_len = c->d_txpLen; A.tmp = c->d_tmp; A.toff = c->d_toff; A.tkeys = c->d_tkeys; A.tsc = c->d_tsc;
+    A.txp_off = c->d_txpOff; A.txp_len = c->d_txpLen; A.tmp = c->d_tmp; A.toff = c->d_toff; A.tsc = c->d_tsc;
     A.match = o->match_score; A.mismatch = o->mismatch_penalty; A.gap_open = o->gap_open; A.gap_extend = o->gap_extend;
     A.long_reads = rq.longReads ? 1 : 0;
     if (rq.longReads && !rq.mergeOnly && sel_ksw_ring_slots(o->dp_bandwidth) > 128) {
@@ -1111,22 +1110,28 @@ static int run_stage_b(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
     } else {
       // plan (per unit) -> ksw2 extension alignments, four per wavefront, any band -> finish (per unit)
       if ((rc = ensure(c->d_tref, c->capTref, 2 * slots + 2))) return rc;
-      if ((rc = ensure(c->d_tcix, c->capTcix, 2 * slots + 2))) return rc;
       if ((rc = ensure(c->d_tasks, c->capTasks, (2 * slots + 2 * K + 2) * (int64_t)qmk_sel_task_bytes()))) return rc;
-      A.tref = c->d_tref; A.tcix = c->d_tcix;
-      HIPCHK(hipMemsetAsync(c->d_ntk, 0, QM_SEL_CHUNKS_B * sizeof(u64), c->stream));
-      // The plan kernel is one divergent thread per unit -- 4 ms of instructions, 29 ms of latency on 10 M units -- and the
-      // ksw2 kernel is bound by VALU issue: the plans of chunks 1.. run on a stream of their own while the alignments of
-      // the chunks before them are computed.
+      if ((rc = ensure(c->d_sides, c->capSides, (2 * slots + 2 * K + 2) * (int64_t)qmk_sel_side_bytes()))) return rc;
+      if ((rc = ensure(c->d_torder, c->capTorder, 2 * slots + 2 * K + 2))) return rc;
+      A.tref = c->d_tref;
+      HIPCHK(hipMemsetAsync(c->d_ntk, 0, 2 * QM_SEL_CHUNKS_B * sizeof(u64), c->stream));
+      // The plan (three kernels: per unit, per alignment question, per question) waits on scattered loads and the ksw2 kernel is
+      // bound by VALU issue: the plans of chunks 1.. run on a stream of their own while the alignments of the chunks before
+      // them are computed.
       HIPCHK(hipEventRecord(c->evPlan[QM_SEL_CHUNKS_B], c->stream));
       HIPCHK(hipStreamWaitEvent(c->planStream, c->evPlan[QM_SEL_CHUNKS_B], 0));
       SelBatch Ak[QM_SEL_CHUNKS_B];
+      static const bool serial = [] { const char* e = getenv("QM_SEL_SERIAL"); return e && atoi(e) != 0; }();   // (profiling: no plan stream, every kernel's duration is its own)
+      hipStream_t planStream = K > 1 && !serial ? c->planStream : c->stream;
       for (int i = 0; i < K; ++i) {
         Ak[i] = A; Ak[i].u0 = cu[i]; Ak[i].u1 = cu[i + 1];
         Ak[i].tasks = (SelTask*)(c->d_tasks + (size_t)(2 * cslot[i] + 2 * i) * qmk_sel_task_bytes());   // at most two tasks per slot
         Ak[i].ntasks = c->d_ntk + i;
-        HIPCHK(qmk_sel_plan(&P, &Ak[i], K > 1 ? c->planStream : c->stream));
-        if (K > 1) HIPCHK(hipEventRecord(c->evPlan[i], c->planStream));
+        Ak[i].sides = (SelSide*)(c->d_sides + (size_t)(2 * cslot[i] + 2 * i) * qmk_sel_side_bytes());       // ... and at most two questions
+        Ak[i].nsides = c->d_ntk + QM_SEL_CHUNKS_B + i;
+        Ak[i].torder = c->d_torder + (size_t)(2 * cslot[i] + 2 * i);
+        HIPCHK(qmk_sel_plan(&P, &Ak[i], c->numCU, planStream));
+        if (K > 1) HIPCHK(hipEventRecord(c->evPlan[i], planStream));
       }
       for (int i = 0; i < K; ++i) {
         if (K > 1) HIPCHK(hipStreamWaitEvent(c->stream, c->evPlan[i], 0));
@@ -1141,6 +1146,15 @@ static int run_stage_b(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
   HIPCHK(hipMemcpyAsync(&total, c->d_offs + n, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  if (o->sel_aln && !rq.mergeOnly) {
+    static const bool dbg = [] { const char* e = getenv("QM_SEL_DEBUG"); return e && atoi(e) != 0; }();
+    if (dbg) {
+      u64 h[2 * QM_SEL_CHUNKS_B];
+      HIPCHK(hipMemcpy(h, c->d_ntk, sizeof(h), hipMemcpyDeviceToHost));
+      u64 nt = 0, nsd = 0; for (int i = 0; i < QM_SEL_CHUNKS_B; ++i) { nt += h[i]; nsd += h[QM_SEL_CHUNKS_B + i]; }
+      fprintf(stderr, "[qm -s] %lld units: %llu alignment questions beyond PERFECT chains, %llu ksw2 alignments\n", (long long)n, (unsigned long long)nsd, (unsigned long long)nt);
+    }
+  }
   if (rq.join) {
     long long b = 0; qm_hit* dst = nullptr;
     if ((rc = rq.join->arrive(rq.part, total, b, dst))) return rc;

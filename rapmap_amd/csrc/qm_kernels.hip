@@ -179,17 +179,44 @@ QM_DEV void sel_flush_counters(unsigned long long* sc, const UnitCounters& uc, u
   __syncthreads();
   if (threadIdx.x < 6 && sc[threadIdx.x]) atomicAdd((unsigned long long*)&counters[threadIdx.x], sc[threadIdx.x]);
 }
-#ifndef QM_PLAN_WPS
-#define QM_PLAN_WPS 4     // waves per SIMD the plan kernel is built for (100 VGPRs; 6 / 8 spill 30 / 91 of them: profiles/r05/plan_wps_ab.txt)
-#endif
-__global__ __launch_bounds__(256, QM_PLAN_WPS) void qm_sel_plan_kernel(PairBatch P, SelBatch A) {
+// plan, step 1: a thread per unit; the wavefront reserves the room of its units' questions with one atomic
+__global__ __launch_bounds__(256) void qm_sel_sides_kernel(PairBatch P, SelBatch A) {
   __shared__ unsigned long long sc[6];
   if (threadIdx.x < 6) sc[threadIdx.x] = 0;
   __syncthreads();
   const long long u = A.u0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
   UnitCounters uc = {0, 0, 0, 0, 0, 0};
-  if (u < A.u1) sel_unit_plan(P, A, u, &uc);
+  const int m = u < A.u1 ? sel_unit_sides_count(P, A, u, &uc) : 0;
+  const int lane = (int)(threadIdx.x & 63);
+  int incl = m;
+  for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+  const int total = __shfl(incl, 63);
+  unsigned long long base = 0;
+  if (lane == 63 && total > 0) base = atomicAdd((unsigned long long*)A.nsides, (unsigned long long)total);
+  base = (unsigned long long)__shfl((long long)base, 63);
+  if (m > 0) sel_unit_sides_write(P, A, u, (long long)base + incl - m);
   sel_flush_counters(sc, uc, P.counters);
+}
+// plan, step 2: sixteen lanes per question -- its 128 characters of read and of target in one round of loads
+struct SelRed16 {
+  QM_DEV int add(int v) const { v += __shfl_xor(v, 8, 16); v += __shfl_xor(v, 4, 16); v += __shfl_xor(v, 2, 16); v += __shfl_xor(v, 1, 16); return v; }
+  QM_DEV u64 bxor(u64 v) const {
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    for (int d = 8; d > 0; d >>= 1) { lo ^= (unsigned)__shfl_xor((int)lo, d, 16); hi ^= (unsigned)__shfl_xor((int)hi, d, 16); }
+    return (u64)lo | ((u64)hi << 32);
+  }
+};
+__global__ __launch_bounds__(256) void qm_sel_score_kernel(PairBatch P, SelBatch A) {
+  const unsigned long long n = *A.nsides;
+  const int l = (int)(threadIdx.x & 15);
+  const SelRed16 red;
+  for (unsigned long long x = (unsigned long long)blockIdx.x * 16 + (threadIdx.x >> 4); x < n; x += (unsigned long long)gridDim.x * 16)
+    sel_side_score<16>(P, A, (long long)x, l, red);
+}
+// plan, step 3: a thread per question
+__global__ __launch_bounds__(256) void qm_sel_dedupe_kernel(SelBatch A) {
+  const unsigned long long n = *A.nsides;
+  for (unsigned long long x = (unsigned long long)blockIdx.x * 256 + threadIdx.x; x < n; x += (unsigned long long)gridDim.x * 256) sel_side_dedupe(A, (long long)x);
 }
 // one row of 16 lanes per ksw2 alignment, four alignments per wavefront (sel_ksw_extz2_rows); RING = column slots per
 // alignment, chosen from --dpBandwidth at launch (sel_ksw_ring_slots)
@@ -560,12 +587,19 @@ hipError_t qmk_sel_slots(const void* pp, hipStream_t st) {
   return hipGetLastError();
 }
 // the three steps of a chunk of units [A.u0, A.u1): plan (per unit) -> ksw2 (four alignments per wavefront) -> finish (per unit)
-hipError_t qmk_sel_plan(const void* pp, const void* ap, hipStream_t st) {
+hipError_t qmk_sel_plan(const void* pp, const void* ap, int num_cu, hipStream_t st) {
   const PairBatch& P = *(const PairBatch*)pp; const SelBatch& A = *(const SelBatch*)ap;
   if (A.u1 <= A.u0) return hipSuccess;
-  hipLaunchKernelGGL(qm_sel_plan_kernel, dim3((unsigned)((A.u1 - A.u0 + 255) / 256)), dim3(256), 0, st, P, A);
+  const long long nu = A.u1 - A.u0;
+  hipLaunchKernelGGL(qm_sel_sides_kernel, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, st, P, A);
+  // the two flat steps stride over a list whose length only the device knows: grids that fill the chip, no larger than the units could need
+  const long long want = (long long)num_cu * 16;
+  const unsigned gs = (unsigned)(nu / 8 + 1 < want ? nu / 8 + 1 : want), gd = (unsigned)(nu / 128 + 1 < want ? nu / 128 + 1 : want);
+  hipLaunchKernelGGL(qm_sel_score_kernel, dim3(gs), dim3(256), 0, st, P, A);
+  hipLaunchKernelGGL(qm_sel_dedupe_kernel, dim3(gd), dim3(256), 0, st, A);
   return hipGetLastError();
 }
+size_t qmk_sel_side_bytes(void) { return sizeof(SelSide); }
 hipError_t qmk_sel_align_finish(const void* pp, const void* ap, int num_cu, hipStream_t st) {
   const PairBatch& P = *(const PairBatch*)pp; const SelBatch& A = *(const SelBatch*)ap;
   if (A.u1 <= A.u0) return hipSuccess;

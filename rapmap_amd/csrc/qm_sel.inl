@@ -566,14 +566,14 @@ struct SelBatch {                    // launch arguments of the -s kernels (on t
   const unsigned char* seq1; const unsigned char* seq2;
   const unsigned char* text; const u32* txp_off; const int* txp_len;
   qm_hit* tmp; const long long* toff;          // per-unit slots for jointHits before the filter
-  u64* tkeys; int* tsc;                        // alignment cache entries, two per slot (left / right)
+  int* tsc;                                    // score per slot-side (left / right)
   int* tref;                                   // per slot-side: -1 score is final / pending in tsc, <= -2 copy of unit-local entry -(ref)-2
-  int* tcix;                                   // alignment-cache entries: unit-local entry a key belongs to
-  struct SelTask* tasks; u64* ntasks;          // ksw2 work list
+  struct SelSide* sides; u64* nsides;          // the chunk's alignment questions (everything but PERFECT chains)
+  struct SelTask* tasks; u64* torder; u64* ntasks;   // ksw2 work: tasks[x] of question x, walked in the order of torder[0 .. *ntasks) (null: tasks[0 ..) as they are)
   long long u0, u1;                            // the units [u0, u1) this launch of plan / finish covers (the batch goes through
                                                // plan -> align -> finish in chunks: the plan of chunk i+1 runs under the align of chunk i)
   int match, mismatch, gap_open, gap_extend, bandwidth, hard_filter, policy;
-  int no_diag;                                 // 1: queue every REGULAR alignment (profiling: QM_SEL_NO_DIAG; sel_plan_side answers the one-mismatch ones itself)
+  int no_diag;                                 // 1: queue every REGULAR alignment (profiling: QM_SEL_NO_DIAG; sel_side_score answers the one-mismatch ones itself)
   int long_reads;                              // the batch holds reads beyond QM_MAX_READ_LEN: the long editions of the alignment kernel
   void* ksw_rows;                              // long reads under a band beyond 97: the alignment blocks in device memory (KswRowT<QM_KSW_RING_GMEM, QM_KSW_MAXLEN_LONG>, four per wavefront)
   int short_len;                               // longest read of the batch that is not beyond QM_MAX_READ_LEN (0: unknown): reads of up to 128
@@ -1173,155 +1173,205 @@ QM_DEV int sel_unit_merge(const PairBatch& P, const SelBatch& A, long long u, Un
 // scores; alignments that have to be run become tasks, alignment-cache hits become references to the entry that owns the
 // score), align (a row of 16 lanes per task), finish (per unit: gate, filter, counters).
 
-// the part of getAlnScore around the alignment itself: returns true when the score is known now (in `score`);
-// otherwise a task was queued or `ref` points at the cache entry whose score will be this one's.
-QM_DEV void sel_plan_side(const SelBatch& A, long long u, long long gbase, int local, int side, u32 tid, int pos,
-                          const unsigned char* read, int readLen, bool fwd, const unsigned char* tseq, int tlen, int maxScore,
-                          int chainStat, bool multiMapping, u64* ckeys, int* cidx, int& cn) {
-  const int LOWEST = (int)0x80000000;
-  const long long g = gbase + local;
-  A.tref[g] = -1;
-  if (chainStat == QM_CS_PERFECT) { A.tsc[g] = maxScore; return; }
-  int s = LOWEST;
-  int roff = 0, rlen = readLen;
-  const bool invalidStart = pos < 0;
-  const bool invalidEnd = pos + rlen >= tlen;
-  if (invalidStart) { roff = -pos; rlen += pos; pos = 0; }
-  if ((invalidStart || invalidEnd) && (A.policy == 1 || A.policy == 2)) { A.tsc[g] = s; return; }
-  if (pos < tlen) {
-    const bool doUngapped = !invalidStart && chainStat == QM_CS_UNGAPPED;
-    const u32 buf = doUngapped ? 0u : 20u;
-    const u32 lnobuf = (u32)(tlen - pos), lbuf = (u32)(rlen + (int)buf);
-    const bool useBuf = lbuf < lnobuf;
-    const u32 tlen1 = lbuf < lnobuf ? lbuf : lnobuf;
-    const unsigned char* tseq1 = tseq + pos;
-    const u32 keyLen = useBuf ? tlen1 - buf : tlen1;
-    u64 key = 0; bool didHash = false;
-    auto hashKey = [&]() {
-      u64 h = hash_mix((u64)keyLen + 0x9E3779B97F4A7C15ULL);
-      u32 i = 0;
-      for (; i < keyLen; i += 8) {
-        u64 w = 0;
-        if (i + 8 <= keyLen) w = load_u64_unaligned(tseq1 + i);      // (little endian: the same word as the byte loop's)
-        else for (u32 t = 0; t < 8 && i + t < keyLen; ++t) w |= (u64)tseq1[i + t] << (8 * t);
-        h = hash_mix(h ^ w);
-      }
-      return h;
-    };
-    if (cn > 0) {
-      key = hashKey(); didHash = true;
-      for (int i = 0; i < cn; ++i) if (ckeys[i * 2] == key) { A.tref[g] = -(cidx[i * 2]) - 2; A.tsc[g] = LOWEST; return; }
-    }
-    if (doUngapped) {
-      const int tlen1s = (int)tlen1;
-      const int alnLen = rlen < tlen1s ? rlen : tlen1s;
-      int sc = 0;
-      int i = 0;
-      for (; i + 8 <= alnLen; i += 8) {                             // eight characters per pair of loads
-        const u64 tw = load_u64_unaligned(tseq1 + i);
-        const u64 rw = fwd ? load_u64_unaligned(read + roff + i) : load_u64_unaligned(read + (readLen - 1 - (roff + i) - 7));
-        for (int t = 0; t < 8; ++t) {
-          unsigned char c1 = (unsigned char)(tw >> (8 * t));
-          const unsigned char c2 = fwd ? (unsigned char)(rw >> (8 * t)) : rc_char((unsigned char)(rw >> (8 * (7 - t))));
-          c1 = (c1 == 'N' || c2 == 'N') ? c2 : c1;
-          sc += (c1 == c2) ? A.match : A.mismatch;
-        }
-      }
-      for (; i < alnLen; ++i) {
-        unsigned char c1 = tseq1[i], c2 = sel_read_char(read, readLen, fwd, roff + i);
-        c1 = (c1 == 'N' || c2 == 'N') ? c2 : c1;
-        sc += (c1 == c2) ? A.match : A.mismatch;
-      }
-      s = sc;
-    } else {
-      // Round 5: the alignment whose answer is known without running it.  The extension alignment starts at (0, 0) and its score is
-      // max(mqe, mte) (SelectiveAlignmentUtils.hpp:355-356, score only, no drop-off: RapMapSAMapper.cpp:198-204).  With the target
-      // at least as long as the query, every path that opens a gap scores at most Smax - (q + e) -- Smax: every query character
-      // at its best score, a match or 0 for an N -- whether it ends in the query's last row or in the target's last column (those
-      // skip target characters); the gapless path from (0, 0) lies in every band and ends in the last row.  So when that path
-      // loses no more than q + e against Smax -- one mismatch under the default scores, i.e. half of the alignments a batch
-      // of 1 %-error reads asks for -- its score IS the alignment's, and no task is queued.  (Not with --dpBandwidth 0: that band's
-      // odd anti-diagonals are empty and the kernel stops at the second one.  Scores small enough for the 8-bit kernel to be exact; the bench's -s leg and the parity tests hold every such score against the oracle's ksw2.)
-      bool known = false;
-      {
-        int a = (signed char)A.match, b = (signed char)A.mismatch;
-        a = a < 0 ? -a : a; b = b > 0 ? -b : b;
-        const int qe = (int)(signed char)A.gap_open + (int)(signed char)A.gap_extend;
-        if (!A.no_diag && A.bandwidth != 0 && (int)tlen1 >= rlen && rlen > 0 && a >= 1 && (signed char)A.gap_open >= 0 && (signed char)A.gap_extend >= 1 && a - b + qe <= 96) {
-          int U = 0, loss = 0, i = 0;
-          auto eight = [&](u64 tw, u64 rw) {
-            for (int t = 0; t < 8; ++t) {
-              const unsigned char ct = sel_nt4((unsigned char)(tw >> (8 * t)));
-              const unsigned char cq = sel_nt4(fwd ? (unsigned char)(rw >> (8 * t)) : rc_char((unsigned char)(rw >> (8 * (7 - t)))));
-              const int mx = cq < 4 ? a : 0, sc = (ct < 4 && cq < 4) ? (ct == cq ? a : b) : 0;
-              U += sc; loss += mx - sc;
-            }
-          };
-          auto rword = [&](int at) { return fwd ? load_u64_unaligned(read + roff + at) : load_u64_unaligned(read + (readLen - 1 - (roff + at) - 7)); };
-          // (four words per trip with their loads issued together was measured slower: 10.3 -> 13.0 ms per chunk -- the kernel's
-          // occupancy pays for the registers)
-          for (; i + 8 <= rlen && loss <= qe; i += 8) eight(load_u64_unaligned(tseq1 + i), rword(i));
-          for (; i < rlen && loss <= qe; ++i) {
-            const unsigned char ct = sel_nt4(tseq1[i]), cq = sel_nt4(sel_read_char(read, readLen, fwd, roff + i));
-            const int mx = cq < 4 ? a : 0, sc = (ct < 4 && cq < 4) ? (ct == cq ? a : b) : 0;
-            U += sc; loss += mx - sc;
-          }
-          if (i >= rlen && loss <= qe) { s = U; known = true; }
-        }
-      }
-      if (!known) {
-        const u64 ti = atomic_add_u64(A.ntasks, 1ULL);
-        SelTask t; t.rd = read; t.tx = tseq1; t.gslot = (int)g; t.rl = readLen; t.roff = roff; t.rlen = rlen; t.tlen1 = (int)tlen1; t.fwd = fwd ? 1 : 0;
-        A.tasks[ti] = t;
-      }
-    }
-    if (multiMapping) {
-      if (!didHash) key = hashKey();
-      ckeys[cn * 2] = key; cidx[cn * 2] = local; cn++;
-    }
+// Round 5: the plan is three flat steps instead of one divergent thread per unit (which spent 47 ms per 10 M pairs waiting
+// on thirteen dependent rounds of scattered 8-byte loads per alignment question, with its lanes idling behind the unit that has
+// the most hits):
+//   sides   (per unit)  merge; a question per hit and mate that is not a PERFECT chain goes on the chunk's list of SelSide
+//   score   (16 lanes per question on the device, 1 in the emulation)  everything of getAlnScore but ksw2: the geometry, the
+//           alignment-cache key of the target window, the ungapped score, the alignment whose answer is known without running
+//           it; a question that needs ksw2 leaves its SelTask in tasks[x]
+//   dedupe  (per question)  the alignment cache: the first earlier question of the unit and mate with the same key owns the score
+//           (a later one points at it); owners that need ksw2 put their index on the order list the alignment kernel walks
+struct SelSide { long long u; long long g; u64 key; int kind; int pad; };   // kind: bit 0 keyed (multi-mapping unit), bit 1 needs ksw2
+
+// which read, orientation, position and chain status the question of slot-side g asks about
+struct SelQ { const unsigned char* read; int readLen; bool fwd; int pos; int cs; };
+QM_DEV SelQ sel_side_question(const PairBatch& P, const SelBatch& A, long long u, const qm_hit& h, int side) {
+  SelQ q;
+  if (side == 0) {
+    q.read = A.seq1 + P.off1[u]; q.readLen = (int)(P.off1[u + 1] - P.off1[u]); q.fwd = h.fwd != 0; q.pos = h.pos; q.cs = h.aln_score & 15;
+  } else {
+    q.read = A.seq2 + P.off2[u]; q.readLen = (int)(P.off2[u + 1] - P.off2[u]); q.cs = (h.aln_score >> 4) & 15;
+    if (h.mate_status == 3) { q.pos = h.mate_pos; q.fwd = h.mate_is_fwd != 0; } else { q.pos = h.pos; q.fwd = h.fwd != 0; }
   }
-  A.tsc[g] = s;
+  return q;
 }
+// the sides of hit h that exist: bit 0 left / single read, bit 1 right
+QM_DEV int sel_hit_sides(const PairBatch& P, const qm_hit& h) { return !P.paired ? 1 : (h.mate_status == 3 ? 3 : (h.mate_status == 1 ? 1 : 2)); }
 
 // merge + post filters of one unit into its temp slots (chain statuses parked in aln_score); returns the hit count
 QM_DEV int sel_unit_merge(const PairBatch& P, const SelBatch& A, long long u, UnitCounters* uc);
 
-QM_DEV void sel_unit_plan(const PairBatch& P, const SelBatch& A, long long u, UnitCounters* uc) {
+// step 1a: merge, PERFECT chains answered (maxScore: SelectiveAlignmentUtils, getAlnScore's first branch); returns how many
+// questions the unit puts on the list
+QM_DEV int sel_unit_sides_count(const PairBatch& P, const SelBatch& A, long long u, UnitCounters* uc) {
   const int n = sel_unit_merge(P, A, u, uc);
   P.cnt[u] = (u32)n;                                       // hits before the score filter; sel_unit_finish overwrites it
-  qm_hit* T = A.tmp + A.toff[u];
+  const qm_hit* T = A.tmp + A.toff[u];
   const long long gbase = 2 * A.toff[u];
-  u64* keys = A.tkeys + gbase; int* cix = A.tcix + gbase;
-  const u32 l1 = (u32)(P.off1[u + 1] - P.off1[u]);
-  const unsigned char* r1 = A.seq1 + P.off1[u];
-  const bool multiMapping = n > 1;
-  int cnL = 0, cnR = 0;
-  if (!P.paired) {
-    const int maxReadScore = A.match * (int)l1;
-    for (int i = 0; i < n; ++i) {
-      const qm_hit& h = T[i];
-      sel_plan_side(A, u, gbase, 2 * i, 0, h.tid, h.pos, r1, (int)l1, h.fwd != 0, A.text + A.txp_off[h.tid], A.txp_len[h.tid], maxReadScore,
-                    h.aln_score & 15, multiMapping, keys, cix, cnL);
-    }
-    return;
-  }
-  const u32 l2 = (u32)(P.off2[u + 1] - P.off2[u]);
-  const unsigned char* r2 = A.seq2 + P.off2[u];
-  const int maxLeftScore = A.match * (int)l1, maxRightScore = A.match * (int)l2;
+  const int maxL = A.match * (int)(P.off1[u + 1] - P.off1[u]);
+  const int maxR = P.paired ? A.match * (int)(P.off2[u + 1] - P.off2[u]) : 0;
+  int m = 0;
   for (int i = 0; i < n; ++i) {
     const qm_hit& h = T[i];
-    const int csL = h.aln_score & 15, csR = (h.aln_score >> 4) & 15;
-    const unsigned char* tseq = A.text + A.txp_off[h.tid];
-    const int tlen = A.txp_len[h.tid];
-    if (h.mate_status == 3) {
-      sel_plan_side(A, u, gbase, 2 * i, 0, h.tid, h.pos, r1, (int)l1, h.fwd != 0, tseq, tlen, maxLeftScore, csL, multiMapping, keys, cix, cnL);
-      sel_plan_side(A, u, gbase, 2 * i + 1, 1, h.tid, h.mate_pos, r2, (int)l2, h.mate_is_fwd != 0, tseq, tlen, maxRightScore, csR, multiMapping, keys + 1, cix + 1, cnR);
-    } else if (h.mate_status == 1) {
-      sel_plan_side(A, u, gbase, 2 * i, 0, h.tid, h.pos, r1, (int)l1, h.fwd != 0, tseq, tlen, maxLeftScore, csL, multiMapping, keys, cix, cnL);
-    } else {
-      sel_plan_side(A, u, gbase, 2 * i + 1, 1, h.tid, h.pos, r2, (int)l2, h.fwd != 0, tseq, tlen, maxRightScore, csR, multiMapping, keys + 1, cix + 1, cnR);
+    const int sides = sel_hit_sides(P, h);
+    for (int sd = 0; sd < 2; ++sd) {
+      if (!((sides >> sd) & 1)) continue;
+      const int cs = sd == 0 ? (h.aln_score & 15) : ((h.aln_score >> 4) & 15);
+      if (cs == QM_CS_PERFECT) { A.tsc[gbase + 2 * i + sd] = sd == 0 ? maxL : maxR; A.tref[gbase + 2 * i + sd] = -1; }
+      else ++m;
     }
   }
+  return m;
+}
+// step 1b: the unit's questions at sides[base ..)
+QM_DEV void sel_unit_sides_write(const PairBatch& P, const SelBatch& A, long long u, long long base) {
+  const int n = (int)P.cnt[u];
+  const qm_hit* T = A.tmp + A.toff[u];
+  const long long gbase = 2 * A.toff[u];
+  for (int i = 0; i < n; ++i) {
+    const qm_hit& h = T[i];
+    const int sides = sel_hit_sides(P, h);
+    for (int sd = 0; sd < 2; ++sd) {
+      if (!((sides >> sd) & 1)) continue;
+      const int cs = sd == 0 ? (h.aln_score & 15) : ((h.aln_score >> 4) & 15);
+      if (cs == QM_CS_PERFECT) continue;
+      SelSide S; S.u = u; S.g = gbase + 2 * i + sd; S.key = 0; S.kind = 0; S.pad = 0;
+      A.sides[base++] = S;
+    }
+  }
+}
+
+// bytes i0 .. i0+7 of p[0 .. len), zero beyond the end
+QM_DEV u64 sel_word_at(const unsigned char* p, int i0, int len) {
+  if (i0 + 8 <= len) return load_u64_unaligned(p + i0);
+  u64 w = 0;
+  for (int t = 0; t < 8 && i0 + t < len; ++t) w |= (u64)p[i0 + t] << (8 * t);
+  return w;
+}
+struct SelRedOne { QM_DEV int add(int v) const { return v; } QM_DEV u64 bxor(u64 v) const { return v; } };   // a group of one lane (emulation)
+
+// step 2: question x, by lane l of a group of G lanes (lane l takes the 8-character words l, l + G, ...); red sums / xors over the group
+template <int G, typename Red>
+QM_DEV void sel_side_score(const PairBatch& P, const SelBatch& A, long long x, int l, const Red& red) {
+  const int LOWEST = (int)0x80000000;
+  const long long u = A.sides[x].u, g = A.sides[x].g;
+  const qm_hit h = A.tmp[g >> 1];
+  const SelQ q = sel_side_question(P, A, u, h, (int)(g & 1));
+  const bool multiMapping = P.cnt[u] > 1;
+  const unsigned char* read = q.read; const int readLen = q.readLen; const bool fwd = q.fwd;
+  const unsigned char* tseq = A.text + A.txp_off[h.tid];
+  const int tlen = A.txp_len[h.tid];
+  int pos = q.pos;
+  int s = LOWEST, kind = 0; u64 key = 0;
+  int roff = 0, rlen = readLen;
+  const bool invalidStart = pos < 0;
+  const bool invalidEnd = pos + rlen >= tlen;
+  if (invalidStart) { roff = -pos; rlen += pos; pos = 0; }
+  const bool dropped = (invalidStart || invalidEnd) && (A.policy == 1 || A.policy == 2);
+  if (!dropped && pos < tlen) {
+    const bool doUngapped = !invalidStart && q.cs == QM_CS_UNGAPPED;
+    const u32 buf = doUngapped ? 0u : 20u;
+    const u32 lnobuf = (u32)(tlen - pos), lbuf = (u32)(rlen + (int)buf);
+    const bool useBuf = lbuf < lnobuf;
+    const int tlen1 = (int)(lbuf < lnobuf ? lbuf : lnobuf);
+    const unsigned char* tseq1 = tseq + pos;
+    const int keyLen = useBuf ? tlen1 - (int)buf : tlen1;
+    // The alignment whose answer is known without running it.  The extension alignment starts at (0, 0) and its score is
+    // max(mqe, mte) (SelectiveAlignmentUtils.hpp:355-356, score only, no drop-off: RapMapSAMapper.cpp:198-204).  With the target
+    // at least as long as the query, every path that opens a gap scores at most Smax - (q + e) -- Smax: every query character
+    // at its best score, a match or 0 for an N -- whether it ends in the query's last row or in the target's last column (those
+    // skip target characters); the gapless path from (0, 0) lies in every band and ends in the last row.  So when that path
+    // loses no more than q + e against Smax -- one mismatch under the default scores, i.e. half of the alignments a batch
+    // of 1 %-error reads asks for -- its score IS the alignment's, and no task is queued.  (Not with --dpBandwidth 0: that band's
+    // odd anti-diagonals are empty and the kernel stops at the second one.  Scores small enough for the 8-bit kernel to be exact;
+    // the bench's -s leg and the parity tests hold every such score against the oracle's ksw2.)
+    int a = (signed char)A.match, b = (signed char)A.mismatch;
+    a = a < 0 ? -a : a; b = b > 0 ? -b : b;
+    const int qe = (int)(signed char)A.gap_open + (int)(signed char)A.gap_extend;
+    const bool diag = !doUngapped && !A.no_diag && A.bandwidth != 0 && tlen1 >= rlen && rlen > 0 && a >= 1 && (signed char)A.gap_open >= 0 &&
+                      (signed char)A.gap_extend >= 1 && a - b + qe <= 96;
+    const int alnLen = rlen < tlen1 ? rlen : tlen1;
+    const int cmpLen = doUngapped ? alnLen : (diag ? rlen : 0);
+    const int hashLen = multiMapping ? keyLen : 0;
+    const int span = cmpLen > hashLen ? cmpLen : hashLen;
+    int sc = 0, loss = 0; u64 hx = 0;
+    for (int i0 = 8 * l; i0 < span; i0 += 8 * G) {
+      const u64 tw = sel_word_at(tseq1, i0, tlen1);
+      if (i0 < hashLen) {
+        const u64 w = i0 + 8 <= hashLen ? tw : (tw & ((1ULL << (8 * (hashLen - i0))) - 1ULL));
+        hx ^= hash_mix(w + (u64)(i0 / 8 + 1) * 0x9E3779B97F4A7C15ULL);      // position-salted, xor-combined: any grouping of the words gives the same key
+      }
+      if (i0 < cmpLen) {
+        const bool fullR = roff + i0 + 8 <= readLen;
+        const int nt = cmpLen - i0 < 8 ? cmpLen - i0 : 8;
+        u64 rw = 0;                                                     // the read's characters i0 .. i0+7 as the alignment sees them
+        if (fullR) {
+          if (fwd) rw = load_u64_unaligned(read + roff + i0);
+          else { const u64 v = __builtin_bswap64(load_u64_unaligned(read + (readLen - 1 - (roff + i0) - 7))); rw = (u64)rc_char4((u32)v) | ((u64)rc_char4((u32)(v >> 32)) << 32); }
+        } else for (int t = 0; t < nt; ++t) rw |= (u64)sel_read_char(read, readLen, fwd, roff + i0 + t) << (8 * t);
+        // eight characters at a time: 0x80 per byte where ...
+        const u32 vm0 = nt >= 4 ? 0x80808080u : (0x80808080u >> (8 * (4 - nt))), vm1 = nt >= 8 ? 0x80808080u : (nt > 4 ? (0x80808080u >> (8 * (8 - nt))) : 0u);
+        const u32 t0 = (u32)tw, t1 = (u32)(tw >> 32), r0 = (u32)rw, r1 = (u32)(rw >> 32);
+        if (doUngapped) {
+          // ... the characters are the same or one of them is 'N' (SelectiveAlignmentUtils.hpp ungapped branch)
+          const u32 m0 = (eq_bytes(t0 ^ r0, 0) | eq_bytes(t0, 'N') | eq_bytes(r0, 'N')) & vm0;
+          const u32 m1 = (eq_bytes(t1 ^ r1, 0) | eq_bytes(t1, 'N') | eq_bytes(r1, 'N')) & vm1;
+          const int m = __builtin_popcount(m0) + __builtin_popcount(m1);
+          sc += m * A.match + (nt - m) * A.mismatch;
+        } else if (((eq_bytes(t0 & 0xfcfcfcfcu, 0) | eq_bytes(r0 & 0xfcfcfcfcu, 0)) & vm0) | ((eq_bytes(t1 & 0xfcfcfcfcu, 0) | eq_bytes(r1 & 0xfcfcfcfcu, 0)) & vm1)) {
+          // a byte below 4 is its own code in seq_nt4_table: character by character
+          for (int t = 0; t < nt; ++t) {
+            const unsigned char ct = sel_nt4((unsigned char)(tw >> (8 * t))), cq = sel_nt4((unsigned char)(rw >> (8 * t)));
+            const int mx = cq < 4 ? a : 0, v = (ct < 4 && cq < 4) ? (ct == cq ? a : b) : 0;
+            sc += v; loss += mx - v;
+          }
+        } else {
+          // ... the byte is one of a c g t in either case (code < 4), and where both are and they are the same letter
+          const u32 at0 = eq_bytes((t0 & 0xdfdfdfdfu) ^ canon4(t0, false), 0), at1 = eq_bytes((t1 & 0xdfdfdfdfu) ^ canon4(t1, false), 0);
+          const u32 aq0 = eq_bytes((r0 & 0xdfdfdfdfu) ^ canon4(r0, false), 0) & vm0, aq1 = eq_bytes((r1 & 0xdfdfdfdfu) ^ canon4(r1, false), 0) & vm1;
+          const u32 e0 = eq_bytes((t0 ^ r0) & 0xdfdfdfdfu, 0) & at0 & aq0, e1 = eq_bytes((t1 ^ r1) & 0xdfdfdfdfu, 0) & at1 & aq1;
+          const int nQ = __builtin_popcount(aq0) + __builtin_popcount(aq1), nBoth = __builtin_popcount(at0 & aq0) + __builtin_popcount(at1 & aq1);
+          const int nEq = __builtin_popcount(e0) + __builtin_popcount(e1);
+          const int v = a * nEq + b * (nBoth - nEq);
+          sc += v; loss += a * nQ - v;
+        }
+      }
+    }
+    sc = red.add(sc); loss = red.add(loss);
+    if (multiMapping) { key = hash_mix(red.bxor(hx) ^ hash_mix((u64)(u32)keyLen + 0x9E3779B97F4A7C15ULL)); kind |= 1; }
+    if (doUngapped) s = sc;
+    else if (diag && loss <= qe) s = sc;
+    else {
+      kind |= 2;
+      if (l == 0) {
+        SelTask t; t.rd = read; t.tx = tseq1; t.gslot = (int)g; t.rl = readLen; t.roff = roff; t.rlen = rlen; t.tlen1 = tlen1; t.fwd = fwd ? 1 : 0;
+        A.tasks[x] = t;
+      }
+    }
+  }
+  if (l == 0) { A.tsc[g] = s; A.tref[g] = -1; A.sides[x].key = key; A.sides[x].kind = kind; }
+}
+
+// step 3: the alignment cache (SelectiveAlignmentUtils.hpp: alnCache keyed by the hash of the target window, per read and mate) and
+// the work list of the alignment kernel
+QM_DEV void sel_side_dedupe(const SelBatch& A, long long x) {
+  const SelSide S = A.sides[x];
+  if (S.kind == 0) return;
+  if (S.kind & 1) {
+    long long own = -1;
+    for (long long y = x - 1; y >= 0; --y) {
+      const SelSide& Y = A.sides[y];
+      if (Y.u != S.u) break;
+      if ((Y.kind & 1) && ((Y.g ^ S.g) & 1) == 0 && Y.key == S.key) own = y;
+    }
+    if (own >= 0) {
+      A.tref[S.g] = -(int)(A.sides[own].g - 2 * A.toff[S.u]) - 2;
+      A.tsc[S.g] = (int)0x80000000;
+      return;
+    }
+  }
+  if (S.kind & 2) A.torder[atomic_add_u64(A.ntasks, 1ULL)] = (u64)x;
 }
 
 // Tasks t0 .. t0+3 (those below nt), one per row of 16 lanes: stage the two score-phase images straight from the read and
@@ -1341,7 +1391,7 @@ QM_DEV void sel_tasks_stage(const SelBatch& A, unsigned long long t0, unsigned l
     const unsigned long long ti = t0 + (unsigned long long)(l >> 4);
     ql[l] = 0; tl[l] = 0; gs[l] = -1; rd[l] = nullptr; tx[l] = nullptr; rl[l] = 0; ro[l] = 0; fw[l] = 0;
     if (ti < nt) {
-      const SelTask t = A.tasks[ti];
+      const SelTask t = A.tasks[A.torder ? A.torder[ti] : ti];
       rd[l] = t.rd; rl[l] = t.rl; tx[l] = t.tx;
       ql[l] = t.rlen; tl[l] = t.tlen1; gs[l] = t.gslot; ro[l] = t.roff; fw[l] = t.fwd;
     }

@@ -294,17 +294,22 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
       long long w = paired ? (long long)(lcnt[2 * u] & 0x7fffffffu) + (lcnt[2 * u + 1] & 0x7fffffffu) : (long long)(lcnt[u] & 0x7fffffffu);
       toff[u + 1] = toff[u] + w / 3 + 1;
     }
-    std::vector<qm_hit> tmp((size_t)toff[nunits] + 1); std::vector<u64> tkeys(2 * (size_t)toff[nunits] + 2); std::vector<int> tsc(2 * (size_t)toff[nunits] + 2);
+    std::vector<qm_hit> tmp((size_t)toff[nunits] + 1); std::vector<int> tsc(2 * (size_t)toff[nunits] + 2);
     SelBatch A; memset(&A, 0, sizeof(A));
     A.seq1 = seq1; A.seq2 = seq2; A.text = text; A.txp_off = txp_off; A.txp_len = txp_len; A.tmp = tmp.data(); A.toff = toff.data();
-    A.tkeys = tkeys.data(); A.tsc = tsc.data();
+    A.tsc = tsc.data();
     A.match = o->match_score; A.mismatch = o->mismatch_penalty; A.gap_open = o->gap_open; A.gap_extend = o->gap_extend;
     A.bandwidth = o->dp_bandwidth; A.hard_filter = o->hard_filter; A.policy = o->aln_policy; A.min_score_fraction = o->min_score_fraction;
     {
-      std::vector<int> tref(2 * (size_t)toff[nunits] + 2), tcix(2 * (size_t)toff[nunits] + 2);
-      std::vector<SelTask> tasks(2 * (size_t)toff[nunits] + 2); u64 ntasks = 0;
-      A.tref = tref.data(); A.tcix = tcix.data(); A.tasks = tasks.data(); A.ntasks = &ntasks;
-      for (long long u = 0; u < nunits; ++u) sel_unit_plan(P, A, u, &uc);
+      std::vector<int> tref(2 * (size_t)toff[nunits] + 2);
+      std::vector<SelTask> tasks(2 * (size_t)toff[nunits] + 2); u64 ntasks = 0, nsides = 0;
+      std::vector<SelSide> sides(2 * (size_t)toff[nunits] + 2); std::vector<u64> torder(2 * (size_t)toff[nunits] + 2);
+      A.tref = tref.data(); A.tasks = tasks.data(); A.ntasks = &ntasks; A.sides = sides.data(); A.nsides = &nsides; A.torder = torder.data();
+      A.u0 = 0; A.u1 = nunits;
+      // the plan's three steps as the kernels run them (qm_sel_sides_kernel, qm_sel_score_kernel with one lane per question, qm_sel_dedupe_kernel)
+      for (long long u = 0; u < nunits; ++u) { const int m = sel_unit_sides_count(P, A, u, &uc); if (m > 0) { sel_unit_sides_write(P, A, u, (long long)nsides); nsides += (u64)m; } }
+      for (u64 x = 0; x < nsides; ++x) sel_side_score<1>(P, A, (long long)x, 0, SelRedOne());
+      for (u64 x = 0; x < nsides; ++x) sel_side_dedupe(A, (long long)x);
       unsigned char codes[512]; sel_ksw_fill_codes(codes, 0, 1);
       bool longReads = false;
       for (long long u = 0; u < nunits; ++u) { if (off1[u + 1] - off1[u] > QM_MAX_READ_LEN || (paired && off2[u + 1] - off2[u] > QM_MAX_READ_LEN)) longReads = true; }
