@@ -1103,7 +1103,7 @@ static int run_stage_b(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
     }
     A.short_len = rq.shortLen;
     A.bandwidth = o->dp_bandwidth; A.hard_filter = o->hard_filter; A.policy = o->aln_policy; A.min_score_fraction = o->min_score_fraction;
-    { static const int noDiag = [] { const char* e = getenv("QM_SEL_NO_DIAG"); return e && atoi(e) != 0 ? 1 : 0; }(); A.no_diag = noDiag; }
+    { static const int noDiag = [] { const char* e = getenv("QM_SEL_NO_DIAG"); return e ? atoi(e) : 0; }(); A.no_diag = noDiag; }
     HIPCHK(hipMemsetAsync(c->d_cnt + n, 0, sizeof(uint32_t), c->stream));
     if (rq.mergeOnly) {
       HIPCHK(qmk_sel_merge(&P, &A, c->stream));            // the merge alone: no alignment, chain statuses stay in aln_score

@@ -198,12 +198,16 @@ __global__ __launch_bounds__(256) void qm_sel_sides_kernel(PairBatch P, SelBatch
   sel_flush_counters(sc, uc, P.counters);
 }
 // plan, step 2: sixteen lanes per question -- its 128 characters of read and of target in one round of loads
-struct SelRed16 {
-  QM_DEV int add(int v) const { v += __shfl_xor(v, 8, 16); v += __shfl_xor(v, 4, 16); v += __shfl_xor(v, 2, 16); v += __shfl_xor(v, 1, 16); return v; }
+struct SelRed16 {                       // all-reduce over a row of 16 lanes by rotations (DPP row_ror:8, 4, 2, 1): every lane ends up with the result
+  template <int CTRL> static QM_DEV int rot(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+  QM_DEV int add(int v) const { v += rot<0x128>(v); v += rot<0x124>(v); v += rot<0x122>(v); v += rot<0x121>(v); return v; }
+  QM_DEV int min(int v) const { int o; o = rot<0x128>(v); v = o < v ? o : v; o = rot<0x124>(v); v = o < v ? o : v; o = rot<0x122>(v); v = o < v ? o : v; o = rot<0x121>(v); v = o < v ? o : v; return v; }
+  QM_DEV int max(int v) const { int o; o = rot<0x128>(v); v = o > v ? o : v; o = rot<0x124>(v); v = o > v ? o : v; o = rot<0x122>(v); v = o > v ? o : v; o = rot<0x121>(v); v = o > v ? o : v; return v; }
   QM_DEV u64 bxor(u64 v) const {
-    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-    for (int d = 8; d > 0; d >>= 1) { lo ^= (unsigned)__shfl_xor((int)lo, d, 16); hi ^= (unsigned)__shfl_xor((int)hi, d, 16); }
-    return (u64)lo | ((u64)hi << 32);
+    int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
+    lo ^= rot<0x128>(lo); hi ^= rot<0x128>(hi); lo ^= rot<0x124>(lo); hi ^= rot<0x124>(hi);
+    lo ^= rot<0x122>(lo); hi ^= rot<0x122>(hi); lo ^= rot<0x121>(lo); hi ^= rot<0x121>(hi);
+    return (u64)(unsigned)lo | ((u64)(unsigned)hi << 32);
   }
 };
 __global__ __launch_bounds__(256) void qm_sel_score_kernel(PairBatch P, SelBatch A) {

@@ -573,7 +573,7 @@ struct SelBatch {                    // launch arguments of the -s kernels (on t
   long long u0, u1;                            // the units [u0, u1) this launch of plan / finish covers (the batch goes through
                                                // plan -> align -> finish in chunks: the plan of chunk i+1 runs under the align of chunk i)
   int match, mismatch, gap_open, gap_extend, bandwidth, hard_filter, policy;
-  int no_diag;                                 // 1: queue every REGULAR alignment (profiling: QM_SEL_NO_DIAG; sel_side_score answers the one-mismatch ones itself)
+  int no_diag;                                 // profiling (QM_SEL_NO_DIAG): 1 queue every REGULAR alignment, 2 only rule 1 of sel_side_score (no two-mismatch answers)
   int long_reads;                              // the batch holds reads beyond QM_MAX_READ_LEN: the long editions of the alignment kernel
   void* ksw_rows;                              // long reads under a band beyond 97: the alignment blocks in device memory (KswRowT<QM_KSW_RING_GMEM, QM_KSW_MAXLEN_LONG>, four per wavefront)
   int short_len;                               // longest read of the batch that is not beyond QM_MAX_READ_LEN (0: unknown): reads of up to 128
@@ -1242,14 +1242,30 @@ QM_DEV void sel_unit_sides_write(const PairBatch& P, const SelBatch& A, long lon
   }
 }
 
-// bytes i0 .. i0+7 of p[0 .. len), zero beyond the end
+// bytes i0 .. i0+7 of p[0 .. len), zero beyond the end -- the last, partial word is the last eight bytes shifted down: no byte loop
 QM_DEV u64 sel_word_at(const unsigned char* p, int i0, int len) {
   if (i0 + 8 <= len) return load_u64_unaligned(p + i0);
+  if (i0 >= len) return 0;
+  if (len >= 8) return load_u64_unaligned(p + len - 8) >> (8 * (i0 + 8 - len));
   u64 w = 0;
   for (int t = 0; t < 8 && i0 + t < len; ++t) w |= (u64)p[i0 + t] << (8 * t);
   return w;
 }
-struct SelRedOne { QM_DEV int add(int v) const { return v; } QM_DEV u64 bxor(u64 v) const { return v; } };   // a group of one lane (emulation)
+// characters j0 .. j0+7 of the read as the alignment sees it (forward, or reverseRead() of it), zero beyond its end
+QM_DEV u64 sel_read_word(const unsigned char* r, int len, bool fwd, int j0) {
+  if (fwd) return sel_word_at(r, j0, len);
+  if (j0 >= len) return 0;
+  u64 v;                                                   // source bytes len-1-j0-7 .. len-1-j0, last one first
+  const int lo = len - 1 - j0 - 7;
+  if (lo >= 0) v = load_u64_unaligned(r + lo);
+  else if (len >= 8) v = load_u64_unaligned(r) << (8 * -lo);
+  else { v = 0; for (int t = 0; t < 8 && j0 + t < len; ++t) v |= (u64)r[len - 1 - j0 - t] << (8 * (7 - t)); }
+  v = __builtin_bswap64(v);
+  const int nv = len - j0 < 8 ? len - j0 : 8;              // the complement table makes 'N' of the zero bytes: cleared again
+  const u64 w = (u64)rc_char4((u32)v) | ((u64)rc_char4((u32)(v >> 32)) << 32);
+  return nv >= 8 ? w : (w & ((1ULL << (8 * nv)) - 1ULL));
+}
+struct SelRedOne { QM_DEV int add(int v) const { return v; } QM_DEV int min(int v) const { return v; } QM_DEV int max(int v) const { return v; } QM_DEV u64 bxor(u64 v) const { return v; } };   // a group of one lane (emulation)
 
 // step 2: question x, by lane l of a group of G lanes (lane l takes the 8-character words l, l + G, ...); red sums / xors over the group
 template <int G, typename Red>
@@ -1277,47 +1293,56 @@ QM_DEV void sel_side_score(const PairBatch& P, const SelBatch& A, long long x, i
     const int tlen1 = (int)(lbuf < lnobuf ? lbuf : lnobuf);
     const unsigned char* tseq1 = tseq + pos;
     const int keyLen = useBuf ? tlen1 - (int)buf : tlen1;
-    // The alignment whose answer is known without running it.  The extension alignment starts at (0, 0) and its score is
+    // Rule 1 -- the alignment whose answer is known without running it.  The extension alignment starts at (0, 0) and its score is
     // max(mqe, mte) (SelectiveAlignmentUtils.hpp:355-356, score only, no drop-off: RapMapSAMapper.cpp:198-204).  With the target
     // at least as long as the query, every path that opens a gap scores at most Smax - (q + e) -- Smax: every query character
     // at its best score, a match or 0 for an N -- whether it ends in the query's last row or in the target's last column (those
     // skip target characters); the gapless path from (0, 0) lies in every band and ends in the last row.  So when that path
-    // loses no more than q + e against Smax -- one mismatch under the default scores, i.e. half of the alignments a batch
-    // of 1 %-error reads asks for -- its score IS the alignment's, and no task is queued.  (Not with --dpBandwidth 0: that band's
-    // odd anti-diagonals are empty and the kernel stops at the second one.  Scores small enough for the 8-bit kernel to be exact;
-    // the bench's -s leg and the parity tests hold every such score against the oracle's ksw2.)
+    // loses no more than q + e against Smax -- one mismatch under the default scores -- its score IS the alignment's, and no task
+    // is queued.  (Not with --dpBandwidth 0: that band's odd anti-diagonals are empty and the kernel stops at the second one.
+    // Scores small enough for the 8-bit kernel to be exact; tests/test_ksw_variants.py, the parity tests and the bench's -s leg hold
+    // every such score against the oracle's ksw2.)
+    // Rule 2 -- two mismatches (loss 2M, M = a - b <= q + e, no N anywhere): besides the gapless path only a path with ONE gap run
+    // and no mismatch at all can lose less -- a run and a mismatch lose q + e + M >= 2M, two runs 2(q + e) >= 2M.  Such a path
+    // follows diagonal 0 up to the run at query position p <= m1 (the first mismatch) and diagonal +L (L target characters
+    // skipped) or -L (L query characters skipped) behind it, so it exists exactly when that diagonal has no mismatch from p on:
+    // the last mismatch of diagonal +L lies before m1, of diagonal -L before m1 + L.  L ranges over the run lengths that lose
+    // less than 2M (q + L e, or q + L (e + a) with the query characters of the run: one and two skipped target characters and one
+    // skipped query character under the default scores); the target has to reach past the longest of them, so that ending in
+    // the target's last column is no option, and the band has to hold them.  The diagonals next to the main one cost a funnel
+    // shift of the words already loaded.
     int a = (signed char)A.match, b = (signed char)A.mismatch;
     a = a < 0 ? -a : a; b = b > 0 ? -b : b;
-    const int qe = (int)(signed char)A.gap_open + (int)(signed char)A.gap_extend;
-    const bool diag = !doUngapped && !A.no_diag && A.bandwidth != 0 && tlen1 >= rlen && rlen > 0 && a >= 1 && (signed char)A.gap_open >= 0 &&
-                      (signed char)A.gap_extend >= 1 && a - b + qe <= 96;
+    const int gq = (int)(signed char)A.gap_open, ge = (int)(signed char)A.gap_extend, qe = gq + ge, M = a - b;
+    const bool diag = !doUngapped && A.no_diag != 1 && A.bandwidth != 0 && tlen1 >= rlen && rlen > 0 && a >= 1 && gq >= 0 && ge >= 1 && a - b + qe <= 96;
+    int Ld = 0, Li = 0;
+    while (Ld < 4 && gq + (Ld + 1) * ge < 2 * M) ++Ld;
+    while (Li < 3 && gq + (Li + 1) * (ge + a) < 2 * M) ++Li;
+    const bool rule2 = diag && A.no_diag != 2 && M <= qe && Ld <= 3 && Li <= 2 && (A.bandwidth < 0 || A.bandwidth >= 8) && tlen1 >= rlen + Ld + 1;
     const int alnLen = rlen < tlen1 ? rlen : tlen1;
     const int cmpLen = doUngapped ? alnLen : (diag ? rlen : 0);
     const int hashLen = multiMapping ? keyLen : 0;
     const int span = cmpLen > hashLen ? cmpLen : hashLen;
-    int sc = 0, loss = 0; u64 hx = 0;
+    int sc = 0, loss = 0, bad = 0, m1 = 0x7fffffff; u64 hx = 0;
+    int hmD[3] = {-1, -1, -1}, hmI[2] = {-1, -1};            // last mismatch of diagonals +1 +2 +3, -1 -2
     for (int i0 = 8 * l; i0 < span; i0 += 8 * G) {
       const u64 tw = sel_word_at(tseq1, i0, tlen1);
       if (i0 < hashLen) {
         const u64 w = i0 + 8 <= hashLen ? tw : (tw & ((1ULL << (8 * (hashLen - i0))) - 1ULL));
-        hx ^= hash_mix(w + (u64)(i0 / 8 + 1) * 0x9E3779B97F4A7C15ULL);      // position-salted, xor-combined: any grouping of the words gives the same key
+        const u32 j = (u32)(i0 >> 3) + 1u;                               // position-salted, xor-combined: any grouping of the words gives the same key
+        hx ^= hash_mix(w + ((u64)(j * 0x7F4A7C15u) | ((u64)(j * 0x9E3779B9u) << 32)));
       }
       if (i0 < cmpLen) {
-        const bool fullR = roff + i0 + 8 <= readLen;
         const int nt = cmpLen - i0 < 8 ? cmpLen - i0 : 8;
-        u64 rw = 0;                                                     // the read's characters i0 .. i0+7 as the alignment sees them
-        if (fullR) {
-          if (fwd) rw = load_u64_unaligned(read + roff + i0);
-          else { const u64 v = __builtin_bswap64(load_u64_unaligned(read + (readLen - 1 - (roff + i0) - 7))); rw = (u64)rc_char4((u32)v) | ((u64)rc_char4((u32)(v >> 32)) << 32); }
-        } else for (int t = 0; t < nt; ++t) rw |= (u64)sel_read_char(read, readLen, fwd, roff + i0 + t) << (8 * t);
+        const u64 rw = sel_read_word(read, readLen, fwd, roff + i0);
         // eight characters at a time: 0x80 per byte where ...
         const u32 vm0 = nt >= 4 ? 0x80808080u : (0x80808080u >> (8 * (4 - nt))), vm1 = nt >= 8 ? 0x80808080u : (nt > 4 ? (0x80808080u >> (8 * (8 - nt))) : 0u);
         const u32 t0 = (u32)tw, t1 = (u32)(tw >> 32), r0 = (u32)rw, r1 = (u32)(rw >> 32);
         if (doUngapped) {
           // ... the characters are the same or one of them is 'N' (SelectiveAlignmentUtils.hpp ungapped branch)
           const u32 m0 = (eq_bytes(t0 ^ r0, 0) | eq_bytes(t0, 'N') | eq_bytes(r0, 'N')) & vm0;
-          const u32 m1 = (eq_bytes(t1 ^ r1, 0) | eq_bytes(t1, 'N') | eq_bytes(r1, 'N')) & vm1;
-          const int m = __builtin_popcount(m0) + __builtin_popcount(m1);
+          const u32 m1b = (eq_bytes(t1 ^ r1, 0) | eq_bytes(t1, 'N') | eq_bytes(r1, 'N')) & vm1;
+          const int m = __builtin_popcount(m0) + __builtin_popcount(m1b);
           sc += m * A.match + (nt - m) * A.mismatch;
         } else if (((eq_bytes(t0 & 0xfcfcfcfcu, 0) | eq_bytes(r0 & 0xfcfcfcfcu, 0)) & vm0) | ((eq_bytes(t1 & 0xfcfcfcfcu, 0) | eq_bytes(r1 & 0xfcfcfcfcu, 0)) & vm1)) {
           // a byte below 4 is its own code in seq_nt4_table: character by character
@@ -1326,6 +1351,7 @@ QM_DEV void sel_side_score(const PairBatch& P, const SelBatch& A, long long x, i
             const int mx = cq < 4 ? a : 0, v = (ct < 4 && cq < 4) ? (ct == cq ? a : b) : 0;
             sc += v; loss += mx - v;
           }
+          bad += 1;
         } else {
           // ... the byte is one of a c g t in either case (code < 4), and where both are and they are the same letter
           const u32 at0 = eq_bytes((t0 & 0xdfdfdfdfu) ^ canon4(t0, false), 0), at1 = eq_bytes((t1 & 0xdfdfdfdfu) ^ canon4(t1, false), 0);
@@ -1335,13 +1361,47 @@ QM_DEV void sel_side_score(const PairBatch& P, const SelBatch& A, long long x, i
           const int nEq = __builtin_popcount(e0) + __builtin_popcount(e1);
           const int v = a * nEq + b * (nBoth - nEq);
           sc += v; loss += a * nQ - v;
+          if (rule2) {
+            // the first position that is not a match, whether anything here is not a c g t, the last mismatch of the neighbouring diagonals
+            const u64 mm = (u64)(vm0 & ~e0) | ((u64)(vm1 & ~e1) << 32);
+            if (mm) { const int p = i0 + (__builtin_ctzll(mm) >> 3); m1 = p < m1 ? p : m1; }
+            bad += __builtin_popcount(vm0 & ~(at0 & aq0)) + __builtin_popcount(vm1 & ~(at1 & aq1));
+            const u64 tn = sel_word_at(tseq1, i0 + 8, tlen1), tp = i0 >= 8 ? load_u64_unaligned(tseq1 + i0 - 8) : 0ULL;
+#pragma unroll
+            for (int d = 1; d <= 3; ++d) {
+              if (d > Ld) continue;
+              const u64 td = (tw >> (8 * d)) | (tn << (64 - 8 * d));
+              const u32 d0 = (u32)td, d1 = (u32)(td >> 32);
+              const u64 dm = (u64)(vm0 & ~eq_bytes((d0 ^ r0) & 0xdfdfdfdfu, 0)) | ((u64)(vm1 & ~eq_bytes((d1 ^ r1) & 0xdfdfdfdfu, 0)) << 32);
+              if (dm) { const int p = i0 + ((63 - __builtin_clzll(dm)) >> 3); hmD[d - 1] = p > hmD[d - 1] ? p : hmD[d - 1]; }
+              if (d == Ld) bad += __builtin_popcount(vm0 & ~eq_bytes((d0 & 0xdfdfdfdfu) ^ canon4(d0, false), 0)) + __builtin_popcount(vm1 & ~eq_bytes((d1 & 0xdfdfdfdfu) ^ canon4(d1, false), 0));
+            }
+#pragma unroll
+            for (int d = 1; d <= 2; ++d) {
+              if (d > Li) continue;
+              const u64 td = (tw << (8 * d)) | (tp >> (64 - 8 * d));
+              const u32 d0 = (u32)td, d1 = (u32)(td >> 32);
+              const u64 dm = (u64)(vm0 & ~eq_bytes((d0 ^ r0) & 0xdfdfdfdfu, 0)) | ((u64)(vm1 & ~eq_bytes((d1 ^ r1) & 0xdfdfdfdfu, 0)) << 32);
+              if (dm) { const int p = i0 + ((63 - __builtin_clzll(dm)) >> 3); hmI[d - 1] = p > hmI[d - 1] ? p : hmI[d - 1]; }
+            }
+          }
         }
       }
     }
     sc = red.add(sc); loss = red.add(loss);
-    if (multiMapping) { key = hash_mix(red.bxor(hx) ^ hash_mix((u64)(u32)keyLen + 0x9E3779B97F4A7C15ULL)); kind |= 1; }
+    if (multiMapping) { key = red.bxor(hx) ^ ((u64)(u32)keyLen * 0x9E3779B97F4A7C15ULL); kind |= 1; }
+    bool known = diag && loss <= qe;
+    if (rule2 && !known && loss == 2 * M && red.add(bad) == 0) {
+      m1 = red.min(m1);
+      int best = 2 * M;
+#pragma unroll
+      for (int d = 1; d <= 3; ++d) if (d <= Ld && red.max(hmD[d - 1]) <= m1 - 1) { const int c = gq + d * ge; best = c < best ? c : best; }
+#pragma unroll
+      for (int d = 1; d <= 2; ++d) if (d <= Li && red.max(hmI[d - 1]) <= m1 + d - 1) { const int c = gq + d * (ge + a); best = c < best ? c : best; }
+      known = true; sc = a * rlen - best;
+    }
     if (doUngapped) s = sc;
-    else if (diag && loss <= qe) s = sc;
+    else if (known) s = sc;
     else {
       kind |= 2;
       if (l == 0) {

@@ -494,3 +494,55 @@ def test_one_diagonal_chaining_editions_equal_the_doubles():
                 assert r == 1, "trial %d: edition %d declined a one-diagonal group" % (trial, which)
                 agreed[which] += 1
     assert agreed[8] > 4000 and agreed[0] > 9000
+
+
+def _edited_pairs(txps, n, seed):
+    """pairs of 100-bp reads (mate 2 from the other strand, 150 bases downstream) with the edits that decide between the gapless
+    path and a path with one gap: two substitutions anywhere, or a one- / two-base deletion or a one-base insertion a few
+    characters from either end of the read (behind it the diagonal has a handful of mismatches, often exactly two)"""
+    rng = np.random.default_rng(seed)
+    B = np.frombuffer(b"ACGT", dtype=np.uint8)
+    comp = np.zeros(256, np.uint8); comp[list(b"ACGT")] = list(b"TGCA")
+    long_enough = [t for t in txps if len(t) >= 400]
+
+    def edit(frag):                                         # frag: 104 characters of transcript, the read is (about) its first 100
+        kind = int(rng.integers(0, 6))
+        r = frag.copy()
+        if kind == 0:
+            for p in rng.choice(100, 2, replace=False): r[p] = B[(np.searchsorted(B, r[p]) + 1 + rng.integers(0, 3)) % 4]
+            return r[:100]
+        near = int(rng.integers(1, 7))
+        p = near if rng.random() < 0.5 else 100 - near
+        if kind in (1, 2): return np.concatenate([r[:p], r[p + 1:]])[:100]                   # one base missing from the read
+        if kind == 3: return np.concatenate([r[:p], r[p + 2:]])[:100]                        # two
+        if kind == 4: return np.concatenate([r[:p], B[rng.integers(0, 4, 1)], r[p:]])[:100]  # one extra
+        for p in rng.choice(100, 3, replace=False): r[p] = B[(np.searchsorted(B, r[p]) + 1) % 4]
+        return r[:100]
+    r1, r2 = [], []
+    for i in range(n):
+        t = long_enough[int(rng.integers(0, len(long_enough)))]
+        p = int(rng.integers(0, len(t) - 360))
+        a = edit(t[p:p + 104]); b = edit(t[p + 150:p + 254])
+        b = comp[b[::-1]]
+        if i % 2: a, b = b, a
+        r1.append(a.tobytes()); r2.append(b.tobytes())
+    return r1, r2
+
+
+@pytest.mark.parametrize("scheme", [dict(), dict(gapOpen=4, gapExtend=2), dict(matchScore=1, mismatchPenalty=-1, gapOpen=1, gapExtend=1),
+                                    dict(dpBandwidth=5), dict(matchScore=2, mismatchPenalty=-4, gapOpen=6, gapExtend=1, dpBandwidth=-1)])
+def test_selective_alignment_answers_known_without_ksw2(synth_medium, oracle_mod, scheme):
+    """sel_side_score's two rules -- the gapless path when it loses no more than one gap, and with two mismatches the best of the
+    gapless path and the few one-gap paths that could beat it -- on reads whose edits sit where those paths differ: every
+    alignment score (they decide the hits that survive) equals the oracle's, which runs ksw2 for all of them"""
+    ix, orc, em, emu = _emu(synth_medium["idx"])
+    r1, r2 = _edited_pairs(synth_medium["txps"], 3000, 99)
+    q1, o1 = pack(r1); q2, o2 = pack(r2)
+    conv = {"gapOpen": "gap_open", "gapExtend": "gap_extend", "matchScore": "match_score", "mismatchPenalty": "mismatch_penalty", "dpBandwidth": "dp_bandwidth"}
+    oo = dict(selAln=1, minScoreFraction=0.5, **scheme); eo = dict(sel_aln=1, min_score_fraction=0.5, **{conv[k]: v for k, v in scheme.items()})
+    res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=8)
+    er = em.map(q1, o1, q2, o2, opts=emu.default_opts(**eo))
+    assert er.status == 0
+    assert res.counters["peHits"] > 1000
+    assert_hits_equal(res.hit_offsets, res.hits, er.hit_offsets, er.hits, "known answers %s" % scheme)
+    assert res.counters == er.counters

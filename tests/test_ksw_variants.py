@@ -207,7 +207,7 @@ def test_ksw_rows_eight_per_wavefront(scheme):
 @pytest.mark.parametrize("scheme", [(2, -4, 4, 2, 15), (2, -4, 4, 2, 1), (2, -4, 4, 2, 5), (1, -1, 1, 1, 15), (2, -6, 5, 3, 33), (4, -4, 6, 2, 20),
                                     (2, -4, 4, 2, 98), (2, -4, 4, 2, -1), (3, -2, 2, 1, 15), (1, 0, 25, 25, 15)])
 def test_gapless_path_wins_when_it_loses_no_more_than_one_gap(scheme):
-    """sel_plan_side's shortcut (rapmap_amd/csrc/qm_sel.inl): with the target at least as long as the query, an extension alignment
+    """sel_side_score's first rule (rapmap_amd/csrc/qm_sel.inl): with the target at least as long as the query, an extension alignment
     whose gapless path loses at most q + e against 'every query character at its best' scores exactly what that path scores.
     Held against the oracle's ksw_extz2 (itself pinned to the reference's kernel compiled in place) on queries with zero, one or
     two differences, N's on either side, indels right behind the start, every length class and band (but --dpBandwidth 0, whose
@@ -236,3 +236,86 @@ def test_gapless_path_wins_when_it_loses_no_more_than_one_gap(scheme):
             assert ref == U, (scheme, qlen, tlen, smax, U, ref)
             hits += 1
     assert hits > 500
+
+
+def _known_answer_rule(q, t, a, b, q_, e_, w):
+    """returns score or None (ask ksw2)"""
+    qlen, tlen = len(q), len(t)
+    aa, bb = abs(a), -abs(b)
+    M = aa - bb; qe = q_ + e_
+    if not (w != 0 and tlen >= qlen and qlen > 0 and aa >= 1 and q_ >= 0 and e_ >= 1 and aa - bb + qe <= 96): return None
+    sc = np.where((q < 4) & (t[:qlen] < 4), np.where(q == t[:qlen], aa, bb), 0)
+    smax = int(np.where(q < 4, aa, 0).sum()); U = int(sc.sum()); loss = smax - U
+    if loss <= qe: return U
+    # extension
+    if M > qe or loss != 2 * M: return None
+    Ld = 0
+    while q_ + (Ld + 1) * e_ < 2 * M: Ld += 1
+    Li = 0
+    while q_ + (Li + 1) * (e_ + aa) < 2 * M: Li += 1
+    if Ld > 3 or Li > 2: return None
+    if not (w < 0 or w >= 8): return None
+    if tlen < qlen + Ld + 1: return None
+    if (q >= 4).any() or (t[:qlen + Ld] >= 4).any(): return None
+    mm = np.nonzero(q != t[:qlen])[0]
+    assert len(mm) == 2
+    m1 = int(mm[0])
+    best = 2 * M
+    for L in range(1, Ld + 1):
+        d = np.nonzero(q != t[L:L + qlen])[0]
+        hm = int(d[-1]) if len(d) else -1
+        if hm <= m1 - 1: best = min(best, q_ + L * e_)
+    for L in range(1, Li + 1):
+        idx = np.arange(L, qlen)
+        d = idx[q[L:] != t[:qlen - L]]
+        hm = int(d[-1]) if len(d) else L - 1
+        if hm <= m1 + L - 1: best = min(best, q_ + L * (e_ + aa))
+    return smax - best
+
+
+@pytest.mark.parametrize("scheme", [(2, -4, 5, 3, 15), (2, -4, 4, 2, 15), (2, -4, 4, 2, 8), (1, -1, 1, 1, 15), (2, -6, 5, 3, 33), (4, -4, 6, 2, 20),
+                                    (2, -4, 4, 2, -1), (3, -2, 2, 1, 15), (2, -4, 5, 3, 9), (1, -3, 2, 1, 15), (2, -4, 6, 1, 15)])
+def test_two_mismatches_lose_to_at_most_one_gap_run(scheme):
+    """sel_side_score's second rule (rapmap_amd/csrc/qm_sel.inl), restated above in numpy: an alignment whose gapless path has exactly
+    two mismatches and no N scores the best of that path and the one-gap-run paths without a mismatch -- found by looking at the last
+    mismatch of the diagonals next to the main one.  Held against the oracle's ksw_extz2 on queries from low-complexity and periodic
+    targets (where the neighbouring diagonals do match), with the substitutions at the ends, true indels, N's."""
+    a, b, q_, e_, w = scheme
+    ol = oracle._lib()
+    ol.qo_ksw_extz2.restype = C.c_int
+    rng = np.random.default_rng(7 + w + q_)
+    tot = ext = gapwin = 0
+    for it in range(6000):
+        qlen = int(rng.integers(3, 141))
+        tlen = qlen + int(rng.integers(0, 25))
+        alpha = int(rng.choice([1, 2, 2, 4, 4, 4]))
+        if rng.random() < 0.3:
+            per = int(rng.integers(1, 4)); unit = rng.integers(0, 4, per)
+            base = np.tile(unit, (tlen + 8) // per + 1)[:tlen + 8].astype(np.uint8)
+        else:
+            base = rng.integers(0, alpha, tlen + 8).astype(np.uint8)
+        t = base[:tlen].copy(); q = base[:qlen].copy()
+        nsub = int(rng.choice([2, 2, 2, 1, 3]))
+        pos = rng.choice(qlen, size=min(nsub, qlen), replace=False)
+        if rng.random() < 0.4 and qlen > 6: pos = np.array([qlen - 1 - int(rng.integers(0, 3)), qlen - 1 - int(rng.integers(3, 6))])[:nsub]
+        if rng.random() < 0.2 and qlen > 6: pos = np.array([int(rng.integers(0, 3)), int(rng.integers(3, 6))])[:nsub]
+        for p in pos: q[p] = (q[p] + 1 + rng.integers(0, 3)) % 4
+        if rng.random() < 0.15 and qlen > 5:
+            p = int(rng.integers(0, qlen - 1))
+            if rng.random() < 0.5: q = np.concatenate([q[:p], q[p + 1:], base[qlen:qlen + 1]])
+            else: q = np.concatenate([q[:p], rng.integers(0, 4, 1).astype(np.uint8), q[p:-1]])
+        if rng.random() < 0.03: q[rng.integers(0, qlen)] = 4
+        if rng.random() < 0.03: t[rng.integers(0, tlen)] = 4
+        r = _known_answer_rule(q, t, a, b, q_, e_, w)
+        if r is None: continue
+        ref = ol.qo_ksw_extz2(qlen, q.ctypes.data_as(C.c_void_p), len(t), t.ctypes.data_as(C.c_void_p), a, b, q_, e_, w)
+        assert r == ref, (scheme, qlen, tlen, r, ref, q.tolist(), t.tolist())
+        tot += 1
+        aa, bb = abs(a), -abs(b)
+        U = int(np.where((q < 4) & (t[:qlen] < 4), np.where(q == t[:qlen], aa, bb), 0).sum())
+        if int(np.where(q < 4, aa, 0).sum()) - U > q_ + e_:
+            ext += 1; gapwin += r != U
+    M = abs(a) + abs(b)
+    if M <= q_ + e_: assert tot > 1000
+    if M <= q_ + e_ and (w < 0 or w >= 8) and q_ + 4 * e_ >= 2 * M and q_ + 3 * (e_ + abs(a)) >= 2 * M:   # (the rule's own limits)
+        assert ext > 300 and gapwin > 0, (tot, ext, gapwin)
