@@ -273,6 +273,7 @@ struct QuasiAlignment {
   const qmap::detail::Chunk* qm_chunk_{nullptr};
   uint64_t qm_gen_{0};
   int64_t qm_read_{-1};
+  int32_t qm_count_{0};                // on the first hit of a read's list as hitsToMappingsSimple handed it out: how many there were
 };
 
 // include/RapMapUtils.hpp:516-525
@@ -415,7 +416,7 @@ struct PinnedBuf {
   ~PinnedBuf() { if (p) qm_pinned_free(p); }
   void* need(size_t bytes, bool keep = false) {
     if (bytes <= cap) return p;
-    const size_t nc = bytes + bytes / 2 + 4096;
+    const size_t nc = (cap ? 2 * bytes : bytes + bytes / 2) + 4096;      // (page-locking costs ~25 ms per 100 MB: a buffer that grows again doubles)
     void* q = qm_pinned_alloc(static_cast<int64_t>(nc));
     if (!q) throw Error(QM_E_NOMEM, "out of page-locked host memory");
     if (keep && p && cap) std::memcpy(q, p, cap);
@@ -545,7 +546,9 @@ class Service {
       auto t1 = tw, t2 = tw, t3 = tw;
       if (!rc) {
         int64_t nHits = 0; qm_counters c{};
-        rc = qm_map_pairs_stages(ctx, &b->opts, b->units, b->s1, b->o1, b->s2, b->o2, &nHits, &c);
+        // one pass at a time uploads + computes, one at a time brings its results down: passes of the dispatchers that would start
+        // together take turns instead, and the upload of one runs under the download of the other (the link is full duplex)
+        { std::lock_guard<std::mutex> ph(muMap_); rc = qm_map_pairs_stages(ctx, &b->opts, b->units, b->s1, b->o1, b->s2, b->o2, &nHits, &c); }
         t1 = std::chrono::steady_clock::now();
         int64_t need = 0;
         if (!rc) rc = qm_stage_bytes(ctx, &need);
@@ -553,7 +556,7 @@ class Service {
           try { b->arena.need(static_cast<size_t>(need)); } catch (const Error& e) { rc = e.code(); err = e.what(); }
         }
         t2 = std::chrono::steady_clock::now();
-        if (!rc) rc = qm_fetch_stages(ctx, b->arena.p, static_cast<int64_t>(b->arena.cap), &b->v);
+        if (!rc) { std::lock_guard<std::mutex> ph(muFetch_); rc = qm_fetch_stages(ctx, b->arena.p, static_cast<int64_t>(b->arena.cap), &b->v); }
         t3 = std::chrono::steady_clock::now();
         if (rc && err.empty()) err = qm_last_error();
       }
@@ -573,6 +576,7 @@ class Service {
   }
   const qm_index* ix_; int device_;
   std::mutex mu_; std::condition_variable cvWork_, cvDone_;
+  std::mutex muMap_, muFetch_;
   std::vector<std::unique_ptr<Batch>> all_;
   std::deque<Batch*> ready_;
   Batch* open_{nullptr};
@@ -615,6 +619,7 @@ struct Chunk {
   const char* s1{nullptr}; const char* s2{nullptr}; const int64_t* o1{nullptr}; const int64_t* o2{nullptr};
   int64_t nPacked{0};
   const void* firstRead{nullptr};      // the group a prefetch_async was issued for (prefetch / wait recognise it)
+  uint64_t settings{0}; const void* owner{nullptr};   // the collector that sent the group and the state of its settings then
   void release() { if (batch && svc) svc->release(batch); batch = nullptr; nreads = 0; }
   void bind(Service* s) { if (svc != s) { if (svc) svc->detach(); svc = s; if (svc) svc->attach(); } }
   ~Chunk() { release(); if (svc) svc->detach(); }
@@ -716,18 +721,19 @@ class SACollector {
   using OffsetT = typename RapMapIndexT::IndexType;
   using HCInfo = rapmap::hit_manager::HitCollectorInfo<rapmap::utils::SAIntervalHit<OffsetT>>;
 
-  void disableNIP() { disableNIP_ = true; }
-  void enableNIP() { disableNIP_ = false; }
-  void setCoverageRequirement(double req) { covReq_ = req; }
+  // (every setter moves settings_: a group that was sent under other settings is not what a later per-read call asks for)
+  void disableNIP() { disableNIP_ = true; ++settings_; }
+  void enableNIP() { disableNIP_ = false; ++settings_; }
+  void setCoverageRequirement(double req) { covReq_ = req; ++settings_; }
   double getCoverageRequirement() const { return covReq_; }
-  void setMaxInterval(OffsetT maxInterval) { maxInterval_ = maxInterval; }
+  void setMaxInterval(OffsetT maxInterval) { maxInterval_ = maxInterval; ++settings_; }
   OffsetT getMaxInterval(OffsetT) const { return maxInterval_; }
   bool getStrictCheck() const { return strictCheck_; }
-  void setStrictCheck(bool sc) { strictCheck_ = sc; }
-  void enableChainScoring() { doChaining_ = true; }
-  void disableChainScoring() { doChaining_ = false; }
+  void setStrictCheck(bool sc) { strictCheck_ = sc; ++settings_; }
+  void enableChainScoring() { doChaining_ = true; ++settings_; }
+  void disableChainScoring() { doChaining_ = false; ++settings_; }
   bool getChainScoring() const { return doChaining_; }
-  void setMaxMMPExtension(int32_t ext) { if (ext > 0) { maxMMPExtension_ = ext; } }
+  void setMaxMMPExtension(int32_t ext) { if (ext > 0) { maxMMPExtension_ = ext; ++settings_; } }
   int32_t getMaxMMPExtension() const { return maxMMPExtension_; }
 
   explicit SACollector(RapMapIndexT* rmi) : rmi_(rmi) {}
@@ -739,7 +745,8 @@ class SACollector {
   template <typename PairRange>
   void prefetch(PairRange& rg, const rapmap::utils::MappingConfig& mc = rapmap::utils::MappingConfig(), bool fuzzyMerge = false,
                 uint32_t maxNumHits = 200) {
-    std::vector<const std::string*> l, r;
+    std::vector<const std::string*>& l = ptrs_[0]; std::vector<const std::string*>& r = ptrs_[1];
+    l.clear(); r.clear();
     for (auto& rp : rg) { l.push_back(&rp.first.seq); r.push_back(&rp.second.seq); }
     prefetchPairs(l, r, mc, fuzzyMerge, maxNumHits);
   }
@@ -751,7 +758,8 @@ class SACollector {
   template <typename PairRange>
   void prefetch_async(PairRange& rg, const rapmap::utils::MappingConfig& mc = rapmap::utils::MappingConfig(), bool fuzzyMerge = false,
                       uint32_t maxNumHits = 200) {
-    std::vector<const std::string*> l, r;
+    std::vector<const std::string*>& l = ptrs_[0]; std::vector<const std::string*>& r = ptrs_[1];
+    l.clear(); r.clear();
     for (auto& rp : rg) { l.push_back(&rp.first.seq); r.push_back(&rp.second.seq); }
     submitPairs(l, r, mc, fuzzyMerge, maxNumHits);
   }
@@ -796,6 +804,7 @@ class SACollector {
     Chunk* ch = chp.get();
     ch->gen = next_gen(); ch->paired = true; ch->nreads = 0; ch->cursor = 0;
     stageOpts(ch->opts);
+    ch->settings = settings_; ch->owner = this;
     apply_mc(mc, ch->opts);
     ch->opts.fuzzy = (fuzzyMerge || mc.doChaining) ? 1 : 0;
     ch->opts.max_num_hits = static_cast<int32_t>(maxNumHits);
@@ -842,7 +851,12 @@ class SACollector {
     hcInfo.maxDist = static_cast<int32_t>(read.length());
     Chunk* ch = chunk_.get();
     if (ch) {
-      qm_opts now; stageOpts(now); now.sel_aln = ch->opts.sel_aln; now.consensus_slack = ch->opts.consensus_slack; now.fuzzy = ch->opts.fuzzy;
+      // the group was sent under the collector's settings of that moment (stageOpts): the same ones now, or the stage settings are compared
+      bool sameSettings = ch->settings == settings_ && ch->owner == this;
+      if (!sameSettings) {
+        qm_opts now; stageOpts(now); now.sel_aln = ch->opts.sel_aln; now.consensus_slack = ch->opts.consensus_slack; now.fuzzy = ch->opts.fuzzy;
+        sameSettings = same_stage_opts(now, ch->opts);
+      }
       // The chunk's reads are recognised in order: by the address and length of their characters AND by the characters
       // themselves (a parser that refills its string buffers in place hands out the same addresses with new contents).  A
       // read the caller skipped does not end the fast path: the next few entries are looked at as well.
@@ -856,7 +870,7 @@ class SACollector {
         if (read.size() && std::memcmp(sq + so[u], read.data(), read.size()) != 0) continue;
         idx = c; ch->cursor = c + 1; break;
       }
-      if (idx >= 0 && same_stage_opts(now, ch->opts) && (doChaining_ ? 1 : 0) == ch->opts.sel_aln) {
+      if (idx >= 0 && sameSettings && (doChaining_ ? 1 : 0) == ch->opts.sel_aln) {
         for (int64_t j = ch->v.iv_off[ch->rbase + idx]; j < ch->v.iv_off[ch->rbase + idx + 1]; ++j) {
           const qm_sa_interval_hit& h = ch->v.iv[j];
           (h.query_rc ? hcInfo.rcSAInts : hcInfo.fwdSAInts).emplace_back(static_cast<OffsetT>(static_cast<uint32_t>(h.begin)), static_cast<OffsetT>(static_cast<uint32_t>(h.end)), h.len, h.query_pos, h.query_rc != 0);
@@ -902,6 +916,8 @@ class SACollector {
   bool strictCheck_{false};
   bool doChaining_{false};
   int32_t maxMMPExtension_{7};
+  uint64_t settings_{0};                                       // moved by every setter
+  std::vector<const std::string*> ptrs_[2];                    // (the group's strings, listed: kept between calls)
   std::unique_ptr<qmap::detail::Chunk> chunk_;                 // the current group
   std::deque<std::unique_ptr<qmap::detail::Chunk>> pending_;   // groups sent ahead (prefetch_async), oldest first
   std::vector<std::unique_ptr<qmap::detail::Chunk>> spare_;    // chunk objects of groups that were given back
@@ -920,18 +936,20 @@ void hitsToMappingsSimple(RapMapIndexT& rmi, rapmap::utils::MappingConfig& mc, r
   const size_t before = hits.size();
   const uint32_t readLen = static_cast<uint32_t>(hcinfo.readLen);
   const Chunk* ch = hcinfo.qm_chunk_;
-  qm_opts o; qm_opts_default(&o);
-  apply_mc(mc, o);
+  if (mc.consistentHits || mc.doChaining != mc.considerMultiPos || (!mc.doChaining && mc.consensusFraction != 1.0f)) { qm_opts t; qm_opts_default(&t); apply_mc(mc, t); }   // (throws)
   if (ch && ch->gen == hcinfo.qm_gen_ && hcinfo.qm_read_ >= 0 && (mc.doChaining ? 1 : 0) == ch->opts.sel_aln &&
-      (!mc.doChaining || o.consensus_slack == ch->opts.consensus_slack) &&
+      (!mc.doChaining || -static_cast<double>(mc.consensusFraction) == ch->opts.consensus_slack) &&
       static_cast<int64_t>(hcinfo.fwdSAInts.size() + hcinfo.rcSAInts.size()) == ch->v.iv_off[ch->rbase + hcinfo.qm_read_ + 1] - ch->v.iv_off[ch->rbase + hcinfo.qm_read_]) {
     // the chunk's pass already turned exactly these intervals into the read's list
     const int64_t r = hcinfo.qm_read_, ar = ch->rbase + r;
     decode_list(ch->v.words + ch->v.list_off[ar], ch->v.list_off[ar + 1] - ch->v.list_off[ar], mc.doChaining, readLen, mateStatus, hits);
     for (size_t i = before; i < hits.size(); ++i) { hits[i].qm_chunk_ = ch; hits[i].qm_gen_ = ch->gen; hits[i].qm_read_ = r; }
+    if (hits.size() > before) hits[before].qm_count_ = static_cast<int32_t>(hits.size() - before);
     return;
   }
   // a batch of one, from the intervals the caller holds
+  qm_opts o; qm_opts_default(&o);
+  apply_mc(mc, o);
   std::vector<qm_sa_interval_hit> iv;
   for (int t = 0; t < 2; ++t) {
     auto& v = t == 0 ? hcinfo.fwdSAInts : hcinfo.rcSAInts;
@@ -967,15 +985,14 @@ inline const qmap::detail::Chunk* merge_source(const std::vector<QuasiAlignment>
   if (a && b && (b->qm_chunk_ != ch || b->qm_gen_ != ch->gen || b->qm_read_ != a->qm_read_ + 1)) return nullptr;
   const int64_t rd = a ? a->qm_read_ : b->qm_read_ - 1;
   if (rd < 0 || (rd & 1)) return nullptr;
-  // the other mate's list must be what the chunk has for it (an emptied vector is an edit)
-  auto count = [&](int64_t read) {
+  // both vectors must be what the chunk has for the two mates: as many hits as hitsToMappingsSimple handed out (noted on the first
+  // one), and an empty vector only where the chunk's list is empty (an emptied vector is an edit)
+  auto intact = [&](const std::vector<QuasiAlignment>& v, int64_t read) {
+    if (!v.empty()) return v.front().qm_count_ == static_cast<int32_t>(v.size());
     const int64_t ar = ch->rbase + read;
-    int64_t g = 0; const uint64_t* w = ch->v.words + ch->v.list_off[ar]; const int64_t n = ch->v.list_off[ar + 1] - ch->v.list_off[ar];
-    if (!chained) { for (int64_t i = 0; i < n; ++i) if (i == 0 || (w[i] >> 33) != (w[i - 1] >> 33)) ++g; return g; }
-    for (int64_t i = 0; i < n;) { i += 2 + static_cast<int64_t>(w[i] >> 36) + static_cast<int64_t>(w[i + 1] >> 32); ++g; }
-    return g;
+    return ch->v.list_off[ar + 1] == ch->v.list_off[ar];
   };
-  if (count(rd) != static_cast<int64_t>(l.size()) || count(rd + 1) != static_cast<int64_t>(r.size())) return nullptr;
+  if (!intact(l, rd) || !intact(r, rd + 1)) return nullptr;
   unit = rd >> 1;
   return ch;
 }

@@ -210,7 +210,10 @@ static int ensure(T*& p, int64_t& cap, int64_t want, int64_t minGrow = 0) {
   if (p) hipFree(p);
   p = nullptr;
   int64_t nc = want + minGrow;
-  if (hipMalloc((void**)&p, (size_t)nc * sizeof(T)) != hipSuccess) { cap = 0; return fail(QM_E_NOMEM, "hipMalloc of %lld bytes failed", (long long)(nc * sizeof(T))); }
+  if (cap > 0 && nc < cap + cap / 2) nc = cap + cap / 2;     // a buffer that grows again grows by half: callers whose batches vary in size (the
+                                                             // compat header's batching service) stop paying a round of hipFree / hipMalloc per new maximum
+  if (nc > want + minGrow && hipMalloc((void**)&p, (size_t)nc * sizeof(T)) != hipSuccess) { p = nullptr; (void)hipGetLastError(); nc = want + minGrow; }   // no room for the slack: the exact size
+  if (!p && hipMalloc((void**)&p, (size_t)nc * sizeof(T)) != hipSuccess) { cap = 0; return fail(QM_E_NOMEM, "hipMalloc of %lld bytes failed", (long long)(nc * sizeof(T))); }
   cap = nc;
   return QM_OK;
 }

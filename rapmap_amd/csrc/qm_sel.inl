@@ -1182,7 +1182,7 @@ QM_DEV int sel_unit_merge(const PairBatch& P, const SelBatch& A, long long u, Un
 //           it; a question that needs ksw2 leaves its SelTask in tasks[x]
 //   dedupe  (per question)  the alignment cache: the first earlier question of the unit and mate with the same key owns the score
 //           (a later one points at it); owners that need ksw2 put their index on the order list the alignment kernel walks
-struct SelSide { long long u; long long g; u64 key; int kind; int pad; };   // kind: bit 0 keyed (multi-mapping unit), bit 1 needs ksw2
+struct SelSide { long long u; long long g; u64 key; int kind; int nth; };   // kind: bit 0 keyed (multi-mapping unit), bit 1 needs ksw2; nth: how many questions of the unit precede this one
 
 // which read, orientation, position and chain status the question of slot-side g asks about
 struct SelQ { const unsigned char* read; int readLen; bool fwd; int pos; int cs; };
@@ -1229,6 +1229,7 @@ QM_DEV void sel_unit_sides_write(const PairBatch& P, const SelBatch& A, long lon
   const int n = (int)P.cnt[u];
   const qm_hit* T = A.tmp + A.toff[u];
   const long long gbase = 2 * A.toff[u];
+  int nth = 0;
   for (int i = 0; i < n; ++i) {
     const qm_hit& h = T[i];
     const int sides = sel_hit_sides(P, h);
@@ -1236,7 +1237,7 @@ QM_DEV void sel_unit_sides_write(const PairBatch& P, const SelBatch& A, long lon
       if (!((sides >> sd) & 1)) continue;
       const int cs = sd == 0 ? (h.aln_score & 15) : ((h.aln_score >> 4) & 15);
       if (cs == QM_CS_PERFECT) continue;
-      SelSide S; S.u = u; S.g = gbase + 2 * i + sd; S.key = 0; S.kind = 0; S.pad = 0;
+      SelSide S; S.u = u; S.g = gbase + 2 * i + sd; S.key = 0; S.kind = 0; S.nth = nth++;
       A.sides[base++] = S;
     }
   }
@@ -1419,10 +1420,9 @@ QM_DEV void sel_side_dedupe(const SelBatch& A, long long x) {
   const SelSide S = A.sides[x];
   if (S.kind == 0) return;
   if (S.kind & 1) {
-    long long own = -1;
-    for (long long y = x - 1; y >= 0; --y) {
+    long long own = -1;                                    // (the unit's earlier questions are the S.nth before this one: loads that do not wait for one another)
+    for (long long y = x - 1; y >= x - S.nth; --y) {
       const SelSide& Y = A.sides[y];
-      if (Y.u != S.u) break;
       if ((Y.kind & 1) && ((Y.g ^ S.g) & 1) == 0 && Y.key == S.key) own = y;
     }
     if (own >= 0) {

@@ -40,7 +40,8 @@ static inline uint64_t hit_digest(uint64_t unit, uint64_t j, const rapmap::utils
   return v;
 }
 
-struct Totals { uint64_t digest = 0, pe = 0, se = 0, tot = 0, reads = 0, tooMany = 0, mapped = 0; double prefetchS = 0, loopS = 0, firstAt = 0, lastAt = 0, goSeenAt = 0; };
+struct Totals { uint64_t ph[5] = {0, 0, 0, 0, 0}; uint64_t digest = 0, pe = 0, se = 0, tot = 0, reads = 0, tooMany = 0, mapped = 0; double prefetchS = 0, loopS = 0, firstAt = 0, lastAt = 0, goSeenAt = 0; };
+static inline uint64_t tick() { return __builtin_ia32_rdtsc(); }
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 template <typename RapMapIndexT>
@@ -69,6 +70,30 @@ static void worker(RapMapIndexT& rmi, std::vector<Group>& groups, const std::vec
     if (prefetch) hitCollector.prefetch(rg, mc, fuzzy, maxNumHits);           // <- the one added line
     const double tp1 = now_s();
     size_t u = unit0;
+    static const bool phases = std::getenv("COMPAT_BENCH_PHASES") != nullptr;     // where the loop's time goes (cycle counter around each stage)
+    if (phases) {
+      for (auto& rpair : rg) {
+        const uint64_t c0 = tick();
+        tooManyHits = false; readLen = rpair.first.seq.length(); ++hc.numReads;
+        leftHCInfo.clear(); rightHCInfo.clear(); jointHits.clear(); leftHits.clear(); rightHits.clear();
+        const uint64_t c1 = tick();
+        bool lh = hitCollector(rpair.first.seq, saSearcher, leftHCInfo);
+        bool rh = hitCollector(rpair.second.seq, saSearcher, rightHCInfo);
+        (void)lh; (void)rh;
+        const uint64_t c2 = tick();
+        rapmap::hit_manager::hitsToMappingsSimple(rmi, mc, MateStatus::PAIRED_END_LEFT, leftHCInfo, leftHits);
+        rapmap::hit_manager::hitsToMappingsSimple(rmi, mc, MateStatus::PAIRED_END_RIGHT, rightHCInfo, rightHits);
+        const uint64_t c3 = tick();
+        rapmap::utils::mergeLeftRightHits(leftHits, rightHits, jointHits, readLen, maxNumHits, tooManyHits, hc);
+        if (jointHits.size() > maxNumHits) { jointHits.clear(); }
+        hc.totHits += jointHits.size();
+        const uint64_t c4 = tick();
+        if (count) { if (!jointHits.empty()) ++T.mapped; for (size_t j = 0; j < jointHits.size(); ++j) T.digest += hit_digest(u, j, jointHits[j]); }
+        const uint64_t c5 = tick();
+        if (count) { T.ph[0] += c1 - c0; T.ph[1] += c2 - c1; T.ph[2] += c3 - c2; T.ph[3] += c4 - c3; T.ph[4] += c5 - c4; }
+        ++u;
+      }
+    } else
     for (auto& rpair : rg) {
       // ---- src/RapMapSAMapper.cpp:461-551
       tooManyHits = false;
@@ -182,6 +207,11 @@ int main(int argc, char** argv) {
                      rep, gmax, fmin, fmax, lmin, lmax, joined);
       }
       Totals S;
+      if (std::getenv("COMPAT_BENCH_PHASES")) {
+        uint64_t ph[5] = {0, 0, 0, 0, 0}; for (auto& x : T) for (int i = 0; i < 5; ++i) ph[i] += x.ph[i];
+        std::fprintf(stderr, "[compat_bench] cycles per pair: clear %.0f, collector x2 %.0f, hitsToMappingsSimple x2 %.0f, merge %.0f, digest %.0f\n",
+                     (double)ph[0] / n, (double)ph[1] / n, (double)ph[2] / n, (double)ph[3] / n, (double)ph[4] / n);
+      }
       for (auto& x : T) { S.digest += x.digest; S.mapped += x.mapped; S.prefetchS += x.prefetchS; S.loopS += x.loopS; }
       if (rep == 0 || (double)n / dt > best) { best = (double)n / dt; secs = dt; joinS = joined - dt; }
       tot = S;
