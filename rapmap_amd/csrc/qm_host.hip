@@ -125,7 +125,7 @@ struct qm_ctx {
   uint32_t* d_lcnt = nullptr; long long* d_loff = nullptr;     // per read: list length / offset
   u64* d_lists = nullptr;                                      // bump-allocated per-read hit lists
   qm_hit* d_hits = nullptr;
-  u64* d_scal = nullptr; /* cursor, counters[6], status */ u64* d_gscr = nullptr;
+  u64* d_scal = nullptr; /* cursor, counters[6], status */ u64* d_gscr = nullptr; unsigned* d_gslots = nullptr;   // (scratch slots' flags: gscr_for)
   u64* d_skip = nullptr; std::vector<uint64_t> skipList; int64_t lastSkipped = 0;   // reads the last call skipped (ReadBatch::skiplist)
   void* d_scanTmp = nullptr; size_t scanTmpBytes = 0;
   uint8_t* d_seq1 = nullptr; uint8_t* d_seq2 = nullptr; long long* d_off1 = nullptr; long long* d_off2 = nullptr;
@@ -514,6 +514,7 @@ int qm_ctx_destroy(qm_ctx* c) {
   if (c->planStream) hipStreamDestroy(c->planStream);
   for (hipEvent_t e : c->evPlan) if (e) hipEventDestroy(e);
   if (c->d_ntk) hipFree(c->d_ntk);
+  if (c->d_gslots) hipFree(c->d_gslots);
   if (c->d_ivcsr) hipFree(c->d_ivcsr);
   if (c->d_lcsr) hipFree(c->d_lcsr);
   if (c->d_ivC) hipFree(c->d_ivC);
@@ -760,6 +761,20 @@ static int len_limit(const qm_opts* o) {
   return QM_MAX_LONG_READ_LEN;
 }
 
+// The general kernels' per-wave scratch in device memory (QM_GSCR_U64 words, 112 KB) for a launch of `grid` blocks: one per launched
+// wave while that is no more than the waves that can be resident at once (64 per CU, generously); beyond that -- the oversubscribed
+// grids -- one per SLOT, and the waves take and return slots as they start and end (ReadBatch::gslots).  Returns the flags, or null.
+static int gscr_for(qm_ctx* c, int grid, unsigned*& slots, int& nslots) {
+  const int64_t waves = (int64_t)grid * 4, cap = (int64_t)c->numCU * 64;
+  slots = nullptr; nslots = 0;
+  int rc = ensure(c->d_gscr, c->capGrid, (waves > cap ? cap : waves) * QM_GSCR_U64);
+  if (rc || waves <= cap) return rc;
+  if (!c->d_gslots && hipMalloc((void**)&c->d_gslots, (size_t)cap * sizeof(unsigned)) != hipSuccess) { c->d_gslots = nullptr; return fail(QM_E_NOMEM, "hipMalloc of the scratch slots' flags failed"); }
+  HIPCHK(hipMemsetAsync(c->d_gslots, 0, (size_t)cap * sizeof(unsigned), c->stream));
+  slots = c->d_gslots; nslots = (int)cap;
+  return QM_OK;
+}
+
 static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n, const void* d_seq1, const void* d_off1, const void* d_seq2,
                        const void* d_off2, int ns, ChunkFeeder* feeder, u64* hscal) {
   int rc;
@@ -775,11 +790,11 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
   static const bool leanOff = [] { const char* e = getenv("QM_NO_LEAN"); return e && atoi(e) != 0; }();
   const bool useLean = !leanOff && rq.mode == QM_RUN_FUSED && !o->sel_aln && o->sensitive && ns == 2 && (c->d_slots || c->d_ph) && c->d_saext &&
                        !rq.keepIntervals && !rq.keepFound && c->ix->k <= 31;
+  unsigned* gslots = nullptr; int ngslots = 0;
   if (!useLean) {
-    // every launched wave of the general kernels owns 112 KB of scratch (and open allocator chunks): an oversubscribed grid is 4 to 12
-    // times the resident one.  When that does not fit next to the index, the launch falls back to the resident grid.
-    rc = ensure(c->d_gscr, c->capGrid, (int64_t)grid * 4 * QM_GSCR_U64);
-    if (rc == QM_E_NOMEM) { grid = qmk_resident_grid(nreads, c->numCU); rc = ensure(c->d_gscr, c->capGrid, (int64_t)grid * 4 * QM_GSCR_U64); }
+    // the general kernels' scratch (gscr_for); when even that does not fit next to the index, the launch falls back to the resident grid
+    rc = gscr_for(c, grid, gslots, ngslots);
+    if (rc == QM_E_NOMEM) { grid = qmk_resident_grid(nreads, c->numCU); rc = gscr_for(c, grid, gslots, ngslots); }
     if (rc) return rc;
   }
   // ... and its -s edition stands in for the chain-scoring collector of a fused -s call (intervals and foundHit out; the list kernels
@@ -825,7 +840,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
     B.seq1 = (const unsigned char*)d_seq1; B.off1 = (const long long*)d_off1;
     B.seq2 = (const unsigned char*)d_seq2; B.off2 = (const long long*)d_off2; B.nreads = nreads;
     B.lcnt = c->d_lcnt; B.loff = c->d_loff; B.lists = c->d_lists; B.cursor = c->d_scal; B.lists_cap = c->capLists;
-    B.status = (int*)(c->d_scal + QM_SC_STATUS); B.gscratch = c->d_gscr; B.skiplist = c->d_skip;
+    B.status = (int*)(c->d_scal + QM_SC_STATUS); B.gscratch = c->d_gscr; B.gslots = gslots; B.ngslots = ngslots; B.skiplist = c->d_skip;
     if (wantIv) { B.iv_out = c->d_iv; B.iv_cnt = c->d_ivcnt; B.iv_off = c->d_ivoff; B.iv_cap = c->capIv; }
     if (wantFound) B.found_out = c->d_found;
     B.iv_in = rq.ivIn; B.iv_in_off = rq.ivInOff; B.len_in = rq.lenIn; B.found_in = rq.foundIn;
@@ -944,11 +959,12 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
       const int64_t nq = (int64_t)hscal[QM_SC_LEANQ];
       if ((rc = ensure(c->d_slowq, c->capSlowq, nq))) return rc;
       const int g2 = qmk_map_grid_ex(nq, c->numCU, 0);
-      if ((rc = ensure(c->d_gscr, c->capGrid, (int64_t)g2 * 4 * QM_GSCR_U64))) return rc;
+      unsigned* gs2 = nullptr; int ngs2 = 0;
+      if ((rc = gscr_for(c, g2, gs2, ngs2))) return rc;
       HIPCHK(hipMemsetAsync(c->d_scal + QM_SC_SLOWQ, 0, sizeof(u64), c->stream));
       HIPCHK(qmk_collect_lean(c->d_lcnt, nreads, c->d_slowq, (unsigned long long*)(c->d_scal + QM_SC_SLOWQ), c->stream));
       ReadBatch S2 = B;
-      S2.slowq = c->d_slowq; S2.nreads = nq; S2.gscratch = c->d_gscr;      // (B was filled in before the scratch existed)
+      S2.slowq = c->d_slowq; S2.nreads = nq; S2.gscratch = c->d_gscr; S2.gslots = gs2; S2.ngslots = ngs2;      // (B was filled in before the scratch existed)
       HIPCHK(hipEventRecord(c->evA, c->stream));
       HIPCHK(qmk_map_reads(&ix, &S2, ns, g2, c->numCU, c->stream));
       HIPCHK(hipEventRecord(c->evB, c->stream));
@@ -969,7 +985,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
       ReadBatch S2 = B;
       S2.slowq = c->d_slowq; S2.nreads = nl_;
       const int g2 = qmk_map_grid_ex(nl_, c->numCU, phc);
-      if (useLean) { if ((rc = ensure(c->d_gscr, c->capGrid, (int64_t)(g2 < grid ? g2 : grid) * 4 * QM_GSCR_U64))) return rc; S2.gscratch = c->d_gscr; }
+      if (useLean) { unsigned* gs3 = nullptr; int ngs3 = 0; if ((rc = gscr_for(c, g2 < grid ? g2 : grid, gs3, ngs3))) return rc; S2.gscratch = c->d_gscr; S2.gslots = gs3; S2.ngslots = ngs3; }
       HIPCHK(qmk_map_reads(&ix, &S2, rq.mode == QM_RUN_COLLECT ? -32 : 32, g2 < grid ? g2 : grid, c->numCU, c->stream));
       HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));

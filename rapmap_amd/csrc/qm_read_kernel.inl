@@ -39,7 +39,21 @@ __global__ __launch_bounds__(64 * WavesPerBlock<NS>::value, WPS) void qm_read_ke
   const int gw = (int)blockIdx.x * WB + wave;            // reads per launch < 2^31: 32-bit slot arithmetic
   const int nw = (int)gridDim.x * WB;
   const int nreads = (int)B.nreads;
-  u64* gscr = B.gscratch + (long long)gw * QM_GSCR_U64;
+  // the wave's 112 KB of device-memory scratch: its own by launch index, or -- a grid several times the resident one -- a slot taken
+  // from the flags (linear probing from a hashed start; there are at least as many slots as resident waves, so one is always free)
+  int gslot = gw;
+  if (B.gslots) {
+    int s = 0;
+    if ((threadIdx.x & 63) == 0) {
+      const unsigned n = (unsigned)B.ngslots;
+      unsigned h = ((unsigned)gw * 2654435761u) % n;
+      while (atomicCAS(&B.gslots[h], 0u, 1u) != 0u) h = h + 1 == n ? 0u : h + 1;
+      s = (int)h;
+    }
+    gslot = __builtin_amdgcn_readfirstlane(s);
+    __threadfence();
+  }
+  u64* gscr = B.gscratch + (long long)gslot * QM_GSCR_U64;
   WaveAlloc wa; wa.base = -1; wa.used = 0; wa.ivBase = -1; wa.ivUsed = 0;
 #ifdef QM_TIMING
   if ((threadIdx.x & 63) == 0) { for (int i = 0; i < 9; ++i) qm_tim[wave][i] = 0; qm_tim[wave][9] = __builtin_readcyclecounter(); }
@@ -57,6 +71,7 @@ __global__ __launch_bounds__(64 * WavesPerBlock<NS>::value, WPS) void qm_read_ke
                     ((F & QM_F_SEL) && B.dyn) ? B.dyn + gw : nullptr);
     par ^= 1;
   }
+  if (B.gslots && (threadIdx.x & 63) == 0) __hip_atomic_store(&B.gslots[gslot], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // (this wave's stores to the slot land before the next holder's)
 #ifdef QM_TIMING
   if ((threadIdx.x & 63) == 0) for (int i = 0; i < 7; ++i) atomicAdd((unsigned long long*)&B.cursor[20 + i], (unsigned long long)qm_tim[wave][i]);
 #endif
