@@ -301,11 +301,12 @@ def roofline(bpp, w, n, kernel_ms, kernel, traffic_key, genes, step_ms=None, ext
     return out
 
 
-def dp_roofline(w, pairs_per_s, step_ms, n, genes):
+def dp_roofline(w, pairs_per_s, step_ms, n, genes, mp=None):
     """-s: the ksw2 work as a compute roofline -- band cells of the reference's algorithm (the alignments it runs: cache misses,
     neither PERFECT nor UNGAPPED chains; oracle counters on this input) per second, against the VALU issue peak for the
-    recurrence.  The device answers part of those alignments without running them (sel_plan_side: a gapless path that loses
-    no more than one gap); the cells are the reference's either way."""
+    recurrence.  The device answers most of those alignments without running them (sel_side_score: a gapless path that loses
+    no more than one gap, and with two mismatches the best of that path and the one-gap-run paths); the cells are the
+    reference's either way, and `device` says how many alignments the device's ksw2 kernel actually ran."""
     cells = w.get("n_cells", 0.0)
     _, _, ent = pmc_traffic("sel", n, genes)
     d = {"alignments_per_pair": round(w.get("n_aln", 0), 3), "band_cells_per_pair": round(cells, 1),
@@ -313,10 +314,20 @@ def dp_roofline(w, pairs_per_s, step_ms, n, genes):
          "frac": round(cells * pairs_per_s / 1e9 / KSW2_PEAK_G_CELLS, 5),
          "peak_is": "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction x 128 cells per 13 packed 16-bit instructions (the recurrence alone)",
          "note": "whole-step rate (the alignment kernels overlap the plan kernels of the following chunks)"}
+    if mp is not None:
+        try:
+            d["device"] = {"alignment_questions_per_pair": round(mp.stat(6) / float(n), 3), "ksw2_alignments_run_per_pair": round(mp.stat(7) / float(n), 3),
+                           "what": "qm_ctx_stat of the last timed step: hits x mates beyond PERFECT chains that getAlnScore is asked about; those of them the "
+                                   "ksw2 kernel ran (the rest: alignment-cache hits, ungapped chains, answers known without ksw2)"}
+        except Exception as ex:  # noqa: BLE001
+            d["device"] = {"error": repr(ex)}
     if ent.get("ksw2_kernel_ms_per_step") and genes == 40000:
         km = ent["ksw2_kernel_ms_per_step"] * (n / float(ent.get("pairs_per_launch", 10_000_000)))
-        d["in_ksw2_kernels"] = {"kernel_ms_per_step": round(km, 2), "G_cell_updates_per_s": round(cells * n / (km * 1e-3) / 1e9, 1),
-                                "frac": round(cells * n / (km * 1e-3) / 1e9 / KSW2_PEAK_G_CELLS, 4),
+        run = d.get("device", {}).get("ksw2_alignments_run_per_pair")
+        share = min(1.0, run / w["n_aln"]) if run is not None and w.get("n_aln", 0) > 0 else 1.0      # the cells of the alignments the kernel itself ran
+        d["in_ksw2_kernels"] = {"kernel_ms_per_step": round(km, 2), "share_of_the_reference_alignments_run": round(share, 4),
+                                "G_cell_updates_per_s": round(share * cells * n / (km * 1e-3) / 1e9, 1),
+                                "frac": round(share * cells * n / (km * 1e-3) / 1e9 / KSW2_PEAK_G_CELLS, 4),
                                 "source": ent.get("source", "profiles/pmc_traffic.json") + " (kernel-trace sum of the alignment kernels of one step)"}
     return d
 
@@ -542,7 +553,7 @@ def main():
         if ph_levels is not None:
             extra["ph_levels_per_probe"] = round(ph_levels, 3)
         if args.sel_aln:   # with -s report the DP cells separately
-            extra["dp"] = dp_roofline(w, value * 1e6, el / args.steps * 1e3, n, args.genes)
+            extra["dp"] = dp_roofline(w, value * 1e6, el / args.steps * 1e3, n, args.genes, mp)
         out["roofline"] = roofline(bpp, w, n, avg_kernel_ms, KERNELS[head_key], head_key, args.genes, step_ms=el / args.steps * 1e3, extra=extra,
                                    whole_step=bool(args.sel_aln))
         out["speedup_vs_cpu_baseline"] = round(value / cpu_val, 2) if cpu_val > 0 else None
@@ -726,7 +737,7 @@ def other_configs(oc, args, ra, qd, oracles, oracle, qi, idx_dir, mp, s1, s2, of
     bpp, w = algorithmic_bytes_per_pair(cp["work"], cp["sample"], L)
     leg("configs[4] selective alignment (-s)", mp, o_sel, "sel", bpp, w, cp,
         "the headline's index and reads with -s: chain-scoring collector, chaining, ksw2 extension alignment, score gate",
-        extra=lambda val, step_ms: {"dp": dp_roofline(w, val * 1e6, step_ms, n, args.genes),
+        extra=lambda val, step_ms: {"dp": dp_roofline(w, val * 1e6, step_ms, n, args.genes, mp),
                                     "note": "kernel_ms spans the two stage-A launches (collector, then intervals -> lists); the plan / ksw2 / finish "
                                             "kernels of stage B-C are in ms_per_step, which is what `frac` is taken over"},
         whole_step=True)

@@ -17,7 +17,7 @@ pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
   echo "# rocprofv3 --kernel-trace --stats -- python bench.py $ARGS --steps 3 --warmup 1"
   f=$(find $OUT/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -10 "$f" | cut -c1-230
   echo "# bench line of that run:"
-  tail -1 $OUT/stats.log | cut -c1-600
+  grep '^{"metric"' $OUT/stats.log | tail -1 | cut -c1-600
   echo "# PMC passes (-- python bench.py $ARGS --steps 1 --warmup 1), per dispatch; FETCH_SIZE / WRITE_SIZE in KiB as reported and in GB"
   python - $OUT <<'PY'
 import csv, sys, collections, glob

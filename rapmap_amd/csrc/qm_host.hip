@@ -156,6 +156,7 @@ struct qm_ctx {
   // last result
   int64_t lastUnits = -1, lastHits = 0; bool lastPaired = false;
   double lastMapMs = 0, lastTotalMs = 0;
+  int64_t lastSelQuestions = 0, lastKswTasks = 0;             // -s: alignment questions beyond PERFECT chains of the last call, ksw2 alignments run for them
   int64_t lastRelaunches = 0, lastSlowReads = 0, lastLeanReads = -1, lastLeanDeferred = 0;   // lastLeanReads: reads the lean kernel was launched over (-1: not used)
   // qm_map_device on a large batch: its parts on helper contexts of the same replica, in flight together (map_device_split)
   uint32_t flags = 0; bool isHelper = false;
@@ -1165,14 +1166,13 @@ static int run_stage_b(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
   HIPCHK(hipMemcpyAsync(&total, c->d_offs + n, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  c->lastSelQuestions = 0; c->lastKswTasks = 0;
   if (o->sel_aln && !rq.mergeOnly) {
+    u64 h[2 * QM_SEL_CHUNKS_B];
+    HIPCHK(hipMemcpy(h, c->d_ntk, sizeof(h), hipMemcpyDeviceToHost));
+    for (int i = 0; i < QM_SEL_CHUNKS_B; ++i) { c->lastKswTasks += (int64_t)h[i]; c->lastSelQuestions += (int64_t)h[QM_SEL_CHUNKS_B + i]; }
     static const bool dbg = [] { const char* e = getenv("QM_SEL_DEBUG"); return e && atoi(e) != 0; }();
-    if (dbg) {
-      u64 h[2 * QM_SEL_CHUNKS_B];
-      HIPCHK(hipMemcpy(h, c->d_ntk, sizeof(h), hipMemcpyDeviceToHost));
-      u64 nt = 0, nsd = 0; for (int i = 0; i < QM_SEL_CHUNKS_B; ++i) { nt += h[i]; nsd += h[QM_SEL_CHUNKS_B + i]; }
-      fprintf(stderr, "[qm -s] %lld units: %llu alignment questions beyond PERFECT chains, %llu ksw2 alignments\n", (long long)n, (unsigned long long)nsd, (unsigned long long)nt);
-    }
+    if (dbg) fprintf(stderr, "[qm -s] %lld units: %lld alignment questions beyond PERFECT chains, %lld ksw2 alignments\n", (long long)n, (long long)c->lastSelQuestions, (long long)c->lastKswTasks);
   }
   if (rq.join) {
     long long b = 0; qm_hit* dst = nullptr;
@@ -1319,13 +1319,13 @@ static int map_device_split(qm_ctx* c, const qm_opts* o, int K, int64_t n, const
   }
   c->lastMapMs = last > first ? last - first : 0;
   float ms = 0; hipEventElapsedTime(&ms, c->evA, c->evB); c->lastTotalMs = ms;
-  c->lastRelaunches = 0; c->lastSlowReads = 0; c->lastSkipped = 0; c->skipList.clear();
+  c->lastRelaunches = 0; c->lastSlowReads = 0; c->lastSkipped = 0; c->skipList.clear(); c->lastSelQuestions = 0; c->lastKswTasks = 0;
   qm_counters sum; memset(&sum, 0, sizeof(sum));
   for (int i = 0; i < K; ++i) {
     sum.pe_hits += ctr[i].pe_hits; sum.se_hits += ctr[i].se_hits; sum.tot_hits += ctr[i].tot_hits; sum.num_reads += ctr[i].num_reads;
     sum.too_many_hits += ctr[i].too_many_hits; sum.mapped += ctr[i].mapped;
     qm_ctx* h = c->helpers[(size_t)i];
-    c->lastRelaunches += h->lastRelaunches; c->lastSlowReads += h->lastSlowReads;
+    c->lastRelaunches += h->lastRelaunches; c->lastSlowReads += h->lastSlowReads; c->lastSelQuestions += h->lastSelQuestions; c->lastKswTasks += h->lastKswTasks;
     // the part's skipped reads, as reads of the whole batch
     int64_t u0 = n * i / K;
     if (K == 2 && firstPct > 0) u0 = i == 0 ? 0 : n * firstPct / 100;
@@ -1805,6 +1805,8 @@ int qm_ctx_stat(const qm_ctx* c, int which, int64_t* value) {
     case QM_STAT_LEAN_READS: *value = c->lastLeanReads; break;
     case QM_STAT_LEAN_DEFERRED: *value = c->lastLeanDeferred; break;
     case QM_STAT_SKIPPED_READS: *value = c->lastSkipped; break;
+    case QM_STAT_SEL_QUESTIONS: *value = c->lastSelQuestions; break;
+    case QM_STAT_KSW2_ALIGNMENTS: *value = c->lastKswTasks; break;
     default: return fail(QM_E_ARG, "unknown statistic %d", which);
   }
   return QM_OK;
