@@ -18,7 +18,7 @@ hipError_t qmk_build_sanext(const unsigned char* text, long long n, const unsign
 hipError_t qmk_build_slots(const void* recs, long long K, void* slots, unsigned long long cap, int k, hipStream_t st);
 hipError_t qmk_build_slots_from_ph(const void* dev_index, long long n, void* slots, unsigned long long cap, unsigned long long* d_bad, hipStream_t st);
 hipError_t qmk_build_phrecs(const unsigned int* data, const unsigned char* lens, long long n, const void* dev_index, void* out, hipStream_t st);
-hipError_t qmk_build_phfilter(const void* recs, long long n, void* filter, unsigned long long mask, hipStream_t st);
+hipError_t qmk_build_phfilter(const void* recs, long long n, void* filter, unsigned long long mask, int k, hipStream_t st);
 int qmk_map_grid(long long n, int num_cu);
 int qmk_map_grid_ex(long long n, int num_cu, int ph_compact);   // ph_compact: the compact -p kernels' oversubscription
 int qmk_grid_oversub_ph(void);

@@ -661,7 +661,7 @@ int qm_ctx_create_ex(const qm_index* ix, int device_id, uint32_t flags, qm_ctx**
       u64* dFil = (u64*)dalloc(fw * 8);
       if (!dFil) { int rc = fail(QM_E_NOMEM, "hipMalloc (perfect hash filter) failed"); qm_ctx_destroy(c); return rc; }
       CK(hipMemsetAsync(dFil, 0, fw * 8, c->stream));
-      CK(qmk_build_phfilter(dRec, (long long)ix->phNelem, dFil, fw - 1, c->stream));
+      CK(qmk_build_phfilter(dRec, (long long)ix->phNelem, dFil, fw - 1, ix->k, c->stream));
       P.filter = dFil; P.filterMask = fw - 1;
     }
     CK(hipMemcpyAsync(dP, &P, sizeof(P), hipMemcpyHostToDevice, c->stream));

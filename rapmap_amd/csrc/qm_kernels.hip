@@ -351,12 +351,12 @@ __global__ void build_phrec_kernel(const u32* data, const unsigned char* lens, l
 }
 
 // membership pre-filter of the compact -p image (PhIndex::filter): four bits per key of the index
-__global__ void build_phfilter_kernel(const PhRec* recs, long long n, unsigned long long* filter, u64 mask) {
+__global__ void build_phfilter_kernel(const PhRec* recs, long long n, unsigned long long* filter, u64 mask, int k) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long stride = (long long)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
     u64 w, bits;
-    ph_filter_slot(recs[i].key, mask, w, bits);
+    ph_filter_slot(recs[i].key, word_rc(recs[i].key, k), mask, w, bits);
     atomicOr(&filter[w], (unsigned long long)bits);
   }
 }
@@ -469,9 +469,9 @@ hipError_t qmk_build_phrecs(const unsigned int* data, const unsigned char* lens,
   return hipGetLastError();
 }
 
-hipError_t qmk_build_phfilter(const void* recs, long long n, void* filter, unsigned long long mask, hipStream_t st) {
+hipError_t qmk_build_phfilter(const void* recs, long long n, void* filter, unsigned long long mask, int k, hipStream_t st) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(build_phfilter_kernel, dim3(4096), dim3(256), 0, st, (const PhRec*)recs, n, (unsigned long long*)filter, (u64)mask);
+  hipLaunchKernelGGL(build_phfilter_kernel, dim3(4096), dim3(256), 0, st, (const PhRec*)recs, n, (unsigned long long*)filter, (u64)mask, k);
   return hipGetLastError();
 }
 

@@ -104,10 +104,10 @@ QM_DEV void lean_find(const DevIndex& ix, const LV<u64>& ck, const LV<bool>& isr
 
 // the same through the compact -p image: the pre-filter for the whole round (one sector per key, no per-lane control flow), then the
 // BooPHF walk for the keys it lets through (present keys and 2e-4 of the absent ones)
-QM_DEV void lean_find_ph(const DevIndex& ix, const LV<u64>& key, const LV<bool>& on, LV<bool>& hit, LV<u32>& lb, LV<u32>& ub) {
+QM_DEV void lean_find_ph(const DevIndex& ix, const LV<u64>& key, const LV<u64>& krc, const LV<bool>& on, LV<bool>& hit, LV<u32>& lb, LV<u32>& ub) {
   LV<bool> want;
   QM_LANES(l) { want[l] = on[l]; }
-  ph_filter_round(ix, key, want);
+  ph_filter_round(ix, key, krc, want);
   QM_LANES(l) {
     bool h = false; u32 a = 0, b = 0;
     if (want[l]) h = find_kmer<QM_F_PH>(ix, key[l], a, b);
@@ -127,24 +127,24 @@ template <bool PH>
 QM_DEV void lean_probe(const DevIndex& ix, const QM_LDS(u64)* pk2, int D, int V, int P, int k, int wb, int ww, LeanWin& W, int stride = 1) {
   if (wb + ww > P) ww = P - wb;
   QM_CNT(3, 1); QM_CNT(4, (ww + stride - 1) / stride);
-  LV<u64> ck; LV<bool> isr, on, hit;
+  LV<u64> ck, cr; LV<bool> isr, on, hit;
   QM_LANES(l) {
     const int j = l & 31;
     const bool in = j < ww && (j & (stride - 1)) == 0;
     const int q = in ? wb + j : 0;
+    const u64 w = lean_kmer(pk2 + 8 * V, q + (V ? D : 0), k), wr = lean_kmer(pk2 + 8 * (1 - V), P - 1 - q + (V ? 0 : D), k);
     if (PH) {
       const bool comp = l >= 32;                           // lanes 32-63: the reverse complement = the other image's k-mer at P - 1 - q
-      ck[l] = lean_kmer(pk2 + 8 * (comp ? 1 - V : V), comp ? P - 1 - q + (V ? 0 : D) : q + (V ? D : 0), k);
+      ck[l] = comp ? wr : w; cr[l] = comp ? w : wr;        // (the structure is keyed by the k-mer itself; the pre-filter's word by the canonical one)
       isr[l] = false;
     } else {
-      const u64 w = lean_kmer(pk2 + 8 * V, q + (V ? D : 0), k), wr = lean_kmer(pk2 + 8 * (1 - V), P - 1 - q + (V ? 0 : D), k);
       const bool big = wr < w;                             // the strand's k-mer is the larger of the two
       ck[l] = big ? wr : w;
       isr[l] = big != (l >= 32);                           // lanes 32-63 ask for the other orientation
     }
     on[l] = in;
   }
-  if (PH) lean_find_ph(ix, ck, on, hit, W.lb, W.ub);
+  if (PH) lean_find_ph(ix, ck, cr, on, hit, W.lb, W.ub);
   else lean_find(ix, ck, isr, on, hit, W.lb, W.ub);
   const u64 fm = ballot(hit);
   W.Fm = (u32)fm; W.Cm = (u32)(fm >> 32); W.Km = (u32)ballot(on); W.wb = wb; W.ww = ww;
@@ -296,7 +296,7 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
   // ---- the first probe of both reads in one round (SACollector.hpp:167-237 starts at position 0; the read's last k-mer is the
   // first thing the reverse-complement pass asks for): lanes 0-3 of each half = the read's k-mer 0, its k-mer P - 1, and --
   // from the second image -- the reverse complements of those two
-  LV<u64> ck; LV<bool> isr, on, hit; LV<u32> plb, pub;
+  LV<u64> ck, cr; LV<bool> isr, on, hit; LV<u32> plb, pub;
   QM_LANES(l) {
     const int h = l >> 5, jj = l & 31;
     const int P = h ? P1 : P0, D = QM_LEAN_MAXLEN - (h ? len1 : len0);
@@ -307,16 +307,16 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
     const QM_LDS(u64)* pkh = (const QM_LDS(u64)*)&M.pk[0][0][0] + 16 * h;
     const bool s = (jj >> 1) & 1;
     const u64 w = lean_kmer(pkh + (s ? 8 : 0), q + (s ? D : 0), k);
-    if (PH) { ck[l] = w; isr[l] = false; }                   // (the lane's own word: jj 2 / 3 read the second image)
+    const u64 wr = lean_kmer(pkh + (s ? 0 : 8), qo + (s ? 0 : D), k);
+    if (PH) { ck[l] = w; cr[l] = wr; isr[l] = false; }       // (the lane's own word: jj 2 / 3 read the second image)
     else {
-      const u64 wr = lean_kmer(pkh + (s ? 0 : 8), qo + (s ? 0 : D), k);
       const bool big = wr < w;
       ck[l] = big ? wr : w; isr[l] = big;
     }
     on[l] = o;
   }
   QM_CNT(3, 1);
-  if (PH) lean_find_ph(ix, ck, on, hit, plb, pub);
+  if (PH) lean_find_ph(ix, ck, cr, on, hit, plb, pub);
   else lean_find(ix, ck, isr, on, hit, plb, pub);
   const u64 fm0 = ballot(hit);
   lds_dma_wait();                                          // what was requested above has landed by now: no store follows an open request

@@ -115,17 +115,21 @@ struct PhIndex {
   u64 lastbitsetrank, nelem;
   int nb_levels;
   // Membership pre-filter (not part of the reference's structure; it changes no answer): one 64-bit word per ~1-2 keys, four
-  // bits set per key (ph_filter_slot).  The large majority of the k-mers a read asks for are NOT in the index (every k-mer
+  // bits set per key (ph_filter_slot).  Round 5: the word is chosen by the CANONICAL k-mer (the smaller of the k-mer and its reverse
+  // complement) and the four bits by the orientation as well, so the two strands' questions about a read position -- the k-mer and its
+  // reverse complement -- read the same word: one sector per position instead of two.  The large majority of the k-mers a read asks for are NOT in the index (every k-mer
   // over a sequencing error, every opposite-strand k-mer); through the levels such a key costs 3.3 sectors on average before
   // it is rejected, here it costs one.  No false negatives, ~2e-4 false positives (which then take the walk and fail there).
   const u64* filter; u64 filterMask;   // null: no filter
 };
-// word and bit mask of a key in the pre-filter: one 32 x 32 -> 64-bit multiply (the bucket hash's product); the word comes from
-// the fold of its halves, the four bit positions from the low half
-QM_DEV void ph_filter_slot(u64 key, u64 mask, u64& word, u64& bits) {
-  const u64 p = (u64)((u32)key ^ 0x9E3779B1u) * (u64)((u32)(key >> 32) ^ 0x85EBCA6Bu);
+// word and bit mask of a key (krc: its reverse complement) in the pre-filter: one 32 x 32 -> 64-bit multiply of the canonical key's
+// halves (the bucket hash's product); the word comes from the fold of the product's halves, the four bit positions from 24 bits of it --
+// the low ones for a key that is its own canonical form, the next ones for one that is the reverse complement of it
+QM_DEV void ph_filter_slot(u64 key, u64 krc, u64 mask, u64& word, u64& bits) {
+  const u64 c = krc < key ? krc : key;
+  const u64 p = (u64)((u32)c ^ 0x9E3779B1u) * (u64)((u32)(c >> 32) ^ 0x85EBCA6Bu);
   word = (u64)((u32)(p >> 32) ^ (u32)p ^ (u32)(p >> 13)) & mask;
-  const u32 lo = (u32)p;
+  const u32 lo = krc < key ? (u32)(p >> 24) : (u32)p;
   bits = (1ULL << (lo & 63)) | (1ULL << ((lo >> 6) & 63)) | (1ULL << ((lo >> 12) & 63)) | (1ULL << ((lo >> 18) & 63));
 }
 inline constexpr u64 ph_filter_words(u64 nelem) { u64 c = 64; while (c < nelem / 2 + 1) c <<= 1; return c; }
@@ -464,12 +468,12 @@ QM_DEV void bucket_insert(Bucket* buckets, u64 hmask, u64 key, int k, u32 lb, u3
 
 // The pre-filter for a whole probe round, without per-lane control flow: every lane loads its word (lanes with nothing to look
 // up read word 0), `want` loses the keys that cannot be in the index.  Only the survivors walk the levels.
-QM_DEV void ph_filter_round(const DevIndex& ix, const LV<u64>& key, LV<bool>& want) {
+QM_DEV void ph_filter_round(const DevIndex& ix, const LV<u64>& key, const LV<u64>& krc, LV<bool>& want) {
   const PhIndex& P = ix.phv;
   if (!P.filter) return;
   QM_LANES(l) {
     u64 w, bits;
-    ph_filter_slot(key[l], P.filterMask, w, bits);
+    ph_filter_slot(key[l], krc[l], P.filterMask, w, bits);
     const u64 x = P.filter[want[l] ? w : 0ULL];
     QM_CNT(1, want[l] ? 1 : 0);
     want[l] = want[l] && (x & bits) == bits;
@@ -831,7 +835,7 @@ QM_DEV void probe_window(const DevIndex& ix, Strand<NS>& S, int p, int width, in
   wave_fence();
   if (!(F & QM_F_PH)) find_dense_round(ix, kq, kr, want, found, val);
   else {
-    ph_filter_round(ix, kq, want);
+    ph_filter_round(ix, kq, kr, want);
     QM_LANES(l) {
       bool hit = false; Iv v = {0, 0};
       if (want[l]) hit = find_kmer<F>(ix, kq[l], v.lb, v.ub);
@@ -875,7 +879,7 @@ QM_DEV bool probe_first(const DevIndex& ix, Strand<NS>& S, int p, Iv* rtab0) {
   wave_fence();
   if (!(F & QM_F_PH)) find_dense_round(ix, kq, kr, want, found, val);
   else {
-    ph_filter_round(ix, kq, want);
+    ph_filter_round(ix, kq, kr, want);
     QM_LANES(l) {
       bool hit = false; Iv v = {0, 0};
       if (want[l]) hit = find_kmer<F>(ix, kq[l], v.lb, v.ub);

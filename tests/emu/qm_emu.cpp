@@ -399,7 +399,7 @@ void* qe_ph_create(const unsigned long long* words, const unsigned long long* ra
     const u64 fw = ph_filter_words(nelem);
     u64* fil = new u64[fw];
     for (u64 i = 0; i < fw; ++i) fil[i] = 0;
-    for (u64 i = 0; i < nelem; ++i) { u64 w, bits; ph_filter_slot(recs[i].key, fw - 1, w, bits); fil[w] |= bits; }
+    for (u64 i = 0; i < nelem; ++i) { u64 w, bits; ph_filter_slot(recs[i].key, word_rc(recs[i].key, k), fw - 1, w, bits); fil[w] |= bits; }
     P->filter = fil; P->filterMask = fw - 1;
   }
   u64 cap = 16; while (cap < (u64)n_ovf * 2) cap <<= 1;
