@@ -17,6 +17,7 @@ r = mp.map_device(n, s1.data_ptr(), off.data_ptr(), s2.data_ptr(), off.data_ptr(
 want = bench.compat_digest(r.hit_offsets, r.hits)
 h1 = s1[: n * 100].cpu().numpy(); h2 = s2[: n * 100].cpu().numpy()
 os.makedirs("/tmp/cp", exist_ok=True)
+open("/tmp/cp/idx.txt", "w").write(idx)
 exe = bench.build_compat_bench("/tmp/cp")
 with open("/tmp/cp/reads.bin", "wb") as f:
     f.write(h1.tobytes()); f.write(h2.tobytes())

@@ -162,8 +162,9 @@ struct ReadBatch {
   u64* cursor;             // bump pointer
   long long lists_cap;
   u64* gscratch;           // per wave: QM_GSCR_U64 words -- of wave gw of the launch, or (gslots != null) of the slot the wave holds while it runs
-  u32* gslots; int ngslots; // oversubscribed grids: one flag per scratch slot (>= the waves that can be resident at once); a wave takes a free one when it
-                           // starts and gives it back when it ends, so the scratch is sized by residency, not by the launch
+  u32* gslots; int ngslots; // oversubscribed grids: one flag per scratch slot (a multiple of 8: an eighth per XCD, each at least the waves that can be
+                           // resident there); a wave takes a free one of its XCD when it starts and gives it back when it ends, so the scratch is
+                           // sized by residency, not by the launch
   int* status;             // sticky error flags (bit0: lists overflow, bit1: interval too wide, bit2: read too long, bit4: interval output overflow)
   // SA-interval hits as an output of their own (HitCollectorInfo::fwdSAInts / rcSAInts): read r's records sit at
   // iv_out[iv_off[r] .. + iv_cnt[r]), forward strand first.  Null unless the caller asked for them.

@@ -40,18 +40,21 @@ __global__ __launch_bounds__(64 * WavesPerBlock<NS>::value, WPS) void qm_read_ke
   const int nw = (int)gridDim.x * WB;
   const int nreads = (int)B.nreads;
   // the wave's 112 KB of device-memory scratch: its own by launch index, or -- a grid several times the resident one -- a slot taken
-  // from the flags (linear probing from a hashed start; there are at least as many slots as resident waves, so one is always free)
+  // from the flags of the XCD the wave runs on (linear probing from a hashed start inside that eighth of the flags: at least twice as
+  // many slots as an XCD's resident waves, so one is always free).  A slot only ever passes between waves of one XCD -- one L2 --, so
+  // handing it on needs no cache maintenance: the holder waits for its own stores to be acknowledged, then clears the flag.  (An
+  // agent-scope release per wave writes the XCD's L2 back: measured, it made a launch over 20 000 reads take a millisecond.)
   int gslot = gw;
   if (B.gslots) {
     int s = 0;
     if ((threadIdx.x & 63) == 0) {
-      const unsigned n = (unsigned)B.ngslots;
-      unsigned h = ((unsigned)gw * 2654435761u) % n;
-      while (atomicCAS(&B.gslots[h], 0u, 1u) != 0u) h = h + 1 == n ? 0u : h + 1;
-      s = (int)h;
+      const unsigned per = (unsigned)B.ngslots >> 3;
+      const unsigned base = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) * per;      // HW_REG_XCC_ID, bits 3:0
+      unsigned h = ((unsigned)gw * 2654435761u) % per;
+      while (atomicCAS(&B.gslots[base + h], 0u, 1u) != 0u) h = h + 1 == per ? 0u : h + 1;
+      s = (int)(base + h);
     }
     gslot = __builtin_amdgcn_readfirstlane(s);
-    __threadfence();
   }
   u64* gscr = B.gscratch + (long long)gslot * QM_GSCR_U64;
   WaveAlloc wa; wa.base = -1; wa.used = 0; wa.ivBase = -1; wa.ivUsed = 0;
@@ -71,7 +74,10 @@ __global__ __launch_bounds__(64 * WavesPerBlock<NS>::value, WPS) void qm_read_ke
                     ((F & QM_F_SEL) && B.dyn) ? B.dyn + gw : nullptr);
     par ^= 1;
   }
-  if (B.gslots && (threadIdx.x & 63) == 0) __hip_atomic_store(&B.gslots[gslot], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // (this wave's stores to the slot land before the next holder's)
+  if (B.gslots) {
+    __builtin_amdgcn_s_waitcnt(0);                           // (this wave's stores to the slot have reached the L2 before the next holder's can)
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(&B.gslots[gslot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 #ifdef QM_TIMING
   if ((threadIdx.x & 63) == 0) for (int i = 0; i < 7; ++i) atomicAdd((unsigned long long*)&B.cursor[20 + i], (unsigned long long)qm_tim[wave][i]);
 #endif
