@@ -1342,13 +1342,15 @@ static int map_device_split(qm_ctx* c, const qm_opts* o, int K, int64_t n, const
 
 int qm_map_device(qm_ctx* c, const qm_opts* o, int64_t n, const void* d_seq1, const void* d_off1, const void* d_seq2,
                   const void* d_off2, int32_t max_read_len, int64_t* n_hits, qm_counters* counters) {
-  // -s: two parts in flight together for batches of 2 M units and more (QM_SPLIT: how many, any mode; 1: none).  Without -s a call
-  // is stage A and little else, and the oversubscribed grid (qmk_map_grid) already gives one launch what the parts gave three.
+  // Two parts in flight together for batches of 2 M units and more (QM_SPLIT: how many; 1: none).  With -s the parts' alignment kernels
+  // run under each other's stage A.  Without -s a call was stage A and little else until round 5; behind the lean kernel the pair
+  // kernels, scans and synchronisations of stage B are a tenth of the step, and the second part's stage A hides the first part's
+  // (434.8 -> 456.7 M pairs/s on config 2).
   const char* me = getenv("QM_SPLIT_MIN");                 // (tests: split small batches too)
   const int64_t minUnits = me && atoll(me) > 0 ? atoll(me) : ((int64_t)1 << 21);
   if (c && o && !c->isHelper && !c->debug && n >= minUnits && d_seq1 && d_off1 && (d_seq2 == nullptr) == (d_off2 == nullptr) && check_opts(o) == QM_OK) {
     const char* se = getenv("QM_SPLIT");
-    int K = se ? atoi(se) : (o->sel_aln ? 2 : 1);
+    int K = se ? atoi(se) : 2;
     if (K > 8) K = 8;
     if (K > 1) return map_device_split(c, o, K, n, d_seq1, d_off1, d_seq2, d_off2, max_read_len, n_hits, counters);
   }
