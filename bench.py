@@ -40,7 +40,7 @@ KERNELS = {
     "ph_compact": "qm_lean_kernel<paired, plain, -p> (stage A: two reads per wavefront and iteration, pre-filter + BooPHF levels walked per lookup)",
     "ph_expanded": "qm_lean_kernel<paired, plain, dense> (the -p index expanded into the canonical bucket table at load)",
     "sel": "qm_lean_kernel<paired, -s, dense> (chain-scoring collector) + qm_h2m_pack_kernel (intervals -> position lists, chaining; several reads per "
-           "wavefront) [+ its wide edition and qm_h2m_kernel<4> for the reads those hand on]; the batch runs as two parts in flight, kernel_ms spans stage A of both",
+           "wavefront) [+ its wide edition and qm_h2m_kernel<4> for the reads those hand on]",
 }
 RANDOM_SECTOR_CEILING_G = 51.0   # G random 64-byte sectors per second: profiles/r01_random_gather_roofline.txt (profiles/microbench/gather_bench.hip)
 # VALU issue peak for the ksw2 recurrence (-s): 1 024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction
@@ -282,8 +282,19 @@ def roofline(bpp, w, n, kernel_ms, kernel, traffic_key, genes, step_ms=None, ext
         traffic = ent["step_hbm_bytes_per_launch"] * (n / float(ent.get("pairs_per_launch", 10_000_000)))
     out = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
            "traffic": traffic, "traffic_source": src, "kernel": kernel, "kernel_ms": round(kernel_ms, 3),
-           "algorithmic_bytes_per_pair": round(bpp, 1), "per_pair_counters": {kk: round(v, 2) for kk, v in w.items()},
-           "pairs_per_launch": n}
+           "algorithmic_bytes_per_pair": round(bpp, 1), "per_pair_counters": {kk: round(v, 2) for kk, v in w.items()}}
+    # a batch of 2 M pairs and more is mapped as parts in flight (qm_map_device, QM_SPLIT, default 2): the parts' stage-A launches run one
+    # after the other (each under the other part's stage B), kernel_ms is their span = the sum of the launches
+    parts = int(os.environ.get("QM_SPLIT", "2")) if n >= (1 << 21) else 1
+    parts = max(1, min(8, parts))
+    out["launches_per_step"] = parts
+    out["pairs_per_launch"] = n // parts
+    out["kernel_ms_per_launch"] = round(kernel_ms / parts, 3)
+    if traffic is not None and not whole_step:
+        out["traffic_per_launch"] = traffic / parts          # (`traffic` is the step's: all launches)
+    out["achieved_is"] = ("algorithmic bytes of one launch (%d pairs) / its duration = bytes of the step's %d launches / kernel_ms; the committed "
+                          "rocprofv3 trace (profiles/r05/pmc_all.sh) runs the batch as ONE launch (QM_SPLIT=1) so that a dispatch of the PMC passes is "
+                          "the whole batch: its average duration is the sum of the parts' launches" % (n // parts, parts))
     if whole_step:
         out["frac_is"] = "whole step: algorithmic bytes of the step / ms_per_step (kernel_ms -- stage A of the two parts in flight -- is reported next to it)"
         if step_ms:
