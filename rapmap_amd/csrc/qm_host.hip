@@ -768,8 +768,10 @@ static int len_limit(const qm_opts* o) {
 static int gscr_for(qm_ctx* c, int grid, unsigned*& slots, int& nslots) {
   const int64_t waves = (int64_t)grid * 4, cap = (int64_t)c->numCU * 64;
   slots = nullptr; nslots = 0;
-  int rc = ensure(c->d_gscr, c->capGrid, (waves > cap ? cap : waves) * QM_GSCR_U64);
-  if (rc || waves <= cap) return rc;
+  const char* fe = getenv("QM_GSCR_SLOTS");                  // (tests: slots for launches that would not need them)
+  const bool force = fe && atoi(fe) != 0;
+  int rc = ensure(c->d_gscr, c->capGrid, (waves > cap || force ? cap : waves) * QM_GSCR_U64);
+  if (rc || (waves <= cap && !force)) return rc;
   if (!c->d_gslots && hipMalloc((void**)&c->d_gslots, (size_t)cap * sizeof(unsigned)) != hipSuccess) { c->d_gslots = nullptr; return fail(QM_E_NOMEM, "hipMalloc of the scratch slots' flags failed"); }
   HIPCHK(hipMemsetAsync(c->d_gslots, 0, (size_t)cap * sizeof(unsigned), c->stream));
   slots = c->d_gslots; nslots = (int)cap;

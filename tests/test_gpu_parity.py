@@ -458,6 +458,10 @@ def test_selective_alignment_medium(synth_medium, oracle_mod):
     gr = mp.map_pairs(q1, o, q2, o, opts=ra.default_opts(sel_aln=1))
     assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "selAln medium")
     assert res.counters == gr.counters
+    # qm_ctx_stat 6 / 7: alignment questions beyond PERFECT chains, and the ksw2 alignments run for them -- with 1 % substitutions most
+    # questions are answered by the alignment cache, the ungapped branch or sel_side_score's two rules
+    asked, ran = mp.stat(6), mp.stat(7)
+    assert asked > n and 0 < ran < asked / 3, (asked, ran)
 
 
 def test_selective_alignment_list_kernels_agree(synth_medium, repeat_data, oracle_mod, monkeypatch):
@@ -893,3 +897,23 @@ def test_lean_kernel_on_the_compact_perfect_hash_image(synth_medium, synth_mediu
     gs = mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(sel_aln=1))
     rs = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(selAln=1), nthreads=4)
     assert_hits_equal(rs.hit_offsets, rs.hits, gs.hit_offsets, gs.hits, "lean edges, compact -p, -s")
+
+
+@pytest.mark.gpu
+def test_general_kernel_scratch_by_slot(synth_medium, oracle_mod, monkeypatch):
+    """the general kernels' device-memory scratch handed out by slot (ReadBatch::gslots: a wave takes a free slot of its XCD when it starts
+    and returns it when it ends -- what an oversubscribed launch over a large batch does), forced here for a launch that would not need
+    it (QM_GSCR_SLOTS): the interval-keeping stage view of the call surface, whose intervals, lists and hits all equal the oracle's"""
+    import rapmap_amd as ra
+    monkeypatch.setenv("QM_GSCR_SLOTS", "1")
+    ix, orc = load_oracle(synth_medium["idx"])
+    qi, mp = _gpu(synth_medium["idx"], debug=True)        # debug: intervals kept -> the general kernel, not the lean one
+    n = 30000
+    o = synth_medium["off"][: n + 1]
+    q1 = synth_medium["seq1"][: o[-1]]; q2 = synth_medium["seq2"][: o[-1]]
+    res = orc.map_pairs(q1, o, q2, o, nthreads=8)
+    for rep in range(2):                                   # (the second call finds every flag cleared by the first)
+        gr = mp.map_pairs(q1, o, q2, o)
+        assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "scratch slots, call %d" % rep)
+        assert res.counters == gr.counters
+        assert mp.stat(3) == -1, "expected the general kernel"
