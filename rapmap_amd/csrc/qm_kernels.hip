@@ -9,6 +9,7 @@
 //   build_slots_kernel    index flattening: bucketized k-mer table (32-byte buckets of two slots) from hash.bin records
 #include <hip/hip_runtime.h>
 #include <cstring>
+#include <type_traits>
 #include <cstdlib>
 #include <rocprim/rocprim.hpp>
 
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256) void qm_sel_sides_kernel(PairBatch P, SelBatch
   if (m > 0) sel_unit_sides_write(P, A, u, (long long)base + incl - m);
   sel_flush_counters(sc, uc, P.counters);
 }
-// plan, step 2: sixteen lanes per question -- its 128 characters of read and of target in one round of loads
+// plan, step 2: a group of lanes per question (qm_sel_score_kernel<G>); the groups' sums / xors by DPP
 struct SelRed16 {                       // all-reduce over a row of 16 lanes by rotations (DPP row_ror:8, 4, 2, 1): every lane ends up with the result
   template <int CTRL> static QM_DEV int rot(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
   QM_DEV int add(int v) const { v += rot<0x128>(v); v += rot<0x124>(v); v += rot<0x122>(v); v += rot<0x121>(v); return v; }
@@ -210,12 +211,47 @@ struct SelRed16 {                       // all-reduce over a row of 16 lanes by 
     return (u64)(unsigned)lo | ((u64)(unsigned)hi << 32);
   }
 };
+// ... or over the eight lanes of a half row: row_half_mirror (lane i <-> 7 - i), then the two quad permutations
+struct SelRed8 {
+  template <int CTRL> static QM_DEV int dpp(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+  QM_DEV int add(int v) const { v += dpp<0x141>(v); v += dpp<0xB1>(v); v += dpp<0x4E>(v); return v; }
+  QM_DEV int min(int v) const { int o; o = dpp<0x141>(v); v = o < v ? o : v; o = dpp<0xB1>(v); v = o < v ? o : v; o = dpp<0x4E>(v); v = o < v ? o : v; return v; }
+  QM_DEV int max(int v) const { int o; o = dpp<0x141>(v); v = o > v ? o : v; o = dpp<0xB1>(v); v = o > v ? o : v; o = dpp<0x4E>(v); v = o > v ? o : v; return v; }
+  QM_DEV u64 bxor(u64 v) const {
+    int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
+    lo ^= dpp<0x141>(lo); hi ^= dpp<0x141>(hi); lo ^= dpp<0xB1>(lo); hi ^= dpp<0xB1>(hi); lo ^= dpp<0x4E>(lo); hi ^= dpp<0x4E>(hi);
+    return (u64)(unsigned)lo | ((u64)(unsigned)hi << 32);
+  }
+};
+struct SelRed4 {                       // ... or the four lanes of a quad
+  template <int CTRL> static QM_DEV int dpp(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+  QM_DEV int add(int v) const { v += dpp<0xB1>(v); v += dpp<0x4E>(v); return v; }
+  QM_DEV int min(int v) const { int o; o = dpp<0xB1>(v); v = o < v ? o : v; o = dpp<0x4E>(v); v = o < v ? o : v; return v; }
+  QM_DEV int max(int v) const { int o; o = dpp<0xB1>(v); v = o > v ? o : v; o = dpp<0x4E>(v); v = o > v ? o : v; return v; }
+  QM_DEV u64 bxor(u64 v) const {
+    int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
+    lo ^= dpp<0xB1>(lo); hi ^= dpp<0xB1>(hi); lo ^= dpp<0x4E>(lo); hi ^= dpp<0x4E>(hi);
+    return (u64)(unsigned)lo | ((u64)(unsigned)hi << 32);
+  }
+};
+struct SelRed2 {                       // ... or a pair of lanes
+  template <int CTRL> static QM_DEV int dpp(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+  QM_DEV int add(int v) const { return v + dpp<0xB1>(v); }
+  QM_DEV int min(int v) const { const int o = dpp<0xB1>(v); return o < v ? o : v; }
+  QM_DEV int max(int v) const { const int o = dpp<0xB1>(v); return o > v ? o : v; }
+  QM_DEV u64 bxor(u64 v) const { int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32); lo ^= dpp<0xB1>(lo); hi ^= dpp<0xB1>(hi); return (u64)(unsigned)lo | ((u64)(unsigned)hi << 32); }
+};
+// Lanes per alignment question (measured on 2 x 100 bp, ms per chunk of 10.7 M questions: 16 lanes 4.08, 8 lanes 3.07, 4 lanes 2.42, 2 lanes 2.09,
+// 1 lane 4.12): the geometry and bookkeeping of a question is per lane whatever the group, so few lanes with several 8-character words each
+// beat one word per lane -- until a lane's loads no longer share lines with its neighbours'.  Longer reads take wider groups.
+template <int G>
 __global__ __launch_bounds__(256) void qm_sel_score_kernel(PairBatch P, SelBatch A) {
   const unsigned long long n = *A.nsides;
-  const int l = (int)(threadIdx.x & 15);
-  const SelRed16 red;
-  for (unsigned long long x = (unsigned long long)blockIdx.x * 16 + (threadIdx.x >> 4); x < n; x += (unsigned long long)gridDim.x * 16)
-    sel_side_score<16>(P, A, (long long)x, l, red);
+  constexpr int PER = 256 / G;
+  const int l = (int)(threadIdx.x & (G - 1));
+  typename std::conditional<G == 16, SelRed16, typename std::conditional<G == 8, SelRed8, typename std::conditional<G == 4, SelRed4, SelRed2>::type>::type>::type red;
+  for (unsigned long long x = (unsigned long long)blockIdx.x * PER + (threadIdx.x / G); x < n; x += (unsigned long long)gridDim.x * PER)
+    sel_side_score<G>(P, A, (long long)x, l, red);
 }
 // plan, step 3: a thread per question
 __global__ __launch_bounds__(256) void qm_sel_dedupe_kernel(SelBatch A) {
@@ -598,8 +634,15 @@ hipError_t qmk_sel_plan(const void* pp, const void* ap, int num_cu, hipStream_t 
   hipLaunchKernelGGL(qm_sel_sides_kernel, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, st, P, A);
   // the two flat steps stride over a list whose length only the device knows: grids that fill the chip, no larger than the units could need
   const long long want = (long long)num_cu * 16;
-  const unsigned gs = (unsigned)(nu / 8 + 1 < want ? nu / 8 + 1 : want), gd = (unsigned)(nu / 128 + 1 < want ? nu / 128 + 1 : want);
-  hipLaunchKernelGGL(qm_sel_score_kernel, dim3(gs), dim3(256), 0, st, P, A);
+  const unsigned gs = (unsigned)(nu / 8 + 1 < want ? nu / 8 + 1 : want),   /* (16 or 32 questions per block and trip) */ gd = (unsigned)(nu / 128 + 1 < want ? nu / 128 + 1 : want);
+  static const int lanesEnv = [] { const char* e = getenv("QM_SCORE_LANES"); return e ? atoi(e) : 0; }();     // (tuning knob: 2, 4, 8 or 16)
+  const int lanes = lanesEnv ? lanesEnv : (A.long_reads ? 8 : (A.short_len > 0 && A.short_len <= 256 ? 2 : 4));   // (2 x 150 and 2 x 250 bp: 2 lanes 55.1 / 19.8, 4 lanes 54.3 / 19.6, 8 lanes 53.5 / 19.6 M pairs/s)
+  switch (lanes) {
+    case 2: hipLaunchKernelGGL(qm_sel_score_kernel<2>, dim3(gs), dim3(256), 0, st, P, A); break;
+    case 4: hipLaunchKernelGGL(qm_sel_score_kernel<4>, dim3(gs), dim3(256), 0, st, P, A); break;
+    case 16: hipLaunchKernelGGL(qm_sel_score_kernel<16>, dim3(gs), dim3(256), 0, st, P, A); break;
+    default: hipLaunchKernelGGL(qm_sel_score_kernel<8>, dim3(gs), dim3(256), 0, st, P, A); break;
+  }
   hipLaunchKernelGGL(qm_sel_dedupe_kernel, dim3(gd), dim3(256), 0, st, A);
   return hipGetLastError();
 }
