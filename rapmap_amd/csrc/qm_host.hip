@@ -1167,11 +1167,12 @@ static int run_stage_b(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
   total = 0;
   HIPCHK(hipMemcpyAsync(&total, c->d_offs + n, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+  u64 h[2 * QM_SEL_CHUNKS_B];
+  const bool selStats = o->sel_aln && !rq.mergeOnly;
+  if (selStats) HIPCHK(hipMemcpyAsync(h, c->d_ntk, sizeof(h), hipMemcpyDeviceToHost, c->stream));   // (with the synchronisation that follows anyway)
   HIPCHK(hipStreamSynchronize(c->stream));
   c->lastSelQuestions = 0; c->lastKswTasks = 0;
-  if (o->sel_aln && !rq.mergeOnly) {
-    u64 h[2 * QM_SEL_CHUNKS_B];
-    HIPCHK(hipMemcpy(h, c->d_ntk, sizeof(h), hipMemcpyDeviceToHost));
+  if (selStats) {
     for (int i = 0; i < QM_SEL_CHUNKS_B; ++i) { c->lastKswTasks += (int64_t)h[i]; c->lastSelQuestions += (int64_t)h[QM_SEL_CHUNKS_B + i]; }
     static const bool dbg = [] { const char* e = getenv("QM_SEL_DEBUG"); return e && atoi(e) != 0; }();
     if (dbg) fprintf(stderr, "[qm -s] %lld units: %lld alignment questions beyond PERFECT chains, %lld ksw2 alignments\n", (long long)n, (long long)c->lastSelQuestions, (long long)c->lastKswTasks);
