@@ -1038,6 +1038,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
     if (status & 4) return fail(QM_E_TOOLONG, "a read is longer than %d characters (-s: the alignment kernels are sized for that; otherwise the long-read pass takes up to %d)", len_limit(o), QM_MAX_LONG_READ_LEN);
     if (status & 2) return fail(QM_E_UNSUPPORTED, "an SA-interval list exceeded %d entries (max_interval too large)", QM_GCAP);
     if (status & 8) return fail(QM_E_STATE, "selective alignment: a read overflowed the scratch sized for it (internal error)");
+    if (status & 64) return fail(QM_E_STATE, "a wavefront found no free scratch slot on its XCD (internal error)");
     if (status & 17) {           // a bump allocator ran out: grow and redo the batch
       if (status & 1) {
         int64_t want = (int64_t)hscal[0] + nreads + (int64_t)grid * 4 * QM_CHUNK;

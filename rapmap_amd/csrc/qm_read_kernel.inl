@@ -51,7 +51,9 @@ __global__ __launch_bounds__(64 * WavesPerBlock<NS>::value, WPS) void qm_read_ke
       const unsigned per = (unsigned)B.ngslots >> 3;
       const unsigned base = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) * per;      // HW_REG_XCC_ID, bits 3:0
       unsigned h = ((unsigned)gw * 2654435761u) % per;
-      while (atomicCAS(&B.gslots[base + h], 0u, 1u) != 0u) h = h + 1 == per ? 0u : h + 1;
+      unsigned tries = 0;                                    // (every spin is bounded: flags that were never cleared must not hang the device)
+      while (atomicCAS(&B.gslots[base + h], 0u, 1u) != 0u && ++tries < 4u * per) h = h + 1 == per ? 0u : h + 1;
+      if (tries >= 4u * per) atomicOr(B.status, 64);         // the host fails the call
       s = (int)(base + h);
     }
     gslot = __builtin_amdgcn_readfirstlane(s);
