@@ -43,6 +43,24 @@ for ph in (False, True):
                     except AssertionError as e:
                         bad += 1; print("MISMATCH ph=%s compact=%s seed=%d len<=%d opts=%s: %s" % (ph, compact, seed, max_len, oo, str(e)[:200]), flush=True)
             print("ph=%s compact=%s seed %d done" % (ph, compact, seed), flush=True)
+        if not ph:
+            # round 5: -s on reads whose edits sit where the gapless path and the one-gap-run paths differ (two substitutions, indels a few
+            # characters from either end), under several score schemes: every answer sel_side_score gives without ksw2 against the oracle's ksw2
+            import test_emu_parity as E
+            for seed in range(seed0, seed0 + seeds):
+                r1, r2 = E._edited_pairs(txps, 4 * n, 777 + seed)
+                q1, o1 = pack(r1); q2, o2 = pack(r2)
+                for oo, go in [({}, {}), ({"gapOpen": 5, "gapExtend": 3}, {"gap_open": 5, "gap_extend": 3}), ({"matchScore": 1, "mismatchPenalty": -1, "gapOpen": 1, "gapExtend": 1},
+                               {"match_score": 1, "mismatch_penalty": -1, "gap_open": 1, "gap_extend": 1}), ({"dpBandwidth": 5}, {"dp_bandwidth": 5}), ({"dpBandwidth": -1, "gapOpen": 6, "gapExtend": 1},
+                               {"dp_bandwidth": -1, "gap_open": 6, "gap_extend": 1}), ({"hardFilter": 1, "minScoreFraction": 0.3}, {"hard_filter": 1, "min_score_fraction": 0.3})]:
+                    res = orc.map_pairs(q1, o1, q2, o2, opts=oracle.default_opts(selAln=1, **oo), nthreads=32)
+                    gr = mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(sel_aln=1, **go))
+                    try:
+                        assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "fuzz -s edited")
+                        assert res.counters == gr.counters
+                    except AssertionError as e:
+                        bad += 1; print("MISMATCH -s edited seed=%d opts=%s: %s" % (seed, oo, str(e)[:200]), flush=True)
+                print("-s edited reads seed %d done: %d pairs, %d questions, %d ksw2 alignments in the last run" % (seed, len(r1), mp.stat(6), mp.stat(7)), flush=True)
         mp.close()
 print("fuzz_more: %d mismatching runs" % bad)
 sys.exit(1 if bad else 0)
