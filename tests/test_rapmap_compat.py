@@ -179,6 +179,12 @@ def test_reference_call_surface_under_worker_threads(synth_medium, oracle_mod, t
     r = subprocess.run([exe, sd["idx"], rp, str(n), str(L), "2", "512", "--use", "5000"], capture_output=True, text=True, timeout=1200)
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert j["pairs"] == 5000 and j["digest"] == bench.compat_digest(res.hit_offsets[:5001], res.hits)
+    # groups a worker has on their way: prefetch() alone (--depth 1), and three sent ahead with prefetch_async (the default is two)
+    for depth in ("1", "3"):
+        r = subprocess.run([exe, sd["idx"], rp, str(n), str(L), "3", "300", "--use", "7000", "--depth", depth], capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, r.stdout + r.stderr
+        j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert j["pairs"] == 7000 and j["digest"] == bench.compat_digest(res.hit_offsets[:7001], res.hits), depth
 
 
 def test_compat_digest_is_order_and_field_sensitive():
