@@ -410,6 +410,81 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
             lb = read_lane(W.lb, p - W.wb); ub = read_lane(W.ub, p - W.wb);
           }
           skip = 0;
+          // -s, a run of capped MMPs in one round: while the read keeps matching, the hits of the walk are maxMMPExtension + 1 positions
+          // apart and each is cut at k + maxMMPExtension, so the next ones (up to four: the positions the strided probe looked up in this
+          // window) are known before this one is extended.  Sixteen lanes per hit check the extension's characters against the narrow
+          // table's entries of the hit's suffixes, all hits at once; the leading hits that do match that far are recorded together --
+          // what the loop below would have done one hit, one round of loads and ~150 scalar instructions at a time -- and the walk
+          // goes on behind them.  Anything else (a hit whose extension stops short, a wide interval, the read's end) takes the loop.
+          if (SEL && p != 0 && !lastSearch && ext >= 1 && ext <= QM_NEXT_BASES && ix.sanext && ((ext + 1) & ext) == 0 && ext + 1 <= 16) {
+            const int st = ext + 1, mlenC = k + ext, rel0b = p - W.wb;
+            int J = 0;
+            u32 lbi[4] = {0, 0, 0, 0}; int wv[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int relj = rel0b + j * st, pj = p + j * st;
+              if (J != j || relj >= W.ww || relj >= 32) continue;
+              if (!((W.Km >> relj) & (W.Fm >> relj) & 1u) || pj + mlenC >= L || sn + j >= QM_LEAN_MAXIV) continue;
+              const u32 a = read_lane(W.lb, relj), b = read_lane(W.ub, relj);
+              const u32 ai = a ? a - 1 : 0;
+              const int w = (int)(b - ai - 1);
+              if (w < 1 || w > 16) continue;
+              lbi[j] = ai; wv[j] = w; J = j + 1;
+            }
+            if (J >= 2) {
+              LV<bool> fullb;
+              QM_LANES(l) {
+                const int g = l >> 4, sI = l & 15;
+                const u32 ai = g == 0 ? lbi[0] : (g == 1 ? lbi[1] : (g == 2 ? lbi[2] : lbi[3]));
+                const int w = g == 0 ? wv[0] : (g == 1 ? wv[1] : (g == 2 ? wv[2] : wv[3]));
+                const bool act = g < J && sI < w;
+                const u32 qn = (u32)lean_kmer(pk2 + 8 * V, p + g * st + k + imgOff, ext);
+                const u32 e = ix.sanext[ai + 1 + (u32)(act ? sI : 0)];
+                const u32 x = ((e & 0x0fffffffu) >> (28 - 2 * ext)) ^ qn;
+                int matched = x ? ((__builtin_clz(x) - (32 - 2 * ext)) >> 1) : ext;
+                const int nv = (int)(e >> 28);
+                matched = matched < nv ? matched : nv;
+                fullb[l] = act && matched == ext;
+              }
+              const u64 bqb = ballot(fullb);
+              int Jd = 0;                                                // the leading hits whose extension matched all it may use, with an interval to record
+              u32 fst[4] = {0, 0, 0, 0}, cn[4] = {0, 0, 0, 0};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const u32 m = (u32)(bqb >> (16 * j)) & 0xffffu;
+                if (Jd != j || j >= J || !m) continue;
+                const u32 f = (u32)ctz32(m), c = 32u - (u32)__builtin_clz(m) - f;
+                if (c >= maxIv) continue;
+                fst[j] = f; cn[j] = c; Jd = j + 1;
+              }
+              if (Jd >= 2) {
+                QM_LANES(l) {
+                  if (l < Jd) {
+                    const u32 ai = l == 0 ? lbi[0] : (l == 1 ? lbi[1] : (l == 2 ? lbi[2] : lbi[3]));
+                    const u32 f = l == 0 ? fst[0] : (l == 1 ? fst[1] : (l == 2 ? fst[2] : fst[3]));
+                    const u32 c = l == 0 ? cn[0] : (l == 1 ? cn[1] : (l == 2 ? cn[2] : cn[3]));
+                    QM_LDS(IntRec)* d = ints + sn + l;
+                    d->b = ai + 1 + f; d->e = ai + 1 + f + c; d->len = (u32)mlenC; d->q = (u32)(p + l * st);
+                  }
+                }
+                // the spot checks and hit counts of hits 1 .. Jd - 1 (each: the spot check behind the hit before it, then the hit itself)
+                ha += 2u * (u32)(Jd - 1);
+                for (int j = 1; j < Jd; ++j) hb += 2u * ((W.Cm >> (rel0b + j * st)) & 1u);
+                QM_CNT(18, Jd);
+                const int corr0 = prevEnd > p ? prevEnd - p : 0;
+                cov += mlenC - corr0 + (Jd - 1) * st;                    // (hit j >= 1 overlaps the one before it by mlen - (maxMMPExtension + 1))
+                sn += Jd;
+                const int pl = p + (Jd - 1) * st;
+                prevEnd = pl + mlenC;
+                lb = lbi[Jd - 1] + 1 + fst[Jd - 1]; ub = lb + cn[Jd - 1];
+                spot = 1; stopAfter = 0; pstride = st <= 32 ? st : 1;
+                p = pl + st;                                             // kp of the last one
+                width = 32;
+                if (p + k == L) lastSearch = 1;
+                continue;
+              }
+            }
+          }
           const u32 lbIn = lb ? lb - 1 : 0;                           // :553
           const int wiv = (int)(ub - lbIn - 1);
           if (wiv < 1 || wiv > 64) { bail = 1; break; }

@@ -272,6 +272,10 @@ SEL_VARIANTS = [
      dict(sel_aln=1, no_orphans=1, no_dovetail=1, consensus_slack=0.35, max_num_hits=1000, aln_policy=1)),          # --mimicBT2
     ("indel", dict(selAln=1, consensusSlack=0.0, gapOpen=6, gapExtend=3, mismatchPenalty=-6, matchScore=3, dpBandwidth=5),
      dict(sel_aln=1, consensus_slack=0.0, gap_open=6, gap_extend=3, mismatch_penalty=-6, match_score=3, dp_bandwidth=5)),
+    # without --strictCheck the other strand's turn depends on the two spot-check counts (hb >= ha): the lean collector's runs of
+    # capped MMPs book several hits' counts at once
+    ("reads", dict(selAln=1, strictCheck=0), dict(sel_aln=1, strict_check=0)),
+    ("indel", dict(selAln=1, strictCheck=0, maxMMPExtension=3), dict(sel_aln=1, strict_check=0, max_mmp_extension=3)),
 ]
 
 
