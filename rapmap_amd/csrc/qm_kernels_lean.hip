@@ -49,7 +49,9 @@ static hipError_t launch_lean(const DevIndex& ix, const ReadBatch& B, int num_cu
     return v;
   }();
   const long long nit = (B.nreads + 1) >> 1;
-  long long g = (long long)num_cu * nb * (PH ? qmk_grid_oversub_ph() : qmk_grid_oversub());
+  // (the plain kernel: twice the general kernels' oversubscription -- 455-466 -> 468-471 M pairs/s with the batch in two parts, whose launches are
+  // short enough for their tails to show; its waves reserve list room in quarters of theirs, QM_LEAN_CHUNK)
+  long long g = (long long)num_cu * nb * (PH ? qmk_grid_oversub_ph() : (SEL ? qmk_grid_oversub() : 2 * qmk_grid_oversub()));
   const long long want = (nit + 3) / 4;
   if (g > want) g = want;
   if (g < 1) g = 1;

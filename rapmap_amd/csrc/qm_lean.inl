@@ -34,6 +34,8 @@ namespace qm {
 #define QM_LEAN_SUF 64           // suffixes a strand's intervals may hold together
 #define QM_LEAN_MAXIV 32         // intervals per strand (a bit each)
 #define QM_SC_LEANQ 30           // scalar slot: reads on the lean kernel's queue
+#define QM_LEAN_CHUNK 1024       // list elements a wave reserves per bump-allocator round trip (a list here holds at most 64): a quarter of the general
+                                 // kernels' QM_CHUNK, so that twice their grid leaves half their slack in the list buffer (the host sizes it for theirs)
 
 struct LeanSuf { u32 tid, pos, qp, iv; };      // one suffix of a recorded interval: transcript, offset in it, queryPos and index of the interval
 
@@ -637,9 +639,9 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
     // ---- the list to B.lists through the wave's chunk of the bump allocator (finish_read)
     long long base = 0;
     if (n > 0) {
-      if (wa.base < 0 || wa.used + n > QM_CHUNK) {
+      if (wa.base < 0 || wa.used + n > QM_LEAN_CHUNK) {
         LV<u64> bv;
-        QM_LANES(l) { bv[l] = 0; if (l == 0) bv[l] = atomic_add_u64(B.cursor, (u64)QM_CHUNK); }
+        QM_LANES(l) { bv[l] = 0; if (l == 0) bv[l] = atomic_add_u64(B.cursor, (u64)QM_LEAN_CHUNK); }
         wa.base = (long long)read_lane(bv, 0); wa.used = 0;
       }
       base = wa.base + wa.used;
