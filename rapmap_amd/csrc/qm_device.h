@@ -14,6 +14,8 @@
 extern "C" {
 hipError_t qmk_build_sainfo(const unsigned int* SA, long long nSA, const unsigned int* offsets, long long T, void* out, hipStream_t st);
 hipError_t qmk_build_saext(const unsigned char* text, long long n, const unsigned int* SA, long long nSA, int k, const void* sainfo, void* out, hipStream_t st);
+hipError_t qmk_build_saext2(const unsigned char* text, long long n, const unsigned int* SA, long long nSA, int k, const void* sainfo, void* out, hipStream_t st);
+size_t qmk_saext2_bytes(void);
 hipError_t qmk_build_sanext(const unsigned char* text, long long n, const unsigned int* SA, long long nSA, int k, unsigned int* out, hipStream_t st);
 hipError_t qmk_build_slots(const void* recs, long long K, void* slots, unsigned long long cap, int k, hipStream_t st);
 hipError_t qmk_build_slots_from_ph(const void* dev_index, long long n, void* slots, unsigned long long cap, unsigned long long* d_bad, hipStream_t st);

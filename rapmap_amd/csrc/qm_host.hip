@@ -90,9 +90,10 @@ struct Replica {
   void* d_ph = nullptr; PhIndex hPh; std::vector<void*> phAllocs; uint32_t* d_txpOff = nullptr; int32_t* d_txpLen = nullptr; int64_t devBytes = 0;
   std::mutex sanextMu; unsigned int* d_sanext = nullptr;   // -s: built by the first -s call of any context of this replica
   void* d_saext = nullptr;                                  // the packed characters behind every suffix's k-mer (SaExt), or null
+  void* d_saext2 = nullptr; bool saext2Tried = false;       // ... the wide edition (SaExt2), built when reads of 129 .. 256 characters first ask (sanextMu)
   ~Replica() {
     hipSetDevice(device);
-    void* ptrs[] = {d_text, d_SA, d_sainfo, d_slots, d_txpOff, d_txpLen, d_sanext, d_saext};
+    void* ptrs[] = {d_text, d_SA, d_sainfo, d_slots, d_txpOff, d_txpLen, d_sanext, d_saext, d_saext2};
     for (void* p : ptrs) if (p) hipFree(p);
     for (void* p : phAllocs) if (p) hipFree(p);
   }
@@ -108,6 +109,7 @@ struct qm_ctx {
   hipStream_t stream = nullptr, copyStream = nullptr;      // kernels / host-buffer uploads (overlapped chunk by chunk)
   unsigned int* d_sanext = nullptr;                         // -s: text characters behind every suffix's k-mer (the replica's, built at its first -s call)
   void* d_saext = nullptr;                                  // the replica's SaExt table
+  void* d_saext2 = nullptr;                                 // ... and its wide edition, once built
   hipStream_t planStream = nullptr;                         // -s: the plan kernels of the later chunks, under the ksw2 kernel of the earlier ones
   hipEvent_t evPlan[QM_SEL_CHUNKS_B + 1] = {};              // ... [i]: chunk i planned; [last]: the plan stream may start
   u64* d_ntk = nullptr;                                     // ... per chunk: a task counter, then (at QM_SEL_CHUNKS_B + i) a counter of alignment questions
@@ -749,7 +751,7 @@ static DevIndex dev_index(const qm_ctx* c) {
   DevIndex ix; ix.text = c->d_text; ix.n = c->ix->n; ix.SA = c->d_SA; ix.nSA = c->ix->nSA;
   ix.sainfo = (const SaInfo*)c->d_sainfo; ix.slots = (const Bucket*)c->d_slots; ix.hmask = c->cap - 1; ix.ph = (const PhIndex*)c->d_ph; ix.k = c->ix->k;
   memset(&ix.phv, 0, sizeof(ix.phv)); if (c->d_ph) ix.phv = c->hPh;
-  ix.sanext = c->d_sanext; ix.saext = (const SaExt*)c->d_saext;
+  ix.sanext = c->d_sanext; ix.saext = (const SaExt*)c->d_saext; ix.saext2 = (const SaExt2*)c->d_saext2;
   return ix;
 }
 
@@ -760,6 +762,27 @@ static DevIndex dev_index(const qm_ctx* c) {
 static int len_limit(const qm_opts* o) {
   (void)o;                                                   // (round 4: with -s too, whatever the band -- a band beyond 97 takes the device-memory edition of the alignment kernel)
   return QM_MAX_LONG_READ_LEN;
+}
+
+// The wide extension table (SaExt2: 224 characters behind every suffix's k-mer, 64 bytes per suffix-array entry) for the one-read-per-
+// wavefront lean kernel: built by the first call that has reads of 129 .. 256 characters, shared by the replica's contexts; a replica
+// that has no room for it (or no SaExt) goes on with the general kernels.
+static bool ensure_saext2(qm_ctx* c) {
+  if (c->d_saext2) return true;
+  if (!c->rep || !c->d_saext || c->ix->nSA <= 0) return false;
+  Replica& R = *c->rep;
+  std::lock_guard<std::mutex> lk(R.sanextMu);
+  if (!R.d_saext2 && !R.saext2Tried) {
+    R.saext2Tried = true;
+    void* p = nullptr;
+    if (hipMalloc(&p, (size_t)c->ix->nSA * qmk_saext2_bytes()) != hipSuccess) { (void)hipGetLastError(); return false; }
+    hipError_t e = qmk_build_saext2(c->d_text, c->ix->n, c->d_SA, c->ix->nSA, c->ix->k, c->d_sainfo, p, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { hipFree(p); (void)hipGetLastError(); return false; }
+    R.d_saext2 = p; R.devBytes += c->ix->nSA * (int64_t)qmk_saext2_bytes();
+  }
+  c->d_saext2 = R.d_saext2; c->devBytes = R.devBytes;
+  return c->d_saext2 != nullptr;
 }
 
 // The general kernels' per-wave scratch in device memory (QM_GSCR_U64 words, 112 KB) for a launch of `grid` blocks: one per launched
@@ -791,8 +814,12 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
   // call on a dense table; the reads it marks instead of mapping go through the general kernel in a second, small launch below.
   // It owns no per-wave scratch in device memory: that is only reserved -- for the small grid -- when the second launch happens.
   static const bool leanOff = [] { const char* e = getenv("QM_NO_LEAN"); return e && atoi(e) != 0; }();
-  const bool useLean = !leanOff && rq.mode == QM_RUN_FUSED && !o->sel_aln && o->sensitive && ns == 2 && (c->d_slots || c->d_ph) && c->d_saext &&
-                       !rq.keepIntervals && !rq.keepFound && c->ix->k <= 31;
+  // Reads of 129 .. 256 characters (slot classes 3 and 4) take its wide edition -- one read per wavefront -- on a dense table, once the
+  // replica holds the wide extension table.
+  static const bool wideOff = [] { const char* e = getenv("QM_NO_LEAN_WIDE"); return e && atoi(e) != 0; }();
+  const bool leanBase = !leanOff && rq.mode == QM_RUN_FUSED && o->sensitive && (c->d_slots || c->d_ph) && c->d_saext && c->ix->k <= 31;
+  const bool leanWide = leanBase && !wideOff && (ns == 3 || ns == 4) && c->d_slots && !c->d_ph && (o->sel_aln || (!rq.keepIntervals && !rq.keepFound)) && ensure_saext2(c);
+  const bool useLean = leanBase && !o->sel_aln && (ns == 2 || leanWide) && !rq.keepIntervals && !rq.keepFound;
   unsigned* gslots = nullptr; int ngslots = 0;
   if (!useLean) {
     // the general kernels' scratch (gscr_for); when even that does not fit next to the index, the launch falls back to the resident grid
@@ -802,7 +829,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
   }
   // ... and its -s edition stands in for the chain-scoring collector of a fused -s call (intervals and foundHit out; the list kernels
   // that follow are the same)
-  const bool useLeanSel = !leanOff && rq.mode == QM_RUN_FUSED && o->sel_aln && o->sensitive && ns == 2 && (c->d_slots || c->d_ph) && c->d_saext && c->ix->k <= 31;
+  const bool useLeanSel = leanBase && o->sel_aln && (ns == 2 || leanWide);
   if (rq.mode != QM_RUN_COLLECT) {
     int64_t wantLists = nreads * 4 + (int64_t)grid * 4 * QM_CHUNK * 2;   // chunked bump allocator: up to one open chunk per wave
     if (c->capLists < wantLists) { if ((rc = ensure(c->d_lists, c->capLists, wantLists))) return rc; }
@@ -844,6 +871,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
     B.seq2 = (const unsigned char*)d_seq2; B.off2 = (const long long*)d_off2; B.nreads = nreads;
     B.lcnt = c->d_lcnt; B.loff = c->d_loff; B.lists = c->d_lists; B.cursor = c->d_scal; B.lists_cap = c->capLists;
     B.status = (int*)(c->d_scal + QM_SC_STATUS); B.gscratch = c->d_gscr; B.gslots = gslots; B.ngslots = ngslots; B.skiplist = c->d_skip;
+    B.lean_wide = leanWide ? 1 : 0;
     if (wantIv) { B.iv_out = c->d_iv; B.iv_cnt = c->d_ivcnt; B.iv_off = c->d_ivoff; B.iv_cap = c->capIv; }
     if (wantFound) B.found_out = c->d_found;
     B.iv_in = rq.ivIn; B.iv_in_off = rq.ivInOff; B.len_in = rq.lenIn; B.found_in = rq.foundIn;

@@ -354,6 +354,12 @@ __global__ void build_saext_kernel(const unsigned char* text, long long n, const
   for (; i < nSA; i += stride) { const SaInfo si = sainfo[i]; out[i] = saext_entry(text, n, (long long)SA[i] + k, si.tid, si.pos); }
 }
 
+__global__ void build_saext2_kernel(const unsigned char* text, long long n, const u32* SA, long long nSA, int k, const SaInfo* sainfo, SaExt2* out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < nSA; i += stride) { const SaInfo si = sainfo[i]; out[i] = saext2_entry(text, n, (long long)SA[i] + k, si.tid, si.pos); }
+}
+
 // -s: the text characters behind the k-mer of every suffix (sanext_entry)
 __global__ void build_sanext_kernel(const unsigned char* text, long long n, const u32* SA, long long nSA, int k, u32* out) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -479,6 +485,11 @@ hipError_t qmk_build_saext(const unsigned char* text, long long n, const unsigne
   if (nSA > 0) hipLaunchKernelGGL(build_saext_kernel, dim3(8192), dim3(256), 0, st, text, n, SA, nSA, k, (const SaInfo*)sainfo, (SaExt*)out);
   return hipGetLastError();
 }
+hipError_t qmk_build_saext2(const unsigned char* text, long long n, const unsigned int* SA, long long nSA, int k, const void* sainfo, void* out, hipStream_t st) {
+  if (nSA > 0) hipLaunchKernelGGL(build_saext2_kernel, dim3(8192), dim3(256), 0, st, text, n, SA, nSA, k, (const SaInfo*)sainfo, (SaExt2*)out);
+  return hipGetLastError();
+}
+size_t qmk_saext2_bytes(void) { return sizeof(SaExt2); }
 hipError_t qmk_build_sanext(const unsigned char* text, long long n, const unsigned int* SA, long long nSA, int k, unsigned int* out, hipStream_t st) {
   if (nSA > 0) hipLaunchKernelGGL(build_sanext_kernel, dim3(4096), dim3(256), 0, st, text, n, SA, nSA, k, out);
   return hipGetLastError();

@@ -30,7 +30,7 @@
 
 namespace qm {
 
-#define QM_LEAN_MAXLEN 128
+#define QM_LEAN_MAXLEN 128       // two reads per wavefront (32 lanes x 4 characters each); the wide edition -- one read over all 64 lanes -- takes 256
 #define QM_LEAN_SUF 64           // suffixes a strand's intervals may hold together
 #define QM_LEAN_MAXIV 32         // intervals per strand (a bit each)
 #define QM_SC_LEANQ 30           // scalar slot: reads on the lean kernel's queue
@@ -125,7 +125,7 @@ QM_DEV void lean_find_ph(const DevIndex& ix, const LV<u64>& key, const LV<u64>& 
 // maxMMPExtension + 1 positions while the read keeps matching, never asks about the positions in between (probe_window).
 // PH: the compact image of a -p index (FrugalBooMap::find over the BooPHF walk, find_kmer<QM_F_PH>, behind the membership pre-filter):
 // the structure is keyed by the k-mer itself, so every lane looks up its own word.
-template <bool PH>
+template <bool PH, int IW = 8>
 QM_DEV void lean_probe(const DevIndex& ix, const QM_LDS(u64)* pk2, int D, int V, int P, int k, int wb, int ww, LeanWin& W, int stride = 1) {
   if (wb + ww > P) ww = P - wb;
   QM_CNT(3, 1); QM_CNT(4, (ww + stride - 1) / stride);
@@ -134,7 +134,7 @@ QM_DEV void lean_probe(const DevIndex& ix, const QM_LDS(u64)* pk2, int D, int V,
     const int j = l & 31;
     const bool in = j < ww && (j & (stride - 1)) == 0;
     const int q = in ? wb + j : 0;
-    const u64 w = lean_kmer(pk2 + 8 * V, q + (V ? D : 0), k), wr = lean_kmer(pk2 + 8 * (1 - V), P - 1 - q + (V ? 0 : D), k);
+    const u64 w = lean_kmer(pk2 + IW * V, q + (V ? D : 0), k), wr = lean_kmer(pk2 + IW * (1 - V), P - 1 - q + (V ? 0 : D), k);
     if (PH) {
       const bool comp = l >= 32;                           // lanes 32-63: the reverse complement = the other image's k-mer at P - 1 - q
       ck[l] = comp ? wr : w; cr[l] = comp ? w : wr;        // (the structure is keyed by the k-mer itself; the pre-filter's word by the canonical one)
@@ -204,9 +204,15 @@ QM_DEV void lean_defer(const ReadBatch& B, int read) {
 
 // offsets of iteration `it` into ostage[par]: pairs: off1[it], off1[it + 1], off2[it], off2[it + 1]; single-end reads 2 it and
 // 2 it + 1: off1[2 it .. 2 it + 2] (the last one only if the second read exists).  Iterations, like reads, are below 2^31 per launch.
-template <bool PAIRED>
+template <bool PAIRED, bool WIDE = false>
 QM_DEV void lean_stage_offsets(const ReadBatch& B, int it, int nit, LeanMem& M, int par) {
   if (it >= nit) return;
+  if (WIDE) {                                              // one read per iteration: its two offsets (pairs: read it = mate it & 1 of pair it >> 1)
+    QM_LANES(l) {
+      if (l < 4) { const long long* o = PAIRED ? (((it & 1) ? B.off2 : B.off1) + (it >> 1)) : (B.off1 + it); lds_dma_u32((const u32*)o + l, M.ostage[par], l); }
+    }
+    return;
+  }
   const int nd = PAIRED ? 8 : (2 * it + 1 < (int)B.nreads ? 6 : 4);
   QM_LANES(l) {
     if (l < nd) {
@@ -217,9 +223,24 @@ QM_DEV void lean_stage_offsets(const ReadBatch& B, int it, int nit, LeanMem& M, 
 }
 QM_DEV long long lean_off64(const LV<u32>& ov, int d) { return (long long)(((u64)read_lane(ov, d + 1) << 32) | (u64)read_lane(ov, d)); }
 // the offsets in ostage[par] (landed) into the request for the two reads' characters
-template <bool PAIRED>
+template <bool PAIRED, bool WIDE = false>
 QM_DEV void lean_stage_chars(const ReadBatch& B, int it, int nit, LeanMem& M, int par) {
   if (it >= nit) return;
+  if (WIDE) {
+    LV<u32> ovw;
+    QM_LANES(l) { ovw[l] = M.ostage[par][l & 7]; }
+    const long long o0 = lean_off64(ovw, 0);
+    int len = (int)(read_lane(ovw, 2) - (u32)o0);
+    if (len > 2 * QM_LEAN_MAXLEN) len = 2 * QM_LEAN_MAXLEN;
+    const unsigned char* p = ((PAIRED && (it & 1)) ? B.seq2 : B.seq1) + o0;
+    const int mis = (int)((unsigned long long)p & 3ULL);
+    const u32* g = (const u32*)(p - mis);
+    const int nd = (mis + len + 3) >> 2;                  // <= 65: the rows of both reads of the narrow edition, one behind the other, hold them
+    u32* row = &M.stage[0][0];
+    QM_LANES(l) { if (l < nd) lds_dma_u32(g + l, row, l); }
+    if (nd > 64) { QM_LANES(l) { if (l == 0) lds_dma_u32(g + 64, row + 64, 0); } }
+    return;
+  }
   const bool have1 = 2 * it + 1 < (int)B.nreads;
   LV<u32> ov;
   QM_LANES(l) { ov[l] = M.ostage[par][l & 7]; }
@@ -241,26 +262,34 @@ QM_DEV void lean_stage_chars(const ReadBatch& B, int it, int nit, LeanMem& M, in
 // One iteration: reads 2 it and 2 it + 1.  Wave-uniform flags are ints on purpose: a bool that lives across a branch is kept as a
 // 64-bit lane mask by this compiler (three scalar instructions per test instead of a compare), and the scalar unit is what these
 // kernels run out of first.
-template <bool PAIRED, bool SEL, bool PH>
+// WIDE: ONE read per iteration over all 64 lanes (up to 256 characters; iteration it = read it); the images of the two strands are 16
+// words apart instead of 8, the MMP extension reads the 224-character table (SaExt2).  The window probes, the walk and hits->mappings
+// are the same code.
+template <bool PAIRED, bool SEL, bool PH, bool WIDE = false>
 QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, int nw, int par, LeanMem& M, WaveAlloc& wa) {
+  constexpr int IW = WIDE ? 16 : 8;                        // words between the two images of a read
+  constexpr int HW = WIDE ? 64 : 32;                       // lanes per read
+  constexpr int MAXLEN = WIDE ? 2 * QM_LEAN_MAXLEN : QM_LEAN_MAXLEN;
+  constexpr int NH = WIDE ? 1 : 2;                         // reads per iteration
   const int k = ix.k;
-  const int r0 = 2 * it;
-  const int have1 = r0 + 1 < (int)B.nreads ? 1 : 0;
+  const int r0 = WIDE ? it : 2 * it;
+  const int have1 = (!WIDE && r0 + 1 < (int)B.nreads) ? 1 : 0;
   // ---- the two reads' characters -> 2-bit images of both strands, four characters per lane
   LV<u32> ov;
   QM_LANES(l) { ov[l] = M.ostage[par][l & 7]; }
   const u32 a0 = read_lane(ov, 0), a1 = read_lane(ov, 2);
   const u32 b0 = read_lane(ov, PAIRED ? 4 : 2), b1 = read_lane(ov, PAIRED ? 6 : 4);
   const int raw0 = (int)(a1 - a0), raw1 = have1 ? (int)(b1 - b0) : 0;
-  const int len0 = raw0 > QM_LEAN_MAXLEN ? QM_LEAN_MAXLEN : raw0, len1 = raw1 > QM_LEAN_MAXLEN ? QM_LEAN_MAXLEN : raw1;
-  const int mis0 = (int)(((u32)(unsigned long long)B.seq1 + a0) & 3u);
+  const int len0 = raw0 > MAXLEN ? MAXLEN : raw0, len1 = raw1 > MAXLEN ? MAXLEN : raw1;
+  const int mis0 = (int)(((u32)(unsigned long long)((WIDE && PAIRED && (it & 1)) ? B.seq2 : B.seq1) + a0) & 3u);
   const int mis1 = (int)(((u32)(unsigned long long)(PAIRED ? B.seq2 : B.seq1) + b0) & 3u);
   QM_LDS(unsigned char)* PKb = (QM_LDS(unsigned char)*)&M.pk[0][0][0];
   LV<bool> bad, rep;
   QM_LANES(l) {
-    const int h = l >> 5, jj = l & 31, base = 4 * jj;
+    const int h = WIDE ? 0 : (l >> 5), jj = l & (HW - 1), base = 4 * jj;
     const int len = h ? len1 : len0, mis = h ? mis1 : mis0;
-    const u32 w0 = M.stage[h][jj], w1 = M.stage[h][jj + 1];
+    const u32* srow = WIDE ? &M.stage[0][0] : &M.stage[h][0];
+    const u32 w0 = srow[jj], w1 = srow[jj + 1];
     const u32 d = align_bytes(w1, w0, mis);                                   // characters base .. base + 3
     const int nb = len - base;
     const u32 lenmask = nb >= 4 ? 0xffffffffu : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
@@ -274,16 +303,16 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
     // the same four bases reverse-complemented (Kmer.hpp:92-100 on a byte): order reversed, every code inverted
     u32 r = brev32(pk) >> 24;
     r = (~(((r >> 1) & 0x55u) | ((r & 0x55u) << 1))) & 0xffu;
-    const int img = 128 * h;                                                   // bytes: image (h, strand) starts at 128 h + 64 strand
+    const int img = 16 * IW * h;                                               // bytes: image (h, strand) starts at 16 IW h + 8 IW strand
     PKb[img + 8 * (jj >> 3) + 7 - (jj & 7)] = (unsigned char)pk;
-    const int mj = 31 - jj;
-    PKb[img + 64 + 8 * (mj >> 3) + 7 - (mj & 7)] = (unsigned char)r;
+    const int mj = HW - 1 - jj;
+    PKb[img + 8 * IW + 8 * (mj >> 3) + 7 - (mj & 7)] = (unsigned char)r;
   }
   const u64 dirty = ballot(bad), reps = ballot(rep);
   wave_fence();
   // the staging rows are free again: the next iteration's characters, and the offsets of the one after it
-  lean_stage_chars<PAIRED>(B, it + nw, nit, M, par ^ 1);
-  lean_stage_offsets<PAIRED>(B, it + 2 * nw, nit, M, par);
+  lean_stage_chars<PAIRED, WIDE>(B, it + nw, nit, M, par ^ 1);
+  lean_stage_offsets<PAIRED, WIDE>(B, it + 2 * nw, nit, M, par);
 #if defined(QM_LEAN_ABLATE) && QM_LEAN_ABLATE == 1    // profiling builds (profiles/r05/ablate_build.sh): the phases up to here, empty lists out
   lds_dma_wait();
   QM_LANES(l) { if (l < 2 && r0 + l < (int)B.nreads) { B.lcnt[r0 + l] = (u32)(dirty & reps & 1); B.loff[r0 + l] = 0; } }
@@ -291,8 +320,9 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
 #endif
   // what this kernel takes: no character but A C G T, no window of k equal bases (k equal characters cover at least (k - 6) / 4
   // whole lanes above: setup_strand's rule for its lazy strands), at most 128 characters
-  const int defer0 = (raw0 > QM_LEAN_MAXLEN || (u32)dirty != 0 || 4 * popc32((u32)reps) + 6 >= k) ? 1 : 0;
-  const int defer1 = (raw1 > QM_LEAN_MAXLEN || (u32)(dirty >> 32) != 0 || 4 * popc32((u32)(reps >> 32)) + 6 >= k) ? 1 : 0;
+  const int defer0 = WIDE ? ((raw0 > MAXLEN || dirty != 0 || 4 * popc64(reps) + 6 >= k) ? 1 : 0)
+                          : ((raw0 > MAXLEN || (u32)dirty != 0 || 4 * popc32((u32)reps) + 6 >= k) ? 1 : 0);
+  const int defer1 = (raw1 > MAXLEN || (u32)(dirty >> 32) != 0 || 4 * popc32((u32)(reps >> 32)) + 6 >= k) ? 1 : 0;
   const int P0 = len0 - k + 1, P1 = len1 - k + 1;
   const int ok0 = (!defer0 && P0 >= 1) ? 1 : 0, ok1 = (have1 && !defer1 && P1 >= 1) ? 1 : 0;
   // ---- the first probe of both reads in one round (SACollector.hpp:167-237 starts at position 0; the read's last k-mer is the
@@ -300,16 +330,16 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
   // from the second image -- the reverse complements of those two
   LV<u64> ck, cr; LV<bool> isr, on, hit; LV<u32> plb, pub;
   QM_LANES(l) {
-    const int h = l >> 5, jj = l & 31;
-    const int P = h ? P1 : P0, D = QM_LEAN_MAXLEN - (h ? len1 : len0);
+    const int h = WIDE ? 0 : (l >> 5), jj = l & 31;
+    const int P = h ? P1 : P0, D = MAXLEN - (h ? len1 : len0);
     const bool lastq = jj == 1 || jj == 2;                 // jj 0: read[0]  1: read[P-1]  2: rc[P-1] (= complement of read[0])  3: rc[0]
-    const bool o = (h ? ok1 : ok0) != 0 && jj < 4 && (P > 1 || !(jj & 1));
+    const bool o = (h ? ok1 : ok0) != 0 && jj < 4 && (P > 1 || !(jj & 1)) && (!WIDE || l < 32);
     const int q = (o && lastq) ? P - 1 : 0;                // position in the lane's own strand (jj >> 1) ...
     const int qo = o ? P - 1 - q : 0;                      // ... and of the reverse complement in the other one
-    const QM_LDS(u64)* pkh = (const QM_LDS(u64)*)&M.pk[0][0][0] + 16 * h;
+    const QM_LDS(u64)* pkh = (const QM_LDS(u64)*)&M.pk[0][0][0] + 2 * IW * h;
     const bool s = (jj >> 1) & 1;
-    const u64 w = lean_kmer(pkh + (s ? 8 : 0), q + (s ? D : 0), k);
-    const u64 wr = lean_kmer(pkh + (s ? 0 : 8), qo + (s ? 0 : D), k);
+    const u64 w = lean_kmer(pkh + (s ? IW : 0), q + (s ? D : 0), k);
+    const u64 wr = lean_kmer(pkh + (s ? 0 : IW), qo + (s ? 0 : D), k);
     if (PH) { ck[l] = w; cr[l] = wr; isr[l] = false; }       // (the lane's own word: jj 2 / 3 read the second image)
     else {
       const bool big = wr < w;
@@ -329,16 +359,16 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
   const int useCov = B.strict_check != 0 ? 1 : 0;          // disableNIP_ && strictCheck_ (SACollector.hpp:138)
   const u32 maxIv = (u32)B.max_interval;
 #pragma nounroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < NH; ++h) {
     if (h > have1) break;
     const int read = r0 + h;
     if (h ? defer1 : defer0) { lean_defer(B, read); continue; }
-    const int L = h ? len1 : len0, P = L - k + 1, D = QM_LEAN_MAXLEN - L;
+    const int L = h ? len1 : len0, P = L - k + 1, D = MAXLEN - L;
     int n = 0, foundHit = 0, bail = 0, selV = 0;
     LV<u64> elem; LV<bool> keep; LV<int> slot;
     QM_LANES(l) { keep[l] = false; slot[l] = 0; elem[l] = 0; }
     if (P >= 1) {
-      const QM_LDS(u64)* pk2 = (const QM_LDS(u64)*)&M.pk[0][0][0] + 16 * h;
+      const QM_LDS(u64)* pk2 = (const QM_LDS(u64)*)&M.pk[0][0][0] + 2 * IW * h;
       const u32 fmh = (u32)(fm0 >> (32 * h));
       const u32 F0 = fmh & 1u, C0 = (fmh >> 2) & 1u;
       LeanWin W; W.wb = 0; W.ww = 1; W.Fm = F0; W.Cm = C0; W.Km = 1u;
@@ -346,7 +376,7 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
       // first-hit scan (:167-237): the first position whose k-mer or reverse complement is in the hash
       int p0 = 0;
       while (p0 < P) {
-        if ((unsigned)(p0 - W.wb) >= (unsigned)W.ww) lean_probe<PH>(ix, pk2, D, 0, P, k, p0, 32, W);
+        if ((unsigned)(p0 - W.wb) >= (unsigned)W.ww) lean_probe<PH, IW>(ix, pk2, D, 0, P, k, p0, 32, W);
         const u32 mm = (W.Fm | W.Cm) >> (p0 - W.wb);
         if (mm) { p0 += ctz32(mm); foundHit = 1; break; }
         p0 = W.wb + W.ww;
@@ -386,7 +416,7 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
             {
               const unsigned relp = (unsigned)(p - W.wb);
               const bool known = relp < (unsigned)W.ww && (!SEL || ((W.Km >> (relp & 31u)) & 1u) != 0);
-              if (!known) lean_probe<PH>(ix, pk2, D, V, P, k, p, width, W, SEL ? pstride : 1);
+              if (!known) lean_probe<PH, IW>(ix, pk2, D, V, P, k, p, width, W, SEL ? pstride : 1);
             }
             width = 32; pstride = 1;
             const int rel = p - W.wb;
@@ -440,7 +470,7 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
                 const u32 ai = g == 0 ? lbi[0] : (g == 1 ? lbi[1] : (g == 2 ? lbi[2] : lbi[3]));
                 const int w = g == 0 ? wv[0] : (g == 1 ? wv[1] : (g == 2 ? wv[2] : wv[3]));
                 const bool act = g < J && sI < w;
-                const u32 qn = (u32)lean_kmer(pk2 + 8 * V, p + g * st + k + imgOff, ext);
+                const u32 qn = (u32)lean_kmer(pk2 + IW * V, p + g * st + k + imgOff, ext);
                 const u32 e = ix.sanext[ai + 1 + (u32)(act ? sI : 0)];
                 const u32 x = ((e & 0x0fffffffu) >> (28 - 2 * ext)) ^ qn;
                 int matched = x ? ((__builtin_clz(x) - (32 - 2 * ext)) >> 1) : ext;
@@ -504,7 +534,7 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
             if (SEL && capped && rem >= 1 && rem <= QM_NEXT_BASES && ix.sanext) {
               // a capped extension: the rem (<= 14) characters behind the k-mer against the narrow table's entry of every suffix
               QM_LANES(l) {
-                const u32 qn = (u32)lean_kmer(pk2 + 8 * V, pos + imgOff, rem);
+                const u32 qn = (u32)lean_kmer(pk2 + IW * V, pos + imgOff, rem);
                 const u32 e = ix.sanext[lbIn + 1 + (u32)(l < wiv ? l : wiv - 1)];
                 const u32 x = ((e & 0x0fffffffu) >> (28 - 2 * rem)) ^ qn;
                 int matched = x ? ((__builtin_clz(x) - (32 - 2 * rem)) >> 1) : rem;
@@ -513,12 +543,41 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
                 lc[l] = l < wiv ? k + matched : -1;
                 fullv[l] = false; tdv[l] = 0; tpv[l] = 0;
               }
+            } else if (WIDE) {
+              // the wide table: 224 characters behind every suffix's k-mer, one 64-byte entry (SaExt2)
+              const int cap = rem < QM_EXT2_BASES ? rem : QM_EXT2_BASES;
+              QM_LANES(l) {
+                const int gq = pos + imgOff, j = gq >> 5, sh = 2 * (gq & 31);
+                const QM_LDS(u64)* img = pk2 + IW * V + j;
+                const unsigned char* ep = (const unsigned char*)&ix.saext2[lbIn + 1 + (u32)(l < wiv ? l : wiv - 1)];
+                U4 e0, e1, e2, e3;
+                load_32(ep, e0, e1); load_32(ep + 32, e2, e3);
+                const u64 tw[7] = {((u64)e0.y << 32) | e0.x, ((u64)e0.w << 32) | e0.z, ((u64)e1.y << 32) | e1.x, ((u64)e1.w << 32) | e1.z,
+                                   ((u64)e2.y << 32) | e2.x, ((u64)e2.w << 32) | e2.z, ((u64)e3.y << 32) | e3.x};
+                u64 wprev = img[0];
+                int matched = QM_EXT2_BASES; bool open = true;
+#pragma unroll
+                for (int t = 0; t < 7; ++t) {
+                  const u64 wnext = img[t + 1];
+                  const u64 q = (wprev << sh) | ((wnext >> 1) >> (63 - sh));
+                  const u64 x = tw[t] ^ q;
+                  if (open && x) { matched = 32 * t + (clz64(x) >> 1); open = false; }
+                  wprev = wnext;
+                }
+                const int nv = (int)(e3.z >> QM_EXT2_TID_BITS);
+                matched = matched < nv ? matched : nv;
+                matched = matched < cap ? matched : cap;
+                fullv[l] = matched == QM_EXT2_BASES;
+                lc[l] = l < wiv ? k + matched : -1;
+                tdv[l] = e3.z & ((1u << QM_EXT2_TID_BITS) - 1); tpv[l] = e3.w;
+              }
+              if (rem > QM_EXT2_BASES) { if (ballot(fullv)) { bail = 1; break; } }   // (a 256-character read matching beyond what the table holds)
             } else {
               const int cap = rem < QM_EXT_BASES ? rem : QM_EXT_BASES;
               QM_LANES(l) {
                 // the strand's characters from pos on, packed like the table's entries (the same words in every lane: broadcast reads)
                 const int gq = pos + imgOff, j = gq >> 5, sh = 2 * (gq & 31);
-                const QM_LDS(u64)* img = pk2 + 8 * V + j;
+                const QM_LDS(u64)* img = pk2 + IW * V + j;
                 const u64 w0 = img[0], w1 = img[1], w2 = img[2], w3 = img[3];
                 const u64 q0 = (w0 << sh) | ((w1 >> 1) >> (63 - sh)), q1 = (w1 << sh) | ((w2 >> 1) >> (63 - sh)), q2 = (w2 << sh) | ((w3 >> 1) >> (63 - sh));
                 U4 a, b;
@@ -623,7 +682,7 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
       }
       const bool fits = base + n <= B.iv_cap;
       if (!fits) { QM_LANES(l) { if (l == 0) *B.status |= 16; } }
-      const int mate = PAIRED ? h : 0;
+      const int mate = PAIRED ? (WIDE ? (read & 1) : h) : 0;
       wave_fence();
       QM_LANES(l) {
         if (l == 0) { B.iv_cnt[read] = fits ? (u32)n : 0u; B.iv_off[read] = base; B.found_out[read] = foundHit ? 1 : 0; }

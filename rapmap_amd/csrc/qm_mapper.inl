@@ -144,6 +144,7 @@ struct DevIndex {
   u64 hmask;
   const u32* sanext;          // -s: per SA entry, the QM_NEXT_BASES text characters behind its k-mer (sanext_entry), or null
   const struct SaExt* saext;  // per SA entry, the QM_EXT_BASES text characters behind its k-mer (saext_entry), or null
+  const struct SaExt2* saext2; // ... the QM_EXT2_BASES characters of the wide edition (saext2_entry), or null: built when reads of 129 .. 256 characters first ask
   const PhIndex* ph;          // perfect-hash index (null for a dense index): the flag the kernels are chosen by
   PhIndex phv;                // ... and its contents, by value: as kernel arguments the fields are scalar loads and the
                               // pointers are known to be global (loaded from a struct in memory they would be generic
@@ -162,6 +163,7 @@ struct ReadBatch {
   u64* cursor;             // bump pointer
   long long lists_cap;
   u64* gscratch;           // per wave: QM_GSCR_U64 words -- of wave gw of the launch, or (gslots != null) of the slot the wave holds while it runs
+  int lean_wide;           // qmk_launch_lean: the one-read-per-wavefront edition (reads of up to 256 characters)
   u32* gslots; int ngslots; // oversubscribed grids: one flag per scratch slot (a multiple of 8: an eighth per XCD, each at least the waves that can be
                            // resident there); a wave takes a free one of its XCD when it starts and gives it back when it ends, so the scratch is
                            // sized by residency, not by the launch
@@ -339,6 +341,27 @@ QM_DEV SaExt saext_entry(const unsigned char* text, long long n, long long pos, 
     nv = t + 1;
   }
   e.tidnv = (tid & ((1u << QM_EXT_TID_BITS) - 1)) | ((u32)nv << QM_EXT_TID_BITS);
+  return e;
+}
+// The wide edition for reads of 129 .. 256 characters (the one-read-per-wavefront lean kernel, qm_lean.inl): 224 characters behind the
+// k-mer -- seven words -- with the transcript (24 bits), the count of valid characters (8 bits) and the offset: 64 bytes, one sector
+// per suffix.  Built at the first call that needs it (like sanext): 16.5 GB for config 2.
+#define QM_EXT2_BASES 224
+#define QM_EXT2_TID_BITS 24
+struct SaExt2 { u64 w[7]; u32 tidnv; int pos; };
+QM_DEV SaExt2 saext2_entry(const unsigned char* text, long long n, long long pos, u32 tid, int tpos) {
+  SaExt2 e; for (int i = 0; i < 7; ++i) e.w[i] = 0;
+  e.pos = tpos;
+  int nv = 0;
+  for (int t = 0; t < QM_EXT2_BASES; ++t) {
+    if (pos + t >= n) break;
+    const unsigned char c = text[pos + t];
+    if (c != 'A' && c != 'C' && c != 'G' && c != 'T') break;
+    const u64 x = (c >> 1) & 3u;
+    e.w[t >> 5] |= (x ^ (x >> 1)) << (62 - 2 * (t & 31));
+    nv = t + 1;
+  }
+  e.tidnv = (tid & ((1u << QM_EXT2_TID_BITS) - 1)) | ((u32)nv << QM_EXT2_TID_BITS);
   return e;
 }
 // where extend_search may leave the (tid, pos) of the suffixes of the interval it returns (LDS; IntervalList::pf)

@@ -43,6 +43,21 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
     }
     ix.saext = saext.data();
   }
+  // the wide table of the one-read-per-wavefront lean kernel (build_saext2_kernel): only for batches with reads of 129 .. 256 characters
+  static std::vector<SaExt2> saext2; static const u32* saext2For = nullptr; static const unsigned char* saext2Text = nullptr;
+  ix.saext2 = nullptr;
+  {
+    long long mx = 0;
+    for (long long u = 0; u < nunits; ++u) { mx = std::max(mx, (long long)(off1[u + 1] - off1[u])); if (off2) mx = std::max(mx, (long long)(off2[u + 1] - off2[u])); }
+    if (ix.saext && ix.slots && !ix.ph && mx > QM_LEAN_MAXLEN && mx <= 2 * QM_LEAN_MAXLEN) {
+      if (saext2For != SA || saext2Text != text || (long long)saext2.size() != nSA) {
+        saext2.resize((size_t)nSA);
+        for (long long i = 0; i < nSA; ++i) { const SaInfo si = ((const SaInfo*)sainfo)[i]; saext2[(size_t)i] = saext2_entry(text, n, (long long)SA[i] + k, si.tid, si.pos); }
+        saext2For = SA; saext2Text = text;
+      }
+      ix.saext2 = saext2.data();
+    }
+  }
   if (o->sel_aln) {
     sanext.resize((size_t)nSA);
     for (long long i = 0; i < nSA; ++i) sanext[(size_t)i] = sanext_entry(text, n, (long long)SA[i] + k);
@@ -205,7 +220,8 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
     if (!(status & 1)) break;
     cap *= 4;
   }
-  if (ns == 2 && (ix.slots || ix.ph) && ix.saext && B.sensitive && !o->sel_aln && !(status & 1) && !getenv("QM_EMU_NO_LEAN")) {
+  const bool leanWide = (ns == 3 || ns == 4) && ix.saext2 != nullptr;       // qm_host.hip, run_stage_a: the wide edition's turn
+  if ((ns == 2 || leanWide) && (ix.slots || ix.ph) && ix.saext && B.sensitive && !o->sel_aln && !(status & 1) && !getenv("QM_EMU_NO_LEAN")) {
     // the lean kernel (qm_lean.inl: two reads per wavefront and iteration) over the same batch, three "waves" with the kernel's own
     // software pipeline: every list it writes must be the one the general kernel wrote for that read word for word (flag bit
     // included); the reads it marks instead are the general kernel's
@@ -214,12 +230,20 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
     u64 scal2[QM_SC_WORDS]; memset(scal2, 0, sizeof(scal2)); int status2 = 0;
     ReadBatch Lb = B; Lb.lcnt = lcnt2.data(); Lb.loff = loff2.data(); Lb.lists = lists2.data(); Lb.lists_cap = cap; Lb.cursor = scal2; Lb.status = &status2;
     Lb.iv_out = nullptr; Lb.iv_cnt = nullptr; Lb.iv_off = nullptr;
-    const long long nit = (nreads + 1) >> 1, NW = 3;
+    const long long nit = leanWide ? nreads : (nreads + 1) >> 1, NW = 3;
     static LeanMem Ms[3];
     for (long long w = 0; w < NW; ++w) {
       LeanMem& M = Ms[w]; memset(&M, 0, sizeof(M));
       WaveAlloc wl; wl.base = -1; wl.used = 0; wl.ivBase = -1; wl.ivUsed = 0;
-      if (paired) {
+      if (leanWide && paired) {
+        lean_stage_offsets<true, true>(Lb, (int)w, (int)nit, M, 0); lean_stage_chars<true, true>(Lb, (int)w, (int)nit, M, 0); lean_stage_offsets<true, true>(Lb, (int)(w + NW), (int)nit, M, 1);
+        int par = 0;
+        for (long long it = w; it < nit; it += NW) { lean_iter<true, false, false, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
+      } else if (leanWide) {
+        lean_stage_offsets<false, true>(Lb, (int)w, (int)nit, M, 0); lean_stage_chars<false, true>(Lb, (int)w, (int)nit, M, 0); lean_stage_offsets<false, true>(Lb, (int)(w + NW), (int)nit, M, 1);
+        int par = 0;
+        for (long long it = w; it < nit; it += NW) { lean_iter<false, false, false, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
+      } else if (paired) {
         lean_stage_offsets<true>(Lb, (int)w, (int)nit, M, 0); lean_stage_chars<true>(Lb, (int)w, (int)nit, M, 0); lean_stage_offsets<true>(Lb, (int)(w + NW), (int)nit, M, 1);
         int par = 0;
         for (long long it = w; it < nit; it += NW) { if (ix.ph) lean_iter<true, false, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); else lean_iter<true, false, false>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
@@ -241,7 +265,7 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
     if (getenv("QM_EMU_LEAN_STATS")) fprintf(stderr, "[qm emu] lean kernel took %lld of %lld reads\n", nreads - deferred, nreads);
     if (bad || (status2 & ~1)) status |= 128;
   }
-  if (ns == 2 && (ix.slots || ix.ph) && ix.saext && ix.sanext && B.sensitive && o->sel_aln && !(status & 1) && !getenv("QM_EMU_NO_LEAN")) {
+  if ((ns == 2 || leanWide) && (ix.slots || ix.ph) && ix.saext && ix.sanext && B.sensitive && o->sel_aln && !(status & 1) && !getenv("QM_EMU_NO_LEAN")) {
     // the lean kernel's -s edition (chain-scoring collector: intervals + foundHit out) over the same batch: every read it takes must
     // carry exactly the interval records the general kernel's walk left for it
     std::vector<u32> lcnt2(nreads + 1, 0); std::vector<long long> loff2(nreads + 1, 0);
@@ -250,12 +274,20 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
     u64 scal2[QM_SC_WORDS]; memset(scal2, 0, sizeof(scal2)); int status2 = 0;
     ReadBatch Lb = B; Lb.lcnt = lcnt2.data(); Lb.loff = loff2.data(); Lb.cursor = scal2; Lb.status = &status2;
     Lb.iv_out = di2.data(); Lb.iv_cnt = dc2.data(); Lb.iv_off = do2.data(); Lb.iv_cap = (long long)di2.size(); Lb.found_out = fo2.data();
-    const long long nit = (nreads + 1) >> 1, NW = 3;
+    const long long nit = leanWide ? nreads : (nreads + 1) >> 1, NW = 3;
     static LeanMem Ms[3];
     for (long long w = 0; w < NW; ++w) {
       LeanMem& M = Ms[w]; memset(&M, 0, sizeof(M));
       WaveAlloc wl; wl.base = -1; wl.used = 0; wl.ivBase = -1; wl.ivUsed = 0;
-      if (paired) {
+      if (leanWide && paired) {
+        lean_stage_offsets<true, true>(Lb, (int)w, (int)nit, M, 0); lean_stage_chars<true, true>(Lb, (int)w, (int)nit, M, 0); lean_stage_offsets<true, true>(Lb, (int)(w + NW), (int)nit, M, 1);
+        int par = 0;
+        for (long long it = w; it < nit; it += NW) { lean_iter<true, true, false, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
+      } else if (leanWide) {
+        lean_stage_offsets<false, true>(Lb, (int)w, (int)nit, M, 0); lean_stage_chars<false, true>(Lb, (int)w, (int)nit, M, 0); lean_stage_offsets<false, true>(Lb, (int)(w + NW), (int)nit, M, 1);
+        int par = 0;
+        for (long long it = w; it < nit; it += NW) { lean_iter<false, true, false, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
+      } else if (paired) {
         lean_stage_offsets<true>(Lb, (int)w, (int)nit, M, 0); lean_stage_chars<true>(Lb, (int)w, (int)nit, M, 0); lean_stage_offsets<true>(Lb, (int)(w + NW), (int)nit, M, 1);
         int par = 0;
         for (long long it = w; it < nit; it += NW) { if (ix.ph) lean_iter<true, true, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); else lean_iter<true, true, false>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
