@@ -565,7 +565,10 @@ def main():
             extra["ph_levels_per_probe"] = round(ph_levels, 3)
         if args.sel_aln:   # with -s report the DP cells separately
             extra["dp"] = dp_roofline(w, value * 1e6, el / args.steps * 1e3, n, args.genes, mp)
-        out["roofline"] = roofline(bpp, w, n, avg_kernel_ms, KERNELS[head_key], head_key, args.genes, step_ms=el / args.steps * 1e3, extra=extra,
+        klabel = KERNELS[head_key]
+        if 128 < L <= 256 and not args.perfect_hash:     # the lean kernel's wide edition
+            klabel = klabel.replace("two reads per wavefront and iteration", "wide edition: ONE read of up to 256 characters per wavefront and iteration, 224-character extension table")
+        out["roofline"] = roofline(bpp, w, n, avg_kernel_ms, klabel, head_key, args.genes, step_ms=el / args.steps * 1e3, extra=extra,
                                    whole_step=bool(args.sel_aln))
         out["speedup_vs_cpu_baseline"] = round(value / cpu_val, 2) if cpu_val > 0 else None
         try:   # the per-pair counters are a property of the input distribution: keep them for the N>1 runs
