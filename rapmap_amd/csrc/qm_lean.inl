@@ -23,8 +23,12 @@
 // strands, a 128-character read that matches beyond the SaExt window -- is marked (QM_LCNT_LEAN in its list-length word, count in
 // scalar slot QM_SC_LEANQ) before anything else was written for it; the host gathers the marks into a queue and qm_read_kernel
 // maps the queue in a second, small launch.
-// Options the kernel is built for: dense table (or the -p image expanded into one), sensitive mode, no -s, no interval /
-// foundHit output; the host launches the general kernel for everything else.
+// Options the kernel is built for: dense table (or the -p image expanded into one; PH: the compact -p image), sensitive mode, lists out
+// or (SEL) the -s collector's interval records; the host launches the general kernel for everything else.
+//
+// WIDE (end of round 5): the same code with ONE read of up to 256 characters per wavefront and iteration -- 64 lanes x 4 characters,
+// the two strands' images 16 words apart, MMP extensions through the 224-character table (SaExt2).  Reads of 129 .. 256 characters on a
+// dense table take it (qm_host.hip, run_stage_a: leanWide).
 #pragma once
 #include "qm_mapper.inl"
 
