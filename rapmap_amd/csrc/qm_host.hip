@@ -814,11 +814,11 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
   // call on a dense table; the reads it marks instead of mapping go through the general kernel in a second, small launch below.
   // It owns no per-wave scratch in device memory: that is only reserved -- for the small grid -- when the second launch happens.
   static const bool leanOff = [] { const char* e = getenv("QM_NO_LEAN"); return e && atoi(e) != 0; }();
-  // Reads of 129 .. 256 characters (slot classes 3 and 4) take its wide edition -- one read per wavefront -- on a dense table, once the
-  // replica holds the wide extension table.
+  // Reads of 129 .. 256 characters (slot classes 3 and 4) take its wide edition -- one read per wavefront -- once the replica holds the
+  // wide extension table.
   static const bool wideOff = [] { const char* e = getenv("QM_NO_LEAN_WIDE"); return e && atoi(e) != 0; }();
   const bool leanBase = !leanOff && rq.mode == QM_RUN_FUSED && o->sensitive && (c->d_slots || c->d_ph) && c->d_saext && c->ix->k <= 31;
-  const bool leanWide = leanBase && !wideOff && (ns == 3 || ns == 4) && c->d_slots && !c->d_ph && (o->sel_aln || (!rq.keepIntervals && !rq.keepFound)) && ensure_saext2(c);
+  const bool leanWide = leanBase && !wideOff && (ns == 3 || ns == 4) && (o->sel_aln || (!rq.keepIntervals && !rq.keepFound)) && ensure_saext2(c);
   const bool useLean = leanBase && !o->sel_aln && (ns == 2 || leanWide) && !rq.keepIntervals && !rq.keepFound;
   unsigned* gslots = nullptr; int ngslots = 0;
   if (!useLean) {

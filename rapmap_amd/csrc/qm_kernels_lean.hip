@@ -67,13 +67,17 @@ static hipError_t launch_lean(const DevIndex& ix, const ReadBatch& B, int num_cu
 extern "C" hipError_t qmk_launch_lean(const void* ixp, const void* bp, int num_cu, hipStream_t st) {
   const DevIndex& ix = *(const DevIndex*)ixp; const ReadBatch& B = *(const ReadBatch*)bp;
   const int v = (B.seq2 ? 4 : 0) | (B.selscr ? 2 : 0) | (ix.ph ? 1 : 0);
-  if (B.lean_wide) {                                       // reads of 129 .. 256 characters: one per wavefront (dense table only)
-    if (ix.ph || !ix.saext2) return hipErrorInvalidValue;
-    switch (v >> 1) {
+  if (B.lean_wide) {                                       // reads of 129 .. 256 characters: one per wavefront
+    if (!ix.saext2) return hipErrorInvalidValue;
+    switch (v) {
       case 0: return launch_lean<false, false, false, true>(ix, B, num_cu, st);
-      case 1: return launch_lean<false, true, false, true>(ix, B, num_cu, st);
-      case 2: return launch_lean<true, false, false, true>(ix, B, num_cu, st);
-      default: return launch_lean<true, true, false, true>(ix, B, num_cu, st);
+      case 1: return launch_lean<false, false, true, true>(ix, B, num_cu, st);
+      case 2: return launch_lean<false, true, false, true>(ix, B, num_cu, st);
+      case 3: return launch_lean<false, true, true, true>(ix, B, num_cu, st);
+      case 4: return launch_lean<true, false, false, true>(ix, B, num_cu, st);
+      case 5: return launch_lean<true, false, true, true>(ix, B, num_cu, st);
+      case 6: return launch_lean<true, true, false, true>(ix, B, num_cu, st);
+      default: return launch_lean<true, true, true, true>(ix, B, num_cu, st);
     }
   }
   switch (v) {

@@ -27,8 +27,8 @@
 // or (SEL) the -s collector's interval records; the host launches the general kernel for everything else.
 //
 // WIDE (end of round 5): the same code with ONE read of up to 256 characters per wavefront and iteration -- 64 lanes x 4 characters,
-// the two strands' images 16 words apart, MMP extensions through the 224-character table (SaExt2).  Reads of 129 .. 256 characters on a
-// dense table take it (qm_host.hip, run_stage_a: leanWide).
+// the two strands' images 16 words apart, MMP extensions through the 224-character table (SaExt2).  Reads of 129 .. 256 characters
+// take it (qm_host.hip, run_stage_a: leanWide).
 #pragma once
 #include "qm_mapper.inl"
 

@@ -49,7 +49,7 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
   {
     long long mx = 0;
     for (long long u = 0; u < nunits; ++u) { mx = std::max(mx, (long long)(off1[u + 1] - off1[u])); if (off2) mx = std::max(mx, (long long)(off2[u + 1] - off2[u])); }
-    if (ix.saext && ix.slots && !ix.ph && mx > QM_LEAN_MAXLEN && mx <= 2 * QM_LEAN_MAXLEN) {
+    if (ix.saext && (ix.slots || ix.ph) && mx > QM_LEAN_MAXLEN && mx <= 2 * QM_LEAN_MAXLEN) {
       if (saext2For != SA || saext2Text != text || (long long)saext2.size() != nSA) {
         saext2.resize((size_t)nSA);
         for (long long i = 0; i < nSA; ++i) { const SaInfo si = ((const SaInfo*)sainfo)[i]; saext2[(size_t)i] = saext2_entry(text, n, (long long)SA[i] + k, si.tid, si.pos); }
@@ -238,11 +238,11 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
       if (leanWide && paired) {
         lean_stage_offsets<true, true>(Lb, (int)w, (int)nit, M, 0); lean_stage_chars<true, true>(Lb, (int)w, (int)nit, M, 0); lean_stage_offsets<true, true>(Lb, (int)(w + NW), (int)nit, M, 1);
         int par = 0;
-        for (long long it = w; it < nit; it += NW) { lean_iter<true, false, false, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
+        for (long long it = w; it < nit; it += NW) { if (ix.ph) lean_iter<true, false, true, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); else lean_iter<true, false, false, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
       } else if (leanWide) {
         lean_stage_offsets<false, true>(Lb, (int)w, (int)nit, M, 0); lean_stage_chars<false, true>(Lb, (int)w, (int)nit, M, 0); lean_stage_offsets<false, true>(Lb, (int)(w + NW), (int)nit, M, 1);
         int par = 0;
-        for (long long it = w; it < nit; it += NW) { lean_iter<false, false, false, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
+        for (long long it = w; it < nit; it += NW) { if (ix.ph) lean_iter<false, false, true, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); else lean_iter<false, false, false, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
       } else if (paired) {
         lean_stage_offsets<true>(Lb, (int)w, (int)nit, M, 0); lean_stage_chars<true>(Lb, (int)w, (int)nit, M, 0); lean_stage_offsets<true>(Lb, (int)(w + NW), (int)nit, M, 1);
         int par = 0;
@@ -282,11 +282,11 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
       if (leanWide && paired) {
         lean_stage_offsets<true, true>(Lb, (int)w, (int)nit, M, 0); lean_stage_chars<true, true>(Lb, (int)w, (int)nit, M, 0); lean_stage_offsets<true, true>(Lb, (int)(w + NW), (int)nit, M, 1);
         int par = 0;
-        for (long long it = w; it < nit; it += NW) { lean_iter<true, true, false, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
+        for (long long it = w; it < nit; it += NW) { if (ix.ph) lean_iter<true, true, true, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); else lean_iter<true, true, false, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
       } else if (leanWide) {
         lean_stage_offsets<false, true>(Lb, (int)w, (int)nit, M, 0); lean_stage_chars<false, true>(Lb, (int)w, (int)nit, M, 0); lean_stage_offsets<false, true>(Lb, (int)(w + NW), (int)nit, M, 1);
         int par = 0;
-        for (long long it = w; it < nit; it += NW) { lean_iter<false, true, false, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
+        for (long long it = w; it < nit; it += NW) { if (ix.ph) lean_iter<false, true, true, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); else lean_iter<false, true, false, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
       } else if (paired) {
         lean_stage_offsets<true>(Lb, (int)w, (int)nit, M, 0); lean_stage_chars<true>(Lb, (int)w, (int)nit, M, 0); lean_stage_offsets<true>(Lb, (int)(w + NW), (int)nit, M, 1);
         int par = 0;
