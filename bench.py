@@ -418,8 +418,8 @@ def compat_face_leg(out, args, idx_dir, hs1, hs2, n, L, want_digest_fn, cores):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--genes", type=int, default=40000, help="synthetic genes (40000 ~ 200k transcripts, 3e8 bases)")
     ap.add_argument("--pairs", type=int, default=None, help="read pairs per GPU per step (default: 10 M = configs[1]; "
                     "12.5 M at 8 GPUs = configs[2], 100 M pairs over the node)")
