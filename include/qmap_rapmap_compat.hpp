@@ -635,12 +635,12 @@ inline void decode_hit(const qm_hit& h, rapmap::utils::QuasiAlignment& q) {
 
 // per-read list words (qmap_mi355.h, "List words") -> the vector hitsToMappingsSimple fills
 inline void decode_list(const uint64_t* w, int64_t n, bool chained, uint32_t readLen, rapmap::utils::MateStatus ms,
-                        std::vector<rapmap::utils::QuasiAlignment>& hits) {
+                        std::vector<rapmap::utils::QuasiAlignment>& hits, const Chunk* src = nullptr, uint64_t gen = 0, int64_t read = -1) {
   using namespace rapmap::utils;
   if (!chained) {
     for (int64_t i = 0; i < n; ++i) {
       hits.emplace_back(static_cast<uint32_t>(w[i] >> 33), static_cast<int32_t>(static_cast<uint32_t>(w[i])), ((w[i] >> 32) & 1) == 0, readLen);
-      hits.back().mateStatus = ms;
+      { QuasiAlignment& q = hits.back(); q.mateStatus = ms; q.qm_chunk_ = src; q.qm_gen_ = gen; q.qm_read_ = read; }
       // --fuzzyIntersection lists keep both orientations of a transcript: the second entry is the first one's
       // oppositeStrandPositions (mergeOrientationUnique, src/HitManager.cpp:846-866)
       const size_t m = hits.size();
@@ -654,7 +654,7 @@ inline void decode_list(const uint64_t* w, int64_t n, bool chained, uint32_t rea
     const int32_t np = static_cast<int32_t>(h >> 36), no = static_cast<int32_t>(w[i + 1] >> 32);
     hits.emplace_back(static_cast<uint32_t>(h), static_cast<int32_t>(static_cast<uint32_t>(w[i + 1])), ((h >> 32) & 1) == 0, readLen);
     QuasiAlignment& q = hits.back();
-    q.mateStatus = ms;
+    q.mateStatus = ms; q.qm_chunk_ = src; q.qm_gen_ = gen; q.qm_read_ = read;
     const ChainStatus cs = static_cast<ChainStatus>((h >> 33) & 7);
     if (ms == MateStatus::PAIRED_END_RIGHT) q.chainStatus.setRight(cs); else q.chainStatus.setLeft(cs);
     for (int32_t t = 0; t < np; ++t) q.allPositions.push_back(static_cast<int32_t>(static_cast<uint32_t>(w[i + 2 + t])));
@@ -942,8 +942,7 @@ void hitsToMappingsSimple(RapMapIndexT& rmi, rapmap::utils::MappingConfig& mc, r
       static_cast<int64_t>(hcinfo.fwdSAInts.size() + hcinfo.rcSAInts.size()) == ch->v.iv_off[ch->rbase + hcinfo.qm_read_ + 1] - ch->v.iv_off[ch->rbase + hcinfo.qm_read_]) {
     // the chunk's pass already turned exactly these intervals into the read's list
     const int64_t r = hcinfo.qm_read_, ar = ch->rbase + r;
-    decode_list(ch->v.words + ch->v.list_off[ar], ch->v.list_off[ar + 1] - ch->v.list_off[ar], mc.doChaining, readLen, mateStatus, hits);
-    for (size_t i = before; i < hits.size(); ++i) { hits[i].qm_chunk_ = ch; hits[i].qm_gen_ = ch->gen; hits[i].qm_read_ = r; }
+    decode_list(ch->v.words + ch->v.list_off[ar], ch->v.list_off[ar + 1] - ch->v.list_off[ar], mc.doChaining, readLen, mateStatus, hits, ch, ch->gen, r);
     if (hits.size() > before) hits[before].qm_count_ = static_cast<int32_t>(hits.size() - before);
     return;
   }
