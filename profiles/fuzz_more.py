@@ -27,7 +27,7 @@ for ph in (False, True):
     for compact in ((False, True) if ph else (False,)):
         mp = ra.QuasiMapper(qi, 0, ph_compact=compact)
         for seed in range(seed0, seed0 + seeds):
-            for max_len in (100, 128, 150, 192, 250, 400):
+            for max_len in (100, 128, 129, 150, 192, 250, 256, 257, 400):
                 r1, r2 = T._fuzz_reads(np.asarray(text), np.asarray(offsets, dtype=np.int64), n if max_len <= 256 else n // 4, 1000 * seed + max_len, max_len)
                 q1, o1 = pack(r1); q2, o2 = pack(r2)
                 sets = [({}, {}), ({"sensitive": 0}, {"sensitive": 0}), ({"fuzzy": 1}, {"fuzzy": 1}), ({"strictCheck": 0}, {"strict_check": 0}),
