@@ -40,8 +40,9 @@ typedef enum qm_status {
  * reads of a batch -- up to QM_MAX_LONG_READ_LEN -- are set aside by the main launch and mapped by a second, small launch of
  * 32-slot kernels (the reference takes any std::string, include/SACollector.hpp:108); with -s the same happens in the
  * collector pass and the alignment kernel runs in its long-image editions (with --dpBandwidth beyond 97 or negative: on blocks
- * in device memory, a ring that holds every column of a 2048-base alignment -- slow, and rare).  Beyond QM_MAX_LONG_READ_LEN the
- * call fails with QM_E_TOOLONG. */
+ * in device memory, a ring that holds every column of a 2048-base alignment -- slow, and rare).  A read beyond QM_MAX_LONG_READ_LEN is
+ * skipped, not mapped (round 5): it comes back without hits and on the skip list (qm_fetch_skipped), the batch goes on; the stage
+ * entries that take caller-supplied lengths (qm_hits_to_mappings, ...) still answer QM_E_TOOLONG. */
 #define QM_MAX_READ_LEN 512
 #define QM_MAX_LONG_READ_LEN 2048
 
