@@ -277,7 +277,8 @@ int qm_last_kernel_ms(const qm_ctx* ctx, double* map_kernel_ms, double* total_ms
  * overflow path of -s (more suffixes than the wave's scratch holds). */
 enum { QM_STAT_RELAUNCHES = 0, QM_STAT_LIST_WORDS = 1, QM_STAT_SLOW_READS = 2, QM_STAT_LEAN_READS = 3, QM_STAT_LEAN_DEFERRED = 4, QM_STAT_SKIPPED_READS = 5,
        QM_STAT_SEL_QUESTIONS = 6,    /* -s: alignments the reference would look at beyond PERFECT chains (one per hit and mate) ... */
-       QM_STAT_KSW2_ALIGNMENTS = 7 };/* ... and the ksw2 alignments the device ran for them (the others: alignment-cache hits, ungapped chains, answers known without ksw2) */
+       QM_STAT_KSW2_ALIGNMENTS = 7,  /* ... the ksw2 alignments the device ran for them (the others: alignment-cache hits, ungapped chains, answers known without ksw2) */
+       QM_STAT_STRIP_ALIGNMENTS = 8 };/* ... and the alignments answered by the exact strip DP instead (gapless path within q + 7 e of the best possible) */
 int qm_ctx_stat(const qm_ctx* ctx, int which, int64_t* value);
 
 /* Reads of the last map call on ctx that were SKIPPED, not mapped (round 5; before, one such read failed the whole batch): a read

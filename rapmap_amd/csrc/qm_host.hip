@@ -158,7 +158,7 @@ struct qm_ctx {
   // last result
   int64_t lastUnits = -1, lastHits = 0; bool lastPaired = false;
   double lastMapMs = 0, lastTotalMs = 0;
-  int64_t lastSelQuestions = 0, lastKswTasks = 0;             // -s: alignment questions beyond PERFECT chains of the last call, ksw2 alignments run for them
+  int64_t lastSelQuestions = 0, lastKswTasks = 0, lastStripTasks = 0;             // -s: alignment questions beyond PERFECT chains of the last call, ksw2 alignments run for them
   int64_t lastRelaunches = 0, lastSlowReads = 0, lastLeanReads = -1, lastLeanDeferred = 0;   // lastLeanReads: reads the lean kernel was launched over (-1: not used)
   // qm_map_device on a large batch: its parts on helper contexts of the same replica, in flight together (map_device_split)
   uint32_t flags = 0; bool isHelper = false;
@@ -555,7 +555,7 @@ int qm_ctx_create_ex(const qm_index* ix, int device_id, uint32_t flags, qm_ctx**
   CK(hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
   CK(hipStreamCreateWithFlags(&c->planStream, hipStreamNonBlocking));
   for (hipEvent_t& e : c->evPlan) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  CK(hipMalloc((void**)&c->d_ntk, 2 * QM_SEL_CHUNKS_B * sizeof(u64)));
+  CK(hipMalloc((void**)&c->d_ntk, 3 * QM_SEL_CHUNKS_B * sizeof(u64)));
   CK(hipEventCreateWithFlags(&c->evCopy, hipEventDisableTiming));
   CK(hipEventCreate(&c->ev0)); CK(hipEventCreate(&c->ev1)); CK(hipEventCreate(&c->evA)); CK(hipEventCreate(&c->evB));
   CK(hipMalloc((void**)&c->d_scal, QM_SC_WORDS * sizeof(u64)));
@@ -1163,9 +1163,10 @@ static int run_stage_b(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
       if ((rc = ensure(c->d_tref, c->capTref, 2 * slots + 2))) return rc;
       if ((rc = ensure(c->d_tasks, c->capTasks, (2 * slots + 2 * K + 2) * (int64_t)qmk_sel_task_bytes()))) return rc;
       if ((rc = ensure(c->d_sides, c->capSides, (2 * slots + 2 * K + 2) * (int64_t)qmk_sel_side_bytes()))) return rc;
-      if ((rc = ensure(c->d_torder, c->capTorder, 2 * slots + 2 * K + 2))) return rc;
+      if ((rc = ensure(c->d_torder, c->capTorder, 2 * (2 * slots + 2 * K + 2)))) return rc;      // (two order lists per chunk: ksw2, strip)
+      static const bool noStrip = [] { const char* e = getenv("QM_SEL_NO_STRIP"); return e && atoi(e) != 0; }();
       A.tref = c->d_tref;
-      HIPCHK(hipMemsetAsync(c->d_ntk, 0, 2 * QM_SEL_CHUNKS_B * sizeof(u64), c->stream));
+      HIPCHK(hipMemsetAsync(c->d_ntk, 0, 3 * QM_SEL_CHUNKS_B * sizeof(u64), c->stream));
       // The plan (three kernels: per unit, per alignment question, per question) waits on scattered loads and the ksw2 kernel is
       // bound by VALU issue: the plans of chunks 1.. run on a stream of their own while the alignments of the chunks before
       // them are computed.
@@ -1181,6 +1182,7 @@ static int run_stage_b(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
         Ak[i].sides = (SelSide*)(c->d_sides + (size_t)(2 * cslot[i] + 2 * i) * qmk_sel_side_bytes());       // ... and at most two questions
         Ak[i].nsides = c->d_ntk + QM_SEL_CHUNKS_B + i;
         Ak[i].torder = c->d_torder + (size_t)(2 * cslot[i] + 2 * i);
+        if (!noStrip) { Ak[i].torder2 = c->d_torder + (size_t)(2 * slots + 2 * K + 2) + (size_t)(2 * cslot[i] + 2 * i); Ak[i].ntasks2 = c->d_ntk + 2 * QM_SEL_CHUNKS_B + i; }
         HIPCHK(qmk_sel_plan(&P, &Ak[i], c->numCU, planStream));
         if (K > 1) HIPCHK(hipEventRecord(c->evPlan[i], planStream));
       }
@@ -1196,13 +1198,14 @@ static int run_stage_b(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
   total = 0;
   HIPCHK(hipMemcpyAsync(&total, c->d_offs + n, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-  u64 h[2 * QM_SEL_CHUNKS_B];
+  u64 h[3 * QM_SEL_CHUNKS_B];
   const bool selStats = o->sel_aln && !rq.mergeOnly;
   if (selStats) HIPCHK(hipMemcpyAsync(h, c->d_ntk, sizeof(h), hipMemcpyDeviceToHost, c->stream));   // (with the synchronisation that follows anyway)
   HIPCHK(hipStreamSynchronize(c->stream));
   c->lastSelQuestions = 0; c->lastKswTasks = 0;
   if (selStats) {
-    for (int i = 0; i < QM_SEL_CHUNKS_B; ++i) { c->lastKswTasks += (int64_t)h[i]; c->lastSelQuestions += (int64_t)h[QM_SEL_CHUNKS_B + i]; }
+    c->lastStripTasks = 0;
+    for (int i = 0; i < QM_SEL_CHUNKS_B; ++i) { c->lastKswTasks += (int64_t)h[i]; c->lastSelQuestions += (int64_t)h[QM_SEL_CHUNKS_B + i]; c->lastStripTasks += (int64_t)h[2 * QM_SEL_CHUNKS_B + i]; }
     static const bool dbg = [] { const char* e = getenv("QM_SEL_DEBUG"); return e && atoi(e) != 0; }();
     if (dbg) fprintf(stderr, "[qm -s] %lld units: %lld alignment questions beyond PERFECT chains, %lld ksw2 alignments\n", (long long)n, (long long)c->lastSelQuestions, (long long)c->lastKswTasks);
   }
@@ -1351,13 +1354,13 @@ static int map_device_split(qm_ctx* c, const qm_opts* o, int K, int64_t n, const
   }
   c->lastMapMs = last > first ? last - first : 0;
   float ms = 0; hipEventElapsedTime(&ms, c->evA, c->evB); c->lastTotalMs = ms;
-  c->lastRelaunches = 0; c->lastSlowReads = 0; c->lastSkipped = 0; c->skipList.clear(); c->lastSelQuestions = 0; c->lastKswTasks = 0;
+  c->lastRelaunches = 0; c->lastSlowReads = 0; c->lastSkipped = 0; c->skipList.clear(); c->lastSelQuestions = 0; c->lastKswTasks = 0; c->lastStripTasks = 0;
   qm_counters sum; memset(&sum, 0, sizeof(sum));
   for (int i = 0; i < K; ++i) {
     sum.pe_hits += ctr[i].pe_hits; sum.se_hits += ctr[i].se_hits; sum.tot_hits += ctr[i].tot_hits; sum.num_reads += ctr[i].num_reads;
     sum.too_many_hits += ctr[i].too_many_hits; sum.mapped += ctr[i].mapped;
     qm_ctx* h = c->helpers[(size_t)i];
-    c->lastRelaunches += h->lastRelaunches; c->lastSlowReads += h->lastSlowReads; c->lastSelQuestions += h->lastSelQuestions; c->lastKswTasks += h->lastKswTasks;
+    c->lastRelaunches += h->lastRelaunches; c->lastSlowReads += h->lastSlowReads; c->lastSelQuestions += h->lastSelQuestions; c->lastKswTasks += h->lastKswTasks; c->lastStripTasks += h->lastStripTasks;
     // the part's skipped reads, as reads of the whole batch
     int64_t u0 = n * i / K;
     if (K == 2 && firstPct > 0) u0 = i == 0 ? 0 : n * firstPct / 100;
@@ -1841,6 +1844,7 @@ int qm_ctx_stat(const qm_ctx* c, int which, int64_t* value) {
     case QM_STAT_SKIPPED_READS: *value = c->lastSkipped; break;
     case QM_STAT_SEL_QUESTIONS: *value = c->lastSelQuestions; break;
     case QM_STAT_KSW2_ALIGNMENTS: *value = c->lastKswTasks; break;
+    case QM_STAT_STRIP_ALIGNMENTS: *value = c->lastStripTasks; break;
     default: return fail(QM_E_ARG, "unknown statistic %d", which);
   }
   return QM_OK;

@@ -253,6 +253,13 @@ __global__ __launch_bounds__(256) void qm_sel_score_kernel(PairBatch P, SelBatch
   for (unsigned long long x = (unsigned long long)blockIdx.x * PER + (threadIdx.x / G); x < n; x += (unsigned long long)gridDim.x * PER)
     sel_side_score<G>(P, A, (long long)x, l, red);
 }
+// the strip alignments (sel_tasks_strip): four per wavefront, sixteen lanes each
+__global__ __launch_bounds__(256) void qm_sel_strip_kernel(SelBatch A) {
+  __shared__ StripMem mem[4];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned long long nt = *A.ntasks2;
+  for (unsigned long long t = ((unsigned long long)blockIdx.x * 4 + wave) * 4; t < nt; t += (unsigned long long)gridDim.x * 16) sel_tasks_strip(A, t, nt, mem[wave]);
+}
 // plan, step 3: a thread per question
 __global__ __launch_bounds__(256) void qm_sel_dedupe_kernel(SelBatch A) {
   const unsigned long long n = *A.nsides;
@@ -655,6 +662,7 @@ hipError_t qmk_sel_plan(const void* pp, const void* ap, int num_cu, hipStream_t 
     default: hipLaunchKernelGGL(qm_sel_score_kernel<8>, dim3(gs), dim3(256), 0, st, P, A); break;
   }
   hipLaunchKernelGGL(qm_sel_dedupe_kernel, dim3(gd), dim3(256), 0, st, A);
+  if (A.torder2) hipLaunchKernelGGL(qm_sel_strip_kernel, dim3((unsigned)(num_cu * 8)), dim3(256), 0, st, A);   // (17 KB of LDS per block: up to nine blocks per CU)
   return hipGetLastError();
 }
 size_t qmk_sel_side_bytes(void) { return sizeof(SelSide); }

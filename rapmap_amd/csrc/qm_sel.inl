@@ -570,10 +570,11 @@ struct SelBatch {                    // launch arguments of the -s kernels (on t
   int* tref;                                   // per slot-side: -1 score is final / pending in tsc, <= -2 copy of unit-local entry -(ref)-2
   struct SelSide* sides; u64* nsides;          // the chunk's alignment questions (everything but PERFECT chains)
   struct SelTask* tasks; u64* torder; u64* ntasks;   // ksw2 work: tasks[x] of question x, walked in the order of torder[0 .. *ntasks) (null: tasks[0 ..) as they are)
+  u64* torder2; u64* ntasks2;                   // ... and the alignments the strip kernel takes (sel_tasks_strip), torder2[0 .. *ntasks2); null: none
   long long u0, u1;                            // the units [u0, u1) this launch of plan / finish covers (the batch goes through
                                                // plan -> align -> finish in chunks: the plan of chunk i+1 runs under the align of chunk i)
   int match, mismatch, gap_open, gap_extend, bandwidth, hard_filter, policy;
-  int no_diag;                                 // profiling (QM_SEL_NO_DIAG): 1 queue every REGULAR alignment, 2 only rule 1 of sel_side_score (no two-mismatch answers)
+  int no_diag;                                 // profiling (QM_SEL_NO_DIAG): 1 queue every REGULAR alignment, 2 only rule 1 of sel_side_score (no two-mismatch answers), 3 rules 1 and 2 but no strip alignments
   int long_reads;                              // the batch holds reads beyond QM_MAX_READ_LEN: the long editions of the alignment kernel
   void* ksw_rows;                              // long reads under a band beyond 97: the alignment blocks in device memory (KswRowT<QM_KSW_RING_GMEM, QM_KSW_MAXLEN_LONG>, four per wavefront)
   int short_len;                               // longest read of the batch that is not beyond QM_MAX_READ_LEN (0: unknown): reads of up to 128
@@ -1405,6 +1406,10 @@ QM_DEV void sel_side_score(const PairBatch& P, const SelBatch& A, long long x, i
     else if (known) s = sc;
     else {
       kind |= 2;
+      // An alignment whose gapless path loses no more than q + 7 e: no path that scores as much leaves the diagonals -7 .. +7 (gap runs
+      // that move it further lose more than that), so an exact affine-gap DP over that strip -- sixteen lanes, one per diagonal
+      // (sel_tasks_strip) -- returns what ksw2 returns, at a quarter of its instructions.
+      if (diag && A.torder2 && A.no_diag != 3 && loss <= gq + 7 * ge && (A.bandwidth < 0 || A.bandwidth >= 9) && readLen <= QM_MAX_READ_LEN) kind |= 4;
       if (l == 0) {
         SelTask t; t.rd = read; t.tx = tseq1; t.gslot = (int)g; t.rl = readLen; t.roff = roff; t.rlen = rlen; t.tlen1 = tlen1; t.fwd = fwd ? 1 : 0;
         A.tasks[x] = t;
@@ -1431,7 +1436,89 @@ QM_DEV void sel_side_dedupe(const SelBatch& A, long long x) {
       return;
     }
   }
-  if (S.kind & 2) A.torder[atomic_add_u64(A.ntasks, 1ULL)] = (u64)x;
+  if (S.kind & 4) A.torder2[atomic_add_u64(A.ntasks2, 1ULL)] = (u64)x;
+  else if (S.kind & 2) A.torder[atomic_add_u64(A.ntasks, 1ULL)] = (u64)x;
+}
+
+// The strip alignments: tasks t0 .. t0+3 of torder2, one per row of 16 lanes, lane c = diagonal c - 7 (target index = query index + c - 7).
+// The extension alignment of ksw_extz2 as a plain recurrence in 32-bit integers -- H(-1,-1) = 0, a gap of length L costs q + L e,
+// score = max over the query's last row and the target's last column -- restricted to the strip, which holds every path that can
+// score as much as the gapless one (sel_side_score sends an alignment here only then).  One query row per trip: the diagonal
+// move stays in its lane, the move down comes from the lane above (row_shl), the moves along the row are an exclusive max scan
+// over the lanes (H + e c is what a gap from lane c' < c brings to lane c, minus q + e c).  Held against the oracle's ksw2 like
+// every other score: tests/test_ksw_variants.py restates it in Python, the emulation and GPU parity tests run it.
+struct StripMem { unsigned char q[4][QM_MAX_READ_LEN + 16]; unsigned char t[4][QM_MAX_READ_LEN + 48]; };
+QM_DEV void sel_tasks_strip(const SelBatch& A, unsigned long long t0, unsigned long long nt, StripMem& M) {
+  const int NEGI = -(1 << 28);
+  LV<const unsigned char*> rd, tx; LV<int> ql, tl, gs, rl, ro, fw;
+  QM_LANES(l) {
+    const unsigned long long ti = t0 + (unsigned long long)(l >> 4);
+    ql[l] = 0; tl[l] = 0; gs[l] = -1; rd[l] = nullptr; tx[l] = nullptr; rl[l] = 0; ro[l] = 0; fw[l] = 0;
+    if (ti < nt) {
+      const SelTask t = A.tasks[A.torder2[ti]];
+      rd[l] = t.rd; rl[l] = t.rl; tx[l] = t.tx; ql[l] = t.rlen; tl[l] = t.tlen1; gs[l] = t.gslot; ro[l] = t.roff; fw[l] = t.fwd;
+    }
+  }
+  const int maxq = wave_max(ql), maxt = wave_max(tl);
+  for (int i0 = 0; i0 < maxt; i0 += 16) {
+    QM_LANES(l) {
+      const int i = i0 + (l & 15), g = l >> 4;
+      if (gs[l] >= 0) {
+        if (i < ql[l]) M.q[g][i] = sel_nt4(sel_read_char(rd[l], rl[l], fw[l] != 0, ro[l] + i));
+        if (i < tl[l]) M.t[g][i] = sel_nt4(tx[l][i]);
+      }
+    }
+  }
+  wave_fence();
+  int a = (signed char)A.match, b = (signed char)A.mismatch;
+  a = a < 0 ? -a : a; b = b > 0 ? -b : b;
+  const int go = (int)(signed char)A.gap_open, ge = (int)(signed char)A.gap_extend;
+  LV<int> Hp, Fp, mq, mt;
+  QM_LANES(l) {
+    const int j = (l & 15) - 8;                             // the row above the first: H(-1, -1) = 0, H(-1, j) = -(q + e (j + 1))
+    Hp[l] = j == -1 ? 0 : ((j >= 0 && j < tl[l]) ? -(go + ge * (j + 1)) : NEGI);
+    Fp[l] = NEGI; mq[l] = NEGI; mt[l] = NEGI;
+  }
+  for (int i = 0; i < maxq; ++i) {
+    LV<int> Hn, Fn, Ht, F, X;
+    row16_shl1(Hp, Hn, NEGI); row16_shl1(Fp, Fn, NEGI);
+    QM_LANES(l) {
+      const int c = l & 15, g = l >> 4, j = i + c - 7;
+      int ht = NEGI, f = NEGI;
+      if (gs[l] >= 0 && i < ql[l]) {
+        if (j == -1) ht = -(go + ge * (i + 1));
+        else if (j >= 0 && j < tl[l]) {
+          const int qc = M.q[g][i], tc = M.t[g][j];
+          const int s = (qc < 4 && tc < 4) ? (qc == tc ? a : b) : 0;
+          const int m = Hp[l] > NEGI ? Hp[l] + s : NEGI;
+          if (Hn[l] > NEGI) f = Hn[l] - go - ge;
+          if (Fn[l] > NEGI) { const int f2 = Fn[l] - ge; f = f2 > f ? f2 : f; }
+          ht = m > f ? m : f;
+        }
+      }
+      Ht[l] = ht; F[l] = f; X[l] = ht > NEGI ? ht + ge * c : NEGI;
+    }
+    row16_scan_max_excl(X, NEGI);
+    QM_LANES(l) {
+      const int c = l & 15, j = i + c - 7;
+      if (gs[l] >= 0 && i < ql[l]) {
+        int h = NEGI;
+        if (j == -1) h = Ht[l];
+        else if (j >= 0 && j < tl[l]) {
+          const int e = X[l] > NEGI ? X[l] - go - ge * c : NEGI;
+          h = Ht[l] > e ? Ht[l] : e;
+          if (i == ql[l] - 1 && h > mq[l]) mq[l] = h;
+          if (j == tl[l] - 1 && h > mt[l]) mt[l] = h;
+        }
+        Hp[l] = h; Fp[l] = F[l];
+      }
+    }
+  }
+  LV<int> r;
+  QM_LANES(l) { r[l] = mq[l] > mt[l] ? mq[l] : mt[l]; }
+  row16_max_all(r);
+  QM_LANES(l) { if (gs[l] >= 0 && (l & 15) == 0) A.tsc[gs[l]] = r[l]; }
+  wave_fence();
 }
 
 // Tasks t0 .. t0+3 (those below nt), one per row of 16 lanes: stage the two score-phase images straight from the read and

@@ -114,6 +114,13 @@ QM_DEV void lane_rotate_up(const LV<int>& in, LV<int>& out) { for (int l = 0; l 
 QM_DEV void row_rotate_up(const LV<int>& in, LV<int>& out) { for (int l = 0; l < 64; ++l) out.v[l] = in.v[(l & ~15) | ((l + 15) & 15)]; }
 // every lane of a row of 16 gets the value of the row's last lane
 QM_DEV void row_last(const LV<int>& in, LV<int>& out) { for (int l = 0; l < 64; ++l) out.v[l] = in.v[l | 15]; }
+// rows of 16 lanes (the -s strip alignments, one diagonal per lane): lane c reads lane c + 1 of its row (the last one: fill);
+// x[c] = max over the lanes below c of its row (lane 0: fill); every lane gets its row's maximum
+QM_DEV void row16_shl1(const LV<int>& in, LV<int>& out, int fill) { for (int l = 0; l < 64; ++l) out.v[l] = (l & 15) == 15 ? fill : in.v[l + 1]; }
+QM_DEV void row16_scan_max_excl(LV<int>& x, int fill) {
+  for (int b = 0; b < 64; b += 16) { int run = fill; for (int l = b; l < b + 16; ++l) { const int t = x.v[l]; x.v[l] = run; run = t > run ? t : run; } }
+}
+QM_DEV void row16_max_all(LV<int>& x) { for (int b = 0; b < 64; b += 16) { int m = x.v[b]; for (int l = b + 1; l < b + 16; ++l) m = x.v[l] > m ? x.v[l] : m; for (int l = b; l < b + 16; ++l) x.v[l] = m; } }
 // every lane gets the minimum over its aligned group of G lanes (G a power of two, wave-uniform)
 QM_DEV void group_min(LV<int>& x, int G) {
   for (int b = 0; b < 64; b += G) {
@@ -202,6 +209,25 @@ QM_DEV void lane_rotate_up(const LV<int>& in, LV<int>& out) { out.v[0] = __built
 QM_DEV void row_rotate_up(const LV<int>& in, LV<int>& out) { out.v[0] = __builtin_amdgcn_update_dpp(0, in.v[0], 0x121, 0xf, 0xf, true); }   // (every lane has a source: no old value to keep)
 // (rare callers only: a trip through the LDS crossbar)
 QM_DEV void row_last(const LV<int>& in, LV<int>& out) { out.v[0] = __shfl(in.v[0], (int)((threadIdx.x & 63) | 15), 64); }
+// rows of 16 lanes (the -s strip alignments): row_shl:1 -- lane c reads lane c + 1, the last lane keeps `fill`; an exclusive max scan by
+// row_shr steps (a lane without a source keeps the fill); the row's maximum in every lane by rotations
+QM_DEV void row16_shl1(const LV<int>& in, LV<int>& out, int fill) { out.v[0] = __builtin_amdgcn_update_dpp(fill, in.v[0], 0x101, 0xf, 0xf, false); }
+QM_DEV void row16_scan_max_excl(LV<int>& x, int fill) {
+  int v = __builtin_amdgcn_update_dpp(fill, x.v[0], 0x111, 0xf, 0xf, false), t;
+  t = __builtin_amdgcn_update_dpp(fill, v, 0x111, 0xf, 0xf, false); v = t > v ? t : v;
+  t = __builtin_amdgcn_update_dpp(fill, v, 0x112, 0xf, 0xf, false); v = t > v ? t : v;
+  t = __builtin_amdgcn_update_dpp(fill, v, 0x114, 0xf, 0xf, false); v = t > v ? t : v;
+  t = __builtin_amdgcn_update_dpp(fill, v, 0x118, 0xf, 0xf, false); v = t > v ? t : v;
+  x.v[0] = v;
+}
+QM_DEV void row16_max_all(LV<int>& x) {
+  int v = x.v[0], t;
+  t = __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false); v = t > v ? t : v;
+  t = __builtin_amdgcn_update_dpp(v, v, 0x124, 0xf, 0xf, false); v = t > v ? t : v;
+  t = __builtin_amdgcn_update_dpp(v, v, 0x122, 0xf, 0xf, false); v = t > v ? t : v;
+  t = __builtin_amdgcn_update_dpp(v, v, 0x121, 0xf, 0xf, false); v = t > v ? t : v;
+  x.v[0] = v;
+}
 // butterfly inside a row of 16 with DPP pairings: lanes ^1, lanes ^2 (quad permutes), then the mirror image within 8 and
 // within 16 -- once the quads are uniform any pairing of the two halves does; across rows the crossbar
 QM_DEV void group_min(LV<int>& x, int G) {

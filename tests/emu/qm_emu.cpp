@@ -335,13 +335,16 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
     {
       std::vector<int> tref(2 * (size_t)toff[nunits] + 2);
       std::vector<SelTask> tasks(2 * (size_t)toff[nunits] + 2); u64 ntasks = 0, nsides = 0;
-      std::vector<SelSide> sides(2 * (size_t)toff[nunits] + 2); std::vector<u64> torder(2 * (size_t)toff[nunits] + 2);
+      std::vector<SelSide> sides(2 * (size_t)toff[nunits] + 2); std::vector<u64> torder(2 * (size_t)toff[nunits] + 2), torder2(2 * (size_t)toff[nunits] + 2); u64 ntasks2 = 0;
       A.tref = tref.data(); A.tasks = tasks.data(); A.ntasks = &ntasks; A.sides = sides.data(); A.nsides = &nsides; A.torder = torder.data();
+      if (!getenv("QM_SEL_NO_STRIP")) { A.torder2 = torder2.data(); A.ntasks2 = &ntasks2; }
       A.u0 = 0; A.u1 = nunits;
       // the plan's three steps as the kernels run them (qm_sel_sides_kernel, qm_sel_score_kernel with one lane per question, qm_sel_dedupe_kernel)
       for (long long u = 0; u < nunits; ++u) { const int m = sel_unit_sides_count(P, A, u, &uc); if (m > 0) { sel_unit_sides_write(P, A, u, (long long)nsides); nsides += (u64)m; } }
       for (u64 x = 0; x < nsides; ++x) sel_side_score<1>(P, A, (long long)x, 0, SelRedOne());
       for (u64 x = 0; x < nsides; ++x) sel_side_dedupe(A, (long long)x);
+      { static StripMem SM; for (u64 t = 0; t < ntasks2; t += 4) sel_tasks_strip(A, t, ntasks2, SM); }      // as qm_sel_strip_kernel
+      if (getenv("QM_EMU_SEL_STATS")) fprintf(stderr, "[qm emu] -s: %llu questions, %llu ksw2 alignments, %llu strip alignments\n", (unsigned long long)nsides, (unsigned long long)ntasks, (unsigned long long)ntasks2);
       unsigned char codes[512]; sel_ksw_fill_codes(codes, 0, 1);
       bool longReads = false;
       for (long long u = 0; u < nunits; ++u) { if (off1[u + 1] - off1[u] > QM_MAX_READ_LEN || (paired && off2[u + 1] - off2[u] > QM_MAX_READ_LEN)) longReads = true; }

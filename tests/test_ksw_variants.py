@@ -319,3 +319,83 @@ def test_two_mismatches_lose_to_at_most_one_gap_run(scheme):
     if M <= q_ + e_: assert tot > 1000
     if M <= q_ + e_ and (w < 0 or w >= 8) and q_ + 4 * e_ >= 2 * M and q_ + 3 * (e_ + abs(a)) >= 2 * M:   # (the rule's own limits)
         assert ext > 300 and gapwin > 0, (tot, ext, gapwin)
+
+
+NEG = -(1 << 28)
+
+def _strip_dp(q, t, a, b, go, ge, half=7):
+    """extension alignment from (0,0), affine gaps go + L*ge, score-only, max(mqe, mte); diagonals -half .. half+1"""
+    qlen, tlen = len(q), len(t)
+    aa, bb = abs(a), -abs(b)
+    W = 2 * half + 2
+    Hp = [NEG] * W; Fp = [NEG] * W
+    for c in range(W):
+        j = c - (half + 1)
+        if j == -1: Hp[c] = 0
+        elif 0 <= j < tlen: Hp[c] = -(go + ge * (j + 1))
+    mqe = NEG; mte = NEG
+    for i in range(qlen):
+        Ht = [NEG] * W; F = [NEG] * W
+        for c in range(W):
+            j = i + c - half
+            if j == -1:
+                Ht[c] = -(go + ge * (i + 1)); continue
+            if j < 0 or j >= tlen: continue
+            s = (aa if q[i] == t[j] else bb) if (q[i] < 4 and t[j] < 4) else 0
+            M = Hp[c] + s if Hp[c] > NEG else NEG
+            f = NEG
+            if c + 1 < W:
+                if Hp[c + 1] > NEG: f = Hp[c + 1] - go - ge
+                if Fp[c + 1] > NEG: f = max(f, Fp[c + 1] - ge)
+            F[c] = f
+            Ht[c] = max(M, f)
+        H = [NEG] * W
+        run = NEG
+        for c in range(W):
+            j = i + c - half
+            E = run - go - ge * c if run > NEG else NEG
+            if j == -1: H[c] = Ht[c]
+            elif 0 <= j < tlen: H[c] = max(Ht[c], E)
+            if Ht[c] > NEG: run = max(run, Ht[c] + ge * c)
+            if 0 <= j < tlen:
+                if i == qlen - 1: mqe = max(mqe, H[c])
+                if j == tlen - 1: mte = max(mte, H[c])
+        Hp, Fp = H, F
+    return max(mqe, mte)
+
+
+@pytest.mark.parametrize("scheme", [(2, -4, 4, 2, 15), (2, -4, 5, 3, 15), (1, -1, 1, 1, 15), (2, -6, 5, 3, 33), (2, -4, 4, 2, -1), (3, -2, 2, 1, 15), (2, -4, 6, 1, 15)])
+def test_strip_dp_equals_ksw2_when_the_gapless_path_is_close(scheme):
+    """sel_tasks_strip (rapmap_amd/csrc/qm_sel.inl), restated above: the extension alignment as a plain affine-gap recurrence over the
+    diagonals -7 .. +8.  When the gapless path loses no more than q + 7 e no path that scores as much leaves that strip, so the strip's
+    maximum over the query's last row and the target's last column is ksw_extz2's score -- held against the oracle's kernel on
+    periodic / low-complexity targets, substitutions, true indels, N's and targets that end right behind the query."""
+    a, b, go, ge, w = scheme
+    ol = oracle._lib()
+    ol.qo_ksw_extz2.restype = C.c_int
+    rng = np.random.default_rng(3 + go + w)
+    used = 0
+    for it in range(2500):
+        qlen = int(rng.integers(3, 141)); tlen = qlen + int(rng.integers(0, 25))
+        alpha = int(rng.choice([1, 2, 4, 4, 4]))
+        if rng.random() < 0.3:
+            per = int(rng.integers(1, 4)); unit = rng.integers(0, 4, per); base = np.tile(unit, (tlen + 8) // per + 1)[:tlen + 8].astype(np.uint8)
+        else:
+            base = rng.integers(0, alpha, tlen + 8).astype(np.uint8)
+        t = base[:tlen].copy(); q = base[:qlen].copy()
+        for p in rng.choice(qlen, size=min(int(rng.integers(0, 5)), qlen), replace=False): q[p] = (q[p] + 1 + rng.integers(0, 3)) % 4
+        if rng.random() < 0.3 and qlen > 5:
+            p = int(rng.integers(0, qlen - 1))
+            if rng.random() < 0.5: q = np.concatenate([q[:p], q[p + 1:], base[qlen:qlen + 1]])
+            else: q = np.concatenate([q[:p], rng.integers(0, 4, 1).astype(np.uint8), q[p:-1]])
+        if rng.random() < 0.1: q[rng.integers(0, qlen)] = 4
+        if rng.random() < 0.1: t[rng.integers(0, tlen)] = 4
+        aa, bb = abs(a), -abs(b)
+        sc = np.where((q < 4) & (t[:qlen] < 4), np.where(q == t[:qlen], aa, bb), 0)
+        loss = int(np.where(q < 4, aa, 0).sum()) - int(sc.sum())
+        if not (tlen >= qlen and loss <= go + 7 * ge and (w < 0 or w >= 9) and aa - bb + go + ge <= 96): continue
+        used += 1
+        r = _strip_dp(q.tolist(), t.tolist(), a, b, go, ge)
+        ref = ol.qo_ksw_extz2(qlen, q.ctypes.data_as(C.c_void_p), len(t), t.ctypes.data_as(C.c_void_p), a, b, go, ge, w)
+        assert r == ref, (scheme, qlen, tlen, loss, r, ref, q.tolist(), t.tolist())
+    assert used > 500
