@@ -328,8 +328,10 @@ def dp_roofline(w, pairs_per_s, step_ms, n, genes, mp=None):
     if mp is not None:
         try:
             d["device"] = {"alignment_questions_per_pair": round(mp.stat(6) / float(n), 3), "ksw2_alignments_run_per_pair": round(mp.stat(7) / float(n), 3),
-                           "what": "qm_ctx_stat of the last timed step: hits x mates beyond PERFECT chains that getAlnScore is asked about; those of them the "
-                                   "ksw2 kernel ran (the rest: alignment-cache hits, ungapped chains, answers known without ksw2)"}
+                           "strip_alignments_run_per_pair": round(mp.stat(8) / float(n), 3),
+                           "what": "qm_ctx_stat of the last call: hits x mates beyond PERFECT chains that getAlnScore is asked about; those of them the "
+                                   "ksw2 kernel ran; those an exact DP over the diagonals -7 .. +8 answered instead (gapless path within q + 7 e of the best "
+                                   "possible); the rest: alignment-cache hits, ungapped chains, answers known without any DP"}
         except Exception as ex:  # noqa: BLE001
             d["device"] = {"error": repr(ex)}
     if ent.get("ksw2_kernel_ms_per_step") and genes == 40000:
