@@ -1482,36 +1482,26 @@ QM_DEV void sel_tasks_strip(const SelBatch& A, unsigned long long t0, unsigned l
   for (int i = 0; i < maxq; ++i) {
     LV<int> Hn, Fn, Ht, F, X;
     row16_shl1(Hp, Hn, NEGI); row16_shl1(Fp, Fn, NEGI);
+    // (no tests for "not reachable": such a value is NEGI give or take a few gap costs, far below every real score, and loses every max)
     QM_LANES(l) {
       const int c = l & 15, g = l >> 4, j = i + c - 7;
-      int ht = NEGI, f = NEGI;
-      if (gs[l] >= 0 && i < ql[l]) {
-        if (j == -1) ht = -(go + ge * (i + 1));
-        else if (j >= 0 && j < tl[l]) {
-          const int qc = M.q[g][i], tc = M.t[g][j];
-          const int s = (qc < 4 && tc < 4) ? (qc == tc ? a : b) : 0;
-          const int m = Hp[l] > NEGI ? Hp[l] + s : NEGI;
-          if (Hn[l] > NEGI) f = Hn[l] - go - ge;
-          if (Fn[l] > NEGI) { const int f2 = Fn[l] - ge; f = f2 > f ? f2 : f; }
-          ht = m > f ? m : f;
-        }
-      }
-      Ht[l] = ht; F[l] = f; X[l] = ht > NEGI ? ht + ge * c : NEGI;
+      const bool act = gs[l] >= 0 && i < ql[l], inr = act && j >= 0 && j < tl[l], bnd = act && j == -1;
+      const int qc = M.q[g][act ? i : 0], tc = M.t[g][inr ? j : 0];
+      const int s = (qc < 4 && tc < 4) ? (qc == tc ? a : b) : 0;
+      const int m = Hp[l] + s, f1 = Hn[l] - go - ge, f2 = Fn[l] - ge;
+      const int f = f1 > f2 ? f1 : f2;
+      const int ht = bnd ? -(go + ge * (i + 1)) : (inr ? (m > f ? m : f) : NEGI);
+      Ht[l] = ht; F[l] = inr ? f : NEGI; X[l] = ht + ge * c;
     }
     row16_scan_max_excl(X, NEGI);
     QM_LANES(l) {
       const int c = l & 15, j = i + c - 7;
-      if (gs[l] >= 0 && i < ql[l]) {
-        int h = NEGI;
-        if (j == -1) h = Ht[l];
-        else if (j >= 0 && j < tl[l]) {
-          const int e = X[l] > NEGI ? X[l] - go - ge * c : NEGI;
-          h = Ht[l] > e ? Ht[l] : e;
-          if (i == ql[l] - 1 && h > mq[l]) mq[l] = h;
-          if (j == tl[l] - 1 && h > mt[l]) mt[l] = h;
-        }
-        Hp[l] = h; Fp[l] = F[l];
-      }
+      const bool act = gs[l] >= 0 && i < ql[l], inr = act && j >= 0 && j < tl[l], bnd = act && j == -1;
+      const int e = X[l] - go - ge * c;
+      const int h = bnd ? Ht[l] : (inr ? (Ht[l] > e ? Ht[l] : e) : NEGI);
+      if (inr && i == ql[l] - 1 && h > mq[l]) mq[l] = h;
+      if (inr && j == tl[l] - 1 && h > mt[l]) mt[l] = h;
+      if (act) { Hp[l] = h; Fp[l] = F[l]; }
     }
   }
   LV<int> r;
