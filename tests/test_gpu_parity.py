@@ -917,3 +917,32 @@ def test_general_kernel_scratch_by_slot(synth_medium, oracle_mod, monkeypatch):
         assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "scratch slots, call %d" % rep)
         assert res.counters == gr.counters
         assert mp.stat(3) == -1, "expected the general kernel"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_len", [150, 256])
+def test_wide_lean_kernel_single_end_and_paired(synth_medium, synth_medium_ph, oracle_mod, max_len):
+    """the lean kernel's wide edition (one read of up to 256 characters per wavefront, qm_lean.inl WIDE) on ragged reads with substitutions,
+    indels, N's and lower case: paired and single-end (an odd count), lists and the -s collector, dense table and compact -p image --
+    what it takes and what it leaves to the general kernel add up to the oracle's hits"""
+    import rapmap_amd as ra
+    for idx, compact in ((synth_medium["idx"], False), (synth_medium_ph["idx"], True)):
+        ix, orc = load_oracle(idx)
+        qi = ra.QuasiIndex(idx)
+        mp = ra.QuasiMapper(qi, 0, debug=False, ph_compact=compact)
+        text, offsets = ra.QuasiIndex(synth_medium["idx"]).arrays()
+        r1, r2 = _fuzz_reads(np.asarray(text), np.asarray(offsets, dtype=np.int64), 3001, 4200 + max_len, max_len)
+        q1, o1 = pack(r1); q2, o2 = pack(r2)
+        for oo, go in (({}, {}), ({"selAln": 1}, {"sel_aln": 1})):
+            res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=8)
+            gr = mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(**go))
+            assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "wide lean, paired %s compact=%s" % (oo, compact))
+            assert res.counters == gr.counters
+            if not oo:
+                assert mp.stat(3) == 2 * len(r1), "the lean kernel was not the one launched"
+                assert 0 < mp.stat(4) < len(r1), "expected most reads taken, some left to the general kernel"
+            rs = orc.map_single(q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=8)
+            gs = mp.map_reads(q2, o2, opts=ra.default_opts(**go))
+            assert_hits_equal(rs.hit_offsets, rs.hits, gs.hit_offsets, gs.hits, "wide lean, single-end %s compact=%s" % (oo, compact))
+            assert rs.counters == gs.counters
+        mp.close()
