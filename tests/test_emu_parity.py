@@ -132,6 +132,15 @@ def test_long_reads_ns4(synth_small, oracle_mod):
     assert er.status == 0 and res.counters["totHits"] > 1000
     assert_hits_equal(res.hit_offsets, res.hits, er.hit_offsets, er.hits, "ns4")
     _cmp_ints(res, er)
+    # single-end (the wide lean kernel's other instantiations are cross-checked inside the emulation: every read it takes, word for word)
+    rs1 = orc.map_single(q2, o, nthreads=4)
+    es1 = em.map(q2, o, ns=4)
+    assert es1.status == 0
+    assert_hits_equal(rs1.hit_offsets, rs1.hits, es1.hit_offsets, es1.hits, "ns4 single-end")
+    rs2 = orc.map_single(q2, o, opts=oracle_mod.default_opts(selAln=1), nthreads=4)
+    es2 = em.map(q2, o, opts=emu.default_opts(sel_aln=1), ns=4)
+    assert (es2.status & 0xff) == 0
+    assert_hits_equal(rs2.hit_offsets, rs2.hits, es2.hit_offsets, es2.hits, "ns4 single-end -s")
     # the NS=2 build must not truncate them silently: they are set aside for the long-read pass, same hits
     er2 = em.map(q1, o, q2, o, ns=2)
     assert (er2.status & 0xff) == 0
