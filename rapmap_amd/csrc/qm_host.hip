@@ -1207,7 +1207,7 @@ static int run_stage_b(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
     c->lastStripTasks = 0;
     for (int i = 0; i < QM_SEL_CHUNKS_B; ++i) { c->lastKswTasks += (int64_t)h[i]; c->lastSelQuestions += (int64_t)h[QM_SEL_CHUNKS_B + i]; c->lastStripTasks += (int64_t)h[2 * QM_SEL_CHUNKS_B + i]; }
     static const bool dbg = [] { const char* e = getenv("QM_SEL_DEBUG"); return e && atoi(e) != 0; }();
-    if (dbg) fprintf(stderr, "[qm -s] %lld units: %lld alignment questions beyond PERFECT chains, %lld ksw2 alignments\n", (long long)n, (long long)c->lastSelQuestions, (long long)c->lastKswTasks);
+    if (dbg) fprintf(stderr, "[qm -s] %lld units: %lld alignment questions beyond PERFECT chains, %lld ksw2 alignments, %lld strip alignments\n", (long long)n, (long long)c->lastSelQuestions, (long long)c->lastKswTasks, (long long)c->lastStripTasks);
   }
   if (rq.join) {
     long long b = 0; qm_hit* dst = nullptr;
