@@ -283,18 +283,20 @@ def roofline(bpp, w, n, kernel_ms, kernel, traffic_key, genes, step_ms=None, ext
     out = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
            "traffic": traffic, "traffic_source": src, "kernel": kernel, "kernel_ms": round(kernel_ms, 3),
            "algorithmic_bytes_per_pair": round(bpp, 1), "per_pair_counters": {kk: round(v, 2) for kk, v in w.items()}}
-    # a batch of 2 M pairs and more is mapped as parts in flight (qm_map_device, QM_SPLIT, default 2): the parts' stage-A launches run one
-    # after the other (each under the other part's stage B), kernel_ms is their span = the sum of the launches
+    # a batch of 2 M pairs and more is mapped as parts in flight (qm_map_device, QM_SPLIT, default 2): the parts' stage-A launches run
+    # AT THE SAME TIME, each over its share of the pairs and each about as long as kernel_ms -- the HIP-event span from the first
+    # launch's start to the last one's end (rocprofv3's average duration per launch of the same command:
+    # profiles/r05/kernel_stats_default_two_parts_r05zg.txt).  achieved = the bytes of all of them / that span: the chip's rate.
     parts = int(os.environ.get("QM_SPLIT", "2")) if n >= (1 << 21) else 1
     parts = max(1, min(8, parts))
     out["launches_per_step"] = parts
+    out["launches_run_concurrently"] = parts > 1
     out["pairs_per_launch"] = n // parts
-    out["kernel_ms_per_launch"] = round(kernel_ms / parts, 3)
     if traffic is not None and not whole_step:
         out["traffic_per_launch"] = traffic / parts          # (`traffic` is the step's: all launches)
-    out["achieved_is"] = ("algorithmic bytes of one launch (%d pairs) / its duration = bytes of the step's %d launches / kernel_ms; the committed "
-                          "rocprofv3 trace (profiles/r05/pmc_all.sh) runs the batch as ONE launch (QM_SPLIT=1) so that a dispatch of the PMC passes is "
-                          "the whole batch: its average duration is the sum of the parts' launches" % (n // parts, parts))
+    out["achieved_is"] = ("algorithmic bytes of the step's %d launch(es) (%d pairs each%s) / kernel_ms, the span of stage A measured with HIP events on "
+                          "the library's streams; the committed PMC passes (profiles/r05/pmc_all.sh) run the batch as ONE launch (QM_SPLIT=1), so that a "
+                          "dispatch is the whole batch: 20.9 ms there" % (parts, n // parts, ", in flight together" if parts > 1 else ""))
     if whole_step:
         out["frac_is"] = "whole step: algorithmic bytes of the step / ms_per_step (kernel_ms -- stage A of the two parts in flight -- is reported next to it)"
         if step_ms:
