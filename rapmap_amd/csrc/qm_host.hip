@@ -1379,8 +1379,9 @@ int qm_map_device(qm_ctx* c, const qm_opts* o, int64_t n, const void* d_seq1, co
                   const void* d_off2, int32_t max_read_len, int64_t* n_hits, qm_counters* counters) {
   // Two parts in flight together for batches of 2 M units and more (QM_SPLIT: how many; 1: none).  With -s the parts' alignment kernels
   // run under each other's stage A.  Without -s a call was stage A and little else until round 5; behind the lean kernel the pair
-  // kernels, scans and synchronisations of stage B are a tenth of the step, and the second part's stage A hides the first part's
-  // (434.8 -> 456.7 M pairs/s on config 2).
+  // kernels, scans and synchronisations of stage B are a tenth of the step: with two parts started together (their stage-A launches
+  // share the chip, each about as long as one launch over the whole batch) whichever part is ahead runs its stage B under the other's
+  // stage A (434.8 -> 456.7 M pairs/s on config 2).
   const char* me = getenv("QM_SPLIT_MIN");                 // (tests: split small batches too)
   const int64_t minUnits = me && atoll(me) > 0 ? atoll(me) : ((int64_t)1 << 21);
   if (c && o && !c->isHelper && !c->debug && n >= minUnits && d_seq1 && d_off1 && (d_seq2 == nullptr) == (d_off2 == nullptr) && check_opts(o) == QM_OK) {
