@@ -820,6 +820,12 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
   const bool leanBase = !leanOff && rq.mode == QM_RUN_FUSED && o->sensitive && (c->d_slots || c->d_ph) && c->d_saext && c->ix->k <= 31;
   const bool leanWide = leanBase && !wideOff && (ns == 3 || ns == 4) && (o->sel_aln || (!rq.keepIntervals && !rq.keepFound)) && ensure_saext2(c);
   const bool useLean = leanBase && !o->sel_aln && (ns == 2 || leanWide) && !rq.keepIntervals && !rq.keepFound;
+  // Pairs of such reads take the pair kernel (qm_duo.inl): the two mates walked in lockstep by the two halves of a wavefront, and -- in a
+  // plain fused call -- merged there (pair_cnt: stage B's count pass finds the pair done, its write pass expands the records)
+  static const bool duoOff = [] { const char* e = getenv("QM_NO_DUO"); return e && atoi(e) != 0; }();
+  const bool useDuo = useLean && !duoOff && paired && ns == 2;
+  const bool duoMerge = useDuo && !rq.mergeOnly && !rq.stageView;
+  if (duoMerge) { if ((rc = ensure(c->d_cnt, c->capCnt, n + 1))) return rc; }
   unsigned* gslots = nullptr; int ngslots = 0;
   if (!useLean) {
     // the general kernels' scratch (gscr_for); when even that does not fit next to the index, the launch falls back to the resident grid
@@ -872,6 +878,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
     B.lcnt = c->d_lcnt; B.loff = c->d_loff; B.lists = c->d_lists; B.cursor = c->d_scal; B.lists_cap = c->capLists;
     B.status = (int*)(c->d_scal + QM_SC_STATUS); B.gscratch = c->d_gscr; B.gslots = gslots; B.ngslots = ngslots; B.skiplist = c->d_skip;
     B.lean_wide = leanWide ? 1 : 0;
+    if (duoMerge) { B.pair_cnt = c->d_cnt; B.max_num_hits = o->max_num_hits; B.no_orphans = o->no_orphans; B.no_dovetail = o->no_dovetail; }
     if (wantIv) { B.iv_out = c->d_iv; B.iv_cnt = c->d_ivcnt; B.iv_off = c->d_ivoff; B.iv_cap = c->capIv; }
     if (wantFound) B.found_out = c->d_found;
     B.iv_in = rq.ivIn; B.iv_in_off = rq.ivInOff; B.len_in = rq.lenIn; B.found_in = rq.foundIn;
@@ -888,6 +895,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
     if (rq.mode == QM_RUN_COLLECT || twoPass) HIPCHK(hipMemsetAsync(c->d_lcnt, 0, (size_t)(nreads + 1) * sizeof(uint32_t), c->stream));   // collector-only kernels write no list lengths: the array only carries the long-read marks
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     auto launch = [&](const ReadBatch& X, int g) -> hipError_t {
+      if (useDuo) return qmk_launch_duo(&ix, &X, c->numCU, c->stream);
       if (useLean || (useLeanSel && ix.sanext)) return qmk_launch_lean(&ix, &X, c->numCU, c->stream);
       if (rq.mode == QM_RUN_FROM_INTERVALS) return qmk_h2m(&ix, &X, g, c->numCU, c->stream);
       if (twoPass) return qmk_map_reads_ex(&ix, &X, ns, 1, g, c->numCU, c->stream);
@@ -915,6 +923,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
         C.nreads = r1 - r0; C.lcnt = B.lcnt + r0; C.loff = B.loff + r0;
         if (C.iv_cnt) { C.iv_cnt = B.iv_cnt + r0; C.iv_off = B.iv_off + r0; }
         if (C.found_out) C.found_out = B.found_out + r0;
+        if (C.pair_cnt) C.pair_cnt = B.pair_cnt + u0;
         HIPCHK(launch(C, qmk_map_grid_ex(r1 - r0, c->numCU, phc)));
       }
       feeder = nullptr;                                   // a retry finds everything resident
@@ -1092,7 +1101,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
   c->lastIvTotal = wantIv ? (int64_t)hscal[QM_SC_IVCUR] : 0;
   c->lastIvReads = wantIv ? nreads : -1;
   c->lastFoundReads = wantFound ? nreads : -1;
-  c->lastListReads = rq.mode != QM_RUN_COLLECT ? nreads : -1;
+  c->lastListReads = (rq.mode != QM_RUN_COLLECT && !duoMerge) ? nreads : -1;   // (pairs the pair kernel merged have no per-read lists)
   c->lastListWords = (int64_t)hscal[0];
   float ms = 0; hipEventElapsedTime(&ms, c->ev0, c->ev1); c->lastMapMs = ms + leanExtraMs;
   return QM_OK;

@@ -61,6 +61,8 @@ namespace qm {
 #define QM_SKIP_CAP 4096           // ... of which this many are listed
 #define QM_LCNT_SLOW 0x7fffffffu   // lcnt value of a read waiting on the slow queue
 #define QM_LCNT_LEAN 0x7ffffffeu   // ... of a read qm_lean_kernel left to the general kernel (qm_lean.inl)
+#define QM_LCNT_PAIR 0x7ffffffdu   // lcnt[2u] of a pair qm_duo_kernel merged itself (qm_duo.inl): the pair's records are at loff[2u], their count in pair_cnt[u]
+#define QM_DUO_ORPHAN 0xffffff0000000000ULL   // ... second word of an orphan's record (| its MateStatus); a paired hit's is the mate's list element
 
 struct Slot { u64 key; int lb; int ub; };          // hash.bin record / small linear-probing tables, key == ~0 empty
 // SA indexes and text positions are UNSIGNED 32-bit on the device: an index whose text needs the reference's int64 instantiation
@@ -190,6 +192,10 @@ struct ReadBatch {
   // scratch (code 2: only with max_interval above its default).  Such a read gets an empty result and an entry here (read | code << 56);
   // the rest of the batch is mapped as if it were not there.  Count: scalar slot QM_SC_SKIPCNT.
   u64* skiplist;
+  // qm_duo_kernel (qm_duo.inl: the two mates of a pair in one wavefront): when set, a pair whose mates were both mapped there is also
+  // MERGED there (mergeLeftRightHits + the per-pair driver): pair_cnt[u] = its hits, lcnt[2u] = QM_LCNT_PAIR, loff[2u] = where its
+  // records sit in `lists` (two words per hit), the HitCounters added to cursor[1..6]; stage B only expands the records
+  u32* pair_cnt; int max_num_hits, no_orphans, no_dovetail;
 };
 
 // stage B launch arguments
@@ -2111,8 +2117,24 @@ QM_DEV int unit_merge_fuzzy(const PairBatch& P, long long u, qm_hit* out, int ca
 // mergeLeftRightHits (RapMapUtils.hpp:1185-1264) + per-pair driver (RapMapSAMapper.cpp:461-551,684-701),
 // or the single-end driver (:232-250).  out == nullptr: count only (and add to the counters);
 // otherwise write the unit's hits to out[0..min(return, cap)), cap = the count pass's result.
+// a record qm_duo_kernel left for a pair it merged itself (qm_duo.inl): {left element, right element} of a paired hit, or
+// {element, QM_DUO_ORPHAN | MateStatus} of an orphan
+QM_DEV qm_hit duo_hit(u64 w0, u64 w1, u32 l1, u32 l2) {
+  if ((w1 & QM_DUO_ORPHAN) == QM_DUO_ORPHAN) { const int ms = (int)(w1 & 0xffu); return orphan_hit(w0, ms == 1 ? l1 : l2, ms); }
+  return paired_hit(w0, w1, l1, l2);
+}
 QM_DEV int unit_merge(const PairBatch& P, long long u, qm_hit* out, int cap, UnitCounters* uc) {
   const int maxHits = P.max_num_hits;
+  if (P.paired && P.lcnt[2 * u] == QM_LCNT_PAIR) {
+    // merged where it was mapped: the count (and the counters) are there already, the write pass expands the records
+    const int c = (int)P.cnt[u];
+    if (out) {
+      const u64* R = P.lists + P.loff[2 * u];
+      const u32 l1 = (u32)(P.off1[u + 1] - P.off1[u]), l2 = (u32)(P.off2[u + 1] - P.off2[u]);
+      for (int i = 0; i < c && i < cap; ++i) out[i] = duo_hit(R[2 * i], R[2 * i + 1], l1, l2);
+    }
+    return c;
+  }
   if (P.paired && P.fuzzy) return unit_merge_fuzzy(P, u, out, cap, uc);
   if (!P.paired) {
     int n = (int)(P.lcnt[u] & 0x7fffffffu);

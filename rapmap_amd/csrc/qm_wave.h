@@ -166,6 +166,16 @@ QM_DEV void load_8_16(const u64* p8, const u64* p16, u64& a, U4& b) { a = *p8; b
 template <int N> QM_DEV void load_8_16xN(const u64* const* B, const int* bit, u64* word, U4* meta) {
   for (int t = 0; t < N; ++t) load_8_16(B[t] + (bit[t] >> 6), B[t] + 6, word[t], meta[t]);
 }
+// ---- half-wavefront helpers (qm_duo.inl: lanes 0-31 and lanes 32-63 each work on a read of their own)
+// every lane gets the 32 ballot bits of its own half
+QM_DEV void half_ballot(const LV<bool>& b, LV<u32>& out) { const u64 m = ballot(b); for (int l = 0; l < 64; ++l) out.v[l] = (u32)(m >> (l & 32)); }
+// out[l] = x[lane idx[l] of l's half]
+QM_DEV void half_read(const LV<u32>& x, const LV<int>& idx, LV<u32>& out) { LV<u32> t; for (int l = 0; l < 64; ++l) t.v[l] = x.v[(l & 32) + (idx.v[l] & 31)]; out = t; }
+// every lane gets the maximum over its half
+QM_DEV void half_max(LV<int>& x) {
+  for (int b = 0; b < 64; b += 32) { int m = x.v[b]; for (int l = b + 1; l < b + 32; ++l) m = x.v[l] > m ? x.v[l] : m; for (int l = b; l < b + 32; ++l) x.v[l] = m; }
+}
+QM_DEV void load_48(const void* p, U4& a, U4& b, U4& c) { a = load_16(p); b = load_16((const unsigned char*)p + 16); c = load_16((const unsigned char*)p + 32); }
 #else
 // DPP reductions (profiles/microbench/dpp_check.hip: row_shr:n gives lane i the value of lane i - n of its row of 16;
 // a lane without a source keeps `old`).  A step is one VALU instruction and no trip through the LDS crossbar --
@@ -312,6 +322,31 @@ template <int N> QM_DEV void load_8_16xN(const u64* const* B, const int* bit, u6
   for (int t = 0; t < N; ++t) asm volatile("" : "+v"(x[t]), "+v"(y[t]));
 #pragma unroll
   for (int t = 0; t < N; ++t) { word[t] = x[t]; meta[t].x = y[t].x; meta[t].y = y[t].y; meta[t].z = y[t].z; meta[t].w = y[t].w; }
+}
+// ---- half-wavefront helpers (qm_duo.inl: lanes 0-31 and lanes 32-63 each work on a read of their own)
+QM_DEV void half_ballot(const LV<bool>& b, LV<u32>& out) {
+  const u64 m = __builtin_amdgcn_ballot_w64(b.v[0]);
+  out.v[0] = (threadIdx.x & 32) ? (u32)(m >> 32) : (u32)m;
+}
+// a trip through the LDS crossbar (ds_bpermute_b32): the index differs between the halves, so it cannot be a v_readlane
+QM_DEV void half_read(const LV<u32>& x, const LV<int>& idx, LV<u32>& out) {
+  out.v[0] = (u32)__builtin_amdgcn_ds_bpermute((int)(((threadIdx.x & 32) + (u32)(idx.v[0] & 31)) << 2), (int)x.v[0]);
+}
+QM_DEV void half_max(LV<int>& x) {
+  int v = x.v[0], t;
+  t = dpp_get<0x111, 0xf>(v); v = t > v ? t : v;           // row_shr:1, 2, 4, 8: lane 15 of every row holds the row's maximum
+  t = dpp_get<0x112, 0xf>(v); v = t > v ? t : v;
+  t = dpp_get<0x114, 0xf>(v); v = t > v ? t : v;
+  t = dpp_get<0x118, 0xf>(v); v = t > v ? t : v;
+  t = dpp_get<0x142, 0xa>(v); v = t > v ? t : v;           // row_bcast:15 into rows 1 and 3: lanes 31 and 63 hold their half's maximum
+  x.v[0] = __builtin_amdgcn_ds_bpermute((int)((threadIdx.x | 31u) << 2), v);
+}
+// three 16-byte loads from one 64-byte bucket, issued back to back and waited for together
+QM_DEV void load_48(const void* p, U4& a, U4& b, U4& c) {
+  typedef u32 v4u __attribute__((ext_vector_type(4)));
+  v4u x = ((const v4u*)p)[0], y = ((const v4u*)p)[1], z = ((const v4u*)p)[2];
+  asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
+  a.x = x.x; a.y = x.y; a.z = x.z; a.w = x.w; b.x = y.x; b.y = y.y; b.z = y.z; b.w = y.w; c.x = z.x; c.y = z.y; c.z = z.z; c.w = z.w;
 }
 #endif
 

@@ -10,6 +10,7 @@ _LIB = os.path.join(_HERE, "libqm_emu.so")
 _SRC = [os.path.join(_HERE, "qm_emu.cpp"),
         os.path.join(_HERE, "../../rapmap_amd/csrc/qm_mapper.inl"),
         os.path.join(_HERE, "../../rapmap_amd/csrc/qm_lean.inl"),
+        os.path.join(_HERE, "../../rapmap_amd/csrc/qm_duo.inl"),
         os.path.join(_HERE, "../../rapmap_amd/csrc/qm_wave.h"),
         os.path.join(_HERE, "../../rapmap_amd/csrc/qm_phflat.h"),
         os.path.join(_HERE, "../../rapmap_amd/csrc/qm_sel.inl"),

@@ -9,6 +9,7 @@ namespace qm { unsigned long long qm_prof[32]; }
 #endif
 #include "../../rapmap_amd/csrc/qm_mapper.inl"
 #include "../../rapmap_amd/csrc/qm_lean.inl"
+#include "../../rapmap_amd/csrc/qm_duo.inl"
 #include "../../rapmap_amd/csrc/qm_phflat.h"
 #include <cstdlib>
 #include <cstring>
@@ -310,6 +311,75 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
     if ((long long)scal2[QM_SC_LEANQ] != deferred) { fprintf(stderr, "[qm emu] lean -s collector: %lld marks, counter says %llu\n", deferred, (unsigned long long)scal2[QM_SC_LEANQ]); ++bad; }
     if (getenv("QM_EMU_LEAN_STATS")) fprintf(stderr, "[qm emu] lean -s collector took %lld of %lld reads\n", nreads - deferred, nreads);
     if (bad || (status2 & ~1)) status |= 128;
+  }
+  if (ns == 2 && paired && (ix.slots || ix.ph) && ix.saext && B.sensitive && !o->sel_aln && !(status & 1) && !getenv("QM_EMU_NO_DUO")) {
+    // the pair kernel (qm_duo.inl: the two mates in lockstep in the two halves of a wavefront, the pair merged there) over the same
+    // batch, three "waves" with the kernel's own software pipeline.  Every pair it merges must carry exactly the hits -- and add
+    // exactly the counters -- that unit_merge makes of the general kernel's lists; every list it writes per read must be the general
+    // kernel's word for word; the reads it marks are the general kernel's.  Twice: with the merge (fused calls) and without
+    // (pair_cnt == null: lists only).
+    for (int pass = 0; pass < 2; ++pass) {
+      std::vector<u32> lcnt2(nreads + 1, 0); std::vector<long long> loff2(nreads + 1, 0); std::vector<u32> pcnt(nunits + 1, 0xdeadbeefu);
+      std::vector<u64> lists2((size_t)cap, 0);
+      u64 scal2[QM_SC_WORDS]; memset(scal2, 0, sizeof(scal2)); int status2 = 0;
+      ReadBatch Lb = B; Lb.lcnt = lcnt2.data(); Lb.loff = loff2.data(); Lb.lists = lists2.data(); Lb.lists_cap = cap; Lb.cursor = scal2; Lb.status = &status2;
+      Lb.iv_out = nullptr; Lb.iv_cnt = nullptr; Lb.iv_off = nullptr;
+      Lb.pair_cnt = pass == 0 ? pcnt.data() : nullptr; Lb.max_num_hits = o->max_num_hits; Lb.no_orphans = o->no_orphans; Lb.no_dovetail = o->no_dovetail;
+      const long long nit = nunits, NW = 3;
+      static DuoMem Ms[3];
+      DuoCtr dc[3];
+      for (long long w = 0; w < NW; ++w) {
+        DuoMem& M = Ms[w]; memset(&M, 0xA5, sizeof(M));
+        for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int c = 4; c < 8; ++c) M.pk[a][b][c] = 0;      // (the kernel's own initialisation)
+        WaveAlloc wl; wl.base = -1; wl.used = 0; wl.ivBase = -1; wl.ivUsed = 0;
+        dc[w] = DuoCtr{0, 0, 0, 0, 0, 0};
+        duo_stage_offsets(Lb, (int)w, (int)nit, M, 0); duo_stage_chars(Lb, (int)w, (int)nit, M, 0); duo_stage_offsets(Lb, (int)(w + NW), (int)nit, M, 1);
+        int par = 0;
+        for (long long it = w; it < nit; it += NW) { if (ix.ph) duo_iter<true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl, dc[w]); else duo_iter<false>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl, dc[w]); par ^= 1; }
+      }
+      PairBatch Pg; memset(&Pg, 0, sizeof(Pg));           // the general kernel's lists through stage B: what a merged pair must equal
+      std::vector<u32> hcg(nunits + 1, 0);
+      Pg.n = nunits; Pg.paired = 1; Pg.off1 = off1; Pg.off2 = off2; Pg.lcnt = lcnt.data(); Pg.loff = loff.data(); Pg.lists = lists.data(); Pg.cnt = hcg.data();
+      Pg.max_num_hits = o->max_num_hits; Pg.no_orphans = o->no_orphans; Pg.no_dovetail = o->no_dovetail; Pg.fuzzy = o->fuzzy;
+      PairBatch Pd = Pg; Pd.lcnt = lcnt2.data(); Pd.loff = loff2.data(); Pd.lists = lists2.data(); Pd.cnt = pcnt.data();
+      UnitCounters want = {0, 0, 0, 0, 0, 0};
+      long long bad = 0, deferred = 0, merged = 0;
+      for (long long u = 0; u < nunits; ++u) {
+        if (lcnt2[2 * u] == QM_LCNT_PAIR) {
+          ++merged;
+          if (pass == 1 || o->fuzzy) { if (bad < 5) fprintf(stderr, "[qm emu] pair kernel: pair %lld merged although it may not be\n", u); ++bad; continue; }
+          UnitCounters uc = {0, 0, 0, 0, 0, 0};
+          const int cg = unit_merge(Pg, u, nullptr, 0, &uc);
+          want.pe += uc.pe; want.se += uc.se; want.tot += uc.tot; want.reads += uc.reads; want.tooMany += uc.tooMany; want.mapped += uc.mapped;
+          bool same = (u32)cg == pcnt[u];
+          if (same && cg > 0) {
+            std::vector<qm_hit> hg((size_t)cg), hd((size_t)cg);
+            unit_merge(Pg, u, hg.data(), cg, nullptr); unit_merge(Pd, u, hd.data(), cg, nullptr);
+            same = memcmp(hg.data(), hd.data(), sizeof(qm_hit) * (size_t)cg) == 0;
+          }
+          if (!same) { if (bad < 5) fprintf(stderr, "[qm emu] pair kernel: pair %lld differs (%u hits vs %d)\n", u, pcnt[u], cg); ++bad; }
+          continue;
+        }
+        for (int m = 0; m < 2; ++m) {
+          const long long r = 2 * u + m;
+          if (lcnt2[r] == QM_LCNT_LEAN) { ++deferred; continue; }
+          bool same = lcnt2[r] == lcnt[r];
+          const long long nwd = lcnt[r] & 0x7fffffffu;
+          for (long long t = 0; same && t < nwd; ++t) same = lists2[loff2[r] + t] == lists[loff[r] + t];
+          if (!same) { if (bad < 5) fprintf(stderr, "[qm emu] pair kernel: read %lld differs (words %u vs %u)\n", r, lcnt2[r], lcnt[r]); ++bad; }
+        }
+      }
+      DuoCtr got = {0, 0, 0, 0, 0, 0};
+      for (long long w = 0; w < NW; ++w) { got.pe += dc[w].pe; got.se += dc[w].se; got.tot += dc[w].tot; got.reads += dc[w].reads; got.tooMany += dc[w].tooMany; got.mapped += dc[w].mapped; }
+      if (got.pe != want.pe || got.se != want.se || got.tot != want.tot || got.reads != want.reads || got.tooMany != want.tooMany || got.mapped != want.mapped) {
+        fprintf(stderr, "[qm emu] pair kernel: counters of the merged pairs %u %u %u %u %u %u, stage B says %llu %llu %llu %llu %llu %llu\n", got.pe, got.se, got.tot, got.reads, got.tooMany, got.mapped,
+                (unsigned long long)want.pe, (unsigned long long)want.se, (unsigned long long)want.tot, (unsigned long long)want.reads, (unsigned long long)want.tooMany, (unsigned long long)want.mapped);
+        ++bad;
+      }
+      if ((long long)scal2[QM_SC_LEANQ] != deferred) { fprintf(stderr, "[qm emu] pair kernel: %lld marks, counter says %llu\n", deferred, (unsigned long long)scal2[QM_SC_LEANQ]); ++bad; }
+      if (getenv("QM_EMU_LEAN_STATS")) fprintf(stderr, "[qm emu] pair kernel (pass %d) took %lld of %lld reads, merged %lld of %lld pairs\n", pass, nreads - deferred, nreads, merged, nunits);
+      if (bad || (status2 & ~1)) status |= 32;
+    }
   }
   PairBatch P; memset(&P, 0, sizeof(P));
   std::vector<u32> hc(nunits + 1, 0); std::vector<long long> offs(nunits + 1, 0);
