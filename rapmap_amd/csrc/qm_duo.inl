@@ -29,15 +29,18 @@
 
 namespace qm {
 
+#ifndef QM_DUO_SUF
 #define QM_DUO_SUF 32            // suffixes a read's intervals may hold together, and the widest interval
+#endif
 #define QM_DUO_MAXIV 32          // intervals per read (a bit each)
 
-struct DuoMem {                                // one wave's LDS slab (2 000 bytes)
+struct DuoMem {                                // one wave's LDS slab (3 024 bytes)
   u64 pk[2][2][8];                             // as LeanMem::pk: [mate][0: the read, 1: mirrored reverse complement][word]; words 4-7 stay zero
   union {
     LeanSuf suf[2][QM_DUO_SUF];                // [mate]: suffixes of the intervals recorded for it
     u64 lst[2][32];                            // ... later its hit list, sorted, for the merge
   };
+  LeanSuf trash[64];                           // where a lane that has nothing to record stores (no branch around the store)
   u32 stage[100];                              // raw characters of the next pair: dwords [0, 32) mate 0, [32, 64) mate 1, [64] / [96] the 33rd dword of mate 0 / 1
   u32 ostage[2][8];                            // offsets of the next / the next but one pair: off1[u], off1[u + 1], off2[u], off2[u + 1]
 };
@@ -108,41 +111,66 @@ QM_DEV void duo_find_ph(const DevIndex& ix, const LV<u64>& w, const LV<u64>& wr,
     }
     wf[l] = a; wc[l] = b;
   }
+  // nearly every position that passes the filter does so in ONE orientation: one walk of the levels for the wave, the k-mer where it
+  // passed and else the reverse complement; a second walk only when some position passed in both
+  LV<bool> both;
   QM_LANES(l) {
+    const bool first = wf[l] || wc[l];
     bool h = false; u32 a = 0, b = 0;
-    if (wf[l]) h = find_kmer<QM_F_PH>(ix, w[l], a, b);
-    fh[l] = h ? 1u : 0u; flb[l] = a; fub[l] = b;
+    if (first) h = find_kmer<QM_F_PH>(ix, wf[l] ? w[l] : wr[l], a, b);
+    const bool isF = wf[l];
+    fh[l] = (h && isF) ? 1u : 0u; flb[l] = isF ? a : 0u; fub[l] = isF ? b : 0u;
+    ch[l] = (h && !isF) ? 1u : 0u; clb[l] = isF ? 0u : a; cub[l] = isF ? 0u : b;
+    both[l] = wf[l] && wc[l];
   }
-  QM_LANES(l) {
-    bool h = false; u32 a = 0, b = 0;
-    if (wc[l]) h = find_kmer<QM_F_PH>(ix, wr[l], a, b);
-    ch[l] = h ? 1u : 0u; clb[l] = a; cub[l] = b;
+  if (ballot(both)) {
+    QM_LANES(l) {
+      bool h = false; u32 a = 0, b = 0;
+      if (both[l]) h = find_kmer<QM_F_PH>(ix, wr[l], a, b);
+      if (both[l]) { ch[l] = h ? 1u : 0u; clb[l] = a; cub[l] = b; }
+    }
   }
 }
 
-// what a half's walk carries (every member: one value per lane, the same in the 32 lanes of a half)
+// What a half's walk carries: every member is one value per lane, the same in the 32 lanes of a half, packed so that the whole state
+// is a dozen registers (the kernel runs at 8 waves per SIMD: 64 registers per lane for everything).
+//   fl: bits 0-1 mode (0: nothing (more) to do, 1: first-hit scan, SACollector.hpp:167-237, 2: getSAHits_ over strand V), then the flags below
+#define QM_DW_MODE 3u
+#define QM_DW_V 4u            // the strand walked: reverseRead(read)
+#define QM_DW_SKIP 8u         // the walk stands on a hit (position p of its window)
+#define QM_DW_SPOT 16u        // the next k-mer is a spot check behind a recorded interval (:602-611)
+#define QM_DW_STOP 32u        // ... after which the walk ends (stopAfter)
+#define QM_DW_LAST 64u        // lastSearch
+#define QM_DW_BAIL 128u       // left to the general kernel
+#define QM_DW_FOUND 256u      // foundHit
+#define QM_DW_DEF 512u        // not taken at all (a character that is not A C G T, a homopolymer window, more than 128 characters)
+#define QM_DW_FL 1024u        // what the first probe learned about the read's last k-mer: it is in the index ...
+#define QM_DW_CL 2048u        // ... its reverse complement is (= the first k-mer of reverseRead(read))
 struct DuoWalk {
-  LV<int> mode;                                // 0: nothing (more) to do, 1: first-hit scan (SACollector.hpp:167-237), 2: getSAHits_ over strand V
-  LV<int> p, V, skip, spot, stopAfter, lastSearch, width, prevEnd;
-  LV<int> wb, ww; LV<u32> Fm, Cm;              // the window: positions [wb, wb + ww) of the strand, bit j = k-mer / reverse complement of position wb + j found
+  LV<u32> fl;
+  LV<int> p;                                   // the position the walk stands on
+  LV<u32> wbw; LV<u32> Fm, Cm;                 // the window: wb | ww << 8 -- positions [wb, wb + ww) of the strand, bit j = k-mer / reverse complement of position wb + j found
   LV<u32> lbw, ubw;                            // ... lane j of the half: the interval of the k-mer at position wb + j
-  LV<u32> lb, ub;                              // the interval the walk stands on
-  LV<u32> ha, hb;                              // hits of the walked strand / of the other one (SACollector.hpp:258,271)
-  LV<int> sn, sufN, minIdx, minSpan, cov, bail, foundHit;
+  LV<u32> rlb, rub;                            // the interval of reverseRead(read)'s first k-mer (the first probe looked it up: the reverse complement of the read's last k-mer)
+  LV<u32> hab;                                 // ha | hb << 16: hits of the walked strand / of the other one (SACollector.hpp:258,271)
+  LV<u32> cntr;                                // sn | sufN << 8: intervals recorded, their suffixes
+  LV<u32> mins;                                // minIdx | minSpan << 8: the first smallest interval (HitManager.cpp:636-641)
+  LV<int> cov, prevEnd;                        // COV only (quasiCoverage > 0): SACollector.hpp:343-358
 };
 
 // Probe positions [p, p + width) of its strand for every half that asked (`need`): lane j of the half looks up position p + j -- the
 // k-mer out of the strand's image, its reverse complement out of the other one (lean_probe) -- and the half's window is replaced.
+// width: 1 for the walk's last look (stopAfter), else 32.
 template <bool PH>
-QM_DEV void duo_probe(const DevIndex& ix, const QM_LDS(u64)* pkw, int k, const LV<int>& Pv, const LV<int>& Lv, const LV<u32>& need, DuoWalk& W) {
+QM_DEV void duo_probe(const DevIndex& ix, const QM_LDS(u64)* pkw, int k, const LV<int>& Lv, const LV<u32>& need, DuoWalk& W) {
   LV<u64> w, wr; LV<u32> on, fh, ch, flb, fub, clb, cub;
   LV<int> wwn;
   QM_LANES(l) {
     const int h = l >> 5, j = l & 31;
-    const int P = Pv[l], D = QM_LEAN_MAXLEN - Lv[l];
-    const int V = W.mode[l] == 2 ? W.V[l] : 0;
-    int nw = W.width[l];
-    if (W.p[l] + nw > P) nw = P - W.p[l];
+    const int P = Lv[l] - k + 1, D = QM_LEAN_MAXLEN - Lv[l];
+    const int V = ((W.fl[l] & QM_DW_MODE) == 2u && (W.fl[l] & QM_DW_V)) ? 1 : 0;
+    int nw = (W.fl[l] & QM_DW_STOP) ? 1 : 32;
+    nw = W.p[l] + nw > P ? P - W.p[l] : nw;
     const bool in = need[l] != 0 && j < nw;
     const int q = in ? W.p[l] + j : 0;
     const QM_LDS(u64)* pkh = pkw + 16 * h;
@@ -157,7 +185,10 @@ QM_DEV void duo_probe(const DevIndex& ix, const QM_LDS(u64)* pkw, int k, const L
   QM_LANES(l) { fb[l] = fh[l] != 0; cb[l] = ch[l] != 0; }
   half_ballot(fb, fm); half_ballot(cb, cm);
   QM_LANES(l) {
-    if (need[l]) { W.wb[l] = W.p[l]; W.ww[l] = wwn[l]; W.Fm[l] = fm[l]; W.Cm[l] = cm[l]; W.lbw[l] = flb[l]; W.ubw[l] = fub[l]; }
+    const bool nd = need[l] != 0;
+    W.wbw[l] = nd ? ((u32)W.p[l] | ((u32)wwn[l] << 8)) : W.wbw[l];
+    W.Fm[l] = nd ? fm[l] : W.Fm[l]; W.Cm[l] = nd ? cm[l] : W.Cm[l];
+    W.lbw[l] = nd ? flb[l] : W.lbw[l]; W.ubw[l] = nd ? fub[l] : W.ubw[l];
   }
 }
 
@@ -187,7 +218,7 @@ QM_DEV void duo_stage_chars(const ReadBatch& B, int it, int nit, DuoMem& M, int 
 }
 
 // One pair: reads 2 it and 2 it + 1.
-template <bool PH>
+template <bool PH, bool COV>
 QM_DEV void duo_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, int nw, int par, DuoMem& M, WaveAlloc& wa, DuoCtr& ctr) {
   const int k = ix.k;
   const QM_LDS(u64)* pkw = (const QM_LDS(u64)*)&M.pk[0][0][0];
@@ -235,7 +266,7 @@ QM_DEV void duo_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, in
   // ---- the first probe of both mates in one round (SACollector.hpp:167-237 starts at position 0; the read's last k-mer is the first
   // thing the reverse-complement pass asks for): lane 0 of a half = position 0, lane 1 = position P - 1, both orientations each
   DuoWalk W;
-  LV<u32> F0, C0, Fl, Cl, s0lb, s0ub, rlb, rub;
+  const u32 maxIv = (u32)B.max_interval;
   {
     LV<u64> w, wr; LV<u32> on, fh, ch, flb, fub, clb, cub;
     QM_LANES(l) {
@@ -252,117 +283,113 @@ QM_DEV void duo_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, in
     if (PH) duo_find_ph(ix, w, wr, on, fh, ch, flb, fub, clb, cub);
     else duo_find(ix, w, wr, on, fh, ch, flb, fub, clb, cub);
     lds_dma_wait();                                        // what was requested above has landed by now: no store follows an open request
-    LV<bool> fb, cb; LV<u32> fm, cm; LV<int> i0, i1;
+    LV<bool> fb, cb; LV<u32> fm, cm, s0lb, s0ub, rlb, rub; LV<int> i0, i1;
     QM_LANES(l) { fb[l] = fh[l] != 0; cb[l] = ch[l] != 0; i0[l] = 0; i1[l] = Pv[l] > 1 ? 1 : 0; }
     half_ballot(fb, fm); half_ballot(cb, cm);
     half_read(flb, i0, s0lb); half_read(fub, i0, s0ub);    // the interval of the read's first k-mer ...
     half_read(clb, i1, rlb); half_read(cub, i1, rub);      // ... and of the reverse complement of its last one = the first k-mer of reverseRead(read)
+    // ---- where the walks start: the read itself from its first hit when that hit is a forward one (SACollector.hpp:247-254), else
+    // reverseRead(read) from 0 (:258-265) -- lean_iter; a read whose first k-mer is in the index in neither orientation scans on (mode 1)
     QM_LANES(l) {
-      F0[l] = fm[l] & 1u; C0[l] = cm[l] & 1u;
-      Fl[l] = Pv[l] > 1 ? (fm[l] >> 1) & 1u : F0[l]; Cl[l] = Pv[l] > 1 ? (cm[l] >> 1) & 1u : C0[l];
+      const bool ok = !defv[l] && Pv[l] >= 1;
+      const u32 F0 = fm[l] & 1u, C0 = cm[l] & 1u;
+      const u32 Fl = Pv[l] > 1 ? (fm[l] >> 1) & 1u : F0, Cl = Pv[l] > 1 ? (cm[l] >> 1) & 1u : C0;
+      const bool fwd = ok && F0 != 0, rev = ok && F0 == 0 && C0 != 0, scan = ok && F0 == 0 && C0 == 0;
+      W.fl[l] = (defv[l] ? QM_DW_DEF : 0u) | (fwd ? (2u | QM_DW_FOUND | QM_DW_SKIP) : 0u) | (rev ? (2u | QM_DW_FOUND | QM_DW_V) : 0u) | (scan ? 1u : 0u) | (Fl ? QM_DW_FL : 0u) | (Cl ? QM_DW_CL : 0u);
+      W.p[l] = scan ? 1 : 0;
+      W.wbw[l] = 0u | (1u << 8);
+      W.Fm[l] = rev ? Cl : F0; W.Cm[l] = rev ? Fl : C0;    // (reverse: what the first probe learned about the read's last k-mer)
+      W.lbw[l] = rev ? rlb[l] : s0lb[l]; W.ubw[l] = rev ? rub[l] : s0ub[l];
+      W.rlb[l] = rlb[l]; W.rub[l] = rub[l];
+      W.hab[l] = (fwd || rev) ? (1u | (fwd ? C0 << 16 : 0u)) : 0u;
+      W.cntr[l] = 0; W.mins[l] = 0x7fffff00u; W.cov[l] = 0; W.prevEnd[l] = 0;
     }
   }
-  const u32 maxIv = (u32)B.max_interval;
-  // ---- where the walks start: the read itself from its first hit when that hit is a forward one (SACollector.hpp:247-254), else
-  // reverseRead(read) from 0 (:258-265) -- lean_iter; a read whose first k-mer is in the index in neither orientation scans on (mode 1)
-  QM_LANES(l) {
-    const bool ok = !defv[l] && Pv[l] >= 1;
-    W.mode[l] = 0; W.p[l] = 0; W.V[l] = 0; W.skip[l] = 0; W.spot[l] = 0; W.stopAfter[l] = 0; W.lastSearch[l] = 0; W.width[l] = 32; W.prevEnd[l] = 0;
-    W.wb[l] = 0; W.ww[l] = 1; W.Fm[l] = F0[l]; W.Cm[l] = C0[l]; W.lbw[l] = s0lb[l]; W.ubw[l] = s0ub[l];
-    W.lb[l] = 0; W.ub[l] = 0; W.ha[l] = 0; W.hb[l] = 0;
-    W.sn[l] = 0; W.sufN[l] = 0; W.minIdx[l] = 0; W.minSpan[l] = 0x7fffffff; W.cov[l] = 0; W.bail[l] = 0; W.foundHit[l] = 0;
-    if (ok) {
-      if (F0[l]) { W.mode[l] = 2; W.foundHit[l] = 1; W.skip[l] = 1; W.lb[l] = s0lb[l]; W.ub[l] = s0ub[l]; W.ha[l] = 1; W.hb[l] = C0[l]; }
-      else if (C0[l]) {
-        W.mode[l] = 2; W.foundHit[l] = 1; W.V[l] = 1; W.ha[l] = 1;
-        W.Fm[l] = Cl[l]; W.Cm[l] = Fl[l]; W.lbw[l] = rlb[l]; W.ubw[l] = rub[l];
-      } else { W.mode[l] = 1; W.p[l] = 1; }
-    }
-  }
-  // ---- the two walks in lockstep
+  // ---- the two walks in lockstep.  Straight-line selects, not branches, inside a phase: a branch on a per-lane condition costs the
+  // scalar unit three instructions (exec mask saved, tested, restored), and the scalar unit is what stage A runs out of first
   while (true) {
     // A: a walk that stands behind its read's last k-mer is through; a window is probed where a walk stands outside its own
     LV<u32> need; LV<bool> live, nb;
     QM_LANES(l) {
-      if (W.mode[l] != 0 && !W.skip[l] && W.p[l] >= Pv[l]) W.mode[l] = 0;      // (scan: no hit anywhere; walk: `if (p >= P) break`)
-      const bool inw = (unsigned)(W.p[l] - W.wb[l]) < (unsigned)W.ww[l];
-      need[l] = (W.mode[l] != 0 && !W.skip[l] && !inw) ? 1u : 0u;
-      live[l] = W.mode[l] != 0; nb[l] = need[l] != 0;
+      const u32 f = W.fl[l];
+      const bool act = (f & QM_DW_MODE) != 0 && !(f & QM_DW_SKIP);
+      const bool end = act && W.p[l] >= Lv[l] - k + 1;                         // (scan: no hit anywhere; walk: `if (p >= P) break`)
+      const u32 f2 = end ? (f & ~QM_DW_MODE) : f;
+      const bool inw = (u32)(W.p[l] - (int)(W.wbw[l] & 0xffu)) < (W.wbw[l] >> 8);
+      const bool nd = act && !end && !inw;
+      W.fl[l] = f2; need[l] = nd ? 1u : 0u; nb[l] = nd; live[l] = (f2 & QM_DW_MODE) != 0;
     }
     if (!ballot(live)) break;
-    if (ballot(nb)) duo_probe<PH>(ix, pkw, k, Pv, Lv, need, W);
+    if (ballot(nb)) duo_probe<PH>(ix, pkw, k, Lv, need, W);
     // B1: the first-hit scan (SACollector.hpp:167-237): the first position whose k-mer or reverse complement is in the hash
     {
-      LV<bool> sc; QM_LANES(l) { sc[l] = W.mode[l] == 1; }
+      LV<bool> sc; QM_LANES(l) { sc[l] = (W.fl[l] & QM_DW_MODE) == 1u; }
       if (ballot(sc)) {
-        LV<int> rel0; LV<u32> found, t0, t1;
+        LV<int> rel0;
         QM_LANES(l) {
-          found[l] = 0; rel0[l] = 0;
-          if (W.mode[l] == 1) {
-            const int rel = W.p[l] - W.wb[l];
-            const u32 mm = (W.Fm[l] | W.Cm[l]) >> rel;
-            if (mm) { W.p[l] += ctz32(mm); found[l] = 1; rel0[l] = W.p[l] - W.wb[l]; }
-            else W.p[l] = W.wb[l] + W.ww[l];
-          }
+          const int wb = (int)(W.wbw[l] & 0xffu), ww = (int)(W.wbw[l] >> 8);
+          const int rel = (W.p[l] - wb) & 31;
+          const u32 mm = (W.Fm[l] | W.Cm[l]) >> rel;
+          const bool found = sc[l] && mm != 0;
+          const int adv = mm ? ctz32(mm) : ww - rel;                          // to the hit, or behind the window
+          W.p[l] = sc[l] ? W.p[l] + adv : W.p[l];
+          rel0[l] = found ? rel + adv : 0;
+          sc[l] = found;
         }
-        half_read(W.lbw, rel0, t0); half_read(W.ubw, rel0, t1);
         QM_LANES(l) {
-          if (found[l]) {
-            W.mode[l] = 2; W.foundHit[l] = 1; W.ha[l] = 1;
-            if ((W.Fm[l] >> rel0[l]) & 1u) { W.V[l] = 0; W.skip[l] = 1; W.lb[l] = t0[l]; W.ub[l] = t1[l]; W.hb[l] = (W.Cm[l] >> rel0[l]) & 1u; }
-            else {
-              // what the first probe learned about the read's last k-mer is the first k-mer of reverseRead(read)
-              W.V[l] = 1; W.hb[l] = 0; W.p[l] = 0; W.wb[l] = 0; W.ww[l] = 1; W.Fm[l] = Cl[l]; W.Cm[l] = Fl[l]; W.lbw[l] = rlb[l]; W.ubw[l] = rub[l];
-            }
-          }
+          const bool fwd = sc[l] && ((W.Fm[l] >> rel0[l]) & 1u) != 0, rev = sc[l] && !fwd;
+          // forward: the walk stands on the hit.  Reverse: reverseRead(read) from 0, whose first k-mer the first probe looked up: what it
+          // learned about the read's last k-mer (SACollector.hpp:258-265)
+          W.hab[l] = sc[l] ? (1u | (fwd ? ((W.Cm[l] >> rel0[l]) & 1u) << 16 : 0u)) : W.hab[l];
+          W.fl[l] = sc[l] ? ((W.fl[l] & ~QM_DW_MODE) | 2u | QM_DW_FOUND | (fwd ? QM_DW_SKIP : QM_DW_V)) : W.fl[l];
+          W.p[l] = rev ? 0 : W.p[l];
+          W.wbw[l] = rev ? (0u | (1u << 8)) : W.wbw[l];
+          W.Fm[l] = rev ? ((W.fl[l] & QM_DW_CL) ? 1u : 0u) : W.Fm[l]; W.Cm[l] = rev ? ((W.fl[l] & QM_DW_FL) ? 1u : 0u) : W.Cm[l];
+          W.lbw[l] = rev ? W.rlb[l] : W.lbw[l]; W.ubw[l] = rev ? W.rub[l] : W.ubw[l];
         }
       }
     }
     // B2: SACollector::getSAHits_ (SACollector.hpp:441-677, NIP disabled) steps to the walk's next hit inside the window
     LV<u32> ext; LV<int> relh; LV<bool> eb;
     QM_LANES(l) {
-      u32 e = (W.mode[l] == 2 && W.skip[l]) ? 1u : 0u;
-      if (W.mode[l] == 2 && !W.skip[l]) {
-        const int rel = W.p[l] - W.wb[l];
-        const u32 fm = W.Fm[l] >> rel, cm = W.Cm[l] >> rel;                    // (no bits beyond the window)
-        const int avail = W.ww[l] - rel;
-        bool go = true;
-        if (W.spot[l]) {                                                       // the k-mer the walk goes on with, spot-checked (:602-611)
-          W.ha[l] += fm & 1u; W.hb[l] += cm & 1u; W.spot[l] = 0;
-          if (W.stopAfter[l]) { W.mode[l] = 0; go = false; }
-        }
-        if (go) {
-          const u32 below = (fm & (0u - fm)) - 1u;                             // the positions before the first hit (all of them without one)
-          W.hb[l] += (u32)popc32(cm & ~fm & below);                            // misses: spotCheck_ of the complement (:667-675)
-          if (!fm) W.p[l] += avail;
-          else {
-            const int ph = ctz32(fm);
-            W.ha[l] += 1;                                                      // spotCheck_ on the hit (:545)
-            W.hb[l] += (cm >> ph) & 1u;
-            W.p[l] += ph; e = 1u;
-          }
-        }
-      }
-      ext[l] = e; eb[l] = e != 0; relh[l] = W.p[l] - W.wb[l];
+      const u32 f = W.fl[l];
+      const int wb = (int)(W.wbw[l] & 0xffu), ww = (int)(W.wbw[l] >> 8);
+      const int relr = W.p[l] - wb;
+      const bool st = (f & (QM_DW_MODE | QM_DW_SKIP)) == 2u && (u32)relr < (u32)ww;   // walking, its window covers p
+      const int rel = relr & 31;
+      const u32 fm = W.Fm[l] >> rel, cm = W.Cm[l] >> rel;                      // (no bits beyond the window)
+      const int avail = ww - rel;
+      const bool sp = st && (f & QM_DW_SPOT) != 0;                             // the k-mer the walk goes on with, spot-checked (:602-611)
+      const bool stop = sp && (f & QM_DW_STOP) != 0;
+      const bool go = st && !stop;
+      const u32 below = (fm & (0u - fm)) - 1u;                                 // the positions before the first hit (all of them without one)
+      const bool hit = go && fm != 0;
+      const int ph = ctz32(fm | 0x80000000u);
+      u32 add = sp ? ((fm & 1u) | ((cm & 1u) << 16)) : 0u;
+      add += go ? ((u32)popc32(cm & ~fm & below) << 16) : 0u;                  // misses: spotCheck_ of the complement (:667-675)
+      add += hit ? (1u | (((cm >> ph) & 1u) << 16)) : 0u;                      // spotCheck_ on the hit (:545)
+      W.hab[l] += add;
+      W.p[l] += go ? (hit ? ph : avail) : 0;
+      u32 f2 = st ? (f & ~QM_DW_SPOT) : f;
+      f2 = stop ? (f2 & ~QM_DW_MODE) : f2;
+      W.fl[l] = f2;
+      const bool e = hit || (f & (QM_DW_MODE | QM_DW_SKIP)) == (2u | QM_DW_SKIP);
+      ext[l] = e ? 1u : 0u; eb[l] = e; relh[l] = (W.p[l] - wb) & 31;
     }
     if (!ballot(eb)) continue;
-    {
-      LV<u32> t0, t1;
-      half_read(W.lbw, relh, t0); half_read(W.ubw, relh, t1);
-      QM_LANES(l) { if (ext[l] && !W.skip[l]) { W.lb[l] = t0[l]; W.ub[l] = t1[l]; } W.skip[l] = 0; }
-    }
+    LV<u32> lbv, ubv;                                                           // the interval of the hit: the lane of the window that owns position p has it
+    half_read(W.lbw, relh, lbv); half_read(W.ubw, relh, ubv);
     // C: the MMP extension (SASearcher.hpp:88-309) in the closed form of extend_search_wide against the packed characters behind
     // every suffix's k-mer (one lane per suffix, one 32-byte load each, lean_iter); the (transcript, position) words of the block it
     // settles on go to the half's stash
     LV<int> lc; LV<u32> tdv, tpv, okw; LV<bool> fullv;
     QM_LANES(l) {
       const int h = l >> 5, j = l & 31;
-      const u32 lbIn = W.lb[l] ? W.lb[l] - 1 : 0;                               // :553
-      const int wiv = (int)(W.ub[l] - lbIn - 1);
+      const u32 lbIn = lbv[l] ? lbv[l] - 1 : 0;                                 // :553
+      const int wiv = (int)(ubv[l] - lbIn - 1);
       const bool e = ext[l] != 0;
       const bool okv = e && wiv >= 1 && wiv <= QM_DUO_SUF;
-      if (e && !okv) { W.bail[l] = 1; W.mode[l] = 0; }
-      const int L = Lv[l], V = W.V[l];
+      const int L = Lv[l], V = (W.fl[l] & QM_DW_V) ? 1 : 0;
       const int pos = W.p[l] + k, rem = L - pos;
       const int cap = rem < QM_EXT_BASES ? rem : QM_EXT_BASES;
       const int gq = (okv ? pos : 0) + (V ? QM_LEAN_MAXLEN - L : 0), jw = gq >> 5, sh = 2 * (gq & 31);
@@ -382,6 +409,7 @@ QM_DEV void duo_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, in
       lc[l] = (okv && j < wiv) ? k + matched : -1;
       tdv[l] = b.z & ((1u << QM_EXT_TID_BITS) - 1); tpv[l] = b.w;
       okw[l] = okv ? 1u : 0u;
+      W.fl[l] = (e && !okv) ? ((W.fl[l] & ~(QM_DW_MODE | QM_DW_SKIP)) | QM_DW_BAIL) : W.fl[l];   // an interval wider than a half
     }
     LV<u32> fullm; half_ballot(fullv, fullm);
     LV<int> mx; QM_LANES(l) { mx[l] = lc[l]; }
@@ -390,56 +418,50 @@ QM_DEV void duo_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, in
     LV<u32> bq; half_ballot(best, bq);
     QM_LANES(l) {
       const int h = l >> 5, j = l & 31;
-      if (okw[l] && fullm[l]) { W.bail[l] = 1; W.mode[l] = 0; }
-      else if (okw[l]) {
-        const int L = Lv[l], pcur = W.p[l], mlen = mx[l];
-        const u32 lbIn = W.lb[l] ? W.lb[l] - 1 : 0;
-        const int first = ctz32(bq[l]), cnt = 32 - __builtin_clz(bq[l] | 1u) - first;
-        W.lb[l] = lbIn + 1 + (u32)first; W.ub[l] = W.lb[l] + (u32)cnt;
-        const int kp = pcur + mlen - (k - 1);
-        int recorded = 0;
-        if ((u32)cnt < maxIv) {                                                // ub > lb && ub - lb < maxInterval (:577-618)
-          if (W.sufN[l] + cnt > QM_DUO_SUF || W.sn[l] >= QM_DUO_MAXIV) { W.bail[l] = 1; W.mode[l] = 0; }
-          else {
-            if (j >= first && j < first + cnt) {
-              QM_LDS(LeanSuf)* d = (QM_LDS(LeanSuf)*)&M.suf[h][W.sufN[l] + j - first];
-              d->tid = tdv[l]; d->pos = tpv[l]; d->qp = (u32)pcur; d->iv = (u32)W.sn[l];
-            }
-            if (cnt < W.minSpan[l]) { W.minSpan[l] = cnt; W.minIdx[l] = W.sn[l]; }
-            W.sufN[l] += cnt; W.sn[l] += 1;
-            const int corr = W.prevEnd[l] > pcur ? W.prevEnd[l] - pcur : 0;
-            W.cov[l] += mlen - corr;
-            W.prevEnd[l] = pcur + mlen;
-            recorded = 1;
-          }
-        }
-        if (W.mode[l] != 0) {
-          if (pcur + mlen >= L) W.mode[l] = 0;                                 // the read is through
-          else {
-            W.spot[l] = recorded;                                              // (:602-611: only behind a recorded interval; kp < P here)
-            W.stopAfter[l] = W.lastSearch[l];
-            if (W.lastSearch[l] && !recorded) W.mode[l] = 0;
-            else {
-              W.p[l] = kp;                                                     // NIP off: lce == matchedLen (:635-647)
-              W.width[l] = W.stopAfter[l] ? 1 : 32;
-              if (kp + k == L) W.lastSearch[l] = 1;
-            }
-          }
-        }
+      const u32 f = W.fl[l];
+      const bool ok = okw[l] != 0, full = ok && fullm[l] != 0, go = ok && !full;
+      const int L = Lv[l], pcur = W.p[l], mlen = mx[l];
+      const int first = ctz32(bq[l] | 0x80000000u), cnt = 32 - __builtin_clz(bq[l] | 1u) - first;
+      const int sn = (int)(W.cntr[l] & 0xffu), sufN = (int)(W.cntr[l] >> 8);
+      const bool narrow = (u32)cnt < maxIv;                                    // ub > lb && ub - lb < maxInterval (:577-618)
+      const bool over = go && narrow && (sufN + cnt > QM_DUO_SUF || sn >= QM_DUO_MAXIV);
+      const bool rec = go && narrow && !over;
+      const bool mine = rec && j >= first && j < first + cnt;
+      // (a lane that records nothing writes to a slot of its own behind the stash: no branch around the store)
+      QM_LDS(LeanSuf)* d = mine ? (QM_LDS(LeanSuf)*)&M.suf[h][sufN + j - first] : (QM_LDS(LeanSuf)*)&M.trash[l];
+      d->tid = tdv[l]; d->pos = tpv[l]; d->qp = (u32)pcur; d->iv = (u32)sn;
+      W.mins[l] = (rec && (u32)cnt < (W.mins[l] >> 8)) ? ((u32)sn | ((u32)cnt << 8)) : W.mins[l];
+      W.cntr[l] += rec ? (1u + ((u32)cnt << 8)) : 0u;
+      if (COV) {
+        const int corr = W.prevEnd[l] > pcur ? W.prevEnd[l] - pcur : 0;
+        W.cov[l] += rec ? mlen - corr : 0;
+        W.prevEnd[l] = rec ? pcur + mlen : W.prevEnd[l];
       }
+      // what follows the hit: the read is through, or the walk goes on at kp with a spot check (:602-611: only behind a recorded interval)
+      const bool through = pcur + mlen >= L;
+      const bool last = (f & QM_DW_LAST) != 0;
+      const bool on = go && !over && !through && !(last && !rec);
+      const int kp = pcur + mlen - (k - 1);                                    // NIP off: lce == matchedLen (:635-647)
+      u32 f2 = f & ~(QM_DW_SPOT | QM_DW_STOP | QM_DW_SKIP);
+      f2 |= (rec ? QM_DW_SPOT : 0u) | (last ? QM_DW_STOP : 0u) | ((kp + k == L) ? QM_DW_LAST : 0u);
+      f2 = on ? f2 : (f & ~(QM_DW_MODE | QM_DW_SKIP));
+      f2 |= (full || over) ? QM_DW_BAIL : 0u;
+      W.fl[l] = ok ? f2 : f;
+      W.p[l] = (ok && on) ? kp : pcur;
     }
   }
   // ---- the other strand's turn (:258 checkRC after the read's own pass, :271 checkFwd after the reverse complement's)?  Such a read is
   // left to the general kernel, like every read that bailed out above.  (:343-358: quasiCoverage)
   const int useCov = B.strict_check != 0 ? 1 : 0;          // disableNIP_ && strictCheck_ (SACollector.hpp:138)
-  LV<int> nsuf, taken;
-  if (B.quasi_cov > 0.0) {
-    QM_LANES(l) { if (W.sn[l] > 0 && Lv[l] > 0) { const double f = (double)W.cov[l] / (double)Lv[l]; if (f < B.quasi_cov) W.sn[l] = 0; } }
-  }
+  LV<int> nsuf, taken, snv;
   QM_LANES(l) {
-    if (W.foundHit[l] && !W.bail[l] && (useCov ? (W.hb[l] > 0) : (W.hb[l] >= W.ha[l]))) W.bail[l] = 1;
-    taken[l] = (defv[l] || W.bail[l]) ? 0 : 1;
-    nsuf[l] = (taken[l] && W.sn[l] > 0) ? W.sufN[l] : 0;
+    const u32 ha = W.hab[l] & 0xffffu, hb = W.hab[l] >> 16;
+    const bool other = (W.fl[l] & QM_DW_FOUND) != 0 && (useCov ? (hb > 0) : (hb >= ha));
+    int sn = (int)(W.cntr[l] & 0xffu);
+    if (COV) { if (sn > 0 && Lv[l] > 0) { const double fr = (double)W.cov[l] / (double)Lv[l]; if (fr < B.quasi_cov) sn = 0; } }
+    taken[l] = ((W.fl[l] & (QM_DW_DEF | QM_DW_BAIL)) != 0 || other) ? 0 : 1;
+    nsuf[l] = (taken[l] && sn > 0) ? (int)(W.cntr[l] >> 8) : 0;
+    snv[l] = sn;
   }
   // ---- hitsToMappingsSimple (HitManager.cpp:691-882) for both mates at once, lane j of a half = suffix j of its stash (lean_h2m): a
   // transcript survives when it was seen in every interval, represented by the entry with the smallest position (the earlier interval
@@ -453,12 +475,12 @@ QM_DEV void duo_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, in
       const int h = l >> 5, j = l & 31, n = nsuf[l];
       const QM_LDS(LeanSuf)* e = (const QM_LDS(LeanSuf)*)&M.suf[h][j < n ? j : 0];
       const u32 t = e->tid, ps = e->pos, qp = e->qp, iv = e->iv;
-      const u32 mi = (u32)W.minIdx[l];
+      const u32 mi = W.mins[l] & 0xffu;
       const u32 ord = iv == mi ? 0u : (iv < mi ? iv + 1u : iv);
       tid[l] = j < n ? t : 0xffffffffu;
       key[l] = j < n ? (((u64)ps << 32) | (u64)(ord * 64u + (u32)j)) : ~0ULL;
       seen[l] = j < n ? (1u << iv) : 0u; lt[l] = 0;
-      elem[l] = mk_elem(t, W.V[l] != 0, (int)(ps - qp));                       // pos - queryPos (:315, :761-767)
+      elem[l] = mk_elem(t, (W.fl[l] & QM_DW_V) != 0, (int)(ps - qp));                       // pos - queryPos (:315, :761-767)
       keepv[l] = j < n ? 1u : 0u;
     }
     if (nmax > 0) {
@@ -483,7 +505,7 @@ QM_DEV void duo_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, in
     }
     LV<bool> kb;
     QM_LANES(l) {
-      const int m = W.sn[l];
+      const int m = snv[l];
       const u32 all = m >= 32 ? 0xffffffffu : ((1u << m) - 1u);
       kb[l] = keepv[l] != 0 && seen[l] == all;
     }
@@ -586,7 +608,7 @@ QM_DEV void duo_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, in
       if (taken[l]) {
         if (fits && keepv[l]) B.lists[bh + slot[l]] = elem[l];
         if (j == 0) {
-          const u32 flag = (B.fuzzy && W.foundHit[l]) ? 0x80000000u : 0u;
+          const u32 flag = (B.fuzzy && (W.fl[l] & QM_DW_FOUND)) ? 0x80000000u : 0u;
           B.lcnt[r0 + h] = (fits ? (u32)(h ? cntB : cntA) : 0u) | flag; B.loff[r0 + h] = fits ? bh : 0;
         }
       } else if (j == 0) { B.lcnt[r0 + h] = QM_LCNT_LEAN; B.loff[r0 + h] = 0; atomic_add_u64(B.cursor + QM_SC_LEANQ, 1ULL); }

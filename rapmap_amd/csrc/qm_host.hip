@@ -745,6 +745,7 @@ struct RunReq {
   // QM_RUN_FROM_INTERVALS: device arrays
   const qm_sa_interval_hit* ivIn = nullptr; const long long* ivInOff = nullptr; const int* lenIn = nullptr; const unsigned char* foundIn = nullptr;
   SplitJoin* join = nullptr; int part = 0;   // one part of a split call (map_device_split): the hits go to the caller's array
+  bool noDuo = false;             // this part takes qm_lean_kernel even where the pair kernel could (map_device_split: parts of both kinds in flight)
 };
 
 static DevIndex dev_index(const qm_ctx* c) {
@@ -823,7 +824,10 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
   // Pairs of such reads take the pair kernel (qm_duo.inl): the two mates walked in lockstep by the two halves of a wavefront, and -- in a
   // plain fused call -- merged there (pair_cnt: stage B's count pass finds the pair done, its write pass expands the records)
   static const bool duoOff = [] { const char* e = getenv("QM_NO_DUO"); return e && atoi(e) != 0; }();
-  const bool useDuo = useLean && !duoOff && paired && ns == 2;
+  // (dense table only: on the compact -p image a position's two orientations are two walks of the BooPHF levels, and a lane per position
+  // serialises them -- 301 M pairs/s against qm_lean_kernel's 323, profiles/r06/exp_mix.txt)
+  static const bool duoPh = [] { const char* e = getenv("QM_DUO_PH"); return e && atoi(e) != 0; }();
+  const bool useDuo = useLean && !duoOff && !rq.noDuo && paired && ns == 2 && (!c->d_ph || duoPh);
   const bool duoMerge = useDuo && !rq.mergeOnly && !rq.stageView;
   if (duoMerge) { if ((rc = ensure(c->d_cnt, c->capCnt, n + 1))) return rc; }
   unsigned* gslots = nullptr; int ngslots = 0;
@@ -1332,6 +1336,11 @@ static int map_device_split(qm_ctx* c, const qm_opts* o, int K, int64_t n, const
   memset(ctr, 0, sizeof(ctr));
   const bool paired = d_seq2 != nullptr;
   static const int firstPct = [] { const char* e = getenv("QM_SPLIT_FIRST"); const int v = e ? atoi(e) : 0; return v > 0 && v < 100 ? v : 0; }();   // (tuning knob: two parts of unequal size)
+  // Which parts take the pair kernel (a bit per part; QM_DUO_PARTS): the others take qm_lean_kernel.  The pair kernel is bound by the
+  // vector units (919 VALU + 470 scalar-side instructions per pair), qm_lean_kernel by the CU's scalar unit (756 + 1 125): with a part
+  // of each kind in flight the two kinds of wavefront share every CU and each loads the unit the other leaves idle -- 492 M pairs/s
+  // against 447 (all parts the pair kernel) and 473 (all parts qm_lean_kernel), profiles/r06/exp_mix.txt
+  static const int duoParts = [] { const char* e = getenv("QM_DUO_PARTS"); return e ? atoi(e) : 0x55; }();   // default: every other part
   c->lastUnits = -1;
   HIPCHK(hipEventRecord(c->evA, c->stream));
   c->pool->run(K, [&](int i) {
@@ -1339,6 +1348,7 @@ static int map_device_split(qm_ctx* c, const qm_opts* o, int K, int64_t n, const
     int64_t u0 = n * i / K, u1 = n * (i + 1) / K;
     if (K == 2 && firstPct > 0) { const int64_t cut = n * firstPct / 100; u0 = i == 0 ? 0 : cut; u1 = i == 0 ? cut : n; }
     RunReq rq; rq.join = &J; rq.part = i;
+    rq.noDuo = ((duoParts >> i) & 1) == 0;
     errs[i][0] = 0;
     int r = map_device_impl(h, o, u1 - u0, d_seq1, (const long long*)d_off1 + u0, d_seq2, d_seq2 ? (const long long*)d_off2 + u0 : nullptr,
                             max_read_len, &nh[i], &ctr[i], nullptr, rq);

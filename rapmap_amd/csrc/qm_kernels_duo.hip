@@ -7,7 +7,7 @@
 
 namespace qm {
 
-template <bool PH>
+template <bool PH, bool COV>
 __global__ __launch_bounds__(256, 8) void qm_duo_kernel(DevIndex ix_, ReadBatch B_) {
   // the argument structs are read through the kernarg segment where they are used (see qm_read_kernel)
   struct Args { DevIndex ix; ReadBatch B; };
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256, 8) void qm_duo_kernel(DevIndex ix_, ReadBatch 
   lds_dma_wait();
   int par = 0;
   for (int it = gw; it < nit; it += nw) {
-    duo_iter<PH>(ix, B, it, nit, nw, par, M, wa, ctr);
+    duo_iter<PH, COV>(ix, B, it, nit, nw, par, M, wa, ctr);
     par ^= 1;
   }
   // the HitCounters of the pairs this wave merged (stage B's count pass adds the others')
@@ -48,11 +48,11 @@ __global__ __launch_bounds__(256, 8) void qm_duo_kernel(DevIndex ix_, ReadBatch 
 
 using namespace qm;
 
-template <bool PH>
+template <bool PH, bool COV>
 static hipError_t launch_duo(const DevIndex& ix, const ReadBatch& B, int num_cu, hipStream_t st) {
   static const int nb = [] {
     int v = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, qm_duo_kernel<PH>, 256, 0) != hipSuccess || v < 1) v = 8;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, qm_duo_kernel<PH, COV>, 256, 0) != hipSuccess || v < 1) v = 8;
     const char* ov = getenv("QM_BLOCKS_PER_CU");
     if (ov && atoi(ov) > 0 && atoi(ov) < v) v = atoi(ov);
     return v;
@@ -63,12 +63,13 @@ static hipError_t launch_duo(const DevIndex& ix, const ReadBatch& B, int num_cu,
   const long long want = (nit + 3) / 4;
   if (g > want) g = want;
   if (g < 1) g = 1;
-  hipLaunchKernelGGL((qm_duo_kernel<PH>), dim3((unsigned)g), dim3(256), 0, st, ix, B);
+  hipLaunchKernelGGL((qm_duo_kernel<PH, COV>), dim3((unsigned)g), dim3(256), 0, st, ix, B);
   return hipGetLastError();
 }
 // paired reads of up to 128 characters, dense table or (ix.ph set) the compact -p image
 extern "C" hipError_t qmk_launch_duo(const void* ixp, const void* bp, int num_cu, hipStream_t st) {
   const DevIndex& ix = *(const DevIndex*)ixp; const ReadBatch& B = *(const ReadBatch*)bp;
   if (!B.seq2 || (B.nreads & 1)) return hipErrorInvalidValue;
-  return ix.ph ? launch_duo<true>(ix, B, num_cu, st) : launch_duo<false>(ix, B, num_cu, st);
+  if (B.quasi_cov > 0.0) return ix.ph ? launch_duo<true, true>(ix, B, num_cu, st) : launch_duo<false, true>(ix, B, num_cu, st);   // (--quasiCoverage: the walks also add up their coverage)
+  return ix.ph ? launch_duo<true, false>(ix, B, num_cu, st) : launch_duo<false, false>(ix, B, num_cu, st);
 }

@@ -231,6 +231,10 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
     u64 scal2[QM_SC_WORDS]; memset(scal2, 0, sizeof(scal2)); int status2 = 0;
     ReadBatch Lb = B; Lb.lcnt = lcnt2.data(); Lb.loff = loff2.data(); Lb.lists = lists2.data(); Lb.lists_cap = cap; Lb.cursor = scal2; Lb.status = &status2;
     Lb.iv_out = nullptr; Lb.iv_cnt = nullptr; Lb.iv_off = nullptr;
+#ifdef QM_PROFILE
+    const unsigned long long prof1 = qm::qm_prof[1], prof3 = qm::qm_prof[3];
+    struct ProfOut { unsigned long long a, b; long long n; ~ProfOut() { fprintf(stderr, "[qm emu prof] lean kernel: %.2f bucket loads, %.2f probe rounds per read\n", (double)(qm::qm_prof[1] - a) / n, (double)(qm::qm_prof[3] - b) / n); } } profOut{prof1, prof3, nreads};
+#endif
     const long long nit = leanWide ? nreads : (nreads + 1) >> 1, NW = 3;
     static LeanMem Ms[3];
     for (long long w = 0; w < NW; ++w) {
@@ -325,6 +329,10 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
       ReadBatch Lb = B; Lb.lcnt = lcnt2.data(); Lb.loff = loff2.data(); Lb.lists = lists2.data(); Lb.lists_cap = cap; Lb.cursor = scal2; Lb.status = &status2;
       Lb.iv_out = nullptr; Lb.iv_cnt = nullptr; Lb.iv_off = nullptr;
       Lb.pair_cnt = pass == 0 ? pcnt.data() : nullptr; Lb.max_num_hits = o->max_num_hits; Lb.no_orphans = o->no_orphans; Lb.no_dovetail = o->no_dovetail;
+#ifdef QM_PROFILE
+      const unsigned long long prof1 = qm::qm_prof[1], prof3 = qm::qm_prof[3];
+      struct ProfOut { unsigned long long a, b; long long n; ~ProfOut() { fprintf(stderr, "[qm emu prof] pair kernel: %.2f bucket loads, %.2f probe rounds per read\n", (double)(qm::qm_prof[1] - a) / n, (double)(qm::qm_prof[3] - b) / n); } } profOut{prof1, prof3, nreads};
+#endif
       const long long nit = nunits, NW = 3;
       static DuoMem Ms[3];
       DuoCtr dc[3];
@@ -335,7 +343,11 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
         dc[w] = DuoCtr{0, 0, 0, 0, 0, 0};
         duo_stage_offsets(Lb, (int)w, (int)nit, M, 0); duo_stage_chars(Lb, (int)w, (int)nit, M, 0); duo_stage_offsets(Lb, (int)(w + NW), (int)nit, M, 1);
         int par = 0;
-        for (long long it = w; it < nit; it += NW) { if (ix.ph) duo_iter<true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl, dc[w]); else duo_iter<false>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl, dc[w]); par ^= 1; }
+        for (long long it = w; it < nit; it += NW) {
+          if (B.quasi_cov > 0.0) { if (ix.ph) duo_iter<true, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl, dc[w]); else duo_iter<false, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl, dc[w]); }
+          else { if (ix.ph) duo_iter<true, false>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl, dc[w]); else duo_iter<false, false>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl, dc[w]); }
+          par ^= 1;
+        }
       }
       PairBatch Pg; memset(&Pg, 0, sizeof(Pg));           // the general kernel's lists through stage B: what a merged pair must equal
       std::vector<u32> hcg(nunits + 1, 0);
