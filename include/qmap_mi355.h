@@ -151,7 +151,10 @@ int qm_ctx_create(const qm_index* ix, int device_id, qm_ctx** out);
  * BooPHF levels walked per lookup, include/BooPHF.hpp:971-1009, + one 16-byte record per k-mer: 1.3 GB for 80 M k-mers).
  * By default a -p index is expanded at load time into the same one-sector bucket table a dense index gets (8.6 GB), after
  * every record has been looked up through the BooPHF walk itself: identical answers, a single HBM round trip per lookup. */
-enum { QM_CTX_PH_COMPACT = 1 };
+/* QM_CTX_NO_PAIR_KERNEL (round 6) -- paired reads of up to 128 characters take qm_lean_kernel alone instead of the pair kernel / a part
+ * of each kind (tests, A/B timing; the answers are the same).  QM_CTX_WIDE_READS -- build the wide extension table (reads of 129 .. 256
+ * characters: 64 bytes per suffix-array entry) with the replica instead of inside the first call that has such reads. */
+enum { QM_CTX_PH_COMPACT = 1, QM_CTX_NO_PAIR_KERNEL = 2, QM_CTX_WIDE_READS = 4 };
 int qm_ctx_create_ex(const qm_index* ix, int device_id, uint32_t flags, qm_ctx** out);
 int qm_ctx_destroy(qm_ctx* ctx);
 int64_t qm_ctx_device_bytes(const qm_ctx* ctx);
@@ -278,7 +281,10 @@ int qm_last_kernel_ms(const qm_ctx* ctx, double* map_kernel_ms, double* total_ms
 enum { QM_STAT_RELAUNCHES = 0, QM_STAT_LIST_WORDS = 1, QM_STAT_SLOW_READS = 2, QM_STAT_LEAN_READS = 3, QM_STAT_LEAN_DEFERRED = 4, QM_STAT_SKIPPED_READS = 5,
        QM_STAT_SEL_QUESTIONS = 6,    /* -s: alignments the reference would look at beyond PERFECT chains (one per hit and mate) ... */
        QM_STAT_KSW2_ALIGNMENTS = 7,  /* ... the ksw2 alignments the device ran for them (the others: alignment-cache hits, ungapped chains, answers known without ksw2) */
-       QM_STAT_STRIP_ALIGNMENTS = 8 };/* ... and the alignments answered by the exact strip DP instead (gapless path within q + 7 e of the best possible) */
+       QM_STAT_STRIP_ALIGNMENTS = 8, /* ... and the alignments answered by the exact strip DP instead (gapless path within q + 7 e of the best possible) */
+       QM_STAT_PAIR_KERNEL_PAIRS = 9, /* pairs the pair kernel (both mates in one wavefront, merged there) was launched over; -1: not used.  An unsplit call only
+                                         (a call mapped in parts reports QM_STAT_LEAN_READS / _DEFERRED summed over its parts and -1 here) */
+       QM_STAT_PAIRS_MERGED = 10 };  /* ... of which it merged itself (the others had a mate left to the general kernel, or the call kept lists) */
 int qm_ctx_stat(const qm_ctx* ctx, int which, int64_t* value);
 
 /* Reads of the last map call on ctx that were SKIPPED, not mapped (round 5; before, one such read failed the whole batch): a read

@@ -276,7 +276,7 @@ class QuasiMapper:
     """One GPU context: the index replicated in HBM + work buffers.  `map_pairs` performs, for every
     pair, SACollector() x2 -> hitsToMappingsSimple() x2 -> mergeLeftRightHits() on one wavefront."""
 
-    def __init__(self, index: QuasiIndex, device=0, debug=False, reuse_results=False, ph_compact=False):
+    def __init__(self, index: QuasiIndex, device=0, debug=False, reuse_results=False, ph_compact=False, pair_kernel=True, wide_reads=False):
         """reuse_results: hit arrays of successive calls share one buffer (views valid until the next call) instead of
         a fresh allocation per batch, whose pages would have to be faulted in again every time -- for streaming callers
         that are done with a batch before they map the next (the CLI)"""
@@ -286,7 +286,8 @@ class QuasiMapper:
         self.index = index
         self._h = C.c_void_p()
         # ph_compact: a -p index keeps the BooPHF / FrugalBooMap structure on the device instead of the expanded bucket table
-        _check(lib().qm_ctx_create_ex(index._h, device, 1 if ph_compact else 0, C.byref(self._h)))
+        # pair_kernel=False: QM_CTX_NO_PAIR_KERNEL (paired reads of up to 128 characters take qm_lean_kernel alone); wide_reads: QM_CTX_WIDE_READS
+        _check(lib().qm_ctx_create_ex(index._h, device, (1 if ph_compact else 0) | (0 if pair_kernel else 2) | (4 if wide_reads else 0), C.byref(self._h)))
         if debug:
             _check(lib().qm_ctx_set_debug(self._h, 1))
         self.device = device
@@ -362,7 +363,8 @@ class QuasiMapper:
     def stat(self, which):
         """qm_ctx_stat: 0 stage-A relaunches of the last call, 1 list buffer capacity (words), 2 reads on the -s slow path,
         3 reads the lean stage-A kernel was launched over (-1: the general kernel ran), 4 reads it left to the general kernel,
-        5 reads that were skipped (qm_fetch_skipped), 6 / 7 / 8 (-s) alignment questions beyond PERFECT chains / ksw2 alignments run for them / alignments the strip DP answered"""
+        5 reads that were skipped (qm_fetch_skipped), 6 / 7 / 8 (-s) alignment questions beyond PERFECT chains / ksw2 alignments run for them / alignments the strip DP answered,
+        9 pairs the pair kernel was launched over (-1: not used), 10 pairs it merged itself"""
         v = C.c_int64()
         _check(lib().qm_ctx_stat(self._h, int(which), C.byref(v)))
         return v.value

@@ -159,6 +159,7 @@ struct qm_ctx {
   int64_t lastUnits = -1, lastHits = 0; bool lastPaired = false;
   double lastMapMs = 0, lastTotalMs = 0;
   int64_t lastSelQuestions = 0, lastKswTasks = 0, lastStripTasks = 0;             // -s: alignment questions beyond PERFECT chains of the last call, ksw2 alignments run for them
+  int64_t lastDuoPairs = -1, lastDuoMerged = 0;   // pairs the pair kernel was launched over (-1: not used), pairs it merged itself
   int64_t lastRelaunches = 0, lastSlowReads = 0, lastLeanReads = -1, lastLeanDeferred = 0;   // lastLeanReads: reads the lean kernel was launched over (-1: not used)
   // qm_map_device on a large batch: its parts on helper contexts of the same replica, in flight together (map_device_split)
   uint32_t flags = 0; bool isHelper = false;
@@ -538,6 +539,7 @@ int qm_ctx_destroy(qm_ctx* c) {
 
 int qm_ctx_create(const qm_index* ix, int device_id, qm_ctx** out) { return qm_ctx_create_ex(ix, device_id, 0, out); }
 
+static bool ensure_saext2(qm_ctx* c);
 int qm_ctx_create_ex(const qm_index* ix, int device_id, uint32_t flags, qm_ctx** out) {
   if (!ix || !out) return fail(QM_E_ARG, "null argument");
   const bool phCompact = ix->perfect && (flags & QM_CTX_PH_COMPACT);
@@ -580,9 +582,12 @@ int qm_ctx_create_ex(const qm_index* ix, int device_id, uint32_t flags, qm_ctx**
       c->d_txpOff = R.d_txpOff; c->d_txpLen = R.d_txpLen; c->devBytes = R.devBytes;
       { std::lock_guard<std::mutex> l2(R.sanextMu); c->d_sanext = R.d_sanext; }
       c->d_saext = R.d_saext;
-      *out = c;
-      return QM_OK;
     }
+  }
+  if (c->rep) {
+    if (flags & QM_CTX_WIDE_READS) (void)ensure_saext2(c);   // (a replica without room for it goes on with the general kernels)
+    *out = c;
+    return QM_OK;
   }
   const size_t pad = 256;
   CK(hipMalloc((void**)&c->d_text, (size_t)ix->n + pad));
@@ -709,6 +714,9 @@ int qm_ctx_create_ex(const qm_index* ix, int device_id, uint32_t flags, qm_ctx**
     c->rep = R;
     g_reps[std::make_pair(ix, repKey)] = R;
   }
+  // the wide extension table with the replica when the caller knows reads of 129 .. 256 characters are coming: otherwise the first call
+  // that has such reads builds it (0.2 s for config 2) inside that call
+  if (flags & QM_CTX_WIDE_READS) (void)ensure_saext2(c);
   *out = c;
   return QM_OK;
 }
@@ -776,7 +784,12 @@ static bool ensure_saext2(qm_ctx* c) {
   if (!R.d_saext2 && !R.saext2Tried) {
     R.saext2Tried = true;
     void* p = nullptr;
-    if (hipMalloc(&p, (size_t)c->ix->nSA * qmk_saext2_bytes()) != hipSuccess) { (void)hipGetLastError(); return false; }
+    // room for the table AND a margin for the work buffers of the replica's contexts (lists, hits, scratch: they grow with the batches);
+    // a replica that cannot spare it stays with the general kernels for such reads
+    size_t freeB = 0, totalB = 0;
+    const size_t need = (size_t)c->ix->nSA * qmk_saext2_bytes(), margin = (size_t)8 << 30;
+    if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || freeB < need + margin) { (void)hipGetLastError(); return false; }
+    if (hipMalloc(&p, need) != hipSuccess) { (void)hipGetLastError(); return false; }
     hipError_t e = qmk_build_saext2(c->d_text, c->ix->n, c->d_SA, c->ix->nSA, c->ix->k, c->d_sainfo, p, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { hipFree(p); (void)hipGetLastError(); return false; }
@@ -827,7 +840,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
   // (dense table only: on the compact -p image a position's two orientations are two walks of the BooPHF levels, and a lane per position
   // serialises them -- 301 M pairs/s against qm_lean_kernel's 323, profiles/r06/exp_mix.txt)
   static const bool duoPh = [] { const char* e = getenv("QM_DUO_PH"); return e && atoi(e) != 0; }();
-  const bool useDuo = useLean && !duoOff && !rq.noDuo && paired && ns == 2 && (!c->d_ph || duoPh);
+  const bool useDuo = useLean && !duoOff && !rq.noDuo && !(c->flags & QM_CTX_NO_PAIR_KERNEL) && paired && ns == 2 && (!c->d_ph || duoPh);
   const bool duoMerge = useDuo && !rq.mergeOnly && !rq.stageView;
   if (duoMerge) { if ((rc = ensure(c->d_cnt, c->capCnt, n + 1))) return rc; }
   unsigned* gslots = nullptr; int ngslots = 0;
@@ -874,6 +887,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
   }
   const DevIndex ix = dev_index(c);
   c->lastRelaunches = 0; c->lastSlowReads = 0; c->lastIvTotal = 0; c->lastLeanReads = useLean ? nreads : -1; c->lastLeanDeferred = 0;
+  c->lastDuoPairs = useDuo ? n : -1; c->lastDuoMerged = 0;
   float leanExtraMs = 0;
   while (true) {
     ReadBatch B; memset(&B, 0, sizeof(B));
@@ -995,6 +1009,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
     HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     int status = (int)(hscal[QM_SC_STATUS] & 0xffffffffu);
+    if (duoMerge) c->lastDuoMerged = (int64_t)hscal[4];        // (numReads so far: the pairs the pair kernel merged; stage B's count pass adds the others)
     if (useLean && hscal[QM_SC_LEANQ] > 0 && !(status & 23)) {
       // what the lean kernel marked instead of mapping (a character that is not A C G T, a long run of one base, a read beyond 128
       // characters, a wide interval, hits on both strands ...): gathered into a queue and mapped by the general kernel; everything it
@@ -1374,11 +1389,14 @@ static int map_device_split(qm_ctx* c, const qm_opts* o, int K, int64_t n, const
   c->lastMapMs = last > first ? last - first : 0;
   float ms = 0; hipEventElapsedTime(&ms, c->evA, c->evB); c->lastTotalMs = ms;
   c->lastRelaunches = 0; c->lastSlowReads = 0; c->lastSkipped = 0; c->skipList.clear(); c->lastSelQuestions = 0; c->lastKswTasks = 0; c->lastStripTasks = 0;
+  c->lastDuoPairs = -1; c->lastDuoMerged = 0; c->lastLeanReads = -1; c->lastLeanDeferred = 0;
   qm_counters sum; memset(&sum, 0, sizeof(sum));
   for (int i = 0; i < K; ++i) {
     sum.pe_hits += ctr[i].pe_hits; sum.se_hits += ctr[i].se_hits; sum.tot_hits += ctr[i].tot_hits; sum.num_reads += ctr[i].num_reads;
     sum.too_many_hits += ctr[i].too_many_hits; sum.mapped += ctr[i].mapped;
     qm_ctx* h = c->helpers[(size_t)i];
+    if (h->lastLeanReads >= 0) { c->lastLeanReads = (c->lastLeanReads < 0 ? 0 : c->lastLeanReads) + h->lastLeanReads; c->lastLeanDeferred += h->lastLeanDeferred; }
+    if (h->lastDuoPairs >= 0) { c->lastDuoMerged += h->lastDuoMerged; }
     c->lastRelaunches += h->lastRelaunches; c->lastSlowReads += h->lastSlowReads; c->lastSelQuestions += h->lastSelQuestions; c->lastKswTasks += h->lastKswTasks; c->lastStripTasks += h->lastStripTasks;
     // the part's skipped reads, as reads of the whole batch
     int64_t u0 = n * i / K;
@@ -1865,6 +1883,8 @@ int qm_ctx_stat(const qm_ctx* c, int which, int64_t* value) {
     case QM_STAT_SEL_QUESTIONS: *value = c->lastSelQuestions; break;
     case QM_STAT_KSW2_ALIGNMENTS: *value = c->lastKswTasks; break;
     case QM_STAT_STRIP_ALIGNMENTS: *value = c->lastStripTasks; break;
+    case QM_STAT_PAIR_KERNEL_PAIRS: *value = c->lastDuoPairs; break;
+    case QM_STAT_PAIRS_MERGED: *value = c->lastDuoMerged; break;
     default: return fail(QM_E_ARG, "unknown statistic %d", which);
   }
   return QM_OK;

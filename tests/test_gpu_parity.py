@@ -29,10 +29,34 @@ VARIANTS = {
 }
 
 
-def _gpu(idx, debug=True, ph_compact=False):
+def _gpu(idx, debug=True, ph_compact=False, pair_kernel=True):
+    """debug=True keeps the SA-interval records of a fused call (qm_fetch_intervals) -- and so runs the GENERAL stage-A kernel; the kernels the
+    headline is quoted on (the pair kernel, qm_lean_kernel) only run with debug=False: _headline() below"""
     import rapmap_amd as ra
     qi = ra.QuasiIndex(idx)
-    return qi, ra.QuasiMapper(qi, 0, debug=debug, ph_compact=ph_compact)
+    return qi, ra.QuasiMapper(qi, 0, debug=debug, ph_compact=ph_compact, pair_kernel=pair_kernel)
+
+
+HEADLINE_KERNELS = ["pair", "lean"]
+
+
+def _headline(idx, kernel, ph_compact=False):
+    """a mapper whose paired calls run the pair kernel (qm_duo.inl) or qm_lean_kernel alone (QM_CTX_NO_PAIR_KERNEL)"""
+    return _gpu(idx, debug=False, ph_compact=ph_compact, pair_kernel=kernel == "pair")
+
+
+def _check_headline(mp, kernel, n_pairs, expect_deferred=True, fuzzy=False, some_merged=True):
+    """the call just made went through the kernel it was meant for, and that kernel decided to leave some reads to the general one"""
+    assert mp.stat(3) == 2 * n_pairs, "the lean / pair kernel did not run"
+    deferred = mp.stat(4)
+    assert (0 < deferred < 2 * n_pairs) if expect_deferred else deferred >= 0, deferred
+    if kernel == "pair":
+        assert mp.stat(9) == n_pairs
+        merged = mp.stat(10)
+        assert merged == 0 if fuzzy else (1 if some_merged else 0) <= merged <= n_pairs - (deferred + 1) // 2, (merged, deferred)
+    else:
+        assert mp.stat(9) == -1
+    return deferred
 
 
 def _cmp_ints(res, offs, ints):
@@ -81,6 +105,67 @@ def test_synth_small(synth_small, oracle_mod, variant):
     assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, variant)
     assert res.counters == gr.counters
     _cmp_ints(res, *mp.intervals(len(o1) - 1))
+
+
+@pytest.mark.parametrize("kernel", HEADLINE_KERNELS)
+@pytest.mark.parametrize("variant", [v for v in sorted(VARIANTS) if "noSensitive" not in v])
+def test_synth_small_through_the_headline_kernels(synth_small, oracle_mod, variant, kernel):
+    """the adversarial golden reads (N's, lower case, IUPAC, reads shorter than k, reads across a `$`, repeat families, indels, ragged
+    lengths) through the kernels the headline is quoted on: what they take must be right, and they must LEAVE the reads they are not
+    built for (with debug=True these reads only ever met the general kernel)"""
+    import rapmap_amd as ra
+    ix, orc = load_oracle(synth_small["idx"])
+    qi, mp = _headline(synth_small["idx"], kernel)
+    q1, o1 = pack(synth_small["reads1"]); q2, o2 = pack(synth_small["reads2"])
+    oo, go = VARIANTS[variant]
+    res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=4)
+    gr = mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(**go))
+    assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "%s through the %s kernel" % (variant, kernel))
+    assert res.counters == gr.counters
+    deferred = _check_headline(mp, kernel, len(o1) - 1, fuzzy="fuzzy" in variant)
+    if variant == "default":
+        assert deferred == 519, deferred          # (what the lane emulation of both kernels leaves on this set: tests/emu, QM_EMU_LEAN_STATS)
+
+
+@pytest.mark.parametrize("kernel", HEADLINE_KERNELS)
+def test_sample_data_through_the_headline_kernels(sample_data, oracle_mod, kernel):
+    import samfmt as sam
+    ix, orc = load_oracle(sample_data["idx"])
+    qi, mp = _headline(sample_data["idx"], kernel)
+    q1, o1 = pack(sample_data["reads1"]); q2, o2 = pack(sample_data["reads2"])
+    res = orc.map_pairs(q1, o1, q2, o2, nthreads=2)
+    gr = mp.map_pairs(q1, o1, q2, o2)
+    assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "sample_data through the %s kernel" % kernel)
+    assert res.counters == gr.counters
+    _check_headline(mp, kernel, len(o1) - 1, expect_deferred=False)
+    body = "".join(sam.format_pair(sample_data["names1"][i], sample_data["reads1"][i], sample_data["names2"][i],
+                                   sample_data["reads2"][i], gr.hits[gr.hit_offsets[i]:gr.hit_offsets[i + 1]],
+                                   qi.txp_names, qi.txp_lens) for i in range(len(o1) - 1))
+    text = "".join(l for l in (sam.sam_header(qi.txp_names, qi.txp_lens) + body).splitlines(True) if not l.startswith("@PG"))
+    want = open(os.path.join(GOLD, "sample_data", "expected_sam_body.md5")).read().strip()
+    assert hashlib.md5(text.encode()).hexdigest() == want
+
+
+@pytest.mark.parametrize("kernel", HEADLINE_KERNELS)
+def test_dollar_repeats_and_runs_through_the_headline_kernels(synth_small, repeat_data, runs_data, oracle_mod, kernel):
+    """reads across a `$`, the > 200-hit and > 1000-interval repeat families (intervals wider than a wavefront, more suffixes than its lanes,
+    hits on both strands, tooManyHits) and windows of k equal bases: every one of them a read these kernels must recognise and leave"""
+    import rapmap_amd as ra
+    from test_emu_parity import _dollar_reads
+    r1, r2 = _dollar_reads(synth_small)
+    sets = [("dollar", synth_small["idx"], r1, r2), ("repeats", repeat_data["idx"], repeat_data["reads1"], repeat_data["reads2"]),
+            ("runs", runs_data["idx"], runs_data["reads1"], runs_data["reads2"])]
+    for name, idx, a, b in sets:
+        ix, orc = load_oracle(idx)
+        qi, mp = _headline(idx, kernel)
+        q1, o1 = pack(a); q2, o2 = pack(b)
+        for oo, go in (({}, {}), ({"fuzzy": 1}, {"fuzzy": 1}), ({"maxNumHits": 5, "noDovetail": 1}, {"max_num_hits": 5, "no_dovetail": 1})):
+            res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=4)
+            gr = mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(**go))
+            assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "%s %s through the %s kernel" % (name, oo, kernel))
+            assert res.counters == gr.counters
+            _check_headline(mp, kernel, len(o1) - 1, expect_deferred=name != "dollar", fuzzy="fuzzy" in oo, some_merged=False)
+        mp.close(); qi.close()
 
 
 def test_dollar_in_reads(synth_small, oracle_mod):
