@@ -27,16 +27,18 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
+if "--build-only" not in sys.argv:      # (BackgroundBuilds' children build an index and exit: no torch)
+    import torch  # noqa: E402
+    import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 # the kernels a configuration launches for stage A (template arguments: 64-character slots, waves per SIMD the launch is
 # sized for, feature flags QM_F_PH = 1, QM_F_NIP = 2, QM_F_SEL = 4, QM_F_COLLECT = 8)
 KERNELS = {
-    "dense": "qm_lean_kernel<paired, plain, dense> (stage A: two reads per wavefront and iteration, canonical bucket table; the reads it "
-             "leaves -- none on this input -- go through qm_read_kernel<2,8,0>)",
+    "dense": "qm_duo_kernel<dense> + qm_lean_kernel<paired, plain, dense>, one part of the batch each, in flight together (stage A: the two mates of a pair in "
+             "one wavefront -- in lockstep in its two halves and merged there / one after the other --, canonical bucket table; the reads they leave "
+             "go through qm_read_kernel<2,8,0>)",
     "ph_compact": "qm_lean_kernel<paired, plain, -p> (stage A: two reads per wavefront and iteration, pre-filter + BooPHF levels walked per lookup)",
     "ph_expanded": "qm_lean_kernel<paired, plain, dense> (the -p index expanded into the canonical bucket table at load)",
     "sel": "qm_lean_kernel<paired, -s, dense> (chain-scoring collector) + qm_h2m_pack_kernel (intervals -> position lists, chaining; several reads per "
@@ -53,18 +55,18 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def build_or_reuse_index(genes, seed, k, rank, world, cache_root, perfect_hash=False):
+def build_or_reuse_index(genes, seed, k, rank, world, cache_root, perfect_hash=False, paralogs=0.0, repeat_family=0, wait_only=False):
     """rank 0 builds the synthetic transcriptome + quasi-index once per box; everybody mmaps it."""
     import rapmap_amd as ra
     from rapmap_amd import synth
-    tag = "g%d_s%d_k%d%s" % (genes, seed, k, "_ph" if perfect_hash else "")
+    tag = "g%d_s%d_k%d%s%s" % (genes, seed, k, "_ph" if perfect_hash else "", ("_par%g_rep%d" % (paralogs, repeat_family)) if (paralogs or repeat_family) else "")
     d = os.path.join(cache_root, "qmap_bench_" + tag)
     idx = os.path.join(d, "idx")
     done = os.path.join(d, "DONE")
-    if rank == 0 and not os.path.exists(done):
+    if rank == 0 and not os.path.exists(done) and not wait_only:
         os.makedirs(d, exist_ok=True)
         t = time.time()
-        names, txps = synth.make_transcriptome(genes, seed=seed)
+        names, txps = synth.make_transcriptome(genes, seed=seed, paralog_frac=paralogs, repeat_family=repeat_family)
         fa = os.path.join(d, "txome.fa")
         synth.write_fasta(fa, names, txps)
         log("transcriptome: %d transcripts, %d bases (%.1fs)" % (len(txps), sum(x.size for x in txps), time.time() - t))
@@ -72,7 +74,7 @@ def build_or_reuse_index(genes, seed, k, rank, world, cache_root, perfect_hash=F
         t = time.time()
         ra.build_index(fa, idx, k=k, threads=min(32, os.cpu_count() or 1), perfect_hash=perfect_hash)
         os.remove(fa)
-        log("quasiindex%s built in %.1fs" % (" -p" if perfect_hash else "", time.time() - t))
+        log("quasiindex%s%s built in %.1fs" % (" -p" if perfect_hash else "", " (paralogs %g, repeat family %d)" % (paralogs, repeat_family) if (paralogs or repeat_family) else "", time.time() - t))
         open(done, "w").write("ok\n")
     # the other ranks wait for the DONE file, not in a collective: a rank that finds the index there starts at once (no rank
     # ever sits in a RCCL barrier for the length of an index build), and the replicas of all ranks upload side by side
@@ -84,6 +86,60 @@ def build_or_reuse_index(genes, seed, k, rank, world, cache_root, perfect_hash=F
     return idx
 
 
+class BackgroundBuilds:
+    """the index builds the later legs need (the -p index of configs[3], the paralog index of the input variants), started as ONE child
+    process when the run begins -- they are CPU work that used to sit between the legs (2 x 35 s of a 200 s run) -- and STOPPED
+    (SIGSTOP / SIGCONT of that child: its builder threads with it) around every timed region, so that no timed step shares the
+    host with them"""
+
+    def __init__(self, specs, args):
+        import subprocess
+        self.ps = {}
+        for spec in specs:           # one child per index: they run side by side with this process's own build of the headline's index
+            cmd = [sys.executable, os.path.abspath(__file__), "--build-only", spec, "--genes", str(args.genes), "--cache", args.cache]
+            self.ps[spec] = subprocess.Popen(cmd, stdout=subprocess.DEVNULL)
+
+    def ok(self, spec):
+        p = self.ps.get(spec)
+        return p is not None and (p.poll() is None or p.returncode == 0)
+
+    def quiet(self):
+        import contextlib
+        import signal
+
+        @contextlib.contextmanager
+        def cm():
+            stopped = []
+            for p in self.ps.values():
+                if p.poll() is None:
+                    try:
+                        os.kill(p.pid, signal.SIGSTOP); stopped.append(p)
+                    except OSError:
+                        pass
+            try:
+                yield
+            finally:
+                for p in stopped:
+                    try:
+                        os.kill(p.pid, signal.SIGCONT)
+                    except OSError:
+                        pass
+        return cm()
+
+    def close(self):
+        for p in self.ps.values():
+            if p.poll() is None:
+                p.wait()
+
+
+def spec_args(spec):
+    """'ph' | 'par<frac>,<family>' -> keyword arguments of build_or_reuse_index"""
+    if spec == "ph":
+        return dict(perfect_hash=True)
+    a, b = spec[3:].split(",")
+    return dict(paralogs=float(a), repeat_family=int(b))
+
+
 def load_text_to_gpu(qi, device):
     """transcript starts / lengths and the concatenated text (rmi.seq) for the read generator"""
     text, offsets = qi.arrays()
@@ -91,7 +147,7 @@ def load_text_to_gpu(qi, device):
     return torch.from_numpy(text).to(device), torch.from_numpy(offsets).to(device), lens.to(device)
 
 
-def make_reads_gpu(text, starts, lens, n_pairs, seed, device, read_len=100, err=0.01, chunk=1 << 20):
+def make_reads_gpu(text, starts, lens, n_pairs, seed, device, read_len=100, err=0.01, n_rate=0.0, chunk=1 << 20):
     """SURVEY.md section 8d generator, on the GPU: fragments N(250,25) clipped to [L,400] from transcripts of
     length >= 400, mate1 = first L bases, mate2 = reverse complement of the last L, mates swapped w.p. 0.5,
     i.i.d. substitutions."""
@@ -125,6 +181,8 @@ def make_reads_gpu(text, starts, lens, n_pairs, seed, device, read_len=100, err=
             shift = torch.randint(1, 4, r.shape, generator=g, device=device)
             sub = bases[(code[r.long()] + shift) % 4]
             r[msk] = sub[msk]
+            if n_rate > 0:                                   # ("also run 0 % and 0.1 % N's")
+                r[torch.rand(r.shape, generator=g, device=device) < n_rate] = ord("N")
         sw = torch.rand(m, generator=g, device=device) < 0.5
         s1[b * L:e * L] = torch.where(sw[:, None], bb, a).reshape(-1)
         s2[b * L:e * L] = torch.where(sw[:, None], a, bb).reshape(-1)
@@ -436,6 +494,13 @@ def main():
     ap.add_argument("--perfect-hash", action="store_true", help="config 4: index built with `quasiindex -p` (BooPHF / FrugalBooMap probe path)")
     ap.add_argument("--ph-compact", action="store_true", help="with --perfect-hash: keep the BooPHF / FrugalBooMap structure on the device "
                     "(walked per lookup) instead of expanding the -p index into the one-sector bucket table at load time")
+    ap.add_argument("--err", type=float, default=0.01, help="substitution rate of the simulated reads (SURVEY.md 8d: 1 %%; the input_variants legs also run 0)")
+    ap.add_argument("--n-rate", type=float, default=0.0, help="share of the read characters replaced by N (the input_variants legs run 0.1 %%)")
+    ap.add_argument("--paralogs", type=float, default=0.0, help="that share of the transcripts again as paralogs with 4 %% substitutions (the input_variants legs run 5 %%)")
+    ap.add_argument("--repeat-family", type=int, default=0, help="one family of that many transcripts around a shared 300-base core (the input_variants legs: 100)")
+    ap.add_argument("--no-input-variants", action="store_true", help="N=1: skip the bounded legs on other input distributions (0 %% errors; N's; paralogs + a repeat family)")
+    ap.add_argument("--variant-pairs", type=int, default=4_000_000, help="pairs per input_variants leg (parity on the first 2 M of them)")
+    ap.add_argument("--build-only", default=None, help=argparse.SUPPRESS)      # (BackgroundBuilds' child: build these indices and exit)
     ap.add_argument("--read-len", type=int, default=100, help="read length (BASELINE.json: 100; 129..256 runs the NS=4 kernels)")
     ap.add_argument("--cache", default=os.environ.get("QMAP_BENCH_CACHE", "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"))
     ap.add_argument("--e2e-dir", default=os.environ.get("QMAP_BENCH_E2E_DIR", "/tmp"), help="where the end_to_end leg puts its FASTQ files")
@@ -444,6 +509,12 @@ def main():
     ap.add_argument("--e2e-copies", type=int, default=4, help="the end_to_end leg's FASTQ files hold the batch this many times (4 x 10 M = 40 M pairs)")
     ap.add_argument("--compat-pairs", type=int, default=8_000_000, help="pairs of the batch the compat_face leg runs through the reference's call surface")
     args = ap.parse_args()
+
+    if args.build_only:
+        os.nice(5)
+        for spec in args.build_only.split(";"):
+            build_or_reuse_index(args.genes, 42, 31, 0, 1, args.cache, **spec_args(spec))
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started as a plain `python bench.py --gpus N`: become the launcher the driver would have used -- one rank per GPU
@@ -487,7 +558,16 @@ def main():
     from rapmap_amd import dist as qd
 
     k, L = 31, args.read_len
-    idx_dir = build_or_reuse_index(args.genes, 42, k, rank, world, args.cache, args.perfect_hash)
+    plain_head = not args.perfect_hash and not args.sel_aln and L == 100 and not args.paralogs and not args.repeat_family
+    bg_specs = []
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and plain_head:
+        if not args.no_other_configs:
+            bg_specs.append("ph")
+        if not args.no_input_variants:
+            bg_specs.append("par0.05,100")
+    bg = BackgroundBuilds(bg_specs, args)
+    args._bg = bg
+    idx_dir = build_or_reuse_index(args.genes, 42, k, rank, world, args.cache, args.perfect_hash, paralogs=args.paralogs, repeat_family=args.repeat_family)
     args._idx_dir = idx_dir
     t = time.time()
     qi = ra.QuasiIndex(idx_dir)
@@ -496,8 +576,7 @@ def main():
         log("index in HBM: %d transcripts, %d text bytes, %d k-mers, %.2f GB on device (%.1fs)" % (
             qi.n_txps, qi.text_len, qi.n_keys, mp.device_bytes / 1e9, time.time() - t))
     text, starts, lens = load_text_to_gpu(qi, device)
-    s1, s2, off = make_reads_gpu(text, starts, lens, args.pairs, 43 + rank, device, read_len=L)
-    del text
+    s1, s2, off = make_reads_gpu(text, starts, lens, args.pairs, 43 + rank, device, read_len=L, err=args.err, n_rate=args.n_rate)
     torch.cuda.synchronize()
     n = args.pairs
     opts = ra.default_opts(sel_aln=1) if args.sel_aln else ra.default_opts()
@@ -505,7 +584,9 @@ def main():
     ptr = (s1.data_ptr(), off.data_ptr(), s2.data_ptr(), off.data_ptr())
     head_key = "sel" if args.sel_aln else (("ph_compact" if args.ph_compact else "ph_expanded") if args.perfect_hash else "dense")
 
-    el, kernel_ms, tot = timed_steps(mp, opts, ptr, n, L, args.steps, args.warmup, world, device, qd)
+    with bg.quiet():
+        el, kernel_ms, tot = timed_steps(mp, opts, ptr, n, L, args.steps, args.warmup, world, device, qd)
+    head_stats = kernel_stats(mp, n)
     total_pairs = n * world * args.steps
     value = total_pairs / el / 1e6
 
@@ -527,6 +608,8 @@ def main():
         }
         avg_kernel_ms = float(np.mean(kernel_ms))
         out["config"]["map_kernel_ms"] = round(avg_kernel_ms, 3)
+        out["config"]["reads"] = {"substitution_rate": args.err, "n_rate": args.n_rate, "paralog_share": args.paralogs, "repeat_family": args.repeat_family}
+        out["stage_a_kernels"] = head_stats
         out["collective"] = ({"backend": dist.get_backend(), "world_size": dist.get_world_size(), "op": "all_reduce(SUM) of the six HitCounters, 48 bytes",
                               "calls": args.steps + args.warmup, "sum_equals_rank_sums": bool(tot["numReads"] == n * world)}
                              if grouped else None)
@@ -538,7 +621,8 @@ def main():
         orc = oracles.get(idx_dir)
         cores = os.cpu_count() or 1
         oopts = oracle.default_opts(**oopts_kw)
-        cp = cpu_and_parity(orc, mp, opts, oopts, s1, s2, off, ptr, n, L, args.cpu_seconds)
+        with bg.quiet():
+            cp = cpu_and_parity(orc, mp, opts, oopts, s1, s2, off, ptr, n, L, args.cpu_seconds)
         sample, best_t, cpu_val = cp["sample"], cp["best_t"], cp["cpu_val"]
         bpp, w = algorithmic_bytes_per_pair(cp["work"], sample, L)
         ph_levels = None
@@ -584,7 +668,8 @@ def main():
         # ---- what a caller sees beyond the in-HBM figure (last bullet); never `value`
         if not args.no_side_legs:
             try:
-                side_legs(out, args, ra, qi, mp, opts, s1, s2, off, n, L, dev_id, cores)
+                with bg.quiet():
+                    side_legs(out, args, ra, qi, mp, opts, s1, s2, off, n, L, dev_id, cores)
             except Exception as ex:           # side measurements: they must not take the bench line down
                 out.setdefault("end_to_end", None); out.setdefault("pcie_inclusive", None)
                 log("side measurements failed: %r" % (ex,))
@@ -597,6 +682,15 @@ def main():
             except Exception as ex:
                 out["other_configs"]["error"] = repr(ex)
                 log("other_configs failed: %r" % (ex,))
+        # ---- other input distributions ("also run 0 % and 0.1 % N's"; paralogs): the stage-A kernels of the headline LEAVE every read they
+        # are not built for to the general kernel, so how fast a batch maps depends on what is in it -- bounded legs, each with parity and its share of left reads
+        if not args.no_input_variants and plain_head:
+            try:
+                out["input_variants"] = input_variant_legs(args, ra, qd, oracles, oracle, qi, idx_dir, mp, text, starts, lens, n, L, dev_id, device, k, value, bg)
+            except Exception as ex:
+                out["input_variants"] = {"error": repr(ex)}
+                log("input_variants failed: %r" % (ex,))
+        bg.close()
     elif rank == 0:
         # N>1 (or --no-cpu-baseline): no oracle leg.  The roofline of rank 0's kernel still uses the algorithmic bytes
         # per pair of this workload: recorded by an N=1 run on this box, else the committed figure of the default workload.
@@ -622,6 +716,79 @@ def main():
     if grouped:
         dist.barrier()
         dist.destroy_process_group()
+
+
+DEFER_WHY = ["a character that is not A C G T (an N ...) or more than 128 characters", "a window of k equal bases",
+             "an SA interval wider than the kernel's lanes / more suffixes or intervals than its stash / a match beyond its extension table",
+             "k-mers of the other orientation on the way: the reference maps the other strand as well"]
+
+
+def kernel_stats(mp, n):
+    """qm_ctx_stat of the call just made: which stage-A kernels it went through and what they left to the general kernel"""
+    try:
+        lean_reads, deferred = mp.stat(3), mp.stat(4)
+        why = [mp.stat(11 + i) for i in range(4)]
+        d = {"reads_through_the_pair_or_lean_kernel": lean_reads, "reads_left_to_the_general_kernel": deferred,
+             "lean_deferred_frac": round(deferred / float(lean_reads), 6) if lean_reads > 0 else None,
+             "pairs_merged_in_the_wavefront": mp.stat(10),
+             "left_because": {DEFER_WHY[i]: why[i] for i in range(4) if why[i]},
+             "what": "a batch of 2 M pairs and more is mapped as two parts in flight: one on the pair kernel (qm_duo_kernel: both mates of a pair walked in "
+                     "lockstep by the two halves of a wavefront, the pair merged there), one on qm_lean_kernel (two mates per wavefront, one after the "
+                     "other) -- vector-bound and scalar-bound wavefronts sharing every CU; a read neither is built for is marked and mapped by "
+                     "qm_read_kernel<2,8,0> in a second, small launch inside map_kernel_ms"}
+        return d
+    except Exception as ex:  # noqa: BLE001
+        return {"error": repr(ex)}
+
+
+def input_variant_legs(args, ra, qd, oracles, oracle, qi, idx_dir, mp, text, starts, lens, n, L, dev_id, device, k, headline, bg):
+    iv = {}
+    m = int(min(n, args.variant_pairs))
+    par = min(m, 2_000_000)
+    opts = ra.default_opts()
+    oopts = oracle.default_opts()
+    cores = os.cpu_count() or 1
+
+    def one(name, mapper, orc, tx, st, ln, what, seed, **gen):
+        s1, s2, off = make_reads_gpu(tx, st, ln, m, seed, device, read_len=L, **gen)
+        torch.cuda.synchronize()
+        ptr = (s1.data_ptr(), off.data_ptr(), s2.data_ptr(), off.data_ptr())
+        with bg.quiet():
+            el, kms, tot = timed_steps(mapper, opts, ptr, m, L, 3, 1, 1, device, qd)
+        val = m * 3 / el / 1e6
+        ks = kernel_stats(mapper, m)
+        h1 = s1[: par * L].cpu().numpy(); h2 = s2[: par * L].cpu().numpy(); ho = off[: par + 1].cpu().numpy()
+        ores = orc.map_pairs(h1, ho, h2, ho, opts=oopts, nthreads=max(1, cores // 2))
+        gr = mapper.map_device(par, ptr[0], ptr[1], ptr[2], ptr[3], L, opts=opts, fetch=True)
+        ok = bool(np.array_equal(gr.hit_offsets, ores.hit_offsets) and gr.hits.tobytes() == ores.hits.tobytes() and gr.counters == ores.counters)
+        leg = {"reads": what, "pairs_per_step": m, "value": round(val, 3), "unit": "M read-pairs/s", "steps": 3, "warmup": 1, "ms_per_step": round(el / 3 * 1e3, 3),
+               "kernel_ms": round(float(np.mean(kms)), 3), "of_headline": round(val / headline, 3), "hits_per_pair": round(tot["totHits"] / max(1, tot["numReads"]), 4),
+               "lean_deferred_frac": ks.get("lean_deferred_frac"), "stage_a_kernels": {kk: ks[kk] for kk in ks if kk != "what"},
+               "parity": {"sample_pairs": par, "bit_identical_to_oracle": ok, "hits": int(ores.hit_offsets[-1])}}
+        if val < 0.7 * headline:
+            lb = ks.get("left_because") or {}
+            top = max(lb, key=lb.get) if lb else None
+            leg["below_70_percent_because"] = ("%.1f %% of the reads are left to the general kernel (one read per wavefront, 255 M pairs/s on clean reads), most of them for: %s (%d reads)"
+                                               % (100.0 * (ks.get("lean_deferred_frac") or 0), top, lb[top])) if top else "no read was left: see kernel_ms against ms_per_step"
+        iv[name] = leg
+        log("input_variants %s: %.1f M pairs/s (%.2f of the headline), %.3f of the reads left to the general kernel, parity %s" % (name, val, val / headline, ks.get("lean_deferred_frac") or 0, ok))
+        del s1, s2, off
+
+    orc = oracles.get(idx_dir)
+    one("err1 (the headline's distribution at this batch size)", mp, orc, text, starts, lens, "1 % substitutions", 143, err=0.01)
+    one("err0", mp, orc, text, starts, lens, "no substitutions: every read matches its transcript end to end", 144, err=0.0)
+    one("err1_N0.1", mp, orc, text, starts, lens, "1 % substitutions and 0.1 % of the characters N (9.5 % of the reads hold one)", 145, err=0.01, n_rate=0.001)
+    # paralogs + a repeat family: an index of its own (built in the background since the run began)
+    kw = dict(paralogs=0.05, repeat_family=100)
+    idx_par = build_or_reuse_index(args.genes, 42, k, 0, 1, args.cache, wait_only=bg.ok("par0.05,100"), **kw)
+    qi_p = ra.QuasiIndex(idx_par)
+    mp_p = ra.QuasiMapper(qi_p, dev_id)
+    tx, st, ln = load_text_to_gpu(qi_p, device)
+    one("paralogs5_family100", mp_p, oracles.get(idx_par), tx, st, ln,
+        "1 % substitutions; the transcriptome holds 5 % of its transcripts a second time as paralogs (4 % substitutions) and one family of 100 transcripts around a shared 300-base core: {} transcripts".format(qi_p.n_txps),
+        146, err=0.01)
+    mp_p.close(); qi_p.close()
+    return iv
 
 
 def side_legs(out, args, ra, qi, mp, opts, s1, s2, off, n, L, dev_id, cores):
@@ -734,7 +901,8 @@ def other_configs(oc, args, ra, qd, oracles, oracle, qi, idx_dir, mp, s1, s2, of
     steps, warm = 3, 1
 
     def leg(name, mapper, o, key, bpp, w, cp, workload, extra=None, whole_step=False):
-        el, kms, tot = timed_steps(mapper, o, ptr, n, L, steps, warm, 1, device, qd)
+        with args._bg.quiet():
+            el, kms, tot = timed_steps(mapper, o, ptr, n, L, steps, warm, 1, device, qd)
         val = n * steps / el / 1e6
         km = float(np.mean(kms))
         oc[name] = {"workload": workload, "value": round(val, 4), "unit": "M read-pairs/s", "steps": steps, "warmup": warm,
@@ -762,7 +930,7 @@ def other_configs(oc, args, ra, qd, oracles, oracle, qi, idx_dir, mp, s1, s2, of
         whole_step=True)
 
     # configs[3]: the same transcriptome indexed with -p, in both device images, same reads (the text is the same)
-    idx_ph = build_or_reuse_index(args.genes, 42, k, 0, 1, args.cache, True)
+    idx_ph = build_or_reuse_index(args.genes, 42, k, 0, 1, args.cache, True, wait_only=args._bg.ok("ph"))      # (built in the background since the run began)
     qi_ph = ra.QuasiIndex(idx_ph)
     assert qi_ph.text_len == qi.text_len and qi_ph.n_txps == qi.n_txps
     o = ra.default_opts()

@@ -284,7 +284,12 @@ enum { QM_STAT_RELAUNCHES = 0, QM_STAT_LIST_WORDS = 1, QM_STAT_SLOW_READS = 2, Q
        QM_STAT_STRIP_ALIGNMENTS = 8, /* ... and the alignments answered by the exact strip DP instead (gapless path within q + 7 e of the best possible) */
        QM_STAT_PAIR_KERNEL_PAIRS = 9, /* pairs the pair kernel (both mates in one wavefront, merged there) was launched over; -1: not used.  An unsplit call only
                                          (a call mapped in parts reports QM_STAT_LEAN_READS / _DEFERRED summed over its parts and -1 here) */
-       QM_STAT_PAIRS_MERGED = 10 };  /* ... of which it merged itself (the others had a mate left to the general kernel, or the call kept lists) */
+       QM_STAT_PAIRS_MERGED = 10,    /* ... of which it merged itself (the others had a mate left to the general kernel, or the call kept lists) */
+       /* why the reads of QM_STAT_LEAN_DEFERRED were left to the general kernel (they add up to it): */
+       QM_STAT_DEFER_DIRTY = 11,     /* a character that is not A C G T (an N ...), or more characters than the kernel's lanes hold */
+       QM_STAT_DEFER_HOMOPOLYMER = 12, /* a window of k equal bases (isHomoPolymer, include/Kmer.hpp:484-487) */
+       QM_STAT_DEFER_WIDE = 13,      /* an SA interval wider than the kernel's lanes, more suffixes / intervals than its stash, a match beyond its extension table */
+       QM_STAT_DEFER_BOTH_STRANDS = 14 }; /* k-mers of the other orientation seen on the way: the reference maps the other strand as well (SACollector.hpp:258,271) */
 int qm_ctx_stat(const qm_ctx* ctx, int which, int64_t* value);
 
 /* Reads of the last map call on ctx that were SKIPPED, not mapped (round 5; before, one such read failed the whole batch): a read

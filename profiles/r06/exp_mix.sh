@@ -8,3 +8,6 @@ run QM_DUO_PARTS=1 QM_SPLIT_FIRST=40
 run QM_DUO_PARTS=1 QM_SPLIT_FIRST=60
 run QM_DUO_PARTS=0
 run QM_DUO_PARTS=5 QM_SPLIT=4
+run QM_DUO_PARTS=1 QM_SPLIT=3
+run QM_DUO_PARTS=3 QM_SPLIT=3
+run QM_DUO_PARTS=1 QM_SPLIT=2

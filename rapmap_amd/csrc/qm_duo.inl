@@ -146,6 +146,7 @@ QM_DEV void duo_find_ph(const DevIndex& ix, const LV<u64>& w, const LV<u64>& wr,
 #define QM_DW_DEF 512u        // not taken at all (a character that is not A C G T, a homopolymer window, more than 128 characters)
 #define QM_DW_FL 1024u        // what the first probe learned about the read's last k-mer: it is in the index ...
 #define QM_DW_CL 2048u        // ... its reverse complement is (= the first k-mer of reverseRead(read))
+#define QM_DW_DEFH 4096u      // (with QM_DW_DEF: because of a window of k equal bases)
 struct DuoWalk {
   LV<u32> fl;
   LV<int> p;                                   // the position the walk stands on
@@ -261,8 +262,8 @@ QM_DEV void duo_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, in
   duo_stage_chars(B, it + nw, nit, M, par ^ 1);
   duo_stage_offsets(B, it + 2 * nw, nit, M, par);
   // what this kernel takes: no character but A C G T, no window of k equal bases, at most 128 characters (lean_iter)
-  LV<int> defv;
-  QM_LANES(l) { defv[l] = (rawv[l] > QM_LEAN_MAXLEN || dirty[l] != 0 || 4 * popc32(reps[l]) + 6 >= k) ? 1 : 0; }
+  LV<int> defv;            // 1: a character that is not A C G T or too many characters, 2: a window of k equal bases
+  QM_LANES(l) { defv[l] = (rawv[l] > QM_LEAN_MAXLEN || dirty[l] != 0) ? 1 : (4 * popc32(reps[l]) + 6 >= k ? 2 : 0); }
   // ---- the first probe of both mates in one round (SACollector.hpp:167-237 starts at position 0; the read's last k-mer is the first
   // thing the reverse-complement pass asks for): lane 0 of a half = position 0, lane 1 = position P - 1, both orientations each
   DuoWalk W;
@@ -295,7 +296,7 @@ QM_DEV void duo_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, in
       const u32 F0 = fm[l] & 1u, C0 = cm[l] & 1u;
       const u32 Fl = Pv[l] > 1 ? (fm[l] >> 1) & 1u : F0, Cl = Pv[l] > 1 ? (cm[l] >> 1) & 1u : C0;
       const bool fwd = ok && F0 != 0, rev = ok && F0 == 0 && C0 != 0, scan = ok && F0 == 0 && C0 == 0;
-      W.fl[l] = (defv[l] ? QM_DW_DEF : 0u) | (fwd ? (2u | QM_DW_FOUND | QM_DW_SKIP) : 0u) | (rev ? (2u | QM_DW_FOUND | QM_DW_V) : 0u) | (scan ? 1u : 0u) | (Fl ? QM_DW_FL : 0u) | (Cl ? QM_DW_CL : 0u);
+      W.fl[l] = (defv[l] ? QM_DW_DEF : 0u) | (defv[l] == 2 ? QM_DW_DEFH : 0u) | (fwd ? (2u | QM_DW_FOUND | QM_DW_SKIP) : 0u) | (rev ? (2u | QM_DW_FOUND | QM_DW_V) : 0u) | (scan ? 1u : 0u) | (Fl ? QM_DW_FL : 0u) | (Cl ? QM_DW_CL : 0u);
       W.p[l] = scan ? 1 : 0;
       W.wbw[l] = 0u | (1u << 8);
       W.Fm[l] = rev ? Cl : F0; W.Cm[l] = rev ? Fl : C0;    // (reverse: what the first probe learned about the read's last k-mer)
@@ -453,13 +454,14 @@ QM_DEV void duo_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, in
   // ---- the other strand's turn (:258 checkRC after the read's own pass, :271 checkFwd after the reverse complement's)?  Such a read is
   // left to the general kernel, like every read that bailed out above.  (:343-358: quasiCoverage)
   const int useCov = B.strict_check != 0 ? 1 : 0;          // disableNIP_ && strictCheck_ (SACollector.hpp:138)
-  LV<int> nsuf, taken, snv;
+  LV<int> nsuf, taken, snv, why;
   QM_LANES(l) {
     const u32 ha = W.hab[l] & 0xffffu, hb = W.hab[l] >> 16;
     const bool other = (W.fl[l] & QM_DW_FOUND) != 0 && (useCov ? (hb > 0) : (hb >= ha));
     int sn = (int)(W.cntr[l] & 0xffu);
     if (COV) { if (sn > 0 && Lv[l] > 0) { const double fr = (double)W.cov[l] / (double)Lv[l]; if (fr < B.quasi_cov) sn = 0; } }
     taken[l] = ((W.fl[l] & (QM_DW_DEF | QM_DW_BAIL)) != 0 || other) ? 0 : 1;
+    why[l] = (W.fl[l] & QM_DW_DEF) ? ((W.fl[l] & QM_DW_DEFH) ? 1 : 0) : ((W.fl[l] & QM_DW_BAIL) ? 2 : 3);
     nsuf[l] = (taken[l] && sn > 0) ? (int)(W.cntr[l] >> 8) : 0;
     snv[l] = sn;
   }
@@ -611,7 +613,12 @@ QM_DEV void duo_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, in
           const u32 flag = (B.fuzzy && (W.fl[l] & QM_DW_FOUND)) ? 0x80000000u : 0u;
           B.lcnt[r0 + h] = (fits ? (u32)(h ? cntB : cntA) : 0u) | flag; B.loff[r0 + h] = fits ? bh : 0;
         }
-      } else if (j == 0) { B.lcnt[r0 + h] = QM_LCNT_LEAN; B.loff[r0 + h] = 0; atomic_add_u64(B.cursor + QM_SC_LEANQ, 1ULL); }
+      } else if (j == 0) {
+        B.lcnt[r0 + h] = QM_LCNT_LEAN; B.loff[r0 + h] = 0; atomic_add_u64(B.cursor + QM_SC_LEANQ, 1ULL);
+#ifndef QM_TIMING
+        atomic_add_u64(B.cursor + QM_SC_DEFER0 + why[l], 1ULL);
+#endif
+      }
     }
   }
 }

@@ -159,6 +159,7 @@ struct qm_ctx {
   int64_t lastUnits = -1, lastHits = 0; bool lastPaired = false;
   double lastMapMs = 0, lastTotalMs = 0;
   int64_t lastSelQuestions = 0, lastKswTasks = 0, lastStripTasks = 0;             // -s: alignment questions beyond PERFECT chains of the last call, ksw2 alignments run for them
+  int64_t lastDefer[4] = {0, 0, 0, 0};            // QM_STAT_DEFER_*
   int64_t lastDuoPairs = -1, lastDuoMerged = 0;   // pairs the pair kernel was launched over (-1: not used), pairs it merged itself
   int64_t lastRelaunches = 0, lastSlowReads = 0, lastLeanReads = -1, lastLeanDeferred = 0;   // lastLeanReads: reads the lean kernel was launched over (-1: not used)
   // qm_map_device on a large batch: its parts on helper contexts of the same replica, in flight together (map_device_split)
@@ -888,6 +889,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
   const DevIndex ix = dev_index(c);
   c->lastRelaunches = 0; c->lastSlowReads = 0; c->lastIvTotal = 0; c->lastLeanReads = useLean ? nreads : -1; c->lastLeanDeferred = 0;
   c->lastDuoPairs = useDuo ? n : -1; c->lastDuoMerged = 0;
+  for (int i = 0; i < 4; ++i) c->lastDefer[i] = 0;
   float leanExtraMs = 0;
   while (true) {
     ReadBatch B; memset(&B, 0, sizeof(B));
@@ -952,6 +954,9 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
       HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
       const int st0 = (int)(hscal[QM_SC_STATUS] & 0xffffffffu);
+#ifndef QM_TIMING
+      for (int i = 0; i < 4; ++i) c->lastDefer[i] = (int64_t)hscal[QM_SC_DEFER0 + i];
+#endif
       if (hscal[QM_SC_LEANQ] > 0 && !(st0 & 23)) {
         const int64_t nq = (int64_t)hscal[QM_SC_LEANQ];
         if ((rc = ensure(c->d_slowq, c->capSlowq, nq))) return rc;
@@ -1009,6 +1014,9 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
     HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     int status = (int)(hscal[QM_SC_STATUS] & 0xffffffffu);
+#ifndef QM_TIMING
+    if (useLean) for (int i = 0; i < 4; ++i) c->lastDefer[i] = (int64_t)hscal[QM_SC_DEFER0 + i];
+#endif
     if (duoMerge) c->lastDuoMerged = (int64_t)hscal[4];        // (numReads so far: the pairs the pair kernel merged; stage B's count pass adds the others)
     if (useLean && hscal[QM_SC_LEANQ] > 0 && !(status & 23)) {
       // what the lean kernel marked instead of mapping (a character that is not A C G T, a long run of one base, a read beyond 128
@@ -1390,6 +1398,7 @@ static int map_device_split(qm_ctx* c, const qm_opts* o, int K, int64_t n, const
   float ms = 0; hipEventElapsedTime(&ms, c->evA, c->evB); c->lastTotalMs = ms;
   c->lastRelaunches = 0; c->lastSlowReads = 0; c->lastSkipped = 0; c->skipList.clear(); c->lastSelQuestions = 0; c->lastKswTasks = 0; c->lastStripTasks = 0;
   c->lastDuoPairs = -1; c->lastDuoMerged = 0; c->lastLeanReads = -1; c->lastLeanDeferred = 0;
+  for (int i = 0; i < 4; ++i) c->lastDefer[i] = 0;
   qm_counters sum; memset(&sum, 0, sizeof(sum));
   for (int i = 0; i < K; ++i) {
     sum.pe_hits += ctr[i].pe_hits; sum.se_hits += ctr[i].se_hits; sum.tot_hits += ctr[i].tot_hits; sum.num_reads += ctr[i].num_reads;
@@ -1397,6 +1406,7 @@ static int map_device_split(qm_ctx* c, const qm_opts* o, int K, int64_t n, const
     qm_ctx* h = c->helpers[(size_t)i];
     if (h->lastLeanReads >= 0) { c->lastLeanReads = (c->lastLeanReads < 0 ? 0 : c->lastLeanReads) + h->lastLeanReads; c->lastLeanDeferred += h->lastLeanDeferred; }
     if (h->lastDuoPairs >= 0) { c->lastDuoMerged += h->lastDuoMerged; }
+    for (int t = 0; t < 4; ++t) c->lastDefer[t] += h->lastDefer[t];
     c->lastRelaunches += h->lastRelaunches; c->lastSlowReads += h->lastSlowReads; c->lastSelQuestions += h->lastSelQuestions; c->lastKswTasks += h->lastKswTasks; c->lastStripTasks += h->lastStripTasks;
     // the part's skipped reads, as reads of the whole batch
     int64_t u0 = n * i / K;
@@ -1885,6 +1895,7 @@ int qm_ctx_stat(const qm_ctx* c, int which, int64_t* value) {
     case QM_STAT_STRIP_ALIGNMENTS: *value = c->lastStripTasks; break;
     case QM_STAT_PAIR_KERNEL_PAIRS: *value = c->lastDuoPairs; break;
     case QM_STAT_PAIRS_MERGED: *value = c->lastDuoMerged; break;
+    case QM_STAT_DEFER_DIRTY: case QM_STAT_DEFER_HOMOPOLYMER: case QM_STAT_DEFER_WIDE: case QM_STAT_DEFER_BOTH_STRANDS: *value = c->lastDefer[which - QM_STAT_DEFER_DIRTY]; break;
     default: return fail(QM_E_ARG, "unknown statistic %d", which);
   }
   return QM_OK;

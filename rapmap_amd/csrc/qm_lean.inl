@@ -38,6 +38,9 @@ namespace qm {
 #define QM_LEAN_SUF 64           // suffixes a strand's intervals may hold together
 #define QM_LEAN_MAXIV 32         // intervals per strand (a bit each)
 #define QM_SC_LEANQ 30           // scalar slot: reads on the lean kernel's queue
+#define QM_SC_DEFER0 20          // ... and why they are there, four slots (not in -DQM_TIMING builds, whose phase sums sit here): 0 a character that is not
+                                 // A C G T or more than 128 (256) characters, 1 a window of k equal bases, 2 an interval wider than the kernel's lanes / more
+                                 // suffixes or intervals than its stash / a match beyond the extension table, 3 hits on the other strand as well
 #define QM_LEAN_CHUNK 1024       // list elements a wave reserves per bump-allocator round trip (a list here holds at most 64): a quarter of the general
                                  // kernels' QM_CHUNK, so that twice their grid leaves half their slack in the list buffer (the host sizes it for theirs)
 
@@ -201,9 +204,16 @@ QM_DEV int lean_h2m(const QM_LDS(LeanSuf)* suf, const LeanStrand& S, bool isRC, 
 
 // a read for the general kernel: marked in its list-length word and counted (the host gathers the marks into a queue, like the
 // reads the general kernels set aside for the long-read pass); nothing else was written for it
-QM_DEV void lean_defer(const ReadBatch& B, int read) {
+QM_DEV void lean_defer(const ReadBatch& B, int read, int why) {
   QM_CNT(19, 1);
-  QM_LANES(l) { if (l == 0) { B.lcnt[read] = QM_LCNT_LEAN; B.loff[read] = 0; atomic_add_u64(B.cursor + QM_SC_LEANQ, 1ULL); } }
+  QM_LANES(l) {
+    if (l == 0) {
+      B.lcnt[read] = QM_LCNT_LEAN; B.loff[read] = 0; atomic_add_u64(B.cursor + QM_SC_LEANQ, 1ULL);
+#ifndef QM_TIMING
+      atomic_add_u64(B.cursor + QM_SC_DEFER0 + why, 1ULL);
+#endif
+    }
+  }
 }
 
 // offsets of iteration `it` into ostage[par]: pairs: off1[it], off1[it + 1], off2[it], off2[it + 1]; single-end reads 2 it and
@@ -324,9 +334,10 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
 #endif
   // what this kernel takes: no character but A C G T, no window of k equal bases (k equal characters cover at least (k - 6) / 4
   // whole lanes above: setup_strand's rule for its lazy strands), at most 128 characters
-  const int defer0 = WIDE ? ((raw0 > MAXLEN || dirty != 0 || 4 * popc64(reps) + 6 >= k) ? 1 : 0)
-                          : ((raw0 > MAXLEN || (u32)dirty != 0 || 4 * popc32((u32)reps) + 6 >= k) ? 1 : 0);
-  const int defer1 = (raw1 > MAXLEN || (u32)(dirty >> 32) != 0 || 4 * popc32((u32)(reps >> 32)) + 6 >= k) ? 1 : 0;
+  // (1: a character that is not A C G T or too many of them, 2: a window of k equal bases -- lean_defer's `why` + 1)
+  const int defer0 = WIDE ? ((raw0 > MAXLEN || dirty != 0) ? 1 : (4 * popc64(reps) + 6 >= k ? 2 : 0))
+                          : ((raw0 > MAXLEN || (u32)dirty != 0) ? 1 : (4 * popc32((u32)reps) + 6 >= k ? 2 : 0));
+  const int defer1 = (raw1 > MAXLEN || (u32)(dirty >> 32) != 0) ? 1 : (4 * popc32((u32)(reps >> 32)) + 6 >= k ? 2 : 0);
   const int P0 = len0 - k + 1, P1 = len1 - k + 1;
   const int ok0 = (!defer0 && P0 >= 1) ? 1 : 0, ok1 = (have1 && !defer1 && P1 >= 1) ? 1 : 0;
   // ---- the first probe of both reads in one round (SACollector.hpp:167-237 starts at position 0; the read's last k-mer is the
@@ -366,7 +377,7 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
   for (int h = 0; h < NH; ++h) {
     if (h > have1) break;
     const int read = r0 + h;
-    if (h ? defer1 : defer0) { lean_defer(B, read); continue; }
+    if (h ? defer1 : defer0) { lean_defer(B, read, (h ? defer1 : defer0) - 1); continue; }
     const int L = h ? len1 : len0, P = L - k + 1, D = MAXLEN - L;
     int n = 0, foundHit = 0, bail = 0, selV = 0;
     LV<u64> elem; LV<bool> keep; LV<int> slot;
@@ -655,7 +666,7 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
           if (p + k == L) lastSearch = 1;
         }
         // the other strand's turn (:258 checkRC after the read's own pass, :271 checkFwd after the reverse complement's)?
-        if (!bail && (useCov ? (hb > 0) : (hb >= ha))) bail = 1;
+        if (!bail && (useCov ? (hb > 0) : (hb >= ha))) bail = 2;
         if (!bail) {
           // (:283-288: the other strand has no coverage and no intervals -- nothing to clear, with or without the slack of -s)
           if (B.quasi_cov > 0.0 && sn > 0) { const double f = (double)cov / (double)L; if (f < B.quasi_cov) sn = 0; }   // :343-358
@@ -671,7 +682,7 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
         }
       }
     }
-    if (bail) { lean_defer(B, read); continue; }
+    if (bail) { lean_defer(B, read, bail == 2 ? 3 : 2); continue; }
     if (SEL) {
       // ---- the collector's output: the read's SA-interval records (one strand's) through the wave's chunk of B.iv_out (dump_intervals),
       // and what SACollector::operator() returned

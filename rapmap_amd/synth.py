@@ -12,8 +12,9 @@ _COMP = np.zeros(256, dtype=np.uint8)
 _COMP[list(b"ACGTN")] = list(b"TGCAN")
 
 
-def make_transcriptome(n_genes, seed=42, paralog_frac=0.0):
-    """-> (names, list of uint8 arrays)"""
+def make_transcriptome(n_genes, seed=42, paralog_frac=0.0, repeat_family=0):
+    """-> (names, list of uint8 arrays).  paralog_frac: that share of the transcripts again as paralogs (4 % substitutions);
+    repeat_family: one family of that many transcripts sharing a 300-base core between unique flanks (intervals wider than a wavefront)"""
     rng = np.random.default_rng(seed)
     names, txps = [], []
     for g in range(n_genes):
@@ -38,6 +39,11 @@ def make_transcriptome(n_genes, seed=42, paralog_frac=0.0):
             t[m] = _B[(np.searchsorted(_B, t[m]) + rng.integers(1, 4, int(m.sum()))) % 4]
             txps.append(t)
             names.append("P%d" % j)
+    if repeat_family > 0:
+        core = _B[rng.integers(0, 4, 300)]
+        for j in range(int(repeat_family)):
+            txps.append(np.concatenate([_B[rng.integers(0, 4, 250)], core, _B[rng.integers(0, 4, 250)]]))
+            names.append("R%d" % j)
     return names, txps
 
 
