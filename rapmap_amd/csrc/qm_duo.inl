@@ -34,31 +34,32 @@ namespace qm {
 #endif
 #define QM_DUO_MAXIV 32          // intervals per read (a bit each)
 
-struct DuoMem {                                // one wave's LDS slab (3 024 bytes)
+struct DuoMem {                                // one wave's LDS slab (4 656 bytes)
   u64 pk[2][2][8];                             // as LeanMem::pk: [mate][0: the read, 1: mirrored reverse complement][word]; words 4-7 stay zero
   union {
     LeanSuf suf[2][QM_DUO_SUF];                // [mate]: suffixes of the intervals recorded for it
     u64 lst[2][32];                            // ... later its hit list, sorted, for the merge
   };
   LeanSuf trash[64];                           // where a lane that has nothing to record stores (no branch around the store)
+  U4 pf[3][34];                                // the next pair's first probe: the 48 bytes of the buckets of its mates' first and last k-mers (lanes 0, 1, 32, 33),
+                                               // fetched straight into here (global_load_lds_dwordx4) while the pair before it is finished
   u32 stage[100];                              // raw characters of the next pair: dwords [0, 32) mate 0, [32, 64) mate 1, [64] / [96] the 33rd dword of mate 0 / 1
   u32 ostage[2][8];                            // offsets of the next / the next but one pair: off1[u], off1[u + 1], off2[u], off2[u + 1]
 };
-struct DuoCtr { u32 pe, se, tot, reads, tooMany, mapped; };   // HitCounters of the pairs this wave merged (wave-uniform)
+typedef PairCtr DuoCtr;
 
 // khash.find for one POSITION per lane: w the k-mer as the read has it, wr its reverse complement.  One bucket of the canonical
 // table holds both; fh / (flb, fub): the k-mer is in the index / its interval, ch / (clb, cub): the same for the reverse complement.
 // Lanes that are not `on` read bucket 0 and come back with nothing.
-QM_DEV void duo_find(const DevIndex& ix, const LV<u64>& w, const LV<u64>& wr, const LV<u32>& on, LV<u32>& fh, LV<u32>& ch,
-                     LV<u32>& flb, LV<u32>& fub, LV<u32>& clb, LV<u32>& cub) {
-  LV<u32> more; LV<u64> bkt, ckv; LV<u32> bigv;
+// duo_find_rest: what follows the first bucket's 48 bytes (a: the two keys, f / r: the interval pairs of the canonical k-mers and of
+// their reverse complements) -- whoever loaded them: duo_find itself, or the prefetch of a pair's first probe (duo_prepare)
+QM_DEV void duo_find_rest(const DevIndex& ix, const LV<u64>& ckv, const LV<u32>& bigv, const LV<u32>& on, LV<U4>& av, LV<U4>& fv, LV<U4>& rv, LV<u64>& bkt,
+                          LV<u32>& fh, LV<u32>& ch, LV<u32>& flb, LV<u32>& fub, LV<u32>& clb, LV<u32>& cub) {
+  LV<u32> more;
   QM_LANES(l) {
-    const bool big = wr[l] < w[l];
-    const u64 ck = big ? wr[l] : w[l];
-    const u64 b = on[l] ? ((u64)bucket_hash(ck) & ix.hmask) : 0ULL;
-    U4 a, f, r;
-    load_48(&ix.slots[b], a, f, r);
-    QM_CNT(1, on[l] ? 1 : 0);
+    const U4 a = av[l], f = fv[l], r = rv[l];
+    const u64 ck = ckv[l];
+    const bool big = bigv[l] != 0;
     const u64 k0r = ((u64)a.y << 32) | a.x, k1 = ((u64)a.w << 32) | a.z;
     const bool h0 = (k0r & ~QM_BK_OVF) == ck, h1 = k1 == ck;
     const u32 cfl = h0 ? f.x : f.z, cfu = h0 ? f.y : f.w, crl = h0 ? r.x : r.z, cru = h0 ? r.y : r.w;   // the canonical k-mer's interval, its reverse complement's
@@ -67,7 +68,6 @@ QM_DEV void duo_find(const DevIndex& ix, const LV<u64>& w, const LV<u64>& wr, co
     flb[l] = al; fub[l] = big ? cru : cfu; clb[l] = bl; cub[l] = big ? cfu : cru;
     fh[l] = (m && al != QM_IV_NONE) ? 1u : 0u; ch[l] = (m && bl != QM_IV_NONE) ? 1u : 0u;
     more[l] = (on[l] != 0 && !(h0 || h1) && k0r != ~0ULL && (k0r & QM_BK_OVF) != 0) ? 1u : 0u;
-    bkt[l] = b; ckv[l] = ck; bigv[l] = big ? 1u : 0u;
   }
   // 0.4 % of the buckets: a key that hashes here lives in a later bucket (lean_find)
   while (true) {
@@ -91,6 +91,20 @@ QM_DEV void duo_find(const DevIndex& ix, const LV<u64>& w, const LV<u64>& wr, co
       bkt[l] = b;
     }
   }
+}
+QM_DEV void duo_find(const DevIndex& ix, const LV<u64>& w, const LV<u64>& wr, const LV<u32>& on, LV<u32>& fh, LV<u32>& ch,
+                     LV<u32>& flb, LV<u32>& fub, LV<u32>& clb, LV<u32>& cub) {
+  LV<u64> bkt, ckv; LV<u32> bigv; LV<U4> av, fv, rv;
+  QM_LANES(l) {
+    const bool big = wr[l] < w[l];
+    const u64 ck = big ? wr[l] : w[l];
+    const u64 b = on[l] ? ((u64)bucket_hash(ck) & ix.hmask) : 0ULL;
+    U4 a, f, r;
+    load_48(&ix.slots[b], a, f, r);
+    QM_CNT(1, on[l] ? 1 : 0);
+    av[l] = a; fv[l] = f; rv[l] = r; bkt[l] = b; ckv[l] = ck; bigv[l] = big ? 1u : 0u;
+  }
+  duo_find_rest(ix, ckv, bigv, on, av, fv, rv, bkt, fh, ch, flb, fub, clb, cub);
 }
 
 // the same through the compact -p image (lean_find_ph): the structure is keyed by the k-mer itself, so a position asks twice -- but the
@@ -218,13 +232,20 @@ QM_DEV void duo_stage_chars(const ReadBatch& B, int it, int nit, DuoMem& M, int 
   }
 }
 
-// One pair: reads 2 it and 2 it + 1.
-template <bool PH, bool COV>
-QM_DEV void duo_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, int nw, int par, DuoMem& M, WaveAlloc& wa, DuoCtr& ctr) {
+// What duo_prepare leaves in registers for the iteration that maps the pair
+struct DuoNext { LV<int> Lv, defv; LV<u64> ck; LV<u32> flg; };    // flg: bit 0 the lane asked (first / last k-mer of its mate), bit 1 its k-mer is the larger of the two orientations
+
+// Pair `it`, first half: the two mates' characters (staged by the iteration before) -> 2-bit images of both strands, four characters
+// per lane (lean_iter); the staging of the pairs behind it; and the FIRST PROBE's requests -- lane 0 of a half = its mate's position 0,
+// lane 1 = position P - 1 (SACollector.hpp:167-237 starts at position 0; the read's last k-mer is the first thing the
+// reverse-complement pass asks for), both orientations each: one canonical bucket per lane, its 48 bytes sent straight to LDS.
+// Runs BEFORE the pair ahead of it is finished (hits -> mappings, merge, write-out), so that trip is over when duo_iter starts.
+template <bool PH>
+QM_DEV void duo_prepare(const DevIndex& ix, const ReadBatch& B, int it, int nit, int nw, int par, DuoMem& M, DuoNext& N) {
+  if (it >= nit) return;
   const int k = ix.k;
   const QM_LDS(u64)* pkw = (const QM_LDS(u64)*)&M.pk[0][0][0];
-  // ---- the two mates' characters -> 2-bit images of both strands, four characters per lane (lean_iter)
-  LV<int> rawv, Lv, Pv;
+  LV<int> rawv;
   LV<bool> bad, rep;
   {
     QM_LDS(unsigned char)* PKb = (QM_LDS(unsigned char)*)&M.pk[0][0][0];
@@ -252,7 +273,7 @@ QM_DEV void duo_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, in
       PKb[img + 8 * (jj >> 3) + 7 - (jj & 7)] = (unsigned char)pk;
       const int mj = 31 - jj;
       PKb[img + 64 + 8 * (mj >> 3) + 7 - (mj & 7)] = (unsigned char)r;
-      rawv[l] = raw; Lv[l] = len; Pv[l] = len - k + 1;
+      rawv[l] = raw; N.Lv[l] = len;
     }
   }
   LV<u32> dirty, reps;
@@ -262,28 +283,61 @@ QM_DEV void duo_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, in
   duo_stage_chars(B, it + nw, nit, M, par ^ 1);
   duo_stage_offsets(B, it + 2 * nw, nit, M, par);
   // what this kernel takes: no character but A C G T, no window of k equal bases, at most 128 characters (lean_iter)
-  LV<int> defv;            // 1: a character that is not A C G T or too many characters, 2: a window of k equal bases
-  QM_LANES(l) { defv[l] = (rawv[l] > QM_LEAN_MAXLEN || dirty[l] != 0) ? 1 : (4 * popc32(reps[l]) + 6 >= k ? 2 : 0); }
-  // ---- the first probe of both mates in one round (SACollector.hpp:167-237 starts at position 0; the read's last k-mer is the first
-  // thing the reverse-complement pass asks for): lane 0 of a half = position 0, lane 1 = position P - 1, both orientations each
+  // 1: a character that is not A C G T or too many characters, 2: a window of k equal bases
+  QM_LANES(l) { N.defv[l] = (rawv[l] > QM_LEAN_MAXLEN || dirty[l] != 0) ? 1 : (4 * popc32(reps[l]) + 6 >= k ? 2 : 0); }
+  QM_LANES(l) {
+    const int h = l >> 5, jj = l & 31;
+    const int P = N.Lv[l] - k + 1, D = QM_LEAN_MAXLEN - N.Lv[l];
+    const bool o = !N.defv[l] && P >= 1 && jj < 2 && (jj == 0 || P > 1);
+    const int q = (o && jj == 1) ? P - 1 : 0;
+    const QM_LDS(u64)* pkh = pkw + 16 * h;
+    const u64 w = lean_kmer(pkh, q, k), wr = lean_kmer(pkh + 8, (o ? P - 1 - q : 0) + D, k);
+    const bool big = wr < w;
+    N.ck[l] = PH ? w : (big ? wr : w);
+    N.flg[l] = (o ? 1u : 0u) | (big ? 2u : 0u);
+    if (!PH && o) {
+      const unsigned char* bp = (const unsigned char*)&ix.slots[(u64)bucket_hash(N.ck[l]) & ix.hmask];
+      QM_CNT(1, 1);
+      lds_dma_u128(bp, &M.pf[0][0], l); lds_dma_u128(bp + 16, &M.pf[1][0], l); lds_dma_u128(bp + 32, &M.pf[2][0], l);
+    }
+  }
+}
+
+// Pair `it` (reads 2 it and 2 it + 1), second half: the first probe's answers, the two walks in lockstep, hits -> mappings, the merge.
+// Between the walks and the rest it runs duo_prepare for the pair the wave maps next.
+template <bool PH, bool COV>
+QM_DEV void duo_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, int nw, int par, DuoMem& M, WaveAlloc& wa, DuoCtr& ctr, DuoNext& N) {
+  const int k = ix.k;
+  const QM_LDS(u64)* pkw = (const QM_LDS(u64)*)&M.pk[0][0][0];
+  LV<int> Lv, Pv, defv;
+  QM_LANES(l) { Lv[l] = N.Lv[l]; Pv[l] = N.Lv[l] - k + 1; defv[l] = N.defv[l]; }
   DuoWalk W;
   const u32 maxIv = (u32)B.max_interval;
   {
-    LV<u64> w, wr; LV<u32> on, fh, ch, flb, fub, clb, cub;
-    QM_LANES(l) {
-      const int h = l >> 5, jj = l & 31;
-      const int P = Pv[l], D = QM_LEAN_MAXLEN - Lv[l];
-      const bool o = !defv[l] && P >= 1 && jj < 2 && (jj == 0 || P > 1);
-      const int q = (o && jj == 1) ? P - 1 : 0;
-      const QM_LDS(u64)* pkh = pkw + 16 * h;
-      w[l] = lean_kmer(pkh, q, k);
-      wr[l] = lean_kmer(pkh + 8, (o ? P - 1 - q : 0) + D, k);
-      on[l] = o ? 1u : 0u;
-    }
+    LV<u32> on, fh, ch, flb, fub, clb, cub;
+    QM_LANES(l) { on[l] = N.flg[l] & 1u; }
     QM_CNT(3, 1);
-    if (PH) duo_find_ph(ix, w, wr, on, fh, ch, flb, fub, clb, cub);
-    else duo_find(ix, w, wr, on, fh, ch, flb, fub, clb, cub);
-    lds_dma_wait();                                        // what was requested above has landed by now: no store follows an open request
+    lds_dma_wait();                                        // the first probe's buckets (and everything else that was requested) have landed
+    if (PH) {
+      LV<u64> w, wr;
+      QM_LANES(l) {
+        const int h = l >> 5, jj = l & 31;
+        const int P = Pv[l], D = QM_LEAN_MAXLEN - Lv[l];
+        const int q = (on[l] && jj == 1) ? P - 1 : 0;
+        const QM_LDS(u64)* pkh = pkw + 16 * h;
+        w[l] = lean_kmer(pkh, q, k);
+        wr[l] = lean_kmer(pkh + 8, (on[l] ? P - 1 - q : 0) + D, k);
+      }
+      duo_find_ph(ix, w, wr, on, fh, ch, flb, fub, clb, cub);
+    } else {
+      LV<U4> av, fv, rv; LV<u64> bkt; LV<u32> bigv;
+      QM_LANES(l) {
+        const int sl = (l & 31) < 2 ? l : 0;                // (only lanes 0, 1, 32, 33 asked: the others read lane 0's slot and ignore it)
+        av[l] = M.pf[0][sl]; fv[l] = M.pf[1][sl]; rv[l] = M.pf[2][sl];
+        bkt[l] = (u64)bucket_hash(N.ck[l]) & ix.hmask; bigv[l] = (N.flg[l] >> 1) & 1u;
+      }
+      duo_find_rest(ix, N.ck, bigv, on, av, fv, rv, bkt, fh, ch, flb, fub, clb, cub);
+    }
     LV<bool> fb, cb; LV<u32> fm, cm, s0lb, s0ub, rlb, rub; LV<int> i0, i1;
     QM_LANES(l) { fb[l] = fh[l] != 0; cb[l] = ch[l] != 0; i0[l] = 0; i1[l] = Pv[l] > 1 ? 1 : 0; }
     half_ballot(fb, fm); half_ballot(cb, cm);
@@ -465,6 +519,9 @@ QM_DEV void duo_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, in
     nsuf[l] = (taken[l] && sn > 0) ? (int)(W.cntr[l] >> 8) : 0;
     snv[l] = sn;
   }
+  // ---- the pair this wave maps next: its images and its first probe's requests, under way while this pair is finished (the images
+  // of this pair are not needed any more: what follows works on the suffix stashes)
+  duo_prepare<PH>(ix, B, it + nw, nit, nw, par ^ 1, M, N);
   // ---- hitsToMappingsSimple (HitManager.cpp:691-882) for both mates at once, lane j of a half = suffix j of its stash (lean_h2m): a
   // transcript survives when it was seen in every interval, represented by the entry with the smallest position (the earlier interval
   // in processing order on ties); survivors go out in ascending transcript order
@@ -524,69 +581,9 @@ QM_DEV void duo_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, in
     wave_fence();
     QM_LANES(l) { if (keepv[l]) M.lst[l >> 5][slot[l]] = elem[l]; }
     wave_fence();
-    const int maxHits = B.max_num_hits;
-    LV<u64> mine, partner; LV<bool> fnd;
-    QM_LANES(l) {
-      const int h = l >> 5, i = l & 31;
-      mine[l] = M.lst[h][i < (h ? cntB : cntA) ? i : 0];
-      partner[l] = 0; fnd[l] = false;
-    }
-    if (cntA > 0) {
-      for (int jj = 0; jj < cntB; ++jj) {
-        QM_LANES(l) {
-          const u64 f = M.lst[1][jj];
-          if (l < cntA && el_tid(f) == el_tid(mine[l])) { partner[l] = f; fnd[l] = true; }
-        }
-      }
-    }
-    const int nm = popc64(ballot(fnd));
-    const int tooMany = nm > maxHits ? 1 : 0;               // :1233-1234
-    LV<bool> kp; LV<u64> w1;
-    int cnt = 0;
-    if (!tooMany && nm > 0) {
-      QM_LANES(l) {
-        bool kq = fnd[l];
-        if (kq && B.no_dovetail) {                          // RapMapSAMapper.cpp:684-698 on the hit paired_hit() would make
-          const int s1 = el_pos(mine[l]) > 0 ? el_pos(mine[l]) : 0, s2 = el_pos(partner[l]) > 0 ? el_pos(partner[l]) : 0;
-          const bool fwd = !el_rc(mine[l]), mfwd = !el_rc(partner[l]);
-          if (fwd != mfwd && ((fwd && s1 > s2) || (mfwd && s2 > s1))) kq = false;
-        }
-        kp[l] = kq; w1[l] = partner[l];
-      }
-      ctr.pe += (u32)nm;
-    } else {
-      const int no = cntA + cntB;
-      const int keepAll = (!tooMany && no > 0 && no <= maxHits && !B.no_orphans) ? 1 : 0;   // RapMapSAMapper.cpp:534-551
-      if (!tooMany && no > 0) ctr.se += (u32)no;
-      QM_LANES(l) {
-        const int h = l >> 5, i = l & 31;
-        bool kq = keepAll && i < (h ? cntB : cntA);
-        // --noDovetail on orphans: matePos = 0, mateIsFwd = true (unit_merge, the oracle): a reverse-strand hit left of the transcript's start
-        if (kq && B.no_dovetail && el_rc(mine[l]) && el_pos(mine[l]) < 0) kq = false;
-        kp[l] = kq; w1[l] = QM_DUO_ORPHAN | (u64)(h ? 2 : 1);
-      }
-    }
-    const u64 kmask = ballot(kp);
-    cnt = popc64(kmask);
-    long long base = 0;
-    if (cnt > 0) {
-      const int nwd = 2 * cnt;
-      if (wa.base < 0 || wa.used + nwd > QM_LEAN_CHUNK) {
-        LV<u64> bv;
-        QM_LANES(l) { bv[l] = 0; if (l == 0) bv[l] = atomic_add_u64(B.cursor, (u64)QM_LEAN_CHUNK); }
-        wa.base = (long long)read_lane(bv, 0); wa.used = 0;
-      }
-      base = wa.base + wa.used;
-      if (base + nwd > B.lists_cap) { QM_LANES(l) { if (l == 0) *B.status |= 1; } cnt = 0; base = 0; }
-      else wa.used += nwd;
-    }
-    if (cnt > 0) {
-      QM_LANES(l) {
-        if (kp[l]) { const int rk = popc64(kmask & lanemask_lt(l)); B.lists[base + 2 * rk] = mine[l]; B.lists[base + 2 * rk + 1] = w1[l]; }
-      }
-    }
-    ctr.reads += 1; ctr.tooMany += (u32)tooMany; ctr.tot += (u32)cnt; ctr.mapped += cnt > 0 ? 1u : 0u;
-    QM_LANES(l) { if (l == 0) { B.pair_cnt[it] = (u32)cnt; B.lcnt[r0] = QM_LCNT_PAIR; B.loff[r0] = base; } }
+    PairCtr d;
+    pair_merge(B, it, (const QM_LDS(u64)*)&M.lst[0][0], cntA, cntB, wa, d);
+    ctr.pe += d.pe; ctr.se += d.se; ctr.tot += d.tot; ctr.reads += d.reads; ctr.tooMany += d.tooMany; ctr.mapped += d.mapped;
     return;
   }
   // ---- a mate was left to the general kernel (or the caller wants lists): the mapped mates' lists per read (finish_read), the others marked

@@ -842,6 +842,8 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
   // serialises them -- 301 M pairs/s against qm_lean_kernel's 323, profiles/r06/exp_mix.txt)
   static const bool duoPh = [] { const char* e = getenv("QM_DUO_PH"); return e && atoi(e) != 0; }();
   const bool useDuo = useLean && !duoOff && !rq.noDuo && !(c->flags & QM_CTX_NO_PAIR_KERNEL) && paired && ns == 2 && (!c->d_ph || duoPh);
+  // (qm_lean_kernel holds both mates of a pair in one wavefront too, but merging there was measured and dropped: that kernel is bound by the CU's scalar unit and
+  // the merge's bookkeeping cost it 1.3 ms per 10 M pairs -- 62 instead of 28 spilled scalar registers -- where stage B saved 0.5: profiles/r06/exp_mix.txt)
   const bool duoMerge = useDuo && !rq.mergeOnly && !rq.stageView;
   if (duoMerge) { if ((rc = ensure(c->d_cnt, c->capCnt, n + 1))) return rc; }
   unsigned* gslots = nullptr; int ngslots = 0;

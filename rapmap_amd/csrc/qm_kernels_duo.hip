@@ -32,8 +32,14 @@ __global__ __launch_bounds__(256, 8) void qm_duo_kernel(DevIndex ix_, ReadBatch 
   duo_stage_offsets(B, gw + nw, nit, M, 1);
   lds_dma_wait();
   int par = 0;
+  DuoNext N;
+  {
+    const int l = (int)(threadIdx.x & 63);
+    N.Lv[l] = 0; N.defv[l] = 0; N.ck[l] = 0; N.flg[l] = 0;
+  }
+  duo_prepare<PH>(ix, B, gw, nit, nw, 0, M, N);             // (every later pair is prepared by the iteration before it)
   for (int it = gw; it < nit; it += nw) {
-    duo_iter<PH, COV>(ix, B, it, nit, nw, par, M, wa, ctr);
+    duo_iter<PH, COV>(ix, B, it, nit, nw, par, M, wa, ctr, N);
     par ^= 1;
   }
   // the HitCounters of the pairs this wave merged (stage B's count pass adds the others')

@@ -202,6 +202,80 @@ QM_DEV int lean_h2m(const QM_LDS(LeanSuf)* suf, const LeanStrand& S, bool isRC, 
   return cnt;
 }
 
+struct PairCtr { u32 pe, se, tot, reads, tooMany, mapped; };   // HitCounters of a pair merged in its wavefront / of all such pairs of a wave (wave-uniform)
+
+// A pair finished in the wavefront that mapped both its mates: mergeLeftRightHits (RapMapUtils.hpp:1185-1264) + the per-pair driver
+// (RapMapSAMapper.cpp:527-551,684-701) on the two sorted lists -- unit_merge.  lst: the two lists in LDS in list order, [0, cntA) the left
+// mate's, [32, 32 + cntB) the right one's (at most 32 elements each); lane i takes left element i and looks for its transcript among the
+// right ones.  Out: pair_cnt[pair] = the pair's hits, lcnt[2 pair] = QM_LCNT_PAIR, loff[2 pair] = where its records sit in B.lists -- two
+// words per hit, {left element, right element} or {element, QM_DUO_ORPHAN | MateStatus} (duo_hit, qm_mapper.inl) --, the HitCounters into ctr.
+QM_DEV void pair_merge(const ReadBatch& B, int pair, const QM_LDS(u64)* lst, int cntA, int cntB, WaveAlloc& wa, PairCtr& ctr) {
+  ctr.pe = 0; ctr.se = 0;
+  const int maxHits = B.max_num_hits;
+  LV<u64> mine, partner; LV<bool> fnd;
+  QM_LANES(l) {
+    const int h = l >> 5, i = l & 31;
+    mine[l] = lst[32 * h + (i < (h ? cntB : cntA) ? i : 0)];
+    partner[l] = 0; fnd[l] = false;
+  }
+  if (cntA > 0) {
+    for (int jj = 0; jj < cntB; ++jj) {
+      QM_LANES(l) {
+        const u64 f = lst[32 + jj];
+        if (l < cntA && el_tid(f) == el_tid(mine[l])) { partner[l] = f; fnd[l] = true; }
+      }
+    }
+  }
+  const int nm = popc64(ballot(fnd));
+  const int tooMany = nm > maxHits ? 1 : 0;               // :1233-1234
+  LV<bool> kp; LV<u64> w1;
+  int cnt = 0;
+  if (!tooMany && nm > 0) {
+    QM_LANES(l) {
+      bool kq = fnd[l];
+      if (kq && B.no_dovetail) {                          // RapMapSAMapper.cpp:684-698 on the hit paired_hit() would make
+        const int s1 = el_pos(mine[l]) > 0 ? el_pos(mine[l]) : 0, s2 = el_pos(partner[l]) > 0 ? el_pos(partner[l]) : 0;
+        const bool fwd = !el_rc(mine[l]), mfwd = !el_rc(partner[l]);
+        if (fwd != mfwd && ((fwd && s1 > s2) || (mfwd && s2 > s1))) kq = false;
+      }
+      kp[l] = kq; w1[l] = partner[l];
+    }
+    ctr.pe = (u32)nm;
+  } else {
+    const int no = cntA + cntB;
+    const int keepAll = (!tooMany && no > 0 && no <= maxHits && !B.no_orphans) ? 1 : 0;   // RapMapSAMapper.cpp:534-551
+    if (!tooMany && no > 0) ctr.se = (u32)no;
+    QM_LANES(l) {
+      const int h = l >> 5, i = l & 31;
+      bool kq = keepAll && i < (h ? cntB : cntA);
+      // --noDovetail on orphans: matePos = 0, mateIsFwd = true (unit_merge, the oracle): a reverse-strand hit left of the transcript's start
+      if (kq && B.no_dovetail && el_rc(mine[l]) && el_pos(mine[l]) < 0) kq = false;
+      kp[l] = kq; w1[l] = QM_DUO_ORPHAN | (u64)(h ? 2 : 1);
+    }
+  }
+  const u64 kmask = ballot(kp);
+  cnt = popc64(kmask);
+  long long base = 0;
+  if (cnt > 0) {
+    const int nwd = 2 * cnt;
+    if (wa.base < 0 || wa.used + nwd > QM_LEAN_CHUNK) {
+      LV<u64> bv;
+      QM_LANES(l) { bv[l] = 0; if (l == 0) bv[l] = atomic_add_u64(B.cursor, (u64)QM_LEAN_CHUNK); }
+      wa.base = (long long)read_lane(bv, 0); wa.used = 0;
+    }
+    base = wa.base + wa.used;
+    if (base + nwd > B.lists_cap) { QM_LANES(l) { if (l == 0) *B.status |= 1; } cnt = 0; base = 0; }
+    else wa.used += nwd;
+  }
+  if (cnt > 0) {
+    QM_LANES(l) {
+      if (kp[l]) { const int rk = popc64(kmask & lanemask_lt(l)); B.lists[base + 2 * rk] = mine[l]; B.lists[base + 2 * rk + 1] = w1[l]; }
+    }
+  }
+  ctr.reads = 1; ctr.tooMany = (u32)tooMany; ctr.tot = (u32)cnt; ctr.mapped = cnt > 0 ? 1u : 0u;       // (this pair's share of the HitCounters: the caller adds it up)
+  QM_LANES(l) { if (l == 0) { B.pair_cnt[pair] = (u32)cnt; B.lcnt[2 * pair] = QM_LCNT_PAIR; B.loff[2 * pair] = base; } }
+}
+
 // a read for the general kernel: marked in its list-length word and counted (the host gathers the marks into a queue, like the
 // reads the general kernels set aside for the long-read pass); nothing else was written for it
 QM_DEV void lean_defer(const ReadBatch& B, int read, int why) {

@@ -160,6 +160,8 @@ QM_DEV long long load_uniform_i64(const long long* p) { return *p; }
 // before the wave reads what it asked for
 QM_DEV void lds_dma_u32(const u32* g, u32* ldsBase, int lane) { ldsBase[lane] = *g; }
 QM_DEV void lds_dma_wait() {}
+// the same for 16 bytes per lane: ldsBase + 16 * lane
+QM_DEV void lds_dma_u128(const void* g, void* ldsBase, int lane) { __builtin_memcpy((unsigned char*)ldsBase + 16 * lane, g, 16); }
 QM_DEV void load_32(const void* p, U4& a, U4& b) { a = load_16(p); b = load_16((const unsigned char*)p + 16); }
 QM_DEV void load_16x2(const void* p, const void* q, U4& a, U4& b) { a = load_16(p); b = load_16(q); }
 QM_DEV void load_8_16(const u64* p8, const u64* p16, u64& a, U4& b) { a = *p8; b = load_16(p16); }
@@ -281,6 +283,11 @@ QM_DEV long long load_uniform_i64(const long long* p) {
 QM_DEV void lds_dma_u32(const u32* g, u32* ldsBase, int) {
   typedef const u32 __attribute__((address_space(1)))* gptr; typedef u32 __attribute__((address_space(3)))* lptr;
   __builtin_amdgcn_global_load_lds((gptr)(unsigned long long)g, (lptr)(unsigned)(unsigned long long)ldsBase, 4, 0, 0);
+}
+// global_load_lds_dwordx4 (gfx950): 16 bytes per lane to ldsBase + 16 * lane id
+QM_DEV void lds_dma_u128(const void* g, void* ldsBase, int) {
+  typedef const u32 __attribute__((address_space(1)))* gptr; typedef u32 __attribute__((address_space(3)))* lptr;
+  __builtin_amdgcn_global_load_lds((gptr)(unsigned long long)g, (lptr)(unsigned)(unsigned long long)ldsBase, 16, 0, 0);
 }
 QM_DEV void lds_dma_wait() { __builtin_amdgcn_s_waitcnt(0x0F70); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }   // vmcnt(0)
 // one 16-byte load that the compiler cannot split into a key load plus a dependent value load

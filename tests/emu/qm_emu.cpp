@@ -323,6 +323,7 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
     // kernel's word for word; the reads it marks are the general kernel's.  Twice: with the merge (fused calls) and without
     // (pair_cnt == null: lists only).
     for (int pass = 0; pass < 2; ++pass) {
+      const char* kname = "pair kernel";
       std::vector<u32> lcnt2(nreads + 1, 0); std::vector<long long> loff2(nreads + 1, 0); std::vector<u32> pcnt(nunits + 1, 0xdeadbeefu);
       std::vector<u64> lists2((size_t)cap, 0);
       u64 scal2[QM_SC_WORDS]; memset(scal2, 0, sizeof(scal2)); int status2 = 0;
@@ -343,9 +344,11 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
         dc[w] = DuoCtr{0, 0, 0, 0, 0, 0};
         duo_stage_offsets(Lb, (int)w, (int)nit, M, 0); duo_stage_chars(Lb, (int)w, (int)nit, M, 0); duo_stage_offsets(Lb, (int)(w + NW), (int)nit, M, 1);
         int par = 0;
+        static DuoNext Nx; memset(&Nx, 0, sizeof(Nx));
+        if (ix.ph) duo_prepare<true>(ix, Lb, (int)w, (int)nit, (int)NW, 0, M, Nx); else duo_prepare<false>(ix, Lb, (int)w, (int)nit, (int)NW, 0, M, Nx);
         for (long long it = w; it < nit; it += NW) {
-          if (B.quasi_cov > 0.0) { if (ix.ph) duo_iter<true, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl, dc[w]); else duo_iter<false, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl, dc[w]); }
-          else { if (ix.ph) duo_iter<true, false>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl, dc[w]); else duo_iter<false, false>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl, dc[w]); }
+          if (B.quasi_cov > 0.0) { if (ix.ph) duo_iter<true, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl, dc[w], Nx); else duo_iter<false, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl, dc[w], Nx); }
+          else { if (ix.ph) duo_iter<true, false>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl, dc[w], Nx); else duo_iter<false, false>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl, dc[w], Nx); }
           par ^= 1;
         }
       }
@@ -359,7 +362,7 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
       for (long long u = 0; u < nunits; ++u) {
         if (lcnt2[2 * u] == QM_LCNT_PAIR) {
           ++merged;
-          if (pass == 1 || o->fuzzy) { if (bad < 5) fprintf(stderr, "[qm emu] pair kernel: pair %lld merged although it may not be\n", u); ++bad; continue; }
+          if (pass == 1 || o->fuzzy) { if (bad < 5) fprintf(stderr, "[qm emu] %s: pair %lld merged although it may not be\n", kname, u); ++bad; continue; }
           UnitCounters uc = {0, 0, 0, 0, 0, 0};
           const int cg = unit_merge(Pg, u, nullptr, 0, &uc);
           want.pe += uc.pe; want.se += uc.se; want.tot += uc.tot; want.reads += uc.reads; want.tooMany += uc.tooMany; want.mapped += uc.mapped;
@@ -369,7 +372,7 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
             unit_merge(Pg, u, hg.data(), cg, nullptr); unit_merge(Pd, u, hd.data(), cg, nullptr);
             same = memcmp(hg.data(), hd.data(), sizeof(qm_hit) * (size_t)cg) == 0;
           }
-          if (!same) { if (bad < 5) fprintf(stderr, "[qm emu] pair kernel: pair %lld differs (%u hits vs %d)\n", u, pcnt[u], cg); ++bad; }
+          if (!same) { if (bad < 5) fprintf(stderr, "[qm emu] %s: pair %lld differs (%u hits vs %d)\n", kname, u, pcnt[u], cg); ++bad; }
           continue;
         }
         for (int m = 0; m < 2; ++m) {
@@ -378,18 +381,18 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
           bool same = lcnt2[r] == lcnt[r];
           const long long nwd = lcnt[r] & 0x7fffffffu;
           for (long long t = 0; same && t < nwd; ++t) same = lists2[loff2[r] + t] == lists[loff[r] + t];
-          if (!same) { if (bad < 5) fprintf(stderr, "[qm emu] pair kernel: read %lld differs (words %u vs %u)\n", r, lcnt2[r], lcnt[r]); ++bad; }
+          if (!same) { if (bad < 5) fprintf(stderr, "[qm emu] %s: read %lld differs (words %u vs %u)\n", kname, r, lcnt2[r], lcnt[r]); ++bad; }
         }
       }
       DuoCtr got = {0, 0, 0, 0, 0, 0};
       for (long long w = 0; w < NW; ++w) { got.pe += dc[w].pe; got.se += dc[w].se; got.tot += dc[w].tot; got.reads += dc[w].reads; got.tooMany += dc[w].tooMany; got.mapped += dc[w].mapped; }
       if (got.pe != want.pe || got.se != want.se || got.tot != want.tot || got.reads != want.reads || got.tooMany != want.tooMany || got.mapped != want.mapped) {
-        fprintf(stderr, "[qm emu] pair kernel: counters of the merged pairs %u %u %u %u %u %u, stage B says %llu %llu %llu %llu %llu %llu\n", got.pe, got.se, got.tot, got.reads, got.tooMany, got.mapped,
+        fprintf(stderr, "[qm emu] %s: counters of the merged pairs %u %u %u %u %u %u, stage B says %llu %llu %llu %llu %llu %llu\n", kname, got.pe, got.se, got.tot, got.reads, got.tooMany, got.mapped,
                 (unsigned long long)want.pe, (unsigned long long)want.se, (unsigned long long)want.tot, (unsigned long long)want.reads, (unsigned long long)want.tooMany, (unsigned long long)want.mapped);
         ++bad;
       }
-      if ((long long)scal2[QM_SC_LEANQ] != deferred) { fprintf(stderr, "[qm emu] pair kernel: %lld marks, counter says %llu\n", deferred, (unsigned long long)scal2[QM_SC_LEANQ]); ++bad; }
-      if (getenv("QM_EMU_LEAN_STATS")) fprintf(stderr, "[qm emu] pair kernel (pass %d) took %lld of %lld reads, merged %lld of %lld pairs\n", pass, nreads - deferred, nreads, merged, nunits);
+      if ((long long)scal2[QM_SC_LEANQ] != deferred) { fprintf(stderr, "[qm emu] %s: %lld marks, counter says %llu\n", kname, deferred, (unsigned long long)scal2[QM_SC_LEANQ]); ++bad; }
+      if (getenv("QM_EMU_LEAN_STATS")) fprintf(stderr, "[qm emu] %s (pass %d) took %lld of %lld reads, merged %lld of %lld pairs\n", kname, pass, nreads - deferred, nreads, merged, nunits);
       if (bad || (status2 & ~1)) status |= 32;
     }
   }
