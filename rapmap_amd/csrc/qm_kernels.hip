@@ -354,24 +354,126 @@ __global__ void build_sainfo_kernel(const u32* SA, long long nSA, const u32* off
   }
 }
 
-// the 96 text characters behind the k-mer of every suffix, packed (saext_entry): one-trip MMP extensions
-__global__ void build_saext_kernel(const unsigned char* text, long long n, const u32* SA, long long nSA, int k, const SaInfo* sainfo, SaExt* out) {
+// ---- the extension tables (saext_entry / saext2_entry / sanext_entry of every suffix-array entry).  Round 5 built them a thread per
+// suffix and a byte load per character: 399 ms and 1.36 TB fetched to write the 8.3 GB of SaExt (82 sectors per entry).  Round 6 packs
+// the text ONCE -- 2 bits per character in the entries' own layout (first character in the top bits of a word) plus one validity bit per
+// character (A C G T) -- and an entry is then a funnel shift out of four to eight consecutive words of that image (65 + 33 MB for config
+// 2: it stays in the last-level cache) and a count of leading validity bits: two or three sectors per entry instead of 82.
+// T[w]: characters [32 w, 32 w + 32); V[w]: characters [64 w, 64 w + 64), bit 63 - t = character 64 w + t is A C G T and below n
+__global__ void pack_text_kernel(const unsigned char* text, long long n, u64* T, u64* V, long long nv64) {
+  long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; w < nv64; w += stride) {
+    u64 t0 = 0, t1 = 0, v = 0;
+    const long long base = 64 * w;
+#pragma unroll 4
+    for (int t = 0; t < 64; t += 8) {
+      u64 ch = 0;
+      if (base + t + 8 <= n) ch = load_u64_unaligned(text + base + t);
+      else { for (int b = 0; b < 8; ++b) if (base + t + b < n) ch |= (u64)text[base + t + b] << (8 * b); }
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const unsigned c = (unsigned)(ch >> (8 * b)) & 0xffu;
+        const bool ok = c == 'A' || c == 'C' || c == 'G' || c == 'T';
+        const u64 x = (c >> 1) & 3u;
+        const u64 code = ok ? (x ^ (x >> 1)) : 0ULL;
+        const int tt = t + b;
+        if (tt < 32) t0 |= code << (62 - 2 * tt); else t1 |= code << (62 - 2 * (tt - 32));
+        v |= (u64)(ok ? 1 : 0) << (63 - tt);
+      }
+    }
+    T[2 * w] = t0; T[2 * w + 1] = t1; V[w] = v;
+  }
+}
+// NW words of packed characters from character p on (the image is padded with zero words), and how many of the first `bases` are valid
+template <int NW>
+QM_DEV int packed_entry_words(const u64* T, const u64* V, long long p, int bases, u64* w) {
+  const long long j = p >> 5; const int sh = 2 * (int)(p & 31);
+  u64 prev = T[j];
+#pragma unroll
+  for (int t = 0; t < NW; ++t) { const u64 nx = T[j + t + 1]; w[t] = (prev << sh) | ((nx >> 1) >> (63 - sh)); prev = nx; }
+  // leading valid characters: validity bits from p on, 64 at a time
+  const long long jv = p >> 6; const int sv = (int)(p & 63);
+  int nv = 0;
+  u64 pv = V[jv];
+#pragma unroll
+  for (int t = 0; t < (64 * NW / 2 + 63) / 64 + 1; ++t) {           // (NW words = 32 NW characters)
+    const u64 nx = V[jv + t + 1];
+    const u64 x = (pv << sv) | ((nx >> 1) >> (63 - sv));
+    const int run = x == ~0ULL ? 64 : __builtin_clzll(~x);
+    if (nv == 64 * t) nv += run;
+    pv = nx;
+  }
+  nv = nv < bases ? nv : bases;
+#pragma unroll
+  for (int t = 0; t < NW; ++t) {
+    const int keep = nv - 32 * t;
+    w[t] = keep >= 32 ? w[t] : (keep <= 0 ? 0ULL : (w[t] & (~0ULL << (64 - 2 * keep))));
+  }
+  return nv;
+}
+__global__ void build_saext_kernel(const u64* T, const u64* V, long long n, const u32* SA, long long nSA, int k, const SaInfo* sainfo, SaExt* out) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long stride = (long long)gridDim.x * blockDim.x;
-  for (; i < nSA; i += stride) { const SaInfo si = sainfo[i]; out[i] = saext_entry(text, n, (long long)SA[i] + k, si.tid, si.pos); }
+  for (; i < nSA; i += stride) {
+    const SaInfo si = sainfo[i];
+    long long p = (long long)SA[i] + k; if (p > n) p = n;            // (behind the text: nothing valid)
+    SaExt e; u64 w[3];
+    const int nv = packed_entry_words<3>(T, V, p, QM_EXT_BASES, w);
+    e.w[0] = w[0]; e.w[1] = w[1]; e.w[2] = w[2]; e.pos = si.pos;
+    e.tidnv = (si.tid & ((1u << QM_EXT_TID_BITS) - 1)) | ((u32)nv << QM_EXT_TID_BITS);
+    out[i] = e;
+  }
 }
-
-__global__ void build_saext2_kernel(const unsigned char* text, long long n, const u32* SA, long long nSA, int k, const SaInfo* sainfo, SaExt2* out) {
+__global__ void build_saext2_kernel(const u64* T, const u64* V, long long n, const u32* SA, long long nSA, int k, const SaInfo* sainfo, SaExt2* out) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   long long stride = (long long)gridDim.x * blockDim.x;
-  for (; i < nSA; i += stride) { const SaInfo si = sainfo[i]; out[i] = saext2_entry(text, n, (long long)SA[i] + k, si.tid, si.pos); }
+  for (; i < nSA; i += stride) {
+    const SaInfo si = sainfo[i];
+    long long p = (long long)SA[i] + k; if (p > n) p = n;
+    SaExt2 e; u64 w[7];
+    const int nv = packed_entry_words<7>(T, V, p, QM_EXT2_BASES, w);
+#pragma unroll
+    for (int t = 0; t < 7; ++t) e.w[t] = w[t];
+    e.pos = si.pos;
+    e.tidnv = (si.tid & ((1u << QM_EXT2_TID_BITS) - 1)) | ((u32)nv << QM_EXT2_TID_BITS);
+    out[i] = e;
+  }
 }
-
 // -s: the text characters behind the k-mer of every suffix (sanext_entry)
-__global__ void build_sanext_kernel(const unsigned char* text, long long n, const u32* SA, long long nSA, int k, u32* out) {
+__global__ void build_sanext_kernel(const u64* T, const u64* V, long long n, const u32* SA, long long nSA, int k, u32* out) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (; i < nSA; i += stride) out[i] = sanext_entry(text, n, (long long)SA[i] + k);
+  for (; i < nSA; i += stride) {
+    long long p = (long long)SA[i] + k; if (p > n) p = n;
+    u64 w[1];
+    const int nv = packed_entry_words<1>(T, V, p, QM_NEXT_BASES, w);
+    out[i] = (u32)(w[0] >> 36) | ((u32)nv << 28);                      // (14 characters at 2 bits: the top 28 bits of the word, in bits 27 .. 0)
+  }
+}
+// the byte-per-character builders of rounds 3-5: kept as the reference the packed builders are checked against (QM_TABLE_CHECK=1: tests)
+__global__ void build_saext_ref_kernel(const unsigned char* text, long long n, const u32* SA, long long nSA, int k, const SaInfo* sainfo, const SaExt* got, u64* bad) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < nSA; i += stride) {
+    const SaInfo si = sainfo[i]; const SaExt e = saext_entry(text, n, (long long)SA[i] + k, si.tid, si.pos); const SaExt g = got[i];
+    if (e.w[0] != g.w[0] || e.w[1] != g.w[1] || e.w[2] != g.w[2] || e.tidnv != g.tidnv || e.pos != g.pos) atomicAdd((unsigned long long*)bad, 1ULL);
+  }
+}
+__global__ void build_saext2_ref_kernel(const unsigned char* text, long long n, const u32* SA, long long nSA, int k, const SaInfo* sainfo, const SaExt2* got, u64* bad) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < nSA; i += stride) {
+    const SaInfo si = sainfo[i]; const SaExt2 e = saext2_entry(text, n, (long long)SA[i] + k, si.tid, si.pos); const SaExt2 g = got[i];
+    bool same = e.tidnv == g.tidnv && e.pos == g.pos;
+    for (int t = 0; t < 7; ++t) same = same && e.w[t] == g.w[t];
+    if (!same) atomicAdd((unsigned long long*)bad, 1ULL);
+  }
+}
+__global__ void build_sanext_ref_kernel(const unsigned char* text, long long n, const u32* SA, long long nSA, int k, const u32* got, u64* bad) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < nSA; i += stride) if (sanext_entry(text, n, (long long)SA[i] + k) != got[i]) atomicAdd((unsigned long long*)bad, 1ULL);
 }
 
 // records: K x {u64 key, u32 lb, u32 ub}: the records of hash.bin (a BigSA index's int64 pairs narrowed by the loader)
@@ -488,18 +590,76 @@ hipError_t qmk_build_sainfo(const unsigned int* SA, long long nSA, const unsigne
   return hipGetLastError();
 }
 
-hipError_t qmk_build_saext(const unsigned char* text, long long n, const unsigned int* SA, long long nSA, int k, const void* sainfo, void* out, hipStream_t st) {
-  if (nSA > 0) hipLaunchKernelGGL(build_saext_kernel, dim3(8192), dim3(256), 0, st, text, n, SA, nSA, k, (const SaInfo*)sainfo, (SaExt*)out);
+// the packed image of the text for the three builders below: allocated, filled and (after the builder) freed per call -- a replica builds
+// each table once.  -> T (n / 32 + 16 words), V (n / 64 + 8 words) in one allocation
+static hipError_t packed_text(const unsigned char* text, long long n, u64** T, u64** V, hipStream_t st) {
+  const long long nv64 = (n + 63) / 64, nT = 2 * nv64 + 16, nV = nv64 + 8;
+  u64* p = nullptr;
+  hipError_t e = hipMalloc((void**)&p, (size_t)(nT + nV) * sizeof(u64));
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(p, 0, (size_t)(nT + nV) * sizeof(u64), st);
+  if (e != hipSuccess) { hipFree(p); return e; }
+  *T = p; *V = p + nT;
+  if (nv64 > 0) hipLaunchKernelGGL(pack_text_kernel, dim3((unsigned)((nv64 + 255) / 256 < 16384 ? (nv64 + 255) / 256 : 16384)), dim3(256), 0, st, text, n, *T, *V, nv64);
   return hipGetLastError();
 }
+static bool table_check() { const char* e = getenv("QM_TABLE_CHECK"); return e && atoi(e) != 0; }   // (read at every build: tests switch it on for one context)
+static hipError_t table_verdict(u64* d_bad, hipStream_t st) {      // QM_TABLE_CHECK: entries that differ from the byte-per-character builder's
+  unsigned long long bad = 0;
+  hipError_t e = hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  hipFree(d_bad);
+  if (e == hipSuccess && bad) { fprintf(stderr, "[qm] QM_TABLE_CHECK: %llu table entries differ from the reference builder's\n", bad); return hipErrorAssert; }
+  return e;
+}
+hipError_t qmk_build_saext(const unsigned char* text, long long n, const unsigned int* SA, long long nSA, int k, const void* sainfo, void* out, hipStream_t st) {
+  if (nSA <= 0) return hipSuccess;
+  u64 *T = nullptr, *V = nullptr;
+  hipError_t e = packed_text(text, n, &T, &V, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(build_saext_kernel, dim3(8192), dim3(256), 0, st, (const u64*)T, (const u64*)V, n, SA, nSA, k, (const SaInfo*)sainfo, (SaExt*)out);
+  e = hipGetLastError();
+  if (e == hipSuccess && table_check()) {
+    u64* d_bad = nullptr; hipMalloc((void**)&d_bad, 8); hipMemsetAsync(d_bad, 0, 8, st);
+    hipLaunchKernelGGL(build_saext_ref_kernel, dim3(8192), dim3(256), 0, st, text, n, SA, nSA, k, (const SaInfo*)sainfo, (const SaExt*)out, d_bad);
+    e = table_verdict(d_bad, st);
+  }
+  hipError_t e2 = hipStreamSynchronize(st);                  // (the image is freed: the builder has to be through)
+  hipFree(T);
+  return e != hipSuccess ? e : e2;
+}
 hipError_t qmk_build_saext2(const unsigned char* text, long long n, const unsigned int* SA, long long nSA, int k, const void* sainfo, void* out, hipStream_t st) {
-  if (nSA > 0) hipLaunchKernelGGL(build_saext2_kernel, dim3(8192), dim3(256), 0, st, text, n, SA, nSA, k, (const SaInfo*)sainfo, (SaExt2*)out);
-  return hipGetLastError();
+  if (nSA <= 0) return hipSuccess;
+  u64 *T = nullptr, *V = nullptr;
+  hipError_t e = packed_text(text, n, &T, &V, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(build_saext2_kernel, dim3(8192), dim3(256), 0, st, (const u64*)T, (const u64*)V, n, SA, nSA, k, (const SaInfo*)sainfo, (SaExt2*)out);
+  e = hipGetLastError();
+  if (e == hipSuccess && table_check()) {
+    u64* d_bad = nullptr; hipMalloc((void**)&d_bad, 8); hipMemsetAsync(d_bad, 0, 8, st);
+    hipLaunchKernelGGL(build_saext2_ref_kernel, dim3(8192), dim3(256), 0, st, text, n, SA, nSA, k, (const SaInfo*)sainfo, (const SaExt2*)out, d_bad);
+    e = table_verdict(d_bad, st);
+  }
+  hipError_t e2 = hipStreamSynchronize(st);
+  hipFree(T);
+  return e != hipSuccess ? e : e2;
 }
 size_t qmk_saext2_bytes(void) { return sizeof(SaExt2); }
 hipError_t qmk_build_sanext(const unsigned char* text, long long n, const unsigned int* SA, long long nSA, int k, unsigned int* out, hipStream_t st) {
-  if (nSA > 0) hipLaunchKernelGGL(build_sanext_kernel, dim3(4096), dim3(256), 0, st, text, n, SA, nSA, k, out);
-  return hipGetLastError();
+  if (nSA <= 0) return hipSuccess;
+  u64 *T = nullptr, *V = nullptr;
+  hipError_t e = packed_text(text, n, &T, &V, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(build_sanext_kernel, dim3(4096), dim3(256), 0, st, (const u64*)T, (const u64*)V, n, SA, nSA, k, out);
+  e = hipGetLastError();
+  if (e == hipSuccess && table_check()) {
+    u64* d_bad = nullptr; hipMalloc((void**)&d_bad, 8); hipMemsetAsync(d_bad, 0, 8, st);
+    hipLaunchKernelGGL(build_sanext_ref_kernel, dim3(4096), dim3(256), 0, st, text, n, SA, nSA, k, (const u32*)out, d_bad);
+    e = table_verdict(d_bad, st);
+  }
+  hipError_t e2 = hipStreamSynchronize(st);
+  hipFree(T);
+  return e != hipSuccess ? e : e2;
 }
 hipError_t qmk_build_slots(const void* recs, long long K, void* slots, unsigned long long cap, int k, hipStream_t st) {
   hipError_t e = hipMemsetAsync(slots, 0xff, cap * sizeof(Bucket), st);

@@ -1031,3 +1031,27 @@ def test_wide_lean_kernel_single_end_and_paired(synth_medium, synth_medium_ph, o
             assert_hits_equal(rs.hit_offsets, rs.hits, gs.hit_offsets, gs.hits, "wide lean, single-end %s compact=%s" % (oo, compact))
             assert rs.counters == gs.counters
         mp.close()
+
+
+@pytest.mark.gpu
+def test_extension_tables_match_the_byte_per_character_builders(synth_medium, oracle_mod, monkeypatch):
+    """round 6 builds SaExt / SaExt2 / sanext out of a 2-bit image of the text (two or three sectors per entry instead of 82); QM_TABLE_CHECK=1
+    holds every entry against the byte-per-character builders of rounds 3-5 on the device and fails the build on a difference"""
+    import rapmap_amd as ra
+    monkeypatch.setenv("QM_TABLE_CHECK", "1")
+    ix, orc = load_oracle(synth_medium["idx"])
+    qi = ra.QuasiIndex(synth_medium["idx"])
+    mp = ra.QuasiMapper(qi, 0, wide_reads=True)            # SaExt with the replica, SaExt2 because asked
+    n = 2000
+    q1, q2, o = synth_medium["seq1"][: n * 100], synth_medium["seq2"][: n * 100], synth_medium["off"][: n + 1]
+    gr = mp.map_pairs(q1, o, q2, o, opts=ra.default_opts(sel_aln=1))       # sanext at the first -s call
+    res = orc.map_pairs(q1, o, q2, o, opts=oracle_mod.default_opts(selAln=1), nthreads=4)
+    assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "-s with checked tables")
+    # the wide table is there (a build that failed its check leaves the replica without it, and reads of 150 characters with the general kernel)
+    from rapmap_amd import synth
+    s1, s2, off, _ = synth.make_reads(synth_medium["txps"], 500, seed=77, read_len=150, err=0.01)
+    gw = mp.map_pairs(s1, off, s2, off)
+    rw = orc.map_pairs(s1, off, s2, off, nthreads=4)
+    assert_hits_equal(rw.hit_offsets, rw.hits, gw.hit_offsets, gw.hits, "150 bp with checked tables")
+    assert mp.stat(3) == 2 * 500, "the wide lean kernel did not run: no SaExt2"
+    mp.close(); qi.close()
