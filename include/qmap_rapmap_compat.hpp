@@ -621,8 +621,8 @@ struct Chunk {
   const void* firstRead{nullptr};      // the group a prefetch_async was issued for (prefetch / wait recognise it)
   uint64_t settings{0}; const void* owner{nullptr};   // the collector that sent the group and the state of its settings then
   void release() { if (batch && svc) svc->release(batch); batch = nullptr; nreads = 0; }
-  void bind(Service* s) { if (svc != s) { if (svc) svc->detach(); svc = s; if (svc) svc->attach(); } }
-  ~Chunk() { release(); if (svc) svc->detach(); }
+  void bind(Service* s) { svc = s; }       // (the service counts COLLECTORS, not chunks: SACollector::count_in -- a collector holds two or three chunk objects)
+  ~Chunk() { release(); }
 };
 inline uint64_t next_gen() { static std::atomic<uint64_t> g{1}; return g++; }
 
@@ -737,6 +737,9 @@ class SACollector {
   int32_t getMaxMMPExtension() const { return maxMMPExtension_; }
 
   explicit SACollector(RapMapIndexT* rmi) : rmi_(rmi) {}
+  ~SACollector() { pending_.clear(); chunk_.reset(); spare_.clear(); count_in(nullptr); }   // (the groups first, then this collector's place among the service's workers)
+  SACollector(const SACollector&) = delete;
+  SACollector& operator=(const SACollector&) = delete;
 
   // ---- the added call (see the head of this file): map a whole chunk in one fused GPU pass --------------------------
   // PairRange: anything iterable whose elements have .first.seq and .second.seq (fastx_parser's ReadPair chunk, a
@@ -770,15 +773,16 @@ class SACollector {
     if (pending_.empty()) throw qmap::Error(QM_E_STATE, "SACollector::wait(): no group was sent with prefetch_async");
     std::unique_ptr<Chunk> ch = std::move(pending_.front());
     pending_.pop_front();
-    // the group that was current is given back: its batch is released, a new generation number makes everything that was handed
-    // out of it stale, and the object itself is kept for a later group (hits and interval lists hold a pointer to it)
-    if (chunk_) { chunk_->release(); chunk_->gen = next_gen(); spare_.push_back(std::move(chunk_)); }
     if (ch->batch) {
       Batch* bt = ch->batch;
+      // (a batch that failed: the group that was current stays current, this one is dropped)
       try { ch->svc->wait_done(bt); } catch (...) { ch->batch = nullptr; throw; }
       ch->v = bt->v;
       ch->nreads = 2 * ch->nPacked;
     }
+    // the group that was current is given back: its batch is released, a new generation number makes everything that was handed
+    // out of it stale, and the object itself is kept for a later group (hits and interval lists hold a pointer to it)
+    if (chunk_) { chunk_->release(); chunk_->gen = next_gen(); spare_.push_back(std::move(chunk_)); }
     last_index().ix = rmi_->handle(); last_index().device = rmi_->device();
     chunk_ = std::move(ch);
   }
@@ -820,6 +824,7 @@ class SACollector {
       pending_.pop_back();
       // join the batch that is open (qmap::detail::Service): this group's place in the batch's page-locked input buffers ...
       Service* svc = service_of(rmi_->handle(), rmi_->device());
+      count_in(svc);
       ch->bind(svc);
       const Service::Place pl = svc->join(ch->opts, n, b1, b2);
       Batch* bt = pl.b;
@@ -921,6 +926,10 @@ class SACollector {
   std::unique_ptr<qmap::detail::Chunk> chunk_;                 // the current group
   std::deque<std::unique_ptr<qmap::detail::Chunk>> pending_;   // groups sent ahead (prefetch_async), oldest first
   std::vector<std::unique_ptr<qmap::detail::Chunk>> spare_;    // chunk objects of groups that were given back
+  // this collector counted once among its service's workers (the dispatcher closes a batch when half of them have joined), whatever the
+  // number of chunk objects it holds (current, sent ahead, spare)
+  qmap::detail::Service* counted_{nullptr};
+  void count_in(qmap::detail::Service* s) { if (counted_ != s) { if (counted_) counted_->detach(); counted_ = s; if (s) s->attach(); } }
 };
 
 // ------------------------------------------------------------------------------------------------ hitsToMappingsSimple

@@ -1,4 +1,3 @@
-import os
 """`python -m rapmap_amd quasiindex|quasimap ...` -- the reference's command line on the MI355X path.
 
 Flag names, defaults and validation follow `rapmap quasiindex` (src/RapMapSAIndexer.cpp:821-927) and
@@ -8,6 +7,7 @@ accepted like the reference accepts it: on its own it changes nothing there eith
 --selAln alone, src/RapMapSAMapper.cpp:182,410).
 """
 import argparse
+import os
 import sys
 import time
 

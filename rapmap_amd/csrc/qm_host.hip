@@ -803,7 +803,10 @@ static bool ensure_saext2(qm_ctx* c) {
 // The general kernels' per-wave scratch in device memory (QM_GSCR_U64 words, 112 KB) for a launch of `grid` blocks: one per launched
 // wave while that is no more than the waves that can be resident at once (64 per CU, generously); beyond that -- the oversubscribed
 // grids -- one per SLOT, and the waves take and return slots as they start and end (ReadBatch::gslots).  Returns the flags, or null.
+// XCDs of the device a context launches on: 32 CUs each on gfx950 (a whole MI355X: 8; its DPX / QPX / CPX partitions: 4 / 2 / 1)
+static int xcds_of(const qm_ctx* c) { const int x = c->numCU / 32; return x < 1 ? 1 : (x > 8 ? 8 : x); }
 static int gscr_for(qm_ctx* c, int grid, unsigned*& slots, int& nslots) {
+  // (64 slots per CU = 2 048 per XCD of 32 CUs, twice the 1 024 wavefronts that can be resident there, whatever the partition)
   const int64_t waves = (int64_t)grid * 4, cap = (int64_t)c->numCU * 64;
   slots = nullptr; nslots = 0;
   const char* fe = getenv("QM_GSCR_SLOTS");                  // (tests: slots for launches that would not need them)
@@ -898,7 +901,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
     B.seq1 = (const unsigned char*)d_seq1; B.off1 = (const long long*)d_off1;
     B.seq2 = (const unsigned char*)d_seq2; B.off2 = (const long long*)d_off2; B.nreads = nreads;
     B.lcnt = c->d_lcnt; B.loff = c->d_loff; B.lists = c->d_lists; B.cursor = c->d_scal; B.lists_cap = c->capLists;
-    B.status = (int*)(c->d_scal + QM_SC_STATUS); B.gscratch = c->d_gscr; B.gslots = gslots; B.ngslots = ngslots; B.skiplist = c->d_skip;
+    B.status = (int*)(c->d_scal + QM_SC_STATUS); B.gscratch = c->d_gscr; B.gslots = gslots; B.ngslots = ngslots; B.gxcd = xcds_of(c); B.skiplist = c->d_skip;
     B.lean_wide = leanWide ? 1 : 0;
     if (duoMerge) { B.pair_cnt = c->d_cnt; B.max_num_hits = o->max_num_hits; B.no_orphans = o->no_orphans; B.no_dovetail = o->no_dovetail; }
     if (wantIv) { B.iv_out = c->d_iv; B.iv_cnt = c->d_ivcnt; B.iv_off = c->d_ivoff; B.iv_cap = c->capIv; }
@@ -946,6 +949,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
         if (C.iv_cnt) { C.iv_cnt = B.iv_cnt + r0; C.iv_off = B.iv_off + r0; }
         if (C.found_out) C.found_out = B.found_out + r0;
         if (C.pair_cnt) C.pair_cnt = B.pair_cnt + u0;
+        C.read_base = r0;                                 // (what the launch calls read 0: for the skip list)
         HIPCHK(launch(C, qmk_map_grid_ex(r1 - r0, c->numCU, phc)));
       }
       feeder = nullptr;                                   // a retry finds everything resident

@@ -166,7 +166,9 @@ struct ReadBatch {
   long long lists_cap;
   u64* gscratch;           // per wave: QM_GSCR_U64 words -- of wave gw of the launch, or (gslots != null) of the slot the wave holds while it runs
   int lean_wide;           // qmk_launch_lean: the one-read-per-wavefront edition (reads of up to 256 characters)
-  u32* gslots; int ngslots; // oversubscribed grids: one flag per scratch slot (a multiple of 8: an eighth per XCD, each at least the waves that can be
+  long long read_base;     // index of this launch's read 0 in the call (chunked host-buffer calls launch per chunk with shifted arrays): for the skip list
+  int gxcd;                // ... the XCDs the slots are divided among (the device's: 8 on a whole MI355X, 4 / 2 / 1 on a DPX / QPX / CPX partition)
+  u32* gslots; int ngslots; // oversubscribed grids: one flag per scratch slot (a multiple of gxcd: a share per XCD, each at least the waves that can be
                            // resident there); a wave takes a free one of its XCD when it starts and gives it back when it ends, so the scratch is
                            // sized by residency, not by the launch
   int* status;             // sticky error flags (bit0: lists overflow, bit1: interval too wide, bit2: read too long, bit4: interval output overflow)
@@ -941,7 +943,7 @@ QM_DEV void skip_read(const ReadBatch& B, long long read, int code) {
   QM_LANES(l) {
     if (l == 0) {
       const u64 i = atomic_add_u64(B.cursor + QM_SC_SKIPCNT, 1ULL);
-      if (B.skiplist && i < QM_SKIP_CAP) B.skiplist[i] = (u64)read | ((u64)code << 56);
+      if (B.skiplist && i < QM_SKIP_CAP) B.skiplist[i] = (u64)(read + B.read_base) | ((u64)code << 56);
     }
   }
 }
@@ -1872,6 +1874,8 @@ QM_DEV void finish_read(const DevIndex& ix, const ReadBatch& B, long long read, 
     }
   } else if (bound > QM_GCAP) {        // only reachable with max_interval > 1000: this read goes without hits, and says so
     skip_read(B, read, 2);
+    // (include/qmap_mi355.h: such a read has no intervals and foundHit false, like a read the long-read pass skips)
+    QM_LANES(l) { if (l == 0) { if (B.iv_out) { B.iv_cnt[read] = 0; B.iv_off[read] = 0; } if (B.found_out) B.found_out[read] = 0; } }
   } else if (bound <= QM_CAP) {
     // the two homes of the sort buffers are two expansions of the routine: behind one set of pointers that may be LDS or
     // global every access is a FLAT instruction -- through the vector-memory path even when it lands in LDS (it was a third

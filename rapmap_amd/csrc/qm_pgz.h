@@ -337,7 +337,8 @@ class PGz {
           if (quit_) return;
           if (!free_.empty()) { o = free_.back(); free_.pop_back(); } else { all_.emplace_back(new Out()); o = all_.back().get(); } }
         o->len = 0;
-        const bool ok = memberOpen_ ? round(*o) : true;
+        bool ok = true;
+        try { ok = memberOpen_ ? round(*o) : true; } catch (const std::bad_alloc&) { err_ = "out of memory while inflating"; ok = false; }
         const bool last = !ok || !memberOpen_;
         { std::lock_guard<std::mutex> lk(mu_);
           if (!ok) failed_ = true;
@@ -403,6 +404,10 @@ class PGz {
       Sink<uint16_t> S{w.sym(), 0, w.symCap, 0};
       uint64_t e = 0;
       const int st = inflate_blocks<uint16_t>(B, limit, S, e);
+      // the symbol buffer is full: this WAS a block start (a false one fails within a few symbols), and the data deflates better than the
+      // buffer was sized for (scanning on from here decoded every true block start of the stretch to the cap and threw it away).
+      // Leave the stretch to the serial redo, whose buffer grows with its output
+      if (st == -2) return;
       if (st < 0 || S.n < 1024) continue;            // (a real block of text is kilobytes)
       w.found = true; w.start = b; w.end = e; w.status = st; w.n = S.n;
       return;
@@ -413,7 +418,7 @@ class PGz {
     const double tA = now();
     const uint64_t total = (uint64_t)(end_ - base_) * 8;
     const uint64_t stretch = stretchBytes_ * 8;
-    int T = T_;
+    int T = serial_ ? 1 : T_;
     while (T > 1 && bit_ + (uint64_t)(T - 1) * stretch + 8 * 65536 >= total) --T;      // no stretch that starts in the file's last bytes
     Work* W = W_.get();
     for (int i = 0; i < T; ++i) { W[(size_t)i].found = false; W[(size_t)i].asBytes = false; W[(size_t)i].badRef = false; W[(size_t)i].n = 0; W[(size_t)i].status = -1; }
@@ -435,13 +440,15 @@ class PGz {
         break;
       }
     };
-    th.emplace_back(run0);
+    std::atomic<bool> oom{false};                    // (Buf::need throws: an exception that leaves a thread's function ends the process)
+    th.emplace_back([&]() { try { run0(); } catch (const std::bad_alloc&) { oom = true; } });
     for (int i = 1; i < T; ++i) th.emplace_back([&, i]() {
       const uint64_t from = bit_ + (uint64_t)i * stretch, lim = std::min(total, bit_ + (uint64_t)(i + 1) * stretch);
       W[(size_t)i].from = from;
-      speculate(W[(size_t)i], from, lim, lim);
+      try { speculate(W[(size_t)i], from, lim, lim); } catch (const std::bad_alloc&) { W[(size_t)i].found = false; }   // (no buffer for the guess: the serial redo takes the stretch)
     });
     for (auto& t : th) t.join();
+    if (oom) { err_ = "out of memory while inflating"; return false; }
     const double tB = now();
     if (W[0].status < 0) { err_ = "corrupt deflate data"; return false; }
     // stitch: a guessed stretch counts if the one in front arrived exactly where it started; else it is decoded again, as bytes
@@ -481,6 +488,9 @@ class PGz {
     for (int i = 0; i < used; ++i) { at[(size_t)i] = totalOut; totalOut += W[(size_t)i].n; }
     O.d.need(totalOut);
     O.len = totalOut;
+    // guesses that keep failing (data that is not text: the block-start test rejects it; data that deflates 10:1 and more: the symbol buffers
+    // overflow) cost a scan or a decode per stretch for nothing: from then on one stretch per round, decoded from the known position
+    if (!serial_ && rounds >= 2 && accepted * 2 < redone) serial_ = true;
     th.clear();
     for (int i = 0; i < used; ++i) th.emplace_back([&, i]() {
       Work& w = W[(size_t)i];
@@ -532,6 +542,7 @@ class PGz {
   std::thread producer_; std::mutex mu_; std::condition_variable cvReady_, cvFree_;
   std::vector<std::unique_ptr<Out>> all_; std::vector<Out*> ready_, free_; Out* cur_ = nullptr; size_t curPos_ = 0;
   bool failed_ = false, done_ = false, quit_ = false;
+  bool serial_ = false;                              // the guesses keep failing: one stretch per round from here on
   std::unique_ptr<Work[]> W_;                        // the workers' buffers, kept from round to round
   std::string err_;
 };

@@ -48,15 +48,17 @@ __global__ __launch_bounds__(64 * WavesPerBlock<NS>::value, WPS) void qm_read_ke
   if (B.gslots) {
     int s = 0;
     if ((threadIdx.x & 63) == 0) {
-      const unsigned per = (unsigned)B.ngslots >> 3;
-      const unsigned base = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) * per;      // HW_REG_XCC_ID, bits 3:0
+      const unsigned nx = B.gxcd > 0 ? (unsigned)B.gxcd : 1u;                            // (the host derives it from the device it launches on: gscr_for)
+      const unsigned per = (unsigned)B.ngslots / nx;
+      const unsigned base = ((__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) % nx) * per;   // HW_REG_XCC_ID, bits 3:0
       unsigned h = ((unsigned)gw * 2654435761u) % per;
       unsigned tries = 0;                                    // (every spin is bounded: flags that were never cleared must not hang the device)
       while (atomicCAS(&B.gslots[base + h], 0u, 1u) != 0u && ++tries < 4u * per) h = h + 1 == per ? 0u : h + 1;
-      if (tries >= 4u * per) atomicOr(B.status, 64);         // the host fails the call
-      s = (int)(base + h);
+      if (tries >= 4u * per) { atomicOr(B.status, 64); s = -1; }   // the host fails the call
+      else s = (int)(base + h);
     }
     gslot = __builtin_amdgcn_readfirstlane(s);
+    if (gslot < 0) return;                                   // no slot: this wave maps nothing rather than write into scratch another wave holds
   }
   u64* gscr = B.gscratch + (long long)gslot * QM_GSCR_U64;
   WaveAlloc wa; wa.base = -1; wa.used = 0; wa.ivBase = -1; wa.ivUsed = 0;
