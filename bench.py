@@ -213,7 +213,7 @@ def ph_walk_addend(idx_dir, n_probe):
 
 def pmc_traffic(key, n, genes):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this command (profiles/pmc_traffic.json, written by
-    profiles/r05/make_pmc_traffic.py from the passes of profiles/r05/pmc_all.sh): a counter run cannot happen inside this process,
+    profiles/r06/make_pmc_traffic.py from the passes of profiles/r06/pmc_all.sh): a counter run cannot happen inside this process,
     so the figure is the one measured on this workload when the profile was taken -- per pair, scaled to this launch -- and says so.
     -> (bytes of the dominant kernel's launch, source, the whole entry)"""
     try:
@@ -275,10 +275,14 @@ class Oracles:
         return self.cache[idx_dir]
 
 
-def timed_steps(mp, opts, ptr, n, L, steps, warmup, world, device, qd):
-    """W untimed + K timed passes of the hot path, bracketed by barrier + synchronize; max over ranks"""
+def timed_steps(mp, opts, ptr, n, L, steps, warmup, world, device, qd, host=None):
+    """W untimed + K timed passes of the hot path, bracketed by barrier + synchronize; max over ranks.
+    host = (packed1, off, exc1, packed2, exc2): --reads-from-host, the batch comes up from page-locked host memory in every step"""
     def step():
-        r = mp.map_device(n, ptr[0], ptr[1], ptr[2], ptr[3], L, opts=opts, fetch=False)
+        if host is not None:
+            r = mp.map_pairs_prepacked(host[0], host[1], host[2], host[3], host[1], host[4], opts=opts, fetch=False)
+        else:
+            r = mp.map_device(n, ptr[0], ptr[1], ptr[2], ptr[3], L, opts=opts, fetch=False)
         tot = qd.all_reduce_counters(r.counters, device=device)   # the path's only collective
         return r, tot
     for _ in range(warmup):
@@ -344,7 +348,7 @@ def roofline(bpp, w, n, kernel_ms, kernel, traffic_key, genes, step_ms=None, ext
     # a batch of 2 M pairs and more is mapped as parts in flight (qm_map_device, QM_SPLIT, default 2): the parts' stage-A launches run
     # AT THE SAME TIME, each over its share of the pairs and each about as long as kernel_ms -- the HIP-event span from the first
     # launch's start to the last one's end (rocprofv3's average duration per launch of the same command:
-    # profiles/r05/kernel_stats_default_two_parts_r05zg.txt).  achieved = the bytes of all of them / that span: the chip's rate.
+    # profiles/r06/kernel_stats_default_two_parts_r06a.txt).  achieved = the bytes of all of them / that span: the chip's rate.
     parts = int(os.environ.get("QM_SPLIT", "2")) if n >= (1 << 21) else 1
     parts = max(1, min(8, parts))
     out["launches_per_step"] = parts
@@ -353,8 +357,8 @@ def roofline(bpp, w, n, kernel_ms, kernel, traffic_key, genes, step_ms=None, ext
     if traffic is not None and not whole_step:
         out["traffic_per_launch"] = traffic / parts          # (`traffic` is the step's: all launches)
     out["achieved_is"] = ("algorithmic bytes of the step's %d launch(es) (%d pairs each%s) / kernel_ms, the span of stage A measured with HIP events on "
-                          "the library's streams; the committed PMC passes (profiles/r05/pmc_all.sh) run the batch as ONE launch (QM_SPLIT=1), so that a "
-                          "dispatch is the whole batch: 20.9 ms there" % (parts, n // parts, ", in flight together" if parts > 1 else ""))
+                          "the library's streams; the committed PMC passes (profiles/r06/pmc_all.sh) run the batch as ONE launch (QM_SPLIT=1) of either "
+                          "stage-A kernel, so that a dispatch is the whole batch: 21.7 ms (pair kernel) / 20.2 ms (qm_lean_kernel) there" % (parts, n // parts, ", in flight together" if parts > 1 else ""))
     if whole_step:
         out["frac_is"] = "whole step: algorithmic bytes of the step / ms_per_step (kernel_ms -- stage A of the two parts in flight -- is reported next to it)"
         if step_ms:
@@ -500,6 +504,9 @@ def main():
     ap.add_argument("--repeat-family", type=int, default=0, help="one family of that many transcripts around a shared 300-base core (the input_variants legs: 100)")
     ap.add_argument("--no-input-variants", action="store_true", help="N=1: skip the bounded legs on other input distributions (0 %% errors; N's; paralogs + a repeat family)")
     ap.add_argument("--variant-pairs", type=int, default=4_000_000, help="pairs per input_variants leg (parity on the first 2 M of them)")
+    ap.add_argument("--reads-from-host", action="store_true", help="every step takes the batch from page-locked HOST buffers, 2-bit packed (qm_map_pairs_packed: upload inside the "
+                    "timed region, as `quasimap --devices` feeds its GPUs) instead of reads resident in HBM: what a scaling run of the PRODUCT path would see; "
+                    "never the contract's `value` (the line says so in config.reads_from_host)")
     ap.add_argument("--build-only", default=None, help=argparse.SUPPRESS)      # (BackgroundBuilds' child: build these indices and exit)
     ap.add_argument("--read-len", type=int, default=100, help="read length (BASELINE.json: 100; 129..256 runs the NS=4 kernels)")
     ap.add_argument("--cache", default=os.environ.get("QMAP_BENCH_CACHE", "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"))
@@ -571,7 +578,7 @@ def main():
     args._idx_dir = idx_dir
     t = time.time()
     qi = ra.QuasiIndex(idx_dir)
-    mp = ra.QuasiMapper(qi, dev_id, ph_compact=args.ph_compact)
+    mp = ra.QuasiMapper(qi, dev_id, ph_compact=args.ph_compact, wide_reads=128 < L <= 256)      # (QM_CTX_WIDE_READS: the wide extension table with the replica, not inside the first timed call)
     if rank == 0:
         log("index in HBM: %d transcripts, %d text bytes, %d k-mers, %.2f GB on device (%.1fs)" % (
             qi.n_txps, qi.text_len, qi.n_keys, mp.device_bytes / 1e9, time.time() - t))
@@ -584,8 +591,15 @@ def main():
     ptr = (s1.data_ptr(), off.data_ptr(), s2.data_ptr(), off.data_ptr())
     head_key = "sel" if args.sel_aln else (("ph_compact" if args.ph_compact else "ph_expanded") if args.perfect_hash else "dense")
 
+    host = None
+    if args.reads_from_host:
+        # the batch as `quasimap --devices` holds it: 2-bit packed (26 bytes per 100-bp read), page-locked; every step uploads it
+        hoff = off.cpu().numpy()
+        p1 = ra.api.pack_2bit(s1[: n * L].cpu().numpy(), hoff); p2 = ra.api.pack_2bit(s2[: n * L].cpu().numpy(), hoff)
+        host = (ra.api.pinned_copy(p1[0]), ra.api.pinned_copy(hoff), ra.api.pinned_copy(p1[2]) if len(p1[2]) else p1[2], ra.api.pinned_copy(p2[0]),
+                ra.api.pinned_copy(p2[2]) if len(p2[2]) else p2[2])
     with bg.quiet():
-        el, kernel_ms, tot = timed_steps(mp, opts, ptr, n, L, args.steps, args.warmup, world, device, qd)
+        el, kernel_ms, tot = timed_steps(mp, opts, ptr, n, L, args.steps, args.warmup, world, device, qd, host=host)
     head_stats = kernel_stats(mp, n)
     total_pairs = n * world * args.steps
     value = total_pairs / el / 1e6
@@ -608,6 +622,9 @@ def main():
         }
         avg_kernel_ms = float(np.mean(kernel_ms))
         out["config"]["map_kernel_ms"] = round(avg_kernel_ms, 3)
+        if args.reads_from_host:
+            out["config"]["reads_from_host"] = ("every step uploads the batch from page-locked host memory, 2-bit packed (%d MB per step), through qm_map_pairs_packed: the product path's "
+                                                "feed, NOT the contract's HBM-resident figure" % ((host[0].nbytes + host[3].nbytes + host[1].nbytes) >> 20))
         out["config"]["reads"] = {"substitution_rate": args.err, "n_rate": args.n_rate, "paralog_share": args.paralogs, "repeat_family": args.repeat_family}
         out["stage_a_kernels"] = head_stats
         out["collective"] = ({"backend": dist.get_backend(), "world_size": dist.get_world_size(), "op": "all_reduce(SUM) of the six HitCounters, 48 bytes",

@@ -426,6 +426,15 @@ class QuasiMapper:
                                          a[1][0].ctypes.data, a[1][1].ctypes.data, a[1][2].ctypes.data, len(a[1][2]), C.byref(nh), C.byref(ctr)))
         return self._finish(n, nh, ctr)
 
+    def map_pairs_prepacked(self, pk1, off1, exc1, pk2, off2, exc2, opts=None, fetch=True):
+        """qm_map_pairs_packed on reads that are packed already (pack_2bit / pinned_copy): what a caller that keeps its batches 2-bit packed pays per call"""
+        opts = opts or default_opts()
+        n = len(off1) - 1
+        nh, ctr = C.c_int64(0), QmCounters()
+        _check(lib().qm_map_pairs_packed(self._h, C.byref(opts), n, pk1.ctypes.data, off1.ctypes.data, exc1.ctypes.data if len(exc1) else None, len(exc1),
+                                         pk2.ctypes.data, off2.ctypes.data, exc2.ctypes.data if len(exc2) else None, len(exc2), C.byref(nh), C.byref(ctr)))
+        return self._finish(n, nh, ctr, fetch=fetch)
+
     def map_reads_packed(self, seq, off, opts=None):
         opts = opts or default_opts()
         pk, off, exc = pack_2bit(seq, off)
@@ -499,6 +508,17 @@ class QuasiMapper:
 
 
 PACK_EXC_DTYPE = np.dtype([("pos", "<u4"), ("ch", "<u4")])
+
+
+def pinned_copy(a):
+    """a copy of the array in page-locked host memory (qm_pinned_alloc; kept for the life of the process): DMA source of the host-buffer calls"""
+    a = np.ascontiguousarray(a)
+    p = lib().qm_pinned_alloc(max(64, a.nbytes))
+    if not p:
+        raise QmError("qm_pinned_alloc(%d) failed" % a.nbytes)
+    v = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(64, a.nbytes),))[: a.nbytes].view(a.dtype).reshape(a.shape)
+    v[...] = a
+    return v
 
 
 def pack_2bit(seq, off):
