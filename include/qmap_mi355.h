@@ -246,6 +246,17 @@ int qm_merge_lists(qm_ctx* ctx, const qm_opts* opts, int64_t n, const int64_t* l
 int qm_fetch_too_many(qm_ctx* ctx, uint8_t* too_many);
 int qm_map_pairs_stages(qm_ctx* ctx, const qm_opts* opts, int64_t n, const char* seq1, const int64_t* off1, const char* seq2,
                         const int64_t* off2, int64_t* n_hits, qm_counters* counters);
+/* Round 6: the same pass for callers that do not look inside the collector's SA-interval records -- the reference's own caller hands its
+ * HitCollectorInfo straight on to hitsToMappingsSimple (src/RapMapSAMapper.cpp:466-486) -- and / or keep their batches 2-bit packed:
+ * QM_STAGES_NO_INTERVALS leaves the interval arrays of the stage view empty (every read's count 0; foundHit, lists, hits and tooMany as
+ * before), which lets the pass run on the pair / lean stage-A kernels and brings half the bytes down; _packed takes the reads as
+ * qm_map_pairs_packed does (26 bytes up per 100-bp read instead of 100).  stage_flags 0 = qm_map_pairs_stages. */
+enum { QM_STAGES_NO_INTERVALS = 1 };
+int qm_map_pairs_stages_ex(qm_ctx* ctx, const qm_opts* opts, int64_t n, const char* seq1, const int64_t* off1, const char* seq2,
+                           const int64_t* off2, uint32_t stage_flags, int64_t* n_hits, qm_counters* counters);
+int qm_map_pairs_stages_packed(qm_ctx* ctx, const qm_opts* opts, int64_t n, const uint8_t* packed1, const int64_t* off1, const qm_pack_exc* exc1,
+                               int64_t n_exc1, const uint8_t* packed2, const int64_t* off2, const qm_pack_exc* exc2, int64_t n_exc2,
+                               uint32_t stage_flags, int64_t* n_hits, qm_counters* counters);
 /* Everything qm_map_pairs_stages kept, brought to the host in ONE go (round 4; what a caller of the reference's per-read call
  * surface needs for a parser chunk of ~10 000 pairs -- src/RapMapSAMapper.cpp:853 -- where five separate fetches, each a
  * synchronous copy of a bump-allocated device buffer, cost far more than the mapping itself).  The per-read interval records

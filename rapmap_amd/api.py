@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "qm_map_pairs", "qm_map_reads", "qm_map_device", "qm_pack_reads", "qm_packed_offset", "qm_packed_bytes", "qm_map_pairs_packed", "qm_map_reads_packed", "qm_fetch_hits", "qm_result_device", "qm_ctx_set_debug",
     "qm_fetch_intervals", "qm_last_kernel_ms", "qm_ctx_stat", "qm_fetch_skipped", "qm_build_index", "qm_build_index_ex",
     "qm_collect_reads", "qm_fetch_found", "qm_hits_to_mappings", "qm_fetch_read_lists", "qm_merge_lists", "qm_fetch_too_many",
-    "qm_map_pairs_stages", "qm_stage_bytes", "qm_fetch_stages", "qm_pinned_alloc", "qm_pinned_free", "qm_ctx_create_ex", "qm_fetch_hits_pinned", "qm_xxh64",
+    "qm_map_pairs_stages", "qm_map_pairs_stages_ex", "qm_map_pairs_stages_packed", "qm_stage_bytes", "qm_fetch_stages", "qm_pinned_alloc", "qm_pinned_free", "qm_ctx_create_ex", "qm_fetch_hits_pinned", "qm_xxh64",
     "qm_stream_open", "qm_stream_open_ex", "qm_stream_reserve", "qm_stream_next", "qm_stream_close", "qm_stream_last_error", "qm_stream_stats", "qm_stream_stats_ex",
     "qm_reader_open", "qm_reader_next", "qm_reader_close", "qm_io_last_error", "qm_sam_header", "qm_sam_records",
     "qm_sam_write", "qm_sam_writer_open", "qm_sam_writer_open_ex", "qm_sam_writer_header", "qm_sam_writer_put", "qm_sam_writer_close", "qm_buf_free",
@@ -443,15 +443,27 @@ class QuasiMapper:
         _check(lib().qm_map_reads_packed(self._h, C.byref(opts), n, pk.ctypes.data, off.ctypes.data, exc.ctypes.data, len(exc), C.byref(nh), C.byref(ctr)))
         return self._finish(n, nh, ctr)
 
-    def map_pairs_stages(self, seq1, off1, seq2, off2, opts=None):
-        """the three stages fused, every stage's output kept: MapResult of the merge (no caller-level bookkeeping)"""
+    def map_pairs_stages(self, seq1, off1, seq2, off2, opts=None, no_intervals=False, packed=False):
+        """the three stages fused, every stage's output kept: MapResult of the merge (no caller-level bookkeeping).
+        no_intervals: QM_STAGES_NO_INTERVALS (the stage view's interval arrays stay empty); packed: the reads go up 2-bit packed"""
         opts = opts or default_opts()
         seq1 = np.ascontiguousarray(seq1, dtype=np.uint8); off1 = np.ascontiguousarray(off1, dtype=np.int64)
         seq2 = np.ascontiguousarray(seq2, dtype=np.uint8); off2 = np.ascontiguousarray(off2, dtype=np.int64)
         n = len(off1) - 1
         nh, ctr = C.c_int64(0), QmCounters()
-        _check(lib().qm_map_pairs_stages(self._h, C.byref(opts), n, seq1.ctypes.data or 1, off1.ctypes.data,
-                                         seq2.ctypes.data or 1, off2.ctypes.data, C.byref(nh), C.byref(ctr)))
+        fl = 1 if no_intervals else 0
+        if packed:
+            a = [pack_2bit(seq1, off1), pack_2bit(seq2, off2)]
+            _check(lib().qm_map_pairs_stages_packed(self._h, C.byref(opts), C.c_int64(n), C.c_void_p(a[0][0].ctypes.data), C.c_void_p(a[0][1].ctypes.data),
+                                                    C.c_void_p(a[0][2].ctypes.data if len(a[0][2]) else None), C.c_int64(len(a[0][2])),
+                                                    C.c_void_p(a[1][0].ctypes.data), C.c_void_p(a[1][1].ctypes.data),
+                                                    C.c_void_p(a[1][2].ctypes.data if len(a[1][2]) else None), C.c_int64(len(a[1][2])), C.c_uint32(fl), C.byref(nh), C.byref(ctr)))
+        elif fl:
+            _check(lib().qm_map_pairs_stages_ex(self._h, C.byref(opts), C.c_int64(n), C.c_void_p(seq1.ctypes.data or 1), C.c_void_p(off1.ctypes.data),
+                                                C.c_void_p(seq2.ctypes.data or 1), C.c_void_p(off2.ctypes.data), C.c_uint32(fl), C.byref(nh), C.byref(ctr)))
+        else:
+            _check(lib().qm_map_pairs_stages(self._h, C.byref(opts), n, seq1.ctypes.data or 1, off1.ctypes.data,
+                                             seq2.ctypes.data or 1, off2.ctypes.data, C.byref(nh), C.byref(ctr)))
         return self._finish(n, nh, ctr)
 
     def fetch_stages(self, pinned=True):

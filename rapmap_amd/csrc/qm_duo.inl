@@ -609,6 +609,7 @@ QM_DEV void duo_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, in
         if (j == 0) {
           const u32 flag = (B.fuzzy && (W.fl[l] & QM_DW_FOUND)) ? 0x80000000u : 0u;
           B.lcnt[r0 + h] = (fits ? (u32)(h ? cntB : cntA) : 0u) | flag; B.loff[r0 + h] = fits ? bh : 0;
+          if (B.found_out) B.found_out[r0 + h] = (W.fl[l] & QM_DW_FOUND) ? 1 : 0;       // (stage views without interval records)
         }
       } else if (j == 0) {
         B.lcnt[r0 + h] = QM_LCNT_LEAN; B.loff[r0 + h] = 0; atomic_add_u64(B.cursor + QM_SC_LEANQ, 1ULL);

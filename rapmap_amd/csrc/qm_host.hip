@@ -836,8 +836,9 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
   // wide extension table.
   static const bool wideOff = [] { const char* e = getenv("QM_NO_LEAN_WIDE"); return e && atoi(e) != 0; }();
   const bool leanBase = !leanOff && rq.mode == QM_RUN_FUSED && o->sensitive && (c->d_slots || c->d_ph) && c->d_saext && c->ix->k <= 31;
-  const bool leanWide = leanBase && !wideOff && (ns == 3 || ns == 4) && (o->sel_aln || (!rq.keepIntervals && !rq.keepFound)) && ensure_saext2(c);
-  const bool useLean = leanBase && !o->sel_aln && (ns == 2 || leanWide) && !rq.keepIntervals && !rq.keepFound;
+  // (a call that keeps the SA-interval records takes the general kernel: the lean kernels do not write them; foundHit they do -- stage views without intervals)
+  const bool leanWide = leanBase && !wideOff && (ns == 3 || ns == 4) && (o->sel_aln || !rq.keepIntervals) && ensure_saext2(c);
+  const bool useLean = leanBase && !o->sel_aln && (ns == 2 || leanWide) && !rq.keepIntervals;
   // Pairs of such reads take the pair kernel (qm_duo.inl): the two mates walked in lockstep by the two halves of a wavefront, and -- in a
   // plain fused call -- merged there (pair_cnt: stage B's count pass finds the pair done, its write pass expands the records)
   static const bool duoOff = [] { const char* e = getenv("QM_NO_DUO"); return e && atoi(e) != 0; }();
@@ -1305,6 +1306,14 @@ static int map_device_impl(qm_ctx* c, const qm_opts* o, int64_t n, const void* d
       HIPCHK(hipMalloc(&c->d_scanTmp, stb ? stb : 16));
       c->scanTmpBytes = stb;
     }
+    if (!r2.keepIntervals) {
+      // a stage view without the SA-interval records (QM_STAGES_NO_INTERVALS): every read's count is zero
+      if ((rc = ensure(c->d_ivcnt, c->capIvCnt, nreads + 1))) return rc;
+      if ((rc = ensure(c->d_ivoff, c->capIvOff, nreads + 1))) return rc;
+      if ((rc = ensure(c->d_iv, c->capIv, 1))) return rc;
+      HIPCHK(hipMemsetAsync(c->d_ivcnt, 0, (size_t)(nreads + 1) * sizeof(uint32_t), c->stream));
+      HIPCHK(hipMemsetAsync(c->d_ivoff, 0, (size_t)(nreads + 1) * sizeof(long long), c->stream));
+    }
     HIPCHK(hipMemsetAsync(c->d_ivcnt + nreads, 0, sizeof(uint32_t), c->stream));
     HIPCHK(hipMemsetAsync(c->d_lcnt + nreads, 0, sizeof(uint32_t), c->stream));
     HIPCHK(qmk_scan_counts(c->d_scanTmp, c->scanTmpBytes, c->d_ivcnt, c->d_ivcsr, nreads + 1, c->stream));
@@ -1532,7 +1541,7 @@ static int unpack_mate(qm_ctx* c, int64_t n, const uint8_t* pk, const int64_t* o
 }
 
 static int map_packed(qm_ctx* c, const qm_opts* o, int64_t n, const uint8_t* pk1, const int64_t* off1, const qm_pack_exc* exc1, int64_t nexc1,
-                      const uint8_t* pk2, const int64_t* off2, const qm_pack_exc* exc2, int64_t nexc2, int64_t* n_hits, qm_counters* counters) {
+                      const uint8_t* pk2, const int64_t* off2, const qm_pack_exc* exc2, int64_t nexc2, int64_t* n_hits, qm_counters* counters, const RunReq& rq = RunReq()) {
   if (!c || n < 0 || (n > 0 && (!pk1 || !off1)) || nexc1 < 0 || nexc2 < 0 || (nexc1 > 0 && !exc1) || (nexc2 > 0 && !exc2)) return fail(QM_E_ARG, "bad argument");
   HIPCHK(hipSetDevice(c->device));
   int rc;
@@ -1543,7 +1552,7 @@ static int map_packed(qm_ctx* c, const qm_opts* o, int64_t n, const uint8_t* pk1
   int32_t maxLen = 0, maxShort = 0;
   if ((rc = unpack_mate(c, n, pk1, off1, exc1, nexc1, c->d_seq1, c->capSeq1, c->d_off1, c->capOff1, c->d_pk1, c->capPk1, c->d_exc1, c->capExc1, maxLen, maxShort))) return rc;
   if (pk2 && (rc = unpack_mate(c, n, pk2, off2, exc2, nexc2, c->d_seq2, c->capSeq2, c->d_off2, c->capOff2, c->d_pk2, c->capPk2, c->d_exc2, c->capExc2, maxLen, maxShort))) return rc;
-  rc = map_device_impl(c, o, n, c->d_seq1, c->d_off1, pk2 ? c->d_seq2 : nullptr, pk2 ? c->d_off2 : nullptr, maxLen, n_hits, counters, nullptr, RunReq(), maxShort > 0 ? maxShort : 1);
+  rc = map_device_impl(c, o, n, c->d_seq1, c->d_off1, pk2 ? c->d_seq2 : nullptr, pk2 ? c->d_off2 : nullptr, maxLen, n_hits, counters, nullptr, rq, maxShort > 0 ? maxShort : 1);
   hipStreamSynchronize(c->stream);                         // nothing of the caller's buffers is in flight after return (error paths too)
   return rc;
 }
@@ -1824,6 +1833,21 @@ int qm_map_pairs_stages(qm_ctx* c, const qm_opts* o, int64_t n, const char* seq1
   if (!seq2 || !off2) return fail(QM_E_ARG, "qm_map_pairs_stages needs both mates");
   RunReq rq; rq.keepIntervals = true; rq.keepFound = true; rq.mergeOnly = true; rq.stageView = true;
   return map_host(c, o, n, seq1, off1, seq2, off2, n_hits, counters, rq);
+}
+
+static RunReq stage_req(uint32_t stage_flags) {
+  RunReq rq; rq.keepIntervals = !(stage_flags & QM_STAGES_NO_INTERVALS); rq.keepFound = true; rq.mergeOnly = true; rq.stageView = true;
+  return rq;
+}
+int qm_map_pairs_stages_ex(qm_ctx* c, const qm_opts* o, int64_t n, const char* seq1, const int64_t* off1, const char* seq2,
+                           const int64_t* off2, uint32_t stage_flags, int64_t* n_hits, qm_counters* counters) {
+  if (!seq2 || !off2) return fail(QM_E_ARG, "qm_map_pairs_stages_ex needs both mates");
+  return map_host(c, o, n, seq1, off1, seq2, off2, n_hits, counters, stage_req(stage_flags));
+}
+int qm_map_pairs_stages_packed(qm_ctx* c, const qm_opts* o, int64_t n, const uint8_t* pk1, const int64_t* off1, const qm_pack_exc* exc1, int64_t nexc1,
+                               const uint8_t* pk2, const int64_t* off2, const qm_pack_exc* exc2, int64_t nexc2, uint32_t stage_flags, int64_t* n_hits, qm_counters* counters) {
+  if (!pk2 || !off2) return fail(QM_E_ARG, "qm_map_pairs_stages_packed needs both mates");
+  return map_packed(c, o, n, pk1, off1, exc1, nexc1, pk2, off2, exc2, nexc2, n_hits, counters, stage_req(stage_flags));
 }
 
 // layout of a qm_fetch_stages arena: eight arrays, each aligned to 64 bytes

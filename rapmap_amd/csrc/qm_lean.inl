@@ -798,7 +798,7 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
     }
     if (n > 0) { QM_LANES(l) { if (keep[l]) B.lists[base + slot[l]] = elem[l]; } }
     const u32 flag = (B.fuzzy && foundHit) ? 0x80000000u : 0u;
-    QM_LANES(l) { if (l == 0) { B.lcnt[read] = (u32)n | flag; B.loff[read] = base; } }
+    QM_LANES(l) { if (l == 0) { B.lcnt[read] = (u32)n | flag; B.loff[read] = base; if (B.found_out) B.found_out[read] = foundHit ? 1 : 0; } }   // (found_out: stage views without interval records)
   }
 }
 

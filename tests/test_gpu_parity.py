@@ -1055,3 +1055,31 @@ def test_extension_tables_match_the_byte_per_character_builders(synth_medium, or
     assert_hits_equal(rw.hit_offsets, rw.hits, gw.hit_offsets, gw.hits, "150 bp with checked tables")
     assert mp.stat(3) == 2 * 500, "the wide lean kernel did not run: no SaExt2"
     mp.close(); qi.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["plain", "fuzzy"])
+def test_stage_view_without_intervals_and_packed(synth_small, oracle_mod, mode):
+    """QM_STAGES_NO_INTERVALS / qm_map_pairs_stages_packed (round 6): everything of the stage view but the interval records -- foundHit, the per-read
+    lists, the merge's hits and tooMany flags -- equals the full pass's, with the reads as characters or 2-bit packed; the pass ran on the
+    pair / lean kernels (the full one keeps intervals: general kernel)"""
+    import rapmap_amd as ra
+    qi, mp = _gpu(synth_small["idx"], debug=False)
+    q1, o1 = pack(synth_small["reads1"]); q2, o2 = pack(synth_small["reads2"])
+    n = len(o1) - 1
+    opts = ra.default_opts(**({"fuzzy": 1} if mode == "fuzzy" else {}))
+    full = mp.map_pairs_stages(q1, o1, q2, o2, opts=opts)
+    vf = {k: (np.array(v, copy=True) if hasattr(v, "shape") else v) for k, v in mp.fetch_stages(pinned=False).items()}
+    assert mp.stat(3) == -1
+    for packed in (False, True):
+        light = mp.map_pairs_stages(q1, o1, q2, o2, opts=opts, no_intervals=True, packed=packed)
+        assert mp.stat(3) == 2 * n and mp.stat(4) > 0, "the lean / pair kernel did not run"
+        v = mp.fetch_stages(pinned=packed)
+        assert np.array_equal(light.hit_offsets, full.hit_offsets) and light.hits.tobytes() == full.hits.tobytes() and light.counters == full.counters
+        assert int(v["iv_off"][-1]) == 0 and v["iv"].size == 0
+        assert np.array_equal(v["found"], vf["found"])
+        assert np.array_equal(v["list_off"], vf["list_off"]) and np.array_equal(v["words"], vf["words"])
+        assert np.array_equal(v["hit_off"], vf["hit_off"]) and v["hits"].tobytes() == vf["hits"].tobytes()
+        assert np.array_equal(v["too_many"], vf["too_many"])
+        mp._arena_cap = 0
+    mp.close(); qi.close()
