@@ -456,22 +456,33 @@ def compat_face_leg(out, args, idx_dir, hs1, hs2, n, L, want_digest_fn, cores):
         rp = os.path.join(td, "reads.bin")
         with open(rp, "wb") as f:
             f.write(hs1[: nc * L].tobytes()); f.write(hs2[: nc * L].tobytes())
-        runs = {}
-        for T in sorted({1, min(8, cores), min(32, cores)}):
-            npairs = nc if T > 1 else min(nc, max(200_000, nc // 8))          # one thread: an eighth of the sample is plenty
-            r = subprocess.run([exe, idx_dir, rp, str(nc), str(L), str(T), "10000", "--use", str(npairs)] + ["--repeat", "3" if T > 1 else "2", "--digest-once"],     # best of the repeats behind the first, which also page-locks the service's buffers and takes the digest
-                               capture_output=True, text=True, timeout=900)
-            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-            if r.returncode != 0 or not line:
-                runs[str(T)] = {"error": (r.stdout + r.stderr)[-300:]}
-                continue
-            j = json.loads(line[-1])
-            runs[str(T)] = {"value": round(j["mpairs_per_s"], 3), "pairs": j["pairs"], "seconds": round(j["seconds"], 4),
-                            "thread_join_seconds_not_timed": round(j.get("thread_join_seconds", 0.0), 4),
-                            "workers_waiting_thread_s": round(j.get("prefetch_thread_s", 0.0), 3), "workers_loop_thread_s": round(j.get("loop_thread_s", 0.0), 3),
-                            "bit_identical_joint_hits": j["digest"] == want_digest_fn(npairs), "totHits": j["totHits"]}
+        def sweep(extra):
+            runs = {}
+            for T in sorted({1, min(8, cores), min(32, cores)}):
+                npairs = nc if T > 1 else min(nc, max(200_000, nc // 8))          # one thread: an eighth of the sample is plenty
+                r = subprocess.run([exe, idx_dir, rp, str(nc), str(L), str(T), "10000", "--use", str(npairs)] + ["--repeat", "3" if T > 1 else "2", "--digest-once"] + extra,     # best of the repeats behind the first, which also page-locks the service's buffers and takes the digest
+                                   capture_output=True, text=True, timeout=900)
+                line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                if r.returncode != 0 or not line:
+                    runs[str(T)] = {"error": (r.stdout + r.stderr)[-300:]}
+                    continue
+                j = json.loads(line[-1])
+                runs[str(T)] = {"value": round(j["mpairs_per_s"], 3), "pairs": j["pairs"], "seconds": round(j["seconds"], 4),
+                                "thread_join_seconds_not_timed": round(j.get("thread_join_seconds", 0.0), 4),
+                                "workers_waiting_thread_s": round(j.get("prefetch_thread_s", 0.0), 3), "workers_loop_thread_s": round(j.get("loop_thread_s", 0.0), 3),
+                                "bit_identical_joint_hits": j["digest"] == want_digest_fn(npairs), "totHits": j["totHits"]}
+            return runs
+        runs = sweep([])
+        # the same callers after ONE more line, `hitCollector.setKeepIntervals(false)` ("I hand HitCollectorInfo on and never look inside": what
+        # src/RapMapSAMapper.cpp:466-486 does): no interval records come down, the device pass runs on the pair / lean kernels
+        runs_ni = sweep(["--no-intervals"])
         best = max((v.get("value", 0) for v in runs.values()), default=0)
         out["compat_face"] = {"value": best, "unit": "M read-pairs/s", "chunk_pairs": 10000, "by_host_threads": runs,
+                              "without_interval_records": {"by_host_threads": runs_ni, "value": max((v.get("value", 0) for v in runs_ni.values()), default=0),
+                                                           "what": "the same run with SACollector::setKeepIntervals(false): fwdSAInts / rcSAInts of every HitCollectorInfo stay empty, "
+                                                                   "everything else -- foundHit, hit lists, merges -- unchanged (same digest)"},
+                              "bytes_per_pair": {"up": "56 (2-bit packed reads + offsets; 216 as characters, QMAP_COMPAT_NO_PACK=1)",
+                                                 "down": "about 330 with the interval records, 170 without (hits 32 B x 3.2, list words 8 B x 6.4, offsets, flags)"},
                               "what": "tests/compat/compat_bench.cpp: T threads, each takes read groups of 10 000 pairs and runs the reference's per-pair "
                                       "sequence (src/RapMapSAMapper.cpp:461-551) through include/qmap_rapmap_compat.hpp, one added line "
                                       "`hitCollector.prefetch(rg)` (the groups of all threads are mapped together by the header's batching service: "

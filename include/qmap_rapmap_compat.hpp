@@ -446,6 +446,12 @@ struct Batch {
   int state{0};                            // 0 free, 1 open, 2 closed (packing / on the device), 3 done, 4 failed
   std::chrono::steady_clock::time_point t0;   // when the first group joined
   qm_opts opts{};
+  uint32_t stageFlags{0};                  // QM_STAGES_NO_INTERVALS when the groups' collectors said they do not look at the interval records
+  // round 6: the same reads 2-bit packed (qm_pack_reads' layout: reads never share a byte, so every worker packs its own slice), the
+  // form they cross PCIe in: 26 bytes per 100-bp read instead of 100.  Characters that are not upper-case A C G T are exceptions; a
+  // batch whose exceptions outgrow the list travels as characters.
+  PinnedBuf pk[2]; uint8_t* p1{nullptr}; uint8_t* p2{nullptr};
+  std::vector<qm_pack_exc> exc1, exc2; bool packedOk{true};
   qm_stage_view v{}; PinnedBuf arena;
   int rc{0}; std::string err;
   void size_for(size_t b1, size_t b2, int64_t n) {
@@ -455,6 +461,8 @@ struct Batch {
     o1 = static_cast<int64_t*>(in[2].need(static_cast<size_t>(wu + 1) * 8)); o2 = static_cast<int64_t*>(in[3].need(static_cast<size_t>(wu + 1) * 8));
     cap1 = in[0].cap - 64; cap2 = in[1].cap - 64; capUnits = static_cast<int64_t>(in[2].cap / 8) - 2;
     if (static_cast<int64_t>(in[3].cap / 8) - 2 < capUnits) capUnits = static_cast<int64_t>(in[3].cap / 8) - 2;
+    p1 = static_cast<uint8_t*>(pk[0].need((in[0].cap >> 2) + static_cast<size_t>(capUnits) + 64));
+    p2 = static_cast<uint8_t*>(pk[1].need((in[1].cap >> 2) + static_cast<size_t>(capUnits) + 64));
   }
 };
 class Service {
@@ -466,6 +474,8 @@ class Service {
     const char* l = std::getenv("QMAP_COMPAT_LINGER_US");
     lingerUs_ = l && std::atoi(l) >= 0 ? std::atoi(l) : 300;
     debug_ = std::getenv("QMAP_COMPAT_DEBUG") != nullptr;
+    const char* np = std::getenv("QMAP_COMPAT_NO_PACK");
+    packUploads_ = !(np && std::atoi(np) != 0);
     for (int i = 0; i < n; ++i) th_.emplace_back([this] { dispatch(); });
   }
   ~Service() {
@@ -475,17 +485,18 @@ class Service {
   }
   // a worker's group joins a batch: its place among the units / characters of the batch
   struct Place { Batch* b; int64_t u0; size_t c1, c2; };
-  Place join(const qm_opts& opts, int64_t n, size_t b1, size_t b2) {
+  Place join(const qm_opts& opts, int64_t n, size_t b1, size_t b2, uint32_t stageFlags = 0) {
     std::unique_lock<std::mutex> lk(mu_);
     Batch* b = open_;
-    if (b && (std::memcmp(&b->opts, &opts, sizeof(qm_opts)) != 0 || b->units + n > b->capUnits || b->used1 + b1 > b->cap1 || b->used2 + b2 > b->cap2)) {
+    if (b && (std::memcmp(&b->opts, &opts, sizeof(qm_opts)) != 0 || b->stageFlags != stageFlags || b->units + n > b->capUnits || b->used1 + b1 > b->cap1 || b->used2 + b2 > b->cap2)) {
       b->state = 2; ready_.push_back(b); open_ = nullptr; b = nullptr;        // other settings, or full: off it goes
     }
     if (!b) {
       for (auto& x : all_) if (x->state == 0) { b = x.get(); break; }
       if (!b) { all_.emplace_back(new Batch()); b = all_.back().get(); }
       b->size_for(b1, b2, n);
-      b->opts = opts; b->units = 0; b->used1 = 0; b->used2 = 0; b->joined = 0; b->packed = 0; b->readers = 0; b->rc = 0; b->err.clear();
+      b->opts = opts; b->stageFlags = stageFlags; b->units = 0; b->used1 = 0; b->used2 = 0; b->joined = 0; b->packed = 0; b->readers = 0; b->rc = 0; b->err.clear();
+      b->exc1.clear(); b->exc2.clear(); b->packedOk = packUploads_;
       b->o1[0] = 0; b->o2[0] = 0;
       b->state = 1; open_ = b;
       b->t0 = std::chrono::steady_clock::now();
@@ -495,6 +506,23 @@ class Service {
     lk.unlock();
     cvWork_.notify_all();
     return p;
+  }
+  // a worker's slice of the batch, 2-bit packed next to the other workers' (place: the group's first unit and first characters); its
+  // exceptions join the batch's lists, a slice with too many of them (lower-case reads ...) sends the whole batch as characters
+  void pack_slice(Batch* b, int64_t u0, int64_t n, size_t c1, size_t c2, const int64_t* o1, const int64_t* o2) {
+    if (!b->packedOk || n <= 0) return;
+    qm_pack_exc ex[2][256]; int64_t ne[2] = {0, 0};
+    std::vector<int64_t> off(static_cast<size_t>(n) + 1);
+    bool ok = true;
+    for (int m = 0; m < 2 && ok; ++m) {
+      const int64_t* o = m ? o2 : o1;
+      off[0] = static_cast<int64_t>(m ? c2 : c1);
+      for (int64_t i = 1; i <= n; ++i) off[static_cast<size_t>(i)] = o[i];         // (o[0] belongs to the group in front: this group's start is its place)
+      ok = qm_pack_reads(m ? b->s2 : b->s1, off.data(), n, (m ? b->p2 : b->p1) + u0, ex[m], 256, &ne[m]) == QM_OK;
+    }
+    std::lock_guard<std::mutex> lk(mu_);
+    if (!ok) { b->packedOk = false; return; }
+    b->exc1.insert(b->exc1.end(), ex[0], ex[0] + ne[0]); b->exc2.insert(b->exc2.end(), ex[1], ex[1] + ne[1]);
   }
   // the worker has packed its reads (it may go on with other work: prefetch_async) ...
   void packed(Batch* b) {
@@ -548,7 +576,10 @@ class Service {
         int64_t nHits = 0; qm_counters c{};
         // one pass at a time uploads + computes, one at a time brings its results down: passes of the dispatchers that would start
         // together take turns instead, and the upload of one runs under the download of the other (the link is full duplex)
-        { std::lock_guard<std::mutex> ph(muMap_); rc = qm_map_pairs_stages(ctx, &b->opts, b->units, b->s1, b->o1, b->s2, b->o2, &nHits, &c); }
+        { std::lock_guard<std::mutex> ph(muMap_);
+          if (b->packedOk) rc = qm_map_pairs_stages_packed(ctx, &b->opts, b->units, b->p1, b->o1, b->exc1.empty() ? nullptr : b->exc1.data(), static_cast<int64_t>(b->exc1.size()),
+                                                           b->p2, b->o2, b->exc2.empty() ? nullptr : b->exc2.data(), static_cast<int64_t>(b->exc2.size()), b->stageFlags, &nHits, &c);
+          else rc = qm_map_pairs_stages_ex(ctx, &b->opts, b->units, b->s1, b->o1, b->s2, b->o2, b->stageFlags, &nHits, &c); }
         t1 = std::chrono::steady_clock::now();
         int64_t need = 0;
         if (!rc) rc = qm_stage_bytes(ctx, &need);
@@ -562,8 +593,9 @@ class Service {
       }
       if (debug_) {
         auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return (long long)std::chrono::duration_cast<std::chrono::microseconds>(c - a).count(); };
-        std::fprintf(stderr, "[qmap service] batch of %lld pairs in %d groups: waited %lld us for company / packers, map %lld us, arena %lld us, fetch %lld us\n",
-                     (long long)b->units, b->joined, us(b->t0, tw), us(tw, t1), us(t1, t2), us(t2, t3));
+        std::fprintf(stderr, "[qmap service] batch of %lld pairs in %d groups (%s, %s): waited %lld us for company / packers, map %lld us, arena %lld us, fetch %lld us\n",
+                     (long long)b->units, b->joined, b->packedOk ? "2-bit packed" : "characters", (b->stageFlags & QM_STAGES_NO_INTERVALS) ? "no interval records" : "interval records",
+                     us(b->t0, tw), us(tw, t1), us(t1, t2), us(t2, t3));
       }
       lk.lock();
       b->rc = rc; b->err = err; b->state = rc ? 4 : 3;
@@ -583,7 +615,7 @@ class Service {
   std::vector<std::thread> th_;
   bool stop_{false};
   int workers_{0}, lingerUs_{300};
-  bool debug_{false};
+  bool debug_{false}, packUploads_{true};
 };
 // the services of this process, one per (index, device); created on first use, dropped when their index is closed (an index
 // that is never closed keeps its service until the process ends: the registry itself is never destroyed)
@@ -736,6 +768,13 @@ class SACollector {
   void setMaxMMPExtension(int32_t ext) { if (ext > 0) { maxMMPExtension_ = ext; ++settings_; } }
   int32_t getMaxMMPExtension() const { return maxMMPExtension_; }
 
+  // Not in the reference: a caller that hands HitCollectorInfo straight on to hitsToMappingsSimple (as src/RapMapSAMapper.cpp:466-486 does)
+  // and never looks inside it can say so -- the groups it sends then come back WITHOUT the SA-interval records (fwdSAInts / rcSAInts stay
+  // empty; foundHit, the hit lists and the merges are what they always are), the device pass runs on the pair / lean kernels and half the
+  // bytes come down.  Default: the records are there.
+  void setKeepIntervals(bool keep) { keepIntervals_ = keep; ++settings_; }
+  bool getKeepIntervals() const { return keepIntervals_; }
+
   explicit SACollector(RapMapIndexT* rmi) : rmi_(rmi) {}
   ~SACollector() { pending_.clear(); chunk_.reset(); spare_.clear(); count_in(nullptr); }   // (the groups first, then this collector's place among the service's workers)
   SACollector(const SACollector&) = delete;
@@ -826,7 +865,7 @@ class SACollector {
       Service* svc = service_of(rmi_->handle(), rmi_->device());
       count_in(svc);
       ch->bind(svc);
-      const Service::Place pl = svc->join(ch->opts, n, b1, b2);
+      const Service::Place pl = svc->join(ch->opts, n, b1, b2, keepIntervals_ ? 0u : static_cast<uint32_t>(QM_STAGES_NO_INTERVALS));
       Batch* bt = pl.b;
       ch->batch = bt;
       // ... the reads packed there, next to the other workers' (the upload is a DMA straight out of these buffers) ...
@@ -841,6 +880,7 @@ class SACollector {
       }
       ch->ubase = pl.u0; ch->rbase = 2 * pl.u0;
       ch->s1 = bt->s1; ch->s2 = bt->s2; ch->o1 = o1; ch->o2 = o2;
+      svc->pack_slice(bt, pl.u0, n, pl.c1, pl.c2, o1, o2);
       // ... and handed to the dispatcher: the batch's one fused pass brings every stage's output of every group in it down in one
       // go (intervals and foundHit per read, per-read lists, merge results and tooMany flags per pair); wait() picks it up
       svc->packed(bt);
@@ -928,6 +968,7 @@ class SACollector {
   std::vector<std::unique_ptr<qmap::detail::Chunk>> spare_;    // chunk objects of groups that were given back
   // this collector counted once among its service's workers (the dispatcher closes a batch when half of them have joined), whatever the
   // number of chunk objects it holds (current, sent ahead, spare)
+  bool keepIntervals_{true};
   qmap::detail::Service* counted_{nullptr};
   void count_in(qmap::detail::Service* s) { if (counted_ != s) { if (counted_) counted_->detach(); counted_ = s; if (s) s->attach(); } }
 };

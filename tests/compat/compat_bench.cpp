@@ -5,7 +5,7 @@
 // only added lines are `hitCollector.prefetch(rg)` and -- for the next group, sent ahead -- `hitCollector.prefetch_async(rg)`.  Compiled against the header ALONE (bench.py's `compat_face` leg and
 // tests/test_rapmap_compat.py build it with g++).
 //
-//   compat_bench INDEX READS.bin NPAIRS READLEN THREADS CHUNK [--no-prefetch] [--repeat R] [--use N] [--mixed] [--depth D]
+//   compat_bench INDEX READS.bin NPAIRS READLEN THREADS CHUNK [--no-prefetch] [--repeat R] [--use N] [--mixed] [--depth D] [--no-intervals]
 //
 // READS.bin: NPAIRS*READLEN characters of the left mates, then as many of the right mates (what bench.py holds in HBM for the
 // headline, copied to the host).  The read groups (std::string pairs, as the parser hands them out) are built before the
@@ -40,6 +40,7 @@ static inline uint64_t hit_digest(uint64_t unit, uint64_t j, const rapmap::utils
   return v;
 }
 
+static bool g_keepIntervals = true; // --no-intervals: the collectors say they do not look inside HitCollectorInfo (SACollector::setKeepIntervals(false))
 static bool g_digest = true;      // --digest-once: the digest of every jointHits vector is taken in the first repeat only (the check), the later repeats time the reference's loop alone
 struct Totals { uint64_t ph[5] = {0, 0, 0, 0, 0}; uint64_t digest = 0, pe = 0, se = 0, tot = 0, reads = 0, tooMany = 0, mapped = 0; double prefetchS = 0, loopS = 0, firstAt = 0, lastAt = 0, goSeenAt = 0; };
 static inline uint64_t tick() { return __builtin_ia32_rdtsc(); }
@@ -56,6 +57,7 @@ static void worker(RapMapIndexT& rmi, std::vector<Group>& groups, const std::vec
   SACollector<RapMapIndexT> hitCollector(&rmi);
   hitCollector.disableNIP();
   hitCollector.setStrictCheck(true);
+  hitCollector.setKeepIntervals(g_keepIntervals);
   rapmap::hit_manager::HitCollectorInfo<rapmap::utils::SAIntervalHit<OffsetT>> leftHCInfo, rightHCInfo;
   rapmap::utils::MappingConfig mc;
   mc.consistentHits = false; mc.doChaining = false;
@@ -153,6 +155,7 @@ int main(int argc, char** argv) {
       if (!std::strcmp(argv[i], "--no-prefetch")) prefetch = false;
       else if (!std::strcmp(argv[i], "--mixed")) mixed = true;
       else if (!std::strcmp(argv[i], "--digest-once")) digestOnce = true;
+      else if (!std::strcmp(argv[i], "--no-intervals")) g_keepIntervals = false;
       else if (!std::strcmp(argv[i], "--repeat") && i + 1 < argc) repeat = std::atoi(argv[++i]);
       else if (!std::strcmp(argv[i], "--depth") && i + 1 < argc) depth = std::max(1, std::atoi(argv[++i]));   // groups a worker has in flight (1: prefetch() alone)
       else if (!std::strcmp(argv[i], "--use") && i + 1 < argc) n = std::min(nFile, (size_t)std::atoll(argv[++i]));   // only the first N pairs of the file

@@ -27,7 +27,7 @@ using ReadPair = std::pair<Read, Read>;
 
 template <typename RapMapIndexT>
 int run(RapMapIndexT& rmi, std::vector<ReadPair>& all, const char* outPath, bool fuzzy, bool chain, bool prefetch, bool noOrphans,
-        uint32_t maxNumHits, bool edit, bool refill, bool evensFirst) {
+        uint32_t maxNumHits, bool edit, bool refill, bool evensFirst, bool noIntervals = false) {
   using OffsetT = typename RapMapIndexT::IndexType;
   using rapmap::utils::MateStatus;
   using rapmap::utils::QuasiAlignment;
@@ -37,6 +37,7 @@ int run(RapMapIndexT& rmi, std::vector<ReadPair>& all, const char* outPath, bool
   SACollector<RapMapIndexT> hitCollector(&rmi);
   hitCollector.disableNIP();                    // sensitive (the CLI default)
   hitCollector.setStrictCheck(true);
+  if (noIntervals) hitCollector.setKeepIntervals(false);     // (not in the reference: "I never look inside HitCollectorInfo")
   rapmap::hit_manager::HitCollectorInfo<rapmap::utils::SAIntervalHit<OffsetT>> leftHCInfo, rightHCInfo;
   rapmap::utils::MappingConfig mc;
   mc.consistentHits = false;
@@ -122,7 +123,7 @@ int mainT(int argc, char** argv) {
   rmi.load(argv[1]);
   std::printf("k %u txps %zu ph %d big %d\n", rmi.k(), rmi.txpNames.size(), (int)rmi.perfectHash(), (int)(sizeof(typename RapMapIndexT::IndexType) == 8));
   if (argc < 4) return 0;
-  bool fuzzy = false, chain = false, prefetch = true, noOrphans = false, edit = false, refill = false, evensFirst = false; uint32_t maxNumHits = 200;
+  bool fuzzy = false, chain = false, prefetch = true, noOrphans = false, edit = false, refill = false, evensFirst = false, noIntervals = false; uint32_t maxNumHits = 200;
   for (int i = 4; i < argc; ++i) {
     if (!std::strcmp(argv[i], "--fuzzy")) fuzzy = true;
     else if (!std::strcmp(argv[i], "--chain")) chain = true;
@@ -131,12 +132,13 @@ int mainT(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--edit")) edit = true;
     else if (!std::strcmp(argv[i], "--refill")) refill = true;
     else if (!std::strcmp(argv[i], "--evens-first")) evensFirst = true;
+    else if (!std::strcmp(argv[i], "--no-intervals")) noIntervals = true;
     else if (!std::strcmp(argv[i], "--maxNumHits") && i + 1 < argc) maxNumHits = (uint32_t)std::atoi(argv[++i]);
   }
   std::vector<ReadPair> all;
   std::ifstream f(argv[2]); std::string a, b;
   while (f >> a >> b) { ReadPair p; p.first.seq = a == "-" ? "" : a; p.second.seq = b == "-" ? "" : b; all.push_back(p); }
-  return run(rmi, all, argv[3], fuzzy, chain, prefetch, noOrphans, maxNumHits, edit, refill, evensFirst);
+  return run(rmi, all, argv[3], fuzzy, chain, prefetch, noOrphans, maxNumHits, edit, refill, evensFirst, noIntervals);
 }
 
 int main(int argc, char** argv) {

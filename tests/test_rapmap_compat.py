@@ -100,6 +100,17 @@ def test_caller_reproduces_the_oracles_joint_hits(caller, sample_data, synth_sma
     want = _want(res, len(r1))
     got = _run(caller, sd["idx"], tmp_path / "pairs.txt", tmp_path / "out.txt", *flags)
     assert got == want, "prefetched chunk: first difference at line %d" % next(i for i, (a, b) in enumerate(zip(got, want)) if a != b)
+    # round 6: a collector that said it never looks inside HitCollectorInfo (setKeepIntervals(false): no interval records come down, the
+    # pass runs on the pair / lean kernels) hands out the same joint hits; so do reads that cross PCIe as characters (QMAP_COMPAT_NO_PACK)
+    got_ni = _run(caller, sd["idx"], tmp_path / "pairs.txt", tmp_path / "out_ni.txt", "--no-intervals", *flags)
+    assert got_ni == want, "without interval records: first difference at line %d" % next(i for i, (a, b) in enumerate(zip(got_ni, want)) if a != b)
+    if mode == "plain":
+        os.environ["QMAP_COMPAT_NO_PACK"] = "1"
+        try:
+            got_np = _run(caller, sd["idx"], tmp_path / "pairs.txt", tmp_path / "out_np.txt", *flags)
+        finally:
+            del os.environ["QMAP_COMPAT_NO_PACK"]
+        assert got_np == want
     # the same calls as batches of one (no prefetch): a few hundred pairs, one GPU launch per call
     m = 300
     _write_pairs(tmp_path / "few.txt", r1[:m], r2[:m])
