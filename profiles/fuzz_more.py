@@ -31,7 +31,8 @@ for ph in (False, True):
                 r1, r2 = T._fuzz_reads(np.asarray(text), np.asarray(offsets, dtype=np.int64), n if max_len <= 256 else n // 4, 1000 * seed + max_len, max_len)
                 q1, o1 = pack(r1); q2, o2 = pack(r2)
                 sets = [({}, {}), ({"sensitive": 0}, {"sensitive": 0}), ({"fuzzy": 1}, {"fuzzy": 1}), ({"strictCheck": 0}, {"strict_check": 0}),
-                        ({"maxNumHits": 2, "noOrphans": 1}, {"max_num_hits": 2, "no_orphans": 1}), ({"quasiCov": 0.8}, {"quasi_cov": 0.8})]
+                        ({"maxNumHits": 2, "noOrphans": 1}, {"max_num_hits": 2, "no_orphans": 1}), ({"quasiCov": 0.8}, {"quasi_cov": 0.8}),
+                        ({"noDovetail": 1, "maxNumHits": 3}, {"no_dovetail": 1, "max_num_hits": 3})]       # (round 6: the pair kernel merges pairs itself: its --noDovetail / maxNumHits rules)
                 if max_len <= 250:
                     sets += [({"selAln": 1}, {"sel_aln": 1}), ({"selAln": 1, "consensusSlack": 0.35, "dpBandwidth": 40}, {"sel_aln": 1, "consensus_slack": 0.35, "dp_bandwidth": 40})]
                 for oo, go in sets:
