@@ -112,15 +112,43 @@ QM_DEV void lean_find(const DevIndex& ix, const LV<u64>& ck, const LV<bool>& isr
 }
 
 // the same through the compact -p image: the pre-filter for the whole round (one sector per key, no per-lane control flow), then the
-// BooPHF walk for the keys it lets through (present keys and 2e-4 of the absent ones)
-QM_DEV void lean_find_ph(const DevIndex& ix, const LV<u64>& key, const LV<u64>& krc, const LV<bool>& on, LV<bool>& hit, LV<u32>& lb, LV<u32>& ub) {
+// BooPHF walk for the keys it lets through (present keys and 2e-4 of the absent ones).
+// Round 6 -- a walk costs three sectors and most of them were wasted: a window that starts behind a sequencing error holds up to thirty
+// k-mers that ARE in the index, the walk only ever uses the FIRST of them (the hit it goes on from) and the reverse complements in front of
+// it (spotCheck_); whatever lies behind that hit is looked at again only if the next MMP ends inside the window, which it rarely does.  So
+// with `upto` the k-mers are walked in position order up to the first one that is confirmed (lanes 0-31: the k-mers, lanes 32-63: the
+// reverse complements of the same positions) and *upto says how many positions of the window were resolved: the caller cuts its
+// window there (a position that falls out of a window and is asked for again is looked up again: look-ups are pure).  8.5 -> 3.5 walks per
+// read on the benchmark's input (tests/emu, QM_PROFILE).
+QM_DEV void lean_find_ph(const DevIndex& ix, const LV<u64>& key, const LV<u64>& krc, const LV<bool>& on, LV<bool>& hit, LV<u32>& lb, LV<u32>& ub, int* upto = nullptr) {
   LV<bool> want;
-  QM_LANES(l) { want[l] = on[l]; }
+  QM_LANES(l) { want[l] = on[l]; hit[l] = false; lb[l] = 0; ub[l] = 0; }
   ph_filter_round(ix, key, krc, want);
-  QM_LANES(l) {
-    bool h = false; u32 a = 0, b = 0;
-    if (want[l]) h = find_kmer<QM_F_PH>(ix, key[l], a, b);
-    hit[l] = h; lb[l] = a; ub[l] = b;
+  if (!upto) {
+    QM_LANES(l) {
+      bool h = false; u32 a = 0, b = 0;
+      if (want[l]) h = find_kmer<QM_F_PH>(ix, key[l], a, b);
+      QM_CNT(21, h ? 1 : 0); QM_CNT(22, on[l] ? 1 : 0);
+      hit[l] = h; lb[l] = a; ub[l] = b;
+    }
+    return;
+  }
+  const u32 fcand = (u32)ballot(want);                       // positions whose k-mer passed the filter
+  int done = 0;
+  while (true) {
+    const u32 rest = done < 32 ? (fcand >> done) : 0u;
+    const int cutoff = rest ? done + ctz32(rest) : 32;       // the first candidate at or behind `done` (32: none)
+    QM_LANES(l) {
+      const int j = l & 31;
+      bool h = false; u32 a = 0, b = 0;
+      const bool mine = want[l] && j >= done && j <= cutoff;
+      if (mine) h = find_kmer<QM_F_PH>(ix, key[l], a, b);
+      QM_CNT(21, h ? 1 : 0);
+      if (mine) { hit[l] = h; lb[l] = a; ub[l] = b; }
+    }
+    if (cutoff >= 32) { *upto = 32; return; }                // every position resolved
+    if ((ballot(hit) >> cutoff) & 1ULL) { *upto = cutoff + 1; return; }
+    done = cutoff + 1;                                       // (a false positive of the filter: on to the next candidate)
   }
 }
 
@@ -133,7 +161,7 @@ QM_DEV void lean_find_ph(const DevIndex& ix, const LV<u64>& key, const LV<u64>& 
 // PH: the compact image of a -p index (FrugalBooMap::find over the BooPHF walk, find_kmer<QM_F_PH>, behind the membership pre-filter):
 // the structure is keyed by the k-mer itself, so every lane looks up its own word.
 template <bool PH, int IW = 8>
-QM_DEV void lean_probe(const DevIndex& ix, const QM_LDS(u64)* pk2, int D, int V, int P, int k, int wb, int ww, LeanWin& W, int stride = 1) {
+QM_DEV void lean_probe(const DevIndex& ix, const QM_LDS(u64)* pk2, int D, int V, int P, int k, int wb, int ww, LeanWin& W, int stride = 1, int cut = 1) {
   if (wb + ww > P) ww = P - wb;
   QM_CNT(3, 1); QM_CNT(4, (ww + stride - 1) / stride);
   LV<u64> ck, cr; LV<bool> isr, on, hit;
@@ -153,10 +181,14 @@ QM_DEV void lean_probe(const DevIndex& ix, const QM_LDS(u64)* pk2, int D, int V,
     }
     on[l] = in;
   }
-  if (PH) lean_find_ph(ix, ck, cr, on, hit, W.lb, W.ub);
+  int upto = 32;
+  // (cut = 0: the -s collector -- its strided windows hold the NEXT hits of the walk on purpose, lean_iter checks up to four of them together)
+  if (PH) lean_find_ph(ix, ck, cr, on, hit, W.lb, W.ub, cut ? &upto : nullptr);
   else lean_find(ix, ck, isr, on, hit, W.lb, W.ub);
   const u64 fm = ballot(hit);
-  W.Fm = (u32)fm; W.Cm = (u32)(fm >> 32); W.Km = (u32)ballot(on); W.wb = wb; W.ww = ww;
+  u32 km = (u32)ballot(on);
+  if (PH && upto < ww) { ww = upto; km &= (1u << upto) - 1u; }      // the window ends behind the first confirmed k-mer (lean_find_ph)
+  W.Fm = (u32)fm; W.Cm = (u32)(fm >> 32); W.Km = km; W.wb = wb; W.ww = ww;
 }
 
 // hitsToMappingsSimple (HitManager.cpp:691-882) for one strand whose intervals hold n <= 64 suffixes, in registers.  Lane l
@@ -465,7 +497,7 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
       // first-hit scan (:167-237): the first position whose k-mer or reverse complement is in the hash
       int p0 = 0;
       while (p0 < P) {
-        if ((unsigned)(p0 - W.wb) >= (unsigned)W.ww) lean_probe<PH, IW>(ix, pk2, D, 0, P, k, p0, 32, W);
+        if ((unsigned)(p0 - W.wb) >= (unsigned)W.ww) lean_probe<PH, IW>(ix, pk2, D, 0, P, k, p0, 32, W, 1, SEL ? 0 : 1);
         const u32 mm = (W.Fm | W.Cm) >> (p0 - W.wb);
         if (mm) { p0 += ctz32(mm); foundHit = 1; break; }
         p0 = W.wb + W.ww;
@@ -505,7 +537,7 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
             {
               const unsigned relp = (unsigned)(p - W.wb);
               const bool known = relp < (unsigned)W.ww && (!SEL || ((W.Km >> (relp & 31u)) & 1u) != 0);
-              if (!known) lean_probe<PH, IW>(ix, pk2, D, V, P, k, p, width, W, SEL ? pstride : 1);
+              if (!known) lean_probe<PH, IW>(ix, pk2, D, V, P, k, p, width, W, SEL ? pstride : 1, SEL ? 0 : 1);
             }
             width = 32; pstride = 1;
             const int rel = p - W.wb;

@@ -515,6 +515,7 @@ QM_DEV void ph_filter_round(const DevIndex& ix, const LV<u64>& key, const LV<u64
 template <int F>
 QM_DEV bool find_kmer(const DevIndex& ix, u64 key, u32& lb, u32& ub) {     // perfect-hash flavour only (dense: find_dense_round)
   const PhIndex& P = ix.phv;
+  QM_CNT(20, 1);
   u64 s0 = 0, s1 = 0, h = 0;
   u64 idx = 0;
   bool inLevel = false;
