@@ -268,7 +268,7 @@ class Oracles:
             oracle.build()
             self.interleaved = interleave_memory(True)
             try:
-                self.cache[idx_dir] = oracle.Oracle(q5.load(idx_dir))
+                self.cache[idx_dir] = oracle.Oracle(q5.load(idx_dir, enum_cache=os.path.join(os.path.dirname(idx_dir), "oracle_enum")))
             finally:
                 interleave_memory(False)
             log("oracle index %s ready (%.1fs)" % (os.path.basename(os.path.dirname(idx_dir)), time.time() - t))
@@ -531,7 +531,13 @@ def main():
     if args.build_only:
         os.nice(5)
         for spec in args.build_only.split(";"):
-            build_or_reuse_index(args.genes, 42, 31, 0, 1, args.cache, **spec_args(spec))
+            idx = build_or_reuse_index(args.genes, 42, 31, 0, 1, args.cache, **spec_args(spec))
+            if spec == "ph":
+                # ... and the table the ORACLE of that index needs (the k-mers of a -p index enumerated from its suffix array: 20 s of numpy that sat
+                # between two legs of the parent) -- test infrastructure prepared in the background like the index itself
+                from oracle import q5
+                q5.load(idx, enum_cache=os.path.join(os.path.dirname(idx), "oracle_enum"))
+                open(os.path.join(os.path.dirname(idx), "DONE_ORACLE"), "w").write("ok\n")
         return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -759,11 +765,13 @@ def kernel_stats(mp, n):
         d = {"reads_through_the_pair_or_lean_kernel": lean_reads, "reads_left_to_the_general_kernel": deferred,
              "lean_deferred_frac": round(deferred / float(lean_reads), 6) if lean_reads > 0 else None,
              "pairs_merged_in_the_wavefront": mp.stat(10),
+             "reads_with_N_mapped_by_the_N_aware_pass": mp.stat(15),
              "left_because": {DEFER_WHY[i]: why[i] for i in range(4) if why[i]},
              "what": "a batch of 2 M pairs and more is mapped as two parts in flight: one on the pair kernel (qm_duo_kernel: both mates of a pair walked in "
                      "lockstep by the two halves of a wavefront, the pair merged there), one on qm_lean_kernel (two mates per wavefront, one after the "
                      "other) -- vector-bound and scalar-bound wavefronts sharing every CU; a read neither is built for is marked and mapped by "
-                     "qm_read_kernel<2,8,0> in a second, small launch inside map_kernel_ms"}
+                     "qm_read_kernel<2,8,0> in a second, small launch inside map_kernel_ms; when 2 048 reads and more were marked for a character "
+                     "outside A C G T, qm_lean_kernel's N-aware edition (k-mers with an N stepped over, MMPs ending at one) goes over the marked reads first"}
         return d
     except Exception as ex:  # noqa: BLE001
         return {"error": repr(ex)}
@@ -927,13 +935,17 @@ def side_legs(out, args, ra, qi, mp, opts, s1, s2, off, n, L, dev_id, cores):
 def other_configs(oc, args, ra, qd, oracles, oracle, qi, idx_dir, mp, s1, s2, off, ptr, n, L, dev_id, device, k, w_dense, bpp_dense):
     """bounded legs (3 timed steps each) of the configurations the headline does not cover, on the same reads"""
     steps, warm = 3, 1
-    # the -p index's oracle (its table is enumerated from the suffix array and the text: 20 s of numpy on one thread) loads while the -s leg runs
+    # the -p index's oracle loads while the oracle of the -s leg maps its sample (its table -- enumerated from the suffix array and the text, 20 s of
+    # numpy -- comes from the background child that built the index: q5.load's enum_cache)
     import threading
     ph_box = {}
 
     def load_ph():
         try:
             ph_box["idx"] = build_or_reuse_index(args.genes, 42, k, 0, 1, args.cache, True, wait_only=args._bg.ok("ph"))      # (built in the background since the run began)
+            marker = os.path.join(os.path.dirname(ph_box["idx"]), "DONE_ORACLE")
+            while args._bg.ps.get("ph") is not None and args._bg.ps["ph"].poll() is None and not os.path.exists(marker):
+                time.sleep(0.25)                             # (the child is still enumerating the oracle's table: q5.load's enum_cache)
             ph_box["orc"] = oracles.get(ph_box["idx"])
         except Exception as ex:  # noqa: BLE001
             ph_box["err"] = ex
@@ -941,6 +953,7 @@ def other_configs(oc, args, ra, qd, oracles, oracle, qi, idx_dir, mp, s1, s2, of
     ph_thread.start()
 
     def leg(name, mapper, o, key, bpp, w, cp, workload, extra=None, whole_step=False):
+        ph_thread.join()                                     # (no timed step beside a thread of this process that holds the interpreter lock for long stretches)
         with args._bg.quiet():
             el, kms, tot = timed_steps(mapper, o, ptr, n, L, steps, warm, 1, device, qd)
         val = n * steps / el / 1e6

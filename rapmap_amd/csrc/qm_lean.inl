@@ -41,6 +41,7 @@ namespace qm {
 #define QM_SC_DEFER0 20          // ... and why they are there, four slots (not in -DQM_TIMING builds, whose phase sums sit here): 0 a character that is not
                                  // A C G T or more than 128 (256) characters, 1 a window of k equal bases, 2 an interval wider than the kernel's lanes / more
                                  // suffixes or intervals than its stash / a match beyond the extension table, 3 hits on the other strand as well
+#define QM_LEAN_NMW 12           // words of a strand's N flags: four of flags, zeros behind them (lean_ndist looks at five from any position up to 128)
 #define QM_LEAN_CHUNK 1024       // list elements a wave reserves per bump-allocator round trip (a list here holds at most 64): a quarter of the general
                                  // kernels' QM_CHUNK, so that twice their grid leaves half their slack in the list buffer (the host sizes it for theirs)
 
@@ -55,11 +56,13 @@ struct LeanMem {                               // one wave's LDS slab (1 632 byt
   };
   u32 stage[2][36];                            // raw characters of the next iteration's two reads (global_load_lds target)
   u32 ostage[2][8];                            // offsets (dwords) of the next / the next but one iteration
+  u32 nm[2][2][QM_LEAN_NMW];                   // [read][strand]: a bit per position that holds an N (round 6; words 4 .. stay zero), written for
+  u32 nmz[QM_LEAN_NMW];                        // reads with N's only; every other read's walks look at nmz: all zero
 };
 
 // the current probe window of a walk: positions [wb, wb + ww) of the strand, bit j of Fm / Cm = k-mer / reverse complement of
 // position wb + j found, lane j (< 32) holds that position's interval
-struct LeanWin { int wb, ww; u32 Fm, Cm, Km; LV<u32> lb, ub; };   // Km: positions of the window that were looked up (-s probes every stride-th)
+struct LeanWin { int wb, ww; u32 Fm, Cm, Km, Xm; LV<u32> lb, ub; };   // Km: positions of the window that were looked up (-s probes every stride-th)
 struct LeanStrand { int n, sufN, minIdx, minSpan, cov; };   // intervals, their suffixes, the first smallest interval (HitManager.cpp:636-641), coverage
 
 QM_DEV int ctz32(u32 x) { return x ? __builtin_ctz(x) : 32; }
@@ -70,6 +73,24 @@ QM_DEV u64 lean_kmer(const QM_LDS(u64)* img, int q, int k) {
   const int j = q >> 5, sh = 2 * (q & 31);
   const u64 w0 = img[j], w1 = img[j + 1];
   return ((w0 << sh) | ((w1 >> 1) >> (63 - sh))) >> (64 - 2 * k);
+}
+
+// Reads with N's (round 6).  SACollector never looks up a k-mer that holds an N (operator(): SACollector.hpp:172-181, getSAHits_: :497-512 --
+// it goes on behind the N, which is what stepping over every such position comes to), spot-checks none (:603-604) and an MMP ends at one
+// (extendSearchNaive compares characters).  nm: the strand's N flags, a bit per position (LeanMem::nm; all zero for a read without).
+// The flags of positions q .. q + 31:
+QM_DEV u32 lean_nbits(const QM_LDS(u32)* nm, int q) {
+  const int i = q >> 5, sh = q & 31;
+  const u32 a = nm[i], b = nm[i + 1];
+  return (a >> sh) | ((b << 1) << (31 - sh));
+}
+// characters from position q to the strand's next N (128 and more: none)
+QM_DEV int lean_ndist(const QM_LDS(u32)* nm, int q) {
+  const int i = q >> 5, sh = q & 31;
+  const u32 a = nm[i], b = nm[i + 1], c = nm[i + 2], d = nm[i + 3], e = nm[i + 4];
+  const u32 x0 = (a >> sh) | ((b << 1) << (31 - sh)), x1 = (b >> sh) | ((c << 1) << (31 - sh));
+  const u32 x2 = (c >> sh) | ((d << 1) << (31 - sh)), x3 = (d >> sh) | ((e << 1) << (31 - sh));
+  return x0 ? __builtin_ctz(x0) : (x1 ? 32 + __builtin_ctz(x1) : (x2 ? 64 + __builtin_ctz(x2) : (x3 ? 96 + __builtin_ctz(x3) : 128)));
 }
 
 // khash.find (RapMapUtils.hpp:65-67) for one key per lane in one round of loads; lanes that are not `on` read bucket 0.
@@ -160,15 +181,23 @@ QM_DEV void lean_find_ph(const DevIndex& ix, const LV<u64>& key, const LV<u64>& 
 // maxMMPExtension + 1 positions while the read keeps matching, never asks about the positions in between (probe_window).
 // PH: the compact image of a -p index (FrugalBooMap::find over the BooPHF walk, find_kmer<QM_F_PH>, behind the membership pre-filter):
 // the structure is keyed by the k-mer itself, so every lane looks up its own word.
-template <bool PH, int IW = 8>
-QM_DEV void lean_probe(const DevIndex& ix, const QM_LDS(u64)* pk2, int D, int V, int P, int k, int wb, int ww, LeanWin& W, int stride = 1, int cut = 1) {
+template <bool PH, int IW = 8, bool NQ = false>
+QM_DEV void lean_probe(const DevIndex& ix, const QM_LDS(u64)* pk2, const QM_LDS(u32)* nm, int D, int V, int P, int k, int wb, int ww, LeanWin& W, int stride = 1, int cut = 1) {
   if (wb + ww > P) ww = P - wb;
   QM_CNT(3, 1); QM_CNT(4, (ww + stride - 1) / stride);
-  LV<u64> ck, cr; LV<bool> isr, on, hit;
+  LV<u64> ck, cr; LV<bool> isr, on, hit, inw, xk;
+  const u32 kmask = (1u << k) - 1u;
   QM_LANES(l) {
     const int j = l & 31;
     const bool in = j < ww && (j & (stride - 1)) == 0;
     const int q = in ? wb + j : 0;
+    bool clean = true;
+    inw[l] = in; xk[l] = false;
+    if (NQ) {
+      const u32 nb = lean_nbits(nm, q);                    // an N inside the k-mer: not looked up (a position like any other that holds nothing);
+      clean = (nb & kmask) == 0;                            // one right behind it: the first-hit scan passes over that k-mer as well (:175 `<=`)
+      xk[l] = in && l < 32 && ((nb >> k) & 1u) != 0;
+    }
     const u64 w = lean_kmer(pk2 + IW * V, q + (V ? D : 0), k), wr = lean_kmer(pk2 + IW * (1 - V), P - 1 - q + (V ? 0 : D), k);
     if (PH) {
       const bool comp = l >= 32;                           // lanes 32-63: the reverse complement = the other image's k-mer at P - 1 - q
@@ -179,16 +208,16 @@ QM_DEV void lean_probe(const DevIndex& ix, const QM_LDS(u64)* pk2, int D, int V,
       ck[l] = big ? wr : w;
       isr[l] = big != (l >= 32);                           // lanes 32-63 ask for the other orientation
     }
-    on[l] = in;
+    on[l] = in && clean;
   }
   int upto = 32;
   // (cut = 0: the -s collector -- its strided windows hold the NEXT hits of the walk on purpose, lean_iter checks up to four of them together)
   if (PH) lean_find_ph(ix, ck, cr, on, hit, W.lb, W.ub, cut ? &upto : nullptr);
   else lean_find(ix, ck, isr, on, hit, W.lb, W.ub);
   const u64 fm = ballot(hit);
-  u32 km = (u32)ballot(on);
+  u32 km = (u32)ballot(inw);
   if (PH && upto < ww) { ww = upto; km &= (1u << upto) - 1u; }      // the window ends behind the first confirmed k-mer (lean_find_ph)
-  W.Fm = (u32)fm; W.Cm = (u32)(fm >> 32); W.Km = km; W.wb = wb; W.ww = ww;
+  W.Fm = (u32)fm; W.Cm = (u32)(fm >> 32); W.Km = km; W.Xm = NQ ? (u32)ballot(xk) : 0u; W.wb = wb; W.ww = ww;
 }
 
 // hitsToMappingsSimple (HitManager.cpp:691-882) for one strand whose intervals hold n <= 64 suffixes, in registers.  Lane l
@@ -324,9 +353,22 @@ QM_DEV void lean_defer(const ReadBatch& B, int read, int why) {
 
 // offsets of iteration `it` into ostage[par]: pairs: off1[it], off1[it + 1], off2[it], off2[it + 1]; single-end reads 2 it and
 // 2 it + 1: off1[2 it .. 2 it + 2] (the last one only if the second read exists).  Iterations, like reads, are below 2^31 per launch.
-template <bool PAIRED, bool WIDE = false>
+template <bool PAIRED, bool WIDE = false, bool NQ = false>
 QM_DEV void lean_stage_offsets(const ReadBatch& B, int it, int nit, LeanMem& M, int par) {
   if (it >= nit) return;
+  if (NQ) {
+    // the N-aware pass over a queue: slots 2 it and 2 it + 1 name the reads (pairs: read r = mate r & 1 of pair r >> 1); their offsets go where
+    // those of a pair's mates go -- dwords 0-3 and 4-7
+    QM_LANES(l) {
+      const long long s = 2LL * it + (l >> 2);
+      if (l < 8 && s < (long long)B.nreads) {
+        const long long r = B.slowq[s];
+        const long long* o = PAIRED ? (((r & 1) ? B.off2 : B.off1) + (r >> 1)) : (B.off1 + r);
+        lds_dma_u32((const u32*)o + (l & 3), M.ostage[par], l);
+      }
+    }
+    return;
+  }
   if (WIDE) {                                              // one read per iteration: its two offsets (pairs: read it = mate it & 1 of pair it >> 1)
     QM_LANES(l) {
       if (l < 4) { const long long* o = PAIRED ? (((it & 1) ? B.off2 : B.off1) + (it >> 1)) : (B.off1 + it); lds_dma_u32((const u32*)o + l, M.ostage[par], l); }
@@ -343,7 +385,7 @@ QM_DEV void lean_stage_offsets(const ReadBatch& B, int it, int nit, LeanMem& M, 
 }
 QM_DEV long long lean_off64(const LV<u32>& ov, int d) { return (long long)(((u64)read_lane(ov, d + 1) << 32) | (u64)read_lane(ov, d)); }
 // the offsets in ostage[par] (landed) into the request for the two reads' characters
-template <bool PAIRED, bool WIDE = false>
+template <bool PAIRED, bool WIDE = false, bool NQ = false>
 QM_DEV void lean_stage_chars(const ReadBatch& B, int it, int nit, LeanMem& M, int par) {
   if (it >= nit) return;
   if (WIDE) {
@@ -367,11 +409,12 @@ QM_DEV void lean_stage_chars(const ReadBatch& B, int it, int nit, LeanMem& M, in
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     if (h && !have1) break;
-    const int d0 = h ? (PAIRED ? 4 : 2) : 0;
+    const int d0 = h ? ((PAIRED || NQ) ? 4 : 2) : 0;
     const long long o0 = lean_off64(ov, d0);
     int len = (int)(read_lane(ov, d0 + 2) - (u32)o0);
     if (len > QM_LEAN_MAXLEN) len = QM_LEAN_MAXLEN;
-    const unsigned char* p = ((h && PAIRED) ? B.seq2 : B.seq1) + o0;
+    const bool second = NQ ? (PAIRED && (B.slowq[2LL * it + h] & 1) != 0) : (h && PAIRED);
+    const unsigned char* p = (second ? B.seq2 : B.seq1) + o0;
     const int mis = (int)((unsigned long long)p & 3ULL);
     const u32* g = (const u32*)(p - mis);
     const int nd = (mis + len + 3) >> 2;                  // <= 33
@@ -385,7 +428,7 @@ QM_DEV void lean_stage_chars(const ReadBatch& B, int it, int nit, LeanMem& M, in
 // WIDE: ONE read per iteration over all 64 lanes (up to 256 characters; iteration it = read it); the images of the two strands are 16
 // words apart instead of 8, the MMP extension reads the 224-character table (SaExt2).  The window probes, the walk and hits->mappings
 // are the same code.
-template <bool PAIRED, bool SEL, bool PH, bool WIDE = false>
+template <bool PAIRED, bool SEL, bool PH, bool WIDE = false, bool NQ = false>
 QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, int nw, int par, LeanMem& M, WaveAlloc& wa) {
   constexpr int IW = WIDE ? 16 : 8;                        // words between the two images of a read
   constexpr int HW = WIDE ? 64 : 32;                       // lanes per read
@@ -398,11 +441,14 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
   LV<u32> ov;
   QM_LANES(l) { ov[l] = M.ostage[par][l & 7]; }
   const u32 a0 = read_lane(ov, 0), a1 = read_lane(ov, 2);
-  const u32 b0 = read_lane(ov, PAIRED ? 4 : 2), b1 = read_lane(ov, PAIRED ? 6 : 4);
+  const u32 b0 = read_lane(ov, (PAIRED || NQ) ? 4 : 2), b1 = read_lane(ov, (PAIRED || NQ) ? 6 : 4);
+  // the reads of the iteration: 2 it and 2 it + 1, or (NQ: the N-aware pass over the queue of the reads the first pass left) what those slots name
+  const int ra = NQ ? (int)B.slowq[r0] : r0, rb = NQ ? (have1 ? (int)B.slowq[r0 + 1] : 0) : r0 + 1;
+  const bool sec0 = NQ ? (PAIRED && (ra & 1)) : (WIDE && PAIRED && (it & 1)), sec1 = NQ ? (PAIRED && (rb & 1)) : PAIRED;
   const int raw0 = (int)(a1 - a0), raw1 = have1 ? (int)(b1 - b0) : 0;
   const int len0 = raw0 > MAXLEN ? MAXLEN : raw0, len1 = raw1 > MAXLEN ? MAXLEN : raw1;
-  const int mis0 = (int)(((u32)(unsigned long long)((WIDE && PAIRED && (it & 1)) ? B.seq2 : B.seq1) + a0) & 3u);
-  const int mis1 = (int)(((u32)(unsigned long long)(PAIRED ? B.seq2 : B.seq1) + b0) & 3u);
+  const int mis0 = (int)(((u32)(unsigned long long)(sec0 ? B.seq2 : B.seq1) + a0) & 3u);
+  const int mis1 = (int)(((u32)(unsigned long long)(sec1 ? B.seq2 : B.seq1) + b0) & 3u);
   QM_LDS(unsigned char)* PKb = (QM_LDS(unsigned char)*)&M.pk[0][0][0];
   LV<bool> bad, rep;
   QM_LANES(l) {
@@ -429,10 +475,43 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
     PKb[img + 8 * IW + 8 * (mj >> 3) + 7 - (mj & 7)] = (unsigned char)r;
   }
   const u64 dirty = ballot(bad), reps = ballot(rep);
+  // a read whose characters outside A C G T are all N / n stays here: the N flags of its two strands go to M.nm (lean_nbits).  Anything
+  // else in it and it is left to the general kernel as before (what the reference makes of such a character is Kmer::fromChars' business)
+  int nn0 = 0, nn1 = 0;
+  if (NQ && !WIDE && dirty != 0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (!(u32)(dirty >> (32 * h))) continue;
+      const int len = h ? len1 : len0, mis = h ? mis1 : mis0;
+      const QM_LDS(unsigned char)* sb = (const QM_LDS(unsigned char)*)&M.stage[h][0] + mis;
+      LV<bool> n0, n1, x0, x1;
+      QM_LANES(l) {
+        const u32 c0 = l < len ? (u32)sb[l] : (u32)'A', c1 = l + 64 < len ? (u32)sb[l + 64] : (u32)'A';
+        const u32 u0 = c0 & 0xdfu, u1 = c1 & 0xdfu;
+        n0[l] = u0 == 'N'; n1[l] = u1 == 'N';
+        x0[l] = !(u0 == 'A' || u0 == 'C' || u0 == 'G' || u0 == 'T' || u0 == 'N');
+        x1[l] = !(u1 == 'A' || u1 == 'C' || u1 == 'G' || u1 == 'T' || u1 == 'N');
+      }
+      const u64 nlo = ballot(n0), nhi = ballot(n1);
+      if ((ballot(x0) | ballot(x1)) != 0) continue;
+      // reverseRead(read): position q holds what position len - 1 - q held -- the 128 flags bit-reversed, shifted down by 128 - len
+      const u64 bl = ((u64)brev32((u32)nhi) << 32) | (u64)brev32((u32)(nhi >> 32)), bh = ((u64)brev32((u32)nlo) << 32) | (u64)brev32((u32)(nlo >> 32));
+      const int sft = 128 - len;                             // 0 .. 127
+      const u64 rlo = sft >= 64 ? (bh >> (sft - 64)) : (sft ? ((bl >> sft) | (bh << (64 - sft))) : bl);
+      const u64 rhi = sft >= 64 ? 0ULL : (bh >> sft);
+      QM_LANES(l) {
+        if (l < 8) {
+          const u64 w = (l & 4) ? ((l & 2) ? rhi : rlo) : ((l & 2) ? nhi : nlo);
+          M.nm[h][l >> 2][l & 3] = (u32)(w >> (32 * (l & 1)));
+        }
+      }
+      if (h) nn1 = 1; else nn0 = 1;
+    }
+  }
   wave_fence();
   // the staging rows are free again: the next iteration's characters, and the offsets of the one after it
-  lean_stage_chars<PAIRED, WIDE>(B, it + nw, nit, M, par ^ 1);
-  lean_stage_offsets<PAIRED, WIDE>(B, it + 2 * nw, nit, M, par);
+  lean_stage_chars<PAIRED, WIDE, NQ>(B, it + nw, nit, M, par ^ 1);
+  lean_stage_offsets<PAIRED, WIDE, NQ>(B, it + 2 * nw, nit, M, par);
 #if defined(QM_LEAN_ABLATE) && QM_LEAN_ABLATE == 1    // profiling builds (profiles/r05/ablate_build.sh): the phases up to here, empty lists out
   lds_dma_wait();
   QM_LANES(l) { if (l < 2 && r0 + l < (int)B.nreads) { B.lcnt[r0 + l] = (u32)(dirty & reps & 1); B.loff[r0 + l] = 0; } }
@@ -441,22 +520,30 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
   // what this kernel takes: no character but A C G T, no window of k equal bases (k equal characters cover at least (k - 6) / 4
   // whole lanes above: setup_strand's rule for its lazy strands), at most 128 characters
   // (1: a character that is not A C G T or too many of them, 2: a window of k equal bases -- lean_defer's `why` + 1)
+  // (bit 4 of the codes: the read has N's and M.nm holds their flags)
   const int defer0 = WIDE ? ((raw0 > MAXLEN || dirty != 0) ? 1 : (4 * popc64(reps) + 6 >= k ? 2 : 0))
-                          : ((raw0 > MAXLEN || (u32)dirty != 0) ? 1 : (4 * popc32((u32)reps) + 6 >= k ? 2 : 0));
-  const int defer1 = (raw1 > MAXLEN || (u32)(dirty >> 32) != 0) ? 1 : (4 * popc32((u32)(reps >> 32)) + 6 >= k ? 2 : 0);
+                          : (((raw0 > MAXLEN || ((u32)dirty != 0 && !nn0)) ? 1 : (4 * popc32((u32)reps) + 6 >= k ? 2 : 0)) | (nn0 << 4));
+  const int defer1 = ((raw1 > MAXLEN || ((u32)(dirty >> 32) != 0 && !nn1)) ? 1 : (4 * popc32((u32)(reps >> 32)) + 6 >= k ? 2 : 0)) | (nn1 << 4);
   const int P0 = len0 - k + 1, P1 = len1 - k + 1;
-  const int ok0 = (!defer0 && P0 >= 1) ? 1 : 0, ok1 = (have1 && !defer1 && P1 >= 1) ? 1 : 0;
+  const int ok0 = (!(defer0 & 15) && P0 >= 1) ? 1 : 0, ok1 = (have1 && !(defer1 & 15) && P1 >= 1) ? 1 : 0;
   // ---- the first probe of both reads in one round (SACollector.hpp:167-237 starts at position 0; the read's last k-mer is the
   // first thing the reverse-complement pass asks for): lanes 0-3 of each half = the read's k-mer 0, its k-mer P - 1, and --
   // from the second image -- the reverse complements of those two
-  LV<u64> ck, cr; LV<bool> isr, on, hit; LV<u32> plb, pub;
+  LV<u64> ck, cr; LV<bool> isr, on, hit, x0k; LV<u32> plb, pub;
   QM_LANES(l) {
     const int h = WIDE ? 0 : (l >> 5), jj = l & 31;
     const int P = h ? P1 : P0, D = MAXLEN - (h ? len1 : len0);
     const bool lastq = jj == 1 || jj == 2;                 // jj 0: read[0]  1: read[P-1]  2: rc[P-1] (= complement of read[0])  3: rc[0]
-    const bool o = (h ? ok1 : ok0) != 0 && jj < 4 && (P > 1 || !(jj & 1)) && (!WIDE || l < 32);
+    bool o = (h ? ok1 : ok0) != 0 && jj < 4 && (P > 1 || !(jj & 1)) && (!WIDE || l < 32);
     const int q = (o && lastq) ? P - 1 : 0;                // position in the lane's own strand (jj >> 1) ...
     const int qo = o ? P - 1 - q : 0;                      // ... and of the reverse complement in the other one
+    x0k[l] = false;
+    if (NQ) {                                              // (a k-mer with an N in it is not looked up: lean_nbits)
+      const QM_LDS(u32)* nmh = (((h ? defer1 : defer0) >> 4) && !WIDE) ? (const QM_LDS(u32)*)&M.nm[h][(jj >> 1) & 1][0] : (const QM_LDS(u32)*)&M.nmz[0];
+      const u32 nb = lean_nbits(nmh, q);
+      x0k[l] = o && jj == 0 && ((nb >> k) & 1u) != 0;
+      o = o && (nb & ((1u << k) - 1u)) == 0;
+    }
     const QM_LDS(u64)* pkh = (const QM_LDS(u64)*)&M.pk[0][0][0] + 2 * IW * h;
     const bool s = (jj >> 1) & 1;
     const u64 w = lean_kmer(pkh + (s ? IW : 0), q + (s ? D : 0), k);
@@ -471,7 +558,7 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
   QM_CNT(3, 1);
   if (PH) lean_find_ph(ix, ck, cr, on, hit, plb, pub);
   else lean_find(ix, ck, isr, on, hit, plb, pub);
-  const u64 fm0 = ballot(hit);
+  const u64 fm0 = ballot(hit), xm0 = NQ ? ballot(x0k) : 0ULL;
   lds_dma_wait();                                          // what was requested above has landed by now: no store follows an open request
 #if defined(QM_LEAN_ABLATE) && QM_LEAN_ABLATE == 2
   QM_LANES(l) { if (l < 2 && r0 + l < (int)B.nreads) { B.lcnt[r0 + l] = (u32)(fm0 & 1 & plb[l] & pub[l]); B.loff[r0 + l] = 0; } }
@@ -482,8 +569,8 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
 #pragma nounroll
   for (int h = 0; h < NH; ++h) {
     if (h > have1) break;
-    const int read = r0 + h;
-    if (h ? defer1 : defer0) { lean_defer(B, read, (h ? defer1 : defer0) - 1); continue; }
+    const int read = h ? rb : ra;
+    if ((h ? defer1 : defer0) & 15) { lean_defer(B, read, ((h ? defer1 : defer0) & 15) - 1); continue; }
     const int L = h ? len1 : len0, P = L - k + 1, D = MAXLEN - L;
     int n = 0, foundHit = 0, bail = 0, selV = 0;
     LV<u64> elem; LV<bool> keep; LV<int> slot;
@@ -492,13 +579,15 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
       const QM_LDS(u64)* pk2 = (const QM_LDS(u64)*)&M.pk[0][0][0] + 2 * IW * h;
       const u32 fmh = (u32)(fm0 >> (32 * h));
       const u32 F0 = fmh & 1u, C0 = (fmh >> 2) & 1u;
-      LeanWin W; W.wb = 0; W.ww = 1; W.Fm = F0; W.Cm = C0; W.Km = 1u;
+      const QM_LDS(u32)* nm0 = (NQ && !WIDE && ((h ? defer1 : defer0) >> 4)) ? (const QM_LDS(u32)*)&M.nm[h][0][0] : (const QM_LDS(u32)*)&M.nmz[0];   // the N flags of the read (of reverseRead(read): QM_LEAN_NMW words on)
+      const int nmStep = (NQ && !WIDE && ((h ? defer1 : defer0) >> 4)) ? QM_LEAN_NMW : 0;
+      LeanWin W; W.wb = 0; W.ww = 1; W.Fm = F0; W.Cm = C0; W.Km = 1u; W.Xm = (u32)(xm0 >> (32 * h)) & 1u;
       { const u32 s0lb = read_lane(plb, 32 * h), s0ub = read_lane(pub, 32 * h); QM_LANES(l) { W.lb[l] = s0lb; W.ub[l] = s0ub; } }
       // first-hit scan (:167-237): the first position whose k-mer or reverse complement is in the hash
       int p0 = 0;
       while (p0 < P) {
-        if ((unsigned)(p0 - W.wb) >= (unsigned)W.ww) lean_probe<PH, IW>(ix, pk2, D, 0, P, k, p0, 32, W, 1, SEL ? 0 : 1);
-        const u32 mm = (W.Fm | W.Cm) >> (p0 - W.wb);
+        if ((unsigned)(p0 - W.wb) >= (unsigned)W.ww) lean_probe<PH, IW, NQ>(ix, pk2, nm0, D, 0, P, k, p0, 32, W, 1, SEL ? 0 : 1);
+        const u32 mm = ((W.Fm | W.Cm) & ~W.Xm) >> (p0 - W.wb);
         if (mm) { p0 += ctz32(mm); foundHit = 1; break; }
         p0 = W.wb + W.ww;
       }
@@ -527,6 +616,7 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
         QM_LDS(LeanSuf)* suf = (QM_LDS(LeanSuf)*)M.suf;
         QM_LDS(IntRec)* ints = (QM_LDS(IntRec)*)M.ints;
         const int imgOff = V ? D : 0;
+        const QM_LDS(u32)* nmV = nm0 + (V ? nmStep : 0);
         const int ext = SEL ? B.max_mmp_ext : 0;                     // -s: every MMP but a read's first is cut at k + maxMMPExtension (:557-575)
         int lastSearch = 0, prevEnd = 0, width = 1, spot = 0, stopAfter = 0, pstride = 1;
         int sn = 0, sufN = 0, minIdx = 0, minSpan = 0x7fffffff, cov = 0;
@@ -537,7 +627,7 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
             {
               const unsigned relp = (unsigned)(p - W.wb);
               const bool known = relp < (unsigned)W.ww && (!SEL || ((W.Km >> (relp & 31u)) & 1u) != 0);
-              if (!known) lean_probe<PH, IW>(ix, pk2, D, V, P, k, p, width, W, SEL ? pstride : 1, SEL ? 0 : 1);
+              if (!known) lean_probe<PH, IW, NQ>(ix, pk2, nmV, D, V, P, k, p, width, W, SEL ? pstride : 1, SEL ? 0 : 1);
             }
             width = 32; pstride = 1;
             const int rel = p - W.wb;
@@ -597,7 +687,9 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
                 int matched = x ? ((__builtin_clz(x) - (32 - 2 * ext)) >> 1) : ext;
                 const int nv = (int)(e >> 28);
                 matched = matched < nv ? matched : nv;
-                fullb[l] = act && matched == ext;
+                bool nfree = true;
+                if (NQ) nfree = (lean_nbits(nmV, p + g * st + k) & ((1u << ext) - 1u)) == 0;   // (an MMP ends at an N)
+                fullb[l] = act && matched == ext && nfree;
               }
               const u64 bqb = ballot(fullb);
               int Jd = 0;                                                // the leading hits whose extension matched all it may use, with an interval to record
@@ -647,7 +739,8 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
           // read's end) is redone cut, from the same interval
           int capped = (SEL && p != 0) ? 1 : 0;
           int mlen = 0, first = 0, cnt = 0;
-          LV<u32> tdv, tpv;
+          LV<u32> tdv, tpv; LV<int> ncap;
+          if (NQ && !WIDE) { QM_LANES(l) { ncap[l] = lean_ndist(nmV, pos); } }   // the extension ends at the strand's next N (extendSearchNaive compares characters)
           while (true) {
             const int cutrem = (L - pos) < ext ? (L - pos) : ext;     // characters a capped extension may use
             const int rem = capped ? cutrem : L - pos;
@@ -661,6 +754,7 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
                 int matched = x ? ((__builtin_clz(x) - (32 - 2 * rem)) >> 1) : rem;
                 const int nv = (int)(e >> 28);
                 matched = matched < nv ? matched : nv;
+                if (NQ && !WIDE) matched = matched < ncap[l] ? matched : ncap[l];
                 lc[l] = l < wiv ? k + matched : -1;
                 fullv[l] = false; tdv[l] = 0; tpv[l] = 0;
               }
@@ -711,6 +805,7 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
                 int matched = xs ? xb + (clz64(xs | 1ULL) >> 1) : QM_EXT_BASES;
                 matched = matched < nv ? matched : nv;
                 matched = matched < cap ? matched : cap;
+                if (NQ) matched = matched < ncap[l] ? matched : ncap[l];
                 fullv[l] = matched == QM_EXT_BASES;
                 lc[l] = l < wiv ? k + matched : -1;
                 tdv[l] = b.z & ((1u << QM_EXT_TID_BITS) - 1); tpv[l] = b.w;
@@ -803,10 +898,10 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
       }
       const bool fits = base + n <= B.iv_cap;
       if (!fits) { QM_LANES(l) { if (l == 0) *B.status |= 16; } }
-      const int mate = PAIRED ? (WIDE ? (read & 1) : h) : 0;
+      const int mate = PAIRED ? ((WIDE || NQ) ? (read & 1) : h) : 0;
       wave_fence();
       QM_LANES(l) {
-        if (l == 0) { B.iv_cnt[read] = fits ? (u32)n : 0u; B.iv_off[read] = base; B.found_out[read] = foundHit ? 1 : 0; }
+        if (l == 0) { B.iv_cnt[read] = fits ? (u32)n : 0u; B.iv_off[read] = base; B.found_out[read] = foundHit ? 1 : 0; if (NQ) B.lcnt[read] = 0; }   // (NQ: the first pass's mark goes)
         if (fits && l < n) {
           const QM_LDS(IntRec)* r = (const QM_LDS(IntRec)*)M.ints + l;
           qm_sa_interval_hit hh; hh.begin = (int)r->b; hh.end = (int)r->e; hh.len = r->len; hh.query_pos = r->q;

@@ -1421,9 +1421,11 @@ QM_DEV void sel_side_score(const PairBatch& P, const SelBatch& A, long long x, i
 
 // step 3: the alignment cache (SelectiveAlignmentUtils.hpp: alnCache keyed by the hash of the target window, per read and mate) and
 // the work list of the alignment kernel
-QM_DEV void sel_side_dedupe(const SelBatch& A, long long x) {
+// (returns the list the question goes on: 0 none, 1 the ksw2 kernel's, 2 the strip kernel's; the caller appends -- qm_sel_dedupe_kernel one
+// atomic per wavefront and list, not one per question: 0.85 M additions to ONE address per chunk were 1.4 of the kernel's 1.8 ms)
+QM_DEV int sel_side_dedupe_list(const SelBatch& A, long long x) {
   const SelSide S = A.sides[x];
-  if (S.kind == 0) return;
+  if (S.kind == 0) return 0;
   if (S.kind & 1) {
     long long own = -1;                                    // (the unit's earlier questions are the S.nth before this one: loads that do not wait for one another)
     for (long long y = x - 1; y >= x - S.nth; --y) {
@@ -1433,11 +1435,15 @@ QM_DEV void sel_side_dedupe(const SelBatch& A, long long x) {
     if (own >= 0) {
       A.tref[S.g] = -(int)(A.sides[own].g - 2 * A.toff[S.u]) - 2;
       A.tsc[S.g] = (int)0x80000000;
-      return;
+      return 0;
     }
   }
-  if (S.kind & 4) A.torder2[atomic_add_u64(A.ntasks2, 1ULL)] = (u64)x;
-  else if (S.kind & 2) A.torder[atomic_add_u64(A.ntasks, 1ULL)] = (u64)x;
+  return (S.kind & 4) ? 2 : ((S.kind & 2) ? 1 : 0);
+}
+QM_DEV void sel_side_dedupe(const SelBatch& A, long long x) {
+  const int w = sel_side_dedupe_list(A, x);
+  if (w == 2) A.torder2[atomic_add_u64(A.ntasks2, 1ULL)] = (u64)x;
+  else if (w == 1) A.torder[atomic_add_u64(A.ntasks, 1ULL)] = (u64)x;
 }
 
 // The strip alignments: tasks t0 .. t0+3 of torder2, one per row of 16 lanes, lane c = diagonal c - 7 (target index = query index + c - 7).

@@ -18,6 +18,31 @@ namespace qm { unsigned long long qm_prof[32]; }
 
 using namespace qm;
 
+// the N-aware pass of stage A (lean_iter<..., NQ>, qm_host.hip run_stage_a): the lean kernel once more over the queue of the reads its first pass
+// marked; what it maps is compared like everything else the lean kernel maps, what it marks again stays marked
+template <bool PAIRED, bool SEL>
+static void emu_n_pass(const qm::DevIndex& ix, qm::ReadBatch Lb, std::vector<long long>& q, u64* scal) {
+  using namespace qm;
+  if (q.empty()) return;
+  scal[QM_SC_LEANQ] = 0;
+  for (int i = 0; i < 4; ++i) scal[QM_SC_DEFER0 + i] = 0;
+  Lb.slowq = q.data(); Lb.nreads = (long long)q.size();
+  const long long nit = (Lb.nreads + 1) >> 1, NW = 3;
+  static LeanMem Ms[3];
+  for (long long w = 0; w < NW; ++w) {
+    LeanMem& M = Ms[w]; memset(&M, 0, sizeof(M));
+    WaveAlloc wl; wl.base = -1; wl.used = 0; wl.ivBase = -1; wl.ivUsed = 0;
+    lean_stage_offsets<PAIRED, false, true>(Lb, (int)w, (int)nit, M, 0); lean_stage_chars<PAIRED, false, true>(Lb, (int)w, (int)nit, M, 0);
+    lean_stage_offsets<PAIRED, false, true>(Lb, (int)(w + NW), (int)nit, M, 1);
+    int par = 0;
+    for (long long it = w; it < nit; it += NW) {
+      if (ix.ph) lean_iter<PAIRED, SEL, true, false, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl);
+      else lean_iter<PAIRED, SEL, false, false, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl);
+      par ^= 1;
+    }
+  }
+}
+
 extern "C" {
 #ifdef QM_PROFILE
 unsigned long long* qe_prof() { return qm::qm_prof; }   // event counters, see QM_CNT in qm_mapper.inl
@@ -258,6 +283,13 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
         for (long long it = w; it < nit; it += NW) { if (ix.ph) lean_iter<false, false, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); else lean_iter<false, false, false>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
       }
     }
+    if (!leanWide && !getenv("QM_EMU_NO_NPASS")) {
+      std::vector<long long> q;
+      for (long long r = 0; r < nreads; ++r) if (lcnt2[r] == QM_LCNT_LEAN) q.push_back(r);
+      const size_t before = q.size();
+      if (paired) emu_n_pass<true, false>(ix, Lb, q, scal2); else emu_n_pass<false, false>(ix, Lb, q, scal2);
+      if (getenv("QM_EMU_LEAN_STATS")) fprintf(stderr, "[qm emu] N-aware pass over %zu reads, %llu marked again\n", before, (unsigned long long)scal2[QM_SC_LEANQ]);
+    }
     long long bad = 0, deferred = 0;
     for (long long r = 0; r < nreads; ++r) {
       if (lcnt2[r] == QM_LCNT_LEAN) { ++deferred; continue; }
@@ -301,6 +333,13 @@ int qe_map(int k, const unsigned char* text, long long n, const u32* SA, long lo
         int par = 0;
         for (long long it = w; it < nit; it += NW) { if (ix.ph) lean_iter<false, true, true>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); else lean_iter<false, true, false>(ix, Lb, (int)it, (int)nit, (int)NW, par, M, wl); par ^= 1; }
       }
+    }
+    if (!leanWide && !getenv("QM_EMU_NO_NPASS")) {
+      std::vector<long long> q;
+      for (long long r = 0; r < nreads; ++r) if (lcnt2[r] == QM_LCNT_LEAN) q.push_back(r);
+      const size_t before = q.size();
+      if (paired) emu_n_pass<true, true>(ix, Lb, q, scal2); else emu_n_pass<false, true>(ix, Lb, q, scal2);
+      if (getenv("QM_EMU_LEAN_STATS")) fprintf(stderr, "[qm emu] N-aware pass (-s collector) over %zu reads, %llu marked again\n", before, (unsigned long long)scal2[QM_SC_LEANQ]);
     }
     long long bad = 0, deferred = 0;
     for (long long r = 0; r < nreads; ++r) {

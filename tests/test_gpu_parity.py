@@ -128,6 +128,38 @@ def test_synth_small_through_the_headline_kernels(synth_small, oracle_mod, varia
 
 
 @pytest.mark.parametrize("kernel", HEADLINE_KERNELS)
+@pytest.mark.parametrize("variant", ["default", "noStrictCheck", "z0.9", "selAln", "selAln_noStrict"])
+def test_reads_with_N_take_the_N_aware_pass(synth_small, oracle_mod, variant, kernel, monkeypatch):
+    """round 6: when enough reads of a batch were left for a character outside A C G T (QM_NPASS_MIN: 2 048, here 1), qm_lean_kernel's
+    N-aware edition goes over the queue of what the first pass left before the general kernel does -- k-mers with an N stepped over
+    (SACollector.hpp:172-181 with its `<=`, :497-512), MMPs ending at one.  Same hits, same counters; the golden set holds reads with an N
+    right behind their first k-mer, all-N mates, IUPAC codes (those stay with the general kernel)."""
+    import rapmap_amd as ra
+    monkeypatch.setenv("QM_NPASS_MIN", "1")
+    ix, orc = load_oracle(synth_small["idx"])
+    qi, mp = _headline(synth_small["idx"], kernel)
+    q1, o1 = pack(synth_small["reads1"]); q2, o2 = pack(synth_small["reads2"])
+    oo, go = {"selAln": ({"selAln": 1}, {"sel_aln": 1}), "selAln_noStrict": ({"selAln": 1, "strictCheck": 0}, {"sel_aln": 1, "strict_check": 0})}.get(variant) or VARIANTS[variant]
+    res = orc.map_pairs(q1, o1, q2, o2, opts=oracle_mod.default_opts(**oo), nthreads=4)
+    gr = mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(**go))
+    assert_hits_equal(res.hit_offsets, res.hits, gr.hit_offsets, gr.hits, "%s, N-aware pass behind the %s kernel" % (variant, kernel))
+    assert res.counters == gr.counters
+    taken = mp.stat(15)
+    assert taken > 300, taken
+    if variant == "default":
+        assert (taken, mp.stat(4)) == (389, 130), (taken, mp.stat(4))      # (the lane emulation: 519 reads left by the first pass, 130 by the second)
+    # single-end: the queue names reads, not mates
+    res1 = orc.map_single(q1, o1, opts=oracle_mod.default_opts(**oo), nthreads=4)
+    gr1 = mp.map_reads(q1, o1, opts=ra.default_opts(**go))
+    assert_hits_equal(res1.hit_offsets, res1.hits, gr1.hit_offsets, gr1.hits, "%s, single-end, N-aware pass" % variant)
+    assert res1.counters == gr1.counters and mp.stat(15) > 100
+    monkeypatch.setenv("QM_NPASS_MIN", "-1")
+    gr2 = mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(**go))
+    assert_hits_equal(res.hit_offsets, res.hits, gr2.hit_offsets, gr2.hits, "%s, no N-aware pass" % variant)
+    assert mp.stat(15) == 0
+
+
+@pytest.mark.parametrize("kernel", HEADLINE_KERNELS)
 def test_sample_data_through_the_headline_kernels(sample_data, oracle_mod, kernel):
     import samfmt as sam
     ix, orc = load_oracle(sample_data["idx"])
