@@ -1516,6 +1516,8 @@ struct HostFeed { qm_ctx* c; const char* seq1; const int64_t* off1; const char* 
 static int host_feed_upload(void* self, int64_t u0, int64_t u1) {
   HostFeed* f = (HostFeed*)self;
   const int64_t a1 = f->off1[u0], b1 = f->off1[u1];
+  // (pageable memory through the runtime's own staging: 35 GB/s on the round's boxes -- eight threads copying into pinned buffers of our own
+  // were no faster, profiles/r06/exp_mix.txt)
   if (b1 > a1) HIPCHK(hipMemcpyAsync(f->c->d_seq1 + a1, f->seq1 + a1, (size_t)(b1 - a1), hipMemcpyHostToDevice, f->c->copyStream));
   if (f->seq2) {
     const int64_t a2 = f->off2[u0], b2 = f->off2[u1];
@@ -1608,14 +1610,18 @@ int qm_map_reads_packed(qm_ctx* c, const qm_opts* o, int64_t n, const uint8_t* p
   return map_packed(c, o, n, pk, off, exc, nexc, nullptr, nullptr, nullptr, 0, n_hits, counters);
 }
 
-int qm_fetch_hits(qm_ctx* c, int64_t* hit_offsets, qm_hit* hits) {
-  if (!c || c->lastUnits < 0) return fail(QM_E_STATE, "no mapping result to fetch");
-  HIPCHK(hipSetDevice(c->device));
-  if (hit_offsets) HIPCHK(hipMemcpy(hit_offsets, c->d_offs, (size_t)(c->lastUnits + 1) * 8, hipMemcpyDeviceToHost));
-  if (hits && c->lastHits > 0) {
-    const size_t bytes = (size_t)c->lastHits * sizeof(qm_hit);
-    if (bytes < ((size_t)64 << 20)) HIPCHK(hipMemcpy(hits, c->d_hits, bytes, hipMemcpyDeviceToHost));
+// device -> the caller's (pageable) memory, one array
+static int staged_download(qm_ctx* c, void* dstv, const void* d_src, size_t bytes) {
+    if (bytes < ((size_t)64 << 20)) HIPCHK(hipMemcpy(dstv, d_src, bytes, hipMemcpyDeviceToHost));
     else {
+      unsigned char* const hits = (unsigned char*)dstv;
+      // (a result array the caller has just allocated is a million page faults: ask for huge pages where the range holds whole ones --
+      // a hint, honoured where transparent huge pages are on `madvise` or `always`)
+      {
+        const uintptr_t a = ((uintptr_t)hits + ((uintptr_t)2 << 20) - 1) & ~(((uintptr_t)2 << 20) - 1), e = ((uintptr_t)hits + bytes) & ~(((uintptr_t)2 << 20) - 1);
+        static const bool thp = [] { const char* v = getenv("QM_FETCH_THP"); return !(v && atoi(v) == 0); }();
+        if (thp && e > a) madvise((void*)a, (size_t)(e - a), MADV_HUGEPAGE);
+      }
       // A large result lands in memory the caller has usually just allocated (every page still to be faulted in), where a
       // plain pageable hipMemcpy runs at ~9 GB/s.  Instead: DMA into two pinned staging buffers in turn at PCIe rate while
       // host threads copy the previous chunk into the caller's array, so the page faults are spread over several cores.
@@ -1627,7 +1633,7 @@ int qm_fetch_hits(qm_ctx* c, int64_t* hit_offsets, qm_hit* hits) {
         hipError_t e = hipEventSynchronize(c->evStage[i & 1]);
         if (e != hipSuccess) return e;
         const size_t off = i * CH, len = off + CH <= bytes ? CH : bytes - off;
-        const unsigned char* src = c->h_stage + (i & 1) * CH; unsigned char* dst = (unsigned char*)hits + off;
+        const unsigned char* src = c->h_stage + (i & 1) * CH; unsigned char* dst = hits + off;
         const int nt = 8; std::vector<std::thread> th;
         const size_t per = ((len + nt - 1) / nt + 4095) & ~(size_t)4095;
         for (int t = 0; t < nt; ++t) {
@@ -1640,13 +1646,21 @@ int qm_fetch_hits(qm_ctx* c, int64_t* hit_offsets, qm_hit* hits) {
       };
       for (size_t i = 0; i < nch; ++i) {
         const size_t off = i * CH, len = off + CH <= bytes ? CH : bytes - off;
-        HIPCHK(hipMemcpyAsync(c->h_stage + (i & 1) * CH, (const unsigned char*)c->d_hits + off, len, hipMemcpyDeviceToHost, c->copyStream));
+        HIPCHK(hipMemcpyAsync(c->h_stage + (i & 1) * CH, (const unsigned char*)d_src + off, len, hipMemcpyDeviceToHost, c->copyStream));
         HIPCHK(hipEventRecord(c->evStage[i & 1], c->copyStream));
         if (i > 0) HIPCHK(drain(i - 1));
       }
       HIPCHK(drain(nch - 1));
     }
-  }
+  return QM_OK;
+}
+
+int qm_fetch_hits(qm_ctx* c, int64_t* hit_offsets, qm_hit* hits) {
+  if (!c || c->lastUnits < 0) return fail(QM_E_STATE, "no mapping result to fetch");
+  HIPCHK(hipSetDevice(c->device));
+  int rc;
+  if (hit_offsets && (rc = staged_download(c, hit_offsets, c->d_offs, (size_t)(c->lastUnits + 1) * 8))) return rc;
+  if (hits && c->lastHits > 0 && (rc = staged_download(c, hits, c->d_hits, (size_t)c->lastHits * sizeof(qm_hit)))) return rc;
   return QM_OK;
 }
 
