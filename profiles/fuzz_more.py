@@ -15,6 +15,7 @@ import test_gpu_parity as T
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+fuzz_n = float(os.environ.get("FUZZ_N", "0"))
 oracle.build()
 d = tempfile.mkdtemp(prefix="fuzz", dir="/dev/shm")
 names, txps = synth.make_transcriptome(600, seed=11)
@@ -29,6 +30,18 @@ for ph in (False, True):
         for seed in range(seed0, seed0 + seeds):
             for max_len in (100, 128, 129, 150, 192, 250, 256, 257, 400):
                 r1, r2 = T._fuzz_reads(np.asarray(text), np.asarray(offsets, dtype=np.int64), n if max_len <= 256 else n // 4, 1000 * seed + max_len, max_len)
+                if fuzz_n > 0:                                   # FUZZ_N=rate: N's (upper and lower case) sprinkled over the reads on top of the generator's own
+                    rngn = np.random.default_rng(77 + 1000 * seed + max_len)
+                    def sprinkle(rs):
+                        out = []
+                        for r in rs:
+                            a = np.frombuffer(r, np.uint8).copy()
+                            if a.size:
+                                w = rngn.random(a.size) < fuzz_n
+                                a[w] = rngn.choice(np.frombuffer(b"NNNn", np.uint8), int(w.sum()))
+                            out.append(a.tobytes())
+                        return out
+                    r1, r2 = sprinkle(r1), sprinkle(r2)
                 q1, o1 = pack(r1); q2, o2 = pack(r2)
                 sets = [({}, {}), ({"sensitive": 0}, {"sensitive": 0}), ({"fuzzy": 1}, {"fuzzy": 1}), ({"strictCheck": 0}, {"strict_check": 0}),
                         ({"maxNumHits": 2, "noOrphans": 1}, {"max_num_hits": 2, "no_orphans": 1}), ({"quasiCov": 0.8}, {"quasi_cov": 0.8}),
@@ -62,6 +75,7 @@ for ph in (False, True):
                     except AssertionError as e:
                         bad += 1; print("MISMATCH -s edited seed=%d opts=%s: %s" % (seed, oo, str(e)[:200]), flush=True)
                 print("-s edited reads seed %d done: %d pairs, %d questions, %d ksw2 alignments in the last run" % (seed, len(r1), mp.stat(6), mp.stat(7)), flush=True)
+        npass_last = mp.stat(15)
         mp.close()
-print("fuzz_more: %d mismatching runs" % bad)
+print("fuzz_more: %d mismatching runs (FUZZ_N=%g, QM_NPASS_MIN=%s; the last call's N-aware pass mapped %d reads)" % (bad, fuzz_n, os.environ.get("QM_NPASS_MIN", "default"), npass_last))
 sys.exit(1 if bad else 0)
