@@ -152,12 +152,32 @@ __global__ __launch_bounds__(256) void qm_pair_count_kernel(PairBatch P) {
   if (threadIdx.x < 6 && sc[threadIdx.x]) atomicAdd((unsigned long long*)&P.counters[threadIdx.x], sc[threadIdx.x]);
 }
 
-// stage B pass 2: write the hits in CSR order
+// stage B pass 2: write the hits in CSR order.  A thread per unit merges (or, for a pair the pair kernel merged, expands) into the wavefront's
+// LDS stage -- the 64 units of a wavefront own ONE contiguous stretch of P.hits, 6.5 KB on the benchmark's input -- and the wavefront copies the
+// stretch out 16 bytes per lane, consecutive lanes to consecutive addresses: a thread per unit writing its own 100 bytes issued a store per
+// hit and lane to 64 different lines (1.05 ms per 5 M pairs at 1.6 TB/s; profiles/r06/timeline.sh).  A wavefront whose units hold more
+// than the stage takes the direct path.
+#define QM_PW_CAP 320
 __global__ __launch_bounds__(256) void qm_pair_write_kernel(PairBatch P) {
-  long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= P.n) return;
-  int c = (int)P.cnt[u];
-  if (c > 0) unit_merge(P, u, P.hits + P.offs[u], c, nullptr);
+  __shared__ __attribute__((aligned(16))) qm_hit stage[4][QM_PW_CAP];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63u);
+  const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = u < P.n ? (int)P.cnt[u] : 0;
+  int incl = c;
+  for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+  const int total = __shfl(incl, 63);
+  if (total == 0) return;
+  if (total > QM_PW_CAP) {
+    if (c > 0) unit_merge(P, u, P.hits + P.offs[u], c, nullptr);
+    return;
+  }
+  if (c > 0) unit_merge(P, u, &stage[wave][incl - c], c, nullptr);
+  const long long base = __shfl(c > 0 ? P.offs[u] - (long long)(incl - c) : 0LL, __builtin_ctzll(__ballot(c > 0)));   // where the wavefront's stretch starts
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // (the merges' stores went through generic pointers: they are in LDS before any lane reads them back)
+  __builtin_amdgcn_wave_barrier();
+  const uint4* src = (const uint4*)&stage[wave][0];
+  uint4* dst = (uint4*)(P.hits + base);
+  for (int i = lane; i < 2 * total; i += 64) dst[i] = src[i];
 }
 
 // -s: per-unit temp slots needed = (list words of the unit) / 3 + 1 (every group has at least three words)
