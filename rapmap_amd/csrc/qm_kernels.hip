@@ -386,10 +386,26 @@ __global__ __launch_bounds__(256) void qm_collect_slow_kernel(const u32* lcnt, l
 
 // -s: surviving hits from the per-unit temp slots to CSR order
 __global__ __launch_bounds__(256) void qm_sel_compact_kernel(PairBatch P, const qm_hit* tmp, const long long* toff) {
-  long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= P.n) return;
-  const int c = (int)P.cnt[u];
-  for (int i = 0; i < c; ++i) P.hits[P.offs[u] + i] = tmp[toff[u] + i];
+  // (through the wavefront's LDS stage and out coalesced, like qm_pair_write_kernel)
+  __shared__ __attribute__((aligned(16))) qm_hit stage[4][QM_PW_CAP];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63u);
+  const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = u < P.n ? (int)P.cnt[u] : 0;
+  int incl = c;
+  for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+  const int total = __shfl(incl, 63);
+  if (total == 0) return;
+  if (total > QM_PW_CAP) {
+    for (int i = 0; i < c; ++i) P.hits[P.offs[u] + i] = tmp[toff[u] + i];
+    return;
+  }
+  for (int i = 0; i < c; ++i) stage[wave][incl - c + i] = tmp[toff[u] + i];
+  const long long base = __shfl(c > 0 ? P.offs[u] - (long long)(incl - c) : 0LL, __builtin_ctzll(__ballot(c > 0)));
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  const uint4* src = (const uint4*)&stage[wave][0];
+  uint4* dst = (uint4*)(P.hits + base);
+  for (int i = lane; i < 2 * total; i += 64) dst[i] = src[i];
 }
 
 __global__ void build_sainfo_kernel(const u32* SA, long long nSA, const u32* offsets, long long T, SaInfo* out) {
