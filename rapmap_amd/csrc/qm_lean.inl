@@ -62,7 +62,7 @@ struct LeanMem {                               // one wave's LDS slab (1 632 byt
 
 // the current probe window of a walk: positions [wb, wb + ww) of the strand, bit j of Fm / Cm = k-mer / reverse complement of
 // position wb + j found, lane j (< 32) holds that position's interval
-struct LeanWin { int wb, ww; u32 Fm, Cm, Km, Xm; LV<u32> lb, ub; };   // Km: positions of the window that were looked up (-s probes every stride-th)
+struct LeanWin { int wb, ww, sh; u32 Fm, Cm, Km, Xm; LV<u32> lb, ub; };   // sh: bit / lane j = position wb + (j << sh) (a strided probe of the -s walk; 0: every position)   // Km: positions of the window that were looked up (-s probes every stride-th)
 struct LeanStrand { int n, sufN, minIdx, minSpan, cov; };   // intervals, their suffixes, the first smallest interval (HitManager.cpp:636-641), coverage
 
 QM_DEV int ctz32(u32 x) { return x ? __builtin_ctz(x) : 32; }
@@ -177,20 +177,22 @@ QM_DEV void lean_find_ph(const DevIndex& ix, const LV<u64>& key, const LV<u64>& 
 // complements.  Both words of a position come out of the read's two images by the same funnel shift -- the reverse complement
 // of the k-mer at q is the k-mer at P - 1 - q of the other image -- and the two lanes of a position read the same bucket.
 // pk2: the read's two images (8 words each), D = 128 - L: where reverseRead(read) starts in the second one.
-// stride (a power of two): only every stride-th position is looked up -- the -s walk, whose capped MMPs advance by exactly
-// maxMMPExtension + 1 positions while the read keeps matching, never asks about the positions in between (probe_window).
+// stride (a power of two): lane j asks about position wb + j * stride -- the -s walk, whose capped MMPs advance by exactly
+// maxMMPExtension + 1 positions while the read keeps matching, never asks about the positions in between (probe_window), so ONE probe
+// answers for every hit the walk can still make on a 100-bp read (round 6; until then a window spanned 32 positions, four of them asked).
 // PH: the compact image of a -p index (FrugalBooMap::find over the BooPHF walk, find_kmer<QM_F_PH>, behind the membership pre-filter):
 // the structure is keyed by the k-mer itself, so every lane looks up its own word.
 template <bool PH, int IW = 8, bool NQ = false>
 QM_DEV void lean_probe(const DevIndex& ix, const QM_LDS(u64)* pk2, const QM_LDS(u32)* nm, int D, int V, int P, int k, int wb, int ww, LeanWin& W, int stride = 1, int cut = 1) {
-  if (wb + ww > P) ww = P - wb;
-  QM_CNT(3, 1); QM_CNT(4, (ww + stride - 1) / stride);
+  const int sh = 31 - __builtin_clz((unsigned)stride);         // (stride: a power of two)
+  { const int left = (P - wb + stride - 1) >> sh; if (ww > left) ww = left; }      // ww: positions asked for, wb + (j << sh) each
+  QM_CNT(3, 1); QM_CNT(4, ww);
   LV<u64> ck, cr; LV<bool> isr, on, hit, inw, xk;
   const u32 kmask = (1u << k) - 1u;
   QM_LANES(l) {
     const int j = l & 31;
-    const bool in = j < ww && (j & (stride - 1)) == 0;
-    const int q = in ? wb + j : 0;
+    const bool in = j < ww;
+    const int q = in ? wb + (j << sh) : 0;
     bool clean = true;
     inw[l] = in; xk[l] = false;
     if (NQ) {
@@ -217,7 +219,7 @@ QM_DEV void lean_probe(const DevIndex& ix, const QM_LDS(u64)* pk2, const QM_LDS(
   const u64 fm = ballot(hit);
   u32 km = (u32)ballot(inw);
   if (PH && upto < ww) { ww = upto; km &= (1u << upto) - 1u; }      // the window ends behind the first confirmed k-mer (lean_find_ph)
-  W.Fm = (u32)fm; W.Cm = (u32)(fm >> 32); W.Km = km; W.Xm = NQ ? (u32)ballot(xk) : 0u; W.wb = wb; W.ww = ww;
+  W.Fm = (u32)fm; W.Cm = (u32)(fm >> 32); W.Km = km; W.Xm = NQ ? (u32)ballot(xk) : 0u; W.wb = wb; W.ww = ww; W.sh = sh;
 }
 
 // hitsToMappingsSimple (HitManager.cpp:691-882) for one strand whose intervals hold n <= 64 suffixes, in registers.  Lane l
@@ -581,7 +583,7 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
       const u32 F0 = fmh & 1u, C0 = (fmh >> 2) & 1u;
       const QM_LDS(u32)* nm0 = (NQ && !WIDE && ((h ? defer1 : defer0) >> 4)) ? (const QM_LDS(u32)*)&M.nm[h][0][0] : (const QM_LDS(u32)*)&M.nmz[0];   // the N flags of the read (of reverseRead(read): QM_LEAN_NMW words on)
       const int nmStep = (NQ && !WIDE && ((h ? defer1 : defer0) >> 4)) ? QM_LEAN_NMW : 0;
-      LeanWin W; W.wb = 0; W.ww = 1; W.Fm = F0; W.Cm = C0; W.Km = 1u; W.Xm = (u32)(xm0 >> (32 * h)) & 1u;
+      LeanWin W; W.wb = 0; W.ww = 1; W.sh = 0; W.Fm = F0; W.Cm = C0; W.Km = 1u; W.Xm = (u32)(xm0 >> (32 * h)) & 1u;
       { const u32 s0lb = read_lane(plb, 32 * h), s0ub = read_lane(pub, 32 * h); QM_LANES(l) { W.lb[l] = s0lb; W.ub[l] = s0ub; } }
       // first-hit scan (:167-237): the first position whose k-mer or reverse complement is in the hash
       int p0 = 0;
@@ -606,7 +608,7 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
           const u32 Fl = P > 1 ? (fmh >> 1) & 1u : F0, Cl = P > 1 ? (fmh >> 3) & 1u : C0;
           const int rl = 32 * h + (P > 1 ? 3 : 2);
           const u32 rlb = read_lane(plb, rl), rub = read_lane(pub, rl);
-          W.wb = 0; W.ww = 1; W.Fm = Cl; W.Cm = Fl; W.Km = 1u;
+          W.wb = 0; W.ww = 1; W.sh = 0; W.Fm = Cl; W.Cm = Fl; W.Km = 1u;
           QM_LANES(l) { W.lb[l] = rlb; W.ub[l] = rub; }
         }
         // ---- SACollector::getSAHits_ (SACollector.hpp:441-677, NIP disabled) over a clean strand: every position below P is
@@ -626,19 +628,14 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
             if (p >= P) break;
             {
               const unsigned relp = (unsigned)(p - W.wb);
-              const bool known = relp < (unsigned)W.ww && (!SEL || ((W.Km >> (relp & 31u)) & 1u) != 0);
+              const bool known = (relp & ((1u << W.sh) - 1u)) == 0 && (relp >> W.sh) < (unsigned)W.ww;
               if (!known) lean_probe<PH, IW, NQ>(ix, pk2, nmV, D, V, P, k, p, width, W, SEL ? pstride : 1, SEL ? 0 : 1);
             }
             width = 32; pstride = 1;
-            const int rel = p - W.wb;
+            const int rel = (p - W.wb) >> W.sh;
             u32 fm = W.Fm >> rel, cm = W.Cm >> rel;                   // (no bits beyond the window)
             int avail = W.ww - rel;
-            if (SEL) {                                                // the stretch of looked-up positions that starts at p
-              const int run = ctz32(~(W.Km >> rel));
-              avail = run < avail ? run : avail;
-              const u32 km = avail >= 32 ? 0xffffffffu : ((1u << avail) - 1u);
-              fm &= km; cm &= km;
-            }
+            if (SEL && W.sh) { avail = 1; fm &= 1u; cm &= 1u; }       // a strided window: the position behind p was not asked about
             if (spot) {                                               // the k-mer the walk goes on with, spot-checked (:602-611)
               ha += fm & 1u; hb += cm & 1u; spot = 0;
               if (stopAfter) break;
@@ -650,39 +647,49 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
             ha += 1;                                                  // spotCheck_ on the hit (:545)
             hb += (cm >> ph) & 1u;
             p += ph;
-            lb = read_lane(W.lb, p - W.wb); ub = read_lane(W.ub, p - W.wb);
+            lb = read_lane(W.lb, (p - W.wb) >> W.sh); ub = read_lane(W.ub, (p - W.wb) >> W.sh);
           }
           skip = 0;
           // -s, a run of capped MMPs in one round: while the read keeps matching, the hits of the walk are maxMMPExtension + 1 positions
-          // apart and each is cut at k + maxMMPExtension, so the next ones (up to four: the positions the strided probe looked up in this
-          // window) are known before this one is extended.  Sixteen lanes per hit check the extension's characters against the narrow
-          // table's entries of the hit's suffixes, all hits at once; the leading hits that do match that far are recorded together --
-          // what the loop below would have done one hit, one round of loads and ~150 scalar instructions at a time -- and the walk
-          // goes on behind them.  Anything else (a hit whose extension stops short, a wide interval, the read's end) takes the loop.
-          if (SEL && p != 0 && !lastSearch && ext >= 1 && ext <= QM_NEXT_BASES && ix.sanext && ((ext + 1) & ext) == 0 && ext + 1 <= 16) {
-            const int st = ext + 1, mlenC = k + ext, rel0b = p - W.wb;
-            int J = 0;
-            u32 lbi[4] = {0, 0, 0, 0}; int wv[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int relj = rel0b + j * st, pj = p + j * st;
-              if (J != j || relj >= W.ww || relj >= 32) continue;
-              if (!((W.Km >> relj) & (W.Fm >> relj) & 1u) || pj + mlenC >= L || sn + j >= QM_LEAN_MAXIV) continue;
-              const u32 a = read_lane(W.lb, relj), b = read_lane(W.ub, relj);
-              const u32 ai = a ? a - 1 : 0;
-              const int w = (int)(b - ai - 1);
-              if (w < 1 || w > 16) continue;
-              lbi[j] = ai; wv[j] = w; J = j + 1;
+          // apart and each is cut at k + maxMMPExtension, so the next ones are known before this one is extended (the strided probe asked
+          // about all of them).  Up to eight hits at a time, eight lanes each -- or four with sixteen lanes each when an interval among
+          // the first four is wider than eight suffixes --: the lanes check the extension's characters against the narrow table's entries
+          // of the hit's suffixes, all hits at once, and the leading hits that do match that far are recorded together -- what the loop
+          // below would have done one hit, one round of loads and ~150 scalar instructions at a time -- and the walk goes on behind them.
+          // Per-hit values live in lanes 0-7 (no scalar arrays).  Anything else (a hit whose extension stops short, a wide interval, the
+          // read's end) takes the loop.
+          if (SEL && p != 0 && !lastSearch && ext >= 1 && ext <= QM_NEXT_BASES && ix.sanext && ((ext + 1) & ext) == 0 && ext + 1 <= 16 &&
+              ((ext + 1) & ((1 << W.sh) - 1)) == 0) {
+            const int st = ext + 1, mlenC = k + ext;
+            const int relb0 = (p - W.wb) >> W.sh, step = st >> W.sh;  // hit j of the run: the window's bit / lane relb0 + j * step
+            LV<int> idxv;
+            QM_LANES(l) { idxv[l] = (relb0 + (l & 7) * step) & 31; }
+            LV<u32> av, bv;
+            wave_read(W.lb, idxv, av); wave_read(W.ub, idxv, bv);
+            LV<u32> aiV, wV; LV<bool> okb, nwb;
+            QM_LANES(l) {
+              const int jh = l & 7, idx = relb0 + jh * step, pj = p + jh * st;
+              const u32 ai = av[l] ? av[l] - 1 : 0;
+              const int w = (int)(bv[l] - ai - 1);
+              const bool ok = l < 8 && idx < W.ww && idx < 32 && ((W.Fm >> (idx & 31)) & 1u) != 0 && pj + mlenC < L && sn + jh < QM_LEAN_MAXIV && w >= 1 && w <= 16;
+              aiV[l] = ok ? ai : 0u; wV[l] = ok ? (u32)w : 0u; okb[l] = ok; nwb[l] = ok && w <= 8;      // (lanes without a hit: entry 1 of the table, ignored)
             }
+            const u32 okm = (u32)ballot(okb) & 0xffu, nwm = (u32)ballot(nwb) & 0xffu;
+            int J16 = ctz32(~okm); J16 = J16 > 4 ? 4 : J16;
+            const int J8 = ctz32(~nwm);
+            const int lsh = J8 > J16 ? 3 : 4;                          // lanes per hit: 8 or 16
+            const int J = J8 > J16 ? J8 : J16;
             if (J >= 2) {
+              LV<int> gv;
+              QM_LANES(l) { gv[l] = l >> lsh; }
+              LV<u32> aiG, wG;
+              wave_read(aiV, gv, aiG); wave_read(wV, gv, wG);
               LV<bool> fullb;
               QM_LANES(l) {
-                const int g = l >> 4, sI = l & 15;
-                const u32 ai = g == 0 ? lbi[0] : (g == 1 ? lbi[1] : (g == 2 ? lbi[2] : lbi[3]));
-                const int w = g == 0 ? wv[0] : (g == 1 ? wv[1] : (g == 2 ? wv[2] : wv[3]));
-                const bool act = g < J && sI < w;
+                const int g = l >> lsh, sI = l & ((1 << lsh) - 1);
+                const bool act = g < J && sI < (int)wG[l];
                 const u32 qn = (u32)lean_kmer(pk2 + IW * V, p + g * st + k + imgOff, ext);
-                const u32 e = ix.sanext[ai + 1 + (u32)(act ? sI : 0)];
+                const u32 e = ix.sanext[aiG[l] + 1 + (u32)(act ? sI : 0)];
                 const u32 x = ((e & 0x0fffffffu) >> (28 - 2 * ext)) ^ qn;
                 int matched = x ? ((__builtin_clz(x) - (32 - 2 * ext)) >> 1) : ext;
                 const int nv = (int)(e >> 28);
@@ -692,36 +699,35 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
                 fullb[l] = act && matched == ext && nfree;
               }
               const u64 bqb = ballot(fullb);
-              int Jd = 0;                                                // the leading hits whose extension matched all it may use, with an interval to record
-              u32 fst[4] = {0, 0, 0, 0}, cn[4] = {0, 0, 0, 0};
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const u32 m = (u32)(bqb >> (16 * j)) & 0xffffu;
-                if (Jd != j || j >= J || !m) continue;
-                const u32 f = (u32)ctz32(m), c = 32u - (u32)__builtin_clz(m) - f;
-                if (c >= maxIv) continue;
-                fst[j] = f; cn[j] = c; Jd = j + 1;
+              // lane j < J: the run of hit j's suffixes whose extension matched all it may use
+              LV<u32> fV, cV; LV<bool> goodb;
+              QM_LANES(l) {
+                const int jh = l & 7;
+                const u32 m = (u32)(bqb >> ((jh << lsh) & 63)) & ((1u << (1 << lsh)) - 1u);
+                const u32 f = m ? (u32)__builtin_ctz(m) : 0u, c = m ? 32u - (u32)__builtin_clz(m) - f : 0u;
+                fV[l] = f; cV[l] = c; goodb[l] = l < J && m != 0 && c < maxIv;
               }
+              const u32 goodm = (u32)ballot(goodb) & 0xffu;
+              const int Jd = ctz32(~goodm);                             // the leading hits with an interval to record
               if (Jd >= 2) {
+                LV<bool> cb;
                 QM_LANES(l) {
                   if (l < Jd) {
-                    const u32 ai = l == 0 ? lbi[0] : (l == 1 ? lbi[1] : (l == 2 ? lbi[2] : lbi[3]));
-                    const u32 f = l == 0 ? fst[0] : (l == 1 ? fst[1] : (l == 2 ? fst[2] : fst[3]));
-                    const u32 c = l == 0 ? cn[0] : (l == 1 ? cn[1] : (l == 2 ? cn[2] : cn[3]));
                     QM_LDS(IntRec)* d = ints + sn + l;
-                    d->b = ai + 1 + f; d->e = ai + 1 + f + c; d->len = (u32)mlenC; d->q = (u32)(p + l * st);
+                    d->b = aiV[l] + 1 + fV[l]; d->e = aiV[l] + 1 + fV[l] + cV[l]; d->len = (u32)mlenC; d->q = (u32)(p + l * st);
                   }
+                  cb[l] = l >= 1 && l < Jd && ((W.Cm >> ((relb0 + (l & 7) * step) & 31)) & 1u) != 0;
                 }
                 // the spot checks and hit counts of hits 1 .. Jd - 1 (each: the spot check behind the hit before it, then the hit itself)
                 ha += 2u * (u32)(Jd - 1);
-                for (int j = 1; j < Jd; ++j) hb += 2u * ((W.Cm >> (rel0b + j * st)) & 1u);
+                hb += 2u * (u32)popc64(ballot(cb));
                 QM_CNT(18, Jd);
                 const int corr0 = prevEnd > p ? prevEnd - p : 0;
                 cov += mlenC - corr0 + (Jd - 1) * st;                    // (hit j >= 1 overlaps the one before it by mlen - (maxMMPExtension + 1))
                 sn += Jd;
                 const int pl = p + (Jd - 1) * st;
                 prevEnd = pl + mlenC;
-                lb = lbi[Jd - 1] + 1 + fst[Jd - 1]; ub = lb + cn[Jd - 1];
+                lb = read_lane(aiV, Jd - 1) + 1 + read_lane(fV, Jd - 1); ub = lb + read_lane(cV, Jd - 1);
                 spot = 1; stopAfter = 0; pstride = st <= 32 ? st : 1;
                 p = pl + st;                                             // kp of the last one
                 width = 32;

@@ -173,6 +173,7 @@ template <int N> QM_DEV void load_8_16xN(const u64* const* B, const int* bit, u6
 QM_DEV void half_ballot(const LV<bool>& b, LV<u32>& out) { const u64 m = ballot(b); for (int l = 0; l < 64; ++l) out.v[l] = (u32)(m >> (l & 32)); }
 // out[l] = x[lane idx[l] of l's half]
 QM_DEV void half_read(const LV<u32>& x, const LV<int>& idx, LV<u32>& out) { LV<u32> t; for (int l = 0; l < 64; ++l) t.v[l] = x.v[(l & 32) + (idx.v[l] & 31)]; out = t; }
+QM_DEV void wave_read(const LV<u32>& x, const LV<int>& idx, LV<u32>& out) { LV<u32> t; for (int l = 0; l < 64; ++l) t.v[l] = x.v[idx.v[l] & 63]; out = t; }
 // every lane gets the maximum over its half
 QM_DEV void half_max(LV<int>& x) {
   for (int b = 0; b < 64; b += 32) { int m = x.v[b]; for (int l = b + 1; l < b + 32; ++l) m = x.v[l] > m ? x.v[l] : m; for (int l = b; l < b + 32; ++l) x.v[l] = m; }
@@ -336,6 +337,10 @@ QM_DEV void half_ballot(const LV<bool>& b, LV<u32>& out) {
   out.v[0] = (threadIdx.x & 32) ? (u32)(m >> 32) : (u32)m;
 }
 // a trip through the LDS crossbar (ds_bpermute_b32): the index differs between the halves, so it cannot be a v_readlane
+// ... the same over the whole wavefront: lane l reads lane idx[l]'s value
+QM_DEV void wave_read(const LV<u32>& x, const LV<int>& idx, LV<u32>& out) {
+  out.v[0] = (u32)__builtin_amdgcn_ds_bpermute((int)((u32)(idx.v[0] & 63) << 2), (int)x.v[0]);
+}
 QM_DEV void half_read(const LV<u32>& x, const LV<int>& idx, LV<u32>& out) {
   out.v[0] = (u32)__builtin_amdgcn_ds_bpermute((int)(((threadIdx.x & 32) + (u32)(idx.v[0] & 31)) << 2), (int)x.v[0]);
 }
