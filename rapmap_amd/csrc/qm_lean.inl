@@ -684,7 +684,7 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
               QM_LANES(l) { gv[l] = l >> lsh; }
               LV<u32> aiG, wG;
               wave_read(aiV, gv, aiG); wave_read(wV, gv, wG);
-              LV<bool> fullb;
+              LV<bool> fullb; LV<int> mv;
               QM_LANES(l) {
                 const int g = l >> lsh, sI = l & ((1 << lsh) - 1);
                 const bool act = g < J && sI < (int)wG[l];
@@ -694,9 +694,9 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
                 int matched = x ? ((__builtin_clz(x) - (32 - 2 * ext)) >> 1) : ext;
                 const int nv = (int)(e >> 28);
                 matched = matched < nv ? matched : nv;
-                bool nfree = true;
-                if (NQ) nfree = (lean_nbits(nmV, p + g * st + k) & ((1u << ext) - 1u)) == 0;   // (an MMP ends at an N)
-                fullb[l] = act && matched == ext && nfree;
+                if (NQ) { const u32 nb = lean_nbits(nmV, p + g * st + k); const int nc = nb ? __builtin_ctz(nb) : 32; matched = matched < nc ? matched : nc; }   // (an MMP ends at an N)
+                fullb[l] = act && matched == ext;
+                mv[l] = act ? matched : -1;
               }
               const u64 bqb = ballot(fullb);
               // lane j < J: the run of hit j's suffixes whose extension matched all it may use
@@ -709,28 +709,56 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
               }
               const u32 goodm = (u32)ballot(goodb) & 0xffu;
               const int Jd = ctz32(~goodm);                             // the leading hits with an interval to record
-              if (Jd >= 2) {
+              // ... and the hit behind them, when its extension stops short on every suffix (the read's next error): its longest match and the
+              // suffixes that reach it are in the lanes already -- recorded here as well instead of by a round of the loop below
+              int Fml = -1, Ff = 0, Fc = 0;
+              if (Jd >= 1 && Jd < J && !((bqb >> ((Jd << lsh) & 63)) & ((1ULL << (1 << lsh)) - 1ULL))) {
+                LV<int> gm;
+                QM_LANES(l) { gm[l] = (l >> lsh) == Jd ? mv[l] : -1; }
+                const int mm = wave_max(gm);
+                LV<bool> bb;
+                QM_LANES(l) { bb[l] = (l >> lsh) == Jd && mv[l] == mm && mm >= 0; }
+                const u32 m = (u32)(ballot(bb) >> ((Jd << lsh) & 63)) & ((1u << (1 << lsh)) - 1u);
+                if (m) {
+                  const u32 f = (u32)__builtin_ctz(m), c = 32u - (u32)__builtin_clz(m) - f;
+                  if (c < maxIv) { Fml = mm; Ff = (int)f; Fc = (int)c; }
+                }
+              }
+              const int Jr = Jd + (Fml >= 0 ? 1 : 0);                    // hits recorded by this round
+              if (Jr >= 2) {
                 LV<bool> cb;
                 QM_LANES(l) {
                   if (l < Jd) {
                     QM_LDS(IntRec)* d = ints + sn + l;
                     d->b = aiV[l] + 1 + fV[l]; d->e = aiV[l] + 1 + fV[l] + cV[l]; d->len = (u32)mlenC; d->q = (u32)(p + l * st);
+                  } else if (l == Jd && Fml >= 0) {
+                    QM_LDS(IntRec)* d = ints + sn + l;
+                    d->b = aiV[l] + 1 + (u32)Ff; d->e = aiV[l] + 1 + (u32)Ff + (u32)Fc; d->len = (u32)(k + Fml); d->q = (u32)(p + l * st);
                   }
-                  cb[l] = l >= 1 && l < Jd && ((W.Cm >> ((relb0 + (l & 7) * step) & 31)) & 1u) != 0;
+                  cb[l] = l >= 1 && l < Jr && ((W.Cm >> ((relb0 + (l & 7) * step) & 31)) & 1u) != 0;
                 }
-                // the spot checks and hit counts of hits 1 .. Jd - 1 (each: the spot check behind the hit before it, then the hit itself)
-                ha += 2u * (u32)(Jd - 1);
+                // the spot checks and hit counts of hits 1 .. Jr - 1 (each: the spot check behind the hit before it, then the hit itself)
+                ha += 2u * (u32)(Jr - 1);
                 hb += 2u * (u32)popc64(ballot(cb));
-                QM_CNT(18, Jd);
+                QM_CNT(18, Jr);
                 const int corr0 = prevEnd > p ? prevEnd - p : 0;
                 cov += mlenC - corr0 + (Jd - 1) * st;                    // (hit j >= 1 overlaps the one before it by mlen - (maxMMPExtension + 1))
-                sn += Jd;
+                sn += Jr;
                 const int pl = p + (Jd - 1) * st;
                 prevEnd = pl + mlenC;
-                lb = read_lane(aiV, Jd - 1) + 1 + read_lane(fV, Jd - 1); ub = lb + read_lane(cV, Jd - 1);
-                spot = 1; stopAfter = 0; pstride = st <= 32 ? st : 1;
-                p = pl + st;                                             // kp of the last one
-                width = 32;
+                spot = 1; stopAfter = 0; width = 32;
+                if (Fml >= 0) {
+                  // the short one: len k + Fml at pl + st; it overlaps the hit before it by mlenC - st, and the walk goes on one past its end (kp)
+                  cov += Fml + 1;
+                  prevEnd = pl + st + k + Fml;
+                  lb = read_lane(aiV, Jd) + 1 + (u32)Ff; ub = lb + (u32)Fc;
+                  pstride = 1;
+                  p = pl + st + Fml + 1;
+                } else {
+                  lb = read_lane(aiV, Jd - 1) + 1 + read_lane(fV, Jd - 1); ub = lb + read_lane(cV, Jd - 1);
+                  pstride = st <= 32 ? st : 1;
+                  p = pl + st;                                           // kp of the last one
+                }
                 if (p + k == L) lastSearch = 1;
                 continue;
               }
@@ -834,7 +862,15 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
               bq = ballot(best);
             }
             first = ctz64(bq); cnt = 64 - clz64(bq) - first;
-            if (SEL && !capped && mlen < L && mlen >= k + ext) { capped = 1; continue; }   // (p == 0 here: mlen >= L <=> the whole read)
+            if (SEL && !capped && mlen < L && mlen >= k + ext) {          // (p == 0 here: mlen >= L <=> the whole read)
+              // redone cut at k + maxMMPExtension from the same interval (:568-575) -- without a second round of loads: the suffixes that match
+              // at least that far are known from this round's lengths
+              LV<bool> fc;
+              QM_LANES(l) { fc[l] = lc[l] >= k + ext; }
+              bq = ballot(fc);
+              mlen = k + ext; first = ctz64(bq); cnt = 64 - clz64(bq) - first;
+              capped = 1;
+            }
             break;
           }
           if (bail) break;
