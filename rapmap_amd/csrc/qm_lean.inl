@@ -658,6 +658,11 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
           // below would have done one hit, one round of loads and ~150 scalar instructions at a time -- and the walk goes on behind them.
           // Per-hit values live in lanes 0-7 (no scalar arrays).  Anything else (a hit whose extension stops short, a wide interval, the
           // read's end) takes the loop.
+          // (a hit the walk found by itself -- behind an error -- in a window that does not hold the walk's next position: the strided probe
+          // that would follow its extension is asked for now, and the hit starts a run instead of taking a round of the loop on its own)
+          if (SEL && p != 0 && !lastSearch && ext >= 1 && ext <= QM_NEXT_BASES && ix.sanext && ((ext + 1) & ext) == 0 && ext + 1 <= 16 &&
+              W.sh == 0 && (p - W.wb) + ext + 1 >= W.ww && p + k + ext < L && p + ext + 1 < P)
+            lean_probe<PH, IW, NQ>(ix, pk2, nmV, D, V, P, k, p, 32, W, ext + 1, 0);
           if (SEL && p != 0 && !lastSearch && ext >= 1 && ext <= QM_NEXT_BASES && ix.sanext && ((ext + 1) & ext) == 0 && ext + 1 <= 16 &&
               ((ext + 1) & ((1 << W.sh) - 1)) == 0) {
             const int st = ext + 1, mlenC = k + ext;
