@@ -47,7 +47,8 @@ for ph in (False, True):
                         ({"maxNumHits": 2, "noOrphans": 1}, {"max_num_hits": 2, "no_orphans": 1}), ({"quasiCov": 0.8}, {"quasi_cov": 0.8}),
                         ({"noDovetail": 1, "maxNumHits": 3}, {"no_dovetail": 1, "max_num_hits": 3})]       # (round 6: the pair kernel merges pairs itself: its --noDovetail / maxNumHits rules)
                 if max_len <= 250:
-                    sets += [({"selAln": 1}, {"sel_aln": 1}), ({"selAln": 1, "consensusSlack": 0.35, "dpBandwidth": 40}, {"sel_aln": 1, "consensus_slack": 0.35, "dp_bandwidth": 40})]
+                    sets += [({"selAln": 1}, {"sel_aln": 1}), ({"selAln": 1, "consensusSlack": 0.35, "dpBandwidth": 40}, {"sel_aln": 1, "consensus_slack": 0.35, "dp_bandwidth": 40}),
+                             ({"selAln": 1, "quasiCov": 0.7}, {"sel_aln": 1, "quasi_cov": 0.7}), ({"selAln": 1, "strictCheck": 0, "maxMMPExtension": 3}, {"sel_aln": 1, "strict_check": 0, "max_mmp_extension": 3})]      # (round 6: the collector's coverage sums and runs under another stride)
                 for oo, go in sets:
                     res = orc.map_pairs(q1, o1, q2, o2, opts=oracle.default_opts(**oo), nthreads=32)
                     gr = mp.map_pairs(q1, o1, q2, o2, opts=ra.default_opts(**go))

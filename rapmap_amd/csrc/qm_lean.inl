@@ -671,17 +671,20 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
             QM_LANES(l) { idxv[l] = (relb0 + (l & 7) * step) & 31; }
             LV<u32> av, bv;
             wave_read(W.lb, idxv, av); wave_read(W.ub, idxv, bv);
-            LV<u32> aiV, wV; LV<bool> okb, nwb;
+            LV<u32> aiV, wV; LV<bool> okb, nwb, tlb;
             QM_LANES(l) {
               const int jh = l & 7, idx = relb0 + jh * step, pj = p + jh * st;
               const u32 ai = av[l] ? av[l] - 1 : 0;
               const int w = (int)(bv[l] - ai - 1);
-              const bool ok = l < 8 && idx < W.ww && idx < 32 && ((W.Fm >> (idx & 31)) & 1u) != 0 && pj + mlenC < L && sn + jh < QM_LEAN_MAXIV && w >= 1 && w <= 16;
+              // (a hit whose cut MMP would reach the read's end -- the walk's last -- may close the run: `tail`)
+              const bool ok = l < 8 && idx < W.ww && idx < 32 && ((W.Fm >> (idx & 31)) & 1u) != 0 && pj + k <= L && sn + jh < QM_LEAN_MAXIV && w >= 1 && w <= 16;
               aiV[l] = ok ? ai : 0u; wV[l] = ok ? (u32)w : 0u; okb[l] = ok; nwb[l] = ok && w <= 8;      // (lanes without a hit: entry 1 of the table, ignored)
+              tlb[l] = ok && pj + mlenC >= L;
             }
-            const u32 okm = (u32)ballot(okb) & 0xffu, nwm = (u32)ballot(nwb) & 0xffu;
-            int J16 = ctz32(~okm); J16 = J16 > 4 ? 4 : J16;
-            const int J8 = ctz32(~nwm);
+            const u32 okm = (u32)ballot(okb) & 0xffu, nwm = (u32)ballot(nwb) & 0xffu, tlm = (u32)ballot(tlb) & 0xffu;
+            const int T = ctz32(tlm);                                   // the first hit that would reach the read's end (32: none in sight)
+            int J16 = ctz32(~okm); J16 = J16 > 4 ? 4 : J16; J16 = J16 > T + 1 ? T + 1 : J16;
+            int J8 = ctz32(~nwm); J8 = J8 > T + 1 ? T + 1 : J8;
             const int lsh = J8 > J16 ? 3 : 4;                          // lanes per hit: 8 or 16
             const int J = J8 > J16 ? J8 : J16;
             if (J >= 2) {
@@ -700,7 +703,8 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
                 const int nv = (int)(e >> 28);
                 matched = matched < nv ? matched : nv;
                 if (NQ) { const u32 nb = lean_nbits(nmV, p + g * st + k); const int nc = nb ? __builtin_ctz(nb) : 32; matched = matched < nc ? matched : nc; }   // (an MMP ends at an N)
-                fullb[l] = act && matched == ext;
+                const int remg = L - (p + g * st + k) < ext ? L - (p + g * st + k) : ext;      // the characters this hit's extension may use (the tail: what is left of the read)
+                fullb[l] = act && matched >= remg;
                 mv[l] = act ? matched : -1;
               }
               const u64 bqb = ballot(fullb);
@@ -717,7 +721,7 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
               // ... and the hit behind them, when its extension stops short on every suffix (the read's next error): its longest match and the
               // suffixes that reach it are in the lanes already -- recorded here as well instead of by a round of the loop below
               int Fml = -1, Ff = 0, Fc = 0;
-              if (Jd >= 1 && Jd < J && !((bqb >> ((Jd << lsh) & 63)) & ((1ULL << (1 << lsh)) - 1ULL))) {
+              if (Jd >= 1 && Jd < J && Jd != T && !((bqb >> ((Jd << lsh) & 63)) & ((1ULL << (1 << lsh)) - 1ULL))) {
                 LV<int> gm;
                 QM_LANES(l) { gm[l] = (l >> lsh) == Jd ? mv[l] : -1; }
                 const int mm = wave_max(gm);
@@ -735,7 +739,8 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
                 QM_LANES(l) {
                   if (l < Jd) {
                     QM_LDS(IntRec)* d = ints + sn + l;
-                    d->b = aiV[l] + 1 + fV[l]; d->e = aiV[l] + 1 + fV[l] + cV[l]; d->len = (u32)mlenC; d->q = (u32)(p + l * st);
+                    d->b = aiV[l] + 1 + fV[l]; d->e = aiV[l] + 1 + fV[l] + cV[l]; d->q = (u32)(p + l * st);
+                    d->len = (u32)(l == T ? L - (p + l * st) : mlenC);     // (the tail's MMP ends with the read)
                   } else if (l == Jd && Fml >= 0) {
                     QM_LDS(IntRec)* d = ints + sn + l;
                     d->b = aiV[l] + 1 + (u32)Ff; d->e = aiV[l] + 1 + (u32)Ff + (u32)Fc; d->len = (u32)(k + Fml); d->q = (u32)(p + l * st);
@@ -747,8 +752,14 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
                 hb += 2u * (u32)popc64(ballot(cb));
                 QM_CNT(18, Jr);
                 const int corr0 = prevEnd > p ? prevEnd - p : 0;
-                cov += mlenC - corr0 + (Jd - 1) * st;                    // (hit j >= 1 overlaps the one before it by mlen - (maxMMPExtension + 1))
                 sn += Jr;
+                if (Jd - 1 == T) {
+                  // the run's last hit matched to the read's end: hits 0 .. T - 1 as ever, the tail overlaps the one before it like they do, and
+                  // the walk is through (`if (p + mlen >= L) break`)
+                  cov += mlenC - corr0 + (T - 1) * st + (L - (p + T * st) - (mlenC - st));
+                  break;
+                }
+                cov += mlenC - corr0 + (Jd - 1) * st;                    // (hit j >= 1 overlaps the one before it by mlen - (maxMMPExtension + 1))
                 const int pl = p + (Jd - 1) * st;
                 prevEnd = pl + mlenC;
                 spot = 1; stopAfter = 0; width = 32;
