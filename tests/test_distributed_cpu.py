@@ -66,3 +66,11 @@ def test_shard_bounds_cover_everything():
             assert b[0][0] == 0 and b[-1][1] == n
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             assert max(e - s for s, e in b) - min(e - s for s, e in b) <= 1
+
+
+def test_counters_without_a_process_group():
+    """a plain one-process run: nothing to sum over, no tensor made for it"""
+    from rapmap_amd import dist as qd
+    c = {k: i + 1 for i, k in enumerate(qd.COUNTER_KEYS)}
+    c["extra"] = 99
+    assert qd.all_reduce_counters(c, device="cpu") == {k: i + 1 for i, k in enumerate(qd.COUNTER_KEYS)}

@@ -286,3 +286,18 @@ def test_vote_ties_disagree_only_over_U(synth_small, oracle_mod):
     withU = run("RYKMSWBDHVNnUu")
     assert withU["conflicts"] > 0 and withU["conflicts_without_U"] == 0, withU
     print("vote ties with U in the reads:", withU)
+
+
+def test_perfect_hash_oracle_table_cache(synth_small_ph, tmp_path):
+    """q5.load(enum_cache=...): the k-mer table of a -p index (enumerated from the suffix array: q5ph.enumerate_intervals) written by one process and
+    read back by another -- bench.py's background child prepares it beside the index it builds -- is the table itself"""
+    import numpy as np
+    from oracle import q5
+    pre = str(tmp_path / "oracle_enum")
+    a = q5.load(synth_small_ph["idx"], enum_cache=pre)          # computes, writes
+    files = sorted(p.name for p in tmp_path.iterdir())
+    assert files == ["oracle_enum_keys.npy", "oracle_enum_lb.npy", "oracle_enum_ub.npy"], files
+    b = q5.load(synth_small_ph["idx"], enum_cache=pre)          # reads
+    c = q5.load(synth_small_ph["idx"])                          # no cache
+    for x, y, z in ((a.hkeys, b.hkeys, c.hkeys), (a.hlb, b.hlb, c.hlb), (a.hub, b.hub, c.hub)):
+        assert x.dtype == y.dtype == z.dtype and np.array_equal(x, y) and np.array_equal(x, z)
