@@ -737,13 +737,14 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
               if (Jr >= 2) {
                 LV<bool> cb;
                 QM_LANES(l) {
-                  if (l < Jd) {
-                    QM_LDS(IntRec)* d = ints + sn + l;
-                    d->b = aiV[l] + 1 + fV[l]; d->e = aiV[l] + 1 + fV[l] + cV[l]; d->q = (u32)(p + l * st);
-                    d->len = (u32)(l == T ? L - (p + l * st) : mlenC);     // (the tail's MMP ends with the read)
-                  } else if (l == Jd && Fml >= 0) {
-                    QM_LDS(IntRec)* d = ints + sn + l;
-                    d->b = aiV[l] + 1 + (u32)Ff; d->e = aiV[l] + 1 + (u32)Ff + (u32)Fc; d->len = (u32)(k + Fml); d->q = (u32)(p + l * st);
+                  {
+                    // (every lane stores: a lane without a record to the second half of the stash's room, which the collector does not use -- a branch
+                    // on a per-lane condition costs the scalar unit its exec-mask juggling, and the scalar unit is what this kernel runs out of)
+                    const bool shortOne = l == Jd && Fml >= 0;
+                    QM_LDS(IntRec)* d = (l < Jr) ? ints + sn + l : ints + QM_LEAN_MAXIV + (l & 31);
+                    const u32 f = shortOne ? (u32)Ff : fV[l], c = shortOne ? (u32)Fc : cV[l];
+                    d->b = aiV[l] + 1 + f; d->e = aiV[l] + 1 + f + c; d->q = (u32)(p + l * st);
+                    d->len = shortOne ? (u32)(k + Fml) : (u32)(l == T ? L - (p + l * st) : mlenC);     // (the tail's MMP ends with the read)
                   }
                   cb[l] = l >= 1 && l < Jr && ((W.Cm >> ((relb0 + (l & 7) * step) & 31)) & 1u) != 0;
                 }
@@ -896,7 +897,7 @@ QM_DEV void lean_iter(const DevIndex& ix, const ReadBatch& B, int it, int nit, i
           if ((u32)cnt < maxIv) {                                      // ub > lb && ub - lb < maxInterval (:577-618)
             if ((!SEL && sufN + cnt > QM_LEAN_SUF) || sn >= QM_LEAN_MAXIV) { bail = 1; break; }
             if (SEL) {
-              QM_LANES(l) { if (l == 0) { QM_LDS(IntRec)* d = ints + sn; d->b = lb; d->e = ub; d->len = (u32)mlen; d->q = (u32)p; } }
+              QM_LANES(l) { QM_LDS(IntRec)* d = l == 0 ? ints + sn : ints + QM_LEAN_MAXIV + (l & 31); d->b = lb; d->e = ub; d->len = (u32)mlen; d->q = (u32)p; }   // (lanes 1 .. 63: into unused room, no branch)
             } else {
               QM_LANES(l) {
                 if (l >= first && l < first + cnt) {
