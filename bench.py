@@ -355,7 +355,7 @@ def roofline(bpp, w, n, kernel_ms, kernel, traffic_key, genes, step_ms=None, ext
     # a batch of 2 M pairs and more is mapped as parts in flight (qm_map_device, QM_SPLIT, default 2): the parts' stage-A launches run
     # AT THE SAME TIME, each over its share of the pairs and each about as long as kernel_ms -- the HIP-event span from the first
     # launch's start to the last one's end (rocprofv3's average duration per launch of the same command:
-    # profiles/r06/kernel_stats_default_two_parts_r06d.txt).  achieved = the bytes of all of them / that span: the chip's rate.
+    # profiles/r06/kernel_stats_default_two_parts_r06e.txt).  achieved = the bytes of all of them / that span: the chip's rate.
     parts = int(os.environ.get("QM_SPLIT", "2")) if n >= (1 << 21) else 1
     parts = max(1, min(8, parts))
     out["launches_per_step"] = parts

@@ -114,6 +114,7 @@ struct qm_ctx {
   hipEvent_t evPlan[QM_SEL_CHUNKS_B + 1] = {};              // ... [i]: chunk i planned; [last]: the plan stream may start
   u64* d_ntk = nullptr;                                     // ... per chunk: a task counter, then (at QM_SEL_CHUNKS_B + i) a counter of alignment questions
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evA = nullptr, evB = nullptr, evCopy = nullptr, evStage[2] = {nullptr, nullptr};
+  hipEvent_t evP0 = nullptr, evP1 = nullptr;                // around the second launches of stage A (the N-aware pass, the general kernel over what is left): evA / evB time the whole call
   unsigned char* h_stage = nullptr;                        // pinned, 2 x 32 MB: result download (qm_fetch_hits)
   // index replica
   uint8_t* d_text = nullptr; uint32_t* d_SA = nullptr; void* d_sainfo = nullptr; void* d_slots = nullptr;
@@ -527,6 +528,8 @@ int qm_ctx_destroy(qm_ctx* c) {
   if (c->d_wordsC) hipFree(c->d_wordsC);
   if (c->h_tot) hipHostFree(c->h_tot);
   if (c->evCopy) hipEventDestroy(c->evCopy);
+  if (c->evP0) hipEventDestroy(c->evP0);
+  if (c->evP1) hipEventDestroy(c->evP1);
   if (c->evStage[0]) hipEventDestroy(c->evStage[0]);
   if (c->evStage[1]) hipEventDestroy(c->evStage[1]);
   if (c->h_stage) hipHostFree(c->h_stage);
@@ -562,6 +565,7 @@ int qm_ctx_create_ex(const qm_index* ix, int device_id, uint32_t flags, qm_ctx**
   CK(hipMalloc((void**)&c->d_ntk, 3 * QM_SEL_CHUNKS_B * sizeof(u64)));
   CK(hipEventCreateWithFlags(&c->evCopy, hipEventDisableTiming));
   CK(hipEventCreate(&c->ev0)); CK(hipEventCreate(&c->ev1)); CK(hipEventCreate(&c->evA)); CK(hipEventCreate(&c->evB));
+  CK(hipEventCreate(&c->evP0)); CK(hipEventCreate(&c->evP1));
   CK(hipMalloc((void**)&c->d_scal, QM_SC_WORDS * sizeof(u64)));
   CK(hipMalloc((void**)&c->d_skip, QM_SKIP_CAP * sizeof(u64)));
   // one builder per (index, device image) at a time: a second thread that asks for the same replica while the first one is
@@ -954,13 +958,13 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
 #endif
       ReadBatch Q = B;
       Q.slowq = c->d_slowq; Q.nreads = nq;
-      HIPCHK(hipEventRecord(c->evA, c->stream));
+      HIPCHK(hipEventRecord(c->evP0, c->stream));
       HIPCHK(qmk_launch_lean_nq(&ix, &Q, c->numCU, c->stream));
-      HIPCHK(hipEventRecord(c->evB, c->stream));
+      HIPCHK(hipEventRecord(c->evP1, c->stream));
       HIPCHK(hipMemsetAsync(c->d_scal + QM_SC_SLOWQ, 0, sizeof(u64), c->stream));
       HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
-      float t = 0; if (hipEventElapsedTime(&t, c->evA, c->evB) == hipSuccess) leanExtraMs += t;
+      float t = 0; if (hipEventElapsedTime(&t, c->evP0, c->evP1) == hipSuccess) leanExtraMs += t;
       c->lastNPass = nq - (int64_t)hscal[QM_SC_LEANQ];
       return QM_OK;
     };
@@ -1078,14 +1082,14 @@ static int run_stage_a(qm_ctx* c, const qm_opts* o, const RunReq& rq, int64_t n,
       HIPCHK(qmk_collect_lean(c->d_lcnt, nreads, c->d_slowq, (unsigned long long*)(c->d_scal + QM_SC_SLOWQ), c->stream));
       ReadBatch S2 = B;
       S2.slowq = c->d_slowq; S2.nreads = nq; S2.gscratch = c->d_gscr; S2.gslots = gs2; S2.ngslots = ngs2;      // (B was filled in before the scratch existed)
-      HIPCHK(hipEventRecord(c->evA, c->stream));
+      HIPCHK(hipEventRecord(c->evP0, c->stream));
       HIPCHK(qmk_map_reads(&ix, &S2, ns, g2, c->numCU, c->stream));
-      HIPCHK(hipEventRecord(c->evB, c->stream));
+      HIPCHK(hipEventRecord(c->evP1, c->stream));
       HIPCHK(hipMemsetAsync(c->d_scal + QM_SC_SLOWQ, 0, sizeof(u64), c->stream));   // (the long-read pass gathers with the same counter)
       HIPCHK(hipMemcpyAsync(hscal, c->d_scal, QM_SC_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
       status = (int)(hscal[QM_SC_STATUS] & 0xffffffffu);
-      float t = 0; if (hipEventElapsedTime(&t, c->evA, c->evB) == hipSuccess) leanExtraMs += t;
+      float t = 0; if (hipEventElapsedTime(&t, c->evP0, c->evP1) == hipSuccess) leanExtraMs += t;
       c->lastLeanDeferred = nq;
     }
     if ((!o->sel_aln || rq.mode == QM_RUN_COLLECT) && rq.mode != QM_RUN_FROM_INTERVALS && hscal[QM_SC_SLOWCNT] > 0 && !(status & 23)) {
